@@ -1,0 +1,174 @@
+/*
+ * kissmcmc_hip.h -- C ABI of the MI355X-native emcee (affine-invariant ensemble sampler) hot path.
+ *
+ * Drop-in boundary.  The reference (mauro3/KissMCMC.jl, pure Julia) has no FFI; the path sits
+ * behind three Julia methods, and this header is what a `ccall` binding for that path binds:
+ *
+ *   emcee(pdf, theta0s; niter, nburnin, nthin, a_scale, ...)     reference src/samplers.jl:188-216
+ *   _emcee(...)  (generation loop, stretch move, accept/reject)  reference src/samplers.jl:232-293
+ *   g_pdf / cdf_g_inv / sample_g                                 reference src/samplers.jl:224-230
+ *
+ * `make_theta0s` (src/samplers.jl:311-349) and `squash_walkers` (src/samplers.jl:372-428) are
+ * host-side pre/post-processing and stay in the host language.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, caller owns every host buffer.
+ *   - Every function returns a kmc_status; kmc_last_error() gives the message of the last
+ *     failure on the calling thread.  Nothing aborts the process.
+ *   - Ensembles are dense row-major [nwalkers][ndim] arrays of double, walker order = the
+ *     reference's (walkers 0..nwalkers/2-1 are the first half of src/samplers.jl:247).
+ *   - "generation" = one pass of src/samplers.jl:245 (two half-steps, every walker proposes
+ *     once).  The reference's `niter`/`nburnin` count log-pdf evaluations; the host shim
+ *     converts with the reference's own integer divisions (src/samplers.jl:203-204).
+ *   - The user closure `pdf` of src/samplers.jl:257 is replaced by a fixed menu of analytic
+ *     log-densities (kmc_density) evaluated on the device.
+ *   - Random stream: Philox4x32-10, counter {step_lo, step_hi, walker_lo, walker_hi},
+ *     key {seed_lo, seed_hi}, step = 2*generation + half, walker = global walker index: the
+ *     block rocRAND's rocrand4() yields after rocrand_init(seed, walker, 4*step).  Results
+ *     are a pure function of (seed, inputs), independent of sharding and launch geometry.
+ */
+#ifndef KISSMCMC_HIP_H
+#define KISSMCMC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KMC_VERSION 100 /* 0.1.0 */
+
+typedef enum kmc_status {
+    KMC_OK = 0,
+    KMC_ERR_A_SCALE = 1,         /* a_scale <= 1                    src/samplers.jl:200 */
+    KMC_ERR_ODD_WALKERS = 2,     /* "Use an even number of walkers." src/samplers.jl:202 */
+    KMC_ERR_TOO_FEW_WALKERS = 3, /* "Use more walkers: at least DOF+2, but better many more." src/samplers.jl:205 */
+    KMC_ERR_BAD_ARG = 4,
+    KMC_ERR_NONFINITE_LOGP = 5,  /* an initial walker has log-pdf -inf/nan (reference: make_theta0s guarantees > -Inf, src/samplers.jl:338) */
+    KMC_ERR_HIP = 6,
+    KMC_ERR_OOM = 7,
+    KMC_ERR_NO_DEVICE = 8,
+    KMC_ERR_UNSUPPORTED = 9
+} kmc_status;
+
+/* Log-density menu (all drop normalisation constants).  p[] = kmc_config.params */
+typedef enum kmc_density {
+    KMC_GAUSSIAN_ISO = 0, /* -1/2 sum_i ((x_i - p0)/p1)^2                       p = {mu, sigma}      */
+    KMC_EXPONENTIAL  = 1, /* any x_i < 0 ? -inf : -p0 * sum_i x_i                p = {rate}           (reference README.md:15) */
+    KMC_ROSENBROCK   = 2, /* -sum_{i<N-1} [p1 (x_{i+1}-x_i^2)^2 + (p0-x_i)^2]/p2 p = {a, b, scale}    (reference test/runtests.jl:68 at N=2, {1,100,20}) */
+    KMC_LOGNORMAL    = 3, /* any x_i <= 0 ? -inf : sum_i [-log x_i - (log x_i - p0)^2/(2 p1^2)]  p = {mu, sigma} */
+    KMC_MVNORMAL2    = 4  /* ndim == 2: -1/2 (d' P d), d = x - {p0,p1}, P = [[p2,p3],[p3,p4]] (precision matrix) */
+} kmc_density;
+
+enum {
+    KMC_F64 = 0 /* state and arithmetic in IEEE double, as the reference (Float64) */
+};
+
+/* kmc_config.flags */
+enum {
+    KMC_STORE_CHAIN = 1u << 0, /* keep thetas      (src/samplers.jl:269) on the device: [nsamples][nwalkers][ndim] */
+    KMC_STORE_LOGP  = 1u << 1, /* keep logdensities (src/samplers.jl:271): [nsamples][nwalkers] */
+    KMC_MOMENTS     = 1u << 2, /* streaming sum x, sum x^2 per dimension over the samples that would be stored */
+    KMC_NO_GRAPH    = 1u << 3  /* launch every half-step eagerly instead of replaying a hipGraph */
+};
+
+typedef struct kmc_config {
+    int32_t  dtype;         /* KMC_F64 */
+    int32_t  density;       /* kmc_density */
+    double   params[8];
+    int64_t  nwalkers;      /* GLOBAL ensemble size (all shards) */
+    int64_t  ndim;
+    int64_t  ngenerations;  /* niter_walker   = niter  / nwalkers   src/samplers.jl:203 */
+    int64_t  nburnin;       /* nburnin_walker = nburnin / nwalkers  src/samplers.jl:204 */
+    int64_t  nthin;         /*                                      src/samplers.jl:190 */
+    double   a_scale;       /*                                      src/samplers.jl:192 */
+    uint64_t seed;
+    uint32_t flags;
+    int32_t  device;        /* HIP device ordinal */
+    int32_t  shard_rank;    /* walker sharding: this sampler updates slice shard_rank ...          */
+    int32_t  shard_count;   /* ... of shard_count of EACH half; 1 = the whole ensemble (default 0 -> 1) */
+} kmc_config;
+
+/* Host output buffers of the one-shot call; any pointer may be NULL. */
+typedef struct kmc_outputs {
+    double*  chain;         /* [nsamples][nwalkers][ndim]  (needs KMC_STORE_CHAIN) */
+    double*  chain_logp;    /* [nsamples][nwalkers]        (needs KMC_STORE_LOGP)  */
+    double*  accept_ratio;  /* [nwalkers]                  src/samplers.jl:291 */
+    int64_t* naccept;       /* [nwalkers] */
+    double*  final_pos;     /* [nwalkers][ndim] */
+    double*  final_logp;    /* [nwalkers] */
+    double*  sum;           /* [ndim]  (needs KMC_MOMENTS) */
+    double*  sumsq;         /* [ndim] */
+    int64_t  nmoment;       /* out: number of (sample, walker) pairs accumulated */
+    int64_t  nsamples;      /* out: (ngenerations - nburnin) / nthin  src/samplers.jl:234 */
+    double   device_ms;     /* out: generation loop only, HIP events on the sampler's stream */
+} kmc_outputs;
+
+typedef struct kmc_sampler kmc_sampler; /* opaque */
+
+/* ---- library ---- */
+int         kmc_version(void);
+int         kmc_device_count(void);
+const char* kmc_last_error(void);
+const char* kmc_status_string(kmc_status st);
+
+/* Validation only: src/samplers.jl:200-205 plus argument sanity. No device needed. */
+kmc_status  kmc_validate(const kmc_config* cfg);
+
+/* Stretch-factor helpers (host): src/samplers.jl:224, :227. */
+double      kmc_g_pdf(double z, double a);
+double      kmc_cdf_g_inv(double u, double a);
+
+/* ---- one-shot: emcee + _emcee, src/samplers.jl:188-293 ---- */
+kmc_status  kmc_emcee_run(const kmc_config* cfg, const double* theta0 /* host [nwalkers][ndim] */,
+                          kmc_outputs* out);
+
+/* ---- stateful sampler (device-resident state; what bench.py and the distributed driver use) ---- */
+kmc_status  kmc_sampler_create(const kmc_config* cfg, kmc_sampler** out);
+void        kmc_sampler_destroy(kmc_sampler* s);
+/* Run on a caller-owned HIP stream (hipStream_t) instead of the sampler's own. */
+kmc_status  kmc_sampler_set_stream(kmc_sampler* s, void* hip_stream);
+/* Upload the ensemble (host, [nwalkers][ndim], global order), evaluate the initial log-pdfs on
+ * the device (src/samplers.jl:209-210), reset generation/counters.  Fails with
+ * KMC_ERR_NONFINITE_LOGP if any is not finite. */
+kmc_status  kmc_sampler_set_positions(kmc_sampler* s, const double* theta_host);
+/* Enqueue `ngenerations` generations (asynchronous).  shard_count must be 1. */
+kmc_status  kmc_sampler_run(kmc_sampler* s, int64_t ngenerations);
+/* Enqueue ONE half-step (src/samplers.jl:248-273) of the current generation over this shard's
+ * slice; half = 1 also advances the generation counter.  For walker-sharded drivers that
+ * exchange the updated slice between half-steps. */
+kmc_status  kmc_sampler_half_step(kmc_sampler* s, int half);
+kmc_status  kmc_sampler_sync(kmc_sampler* s);
+/* Milliseconds between the start of the first and the end of the last generation enqueued by
+ * the most recent kmc_sampler_run (HIP events); synchronises. */
+kmc_status  kmc_sampler_last_run_ms(kmc_sampler* s, double* ms);
+int64_t     kmc_sampler_generation(const kmc_sampler* s);
+int64_t     kmc_sampler_nsamples(const kmc_sampler* s);
+/* Number of half-step kernel launches enqueued so far and the algorithmic bytes each moves
+ * (read (2 ndim + 1) * 8, write (ndim + 1) * 8 per walker-step). */
+int64_t     kmc_sampler_launch_count(const kmc_sampler* s);
+
+/* Device pointers for zero-copy exchange (torch / RCCL): which = 0 positions [nwalkers][ndim],
+ * 1 logp [nwalkers], 2 naccept (uint32 [nwalkers]). */
+void*       kmc_sampler_device_ptr(kmc_sampler* s, int which);
+
+/* Downloads (synchronise the sampler's stream first). */
+kmc_status  kmc_sampler_get_positions(kmc_sampler* s, double* host /* [nwalkers][ndim] */);
+kmc_status  kmc_sampler_get_logp(kmc_sampler* s, double* host /* [nwalkers] */);
+kmc_status  kmc_sampler_get_naccept(kmc_sampler* s, int64_t* host /* [nwalkers] */);
+kmc_status  kmc_sampler_get_accept_ratio(kmc_sampler* s, double* host /* [nwalkers] */);
+kmc_status  kmc_sampler_get_moments(kmc_sampler* s, double* sum, double* sumsq /* [ndim] */, int64_t* n);
+/* Chain of this shard: [nsamples][nlocal][ndim] and [nsamples][nlocal]; nlocal = nwalkers /
+ * shard_count, local order = (first-half slice, second-half slice).  With shard_count == 1
+ * this is the global walker order. */
+kmc_status  kmc_sampler_get_chain(kmc_sampler* s, double* chain, double* chain_logp);
+
+/* ---- stateless device ops on caller-owned device memory ---- */
+/* logp[i] = log pdf(pos[i]) for nrows rows, src/samplers.jl:209. */
+kmc_status  kmc_logpdf_eval(const kmc_config* cfg, const double* pos_dev, double* logp_dev,
+                            int64_t nrows, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KISSMCMC_HIP_H */

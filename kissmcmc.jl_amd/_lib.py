@@ -1,0 +1,136 @@
+"""ctypes binding of ``libkissmcmc_hip.so`` (the C ABI in ``include/kissmcmc_hip.h``).
+
+There is no CPU fallback: if the library is missing, or no HIP device is visible when a sampler
+is created, this fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libkissmcmc_hip.so")
+
+# kmc_status
+OK, ERR_A_SCALE, ERR_ODD_WALKERS, ERR_TOO_FEW_WALKERS, ERR_BAD_ARG, ERR_NONFINITE_LOGP, \
+    ERR_HIP, ERR_OOM, ERR_NO_DEVICE, ERR_UNSUPPORTED = range(10)
+# kmc_density
+GAUSSIAN_ISO, EXPONENTIAL, ROSENBROCK, LOGNORMAL, MVNORMAL2 = range(5)
+F64 = 0
+STORE_CHAIN, STORE_LOGP, MOMENTS, NO_GRAPH = 1, 2, 4, 8
+
+# Every symbol include/kissmcmc_hip.h declares (tests check they are all exported).
+SYMBOLS = [
+    "kmc_version", "kmc_device_count", "kmc_last_error", "kmc_status_string", "kmc_validate",
+    "kmc_g_pdf", "kmc_cdf_g_inv", "kmc_emcee_run", "kmc_sampler_create", "kmc_sampler_destroy",
+    "kmc_sampler_set_stream", "kmc_sampler_set_positions", "kmc_sampler_run", "kmc_sampler_half_step",
+    "kmc_sampler_sync", "kmc_sampler_last_run_ms", "kmc_sampler_generation", "kmc_sampler_nsamples",
+    "kmc_sampler_launch_count", "kmc_sampler_device_ptr", "kmc_sampler_get_positions",
+    "kmc_sampler_get_logp", "kmc_sampler_get_naccept", "kmc_sampler_get_accept_ratio",
+    "kmc_sampler_get_moments", "kmc_sampler_get_chain", "kmc_logpdf_eval",
+]
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int32),
+        ("density", C.c_int32),
+        ("params", C.c_double * 8),
+        ("nwalkers", C.c_int64),
+        ("ndim", C.c_int64),
+        ("ngenerations", C.c_int64),
+        ("nburnin", C.c_int64),
+        ("nthin", C.c_int64),
+        ("a_scale", C.c_double),
+        ("seed", C.c_uint64),
+        ("flags", C.c_uint32),
+        ("device", C.c_int32),
+        ("shard_rank", C.c_int32),
+        ("shard_count", C.c_int32),
+    ]
+
+
+class Outputs(C.Structure):
+    _fields_ = [
+        ("chain", C.POINTER(C.c_double)),
+        ("chain_logp", C.POINTER(C.c_double)),
+        ("accept_ratio", C.POINTER(C.c_double)),
+        ("naccept", C.POINTER(C.c_int64)),
+        ("final_pos", C.POINTER(C.c_double)),
+        ("final_logp", C.POINTER(C.c_double)),
+        ("sum", C.POINTER(C.c_double)),
+        ("sumsq", C.POINTER(C.c_double)),
+        ("nmoment", C.c_int64),
+        ("nsamples", C.c_int64),
+        ("device_ms", C.c_double),
+    ]
+
+
+class KmcError(RuntimeError):
+    """A non-zero ``kmc_status``; ``.status`` holds the code."""
+
+    def __init__(self, status: int, message: str):
+        super().__init__(message)
+        self.status = status
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m kissmcmc_jl_amd.build` "
+            "(hipcc --offload-arch=gfx950). The emcee hot path has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    dp = C.POINTER(C.c_double)
+    ip = C.POINTER(C.c_int64)
+    vp = C.c_void_p
+    cfgp = C.POINTER(Config)
+    L.kmc_version.restype = C.c_int
+    L.kmc_device_count.restype = C.c_int
+    L.kmc_last_error.restype = C.c_char_p
+    L.kmc_status_string.restype = C.c_char_p
+    L.kmc_status_string.argtypes = [C.c_int]
+    L.kmc_validate.argtypes = [cfgp]
+    L.kmc_g_pdf.restype = C.c_double
+    L.kmc_g_pdf.argtypes = [C.c_double, C.c_double]
+    L.kmc_cdf_g_inv.restype = C.c_double
+    L.kmc_cdf_g_inv.argtypes = [C.c_double, C.c_double]
+    L.kmc_emcee_run.argtypes = [cfgp, dp, C.POINTER(Outputs)]
+    L.kmc_sampler_create.argtypes = [cfgp, C.POINTER(vp)]
+    L.kmc_sampler_destroy.restype = None
+    L.kmc_sampler_destroy.argtypes = [vp]
+    L.kmc_sampler_set_stream.argtypes = [vp, vp]
+    L.kmc_sampler_set_positions.argtypes = [vp, dp]
+    L.kmc_sampler_run.argtypes = [vp, C.c_int64]
+    L.kmc_sampler_half_step.argtypes = [vp, C.c_int]
+    L.kmc_sampler_sync.argtypes = [vp]
+    L.kmc_sampler_last_run_ms.argtypes = [vp, dp]
+    L.kmc_sampler_generation.restype = C.c_int64
+    L.kmc_sampler_generation.argtypes = [vp]
+    L.kmc_sampler_nsamples.restype = C.c_int64
+    L.kmc_sampler_nsamples.argtypes = [vp]
+    L.kmc_sampler_launch_count.restype = C.c_int64
+    L.kmc_sampler_launch_count.argtypes = [vp]
+    L.kmc_sampler_device_ptr.restype = vp
+    L.kmc_sampler_device_ptr.argtypes = [vp, C.c_int]
+    L.kmc_sampler_get_positions.argtypes = [vp, dp]
+    L.kmc_sampler_get_logp.argtypes = [vp, dp]
+    L.kmc_sampler_get_naccept.argtypes = [vp, ip]
+    L.kmc_sampler_get_accept_ratio.argtypes = [vp, dp]
+    L.kmc_sampler_get_moments.argtypes = [vp, dp, dp, ip]
+    L.kmc_sampler_get_chain.argtypes = [vp, dp, dp]
+    L.kmc_logpdf_eval.argtypes = [cfgp, vp, vp, C.c_int64, vp]
+    _lib = L
+    return L
+
+
+def check(status: int) -> None:
+    if status != OK:
+        L = lib()
+        msg = L.kmc_last_error().decode() or L.kmc_status_string(status).decode()
+        raise KmcError(status, msg)

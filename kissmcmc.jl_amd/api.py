@@ -1,0 +1,201 @@
+"""Host-side mirror of the reference's public interface for the emcee path -- same names,
+argument meaning and error behaviour -- over the C ABI:
+
+* ``emcee(pdf, theta0s; niter, nburnin, nthin, a_scale, ...)``  reference ``src/samplers.jl:188-216``
+* ``make_theta0s(theta0, ball_radius, pdf, nwalkers; ...)``      reference ``src/samplers.jl:311-349``
+* ``squash_walkers(thetas, accept_ratio, logdensities, blobs; ...)``  reference ``src/samplers.jl:372-428``
+
+Differences from the reference, all forced by the device boundary:
+``pdf`` must be a menu density (:mod:`.densities`); ``hasblob=True`` is rejected; a ``seed``
+keyword makes runs reproducible (the reference never seeds); outputs are dense ndarrays indexed
+``thetas[walker][sample]`` instead of vectors of vectors.
+"""
+from __future__ import annotations
+
+import sys
+
+import numpy as np
+
+from . import _lib
+from .densities import DeviceLogPdf
+from .sampler import Sampler
+
+
+def _fresh_seed() -> int:
+    return int(np.random.SeedSequence().generate_state(2, dtype=np.uint32).astype(np.uint64) @ np.array([1, 1 << 32], dtype=np.uint64))
+
+
+def emcee_counts(niter: int, nwalkers: int, nburnin=None, nthin: int = 1):
+    """The reference's integer bookkeeping: ``niter``/``nburnin`` count log-pdf evaluations over
+    all walkers (``src/samplers.jl:159``); per-walker counts are the floor divisions of
+    ``src/samplers.jl:203-204`` and the stored samples per walker that of ``:234``."""
+    if nburnin is None:
+        nburnin = niter // 2                                   # :190
+    niter_walker = niter // nwalkers                           # :203
+    nburnin_walker = nburnin // nwalkers                       # :204
+    nsamples_walker = (niter_walker - nburnin_walker) // nthin  # :234
+    return niter_walker, nburnin_walker, nsamples_walker
+
+
+def emcee(pdf, theta0s, niter: int = 10 ** 5, nburnin=None, nthin: int = 1, a_scale: float = 2.0,
+          use_progress_meter: bool = True, hasblob: bool = False, init_blobs=None, reduce_blob=None,
+          seed=None, device: int = 0):
+    """The affine-invariant ensemble sampler, on one MI355X.
+
+    Returns ``(thetas, accept_ratio, logdensities, blobs)`` like the reference
+    (``src/samplers.jl:292``): ``thetas[w][k]`` is sample ``k`` of walker ``w``
+    (shape ``[nwalkers, nsamples]`` for scalar walkers, ``[nwalkers, nsamples, ndim]`` otherwise),
+    ``accept_ratio[w]``, ``logdensities[w][k]``, and ``blobs = None``.
+    """
+    if hasblob or init_blobs is not None or reduce_blob is not None:
+        raise NotImplementedError("blobs are arbitrary host objects and cannot cross the device boundary "
+                                  "(hasblob=True is not supported by the HIP emcee path)")
+    if not isinstance(pdf, DeviceLogPdf):
+        raise TypeError("emcee on the device needs a menu log-density (GaussianIso, Exponential, Rosenbrock, "
+                        f"LogNormal, MvNormal2); got {type(pdf).__name__}. There is no CPU fallback.")
+    theta0s = np.array(theta0s, dtype=np.float64)              # :198 deepcopy
+    scalar_walkers = theta0s.ndim == 1
+    if scalar_walkers:
+        theta0s = theta0s[:, None]
+    if theta0s.ndim != 2:
+        raise ValueError("theta0s must be a vector of walkers (scalars or equal-length vectors)")
+    nwalkers, ndim = theta0s.shape
+    # the reference's asserts, in its order (:200, :202, :205)
+    if not a_scale > 1:
+        raise AssertionError("a_scale>1")
+    if nwalkers % 2 != 0:
+        raise AssertionError("Use an even number of walkers.")
+    niter_walker, nburnin_walker, nsamples_walker = emcee_counts(niter, nwalkers, nburnin, nthin)
+    if nwalkers < ndim + 2:
+        raise AssertionError("Use more walkers: at least DOF+2, but better many more.")
+    if seed is None:
+        seed = _fresh_seed()
+
+    with Sampler(pdf, nwalkers, ndim, niter_walker, nburnin_walker, nthin, a_scale, seed,
+                 store_chain=True, store_logp=True, device=device) as s:
+        try:
+            s.set_positions(theta0s)
+        except _lib.KmcError as e:
+            if e.status == _lib.ERR_NONFINITE_LOGP:
+                raise ValueError(f"{e} (use make_theta0s to build an initial ensemble with pdf > -Inf)") from e
+            raise
+        if use_progress_meter and niter_walker > 0:
+            nchunks = min(20, niter_walker)
+            done = 0
+            for c in range(nchunks):
+                upto = (niter_walker * (c + 1)) // nchunks
+                s.run(upto - done)
+                done = upto
+                s.sync()
+                na = s.naccept()
+                nn = max(1, done - nburnin_walker if done > nburnin_walker else done)
+                print(f"\remcee, niter={niter}, nwalkers={nwalkers}: generation {done}/{niter_walker} "
+                      f"accept_ratio_mean={na.mean() / nn:.3g} burnin_phase={done <= nburnin_walker}",
+                      end="", file=sys.stderr)
+            print(file=sys.stderr)
+        else:
+            s.run(niter_walker)
+        s.sync()
+        chain, chain_logp = s.chain(logp=True)
+        accept_ratio = s.accept_ratio()
+
+    thetas = np.ascontiguousarray(chain.transpose(1, 0, 2))    # [walker][sample][dim]
+    if scalar_walkers:
+        thetas = thetas[:, :, 0]
+    logdensities = np.ascontiguousarray(chain_logp.T)          # [walker][sample]
+    assert thetas.shape[1] == nsamples_walker
+    return thetas, accept_ratio, logdensities, None
+
+
+def make_theta0s(theta0, ball_radius, pdf, nwalkers: int, ball_radius_halfing_steps: int = 7,
+                 ntries: int = 100, hasblob: bool = False, rng=None):
+    """Initial ensemble in a Gaussian ball around ``theta0`` with ``pdf > -Inf``
+    (reference ``src/samplers.jl:311-349``).  ``rng`` is a ``numpy.random.Generator`` (or a seed);
+    the normal draws are consumed walker by walker, try by try, like the reference's ``randn``.
+
+    Returns an array of shape ``[nwalkers]`` (scalar ``theta0``) or ``[nwalkers, npara]``.
+    Unlike the reference -- whose final ``error(...)`` is unreachable -- this
+    raises when no admissible point is found for a walker.
+    """
+    if hasblob:
+        raise NotImplementedError("hasblob=True is not supported by the HIP emcee path")
+    if not callable(pdf):
+        raise TypeError("pdf must be callable")
+    rng = np.random.default_rng(rng)
+    scalar = np.ndim(theta0) == 0
+    theta0 = float(theta0) if scalar else np.asarray(theta0, dtype=np.float64)
+    npara = 1 if scalar else theta0.shape[0]                   # :315
+    if np.ndim(ball_radius) == 0 and not scalar:               # :316-318
+        ball_radius = np.ones(npara) * float(ball_radius)
+    ball_radius = float(ball_radius) if np.ndim(ball_radius) == 0 else np.asarray(ball_radius, dtype=np.float64)
+    if np.size(ball_radius) != npara:                          # :319
+        raise AssertionError("length(ball_radius)==npara")
+
+    # Fast path: when every first try is admissible the result equals the sequential loop's.
+    state = rng.bit_generator.state
+    if scalar:
+        cand = theta0 + rng.standard_normal(nwalkers) * ball_radius
+        rows = cand[:, None]
+    else:
+        cand = theta0 + rng.standard_normal((nwalkers, npara)) * ball_radius
+        rows = cand
+    finite = getattr(pdf, "finite_rows", None)
+    ok = finite(rows) if finite is not None else np.array([pdf(r if not scalar else r[0]) > -np.inf for r in rows])
+    if bool(np.all(ok)):
+        return cand
+    rng.bit_generator.state = state
+
+    out = []
+    for i in range(1, nwalkers + 1):                           # :323
+        for k in range(1, ball_radius_halfing_steps + 1):      # :324
+            ball_radius = ball_radius * (1 / 2 ** (k - 1))     # :326 (never reset, as in the reference)
+            for _ in range(ntries):                            # :327
+                if npara == 1:                                 # :328-332
+                    tmp = theta0 + rng.standard_normal() * ball_radius
+                else:
+                    tmp = theta0 + rng.standard_normal(npara) * ball_radius
+                if pdf(tmp) > -np.inf:                         # :336-338
+                    out.append(tmp)
+                    break
+            if len(out) == i:                                  # :343
+                break
+        if len(out) != i:
+            raise RuntimeError("Could not find suitable initial theta.  PDF is zero in too many places inside ball.")
+    return np.array(out, dtype=np.float64).reshape((nwalkers,) if scalar else (nwalkers, npara))
+
+
+def squash_walkers(thetas, accept_ratio, logdensities=None, blobs=None, drop_low_accept_ratio: bool = False,
+                   drop_fact=2, verbose: bool = True, order: bool = False, merge_blobs=None):
+    """Put the samples of all walkers into one array (reference ``src/samplers.jl:372-428``).
+
+    Default order is walker-major (``[w1 samples..., w2 samples..., ...]``, ``:398-399``);
+    ``order=True`` gives sample-major with walkers in index order inside each step (``:415-426``).
+    Returns ``(thetas, mean(accept_ratio[kept]), logdensities, blobs)``.
+    """
+    if blobs is not None:
+        raise NotImplementedError("blobs are not produced by the HIP emcee path")
+    thetas = np.asarray(thetas)
+    accept_ratio = np.asarray(accept_ratio, dtype=np.float64)
+    nwalkers = accept_ratio.shape[0]                           # :379
+    if drop_low_accept_ratio:                                  # :380-393
+        ma = float(np.median(accept_ratio))
+        sa = float(np.std(accept_ratio, ddof=1))
+        if verbose:
+            print(f"Median accept ratio is {ma}, standard deviation is {sa}\n")
+        keep = ~(accept_ratio <= ma - drop_fact * sa)
+        if verbose:
+            for nc in np.nonzero(~keep)[0]:
+                print(f"Dropping walker {nc + 1} with low accept ratio {accept_ratio[nc]}")
+        walkers2keep = np.nonzero(keep)[0]
+    else:
+        walkers2keep = np.arange(nwalkers)                     # :395
+
+    def flat(a):
+        a = np.asarray(a)[walkers2keep]                        # [kept][sample](...)
+        if order:                                              # :415-426: stable sort by sample index
+            a = np.swapaxes(a, 0, 1)
+        return np.ascontiguousarray(a).reshape((-1,) + a.shape[2:])
+
+    t = flat(thetas)                                           # :398-399
+    l = None if logdensities is None else flat(logdensities)   # :401-406
+    return t, float(np.mean(accept_ratio[walkers2keep])), l, None   # :427

@@ -1,0 +1,702 @@
+// kmc_api.hip -- host side of the C ABI declared in include/kissmcmc_hip.h.
+//
+// Implements the reference's `emcee` front-end bookkeeping (src/samplers.jl:188-216) and the
+// `_emcee` generation loop (src/samplers.jl:232-293) as a stream of half-step kernel launches:
+// two dependent launches per generation, replayed from a hipGraph in chunks of
+// kGraphChunk generations (the kernel boundary is the join of src/samplers.jl:273).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/kissmcmc_hip.h"
+#include "kmc_kernels.hpp"
+
+using namespace kmc;
+
+#define KMC_EXPORT extern "C" __attribute__((visibility("default")))
+
+namespace {
+
+thread_local std::string g_err;
+
+kmc_status fail(kmc_status st, const std::string& msg)
+{
+    g_err = msg;
+    return st;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            (void)hipGetLastError();                                                           \
+            return fail(e_ == hipErrorOutOfMemory ? KMC_ERR_OOM : KMC_ERR_HIP,                 \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                    \
+        }                                                                                      \
+    } while (0)
+
+#define KMC_TRY(expr)                                                                          \
+    do {                                                                                       \
+        kmc_status s_ = (expr);                                                                \
+        if (s_ != KMC_OK) return s_;                                                           \
+    } while (0)
+
+constexpr int64_t kGraphChunk = 64;   // generations per hipGraph replay (128 kernel nodes + 1)
+
+using HalfStepFn = void (*)(const HalfStepArgs);
+using LogpdfFn = void (*)(const double*, double*, int64_t, int, DensityParams);
+
+struct Plan {
+    HalfStepFn fn = nullptr;
+    bool vec = false;
+    int L = 1, K = 1, ITER = 1;
+};
+
+// ---- kernel table ------------------------------------------------------------------------
+template <class D, int L, int K>
+HalfStepFn vec_iter(int iter)
+{
+    switch (iter) {
+    case 1: return half_step_vec<D, L, K, 1>;
+    case 2: return half_step_vec<D, L, K, 2>;
+    case 4: return half_step_vec<D, L, K, 4>;
+    default: return nullptr;
+    }
+}
+
+template <class D>
+HalfStepFn vec_lookup(int L, int K, int iter)
+{
+    if constexpr (!D::kHasFrag) {
+        return nullptr;
+    } else {
+#define KMC_LK(l, k) if (L == l && K == k) return vec_iter<D, l, k>(iter);
+        KMC_LK(4, 1) KMC_LK(8, 1) KMC_LK(16, 1) KMC_LK(32, 1) KMC_LK(64, 1)
+        KMC_LK(8, 2) KMC_LK(16, 2) KMC_LK(32, 2) KMC_LK(64, 2)
+        KMC_LK(64, 4) KMC_LK(64, 8)
+#undef KMC_LK
+        return nullptr;
+    }
+}
+
+template <class D>
+void density_fns(int L, int K, int iter, HalfStepFn* vec, HalfStepFn* gen, LogpdfFn* lp)
+{
+    *vec = vec_lookup<D>(L, K, iter);
+    *gen = half_step_generic<D>;
+    *lp = logpdf_rows<D>;
+}
+
+bool lookup(int density, int L, int K, int iter, HalfStepFn* vec, HalfStepFn* gen, LogpdfFn* lp)
+{
+    switch (density) {
+    case KMC_GAUSSIAN_ISO: density_fns<GaussianIso>(L, K, iter, vec, gen, lp); return true;
+    case KMC_EXPONENTIAL: density_fns<Exponential>(L, K, iter, vec, gen, lp); return true;
+    case KMC_ROSENBROCK: density_fns<Rosenbrock>(L, K, iter, vec, gen, lp); return true;
+    case KMC_LOGNORMAL: density_fns<LogNormal>(L, K, iter, vec, gen, lp); return true;
+    case KMC_MVNORMAL2: density_fns<MvNormal2>(L, K, iter, vec, gen, lp); return true;
+    default: return false;
+    }
+}
+
+// Default geometry per ndim; KMC_PLAN="L,K,ITER" (or "generic") overrides for tuning.
+Plan make_plan(const kmc_config& c, int64_t n_active)
+{
+    Plan p;
+    HalfStepFn vec = nullptr, gen = nullptr;
+    LogpdfFn lp = nullptr;
+    int L = 0, K = 0, iter = 1;
+    const char* env = std::getenv("KMC_PLAN");
+    bool force_generic = false;
+    if (env && std::strcmp(env, "generic") == 0) force_generic = true;
+    else if (env && std::sscanf(env, "%d,%d,%d", &L, &K, &iter) == 3) { /* forced */ }
+    else {
+        L = 0;
+        const int64_t nd = c.ndim;
+        if (nd % 2 == 0) {
+            struct { int nd, L, K; } tbl[] = {{8, 4, 1},   {16, 8, 1},   {32, 16, 1},  {64, 32, 1}, {128, 64, 1},
+                                              {256, 64, 2}, {512, 64, 4}, {1024, 64, 8}};
+            for (auto& t : tbl)
+                if (t.nd == nd) { L = t.L; K = t.K; }
+        }
+        // enough walkers per group to amortise the scalar work, while keeping >= ~2048 waves
+        iter = 1;
+        if (L > 0) {
+            const int64_t waves1 = n_active * L / 64;
+            if (waves1 >= 8192) iter = 4;
+            else if (waves1 >= 4096) iter = 2;
+        }
+    }
+    lookup(c.density, L, K, iter, &vec, &gen, &lp);
+    if (!force_generic && L > 0 && 2 * L * K == c.ndim && vec != nullptr) {
+        p.fn = vec; p.vec = true; p.L = L; p.K = K; p.ITER = iter;
+    } else {
+        p.fn = gen; p.vec = false; p.L = 1; p.K = 1; p.ITER = 1;
+    }
+    return p;
+}
+
+kmc_status digest_params(const kmc_config& c, DensityParams* dp)
+{
+    for (double& v : dp->p) v = 0.0;
+    const double* p = c.params;
+    switch (c.density) {
+    case KMC_GAUSSIAN_ISO:
+        if (!(p[1] > 0.0)) return fail(KMC_ERR_BAD_ARG, "gaussian: sigma must be > 0");
+        dp->p[0] = p[0]; dp->p[1] = 1.0 / p[1];
+        return KMC_OK;
+    case KMC_EXPONENTIAL:
+        if (!(p[0] > 0.0)) return fail(KMC_ERR_BAD_ARG, "exponential: rate must be > 0");
+        dp->p[0] = p[0];
+        return KMC_OK;
+    case KMC_ROSENBROCK:
+        if (!(p[2] > 0.0)) return fail(KMC_ERR_BAD_ARG, "rosenbrock: scale must be > 0");
+        dp->p[0] = p[0]; dp->p[1] = p[1]; dp->p[2] = 1.0 / p[2];
+        return KMC_OK;
+    case KMC_LOGNORMAL:
+        if (!(p[1] > 0.0)) return fail(KMC_ERR_BAD_ARG, "lognormal: sigma must be > 0");
+        dp->p[0] = p[0]; dp->p[1] = p[1];
+        return KMC_OK;
+    case KMC_MVNORMAL2:
+        for (int i = 0; i < 5; ++i) dp->p[i] = p[i];
+        return KMC_OK;
+    default:
+        return fail(KMC_ERR_BAD_ARG, "unknown density id");
+    }
+}
+
+}  // namespace
+
+struct kmc_sampler {
+    kmc_config cfg{};
+    int64_t h = 0, h_loc = 0, active_begin = 0, nlocal = 0, nsamples = 0;
+    DensityParams dp{};
+    Plan plan{};
+    LogpdfFn logpdf_fn = nullptr;
+    int grid = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    double* d_pos = nullptr;
+    double* d_logp = nullptr;
+    uint32_t* d_naccept = nullptr;
+    int64_t* d_gen = nullptr;
+    double* d_chain = nullptr;
+    double* d_chain_logp = nullptr;
+    double* d_msum = nullptr;
+    double* d_msumsq = nullptr;
+    int64_t macc_stride = 0, macc_elems = 0;
+    int64_t generation = 0;   // generations enqueued so far
+    int64_t dev_gen = 0;      // value the device counter will hold once the stream drains
+    int64_t launches = 0;
+    hipGraphExec_t graph_exec = nullptr;
+    hipGraph_t graph = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool have_run_events = false;
+    bool positions_set = false;
+};
+
+namespace {
+
+HalfStepArgs make_args(const kmc_sampler* s, int half, bool graph_mode, int64_t gen_offset)
+{
+    HalfStepArgs a{};
+    a.pos = s->d_pos;
+    a.logp = s->d_logp;
+    a.naccept = s->d_naccept;
+    a.gen_base = graph_mode ? s->d_gen : nullptr;
+    a.gen_offset = gen_offset;
+    a.nburnin = s->cfg.nburnin;
+    a.nthin = s->cfg.nthin;
+    a.nsamples = s->nsamples;
+    a.nhalf = s->h;
+    a.active_begin = s->active_begin;
+    a.n_active = (int32_t)s->h_loc;
+    a.half = half;
+    a.ndim = (int32_t)s->cfg.ndim;
+    a.dc.seed_lo = (uint32_t)s->cfg.seed;
+    a.dc.seed_hi = (uint32_t)(s->cfg.seed >> 32);
+    a.dc.nhalf = (uint32_t)s->h;
+    a.dc.c0 = std::sqrt(1.0 / s->cfg.a_scale);                            // src/samplers.jl:227
+    a.dc.c1 = std::sqrt(s->cfg.a_scale) - std::sqrt(1.0 / s->cfg.a_scale);
+    a.dc.nm1 = (double)(s->cfg.ndim - 1);
+    a.dp = s->dp;
+    a.chain = s->d_chain;
+    a.chain_logp = s->d_chain_logp;
+    a.chain_rows = s->nlocal;
+    a.chain_row0 = (int64_t)half * s->h_loc;
+    a.msum = s->d_msum;
+    a.msumsq = s->d_msumsq;
+    a.macc_stride = s->macc_stride;
+    return a;
+}
+
+kmc_status launch_half(kmc_sampler* s, int half, bool graph_mode, int64_t gen_offset)
+{
+    const HalfStepArgs a = make_args(s, half, graph_mode, gen_offset);
+    hipLaunchKernelGGL(s->plan.fn, dim3(s->grid), dim3(256), 0, s->stream, a);
+    HIP_TRY(hipGetLastError());
+    return KMC_OK;
+}
+
+kmc_status sync_device_counter(kmc_sampler* s)
+{
+    if (s->dev_gen != s->generation) {
+        hipLaunchKernelGGL(bump_generation, dim3(1), dim3(1), 0, s->stream, s->d_gen,
+                           s->generation - s->dev_gen);
+        HIP_TRY(hipGetLastError());
+        s->dev_gen = s->generation;
+    }
+    return KMC_OK;
+}
+
+kmc_status ensure_graph(kmc_sampler* s)
+{
+    if (s->graph_exec) return KMC_OK;
+    HIP_TRY(hipStreamBeginCapture(s->stream, hipStreamCaptureModeRelaxed));
+    kmc_status st = KMC_OK;
+    for (int64_t g = 0; g < kGraphChunk && st == KMC_OK; ++g)
+        for (int half = 0; half < 2 && st == KMC_OK; ++half) st = launch_half(s, half, true, g);
+    if (st == KMC_OK) {
+        hipLaunchKernelGGL(bump_generation, dim3(1), dim3(1), 0, s->stream, s->d_gen, kGraphChunk);
+    }
+    hipGraph_t graph = nullptr;
+    hipError_t e = hipStreamEndCapture(s->stream, &graph);
+    if (st != KMC_OK) { if (graph) (void)hipGraphDestroy(graph); return st; }
+    HIP_TRY(e);
+    s->graph = graph;
+    HIP_TRY(hipGraphInstantiate(&s->graph_exec, graph, nullptr, nullptr, 0));
+    return KMC_OK;
+}
+
+int64_t samples_done(const kmc_sampler* s)
+{
+    const int64_t post = s->generation - s->cfg.nburnin;
+    if (post <= 0) return 0;
+    const int64_t k = post / s->cfg.nthin;
+    return k < s->nsamples ? k : s->nsamples;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// library
+// ------------------------------------------------------------------------------------------
+KMC_EXPORT int kmc_version(void) { return KMC_VERSION; }
+
+KMC_EXPORT int kmc_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+KMC_EXPORT const char* kmc_last_error(void) { return g_err.c_str(); }
+
+KMC_EXPORT const char* kmc_status_string(kmc_status st)
+{
+    switch (st) {
+    case KMC_OK: return "ok";
+    case KMC_ERR_A_SCALE: return "a_scale must be > 1";
+    case KMC_ERR_ODD_WALKERS: return "Use an even number of walkers.";
+    case KMC_ERR_TOO_FEW_WALKERS: return "Use more walkers: at least DOF+2, but better many more.";
+    case KMC_ERR_BAD_ARG: return "bad argument";
+    case KMC_ERR_NONFINITE_LOGP: return "initial walker with non-finite log-pdf";
+    case KMC_ERR_HIP: return "HIP runtime error";
+    case KMC_ERR_OOM: return "out of device memory";
+    case KMC_ERR_NO_DEVICE: return "no HIP device";
+    case KMC_ERR_UNSUPPORTED: return "unsupported configuration";
+    }
+    return "unknown status";
+}
+
+// src/samplers.jl:200-205
+KMC_EXPORT kmc_status kmc_validate(const kmc_config* c)
+{
+    if (!c) return fail(KMC_ERR_BAD_ARG, "null config");
+    if (c->dtype != KMC_F64) return fail(KMC_ERR_UNSUPPORTED, "only KMC_F64 is implemented");
+    if (c->nwalkers <= 0 || c->ndim <= 0 || c->nthin <= 0 || c->ngenerations < 0 || c->nburnin < 0)
+        return fail(KMC_ERR_BAD_ARG, "nwalkers, ndim, nthin must be > 0 and ngenerations, nburnin >= 0");
+    if (!(c->a_scale > 1.0)) return fail(KMC_ERR_A_SCALE, kmc_status_string(KMC_ERR_A_SCALE));
+    if (c->nwalkers % 2 != 0) return fail(KMC_ERR_ODD_WALKERS, kmc_status_string(KMC_ERR_ODD_WALKERS));
+    if (c->nwalkers < c->ndim + 2) return fail(KMC_ERR_TOO_FEW_WALKERS, kmc_status_string(KMC_ERR_TOO_FEW_WALKERS));
+    if (c->nwalkers / 2 >= (int64_t)1 << 31 || c->ndim >= (int64_t)1 << 24)
+        return fail(KMC_ERR_UNSUPPORTED, "ensemble too large");
+    if (c->density == KMC_ROSENBROCK && c->ndim < 2) return fail(KMC_ERR_BAD_ARG, "rosenbrock needs ndim >= 2");
+    if (c->density == KMC_MVNORMAL2 && c->ndim != 2) return fail(KMC_ERR_BAD_ARG, "mvnormal2 needs ndim == 2");
+    const int P = c->shard_count <= 0 ? 1 : c->shard_count;
+    if (c->shard_rank < 0 || c->shard_rank >= P) return fail(KMC_ERR_BAD_ARG, "shard_rank out of range");
+    if ((c->nwalkers / 2) % P != 0) return fail(KMC_ERR_BAD_ARG, "nwalkers/2 must be divisible by shard_count");
+    DensityParams dp;
+    return digest_params(*c, &dp);
+}
+
+KMC_EXPORT double kmc_g_pdf(double z, double a)   // src/samplers.jl:224
+{
+    return (1.0 / a <= z && z <= a) ? 1.0 / std::sqrt(z) * 1.0 / (2.0 * (std::sqrt(a) - std::sqrt(1.0 / a))) : 0.0;
+}
+
+KMC_EXPORT double kmc_cdf_g_inv(double u, double a)   // src/samplers.jl:227
+{
+    const double t = std::fma(u, std::sqrt(a) - std::sqrt(1.0 / a), std::sqrt(1.0 / a));
+    return t * t;
+}
+
+// ------------------------------------------------------------------------------------------
+// sampler
+// ------------------------------------------------------------------------------------------
+KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** out)
+{
+    if (!out) return fail(KMC_ERR_BAD_ARG, "null out");
+    *out = nullptr;
+    KMC_TRY(kmc_validate(cfg));
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        (void)hipGetLastError();
+        return fail(KMC_ERR_NO_DEVICE, "no HIP device visible: the emcee hot path has no CPU fallback");
+    }
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(KMC_ERR_BAD_ARG, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(cfg->device));
+
+    kmc_sampler* s = new kmc_sampler();
+    s->cfg = *cfg;
+    if (s->cfg.shard_count <= 0) s->cfg.shard_count = 1;
+    s->h = cfg->nwalkers / 2;
+    s->h_loc = s->h / s->cfg.shard_count;
+    s->active_begin = s->h_loc * s->cfg.shard_rank;
+    s->nlocal = 2 * s->h_loc;
+    s->nsamples = cfg->ngenerations > cfg->nburnin ? (cfg->ngenerations - cfg->nburnin) / cfg->nthin : 0;   // :234
+    kmc_status st = digest_params(*cfg, &s->dp);
+    if (st != KMC_OK) { delete s; return st; }
+    s->plan = make_plan(s->cfg, s->h_loc);
+    {
+        HalfStepFn v, g;
+        lookup(cfg->density, 0, 0, 1, &v, &g, &s->logpdf_fn);
+    }
+    const int64_t groups = (s->h_loc + s->plan.ITER - 1) / s->plan.ITER;
+    const int64_t threads = groups * s->plan.L;
+    s->grid = (int)((threads + 255) / 256);
+    s->macc_stride = (int64_t)s->grid * 256;
+    s->macc_elems = s->plan.vec ? s->macc_stride * 2 * s->plan.K : s->macc_stride * cfg->ndim;
+
+#define CREATE_TRY(expr)                                                                       \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            (void)hipGetLastError();                                                           \
+            kmc_status r_ = fail(e_ == hipErrorOutOfMemory ? KMC_ERR_OOM : KMC_ERR_HIP,        \
+                                 std::string(#expr) + ": " + hipGetErrorString(e_));           \
+            kmc_sampler_destroy(s);                                                            \
+            return r_;                                                                         \
+        }                                                                                      \
+    } while (0)
+
+    CREATE_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    s->own_stream = true;
+    CREATE_TRY(hipEventCreate(&s->ev0));
+    CREATE_TRY(hipEventCreate(&s->ev1));
+    const size_t nw = (size_t)cfg->nwalkers, nd = (size_t)cfg->ndim;
+    CREATE_TRY(hipMalloc(&s->d_pos, nw * nd * sizeof(double)));
+    CREATE_TRY(hipMalloc(&s->d_logp, nw * sizeof(double)));
+    CREATE_TRY(hipMalloc(&s->d_naccept, nw * sizeof(uint32_t)));
+    CREATE_TRY(hipMalloc(&s->d_gen, 64));
+    CREATE_TRY(hipMemset(s->d_gen, 0, 64));
+    CREATE_TRY(hipMemset(s->d_naccept, 0, nw * sizeof(uint32_t)));
+    if (cfg->flags & KMC_MOMENTS) {
+        CREATE_TRY(hipMalloc(&s->d_msum, (size_t)s->macc_elems * sizeof(double)));
+        CREATE_TRY(hipMalloc(&s->d_msumsq, (size_t)s->macc_elems * sizeof(double)));
+        CREATE_TRY(hipMemset(s->d_msum, 0, (size_t)s->macc_elems * sizeof(double)));
+        CREATE_TRY(hipMemset(s->d_msumsq, 0, (size_t)s->macc_elems * sizeof(double)));
+    }
+    if ((cfg->flags & KMC_STORE_CHAIN) && s->nsamples > 0)
+        CREATE_TRY(hipMalloc(&s->d_chain, (size_t)s->nsamples * (size_t)s->nlocal * nd * sizeof(double)));
+    if ((cfg->flags & KMC_STORE_LOGP) && s->nsamples > 0)
+        CREATE_TRY(hipMalloc(&s->d_chain_logp, (size_t)s->nsamples * (size_t)s->nlocal * sizeof(double)));
+#undef CREATE_TRY
+    *out = s;
+    return KMC_OK;
+}
+
+KMC_EXPORT void kmc_sampler_destroy(kmc_sampler* s)
+{
+    if (!s) return;
+    (void)hipSetDevice(s->cfg.device);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    if (s->graph_exec) (void)hipGraphExecDestroy(s->graph_exec);
+    if (s->graph) (void)hipGraphDestroy(s->graph);
+    if (s->ev0) (void)hipEventDestroy(s->ev0);
+    if (s->ev1) (void)hipEventDestroy(s->ev1);
+    (void)hipFree(s->d_pos);
+    (void)hipFree(s->d_logp);
+    (void)hipFree(s->d_naccept);
+    (void)hipFree(s->d_gen);
+    (void)hipFree(s->d_chain);
+    (void)hipFree(s->d_chain_logp);
+    (void)hipFree(s->d_msum);
+    (void)hipFree(s->d_msumsq);
+    if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
+    (void)hipGetLastError();
+    delete s;
+}
+
+KMC_EXPORT kmc_status kmc_sampler_set_stream(kmc_sampler* s, void* hip_stream)
+{
+    if (!s) return fail(KMC_ERR_BAD_ARG, "null sampler");
+    HIP_TRY(hipSetDevice(s->cfg.device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
+    s->stream = (hipStream_t)hip_stream;
+    s->own_stream = false;
+    return KMC_OK;
+}
+
+KMC_EXPORT kmc_status kmc_sampler_set_positions(kmc_sampler* s, const double* theta_host)
+{
+    if (!s || !theta_host) return fail(KMC_ERR_BAD_ARG, "null argument");
+    HIP_TRY(hipSetDevice(s->cfg.device));
+    const size_t nw = (size_t)s->cfg.nwalkers, nd = (size_t)s->cfg.ndim;
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(hipMemcpy(s->d_pos, theta_host, nw * nd * sizeof(double), hipMemcpyHostToDevice));   // :198 (caller's array untouched)
+    hipLaunchKernelGGL(s->logpdf_fn, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s->stream,
+                       (const double*)s->d_pos, s->d_logp, (int64_t)nw, (int)nd, s->dp);          // :209-210
+    HIP_TRY(hipGetLastError());
+    std::vector<double> lp(nw);
+    HIP_TRY(hipMemcpyAsync(lp.data(), s->d_logp, nw * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipMemsetAsync(s->d_naccept, 0, nw * sizeof(uint32_t), s->stream));
+    HIP_TRY(hipMemsetAsync(s->d_gen, 0, 64, s->stream));
+    if (s->d_msum) {
+        HIP_TRY(hipMemsetAsync(s->d_msum, 0, (size_t)s->macc_elems * sizeof(double), s->stream));
+        HIP_TRY(hipMemsetAsync(s->d_msumsq, 0, (size_t)s->macc_elems * sizeof(double), s->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    s->generation = 0;
+    s->dev_gen = 0;
+    s->launches = 0;
+    s->have_run_events = false;
+    for (size_t w = 0; w < nw; ++w)
+        if (!std::isfinite(lp[w])) {
+            s->positions_set = false;
+            return fail(KMC_ERR_NONFINITE_LOGP,
+                        "walker " + std::to_string(w) + " has a non-finite initial log-pdf");
+        }
+    s->positions_set = true;
+    return KMC_OK;
+}
+
+KMC_EXPORT kmc_status kmc_sampler_run(kmc_sampler* s, int64_t ngen)
+{
+    if (!s || ngen < 0) return fail(KMC_ERR_BAD_ARG, "bad argument");
+    if (!s->positions_set) return fail(KMC_ERR_BAD_ARG, "kmc_sampler_set_positions has not succeeded yet");
+    if (s->cfg.shard_count != 1)
+        return fail(KMC_ERR_UNSUPPORTED, "kmc_sampler_run needs shard_count == 1; sharded drivers call kmc_sampler_half_step");
+    HIP_TRY(hipSetDevice(s->cfg.device));
+    HIP_TRY(hipEventRecord(s->ev0, s->stream));
+    const bool use_graph = !(s->cfg.flags & KMC_NO_GRAPH);
+    while (use_graph && ngen >= kGraphChunk) {
+        KMC_TRY(ensure_graph(s));
+        KMC_TRY(sync_device_counter(s));
+        HIP_TRY(hipGraphLaunch(s->graph_exec, s->stream));
+        s->generation += kGraphChunk;
+        s->dev_gen += kGraphChunk;
+        s->launches += 2 * kGraphChunk;
+        ngen -= kGraphChunk;
+    }
+    for (; ngen > 0; --ngen) {
+        for (int half = 0; half < 2; ++half) KMC_TRY(launch_half(s, half, false, s->generation));
+        s->generation += 1;
+        s->launches += 2;
+    }
+    HIP_TRY(hipEventRecord(s->ev1, s->stream));
+    s->have_run_events = true;
+    return KMC_OK;
+}
+
+KMC_EXPORT kmc_status kmc_sampler_half_step(kmc_sampler* s, int half)
+{
+    if (!s || (half != 0 && half != 1)) return fail(KMC_ERR_BAD_ARG, "bad argument");
+    if (!s->positions_set) return fail(KMC_ERR_BAD_ARG, "kmc_sampler_set_positions has not succeeded yet");
+    HIP_TRY(hipSetDevice(s->cfg.device));
+    KMC_TRY(launch_half(s, half, false, s->generation));
+    s->launches += 1;
+    if (half == 1) s->generation += 1;
+    return KMC_OK;
+}
+
+KMC_EXPORT kmc_status kmc_sampler_sync(kmc_sampler* s)
+{
+    if (!s) return fail(KMC_ERR_BAD_ARG, "null sampler");
+    HIP_TRY(hipSetDevice(s->cfg.device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return KMC_OK;
+}
+
+KMC_EXPORT kmc_status kmc_sampler_last_run_ms(kmc_sampler* s, double* ms)
+{
+    if (!s || !ms) return fail(KMC_ERR_BAD_ARG, "null argument");
+    if (!s->have_run_events) return fail(KMC_ERR_BAD_ARG, "no kmc_sampler_run yet");
+    HIP_TRY(hipSetDevice(s->cfg.device));
+    HIP_TRY(hipEventSynchronize(s->ev1));
+    float f = 0.f;
+    HIP_TRY(hipEventElapsedTime(&f, s->ev0, s->ev1));
+    *ms = (double)f;
+    return KMC_OK;
+}
+
+KMC_EXPORT int64_t kmc_sampler_generation(const kmc_sampler* s) { return s ? s->generation : -1; }
+KMC_EXPORT int64_t kmc_sampler_nsamples(const kmc_sampler* s) { return s ? s->nsamples : -1; }
+KMC_EXPORT int64_t kmc_sampler_launch_count(const kmc_sampler* s) { return s ? s->launches : -1; }
+
+KMC_EXPORT void* kmc_sampler_device_ptr(kmc_sampler* s, int which)
+{
+    if (!s) return nullptr;
+    switch (which) {
+    case 0: return s->d_pos;
+    case 1: return s->d_logp;
+    case 2: return s->d_naccept;
+    default: return nullptr;
+    }
+}
+
+KMC_EXPORT kmc_status kmc_sampler_get_positions(kmc_sampler* s, double* host)
+{
+    if (!s || !host) return fail(KMC_ERR_BAD_ARG, "null argument");
+    HIP_TRY(hipSetDevice(s->cfg.device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(hipMemcpy(host, s->d_pos, (size_t)s->cfg.nwalkers * (size_t)s->cfg.ndim * sizeof(double), hipMemcpyDeviceToHost));
+    return KMC_OK;
+}
+
+KMC_EXPORT kmc_status kmc_sampler_get_logp(kmc_sampler* s, double* host)
+{
+    if (!s || !host) return fail(KMC_ERR_BAD_ARG, "null argument");
+    HIP_TRY(hipSetDevice(s->cfg.device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(hipMemcpy(host, s->d_logp, (size_t)s->cfg.nwalkers * sizeof(double), hipMemcpyDeviceToHost));
+    return KMC_OK;
+}
+
+KMC_EXPORT kmc_status kmc_sampler_get_naccept(kmc_sampler* s, int64_t* host)
+{
+    if (!s || !host) return fail(KMC_ERR_BAD_ARG, "null argument");
+    HIP_TRY(hipSetDevice(s->cfg.device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    std::vector<uint32_t> tmp((size_t)s->cfg.nwalkers);
+    HIP_TRY(hipMemcpy(tmp.data(), s->d_naccept, tmp.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < tmp.size(); ++i) host[i] = (int64_t)tmp[i];
+    return KMC_OK;
+}
+
+KMC_EXPORT kmc_status kmc_sampler_get_accept_ratio(kmc_sampler* s, double* host)
+{
+    if (!s || !host) return fail(KMC_ERR_BAD_ARG, "null argument");
+    std::vector<int64_t> na((size_t)s->cfg.nwalkers);
+    KMC_TRY(kmc_sampler_get_naccept(s, na.data()));
+    const double denom = (double)(s->generation - s->cfg.nburnin);   // :291 (0 -> inf/nan like the reference)
+    for (size_t i = 0; i < na.size(); ++i) host[i] = (double)na[i] / denom;
+    return KMC_OK;
+}
+
+KMC_EXPORT kmc_status kmc_sampler_get_moments(kmc_sampler* s, double* sum, double* sumsq, int64_t* n)
+{
+    if (!s) return fail(KMC_ERR_BAD_ARG, "null sampler");
+    if (!s->d_msum) return fail(KMC_ERR_BAD_ARG, "sampler was created without KMC_MOMENTS");
+    HIP_TRY(hipSetDevice(s->cfg.device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    const int64_t nd = s->cfg.ndim;
+    std::vector<double> hs((size_t)s->macc_elems), hq((size_t)s->macc_elems);
+    HIP_TRY(hipMemcpy(hs.data(), s->d_msum, hs.size() * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(hq.data(), s->d_msumsq, hq.size() * sizeof(double), hipMemcpyDeviceToHost));
+    std::vector<double> S((size_t)nd, 0.0), Q((size_t)nd, 0.0);
+    if (s->plan.vec) {
+        const int L = s->plan.L, K = s->plan.K;
+        for (int k = 0; k < K; ++k)
+            for (int64_t t = 0; t < s->macc_stride; ++t) {
+                const int64_t d0 = 2 * ((int64_t)k * L + (t % L));
+                const int64_t idx = 2 * ((int64_t)k * s->macc_stride + t);
+                S[d0] += hs[idx]; S[d0 + 1] += hs[idx + 1];
+                Q[d0] += hq[idx]; Q[d0 + 1] += hq[idx + 1];
+            }
+    } else {
+        for (int64_t d = 0; d < nd; ++d)
+            for (int64_t t = 0; t < s->macc_stride; ++t) {
+                S[d] += hs[d * s->macc_stride + t];
+                Q[d] += hq[d * s->macc_stride + t];
+            }
+    }
+    for (int64_t d = 0; d < nd; ++d) {
+        if (sum) sum[d] = S[d];
+        if (sumsq) sumsq[d] = Q[d];
+    }
+    if (n) *n = samples_done(s) * s->nlocal;
+    return KMC_OK;
+}
+
+KMC_EXPORT kmc_status kmc_sampler_get_chain(kmc_sampler* s, double* chain, double* chain_logp)
+{
+    if (!s) return fail(KMC_ERR_BAD_ARG, "null sampler");
+    HIP_TRY(hipSetDevice(s->cfg.device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    const size_t rows = (size_t)samples_done(s) * (size_t)s->nlocal;
+    if (chain) {
+        if (!s->d_chain && s->nsamples > 0) return fail(KMC_ERR_BAD_ARG, "sampler was created without KMC_STORE_CHAIN");
+        if (rows) HIP_TRY(hipMemcpy(chain, s->d_chain, rows * (size_t)s->cfg.ndim * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    if (chain_logp) {
+        if (!s->d_chain_logp && s->nsamples > 0) return fail(KMC_ERR_BAD_ARG, "sampler was created without KMC_STORE_LOGP");
+        if (rows) HIP_TRY(hipMemcpy(chain_logp, s->d_chain_logp, rows * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    return KMC_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// one-shot: emcee(), src/samplers.jl:188-216 + :232-293
+// ------------------------------------------------------------------------------------------
+KMC_EXPORT kmc_status kmc_emcee_run(const kmc_config* cfg, const double* theta0, kmc_outputs* out)
+{
+    if (!cfg || !theta0 || !out) return fail(KMC_ERR_BAD_ARG, "null argument");
+    kmc_config c = *cfg;
+    if (out->chain) c.flags |= KMC_STORE_CHAIN;
+    if (out->chain_logp) c.flags |= KMC_STORE_LOGP;
+    if (out->sum || out->sumsq) c.flags |= KMC_MOMENTS;
+    c.shard_rank = 0;
+    c.shard_count = 1;
+    kmc_sampler* s = nullptr;
+    KMC_TRY(kmc_sampler_create(&c, &s));
+    kmc_status st = kmc_sampler_set_positions(s, theta0);
+    if (st == KMC_OK) st = kmc_sampler_run(s, c.ngenerations);
+    if (st == KMC_OK) st = kmc_sampler_sync(s);
+    if (st == KMC_OK) st = kmc_sampler_last_run_ms(s, &out->device_ms);
+    if (st == KMC_OK && (out->chain || out->chain_logp)) st = kmc_sampler_get_chain(s, out->chain, out->chain_logp);
+    if (st == KMC_OK && out->accept_ratio) st = kmc_sampler_get_accept_ratio(s, out->accept_ratio);
+    if (st == KMC_OK && out->naccept) st = kmc_sampler_get_naccept(s, out->naccept);
+    if (st == KMC_OK && out->final_pos) st = kmc_sampler_get_positions(s, out->final_pos);
+    if (st == KMC_OK && out->final_logp) st = kmc_sampler_get_logp(s, out->final_logp);
+    out->nmoment = 0;
+    if (st == KMC_OK && (out->sum || out->sumsq)) st = kmc_sampler_get_moments(s, out->sum, out->sumsq, &out->nmoment);
+    out->nsamples = s->nsamples;
+    kmc_sampler_destroy(s);
+    return st;
+}
+
+// ------------------------------------------------------------------------------------------
+// stateless op
+// ------------------------------------------------------------------------------------------
+KMC_EXPORT kmc_status kmc_logpdf_eval(const kmc_config* cfg, const double* pos_dev, double* logp_dev,
+                                      int64_t nrows, void* hip_stream)
+{
+    if (!cfg || !pos_dev || !logp_dev || nrows < 0) return fail(KMC_ERR_BAD_ARG, "bad argument");
+    DensityParams dp;
+    KMC_TRY(digest_params(*cfg, &dp));
+    HalfStepFn v, g;
+    LogpdfFn lp = nullptr;
+    if (!lookup(cfg->density, 0, 0, 1, &v, &g, &lp)) return fail(KMC_ERR_BAD_ARG, "unknown density id");
+    if (nrows == 0) return KMC_OK;
+    hipLaunchKernelGGL(lp, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream,
+                       pos_dev, logp_dev, nrows, (int)cfg->ndim, dp);
+    HIP_TRY(hipGetLastError());
+    return KMC_OK;
+}

@@ -1,0 +1,230 @@
+// kmc_device.hpp -- device-side building blocks of the stretch-move half-step (gfx950).
+//
+//   Philox4x32-10 counter RNG + the three per-walker-step draws   (reference src/samplers.jl:250,252,260)
+//   stretch-factor inverse CDF                                     (reference src/samplers.jl:227)
+//   the log-density menu standing in for the user closure          (reference src/samplers.jl:257)
+//
+// Arithmetic contract (mirrored by the CPU oracle so that accept decisions and positions agree
+// bit for bit): compiled with -ffp-contract=off; every fused multiply-add is an explicit fma().
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace kmc {
+
+// ------------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al., SC'11).  One call = 128 random bits for one walker-step.
+// ------------------------------------------------------------------------------------------
+struct U4 { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                            uint32_t k0, uint32_t k1)
+{
+    constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
+        const uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0;
+        const uint32_t n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += W0; k1 += W1;
+    }
+    return U4{c0, c1, c2, c3};
+}
+
+// The random inputs of one walker-step.
+struct Draw {
+    uint32_t partner;  // index into the complementary half, uniform with replacement  (:250)
+    double   z;        // stretch factor ~ g                                           (:252)
+    double   t1;       // (N-1) * log z                                                (:260)
+    double   lu;       // log(rand())                                                  (:260)
+};
+
+struct DrawConsts {
+    uint32_t seed_lo, seed_hi;
+    uint32_t nhalf;
+    double   c0, c1;   // sqrt(1/a), sqrt(a) - sqrt(1/a)   (:227, hoisted)
+    double   nm1;      // N - 1
+};
+
+__device__ __forceinline__ Draw draw_step(const DrawConsts& dc, uint64_t step, uint64_t walker)
+{
+    const U4 w = philox4x32_10((uint32_t)step, (uint32_t)(step >> 32),
+                               (uint32_t)walker, (uint32_t)(walker >> 32), dc.seed_lo, dc.seed_hi);
+    Draw d;
+    d.partner = __umulhi(w.x, dc.nhalf);
+    const double uz = ((double)w.y + 0.5) * 0x1.0p-32;
+    const double t  = fma(uz, dc.c1, dc.c0);
+    d.z = t * t;
+    const uint64_t k = ((uint64_t)w.z << 20) | (uint64_t)(w.w >> 12);
+    const double ua = ((double)k + 0.5) * 0x1.0p-52;
+    d.t1 = dc.nm1 * log(d.z);
+    d.lu = log(ua);
+    return d;
+}
+
+// (N-1) log z + p1 - p0 >= log u, evaluated left to right like the reference (:260).
+__device__ __forceinline__ bool accept_test(const Draw& d, double p1, double p0)
+{
+    return ((d.t1 + p1) - p0) >= d.lu;
+}
+
+// ------------------------------------------------------------------------------------------
+// Density menu.  Two interfaces per density:
+//   Seq  : element-by-element in index order (generic one-walker-per-lane kernel, initial
+//          log-pdf evaluation); same summation order as the oracle's scalar loop.
+//   frag : a walker's row striped over L lanes, K chunks of 2 doubles per lane
+//          (lane j, chunk k holds elements 2(kL+j), 2(kL+j)+1); returns the lane's partial
+//          sum S_j; the kernel reduces over lanes and calls finish(S).
+// Parameters are pre-digested on the host into DensityParams.
+// ------------------------------------------------------------------------------------------
+struct DensityParams { double p[6]; };
+
+template <int L>
+__device__ __forceinline__ double group_shfl_down1(double v)
+{   // value of lane j+1 of the L-lane group (garbage for j == L-1)
+    return __shfl_down(v, 1, L);
+}
+template <int L>
+__device__ __forceinline__ double group_bcast0(double v)
+{
+    return __shfl(v, 0, L);
+}
+
+struct GaussianIso {   // p = {mu, 1/sigma}
+    static constexpr bool kHasFrag = true;
+    struct Seq { double s; };
+    __device__ static void seq_init(Seq& q) { q.s = 0.0; }
+    __device__ static void seq_add(Seq& q, double x, int, const DensityParams& P)
+    {
+        const double t = (x - P.p[0]) * P.p[1];
+        q.s += t * t;
+    }
+    __device__ static double seq_finish(const Seq& q, int, const DensityParams&) { return -0.5 * q.s; }
+
+    template <int L, int K>
+    __device__ static double frag_partial(const double2 (&y)[K], int, int, const DensityParams& P)
+    {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const double t0 = (y[k].x - P.p[0]) * P.p[1];
+            const double t1 = (y[k].y - P.p[0]) * P.p[1];
+            s += t0 * t0;
+            s += t1 * t1;
+        }
+        return s;
+    }
+    __device__ static double finish(double S, const DensityParams&) { return -0.5 * S; }
+};
+
+struct Exponential {   // p = {rate};  README.md:15  x<0 ? -Inf : -x
+    static constexpr bool kHasFrag = true;
+    struct Seq { double s; bool neg; };
+    __device__ static void seq_init(Seq& q) { q.s = 0.0; q.neg = false; }
+    __device__ static void seq_add(Seq& q, double x, int, const DensityParams&)
+    {
+        q.neg = q.neg || (x < 0.0);
+        q.s += x;
+    }
+    __device__ static double seq_finish(const Seq& q, int, const DensityParams& P)
+    {
+        return q.neg ? -INFINITY : -(P.p[0] * q.s);
+    }
+    template <int L, int K>
+    __device__ static double frag_partial(const double2 (&y)[K], int, int, const DensityParams&)
+    {
+        double s = 0.0;
+        bool neg = false;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            neg = neg || (y[k].x < 0.0) || (y[k].y < 0.0);
+            s += y[k].x;
+            s += y[k].y;
+        }
+        return neg ? INFINITY : s;   // +inf propagates through the lane reduction
+    }
+    __device__ static double finish(double S, const DensityParams& P)
+    {
+        return (S == INFINITY) ? -INFINITY : -(P.p[0] * S);
+    }
+};
+
+struct Rosenbrock {   // p = {a, b, 1/scale}; chained form, reduces to test/runtests.jl:68 at N = 2
+    static constexpr bool kHasFrag = true;
+    struct Seq { double s, prev; };
+    __device__ static void seq_init(Seq& q) { q.s = 0.0; q.prev = 0.0; }
+    __device__ static void seq_add(Seq& q, double x, int d, const DensityParams& P)
+    {
+        if (d > 0) {
+            const double dd = x - q.prev * q.prev;
+            const double e  = P.p[0] - q.prev;
+            q.s += P.p[1] * (dd * dd) + e * e;
+        }
+        q.prev = x;
+    }
+    __device__ static double seq_finish(const Seq& q, int, const DensityParams& P) { return -(q.s * P.p[2]); }
+
+    template <int L, int K>
+    __device__ static double frag_partial(const double2 (&y)[K], int j, int ndim, const DensityParams& P)
+    {
+        const double a = P.p[0], b = P.p[1];
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const double x0 = y[k].x, x1 = y[k].y;
+            // term i = 2(kL+j): uses x_{i+1} = x1 (always exists)
+            {
+                const double dd = x1 - x0 * x0;
+                const double e  = a - x0;
+                s += b * (dd * dd) + e * e;
+            }
+            // term i+1: needs x_{i+2} = first element of the next lane (or of chunk k+1, lane 0)
+            double nxt = group_shfl_down1<L>(x0);
+            if (k + 1 < K) {
+                const double wrap = group_bcast0<L>(y[k + 1 < K ? k + 1 : k].x);
+                nxt = (j == L - 1) ? wrap : nxt;
+            }
+            const int i1 = 2 * (k * L + j) + 1;
+            if (i1 < ndim - 1) {
+                const double dd = nxt - x1 * x1;
+                const double e  = a - x1;
+                s += b * (dd * dd) + e * e;
+            }
+        }
+        return s;
+    }
+    __device__ static double finish(double S, const DensityParams& P) { return -(S * P.p[2]); }
+};
+
+struct LogNormal {   // p = {mu, sigma}
+    static constexpr bool kHasFrag = false;
+    struct Seq { double s; bool bad; };
+    __device__ static void seq_init(Seq& q) { q.s = 0.0; q.bad = false; }
+    __device__ static void seq_add(Seq& q, double x, int, const DensityParams& P)
+    {
+        if (!(x > 0.0)) { q.bad = true; return; }
+        const double lx = log(x);
+        const double t = (lx - P.p[0]) / P.p[1];
+        q.s += -lx - 0.5 * t * t;
+    }
+    __device__ static double seq_finish(const Seq& q, int, const DensityParams&) { return q.bad ? -INFINITY : q.s; }
+};
+
+struct MvNormal2 {   // p = {m1, m2, P11, P12, P22}
+    static constexpr bool kHasFrag = false;
+    struct Seq { double d0, r; };
+    __device__ static void seq_init(Seq& q) { q.d0 = 0.0; q.r = 0.0; }
+    __device__ static void seq_add(Seq& q, double x, int d, const DensityParams& P)
+    {
+        if (d == 0) q.d0 = x - P.p[0];
+        else if (d == 1) {
+            const double d1 = x - P.p[1];
+            q.r = -0.5 * (P.p[2] * q.d0 * q.d0 + 2.0 * P.p[3] * q.d0 * d1 + P.p[4] * d1 * d1);
+        }
+    }
+    __device__ static double seq_finish(const Seq& q, int, const DensityParams&) { return q.r; }
+};
+
+}  // namespace kmc

@@ -1,0 +1,163 @@
+"""The log-density menu that replaces the reference's arbitrary ``pdf`` closure
+(reference ``src/samplers.jl:257``) on the device.
+
+Each object carries the ``kmc_density`` id and parameter vector handed to the C ABI, and is
+callable on a single host ``theta`` with the same formula -- that host evaluation is used only
+where the reference itself evaluates ``pdf`` outside the sampling loop, i.e. by
+``make_theta0s`` to test ``pdf(theta) > -Inf`` (``src/samplers.jl:336-338``).
+Normalisation constants are dropped.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from . import _lib
+
+
+class DeviceLogPdf:
+    """Base class: a log-density the HIP kernels know how to evaluate."""
+
+    density_id: int = -1
+    name = "?"
+
+    def params(self):
+        raise NotImplementedError
+
+    def __call__(self, theta):
+        raise NotImplementedError
+
+    def check_ndim(self, ndim: int) -> None:
+        pass
+
+    def finite_rows(self, X):
+        """Vectorised ``pdf(row) > -Inf`` for the rows of ``X`` (used by ``make_theta0s``)."""
+        X = np.asarray(X, dtype=np.float64)
+        return np.all(np.isfinite(X), axis=1)
+
+    def __repr__(self):
+        return f"{type(self).__name__}({', '.join(f'{v:g}' for v in self.params())})"
+
+
+class GaussianIso(DeviceLogPdf):
+    """``-1/2 * sum(((x - mu)/sigma)^2)`` (cf. reference ``test/runtests.jl:80`` for ``mu=-5, sigma=3``)."""
+
+    density_id = _lib.GAUSSIAN_ISO
+    name = "gaussian_iso"
+
+    def __init__(self, mu: float = 0.0, sigma: float = 1.0):
+        if not sigma > 0:
+            raise ValueError("sigma must be > 0")
+        self.mu, self.sigma = float(mu), float(sigma)
+
+    def params(self):
+        return [self.mu, self.sigma]
+
+    def __call__(self, theta):
+        t = (np.asarray(theta, dtype=np.float64) - self.mu) * (1.0 / self.sigma)
+        return float(-0.5 * np.sum(t * t))
+
+
+class Exponential(DeviceLogPdf):
+    """``any(x < 0) ? -Inf : -rate * sum(x)`` -- the README density (reference ``README.md:15``)."""
+
+    density_id = _lib.EXPONENTIAL
+    name = "exponential"
+
+    def __init__(self, rate: float = 1.0):
+        if not rate > 0:
+            raise ValueError("rate must be > 0")
+        self.rate = float(rate)
+
+    def params(self):
+        return [self.rate]
+
+    def __call__(self, theta):
+        x = np.atleast_1d(np.asarray(theta, dtype=np.float64))
+        if np.any(x < 0):
+            return -math.inf
+        return float(-(self.rate * np.sum(x)))
+
+    def finite_rows(self, X):
+        X = np.asarray(X, dtype=np.float64)
+        return np.all(np.isfinite(X), axis=1) & ~np.any(X < 0, axis=1)
+
+
+class Rosenbrock(DeviceLogPdf):
+    """Chained Rosenbrock ``-sum_{i<N-1}[b (x_{i+1} - x_i^2)^2 + (a - x_i)^2] / scale``; at ``N = 2``
+    with the defaults this is the reference's test density (``test/runtests.jl:68``)."""
+
+    density_id = _lib.ROSENBROCK
+    name = "rosenbrock"
+
+    def __init__(self, a: float = 1.0, b: float = 100.0, scale: float = 20.0):
+        if not scale > 0:
+            raise ValueError("scale must be > 0")
+        self.a, self.b, self.scale = float(a), float(b), float(scale)
+
+    def params(self):
+        return [self.a, self.b, self.scale]
+
+    def check_ndim(self, ndim):
+        if ndim < 2:
+            raise ValueError("Rosenbrock needs at least 2 dimensions")
+
+    def __call__(self, theta):
+        x = np.asarray(theta, dtype=np.float64)
+        s = np.sum(self.b * (x[1:] - x[:-1] ** 2) ** 2 + (self.a - x[:-1]) ** 2)
+        return float(-(s / self.scale))
+
+
+class LogNormal(DeviceLogPdf):
+    """Independent log-normal per dimension (reference test target ``LogNormal(0,1)``, ``test/runtests.jl:57``)."""
+
+    density_id = _lib.LOGNORMAL
+    name = "lognormal"
+
+    def __init__(self, mu: float = 0.0, sigma: float = 1.0):
+        if not sigma > 0:
+            raise ValueError("sigma must be > 0")
+        self.mu, self.sigma = float(mu), float(sigma)
+
+    def params(self):
+        return [self.mu, self.sigma]
+
+    def __call__(self, theta):
+        x = np.atleast_1d(np.asarray(theta, dtype=np.float64))
+        if np.any(~(x > 0)):
+            return -math.inf
+        lx = np.log(x)
+        return float(np.sum(-lx - 0.5 * ((lx - self.mu) / self.sigma) ** 2))
+
+    def finite_rows(self, X):
+        X = np.asarray(X, dtype=np.float64)
+        return np.all(np.isfinite(X), axis=1) & np.all(X > 0, axis=1)
+
+
+class MvNormal2(DeviceLogPdf):
+    """2-D normal with mean ``mean`` and covariance ``cov`` (reference test target ``test/runtests.jl:62``)."""
+
+    density_id = _lib.MVNORMAL2
+    name = "mvnormal2"
+
+    def __init__(self, mean, cov):
+        mean = np.asarray(mean, dtype=np.float64)
+        cov = np.asarray(cov, dtype=np.float64)
+        if mean.shape != (2,) or cov.shape != (2, 2):
+            raise ValueError("MvNormal2 needs a 2-vector mean and a 2x2 covariance")
+        self.mean, self.cov = mean, cov
+        self.prec = np.linalg.inv(cov)
+
+    def params(self):
+        P = self.prec
+        return [float(self.mean[0]), float(self.mean[1]), float(P[0, 0]), float(0.5 * (P[0, 1] + P[1, 0])), float(P[1, 1])]
+
+    def check_ndim(self, ndim):
+        if ndim != 2:
+            raise ValueError("MvNormal2 is 2-dimensional")
+
+    def __call__(self, theta):
+        p = self.params()
+        d0, d1 = float(theta[0]) - p[0], float(theta[1]) - p[1]
+        return -0.5 * (p[2] * d0 * d0 + 2.0 * p[3] * d0 * d1 + p[4] * d1 * d1)

@@ -1,0 +1,155 @@
+"""Thin object wrapper over the stateful C ABI (``kmc_sampler_*`` in ``include/kissmcmc_hip.h``).
+
+The ensemble lives in HBM for the lifetime of the object; ``run`` enqueues generations of the
+reference's ``_emcee`` loop (``src/samplers.jl:245-290``) as HIP kernel launches.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .densities import DeviceLogPdf
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class Sampler:
+    def __init__(self, pdf: DeviceLogPdf, nwalkers: int, ndim: int, ngenerations: int, nburnin: int = 0,
+                 nthin: int = 1, a_scale: float = 2.0, seed: int = 0, store_chain: bool = False,
+                 store_logp: bool = False, moments: bool = False, use_graph: bool = True,
+                 device: int = 0, shard_rank: int = 0, shard_count: int = 1):
+        if not isinstance(pdf, DeviceLogPdf):
+            raise TypeError(
+                "the device emcee path evaluates a fixed menu of log-densities "
+                "(GaussianIso, Exponential, Rosenbrock, LogNormal, MvNormal2); "
+                f"got {type(pdf).__name__}. There is no CPU fallback for arbitrary callables.")
+        pdf.check_ndim(int(ndim))
+        self.pdf = pdf
+        self._h = None
+        cfg = _lib.Config()
+        cfg.dtype = _lib.F64
+        cfg.density = pdf.density_id
+        p = list(pdf.params()) + [0.0] * 8
+        for i in range(8):
+            cfg.params[i] = float(p[i])
+        cfg.nwalkers, cfg.ndim = int(nwalkers), int(ndim)
+        cfg.ngenerations, cfg.nburnin, cfg.nthin = int(ngenerations), int(nburnin), int(nthin)
+        cfg.a_scale = float(a_scale)
+        cfg.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        flags = 0
+        if store_chain:
+            flags |= _lib.STORE_CHAIN
+        if store_logp:
+            flags |= _lib.STORE_LOGP
+        if moments:
+            flags |= _lib.MOMENTS
+        if not use_graph:
+            flags |= _lib.NO_GRAPH
+        cfg.flags = flags
+        cfg.device = int(device)
+        cfg.shard_rank, cfg.shard_count = int(shard_rank), int(shard_count)
+        self.cfg = cfg
+        self._L = _lib.lib()
+        h = C.c_void_p()
+        _lib.check(self._L.kmc_sampler_create(C.byref(cfg), C.byref(h)))
+        self._h = h
+        self.nwalkers, self.ndim = int(nwalkers), int(ndim)
+        self.nlocal = self.nwalkers // max(1, int(shard_count))
+
+    # -- lifecycle --------------------------------------------------------------------------
+    def close(self):
+        if self._h is not None:
+            self._L.kmc_sampler_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- control ----------------------------------------------------------------------------
+    def set_stream(self, hip_stream: int):
+        _lib.check(self._L.kmc_sampler_set_stream(self._h, C.c_void_p(hip_stream)))
+
+    def set_positions(self, theta):
+        theta = np.ascontiguousarray(np.asarray(theta, dtype=np.float64).reshape(self.nwalkers, self.ndim))
+        _lib.check(self._L.kmc_sampler_set_positions(self._h, _dp(theta)))
+
+    def run(self, ngenerations: int):
+        _lib.check(self._L.kmc_sampler_run(self._h, int(ngenerations)))
+
+    def half_step(self, half: int):
+        _lib.check(self._L.kmc_sampler_half_step(self._h, int(half)))
+
+    def sync(self):
+        _lib.check(self._L.kmc_sampler_sync(self._h))
+
+    def last_run_ms(self) -> float:
+        ms = C.c_double()
+        _lib.check(self._L.kmc_sampler_last_run_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    @property
+    def generation(self) -> int:
+        return int(self._L.kmc_sampler_generation(self._h))
+
+    @property
+    def nsamples(self) -> int:
+        return int(self._L.kmc_sampler_nsamples(self._h))
+
+    @property
+    def launch_count(self) -> int:
+        return int(self._L.kmc_sampler_launch_count(self._h))
+
+    def device_ptr(self, which: int) -> int:
+        return int(self._L.kmc_sampler_device_ptr(self._h, int(which)) or 0)
+
+    # -- downloads --------------------------------------------------------------------------
+    def positions(self) -> np.ndarray:
+        out = np.empty((self.nwalkers, self.ndim))
+        _lib.check(self._L.kmc_sampler_get_positions(self._h, _dp(out)))
+        return out
+
+    def logp(self) -> np.ndarray:
+        out = np.empty(self.nwalkers)
+        _lib.check(self._L.kmc_sampler_get_logp(self._h, _dp(out)))
+        return out
+
+    def naccept(self) -> np.ndarray:
+        out = np.empty(self.nwalkers, dtype=np.int64)
+        _lib.check(self._L.kmc_sampler_get_naccept(self._h, out.ctypes.data_as(C.POINTER(C.c_int64))))
+        return out
+
+    def accept_ratio(self) -> np.ndarray:
+        out = np.empty(self.nwalkers)
+        _lib.check(self._L.kmc_sampler_get_accept_ratio(self._h, _dp(out)))
+        return out
+
+    def moments(self):
+        """``(sum[ndim], sumsq[ndim], n)`` over the samples that would be stored."""
+        s = np.empty(self.ndim)
+        q = np.empty(self.ndim)
+        n = C.c_int64()
+        _lib.check(self._L.kmc_sampler_get_moments(self._h, _dp(s), _dp(q), C.byref(n)))
+        return s, q, n.value
+
+    def chain(self, logp: bool = True):
+        """``(chain [nsamples_done, nlocal, ndim], chain_logp [nsamples_done, nlocal] | None)``."""
+        ns = self.nsamples
+        post = self.generation - self.cfg.nburnin
+        done = 0 if post <= 0 else min(ns, post // self.cfg.nthin)
+        ch = np.empty((done, self.nlocal, self.ndim))
+        lp = np.empty((done, self.nlocal)) if logp else None
+        _lib.check(self._L.kmc_sampler_get_chain(self._h, _dp(ch), _dp(lp) if logp else None))
+        return ch, lp

@@ -1,0 +1,175 @@
+"""CPU ORACLE -- test infrastructure, NOT product code.
+
+ctypes bindings for ``oracle/kmc_oracle.c`` (a plain-C fp64 restatement of the reference's
+``emcee`` hot path, reference ``src/samplers.jl:188-293``) plus pure-Python restatements of the
+host-side pre/post-processing (``make_theta0s`` ``src/samplers.jl:311-349``, ``squash_walkers``
+``src/samplers.jl:372-428``) in :mod:`oracle.host`.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this package.  Parity status: pinned against the reference's own known-answer and statistical
+tests (``tests/test_oracle_pins.py``); bit-level parity with the reference is undefined because
+the reference never seeds its RNG (see the header of ``kmc_oracle.c``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libkmc_oracle.so")
+
+GAUSSIAN_ISO, EXPONENTIAL, ROSENBROCK, LOGNORMAL, MVNORMAL2 = 0, 1, 2, 3, 4
+OK, ERR_A_SCALE, ERR_ODD_WALKERS, ERR_TOO_FEW_WALKERS, ERR_BAD_ARG, ERR_NONFINITE_LOGP = range(6)
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("density", C.c_int32),
+        ("nthreads", C.c_int32),
+        ("params", C.c_double * 8),
+        ("nwalkers", C.c_int64),
+        ("ndim", C.c_int64),
+        ("ngenerations", C.c_int64),
+        ("nburnin", C.c_int64),
+        ("nthin", C.c_int64),
+        ("a_scale", C.c_double),
+        ("seed", C.c_uint64),
+    ]
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with gcc (``make -C oracle``)."""
+    src = os.path.join(_HERE, "kmc_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        L = C.CDLL(_SO)
+        dp = C.POINTER(C.c_double)
+        L.kmco_philox4x32_10.argtypes = [C.POINTER(C.c_uint32)] * 3
+        L.kmco_g_pdf.restype = C.c_double
+        L.kmco_g_pdf.argtypes = [C.c_double, C.c_double]
+        L.kmco_cdf_g_inv.restype = C.c_double
+        L.kmco_cdf_g_inv.argtypes = [C.c_double, C.c_double]
+        L.kmco_sample_g.restype = C.c_double
+        L.kmco_sample_g.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_double]
+        L.kmco_draw.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int64,
+                                C.POINTER(C.c_int64), dp, dp]
+        L.kmco_logpdf.restype = C.c_double
+        L.kmco_logpdf.argtypes = [C.c_int32, dp, dp, C.c_int64]
+        L.kmco_validate.argtypes = [C.POINTER(Config)]
+        L.kmco_half_step.restype = None
+        L.kmco_half_step.argtypes = [C.POINTER(Config), dp, dp, C.POINTER(C.c_int64),
+                                     C.c_int64, C.c_int, C.c_int64, C.c_int64, C.c_int]
+        L.kmco_emcee.argtypes = [C.POINTER(Config), dp, dp, dp, dp, C.POINTER(C.c_int64),
+                                 dp, dp, dp, dp, C.POINTER(C.c_int64)]
+        assert L.kmco_sizeof_config() == C.sizeof(Config)
+        _lib = L
+    return _lib
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_int64))
+
+
+def make_config(density, params, nwalkers, ndim, ngenerations=0, nburnin=0, nthin=1,
+                a_scale=2.0, seed=0, nthreads=1) -> Config:
+    c = Config()
+    c.density = int(density)
+    c.nthreads = int(nthreads)
+    p = list(params) + [0.0] * (8 - len(params))
+    for i in range(8):
+        c.params[i] = float(p[i])
+    c.nwalkers, c.ndim = int(nwalkers), int(ndim)
+    c.ngenerations, c.nburnin, c.nthin = int(ngenerations), int(nburnin), int(nthin)
+    c.a_scale, c.seed = float(a_scale), int(seed)
+    return c
+
+
+def philox4x32_10(ctr, key):
+    c = (C.c_uint32 * 4)(*ctr)
+    k = (C.c_uint32 * 2)(*key)
+    o = (C.c_uint32 * 4)()
+    lib().kmco_philox4x32_10(c, k, o)
+    return tuple(int(v) for v in o)
+
+
+def g_pdf(z, a):
+    return lib().kmco_g_pdf(z, a)
+
+
+def cdf_g_inv(u, a):
+    return lib().kmco_cdf_g_inv(u, a)
+
+
+def sample_g(seed, step, walker, a):
+    return lib().kmco_sample_g(seed, step, walker, a)
+
+
+def draw(seed, step, walker, nhalf):
+    p = C.c_int64()
+    uz = C.c_double()
+    ua = C.c_double()
+    lib().kmco_draw(seed, step, walker, nhalf, C.byref(p), C.byref(uz), C.byref(ua))
+    return p.value, uz.value, ua.value
+
+
+def logpdf(density, params, x):
+    x = np.ascontiguousarray(np.atleast_1d(x), dtype=np.float64)
+    p = np.zeros(8)
+    p[: len(params)] = params
+    return lib().kmco_logpdf(int(density), _dp(p), _dp(x), x.size)
+
+
+def logpdf_batch(density, params, X):
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    return np.array([logpdf(density, params, row) for row in X.reshape(X.shape[0], -1)])
+
+
+def half_step(cfg: Config, pos, logp, naccept, generation, half, active_begin=0, n_active=None,
+              count_accept=True):
+    """In-place half-step on ``pos [nw,nd]``, ``logp [nw]``, ``naccept [nw] int64``."""
+    assert pos.dtype == np.float64 and pos.flags.c_contiguous
+    assert logp.dtype == np.float64 and naccept.dtype == np.int64
+    if n_active is None:
+        n_active = cfg.nwalkers // 2
+    lib().kmco_half_step(C.byref(cfg), _dp(pos), _dp(logp), _ip(naccept), int(generation), int(half),
+                         int(active_begin), int(n_active), int(bool(count_accept)))
+
+
+def emcee(cfg: Config, theta0, store_chain=True, moments=True):
+    """Run the oracle sampler.  Returns a dict of dense arrays (see kmc_oracle.c: kmco_emcee)."""
+    nw, nd = cfg.nwalkers, cfg.ndim
+    theta0 = np.ascontiguousarray(np.asarray(theta0, dtype=np.float64).reshape(nw, nd))
+    ns = max(0, (cfg.ngenerations - cfg.nburnin) // cfg.nthin)
+    chain = np.zeros((ns, nw, nd)) if store_chain else None
+    chain_logp = np.zeros((ns, nw)) if store_chain else None
+    acc = np.zeros(nw)
+    nacc = np.zeros(nw, dtype=np.int64)
+    fpos = np.zeros((nw, nd))
+    flogp = np.zeros(nw)
+    msum = np.zeros(nd) if moments else None
+    msq = np.zeros(nd) if moments else None
+    nmom = C.c_int64(0)
+    with np.errstate(all="ignore"):
+        st = lib().kmco_emcee(C.byref(cfg), _dp(theta0), _dp(chain), _dp(chain_logp), _dp(acc), _ip(nacc),
+                              _dp(fpos), _dp(flogp), _dp(msum), _dp(msq), C.byref(nmom))
+    return dict(status=st, chain=chain, chain_logp=chain_logp, accept_ratio=acc, naccept=nacc,
+                final_pos=fpos, final_logp=flogp, sum=msum, sumsq=msq, nmoment=nmom.value,
+                nsamples=ns)

@@ -1,0 +1,314 @@
+/*
+ * kmc_oracle.c -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * A plain-C, fp64 restatement of KissMCMC.jl's `emcee` affine-invariant ensemble sampler
+ * hot path.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
+ * this library; the product path (kissmcmc.jl_amd/) never links, imports or calls it.
+ *
+ * Parity status: the reference (pure Julia) cannot be compiled or imported in this image
+ * (no julia binary), it holds no golden vectors and never seeds its RNG
+ * (reference src/samplers.jl:248-260 draws from the implicit default RNG inside
+ * Threads.@threads), so bit-level parity with the reference is undefined.  This oracle is
+ * pinned against every known-answer and statistical test the reference's own suite holds
+ * for this path (reference test/emcee.jl:2-14 g-dist; test/emcee.jl:17-48 over the cases of
+ * test/runtests.jl:52-107) -- see tests/test_oracle_pins.py -- and its Philox generator
+ * against the published Random123 known-answer vectors.
+ *
+ * Each function cites the reference file:line it follows (paths relative to the reference
+ * repository root).
+ *
+ * Random stream (the build's own contract; the reference has none): Philox4x32-10
+ * (Salmon, Moraes, Dror, Shaw, SC'11), counter = {step_lo, step_hi, walker_lo, walker_hi},
+ * key = {seed_lo, seed_hi}, step = 2*generation + half, walker = GLOBAL walker index.
+ * This is the block rocRAND returns from rocrand4() after
+ * rocrand_init(seed, /subsequence/ walker, /offset/ 4*step, &state).
+ * The four output words w0..w3 give, per walker-step:
+ *   partner = floor(w0 * nhalf / 2^32)                      (src/samplers.jl:250)
+ *   u_z     = (w1 + 0.5) * 2^-32              in (0,1)      (src/samplers.jl:230)
+ *   u_acc   = (((w2 << 20) | (w3 >> 12)) + 0.5) * 2^-52     in (0,1)   (src/samplers.jl:260)
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define KMCO_API __attribute__((visibility("default")))
+
+/* ---- status codes (same numbering as include/kissmcmc_hip.h, restated here) ---- */
+enum {
+    KMCO_OK = 0,
+    KMCO_ERR_A_SCALE = 1,         /* src/samplers.jl:200  @assert a_scale>1 */
+    KMCO_ERR_ODD_WALKERS = 2,     /* src/samplers.jl:202  "Use an even number of walkers." */
+    KMCO_ERR_TOO_FEW_WALKERS = 3, /* src/samplers.jl:205  "Use more walkers: at least DOF+2..." */
+    KMCO_ERR_BAD_ARG = 4,
+    KMCO_ERR_NONFINITE_LOGP = 5
+};
+
+/* ---- density menu ---- */
+enum {
+    KMCO_GAUSSIAN_ISO = 0, /* -1/2 sum(((x-mu)/sigma)^2); params {mu, sigma}. cf. docstring example src/samplers.jl:186 and test/runtests.jl:80 */
+    KMCO_EXPONENTIAL = 1,  /* sum(x<0 ? -inf : -rate*x); params {rate}. README.md:15 */
+    KMCO_ROSENBROCK = 2,   /* -sum_{i<N-1}[b(x_{i+1}-x_i^2)^2 + (a-x_i)^2]/scale; params {a,b,scale}. test/runtests.jl:68 at N=2,(1,100,20) */
+    KMCO_LOGNORMAL = 3,    /* sum(x>0 ? -log x - (log x - mu)^2/(2 sigma^2) : -inf); params {mu, sigma}. test/runtests.jl:57 up to a constant */
+    KMCO_MVNORMAL2 = 4     /* 2-D normal, params {m1, m2, P11, P12, P22} (precision matrix). test/runtests.jl:62 up to a constant */
+};
+
+typedef struct {
+    int32_t  density;
+    int32_t  nthreads;      /* OpenMP threads for the walker loop; <=1: serial */
+    double   params[8];
+    int64_t  nwalkers;
+    int64_t  ndim;
+    int64_t  ngenerations;  /* niter_walker      src/samplers.jl:203 */
+    int64_t  nburnin;       /* nburnin_walker    src/samplers.jl:204 */
+    int64_t  nthin;         /*                   src/samplers.jl:190 */
+    double   a_scale;       /*                   src/samplers.jl:192 */
+    uint64_t seed;
+} kmco_config;
+
+/* ------------------------------------------------------------------------------------------
+ * Philox4x32-10, Random123 (Salmon et al. 2011).  Published algorithm, restated.
+ * ---------------------------------------------------------------------------------------- */
+KMCO_API void kmco_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
+    uint32_t k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Stretch-factor distribution g(z) ~ 1/sqrt(z) on [1/a, a].
+ * ---------------------------------------------------------------------------------------- */
+/* src/samplers.jl:224 */
+KMCO_API double kmco_g_pdf(double z, double a)
+{
+    return (1.0 / a <= z && z <= a) ? 1.0 / sqrt(z) * 1.0 / (2.0 * (sqrt(a) - sqrt(1.0 / a))) : 0.0;
+}
+
+/* src/samplers.jl:227.  Written as t = u*c1 + c0 (one fused multiply-add), z = t*t, with
+ * c1 = sqrt(a)-sqrt(1/a), c0 = sqrt(1/a) hoisted, so the device kernel can match it bit for bit. */
+static inline double g_c0(double a) { return sqrt(1.0 / a); }
+static inline double g_c1(double a) { return sqrt(a) - sqrt(1.0 / a); }
+KMCO_API double kmco_cdf_g_inv(double u, double a)
+{
+    double t = fma(u, g_c1(a), g_c0(a));
+    return t * t;
+}
+
+/* One walker-step's random draws.  src/samplers.jl:250 (partner), :252/:230 (z), :260 (rand()). */
+KMCO_API void kmco_draw(uint64_t seed, uint64_t step, uint64_t walker, int64_t nhalf,
+                        int64_t* partner, double* u_z, double* u_acc)
+{
+    uint32_t ctr[4] = {(uint32_t)step, (uint32_t)(step >> 32), (uint32_t)walker, (uint32_t)(walker >> 32)};
+    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    uint32_t w[4];
+    kmco_philox4x32_10(ctr, key, w);
+    *partner = (int64_t)(((uint64_t)w[0] * (uint64_t)nhalf) >> 32);
+    *u_z = ((double)w[1] + 0.5) * 0x1.0p-32;
+    uint64_t k = ((uint64_t)w[2] << 20) | (uint64_t)(w[3] >> 12);
+    *u_acc = ((double)k + 0.5) * 0x1.0p-52;
+}
+
+/* sample_g for a seeded stream: src/samplers.jl:230 */
+KMCO_API double kmco_sample_g(uint64_t seed, uint64_t step, uint64_t walker, double a)
+{
+    int64_t p; double uz, ua;
+    kmco_draw(seed, step, walker, 2, &p, &uz, &ua);
+    return kmco_cdf_g_inv(uz, a);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Density menu (stands in for the user closure `pdf(theta)` of src/samplers.jl:257).
+ * ---------------------------------------------------------------------------------------- */
+KMCO_API double kmco_logpdf(int32_t density, const double* params, const double* x, int64_t ndim)
+{
+    switch (density) {
+    case KMCO_GAUSSIAN_ISO: {
+        const double mu = params[0], inv_sigma = 1.0 / params[1];
+        double s = 0.0;
+        for (int64_t i = 0; i < ndim; ++i) {
+            double t = (x[i] - mu) * inv_sigma;
+            s += t * t;
+        }
+        return -0.5 * s;
+    }
+    case KMCO_EXPONENTIAL: { /* README.md:15: x<0 ? -Inf : -x */
+        const double rate = params[0];
+        double s = 0.0;
+        for (int64_t i = 0; i < ndim; ++i) {
+            if (x[i] < 0.0) return -INFINITY;
+            s += x[i];
+        }
+        return -(rate * s);
+    }
+    case KMCO_ROSENBROCK: { /* test/runtests.jl:68 at ndim=2: -(100*(x2-x1^2)^2 + (1-x1)^2)/20 */
+        const double a = params[0], b = params[1], inv_scale = 1.0 / params[2];
+        double s = 0.0;
+        for (int64_t i = 0; i + 1 < ndim; ++i) {
+            double d = x[i + 1] - x[i] * x[i];
+            double e = a - x[i];
+            s += b * (d * d) + e * e;
+        }
+        return -(s * inv_scale);
+    }
+    case KMCO_LOGNORMAL: {
+        const double mu = params[0], sigma = params[1];
+        double s = 0.0;
+        for (int64_t i = 0; i < ndim; ++i) {
+            if (!(x[i] > 0.0)) return -INFINITY;
+            double lx = log(x[i]);
+            double t = (lx - mu) / sigma;
+            s += -lx - 0.5 * t * t;
+        }
+        return s;
+    }
+    case KMCO_MVNORMAL2: {
+        if (ndim != 2) return NAN;
+        double d0 = x[0] - params[0], d1 = x[1] - params[1];
+        return -0.5 * (params[2] * d0 * d0 + 2.0 * params[3] * d0 * d1 + params[4] * d1 * d1);
+    }
+    default:
+        return NAN;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Validation: src/samplers.jl:200-205.
+ * ---------------------------------------------------------------------------------------- */
+KMCO_API int kmco_validate(const kmco_config* c)
+{
+    if (!c || c->nwalkers <= 0 || c->ndim <= 0 || c->nthin <= 0 || c->ngenerations < 0 || c->nburnin < 0)
+        return KMCO_ERR_BAD_ARG;
+    if (!(c->a_scale > 1.0)) return KMCO_ERR_A_SCALE;
+    if (c->nwalkers % 2 != 0) return KMCO_ERR_ODD_WALKERS;
+    if (c->nwalkers < c->ndim + 2) return KMCO_ERR_TOO_FEW_WALKERS;
+    if (c->density == KMCO_ROSENBROCK && c->ndim < 2) return KMCO_ERR_BAD_ARG;
+    if (c->density == KMCO_MVNORMAL2 && c->ndim != 2) return KMCO_ERR_BAD_ARG;
+    return KMCO_OK;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * One half-step over a contiguous range of active walkers -- the body of the
+ * Threads.@threads loop, src/samplers.jl:248-273 (without storage, which the caller does).
+ *
+ *   pos     [nwalkers][ndim] row-major, global walker order
+ *   logp    [nwalkers]
+ *   naccept [nwalkers]
+ *   half    0: update walkers [0,h) with partners from [h,2h); 1: swapped  (src/samplers.jl:247)
+ *   active_begin, n_active: sub-range of the active half handled by this call (walker sharding)
+ * ---------------------------------------------------------------------------------------- */
+KMCO_API void kmco_half_step(const kmco_config* c, double* pos, double* logp, int64_t* naccept,
+                             int64_t generation, int half, int64_t active_begin, int64_t n_active,
+                             int count_accept)
+{
+    const int64_t nd = c->ndim, h = c->nwalkers / 2;
+    const double c0 = g_c0(c->a_scale), c1 = g_c1(c->a_scale);
+    const double nm1 = (double)(nd - 1);
+    const uint64_t step = 2ull * (uint64_t)generation + (uint64_t)half;
+    const int64_t act0 = (int64_t)half * h, oth0 = (int64_t)(1 - half) * h;
+
+#pragma omp parallel num_threads(c->nthreads > 1 ? c->nthreads : 1)
+    {
+        double* y = (double*)malloc(sizeof(double) * (size_t)nd);
+#pragma omp for schedule(static)
+        for (int64_t i = 0; i < n_active; ++i) {
+            const int64_t nc = act0 + active_begin + i;           /* :248 */
+            int64_t no_rel; double uz, ua;
+            kmco_draw(c->seed, step, (uint64_t)nc, h, &no_rel, &uz, &ua);
+            const int64_t no = oth0 + no_rel;                      /* :250 rand(ncos) */
+            const double t = fma(uz, c1, c0);
+            const double z = t * t;                                /* :252 sample_g */
+            const double* xc = pos + nc * nd;
+            const double* xo = pos + no * nd;
+            for (int64_t d = 0; d < nd; ++d)                       /* :255 theta0s[no] .+ z .* (theta0s[nc] .- theta0s[no]) */
+                y[d] = fma(z, xc[d] - xo[d], xo[d]);
+            const double p1 = kmco_logpdf(c->density, c->params, y, nd);   /* :257 */
+            const double lhs = (nm1 * log(z) + p1) - logp[nc];     /* :260, left to right */
+            if (lhs >= log(ua)) {                                  /* :260 note >= */
+                memcpy(pos + nc * nd, y, sizeof(double) * (size_t)nd);     /* :261 */
+                logp[nc] = p1;                                     /* :262 */
+                if (count_accept) naccept[nc] += 1;                /* :265 (counts before n==0 are zeroed at :285-288) */
+            }
+        }
+        free(y);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * emcee + _emcee on dense arrays: src/samplers.jl:188-216 and :232-293.
+ *
+ * Outputs (any may be NULL):
+ *   chain        [nsamples][nwalkers][ndim]   sample k of walker w = thetas[w][k] of :269
+ *   chain_logp   [nsamples][nwalkers]                              logdensities[w][k] of :271
+ *   accept_ratio [nwalkers]                                        :291
+ *   naccept      [nwalkers]
+ *   final_pos    [nwalkers][ndim], final_logp [nwalkers]
+ *   msum, msumsq [ndim]  sum over stored samples and walkers of x, x^2;  *nmoment = count
+ * nsamples = (ngenerations - nburnin) / nthin   (:234)
+ * ---------------------------------------------------------------------------------------- */
+KMCO_API int kmco_emcee(const kmco_config* c, const double* theta0,
+                        double* chain, double* chain_logp, double* accept_ratio, int64_t* naccept_out,
+                        double* final_pos, double* final_logp,
+                        double* msum, double* msumsq, int64_t* nmoment)
+{
+    int st = kmco_validate(c);
+    if (st != KMCO_OK) return st;
+    const int64_t nw = c->nwalkers, nd = c->ndim, h = nw / 2;
+
+    double* pos = (double*)malloc(sizeof(double) * (size_t)(nw * nd));
+    double* logp = (double*)malloc(sizeof(double) * (size_t)nw);
+    int64_t* nacc = (int64_t*)calloc((size_t)nw, sizeof(int64_t));
+    memcpy(pos, theta0, sizeof(double) * (size_t)(nw * nd));   /* :198 deepcopy */
+    for (int64_t w = 0; w < nw; ++w) {                          /* :209-210 initial log-pdfs */
+        logp[w] = kmco_logpdf(c->density, c->params, pos + w * nd, nd);
+        if (!isfinite(logp[w])) { free(pos); free(logp); free(nacc); return KMCO_ERR_NONFINITE_LOGP; }
+    }
+    if (msum) memset(msum, 0, sizeof(double) * (size_t)nd);
+    if (msumsq) memset(msumsq, 0, sizeof(double) * (size_t)nd);
+    int64_t nmom = 0;
+
+    /* generation g in [0,G)  <->  reference n = g + 1 - nburnin  (:245) */
+    for (int64_t g = 0; g < c->ngenerations; ++g) {
+        const int64_t n = g + 1 - c->nburnin;
+        for (int half = 0; half < 2; ++half)                    /* :246-247 */
+            kmco_half_step(c, pos, logp, nacc, g, half, 0, h, /*count_accept=*/n > 0);
+        if (n > 0 && n % c->nthin == 0) {                       /* :268 */
+            const int64_t k = n / c->nthin - 1;
+            if (k < (c->ngenerations - c->nburnin) / c->nthin) {
+                if (chain) memcpy(chain + k * nw * nd, pos, sizeof(double) * (size_t)(nw * nd));
+                if (chain_logp) memcpy(chain_logp + k * nw, logp, sizeof(double) * (size_t)nw);
+                if (msum || msumsq) {
+                    for (int64_t w = 0; w < nw; ++w)
+                        for (int64_t d = 0; d < nd; ++d) {
+                            double v = pos[w * nd + d];
+                            if (msum) msum[d] += v;
+                            if (msumsq) msumsq[d] += v * v;
+                        }
+                }
+                nmom += nw;
+            }
+        }
+    }
+    const double denom = (double)(c->ngenerations - c->nburnin);   /* :291 (may be 0 -> inf/nan, as in the reference) */
+    for (int64_t w = 0; w < nw; ++w) {
+        if (accept_ratio) accept_ratio[w] = (double)nacc[w] / denom;
+        if (naccept_out) naccept_out[w] = nacc[w];
+    }
+    if (final_pos) memcpy(final_pos, pos, sizeof(double) * (size_t)(nw * nd));
+    if (final_logp) memcpy(final_logp, logp, sizeof(double) * (size_t)nw);
+    if (nmoment) *nmoment = nmom;
+    free(pos); free(logp); free(nacc);
+    return KMCO_OK;
+}
+
+KMCO_API int kmco_sizeof_config(void) { return (int)sizeof(kmco_config); }
