@@ -128,6 +128,10 @@ kmc_status  kmc_sampler_create(const kmc_config* cfg, kmc_sampler** out);
 void        kmc_sampler_destroy(kmc_sampler* s);
 /* Run on a caller-owned HIP stream (hipStream_t) instead of the sampler's own. */
 kmc_status  kmc_sampler_set_stream(kmc_sampler* s, void* hip_stream);
+/* Use a caller-owned device buffer (double [nwalkers][ndim], e.g. a torch tensor's data_ptr) for
+ * the ensemble instead of the sampler's own allocation, so a collective library can gather
+ * into it in place.  The caller keeps it alive; call before kmc_sampler_set_positions. */
+kmc_status  kmc_sampler_bind_positions(kmc_sampler* s, void* pos_dev);
 /* Upload the ensemble (host, [nwalkers][ndim], global order), evaluate the initial log-pdfs on
  * the device (src/samplers.jl:209-210), reset generation/counters.  Fails with
  * KMC_ERR_NONFINITE_LOGP if any is not finite. */

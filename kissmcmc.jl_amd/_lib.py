@@ -23,7 +23,7 @@ STORE_CHAIN, STORE_LOGP, MOMENTS, NO_GRAPH = 1, 2, 4, 8
 SYMBOLS = [
     "kmc_version", "kmc_device_count", "kmc_last_error", "kmc_status_string", "kmc_validate",
     "kmc_g_pdf", "kmc_cdf_g_inv", "kmc_emcee_run", "kmc_sampler_create", "kmc_sampler_destroy",
-    "kmc_sampler_set_stream", "kmc_sampler_set_positions", "kmc_sampler_run", "kmc_sampler_half_step",
+    "kmc_sampler_set_stream", "kmc_sampler_bind_positions", "kmc_sampler_set_positions", "kmc_sampler_run", "kmc_sampler_half_step",
     "kmc_sampler_sync", "kmc_sampler_last_run_ms", "kmc_sampler_generation", "kmc_sampler_nsamples",
     "kmc_sampler_launch_count", "kmc_sampler_device_ptr", "kmc_sampler_get_positions",
     "kmc_sampler_get_logp", "kmc_sampler_get_naccept", "kmc_sampler_get_accept_ratio",
@@ -105,6 +105,7 @@ def lib() -> C.CDLL:
     L.kmc_sampler_destroy.restype = None
     L.kmc_sampler_destroy.argtypes = [vp]
     L.kmc_sampler_set_stream.argtypes = [vp, vp]
+    L.kmc_sampler_bind_positions.argtypes = [vp, vp]
     L.kmc_sampler_set_positions.argtypes = [vp, dp]
     L.kmc_sampler_run.argtypes = [vp, C.c_int64]
     L.kmc_sampler_half_step.argtypes = [vp, C.c_int]

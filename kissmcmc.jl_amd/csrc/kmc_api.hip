@@ -58,13 +58,23 @@ struct Plan {
 };
 
 // ---- kernel table ------------------------------------------------------------------------
+template <class D, int L, int K, int ITER>
+HalfStepFn vec_one()
+{
+    // a group's ITER scalar lanes must fit in its L lanes; keep the register tile (ITER*K chunks) bounded
+    if constexpr (ITER <= L && ITER * K <= 16) return half_step_vec<D, L, K, ITER>;
+    else return nullptr;
+}
+
 template <class D, int L, int K>
 HalfStepFn vec_iter(int iter)
 {
     switch (iter) {
-    case 1: return half_step_vec<D, L, K, 1>;
-    case 2: return half_step_vec<D, L, K, 2>;
-    case 4: return half_step_vec<D, L, K, 4>;
+    case 1: return vec_one<D, L, K, 1>();
+    case 2: return vec_one<D, L, K, 2>();
+    case 4: return vec_one<D, L, K, 4>();
+    case 8: return vec_one<D, L, K, 8>();
+    case 16: return vec_one<D, L, K, 16>();
     default: return nullptr;
     }
 }
@@ -124,12 +134,12 @@ Plan make_plan(const kmc_config& c, int64_t n_active)
             for (auto& t : tbl)
                 if (t.nd == nd) { L = t.L; K = t.K; }
         }
-        // enough walkers per group to amortise the scalar work, while keeping >= ~2048 waves
+        // walkers per group: amortise the per-walker scalar work (Philox, two logs) over the
+        // wave while keeping >= ~2048 waves (two per SIMD) in the grid
         iter = 1;
         if (L > 0) {
             const int64_t waves1 = n_active * L / 64;
-            if (waves1 >= 8192) iter = 4;
-            else if (waves1 >= 4096) iter = 2;
+            while (iter * 2 <= L && iter * 2 * K <= 16 && waves1 / (iter * 2) >= 2048 && iter < 16) iter *= 2;
         }
     }
     lookup(c.density, L, K, iter, &vec, &gen, &lp);
@@ -182,9 +192,11 @@ struct kmc_sampler {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     double* d_pos = nullptr;
+    bool own_pos = true;
     double* d_logp = nullptr;
     uint32_t* d_naccept = nullptr;
     int64_t* d_gen = nullptr;
+    SchedEntry* d_sched = nullptr;
     double* d_chain = nullptr;
     double* d_chain_logp = nullptr;
     double* d_msum = nullptr;
@@ -202,17 +214,17 @@ struct kmc_sampler {
 
 namespace {
 
+// graph_mode: the generation is (device counter) + gen_offset, looked up in the device schedule
+// table; otherwise gen_offset is the absolute generation and its schedule travels in the args.
 HalfStepArgs make_args(const kmc_sampler* s, int half, bool graph_mode, int64_t gen_offset)
 {
     HalfStepArgs a{};
     a.pos = s->d_pos;
     a.logp = s->d_logp;
     a.naccept = s->d_naccept;
-    a.gen_base = graph_mode ? s->d_gen : nullptr;
-    a.gen_offset = gen_offset;
-    a.nburnin = s->cfg.nburnin;
-    a.nthin = s->cfg.nthin;
-    a.nsamples = s->nsamples;
+    a.sched_table = graph_mode ? s->d_sched : nullptr;
+    a.sched_index = graph_mode ? (int32_t)gen_offset : 0;
+    a.sched_inline = make_sched(gen_offset, s->cfg.nburnin, s->cfg.nthin, s->nsamples);
     a.nhalf = s->h;
     a.active_begin = s->active_begin;
     a.n_active = (int32_t)s->h_loc;
@@ -243,11 +255,16 @@ kmc_status launch_half(kmc_sampler* s, int half, bool graph_mode, int64_t gen_of
     return KMC_OK;
 }
 
+void launch_advance(kmc_sampler* s, int n, int64_t by)
+{
+    hipLaunchKernelGGL(advance_schedule, dim3(1), dim3(64), 0, s->stream, s->d_gen, s->d_sched, n, by,
+                       s->cfg.nburnin, s->cfg.nthin, s->nsamples);
+}
+
 kmc_status sync_device_counter(kmc_sampler* s)
 {
     if (s->dev_gen != s->generation) {
-        hipLaunchKernelGGL(bump_generation, dim3(1), dim3(1), 0, s->stream, s->d_gen,
-                           s->generation - s->dev_gen);
+        launch_advance(s, 0, s->generation - s->dev_gen);
         HIP_TRY(hipGetLastError());
         s->dev_gen = s->generation;
     }
@@ -259,11 +276,10 @@ kmc_status ensure_graph(kmc_sampler* s)
     if (s->graph_exec) return KMC_OK;
     HIP_TRY(hipStreamBeginCapture(s->stream, hipStreamCaptureModeRelaxed));
     kmc_status st = KMC_OK;
+    launch_advance(s, (int)kGraphChunk, 0);                 // schedule table of this chunk
     for (int64_t g = 0; g < kGraphChunk && st == KMC_OK; ++g)
         for (int half = 0; half < 2 && st == KMC_OK; ++half) st = launch_half(s, half, true, g);
-    if (st == KMC_OK) {
-        hipLaunchKernelGGL(bump_generation, dim3(1), dim3(1), 0, s->stream, s->d_gen, kGraphChunk);
-    }
+    if (st == KMC_OK) launch_advance(s, 0, kGraphChunk);   // device counter += chunk
     hipGraph_t graph = nullptr;
     hipError_t e = hipStreamEndCapture(s->stream, &graph);
     if (st != KMC_OK) { if (graph) (void)hipGraphDestroy(graph); return st; }
@@ -377,9 +393,10 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         HalfStepFn v, g;
         lookup(cfg->density, 0, 0, 1, &v, &g, &s->logpdf_fn);
     }
-    const int64_t groups = (s->h_loc + s->plan.ITER - 1) / s->plan.ITER;
-    const int64_t threads = groups * s->plan.L;
-    s->grid = (int)((threads + 255) / 256);
+    // vec: a wave owns W = (64/L)*ITER walkers; generic: one walker per lane
+    const int64_t per_wave = s->plan.vec ? (int64_t)(64 / s->plan.L) * s->plan.ITER : 64;
+    const int64_t waves = (s->h_loc + per_wave - 1) / per_wave;
+    s->grid = (int)((waves + 3) / 4);
     s->macc_stride = (int64_t)s->grid * 256;
     s->macc_elems = s->plan.vec ? s->macc_stride * 2 * s->plan.K : s->macc_stride * cfg->ndim;
 
@@ -403,8 +420,10 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
     CREATE_TRY(hipMalloc(&s->d_pos, nw * nd * sizeof(double)));
     CREATE_TRY(hipMalloc(&s->d_logp, nw * sizeof(double)));
     CREATE_TRY(hipMalloc(&s->d_naccept, nw * sizeof(uint32_t)));
+    static_assert(kGraphChunk <= 64, "advance_schedule runs one 64-thread block");
     CREATE_TRY(hipMalloc(&s->d_gen, 64));
     CREATE_TRY(hipMemset(s->d_gen, 0, 64));
+    CREATE_TRY(hipMalloc(&s->d_sched, (size_t)kGraphChunk * sizeof(SchedEntry)));
     CREATE_TRY(hipMemset(s->d_naccept, 0, nw * sizeof(uint32_t)));
     if (cfg->flags & KMC_MOMENTS) {
         CREATE_TRY(hipMalloc(&s->d_msum, (size_t)s->macc_elems * sizeof(double)));
@@ -430,10 +449,11 @@ KMC_EXPORT void kmc_sampler_destroy(kmc_sampler* s)
     if (s->graph) (void)hipGraphDestroy(s->graph);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
-    (void)hipFree(s->d_pos);
+    if (s->own_pos) (void)hipFree(s->d_pos);
     (void)hipFree(s->d_logp);
     (void)hipFree(s->d_naccept);
     (void)hipFree(s->d_gen);
+    (void)hipFree(s->d_sched);
     (void)hipFree(s->d_chain);
     (void)hipFree(s->d_chain_logp);
     (void)hipFree(s->d_msum);
@@ -451,6 +471,20 @@ KMC_EXPORT kmc_status kmc_sampler_set_stream(kmc_sampler* s, void* hip_stream)
     if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
     s->stream = (hipStream_t)hip_stream;
     s->own_stream = false;
+    return KMC_OK;
+}
+
+KMC_EXPORT kmc_status kmc_sampler_bind_positions(kmc_sampler* s, void* pos_dev)
+{
+    if (!s || !pos_dev) return fail(KMC_ERR_BAD_ARG, "null argument");
+    HIP_TRY(hipSetDevice(s->cfg.device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    if (s->graph_exec) { (void)hipGraphExecDestroy(s->graph_exec); s->graph_exec = nullptr; }
+    if (s->graph) { (void)hipGraphDestroy(s->graph); s->graph = nullptr; }
+    if (s->own_pos) (void)hipFree(s->d_pos);
+    s->d_pos = static_cast<double*>(pos_dev);
+    s->own_pos = false;
+    s->positions_set = false;
     return KMC_OK;
 }
 

@@ -23,11 +23,11 @@ __device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c
     constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
-        const uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
-        const uint32_t n0 = hi1 ^ c1 ^ k0;
-        const uint32_t n2 = hi0 ^ c3 ^ k1;
-        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        const uint64_t p0 = (uint64_t)M0 * c0;   // one v_mad_u64_u32 each
+        const uint64_t p1 = (uint64_t)M1 * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c0 = n0; c1 = (uint32_t)p1; c2 = n2; c3 = (uint32_t)p0;
         k0 += W0; k1 += W1;
     }
     return U4{c0, c1, c2, c3};
@@ -81,10 +81,38 @@ __device__ __forceinline__ bool accept_test(const Draw& d, double p1, double p0)
 // ------------------------------------------------------------------------------------------
 struct DensityParams { double p[6]; };
 
+// ---- cross-lane helpers (wave64; DPP where the pattern allows, LDS crossbar otherwise) ----
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double bperm_f64(int byte_addr, double v)
+{
+    const int lo = __builtin_amdgcn_ds_bpermute(byte_addr, __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute(byte_addr, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+// Sum over the L lanes of a group; every lane of the group ends with the same bits
+// (each butterfly level adds the same two operands on both sides).
+template <int L>
+__device__ __forceinline__ double group_sum(double v)
+{
+    if constexpr (L >= 2)  v += dpp_f64<0xB1>(v);    // quad_perm [1,0,3,2]  : lane ^ 1
+    if constexpr (L >= 4)  v += dpp_f64<0x4E>(v);    // quad_perm [2,3,0,1]  : lane ^ 2
+    if constexpr (L >= 8)  v += dpp_f64<0x141>(v);   // row_half_mirror      : other quad pair
+    if constexpr (L >= 16) v += dpp_f64<0x140>(v);   // row_mirror           : other 8-lane half
+    if constexpr (L >= 32) v += __shfl_xor(v, 16, 64);
+    if constexpr (L >= 64) v += __shfl_xor(v, 32, 64);
+    return v;
+}
 template <int L>
 __device__ __forceinline__ double group_shfl_down1(double v)
-{   // value of lane j+1 of the L-lane group (garbage for j == L-1)
-    return __shfl_down(v, 1, L);
+{   // value of lane j+1 (wave_shl:1); lane L-1 of a group receives the next group's lane 0 -- unused
+    return dpp_f64<0x130>(v);
 }
 template <int L>
 __device__ __forceinline__ double group_bcast0(double v)

@@ -11,11 +11,17 @@
 //
 // Two kernels:
 //   half_step_vec<Density, L, K, ITER>  ndim == 2*L*K.  A walker's 16*L*K-byte row is striped
-//       over L lanes of one wave (16 B per lane per chunk), so both the own row and the randomly
-//       drawn partner row are read as fully coalesced 16-B-per-lane segments; the log-pdf is a
-//       cross-lane reduction; the proposal stays in registers until the accept decision and is
-//       stored only on accept.  Each L-lane group walks ITER walkers with all loads issued
-//       up front.
+//       over the L lanes of a group (16 B per lane per chunk), so the own row and the randomly
+//       drawn partner row are both read as fully coalesced 16-B-per-lane segments, and the
+//       log-pdf is a DPP reduction over the group.  A wave owns W = (64/L)*ITER consecutive
+//       walkers and works in two layouts:
+//         "scalar" layout  lane (g,j), j < ITER, owns walker slot j*G+g: Philox, partner, z,
+//                          log z, log u, p0, the accept test -- once per walker, not per lane;
+//         "row" layout     group g, iteration it, owns slot it*G+g: loads, stretch move,
+//                          density partial sums, stores.
+//       Scalars travel scalar->row by ds_bpermute (partner, z), row->scalar for free (the lane
+//       with j == it keeps the reduced log-pdf), and the accept bits come back as a ballot mask.
+//       The proposal stays in registers until the accept decision and is stored only on accept.
 //   half_step_generic<Density>          any ndim; one walker per lane, scalar loops.  Used for
 //       the reference's own 1-D/2-D cases and odd sizes.
 #pragma once
@@ -23,61 +29,60 @@
 
 namespace kmc {
 
-struct HalfStepArgs {
-    double*        pos;
-    double*        logp;
-    uint32_t*      naccept;
-    const int64_t* gen_base;     // device generation counter (graph replay) or nullptr
-    int64_t        gen_offset;   // generation = gen_offset + (gen_base ? *gen_base : 0)
-    int64_t        nburnin;
-    int64_t        nthin;
-    int64_t        nsamples;     // stored-sample capacity
-    int64_t        nhalf;        // h = nwalkers / 2 (global)
-    int64_t        active_begin; // first active index (within the half) of this shard
-    int32_t        n_active;     // number of active walkers of this shard
-    int32_t        half;         // 0: update [0,h) against [h,2h); 1: swapped       (:247)
-    int32_t        ndim;
-    int32_t        pad_;
-    DrawConsts     dc;
-    DensityParams  dp;
-    double*        chain;        // [nsamples][chain_rows][ndim] or nullptr          (:269)
-    double*        chain_logp;   // [nsamples][chain_rows] or nullptr                (:271)
-    int64_t        chain_rows;   // rows per sample slot
-    int64_t        chain_row0;   // row of this launch's first active walker in a slot
-    double*        msum;         // per-thread moment accumulators or nullptr
-    double*        msumsq;
-    int64_t        macc_stride;  // threads in the accumulator grid
+// What the reference's loop variable n (src/samplers.jl:245) implies for one generation.
+struct SchedEntry {
+    int64_t  gen;     // generation index g in [0, G);  n = g + 1 - nburnin
+    int64_t  slot;    // stored-sample index k when (flags & kSample)
+    uint32_t flags;
+    uint32_t pad_;
 };
+enum : uint32_t { kCount = 1u, kSample = 2u };
 
-struct Schedule {
-    int64_t gen;
-    bool    count;   // post burn-in: count acceptances            (:265, :285-288)
-    bool    sample;  // this generation's state is a stored sample (:268)
-    int64_t slot;    // its index k
-};
-
-__device__ __forceinline__ Schedule schedule_of(const HalfStepArgs& a)
+__host__ __device__ inline SchedEntry make_sched(int64_t gen, int64_t nburnin, int64_t nthin, int64_t nsamples)
 {
-    Schedule s;
-    s.gen = a.gen_offset + (a.gen_base ? *a.gen_base : 0);
-    const int64_t n = s.gen + 1 - a.nburnin;          // the reference's loop variable n (:245)
-    s.count = n > 0;
-    s.sample = false;
-    s.slot = 0;
+    SchedEntry e{gen, 0, 0u, 0u};
+    const int64_t n = gen + 1 - nburnin;
     if (n > 0) {
-        if (a.nthin == 1) { s.sample = true; s.slot = n - 1; }
-        else if (n % a.nthin == 0) { s.sample = true; s.slot = n / a.nthin - 1; }
-        if (s.slot >= a.nsamples) s.sample = false;
+        e.flags |= kCount;                              // :265, counters restart at n == 0 (:285-288)
+        if (n % nthin == 0) {                           // :268
+            const int64_t k = n / nthin - 1;
+            if (k < nsamples) { e.flags |= kSample; e.slot = k; }
+        }
     }
-    return s;
+    return e;
 }
 
-template <int L>
-__device__ __forceinline__ double group_sum(double v)
+struct HalfStepArgs {
+    double*           pos;
+    double*           logp;
+    uint32_t*         naccept;
+    const SchedEntry* sched_table;  // device table (graph replay) or nullptr
+    SchedEntry        sched_inline; // used when sched_table == nullptr
+    int32_t           sched_index;
+    int32_t           half;         // 0: update [0,h) against [h,2h); 1: swapped       (:247)
+    int64_t           nhalf;        // h = nwalkers / 2 (global)
+    int64_t           active_begin; // first active index (within the half) of this shard
+    int32_t           n_active;     // number of active walkers of this shard
+    int32_t           ndim;
+    DrawConsts        dc;
+    DensityParams     dp;
+    double*           chain;        // [nsamples][chain_rows][ndim] or nullptr          (:269)
+    double*           chain_logp;   // [nsamples][chain_rows] or nullptr                (:271)
+    int64_t           chain_rows;   // rows per sample slot
+    int64_t           chain_row0;   // row of this launch's first active walker in a slot
+    double*           msum;         // per-thread moment accumulators or nullptr
+    double*           msumsq;
+    int64_t           macc_stride;  // threads in the accumulator grid
+};
+
+__device__ __forceinline__ SchedEntry schedule_of(const HalfStepArgs& a)
 {
-#pragma unroll
-    for (int m = 1; m < L; m <<= 1) v += __shfl_xor(v, m, 64);
-    return v;
+    return a.sched_table ? a.sched_table[a.sched_index] : a.sched_inline;
+}
+
+__device__ __forceinline__ double2 sel2(bool c, const double2& a, const double2& b)
+{
+    return make_double2(c ? a.x : b.x, c ? a.y : b.y);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -87,86 +92,108 @@ template <class Dens, int L, int K, int ITER>
 __global__ __launch_bounds__(256) void half_step_vec(const HalfStepArgs a)
 {
     static_assert(L >= 1 && L <= 64 && (L & (L - 1)) == 0, "L must be a power of two <= 64");
-    const int tid = blockIdx.x * 256 + threadIdx.x;
-    const int j   = threadIdx.x & (L - 1);
-    const int grp = tid / L;
-    const int ndim = 2 * L * K;
-    const Schedule sch = schedule_of(a);
-    const uint64_t step = 2ull * (uint64_t)sch.gen + (uint64_t)a.half;
+    static_assert(ITER >= 1 && ITER <= L, "a group's scalar lanes must cover its iterations");
+    constexpr int G = 64 / L;          // groups = walkers in flight per wave
+    constexpr int W = G * ITER;        // walkers per wave
+    constexpr int ndim = 2 * L * K;
+    const int tid   = blockIdx.x * 256 + threadIdx.x;
+    const int lane  = threadIdx.x & 63;
+    const int j     = lane & (L - 1);
+    const int g     = lane / L;
+    const int gbase = lane & ~(L - 1);                  // first lane of this group
+    const int w0    = (tid >> 6) * W;                   // first active index of this wave
+    const int nact  = a.n_active;
     const int64_t act0 = (int64_t)a.half * a.nhalf + a.active_begin;   // global index of active walker 0
     const int64_t oth0 = (int64_t)(1 - a.half) * a.nhalf;
 
-    bool     valid[ITER];
-    int64_t  gw[ITER];
-    Draw     dr[ITER];
-    double   p0[ITER];
-    double2  xc[ITER][K], xo[ITER][K];
-
+    // ---- row layout: own rows of every iteration (independent of the random draws) ----------
+    bool    validB[ITER];
+    double2 xc[ITER][K], xo[ITER][K];
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
-        const int i = grp * ITER + it;
-        valid[it] = i < a.n_active;
-        gw[it] = act0 + (valid[it] ? i : a.n_active - 1);
-        const double2* own = reinterpret_cast<const double2*>(a.pos + gw[it] * ndim);
+        const int i = w0 + it * G + g;
+        validB[it] = i < nact;
+        const double2* own = reinterpret_cast<const double2*>(a.pos + (act0 + (validB[it] ? i : nact - 1)) * ndim);
 #pragma unroll
         for (int k = 0; k < K; ++k) xc[it][k] = own[k * L + j];
-        p0[it] = a.logp[gw[it]];
     }
+
+    // ---- scalar layout: one walker per lane (j < ITER) ---------------------------------------
+    const SchedEntry sch = schedule_of(a);
+    const bool count  = (sch.flags & kCount) != 0;
+    const bool sample = (sch.flags & kSample) != 0;
+    const uint64_t step = 2ull * (uint64_t)sch.gen + (uint64_t)a.half;
+    const int  iA     = w0 + (j < ITER ? j : 0) * G + g;
+    const bool validA = (j < ITER) && (iA < nact);
+    const int64_t gwA = act0 + (iA < nact ? iA : nact - 1);
+    const double   p0 = a.logp[gwA];
+    const uint32_t na = a.naccept[gwA];
+    const Draw dr = draw_step(a.dc, step, (uint64_t)gwA);               // :250, :252
+
+    // ---- scalar -> row: partner index and z of slot it*G+g live in lane gbase+it -------------
+    double zB[ITER];
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
-        dr[it] = draw_step(a.dc, step, (uint64_t)gw[it]);
-        const double2* oth = reinterpret_cast<const double2*>(a.pos + (oth0 + dr[it].partner) * ndim);
+        const int src = (gbase + it) * 4;
+        const uint32_t partner = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)dr.partner);
+        zB[it] = bperm_f64(src, dr.z);
+        const double2* oth = reinterpret_cast<const double2*>(a.pos + (oth0 + partner) * ndim);
 #pragma unroll
         for (int k = 0; k < K; ++k) xo[it][k] = oth[k * L + j];
     }
 
-    const bool do_mom = sch.sample && a.msum != nullptr;
+    // ---- stretch move + log-pdf; xo becomes the proposal ------------------------------------
+    double myp1 = 0.0;
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {                                   // :255
+            xo[it][k].x = fma(zB[it], xc[it][k].x - xo[it][k].x, xo[it][k].x);
+            xo[it][k].y = fma(zB[it], xc[it][k].y - xo[it][k].y, xo[it][k].y);
+        }
+        const double S  = group_sum<L>(Dens::template frag_partial<L, K>(xo[it], j, ndim, a.dp));
+        const double p1 = Dens::finish(S, a.dp);                         // :257
+        myp1 = (j == it) ? p1 : myp1;                                   // row -> scalar, no traffic
+    }
+
+    // ---- accept test in the scalar layout ---------------------------------------------------
+    const bool acc = validA && accept_test(dr, myp1, p0);               // :260
+    const unsigned long long accmask = __ballot(acc);
+    if (acc) {
+        a.logp[gwA] = myp1;                                             // :262
+        if (count) a.naccept[gwA] = na + 1u;                            // :265
+    }
+    if (sample && a.chain_logp != nullptr && validA)                    // :271
+        a.chain_logp[sch.slot * a.chain_rows + a.chain_row0 + iA] = acc ? myp1 : p0;
+
+    // ---- row layout again: store accepted proposals, samples, moments -----------------------
     double2 ms[K], mq[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) { ms[k] = make_double2(0.0, 0.0); mq[k] = make_double2(0.0, 0.0); }
-
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
-        double2 y[K];
+        const bool accB = ((accmask >> (gbase + it)) & 1ull) != 0;
+        if (accB) {                                                     // :261
+            double2* own = reinterpret_cast<double2*>(a.pos + (act0 + w0 + it * G + g) * ndim);
 #pragma unroll
-        for (int k = 0; k < K; ++k) {                                   // :255
-            y[k].x = fma(dr[it].z, xc[it][k].x - xo[it][k].x, xo[it][k].x);
-            y[k].y = fma(dr[it].z, xc[it][k].y - xo[it][k].y, xo[it][k].y);
+            for (int k = 0; k < K; ++k) own[k * L + j] = xo[it][k];
         }
-        const double S  = group_sum<L>(Dens::template frag_partial<L, K>(y, j, ndim, a.dp));
-        const double p1 = Dens::finish(S, a.dp);                         // :257
-        const bool acc = accept_test(dr[it], p1, p0[it]) && valid[it];   // :260
-        if (acc) {                                                       // :261-265
-            double2* own = reinterpret_cast<double2*>(a.pos + gw[it] * ndim);
-#pragma unroll
-            for (int k = 0; k < K; ++k) own[k * L + j] = y[k];
-            if (j == 0) {
-                a.logp[gw[it]] = p1;
-                if (sch.count) atomicAdd(&a.naccept[gw[it]], 1u);
-            }
-        }
-        if (sch.sample) {                                                // :268-271
+        if (sample) {                                                   // :268-269
+            double2* dst = nullptr;
+            if (a.chain != nullptr && validB[it])
+                dst = reinterpret_cast<double2*>(a.chain + (sch.slot * a.chain_rows + a.chain_row0 + w0 + it * G + g) * ndim);
 #pragma unroll
             for (int k = 0; k < K; ++k) {
-                const double2 cur = acc ? y[k] : xc[it][k];
-                if (valid[it]) {
+                const double2 cur = sel2(accB, xo[it][k], xc[it][k]);
+                if (validB[it]) {
                     ms[k].x += cur.x; ms[k].y += cur.y;
                     mq[k].x += cur.x * cur.x; mq[k].y += cur.y * cur.y;
                 }
-            }
-            if (a.chain != nullptr && valid[it]) {
-                const int64_t row = sch.slot * a.chain_rows + a.chain_row0 + (grp * ITER + it);
-                double2* dst = reinterpret_cast<double2*>(a.chain + row * ndim);
-#pragma unroll
-                for (int k = 0; k < K; ++k) dst[k * L + j] = acc ? y[k] : xc[it][k];
-            }
-            if (a.chain_logp != nullptr && valid[it] && j == 0) {
-                const int64_t row = sch.slot * a.chain_rows + a.chain_row0 + (grp * ITER + it);
-                a.chain_logp[row] = acc ? p1 : p0[it];
+                if (dst) dst[k * L + j] = cur;
             }
         }
     }
-    if (do_mom) {
+    if (sample && a.msum != nullptr) {
         double2* s = reinterpret_cast<double2*>(a.msum);
         double2* q = reinterpret_cast<double2*>(a.msumsq);
 #pragma unroll
@@ -189,7 +216,9 @@ __global__ __launch_bounds__(256) void half_step_generic(const HalfStepArgs a)
     const int tid = blockIdx.x * 256 + threadIdx.x;
     if (tid >= a.n_active) return;
     const int ndim = a.ndim;
-    const Schedule sch = schedule_of(a);
+    const SchedEntry sch = schedule_of(a);
+    const bool count  = (sch.flags & kCount) != 0;
+    const bool sample = (sch.flags & kSample) != 0;
     const uint64_t step = 2ull * (uint64_t)sch.gen + (uint64_t)a.half;
     const int64_t gw = (int64_t)a.half * a.nhalf + a.active_begin + tid;
     const Draw dr = draw_step(a.dc, step, (uint64_t)gw);
@@ -206,8 +235,8 @@ __global__ __launch_bounds__(256) void half_step_generic(const HalfStepArgs a)
     const double p1 = Dens::seq_finish(q, ndim, a.dp);                   // :257
     const bool acc = accept_test(dr, p1, p0);                           // :260
 
-    const bool do_mom = sch.sample && a.msum != nullptr;
-    const bool do_chain = sch.sample && a.chain != nullptr;
+    const bool do_mom = sample && a.msum != nullptr;
+    const bool do_chain = sample && a.chain != nullptr;
     const int64_t row = sch.slot * a.chain_rows + a.chain_row0 + tid;
     if (acc || do_mom || do_chain) {
         for (int d = 0; d < ndim; ++d) {
@@ -224,9 +253,9 @@ __global__ __launch_bounds__(256) void half_step_generic(const HalfStepArgs a)
     }
     if (acc) {
         a.logp[gw] = p1;                                                // :262
-        if (sch.count) a.naccept[gw] += 1u;                             // :265
+        if (count) a.naccept[gw] += 1u;                                 // :265
     }
-    if (sch.sample && a.chain_logp != nullptr) a.chain_logp[row] = acc ? p1 : p0;   // :271
+    if (sample && a.chain_logp != nullptr) a.chain_logp[row] = acc ? p1 : p0;   // :271
 }
 
 // Initial log-pdfs, src/samplers.jl:209.
@@ -242,6 +271,15 @@ __global__ __launch_bounds__(256) void logpdf_rows(const double* __restrict__ po
     logp[r] = Dens::seq_finish(q, ndim, dp);
 }
 
-__global__ void bump_generation(int64_t* gen, int64_t by) { *gen += by; }
+// Graph replay support: the device-side generation counter and the schedule table of the next
+// `n` generations (one thread each).  *gen += by happens before the table is rebuilt.
+__global__ void advance_schedule(int64_t* gen, SchedEntry* table, int n, int64_t by,
+                                 int64_t nburnin, int64_t nthin, int64_t nsamples)
+{
+    const int64_t base = *gen + by;
+    __syncthreads();
+    if ((int)threadIdx.x < n) table[threadIdx.x] = make_sched(base + threadIdx.x, nburnin, nthin, nsamples);
+    if (threadIdx.x == 0) *gen = base;
+}
 
 }  // namespace kmc

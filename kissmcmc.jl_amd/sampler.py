@@ -82,6 +82,10 @@ class Sampler:
     def set_stream(self, hip_stream: int):
         _lib.check(self._L.kmc_sampler_set_stream(self._h, C.c_void_p(hip_stream)))
 
+    def bind_positions(self, device_ptr: int):
+        """Use a caller-owned device buffer (``double [nwalkers][ndim]``) for the ensemble."""
+        _lib.check(self._L.kmc_sampler_bind_positions(self._h, C.c_void_p(device_ptr)))
+
     def set_positions(self, theta):
         theta = np.ascontiguousarray(np.asarray(theta, dtype=np.float64).reshape(self.nwalkers, self.ndim))
         _lib.check(self._L.kmc_sampler_set_positions(self._h, _dp(theta)))
