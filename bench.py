@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""Headline benchmark: walker-steps/s of the emcee stretch-move hot path on MI355X.
+
+Workload (BASELINE.json configs[1], "C2"): 65 536 walkers x 32-dim isotropic Gaussian, fp64,
+a = 2, 10^4 generations (burn-in = first half), streaming moments ON, chain storage OFF.
+One bench "step" = GENS_PER_STEP (1000) generations = 65.536e6 walker-steps per GPU, so the
+default --steps 10 is exactly the 10^4-generation job.  With --gpus N (launched by
+torch.distributed.run, one rank per GPU) the ensemble is 65 536 x N walkers, walker-sharded with an
+RCCL all-gather of the updated half after every half-step (weak scaling, config C4 at N = 8).
+
+Prints ONE JSON line (rank 0).  `value` = all walker-steps of the timed region / wall time
+(max over ranks) with the ensemble resident in HBM.  `roofline` prices the half-step kernel
+against the 8 TB/s HBM spec using ALGORITHMIC read bytes ((2*ndim+1)*8 B per walker-step,
+SURVEY.md 8(d)); `cpu_baseline` times the CPU oracle (a port of the reference algorithm, not
+KissMCMC.jl itself) on this box's host cores on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+NWALKERS_PER_GPU = 65536
+NDIM = 32
+GENS_PER_STEP = 1000
+SEED = 12345
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy rate is 6290 GB/s
+
+
+def theta0_c2(nwalkers: int) -> np.ndarray:
+    """theta0 = 0 + 0.1 * N(0, I): make_theta0s(zeros(32), 0.1, pdf, nwalkers) (reference test default ball_radius)."""
+    import kissmcmc_jl_amd as kmc
+    return kmc.make_theta0s(np.zeros(NDIM), 0.1, kmc.GaussianIso(), nwalkers, rng=SEED)
+
+
+def cpu_baseline(budget_s: float = 10.0):
+    """Oracle (C + OpenMP over the active half, like Threads.@threads at src/samplers.jl:248) on C2's
+    shape for a bounded number of generations."""
+    import oracle
+    oracle.build()
+    cores = max(1, min(os.cpu_count() or 1, 64))
+    th = theta0_c2(NWALKERS_PER_GPU)
+    probe = 4
+
+    def run(G):
+        cfg = oracle.make_config(oracle.GAUSSIAN_ISO, [0.0, 1.0], NWALKERS_PER_GPU, NDIM, G, G // 2, 1, 2.0, SEED,
+                                 nthreads=cores)
+        t0 = time.perf_counter()
+        r = oracle.emcee(cfg, th, store_chain=False)
+        assert r["status"] == 0
+        return time.perf_counter() - t0
+
+    run(1)                       # thread pool warm-up
+    t = run(probe)
+    G = int(max(probe, min(4000, budget_s / max(t / probe, 1e-6))))
+    t = run(G)
+    return {"value": NWALKERS_PER_GPU * G / t, "unit": "walker-steps/s", "cores": cores, "kind": "port",
+            "sample": f"C2 shape (65536 walkers x 32-dim Gaussian, fp64), {G} generations = {NWALKERS_PER_GPU * G:.3g} walker-steps, {t:.1f} s wall"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import kissmcmc_jl_amd as kmc
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run --nproc-per-node {args.gpus}")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP emcee path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    nw = NWALKERS_PER_GPU * world
+    G = args.steps * GENS_PER_STEP
+    nburn = G // 2
+    pdf = kmc.GaussianIso()
+    th = theta0_c2(nw)
+    launches = 0
+
+    if world == 1:
+        s = kmc.Sampler(pdf, nw, NDIM, G, nburn, 1, 2.0, SEED, moments=True, device=local_rank)
+        s.set_positions(th)
+        for _ in range(args.warmup):
+            s.run(GENS_PER_STEP)
+        s.sync()
+        s.set_positions(th)                      # restart: the timed region is the whole C2 job
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        s.run(G)                                 # exactly `steps` steps of GENS_PER_STEP generations
+        s.sync()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        event_ms = s.last_run_ms()               # HIP events on the sampler's own stream
+        launches = s.launch_count
+        msum, msq, nmom = s.moments()
+        acc = float(s.accept_ratio().mean())
+        s.close()
+    else:
+        from kissmcmc_jl_amd.distributed import HipShardExecutor, ShardedEmcee
+        ex = HipShardExecutor(pdf, nw, NDIM, G, nburn, 1, 2.0, SEED, rank=rank, world=world, device=local_rank)
+        ex.set_positions(th)
+        drv = ShardedEmcee(ex, nw, NDIM)
+        drv.run(min(args.warmup * GENS_PER_STEP, 200))   # warm-up: kernels + RCCL rings
+        ex.sync()
+        ex.set_positions(th)
+        drv.generation = 0
+        dist.barrier()
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()                             # the executor launches on torch's current stream
+        drv.run(G)
+        ev1.record()
+        ex.sync()
+        torch.cuda.synchronize()
+        dist.barrier()
+        elapsed = time.perf_counter() - t0
+        event_ms = ev0.elapsed_time(ev1)
+        launches = 2 * G
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        msum, msq, nmom = drv.moments()
+        acc = float(drv.naccept().sum() / nw / max(1, G - nburn))
+        ex.close()
+
+    if rank == 0:
+        steps_total = float(nw) * G
+        value = steps_total / elapsed
+        mean = msum / max(1, nmom)
+        var = msq / max(1, nmom) - mean ** 2
+        # dominant kernel: half_step_vec<GaussianIso,...>; one launch = one half-step of this rank
+        walkers_per_launch = NWALKERS_PER_GPU // 2
+        b_read = (2 * NDIM + 1) * 8
+        b_total = (3 * NDIM + 2) * 8
+        launch_us = event_ms * 1e3 / max(1, launches)
+        achieved = walkers_per_launch * b_read / (launch_us * 1e-6) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_c2.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "walker-steps/sec", "value": value, "unit": "walker-steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"C2: emcee stretch move, {NWALKERS_PER_GPU} walkers/GPU x {NDIM}-dim isotropic Gaussian, "
+                                   f"{G} generations (burn-in {nburn}), a=2, streaming moments on, chain off",
+                       "nwalkers_total": nw, "ndim": NDIM, "generations": G, "gens_per_step": GENS_PER_STEP,
+                       "parallelism": "single GPU" if world == 1 else f"walker-sharded x{world}, RCCL all-gather per half-step"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "half_step_vec<GaussianIso>", "launches": launches, "avg_launch_us": launch_us,
+                         "algorithmic_read_bytes_per_launch": walkers_per_launch * b_read,
+                         "algorithmic_total_bytes_per_launch": walkers_per_launch * b_total,
+                         "note": "achieved = algorithmic READ bytes ((2*ndim+1)*8 B per walker-step) / average launch-to-launch "
+                                 "time from HIP events over the timed region (includes the ~1.5 us kernel boundary)"},
+            "check": {"accept_ratio_mean": acc, "posterior_mean_absmax": float(np.abs(mean).max()),
+                      "posterior_var_min": float(var.min()), "posterior_var_max": float(var.max()),
+                      "nmoment": int(nmom)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

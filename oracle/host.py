@@ -37,6 +37,10 @@ def make_theta0s(theta0, ball_radius, pdf, nwalkers, rng, ball_radius_halfing_st
     if np.ndim(ball_radius) == 0 and not scalar:               # :316-318
         ball_radius = np.ones(npara) * ball_radius
     assert np.size(ball_radius) == npara                       # :319
+    if np.ndim(ball_radius) != 0:
+        ball_radius = np.asarray(ball_radius, dtype=np.float64)
+    if not scalar:
+        theta0 = np.asarray(theta0, dtype=np.float64)
     theta0s = []                                               # :321
     for i in range(1, nwalkers + 1):                           # :323
         for k in range(1, ball_radius_halfing_steps + 1):      # :324

@@ -1,0 +1,132 @@
+"""The C-ABI shared library loads and exports every symbol include/kissmcmc_hip.h declares;
+calls that need no device behave (validation, g helpers, error strings).  No compute here."""
+import ctypes as C
+import os
+import re
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "kissmcmc_hip.h")
+
+
+def _declared_symbols():
+    txt = open(HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(kmc_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol(kmc):
+    from kissmcmc_jl_amd import _lib
+    L = _lib.lib()
+    declared = _declared_symbols()
+    assert len(declared) >= 25
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in the header but not exported"
+    assert sorted(_lib.SYMBOLS) == declared
+    assert L.kmc_version() == 100
+
+
+def test_struct_layout_matches_header(kmc, tmp_path):
+    """sizeof/offsetof of kmc_config and kmc_outputs as gcc sees the header == the ctypes mirror."""
+    from kissmcmc_jl_amd import _lib
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "kissmcmc_hip.h"\n'
+                   'int main(void){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(kmc_config), offsetof(kmc_config, nwalkers),'
+                   ' offsetof(kmc_config, seed), offsetof(kmc_config, shard_count), sizeof(kmc_outputs), offsetof(kmc_outputs, device_ms));return 0;}\n')
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    want = [C.sizeof(_lib.Config), _lib.Config.nwalkers.offset, _lib.Config.seed.offset, _lib.Config.shard_count.offset,
+            C.sizeof(_lib.Outputs), _lib.Outputs.device_ms.offset]
+    assert got == want
+
+
+def _cfg(_lib, **kw):
+    c = _lib.Config()
+    c.dtype, c.density = _lib.F64, _lib.GAUSSIAN_ISO
+    c.params[0], c.params[1] = 0.0, 1.0
+    c.nwalkers, c.ndim, c.ngenerations, c.nburnin, c.nthin = 10, 2, 10, 5, 1
+    c.a_scale, c.seed = 2.0, 1
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c
+
+
+def test_validate_returns_the_reference_assert_conditions(kmc):
+    from kissmcmc_jl_amd import _lib
+    L = _lib.lib()
+    v = lambda **kw: L.kmc_validate(C.byref(_cfg(_lib, **kw)))
+    assert v() == _lib.OK
+    assert v(a_scale=1.0) == _lib.ERR_A_SCALE                    # samplers.jl:200
+    assert v(nwalkers=11) == _lib.ERR_ODD_WALKERS                # :202
+    assert L.kmc_last_error() == b"Use an even number of walkers."
+    assert v(nwalkers=2) == _lib.ERR_TOO_FEW_WALKERS             # :205
+    assert L.kmc_last_error() == b"Use more walkers: at least DOF+2, but better many more."
+    assert v(nwalkers=4) == _lib.OK
+    assert v(nthin=0) == _lib.ERR_BAD_ARG
+    assert v(density=99) == _lib.ERR_BAD_ARG
+    assert v(dtype=7) == _lib.ERR_UNSUPPORTED
+    assert v(shard_count=3) == _lib.ERR_BAD_ARG                  # 5 walkers per half not divisible by 3
+    assert v(shard_count=5, shard_rank=4) == _lib.OK
+    assert v(density=_lib.ROSENBROCK, ndim=1, nwalkers=10) == _lib.ERR_BAD_ARG
+    assert L.kmc_validate(None) == _lib.ERR_BAD_ARG
+
+
+def test_g_helpers_known_answers(kmc):
+    """reference test/emcee.jl:6-8 on the product's host helpers."""
+    a = 3.5
+    assert kmc.cdf_g_inv(1, a) == pytest.approx(a, rel=1e-12)
+    assert kmc.cdf_g_inv(0, a) == pytest.approx(1 / a, rel=1e-12)
+    assert kmc.g_pdf(1 / a - 1e-9, a) == 0.0 and kmc.g_pdf(a + 1e-9, a) == 0.0
+    z = np.arange(1 / a, a, 0.001)
+    assert np.sum([kmc.g_pdf(v, a) for v in z]) * 0.001 == pytest.approx(1.0, abs=2e-3)
+
+
+def test_product_never_touches_the_oracle():
+    """The product package must not import, link or execute anything under oracle/."""
+    pkg = os.path.join(ROOT, "kissmcmc.jl_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp", ".jl")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "kmco_" not in txt, f
+                assert "libkmc_oracle" not in txt, f
+
+
+def test_sampler_fails_loudly_without_a_device(kmc):
+    from kissmcmc_jl_amd import _lib
+    if _lib.lib().kmc_device_count() > 0:
+        pytest.skip("a HIP device is visible")
+    with pytest.raises(kmc.KmcError, match="no CPU fallback") as e:
+        kmc.Sampler(kmc.GaussianIso(), 10, 2, 10)
+    assert e.value.status == _lib.ERR_NO_DEVICE
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not available")
+def test_stream_is_rocrand_philox(oracle, tmp_path):
+    """The oracle's draw block == rocRAND's host-callable Philox4x32-10 engine after
+    rocrand_init(seed, subsequence = walker, offset = 4 * step): the stream the kernels document."""
+    src = tmp_path / "rr.cpp"
+    src.write_text(r'''
+#include <cstdio>
+#include <cstdlib>
+#include <rocrand/rocrand_philox4x32_10.h>
+int main(int argc, char** argv) {
+    unsigned long long seed = strtoull(argv[1], 0, 0), step = strtoull(argv[2], 0, 0), walker = strtoull(argv[3], 0, 0);
+    rocrand_device::philox4x32_10_engine e(seed, walker, 4ULL * step);
+    uint4 r = e.next4();
+    printf("%u %u %u %u\n", r.x, r.y, r.z, r.w);
+    return 0;
+}''')
+    exe = tmp_path / "rr"
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    subprocess.check_call([hipcc, "-O1", "--offload-arch=gfx950", str(src), "-o", str(exe)], stderr=subprocess.DEVNULL)
+    for seed, step, walker in [(0, 0, 0), (12345, 7, 65535), (0xDEADBEEFCAFEF00D, 2 ** 33 + 5, 2 ** 32 + 9)]:
+        got = tuple(int(v) for v in subprocess.check_output([str(exe), str(seed), str(step), str(walker)]).split())
+        want = oracle.philox4x32_10((step & 0xFFFFFFFF, step >> 32, walker & 0xFFFFFFFF, walker >> 32),
+                                    (seed & 0xFFFFFFFF, seed >> 32))
+        assert got == want

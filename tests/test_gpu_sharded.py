@@ -1,0 +1,75 @@
+"""GPU: walker sharding on ONE device.  P logical shards (P samplers with shard_rank r sharing one
+position buffer, a device-local stand-in for the RCCL all-gather) must reproduce the unsharded
+run bit for bit; and the torch.distributed driver runs with world_size 1 on the nccl backend."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("P", [2, 4, 8])
+def test_logical_shards_on_one_gpu_equal_unsharded(kmc, oracle, P):
+    import torch
+    nw, nd, G, nburn, seed = 512, 32, 12, 4, 21
+    th = np.random.default_rng(1).standard_normal((nw, nd))
+    pdf = kmc.GaussianIso()
+    pos = torch.empty((nw, nd), dtype=torch.float64, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    shards = []
+    for r in range(P):
+        s = kmc.Sampler(pdf, nw, nd, G, nburn, 1, 2.0, seed, moments=True, use_graph=False, shard_rank=r, shard_count=P)
+        s.bind_positions(pos.data_ptr())
+        s.set_stream(stream)
+        s.set_positions(th)
+        shards.append(s)
+    for g in range(G):
+        for half in (0, 1):
+            for s in shards:        # same stream: all shards of a half-step, then the next half-step
+                s.half_step(half)
+    torch.cuda.synchronize()
+    cfg = oracle.make_config(oracle.GAUSSIAN_ISO, [0.0, 1.0], nw, nd, G, nburn, 1, 2.0, seed)
+    ref = oracle.emcee(cfg, th, store_chain=False)
+    np.testing.assert_array_equal(pos.cpu().numpy(), ref["final_pos"])
+    nacc = sum(s.naccept() for s in shards)
+    np.testing.assert_array_equal(nacc, ref["naccept"])
+    S = sum(s.moments()[0] for s in shards); Q = sum(s.moments()[1] for s in shards); n = sum(s.moments()[2] for s in shards)
+    assert n == ref["nmoment"]
+    np.testing.assert_allclose(S, ref["sum"], rtol=1e-11, atol=1e-9)
+    np.testing.assert_allclose(Q, ref["sumsq"], rtol=1e-11, atol=1e-9)
+    with pytest.raises(kmc.KmcError, match="shard_count == 1"):
+        shards[0].run(1)
+    for s in shards:
+        s.close()
+
+
+def test_distributed_driver_world1_nccl(kmc, oracle):
+    import torch
+    import torch.distributed as dist
+    from kissmcmc_jl_amd.distributed import HipShardExecutor, ShardedEmcee
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1)
+        created = True
+    try:
+        nw, nd, G, nburn, seed = 256, 32, 10, 3, 8
+        th = np.random.default_rng(2).standard_normal((nw, nd))
+        ex = HipShardExecutor(kmc.GaussianIso(), nw, nd, G, nburn, 1, 2.0, seed, rank=0, world=1)
+        ex.set_positions(th)
+        drv = ShardedEmcee(ex, nw, nd)
+        drv.run(G)
+        ex.sync()
+        cfg = oracle.make_config(oracle.GAUSSIAN_ISO, [0.0, 1.0], nw, nd, G, nburn, 1, 2.0, seed)
+        ref = oracle.emcee(cfg, th, store_chain=False)
+        np.testing.assert_array_equal(drv.positions(), ref["final_pos"])
+        np.testing.assert_array_equal(drv.naccept(), ref["naccept"])
+        s, q, n = drv.moments()
+        assert n == ref["nmoment"]
+        np.testing.assert_allclose(s, ref["sum"], rtol=1e-11, atol=1e-9)
+        ex.close()
+    finally:
+        if created:
+            dist.destroy_process_group()
