@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libkissmcmc_hip.so")
+# KMC_LIB_PATH selects an experiment build of the same library (see build.py); default in-tree.
+LIB_PATH = os.environ.get("KMC_LIB_PATH") or os.path.join(_HERE, "libkissmcmc_hip.so")
 
 # kmc_status
 OK, ERR_A_SCALE, ERR_ODD_WALKERS, ERR_TOO_FEW_WALKERS, ERR_BAD_ARG, ERR_NONFINITE_LOGP, \

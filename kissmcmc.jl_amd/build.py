@@ -29,15 +29,16 @@ def stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile csrc/*.hip into libkissmcmc_hip.so next to this file (in-tree, so it travels)."""
-    if force or stale():
-        cmd = [_hipcc(), *FLAGS, *[os.path.join(CSRC, f) for f in SOURCES], "-o", LIB + ".tmp"]
+def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str = LIB) -> str:
+    """Compile csrc/*.hip into libkissmcmc_hip.so next to this file (in-tree, so it travels).
+    ``extra_flags``/``out`` build experiment variants (e.g. ``-DKMC_STORE_SC1``) side by side."""
+    if force or out != LIB or stale():
+        cmd = [_hipcc(), *FLAGS, *extra_flags, *[os.path.join(CSRC, f) for f in SOURCES], "-o", out + ".tmp"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
-        os.replace(LIB + ".tmp", LIB)
-    return LIB
+        os.replace(out + ".tmp", out)
+    return out
 
 
 if __name__ == "__main__":

@@ -87,8 +87,9 @@ HalfStepFn vec_lookup(int L, int K, int iter)
     } else {
 #define KMC_LK(l, k) if (L == l && K == k) return vec_iter<D, l, k>(iter);
         KMC_LK(4, 1) KMC_LK(8, 1) KMC_LK(16, 1) KMC_LK(32, 1) KMC_LK(64, 1)
-        KMC_LK(8, 2) KMC_LK(16, 2) KMC_LK(32, 2) KMC_LK(64, 2)
-        KMC_LK(64, 4) KMC_LK(64, 8)
+        KMC_LK(4, 2) KMC_LK(8, 2) KMC_LK(16, 2) KMC_LK(32, 2) KMC_LK(64, 2)
+        KMC_LK(4, 4) KMC_LK(8, 4) KMC_LK(16, 4) KMC_LK(32, 4) KMC_LK(64, 4)
+        KMC_LK(64, 8)
 #undef KMC_LK
         return nullptr;
     }
@@ -129,17 +130,19 @@ Plan make_plan(const kmc_config& c, int64_t n_active)
         L = 0;
         const int64_t nd = c.ndim;
         if (nd % 2 == 0) {
-            struct { int nd, L, K; } tbl[] = {{8, 4, 1},   {16, 8, 1},   {32, 16, 1},  {64, 32, 1}, {128, 64, 1},
+            // measured on MI355X (scripts/quick_bench.py): 4 lanes x 2 chunks per 64 B of row
+            struct { int nd, L, K; } tbl[] = {{8, 4, 1},    {16, 4, 2},   {32, 8, 2},   {64, 16, 2}, {128, 32, 2},
                                               {256, 64, 2}, {512, 64, 4}, {1024, 64, 8}};
             for (auto& t : tbl)
                 if (t.nd == nd) { L = t.L; K = t.K; }
         }
-        // walkers per group: amortise the per-walker scalar work (Philox, two logs) over the
-        // wave while keeping >= ~2048 waves (two per SIMD) in the grid
+        // walkers per group (ITER): two amortise the per-walker scalar work (Philox, two logs) over
+        // the wave; more only while the grid keeps >= 4096 waves (large ensembles)
         iter = 1;
         if (L > 0) {
             const int64_t waves1 = n_active * L / 64;
-            while (iter * 2 <= L && iter * 2 * K <= 16 && waves1 / (iter * 2) >= 2048 && iter < 16) iter *= 2;
+            if (2 <= L && 2 * K <= 16 && waves1 / 2 >= 1024) iter = 2;
+            while (iter >= 2 && iter * 2 <= L && iter * 2 * K <= 16 && waves1 / (iter * 2) >= 4096 && iter < 16) iter *= 2;
         }
     }
     lookup(c.density, L, K, iter, &vec, &gen, &lp);

@@ -48,10 +48,19 @@ struct DrawConsts {
     double   nm1;      // N - 1
 };
 
-__device__ __forceinline__ Draw draw_step(const DrawConsts& dc, uint64_t step, uint64_t walker)
+// Split in two so a kernel can issue the partner-row loads (which need only the partner index)
+// before it spends ~100 instructions on the two logarithms.
+__device__ __forceinline__ U4 draw_bits(const DrawConsts& dc, uint64_t step, uint64_t walker)
 {
-    const U4 w = philox4x32_10((uint32_t)step, (uint32_t)(step >> 32),
-                               (uint32_t)walker, (uint32_t)(walker >> 32), dc.seed_lo, dc.seed_hi);
+    return philox4x32_10((uint32_t)step, (uint32_t)(step >> 32),
+                         (uint32_t)walker, (uint32_t)(walker >> 32), dc.seed_lo, dc.seed_hi);
+}
+__device__ __forceinline__ uint32_t draw_partner(const DrawConsts& dc, const U4& w)
+{
+    return __umulhi(w.x, dc.nhalf);
+}
+__device__ __forceinline__ Draw draw_finish(const DrawConsts& dc, const U4& w)
+{
     Draw d;
     d.partner = __umulhi(w.x, dc.nhalf);
     const double uz = ((double)w.y + 0.5) * 0x1.0p-32;
@@ -62,6 +71,10 @@ __device__ __forceinline__ Draw draw_step(const DrawConsts& dc, uint64_t step, u
     d.t1 = dc.nm1 * log(d.z);
     d.lu = log(ua);
     return d;
+}
+__device__ __forceinline__ Draw draw_step(const DrawConsts& dc, uint64_t step, uint64_t walker)
+{
+    return draw_finish(dc, draw_bits(dc, step, walker));
 }
 
 // (N-1) log z + p1 - p0 >= log u, evaluated left to right like the reference (:260).
@@ -107,6 +120,18 @@ __device__ __forceinline__ double group_sum(double v)
     if constexpr (L >= 16) v += dpp_f64<0x140>(v);   // row_mirror           : other 8-lane half
     if constexpr (L >= 32) v += __shfl_xor(v, 16, 64);
     if constexpr (L >= 64) v += __shfl_xor(v, 32, 64);
+    return v;
+}
+// Sum of the values held by lanes {j, j+L, j+2L, ...} (one per group); valid in group 0.
+template <int L>
+__device__ __forceinline__ double wave_fold(double v)
+{
+    if constexpr (L <= 1)  v += dpp_f64<0xB1>(v);
+    if constexpr (L <= 2)  v += dpp_f64<0x4E>(v);
+    if constexpr (L <= 4)  v += dpp_f64<0x124>(v);   // row_ror:4
+    if constexpr (L <= 8)  v += dpp_f64<0x128>(v);   // row_ror:8
+    if constexpr (L <= 16) v += __shfl_xor(v, 16, 64);
+    if constexpr (L <= 32) v += __shfl_xor(v, 32, 64);
     return v;
 }
 template <int L>

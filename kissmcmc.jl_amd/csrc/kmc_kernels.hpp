@@ -80,6 +80,19 @@ __device__ __forceinline__ SchedEntry schedule_of(const HalfStepArgs& a)
     return a.sched_table ? a.sched_table[a.sched_index] : a.sched_inline;
 }
 
+// Row store.  KMC_STORE_SC1: write-through (sc1) so the kernel leaves no dirty lines for the
+// end-of-kernel write-back (the next half-step's readers sit on other XCDs anyway).
+__device__ __forceinline__ void store_row16(double2* p, const double2& v)
+{
+#ifdef KMC_STORE_SC1
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    const v2d t = {v.x, v.y};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(t) : "memory");
+#else
+    *p = v;
+#endif
+}
+
 __device__ __forceinline__ double2 sel2(bool c, const double2& a, const double2& b)
 {
     return make_double2(c ? a.x : b.x, c ? a.y : b.y);
@@ -123,24 +136,38 @@ __global__ __launch_bounds__(256) void half_step_vec(const HalfStepArgs a)
     const bool count  = (sch.flags & kCount) != 0;
     const bool sample = (sch.flags & kSample) != 0;
     const uint64_t step = 2ull * (uint64_t)sch.gen + (uint64_t)a.half;
+    // moment accumulators of this wave (group 0 lanes): fetched now, used at the very end
+    const bool do_mom = sample && a.msum != nullptr;
+    double2 accs[K], accq[K];
+    if (do_mom && g == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int64_t idx = (int64_t)k * a.macc_stride + tid;
+            accs[k] = reinterpret_cast<const double2*>(a.msum)[idx];
+            accq[k] = reinterpret_cast<const double2*>(a.msumsq)[idx];
+        }
+    }
     const int  iA     = w0 + (j < ITER ? j : 0) * G + g;
     const bool validA = (j < ITER) && (iA < nact);
     const int64_t gwA = act0 + (iA < nact ? iA : nact - 1);
     const double   p0 = a.logp[gwA];
     const uint32_t na = a.naccept[gwA];
-    const Draw dr = draw_step(a.dc, step, (uint64_t)gwA);               // :250, :252
+    const U4 bits = draw_bits(a.dc, step, (uint64_t)gwA);
+    const uint32_t partnerA = draw_partner(a.dc, bits);                 // :250
 
-    // ---- scalar -> row: partner index and z of slot it*G+g live in lane gbase+it -------------
-    double zB[ITER];
+    // ---- scalar -> row: the partner index of slot it*G+g lives in lane gbase+it; get the
+    //      partner-row loads in flight before the logarithms --------------------------------
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
-        const int src = (gbase + it) * 4;
-        const uint32_t partner = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)dr.partner);
-        zB[it] = bperm_f64(src, dr.z);
+        const uint32_t partner = (uint32_t)__builtin_amdgcn_ds_bpermute((gbase + it) * 4, (int)partnerA);
         const double2* oth = reinterpret_cast<const double2*>(a.pos + (oth0 + partner) * ndim);
 #pragma unroll
         for (int k = 0; k < K; ++k) xo[it][k] = oth[k * L + j];
     }
+    const Draw dr = draw_finish(a.dc, bits);                            // :252, log z, log u
+    double zB[ITER];
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) zB[it] = bperm_f64((gbase + it) * 4, dr.z);
 
     // ---- stretch move + log-pdf; xo becomes the proposal ------------------------------------
     double myp1 = 0.0;
@@ -176,7 +203,7 @@ __global__ __launch_bounds__(256) void half_step_vec(const HalfStepArgs a)
         if (accB) {                                                     // :261
             double2* own = reinterpret_cast<double2*>(a.pos + (act0 + w0 + it * G + g) * ndim);
 #pragma unroll
-            for (int k = 0; k < K; ++k) own[k * L + j] = xo[it][k];
+            for (int k = 0; k < K; ++k) store_row16(&own[k * L + j], xo[it][k]);
         }
         if (sample) {                                                   // :268-269
             double2* dst = nullptr;
@@ -193,16 +220,25 @@ __global__ __launch_bounds__(256) void half_step_vec(const HalfStepArgs a)
             }
         }
     }
-    if (sample && a.msum != nullptr) {
-        double2* s = reinterpret_cast<double2*>(a.msum);
-        double2* q = reinterpret_cast<double2*>(a.msumsq);
+    if (do_mom) {
+        // fold the G groups of the wave (same dimensions, different walkers) into group 0 first:
+        // 1/G of the accumulator traffic for a few cross-lane moves
+        if constexpr (L < 64) {
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const int64_t idx = (int64_t)k * a.macc_stride + tid;
-            double2 sv = s[idx], qv = q[idx];
-            sv.x += ms[k].x; sv.y += ms[k].y;
-            qv.x += mq[k].x; qv.y += mq[k].y;
-            s[idx] = sv; q[idx] = qv;
+            for (int k = 0; k < K; ++k) {
+                ms[k].x = wave_fold<L>(ms[k].x); ms[k].y = wave_fold<L>(ms[k].y);
+                mq[k].x = wave_fold<L>(mq[k].x); mq[k].y = wave_fold<L>(mq[k].y);
+            }
+        }
+        if (g == 0) {
+            double2* s = reinterpret_cast<double2*>(a.msum);
+            double2* q = reinterpret_cast<double2*>(a.msumsq);
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const int64_t idx = (int64_t)k * a.macc_stride + tid;
+                s[idx] = make_double2(accs[k].x + ms[k].x, accs[k].y + ms[k].y);
+                q[idx] = make_double2(accq[k].x + mq[k].x, accq[k].y + mq[k].y);
+            }
         }
     }
 }

@@ -1,0 +1,151 @@
+# KissMCMCHIP.jl -- thin `ccall` shim over libkissmcmc_hip.so (C ABI: include/kissmcmc_hip.h).
+#
+# Keeps the call surface of KissMCMC.jl's emcee path (reference src/samplers.jl:188-216, :311-349,
+# :372-428): `emcee(pdf, theta0s; niter, nburnin, nthin, a_scale, ...)`, `make_theta0s`,
+# `squash_walkers`.  `pdf` must be one of the menu densities below (the device cannot run an
+# arbitrary Julia closure); any other callable throws -- there is no CPU fallback here, use
+# KissMCMC.emcee for that.
+#
+# NOT EXECUTED in the build environment (no julia binary there).  Every call it makes is mirrored
+# 1:1 by the Python ctypes host (kissmcmc.jl_amd/_lib.py, api.py), which is what the tests drive.
+module KissMCMCHIP
+
+export emcee, make_theta0s, squash_walkers, GaussianIso, Exponential, Rosenbrock, LogNormal, MvNormal2
+
+using Statistics: mean, median, std
+using LinearAlgebra: inv
+
+const LIB = get(ENV, "KMC_LIB_PATH", joinpath(@__DIR__, "..", "libkissmcmc_hip.so"))
+
+# ---- menu densities: callable on the host with the same formula the kernels use ----------------
+abstract type DeviceLogPdf end
+struct GaussianIso <: DeviceLogPdf; mu::Float64; sigma::Float64; end
+GaussianIso() = GaussianIso(0.0, 1.0)
+struct Exponential <: DeviceLogPdf; rate::Float64; end
+Exponential() = Exponential(1.0)
+struct Rosenbrock <: DeviceLogPdf; a::Float64; b::Float64; scale::Float64; end
+Rosenbrock() = Rosenbrock(1.0, 100.0, 20.0)
+struct LogNormal <: DeviceLogPdf; mu::Float64; sigma::Float64; end
+struct MvNormal2 <: DeviceLogPdf; mean::Vector{Float64}; prec::Matrix{Float64}; end
+MvNormal2(mean, cov::AbstractMatrix) = MvNormal2(collect(Float64, mean), inv(Matrix{Float64}(cov)))
+
+(d::GaussianIso)(x) = -0.5 * sum(((x .- d.mu) ./ d.sigma) .^ 2)
+(d::Exponential)(x) = any(x .< 0) ? -Inf : -d.rate * sum(x)          # README.md:15
+(d::Rosenbrock)(x) = -sum(d.b .* (x[2:end] .- x[1:end-1] .^ 2) .^ 2 .+ (d.a .- x[1:end-1]) .^ 2) / d.scale  # test/runtests.jl:68
+(d::LogNormal)(x) = any(x .<= 0) ? -Inf : sum(-log.(x) .- 0.5 .* ((log.(x) .- d.mu) ./ d.sigma) .^ 2)
+(d::MvNormal2)(x) = -0.5 * ((x .- d.mean)' * d.prec * (x .- d.mean))
+
+density_id(::GaussianIso) = Cint(0); params(d::GaussianIso) = [d.mu, d.sigma]
+density_id(::Exponential) = Cint(1); params(d::Exponential) = [d.rate]
+density_id(::Rosenbrock) = Cint(2);  params(d::Rosenbrock) = [d.a, d.b, d.scale]
+density_id(::LogNormal) = Cint(3);   params(d::LogNormal) = [d.mu, d.sigma]
+density_id(::MvNormal2) = Cint(4);   params(d::MvNormal2) = [d.mean[1], d.mean[2], d.prec[1,1], 0.5 * (d.prec[1,2] + d.prec[2,1]), d.prec[2,2]]
+
+# ---- C structs (layout checked against the header by tests/test_c_abi.py on the Python mirror) ---
+struct KmcConfig
+    dtype::Int32; density::Int32
+    params::NTuple{8,Float64}
+    nwalkers::Int64; ndim::Int64; ngenerations::Int64; nburnin::Int64; nthin::Int64
+    a_scale::Float64; seed::UInt64
+    flags::UInt32; device::Int32; shard_rank::Int32; shard_count::Int32
+end
+
+mutable struct KmcOutputs
+    chain::Ptr{Float64}; chain_logp::Ptr{Float64}; accept_ratio::Ptr{Float64}; naccept::Ptr{Int64}
+    final_pos::Ptr{Float64}; final_logp::Ptr{Float64}; sum::Ptr{Float64}; sumsq::Ptr{Float64}
+    nmoment::Int64; nsamples::Int64; device_ms::Float64
+end
+
+last_error() = unsafe_string(ccall((:kmc_last_error, LIB), Cstring, ()))
+
+"""
+    emcee(pdf::DeviceLogPdf, theta0s; niter=10^5, nburnin=niter÷2, nthin=1, a_scale=2.0,
+          use_progress_meter=true, hasblob=false, seed=rand(UInt64), device=0)
+
+Same meaning as KissMCMC.emcee (src/samplers.jl:188-197); returns
+`(thetas, accept_ratio, logdensities, blobs)` with `thetas[w][k]` (src/samplers.jl:292).
+"""
+function emcee(pdf::DeviceLogPdf, theta0s; niter=10^5, nburnin=niter ÷ 2, nthin=1, a_scale=2.0,
+               use_progress_meter=true, hasblob=false, seed=rand(UInt64), device=0)
+    hasblob && error("hasblob=true is not supported by the HIP emcee path")
+    nwalkers = length(theta0s)
+    scalar = theta0s[1] isa Number
+    ndim = length(theta0s[1])
+    @assert a_scale > 1                                                                  # :200
+    @assert iseven(nwalkers) "Use an even number of walkers."                           # :202
+    niter_walker = niter ÷ nwalkers                                                      # :203
+    nburnin_walker = nburnin ÷ nwalkers                                                  # :204
+    @assert nwalkers >= ndim + 2 "Use more walkers: at least DOF+2, but better many more."  # :205
+    nsamples = max(0, (niter_walker - nburnin_walker) ÷ nthin)                           # :234
+
+    theta = Matrix{Float64}(undef, ndim, nwalkers)        # column-major [dim, walker] == C row-major [walker][dim]
+    for w in 1:nwalkers, d in 1:ndim
+        theta[d, w] = scalar ? theta0s[w] : theta0s[w][d]                                # :198 deep copy
+    end
+    p = params(pdf); p8 = ntuple(i -> i <= length(p) ? p[i] : 0.0, 8)
+    cfg = Ref(KmcConfig(0, density_id(pdf), p8, nwalkers, ndim, niter_walker, nburnin_walker, nthin,
+                        a_scale, UInt64(seed), 0x3, Int32(device), 0, 1))       # flags: STORE_CHAIN | STORE_LOGP
+    chain = Array{Float64}(undef, ndim, nwalkers, nsamples)
+    clogp = Array{Float64}(undef, nwalkers, nsamples)
+    acc = Vector{Float64}(undef, nwalkers)
+    out = KmcOutputs(pointer(chain), pointer(clogp), pointer(acc), C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, 0, 0, 0.0)
+    st = GC.@preserve theta chain clogp acc ccall((:kmc_emcee_run, LIB), Cint,
+                                                   (Ref{KmcConfig}, Ptr{Float64}, Ref{KmcOutputs}), cfg, theta, out)
+    st == 0 || error("kmc_emcee_run failed ($st): $(last_error())")
+    thetas = scalar ? [[chain[1, w, k] for k in 1:nsamples] for w in 1:nwalkers] :
+                      [[chain[:, w, k] for k in 1:nsamples] for w in 1:nwalkers]
+    logdensities = [[clogp[w, k] for k in 1:nsamples] for w in 1:nwalkers]
+    return thetas, acc, logdensities, nothing                                            # :292
+end
+emcee(pdf, theta0s; kw...) = error("emcee on the device needs a menu log-density (GaussianIso, Exponential, Rosenbrock, LogNormal, MvNormal2); use KissMCMC.emcee for arbitrary closures")
+
+"src/samplers.jl:311-349 (host side, runs once)."
+function make_theta0s(theta0::T, ball_radius, pdf, nwalkers; ball_radius_halfing_steps=7, ntries=100, hasblob=false) where T
+    hasblob && error("hasblob=true is not supported by the HIP emcee path")
+    npara = length(theta0)
+    if ball_radius isa Number && !(T <: Number)
+        ball_radius = ones(npara) * ball_radius
+    end
+    @assert length(ball_radius) == npara
+    theta0s = T[]
+    for i = 1:nwalkers
+        for k = 1:ball_radius_halfing_steps
+            ball_radius *= 1 / 2^(k - 1)
+            for _ = 1:ntries
+                tmp = npara == 1 ? theta0 .+ randn() .* ball_radius : theta0 .+ randn(npara) .* ball_radius
+                if pdf(tmp) > -Inf
+                    push!(theta0s, tmp)
+                    break
+                end
+            end
+            length(theta0s) == i && break
+        end
+        length(theta0s) == i || error("Could not find suitable initial theta.  PDF is zero in too many places inside ball.")
+    end
+    return theta0s
+end
+
+"src/samplers.jl:372-428 (host post-processing)."
+function squash_walkers(thetas, accept_ratio, logdensities=nothing, blobs=nothing;
+                        drop_low_accept_ratio=false, drop_fact=2, verbose=true, order=false)
+    blobs === nothing || error("blobs are not produced by the HIP emcee path")
+    nwalkers = length(accept_ratio)
+    walkers2keep = if drop_low_accept_ratio
+        ma, sa = median(accept_ratio), std(accept_ratio)
+        verbose && println("Median accept ratio is $ma, standard deviation is $sa\n")
+        [nc for nc in 1:nwalkers if !(accept_ratio[nc] <= ma - drop_fact * sa)]
+    else
+        collect(1:nwalkers)
+    end
+    t = reduce(vcat, thetas[walkers2keep])
+    l = logdensities === nothing ? nothing : reduce(vcat, logdensities[walkers2keep])
+    if order
+        ns = length(thetas[1])
+        perm = sortperm(repeat(1:ns, length(walkers2keep)))
+        t = t[perm]
+        l === nothing || (l = l[perm])
+    end
+    return t, mean(accept_ratio[walkers2keep]), l, nothing
+end
+
+end # module

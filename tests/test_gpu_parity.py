@@ -91,7 +91,7 @@ def test_matches_oracle(kmc, oracle, name, nw, nd, G, nburn, nthin):
     _compare(ref, got)
 
 
-@pytest.mark.parametrize("plan", ["generic", "16,1,1", "16,1,2", "16,1,4", "16,1,8", "16,1,16", "8,2,1", "8,2,4", "8,2,8"])
+@pytest.mark.parametrize("plan", ["generic", "16,1,1", "16,1,2", "16,1,4", "16,1,8", "16,1,16", "8,2,1", "8,2,4", "8,2,8", "4,4,1", "4,4,4", "4,2,2"])
 def test_every_geometry_gives_the_same_chain(kmc, oracle, plan, monkeypatch):
     """The result is a pure function of (seed, inputs): launch geometry must not matter."""
     ref, got = _run_both(kmc, oracle, "gauss", 512, 32, 70, 20, 1, seed=99, plan=plan, monkeypatch=monkeypatch)
