@@ -85,11 +85,18 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP emcee path has no CPU fallback")
+    # one rank per GPU; (testing only: KMC_BENCH_BACKEND=gloo lets several ranks share one GPU,
+    # which RCCL refuses -- the peer-to-peer exchange itself is the same code)
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("KMC_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     nw = NWALKERS_PER_GPU * world
     G = args.steps * GENS_PER_STEP
@@ -117,33 +124,72 @@ def main():
         acc = float(s.accept_ratio().mean())
         s.close()
     else:
-        from kissmcmc_jl_amd.distributed import HipShardExecutor, ShardedEmcee
-        ex = HipShardExecutor(pdf, nw, NDIM, G, nburn, 1, 2.0, SEED, rank=rank, world=world, device=local_rank)
-        ex.set_positions(th)
-        drv = ShardedEmcee(ex, nw, NDIM)
-        drv.run(min(args.warmup * GENS_PER_STEP, 200))   # warm-up: kernels + RCCL rings
-        ex.sync()
-        ex.set_positions(th)
-        drv.generation = 0
-        dist.barrier()
-        torch.cuda.synchronize()
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        t0 = time.perf_counter()
-        ev0.record()                             # the executor launches on torch's current stream
-        drv.run(G)
-        ev1.record()
-        ex.sync()
-        torch.cuda.synchronize()
-        dist.barrier()
-        elapsed = time.perf_counter() - t0
-        event_ms = ev0.elapsed_time(ev1)
-        launches = 2 * G
+        # Walker-sharded, one rank per GPU.  Preferred exchange: peer-to-peer partner reads over
+        # xGMI (KMC_P2P: only the rows that are drawn cross the fabric, the whole run is enqueued
+        # like the single-GPU case).  If the IPC set-up fails on any rank, every rank falls back to
+        # the RCCL all-gather of the updated half after each half-step.
+        from kissmcmc_jl_amd.distributed import HipShardExecutor, P2PEmcee, ShardedEmcee
+        mode = os.environ.get("KMC_BENCH_EXCHANGE", "p2p")
+        drv = None
+        ok = torch.ones(1, device="cuda")
+        if mode == "p2p":
+            try:
+                drv = P2PEmcee(pdf, nw, NDIM, G, nburn, 1, 2.0, SEED, device=local_rank)
+            except Exception as e:  # noqa: BLE001
+                print(f"[rank {rank}] p2p set-up failed ({e}); falling back to all-gather", file=sys.stderr)
+                ok.zero_()
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if ok.item() == 0:
+                if drv is not None:
+                    drv.sampler.close()
+                drv, mode = None, "allgather"
+        if mode == "p2p":
+            drv.set_positions(th)
+            drv.run(args.warmup * GENS_PER_STEP)
+            drv.sync()
+            drv.set_positions(th)                # barriers inside; restart the job
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            drv.run(G)
+            drv.sync()
+            torch.cuda.synchronize()
+            dist.barrier()
+            elapsed = time.perf_counter() - t0
+            event_ms = drv.sampler.last_run_ms()
+            launches = drv.sampler.launch_count
+            msum, msq, nmom = drv.moments()
+            acc = float(drv.naccept().sum() / nw / max(1, G - nburn))
+            drv.close()
+            parallelism = f"walker-sharded x{world}, peer-to-peer partner reads over xGMI (IPC), progress-flag ordering"
+        else:
+            ex = HipShardExecutor(pdf, nw, NDIM, G, nburn, 1, 2.0, SEED, rank=rank, world=world, device=local_rank)
+            ex.set_positions(th)
+            sdrv = ShardedEmcee(ex, nw, NDIM)
+            sdrv.run(min(args.warmup * GENS_PER_STEP, 100))   # warm-up: kernels + RCCL rings
+            ex.sync()
+            ex.set_positions(th)
+            sdrv.generation = 0
+            dist.barrier()
+            torch.cuda.synchronize()
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0 = time.perf_counter()
+            ev0.record()                         # the executor launches on torch's current stream
+            sdrv.run(G)
+            ev1.record()
+            ex.sync()
+            torch.cuda.synchronize()
+            dist.barrier()
+            elapsed = time.perf_counter() - t0
+            event_ms = ev0.elapsed_time(ev1)
+            launches = 2 * G
+            msum, msq, nmom = sdrv.moments()
+            acc = float(sdrv.naccept().sum() / nw / max(1, G - nburn))
+            ex.close()
+            parallelism = f"walker-sharded x{world}, RCCL all-gather of the updated half per half-step"
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        msum, msq, nmom = drv.moments()
-        acc = float(drv.naccept().sum() / nw / max(1, G - nburn))
-        ex.close()
 
     if rank == 0:
         steps_total = float(nw) * G
@@ -170,7 +216,7 @@ def main():
             "config": {"workload": f"C2: emcee stretch move, {NWALKERS_PER_GPU} walkers/GPU x {NDIM}-dim isotropic Gaussian, "
                                    f"{G} generations (burn-in {nburn}), a=2, streaming moments on, chain off",
                        "nwalkers_total": nw, "ndim": NDIM, "generations": G, "gens_per_step": GENS_PER_STEP,
-                       "parallelism": "single GPU" if world == 1 else f"walker-sharded x{world}, RCCL all-gather per half-step"},
+                       "parallelism": "single GPU" if world == 1 else parallelism},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "half_step_vec<GaussianIso>", "launches": launches, "avg_launch_us": launch_us,

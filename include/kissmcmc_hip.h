@@ -69,8 +69,14 @@ enum {
     KMC_STORE_CHAIN = 1u << 0, /* keep thetas      (src/samplers.jl:269) on the device: [nsamples][nwalkers][ndim] */
     KMC_STORE_LOGP  = 1u << 1, /* keep logdensities (src/samplers.jl:271): [nsamples][nwalkers] */
     KMC_MOMENTS     = 1u << 2, /* streaming sum x, sum x^2 per dimension over the samples that would be stored */
-    KMC_NO_GRAPH    = 1u << 3  /* launch every half-step eagerly instead of replaying a hipGraph */
+    KMC_NO_GRAPH    = 1u << 3, /* launch every half-step eagerly instead of replaying a hipGraph */
+    KMC_P2P         = 1u << 4  /* walker sharding with peer-to-peer partner reads over xGMI: the sampler holds only
+                                  its shard ([2][nwalkers/2/shard_count][ndim], halves back to back), reads partner
+                                  rows straight from the owning rank's HBM and synchronises half-steps with
+                                  per-rank progress flags; needs kmc_sampler_p2p_export/_connect (<= 8 shards) */
 };
+
+#define KMC_P2P_HANDLE_BYTES 128
 
 typedef struct kmc_config {
     int32_t  dtype;         /* KMC_F64 */
@@ -132,6 +138,14 @@ kmc_status  kmc_sampler_set_stream(kmc_sampler* s, void* hip_stream);
  * the ensemble instead of the sampler's own allocation, so a collective library can gather
  * into it in place.  The caller keeps it alive; call before kmc_sampler_set_positions. */
 kmc_status  kmc_sampler_bind_positions(kmc_sampler* s, void* pos_dev);
+/* KMC_P2P: export this sampler's IPC handles (KMC_P2P_HANDLE_BYTES), to be all-gathered by the
+ * caller (one process per GPU), then connect with the blobs of all shard_count ranks in rank order.
+ * With KMC_P2P, kmc_sampler_set_positions still takes the GLOBAL ensemble (each rank keeps its
+ * slices; barrier across ranks before the first run), while get_positions/get_logp/get_naccept/
+ * get_accept_ratio return this shard's nwalkers/shard_count rows (first-half slice, then
+ * second-half slice). */
+kmc_status  kmc_sampler_p2p_export(kmc_sampler* s, void* handle_out);
+kmc_status  kmc_sampler_p2p_connect(kmc_sampler* s, const void* handles /* [shard_count][KMC_P2P_HANDLE_BYTES] */);
 /* Upload the ensemble (host, [nwalkers][ndim], global order), evaluate the initial log-pdfs on
  * the device (src/samplers.jl:209-210), reset generation/counters.  Fails with
  * KMC_ERR_NONFINITE_LOGP if any is not finite. */

@@ -18,13 +18,14 @@ OK, ERR_A_SCALE, ERR_ODD_WALKERS, ERR_TOO_FEW_WALKERS, ERR_BAD_ARG, ERR_NONFINIT
 # kmc_density
 GAUSSIAN_ISO, EXPONENTIAL, ROSENBROCK, LOGNORMAL, MVNORMAL2 = range(5)
 F64 = 0
-STORE_CHAIN, STORE_LOGP, MOMENTS, NO_GRAPH = 1, 2, 4, 8
+STORE_CHAIN, STORE_LOGP, MOMENTS, NO_GRAPH, P2P = 1, 2, 4, 8, 16
+P2P_HANDLE_BYTES = 128
 
 # Every symbol include/kissmcmc_hip.h declares (tests check they are all exported).
 SYMBOLS = [
     "kmc_version", "kmc_device_count", "kmc_last_error", "kmc_status_string", "kmc_validate",
     "kmc_g_pdf", "kmc_cdf_g_inv", "kmc_emcee_run", "kmc_sampler_create", "kmc_sampler_destroy",
-    "kmc_sampler_set_stream", "kmc_sampler_bind_positions", "kmc_sampler_set_positions", "kmc_sampler_run", "kmc_sampler_half_step",
+    "kmc_sampler_set_stream", "kmc_sampler_bind_positions", "kmc_sampler_p2p_export", "kmc_sampler_p2p_connect", "kmc_sampler_set_positions", "kmc_sampler_run", "kmc_sampler_half_step",
     "kmc_sampler_sync", "kmc_sampler_last_run_ms", "kmc_sampler_generation", "kmc_sampler_nsamples",
     "kmc_sampler_launch_count", "kmc_sampler_device_ptr", "kmc_sampler_get_positions",
     "kmc_sampler_get_logp", "kmc_sampler_get_naccept", "kmc_sampler_get_accept_ratio",
@@ -82,6 +83,14 @@ def lib() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch wheels bundle their own HIP/HSA runtime.  If this library (linked against
+    # /opt/rocm) initialises HIP before torch's copies are loaded, torch later finds no GPU; loading
+    # torch's libraries first keeps both usable in one process.  Pure C-ABI users are unaffected.
+    if os.environ.get("KMC_NO_TORCH_PRELOAD") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -m kissmcmc_jl_amd.build` "
@@ -107,6 +116,8 @@ def lib() -> C.CDLL:
     L.kmc_sampler_destroy.argtypes = [vp]
     L.kmc_sampler_set_stream.argtypes = [vp, vp]
     L.kmc_sampler_bind_positions.argtypes = [vp, vp]
+    L.kmc_sampler_p2p_export.argtypes = [vp, vp]
+    L.kmc_sampler_p2p_connect.argtypes = [vp, vp]
     L.kmc_sampler_set_positions.argtypes = [vp, dp]
     L.kmc_sampler_run.argtypes = [vp, C.c_int64]
     L.kmc_sampler_half_step.argtypes = [vp, C.c_int]

@@ -58,34 +58,34 @@ struct Plan {
 };
 
 // ---- kernel table ------------------------------------------------------------------------
-template <class D, int L, int K, int ITER>
+template <class D, int L, int K, int ITER, bool P2P>
 HalfStepFn vec_one()
 {
     // a group's ITER scalar lanes must fit in its L lanes; keep the register tile (ITER*K chunks) bounded
-    if constexpr (ITER <= L && ITER * K <= 16) return half_step_vec<D, L, K, ITER>;
+    if constexpr (ITER <= L && ITER * K <= 16) return half_step_vec<D, L, K, ITER, P2P>;
     else return nullptr;
 }
 
-template <class D, int L, int K>
+template <class D, int L, int K, bool P2P>
 HalfStepFn vec_iter(int iter)
 {
     switch (iter) {
-    case 1: return vec_one<D, L, K, 1>();
-    case 2: return vec_one<D, L, K, 2>();
-    case 4: return vec_one<D, L, K, 4>();
-    case 8: return vec_one<D, L, K, 8>();
-    case 16: return vec_one<D, L, K, 16>();
+    case 1: return vec_one<D, L, K, 1, P2P>();
+    case 2: return vec_one<D, L, K, 2, P2P>();
+    case 4: return vec_one<D, L, K, 4, P2P>();
+    case 8: return vec_one<D, L, K, 8, P2P>();
+    case 16: return vec_one<D, L, K, 16, P2P>();
     default: return nullptr;
     }
 }
 
 template <class D>
-HalfStepFn vec_lookup(int L, int K, int iter)
+HalfStepFn vec_lookup(int L, int K, int iter, bool p2p)
 {
     if constexpr (!D::kHasFrag) {
         return nullptr;
     } else {
-#define KMC_LK(l, k) if (L == l && K == k) return vec_iter<D, l, k>(iter);
+#define KMC_LK(l, k) if (L == l && K == k) return p2p ? vec_iter<D, l, k, true>(iter) : vec_iter<D, l, k, false>(iter);
         KMC_LK(4, 1) KMC_LK(8, 1) KMC_LK(16, 1) KMC_LK(32, 1) KMC_LK(64, 1)
         KMC_LK(4, 2) KMC_LK(8, 2) KMC_LK(16, 2) KMC_LK(32, 2) KMC_LK(64, 2)
         KMC_LK(4, 4) KMC_LK(8, 4) KMC_LK(16, 4) KMC_LK(32, 4) KMC_LK(64, 4)
@@ -96,21 +96,21 @@ HalfStepFn vec_lookup(int L, int K, int iter)
 }
 
 template <class D>
-void density_fns(int L, int K, int iter, HalfStepFn* vec, HalfStepFn* gen, LogpdfFn* lp)
+void density_fns(int L, int K, int iter, bool p2p, HalfStepFn* vec, HalfStepFn* gen, LogpdfFn* lp)
 {
-    *vec = vec_lookup<D>(L, K, iter);
-    *gen = half_step_generic<D>;
+    *vec = vec_lookup<D>(L, K, iter, p2p);
+    *gen = p2p ? half_step_generic<D, true> : half_step_generic<D, false>;
     *lp = logpdf_rows<D>;
 }
 
-bool lookup(int density, int L, int K, int iter, HalfStepFn* vec, HalfStepFn* gen, LogpdfFn* lp)
+bool lookup(int density, int L, int K, int iter, bool p2p, HalfStepFn* vec, HalfStepFn* gen, LogpdfFn* lp)
 {
     switch (density) {
-    case KMC_GAUSSIAN_ISO: density_fns<GaussianIso>(L, K, iter, vec, gen, lp); return true;
-    case KMC_EXPONENTIAL: density_fns<Exponential>(L, K, iter, vec, gen, lp); return true;
-    case KMC_ROSENBROCK: density_fns<Rosenbrock>(L, K, iter, vec, gen, lp); return true;
-    case KMC_LOGNORMAL: density_fns<LogNormal>(L, K, iter, vec, gen, lp); return true;
-    case KMC_MVNORMAL2: density_fns<MvNormal2>(L, K, iter, vec, gen, lp); return true;
+    case KMC_GAUSSIAN_ISO: density_fns<GaussianIso>(L, K, iter, p2p, vec, gen, lp); return true;
+    case KMC_EXPONENTIAL: density_fns<Exponential>(L, K, iter, p2p, vec, gen, lp); return true;
+    case KMC_ROSENBROCK: density_fns<Rosenbrock>(L, K, iter, p2p, vec, gen, lp); return true;
+    case KMC_LOGNORMAL: density_fns<LogNormal>(L, K, iter, p2p, vec, gen, lp); return true;
+    case KMC_MVNORMAL2: density_fns<MvNormal2>(L, K, iter, p2p, vec, gen, lp); return true;
     default: return false;
     }
 }
@@ -145,7 +145,7 @@ Plan make_plan(const kmc_config& c, int64_t n_active)
             while (iter >= 2 && iter * 2 <= L && iter * 2 * K <= 16 && waves1 / (iter * 2) >= 4096 && iter < 16) iter *= 2;
         }
     }
-    lookup(c.density, L, K, iter, &vec, &gen, &lp);
+    lookup(c.density, L, K, iter, (c.flags & KMC_P2P) != 0, &vec, &gen, &lp);
     if (!force_generic && L > 0 && 2 * L * K == c.ndim && vec != nullptr) {
         p.fn = vec; p.vec = true; p.L = L; p.K = K; p.ITER = iter;
     } else {
@@ -213,6 +213,14 @@ struct kmc_sampler {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool have_run_events = false;
     bool positions_set = false;
+    // peer-to-peer sharding (KMC_P2P)
+    bool p2p = false;
+    bool connected = false;
+    int64_t nrows = 0;                                   // rows held by this sampler (nwalkers, or nlocal for P2P)
+    unsigned long long* d_flags = nullptr;               // fine-grained progress flags [shard_count]
+    unsigned long long* d_err = nullptr;
+    double* peer_pos[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    unsigned long long* peer_flags[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 namespace {
@@ -228,8 +236,14 @@ HalfStepArgs make_args(const kmc_sampler* s, int half, bool graph_mode, int64_t 
     a.sched_table = graph_mode ? s->d_sched : nullptr;
     a.sched_index = graph_mode ? (int32_t)gen_offset : 0;
     a.sched_inline = make_sched(gen_offset, s->cfg.nburnin, s->cfg.nthin, s->nsamples);
-    a.nhalf = s->h;
-    a.active_begin = s->active_begin;
+    a.gw0 = (int64_t)half * s->h + s->active_begin;
+    a.own_row0 = s->p2p ? (int64_t)half * s->h_loc : a.gw0;
+    a.oth_row0 = s->p2p ? (int64_t)(1 - half) * s->h_loc : (int64_t)(1 - half) * s->h;
+    a.hloc = (uint32_t)s->h_loc;
+    a.nranks = s->cfg.shard_count;
+    for (int r = 0; r < 8; ++r) a.peer_pos[r] = s->peer_pos[r];
+    a.flags = s->d_flags;
+    a.err = s->d_err;
     a.n_active = (int32_t)s->h_loc;
     a.half = half;
     a.ndim = (int32_t)s->cfg.ndim;
@@ -255,6 +269,19 @@ kmc_status launch_half(kmc_sampler* s, int half, bool graph_mode, int64_t gen_of
     const HalfStepArgs a = make_args(s, half, graph_mode, gen_offset);
     hipLaunchKernelGGL(s->plan.fn, dim3(s->grid), dim3(256), 0, s->stream, a);
     HIP_TRY(hipGetLastError());
+    if (s->p2p && s->cfg.shard_count > 1) {
+        // the kernel boundary puts this half-step's rows in memory; then publish the progress
+        SignalArgs sg{};
+        for (int r = 0; r < 8; ++r) sg.peer_flags[r] = s->peer_flags[r];
+        sg.nranks = s->cfg.shard_count;
+        sg.me = s->cfg.shard_rank;
+        sg.sched_table = a.sched_table;
+        sg.sched_inline = a.sched_inline;
+        sg.sched_index = a.sched_index;
+        sg.half = half;
+        hipLaunchKernelGGL(p2p_signal, dim3(1), dim3(64), 0, s->stream, sg);
+        HIP_TRY(hipGetLastError());
+    }
     return KMC_OK;
 }
 
@@ -350,6 +377,7 @@ KMC_EXPORT kmc_status kmc_validate(const kmc_config* c)
     const int P = c->shard_count <= 0 ? 1 : c->shard_count;
     if (c->shard_rank < 0 || c->shard_rank >= P) return fail(KMC_ERR_BAD_ARG, "shard_rank out of range");
     if ((c->nwalkers / 2) % P != 0) return fail(KMC_ERR_BAD_ARG, "nwalkers/2 must be divisible by shard_count");
+    if ((c->flags & KMC_P2P) && P > 8) return fail(KMC_ERR_UNSUPPORTED, "KMC_P2P supports at most 8 shards (one node)");
     DensityParams dp;
     return digest_params(*c, &dp);
 }
@@ -394,7 +422,7 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
     s->plan = make_plan(s->cfg, s->h_loc);
     {
         HalfStepFn v, g;
-        lookup(cfg->density, 0, 0, 1, &v, &g, &s->logpdf_fn);
+        lookup(cfg->density, 0, 0, 1, false, &v, &g, &s->logpdf_fn);
     }
     // vec: a wave owns W = (64/L)*ITER walkers; generic: one walker per lane
     const int64_t per_wave = s->plan.vec ? (int64_t)(64 / s->plan.L) * s->plan.ITER : 64;
@@ -419,7 +447,15 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
     s->own_stream = true;
     CREATE_TRY(hipEventCreate(&s->ev0));
     CREATE_TRY(hipEventCreate(&s->ev1));
-    const size_t nw = (size_t)cfg->nwalkers, nd = (size_t)cfg->ndim;
+    s->p2p = (cfg->flags & KMC_P2P) != 0;
+    s->nrows = s->p2p ? s->nlocal : cfg->nwalkers;
+    const size_t nw = (size_t)s->nrows, nd = (size_t)cfg->ndim;
+    if (s->p2p) {
+        CREATE_TRY(hipExtMallocWithFlags((void**)&s->d_flags, 4096, hipDeviceMallocFinegrained));
+        CREATE_TRY(hipMemset(s->d_flags, 0, 4096));
+        CREATE_TRY(hipMalloc((void**)&s->d_err, 64));
+        CREATE_TRY(hipMemset(s->d_err, 0, 64));
+    }
     CREATE_TRY(hipMalloc(&s->d_pos, nw * nd * sizeof(double)));
     CREATE_TRY(hipMalloc(&s->d_logp, nw * sizeof(double)));
     CREATE_TRY(hipMalloc(&s->d_naccept, nw * sizeof(uint32_t)));
@@ -439,6 +475,11 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
     if ((cfg->flags & KMC_STORE_LOGP) && s->nsamples > 0)
         CREATE_TRY(hipMalloc(&s->d_chain_logp, (size_t)s->nsamples * (size_t)s->nlocal * sizeof(double)));
 #undef CREATE_TRY
+    if (s->p2p) {
+        s->peer_pos[s->cfg.shard_rank] = s->d_pos;
+        s->peer_flags[s->cfg.shard_rank] = s->d_flags;
+        s->connected = s->cfg.shard_count == 1;
+    }
     *out = s;
     return KMC_OK;
 }
@@ -452,6 +493,15 @@ KMC_EXPORT void kmc_sampler_destroy(kmc_sampler* s)
     if (s->graph) (void)hipGraphDestroy(s->graph);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
+    if (s->p2p) {
+        for (int r = 0; r < 8; ++r) {
+            if (r == s->cfg.shard_rank) continue;
+            if (s->peer_pos[r]) (void)hipIpcCloseMemHandle(s->peer_pos[r]);
+            if (s->peer_flags[r]) (void)hipIpcCloseMemHandle(s->peer_flags[r]);
+        }
+        (void)hipFree(s->d_flags);
+        (void)hipFree(s->d_err);
+    }
     if (s->own_pos) (void)hipFree(s->d_pos);
     (void)hipFree(s->d_logp);
     (void)hipFree(s->d_naccept);
@@ -480,10 +530,20 @@ KMC_EXPORT kmc_status kmc_sampler_set_stream(kmc_sampler* s, void* hip_stream)
 KMC_EXPORT kmc_status kmc_sampler_bind_positions(kmc_sampler* s, void* pos_dev)
 {
     if (!s || !pos_dev) return fail(KMC_ERR_BAD_ARG, "null argument");
+    if (s->p2p) return fail(KMC_ERR_UNSUPPORTED, "KMC_P2P samplers export their own position buffer");
     HIP_TRY(hipSetDevice(s->cfg.device));
     HIP_TRY(hipStreamSynchronize(s->stream));
     if (s->graph_exec) { (void)hipGraphExecDestroy(s->graph_exec); s->graph_exec = nullptr; }
     if (s->graph) { (void)hipGraphDestroy(s->graph); s->graph = nullptr; }
+    if (s->p2p) {
+        for (int r = 0; r < 8; ++r) {
+            if (r == s->cfg.shard_rank) continue;
+            if (s->peer_pos[r]) (void)hipIpcCloseMemHandle(s->peer_pos[r]);
+            if (s->peer_flags[r]) (void)hipIpcCloseMemHandle(s->peer_flags[r]);
+        }
+        (void)hipFree(s->d_flags);
+        (void)hipFree(s->d_err);
+    }
     if (s->own_pos) (void)hipFree(s->d_pos);
     s->d_pos = static_cast<double*>(pos_dev);
     s->own_pos = false;
@@ -491,13 +551,59 @@ KMC_EXPORT kmc_status kmc_sampler_bind_positions(kmc_sampler* s, void* pos_dev)
     return KMC_OK;
 }
 
+// ---- peer-to-peer sharding ---------------------------------------------------------------
+struct P2PHandle { hipIpcMemHandle_t pos, flags; };
+static_assert(sizeof(P2PHandle) == KMC_P2P_HANDLE_BYTES, "handle blob size");
+
+KMC_EXPORT kmc_status kmc_sampler_p2p_export(kmc_sampler* s, void* handle_out)
+{
+    if (!s || !handle_out) return fail(KMC_ERR_BAD_ARG, "null argument");
+    if (!s->p2p) return fail(KMC_ERR_BAD_ARG, "sampler was created without KMC_P2P");
+    HIP_TRY(hipSetDevice(s->cfg.device));
+    P2PHandle h;
+    HIP_TRY(hipIpcGetMemHandle(&h.pos, s->d_pos));
+    HIP_TRY(hipIpcGetMemHandle(&h.flags, s->d_flags));
+    std::memcpy(handle_out, &h, sizeof(h));
+    return KMC_OK;
+}
+
+KMC_EXPORT kmc_status kmc_sampler_p2p_connect(kmc_sampler* s, const void* handles)
+{
+    if (!s || !handles) return fail(KMC_ERR_BAD_ARG, "null argument");
+    if (!s->p2p) return fail(KMC_ERR_BAD_ARG, "sampler was created without KMC_P2P");
+    if (s->connected) return KMC_OK;
+    HIP_TRY(hipSetDevice(s->cfg.device));
+    const P2PHandle* h = static_cast<const P2PHandle*>(handles);
+    for (int r = 0; r < s->cfg.shard_count; ++r) {
+        if (r == s->cfg.shard_rank) continue;
+        void* p = nullptr;
+        HIP_TRY(hipIpcOpenMemHandle(&p, h[r].pos, hipIpcMemLazyEnablePeerAccess));
+        s->peer_pos[r] = static_cast<double*>(p);
+        HIP_TRY(hipIpcOpenMemHandle(&p, h[r].flags, hipIpcMemLazyEnablePeerAccess));
+        s->peer_flags[r] = static_cast<unsigned long long*>(p);
+    }
+    s->connected = true;
+    return KMC_OK;
+}
+
 KMC_EXPORT kmc_status kmc_sampler_set_positions(kmc_sampler* s, const double* theta_host)
 {
     if (!s || !theta_host) return fail(KMC_ERR_BAD_ARG, "null argument");
     HIP_TRY(hipSetDevice(s->cfg.device));
-    const size_t nw = (size_t)s->cfg.nwalkers, nd = (size_t)s->cfg.ndim;
+    const size_t nw = (size_t)s->nrows, nd = (size_t)s->cfg.ndim;
     HIP_TRY(hipStreamSynchronize(s->stream));
-    HIP_TRY(hipMemcpy(s->d_pos, theta_host, nw * nd * sizeof(double), hipMemcpyHostToDevice));   // :198 (caller's array untouched)
+    if (!s->p2p) {
+        HIP_TRY(hipMemcpy(s->d_pos, theta_host, nw * nd * sizeof(double), hipMemcpyHostToDevice));   // :198 (caller's array untouched)
+    } else {
+        // theta_host is the GLOBAL ensemble; keep this shard's slice of each half: local rows
+        // [0,h_loc) = global [begin, begin+h_loc), local [h_loc,2h_loc) = global [h+begin, ...)
+        const size_t slice = (size_t)s->h_loc * nd;
+        HIP_TRY(hipMemcpy(s->d_pos, theta_host + (size_t)s->active_begin * nd, slice * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(s->d_pos + slice, theta_host + ((size_t)s->h + (size_t)s->active_begin) * nd,
+                          slice * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemset(s->d_flags, 0, 4096));     // callers barrier across ranks before running
+        HIP_TRY(hipMemset(s->d_err, 0, 64));
+    }
     hipLaunchKernelGGL(s->logpdf_fn, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s->stream,
                        (const double*)s->d_pos, s->d_logp, (int64_t)nw, (int)nd, s->dp);          // :209-210
     HIP_TRY(hipGetLastError());
@@ -528,8 +634,9 @@ KMC_EXPORT kmc_status kmc_sampler_run(kmc_sampler* s, int64_t ngen)
 {
     if (!s || ngen < 0) return fail(KMC_ERR_BAD_ARG, "bad argument");
     if (!s->positions_set) return fail(KMC_ERR_BAD_ARG, "kmc_sampler_set_positions has not succeeded yet");
-    if (s->cfg.shard_count != 1)
-        return fail(KMC_ERR_UNSUPPORTED, "kmc_sampler_run needs shard_count == 1; sharded drivers call kmc_sampler_half_step");
+    if (s->cfg.shard_count != 1 && !s->p2p)
+        return fail(KMC_ERR_UNSUPPORTED, "kmc_sampler_run needs shard_count == 1 or KMC_P2P; replica-sharded drivers call kmc_sampler_half_step");
+    if (s->p2p && !s->connected) return fail(KMC_ERR_BAD_ARG, "kmc_sampler_p2p_connect has not been called");
     HIP_TRY(hipSetDevice(s->cfg.device));
     HIP_TRY(hipEventRecord(s->ev0, s->stream));
     const bool use_graph = !(s->cfg.flags & KMC_NO_GRAPH);
@@ -556,6 +663,7 @@ KMC_EXPORT kmc_status kmc_sampler_half_step(kmc_sampler* s, int half)
 {
     if (!s || (half != 0 && half != 1)) return fail(KMC_ERR_BAD_ARG, "bad argument");
     if (!s->positions_set) return fail(KMC_ERR_BAD_ARG, "kmc_sampler_set_positions has not succeeded yet");
+    if (s->p2p && !s->connected) return fail(KMC_ERR_BAD_ARG, "kmc_sampler_p2p_connect has not been called");
     HIP_TRY(hipSetDevice(s->cfg.device));
     KMC_TRY(launch_half(s, half, false, s->generation));
     s->launches += 1;
@@ -568,6 +676,13 @@ KMC_EXPORT kmc_status kmc_sampler_sync(kmc_sampler* s)
     if (!s) return fail(KMC_ERR_BAD_ARG, "null sampler");
     HIP_TRY(hipSetDevice(s->cfg.device));
     HIP_TRY(hipStreamSynchronize(s->stream));
+    if (s->p2p) {
+        unsigned long long e = 0;
+        HIP_TRY(hipMemcpy(&e, s->d_err, sizeof(e), hipMemcpyDeviceToHost));
+        if (e != 0)
+            return fail(KMC_ERR_HIP, "p2p: timed out waiting for a peer before half-step " + std::to_string(e - 1) +
+                                     " (results are invalid)");
+    }
     return KMC_OK;
 }
 
@@ -603,7 +718,7 @@ KMC_EXPORT kmc_status kmc_sampler_get_positions(kmc_sampler* s, double* host)
     if (!s || !host) return fail(KMC_ERR_BAD_ARG, "null argument");
     HIP_TRY(hipSetDevice(s->cfg.device));
     HIP_TRY(hipStreamSynchronize(s->stream));
-    HIP_TRY(hipMemcpy(host, s->d_pos, (size_t)s->cfg.nwalkers * (size_t)s->cfg.ndim * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(host, s->d_pos, (size_t)s->nrows * (size_t)s->cfg.ndim * sizeof(double), hipMemcpyDeviceToHost));
     return KMC_OK;
 }
 
@@ -612,7 +727,7 @@ KMC_EXPORT kmc_status kmc_sampler_get_logp(kmc_sampler* s, double* host)
     if (!s || !host) return fail(KMC_ERR_BAD_ARG, "null argument");
     HIP_TRY(hipSetDevice(s->cfg.device));
     HIP_TRY(hipStreamSynchronize(s->stream));
-    HIP_TRY(hipMemcpy(host, s->d_logp, (size_t)s->cfg.nwalkers * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(host, s->d_logp, (size_t)s->nrows * sizeof(double), hipMemcpyDeviceToHost));
     return KMC_OK;
 }
 
@@ -621,7 +736,7 @@ KMC_EXPORT kmc_status kmc_sampler_get_naccept(kmc_sampler* s, int64_t* host)
     if (!s || !host) return fail(KMC_ERR_BAD_ARG, "null argument");
     HIP_TRY(hipSetDevice(s->cfg.device));
     HIP_TRY(hipStreamSynchronize(s->stream));
-    std::vector<uint32_t> tmp((size_t)s->cfg.nwalkers);
+    std::vector<uint32_t> tmp((size_t)s->nrows);
     HIP_TRY(hipMemcpy(tmp.data(), s->d_naccept, tmp.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
     for (size_t i = 0; i < tmp.size(); ++i) host[i] = (int64_t)tmp[i];
     return KMC_OK;
@@ -630,7 +745,7 @@ KMC_EXPORT kmc_status kmc_sampler_get_naccept(kmc_sampler* s, int64_t* host)
 KMC_EXPORT kmc_status kmc_sampler_get_accept_ratio(kmc_sampler* s, double* host)
 {
     if (!s || !host) return fail(KMC_ERR_BAD_ARG, "null argument");
-    std::vector<int64_t> na((size_t)s->cfg.nwalkers);
+    std::vector<int64_t> na((size_t)s->nrows);
     KMC_TRY(kmc_sampler_get_naccept(s, na.data()));
     const double denom = (double)(s->generation - s->cfg.nburnin);   // :291 (0 -> inf/nan like the reference)
     for (size_t i = 0; i < na.size(); ++i) host[i] = (double)na[i] / denom;
@@ -730,7 +845,7 @@ KMC_EXPORT kmc_status kmc_logpdf_eval(const kmc_config* cfg, const double* pos_d
     KMC_TRY(digest_params(*cfg, &dp));
     HalfStepFn v, g;
     LogpdfFn lp = nullptr;
-    if (!lookup(cfg->density, 0, 0, 1, &v, &g, &lp)) return fail(KMC_ERR_BAD_ARG, "unknown density id");
+    if (!lookup(cfg->density, 0, 0, 1, false, &v, &g, &lp)) return fail(KMC_ERR_BAD_ARG, "unknown density id");
     if (nrows == 0) return KMC_OK;
     hipLaunchKernelGGL(lp, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream,
                        pos_dev, logp_dev, nrows, (int)cfg->ndim, dp);

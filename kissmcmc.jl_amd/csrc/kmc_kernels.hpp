@@ -60,10 +60,18 @@ struct HalfStepArgs {
     SchedEntry        sched_inline; // used when sched_table == nullptr
     int32_t           sched_index;
     int32_t           half;         // 0: update [0,h) against [h,2h); 1: swapped       (:247)
-    int64_t           nhalf;        // h = nwalkers / 2 (global)
-    int64_t           active_begin; // first active index (within the half) of this shard
+    int64_t           gw0;          // GLOBAL walker index of this launch's active walker 0 (keys the RNG)
+    int64_t           own_row0;     // its row in pos / index in logp, naccept
+    int64_t           oth_row0;     // row of the complementary half's walker 0 (in each peer's pos for P2P)
     int32_t           n_active;     // number of active walkers of this shard
     int32_t           ndim;
+    // peer-to-peer sharding (P2P kernels only): partner p of the complementary half lives on rank
+    // p / hloc at row oth_row0 + p % hloc of that rank's pos
+    uint32_t          hloc;
+    int32_t           nranks;
+    double*           peer_pos[8];
+    const unsigned long long* flags; // flags[r] = number of half-steps rank r has completed
+    unsigned long long* err;         // set non-zero when a wait times out
     DrawConsts        dc;
     DensityParams     dp;
     double*           chain;        // [nsamples][chain_rows][ndim] or nullptr          (:269)
@@ -101,7 +109,28 @@ __device__ __forceinline__ double2 sel2(bool c, const double2& a, const double2&
 // ------------------------------------------------------------------------------------------
 // Vector kernel.
 // ------------------------------------------------------------------------------------------
-template <class Dens, int L, int K, int ITER>
+// Bounded wait until every rank has completed `need` half-steps (P2P only).  flags[] is this
+// rank's fine-grained progress array, written by the peers' signal kernels over xGMI.
+__device__ __forceinline__ void wait_for_peers(const HalfStepArgs& a, unsigned long long need, int lane)
+{
+    bool ok = lane >= a.nranks ||
+              __hip_atomic_load(a.flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= need;
+    unsigned spins = 0;
+    while (!__all(ok)) {
+        __builtin_amdgcn_s_sleep(2);
+        ok = lane >= a.nranks ||
+             __hip_atomic_load(a.flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= need;
+        if (++spins > 4000000u) {                 // seconds: a peer died -- flag it and fall through
+            if (lane == 0) __hip_atomic_store(a.err, need + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+    }
+    // No cache invalidate is needed: L1/L2 were invalidated at kernel start and no peer row has
+    // been loaded by this kernel before this point; the fence only pins the compiler's load order.
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <class Dens, int L, int K, int ITER, bool P2P>
 __global__ __launch_bounds__(256) void half_step_vec(const HalfStepArgs a)
 {
     static_assert(L >= 1 && L <= 64 && (L & (L - 1)) == 0, "L must be a power of two <= 64");
@@ -116,8 +145,6 @@ __global__ __launch_bounds__(256) void half_step_vec(const HalfStepArgs a)
     const int gbase = lane & ~(L - 1);                  // first lane of this group
     const int w0    = (tid >> 6) * W;                   // first active index of this wave
     const int nact  = a.n_active;
-    const int64_t act0 = (int64_t)a.half * a.nhalf + a.active_begin;   // global index of active walker 0
-    const int64_t oth0 = (int64_t)(1 - a.half) * a.nhalf;
 
     // ---- row layout: own rows of every iteration (independent of the random draws) ----------
     bool    validB[ITER];
@@ -126,7 +153,7 @@ __global__ __launch_bounds__(256) void half_step_vec(const HalfStepArgs a)
     for (int it = 0; it < ITER; ++it) {
         const int i = w0 + it * G + g;
         validB[it] = i < nact;
-        const double2* own = reinterpret_cast<const double2*>(a.pos + (act0 + (validB[it] ? i : nact - 1)) * ndim);
+        const double2* own = reinterpret_cast<const double2*>(a.pos + (a.own_row0 + (validB[it] ? i : nact - 1)) * ndim);
 #pragma unroll
         for (int k = 0; k < K; ++k) xc[it][k] = own[k * L + j];
     }
@@ -149,20 +176,41 @@ __global__ __launch_bounds__(256) void half_step_vec(const HalfStepArgs a)
     }
     const int  iA     = w0 + (j < ITER ? j : 0) * G + g;
     const bool validA = (j < ITER) && (iA < nact);
-    const int64_t gwA = act0 + (iA < nact ? iA : nact - 1);
-    const double   p0 = a.logp[gwA];
-    const uint32_t na = a.naccept[gwA];
-    const U4 bits = draw_bits(a.dc, step, (uint64_t)gwA);
+    const int      iAc = iA < nact ? iA : nact - 1;
+    const int64_t  rowA = a.own_row0 + iAc;                              // row in pos / index in logp, naccept
+    const double   p0 = a.logp[rowA];
+    const uint32_t na = a.naccept[rowA];
+    const U4 bits = draw_bits(a.dc, step, (uint64_t)(a.gw0 + iAc));     // RNG keyed by the GLOBAL walker index
     const uint32_t partnerA = draw_partner(a.dc, bits);                 // :250
 
-    // ---- scalar -> row: the partner index of slot it*G+g lives in lane gbase+it; get the
-    //      partner-row loads in flight before the logarithms --------------------------------
+    // ---- scalar -> row: the partner of slot it*G+g lives in lane gbase+it; get the partner-row
+    //      loads in flight before the logarithms ---------------------------------------------
+    if constexpr (!P2P) {
 #pragma unroll
-    for (int it = 0; it < ITER; ++it) {
-        const uint32_t partner = (uint32_t)__builtin_amdgcn_ds_bpermute((gbase + it) * 4, (int)partnerA);
-        const double2* oth = reinterpret_cast<const double2*>(a.pos + (oth0 + partner) * ndim);
+        for (int it = 0; it < ITER; ++it) {
+            const uint32_t partner = (uint32_t)__builtin_amdgcn_ds_bpermute((gbase + it) * 4, (int)partnerA);
+            const double2* oth = reinterpret_cast<const double2*>(a.pos + (a.oth_row0 + partner) * ndim);
 #pragma unroll
-        for (int k = 0; k < K; ++k) xo[it][k] = oth[k * L + j];
+            for (int k = 0; k < K; ++k) xo[it][k] = oth[k * L + j];
+        }
+    } else {
+        // owner rank and row of the partner, resolved once per walker; the row address travels
+        const uint32_t q = partnerA / a.hloc;
+        const uint32_t r = partnerA - q * a.hloc;
+        const double* base = a.peer_pos[0];
+#pragma unroll
+        for (int t = 1; t < 8; ++t) base = (q == (uint32_t)t) ? a.peer_pos[t] : base;
+        const unsigned long long addrA = (unsigned long long)(base + (a.oth_row0 + r) * ndim);
+        if (a.nranks > 1) wait_for_peers(a, step, lane);   // every rank has finished half-step `step - 1`
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int src = (gbase + it) * 4;
+            const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)(unsigned)addrA);
+            const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)(unsigned)(addrA >> 32));
+            const double2* oth = reinterpret_cast<const double2*>(((unsigned long long)hi << 32) | lo);
+#pragma unroll
+            for (int k = 0; k < K; ++k) xo[it][k] = oth[k * L + j];
+        }
     }
     const Draw dr = draw_finish(a.dc, bits);                            // :252, log z, log u
     double zB[ITER];
@@ -187,8 +235,8 @@ __global__ __launch_bounds__(256) void half_step_vec(const HalfStepArgs a)
     const bool acc = validA && accept_test(dr, myp1, p0);               // :260
     const unsigned long long accmask = __ballot(acc);
     if (acc) {
-        a.logp[gwA] = myp1;                                             // :262
-        if (count) a.naccept[gwA] = na + 1u;                            // :265
+        a.logp[rowA] = myp1;                                            // :262
+        if (count) a.naccept[rowA] = na + 1u;                           // :265
     }
     if (sample && a.chain_logp != nullptr && validA)                    // :271
         a.chain_logp[sch.slot * a.chain_rows + a.chain_row0 + iA] = acc ? myp1 : p0;
@@ -201,7 +249,7 @@ __global__ __launch_bounds__(256) void half_step_vec(const HalfStepArgs a)
     for (int it = 0; it < ITER; ++it) {
         const bool accB = ((accmask >> (gbase + it)) & 1ull) != 0;
         if (accB) {                                                     // :261
-            double2* own = reinterpret_cast<double2*>(a.pos + (act0 + w0 + it * G + g) * ndim);
+            double2* own = reinterpret_cast<double2*>(a.pos + (a.own_row0 + w0 + it * G + g) * ndim);
 #pragma unroll
             for (int k = 0; k < K; ++k) store_row16(&own[k * L + j], xo[it][k]);
         }
@@ -246,20 +294,31 @@ __global__ __launch_bounds__(256) void half_step_vec(const HalfStepArgs a)
 // ------------------------------------------------------------------------------------------
 // Generic kernel: one walker per lane, any ndim.
 // ------------------------------------------------------------------------------------------
-template <class Dens>
+template <class Dens, bool P2P>
 __global__ __launch_bounds__(256) void half_step_generic(const HalfStepArgs a)
 {
     const int tid = blockIdx.x * 256 + threadIdx.x;
+    const SchedEntry sch = schedule_of(a);
+    const uint64_t step = 2ull * (uint64_t)sch.gen + (uint64_t)a.half;
+    if constexpr (P2P) { if (a.nranks > 1) wait_for_peers(a, step, (int)(threadIdx.x & 63)); }   // whole waves, before any exit
     if (tid >= a.n_active) return;
     const int ndim = a.ndim;
-    const SchedEntry sch = schedule_of(a);
     const bool count  = (sch.flags & kCount) != 0;
     const bool sample = (sch.flags & kSample) != 0;
-    const uint64_t step = 2ull * (uint64_t)sch.gen + (uint64_t)a.half;
-    const int64_t gw = (int64_t)a.half * a.nhalf + a.active_begin + tid;
-    const Draw dr = draw_step(a.dc, step, (uint64_t)gw);
+    const int64_t gw = a.own_row0 + tid;                                // row in pos / index in logp, naccept
+    const Draw dr = draw_step(a.dc, step, (uint64_t)(a.gw0 + tid));
     double* own = a.pos + gw * ndim;
-    const double* oth = a.pos + ((int64_t)(1 - a.half) * a.nhalf + dr.partner) * ndim;
+    const double* oth;
+    if constexpr (!P2P) {
+        oth = a.pos + (a.oth_row0 + dr.partner) * ndim;
+    } else {
+        const uint32_t q = dr.partner / a.hloc;
+        const uint32_t r = dr.partner - q * a.hloc;
+        const double* base = a.peer_pos[0];
+#pragma unroll
+        for (int t = 1; t < 8; ++t) base = (q == (uint32_t)t) ? a.peer_pos[t] : base;
+        oth = base + (a.oth_row0 + r) * ndim;
+    }
     const double p0 = a.logp[gw];
 
     typename Dens::Seq q;
@@ -305,6 +364,26 @@ __global__ __launch_bounds__(256) void logpdf_rows(const double* __restrict__ po
     Dens::seq_init(q);
     for (int d = 0; d < ndim; ++d) Dens::seq_add(q, pos[r * ndim + d], d, dp);
     logp[r] = Dens::seq_finish(q, ndim, dp);
+}
+
+// P2P: after a half-step kernel has drained (kernel boundary = its rows are in memory), tell every
+// rank -- including this one -- that this rank has completed half-step `step` (flag = step + 1).
+struct SignalArgs {
+    unsigned long long* peer_flags[8];   // peer_flags[r] = rank r's flags array
+    int32_t             nranks;
+    int32_t             me;
+    const SchedEntry*   sched_table;
+    SchedEntry          sched_inline;
+    int32_t             sched_index;
+    int32_t             half;
+};
+__global__ void p2p_signal(const SignalArgs a)
+{
+    const SchedEntry sch = a.sched_table ? a.sched_table[a.sched_index] : a.sched_inline;
+    const unsigned long long done = 2ull * (unsigned long long)sch.gen + (unsigned long long)a.half + 1ull;
+    __threadfence_system();
+    if ((int)threadIdx.x < a.nranks)
+        __hip_atomic_store(a.peer_flags[threadIdx.x] + a.me, done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // Graph replay support: the device-side generation counter and the schedule table of the next

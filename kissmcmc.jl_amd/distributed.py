@@ -87,6 +87,92 @@ class HipShardExecutor:
         self.sampler.close()
 
 
+def local_to_global(local, nwalkers: int, world: int):
+    """Assemble per-rank arrays in P2P local order (first-half slice, then second-half slice) into
+    the global walker order.  ``local``: list over ranks of arrays ``[2*h/world, ...]``."""
+    h = nwalkers // 2
+    n = h // world
+    first = [np.asarray(a)[:n] for a in local]
+    second = [np.asarray(a)[n:] for a in local]
+    return np.concatenate(first + second, axis=0)
+
+
+class P2PEmcee:
+    """Walker-sharded emcee with peer-to-peer partner reads (``KMC_P2P``): each rank holds only its
+    own walkers, the half-step kernel reads partner rows straight from the owning GPU's HBM over
+    xGMI, and half-steps are ordered by per-rank progress flags written by tiny signal kernels --
+    no host involvement and no collective on the data path: the whole run is enqueued (hipGraph
+    replay) like the single-GPU case.  Compared with all-gathering the updated half after every
+    half-step this moves only the rows that are actually drawn (1/P of the bytes).
+
+    ``torch.distributed`` (any backend) is used for the rendezvous (IPC handle exchange, barriers)
+    and for assembling results.
+    """
+
+    def __init__(self, pdf, nwalkers, ndim, ngenerations, nburnin=0, nthin=1, a_scale=2.0, seed=0,
+                 device=0, moments=True, group=None, use_graph=True):
+        from .sampler import Sampler
+        self.group = group
+        self.rank = dist.get_rank(group) if dist is not None and dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist is not None and dist.is_initialized() else 1
+        self.nwalkers, self.ndim = int(nwalkers), int(ndim)
+        shard_slice(self.nwalkers, self.rank, self.world)
+        self.sampler = Sampler(pdf, nwalkers, ndim, ngenerations, nburnin, nthin, a_scale, seed,
+                               moments=moments, use_graph=use_graph, device=device,
+                               shard_rank=self.rank, shard_count=self.world, p2p=True)
+        if self.world > 1:
+            blobs = [None] * self.world
+            dist.all_gather_object(blobs, self.sampler.p2p_export(), group=group)
+            self.sampler.p2p_connect(blobs)
+
+    def _barrier(self):
+        if self.world > 1:
+            dist.barrier(group=self.group)
+
+    def set_positions(self, theta_global):
+        self._barrier()                 # nobody is still reading this rank's rows or flags
+        self.sampler.set_positions(theta_global)
+        self._barrier()                 # every rank's rows are in place and its flags are zero
+
+    def run(self, ngenerations: int):
+        self.sampler.run(ngenerations)  # asynchronous; ordering across ranks happens on the devices
+
+    def sync(self):
+        self.sampler.sync()
+
+    def close(self):
+        self.sync()
+        self._barrier()                 # peers may still be reading this rank's rows
+        self.sampler.close()
+
+    # -- results ----------------------------------------------------------------------------
+    def _gather(self, local):
+        if self.world == 1:
+            return local_to_global([local], self.nwalkers, 1)
+        parts = [None] * self.world
+        dist.all_gather_object(parts, local, group=self.group)
+        return local_to_global(parts, self.nwalkers, self.world)
+
+    def positions(self):
+        return self._gather(self.sampler.positions())
+
+    def logp(self):
+        return self._gather(self.sampler.logp())
+
+    def naccept(self):
+        return self._gather(self.sampler.naccept())
+
+    def moments(self):
+        s, q, n = self.sampler.moments()
+        if self.world > 1:
+            parts = [None] * self.world
+            dist.all_gather_object(parts, (s, q, n), group=self.group)
+            s = sum(p[0] for p in parts)
+            q = sum(p[1] for p in parts)
+            n = sum(p[2] for p in parts)
+        return s, q, n
+
+
 class ShardedEmcee:
     """The generation loop of ``_emcee`` (``src/samplers.jl:245-290``) over ``world`` ranks."""
 

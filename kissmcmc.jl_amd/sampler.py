@@ -21,7 +21,7 @@ class Sampler:
     def __init__(self, pdf: DeviceLogPdf, nwalkers: int, ndim: int, ngenerations: int, nburnin: int = 0,
                  nthin: int = 1, a_scale: float = 2.0, seed: int = 0, store_chain: bool = False,
                  store_logp: bool = False, moments: bool = False, use_graph: bool = True,
-                 device: int = 0, shard_rank: int = 0, shard_count: int = 1):
+                 device: int = 0, shard_rank: int = 0, shard_count: int = 1, p2p: bool = False):
         if not isinstance(pdf, DeviceLogPdf):
             raise TypeError(
                 "the device emcee path evaluates a fixed menu of log-densities "
@@ -49,6 +49,8 @@ class Sampler:
             flags |= _lib.MOMENTS
         if not use_graph:
             flags |= _lib.NO_GRAPH
+        if p2p:
+            flags |= _lib.P2P
         cfg.flags = flags
         cfg.device = int(device)
         cfg.shard_rank, cfg.shard_count = int(shard_rank), int(shard_count)
@@ -59,6 +61,9 @@ class Sampler:
         self._h = h
         self.nwalkers, self.ndim = int(nwalkers), int(ndim)
         self.nlocal = self.nwalkers // max(1, int(shard_count))
+        self.p2p = bool(p2p)
+        # rows this object holds: the whole ensemble, or (P2P) this shard's slices of both halves
+        self.nrows = self.nlocal if self.p2p else self.nwalkers
 
     # -- lifecycle --------------------------------------------------------------------------
     def close(self):
@@ -85,6 +90,19 @@ class Sampler:
     def bind_positions(self, device_ptr: int):
         """Use a caller-owned device buffer (``double [nwalkers][ndim]``) for the ensemble."""
         _lib.check(self._L.kmc_sampler_bind_positions(self._h, C.c_void_p(device_ptr)))
+
+    def p2p_export(self) -> bytes:
+        """IPC handle blob of this shard (to be all-gathered across the ranks)."""
+        buf = C.create_string_buffer(_lib.P2P_HANDLE_BYTES)
+        _lib.check(self._L.kmc_sampler_p2p_export(self._h, buf))
+        return buf.raw
+
+    def p2p_connect(self, blobs):
+        """``blobs``: the export blobs of all ``shard_count`` ranks, in rank order."""
+        raw = b"".join(bytes(b) for b in blobs)
+        assert len(raw) == _lib.P2P_HANDLE_BYTES * self.cfg.shard_count
+        buf = C.create_string_buffer(raw, len(raw))
+        _lib.check(self._L.kmc_sampler_p2p_connect(self._h, buf))
 
     def set_positions(self, theta):
         theta = np.ascontiguousarray(np.asarray(theta, dtype=np.float64).reshape(self.nwalkers, self.ndim))
@@ -121,22 +139,22 @@ class Sampler:
 
     # -- downloads --------------------------------------------------------------------------
     def positions(self) -> np.ndarray:
-        out = np.empty((self.nwalkers, self.ndim))
+        out = np.empty((self.nrows, self.ndim))
         _lib.check(self._L.kmc_sampler_get_positions(self._h, _dp(out)))
         return out
 
     def logp(self) -> np.ndarray:
-        out = np.empty(self.nwalkers)
+        out = np.empty(self.nrows)
         _lib.check(self._L.kmc_sampler_get_logp(self._h, _dp(out)))
         return out
 
     def naccept(self) -> np.ndarray:
-        out = np.empty(self.nwalkers, dtype=np.int64)
+        out = np.empty(self.nrows, dtype=np.int64)
         _lib.check(self._L.kmc_sampler_get_naccept(self._h, out.ctypes.data_as(C.POINTER(C.c_int64))))
         return out
 
     def accept_ratio(self) -> np.ndarray:
-        out = np.empty(self.nwalkers)
+        out = np.empty(self.nrows)
         _lib.check(self._L.kmc_sampler_get_accept_ratio(self._h, _dp(out)))
         return out
 
