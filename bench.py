@@ -6,7 +6,8 @@ a = 2, 10^4 generations (burn-in = first half), streaming moments ON, chain stor
 One bench "step" = GENS_PER_STEP (1000) generations = 65.536e6 walker-steps per GPU, so the
 default --steps 10 is exactly the 10^4-generation job.  With --gpus N (launched by
 torch.distributed.run, one rank per GPU) the ensemble is 65 536 x N walkers, walker-sharded with an
-RCCL all-gather of the updated half after every half-step (weak scaling, config C4 at N = 8).
+peer-to-peer partner reads over xGMI (KMC_P2P; falls back to an RCCL all-gather of the updated half per
+half-step if the IPC set-up fails) -- weak scaling, config C4 at N = 8.
 
 Prints ONE JSON line (rank 0).  `value` = all walker-steps of the timed region / wall time
 (max over ranks) with the ensemble resident in HBM.  `roofline` prices the half-step kernel
@@ -204,7 +205,7 @@ def main():
         achieved = walkers_per_launch * b_read / (launch_us * 1e-6) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_c2.json")
-        if os.path.exists(tpath):
+        if world == 1 and os.path.exists(tpath):
             try:
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
             except Exception:
