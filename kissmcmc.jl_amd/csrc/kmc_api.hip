@@ -79,6 +79,39 @@ HalfStepFn vec_iter(int iter)
     }
 }
 
+using FlushFn = void (*)(const FlushArgs);
+
+template <int L, int K, int ITER>
+FlushFn flush_one()
+{
+    if constexpr (ITER <= L && ITER * K <= 16) return flush_moments_vec<L, K, ITER>;
+    else return nullptr;
+}
+
+template <int L, int K>
+FlushFn flush_iter(int iter)
+{
+    switch (iter) {
+    case 1: return flush_one<L, K, 1>();
+    case 2: return flush_one<L, K, 2>();
+    case 4: return flush_one<L, K, 4>();
+    case 8: return flush_one<L, K, 8>();
+    case 16: return flush_one<L, K, 16>();
+    default: return nullptr;
+    }
+}
+
+FlushFn flush_lookup(int L, int K, int iter)
+{
+#define KMC_LK(l, k) if (L == l && K == k) return flush_iter<l, k>(iter);
+    KMC_LK(4, 1) KMC_LK(8, 1) KMC_LK(16, 1) KMC_LK(32, 1) KMC_LK(64, 1)
+    KMC_LK(4, 2) KMC_LK(8, 2) KMC_LK(16, 2) KMC_LK(32, 2) KMC_LK(64, 2)
+    KMC_LK(4, 4) KMC_LK(8, 4) KMC_LK(16, 4) KMC_LK(32, 4) KMC_LK(64, 4)
+    KMC_LK(64, 8)
+#undef KMC_LK
+    return nullptr;
+}
+
 template <class D>
 HalfStepFn vec_lookup(int L, int K, int iter, bool p2p)
 {
@@ -204,6 +237,7 @@ struct kmc_sampler {
     double* d_chain_logp = nullptr;
     double* d_msum = nullptr;
     double* d_msumsq = nullptr;
+    uint32_t* d_klast = nullptr;      // vec kernels: samples already credited per walker
     int64_t macc_stride = 0, macc_elems = 0;
     int64_t generation = 0;   // generations enqueued so far
     int64_t dev_gen = 0;      // value the device counter will hold once the stream drains
@@ -261,6 +295,7 @@ HalfStepArgs make_args(const kmc_sampler* s, int half, bool graph_mode, int64_t 
     a.msum = s->d_msum;
     a.msumsq = s->d_msumsq;
     a.macc_stride = s->macc_stride;
+    a.klast = s->d_klast;
     return a;
 }
 
@@ -469,6 +504,10 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         CREATE_TRY(hipMalloc(&s->d_msumsq, (size_t)s->macc_elems * sizeof(double)));
         CREATE_TRY(hipMemset(s->d_msum, 0, (size_t)s->macc_elems * sizeof(double)));
         CREATE_TRY(hipMemset(s->d_msumsq, 0, (size_t)s->macc_elems * sizeof(double)));
+        if (s->plan.vec) {
+            CREATE_TRY(hipMalloc((void**)&s->d_klast, nw * sizeof(uint32_t)));
+            CREATE_TRY(hipMemset(s->d_klast, 0, nw * sizeof(uint32_t)));
+        }
     }
     if ((cfg->flags & KMC_STORE_CHAIN) && s->nsamples > 0)
         CREATE_TRY(hipMalloc(&s->d_chain, (size_t)s->nsamples * (size_t)s->nlocal * nd * sizeof(double)));
@@ -511,6 +550,7 @@ KMC_EXPORT void kmc_sampler_destroy(kmc_sampler* s)
     (void)hipFree(s->d_chain_logp);
     (void)hipFree(s->d_msum);
     (void)hipFree(s->d_msumsq);
+    (void)hipFree(s->d_klast);
     if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
     (void)hipGetLastError();
     delete s;
@@ -614,6 +654,7 @@ KMC_EXPORT kmc_status kmc_sampler_set_positions(kmc_sampler* s, const double* th
     if (s->d_msum) {
         HIP_TRY(hipMemsetAsync(s->d_msum, 0, (size_t)s->macc_elems * sizeof(double), s->stream));
         HIP_TRY(hipMemsetAsync(s->d_msumsq, 0, (size_t)s->macc_elems * sizeof(double), s->stream));
+        if (s->d_klast) HIP_TRY(hipMemsetAsync(s->d_klast, 0, nw * sizeof(uint32_t), s->stream));
     }
     HIP_TRY(hipStreamSynchronize(s->stream));
     s->generation = 0;
@@ -757,6 +798,24 @@ KMC_EXPORT kmc_status kmc_sampler_get_moments(kmc_sampler* s, double* sum, doubl
     if (!s) return fail(KMC_ERR_BAD_ARG, "null sampler");
     if (!s->d_msum) return fail(KMC_ERR_BAD_ARG, "sampler was created without KMC_MOMENTS");
     HIP_TRY(hipSetDevice(s->cfg.device));
+    if (s->plan.vec) {
+        // sojourn-weighted accumulation: credit every walker's current value up to now
+        FlushFn fl = flush_lookup(s->plan.L, s->plan.K, s->plan.ITER);
+        if (!fl) return fail(KMC_ERR_UNSUPPORTED, "no flush kernel for this geometry");
+        for (int half = 0; half < 2; ++half) {
+            FlushArgs fa{};
+            fa.pos = s->d_pos;
+            fa.klast = s->d_klast;
+            fa.msum = s->d_msum;
+            fa.msumsq = s->d_msumsq;
+            fa.macc_stride = s->macc_stride;
+            fa.row0 = s->p2p ? (int64_t)half * s->h_loc : (int64_t)half * s->h + s->active_begin;
+            fa.n_active = (int32_t)s->h_loc;
+            fa.nsamp = (uint32_t)samples_done(s);
+            hipLaunchKernelGGL(fl, dim3(s->grid), dim3(256), 0, s->stream, fa);
+            HIP_TRY(hipGetLastError());
+        }
+    }
     HIP_TRY(hipStreamSynchronize(s->stream));
     const int64_t nd = s->cfg.ndim;
     std::vector<double> hs((size_t)s->macc_elems), hq((size_t)s->macc_elems);

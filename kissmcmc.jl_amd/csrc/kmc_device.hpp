@@ -109,6 +109,25 @@ __device__ __forceinline__ double bperm_f64(int byte_addr, double v)
     const int hi = __builtin_amdgcn_ds_bpermute(byte_addr, __double2hiint(v));
     return __hiloint2double(hi, lo);
 }
+// v + (v of lane ^ 16) and v + (v of lane ^ 32) with gfx950's v_permlane{16,32}_swap: the swap of
+// a value with a copy of itself leaves {even rows, even rows} in one register and {odd rows, odd
+// rows} in the other, so their sum is the xor-butterfly level -- two VALU ops per 32-bit word,
+// no LDS crossbar round trip.
+__device__ __forceinline__ double xor16_sum(double v)
+{
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+}
+__device__ __forceinline__ double xor32_sum(double v)
+{
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+}
+
 // Sum over the L lanes of a group; every lane of the group ends with the same bits
 // (each butterfly level adds the same two operands on both sides).
 template <int L>
@@ -118,8 +137,8 @@ __device__ __forceinline__ double group_sum(double v)
     if constexpr (L >= 4)  v += dpp_f64<0x4E>(v);    // quad_perm [2,3,0,1]  : lane ^ 2
     if constexpr (L >= 8)  v += dpp_f64<0x141>(v);   // row_half_mirror      : other quad pair
     if constexpr (L >= 16) v += dpp_f64<0x140>(v);   // row_mirror           : other 8-lane half
-    if constexpr (L >= 32) v += __shfl_xor(v, 16, 64);
-    if constexpr (L >= 64) v += __shfl_xor(v, 32, 64);
+    if constexpr (L >= 32) v = xor16_sum(v);
+    if constexpr (L >= 64) v = xor32_sum(v);
     return v;
 }
 // Sum of the values held by lanes {j, j+L, j+2L, ...} (one per group); valid in group 0.
@@ -130,8 +149,8 @@ __device__ __forceinline__ double wave_fold(double v)
     if constexpr (L <= 2)  v += dpp_f64<0x4E>(v);
     if constexpr (L <= 4)  v += dpp_f64<0x124>(v);   // row_ror:4
     if constexpr (L <= 8)  v += dpp_f64<0x128>(v);   // row_ror:8
-    if constexpr (L <= 16) v += __shfl_xor(v, 16, 64);
-    if constexpr (L <= 32) v += __shfl_xor(v, 32, 64);
+    if constexpr (L <= 16) v = xor16_sum(v);
+    if constexpr (L <= 32) v = xor32_sum(v);
     return v;
 }
 template <int L>

@@ -34,7 +34,7 @@ struct SchedEntry {
     int64_t  gen;     // generation index g in [0, G);  n = g + 1 - nburnin
     int64_t  slot;    // stored-sample index k when (flags & kSample)
     uint32_t flags;
-    uint32_t pad_;
+    uint32_t nbefore; // number of samples taken by generations < gen (sojourn-weighted moments)
 };
 enum : uint32_t { kCount = 1u, kSample = 2u };
 
@@ -42,6 +42,10 @@ __host__ __device__ inline SchedEntry make_sched(int64_t gen, int64_t nburnin, i
 {
     SchedEntry e{gen, 0, 0u, 0u};
     const int64_t n = gen + 1 - nburnin;
+    if (n > 1) {
+        const int64_t nb = (n - 1) / nthin;
+        e.nbefore = (uint32_t)(nb < nsamples ? nb : nsamples);
+    }
     if (n > 0) {
         e.flags |= kCount;                              // :265, counters restart at n == 0 (:285-288)
         if (n % nthin == 0) {                           // :268
@@ -81,6 +85,7 @@ struct HalfStepArgs {
     double*           msum;         // per-thread moment accumulators or nullptr
     double*           msumsq;
     int64_t           macc_stride;  // threads in the accumulator grid
+    uint32_t*         klast;        // vec kernels: per walker, samples already credited to the moments
 };
 
 __device__ __forceinline__ SchedEntry schedule_of(const HalfStepArgs& a)
@@ -109,6 +114,33 @@ __device__ __forceinline__ double2 sel2(bool c, const double2& a, const double2&
 // ------------------------------------------------------------------------------------------
 // Vector kernel.
 // ------------------------------------------------------------------------------------------
+// Fold the wave's G groups (same dimensions, different walkers) into group 0 and add the result to
+// that wave's accumulator slots: 1/G of the accumulator traffic for a few cross-lane moves.
+template <int L, int K, bool HAVE_OLD>
+__device__ __forceinline__ void accumulate_wave(double* msum, double* msumsq, int64_t stride, int tid, int g,
+                                                double2 (&ms)[K], double2 (&mq)[K],
+                                                const double2 (&olds)[K], const double2 (&oldq)[K])
+{
+    if constexpr (L < 64) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            ms[k].x = wave_fold<L>(ms[k].x); ms[k].y = wave_fold<L>(ms[k].y);
+            mq[k].x = wave_fold<L>(mq[k].x); mq[k].y = wave_fold<L>(mq[k].y);
+        }
+    }
+    if (g == 0) {
+        double2* s = reinterpret_cast<double2*>(msum);
+        double2* q = reinterpret_cast<double2*>(msumsq);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int64_t idx = (int64_t)k * stride + tid;
+            const double2 sv = HAVE_OLD ? olds[k] : s[idx], qv = HAVE_OLD ? oldq[k] : q[idx];
+            s[idx] = make_double2(sv.x + ms[k].x, sv.y + ms[k].y);
+            q[idx] = make_double2(qv.x + mq[k].x, qv.y + mq[k].y);
+        }
+    }
+}
+
 // Bounded wait until every rank has completed `need` half-steps (P2P only).  flags[] is this
 // rank's fine-grained progress array, written by the peers' signal kernels over xGMI.
 __device__ __forceinline__ void wait_for_peers(const HalfStepArgs& a, unsigned long long need, int lane)
@@ -116,6 +148,8 @@ __device__ __forceinline__ void wait_for_peers(const HalfStepArgs& a, unsigned l
     bool ok = lane >= a.nranks ||
               __hip_atomic_load(a.flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= need;
     unsigned spins = 0;
+    // once a wait has timed out the run is invalid: do not pay the timeout again at every step
+    if (__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) ok = true;
     while (!__all(ok)) {
         __builtin_amdgcn_s_sleep(2);
         ok = lane >= a.nranks ||
@@ -163,15 +197,22 @@ __global__ __launch_bounds__(256) void half_step_vec(const HalfStepArgs a)
     const bool count  = (sch.flags & kCount) != 0;
     const bool sample = (sch.flags & kSample) != 0;
     const uint64_t step = 2ull * (uint64_t)sch.gen + (uint64_t)a.half;
-    // moment accumulators of this wave (group 0 lanes): fetched now, used at the very end
-    const bool do_mom = sample && a.msum != nullptr;
+    // Streaming moments are sojourn-weighted: a walker's value is credited, times the number of
+    // samples it stood for, when it is replaced (and by flush_moments_vec at read-out).  Only waves
+    // with an accepted move touch their accumulators -- at low acceptance (large ndim) almost none.
+    const bool do_mom = count && a.msum != nullptr;
+    // small rows: nearly every wave has an accepted move, so fetch its accumulator slots now and
+    // keep that latency off the kernel's tail; large rows: fetch only when needed
+    constexpr bool kPrefetchAcc = K <= 2;
     double2 accs[K], accq[K];
-    if (do_mom && g == 0) {
+    if constexpr (kPrefetchAcc) {
+        if (do_mom && g == 0) {
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const int64_t idx = (int64_t)k * a.macc_stride + tid;
-            accs[k] = reinterpret_cast<const double2*>(a.msum)[idx];
-            accq[k] = reinterpret_cast<const double2*>(a.msumsq)[idx];
+            for (int k = 0; k < K; ++k) {
+                const int64_t idx = (int64_t)k * a.macc_stride + tid;
+                accs[k] = reinterpret_cast<const double2*>(a.msum)[idx];
+                accq[k] = reinterpret_cast<const double2*>(a.msumsq)[idx];
+            }
         }
     }
     const int  iA     = w0 + (j < ITER ? j : 0) * G + g;
@@ -180,6 +221,7 @@ __global__ __launch_bounds__(256) void half_step_vec(const HalfStepArgs a)
     const int64_t  rowA = a.own_row0 + iAc;                              // row in pos / index in logp, naccept
     const double   p0 = a.logp[rowA];
     const uint32_t na = a.naccept[rowA];
+    const uint32_t kl = do_mom ? a.klast[rowA] : 0u;
     const U4 bits = draw_bits(a.dc, step, (uint64_t)(a.gw0 + iAc));     // RNG keyed by the GLOBAL walker index
     const uint32_t partnerA = draw_partner(a.dc, bits);                 // :250
 
@@ -237,7 +279,10 @@ __global__ __launch_bounds__(256) void half_step_vec(const HalfStepArgs a)
     if (acc) {
         a.logp[rowA] = myp1;                                            // :262
         if (count) a.naccept[rowA] = na + 1u;                           // :265
+        if (do_mom) a.klast[rowA] = sch.nbefore;
     }
+    const uint32_t wA = (acc && do_mom) ? sch.nbefore - kl : 0u;        // samples the replaced value stood for
+    const bool any_w = __ballot(wA != 0u) != 0ull;
     if (sample && a.chain_logp != nullptr && validA)                    // :271
         a.chain_logp[sch.slot * a.chain_rows + a.chain_row0 + iA] = acc ? myp1 : p0;
 
@@ -253,42 +298,75 @@ __global__ __launch_bounds__(256) void half_step_vec(const HalfStepArgs a)
 #pragma unroll
             for (int k = 0; k < K; ++k) store_row16(&own[k * L + j], xo[it][k]);
         }
-        if (sample) {                                                   // :268-269
-            double2* dst = nullptr;
-            if (a.chain != nullptr && validB[it])
-                dst = reinterpret_cast<double2*>(a.chain + (sch.slot * a.chain_rows + a.chain_row0 + w0 + it * G + g) * ndim);
+        if (any_w) {
+            const double wB = (double)(uint32_t)__builtin_amdgcn_ds_bpermute((gbase + it) * 4, (int)wA);
 #pragma unroll
             for (int k = 0; k < K; ++k) {
-                const double2 cur = sel2(accB, xo[it][k], xc[it][k]);
-                if (validB[it]) {
-                    ms[k].x += cur.x; ms[k].y += cur.y;
-                    mq[k].x += cur.x * cur.x; mq[k].y += cur.y * cur.y;
-                }
-                if (dst) dst[k * L + j] = cur;
+                ms[k].x += xc[it][k].x * wB; ms[k].y += xc[it][k].y * wB;
+                mq[k].x += (xc[it][k].x * xc[it][k].x) * wB; mq[k].y += (xc[it][k].y * xc[it][k].y) * wB;
+            }
+        }
+        if (sample && a.chain != nullptr && validB[it]) {               // :268-269
+            double2* dst = reinterpret_cast<double2*>(a.chain + (sch.slot * a.chain_rows + a.chain_row0 + w0 + it * G + g) * ndim);
+#pragma unroll
+            for (int k = 0; k < K; ++k) dst[k * L + j] = sel2(accB, xo[it][k], xc[it][k]);
+        }
+    }
+    if (any_w) {
+        if constexpr (kPrefetchAcc) accumulate_wave<L, K, true>(a.msum, a.msumsq, a.macc_stride, tid, g, ms, mq, accs, accq);
+        else accumulate_wave<L, K, false>(a.msum, a.msumsq, a.macc_stride, tid, g, ms, mq, accs, accq);
+    }
+}
+
+// Moment read-out: credit every walker's current value with the samples it has stood for since it
+// was last credited (S = samples taken so far), same lane mapping as half_step_vec.
+struct FlushArgs {
+    const double* pos;
+    uint32_t*     klast;
+    double*       msum;
+    double*       msumsq;
+    int64_t       macc_stride;
+    int64_t       row0;      // first row of this launch in pos / klast
+    int32_t       n_active;
+    uint32_t      nsamp;     // S
+};
+
+template <int L, int K, int ITER>
+__global__ __launch_bounds__(256) void flush_moments_vec(const FlushArgs a)
+{
+    constexpr int G = 64 / L;
+    constexpr int W = G * ITER;
+    constexpr int ndim = 2 * L * K;
+    const int tid  = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int j    = lane & (L - 1);
+    const int g    = lane / L;
+    const int w0   = (tid >> 6) * W;
+    double2 ms[K], mq[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) { ms[k] = make_double2(0.0, 0.0); mq[k] = make_double2(0.0, 0.0); }
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const int i = w0 + it * G + g;
+        if (i < a.n_active) {
+            const int64_t row = a.row0 + i;
+            const double w = (double)(a.nsamp - a.klast[row]);
+            const double2* x = reinterpret_cast<const double2*>(a.pos + row * ndim);
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const double2 v = x[k * L + j];
+                ms[k].x += v.x * w; ms[k].y += v.y * w;
+                mq[k].x += (v.x * v.x) * w; mq[k].y += (v.y * v.y) * w;
             }
         }
     }
-    if (do_mom) {
-        // fold the G groups of the wave (same dimensions, different walkers) into group 0 first:
-        // 1/G of the accumulator traffic for a few cross-lane moves
-        if constexpr (L < 64) {
+    __syncthreads();                       // every lane has read klast before anyone rewrites it
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
-                ms[k].x = wave_fold<L>(ms[k].x); ms[k].y = wave_fold<L>(ms[k].y);
-                mq[k].x = wave_fold<L>(mq[k].x); mq[k].y = wave_fold<L>(mq[k].y);
-            }
-        }
-        if (g == 0) {
-            double2* s = reinterpret_cast<double2*>(a.msum);
-            double2* q = reinterpret_cast<double2*>(a.msumsq);
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-                const int64_t idx = (int64_t)k * a.macc_stride + tid;
-                s[idx] = make_double2(accs[k].x + ms[k].x, accs[k].y + ms[k].y);
-                q[idx] = make_double2(accq[k].x + mq[k].x, accq[k].y + mq[k].y);
-            }
-        }
+    for (int it = 0; it < ITER; ++it) {
+        const int i = w0 + it * G + g;
+        if (i < a.n_active && j == 0) a.klast[a.row0 + i] = a.nsamp;
     }
+    accumulate_wave<L, K, false>(a.msum, a.msumsq, a.macc_stride, tid, g, ms, mq, ms, mq);
 }
 
 // ------------------------------------------------------------------------------------------
