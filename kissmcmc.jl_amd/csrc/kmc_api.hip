@@ -225,6 +225,7 @@ struct kmc_sampler {
     Plan plan{};
     LogpdfFn logpdf_fn = nullptr;
     int grid = 0;
+    int tpb = 256;
     hipStream_t stream = nullptr;
     bool own_stream = false;
     double* d_pos = nullptr;
@@ -302,7 +303,7 @@ HalfStepArgs make_args(const kmc_sampler* s, int half, bool graph_mode, int64_t 
 kmc_status launch_half(kmc_sampler* s, int half, bool graph_mode, int64_t gen_offset)
 {
     const HalfStepArgs a = make_args(s, half, graph_mode, gen_offset);
-    hipLaunchKernelGGL(s->plan.fn, dim3(s->grid), dim3(256), 0, s->stream, a);
+    hipLaunchKernelGGL(s->plan.fn, dim3(s->grid), dim3(s->tpb), 0, s->stream, a);
     HIP_TRY(hipGetLastError());
     if (s->p2p && s->cfg.shard_count > 1) {
         // the kernel boundary puts this half-step's rows in memory; then publish the progress
@@ -462,8 +463,11 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
     // vec: a wave owns W = (64/L)*ITER walkers; generic: one walker per lane
     const int64_t per_wave = s->plan.vec ? (int64_t)(64 / s->plan.L) * s->plan.ITER : 64;
     const int64_t waves = (s->h_loc + per_wave - 1) / per_wave;
-    s->grid = (int)((waves + 3) / 4);
-    s->macc_stride = (int64_t)s->grid * 256;
+    // vec kernels: kTPB threads per workgroup; the generic kernel keeps 256
+    const int tpb = s->plan.vec ? kTPB : 256;
+    s->tpb = tpb;
+    s->grid = (int)((waves * 64 + tpb - 1) / tpb);
+    s->macc_stride = (int64_t)s->grid * tpb;
     s->macc_elems = s->plan.vec ? s->macc_stride * 2 * s->plan.K : s->macc_stride * cfg->ndim;
 
 #define CREATE_TRY(expr)                                                                       \
@@ -812,7 +816,7 @@ KMC_EXPORT kmc_status kmc_sampler_get_moments(kmc_sampler* s, double* sum, doubl
             fa.row0 = s->p2p ? (int64_t)half * s->h_loc : (int64_t)half * s->h + s->active_begin;
             fa.n_active = (int32_t)s->h_loc;
             fa.nsamp = (uint32_t)samples_done(s);
-            hipLaunchKernelGGL(fl, dim3(s->grid), dim3(256), 0, s->stream, fa);
+            hipLaunchKernelGGL(fl, dim3(s->grid), dim3(s->tpb), 0, s->stream, fa);
             HIP_TRY(hipGetLastError());
         }
     }

@@ -27,7 +27,13 @@
 #pragma once
 #include "kmc_device.hpp"
 
+#ifndef KMC_TPB
+#define KMC_TPB 256   // threads per workgroup of the half-step kernels (waves are independent)
+#endif
+
 namespace kmc {
+
+constexpr int kTPB = KMC_TPB;
 
 // What the reference's loop variable n (src/samplers.jl:245) implies for one generation.
 struct SchedEntry {
@@ -121,6 +127,7 @@ __device__ __forceinline__ void accumulate_wave(double* msum, double* msumsq, in
                                                 double2 (&ms)[K], double2 (&mq)[K],
                                                 const double2 (&olds)[K], const double2 (&oldq)[K])
 {
+#ifndef KMC_DIAG_NOFOLD
     if constexpr (L < 64) {
 #pragma unroll
         for (int k = 0; k < K; ++k) {
@@ -128,7 +135,12 @@ __device__ __forceinline__ void accumulate_wave(double* msum, double* msumsq, in
             mq[k].x = wave_fold<L>(mq[k].x); mq[k].y = wave_fold<L>(mq[k].y);
         }
     }
+#endif
+#ifdef KMC_DIAG_NORMW
+    if (g == 0 && ms[0].x == 1.2345e300) {
+#else
     if (g == 0) {
+#endif
         double2* s = reinterpret_cast<double2*>(msum);
         double2* q = reinterpret_cast<double2*>(msumsq);
 #pragma unroll
@@ -165,14 +177,14 @@ __device__ __forceinline__ void wait_for_peers(const HalfStepArgs& a, unsigned l
 }
 
 template <class Dens, int L, int K, int ITER, bool P2P>
-__global__ __launch_bounds__(256) void half_step_vec(const HalfStepArgs a)
+__global__ __launch_bounds__(kTPB) void half_step_vec(const HalfStepArgs a)
 {
     static_assert(L >= 1 && L <= 64 && (L & (L - 1)) == 0, "L must be a power of two <= 64");
     static_assert(ITER >= 1 && ITER <= L, "a group's scalar lanes must cover its iterations");
     constexpr int G = 64 / L;          // groups = walkers in flight per wave
     constexpr int W = G * ITER;        // walkers per wave
     constexpr int ndim = 2 * L * K;
-    const int tid   = blockIdx.x * 256 + threadIdx.x;
+    const int tid   = blockIdx.x * kTPB + threadIdx.x;
     const int lane  = threadIdx.x & 63;
     const int j     = lane & (L - 1);
     const int g     = lane / L;
@@ -332,12 +344,12 @@ struct FlushArgs {
 };
 
 template <int L, int K, int ITER>
-__global__ __launch_bounds__(256) void flush_moments_vec(const FlushArgs a)
+__global__ __launch_bounds__(kTPB) void flush_moments_vec(const FlushArgs a)
 {
     constexpr int G = 64 / L;
     constexpr int W = G * ITER;
     constexpr int ndim = 2 * L * K;
-    const int tid  = blockIdx.x * 256 + threadIdx.x;
+    const int tid  = blockIdx.x * kTPB + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const int j    = lane & (L - 1);
     const int g    = lane / L;
