@@ -49,7 +49,7 @@ kmc_status fail(kmc_status st, const std::string& msg)
 constexpr int64_t kGraphChunk = 64;   // generations per hipGraph replay (128 kernel nodes + 1)
 
 using HalfStepFn = void (*)(const HalfStepArgs);
-using LogpdfFn = void (*)(const double*, double*, int64_t, int, DensityParams);
+using LogpdfFn = void (*)(const double*, double*, int64_t, int, int, DensityParams);
 
 struct Plan {
     HalfStepFn fn = nullptr;
@@ -58,27 +58,6 @@ struct Plan {
 };
 
 // ---- kernel table ------------------------------------------------------------------------
-template <class D, int L, int K, int ITER, bool P2P>
-HalfStepFn vec_one()
-{
-    // a group's ITER scalar lanes must fit in its L lanes; keep the register tile (ITER*K chunks) bounded
-    if constexpr (ITER <= L && ITER * K <= 16) return half_step_vec<D, L, K, ITER, P2P>;
-    else return nullptr;
-}
-
-template <class D, int L, int K, bool P2P>
-HalfStepFn vec_iter(int iter)
-{
-    switch (iter) {
-    case 1: return vec_one<D, L, K, 1, P2P>();
-    case 2: return vec_one<D, L, K, 2, P2P>();
-    case 4: return vec_one<D, L, K, 4, P2P>();
-    case 8: return vec_one<D, L, K, 8, P2P>();
-    case 16: return vec_one<D, L, K, 16, P2P>();
-    default: return nullptr;
-    }
-}
-
 using FlushFn = void (*)(const FlushArgs);
 
 template <int L, int K, int ITER>
@@ -104,46 +83,77 @@ FlushFn flush_iter(int iter)
 FlushFn flush_lookup(int L, int K, int iter)
 {
 #define KMC_LK(l, k) if (L == l && K == k) return flush_iter<l, k>(iter);
-    KMC_LK(4, 1) KMC_LK(8, 1) KMC_LK(16, 1) KMC_LK(32, 1) KMC_LK(64, 1)
+    KMC_LK(1, 1) KMC_LK(2, 1) KMC_LK(4, 1) KMC_LK(8, 1) KMC_LK(16, 1) KMC_LK(32, 1) KMC_LK(64, 1)
     KMC_LK(4, 2) KMC_LK(8, 2) KMC_LK(16, 2) KMC_LK(32, 2) KMC_LK(64, 2)
-    KMC_LK(4, 4) KMC_LK(8, 4) KMC_LK(16, 4) KMC_LK(32, 4) KMC_LK(64, 4)
+    KMC_LK(4, 4) KMC_LK(8, 4) KMC_LK(64, 4)
     KMC_LK(64, 8)
 #undef KMC_LK
     return nullptr;
 }
 
+template <class D, int L, int K, int ITER, bool P2P, bool RAGGED>
+HalfStepFn vec_one()
+{
+    // a group's ITER scalar lanes must fit in its L lanes; keep the register tile (ITER*K chunks) bounded
+    if constexpr (ITER <= L && ITER * K <= 16) return half_step_vec<D, L, K, ITER, P2P, RAGGED>;
+    else return nullptr;
+}
+
+template <class D, int L, int K, bool P2P, bool RAGGED>
+HalfStepFn vec_iter(int iter)
+{
+    switch (iter) {
+    case 1: return vec_one<D, L, K, 1, P2P, RAGGED>();
+    case 2: return vec_one<D, L, K, 2, P2P, RAGGED>();
+    case 4: return vec_one<D, L, K, 4, P2P, RAGGED>();
+    case 8: if constexpr (!RAGGED) return vec_one<D, L, K, 8, P2P, RAGGED>(); else return nullptr;
+    case 16: if constexpr (!RAGGED) return vec_one<D, L, K, 16, P2P, RAGGED>(); else return nullptr;
+    default: return nullptr;
+    }
+}
+
+template <class D, int L, int K>
+HalfStepFn vec_pick(int iter, bool p2p, bool ragged)
+{
+    if (ragged) return p2p ? vec_iter<D, L, K, true, true>(iter) : vec_iter<D, L, K, false, true>(iter);
+    return p2p ? vec_iter<D, L, K, true, false>(iter) : vec_iter<D, L, K, false, false>(iter);
+}
+
+// exact geometries (ndim == 2*L*K): every tuning combination; ragged ones: what make_plan picks
 template <class D>
-HalfStepFn vec_lookup(int L, int K, int iter, bool p2p)
+HalfStepFn vec_lookup(int L, int K, int iter, bool p2p, bool ragged)
 {
     if constexpr (!D::kHasFrag) {
         return nullptr;
     } else {
-#define KMC_LK(l, k) if (L == l && K == k) return p2p ? vec_iter<D, l, k, true>(iter) : vec_iter<D, l, k, false>(iter);
-        KMC_LK(4, 1) KMC_LK(8, 1) KMC_LK(16, 1) KMC_LK(32, 1) KMC_LK(64, 1)
-        KMC_LK(4, 2) KMC_LK(8, 2) KMC_LK(16, 2) KMC_LK(32, 2) KMC_LK(64, 2)
-        KMC_LK(4, 4) KMC_LK(8, 4) KMC_LK(16, 4) KMC_LK(32, 4) KMC_LK(64, 4)
-        KMC_LK(64, 8)
+#define KMC_LK(l, k) if (L == l && K == k) return vec_pick<D, l, k>(iter, p2p, ragged);
+        KMC_LK(1, 1) KMC_LK(2, 1) KMC_LK(4, 1) KMC_LK(4, 2) KMC_LK(8, 2) KMC_LK(16, 2) KMC_LK(32, 2) KMC_LK(64, 2)
+        KMC_LK(64, 4) KMC_LK(64, 8)
+#undef KMC_LK
+        if (ragged) return nullptr;
+#define KMC_LK(l, k) if (L == l && K == k) return vec_pick<D, l, k>(iter, p2p, false);
+        KMC_LK(8, 1) KMC_LK(16, 1) KMC_LK(32, 1) KMC_LK(64, 1) KMC_LK(4, 4) KMC_LK(8, 4)
 #undef KMC_LK
         return nullptr;
     }
 }
 
 template <class D>
-void density_fns(int L, int K, int iter, bool p2p, HalfStepFn* vec, HalfStepFn* gen, LogpdfFn* lp)
+void density_fns(int L, int K, int iter, bool p2p, bool ragged, HalfStepFn* vec, HalfStepFn* gen, LogpdfFn* lp)
 {
-    *vec = vec_lookup<D>(L, K, iter, p2p);
+    *vec = vec_lookup<D>(L, K, iter, p2p, ragged);
     *gen = p2p ? half_step_generic<D, true> : half_step_generic<D, false>;
     *lp = logpdf_rows<D>;
 }
 
-bool lookup(int density, int L, int K, int iter, bool p2p, HalfStepFn* vec, HalfStepFn* gen, LogpdfFn* lp)
+bool lookup(int density, int L, int K, int iter, bool p2p, bool ragged, HalfStepFn* vec, HalfStepFn* gen, LogpdfFn* lp)
 {
     switch (density) {
-    case KMC_GAUSSIAN_ISO: density_fns<GaussianIso>(L, K, iter, p2p, vec, gen, lp); return true;
-    case KMC_EXPONENTIAL: density_fns<Exponential>(L, K, iter, p2p, vec, gen, lp); return true;
-    case KMC_ROSENBROCK: density_fns<Rosenbrock>(L, K, iter, p2p, vec, gen, lp); return true;
-    case KMC_LOGNORMAL: density_fns<LogNormal>(L, K, iter, p2p, vec, gen, lp); return true;
-    case KMC_MVNORMAL2: density_fns<MvNormal2>(L, K, iter, p2p, vec, gen, lp); return true;
+    case KMC_GAUSSIAN_ISO: density_fns<GaussianIso>(L, K, iter, p2p, ragged, vec, gen, lp); return true;
+    case KMC_EXPONENTIAL: density_fns<Exponential>(L, K, iter, p2p, ragged, vec, gen, lp); return true;
+    case KMC_ROSENBROCK: density_fns<Rosenbrock>(L, K, iter, p2p, ragged, vec, gen, lp); return true;
+    case KMC_LOGNORMAL: density_fns<LogNormal>(L, K, iter, p2p, ragged, vec, gen, lp); return true;
+    case KMC_MVNORMAL2: density_fns<MvNormal2>(L, K, iter, p2p, ragged, vec, gen, lp); return true;
     default: return false;
     }
 }
@@ -161,14 +171,15 @@ Plan make_plan(const kmc_config& c, int64_t n_active)
     else if (env && std::sscanf(env, "%d,%d,%d", &L, &K, &iter) == 3) { /* forced */ }
     else {
         L = 0;
-        const int64_t nd = c.ndim;
-        if (nd % 2 == 0) {
-            // measured on MI355X (scripts/quick_bench.py): 4 lanes x 2 chunks per 64 B of row
-            struct { int nd, L, K; } tbl[] = {{8, 4, 1},    {16, 4, 2},   {32, 8, 2},   {64, 16, 2}, {128, 32, 2},
-                                              {256, 64, 2}, {512, 64, 4}, {1024, 64, 8}};
-            for (auto& t : tbl)
-                if (t.nd == nd) { L = t.L; K = t.K; }
-        }
+        // a row = ceil(ndim/2) 16-byte chunks, striped over L lanes x K chunks (2*L*K >= ndim; the
+        // ragged tail is masked).  Measured on MI355X (scripts/quick_bench.py): 4 lanes x 2 chunks
+        // per 64 B of row is the sweet spot.
+        const int64_t chunks = (c.ndim + 1) / 2;
+        auto pow2ceil = [](int64_t v) { int p = 1; while (p < v) p <<= 1; return p; };
+        if (chunks <= 4) { L = pow2ceil(chunks); K = 1; }
+        else if (chunks <= 128) { L = pow2ceil((chunks + 1) / 2); K = 2; }
+        else if (chunks <= 256) { L = 64; K = 4; }
+        else if (chunks <= 512) { L = 64; K = 8; }
         // walkers per group (ITER): two amortise the per-walker scalar work (Philox, two logs) over
         // the wave; more only while the grid keeps >= 4096 waves (large ensembles)
         iter = 1;
@@ -178,8 +189,10 @@ Plan make_plan(const kmc_config& c, int64_t n_active)
             while (iter >= 2 && iter * 2 <= L && iter * 2 * K <= 16 && waves1 / (iter * 2) >= 4096 && iter < 16) iter *= 2;
         }
     }
-    lookup(c.density, L, K, iter, (c.flags & KMC_P2P) != 0, &vec, &gen, &lp);
-    if (!force_generic && L > 0 && 2 * L * K == c.ndim && vec != nullptr) {
+    const bool ragged = L > 0 && 2 * L * K != c.ndim;
+    if (ragged && iter > 4) iter = 4;
+    lookup(c.density, L, K, iter, (c.flags & KMC_P2P) != 0, ragged, &vec, &gen, &lp);
+    if (!force_generic && L > 0 && 2 * L * K >= c.ndim && vec != nullptr) {
         p.fn = vec; p.vec = true; p.L = L; p.K = K; p.ITER = iter;
     } else {
         p.fn = gen; p.vec = false; p.L = 1; p.K = 1; p.ITER = 1;
@@ -221,6 +234,7 @@ kmc_status digest_params(const kmc_config& c, DensityParams* dp)
 struct kmc_sampler {
     kmc_config cfg{};
     int64_t h = 0, h_loc = 0, active_begin = 0, nlocal = 0, nsamples = 0;
+    int64_t ld = 0;                    // device row stride in doubles (ndim rounded up to even)
     DensityParams dp{};
     Plan plan{};
     LogpdfFn logpdf_fn = nullptr;
@@ -282,6 +296,7 @@ HalfStepArgs make_args(const kmc_sampler* s, int half, bool graph_mode, int64_t 
     a.n_active = (int32_t)s->h_loc;
     a.half = half;
     a.ndim = (int32_t)s->cfg.ndim;
+    a.ld = (int32_t)s->ld;
     a.dc.seed_lo = (uint32_t)s->cfg.seed;
     a.dc.seed_hi = (uint32_t)(s->cfg.seed >> 32);
     a.dc.nhalf = (uint32_t)s->h;
@@ -353,6 +368,22 @@ kmc_status ensure_graph(kmc_sampler* s)
     s->graph = graph;
     HIP_TRY(hipGraphInstantiate(&s->graph_exec, graph, nullptr, nullptr, 0));
     return KMC_OK;
+}
+
+// Host rows are dense [rows][ndim]; device rows have stride ld (= ndim, or ndim+1 for odd ndim).
+hipError_t upload_rows(const kmc_sampler* s, double* dst_dev, const double* src_host, size_t rows)
+{
+    const size_t nd = (size_t)s->cfg.ndim, ld = (size_t)s->ld;
+    if (rows == 0) return hipSuccess;
+    if (ld == nd) return hipMemcpy(dst_dev, src_host, rows * nd * sizeof(double), hipMemcpyHostToDevice);
+    return hipMemcpy2D(dst_dev, ld * sizeof(double), src_host, nd * sizeof(double), nd * sizeof(double), rows, hipMemcpyHostToDevice);
+}
+hipError_t download_rows(const kmc_sampler* s, double* dst_host, const double* src_dev, size_t rows)
+{
+    const size_t nd = (size_t)s->cfg.ndim, ld = (size_t)s->ld;
+    if (rows == 0) return hipSuccess;
+    if (ld == nd) return hipMemcpy(dst_host, src_dev, rows * nd * sizeof(double), hipMemcpyDeviceToHost);
+    return hipMemcpy2D(dst_host, nd * sizeof(double), src_dev, ld * sizeof(double), nd * sizeof(double), rows, hipMemcpyDeviceToHost);
 }
 
 int64_t samples_done(const kmc_sampler* s)
@@ -453,12 +484,13 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
     s->active_begin = s->h_loc * s->cfg.shard_rank;
     s->nlocal = 2 * s->h_loc;
     s->nsamples = cfg->ngenerations > cfg->nburnin ? (cfg->ngenerations - cfg->nburnin) / cfg->nthin : 0;   // :234
+    s->ld = cfg->ndim + (cfg->ndim & 1);      // 16-byte aligned rows for the double2 kernels
     kmc_status st = digest_params(*cfg, &s->dp);
     if (st != KMC_OK) { delete s; return st; }
     s->plan = make_plan(s->cfg, s->h_loc);
     {
         HalfStepFn v, g;
-        lookup(cfg->density, 0, 0, 1, false, &v, &g, &s->logpdf_fn);
+        lookup(cfg->density, 0, 0, 1, false, false, &v, &g, &s->logpdf_fn);
     }
     // vec: a wave owns W = (64/L)*ITER walkers; generic: one walker per lane
     const int64_t per_wave = s->plan.vec ? (int64_t)(64 / s->plan.L) * s->plan.ITER : 64;
@@ -488,14 +520,16 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
     CREATE_TRY(hipEventCreate(&s->ev1));
     s->p2p = (cfg->flags & KMC_P2P) != 0;
     s->nrows = s->p2p ? s->nlocal : cfg->nwalkers;
-    const size_t nw = (size_t)s->nrows, nd = (size_t)cfg->ndim;
+    const size_t nw = (size_t)s->nrows;
     if (s->p2p) {
         CREATE_TRY(hipExtMallocWithFlags((void**)&s->d_flags, 4096, hipDeviceMallocFinegrained));
         CREATE_TRY(hipMemset(s->d_flags, 0, 4096));
         CREATE_TRY(hipMalloc((void**)&s->d_err, 64));
         CREATE_TRY(hipMemset(s->d_err, 0, 64));
     }
-    CREATE_TRY(hipMalloc(&s->d_pos, nw * nd * sizeof(double)));
+    const size_t ldz = (size_t)s->ld;
+    CREATE_TRY(hipMalloc(&s->d_pos, nw * ldz * sizeof(double)));
+    CREATE_TRY(hipMemset(s->d_pos, 0, nw * ldz * sizeof(double)));     // the pad column of odd ndim stays 0
     CREATE_TRY(hipMalloc(&s->d_logp, nw * sizeof(double)));
     CREATE_TRY(hipMalloc(&s->d_naccept, nw * sizeof(uint32_t)));
     static_assert(kGraphChunk <= 64, "advance_schedule runs one 64-thread block");
@@ -514,7 +548,7 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         }
     }
     if ((cfg->flags & KMC_STORE_CHAIN) && s->nsamples > 0)
-        CREATE_TRY(hipMalloc(&s->d_chain, (size_t)s->nsamples * (size_t)s->nlocal * nd * sizeof(double)));
+        CREATE_TRY(hipMalloc(&s->d_chain, (size_t)s->nsamples * (size_t)s->nlocal * ldz * sizeof(double)));
     if ((cfg->flags & KMC_STORE_LOGP) && s->nsamples > 0)
         CREATE_TRY(hipMalloc(&s->d_chain_logp, (size_t)s->nsamples * (size_t)s->nlocal * sizeof(double)));
 #undef CREATE_TRY
@@ -575,6 +609,7 @@ KMC_EXPORT kmc_status kmc_sampler_bind_positions(kmc_sampler* s, void* pos_dev)
 {
     if (!s || !pos_dev) return fail(KMC_ERR_BAD_ARG, "null argument");
     if (s->p2p) return fail(KMC_ERR_UNSUPPORTED, "KMC_P2P samplers export their own position buffer");
+    if (s->ld != s->cfg.ndim) return fail(KMC_ERR_UNSUPPORTED, "kmc_sampler_bind_positions needs an even ndim (16-byte rows)");
     HIP_TRY(hipSetDevice(s->cfg.device));
     HIP_TRY(hipStreamSynchronize(s->stream));
     if (s->graph_exec) { (void)hipGraphExecDestroy(s->graph_exec); s->graph_exec = nullptr; }
@@ -637,19 +672,18 @@ KMC_EXPORT kmc_status kmc_sampler_set_positions(kmc_sampler* s, const double* th
     const size_t nw = (size_t)s->nrows, nd = (size_t)s->cfg.ndim;
     HIP_TRY(hipStreamSynchronize(s->stream));
     if (!s->p2p) {
-        HIP_TRY(hipMemcpy(s->d_pos, theta_host, nw * nd * sizeof(double), hipMemcpyHostToDevice));   // :198 (caller's array untouched)
+        HIP_TRY(upload_rows(s, s->d_pos, theta_host, nw));   // :198 (caller's array untouched)
     } else {
         // theta_host is the GLOBAL ensemble; keep this shard's slice of each half: local rows
         // [0,h_loc) = global [begin, begin+h_loc), local [h_loc,2h_loc) = global [h+begin, ...)
-        const size_t slice = (size_t)s->h_loc * nd;
-        HIP_TRY(hipMemcpy(s->d_pos, theta_host + (size_t)s->active_begin * nd, slice * sizeof(double), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(s->d_pos + slice, theta_host + ((size_t)s->h + (size_t)s->active_begin) * nd,
-                          slice * sizeof(double), hipMemcpyHostToDevice));
+        const size_t hl = (size_t)s->h_loc;
+        HIP_TRY(upload_rows(s, s->d_pos, theta_host + (size_t)s->active_begin * nd, hl));
+        HIP_TRY(upload_rows(s, s->d_pos + hl * (size_t)s->ld, theta_host + ((size_t)s->h + (size_t)s->active_begin) * nd, hl));
         HIP_TRY(hipMemset(s->d_flags, 0, 4096));     // callers barrier across ranks before running
         HIP_TRY(hipMemset(s->d_err, 0, 64));
     }
     hipLaunchKernelGGL(s->logpdf_fn, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s->stream,
-                       (const double*)s->d_pos, s->d_logp, (int64_t)nw, (int)nd, s->dp);          // :209-210
+                       (const double*)s->d_pos, s->d_logp, (int64_t)nw, (int)nd, (int)s->ld, s->dp);   // :209-210
     HIP_TRY(hipGetLastError());
     std::vector<double> lp(nw);
     HIP_TRY(hipMemcpyAsync(lp.data(), s->d_logp, nw * sizeof(double), hipMemcpyDeviceToHost, s->stream));
@@ -763,7 +797,7 @@ KMC_EXPORT kmc_status kmc_sampler_get_positions(kmc_sampler* s, double* host)
     if (!s || !host) return fail(KMC_ERR_BAD_ARG, "null argument");
     HIP_TRY(hipSetDevice(s->cfg.device));
     HIP_TRY(hipStreamSynchronize(s->stream));
-    HIP_TRY(hipMemcpy(host, s->d_pos, (size_t)s->nrows * (size_t)s->cfg.ndim * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(download_rows(s, host, s->d_pos, (size_t)s->nrows));
     return KMC_OK;
 }
 
@@ -816,6 +850,7 @@ KMC_EXPORT kmc_status kmc_sampler_get_moments(kmc_sampler* s, double* sum, doubl
             fa.row0 = s->p2p ? (int64_t)half * s->h_loc : (int64_t)half * s->h + s->active_begin;
             fa.n_active = (int32_t)s->h_loc;
             fa.nsamp = (uint32_t)samples_done(s);
+            fa.ld = (int32_t)s->ld;
             hipLaunchKernelGGL(fl, dim3(s->grid), dim3(s->tpb), 0, s->stream, fa);
             HIP_TRY(hipGetLastError());
         }
@@ -832,8 +867,8 @@ KMC_EXPORT kmc_status kmc_sampler_get_moments(kmc_sampler* s, double* sum, doubl
             for (int64_t t = 0; t < s->macc_stride; ++t) {
                 const int64_t d0 = 2 * ((int64_t)k * L + (t % L));
                 const int64_t idx = 2 * ((int64_t)k * s->macc_stride + t);
-                S[d0] += hs[idx]; S[d0 + 1] += hs[idx + 1];
-                Q[d0] += hq[idx]; Q[d0 + 1] += hq[idx + 1];
+                if (d0 < nd) { S[d0] += hs[idx]; Q[d0] += hq[idx]; }
+                if (d0 + 1 < nd) { S[d0 + 1] += hs[idx + 1]; Q[d0 + 1] += hq[idx + 1]; }
             }
     } else {
         for (int64_t d = 0; d < nd; ++d)
@@ -858,7 +893,7 @@ KMC_EXPORT kmc_status kmc_sampler_get_chain(kmc_sampler* s, double* chain, doubl
     const size_t rows = (size_t)samples_done(s) * (size_t)s->nlocal;
     if (chain) {
         if (!s->d_chain && s->nsamples > 0) return fail(KMC_ERR_BAD_ARG, "sampler was created without KMC_STORE_CHAIN");
-        if (rows) HIP_TRY(hipMemcpy(chain, s->d_chain, rows * (size_t)s->cfg.ndim * sizeof(double), hipMemcpyDeviceToHost));
+        HIP_TRY(download_rows(s, chain, s->d_chain, rows));
     }
     if (chain_logp) {
         if (!s->d_chain_logp && s->nsamples > 0) return fail(KMC_ERR_BAD_ARG, "sampler was created without KMC_STORE_LOGP");
@@ -908,10 +943,10 @@ KMC_EXPORT kmc_status kmc_logpdf_eval(const kmc_config* cfg, const double* pos_d
     KMC_TRY(digest_params(*cfg, &dp));
     HalfStepFn v, g;
     LogpdfFn lp = nullptr;
-    if (!lookup(cfg->density, 0, 0, 1, false, &v, &g, &lp)) return fail(KMC_ERR_BAD_ARG, "unknown density id");
+    if (!lookup(cfg->density, 0, 0, 1, false, false, &v, &g, &lp)) return fail(KMC_ERR_BAD_ARG, "unknown density id");
     if (nrows == 0) return KMC_OK;
     hipLaunchKernelGGL(lp, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream,
-                       pos_dev, logp_dev, nrows, (int)cfg->ndim, dp);
+                       pos_dev, logp_dev, nrows, (int)cfg->ndim, (int)cfg->ndim, dp);
     HIP_TRY(hipGetLastError());
     return KMC_OK;
 }

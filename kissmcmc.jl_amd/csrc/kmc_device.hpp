@@ -176,15 +176,16 @@ struct GaussianIso {   // p = {mu, 1/sigma}
     __device__ static double seq_finish(const Seq& q, int, const DensityParams&) { return -0.5 * q.s; }
 
     template <int L, int K>
-    __device__ static double frag_partial(const double2 (&y)[K], int, int, const DensityParams& P)
+    __device__ static double frag_partial(const double2 (&y)[K], int j, int ndim, const DensityParams& P)
     {
         double s = 0.0;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
+            const int e0 = 2 * (k * L + j);
             const double t0 = (y[k].x - P.p[0]) * P.p[1];
             const double t1 = (y[k].y - P.p[0]) * P.p[1];
-            s += t0 * t0;
-            s += t1 * t1;
+            s += (e0 < ndim) ? t0 * t0 : 0.0;       // elements >= ndim are padding (ragged last chunk)
+            s += (e0 + 1 < ndim) ? t1 * t1 : 0.0;
         }
         return s;
     }
@@ -205,15 +206,17 @@ struct Exponential {   // p = {rate};  README.md:15  x<0 ? -Inf : -x
         return q.neg ? -INFINITY : -(P.p[0] * q.s);
     }
     template <int L, int K>
-    __device__ static double frag_partial(const double2 (&y)[K], int, int, const DensityParams&)
+    __device__ static double frag_partial(const double2 (&y)[K], int j, int ndim, const DensityParams&)
     {
         double s = 0.0;
         bool neg = false;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            neg = neg || (y[k].x < 0.0) || (y[k].y < 0.0);
-            s += y[k].x;
-            s += y[k].y;
+            const int e0 = 2 * (k * L + j);
+            const bool v0 = e0 < ndim, v1 = e0 + 1 < ndim;
+            neg = neg || (v0 && y[k].x < 0.0) || (v1 && y[k].y < 0.0);
+            s += v0 ? y[k].x : 0.0;
+            s += v1 ? y[k].y : 0.0;
         }
         return neg ? INFINITY : s;   // +inf propagates through the lane reduction
     }
@@ -246,8 +249,8 @@ struct Rosenbrock {   // p = {a, b, 1/scale}; chained form, reduces to test/runt
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const double x0 = y[k].x, x1 = y[k].y;
-            // term i = 2(kL+j): uses x_{i+1} = x1 (always exists)
-            {
+            // term i = 2(kL+j): uses x_{i+1} = x1 (exists unless the row ends inside this chunk)
+            if (2 * (k * L + j) < ndim - 1) {
                 const double dd = x1 - x0 * x0;
                 const double e  = a - x0;
                 s += b * (dd * dd) + e * e;
@@ -271,7 +274,31 @@ struct Rosenbrock {   // p = {a, b, 1/scale}; chained form, reduces to test/runt
 };
 
 struct LogNormal {   // p = {mu, sigma}
-    static constexpr bool kHasFrag = false;
+    static constexpr bool kHasFrag = true;
+    template <int L, int K>
+    __device__ static double frag_partial(const double2 (&y)[K], int j, int ndim, const DensityParams& P)
+    {
+        double s = 0.0;
+        bool bad = false;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int e0 = 2 * (k * L + j);
+            const double xs[2] = {y[k].x, y[k].y};
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                if (e0 + e < ndim) {
+                    if (!(xs[e] > 0.0)) bad = true;
+                    else {
+                        const double lx = log(xs[e]);
+                        const double t = (lx - P.p[0]) / P.p[1];
+                        s += -lx - 0.5 * t * t;
+                    }
+                }
+            }
+        }
+        return bad ? -INFINITY : s;   // -inf propagates through the lane reduction
+    }
+    __device__ static double finish(double S, const DensityParams&) { return S; }
     struct Seq { double s; bool bad; };
     __device__ static void seq_init(Seq& q) { q.s = 0.0; q.bad = false; }
     __device__ static void seq_add(Seq& q, double x, int, const DensityParams& P)
@@ -285,7 +312,15 @@ struct LogNormal {   // p = {mu, sigma}
 };
 
 struct MvNormal2 {   // p = {m1, m2, P11, P12, P22}
-    static constexpr bool kHasFrag = false;
+    static constexpr bool kHasFrag = true;
+    template <int L, int K>
+    __device__ static double frag_partial(const double2 (&y)[K], int j, int, const DensityParams& P)
+    {   // ndim == 2: the whole row is chunk 0 of lane 0 of the group
+        const double d0 = y[0].x - P.p[0], d1 = y[0].y - P.p[1];
+        const double r = -0.5 * (P.p[2] * d0 * d0 + 2.0 * P.p[3] * d0 * d1 + P.p[4] * d1 * d1);
+        return j == 0 ? r : 0.0;
+    }
+    __device__ static double finish(double S, const DensityParams&) { return S; }
     struct Seq { double d0, r; };
     __device__ static void seq_init(Seq& q) { q.d0 = 0.0; q.r = 0.0; }
     __device__ static void seq_add(Seq& q, double x, int d, const DensityParams& P)

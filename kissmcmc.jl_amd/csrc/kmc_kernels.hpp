@@ -75,6 +75,8 @@ struct HalfStepArgs {
     int64_t           oth_row0;     // row of the complementary half's walker 0 (in each peer's pos for P2P)
     int32_t           n_active;     // number of active walkers of this shard
     int32_t           ndim;
+    int32_t           ld;           // row stride of pos / chain in doubles: ndim rounded up to even (16-B rows)
+    int32_t           pad_;
     // peer-to-peer sharding (P2P kernels only): partner p of the complementary half lives on rank
     // p / hloc at row oth_row0 + p % hloc of that rank's pos
     uint32_t          hloc;
@@ -176,14 +178,17 @@ __device__ __forceinline__ void wait_for_peers(const HalfStepArgs& a, unsigned l
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <class Dens, int L, int K, int ITER, bool P2P>
+// RAGGED = false: ndim == 2*L*K exactly (row stride and every mask fold at compile time);
+// RAGGED = true : ndim < 2*L*K, runtime row stride a.ld and masked tail chunks.
+template <class Dens, int L, int K, int ITER, bool P2P, bool RAGGED>
 __global__ __launch_bounds__(kTPB) void half_step_vec(const HalfStepArgs a)
 {
     static_assert(L >= 1 && L <= 64 && (L & (L - 1)) == 0, "L must be a power of two <= 64");
     static_assert(ITER >= 1 && ITER <= L, "a group's scalar lanes must cover its iterations");
     constexpr int G = 64 / L;          // groups = walkers in flight per wave
     constexpr int W = G * ITER;        // walkers per wave
-    constexpr int ndim = 2 * L * K;
+    const int ndim = RAGGED ? a.ndim : 2 * L * K;        // ragged: chunks past the row's end are skipped
+    const int64_t ld = RAGGED ? (int64_t)a.ld : (int64_t)(2 * L * K);
     const int tid   = blockIdx.x * kTPB + threadIdx.x;
     const int lane  = threadIdx.x & 63;
     const int j     = lane & (L - 1);
@@ -191,6 +196,10 @@ __global__ __launch_bounds__(kTPB) void half_step_vec(const HalfStepArgs a)
     const int gbase = lane & ~(L - 1);                  // first lane of this group
     const int w0    = (tid >> 6) * W;                   // first active index of this wave
     const int nact  = a.n_active;
+    bool cv[K];                                         // chunk k of this lane lies inside the row
+#pragma unroll
+    for (int k = 0; k < K; ++k) cv[k] = !RAGGED || 2 * (k * L + j) < (int)ld;
+    const double2 zero2 = make_double2(0.0, 0.0);
 
     // ---- row layout: own rows of every iteration (independent of the random draws) ----------
     bool    validB[ITER];
@@ -199,9 +208,9 @@ __global__ __launch_bounds__(kTPB) void half_step_vec(const HalfStepArgs a)
     for (int it = 0; it < ITER; ++it) {
         const int i = w0 + it * G + g;
         validB[it] = i < nact;
-        const double2* own = reinterpret_cast<const double2*>(a.pos + (a.own_row0 + (validB[it] ? i : nact - 1)) * ndim);
+        const double2* own = reinterpret_cast<const double2*>(a.pos + (a.own_row0 + (validB[it] ? i : nact - 1)) * ld);
 #pragma unroll
-        for (int k = 0; k < K; ++k) xc[it][k] = own[k * L + j];
+        for (int k = 0; k < K; ++k) xc[it][k] = cv[k] ? own[k * L + j] : zero2;
     }
 
     // ---- scalar layout: one walker per lane (j < ITER) ---------------------------------------
@@ -243,9 +252,9 @@ __global__ __launch_bounds__(kTPB) void half_step_vec(const HalfStepArgs a)
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
             const uint32_t partner = (uint32_t)__builtin_amdgcn_ds_bpermute((gbase + it) * 4, (int)partnerA);
-            const double2* oth = reinterpret_cast<const double2*>(a.pos + (a.oth_row0 + partner) * ndim);
+            const double2* oth = reinterpret_cast<const double2*>(a.pos + (a.oth_row0 + partner) * ld);
 #pragma unroll
-            for (int k = 0; k < K; ++k) xo[it][k] = oth[k * L + j];
+            for (int k = 0; k < K; ++k) xo[it][k] = cv[k] ? oth[k * L + j] : zero2;
         }
     } else {
         // owner rank and row of the partner, resolved once per walker; the row address travels
@@ -254,7 +263,7 @@ __global__ __launch_bounds__(kTPB) void half_step_vec(const HalfStepArgs a)
         const double* base = a.peer_pos[0];
 #pragma unroll
         for (int t = 1; t < 8; ++t) base = (q == (uint32_t)t) ? a.peer_pos[t] : base;
-        const unsigned long long addrA = (unsigned long long)(base + (a.oth_row0 + r) * ndim);
+        const unsigned long long addrA = (unsigned long long)(base + (a.oth_row0 + r) * ld);
         if (a.nranks > 1) wait_for_peers(a, step, lane);   // every rank has finished half-step `step - 1`
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
@@ -263,7 +272,7 @@ __global__ __launch_bounds__(kTPB) void half_step_vec(const HalfStepArgs a)
             const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)(unsigned)(addrA >> 32));
             const double2* oth = reinterpret_cast<const double2*>(((unsigned long long)hi << 32) | lo);
 #pragma unroll
-            for (int k = 0; k < K; ++k) xo[it][k] = oth[k * L + j];
+            for (int k = 0; k < K; ++k) xo[it][k] = cv[k] ? oth[k * L + j] : zero2;
         }
     }
     const Draw dr = draw_finish(a.dc, bits);                            // :252, log z, log u
@@ -306,9 +315,9 @@ __global__ __launch_bounds__(kTPB) void half_step_vec(const HalfStepArgs a)
     for (int it = 0; it < ITER; ++it) {
         const bool accB = ((accmask >> (gbase + it)) & 1ull) != 0;
         if (accB) {                                                     // :261
-            double2* own = reinterpret_cast<double2*>(a.pos + (a.own_row0 + w0 + it * G + g) * ndim);
+            double2* own = reinterpret_cast<double2*>(a.pos + (a.own_row0 + w0 + it * G + g) * ld);
 #pragma unroll
-            for (int k = 0; k < K; ++k) store_row16(&own[k * L + j], xo[it][k]);
+            for (int k = 0; k < K; ++k) if (cv[k]) store_row16(&own[k * L + j], xo[it][k]);
         }
         if (any_w) {
             const double wB = (double)(uint32_t)__builtin_amdgcn_ds_bpermute((gbase + it) * 4, (int)wA);
@@ -319,9 +328,9 @@ __global__ __launch_bounds__(kTPB) void half_step_vec(const HalfStepArgs a)
             }
         }
         if (sample && a.chain != nullptr && validB[it]) {               // :268-269
-            double2* dst = reinterpret_cast<double2*>(a.chain + (sch.slot * a.chain_rows + a.chain_row0 + w0 + it * G + g) * ndim);
+            double2* dst = reinterpret_cast<double2*>(a.chain + (sch.slot * a.chain_rows + a.chain_row0 + w0 + it * G + g) * ld);
 #pragma unroll
-            for (int k = 0; k < K; ++k) dst[k * L + j] = sel2(accB, xo[it][k], xc[it][k]);
+            for (int k = 0; k < K; ++k) if (cv[k]) dst[k * L + j] = sel2(accB, xo[it][k], xc[it][k]);
         }
     }
     if (any_w) {
@@ -341,6 +350,7 @@ struct FlushArgs {
     int64_t       row0;      // first row of this launch in pos / klast
     int32_t       n_active;
     uint32_t      nsamp;     // S
+    int32_t       ld;        // row stride in doubles
 };
 
 template <int L, int K, int ITER>
@@ -348,7 +358,7 @@ __global__ __launch_bounds__(kTPB) void flush_moments_vec(const FlushArgs a)
 {
     constexpr int G = 64 / L;
     constexpr int W = G * ITER;
-    constexpr int ndim = 2 * L * K;
+    const int64_t ld = a.ld;
     const int tid  = blockIdx.x * kTPB + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const int j    = lane & (L - 1);
@@ -363,10 +373,10 @@ __global__ __launch_bounds__(kTPB) void flush_moments_vec(const FlushArgs a)
         if (i < a.n_active) {
             const int64_t row = a.row0 + i;
             const double w = (double)(a.nsamp - a.klast[row]);
-            const double2* x = reinterpret_cast<const double2*>(a.pos + row * ndim);
+            const double2* x = reinterpret_cast<const double2*>(a.pos + row * ld);
 #pragma unroll
             for (int k = 0; k < K; ++k) {
-                const double2 v = x[k * L + j];
+                const double2 v = 2 * (k * L + j) < (int)ld ? x[k * L + j] : make_double2(0.0, 0.0);
                 ms[k].x += v.x * w; ms[k].y += v.y * w;
                 mq[k].x += (v.x * v.x) * w; mq[k].y += (v.y * v.y) * w;
             }
@@ -397,17 +407,18 @@ __global__ __launch_bounds__(256) void half_step_generic(const HalfStepArgs a)
     const bool sample = (sch.flags & kSample) != 0;
     const int64_t gw = a.own_row0 + tid;                                // row in pos / index in logp, naccept
     const Draw dr = draw_step(a.dc, step, (uint64_t)(a.gw0 + tid));
-    double* own = a.pos + gw * ndim;
+    const int64_t ld = a.ld;
+    double* own = a.pos + gw * ld;
     const double* oth;
     if constexpr (!P2P) {
-        oth = a.pos + (a.oth_row0 + dr.partner) * ndim;
+        oth = a.pos + (a.oth_row0 + dr.partner) * ld;
     } else {
         const uint32_t q = dr.partner / a.hloc;
         const uint32_t r = dr.partner - q * a.hloc;
         const double* base = a.peer_pos[0];
 #pragma unroll
         for (int t = 1; t < 8; ++t) base = (q == (uint32_t)t) ? a.peer_pos[t] : base;
-        oth = base + (a.oth_row0 + r) * ndim;
+        oth = base + (a.oth_row0 + r) * ld;
     }
     const double p0 = a.logp[gw];
 
@@ -428,7 +439,7 @@ __global__ __launch_bounds__(256) void half_step_generic(const HalfStepArgs a)
             const double xcd = own[d];
             const double cur = acc ? fma(dr.z, xcd - oth[d], oth[d]) : xcd;
             if (acc) own[d] = cur;                                      // :261
-            if (do_chain) a.chain[row * ndim + d] = cur;                // :269
+            if (do_chain) a.chain[row * ld + d] = cur;                  // :269
             if (do_mom) {
                 const int64_t idx = (int64_t)d * a.macc_stride + tid;
                 a.msum[idx] += cur;
@@ -446,13 +457,13 @@ __global__ __launch_bounds__(256) void half_step_generic(const HalfStepArgs a)
 // Initial log-pdfs, src/samplers.jl:209.
 template <class Dens>
 __global__ __launch_bounds__(256) void logpdf_rows(const double* __restrict__ pos, double* __restrict__ logp,
-                                                   int64_t nrows, int ndim, DensityParams dp)
+                                                   int64_t nrows, int ndim, int ld, DensityParams dp)
 {
     const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (r >= nrows) return;
     typename Dens::Seq q;
     Dens::seq_init(q);
-    for (int d = 0; d < ndim; ++d) Dens::seq_add(q, pos[r * ndim + d], d, dp);
+    for (int d = 0; d < ndim; ++d) Dens::seq_add(q, pos[r * ld + d], d, dp);
     logp[r] = Dens::seq_finish(q, ndim, dp);
 }
 

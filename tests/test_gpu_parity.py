@@ -82,6 +82,21 @@ CASES = [
     ("rosen", 256, 64, 30, 10, 1),      # chained Rosenbrock on the vector kernel (C3 shape)
     ("rosen", 2100, 1024, 4, 1, 1),     # K > 1: neighbour wraps across chunks
     ("lognormal", 100, 1, 200, 100, 1),
+    # ragged sizes: ndim not a power of two / odd (masked last chunk, padded row stride)
+    ("gauss", 200, 3, 60, 20, 1),
+    ("gauss_shift", 256, 5, 60, 20, 2),
+    ("expo", 128, 7, 50, 10, 1),
+    ("rosen", 128, 10, 80, 20, 1),
+    ("rosen", 130, 9, 80, 20, 1),
+    ("gauss", 300, 33, 40, 10, 1),
+    ("rosen", 256, 50, 40, 10, 1),
+    ("lognormal", 128, 6, 60, 20, 1),
+    ("gauss", 512, 100, 30, 10, 1),
+    ("gauss_shift", 600, 200, 20, 5, 1),
+    ("rosen", 700, 300, 10, 3, 1),
+    ("expo", 1100, 1000, 6, 2, 1),
+    ("gauss", 1100, 1023, 6, 2, 1),
+    ("gauss", 1040, 1026, 4, 1, 1),     # beyond the vector kernel's 1024: generic kernel
 ]
 
 
