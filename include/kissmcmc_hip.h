@@ -57,7 +57,9 @@ typedef enum kmc_density {
     KMC_EXPONENTIAL  = 1, /* any x_i < 0 ? -inf : -p0 * sum_i x_i                p = {rate}           (reference README.md:15) */
     KMC_ROSENBROCK   = 2, /* -sum_{i<N-1} [p1 (x_{i+1}-x_i^2)^2 + (p0-x_i)^2]/p2 p = {a, b, scale}    (reference test/runtests.jl:68 at N=2, {1,100,20}) */
     KMC_LOGNORMAL    = 3, /* any x_i <= 0 ? -inf : sum_i [-log x_i - (log x_i - p0)^2/(2 p1^2)]  p = {mu, sigma} */
-    KMC_MVNORMAL2    = 4  /* ndim == 2: -1/2 (d' P d), d = x - {p0,p1}, P = [[p2,p3],[p3,p4]] (precision matrix) */
+    KMC_MVNORMAL2    = 4, /* ndim == 2: -1/2 (d' P d), d = x - {p0,p1}, P = [[p2,p3],[p3,p4]] (precision matrix) */
+    KMC_USER_DENSITY = 100 /* runtime-compiled: sum_d term(x_d) + sum_{d<n-1} pair(x_d, x_{d+1}); kmc_config.user_density
+                              holds the handle made by kmc_user_density_create; params[0..5] are passed to it as p[] */
 } kmc_density;
 
 enum {
@@ -93,6 +95,7 @@ typedef struct kmc_config {
     int32_t  device;        /* HIP device ordinal */
     int32_t  shard_rank;    /* walker sharding: this sampler updates slice shard_rank ...          */
     int32_t  shard_count;   /* ... of shard_count of EACH half; 1 = the whole ensemble (default 0 -> 1) */
+    void*    user_density;  /* kmc_user_density* when density == KMC_USER_DENSITY, else NULL */
 } kmc_config;
 
 /* Host output buffers of the one-shot call; any pointer may be NULL. */
@@ -111,6 +114,7 @@ typedef struct kmc_outputs {
 } kmc_outputs;
 
 typedef struct kmc_sampler kmc_sampler; /* opaque */
+typedef struct kmc_user_density kmc_user_density; /* opaque */
 
 /* ---- library ---- */
 int         kmc_version(void);
@@ -124,6 +128,15 @@ kmc_status  kmc_validate(const kmc_config* cfg);
 /* Stretch-factor helpers (host): src/samplers.jl:224, :227. */
 double      kmc_g_pdf(double z, double a);
 double      kmc_cdf_g_inv(double u, double a);
+
+/* ---- user-supplied log-densities: the device-side stand-in for the arbitrary `pdf` closure of
+ *      src/samplers.jl:257.  Two C expressions are compiled at run time (hiprtc, gfx950) into the
+ *      same kernels:  log p(x) = sum_d TERM + sum_{d<n-1} PAIR, where
+ *        term_expr may use  x (= x_d), d, n (= ndim), p (const double*, = params[0..5]);
+ *        pair_expr may use  x (= x_d), y (= x_{d+1}), d, n, p;   NULL/"" = no pair term.
+ *      A term may evaluate to -INFINITY to reject a proposal.  Not available with KMC_P2P. */
+kmc_status  kmc_user_density_create(const char* term_expr, const char* pair_expr, kmc_user_density** out);
+void        kmc_user_density_destroy(kmc_user_density* ud);
 
 /* ---- one-shot: emcee + _emcee, src/samplers.jl:188-293 ---- */
 kmc_status  kmc_emcee_run(const kmc_config* cfg, const double* theta0 /* host [nwalkers][ndim] */,
@@ -185,6 +198,9 @@ kmc_status  kmc_sampler_get_chain(kmc_sampler* s, double* chain, double* chain_l
 /* logp[i] = log pdf(pos[i]) for nrows rows, src/samplers.jl:209. */
 kmc_status  kmc_logpdf_eval(const kmc_config* cfg, const double* pos_dev, double* logp_dev,
                             int64_t nrows, void* hip_stream);
+
+/* Same on dense host rows [nrows][ndim] (allocates, copies, evaluates, copies back). */
+kmc_status  kmc_logpdf_eval_host(const kmc_config* cfg, const double* pos_host, double* logp_host, int64_t nrows);
 
 #ifdef __cplusplus
 }

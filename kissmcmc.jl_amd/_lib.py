@@ -17,6 +17,7 @@ OK, ERR_A_SCALE, ERR_ODD_WALKERS, ERR_TOO_FEW_WALKERS, ERR_BAD_ARG, ERR_NONFINIT
     ERR_HIP, ERR_OOM, ERR_NO_DEVICE, ERR_UNSUPPORTED = range(10)
 # kmc_density
 GAUSSIAN_ISO, EXPONENTIAL, ROSENBROCK, LOGNORMAL, MVNORMAL2 = range(5)
+USER_DENSITY = 100
 F64 = 0
 STORE_CHAIN, STORE_LOGP, MOMENTS, NO_GRAPH, P2P = 1, 2, 4, 8, 16
 P2P_HANDLE_BYTES = 128
@@ -29,7 +30,8 @@ SYMBOLS = [
     "kmc_sampler_sync", "kmc_sampler_last_run_ms", "kmc_sampler_generation", "kmc_sampler_nsamples",
     "kmc_sampler_launch_count", "kmc_sampler_device_ptr", "kmc_sampler_get_positions",
     "kmc_sampler_get_logp", "kmc_sampler_get_naccept", "kmc_sampler_get_accept_ratio",
-    "kmc_sampler_get_moments", "kmc_sampler_get_chain", "kmc_logpdf_eval",
+    "kmc_sampler_get_moments", "kmc_sampler_get_chain", "kmc_logpdf_eval", "kmc_logpdf_eval_host",
+    "kmc_user_density_create", "kmc_user_density_destroy",
 ]
 
 
@@ -49,6 +51,7 @@ class Config(C.Structure):
         ("device", C.c_int32),
         ("shard_rank", C.c_int32),
         ("shard_count", C.c_int32),
+        ("user_density", C.c_void_p),
     ]
 
 
@@ -138,6 +141,10 @@ def lib() -> C.CDLL:
     L.kmc_sampler_get_moments.argtypes = [vp, dp, dp, ip]
     L.kmc_sampler_get_chain.argtypes = [vp, dp, dp]
     L.kmc_logpdf_eval.argtypes = [cfgp, vp, vp, C.c_int64, vp]
+    L.kmc_logpdf_eval_host.argtypes = [cfgp, dp, dp, C.c_int64]
+    L.kmc_user_density_create.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(vp)]
+    L.kmc_user_density_destroy.restype = None
+    L.kmc_user_density_destroy.argtypes = [vp]
     _lib = L
     return L
 

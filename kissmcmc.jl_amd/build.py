@@ -33,7 +33,8 @@ def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str =
     """Compile csrc/*.hip into libkissmcmc_hip.so next to this file (in-tree, so it travels).
     ``extra_flags``/``out`` build experiment variants (e.g. ``-DKMC_STORE_SC1``) side by side."""
     if force or out != LIB or stale():
-        cmd = [_hipcc(), *FLAGS, *extra_flags, *[os.path.join(CSRC, f) for f in SOURCES], "-o", out + ".tmp"]
+        cmd = [_hipcc(), *FLAGS, *extra_flags, *[os.path.join(CSRC, f) for f in SOURCES], "-o", out + ".tmp",
+               "-lhiprtc", "-ldl"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -5,8 +5,14 @@
 // two dependent launches per generation, replayed from a hipGraph in chunks of
 // kGraphChunk generations (the kernel boundary is the join of src/samplers.jl:273).
 #include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
+#include <dlfcn.h>
 
 #include <cmath>
+#include <fstream>
+#include <map>
+#include <mutex>
+#include <sstream>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -19,6 +25,8 @@
 using namespace kmc;
 
 #define KMC_EXPORT extern "C" __attribute__((visibility("default")))
+
+KMC_EXPORT int kmc_version(void);
 
 namespace {
 
@@ -49,11 +57,12 @@ kmc_status fail(kmc_status st, const std::string& msg)
 constexpr int64_t kGraphChunk = 64;   // generations per hipGraph replay (128 kernel nodes + 1)
 
 using HalfStepFn = void (*)(const HalfStepArgs);
-using LogpdfFn = void (*)(const double*, double*, int64_t, int, int, DensityParams);
+using LogpdfFn = void (*)(const LogpdfArgs);
 
 struct Plan {
     HalfStepFn fn = nullptr;
     bool vec = false;
+    bool ragged = false;
     int L = 1, K = 1, ITER = 1;
 };
 
@@ -191,6 +200,16 @@ Plan make_plan(const kmc_config& c, int64_t n_active)
     }
     const bool ragged = L > 0 && 2 * L * K != c.ndim;
     if (ragged && iter > 4) iter = 4;
+    p.ragged = ragged;
+    if (c.density == KMC_USER_DENSITY) {
+        // kernels are compiled for exactly this geometry when the sampler is created
+        if (!force_generic && L > 0 && 2 * L * K >= c.ndim && iter <= L && iter * K <= 16) {
+            p.vec = true; p.L = L; p.K = K; p.ITER = iter;
+        } else {
+            p.vec = false; p.L = 1; p.K = 1; p.ITER = 1;
+        }
+        return p;
+    }
     lookup(c.density, L, K, iter, (c.flags & KMC_P2P) != 0, ragged, &vec, &gen, &lp);
     if (!force_generic && L > 0 && 2 * L * K >= c.ndim && vec != nullptr) {
         p.fn = vec; p.vec = true; p.L = L; p.K = K; p.ITER = iter;
@@ -203,8 +222,14 @@ Plan make_plan(const kmc_config& c, int64_t n_active)
 kmc_status digest_params(const kmc_config& c, DensityParams* dp)
 {
     for (double& v : dp->p) v = 0.0;
+    dp->ndim = (int32_t)c.ndim;
+    dp->pad_ = 0;
     const double* p = c.params;
     switch (c.density) {
+    case KMC_USER_DENSITY:
+        if (!c.user_density) return fail(KMC_ERR_BAD_ARG, "KMC_USER_DENSITY needs kmc_config.user_density");
+        for (int i = 0; i < 6; ++i) dp->p[i] = p[i];
+        return KMC_OK;
     case KMC_GAUSSIAN_ISO:
         if (!(p[1] > 0.0)) return fail(KMC_ERR_BAD_ARG, "gaussian: sigma must be > 0");
         dp->p[0] = p[0]; dp->p[1] = 1.0 / p[1];
@@ -231,6 +256,137 @@ kmc_status digest_params(const kmc_config& c, DensityParams* dp)
 
 }  // namespace
 
+// ------------------------------------------------------------------------------------------
+// User-supplied densities: two C expressions compiled at run time (hiprtc) into the same kernels.
+// ------------------------------------------------------------------------------------------
+struct kmc_user_density {
+    std::string term, pair;
+    bool has_pair = false;
+    std::mutex mu;
+    std::map<std::string, std::vector<char>> code;   // geometry key -> gfx950 code object
+};
+
+namespace {
+
+struct UserKernels {
+    hipModule_t mod = nullptr;
+    hipFunction_t vec = nullptr, generic = nullptr, logpdf = nullptr;
+};
+
+std::string read_file(const std::string& path)
+{
+    std::ifstream f(path, std::ios::binary);
+    std::stringstream ss;
+    ss << f.rdbuf();
+    return ss.str();
+}
+
+// directory of this shared library (the kernel headers are shipped next to it in csrc/)
+std::string library_dir()
+{
+    Dl_info info;
+    if (dladdr(reinterpret_cast<void*>(&kmc_version), &info) && info.dli_fname) {
+        std::string p(info.dli_fname);
+        const size_t k = p.find_last_of('/');
+        return k == std::string::npos ? std::string(".") : p.substr(0, k);
+    }
+    return ".";
+}
+
+kmc_status compile_user(kmc_user_density* ud, bool with_vec, int L, int K, int iter, bool ragged,
+                        const std::vector<char>** out)
+{
+    char key[64];
+    std::snprintf(key, sizeof(key), "%d:%d,%d,%d,%d", (int)with_vec, L, K, iter, (int)ragged);
+    std::lock_guard<std::mutex> lock(ud->mu);
+    auto it = ud->code.find(key);
+    if (it != ud->code.end()) { *out = &it->second; return KMC_OK; }
+
+    const char* envdir = std::getenv("KMC_CSRC_DIR");
+    const std::string dir = envdir ? std::string(envdir) : library_dir() + "/csrc";
+    const std::string h_dev = read_file(dir + "/kmc_device.hpp"), h_ker = read_file(dir + "/kmc_kernels.hpp");
+    if (h_dev.empty() || h_ker.empty())
+        return fail(KMC_ERR_BAD_ARG, "user density: kernel headers not found in " + dir + " (set KMC_CSRC_DIR)");
+
+    std::ostringstream src;
+    src << "#define KMC_TPB " << kTPB << "\n#include \"kmc_kernels.hpp\"\n"
+        << "namespace {\nstruct UserF {\n"
+        << "  static constexpr bool kHasPair = " << (ud->has_pair ? "true" : "false") << ";\n"
+        << "  __device__ static double term(double x, int d, int n, const double* p) { (void)d; (void)n; (void)p; return (" << ud->term << "); }\n"
+        << "  __device__ static double pair(double x, double y, int d, int n, const double* p) { (void)x; (void)y; (void)d; (void)n; (void)p; return ("
+        << (ud->has_pair ? ud->pair : std::string("0.0")) << "); }\n};\n}\n"
+        << "using UD = kmc::TermPairDensity<UserF>;\n"
+        << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_generic(const kmc::HalfStepArgs a) { kmc::half_step_generic_body<UD, false>(a); }\n"
+        << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_logpdf(const kmc::LogpdfArgs a) { kmc::logpdf_rows_body<UD>(a); }\n";
+    if (with_vec)
+        src << "extern \"C\" __global__ __launch_bounds__(" << kTPB << ") void kmc_user_vec(const kmc::HalfStepArgs a) { kmc::half_step_vec_body<UD, "
+            << L << ", " << K << ", " << iter << ", false, " << (ragged ? "true" : "false") << ">(a); }\n";
+    const std::string text = src.str();
+
+    hiprtcProgram prog = nullptr;
+    const char* headers[2] = {h_ker.c_str(), h_dev.c_str()};
+    const char* names[2] = {"kmc_kernels.hpp", "kmc_device.hpp"};
+    if (hiprtcCreateProgram(&prog, text.c_str(), "kmc_user_density.hip", 2, headers, names) != HIPRTC_SUCCESS)
+        return fail(KMC_ERR_HIP, "hiprtcCreateProgram failed");
+    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"};
+    const hiprtcResult r = hiprtcCompileProgram(prog, 4, opts);
+    if (r != HIPRTC_SUCCESS) {
+        size_t n = 0;
+        hiprtcGetProgramLogSize(prog, &n);
+        std::string log(n, '\0');
+        if (n) hiprtcGetProgramLog(prog, &log[0]);
+        hiprtcDestroyProgram(&prog);
+        return fail(KMC_ERR_BAD_ARG, "user density does not compile:\n" + log);
+    }
+    size_t n = 0;
+    hiprtcGetCodeSize(prog, &n);
+    std::vector<char> code(n);
+    hiprtcGetCode(prog, code.data());
+    hiprtcDestroyProgram(&prog);
+    auto ins = ud->code.emplace(key, std::move(code));
+    *out = &ins.first->second;
+    return KMC_OK;
+}
+
+kmc_status load_user(kmc_user_density* ud, bool with_vec, int L, int K, int iter, bool ragged, UserKernels* uk)
+{
+    const std::vector<char>* code = nullptr;
+    KMC_TRY(compile_user(ud, with_vec, L, K, iter, ragged, &code));
+    HIP_TRY(hipModuleLoadData(&uk->mod, code->data()));
+    HIP_TRY(hipModuleGetFunction(&uk->generic, uk->mod, "kmc_user_generic"));
+    HIP_TRY(hipModuleGetFunction(&uk->logpdf, uk->mod, "kmc_user_logpdf"));
+    if (with_vec) HIP_TRY(hipModuleGetFunction(&uk->vec, uk->mod, "kmc_user_vec"));
+    return KMC_OK;
+}
+
+template <class Args>
+hipError_t launch_module(hipFunction_t f, unsigned grid, unsigned tpb, hipStream_t st, const Args& args)
+{
+    Args copy = args;
+    size_t size = sizeof(Args);
+    void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &copy, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+    return hipModuleLaunchKernel(f, grid, 1, 1, tpb, 1, 1, 0, st, nullptr, extra);
+}
+
+}  // namespace
+
+KMC_EXPORT kmc_status kmc_user_density_create(const char* term_expr, const char* pair_expr, kmc_user_density** out)
+{
+    if (!term_expr || !out) return fail(KMC_ERR_BAD_ARG, "null argument");
+    *out = nullptr;
+    kmc_user_density* ud = new kmc_user_density();
+    ud->term = term_expr;
+    ud->has_pair = pair_expr != nullptr && pair_expr[0] != '\0';
+    if (ud->has_pair) ud->pair = pair_expr;
+    const std::vector<char>* code = nullptr;
+    const kmc_status st = compile_user(ud, false, 0, 0, 0, false, &code);   // syntax check now, not at first use
+    if (st != KMC_OK) { delete ud; return st; }
+    *out = ud;
+    return KMC_OK;
+}
+
+KMC_EXPORT void kmc_user_density_destroy(kmc_user_density* ud) { delete ud; }
+
 struct kmc_sampler {
     kmc_config cfg{};
     int64_t h = 0, h_loc = 0, active_begin = 0, nlocal = 0, nsamples = 0;
@@ -238,6 +394,8 @@ struct kmc_sampler {
     DensityParams dp{};
     Plan plan{};
     LogpdfFn logpdf_fn = nullptr;
+    kmc_user_density* user = nullptr;     // KMC_USER_DENSITY: kernels come from a runtime-compiled module
+    UserKernels uk{};
     int grid = 0;
     int tpb = 256;
     hipStream_t stream = nullptr;
@@ -318,8 +476,12 @@ HalfStepArgs make_args(const kmc_sampler* s, int half, bool graph_mode, int64_t 
 kmc_status launch_half(kmc_sampler* s, int half, bool graph_mode, int64_t gen_offset)
 {
     const HalfStepArgs a = make_args(s, half, graph_mode, gen_offset);
-    hipLaunchKernelGGL(s->plan.fn, dim3(s->grid), dim3(s->tpb), 0, s->stream, a);
-    HIP_TRY(hipGetLastError());
+    if (s->user) {
+        HIP_TRY(launch_module(s->plan.vec ? s->uk.vec : s->uk.generic, (unsigned)s->grid, (unsigned)s->tpb, s->stream, a));
+    } else {
+        hipLaunchKernelGGL(s->plan.fn, dim3(s->grid), dim3(s->tpb), 0, s->stream, a);
+        HIP_TRY(hipGetLastError());
+    }
     if (s->p2p && s->cfg.shard_count > 1) {
         // the kernel boundary puts this half-step's rows in memory; then publish the progress
         SignalArgs sg{};
@@ -439,6 +601,7 @@ KMC_EXPORT kmc_status kmc_validate(const kmc_config* c)
     if (c->nwalkers < c->ndim + 2) return fail(KMC_ERR_TOO_FEW_WALKERS, kmc_status_string(KMC_ERR_TOO_FEW_WALKERS));
     if (c->nwalkers / 2 >= (int64_t)1 << 31 || c->ndim >= (int64_t)1 << 24)
         return fail(KMC_ERR_UNSUPPORTED, "ensemble too large");
+    if (c->density == KMC_USER_DENSITY && !c->user_density) return fail(KMC_ERR_BAD_ARG, "KMC_USER_DENSITY needs kmc_config.user_density");
     if (c->density == KMC_ROSENBROCK && c->ndim < 2) return fail(KMC_ERR_BAD_ARG, "rosenbrock needs ndim >= 2");
     if (c->density == KMC_MVNORMAL2 && c->ndim != 2) return fail(KMC_ERR_BAD_ARG, "mvnormal2 needs ndim == 2");
     const int P = c->shard_count <= 0 ? 1 : c->shard_count;
@@ -488,7 +651,12 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
     kmc_status st = digest_params(*cfg, &s->dp);
     if (st != KMC_OK) { delete s; return st; }
     s->plan = make_plan(s->cfg, s->h_loc);
-    {
+    if (cfg->density == KMC_USER_DENSITY) {
+        if (cfg->flags & KMC_P2P) { delete s; return fail(KMC_ERR_UNSUPPORTED, "user densities are not available with KMC_P2P yet"); }
+        s->user = static_cast<kmc_user_density*>(cfg->user_density);
+        st = load_user(s->user, s->plan.vec, s->plan.L, s->plan.K, s->plan.ITER, s->plan.ragged, &s->uk);
+        if (st != KMC_OK) { delete s; return st; }
+    } else {
         HalfStepFn v, g;
         lookup(cfg->density, 0, 0, 1, false, false, &v, &g, &s->logpdf_fn);
     }
@@ -567,6 +735,7 @@ KMC_EXPORT void kmc_sampler_destroy(kmc_sampler* s)
     (void)hipSetDevice(s->cfg.device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     if (s->graph_exec) (void)hipGraphExecDestroy(s->graph_exec);
+    if (s->uk.mod) (void)hipModuleUnload(s->uk.mod);
     if (s->graph) (void)hipGraphDestroy(s->graph);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
@@ -682,9 +851,15 @@ KMC_EXPORT kmc_status kmc_sampler_set_positions(kmc_sampler* s, const double* th
         HIP_TRY(hipMemset(s->d_flags, 0, 4096));     // callers barrier across ranks before running
         HIP_TRY(hipMemset(s->d_err, 0, 64));
     }
-    hipLaunchKernelGGL(s->logpdf_fn, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s->stream,
-                       (const double*)s->d_pos, s->d_logp, (int64_t)nw, (int)nd, (int)s->ld, s->dp);   // :209-210
-    HIP_TRY(hipGetLastError());
+    {
+        const LogpdfArgs la{s->d_pos, s->d_logp, (int64_t)nw, (int32_t)nd, (int32_t)s->ld, s->dp};   // :209-210
+        if (s->user) {
+            HIP_TRY(launch_module(s->uk.logpdf, (unsigned)((nw + 255) / 256), 256u, s->stream, la));
+        } else {
+            hipLaunchKernelGGL(s->logpdf_fn, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s->stream, la);
+            HIP_TRY(hipGetLastError());
+        }
+    }
     std::vector<double> lp(nw);
     HIP_TRY(hipMemcpyAsync(lp.data(), s->d_logp, nw * sizeof(double), hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipMemsetAsync(s->d_naccept, 0, nw * sizeof(uint32_t), s->stream));
@@ -941,12 +1116,50 @@ KMC_EXPORT kmc_status kmc_logpdf_eval(const kmc_config* cfg, const double* pos_d
     if (!cfg || !pos_dev || !logp_dev || nrows < 0) return fail(KMC_ERR_BAD_ARG, "bad argument");
     DensityParams dp;
     KMC_TRY(digest_params(*cfg, &dp));
+    if (nrows == 0) return KMC_OK;
+    const LogpdfArgs la{pos_dev, logp_dev, nrows, (int32_t)cfg->ndim, (int32_t)cfg->ndim, dp};
+    const unsigned grid = (unsigned)((nrows + 255) / 256);
+    if (cfg->density == KMC_USER_DENSITY) {
+        UserKernels uk;
+        KMC_TRY(load_user(static_cast<kmc_user_density*>(cfg->user_density), false, 0, 0, 0, false, &uk));
+        const hipError_t e = launch_module(uk.logpdf, grid, 256u, (hipStream_t)hip_stream, la);
+        if (e == hipSuccess) (void)hipStreamSynchronize((hipStream_t)hip_stream);   // the module is unloaded below
+        (void)hipModuleUnload(uk.mod);
+        HIP_TRY(e);
+        return KMC_OK;
+    }
     HalfStepFn v, g;
     LogpdfFn lp = nullptr;
     if (!lookup(cfg->density, 0, 0, 1, false, false, &v, &g, &lp)) return fail(KMC_ERR_BAD_ARG, "unknown density id");
-    if (nrows == 0) return KMC_OK;
-    hipLaunchKernelGGL(lp, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream,
-                       pos_dev, logp_dev, nrows, (int)cfg->ndim, (int)cfg->ndim, dp);
+    hipLaunchKernelGGL(lp, dim3(grid), dim3(256), 0, (hipStream_t)hip_stream, la);
     HIP_TRY(hipGetLastError());
+    return KMC_OK;
+}
+
+// Host-buffer convenience: logp[i] = log pdf(pos[i]) for dense host rows (used by the host shims for
+// make_theta0s' `pdf(theta) > -Inf` test with runtime-compiled densities).
+KMC_EXPORT kmc_status kmc_logpdf_eval_host(const kmc_config* cfg, const double* pos_host, double* logp_host, int64_t nrows)
+{
+    if (!cfg || !pos_host || !logp_host || nrows < 0) return fail(KMC_ERR_BAD_ARG, "bad argument");
+    if (nrows == 0) return KMC_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        (void)hipGetLastError();
+        return fail(KMC_ERR_NO_DEVICE, "no HIP device visible");
+    }
+    HIP_TRY(hipSetDevice(cfg->device));
+    double *dpos = nullptr, *dlp = nullptr;
+    const size_t nb = (size_t)nrows * (size_t)cfg->ndim * sizeof(double);
+    HIP_TRY(hipMalloc(&dpos, nb));
+    hipError_t e = hipMalloc(&dlp, (size_t)nrows * sizeof(double));
+    kmc_status st = KMC_OK;
+    if (e == hipSuccess) e = hipMemcpy(dpos, pos_host, nb, hipMemcpyHostToDevice);
+    if (e == hipSuccess) st = kmc_logpdf_eval(cfg, dpos, dlp, nrows, nullptr);
+    if (e == hipSuccess && st == KMC_OK) e = hipDeviceSynchronize();
+    if (e == hipSuccess && st == KMC_OK) e = hipMemcpy(logp_host, dlp, (size_t)nrows * sizeof(double), hipMemcpyDeviceToHost);
+    (void)hipFree(dpos);
+    (void)hipFree(dlp);
+    if (st != KMC_OK) return st;
+    HIP_TRY(e);
     return KMC_OK;
 }

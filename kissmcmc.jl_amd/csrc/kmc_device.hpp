@@ -7,8 +7,18 @@
 // Arithmetic contract (mirrored by the CPU oracle so that accept decisions and positions agree
 // bit for bit): compiled with -ffp-contract=off; every fused multiply-add is an explicit fma().
 #pragma once
+#ifndef __HIPCC_RTC__            // hiprtc (runtime-compiled user densities) brings its own HIP prelude
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#else
+typedef int                int32_t;
+typedef unsigned int       uint32_t;
+typedef long long          int64_t;
+typedef unsigned long long uint64_t;
+#ifndef INFINITY
+#define INFINITY (__builtin_inf())
+#endif
+#endif
 
 namespace kmc {
 
@@ -92,7 +102,7 @@ __device__ __forceinline__ bool accept_test(const Draw& d, double p1, double p0)
 //          sum S_j; the kernel reduces over lanes and calls finish(S).
 // Parameters are pre-digested on the host into DensityParams.
 // ------------------------------------------------------------------------------------------
-struct DensityParams { double p[6]; };
+struct DensityParams { double p[6]; int32_t ndim; int32_t pad_; };
 
 // ---- cross-lane helpers (wave64; DPP where the pattern allows, LDS crossbar otherwise) ----
 template <int CTRL>
@@ -332,6 +342,51 @@ struct MvNormal2 {   // p = {m1, m2, P11, P12, P22}
         }
     }
     __device__ static double seq_finish(const Seq& q, int, const DensityParams&) { return q.r; }
+};
+
+// ------------------------------------------------------------------------------------------
+// User-supplied densities (runtime-compiled with hiprtc, the device-side answer to the reference's
+// arbitrary `pdf` closure, src/samplers.jl:257):
+//     log p(x) = sum_d F::term(x_d, d, n, p)  +  sum_{d < n-1} F::pair(x_d, x_{d+1}, d, n, p)
+// F is a functor struct generated from the user's two C expressions.  A term may be -INFINITY to
+// reject a proposal (it propagates through the sums).
+// ------------------------------------------------------------------------------------------
+template <class F>
+struct TermPairDensity {
+    static constexpr bool kHasFrag = true;
+    struct Seq { double s, prev; };
+    __device__ static void seq_init(Seq& q) { q.s = 0.0; q.prev = 0.0; }
+    __device__ static void seq_add(Seq& q, double x, int d, const DensityParams& P)
+    {
+        if (F::kHasPair && d > 0) q.s += F::pair(q.prev, x, d - 1, P.ndim, P.p);
+        q.s += F::term(x, d, P.ndim, P.p);
+        q.prev = x;
+    }
+    __device__ static double seq_finish(const Seq& q, int, const DensityParams&) { return q.s; }
+
+    template <int L, int K>
+    __device__ static double frag_partial(const double2 (&y)[K], int j, int ndim, const DensityParams& P)
+    {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int e0 = 2 * (k * L + j);
+            const double x0 = y[k].x, x1 = y[k].y;
+            if (e0 < ndim) s += F::term(x0, e0, ndim, P.p);
+            if (e0 + 1 < ndim) s += F::term(x1, e0 + 1, ndim, P.p);
+            if constexpr (F::kHasPair) {
+                double nxt = group_shfl_down1<L>(x0);           // executed by every lane (no divergence)
+                if (k + 1 < K) {
+                    const double wrap = group_bcast0<L>(y[k + 1 < K ? k + 1 : k].x);
+                    nxt = (j == L - 1) ? wrap : nxt;
+                }
+                if (e0 < ndim - 1) s += F::pair(x0, x1, e0, ndim, P.p);
+                if (e0 + 1 < ndim - 1) s += F::pair(x1, nxt, e0 + 1, ndim, P.p);
+            }
+        }
+        return s;
+    }
+    __device__ static double finish(double S, const DensityParams&) { return S; }
 };
 
 }  // namespace kmc

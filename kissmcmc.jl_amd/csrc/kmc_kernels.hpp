@@ -181,7 +181,7 @@ __device__ __forceinline__ void wait_for_peers(const HalfStepArgs& a, unsigned l
 // RAGGED = false: ndim == 2*L*K exactly (row stride and every mask fold at compile time);
 // RAGGED = true : ndim < 2*L*K, runtime row stride a.ld and masked tail chunks.
 template <class Dens, int L, int K, int ITER, bool P2P, bool RAGGED>
-__global__ __launch_bounds__(kTPB) void half_step_vec(const HalfStepArgs a)
+__device__ __forceinline__ void half_step_vec_body(const HalfStepArgs& a)
 {
     static_assert(L >= 1 && L <= 64 && (L & (L - 1)) == 0, "L must be a power of two <= 64");
     static_assert(ITER >= 1 && ITER <= L, "a group's scalar lanes must cover its iterations");
@@ -339,6 +339,12 @@ __global__ __launch_bounds__(kTPB) void half_step_vec(const HalfStepArgs a)
     }
 }
 
+template <class Dens, int L, int K, int ITER, bool P2P, bool RAGGED>
+__global__ __launch_bounds__(kTPB) void half_step_vec(const HalfStepArgs a)
+{
+    half_step_vec_body<Dens, L, K, ITER, P2P, RAGGED>(a);
+}
+
 // Moment read-out: credit every walker's current value with the samples it has stood for since it
 // was last credited (S = samples taken so far), same lane mapping as half_step_vec.
 struct FlushArgs {
@@ -395,7 +401,7 @@ __global__ __launch_bounds__(kTPB) void flush_moments_vec(const FlushArgs a)
 // Generic kernel: one walker per lane, any ndim.
 // ------------------------------------------------------------------------------------------
 template <class Dens, bool P2P>
-__global__ __launch_bounds__(256) void half_step_generic(const HalfStepArgs a)
+__device__ __forceinline__ void half_step_generic_body(const HalfStepArgs& a)
 {
     const int tid = blockIdx.x * 256 + threadIdx.x;
     const SchedEntry sch = schedule_of(a);
@@ -454,17 +460,37 @@ __global__ __launch_bounds__(256) void half_step_generic(const HalfStepArgs a)
     if (sample && a.chain_logp != nullptr) a.chain_logp[row] = acc ? p1 : p0;   // :271
 }
 
+template <class Dens, bool P2P>
+__global__ __launch_bounds__(256) void half_step_generic(const HalfStepArgs a)
+{
+    half_step_generic_body<Dens, P2P>(a);
+}
+
 // Initial log-pdfs, src/samplers.jl:209.
+struct LogpdfArgs {
+    const double* pos;
+    double*       logp;
+    int64_t       nrows;
+    int32_t       ndim;
+    int32_t       ld;
+    DensityParams dp;
+};
+
 template <class Dens>
-__global__ __launch_bounds__(256) void logpdf_rows(const double* __restrict__ pos, double* __restrict__ logp,
-                                                   int64_t nrows, int ndim, int ld, DensityParams dp)
+__device__ __forceinline__ void logpdf_rows_body(const LogpdfArgs& a)
 {
     const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (r >= nrows) return;
+    if (r >= a.nrows) return;
     typename Dens::Seq q;
     Dens::seq_init(q);
-    for (int d = 0; d < ndim; ++d) Dens::seq_add(q, pos[r * ld + d], d, dp);
-    logp[r] = Dens::seq_finish(q, ndim, dp);
+    for (int d = 0; d < a.ndim; ++d) Dens::seq_add(q, a.pos[r * a.ld + d], d, a.dp);
+    a.logp[r] = Dens::seq_finish(q, a.ndim, a.dp);
+}
+
+template <class Dens>
+__global__ __launch_bounds__(256) void logpdf_rows(const LogpdfArgs a)
+{
+    logpdf_rows_body<Dens>(a);
 }
 
 // P2P: after a half-step kernel has drained (kernel boundary = its rows are in memory), tell every

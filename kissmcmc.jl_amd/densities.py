@@ -21,6 +21,7 @@ class DeviceLogPdf:
 
     density_id: int = -1
     name = "?"
+    user_handle = None      # kmc_user_density* for runtime-compiled densities
 
     def params(self):
         raise NotImplementedError
@@ -161,3 +162,70 @@ class MvNormal2(DeviceLogPdf):
         p = self.params()
         d0, d1 = float(theta[0]) - p[0], float(theta[1]) - p[1]
         return -0.5 * (p[2] * d0 * d0 + 2.0 * p[3] * d0 * d1 + p[4] * d1 * d1)
+
+
+class ExprDensity(DeviceLogPdf):
+    """A user-supplied log-density, compiled at run time (hiprtc) into the same HIP kernels -- the
+    device-side answer to the reference's arbitrary ``pdf`` closure (``src/samplers.jl:257``)::
+
+        log p(x) = sum_d  TERM(x_d)  +  sum_{d < n-1}  PAIR(x_d, x_{d+1})
+
+    ``term`` and ``pair`` are C expressions of type double.  ``term`` may use ``x`` (= x_d), ``d``,
+    ``n`` (= ndim) and ``p`` (``params``, up to 6 doubles); ``pair`` may use ``x`` (= x_d), ``y``
+    (= x_{d+1}), ``d``, ``n``, ``p``.  A term may evaluate to ``-INFINITY`` to reject a proposal.
+    Examples: ``ExprDensity("-0.5*x*x")`` (standard normal per dimension);
+    ``ExprDensity("d < n-1 ? -(1-x)*(1-x)/20 : 0.0", "-100*(y-x*x)*(y-x*x)/20")`` (the reference's
+    Rosenbrock test density, ``test/runtests.jl:68``, chained to any ndim).
+
+    Calling the object on a host ``theta`` (what ``make_theta0s`` does) evaluates it on the device.
+    """
+
+    density_id = _lib.USER_DENSITY
+    name = "expr"
+
+    def __init__(self, term: str, pair: str | None = None, params=()):
+        import ctypes as C
+        if len(params) > 6:
+            raise ValueError("at most 6 parameters")
+        self.term, self.pair = str(term), (str(pair) if pair else None)
+        self._params = [float(v) for v in params]
+        self._L = _lib.lib()
+        h = C.c_void_p()
+        _lib.check(self._L.kmc_user_density_create(self.term.encode(), self.pair.encode() if self.pair else None,
+                                                   C.byref(h)))
+        self.user_handle = h
+
+    def __del__(self):
+        try:
+            if self.user_handle is not None:
+                self._L.kmc_user_density_destroy(self.user_handle)
+                self.user_handle = None
+        except Exception:
+            pass
+
+    def params(self):
+        return list(self._params)
+
+    def __repr__(self):
+        return f"ExprDensity(term={self.term!r}, pair={self.pair!r}, params={self._params})"
+
+    def _eval_rows(self, X):
+        import ctypes as C
+        X = np.ascontiguousarray(np.asarray(X, dtype=np.float64))
+        n, nd = X.shape
+        cfg = _lib.Config()
+        cfg.dtype, cfg.density = _lib.F64, self.density_id
+        for i, v in enumerate(self._params):
+            cfg.params[i] = v
+        cfg.nwalkers, cfg.ndim, cfg.nthin, cfg.a_scale = max(2, n + (n & 1)), nd, 1, 2.0
+        cfg.user_density = self.user_handle
+        out = np.empty(n)
+        dp = C.POINTER(C.c_double)
+        _lib.check(self._L.kmc_logpdf_eval_host(C.byref(cfg), X.ctypes.data_as(dp), out.ctypes.data_as(dp), n))
+        return out
+
+    def __call__(self, theta):
+        return float(self._eval_rows(np.atleast_1d(np.asarray(theta, dtype=np.float64))[None, :])[0])
+
+    def finite_rows(self, X):
+        return self._eval_rows(X) > -np.inf

@@ -10,7 +10,7 @@
 # 1:1 by the Python ctypes host (kissmcmc.jl_amd/_lib.py, api.py), which is what the tests drive.
 module KissMCMCHIP
 
-export emcee, make_theta0s, squash_walkers, GaussianIso, Exponential, Rosenbrock, LogNormal, MvNormal2
+export emcee, make_theta0s, squash_walkers, GaussianIso, Exponential, Rosenbrock, LogNormal, MvNormal2, ExprDensity
 
 using Statistics: mean, median, std
 using LinearAlgebra: inv
@@ -41,6 +41,30 @@ density_id(::Rosenbrock) = Cint(2);  params(d::Rosenbrock) = [d.a, d.b, d.scale]
 density_id(::LogNormal) = Cint(3);   params(d::LogNormal) = [d.mu, d.sigma]
 density_id(::MvNormal2) = Cint(4);   params(d::MvNormal2) = [d.mean[1], d.mean[2], d.prec[1,1], 0.5 * (d.prec[1,2] + d.prec[2,1]), d.prec[2,2]]
 
+# Runtime-compiled user density (hiprtc): log p = sum_d term(x_d) + sum_{d<n-1} pair(x_d, x_{d+1}); see
+# kmc_user_density_create in include/kissmcmc_hip.h.  The host call evaluates it on the device.
+mutable struct ExprDensity <: DeviceLogPdf
+    handle::Ptr{Cvoid}; p::Vector{Float64}
+    function ExprDensity(term::String, pair::Union{String,Nothing}=nothing; params=Float64[])
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        st = ccall((:kmc_user_density_create, LIB), Cint, (Cstring, Cstring, Ref{Ptr{Cvoid}}), term, pair === nothing ? "" : pair, h)
+        st == 0 || error("kmc_user_density_create failed: $(last_error())")
+        d = new(h[], collect(Float64, params))
+        finalizer(x -> ccall((:kmc_user_density_destroy, LIB), Cvoid, (Ptr{Cvoid},), x.handle), d)
+        return d
+    end
+end
+density_id(::ExprDensity) = Cint(100); params(d::ExprDensity) = d.p
+user_handle(d::ExprDensity) = d.handle
+user_handle(::DeviceLogPdf) = C_NULL
+function (d::ExprDensity)(x)
+    xs = collect(Float64, x isa Number ? [x] : x); out = Ref(0.0)
+    p8 = ntuple(i -> i <= length(d.p) ? d.p[i] : 0.0, 8)
+    cfg = Ref(KmcConfig(0, Cint(100), p8, 2, length(xs), 0, 0, 1, 2.0, UInt64(0), 0, 0, 0, 1, d.handle))
+    st = ccall((:kmc_logpdf_eval_host, LIB), Cint, (Ref{KmcConfig}, Ptr{Float64}, Ref{Float64}, Int64), cfg, xs, out, 1)
+    st == 0 || error(last_error()); out[]
+end
+
 # ---- C structs (layout checked against the header by tests/test_c_abi.py on the Python mirror) ---
 struct KmcConfig
     dtype::Int32; density::Int32
@@ -48,6 +72,7 @@ struct KmcConfig
     nwalkers::Int64; ndim::Int64; ngenerations::Int64; nburnin::Int64; nthin::Int64
     a_scale::Float64; seed::UInt64
     flags::UInt32; device::Int32; shard_rank::Int32; shard_count::Int32
+    user_density::Ptr{Cvoid}
 end
 
 mutable struct KmcOutputs
@@ -84,7 +109,7 @@ function emcee(pdf::DeviceLogPdf, theta0s; niter=10^5, nburnin=niter ÷ 2, nthin
     end
     p = params(pdf); p8 = ntuple(i -> i <= length(p) ? p[i] : 0.0, 8)
     cfg = Ref(KmcConfig(0, density_id(pdf), p8, nwalkers, ndim, niter_walker, nburnin_walker, nthin,
-                        a_scale, UInt64(seed), 0x3, Int32(device), 0, 1))       # flags: STORE_CHAIN | STORE_LOGP
+                        a_scale, UInt64(seed), 0x3, Int32(device), 0, 1, user_handle(pdf)))   # flags: STORE_CHAIN | STORE_LOGP
     chain = Array{Float64}(undef, ndim, nwalkers, nsamples)
     clogp = Array{Float64}(undef, nwalkers, nsamples)
     acc = Vector{Float64}(undef, nwalkers)

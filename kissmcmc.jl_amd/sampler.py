@@ -54,6 +54,7 @@ class Sampler:
         cfg.flags = flags
         cfg.device = int(device)
         cfg.shard_rank, cfg.shard_count = int(shard_rank), int(shard_count)
+        cfg.user_density = pdf.user_handle     # runtime-compiled density (ExprDensity) or None
         self.cfg = cfg
         self._L = _lib.lib()
         h = C.c_void_p()

@@ -36,11 +36,11 @@ def test_struct_layout_matches_header(kmc, tmp_path):
     src = tmp_path / "layout.c"
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "kissmcmc_hip.h"\n'
                    'int main(void){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(kmc_config), offsetof(kmc_config, nwalkers),'
-                   ' offsetof(kmc_config, seed), offsetof(kmc_config, shard_count), sizeof(kmc_outputs), offsetof(kmc_outputs, device_ms));return 0;}\n')
+                   ' offsetof(kmc_config, seed), offsetof(kmc_config, user_density), sizeof(kmc_outputs), offsetof(kmc_outputs, device_ms));return 0;}\n')
     exe = tmp_path / "layout"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
-    want = [C.sizeof(_lib.Config), _lib.Config.nwalkers.offset, _lib.Config.seed.offset, _lib.Config.shard_count.offset,
+    want = [C.sizeof(_lib.Config), _lib.Config.nwalkers.offset, _lib.Config.seed.offset, _lib.Config.user_density.offset,
             C.sizeof(_lib.Outputs), _lib.Outputs.device_ms.offset]
     assert got == want
 
@@ -84,6 +84,23 @@ def test_g_helpers_known_answers(kmc):
     assert kmc.g_pdf(1 / a - 1e-9, a) == 0.0 and kmc.g_pdf(a + 1e-9, a) == 0.0
     z = np.arange(1 / a, a, 0.001)
     assert np.sum([kmc.g_pdf(v, a) for v in z]) * 0.001 == pytest.approx(1.0, abs=2e-3)
+
+
+def test_user_density_compiles_and_reports_syntax_errors(kmc):
+    """hiprtc runs offline (no GPU needed): a valid expression pair compiles for gfx950, a broken one
+    returns KMC_ERR_BAD_ARG with the compiler's message."""
+    from kissmcmc_jl_amd import _lib
+    d = kmc.ExprDensity("d < n-1 ? -(p[0]-x)*(p[0]-x)/p[2] : 0.0", "-p[1]*(y-x*x)*(y-x*x)/p[2]", params=[1, 100, 20])
+    assert d.user_handle is not None and d.params() == [1.0, 100.0, 20.0]
+    with pytest.raises(kmc.KmcError, match="undeclared identifier 'z'") as e:
+        kmc.ExprDensity("-0.5*x*z")
+    assert e.value.status == _lib.ERR_BAD_ARG
+    with pytest.raises(ValueError):
+        kmc.ExprDensity("x", params=range(7))
+    c = _cfg(_lib, density=_lib.USER_DENSITY)
+    assert _lib.lib().kmc_validate(C.byref(c)) == _lib.ERR_BAD_ARG     # handle missing
+    c.user_density = d.user_handle
+    assert _lib.lib().kmc_validate(C.byref(c)) == _lib.OK
 
 
 def test_product_never_touches_the_oracle():

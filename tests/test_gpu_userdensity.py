@@ -1,0 +1,92 @@
+"""GPU: runtime-compiled user log-densities (ExprDensity, hiprtc) -- the device-side stand-in for the
+reference's arbitrary `pdf` closure (src/samplers.jl:257).  Expressions that restate a menu density
+must reproduce the oracle's chains for that density: identical accept decisions and positions,
+log-pdfs to 1e-12 (different but equivalent arithmetic)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GAUSS = ("-0.5*x*x", None, [])
+ROSEN = ("d < n-1 ? -((p[0]-x)*(p[0]-x))/p[2] : 0.0", "-(p[1]*((y-x*x)*(y-x*x)))/p[2]", [1.0, 100.0, 20.0])
+EXPO = ("x < 0.0 ? -INFINITY : -p[0]*x", None, [1.0])
+
+
+def _run(kmc, pdf, th, G, nburn, seed):
+    nw, nd = th.shape
+    with kmc.Sampler(pdf, nw, nd, G, nburn, 1, 2.0, seed, store_chain=True, store_logp=True, moments=True) as s:
+        s.set_positions(th)
+        s.run(G)
+        s.sync()
+        ch, cl = s.chain()
+        m = s.moments()
+        return dict(pos=s.positions(), logp=s.logp(), nacc=s.naccept(), chain=ch, chain_logp=cl, sum=m[0], n=m[2])
+
+
+def _check(oracle, did, params, th, G, nburn, seed, got):
+    nw, nd = th.shape
+    ref = oracle.emcee(oracle.make_config(did, params, nw, nd, G, nburn, 1, 2.0, seed), th)
+    np.testing.assert_array_equal(got["nacc"], ref["naccept"])
+    np.testing.assert_array_equal(got["pos"], ref["final_pos"])
+    np.testing.assert_array_equal(got["chain"], ref["chain"])
+    tol = 1e-12 * np.maximum(1.0, np.abs(ref["final_logp"]))
+    assert np.all(np.abs(got["logp"] - ref["final_logp"]) <= tol)
+    assert got["n"] == ref["nmoment"]
+    np.testing.assert_allclose(got["sum"], ref["sum"], rtol=1e-11, atol=1e-9)
+
+
+@pytest.mark.parametrize("nw,nd,plan", [(256, 32, ""), (200, 5, ""), (128, 1, ""), (256, 32, "generic"), (600, 200, "")])
+def test_expr_gaussian_equals_menu_gaussian(kmc, oracle, nw, nd, plan, monkeypatch):
+    if plan:
+        monkeypatch.setenv("KMC_PLAN", plan)
+    th = np.random.default_rng(nd).standard_normal((nw, nd))
+    pdf = kmc.ExprDensity(GAUSS[0])
+    got = _run(kmc, pdf, th, 80, 20, 7)          # one graph replay + eager tail
+    _check(oracle, oracle.GAUSSIAN_ISO, [0.0, 1.0], th, 80, 20, 7, got)
+
+
+@pytest.mark.parametrize("nw,nd", [(100, 2), (256, 64), (130, 9), (2100, 1024)])
+def test_expr_rosenbrock_pair_term(kmc, oracle, nw, nd):
+    th = 0.1 * np.random.default_rng(nd).standard_normal((nw, nd))
+    pdf = kmc.ExprDensity(ROSEN[0], ROSEN[1], ROSEN[2])
+    G = 60 if nd < 1000 else 4
+    got = _run(kmc, pdf, th, G, G // 3, 11)
+    _check(oracle, oracle.ROSENBROCK, ROSEN[2], th, G, G // 3, 11, got)
+
+
+def test_expr_exponential_rejects_with_minus_infinity(kmc, oracle):
+    th = 0.5 + 0.1 * np.abs(np.random.default_rng(1).standard_normal((100, 1)))
+    pdf = kmc.ExprDensity(EXPO[0], params=EXPO[2])
+    got = _run(kmc, pdf, th, 300, 150, 3)
+    _check(oracle, oracle.EXPONENTIAL, [1.0], th, 300, 150, 3, got)
+    assert got["pos"].min() >= 0.0
+
+
+def test_expr_density_through_the_drop_in_api(kmc):
+    """README sequence with a user expression instead of a menu density; make_theta0s evaluates the
+    expression on the device for its `pdf(theta) > -Inf` test (src/samplers.jl:336-338)."""
+    logpdf = kmc.ExprDensity("x < 0.0 ? -INFINITY : -x")        # README.md:15
+    assert logpdf(0.5) == -0.5 and logpdf(-1.0) == -np.inf
+    theta0s = kmc.make_theta0s(0.05, 0.1, logpdf, 100, rng=5)   # a third of the first tries are rejected
+    assert theta0s.shape == (100,) and np.all(theta0s >= 0)
+    thetas, acc, logd, blobs = kmc.emcee(logpdf, theta0s, niter=10 ** 5, use_progress_meter=False, seed=8)
+    t, mean_acc = kmc.squash_walkers(thetas, acc)[:2]
+    assert t.shape == (50000,) and abs(mean_acc - 0.745) < 0.02
+    assert abs(t.mean() - 1.0) < 0.08 and t.min() >= 0.0
+    np.testing.assert_allclose(logd, -thetas, rtol=0, atol=1e-15)
+
+
+def test_expr_density_at_c2_size_speed_and_moments(kmc):
+    """Full C2 shape with a user expression: same kernel structure, so the same ballpark speed."""
+    th = np.random.default_rng(3).standard_normal((65536, 32))
+    pdf = kmc.ExprDensity("-0.5*x*x")
+    with kmc.Sampler(pdf, 65536, 32, 2000, 1000, 1, 2.0, 5, moments=True) as s:
+        s.set_positions(th)
+        s.run(2000)
+        s.sync()
+        ms = s.last_run_ms()
+        msum, msq, n = s.moments()
+    mean = msum / n
+    var = msq / n - mean ** 2
+    assert np.all(np.abs(mean) < 0.02) and np.all(np.abs(var - 1.0) < 0.02)
+    assert ms / 4000 * 1e3 < 12.0, f"{ms / 4000 * 1e3:.2f} us per half-step"
