@@ -8,9 +8,10 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(_HERE, "libkissmcmc_hip.so")
-SOURCES = ["kmc_api.hip"]
-HEADERS = ["kmc_device.hpp", "kmc_kernels.hpp", os.path.join("..", "..", "include", "kissmcmc_hip.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+SOURCES = ["kmc_api.hip", "kmc_inst_gaussian_iso.hip", "kmc_inst_exponential.hip", "kmc_inst_rosenbrock.hip",
+           "kmc_inst_lognormal.hip", "kmc_inst_mvnormal2.hip"]
+HEADERS = ["kmc_device.hpp", "kmc_kernels.hpp", "kmc_tables.hpp", os.path.join("..", "..", "include", "kissmcmc_hip.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 
 
@@ -30,15 +31,32 @@ def stale() -> bool:
 
 
 def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str = LIB) -> str:
-    """Compile csrc/*.hip into libkissmcmc_hip.so next to this file (in-tree, so it travels).
-    ``extra_flags``/``out`` build experiment variants (e.g. ``-DKMC_STORE_SC1``) side by side."""
-    if force or out != LIB or stale():
-        cmd = [_hipcc(), *FLAGS, *extra_flags, *[os.path.join(CSRC, f) for f in SOURCES], "-o", out + ".tmp",
-               "-lhiprtc", "-ldl"]
+    """Compile csrc/*.hip (one translation unit per density, in parallel) and link
+    libkissmcmc_hip.so next to this file (in-tree, so it travels with the snapshot).
+    ``extra_flags``/``out`` build experiment variants (e.g. ``-DKMC_TPB=128``) side by side."""
+    if not (force or out != LIB or stale()):
+        return out
+    from concurrent.futures import ThreadPoolExecutor
+    hipcc = _hipcc()
+    objdir = os.path.join(_HERE, "build_obj" + ("" if out == LIB else "_" + os.path.basename(out)))
+    os.makedirs(objdir, exist_ok=True)
+
+    def compile_one(src):
+        obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+        cmd = [hipcc, *FLAGS, *extra_flags, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
-        os.replace(out + ".tmp", out)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", out + ".tmp", "-lhiprtc", "-ldl"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    os.replace(out + ".tmp", out)
+    shutil.rmtree(objdir, ignore_errors=True)
     return out
 
 

@@ -20,7 +20,8 @@
 #include <vector>
 
 #include "../../include/kissmcmc_hip.h"
-#include "kmc_kernels.hpp"
+#define KMC_DEFINE_DRIVER_KERNELS
+#include "kmc_tables.hpp"
 
 using namespace kmc;
 
@@ -56,8 +57,6 @@ kmc_status fail(kmc_status st, const std::string& msg)
 
 constexpr int64_t kGraphChunk = 64;   // generations per hipGraph replay (128 kernel nodes + 1)
 
-using HalfStepFn = void (*)(const HalfStepArgs);
-using LogpdfFn = void (*)(const LogpdfArgs);
 
 struct Plan {
     HalfStepFn fn = nullptr;
@@ -67,7 +66,6 @@ struct Plan {
 };
 
 // ---- kernel table ------------------------------------------------------------------------
-using FlushFn = void (*)(const FlushArgs);
 
 template <int L, int K, int ITER>
 FlushFn flush_one()
@@ -100,69 +98,14 @@ FlushFn flush_lookup(int L, int K, int iter)
     return nullptr;
 }
 
-template <class D, int L, int K, int ITER, bool P2P, bool RAGGED>
-HalfStepFn vec_one()
-{
-    // a group's ITER scalar lanes must fit in its L lanes; keep the register tile (ITER*K chunks) bounded
-    if constexpr (ITER <= L && ITER * K <= 16) return half_step_vec<D, L, K, ITER, P2P, RAGGED>;
-    else return nullptr;
-}
-
-template <class D, int L, int K, bool P2P, bool RAGGED>
-HalfStepFn vec_iter(int iter)
-{
-    switch (iter) {
-    case 1: return vec_one<D, L, K, 1, P2P, RAGGED>();
-    case 2: return vec_one<D, L, K, 2, P2P, RAGGED>();
-    case 4: return vec_one<D, L, K, 4, P2P, RAGGED>();
-    case 8: if constexpr (!RAGGED) return vec_one<D, L, K, 8, P2P, RAGGED>(); else return nullptr;
-    case 16: if constexpr (!RAGGED) return vec_one<D, L, K, 16, P2P, RAGGED>(); else return nullptr;
-    default: return nullptr;
-    }
-}
-
-template <class D, int L, int K>
-HalfStepFn vec_pick(int iter, bool p2p, bool ragged)
-{
-    if (ragged) return p2p ? vec_iter<D, L, K, true, true>(iter) : vec_iter<D, L, K, false, true>(iter);
-    return p2p ? vec_iter<D, L, K, true, false>(iter) : vec_iter<D, L, K, false, false>(iter);
-}
-
-// exact geometries (ndim == 2*L*K): every tuning combination; ragged ones: what make_plan picks
-template <class D>
-HalfStepFn vec_lookup(int L, int K, int iter, bool p2p, bool ragged)
-{
-    if constexpr (!D::kHasFrag) {
-        return nullptr;
-    } else {
-#define KMC_LK(l, k) if (L == l && K == k) return vec_pick<D, l, k>(iter, p2p, ragged);
-        KMC_LK(1, 1) KMC_LK(2, 1) KMC_LK(4, 1) KMC_LK(4, 2) KMC_LK(8, 2) KMC_LK(16, 2) KMC_LK(32, 2) KMC_LK(64, 2)
-        KMC_LK(64, 4) KMC_LK(64, 8)
-#undef KMC_LK
-        if (ragged) return nullptr;
-#define KMC_LK(l, k) if (L == l && K == k) return vec_pick<D, l, k>(iter, p2p, false);
-        KMC_LK(8, 1) KMC_LK(16, 1) KMC_LK(32, 1) KMC_LK(64, 1) KMC_LK(4, 4) KMC_LK(8, 4)
-#undef KMC_LK
-        return nullptr;
-    }
-}
-
-template <class D>
-void density_fns(int L, int K, int iter, bool p2p, bool ragged, HalfStepFn* vec, HalfStepFn* gen, LogpdfFn* lp)
-{
-    *vec = vec_lookup<D>(L, K, iter, p2p, ragged);
-    *gen = p2p ? half_step_generic<D, true> : half_step_generic<D, false>;
-    *lp = logpdf_rows<D>;
-}
-
 bool lookup(int density, int L, int K, int iter, bool p2p, bool ragged, HalfStepFn* vec, HalfStepFn* gen, LogpdfFn* lp)
 {
     switch (density) {
-    case KMC_GAUSSIAN_ISO: density_fns<GaussianIso>(L, K, iter, p2p, ragged, vec, gen, lp); return true;
-    case KMC_EXPONENTIAL: density_fns<Exponential>(L, K, iter, p2p, ragged, vec, gen, lp); return true;
-    case KMC_ROSENBROCK: density_fns<Rosenbrock>(L, K, iter, p2p, ragged, vec, gen, lp); return true;
-    case KMC_LOGNORMAL: density_fns<LogNormal>(L, K, iter, p2p, ragged, vec, gen, lp); return true;
-    case KMC_MVNORMAL2: density_fns<MvNormal2>(L, K, iter, p2p, ragged, vec, gen, lp); return true;
+    case KMC_GAUSSIAN_ISO: table_gaussian_iso(L, K, iter, p2p, ragged, vec, gen, lp); return true;
+    case KMC_EXPONENTIAL: table_exponential(L, K, iter, p2p, ragged, vec, gen, lp); return true;
+    case KMC_ROSENBROCK: table_rosenbrock(L, K, iter, p2p, ragged, vec, gen, lp); return true;
+    case KMC_LOGNORMAL: table_lognormal(L, K, iter, p2p, ragged, vec, gen, lp); return true;
+    case KMC_MVNORMAL2: table_mvnormal2(L, K, iter, p2p, ragged, vec, gen, lp); return true;
     default: return false;
     }
 }
@@ -200,6 +143,7 @@ Plan make_plan(const kmc_config& c, int64_t n_active)
     }
     const bool ragged = L > 0 && 2 * L * K != c.ndim;
     if (ragged && iter > 4) iter = 4;
+    if ((c.flags & KMC_P2P) && iter > 8) iter = 8;
     p.ragged = ragged;
     if (c.density == KMC_USER_DENSITY) {
         // kernels are compiled for exactly this geometry when the sampler is created

@@ -1,0 +1,10 @@
+// Kernel instantiations for the MvNormal2 log-density (one translation unit per density).
+#define KMC_TABLES_IMPL
+#include "kmc_tables.hpp"
+
+namespace kmc {
+void table_mvnormal2(int L, int K, int iter, bool p2p, bool ragged, HalfStepFn* vec, HalfStepFn* gen, LogpdfFn* lp)
+{
+    density_fns<MvNormal2>(L, K, iter, p2p, ragged, vec, gen, lp);
+}
+}  // namespace kmc

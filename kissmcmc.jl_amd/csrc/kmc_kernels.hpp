@@ -504,6 +504,7 @@ struct SignalArgs {
     int32_t             sched_index;
     int32_t             half;
 };
+#ifdef KMC_DEFINE_DRIVER_KERNELS   // non-template kernels: defined once, in kmc_api.hip
 __global__ void p2p_signal(const SignalArgs a)
 {
     const SchedEntry sch = a.sched_table ? a.sched_table[a.sched_index] : a.sched_inline;
@@ -523,5 +524,6 @@ __global__ void advance_schedule(int64_t* gen, SchedEntry* table, int n, int64_t
     if ((int)threadIdx.x < n) table[threadIdx.x] = make_sched(base + threadIdx.x, nburnin, nthin, nsamples);
     if (threadIdx.x == 0) *gen = base;
 }
+#endif  // KMC_DEFINE_DRIVER_KERNELS
 
 }  // namespace kmc
