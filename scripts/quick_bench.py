@@ -34,11 +34,13 @@ def main():
     variants = []
     for plan in plans:
         for mom in moms:
-            if plan:
-                os.environ["KMC_PLAN"] = plan
+            eager = plan.endswith("e")           # "L,K,ITERe" = same geometry, eager launches (no hipGraph)
+            pl = plan.rstrip("e")
+            if pl:
+                os.environ["KMC_PLAN"] = pl
             else:
                 os.environ.pop("KMC_PLAN", None)
-            s = kmc.Sampler(pdf, nw, nd, 10 ** 9, 0, 1, 2.0, 7, moments=mom)
+            s = kmc.Sampler(pdf, nw, nd, 10 ** 9, 0, 1, 2.0, 7, moments=mom, use_graph=not eager)
             s.set_positions(th)
             s.run(128)
             s.sync()

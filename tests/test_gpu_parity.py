@@ -97,6 +97,11 @@ CASES = [
     ("expo", 1100, 1000, 6, 2, 1),
     ("gauss", 1100, 1023, 6, 2, 1),
     ("gauss", 1040, 1026, 4, 1, 1),     # beyond the vector kernel's 1024: generic kernel
+    # smallest legal ensembles: nwalkers == ndim + 2 (src/samplers.jl:205), two walkers per half
+    ("gauss", 4, 2, 300, 100, 1),
+    ("expo", 4, 1, 300, 100, 1),
+    ("rosen", 6, 4, 200, 50, 3),
+    ("gauss", 34, 32, 100, 30, 1),
 ]
 
 
@@ -111,6 +116,42 @@ def test_every_geometry_gives_the_same_chain(kmc, oracle, plan, monkeypatch):
     """The result is a pure function of (seed, inputs): launch geometry must not matter."""
     ref, got = _run_both(kmc, oracle, "gauss", 512, 32, 70, 20, 1, seed=99, plan=plan, monkeypatch=monkeypatch)
     _compare(ref, got)
+
+
+@pytest.mark.parametrize("a_scale", [1.0001, 1.5, 3.5, 10.0])
+def test_stretch_scale(kmc, oracle, a_scale):
+    """a_scale only needs to be > 1 (src/samplers.jl:200); z in [1/a, a]."""
+    pdf, did, params = _densities(kmc, oracle)["gauss"]
+    th = _theta0("gauss", 128, 8, 3)
+    ref = oracle.emcee(oracle.make_config(did, params, 128, 8, 90, 20, 1, a_scale, 77), th)
+    with kmc.Sampler(pdf, 128, 8, 90, 20, 1, a_scale, 77, store_chain=True, store_logp=True, moments=True) as s:
+        s.set_positions(th)
+        s.run(90)
+        s.sync()
+        got = dict(final_pos=s.positions(), final_logp=s.logp(), naccept=s.naccept(), accept_ratio=s.accept_ratio())
+        got["chain"], got["chain_logp"] = s.chain()
+        got["sum"], got["sumsq"], got["nmoment"] = s.moments()
+    _compare(ref, got)
+
+
+def test_run_in_pieces_equals_one_run(kmc, oracle):
+    """Progress-meter style chunked runs, a mid-run moments read-out and a restart from the same
+    positions all leave the chain unchanged."""
+    pdf, did, params = _densities(kmc, oracle)["gauss"]
+    th = _theta0("gauss", 256, 32, 4)
+    ref = oracle.emcee(oracle.make_config(did, params, 256, 32, 200, 60, 2, 2.0, 5), th)
+    with kmc.Sampler(pdf, 256, 32, 200, 60, 2, 2.0, 5, store_chain=True, store_logp=True, moments=True) as s:
+        for attempt in range(2):
+            s.set_positions(th)
+            for n in (1, 63, 64, 7, 65):
+                s.run(n)
+                s.sync()
+                s.moments()              # flushes the sojourn-weighted accumulators mid-run
+            assert s.generation == 200
+            got = dict(final_pos=s.positions(), final_logp=s.logp(), naccept=s.naccept(), accept_ratio=s.accept_ratio())
+            got["chain"], got["chain_logp"] = s.chain()
+            got["sum"], got["sumsq"], got["nmoment"] = s.moments()
+            _compare(ref, got)
 
 
 def test_graph_replay_equals_eager(kmc, oracle):
