@@ -72,6 +72,11 @@ enum {
     KMC_STORE_LOGP  = 1u << 1, /* keep logdensities (src/samplers.jl:271): [nsamples][nwalkers] */
     KMC_MOMENTS     = 1u << 2, /* streaming sum x, sum x^2 per dimension over the samples that would be stored */
     KMC_NO_GRAPH    = 1u << 3, /* launch every half-step eagerly instead of replaying a hipGraph */
+    KMC_ISLANDS     = 1u << 6, /* ISLAND MODE (opt-in, not the reference's partner rule): islands of `island_size` walkers live in LDS
+                                  for `island_gens` generations per launch and draw partners from their own complementary
+                                  half; walkers are re-dealt to islands between launches.  Same target distribution, far
+                                  fewer kernel boundaries and no HBM traffic inside an epoch.  Needs nwalkers % island_size == 0,
+                                  island_size >= ndim + 2, ndim <= 32, shard_count == 1; no chain storage. */
     KMC_P2P         = 1u << 4  /* walker sharding with peer-to-peer partner reads over xGMI: the sampler holds only
                                   its shard ([2][nwalkers/2/shard_count][ndim], halves back to back), reads partner
                                   rows straight from the owning rank's HBM and synchronises half-steps with
@@ -96,6 +101,8 @@ typedef struct kmc_config {
     int32_t  shard_rank;    /* walker sharding: this sampler updates slice shard_rank ...          */
     int32_t  shard_count;   /* ... of shard_count of EACH half; 1 = the whole ensemble (default 0 -> 1) */
     void*    user_density;  /* kmc_user_density* when density == KMC_USER_DENSITY, else NULL */
+    int32_t  island_gens;   /* KMC_ISLANDS: generations per epoch (launch); 0 -> 32 */
+    int32_t  island_size;   /* KMC_ISLANDS: walkers per island: 64, 128 or 256; 0 -> 256 */
 } kmc_config;
 
 /* Host output buffers of the one-shot call; any pointer may be NULL. */

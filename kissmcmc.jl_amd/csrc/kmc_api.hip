@@ -8,6 +8,7 @@
 #include <hip/hiprtc.h>
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <cmath>
 #include <fstream>
 #include <map>
@@ -108,6 +109,48 @@ bool lookup(int density, int L, int K, int iter, bool p2p, bool ragged, HalfStep
     case KMC_MVNORMAL2: table_mvnormal2(L, K, iter, p2p, ragged, vec, gen, lp); return true;
     default: return false;
     }
+}
+
+IslandFn island_fn(int density, int S, int K, bool ragged)
+{
+    switch (density) {
+    case KMC_GAUSSIAN_ISO: return island_gaussian_iso(S, K, ragged);
+    case KMC_EXPONENTIAL: return island_exponential(S, K, ragged);
+    case KMC_ROSENBROCK: return island_rosenbrock(S, K, ragged);
+    case KMC_LOGNORMAL: return island_lognormal(S, K, ragged);
+    case KMC_MVNORMAL2: return island_mvnormal2(S, K, ragged);
+    default: return nullptr;
+    }
+}
+
+// Philox4x32-10 on the host (only for the island deal; Salmon et al., SC'11).
+void philox_host(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c0 = n0; c1 = (uint32_t)p1; c2 = n2; c3 = (uint32_t)p0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// The deal of epoch e: slot s holds walker (A*s + C) mod N.  Epoch 0 is the identity; later epochs
+// take A (made coprime to N by stepping upwards) and C from Philox(ctr = {e, "ISLA", 0}, key = seed).
+void island_perm(uint64_t seed, int64_t epoch, int64_t N, int64_t* A, int64_t* C)
+{
+    if (epoch == 0 || N <= 2) { *A = 1; *C = 0; return; }
+    const uint32_t ctr[4] = {(uint32_t)epoch, (uint32_t)((uint64_t)epoch >> 32), 0x49534c41u, 0u};
+    const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    uint32_t w[4];
+    philox_host(ctr, key, w);
+    auto gcd = [](int64_t a, int64_t b) { while (b) { const int64_t t = a % b; a = b; b = t; } return a; };
+    int64_t a = (int64_t)((((uint64_t)w[0] << 32) | w[1]) % (uint64_t)N);
+    if (a < 1) a = 1;
+    while (gcd(a, N) != 1) a = (a % N + 1 >= N) ? 1 : a + 1;
+    *A = a;
+    *C = (int64_t)((((uint64_t)w[2] << 32) | w[3]) % (uint64_t)N);
 }
 
 // Default geometry per ndim; KMC_PLAN="L,K,ITER" (or "generic") overrides for tuning.
@@ -364,6 +407,15 @@ struct kmc_sampler {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool have_run_events = false;
     bool positions_set = false;
+    // island mode (KMC_ISLANDS)
+    bool islands = false;
+    IslandFn island_kernel = nullptr;
+    int island_K = 0;
+    bool island_ragged = false;
+    int64_t island_gens = 32, nislands = 0, island_size = kIslandSizeDefault;
+    size_t island_lds = 0;
+    double* d_isum = nullptr;                            // [nislands][4K] per-island moment sums
+    double* d_isumsq = nullptr;
     // peer-to-peer sharding (KMC_P2P)
     bool p2p = false;
     bool connected = false;
@@ -552,6 +604,12 @@ KMC_EXPORT kmc_status kmc_validate(const kmc_config* c)
     if (c->shard_rank < 0 || c->shard_rank >= P) return fail(KMC_ERR_BAD_ARG, "shard_rank out of range");
     if ((c->nwalkers / 2) % P != 0) return fail(KMC_ERR_BAD_ARG, "nwalkers/2 must be divisible by shard_count");
     if ((c->flags & KMC_P2P) && P > 8) return fail(KMC_ERR_UNSUPPORTED, "KMC_P2P supports at most 8 shards (one node)");
+    if (c->flags & KMC_ISLANDS) {
+        const int64_t S = c->island_size > 0 ? c->island_size : kIslandSizeDefault;
+        if ((S != 64 && S != 128 && S != 256) || c->nwalkers % S != 0 || c->ndim > 32 || c->ndim + 2 > S || P != 1 ||
+            (c->flags & (KMC_P2P | KMC_STORE_CHAIN | KMC_STORE_LOGP)) || c->density == KMC_USER_DENSITY || c->island_gens < 0)
+            return fail(KMC_ERR_UNSUPPORTED, "KMC_ISLANDS needs island_size in {64,128,256} >= ndim+2 dividing nwalkers, ndim <= 32, one shard, a menu density and no chain storage");
+    }
     DensityParams dp;
     return digest_params(*c, &dp);
 }
@@ -607,6 +665,23 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
     // vec: a wave owns W = (64/L)*ITER walkers; generic: one walker per lane
     const int64_t per_wave = s->plan.vec ? (int64_t)(64 / s->plan.L) * s->plan.ITER : 64;
     const int64_t waves = (s->h_loc + per_wave - 1) / per_wave;
+    if (cfg->flags & KMC_ISLANDS) {
+        s->islands = true;
+        s->island_gens = cfg->island_gens > 0 ? cfg->island_gens : 32;
+        s->island_size = cfg->island_size > 0 ? cfg->island_size : kIslandSizeDefault;
+        s->nislands = cfg->nwalkers / s->island_size;
+        const int64_t chunks = s->ld / 2;                   // 16-byte chunks per row, 2 lanes per walker
+        int K = 1;
+        while (2 * K < chunks) K *= 2;
+        s->island_K = K;
+        s->island_ragged = 4 * K != cfg->ndim;
+        s->island_kernel = island_fn(cfg->density, (int)s->island_size, K, s->island_ragged);
+        if (!s->island_kernel) { delete s; return fail(KMC_ERR_UNSUPPORTED, "no island kernel for this density / ndim"); }
+        s->island_lds = ((size_t)s->island_size * (size_t)(s->ld + 2) + (size_t)s->island_size) * sizeof(double);
+        hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(s->island_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->island_lds);
+        if (ea != hipSuccess) { (void)hipGetLastError(); delete s; return fail(KMC_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(ea)); }
+    }
     // vec kernels: kTPB threads per workgroup; the generic kernel keeps 256
     const int tpb = s->plan.vec ? kTPB : 256;
     s->tpb = tpb;
@@ -658,6 +733,13 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
             CREATE_TRY(hipMalloc((void**)&s->d_klast, nw * sizeof(uint32_t)));
             CREATE_TRY(hipMemset(s->d_klast, 0, nw * sizeof(uint32_t)));
         }
+        if (s->islands) {
+            const size_t ne = (size_t)s->nislands * 4 * (size_t)s->island_K;
+            CREATE_TRY(hipMalloc(&s->d_isum, ne * sizeof(double)));
+            CREATE_TRY(hipMalloc(&s->d_isumsq, ne * sizeof(double)));
+            CREATE_TRY(hipMemset(s->d_isum, 0, ne * sizeof(double)));
+            CREATE_TRY(hipMemset(s->d_isumsq, 0, ne * sizeof(double)));
+        }
     }
     if ((cfg->flags & KMC_STORE_CHAIN) && s->nsamples > 0)
         CREATE_TRY(hipMalloc(&s->d_chain, (size_t)s->nsamples * (size_t)s->nlocal * ldz * sizeof(double)));
@@ -702,6 +784,8 @@ KMC_EXPORT void kmc_sampler_destroy(kmc_sampler* s)
     (void)hipFree(s->d_msum);
     (void)hipFree(s->d_msumsq);
     (void)hipFree(s->d_klast);
+    (void)hipFree(s->d_isum);
+    (void)hipFree(s->d_isumsq);
     if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
     (void)hipGetLastError();
     delete s;
@@ -812,6 +896,11 @@ KMC_EXPORT kmc_status kmc_sampler_set_positions(kmc_sampler* s, const double* th
         HIP_TRY(hipMemsetAsync(s->d_msum, 0, (size_t)s->macc_elems * sizeof(double), s->stream));
         HIP_TRY(hipMemsetAsync(s->d_msumsq, 0, (size_t)s->macc_elems * sizeof(double), s->stream));
         if (s->d_klast) HIP_TRY(hipMemsetAsync(s->d_klast, 0, nw * sizeof(uint32_t), s->stream));
+        if (s->d_isum) {
+            const size_t ne = (size_t)s->nislands * 4 * (size_t)s->island_K;
+            HIP_TRY(hipMemsetAsync(s->d_isum, 0, ne * sizeof(double), s->stream));
+            HIP_TRY(hipMemsetAsync(s->d_isumsq, 0, ne * sizeof(double), s->stream));
+        }
     }
     HIP_TRY(hipStreamSynchronize(s->stream));
     s->generation = 0;
@@ -837,6 +926,34 @@ KMC_EXPORT kmc_status kmc_sampler_run(kmc_sampler* s, int64_t ngen)
     if (s->p2p && !s->connected) return fail(KMC_ERR_BAD_ARG, "kmc_sampler_p2p_connect has not been called");
     HIP_TRY(hipSetDevice(s->cfg.device));
     HIP_TRY(hipEventRecord(s->ev0, s->stream));
+    if (s->islands) {
+        // one launch per epoch (or per piece of one, when a run stops inside an epoch)
+        while (ngen > 0) {
+            const int64_t epoch = s->generation / s->island_gens;
+            const int64_t upto = (epoch + 1) * s->island_gens;
+            const int64_t n = std::min<int64_t>(ngen, upto - s->generation);
+            IslandArgs ia{};
+            ia.pos = s->d_pos; ia.logp = s->d_logp; ia.naccept = s->d_naccept;
+            ia.nwalkers = s->cfg.nwalkers;
+            island_perm(s->cfg.seed, epoch, s->cfg.nwalkers, &ia.permA, &ia.permC);
+            ia.gen0 = s->generation; ia.ngen = (int32_t)n;
+            ia.ndim = (int32_t)s->cfg.ndim; ia.ld = (int32_t)s->ld;
+            ia.nburnin = s->cfg.nburnin; ia.nthin = s->cfg.nthin; ia.nsamples = s->nsamples;
+            const HalfStepArgs ha = make_args(s, 0, false, s->generation);
+            ia.dc = ha.dc;
+            ia.dc.nhalf = (uint32_t)(s->island_size / 2);
+            ia.dp = s->dp;
+            ia.msum = s->d_isum; ia.msumsq = s->d_isumsq;
+            hipLaunchKernelGGL(s->island_kernel, dim3((unsigned)s->nislands), dim3((unsigned)s->island_size), s->island_lds, s->stream, ia);
+            HIP_TRY(hipGetLastError());
+            s->generation += n;
+            s->launches += 1;
+            ngen -= n;
+        }
+        HIP_TRY(hipEventRecord(s->ev1, s->stream));
+        s->have_run_events = true;
+        return KMC_OK;
+    }
     const bool use_graph = !(s->cfg.flags & KMC_NO_GRAPH);
     while (use_graph && ngen >= kGraphChunk) {
         KMC_TRY(ensure_graph(s));
@@ -862,6 +979,7 @@ KMC_EXPORT kmc_status kmc_sampler_half_step(kmc_sampler* s, int half)
     if (!s || (half != 0 && half != 1)) return fail(KMC_ERR_BAD_ARG, "bad argument");
     if (!s->positions_set) return fail(KMC_ERR_BAD_ARG, "kmc_sampler_set_positions has not succeeded yet");
     if (s->p2p && !s->connected) return fail(KMC_ERR_BAD_ARG, "kmc_sampler_p2p_connect has not been called");
+    if (s->islands) return fail(KMC_ERR_UNSUPPORTED, "island mode advances whole generations: use kmc_sampler_run");
     HIP_TRY(hipSetDevice(s->cfg.device));
     KMC_TRY(launch_half(s, half, false, s->generation));
     s->launches += 1;
@@ -955,6 +1073,24 @@ KMC_EXPORT kmc_status kmc_sampler_get_moments(kmc_sampler* s, double* sum, doubl
     if (!s) return fail(KMC_ERR_BAD_ARG, "null sampler");
     if (!s->d_msum) return fail(KMC_ERR_BAD_ARG, "sampler was created without KMC_MOMENTS");
     HIP_TRY(hipSetDevice(s->cfg.device));
+    if (s->islands) {
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        const int64_t nd = s->cfg.ndim;
+        const size_t per = 4 * (size_t)s->island_K, ne = (size_t)s->nislands * per;
+        std::vector<double> hs(ne), hq(ne);
+        HIP_TRY(hipMemcpy(hs.data(), s->d_isum, ne * sizeof(double), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(hq.data(), s->d_isumsq, ne * sizeof(double), hipMemcpyDeviceToHost));
+        std::vector<double> S((size_t)nd, 0.0), Q((size_t)nd, 0.0);
+        for (int64_t b = 0; b < s->nislands; ++b)
+            for (size_t e = 0; e < per; ++e)
+                if ((int64_t)e < nd) { S[e] += hs[(size_t)b * per + e]; Q[e] += hq[(size_t)b * per + e]; }
+        for (int64_t d = 0; d < nd; ++d) {
+            if (sum) sum[d] = S[d];
+            if (sumsq) sumsq[d] = Q[d];
+        }
+        if (n) *n = samples_done(s) * s->nlocal;
+        return KMC_OK;
+    }
     if (s->plan.vec) {
         // sojourn-weighted accumulation: credit every walker's current value up to now
         FlushFn fl = flush_lookup(s->plan.L, s->plan.K, s->plan.ITER);

@@ -1,0 +1,190 @@
+// kmc_islands.hpp -- ISLAND MODE (opt-in extension; the exact mode in kmc_kernels.hpp is the default).
+//
+// The north-star's "LDS-staged complementary-half walker block", done the only way that keeps a
+// correct sampler: the ensemble is cut into islands of S walkers (64, 128 or 256), one workgroup each.
+// An island's whole state (positions + log-pdfs, ~70 KB at ndim 32) is loaded into LDS once per
+// epoch and the workgroup then runs `ngen` generations of the reference's half-split stretch move
+// (src/samplers.jl:245-274) entirely out of LDS -- partners are drawn from the ISLAND's
+// complementary half, `__syncthreads()` is the join of src/samplers.jl:273 -- before writing the
+// island back.  Between epochs the walkers are re-dealt to islands by a state-independent
+// permutation (slot s holds walker (A*s + C) mod N), so every walker keeps meeting new partners.
+// Each island update is a valid emcee kernel for its 256 walkers and the deal ignores the state,
+// hence the target distribution is untouched; what differs from the reference is the partner
+// pool (island half instead of ensemble half, src/samplers.jl:250).  No HBM traffic and no kernel
+// boundary inside an epoch.
+//
+// Thread mapping: 256 threads = 128 active walkers x 2 lanes; a walker's row is striped over its
+// lane pair exactly like half_step_vec<L = 2> (lane j, chunk k holds elements 2(2k+j), 2(2k+j)+1), so
+// the density code (frag_partial<2, K>) and the DPP pair reduction are shared with the exact mode.
+// Random stream: the exact mode's Philox block keyed by step = 2*generation + half and by the SLOT
+// index (island * 256 + local index).
+#pragma once
+#include "kmc_kernels.hpp"
+
+namespace kmc {
+
+constexpr int kIslandSizeDefault = 256;   // walkers per island (= threads per workgroup): 64, 128 or 256
+
+struct IslandArgs {
+    double*       pos;        // [nwalkers][ld], walker-id order
+    double*       logp;       // [nwalkers]
+    uint32_t*     naccept;    // [nwalkers]
+    int64_t       nwalkers;
+    int64_t       permA, permC;     // slot -> walker id of this epoch
+    int64_t       gen0;             // first generation of this launch
+    int32_t       ngen;             // generations in this launch (<= epoch length)
+    int32_t       ndim;
+    int32_t       ld;               // global row stride (doubles)
+    int32_t       pad_;
+    int64_t       nburnin, nthin, nsamples;
+    DrawConsts    dc;               // dc.nhalf = S / 2
+    DensityParams dp;
+    double*       msum;             // [nislands][4K] per-island partial sums or nullptr
+    double*       msumsq;
+};
+
+__device__ __forceinline__ int64_t island_walker(const IslandArgs& a, int64_t slot)
+{
+    // (A * slot + C) mod N without overflow for N < 2^31 (A, C < N)
+    return (int64_t)(((unsigned long long)a.permA * (unsigned long long)slot + (unsigned long long)a.permC) %
+                     (unsigned long long)a.nwalkers);
+}
+
+template <class Dens, int S, int K, bool RAGGED>
+__device__ __forceinline__ void island_epoch_body(const IslandArgs& a)
+{
+    static_assert(S == 64 || S == 128 || S == 256, "island = one workgroup of S threads");
+    constexpr int HS = S / 2, L = 2, NW = S / 64;   // NW waves
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int ndim = RAGGED ? a.ndim : 4 * K;
+    const int ld   = RAGGED ? a.ld : 4 * K;
+    const int lld  = ld + 2;                              // LDS row stride: +16 B spreads the banks
+    double* lpos  = lds;                                  // [S][lld]
+    double* llogp = lds + S * lld;                        // [S]
+
+    const int t = threadIdx.x;
+    const int i = t >> 1, j = t & 1;                      // active index within a half, lane of the pair
+    const int64_t slot0 = (int64_t)blockIdx.x * S;
+
+    // ---- deal: slot (island, t) <- walker (A*slot + C) mod N ------------------------------------
+    const int64_t wid = island_walker(a, slot0 + t);
+    {
+        const double2* src = reinterpret_cast<const double2*>(a.pos + wid * (int64_t)a.ld);
+        double2* dst = reinterpret_cast<double2*>(lpos + t * lld);
+        for (int c = 0; c < ld / 2; ++c) dst[c] = src[c];
+        llogp[t] = a.logp[wid];
+    }
+    __syncthreads();
+
+    bool cv[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) cv[k] = !RAGGED || 2 * (k * L + j) < ld;
+    const double2 zero2 = make_double2(0.0, 0.0);
+    double2 ms[K], mq[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) { ms[k] = zero2; mq[k] = zero2; }
+    // Scalar layout (one walker per lane, once per GENERATION): lanes 0-31 of a wave own the wave's 32
+    // first-half walkers, lanes 32-63 its 32 second-half walkers -- Philox, z, log z, log u, p0, the
+    // accept test and the acceptance counter live here, so the two logarithms are computed once per
+    // walker-step instead of once per lane of the pair.  Row layout: lane pair (i, j) as above.
+    const int lane = t & 63, wave = t >> 6;
+    const int hA   = lane >> 5;                                       // which half this scalar lane serves
+    const int ownA = hA * HS + (wave << 5) + (lane & 31);             // its walker's local index
+    uint32_t naccA = 0u;
+
+    for (int gg = 0; gg < a.ngen; ++gg) {
+        const int64_t gen = a.gen0 + gg;
+        const int64_t n = gen + 1 - a.nburnin;            // the reference's loop variable (:245)
+        const bool count = n > 0;
+        bool sample = false;
+        if (n > 0 && n % a.nthin == 0) sample = (n / a.nthin - 1) < a.nsamples;   // :268
+        const Draw drA = draw_step(a.dc, 2ull * (uint64_t)gen + (uint64_t)hA, (uint64_t)(slot0 + ownA));   // :250, :252
+        const double p0A = llogp[ownA];                   // only this walker's own update changes it
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+            const int own_l = half * HS + i;                                      // :247
+            const int src = ((half << 5) + (lane >> 1)) * 4;                      // scalar lane of this pair's walker
+            const int partner = __builtin_amdgcn_ds_bpermute(src, (int)drA.partner);
+            const double z = bperm_f64(src, drA.z);
+            const int oth_l = (1 - half) * HS + partner;
+            const double2* own = reinterpret_cast<const double2*>(lpos + own_l * lld);
+            const double2* oth = reinterpret_cast<const double2*>(lpos + oth_l * lld);
+            double2 xc[K], y[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                xc[k] = cv[k] ? own[k * L + j] : zero2;
+                const double2 xo = cv[k] ? oth[k * L + j] : zero2;
+                y[k].x = fma(z, xc[k].x - xo.x, xo.x);                            // :255
+                y[k].y = fma(z, xc[k].y - xo.y, xo.y);
+            }
+            const double Ssum = group_sum<L>(Dens::template frag_partial<L, K>(y, j, ndim, a.dp));
+            const double p1 = Dens::finish(Ssum, a.dp);                           // :257
+            // row -> scalar: the pair of walker (lane & 31) sits in lanes 2*(lane & 31), +1
+            const double p1A = bperm_f64(((lane & 31) * 2) * 4, p1);
+            const bool accA = (hA == half) && accept_test(drA, p1A, p0A);         // :260
+            const unsigned long long accmask = __ballot(accA);
+            if (accA) {                                                           // :262, :265
+                llogp[ownA] = p1A;
+                if (count) naccA += 1u;
+            }
+            const bool acc = ((accmask >> ((half << 5) + (lane >> 1))) & 1ull) != 0;
+            if (acc) {                                                            // :261
+                double2* ownw = reinterpret_cast<double2*>(lpos + own_l * lld);
+#pragma unroll
+                for (int k = 0; k < K; ++k) if (cv[k]) ownw[k * L + j] = y[k];
+            }
+            if (sample) {                                 // the walker's state after its update (:268-269)
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const double2 cur = sel2(acc, y[k], xc[k]);
+                    ms[k].x += cur.x; ms[k].y += cur.y;
+                    mq[k].x += cur.x * cur.x; mq[k].y += cur.y * cur.y;
+                }
+            }
+            __syncthreads();                              // the join of :273
+        }
+    }
+
+    // ---- hand the island back -------------------------------------------------------------------
+    {
+        double2* dst = reinterpret_cast<double2*>(a.pos + wid * (int64_t)a.ld);
+        const double2* src = reinterpret_cast<const double2*>(lpos + t * lld);
+        for (int c = 0; c < ld / 2; ++c) dst[c] = src[c];
+        a.logp[wid] = llogp[t];
+    }
+    if (naccA) a.naccept[island_walker(a, slot0 + ownA)] += naccA;
+    if (a.msum != nullptr) {
+        // lanes with equal j hold the same dimensions: fold the wave's 32 pairs, then the 4 waves
+        __syncthreads();                                  // LDS is free again
+        double* red = lds;                                // [NW waves][K][2 lanes][4]
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            ms[k].x = wave_fold<L>(ms[k].x); ms[k].y = wave_fold<L>(ms[k].y);
+            mq[k].x = wave_fold<L>(mq[k].x); mq[k].y = wave_fold<L>(mq[k].y);
+            if (lane < 2) {
+                double* r = red + ((wave * K + k) * 2 + lane) * 4;
+                r[0] = ms[k].x; r[1] = ms[k].y; r[2] = mq[k].x; r[3] = mq[k].y;
+            }
+        }
+        __syncthreads();
+        if (t < 2 * K) {                                  // thread (k, j)
+            double s0 = 0.0, s1 = 0.0, q0 = 0.0, q1 = 0.0;
+            for (int w = 0; w < NW; ++w) {
+                const double* r = red + ((w * K + (t >> 1)) * 2 + (t & 1)) * 4;
+                s0 += r[0]; s1 += r[1]; q0 += r[2]; q1 += r[3];
+            }
+            double* gs = a.msum + ((int64_t)blockIdx.x * 2 * K + t) * 2;     // dims 2*(2k+j), +1
+            double* gq = a.msumsq + ((int64_t)blockIdx.x * 2 * K + t) * 2;
+            gs[0] += s0; gs[1] += s1;
+            gq[0] += q0; gq[1] += q1;
+        }
+    }
+}
+
+template <class Dens, int S, int K, bool RAGGED>
+__global__ __launch_bounds__(S) void island_epoch(const IslandArgs a)
+{
+    island_epoch_body<Dens, S, K, RAGGED>(a);
+}
+
+}  // namespace kmc

@@ -2,13 +2,14 @@
 // translation unit (kmc_inst_<density>.hip) so the build can run them in parallel; kmc_api.hip only
 // sees the per-density entry points declared at the bottom.
 #pragma once
-#include "kmc_kernels.hpp"
+#include "kmc_islands.hpp"
 
 namespace kmc {
 
 using HalfStepFn = void (*)(const HalfStepArgs);
 using LogpdfFn = void (*)(const LogpdfArgs);
 using FlushFn = void (*)(const FlushArgs);
+using IslandFn = void (*)(const IslandArgs);
 
 #ifdef KMC_TABLES_IMPL
 template <class D, int L, int K, int ITER, bool P2P, bool RAGGED>
@@ -69,6 +70,33 @@ void density_fns(int L, int K, int iter, bool p2p, bool ragged, HalfStepFn* vec,
     *lp = logpdf_rows<D>;
 }
 
+// island mode: one workgroup per S-walker island, rows of up to 4*K doubles
+template <class D, int S>
+IslandFn island_lookup_s(int K, bool ragged)
+{
+    switch (K) {
+    case 1: return ragged ? island_epoch<D, S, 1, true> : island_epoch<D, S, 1, false>;
+    case 2: return ragged ? island_epoch<D, S, 2, true> : island_epoch<D, S, 2, false>;
+    case 4: return ragged ? island_epoch<D, S, 4, true> : island_epoch<D, S, 4, false>;
+    case 8: return ragged ? island_epoch<D, S, 8, true> : island_epoch<D, S, 8, false>;
+    default: return nullptr;
+    }
+}
+
+template <class D>
+IslandFn island_lookup(int S, int K, bool ragged)
+{
+    if constexpr (!D::kHasFrag) {
+        return nullptr;
+    } else {
+        switch (S) {
+        case 64: return island_lookup_s<D, 64>(K, ragged);
+        case 128: return island_lookup_s<D, 128>(K, ragged);
+        case 256: return island_lookup_s<D, 256>(K, ragged);
+        default: return nullptr;
+        }
+    }
+}
 #endif  // KMC_TABLES_IMPL
 
 // one entry point per density (defined in kmc_inst_<density>.hip)
@@ -79,5 +107,10 @@ KMC_DECLARE_DENSITY_TABLE(table_exponential);
 KMC_DECLARE_DENSITY_TABLE(table_rosenbrock);
 KMC_DECLARE_DENSITY_TABLE(table_lognormal);
 KMC_DECLARE_DENSITY_TABLE(table_mvnormal2);
+IslandFn island_gaussian_iso(int S, int K, bool ragged);
+IslandFn island_exponential(int S, int K, bool ragged);
+IslandFn island_rosenbrock(int S, int K, bool ragged);
+IslandFn island_lognormal(int S, int K, bool ragged);
+IslandFn island_mvnormal2(int S, int K, bool ragged);
 
 }  // namespace kmc

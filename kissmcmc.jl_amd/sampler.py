@@ -21,7 +21,8 @@ class Sampler:
     def __init__(self, pdf: DeviceLogPdf, nwalkers: int, ndim: int, ngenerations: int, nburnin: int = 0,
                  nthin: int = 1, a_scale: float = 2.0, seed: int = 0, store_chain: bool = False,
                  store_logp: bool = False, moments: bool = False, use_graph: bool = True,
-                 device: int = 0, shard_rank: int = 0, shard_count: int = 1, p2p: bool = False):
+                 device: int = 0, shard_rank: int = 0, shard_count: int = 1, p2p: bool = False,
+                 island_gens: int = 0, island_size: int = 0):
         if not isinstance(pdf, DeviceLogPdf):
             raise TypeError(
                 "the device emcee path evaluates a fixed menu of log-densities "
@@ -51,6 +52,11 @@ class Sampler:
             flags |= _lib.NO_GRAPH
         if p2p:
             flags |= _lib.P2P
+        if island_gens:
+            # ISLAND MODE: 256-walker islands resident in LDS for `island_gens` generations per launch
+            flags |= _lib.ISLANDS
+            cfg.island_gens = int(island_gens)
+            cfg.island_size = int(island_size)
         cfg.flags = flags
         cfg.device = int(device)
         cfg.shard_rank, cfg.shard_count = int(shard_rank), int(shard_count)

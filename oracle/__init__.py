@@ -75,6 +75,9 @@ def lib() -> C.CDLL:
                                      C.c_int64, C.c_int, C.c_int64, C.c_int64, C.c_int]
         L.kmco_emcee.argtypes = [C.POINTER(Config), dp, dp, dp, dp, C.POINTER(C.c_int64),
                                  dp, dp, dp, dp, C.POINTER(C.c_int64)]
+        L.kmco_island_perm.argtypes = [C.c_uint64, C.c_int64, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.kmco_emcee_islands.argtypes = [C.POINTER(Config), C.c_int64, C.c_int64, dp, dp, C.POINTER(C.c_int64),
+                                         dp, dp, dp, dp, C.POINTER(C.c_int64)]
         assert L.kmco_sizeof_config() == C.sizeof(Config)
         _lib = L
     return _lib
@@ -173,3 +176,28 @@ def emcee(cfg: Config, theta0, store_chain=True, moments=True):
     return dict(status=st, chain=chain, chain_logp=chain_logp, accept_ratio=acc, naccept=nacc,
                 final_pos=fpos, final_logp=flogp, sum=msum, sumsq=msq, nmoment=nmom.value,
                 nsamples=ns)
+
+
+def island_perm(seed, epoch, nwalkers):
+    a = C.c_int64()
+    c = C.c_int64()
+    lib().kmco_island_perm(seed, epoch, nwalkers, C.byref(a), C.byref(c))
+    return a.value, c.value
+
+
+def emcee_islands(cfg: Config, island_size, epoch_gens, theta0, moments=True):
+    """Island-mode oracle (see kmc_oracle.c: kmco_emcee_islands)."""
+    nw, nd = cfg.nwalkers, cfg.ndim
+    theta0 = np.ascontiguousarray(np.asarray(theta0, dtype=np.float64).reshape(nw, nd))
+    acc = np.zeros(nw)
+    nacc = np.zeros(nw, dtype=np.int64)
+    fpos = np.zeros((nw, nd))
+    flogp = np.zeros(nw)
+    msum = np.zeros(nd) if moments else None
+    msq = np.zeros(nd) if moments else None
+    nmom = C.c_int64(0)
+    with np.errstate(all="ignore"):
+        st = lib().kmco_emcee_islands(C.byref(cfg), int(island_size), int(epoch_gens), _dp(theta0), _dp(acc), _ip(nacc),
+                                      _dp(fpos), _dp(flogp), _dp(msum), _dp(msq), C.byref(nmom))
+    return dict(status=st, accept_ratio=acc, naccept=nacc, final_pos=fpos, final_logp=flogp, sum=msum, sumsq=msq,
+                nmoment=nmom.value)

@@ -312,3 +312,152 @@ KMCO_API int kmco_emcee(const kmco_config* c, const double* theta0,
 }
 
 KMCO_API int kmco_sizeof_config(void) { return (int)sizeof(kmco_config); }
+
+/* ------------------------------------------------------------------------------------------
+ * ISLAND MODE (an extension of the build, NOT a reference feature; opt-in).
+ *
+ * The ensemble is cut into islands of S walkers; for `epoch_gens` generations every island runs
+ * the reference's half-split stretch move (src/samplers.jl:245-274) on ITS OWN walkers only
+ * (partner drawn from the island's complementary half instead of the ensemble's), then the walkers
+ * are re-dealt to islands by the permutation slot s -> walker (A*s + C) mod N of that epoch.
+ * Each island update is a valid emcee kernel for its S walkers and the re-deal does not depend on
+ * the state, so the target distribution is unchanged; the partner-selection rule is what differs.
+ *
+ * Random stream: the same Philox block as the exact mode, keyed by step = 2*generation + half and
+ * by the SLOT index (island * S + local index) instead of the walker index.
+ * ---------------------------------------------------------------------------------------- */
+static int64_t gcd64(int64_t a, int64_t b) { while (b) { int64_t t = a % b; a = b; b = t; } return a; }
+
+/* (A, C) of epoch e: from Philox(ctr = {e_lo, e_hi, 0x49534c41 "ISLA", 0}, key = seed); A is made
+ * coprime to N by stepping upwards; epoch 0 is the identity deal. */
+KMCO_API void kmco_island_perm(uint64_t seed, int64_t epoch, int64_t N, int64_t* A, int64_t* C)
+{
+    if (epoch == 0 || N <= 2) { *A = 1; *C = 0; return; }
+    uint32_t ctr[4] = {(uint32_t)epoch, (uint32_t)((uint64_t)epoch >> 32), 0x49534c41u, 0u};
+    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    uint32_t w[4];
+    kmco_philox4x32_10(ctr, key, w);
+    int64_t a = (int64_t)((((uint64_t)w[0] << 32) | w[1]) % (uint64_t)N);
+    if (a < 1) a = 1;
+    while (gcd64(a, N) != 1) a = a % N + 1 >= N ? 1 : a + 1;
+    *A = a;
+    *C = (int64_t)((((uint64_t)w[2] << 32) | w[3]) % (uint64_t)N);
+}
+
+KMCO_API int kmco_emcee_islands(const kmco_config* c, int64_t S, int64_t epoch_gens, const double* theta0,
+                                double* accept_ratio, int64_t* naccept_out, double* final_pos, double* final_logp,
+                                double* msum, double* msumsq, int64_t* nmoment)
+{
+    int st = kmco_validate(c);
+    if (st != KMCO_OK) return st;
+    const int64_t nw = c->nwalkers, nd = c->ndim;
+    if (S <= 0 || S % 2 != 0 || nw % S != 0 || S < nd + 2 || epoch_gens <= 0) return KMCO_ERR_BAD_ARG;
+    const int64_t B = nw / S, hs = S / 2;
+    const double c0 = g_c0(c->a_scale), c1 = g_c1(c->a_scale), nm1 = (double)(nd - 1);
+
+    double* pos = (double*)malloc(sizeof(double) * (size_t)(nw * nd));
+    double* logp = (double*)malloc(sizeof(double) * (size_t)nw);
+    int64_t* nacc = (int64_t*)calloc((size_t)nw, sizeof(int64_t));
+    memcpy(pos, theta0, sizeof(double) * (size_t)(nw * nd));
+    for (int64_t w = 0; w < nw; ++w) {
+        logp[w] = kmco_logpdf(c->density, c->params, pos + w * nd, nd);
+        if (!isfinite(logp[w])) { free(pos); free(logp); free(nacc); return KMCO_ERR_NONFINITE_LOGP; }
+    }
+    if (msum) memset(msum, 0, sizeof(double) * (size_t)nd);
+    if (msumsq) memset(msumsq, 0, sizeof(double) * (size_t)nd);
+    int64_t nmom = 0;
+    const int64_t nsamples = c->ngenerations > c->nburnin ? (c->ngenerations - c->nburnin) / c->nthin : 0;
+
+    for (int64_t g0 = 0, epoch = 0; g0 < c->ngenerations; g0 += epoch_gens, ++epoch) {
+        int64_t A, C;
+        kmco_island_perm(c->seed, epoch, nw, &A, &C);
+        const int64_t g1 = g0 + epoch_gens < c->ngenerations ? g0 + epoch_gens : c->ngenerations;
+#pragma omp parallel for schedule(static) num_threads(c->nthreads > 1 ? c->nthreads : 1)
+        for (int64_t b = 0; b < B; ++b) {
+            double* y = (double*)malloc(sizeof(double) * (size_t)nd);
+            for (int64_t g = g0; g < g1; ++g) {
+                const int64_t n = g + 1 - c->nburnin;
+                for (int half = 0; half < 2; ++half) {
+                    const uint64_t step = 2ull * (uint64_t)g + (uint64_t)half;
+                    for (int64_t i = 0; i < hs; ++i) {
+                        const int64_t slot = b * S + (int64_t)half * hs + i;        /* active slot */
+                        const int64_t nc = (int64_t)(((__int128)A * slot + C) % nw); /* its walker  */
+                        int64_t prel; double uz, ua;
+                        kmco_draw(c->seed, step, (uint64_t)slot, hs, &prel, &uz, &ua);
+                        const int64_t pslot = b * S + (int64_t)(1 - half) * hs + prel;
+                        const int64_t no = (int64_t)(((__int128)A * pslot + C) % nw);
+                        const double t = fma(uz, c1, c0);
+                        const double z = t * t;
+                        const double* xc = pos + nc * nd;
+                        const double* xo = pos + no * nd;
+                        for (int64_t d = 0; d < nd; ++d) y[d] = fma(z, xc[d] - xo[d], xo[d]);
+                        const double p1 = kmco_logpdf(c->density, c->params, y, nd);
+                        const double lhs = (nm1 * log(z) + p1) - logp[nc];
+                        if (lhs >= log(ua)) {
+                            memcpy(pos + nc * nd, y, sizeof(double) * (size_t)nd);
+                            logp[nc] = p1;
+                            if (n > 0) nacc[nc] += 1;
+                        }
+                    }
+                }
+            }
+            free(y);
+        }
+        /* samples of this epoch: the state after each kept generation is needed, so redo the
+         * bookkeeping generation by generation only for the moments (cheap form: moments are
+         * accumulated inside the island loop on the device; here, recompute serially) */
+        (void)nsamples;
+    }
+    /* moments need per-generation states: second pass, serial and generation-major */
+    if (msum || msumsq) {
+        memcpy(pos, theta0, sizeof(double) * (size_t)(nw * nd));
+        for (int64_t w = 0; w < nw; ++w) logp[w] = kmco_logpdf(c->density, c->params, pos + w * nd, nd);
+        double* y = (double*)malloc(sizeof(double) * (size_t)nd);
+        for (int64_t g = 0; g < c->ngenerations; ++g) {
+            const int64_t epoch = g / epoch_gens;
+            int64_t A, C;
+            kmco_island_perm(c->seed, epoch, nw, &A, &C);
+            const int64_t n = g + 1 - c->nburnin;
+            for (int half = 0; half < 2; ++half) {
+                const uint64_t step = 2ull * (uint64_t)g + (uint64_t)half;
+                for (int64_t b = 0; b < B; ++b)
+                    for (int64_t i = 0; i < hs; ++i) {
+                        const int64_t slot = b * S + (int64_t)half * hs + i;
+                        const int64_t nc = (int64_t)(((__int128)A * slot + C) % nw);
+                        int64_t prel; double uz, ua;
+                        kmco_draw(c->seed, step, (uint64_t)slot, hs, &prel, &uz, &ua);
+                        const int64_t pslot = b * S + (int64_t)(1 - half) * hs + prel;
+                        const int64_t no = (int64_t)(((__int128)A * pslot + C) % nw);
+                        const double t = fma(uz, c1, c0);
+                        const double z = t * t;
+                        const double* xc = pos + nc * nd;
+                        const double* xo = pos + no * nd;
+                        for (int64_t d = 0; d < nd; ++d) y[d] = fma(z, xc[d] - xo[d], xo[d]);
+                        const double p1 = kmco_logpdf(c->density, c->params, y, nd);
+                        const double lhs = (nm1 * log(z) + p1) - logp[nc];
+                        if (lhs >= log(ua)) { memcpy(pos + nc * nd, y, sizeof(double) * (size_t)nd); logp[nc] = p1; }
+                    }
+            }
+            if (n > 0 && n % c->nthin == 0 && n / c->nthin - 1 < nsamples) {
+                for (int64_t w = 0; w < nw; ++w)
+                    for (int64_t d = 0; d < nd; ++d) {
+                        const double v = pos[w * nd + d];
+                        if (msum) msum[d] += v;
+                        if (msumsq) msumsq[d] += v * v;
+                    }
+                nmom += nw;
+            }
+        }
+        free(y);
+    }
+    const double denom = (double)(c->ngenerations - c->nburnin);
+    for (int64_t w = 0; w < nw; ++w) {
+        if (accept_ratio) accept_ratio[w] = (double)nacc[w] / denom;
+        if (naccept_out) naccept_out[w] = nacc[w];
+    }
+    if (final_pos) memcpy(final_pos, pos, sizeof(double) * (size_t)(nw * nd));
+    if (final_logp) memcpy(final_logp, logp, sizeof(double) * (size_t)nw);
+    if (nmoment) *nmoment = nmom;
+    free(pos); free(logp); free(nacc);
+    return KMCO_OK;
+}
