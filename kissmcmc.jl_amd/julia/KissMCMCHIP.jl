@@ -60,7 +60,7 @@ user_handle(::DeviceLogPdf) = C_NULL
 function (d::ExprDensity)(x)
     xs = collect(Float64, x isa Number ? [x] : x); out = Ref(0.0)
     p8 = ntuple(i -> i <= length(d.p) ? d.p[i] : 0.0, 8)
-    cfg = Ref(KmcConfig(0, Cint(100), p8, 2, length(xs), 0, 0, 1, 2.0, UInt64(0), 0, 0, 0, 1, d.handle))
+    cfg = Ref(KmcConfig(0, Cint(100), p8, 2, length(xs), 0, 0, 1, 2.0, UInt64(0), 0, 0, 0, 1, d.handle, 0, 0))
     st = ccall((:kmc_logpdf_eval_host, LIB), Cint, (Ref{KmcConfig}, Ptr{Float64}, Ref{Float64}, Int64), cfg, xs, out, 1)
     st == 0 || error(last_error()); out[]
 end
@@ -73,6 +73,7 @@ struct KmcConfig
     a_scale::Float64; seed::UInt64
     flags::UInt32; device::Int32; shard_rank::Int32; shard_count::Int32
     user_density::Ptr{Cvoid}
+    island_gens::Int32; island_size::Int32     # KMC_ISLANDS (opt-in island mode); 0 = defaults
 end
 
 mutable struct KmcOutputs
@@ -109,7 +110,7 @@ function emcee(pdf::DeviceLogPdf, theta0s; niter=10^5, nburnin=niter ÷ 2, nthin
     end
     p = params(pdf); p8 = ntuple(i -> i <= length(p) ? p[i] : 0.0, 8)
     cfg = Ref(KmcConfig(0, density_id(pdf), p8, nwalkers, ndim, niter_walker, nburnin_walker, nthin,
-                        a_scale, UInt64(seed), 0x3, Int32(device), 0, 1, user_handle(pdf)))   # flags: STORE_CHAIN | STORE_LOGP
+                        a_scale, UInt64(seed), 0x3, Int32(device), 0, 1, user_handle(pdf), 0, 0))   # flags: STORE_CHAIN | STORE_LOGP
     chain = Array{Float64}(undef, ndim, nwalkers, nsamples)
     clogp = Array{Float64}(undef, nwalkers, nsamples)
     acc = Vector{Float64}(undef, nwalkers)
