@@ -123,6 +123,18 @@ IslandFn island_fn(int density, int S, int K, bool ragged)
     }
 }
 
+ResidentFn resident_fn(int density, int K, bool ragged)
+{
+    switch (density) {
+    case KMC_GAUSSIAN_ISO: return resident_gaussian_iso(K, ragged);
+    case KMC_EXPONENTIAL: return resident_exponential(K, ragged);
+    case KMC_ROSENBROCK: return resident_rosenbrock(K, ragged);
+    case KMC_LOGNORMAL: return resident_lognormal(K, ragged);
+    case KMC_MVNORMAL2: return resident_mvnormal2(K, ragged);
+    default: return nullptr;
+    }
+}
+
 // Philox4x32-10 on the host (only for the island deal; Salmon et al., SC'11).
 void philox_host(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
 {
@@ -407,6 +419,9 @@ struct kmc_sampler {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool have_run_events = false;
     bool positions_set = false;
+    // resident mode: exact sampler, whole (small) ensemble in one workgroup's LDS, many generations per launch
+    bool resident = false;
+    ResidentFn resident_kernel = nullptr;
     // island mode (KMC_ISLANDS)
     bool islands = false;
     IslandFn island_kernel = nullptr;
@@ -682,6 +697,26 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->island_lds);
         if (ea != hipSuccess) { (void)hipGetLastError(); delete s; return fail(KMC_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(ea)); }
     }
+    if (!s->islands && cfg->density != KMC_USER_DENSITY && cfg->nwalkers <= 256 && cfg->ndim <= 32 &&
+        s->cfg.shard_count == 1 && !(cfg->flags & (KMC_P2P | KMC_NO_GRAPH)) && std::getenv("KMC_NO_RESIDENT") == nullptr) {
+        const int64_t chunks = s->ld / 2;
+        int K = 1;
+        while (2 * K < chunks) K *= 2;
+        ResidentFn rf = resident_fn(cfg->density, K, 4 * K != cfg->ndim);
+        if (rf) {
+            s->island_lds = ((size_t)cfg->nwalkers * (size_t)(s->ld + 2) + (size_t)cfg->nwalkers) * sizeof(double);
+            if (s->island_lds < 4096) s->island_lds = 4096;     // the moment reduction reuses the buffer
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(rf), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)s->island_lds) == hipSuccess) {
+                s->resident = true;
+                s->resident_kernel = rf;
+                s->island_K = K;
+                s->nislands = 1;
+            } else {
+                (void)hipGetLastError();
+            }
+        }
+    }
     // vec kernels: kTPB threads per workgroup; the generic kernel keeps 256
     const int tpb = s->plan.vec ? kTPB : 256;
     s->tpb = tpb;
@@ -733,7 +768,7 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
             CREATE_TRY(hipMalloc((void**)&s->d_klast, nw * sizeof(uint32_t)));
             CREATE_TRY(hipMemset(s->d_klast, 0, nw * sizeof(uint32_t)));
         }
-        if (s->islands) {
+        if (s->islands || s->resident) {
             const size_t ne = (size_t)s->nislands * 4 * (size_t)s->island_K;
             CREATE_TRY(hipMalloc(&s->d_isum, ne * sizeof(double)));
             CREATE_TRY(hipMalloc(&s->d_isumsq, ne * sizeof(double)));
@@ -926,6 +961,33 @@ KMC_EXPORT kmc_status kmc_sampler_run(kmc_sampler* s, int64_t ngen)
     if (s->p2p && !s->connected) return fail(KMC_ERR_BAD_ARG, "kmc_sampler_p2p_connect has not been called");
     HIP_TRY(hipSetDevice(s->cfg.device));
     HIP_TRY(hipEventRecord(s->ev0, s->stream));
+    if (s->resident) {
+        // the whole ensemble lives in one workgroup's LDS; a launch carries up to 4096 generations
+        while (ngen > 0) {
+            const int64_t n = std::min<int64_t>(ngen, 4096);
+            ResidentArgs ra{};
+            IslandArgs& ia = ra.is;
+            ia.pos = s->d_pos; ia.logp = s->d_logp; ia.naccept = s->d_naccept;
+            ia.nwalkers = s->cfg.nwalkers; ia.permA = 1; ia.permC = 0;
+            ia.gen0 = s->generation; ia.ngen = (int32_t)n;
+            ia.ndim = (int32_t)s->cfg.ndim; ia.ld = (int32_t)s->ld;
+            ia.nburnin = s->cfg.nburnin; ia.nthin = s->cfg.nthin; ia.nsamples = s->nsamples;
+            const HalfStepArgs ha = make_args(s, 0, false, s->generation);
+            ia.dc = ha.dc;                       // nhalf = nwalkers / 2, as in the multi-launch kernels
+            ia.dp = s->dp;
+            ia.msum = s->d_isum; ia.msumsq = s->d_isumsq;
+            ra.S = (int32_t)s->cfg.nwalkers;
+            ra.chain = s->d_chain; ra.chain_logp = s->d_chain_logp;
+            hipLaunchKernelGGL(s->resident_kernel, dim3(1), dim3(256), s->island_lds, s->stream, ra);
+            HIP_TRY(hipGetLastError());
+            s->generation += n;
+            s->launches += 1;
+            ngen -= n;
+        }
+        HIP_TRY(hipEventRecord(s->ev1, s->stream));
+        s->have_run_events = true;
+        return KMC_OK;
+    }
     if (s->islands) {
         // one launch per epoch (or per piece of one, when a run stops inside an epoch)
         while (ngen > 0) {
@@ -980,6 +1042,7 @@ KMC_EXPORT kmc_status kmc_sampler_half_step(kmc_sampler* s, int half)
     if (!s->positions_set) return fail(KMC_ERR_BAD_ARG, "kmc_sampler_set_positions has not succeeded yet");
     if (s->p2p && !s->connected) return fail(KMC_ERR_BAD_ARG, "kmc_sampler_p2p_connect has not been called");
     if (s->islands) return fail(KMC_ERR_UNSUPPORTED, "island mode advances whole generations: use kmc_sampler_run");
+    if (s->resident) return fail(KMC_ERR_UNSUPPORTED, "this small ensemble runs in resident mode (whole generations per launch); create it with KMC_NO_GRAPH to step by halves");
     HIP_TRY(hipSetDevice(s->cfg.device));
     KMC_TRY(launch_half(s, half, false, s->generation));
     s->launches += 1;
@@ -1073,7 +1136,7 @@ KMC_EXPORT kmc_status kmc_sampler_get_moments(kmc_sampler* s, double* sum, doubl
     if (!s) return fail(KMC_ERR_BAD_ARG, "null sampler");
     if (!s->d_msum) return fail(KMC_ERR_BAD_ARG, "sampler was created without KMC_MOMENTS");
     HIP_TRY(hipSetDevice(s->cfg.device));
-    if (s->islands) {
+    if (s->islands || s->resident) {
         HIP_TRY(hipStreamSynchronize(s->stream));
         const int64_t nd = s->cfg.ndim;
         const size_t per = 4 * (size_t)s->island_K, ne = (size_t)s->nislands * per;

@@ -8,4 +8,5 @@ void table_lognormal(int L, int K, int iter, bool p2p, bool ragged, HalfStepFn* 
     density_fns<LogNormal>(L, K, iter, p2p, ragged, vec, gen, lp);
 }
 IslandFn island_lognormal(int S, int K, bool ragged) { return island_lookup<LogNormal>(S, K, ragged); }
+ResidentFn resident_lognormal(int K, bool ragged) { return resident_lookup<LogNormal>(K, ragged); }
 }  // namespace kmc

@@ -187,4 +187,165 @@ __global__ __launch_bounds__(S) void island_epoch(const IslandArgs a)
     island_epoch_body<Dens, S, K, RAGGED>(a);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// RESIDENT mode: the EXACT sampler for small ensembles (nwalkers <= 256, ndim <= 32).
+//
+// When the whole ensemble fits one workgroup's LDS, "the island's complementary half" IS the
+// ensemble's complementary half: a single island with the identity deal and the RNG keyed by the
+// walker index is the reference's algorithm unchanged -- bit-identical to half_step_vec/generic --
+// but a launch now carries many generations (the reference's own sizes: 100 walkers, 10^5..10^7
+// evaluations) instead of half of one, with `__syncthreads()` as the join of src/samplers.jl:273.
+// Unlike the island kernel this one takes any even S <= 256 and also stores the chain (:269-271).
+// ------------------------------------------------------------------------------------------------
+struct ResidentArgs {
+    IslandArgs    is;           // pos/logp/naccept, generations, schedule, draws, density, per-block moments
+    int32_t       S;            // nwalkers (even, <= 256)
+    int32_t       pad_;
+    double*       chain;        // [nsamples][S][ld] or nullptr
+    double*       chain_logp;   // [nsamples][S] or nullptr
+};
+
+template <class Dens, int K, bool RAGGED>
+__device__ __forceinline__ void resident_body(const ResidentArgs& ra)
+{
+    const IslandArgs& a = ra.is;
+    constexpr int L = 2;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int S = ra.S, HS = S / 2;
+    const int ndim = RAGGED ? a.ndim : 4 * K;
+    const int ld   = RAGGED ? a.ld : 4 * K;
+    const int lld  = ld + 2;
+    double* lpos  = lds;                                  // [S][lld]
+    double* llogp = lds + S * lld;                        // [S]
+
+    const int t = threadIdx.x;
+    const int i = t >> 1, j = t & 1;
+    const bool rowv = i < HS;                             // this lane pair has a walker in each half
+    if (t < S) {
+        const double2* src = reinterpret_cast<const double2*>(a.pos + (int64_t)t * a.ld);
+        double2* dst = reinterpret_cast<double2*>(lpos + t * lld);
+        for (int c = 0; c < ld / 2; ++c) dst[c] = src[c];
+        llogp[t] = a.logp[t];
+    }
+    __syncthreads();
+
+    bool cv[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) cv[k] = !RAGGED || 2 * (k * L + j) < ld;
+    const double2 zero2 = make_double2(0.0, 0.0);
+    double2 ms[K], mq[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) { ms[k] = zero2; mq[k] = zero2; }
+    const int lane = t & 63, wave = t >> 6;
+    const int hA   = lane >> 5;
+    const int iA   = (wave << 5) + (lane & 31);           // index within the half served by this scalar lane
+    const bool scv = iA < HS;
+    const int ownA = hA * HS + (scv ? iA : 0);
+    uint32_t naccA = 0u;
+
+    for (int gg = 0; gg < a.ngen; ++gg) {
+        const int64_t gen = a.gen0 + gg;
+        const int64_t n = gen + 1 - a.nburnin;            // the reference's loop variable (:245)
+        const bool count = n > 0;
+        bool sample = false;
+        int64_t slot = 0;
+        if (n > 0 && n % a.nthin == 0) { slot = n / a.nthin - 1; sample = slot < a.nsamples; }   // :268
+        const Draw drA = draw_step(a.dc, 2ull * (uint64_t)gen + (uint64_t)hA, (uint64_t)ownA);   // keyed by the walker index
+        const double p0A = llogp[ownA];
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+            const int own_l = half * HS + (rowv ? i : 0);                         // :247
+            const int src = ((half << 5) + (lane >> 1)) * 4;
+            const int partner = __builtin_amdgcn_ds_bpermute(src, (int)drA.partner);
+            const double z = bperm_f64(src, drA.z);
+            const int oth_l = (1 - half) * HS + (rowv ? partner : 0);
+            const double2* own = reinterpret_cast<const double2*>(lpos + own_l * lld);
+            const double2* oth = reinterpret_cast<const double2*>(lpos + oth_l * lld);
+            double2 xc[K], y[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                xc[k] = cv[k] ? own[k * L + j] : zero2;
+                const double2 xo = cv[k] ? oth[k * L + j] : zero2;
+                y[k].x = fma(z, xc[k].x - xo.x, xo.x);                            // :255
+                y[k].y = fma(z, xc[k].y - xo.y, xo.y);
+            }
+            const double Ssum = group_sum<L>(Dens::template frag_partial<L, K>(y, j, ndim, a.dp));
+            const double p1 = Dens::finish(Ssum, a.dp);                           // :257
+            const double p1A = bperm_f64(((lane & 31) * 2) * 4, p1);
+            const bool accA = scv && (hA == half) && accept_test(drA, p1A, p0A);  // :260
+            const unsigned long long accmask = __ballot(accA);
+            if (accA) {                                                           // :262, :265
+                llogp[ownA] = p1A;
+                if (count) naccA += 1u;
+            }
+            const bool acc = ((accmask >> ((half << 5) + (lane >> 1))) & 1ull) != 0;
+            if (acc) {                                                            // :261
+                double2* ownw = reinterpret_cast<double2*>(lpos + own_l * lld);
+#pragma unroll
+                for (int k = 0; k < K; ++k) if (cv[k]) ownw[k * L + j] = y[k];
+            }
+            if (sample && rowv) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const double2 cur = sel2(acc, y[k], xc[k]);
+                    ms[k].x += cur.x; ms[k].y += cur.y;
+                    mq[k].x += cur.x * cur.x; mq[k].y += cur.y * cur.y;
+                }
+            }
+            __syncthreads();                              // the join of :273
+        }
+        if (sample && (ra.chain != nullptr || ra.chain_logp != nullptr)) {       // :268-271
+            if (t < S) {
+                if (ra.chain != nullptr) {
+                    double2* dst = reinterpret_cast<double2*>(ra.chain + (slot * S + t) * (int64_t)a.ld);
+                    const double2* src2 = reinterpret_cast<const double2*>(lpos + t * lld);
+                    for (int c = 0; c < ld / 2; ++c) dst[c] = src2[c];
+                }
+                if (ra.chain_logp != nullptr) ra.chain_logp[slot * S + t] = llogp[t];
+            }
+            // rows are only read here; the next generation's first writes come after its own barrier-free
+            // reads, by other threads -> order them
+            __syncthreads();
+        }
+    }
+
+    if (t < S) {
+        double2* dst = reinterpret_cast<double2*>(a.pos + (int64_t)t * a.ld);
+        const double2* src = reinterpret_cast<const double2*>(lpos + t * lld);
+        for (int c = 0; c < ld / 2; ++c) dst[c] = src[c];
+        a.logp[t] = llogp[t];
+    }
+    if (naccA) a.naccept[ownA] += naccA;
+    if (a.msum != nullptr) {
+        __syncthreads();
+        double* red = lds;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            ms[k].x = wave_fold<L>(ms[k].x); ms[k].y = wave_fold<L>(ms[k].y);
+            mq[k].x = wave_fold<L>(mq[k].x); mq[k].y = wave_fold<L>(mq[k].y);
+            if (lane < 2) {
+                double* r = red + ((wave * K + k) * 2 + lane) * 4;
+                r[0] = ms[k].x; r[1] = ms[k].y; r[2] = mq[k].x; r[3] = mq[k].y;
+            }
+        }
+        __syncthreads();
+        if (t < 2 * K) {
+            double s0 = 0.0, s1 = 0.0, q0 = 0.0, q1 = 0.0;
+            for (int w = 0; w < 4; ++w) {
+                const double* r = red + ((w * K + (t >> 1)) * 2 + (t & 1)) * 4;
+                s0 += r[0]; s1 += r[1]; q0 += r[2]; q1 += r[3];
+            }
+            a.msum[2 * t] += s0; a.msum[2 * t + 1] += s1;
+            a.msumsq[2 * t] += q0; a.msumsq[2 * t + 1] += q1;
+        }
+    }
+}
+
+template <class Dens, int K, bool RAGGED>
+__global__ __launch_bounds__(256) void resident_epoch(const ResidentArgs a)
+{
+    resident_body<Dens, K, RAGGED>(a);
+}
+
 }  // namespace kmc

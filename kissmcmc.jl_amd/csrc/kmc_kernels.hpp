@@ -129,7 +129,6 @@ __device__ __forceinline__ void accumulate_wave(double* msum, double* msumsq, in
                                                 double2 (&ms)[K], double2 (&mq)[K],
                                                 const double2 (&olds)[K], const double2 (&oldq)[K])
 {
-#ifndef KMC_DIAG_NOFOLD
     if constexpr (L < 64) {
 #pragma unroll
         for (int k = 0; k < K; ++k) {
@@ -137,12 +136,7 @@ __device__ __forceinline__ void accumulate_wave(double* msum, double* msumsq, in
             mq[k].x = wave_fold<L>(mq[k].x); mq[k].y = wave_fold<L>(mq[k].y);
         }
     }
-#endif
-#ifdef KMC_DIAG_NORMW
-    if (g == 0 && ms[0].x == 1.2345e300) {
-#else
     if (g == 0) {
-#endif
         double2* s = reinterpret_cast<double2*>(msum);
         double2* q = reinterpret_cast<double2*>(msumsq);
 #pragma unroll

@@ -10,6 +10,7 @@ using HalfStepFn = void (*)(const HalfStepArgs);
 using LogpdfFn = void (*)(const LogpdfArgs);
 using FlushFn = void (*)(const FlushArgs);
 using IslandFn = void (*)(const IslandArgs);
+using ResidentFn = void (*)(const ResidentArgs);
 
 #ifdef KMC_TABLES_IMPL
 template <class D, int L, int K, int ITER, bool P2P, bool RAGGED>
@@ -97,6 +98,22 @@ IslandFn island_lookup(int S, int K, bool ragged)
         }
     }
 }
+// resident mode: the exact sampler for ensembles that fit one workgroup's LDS
+template <class D>
+ResidentFn resident_lookup(int K, bool ragged)
+{
+    if constexpr (!D::kHasFrag) {
+        return nullptr;
+    } else {
+        switch (K) {
+        case 1: return ragged ? resident_epoch<D, 1, true> : resident_epoch<D, 1, false>;
+        case 2: return ragged ? resident_epoch<D, 2, true> : resident_epoch<D, 2, false>;
+        case 4: return ragged ? resident_epoch<D, 4, true> : resident_epoch<D, 4, false>;
+        case 8: return ragged ? resident_epoch<D, 8, true> : resident_epoch<D, 8, false>;
+        default: return nullptr;
+        }
+    }
+}
 #endif  // KMC_TABLES_IMPL
 
 // one entry point per density (defined in kmc_inst_<density>.hip)
@@ -108,9 +125,14 @@ KMC_DECLARE_DENSITY_TABLE(table_rosenbrock);
 KMC_DECLARE_DENSITY_TABLE(table_lognormal);
 KMC_DECLARE_DENSITY_TABLE(table_mvnormal2);
 IslandFn island_gaussian_iso(int S, int K, bool ragged);
+ResidentFn resident_gaussian_iso(int K, bool ragged);
 IslandFn island_exponential(int S, int K, bool ragged);
+ResidentFn resident_exponential(int K, bool ragged);
 IslandFn island_rosenbrock(int S, int K, bool ragged);
+ResidentFn resident_rosenbrock(int K, bool ragged);
 IslandFn island_lognormal(int S, int K, bool ragged);
+ResidentFn resident_lognormal(int K, bool ragged);
 IslandFn island_mvnormal2(int S, int K, bool ragged);
+ResidentFn resident_mvnormal2(int K, bool ragged);
 
 }  // namespace kmc

@@ -161,3 +161,16 @@ def test_graph_replay_equals_eager(kmc, oracle):
     ref2, got2 = _run_both(kmc, oracle, "gauss", 256, 32, 150, 70, 3, seed=5, use_graph=False)
     _compare(ref2, got2)
     np.testing.assert_array_equal(got["chain"], got2["chain"])
+
+
+@pytest.mark.parametrize("name,nw,nd", [("expo", 100, 1), ("rosen", 100, 2), ("gauss", 256, 32), ("gauss", 34, 32), ("lognormal", 64, 3)])
+def test_resident_small_ensemble_kernel_is_the_same_sampler(kmc, oracle, name, nw, nd, monkeypatch):
+    """nwalkers <= 256: the whole ensemble runs out of one workgroup's LDS, many generations per launch
+    (resident mode).  It must be indistinguishable from the launch-per-half-step kernels and the oracle."""
+    ref, res = _run_both(kmc, oracle, name, nw, nd, 200, 60, 2, seed=321)
+    _compare(ref, res)
+    monkeypatch.setenv("KMC_NO_RESIDENT", "1")
+    ref2, multi = _run_both(kmc, oracle, name, nw, nd, 200, 60, 2, seed=321)
+    _compare(ref2, multi)
+    np.testing.assert_array_equal(res["chain"], multi["chain"])
+    np.testing.assert_array_equal(res["naccept"], multi["naccept"])
