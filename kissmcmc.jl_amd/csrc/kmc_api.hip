@@ -269,7 +269,7 @@ namespace {
 
 struct UserKernels {
     hipModule_t mod = nullptr;
-    hipFunction_t vec = nullptr, generic = nullptr, logpdf = nullptr;
+    hipFunction_t vec = nullptr, generic = nullptr, logpdf = nullptr, resident = nullptr;
 };
 
 std::string read_file(const std::string& path)
@@ -293,22 +293,23 @@ std::string library_dir()
 }
 
 kmc_status compile_user(kmc_user_density* ud, bool with_vec, int L, int K, int iter, bool ragged,
-                        const std::vector<char>** out)
+                        int resident_K, bool resident_ragged, const std::vector<char>** out)
 {
-    char key[64];
-    std::snprintf(key, sizeof(key), "%d:%d,%d,%d,%d", (int)with_vec, L, K, iter, (int)ragged);
+    char key[96];
+    std::snprintf(key, sizeof(key), "%d:%d,%d,%d,%d|%d,%d", (int)with_vec, L, K, iter, (int)ragged, resident_K, (int)resident_ragged);
     std::lock_guard<std::mutex> lock(ud->mu);
     auto it = ud->code.find(key);
     if (it != ud->code.end()) { *out = &it->second; return KMC_OK; }
 
     const char* envdir = std::getenv("KMC_CSRC_DIR");
     const std::string dir = envdir ? std::string(envdir) : library_dir() + "/csrc";
-    const std::string h_dev = read_file(dir + "/kmc_device.hpp"), h_ker = read_file(dir + "/kmc_kernels.hpp");
-    if (h_dev.empty() || h_ker.empty())
+    const std::string h_dev = read_file(dir + "/kmc_device.hpp"), h_ker = read_file(dir + "/kmc_kernels.hpp"),
+                      h_isl = read_file(dir + "/kmc_islands.hpp");
+    if (h_dev.empty() || h_ker.empty() || h_isl.empty())
         return fail(KMC_ERR_BAD_ARG, "user density: kernel headers not found in " + dir + " (set KMC_CSRC_DIR)");
 
     std::ostringstream src;
-    src << "#define KMC_TPB " << kTPB << "\n#include \"kmc_kernels.hpp\"\n"
+    src << "#define KMC_TPB " << kTPB << "\n#include \"kmc_islands.hpp\"\n"
         << "namespace {\nstruct UserF {\n"
         << "  static constexpr bool kHasPair = " << (ud->has_pair ? "true" : "false") << ";\n"
         << "  __device__ static double term(double x, int d, int n, const double* p) { (void)d; (void)n; (void)p; return (" << ud->term << "); }\n"
@@ -320,12 +321,15 @@ kmc_status compile_user(kmc_user_density* ud, bool with_vec, int L, int K, int i
     if (with_vec)
         src << "extern \"C\" __global__ __launch_bounds__(" << kTPB << ") void kmc_user_vec(const kmc::HalfStepArgs a) { kmc::half_step_vec_body<UD, "
             << L << ", " << K << ", " << iter << ", false, " << (ragged ? "true" : "false") << ">(a); }\n";
+    if (resident_K > 0)
+        src << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_resident(const kmc::ResidentArgs a) { kmc::resident_body<UD, "
+            << resident_K << ", " << (resident_ragged ? "true" : "false") << ">(a); }\n";
     const std::string text = src.str();
 
     hiprtcProgram prog = nullptr;
-    const char* headers[2] = {h_ker.c_str(), h_dev.c_str()};
-    const char* names[2] = {"kmc_kernels.hpp", "kmc_device.hpp"};
-    if (hiprtcCreateProgram(&prog, text.c_str(), "kmc_user_density.hip", 2, headers, names) != HIPRTC_SUCCESS)
+    const char* headers[3] = {h_ker.c_str(), h_dev.c_str(), h_isl.c_str()};
+    const char* names[3] = {"kmc_kernels.hpp", "kmc_device.hpp", "kmc_islands.hpp"};
+    if (hiprtcCreateProgram(&prog, text.c_str(), "kmc_user_density.hip", 3, headers, names) != HIPRTC_SUCCESS)
         return fail(KMC_ERR_HIP, "hiprtcCreateProgram failed");
     const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"};
     const hiprtcResult r = hiprtcCompileProgram(prog, 4, opts);
@@ -347,24 +351,26 @@ kmc_status compile_user(kmc_user_density* ud, bool with_vec, int L, int K, int i
     return KMC_OK;
 }
 
-kmc_status load_user(kmc_user_density* ud, bool with_vec, int L, int K, int iter, bool ragged, UserKernels* uk)
+kmc_status load_user(kmc_user_density* ud, bool with_vec, int L, int K, int iter, bool ragged, UserKernels* uk,
+                     int resident_K = 0, bool resident_ragged = false)
 {
     const std::vector<char>* code = nullptr;
-    KMC_TRY(compile_user(ud, with_vec, L, K, iter, ragged, &code));
+    KMC_TRY(compile_user(ud, with_vec, L, K, iter, ragged, resident_K, resident_ragged, &code));
     HIP_TRY(hipModuleLoadData(&uk->mod, code->data()));
     HIP_TRY(hipModuleGetFunction(&uk->generic, uk->mod, "kmc_user_generic"));
     HIP_TRY(hipModuleGetFunction(&uk->logpdf, uk->mod, "kmc_user_logpdf"));
     if (with_vec) HIP_TRY(hipModuleGetFunction(&uk->vec, uk->mod, "kmc_user_vec"));
+    if (resident_K > 0) HIP_TRY(hipModuleGetFunction(&uk->resident, uk->mod, "kmc_user_resident"));
     return KMC_OK;
 }
 
 template <class Args>
-hipError_t launch_module(hipFunction_t f, unsigned grid, unsigned tpb, hipStream_t st, const Args& args)
+hipError_t launch_module(hipFunction_t f, unsigned grid, unsigned tpb, hipStream_t st, const Args& args, unsigned lds_bytes = 0)
 {
     Args copy = args;
     size_t size = sizeof(Args);
     void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &copy, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
-    return hipModuleLaunchKernel(f, grid, 1, 1, tpb, 1, 1, 0, st, nullptr, extra);
+    return hipModuleLaunchKernel(f, grid, 1, 1, tpb, 1, 1, lds_bytes, st, nullptr, extra);
 }
 
 }  // namespace
@@ -378,7 +384,7 @@ KMC_EXPORT kmc_status kmc_user_density_create(const char* term_expr, const char*
     ud->has_pair = pair_expr != nullptr && pair_expr[0] != '\0';
     if (ud->has_pair) ud->pair = pair_expr;
     const std::vector<char>* code = nullptr;
-    const kmc_status st = compile_user(ud, false, 0, 0, 0, false, &code);   // syntax check now, not at first use
+    const kmc_status st = compile_user(ud, false, 0, 0, 0, false, 0, false, &code);   // syntax check now, not at first use
     if (st != KMC_OK) { delete ud; return st; }
     *out = ud;
     return KMC_OK;
@@ -671,8 +677,22 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
     if (cfg->density == KMC_USER_DENSITY) {
         if (cfg->flags & KMC_P2P) { delete s; return fail(KMC_ERR_UNSUPPORTED, "user densities are not available with KMC_P2P yet"); }
         s->user = static_cast<kmc_user_density*>(cfg->user_density);
-        st = load_user(s->user, s->plan.vec, s->plan.L, s->plan.K, s->plan.ITER, s->plan.ragged, &s->uk);
+        // small ensembles: resident mode too (one workgroup, LDS within the default 64 KiB limit)
+        int rK = 0;
+        const size_t rlds = ((size_t)cfg->nwalkers * (size_t)(s->ld + 2) + (size_t)cfg->nwalkers) * sizeof(double);
+        if (cfg->nwalkers <= 256 && cfg->ndim <= 32 && s->cfg.shard_count == 1 && !(cfg->flags & (KMC_P2P | KMC_NO_GRAPH | KMC_ISLANDS)) &&
+            rlds <= 60 * 1024 && std::getenv("KMC_NO_RESIDENT") == nullptr) {
+            rK = 1;
+            while (2 * rK < s->ld / 2) rK *= 2;
+        }
+        st = load_user(s->user, s->plan.vec, s->plan.L, s->plan.K, s->plan.ITER, s->plan.ragged, &s->uk, rK, 4 * rK != cfg->ndim);
         if (st != KMC_OK) { delete s; return st; }
+        if (rK > 0) {
+            s->resident = true;
+            s->island_K = rK;
+            s->nislands = 1;
+            s->island_lds = rlds < 4096 ? 4096 : rlds;
+        }
     } else {
         HalfStepFn v, g;
         lookup(cfg->density, 0, 0, 1, false, false, &v, &g, &s->logpdf_fn);
@@ -978,8 +998,12 @@ KMC_EXPORT kmc_status kmc_sampler_run(kmc_sampler* s, int64_t ngen)
             ia.msum = s->d_isum; ia.msumsq = s->d_isumsq;
             ra.S = (int32_t)s->cfg.nwalkers;
             ra.chain = s->d_chain; ra.chain_logp = s->d_chain_logp;
-            hipLaunchKernelGGL(s->resident_kernel, dim3(1), dim3(256), s->island_lds, s->stream, ra);
-            HIP_TRY(hipGetLastError());
+            if (s->user) {
+                HIP_TRY(launch_module(s->uk.resident, 1u, 256u, s->stream, ra, (unsigned)s->island_lds));
+            } else {
+                hipLaunchKernelGGL(s->resident_kernel, dim3(1), dim3(256), s->island_lds, s->stream, ra);
+                HIP_TRY(hipGetLastError());
+            }
             s->generation += n;
             s->launches += 1;
             ngen -= n;
