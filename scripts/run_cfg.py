@@ -1,0 +1,31 @@
+"""Run one BASELINE config for a number of generations (a plain target for rocprofv3).
+Usage: python3 scripts/run_cfg.py C5 [generations] [moments 0/1]"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import kissmcmc_jl_amd as kmc
+
+CONFIGS = {
+    "C2": (kmc.GaussianIso(), 65536, 32),
+    "C3": (kmc.Rosenbrock(), 16384, 64),
+    "C5": (kmc.GaussianIso(), 8192, 1024),
+    "C1": (kmc.Exponential(), 100, 1),
+}
+name = sys.argv[1]
+G = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+mom = bool(int(sys.argv[3])) if len(sys.argv) > 3 else True
+pdf, nw, nd = CONFIGS[name]
+rng = np.random.default_rng(0)
+th = rng.standard_normal((nw, nd))
+if name == "C1":
+    th = 0.5 + 0.1 * np.abs(th)
+if name == "C3":
+    th *= 0.1
+with kmc.Sampler(pdf, nw, nd, 10 ** 9, 0, 1, 2.0, 7, moments=mom) as s:
+    s.set_positions(th)
+    s.run(G)
+    s.sync()
+    print(name, "generations", G, "ms", s.last_run_ms(), "us/half-step", s.last_run_ms() / (2 * G) * 1e3)

@@ -24,8 +24,12 @@ def counters(path, key):
 
 
 def main():
+    global SRC
     tag = sys.argv[1]
     key = sys.argv[2] if len(sys.argv) > 2 else "half_step_vec"
+    if len(sys.argv) > 3:                     # alternative rocprofv3 output directory under gpurun_out/
+        SRC = os.path.join(ROOT, "gpurun_out", sys.argv[3])
+    write_traffic = len(sys.argv) <= 3
     os.makedirs(DST, exist_ok=True)
     shutil.copy(os.path.join(SRC, "kt", "c2_kernel_stats.csv"), os.path.join(DST, f"{tag}_kernel_stats.csv"))
     out = {"tag": tag, "kernel": key,
@@ -61,8 +65,9 @@ def main():
         h, m = pm["TCC_HIT_sum"]["mean"], pm["TCC_MISS_sum"]["mean"]
         out["l2_hit_rate"] = h / (h + m)
     json.dump(out, open(os.path.join(DST, f"{tag}_summary.json"), "w"), indent=1)
-    json.dump({"hbm_bytes_per_launch": out.get("hbm_bytes_per_launch"), "source": f"profiles/{tag}_summary.json"},
-              open(os.path.join(DST, "traffic_c2.json"), "w"))
+    if write_traffic:
+        json.dump({"hbm_bytes_per_launch": out.get("hbm_bytes_per_launch"), "source": f"profiles/{tag}_summary.json"},
+                  open(os.path.join(DST, "traffic_c2.json"), "w"))
     print(json.dumps(out, indent=1))
 
 
