@@ -167,6 +167,38 @@ def main():
                 if drv is not None:
                     drv.sampler.close()
                 drv, mode = None, "allgather"
+        p2p_validated = None
+        if mode == "p2p":
+            # Self-check before anything is timed: 80 generations (one hipGraph replay + an eager tail)
+            # through the peer-to-peer exchange must reproduce, bit for bit, the same generations of the
+            # whole ensemble on ONE GPU (rank 0 runs it unsharded).  Any error, time-out or mismatch on
+            # any rank sends every rank to the all-gather path.
+            vgen = 80
+            try:
+                drv.set_positions(th)
+                drv.run(vgen)
+                drv.sync()
+                vpos, vacc = drv.positions(), drv.naccept()
+                if rank == 0:
+                    with kmc.Sampler(pdf, nw, NDIM, G, nburn, 1, 2.0, SEED, device=local_rank) as ref:
+                        ref.set_positions(th)
+                        ref.run(vgen)
+                        ref.sync()
+                        if not (np.array_equal(ref.positions(), vpos) and np.array_equal(ref.naccept(), vacc)):
+                            print("[rank 0] p2p self-check: sharded run differs from the single-GPU run; "
+                                  "falling back to all-gather", file=sys.stderr)
+                            ok.zero_()
+            except Exception as e:  # noqa: BLE001
+                print(f"[rank {rank}] p2p self-check failed ({e}); falling back to all-gather", file=sys.stderr)
+                ok.zero_()
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            p2p_validated = bool(ok.item() != 0)
+            if not p2p_validated:
+                try:
+                    drv.sampler.close()
+                except Exception:  # noqa: BLE001
+                    pass
+                drv, mode = None, "allgather"
         if mode == "p2p":
             drv.set_positions(th)
             drv.run(args.warmup * GENS_PER_STEP)
@@ -185,7 +217,8 @@ def main():
             msum, msq, nmom = drv.moments()
             acc = float(drv.naccept().sum() / nw / max(1, G - nburn))
             drv.close()
-            parallelism = f"walker-sharded x{world}, peer-to-peer partner reads over xGMI (IPC), progress-flag ordering"
+            parallelism = (f"walker-sharded x{world}, peer-to-peer partner reads over xGMI (IPC), progress-flag ordering; "
+                           "self-check vs the unsharded single-GPU run: bit-identical")
         else:
             ex = HipShardExecutor(pdf, nw, NDIM, G, nburn, 1, 2.0, SEED, rank=rank, world=world, device=local_rank)
             ex.set_positions(th)

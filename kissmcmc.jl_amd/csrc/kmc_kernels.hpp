@@ -162,7 +162,7 @@ __device__ __forceinline__ void wait_for_peers(const HalfStepArgs& a, unsigned l
         __builtin_amdgcn_s_sleep(2);
         ok = lane >= a.nranks ||
              __hip_atomic_load(a.flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= need;
-        if (++spins > 4000000u) {                 // seconds: a peer died -- flag it and fall through
+        if (++spins > 30000000u) {                // tens of seconds: a peer died -- flag it and fall through
             if (lane == 0) __hip_atomic_store(a.err, need + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             break;
         }

@@ -32,7 +32,7 @@ def test_p2p_single_rank_equals_plain_sampler(kmc, oracle):
     assert mom[2] == ref["nmoment"]
 
 
-def _worker(rank, world, port, outdir, plan):
+def _worker(rank, world, port, outdir, plan, late_rank=-1):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     import kissmcmc_jl_amd as kmc
@@ -45,6 +45,9 @@ def _worker(rank, world, port, outdir, plan):
     try:
         drv = P2PEmcee(kmc.GaussianIso(), NW, ND, G, NBURN, 1, 2.0, SEED, device=0)
         drv.set_positions(_theta0())
+        if rank == late_rank:
+            import time
+            time.sleep(1.5)              # uneven start: the others spin on this rank's progress flag meanwhile
         drv.run(G)                       # graph replays + eager tail, all enqueued at once
         drv.sync()
         pos, logp, nacc = drv.positions(), drv.logp(), drv.naccept()
@@ -74,3 +77,15 @@ def test_p2p_processes_sharing_one_gpu_equal_oracle(oracle, tmp_path, world, pla
     assert np.all(np.abs(z["logp"] - ref["final_logp"]) <= 1e-12 * np.maximum(1.0, np.abs(ref["final_logp"])))
     assert int(z["n"]) == ref["nmoment"]
     np.testing.assert_allclose(z["s"], ref["sum"], rtol=1e-11, atol=1e-9)
+
+
+def test_p2p_tolerates_a_late_rank(oracle, tmp_path):
+    """One rank starts 1.5 s after the others: they wait inside their first half-step (bounded spin on
+    the late rank's progress flag) and the result is still bit-exact."""
+    import torch.multiprocessing as mp
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), "", 1), nprocs=2, join=True)
+    ref = oracle.emcee(oracle.make_config(oracle.GAUSSIAN_ISO, [0.0, 1.0], NW, ND, G, NBURN, 1, 2.0, SEED),
+                       _theta0(), store_chain=False)
+    z = np.load(os.path.join(str(tmp_path), "out.npz"))
+    np.testing.assert_array_equal(z["nacc"], ref["naccept"])
+    np.testing.assert_array_equal(z["pos"], ref["final_pos"])
