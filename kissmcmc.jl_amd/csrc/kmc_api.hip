@@ -686,7 +686,7 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
             while (2 * rK < s->ld / 2) rK *= 2;
         }
         st = load_user(s->user, s->plan.vec, s->plan.L, s->plan.K, s->plan.ITER, s->plan.ragged, &s->uk, rK, 4 * rK != cfg->ndim);
-        if (st != KMC_OK) { delete s; return st; }
+        if (st != KMC_OK) { kmc_sampler_destroy(s); return st; }
         if (rK > 0) {
             s->resident = true;
             s->island_K = rK;
@@ -711,11 +711,11 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         s->island_K = K;
         s->island_ragged = 4 * K != cfg->ndim;
         s->island_kernel = island_fn(cfg->density, (int)s->island_size, K, s->island_ragged);
-        if (!s->island_kernel) { delete s; return fail(KMC_ERR_UNSUPPORTED, "no island kernel for this density / ndim"); }
+        if (!s->island_kernel) { kmc_sampler_destroy(s); return fail(KMC_ERR_UNSUPPORTED, "no island kernel for this density / ndim"); }
         s->island_lds = ((size_t)s->island_size * (size_t)(s->ld + 2) + (size_t)s->island_size) * sizeof(double);
         hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(s->island_kernel),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->island_lds);
-        if (ea != hipSuccess) { (void)hipGetLastError(); delete s; return fail(KMC_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(ea)); }
+        if (ea != hipSuccess) { (void)hipGetLastError(); kmc_sampler_destroy(s); return fail(KMC_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(ea)); }
     }
     if (!s->islands && cfg->density != KMC_USER_DENSITY && cfg->nwalkers <= 256 && cfg->ndim <= 32 &&
         s->cfg.shard_count == 1 && !(cfg->flags & (KMC_P2P | KMC_NO_GRAPH)) && std::getenv("KMC_NO_RESIDENT") == nullptr) {

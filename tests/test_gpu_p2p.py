@@ -89,3 +89,47 @@ def test_p2p_tolerates_a_late_rank(oracle, tmp_path):
     z = np.load(os.path.join(str(tmp_path), "out.npz"))
     np.testing.assert_array_equal(z["nacc"], ref["naccept"])
     np.testing.assert_array_equal(z["pos"], ref["final_pos"])
+
+
+def _long_worker(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import kissmcmc_jl_amd as kmc
+    from kissmcmc_jl_amd.distributed import P2PEmcee
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        nw, nd, G = 32768, 32, 700
+        th = np.random.default_rng(99).standard_normal((nw, nd))
+        drv = P2PEmcee(kmc.GaussianIso(), nw, nd, G, 100, 1, 2.0, 2718, device=0)
+        drv.set_positions(th)
+        drv.run(G)
+        drv.sync()
+        pos, nacc = drv.positions(), drv.naccept()
+        s, q, n = drv.moments()
+        if rank == 0:
+            np.savez(os.path.join(outdir, "long.npz"), pos=pos, nacc=nacc, s=s, n=n)
+        drv.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_p2p_long_run_equals_unsharded_gpu_run(kmc, tmp_path):
+    """700 generations (ten hipGraph replays + tail) of a 32 768-walker ensemble over two processes:
+    1400 flag-ordered half-steps with peer reads; any stale or torn row would break bit-equality with
+    the one-process run of the same ensemble."""
+    import torch.multiprocessing as mp
+    mp.spawn(_long_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    nw, nd, G = 32768, 32, 700
+    th = np.random.default_rng(99).standard_normal((nw, nd))
+    with kmc.Sampler(kmc.GaussianIso(), nw, nd, G, 100, 1, 2.0, 2718, moments=True) as s:
+        s.set_positions(th)
+        s.run(G)
+        s.sync()
+        pos, nacc, mom = s.positions(), s.naccept(), s.moments()
+    z = np.load(os.path.join(str(tmp_path), "long.npz"))
+    np.testing.assert_array_equal(z["pos"], pos)
+    np.testing.assert_array_equal(z["nacc"], nacc)
+    assert int(z["n"]) == mom[2]
+    np.testing.assert_allclose(z["s"], mom[0], rtol=1e-11, atol=1e-8)
