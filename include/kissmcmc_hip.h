@@ -76,7 +76,8 @@ enum {
                                   for `island_gens` generations per launch and draw partners from their own complementary
                                   half; walkers are re-dealt to islands between launches.  Same target distribution, far
                                   fewer kernel boundaries and no HBM traffic inside an epoch.  Needs nwalkers % island_size == 0,
-                                  island_size >= ndim + 2, ndim <= 32, shard_count == 1; no chain storage. */
+                                  island_size >= ndim + 2, ndim <= 32, shard_count == 1; no chain storage.  Works with user densities
+                                  when island_size * (ndim + 3) * 8 B <= 60 KiB. */
     KMC_P2P         = 1u << 4  /* walker sharding with peer-to-peer partner reads over xGMI: the sampler holds only
                                   its shard ([2][nwalkers/2/shard_count][ndim], halves back to back), reads partner
                                   rows straight from the owning rank's HBM and synchronises half-steps with
@@ -141,7 +142,8 @@ double      kmc_cdf_g_inv(double u, double a);
  *      same kernels:  log p(x) = sum_d TERM + sum_{d<n-1} PAIR, where
  *        term_expr may use  x (= x_d), d, n (= ndim), p (const double*, = params[0..5]);
  *        pair_expr may use  x (= x_d), y (= x_{d+1}), d, n, p;   NULL/"" = no pair term.
- *      A term may evaluate to -INFINITY to reject a proposal.  Not available with KMC_P2P. */
+ *      A term may evaluate to -INFINITY to reject a proposal.  Works in the multi-launch, resident and
+ *      island modes; not available with KMC_P2P. */
 kmc_status  kmc_user_density_create(const char* term_expr, const char* pair_expr, kmc_user_density** out);
 void        kmc_user_density_destroy(kmc_user_density* ud);
 

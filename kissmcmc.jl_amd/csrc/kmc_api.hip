@@ -269,7 +269,7 @@ namespace {
 
 struct UserKernels {
     hipModule_t mod = nullptr;
-    hipFunction_t vec = nullptr, generic = nullptr, logpdf = nullptr, resident = nullptr;
+    hipFunction_t vec = nullptr, generic = nullptr, logpdf = nullptr, resident = nullptr, island = nullptr;
 };
 
 std::string read_file(const std::string& path)
@@ -293,10 +293,12 @@ std::string library_dir()
 }
 
 kmc_status compile_user(kmc_user_density* ud, bool with_vec, int L, int K, int iter, bool ragged,
-                        int resident_K, bool resident_ragged, const std::vector<char>** out)
+                        int resident_K, bool resident_ragged, int island_S, const std::vector<char>** out)
 {
+    // resident_K also sizes the island kernel (same row striping: 2 lanes per walker, K chunks)
     char key[96];
-    std::snprintf(key, sizeof(key), "%d:%d,%d,%d,%d|%d,%d", (int)with_vec, L, K, iter, (int)ragged, resident_K, (int)resident_ragged);
+    std::snprintf(key, sizeof(key), "%d:%d,%d,%d,%d|%d,%d|%d", (int)with_vec, L, K, iter, (int)ragged, resident_K,
+                  (int)resident_ragged, island_S);
     std::lock_guard<std::mutex> lock(ud->mu);
     auto it = ud->code.find(key);
     if (it != ud->code.end()) { *out = &it->second; return KMC_OK; }
@@ -321,9 +323,12 @@ kmc_status compile_user(kmc_user_density* ud, bool with_vec, int L, int K, int i
     if (with_vec)
         src << "extern \"C\" __global__ __launch_bounds__(" << kTPB << ") void kmc_user_vec(const kmc::HalfStepArgs a) { kmc::half_step_vec_body<UD, "
             << L << ", " << K << ", " << iter << ", false, " << (ragged ? "true" : "false") << ">(a); }\n";
-    if (resident_K > 0)
+    if (resident_K > 0 && island_S == 0)
         src << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_resident(const kmc::ResidentArgs a) { kmc::resident_body<UD, "
             << resident_K << ", " << (resident_ragged ? "true" : "false") << ">(a); }\n";
+    if (resident_K > 0 && island_S > 0)
+        src << "extern \"C\" __global__ __launch_bounds__(" << island_S << ") void kmc_user_island(const kmc::IslandArgs a) { kmc::island_epoch_body<UD, "
+            << island_S << ", " << resident_K << ", " << (resident_ragged ? "true" : "false") << ">(a); }\n";
     const std::string text = src.str();
 
     hiprtcProgram prog = nullptr;
@@ -352,15 +357,16 @@ kmc_status compile_user(kmc_user_density* ud, bool with_vec, int L, int K, int i
 }
 
 kmc_status load_user(kmc_user_density* ud, bool with_vec, int L, int K, int iter, bool ragged, UserKernels* uk,
-                     int resident_K = 0, bool resident_ragged = false)
+                     int resident_K = 0, bool resident_ragged = false, int island_S = 0)
 {
     const std::vector<char>* code = nullptr;
-    KMC_TRY(compile_user(ud, with_vec, L, K, iter, ragged, resident_K, resident_ragged, &code));
+    KMC_TRY(compile_user(ud, with_vec, L, K, iter, ragged, resident_K, resident_ragged, island_S, &code));
     HIP_TRY(hipModuleLoadData(&uk->mod, code->data()));
     HIP_TRY(hipModuleGetFunction(&uk->generic, uk->mod, "kmc_user_generic"));
     HIP_TRY(hipModuleGetFunction(&uk->logpdf, uk->mod, "kmc_user_logpdf"));
     if (with_vec) HIP_TRY(hipModuleGetFunction(&uk->vec, uk->mod, "kmc_user_vec"));
-    if (resident_K > 0) HIP_TRY(hipModuleGetFunction(&uk->resident, uk->mod, "kmc_user_resident"));
+    if (resident_K > 0 && island_S == 0) HIP_TRY(hipModuleGetFunction(&uk->resident, uk->mod, "kmc_user_resident"));
+    if (resident_K > 0 && island_S > 0) HIP_TRY(hipModuleGetFunction(&uk->island, uk->mod, "kmc_user_island"));
     return KMC_OK;
 }
 
@@ -384,7 +390,7 @@ KMC_EXPORT kmc_status kmc_user_density_create(const char* term_expr, const char*
     ud->has_pair = pair_expr != nullptr && pair_expr[0] != '\0';
     if (ud->has_pair) ud->pair = pair_expr;
     const std::vector<char>* code = nullptr;
-    const kmc_status st = compile_user(ud, false, 0, 0, 0, false, 0, false, &code);   // syntax check now, not at first use
+    const kmc_status st = compile_user(ud, false, 0, 0, 0, false, 0, false, 0, &code);   // syntax check now, not at first use
     if (st != KMC_OK) { delete ud; return st; }
     *out = ud;
     return KMC_OK;
@@ -628,8 +634,10 @@ KMC_EXPORT kmc_status kmc_validate(const kmc_config* c)
     if (c->flags & KMC_ISLANDS) {
         const int64_t S = c->island_size > 0 ? c->island_size : kIslandSizeDefault;
         if ((S != 64 && S != 128 && S != 256) || c->nwalkers % S != 0 || c->ndim > 32 || c->ndim + 2 > S || P != 1 ||
-            (c->flags & (KMC_P2P | KMC_STORE_CHAIN | KMC_STORE_LOGP)) || c->density == KMC_USER_DENSITY || c->island_gens < 0)
-            return fail(KMC_ERR_UNSUPPORTED, "KMC_ISLANDS needs island_size in {64,128,256} >= ndim+2 dividing nwalkers, ndim <= 32, one shard, a menu density and no chain storage");
+            (c->flags & (KMC_P2P | KMC_STORE_CHAIN | KMC_STORE_LOGP)) || c->island_gens < 0)
+            return fail(KMC_ERR_UNSUPPORTED, "KMC_ISLANDS needs island_size in {64,128,256} >= ndim+2 dividing nwalkers, ndim <= 32, one shard and no chain storage");
+        if (c->density == KMC_USER_DENSITY && (size_t)S * (size_t)(c->ndim + (c->ndim & 1) + 3) * sizeof(double) > 60 * 1024)
+            return fail(KMC_ERR_UNSUPPORTED, "KMC_ISLANDS with a user density: island_size * (ndim + 3) * 8 must stay below 60 KiB (use island_size 128 or 64)");
     }
     DensityParams dp;
     return digest_params(*c, &dp);
@@ -685,8 +693,15 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
             rK = 1;
             while (2 * rK < s->ld / 2) rK *= 2;
         }
-        st = load_user(s->user, s->plan.vec, s->plan.L, s->plan.K, s->plan.ITER, s->plan.ragged, &s->uk, rK, 4 * rK != cfg->ndim);
+        int iS = 0;
+        if (cfg->flags & KMC_ISLANDS) {
+            iS = cfg->island_size > 0 ? cfg->island_size : kIslandSizeDefault;
+            rK = 1;
+            while (2 * rK < s->ld / 2) rK *= 2;
+        }
+        st = load_user(s->user, s->plan.vec, s->plan.L, s->plan.K, s->plan.ITER, s->plan.ragged, &s->uk, rK, 4 * rK != cfg->ndim, iS);
         if (st != KMC_OK) { kmc_sampler_destroy(s); return st; }
+        if (iS > 0) rK = 0;     // island mode is set up below, not resident mode
         if (rK > 0) {
             s->resident = true;
             s->island_K = rK;
@@ -710,11 +725,15 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         while (2 * K < chunks) K *= 2;
         s->island_K = K;
         s->island_ragged = 4 * K != cfg->ndim;
-        s->island_kernel = island_fn(cfg->density, (int)s->island_size, K, s->island_ragged);
-        if (!s->island_kernel) { kmc_sampler_destroy(s); return fail(KMC_ERR_UNSUPPORTED, "no island kernel for this density / ndim"); }
         s->island_lds = ((size_t)s->island_size * (size_t)(s->ld + 2) + (size_t)s->island_size) * sizeof(double);
-        hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(s->island_kernel),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->island_lds);
+        if (s->island_lds < 4096) s->island_lds = 4096;          // the moment reduction reuses the buffer
+        hipError_t ea = hipSuccess;
+        if (!s->user) {
+            s->island_kernel = island_fn(cfg->density, (int)s->island_size, K, s->island_ragged);
+            if (!s->island_kernel) { kmc_sampler_destroy(s); return fail(KMC_ERR_UNSUPPORTED, "no island kernel for this density / ndim"); }
+            ea = hipFuncSetAttribute(reinterpret_cast<const void*>(s->island_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->island_lds);
+        }
         if (ea != hipSuccess) { (void)hipGetLastError(); kmc_sampler_destroy(s); return fail(KMC_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(ea)); }
     }
     if (!s->islands && cfg->density != KMC_USER_DENSITY && cfg->nwalkers <= 256 && cfg->ndim <= 32 &&
@@ -1030,8 +1049,12 @@ KMC_EXPORT kmc_status kmc_sampler_run(kmc_sampler* s, int64_t ngen)
             ia.dc.nhalf = (uint32_t)(s->island_size / 2);
             ia.dp = s->dp;
             ia.msum = s->d_isum; ia.msumsq = s->d_isumsq;
-            hipLaunchKernelGGL(s->island_kernel, dim3((unsigned)s->nislands), dim3((unsigned)s->island_size), s->island_lds, s->stream, ia);
-            HIP_TRY(hipGetLastError());
+            if (s->user) {
+                HIP_TRY(launch_module(s->uk.island, (unsigned)s->nislands, (unsigned)s->island_size, s->stream, ia, (unsigned)s->island_lds));
+            } else {
+                hipLaunchKernelGGL(s->island_kernel, dim3((unsigned)s->nislands), dim3((unsigned)s->island_size), s->island_lds, s->stream, ia);
+                HIP_TRY(hipGetLastError());
+            }
             s->generation += n;
             s->launches += 1;
             ngen -= n;

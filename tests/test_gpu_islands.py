@@ -98,3 +98,23 @@ def test_island_mode_rejects_unsupported_configs(kmc):
         kmc.Sampler(kmc.GaussianIso(), 1024, 64, 10, island_gens=8)          # ndim > 32
     with pytest.raises(kmc.KmcError, match="KMC_ISLANDS needs"):
         kmc.Sampler(kmc.GaussianIso(), 1024, 32, 10, island_gens=8, store_chain=True)
+
+
+@pytest.mark.parametrize("S", [64, 128])
+def test_island_mode_with_a_runtime_compiled_density(kmc, oracle, S):
+    """ExprDensity in island mode (hiprtc-compiled island kernel): same chains as the menu density's
+    island oracle."""
+    nw, nd, G, nburn, k = 1024, 16, 60, 20, 12
+    th = 0.1 * np.random.default_rng(4).standard_normal((nw, nd))
+    pdf = kmc.ExprDensity("d < n-1 ? -((p[0]-x)*(p[0]-x))/p[2] : 0.0", "-(p[1]*((y-x*x)*(y-x*x)))/p[2]", [1.0, 100.0, 20.0])
+    with kmc.Sampler(pdf, nw, nd, G, nburn, 1, 2.0, 77, moments=True, island_gens=k, island_size=S) as s:
+        s.set_positions(th)
+        s.run(G)
+        s.sync()
+        pos, nacc, mom = s.positions(), s.naccept(), s.moments()
+    cfg = oracle.make_config(oracle.ROSENBROCK, [1.0, 100.0, 20.0], nw, nd, G, nburn, 1, 2.0, 77, nthreads=4)
+    ref = oracle.emcee_islands(cfg, S, k, th)
+    np.testing.assert_array_equal(nacc, ref["naccept"])
+    np.testing.assert_array_equal(pos, ref["final_pos"])
+    assert mom[2] == ref["nmoment"]
+    np.testing.assert_allclose(mom[0], ref["sum"], rtol=1e-11, atol=1e-9)
