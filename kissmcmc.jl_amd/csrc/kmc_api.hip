@@ -636,7 +636,7 @@ KMC_EXPORT kmc_status kmc_validate(const kmc_config* c)
         if ((S != 64 && S != 128 && S != 256) || c->nwalkers % S != 0 || c->ndim > 32 || c->ndim + 2 > S || P != 1 ||
             (c->flags & (KMC_P2P | KMC_STORE_CHAIN | KMC_STORE_LOGP)) || c->island_gens < 0)
             return fail(KMC_ERR_UNSUPPORTED, "KMC_ISLANDS needs island_size in {64,128,256} >= ndim+2 dividing nwalkers, ndim <= 32, one shard and no chain storage");
-        if (c->density == KMC_USER_DENSITY && (size_t)S * (size_t)(c->ndim + (c->ndim & 1) + 3) * sizeof(double) > 60 * 1024)
+        if (c->density == KMC_USER_DENSITY && (size_t)S * (size_t)(2 * c->ndim + 9) * sizeof(double) > 60 * 1024)
             return fail(KMC_ERR_UNSUPPORTED, "KMC_ISLANDS with a user density: island_size * (ndim + 3) * 8 must stay below 60 KiB (use island_size 128 or 64)");
     }
     DensityParams dp;
@@ -686,13 +686,12 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         if (cfg->flags & KMC_P2P) { delete s; return fail(KMC_ERR_UNSUPPORTED, "user densities are not available with KMC_P2P yet"); }
         s->user = static_cast<kmc_user_density*>(cfg->user_density);
         // small ensembles: resident mode too (one workgroup, LDS within the default 64 KiB limit)
-        int rK = 0;
-        const size_t rlds = ((size_t)cfg->nwalkers * (size_t)(s->ld + 2) + (size_t)cfg->nwalkers) * sizeof(double);
+        int rK = 0, rK0 = 1;
+        while (2 * rK0 < s->ld / 2) rK0 *= 2;
+        const size_t rlds = ((size_t)cfg->nwalkers * (size_t)(4 * (rK0 + 1)) + (size_t)cfg->nwalkers) * sizeof(double);
         if (cfg->nwalkers <= 256 && cfg->ndim <= 32 && s->cfg.shard_count == 1 && !(cfg->flags & (KMC_P2P | KMC_NO_GRAPH | KMC_ISLANDS)) &&
-            rlds <= 60 * 1024 && std::getenv("KMC_NO_RESIDENT") == nullptr) {
-            rK = 1;
-            while (2 * rK < s->ld / 2) rK *= 2;
-        }
+            rlds <= 60 * 1024 && std::getenv("KMC_NO_RESIDENT") == nullptr)
+            rK = rK0;
         int iS = 0;
         if (cfg->flags & KMC_ISLANDS) {
             iS = cfg->island_size > 0 ? cfg->island_size : kIslandSizeDefault;
@@ -725,7 +724,7 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         while (2 * K < chunks) K *= 2;
         s->island_K = K;
         s->island_ragged = 4 * K != cfg->ndim;
-        s->island_lds = ((size_t)s->island_size * (size_t)(s->ld + 2) + (size_t)s->island_size) * sizeof(double);
+        s->island_lds = ((size_t)s->island_size * (size_t)(4 * (K + 1)) + (size_t)s->island_size) * sizeof(double);
         if (s->island_lds < 4096) s->island_lds = 4096;          // the moment reduction reuses the buffer
         hipError_t ea = hipSuccess;
         if (!s->user) {
@@ -743,7 +742,7 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         while (2 * K < chunks) K *= 2;
         ResidentFn rf = resident_fn(cfg->density, K, 4 * K != cfg->ndim);
         if (rf) {
-            s->island_lds = ((size_t)cfg->nwalkers * (size_t)(s->ld + 2) + (size_t)cfg->nwalkers) * sizeof(double);
+            s->island_lds = ((size_t)cfg->nwalkers * (size_t)(4 * (K + 1)) + (size_t)cfg->nwalkers) * sizeof(double);
             if (s->island_lds < 4096) s->island_lds = 4096;     // the moment reduction reuses the buffer
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(rf), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)s->island_lds) == hipSuccess) {

@@ -58,7 +58,10 @@ __device__ __forceinline__ void island_epoch_body(const IslandArgs& a)
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int ndim = RAGGED ? a.ndim : 4 * K;
     const int ld   = RAGGED ? a.ld : 4 * K;
-    const int lld  = ld + 2;                              // LDS row stride: +16 B spreads the banks
+    // LDS row: the two lanes' chunk sets kept apart, K+1 slots each -- chunk (k, j) sits at slot
+    // j*(K+1) + k.  Rows then start 8(K+1) banks apart and the two lanes of a pair 4(K+1) banks apart,
+    // which makes the 16-lane ds_read_b128 groups of the own-row reads conflict-free for K >= 2.
+    constexpr int lld = 4 * (K + 1);                      // doubles per LDS row
     double* lpos  = lds;                                  // [S][lld]
     double* llogp = lds + S * lld;                        // [S]
 
@@ -71,7 +74,7 @@ __device__ __forceinline__ void island_epoch_body(const IslandArgs& a)
     {
         const double2* src = reinterpret_cast<const double2*>(a.pos + wid * (int64_t)a.ld);
         double2* dst = reinterpret_cast<double2*>(lpos + t * lld);
-        for (int c = 0; c < ld / 2; ++c) dst[c] = src[c];
+        for (int c = 0; c < ld / 2; ++c) dst[(c & 1) * (K + 1) + (c >> 1)] = src[c];
         llogp[t] = a.logp[wid];
     }
     __syncthreads();
@@ -112,8 +115,8 @@ __device__ __forceinline__ void island_epoch_body(const IslandArgs& a)
             double2 xc[K], y[K];
 #pragma unroll
             for (int k = 0; k < K; ++k) {
-                xc[k] = cv[k] ? own[k * L + j] : zero2;
-                const double2 xo = cv[k] ? oth[k * L + j] : zero2;
+                xc[k] = cv[k] ? own[j * (K + 1) + k] : zero2;
+                const double2 xo = cv[k] ? oth[j * (K + 1) + k] : zero2;
                 y[k].x = fma(z, xc[k].x - xo.x, xo.x);                            // :255
                 y[k].y = fma(z, xc[k].y - xo.y, xo.y);
             }
@@ -131,7 +134,7 @@ __device__ __forceinline__ void island_epoch_body(const IslandArgs& a)
             if (acc) {                                                            // :261
                 double2* ownw = reinterpret_cast<double2*>(lpos + own_l * lld);
 #pragma unroll
-                for (int k = 0; k < K; ++k) if (cv[k]) ownw[k * L + j] = y[k];
+                for (int k = 0; k < K; ++k) if (cv[k]) ownw[j * (K + 1) + k] = y[k];
             }
             if (sample) {                                 // the walker's state after its update (:268-269)
 #pragma unroll
@@ -149,7 +152,7 @@ __device__ __forceinline__ void island_epoch_body(const IslandArgs& a)
     {
         double2* dst = reinterpret_cast<double2*>(a.pos + wid * (int64_t)a.ld);
         const double2* src = reinterpret_cast<const double2*>(lpos + t * lld);
-        for (int c = 0; c < ld / 2; ++c) dst[c] = src[c];
+        for (int c = 0; c < ld / 2; ++c) dst[c] = src[(c & 1) * (K + 1) + (c >> 1)];
         a.logp[wid] = llogp[t];
     }
     if (naccA) a.naccept[island_walker(a, slot0 + ownA)] += naccA;
@@ -215,7 +218,7 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& ra)
     const int S = ra.S, HS = S / 2;
     const int ndim = RAGGED ? a.ndim : 4 * K;
     const int ld   = RAGGED ? a.ld : 4 * K;
-    const int lld  = ld + 2;
+    constexpr int lld = 4 * (K + 1);                      // same LDS row layout as the island kernel
     double* lpos  = lds;                                  // [S][lld]
     double* llogp = lds + S * lld;                        // [S]
 
@@ -225,7 +228,7 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& ra)
     if (t < S) {
         const double2* src = reinterpret_cast<const double2*>(a.pos + (int64_t)t * a.ld);
         double2* dst = reinterpret_cast<double2*>(lpos + t * lld);
-        for (int c = 0; c < ld / 2; ++c) dst[c] = src[c];
+        for (int c = 0; c < ld / 2; ++c) dst[(c & 1) * (K + 1) + (c >> 1)] = src[c];
         llogp[t] = a.logp[t];
     }
     __syncthreads();
@@ -265,8 +268,8 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& ra)
             double2 xc[K], y[K];
 #pragma unroll
             for (int k = 0; k < K; ++k) {
-                xc[k] = cv[k] ? own[k * L + j] : zero2;
-                const double2 xo = cv[k] ? oth[k * L + j] : zero2;
+                xc[k] = cv[k] ? own[j * (K + 1) + k] : zero2;
+                const double2 xo = cv[k] ? oth[j * (K + 1) + k] : zero2;
                 y[k].x = fma(z, xc[k].x - xo.x, xo.x);                            // :255
                 y[k].y = fma(z, xc[k].y - xo.y, xo.y);
             }
@@ -283,7 +286,7 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& ra)
             if (acc) {                                                            // :261
                 double2* ownw = reinterpret_cast<double2*>(lpos + own_l * lld);
 #pragma unroll
-                for (int k = 0; k < K; ++k) if (cv[k]) ownw[k * L + j] = y[k];
+                for (int k = 0; k < K; ++k) if (cv[k]) ownw[j * (K + 1) + k] = y[k];
             }
             if (sample && rowv) {
 #pragma unroll
@@ -300,7 +303,7 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& ra)
                 if (ra.chain != nullptr) {
                     double2* dst = reinterpret_cast<double2*>(ra.chain + (slot * S + t) * (int64_t)a.ld);
                     const double2* src2 = reinterpret_cast<const double2*>(lpos + t * lld);
-                    for (int c = 0; c < ld / 2; ++c) dst[c] = src2[c];
+                    for (int c = 0; c < ld / 2; ++c) dst[c] = src2[(c & 1) * (K + 1) + (c >> 1)];
                 }
                 if (ra.chain_logp != nullptr) ra.chain_logp[slot * S + t] = llogp[t];
             }
@@ -313,7 +316,7 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& ra)
     if (t < S) {
         double2* dst = reinterpret_cast<double2*>(a.pos + (int64_t)t * a.ld);
         const double2* src = reinterpret_cast<const double2*>(lpos + t * lld);
-        for (int c = 0; c < ld / 2; ++c) dst[c] = src[c];
+        for (int c = 0; c < ld / 2; ++c) dst[c] = src[(c & 1) * (K + 1) + (c >> 1)];
         a.logp[t] = llogp[t];
     }
     if (naccA) a.naccept[ownA] += naccA;
