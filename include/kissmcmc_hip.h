@@ -172,6 +172,19 @@ kmc_status  kmc_sampler_p2p_connect(kmc_sampler* s, const void* handles /* [shar
  * the device (src/samplers.jl:209-210), reset generation/counters.  Fails with
  * KMC_ERR_NONFINITE_LOGP if any is not finite. */
 kmc_status  kmc_sampler_set_positions(kmc_sampler* s, const double* theta_host);
+/* Device-side make_theta0s (src/samplers.jl:311-349, intended behaviour): every walker gets
+ * theta0 + N(0, diag(ball_radius^2)), redrawn (seeded Philox/Box-Muller) while its log-pdf is -inf, the
+ * ball shrinking by the reference's factors 1, 1/2, 1/8, ... after every `ntries` failures; then the
+ * sampler is ready to run as after kmc_sampler_set_positions.  KMC_ERR_NONFINITE_LOGP (with the
+ * reference's message) if a walker finds no admissible point. */
+kmc_status  kmc_sampler_init_ball(kmc_sampler* s, const double* theta0 /* [ndim] */, const double* ball_radius /* [ndim] */,
+                                  uint64_t seed, int halving_steps /* 7 */, int ntries /* 100 */);
+/* Checkpoint / resume: restore positions [rows][ndim], log-pdfs, acceptance counters (may be NULL = 0)
+ * and the generation counter of a previous sampler with the same config.  The random stream is a pure
+ * function of (seed, generation, walker), so the continued run is bit-identical to an uninterrupted
+ * one; moments restart at the restored generation.  Not with chain storage, single GPU. */
+kmc_status  kmc_sampler_set_state(kmc_sampler* s, const double* pos_host, const double* logp_host,
+                                  const int64_t* naccept_host, int64_t generation);
 /* Enqueue `ngenerations` generations (asynchronous).  shard_count must be 1. */
 kmc_status  kmc_sampler_run(kmc_sampler* s, int64_t ngenerations);
 /* Enqueue ONE half-step (src/samplers.jl:248-273) of the current generation over this shard's

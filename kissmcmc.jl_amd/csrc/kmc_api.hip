@@ -135,6 +135,18 @@ ResidentFn resident_fn(int density, int K, bool ragged)
     }
 }
 
+InitBallFn init_ball_fn(int density)
+{
+    switch (density) {
+    case KMC_GAUSSIAN_ISO: return init_ball_gaussian_iso();
+    case KMC_EXPONENTIAL: return init_ball_exponential();
+    case KMC_ROSENBROCK: return init_ball_rosenbrock();
+    case KMC_LOGNORMAL: return init_ball_lognormal();
+    case KMC_MVNORMAL2: return init_ball_mvnormal2();
+    default: return nullptr;
+    }
+}
+
 // Philox4x32-10 on the host (only for the island deal; Salmon et al., SC'11).
 void philox_host(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
 {
@@ -269,7 +281,7 @@ namespace {
 
 struct UserKernels {
     hipModule_t mod = nullptr;
-    hipFunction_t vec = nullptr, generic = nullptr, logpdf = nullptr, resident = nullptr, island = nullptr;
+    hipFunction_t vec = nullptr, generic = nullptr, logpdf = nullptr, resident = nullptr, island = nullptr, init_ball = nullptr;
 };
 
 std::string read_file(const std::string& path)
@@ -319,7 +331,8 @@ kmc_status compile_user(kmc_user_density* ud, bool with_vec, int L, int K, int i
         << (ud->has_pair ? ud->pair : std::string("0.0")) << "); }\n};\n}\n"
         << "using UD = kmc::TermPairDensity<UserF>;\n"
         << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_generic(const kmc::HalfStepArgs a) { kmc::half_step_generic_body<UD, false>(a); }\n"
-        << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_logpdf(const kmc::LogpdfArgs a) { kmc::logpdf_rows_body<UD>(a); }\n";
+        << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_logpdf(const kmc::LogpdfArgs a) { kmc::logpdf_rows_body<UD>(a); }\n"
+        << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_init_ball(const kmc::InitBallArgs a) { kmc::init_ball_body<UD>(a); }\n";
     if (with_vec)
         src << "extern \"C\" __global__ __launch_bounds__(" << kTPB << ") void kmc_user_vec(const kmc::HalfStepArgs a) { kmc::half_step_vec_body<UD, "
             << L << ", " << K << ", " << iter << ", false, " << (ragged ? "true" : "false") << ">(a); }\n";
@@ -364,6 +377,7 @@ kmc_status load_user(kmc_user_density* ud, bool with_vec, int L, int K, int iter
     HIP_TRY(hipModuleLoadData(&uk->mod, code->data()));
     HIP_TRY(hipModuleGetFunction(&uk->generic, uk->mod, "kmc_user_generic"));
     HIP_TRY(hipModuleGetFunction(&uk->logpdf, uk->mod, "kmc_user_logpdf"));
+    HIP_TRY(hipModuleGetFunction(&uk->init_ball, uk->mod, "kmc_user_init_ball"));
     if (with_vec) HIP_TRY(hipModuleGetFunction(&uk->vec, uk->mod, "kmc_user_vec"));
     if (resident_K > 0 && island_S == 0) HIP_TRY(hipModuleGetFunction(&uk->resident, uk->mod, "kmc_user_resident"));
     if (resident_K > 0 && island_S > 0) HIP_TRY(hipModuleGetFunction(&uk->island, uk->mod, "kmc_user_island"));
@@ -423,6 +437,7 @@ struct kmc_sampler {
     double* d_msumsq = nullptr;
     uint32_t* d_klast = nullptr;      // vec kernels: samples already credited per walker
     int64_t macc_stride = 0, macc_elems = 0;
+    int64_t moment_base = 0;  // samples that precede the restored state (kmc_sampler_set_state)
     int64_t generation = 0;   // generations enqueued so far
     int64_t dev_gen = 0;      // value the device counter will hold once the stream drains
     int64_t launches = 0;
@@ -935,6 +950,134 @@ KMC_EXPORT kmc_status kmc_sampler_p2p_connect(kmc_sampler* s, const void* handle
     return KMC_OK;
 }
 
+namespace {
+
+// Everything set_positions does after the rows are in place: initial log-pdfs (src/samplers.jl:209-210)
+// unless they are supplied, counters, accumulators, finiteness check.
+kmc_status reset_run_state(kmc_sampler* s, bool eval_logp, int64_t generation, uint32_t klast_value)
+{
+    const size_t nw = (size_t)s->nrows, nd = (size_t)s->cfg.ndim;
+    if (eval_logp) {
+        const LogpdfArgs la{s->d_pos, s->d_logp, (int64_t)nw, (int32_t)nd, (int32_t)s->ld, s->dp};
+        if (s->user) {
+            HIP_TRY(launch_module(s->uk.logpdf, (unsigned)((nw + 255) / 256), 256u, s->stream, la));
+        } else {
+            hipLaunchKernelGGL(s->logpdf_fn, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s->stream, la);
+            HIP_TRY(hipGetLastError());
+        }
+    }
+    std::vector<double> lp(nw);
+    HIP_TRY(hipMemcpyAsync(lp.data(), s->d_logp, nw * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    if (s->d_msum) {
+        HIP_TRY(hipMemsetAsync(s->d_msum, 0, (size_t)s->macc_elems * sizeof(double), s->stream));
+        HIP_TRY(hipMemsetAsync(s->d_msumsq, 0, (size_t)s->macc_elems * sizeof(double), s->stream));
+        if (s->d_klast) HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)s->d_klast, (int)klast_value, nw, s->stream));
+        if (s->d_isum) {
+            const size_t ne = (size_t)s->nislands * 4 * (size_t)s->island_K;
+            HIP_TRY(hipMemsetAsync(s->d_isum, 0, ne * sizeof(double), s->stream));
+            HIP_TRY(hipMemsetAsync(s->d_isumsq, 0, ne * sizeof(double), s->stream));
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    s->generation = generation;
+    s->launches = 0;
+    s->have_run_events = false;
+    for (size_t w = 0; w < nw; ++w)
+        if (!std::isfinite(lp[w])) {
+            s->positions_set = false;
+            return fail(KMC_ERR_NONFINITE_LOGP, "walker " + std::to_string(w) + " has a non-finite initial log-pdf");
+        }
+    s->positions_set = true;
+    return KMC_OK;
+}
+
+}  // namespace
+
+// Device-side make_theta0s: src/samplers.jl:311-349 (see init_ball in kmc_kernels.hpp).
+KMC_EXPORT kmc_status kmc_sampler_init_ball(kmc_sampler* s, const double* theta0, const double* ball_radius,
+                                            uint64_t seed, int halving_steps, int ntries)
+{
+    if (!s || !theta0 || !ball_radius || halving_steps < 1 || ntries < 1) return fail(KMC_ERR_BAD_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(s->cfg.device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    const size_t nd = (size_t)s->cfg.ndim;
+    double* d_par = nullptr;
+    unsigned long long* d_fail = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_par, 2 * nd * sizeof(double)));
+    hipError_t e = hipMalloc((void**)&d_fail, sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemcpy(d_par, theta0, nd * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_par + nd, ball_radius, nd * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(d_fail, 0, sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(s->d_pos, 0, (size_t)s->nrows * (size_t)s->ld * sizeof(double));
+    InitBallFn fn = s->user ? nullptr : init_ball_fn(s->cfg.density);
+    const int pieces = s->p2p ? 2 : 1;
+    for (int piece = 0; piece < pieces && e == hipSuccess; ++piece) {
+        InitBallArgs a{};
+        const int64_t rows = s->p2p ? s->h_loc : s->nrows;
+        a.pos = s->d_pos + (size_t)piece * (size_t)s->h_loc * (size_t)s->ld;
+        a.logp = s->d_logp + (size_t)piece * (size_t)s->h_loc;
+        a.theta0 = d_par; a.radius = d_par + nd;
+        a.nrows = rows;
+        a.row_walker0 = s->p2p ? (int64_t)piece * s->h + s->active_begin : 0;
+        a.ndim = (int32_t)nd; a.ld = (int32_t)s->ld;
+        a.halving_steps = halving_steps; a.ntries = ntries;
+        a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
+        a.dp = s->dp;
+        a.fail = d_fail;
+        const unsigned grid = (unsigned)((rows + 255) / 256);
+        if (s->user) e = launch_module(s->uk.init_ball, grid, 256u, s->stream, a);
+        else { hipLaunchKernelGGL(fn, dim3(grid), dim3(256), 0, s->stream, a); e = hipGetLastError(); }
+    }
+    unsigned long long nfail = 0;
+    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+    if (e == hipSuccess) e = hipMemcpy(&nfail, d_fail, sizeof(nfail), hipMemcpyDeviceToHost);
+    (void)hipFree(d_par);
+    (void)hipFree(d_fail);
+    HIP_TRY(e);
+    if (nfail != 0) {
+        s->positions_set = false;
+        return fail(KMC_ERR_NONFINITE_LOGP, "Could not find suitable initial theta.  PDF is zero in too many places inside ball. (" +
+                                            std::to_string(nfail) + " walkers)");
+    }
+    HIP_TRY(hipMemsetAsync(s->d_naccept, 0, (size_t)s->nrows * sizeof(uint32_t), s->stream));
+    HIP_TRY(hipMemsetAsync(s->d_gen, 0, 64, s->stream));
+    if (s->p2p) {
+        HIP_TRY(hipMemset(s->d_flags, 0, 4096));
+        HIP_TRY(hipMemset(s->d_err, 0, 64));
+    }
+    s->dev_gen = 0;
+    s->moment_base = 0;
+    return reset_run_state(s, /*eval_logp=*/false, 0, 0u);
+}
+
+// Checkpoint / resume: restore (positions, log-pdfs, acceptance counters, generation).  The random
+// stream is a pure function of (seed, generation, walker), so the continued run is bit-identical to an
+// uninterrupted one.  Moments and the chain restart at the restored generation.
+KMC_EXPORT kmc_status kmc_sampler_set_state(kmc_sampler* s, const double* pos_host, const double* logp_host,
+                                            const int64_t* naccept_host, int64_t generation)
+{
+    if (!s || !pos_host || !logp_host || generation < 0) return fail(KMC_ERR_BAD_ARG, "bad argument");
+    if (s->d_chain || s->d_chain_logp) return fail(KMC_ERR_UNSUPPORTED, "kmc_sampler_set_state: not with chain storage (download the chain before checkpointing)");
+    if (s->p2p && s->cfg.shard_count > 1)
+        return fail(KMC_ERR_UNSUPPORTED, "kmc_sampler_set_state: P2P progress flags restart at 0; restore is single-GPU for now");
+    HIP_TRY(hipSetDevice(s->cfg.device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    const size_t nw = (size_t)s->nrows;
+    HIP_TRY(upload_rows(s, s->d_pos, pos_host, nw));
+    HIP_TRY(hipMemcpy(s->d_logp, logp_host, nw * sizeof(double), hipMemcpyHostToDevice));
+    std::vector<uint32_t> na(nw, 0u);
+    if (naccept_host) for (size_t i = 0; i < nw; ++i) na[i] = (uint32_t)naccept_host[i];
+    HIP_TRY(hipMemcpy(s->d_naccept, na.data(), nw * sizeof(uint32_t), hipMemcpyHostToDevice));
+    if (s->p2p) {
+        HIP_TRY(hipMemset(s->d_flags, 0, 4096));
+        HIP_TRY(hipMemset(s->d_err, 0, 64));
+    }
+    s->generation = generation;            // the device counter follows at the next graph replay
+    const int64_t done = samples_done(s);
+    s->moment_base = done;
+    return reset_run_state(s, /*eval_logp=*/false, generation, (uint32_t)done);
+}
+
 KMC_EXPORT kmc_status kmc_sampler_set_positions(kmc_sampler* s, const double* theta_host)
 {
     if (!s || !theta_host) return fail(KMC_ERR_BAD_ARG, "null argument");
@@ -978,6 +1121,7 @@ KMC_EXPORT kmc_status kmc_sampler_set_positions(kmc_sampler* s, const double* th
     HIP_TRY(hipStreamSynchronize(s->stream));
     s->generation = 0;
     s->dev_gen = 0;
+    s->moment_base = 0;
     s->launches = 0;
     s->have_run_events = false;
     for (size_t w = 0; w < nw; ++w)
@@ -1197,7 +1341,7 @@ KMC_EXPORT kmc_status kmc_sampler_get_moments(kmc_sampler* s, double* sum, doubl
             if (sum) sum[d] = S[d];
             if (sumsq) sumsq[d] = Q[d];
         }
-        if (n) *n = samples_done(s) * s->nlocal;
+        if (n) *n = (samples_done(s) - s->moment_base) * s->nlocal;
         return KMC_OK;
     }
     if (s->plan.vec) {
@@ -1245,7 +1389,7 @@ KMC_EXPORT kmc_status kmc_sampler_get_moments(kmc_sampler* s, double* sum, doubl
         if (sum) sum[d] = S[d];
         if (sumsq) sumsq[d] = Q[d];
     }
-    if (n) *n = samples_done(s) * s->nlocal;
+    if (n) *n = (samples_done(s) - s->moment_base) * s->nlocal;
     return KMC_OK;
 }
 

@@ -498,6 +498,70 @@ struct SignalArgs {
     int32_t             sched_index;
     int32_t             half;
 };
+// Device-side make_theta0s (reference src/samplers.jl:311-349, the intended behaviour): walker w gets
+// theta0 + N(0, diag(r^2)), redrawn while its log-pdf is -inf -- up to `ntries` draws per ball size,
+// the ball shrinking by the reference's cumulative factors 1, 1/2, 1/8, 1/64, ... per halving step
+// (:326), reset for every walker.  Normals: Box-Muller on Philox4x32-10 keyed by
+// (seed ^ "BALL", try index, walker, pair of dimensions).  fail[0] counts walkers left without an
+// admissible point.
+struct InitBallArgs {
+    double*       pos;        // [nrows][ld]
+    double*       logp;       // [nrows]
+    const double* theta0;     // [ndim]
+    const double* radius;     // [ndim]
+    int64_t       nrows;
+    int64_t       row_walker0;   // global walker index of row 0 (P2P shards pass their slices separately)
+    int32_t       ndim, ld;
+    int32_t       halving_steps, ntries;
+    uint32_t      seed_lo, seed_hi;
+    DensityParams dp;
+    unsigned long long* fail;
+};
+
+template <class Dens>
+__device__ __forceinline__ void init_ball_body(const InitBallArgs& a)
+{
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= a.nrows) return;
+    const uint64_t walker = (uint64_t)(a.row_walker0 + r);
+    double* x = a.pos + r * a.ld;
+    double shrink = 1.0;
+    uint32_t attempt = 0;
+    for (int k = 1; k <= a.halving_steps; ++k) {
+        shrink *= 1.0 / (double)(1u << (k - 1));                              // :326
+        for (int t = 0; t < a.ntries; ++t, ++attempt) {
+            typename Dens::Seq q;
+            Dens::seq_init(q);
+            for (int d = 0; d < a.ndim; d += 2) {
+                const U4 w = philox4x32_10(attempt, (uint32_t)(d >> 1), (uint32_t)walker, (uint32_t)(walker >> 32),
+                                           a.seed_lo ^ 0x42414c4cu, a.seed_hi);
+                const double u1 = ((double)(((uint64_t)w.x << 20) | (w.y >> 12)) + 0.5) * 0x1.0p-52;
+                const double u2 = ((double)w.z + 0.5) * 0x1.0p-32;
+                const double rad = sqrt(-2.0 * log(u1));
+                double sn, cs;
+                sincos(6.283185307179586476925286766559 * u2, &sn, &cs);
+                const double n0 = rad * cs, n1 = rad * sn;
+                x[d] = a.theta0[d] + n0 * (a.radius[d] * shrink);             // :328-332
+                Dens::seq_add(q, x[d], d, a.dp);
+                if (d + 1 < a.ndim) {
+                    x[d + 1] = a.theta0[d + 1] + n1 * (a.radius[d + 1] * shrink);
+                    Dens::seq_add(q, x[d + 1], d + 1, a.dp);
+                }
+            }
+            const double p = Dens::seq_finish(q, a.ndim, a.dp);
+            if (p > -INFINITY && p == p) { a.logp[r] = p; return; }           // :338
+        }
+    }
+    a.logp[r] = -INFINITY;
+    atomicAdd(a.fail, 1ull);
+}
+
+template <class Dens>
+__global__ __launch_bounds__(256) void init_ball(const InitBallArgs a)
+{
+    init_ball_body<Dens>(a);
+}
+
 #ifdef KMC_DEFINE_DRIVER_KERNELS   // non-template kernels: defined once, in kmc_api.hip
 __global__ void p2p_signal(const SignalArgs a)
 {

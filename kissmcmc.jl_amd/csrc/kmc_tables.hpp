@@ -11,6 +11,7 @@ using LogpdfFn = void (*)(const LogpdfArgs);
 using FlushFn = void (*)(const FlushArgs);
 using IslandFn = void (*)(const IslandArgs);
 using ResidentFn = void (*)(const ResidentArgs);
+using InitBallFn = void (*)(const InitBallArgs);
 
 #ifdef KMC_TABLES_IMPL
 template <class D, int L, int K, int ITER, bool P2P, bool RAGGED>
@@ -126,13 +127,18 @@ KMC_DECLARE_DENSITY_TABLE(table_lognormal);
 KMC_DECLARE_DENSITY_TABLE(table_mvnormal2);
 IslandFn island_gaussian_iso(int S, int K, bool ragged);
 ResidentFn resident_gaussian_iso(int K, bool ragged);
+InitBallFn init_ball_gaussian_iso();
 IslandFn island_exponential(int S, int K, bool ragged);
 ResidentFn resident_exponential(int K, bool ragged);
+InitBallFn init_ball_exponential();
 IslandFn island_rosenbrock(int S, int K, bool ragged);
 ResidentFn resident_rosenbrock(int K, bool ragged);
+InitBallFn init_ball_rosenbrock();
 IslandFn island_lognormal(int S, int K, bool ragged);
 ResidentFn resident_lognormal(int K, bool ragged);
+InitBallFn init_ball_lognormal();
 IslandFn island_mvnormal2(int S, int K, bool ragged);
 ResidentFn resident_mvnormal2(int K, bool ragged);
+InitBallFn init_ball_mvnormal2();
 
 }  // namespace kmc

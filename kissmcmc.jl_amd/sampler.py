@@ -115,6 +115,33 @@ class Sampler:
         theta = np.ascontiguousarray(np.asarray(theta, dtype=np.float64).reshape(self.nwalkers, self.ndim))
         _lib.check(self._L.kmc_sampler_set_positions(self._h, _dp(theta)))
 
+    def init_ball(self, theta0, ball_radius, seed: int = 0, ball_radius_halfing_steps: int = 7, ntries: int = 100):
+        """Device-side ``make_theta0s`` (reference ``src/samplers.jl:311-349``): seeded Gaussian ball
+        around ``theta0`` with ``pdf > -Inf``, generated and checked on the GPU; the sampler is then
+        ready to run (no host ensemble, no H2D copy)."""
+        th = np.ascontiguousarray(np.broadcast_to(np.asarray(theta0, dtype=np.float64), (self.ndim,)))
+        r = np.ascontiguousarray(np.broadcast_to(np.asarray(ball_radius, dtype=np.float64), (self.ndim,)))
+        try:
+            _lib.check(self._L.kmc_sampler_init_ball(self._h, _dp(th), _dp(r), int(seed) & 0xFFFFFFFFFFFFFFFF,
+                                                     int(ball_radius_halfing_steps), int(ntries)))
+        except _lib.KmcError as e:
+            if e.status == _lib.ERR_NONFINITE_LOGP:
+                raise RuntimeError(str(e)) from e
+            raise
+
+    def state(self):
+        """Checkpoint: ``dict(positions, logp, naccept, generation)`` (synchronises)."""
+        return dict(positions=self.positions(), logp=self.logp(), naccept=self.naccept(), generation=self.generation)
+
+    def restore(self, state):
+        """Resume from :meth:`state` of a sampler with the same configuration and seed: the continued
+        run is bit-identical to an uninterrupted one (moments restart at the restored generation)."""
+        pos = np.ascontiguousarray(np.asarray(state["positions"], dtype=np.float64).reshape(self.nrows, self.ndim))
+        lp = np.ascontiguousarray(np.asarray(state["logp"], dtype=np.float64))
+        na = np.ascontiguousarray(np.asarray(state["naccept"], dtype=np.int64))
+        _lib.check(self._L.kmc_sampler_set_state(self._h, _dp(pos), _dp(lp), na.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                 int(state["generation"])))
+
     def run(self, ngenerations: int):
         _lib.check(self._L.kmc_sampler_run(self._h, int(ngenerations)))
 
