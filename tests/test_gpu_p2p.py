@@ -37,6 +37,8 @@ def _worker(rank, world, port, outdir, plan, late_rank=-1):
     import torch.distributed as dist
     import kissmcmc_jl_amd as kmc
     from kissmcmc_jl_amd.distributed import P2PEmcee
+    if plan == "rosen-ragged":
+        return _worker_rosen(rank, world, port, outdir)
     if plan:
         os.environ["KMC_PLAN"] = plan
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -57,6 +59,43 @@ def _worker(rank, world, port, outdir, plan, late_rank=-1):
         drv.close()
     finally:
         dist.destroy_process_group()
+
+
+RNW, RND, RG = 768, 9, 90      # odd ndim: padded rows + masked tail chunk through the peer pointers
+
+
+def _rosen_theta0():
+    return 0.1 * np.random.default_rng(12).standard_normal((RNW, RND))
+
+
+def _worker_rosen(rank, world, port, outdir):
+    import torch.distributed as dist
+    import kissmcmc_jl_amd as kmc
+    from kissmcmc_jl_amd.distributed import P2PEmcee
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        drv = P2PEmcee(kmc.Rosenbrock(), RNW, RND, RG, 30, 1, 2.0, 99, device=0)
+        drv.set_positions(_rosen_theta0())
+        drv.run(RG)
+        drv.sync()
+        pos, nacc = drv.positions(), drv.naccept()
+        if rank == 0:
+            np.savez(os.path.join(outdir, "rosen.npz"), pos=pos, nacc=nacc)
+        drv.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_p2p_rosenbrock_odd_ndim(oracle, tmp_path):
+    import torch.multiprocessing as mp
+    mp.spawn(_worker, args=(3, _free_port(), str(tmp_path), "rosen-ragged"), nprocs=3, join=True)
+    ref = oracle.emcee(oracle.make_config(oracle.ROSENBROCK, [1.0, 100.0, 20.0], RNW, RND, RG, 30, 1, 2.0, 99),
+                       _rosen_theta0(), store_chain=False)
+    z = np.load(os.path.join(str(tmp_path), "rosen.npz"))
+    np.testing.assert_array_equal(z["nacc"], ref["naccept"])
+    np.testing.assert_array_equal(z["pos"], ref["final_pos"])
 
 
 def _free_port():
