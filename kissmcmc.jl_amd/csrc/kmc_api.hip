@@ -123,14 +123,14 @@ IslandFn island_fn(int density, int S, int K, bool ragged)
     }
 }
 
-ResidentFn resident_fn(int density, int K, bool ragged)
+ResidentFn resident_fn(int density, int tpb, int K, bool ragged)
 {
     switch (density) {
-    case KMC_GAUSSIAN_ISO: return resident_gaussian_iso(K, ragged);
-    case KMC_EXPONENTIAL: return resident_exponential(K, ragged);
-    case KMC_ROSENBROCK: return resident_rosenbrock(K, ragged);
-    case KMC_LOGNORMAL: return resident_lognormal(K, ragged);
-    case KMC_MVNORMAL2: return resident_mvnormal2(K, ragged);
+    case KMC_GAUSSIAN_ISO: return resident_gaussian_iso(tpb, K, ragged);
+    case KMC_EXPONENTIAL: return resident_exponential(tpb, K, ragged);
+    case KMC_ROSENBROCK: return resident_rosenbrock(tpb, K, ragged);
+    case KMC_LOGNORMAL: return resident_lognormal(tpb, K, ragged);
+    case KMC_MVNORMAL2: return resident_mvnormal2(tpb, K, ragged);
     default: return nullptr;
     }
 }
@@ -449,6 +449,7 @@ struct kmc_sampler {
     // resident mode: exact sampler, whole (small) ensemble in one workgroup's LDS, many generations per launch
     bool resident = false;
     ResidentFn resident_kernel = nullptr;
+    int resident_tpb = 256;
     // island mode (KMC_ISLANDS)
     bool islands = false;
     IslandFn island_kernel = nullptr;
@@ -750,15 +751,18 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         }
         if (ea != hipSuccess) { (void)hipGetLastError(); kmc_sampler_destroy(s); return fail(KMC_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(ea)); }
     }
-    if (!s->islands && cfg->density != KMC_USER_DENSITY && cfg->nwalkers <= 256 && cfg->ndim <= 32 &&
+    if (!s->islands && cfg->density != KMC_USER_DENSITY && cfg->nwalkers <= 1024 && cfg->ndim <= 32 &&
         s->cfg.shard_count == 1 && !(cfg->flags & (KMC_P2P | KMC_NO_GRAPH)) && std::getenv("KMC_NO_RESIDENT") == nullptr) {
         const int64_t chunks = s->ld / 2;
         int K = 1;
         while (2 * K < chunks) K *= 2;
-        ResidentFn rf = resident_fn(cfg->density, K, 4 * K != cfg->ndim);
+        const int rtpb = cfg->nwalkers <= 256 ? 256 : (cfg->nwalkers <= 512 ? 512 : 1024);
+        const size_t need = ((size_t)cfg->nwalkers * (size_t)(4 * (K + 1)) + (size_t)cfg->nwalkers) * sizeof(double);
+        ResidentFn rf = need <= 156 * 1024 ? resident_fn(cfg->density, rtpb, K, 4 * K != cfg->ndim) : nullptr;
         if (rf) {
-            s->island_lds = ((size_t)cfg->nwalkers * (size_t)(4 * (K + 1)) + (size_t)cfg->nwalkers) * sizeof(double);
-            if (s->island_lds < 4096) s->island_lds = 4096;     // the moment reduction reuses the buffer
+            s->resident_tpb = rtpb;
+            s->island_lds = need;
+            if (s->island_lds < 8192) s->island_lds = 8192;     // the moment reduction reuses the buffer
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(rf), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)s->island_lds) == hipSuccess) {
                 s->resident = true;
@@ -1163,7 +1167,7 @@ KMC_EXPORT kmc_status kmc_sampler_run(kmc_sampler* s, int64_t ngen)
             if (s->user) {
                 HIP_TRY(launch_module(s->uk.resident, 1u, 256u, s->stream, ra, (unsigned)s->island_lds));
             } else {
-                hipLaunchKernelGGL(s->resident_kernel, dim3(1), dim3(256), s->island_lds, s->stream, ra);
+                hipLaunchKernelGGL(s->resident_kernel, dim3(1), dim3((unsigned)s->resident_tpb), s->island_lds, s->stream, ra);
                 HIP_TRY(hipGetLastError());
             }
             s->generation += n;

@@ -8,6 +8,6 @@ void table_exponential(int L, int K, int iter, bool p2p, bool ragged, HalfStepFn
     density_fns<Exponential>(L, K, iter, p2p, ragged, vec, gen, lp);
 }
 IslandFn island_exponential(int S, int K, bool ragged) { return island_lookup<Exponential>(S, K, ragged); }
-ResidentFn resident_exponential(int K, bool ragged) { return resident_lookup<Exponential>(K, ragged); }
+ResidentFn resident_exponential(int tpb, int K, bool ragged) { return resident_lookup<Exponential>(tpb, K, ragged); }
 InitBallFn init_ball_exponential() { return init_ball<Exponential>; }
 }  // namespace kmc

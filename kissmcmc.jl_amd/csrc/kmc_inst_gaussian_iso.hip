@@ -8,6 +8,6 @@ void table_gaussian_iso(int L, int K, int iter, bool p2p, bool ragged, HalfStepF
     density_fns<GaussianIso>(L, K, iter, p2p, ragged, vec, gen, lp);
 }
 IslandFn island_gaussian_iso(int S, int K, bool ragged) { return island_lookup<GaussianIso>(S, K, ragged); }
-ResidentFn resident_gaussian_iso(int K, bool ragged) { return resident_lookup<GaussianIso>(K, ragged); }
+ResidentFn resident_gaussian_iso(int tpb, int K, bool ragged) { return resident_lookup<GaussianIso>(tpb, K, ragged); }
 InitBallFn init_ball_gaussian_iso() { return init_ball<GaussianIso>; }
 }  // namespace kmc

@@ -8,6 +8,6 @@ void table_lognormal(int L, int K, int iter, bool p2p, bool ragged, HalfStepFn* 
     density_fns<LogNormal>(L, K, iter, p2p, ragged, vec, gen, lp);
 }
 IslandFn island_lognormal(int S, int K, bool ragged) { return island_lookup<LogNormal>(S, K, ragged); }
-ResidentFn resident_lognormal(int K, bool ragged) { return resident_lookup<LogNormal>(K, ragged); }
+ResidentFn resident_lognormal(int tpb, int K, bool ragged) { return resident_lookup<LogNormal>(tpb, K, ragged); }
 InitBallFn init_ball_lognormal() { return init_ball<LogNormal>; }
 }  // namespace kmc

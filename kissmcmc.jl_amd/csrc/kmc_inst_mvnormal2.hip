@@ -8,6 +8,6 @@ void table_mvnormal2(int L, int K, int iter, bool p2p, bool ragged, HalfStepFn* 
     density_fns<MvNormal2>(L, K, iter, p2p, ragged, vec, gen, lp);
 }
 IslandFn island_mvnormal2(int S, int K, bool ragged) { return island_lookup<MvNormal2>(S, K, ragged); }
-ResidentFn resident_mvnormal2(int K, bool ragged) { return resident_lookup<MvNormal2>(K, ragged); }
+ResidentFn resident_mvnormal2(int tpb, int K, bool ragged) { return resident_lookup<MvNormal2>(tpb, K, ragged); }
 InitBallFn init_ball_mvnormal2() { return init_ball<MvNormal2>; }
 }  // namespace kmc

@@ -8,6 +8,6 @@ void table_rosenbrock(int L, int K, int iter, bool p2p, bool ragged, HalfStepFn*
     density_fns<Rosenbrock>(L, K, iter, p2p, ragged, vec, gen, lp);
 }
 IslandFn island_rosenbrock(int S, int K, bool ragged) { return island_lookup<Rosenbrock>(S, K, ragged); }
-ResidentFn resident_rosenbrock(int K, bool ragged) { return resident_lookup<Rosenbrock>(K, ragged); }
+ResidentFn resident_rosenbrock(int tpb, int K, bool ragged) { return resident_lookup<Rosenbrock>(tpb, K, ragged); }
 InitBallFn init_ball_rosenbrock() { return init_ball<Rosenbrock>; }
 }  // namespace kmc

@@ -192,26 +192,28 @@ __global__ __launch_bounds__(S) void island_epoch(const IslandArgs a)
 
 
 // ------------------------------------------------------------------------------------------------
-// RESIDENT mode: the EXACT sampler for small ensembles (nwalkers <= 256, ndim <= 32).
+// RESIDENT mode: the EXACT sampler for small ensembles (nwalkers <= 1024 and the ensemble fits 160 KiB of LDS).
 //
 // When the whole ensemble fits one workgroup's LDS, "the island's complementary half" IS the
 // ensemble's complementary half: a single island with the identity deal and the RNG keyed by the
 // walker index is the reference's algorithm unchanged -- bit-identical to half_step_vec/generic --
 // but a launch now carries many generations (the reference's own sizes: 100 walkers, 10^5..10^7
 // evaluations) instead of half of one, with `__syncthreads()` as the join of src/samplers.jl:273.
-// Unlike the island kernel this one takes any even S <= 256 and also stores the chain (:269-271).
+// Unlike the island kernel this one takes any even S <= TPB (256, 512 or 1024 threads, as LDS allows)
+// and also stores the chain (:269-271).
 // ------------------------------------------------------------------------------------------------
 struct ResidentArgs {
     IslandArgs    is;           // pos/logp/naccept, generations, schedule, draws, density, per-block moments
-    int32_t       S;            // nwalkers (even, <= 256)
+    int32_t       S;            // nwalkers (even, <= threads per workgroup)
     int32_t       pad_;
     double*       chain;        // [nsamples][S][ld] or nullptr
     double*       chain_logp;   // [nsamples][S] or nullptr
 };
 
-template <class Dens, int K, bool RAGGED>
+template <class Dens, int K, bool RAGGED, int TPB = 256>
 __device__ __forceinline__ void resident_body(const ResidentArgs& ra)
 {
+    static_assert(TPB == 256 || TPB == 512 || TPB == 1024, "one workgroup: TPB threads = TPB/2 lane pairs");
     const IslandArgs& a = ra.is;
     constexpr int L = 2;
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -335,7 +337,7 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& ra)
         __syncthreads();
         if (t < 2 * K) {
             double s0 = 0.0, s1 = 0.0, q0 = 0.0, q1 = 0.0;
-            for (int w = 0; w < 4; ++w) {
+            for (int w = 0; w < TPB / 64; ++w) {
                 const double* r = red + ((w * K + (t >> 1)) * 2 + (t & 1)) * 4;
                 s0 += r[0]; s1 += r[1]; q0 += r[2]; q1 += r[3];
             }
@@ -345,10 +347,10 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& ra)
     }
 }
 
-template <class Dens, int K, bool RAGGED>
-__global__ __launch_bounds__(256) void resident_epoch(const ResidentArgs a)
+template <class Dens, int K, bool RAGGED, int TPB>
+__global__ __launch_bounds__(TPB) void resident_epoch(const ResidentArgs a)
 {
-    resident_body<Dens, K, RAGGED>(a);
+    resident_body<Dens, K, RAGGED, TPB>(a);
 }
 
 }  // namespace kmc

@@ -100,17 +100,28 @@ IslandFn island_lookup(int S, int K, bool ragged)
     }
 }
 // resident mode: the exact sampler for ensembles that fit one workgroup's LDS
+template <class D, int TPB>
+ResidentFn resident_lookup_t(int K, bool ragged)
+{
+    switch (K) {
+    case 1: return ragged ? resident_epoch<D, 1, true, TPB> : resident_epoch<D, 1, false, TPB>;
+    case 2: return ragged ? resident_epoch<D, 2, true, TPB> : resident_epoch<D, 2, false, TPB>;
+    case 4: return ragged ? resident_epoch<D, 4, true, TPB> : resident_epoch<D, 4, false, TPB>;
+    case 8: return ragged ? resident_epoch<D, 8, true, TPB> : resident_epoch<D, 8, false, TPB>;
+    default: return nullptr;
+    }
+}
+
 template <class D>
-ResidentFn resident_lookup(int K, bool ragged)
+ResidentFn resident_lookup(int tpb, int K, bool ragged)
 {
     if constexpr (!D::kHasFrag) {
         return nullptr;
     } else {
-        switch (K) {
-        case 1: return ragged ? resident_epoch<D, 1, true> : resident_epoch<D, 1, false>;
-        case 2: return ragged ? resident_epoch<D, 2, true> : resident_epoch<D, 2, false>;
-        case 4: return ragged ? resident_epoch<D, 4, true> : resident_epoch<D, 4, false>;
-        case 8: return ragged ? resident_epoch<D, 8, true> : resident_epoch<D, 8, false>;
+        switch (tpb) {
+        case 256: return resident_lookup_t<D, 256>(K, ragged);
+        case 512: return resident_lookup_t<D, 512>(K, ragged);
+        case 1024: return resident_lookup_t<D, 1024>(K, ragged);
         default: return nullptr;
         }
     }
@@ -126,19 +137,19 @@ KMC_DECLARE_DENSITY_TABLE(table_rosenbrock);
 KMC_DECLARE_DENSITY_TABLE(table_lognormal);
 KMC_DECLARE_DENSITY_TABLE(table_mvnormal2);
 IslandFn island_gaussian_iso(int S, int K, bool ragged);
-ResidentFn resident_gaussian_iso(int K, bool ragged);
+ResidentFn resident_gaussian_iso(int tpb, int K, bool ragged);
 InitBallFn init_ball_gaussian_iso();
 IslandFn island_exponential(int S, int K, bool ragged);
-ResidentFn resident_exponential(int K, bool ragged);
+ResidentFn resident_exponential(int tpb, int K, bool ragged);
 InitBallFn init_ball_exponential();
 IslandFn island_rosenbrock(int S, int K, bool ragged);
-ResidentFn resident_rosenbrock(int K, bool ragged);
+ResidentFn resident_rosenbrock(int tpb, int K, bool ragged);
 InitBallFn init_ball_rosenbrock();
 IslandFn island_lognormal(int S, int K, bool ragged);
-ResidentFn resident_lognormal(int K, bool ragged);
+ResidentFn resident_lognormal(int tpb, int K, bool ragged);
 InitBallFn init_ball_lognormal();
 IslandFn island_mvnormal2(int S, int K, bool ragged);
-ResidentFn resident_mvnormal2(int K, bool ragged);
+ResidentFn resident_mvnormal2(int tpb, int K, bool ragged);
 InitBallFn init_ball_mvnormal2();
 
 }  // namespace kmc

@@ -163,7 +163,8 @@ def test_graph_replay_equals_eager(kmc, oracle):
     np.testing.assert_array_equal(got["chain"], got2["chain"])
 
 
-@pytest.mark.parametrize("name,nw,nd", [("expo", 100, 1), ("rosen", 100, 2), ("gauss", 256, 32), ("gauss", 34, 32), ("lognormal", 64, 3)])
+@pytest.mark.parametrize("name,nw,nd", [("expo", 100, 1), ("rosen", 100, 2), ("gauss", 256, 32), ("gauss", 34, 32), ("lognormal", 64, 3),
+                                        ("gauss", 512, 32), ("rosen", 400, 16), ("expo", 1024, 8), ("gauss", 1000, 3)])
 def test_resident_small_ensemble_kernel_is_the_same_sampler(kmc, oracle, name, nw, nd, monkeypatch):
     """nwalkers <= 256: the whole ensemble runs out of one workgroup's LDS, many generations per launch
     (resident mode).  It must be indistinguishable from the launch-per-half-step kernels and the oracle."""
