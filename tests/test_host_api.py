@@ -107,3 +107,25 @@ def test_density_host_formulas_match_oracle(kmc, oracle):
             assert (a == b) or abs(a - b) <= 1e-12 * max(1.0, abs(b)), (pdf, x, a, b)
         X = rng.standard_normal((50, nd))
         np.testing.assert_array_equal(pdf.finite_rows(X), np.array([pdf(r) > -np.inf for r in X]))
+
+
+def test_local_to_global_reassembles_p2p_shards(kmc):
+    """P2P local order (first-half slice, then second-half slice per rank) -> global walker order."""
+    from kissmcmc_jl_amd.distributed import local_to_global, shard_slice
+    nw, world = 48, 4
+    glob = np.arange(nw * 3, dtype=np.float64).reshape(nw, 3)
+    h = nw // 2
+    parts = []
+    for r in range(world):
+        b, n = shard_slice(nw, r, world)
+        parts.append(np.concatenate([glob[b:b + n], glob[h + b:h + b + n]]))
+    np.testing.assert_array_equal(local_to_global(parts, nw, world), glob)
+    np.testing.assert_array_equal(local_to_global([glob], nw, 1), glob)
+
+
+def test_expr_density_host_interface(kmc):
+    """ExprDensity objects carry the id/params the C ABI needs (compilation itself: test_c_abi.py)."""
+    from kissmcmc_jl_amd import _lib
+    d = kmc.ExprDensity("-0.5*p[0]*x*x", params=[2.0])
+    assert d.density_id == _lib.USER_DENSITY and d.params() == [2.0] and d.user_handle is not None
+    assert "ExprDensity" in repr(d)
