@@ -258,7 +258,12 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepArgs& a)
 #pragma unroll
         for (int t = 1; t < 8; ++t) base = (q == (uint32_t)t) ? a.peer_pos[t] : base;
         const unsigned long long addrA = (unsigned long long)(base + (a.oth_row0 + r) * ld);
-        if (a.nranks > 1) wait_for_peers(a, step, lane);   // every rank has finished half-step `step - 1`
+        if (a.nranks > 1) {
+            // every rank must have finished half-step `step - 1`: one polling wave per workgroup (the
+            // flags sit in uncached fine-grained memory), the other waves wait at the barrier
+            if ((threadIdx.x >> 6) == 0) wait_for_peers(a, step, lane);
+            __syncthreads();
+        }
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
             const int src = (gbase + it) * 4;
