@@ -155,50 +155,59 @@ def main():
         from kissmcmc_jl_amd.distributed import HipShardExecutor, P2PEmcee, ShardedEmcee
         mode = os.environ.get("KMC_BENCH_EXCHANGE", "p2p")
         drv = None
-        ok = torch.ones(1, device="cuda")
-        if mode == "p2p":
+
+        def try_p2p(finegrained):
+            """Set up the peer-to-peer exchange and self-check it: 80 generations (one hipGraph replay + an
+            eager tail) must reproduce, bit for bit, the same generations of the whole ensemble on ONE GPU
+            (rank 0 runs it unsharded).  Any error, time-out or mismatch on any rank -> None on every rank."""
+            ok = torch.ones(1, device="cuda")
+            d = None
             try:
-                drv = P2PEmcee(pdf, nw, NDIM, G, nburn, 1, 2.0, SEED, device=local_rank)
+                d = P2PEmcee(pdf, nw, NDIM, G, nburn, 1, 2.0, SEED, device=local_rank, finegrained=finegrained)
             except Exception as e:  # noqa: BLE001
-                print(f"[rank {rank}] p2p set-up failed ({e}); falling back to all-gather", file=sys.stderr)
+                print(f"[rank {rank}] p2p set-up failed ({e})", file=sys.stderr)
                 ok.zero_()
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if ok.item() == 0:
-                if drv is not None:
-                    drv.sampler.close()
-                drv, mode = None, "allgather"
-        p2p_validated = None
-        if mode == "p2p":
-            # Self-check before anything is timed: 80 generations (one hipGraph replay + an eager tail)
-            # through the peer-to-peer exchange must reproduce, bit for bit, the same generations of the
-            # whole ensemble on ONE GPU (rank 0 runs it unsharded).  Any error, time-out or mismatch on
-            # any rank sends every rank to the all-gather path.
-            vgen = 80
-            try:
-                drv.set_positions(th)
-                drv.run(vgen)
-                drv.sync()
-                vpos, vacc = drv.positions(), drv.naccept()
-                if rank == 0:
-                    with kmc.Sampler(pdf, nw, NDIM, G, nburn, 1, 2.0, SEED, device=local_rank) as ref:
-                        ref.set_positions(th)
-                        ref.run(vgen)
-                        ref.sync()
-                        if not (np.array_equal(ref.positions(), vpos) and np.array_equal(ref.naccept(), vacc)):
-                            print("[rank 0] p2p self-check: sharded run differs from the single-GPU run; "
-                                  "falling back to all-gather", file=sys.stderr)
-                            ok.zero_()
-            except Exception as e:  # noqa: BLE001
-                print(f"[rank {rank}] p2p self-check failed ({e}); falling back to all-gather", file=sys.stderr)
-                ok.zero_()
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            p2p_validated = bool(ok.item() != 0)
-            if not p2p_validated:
+            if ok.item() != 0:
+                vgen = 80
                 try:
-                    drv.sampler.close()
-                except Exception:  # noqa: BLE001
-                    pass
-                drv, mode = None, "allgather"
+                    d.set_positions(th)
+                    d.run(vgen)
+                    d.sync()
+                    vpos, vacc = d.positions(), d.naccept()
+                    if rank == 0:
+                        with kmc.Sampler(pdf, nw, NDIM, G, nburn, 1, 2.0, SEED, device=local_rank) as ref:
+                            ref.set_positions(th)
+                            ref.run(vgen)
+                            ref.sync()
+                            if not (np.array_equal(ref.positions(), vpos) and np.array_equal(ref.naccept(), vacc)):
+                                print(f"[rank 0] p2p self-check (finegrained={finegrained}): sharded run differs from the "
+                                      "single-GPU run", file=sys.stderr)
+                                ok.zero_()
+                except Exception as e:  # noqa: BLE001
+                    print(f"[rank {rank}] p2p self-check failed ({e})", file=sys.stderr)
+                    ok.zero_()
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if ok.item() == 0:
+                if d is not None:
+                    try:
+                        d.sampler.close()
+                    except Exception:  # noqa: BLE001
+                        pass
+                return None
+            return d
+
+        p2p_memory = None
+        if mode == "p2p":
+            for fine in (False, True):       # plain device memory first, then fine-grained rows, then all-gather
+                drv = try_p2p(fine)
+                if drv is not None:
+                    p2p_memory = "fine-grained" if fine else "coarse-grained"
+                    break
+            if drv is None:
+                if rank == 0:
+                    print("[rank 0] falling back to the RCCL all-gather exchange", file=sys.stderr)
+                mode = "allgather"
         if mode == "p2p":
             drv.set_positions(th)
             drv.run(args.warmup * GENS_PER_STEP)
@@ -217,8 +226,8 @@ def main():
             msum, msq, nmom = drv.moments()
             acc = float(drv.naccept().sum() / nw / max(1, G - nburn))
             drv.close()
-            parallelism = (f"walker-sharded x{world}, peer-to-peer partner reads over xGMI (IPC), progress-flag ordering; "
-                           "self-check vs the unsharded single-GPU run: bit-identical")
+            parallelism = (f"walker-sharded x{world}, peer-to-peer partner reads over xGMI (IPC, {p2p_memory} rows), "
+                           "progress-flag ordering; self-check vs the unsharded single-GPU run: bit-identical")
         else:
             ex = HipShardExecutor(pdf, nw, NDIM, G, nburn, 1, 2.0, SEED, rank=rank, world=world, device=local_rank)
             ex.set_positions(th)

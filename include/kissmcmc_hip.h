@@ -78,6 +78,7 @@ enum {
                                   fewer kernel boundaries and no HBM traffic inside an epoch.  Needs nwalkers % island_size == 0,
                                   island_size >= ndim + 2, ndim <= 32, shard_count == 1; no chain storage.  Works with user densities
                                   when island_size * (ndim + 3) * 8 B <= 60 KiB. */
+    KMC_P2P_FINEGRAINED = 1u << 7, /* with KMC_P2P: keep the rows in fine-grained (coherent, uncached-for-peers) device memory */
     KMC_P2P         = 1u << 4  /* walker sharding with peer-to-peer partner reads over xGMI: the sampler holds only
                                   its shard ([2][nwalkers/2/shard_count][ndim], halves back to back), reads partner
                                   rows straight from the owning rank's HBM and synchronises half-steps with

@@ -19,7 +19,7 @@ OK, ERR_A_SCALE, ERR_ODD_WALKERS, ERR_TOO_FEW_WALKERS, ERR_BAD_ARG, ERR_NONFINIT
 GAUSSIAN_ISO, EXPONENTIAL, ROSENBROCK, LOGNORMAL, MVNORMAL2 = range(5)
 USER_DENSITY = 100
 F64 = 0
-STORE_CHAIN, STORE_LOGP, MOMENTS, NO_GRAPH, P2P, ISLANDS = 1, 2, 4, 8, 16, 64
+STORE_CHAIN, STORE_LOGP, MOMENTS, NO_GRAPH, P2P, ISLANDS, P2P_FINEGRAINED = 1, 2, 4, 8, 16, 64, 128
 P2P_HANDLE_BYTES = 128
 
 # Every symbol include/kissmcmc_hip.h declares (tests check they are all exported).

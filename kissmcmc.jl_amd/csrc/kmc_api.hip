@@ -486,6 +486,8 @@ HalfStepArgs make_args(const kmc_sampler* s, int half, bool graph_mode, int64_t 
     a.own_row0 = s->p2p ? (int64_t)half * s->h_loc : a.gw0;
     a.oth_row0 = s->p2p ? (int64_t)(1 - half) * s->h_loc : (int64_t)(1 - half) * s->h;
     a.hloc = (uint32_t)s->h_loc;
+    a.hloc_shift = -1;
+    if (s->h_loc > 0 && (s->h_loc & (s->h_loc - 1)) == 0) { a.hloc_shift = 0; while (((int64_t)1 << a.hloc_shift) < s->h_loc) ++a.hloc_shift; }
     a.nranks = s->cfg.shard_count;
     for (int r = 0; r < 8; ++r) a.peer_pos[r] = s->peer_pos[r];
     a.flags = s->d_flags;
@@ -807,7 +809,10 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         CREATE_TRY(hipMemset(s->d_err, 0, 64));
     }
     const size_t ldz = (size_t)s->ld;
-    CREATE_TRY(hipMalloc(&s->d_pos, nw * ldz * sizeof(double)));
+    if (s->p2p && (cfg->flags & KMC_P2P_FINEGRAINED))   // peers map the rows uncached: nothing of them can go stale in a reader's L2
+        CREATE_TRY(hipExtMallocWithFlags((void**)&s->d_pos, nw * ldz * sizeof(double), hipDeviceMallocFinegrained));
+    else
+        CREATE_TRY(hipMalloc(&s->d_pos, nw * ldz * sizeof(double)));
     CREATE_TRY(hipMemset(s->d_pos, 0, nw * ldz * sizeof(double)));     // the pad column of odd ndim stays 0
     CREATE_TRY(hipMalloc(&s->d_logp, nw * sizeof(double)));
     CREATE_TRY(hipMalloc(&s->d_naccept, nw * sizeof(uint32_t)));

@@ -76,7 +76,7 @@ struct HalfStepArgs {
     int32_t           n_active;     // number of active walkers of this shard
     int32_t           ndim;
     int32_t           ld;           // row stride of pos / chain in doubles: ndim rounded up to even (16-B rows)
-    int32_t           pad_;
+    int32_t           hloc_shift;   // log2(hloc) when hloc is a power of two, else -1
     // peer-to-peer sharding (P2P kernels only): partner p of the complementary half lives on rank
     // p / hloc at row oth_row0 + p % hloc of that rank's pos
     uint32_t          hloc;
@@ -252,7 +252,7 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepArgs& a)
         }
     } else {
         // owner rank and row of the partner, resolved once per walker; the row address travels
-        const uint32_t q = partnerA / a.hloc;
+        const uint32_t q = a.hloc_shift >= 0 ? partnerA >> a.hloc_shift : partnerA / a.hloc;
         const uint32_t r = partnerA - q * a.hloc;
         const double* base = a.peer_pos[0];
 #pragma unroll
@@ -418,7 +418,7 @@ __device__ __forceinline__ void half_step_generic_body(const HalfStepArgs& a)
     if constexpr (!P2P) {
         oth = a.pos + (a.oth_row0 + dr.partner) * ld;
     } else {
-        const uint32_t q = dr.partner / a.hloc;
+        const uint32_t q = a.hloc_shift >= 0 ? dr.partner >> a.hloc_shift : dr.partner / a.hloc;
         const uint32_t r = dr.partner - q * a.hloc;
         const double* base = a.peer_pos[0];
 #pragma unroll

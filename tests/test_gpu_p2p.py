@@ -172,3 +172,36 @@ def test_p2p_long_run_equals_unsharded_gpu_run(kmc, tmp_path):
     np.testing.assert_array_equal(z["nacc"], nacc)
     assert int(z["n"]) == mom[2]
     np.testing.assert_allclose(z["s"], mom[0], rtol=1e-11, atol=1e-8)
+
+
+def _fine_worker(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import kissmcmc_jl_amd as kmc
+    from kissmcmc_jl_amd.distributed import P2PEmcee
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        drv = P2PEmcee(kmc.GaussianIso(), NW, ND, G, NBURN, 1, 2.0, SEED, device=0, finegrained=True)
+        drv.set_positions(_theta0())
+        drv.run(G)
+        drv.sync()
+        pos, nacc = drv.positions(), drv.naccept()
+        if rank == 0:
+            np.savez(os.path.join(outdir, "fine.npz"), pos=pos, nacc=nacc)
+        drv.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_p2p_with_finegrained_rows(oracle, tmp_path):
+    """KMC_P2P_FINEGRAINED: rows in fine-grained device memory (what bench.py tries if the plain mapping
+    fails its self-check on a multi-GPU node)."""
+    import torch.multiprocessing as mp
+    mp.spawn(_fine_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    ref = oracle.emcee(oracle.make_config(oracle.GAUSSIAN_ISO, [0.0, 1.0], NW, ND, G, NBURN, 1, 2.0, SEED),
+                       _theta0(), store_chain=False)
+    z = np.load(os.path.join(str(tmp_path), "fine.npz"))
+    np.testing.assert_array_equal(z["nacc"], ref["naccept"])
+    np.testing.assert_array_equal(z["pos"], ref["final_pos"])
