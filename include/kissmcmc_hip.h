@@ -202,6 +202,9 @@ int64_t     kmc_sampler_nsamples(const kmc_sampler* s);
  * (read (2 ndim + 1) * 8, write (ndim + 1) * 8 per walker-step). */
 int64_t     kmc_sampler_launch_count(const kmc_sampler* s);
 
+/* One line describing how this sampler executes (kernel family and geometry, exchange scheme). */
+kmc_status  kmc_sampler_describe(const kmc_sampler* s, char* buf, int64_t buflen);
+
 /* Device pointers for zero-copy exchange (torch / RCCL): which = 0 positions [nwalkers][ndim],
  * 1 logp [nwalkers], 2 naccept (uint32 [nwalkers]). */
 void*       kmc_sampler_device_ptr(kmc_sampler* s, int which);

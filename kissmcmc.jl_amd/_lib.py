@@ -28,7 +28,7 @@ SYMBOLS = [
     "kmc_g_pdf", "kmc_cdf_g_inv", "kmc_emcee_run", "kmc_sampler_create", "kmc_sampler_destroy",
     "kmc_sampler_set_stream", "kmc_sampler_bind_positions", "kmc_sampler_p2p_export", "kmc_sampler_p2p_connect", "kmc_sampler_set_positions", "kmc_sampler_init_ball", "kmc_sampler_set_state", "kmc_sampler_run", "kmc_sampler_half_step",
     "kmc_sampler_sync", "kmc_sampler_last_run_ms", "kmc_sampler_generation", "kmc_sampler_nsamples",
-    "kmc_sampler_launch_count", "kmc_sampler_device_ptr", "kmc_sampler_get_positions",
+    "kmc_sampler_launch_count", "kmc_sampler_describe", "kmc_sampler_device_ptr", "kmc_sampler_get_positions",
     "kmc_sampler_get_logp", "kmc_sampler_get_naccept", "kmc_sampler_get_accept_ratio",
     "kmc_sampler_get_moments", "kmc_sampler_get_chain", "kmc_logpdf_eval", "kmc_logpdf_eval_host",
     "kmc_user_density_create", "kmc_user_density_destroy",
@@ -136,6 +136,7 @@ def lib() -> C.CDLL:
     L.kmc_sampler_nsamples.argtypes = [vp]
     L.kmc_sampler_launch_count.restype = C.c_int64
     L.kmc_sampler_launch_count.argtypes = [vp]
+    L.kmc_sampler_describe.argtypes = [vp, C.c_char_p, C.c_int64]
     L.kmc_sampler_device_ptr.restype = vp
     L.kmc_sampler_device_ptr.argtypes = [vp, C.c_int]
     L.kmc_sampler_get_positions.argtypes = [vp, dp]

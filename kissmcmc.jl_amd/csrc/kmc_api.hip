@@ -1280,6 +1280,31 @@ KMC_EXPORT int64_t kmc_sampler_generation(const kmc_sampler* s) { return s ? s->
 KMC_EXPORT int64_t kmc_sampler_nsamples(const kmc_sampler* s) { return s ? s->nsamples : -1; }
 KMC_EXPORT int64_t kmc_sampler_launch_count(const kmc_sampler* s) { return s ? s->launches : -1; }
 
+// Human-readable description of how this sampler executes (kernel family, geometry, exchange).
+KMC_EXPORT kmc_status kmc_sampler_describe(const kmc_sampler* s, char* buf, int64_t buflen)
+{
+    if (!s || !buf || buflen <= 0) return fail(KMC_ERR_BAD_ARG, "bad argument");
+    std::ostringstream o;
+    if (s->islands)
+        o << "island mode: " << s->nislands << " islands of " << s->island_size << " walkers in LDS, " << s->island_gens
+          << " generations per launch, rows 2 lanes x " << s->island_K << " chunks";
+    else if (s->resident)
+        o << "resident mode (exact): whole ensemble in one workgroup's LDS (" << (s->user ? 256 : s->resident_tpb)
+          << " threads), up to 4096 generations per launch, rows 2 lanes x " << s->island_K << " chunks";
+    else if (s->plan.vec)
+        o << "multi-launch (exact): half_step_vec L=" << s->plan.L << " K=" << s->plan.K << " ITER=" << s->plan.ITER
+          << (s->plan.ragged ? " ragged" : " exact-size") << ", grid " << s->grid << " x " << s->tpb
+          << ((s->cfg.flags & KMC_NO_GRAPH) ? ", eager launches" : ", hipGraph replay of 64 generations");
+    else
+        o << "multi-launch (exact): half_step_generic (one walker per lane), grid " << s->grid << " x 256";
+    if (s->user) o << "; runtime-compiled density";
+    if (s->p2p) o << "; P2P shard " << s->cfg.shard_rank << "/" << s->cfg.shard_count << (s->connected ? "" : " (not connected)");
+    else if (s->cfg.shard_count > 1) o << "; replica shard " << s->cfg.shard_rank << "/" << s->cfg.shard_count;
+    const std::string t = o.str();
+    std::snprintf(buf, (size_t)buflen, "%s", t.c_str());
+    return KMC_OK;
+}
+
 KMC_EXPORT void* kmc_sampler_device_ptr(kmc_sampler* s, int which)
 {
     if (!s) return nullptr;

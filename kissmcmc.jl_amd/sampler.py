@@ -170,6 +170,15 @@ class Sampler:
     def launch_count(self) -> int:
         return int(self._L.kmc_sampler_launch_count(self._h))
 
+    def describe(self) -> str:
+        """How this sampler executes: kernel family, geometry, exchange scheme."""
+        buf = C.create_string_buffer(512)
+        _lib.check(self._L.kmc_sampler_describe(self._h, buf, 512))
+        return buf.value.decode()
+
+    def __repr__(self):
+        return f"<Sampler {self.nwalkers}x{self.ndim} {self.pdf!r}: {self.describe()}>"
+
     def device_ptr(self, which: int) -> int:
         return int(self._L.kmc_sampler_device_ptr(self._h, int(which)) or 0)
 

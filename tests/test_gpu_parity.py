@@ -175,3 +175,16 @@ def test_resident_small_ensemble_kernel_is_the_same_sampler(kmc, oracle, name, n
     _compare(ref2, multi)
     np.testing.assert_array_equal(res["chain"], multi["chain"])
     np.testing.assert_array_equal(res["naccept"], multi["naccept"])
+
+
+def test_describe_reports_the_execution_mode(kmc):
+    with kmc.Sampler(kmc.GaussianIso(), 65536, 32, 10) as s:
+        assert "half_step_vec L=8 K=2 ITER=2 exact-size" in s.describe() and "hipGraph" in s.describe()
+    with kmc.Sampler(kmc.GaussianIso(), 100, 1, 10) as s:
+        assert "resident mode" in s.describe()
+    with kmc.Sampler(kmc.GaussianIso(), 4096, 10, 10, use_graph=False) as s:
+        assert "ragged" in s.describe() and "eager" in s.describe()
+    with kmc.Sampler(kmc.GaussianIso(), 4096, 1030, 10) as s:
+        assert "half_step_generic" in s.describe()
+    with kmc.Sampler(kmc.GaussianIso(), 1024, 8, 10, island_gens=4) as s:
+        assert "island mode: 4 islands of 256" in repr(s)
