@@ -58,9 +58,18 @@ typedef enum kmc_density {
     KMC_ROSENBROCK   = 2, /* -sum_{i<N-1} [p1 (x_{i+1}-x_i^2)^2 + (p0-x_i)^2]/p2 p = {a, b, scale}    (reference test/runtests.jl:68 at N=2, {1,100,20}) */
     KMC_LOGNORMAL    = 3, /* any x_i <= 0 ? -inf : sum_i [-log x_i - (log x_i - p0)^2/(2 p1^2)]  p = {mu, sigma} */
     KMC_MVNORMAL2    = 4, /* ndim == 2: -1/2 (d' P d), d = x - {p0,p1}, P = [[p2,p3],[p3,p4]] (precision matrix) */
-    KMC_USER_DENSITY = 100 /* runtime-compiled: sum_d term(x_d) + sum_{d<n-1} pair(x_d, x_{d+1}); kmc_config.user_density
+    KMC_USER_DENSITY = 100, /* runtime-compiled: sum_d term(x_d) + sum_{d<n-1} pair(x_d, x_{d+1}); kmc_config.user_density
                               holds the handle made by kmc_user_density_create; params[0..5] are passed to it as p[] */
+    KMC_HOST_DENSITY = 101  /* ANY log-density, evaluated by the caller: per half-step the device writes the batch of
+                              proposals, kmc_config.host_logpdf evaluates it on the host, the device accepts/rejects.
+                              Keeps the reference's arbitrary `pdf` closure (src/samplers.jl:257); bound by the callback
+                              and one PCIe round trip per half-step.  Single GPU, no island mode. */
 } kmc_density;
+
+/* KMC_HOST_DENSITY callback: rows = dense [nrows][ndim]; write the log-pdf of every row to logp_out[nrows].
+   Return 0, or non-zero to abort the run (kmc_sampler_run then returns KMC_ERR_BAD_ARG).  Called on the
+   thread that called kmc_sampler_set_positions / kmc_sampler_run / kmc_emcee_run. */
+typedef int (*kmc_host_logpdf_fn)(const double* rows, int64_t nrows, int64_t ndim, double* logp_out, void* user);
 
 enum {
     KMC_F64 = 0 /* state and arithmetic in IEEE double, as the reference (Float64) */
@@ -105,6 +114,8 @@ typedef struct kmc_config {
     void*    user_density;  /* kmc_user_density* when density == KMC_USER_DENSITY, else NULL */
     int32_t  island_gens;   /* KMC_ISLANDS: generations per epoch (launch); 0 -> 32 */
     int32_t  island_size;   /* KMC_ISLANDS: walkers per island: 64, 128 or 256; 0 -> 256 */
+    kmc_host_logpdf_fn host_logpdf; /* KMC_HOST_DENSITY: the callback, else NULL */
+    void*    host_user;     /* passed through to host_logpdf */
 } kmc_config;
 
 /* Host output buffers of the one-shot call; any pointer may be NULL. */

@@ -10,12 +10,13 @@ fallback -- without the library or a HIP device the sampler raises.
 from . import _lib
 from ._lib import KmcError
 from .api import emcee, emcee_counts, make_theta0s, squash_walkers
-from .densities import DeviceLogPdf, Exponential, ExprDensity, GaussianIso, LogNormal, MvNormal2, Rosenbrock
+from .densities import (DeviceLogPdf, Exponential, ExprDensity, GaussianIso, HostLogPdf, LogNormal, MvNormal2,
+                        Rosenbrock)
 from .sampler import Sampler
 
 __all__ = [
     "emcee", "make_theta0s", "squash_walkers", "emcee_counts", "Sampler", "KmcError",
-    "DeviceLogPdf", "GaussianIso", "Exponential", "Rosenbrock", "LogNormal", "MvNormal2", "ExprDensity",
+    "DeviceLogPdf", "GaussianIso", "Exponential", "Rosenbrock", "LogNormal", "MvNormal2", "ExprDensity", "HostLogPdf",
     "cdf_g_inv", "g_pdf",
 ]
 

@@ -18,6 +18,8 @@ OK, ERR_A_SCALE, ERR_ODD_WALKERS, ERR_TOO_FEW_WALKERS, ERR_BAD_ARG, ERR_NONFINIT
 # kmc_density
 GAUSSIAN_ISO, EXPONENTIAL, ROSENBROCK, LOGNORMAL, MVNORMAL2 = range(5)
 USER_DENSITY = 100
+HOST_DENSITY = 101
+HOST_LOGPDF_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int64, C.c_int64, C.POINTER(C.c_double), C.c_void_p)
 F64 = 0
 STORE_CHAIN, STORE_LOGP, MOMENTS, NO_GRAPH, P2P, ISLANDS, P2P_FINEGRAINED = 1, 2, 4, 8, 16, 64, 128
 P2P_HANDLE_BYTES = 128
@@ -54,6 +56,8 @@ class Config(C.Structure):
         ("user_density", C.c_void_p),
         ("island_gens", C.c_int32),
         ("island_size", C.c_int32),
+        ("host_logpdf", C.c_void_p),
+        ("host_user", C.c_void_p),
     ]
 
 

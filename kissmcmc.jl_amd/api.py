@@ -17,7 +17,7 @@ import sys
 import numpy as np
 
 from . import _lib
-from .densities import DeviceLogPdf
+from .densities import DeviceLogPdf, HostLogPdf
 from .sampler import Sampler
 
 
@@ -50,11 +50,14 @@ def emcee(pdf, theta0s, niter: int = 10 ** 5, nburnin=None, nthin: int = 1, a_sc
     if hasblob or init_blobs is not None or reduce_blob is not None:
         raise NotImplementedError("blobs are arbitrary host objects and cannot cross the device boundary "
                                   "(hasblob=True is not supported by the HIP emcee path)")
-    if not isinstance(pdf, DeviceLogPdf):
-        raise TypeError("emcee on the device needs a menu log-density (GaussianIso, Exponential, Rosenbrock, "
-                        f"LogNormal, MvNormal2); got {type(pdf).__name__}. There is no CPU fallback.")
     theta0s = np.array(theta0s, dtype=np.float64)              # :198 deepcopy
     scalar_walkers = theta0s.ndim == 1
+    if not isinstance(pdf, DeviceLogPdf):
+        if not callable(pdf):
+            raise TypeError(f"pdf must be a log-density object or a callable; got {type(pdf).__name__}")
+        # an arbitrary closure, as in the reference (:257): the moves and the accept test run on the
+        # device, the closure is evaluated on the host on each half-step's batch of proposals
+        pdf = HostLogPdf(pdf, scalar=scalar_walkers)
     if scalar_walkers:
         theta0s = theta0s[:, None]
     if theta0s.ndim != 2:

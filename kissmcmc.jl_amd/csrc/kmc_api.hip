@@ -212,6 +212,11 @@ Plan make_plan(const kmc_config& c, int64_t n_active)
     if (ragged && iter > 4) iter = 4;
     if ((c.flags & KMC_P2P) && iter > 8) iter = 8;
     p.ragged = ragged;
+    if (c.density == KMC_HOST_DENSITY) {
+        // bound by the host callback: the one-walker-per-lane kernel, any ndim
+        p.fn = half_step_host(); p.vec = false; p.ragged = false; p.L = 1; p.K = 1; p.ITER = 1;
+        return p;
+    }
     if (c.density == KMC_USER_DENSITY) {
         // kernels are compiled for exactly this geometry when the sampler is created
         if (!force_generic && L > 0 && 2 * L * K >= c.ndim && iter <= L && iter * K <= 16) {
@@ -240,6 +245,8 @@ kmc_status digest_params(const kmc_config& c, DensityParams* dp)
     case KMC_USER_DENSITY:
         if (!c.user_density) return fail(KMC_ERR_BAD_ARG, "KMC_USER_DENSITY needs kmc_config.user_density");
         for (int i = 0; i < 6; ++i) dp->p[i] = p[i];
+        return KMC_OK;
+    case KMC_HOST_DENSITY:
         return KMC_OK;
     case KMC_GAUSSIAN_ISO:
         if (!(p[1] > 0.0)) return fail(KMC_ERR_BAD_ARG, "gaussian: sigma must be > 0");
@@ -446,6 +453,12 @@ struct kmc_sampler {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool have_run_events = false;
     bool positions_set = false;
+    // host-evaluated density (KMC_HOST_DENSITY)
+    bool host_eval = false;
+    double* d_prop = nullptr;          // [h][ld] proposals of the current half-step
+    double* d_p1 = nullptr;            // [h] their log-pdfs, as returned by the callback
+    double* h_prop = nullptr;          // pinned, dense [h][ndim]
+    double* h_p1 = nullptr;            // pinned [h]
     // resident mode: exact sampler, whole (small) ensemble in one workgroup's LDS, many generations per launch
     bool resident = false;
     ResidentFn resident_kernel = nullptr;
@@ -643,6 +656,11 @@ KMC_EXPORT kmc_status kmc_validate(const kmc_config* c)
     if (c->nwalkers / 2 >= (int64_t)1 << 31 || c->ndim >= (int64_t)1 << 24)
         return fail(KMC_ERR_UNSUPPORTED, "ensemble too large");
     if (c->density == KMC_USER_DENSITY && !c->user_density) return fail(KMC_ERR_BAD_ARG, "KMC_USER_DENSITY needs kmc_config.user_density");
+    if (c->density == KMC_HOST_DENSITY) {
+        if (!c->host_logpdf) return fail(KMC_ERR_BAD_ARG, "KMC_HOST_DENSITY needs kmc_config.host_logpdf");
+        if ((c->flags & (KMC_P2P | KMC_ISLANDS)) || c->shard_count > 1)
+            return fail(KMC_ERR_UNSUPPORTED, "KMC_HOST_DENSITY runs on one GPU, without KMC_P2P / KMC_ISLANDS / sharding");
+    }
     if (c->density == KMC_ROSENBROCK && c->ndim < 2) return fail(KMC_ERR_BAD_ARG, "rosenbrock needs ndim >= 2");
     if (c->density == KMC_MVNORMAL2 && c->ndim != 2) return fail(KMC_ERR_BAD_ARG, "mvnormal2 needs ndim == 2");
     const int P = c->shard_count <= 0 ? 1 : c->shard_count;
@@ -725,6 +743,8 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
             s->nislands = 1;
             s->island_lds = rlds < 4096 ? 4096 : rlds;
         }
+    } else if (cfg->density == KMC_HOST_DENSITY) {
+        s->host_eval = true;
     } else {
         HalfStepFn v, g;
         lookup(cfg->density, 0, 0, 1, false, false, &v, &g, &s->logpdf_fn);
@@ -753,7 +773,7 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         }
         if (ea != hipSuccess) { (void)hipGetLastError(); kmc_sampler_destroy(s); return fail(KMC_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(ea)); }
     }
-    if (!s->islands && cfg->density != KMC_USER_DENSITY && cfg->nwalkers <= 1024 && cfg->ndim <= 32 &&
+    if (!s->islands && cfg->density != KMC_USER_DENSITY && !s->host_eval && cfg->nwalkers <= 1024 && cfg->ndim <= 32 &&
         s->cfg.shard_count == 1 && !(cfg->flags & (KMC_P2P | KMC_NO_GRAPH)) && std::getenv("KMC_NO_RESIDENT") == nullptr) {
         const int64_t chunks = s->ld / 2;
         int K = 1;
@@ -838,6 +858,12 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
             CREATE_TRY(hipMemset(s->d_isumsq, 0, ne * sizeof(double)));
         }
     }
+    if (s->host_eval) {
+        CREATE_TRY(hipMalloc(&s->d_prop, (size_t)s->h * ldz * sizeof(double)));
+        CREATE_TRY(hipMalloc(&s->d_p1, (size_t)s->h * sizeof(double)));
+        CREATE_TRY(hipHostMalloc((void**)&s->h_prop, (size_t)s->h * (size_t)cfg->ndim * sizeof(double), hipHostMallocDefault));
+        CREATE_TRY(hipHostMalloc((void**)&s->h_p1, (size_t)s->h * sizeof(double), hipHostMallocDefault));
+    }
     if ((cfg->flags & KMC_STORE_CHAIN) && s->nsamples > 0)
         CREATE_TRY(hipMalloc(&s->d_chain, (size_t)s->nsamples * (size_t)s->nlocal * ldz * sizeof(double)));
     if ((cfg->flags & KMC_STORE_LOGP) && s->nsamples > 0)
@@ -883,6 +909,10 @@ KMC_EXPORT void kmc_sampler_destroy(kmc_sampler* s)
     (void)hipFree(s->d_klast);
     (void)hipFree(s->d_isum);
     (void)hipFree(s->d_isumsq);
+    (void)hipFree(s->d_prop);
+    (void)hipFree(s->d_p1);
+    if (s->h_prop) (void)hipHostFree(s->h_prop);
+    if (s->h_p1) (void)hipHostFree(s->h_p1);
     if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
     (void)hipGetLastError();
     delete s;
@@ -908,15 +938,6 @@ KMC_EXPORT kmc_status kmc_sampler_bind_positions(kmc_sampler* s, void* pos_dev)
     HIP_TRY(hipStreamSynchronize(s->stream));
     if (s->graph_exec) { (void)hipGraphExecDestroy(s->graph_exec); s->graph_exec = nullptr; }
     if (s->graph) { (void)hipGraphDestroy(s->graph); s->graph = nullptr; }
-    if (s->p2p) {
-        for (int r = 0; r < 8; ++r) {
-            if (r == s->cfg.shard_rank) continue;
-            if (s->peer_pos[r]) (void)hipIpcCloseMemHandle(s->peer_pos[r]);
-            if (s->peer_flags[r]) (void)hipIpcCloseMemHandle(s->peer_flags[r]);
-        }
-        (void)hipFree(s->d_flags);
-        (void)hipFree(s->d_err);
-    }
     if (s->own_pos) (void)hipFree(s->d_pos);
     s->d_pos = static_cast<double*>(pos_dev);
     s->own_pos = false;
@@ -1007,6 +1028,7 @@ KMC_EXPORT kmc_status kmc_sampler_init_ball(kmc_sampler* s, const double* theta0
                                             uint64_t seed, int halving_steps, int ntries)
 {
     if (!s || !theta0 || !ball_radius || halving_steps < 1 || ntries < 1) return fail(KMC_ERR_BAD_ARG, "bad argument");
+    if (s->host_eval) return fail(KMC_ERR_UNSUPPORTED, "kmc_sampler_init_ball evaluates the density on the device; with KMC_HOST_DENSITY build the ball on the host");
     HIP_TRY(hipSetDevice(s->cfg.device));
     HIP_TRY(hipStreamSynchronize(s->stream));
     const size_t nd = (size_t)s->cfg.ndim;
@@ -1104,7 +1126,14 @@ KMC_EXPORT kmc_status kmc_sampler_set_positions(kmc_sampler* s, const double* th
         HIP_TRY(hipMemset(s->d_flags, 0, 4096));     // callers barrier across ranks before running
         HIP_TRY(hipMemset(s->d_err, 0, 64));
     }
-    {
+    if (s->host_eval) {                                          // :209-210, on the caller's thread
+        std::vector<double> lp0(nw);
+        if (s->cfg.host_logpdf(theta_host, (int64_t)nw, (int64_t)nd, lp0.data(), s->cfg.host_user) != 0) {
+            s->positions_set = false;
+            return fail(KMC_ERR_BAD_ARG, "the host log-pdf callback failed on the initial ensemble");
+        }
+        HIP_TRY(hipMemcpy(s->d_logp, lp0.data(), nw * sizeof(double), hipMemcpyHostToDevice));
+    } else {
         const LogpdfArgs la{s->d_pos, s->d_logp, (int64_t)nw, (int32_t)nd, (int32_t)s->ld, s->dp};   // :209-210
         if (s->user) {
             HIP_TRY(launch_module(s->uk.logpdf, (unsigned)((nw + 255) / 256), 256u, s->stream, la));
@@ -1215,6 +1244,36 @@ KMC_EXPORT kmc_status kmc_sampler_run(kmc_sampler* s, int64_t ngen)
         s->have_run_events = true;
         return KMC_OK;
     }
+    if (s->host_eval) {
+        // per half-step: PROPOSE on the device -> proposals to the host -> callback -> log-pdfs back
+        // -> ACCEPT on the device (which recomputes the same proposals from the same draws)
+        const size_t hh = (size_t)s->h, nd = (size_t)s->cfg.ndim, ld = (size_t)s->ld;
+        for (; ngen > 0; --ngen) {
+            for (int half = 0; half < 2; ++half) {
+                HalfStepArgs a = make_args(s, half, false, s->generation);
+                a.prop_out = s->d_prop;
+                hipLaunchKernelGGL(s->plan.fn, dim3(s->grid), dim3(s->tpb), 0, s->stream, a);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipMemcpy2DAsync(s->h_prop, nd * sizeof(double), s->d_prop, ld * sizeof(double), nd * sizeof(double), hh,
+                                         hipMemcpyDeviceToHost, s->stream));
+                HIP_TRY(hipStreamSynchronize(s->stream));
+                if (s->cfg.host_logpdf(s->h_prop, (int64_t)hh, (int64_t)nd, s->h_p1, s->cfg.host_user) != 0) {   // :257
+                    s->positions_set = false;
+                    return fail(KMC_ERR_BAD_ARG, "the host log-pdf callback failed in generation " + std::to_string(s->generation));
+                }
+                HIP_TRY(hipMemcpyAsync(s->d_p1, s->h_p1, hh * sizeof(double), hipMemcpyHostToDevice, s->stream));
+                a.prop_out = nullptr;
+                a.p1_in = s->d_p1;
+                hipLaunchKernelGGL(s->plan.fn, dim3(s->grid), dim3(s->tpb), 0, s->stream, a);
+                HIP_TRY(hipGetLastError());
+                s->launches += 2;
+            }
+            s->generation += 1;
+        }
+        HIP_TRY(hipEventRecord(s->ev1, s->stream));
+        s->have_run_events = true;
+        return KMC_OK;
+    }
     const bool use_graph = !(s->cfg.flags & KMC_NO_GRAPH);
     while (use_graph && ngen >= kGraphChunk) {
         KMC_TRY(ensure_graph(s));
@@ -1241,6 +1300,7 @@ KMC_EXPORT kmc_status kmc_sampler_half_step(kmc_sampler* s, int half)
     if (!s->positions_set) return fail(KMC_ERR_BAD_ARG, "kmc_sampler_set_positions has not succeeded yet");
     if (s->p2p && !s->connected) return fail(KMC_ERR_BAD_ARG, "kmc_sampler_p2p_connect has not been called");
     if (s->islands) return fail(KMC_ERR_UNSUPPORTED, "island mode advances whole generations: use kmc_sampler_run");
+    if (s->host_eval) return fail(KMC_ERR_UNSUPPORTED, "KMC_HOST_DENSITY: a half-step includes the host callback; use kmc_sampler_run");
     if (s->resident) return fail(KMC_ERR_UNSUPPORTED, "this small ensemble runs in resident mode (whole generations per launch); create it with KMC_NO_GRAPH to step by halves");
     HIP_TRY(hipSetDevice(s->cfg.device));
     KMC_TRY(launch_half(s, half, false, s->generation));
@@ -1291,6 +1351,9 @@ KMC_EXPORT kmc_status kmc_sampler_describe(const kmc_sampler* s, char* buf, int6
     else if (s->resident)
         o << "resident mode (exact): whole ensemble in one workgroup's LDS (" << (s->user ? 256 : s->resident_tpb)
           << " threads), up to 4096 generations per launch, rows 2 lanes x " << s->island_K << " chunks";
+    else if (s->host_eval)
+        o << "host-evaluated density (exact): per half-step propose kernel -> D2H -> callback -> H2D -> accept kernel, grid "
+          << s->grid << " x 256";
     else if (s->plan.vec)
         o << "multi-launch (exact): half_step_vec L=" << s->plan.L << " K=" << s->plan.K << " ITER=" << s->plan.ITER
           << (s->plan.ragged ? " ragged" : " exact-size") << ", grid " << s->grid << " x " << s->tpb
@@ -1495,6 +1558,7 @@ KMC_EXPORT kmc_status kmc_logpdf_eval(const kmc_config* cfg, const double* pos_d
         HIP_TRY(e);
         return KMC_OK;
     }
+    if (cfg->density == KMC_HOST_DENSITY) return fail(KMC_ERR_UNSUPPORTED, "KMC_HOST_DENSITY is evaluated by the caller, not on the device");
     HalfStepFn v, g;
     LogpdfFn lp = nullptr;
     if (!lookup(cfg->density, 0, 0, 1, false, false, &v, &g, &lp)) return fail(KMC_ERR_BAD_ARG, "unknown density id");

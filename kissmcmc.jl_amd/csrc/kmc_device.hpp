@@ -345,6 +345,24 @@ struct MvNormal2 {   // p = {m1, m2, P11, P12, P22}
 };
 
 // ------------------------------------------------------------------------------------------
+// Host-evaluated density (KMC_HOST_DENSITY): the log-pdf of a proposal is whatever the caller's
+// callback returned for it -- the reference's arbitrary `pdf` closure (src/samplers.jl:257) kept on
+// the host.  A half-step is then two launches of the generic kernel: a PROPOSE pass that writes the
+// proposals for the host to evaluate, and an ACCEPT pass that recomputes the same proposals (same
+// counter-based draws, untouched rows) and reads their log-pdfs from p1_in.
+// ------------------------------------------------------------------------------------------
+struct HostEval {
+    static constexpr bool kHasFrag = false;
+    static constexpr bool kHostEval = true;
+    struct Seq { };
+    __device__ static void seq_init(Seq&) { }
+    __device__ static void seq_add(Seq&, double, int, const DensityParams&) { }
+    __device__ static double seq_finish(const Seq&, int, const DensityParams&) { return 0.0; }
+};
+template <class D, class = void> struct HostEvalTrait { static constexpr bool value = false; };
+template <class D> struct HostEvalTrait<D, decltype((void)D::kHostEval)> { static constexpr bool value = true; };
+
+// ------------------------------------------------------------------------------------------
 // User-supplied densities (runtime-compiled with hiprtc, the device-side answer to the reference's
 // arbitrary `pdf` closure, src/samplers.jl:257):
 //     log p(x) = sum_d F::term(x_d, d, n, p)  +  sum_{d < n-1} F::pair(x_d, x_{d+1}, d, n, p)

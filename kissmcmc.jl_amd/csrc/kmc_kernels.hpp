@@ -94,6 +94,9 @@ struct HalfStepArgs {
     double*           msumsq;
     int64_t           macc_stride;  // threads in the accumulator grid
     uint32_t*         klast;        // vec kernels: per walker, samples already credited to the moments
+    // host-evaluated densities (HostEval) only
+    double*           prop_out;     // PROPOSE pass: proposals [n_active][ld]; nothing else is touched
+    const double*     p1_in;        // ACCEPT pass: log-pdf of proposal i as evaluated by the host
 };
 
 __device__ __forceinline__ SchedEntry schedule_of(const HalfStepArgs& a)
@@ -427,13 +430,21 @@ __device__ __forceinline__ void half_step_generic_body(const HalfStepArgs& a)
     }
     const double p0 = a.logp[gw];
 
+    constexpr bool kHost = HostEvalTrait<Dens>::value;
+    if constexpr (kHost) {
+        if (a.prop_out != nullptr) {                                    // PROPOSE pass
+            for (int d = 0; d < ndim; ++d) a.prop_out[(int64_t)tid * ld + d] = fma(dr.z, own[d] - oth[d], oth[d]);
+            return;
+        }
+    }
     typename Dens::Seq q;
     Dens::seq_init(q);
     for (int d = 0; d < ndim; ++d) {
         const double y = fma(dr.z, own[d] - oth[d], oth[d]);            // :255
         Dens::seq_add(q, y, d, a.dp);
     }
-    const double p1 = Dens::seq_finish(q, ndim, a.dp);                   // :257
+    double p1 = Dens::seq_finish(q, ndim, a.dp);                         // :257
+    if constexpr (kHost) p1 = a.p1_in[tid];
     const bool acc = accept_test(dr, p1, p0);                           // :260
 
     const bool do_mom = sample && a.msum != nullptr;

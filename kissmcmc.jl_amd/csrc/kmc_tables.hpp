@@ -136,6 +136,7 @@ KMC_DECLARE_DENSITY_TABLE(table_exponential);
 KMC_DECLARE_DENSITY_TABLE(table_rosenbrock);
 KMC_DECLARE_DENSITY_TABLE(table_lognormal);
 KMC_DECLARE_DENSITY_TABLE(table_mvnormal2);
+HalfStepFn half_step_host();
 IslandFn island_gaussian_iso(int S, int K, bool ragged);
 ResidentFn resident_gaussian_iso(int tpb, int K, bool ragged);
 InitBallFn init_ball_gaussian_iso();

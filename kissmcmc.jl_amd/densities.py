@@ -229,3 +229,61 @@ class ExprDensity(DeviceLogPdf):
 
     def finite_rows(self, X):
         return self._eval_rows(X) > -np.inf
+
+
+class HostLogPdf(DeviceLogPdf):
+    """ANY Python callable as the log-density -- the reference's ``pdf`` closure
+    (``src/samplers.jl:257``) kept on the host.  The stretch move, the random draws, the accept test,
+    the counters and the sample storage stay on the GPU; per half-step the device hands the batch of
+    proposals to ``fn`` and takes their log-pdfs back (``KMC_HOST_DENSITY`` in
+    ``include/kissmcmc_hip.h``).  Bound by ``fn`` and one PCIe round trip per half-step, so this is
+    the *general* route, not the fast one -- prefer a menu density or :class:`ExprDensity` when the
+    density can be written as one.
+
+    ``fn(theta)`` gets one walker: a float when ``scalar`` (the reference's 1-D convention, where
+    ``theta0s`` is a vector of numbers) else a 1-D array.  With ``vectorized=True`` it gets the whole
+    batch ``[nrows, ndim]`` and must return ``nrows`` log-pdfs.
+    """
+
+    density_id = _lib.HOST_DENSITY
+    name = "host"
+
+    def __init__(self, fn, vectorized: bool = False, scalar: bool = False):
+        if not callable(fn):
+            raise TypeError("pdf must be callable")
+        self.fn, self.vectorized, self.scalar = fn, bool(vectorized), bool(scalar)
+        self.error = None          # exception raised by fn inside the C callback, re-raised by Sampler
+
+        def _cb(rows, nrows, ndim, out, _user):
+            try:
+                X = np.ctypeslib.as_array(rows, shape=(nrows, ndim))
+                np.ctypeslib.as_array(out, shape=(nrows,))[:] = self.eval_rows(X)
+                return 0
+            except BaseException as e:      # never unwind through the C frames
+                self.error = e
+                return 1
+
+        self.c_callback = _lib.HOST_LOGPDF_FN(_cb)
+
+    def params(self):
+        return []
+
+    def eval_rows(self, X):
+        X = np.asarray(X, dtype=np.float64)
+        if self.vectorized:
+            r = np.asarray(self.fn(X[:, 0] if self.scalar else X), dtype=np.float64).reshape(-1)
+            if r.shape[0] != X.shape[0]:
+                raise ValueError(f"vectorized pdf returned {r.shape[0]} values for {X.shape[0]} rows")
+            return r
+        if self.scalar:
+            return np.array([float(self.fn(float(v))) for v in X[:, 0]], dtype=np.float64)
+        return np.array([float(self.fn(row.copy())) for row in X], dtype=np.float64)
+
+    def __call__(self, theta):
+        return float(self.fn(theta))
+
+    def finite_rows(self, X):
+        return self.eval_rows(X) > -np.inf
+
+    def __repr__(self):
+        return f"HostLogPdf({getattr(self.fn, '__name__', type(self.fn).__name__)})"

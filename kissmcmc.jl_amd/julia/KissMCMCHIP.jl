@@ -2,15 +2,16 @@
 #
 # Keeps the call surface of KissMCMC.jl's emcee path (reference src/samplers.jl:188-216, :311-349,
 # :372-428): `emcee(pdf, theta0s; niter, nburnin, nthin, a_scale, ...)`, `make_theta0s`,
-# `squash_walkers`.  `pdf` must be one of the menu densities below (the device cannot run an
-# arbitrary Julia closure); any other callable throws -- there is no CPU fallback here, use
-# KissMCMC.emcee for that.
+# `squash_walkers`.  `pdf` is one of the menu densities below or an `ExprDensity` (evaluated on the
+# device), or ANY Julia callable: that one stays on the host (`HostLogPdf`, KMC_HOST_DENSITY) and is
+# called on each half-step's batch of proposals while the moves, draws, accept test and storage run
+# on the GPU.  There is no CPU fallback for the sampler itself.
 #
 # NOT EXECUTED in the build environment (no julia binary there).  Every call it makes is mirrored
 # 1:1 by the Python ctypes host (kissmcmc.jl_amd/_lib.py, api.py), which is what the tests drive.
 module KissMCMCHIP
 
-export emcee, make_theta0s, squash_walkers, GaussianIso, Exponential, Rosenbrock, LogNormal, MvNormal2, ExprDensity
+export emcee, make_theta0s, squash_walkers, GaussianIso, Exponential, Rosenbrock, LogNormal, MvNormal2, ExprDensity, HostLogPdf
 
 using Statistics: mean, median, std
 using LinearAlgebra: inv
@@ -60,9 +61,28 @@ user_handle(::DeviceLogPdf) = C_NULL
 function (d::ExprDensity)(x)
     xs = collect(Float64, x isa Number ? [x] : x); out = Ref(0.0)
     p8 = ntuple(i -> i <= length(d.p) ? d.p[i] : 0.0, 8)
-    cfg = Ref(KmcConfig(0, Cint(100), p8, 2, length(xs), 0, 0, 1, 2.0, UInt64(0), 0, 0, 0, 1, d.handle, 0, 0))
+    cfg = Ref(KmcConfig(0, Cint(100), p8, 2, length(xs), 0, 0, 1, 2.0, UInt64(0), 0, 0, 0, 1, d.handle, 0, 0, C_NULL, C_NULL))
     st = ccall((:kmc_logpdf_eval_host, LIB), Cint, (Ref{KmcConfig}, Ptr{Float64}, Ref{Float64}, Int64), cfg, xs, out, 1)
     st == 0 || error(last_error()); out[]
+end
+
+# Any Julia callable as the log-density (the reference's closure, src/samplers.jl:257), evaluated on
+# the host: kmc_config.host_logpdf points at `host_trampoline`, host_user at the wrapper object.
+mutable struct HostLogPdf{F} <: DeviceLogPdf; f::F; scalar::Bool; end
+HostLogPdf(f) = HostLogPdf(f, false)
+(d::HostLogPdf)(x) = d.f(x)
+density_id(::HostLogPdf) = Cint(101); params(::HostLogPdf) = Float64[]
+function host_trampoline(rows::Ptr{Float64}, nrows::Int64, ndim::Int64, out::Ptr{Float64}, user::Ptr{Cvoid})::Cint
+    try
+        d = unsafe_pointer_to_objref(user)
+        X = unsafe_wrap(Array, rows, (ndim, nrows))       # column w = proposal of walker w
+        for w in 1:nrows
+            unsafe_store!(out, Float64(d.scalar ? d.f(X[1, w]) : d.f(X[:, w])), w)
+        end
+        return Cint(0)
+    catch
+        return Cint(1)                                     # kmc_emcee_run then fails with KMC_ERR_BAD_ARG
+    end
 end
 
 # ---- C structs (layout checked against the header by tests/test_c_abi.py on the Python mirror) ---
@@ -74,6 +94,7 @@ struct KmcConfig
     flags::UInt32; device::Int32; shard_rank::Int32; shard_count::Int32
     user_density::Ptr{Cvoid}
     island_gens::Int32; island_size::Int32     # KMC_ISLANDS (opt-in island mode); 0 = defaults
+    host_logpdf::Ptr{Cvoid}; host_user::Ptr{Cvoid}   # KMC_HOST_DENSITY callback and its context
 end
 
 mutable struct KmcOutputs
@@ -109,13 +130,19 @@ function emcee(pdf::DeviceLogPdf, theta0s; niter=10^5, nburnin=niter ÷ 2, nthin
         theta[d, w] = scalar ? theta0s[w] : theta0s[w][d]                                # :198 deep copy
     end
     p = params(pdf); p8 = ntuple(i -> i <= length(p) ? p[i] : 0.0, 8)
+    host_fn, host_ctx = C_NULL, C_NULL
+    if pdf isa HostLogPdf
+        pdf.scalar = scalar
+        host_fn = @cfunction(host_trampoline, Cint, (Ptr{Float64}, Int64, Int64, Ptr{Float64}, Ptr{Cvoid}))
+        host_ctx = pointer_from_objref(pdf)
+    end
     cfg = Ref(KmcConfig(0, density_id(pdf), p8, nwalkers, ndim, niter_walker, nburnin_walker, nthin,
-                        a_scale, UInt64(seed), 0x3, Int32(device), 0, 1, user_handle(pdf), 0, 0))   # flags: STORE_CHAIN | STORE_LOGP
+                        a_scale, UInt64(seed), 0x3, Int32(device), 0, 1, user_handle(pdf), 0, 0, host_fn, host_ctx))   # flags: STORE_CHAIN | STORE_LOGP
     chain = Array{Float64}(undef, ndim, nwalkers, nsamples)
     clogp = Array{Float64}(undef, nwalkers, nsamples)
     acc = Vector{Float64}(undef, nwalkers)
     out = KmcOutputs(pointer(chain), pointer(clogp), pointer(acc), C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, 0, 0, 0.0)
-    st = GC.@preserve theta chain clogp acc ccall((:kmc_emcee_run, LIB), Cint,
+    st = GC.@preserve pdf theta chain clogp acc ccall((:kmc_emcee_run, LIB), Cint,
                                                    (Ref{KmcConfig}, Ptr{Float64}, Ref{KmcOutputs}), cfg, theta, out)
     st == 0 || error("kmc_emcee_run failed ($st): $(last_error())")
     thetas = scalar ? [[chain[1, w, k] for k in 1:nsamples] for w in 1:nwalkers] :
@@ -123,7 +150,7 @@ function emcee(pdf::DeviceLogPdf, theta0s; niter=10^5, nburnin=niter ÷ 2, nthin
     logdensities = [[clogp[w, k] for k in 1:nsamples] for w in 1:nwalkers]
     return thetas, acc, logdensities, nothing                                            # :292
 end
-emcee(pdf, theta0s; kw...) = error("emcee on the device needs a menu log-density (GaussianIso, Exponential, Rosenbrock, LogNormal, MvNormal2); use KissMCMC.emcee for arbitrary closures")
+emcee(pdf, theta0s; kw...) = emcee(HostLogPdf(pdf), theta0s; kw...)     # arbitrary closure: evaluated on the host
 
 "src/samplers.jl:311-349 (host side, runs once)."
 function make_theta0s(theta0::T, ball_radius, pdf, nwalkers; ball_radius_halfing_steps=7, ntries=100, hasblob=false) where T

@@ -25,9 +25,9 @@ class Sampler:
                  island_gens: int = 0, island_size: int = 0, p2p_finegrained: bool = False):
         if not isinstance(pdf, DeviceLogPdf):
             raise TypeError(
-                "the device emcee path evaluates a fixed menu of log-densities "
-                "(GaussianIso, Exponential, Rosenbrock, LogNormal, MvNormal2); "
-                f"got {type(pdf).__name__}. There is no CPU fallback for arbitrary callables.")
+                "pdf must be a menu log-density (GaussianIso, Exponential, Rosenbrock, LogNormal, MvNormal2), "
+                "an ExprDensity (compiled for the device) or a HostLogPdf (any callable, evaluated on the host "
+                f"per half-step); got {type(pdf).__name__}.")
         pdf.check_ndim(int(ndim))
         self.pdf = pdf
         self._h = None
@@ -63,6 +63,9 @@ class Sampler:
         cfg.device = int(device)
         cfg.shard_rank, cfg.shard_count = int(shard_rank), int(shard_count)
         cfg.user_density = pdf.user_handle     # runtime-compiled density (ExprDensity) or None
+        cb = getattr(pdf, "c_callback", None)  # host-evaluated density (HostLogPdf) or None
+        if cb is not None:
+            cfg.host_logpdf = C.cast(cb, C.c_void_p)
         self.cfg = cfg
         self._L = _lib.lib()
         h = C.c_void_p()
@@ -115,7 +118,7 @@ class Sampler:
 
     def set_positions(self, theta):
         theta = np.ascontiguousarray(np.asarray(theta, dtype=np.float64).reshape(self.nwalkers, self.ndim))
-        _lib.check(self._L.kmc_sampler_set_positions(self._h, _dp(theta)))
+        self._check_host(self._L.kmc_sampler_set_positions(self._h, _dp(theta)))
 
     def init_ball(self, theta0, ball_radius, seed: int = 0, ball_radius_halfing_steps: int = 7, ntries: int = 100):
         """Device-side ``make_theta0s`` (reference ``src/samplers.jl:311-349``): seeded Gaussian ball
@@ -144,8 +147,16 @@ class Sampler:
         _lib.check(self._L.kmc_sampler_set_state(self._h, _dp(pos), _dp(lp), na.ctypes.data_as(C.POINTER(C.c_int64)),
                                                  int(state["generation"])))
 
+    def _check_host(self, status):
+        """Re-raise an exception the host log-pdf raised inside the C callback, else check the status."""
+        err = getattr(self.pdf, "error", None)
+        if status != _lib.OK and err is not None:
+            self.pdf.error = None
+            raise err
+        _lib.check(status)
+
     def run(self, ngenerations: int):
-        _lib.check(self._L.kmc_sampler_run(self._h, int(ngenerations)))
+        self._check_host(self._L.kmc_sampler_run(self._h, int(ngenerations)))
 
     def half_step(self, half: int):
         _lib.check(self._L.kmc_sampler_half_step(self._h, int(half)))

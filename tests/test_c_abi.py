@@ -36,11 +36,11 @@ def test_struct_layout_matches_header(kmc, tmp_path):
     src = tmp_path / "layout.c"
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "kissmcmc_hip.h"\n'
                    'int main(void){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(kmc_config), offsetof(kmc_config, nwalkers),'
-                   ' offsetof(kmc_config, seed), offsetof(kmc_config, user_density), sizeof(kmc_outputs), offsetof(kmc_outputs, device_ms));return 0;}\n')
+                   ' offsetof(kmc_config, seed), offsetof(kmc_config, host_logpdf), sizeof(kmc_outputs), offsetof(kmc_outputs, device_ms));return 0;}\n')
     exe = tmp_path / "layout"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
-    want = [C.sizeof(_lib.Config), _lib.Config.nwalkers.offset, _lib.Config.seed.offset, _lib.Config.user_density.offset,
+    want = [C.sizeof(_lib.Config), _lib.Config.nwalkers.offset, _lib.Config.seed.offset, _lib.Config.host_logpdf.offset,
             C.sizeof(_lib.Outputs), _lib.Outputs.device_ms.offset]
     assert got == want
 

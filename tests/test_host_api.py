@@ -86,8 +86,14 @@ def test_emcee_argument_checks_match_reference_asserts(kmc):
         kmc.emcee(g, np.zeros((11, 2)), use_progress_meter=False)                        # :202
     with pytest.raises(AssertionError, match="Use more walkers: at least DOF\\+2"):
         kmc.emcee(g, np.zeros((2, 2)), use_progress_meter=False)                         # :205
-    with pytest.raises(TypeError, match="no CPU fallback"):
-        kmc.emcee(lambda x: -np.sum(x ** 2), th, use_progress_meter=False)
+    with pytest.raises(TypeError, match="callable"):
+        kmc.emcee("not a density", th, use_progress_meter=False)
+    from kissmcmc_jl_amd import _lib
+    if _lib.lib().kmc_device_count() == 0:
+        # a closure is evaluated on the host, but the sampler itself has no CPU fallback
+        with pytest.raises(kmc.KmcError) as e:
+            kmc.emcee(lambda x: -np.sum(x ** 2), th, use_progress_meter=False)
+        assert e.value.status == _lib.ERR_NO_DEVICE
     with pytest.raises(NotImplementedError):
         kmc.emcee(g, th, hasblob=True)
 
