@@ -493,6 +493,7 @@ HalfStepArgs make_args(const kmc_sampler* s, int half, bool graph_mode, int64_t 
     a.logp = s->d_logp;
     a.naccept = s->d_naccept;
     a.sched_table = graph_mode ? s->d_sched : nullptr;
+    if (graph_mode && std::getenv("KMC_EXP_INLINE")) a.sched_table = nullptr;   // EXPERIMENT (timing only)
     a.sched_index = graph_mode ? (int32_t)gen_offset : 0;
     a.sched_inline = make_sched(gen_offset, s->cfg.nburnin, s->cfg.nthin, s->nsamples);
     a.gw0 = (int64_t)half * s->h + s->active_begin;

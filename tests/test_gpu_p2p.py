@@ -104,7 +104,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world,plan", [(2, ""), (4, ""), (2, "generic")]   # the GPU box allows 6 processes on the card: parent + 4 ranks at most)
+@pytest.mark.parametrize("world,plan", [(2, ""), (4, ""), (2, "generic")])   # the GPU box allows 6 processes on the card: parent + 4 ranks at most
 def test_p2p_processes_sharing_one_gpu_equal_oracle(oracle, tmp_path, world, plan):
     import torch.multiprocessing as mp
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), plan), nprocs=world, join=True)
