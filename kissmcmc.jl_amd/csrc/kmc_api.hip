@@ -492,9 +492,8 @@ HalfStepArgs make_args(const kmc_sampler* s, int half, bool graph_mode, int64_t 
     a.pos = s->d_pos;
     a.logp = s->d_logp;
     a.naccept = s->d_naccept;
-    a.sched_table = graph_mode ? s->d_sched : nullptr;
-    if (graph_mode && std::getenv("KMC_EXP_INLINE")) a.sched_table = nullptr;   // EXPERIMENT (timing only)
-    a.sched_index = graph_mode ? (int32_t)gen_offset : 0;
+    a.sched_table = s->d_sched;
+    a.sched_index = graph_mode ? (int32_t)gen_offset : -1;
     a.sched_inline = make_sched(gen_offset, s->cfg.nburnin, s->cfg.nthin, s->nsamples);
     a.gw0 = (int64_t)half * s->h + s->active_begin;
     a.own_row0 = s->p2p ? (int64_t)half * s->h_loc : a.gw0;

@@ -11,3 +11,10 @@ IslandFn island_gaussian_iso(int S, int K, bool ragged) { return island_lookup<G
 ResidentFn resident_gaussian_iso(int tpb, int K, bool ragged) { return resident_lookup<GaussianIso>(tpb, K, ragged); }
 InitBallFn init_ball_gaussian_iso() { return init_ball<GaussianIso>; }
 }  // namespace kmc
+
+#ifdef KMC_PROBE   // diagnostic build only (scripts/probe_timeline.py)
+extern "C" __attribute__((visibility("default"))) int kmc_probe_read(void* out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(kmc::g_probe), sizeof(kmc::g_probe));
+}
+#endif

@@ -41,12 +41,14 @@ struct SchedEntry {
     int64_t  slot;    // stored-sample index k when (flags & kSample)
     uint32_t flags;
     uint32_t nbefore; // number of samples taken by generations < gen (sojourn-weighted moments)
+    uint32_t pad_[2]; // 32 bytes: one s_load_dwordx8 per entry
 };
+static_assert(sizeof(SchedEntry) == 32, "schedule_of loads an entry as eight dwords");
 enum : uint32_t { kCount = 1u, kSample = 2u };
 
 __host__ __device__ inline SchedEntry make_sched(int64_t gen, int64_t nburnin, int64_t nthin, int64_t nsamples)
 {
-    SchedEntry e{gen, 0, 0u, 0u};
+    SchedEntry e{gen, 0, 0u, 0u, {0u, 0u}};
     const int64_t n = gen + 1 - nburnin;
     if (n > 1) {
         const int64_t nb = (n - 1) / nthin;
@@ -66,9 +68,9 @@ struct HalfStepArgs {
     double*           pos;
     double*           logp;
     uint32_t*         naccept;
-    const SchedEntry* sched_table;  // device table (graph replay) or nullptr
-    SchedEntry        sched_inline; // used when sched_table == nullptr
-    int32_t           sched_index;
+    const SchedEntry* sched_table;  // device table (always valid)
+    SchedEntry        sched_inline; // used when sched_index < 0 (eager launches)
+    int32_t           sched_index;  // entry of sched_table (graph replay), or -1
     int32_t           half;         // 0: update [0,h) against [h,2h); 1: swapped       (:247)
     int64_t           gw0;          // GLOBAL walker index of this launch's active walker 0 (keys the RNG)
     int64_t           own_row0;     // its row in pos / index in logp, naccept
@@ -99,9 +101,24 @@ struct HalfStepArgs {
     const double*     p1_in;        // ACCEPT pass: log-pdf of proposal i as evaluated by the host
 };
 
+// One scalar load of the whole 32-byte entry (s_load_dwordx8; the scalar cache is invalidated at
+// kernel start and the table is only written by advance_schedule between launches), issued as soon
+// as the kernarg is in: nothing in the kernel's prologue waits on vector memory, and the entry is one
+// round trip instead of one per field.  sched_index < 0: the entry travels in the args (eager
+// launches); sched_table is a valid pointer either way.
 __device__ __forceinline__ SchedEntry schedule_of(const HalfStepArgs& a)
 {
-    return a.sched_table ? a.sched_table[a.sched_index] : a.sched_inline;
+    typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+    const bool inl = a.sched_index < 0;
+    const SchedEntry* p = a.sched_table + (inl ? 0 : a.sched_index);
+    u32x8 r;
+    asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(p));
+    SchedEntry t;
+    t.gen     = inl ? a.sched_inline.gen     : (int64_t)(((uint64_t)r[1] << 32) | r[0]);
+    t.slot    = inl ? a.sched_inline.slot    : (int64_t)(((uint64_t)r[3] << 32) | r[2]);
+    t.flags   = inl ? a.sched_inline.flags   : r[4];
+    t.nbefore = inl ? a.sched_inline.nbefore : r[5];
+    return t;
 }
 
 // Row store.  KMC_STORE_SC1: write-through (sc1) so the kernel leaves no dirty lines for the
@@ -175,6 +192,13 @@ __device__ __forceinline__ void wait_for_peers(const HalfStepArgs& a, unsigned l
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+#ifdef KMC_PROBE   // diagnostic build only: per-wave 100 MHz timestamps of the last launch of each half
+static __device__ unsigned long long g_probe[2][8192][4];
+#define KMC_STAMP(i) do { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); stamp[i] = t_; } while (0)
+#else
+#define KMC_STAMP(i) do { } while (0)
+#endif
+
 // RAGGED = false: ndim == 2*L*K exactly (row stride and every mask fold at compile time);
 // RAGGED = true : ndim < 2*L*K, runtime row stride a.ld and masked tail chunks.
 template <class Dens, int L, int K, int ITER, bool P2P, bool RAGGED>
@@ -197,6 +221,13 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepArgs& a)
 #pragma unroll
     for (int k = 0; k < K; ++k) cv[k] = !RAGGED || 2 * (k * L + j) < (int)ld;
     const double2 zero2 = make_double2(0.0, 0.0);
+#ifdef KMC_PROBE
+    unsigned long long stamp[4];
+#endif
+    KMC_STAMP(0);
+    // have the schedule entry's address in the first kernarg batch, so its load goes out together with
+    // the second batch (one scalar round trip for both)
+    asm volatile("" :: "s"(a.sched_index), "s"(a.sched_table));
 
     // ---- row layout: own rows of every iteration (independent of the random draws) ----------
     bool    validB[ITER];
@@ -242,6 +273,7 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepArgs& a)
     const uint32_t kl = do_mom ? a.klast[rowA] : 0u;
     const U4 bits = draw_bits(a.dc, step, (uint64_t)(a.gw0 + iAc));     // RNG keyed by the GLOBAL walker index
     const uint32_t partnerA = draw_partner(a.dc, bits);                 // :250
+    KMC_STAMP(1);
 
     // ---- scalar -> row: the partner of slot it*G+g lives in lane gbase+it; get the partner-row
     //      loads in flight before the logarithms ---------------------------------------------
@@ -296,6 +328,7 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepArgs& a)
         myp1 = (j == it) ? p1 : myp1;                                   // row -> scalar, no traffic
     }
 
+    KMC_STAMP(2);
     // ---- accept test in the scalar layout ---------------------------------------------------
     const bool acc = validA && accept_test(dr, myp1, p0);               // :260
     const unsigned long long accmask = __ballot(acc);
@@ -339,6 +372,10 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepArgs& a)
         if constexpr (kPrefetchAcc) accumulate_wave<L, K, true>(a.msum, a.msumsq, a.macc_stride, tid, g, ms, mq, accs, accq);
         else accumulate_wave<L, K, false>(a.msum, a.msumsq, a.macc_stride, tid, g, ms, mq, accs, accq);
     }
+    KMC_STAMP(3);
+#ifdef KMC_PROBE
+    if (lane == 0 && (tid >> 6) < 8192) for (int q = 0; q < 4; ++q) g_probe[a.half][tid >> 6][q] = stamp[q];
+#endif
 }
 
 template <class Dens, int L, int K, int ITER, bool P2P, bool RAGGED>
@@ -581,7 +618,7 @@ __global__ __launch_bounds__(256) void init_ball(const InitBallArgs a)
 #ifdef KMC_DEFINE_DRIVER_KERNELS   // non-template kernels: defined once, in kmc_api.hip
 __global__ void p2p_signal(const SignalArgs a)
 {
-    const SchedEntry sch = a.sched_table ? a.sched_table[a.sched_index] : a.sched_inline;
+    const SchedEntry sch = a.sched_index >= 0 ? a.sched_table[a.sched_index] : a.sched_inline;
     const unsigned long long done = 2ull * (unsigned long long)sch.gen + (unsigned long long)a.half + 1ull;
     __threadfence_system();
     if ((int)threadIdx.x < a.nranks)

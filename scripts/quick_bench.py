@@ -35,12 +35,7 @@ def main():
     for plan in plans:
         for mom in moms:
             eager = plan.endswith("e")           # "L,K,ITERe" = same geometry, eager launches (no hipGraph)
-            inl = plan.endswith("i")             # experiment: schedule inline in the graph's kernel nodes
-            pl = plan.rstrip("ei")
-            if inl:
-                os.environ["KMC_EXP_INLINE"] = "1"
-            else:
-                os.environ.pop("KMC_EXP_INLINE", None)
+            pl = plan.rstrip("e")
             if pl:
                 os.environ["KMC_PLAN"] = pl
             else:
