@@ -239,6 +239,54 @@ kmc_status  kmc_logpdf_eval(const kmc_config* cfg, const double* pos_dev, double
 /* Same on dense host rows [nrows][ndim] (allocates, copies, evaluates, copies back). */
 kmc_status  kmc_logpdf_eval_host(const kmc_config* cfg, const double* pos_host, double* logp_host, int64_t nrows);
 
+/* ---- many-chain Metropolis: metropolis / _metropolis, reference src/samplers.jl:59-128 ----
+ *
+ * The reference's `metropolis(pdf, sample_ppdf, theta0; niter, nburnin, nthin)` is one serial Markov
+ * chain; the device form runs `nchains` independent chains at once, one per lane, each the reference's
+ * loop (src/samplers.jl:96-126): propose theta1 = sample_ppdf(theta0), accept iff
+ * p1 - p0 > log(rand()) (strict, :101), store the current state every nthin-th step after burn-in
+ * (:108-116), count accepted steps after burn-in (:105, :122-125), accept_ratio = naccept /
+ * (niter - nburnin) (:127).  `niter`, `nburnin` count steps PER CHAIN, as in the reference.
+ * `sample_ppdf` is the symmetric Gaussian step of the reference's tests, theta + step .* randn(ndim)
+ * (test/runtests.jl:54,59,64,75), `pdf` a menu or runtime-compiled density.
+ * Random stream: Philox4x32-10, key {seed_lo ^ 0x4d455452, seed_hi}, counter {it_lo, it_hi, chain, block};
+ * block 0 = words (w0,w1) -> Box-Muller pair for dimensions 0,1 and (w2<<20 | w3>>12) -> the accept uniform;
+ * block b >= 1 = (w0,w1) -> dimensions 4b-2,4b-1 and (w2,w3) -> dimensions 4b,4b+1.  A chain's result is
+ * a pure function of (seed, chain index, inputs). */
+typedef struct kmc_metropolis_config {
+    int32_t  dtype;         /* KMC_F64 */
+    int32_t  density;       /* kmc_density (menu or KMC_USER_DENSITY) */
+    double   params[8];
+    int64_t  nchains;       /* independent chains (the reference: 1) */
+    int64_t  ndim;
+    int64_t  niter;         /* steps per chain                      src/samplers.jl:62 */
+    int64_t  nburnin;       /* discarded initial steps per chain    src/samplers.jl:63 */
+    int64_t  nthin;         /*                                      src/samplers.jl:64 */
+    const double* step;     /* host [ndim]: proposal scale per dimension (theta + step .* randn) */
+    uint64_t seed;
+    uint32_t flags;         /* KMC_STORE_CHAIN | KMC_STORE_LOGP | KMC_MOMENTS */
+    int32_t  device;
+    void*    user_density;  /* kmc_user_density* when density == KMC_USER_DENSITY */
+} kmc_metropolis_config;
+
+typedef struct kmc_metropolis_outputs {
+    double*  chain;         /* [nsamples][nchains][ndim]   thetas      (needs KMC_STORE_CHAIN)  :113 */
+    double*  chain_logp;    /* [nsamples][nchains]         logdensities (needs KMC_STORE_LOGP)  :115 */
+    double*  accept_ratio;  /* [nchains]                                                        :127 */
+    int64_t* naccept;       /* [nchains] */
+    double*  final_pos;     /* [nchains][ndim] */
+    double*  final_logp;    /* [nchains] */
+    double*  chain_sum;     /* [nchains][ndim] per-chain sum over the stored samples (needs KMC_MOMENTS) */
+    double*  chain_sumsq;   /* [nchains][ndim] */
+    int64_t  nsamples;      /* out: (niter - nburnin) / nthin   src/samplers.jl:88 */
+    double   device_ms;     /* out: the sampling kernels only (HIP events) */
+} kmc_metropolis_outputs;
+
+/* Argument sanity only (the reference asserts nothing for metropolis).  No device needed. */
+kmc_status  kmc_metropolis_validate(const kmc_metropolis_config* cfg);
+kmc_status  kmc_metropolis_run(const kmc_metropolis_config* cfg, const double* theta0 /* host [nchains][ndim] */,
+                               kmc_metropolis_outputs* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -33,7 +33,7 @@ SYMBOLS = [
     "kmc_sampler_launch_count", "kmc_sampler_describe", "kmc_sampler_device_ptr", "kmc_sampler_get_positions",
     "kmc_sampler_get_logp", "kmc_sampler_get_naccept", "kmc_sampler_get_accept_ratio",
     "kmc_sampler_get_moments", "kmc_sampler_get_chain", "kmc_logpdf_eval", "kmc_logpdf_eval_host",
-    "kmc_user_density_create", "kmc_user_density_destroy",
+    "kmc_user_density_create", "kmc_user_density_destroy", "kmc_metropolis_validate", "kmc_metropolis_run",
 ]
 
 
@@ -72,6 +72,39 @@ class Outputs(C.Structure):
         ("sum", C.POINTER(C.c_double)),
         ("sumsq", C.POINTER(C.c_double)),
         ("nmoment", C.c_int64),
+        ("nsamples", C.c_int64),
+        ("device_ms", C.c_double),
+    ]
+
+
+class MetropolisConfig(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int32),
+        ("density", C.c_int32),
+        ("params", C.c_double * 8),
+        ("nchains", C.c_int64),
+        ("ndim", C.c_int64),
+        ("niter", C.c_int64),
+        ("nburnin", C.c_int64),
+        ("nthin", C.c_int64),
+        ("step", C.POINTER(C.c_double)),
+        ("seed", C.c_uint64),
+        ("flags", C.c_uint32),
+        ("device", C.c_int32),
+        ("user_density", C.c_void_p),
+    ]
+
+
+class MetropolisOutputs(C.Structure):
+    _fields_ = [
+        ("chain", C.POINTER(C.c_double)),
+        ("chain_logp", C.POINTER(C.c_double)),
+        ("accept_ratio", C.POINTER(C.c_double)),
+        ("naccept", C.POINTER(C.c_int64)),
+        ("final_pos", C.POINTER(C.c_double)),
+        ("final_logp", C.POINTER(C.c_double)),
+        ("chain_sum", C.POINTER(C.c_double)),
+        ("chain_sumsq", C.POINTER(C.c_double)),
         ("nsamples", C.c_int64),
         ("device_ms", C.c_double),
     ]
@@ -154,6 +187,8 @@ def lib() -> C.CDLL:
     L.kmc_user_density_create.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(vp)]
     L.kmc_user_density_destroy.restype = None
     L.kmc_user_density_destroy.argtypes = [vp]
+    L.kmc_metropolis_validate.argtypes = [C.POINTER(MetropolisConfig)]
+    L.kmc_metropolis_run.argtypes = [C.POINTER(MetropolisConfig), dp, C.POINTER(MetropolisOutputs)]
     _lib = L
     return L
 

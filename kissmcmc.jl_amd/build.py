@@ -10,7 +10,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(_HERE, "libkissmcmc_hip.so")
 SOURCES = ["kmc_api.hip", "kmc_inst_gaussian_iso.hip", "kmc_inst_exponential.hip", "kmc_inst_rosenbrock.hip",
            "kmc_inst_lognormal.hip", "kmc_inst_mvnormal2.hip", "kmc_inst_host.hip"]
-HEADERS = ["kmc_device.hpp", "kmc_kernels.hpp", "kmc_islands.hpp", "kmc_tables.hpp", os.path.join("..", "..", "include", "kissmcmc_hip.h")]
+HEADERS = ["kmc_device.hpp", "kmc_kernels.hpp", "kmc_islands.hpp", "kmc_metropolis.hpp", "kmc_tables.hpp", os.path.join("..", "..", "include", "kissmcmc_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 

@@ -10,4 +10,5 @@ void table_exponential(int L, int K, int iter, bool p2p, bool ragged, HalfStepFn
 IslandFn island_exponential(int S, int K, bool ragged) { return island_lookup<Exponential>(S, K, ragged); }
 ResidentFn resident_exponential(int tpb, int K, bool ragged) { return resident_lookup<Exponential>(tpb, K, ragged); }
 InitBallFn init_ball_exponential() { return init_ball<Exponential>; }
+MetropolisFn metropolis_exponential(int ndim) { return metropolis_lookup<Exponential>(ndim); }
 }  // namespace kmc

@@ -10,6 +10,7 @@ void table_gaussian_iso(int L, int K, int iter, bool p2p, bool ragged, HalfStepF
 IslandFn island_gaussian_iso(int S, int K, bool ragged) { return island_lookup<GaussianIso>(S, K, ragged); }
 ResidentFn resident_gaussian_iso(int tpb, int K, bool ragged) { return resident_lookup<GaussianIso>(tpb, K, ragged); }
 InitBallFn init_ball_gaussian_iso() { return init_ball<GaussianIso>; }
+MetropolisFn metropolis_gaussian_iso(int ndim) { return metropolis_lookup<GaussianIso>(ndim); }
 }  // namespace kmc
 
 #ifdef KMC_PROBE   // diagnostic build only (scripts/probe_timeline.py)

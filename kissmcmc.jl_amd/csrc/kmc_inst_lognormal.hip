@@ -10,4 +10,5 @@ void table_lognormal(int L, int K, int iter, bool p2p, bool ragged, HalfStepFn* 
 IslandFn island_lognormal(int S, int K, bool ragged) { return island_lookup<LogNormal>(S, K, ragged); }
 ResidentFn resident_lognormal(int tpb, int K, bool ragged) { return resident_lookup<LogNormal>(tpb, K, ragged); }
 InitBallFn init_ball_lognormal() { return init_ball<LogNormal>; }
+MetropolisFn metropolis_lognormal(int ndim) { return metropolis_lookup<LogNormal>(ndim); }
 }  // namespace kmc

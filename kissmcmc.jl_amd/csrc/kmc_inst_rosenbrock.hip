@@ -10,4 +10,5 @@ void table_rosenbrock(int L, int K, int iter, bool p2p, bool ragged, HalfStepFn*
 IslandFn island_rosenbrock(int S, int K, bool ragged) { return island_lookup<Rosenbrock>(S, K, ragged); }
 ResidentFn resident_rosenbrock(int tpb, int K, bool ragged) { return resident_lookup<Rosenbrock>(tpb, K, ragged); }
 InitBallFn init_ball_rosenbrock() { return init_ball<Rosenbrock>; }
+MetropolisFn metropolis_rosenbrock(int ndim) { return metropolis_lookup<Rosenbrock>(ndim); }
 }  // namespace kmc

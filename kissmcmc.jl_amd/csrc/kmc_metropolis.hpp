@@ -1,0 +1,209 @@
+// kmc_metropolis.hpp -- many independent Metropolis chains, one chain per lane (gfx950).
+//
+// The reference's `metropolis` / `_metropolis` (src/samplers.jl:59-128) is one serial Markov chain:
+// nothing to parallelise inside it.  The data-parallel form is MANY chains at once -- every lane
+// runs the reference's loop (src/samplers.jl:96-126) on its own chain, state in registers, the whole
+// iteration range of a launch inside the kernel (chains never talk to each other, so there is no
+// join and no kernel boundary per step).  Same log-density menu as the emcee path (the Seq
+// interface: element by element in index order, so log-pdfs match a scalar CPU loop).
+//
+// Proposal: the symmetric Gaussian step every reference test uses, `theta -> c .* randn(n) .+ theta`
+// (test/runtests.jl:54,59,64,75), with one scale per dimension.
+//
+// Random stream (the build's contract; the reference never seeds): Philox4x32-10,
+//   key     = {seed_lo ^ 0x4d455452 ("METR"), seed_hi}
+//   counter = {it_lo, it_hi, chain, block}      it = 0-based iteration, chain = chain index
+//   block 0:  words w0,w1 -> normal pair for dimensions 0,1;  (w2 << 20 | w3 >> 12) -> the accept uniform
+//   block b>=1: words w0,w1 -> dimensions 4b-2, 4b-1;  w2,w3 -> dimensions 4b, 4b+1
+//   normal pair from words (a, b): u1 = (a + 1/2) 2^-32, u2 = (b + 1/2) 2^-32,
+//       r = sqrt(-2 log u1), n0 = r cos(2 pi u2), n1 = r sin(2 pi u2)           (Box-Muller)
+// A chain's result is a pure function of (seed, chain index, inputs): independent of launch geometry
+// and of how the iteration range is cut into launches.
+#pragma once
+#include "kmc_device.hpp"
+
+namespace kmc {
+
+struct MetropolisArgs {
+    double*       pos;         // [nchains][ndim] theta0 of every chain (in/out)
+    double*       logp;        // [nchains] p0
+    uint32_t*     naccept;     // [nchains] accepted steps with n > 0                  (:106, :124)
+    double*       chain;       // [nsamples][nchains][ndim] or nullptr                 (:117)
+    double*       chain_logp;  // [nsamples][nchains] or nullptr                       (:119)
+    double*       csum;        // [nchains][ndim] per-chain sum over the stored samples, or nullptr
+    double*       csumsq;
+    const double* step;        // [ndim] proposal scale per dimension
+    double*       scratch;     // any-ndim kernel: [nchains][ndim] proposal buffer
+    int64_t       nchains;
+    int64_t       it0, it1;    // iterations of this launch (0-based); reference n = it + 1 - nburnin (:96)
+    int64_t       nburnin, nthin, nsamples;
+    int64_t       cnt0;        // steps with n > 0 since the last stored sample, at it0
+    int64_t       slot0;       // samples stored before it0
+    int32_t       ndim;
+    uint32_t      seed_lo, seed_hi;
+    DensityParams dp;
+};
+
+__device__ __forceinline__ void normal_pair(uint32_t a, uint32_t b, double& n0, double& n1)
+{
+    const double u1 = ((double)a + 0.5) * 0x1.0p-32;
+    const double u2 = ((double)b + 0.5) * 0x1.0p-32;
+    const double r = sqrt(-2.0 * log(u1));
+    double sn, cs;
+    sincos(6.283185307179586476925286766559 * u2, &sn, &cs);
+    n0 = r * cs;
+    n1 = r * sn;
+}
+
+// ND > 0: ndim <= ND, the chain lives in registers.
+template <class Dens, int ND>
+__device__ __forceinline__ void metropolis_chains_body(const MetropolisArgs& a)
+{
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= a.nchains) return;
+    const int ndim = a.ndim;
+    double x[ND], y[ND], sc[ND], s1[ND], s2[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+        x[d]  = d < ndim ? a.pos[c * ndim + d] : 0.0;
+        sc[d] = d < ndim ? a.step[d] : 0.0;
+        s1[d] = (a.csum != nullptr && d < ndim) ? a.csum[c * ndim + d] : 0.0;
+        s2[d] = (a.csum != nullptr && d < ndim) ? a.csumsq[c * ndim + d] : 0.0;
+    }
+    double   p0  = a.logp[c];
+    uint32_t na  = a.naccept[c];
+    int64_t  cnt = a.cnt0, slot = a.slot0;
+    int64_t  n   = a.it0 + 1 - a.nburnin;                                    // :96
+    const uint32_t k0 = a.seed_lo ^ 0x4d455452u, k1 = a.seed_hi;
+    for (int64_t it = a.it0; it < a.it1; ++it, ++n) {
+        const U4 w = philox4x32_10((uint32_t)it, (uint32_t)((uint64_t)it >> 32), (uint32_t)c, 0u, k0, k1);
+        double nr[ND + 4];
+        normal_pair(w.x, w.y, nr[0], nr[1]);
+        if constexpr (ND > 2) {
+#pragma unroll
+            for (int b = 1; 4 * b - 2 < ND; ++b) {
+                if (4 * b - 2 < ndim) {
+                    const U4 v = philox4x32_10((uint32_t)it, (uint32_t)((uint64_t)it >> 32), (uint32_t)c, (uint32_t)b, k0, k1);
+                    normal_pair(v.x, v.y, nr[4 * b - 2], nr[4 * b - 1]);
+                    normal_pair(v.z, v.w, nr[4 * b], nr[4 * b + 1]);
+                }
+            }
+        }
+        typename Dens::Seq q;
+        Dens::seq_init(q);
+#pragma unroll
+        for (int d = 0; d < ND; ++d) {
+            if (d < ndim) {
+                y[d] = fma(sc[d], nr[d], x[d]);                              // :98  theta1 = sample_ppdf(theta0)
+                Dens::seq_add(q, y[d], d, a.dp);
+            }
+        }
+        const double p1 = Dens::seq_finish(q, ndim, a.dp);                   // :99
+        const uint64_t kk = ((uint64_t)w.z << 20) | (uint64_t)(w.w >> 12);
+        const double lu = log(((double)kk + 0.5) * 0x1.0p-52);
+        if (p1 - p0 > lu) {                                                  // :101, note the strict >
+#pragma unroll
+            for (int d = 0; d < ND; ++d) x[d] = y[d];                        // :102
+            p0 = p1;                                                         // :104
+            na += n > 0 ? 1u : 0u;                                           // :105; counters restart at n == 0 (:122-125)
+        }
+        if (n > 0) {                                                         // :108 rem(n, nthin) == 0, :112 n > 0
+            if (++cnt == a.nthin) {
+                cnt = 0;
+                if (slot < a.nsamples) {
+                    if (a.chain != nullptr) {
+#pragma unroll
+                        for (int d = 0; d < ND; ++d)
+                            if (d < ndim) a.chain[(slot * a.nchains + c) * ndim + d] = x[d];     // :113
+                    }
+                    if (a.chain_logp != nullptr) a.chain_logp[slot * a.nchains + c] = p0;        // :115
+#pragma unroll
+                    for (int d = 0; d < ND; ++d) { s1[d] += x[d]; s2[d] += x[d] * x[d]; }
+                }
+                ++slot;
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+        if (d < ndim) {
+            a.pos[c * ndim + d] = x[d];
+            if (a.csum != nullptr) { a.csum[c * ndim + d] = s1[d]; a.csumsq[c * ndim + d] = s2[d]; }
+        }
+    }
+    a.logp[c] = p0;
+    a.naccept[c] = na;
+}
+
+// Any ndim: the chain stays in memory, the proposal goes through a scratch row.
+template <class Dens>
+__device__ __forceinline__ void metropolis_chains_any_body(const MetropolisArgs& a)
+{
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= a.nchains) return;
+    const int ndim = a.ndim;
+    double* x = a.pos + c * ndim;
+    double* y = a.scratch + c * ndim;
+    double   p0  = a.logp[c];
+    uint32_t na  = a.naccept[c];
+    int64_t  cnt = a.cnt0, slot = a.slot0;
+    int64_t  n   = a.it0 + 1 - a.nburnin;
+    const uint32_t k0 = a.seed_lo ^ 0x4d455452u, k1 = a.seed_hi;
+    for (int64_t it = a.it0; it < a.it1; ++it, ++n) {
+        const U4 w = philox4x32_10((uint32_t)it, (uint32_t)((uint64_t)it >> 32), (uint32_t)c, 0u, k0, k1);
+        typename Dens::Seq q;
+        Dens::seq_init(q);
+        double n0, n1, n2 = 0.0, n3 = 0.0;
+        normal_pair(w.x, w.y, n0, n1);
+        for (int d = 0; d < ndim; ++d) {
+            double nd;
+            if (d < 2) nd = d == 0 ? n0 : n1;
+            else {
+                const int r = (d - 2) & 3;
+                if (r == 0) {
+                    const U4 v = philox4x32_10((uint32_t)it, (uint32_t)((uint64_t)it >> 32), (uint32_t)c,
+                                               (uint32_t)(1 + ((d - 2) >> 2)), k0, k1);
+                    normal_pair(v.x, v.y, n0, n1);
+                    normal_pair(v.z, v.w, n2, n3);
+                }
+                nd = r == 0 ? n0 : r == 1 ? n1 : r == 2 ? n2 : n3;
+            }
+            const double yd = fma(a.step[d], nd, x[d]);                      // :98
+            y[d] = yd;
+            Dens::seq_add(q, yd, d, a.dp);
+        }
+        const double p1 = Dens::seq_finish(q, ndim, a.dp);                   // :99
+        const uint64_t kk = ((uint64_t)w.z << 20) | (uint64_t)(w.w >> 12);
+        const double lu = log(((double)kk + 0.5) * 0x1.0p-52);
+        if (p1 - p0 > lu) {                                                  // :101
+            for (int d = 0; d < ndim; ++d) x[d] = y[d];
+            p0 = p1;
+            na += n > 0 ? 1u : 0u;
+        }
+        if (n > 0) {
+            if (++cnt == a.nthin) {
+                cnt = 0;
+                if (slot < a.nsamples) {
+                    for (int d = 0; d < ndim; ++d) {
+                        const double v = x[d];
+                        if (a.chain != nullptr) a.chain[(slot * a.nchains + c) * ndim + d] = v;
+                        if (a.csum != nullptr) { a.csum[c * ndim + d] += v; a.csumsq[c * ndim + d] += v * v; }
+                    }
+                    if (a.chain_logp != nullptr) a.chain_logp[slot * a.nchains + c] = p0;
+                }
+                ++slot;
+            }
+        }
+    }
+    a.logp[c] = p0;
+    a.naccept[c] = na;
+}
+
+template <class Dens, int ND>
+__global__ __launch_bounds__(256) void metropolis_chains(const MetropolisArgs a)
+{
+    if constexpr (ND > 0) metropolis_chains_body<Dens, ND>(a);
+    else metropolis_chains_any_body<Dens>(a);
+}
+
+}  // namespace kmc

@@ -3,6 +3,7 @@
 // sees the per-density entry points declared at the bottom.
 #pragma once
 #include "kmc_islands.hpp"
+#include "kmc_metropolis.hpp"
 
 namespace kmc {
 
@@ -12,6 +13,7 @@ using FlushFn = void (*)(const FlushArgs);
 using IslandFn = void (*)(const IslandArgs);
 using ResidentFn = void (*)(const ResidentArgs);
 using InitBallFn = void (*)(const InitBallArgs);
+using MetropolisFn = void (*)(const MetropolisArgs);
 
 #ifdef KMC_TABLES_IMPL
 template <class D, int L, int K, int ITER, bool P2P, bool RAGGED>
@@ -126,6 +128,17 @@ ResidentFn resident_lookup(int tpb, int K, bool ragged)
         }
     }
 }
+// many-chain Metropolis: the chain in registers up to 16 dimensions, in memory beyond
+template <class D>
+MetropolisFn metropolis_lookup(int ndim)
+{
+    if (ndim <= 1) return metropolis_chains<D, 1>;
+    if (ndim <= 2) return metropolis_chains<D, 2>;
+    if (ndim <= 4) return metropolis_chains<D, 4>;
+    if (ndim <= 8) return metropolis_chains<D, 8>;
+    if (ndim <= 16) return metropolis_chains<D, 16>;
+    return metropolis_chains<D, 0>;
+}
 #endif  // KMC_TABLES_IMPL
 
 // one entry point per density (defined in kmc_inst_<density>.hip)
@@ -140,17 +153,22 @@ HalfStepFn half_step_host();
 IslandFn island_gaussian_iso(int S, int K, bool ragged);
 ResidentFn resident_gaussian_iso(int tpb, int K, bool ragged);
 InitBallFn init_ball_gaussian_iso();
+MetropolisFn metropolis_gaussian_iso(int ndim);
 IslandFn island_exponential(int S, int K, bool ragged);
 ResidentFn resident_exponential(int tpb, int K, bool ragged);
 InitBallFn init_ball_exponential();
+MetropolisFn metropolis_exponential(int ndim);
 IslandFn island_rosenbrock(int S, int K, bool ragged);
 ResidentFn resident_rosenbrock(int tpb, int K, bool ragged);
 InitBallFn init_ball_rosenbrock();
+MetropolisFn metropolis_rosenbrock(int ndim);
 IslandFn island_lognormal(int S, int K, bool ragged);
 ResidentFn resident_lognormal(int tpb, int K, bool ragged);
 InitBallFn init_ball_lognormal();
+MetropolisFn metropolis_lognormal(int ndim);
 IslandFn island_mvnormal2(int S, int K, bool ragged);
 ResidentFn resident_mvnormal2(int tpb, int K, bool ragged);
 InitBallFn init_ball_mvnormal2();
+MetropolisFn metropolis_mvnormal2(int ndim);
 
 }  // namespace kmc

@@ -40,6 +40,20 @@ class Config(C.Structure):
     ]
 
 
+class MetropolisConfig(C.Structure):
+    _fields_ = [
+        ("density", C.c_int32),
+        ("nthreads", C.c_int32),
+        ("params", C.c_double * 8),
+        ("nchains", C.c_int64),
+        ("ndim", C.c_int64),
+        ("niter", C.c_int64),
+        ("nburnin", C.c_int64),
+        ("nthin", C.c_int64),
+        ("seed", C.c_uint64),
+    ]
+
+
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (``make -C oracle``)."""
     src = os.path.join(_HERE, "kmc_oracle.c")
@@ -79,6 +93,10 @@ def lib() -> C.CDLL:
         L.kmco_emcee_islands.argtypes = [C.POINTER(Config), C.c_int64, C.c_int64, dp, dp, C.POINTER(C.c_int64),
                                          dp, dp, dp, dp, C.POINTER(C.c_int64)]
         assert L.kmco_sizeof_config() == C.sizeof(Config)
+        L.kmco_metropolis_draw.restype = None
+        L.kmco_metropolis_draw.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int64, dp, dp]
+        L.kmco_metropolis.argtypes = [C.POINTER(MetropolisConfig), dp, dp, dp, dp, dp, C.POINTER(C.c_int64), dp, dp, dp, dp]
+        assert L.kmco_sizeof_metropolis_config() == C.sizeof(MetropolisConfig)
         _lib = L
     return _lib
 
@@ -201,3 +219,42 @@ def emcee_islands(cfg: Config, island_size, epoch_gens, theta0, moments=True):
                                       _dp(fpos), _dp(flogp), _dp(msum), _dp(msq), C.byref(nmom))
     return dict(status=st, accept_ratio=acc, naccept=nacc, final_pos=fpos, final_logp=flogp, sum=msum, sumsq=msq,
                 nmoment=nmom.value)
+
+
+def metropolis_draw(seed, it, chain, ndim):
+    """The ndim standard normals and the accept uniform of (iteration, chain)."""
+    nrm = np.zeros(ndim)
+    ua = C.c_double()
+    lib().kmco_metropolis_draw(int(seed), int(it), int(chain), int(ndim), _dp(nrm), C.byref(ua))
+    return nrm, ua.value
+
+
+def metropolis(density, params, theta0, step, niter, nburnin=None, nthin=1, seed=0, nthreads=1,
+               store_chain=True, moments=True):
+    """Many-chain Metropolis oracle (kmc_oracle.c: kmco_metropolis; reference src/samplers.jl:59-128 per chain).
+    ``theta0 [nchains, ndim]``, ``step`` scalar or ``[ndim]``; ``niter``/``nburnin`` are steps per chain."""
+    theta0 = np.ascontiguousarray(np.asarray(theta0, dtype=np.float64))
+    nc, nd = theta0.shape
+    if nburnin is None:
+        nburnin = niter // 2                                       # src/samplers.jl:63
+    c = MetropolisConfig()
+    c.density, c.nthreads = int(density), int(nthreads)
+    p = list(params) + [0.0] * (8 - len(params))
+    for i in range(8):
+        c.params[i] = float(p[i])
+    c.nchains, c.ndim, c.niter, c.nburnin, c.nthin, c.seed = nc, nd, int(niter), int(nburnin), int(nthin), int(seed)
+    step = np.ascontiguousarray(np.broadcast_to(np.asarray(step, dtype=np.float64), (nd,)))
+    ns = max(0, (niter - nburnin) // nthin)
+    chain = np.zeros((ns, nc, nd)) if store_chain else None
+    chain_logp = np.zeros((ns, nc)) if store_chain else None
+    acc = np.zeros(nc)
+    nacc = np.zeros(nc, dtype=np.int64)
+    fpos = np.zeros((nc, nd))
+    flogp = np.zeros(nc)
+    csum = np.zeros((nc, nd)) if moments else None
+    csq = np.zeros((nc, nd)) if moments else None
+    with np.errstate(all="ignore"):
+        st = lib().kmco_metropolis(C.byref(c), _dp(theta0), _dp(step), _dp(chain), _dp(chain_logp), _dp(acc), _ip(nacc),
+                                   _dp(fpos), _dp(flogp), _dp(csum), _dp(csq))
+    return dict(status=st, chain=chain, chain_logp=chain_logp, accept_ratio=acc, naccept=nacc, final_pos=fpos,
+                final_logp=flogp, chain_sum=csum, chain_sumsq=csq, nsamples=ns)

@@ -461,3 +461,125 @@ KMCO_API int kmco_emcee_islands(const kmco_config* c, int64_t S, int64_t epoch_g
     free(pos); free(logp); free(nacc);
     return KMCO_OK;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * MANY-CHAIN METROPOLIS: metropolis / _metropolis, src/samplers.jl:59-128, restated for `nchains`
+ * independent chains (the reference runs one; chain c here is exactly one run of the reference's
+ * loop with its own random stream).
+ *
+ * Proposal (the reference takes any symmetric `sample_ppdf`; its tests all use this one,
+ * test/runtests.jl:54,59,64,75):  theta1 = theta0 .+ step .* randn(ndim).
+ *
+ * Random stream (the build's contract, restated independently of the product code):
+ * Philox4x32-10, key = {seed_lo ^ 0x4d455452, seed_hi}, counter = {it_lo, it_hi, chain, block},
+ * it = 0-based iteration.  Block 0: words (w0,w1) -> Box-Muller pair for dimensions 0,1;
+ * ((w2 << 20) | (w3 >> 12) + 1/2) 2^-52 -> the accept uniform.  Block b >= 1: (w0,w1) -> dimensions
+ * 4b-2, 4b-1; (w2,w3) -> dimensions 4b, 4b+1.  Pair from words (a,b): u1 = (a+1/2) 2^-32,
+ * u2 = (b+1/2) 2^-32, r = sqrt(-2 log u1), n0 = r cos(2 pi u2), n1 = r sin(2 pi u2).
+ * log/sin/cos come from the platform libm, so device and host agree to rounding, not bit for bit.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t  density;
+    int32_t  nthreads;      /* OpenMP threads over the chains; <=1: serial */
+    double   params[8];
+    int64_t  nchains;
+    int64_t  ndim;
+    int64_t  niter;         /* src/samplers.jl:62 */
+    int64_t  nburnin;       /* src/samplers.jl:63 */
+    int64_t  nthin;         /* src/samplers.jl:64 */
+    uint64_t seed;
+} kmco_metropolis_config;
+
+static void kmco_normal_pair(uint32_t a, uint32_t b, double* n0, double* n1)
+{
+    const double u1 = ((double)a + 0.5) * 0x1.0p-32;
+    const double u2 = ((double)b + 0.5) * 0x1.0p-32;
+    const double r = sqrt(-2.0 * log(u1));
+    const double ang = 6.283185307179586476925286766559 * u2;
+    *n0 = r * cos(ang);
+    *n1 = r * sin(ang);
+}
+
+/* the ndim standard normals and the accept uniform of (iteration it, chain) */
+KMCO_API void kmco_metropolis_draw(uint64_t seed, uint64_t it, uint64_t chain, int64_t ndim, double* normals, double* u_acc)
+{
+    const uint32_t key[2] = {(uint32_t)seed ^ 0x4d455452u, (uint32_t)(seed >> 32)};
+    uint32_t ctr[4] = {(uint32_t)it, (uint32_t)(it >> 32), (uint32_t)chain, 0u};
+    uint32_t w[4];
+    kmco_philox4x32_10(ctr, key, w);
+    const uint64_t k = ((uint64_t)w[2] << 20) | (uint64_t)(w[3] >> 12);
+    *u_acc = ((double)k + 0.5) * 0x1.0p-52;
+    double n0, n1;
+    kmco_normal_pair(w[0], w[1], &n0, &n1);
+    if (ndim > 0) normals[0] = n0;
+    if (ndim > 1) normals[1] = n1;
+    for (int64_t b = 1; 4 * b - 2 < ndim; ++b) {
+        ctr[3] = (uint32_t)b;
+        kmco_philox4x32_10(ctr, key, w);
+        double m[4];
+        kmco_normal_pair(w[0], w[1], &m[0], &m[1]);
+        kmco_normal_pair(w[2], w[3], &m[2], &m[3]);
+        for (int q = 0; q < 4; ++q)
+            if (4 * b - 2 + q < ndim) normals[4 * b - 2 + q] = m[q];
+    }
+}
+
+/* Outputs (any may be NULL): chain [nsamples][nchains][ndim] (thetas, :113), chain_logp [nsamples][nchains]
+ * (logdensities, :115), accept_ratio [nchains] (:127), naccept [nchains], final_pos, final_logp, chain_sum /
+ * chain_sumsq [nchains][ndim] (per-chain sums over the stored samples).  nsamples = (niter - nburnin) / nthin (:88). */
+KMCO_API int kmco_metropolis(const kmco_metropolis_config* c, const double* theta0, const double* step,
+                             double* chain, double* chain_logp, double* accept_ratio, int64_t* naccept_out,
+                             double* final_pos, double* final_logp, double* chain_sum, double* chain_sumsq)
+{
+    if (!c || !theta0 || !step || c->nchains <= 0 || c->ndim <= 0 || c->nthin <= 0 || c->niter < 0 || c->nburnin < 0)
+        return KMCO_ERR_BAD_ARG;
+    if (c->density == KMCO_ROSENBROCK && c->ndim < 2) return KMCO_ERR_BAD_ARG;
+    if (c->density == KMCO_MVNORMAL2 && c->ndim != 2) return KMCO_ERR_BAD_ARG;
+    const int64_t nc = c->nchains, nd = c->ndim;
+    const int64_t nsamples = c->niter > c->nburnin ? (c->niter - c->nburnin) / c->nthin : 0;   /* :88 */
+
+#pragma omp parallel for schedule(static) num_threads(c->nthreads > 1 ? c->nthreads : 1)
+    for (int64_t ch = 0; ch < nc; ++ch) {
+        double* th0 = (double*)malloc(sizeof(double) * (size_t)nd * 3);
+        double* th1 = th0 + nd;
+        double* nrm = th1 + nd;
+        memcpy(th0, theta0 + ch * nd, sizeof(double) * (size_t)nd);                 /* :68 deepcopy */
+        double p0 = kmco_logpdf(c->density, c->params, th0, nd);                     /* :70 */
+        int64_t naccept = 0;                                                         /* :94 */
+        int64_t k = 0;
+        if (chain_sum) for (int64_t d = 0; d < nd; ++d) chain_sum[ch * nd + d] = 0.0;
+        if (chain_sumsq) for (int64_t d = 0; d < nd; ++d) chain_sumsq[ch * nd + d] = 0.0;
+        for (int64_t n = 1 - c->nburnin; n <= c->niter - c->nburnin; ++n) {         /* :96 */
+            const uint64_t it = (uint64_t)(n + c->nburnin - 1);
+            double ua;
+            kmco_metropolis_draw(c->seed, it, (uint64_t)ch, nd, nrm, &ua);
+            for (int64_t d = 0; d < nd; ++d) th1[d] = fma(step[d], nrm[d], th0[d]);  /* :98 theta1 = sample_ppdf(theta0) */
+            const double p1 = kmco_logpdf(c->density, c->params, th1, nd);          /* :99 */
+            if (p1 - p0 > log(ua)) {                                                 /* :101 strict > */
+                memcpy(th0, th1, sizeof(double) * (size_t)nd);                      /* :102 */
+                p0 = p1;                                                             /* :104 */
+                naccept += 1;                                                        /* :105 */
+            }
+            if (n % c->nthin == 0) {                                                 /* :108 rem(n, nthin) == 0 */
+                if (n > 0 && k < nsamples) {                                         /* :112 after burn-in */
+                    if (chain) memcpy(chain + (k * nc + ch) * nd, th0, sizeof(double) * (size_t)nd);   /* :113 */
+                    if (chain_logp) chain_logp[k * nc + ch] = p0;                    /* :115 */
+                    for (int64_t d = 0; d < nd; ++d) {
+                        if (chain_sum) chain_sum[ch * nd + d] += th0[d];
+                        if (chain_sumsq) chain_sumsq[ch * nd + d] += th0[d] * th0[d];
+                    }
+                    ++k;
+                }
+            }
+            if (n == 0) naccept = 0;                                                 /* :122-125 */
+        }
+        if (accept_ratio) accept_ratio[ch] = (double)naccept / (double)(c->niter - c->nburnin);   /* :127 */
+        if (naccept_out) naccept_out[ch] = naccept;
+        if (final_pos) memcpy(final_pos + ch * nd, th0, sizeof(double) * (size_t)nd);
+        if (final_logp) final_logp[ch] = p0;
+        free(th0);
+    }
+    return KMCO_OK;
+}
+
+KMCO_API int kmco_sizeof_metropolis_config(void) { return (int)sizeof(kmco_metropolis_config); }

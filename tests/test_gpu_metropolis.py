@@ -1,0 +1,118 @@
+"""GPU leg of the many-chain Metropolis path (reference src/samplers.jl:59-128): the HIP kernel through the
+C ABI against the oracle and the committed golden fixtures.  Tolerance (written here, as the path is floating
+point with libm calls): accept decisions and counters identical; states, chains and sums within 1e-11
+(device log/sin/cos vs glibc differ by <= 1 ulp in the Box-Muller normals), log-pdfs within 1e-10."""
+import numpy as np
+import pytest
+
+import refcases
+from test_metropolis_cpu import compare_golden, golden_names, load_golden
+
+pytestmark = pytest.mark.gpu
+
+_DENS = {0: lambda k, p: k.GaussianIso(p[0], p[1]), 1: lambda k, p: k.Exponential(p[0]),
+         2: lambda k, p: k.Rosenbrock(p[0], p[1], p[2]), 3: lambda k, p: k.LogNormal(p[0], p[1])}
+
+
+def _pdf(kmc, z):
+    if z["density"] == 4:
+        P = np.array([[z["params"][2], z["params"][3]], [z["params"][3], z["params"][4]]])
+        pdf = kmc.MvNormal2(z["params"][:2], np.linalg.inv(P))
+        raw = [float(v) for v in z["params"][:5]]
+        pdf.params = lambda: raw          # the fixture's precision matrix verbatim, not inv(inv(P))
+        return pdf
+    return _DENS[z["density"]](kmc, z["params"])
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_kernel_reproduces_metropolis_golden(kmc, name):
+    from kissmcmc_jl_amd.metropolis import run_chains
+    z = load_golden(name)
+    r = run_chains(_pdf(kmc, z), kmc.GaussianStep(z["step"]), z["theta0"], z["niter"], z["nburnin"], z["nthin"], z["seed"],
+                   moments=True)
+    compare_golden(z, r, exact=False)
+    np.testing.assert_array_equal(r["accept_ratio"], r["naccept"] / (z["niter"] - z["nburnin"]))    # samplers.jl:127
+
+
+@pytest.mark.parametrize("ndim", [1, 2, 3, 5, 8, 13, 16, 17, 40])
+def test_every_register_geometry_equals_the_oracle(kmc, oracle, ndim):
+    """ndim 1..16 run in registers (5 kernel geometries), beyond that from memory; odd sizes mask the tail."""
+    from kissmcmc_jl_amd.metropolis import run_chains
+    nc, niter, nburn, nthin, seed = 777, 70, 21, 3, 100 + ndim          # a ragged last workgroup
+    th = 0.3 * np.random.default_rng(ndim).standard_normal((nc, ndim))
+    step = np.linspace(0.2, 0.6, ndim)
+    r = run_chains(kmc.GaussianIso(0.1, 1.3), kmc.GaussianStep(step), th, niter, nburn, nthin, seed, moments=True)
+    ref = oracle.metropolis(oracle.GAUSSIAN_ISO, [0.1, 1.3], th, step, niter, nburn, nthin, seed)
+    np.testing.assert_array_equal(r["naccept"], ref["naccept"])
+    np.testing.assert_allclose(r["chain"], ref["chain"], rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(r["chain_logp"], ref["chain_logp"], rtol=1e-10, atol=1e-10)
+    np.testing.assert_allclose(r["final_pos"], ref["final_pos"], rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(r["chain_sum"], ref["chain_sum"], rtol=1e-10, atol=1e-10)
+    np.testing.assert_allclose(r["chain_sumsq"], ref["chain_sumsq"], rtol=1e-10, atol=1e-10)
+
+
+def test_long_run_is_cut_into_launches_without_a_seam(kmc, oracle):
+    """More iterations than one launch carries (65 536): thinning phase, sample slots and counters continue."""
+    from kissmcmc_jl_amd.metropolis import run_chains
+    nc, niter, nburn, nthin = 64, 140001, 30000, 7
+    th = np.random.default_rng(5).standard_normal((nc, 2))
+    pdf = kmc.Rosenbrock()
+    r = run_chains(pdf, kmc.GaussianStep(0.5), th, niter, nburn, nthin, 77, moments=True)
+    ref = oracle.metropolis(oracle.ROSENBROCK, [1.0, 100.0, 20.0], th, 0.5, niter, nburn, nthin, 77, nthreads=8)
+    assert r["chain"].shape == ((niter - nburn) // nthin, nc, 2)
+    np.testing.assert_array_equal(r["naccept"], ref["naccept"])
+    np.testing.assert_allclose(r["chain"], ref["chain"], rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize("case", [c for c in refcases.CASES if c["niter"] <= 10 ** 5], ids=lambda c: c["name"])
+def test_reference_metropolis_cases_drop_in(kmc, case):
+    """reference test/metro.jl:2-21 through the reference's own signature (one chain = one lane)."""
+    if case["dens"] == "gauss":
+        pdf = kmc.GaussianIso(*case["params"])
+    else:
+        pdf = kmc.MvNormal2(case["params"]["mean"], case["params"]["cov"])
+    thetas, accept_ratio, logdensities, blobs = kmc.metropolis(pdf, kmc.GaussianStep(case["mstep"]), case["theta0"],
+                                                               niter=case["niter"], use_progress_meter=False, seed=31)
+    assert blobs is None                                                    # metro.jl:12
+    assert len(thetas) == case["niter"] // 2                                # metro.jl:13
+    assert len(logdensities) == case["niter"] // 2                          # metro.jl:14
+    assert 0.15 < accept_ratio < 0.45                                       # metro.jl:15
+    refcases.check_mean_std(thetas, case, case["tolm"])                     # metro.jl:16
+    assert thetas.shape == ((case["niter"] // 2,) if np.ndim(case["theta0"]) == 0 else (case["niter"] // 2, 2))
+
+
+def test_many_chains_recover_the_slow_reference_cases(kmc):
+    """The reference needs niter = 10^7 on ONE chain for LogNormal and Rosenbrock (test/runtests.jl:57-61, :68-79);
+    4096 chains x 20 000 steps give the same statistics (reference tolerances) from one launch."""
+    cases = {c["name"]: c for c in refcases.CASES}
+    c = cases["lognormal(0,1)"]
+    th, acc, logd, _ = kmc.metropolis_chains(kmc.LogNormal(0.0, 1.0), kmc.GaussianStep(c["mstep"]), np.full(4096, c["theta0"]),
+                                             niter=20000, nthin=10, seed=5)
+    assert th.shape == (4096, 1000) and logd.shape == (4096, 1000)
+    assert 0.15 < acc.mean() < 0.45
+    flat, accm, l, _ = kmc.squash_walkers(th, acc, logd)
+    assert flat.shape == (4096 * 1000,)
+    refcases.check_mean_std(flat, c, c["tolm"])
+    c = cases["rosenbrock2"]
+    th, acc, logd, _ = kmc.metropolis_chains(kmc.Rosenbrock(), kmc.GaussianStep(c["mstep"]), np.zeros((4096, 2)),
+                                             niter=20000, nthin=10, seed=6)
+    assert 0.15 < acc.mean() < 0.45
+    refcases.check_mean_std(th.reshape(-1, 2), c, c["tolm"])
+
+
+def test_user_density_runs_in_the_metropolis_kernel(kmc, oracle):
+    """Runtime-compiled log-density (hiprtc) in the many-chain kernel = the menu Gaussian, bit for bit."""
+    from kissmcmc_jl_amd.metropolis import run_chains
+    th = np.random.default_rng(1).standard_normal((500, 3))
+    user = kmc.ExprDensity("-0.5 * ((x - p[0]) * p[1]) * ((x - p[0]) * p[1])", params=[0.2, 1.0 / 1.5])
+    a = run_chains(user, kmc.GaussianStep(0.8), th, 60, 20, 1, 9)
+    b = run_chains(kmc.GaussianIso(0.2, 1.5), kmc.GaussianStep(0.8), th, 60, 20, 1, 9)
+    np.testing.assert_array_equal(a["naccept"], b["naccept"])
+    np.testing.assert_allclose(a["chain"], b["chain"], rtol=1e-12, atol=1e-12)
+
+
+def test_minus_inf_start_is_carried_like_the_reference(kmc):
+    """The reference's metropolis does not require pdf(theta0) > -Inf (src/samplers.jl:70): the first finite proposal
+    is accepted (p1 - (-Inf) = Inf > log u)."""
+    th, acc, logd, _ = kmc.metropolis_chains(kmc.Exponential(), kmc.GaussianStep(2.0), np.full(64, -1.0), niter=400, nburnin=0, seed=2)
+    assert np.all(th[:, -1] >= 0.0) and np.all(np.isfinite(logd[:, -1]))
