@@ -1671,14 +1671,15 @@ kmc_status compile_user_metropolis(kmc_user_density* ud, int ND, const std::vect
 // device buffers of one kmc_metropolis_run call
 struct MetroBuffers {
     double *pos = nullptr, *logp = nullptr, *chain = nullptr, *chain_logp = nullptr, *csum = nullptr, *csumsq = nullptr,
-           *step = nullptr, *scratch = nullptr;
+           *step = nullptr, *xt = nullptr, *yt = nullptr, *st1 = nullptr, *st2 = nullptr;
     uint32_t* naccept = nullptr;
     hipModule_t mod = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     ~MetroBuffers()
     {
         (void)hipFree(pos); (void)hipFree(logp); (void)hipFree(chain); (void)hipFree(chain_logp); (void)hipFree(csum);
-        (void)hipFree(csumsq); (void)hipFree(step); (void)hipFree(scratch); (void)hipFree(naccept);
+        (void)hipFree(csumsq); (void)hipFree(step); (void)hipFree(xt); (void)hipFree(yt); (void)hipFree(st1); (void)hipFree(st2);
+        (void)hipFree(naccept);
         if (mod) (void)hipModuleUnload(mod);
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
@@ -1760,7 +1761,16 @@ KMC_EXPORT kmc_status kmc_metropolis_run(const kmc_metropolis_config* c, const d
         HIP_TRY(hipMemset(b.csumsq, 0, rows));
     }
     const int ND = metropolis_nd(nd);
-    if (ND == 0) HIP_TRY(hipMalloc(&b.scratch, rows));
+    if (ND == 0) {      // chains too long for registers: state kept dimension-major in memory
+        HIP_TRY(hipMalloc(&b.xt, rows));
+        HIP_TRY(hipMalloc(&b.yt, rows));
+        if (want_mom) {
+            HIP_TRY(hipMalloc(&b.st1, rows));
+            HIP_TRY(hipMalloc(&b.st2, rows));
+            HIP_TRY(hipMemset(b.st1, 0, rows));
+            HIP_TRY(hipMemset(b.st2, 0, rows));
+        }
+    }
 
     MetropolisFn fn = nullptr;
     hipFunction_t ufn = nullptr, ulp = nullptr;
@@ -1787,6 +1797,13 @@ KMC_EXPORT kmc_status kmc_metropolis_run(const kmc_metropolis_config* c, const d
         HIP_TRY(hipGetLastError());
     }
 
+    auto transpose = [&](const double* src, double* dst, bool to_dim_major) {
+        const TransposeArgs ta{src, dst, nc, (int32_t)nd, to_dim_major ? 1 : 0};
+        hipLaunchKernelGGL(metropolis_transpose, dim3(grid), dim3(256), 0, nullptr, ta);
+        return hipGetLastError();
+    };
+    if (ND == 0) HIP_TRY(transpose(b.pos, b.xt, true));
+
     HIP_TRY(hipEventCreate(&b.ev0));
     HIP_TRY(hipEventCreate(&b.ev1));
     HIP_TRY(hipEventRecord(b.ev0, nullptr));
@@ -1795,7 +1812,7 @@ KMC_EXPORT kmc_status kmc_metropolis_run(const kmc_metropolis_config* c, const d
         MetropolisArgs a{};
         a.pos = b.pos; a.logp = b.logp; a.naccept = b.naccept;
         a.chain = b.chain; a.chain_logp = b.chain_logp; a.csum = b.csum; a.csumsq = b.csumsq;
-        a.step = b.step; a.scratch = b.scratch;
+        a.step = b.step; a.xt = b.xt; a.yt = b.yt; a.st1 = b.st1; a.st2 = b.st2;
         a.nchains = nc;
         a.it0 = it0; a.it1 = std::min<int64_t>(c->niter, it0 + kItersPerLaunch);
         a.nburnin = c->nburnin; a.nthin = c->nthin; a.nsamples = nsamples;
@@ -1812,7 +1829,12 @@ KMC_EXPORT kmc_status kmc_metropolis_run(const kmc_metropolis_config* c, const d
         }
     }
     HIP_TRY(hipEventRecord(b.ev1, nullptr));
+    if (ND == 0) {
+        HIP_TRY(transpose(b.xt, b.pos, false));
+        if (want_mom) { HIP_TRY(transpose(b.st1, b.csum, false)); HIP_TRY(transpose(b.st2, b.csumsq, false)); }
+    }
     HIP_TRY(hipEventSynchronize(b.ev1));
+    HIP_TRY(hipDeviceSynchronize());
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, b.ev0, b.ev1));
     out->device_ms = (double)ms;

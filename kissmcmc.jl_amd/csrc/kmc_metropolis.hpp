@@ -33,7 +33,10 @@ struct MetropolisArgs {
     double*       csum;        // [nchains][ndim] per-chain sum over the stored samples, or nullptr
     double*       csumsq;
     const double* step;        // [ndim] proposal scale per dimension
-    double*       scratch;     // any-ndim kernel: [nchains][ndim] proposal buffer
+    double*       xt;          // any-ndim kernel: the chains' state, DIMENSION-major [ndim][nchains] (coalesced over lanes)
+    double*       yt;          // any-ndim kernel: the proposals, [ndim][nchains]
+    double*       st1;         // any-ndim kernel: per-chain sums, [ndim][nchains], or nullptr
+    double*       st2;
     int64_t       nchains;
     int64_t       it0, it1;    // iterations of this launch (0-based); reference n = it + 1 - nburnin (:96)
     int64_t       nburnin, nthin, nsamples;
@@ -135,15 +138,18 @@ __device__ __forceinline__ void metropolis_chains_body(const MetropolisArgs& a)
     a.naccept[c] = na;
 }
 
-// Any ndim: the chain stays in memory, the proposal goes through a scratch row.
+// Any ndim: the chain stays in memory, dimension-major ([ndim][nchains]) so that the 64 chains of a wave
+// read and write consecutive doubles; pos / csum (chain-major, the C ABI's layout) are converted by
+// metropolis_transpose before the first and after the last launch.
 template <class Dens>
 __device__ __forceinline__ void metropolis_chains_any_body(const MetropolisArgs& a)
 {
     const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (c >= a.nchains) return;
     const int ndim = a.ndim;
-    double* x = a.pos + c * ndim;
-    double* y = a.scratch + c * ndim;
+    const int64_t nc = a.nchains;
+    double* x = a.xt + c;
+    double* y = a.yt + c;
     double   p0  = a.logp[c];
     uint32_t na  = a.naccept[c];
     int64_t  cnt = a.cnt0, slot = a.slot0;
@@ -168,29 +174,35 @@ __device__ __forceinline__ void metropolis_chains_any_body(const MetropolisArgs&
                 }
                 nd = r == 0 ? n0 : r == 1 ? n1 : r == 2 ? n2 : n3;
             }
-            const double yd = fma(a.step[d], nd, x[d]);                      // :98
-            y[d] = yd;
+            const double yd = fma(a.step[d], nd, x[(int64_t)d * nc]);        // :98
+            y[(int64_t)d * nc] = yd;
             Dens::seq_add(q, yd, d, a.dp);
         }
         const double p1 = Dens::seq_finish(q, ndim, a.dp);                   // :99
         const uint64_t kk = ((uint64_t)w.z << 20) | (uint64_t)(w.w >> 12);
         const double lu = log(((double)kk + 0.5) * 0x1.0p-52);
-        if (p1 - p0 > lu) {                                                  // :101
-            for (int d = 0; d < ndim; ++d) x[d] = y[d];
+        const bool acc = p1 - p0 > lu;                                       // :101
+        if (acc) {
             p0 = p1;
             na += n > 0 ? 1u : 0u;
         }
-        if (n > 0) {
-            if (++cnt == a.nthin) {
-                cnt = 0;
-                if (slot < a.nsamples) {
-                    for (int d = 0; d < ndim; ++d) {
-                        const double v = x[d];
-                        if (a.chain != nullptr) a.chain[(slot * a.nchains + c) * ndim + d] = v;
-                        if (a.csum != nullptr) { a.csum[c * ndim + d] += v; a.csumsq[c * ndim + d] += v * v; }
-                    }
-                    if (a.chain_logp != nullptr) a.chain_logp[slot * a.nchains + c] = p0;
+        bool store = false;
+        if (n > 0 && ++cnt == a.nthin) {
+            cnt = 0;
+            store = slot < a.nsamples;
+            if (!store) ++slot;
+        }
+        if (acc || store) {
+            for (int d = 0; d < ndim; ++d) {
+                const double v = acc ? y[(int64_t)d * nc] : x[(int64_t)d * nc];
+                if (acc) x[(int64_t)d * nc] = v;                             // :102
+                if (store) {
+                    if (a.chain != nullptr) a.chain[(slot * nc + c) * ndim + d] = v;             // :113
+                    if (a.st1 != nullptr) { a.st1[(int64_t)d * nc + c] += v; a.st2[(int64_t)d * nc + c] += v * v; }
                 }
+            }
+            if (store) {
+                if (a.chain_logp != nullptr) a.chain_logp[slot * nc + c] = p0;                   // :115
                 ++slot;
             }
         }
@@ -199,11 +211,32 @@ __device__ __forceinline__ void metropolis_chains_any_body(const MetropolisArgs&
     a.naccept[c] = na;
 }
 
+// chain-major [nchains][ndim] <-> dimension-major [ndim][nchains] (once per run, either side of the launches)
+struct TransposeArgs {
+    const double* src;
+    double*       dst;
+    int64_t       nchains;
+    int32_t       ndim;
+    int32_t       to_dim_major;
+};
+
 template <class Dens, int ND>
 __global__ __launch_bounds__(256) void metropolis_chains(const MetropolisArgs a)
 {
     if constexpr (ND > 0) metropolis_chains_body<Dens, ND>(a);
     else metropolis_chains_any_body<Dens>(a);
 }
+
+#ifdef KMC_DEFINE_DRIVER_KERNELS
+__global__ __launch_bounds__(256) void metropolis_transpose(const TransposeArgs a)
+{
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= a.nchains) return;
+    for (int d = 0; d < a.ndim; ++d) {
+        if (a.to_dim_major) a.dst[(int64_t)d * a.nchains + c] = a.src[c * a.ndim + d];
+        else a.dst[c * a.ndim + d] = a.src[(int64_t)d * a.nchains + c];
+    }
+}
+#endif
 
 }  // namespace kmc
