@@ -11,7 +11,7 @@
 # 1:1 by the Python ctypes host (kissmcmc.jl_amd/_lib.py, api.py), which is what the tests drive.
 module KissMCMCHIP
 
-export emcee, make_theta0s, squash_walkers, GaussianIso, Exponential, Rosenbrock, LogNormal, MvNormal2, ExprDensity, HostLogPdf
+export emcee, make_theta0s, squash_walkers, metropolis, metropolis_chains, GaussianStep, GaussianIso, Exponential, Rosenbrock, LogNormal, MvNormal2, ExprDensity, HostLogPdf
 
 using Statistics: mean, median, std
 using LinearAlgebra: inv
@@ -151,6 +151,72 @@ function emcee(pdf::DeviceLogPdf, theta0s; niter=10^5, nburnin=niter ÷ 2, nthin
     return thetas, acc, logdensities, nothing                                            # :292
 end
 emcee(pdf, theta0s; kw...) = emcee(HostLogPdf(pdf), theta0s; kw...)     # arbitrary closure: evaluated on the host
+
+# ---- many-chain Metropolis: metropolis / _metropolis, src/samplers.jl:59-128 ---------------------
+"Symmetric proposal `theta -> scale .* randn(n) .+ theta` (the one all reference tests use, test/runtests.jl:54,59,64,75)."
+struct GaussianStep; scale::Vector{Float64}; end
+GaussianStep(c::Real) = GaussianStep([Float64(c)])
+
+struct KmcMetropolisConfig
+    dtype::Int32; density::Int32
+    params::NTuple{8,Float64}
+    nchains::Int64; ndim::Int64; niter::Int64; nburnin::Int64; nthin::Int64
+    step::Ptr{Float64}; seed::UInt64
+    flags::UInt32; device::Int32
+    user_density::Ptr{Cvoid}
+end
+
+mutable struct KmcMetropolisOutputs
+    chain::Ptr{Float64}; chain_logp::Ptr{Float64}; accept_ratio::Ptr{Float64}; naccept::Ptr{Int64}
+    final_pos::Ptr{Float64}; final_logp::Ptr{Float64}; chain_sum::Ptr{Float64}; chain_sumsq::Ptr{Float64}
+    nsamples::Int64; device_ms::Float64
+end
+
+"""
+    metropolis_chains(pdf::DeviceLogPdf, sample_ppdf::GaussianStep, theta0s; niter=10^5, nburnin=niter÷2, nthin=1, seed, device)
+
+One independent Metropolis chain (src/samplers.jl:96-126) per element of `theta0s`, one chain per GPU lane;
+`niter`/`nburnin` count steps per chain.  Returns `(thetas, accept_ratio, logdensities, nothing)` shaped like
+`emcee`'s output (`thetas[chain][sample]`), so `squash_walkers` applies.
+"""
+function metropolis_chains(pdf::DeviceLogPdf, sample_ppdf::GaussianStep, theta0s; niter=10^5, nburnin=niter ÷ 2, nthin=1,
+                           hasblob=false, seed=rand(UInt64), device=0)
+    hasblob && error("hasblob=true is not supported by the HIP samplers")
+    pdf isa HostLogPdf && error("the many-chain Metropolis kernel needs a device log-density (menu or ExprDensity)")
+    nchains = length(theta0s); scalar = theta0s[1] isa Number; ndim = length(theta0s[1])
+    nsamples = niter > nburnin ? (niter - nburnin) ÷ nthin : 0                            # :88
+    theta = Matrix{Float64}(undef, ndim, nchains)          # column-major [dim, chain] == C row-major [chain][dim]
+    for c in 1:nchains, d in 1:ndim
+        theta[d, c] = scalar ? theta0s[c] : theta0s[c][d]                                # :68 deep copy
+    end
+    step = length(sample_ppdf.scale) == 1 ? fill(sample_ppdf.scale[1], ndim) : copy(sample_ppdf.scale)
+    @assert length(step) == ndim
+    p = params(pdf); p8 = ntuple(i -> i <= length(p) ? p[i] : 0.0, 8)
+    chain = Array{Float64}(undef, ndim, nchains, nsamples)
+    clogp = Array{Float64}(undef, nchains, nsamples)
+    acc = Vector{Float64}(undef, nchains)
+    out = KmcMetropolisOutputs(pointer(chain), pointer(clogp), pointer(acc), C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, 0, 0.0)
+    st = GC.@preserve pdf theta step chain clogp acc begin
+        cfg = Ref(KmcMetropolisConfig(0, density_id(pdf), p8, nchains, ndim, niter, nburnin, nthin, pointer(step), UInt64(seed),
+                                      0x3, Int32(device), user_handle(pdf)))                 # flags: STORE_CHAIN | STORE_LOGP
+        ccall((:kmc_metropolis_run, LIB), Cint, (Ref{KmcMetropolisConfig}, Ptr{Float64}, Ref{KmcMetropolisOutputs}), cfg, theta, out)
+    end
+    st == 0 || error("kmc_metropolis_run failed ($st): $(last_error())")
+    thetas = scalar ? [[chain[1, c, k] for k in 1:nsamples] for c in 1:nchains] :
+                      [[chain[:, c, k] for k in 1:nsamples] for c in 1:nchains]
+    return thetas, acc, [[clogp[c, k] for k in 1:nsamples] for c in 1:nchains], nothing
+end
+
+"""
+    metropolis(pdf::DeviceLogPdf, sample_ppdf::GaussianStep, theta0; niter=10^5, nburnin=niter÷2, nthin=1, ...)
+
+KissMCMC.metropolis' signature and return value (src/samplers.jl:59-77, :128) for one chain (a single lane:
+a drop-in, not a fast path -- use `metropolis_chains` for throughput).
+"""
+function metropolis(pdf::DeviceLogPdf, sample_ppdf::GaussianStep, theta0; use_progress_meter=true, kw...)
+    thetas, acc, logd, _ = metropolis_chains(pdf, sample_ppdf, [theta0]; kw...)
+    return thetas[1], acc[1], logd[1], nothing                                           # :128
+end
 
 "src/samplers.jl:311-349 (host side, runs once)."
 function make_theta0s(theta0::T, ball_radius, pdf, nwalkers; ball_radius_halfing_steps=7, ntries=100, hasblob=false) where T
