@@ -11,6 +11,8 @@ LIB = os.path.join(_HERE, "libkissmcmc_hip.so")
 SOURCES = ["kmc_api.hip", "kmc_inst_gaussian_iso.hip", "kmc_inst_exponential.hip", "kmc_inst_rosenbrock.hip",
            "kmc_inst_lognormal.hip", "kmc_inst_mvnormal2.hip", "kmc_inst_host.hip"]
 HEADERS = ["kmc_device.hpp", "kmc_kernels.hpp", "kmc_islands.hpp", "kmc_metropolis.hpp", "kmc_tables.hpp", os.path.join("..", "..", "include", "kissmcmc_hip.h")]
+# kernarg preload: the half-step kernels' leading scalar parameters arrive in SGPRs at wave launch (kmc_kernels.hpp)
+PRELOAD = ["-mllvm", "-amdgpu-kernarg-preload-count=14"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 
@@ -30,7 +32,7 @@ def stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str = LIB) -> str:
+def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str = LIB, preload: bool = True) -> str:
     """Compile csrc/*.hip (one translation unit per density, in parallel) and link
     libkissmcmc_hip.so next to this file (in-tree, so it travels with the snapshot).
     ``extra_flags``/``out`` build experiment variants (e.g. ``-DKMC_TPB=128``) side by side."""
@@ -43,7 +45,7 @@ def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str =
 
     def compile_one(src):
         obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
-        cmd = [hipcc, *FLAGS, *extra_flags, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, *FLAGS, *(PRELOAD if preload else ()), *extra_flags, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -344,12 +344,12 @@ kmc_status compile_user(kmc_user_density* ud, bool with_vec, int L, int K, int i
     std::ostringstream src;
     src << "#define KMC_TPB " << kTPB << "\n#include \"kmc_islands.hpp\"\n" << user_functor_source(ud)
         << "using UD = kmc::TermPairDensity<UserF>;\n"
-        << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_generic(const kmc::HalfStepArgs a) { kmc::half_step_generic_body<UD, false>(a); }\n"
+        << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_generic(KMC_FRONT_PARAMS, const kmc::HalfStepArgs a) { kmc::half_step_generic_body<UD, false>(KMC_FRONT_PACK, a); }\n"
         << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_logpdf(const kmc::LogpdfArgs a) { kmc::logpdf_rows_body<UD>(a); }\n"
         << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_init_ball(const kmc::InitBallArgs a) { kmc::init_ball_body<UD>(a); }\n";
     if (with_vec)
-        src << "extern \"C\" __global__ __launch_bounds__(" << kTPB << ") void kmc_user_vec(const kmc::HalfStepArgs a) { kmc::half_step_vec_body<UD, "
-            << L << ", " << K << ", " << iter << ", false, " << (ragged ? "true" : "false") << ">(a); }\n";
+        src << "extern \"C\" __global__ __launch_bounds__(" << kTPB << ") void kmc_user_vec(KMC_FRONT_PARAMS, const kmc::HalfStepArgs a) { kmc::half_step_vec_body<UD, "
+            << L << ", " << K << ", " << iter << ", false, " << (ragged ? "true" : "false") << ">(KMC_FRONT_PACK, a); }\n";
     if (resident_K > 0 && island_S == 0)
         src << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_resident(const kmc::ResidentArgs a) { kmc::resident_body<UD, "
             << resident_K << ", " << (resident_ragged ? "true" : "false") << ">(a); }\n";
@@ -363,8 +363,8 @@ kmc_status compile_user(kmc_user_density* ud, bool with_vec, int L, int K, int i
     const char* names[3] = {"kmc_kernels.hpp", "kmc_device.hpp", "kmc_islands.hpp"};
     if (hiprtcCreateProgram(&prog, text.c_str(), "kmc_user_density.hip", 3, headers, names) != HIPRTC_SUCCESS)
         return fail(KMC_ERR_HIP, "hiprtcCreateProgram failed");
-    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"};
-    const hiprtcResult r = hiprtcCompileProgram(prog, 4, opts);
+    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-mllvm", "-amdgpu-kernarg-preload-count=14"};
+    const hiprtcResult r = hiprtcCompileProgram(prog, 6, opts);
     if (r != HIPRTC_SUCCESS) {
         size_t n = 0;
         hiprtcGetProgramLogSize(prog, &n);
@@ -534,15 +534,34 @@ HalfStepArgs make_args(const kmc_sampler* s, int half, bool graph_mode, int64_t 
     return a;
 }
 
+// the leading scalar kernel parameters (kernarg preload, see HalfStepFront)
+HalfStepFront front_of(const HalfStepArgs& a)
+{
+    HalfStepFront f{};
+    f.pos = a.pos;
+    f.sched = a.sched_table + (a.sched_index < 0 ? 0 : a.sched_index);
+    f.gw0 = a.gw0;
+    f.own_row0 = (int32_t)a.own_row0;
+    f.oth_row0 = (int32_t)a.oth_row0;
+    f.n_active = a.n_active;
+    f.seed_lo = a.dc.seed_lo; f.seed_hi = a.dc.seed_hi; f.nhalf = a.dc.nhalf;
+    f.half = a.half;
+    return f;
+}
+
+// kernarg image of (KMC_FRONT_PARAMS, const HalfStepArgs): the scalars at their natural alignment, then the struct
+struct HalfStepLaunch {
+    HalfStepFront f;
+    HalfStepArgs  a;
+};
+static_assert(offsetof(HalfStepLaunch, a) == 56 && offsetof(HalfStepFront, half) == 48, "kernarg layout of the half-step kernels");
+
+hipError_t launch_half_kernel(const kmc_sampler* s, const HalfStepArgs& a);
+
 kmc_status launch_half(kmc_sampler* s, int half, bool graph_mode, int64_t gen_offset)
 {
     const HalfStepArgs a = make_args(s, half, graph_mode, gen_offset);
-    if (s->user) {
-        HIP_TRY(launch_module(s->plan.vec ? s->uk.vec : s->uk.generic, (unsigned)s->grid, (unsigned)s->tpb, s->stream, a));
-    } else {
-        hipLaunchKernelGGL(s->plan.fn, dim3(s->grid), dim3(s->tpb), 0, s->stream, a);
-        HIP_TRY(hipGetLastError());
-    }
+    HIP_TRY(launch_half_kernel(s, a));
     if (s->p2p && s->cfg.shard_count > 1) {
         // the kernel boundary puts this half-step's rows in memory; then publish the progress
         SignalArgs sg{};
@@ -557,6 +576,18 @@ kmc_status launch_half(kmc_sampler* s, int half, bool graph_mode, int64_t gen_of
         HIP_TRY(hipGetLastError());
     }
     return KMC_OK;
+}
+
+hipError_t launch_half_kernel(const kmc_sampler* s, const HalfStepArgs& a)
+{
+    const HalfStepFront f = front_of(a);
+    if (s->user) {
+        const HalfStepLaunch la{f, a};
+        return launch_module(s->plan.vec ? s->uk.vec : s->uk.generic, (unsigned)s->grid, (unsigned)s->tpb, s->stream, la);
+    }
+    hipLaunchKernelGGL(s->plan.fn, dim3(s->grid), dim3(s->tpb), 0, s->stream, f.pos, f.sched, f.gw0, f.own_row0, f.oth_row0,
+                       f.n_active, f.seed_lo, f.seed_hi, f.nhalf, f.half, a);
+    return hipGetLastError();
 }
 
 void launch_advance(kmc_sampler* s, int n, int64_t by)
@@ -1259,8 +1290,7 @@ KMC_EXPORT kmc_status kmc_sampler_run(kmc_sampler* s, int64_t ngen)
             for (int half = 0; half < 2; ++half) {
                 HalfStepArgs a = make_args(s, half, false, s->generation);
                 a.prop_out = s->d_prop;
-                hipLaunchKernelGGL(s->plan.fn, dim3(s->grid), dim3(s->tpb), 0, s->stream, a);
-                HIP_TRY(hipGetLastError());
+                HIP_TRY(launch_half_kernel(s, a));
                 HIP_TRY(hipMemcpy2DAsync(s->h_prop, nd * sizeof(double), s->d_prop, ld * sizeof(double), nd * sizeof(double), hh,
                                          hipMemcpyDeviceToHost, s->stream));
                 HIP_TRY(hipStreamSynchronize(s->stream));
@@ -1271,8 +1301,7 @@ KMC_EXPORT kmc_status kmc_sampler_run(kmc_sampler* s, int64_t ngen)
                 HIP_TRY(hipMemcpyAsync(s->d_p1, s->h_p1, hh * sizeof(double), hipMemcpyHostToDevice, s->stream));
                 a.prop_out = nullptr;
                 a.p1_in = s->d_p1;
-                hipLaunchKernelGGL(s->plan.fn, dim3(s->grid), dim3(s->tpb), 0, s->stream, a);
-                HIP_TRY(hipGetLastError());
+                HIP_TRY(launch_half_kernel(s, a));
                 s->launches += 2;
             }
             s->generation += 1;

@@ -101,18 +101,38 @@ struct HalfStepArgs {
     const double*     p1_in;        // ACCEPT pass: log-pdf of proposal i as evaluated by the host
 };
 
+// The fields a wave needs before it can issue its first loads travel as LEADING SCALAR kernel parameters, ahead
+// of the argument struct: built with -mllvm -amdgpu-kernarg-preload-count=14, gfx950 delivers them in SGPRs at
+// wave launch (kernarg preload), so the own-row loads, the schedule entry and the Philox block do not wait for
+// the kernarg fetch (one scalar-memory round trip right after the kernel boundary).  Without the flag they are
+// ordinary kernel arguments -- same code, same results.
+struct HalfStepFront {
+    double*           pos;        // = HalfStepArgs::pos
+    const SchedEntry* sched;      // this launch's schedule entry (sched_table + sched_index; entry 0 when sched_index < 0)
+    int64_t           gw0;        // = HalfStepArgs::gw0
+    int32_t           own_row0;   // = HalfStepArgs::own_row0, oth_row0 (rows fit 31 bits: nwalkers < 2^31)
+    int32_t           oth_row0;
+    int32_t           n_active;
+    uint32_t          seed_lo, seed_hi, nhalf;
+    int32_t           half;
+};
+#define KMC_FRONT_PARAMS double* f_pos, const kmc::SchedEntry* f_sched, int64_t f_gw0, int32_t f_own_row0, int32_t f_oth_row0, \
+                         int32_t f_n_active, uint32_t f_seed_lo, uint32_t f_seed_hi, uint32_t f_nhalf, int32_t f_half
+#define KMC_FRONT_PACK kmc::HalfStepFront{f_pos, f_sched, f_gw0, f_own_row0, f_oth_row0, f_n_active, f_seed_lo, f_seed_hi, f_nhalf, f_half}
+#define KMC_FRONT_TYPES double*, const kmc::SchedEntry*, int64_t, int32_t, int32_t, int32_t, uint32_t, uint32_t, uint32_t, int32_t
+
 // One scalar load of the whole 32-byte entry (s_load_dwordx8; the scalar cache is invalidated at
 // kernel start and the table is only written by advance_schedule between launches), issued as soon
 // as the kernarg is in: nothing in the kernel's prologue waits on vector memory, and the entry is one
 // round trip instead of one per field.  sched_index < 0: the entry travels in the args (eager
 // launches); sched_table is a valid pointer either way.
-__device__ __forceinline__ SchedEntry schedule_of(const HalfStepArgs& a)
+__device__ __forceinline__ SchedEntry schedule_of(const HalfStepFront& f, const HalfStepArgs& a)
 {
     typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
-    const bool inl = a.sched_index < 0;
-    const SchedEntry* p = a.sched_table + (inl ? 0 : a.sched_index);
+    const SchedEntry* p = f.sched;               // always a valid entry address (entry 0 for eager launches)
     u32x8 r;
     asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(p));
+    const bool inl = a.sched_index < 0;
     SchedEntry t;
     t.gen     = inl ? a.sched_inline.gen     : (int64_t)(((uint64_t)r[1] << 32) | r[0]);
     t.slot    = inl ? a.sched_inline.slot    : (int64_t)(((uint64_t)r[3] << 32) | r[2]);
@@ -202,7 +222,7 @@ static __device__ unsigned long long g_probe[2][8192][4];
 // RAGGED = false: ndim == 2*L*K exactly (row stride and every mask fold at compile time);
 // RAGGED = true : ndim < 2*L*K, runtime row stride a.ld and masked tail chunks.
 template <class Dens, int L, int K, int ITER, bool P2P, bool RAGGED>
-__device__ __forceinline__ void half_step_vec_body(const HalfStepArgs& a)
+__device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const HalfStepArgs& a)
 {
     static_assert(L >= 1 && L <= 64 && (L & (L - 1)) == 0, "L must be a power of two <= 64");
     static_assert(ITER >= 1 && ITER <= L, "a group's scalar lanes must cover its iterations");
@@ -216,7 +236,7 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepArgs& a)
     const int g     = lane / L;
     const int gbase = lane & ~(L - 1);                  // first lane of this group
     const int w0    = (tid >> 6) * W;                   // first active index of this wave
-    const int nact  = a.n_active;
+    const int nact  = f.n_active;
     bool cv[K];                                         // chunk k of this lane lies inside the row
 #pragma unroll
     for (int k = 0; k < K; ++k) cv[k] = !RAGGED || 2 * (k * L + j) < (int)ld;
@@ -225,9 +245,6 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepArgs& a)
     unsigned long long stamp[4];
 #endif
     KMC_STAMP(0);
-    // have the schedule entry's address in the first kernarg batch, so its load goes out together with
-    // the second batch (one scalar round trip for both)
-    asm volatile("" :: "s"(a.sched_index), "s"(a.sched_table));
 
     // ---- row layout: own rows of every iteration (independent of the random draws) ----------
     bool    validB[ITER];
@@ -236,16 +253,18 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepArgs& a)
     for (int it = 0; it < ITER; ++it) {
         const int i = w0 + it * G + g;
         validB[it] = i < nact;
-        const double2* own = reinterpret_cast<const double2*>(a.pos + (a.own_row0 + (validB[it] ? i : nact - 1)) * ld);
+        const double2* own = reinterpret_cast<const double2*>(f.pos + ((int64_t)f.own_row0 + (validB[it] ? i : nact - 1)) * ld);
 #pragma unroll
         for (int k = 0; k < K; ++k) xc[it][k] = cv[k] ? own[k * L + j] : zero2;
     }
 
     // ---- scalar layout: one walker per lane (j < ITER) ---------------------------------------
-    const SchedEntry sch = schedule_of(a);
+    const SchedEntry sch = schedule_of(f, a);
     const bool count  = (sch.flags & kCount) != 0;
     const bool sample = (sch.flags & kSample) != 0;
-    const uint64_t step = 2ull * (uint64_t)sch.gen + (uint64_t)a.half;
+    const uint64_t step = 2ull * (uint64_t)sch.gen + (uint64_t)f.half;
+    DrawConsts dc = a.dc;                                               // seed and nhalf from the front parameters
+    dc.seed_lo = f.seed_lo; dc.seed_hi = f.seed_hi; dc.nhalf = f.nhalf;
     // Streaming moments are sojourn-weighted: a walker's value is credited, times the number of
     // samples it stood for, when it is replaced (and by flush_moments_vec at read-out).  Only waves
     // with an accepted move touch their accumulators -- at low acceptance (large ndim) almost none.
@@ -267,12 +286,12 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepArgs& a)
     const int  iA     = w0 + (j < ITER ? j : 0) * G + g;
     const bool validA = (j < ITER) && (iA < nact);
     const int      iAc = iA < nact ? iA : nact - 1;
-    const int64_t  rowA = a.own_row0 + iAc;                              // row in pos / index in logp, naccept
+    const int64_t  rowA = (int64_t)f.own_row0 + iAc;                     // row in pos / index in logp, naccept
     const double   p0 = a.logp[rowA];
     const uint32_t na = a.naccept[rowA];
     const uint32_t kl = do_mom ? a.klast[rowA] : 0u;
-    const U4 bits = draw_bits(a.dc, step, (uint64_t)(a.gw0 + iAc));     // RNG keyed by the GLOBAL walker index
-    const uint32_t partnerA = draw_partner(a.dc, bits);                 // :250
+    const U4 bits = draw_bits(dc, step, (uint64_t)(f.gw0 + iAc));       // RNG keyed by the GLOBAL walker index
+    const uint32_t partnerA = draw_partner(dc, bits);                   // :250
     KMC_STAMP(1);
 
     // ---- scalar -> row: the partner of slot it*G+g lives in lane gbase+it; get the partner-row
@@ -281,7 +300,7 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepArgs& a)
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
             const uint32_t partner = (uint32_t)__builtin_amdgcn_ds_bpermute((gbase + it) * 4, (int)partnerA);
-            const double2* oth = reinterpret_cast<const double2*>(a.pos + (a.oth_row0 + partner) * ld);
+            const double2* oth = reinterpret_cast<const double2*>(f.pos + ((int64_t)f.oth_row0 + partner) * ld);
 #pragma unroll
             for (int k = 0; k < K; ++k) xo[it][k] = cv[k] ? oth[k * L + j] : zero2;
         }
@@ -292,7 +311,7 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepArgs& a)
         const double* base = a.peer_pos[0];
 #pragma unroll
         for (int t = 1; t < 8; ++t) base = (q == (uint32_t)t) ? a.peer_pos[t] : base;
-        const unsigned long long addrA = (unsigned long long)(base + (a.oth_row0 + r) * ld);
+        const unsigned long long addrA = (unsigned long long)(base + ((int64_t)f.oth_row0 + r) * ld);
         if (a.nranks > 1) {
             // every rank must have finished half-step `step - 1`: one polling wave per workgroup (the
             // flags sit in uncached fine-grained memory), the other waves wait at the barrier
@@ -309,7 +328,7 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepArgs& a)
             for (int k = 0; k < K; ++k) xo[it][k] = cv[k] ? oth[k * L + j] : zero2;
         }
     }
-    const Draw dr = draw_finish(a.dc, bits);                            // :252, log z, log u
+    const Draw dr = draw_finish(dc, bits);                              // :252, log z, log u
     double zB[ITER];
 #pragma unroll
     for (int it = 0; it < ITER; ++it) zB[it] = bperm_f64((gbase + it) * 4, dr.z);
@@ -350,7 +369,7 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepArgs& a)
     for (int it = 0; it < ITER; ++it) {
         const bool accB = ((accmask >> (gbase + it)) & 1ull) != 0;
         if (accB) {                                                     // :261
-            double2* own = reinterpret_cast<double2*>(a.pos + (a.own_row0 + w0 + it * G + g) * ld);
+            double2* own = reinterpret_cast<double2*>(f.pos + ((int64_t)f.own_row0 + w0 + it * G + g) * ld);
 #pragma unroll
             for (int k = 0; k < K; ++k) if (cv[k]) store_row16(&own[k * L + j], xo[it][k]);
         }
@@ -374,14 +393,14 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepArgs& a)
     }
     KMC_STAMP(3);
 #ifdef KMC_PROBE
-    if (lane == 0 && (tid >> 6) < 8192) for (int q = 0; q < 4; ++q) g_probe[a.half][tid >> 6][q] = stamp[q];
+    if (lane == 0 && (tid >> 6) < 8192) for (int q = 0; q < 4; ++q) g_probe[f.half][tid >> 6][q] = stamp[q];
 #endif
 }
 
 template <class Dens, int L, int K, int ITER, bool P2P, bool RAGGED>
-__global__ __launch_bounds__(kTPB) void half_step_vec(const HalfStepArgs a)
+__global__ __launch_bounds__(kTPB) void half_step_vec(KMC_FRONT_PARAMS, const HalfStepArgs a)
 {
-    half_step_vec_body<Dens, L, K, ITER, P2P, RAGGED>(a);
+    half_step_vec_body<Dens, L, K, ITER, P2P, RAGGED>(KMC_FRONT_PACK, a);
 }
 
 // Moment read-out: credit every walker's current value with the samples it has stood for since it
@@ -440,10 +459,10 @@ __global__ __launch_bounds__(kTPB) void flush_moments_vec(const FlushArgs a)
 // Generic kernel: one walker per lane, any ndim.
 // ------------------------------------------------------------------------------------------
 template <class Dens, bool P2P>
-__device__ __forceinline__ void half_step_generic_body(const HalfStepArgs& a)
+__device__ __forceinline__ void half_step_generic_body(const HalfStepFront& f, const HalfStepArgs& a)
 {
     const int tid = blockIdx.x * 256 + threadIdx.x;
-    const SchedEntry sch = schedule_of(a);
+    const SchedEntry sch = schedule_of(f, a);
     const uint64_t step = 2ull * (uint64_t)sch.gen + (uint64_t)a.half;
     if constexpr (P2P) { if (a.nranks > 1) wait_for_peers(a, step, (int)(threadIdx.x & 63)); }   // whole waves, before any exit
     if (tid >= a.n_active) return;
@@ -508,9 +527,9 @@ __device__ __forceinline__ void half_step_generic_body(const HalfStepArgs& a)
 }
 
 template <class Dens, bool P2P>
-__global__ __launch_bounds__(256) void half_step_generic(const HalfStepArgs a)
+__global__ __launch_bounds__(256) void half_step_generic(KMC_FRONT_PARAMS, const HalfStepArgs a)
 {
-    half_step_generic_body<Dens, P2P>(a);
+    half_step_generic_body<Dens, P2P>(KMC_FRONT_PACK, a);
 }
 
 // Initial log-pdfs, src/samplers.jl:209.

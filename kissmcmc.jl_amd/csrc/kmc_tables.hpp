@@ -7,7 +7,7 @@
 
 namespace kmc {
 
-using HalfStepFn = void (*)(const HalfStepArgs);
+using HalfStepFn = void (*)(KMC_FRONT_TYPES, const HalfStepArgs);
 using LogpdfFn = void (*)(const LogpdfArgs);
 using FlushFn = void (*)(const FlushArgs);
 using IslandFn = void (*)(const IslandArgs);
