@@ -450,6 +450,7 @@ struct kmc_sampler {
     double* d_msum = nullptr;
     double* d_msumsq = nullptr;
     uint32_t* d_klast = nullptr;      // vec kernels: samples already credited per walker
+    double2* d_ring = nullptr;        // vec kernels: parked draws of the walkers' next steps, [4][nrows] x 32 B (HalfStepArgs::ring)
     int64_t macc_stride = 0, macc_elems = 0;
     int64_t moment_base = 0;  // samples that precede the restored state (kmc_sampler_set_state)
     int64_t generation = 0;   // generations enqueued so far
@@ -531,6 +532,9 @@ HalfStepArgs make_args(const kmc_sampler* s, int half, bool graph_mode, int64_t 
     a.msumsq = s->d_msumsq;
     a.macc_stride = s->macc_stride;
     a.klast = s->d_klast;
+    a.ring = s->d_ring;
+    a.ring_rows = s->nrows;
+    a.ring_slot = (int32_t)(gen_offset & 3);
     return a;
 }
 
@@ -542,8 +546,8 @@ HalfStepFront front_of(const HalfStepArgs& a)
     f.sched = a.sched_table + (a.sched_index < 0 ? 0 : a.sched_index);
     f.gw0 = a.gw0;
     f.own_row0 = (int32_t)a.own_row0;
-    f.oth_row0 = (int32_t)a.oth_row0;
     f.n_active = a.n_active;
+    f.ring_now = a.ring ? a.ring + (int64_t)a.ring_slot * a.ring_rows * 2 : nullptr;
     f.seed_lo = a.dc.seed_lo; f.seed_hi = a.dc.seed_hi; f.nhalf = a.dc.nhalf;
     f.half = a.half;
     return f;
@@ -554,7 +558,7 @@ struct HalfStepLaunch {
     HalfStepFront f;
     HalfStepArgs  a;
 };
-static_assert(offsetof(HalfStepLaunch, a) == 56 && offsetof(HalfStepFront, half) == 48, "kernarg layout of the half-step kernels");
+static_assert(offsetof(HalfStepLaunch, a) == 56 && offsetof(HalfStepFront, ring_now) == 32 && offsetof(HalfStepFront, half) == 52, "kernarg layout of the half-step kernels");
 
 hipError_t launch_half_kernel(const kmc_sampler* s, const HalfStepArgs& a);
 
@@ -585,8 +589,8 @@ hipError_t launch_half_kernel(const kmc_sampler* s, const HalfStepArgs& a)
         const HalfStepLaunch la{f, a};
         return launch_module(s->plan.vec ? s->uk.vec : s->uk.generic, (unsigned)s->grid, (unsigned)s->tpb, s->stream, la);
     }
-    hipLaunchKernelGGL(s->plan.fn, dim3(s->grid), dim3(s->tpb), 0, s->stream, f.pos, f.sched, f.gw0, f.own_row0, f.oth_row0,
-                       f.n_active, f.seed_lo, f.seed_hi, f.nhalf, f.half, a);
+    hipLaunchKernelGGL(s->plan.fn, dim3(s->grid), dim3(s->tpb), 0, s->stream, f.pos, f.sched, f.gw0, f.own_row0, f.n_active,
+                       f.ring_now, f.seed_lo, f.seed_hi, f.nhalf, f.half, a);
     return hipGetLastError();
 }
 
@@ -879,6 +883,13 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
     CREATE_TRY(hipMemset(s->d_gen, 0, 64));
     CREATE_TRY(hipMalloc(&s->d_sched, (size_t)kGraphChunk * sizeof(SchedEntry)));
     CREATE_TRY(hipMemset(s->d_naccept, 0, nw * sizeof(uint32_t)));
+    if (s->plan.vec && !s->islands && !s->resident && s->plan.L >= 16 && s->plan.L / s->plan.ITER >= 2 &&
+        std::getenv("KMC_NO_DRAW_RING") == nullptr) {
+        // draw ring: 4 slots x rows x 32 B; tags start at 0xffffffff (no step carries it), so nothing is "parked" yet
+        const size_t nb = 4 * (size_t)s->nrows * 2 * sizeof(double2);
+        CREATE_TRY(hipMalloc((void**)&s->d_ring, nb));
+        CREATE_TRY(hipMemset(s->d_ring, 0xff, nb));
+    }
     if (cfg->flags & KMC_MOMENTS) {
         CREATE_TRY(hipMalloc(&s->d_msum, (size_t)s->macc_elems * sizeof(double)));
         CREATE_TRY(hipMalloc(&s->d_msumsq, (size_t)s->macc_elems * sizeof(double)));
@@ -945,6 +956,7 @@ KMC_EXPORT void kmc_sampler_destroy(kmc_sampler* s)
     (void)hipFree(s->d_msum);
     (void)hipFree(s->d_msumsq);
     (void)hipFree(s->d_klast);
+    (void)hipFree(s->d_ring);
     (void)hipFree(s->d_isum);
     (void)hipFree(s->d_isumsq);
     (void)hipFree(s->d_prop);

@@ -96,6 +96,14 @@ struct HalfStepArgs {
     double*           msumsq;
     int64_t           macc_stride;  // threads in the accumulator grid
     uint32_t*         klast;        // vec kernels: per walker, samples already credited to the moments
+    // draw ring (vec kernels): the per-walker-step draws {partner, z, (N-1) log z, log u} are pure functions of
+    // (seed, step, walker), and in the scalar layout only ITER of a group's L lanes carry a walker -- so a wave
+    // computes them for this step AND the walkers' next Q-1 steps at once (all lanes busy, same instruction
+    // count) and parks the future ones here: [4 slots][rows] entries of 32 B {t1, lu | z, partner + step tag}.
+    // The next Q-1 launches of these walkers load one entry instead of running Philox and two logarithms.
+    double2*          ring;         // or nullptr
+    int64_t           ring_rows;    // rows per slot
+    int32_t           ring_slot;    // slot of this generation (generation & 3)
     // host-evaluated densities (HostEval) only
     double*           prop_out;     // PROPOSE pass: proposals [n_active][ld]; nothing else is touched
     const double*     p1_in;        // ACCEPT pass: log-pdf of proposal i as evaluated by the host
@@ -110,16 +118,16 @@ struct HalfStepFront {
     double*           pos;        // = HalfStepArgs::pos
     const SchedEntry* sched;      // this launch's schedule entry (sched_table + sched_index; entry 0 when sched_index < 0)
     int64_t           gw0;        // = HalfStepArgs::gw0
-    int32_t           own_row0;   // = HalfStepArgs::own_row0, oth_row0 (rows fit 31 bits: nwalkers < 2^31)
-    int32_t           oth_row0;
-    int32_t           n_active;
+    int32_t           own_row0;   // = HalfStepArgs::own_row0 (rows fit 31 bits: nwalkers < 2^31); the complementary half
+    int32_t           n_active;   //   starts at row (1 - half) * (P2P ? n_active : nhalf)
+    const double2*    ring_now;   // draw ring, slot of THIS generation: entry of row r at ring_now[2 r] (nullptr: no ring)
     uint32_t          seed_lo, seed_hi, nhalf;
     int32_t           half;
 };
-#define KMC_FRONT_PARAMS double* f_pos, const kmc::SchedEntry* f_sched, int64_t f_gw0, int32_t f_own_row0, int32_t f_oth_row0, \
-                         int32_t f_n_active, uint32_t f_seed_lo, uint32_t f_seed_hi, uint32_t f_nhalf, int32_t f_half
-#define KMC_FRONT_PACK kmc::HalfStepFront{f_pos, f_sched, f_gw0, f_own_row0, f_oth_row0, f_n_active, f_seed_lo, f_seed_hi, f_nhalf, f_half}
-#define KMC_FRONT_TYPES double*, const kmc::SchedEntry*, int64_t, int32_t, int32_t, int32_t, uint32_t, uint32_t, uint32_t, int32_t
+#define KMC_FRONT_PARAMS double* f_pos, const kmc::SchedEntry* f_sched, int64_t f_gw0, int32_t f_own_row0, int32_t f_n_active, \
+                         const double2* f_ring_now, uint32_t f_seed_lo, uint32_t f_seed_hi, uint32_t f_nhalf, int32_t f_half
+#define KMC_FRONT_PACK kmc::HalfStepFront{f_pos, f_sched, f_gw0, f_own_row0, f_n_active, f_ring_now, f_seed_lo, f_seed_hi, f_nhalf, f_half}
+#define KMC_FRONT_TYPES double*, const kmc::SchedEntry*, int64_t, int32_t, int32_t, const double2*, uint32_t, uint32_t, uint32_t, int32_t
 
 // One scalar load of the whole 32-byte entry (s_load_dwordx8; the scalar cache is invalidated at
 // kernel start and the table is only written by advance_schedule between launches), issued as soon
@@ -246,6 +254,26 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
 #endif
     KMC_STAMP(0);
 
+    // ---- scalar layout: one walker per lane.  Lane (g, j) carries walker slot js = j % ITER of its group and,
+    //      when draws are computed, the walker's q-th next step, q = j / ITER < Q; the lanes with q == 0
+    //      (j < ITER) feed this launch -------------------------------------------------------------------
+    constexpr int Q = (L / ITER) >= 4 ? 4 : (L / ITER);                 // steps drawn per heavy launch
+    // worth it when a wave carries few walkers (long rows): at <= 8 walkers per wave the per-walker scalar work
+    // dominates the wave's instruction count; with more (C2: 16) the extra load in the chain costs what it saves
+    constexpr bool kRing = Q >= 2 && L >= 16;
+    const int64_t oth_row0 = (int64_t)(1 - f.half) * (int64_t)(P2P ? (uint32_t)f.n_active : f.nhalf);
+    const int  jq     = j / ITER, js = j - jq * ITER;
+    const bool useA   = jq == 0;
+    const int  iA     = w0 + (jq < Q ? js : 0) * G + g;
+    const bool validA = useA && (iA < nact);
+    const int      iAc = iA < nact ? iA : nact - 1;
+    const int64_t  rowA = (int64_t)f.own_row0 + iAc;                     // row in pos / index in logp, naccept
+    const bool ring_on = kRing && f.ring_now != nullptr;
+    double2 e0 = zero2, e1 = zero2;                                     // this launch's parked draws, if any
+    if constexpr (kRing) {
+        if (ring_on && useA) { e0 = f.ring_now[2 * rowA]; e1 = f.ring_now[2 * rowA + 1]; }
+    }
+
     // ---- row layout: own rows of every iteration (independent of the random draws) ----------
     bool    validB[ITER];
     double2 xc[ITER][K], xo[ITER][K];
@@ -258,7 +286,6 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
         for (int k = 0; k < K; ++k) xc[it][k] = cv[k] ? own[k * L + j] : zero2;
     }
 
-    // ---- scalar layout: one walker per lane (j < ITER) ---------------------------------------
     const SchedEntry sch = schedule_of(f, a);
     const bool count  = (sch.flags & kCount) != 0;
     const bool sample = (sch.flags & kSample) != 0;
@@ -283,15 +310,18 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
             }
         }
     }
-    const int  iA     = w0 + (j < ITER ? j : 0) * G + g;
-    const bool validA = (j < ITER) && (iA < nact);
-    const int      iAc = iA < nact ? iA : nact - 1;
-    const int64_t  rowA = (int64_t)f.own_row0 + iAc;                     // row in pos / index in logp, naccept
     const double   p0 = a.logp[rowA];
     const uint32_t na = a.naccept[rowA];
     const uint32_t kl = do_mom ? a.klast[rowA] : 0u;
-    const U4 bits = draw_bits(dc, step, (uint64_t)(f.gw0 + iAc));       // RNG keyed by the GLOBAL walker index
-    const uint32_t partnerA = draw_partner(dc, bits);                   // :250
+    // parked draws are valid iff they carry this step's tag (wave-uniform decision)
+    const uint32_t e1y_lo = (uint32_t)__double2loint(e1.y), e1y_hi = (uint32_t)__double2hiint(e1.y);
+    const bool fresh = ring_on && __all(!useA || e1y_hi == (uint32_t)step);
+    U4 bits{0u, 0u, 0u, 0u};
+    uint32_t partnerA = e1y_lo;                                         // :250
+    if (!fresh) {
+        bits = draw_bits(dc, step + 2ull * (uint64_t)jq, (uint64_t)(f.gw0 + iAc));   // RNG keyed by the GLOBAL walker index
+        partnerA = draw_partner(dc, bits);
+    }
     KMC_STAMP(1);
 
     // ---- scalar -> row: the partner of slot it*G+g lives in lane gbase+it; get the partner-row
@@ -300,7 +330,7 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
             const uint32_t partner = (uint32_t)__builtin_amdgcn_ds_bpermute((gbase + it) * 4, (int)partnerA);
-            const double2* oth = reinterpret_cast<const double2*>(f.pos + ((int64_t)f.oth_row0 + partner) * ld);
+            const double2* oth = reinterpret_cast<const double2*>(f.pos + (oth_row0 + partner) * ld);
 #pragma unroll
             for (int k = 0; k < K; ++k) xo[it][k] = cv[k] ? oth[k * L + j] : zero2;
         }
@@ -311,7 +341,7 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
         const double* base = a.peer_pos[0];
 #pragma unroll
         for (int t = 1; t < 8; ++t) base = (q == (uint32_t)t) ? a.peer_pos[t] : base;
-        const unsigned long long addrA = (unsigned long long)(base + ((int64_t)f.oth_row0 + r) * ld);
+        const unsigned long long addrA = (unsigned long long)(base + (oth_row0 + r) * ld);
         if (a.nranks > 1) {
             // every rank must have finished half-step `step - 1`: one polling wave per workgroup (the
             // flags sit in uncached fine-grained memory), the other waves wait at the barrier
@@ -328,7 +358,18 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
             for (int k = 0; k < K; ++k) xo[it][k] = cv[k] ? oth[k * L + j] : zero2;
         }
     }
-    const Draw dr = draw_finish(dc, bits);                              // :252, log z, log u
+    Draw dr;
+    dr.partner = partnerA; dr.z = e1.x; dr.t1 = e0.x; dr.lu = e0.y;
+    if (!fresh) {
+        dr = draw_finish(dc, bits);                                     // :252, log z, log u
+        if constexpr (kRing) {
+            if (ring_on && jq >= 1 && jq < Q && iA < nact) {            // park the walkers' next steps
+                double2* slot = a.ring + ((int64_t)((a.ring_slot + jq) & 3) * a.ring_rows + rowA) * 2;
+                slot[0] = make_double2(dr.t1, dr.lu);
+                slot[1] = make_double2(dr.z, __hiloint2double((int)(uint32_t)(step + 2ull * (uint64_t)jq), (int)dr.partner));
+            }
+        }
+    }
     double zB[ITER];
 #pragma unroll
     for (int it = 0; it < ITER; ++it) zB[it] = bperm_f64((gbase + it) * 4, dr.z);
