@@ -1514,7 +1514,21 @@ KMC_EXPORT kmc_status kmc_sampler_get_moments(kmc_sampler* s, double* sum, doubl
     HIP_TRY(hipMemcpy(hs.data(), s->d_msum, hs.size() * sizeof(double), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(hq.data(), s->d_msumsq, hq.size() * sizeof(double), hipMemcpyDeviceToHost));
     std::vector<double> S((size_t)nd, 0.0), Q((size_t)nd, 0.0);
-    if (s->plan.vec) {
+    if (s->plan.vec && s->plan.K == 2 && (s->plan.L == 8 || s->plan.L == 16 || s->plan.L == 32)) {
+        // transposed fold (kmc_kernels.hpp, FoldT): every lane of a wave owns NVL of the wave's 8 L / 64 * 64 sums
+        const int L = s->plan.L, NVL = 8 * L / 64;
+        const int64_t nwaves = s->macc_stride / 64;
+        for (int64_t w = 0; w < nwaves; ++w)
+            for (int r = 0; r < NVL; ++r)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int b3 = (lane >> 3) & 1, b4 = (lane >> 4) & 1, b5 = (lane >> 5) & 1;
+                    const int v = L == 8 ? 4 * b3 + 2 * b4 + b5 : L == 16 ? 4 * b4 + 2 * b5 + r : 4 * b5 + r;
+                    const int64_t d = 2 * ((int64_t)((v >> 1) & 1) * L + (lane & (L - 1))) + (v & 1);
+                    if (d >= nd) continue;
+                    const double x = hs[(size_t)((w * NVL + r) * 64 + lane)];
+                    if (v >> 2) Q[(size_t)d] += x; else S[(size_t)d] += x;
+                }
+    } else if (s->plan.vec) {
         const int L = s->plan.L, K = s->plan.K;
         for (int k = 0; k < K; ++k)
             for (int64_t t = 0; t < s->macc_stride; ++t) {

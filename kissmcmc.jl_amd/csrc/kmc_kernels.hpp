@@ -170,13 +170,67 @@ __device__ __forceinline__ double2 sel2(bool c, const double2& a, const double2&
 // ------------------------------------------------------------------------------------------
 // Vector kernel.
 // ------------------------------------------------------------------------------------------
-// Fold the wave's G groups (same dimensions, different walkers) into group 0 and add the result to
-// that wave's accumulator slots: 1/G of the accumulator traffic for a few cross-lane moves.
+// Fold the wave's G groups (same dimensions, different walkers) and add the result to that wave's accumulator
+// slots.  Two forms:
+//   * transposed (K == 2, L = 8/16/32 -- ndim 17..128): a reduce-scatter over the groups.  At each butterfly level a
+//     lane keeps half of its values and hands the other half to its partner (v_permlane{16,32}_swap do exactly this
+//     exchange in one instruction per word), so the 8 per-lane sums {sum x, sum x^2} x {4 elements} shrink to
+//     8 L / 64 values per lane, every lane ends up owning a different piece, and the accumulator update is one
+//     coalesced 8-byte read-modify-write per lane: a third of the cross-lane instructions of the plain butterfly.
+//     Lane l keeps, as its r-th value, original index  L = 8: 4 b3 + 2 b4 + b5;  L = 16: 4 b4 + 2 b5 + r;
+//     L = 32: 4 b5 + r  (b_i = bit i of l); index = which * 4 + k * 2 + xy, element 2 (k L + l mod L) + xy.
+//     Slot of (wave w, r, lane l): msum[(w * NVL + r) * 64 + l]; msumsq is unused.
+//   * plain: every value folded into group 0, whose lanes update [K][threads] double2 slots.
+template <int L, int K>
+struct FoldT {
+    static constexpr bool on = (K == 2) && (L == 8 || L == 16 || L == 32);
+    static constexpr int NVL = on ? (8 * L) / 64 : 1;
+};
+
+__device__ __forceinline__ double swap16_sum(double a, double b)
+{   // even 16-lane rows: a + a of the odd partner row; odd rows: b + b of the even partner row
+    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ __forceinline__ double swap32_sum(double a, double b)
+{   // lanes < 32: a + a of lane + 32; lanes >= 32: b + b of lane - 32
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+
 template <int L, int K, bool HAVE_OLD>
 __device__ __forceinline__ void accumulate_wave(double* msum, double* msumsq, int64_t stride, int tid, int g,
                                                 double2 (&ms)[K], double2 (&mq)[K],
-                                                const double2 (&olds)[K], const double2 (&oldq)[K])
+                                                const double2 (&olds)[K], const double2 (&oldq)[K], const double (&oldt)[4])
 {
+    if constexpr (FoldT<L, K>::on) {
+        constexpr int NVL = FoldT<L, K>::NVL;
+        const int lane = tid & 63;
+        double v[8] = {ms[0].x, ms[0].y, ms[1].x, ms[1].y, mq[0].x, mq[0].y, mq[1].x, mq[1].y};
+        int n = 8;
+        if constexpr (L == 8) {                          // lane ^ 8, inside the 16-lane row
+            const bool hi = (lane & 8) != 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const double keep = hi ? v[i + 4] : v[i], send = hi ? v[i] : v[i + 4];
+                v[i] = keep + dpp_f64<0x128>(send);      // row_ror:8
+            }
+            n = 4;
+        }
+        if constexpr (L <= 16) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (i < n / 2) v[i] = swap16_sum(v[i], v[i + n / 2]);
+            n /= 2;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (i < n / 2) v[i] = swap32_sum(v[i], v[i + n / 2]);
+        double* slot = msum + ((int64_t)(tid >> 6) * NVL) * 64 + lane;
+#pragma unroll
+        for (int r = 0; r < NVL; ++r) slot[r * 64] = (HAVE_OLD ? oldt[r] : slot[r * 64]) + v[r];
+        return;
+    }
     if constexpr (L < 64) {
 #pragma unroll
         for (int k = 0; k < K; ++k) {
@@ -300,7 +354,13 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
     // keep that latency off the kernel's tail; large rows: fetch only when needed
     constexpr bool kPrefetchAcc = K <= 2;
     double2 accs[K], accq[K];
-    if constexpr (kPrefetchAcc) {
+    double  acct[4] = {0.0, 0.0, 0.0, 0.0};
+    if constexpr (FoldT<L, K>::on) {
+        if (do_mom) {
+#pragma unroll
+            for (int r = 0; r < FoldT<L, K>::NVL; ++r) acct[r] = a.msum[((int64_t)(tid >> 6) * FoldT<L, K>::NVL + r) * 64 + lane];
+        }
+    } else if constexpr (kPrefetchAcc) {
         if (do_mom && g == 0) {
 #pragma unroll
             for (int k = 0; k < K; ++k) {
@@ -324,44 +384,61 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
     }
     KMC_STAMP(1);
 
-    // ---- scalar -> row: the partner of slot it*G+g lives in lane gbase+it; get the partner-row
-    //      loads in flight before the logarithms ---------------------------------------------
-    if constexpr (!P2P) {
-#pragma unroll
-        for (int it = 0; it < ITER; ++it) {
-            const uint32_t partner = (uint32_t)__builtin_amdgcn_ds_bpermute((gbase + it) * 4, (int)partnerA);
-            const double2* oth = reinterpret_cast<const double2*>(f.pos + (oth_row0 + partner) * ld);
-#pragma unroll
-            for (int k = 0; k < K; ++k) xo[it][k] = cv[k] ? oth[k * L + j] : zero2;
-        }
-    } else {
+    // ---- scalar -> row: the partner of slot it*G+g lives in lane gbase+it.  The partner-row loads of the first
+    //      half of the iterations go out, then the first logarithm, then the other half, then the second
+    //      logarithm: measured best at C2 (all loads first: +0.15 us per half-step; loads after both logs: same),
+    //      and pinned with scheduling barriers because the compiler's own placement moves with unrelated edits ----
+    unsigned long long addrA = 0ull;                                    // P2P: the partner row's address
+    if constexpr (P2P) {
         // owner rank and row of the partner, resolved once per walker; the row address travels
         const uint32_t q = a.hloc_shift >= 0 ? partnerA >> a.hloc_shift : partnerA / a.hloc;
         const uint32_t r = partnerA - q * a.hloc;
         const double* base = a.peer_pos[0];
 #pragma unroll
         for (int t = 1; t < 8; ++t) base = (q == (uint32_t)t) ? a.peer_pos[t] : base;
-        const unsigned long long addrA = (unsigned long long)(base + (oth_row0 + r) * ld);
+        addrA = (unsigned long long)(base + (oth_row0 + r) * ld);
         if (a.nranks > 1) {
             // every rank must have finished half-step `step - 1`: one polling wave per workgroup (the
             // flags sit in uncached fine-grained memory), the other waves wait at the barrier
             if ((threadIdx.x >> 6) == 0) wait_for_peers(a, step, lane);
             __syncthreads();
         }
-#pragma unroll
-        for (int it = 0; it < ITER; ++it) {
+    }
+    auto load_partner_rows = [&](int it) {
+        const double2* oth;
+        if constexpr (!P2P) {
+            const uint32_t partner = (uint32_t)__builtin_amdgcn_ds_bpermute((gbase + it) * 4, (int)partnerA);
+            oth = reinterpret_cast<const double2*>(f.pos + (oth_row0 + partner) * ld);
+        } else {
             const int src = (gbase + it) * 4;
             const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)(unsigned)addrA);
             const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)(unsigned)(addrA >> 32));
-            const double2* oth = reinterpret_cast<const double2*>(((unsigned long long)hi << 32) | lo);
-#pragma unroll
-            for (int k = 0; k < K; ++k) xo[it][k] = cv[k] ? oth[k * L + j] : zero2;
+            oth = reinterpret_cast<const double2*>(((unsigned long long)hi << 32) | lo);
         }
-    }
+#pragma unroll
+        for (int k = 0; k < K; ++k) xo[it][k] = cv[k] ? oth[k * L + j] : zero2;
+    };
+    constexpr int kFirst = ITER >= 2 ? ITER / 2 : ITER;                 // iterations whose loads precede the first logarithm
+#pragma unroll
+    for (int it = 0; it < kFirst; ++it) load_partner_rows(it);
+    __builtin_amdgcn_sched_barrier(0);
     Draw dr;
     dr.partner = partnerA; dr.z = e1.x; dr.t1 = e0.x; dr.lu = e0.y;
+    double ua = 0.5;
+    if (!fresh) {                                                       // the arithmetic of draw_finish, in two parts
+        const double uz = ((double)bits.y + 0.5) * 0x1.0p-32;
+        const double t  = fma(uz, dc.c1, dc.c0);
+        dr.z = t * t;                                                   // :252
+        const uint64_t kk = ((uint64_t)bits.z << 20) | (uint64_t)(bits.w >> 12);
+        ua = ((double)kk + 0.5) * 0x1.0p-52;
+        dr.t1 = dc.nm1 * log(dr.z);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int it = kFirst; it < ITER; ++it) load_partner_rows(it);
+    __builtin_amdgcn_sched_barrier(0);
     if (!fresh) {
-        dr = draw_finish(dc, bits);                                     // :252, log z, log u
+        dr.lu = log(ua);                                                // :260
         if constexpr (kRing) {
             if (ring_on && jq >= 1 && jq < Q && iA < nact) {            // park the walkers' next steps
                 double2* slot = a.ring + ((int64_t)((a.ring_slot + jq) & 3) * a.ring_rows + rowA) * 2;
@@ -429,8 +506,8 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
         }
     }
     if (any_w) {
-        if constexpr (kPrefetchAcc) accumulate_wave<L, K, true>(a.msum, a.msumsq, a.macc_stride, tid, g, ms, mq, accs, accq);
-        else accumulate_wave<L, K, false>(a.msum, a.msumsq, a.macc_stride, tid, g, ms, mq, accs, accq);
+        if constexpr (kPrefetchAcc) accumulate_wave<L, K, true>(a.msum, a.msumsq, a.macc_stride, tid, g, ms, mq, accs, accq, acct);
+        else accumulate_wave<L, K, false>(a.msum, a.msumsq, a.macc_stride, tid, g, ms, mq, accs, accq, acct);
     }
     KMC_STAMP(3);
 #ifdef KMC_PROBE
@@ -493,7 +570,8 @@ __global__ __launch_bounds__(kTPB) void flush_moments_vec(const FlushArgs a)
         const int i = w0 + it * G + g;
         if (i < a.n_active && j == 0) a.klast[a.row0 + i] = a.nsamp;
     }
-    accumulate_wave<L, K, false>(a.msum, a.msumsq, a.macc_stride, tid, g, ms, mq, ms, mq);
+    const double none[4] = {0.0, 0.0, 0.0, 0.0};
+    accumulate_wave<L, K, false>(a.msum, a.msumsq, a.macc_stride, tid, g, ms, mq, ms, mq, none);
 }
 
 // ------------------------------------------------------------------------------------------
