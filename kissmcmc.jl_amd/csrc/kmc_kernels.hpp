@@ -140,6 +140,9 @@ __device__ __forceinline__ SchedEntry schedule_of(const HalfStepFront& f, const 
     const SchedEntry* p = f.sched;               // always a valid entry address (entry 0 for eager launches)
     u32x8 r;
     asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(p));
+    // the in-args copy is requested together with the rest of the struct, not lazily after this wait
+    asm volatile("" :: "s"(a.sched_index), "s"(a.sched_inline.gen), "s"(a.sched_inline.slot), "s"(a.sched_inline.flags),
+                 "s"(a.sched_inline.nbefore));
     const bool inl = a.sched_index < 0;
     SchedEntry t;
     t.gen     = inl ? a.sched_inline.gen     : (int64_t)(((uint64_t)r[1] << 32) | r[0]);
@@ -341,6 +344,10 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
     }
 
     const SchedEntry sch = schedule_of(f, a);
+    // one scalar round trip for the whole argument struct and the schedule entry: have every field the kernel uses
+    // later requested by now (otherwise the compiler fetches some lazily, a second round trip in front of Philox)
+    asm volatile("" :: "s"(a.logp), "s"(a.naccept), "s"(a.chain), "s"(a.chain_logp), "s"(a.chain_rows), "s"(a.chain_row0),
+                 "s"(a.msum), "s"(a.msumsq), "s"(a.macc_stride), "s"(a.klast));
     const bool count  = (sch.flags & kCount) != 0;
     const bool sample = (sch.flags & kSample) != 0;
     const uint64_t step = 2ull * (uint64_t)sch.gen + (uint64_t)f.half;
