@@ -121,6 +121,7 @@ def main():
         elapsed = time.perf_counter() - t0
         event_ms = s.last_run_ms()               # HIP events on the sampler's own stream
         launches = s.launch_count
+        how = s.describe()
         msum, msq, nmom = s.moments()
         acc = float(s.accept_ratio().mean())
         s.close()
@@ -282,7 +283,8 @@ def main():
             "config": {"workload": f"C2: emcee stretch move, {NWALKERS_PER_GPU} walkers/GPU x {NDIM}-dim isotropic Gaussian, "
                                    f"{G} generations (burn-in {nburn}), a=2, streaming moments on, chain off",
                        "nwalkers_total": nw, "ndim": NDIM, "generations": G, "gens_per_step": GENS_PER_STEP,
-                       "parallelism": "single GPU" if world == 1 else parallelism},
+                       "parallelism": "single GPU" if world == 1 else parallelism,
+                       "execution": how if world == 1 else None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "half_step_vec<GaussianIso>", "launches": launches, "avg_launch_us": launch_us,

@@ -456,8 +456,19 @@ struct kmc_sampler {
     int64_t generation = 0;   // generations enqueued so far
     int64_t dev_gen = 0;      // value the device counter will hold once the stream drains
     int64_t launches = 0;
+    int launch_mode = 0;      // 0: not decided, 1: table graph, 2: eager launches, 3: updated graph (kmc_sampler_run)
+    float calib_graph_ms = 0.f, calib_eager_ms = 0.f;   // one chunk each, when measured
     hipGraphExec_t graph_exec = nullptr;
     hipGraph_t graph = nullptr;
+    // "updated graph": a chain of kGraphChunk * 2 kernel nodes launched in the eager form (step among the preloaded
+    // parameters, schedule entry in the args), their parameters rewritten before every replay; two executables
+    // alternate so that one is updated while the other runs
+    hipGraph_t ugraph = nullptr;
+    hipGraphExec_t uexec[2] = {nullptr, nullptr};
+    hipEvent_t udone[2] = {nullptr, nullptr};
+    bool uinflight[2] = {false, false};
+    int unext = 0;
+    std::vector<hipGraphNode_t> unodes;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool have_run_events = false;
     bool positions_set = false;
@@ -543,8 +554,9 @@ HalfStepFront front_of(const HalfStepArgs& a)
 {
     HalfStepFront f{};
     f.pos = a.pos;
-    f.sched = a.sched_table + (a.sched_index < 0 ? 0 : a.sched_index);
-    f.gw0 = a.gw0;
+    f.sched = a.sched_index < 0 ? nullptr : a.sched_table + a.sched_index;
+    f.step = (uint32_t)(2ull * (uint64_t)a.sched_inline.gen + (uint64_t)a.half);       // used when sched == nullptr
+    f.gw0 = (uint32_t)a.gw0;
     f.own_row0 = (int32_t)a.own_row0;
     f.n_active = a.n_active;
     f.ring_now = a.ring ? a.ring + (int64_t)a.ring_slot * a.ring_rows * 2 : nullptr;
@@ -558,7 +570,7 @@ struct HalfStepLaunch {
     HalfStepFront f;
     HalfStepArgs  a;
 };
-static_assert(offsetof(HalfStepLaunch, a) == 56 && offsetof(HalfStepFront, ring_now) == 32 && offsetof(HalfStepFront, half) == 52, "kernarg layout of the half-step kernels");
+static_assert(offsetof(HalfStepLaunch, a) == 56 && offsetof(HalfStepFront, ring_now) == 16 && offsetof(HalfStepFront, step) == 52, "kernarg layout of the half-step kernels");
 
 hipError_t launch_half_kernel(const kmc_sampler* s, const HalfStepArgs& a);
 
@@ -589,8 +601,8 @@ hipError_t launch_half_kernel(const kmc_sampler* s, const HalfStepArgs& a)
         const HalfStepLaunch la{f, a};
         return launch_module(s->plan.vec ? s->uk.vec : s->uk.generic, (unsigned)s->grid, (unsigned)s->tpb, s->stream, la);
     }
-    hipLaunchKernelGGL(s->plan.fn, dim3(s->grid), dim3(s->tpb), 0, s->stream, f.pos, f.sched, f.gw0, f.own_row0, f.n_active,
-                       f.ring_now, f.seed_lo, f.seed_hi, f.nhalf, f.half, a);
+    hipLaunchKernelGGL(s->plan.fn, dim3(s->grid), dim3(s->tpb), 0, s->stream, f.pos, f.sched, f.ring_now, f.gw0, f.own_row0, f.n_active,
+                       f.seed_lo, f.seed_hi, f.nhalf, f.half, f.step, a);
     return hipGetLastError();
 }
 
@@ -625,6 +637,82 @@ kmc_status ensure_graph(kmc_sampler* s)
     HIP_TRY(e);
     s->graph = graph;
     HIP_TRY(hipGraphInstantiate(&s->graph_exec, graph, nullptr, nullptr, 0));
+    return KMC_OK;
+}
+
+// ---- updated graph --------------------------------------------------------------------------------------
+struct KernelParamPack {      // storage the kernelParams pointers of one node refer to
+    HalfStepFront f;
+    HalfStepArgs a;
+    void* ptrs[12];
+    void bind()
+    {
+        ptrs[0] = &f.pos; ptrs[1] = &f.sched; ptrs[2] = &f.ring_now; ptrs[3] = &f.gw0; ptrs[4] = &f.own_row0; ptrs[5] = &f.n_active;
+        ptrs[6] = &f.seed_lo; ptrs[7] = &f.seed_hi; ptrs[8] = &f.nhalf; ptrs[9] = &f.half; ptrs[10] = &f.step; ptrs[11] = &a;
+    }
+};
+
+hipKernelNodeParams node_params(const kmc_sampler* s, KernelParamPack* pk)
+{
+    hipKernelNodeParams np{};
+    np.func = reinterpret_cast<void*>(s->plan.fn);
+    np.gridDim = dim3((unsigned)s->grid);
+    np.blockDim = dim3((unsigned)s->tpb);
+    np.sharedMemBytes = 0;
+    np.kernelParams = pk->ptrs;
+    np.extra = nullptr;
+    return np;
+}
+
+bool updated_graph_possible(const kmc_sampler* s)
+{
+    return !s->user && !s->p2p && !s->host_eval && !s->islands && !s->resident && s->plan.fn != nullptr;
+}
+
+kmc_status ensure_updated_graph(kmc_sampler* s)
+{
+    if (s->uexec[0]) return KMC_OK;
+    HIP_TRY(hipGraphCreate(&s->ugraph, 0));
+    s->unodes.assign((size_t)(2 * kGraphChunk), nullptr);
+    KernelParamPack pk;
+    pk.bind();
+    hipGraphNode_t prev = nullptr;
+    for (int64_t g = 0; g < kGraphChunk; ++g)
+        for (int half = 0; half < 2; ++half) {
+            pk.a = make_args(s, half, false, g);
+            pk.f = front_of(pk.a);
+            const hipKernelNodeParams np = node_params(s, &pk);
+            hipGraphNode_t node = nullptr;
+            HIP_TRY(hipGraphAddKernelNode(&node, s->ugraph, prev ? &prev : nullptr, prev ? 1 : 0, &np));
+            s->unodes[(size_t)(2 * g + half)] = node;
+            prev = node;
+        }
+    for (int i = 0; i < 2; ++i) {
+        HIP_TRY(hipGraphInstantiate(&s->uexec[i], s->ugraph, nullptr, nullptr, 0));
+        HIP_TRY(hipEventCreateWithFlags(&s->udone[i], hipEventDisableTiming));
+    }
+    return KMC_OK;
+}
+
+// one replay of kGraphChunk generations starting at s->generation
+kmc_status launch_updated_graph(kmc_sampler* s)
+{
+    KMC_TRY(ensure_updated_graph(s));
+    const int i = s->unext;
+    if (s->uinflight[i]) { HIP_TRY(hipEventSynchronize(s->udone[i])); s->uinflight[i] = false; }
+    KernelParamPack pk;
+    pk.bind();
+    for (int64_t g = 0; g < kGraphChunk; ++g)
+        for (int half = 0; half < 2; ++half) {
+            pk.a = make_args(s, half, false, s->generation + g);
+            pk.f = front_of(pk.a);
+            const hipKernelNodeParams np = node_params(s, &pk);
+            HIP_TRY(hipGraphExecKernelNodeSetParams(s->uexec[i], s->unodes[(size_t)(2 * g + half)], &np));
+        }
+    HIP_TRY(hipGraphLaunch(s->uexec[i], s->stream));
+    HIP_TRY(hipEventRecord(s->udone[i], s->stream));
+    s->uinflight[i] = true;
+    s->unext = 1 - i;
     return KMC_OK;
 }
 
@@ -695,8 +783,9 @@ KMC_EXPORT kmc_status kmc_validate(const kmc_config* c)
     if (!(c->a_scale > 1.0)) return fail(KMC_ERR_A_SCALE, kmc_status_string(KMC_ERR_A_SCALE));
     if (c->nwalkers % 2 != 0) return fail(KMC_ERR_ODD_WALKERS, kmc_status_string(KMC_ERR_ODD_WALKERS));
     if (c->nwalkers < c->ndim + 2) return fail(KMC_ERR_TOO_FEW_WALKERS, kmc_status_string(KMC_ERR_TOO_FEW_WALKERS));
-    if (c->nwalkers / 2 >= (int64_t)1 << 31 || c->ndim >= (int64_t)1 << 24)
+    if (c->nwalkers >= (int64_t)1 << 31 || c->ndim >= (int64_t)1 << 24)
         return fail(KMC_ERR_UNSUPPORTED, "ensemble too large");
+    if (c->ngenerations >= (int64_t)1 << 31) return fail(KMC_ERR_UNSUPPORTED, "at most 2^31 - 1 generations (the step index is 32 bits)");
     if (c->density == KMC_USER_DENSITY && !c->user_density) return fail(KMC_ERR_BAD_ARG, "KMC_USER_DENSITY needs kmc_config.user_density");
     if (c->density == KMC_HOST_DENSITY) {
         if (!c->host_logpdf) return fail(KMC_ERR_BAD_ARG, "KMC_HOST_DENSITY needs kmc_config.host_logpdf");
@@ -932,6 +1021,11 @@ KMC_EXPORT void kmc_sampler_destroy(kmc_sampler* s)
     if (!s) return;
     (void)hipSetDevice(s->cfg.device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
+    for (int i = 0; i < 2; ++i) {
+        if (s->uexec[i]) (void)hipGraphExecDestroy(s->uexec[i]);
+        if (s->udone[i]) (void)hipEventDestroy(s->udone[i]);
+    }
+    if (s->ugraph) (void)hipGraphDestroy(s->ugraph);
     if (s->graph_exec) (void)hipGraphExecDestroy(s->graph_exec);
     if (s->uk.mod) (void)hipModuleUnload(s->uk.mod);
     if (s->graph) (void)hipGraphDestroy(s->graph);
@@ -988,6 +1082,11 @@ KMC_EXPORT kmc_status kmc_sampler_bind_positions(kmc_sampler* s, void* pos_dev)
     HIP_TRY(hipStreamSynchronize(s->stream));
     if (s->graph_exec) { (void)hipGraphExecDestroy(s->graph_exec); s->graph_exec = nullptr; }
     if (s->graph) { (void)hipGraphDestroy(s->graph); s->graph = nullptr; }
+    for (int i = 0; i < 2; ++i) {
+        if (s->uexec[i]) { (void)hipGraphExecDestroy(s->uexec[i]); s->uexec[i] = nullptr; }
+        s->uinflight[i] = false;
+    }
+    if (s->ugraph) { (void)hipGraphDestroy(s->ugraph); s->ugraph = nullptr; }
     if (s->own_pos) (void)hipFree(s->d_pos);
     s->d_pos = static_cast<double*>(pos_dev);
     s->own_pos = false;
@@ -1229,6 +1328,7 @@ KMC_EXPORT kmc_status kmc_sampler_run(kmc_sampler* s, int64_t ngen)
     if (s->cfg.shard_count != 1 && !s->p2p)
         return fail(KMC_ERR_UNSUPPORTED, "kmc_sampler_run needs shard_count == 1 or KMC_P2P; replica-sharded drivers call kmc_sampler_half_step");
     if (s->p2p && !s->connected) return fail(KMC_ERR_BAD_ARG, "kmc_sampler_p2p_connect has not been called");
+    if (s->generation + ngen >= (int64_t)1 << 31) return fail(KMC_ERR_UNSUPPORTED, "at most 2^31 - 1 generations (the step index is 32 bits)");
     HIP_TRY(hipSetDevice(s->cfg.device));
     HIP_TRY(hipEventRecord(s->ev0, s->stream));
     if (s->resident) {
@@ -1322,8 +1422,7 @@ KMC_EXPORT kmc_status kmc_sampler_run(kmc_sampler* s, int64_t ngen)
         s->have_run_events = true;
         return KMC_OK;
     }
-    const bool use_graph = !(s->cfg.flags & KMC_NO_GRAPH);
-    while (use_graph && ngen >= kGraphChunk) {
+    auto graph_chunk = [&]() -> kmc_status {
         KMC_TRY(ensure_graph(s));
         KMC_TRY(sync_device_counter(s));
         HIP_TRY(hipGraphLaunch(s->graph_exec, s->stream));
@@ -1331,12 +1430,66 @@ KMC_EXPORT kmc_status kmc_sampler_run(kmc_sampler* s, int64_t ngen)
         s->dev_gen += kGraphChunk;
         s->launches += 2 * kGraphChunk;
         ngen -= kGraphChunk;
+        return KMC_OK;
+    };
+    auto eager_generations = [&](int64_t n) -> kmc_status {
+        for (; n > 0; --n, --ngen) {
+            for (int half = 0; half < 2; ++half) KMC_TRY(launch_half(s, half, false, s->generation));
+            s->generation += 1;
+            s->launches += 2;
+        }
+        return KMC_OK;
+    };
+    auto updated_chunk = [&]() -> kmc_status {
+        KMC_TRY(launch_updated_graph(s));
+        s->generation += kGraphChunk;
+        s->launches += 2 * kGraphChunk;
+        ngen -= kGraphChunk;
+        return KMC_OK;
+    };
+    // How to issue the launches?  Same kernels, same results, three ways:
+    //   1 table graph   -- hipGraph replay; the kernels read their generation from a device table (one scalar round
+    //                      trip in front of Philox);
+    //   2 eager         -- the step travels among the preloaded kernel parameters, Philox starts at wave entry (C2:
+    //                      4.15 against 4.35 us per half-step) -- while the host launches faster than the GPU drains;
+    //                      measured: it does for ~2000 launches, then settles at ~4.8 us per launch;
+    //   3 updated graph -- the eager form of the kernels inside a graph whose node parameters are rewritten before
+    //                      every replay (two executables alternate).
+    // A long run measures 1 against 3 once (four chunks each, HIP events: a starved GPU shows as idle time between
+    // the events) and keeps the faster; KMC_LAUNCH=graph|eager|updated decides without measuring.
+    bool use_graph = !(s->cfg.flags & KMC_NO_GRAPH);
+    if (use_graph && s->launch_mode == 0) {
+        const char* env = std::getenv("KMC_LAUNCH");
+        if (env && std::strcmp(env, "graph") == 0) s->launch_mode = 1;
+        else if (env && std::strcmp(env, "eager") == 0) s->launch_mode = 2;
+        else if (env && std::strcmp(env, "updated") == 0 && updated_graph_possible(s)) s->launch_mode = 3;
+        else if (!updated_graph_possible(s)) s->launch_mode = 1;
+        else if (ngen >= 12 * kGraphChunk) {
+            hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+            HIP_TRY(hipEventCreate(&e0));
+            HIP_TRY(hipEventCreate(&e1));
+            HIP_TRY(hipEventCreate(&e2));
+            kmc_status st = graph_chunk();                                    // warm: instantiation, code objects
+            if (st == KMC_OK) st = updated_chunk();
+            if (st == KMC_OK) st = updated_chunk();
+            if (st == KMC_OK && hipEventRecord(e0, s->stream) != hipSuccess) st = KMC_ERR_HIP;
+            for (int r = 0; r < 4 && st == KMC_OK; ++r) st = graph_chunk();
+            if (st == KMC_OK && hipEventRecord(e1, s->stream) != hipSuccess) st = KMC_ERR_HIP;
+            for (int r = 0; r < 4 && st == KMC_OK; ++r) st = updated_chunk();
+            if (st == KMC_OK && hipEventRecord(e2, s->stream) != hipSuccess) st = KMC_ERR_HIP;
+            float tg = 0.f, tu = 0.f;
+            if (st == KMC_OK && (hipEventSynchronize(e2) != hipSuccess || hipEventElapsedTime(&tg, e0, e1) != hipSuccess ||
+                                 hipEventElapsedTime(&tu, e1, e2) != hipSuccess)) st = KMC_ERR_HIP;
+            (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
+            if (st != KMC_OK) return st == KMC_ERR_HIP ? fail(st, "launch-mode calibration failed") : st;
+            s->launch_mode = tu < 0.98f * tg ? 3 : 1;                         // the updated graph must win clearly
+            s->calib_graph_ms = tg / 4.f; s->calib_eager_ms = tu / 4.f;
+        }
     }
-    for (; ngen > 0; --ngen) {
-        for (int half = 0; half < 2; ++half) KMC_TRY(launch_half(s, half, false, s->generation));
-        s->generation += 1;
-        s->launches += 2;
-    }
+    if (s->launch_mode == 2) use_graph = false;
+    if (s->launch_mode == 3) { while (use_graph && ngen >= kGraphChunk) KMC_TRY(updated_chunk()); }
+    else { while (use_graph && ngen >= kGraphChunk) KMC_TRY(graph_chunk()); }
+    KMC_TRY(eager_generations(ngen));
     HIP_TRY(hipEventRecord(s->ev1, s->stream));
     s->have_run_events = true;
     return KMC_OK;
@@ -1350,6 +1503,7 @@ KMC_EXPORT kmc_status kmc_sampler_half_step(kmc_sampler* s, int half)
     if (s->islands) return fail(KMC_ERR_UNSUPPORTED, "island mode advances whole generations: use kmc_sampler_run");
     if (s->host_eval) return fail(KMC_ERR_UNSUPPORTED, "KMC_HOST_DENSITY: a half-step includes the host callback; use kmc_sampler_run");
     if (s->resident) return fail(KMC_ERR_UNSUPPORTED, "this small ensemble runs in resident mode (whole generations per launch); create it with KMC_NO_GRAPH to step by halves");
+    if (s->generation >= ((int64_t)1 << 31) - 1) return fail(KMC_ERR_UNSUPPORTED, "at most 2^31 - 1 generations (the step index is 32 bits)");
     HIP_TRY(hipSetDevice(s->cfg.device));
     KMC_TRY(launch_half(s, half, false, s->generation));
     s->launches += 1;
@@ -1402,11 +1556,18 @@ KMC_EXPORT kmc_status kmc_sampler_describe(const kmc_sampler* s, char* buf, int6
     else if (s->host_eval)
         o << "host-evaluated density (exact): per half-step propose kernel -> D2H -> callback -> H2D -> accept kernel, grid "
           << s->grid << " x 256";
-    else if (s->plan.vec)
+    else if (s->plan.vec) {
         o << "multi-launch (exact): half_step_vec L=" << s->plan.L << " K=" << s->plan.K << " ITER=" << s->plan.ITER
           << (s->plan.ragged ? " ragged" : " exact-size") << ", grid " << s->grid << " x " << s->tpb
-          << ((s->cfg.flags & KMC_NO_GRAPH) ? ", eager launches" : ", hipGraph replay of 64 generations");
-    else
+          << (((s->cfg.flags & KMC_NO_GRAPH) || s->launch_mode == 2) ? ", eager launches"
+              : s->launch_mode == 3 ? ", hipGraph replay of 64 generations with per-replay parameter updates (step preloaded)"
+                                    : ", hipGraph replay of 64 generations");
+        if (s->calib_graph_ms > 0.f) {
+            char b[128];
+            std::snprintf(b, sizeof(b), " (measured per 64 generations: table graph %.3f ms, updated graph %.3f ms)", s->calib_graph_ms, s->calib_eager_ms);
+            o << b;
+        }
+    } else
         o << "multi-launch (exact): half_step_generic (one walker per lane), grid " << s->grid << " x 256";
     if (s->user) o << "; runtime-compiled density";
     if (s->p2p) o << "; P2P shard " << s->cfg.shard_rank << "/" << s->cfg.shard_count << (s->connected ? "" : " (not connected)");

@@ -116,40 +116,41 @@ struct HalfStepArgs {
 // ordinary kernel arguments -- same code, same results.
 struct HalfStepFront {
     double*           pos;        // = HalfStepArgs::pos
-    const SchedEntry* sched;      // this launch's schedule entry (sched_table + sched_index; entry 0 when sched_index < 0)
-    int64_t           gw0;        // = HalfStepArgs::gw0
-    int32_t           own_row0;   // = HalfStepArgs::own_row0 (rows fit 31 bits: nwalkers < 2^31); the complementary half
-    int32_t           n_active;   //   starts at row (1 - half) * (P2P ? n_active : nhalf)
+    const SchedEntry* sched;      // this launch's schedule entry (sched_table + sched_index), or nullptr: eager launch, the
+                                  //   entry travels in the args (sched_inline) and the step below
     const double2*    ring_now;   // draw ring, slot of THIS generation: entry of row r at ring_now[2 r] (nullptr: no ring)
+    uint32_t          gw0;        // = HalfStepArgs::gw0 (walker indices fit 31 bits)
+    int32_t           own_row0;   // = HalfStepArgs::own_row0; the complementary half starts at row
+    int32_t           n_active;   //   (1 - half) * (P2P ? n_active : nhalf)
     uint32_t          seed_lo, seed_hi, nhalf;
     int32_t           half;
-};
-#define KMC_FRONT_PARAMS double* f_pos, const kmc::SchedEntry* f_sched, int64_t f_gw0, int32_t f_own_row0, int32_t f_n_active, \
-                         const double2* f_ring_now, uint32_t f_seed_lo, uint32_t f_seed_hi, uint32_t f_nhalf, int32_t f_half
-#define KMC_FRONT_PACK kmc::HalfStepFront{f_pos, f_sched, f_gw0, f_own_row0, f_n_active, f_ring_now, f_seed_lo, f_seed_hi, f_nhalf, f_half}
-#define KMC_FRONT_TYPES double*, const kmc::SchedEntry*, int64_t, int32_t, int32_t, const double2*, uint32_t, uint32_t, uint32_t, int32_t
+    uint32_t          step;       // sched == nullptr (eager launch): 2 * generation + half, known at launch time (< 2^32)
+};                                // 14 dwords: all of it is preloaded (16 user SGPRs - 2 for the kernarg pointer)
+#define KMC_FRONT_PARAMS double* f_pos, const kmc::SchedEntry* f_sched, const double2* f_ring_now, uint32_t f_gw0, int32_t f_own_row0, \
+                         int32_t f_n_active, uint32_t f_seed_lo, uint32_t f_seed_hi, uint32_t f_nhalf, int32_t f_half, uint32_t f_step
+#define KMC_FRONT_PACK kmc::HalfStepFront{f_pos, f_sched, f_ring_now, f_gw0, f_own_row0, f_n_active, f_seed_lo, f_seed_hi, f_nhalf, f_half, f_step}
+#define KMC_FRONT_TYPES double*, const kmc::SchedEntry*, const double2*, uint32_t, int32_t, int32_t, uint32_t, uint32_t, uint32_t, int32_t, uint32_t
 
-// One scalar load of the whole 32-byte entry (s_load_dwordx8; the scalar cache is invalidated at
-// kernel start and the table is only written by advance_schedule between launches), issued as soon
-// as the kernarg is in: nothing in the kernel's prologue waits on vector memory, and the entry is one
-// round trip instead of one per field.  sched_index < 0: the entry travels in the args (eager
-// launches); sched_table is a valid pointer either way.
-__device__ __forceinline__ SchedEntry schedule_of(const HalfStepFront& f, const HalfStepArgs& a)
+// Graph replay: one scalar load of the whole 32-byte entry (s_load_dwordx8; the scalar cache is invalidated at
+// kernel start and the table is only written by advance_schedule between launches) -- one round trip, issued
+// together with the rest of the argument struct.  Eager launch (f.sched == nullptr): the entry is in the args and
+// the step among the preloaded parameters, so Philox starts at wave entry without waiting for memory at all.
+__device__ __forceinline__ SchedEntry schedule_entry(const HalfStepFront& f)
 {
     typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
-    const SchedEntry* p = f.sched;               // always a valid entry address (entry 0 for eager launches)
     u32x8 r;
-    asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(p));
-    // the in-args copy is requested together with the rest of the struct, not lazily after this wait
-    asm volatile("" :: "s"(a.sched_index), "s"(a.sched_inline.gen), "s"(a.sched_inline.slot), "s"(a.sched_inline.flags),
-                 "s"(a.sched_inline.nbefore));
-    const bool inl = a.sched_index < 0;
+    asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(f.sched));
     SchedEntry t;
-    t.gen     = inl ? a.sched_inline.gen     : (int64_t)(((uint64_t)r[1] << 32) | r[0]);
-    t.slot    = inl ? a.sched_inline.slot    : (int64_t)(((uint64_t)r[3] << 32) | r[2]);
-    t.flags   = inl ? a.sched_inline.flags   : r[4];
-    t.nbefore = inl ? a.sched_inline.nbefore : r[5];
+    t.gen     = (int64_t)(((uint64_t)r[1] << 32) | r[0]);
+    t.slot    = (int64_t)(((uint64_t)r[3] << 32) | r[2]);
+    t.flags   = r[4];
+    t.nbefore = r[5];
     return t;
+}
+__device__ __forceinline__ SchedEntry schedule_of(const HalfStepFront& f, const HalfStepArgs& a)
+{
+    if (f.sched == nullptr) return a.sched_inline;
+    return schedule_entry(f);
 }
 
 // Row store.  KMC_STORE_SC1: write-through (sc1) so the kernel leaves no dirty lines for the
@@ -343,53 +344,24 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
         for (int k = 0; k < K; ++k) xc[it][k] = cv[k] ? own[k * L + j] : zero2;
     }
 
-    const SchedEntry sch = schedule_of(f, a);
-    // one scalar round trip for the whole argument struct and the schedule entry: have every field the kernel uses
-    // later requested by now (otherwise the compiler fetches some lazily, a second round trip in front of Philox)
-    asm volatile("" :: "s"(a.logp), "s"(a.naccept), "s"(a.chain), "s"(a.chain_logp), "s"(a.chain_rows), "s"(a.chain_row0),
-                 "s"(a.msum), "s"(a.msumsq), "s"(a.macc_stride), "s"(a.klast));
-    const bool count  = (sch.flags & kCount) != 0;
-    const bool sample = (sch.flags & kSample) != 0;
-    const uint64_t step = 2ull * (uint64_t)sch.gen + (uint64_t)f.half;
-    DrawConsts dc = a.dc;                                               // seed and nhalf from the front parameters
-    dc.seed_lo = f.seed_lo; dc.seed_hi = f.seed_hi; dc.nhalf = f.nhalf;
-    // Streaming moments are sojourn-weighted: a walker's value is credited, times the number of
-    // samples it stood for, when it is replaced (and by flush_moments_vec at read-out).  Only waves
-    // with an accepted move touch their accumulators -- at low acceptance (large ndim) almost none.
-    const bool do_mom = count && a.msum != nullptr;
-    // small rows: nearly every wave has an accepted move, so fetch its accumulator slots now and
-    // keep that latency off the kernel's tail; large rows: fetch only when needed
-    constexpr bool kPrefetchAcc = K <= 2;
-    double2 accs[K], accq[K];
-    double  acct[4] = {0.0, 0.0, 0.0, 0.0};
-    if constexpr (FoldT<L, K>::on) {
-        if (do_mom) {
-#pragma unroll
-            for (int r = 0; r < FoldT<L, K>::NVL; ++r) acct[r] = a.msum[((int64_t)(tid >> 6) * FoldT<L, K>::NVL + r) * 64 + lane];
-        }
-    } else if constexpr (kPrefetchAcc) {
-        if (do_mom && g == 0) {
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-                const int64_t idx = (int64_t)k * a.macc_stride + tid;
-                accs[k] = reinterpret_cast<const double2*>(a.msum)[idx];
-                accq[k] = reinterpret_cast<const double2*>(a.msumsq)[idx];
-            }
-        }
-    }
-    const double   p0 = a.logp[rowA];
-    const uint32_t na = a.naccept[rowA];
-    const uint32_t kl = do_mom ? a.klast[rowA] : 0u;
+    // ---- the step, then Philox: nothing here touches the argument struct.  Eager launch: the step is a preloaded
+    //      parameter, so the partner index is known without any memory access; graph replay: one scalar round trip
+    //      for the schedule entry (the struct's fields ride the same round trip, see below) -----------------------
+    const bool eager = f.sched == nullptr;
+    SchedEntry sch_t{0, 0, 0u, 0u, {0u, 0u}};
+    if (!eager) sch_t = schedule_entry(f);
+    const uint64_t step = eager ? (uint64_t)f.step : 2ull * (uint64_t)sch_t.gen + (uint64_t)f.half;
+    DrawConsts dcf{};                                                   // what Philox and the partner index need
+    dcf.seed_lo = f.seed_lo; dcf.seed_hi = f.seed_hi; dcf.nhalf = f.nhalf;
     // parked draws are valid iff they carry this step's tag (wave-uniform decision)
     const uint32_t e1y_lo = (uint32_t)__double2loint(e1.y), e1y_hi = (uint32_t)__double2hiint(e1.y);
     const bool fresh = ring_on && __all(!useA || e1y_hi == (uint32_t)step);
     U4 bits{0u, 0u, 0u, 0u};
     uint32_t partnerA = e1y_lo;                                         // :250
     if (!fresh) {
-        bits = draw_bits(dc, step + 2ull * (uint64_t)jq, (uint64_t)(f.gw0 + iAc));   // RNG keyed by the GLOBAL walker index
-        partnerA = draw_partner(dc, bits);
+        bits = draw_bits(dcf, step + 2ull * (uint64_t)jq, (uint64_t)f.gw0 + (uint64_t)iAc);   // RNG keyed by the GLOBAL walker index
+        partnerA = draw_partner(dcf, bits);
     }
-    KMC_STAMP(1);
 
     // ---- scalar -> row: the partner of slot it*G+g lives in lane gbase+it.  The partner-row loads of the first
     //      half of the iterations go out, then the first logarithm, then the other half, then the second
@@ -429,6 +401,51 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
 #pragma unroll
     for (int it = 0; it < kFirst; ++it) load_partner_rows(it);
     __builtin_amdgcn_sched_barrier(0);
+
+    // ---- from here on the argument struct: one scalar round trip for all of it (have every field the kernel
+    //      uses later requested by now, otherwise the compiler fetches some lazily: a round trip each) ----------
+    asm volatile("" :: "s"(a.logp), "s"(a.naccept), "s"(a.chain), "s"(a.chain_logp), "s"(a.chain_rows), "s"(a.chain_row0),
+                 "s"(a.msum), "s"(a.msumsq), "s"(a.macc_stride), "s"(a.klast), "s"(a.sched_inline.gen), "s"(a.sched_inline.slot),
+                 "s"(a.sched_inline.flags), "s"(a.sched_inline.nbefore));
+    // (the launch kind again, opaque to the optimiser: merged with the branch above it would pull the struct's first
+    //  use -- and the wait for it -- in front of Philox)
+    int eager_late = eager ? 1 : 0;
+    asm volatile("" : "+v"(eager_late));
+    eager_late = __builtin_amdgcn_readfirstlane(eager_late);
+    SchedEntry sch = sch_t;
+    if (eager_late != 0) sch = a.sched_inline;
+    const bool count  = (sch.flags & kCount) != 0;
+    const bool sample = (sch.flags & kSample) != 0;
+    DrawConsts dc = a.dc;                                               // seed and nhalf from the front parameters
+    dc.seed_lo = f.seed_lo; dc.seed_hi = f.seed_hi; dc.nhalf = f.nhalf;
+    // Streaming moments are sojourn-weighted: a walker's value is credited, times the number of
+    // samples it stood for, when it is replaced (and by flush_moments_vec at read-out).  Only waves
+    // with an accepted move touch their accumulators -- at low acceptance (large ndim) almost none.
+    const bool do_mom = count && a.msum != nullptr;
+    // small rows: nearly every wave has an accepted move, so fetch its accumulator slots now and
+    // keep that latency off the kernel's tail; large rows: fetch only when needed
+    constexpr bool kPrefetchAcc = K <= 2;
+    double2 accs[K], accq[K];
+    double  acct[4] = {0.0, 0.0, 0.0, 0.0};
+    if constexpr (FoldT<L, K>::on) {
+        if (do_mom) {
+#pragma unroll
+            for (int r = 0; r < FoldT<L, K>::NVL; ++r) acct[r] = a.msum[((int64_t)(tid >> 6) * FoldT<L, K>::NVL + r) * 64 + lane];
+        }
+    } else if constexpr (kPrefetchAcc) {
+        if (do_mom && g == 0) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const int64_t idx = (int64_t)k * a.macc_stride + tid;
+                accs[k] = reinterpret_cast<const double2*>(a.msum)[idx];
+                accq[k] = reinterpret_cast<const double2*>(a.msumsq)[idx];
+            }
+        }
+    }
+    const double   p0 = a.logp[rowA];
+    const uint32_t na = a.naccept[rowA];
+    const uint32_t kl = do_mom ? a.klast[rowA] : 0u;
+    KMC_STAMP(1);
     Draw dr;
     dr.partner = partnerA; dr.z = e1.x; dr.t1 = e0.x; dr.lu = e0.y;
     double ua = 0.5;
@@ -589,7 +606,7 @@ __device__ __forceinline__ void half_step_generic_body(const HalfStepFront& f, c
 {
     const int tid = blockIdx.x * 256 + threadIdx.x;
     const SchedEntry sch = schedule_of(f, a);
-    const uint64_t step = 2ull * (uint64_t)sch.gen + (uint64_t)a.half;
+    const uint64_t step = 2ull * (uint64_t)sch.gen + (uint64_t)a.half;      // (eager: sched_inline.gen)
     if constexpr (P2P) { if (a.nranks > 1) wait_for_peers(a, step, (int)(threadIdx.x & 63)); }   // whole waves, before any exit
     if (tid >= a.n_active) return;
     const int ndim = a.ndim;
