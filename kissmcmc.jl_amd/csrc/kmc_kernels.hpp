@@ -153,18 +153,38 @@ __device__ __forceinline__ SchedEntry schedule_of(const HalfStepFront& f, const 
     return schedule_entry(f);
 }
 
-// Row store.  KMC_STORE_SC1: write-through (sc1) so the kernel leaves no dirty lines for the
-// end-of-kernel write-back (the next half-step's readers sit on other XCDs anyway).
-__device__ __forceinline__ void store_row16(double2* p, const double2& v)
+// Stores of the half-step kernels are WRITE-THROUGH (sc0 sc1): the line goes to memory while the kernel is still
+// running instead of sitting dirty in the XCD's L2 until the end-of-kernel write-back, which is part of the
+// dependent-kernel boundary every half-step pays (C2: 4.27 -> 3.92 us per half-step; the next launch's readers sit
+// on other XCDs and must get the data from memory anyway).  -DKMC_STORE_PLAIN: ordinary stores (A/B builds).
+// The s_nop covers the store-data hazard the compiler cannot see through the asm.
+__device__ __forceinline__ void store_wt(double2* p, const double2& v)
 {
-#ifdef KMC_STORE_SC1
+#ifndef KMC_STORE_PLAIN
     typedef double v2d __attribute__((ext_vector_type(2)));
     const v2d t = {v.x, v.y};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(t) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(p), "v"(t) : "memory");
 #else
     *p = v;
 #endif
 }
+__device__ __forceinline__ void store_wt(double* p, double v)
+{
+#ifndef KMC_STORE_PLAIN
+    asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ void store_wt(uint32_t* p, uint32_t v)
+{
+#ifndef KMC_STORE_PLAIN
+    asm volatile("global_store_dword %0, %1, off sc0 sc1\n\ts_nop 0" :: "v"(p), "v"(v) : "memory");
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ void store_row16(double2* p, const double2& v) { store_wt(p, v); }
 
 __device__ __forceinline__ double2 sel2(bool c, const double2& a, const double2& b)
 {
@@ -232,7 +252,7 @@ __device__ __forceinline__ void accumulate_wave(double* msum, double* msumsq, in
         for (int i = 0; i < 4; ++i) if (i < n / 2) v[i] = swap32_sum(v[i], v[i + n / 2]);
         double* slot = msum + ((int64_t)(tid >> 6) * NVL) * 64 + lane;
 #pragma unroll
-        for (int r = 0; r < NVL; ++r) slot[r * 64] = (HAVE_OLD ? oldt[r] : slot[r * 64]) + v[r];
+        for (int r = 0; r < NVL; ++r) store_wt(&slot[r * 64], (HAVE_OLD ? oldt[r] : slot[r * 64]) + v[r]);
         return;
     }
     if constexpr (L < 64) {
@@ -249,8 +269,13 @@ __device__ __forceinline__ void accumulate_wave(double* msum, double* msumsq, in
         for (int k = 0; k < K; ++k) {
             const int64_t idx = (int64_t)k * stride + tid;
             const double2 sv = HAVE_OLD ? olds[k] : s[idx], qv = HAVE_OLD ? oldq[k] : q[idx];
-            s[idx] = make_double2(sv.x + ms[k].x, sv.y + ms[k].y);
-            q[idx] = make_double2(qv.x + mq[k].x, qv.y + mq[k].y);
+            if constexpr (HAVE_OLD) {
+                store_wt(&s[idx], make_double2(sv.x + ms[k].x, sv.y + ms[k].y));
+                store_wt(&q[idx], make_double2(qv.x + mq[k].x, qv.y + mq[k].y));
+            } else {      // long rows: 16 KB per accepted wave -- plain stores (write-through measured slower here)
+                s[idx] = make_double2(sv.x + ms[k].x, sv.y + ms[k].y);
+                q[idx] = make_double2(qv.x + mq[k].x, qv.y + mq[k].y);
+            }
         }
     }
 }
@@ -466,8 +491,8 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
         if constexpr (kRing) {
             if (ring_on && jq >= 1 && jq < Q && iA < nact) {            // park the walkers' next steps
                 double2* slot = a.ring + ((int64_t)((a.ring_slot + jq) & 3) * a.ring_rows + rowA) * 2;
-                slot[0] = make_double2(dr.t1, dr.lu);
-                slot[1] = make_double2(dr.z, __hiloint2double((int)(uint32_t)(step + 2ull * (uint64_t)jq), (int)dr.partner));
+                store_wt(&slot[0], make_double2(dr.t1, dr.lu));
+                store_wt(&slot[1], make_double2(dr.z, __hiloint2double((int)(uint32_t)(step + 2ull * (uint64_t)jq), (int)dr.partner)));
             }
         }
     }
@@ -494,14 +519,14 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
     const bool acc = validA && accept_test(dr, myp1, p0);               // :260
     const unsigned long long accmask = __ballot(acc);
     if (acc) {
-        a.logp[rowA] = myp1;                                            // :262
-        if (count) a.naccept[rowA] = na + 1u;                           // :265
-        if (do_mom) a.klast[rowA] = sch.nbefore;
+        store_wt(&a.logp[rowA], myp1);                                  // :262
+        if (count) store_wt(&a.naccept[rowA], na + 1u);                 // :265
+        if (do_mom) store_wt(&a.klast[rowA], sch.nbefore);
     }
     const uint32_t wA = (acc && do_mom) ? sch.nbefore - kl : 0u;        // samples the replaced value stood for
     const bool any_w = __ballot(wA != 0u) != 0ull;
     if (sample && a.chain_logp != nullptr && validA)                    // :271
-        a.chain_logp[sch.slot * a.chain_rows + a.chain_row0 + iA] = acc ? myp1 : p0;
+        store_wt(&a.chain_logp[sch.slot * a.chain_rows + a.chain_row0 + iA], acc ? myp1 : p0);
 
     // ---- row layout again: store accepted proposals, samples, moments -----------------------
     double2 ms[K], mq[K];
@@ -526,7 +551,7 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
         if (sample && a.chain != nullptr && validB[it]) {               // :268-269
             double2* dst = reinterpret_cast<double2*>(a.chain + (sch.slot * a.chain_rows + a.chain_row0 + w0 + it * G + g) * ld);
 #pragma unroll
-            for (int k = 0; k < K; ++k) if (cv[k]) dst[k * L + j] = sel2(accB, xo[it][k], xc[it][k]);
+            for (int k = 0; k < K; ++k) if (cv[k]) store_wt(&dst[k * L + j], sel2(accB, xo[it][k], xc[it][k]));
         }
     }
     if (any_w) {
