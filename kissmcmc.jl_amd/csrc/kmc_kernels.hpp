@@ -185,6 +185,17 @@ __device__ __forceinline__ void store_wt(uint32_t* p, uint32_t v)
 #endif
 }
 __device__ __forceinline__ void store_row16(double2* p, const double2& v) { store_wt(p, v); }
+// Row load: every row is read once per launch.  -DKMC_LOAD_NT: non-temporal (A/B builds).
+__device__ __forceinline__ double2 load_row16(const double2* p)
+{
+#ifdef KMC_LOAD_NT
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    const v2d t = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(p));
+    return make_double2(t.x, t.y);
+#else
+    return *p;
+#endif
+}
 
 __device__ __forceinline__ double2 sel2(bool c, const double2& a, const double2& b)
 {
@@ -366,7 +377,7 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
         validB[it] = i < nact;
         const double2* own = reinterpret_cast<const double2*>(f.pos + ((int64_t)f.own_row0 + (validB[it] ? i : nact - 1)) * ld);
 #pragma unroll
-        for (int k = 0; k < K; ++k) xc[it][k] = cv[k] ? own[k * L + j] : zero2;
+        for (int k = 0; k < K; ++k) xc[it][k] = cv[k] ? load_row16(&own[k * L + j]) : zero2;
     }
 
     // ---- the step, then Philox: nothing here touches the argument struct.  Eager launch: the step is a preloaded
@@ -420,7 +431,7 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
             oth = reinterpret_cast<const double2*>(((unsigned long long)hi << 32) | lo);
         }
 #pragma unroll
-        for (int k = 0; k < K; ++k) xo[it][k] = cv[k] ? oth[k * L + j] : zero2;
+        for (int k = 0; k < K; ++k) xo[it][k] = cv[k] ? load_row16(&oth[k * L + j]) : zero2;
     };
     constexpr int kFirst = ITER >= 2 ? ITER / 2 : ITER;                 // iterations whose loads precede the first logarithm
 #pragma unroll
