@@ -1441,7 +1441,10 @@ KMC_EXPORT kmc_status kmc_sampler_run(kmc_sampler* s, int64_t ngen)
         return KMC_OK;
     };
     auto updated_chunk = [&]() -> kmc_status {
-        KMC_TRY(launch_updated_graph(s));
+        if (launch_updated_graph(s) != KMC_OK) {       // nothing was enqueued: fall back to the table graph for good
+            s->launch_mode = 1;
+            return graph_chunk();
+        }
         s->generation += kGraphChunk;
         s->launches += 2 * kGraphChunk;
         ngen -= kGraphChunk;
@@ -1482,13 +1485,17 @@ KMC_EXPORT kmc_status kmc_sampler_run(kmc_sampler* s, int64_t ngen)
                                  hipEventElapsedTime(&tu, e1, e2) != hipSuccess)) st = KMC_ERR_HIP;
             (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
             if (st != KMC_OK) return st == KMC_ERR_HIP ? fail(st, "launch-mode calibration failed") : st;
-            s->launch_mode = tu < 0.98f * tg ? 3 : 1;                         // the updated graph must win clearly
-            s->calib_graph_ms = tg / 4.f; s->calib_eager_ms = tu / 4.f;
+            if (s->launch_mode == 0) {
+                s->launch_mode = tu < 0.98f * tg ? 3 : 1;                     // the updated graph must win clearly
+                s->calib_graph_ms = tg / 4.f; s->calib_eager_ms = tu / 4.f;
+            }
         }
     }
     if (s->launch_mode == 2) use_graph = false;
-    if (s->launch_mode == 3) { while (use_graph && ngen >= kGraphChunk) KMC_TRY(updated_chunk()); }
-    else { while (use_graph && ngen >= kGraphChunk) KMC_TRY(graph_chunk()); }
+    while (use_graph && ngen >= kGraphChunk) {
+        if (s->launch_mode == 3) KMC_TRY(updated_chunk());
+        else KMC_TRY(graph_chunk());
+    }
     KMC_TRY(eager_generations(ngen));
     HIP_TRY(hipEventRecord(s->ev1, s->stream));
     s->have_run_events = true;

@@ -188,3 +188,38 @@ def test_describe_reports_the_execution_mode(kmc):
         assert "half_step_generic" in s.describe()
     with kmc.Sampler(kmc.GaussianIso(), 1024, 8, 10, island_gens=4) as s:
         assert "island mode: 4 islands of 256" in repr(s)
+
+
+@pytest.mark.parametrize("mode", ["graph", "eager", "updated", None])
+def test_launch_modes_are_the_same_sampler(kmc, oracle, mode, monkeypatch):
+    """kmc_sampler_run issues the half-steps as a table-driven hipGraph, as eager launches, or as a graph whose node
+    parameters are rewritten before every replay (KMC_LAUNCH; unset: a long run measures and picks): the kernels take
+    their generation from a device table in the first case and from preloaded kernel parameters in the others --
+    same draws, same result, and a chunked run crosses every seam (calibration, replay, eager tail)."""
+    if mode is None:
+        monkeypatch.delenv("KMC_LAUNCH", raising=False)
+    else:
+        monkeypatch.setenv("KMC_LAUNCH", mode)
+    nw, nd, G, nburn, nthin, seed = 2048, 32, 1000, 301, 7, 23
+    th = np.random.default_rng(4).standard_normal((nw, nd))
+    with kmc.Sampler(kmc.GaussianIso(), nw, nd, G, nburn, nthin, 2.0, seed, store_chain=True, store_logp=True, moments=True) as s:
+        s.set_positions(th)
+        s.run(900)          # long enough for the one-off measurement when the mode is not forced
+        s.run(37)
+        s.run(63)
+        s.sync()
+        pos, nacc = s.positions(), s.naccept()
+        chain, clogp = s.chain()
+        msum, msq, n = s.moments()
+        how = s.describe()
+    ref = oracle.emcee(oracle.make_config(oracle.GAUSSIAN_ISO, [0.0, 1.0], nw, nd, G, nburn, nthin, 2.0, seed, nthreads=8), th)
+    np.testing.assert_array_equal(nacc, ref["naccept"])
+    np.testing.assert_array_equal(pos, ref["final_pos"])
+    np.testing.assert_array_equal(chain, ref["chain"])
+    assert n == ref["nmoment"]
+    np.testing.assert_allclose(msum, ref["sum"], rtol=1e-11, atol=1e-9)
+    np.testing.assert_allclose(msq, ref["sumsq"], rtol=1e-11, atol=1e-9)
+    if mode == "updated":
+        assert "parameter updates" in how
+    if mode == "eager":
+        assert "eager" in how
