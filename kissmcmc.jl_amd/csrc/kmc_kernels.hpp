@@ -491,14 +491,14 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
         dr.z = t * t;                                                   // :252
         const uint64_t kk = ((uint64_t)bits.z << 20) | (uint64_t)(bits.w >> 12);
         ua = ((double)kk + 0.5) * 0x1.0p-52;
-        dr.t1 = dc.nm1 * log(dr.z);
+        dr.t1 = dc.nm1 * log_pos_normal(dr.z);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int it = kFirst; it < ITER; ++it) load_partner_rows(it);
     __builtin_amdgcn_sched_barrier(0);
     if (!fresh) {
-        dr.lu = log(ua);                                                // :260
+        dr.lu = log_pos_normal(ua);                                     // :260
         if constexpr (kRing) {
             if (ring_on && jq >= 1 && jq < Q && iA < nact) {            // park the walkers' next steps
                 double2* slot = a.ring + ((int64_t)((a.ring_slot + jq) & 3) * a.ring_rows + rowA) * 2;
