@@ -51,7 +51,7 @@ __device__ __forceinline__ void normal_pair(uint32_t a, uint32_t b, double& n0, 
 {
     const double u1 = ((double)a + 0.5) * 0x1.0p-32;
     const double u2 = ((double)b + 0.5) * 0x1.0p-32;
-    const double r = sqrt(-2.0 * log(u1));
+    const double r = sqrt(-2.0 * log_pos_normal(u1));     // u1 in (0,1): positive, normal
     double sn, cs;
     sincos(6.283185307179586476925286766559 * u2, &sn, &cs);
     n0 = r * cs;
@@ -103,7 +103,7 @@ __device__ __forceinline__ void metropolis_chains_body(const MetropolisArgs& a)
         }
         const double p1 = Dens::seq_finish(q, ndim, a.dp);                   // :99
         const uint64_t kk = ((uint64_t)w.z << 20) | (uint64_t)(w.w >> 12);
-        const double lu = log(((double)kk + 0.5) * 0x1.0p-52);
+        const double lu = log_pos_normal(((double)kk + 0.5) * 0x1.0p-52);
         if (p1 - p0 > lu) {                                                  // :101, note the strict >
 #pragma unroll
             for (int d = 0; d < ND; ++d) x[d] = y[d];                        // :102
@@ -180,7 +180,7 @@ __device__ __forceinline__ void metropolis_chains_any_body(const MetropolisArgs&
         }
         const double p1 = Dens::seq_finish(q, ndim, a.dp);                   // :99
         const uint64_t kk = ((uint64_t)w.z << 20) | (uint64_t)(w.w >> 12);
-        const double lu = log(((double)kk + 0.5) * 0x1.0p-52);
+        const double lu = log_pos_normal(((double)kk + 0.5) * 0x1.0p-52);
         const bool acc = p1 - p0 > lu;                                       // :101
         if (acc) {
             p0 = p1;
