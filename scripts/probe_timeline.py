@@ -20,13 +20,14 @@ if not os.path.exists(VAR):
 import kissmcmc_jl_amd as kmc
 from kissmcmc_jl_amd import _lib
 
-CONFIGS = {"C2": (kmc.GaussianIso(), 65536, 32), "C5": (kmc.GaussianIso(), 8192, 1024), "C4s": (kmc.GaussianIso(), 524288, 32)}
+CONFIGS = {"C2": (kmc.GaussianIso(), 65536, 32), "C3": (kmc.Rosenbrock(), 16384, 64), "C5": (kmc.GaussianIso(), 8192, 1024),
+           "C4s": (kmc.GaussianIso(), 524288, 32)}
 
 
 def main():
     name = sys.argv[1] if len(sys.argv) > 1 else "C2"
     pdf, nw, nd = CONFIGS[name]
-    th = np.random.default_rng(0).standard_normal((nw, nd))
+    th = np.random.default_rng(0).standard_normal((nw, nd)) * (0.1 if name == "C3" else 1.0)
     L = _lib.lib()
     for mom in (True, False):
         s = kmc.Sampler(pdf, nw, nd, 10 ** 9, 0, 1, 2.0, 7, moments=mom)
