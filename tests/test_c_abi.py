@@ -43,6 +43,16 @@ def test_struct_layout_matches_header(kmc, tmp_path):
     want = [C.sizeof(_lib.Config), _lib.Config.nwalkers.offset, _lib.Config.seed.offset, _lib.Config.host_logpdf.offset,
             C.sizeof(_lib.Outputs), _lib.Outputs.device_ms.offset]
     assert got == want
+    # the Metropolis structs (reference src/samplers.jl:59-128)
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "kissmcmc_hip.h"\n'
+                   'int main(void){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(kmc_metropolis_config), offsetof(kmc_metropolis_config, nchains),'
+                   ' offsetof(kmc_metropolis_config, step), offsetof(kmc_metropolis_config, user_density), sizeof(kmc_metropolis_outputs),'
+                   ' offsetof(kmc_metropolis_outputs, device_ms));return 0;}\n')
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    want = [C.sizeof(_lib.MetropolisConfig), _lib.MetropolisConfig.nchains.offset, _lib.MetropolisConfig.step.offset,
+            _lib.MetropolisConfig.user_density.offset, C.sizeof(_lib.MetropolisOutputs), _lib.MetropolisOutputs.device_ms.offset]
+    assert got == want
 
 
 def _cfg(_lib, **kw):
