@@ -199,8 +199,15 @@ __device__ __forceinline__ double group_shfl_down1(double v)
 }
 template <int L>
 __device__ __forceinline__ double group_bcast0(double v)
-{
-    return __shfl(v, 0, L);
+{   // value of the group's lane 0, in every lane of the group
+    if constexpr (L == 1) return v;
+    else if constexpr (L == 2) return dpp_f64<0xA0>(v);                  // quad_perm [0,0,2,2]
+    else if constexpr (L == 4) return dpp_f64<0x00>(v);                  // quad_perm [0,0,0,0]
+    else if constexpr (L == 16) return dpp_f64<0x150>(v);                // row_newbcast:0 (gfx90a+): lane 0 of each 16-lane row
+    else if constexpr (L == 8) {                                        // two groups per row: lanes 0 and 8
+        const double lo = dpp_f64<0x150>(v), hi = dpp_f64<0x158>(v);
+        return (threadIdx.x & 8) ? hi : lo;
+    } else return __shfl(v, 0, L);
 }
 
 struct GaussianIso {   // p = {mu, 1/sigma}
