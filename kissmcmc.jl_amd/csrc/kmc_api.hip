@@ -469,6 +469,7 @@ struct kmc_sampler {
     bool uinflight[2] = {false, false};
     int unext = 0;
     std::vector<hipGraphNode_t> unodes;
+    int64_t uchunk = 64;      // generations per replay of the updated graph
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool have_run_events = false;
     bool positions_set = false;
@@ -673,11 +674,11 @@ kmc_status ensure_updated_graph(kmc_sampler* s)
 {
     if (s->uexec[0]) return KMC_OK;
     HIP_TRY(hipGraphCreate(&s->ugraph, 0));
-    s->unodes.assign((size_t)(2 * kGraphChunk), nullptr);
+    s->unodes.assign((size_t)(2 * s->uchunk), nullptr);
     KernelParamPack pk;
     pk.bind();
     hipGraphNode_t prev = nullptr;
-    for (int64_t g = 0; g < kGraphChunk; ++g)
+    for (int64_t g = 0; g < s->uchunk; ++g)
         for (int half = 0; half < 2; ++half) {
             pk.a = make_args(s, half, false, g);
             pk.f = front_of(pk.a);
@@ -702,7 +703,7 @@ kmc_status launch_updated_graph(kmc_sampler* s)
     if (s->uinflight[i]) { HIP_TRY(hipEventSynchronize(s->udone[i])); s->uinflight[i] = false; }
     KernelParamPack pk;
     pk.bind();
-    for (int64_t g = 0; g < kGraphChunk; ++g)
+    for (int64_t g = 0; g < s->uchunk; ++g)
         for (int half = 0; half < 2; ++half) {
             pk.a = make_args(s, half, false, s->generation + g);
             pk.f = front_of(pk.a);
@@ -1445,9 +1446,9 @@ KMC_EXPORT kmc_status kmc_sampler_run(kmc_sampler* s, int64_t ngen)
             s->launch_mode = 1;
             return graph_chunk();
         }
-        s->generation += kGraphChunk;
-        s->launches += 2 * kGraphChunk;
-        ngen -= kGraphChunk;
+        s->generation += s->uchunk;
+        s->launches += 2 * s->uchunk;
+        ngen -= s->uchunk;
         return KMC_OK;
     };
     // How to issue the launches?  Same kernels, same results, three ways:
@@ -1462,12 +1463,14 @@ KMC_EXPORT kmc_status kmc_sampler_run(kmc_sampler* s, int64_t ngen)
     // the events) and keeps the faster; KMC_LAUNCH=graph|eager|updated decides without measuring.
     bool use_graph = !(s->cfg.flags & KMC_NO_GRAPH);
     if (use_graph && s->launch_mode == 0) {
+        if (!s->uexec[0])
+            if (const char* e = std::getenv("KMC_UPD_CHUNK")) { const long v = std::atol(e); if (v >= 16 && v <= 1024) s->uchunk = v; }
         const char* env = std::getenv("KMC_LAUNCH");
         if (env && std::strcmp(env, "graph") == 0) s->launch_mode = 1;
         else if (env && std::strcmp(env, "eager") == 0) s->launch_mode = 2;
         else if (env && std::strcmp(env, "updated") == 0 && updated_graph_possible(s)) s->launch_mode = 3;
         else if (!updated_graph_possible(s)) s->launch_mode = 1;
-        else if (ngen >= 12 * kGraphChunk) {
+        else if (ngen >= 11 * std::max<int64_t>(kGraphChunk, s->uchunk) + kGraphChunk) {
             hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
             HIP_TRY(hipEventCreate(&e0));
             HIP_TRY(hipEventCreate(&e1));
@@ -1476,9 +1479,10 @@ KMC_EXPORT kmc_status kmc_sampler_run(kmc_sampler* s, int64_t ngen)
             if (st == KMC_OK) st = updated_chunk();
             if (st == KMC_OK) st = updated_chunk();
             if (st == KMC_OK && hipEventRecord(e0, s->stream) != hipSuccess) st = KMC_ERR_HIP;
-            for (int r = 0; r < 4 && st == KMC_OK; ++r) st = graph_chunk();
+            const int64_t gens = 4 * std::max<int64_t>(kGraphChunk, s->uchunk);
+            for (int64_t r = 0; r < gens / kGraphChunk && st == KMC_OK; ++r) st = graph_chunk();
             if (st == KMC_OK && hipEventRecord(e1, s->stream) != hipSuccess) st = KMC_ERR_HIP;
-            for (int r = 0; r < 4 && st == KMC_OK; ++r) st = updated_chunk();
+            for (int64_t r = 0; r < gens / s->uchunk && st == KMC_OK && s->launch_mode == 0; ++r) st = updated_chunk();
             if (st == KMC_OK && hipEventRecord(e2, s->stream) != hipSuccess) st = KMC_ERR_HIP;
             float tg = 0.f, tu = 0.f;
             if (st == KMC_OK && (hipEventSynchronize(e2) != hipSuccess || hipEventElapsedTime(&tg, e0, e1) != hipSuccess ||
@@ -1487,15 +1491,13 @@ KMC_EXPORT kmc_status kmc_sampler_run(kmc_sampler* s, int64_t ngen)
             if (st != KMC_OK) return st == KMC_ERR_HIP ? fail(st, "launch-mode calibration failed") : st;
             if (s->launch_mode == 0) {
                 s->launch_mode = tu < 0.98f * tg ? 3 : 1;                     // the updated graph must win clearly
-                s->calib_graph_ms = tg / 4.f; s->calib_eager_ms = tu / 4.f;
+                s->calib_graph_ms = tg * (float)kGraphChunk / (float)gens; s->calib_eager_ms = tu * (float)kGraphChunk / (float)gens;
             }
         }
     }
     if (s->launch_mode == 2) use_graph = false;
-    while (use_graph && ngen >= kGraphChunk) {
-        if (s->launch_mode == 3) KMC_TRY(updated_chunk());
-        else KMC_TRY(graph_chunk());
-    }
+    while (use_graph && s->launch_mode == 3 && ngen >= s->uchunk) KMC_TRY(updated_chunk());
+    while (use_graph && ngen >= kGraphChunk) KMC_TRY(graph_chunk());
     KMC_TRY(eager_generations(ngen));
     HIP_TRY(hipEventRecord(s->ev1, s->stream));
     s->have_run_events = true;
