@@ -287,6 +287,15 @@ kmc_status  kmc_metropolis_validate(const kmc_metropolis_config* cfg);
 kmc_status  kmc_metropolis_run(const kmc_metropolis_config* cfg, const double* theta0 /* host [nchains][ndim] */,
                                kmc_metropolis_outputs* out);
 
+/* ---- convergence diagnostics: int_acorr / acor1d / auto_window, reference src/analysis.jl:140-167, :252-273, :280-285 ----
+ * (that file is entirely commented out in the reference: the code is followed as written, there is no live behaviour to
+ * match).  Integrated autocorrelation time per dimension of a chain as the samplers produce it, chain_host
+ * [nsamples][nwalkers][ndim]: circular FFT autocorrelation of every walker's series normalised by its lag-0 value, first
+ * nsamples/2 lags, averaged over walkers; tau = 2 cumsum(rho) - 1 at the first window M >= c tau(M); converged =
+ * nsamples / tau (the reference suggests > 50).  All -1 if any value is NaN (:161-165).  Needs libhipfft.so at run time. */
+kmc_status  kmc_int_acorr(const double* chain_host, int64_t nsamples, int64_t nwalkers, int64_t ndim, double c /* 5 */,
+                          int device, double* tau /* [ndim] */, double* converged /* [ndim] */);
+
 #ifdef __cplusplus
 }
 #endif

@@ -11,7 +11,7 @@
 # 1:1 by the Python ctypes host (kissmcmc.jl_amd/_lib.py, api.py), which is what the tests drive.
 module KissMCMCHIP
 
-export emcee, make_theta0s, squash_walkers, metropolis, metropolis_chains, GaussianStep, GaussianIso, Exponential, Rosenbrock, LogNormal, MvNormal2, ExprDensity, HostLogPdf
+export emcee, make_theta0s, squash_walkers, metropolis, metropolis_chains, GaussianStep, int_acorr, GaussianIso, Exponential, Rosenbrock, LogNormal, MvNormal2, ExprDensity, HostLogPdf
 
 using Statistics: mean, median, std
 using LinearAlgebra: inv
@@ -216,6 +216,26 @@ a drop-in, not a fast path -- use `metropolis_chains` for throughput).
 function metropolis(pdf::DeviceLogPdf, sample_ppdf::GaussianStep, theta0; use_progress_meter=true, kw...)
     thetas, acc, logd, _ = metropolis_chains(pdf, sample_ppdf, [theta0]; kw...)
     return thetas[1], acc[1], logd[1], nothing                                           # :128
+end
+
+"""
+    int_acorr(thetas; c=5, device=0)
+
+Integrated autocorrelation time per dimension (src/analysis.jl:140-167, commented out in the reference; followed as
+written) of `thetas[walker][sample]` as `emcee` / `metropolis_chains` return it.  Returns `(tau, converged)`.
+"""
+function int_acorr(thetas; c=5, device=0)
+    @assert c > 1
+    nw = length(thetas); ns = length(thetas[1]); nd = length(thetas[1][1])
+    chain = Array{Float64}(undef, nd, nw, ns)              # column-major == C [sample][walker][dim]
+    for w in 1:nw, k in 1:ns, d in 1:nd
+        chain[d, w, k] = nd == 1 ? thetas[w][k][1] : thetas[w][k][d]
+    end
+    tau = Vector{Float64}(undef, nd); conv = Vector{Float64}(undef, nd)
+    st = ccall((:kmc_int_acorr, LIB), Cint, (Ptr{Float64}, Int64, Int64, Int64, Float64, Cint, Ptr{Float64}, Ptr{Float64}),
+               chain, ns, nw, nd, Float64(c), Cint(device), tau, conv)
+    st == 0 || error("kmc_int_acorr failed ($st): $(last_error())")
+    return tau, conv
 end
 
 "src/samplers.jl:311-349 (host side, runs once)."

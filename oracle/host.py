@@ -98,3 +98,59 @@ def squash_walkers(thetas, accept_ratio, logdensities=None, blobs=None, drop_low
         t = [t[i] for i in perm]
     mean_acc = sum(accept_ratio[w] for w in walkers2keep) / len(walkers2keep)   # :427
     return t, mean_acc, l, b
+
+
+# ---- integrated autocorrelation time: the (commented-out) int_acorr / acor1d / auto_window / eff_samples of
+#      reference src/analysis.jl:140-167 (int_acorr), :185-191 (eff_samples), :252-273 (acor1d), :280-285 (auto_window).
+#      The reference file is 100 % commented out -- there is no live behaviour and no reference test for it; this
+#      restates the code as written (circular autocorrelation: the FFT is NOT zero-padded, :258-260), numpy FFT. ----
+def acor1d(x, norm=True):
+    """reference src/analysis.jl:252-273"""
+    import numpy as np
+    x = np.asarray(x, dtype=np.float64)
+    f = np.fft.fft(x - x.mean())                       # :258
+    acf = np.real(np.fft.ifft(f * np.conj(f)))         # :259
+    acf = acf / (4 * len(x))                           # :260
+    if norm:
+        acf = acf / acf[0]                             # :264
+    return acf[: len(acf) // 2]                        # :267
+
+
+def auto_window(taus, c):
+    """reference src/analysis.jl:280-285 (1-based i, returned 0-based here)"""
+    for i, t in enumerate(taus, start=1):
+        if i >= c * t:
+            return i - 1
+    return len(taus) - 2                               # length(taus)-1, 1-based
+
+
+def int_acorr(thetas, c=5):
+    """reference src/analysis.jl:140-167; thetas[ntheta][nsamples][nchains].  Returns (tau[ntheta], converged[ntheta])."""
+    import numpy as np
+    thetas = np.asarray(thetas, dtype=np.float64)
+    assert c > 1                                       # :141
+    ntheta, nsamples, nchains = thetas.shape           # :143
+    out = []
+    for n in range(ntheta):                            # :145
+        rho = np.zeros(nsamples // 2)                  # :147
+        for cc in range(nchains):
+            rho += acor1d(thetas[n, :, cc])            # :149
+        rho /= nchains                                 # :151
+        taus = 2 * np.cumsum(rho) - 1                  # :153
+        out.append(taus[auto_window(taus, c)])         # :154-155
+    out = np.array(out)
+    converged = nsamples / out                         # :157
+    if np.any(np.isnan(out)) or np.any(np.isnan(converged)):   # :161-165
+        out = out * 0 - 1
+        converged = converged * 0 - 1
+    return out, converged
+
+
+def eff_samples(thetas, c=5):
+    """reference src/analysis.jl:185-191"""
+    import numpy as np
+    thetas = np.asarray(thetas, dtype=np.float64)
+    acorr, converged = int_acorr(thetas, c=c)
+    ns = thetas.shape[1] / acorr * thetas.shape[2]
+    return (int(round(float(np.mean(ns)))), int(round((thetas.shape[1] * thetas.shape[2]) // float(np.mean(ns)))),
+            float(np.mean(converged)), np.round(ns).astype(np.int64), acorr, converged)
