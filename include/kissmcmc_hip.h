@@ -295,6 +295,8 @@ kmc_status  kmc_metropolis_run(const kmc_metropolis_config* cfg, const double* t
  * nsamples / tau (the reference suggests > 50).  All -1 if any value is NaN (:161-165).  Needs libhipfft.so at run time. */
 kmc_status  kmc_int_acorr(const double* chain_host, int64_t nsamples, int64_t nwalkers, int64_t ndim, double c /* 5 */,
                           int device, double* tau /* [ndim] */, double* converged /* [ndim] */);
+/* The same on the chain a sampler holds on the device (KMC_STORE_CHAIN, the samples stored so far; even ndim). */
+kmc_status  kmc_sampler_int_acorr(kmc_sampler* s, double c, double* tau, double* converged);
 
 #ifdef __cplusplus
 }

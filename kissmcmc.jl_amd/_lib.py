@@ -33,7 +33,7 @@ SYMBOLS = [
     "kmc_sampler_launch_count", "kmc_sampler_describe", "kmc_sampler_device_ptr", "kmc_sampler_get_positions",
     "kmc_sampler_get_logp", "kmc_sampler_get_naccept", "kmc_sampler_get_accept_ratio",
     "kmc_sampler_get_moments", "kmc_sampler_get_chain", "kmc_logpdf_eval", "kmc_logpdf_eval_host",
-    "kmc_user_density_create", "kmc_user_density_destroy", "kmc_metropolis_validate", "kmc_metropolis_run", "kmc_int_acorr",
+    "kmc_user_density_create", "kmc_user_density_destroy", "kmc_metropolis_validate", "kmc_metropolis_run", "kmc_int_acorr", "kmc_sampler_int_acorr",
 ]
 
 
@@ -190,6 +190,7 @@ def lib() -> C.CDLL:
     L.kmc_metropolis_validate.argtypes = [C.POINTER(MetropolisConfig)]
     L.kmc_metropolis_run.argtypes = [C.POINTER(MetropolisConfig), dp, C.POINTER(MetropolisOutputs)]
     L.kmc_int_acorr.argtypes = [dp, C.c_int64, C.c_int64, C.c_int64, C.c_double, C.c_int, dp, dp]
+    L.kmc_sampler_int_acorr.argtypes = [vp, C.c_double, dp, dp]
     _lib = L
     return L
 

@@ -2167,36 +2167,26 @@ struct AcorrBuffers {
 
 }  // namespace
 
-KMC_EXPORT kmc_status kmc_int_acorr(const double* chain_host, int64_t nsamples, int64_t nwalkers, int64_t ndim, double c,
-                                    int device, double* tau, double* converged)
+namespace {
+
+// chain_dev: [nsamples][nwalkers][ndim] on the current device
+kmc_status int_acorr_device(const double* chain_dev, int64_t nsamples, int64_t nwalkers, int64_t ndim, double c,
+                            double* tau, double* converged)
 {
-    if (!chain_host || !tau || !converged) return fail(KMC_ERR_BAD_ARG, "null argument");
-    if (!(c > 1.0)) return fail(KMC_ERR_BAD_ARG, "c>1");                                      // :141 @assert c>1
-    if (nsamples < 4 || nwalkers <= 0 || ndim <= 0) return fail(KMC_ERR_BAD_ARG, "need nsamples >= 4, nwalkers, ndim > 0");
     const int64_t batch = nwalkers * ndim, nlag = nsamples / 2, nfreq = nsamples / 2 + 1;
-    if (nsamples >= ((int64_t)1 << 31) || batch >= ((int64_t)1 << 31)) return fail(KMC_ERR_UNSUPPORTED, "chain too large");
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
-        (void)hipGetLastError();
-        return fail(KMC_ERR_NO_DEVICE, "no HIP device visible");
-    }
-    if (device < 0 || device >= ndev) return fail(KMC_ERR_BAD_ARG, "device ordinal out of range");
-    HIP_TRY(hipSetDevice(device));
     AcorrBuffers b;
     b.api = hipfft_api();
     if (!b.api) return fail(KMC_ERR_UNSUPPORTED, "libhipfft.so could not be loaded");
     const size_t nreal = (size_t)nsamples * (size_t)batch;
-    HIP_TRY(hipMalloc(&b.chain, nreal * sizeof(double)));
     HIP_TRY(hipMalloc(&b.y, nreal * sizeof(double)));
     HIP_TRY(hipMalloc((void**)&b.z, (size_t)nfreq * (size_t)batch * sizeof(double2)));
     HIP_TRY(hipMalloc(&b.rho, (size_t)nlag * (size_t)ndim * sizeof(double)));
-    HIP_TRY(hipMemcpy(b.chain, chain_host, nreal * sizeof(double), hipMemcpyHostToDevice));
     // series b = (walker, dimension) is element b of every sample's [nwalkers][ndim] block: stride batch, distance 1
     int n[1] = {(int)nsamples}, inembed[1] = {(int)nsamples}, onembed[1] = {(int)nfreq};
     if (b.api->plan_many(&b.fwd, 1, n, inembed, (int)batch, 1, onembed, (int)batch, 1, HIPFFT_D2Z, (int)batch) != HIPFFT_SUCCESS ||
         b.api->plan_many(&b.inv, 1, n, onembed, (int)batch, 1, inembed, (int)batch, 1, HIPFFT_Z2D, (int)batch) != HIPFFT_SUCCESS)
         return fail(KMC_ERR_HIP, "hipfftPlanMany failed");
-    hipLaunchKernelGGL(acorr_center, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, nullptr, b.chain, b.y, nsamples, batch);
+    hipLaunchKernelGGL(acorr_center, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, nullptr, chain_dev, b.y, nsamples, batch);
     HIP_TRY(hipGetLastError());
     if (b.api->exec_d2z(b.fwd, b.y, reinterpret_cast<hipfftDoubleComplex*>(b.z)) != HIPFFT_SUCCESS) return fail(KMC_ERR_HIP, "hipfftExecD2Z failed");
     const int64_t nz = nfreq * batch;
@@ -2210,18 +2200,61 @@ KMC_EXPORT kmc_status kmc_int_acorr(const double* chain_host, int64_t nsamples, 
     bool bad = false;
     for (int64_t d = 0; d < ndim; ++d) {
         const double* r = rho.data() + d * nlag;
-        double cum = 0.0, t = 0.0;
+        double cum = 0.0;
         int64_t window = nlag - 2;                                       // :284 length(taus)-1 (1-based)
         std::vector<double> taus((size_t)nlag);
         for (int64_t i = 0; i < nlag; ++i) { cum += r[i]; taus[(size_t)i] = 2.0 * cum - 1.0; }   // :153
         for (int64_t i = 0; i < nlag; ++i)
             if ((double)(i + 1) >= c * taus[(size_t)i]) { window = i; break; }                   // :281-283
         if (window < 0) window = 0;
-        t = taus[(size_t)window];                                        // :155
+        const double t = taus[(size_t)window];                           // :155
         tau[d] = t;
         converged[d] = (double)nsamples / t;                             // :157
         if (t != t || converged[d] != converged[d]) bad = true;
     }
     if (bad) for (int64_t d = 0; d < ndim; ++d) { tau[d] = -1.0; converged[d] = -1.0; }          // :161-165
     return KMC_OK;
+}
+
+kmc_status int_acorr_check(int64_t nsamples, int64_t nwalkers, int64_t ndim, double c, const double* tau, const double* converged)
+{
+    if (!tau || !converged) return fail(KMC_ERR_BAD_ARG, "null argument");
+    if (!(c > 1.0)) return fail(KMC_ERR_BAD_ARG, "c>1");                                      // :141 @assert c>1
+    if (nsamples < 4 || nwalkers <= 0 || ndim <= 0) return fail(KMC_ERR_BAD_ARG, "need nsamples >= 4, nwalkers, ndim > 0");
+    if (nsamples >= ((int64_t)1 << 31) || nwalkers * ndim >= ((int64_t)1 << 31)) return fail(KMC_ERR_UNSUPPORTED, "chain too large");
+    return KMC_OK;
+}
+
+}  // namespace
+
+KMC_EXPORT kmc_status kmc_int_acorr(const double* chain_host, int64_t nsamples, int64_t nwalkers, int64_t ndim, double c,
+                                    int device, double* tau, double* converged)
+{
+    if (!chain_host) return fail(KMC_ERR_BAD_ARG, "null argument");
+    KMC_TRY(int_acorr_check(nsamples, nwalkers, ndim, c, tau, converged));
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        (void)hipGetLastError();
+        return fail(KMC_ERR_NO_DEVICE, "no HIP device visible");
+    }
+    if (device < 0 || device >= ndev) return fail(KMC_ERR_BAD_ARG, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(device));
+    AcorrBuffers b;
+    const size_t nreal = (size_t)nsamples * (size_t)nwalkers * (size_t)ndim;
+    HIP_TRY(hipMalloc(&b.chain, nreal * sizeof(double)));
+    HIP_TRY(hipMemcpy(b.chain, chain_host, nreal * sizeof(double), hipMemcpyHostToDevice));
+    return int_acorr_device(b.chain, nsamples, nwalkers, ndim, c, tau, converged);
+}
+
+// The same on the chain a sampler holds on the device (KMC_STORE_CHAIN; the samples stored so far): no host round trip.
+KMC_EXPORT kmc_status kmc_sampler_int_acorr(kmc_sampler* s, double c, double* tau, double* converged)
+{
+    if (!s) return fail(KMC_ERR_BAD_ARG, "null sampler");
+    if (!s->d_chain) return fail(KMC_ERR_BAD_ARG, "sampler was created without KMC_STORE_CHAIN");
+    if (s->ld != s->cfg.ndim) return fail(KMC_ERR_UNSUPPORTED, "odd ndim: rows are padded on the device; use kmc_int_acorr on the downloaded chain");
+    HIP_TRY(hipSetDevice(s->cfg.device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    const int64_t ns = samples_done(s);
+    KMC_TRY(int_acorr_check(ns, s->nlocal, s->cfg.ndim, c, tau, converged));
+    return int_acorr_device(s->d_chain, ns, s->nlocal, s->cfg.ndim, c, tau, converged);
 }

@@ -190,6 +190,15 @@ class Sampler:
     def __repr__(self):
         return f"<Sampler {self.nwalkers}x{self.ndim} {self.pdf!r}: {self.describe()}>"
 
+    def int_acorr(self, c: float = 5.0):
+        """Integrated autocorrelation time per dimension of the chain stored so far, computed where it lies (on the
+        device): ``(tau[ndim], nsamples / tau)``; see :func:`kissmcmc_jl_amd.int_acorr`."""
+        tau = np.zeros(self.ndim)
+        conv = np.zeros(self.ndim)
+        dp = C.POINTER(C.c_double)
+        _lib.check(self._L.kmc_sampler_int_acorr(self._h, float(c), tau.ctypes.data_as(dp), conv.ctypes.data_as(dp)))
+        return tau, conv
+
     def device_ptr(self, which: int) -> int:
         return int(self._L.kmc_sampler_device_ptr(self._h, int(which)) or 0)
 

@@ -68,3 +68,19 @@ def test_gpu_diagnostics_on_a_real_run(kmc):
     assert 128 * 2000 / 40 < neff < 128 * 2000 / 2 and np.allclose(taus, tau)
     with pytest.warns(UserWarning, match="likely not accurate"):
         kmc.int_acorr(thetas[:, :60], warn=True)
+
+
+@pytest.mark.gpu
+def test_gpu_sampler_int_acorr_runs_on_the_device_chain(kmc):
+    nw, nd, G = 256, 8, 1200
+    th = np.random.default_rng(2).standard_normal((nw, nd))
+    with kmc.Sampler(kmc.GaussianIso(), nw, nd, G, 200, 1, 2.0, 5, store_chain=True) as s:
+        s.set_positions(th)
+        s.run(G)
+        s.sync()
+        tau, conv = s.int_acorr()
+        chain, _ = s.chain(logp=False)
+    rtau, rconv = kmc.int_acorr(chain.transpose(1, 0, 2), warn=False)
+    np.testing.assert_allclose(tau, rtau, rtol=1e-12)
+    otau, _ = ohost.int_acorr(chain.transpose(2, 0, 1))
+    np.testing.assert_allclose(tau, otau, rtol=1e-9)
