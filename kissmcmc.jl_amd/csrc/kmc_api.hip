@@ -973,7 +973,7 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
     CREATE_TRY(hipMemset(s->d_gen, 0, 64));
     CREATE_TRY(hipMalloc(&s->d_sched, (size_t)kGraphChunk * sizeof(SchedEntry)));
     CREATE_TRY(hipMemset(s->d_naccept, 0, nw * sizeof(uint32_t)));
-    if (s->plan.vec && !s->islands && !s->resident && s->plan.L >= 16 && s->plan.L / s->plan.ITER >= 2 &&
+    if (s->plan.vec && !s->islands && !s->resident && s->plan.L >= 16 && s->plan.L <= 32 && s->plan.L / s->plan.ITER >= 2 &&
         std::getenv("KMC_NO_DRAW_RING") == nullptr) {
         // draw ring: 4 slots x rows x 32 B; tags start at 0xffffffff (no step carries it), so nothing is "parked" yet
         const size_t nb = 4 * (size_t)s->nrows * 2 * sizeof(double2);

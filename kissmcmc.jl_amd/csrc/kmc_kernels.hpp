@@ -354,7 +354,9 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
     constexpr int Q = (L / ITER) >= 4 ? 4 : (L / ITER);                 // steps drawn per heavy launch
     // worth it when a wave carries few walkers (long rows): at <= 8 walkers per wave the per-walker scalar work
     // dominates the wave's instruction count; with more (C2: 16) the extra load in the chain costs what it saves
-    constexpr bool kRing = Q >= 2 && L >= 16;
+    // (with the eager-form launches, where Philox starts at wave entry, it is worth +-2 %; it still pays +5 % under
+    //  the table graph, e.g. for the P2P shards.  L = 64: slightly negative, off)
+    constexpr bool kRing = Q >= 2 && L >= 16 && L <= 32;
     const int64_t oth_row0 = (int64_t)(1 - f.half) * (int64_t)(P2P ? (uint32_t)f.n_active : f.nhalf);
     const int  jq     = j / ITER, js = j - jq * ITER;
     const bool useA   = jq == 0;
