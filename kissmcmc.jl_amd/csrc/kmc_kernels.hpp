@@ -22,8 +22,13 @@
 //       Scalars travel scalar->row by ds_bpermute (partner, z), row->scalar for free (the lane
 //       with j == it keeps the reduced log-pdf), and the accept bits come back as a ballot mask.
 //       The proposal stays in registers until the accept decision and is stored only on accept.
-//   half_step_generic<Density>          any ndim; one walker per lane, scalar loops.  Used for
-//       the reference's own 1-D/2-D cases and odd sizes.
+//       What the kernel is built around (each measured): nothing in front of Philox waits for
+//       memory (the first 14 dwords of the arguments are preloaded into SGPRs; an eager-form launch carries its
+//       step there too); the argument struct is one scalar round trip; partner-row loads are in flight before the
+//       two logarithms; every store is write-through, so the end-of-kernel write-back of the half-step boundary
+//       finds nothing dirty; streaming moments are a reduce-scatter over the wave.
+//   half_step_generic<Density>          any ndim; one walker per lane, scalar loops.  Used for ndim > 1024, for
+//       host-evaluated densities and with KMC_PLAN=generic.
 #pragma once
 #include "kmc_device.hpp"
 
