@@ -84,6 +84,22 @@ def test_validate_returns_the_reference_assert_conditions(kmc):
     assert v(shard_count=5, shard_rank=4) == _lib.OK
     assert v(density=_lib.ROSENBROCK, ndim=1, nwalkers=10) == _lib.ERR_BAD_ARG
     assert L.kmc_validate(None) == _lib.ERR_BAD_ARG
+    assert v(ngenerations=2 ** 31) == _lib.ERR_UNSUPPORTED       # the step index 2 g + half is 32 bits
+    assert v(ngenerations=2 ** 31 - 1) == _lib.OK
+    assert v(nwalkers=2 ** 31, ndim=2) == _lib.ERR_UNSUPPORTED   # row indices are 31 bits
+
+
+def test_int_acorr_argument_checks_need_no_device(kmc):
+    from kissmcmc_jl_amd import _lib
+    L = _lib.lib()
+    dp = C.POINTER(C.c_double)
+    x = np.zeros(64)
+    out = np.zeros(2)
+    p = lambda a: a.ctypes.data_as(dp)
+    assert L.kmc_int_acorr(p(x), 32, 1, 2, 1.0, 0, p(out), p(out)) == _lib.ERR_BAD_ARG      # @assert c>1, analysis.jl:141
+    assert L.kmc_int_acorr(p(x), 3, 1, 2, 5.0, 0, p(out), p(out)) == _lib.ERR_BAD_ARG       # too short
+    assert L.kmc_int_acorr(None, 32, 1, 2, 5.0, 0, p(out), p(out)) == _lib.ERR_BAD_ARG
+    assert L.kmc_sampler_int_acorr(None, 5.0, p(out), p(out)) == _lib.ERR_BAD_ARG
 
 
 def test_g_helpers_known_answers(kmc):
