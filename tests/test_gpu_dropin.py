@@ -85,3 +85,21 @@ def test_zero_generations_and_degenerate_burnin(kmc):
     thetas, acc, logd, _ = kmc.emcee(pdf, np.zeros((10, 2)), niter=5, use_progress_meter=False, seed=1)
     assert thetas.shape == (10, 0, 2) and logd.shape == (10, 0)
     assert np.all(np.isnan(acc))
+
+
+def test_readme_call_sequence_in_plain_c(tmp_path):
+    """examples/readme_call.c: the reference README's emcee call (README.md:15-27) through the C ABI alone -- compiled
+    with gcc against include/kissmcmc_hip.h and the shared library, no Python or torch in the process."""
+    import os
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    exe = str(tmp_path / "readme_call")
+    libdir = os.path.join(root, "kissmcmc.jl_amd")
+    subprocess.check_call(["gcc", "-O2", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "readme_call.c"),
+                           "-o", exe, "-L", libdir, "-lkissmcmc_hip", "-lm", f"-Wl,-rpath,{libdir}"])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.startswith("samples 50000 ")
