@@ -296,6 +296,14 @@ def main():
                       "posterior_var_min": float(var.min()), "posterior_var_max": float(var.max()),
                       "nmoment": int(nmom)},
         }
+        if world > 1:
+            # what the exchange has to move: partners are uniform over the whole complementary half,
+            # so (P-1)/P of a rank's partner rows are remote, 1/P from each peer over that pair's single xGMI link
+            rows_per_peer = walkers_per_launch / world
+            out["fabric"] = {"remote_partner_bytes_per_gpu_per_launch": rows_per_peer * (world - 1) * NDIM * 8,
+                             "bytes_per_link_per_launch": rows_per_peer * NDIM * 8,
+                             "link_bound_us_at_77GBs": rows_per_peer * NDIM * 8 / 77e9 * 1e6,
+                             "note": "P2P pull of the drawn rows only; link figure = one xGMI link, one direction (~77 GB/s)"}
         if world == 1:
             out["island_mode"] = island
         if world == 1 and not args.no_cpu_baseline:
