@@ -88,6 +88,9 @@ enum {
                                   island_size >= ndim + 2, ndim <= 32, shard_count == 1; no chain storage.  Works with user densities
                                   when island_size * (ndim + 3) * 8 B <= 60 KiB. */
     KMC_P2P_FINEGRAINED = 1u << 7, /* with KMC_P2P: keep the rows in fine-grained (coherent, uncached-for-peers) device memory */
+    KMC_P2P_FOLD_SIGNAL = 1u << 8, /* with KMC_P2P: the half-step kernel itself publishes the progress flag (its stores are
+                                      write-through; the last workgroup to drain them signals every rank) instead of a separate
+                                      signal kernel after it: one kernel boundary less per half-step */
     KMC_P2P         = 1u << 4  /* walker sharding with peer-to-peer partner reads over xGMI: the sampler holds only
                                   its shard ([2][nwalkers/2/shard_count][ndim], halves back to back), reads partner
                                   rows straight from the owning rank's HBM and synchronises half-steps with

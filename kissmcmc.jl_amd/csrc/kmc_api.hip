@@ -498,6 +498,8 @@ struct kmc_sampler {
     int64_t nrows = 0;                                   // rows held by this sampler (nwalkers, or nlocal for P2P)
     unsigned long long* d_flags = nullptr;               // fine-grained progress flags [shard_count]
     unsigned long long* d_err = nullptr;
+    uint32_t* d_done = nullptr;                          // KMC_P2P_FOLD_SIGNAL: workgroups drained, per launch
+    bool fold_signal = false;
     double* peer_pos[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     unsigned long long* peer_flags[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
@@ -525,6 +527,9 @@ HalfStepArgs make_args(const kmc_sampler* s, int half, bool graph_mode, int64_t 
     for (int r = 0; r < 8; ++r) a.peer_pos[r] = s->peer_pos[r];
     a.flags = s->d_flags;
     a.err = s->d_err;
+    for (int r = 0; r < 8; ++r) a.peer_flags[r] = s->peer_flags[r];
+    a.done_count = s->fold_signal ? s->d_done : nullptr;
+    a.me = s->cfg.shard_rank;
     a.n_active = (int32_t)s->h_loc;
     a.half = half;
     a.ndim = (int32_t)s->cfg.ndim;
@@ -579,7 +584,7 @@ kmc_status launch_half(kmc_sampler* s, int half, bool graph_mode, int64_t gen_of
 {
     const HalfStepArgs a = make_args(s, half, graph_mode, gen_offset);
     HIP_TRY(launch_half_kernel(s, a));
-    if (s->p2p && s->cfg.shard_count > 1) {
+    if (s->p2p && s->cfg.shard_count > 1 && !s->fold_signal) {
         // the kernel boundary puts this half-step's rows in memory; then publish the progress
         SignalArgs sg{};
         for (int r = 0; r < 8; ++r) sg.peer_flags[r] = s->peer_flags[r];
@@ -959,6 +964,10 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         CREATE_TRY(hipMemset(s->d_flags, 0, 4096));
         CREATE_TRY(hipMalloc((void**)&s->d_err, 64));
         CREATE_TRY(hipMemset(s->d_err, 0, 64));
+        CREATE_TRY(hipMalloc((void**)&s->d_done, 64));
+        CREATE_TRY(hipMemset(s->d_done, 0, 64));
+        // the kernel can publish its own completion only where all its stores are write-through: the vector kernels
+        s->fold_signal = (cfg->flags & KMC_P2P_FOLD_SIGNAL) != 0 && s->plan.vec && s->user == nullptr;
     }
     const size_t ldz = (size_t)s->ld;
     if (s->p2p && (cfg->flags & KMC_P2P_FINEGRAINED))   // peers map the rows uncached: nothing of them can go stale in a reader's L2
@@ -1040,6 +1049,7 @@ KMC_EXPORT void kmc_sampler_destroy(kmc_sampler* s)
         }
         (void)hipFree(s->d_flags);
         (void)hipFree(s->d_err);
+        (void)hipFree(s->d_done);
     }
     if (s->own_pos) (void)hipFree(s->d_pos);
     (void)hipFree(s->d_logp);
@@ -1225,6 +1235,7 @@ KMC_EXPORT kmc_status kmc_sampler_init_ball(kmc_sampler* s, const double* theta0
     if (s->p2p) {
         HIP_TRY(hipMemset(s->d_flags, 0, 4096));
         HIP_TRY(hipMemset(s->d_err, 0, 64));
+        if (s->d_done) HIP_TRY(hipMemset(s->d_done, 0, 64));
     }
     s->dev_gen = 0;
     s->moment_base = 0;
@@ -1252,6 +1263,7 @@ KMC_EXPORT kmc_status kmc_sampler_set_state(kmc_sampler* s, const double* pos_ho
     if (s->p2p) {
         HIP_TRY(hipMemset(s->d_flags, 0, 4096));
         HIP_TRY(hipMemset(s->d_err, 0, 64));
+        if (s->d_done) HIP_TRY(hipMemset(s->d_done, 0, 64));
     }
     s->generation = generation;            // the device counter follows at the next graph replay
     const int64_t done = samples_done(s);
@@ -1275,6 +1287,7 @@ KMC_EXPORT kmc_status kmc_sampler_set_positions(kmc_sampler* s, const double* th
         HIP_TRY(upload_rows(s, s->d_pos + hl * (size_t)s->ld, theta_host + ((size_t)s->h + (size_t)s->active_begin) * nd, hl));
         HIP_TRY(hipMemset(s->d_flags, 0, 4096));     // callers barrier across ranks before running
         HIP_TRY(hipMemset(s->d_err, 0, 64));
+        if (s->d_done) HIP_TRY(hipMemset(s->d_done, 0, 64));
     }
     if (s->host_eval) {                                          // :209-210, on the caller's thread
         std::vector<double> lp0(nw);

@@ -91,6 +91,10 @@ struct HalfStepArgs {
     double*           peer_pos[8];
     const unsigned long long* flags; // flags[r] = number of half-steps rank r has completed
     unsigned long long* err;         // set non-zero when a wait times out
+    // KMC_P2P_FOLD_SIGNAL: the kernel publishes its own completion (vec kernels)
+    unsigned long long* peer_flags[8]; // peer_flags[r] = rank r's flags array
+    uint32_t*         done_count;    // workgroups of this launch that have drained their stores; nullptr: separate signal kernel
+    int32_t           me;            // this rank
     DrawConsts        dc;
     DensityParams     dp;
     double*           chain;        // [nsamples][chain_rows][ndim] or nullptr          (:269)
@@ -575,6 +579,26 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
     if (any_w) {
         if constexpr (kPrefetchAcc) accumulate_wave<L, K, true>(a.msum, a.msumsq, a.macc_stride, tid, g, ms, mq, accs, accq, acct);
         else accumulate_wave<L, K, false>(a.msum, a.msumsq, a.macc_stride, tid, g, ms, mq, accs, accq, acct);
+    }
+    if constexpr (P2P) {
+        // KMC_P2P_FOLD_SIGNAL: every store above is write-through, so once a workgroup's stores have drained they are
+        // in memory, where the peers read them; the last workgroup to get there tells every rank that this rank has
+        // completed half-step `step` (flag = step + 1) -- what the separate p2p_signal kernel does one boundary later
+        if (a.nranks > 1 && a.done_count != nullptr) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                // relaxed: the data are already in memory (write-through stores, drained above); an acquire here would
+                // invalidate the L2 once per workgroup under the waves that are still loading
+                const uint32_t before = __hip_atomic_fetch_add(a.done_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (before == gridDim.x - 1u) {
+                    __hip_atomic_store(a.done_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __threadfence_system();
+                    for (int r = 0; r < a.nranks; ++r)
+                        __hip_atomic_store(a.peer_flags[r] + a.me, (unsigned long long)step + 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
+        }
     }
     KMC_STAMP(3);
 #ifdef KMC_PROBE

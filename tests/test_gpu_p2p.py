@@ -39,13 +39,14 @@ def _worker(rank, world, port, outdir, plan, late_rank=-1):
     from kissmcmc_jl_amd.distributed import P2PEmcee
     if plan == "rosen-ragged":
         return _worker_rosen(rank, world, port, outdir)
-    if plan:
+    fold = plan == "fold"
+    if plan and not fold:
         os.environ["KMC_PLAN"] = plan
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)   # rendezvous only (same GPU: RCCL would refuse)
     try:
-        drv = P2PEmcee(kmc.GaussianIso(), NW, ND, G, NBURN, 1, 2.0, SEED, device=0)
+        drv = P2PEmcee(kmc.GaussianIso(), NW, ND, G, NBURN, 1, 2.0, SEED, device=0, fold_signal=fold)
         drv.set_positions(_theta0())
         if rank == late_rank:
             import time
@@ -104,7 +105,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world,plan", [(2, ""), (4, ""), (2, "generic")])   # the GPU box allows 6 processes on the card: parent + 4 ranks at most
+@pytest.mark.parametrize("world,plan", [(2, ""), (4, ""), (2, "generic"), (2, "fold"), (4, "fold")])   # the GPU box allows 6 processes on the card: parent + 4 ranks at most
 def test_p2p_processes_sharing_one_gpu_equal_oracle(oracle, tmp_path, world, plan):
     import torch.multiprocessing as mp
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), plan), nprocs=world, join=True)
@@ -123,6 +124,13 @@ def test_p2p_tolerates_a_late_rank(oracle, tmp_path):
     the late rank's progress flag) and the result is still bit-exact."""
     import torch.multiprocessing as mp
     mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), "", 1), nprocs=2, join=True)
+    ref = oracle.emcee(oracle.make_config(oracle.GAUSSIAN_ISO, [0.0, 1.0], NW, ND, G, NBURN, 1, 2.0, SEED),
+                       _theta0(), store_chain=False)
+    z = np.load(os.path.join(str(tmp_path), "out.npz"))
+    np.testing.assert_array_equal(z["nacc"], ref["naccept"])
+    np.testing.assert_array_equal(z["pos"], ref["final_pos"])
+    # the same with the progress signal folded into the half-step kernel (KMC_P2P_FOLD_SIGNAL)
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), "fold", 1), nprocs=2, join=True)
     ref = oracle.emcee(oracle.make_config(oracle.GAUSSIAN_ISO, [0.0, 1.0], NW, ND, G, NBURN, 1, 2.0, SEED),
                        _theta0(), store_chain=False)
     z = np.load(os.path.join(str(tmp_path), "out.npz"))
