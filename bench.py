@@ -157,7 +157,7 @@ def main():
         mode = os.environ.get("KMC_BENCH_EXCHANGE", "p2p")
         drv = None
 
-        def try_p2p(finegrained, fold_signal=False):
+        def try_p2p(finegrained, fold_signal=False, push=False):
             """Set up the peer-to-peer exchange and self-check it: 240 generations (hipGraph replays + an eager tail)
             must reproduce, bit for bit, the same generations of the whole ensemble on ONE GPU (rank 0 runs it
             unsharded).  Any error, time-out or mismatch on any rank -> None on every rank."""
@@ -165,7 +165,7 @@ def main():
             d = None
             try:
                 d = P2PEmcee(pdf, nw, NDIM, G, nburn, 1, 2.0, SEED, device=local_rank, finegrained=finegrained,
-                             fold_signal=fold_signal)
+                             fold_signal=fold_signal, push=push)
             except Exception as e:  # noqa: BLE001
                 print(f"[rank {rank}] p2p set-up failed ({e})", file=sys.stderr)
                 ok.zero_()
@@ -183,7 +183,7 @@ def main():
                             ref.run(vgen)
                             ref.sync()
                             if not (np.array_equal(ref.positions(), vpos) and np.array_equal(ref.naccept(), vacc)):
-                                print(f"[rank 0] p2p self-check (finegrained={finegrained}, fold_signal={fold_signal}): "
+                                print(f"[rank 0] p2p self-check (finegrained={finegrained}, fold_signal={fold_signal}, push={push}): "
                                       "sharded run differs from the single-GPU run", file=sys.stderr)
                                 ok.zero_()
                 except Exception as e:  # noqa: BLE001
@@ -215,13 +215,18 @@ def main():
 
         p2p_memory = None
         if mode == "p2p":
-            # candidates, each admitted only by the bit-exact self-check; of the admitted ones the faster (measured) runs.
-            # fold: the half-step kernel publishes its own progress flag (one kernel boundary less per half-step);
-            # plain: a separate signal kernel after every half-step; fine-grained rows only if neither passes.
+            # candidates, each admitted only by the bit-exact self-check; of the admitted ones the fastest (measured) runs.
+            #   pull: partner rows are read from the owning GPU (every drawn row crosses the fabric once);
+            #   push: every rank keeps local copies of the other shards, accepted rows are written to all peers (only
+            #         accepted rows cross the fabric, once per peer): less per link for few ranks, more for many;
+            #   folded signal: the half-step kernel publishes its own progress flag (one kernel boundary less per
+            #         half-step) instead of a separate signal kernel.  Fine-grained rows only if nothing passes.
             tried = []
-            for label, fine, fold in (("coarse-grained rows, signal folded into the kernel", False, True),
-                                      ("coarse-grained rows, signal kernel", False, False)):
-                cand = try_p2p(fine, fold)
+            for label, fold, push in (("pull of drawn rows, signal folded into the kernel", True, False),
+                                      ("pull of drawn rows, signal kernel", False, False),
+                                      ("push of accepted rows into local copies, signal folded into the kernel", True, True),
+                                      ("push of accepted rows into local copies, signal kernel", False, True)):
+                cand = try_p2p(False, fold, push)
                 if cand is None:
                     continue
                 tc = time_short(cand)
@@ -235,7 +240,7 @@ def main():
             if drv is None:
                 drv = try_p2p(True, False)
                 if drv is not None:
-                    p2p_memory = "fine-grained rows, signal kernel"
+                    p2p_memory = "pull of drawn rows, fine-grained memory, signal kernel"
             if rank == 0 and tried:
                 print("[rank 0] p2p variants, s per 256 generations: " + "; ".join(f"{l}: {t:.4f}" for l, t in tried), file=sys.stderr)
             if drv is None:
@@ -260,7 +265,7 @@ def main():
             msum, msq, nmom = drv.moments()
             acc = float(drv.naccept().sum() / nw / max(1, G - nburn))
             drv.close()
-            parallelism = (f"walker-sharded x{world}, peer-to-peer partner reads over xGMI (IPC, {p2p_memory}), "
+            parallelism = (f"walker-sharded x{world}, peer-to-peer exchange over xGMI (IPC): {p2p_memory}; "
                            "progress-flag ordering; self-check vs the unsharded single-GPU run: bit-identical")
         else:
             ex = HipShardExecutor(pdf, nw, NDIM, G, nburn, 1, 2.0, SEED, rank=rank, world=world, device=local_rank)
@@ -336,7 +341,10 @@ def main():
             out["fabric"] = {"remote_partner_bytes_per_gpu_per_launch": rows_per_peer * (world - 1) * NDIM * 8,
                              "bytes_per_link_per_launch": rows_per_peer * NDIM * 8,
                              "link_bound_us_at_77GBs": rows_per_peer * NDIM * 8 / 77e9 * 1e6,
-                             "note": "P2P pull of the drawn rows only; link figure = one xGMI link, one direction (~77 GB/s)"}
+                             "push_bytes_per_link_per_launch": acc * walkers_per_launch * NDIM * 8,
+                             "note": "pull variants move every drawn row once (bytes_per_link from each peer); push variants move "
+                                     "accepted rows only (push_bytes_per_link to each peer); link figure = one xGMI link, one "
+                                     "direction (~77 GB/s); config.parallelism names the variant that ran"}
         if world == 1:
             out["island_mode"] = island
         if world == 1 and not args.no_cpu_baseline:

@@ -88,6 +88,11 @@ enum {
                                   island_size >= ndim + 2, ndim <= 32, shard_count == 1; no chain storage.  Works with user densities
                                   when island_size * (ndim + 3) * 8 B <= 60 KiB. */
     KMC_P2P_FINEGRAINED = 1u << 7, /* with KMC_P2P: keep the rows in fine-grained (coherent, uncached-for-peers) device memory */
+    KMC_P2P_PUSH    = 1u << 9, /* with KMC_P2P: every rank keeps local copies ("shadows") of all the other shards and reads its
+                                  partner rows from them; a rank that accepts a move writes the new row into its shadow on
+                                  every peer as well (posted write-through stores over xGMI).  Only accepted rows cross the
+                                  fabric (C2: 23 %), once per peer, instead of every drawn row once: less per link for few
+                                  ranks, more for many.  Not with KMC_P2P_FINEGRAINED / kmc_sampler_init_ball. */
     KMC_P2P_FOLD_SIGNAL = 1u << 8, /* with KMC_P2P: the half-step kernel itself publishes the progress flag (its stores are
                                       write-through; the last workgroup to drain them signals every rank) instead of a separate
                                       signal kernel after it: one kernel boundary less per half-step */

@@ -500,6 +500,7 @@ struct kmc_sampler {
     unsigned long long* d_err = nullptr;
     uint32_t* d_done = nullptr;                          // KMC_P2P_FOLD_SIGNAL: workgroups drained, per launch
     bool fold_signal = false;
+    bool push = false;                                   // KMC_P2P_PUSH: d_pos = (1 + shard_count) blocks, see HalfStepArgs::push
     double* peer_pos[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     unsigned long long* peer_flags[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
@@ -530,6 +531,8 @@ HalfStepArgs make_args(const kmc_sampler* s, int half, bool graph_mode, int64_t 
     for (int r = 0; r < 8; ++r) a.peer_flags[r] = s->peer_flags[r];
     a.done_count = s->fold_signal ? s->d_done : nullptr;
     a.me = s->cfg.shard_rank;
+    a.push = s->push ? 1 : 0;
+    a.shard_stride = (int64_t)s->nrows * s->ld;
     a.n_active = (int32_t)s->h_loc;
     a.half = half;
     a.ndim = (int32_t)s->cfg.ndim;
@@ -968,13 +971,15 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         CREATE_TRY(hipMemset(s->d_done, 0, 64));
         // the kernel can publish its own completion only where all its stores are write-through: the vector kernels
         s->fold_signal = (cfg->flags & KMC_P2P_FOLD_SIGNAL) != 0 && s->plan.vec && s->user == nullptr;
+        s->push = (cfg->flags & KMC_P2P_PUSH) != 0 && s->plan.vec && s->user == nullptr && !(cfg->flags & KMC_P2P_FINEGRAINED) &&
+                  s->cfg.shard_count > 1;
     }
     const size_t ldz = (size_t)s->ld;
     if (s->p2p && (cfg->flags & KMC_P2P_FINEGRAINED))   // peers map the rows uncached: nothing of them can go stale in a reader's L2
         CREATE_TRY(hipExtMallocWithFlags((void**)&s->d_pos, nw * ldz * sizeof(double), hipDeviceMallocFinegrained));
     else
-        CREATE_TRY(hipMalloc(&s->d_pos, nw * ldz * sizeof(double)));
-    CREATE_TRY(hipMemset(s->d_pos, 0, nw * ldz * sizeof(double)));     // the pad column of odd ndim stays 0
+        CREATE_TRY(hipMalloc(&s->d_pos, (s->push ? 1 + (size_t)s->cfg.shard_count : 1) * nw * ldz * sizeof(double)));
+    CREATE_TRY(hipMemset(s->d_pos, 0, (s->push ? 1 + (size_t)s->cfg.shard_count : 1) * nw * ldz * sizeof(double)));   // the pad column of odd ndim stays 0
     CREATE_TRY(hipMalloc(&s->d_logp, nw * sizeof(double)));
     CREATE_TRY(hipMalloc(&s->d_naccept, nw * sizeof(uint32_t)));
     static_assert(kGraphChunk <= 64, "advance_schedule runs one 64-thread block");
@@ -1189,6 +1194,7 @@ KMC_EXPORT kmc_status kmc_sampler_init_ball(kmc_sampler* s, const double* theta0
 {
     if (!s || !theta0 || !ball_radius || halving_steps < 1 || ntries < 1) return fail(KMC_ERR_BAD_ARG, "bad argument");
     if (s->host_eval) return fail(KMC_ERR_UNSUPPORTED, "kmc_sampler_init_ball evaluates the density on the device; with KMC_HOST_DENSITY build the ball on the host");
+    if (s->push) return fail(KMC_ERR_UNSUPPORTED, "kmc_sampler_init_ball fills this rank's rows only; with KMC_P2P_PUSH use kmc_sampler_set_positions (the peers' copies must be filled too)");
     HIP_TRY(hipSetDevice(s->cfg.device));
     HIP_TRY(hipStreamSynchronize(s->stream));
     const size_t nd = (size_t)s->cfg.ndim;
@@ -1285,6 +1291,14 @@ KMC_EXPORT kmc_status kmc_sampler_set_positions(kmc_sampler* s, const double* th
         const size_t hl = (size_t)s->h_loc;
         HIP_TRY(upload_rows(s, s->d_pos, theta_host + (size_t)s->active_begin * nd, hl));
         HIP_TRY(upload_rows(s, s->d_pos + hl * (size_t)s->ld, theta_host + ((size_t)s->h + (size_t)s->active_begin) * nd, hl));
+        if (s->push) {      // the local copies of the other shards (block 1 + q = rank q's rows)
+            for (int q = 0; q < s->cfg.shard_count; ++q) {
+                if (q == s->cfg.shard_rank) continue;
+                double* blk = s->d_pos + (size_t)(1 + q) * nw * (size_t)s->ld;
+                HIP_TRY(upload_rows(s, blk, theta_host + (size_t)q * hl * nd, hl));
+                HIP_TRY(upload_rows(s, blk + hl * (size_t)s->ld, theta_host + ((size_t)s->h + (size_t)q * hl) * nd, hl));
+            }
+        }
         HIP_TRY(hipMemset(s->d_flags, 0, 4096));     // callers barrier across ranks before running
         HIP_TRY(hipMemset(s->d_err, 0, 64));
         if (s->d_done) HIP_TRY(hipMemset(s->d_done, 0, 64));

@@ -95,6 +95,11 @@ struct HalfStepArgs {
     unsigned long long* peer_flags[8]; // peer_flags[r] = rank r's flags array
     uint32_t*         done_count;    // workgroups of this launch that have drained their stores; nullptr: separate signal kernel
     int32_t           me;            // this rank
+    // KMC_P2P_PUSH: pos is (1 + nranks) blocks of shard_stride doubles -- block 0 this rank's rows, block 1 + q a local
+    // copy of rank q's; partner rows are read from the local copies, accepted rows are also written to block 1 + me of
+    // every peer (peer_pos[r] = rank r's pos)
+    int32_t           push;
+    int64_t           shard_stride;
     DrawConsts        dc;
     DensityParams     dp;
     double*           chain;        // [nsamples][chain_rows][ndim] or nullptr          (:269)
@@ -422,6 +427,7 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
         const double* base = a.peer_pos[0];
 #pragma unroll
         for (int t = 1; t < 8; ++t) base = (q == (uint32_t)t) ? a.peer_pos[t] : base;
+        if (a.push) base = (q == (uint32_t)a.me) ? a.pos : a.pos + (int64_t)(1u + q) * a.shard_stride;   // local copy of rank q's shard
         addrA = (unsigned long long)(base + (oth_row0 + r) * ld);
         if (a.nranks > 1) {
             // every rank must have finished half-step `step - 1`: one polling wave per workgroup (the
@@ -561,6 +567,17 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
             double2* own = reinterpret_cast<double2*>(f.pos + ((int64_t)f.own_row0 + w0 + it * G + g) * ld);
 #pragma unroll
             for (int k = 0; k < K; ++k) if (cv[k]) store_row16(&own[k * L + j], xo[it][k]);
+            if constexpr (P2P) {
+                if (a.push) {                                           // ... and into this rank's shadow on every peer
+                    const int64_t off = (int64_t)(1 + a.me) * a.shard_stride + ((int64_t)f.own_row0 + w0 + it * G + g) * ld;
+                    for (int r = 0; r < a.nranks; ++r) {
+                        if (r == a.me) continue;
+                        double2* rem = reinterpret_cast<double2*>(a.peer_pos[r] + off);
+#pragma unroll
+                        for (int k = 0; k < K; ++k) if (cv[k]) store_wt(&rem[k * L + j], xo[it][k]);
+                    }
+                }
+            }
         }
         if (any_w) {
             const double wB = (double)(uint32_t)__builtin_amdgcn_ds_bpermute((gbase + it) * 4, (int)wA);

@@ -110,7 +110,7 @@ class P2PEmcee:
     """
 
     def __init__(self, pdf, nwalkers, ndim, ngenerations, nburnin=0, nthin=1, a_scale=2.0, seed=0,
-                 device=0, moments=True, group=None, use_graph=True, finegrained=False, fold_signal=False):
+                 device=0, moments=True, group=None, use_graph=True, finegrained=False, fold_signal=False, push=False):
         from .sampler import Sampler
         self.group = group
         self.rank = dist.get_rank(group) if dist is not None and dist.is_initialized() else 0
@@ -120,7 +120,7 @@ class P2PEmcee:
         self.sampler = Sampler(pdf, nwalkers, ndim, ngenerations, nburnin, nthin, a_scale, seed,
                                moments=moments, use_graph=use_graph, device=device,
                                shard_rank=self.rank, shard_count=self.world, p2p=True, p2p_finegrained=finegrained,
-                               p2p_fold=fold_signal)
+                               p2p_fold=fold_signal, p2p_push=push)
         if self.world > 1:
             blobs = [None] * self.world
             dist.all_gather_object(blobs, self.sampler.p2p_export(), group=group)

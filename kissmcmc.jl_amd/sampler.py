@@ -22,7 +22,7 @@ class Sampler:
                  nthin: int = 1, a_scale: float = 2.0, seed: int = 0, store_chain: bool = False,
                  store_logp: bool = False, moments: bool = False, use_graph: bool = True,
                  device: int = 0, shard_rank: int = 0, shard_count: int = 1, p2p: bool = False,
-                 island_gens: int = 0, island_size: int = 0, p2p_finegrained: bool = False, p2p_fold: bool = False):
+                 island_gens: int = 0, island_size: int = 0, p2p_finegrained: bool = False, p2p_fold: bool = False, p2p_push: bool = False):
         if not isinstance(pdf, DeviceLogPdf):
             raise TypeError(
                 "pdf must be a menu log-density (GaussianIso, Exponential, Rosenbrock, LogNormal, MvNormal2), "
@@ -56,6 +56,8 @@ class Sampler:
                 flags |= _lib.P2P_FINEGRAINED
             if p2p_fold:
                 flags |= _lib.P2P_FOLD_SIGNAL
+            if p2p_push:
+                flags |= _lib.P2P_PUSH
         if island_gens:
             # ISLAND MODE: 256-walker islands resident in LDS for `island_gens` generations per launch
             flags |= _lib.ISLANDS
