@@ -28,7 +28,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-NWALKERS_PER_GPU = 65536
+NWALKERS_PER_GPU = int(os.environ.get("KMC_BENCH_WALKERS", 65536))   # (override: rehearsing several ranks on ONE GPU only)
 NDIM = 32
 GENS_PER_STEP = 1000
 SEED = 12345
