@@ -5,9 +5,11 @@ Workload (BASELINE.json configs[1], "C2"): 65 536 walkers x 32-dim isotropic Gau
 a = 2, 10^4 generations (burn-in = first half), streaming moments ON, chain storage OFF.
 One bench "step" = GENS_PER_STEP (1000) generations = 65.536e6 walker-steps per GPU, so the
 default --steps 10 is exactly the 10^4-generation job.  With --gpus N (launched by
-torch.distributed.run, one rank per GPU) the ensemble is 65 536 x N walkers, walker-sharded with an
-peer-to-peer partner reads over xGMI (KMC_P2P; falls back to an RCCL all-gather of the updated half per
-half-step if the IPC set-up fails) -- weak scaling, config C4 at N = 8.
+torch.distributed.run, one rank per GPU) the ensemble is 65 536 x N walkers, walker-sharded with a
+peer-to-peer exchange over xGMI (KMC_P2P: pull of the drawn partner rows, or push of the accepted rows into
+local copies, each with a signal kernel or the signal folded into the half-step kernel -- every variant is
+admitted by a bit-exact self-check against the unsharded run, timed, and the fastest runs; falls back to an
+RCCL all-gather of the updated half per half-step if none passes) -- weak scaling, config C4 at N = 8.
 
 Prints ONE JSON line (rank 0).  `value` = all walker-steps of the timed region / wall time
 (max over ranks) with the ensemble resident in HBM.  `roofline` prices the half-step kernel
