@@ -342,13 +342,13 @@ kmc_status compile_user(kmc_user_density* ud, bool with_vec, int L, int K, int i
         return fail(KMC_ERR_BAD_ARG, "user density: kernel headers not found in " + dir + " (set KMC_CSRC_DIR)");
 
     std::ostringstream src;
-    src << "#define KMC_TPB " << kTPB << "\n#include \"kmc_islands.hpp\"\n" << user_functor_source(ud)
+    src << "#include \"kmc_islands.hpp\"\n" << user_functor_source(ud)
         << "using UD = kmc::TermPairDensity<UserF>;\n"
         << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_generic(KMC_FRONT_PARAMS, const kmc::HalfStepArgs a) { kmc::half_step_generic_body<UD, false>(KMC_FRONT_PACK, a); }\n"
         << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_logpdf(const kmc::LogpdfArgs a) { kmc::logpdf_rows_body<UD>(a); }\n"
         << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_init_ball(const kmc::InitBallArgs a) { kmc::init_ball_body<UD>(a); }\n";
     if (with_vec)
-        src << "extern \"C\" __global__ __launch_bounds__(" << kTPB << ") void kmc_user_vec(KMC_FRONT_PARAMS, const kmc::HalfStepArgs a) { kmc::half_step_vec_body<UD, "
+        src << "extern \"C\" __global__ __launch_bounds__(" << vec_tpb(L) << ") void kmc_user_vec(KMC_FRONT_PARAMS, const kmc::HalfStepArgs a) { kmc::half_step_vec_body<UD, "
             << L << ", " << K << ", " << iter << ", false, " << (ragged ? "true" : "false") << ">(KMC_FRONT_PACK, a); }\n";
     if (resident_K > 0 && island_S == 0)
         src << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_resident(const kmc::ResidentArgs a) { kmc::resident_body<UD, "
@@ -936,8 +936,8 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
             }
         }
     }
-    // vec kernels: kTPB threads per workgroup; the generic kernel keeps 256
-    const int tpb = s->plan.vec ? kTPB : 256;
+    // vec kernels: vec_tpb(L) threads per workgroup; the generic kernel keeps 256
+    const int tpb = s->plan.vec ? vec_tpb(s->plan.L) : 256;
     s->tpb = tpb;
     s->grid = (int)((waves * 64 + tpb - 1) / tpb);
     s->macc_stride = (int64_t)s->grid * tpb;

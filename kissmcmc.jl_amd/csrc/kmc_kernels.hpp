@@ -34,11 +34,24 @@
 
 #ifndef KMC_TPB
 #define KMC_TPB 256   // threads per workgroup of the half-step kernels (waves are independent)
+#else
+#define KMC_TPB_FORCED 1
 #endif
 
 namespace kmc {
 
 constexpr int kTPB = KMC_TPB;
+// Workgroup size of the vector kernels by lane-group width: short rows (L <= 8, ndim <= 32) run 3-4 % faster in
+// 128-thread workgroups (measured at C2 in two separate A/B runs), longer rows do not
+// (-DKMC_TPB=n forces one size for every geometry).
+__host__ __device__ constexpr int vec_tpb(int L)
+{
+#ifdef KMC_TPB_FORCED
+    return kTPB;
+#else
+    return L <= 8 ? 128 : kTPB;
+#endif
+}
 
 // What the reference's loop variable n (src/samplers.jl:245) implies for one generation.
 struct SchedEntry {
@@ -346,7 +359,7 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
     constexpr int W = G * ITER;        // walkers per wave
     const int ndim = RAGGED ? a.ndim : 2 * L * K;        // ragged: chunks past the row's end are skipped
     const int64_t ld = RAGGED ? (int64_t)a.ld : (int64_t)(2 * L * K);
-    const int tid   = blockIdx.x * kTPB + threadIdx.x;
+    const int tid   = blockIdx.x * vec_tpb(L) + threadIdx.x;
     const int lane  = threadIdx.x & 63;
     const int j     = lane & (L - 1);
     const int g     = lane / L;
@@ -624,7 +637,7 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
 }
 
 template <class Dens, int L, int K, int ITER, bool P2P, bool RAGGED>
-__global__ __launch_bounds__(kTPB) void half_step_vec(KMC_FRONT_PARAMS, const HalfStepArgs a)
+__global__ __launch_bounds__(vec_tpb(L)) void half_step_vec(KMC_FRONT_PARAMS, const HalfStepArgs a)
 {
     half_step_vec_body<Dens, L, K, ITER, P2P, RAGGED>(KMC_FRONT_PACK, a);
 }
@@ -644,12 +657,12 @@ struct FlushArgs {
 };
 
 template <int L, int K, int ITER>
-__global__ __launch_bounds__(kTPB) void flush_moments_vec(const FlushArgs a)
+__global__ __launch_bounds__(vec_tpb(L)) void flush_moments_vec(const FlushArgs a)
 {
     constexpr int G = 64 / L;
     constexpr int W = G * ITER;
     const int64_t ld = a.ld;
-    const int tid  = blockIdx.x * kTPB + threadIdx.x;
+    const int tid  = blockIdx.x * vec_tpb(L) + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const int j    = lane & (L - 1);
     const int g    = lane / L;
