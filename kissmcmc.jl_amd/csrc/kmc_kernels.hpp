@@ -41,15 +41,16 @@
 namespace kmc {
 
 constexpr int kTPB = KMC_TPB;
-// Workgroup size of the vector kernels by lane-group width: short rows (L <= 8, ndim <= 32) run 3-4 % faster in
-// 128-thread workgroups (measured at C2 in two separate A/B runs), longer rows do not
+// Workgroup size of the vector kernels by lane-group width, from repeated A/B runs of forced sizes: L <= 8 (ndim <= 32,
+// C2) 128 threads (-3 % against 256), L = 16 (C3) 64 threads (-2.5 %; 128 is 8 % SLOWER there with moments on), longer
+// rows (C5) 256
 // (-DKMC_TPB=n forces one size for every geometry).
 __host__ __device__ constexpr int vec_tpb(int L)
 {
 #ifdef KMC_TPB_FORCED
     return kTPB;
 #else
-    return L <= 8 ? 128 : kTPB;
+    return L <= 8 ? 128 : L == 16 ? 64 : kTPB;
 #endif
 }
 
