@@ -53,9 +53,16 @@ __device__ __forceinline__ void normal_pair(uint32_t a, uint32_t b, double& n0, 
     const double u2 = ((double)b + 0.5) * 0x1.0p-32;
     const double r = sqrt(-2.0 * log_pos_normal(u1));     // u1 in (0,1): positive, normal
     double sn, cs;
-    sincos(6.283185307179586476925286766559 * u2, &sn, &cs);
+    sincospi(2.0 * u2, &sn, &cs);        // = sincos(2 pi u2) without the argument reduction (agrees to rounding)
     n0 = r * cs;
     n1 = r * sn;
+}
+
+__device__ __forceinline__ double normal_first(uint32_t a, uint32_t b)
+{   // n0 of normal_pair alone (1-D chains)
+    const double u1 = ((double)a + 0.5) * 0x1.0p-32;
+    const double u2 = ((double)b + 0.5) * 0x1.0p-32;
+    return sqrt(-2.0 * log_pos_normal(u1)) * cospi(2.0 * u2);
 }
 
 // ND > 0: ndim <= ND, the chain lives in registers.
@@ -81,7 +88,8 @@ __device__ __forceinline__ void metropolis_chains_body(const MetropolisArgs& a)
     for (int64_t it = a.it0; it < a.it1; ++it, ++n) {
         const U4 w = philox4x32_10((uint32_t)it, (uint32_t)((uint64_t)it >> 32), (uint32_t)c, 0u, k0, k1);
         double nr[ND + 4];
-        normal_pair(w.x, w.y, nr[0], nr[1]);
+        if constexpr (ND == 1) nr[0] = normal_first(w.x, w.y);
+        else normal_pair(w.x, w.y, nr[0], nr[1]);
         if constexpr (ND > 2) {
 #pragma unroll
             for (int b = 1; 4 * b - 2 < ND; ++b) {
