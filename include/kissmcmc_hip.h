@@ -70,6 +70,13 @@ typedef enum kmc_density {
    Return 0, or non-zero to abort the run (kmc_sampler_run then returns KMC_ERR_BAD_ARG).  Called on the
    thread that called kmc_sampler_set_positions / kmc_sampler_run / kmc_emcee_run. */
 typedef int (*kmc_host_logpdf_fn)(const double* rows, int64_t nrows, int64_t ndim, double* logp_out, void* user);
+/* KMC_HOST_DENSITY, optional: called after the accept test of every half-step with its outcome, so the caller can
+   carry per-walker side data of its density (the reference's blobs: `blob0s[nc] = blob1` on accept :264,
+   `reduce_blob!(blobs[nc], blob0s[nc])` when the state is stored :270).  accepted[i] = 1 when row i of the batch
+   host_logpdf has just evaluated replaced walker row0 + i; stored = 1 when this generation's states are stored
+   (after burn-in, every nthin-th).  Return 0, or non-zero to abort the run. */
+typedef int (*kmc_host_accepted_fn)(const uint8_t* accepted, int64_t nrows, int64_t row0, int64_t generation,
+                                    int32_t stored, void* user);
 
 enum {
     KMC_F64 = 0 /* state and arithmetic in IEEE double, as the reference (Float64) */
@@ -123,7 +130,8 @@ typedef struct kmc_config {
     int32_t  island_gens;   /* KMC_ISLANDS: generations per epoch (launch); 0 -> 32 */
     int32_t  island_size;   /* KMC_ISLANDS: walkers per island: 64, 128 or 256; 0 -> 256 */
     kmc_host_logpdf_fn host_logpdf; /* KMC_HOST_DENSITY: the callback, else NULL */
-    void*    host_user;     /* passed through to host_logpdf */
+    void*    host_user;     /* passed through to host_logpdf / host_accepted */
+    kmc_host_accepted_fn host_accepted; /* KMC_HOST_DENSITY: per-half-step accept outcomes, or NULL */
 } kmc_config;
 
 /* Host output buffers of the one-shot call; any pointer may be NULL. */

@@ -6,9 +6,10 @@ argument meaning and error behaviour -- over the C ABI:
 * ``squash_walkers(thetas, accept_ratio, logdensities, blobs; ...)``  reference ``src/samplers.jl:372-428``
 
 Differences from the reference, all forced by the device boundary:
-``pdf`` must be a menu density (:mod:`.densities`); ``hasblob=True`` is rejected; a ``seed``
-keyword makes runs reproducible (the reference never seeds); outputs are dense ndarrays indexed
-``thetas[walker][sample]`` instead of vectors of vectors.
+``pdf`` is a device density (:mod:`.densities`) or any host callable (evaluated on the host per
+half-step; the only kind that can carry blobs, ``hasblob=True``); a ``seed`` keyword makes runs
+reproducible (the reference never seeds); outputs are dense ndarrays indexed
+``thetas[walker][sample]`` instead of vectors of vectors (blobs: a list per walker).
 """
 from __future__ import annotations
 
@@ -45,13 +46,26 @@ def emcee(pdf, theta0s, niter: int = 10 ** 5, nburnin=None, nthin: int = 1, a_sc
     Returns ``(thetas, accept_ratio, logdensities, blobs)`` like the reference
     (``src/samplers.jl:292``): ``thetas[w][k]`` is sample ``k`` of walker ``w``
     (shape ``[nwalkers, nsamples]`` for scalar walkers, ``[nwalkers, nsamples, ndim]`` otherwise),
-    ``accept_ratio[w]``, ``logdensities[w][k]``, and ``blobs = None``.
+    ``accept_ratio[w]``, ``logdensities[w][k]``, and ``blobs`` (``None`` unless ``hasblob``).
+
+    ``hasblob=True`` (``:150-151, :194-196``): ``pdf`` is a host callable returning ``(p, blob)``; the blobs
+    stay on the host and follow the device's accept decisions.  ``blobs[w] = init_blobs(blob0s[w],
+    nsamples_walker)`` (default: an empty list) and ``reduce_blob(blobs[w], blob)`` (default: append) is
+    called for every stored sample with the walker's current blob (``:270``).
     """
-    if hasblob or init_blobs is not None or reduce_blob is not None:
-        raise NotImplementedError("blobs are arbitrary host objects and cannot cross the device boundary "
-                                  "(hasblob=True is not supported by the HIP emcee path)")
     theta0s = np.array(theta0s, dtype=np.float64)              # :198 deepcopy
     scalar_walkers = theta0s.ndim == 1
+    if not hasblob and (init_blobs is not None or reduce_blob is not None):
+        raise ValueError("init_blobs / reduce_blob need hasblob=True")
+    if hasblob:
+        if isinstance(pdf, HostLogPdf):
+            if not pdf.hasblob:
+                raise ValueError("hasblob=True needs HostLogPdf(..., hasblob=True)")
+        elif isinstance(pdf, DeviceLogPdf):
+            raise NotImplementedError("blobs are host objects: hasblob=True needs a host callable as pdf "
+                                      "(device densities return the log-pdf alone)")
+        elif callable(pdf):
+            pdf = HostLogPdf(pdf, scalar=scalar_walkers, hasblob=True)
     if not isinstance(pdf, DeviceLogPdf):
         if not callable(pdf):
             raise TypeError(f"pdf must be a log-density object or a callable; got {type(pdf).__name__}")
@@ -82,6 +96,24 @@ def emcee(pdf, theta0s, niter: int = 10 ** 5, nburnin=None, nthin: int = 1, a_sc
             if e.status == _lib.ERR_NONFINITE_LOGP:
                 raise ValueError(f"{e} (use make_theta0s to build an initial ensemble with pdf > -Inf)") from e
             raise
+        blobs = None
+        if hasblob:
+            if init_blobs is None:
+                init_blobs = lambda blob0, nsamples: []        # init_output_vector :80-85
+            if reduce_blob is None:
+                reduce_blob = lambda bs, b: bs.append(b)       # push!  :196
+            blob0s = list(pdf.last_blobs)                      # :209-210, from the initial evaluations
+            blobs = [init_blobs(blob0s[w], nsamples_walker) for w in range(nwalkers)]   # :238
+
+            def on_accepted(accepted, row0, generation, stored):
+                batch = pdf.last_blobs
+                for i in np.nonzero(accepted)[0]:
+                    blob0s[row0 + i] = batch[i]                # :264
+                if stored:
+                    for w in range(row0, row0 + accepted.shape[0]):
+                        reduce_blob(blobs[w], blob0s[w])       # :270
+
+            pdf.on_accepted = on_accepted
         if use_progress_meter and niter_walker > 0:
             nchunks = min(20, niter_walker)
             done = 0
@@ -107,7 +139,9 @@ def emcee(pdf, theta0s, niter: int = 10 ** 5, nburnin=None, nthin: int = 1, a_sc
         thetas = thetas[:, :, 0]
     logdensities = np.ascontiguousarray(chain_logp.T)          # [walker][sample]
     assert thetas.shape[1] == nsamples_walker
-    return thetas, accept_ratio, logdensities, None
+    if hasblob:
+        pdf.on_accepted = None
+    return thetas, accept_ratio, logdensities, blobs
 
 
 def make_theta0s(theta0, ball_radius, pdf, nwalkers: int, ball_radius_halfing_steps: int = 7,
@@ -120,10 +154,13 @@ def make_theta0s(theta0, ball_radius, pdf, nwalkers: int, ball_radius_halfing_st
     Unlike the reference -- whose final ``error(...)`` is unreachable -- this
     raises when no admissible point is found for a walker.
     """
-    if hasblob:
-        raise NotImplementedError("hasblob=True is not supported by the HIP emcee path")
     if not callable(pdf):
         raise TypeError("pdf must be callable")
+    if hasblob and isinstance(pdf, DeviceLogPdf) and not getattr(pdf, "hasblob", False):
+        raise NotImplementedError("hasblob=True needs a host callable returning (p, blob)")
+    if hasblob and not getattr(pdf, "hasblob", False):          # :333-337  p0, blob0 = pdf(tmp)
+        pdf_blob = pdf
+        pdf = lambda t: pdf_blob(t)[0]
     rng = np.random.default_rng(rng)
     scalar = np.ndim(theta0) == 0
     theta0 = float(theta0) if scalar else np.asarray(theta0, dtype=np.float64)
@@ -175,8 +212,6 @@ def squash_walkers(thetas, accept_ratio, logdensities=None, blobs=None, drop_low
     ``order=True`` gives sample-major with walkers in index order inside each step (``:415-426``).
     Returns ``(thetas, mean(accept_ratio[kept]), logdensities, blobs)``.
     """
-    if blobs is not None:
-        raise NotImplementedError("blobs are not produced by the HIP emcee path")
     thetas = np.asarray(thetas)
     accept_ratio = np.asarray(accept_ratio, dtype=np.float64)
     nwalkers = accept_ratio.shape[0]                           # :379
@@ -201,4 +236,17 @@ def squash_walkers(thetas, accept_ratio, logdensities=None, blobs=None, drop_low
 
     t = flat(thetas)                                           # :398-399
     l = None if logdensities is None else flat(logdensities)   # :401-406
-    return t, float(np.mean(accept_ratio[walkers2keep])), l, None   # :427
+    b = None
+    if blobs is not None:                                      # :408-413
+        import copy
+        if merge_blobs is None:
+            merge_blobs = lambda b1, b2: b1.extend(b2)         # append!
+        b = copy.deepcopy(blobs[walkers2keep[0]])
+        for w in walkers2keep[1:]:
+            merge_blobs(b, blobs[w])
+        if order:                                              # :415-421: b[perm], walker-major -> sample-major
+            nc, ns = len(walkers2keep), thetas.shape[1]
+            if len(b) != nc * ns:
+                raise ValueError("order=True needs one stored blob per sample (blobs kept in vectors)")
+            b = [b[w * ns + k] for k in range(ns) for w in range(nc)]
+    return t, float(np.mean(accept_ratio[walkers2keep])), l, b   # :427

@@ -479,6 +479,8 @@ struct kmc_sampler {
     double* d_p1 = nullptr;            // [h] their log-pdfs, as returned by the callback
     double* h_prop = nullptr;          // pinned, dense [h][ndim]
     double* h_p1 = nullptr;            // pinned [h]
+    uint8_t* d_acc = nullptr;          // [h] accept outcomes of the current half-step (host_accepted only)
+    uint8_t* h_acc = nullptr;          // pinned [h]
     // resident mode: exact sampler, whole (small) ensemble in one workgroup's LDS, many generations per launch
     bool resident = false;
     ResidentFn resident_kernel = nullptr;
@@ -801,6 +803,7 @@ KMC_EXPORT kmc_status kmc_validate(const kmc_config* c)
         if ((c->flags & (KMC_P2P | KMC_ISLANDS)) || c->shard_count > 1)
             return fail(KMC_ERR_UNSUPPORTED, "KMC_HOST_DENSITY runs on one GPU, without KMC_P2P / KMC_ISLANDS / sharding");
     }
+    if (c->host_accepted && c->density != KMC_HOST_DENSITY) return fail(KMC_ERR_BAD_ARG, "kmc_config.host_accepted needs KMC_HOST_DENSITY");
     if (c->density == KMC_ROSENBROCK && c->ndim < 2) return fail(KMC_ERR_BAD_ARG, "rosenbrock needs ndim >= 2");
     if (c->density == KMC_MVNORMAL2 && c->ndim != 2) return fail(KMC_ERR_BAD_ARG, "mvnormal2 needs ndim == 2");
     const int P = c->shard_count <= 0 ? 1 : c->shard_count;
@@ -1016,6 +1019,10 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         CREATE_TRY(hipMalloc(&s->d_p1, (size_t)s->h * sizeof(double)));
         CREATE_TRY(hipHostMalloc((void**)&s->h_prop, (size_t)s->h * (size_t)cfg->ndim * sizeof(double), hipHostMallocDefault));
         CREATE_TRY(hipHostMalloc((void**)&s->h_p1, (size_t)s->h * sizeof(double), hipHostMallocDefault));
+        if (cfg->host_accepted) {
+            CREATE_TRY(hipMalloc(&s->d_acc, (size_t)s->h));
+            CREATE_TRY(hipHostMalloc((void**)&s->h_acc, (size_t)s->h, hipHostMallocDefault));
+        }
     }
     if ((cfg->flags & KMC_STORE_CHAIN) && s->nsamples > 0)
         CREATE_TRY(hipMalloc(&s->d_chain, (size_t)s->nsamples * (size_t)s->nlocal * ldz * sizeof(double)));
@@ -1073,6 +1080,8 @@ KMC_EXPORT void kmc_sampler_destroy(kmc_sampler* s)
     (void)hipFree(s->d_p1);
     if (s->h_prop) (void)hipHostFree(s->h_prop);
     if (s->h_p1) (void)hipHostFree(s->h_p1);
+    (void)hipFree(s->d_acc);
+    if (s->h_acc) (void)hipHostFree(s->h_acc);
     if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
     (void)hipGetLastError();
     delete s;
@@ -1441,8 +1450,18 @@ KMC_EXPORT kmc_status kmc_sampler_run(kmc_sampler* s, int64_t ngen)
                 HIP_TRY(hipMemcpyAsync(s->d_p1, s->h_p1, hh * sizeof(double), hipMemcpyHostToDevice, s->stream));
                 a.prop_out = nullptr;
                 a.p1_in = s->d_p1;
+                a.acc_out = s->d_acc;
                 HIP_TRY(launch_half_kernel(s, a));
                 s->launches += 2;
+                if (s->cfg.host_accepted) {
+                    HIP_TRY(hipMemcpyAsync(s->h_acc, s->d_acc, hh, hipMemcpyDeviceToHost, s->stream));
+                    HIP_TRY(hipStreamSynchronize(s->stream));
+                    const int32_t stored = (a.sched_inline.flags & kSample) != 0 ? 1 : 0;
+                    if (s->cfg.host_accepted(s->h_acc, (int64_t)hh, (int64_t)half * (int64_t)hh, s->generation, stored, s->cfg.host_user) != 0) {
+                        s->positions_set = false;
+                        return fail(KMC_ERR_BAD_ARG, "the host accept callback failed in generation " + std::to_string(s->generation));
+                    }
+                }
             }
             s->generation += 1;
         }

@@ -135,6 +135,7 @@ struct HalfStepArgs {
     // host-evaluated densities (HostEval) only
     double*           prop_out;     // PROPOSE pass: proposals [n_active][ld]; nothing else is touched
     const double*     p1_in;        // ACCEPT pass: log-pdf of proposal i as evaluated by the host
+    unsigned char*    acc_out;      // ACCEPT pass, optional: 1 where proposal i replaced its walker (:261), else 0
 };
 
 // The fields a wave needs before it can issue its first loads travel as LEADING SCALAR kernel parameters, ahead
@@ -743,6 +744,7 @@ __device__ __forceinline__ void half_step_generic_body(const HalfStepFront& f, c
     double p1 = Dens::seq_finish(q, ndim, a.dp);                         // :257
     if constexpr (kHost) p1 = a.p1_in[tid];
     const bool acc = accept_test(dr, p1, p0);                           // :260
+    if constexpr (kHost) { if (a.acc_out != nullptr) a.acc_out[tid] = acc ? 1 : 0; }
 
     const bool do_mom = sample && a.msum != nullptr;
     const bool do_chain = sample && a.chain != nullptr;

@@ -243,16 +243,36 @@ class HostLogPdf(DeviceLogPdf):
     ``fn(theta)`` gets one walker: a float when ``scalar`` (the reference's 1-D convention, where
     ``theta0s`` is a vector of numbers) else a 1-D array.  With ``vectorized=True`` it gets the whole
     batch ``[nrows, ndim]`` and must return ``nrows`` log-pdfs.
+
+    ``hasblob=True``: ``fn`` returns ``(p, blob)`` (``src/samplers.jl:150-151``; vectorized: ``(ps, blobs)``
+    with one blob per row).  The blobs of the batch evaluated last are kept in ``last_blobs`` and the
+    device reports each half-step's accept outcomes to ``on_accepted(accepted, row0, generation, stored)``
+    (``kmc_config.host_accepted``), which is how :func:`kissmcmc_jl_amd.emcee` carries the reference's
+    ``blob0s`` / ``reduce_blob!`` (``:264, :270``) on the host.
     """
 
     density_id = _lib.HOST_DENSITY
     name = "host"
 
-    def __init__(self, fn, vectorized: bool = False, scalar: bool = False):
+    def __init__(self, fn, vectorized: bool = False, scalar: bool = False, hasblob: bool = False):
         if not callable(fn):
             raise TypeError("pdf must be callable")
-        self.fn, self.vectorized, self.scalar = fn, bool(vectorized), bool(scalar)
+        self.fn, self.vectorized, self.scalar, self.hasblob = fn, bool(vectorized), bool(scalar), bool(hasblob)
         self.error = None          # exception raised by fn inside the C callback, re-raised by Sampler
+        self.last_blobs = None     # hasblob: blobs of the rows evaluated last, in row order
+        self.on_accepted = None    # hasblob: callable(accepted uint8[nrows], row0, generation, stored)
+        self.c_accepted = None
+        if self.hasblob:
+            def _acc(flags, nrows, row0, generation, stored, _user):
+                try:
+                    if self.on_accepted is not None:
+                        self.on_accepted(np.ctypeslib.as_array(flags, shape=(nrows,)), int(row0), int(generation), bool(stored))
+                    return 0
+                except BaseException as e:  # never unwind through the C frames
+                    self.error = e
+                    return 1
+
+            self.c_accepted = _lib.HOST_ACCEPTED_FN(_acc)
 
         def _cb(rows, nrows, ndim, out, _user):
             try:
@@ -271,16 +291,27 @@ class HostLogPdf(DeviceLogPdf):
     def eval_rows(self, X):
         X = np.asarray(X, dtype=np.float64)
         if self.vectorized:
-            r = np.asarray(self.fn(X[:, 0] if self.scalar else X), dtype=np.float64).reshape(-1)
+            r = self.fn(X[:, 0] if self.scalar else X)
+            if self.hasblob:
+                r, blobs = r
+                blobs = list(blobs)
+                if len(blobs) != X.shape[0]:
+                    raise ValueError(f"vectorized pdf returned {len(blobs)} blobs for {X.shape[0]} rows")
+                self.last_blobs = blobs
+            r = np.asarray(r, dtype=np.float64).reshape(-1)
             if r.shape[0] != X.shape[0]:
                 raise ValueError(f"vectorized pdf returned {r.shape[0]} values for {X.shape[0]} rows")
             return r
-        if self.scalar:
-            return np.array([float(self.fn(float(v))) for v in X[:, 0]], dtype=np.float64)
-        return np.array([float(self.fn(row.copy())) for row in X], dtype=np.float64)
+        args = (float(v) for v in X[:, 0]) if self.scalar else (row.copy() for row in X)
+        if self.hasblob:
+            res = [self.fn(t) for t in args]                   # p1, blob1 = pdf(theta1)  :257
+            self.last_blobs = [b for _, b in res]
+            return np.array([float(p) for p, _ in res], dtype=np.float64)
+        return np.array([float(self.fn(t)) for t in args], dtype=np.float64)
 
     def __call__(self, theta):
-        return float(self.fn(theta))
+        r = self.fn(theta)
+        return float(r[0] if self.hasblob else r)
 
     def finite_rows(self, X):
         return self.eval_rows(X) > -np.inf

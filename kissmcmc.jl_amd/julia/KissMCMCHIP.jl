@@ -61,27 +61,60 @@ user_handle(::DeviceLogPdf) = C_NULL
 function (d::ExprDensity)(x)
     xs = collect(Float64, x isa Number ? [x] : x); out = Ref(0.0)
     p8 = ntuple(i -> i <= length(d.p) ? d.p[i] : 0.0, 8)
-    cfg = Ref(KmcConfig(0, Cint(100), p8, 2, length(xs), 0, 0, 1, 2.0, UInt64(0), 0, 0, 0, 1, d.handle, 0, 0, C_NULL, C_NULL))
+    cfg = Ref(KmcConfig(0, Cint(100), p8, 2, length(xs), 0, 0, 1, 2.0, UInt64(0), 0, 0, 0, 1, d.handle, 0, 0, C_NULL, C_NULL, C_NULL))
     st = ccall((:kmc_logpdf_eval_host, LIB), Cint, (Ref{KmcConfig}, Ptr{Float64}, Ref{Float64}, Int64), cfg, xs, out, 1)
     st == 0 || error(last_error()); out[]
 end
 
 # Any Julia callable as the log-density (the reference's closure, src/samplers.jl:257), evaluated on
 # the host: kmc_config.host_logpdf points at `host_trampoline`, host_user at the wrapper object.
-mutable struct HostLogPdf{F} <: DeviceLogPdf; f::F; scalar::Bool; end
-HostLogPdf(f) = HostLogPdf(f, false)
+# With hasblob the closure returns (p, blob) (src/samplers.jl:150-151): the blobs stay on the host --
+# `batch` holds those of the rows evaluated last, `blob0s` the walkers' current ones (:264), `blobs` the
+# per-walker storage (:238, :270) -- and follow the device's accept decisions, reported per half-step
+# through kmc_config.host_accepted (`accepted_trampoline`).
+mutable struct HostLogPdf{F} <: DeviceLogPdf
+    f::F; scalar::Bool; hasblob::Bool
+    batch::Vector{Any}; blob0s::Vector{Any}; blobs::Vector{Any}
+    init_blobs::Any; reduce_blob!::Any; nsamples::Int
+end
+HostLogPdf(f; hasblob=false) = HostLogPdf(f, false, hasblob, Any[], Any[], Any[], nothing, nothing, 0)
 (d::HostLogPdf)(x) = d.f(x)
 density_id(::HostLogPdf) = Cint(101); params(::HostLogPdf) = Float64[]
 function host_trampoline(rows::Ptr{Float64}, nrows::Int64, ndim::Int64, out::Ptr{Float64}, user::Ptr{Cvoid})::Cint
     try
         d = unsafe_pointer_to_objref(user)
         X = unsafe_wrap(Array, rows, (ndim, nrows))       # column w = proposal of walker w
+        d.hasblob && resize!(d.batch, nrows)
         for w in 1:nrows
-            unsafe_store!(out, Float64(d.scalar ? d.f(X[1, w]) : d.f(X[:, w])), w)
+            r = d.scalar ? d.f(X[1, w]) : d.f(X[:, w])
+            if d.hasblob
+                unsafe_store!(out, Float64(r[1]), w); d.batch[w] = r[2]                 # p1, blob1 = pdf(theta1)  :257
+            else
+                unsafe_store!(out, Float64(r), w)
+            end
         end
         return Cint(0)
     catch
         return Cint(1)                                     # kmc_emcee_run then fails with KMC_ERR_BAD_ARG
+    end
+end
+function accepted_trampoline(accepted::Ptr{UInt8}, nrows::Int64, row0::Int64, generation::Int64, stored::Int32, user::Ptr{Cvoid})::Cint
+    try
+        d = unsafe_pointer_to_objref(user)
+        if isempty(d.blob0s)        # first half-step: the last full evaluation was the initial one (:209-210)
+            error("initial blobs missing")
+        end
+        for i in 1:nrows
+            unsafe_load(accepted, i) != 0 && (d.blob0s[row0 + i] = d.batch[i])          # :264
+        end
+        if stored != 0
+            for w in (row0 + 1):(row0 + nrows)
+                d.reduce_blob!(d.blobs[w], d.blob0s[w])                                  # :270
+            end
+        end
+        return Cint(0)
+    catch
+        return Cint(1)
     end
 end
 
@@ -95,6 +128,7 @@ struct KmcConfig
     user_density::Ptr{Cvoid}
     island_gens::Int32; island_size::Int32     # KMC_ISLANDS (opt-in island mode); 0 = defaults
     host_logpdf::Ptr{Cvoid}; host_user::Ptr{Cvoid}   # KMC_HOST_DENSITY callback and its context
+    host_accepted::Ptr{Cvoid}                         # KMC_HOST_DENSITY: accept outcomes per half-step (blobs), or NULL
 end
 
 mutable struct KmcOutputs
@@ -107,14 +141,19 @@ last_error() = unsafe_string(ccall((:kmc_last_error, LIB), Cstring, ()))
 
 """
     emcee(pdf::DeviceLogPdf, theta0s; niter=10^5, nburnin=niter÷2, nthin=1, a_scale=2.0,
-          use_progress_meter=true, hasblob=false, seed=rand(UInt64), device=0)
+          use_progress_meter=true, hasblob=false, init_blobs, reduce_blob!, seed=rand(UInt64), device=0)
 
 Same meaning as KissMCMC.emcee (src/samplers.jl:188-197); returns
 `(thetas, accept_ratio, logdensities, blobs)` with `thetas[w][k]` (src/samplers.jl:292).
+`hasblob=true` needs a host closure as `pdf` (blobs are host objects).
 """
 function emcee(pdf::DeviceLogPdf, theta0s; niter=10^5, nburnin=niter ÷ 2, nthin=1, a_scale=2.0,
-               use_progress_meter=true, hasblob=false, seed=rand(UInt64), device=0)
-    hasblob && error("hasblob=true is not supported by the HIP emcee path")
+               use_progress_meter=true, hasblob=false,
+               init_blobs=(blob0, nsamples) -> sizehint!(typeof(blob0)[], nsamples),      # init_output_vector :80-85
+               reduce_blob! =(blobs, blob) -> push!(blobs, blob),                         # :196
+               seed=rand(UInt64), device=0)
+    hasblob && !(pdf isa HostLogPdf && pdf.hasblob) &&
+        error("hasblob=true needs a host closure as pdf: device densities return the log-pdf alone")
     nwalkers = length(theta0s)
     scalar = theta0s[1] isa Number
     ndim = length(theta0s[1])
@@ -130,14 +169,23 @@ function emcee(pdf::DeviceLogPdf, theta0s; niter=10^5, nburnin=niter ÷ 2, nthin
         theta[d, w] = scalar ? theta0s[w] : theta0s[w][d]                                # :198 deep copy
     end
     p = params(pdf); p8 = ntuple(i -> i <= length(p) ? p[i] : 0.0, 8)
-    host_fn, host_ctx = C_NULL, C_NULL
+    host_fn, host_ctx, acc_fn = C_NULL, C_NULL, C_NULL
     if pdf isa HostLogPdf
         pdf.scalar = scalar
         host_fn = @cfunction(host_trampoline, Cint, (Ptr{Float64}, Int64, Int64, Ptr{Float64}, Ptr{Cvoid}))
         host_ctx = pointer_from_objref(pdf)
+        if pdf.hasblob
+            # the initial evaluations (:209-210) here, so that blob storage exists before the run; the library
+            # evaluates the same rows once more for its own log-pdfs
+            tmp = [pdf.f(scalar ? theta0s[w] : collect(Float64, theta0s[w])) for w in 1:nwalkers]
+            pdf.blob0s = Any[t[2] for t in tmp]
+            pdf.blobs = Any[init_blobs(pdf.blob0s[w], nsamples) for w in 1:nwalkers]      # :238
+            pdf.init_blobs, pdf.reduce_blob!, pdf.nsamples = init_blobs, reduce_blob!, nsamples
+            acc_fn = @cfunction(accepted_trampoline, Cint, (Ptr{UInt8}, Int64, Int64, Int64, Int32, Ptr{Cvoid}))
+        end
     end
     cfg = Ref(KmcConfig(0, density_id(pdf), p8, nwalkers, ndim, niter_walker, nburnin_walker, nthin,
-                        a_scale, UInt64(seed), 0x3, Int32(device), 0, 1, user_handle(pdf), 0, 0, host_fn, host_ctx))   # flags: STORE_CHAIN | STORE_LOGP
+                        a_scale, UInt64(seed), 0x3, Int32(device), 0, 1, user_handle(pdf), 0, 0, host_fn, host_ctx, acc_fn))   # flags: STORE_CHAIN | STORE_LOGP
     chain = Array{Float64}(undef, ndim, nwalkers, nsamples)
     clogp = Array{Float64}(undef, nwalkers, nsamples)
     acc = Vector{Float64}(undef, nwalkers)
@@ -148,9 +196,10 @@ function emcee(pdf::DeviceLogPdf, theta0s; niter=10^5, nburnin=niter ÷ 2, nthin
     thetas = scalar ? [[chain[1, w, k] for k in 1:nsamples] for w in 1:nwalkers] :
                       [[chain[:, w, k] for k in 1:nsamples] for w in 1:nwalkers]
     logdensities = [[clogp[w, k] for k in 1:nsamples] for w in 1:nwalkers]
-    return thetas, acc, logdensities, nothing                                            # :292
+    return thetas, acc, logdensities, (pdf isa HostLogPdf && pdf.hasblob) ? pdf.blobs : nothing   # :292
 end
-emcee(pdf, theta0s; kw...) = emcee(HostLogPdf(pdf), theta0s; kw...)     # arbitrary closure: evaluated on the host
+# arbitrary closure: evaluated on the host
+emcee(pdf, theta0s; hasblob=false, kw...) = emcee(HostLogPdf(pdf; hasblob=hasblob), theta0s; hasblob=hasblob, kw...)
 
 # ---- many-chain Metropolis: metropolis / _metropolis, src/samplers.jl:59-128 ---------------------
 "Symmetric proposal `theta -> scale .* randn(n) .+ theta` (the one all reference tests use, test/runtests.jl:54,59,64,75)."
@@ -240,7 +289,6 @@ end
 
 "src/samplers.jl:311-349 (host side, runs once)."
 function make_theta0s(theta0::T, ball_radius, pdf, nwalkers; ball_radius_halfing_steps=7, ntries=100, hasblob=false) where T
-    hasblob && error("hasblob=true is not supported by the HIP emcee path")
     npara = length(theta0)
     if ball_radius isa Number && !(T <: Number)
         ball_radius = ones(npara) * ball_radius
@@ -252,7 +300,8 @@ function make_theta0s(theta0::T, ball_radius, pdf, nwalkers; ball_radius_halfing
             ball_radius *= 1 / 2^(k - 1)
             for _ = 1:ntries
                 tmp = npara == 1 ? theta0 .+ randn() .* ball_radius : theta0 .+ randn(npara) .* ball_radius
-                if pdf(tmp) > -Inf
+                p0 = hasblob ? pdf(tmp)[1] : pdf(tmp)                                   # :333-337
+                if p0 > -Inf
                     push!(theta0s, tmp)
                     break
                 end
@@ -266,8 +315,7 @@ end
 
 "src/samplers.jl:372-428 (host post-processing)."
 function squash_walkers(thetas, accept_ratio, logdensities=nothing, blobs=nothing;
-                        drop_low_accept_ratio=false, drop_fact=2, verbose=true, order=false)
-    blobs === nothing || error("blobs are not produced by the HIP emcee path")
+                        drop_low_accept_ratio=false, drop_fact=2, verbose=true, order=false, merge_blobs! =append!)
     nwalkers = length(accept_ratio)
     walkers2keep = if drop_low_accept_ratio
         ma, sa = median(accept_ratio), std(accept_ratio)
@@ -278,13 +326,21 @@ function squash_walkers(thetas, accept_ratio, logdensities=nothing, blobs=nothin
     end
     t = reduce(vcat, thetas[walkers2keep])
     l = logdensities === nothing ? nothing : reduce(vcat, logdensities[walkers2keep])
+    b = nothing
+    if blobs !== nothing                                                                  # :408-413
+        b = deepcopy(blobs[walkers2keep[1]])
+        for w in walkers2keep[2:end]
+            merge_blobs!(b, blobs[w])
+        end
+    end
     if order
         ns = length(thetas[1])
         perm = sortperm(repeat(1:ns, length(walkers2keep)))
         t = t[perm]
         l === nothing || (l = l[perm])
+        b === nothing || (b = b[perm])
     end
-    return t, mean(accept_ratio[walkers2keep]), l, nothing
+    return t, mean(accept_ratio[walkers2keep]), l, b
 end
 
 end # module

@@ -70,6 +70,8 @@ class Sampler:
         cb = getattr(pdf, "c_callback", None)  # host-evaluated density (HostLogPdf) or None
         if cb is not None:
             cfg.host_logpdf = C.cast(cb, C.c_void_p)
+            if getattr(pdf, "c_accepted", None) is not None:   # accept outcomes back to the host (blobs)
+                cfg.host_accepted = C.cast(pdf.c_accepted, C.c_void_p)
         self.cfg = cfg
         self._L = _lib.lib()
         h = C.c_void_p()

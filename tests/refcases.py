@@ -1,5 +1,5 @@
-"""The reference's own test cases (reference ``test/runtests.jl:52-107``; the two blob cases are out of
-scope) restated as data, for both the oracle pins and the GPU drop-in tests.  ``tol`` is the emcee
+"""The reference's own test cases (reference ``test/runtests.jl:52-107``; the two blob cases, :80-107,
+are in tests/test_gpu_hostdensity.py) restated as data, for both the oracle pins and the GPU drop-in tests.  ``tol`` is the emcee
 tolerance ``tole``; ``mstep`` the scale c of the Metropolis proposal ``theta -> c*randn(n) .+ theta`` and
 ``tolm`` the Metropolis tolerance (``test/metro.jl``)."""
 import math

@@ -128,3 +128,118 @@ def test_host_density_through_the_c_abi_one_shot(kmc, oracle):
     c.host_logpdf = C.cast(cb, C.c_void_p)
     c.flags = _lib.P2P
     assert L.kmc_validate(C.byref(c)) == _lib.ERR_UNSUPPORTED
+
+
+# ---- blobs (hasblob=true): src/samplers.jl:150-151, :208-210, :264, :270; test/runtests.jl:80-107 ----
+
+def test_blobs_follow_the_walkers_exactly(kmc):
+    """blob = (theta, p): the stored blobs must then equal the stored thetas / logdensities entry by entry --
+    blob0s[nc] = blob1 exactly when theta0s[nc] = theta1 (:261-264), reduce_blob! exactly when stored (:268-271)."""
+    lp = lambda x: -0.5 * float(x @ x)
+    th = 0.4 * np.random.default_rng(11).standard_normal((24, 3))
+    kw = dict(niter=24 * 60, nburnin=24 * 13, nthin=3, use_progress_meter=False, seed=21)
+    thetas, acc, logd, blobs = kmc.emcee(lambda x: (lp(x), (x.copy(), lp(x))), th, hasblob=True, **kw)
+    assert len(blobs) == 24 and all(len(b) == thetas.shape[1] == (60 - 13) // 3 for b in blobs)
+    for w in range(24):
+        np.testing.assert_array_equal(np.array([b[0] for b in blobs[w]]), thetas[w])
+        np.testing.assert_array_equal(np.array([b[1] for b in blobs[w]]), logd[w])
+    # and the sampler itself is unchanged by carrying blobs
+    t2, a2, l2, b2 = kmc.emcee(lp, th, **kw)
+    assert b2 is None
+    np.testing.assert_array_equal(t2, thetas)
+    np.testing.assert_array_equal(a2, acc)
+    # squash_walkers: default append! / order=true keep blobs aligned with the samples (:408-421)
+    for order in (False, True):
+        t, _, l, b = kmc.squash_walkers(thetas, acc, logd, blobs, order=order, verbose=False)
+        np.testing.assert_array_equal(np.array([x[0] for x in b]), t)
+        np.testing.assert_array_equal(np.array([x[1] for x in b]), l)
+
+
+def test_reference_blob_cases(kmc):
+    """reference test/runtests.jl:80-107 through test/emcee.jl:21-45: blob = ones(1000), default reductions
+    (blob_truths = 5000 x ones(1000)) and the sum reduction (blob_truths = [5000])."""
+    from refcases import CASES, check_mean_std
+    case = CASES[0]
+    pdf = lambda x: (-(x + 5) ** 2 / (2 * 3.0 ** 2), np.ones(1000))
+    theta0s = kmc.make_theta0s(-4.0, 0.1, pdf, 100, hasblob=True, rng=5)
+    samples = kmc.emcee(pdf, theta0s, niter=10 ** 4, hasblob=True, use_progress_meter=False, seed=8)
+    assert [len(x) for x in samples] == [100, 100, 100, 100]
+    assert samples[0].shape[1] == 10 ** 4 // 100 // 2
+    thetas, ar, logd, blobs = kmc.squash_walkers(*samples, verbose=False)
+    assert len(thetas) == len(logd) == 10 ** 4 // 2 and ar > 0.1
+    check_mean_std(thetas, case)
+    assert len(blobs) == 10 ** 4 // 2 and all(np.array_equal(b, np.ones(1000)) for b in blobs)
+
+    def add(blobs, blob):
+        blobs[0] += blob[0]
+
+    samples = kmc.emcee(pdf, theta0s, niter=10 ** 4, hasblob=True, use_progress_meter=False, seed=9,
+                        init_blobs=lambda blob0, nsamples: [0], reduce_blob=add)
+    assert len(samples[3]) == 100 and all(b == [50] for b in samples[3])
+    thetas, ar, logd, blobs = kmc.squash_walkers(*samples, verbose=False, merge_blobs=add)
+    check_mean_std(thetas, case)
+    assert blobs == [10 ** 4 // 2]
+
+
+def test_vectorized_blobs_and_misuse(kmc):
+    th = 0.3 * np.random.default_rng(4).standard_normal((16, 2))
+    f = lambda X: (-0.5 * (X * X).sum(axis=1), [tuple(r) for r in X])
+    pdf = kmc.HostLogPdf(f, vectorized=True, hasblob=True)
+    thetas, acc, logd, blobs = kmc.emcee(pdf, th, niter=16 * 10, nburnin=0, hasblob=True, use_progress_meter=False, seed=2)
+    for w in range(16):
+        np.testing.assert_array_equal(np.array(blobs[w]), thetas[w])
+    with pytest.raises(NotImplementedError, match="host callable"):
+        kmc.emcee(kmc.GaussianIso(), th, niter=160, hasblob=True, use_progress_meter=False)
+    with pytest.raises(ValueError, match="hasblob=True"):
+        kmc.emcee(lambda x: 0.0, th, niter=160, init_blobs=lambda b, n: [], use_progress_meter=False)
+
+    def boom(blobs, blob):
+        raise KeyError("reduce")
+
+    with pytest.raises(KeyError, match="reduce"):
+        kmc.emcee(lambda x: (-0.5 * float(x @ x), 1), th, niter=160, nburnin=0, hasblob=True, reduce_blob=boom,
+                  use_progress_meter=False)
+
+
+def test_accept_outcomes_through_the_c_abi(kmc, oracle):
+    """kmc_config.host_accepted: per half-step flags = the oracle's accept decisions (difference of its counters)."""
+    from kissmcmc_jl_amd import _lib
+    L = _lib.lib()
+    nw, nd, G = 20, 3, 12
+    th = np.ascontiguousarray(0.3 * np.random.default_rng(1).standard_normal((nw, nd)))
+    seen = []
+
+    @_lib.HOST_LOGPDF_FN
+    def cb(rows, nrows, ndim, out, user):
+        X = np.ctypeslib.as_array(rows, shape=(nrows, ndim))
+        for i in range(nrows):
+            out[i] = oracle.logpdf(0, [0.0, 1.0], X[i])
+        return 0
+
+    @_lib.HOST_ACCEPTED_FN
+    def acc_cb(flags, nrows, row0, generation, stored, user):
+        seen.append((int(generation), int(row0), int(stored), np.ctypeslib.as_array(flags, shape=(nrows,)).copy()))
+        return 0
+
+    c = _lib.Config()
+    c.dtype, c.density = _lib.F64, _lib.HOST_DENSITY
+    c.nwalkers, c.ndim, c.ngenerations, c.nburnin, c.nthin, c.a_scale, c.seed = nw, nd, G, 4, 2, 2.0, 6
+    c.host_logpdf = C.cast(cb, C.c_void_p)
+    c.host_accepted = C.cast(acc_cb, C.c_void_p)
+    nacc = np.zeros(nw, dtype=np.int64)
+    out = _lib.Outputs()
+    out.naccept = nacc.ctypes.data_as(C.POINTER(C.c_int64))
+    _lib.check(L.kmc_emcee_run(C.byref(c), th.ctypes.data_as(C.POINTER(C.c_double)), C.byref(out)))
+    assert [(g, r0) for g, r0, _, _ in seen] == [(g, r0) for g in range(G) for r0 in (0, nw // 2)]
+    assert [st for _, _, st, _ in seen[::2]] == [int(g >= 4 and (g - 4 + 1) % 2 == 0) for g in range(G)]   # :268, n = g - nburnin + 1
+    total = np.zeros(nw, dtype=np.int64)
+    for g, r0, _, fl in seen:
+        assert set(np.unique(fl)) <= {0, 1}
+        if g >= 4:                                  # counters restart after burn-in (:285-288)
+            total[r0:r0 + nw // 2] += fl
+    np.testing.assert_array_equal(total, nacc)
+    ref = oracle.emcee(oracle.make_config(0, [0.0, 1.0], nw, nd, G, 4, 2, 2.0, 6), th)
+    np.testing.assert_array_equal(nacc, ref["naccept"])
+    # the callback belongs to KMC_HOST_DENSITY
+    c.density, c.host_logpdf = 0, None
+    assert L.kmc_validate(C.byref(c)) == _lib.ERR_BAD_ARG

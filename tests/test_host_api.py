@@ -135,3 +135,24 @@ def test_expr_density_host_interface(kmc):
     d = kmc.ExprDensity("-0.5*p[0]*x*x", params=[2.0])
     assert d.density_id == _lib.USER_DENSITY and d.params() == [2.0] and d.user_handle is not None
     assert "ExprDensity" in repr(d)
+
+
+def test_squash_walkers_blobs_and_make_theta0s_hasblob(kmc):
+    """src/samplers.jl:408-421 (blobs through squash_walkers) and :333-337 (make_theta0s with a (p, blob) pdf)."""
+    rng = np.random.default_rng(0)
+    thetas = rng.standard_normal((6, 4))
+    acc = np.array([0.3, 0.31, 0.29, 0.3, 0.01, 0.3])
+    blobs = [[(w, k) for k in range(4)] for w in range(6)]
+    t, a, l, b = kmc.squash_walkers(thetas, acc, None, blobs, verbose=False)
+    assert b == [(w, k) for w in range(6) for k in range(4)] and blobs[0] == [(0, k) for k in range(4)]   # deepcopy :411
+    t, a, l, b = kmc.squash_walkers(thetas, acc, None, blobs, verbose=False, order=True, drop_low_accept_ratio=True, drop_fact=1)
+    assert b == [(w, k) for k in range(4) for w in (0, 1, 2, 3, 5)]
+    np.testing.assert_array_equal(t, thetas[[0, 1, 2, 3, 5]].T.reshape(-1))
+    sums = [[float(w)] for w in range(6)]
+
+    def add(b1, b2):
+        b1[0] += b2[0]
+
+    assert kmc.squash_walkers(thetas, acc, None, sums, verbose=False, merge_blobs=add)[3] == [15.0] and sums[0] == [0.0]
+    th = kmc.make_theta0s(0.5, 0.1, lambda x: (-x if x >= 0 else -np.inf, "blob"), 10, hasblob=True, rng=3)
+    assert th.shape == (10,) and np.all(th >= 0)
