@@ -79,7 +79,12 @@ typedef int (*kmc_host_accepted_fn)(const uint8_t* accepted, int64_t nrows, int6
                                     int32_t stored, void* user);
 
 enum {
-    KMC_F64 = 0 /* state and arithmetic in IEEE double, as the reference (Float64) */
+    KMC_F64 = 0, /* state and arithmetic in IEEE double, as the reference (Float64) */
+    KMC_F32 = 1  /* throughput option: walker rows and the stored chain are kept in IEEE single ON THE DEVICE (half the
+                    row bytes); a proposal is rounded to single before its log-density is evaluated, so a stored row and
+                    its log-pdf belong together; draws, log-densities, the accept test, counters and moments stay double,
+                    and so does every HOST buffer of this interface.  Built-in densities, one GPU (no KMC_P2P /
+                    KMC_ISLANDS / sharding / kmc_sampler_bind_positions). */
 };
 
 /* kmc_config.flags */
@@ -112,7 +117,7 @@ enum {
 #define KMC_P2P_HANDLE_BYTES 128
 
 typedef struct kmc_config {
-    int32_t  dtype;         /* KMC_F64 */
+    int32_t  dtype;         /* KMC_F64 or KMC_F32 (device storage of the rows) */
     int32_t  density;       /* kmc_density */
     double   params[8];
     int64_t  nwalkers;      /* GLOBAL ensemble size (all shards) */

@@ -22,6 +22,7 @@ HOST_DENSITY = 101
 HOST_LOGPDF_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int64, C.c_int64, C.POINTER(C.c_double), C.c_void_p)
 HOST_ACCEPTED_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_uint8), C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_void_p)
 F64 = 0
+F32 = 1       # rows and chain kept in float on the device; arithmetic and host buffers stay double
 STORE_CHAIN, STORE_LOGP, MOMENTS, NO_GRAPH, P2P, ISLANDS, P2P_FINEGRAINED, P2P_FOLD_SIGNAL, P2P_PUSH = 1, 2, 4, 8, 16, 64, 128, 256, 512
 P2P_HANDLE_BYTES = 128
 

@@ -40,8 +40,9 @@ def emcee_counts(niter: int, nwalkers: int, nburnin=None, nthin: int = 1):
 
 def emcee(pdf, theta0s, niter: int = 10 ** 5, nburnin=None, nthin: int = 1, a_scale: float = 2.0,
           use_progress_meter: bool = True, hasblob: bool = False, init_blobs=None, reduce_blob=None,
-          seed=None, device: int = 0):
-    """The affine-invariant ensemble sampler, on one MI355X.
+          seed=None, device: int = 0, dtype: str = "f64"):
+    """The affine-invariant ensemble sampler, on one MI355X.  ``dtype="f32"`` keeps the walkers in single
+    precision on the device (a throughput option, built-in densities; everything returned is still float64).
 
     Returns ``(thetas, accept_ratio, logdensities, blobs)`` like the reference
     (``src/samplers.jl:292``): ``thetas[w][k]`` is sample ``k`` of walker ``w``
@@ -89,7 +90,7 @@ def emcee(pdf, theta0s, niter: int = 10 ** 5, nburnin=None, nthin: int = 1, a_sc
         seed = _fresh_seed()
 
     with Sampler(pdf, nwalkers, ndim, niter_walker, nburnin_walker, nthin, a_scale, seed,
-                 store_chain=True, store_logp=True, device=device) as s:
+                 store_chain=True, store_logp=True, device=device, dtype=dtype) as s:
         try:
             s.set_positions(theta0s)
         except _lib.KmcError as e:

@@ -68,29 +68,29 @@ struct Plan {
 
 // ---- kernel table ------------------------------------------------------------------------
 
-template <int L, int K, int ITER>
+template <int L, int K, int ITER, class T>
 FlushFn flush_one()
 {
-    if constexpr (ITER <= L && ITER * K <= 16) return flush_moments_vec<L, K, ITER>;
+    if constexpr (ITER <= L && ITER * K <= 16) return flush_moments_vec<L, K, ITER, T>;
     else return nullptr;
 }
 
 template <int L, int K>
-FlushFn flush_iter(int iter)
+FlushFn flush_iter(int iter, bool f32)
 {
     switch (iter) {
-    case 1: return flush_one<L, K, 1>();
-    case 2: return flush_one<L, K, 2>();
-    case 4: return flush_one<L, K, 4>();
-    case 8: return flush_one<L, K, 8>();
-    case 16: return flush_one<L, K, 16>();
+    case 1: return f32 ? flush_one<L, K, 1, float>() : flush_one<L, K, 1, double>();
+    case 2: return f32 ? flush_one<L, K, 2, float>() : flush_one<L, K, 2, double>();
+    case 4: return f32 ? flush_one<L, K, 4, float>() : flush_one<L, K, 4, double>();
+    case 8: return f32 ? nullptr : flush_one<L, K, 8, double>();
+    case 16: return f32 ? nullptr : flush_one<L, K, 16, double>();
     default: return nullptr;
     }
 }
 
-FlushFn flush_lookup(int L, int K, int iter)
+FlushFn flush_lookup(int L, int K, int iter, bool f32)
 {
-#define KMC_LK(l, k) if (L == l && K == k) return flush_iter<l, k>(iter);
+#define KMC_LK(l, k) if (L == l && K == k) return flush_iter<l, k>(iter, f32);
     KMC_LK(1, 1) KMC_LK(2, 1) KMC_LK(4, 1) KMC_LK(8, 1) KMC_LK(16, 1) KMC_LK(32, 1) KMC_LK(64, 1)
     KMC_LK(4, 2) KMC_LK(8, 2) KMC_LK(16, 2) KMC_LK(32, 2) KMC_LK(64, 2)
     KMC_LK(4, 4) KMC_LK(8, 4) KMC_LK(64, 4)
@@ -99,14 +99,14 @@ FlushFn flush_lookup(int L, int K, int iter)
     return nullptr;
 }
 
-bool lookup(int density, int L, int K, int iter, bool p2p, bool ragged, HalfStepFn* vec, HalfStepFn* gen, LogpdfFn* lp)
+bool lookup(int density, int L, int K, int iter, bool p2p, bool ragged, bool f32, HalfStepFn* vec, HalfStepFn* gen, LogpdfFn* lp)
 {
     switch (density) {
-    case KMC_GAUSSIAN_ISO: table_gaussian_iso(L, K, iter, p2p, ragged, vec, gen, lp); return true;
-    case KMC_EXPONENTIAL: table_exponential(L, K, iter, p2p, ragged, vec, gen, lp); return true;
-    case KMC_ROSENBROCK: table_rosenbrock(L, K, iter, p2p, ragged, vec, gen, lp); return true;
-    case KMC_LOGNORMAL: table_lognormal(L, K, iter, p2p, ragged, vec, gen, lp); return true;
-    case KMC_MVNORMAL2: table_mvnormal2(L, K, iter, p2p, ragged, vec, gen, lp); return true;
+    case KMC_GAUSSIAN_ISO: table_gaussian_iso(L, K, iter, p2p, ragged, f32, vec, gen, lp); return true;
+    case KMC_EXPONENTIAL: table_exponential(L, K, iter, p2p, ragged, f32, vec, gen, lp); return true;
+    case KMC_ROSENBROCK: table_rosenbrock(L, K, iter, p2p, ragged, f32, vec, gen, lp); return true;
+    case KMC_LOGNORMAL: table_lognormal(L, K, iter, p2p, ragged, f32, vec, gen, lp); return true;
+    case KMC_MVNORMAL2: table_mvnormal2(L, K, iter, p2p, ragged, f32, vec, gen, lp); return true;
     default: return false;
     }
 }
@@ -209,7 +209,8 @@ Plan make_plan(const kmc_config& c, int64_t n_active)
         }
     }
     const bool ragged = L > 0 && 2 * L * K != c.ndim;
-    if (ragged && iter > 4) iter = 4;
+    const bool f32 = c.dtype == KMC_F32;
+    if ((ragged || f32) && iter > 4) iter = 4;
     if ((c.flags & KMC_P2P) && iter > 8) iter = 8;
     p.ragged = ragged;
     if (c.density == KMC_HOST_DENSITY) {
@@ -226,7 +227,7 @@ Plan make_plan(const kmc_config& c, int64_t n_active)
         }
         return p;
     }
-    lookup(c.density, L, K, iter, (c.flags & KMC_P2P) != 0, ragged, &vec, &gen, &lp);
+    lookup(c.density, L, K, iter, (c.flags & KMC_P2P) != 0, ragged, f32, &vec, &gen, &lp);
     if (!force_generic && L > 0 && 2 * L * K >= c.ndim && vec != nullptr) {
         p.fn = vec; p.vec = true; p.L = L; p.K = K; p.ITER = iter;
     } else {
@@ -439,7 +440,8 @@ struct kmc_sampler {
     int tpb = 256;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    double* d_pos = nullptr;
+    double* d_pos = nullptr;           // rows [nrows][ld]; float elements when f32 (KMC_F32)
+    bool f32 = false;
     bool own_pos = true;
     double* d_logp = nullptr;
     uint32_t* d_naccept = nullptr;
@@ -728,10 +730,17 @@ kmc_status launch_updated_graph(kmc_sampler* s)
 }
 
 // Host rows are dense [rows][ndim]; device rows have stride ld (= ndim, or ndim+1 for odd ndim).
+// KMC_F32: the device rows are float (dst_dev / src_dev are then the raw buffers); the host side stays double.
 hipError_t upload_rows(const kmc_sampler* s, double* dst_dev, const double* src_host, size_t rows)
 {
     const size_t nd = (size_t)s->cfg.ndim, ld = (size_t)s->ld;
     if (rows == 0) return hipSuccess;
+    if (s->f32) {
+        std::vector<float> t(rows * ld, 0.0f);
+        for (size_t r = 0; r < rows; ++r)
+            for (size_t d = 0; d < nd; ++d) t[r * ld + d] = (float)src_host[r * nd + d];
+        return hipMemcpy(dst_dev, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice);
+    }
     if (ld == nd) return hipMemcpy(dst_dev, src_host, rows * nd * sizeof(double), hipMemcpyHostToDevice);
     return hipMemcpy2D(dst_dev, ld * sizeof(double), src_host, nd * sizeof(double), nd * sizeof(double), rows, hipMemcpyHostToDevice);
 }
@@ -739,6 +748,18 @@ hipError_t download_rows(const kmc_sampler* s, double* dst_host, const double* s
 {
     const size_t nd = (size_t)s->cfg.ndim, ld = (size_t)s->ld;
     if (rows == 0) return hipSuccess;
+    if (s->f32) {
+        const size_t slab = (size_t)1 << 22;                   // rows per copy: bounds the host staging buffer
+        std::vector<float> t((rows < slab ? rows : slab) * ld);
+        for (size_t r0 = 0; r0 < rows; r0 += slab) {
+            const size_t n = rows - r0 < slab ? rows - r0 : slab;
+            const hipError_t e = hipMemcpy(t.data(), reinterpret_cast<const float*>(src_dev) + r0 * ld, n * ld * sizeof(float), hipMemcpyDeviceToHost);
+            if (e != hipSuccess) return e;
+            for (size_t r = 0; r < n; ++r)
+                for (size_t d = 0; d < nd; ++d) dst_host[(r0 + r) * nd + d] = (double)t[r * ld + d];
+        }
+        return hipSuccess;
+    }
     if (ld == nd) return hipMemcpy(dst_host, src_dev, rows * nd * sizeof(double), hipMemcpyDeviceToHost);
     return hipMemcpy2D(dst_host, nd * sizeof(double), src_dev, ld * sizeof(double), nd * sizeof(double), rows, hipMemcpyDeviceToHost);
 }
@@ -788,7 +809,6 @@ KMC_EXPORT const char* kmc_status_string(kmc_status st)
 KMC_EXPORT kmc_status kmc_validate(const kmc_config* c)
 {
     if (!c) return fail(KMC_ERR_BAD_ARG, "null config");
-    if (c->dtype != KMC_F64) return fail(KMC_ERR_UNSUPPORTED, "only KMC_F64 is implemented");
     if (c->nwalkers <= 0 || c->ndim <= 0 || c->nthin <= 0 || c->ngenerations < 0 || c->nburnin < 0)
         return fail(KMC_ERR_BAD_ARG, "nwalkers, ndim, nthin must be > 0 and ngenerations, nburnin >= 0");
     if (!(c->a_scale > 1.0)) return fail(KMC_ERR_A_SCALE, kmc_status_string(KMC_ERR_A_SCALE));
@@ -802,6 +822,13 @@ KMC_EXPORT kmc_status kmc_validate(const kmc_config* c)
         if (!c->host_logpdf) return fail(KMC_ERR_BAD_ARG, "KMC_HOST_DENSITY needs kmc_config.host_logpdf");
         if ((c->flags & (KMC_P2P | KMC_ISLANDS)) || c->shard_count > 1)
             return fail(KMC_ERR_UNSUPPORTED, "KMC_HOST_DENSITY runs on one GPU, without KMC_P2P / KMC_ISLANDS / sharding");
+    }
+    if (c->dtype != KMC_F64 && c->dtype != KMC_F32) return fail(KMC_ERR_UNSUPPORTED, "dtype must be KMC_F64 or KMC_F32");
+    if (c->dtype == KMC_F32) {
+        if ((c->flags & (KMC_P2P | KMC_ISLANDS)) || c->shard_count > 1)
+            return fail(KMC_ERR_UNSUPPORTED, "KMC_F32 rows: one GPU, without KMC_P2P / KMC_ISLANDS / sharding");
+        if (c->density == KMC_USER_DENSITY || c->density == KMC_HOST_DENSITY)
+            return fail(KMC_ERR_UNSUPPORTED, "KMC_F32 rows: built-in densities only");
     }
     if (c->host_accepted && c->density != KMC_HOST_DENSITY) return fail(KMC_ERR_BAD_ARG, "kmc_config.host_accepted needs KMC_HOST_DENSITY");
     if (c->density == KMC_ROSENBROCK && c->ndim < 2) return fail(KMC_ERR_BAD_ARG, "rosenbrock needs ndim >= 2");
@@ -857,7 +884,8 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
     s->active_begin = s->h_loc * s->cfg.shard_rank;
     s->nlocal = 2 * s->h_loc;
     s->nsamples = cfg->ngenerations > cfg->nburnin ? (cfg->ngenerations - cfg->nburnin) / cfg->nthin : 0;   // :234
-    s->ld = cfg->ndim + (cfg->ndim & 1);      // 16-byte aligned rows for the double2 kernels
+    s->ld = cfg->ndim + (cfg->ndim & 1);      // whole two-element chunks: 16-byte aligned double rows, 8-byte aligned float rows
+    s->f32 = cfg->dtype == KMC_F32;
     kmc_status st = digest_params(*cfg, &s->dp);
     if (st != KMC_OK) { delete s; return st; }
     s->plan = make_plan(s->cfg, s->h_loc);
@@ -890,7 +918,7 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         s->host_eval = true;
     } else {
         HalfStepFn v, g;
-        lookup(cfg->density, 0, 0, 1, false, false, &v, &g, &s->logpdf_fn);
+        lookup(cfg->density, 0, 0, 1, false, false, false, &v, &g, &s->logpdf_fn);
     }
     // vec: a wave owns W = (64/L)*ITER walkers; generic: one walker per lane
     const int64_t per_wave = s->plan.vec ? (int64_t)(64 / s->plan.L) * s->plan.ITER : 64;
@@ -916,7 +944,7 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         }
         if (ea != hipSuccess) { (void)hipGetLastError(); kmc_sampler_destroy(s); return fail(KMC_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(ea)); }
     }
-    if (!s->islands && cfg->density != KMC_USER_DENSITY && !s->host_eval && cfg->nwalkers <= 1024 && cfg->ndim <= 32 &&
+    if (!s->islands && !s->f32 && cfg->density != KMC_USER_DENSITY && !s->host_eval && cfg->nwalkers <= 1024 && cfg->ndim <= 32 &&
         s->cfg.shard_count == 1 && !(cfg->flags & (KMC_P2P | KMC_NO_GRAPH)) && std::getenv("KMC_NO_RESIDENT") == nullptr) {
         const int64_t chunks = s->ld / 2;
         int K = 1;
@@ -978,11 +1006,12 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
                   s->cfg.shard_count > 1;
     }
     const size_t ldz = (size_t)s->ld;
+    const size_t esz = s->f32 ? sizeof(float) : sizeof(double);      // element size of rows and chain
     if (s->p2p && (cfg->flags & KMC_P2P_FINEGRAINED))   // peers map the rows uncached: nothing of them can go stale in a reader's L2
         CREATE_TRY(hipExtMallocWithFlags((void**)&s->d_pos, nw * ldz * sizeof(double), hipDeviceMallocFinegrained));
     else
-        CREATE_TRY(hipMalloc(&s->d_pos, (s->push ? 1 + (size_t)s->cfg.shard_count : 1) * nw * ldz * sizeof(double)));
-    CREATE_TRY(hipMemset(s->d_pos, 0, (s->push ? 1 + (size_t)s->cfg.shard_count : 1) * nw * ldz * sizeof(double)));   // the pad column of odd ndim stays 0
+        CREATE_TRY(hipMalloc(&s->d_pos, (s->push ? 1 + (size_t)s->cfg.shard_count : 1) * nw * ldz * esz));
+    CREATE_TRY(hipMemset(s->d_pos, 0, (s->push ? 1 + (size_t)s->cfg.shard_count : 1) * nw * ldz * esz));   // the pad column of odd ndim stays 0
     CREATE_TRY(hipMalloc(&s->d_logp, nw * sizeof(double)));
     CREATE_TRY(hipMalloc(&s->d_naccept, nw * sizeof(uint32_t)));
     static_assert(kGraphChunk <= 64, "advance_schedule runs one 64-thread block");
@@ -1025,7 +1054,7 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         }
     }
     if ((cfg->flags & KMC_STORE_CHAIN) && s->nsamples > 0)
-        CREATE_TRY(hipMalloc(&s->d_chain, (size_t)s->nsamples * (size_t)s->nlocal * ldz * sizeof(double)));
+        CREATE_TRY(hipMalloc(&s->d_chain, (size_t)s->nsamples * (size_t)s->nlocal * ldz * esz));
     if ((cfg->flags & KMC_STORE_LOGP) && s->nsamples > 0)
         CREATE_TRY(hipMalloc(&s->d_chain_logp, (size_t)s->nsamples * (size_t)s->nlocal * sizeof(double)));
 #undef CREATE_TRY
@@ -1102,6 +1131,7 @@ KMC_EXPORT kmc_status kmc_sampler_bind_positions(kmc_sampler* s, void* pos_dev)
 {
     if (!s || !pos_dev) return fail(KMC_ERR_BAD_ARG, "null argument");
     if (s->p2p) return fail(KMC_ERR_UNSUPPORTED, "KMC_P2P samplers export their own position buffer");
+    if (s->f32) return fail(KMC_ERR_UNSUPPORTED, "kmc_sampler_bind_positions takes double rows; a KMC_F32 sampler keeps its own float rows");
     if (s->ld != s->cfg.ndim) return fail(KMC_ERR_UNSUPPORTED, "kmc_sampler_bind_positions needs an even ndim (16-byte rows)");
     HIP_TRY(hipSetDevice(s->cfg.device));
     HIP_TRY(hipStreamSynchronize(s->stream));
@@ -1156,20 +1186,52 @@ KMC_EXPORT kmc_status kmc_sampler_p2p_connect(kmc_sampler* s, const void* handle
 
 namespace {
 
+// Initial log-pdfs of the rows in d_pos (src/samplers.jl:209-210) into d_logp, on the sampler's stream.  KMC_F32: the
+// log-pdf kernels read double rows, so the float rows are widened (exactly) into a scratch buffer first.
+__global__ __launch_bounds__(256) void widen_rows(const float* src, double* dst, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = (double)src[i];
+}
+__global__ __launch_bounds__(256) void narrow_rows(const double* src, float* dst, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = (float)src[i];
+}
+
+kmc_status eval_initial_logp(kmc_sampler* s)
+{
+    const size_t nw = (size_t)s->nrows, nd = (size_t)s->cfg.ndim;
+    double* rows = s->d_pos;
+    double* scratch = nullptr;
+    if (s->f32) {
+        const int64_t n = (int64_t)(nw * (size_t)s->ld);
+        HIP_TRY(hipMalloc((void**)&scratch, (size_t)n * sizeof(double)));
+        hipLaunchKernelGGL(widen_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, reinterpret_cast<const float*>(s->d_pos), scratch, n);
+        rows = scratch;
+    }
+    const LogpdfArgs la{rows, s->d_logp, (int64_t)nw, (int32_t)nd, (int32_t)s->ld, s->dp};
+    hipError_t e = hipSuccess;
+    if (s->user) {
+        e = launch_module(s->uk.logpdf, (unsigned)((nw + 255) / 256), 256u, s->stream, la);
+    } else {
+        hipLaunchKernelGGL(s->logpdf_fn, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s->stream, la);
+        e = hipGetLastError();
+    }
+    if (scratch) {
+        if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+        (void)hipFree(scratch);
+    }
+    HIP_TRY(e);
+    return KMC_OK;
+}
+
 // Everything set_positions does after the rows are in place: initial log-pdfs (src/samplers.jl:209-210)
 // unless they are supplied, counters, accumulators, finiteness check.
 kmc_status reset_run_state(kmc_sampler* s, bool eval_logp, int64_t generation, uint32_t klast_value)
 {
-    const size_t nw = (size_t)s->nrows, nd = (size_t)s->cfg.ndim;
-    if (eval_logp) {
-        const LogpdfArgs la{s->d_pos, s->d_logp, (int64_t)nw, (int32_t)nd, (int32_t)s->ld, s->dp};
-        if (s->user) {
-            HIP_TRY(launch_module(s->uk.logpdf, (unsigned)((nw + 255) / 256), 256u, s->stream, la));
-        } else {
-            hipLaunchKernelGGL(s->logpdf_fn, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s->stream, la);
-            HIP_TRY(hipGetLastError());
-        }
-    }
+    const size_t nw = (size_t)s->nrows;
+    if (eval_logp) KMC_TRY(eval_initial_logp(s));
     std::vector<double> lp(nw);
     HIP_TRY(hipMemcpyAsync(lp.data(), s->d_logp, nw * sizeof(double), hipMemcpyDeviceToHost, s->stream));
     if (s->d_msum) {
@@ -1214,13 +1276,16 @@ KMC_EXPORT kmc_status kmc_sampler_init_ball(kmc_sampler* s, const double* theta0
     if (e == hipSuccess) e = hipMemcpy(d_par, theta0, nd * sizeof(double), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d_par + nd, ball_radius, nd * sizeof(double), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(d_fail, 0, sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMemset(s->d_pos, 0, (size_t)s->nrows * (size_t)s->ld * sizeof(double));
+    const size_t nelem = (size_t)s->nrows * (size_t)s->ld;
+    double* d_ball = s->d_pos;                  // KMC_F32: the ball is drawn in double, then rounded into the float rows
+    if (s->f32 && e == hipSuccess) e = hipMalloc((void**)&d_ball, nelem * sizeof(double));
+    if (e == hipSuccess) e = hipMemset(d_ball, 0, nelem * sizeof(double));
     InitBallFn fn = s->user ? nullptr : init_ball_fn(s->cfg.density);
     const int pieces = s->p2p ? 2 : 1;
     for (int piece = 0; piece < pieces && e == hipSuccess; ++piece) {
         InitBallArgs a{};
         const int64_t rows = s->p2p ? s->h_loc : s->nrows;
-        a.pos = s->d_pos + (size_t)piece * (size_t)s->h_loc * (size_t)s->ld;
+        a.pos = d_ball + (size_t)piece * (size_t)s->h_loc * (size_t)s->ld;
         a.logp = s->d_logp + (size_t)piece * (size_t)s->h_loc;
         a.theta0 = d_par; a.radius = d_par + nd;
         a.nrows = rows;
@@ -1235,10 +1300,15 @@ KMC_EXPORT kmc_status kmc_sampler_init_ball(kmc_sampler* s, const double* theta0
         else { hipLaunchKernelGGL(fn, dim3(grid), dim3(256), 0, s->stream, a); e = hipGetLastError(); }
     }
     unsigned long long nfail = 0;
+    if (s->f32 && e == hipSuccess) {
+        hipLaunchKernelGGL(narrow_rows, dim3((unsigned)((nelem + 255) / 256)), dim3(256), 0, s->stream, d_ball, reinterpret_cast<float*>(s->d_pos), (int64_t)nelem);
+        e = hipGetLastError();
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
     if (e == hipSuccess) e = hipMemcpy(&nfail, d_fail, sizeof(nfail), hipMemcpyDeviceToHost);
     (void)hipFree(d_par);
     (void)hipFree(d_fail);
+    if (s->f32) (void)hipFree(d_ball);
     HIP_TRY(e);
     if (nfail != 0) {
         s->positions_set = false;
@@ -1254,7 +1324,7 @@ KMC_EXPORT kmc_status kmc_sampler_init_ball(kmc_sampler* s, const double* theta0
     }
     s->dev_gen = 0;
     s->moment_base = 0;
-    return reset_run_state(s, /*eval_logp=*/false, 0, 0u);
+    return reset_run_state(s, /*eval_logp=*/s->f32, 0, 0u);      // KMC_F32: the log-pdfs of the rows as rounded
 }
 
 // Checkpoint / resume: restore (positions, log-pdfs, acceptance counters, generation).  The random
@@ -1320,13 +1390,7 @@ KMC_EXPORT kmc_status kmc_sampler_set_positions(kmc_sampler* s, const double* th
         }
         HIP_TRY(hipMemcpy(s->d_logp, lp0.data(), nw * sizeof(double), hipMemcpyHostToDevice));
     } else {
-        const LogpdfArgs la{s->d_pos, s->d_logp, (int64_t)nw, (int32_t)nd, (int32_t)s->ld, s->dp};   // :209-210
-        if (s->user) {
-            HIP_TRY(launch_module(s->uk.logpdf, (unsigned)((nw + 255) / 256), 256u, s->stream, la));
-        } else {
-            hipLaunchKernelGGL(s->logpdf_fn, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s->stream, la);
-            HIP_TRY(hipGetLastError());
-        }
+        KMC_TRY(eval_initial_logp(s));                           // :209-210
     }
     std::vector<double> lp(nw);
     HIP_TRY(hipMemcpyAsync(lp.data(), s->d_logp, nw * sizeof(double), hipMemcpyDeviceToHost, s->stream));
@@ -1624,6 +1688,7 @@ KMC_EXPORT kmc_status kmc_sampler_describe(const kmc_sampler* s, char* buf, int6
         }
     } else
         o << "multi-launch (exact): half_step_generic (one walker per lane), grid " << s->grid << " x 256";
+    if (s->f32) o << "; rows kept in float (KMC_F32), arithmetic in double";
     if (s->user) o << "; runtime-compiled density";
     if (s->p2p) o << "; P2P shard " << s->cfg.shard_rank << "/" << s->cfg.shard_count << (s->connected ? "" : " (not connected)");
     else if (s->cfg.shard_count > 1) o << "; replica shard " << s->cfg.shard_rank << "/" << s->cfg.shard_count;
@@ -1707,7 +1772,7 @@ KMC_EXPORT kmc_status kmc_sampler_get_moments(kmc_sampler* s, double* sum, doubl
     }
     if (s->plan.vec) {
         // sojourn-weighted accumulation: credit every walker's current value up to now
-        FlushFn fl = flush_lookup(s->plan.L, s->plan.K, s->plan.ITER);
+        FlushFn fl = flush_lookup(s->plan.L, s->plan.K, s->plan.ITER, s->f32);
         if (!fl) return fail(KMC_ERR_UNSUPPORTED, "no flush kernel for this geometry");
         for (int half = 0; half < 2; ++half) {
             FlushArgs fa{};
@@ -1839,7 +1904,7 @@ KMC_EXPORT kmc_status kmc_logpdf_eval(const kmc_config* cfg, const double* pos_d
     if (cfg->density == KMC_HOST_DENSITY) return fail(KMC_ERR_UNSUPPORTED, "KMC_HOST_DENSITY is evaluated by the caller, not on the device");
     HalfStepFn v, g;
     LogpdfFn lp = nullptr;
-    if (!lookup(cfg->density, 0, 0, 1, false, false, &v, &g, &lp)) return fail(KMC_ERR_BAD_ARG, "unknown density id");
+    if (!lookup(cfg->density, 0, 0, 1, false, false, false, &v, &g, &lp)) return fail(KMC_ERR_BAD_ARG, "unknown density id");
     hipLaunchKernelGGL(lp, dim3(grid), dim3(256), 0, (hipStream_t)hip_stream, la);
     HIP_TRY(hipGetLastError());
     return KMC_OK;
@@ -2063,7 +2128,7 @@ KMC_EXPORT kmc_status kmc_metropolis_run(const kmc_metropolis_config* c, const d
     else {
         HalfStepFn v, g;
         LogpdfFn lp = nullptr;
-        lookup(c->density, 0, 0, 1, false, false, &v, &g, &lp);
+        lookup(c->density, 0, 0, 1, false, false, false, &v, &g, &lp);
         hipLaunchKernelGGL(lp, dim3(grid), dim3(256), 0, nullptr, la);
         HIP_TRY(hipGetLastError());
     }
@@ -2298,6 +2363,7 @@ KMC_EXPORT kmc_status kmc_sampler_int_acorr(kmc_sampler* s, double c, double* ta
     if (!s) return fail(KMC_ERR_BAD_ARG, "null sampler");
     if (!s->d_chain) return fail(KMC_ERR_BAD_ARG, "sampler was created without KMC_STORE_CHAIN");
     if (s->ld != s->cfg.ndim) return fail(KMC_ERR_UNSUPPORTED, "odd ndim: rows are padded on the device; use kmc_int_acorr on the downloaded chain");
+    if (s->f32) return fail(KMC_ERR_UNSUPPORTED, "KMC_F32: the device chain is float; use kmc_int_acorr on the downloaded chain");
     HIP_TRY(hipSetDevice(s->cfg.device));
     HIP_TRY(hipStreamSynchronize(s->stream));
     const int64_t ns = samples_done(s);

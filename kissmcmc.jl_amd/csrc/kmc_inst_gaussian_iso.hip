@@ -3,9 +3,9 @@
 #include "kmc_tables.hpp"
 
 namespace kmc {
-void table_gaussian_iso(int L, int K, int iter, bool p2p, bool ragged, HalfStepFn* vec, HalfStepFn* gen, LogpdfFn* lp)
+void table_gaussian_iso(int L, int K, int iter, bool p2p, bool ragged, bool f32, HalfStepFn* vec, HalfStepFn* gen, LogpdfFn* lp)
 {
-    density_fns<GaussianIso>(L, K, iter, p2p, ragged, vec, gen, lp);
+    density_fns<GaussianIso>(L, K, iter, p2p, ragged, f32, vec, gen, lp);
 }
 IslandFn island_gaussian_iso(int S, int K, bool ragged) { return island_lookup<GaussianIso>(S, K, ragged); }
 ResidentFn resident_gaussian_iso(int tpb, int K, bool ragged) { return resident_lookup<GaussianIso>(tpb, K, ragged); }

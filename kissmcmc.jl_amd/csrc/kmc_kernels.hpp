@@ -96,7 +96,7 @@ struct HalfStepArgs {
     int64_t           oth_row0;     // row of the complementary half's walker 0 (in each peer's pos for P2P)
     int32_t           n_active;     // number of active walkers of this shard
     int32_t           ndim;
-    int32_t           ld;           // row stride of pos / chain in doubles: ndim rounded up to even (16-B rows)
+    int32_t           ld;           // row stride of pos / chain in ELEMENTS (double, or float with KMC_F32): ndim rounded up to even
     int32_t           hloc_shift;   // log2(hloc) when hloc is a power of two, else -1
     // peer-to-peer sharding (P2P kernels only): partner p of the complementary half lives on rank
     // p / hloc at row oth_row0 + p % hloc of that rank's pos
@@ -226,6 +226,31 @@ __device__ __forceinline__ double2 load_row16(const double2* p)
 #endif
 }
 
+// Storage type T of the walker rows and the chain: double (KMC_F64) or float (KMC_F32: half the row bytes; the
+// arithmetic stays double -- a chunk is widened on load, and a proposal is rounded to single BEFORE its log-density
+// is evaluated, so a stored row and its stored log-pdf always belong together).
+template <class T> struct RowOf;
+template <> struct RowOf<double> { using V2 = double2; };
+template <> struct RowOf<float>  { using V2 = float2; };
+__device__ __forceinline__ void store_wt(float2* p, const float2& v)
+{
+#ifndef KMC_STORE_PLAIN
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const v2f t = {v.x, v.y};
+    asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(p), "v"(t) : "memory");
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ double2 load_row(const double2* p) { return load_row16(p); }
+__device__ __forceinline__ double2 load_row(const float2* p) { const float2 v = *p; return make_double2((double)v.x, (double)v.y); }
+__device__ __forceinline__ void store_row(double2* p, const double2& v) { store_wt(p, v); }
+__device__ __forceinline__ void store_row(float2* p, const double2& v) { store_wt(p, make_float2((float)v.x, (float)v.y)); }
+template <class T> __device__ __forceinline__ double as_stored(double v)
+{
+    if constexpr (sizeof(T) == 4) return (double)(float)v; else return v;
+}
+
 __device__ __forceinline__ double2 sel2(bool c, const double2& a, const double2& b)
 {
     return make_double2(c ? a.x : b.x, c ? a.y : b.y);
@@ -352,10 +377,13 @@ static __device__ unsigned long long g_probe[2][8192][4];
 
 // RAGGED = false: ndim == 2*L*K exactly (row stride and every mask fold at compile time);
 // RAGGED = true : ndim < 2*L*K, runtime row stride a.ld and masked tail chunks.
-template <class Dens, int L, int K, int ITER, bool P2P, bool RAGGED>
+template <class Dens, int L, int K, int ITER, bool P2P, bool RAGGED, class T = double>
 __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const HalfStepArgs& a)
 {
     static_assert(L >= 1 && L <= 64 && (L & (L - 1)) == 0, "L must be a power of two <= 64");
+    static_assert(!P2P || sizeof(T) == 8, "the peer-to-peer kernels keep double rows");
+    using V2 = typename RowOf<T>::V2;                   // one chunk = two consecutive elements of a row
+    T* const posT = reinterpret_cast<T*>(f.pos);
     static_assert(ITER >= 1 && ITER <= L, "a group's scalar lanes must cover its iterations");
     constexpr int G = 64 / L;          // groups = walkers in flight per wave
     constexpr int W = G * ITER;        // walkers per wave
@@ -406,9 +434,9 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
     for (int it = 0; it < ITER; ++it) {
         const int i = w0 + it * G + g;
         validB[it] = i < nact;
-        const double2* own = reinterpret_cast<const double2*>(f.pos + ((int64_t)f.own_row0 + (validB[it] ? i : nact - 1)) * ld);
+        const V2* own = reinterpret_cast<const V2*>(posT + ((int64_t)f.own_row0 + (validB[it] ? i : nact - 1)) * ld);
 #pragma unroll
-        for (int k = 0; k < K; ++k) xc[it][k] = cv[k] ? load_row16(&own[k * L + j]) : zero2;
+        for (int k = 0; k < K; ++k) xc[it][k] = cv[k] ? load_row(&own[k * L + j]) : zero2;
     }
 
     // ---- the step, then Philox: nothing here touches the argument struct.  Eager launch: the step is a preloaded
@@ -452,18 +480,18 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
         }
     }
     auto load_partner_rows = [&](int it) {
-        const double2* oth;
+        const V2* oth;
         if constexpr (!P2P) {
             const uint32_t partner = (uint32_t)__builtin_amdgcn_ds_bpermute((gbase + it) * 4, (int)partnerA);
-            oth = reinterpret_cast<const double2*>(f.pos + (oth_row0 + partner) * ld);
+            oth = reinterpret_cast<const V2*>(posT + (oth_row0 + partner) * ld);
         } else {
             const int src = (gbase + it) * 4;
             const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)(unsigned)addrA);
             const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)(unsigned)(addrA >> 32));
-            oth = reinterpret_cast<const double2*>(((unsigned long long)hi << 32) | lo);
+            oth = reinterpret_cast<const V2*>(((unsigned long long)hi << 32) | lo);
         }
 #pragma unroll
-        for (int k = 0; k < K; ++k) xo[it][k] = cv[k] ? load_row16(&oth[k * L + j]) : zero2;
+        for (int k = 0; k < K; ++k) xo[it][k] = cv[k] ? load_row(&oth[k * L + j]) : zero2;
     };
     constexpr int kFirst = ITER >= 2 ? ITER / 2 : ITER;                 // iterations whose loads precede the first logarithm
 #pragma unroll
@@ -549,8 +577,8 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
     for (int it = 0; it < ITER; ++it) {
 #pragma unroll
         for (int k = 0; k < K; ++k) {                                   // :255
-            xo[it][k].x = fma(zB[it], xc[it][k].x - xo[it][k].x, xo[it][k].x);
-            xo[it][k].y = fma(zB[it], xc[it][k].y - xo[it][k].y, xo[it][k].y);
+            xo[it][k].x = as_stored<T>(fma(zB[it], xc[it][k].x - xo[it][k].x, xo[it][k].x));
+            xo[it][k].y = as_stored<T>(fma(zB[it], xc[it][k].y - xo[it][k].y, xo[it][k].y));
         }
         const double S  = group_sum<L>(Dens::template frag_partial<L, K>(xo[it], j, ndim, a.dp));
         const double p1 = Dens::finish(S, a.dp);                         // :257
@@ -579,9 +607,9 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
     for (int it = 0; it < ITER; ++it) {
         const bool accB = ((accmask >> (gbase + it)) & 1ull) != 0;
         if (accB) {                                                     // :261
-            double2* own = reinterpret_cast<double2*>(f.pos + ((int64_t)f.own_row0 + w0 + it * G + g) * ld);
+            V2* own = reinterpret_cast<V2*>(posT + ((int64_t)f.own_row0 + w0 + it * G + g) * ld);
 #pragma unroll
-            for (int k = 0; k < K; ++k) if (cv[k]) store_row16(&own[k * L + j], xo[it][k]);
+            for (int k = 0; k < K; ++k) if (cv[k]) store_row(&own[k * L + j], xo[it][k]);
             if constexpr (P2P) {
                 if (a.push) {                                           // ... and into this rank's shadow on every peer
                     const int64_t off = (int64_t)(1 + a.me) * a.shard_stride + ((int64_t)f.own_row0 + w0 + it * G + g) * ld;
@@ -603,9 +631,9 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
             }
         }
         if (sample && a.chain != nullptr && validB[it]) {               // :268-269
-            double2* dst = reinterpret_cast<double2*>(a.chain + (sch.slot * a.chain_rows + a.chain_row0 + w0 + it * G + g) * ld);
+            V2* dst = reinterpret_cast<V2*>(reinterpret_cast<T*>(a.chain) + (sch.slot * a.chain_rows + a.chain_row0 + w0 + it * G + g) * ld);
 #pragma unroll
-            for (int k = 0; k < K; ++k) if (cv[k]) store_wt(&dst[k * L + j], sel2(accB, xo[it][k], xc[it][k]));
+            for (int k = 0; k < K; ++k) if (cv[k]) store_row(&dst[k * L + j], sel2(accB, xo[it][k], xc[it][k]));
         }
     }
     if (any_w) {
@@ -638,10 +666,10 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
 #endif
 }
 
-template <class Dens, int L, int K, int ITER, bool P2P, bool RAGGED>
+template <class Dens, int L, int K, int ITER, bool P2P, bool RAGGED, class T = double>
 __global__ __launch_bounds__(vec_tpb(L)) void half_step_vec(KMC_FRONT_PARAMS, const HalfStepArgs a)
 {
-    half_step_vec_body<Dens, L, K, ITER, P2P, RAGGED>(KMC_FRONT_PACK, a);
+    half_step_vec_body<Dens, L, K, ITER, P2P, RAGGED, T>(KMC_FRONT_PACK, a);
 }
 
 // Moment read-out: credit every walker's current value with the samples it has stood for since it
@@ -658,9 +686,10 @@ struct FlushArgs {
     int32_t       ld;        // row stride in doubles
 };
 
-template <int L, int K, int ITER>
+template <int L, int K, int ITER, class T = double>
 __global__ __launch_bounds__(vec_tpb(L)) void flush_moments_vec(const FlushArgs a)
 {
+    using V2 = typename RowOf<T>::V2;
     constexpr int G = 64 / L;
     constexpr int W = G * ITER;
     const int64_t ld = a.ld;
@@ -678,10 +707,10 @@ __global__ __launch_bounds__(vec_tpb(L)) void flush_moments_vec(const FlushArgs 
         if (i < a.n_active) {
             const int64_t row = a.row0 + i;
             const double w = (double)(a.nsamp - a.klast[row]);
-            const double2* x = reinterpret_cast<const double2*>(a.pos + row * ld);
+            const V2* x = reinterpret_cast<const V2*>(reinterpret_cast<const T*>(a.pos) + row * ld);
 #pragma unroll
             for (int k = 0; k < K; ++k) {
-                const double2 v = 2 * (k * L + j) < (int)ld ? x[k * L + j] : make_double2(0.0, 0.0);
+                const double2 v = 2 * (k * L + j) < (int)ld ? load_row(&x[k * L + j]) : make_double2(0.0, 0.0);
                 ms[k].x += v.x * w; ms[k].y += v.y * w;
                 mq[k].x += (v.x * v.x) * w; mq[k].y += (v.y * v.y) * w;
             }
@@ -700,9 +729,10 @@ __global__ __launch_bounds__(vec_tpb(L)) void flush_moments_vec(const FlushArgs 
 // ------------------------------------------------------------------------------------------
 // Generic kernel: one walker per lane, any ndim.
 // ------------------------------------------------------------------------------------------
-template <class Dens, bool P2P>
+template <class Dens, bool P2P, class T = double>
 __device__ __forceinline__ void half_step_generic_body(const HalfStepFront& f, const HalfStepArgs& a)
 {
+    static_assert(!P2P || sizeof(T) == 8, "the peer-to-peer kernels keep double rows");
     const int tid = blockIdx.x * 256 + threadIdx.x;
     const SchedEntry sch = schedule_of(f, a);
     const uint64_t step = 2ull * (uint64_t)sch.gen + (uint64_t)a.half;      // (eager: sched_inline.gen)
@@ -714,31 +744,31 @@ __device__ __forceinline__ void half_step_generic_body(const HalfStepFront& f, c
     const int64_t gw = a.own_row0 + tid;                                // row in pos / index in logp, naccept
     const Draw dr = draw_step(a.dc, step, (uint64_t)(a.gw0 + tid));
     const int64_t ld = a.ld;
-    double* own = a.pos + gw * ld;
-    const double* oth;
+    T* own = reinterpret_cast<T*>(a.pos) + gw * ld;
+    const T* oth;
     if constexpr (!P2P) {
-        oth = a.pos + (a.oth_row0 + dr.partner) * ld;
+        oth = reinterpret_cast<const T*>(a.pos) + (a.oth_row0 + dr.partner) * ld;
     } else {
         const uint32_t q = a.hloc_shift >= 0 ? dr.partner >> a.hloc_shift : dr.partner / a.hloc;
         const uint32_t r = dr.partner - q * a.hloc;
         const double* base = a.peer_pos[0];
 #pragma unroll
         for (int t = 1; t < 8; ++t) base = (q == (uint32_t)t) ? a.peer_pos[t] : base;
-        oth = base + (a.oth_row0 + r) * ld;
+        oth = reinterpret_cast<const T*>(base) + (a.oth_row0 + r) * ld;
     }
     const double p0 = a.logp[gw];
 
     constexpr bool kHost = HostEvalTrait<Dens>::value;
     if constexpr (kHost) {
         if (a.prop_out != nullptr) {                                    // PROPOSE pass
-            for (int d = 0; d < ndim; ++d) a.prop_out[(int64_t)tid * ld + d] = fma(dr.z, own[d] - oth[d], oth[d]);
+            for (int d = 0; d < ndim; ++d) a.prop_out[(int64_t)tid * ld + d] = fma(dr.z, (double)own[d] - (double)oth[d], (double)oth[d]);
             return;
         }
     }
     typename Dens::Seq q;
     Dens::seq_init(q);
     for (int d = 0; d < ndim; ++d) {
-        const double y = fma(dr.z, own[d] - oth[d], oth[d]);            // :255
+        const double y = as_stored<T>(fma(dr.z, (double)own[d] - (double)oth[d], (double)oth[d]));   // :255
         Dens::seq_add(q, y, d, a.dp);
     }
     double p1 = Dens::seq_finish(q, ndim, a.dp);                         // :257
@@ -751,10 +781,10 @@ __device__ __forceinline__ void half_step_generic_body(const HalfStepFront& f, c
     const int64_t row = sch.slot * a.chain_rows + a.chain_row0 + tid;
     if (acc || do_mom || do_chain) {
         for (int d = 0; d < ndim; ++d) {
-            const double xcd = own[d];
-            const double cur = acc ? fma(dr.z, xcd - oth[d], oth[d]) : xcd;
-            if (acc) own[d] = cur;                                      // :261
-            if (do_chain) a.chain[row * ld + d] = cur;                  // :269
+            const double xcd = (double)own[d];
+            const double cur = acc ? as_stored<T>(fma(dr.z, xcd - (double)oth[d], (double)oth[d])) : xcd;
+            if (acc) own[d] = (T)cur;                                   // :261
+            if (do_chain) reinterpret_cast<T*>(a.chain)[row * ld + d] = (T)cur;   // :269
             if (do_mom) {
                 const int64_t idx = (int64_t)d * a.macc_stride + tid;
                 a.msum[idx] += cur;
@@ -769,10 +799,10 @@ __device__ __forceinline__ void half_step_generic_body(const HalfStepFront& f, c
     if (sample && a.chain_logp != nullptr) a.chain_logp[row] = acc ? p1 : p0;   // :271
 }
 
-template <class Dens, bool P2P>
+template <class Dens, bool P2P, class T = double>
 __global__ __launch_bounds__(256) void half_step_generic(KMC_FRONT_PARAMS, const HalfStepArgs a)
 {
-    half_step_generic_body<Dens, P2P>(KMC_FRONT_PACK, a);
+    half_step_generic_body<Dens, P2P, T>(KMC_FRONT_PACK, a);
 }
 
 // Initial log-pdfs, src/samplers.jl:209.

@@ -16,50 +16,54 @@ using InitBallFn = void (*)(const InitBallArgs);
 using MetropolisFn = void (*)(const MetropolisArgs);
 
 #ifdef KMC_TABLES_IMPL
-template <class D, int L, int K, int ITER, bool P2P, bool RAGGED>
+template <class D, int L, int K, int ITER, bool P2P, bool RAGGED, class T>
 HalfStepFn vec_one()
 {
     // a group's ITER scalar lanes must fit in its L lanes; keep the register tile (ITER*K chunks) bounded
-    if constexpr (ITER <= L && ITER * K <= 16) return half_step_vec<D, L, K, ITER, P2P, RAGGED>;
+    if constexpr (ITER <= L && ITER * K <= 16) return half_step_vec<D, L, K, ITER, P2P, RAGGED, T>;
     else return nullptr;
 }
 
-template <class D, int L, int K, bool P2P, bool RAGGED>
+template <class D, int L, int K, bool P2P, bool RAGGED, class T>
 HalfStepFn vec_iter(int iter)
 {
-    // full ITER range only for the single-GPU exact kernels (tuning); the others: what make_plan picks
-    constexpr bool kWide = !P2P && !RAGGED;
+    // full ITER range only for the single-GPU exact double kernels (tuning); the others: what make_plan picks
+    constexpr bool kWide = !P2P && !RAGGED && sizeof(T) == 8;
     switch (iter) {
-    case 1: return vec_one<D, L, K, 1, P2P, RAGGED>();
-    case 2: return vec_one<D, L, K, 2, P2P, RAGGED>();
-    case 4: return vec_one<D, L, K, 4, P2P, RAGGED>();
-    case 8: if constexpr (kWide || (P2P && !RAGGED)) return vec_one<D, L, K, 8, P2P, RAGGED>(); else return nullptr;
-    case 16: if constexpr (kWide) return vec_one<D, L, K, 16, P2P, RAGGED>(); else return nullptr;
+    case 1: return vec_one<D, L, K, 1, P2P, RAGGED, T>();
+    case 2: return vec_one<D, L, K, 2, P2P, RAGGED, T>();
+    case 4: return vec_one<D, L, K, 4, P2P, RAGGED, T>();
+    case 8: if constexpr (kWide || (P2P && !RAGGED)) return vec_one<D, L, K, 8, P2P, RAGGED, T>(); else return nullptr;
+    case 16: if constexpr (kWide) return vec_one<D, L, K, 16, P2P, RAGGED, T>(); else return nullptr;
     default: return nullptr;
     }
 }
 
 template <class D, int L, int K>
-HalfStepFn vec_pick(int iter, bool p2p, bool ragged)
+HalfStepFn vec_pick(int iter, bool p2p, bool ragged, bool f32)
 {
-    if (ragged) return p2p ? vec_iter<D, L, K, true, true>(iter) : vec_iter<D, L, K, false, true>(iter);
-    return p2p ? vec_iter<D, L, K, true, false>(iter) : vec_iter<D, L, K, false, false>(iter);
+    if (f32) {      // KMC_F32: single rows, one GPU
+        if (p2p) return nullptr;
+        return ragged ? vec_iter<D, L, K, false, true, float>(iter) : vec_iter<D, L, K, false, false, float>(iter);
+    }
+    if (ragged) return p2p ? vec_iter<D, L, K, true, true, double>(iter) : vec_iter<D, L, K, false, true, double>(iter);
+    return p2p ? vec_iter<D, L, K, true, false, double>(iter) : vec_iter<D, L, K, false, false, double>(iter);
 }
 
 // geometries make_plan can pick: exact + ragged, single-GPU + P2P; the extra exact single-GPU ones
 // exist for tuning (KMC_PLAN)
 template <class D>
-HalfStepFn vec_lookup(int L, int K, int iter, bool p2p, bool ragged)
+HalfStepFn vec_lookup(int L, int K, int iter, bool p2p, bool ragged, bool f32)
 {
     if constexpr (!D::kHasFrag) {
         return nullptr;
     } else {
-#define KMC_LK(l, k) if (L == l && K == k) return vec_pick<D, l, k>(iter, p2p, ragged);
+#define KMC_LK(l, k) if (L == l && K == k) return vec_pick<D, l, k>(iter, p2p, ragged, f32);
         KMC_LK(1, 1) KMC_LK(2, 1) KMC_LK(4, 1) KMC_LK(4, 2) KMC_LK(8, 2) KMC_LK(16, 2) KMC_LK(32, 2) KMC_LK(64, 2)
         KMC_LK(64, 4) KMC_LK(64, 8)
 #undef KMC_LK
-        if (ragged || p2p) return nullptr;
-#define KMC_LK(l, k) if (L == l && K == k) return vec_iter<D, l, k, false, false>(iter);
+        if (ragged || p2p || f32) return nullptr;
+#define KMC_LK(l, k) if (L == l && K == k) return vec_iter<D, l, k, false, false, double>(iter);
         KMC_LK(8, 1) KMC_LK(16, 1) KMC_LK(32, 1) KMC_LK(64, 1) KMC_LK(4, 4) KMC_LK(8, 4)
 #undef KMC_LK
         return nullptr;
@@ -67,10 +71,11 @@ HalfStepFn vec_lookup(int L, int K, int iter, bool p2p, bool ragged)
 }
 
 template <class D>
-void density_fns(int L, int K, int iter, bool p2p, bool ragged, HalfStepFn* vec, HalfStepFn* gen, LogpdfFn* lp)
+void density_fns(int L, int K, int iter, bool p2p, bool ragged, bool f32, HalfStepFn* vec, HalfStepFn* gen, LogpdfFn* lp)
 {
-    *vec = vec_lookup<D>(L, K, iter, p2p, ragged);
-    *gen = p2p ? half_step_generic<D, true> : half_step_generic<D, false>;
+    *vec = vec_lookup<D>(L, K, iter, p2p, ragged, f32);
+    if (f32) *gen = p2p ? nullptr : half_step_generic<D, false, float>;
+    else *gen = p2p ? half_step_generic<D, true, double> : half_step_generic<D, false, double>;
     *lp = logpdf_rows<D>;
 }
 
@@ -143,7 +148,7 @@ MetropolisFn metropolis_lookup(int ndim)
 
 // one entry point per density (defined in kmc_inst_<density>.hip)
 #define KMC_DECLARE_DENSITY_TABLE(name) \
-    void name(int L, int K, int iter, bool p2p, bool ragged, HalfStepFn* vec, HalfStepFn* gen, LogpdfFn* lp)
+    void name(int L, int K, int iter, bool p2p, bool ragged, bool f32, HalfStepFn* vec, HalfStepFn* gen, LogpdfFn* lp)
 KMC_DECLARE_DENSITY_TABLE(table_gaussian_iso);
 KMC_DECLARE_DENSITY_TABLE(table_exponential);
 KMC_DECLARE_DENSITY_TABLE(table_rosenbrock);

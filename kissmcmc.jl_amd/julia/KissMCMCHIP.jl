@@ -141,7 +141,7 @@ last_error() = unsafe_string(ccall((:kmc_last_error, LIB), Cstring, ()))
 
 """
     emcee(pdf::DeviceLogPdf, theta0s; niter=10^5, nburnin=niter÷2, nthin=1, a_scale=2.0,
-          use_progress_meter=true, hasblob=false, init_blobs, reduce_blob!, seed=rand(UInt64), device=0)
+          use_progress_meter=true, hasblob=false, init_blobs, reduce_blob!, seed=rand(UInt64), device=0, dtype=:f64)
 
 Same meaning as KissMCMC.emcee (src/samplers.jl:188-197); returns
 `(thetas, accept_ratio, logdensities, blobs)` with `thetas[w][k]` (src/samplers.jl:292).
@@ -151,7 +151,7 @@ function emcee(pdf::DeviceLogPdf, theta0s; niter=10^5, nburnin=niter ÷ 2, nthin
                use_progress_meter=true, hasblob=false,
                init_blobs=(blob0, nsamples) -> sizehint!(typeof(blob0)[], nsamples),      # init_output_vector :80-85
                reduce_blob! =(blobs, blob) -> push!(blobs, blob),                         # :196
-               seed=rand(UInt64), device=0)
+               seed=rand(UInt64), device=0, dtype=:f64)     # dtype=:f32: float rows on the device (KMC_F32), built-in densities
     hasblob && !(pdf isa HostLogPdf && pdf.hasblob) &&
         error("hasblob=true needs a host closure as pdf: device densities return the log-pdf alone")
     nwalkers = length(theta0s)
@@ -184,7 +184,7 @@ function emcee(pdf::DeviceLogPdf, theta0s; niter=10^5, nburnin=niter ÷ 2, nthin
             acc_fn = @cfunction(accepted_trampoline, Cint, (Ptr{UInt8}, Int64, Int64, Int64, Int32, Ptr{Cvoid}))
         end
     end
-    cfg = Ref(KmcConfig(0, density_id(pdf), p8, nwalkers, ndim, niter_walker, nburnin_walker, nthin,
+    cfg = Ref(KmcConfig(dtype == :f32 ? 1 : 0, density_id(pdf), p8, nwalkers, ndim, niter_walker, nburnin_walker, nthin,
                         a_scale, UInt64(seed), 0x3, Int32(device), 0, 1, user_handle(pdf), 0, 0, host_fn, host_ctx, acc_fn))   # flags: STORE_CHAIN | STORE_LOGP
     chain = Array{Float64}(undef, ndim, nwalkers, nsamples)
     clogp = Array{Float64}(undef, nwalkers, nsamples)

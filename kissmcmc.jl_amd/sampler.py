@@ -22,7 +22,8 @@ class Sampler:
                  nthin: int = 1, a_scale: float = 2.0, seed: int = 0, store_chain: bool = False,
                  store_logp: bool = False, moments: bool = False, use_graph: bool = True,
                  device: int = 0, shard_rank: int = 0, shard_count: int = 1, p2p: bool = False,
-                 island_gens: int = 0, island_size: int = 0, p2p_finegrained: bool = False, p2p_fold: bool = False, p2p_push: bool = False):
+                 island_gens: int = 0, island_size: int = 0, p2p_finegrained: bool = False, p2p_fold: bool = False, p2p_push: bool = False,
+                 dtype: str = "f64"):
         if not isinstance(pdf, DeviceLogPdf):
             raise TypeError(
                 "pdf must be a menu log-density (GaussianIso, Exponential, Rosenbrock, LogNormal, MvNormal2), "
@@ -32,7 +33,9 @@ class Sampler:
         self.pdf = pdf
         self._h = None
         cfg = _lib.Config()
-        cfg.dtype = _lib.F64
+        if dtype not in ("f64", "f32"):
+            raise ValueError("dtype must be 'f64' (the reference's Float64) or 'f32' (float rows on the device)")
+        cfg.dtype = _lib.F32 if dtype == "f32" else _lib.F64
         cfg.density = pdf.density_id
         p = list(pdf.params()) + [0.0] * 8
         for i in range(8):

@@ -37,6 +37,8 @@ class Config(C.Structure):
         ("nthin", C.c_int64),
         ("a_scale", C.c_double),
         ("seed", C.c_uint64),
+        ("state_f32", C.c_int32),
+        ("pad_", C.c_int32),
     ]
 
 
@@ -110,7 +112,7 @@ def _ip(a):
 
 
 def make_config(density, params, nwalkers, ndim, ngenerations=0, nburnin=0, nthin=1,
-                a_scale=2.0, seed=0, nthreads=1) -> Config:
+                a_scale=2.0, seed=0, nthreads=1, state_f32=False) -> Config:
     c = Config()
     c.density = int(density)
     c.nthreads = int(nthreads)
@@ -120,6 +122,7 @@ def make_config(density, params, nwalkers, ndim, ngenerations=0, nburnin=0, nthi
     c.nwalkers, c.ndim = int(nwalkers), int(ndim)
     c.ngenerations, c.nburnin, c.nthin = int(ngenerations), int(nburnin), int(nthin)
     c.a_scale, c.seed = float(a_scale), int(seed)
+    c.state_f32 = 1 if state_f32 else 0
     return c
 
 

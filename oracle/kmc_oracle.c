@@ -64,6 +64,10 @@ typedef struct {
     int64_t  nthin;         /*                   src/samplers.jl:190 */
     double   a_scale;       /*                   src/samplers.jl:192 */
     uint64_t seed;
+    int32_t  state_f32;     /* the build's KMC_F32 option (not a reference feature): the walkers are kept in IEEE single --
+                               the initial ensemble and every proposal are rounded to float before the log-density is
+                               evaluated; all arithmetic stays double */
+    int32_t  pad_;
 } kmco_config;
 
 /* ------------------------------------------------------------------------------------------
@@ -232,6 +236,8 @@ KMCO_API void kmco_half_step(const kmco_config* c, double* pos, double* logp, in
             const double* xo = pos + no * nd;
             for (int64_t d = 0; d < nd; ++d)                       /* :255 theta0s[no] .+ z .* (theta0s[nc] .- theta0s[no]) */
                 y[d] = fma(z, xc[d] - xo[d], xo[d]);
+            if (c->state_f32)
+                for (int64_t d = 0; d < nd; ++d) y[d] = (double)(float)y[d];
             const double p1 = kmco_logpdf(c->density, c->params, y, nd);   /* :257 */
             const double lhs = (nm1 * log(z) + p1) - logp[nc];     /* :260, left to right */
             if (lhs >= log(ua)) {                                  /* :260 note >= */
@@ -269,6 +275,8 @@ KMCO_API int kmco_emcee(const kmco_config* c, const double* theta0,
     double* logp = (double*)malloc(sizeof(double) * (size_t)nw);
     int64_t* nacc = (int64_t*)calloc((size_t)nw, sizeof(int64_t));
     memcpy(pos, theta0, sizeof(double) * (size_t)(nw * nd));   /* :198 deepcopy */
+    if (c->state_f32)
+        for (int64_t i = 0; i < nw * nd; ++i) pos[i] = (double)(float)pos[i];
     for (int64_t w = 0; w < nw; ++w) {                          /* :209-210 initial log-pdfs */
         logp[w] = kmco_logpdf(c->density, c->params, pos + w * nd, nd);
         if (!isfinite(logp[w])) { free(pos); free(logp); free(nacc); return KMCO_ERR_NONFINITE_LOGP; }

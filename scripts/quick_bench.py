@@ -1,7 +1,7 @@
 """Interleaved timing of the half-step kernel at the BASELINE configs for several launch geometries
 (one process, round-robin over variants; median and min reported -- cdna guide rule 24).
 Usage: python scripts/quick_bench.py CONFIG [plan ...]    plan = "L,K,ITER" | "generic" | "" (default)
-       env QB_MOMENTS=0/1 (default both), QB_ROUNDS (default 7), QB_GENS (default per config)"""
+       env QB_MOMENTS=0/1 (default both), QB_ROUNDS (default 7), QB_GENS (default per config), QB_DTYPE=f64|f32|both"""
 import os
 import statistics
 import sys
@@ -32,7 +32,9 @@ def main():
     if cfgname == "C3":
         th *= 0.1
     variants = []
-    for plan in plans:
+    dts = os.environ.get("QB_DTYPE", "f64")
+    dts = ["f64", "f32"] if dts == "both" else [dts]
+    for plan, dt in [(p, d) for p in plans for d in dts]:
         for mom in moms:
             eager = plan.endswith("e")           # "L,K,ITERe" = same geometry, eager launches (no hipGraph)
             pl = plan.rstrip("e")
@@ -40,22 +42,22 @@ def main():
                 os.environ["KMC_PLAN"] = pl
             else:
                 os.environ.pop("KMC_PLAN", None)
-            s = kmc.Sampler(pdf, nw, nd, 10 ** 9, 0, 1, 2.0, 7, moments=mom, use_graph=not eager)
+            s = kmc.Sampler(pdf, nw, nd, 10 ** 9, 0, 1, 2.0, 7, moments=mom, use_graph=not eager, dtype=dt)
             s.set_positions(th)
             s.run(128)
             s.sync()
-            variants.append((plan or "default", mom, s, []))
+            variants.append(((plan or "default") + ("/f32" if dt == "f32" else ""), mom, s, []))
     for _ in range(rounds):
         for plan, mom, s, times in variants:
             s.run(G)
             s.sync()
             times.append(s.last_run_ms())
-    br = (2 * nd + 1) * 8
     for plan, mom, s, times in variants:
+        br = (2 * nd * (4 if plan.endswith("/f32") else 8)) + 8
         med, mn = statistics.median(times), min(times)
         acc = s.naccept().mean() / s.generation
         steps = nw * G / (med * 1e-3)
-        print(f"{cfgname} plan={plan:10s} moments={int(mom)}  median {med / (2 * G) * 1e3:7.2f} us/half-step (min {mn / (2 * G) * 1e3:6.2f})  "
+        print(f"{cfgname} plan={plan:12s} moments={int(mom)}  median {med / (2 * G) * 1e3:7.2f} us/half-step (min {mn / (2 * G) * 1e3:6.2f})  "
               f"{steps / 1e9:7.3f} Gsteps/s  read {steps * br / 1e12:6.3f} TB/s  acc={acc:.3f}", flush=True)
         s.close()
 

@@ -1,0 +1,128 @@
+"""GPU: the KMC_F32 option (include/kissmcmc_hip.h) -- walker rows and the stored chain kept in IEEE single on the
+device, arithmetic in double -- against the oracle run with ``state_f32`` (the initial ensemble and every proposal
+rounded to float before the log-density is evaluated).  Same bar as the double path: identical accept decisions,
+bit-identical positions and chain, log-pdfs within 1e-12 relative; and the reference's statistical pins."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from test_gpu_parity import _compare, _densities, _theta0
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # name, nwalkers, ndim, G, nburnin, nthin
+    ("gauss", 64, 4, 50, 10, 1),
+    ("gauss", 4096, 32, 30, 10, 1),      # the C2 geometry (L=8 K=2, two walkers per group)
+    ("gauss", 130, 32, 30, 5, 2),        # partial last wave
+    ("gauss", 256, 64, 20, 4, 1),
+    ("gauss", 1040, 1024, 6, 2, 1),      # L=64 K=8
+    ("gauss_shift", 100, 1, 200, 100, 1),
+    ("expo", 100, 1, 300, 150, 1),       # README shape
+    ("rosen", 100, 2, 300, 100, 1),
+    ("rosen", 2048, 64, 30, 10, 1),      # C3 geometry
+    ("lognormal", 128, 6, 60, 20, 1),
+    ("gauss", 300, 33, 40, 10, 1),       # odd ndim: padded float rows
+    ("rosen", 130, 9, 80, 20, 1),
+    ("gauss", 1040, 1026, 4, 1, 1),      # beyond the vector kernels: generic kernel
+    ("gauss", 34, 32, 100, 30, 1),
+]
+
+
+def _run_f32(kmc, oracle, name, nw, nd, G, nburn, nthin, seed, use_graph=True):
+    pdf, did, params = _densities(kmc, oracle)[name]
+    th = _theta0(name, nw, nd, seed)
+    ref = oracle.emcee(oracle.make_config(did, params, nw, nd, G, nburn, nthin, 2.0, seed, state_f32=True), th)
+    with kmc.Sampler(pdf, nw, nd, G, nburn, nthin, 2.0, seed, store_chain=True, store_logp=True, moments=True,
+                     use_graph=use_graph, dtype="f32") as s:
+        assert "float" in s.describe()
+        s.set_positions(th)
+        s.run(G)
+        s.sync()
+        got = dict(final_pos=s.positions(), final_logp=s.logp(), naccept=s.naccept(), accept_ratio=s.accept_ratio())
+        got["chain"], got["chain_logp"] = s.chain()
+        got["sum"], got["sumsq"], got["nmoment"] = s.moments()
+    return ref, got, th
+
+
+@pytest.mark.parametrize("name,nw,nd,G,nburn,nthin", CASES)
+def test_f32_rows_match_the_oracle(kmc, oracle, name, nw, nd, G, nburn, nthin):
+    ref, got, th = _run_f32(kmc, oracle, name, nw, nd, G, nburn, nthin, seed=77 + nd)
+    _compare(ref, got)
+    # everything stored is representable in single, and the run differs from the double one
+    assert np.array_equal(got["chain"], got["chain"].astype(np.float32).astype(np.float64))
+    assert np.array_equal(got["final_pos"], got["final_pos"].astype(np.float32).astype(np.float64))
+
+
+def test_f32_eager_and_state_round_trip(kmc, oracle):
+    ref, got, th = _run_f32(kmc, oracle, "gauss", 512, 32, 24, 4, 1, seed=5, use_graph=False)
+    _compare(ref, got)
+    pdf = kmc.GaussianIso()
+    with kmc.Sampler(pdf, 512, 32, 24, 4, 1, 2.0, 5, dtype="f32") as a, kmc.Sampler(pdf, 512, 32, 24, 4, 1, 2.0, 5, dtype="f32") as b:
+        a.set_positions(th)
+        a.run(10)
+        a.sync()
+        b.restore(a.state())
+        b.run(14)
+        b.sync()
+        np.testing.assert_array_equal(b.positions(), ref["final_pos"])
+        np.testing.assert_array_equal(b.naccept(), ref["naccept"])
+
+
+def test_f32_init_ball_and_reference_pins(kmc):
+    """the reference's Normal(-5,3) case (test/runtests.jl:53-56) through emcee(..., dtype="f32")."""
+    from refcases import CASES as REF, check_mean_std
+    case = REF[0]
+    pdf = kmc.GaussianIso(-5.0, 3.0)
+    theta0s = kmc.make_theta0s(-4.0, 0.1, pdf, 100, rng=2)
+    thetas, ar, logd, blobs = kmc.emcee(pdf, theta0s, niter=10 ** 5, use_progress_meter=False, seed=4, dtype="f32")
+    assert thetas.shape == (100, 500) and np.all(ar > 0.1)
+    t, a, l, _ = kmc.squash_walkers(thetas, ar, logd, verbose=False)
+    check_mean_std(t, case)
+    np.testing.assert_allclose(l, [pdf(float(v)) for v in t], rtol=1e-12, atol=1e-12)   # logp of the rows as stored
+    with kmc.Sampler(kmc.Exponential(), 256, 3, 10, dtype="f32") as s:
+        s.init_ball(np.full(3, 0.05), np.full(3, 0.1), seed=9)
+        x, lp = s.positions(), s.logp()
+        assert np.all(x >= 0) and np.array_equal(x, x.astype(np.float32).astype(np.float64))
+        np.testing.assert_allclose(lp, -x.sum(axis=1), rtol=1e-14)
+
+
+def test_f32_statistics_at_c2_geometry(kmc):
+    """moments and acceptance of a stationary Gaussian ensemble, float rows against double rows (same seed: the
+    chains decorrelate after the first rounding difference, the statistics must agree)."""
+    rng = np.random.default_rng(0)
+    th = rng.standard_normal((8192, 32))
+    out = {}
+    for dt in ("f64", "f32"):
+        with kmc.Sampler(kmc.GaussianIso(), 8192, 32, 400, 100, 1, 2.0, 3, moments=True, dtype=dt) as s:
+            s.set_positions(th)
+            s.run(400)
+            s.sync()
+            sm, sq, n = s.moments()
+            out[dt] = (sm / n, sq / n - (sm / n) ** 2, s.accept_ratio().mean())
+    for k in range(2):
+        np.testing.assert_allclose(out["f32"][k], out["f64"][k], atol=0.02)
+    assert abs(out["f32"][2] - out["f64"][2]) < 0.003
+    assert np.all(np.abs(out["f32"][0]) < 0.03) and np.all(np.abs(out["f32"][1] - 1.0) < 0.05)
+
+
+def test_f32_is_refused_where_it_is_not_built(kmc):
+    from kissmcmc_jl_amd import _lib
+    L = _lib.lib()
+    c = _lib.Config()
+    c.dtype, c.density = _lib.F32, 0
+    c.params[0], c.params[1] = 0.0, 1.0
+    c.nwalkers, c.ndim, c.ngenerations, c.nthin, c.a_scale = 64, 4, 10, 1, 2.0
+    assert L.kmc_validate(C.byref(c)) == _lib.OK
+    c.flags = _lib.P2P
+    assert L.kmc_validate(C.byref(c)) == _lib.ERR_UNSUPPORTED
+    c.flags, c.shard_count = 0, 2
+    assert L.kmc_validate(C.byref(c)) == _lib.ERR_UNSUPPORTED
+    c.shard_count, c.dtype = 1, 7
+    assert L.kmc_validate(C.byref(c)) == _lib.ERR_UNSUPPORTED
+    with pytest.raises(_lib.KmcError):
+        kmc.Sampler(kmc.ExprDensity("-0.5*x*x"), 64, 4, 10, dtype="f32")
+    with kmc.Sampler(kmc.GaussianIso(), 64, 4, 10, dtype="f32") as s:
+        with pytest.raises(_lib.KmcError, match="double rows"):
+            s.bind_positions(1 << 20)
