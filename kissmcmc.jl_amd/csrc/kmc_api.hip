@@ -451,7 +451,7 @@ struct kmc_sampler {
     double* d_chain_logp = nullptr;
     double* d_msum = nullptr;
     double* d_msumsq = nullptr;
-    uint32_t* d_klast = nullptr;      // vec kernels: samples already credited per walker
+    uint32_t* d_klast = nullptr;      // vec kernels: samples already credited per walker (d_logp, d_naccept, d_klast: one block)
     double2* d_ring = nullptr;        // vec kernels: parked draws of the walkers' next steps, [4][nrows] x 32 B (HalfStepArgs::ring)
     int64_t macc_stride = 0, macc_elems = 0;
     int64_t moment_base = 0;  // samples that precede the restored state (kmc_sampler_set_state)
@@ -570,11 +570,10 @@ HalfStepFront front_of(const HalfStepArgs& a)
     f.sched = a.sched_index < 0 ? nullptr : a.sched_table + a.sched_index;
     f.step = (uint32_t)(2ull * (uint64_t)a.sched_inline.gen + (uint64_t)a.half);       // used when sched == nullptr
     f.gw0 = (uint32_t)a.gw0;
-    f.own_row0 = (int32_t)a.own_row0;
-    f.n_active = a.n_active;
+    f.logp = a.logp;
+    f.nact_half = (uint32_t)a.n_active | ((uint32_t)a.half << 31);
     f.ring_now = a.ring ? a.ring + (int64_t)a.ring_slot * a.ring_rows * 2 : nullptr;
     f.seed_lo = a.dc.seed_lo; f.seed_hi = a.dc.seed_hi; f.nhalf = a.dc.nhalf;
-    f.half = a.half;
     return f;
 }
 
@@ -614,8 +613,8 @@ hipError_t launch_half_kernel(const kmc_sampler* s, const HalfStepArgs& a)
         const HalfStepLaunch la{f, a};
         return launch_module(s->plan.vec ? s->uk.vec : s->uk.generic, (unsigned)s->grid, (unsigned)s->tpb, s->stream, la);
     }
-    hipLaunchKernelGGL(s->plan.fn, dim3(s->grid), dim3(s->tpb), 0, s->stream, f.pos, f.sched, f.ring_now, f.gw0, f.own_row0, f.n_active,
-                       f.seed_lo, f.seed_hi, f.nhalf, f.half, f.step, a);
+    hipLaunchKernelGGL(s->plan.fn, dim3(s->grid), dim3(s->tpb), 0, s->stream, f.pos, f.sched, f.ring_now, f.logp, f.gw0, f.nact_half,
+                       f.seed_lo, f.seed_hi, f.nhalf, f.step, a);
     return hipGetLastError();
 }
 
@@ -657,11 +656,11 @@ kmc_status ensure_graph(kmc_sampler* s)
 struct KernelParamPack {      // storage the kernelParams pointers of one node refer to
     HalfStepFront f;
     HalfStepArgs a;
-    void* ptrs[12];
+    void* ptrs[11];
     void bind()
     {
-        ptrs[0] = &f.pos; ptrs[1] = &f.sched; ptrs[2] = &f.ring_now; ptrs[3] = &f.gw0; ptrs[4] = &f.own_row0; ptrs[5] = &f.n_active;
-        ptrs[6] = &f.seed_lo; ptrs[7] = &f.seed_hi; ptrs[8] = &f.nhalf; ptrs[9] = &f.half; ptrs[10] = &f.step; ptrs[11] = &a;
+        ptrs[0] = &f.pos; ptrs[1] = &f.sched; ptrs[2] = &f.ring_now; ptrs[3] = &f.logp; ptrs[4] = &f.gw0; ptrs[5] = &f.nact_half;
+        ptrs[6] = &f.seed_lo; ptrs[7] = &f.seed_hi; ptrs[8] = &f.nhalf; ptrs[9] = &f.step; ptrs[10] = &a;
     }
 };
 
@@ -1012,8 +1011,12 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
     else
         CREATE_TRY(hipMalloc(&s->d_pos, (s->push ? 1 + (size_t)s->cfg.shard_count : 1) * nw * ldz * esz));
     CREATE_TRY(hipMemset(s->d_pos, 0, (s->push ? 1 + (size_t)s->cfg.shard_count : 1) * nw * ldz * esz));   // the pad column of odd ndim stays 0
-    CREATE_TRY(hipMalloc(&s->d_logp, nw * sizeof(double)));
-    CREATE_TRY(hipMalloc(&s->d_naccept, nw * sizeof(uint32_t)));
+    // per-walker block {logp[nrows], naccept[nrows], klast[nrows]}: one allocation, so the half-step kernels reach all
+    // three from one preloaded pointer (HalfStepFront::logp)
+    CREATE_TRY(hipMalloc(&s->d_logp, nw * (sizeof(double) + 2 * sizeof(uint32_t))));
+    s->d_naccept = reinterpret_cast<uint32_t*>(s->d_logp + nw);
+    s->d_klast = s->d_naccept + nw;
+    CREATE_TRY(hipMemset(s->d_klast, 0, nw * sizeof(uint32_t)));
     static_assert(kGraphChunk <= 64, "advance_schedule runs one 64-thread block");
     CREATE_TRY(hipMalloc(&s->d_gen, 64));
     CREATE_TRY(hipMemset(s->d_gen, 0, 64));
@@ -1031,10 +1034,6 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         CREATE_TRY(hipMalloc(&s->d_msumsq, (size_t)s->macc_elems * sizeof(double)));
         CREATE_TRY(hipMemset(s->d_msum, 0, (size_t)s->macc_elems * sizeof(double)));
         CREATE_TRY(hipMemset(s->d_msumsq, 0, (size_t)s->macc_elems * sizeof(double)));
-        if (s->plan.vec) {
-            CREATE_TRY(hipMalloc((void**)&s->d_klast, nw * sizeof(uint32_t)));
-            CREATE_TRY(hipMemset(s->d_klast, 0, nw * sizeof(uint32_t)));
-        }
         if (s->islands || s->resident) {
             const size_t ne = (size_t)s->nislands * 4 * (size_t)s->island_K;
             CREATE_TRY(hipMalloc(&s->d_isum, ne * sizeof(double)));
@@ -1093,15 +1092,13 @@ KMC_EXPORT void kmc_sampler_destroy(kmc_sampler* s)
         (void)hipFree(s->d_done);
     }
     if (s->own_pos) (void)hipFree(s->d_pos);
-    (void)hipFree(s->d_logp);
-    (void)hipFree(s->d_naccept);
+    (void)hipFree(s->d_logp);          // the {logp, naccept, klast} block
     (void)hipFree(s->d_gen);
     (void)hipFree(s->d_sched);
     (void)hipFree(s->d_chain);
     (void)hipFree(s->d_chain_logp);
     (void)hipFree(s->d_msum);
     (void)hipFree(s->d_msumsq);
-    (void)hipFree(s->d_klast);
     (void)hipFree(s->d_ring);
     (void)hipFree(s->d_isum);
     (void)hipFree(s->d_isumsq);

@@ -138,8 +138,18 @@ template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double v)
 {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    if constexpr (CTRL == 0x130) {                  // wave_shl: lane 63 has no source and keeps its own value
+        lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+        hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    } else {
+        // every lane has a source (quad_perm / row_mirror / row_ror / row_newbcast, all rows and banks enabled), so
+        // the "old" operand is never read: leave it undefined instead of paying a v_mov per word to initialise it
+        int ol, oh;
+        asm volatile("" : "=v"(ol));
+        asm volatile("" : "=v"(oh));
+        lo = __builtin_amdgcn_update_dpp(ol, lo, CTRL, 0xF, 0xF, false);
+        hi = __builtin_amdgcn_update_dpp(oh, hi, CTRL, 0xF, 0xF, false);
+    }
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double bperm_f64(int byte_addr, double v)

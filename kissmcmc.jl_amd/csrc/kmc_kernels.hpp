@@ -148,17 +148,20 @@ struct HalfStepFront {
     const SchedEntry* sched;      // this launch's schedule entry (sched_table + sched_index), or nullptr: eager launch, the
                                   //   entry travels in the args (sched_inline) and the step below
     const double2*    ring_now;   // draw ring, slot of THIS generation: entry of row r at ring_now[2 r] (nullptr: no ring)
-    uint32_t          gw0;        // = HalfStepArgs::gw0 (walker indices fit 31 bits)
-    int32_t           own_row0;   // = HalfStepArgs::own_row0; the complementary half starts at row
-    int32_t           n_active;   //   (1 - half) * (P2P ? n_active : nhalf)
+    double*           logp;       // = HalfStepArgs::logp, the head of the per-walker block {logp[nrows], naccept[nrows],
+                                  //   klast[nrows]} (one allocation): a walker's log-pdf and counters are requested at wave
+                                  //   entry, with its row, instead of one round trip after the argument struct has arrived
+    uint32_t          gw0;        // = HalfStepArgs::gw0 (walker indices fit 31 bits); own_row0 = P2P ? half * n_active : gw0
+    uint32_t          nact_half;  // n_active | half << 31; the complementary half starts at row (1 - half) * (P2P ? n_active : nhalf)
     uint32_t          seed_lo, seed_hi, nhalf;
-    int32_t           half;
     uint32_t          step;       // sched == nullptr (eager launch): 2 * generation + half, known at launch time (< 2^32)
+    __host__ __device__ int32_t n_active() const { return (int32_t)(nact_half & 0x7fffffffu); }
+    __host__ __device__ int32_t half() const { return (int32_t)(nact_half >> 31); }
 };                                // 14 dwords: all of it is preloaded (16 user SGPRs - 2 for the kernarg pointer)
-#define KMC_FRONT_PARAMS double* f_pos, const kmc::SchedEntry* f_sched, const double2* f_ring_now, uint32_t f_gw0, int32_t f_own_row0, \
-                         int32_t f_n_active, uint32_t f_seed_lo, uint32_t f_seed_hi, uint32_t f_nhalf, int32_t f_half, uint32_t f_step
-#define KMC_FRONT_PACK kmc::HalfStepFront{f_pos, f_sched, f_ring_now, f_gw0, f_own_row0, f_n_active, f_seed_lo, f_seed_hi, f_nhalf, f_half, f_step}
-#define KMC_FRONT_TYPES double*, const kmc::SchedEntry*, const double2*, uint32_t, int32_t, int32_t, uint32_t, uint32_t, uint32_t, int32_t, uint32_t
+#define KMC_FRONT_PARAMS double* f_pos, const kmc::SchedEntry* f_sched, const double2* f_ring_now, double* f_logp, uint32_t f_gw0, \
+                         uint32_t f_nact_half, uint32_t f_seed_lo, uint32_t f_seed_hi, uint32_t f_nhalf, uint32_t f_step
+#define KMC_FRONT_PACK kmc::HalfStepFront{f_pos, f_sched, f_ring_now, f_logp, f_gw0, f_nact_half, f_seed_lo, f_seed_hi, f_nhalf, f_step}
+#define KMC_FRONT_TYPES double*, const kmc::SchedEntry*, const double2*, double*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t
 
 // Graph replay: one scalar load of the whole 32-byte entry (s_load_dwordx8; the scalar cache is invalidated at
 // kernel start and the table is only written by advance_schedule between launches) -- one round trip, issued
@@ -395,7 +398,9 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
     const int g     = lane / L;
     const int gbase = lane & ~(L - 1);                  // first lane of this group
     const int w0    = (tid >> 6) * W;                   // first active index of this wave
-    const int nact  = f.n_active;
+    const int nact  = f.n_active();
+    const int half  = f.half();
+    const int64_t own_row0 = P2P ? (int64_t)half * nact : (int64_t)f.gw0;    // row of active walker 0 in pos / logp / naccept
     bool cv[K];                                         // chunk k of this lane lies inside the row
 #pragma unroll
     for (int k = 0; k < K; ++k) cv[k] = !RAGGED || 2 * (k * L + j) < (int)ld;
@@ -414,13 +419,13 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
     // (with the eager-form launches, where Philox starts at wave entry, it is worth +-2 %; it still pays +5 % under
     //  the table graph, e.g. for the P2P shards.  L = 64: slightly negative, off)
     constexpr bool kRing = Q >= 2 && L >= 16 && L <= 32;
-    const int64_t oth_row0 = (int64_t)(1 - f.half) * (int64_t)(P2P ? (uint32_t)f.n_active : f.nhalf);
+    const int64_t oth_row0 = (int64_t)(1 - half) * (int64_t)(P2P ? (uint32_t)nact : f.nhalf);
     const int  jq     = j / ITER, js = j - jq * ITER;
     const bool useA   = jq == 0;
     const int  iA     = w0 + (jq < Q ? js : 0) * G + g;
     const bool validA = useA && (iA < nact);
     const int      iAc = iA < nact ? iA : nact - 1;
-    const int64_t  rowA = (int64_t)f.own_row0 + iAc;                     // row in pos / index in logp, naccept
+    const int64_t  rowA = own_row0 + iAc;                                // row in pos / index in logp, naccept
     const bool ring_on = kRing && f.ring_now != nullptr;
     double2 e0 = zero2, e1 = zero2;                                     // this launch's parked draws, if any
     if constexpr (kRing) {
@@ -434,10 +439,18 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
     for (int it = 0; it < ITER; ++it) {
         const int i = w0 + it * G + g;
         validB[it] = i < nact;
-        const V2* own = reinterpret_cast<const V2*>(posT + ((int64_t)f.own_row0 + (validB[it] ? i : nact - 1)) * ld);
+        const V2* own = reinterpret_cast<const V2*>(posT + (own_row0 + (validB[it] ? i : nact - 1)) * ld);
 #pragma unroll
         for (int k = 0; k < K; ++k) xc[it][k] = cv[k] ? load_row(&own[k * L + j]) : zero2;
     }
+
+    // ---- the walker's log-pdf and counters: same block, addressed from the preloaded parameters alone -------------
+    const int64_t nrows_blk = 2 * (int64_t)(P2P ? (uint32_t)nact : f.nhalf);
+    uint32_t* const naccept_p = reinterpret_cast<uint32_t*>(f.logp + nrows_blk);
+    uint32_t* const klast_p = naccept_p + nrows_blk;
+    const double   p0 = f.logp[rowA];
+    const uint32_t na = naccept_p[rowA];
+    const uint32_t kl = klast_p[rowA];
 
     // ---- the step, then Philox: nothing here touches the argument struct.  Eager launch: the step is a preloaded
     //      parameter, so the partner index is known without any memory access; graph replay: one scalar round trip
@@ -445,7 +458,7 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
     const bool eager = f.sched == nullptr;
     SchedEntry sch_t{0, 0, 0u, 0u, {0u, 0u}};
     if (!eager) sch_t = schedule_entry(f);
-    const uint64_t step = eager ? (uint64_t)f.step : 2ull * (uint64_t)sch_t.gen + (uint64_t)f.half;
+    const uint64_t step = eager ? (uint64_t)f.step : 2ull * (uint64_t)sch_t.gen + (uint64_t)half;
     DrawConsts dcf{};                                                   // what Philox and the partner index need
     dcf.seed_lo = f.seed_lo; dcf.seed_hi = f.seed_hi; dcf.nhalf = f.nhalf;
     // parked draws are valid iff they carry this step's tag (wave-uniform decision)
@@ -500,8 +513,8 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
 
     // ---- from here on the argument struct: one scalar round trip for all of it (have every field the kernel
     //      uses later requested by now, otherwise the compiler fetches some lazily: a round trip each) ----------
-    asm volatile("" :: "s"(a.logp), "s"(a.naccept), "s"(a.chain), "s"(a.chain_logp), "s"(a.chain_rows), "s"(a.chain_row0),
-                 "s"(a.msum), "s"(a.msumsq), "s"(a.macc_stride), "s"(a.klast), "s"(a.sched_inline.gen), "s"(a.sched_inline.slot),
+    asm volatile("" :: "s"(a.chain), "s"(a.chain_logp), "s"(a.chain_rows), "s"(a.chain_row0),
+                 "s"(a.msum), "s"(a.msumsq), "s"(a.macc_stride), "s"(a.sched_inline.gen), "s"(a.sched_inline.slot),
                  "s"(a.sched_inline.flags), "s"(a.sched_inline.nbefore));
     // (the launch kind again, opaque to the optimiser: merged with the branch above it would pull the struct's first
     //  use -- and the wait for it -- in front of Philox)
@@ -538,9 +551,6 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
             }
         }
     }
-    const double   p0 = a.logp[rowA];
-    const uint32_t na = a.naccept[rowA];
-    const uint32_t kl = do_mom ? a.klast[rowA] : 0u;
     KMC_STAMP(1);
     Draw dr;
     dr.partner = partnerA; dr.z = e1.x; dr.t1 = e0.x; dr.lu = e0.y;
@@ -590,9 +600,9 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
     const bool acc = validA && accept_test(dr, myp1, p0);               // :260
     const unsigned long long accmask = __ballot(acc);
     if (acc) {
-        store_wt(&a.logp[rowA], myp1);                                  // :262
-        if (count) store_wt(&a.naccept[rowA], na + 1u);                 // :265
-        if (do_mom) store_wt(&a.klast[rowA], sch.nbefore);
+        store_wt(&f.logp[rowA], myp1);                                  // :262
+        if (count) store_wt(&naccept_p[rowA], na + 1u);                 // :265
+        if (do_mom) store_wt(&klast_p[rowA], sch.nbefore);
     }
     const uint32_t wA = (acc && do_mom) ? sch.nbefore - kl : 0u;        // samples the replaced value stood for
     const bool any_w = __ballot(wA != 0u) != 0ull;
@@ -607,12 +617,12 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
     for (int it = 0; it < ITER; ++it) {
         const bool accB = ((accmask >> (gbase + it)) & 1ull) != 0;
         if (accB) {                                                     // :261
-            V2* own = reinterpret_cast<V2*>(posT + ((int64_t)f.own_row0 + w0 + it * G + g) * ld);
+            V2* own = reinterpret_cast<V2*>(posT + (own_row0 + w0 + it * G + g) * ld);
 #pragma unroll
             for (int k = 0; k < K; ++k) if (cv[k]) store_row(&own[k * L + j], xo[it][k]);
             if constexpr (P2P) {
                 if (a.push) {                                           // ... and into this rank's shadow on every peer
-                    const int64_t off = (int64_t)(1 + a.me) * a.shard_stride + ((int64_t)f.own_row0 + w0 + it * G + g) * ld;
+                    const int64_t off = (int64_t)(1 + a.me) * a.shard_stride + (own_row0 + w0 + it * G + g) * ld;
                     for (int r = 0; r < a.nranks; ++r) {
                         if (r == a.me) continue;
                         double2* rem = reinterpret_cast<double2*>(a.peer_pos[r] + off);
@@ -662,7 +672,7 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
     }
     KMC_STAMP(3);
 #ifdef KMC_PROBE
-    if (lane == 0 && (tid >> 6) < 8192) for (int q = 0; q < 4; ++q) g_probe[f.half][tid >> 6][q] = stamp[q];
+    if (lane == 0 && (tid >> 6) < 8192) for (int q = 0; q < 4; ++q) g_probe[half][tid >> 6][q] = stamp[q];
 #endif
 }
 
