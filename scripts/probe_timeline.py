@@ -21,7 +21,7 @@ import kissmcmc_jl_amd as kmc
 from kissmcmc_jl_amd import _lib
 
 CONFIGS = {"C2": (kmc.GaussianIso(), 65536, 32), "C3": (kmc.Rosenbrock(), 16384, 64), "C5": (kmc.GaussianIso(), 8192, 1024),
-           "C4s": (kmc.GaussianIso(), 524288, 32)}
+           "C4s": (kmc.GaussianIso(), 524288, 32), "S8k": (kmc.GaussianIso(), 8192, 32)}    # S8k: one wave per CU
 
 
 def main():
