@@ -83,8 +83,8 @@ enum {
     KMC_F32 = 1  /* throughput option: walker rows and the stored chain are kept in IEEE single ON THE DEVICE (half the
                     row bytes); a proposal is rounded to single before its log-density is evaluated, so a stored row and
                     its log-pdf belong together; draws, log-densities, the accept test, counters and moments stay double,
-                    and so does every HOST buffer of this interface.  Built-in densities, one GPU (no KMC_P2P /
-                    KMC_ISLANDS / sharding / kmc_sampler_bind_positions). */
+                    and so does every HOST buffer of this interface.  Densities evaluated on the device (built-in or
+                    runtime-compiled), one GPU (no KMC_P2P / KMC_ISLANDS / sharding / kmc_sampler_bind_positions). */
 };
 
 /* kmc_config.flags */

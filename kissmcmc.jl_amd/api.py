@@ -42,7 +42,7 @@ def emcee(pdf, theta0s, niter: int = 10 ** 5, nburnin=None, nthin: int = 1, a_sc
           use_progress_meter: bool = True, hasblob: bool = False, init_blobs=None, reduce_blob=None,
           seed=None, device: int = 0, dtype: str = "f64"):
     """The affine-invariant ensemble sampler, on one MI355X.  ``dtype="f32"`` keeps the walkers in single
-    precision on the device (a throughput option, built-in densities; everything returned is still float64).
+    precision on the device (a throughput option, device densities; everything returned is still float64).
 
     Returns ``(thetas, accept_ratio, logdensities, blobs)`` like the reference
     (``src/samplers.jl:292``): ``thetas[w][k]`` is sample ``k`` of walker ``w``

@@ -325,12 +325,13 @@ std::string user_functor_source(const kmc_user_density* ud)
 }
 
 kmc_status compile_user(kmc_user_density* ud, bool with_vec, int L, int K, int iter, bool ragged,
-                        int resident_K, bool resident_ragged, int island_S, const std::vector<char>** out)
+                        int resident_K, bool resident_ragged, int island_S, bool f32, const std::vector<char>** out)
 {
     // resident_K also sizes the island kernel (same row striping: 2 lanes per walker, K chunks)
     char key[96];
-    std::snprintf(key, sizeof(key), "%d:%d,%d,%d,%d|%d,%d|%d", (int)with_vec, L, K, iter, (int)ragged, resident_K,
-                  (int)resident_ragged, island_S);
+    std::snprintf(key, sizeof(key), "%d:%d,%d,%d,%d|%d,%d|%d|%d", (int)with_vec, L, K, iter, (int)ragged, resident_K,
+                  (int)resident_ragged, island_S, (int)f32);
+    const char* rowt = f32 ? "float" : "double";       // storage type of the walker rows (KMC_F32 / KMC_F64)
     std::lock_guard<std::mutex> lock(ud->mu);
     auto it = ud->code.find(key);
     if (it != ud->code.end()) { *out = &it->second; return KMC_OK; }
@@ -345,12 +346,12 @@ kmc_status compile_user(kmc_user_density* ud, bool with_vec, int L, int K, int i
     std::ostringstream src;
     src << "#include \"kmc_islands.hpp\"\n" << user_functor_source(ud)
         << "using UD = kmc::TermPairDensity<UserF>;\n"
-        << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_generic(KMC_FRONT_PARAMS, const kmc::HalfStepArgs a) { kmc::half_step_generic_body<UD, false>(KMC_FRONT_PACK, a); }\n"
+        << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_generic(KMC_FRONT_PARAMS, const kmc::HalfStepArgs a) { kmc::half_step_generic_body<UD, false, " << rowt << ">(KMC_FRONT_PACK, a); }\n"
         << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_logpdf(const kmc::LogpdfArgs a) { kmc::logpdf_rows_body<UD>(a); }\n"
         << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_init_ball(const kmc::InitBallArgs a) { kmc::init_ball_body<UD>(a); }\n";
     if (with_vec)
         src << "extern \"C\" __global__ __launch_bounds__(" << vec_tpb(L) << ") void kmc_user_vec(KMC_FRONT_PARAMS, const kmc::HalfStepArgs a) { kmc::half_step_vec_body<UD, "
-            << L << ", " << K << ", " << iter << ", false, " << (ragged ? "true" : "false") << ">(KMC_FRONT_PACK, a); }\n";
+            << L << ", " << K << ", " << iter << ", false, " << (ragged ? "true" : "false") << ", " << rowt << ">(KMC_FRONT_PACK, a); }\n";
     if (resident_K > 0 && island_S == 0)
         src << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_resident(const kmc::ResidentArgs a) { kmc::resident_body<UD, "
             << resident_K << ", " << (resident_ragged ? "true" : "false") << ">(a); }\n";
@@ -385,10 +386,10 @@ kmc_status compile_user(kmc_user_density* ud, bool with_vec, int L, int K, int i
 }
 
 kmc_status load_user(kmc_user_density* ud, bool with_vec, int L, int K, int iter, bool ragged, UserKernels* uk,
-                     int resident_K = 0, bool resident_ragged = false, int island_S = 0)
+                     int resident_K = 0, bool resident_ragged = false, int island_S = 0, bool f32 = false)
 {
     const std::vector<char>* code = nullptr;
-    KMC_TRY(compile_user(ud, with_vec, L, K, iter, ragged, resident_K, resident_ragged, island_S, &code));
+    KMC_TRY(compile_user(ud, with_vec, L, K, iter, ragged, resident_K, resident_ragged, island_S, f32, &code));
     HIP_TRY(hipModuleLoadData(&uk->mod, code->data()));
     HIP_TRY(hipModuleGetFunction(&uk->generic, uk->mod, "kmc_user_generic"));
     HIP_TRY(hipModuleGetFunction(&uk->logpdf, uk->mod, "kmc_user_logpdf"));
@@ -419,7 +420,7 @@ KMC_EXPORT kmc_status kmc_user_density_create(const char* term_expr, const char*
     ud->has_pair = pair_expr != nullptr && pair_expr[0] != '\0';
     if (ud->has_pair) ud->pair = pair_expr;
     const std::vector<char>* code = nullptr;
-    const kmc_status st = compile_user(ud, false, 0, 0, 0, false, 0, false, 0, &code);   // syntax check now, not at first use
+    const kmc_status st = compile_user(ud, false, 0, 0, 0, false, 0, false, 0, false, &code);   // syntax check now, not at first use
     if (st != KMC_OK) { delete ud; return st; }
     *out = ud;
     return KMC_OK;
@@ -826,8 +827,8 @@ KMC_EXPORT kmc_status kmc_validate(const kmc_config* c)
     if (c->dtype == KMC_F32) {
         if ((c->flags & (KMC_P2P | KMC_ISLANDS)) || c->shard_count > 1)
             return fail(KMC_ERR_UNSUPPORTED, "KMC_F32 rows: one GPU, without KMC_P2P / KMC_ISLANDS / sharding");
-        if (c->density == KMC_USER_DENSITY || c->density == KMC_HOST_DENSITY)
-            return fail(KMC_ERR_UNSUPPORTED, "KMC_F32 rows: built-in densities only");
+        if (c->density == KMC_HOST_DENSITY)
+            return fail(KMC_ERR_UNSUPPORTED, "KMC_F32 rows: densities evaluated on the device only (built-in or runtime-compiled)");
     }
     if (c->host_accepted && c->density != KMC_HOST_DENSITY) return fail(KMC_ERR_BAD_ARG, "kmc_config.host_accepted needs KMC_HOST_DENSITY");
     if (c->density == KMC_ROSENBROCK && c->ndim < 2) return fail(KMC_ERR_BAD_ARG, "rosenbrock needs ndim >= 2");
@@ -895,7 +896,7 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         int rK = 0, rK0 = 1;
         while (2 * rK0 < s->ld / 2) rK0 *= 2;
         const size_t rlds = ((size_t)cfg->nwalkers * (size_t)(4 * (rK0 + 1)) + (size_t)cfg->nwalkers) * sizeof(double);
-        if (cfg->nwalkers <= 256 && cfg->ndim <= 32 && s->cfg.shard_count == 1 && !(cfg->flags & (KMC_P2P | KMC_NO_GRAPH | KMC_ISLANDS)) &&
+        if (!s->f32 && cfg->nwalkers <= 256 && cfg->ndim <= 32 && s->cfg.shard_count == 1 && !(cfg->flags & (KMC_P2P | KMC_NO_GRAPH | KMC_ISLANDS)) &&
             rlds <= 60 * 1024 && std::getenv("KMC_NO_RESIDENT") == nullptr)
             rK = rK0;
         int iS = 0;
@@ -904,7 +905,7 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
             rK = 1;
             while (2 * rK < s->ld / 2) rK *= 2;
         }
-        st = load_user(s->user, s->plan.vec, s->plan.L, s->plan.K, s->plan.ITER, s->plan.ragged, &s->uk, rK, 4 * rK != cfg->ndim, iS);
+        st = load_user(s->user, s->plan.vec, s->plan.L, s->plan.K, s->plan.ITER, s->plan.ragged, &s->uk, rK, 4 * rK != cfg->ndim, iS, s->f32);
         if (st != KMC_OK) { kmc_sampler_destroy(s); return st; }
         if (iS > 0) rK = 0;     // island mode is set up below, not resident mode
         if (rK > 0) {

@@ -121,8 +121,30 @@ def test_f32_is_refused_where_it_is_not_built(kmc):
     assert L.kmc_validate(C.byref(c)) == _lib.ERR_UNSUPPORTED
     c.shard_count, c.dtype = 1, 7
     assert L.kmc_validate(C.byref(c)) == _lib.ERR_UNSUPPORTED
-    with pytest.raises(_lib.KmcError):
-        kmc.Sampler(kmc.ExprDensity("-0.5*x*x"), 64, 4, 10, dtype="f32")
+    with pytest.raises(_lib.KmcError, match="evaluated on the device"):
+        kmc.Sampler(kmc.HostLogPdf(lambda x: 0.0), 64, 4, 10, dtype="f32")
     with kmc.Sampler(kmc.GaussianIso(), 64, 4, 10, dtype="f32") as s:
         with pytest.raises(_lib.KmcError, match="double rows"):
             s.bind_positions(1 << 20)
+
+
+@pytest.mark.parametrize("nw,nd,plan", [(256, 32, ""), (200, 5, ""), (256, 64, ""), (256, 32, "generic")])
+def test_f32_rows_with_runtime_compiled_densities(kmc, oracle, nw, nd, plan, monkeypatch):
+    """ExprDensity restating a menu density, float rows: the oracle's state_f32 chain of that density."""
+    if plan:
+        monkeypatch.setenv("KMC_PLAN", plan)
+    rosen = nd == 64
+    pdf = (kmc.ExprDensity("d < n-1 ? -((p[0]-x)*(p[0]-x))/p[2] : 0.0", "-(p[1]*((y-x*x)*(y-x*x)))/p[2]", [1.0, 100.0, 20.0])
+           if rosen else kmc.ExprDensity("-0.5*x*x"))
+    did, params = (oracle.ROSENBROCK, [1.0, 100.0, 20.0]) if rosen else (oracle.GAUSSIAN_ISO, [0.0, 1.0])
+    th = (0.1 if rosen else 1.0) * np.random.default_rng(nd).standard_normal((nw, nd))
+    G, nburn, seed = 80, 20, 7
+    ref = oracle.emcee(oracle.make_config(did, params, nw, nd, G, nburn, 1, 2.0, seed, state_f32=True), th)
+    with kmc.Sampler(pdf, nw, nd, G, nburn, 1, 2.0, seed, store_chain=True, store_logp=True, moments=True, dtype="f32") as s:
+        s.set_positions(th)
+        s.run(G)
+        s.sync()
+        got = dict(final_pos=s.positions(), final_logp=s.logp(), naccept=s.naccept(), accept_ratio=s.accept_ratio())
+        got["chain"], got["chain_logp"] = s.chain()
+        got["sum"], got["sumsq"], got["nmoment"] = s.moments()
+    _compare(ref, got)
