@@ -123,10 +123,13 @@ def emcee(pdf, theta0s, niter: int = 10 ** 5, nburnin=None, nthin: int = 1, a_sc
                 s.run(upto - done)
                 done = upto
                 s.sync()
-                na = s.naccept()
+                na = s.naccept().astype(np.float64)
                 nn = max(1, done - nburnin_walker if done > nburnin_walker else done)
+                macc, sacc = na.mean(), np.sqrt(na.var(ddof=1))          # :276-278
+                outl = int(np.sum(np.abs(na - macc) > 2 * sacc))
                 print(f"\remcee, niter={niter}, nwalkers={nwalkers}: generation {done}/{niter_walker} "
-                      f"accept_ratio_mean={na.mean() / nn:.3g} burnin_phase={done <= nburnin_walker}",
+                      f"accept_ratio_mean={macc / nn:.3g} accept_ratio_std={sacc / nn:.3g} "
+                      f"accept_ratio_outliers={outl} burnin_phase={done <= nburnin_walker}",      # :279-283
                       end="", file=sys.stderr)
             print(file=sys.stderr)
         else:

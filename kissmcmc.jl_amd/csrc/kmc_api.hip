@@ -1953,7 +1953,7 @@ MetropolisFn metropolis_fn(int density, int ndim)
     }
 }
 
-int metropolis_nd(int64_t ndim) { return ndim <= 1 ? 1 : ndim <= 2 ? 2 : ndim <= 4 ? 4 : ndim <= 8 ? 8 : ndim <= 16 ? 16 : 0; }
+int metropolis_nd(int64_t ndim) { return ndim <= 1 ? 1 : ndim <= 2 ? 2 : ndim <= 4 ? 4 : ndim <= 8 ? 8 : ndim <= 16 ? 16 : ndim <= 32 ? 32 : 0; }
 
 // runtime-compiled density: the Metropolis kernel (and the initial log-pdf kernel) for one register geometry
 kmc_status compile_user_metropolis(kmc_user_density* ud, int ND, const std::vector<char>** out)
@@ -2115,7 +2115,7 @@ KMC_EXPORT kmc_status kmc_metropolis_run(const kmc_metropolis_config* c, const d
         HIP_TRY(hipModuleGetFunction(&ufn, b.mod, "kmc_user_metropolis"));
         HIP_TRY(hipModuleGetFunction(&ulp, b.mod, "kmc_user_logpdf"));
     } else {
-        fn = metropolis_fn(c->density, (int)std::min<int64_t>(nd, 17));
+        fn = metropolis_fn(c->density, (int)std::min<int64_t>(nd, 1 << 20));    // the geometry follows ndim (registers <= 32)
         if (!fn) return fail(KMC_ERR_BAD_ARG, "unknown density id");
     }
     const unsigned grid = (unsigned)((nc + 255) / 256);

@@ -133,7 +133,7 @@ ResidentFn resident_lookup(int tpb, int K, bool ragged)
         }
     }
 }
-// many-chain Metropolis: the chain in registers up to 16 dimensions, in memory beyond
+// many-chain Metropolis: the chain in registers up to 32 dimensions, in memory beyond
 template <class D>
 MetropolisFn metropolis_lookup(int ndim)
 {
@@ -142,6 +142,7 @@ MetropolisFn metropolis_lookup(int ndim)
     if (ndim <= 4) return metropolis_chains<D, 4>;
     if (ndim <= 8) return metropolis_chains<D, 8>;
     if (ndim <= 16) return metropolis_chains<D, 16>;
+    if (ndim <= 32) return metropolis_chains<D, 32>;
     return metropolis_chains<D, 0>;
 }
 #endif  // KMC_TABLES_IMPL

@@ -15,7 +15,8 @@ CASES = [
     ("rosenbrock 2-D, step 0.5", lambda: kmc.Rosenbrock(), 2, 0.5, 0.0),
     ("gaussian 8-D, step 0.5", lambda: kmc.GaussianIso(), 8, 0.5, 0.0),
     ("gaussian 16-D, step 0.4", lambda: kmc.GaussianIso(), 16, 0.4, 0.0),
-    ("gaussian 32-D, step 0.3 (chain in memory)", lambda: kmc.GaussianIso(), 32, 0.3, 0.0),
+    ("gaussian 32-D, step 0.3", lambda: kmc.GaussianIso(), 32, 0.3, 0.0),
+    ("gaussian 64-D, step 0.2 (chain in memory)", lambda: kmc.GaussianIso(), 64, 0.2, 0.0),
 ]
 
 

@@ -34,9 +34,9 @@ def test_kernel_reproduces_metropolis_golden(kmc, name):
     np.testing.assert_array_equal(r["accept_ratio"], r["naccept"] / (z["niter"] - z["nburnin"]))    # samplers.jl:127
 
 
-@pytest.mark.parametrize("ndim", [1, 2, 3, 5, 8, 13, 16, 17, 40])
+@pytest.mark.parametrize("ndim", [1, 2, 3, 5, 8, 13, 16, 17, 32, 33, 40])
 def test_every_register_geometry_equals_the_oracle(kmc, oracle, ndim):
-    """ndim 1..16 run in registers (5 kernel geometries), beyond that from memory; odd sizes mask the tail."""
+    """ndim 1..32 run in registers (6 kernel geometries), beyond that from memory; odd sizes mask the tail."""
     from kissmcmc_jl_amd.metropolis import run_chains
     nc, niter, nburn, nthin, seed = 777, 70, 21, 3, 100 + ndim          # a ragged last workgroup
     th = 0.3 * np.random.default_rng(ndim).standard_normal((nc, ndim))
