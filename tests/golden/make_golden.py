@@ -2,7 +2,7 @@
 
 The reference (Julia) cannot run here and holds no golden vectors of its own,
 so these fixtures pin the *oracle's* seeded output: inputs + expected outputs only, no code.
-Re-run:  python tests/golden/make_golden.py
+Re-run:  python tests/golden/make_golden.py [--all]   (without --all only missing fixtures are written)
 """
 import os
 import sys
@@ -24,6 +24,10 @@ CASES = [
     ("rosen_256x64", oracle.ROSENBROCK, [1.0, 100.0, 20.0], 256, 64, 30, 10, 1, 2.0, 17, "small"),
     ("gauss_a35_128x8", oracle.GAUSSIAN_ISO, [0.0, 1.0], 128, 8, 60, 0, 1, 3.5, 18, "normal"),
     ("gauss_1040x1024", oracle.GAUSSIAN_ISO, [0.0, 1.0], 1040, 1024, 3, 1, 1, 2.0, 19, "hash"),
+    # float rows (KMC_F32 / the oracle's state_f32): names end in _f32
+    ("gauss_256x32_f32", oracle.GAUSSIAN_ISO, [0.0, 1.0], 256, 32, 40, 10, 2, 2.0, 21, "normal"),
+    ("rosen_256x64_f32", oracle.ROSENBROCK, [1.0, 100.0, 20.0], 256, 64, 30, 10, 1, 2.0, 22, "small"),
+    ("expo_100x1_f32", oracle.EXPONENTIAL, [1.0], 100, 1, 200, 100, 1, 2.0, 23, "positive"),
 ]
 
 
@@ -47,8 +51,10 @@ def theta0(kind, nw, nd, seed):
 
 def main():
     for name, did, params, nw, nd, G, nburn, nthin, a, seed, init in CASES:
+        if os.path.exists(os.path.join(HERE, name + ".npz")) and "--all" not in sys.argv:
+            continue                                   # existing fixtures are rewritten only on request
         th = theta0(init, nw, nd, seed)
-        cfg = oracle.make_config(did, params, nw, nd, G, nburn, nthin, a, seed)
+        cfg = oracle.make_config(did, params, nw, nd, G, nburn, nthin, a, seed, state_f32=name.endswith("_f32"))
         r = oracle.emcee(cfg, th)
         assert r["status"] == 0
         big = init == "hash"

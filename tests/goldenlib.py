@@ -27,6 +27,7 @@ def load(name):
         z[k] = int(z[k])
     z["a_scale"] = float(z["a_scale"])
     z["init"] = str(z["init"])
+    z["f32"] = name.endswith("_f32")      # float rows: KMC_F32 on the device, state_f32 in the oracle
     if "theta0" not in z:   # formula-defined input (big case)
         z["theta0"] = _make_golden().theta0(z["init"], z["nwalkers"], z["ndim"], z["seed"])
     return z

@@ -9,7 +9,7 @@ import goldenlib
 def test_oracle_reproduces_golden(oracle, name):
     z = goldenlib.load(name)
     cfg = oracle.make_config(z["density"], list(z["params"]), z["nwalkers"], z["ndim"], z["G"], z["nburnin"],
-                             z["nthin"], z["a_scale"], z["seed"])
+                             z["nthin"], z["a_scale"], z["seed"], state_f32=z["f32"])
     r = oracle.emcee(cfg, z["theta0"])
     assert r["status"] == 0
     goldenlib.compare(z, r["final_pos"], r["final_logp"], r["naccept"], r["sum"], r["sumsq"], r["nmoment"],

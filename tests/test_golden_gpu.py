@@ -17,7 +17,7 @@ def test_sampler_reproduces_golden(kmc, name):
     z = goldenlib.load(name)
     pdf = _DENS[z["density"]](kmc, z["params"])
     with kmc.Sampler(pdf, z["nwalkers"], z["ndim"], z["G"], z["nburnin"], z["nthin"], z["a_scale"], z["seed"],
-                     store_chain=True, store_logp=True, moments=True) as s:
+                     store_chain=True, store_logp=True, moments=True, dtype="f32" if z["f32"] else "f64") as s:
         s.set_positions(z["theta0"])
         s.run(z["G"])
         s.sync()
@@ -26,7 +26,7 @@ def test_sampler_reproduces_golden(kmc, name):
         goldenlib.compare(z, s.positions(), s.logp(), s.naccept(), msum, msq, n, chain, chain_logp)
 
 
-@pytest.mark.parametrize("name", ["gauss_64x4", "expo_100x1_readme", "rosen_256x64"])
+@pytest.mark.parametrize("name", ["gauss_64x4", "expo_100x1_readme", "rosen_256x64", "rosen_256x64_f32"])
 def test_one_shot_c_abi_reproduces_golden(kmc, name):
     """kmc_emcee_run with caller-owned host buffers (the entry point a ccall binding uses)."""
     from kissmcmc_jl_amd import _lib
@@ -34,7 +34,7 @@ def test_one_shot_c_abi_reproduces_golden(kmc, name):
     nw, nd = z["nwalkers"], z["ndim"]
     ns = (z["G"] - z["nburnin"]) // z["nthin"]
     cfg = _lib.Config()
-    cfg.dtype, cfg.density = _lib.F64, z["density"]
+    cfg.dtype, cfg.density = (_lib.F32 if z["f32"] else _lib.F64), z["density"]
     for i, v in enumerate(z["params"]):
         cfg.params[i] = float(v)
     cfg.nwalkers, cfg.ndim, cfg.ngenerations, cfg.nburnin, cfg.nthin = nw, nd, z["G"], z["nburnin"], z["nthin"]
