@@ -200,11 +200,13 @@ Plan make_plan(const kmc_config& c, int64_t n_active)
         else if (chunks <= 256) { L = 64; K = 4; }
         else if (chunks <= 512) { L = 64; K = 8; }
         // walkers per group (ITER): two amortise the per-walker scalar work (Philox, two logs) over
-        // the wave; more only while the grid keeps >= 4096 waves (large ensembles)
+        // the wave -- once that still leaves 1.5 waves per SIMD (measured: 2048 single-walker waves run 3-6 % faster
+        // as they are, C3 and 32 768 x 32; 3072 and more are faster paired); more only while the grid keeps >= 4096
+        // waves (large ensembles)
         iter = 1;
         if (L > 0) {
             const int64_t waves1 = n_active * L / 64;
-            if (2 <= L && 2 * K <= 16 && waves1 / 2 >= 1024) iter = 2;
+            if (2 <= L && 2 * K <= 16 && waves1 >= 3072) iter = 2;
             while (iter >= 2 && iter * 2 <= L && iter * 2 * K <= 16 && waves1 / (iter * 2) >= 4096 && iter < 16) iter *= 2;
         }
     }

@@ -17,6 +17,8 @@ CONFIGS = {
     "C5": (kmc.GaussianIso(), 8192, 1024, 256),
     "C1": (kmc.Exponential(), 100, 1, 1024),
     "C4s": (kmc.GaussianIso(), 524288, 32, 128),     # one GPU doing the whole 8-GPU ensemble
+    "S32k": (kmc.GaussianIso(), 32768, 32, 1024),
+    "S24k64": (kmc.GaussianIso(), 24576, 64, 1024),
 }
 
 
