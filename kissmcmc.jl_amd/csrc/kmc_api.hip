@@ -454,6 +454,12 @@ struct kmc_sampler {
     double* d_chain_logp = nullptr;
     double* d_msum = nullptr;
     double* d_msumsq = nullptr;
+    double2* d_mring = nullptr;       // moment ring (HalfStepArgs::mring): [waves][mring_depth][K][64] rows
+    double* d_mring_w = nullptr;      //   and [waves][mring_depth] weights
+    uint32_t* d_mcnt = nullptr;       // [waves] entries posted, then [waves] entries swept (one allocation)
+    int mring_depth = 0;
+    int64_t mring_waves = 0;
+    int64_t gens_since_sweep = 0;
     uint32_t* d_klast = nullptr;      // vec kernels: samples already credited per walker (d_logp, d_naccept, d_klast: one block)
     double2* d_ring = nullptr;        // vec kernels: parked draws of the walkers' next steps, [4][nrows] x 32 B (HalfStepArgs::ring)
     int64_t macc_stride = 0, macc_elems = 0;
@@ -559,6 +565,11 @@ HalfStepArgs make_args(const kmc_sampler* s, int half, bool graph_mode, int64_t 
     a.msumsq = s->d_msumsq;
     a.macc_stride = s->macc_stride;
     a.klast = s->d_klast;
+    a.mring = s->d_mring;
+    a.mring_w = s->d_mring_w;
+    a.mcnt = s->d_mcnt;
+    a.mswept = s->d_mcnt ? s->d_mcnt + s->mring_waves : nullptr;
+    a.mring_depth = s->mring_depth;
     a.ring = s->d_ring;
     a.ring_rows = s->nrows;
     a.ring_slot = (int32_t)(gen_offset & 3);
@@ -618,6 +629,22 @@ hipError_t launch_half_kernel(const kmc_sampler* s, const HalfStepArgs& a)
     }
     hipLaunchKernelGGL(s->plan.fn, dim3(s->grid), dim3(s->tpb), 0, s->stream, f.pos, f.sched, f.ring_now, f.logp, f.gw0, f.nact_half,
                        f.seed_lo, f.seed_hi, f.nhalf, f.step, a);
+    return hipGetLastError();
+}
+
+// Fold the moment ring's posted entries into the accumulators (between graph chunks / before a read-out).
+constexpr int64_t kSweepEvery = 64;        // generations between sweeps of eager launches (a graph chunk is 64 too)
+hipError_t launch_sweep(kmc_sampler* s)
+{
+    s->gens_since_sweep = 0;
+    if (!s->d_mring) return hipSuccess;
+    SweepArgs a{};
+    a.ring = s->d_mring; a.ring_w = s->d_mring_w; a.cnt = s->d_mcnt; a.swept = s->d_mcnt + s->mring_waves;
+    a.msum = s->d_msum; a.msumsq = s->d_msumsq; a.macc_stride = s->macc_stride;
+    a.K = s->plan.K; a.depth = s->mring_depth;
+    hipLaunchKernelGGL(moments_sweep, dim3((unsigned)(s->mring_waves * s->plan.K)), dim3(64), 0, s->stream, a);
+    hipLaunchKernelGGL(moments_swept, dim3((unsigned)((s->mring_waves + 255) / 256)), dim3(256), 0, s->stream,
+                       s->d_mcnt, s->d_mcnt + s->mring_waves, s->mring_waves);
     return hipGetLastError();
 }
 
@@ -1037,6 +1064,23 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         CREATE_TRY(hipMalloc(&s->d_msumsq, (size_t)s->macc_elems * sizeof(double)));
         CREATE_TRY(hipMemset(s->d_msum, 0, (size_t)s->macc_elems * sizeof(double)));
         CREATE_TRY(hipMemset(s->d_msumsq, 0, (size_t)s->macc_elems * sizeof(double)));
+        if (s->plan.vec && s->plan.L == 64 && s->plan.K > 2 && !s->islands && !s->resident && std::getenv("KMC_NO_MOMENT_RING") == nullptr) {
+            // moment ring for long rows (kmc_kernels.hpp, HalfStepArgs::mring): up to 32 posted entries per wave,
+            // within 1 GiB in all; swept every kSweepEvery generations
+            const int64_t nwaves = s->macc_stride / 64;
+            const size_t slot = (size_t)s->plan.K * 64 * sizeof(double2);       // one row
+            int64_t depth = (int64_t)(((size_t)1 << 30) / ((size_t)nwaves * slot));
+            if (depth > 32) depth = 32;
+            if (const char* e = std::getenv("KMC_MOMENT_RING_DEPTH")) { const long v = std::atol(e); if (v >= 1 && v < depth) depth = v; }   // tests: force overflows
+            if (depth >= 4 || (depth >= 2 && std::getenv("KMC_MOMENT_RING_DEPTH") != nullptr)) {
+                CREATE_TRY(hipMalloc((void**)&s->d_mring, (size_t)nwaves * (size_t)depth * slot));
+                CREATE_TRY(hipMalloc((void**)&s->d_mring_w, (size_t)nwaves * (size_t)depth * sizeof(double)));
+                CREATE_TRY(hipMalloc((void**)&s->d_mcnt, 2 * (size_t)nwaves * sizeof(uint32_t)));
+                CREATE_TRY(hipMemset(s->d_mcnt, 0, 2 * (size_t)nwaves * sizeof(uint32_t)));
+                s->mring_depth = (int)depth;
+                s->mring_waves = nwaves;
+            }
+        }
         if (s->islands || s->resident) {
             const size_t ne = (size_t)s->nislands * 4 * (size_t)s->island_K;
             CREATE_TRY(hipMalloc(&s->d_isum, ne * sizeof(double)));
@@ -1096,6 +1140,9 @@ KMC_EXPORT void kmc_sampler_destroy(kmc_sampler* s)
     }
     if (s->own_pos) (void)hipFree(s->d_pos);
     (void)hipFree(s->d_logp);          // the {logp, naccept, klast} block
+    (void)hipFree(s->d_mring);
+    (void)hipFree(s->d_mring_w);
+    (void)hipFree(s->d_mcnt);
     (void)hipFree(s->d_gen);
     (void)hipFree(s->d_sched);
     (void)hipFree(s->d_chain);
@@ -1238,6 +1285,7 @@ kmc_status reset_run_state(kmc_sampler* s, bool eval_logp, int64_t generation, u
         HIP_TRY(hipMemsetAsync(s->d_msum, 0, (size_t)s->macc_elems * sizeof(double), s->stream));
         HIP_TRY(hipMemsetAsync(s->d_msumsq, 0, (size_t)s->macc_elems * sizeof(double), s->stream));
         if (s->d_klast) HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)s->d_klast, (int)klast_value, nw, s->stream));
+        if (s->d_mcnt) HIP_TRY(hipMemsetAsync(s->d_mcnt, 0, 2 * (size_t)s->mring_waves * sizeof(uint32_t), s->stream));
         if (s->d_isum) {
             const size_t ne = (size_t)s->nislands * 4 * (size_t)s->island_K;
             HIP_TRY(hipMemsetAsync(s->d_isum, 0, ne * sizeof(double), s->stream));
@@ -1400,6 +1448,7 @@ KMC_EXPORT kmc_status kmc_sampler_set_positions(kmc_sampler* s, const double* th
         HIP_TRY(hipMemsetAsync(s->d_msum, 0, (size_t)s->macc_elems * sizeof(double), s->stream));
         HIP_TRY(hipMemsetAsync(s->d_msumsq, 0, (size_t)s->macc_elems * sizeof(double), s->stream));
         if (s->d_klast) HIP_TRY(hipMemsetAsync(s->d_klast, 0, nw * sizeof(uint32_t), s->stream));
+        if (s->d_mcnt) HIP_TRY(hipMemsetAsync(s->d_mcnt, 0, 2 * (size_t)s->mring_waves * sizeof(uint32_t), s->stream));
         if (s->d_isum) {
             const size_t ne = (size_t)s->nislands * 4 * (size_t)s->island_K;
             HIP_TRY(hipMemsetAsync(s->d_isum, 0, ne * sizeof(double), s->stream));
@@ -1537,6 +1586,7 @@ KMC_EXPORT kmc_status kmc_sampler_run(kmc_sampler* s, int64_t ngen)
         KMC_TRY(ensure_graph(s));
         KMC_TRY(sync_device_counter(s));
         HIP_TRY(hipGraphLaunch(s->graph_exec, s->stream));
+        HIP_TRY(launch_sweep(s));
         s->generation += kGraphChunk;
         s->dev_gen += kGraphChunk;
         s->launches += 2 * kGraphChunk;
@@ -1548,6 +1598,7 @@ KMC_EXPORT kmc_status kmc_sampler_run(kmc_sampler* s, int64_t ngen)
             for (int half = 0; half < 2; ++half) KMC_TRY(launch_half(s, half, false, s->generation));
             s->generation += 1;
             s->launches += 2;
+            if (++s->gens_since_sweep >= kSweepEvery) HIP_TRY(launch_sweep(s));
         }
         return KMC_OK;
     };
@@ -1556,6 +1607,7 @@ KMC_EXPORT kmc_status kmc_sampler_run(kmc_sampler* s, int64_t ngen)
             s->launch_mode = 1;
             return graph_chunk();
         }
+        HIP_TRY(launch_sweep(s));
         s->generation += s->uchunk;
         s->launches += 2 * s->uchunk;
         ngen -= s->uchunk;
@@ -1626,7 +1678,10 @@ KMC_EXPORT kmc_status kmc_sampler_half_step(kmc_sampler* s, int half)
     HIP_TRY(hipSetDevice(s->cfg.device));
     KMC_TRY(launch_half(s, half, false, s->generation));
     s->launches += 1;
-    if (half == 1) s->generation += 1;
+    if (half == 1) {
+        s->generation += 1;
+        if (++s->gens_since_sweep >= kSweepEvery) HIP_TRY(launch_sweep(s));
+    }
     return KMC_OK;
 }
 
@@ -1770,6 +1825,7 @@ KMC_EXPORT kmc_status kmc_sampler_get_moments(kmc_sampler* s, double* sum, doubl
         if (n) *n = (samples_done(s) - s->moment_base) * s->nlocal;
         return KMC_OK;
     }
+    HIP_TRY(launch_sweep(s));                                   // posted ring entries first, in their order
     if (s->plan.vec) {
         // sojourn-weighted accumulation: credit every walker's current value up to now
         FlushFn fl = flush_lookup(s->plan.L, s->plan.K, s->plan.ITER, s->f32);

@@ -136,6 +136,17 @@ struct HalfStepArgs {
     double*           prop_out;     // PROPOSE pass: proposals [n_active][ld]; nothing else is touched
     const double*     p1_in;        // ACCEPT pass: log-pdf of proposal i as evaluated by the host
     unsigned char*    acc_out;      // ACCEPT pass, optional: 1 where proposal i replaced its walker (:261), else 0
+    // moment ring (long rows: K > 2, L == 64, where the accumulators are NOT prefetched): a wave with an accepted move
+    // POSTS the replaced row and its weight into its next ring slot instead of reading, adding to and rewriting its
+    // accumulator slots -- in a bandwidth-saturated launch a dependent round trip issued at the end of a wave queues
+    // behind everybody's row loads (C5: the 4-8 % of waves that accept ended ~3 us after the rest).  moments_sweep
+    // folds the posted entries into msum / msumsq between graph chunks, in order.  Entries posted / folded so far are
+    // counted per wave (mcnt / mswept, read at wave entry); a ring without room falls back to the read-modify-write.
+    double2*          mring;        // [waves][mring_depth][K][64]: the replaced row as the lanes hold it, or nullptr
+    double*           mring_w;      // [waves][mring_depth]: its weight (samples it stood for)
+    uint32_t*         mcnt;         // [waves]
+    const uint32_t*   mswept;       // [waves]
+    int32_t           mring_depth;
 };
 
 // The fields a wave needs before it can issue its first loads travel as LEADING SCALAR kernel parameters, ahead
@@ -534,6 +545,8 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
     // small rows: nearly every wave has an accepted move, so fetch its accumulator slots now and
     // keep that latency off the kernel's tail; large rows: fetch only when needed
     constexpr bool kPrefetchAcc = K <= 2;
+    constexpr bool kMomRing = !kPrefetchAcc && !FoldT<L, K>::on && L == 64;          // HalfStepArgs::mring
+    if constexpr (kMomRing) asm volatile("" :: "s"(a.mring), "s"(a.mring_w), "s"(a.mcnt), "s"(a.mswept), "s"(a.mring_depth));
     double2 accs[K], accq[K];
     double  acct[4] = {0.0, 0.0, 0.0, 0.0};
     if constexpr (FoldT<L, K>::on) {
@@ -550,6 +563,10 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
                 accq[k] = reinterpret_cast<const double2*>(a.msumsq)[idx];
             }
         }
+    }
+    uint32_t ring_posted = 0u, ring_swept = 0u;
+    if constexpr (kMomRing) {
+        if (do_mom && a.mring != nullptr) { ring_posted = a.mcnt[tid >> 6]; ring_swept = a.mswept[tid >> 6]; }
     }
     KMC_STAMP(1);
     Draw dr;
@@ -613,6 +630,9 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
     double2 ms[K], mq[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) { ms[k] = make_double2(0.0, 0.0); mq[k] = make_double2(0.0, 0.0); }
+    // room for one entry per walker of the wave? (wave-uniform; kMomRing geometries have one group per wave)
+    const bool use_ring = kMomRing && a.mring != nullptr && ring_posted - ring_swept + (uint32_t)ITER <= (uint32_t)a.mring_depth;
+    uint32_t ring_new = 0u;
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
         const bool accB = ((accmask >> (gbase + it)) & 1ull) != 0;
@@ -634,10 +654,21 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
         }
         if (any_w) {
             const double wB = (double)(uint32_t)__builtin_amdgcn_ds_bpermute((gbase + it) * 4, (int)wA);
+            if (use_ring) {
+                if (wB != 0.0) {                                          // wave-uniform (L == 64: one group)
+                    const int64_t e = (int64_t)(tid >> 6) * a.mring_depth + (int64_t)((ring_posted + ring_new) % (uint32_t)a.mring_depth);
+                    double2* slot = a.mring + e * K * 64 + lane;
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
-                ms[k].x += xc[it][k].x * wB; ms[k].y += xc[it][k].y * wB;
-                mq[k].x += (xc[it][k].x * xc[it][k].x) * wB; mq[k].y += (xc[it][k].y * xc[it][k].y) * wB;
+                    for (int k = 0; k < K; ++k) slot[k * 64] = xc[it][k];
+                    if (lane == 0) a.mring_w[e] = wB;
+                    ring_new += 1u;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    ms[k].x += xc[it][k].x * wB; ms[k].y += xc[it][k].y * wB;
+                    mq[k].x += (xc[it][k].x * xc[it][k].x) * wB; mq[k].y += (xc[it][k].y * xc[it][k].y) * wB;
+                }
             }
         }
         if (sample && a.chain != nullptr && validB[it]) {               // :268-269
@@ -647,8 +678,12 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
         }
     }
     if (any_w) {
-        if constexpr (kPrefetchAcc) accumulate_wave<L, K, true>(a.msum, a.msumsq, a.macc_stride, tid, g, ms, mq, accs, accq, acct);
-        else accumulate_wave<L, K, false>(a.msum, a.msumsq, a.macc_stride, tid, g, ms, mq, accs, accq, acct);
+        if (use_ring) {
+            if (lane == 0) a.mcnt[tid >> 6] = ring_posted + ring_new;
+        } else {
+            if constexpr (kPrefetchAcc) accumulate_wave<L, K, true>(a.msum, a.msumsq, a.macc_stride, tid, g, ms, mq, accs, accq, acct);
+            else accumulate_wave<L, K, false>(a.msum, a.msumsq, a.macc_stride, tid, g, ms, mq, accs, accq, acct);
+        }
     }
     if constexpr (P2P) {
         // KMC_P2P_FOLD_SIGNAL: every store above is write-through, so once a workgroup's stores have drained they are
@@ -917,7 +952,48 @@ __global__ __launch_bounds__(256) void init_ball(const InitBallArgs a)
     init_ball_body<Dens>(a);
 }
 
+// Folds the moment ring's posted entries into the accumulators, oldest first (one 64-lane workgroup per wave of the
+// half-step grid; same slot mapping as accumulate_wave's plain form: slot k of global thread t at [k * stride + t]).
+struct SweepArgs {
+    const double2* ring;
+    const double*  ring_w;
+    const uint32_t* cnt;
+    uint32_t*      swept;
+    double*        msum;
+    double*        msumsq;
+    int64_t        macc_stride;
+    int32_t        K, depth;
+};
+
 #ifdef KMC_DEFINE_DRIVER_KERNELS   // non-template kernels: defined once, in kmc_api.hip
+// one 64-lane workgroup per (wave of the half-step grid, chunk k): sum += x w, sumsq += x^2 w over the wave's posted rows
+__global__ __launch_bounds__(64) void moments_sweep(const SweepArgs a)
+{
+    const int64_t wave = blockIdx.x / a.K;
+    const int k = (int)(blockIdx.x - wave * a.K);
+    const int lane = threadIdx.x;
+    const uint32_t c = a.cnt[wave], sw = a.swept[wave];
+    if (c == sw) return;
+    double2* s = reinterpret_cast<double2*>(a.msum) + (int64_t)k * a.macc_stride + wave * 64 + lane;
+    double2* q = reinterpret_cast<double2*>(a.msumsq) + (int64_t)k * a.macc_stride + wave * 64 + lane;
+    double2 sv = *s, qv = *q;
+    for (uint32_t e = sw; e != c; ++e) {
+        const int64_t slot = wave * a.depth + (int64_t)(e % (uint32_t)a.depth);
+        const double w = a.ring_w[slot];
+        const double2 x = a.ring[(slot * a.K + k) * 64 + lane];
+        sv.x += x.x * w; sv.y += x.y * w;
+        qv.x += (x.x * x.x) * w; qv.y += (x.y * x.y) * w;
+    }
+    *s = sv;
+    *q = qv;
+}
+// after moments_sweep: everything posted has been folded
+__global__ __launch_bounds__(256) void moments_swept(const uint32_t* cnt, uint32_t* swept, int64_t nwaves)
+{
+    const int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (w < nwaves) swept[w] = cnt[w];
+}
+
 __global__ void p2p_signal(const SignalArgs a)
 {
     const SchedEntry sch = a.sched_index >= 0 ? a.sched_table[a.sched_index] : a.sched_inline;

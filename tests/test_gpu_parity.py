@@ -223,3 +223,35 @@ def test_launch_modes_are_the_same_sampler(kmc, oracle, mode, monkeypatch):
         assert "parameter updates" in how
     if mode == "eager":
         assert "eager" in how
+
+
+@pytest.mark.parametrize("depth", [None, 2, "off"])
+def test_moment_ring_of_long_rows(kmc, oracle, depth, monkeypatch):
+    """ndim > 256: waves with an accepted move post the replaced row into a per-wave ring and moments_sweep folds the
+    entries between graph chunks (HalfStepArgs::mring).  Same sums with the default depth, with a two-entry ring that
+    overflows into the read-modify-write path all the time, and without the ring; 200 generations cross three graph
+    chunks, an eager tail and a read-out in the middle."""
+    if depth == "off":
+        monkeypatch.setenv("KMC_NO_MOMENT_RING", "1")
+    elif depth is not None:
+        monkeypatch.setenv("KMC_MOMENT_RING_DEPTH", str(depth))
+    nw, nd, G, nburn, nthin, seed = 1040, 600, 200, 20, 1, 5
+    th = np.random.default_rng(3).standard_normal((nw, nd))
+    with kmc.Sampler(kmc.GaussianIso(), nw, nd, G, nburn, nthin, 2.0, seed, moments=True) as s:
+        s.set_positions(th)
+        s.run(130)
+        s.sync()
+        mid = s.moments()
+        s.run(70)
+        s.sync()
+        msum, msq, n = s.moments()
+        nacc = s.naccept()
+    cfg = lambda g: oracle.make_config(oracle.GAUSSIAN_ISO, [0.0, 1.0], nw, nd, g, nburn, nthin, 2.0, seed, nthreads=8)
+    ref_mid = oracle.emcee(cfg(130), th, store_chain=False)
+    ref = oracle.emcee(cfg(G), th, store_chain=False)
+    np.testing.assert_array_equal(nacc, ref["naccept"])
+    assert mid[2] == ref_mid["nmoment"] and n == ref["nmoment"]
+    np.testing.assert_allclose(mid[0], ref_mid["sum"], rtol=1e-11, atol=1e-9)
+    np.testing.assert_allclose(mid[1], ref_mid["sumsq"], rtol=1e-11, atol=1e-9)
+    np.testing.assert_allclose(msum, ref["sum"], rtol=1e-11, atol=1e-9)
+    np.testing.assert_allclose(msq, ref["sumsq"], rtol=1e-11, atol=1e-9)
