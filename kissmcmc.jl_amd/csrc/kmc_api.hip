@@ -1064,13 +1064,13 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         CREATE_TRY(hipMalloc(&s->d_msumsq, (size_t)s->macc_elems * sizeof(double)));
         CREATE_TRY(hipMemset(s->d_msum, 0, (size_t)s->macc_elems * sizeof(double)));
         CREATE_TRY(hipMemset(s->d_msumsq, 0, (size_t)s->macc_elems * sizeof(double)));
-        if (s->plan.vec && s->plan.L == 64 && s->plan.K > 2 && !s->islands && !s->resident && std::getenv("KMC_NO_MOMENT_RING") == nullptr) {
-            // moment ring for long rows (kmc_kernels.hpp, HalfStepArgs::mring): up to 32 posted entries per wave,
-            // within 1 GiB in all; swept every kSweepEvery generations
+        if (s->plan.vec && s->plan.L == 64 && !s->islands && !s->resident && std::getenv("KMC_NO_MOMENT_RING") == nullptr) {
+            // moment ring for long rows (kmc_kernels.hpp, HalfStepArgs::mring): up to 128 posted rows per wave,
+            // within 512 MiB in all; swept every kSweepEvery generations
             const int64_t nwaves = s->macc_stride / 64;
             const size_t slot = (size_t)s->plan.K * 64 * sizeof(double2);       // one row
-            int64_t depth = (int64_t)(((size_t)1 << 30) / ((size_t)nwaves * slot));
-            if (depth > 32) depth = 32;
+            int64_t depth = (int64_t)(((size_t)1 << 29) / ((size_t)nwaves * slot));
+            if (depth > 128) depth = 128;
             if (const char* e = std::getenv("KMC_MOMENT_RING_DEPTH")) { const long v = std::atol(e); if (v >= 1 && v < depth) depth = v; }   // tests: force overflows
             if (depth >= 4 || (depth >= 2 && std::getenv("KMC_MOMENT_RING_DEPTH") != nullptr)) {
                 CREATE_TRY(hipMalloc((void**)&s->d_mring, (size_t)nwaves * (size_t)depth * slot));

@@ -136,7 +136,7 @@ struct HalfStepArgs {
     double*           prop_out;     // PROPOSE pass: proposals [n_active][ld]; nothing else is touched
     const double*     p1_in;        // ACCEPT pass: log-pdf of proposal i as evaluated by the host
     unsigned char*    acc_out;      // ACCEPT pass, optional: 1 where proposal i replaced its walker (:261), else 0
-    // moment ring (long rows: K > 2, L == 64, where the accumulators are NOT prefetched): a wave with an accepted move
+    // moment ring (long rows: L == 64, ndim > 128, where the accumulators are NOT prefetched): a wave with an accepted move
     // POSTS the replaced row and its weight into its next ring slot instead of reading, adding to and rewriting its
     // accumulator slots -- in a bandwidth-saturated launch a dependent round trip issued at the end of a wave queues
     // behind everybody's row loads (C5: the 4-8 % of waves that accept ended ~3 us after the rest).  moments_sweep
@@ -544,7 +544,7 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
     const bool do_mom = count && a.msum != nullptr;
     // small rows: nearly every wave has an accepted move, so fetch its accumulator slots now and
     // keep that latency off the kernel's tail; large rows: fetch only when needed
-    constexpr bool kPrefetchAcc = K <= 2;
+    constexpr bool kPrefetchAcc = K <= 2 && L != 64;                   // L == 64: the moment ring instead (below)
     constexpr bool kMomRing = !kPrefetchAcc && !FoldT<L, K>::on && L == 64;          // HalfStepArgs::mring
     if constexpr (kMomRing) asm volatile("" :: "s"(a.mring), "s"(a.mring_w), "s"(a.mcnt), "s"(a.mswept), "s"(a.mring_depth));
     double2 accs[K], accq[K];

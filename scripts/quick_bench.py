@@ -18,6 +18,9 @@ CONFIGS = {
     "C1": (kmc.Exponential(), 100, 1, 1024),
     "C4s": (kmc.GaussianIso(), 524288, 32, 128),     # one GPU doing the whole 8-GPU ensemble
     "S32k": (kmc.GaussianIso(), 32768, 32, 1024),
+    "W128": (kmc.GaussianIso(), 65536, 128, 256),
+    "W256": (kmc.GaussianIso(), 32768, 256, 256),
+    "W512": (kmc.GaussianIso(), 16384, 512, 256),
     "S24k64": (kmc.GaussianIso(), 24576, 64, 1024),
 }
 
