@@ -115,37 +115,45 @@ def emcee(pdf, theta0s, niter: int = 10 ** 5, nburnin=None, nthin: int = 1, a_sc
                         reduce_blob(blobs[w], blob0s[w])       # :270
 
             pdf.on_accepted = on_accepted
-        if use_progress_meter and niter_walker > 0:
-            nchunks = min(20, niter_walker)
-            done = 0
-            for c in range(nchunks):
-                upto = (niter_walker * (c + 1)) // nchunks
-                s.run(upto - done)
-                done = upto
-                s.sync()
-                na = s.naccept().astype(np.float64)
-                nn = max(1, done - nburnin_walker if done > nburnin_walker else done)
-                macc, sacc = na.mean(), np.sqrt(na.var(ddof=1))          # :276-278
-                outl = int(np.sum(np.abs(na - macc) > 2 * sacc))
-                print(f"\remcee, niter={niter}, nwalkers={nwalkers}: generation {done}/{niter_walker} "
-                      f"accept_ratio_mean={macc / nn:.3g} accept_ratio_std={sacc / nn:.3g} "
-                      f"accept_ratio_outliers={outl} burnin_phase={done <= nburnin_walker}",      # :279-283
-                      end="", file=sys.stderr)
-            print(file=sys.stderr)
-        else:
-            s.run(niter_walker)
-        s.sync()
-        chain, chain_logp = s.chain(logp=True)
-        accept_ratio = s.accept_ratio()
+        try:
+            _run_generations(s, niter, nwalkers, niter_walker, nburnin_walker, use_progress_meter)
+            chain, chain_logp = s.chain(logp=True)
+            accept_ratio = s.accept_ratio()
+        finally:
+            if hasblob:
+                pdf.on_accepted = None                         # the closure holds this call's blob storage
 
     thetas = np.ascontiguousarray(chain.transpose(1, 0, 2))    # [walker][sample][dim]
     if scalar_walkers:
         thetas = thetas[:, :, 0]
     logdensities = np.ascontiguousarray(chain_logp.T)          # [walker][sample]
     assert thetas.shape[1] == nsamples_walker
-    if hasblob:
-        pdf.on_accepted = None
     return thetas, accept_ratio, logdensities, blobs
+
+
+def _run_generations(s, niter, nwalkers, niter_walker, nburnin_walker, use_progress_meter):
+    """All generations of one emcee call, in up to 20 pieces with a progress line on stderr after each
+    (the reference's ProgressMeter values, ``src/samplers.jl:275-284``) or in one piece."""
+    if use_progress_meter and niter_walker > 0:
+        nchunks = min(20, niter_walker)
+        done = 0
+        for c in range(nchunks):
+            upto = (niter_walker * (c + 1)) // nchunks
+            s.run(upto - done)
+            done = upto
+            s.sync()
+            na = s.naccept().astype(np.float64)
+            nn = max(1, done - nburnin_walker if done > nburnin_walker else done)
+            macc, sacc = na.mean(), np.sqrt(na.var(ddof=1))          # :276-278
+            outl = int(np.sum(np.abs(na - macc) > 2 * sacc))
+            print(f"\remcee, niter={niter}, nwalkers={nwalkers}: generation {done}/{niter_walker} "
+                  f"accept_ratio_mean={macc / nn:.3g} accept_ratio_std={sacc / nn:.3g} "
+                  f"accept_ratio_outliers={outl} burnin_phase={done <= nburnin_walker}",      # :279-283
+                  end="", file=sys.stderr)
+        print(file=sys.stderr)
+    else:
+        s.run(niter_walker)
+    s.sync()
 
 
 def make_theta0s(theta0, ball_radius, pdf, nwalkers: int, ball_radius_halfing_steps: int = 7,
