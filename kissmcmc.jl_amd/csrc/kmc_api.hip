@@ -1744,6 +1744,7 @@ KMC_EXPORT kmc_status kmc_sampler_describe(const kmc_sampler* s, char* buf, int6
     } else
         o << "multi-launch (exact): half_step_generic (one walker per lane), grid " << s->grid << " x 256";
     if (s->f32) o << "; rows kept in float (KMC_F32), arithmetic in double";
+    if (s->d_mring) o << "; moments through a ring of " << s->mring_depth << " posted rows per wave";
     if (s->user) o << "; runtime-compiled density";
     if (s->p2p) o << "; P2P shard " << s->cfg.shard_rank << "/" << s->cfg.shard_count << (s->connected ? "" : " (not connected)");
     else if (s->cfg.shard_count > 1) o << "; replica shard " << s->cfg.shard_rank << "/" << s->cfg.shard_count;

@@ -246,6 +246,7 @@ def test_moment_ring_of_long_rows(kmc, oracle, depth, monkeypatch):
         s.sync()
         msum, msq, n = s.moments()
         nacc = s.naccept()
+        assert ("ring of" in s.describe()) == (depth != "off")
     cfg = lambda g: oracle.make_config(oracle.GAUSSIAN_ISO, [0.0, 1.0], nw, nd, g, nburn, nthin, 2.0, seed, nthreads=8)
     ref_mid = oracle.emcee(cfg(130), th, store_chain=False)
     ref = oracle.emcee(cfg(G), th, store_chain=False)
