@@ -216,6 +216,7 @@ def main():
             return float(t.item())
 
         p2p_memory = None
+        tried = []
         if mode == "p2p":
             # candidates, each admitted only by the bit-exact self-check; of the admitted ones the fastest (measured) runs.
             #   pull: partner rows are read from the owning GPU (every drawn row crosses the fabric once);
@@ -223,7 +224,6 @@ def main():
             #         accepted rows cross the fabric, once per peer): less per link for few ranks, more for many;
             #   folded signal: the half-step kernel publishes its own progress flag (one kernel boundary less per
             #         half-step) instead of a separate signal kernel.  Fine-grained rows only if nothing passes.
-            tried = []
             for label, fold, push in (("pull of drawn rows, signal folded into the kernel", True, False),
                                       ("pull of drawn rows, signal kernel", False, False),
                                       ("push of accepted rows into local copies, signal folded into the kernel", True, True),
@@ -344,6 +344,7 @@ def main():
                              "bytes_per_link_per_launch": rows_per_peer * NDIM * 8,
                              "link_bound_us_at_77GBs": rows_per_peer * NDIM * 8 / 77e9 * 1e6,
                              "push_bytes_per_link_per_launch": acc * walkers_per_launch * NDIM * 8,
+                             "variants_us_per_launch": {label: tc / 512 * 1e6 for label, tc in tried},   # 256 generations each
                              "note": "pull variants move every drawn row once (bytes_per_link from each peer); push variants move "
                                      "accepted rows only (push_bytes_per_link to each peer); link figure = one xGMI link, one "
                                      "direction (~77 GB/s); config.parallelism names the variant that ran"}
