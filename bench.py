@@ -159,7 +159,7 @@ def main():
         mode = os.environ.get("KMC_BENCH_EXCHANGE", "p2p")
         drv = None
 
-        def try_p2p(finegrained, fold_signal=False, push=False):
+        def try_p2p(finegrained, fold_signal=False, push=False, lazy=False):
             """Set up the peer-to-peer exchange and self-check it: 240 generations (hipGraph replays + an eager tail)
             must reproduce, bit for bit, the same generations of the whole ensemble on ONE GPU (rank 0 runs it
             unsharded).  Any error, time-out or mismatch on any rank -> None on every rank."""
@@ -167,7 +167,7 @@ def main():
             d = None
             try:
                 d = P2PEmcee(pdf, nw, NDIM, G, nburn, 1, 2.0, SEED, device=local_rank, finegrained=finegrained,
-                             fold_signal=fold_signal, push=push)
+                             fold_signal=fold_signal, push=push, lazy=lazy)
             except Exception as e:  # noqa: BLE001
                 print(f"[rank {rank}] p2p set-up failed ({e})", file=sys.stderr)
                 ok.zero_()
@@ -185,7 +185,7 @@ def main():
                             ref.run(vgen)
                             ref.sync()
                             if not (np.array_equal(ref.positions(), vpos) and np.array_equal(ref.naccept(), vacc)):
-                                print(f"[rank 0] p2p self-check (finegrained={finegrained}, fold_signal={fold_signal}, push={push}): "
+                                print(f"[rank 0] p2p self-check (finegrained={finegrained}, fold_signal={fold_signal}, push={push}, lazy={lazy}): "
                                       "sharded run differs from the single-GPU run", file=sys.stderr)
                                 ok.zero_()
                 except Exception as e:  # noqa: BLE001
@@ -222,13 +222,16 @@ def main():
             #   pull: partner rows are read from the owning GPU (every drawn row crosses the fabric once);
             #   push: every rank keeps local copies of the other shards, accepted rows are written to all peers (only
             #         accepted rows cross the fabric, once per peer): less per link for few ranks, more for many;
+            #   lazy pull: local copies as for push, but filled on demand -- a rank publishes its accept bytes, a reader
+            #         pulls a drawn row only when its copy is older than the row's last accept (fewest bytes per link);
             #   folded signal: the half-step kernel publishes its own progress flag (one kernel boundary less per
             #         half-step) instead of a separate signal kernel.  Fine-grained rows only if nothing passes.
-            for label, fold, push in (("pull of drawn rows, signal folded into the kernel", True, False),
-                                      ("pull of drawn rows, signal kernel", False, False),
-                                      ("push of accepted rows into local copies, signal folded into the kernel", True, True),
-                                      ("push of accepted rows into local copies, signal kernel", False, True)):
-                cand = try_p2p(False, fold, push)
+            for label, fold, push, lazy in (("pull of drawn rows, signal folded into the kernel", True, False, False),
+                                            ("pull of drawn rows, signal kernel", False, False, False),
+                                            ("push of accepted rows into local copies, signal folded into the kernel", True, True, False),
+                                            ("push of accepted rows into local copies, signal kernel", False, True, False),
+                                            ("lazy pull into local copies (accept bytes published, rows pulled when stale)", False, False, True)):
+                cand = try_p2p(False, fold, push, lazy)
                 if cand is None:
                     continue
                 tc = time_short(cand)
@@ -266,6 +269,7 @@ def main():
             launches = drv.sampler.launch_count
             msum, msq, nmom = drv.moments()
             acc = float(drv.naccept().sum() / nw / max(1, G - nburn))
+            lazy_stats = drv.sampler.p2p_stats()         # (remote partner draws, pulled) on this rank; (0, 0) unless lazy ran
             drv.close()
             parallelism = (f"walker-sharded x{world}, peer-to-peer exchange over xGMI (IPC): {p2p_memory}; "
                            "progress-flag ordering; self-check vs the unsharded single-GPU run: bit-identical")
@@ -345,6 +349,7 @@ def main():
                              "link_bound_us_at_77GBs": rows_per_peer * NDIM * 8 / 77e9 * 1e6,
                              "push_bytes_per_link_per_launch": acc * walkers_per_launch * NDIM * 8,
                              "variants_us_per_launch": {label: tc / 512 * 1e6 for label, tc in tried},   # 256 generations each
+                             "lazy_pulled_fraction_rank0": (lazy_stats[1] / lazy_stats[0]) if (mode == "p2p" and lazy_stats[0]) else None,
                              "note": "pull variants move every drawn row once (bytes_per_link from each peer); push variants move "
                                      "accepted rows only (push_bytes_per_link to each peer); link figure = one xGMI link, one "
                                      "direction (~77 GB/s); config.parallelism names the variant that ran"}

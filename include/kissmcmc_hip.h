@@ -105,6 +105,13 @@ enum {
                                   every peer as well (posted write-through stores over xGMI).  Only accepted rows cross the
                                   fabric (C2: 23 %), once per peer, instead of every drawn row once: less per link for few
                                   ranks, more for many.  Not with KMC_P2P_FINEGRAINED / kmc_sampler_init_ball. */
+    KMC_P2P_LAZY    = 1u << 10, /* with KMC_P2P: the local copies of KMC_P2P_PUSH, filled on demand.  A rank publishes the
+                                   accept bytes of each half-step (one byte per active walker, to every peer, with the progress
+                                   flag) instead of any rows; a reader pulls a drawn row from its owner only when its local
+                                   copy is older than the row's last accept, and keeps it.  Expected share of draws that
+                                   cross a link at C2's acceptance: 0.38 / 0.55 / 0.71 at 2 / 4 / 8 ranks.  Needs
+                                   nwalkers / 2 / shard_count to be a multiple of 16; not with KMC_P2P_FINEGRAINED /
+                                   KMC_P2P_FOLD_SIGNAL / kmc_sampler_init_ball. */
     KMC_P2P_FOLD_SIGNAL = 1u << 8, /* with KMC_P2P: the half-step kernel itself publishes the progress flag (its stores are
                                       write-through; the last workgroup to drain them signals every rank) instead of a separate
                                       signal kernel after it: one kernel boundary less per half-step */
@@ -201,6 +208,9 @@ kmc_status  kmc_sampler_bind_positions(kmc_sampler* s, void* pos_dev);
  * second-half slice). */
 kmc_status  kmc_sampler_p2p_export(kmc_sampler* s, void* handle_out);
 kmc_status  kmc_sampler_p2p_connect(kmc_sampler* s, const void* handles /* [shard_count][KMC_P2P_HANDLE_BYTES] */);
+/* KMC_P2P_LAZY: counts since kmc_sampler_set_positions -- out[0] = partner draws that fell on another rank's rows,
+   out[1] = those of them that were pulled over the fabric (the others were served by the local copy). */
+kmc_status  kmc_sampler_p2p_stats(kmc_sampler* s, uint64_t out[2]);
 /* Upload the ensemble (host, [nwalkers][ndim], global order), evaluate the initial log-pdfs on
  * the device (src/samplers.jl:209-210), reset generation/counters.  Fails with
  * KMC_ERR_NONFINITE_LOGP if any is not finite. */

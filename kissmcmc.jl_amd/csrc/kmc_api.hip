@@ -513,7 +513,10 @@ struct kmc_sampler {
     unsigned long long* d_err = nullptr;
     uint32_t* d_done = nullptr;                          // KMC_P2P_FOLD_SIGNAL: workgroups drained, per launch
     bool fold_signal = false;
-    bool push = false;                                   // KMC_P2P_PUSH: d_pos = (1 + shard_count) blocks, see HalfStepArgs::push
+    bool push = false;                                   // KMC_P2P_PUSH / KMC_P2P_LAZY: d_pos = (1 + shard_count) blocks, see HalfStepArgs::push
+    bool lazy = false;                                   // KMC_P2P_LAZY: + accept-byte maps behind the blocks, stamps in d_lazy
+    unsigned char* d_lazy = nullptr;                     // {amap_out[4][h_loc], fetched[P][2][h_loc] u32, modified[P][2][h_loc] u32}
+    unsigned char* peer_amap_in[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     double* peer_pos[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     unsigned long long* peer_flags[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
@@ -544,7 +547,15 @@ HalfStepArgs make_args(const kmc_sampler* s, int half, bool graph_mode, int64_t 
     for (int r = 0; r < 8; ++r) a.peer_flags[r] = s->peer_flags[r];
     a.done_count = s->fold_signal ? s->d_done : nullptr;
     a.me = s->cfg.shard_rank;
-    a.push = s->push ? 1 : 0;
+    a.push = s->lazy ? 2 : s->push ? 1 : 0;
+    if (s->lazy) {
+        const size_t hl = (size_t)s->h_loc, P = (size_t)s->cfg.shard_count;
+        a.lz_amap_in = s->peer_amap_in[s->cfg.shard_rank];
+        a.lz_amap_out = s->d_lazy;
+        a.lz_fetched = reinterpret_cast<uint32_t*>(s->d_lazy + 4 * hl);
+        a.lz_modified = a.lz_fetched + P * 2 * hl;
+        a.lz_stats = reinterpret_cast<unsigned long long*>(a.lz_modified + P * 2 * hl);
+    }
     a.shard_stride = (int64_t)s->nrows * s->ld;
     a.n_active = (int32_t)s->h_loc;
     a.half = half;
@@ -614,7 +625,12 @@ kmc_status launch_half(kmc_sampler* s, int half, bool graph_mode, int64_t gen_of
         sg.sched_inline = a.sched_inline;
         sg.sched_index = a.sched_index;
         sg.half = half;
-        hipLaunchKernelGGL(p2p_signal, dim3(1), dim3(64), 0, s->stream, sg);
+        if (s->lazy) {
+            sg.amap_out = s->d_lazy;
+            for (int r = 0; r < 8; ++r) sg.peer_amap_in[r] = s->peer_amap_in[r];
+            sg.hloc = s->h_loc;
+        }
+        hipLaunchKernelGGL(p2p_signal, dim3(1), dim3(s->lazy ? 256 : 64), 0, s->stream, sg);
         HIP_TRY(hipGetLastError());
     }
     return KMC_OK;
@@ -1031,16 +1047,27 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         CREATE_TRY(hipMemset(s->d_done, 0, 64));
         // the kernel can publish its own completion only where all its stores are write-through: the vector kernels
         s->fold_signal = (cfg->flags & KMC_P2P_FOLD_SIGNAL) != 0 && s->plan.vec && s->user == nullptr;
-        s->push = (cfg->flags & KMC_P2P_PUSH) != 0 && s->plan.vec && s->user == nullptr && !(cfg->flags & KMC_P2P_FINEGRAINED) &&
+        s->push = (cfg->flags & (KMC_P2P_PUSH | KMC_P2P_LAZY)) != 0 && s->plan.vec && s->user == nullptr && !(cfg->flags & KMC_P2P_FINEGRAINED) &&
                   s->cfg.shard_count > 1;
+        s->lazy = s->push && (cfg->flags & KMC_P2P_LAZY) != 0 && s->h_loc % 16 == 0 && !s->f32;
+        if (s->lazy) s->fold_signal = false;             // the accept bytes travel with the signal kernel
     }
+    // KMC_P2P_LAZY: room for every rank's accept-byte maps behind the row blocks (peers write them: same allocation)
+    const size_t amap_bytes = s->lazy ? (size_t)s->cfg.shard_count * 4 * (size_t)s->h_loc : 0;
     const size_t ldz = (size_t)s->ld;
     const size_t esz = s->f32 ? sizeof(float) : sizeof(double);      // element size of rows and chain
     if (s->p2p && (cfg->flags & KMC_P2P_FINEGRAINED))   // peers map the rows uncached: nothing of them can go stale in a reader's L2
         CREATE_TRY(hipExtMallocWithFlags((void**)&s->d_pos, nw * ldz * sizeof(double), hipDeviceMallocFinegrained));
     else
-        CREATE_TRY(hipMalloc(&s->d_pos, (s->push ? 1 + (size_t)s->cfg.shard_count : 1) * nw * ldz * esz));
-    CREATE_TRY(hipMemset(s->d_pos, 0, (s->push ? 1 + (size_t)s->cfg.shard_count : 1) * nw * ldz * esz));   // the pad column of odd ndim stays 0
+        CREATE_TRY(hipMalloc(&s->d_pos, (s->push ? 1 + (size_t)s->cfg.shard_count : 1) * nw * ldz * esz + amap_bytes));
+    CREATE_TRY(hipMemset(s->d_pos, 0, (s->push ? 1 + (size_t)s->cfg.shard_count : 1) * nw * ldz * esz + amap_bytes));   // the pad column of odd ndim stays 0
+    if (s->lazy) {
+        const size_t P = (size_t)s->cfg.shard_count, hl = (size_t)s->h_loc;
+        const size_t nb = 4 * hl + 2 * P * 2 * hl * sizeof(uint32_t) + 16;
+        CREATE_TRY(hipMalloc((void**)&s->d_lazy, nb));
+        CREATE_TRY(hipMemset(s->d_lazy, 0, nb));
+        s->peer_amap_in[s->cfg.shard_rank] = reinterpret_cast<unsigned char*>(s->d_pos) + (1 + P) * nw * ldz * esz;
+    }
     // per-walker block {logp[nrows], naccept[nrows], klast[nrows]}: one allocation, so the half-step kernels reach all
     // three from one preloaded pointer (HalfStepFront::logp)
     CREATE_TRY(hipMalloc(&s->d_logp, nw * (sizeof(double) + 2 * sizeof(uint32_t))));
@@ -1141,6 +1168,7 @@ KMC_EXPORT void kmc_sampler_destroy(kmc_sampler* s)
     if (s->own_pos) (void)hipFree(s->d_pos);
     (void)hipFree(s->d_logp);          // the {logp, naccept, klast} block
     (void)hipFree(s->d_mring);
+    (void)hipFree(s->d_lazy);
     (void)hipFree(s->d_mring_w);
     (void)hipFree(s->d_mcnt);
     (void)hipFree(s->d_gen);
@@ -1224,10 +1252,26 @@ KMC_EXPORT kmc_status kmc_sampler_p2p_connect(kmc_sampler* s, const void* handle
         void* p = nullptr;
         HIP_TRY(hipIpcOpenMemHandle(&p, h[r].pos, hipIpcMemLazyEnablePeerAccess));
         s->peer_pos[r] = static_cast<double*>(p);
+        if (s->lazy)
+            s->peer_amap_in[r] = static_cast<unsigned char*>(p) + (size_t)(1 + s->cfg.shard_count) * (size_t)s->nrows * (size_t)s->ld * sizeof(double);
         HIP_TRY(hipIpcOpenMemHandle(&p, h[r].flags, hipIpcMemLazyEnablePeerAccess));
         s->peer_flags[r] = static_cast<unsigned long long*>(p);
     }
     s->connected = true;
+    return KMC_OK;
+}
+
+KMC_EXPORT kmc_status kmc_sampler_p2p_stats(kmc_sampler* s, uint64_t out[2])
+{
+    if (!s || !out) return fail(KMC_ERR_BAD_ARG, "null argument");
+    out[0] = out[1] = 0;
+    if (!s->lazy) return KMC_OK;
+    HIP_TRY(hipSetDevice(s->cfg.device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    const size_t hl = (size_t)s->h_loc, P = (size_t)s->cfg.shard_count;
+    unsigned long long v[2] = {0ull, 0ull};
+    HIP_TRY(hipMemcpy(v, s->d_lazy + 4 * hl + 2 * P * 2 * hl * sizeof(uint32_t), sizeof(v), hipMemcpyDeviceToHost));
+    out[0] = v[0]; out[1] = v[1];
     return KMC_OK;
 }
 
@@ -1429,6 +1473,11 @@ KMC_EXPORT kmc_status kmc_sampler_set_positions(kmc_sampler* s, const double* th
         HIP_TRY(hipMemset(s->d_flags, 0, 4096));     // callers barrier across ranks before running
         HIP_TRY(hipMemset(s->d_err, 0, 64));
         if (s->d_done) HIP_TRY(hipMemset(s->d_done, 0, 64));
+        if (s->lazy) {                               // every shadow is current, nothing has been accepted yet
+            const size_t P = (size_t)s->cfg.shard_count, hl = (size_t)s->h_loc;
+            HIP_TRY(hipMemset(s->d_lazy, 0, 4 * hl + 2 * P * 2 * hl * sizeof(uint32_t) + 16));
+            HIP_TRY(hipMemset(s->peer_amap_in[s->cfg.shard_rank], 0, P * 4 * hl));
+        }
     }
     if (s->host_eval) {                                          // :209-210, on the caller's thread
         std::vector<double> lp0(nw);
@@ -1743,6 +1792,8 @@ KMC_EXPORT kmc_status kmc_sampler_describe(const kmc_sampler* s, char* buf, int6
         }
     } else
         o << "multi-launch (exact): half_step_generic (one walker per lane), grid " << s->grid << " x 256";
+    if (s->lazy) o << "; lazy pull into local copies (KMC_P2P_LAZY)";
+    else if (s->push) o << "; accepted rows pushed into the peers' local copies (KMC_P2P_PUSH)";
     if (s->f32) o << "; rows kept in float (KMC_F32), arithmetic in double";
     if (s->d_mring) o << "; moments through a ring of " << s->mring_depth << " posted rows per wave";
     if (s->user) o << "; runtime-compiled density";

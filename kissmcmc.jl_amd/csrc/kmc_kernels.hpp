@@ -147,6 +147,18 @@ struct HalfStepArgs {
     uint32_t*         mcnt;         // [waves]
     const uint32_t*   mswept;       // [waves]
     int32_t           mring_depth;
+    // KMC_P2P_LAZY (push == 2): the shadow blocks of KMC_P2P_PUSH, filled on demand.  Nobody pushes rows; a rank
+    // publishes the ACCEPT BYTES of each half-step instead (one byte per active walker, copied into every peer's
+    // lz_amap_in by the signal kernel, slot = step & 3), and a reader pulls a drawn remote row only when its shadow
+    // copy is older than the row's last accept -- it then keeps the row in the shadow.  Per remote row the reader
+    // holds two stamps (step + 1; 0 = never): lz_modified, the last accept it has heard of (absorbed from the byte
+    // maps, one launch late), and lz_fetched, its last pull.  A row is pulled when the newest map flags it, when
+    // modified > fetched, or when fetched carries THIS step (another wave is rewriting the shadow right now).
+    const unsigned char* lz_amap_in;   // [nranks][4][hloc]  (inside the exported row allocation: peers write it)
+    unsigned char*    lz_amap_out;     // [4][hloc]
+    uint32_t*         lz_fetched;      // [nranks][2][hloc]
+    uint32_t*         lz_modified;     // [nranks][2][hloc]
+    unsigned long long* lz_stats;      // [0] remote partner draws, [1] of them pulled over the fabric
 };
 
 // The fields a wave needs before it can issue its first loads travel as LEADING SCALAR kernel parameters, ahead
@@ -487,6 +499,8 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
     //      logarithm: measured best at C2 (all loads first: +0.15 us per half-step; loads after both logs: same),
     //      and pinned with scheduling barriers because the compiler's own placement moves with unrelated edits ----
     unsigned long long addrA = 0ull;                                    // P2P: the partner row's address
+    unsigned long long addrS = 0ull;                                    // KMC_P2P_LAZY: where a pulled row goes in the local shadow
+    unsigned long long shadowB[ITER];
     if constexpr (P2P) {
         // owner rank and row of the partner, resolved once per walker; the row address travels
         const uint32_t q = a.hloc_shift >= 0 ? partnerA >> a.hloc_shift : partnerA / a.hloc;
@@ -502,6 +516,47 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
             if ((threadIdx.x >> 6) == 0) wait_for_peers(a, step, lane);
             __syncthreads();
         }
+        if (a.push == 2) {                                              // KMC_P2P_LAZY
+            const uint32_t stamp = (uint32_t)step + 1u;
+            const int64_t hl = (int64_t)a.hloc;
+            if (step > 0) {
+                // absorb the accept bytes of half-step step - 1 (the partner half's last update) into the stamps
+                const uint32_t* maps = reinterpret_cast<const uint32_t*>(a.lz_amap_in);
+                const int64_t wpr = hl / 4, nthr = (int64_t)gridDim.x * vec_tpb(L);
+                for (int64_t w = tid; w < (int64_t)a.nranks * wpr; w += nthr) {
+                    const int64_t qq = w / wpr, ww = w - qq * wpr;
+                    if (qq == a.me) continue;
+                    const uint32_t word = maps[(qq * 4 + (int64_t)((step - 1) & 3)) * wpr + ww];
+                    if (word != 0u) {
+                        uint32_t* m = a.lz_modified + (qq * 2 + (1 - half)) * hl + 4 * ww;
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) if ((word >> (8 * b)) & 0xffu) m[b] = (uint32_t)step;     // = (step - 1) + 1
+                    }
+                }
+            }
+            // this walker's partner: from the local shadow unless the owner's copy is newer
+            bool remote = false, pulled = false;
+            if (q != (uint32_t)a.me && validA) {
+                remote = true;
+                const int64_t x = ((int64_t)q * 2 + (1 - half)) * hl + r;
+                const uint32_t fe = a.lz_fetched[x], mo = a.lz_modified[x];
+                const unsigned am = step > 0 ? a.lz_amap_in[((int64_t)q * 4 + (int64_t)((step - 1) & 3)) * hl + r] : 0u;
+                if (am != 0u || mo > fe || fe == stamp) {
+                    addrS = addrA;                                      // (push != 0: addrA is the shadow row)
+                    const double* rb = a.peer_pos[0];
+#pragma unroll
+                    for (int t = 1; t < 8; ++t) rb = (q == (uint32_t)t) ? a.peer_pos[t] : rb;
+                    addrA = (unsigned long long)(rb + (oth_row0 + r) * ld);
+                    a.lz_fetched[x] = stamp;
+                    pulled = true;
+                }
+            }
+            const unsigned long long nrem = __ballot(remote), npul = __ballot(pulled);
+            if (lane == 0 && nrem != 0ull) {
+                atomicAdd(&a.lz_stats[0], (unsigned long long)__popcll(nrem));
+                if (npul != 0ull) atomicAdd(&a.lz_stats[1], (unsigned long long)__popcll(npul));
+            }
+        }
     }
     auto load_partner_rows = [&](int it) {
         const V2* oth;
@@ -513,6 +568,12 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
             const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)(unsigned)addrA);
             const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)(unsigned)(addrA >> 32));
             oth = reinterpret_cast<const V2*>(((unsigned long long)hi << 32) | lo);
+            shadowB[it] = 0ull;
+            if (a.push == 2) {
+                const unsigned slo = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)(unsigned)addrS);
+                const unsigned shi = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)(unsigned)(addrS >> 32));
+                shadowB[it] = ((unsigned long long)shi << 32) | slo;
+            }
         }
 #pragma unroll
         for (int k = 0; k < K; ++k) xo[it][k] = cv[k] ? load_row(&oth[k * L + j]) : zero2;
@@ -598,6 +659,18 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
 #pragma unroll
     for (int it = 0; it < ITER; ++it) zB[it] = bperm_f64((gbase + it) * 4, dr.z);
 
+    if constexpr (P2P) {
+        if (a.push == 2) {                                              // keep the rows just pulled
+#pragma unroll
+            for (int it = 0; it < ITER; ++it) {
+                if (shadowB[it] != 0ull) {
+                    double2* sh = reinterpret_cast<double2*>(shadowB[it]);
+#pragma unroll
+                    for (int k = 0; k < K; ++k) if (cv[k]) store_wt(&sh[k * L + j], xo[it][k]);
+                }
+            }
+        }
+    }
     // ---- stretch move + log-pdf; xo becomes the proposal ------------------------------------
     double myp1 = 0.0;
 #pragma unroll
@@ -621,6 +694,9 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
         if (count) store_wt(&naccept_p[rowA], na + 1u);                 // :265
         if (do_mom) store_wt(&klast_p[rowA], sch.nbefore);
     }
+    if constexpr (P2P) {
+        if (a.push == 2 && validA) a.lz_amap_out[(int64_t)(step & 3) * (int64_t)a.hloc + iA] = acc ? 1 : 0;
+    }
     const uint32_t wA = (acc && do_mom) ? sch.nbefore - kl : 0u;        // samples the replaced value stood for
     const bool any_w = __ballot(wA != 0u) != 0ull;
     if (sample && a.chain_logp != nullptr && validA)                    // :271
@@ -641,7 +717,7 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
 #pragma unroll
             for (int k = 0; k < K; ++k) if (cv[k]) store_row(&own[k * L + j], xo[it][k]);
             if constexpr (P2P) {
-                if (a.push) {                                           // ... and into this rank's shadow on every peer
+                if (a.push == 1) {                                      // ... and into this rank's shadow on every peer
                     const int64_t off = (int64_t)(1 + a.me) * a.shard_stride + (own_row0 + w0 + it * G + g) * ld;
                     for (int r = 0; r < a.nranks; ++r) {
                         if (r == a.me) continue;
@@ -887,6 +963,10 @@ struct SignalArgs {
     SchedEntry          sched_inline;
     int32_t             sched_index;
     int32_t             half;
+    // KMC_P2P_LAZY: this half-step's accept bytes go to every peer before the flag
+    const unsigned char* amap_out;      // [4][hloc] or nullptr
+    unsigned char*      peer_amap_in[8]; // peer r's lz_amap_in
+    int64_t             hloc;
 };
 // Device-side make_theta0s (reference src/samplers.jl:311-349, the intended behaviour): walker w gets
 // theta0 + N(0, diag(r^2)), redrawn while its log-pdf is -inf -- up to `ntries` draws per ball size,
@@ -998,6 +1078,17 @@ __global__ void p2p_signal(const SignalArgs a)
 {
     const SchedEntry sch = a.sched_index >= 0 ? a.sched_table[a.sched_index] : a.sched_inline;
     const unsigned long long done = 2ull * (unsigned long long)sch.gen + (unsigned long long)a.half + 1ull;
+    if (a.amap_out != nullptr) {
+        const int64_t slot = (int64_t)((done - 1ull) & 3ull);
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(a.amap_out + slot * a.hloc);
+        for (int r = 0; r < a.nranks; ++r) {
+            if (r == a.me) continue;
+            uint32_t* dst = reinterpret_cast<uint32_t*>(a.peer_amap_in[r] + ((int64_t)a.me * 4 + slot) * a.hloc);
+            for (int64_t w = threadIdx.x; w < a.hloc / 4; w += blockDim.x) dst[w] = src[w];
+        }
+        __threadfence_system();
+        __syncthreads();
+    }
     __threadfence_system();
     if ((int)threadIdx.x < a.nranks)
         __hip_atomic_store(a.peer_flags[threadIdx.x] + a.me, done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -105,12 +105,18 @@ class P2PEmcee:
     replay) like the single-GPU case.  Compared with all-gathering the updated half after every
     half-step this moves only the rows that are actually drawn (1/P of the bytes).
 
+    Variants of the exchange (all bit-identical; ``bench.py`` picks by measurement): ``push`` keeps local copies of
+    the other shards and writes accepted rows to every peer (``KMC_P2P_PUSH``); ``lazy`` keeps the same copies but
+    fills them on demand -- ranks publish their accept bytes, a reader pulls a row only when its copy is older than
+    the row's last accept (``KMC_P2P_LAZY``, ``Sampler.p2p_stats()``); ``fold_signal`` lets the half-step kernel
+    publish its own progress flag (``KMC_P2P_FOLD_SIGNAL``); ``finegrained`` puts the rows in fine-grained memory.
+
     ``torch.distributed`` (any backend) is used for the rendezvous (IPC handle exchange, barriers)
     and for assembling results.
     """
 
     def __init__(self, pdf, nwalkers, ndim, ngenerations, nburnin=0, nthin=1, a_scale=2.0, seed=0,
-                 device=0, moments=True, group=None, use_graph=True, finegrained=False, fold_signal=False, push=False):
+                 device=0, moments=True, group=None, use_graph=True, finegrained=False, fold_signal=False, push=False, lazy=False):
         from .sampler import Sampler
         self.group = group
         self.rank = dist.get_rank(group) if dist is not None and dist.is_initialized() else 0
@@ -120,7 +126,7 @@ class P2PEmcee:
         self.sampler = Sampler(pdf, nwalkers, ndim, ngenerations, nburnin, nthin, a_scale, seed,
                                moments=moments, use_graph=use_graph, device=device,
                                shard_rank=self.rank, shard_count=self.world, p2p=True, p2p_finegrained=finegrained,
-                               p2p_fold=fold_signal, p2p_push=push)
+                               p2p_fold=fold_signal, p2p_push=push, p2p_lazy=lazy)
         if self.world > 1:
             blobs = [None] * self.world
             dist.all_gather_object(blobs, self.sampler.p2p_export(), group=group)

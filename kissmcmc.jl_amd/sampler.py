@@ -23,7 +23,7 @@ class Sampler:
                  store_logp: bool = False, moments: bool = False, use_graph: bool = True,
                  device: int = 0, shard_rank: int = 0, shard_count: int = 1, p2p: bool = False,
                  island_gens: int = 0, island_size: int = 0, p2p_finegrained: bool = False, p2p_fold: bool = False, p2p_push: bool = False,
-                 dtype: str = "f64"):
+                 dtype: str = "f64", p2p_lazy: bool = False):
         if not isinstance(pdf, DeviceLogPdf):
             raise TypeError(
                 "pdf must be a menu log-density (GaussianIso, Exponential, Rosenbrock, LogNormal, MvNormal2), "
@@ -61,6 +61,8 @@ class Sampler:
                 flags |= _lib.P2P_FOLD_SIGNAL
             if p2p_push:
                 flags |= _lib.P2P_PUSH
+            if p2p_lazy:
+                flags |= _lib.P2P_LAZY
         if island_gens:
             # ISLAND MODE: 256-walker islands resident in LDS for `island_gens` generations per launch
             flags |= _lib.ISLANDS
@@ -111,6 +113,12 @@ class Sampler:
     def bind_positions(self, device_ptr: int):
         """Use a caller-owned device buffer (``double [nwalkers][ndim]``) for the ensemble."""
         _lib.check(self._L.kmc_sampler_bind_positions(self._h, C.c_void_p(device_ptr)))
+
+    def p2p_stats(self):
+        """KMC_P2P_LAZY: (partner draws on other ranks' rows, those pulled over the fabric) since set_positions."""
+        v = (C.c_uint64 * 2)()
+        _lib.check(self._L.kmc_sampler_p2p_stats(self._h, v))
+        return int(v[0]), int(v[1])
 
     def p2p_export(self) -> bytes:
         """IPC handle blob of this shard (to be all-gathered across the ranks)."""

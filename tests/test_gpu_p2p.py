@@ -41,13 +41,16 @@ def _worker(rank, world, port, outdir, plan, late_rank=-1):
         return _worker_rosen(rank, world, port, outdir)
     fold = plan in ("fold", "push-fold")
     push = plan in ("push", "push-fold")
-    if plan and not (fold or push):
+    lazy = plan == "lazy"
+    if plan and not (fold or push or lazy):
         os.environ["KMC_PLAN"] = plan
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)   # rendezvous only (same GPU: RCCL would refuse)
     try:
-        drv = P2PEmcee(kmc.GaussianIso(), NW, ND, G, NBURN, 1, 2.0, SEED, device=0, fold_signal=fold, push=push)
+        drv = P2PEmcee(kmc.GaussianIso(), NW, ND, G, NBURN, 1, 2.0, SEED, device=0, fold_signal=fold, push=push, lazy=lazy)
+        if lazy:
+            assert "lazy" in drv.sampler.describe()
         drv.set_positions(_theta0())
         if rank == late_rank:
             import time
@@ -107,7 +110,7 @@ def _free_port():
 
 
 @pytest.mark.parametrize("world,plan", [(2, ""), (4, ""), (2, "generic"), (2, "fold"), (4, "fold"), (2, "push"), (4, "push"),
-                                        (2, "push-fold")])   # the GPU box allows 6 processes on the card: parent + 4 ranks at most
+                                        (2, "push-fold"), (2, "lazy"), (4, "lazy")])   # the GPU box allows 6 processes on the card: parent + 4 ranks at most
 def test_p2p_processes_sharing_one_gpu_equal_oracle(oracle, tmp_path, world, plan):
     import torch.multiprocessing as mp
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), plan), nprocs=world, join=True)
