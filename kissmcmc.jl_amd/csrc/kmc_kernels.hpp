@@ -1086,10 +1086,9 @@ __global__ void p2p_signal(const SignalArgs a)
             uint32_t* dst = reinterpret_cast<uint32_t*>(a.peer_amap_in[r] + ((int64_t)a.me * 4 + slot) * a.hloc);
             for (int64_t w = threadIdx.x; w < a.hloc / 4; w += blockDim.x) dst[w] = src[w];
         }
-        __threadfence_system();
-        __syncthreads();
     }
     __threadfence_system();
+    if (a.amap_out != nullptr) __syncthreads();          // every thread's bytes are out before the flags
     if ((int)threadIdx.x < a.nranks)
         __hip_atomic_store(a.peer_flags[threadIdx.x] + a.me, done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
