@@ -230,7 +230,8 @@ def main():
                                             ("pull of drawn rows, signal kernel", False, False, False),
                                             ("push of accepted rows into local copies, signal folded into the kernel", True, True, False),
                                             ("push of accepted rows into local copies, signal kernel", False, True, False),
-                                            ("lazy pull into local copies (accept bytes published, rows pulled when stale)", False, False, True)):
+                                            ("lazy pull into local copies (accept bytes published, rows pulled when stale), signal kernel", False, False, True),
+                                            ("lazy pull into local copies (accept bytes published, rows pulled when stale), signal folded into the kernel", True, False, True)):
                 cand = try_p2p(False, fold, push, lazy)
                 if cand is None:
                     continue

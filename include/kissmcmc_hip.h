@@ -111,7 +111,8 @@ enum {
                                    copy is older than the row's last accept, and keeps it.  Expected share of draws that
                                    cross a link at C2's acceptance: 0.38 / 0.55 / 0.71 at 2 / 4 / 8 ranks.  Needs
                                    nwalkers / 2 / shard_count to be a multiple of 16; not with KMC_P2P_FINEGRAINED /
-                                   KMC_P2P_FOLD_SIGNAL / kmc_sampler_init_ball. */
+                                   kmc_sampler_init_ball.  With KMC_P2P_FOLD_SIGNAL the half-step kernel writes its accept
+                                   bytes to the peers itself. */
     KMC_P2P_FOLD_SIGNAL = 1u << 8, /* with KMC_P2P: the half-step kernel itself publishes the progress flag (its stores are
                                       write-through; the last workgroup to drain them signals every rank) instead of a separate
                                       signal kernel after it: one kernel boundary less per half-step */

@@ -555,6 +555,7 @@ HalfStepArgs make_args(const kmc_sampler* s, int half, bool graph_mode, int64_t 
         a.lz_fetched = reinterpret_cast<uint32_t*>(s->d_lazy + 4 * hl);
         a.lz_modified = a.lz_fetched + P * 2 * hl;
         a.lz_stats = reinterpret_cast<unsigned long long*>(a.lz_modified + P * 2 * hl);
+        if (s->fold_signal) for (int r = 0; r < 8; ++r) a.lz_peer_amap[r] = s->peer_amap_in[r];
     }
     a.shard_stride = (int64_t)s->nrows * s->ld;
     a.n_active = (int32_t)s->h_loc;
@@ -1050,7 +1051,6 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         s->push = (cfg->flags & (KMC_P2P_PUSH | KMC_P2P_LAZY)) != 0 && s->plan.vec && s->user == nullptr && !(cfg->flags & KMC_P2P_FINEGRAINED) &&
                   s->cfg.shard_count > 1;
         s->lazy = s->push && (cfg->flags & KMC_P2P_LAZY) != 0 && s->h_loc % 16 == 0 && !s->f32;
-        if (s->lazy) s->fold_signal = false;             // the accept bytes travel with the signal kernel
     }
     // KMC_P2P_LAZY: room for every rank's accept-byte maps behind the row blocks (peers write them: same allocation)
     const size_t amap_bytes = s->lazy ? (size_t)s->cfg.shard_count * 4 * (size_t)s->h_loc : 0;

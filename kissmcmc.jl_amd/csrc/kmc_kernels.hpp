@@ -159,6 +159,8 @@ struct HalfStepArgs {
     uint32_t*         lz_fetched;      // [nranks][2][hloc]
     uint32_t*         lz_modified;     // [nranks][2][hloc]
     unsigned long long* lz_stats;      // [0] remote partner draws, [1] of them pulled over the fabric
+    unsigned char*    lz_peer_amap[8]; // with KMC_P2P_FOLD_SIGNAL: rank r's lz_amap_in -- the kernel writes its accept bytes
+                                       //   there itself (no signal kernel); all nullptr otherwise
 };
 
 // The fields a wave needs before it can issue its first loads travel as LEADING SCALAR kernel parameters, ahead
@@ -235,6 +237,15 @@ __device__ __forceinline__ void store_wt(uint32_t* p, uint32_t v)
 {
 #ifndef KMC_STORE_PLAIN
     asm volatile("global_store_dword %0, %1, off sc0 sc1\n\ts_nop 0" :: "v"(p), "v"(v) : "memory");
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ void store_wt(unsigned char* p, unsigned char v)
+{
+#ifndef KMC_STORE_PLAIN
+    const uint32_t t = v;
+    asm volatile("global_store_byte %0, %1, off sc0 sc1\n\ts_nop 0" :: "v"(p), "v"(t) : "memory");
 #else
     *p = v;
 #endif
@@ -695,7 +706,16 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
         if (do_mom) store_wt(&klast_p[rowA], sch.nbefore);
     }
     if constexpr (P2P) {
-        if (a.push == 2 && validA) a.lz_amap_out[(int64_t)(step & 3) * (int64_t)a.hloc + iA] = acc ? 1 : 0;
+        if (a.push == 2 && validA) {
+            const unsigned char byte = acc ? 1 : 0;
+            if (a.done_count == nullptr) {
+                a.lz_amap_out[(int64_t)(step & 3) * (int64_t)a.hloc + iA] = byte;       // the signal kernel forwards it
+            } else {                                                     // folded signal: straight to every peer
+                const int64_t at = ((int64_t)a.me * 4 + (int64_t)(step & 3)) * (int64_t)a.hloc + iA;
+                for (int r = 0; r < a.nranks; ++r)
+                    if (r != a.me) store_wt(&a.lz_peer_amap[r][at], byte);      // write-through: in the peer's memory once drained
+            }
+        }
     }
     const uint32_t wA = (acc && do_mom) ? sch.nbefore - kl : 0u;        // samples the replaced value stood for
     const bool any_w = __ballot(wA != 0u) != 0ull;

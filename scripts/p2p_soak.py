@@ -60,7 +60,7 @@ def main():
         pos, nacc, mom = s.positions(), s.naccept(), s.moments()
     bad = 0
     for world in (2, 4):
-        for fold, push, lazy in ((False, False, False), (True, False, False), (False, True, False), (True, True, False), (False, False, True)):
+        for fold, push, lazy in ((False, False, False), (True, False, False), (False, True, False), (True, True, False), (False, False, True), (True, False, True)):
             with tempfile.TemporaryDirectory() as d:
                 t0 = time.time()
                 mp.spawn(worker, args=(world, free_port(), d, fold, push, G, lazy), nprocs=world, join=True)

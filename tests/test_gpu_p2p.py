@@ -39,9 +39,9 @@ def _worker(rank, world, port, outdir, plan, late_rank=-1):
     from kissmcmc_jl_amd.distributed import P2PEmcee
     if plan == "rosen-ragged":
         return _worker_rosen(rank, world, port, outdir)
-    fold = plan in ("fold", "push-fold")
+    fold = plan in ("fold", "push-fold", "lazy-fold")
     push = plan in ("push", "push-fold")
-    lazy = plan == "lazy"
+    lazy = plan in ("lazy", "lazy-fold")
     if plan and not (fold or push or lazy):
         os.environ["KMC_PLAN"] = plan
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -110,7 +110,7 @@ def _free_port():
 
 
 @pytest.mark.parametrize("world,plan", [(2, ""), (4, ""), (2, "generic"), (2, "fold"), (4, "fold"), (2, "push"), (4, "push"),
-                                        (2, "push-fold"), (2, "lazy"), (4, "lazy")])   # the GPU box allows 6 processes on the card: parent + 4 ranks at most
+                                        (2, "push-fold"), (2, "lazy"), (4, "lazy"), (2, "lazy-fold"), (4, "lazy-fold")])   # the GPU box allows 6 processes on the card: parent + 4 ranks at most
 def test_p2p_processes_sharing_one_gpu_equal_oracle(oracle, tmp_path, world, plan):
     import torch.multiprocessing as mp
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), plan), nprocs=world, join=True)
