@@ -209,7 +209,11 @@ kmc_status  kmc_sampler_bind_positions(kmc_sampler* s, void* pos_dev);
  * second-half slice). */
 kmc_status  kmc_sampler_p2p_export(kmc_sampler* s, void* handle_out);
 kmc_status  kmc_sampler_p2p_connect(kmc_sampler* s, const void* handles /* [shard_count][KMC_P2P_HANDLE_BYTES] */);
-/* KMC_P2P_LAZY: counts since kmc_sampler_set_positions -- out[0] = partner draws that fell on another rank's rows,
+/* The same wiring for shards that live in ONE process on one device (no IPC): shards[r] = the sampler of shard r.
+   They run concurrently on their own streams like ranks on separate GPUs (single-process tests, timing, profiling). */
+kmc_status  kmc_sampler_p2p_connect_local(kmc_sampler* s, kmc_sampler* const* shards /* [shard_count] */);
+/* KMC_P2P_LAZY, sampler created with KMC_P2P_STATS=1 in the environment (diagnostics: the counting costs same-address
+   atomics; zeros otherwise): counts since kmc_sampler_set_positions -- out[0] = partner draws that fell on another rank's rows,
    out[1] = those of them that were pulled over the fabric (the others were served by the local copy). */
 kmc_status  kmc_sampler_p2p_stats(kmc_sampler* s, uint64_t out[2]);
 /* Upload the ensemble (host, [nwalkers][ndim], global order), evaluate the initial log-pdfs on

@@ -515,6 +515,7 @@ struct kmc_sampler {
     bool fold_signal = false;
     bool push = false;                                   // KMC_P2P_PUSH / KMC_P2P_LAZY: d_pos = (1 + shard_count) blocks, see HalfStepArgs::push
     bool lazy = false;                                   // KMC_P2P_LAZY: + accept-byte maps behind the blocks, stamps in d_lazy
+    bool lazy_stats = false;                             // KMC_P2P_STATS=1: count remote draws / pulls (kmc_sampler_p2p_stats)
     unsigned char* d_lazy = nullptr;                     // {amap_out[4][h_loc], fetched[P][2][h_loc] u32, modified[P][2][h_loc] u32}
     unsigned char* peer_amap_in[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     double* peer_pos[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -554,7 +555,7 @@ HalfStepArgs make_args(const kmc_sampler* s, int half, bool graph_mode, int64_t 
         a.lz_amap_out = s->d_lazy;
         a.lz_fetched = reinterpret_cast<uint32_t*>(s->d_lazy + 4 * hl);
         a.lz_modified = a.lz_fetched + P * 2 * hl;
-        a.lz_stats = reinterpret_cast<unsigned long long*>(a.lz_modified + P * 2 * hl);
+        a.lz_stats = s->lazy_stats ? reinterpret_cast<unsigned long long*>(a.lz_modified + P * 2 * hl) : nullptr;
         if (s->fold_signal) for (int r = 0; r < 8; ++r) a.lz_peer_amap[r] = s->peer_amap_in[r];
     }
     a.shard_stride = (int64_t)s->nrows * s->ld;
@@ -1051,6 +1052,7 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         s->push = (cfg->flags & (KMC_P2P_PUSH | KMC_P2P_LAZY)) != 0 && s->plan.vec && s->user == nullptr && !(cfg->flags & KMC_P2P_FINEGRAINED) &&
                   s->cfg.shard_count > 1;
         s->lazy = s->push && (cfg->flags & KMC_P2P_LAZY) != 0 && s->h_loc % 16 == 0 && !s->f32;
+        if (const char* e = std::getenv("KMC_P2P_STATS")) s->lazy_stats = s->lazy && e[0] == '1';
     }
     // KMC_P2P_LAZY: room for every rank's accept-byte maps behind the row blocks (peers write them: same allocation)
     const size_t amap_bytes = s->lazy ? (size_t)s->cfg.shard_count * 4 * (size_t)s->h_loc : 0;
@@ -1256,6 +1258,26 @@ KMC_EXPORT kmc_status kmc_sampler_p2p_connect(kmc_sampler* s, const void* handle
             s->peer_amap_in[r] = static_cast<unsigned char*>(p) + (size_t)(1 + s->cfg.shard_count) * (size_t)s->nrows * (size_t)s->ld * sizeof(double);
         HIP_TRY(hipIpcOpenMemHandle(&p, h[r].flags, hipIpcMemLazyEnablePeerAccess));
         s->peer_flags[r] = static_cast<unsigned long long*>(p);
+    }
+    s->connected = true;
+    return KMC_OK;
+}
+
+// All the shards in ONE process (and, here, on one device): wire the peers' buffers directly, no IPC.  The shards
+// then run concurrently on their own streams exactly like ranks on separate GPUs -- for single-process tests,
+// timing and profiling of the exchange variants.
+KMC_EXPORT kmc_status kmc_sampler_p2p_connect_local(kmc_sampler* s, kmc_sampler* const* shards)
+{
+    if (!s || !shards) return fail(KMC_ERR_BAD_ARG, "null argument");
+    if (!s->p2p) return fail(KMC_ERR_BAD_ARG, "sampler was created without KMC_P2P");
+    for (int r = 0; r < s->cfg.shard_count; ++r) {
+        const kmc_sampler* o = shards[r];
+        if (!o || !o->p2p || o->cfg.shard_count != s->cfg.shard_count || o->cfg.shard_rank != r || o->cfg.device != s->cfg.device ||
+            o->nrows != s->nrows || o->ld != s->ld || o->lazy != s->lazy || o->push != s->push)
+            return fail(KMC_ERR_BAD_ARG, "kmc_sampler_p2p_connect_local: shards[r] must be shard r of the same configuration on the same device");
+        s->peer_pos[r] = o->d_pos;
+        s->peer_flags[r] = o->d_flags;
+        s->peer_amap_in[r] = o->peer_amap_in[r];
     }
     s->connected = true;
     return KMC_OK;

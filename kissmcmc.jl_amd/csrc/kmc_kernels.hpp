@@ -158,7 +158,7 @@ struct HalfStepArgs {
     unsigned char*    lz_amap_out;     // [4][hloc]
     uint32_t*         lz_fetched;      // [nranks][2][hloc]
     uint32_t*         lz_modified;     // [nranks][2][hloc]
-    unsigned long long* lz_stats;      // [0] remote partner draws, [1] of them pulled over the fabric
+    unsigned long long* lz_stats;      // diagnostics, or nullptr: [0] remote partner draws, [1] of them pulled over the fabric
     unsigned char*    lz_peer_amap[8]; // with KMC_P2P_FOLD_SIGNAL: rank r's lz_amap_in -- the kernel writes its accept bytes
                                        //   there itself (no signal kernel); all nullptr otherwise
 };
@@ -510,24 +510,51 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
     //      logarithm: measured best at C2 (all loads first: +0.15 us per half-step; loads after both logs: same),
     //      and pinned with scheduling barriers because the compiler's own placement moves with unrelated edits ----
     unsigned long long addrA = 0ull;                                    // P2P: the partner row's address
-    unsigned long long addrS = 0ull;                                    // KMC_P2P_LAZY: where a pulled row goes in the local shadow
-    unsigned long long shadowB[ITER];
+    unsigned long long shadowB[ITER];                                   // KMC_P2P_LAZY: where a pulled row goes in the local shadow (0: not pulled)
+    auto load_partner_rows = [&](int it) {
+        const V2* oth;
+        if constexpr (!P2P) {
+            const uint32_t partner = (uint32_t)__builtin_amdgcn_ds_bpermute((gbase + it) * 4, (int)partnerA);
+            oth = reinterpret_cast<const V2*>(posT + (oth_row0 + partner) * ld);
+        } else {
+            const int src = (gbase + it) * 4;
+            const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)(unsigned)addrA);
+            const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)(unsigned)(addrA >> 32));
+            shadowB[it] = ((unsigned long long)hi << 32) | lo;          // (lazy: the local copy's address, kept or zeroed below)
+            oth = reinterpret_cast<const V2*>(shadowB[it]);
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) xo[it][k] = cv[k] ? load_row(&oth[k * L + j]) : zero2;
+    };
+    bool lazy = false;
     if constexpr (P2P) {
+        lazy = a.push == 2;
         // owner rank and row of the partner, resolved once per walker; the row address travels
         const uint32_t q = a.hloc_shift >= 0 ? partnerA >> a.hloc_shift : partnerA / a.hloc;
         const uint32_t r = partnerA - q * a.hloc;
         const double* base = a.peer_pos[0];
 #pragma unroll
         for (int t = 1; t < 8; ++t) base = (q == (uint32_t)t) ? a.peer_pos[t] : base;
+        const double* remote_base = base;
         if (a.push) base = (q == (uint32_t)a.me) ? a.pos : a.pos + (int64_t)(1u + q) * a.shard_stride;   // local copy of rank q's shard
         addrA = (unsigned long long)(base + (oth_row0 + r) * ld);
+        // KMC_P2P_LAZY: the local copies and this reader's stamps do not depend on the peers' progress -- request them
+        // now, speculatively; whether a copy is still good is decided after the wait (newest accept bytes)
+        const bool remoteA = lazy && q != (uint32_t)a.me && validA;
+        const int64_t xs = ((int64_t)q * 2 + (1 - half)) * (int64_t)a.hloc + r;
+        uint32_t fe = 0u, mo = 0u;
+        if (remoteA) { fe = a.lz_fetched[xs]; mo = a.lz_modified[xs]; }
+        if (lazy) {
+#pragma unroll
+            for (int it = 0; it < ITER; ++it) load_partner_rows(it);
+        }
         if (a.nranks > 1) {
             // every rank must have finished half-step `step - 1`: one polling wave per workgroup (the
             // flags sit in uncached fine-grained memory), the other waves wait at the barrier
             if ((threadIdx.x >> 6) == 0) wait_for_peers(a, step, lane);
             __syncthreads();
         }
-        if (a.push == 2) {                                              // KMC_P2P_LAZY
+        if (lazy) {
             const uint32_t stamp = (uint32_t)step + 1u;
             const int64_t hl = (int64_t)a.hloc;
             if (step > 0) {
@@ -545,53 +572,43 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
                     }
                 }
             }
-            // this walker's partner: from the local shadow unless the owner's copy is newer
-            bool remote = false, pulled = false;
-            if (q != (uint32_t)a.me && validA) {
-                remote = true;
-                const int64_t x = ((int64_t)q * 2 + (1 - half)) * hl + r;
-                const uint32_t fe = a.lz_fetched[x], mo = a.lz_modified[x];
+            // this walker's partner: the local copy unless the owner's row is newer -- then from the owner, again
+            unsigned long long addrR = 0ull;
+            if (remoteA) {
                 const unsigned am = step > 0 ? a.lz_amap_in[((int64_t)q * 4 + (int64_t)((step - 1) & 3)) * hl + r] : 0u;
                 if (am != 0u || mo > fe || fe == stamp) {
-                    addrS = addrA;                                      // (push != 0: addrA is the shadow row)
-                    const double* rb = a.peer_pos[0];
-#pragma unroll
-                    for (int t = 1; t < 8; ++t) rb = (q == (uint32_t)t) ? a.peer_pos[t] : rb;
-                    addrA = (unsigned long long)(rb + (oth_row0 + r) * ld);
-                    a.lz_fetched[x] = stamp;
-                    pulled = true;
+                    addrR = (unsigned long long)(remote_base + (oth_row0 + r) * ld);
+                    a.lz_fetched[xs] = stamp;
                 }
             }
-            const unsigned long long nrem = __ballot(remote), npul = __ballot(pulled);
-            if (lane == 0 && nrem != 0ull) {
-                atomicAdd(&a.lz_stats[0], (unsigned long long)__popcll(nrem));
-                if (npul != 0ull) atomicAdd(&a.lz_stats[1], (unsigned long long)__popcll(npul));
+            if (a.lz_stats != nullptr) {                                 // diagnostics only (KMC_P2P_STATS=1): same-address atomics
+                const unsigned long long nrem = __ballot(remoteA), npul = __ballot(addrR != 0ull);
+                if (lane == 0 && nrem != 0ull) {
+                    atomicAdd(&a.lz_stats[0], (unsigned long long)__popcll(nrem));
+                    if (npul != 0ull) atomicAdd(&a.lz_stats[1], (unsigned long long)__popcll(npul));
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < ITER; ++it) {
+                const int src = (gbase + it) * 4;
+                const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)(unsigned)addrR);
+                const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)(unsigned)(addrR >> 32));
+                const unsigned long long rem = ((unsigned long long)hi << 32) | lo;
+                if (rem != 0ull) {
+                    const V2* oth = reinterpret_cast<const V2*>(rem);
+#pragma unroll
+                    for (int k = 0; k < K; ++k) xo[it][k] = cv[k] ? load_row(&oth[k * L + j]) : zero2;
+                } else {
+                    shadowB[it] = 0ull;                                  // the copy was good: nothing to write back
+                }
             }
         }
     }
-    auto load_partner_rows = [&](int it) {
-        const V2* oth;
-        if constexpr (!P2P) {
-            const uint32_t partner = (uint32_t)__builtin_amdgcn_ds_bpermute((gbase + it) * 4, (int)partnerA);
-            oth = reinterpret_cast<const V2*>(posT + (oth_row0 + partner) * ld);
-        } else {
-            const int src = (gbase + it) * 4;
-            const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)(unsigned)addrA);
-            const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)(unsigned)(addrA >> 32));
-            oth = reinterpret_cast<const V2*>(((unsigned long long)hi << 32) | lo);
-            shadowB[it] = 0ull;
-            if (a.push == 2) {
-                const unsigned slo = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)(unsigned)addrS);
-                const unsigned shi = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)(unsigned)(addrS >> 32));
-                shadowB[it] = ((unsigned long long)shi << 32) | slo;
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < K; ++k) xo[it][k] = cv[k] ? load_row(&oth[k * L + j]) : zero2;
-    };
     constexpr int kFirst = ITER >= 2 ? ITER / 2 : ITER;                 // iterations whose loads precede the first logarithm
+    if (!lazy) {
 #pragma unroll
-    for (int it = 0; it < kFirst; ++it) load_partner_rows(it);
+        for (int it = 0; it < kFirst; ++it) load_partner_rows(it);
+    }
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- from here on the argument struct: one scalar round trip for all of it (have every field the kernel
@@ -653,8 +670,10 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
         dr.t1 = dc.nm1 * log_pos_normal(dr.z);
     }
     __builtin_amdgcn_sched_barrier(0);
+    if (!lazy) {
 #pragma unroll
-    for (int it = kFirst; it < ITER; ++it) load_partner_rows(it);
+        for (int it = kFirst; it < ITER; ++it) load_partner_rows(it);
+    }
     __builtin_amdgcn_sched_barrier(0);
     if (!fresh) {
         dr.lu = log_pos_normal(ua);                                     // :260

@@ -114,6 +114,13 @@ class Sampler:
         """Use a caller-owned device buffer (``double [nwalkers][ndim]``) for the ensemble."""
         _lib.check(self._L.kmc_sampler_bind_positions(self._h, C.c_void_p(device_ptr)))
 
+    @staticmethod
+    def p2p_connect_local(shards):
+        """Wire KMC_P2P samplers that live in this process (``shards[r]`` = shard r, same device) to each other."""
+        arr = (C.c_void_p * len(shards))(*[s._h for s in shards])
+        for s in shards:
+            _lib.check(s._L.kmc_sampler_p2p_connect_local(s._h, arr))
+
     def p2p_stats(self):
         """KMC_P2P_LAZY: (partner draws on other ranks' rows, those pulled over the fabric) since set_positions."""
         v = (C.c_uint64 * 2)()

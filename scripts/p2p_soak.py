@@ -1,6 +1,6 @@
 """Soak of the peer-to-peer exchange variants on ONE GPU (processes share the card; IPC handles, flags and peer-mapped
 rows are the ones an 8-GPU node uses): every variant x {2, 4} ranks runs G generations of an 8192 x 32 ensemble and
-must end in exactly the state of the unsharded run.  Usage (GPU box): python scripts/p2p_soak.py [G]"""
+must end in exactly the state of the unsharded run.  Usage (GPU box): python scripts/p2p_soak.py [G] [--stats]"""
 import os
 import socket
 import sys
@@ -8,6 +8,8 @@ import tempfile
 import time
 
 import numpy as np
+
+os.environ.setdefault("KMC_P2P_STATS", "1" if "--stats" in sys.argv else "0")
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -34,7 +36,8 @@ def worker(rank, world, port, outdir, fold, push, G, lazy=False):
         pos, nacc = drv.positions(), drv.naccept()
         if lazy:
             rem, pul = drv.sampler.p2p_stats()
-            print(f"   rank {rank}: {rem} remote partner draws, {pul} pulled over the fabric ({pul / max(1, rem):.3f})", flush=True)
+            if rem:
+                print(f"   rank {rank}: {rem} remote partner draws, {pul} pulled over the fabric ({pul / rem:.3f})", flush=True)
         s, q, n = drv.moments()
         if rank == 0:
             np.savez(os.path.join(outdir, "out.npz"), pos=pos, nacc=nacc, s=s, n=n)

@@ -218,3 +218,31 @@ def test_p2p_with_finegrained_rows(oracle, tmp_path):
     z = np.load(os.path.join(str(tmp_path), "fine.npz"))
     np.testing.assert_array_equal(z["nacc"], ref["naccept"])
     np.testing.assert_array_equal(z["pos"], ref["final_pos"])
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(p2p_push=True), dict(p2p_lazy=True), dict(p2p_lazy=True, p2p_fold=True)],
+                         ids=["pull", "push", "lazy", "lazy-fold"])
+def test_two_shards_in_one_process(kmc, oracle, kw):
+    """kmc_sampler_p2p_connect_local: both shards live in this process and run concurrently on their own streams,
+    ordered by the same progress flags (what scripts/p2p_local_bench.py times); result = the oracle's."""
+    th = _theta0()
+    G = 128         # whole hipGraph chunks only: eager launches of two streams of ONE process are not reliably concurrent
+    shards = [kmc.Sampler(kmc.GaussianIso(), NW, ND, G, NBURN, 1, 2.0, SEED, moments=True, shard_rank=r, shard_count=2, p2p=True, **kw)
+              for r in range(2)]
+    try:
+        kmc.Sampler.p2p_connect_local(shards)
+        for sh in shards:
+            sh.set_positions(th)
+        for sh in shards:
+            sh.run(G)
+        for sh in shards:
+            sh.sync()
+        from kissmcmc_jl_amd.distributed import local_to_global
+        pos = local_to_global([sh.positions() for sh in shards], NW, 2)
+        nacc = local_to_global([sh.naccept() for sh in shards], NW, 2)
+    finally:
+        for sh in shards:
+            sh.close()
+    ref = oracle.emcee(oracle.make_config(oracle.GAUSSIAN_ISO, [0.0, 1.0], NW, ND, G, NBURN, 1, 2.0, SEED), th, store_chain=False)
+    np.testing.assert_array_equal(pos, ref["final_pos"])
+    np.testing.assert_array_equal(nacc, ref["naccept"])
