@@ -516,7 +516,7 @@ struct kmc_sampler {
     bool push = false;                                   // KMC_P2P_PUSH / KMC_P2P_LAZY: d_pos = (1 + shard_count) blocks, see HalfStepArgs::push
     bool lazy = false;                                   // KMC_P2P_LAZY: + accept-byte maps behind the blocks, stamps in d_lazy
     bool lazy_stats = false;                             // KMC_P2P_STATS=1: count remote draws / pulls (kmc_sampler_p2p_stats)
-    unsigned char* d_lazy = nullptr;                     // {amap_out[4][h_loc], fetched[P][2][h_loc] u32, modified[P][2][h_loc] u32}
+    unsigned char* d_lazy = nullptr;                     // {stamps[P][2][h_loc] {fetched, modified}, stats[2]}
     unsigned char* peer_amap_in[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     double* peer_pos[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     unsigned long long* peer_flags[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -552,11 +552,9 @@ HalfStepArgs make_args(const kmc_sampler* s, int half, bool graph_mode, int64_t 
     if (s->lazy) {
         const size_t hl = (size_t)s->h_loc, P = (size_t)s->cfg.shard_count;
         a.lz_amap_in = s->peer_amap_in[s->cfg.shard_rank];
-        a.lz_amap_out = s->d_lazy;
-        a.lz_fetched = reinterpret_cast<uint32_t*>(s->d_lazy + 4 * hl);
-        a.lz_modified = a.lz_fetched + P * 2 * hl;
-        a.lz_stats = s->lazy_stats ? reinterpret_cast<unsigned long long*>(a.lz_modified + P * 2 * hl) : nullptr;
-        if (s->fold_signal) for (int r = 0; r < 8; ++r) a.lz_peer_amap[r] = s->peer_amap_in[r];
+        a.lz_stamps = reinterpret_cast<uint2*>(s->d_lazy);
+        a.lz_stats = s->lazy_stats ? reinterpret_cast<unsigned long long*>(a.lz_stamps + P * 2 * hl) : nullptr;
+        for (int r = 0; r < 8; ++r) a.lz_peer_amap[r] = s->peer_amap_in[r];
     }
     a.shard_stride = (int64_t)s->nrows * s->ld;
     a.n_active = (int32_t)s->h_loc;
@@ -627,12 +625,7 @@ kmc_status launch_half(kmc_sampler* s, int half, bool graph_mode, int64_t gen_of
         sg.sched_inline = a.sched_inline;
         sg.sched_index = a.sched_index;
         sg.half = half;
-        if (s->lazy) {
-            sg.amap_out = s->d_lazy;
-            for (int r = 0; r < 8; ++r) sg.peer_amap_in[r] = s->peer_amap_in[r];
-            sg.hloc = s->h_loc;
-        }
-        hipLaunchKernelGGL(p2p_signal, dim3(1), dim3(s->lazy ? 256 : 64), 0, s->stream, sg);
+        hipLaunchKernelGGL(p2p_signal, dim3(1), dim3(64), 0, s->stream, sg);
         HIP_TRY(hipGetLastError());
     }
     return KMC_OK;
@@ -1065,7 +1058,7 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
     CREATE_TRY(hipMemset(s->d_pos, 0, (s->push ? 1 + (size_t)s->cfg.shard_count : 1) * nw * ldz * esz + amap_bytes));   // the pad column of odd ndim stays 0
     if (s->lazy) {
         const size_t P = (size_t)s->cfg.shard_count, hl = (size_t)s->h_loc;
-        const size_t nb = 4 * hl + 2 * P * 2 * hl * sizeof(uint32_t) + 16;
+        const size_t nb = 2 * P * 2 * hl * sizeof(uint32_t) + 16;
         CREATE_TRY(hipMalloc((void**)&s->d_lazy, nb));
         CREATE_TRY(hipMemset(s->d_lazy, 0, nb));
         s->peer_amap_in[s->cfg.shard_rank] = reinterpret_cast<unsigned char*>(s->d_pos) + (1 + P) * nw * ldz * esz;
@@ -1292,7 +1285,7 @@ KMC_EXPORT kmc_status kmc_sampler_p2p_stats(kmc_sampler* s, uint64_t out[2])
     HIP_TRY(hipStreamSynchronize(s->stream));
     const size_t hl = (size_t)s->h_loc, P = (size_t)s->cfg.shard_count;
     unsigned long long v[2] = {0ull, 0ull};
-    HIP_TRY(hipMemcpy(v, s->d_lazy + 4 * hl + 2 * P * 2 * hl * sizeof(uint32_t), sizeof(v), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(v, s->d_lazy + 2 * P * 2 * hl * sizeof(uint32_t), sizeof(v), hipMemcpyDeviceToHost));
     out[0] = v[0]; out[1] = v[1];
     return KMC_OK;
 }
@@ -1497,7 +1490,7 @@ KMC_EXPORT kmc_status kmc_sampler_set_positions(kmc_sampler* s, const double* th
         if (s->d_done) HIP_TRY(hipMemset(s->d_done, 0, 64));
         if (s->lazy) {                               // every shadow is current, nothing has been accepted yet
             const size_t P = (size_t)s->cfg.shard_count, hl = (size_t)s->h_loc;
-            HIP_TRY(hipMemset(s->d_lazy, 0, 4 * hl + 2 * P * 2 * hl * sizeof(uint32_t) + 16));
+            HIP_TRY(hipMemset(s->d_lazy, 0, 2 * P * 2 * hl * sizeof(uint32_t) + 16));
             HIP_TRY(hipMemset(s->peer_amap_in[s->cfg.shard_rank], 0, P * 4 * hl));
         }
     }

@@ -148,19 +148,16 @@ struct HalfStepArgs {
     const uint32_t*   mswept;       // [waves]
     int32_t           mring_depth;
     // KMC_P2P_LAZY (push == 2): the shadow blocks of KMC_P2P_PUSH, filled on demand.  Nobody pushes rows; a rank
-    // publishes the ACCEPT BYTES of each half-step instead (one byte per active walker, copied into every peer's
-    // lz_amap_in by the signal kernel, slot = step & 3), and a reader pulls a drawn remote row only when its shadow
+    // publishes the ACCEPT BYTES of each half-step instead (one byte per active walker, written into every peer's
+    // lz_amap_in by the half-step kernel, slot = step & 3), and a reader pulls a drawn remote row only when its shadow
     // copy is older than the row's last accept -- it then keeps the row in the shadow.  Per remote row the reader
-    // holds two stamps (step + 1; 0 = never): lz_modified, the last accept it has heard of (absorbed from the byte
-    // maps, one launch late), and lz_fetched, its last pull.  A row is pulled when the newest map flags it, when
+    // holds two stamps (step + 1; 0 = never; lz_stamps): modified, the last accept it has heard of (absorbed from the byte
+    // maps, one launch late), and fetched, its last pull.  A row is pulled when the newest map flags it, when
     // modified > fetched, or when fetched carries THIS step (another wave is rewriting the shadow right now).
     const unsigned char* lz_amap_in;   // [nranks][4][hloc]  (inside the exported row allocation: peers write it)
-    unsigned char*    lz_amap_out;     // [4][hloc]
-    uint32_t*         lz_fetched;      // [nranks][2][hloc]
-    uint32_t*         lz_modified;     // [nranks][2][hloc]
+    uint2*            lz_stamps;       // [nranks][2][hloc] {x: fetched, y: modified} -- one 8-byte load per walker-step
     unsigned long long* lz_stats;      // diagnostics, or nullptr: [0] remote partner draws, [1] of them pulled over the fabric
-    unsigned char*    lz_peer_amap[8]; // with KMC_P2P_FOLD_SIGNAL: rank r's lz_amap_in -- the kernel writes its accept bytes
-                                       //   there itself (no signal kernel); all nullptr otherwise
+    unsigned char*    lz_peer_amap[8]; // rank r's lz_amap_in: the kernel writes its accept bytes there itself
 };
 
 // The fields a wave needs before it can issue its first loads travel as LEADING SCALAR kernel parameters, ahead
@@ -543,7 +540,7 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
         const bool remoteA = lazy && q != (uint32_t)a.me && validA;
         const int64_t xs = ((int64_t)q * 2 + (1 - half)) * (int64_t)a.hloc + r;
         uint32_t fe = 0u, mo = 0u;
-        if (remoteA) { fe = a.lz_fetched[xs]; mo = a.lz_modified[xs]; }
+        if (remoteA) { const uint2 st = a.lz_stamps[xs]; fe = st.x; mo = st.y; }
         if (lazy) {
 #pragma unroll
             for (int it = 0; it < ITER; ++it) load_partner_rows(it);
@@ -566,9 +563,9 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
                     if (qq == a.me) continue;
                     const uint32_t word = maps[(qq * 4 + (int64_t)((step - 1) & 3)) * wpr + ww];
                     if (word != 0u) {
-                        uint32_t* m = a.lz_modified + (qq * 2 + (1 - half)) * hl + 4 * ww;
+                        uint2* m = a.lz_stamps + (qq * 2 + (1 - half)) * hl + 4 * ww;
 #pragma unroll
-                        for (int b = 0; b < 4; ++b) if ((word >> (8 * b)) & 0xffu) m[b] = (uint32_t)step;     // = (step - 1) + 1
+                        for (int b = 0; b < 4; ++b) if ((word >> (8 * b)) & 0xffu) m[b].y = (uint32_t)step;   // = (step - 1) + 1
                     }
                 }
             }
@@ -578,7 +575,7 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
                 const unsigned am = step > 0 ? a.lz_amap_in[((int64_t)q * 4 + (int64_t)((step - 1) & 3)) * hl + r] : 0u;
                 if (am != 0u || mo > fe || fe == stamp) {
                     addrR = (unsigned long long)(remote_base + (oth_row0 + r) * ld);
-                    a.lz_fetched[xs] = stamp;
+                    a.lz_stamps[xs].x = stamp;
                 }
             }
             if (a.lz_stats != nullptr) {                                 // diagnostics only (KMC_P2P_STATS=1): same-address atomics
@@ -726,14 +723,12 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
     }
     if constexpr (P2P) {
         if (a.push == 2 && validA) {
+            // straight into every peer's map (write-through: in the peer's memory once drained, i.e. before this
+            // half-step's progress flag -- from the signal kernel one boundary later, or from this kernel's last workgroup)
             const unsigned char byte = acc ? 1 : 0;
-            if (a.done_count == nullptr) {
-                a.lz_amap_out[(int64_t)(step & 3) * (int64_t)a.hloc + iA] = byte;       // the signal kernel forwards it
-            } else {                                                     // folded signal: straight to every peer
-                const int64_t at = ((int64_t)a.me * 4 + (int64_t)(step & 3)) * (int64_t)a.hloc + iA;
-                for (int r = 0; r < a.nranks; ++r)
-                    if (r != a.me) store_wt(&a.lz_peer_amap[r][at], byte);      // write-through: in the peer's memory once drained
-            }
+            const int64_t at = ((int64_t)a.me * 4 + (int64_t)(step & 3)) * (int64_t)a.hloc + iA;
+            for (int r = 0; r < a.nranks; ++r)
+                if (r != a.me) store_wt(&a.lz_peer_amap[r][at], byte);
         }
     }
     const uint32_t wA = (acc && do_mom) ? sch.nbefore - kl : 0u;        // samples the replaced value stood for
@@ -1002,10 +997,6 @@ struct SignalArgs {
     SchedEntry          sched_inline;
     int32_t             sched_index;
     int32_t             half;
-    // KMC_P2P_LAZY: this half-step's accept bytes go to every peer before the flag
-    const unsigned char* amap_out;      // [4][hloc] or nullptr
-    unsigned char*      peer_amap_in[8]; // peer r's lz_amap_in
-    int64_t             hloc;
 };
 // Device-side make_theta0s (reference src/samplers.jl:311-349, the intended behaviour): walker w gets
 // theta0 + N(0, diag(r^2)), redrawn while its log-pdf is -inf -- up to `ntries` draws per ball size,
@@ -1117,17 +1108,7 @@ __global__ void p2p_signal(const SignalArgs a)
 {
     const SchedEntry sch = a.sched_index >= 0 ? a.sched_table[a.sched_index] : a.sched_inline;
     const unsigned long long done = 2ull * (unsigned long long)sch.gen + (unsigned long long)a.half + 1ull;
-    if (a.amap_out != nullptr) {
-        const int64_t slot = (int64_t)((done - 1ull) & 3ull);
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(a.amap_out + slot * a.hloc);
-        for (int r = 0; r < a.nranks; ++r) {
-            if (r == a.me) continue;
-            uint32_t* dst = reinterpret_cast<uint32_t*>(a.peer_amap_in[r] + ((int64_t)a.me * 4 + slot) * a.hloc);
-            for (int64_t w = threadIdx.x; w < a.hloc / 4; w += blockDim.x) dst[w] = src[w];
-        }
-    }
     __threadfence_system();
-    if (a.amap_out != nullptr) __syncthreads();          // every thread's bytes are out before the flags
     if ((int)threadIdx.x < a.nranks)
         __hip_atomic_store(a.peer_flags[threadIdx.x] + a.me, done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
