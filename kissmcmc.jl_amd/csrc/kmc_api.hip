@@ -1038,8 +1038,8 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         CREATE_TRY(hipMemset(s->d_flags, 0, 4096));
         CREATE_TRY(hipMalloc((void**)&s->d_err, 64));
         CREATE_TRY(hipMemset(s->d_err, 0, 64));
-        CREATE_TRY(hipMalloc((void**)&s->d_done, 64));
-        CREATE_TRY(hipMemset(s->d_done, 0, 64));
+        CREATE_TRY(hipMalloc((void**)&s->d_done, 33 * 64));
+        CREATE_TRY(hipMemset(s->d_done, 0, 33 * 64));
         // the kernel can publish its own completion only where all its stores are write-through: the vector kernels
         s->fold_signal = (cfg->flags & KMC_P2P_FOLD_SIGNAL) != 0 && s->plan.vec && s->user == nullptr;
         s->push = (cfg->flags & (KMC_P2P_PUSH | KMC_P2P_LAZY)) != 0 && s->plan.vec && s->user == nullptr && !(cfg->flags & KMC_P2P_FINEGRAINED) &&
@@ -1427,7 +1427,7 @@ KMC_EXPORT kmc_status kmc_sampler_init_ball(kmc_sampler* s, const double* theta0
     if (s->p2p) {
         HIP_TRY(hipMemset(s->d_flags, 0, 4096));
         HIP_TRY(hipMemset(s->d_err, 0, 64));
-        if (s->d_done) HIP_TRY(hipMemset(s->d_done, 0, 64));
+        if (s->d_done) HIP_TRY(hipMemset(s->d_done, 0, 33 * 64));
     }
     s->dev_gen = 0;
     s->moment_base = 0;
@@ -1455,7 +1455,7 @@ KMC_EXPORT kmc_status kmc_sampler_set_state(kmc_sampler* s, const double* pos_ho
     if (s->p2p) {
         HIP_TRY(hipMemset(s->d_flags, 0, 4096));
         HIP_TRY(hipMemset(s->d_err, 0, 64));
-        if (s->d_done) HIP_TRY(hipMemset(s->d_done, 0, 64));
+        if (s->d_done) HIP_TRY(hipMemset(s->d_done, 0, 33 * 64));
     }
     s->generation = generation;            // the device counter follows at the next graph replay
     const int64_t done = samples_done(s);
@@ -1487,7 +1487,7 @@ KMC_EXPORT kmc_status kmc_sampler_set_positions(kmc_sampler* s, const double* th
         }
         HIP_TRY(hipMemset(s->d_flags, 0, 4096));     // callers barrier across ranks before running
         HIP_TRY(hipMemset(s->d_err, 0, 64));
-        if (s->d_done) HIP_TRY(hipMemset(s->d_done, 0, 64));
+        if (s->d_done) HIP_TRY(hipMemset(s->d_done, 0, 33 * 64));
         if (s->lazy) {                               // every shadow is current, nothing has been accepted yet
             const size_t P = (size_t)s->cfg.shard_count, hl = (size_t)s->h_loc;
             HIP_TRY(hipMemset(s->d_lazy, 0, 2 * P * 2 * hl * sizeof(uint32_t) + 16));
