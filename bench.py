@@ -201,7 +201,7 @@ def main():
                 return None
             return d
 
-        def time_short(d, gens=256):
+        def time_short(d, gens=1024):       # long enough to reach the steady state of the replayed graphs (16 chunks)
             """Seconds for `gens` generations (max over ranks), from a common start."""
             d.set_positions(th)
             dist.barrier()
@@ -248,7 +248,7 @@ def main():
                 if drv is not None:
                     p2p_memory = "pull of drawn rows, fine-grained memory, signal kernel"
             if rank == 0 and tried:
-                print("[rank 0] p2p variants, s per 256 generations: " + "; ".join(f"{l}: {t:.4f}" for l, t in tried), file=sys.stderr)
+                print("[rank 0] p2p variants, s per 1024 generations: " + "; ".join(f"{l}: {t:.4f}" for l, t in tried), file=sys.stderr)
             if drv is None:
                 if rank == 0:
                     print("[rank 0] falling back to the RCCL all-gather exchange", file=sys.stderr)
@@ -349,7 +349,7 @@ def main():
                              "bytes_per_link_per_launch": rows_per_peer * NDIM * 8,
                              "link_bound_us_at_77GBs": rows_per_peer * NDIM * 8 / 77e9 * 1e6,
                              "push_bytes_per_link_per_launch": acc * walkers_per_launch * NDIM * 8,
-                             "variants_us_per_launch": {label: tc / 512 * 1e6 for label, tc in tried},   # 256 generations each
+                             "variants_us_per_launch": {label: tc / 2048 * 1e6 for label, tc in tried},   # 1024 generations each
                              "lazy_pulled_fraction_rank0": (lazy_stats[1] / lazy_stats[0]) if (mode == "p2p" and lazy_stats[0]) else None,
                              "note": "pull variants move every drawn row once (bytes_per_link from each peer); push variants move "
                                      "accepted rows only (push_bytes_per_link to each peer); link figure = one xGMI link, one "
