@@ -1,7 +1,9 @@
 """The peer-to-peer exchange variants with all shards in ONE process on one GPU (kmc_sampler_p2p_connect_local): the
 shards run concurrently on their own streams, ordered by the same progress flags, so kernel cost and protocol overhead
 of the variants can be compared (and profiled) without processes time-slicing the card.  "Remote" rows are local here:
-this measures everything except the fabric.  Usage: python scripts/p2p_local_bench.py [world] [walkers_per_shard] [G] [--stats]"""
+this measures everything except the fabric.  One host thread enqueues the shards one after the other, so G must stay
+small enough for a whole run to fit the launch queues (a few thousand generations), or the first shard blocks the host
+while it waits for the second.  Usage: python scripts/p2p_local_bench.py [world] [walkers_per_shard] [G] [--stats]"""
 import os
 import sys
 import time
