@@ -57,6 +57,7 @@ kmc_status fail(kmc_status st, const std::string& msg)
     } while (0)
 
 constexpr int64_t kGraphChunk = 64;   // generations per hipGraph replay (128 kernel nodes + 1)
+constexpr int kUExec = 6;             // executables of the "updated graph" launch mode (kmc_sampler::uexec)
 
 
 struct Plan {
@@ -472,12 +473,14 @@ struct kmc_sampler {
     hipGraphExec_t graph_exec = nullptr;
     hipGraph_t graph = nullptr;
     // "updated graph": a chain of kGraphChunk * 2 kernel nodes launched in the eager form (step among the preloaded
-    // parameters, schedule entry in the args), their parameters rewritten before every replay; two executables
-    // alternate so that one is updated while the other runs
+    // parameters, schedule entry in the args), their parameters rewritten before every replay; kUExec executables
+    // take turns, so the host updates up to kUExec - 1 replays ahead of the one that is running (two were enough for
+    // a quiet host -- the update of 128 nodes takes about as long as their replay -- but left a single replay of
+    // slack: one scheduling hiccup of the host process starved the GPU, 4.27 instead of 3.8 us per launch in one run)
     hipGraph_t ugraph = nullptr;
-    hipGraphExec_t uexec[2] = {nullptr, nullptr};
-    hipEvent_t udone[2] = {nullptr, nullptr};
-    bool uinflight[2] = {false, false};
+    hipGraphExec_t uexec[kUExec] = {};
+    hipEvent_t udone[kUExec] = {};
+    bool uinflight[kUExec] = {};
     int unext = 0;
     std::vector<hipGraphNode_t> unodes;
     int64_t uchunk = 64;      // generations per replay of the updated graph
@@ -740,7 +743,7 @@ kmc_status ensure_updated_graph(kmc_sampler* s)
             s->unodes[(size_t)(2 * g + half)] = node;
             prev = node;
         }
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < kUExec; ++i) {
         HIP_TRY(hipGraphInstantiate(&s->uexec[i], s->ugraph, nullptr, nullptr, 0));
         HIP_TRY(hipEventCreateWithFlags(&s->udone[i], hipEventDisableTiming));
     }
@@ -765,7 +768,7 @@ kmc_status launch_updated_graph(kmc_sampler* s)
     HIP_TRY(hipGraphLaunch(s->uexec[i], s->stream));
     HIP_TRY(hipEventRecord(s->udone[i], s->stream));
     s->uinflight[i] = true;
-    s->unext = 1 - i;
+    s->unext = (i + 1) % kUExec;
     return KMC_OK;
 }
 
@@ -1140,7 +1143,7 @@ KMC_EXPORT void kmc_sampler_destroy(kmc_sampler* s)
     if (!s) return;
     (void)hipSetDevice(s->cfg.device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < kUExec; ++i) {
         if (s->uexec[i]) (void)hipGraphExecDestroy(s->uexec[i]);
         if (s->udone[i]) (void)hipEventDestroy(s->udone[i]);
     }
@@ -1207,7 +1210,7 @@ KMC_EXPORT kmc_status kmc_sampler_bind_positions(kmc_sampler* s, void* pos_dev)
     HIP_TRY(hipStreamSynchronize(s->stream));
     if (s->graph_exec) { (void)hipGraphExecDestroy(s->graph_exec); s->graph_exec = nullptr; }
     if (s->graph) { (void)hipGraphDestroy(s->graph); s->graph = nullptr; }
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < kUExec; ++i) {
         if (s->uexec[i]) { (void)hipGraphExecDestroy(s->uexec[i]); s->uexec[i] = nullptr; }
         s->uinflight[i] = false;
     }

@@ -250,6 +250,35 @@ KMCO_API void kmco_half_step(const kmco_config* c, double* pos, double* logp, in
     }
 }
 
+/* Streaming moments of one stored generation (the build's stand-in for a reduce_blob! that sums,
+ * src/samplers.jl:270 / test/runtests.jl:102-105): msum[d] += sum_w x[w][d], msumsq[d] += sum_w x[w][d]^2.
+ * Threaded like the walker loop: fixed blocks of KMCO_MBLK walkers are summed into per-block partials
+ * (parallel for), the partials are then added in block order -- the result does not depend on the
+ * thread count.  part: scratch [nblk][2][nd]. */
+#define KMCO_MBLK 256
+static void moments_add(const double* pos, int64_t nw, int64_t nd, double* msum, double* msumsq,
+                        double* part, int64_t nblk, int nthreads)
+{
+#pragma omp parallel for schedule(static) num_threads(nthreads > 1 ? nthreads : 1)
+    for (int64_t b = 0; b < nblk; ++b) {
+        double* ps = part + b * 2 * nd;
+        double* pq = ps + nd;
+        for (int64_t d = 0; d < nd; ++d) { ps[d] = 0.0; pq[d] = 0.0; }
+        const int64_t w1 = (b + 1) * KMCO_MBLK < nw ? (b + 1) * KMCO_MBLK : nw;
+        for (int64_t w = b * KMCO_MBLK; w < w1; ++w)
+            for (int64_t d = 0; d < nd; ++d) {
+                const double v = pos[w * nd + d];
+                ps[d] += v;
+                pq[d] += v * v;
+            }
+    }
+    for (int64_t b = 0; b < nblk; ++b)
+        for (int64_t d = 0; d < nd; ++d) {
+            if (msum) msum[d] += part[b * 2 * nd + d];
+            if (msumsq) msumsq[d] += part[b * 2 * nd + nd + d];
+        }
+}
+
 /* ------------------------------------------------------------------------------------------
  * emcee + _emcee on dense arrays: src/samplers.jl:188-216 and :232-293.
  *
@@ -284,6 +313,8 @@ KMCO_API int kmco_emcee(const kmco_config* c, const double* theta0,
     if (msum) memset(msum, 0, sizeof(double) * (size_t)nd);
     if (msumsq) memset(msumsq, 0, sizeof(double) * (size_t)nd);
     int64_t nmom = 0;
+    const int64_t nblk = (nw + KMCO_MBLK - 1) / KMCO_MBLK;
+    double* mpart = (msum || msumsq) ? (double*)malloc(sizeof(double) * (size_t)(nblk * 2 * nd)) : NULL;
 
     /* generation g in [0,G)  <->  reference n = g + 1 - nburnin  (:245) */
     for (int64_t g = 0; g < c->ngenerations; ++g) {
@@ -295,14 +326,7 @@ KMCO_API int kmco_emcee(const kmco_config* c, const double* theta0,
             if (k < (c->ngenerations - c->nburnin) / c->nthin) {
                 if (chain) memcpy(chain + k * nw * nd, pos, sizeof(double) * (size_t)(nw * nd));
                 if (chain_logp) memcpy(chain_logp + k * nw, logp, sizeof(double) * (size_t)nw);
-                if (msum || msumsq) {
-                    for (int64_t w = 0; w < nw; ++w)
-                        for (int64_t d = 0; d < nd; ++d) {
-                            double v = pos[w * nd + d];
-                            if (msum) msum[d] += v;
-                            if (msumsq) msumsq[d] += v * v;
-                        }
-                }
+                if (msum || msumsq) moments_add(pos, nw, nd, msum, msumsq, mpart, nblk, c->nthreads);
                 nmom += nw;
             }
         }
@@ -315,7 +339,7 @@ KMCO_API int kmco_emcee(const kmco_config* c, const double* theta0,
     if (final_pos) memcpy(final_pos, pos, sizeof(double) * (size_t)(nw * nd));
     if (final_logp) memcpy(final_logp, logp, sizeof(double) * (size_t)nw);
     if (nmoment) *nmoment = nmom;
-    free(pos); free(logp); free(nacc);
+    free(pos); free(logp); free(nacc); free(mpart);
     return KMCO_OK;
 }
 

@@ -1,4 +1,4 @@
-"""Run one BASELINE config for a number of generations (a plain target for rocprofv3).
+"""Run one BASELINE config twice for a number of generations -- warm-up, then timed (a plain target for rocprofv3).
 Usage: python3 scripts/run_cfg.py C5 [generations] [moments 0/1]"""
 import os
 import sys
@@ -26,6 +26,9 @@ if name == "C3":
     th *= 0.1
 with kmc.Sampler(pdf, nw, nd, 10 ** 9, 0, 1, 2.0, 7, moments=mom) as s:
     s.set_positions(th)
-    s.run(G)
+    s.run(G)            # warm-up: code objects, graph instantiation, launch-mode measurement
     s.sync()
-    print(name, "generations", G, "ms", s.last_run_ms(), "us/half-step", s.last_run_ms() / (2 * G) * 1e3)
+    s.run(G)            # timed (HIP events on the sampler's stream); a trace's second half of dispatches is this run
+    s.sync()
+    print(name, "generations", G, "moments", int(mom), "ms", s.last_run_ms(), "us/half-step", s.last_run_ms() / (2 * G) * 1e3)
+    print(s.describe())
