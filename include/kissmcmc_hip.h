@@ -221,10 +221,19 @@ kmc_status  kmc_sampler_p2p_stats(kmc_sampler* s, uint64_t out[2]);
  * KMC_ERR_NONFINITE_LOGP if any is not finite. */
 kmc_status  kmc_sampler_set_positions(kmc_sampler* s, const double* theta_host);
 /* Device-side make_theta0s (src/samplers.jl:311-349, intended behaviour): every walker gets
- * theta0 + N(0, diag(ball_radius^2)), redrawn (seeded Philox/Box-Muller) while its log-pdf is -inf, the
- * ball shrinking by the reference's factors 1, 1/2, 1/8, ... after every `ntries` failures; then the
- * sampler is ready to run as after kmc_sampler_set_positions.  KMC_ERR_NONFINITE_LOGP (with the
- * reference's message) if a walker finds no admissible point. */
+ * theta0 + N(0, diag(ball_radius^2)), redrawn while its log-pdf is -inf (:336-341), up to `ntries` draws per ball
+ * size (:327), the ball shrinking WITHIN A WALKER by the reference's compounding factors 1, 1/2, 1/8, 1/64, ...
+ * (:326) over `halving_steps` sizes (any value >= 1; the factor underflows to 0, i.e. theta0 itself, near 47).
+ * Two deliberate differences from the reference's loop: the shrink factor restarts at 1 for every walker (the
+ * reference never resets ball_radius, so one unlucky walker would shrink the ball of all later ones; walkers here
+ * are independent and drawn in parallel -- the host-side make_theta0s of the shims keeps the reference's sequential
+ * behaviour), and a walker that finds no admissible point is an error (KMC_ERR_NONFINITE_LOGP with the
+ * reference's message; its own error() at :345 is unreachable).
+ * Random stream: Philox4x32-10, key {seed_lo ^ 0x42414c4c, seed_hi}, counter {attempt, d / 2, walker_lo, walker_hi}
+ * (attempt = 0-based try index of that walker over all ball sizes, walker = GLOBAL walker index); words (w0,w1,w2)
+ * -> u1 = (((w0 << 20) | (w1 >> 12)) + 1/2) 2^-52, u2 = (w2 + 1/2) 2^-32, Box-Muller pair sqrt(-2 log u1) {cos, sin}(2 pi u2)
+ * for dimensions d, d + 1.  A pure function of (seed, walker): sharded samplers draw their own rows of the same ball.
+ * Afterwards the sampler is ready to run, as after kmc_sampler_set_positions. */
 kmc_status  kmc_sampler_init_ball(kmc_sampler* s, const double* theta0 /* [ndim] */, const double* ball_radius /* [ndim] */,
                                   uint64_t seed, int halving_steps /* 7 */, int ntries /* 100 */);
 /* Checkpoint / resume: restore positions [rows][ndim], log-pdfs, acceptance counters (may be NULL = 0)

@@ -1040,7 +1040,7 @@ __device__ __forceinline__ void init_ball_body(const InitBallArgs& a)
     double shrink = 1.0;
     uint32_t attempt = 0;
     for (int k = 1; k <= a.halving_steps; ++k) {
-        shrink *= 1.0 / (double)(1u << (k - 1));                              // :326
+        shrink *= ldexp(1.0, -(k - 1));                                        // :326  1/2^(k-1), exact for any k
         for (int t = 0; t < a.ntries; ++t, ++attempt) {
             typename Dens::Seq q;
             Dens::seq_init(q);

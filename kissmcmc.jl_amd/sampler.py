@@ -147,7 +147,13 @@ class Sampler:
     def init_ball(self, theta0, ball_radius, seed: int = 0, ball_radius_halfing_steps: int = 7, ntries: int = 100):
         """Device-side ``make_theta0s`` (reference ``src/samplers.jl:311-349``): seeded Gaussian ball
         around ``theta0`` with ``pdf > -Inf``, generated and checked on the GPU; the sampler is then
-        ready to run (no host ensemble, no H2D copy)."""
+        ready to run (no host ensemble, no H2D copy).
+
+        Differs from the host-side :func:`~kissmcmc_jl_amd.make_theta0s` in two documented ways: the random stream
+        (Philox keyed by ``(seed, walker)``, not a numpy generator consumed walker by walker) and the ball's shrink
+        factor, which restarts at 1 for every walker here -- the host function follows the reference, where
+        ``ball_radius`` is never reset (``:326``) and one walker's retries shrink the ball of all later ones.  The two
+        agree in distribution whenever no walker needs more than ``ntries`` draws."""
         th = np.ascontiguousarray(np.broadcast_to(np.asarray(theta0, dtype=np.float64), (self.ndim,)))
         r = np.ascontiguousarray(np.broadcast_to(np.asarray(ball_radius, dtype=np.float64), (self.ndim,)))
         try:

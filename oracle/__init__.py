@@ -95,6 +95,9 @@ def lib() -> C.CDLL:
         L.kmco_emcee_islands.argtypes = [C.POINTER(Config), C.c_int64, C.c_int64, dp, dp, C.POINTER(C.c_int64),
                                          dp, dp, dp, dp, C.POINTER(C.c_int64)]
         assert L.kmco_sizeof_config() == C.sizeof(Config)
+        L.kmco_init_ball.restype = C.c_int64
+        L.kmco_init_ball.argtypes = [C.c_int32, dp, dp, dp, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_uint64,
+                                     dp, dp, C.POINTER(C.c_int64)]
         L.kmco_metropolis_draw.restype = None
         L.kmco_metropolis_draw.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int64, dp, dp]
         L.kmco_metropolis.argtypes = [C.POINTER(MetropolisConfig), dp, dp, dp, dp, dp, C.POINTER(C.c_int64), dp, dp, dp, dp]
@@ -197,6 +200,22 @@ def emcee(cfg: Config, theta0, store_chain=True, moments=True):
     return dict(status=st, chain=chain, chain_logp=chain_logp, accept_ratio=acc, naccept=nacc,
                 final_pos=fpos, final_logp=flogp, sum=msum, sumsq=msq, nmoment=nmom.value,
                 nsamples=ns)
+
+
+def init_ball(density, params, theta0, ball_radius, nrows, ndim, seed=0, halving_steps=7, ntries=100, walker0=0):
+    """Seeded initial ball (kmc_oracle.c: kmco_init_ball; reference src/samplers.jl:311-349, per-walker shrink).
+    Returns dict(pos [nrows, ndim], logp [nrows], attempts [nrows] (tries used, -1 = none admissible), nfail)."""
+    p = np.zeros(8)
+    p[: len(params)] = params
+    th = np.ascontiguousarray(np.broadcast_to(np.asarray(theta0, dtype=np.float64), (ndim,)))
+    rad = np.ascontiguousarray(np.broadcast_to(np.asarray(ball_radius, dtype=np.float64), (ndim,)))
+    pos = np.zeros((nrows, ndim))
+    logp = np.zeros(nrows)
+    att = np.zeros(nrows, dtype=np.int64)
+    with np.errstate(all="ignore"):
+        nfail = lib().kmco_init_ball(int(density), _dp(p), _dp(th), _dp(rad), int(nrows), int(walker0), int(ndim),
+                                     int(halving_steps), int(ntries), int(seed) & 0xFFFFFFFFFFFFFFFF, _dp(pos), _dp(logp), _ip(att))
+    return dict(pos=pos, logp=logp, attempts=att, nfail=int(nfail))
 
 
 def island_perm(seed, epoch, nwalkers):

@@ -346,6 +346,73 @@ KMCO_API int kmco_emcee(const kmco_config* c, const double* theta0,
 KMCO_API int kmco_sizeof_config(void) { return (int)sizeof(kmco_config); }
 
 /* ------------------------------------------------------------------------------------------
+ * Seeded make_theta0s on dense arrays: src/samplers.jl:311-349 -- the restatement of the product's
+ * DEVICE-side initial ball (kmc_sampler_init_ball); the host-side make_theta0s, which draws from a
+ * caller-supplied generator in the reference's sequential order, is restated in oracle/host.py.
+ *
+ * Reference loop (per walker i, :323): for k in 1:ball_radius_halfing_steps (:324) the radius is scaled by
+ * 1/2^(k-1) (:326), then up to ntries (:327) candidates theta0 .+ randn(npara) .* ball_radius (:328-332)
+ * are tried and the first with pdf > -Inf is kept (:336-341).  Followed as INTENDED where the
+ * reference's own code is order-dependent or unreachable:
+ *   - the shrink factor restarts at 1 for every walker (the reference never resets ball_radius, so
+ *     the shrinkage of one unlucky walker would carry over to all later ones, :326) -- walkers are
+ *     then independent of each other, which is what lets the device draw them in parallel;
+ *   - a walker that finds no admissible point is reported (return value = number of such walkers;
+ *     the reference's error(...) at :345 is unreachable).
+ * Within a walker the compounding 1, 1/2, 1/8, 1/64, ... of :326 is kept.
+ *
+ * Random stream (the build's contract; the reference draws from an unseeded global generator):
+ * Philox4x32-10, key = {seed_lo ^ 0x42414c4c ("BALL"), seed_hi}, counter = {attempt, pair, walker_lo,
+ * walker_hi}; attempt = 0-based index of the try over ALL ball sizes of this walker, pair = d / 2.
+ * Words (w0, w1, w2): u1 = (((w0 << 20) | (w1 >> 12)) + 1/2) 2^-52, u2 = (w2 + 1/2) 2^-32,
+ * r = sqrt(-2 log u1); dimension 2 pair gets r cos(2 pi u2), dimension 2 pair + 1 gets r sin(2 pi u2).
+ * log / sin / cos come from the platform libm: device and host agree to rounding, not bit for bit.
+ *
+ *   theta0, radius [ndim];  pos [nrows][ndim], logp [nrows], attempts [nrows] (tries used, or -1) -- any
+ *   output may be NULL;  row r is GLOBAL walker walker0 + r.
+ * ---------------------------------------------------------------------------------------- */
+KMCO_API int64_t kmco_init_ball(int32_t density, const double* params, const double* theta0, const double* radius,
+                                int64_t nrows, int64_t walker0, int64_t ndim, int32_t halving_steps, int32_t ntries,
+                                uint64_t seed, double* pos, double* logp, int64_t* attempts)
+{
+    if (!params || !theta0 || !radius || nrows < 0 || ndim <= 0 || halving_steps < 1 || ntries < 1) return -1;
+    const uint32_t key[2] = {(uint32_t)seed ^ 0x42414c4cu, (uint32_t)(seed >> 32)};
+    int64_t nfail = 0;
+    double* x = (double*)malloc(sizeof(double) * (size_t)ndim);
+    for (int64_t r = 0; r < nrows; ++r) {                                      /* :323 */
+        const uint64_t walker = (uint64_t)(walker0 + r);
+        double shrink = 1.0;
+        uint32_t attempt = 0;
+        int found = 0;
+        double p = -INFINITY;
+        for (int k = 1; k <= halving_steps && !found; ++k) {                   /* :324 */
+            shrink *= ldexp(1.0, -(k - 1));                                    /* :326 ball_radius *= 1/2^(k-1) */
+            for (int t = 0; t < ntries && !found; ++t, ++attempt) {            /* :327 */
+                for (int64_t d = 0; d < ndim; d += 2) {                        /* :328-332 theta0 .+ randn(npara) .* ball_radius */
+                    const uint32_t ctr[4] = {attempt, (uint32_t)(d >> 1), (uint32_t)walker, (uint32_t)(walker >> 32)};
+                    uint32_t w[4];
+                    kmco_philox4x32_10(ctr, key, w);
+                    const double u1 = ((double)(((uint64_t)w[0] << 20) | (uint64_t)(w[1] >> 12)) + 0.5) * 0x1.0p-52;
+                    const double u2 = ((double)w[2] + 0.5) * 0x1.0p-32;
+                    const double rad = sqrt(-2.0 * log(u1));
+                    const double ang = 6.283185307179586476925286766559 * u2;
+                    x[d] = theta0[d] + (rad * cos(ang)) * (radius[d] * shrink);
+                    if (d + 1 < ndim) x[d + 1] = theta0[d + 1] + (rad * sin(ang)) * (radius[d + 1] * shrink);
+                }
+                p = kmco_logpdf(density, params, x, ndim);                     /* :336 */
+                if (p > -INFINITY && p == p) found = 1;                        /* :338 */
+            }
+        }
+        if (!found) { ++nfail; p = -INFINITY; }                                /* :345 (intended) */
+        if (pos) memcpy(pos + r * ndim, x, sizeof(double) * (size_t)ndim);     /* :339 */
+        if (logp) logp[r] = p;
+        if (attempts) attempts[r] = found ? (int64_t)attempt : -1;
+    }
+    free(x);
+    return nfail;
+}
+
+/* ------------------------------------------------------------------------------------------
  * ISLAND MODE (an extension of the build, NOT a reference feature; opt-in).
  *
  * The ensemble is cut into islands of S walkers; for `epoch_gens` generations every island runs

@@ -2,7 +2,97 @@
 import numpy as np
 import pytest
 
+import glob
+import os
+
 pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+BALL_FIX = sorted(glob.glob(os.path.join(HERE, "golden", "init_ball", "*.npz")))
+_DENS = {0: lambda k, p: k.GaussianIso(p[0], p[1]), 1: lambda k, p: k.Exponential(p[0]), 3: lambda k, p: k.LogNormal(p[0], p[1])}
+# device log / sincos against glibc: <= a few ulp in each normal; positions = theta0 + normal * radius
+BALL_RTOL, BALL_ATOL = 1e-11, 1e-13
+
+
+def _ball_matches(pos, logp, ref_pos, ref_logp, scale=1.0):
+    np.testing.assert_allclose(pos, ref_pos, rtol=BALL_RTOL, atol=BALL_ATOL * scale)
+    np.testing.assert_allclose(logp, ref_logp, rtol=1e-10, atol=1e-10 * scale)
+
+
+@pytest.mark.parametrize("path", BALL_FIX, ids=[os.path.basename(p)[:-4] for p in BALL_FIX])
+def test_init_ball_equals_golden_fixture(kmc, path):
+    """kmc_sampler_init_ball against the committed oracle output (tests/golden/init_ball): the same try is kept for every
+    walker -- identical accept / retry / shrink decisions -- and its coordinates agree to rounding."""
+    z = dict(np.load(path))
+    nw, nd = int(z["nwalkers"]), int(z["ndim"])
+    pdf = _DENS[int(z["density"])](kmc, z["params"])
+    with kmc.Sampler(pdf, nw, nd, 10) as s:
+        if int(z["nfail"]) > 0:
+            with pytest.raises(RuntimeError, match=rf"Could not find suitable initial theta.*\({int(z['nfail'])} walkers\)"):
+                s.init_ball(z["theta0"], z["radius"], seed=int(z["seed"]), ball_radius_halfing_steps=int(z["halving_steps"]), ntries=int(z["ntries"]))
+            return
+        s.init_ball(z["theta0"], z["radius"], seed=int(z["seed"]), ball_radius_halfing_steps=int(z["halving_steps"]), ntries=int(z["ntries"]))
+        _ball_matches(s.positions(), s.logp(), z["pos"], z["logp"])
+
+
+@pytest.mark.parametrize("case", ["gauss_65536x32", "expo_retry_4096x3", "expo_shrink_2048x8", "lognormal_odd_1000x7", "rosen_16384x64",
+                                  "halving_40"])
+def test_init_ball_equals_oracle(kmc, oracle, case):
+    """The device-side make_theta0s (reference src/samplers.jl:311-349) against its CPU restatement kmco_init_ball on the
+    same seed: positions within 1e-11 (a different try for any walker would be off by O(radius)), log-pdfs within 1e-10;
+    including retries (pdf = -Inf inside the ball), the per-walker shrinking ball and halving_steps > 32 (formerly a
+    shift by more than the word size)."""
+    cfg = {
+        "gauss_65536x32": (kmc.GaussianIso(), oracle.GAUSSIAN_ISO, [0.0, 1.0], np.linspace(-1, 1, 32), np.linspace(0.05, 0.2, 32), 65536, 32, 7, 100, 42),
+        "expo_retry_4096x3": (kmc.Exponential(), oracle.EXPONENTIAL, [1.0], 0.02, 0.1, 4096, 3, 7, 100, 7),
+        "expo_shrink_2048x8": (kmc.Exponential(), oracle.EXPONENTIAL, [1.0], 0.01, 1.0, 2048, 8, 7, 3, 5),
+        "lognormal_odd_1000x7": (kmc.LogNormal(), oracle.LOGNORMAL, [0.0, 1.0], 0.3, 0.5, 1000, 7, 7, 100, 9),
+        "rosen_16384x64": (kmc.Rosenbrock(), oracle.ROSENBROCK, [1.0, 100.0, 20.0], 0.0, 0.1, 16384, 64, 7, 100, 1),
+        "halving_40": (kmc.Exponential(), oracle.EXPONENTIAL, [1.0], 1e-160, 1.0, 512, 6, 40, 1, 13),   # admissible from k ~ 33 on
+    }[case]
+    pdf, did, params, th, rad, nw, nd, hs, nt, seed = cfg
+    ref = oracle.init_ball(did, params, th, rad, nw, nd, seed=seed, halving_steps=hs, ntries=nt)
+    assert ref["nfail"] == 0
+    if "retry" in case or "shrink" in case or "halving" in case:
+        assert (ref["attempts"] > 1).mean() > 0.3                     # the case does exercise retries
+    if "shrink" in case:
+        assert (ref["attempts"] > 2 * nt).any()                       # ... and the third ball size
+    if "halving" in case:
+        assert (ref["attempts"] > 32).mean() > 0.3                    # ball sizes beyond 1/2^31
+    with kmc.Sampler(pdf, nw, nd, 10) as s:
+        s.init_ball(th, rad, seed=seed, ball_radius_halfing_steps=hs, ntries=nt)
+        _ball_matches(s.positions(), s.logp(), ref["pos"], ref["logp"], scale=1e-160 if "halving" in case else 1.0)
+        s.run(4)                                                      # the sampler is ready to run
+        s.sync()
+
+
+@pytest.mark.parametrize("nw,nd,did", [(4096, 32, 0), (100, 2, 2)])     # multi-launch path; resident path (Rosenbrock)
+def test_checkpoint_resume_equals_the_oracle_run(kmc, oracle, nw, nd, did):
+    """state() at generation 130 -> restore() into a NEW sampler -> the rest of the run: final positions and acceptance
+    counters must be those of the ORACLE's uninterrupted run (not merely of another HIP run)."""
+    pdf = kmc.GaussianIso() if did == 0 else kmc.Rosenbrock()
+    params = [0.0, 1.0] if did == 0 else [1.0, 100.0, 20.0]
+    th = (1.0 if did == 0 else 0.1) * np.random.default_rng(4).standard_normal((nw, nd))
+    G, nburn, seed = 200, 50, 21
+    ref = oracle.emcee(oracle.make_config(did, params, nw, nd, G, nburn, 1, 2.0, seed), th, store_chain=False)
+    assert ref["status"] == 0
+    with kmc.Sampler(pdf, nw, nd, G, nburn, 1, 2.0, seed, moments=True) as b:
+        b.set_positions(th)
+        b.run(130)
+        b.sync()
+        ck = b.state()
+        m1 = b.moments()
+    with kmc.Sampler(pdf, nw, nd, G, nburn, 1, 2.0, seed, moments=True) as c:
+        c.restore(ck)
+        c.run(G - 130)
+        c.sync()
+        np.testing.assert_array_equal(c.positions(), ref["final_pos"])
+        np.testing.assert_array_equal(c.naccept(), ref["naccept"])
+        assert np.all(np.abs(c.logp() - ref["final_logp"]) <= 1e-12 * np.maximum(1.0, np.abs(ref["final_logp"])))
+        m2 = c.moments()
+        assert m1[2] + m2[2] == ref["nmoment"]
+        np.testing.assert_allclose(m1[0] + m2[0], ref["sum"], rtol=1e-11, atol=1e-8)
+        np.testing.assert_allclose(m1[1] + m2[1], ref["sumsq"], rtol=1e-11, atol=1e-8)
 
 
 def test_init_ball_statistics_and_determinism(kmc):
