@@ -5,11 +5,12 @@ Workload (BASELINE.json configs[1], "C2"): 65 536 walkers x 32-dim isotropic Gau
 a = 2, 10^4 generations (burn-in = first half), streaming moments ON, chain storage OFF.
 One bench "step" = GENS_PER_STEP (1000) generations = 65.536e6 walker-steps per GPU, so the
 default --steps 10 is exactly the 10^4-generation job.  With --gpus N (launched by
-torch.distributed.run, one rank per GPU) the ensemble is 65 536 x N walkers, walker-sharded with a
-peer-to-peer exchange over xGMI (KMC_P2P: pull of the drawn partner rows, or push of the accepted rows into
-local copies, each with a signal kernel or the signal folded into the half-step kernel -- every variant is
-admitted by a bit-exact self-check against the unsharded run, timed, and the fastest runs; falls back to an
-RCCL all-gather of the updated half per half-step if none passes) -- weak scaling, config C4 at N = 8.
+torch.distributed.run, one rank per GPU) the ensemble is 65 536 x N walkers, walker-sharded with the reference's EXACT
+partner rule and a peer-to-peer exchange over xGMI (KMC_P2P, pull of the drawn partner rows with system-scope loads +
+signal kernel; admitted by a bit-exact self-check, and the timed run itself is verified against the unsharded run;
+KMC_BENCH_EXCHANGE=all measures the other five variants too, =allgather -- or any failure -- runs the RCCL all-gather of
+the updated half per half-step) -- weak scaling, config C4 at N = 8.  Extra key `dealt_mode` (N > 1, never `value`):
+the same job as dealt sub-ensembles, one RCCL all_to_all_single per 64 generations instead of an exchange per half-step.
 
 Prints ONE JSON line (rank 0).  `value` = all walker-steps of the timed region / wall time
 (max over ranks) with the ensemble resident in HBM.  `roofline` prices the half-step kernel
@@ -232,28 +233,43 @@ def main():
         except Exception as e:  # noqa: BLE001
             island = {"error": str(e)}
     else:
-        # Walker-sharded, one rank per GPU.  Preferred exchange: peer-to-peer partner reads over
-        # xGMI (KMC_P2P: only the rows that are drawn cross the fabric, the whole run is enqueued
-        # like the single-GPU case).  If the IPC set-up fails on any rank, every rank falls back to
-        # the RCCL all-gather of the updated half after each half-step.
+        # Walker-sharded, one rank per GPU, EXACT partner rule (reference src/samplers.jl:250: partners from the whole
+        # complementary half).  Exchange: peer-to-peer partner reads over xGMI (KMC_P2P: only the rows that are drawn cross
+        # the fabric, the whole run is enqueued like the single-GPU case).  By default ONE variant is set up -- pull of the
+        # drawn rows (system-scope loads), separate signal kernel: the one whose correctness does not depend on cache state
+        # -- admitted by a bit-exact self-check; KMC_BENCH_EXCHANGE=all also tries the other variants and runs the fastest
+        # admitted one; KMC_BENCH_EXCHANGE=allgather (or any failure) uses the RCCL all-gather of the updated half per
+        # half-step.  The TIMED run itself is then verified against the unsharded run of the whole ensemble on rank 0.
         from kissmcmc_jl_amd.distributed import HipShardExecutor, P2PEmcee, ShardedEmcee
         mode = os.environ.get("KMC_BENCH_EXCHANGE", "p2p")
         drv = None
+
+        def all_ok(flag: bool) -> bool:
+            t = torch.tensor([1.0 if flag else 0.0], device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return t.item() != 0
+
+        def unsharded(gens):
+            """(positions, naccept, moments) of the whole ensemble after `gens` generations on ONE GPU (this rank's)."""
+            with kmc.Sampler(pdf, nw, NDIM, G, nburn, 1, 2.0, SEED, moments=True, device=local_rank) as ref:
+                ref.set_positions(th)
+                ref.run(gens)
+                ref.sync()
+                return ref.positions(), ref.naccept(), ref.moments()
 
         def try_p2p(finegrained, fold_signal=False, push=False, lazy=False):
             """Set up the peer-to-peer exchange and self-check it: 240 generations (hipGraph replays + an eager tail)
             must reproduce, bit for bit, the same generations of the whole ensemble on ONE GPU (rank 0 runs it
             unsharded).  Any error, time-out or mismatch on any rank -> None on every rank."""
-            ok = torch.ones(1, device="cuda")
             d = None
+            ok = True
             try:
                 d = P2PEmcee(pdf, nw, NDIM, G, nburn, 1, 2.0, SEED, device=local_rank, finegrained=finegrained,
                              fold_signal=fold_signal, push=push, lazy=lazy)
             except Exception as e:  # noqa: BLE001
                 print(f"[rank {rank}] p2p set-up failed ({e})", file=sys.stderr)
-                ok.zero_()
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if ok.item() != 0:
+                ok = False
+            if all_ok(ok):
                 vgen = 240
                 try:
                     d.set_positions(th)
@@ -261,19 +277,18 @@ def main():
                     d.sync()
                     vpos, vacc = d.positions(), d.naccept()
                     if rank == 0:
-                        with kmc.Sampler(pdf, nw, NDIM, G, nburn, 1, 2.0, SEED, device=local_rank) as ref:
-                            ref.set_positions(th)
-                            ref.run(vgen)
-                            ref.sync()
-                            if not (np.array_equal(ref.positions(), vpos) and np.array_equal(ref.naccept(), vacc)):
-                                print(f"[rank 0] p2p self-check (finegrained={finegrained}, fold_signal={fold_signal}, push={push}, lazy={lazy}): "
-                                      "sharded run differs from the single-GPU run", file=sys.stderr)
-                                ok.zero_()
+                        rpos, racc, _ = unsharded(vgen)
+                        if not (np.array_equal(rpos, vpos) and np.array_equal(racc, vacc)):
+                            print(f"[rank 0] p2p self-check (finegrained={finegrained}, fold_signal={fold_signal}, push={push}, lazy={lazy}): "
+                                  "sharded run differs from the single-GPU run", file=sys.stderr)
+                            ok = False
                 except Exception as e:  # noqa: BLE001
                     print(f"[rank {rank}] p2p self-check failed ({e})", file=sys.stderr)
-                    ok.zero_()
-                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if ok.item() == 0:
+                    ok = False
+                ok = all_ok(ok)
+            else:
+                ok = False
+            if not ok:
                 if d is not None:
                     try:
                         d.sampler.close()
@@ -298,24 +313,29 @@ def main():
 
         p2p_memory = None
         tried = []
-        if mode == "p2p":
-            # candidates, each admitted only by the bit-exact self-check; of the admitted ones the fastest (measured) runs.
+        verified = None
+        if mode in ("p2p", "all"):
             #   pull: partner rows are read from the owning GPU (every drawn row crosses the fabric once);
-            #   push: every rank keeps local copies of the other shards, accepted rows are written to all peers (only
-            #         accepted rows cross the fabric, once per peer): less per link for few ranks, more for many;
-            #   lazy pull: local copies as for push, but filled on demand -- a rank publishes its accept bytes, a reader
-            #         pulls a drawn row only when its copy is older than the row's last accept (fewest bytes per link);
-            #   folded signal: the half-step kernel publishes its own progress flag (one kernel boundary less per
-            #         half-step) instead of a separate signal kernel.  Fine-grained rows only if nothing passes.
-            for label, fold, push, lazy in (("pull of drawn rows, signal folded into the kernel", True, False, False),
-                                            ("pull of drawn rows, signal kernel", False, False, False),
-                                            ("push of accepted rows into local copies, signal folded into the kernel", True, True, False),
-                                            ("push of accepted rows into local copies, signal kernel", False, True, False),
-                                            ("lazy pull into local copies (accept bytes published, rows pulled when stale), signal kernel", False, False, True),
-                                            ("lazy pull into local copies (accept bytes published, rows pulled when stale), signal folded into the kernel", True, False, True)):
+            #   push: every rank keeps local copies of the other shards, accepted rows are written to all peers;
+            #   lazy pull: local copies filled on demand (accept bytes published, rows pulled when stale);
+            #   folded signal: the half-step kernel publishes its own progress flag instead of a separate signal kernel.
+            # push / lazy have peers write into plain device memory the local kernel then reads through its own L2: whether
+            # that L2 can serve stale lines could never be observed on one GPU -- they run only on request and only if
+            # their self-check passes.
+            cands = [("pull of drawn rows (system-scope loads), signal kernel", False, False, False)]
+            if mode == "all":
+                cands += [("pull of drawn rows (system-scope loads), signal folded into the kernel", True, False, False),
+                          ("push of accepted rows into local copies, signal kernel", False, True, False),
+                          ("push of accepted rows into local copies, signal folded into the kernel", True, True, False),
+                          ("lazy pull into local copies, signal kernel", False, False, True),
+                          ("lazy pull into local copies, signal folded into the kernel", True, False, True)]
+            for label, fold, push, lazy in cands:
                 cand = try_p2p(False, fold, push, lazy)
                 if cand is None:
                     continue
+                if len(cands) == 1:
+                    drv, p2p_memory = cand, label
+                    break
                 tc = time_short(cand)
                 tried.append((label, tc))
                 if drv is None or tc < best_t:
@@ -327,13 +347,16 @@ def main():
             if drv is None:
                 drv = try_p2p(True, False)
                 if drv is not None:
-                    p2p_memory = "pull of drawn rows, fine-grained memory, signal kernel"
+                    p2p_memory = "pull of drawn rows, rows in fine-grained memory, signal kernel"
             if rank == 0 and tried:
                 print("[rank 0] p2p variants, s per 1024 generations: " + "; ".join(f"{l}: {t:.4f}" for l, t in tried), file=sys.stderr)
             if drv is None:
                 if rank == 0:
                     print("[rank 0] falling back to the RCCL all-gather exchange", file=sys.stderr)
                 mode = "allgather"
+            else:
+                mode = "p2p"
+        lazy_stats = (0, 0)
         if mode == "p2p":
             drv.set_positions(th)
             drv.run(args.warmup * GENS_PER_STEP)
@@ -350,11 +373,19 @@ def main():
             event_ms = drv.sampler.last_run_ms()
             launches = drv.sampler.launch_count
             msum, msq, nmom = drv.moments()
-            acc = float(drv.naccept().sum() / nw / max(1, G - nburn))
+            fpos, facc = drv.positions(), drv.naccept()
+            acc = float(facc.sum() / nw / max(1, G - nburn))
             lazy_stats = drv.sampler.p2p_stats()         # (remote partner draws, pulled) on this rank; (0, 0) unless lazy ran
             drv.close()
-            parallelism = (f"walker-sharded x{world}, peer-to-peer exchange over xGMI (IPC): {p2p_memory}; "
-                           "progress-flag ordering; self-check vs the unsharded single-GPU run: bit-identical")
+            # the timed run itself, against the unsharded run of the whole job on one GPU (rank 0)
+            if rank == 0:
+                rpos, racc, (rs, rq, rn) = unsharded(G)
+                verified = bool(np.array_equal(rpos, fpos) and np.array_equal(racc, facc) and rn == nmom and
+                                np.allclose(rs, msum, rtol=1e-10, atol=1e-6) and np.allclose(rq, msq, rtol=1e-10, atol=1e-6))
+                if not verified:
+                    print("[rank 0] the TIMED sharded run differs from the unsharded run of the same job", file=sys.stderr)
+            parallelism = (f"walker-sharded x{world}, exact partner rule, peer-to-peer exchange over xGMI (IPC): {p2p_memory}; "
+                           "progress-flag ordering")
         else:
             ex = HipShardExecutor(pdf, nw, NDIM, G, nburn, 1, 2.0, SEED, rank=rank, world=world, device=local_rank)
             ex.set_positions(th)
@@ -377,12 +408,54 @@ def main():
             event_ms = ev0.elapsed_time(ev1)
             launches = 2 * G
             msum, msq, nmom = sdrv.moments()
-            acc = float(sdrv.naccept().sum() / nw / max(1, G - nburn))
+            facc = sdrv.naccept()
+            fpos = sdrv.positions()
+            acc = float(facc.sum() / nw / max(1, G - nburn))
             ex.close()
-            parallelism = f"walker-sharded x{world}, RCCL all-gather of the updated half per half-step"
+            if rank == 0:
+                rpos, racc, (rs, rq, rn) = unsharded(G)
+                verified = bool(np.array_equal(rpos, fpos) and np.array_equal(racc, facc))
+            parallelism = f"walker-sharded x{world}, exact partner rule, RCCL all-gather of the updated half per half-step"
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+        # Extra, NOT `value`: dealt sub-ensembles -- every GPU runs the reference's algorithm unchanged on its own 65 536
+        # walkers (partners from its own complementary half) for an epoch, then ONE RCCL all_to_all_single re-deals the
+        # walkers across the GPUs (state-independent permutation).  Same target distribution, no per-half-step exchange.
+        dealt = None
+        try:
+            from kissmcmc_jl_amd.distributed import DealtEmcee, HipDealExecutor
+            epoch = int(os.environ.get("KMC_BENCH_DEAL_EPOCH", 64))
+            dex = HipDealExecutor(pdf, NWALKERS_PER_GPU, NDIM, G, nburn, 1, 2.0, SEED, rank=rank, world=world, device=local_rank)
+            dd = DealtEmcee(dex, nw, NDIM, epoch)
+            dd.set_positions(th)
+            dd.run(args.warmup * GENS_PER_STEP)
+            dd.sync()
+            dd.set_positions(th)
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            dd.run(G)
+            dd.sync()
+            torch.cuda.synchronize()
+            dist.barrier()
+            dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+            res = dd.results()
+            dd.close()
+            dmean = res["sum"] / max(1, res["n"])
+            dvar = res["sumsq"] / max(1, res["n"]) - dmean ** 2
+            dealt = {"value": float(nw) * G / float(dt.item()), "unit": "walker-steps/s", "epoch_generations": epoch, "deals": dd.deals,
+                     "all_to_all_bytes_per_gpu_per_deal": NWALKERS_PER_GPU * (NDIM + 2) * 8,
+                     "accept_ratio_mean": float(res["naccept"].sum() / nw / max(1, G - nburn)),
+                     "posterior_mean_absmax": float(np.abs(dmean).max()),
+                     "posterior_var_minmax": [float(dvar.min()), float(dvar.max())], "nmoment": int(res["n"]),
+                     "note": "dealt sub-ensembles (kmc_config.deal_count): same target distribution, partner pool = this GPU's complementary "
+                             "half (not the reference's whole-ensemble rule), walkers re-dealt across the GPUs by one RCCL all_to_all_single "
+                             "per epoch; bit-identical to the oracle's restatement kmco_emcee_dealt (tests/test_gpu_dealt.py)"}
+        except Exception as e:  # noqa: BLE001
+            dealt = {"error": str(e)}
 
     if rank == 0:
         steps_total = float(nw) * G
@@ -425,6 +498,8 @@ def main():
                       "nmoment": int(nmom)},
         }
         if world > 1:
+            out["check"]["timed_run_equals_unsharded_run"] = verified
+            out["dealt_mode"] = dealt
             # what the exchange has to move: partners are uniform over the whole complementary half,
             # so (P-1)/P of a rank's partner rows are remote, 1/P from each peer over that pair's single xGMI link
             rows_per_peer = walkers_per_launch / world
@@ -436,7 +511,8 @@ def main():
                              "lazy_pulled_fraction_rank0": (lazy_stats[1] / lazy_stats[0]) if (mode == "p2p" and lazy_stats[0]) else None,
                              "note": "pull variants move every drawn row once (bytes_per_link from each peer); push variants move "
                                      "accepted rows only (push_bytes_per_link to each peer); link figure = one xGMI link, one "
-                                     "direction (~77 GB/s); config.parallelism names the variant that ran"}
+                                     "direction (~77 GB/s); config.parallelism names the variant that ran (default: one variant; "
+                                     "KMC_BENCH_EXCHANGE=all measures all six)"}
         if world == 1:
             out["island_mode"] = island
             if not args.no_other_configs:

@@ -145,6 +145,8 @@ typedef struct kmc_config {
     kmc_host_logpdf_fn host_logpdf; /* KMC_HOST_DENSITY: the callback, else NULL */
     void*    host_user;     /* passed through to host_logpdf / host_accepted */
     kmc_host_accepted_fn host_accepted; /* KMC_HOST_DENSITY: per-half-step accept outcomes, or NULL */
+    int32_t  deal_rank;     /* DEALT SUB-ENSEMBLES (opt-in, not the reference's partner rule; see kmc_sampler_deal_pack): this sampler is */
+    int32_t  deal_count;    /* sub-ensemble deal_rank of deal_count; 0 = off.  nwalkers is then THIS sub-ensemble's size */
 } kmc_config;
 
 /* Host output buffers of the one-shot call; any pointer may be NULL. */
@@ -167,6 +169,10 @@ typedef struct kmc_user_density kmc_user_density; /* opaque */
 
 /* ---- library ---- */
 int         kmc_version(void);
+/* sizeof(kmc_config) / sizeof(kmc_metropolis_config) as this library was built: a binding checks them against its own
+   mirror of the structs when it loads the library, so layout drift fails loudly before the first real call. */
+int         kmc_sizeof_config(void);
+int         kmc_sizeof_metropolis_config(void);
 int         kmc_device_count(void);
 const char* kmc_last_error(void);
 const char* kmc_status_string(kmc_status st);
@@ -275,6 +281,38 @@ kmc_status  kmc_sampler_get_moments(kmc_sampler* s, double* sum, double* sumsq /
  * shard_count, local order = (first-half slice, second-half slice).  With shard_count == 1
  * this is the global walker order. */
 kmc_status  kmc_sampler_get_chain(kmc_sampler* s, double* chain, double* chain_logp);
+
+/* ---- dealt sub-ensembles: the multi-GPU mode WITHOUT a per-half-step exchange (opt-in extension) ----
+ *
+ * The reference draws partners from the whole complementary half (src/samplers.jl:250), which across GPUs costs one
+ * exchange of walker rows per half-step (KMC_P2P, or an all-gather): fabric-bound on point-to-point xGMI.  Here each
+ * GPU instead runs the reference's algorithm UNCHANGED on its own sub-ensemble of S = kmc_config.nwalkers walkers
+ * (partners from that sub-ensemble's complementary half; an ordinary sampler: hipGraph replay, moments, ...) for an
+ * epoch of E generations, and between epochs the walkers are RE-DEALT across the deal_count sub-ensembles by a
+ * state-independent permutation: one all-to-all of S (ndim + 2) doubles per GPU per epoch (RCCL all_to_all_single in
+ * the Python driver) instead of 2 E exchanges.  Every sub-ensemble update is a valid emcee move for its walkers and
+ * the deal ignores the state, so the target distribution is unchanged; the partner pool is what differs from the
+ * reference, which is why this is opt-in and never what bench.py reports as `value`.
+ *
+ * Contract (restated by the oracle, kmco_emcee_dealt):
+ *   - sub-ensemble r of P initially holds global walkers [r S, (r+1) S) (kmc_sampler_set_positions takes ITS rows);
+ *     its Philox key is kmc_deal_seed(seed, r) = seed + (r + 1) * 0x9E3779B97F4A7C15 (mod 2^64), walker index =
+ *     local slot, so the draws of a slot do not depend on which walker sits in it;
+ *   - after generation g with (g + 1) % E == 0 the deal of epoch e = (g + 1) / E - 1 happens: slot j of
+ *     sub-ensemble r goes to send position t = (A j + C) mod S, (A, C) = kmc_deal_perm(seed, e, r, S); chunk
+ *     q = t / (S / P) of the send buffer goes to sub-ensemble q and lands at its slots [r S / P, (r + 1) S / P)
+ *     in order -- exactly what all_to_all_single(recv, send) with equal splits does;
+ *   - a walker carries its position, log-pdf, acceptance counter and global index (kmc_sampler_get_walker_ids).
+ * kmc_sampler_deal_pack first credits every walker's current value to the streaming moments (they are per slot).
+ * Needs S % (2 P) == 0, KMC_F64, a device density, no chain storage / KMC_P2P / KMC_ISLANDS / sharding. */
+uint64_t    kmc_deal_seed(uint64_t seed, int32_t deal_rank);
+kmc_status  kmc_deal_perm(uint64_t seed, int64_t epoch, int32_t deal_rank, int64_t S, int64_t* A, int64_t* C);
+/* Enqueue (on the sampler's stream) the packing of this sub-ensemble's S rows of ndim + 2 doubles into send_dev
+ * (device, S * (ndim + 2) doubles), shuffled for the deal of `epoch`; and the taking-over of a received buffer. */
+kmc_status  kmc_sampler_deal_pack(kmc_sampler* s, int64_t epoch, void* send_dev);
+kmc_status  kmc_sampler_deal_unpack(kmc_sampler* s, const void* recv_dev);
+/* Global walker index held by each local slot (host, [nwalkers]); row order of get_positions / get_naccept. */
+kmc_status  kmc_sampler_get_walker_ids(kmc_sampler* s, int64_t* host);
 
 /* ---- stateless device ops on caller-owned device memory ---- */
 /* logp[i] = log pdf(pos[i]) for nrows rows, src/samplers.jl:209. */

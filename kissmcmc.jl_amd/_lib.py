@@ -37,6 +37,8 @@ SYMBOLS = [
     "kmc_sampler_get_logp", "kmc_sampler_get_naccept", "kmc_sampler_get_accept_ratio",
     "kmc_sampler_get_moments", "kmc_sampler_get_chain", "kmc_logpdf_eval", "kmc_logpdf_eval_host",
     "kmc_user_density_create", "kmc_user_density_destroy", "kmc_metropolis_validate", "kmc_metropolis_run", "kmc_int_acorr", "kmc_sampler_int_acorr",
+    "kmc_sizeof_config", "kmc_sizeof_metropolis_config", "kmc_deal_seed", "kmc_deal_perm", "kmc_sampler_deal_pack", "kmc_sampler_deal_unpack",
+    "kmc_sampler_get_walker_ids",
 ]
 
 
@@ -62,6 +64,8 @@ class Config(C.Structure):
         ("host_logpdf", C.c_void_p),
         ("host_user", C.c_void_p),
         ("host_accepted", C.c_void_p),
+        ("deal_rank", C.c_int32),
+        ("deal_count", C.c_int32),
     ]
 
 
@@ -197,6 +201,16 @@ def lib() -> C.CDLL:
     L.kmc_metropolis_run.argtypes = [C.POINTER(MetropolisConfig), dp, C.POINTER(MetropolisOutputs)]
     L.kmc_int_acorr.argtypes = [dp, C.c_int64, C.c_int64, C.c_int64, C.c_double, C.c_int, dp, dp]
     L.kmc_sampler_int_acorr.argtypes = [vp, C.c_double, dp, dp]
+    L.kmc_deal_seed.restype = C.c_uint64
+    L.kmc_deal_seed.argtypes = [C.c_uint64, C.c_int32]
+    L.kmc_deal_perm.argtypes = [C.c_uint64, C.c_int64, C.c_int32, C.c_int64, ip, ip]
+    L.kmc_sampler_deal_pack.argtypes = [vp, C.c_int64, vp]
+    L.kmc_sampler_deal_unpack.argtypes = [vp, vp]
+    L.kmc_sampler_get_walker_ids.argtypes = [vp, ip]
+    # layout drift between this mirror and the library fails here, at load, not inside the first real call
+    if L.kmc_sizeof_config() != C.sizeof(Config) or L.kmc_sizeof_metropolis_config() != C.sizeof(MetropolisConfig):
+        raise ImportError(f"{LIB_PATH}: struct layout mismatch (kmc_config {L.kmc_sizeof_config()} vs {C.sizeof(Config)} bytes, "
+                          f"kmc_metropolis_config {L.kmc_sizeof_metropolis_config()} vs {C.sizeof(MetropolisConfig)}): rebuild the library")
     _lib = L
     return L
 

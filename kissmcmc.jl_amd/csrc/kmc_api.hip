@@ -178,6 +178,24 @@ void island_perm(uint64_t seed, int64_t epoch, int64_t N, int64_t* A, int64_t* C
     *C = (int64_t)((((uint64_t)w[2] << 32) | w[3]) % (uint64_t)N);
 }
 
+// Dealt sub-ensembles (kmc_config.deal_count): the Philox key of sub-ensemble r, and the affine shuffle (A, C) its S
+// slots go through before the deal of `epoch` (A coprime to S) -- from Philox(ctr = {epoch, "DEAL", r}, key = seed).
+constexpr uint64_t kDealSeedStride = 0x9E3779B97F4A7C15ull;
+uint64_t deal_seed(uint64_t seed, int32_t rank) { return seed + (uint64_t)(rank + 1) * kDealSeedStride; }
+void deal_perm(uint64_t seed, int64_t epoch, int32_t rank, int64_t S, int64_t* A, int64_t* C)
+{
+    const uint32_t ctr[4] = {(uint32_t)epoch, (uint32_t)((uint64_t)epoch >> 32), 0x4445414cu, (uint32_t)rank};
+    const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    uint32_t w[4];
+    philox_host(ctr, key, w);
+    auto gcd = [](int64_t a, int64_t b) { while (b) { const int64_t t = a % b; a = b; b = t; } return a; };
+    int64_t a = (int64_t)((((uint64_t)w[0] << 32) | w[1]) % (uint64_t)S);
+    if (a < 1) a = 1;
+    while (gcd(a, S) != 1) a = (a + 1 >= S) ? 1 : a + 1;
+    *A = a;
+    *C = (int64_t)((((uint64_t)w[2] << 32) | w[3]) % (uint64_t)S);
+}
+
 // Default geometry per ndim; KMC_PLAN="L,K,ITER" (or "generic") overrides for tuning.
 Plan make_plan(const kmc_config& c, int64_t n_active)
 {
@@ -464,6 +482,8 @@ struct kmc_sampler {
     uint32_t* d_klast = nullptr;      // vec kernels: samples already credited per walker (d_logp, d_naccept, d_klast: one block)
     double2* d_ring = nullptr;        // vec kernels: parked draws of the walkers' next steps, [4][nrows] x 32 B (HalfStepArgs::ring)
     int64_t macc_stride = 0, macc_elems = 0;
+    uint32_t* d_ids = nullptr;        // dealt sub-ensembles: global walker index held by each slot
+    uint64_t user_seed = 0;           //   the caller's seed (cfg.seed is then this sub-ensemble's Philox key)
     int64_t moment_base = 0;  // samples that precede the restored state (kmc_sampler_set_state)
     int64_t generation = 0;   // generations enqueued so far
     int64_t dev_gen = 0;      // value the device counter will hold once the stream drains
@@ -815,6 +835,46 @@ int64_t samples_done(const kmc_sampler* s)
     return k < s->nsamples ? k : s->nsamples;
 }
 
+// KMC_P2P: a half-step kernel that gave up waiting for a peer has flagged it in d_err, and everything computed after that
+// is invalid -- every read-out of a P2P sampler checks (call after the stream has drained).
+kmc_status check_p2p_err(kmc_sampler* s)
+{
+    if (!s->p2p || !s->d_err) return KMC_OK;
+    unsigned long long e = 0;
+    HIP_TRY(hipMemcpy(&e, s->d_err, sizeof(e), hipMemcpyDeviceToHost));
+    if (e != 0)
+        return fail(KMC_ERR_HIP, "p2p: timed out waiting for a peer before half-step " + std::to_string(e - 1) + " (results are invalid)");
+    return KMC_OK;
+}
+
+// Streaming moments of the multi-launch kernels are sojourn-weighted (a walker's value is credited when it is replaced):
+// credit every walker's CURRENT value with the samples it has stood for so far (enqueued on the sampler's stream; after
+// it every klast equals the number of samples taken).  Before a read-out, and before walkers change slots (deal).
+kmc_status flush_moments_now(kmc_sampler* s)
+{
+    if (!s->d_msum || s->islands || s->resident) return KMC_OK;
+    HIP_TRY(launch_sweep(s));                                   // posted ring entries first, in their order
+    if (s->plan.vec) {
+        FlushFn fl = flush_lookup(s->plan.L, s->plan.K, s->plan.ITER, s->f32);
+        if (!fl) return fail(KMC_ERR_UNSUPPORTED, "no flush kernel for this geometry");
+        for (int half = 0; half < 2; ++half) {
+            FlushArgs fa{};
+            fa.pos = s->d_pos;
+            fa.klast = s->d_klast;
+            fa.msum = s->d_msum;
+            fa.msumsq = s->d_msumsq;
+            fa.macc_stride = s->macc_stride;
+            fa.row0 = s->p2p ? (int64_t)half * s->h_loc : (int64_t)half * s->h + s->active_begin;
+            fa.n_active = (int32_t)s->h_loc;
+            fa.nsamp = (uint32_t)samples_done(s);
+            fa.ld = (int32_t)s->ld;
+            hipLaunchKernelGGL(fl, dim3(s->grid), dim3(s->tpb), 0, s->stream, fa);
+            HIP_TRY(hipGetLastError());
+        }
+    }
+    return KMC_OK;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------
@@ -888,6 +948,15 @@ KMC_EXPORT kmc_status kmc_validate(const kmc_config* c)
         if (c->density == KMC_USER_DENSITY && (size_t)S * (size_t)(2 * c->ndim + 9) * sizeof(double) > 60 * 1024)
             return fail(KMC_ERR_UNSUPPORTED, "KMC_ISLANDS with a user density: island_size * (ndim + 3) * 8 must stay below 60 KiB (use island_size 128 or 64)");
     }
+    if (c->deal_count < 0 || (c->deal_count > 0 && (c->deal_rank < 0 || c->deal_rank >= c->deal_count)))
+        return fail(KMC_ERR_BAD_ARG, "deal_rank / deal_count out of range");
+    if (c->deal_count > 0) {
+        if (P != 1 || (c->flags & (KMC_P2P | KMC_ISLANDS | KMC_STORE_CHAIN | KMC_STORE_LOGP)) || c->dtype != KMC_F64 || c->density == KMC_HOST_DENSITY)
+            return fail(KMC_ERR_UNSUPPORTED, "dealt sub-ensembles: KMC_F64, a device density, one shard, no chain storage / KMC_P2P / KMC_ISLANDS");
+        if (c->nwalkers % c->deal_count != 0)
+            return fail(KMC_ERR_BAD_ARG, "dealt sub-ensembles: nwalkers (this sub-ensemble's size) must be divisible by deal_count");
+        if (c->nwalkers * (int64_t)c->deal_count >= (int64_t)1 << 32) return fail(KMC_ERR_UNSUPPORTED, "dealt sub-ensembles: at most 2^32 - 1 walkers in all");
+    }
     DensityParams dp;
     return digest_params(*c, &dp);
 }
@@ -921,6 +990,8 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
 
     kmc_sampler* s = new kmc_sampler();
     s->cfg = *cfg;
+    s->user_seed = cfg->seed;
+    if (cfg->deal_count > 0) s->cfg.seed = deal_seed(cfg->seed, cfg->deal_rank);    // this sub-ensemble's Philox key
     if (s->cfg.shard_count <= 0) s->cfg.shard_count = 1;
     s->h = cfg->nwalkers / 2;
     s->h_loc = s->h / s->cfg.shard_count;
@@ -1077,6 +1148,7 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
     CREATE_TRY(hipMemset(s->d_gen, 0, 64));
     CREATE_TRY(hipMalloc(&s->d_sched, (size_t)kGraphChunk * sizeof(SchedEntry)));
     CREATE_TRY(hipMemset(s->d_naccept, 0, nw * sizeof(uint32_t)));
+    if (cfg->deal_count > 0) CREATE_TRY(hipMalloc((void**)&s->d_ids, nw * sizeof(uint32_t)));
     if (s->plan.vec && !s->islands && !s->resident && s->plan.L >= 16 && s->plan.L <= 32 && s->plan.L / s->plan.ITER >= 2 &&
         std::getenv("KMC_NO_DRAW_RING") == nullptr) {
         // draw ring: 4 slots x rows x 32 B; tags start at 0xffffffff (no step carries it), so nothing is "parked" yet
@@ -1166,6 +1238,7 @@ KMC_EXPORT void kmc_sampler_destroy(kmc_sampler* s)
     if (s->own_pos) (void)hipFree(s->d_pos);
     (void)hipFree(s->d_logp);          // the {logp, naccept, klast} block
     (void)hipFree(s->d_mring);
+    (void)hipFree(s->d_ids);
     (void)hipFree(s->d_lazy);
     (void)hipFree(s->d_mring_w);
     (void)hipFree(s->d_mcnt);
@@ -1399,7 +1472,8 @@ KMC_EXPORT kmc_status kmc_sampler_init_ball(kmc_sampler* s, const double* theta0
         a.logp = s->d_logp + (size_t)piece * (size_t)s->h_loc;
         a.theta0 = d_par; a.radius = d_par + nd;
         a.nrows = rows;
-        a.row_walker0 = s->p2p ? (int64_t)piece * s->h + s->active_begin : 0;
+        a.row_walker0 = s->p2p ? (int64_t)piece * s->h + s->active_begin
+                               : (s->cfg.deal_count > 0 ? (int64_t)s->cfg.deal_rank * s->nrows : 0);   // rows of ONE global ball
         a.ndim = (int32_t)nd; a.ld = (int32_t)s->ld;
         a.halving_steps = halving_steps; a.ntries = ntries;
         a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
@@ -1434,6 +1508,11 @@ KMC_EXPORT kmc_status kmc_sampler_init_ball(kmc_sampler* s, const double* theta0
     }
     s->dev_gen = 0;
     s->moment_base = 0;
+    if (s->d_ids) {
+        hipLaunchKernelGGL(deal_init_ids, dim3((unsigned)((s->nrows + 255) / 256)), dim3(256), 0, s->stream, s->d_ids, s->nrows,
+                           (uint32_t)((uint64_t)s->cfg.deal_rank * (uint64_t)s->nrows));
+        HIP_TRY(hipGetLastError());
+    }
     return reset_run_state(s, /*eval_logp=*/s->f32, 0, 0u);      // KMC_F32: the log-pdfs of the rows as rounded
 }
 
@@ -1445,6 +1524,7 @@ KMC_EXPORT kmc_status kmc_sampler_set_state(kmc_sampler* s, const double* pos_ho
 {
     if (!s || !pos_host || !logp_host || generation < 0) return fail(KMC_ERR_BAD_ARG, "bad argument");
     if (s->d_chain || s->d_chain_logp) return fail(KMC_ERR_UNSUPPORTED, "kmc_sampler_set_state: not with chain storage (download the chain before checkpointing)");
+    if (s->d_ids) return fail(KMC_ERR_UNSUPPORTED, "kmc_sampler_set_state: not for dealt sub-ensembles (the slot -> walker map is not part of the state yet)");
     if (s->p2p && s->cfg.shard_count > 1)
         return fail(KMC_ERR_UNSUPPORTED, "kmc_sampler_set_state: P2P progress flags restart at 0; restore is single-GPU for now");
     HIP_TRY(hipSetDevice(s->cfg.device));
@@ -1521,6 +1601,11 @@ KMC_EXPORT kmc_status kmc_sampler_set_positions(kmc_sampler* s, const double* th
             HIP_TRY(hipMemsetAsync(s->d_isum, 0, ne * sizeof(double), s->stream));
             HIP_TRY(hipMemsetAsync(s->d_isumsq, 0, ne * sizeof(double), s->stream));
         }
+    }
+    if (s->d_ids) {                                              // dealt sub-ensembles: slot i holds global walker r S + i
+        hipLaunchKernelGGL(deal_init_ids, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s->stream, s->d_ids, (int64_t)nw,
+                           (uint32_t)((uint64_t)s->cfg.deal_rank * (uint64_t)nw));
+        HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipStreamSynchronize(s->stream));
     s->generation = 0;
@@ -1757,14 +1842,7 @@ KMC_EXPORT kmc_status kmc_sampler_sync(kmc_sampler* s)
     if (!s) return fail(KMC_ERR_BAD_ARG, "null sampler");
     HIP_TRY(hipSetDevice(s->cfg.device));
     HIP_TRY(hipStreamSynchronize(s->stream));
-    if (s->p2p) {
-        unsigned long long e = 0;
-        HIP_TRY(hipMemcpy(&e, s->d_err, sizeof(e), hipMemcpyDeviceToHost));
-        if (e != 0)
-            return fail(KMC_ERR_HIP, "p2p: timed out waiting for a peer before half-step " + std::to_string(e - 1) +
-                                     " (results are invalid)");
-    }
-    return KMC_OK;
+    return check_p2p_err(s);
 }
 
 KMC_EXPORT kmc_status kmc_sampler_last_run_ms(kmc_sampler* s, double* ms)
@@ -1813,6 +1891,7 @@ KMC_EXPORT kmc_status kmc_sampler_describe(const kmc_sampler* s, char* buf, int6
     if (s->lazy) o << "; lazy pull into local copies (KMC_P2P_LAZY)";
     else if (s->push) o << "; accepted rows pushed into the peers' local copies (KMC_P2P_PUSH)";
     if (s->f32) o << "; rows kept in float (KMC_F32), arithmetic in double";
+    if (s->d_ids) o << "; dealt sub-ensemble " << s->cfg.deal_rank << "/" << s->cfg.deal_count << " (walkers re-dealt between epochs)";
     if (s->d_mring) o << "; moments through a ring of " << s->mring_depth << " posted rows per wave";
     if (s->user) o << "; runtime-compiled density";
     if (s->p2p) o << "; P2P shard " << s->cfg.shard_rank << "/" << s->cfg.shard_count << (s->connected ? "" : " (not connected)");
@@ -1838,6 +1917,7 @@ KMC_EXPORT kmc_status kmc_sampler_get_positions(kmc_sampler* s, double* host)
     if (!s || !host) return fail(KMC_ERR_BAD_ARG, "null argument");
     HIP_TRY(hipSetDevice(s->cfg.device));
     HIP_TRY(hipStreamSynchronize(s->stream));
+    KMC_TRY(check_p2p_err(s));
     HIP_TRY(download_rows(s, host, s->d_pos, (size_t)s->nrows));
     return KMC_OK;
 }
@@ -1847,6 +1927,7 @@ KMC_EXPORT kmc_status kmc_sampler_get_logp(kmc_sampler* s, double* host)
     if (!s || !host) return fail(KMC_ERR_BAD_ARG, "null argument");
     HIP_TRY(hipSetDevice(s->cfg.device));
     HIP_TRY(hipStreamSynchronize(s->stream));
+    KMC_TRY(check_p2p_err(s));
     HIP_TRY(hipMemcpy(host, s->d_logp, (size_t)s->nrows * sizeof(double), hipMemcpyDeviceToHost));
     return KMC_OK;
 }
@@ -1856,6 +1937,7 @@ KMC_EXPORT kmc_status kmc_sampler_get_naccept(kmc_sampler* s, int64_t* host)
     if (!s || !host) return fail(KMC_ERR_BAD_ARG, "null argument");
     HIP_TRY(hipSetDevice(s->cfg.device));
     HIP_TRY(hipStreamSynchronize(s->stream));
+    KMC_TRY(check_p2p_err(s));
     std::vector<uint32_t> tmp((size_t)s->nrows);
     HIP_TRY(hipMemcpy(tmp.data(), s->d_naccept, tmp.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
     for (size_t i = 0; i < tmp.size(); ++i) host[i] = (int64_t)tmp[i];
@@ -1895,27 +1977,9 @@ KMC_EXPORT kmc_status kmc_sampler_get_moments(kmc_sampler* s, double* sum, doubl
         if (n) *n = (samples_done(s) - s->moment_base) * s->nlocal;
         return KMC_OK;
     }
-    HIP_TRY(launch_sweep(s));                                   // posted ring entries first, in their order
-    if (s->plan.vec) {
-        // sojourn-weighted accumulation: credit every walker's current value up to now
-        FlushFn fl = flush_lookup(s->plan.L, s->plan.K, s->plan.ITER, s->f32);
-        if (!fl) return fail(KMC_ERR_UNSUPPORTED, "no flush kernel for this geometry");
-        for (int half = 0; half < 2; ++half) {
-            FlushArgs fa{};
-            fa.pos = s->d_pos;
-            fa.klast = s->d_klast;
-            fa.msum = s->d_msum;
-            fa.msumsq = s->d_msumsq;
-            fa.macc_stride = s->macc_stride;
-            fa.row0 = s->p2p ? (int64_t)half * s->h_loc : (int64_t)half * s->h + s->active_begin;
-            fa.n_active = (int32_t)s->h_loc;
-            fa.nsamp = (uint32_t)samples_done(s);
-            fa.ld = (int32_t)s->ld;
-            hipLaunchKernelGGL(fl, dim3(s->grid), dim3(s->tpb), 0, s->stream, fa);
-            HIP_TRY(hipGetLastError());
-        }
-    }
+    KMC_TRY(flush_moments_now(s));
     HIP_TRY(hipStreamSynchronize(s->stream));
+    KMC_TRY(check_p2p_err(s));
     const int64_t nd = s->cfg.ndim;
     std::vector<double> hs((size_t)s->macc_elems), hq((size_t)s->macc_elems);
     HIP_TRY(hipMemcpy(hs.data(), s->d_msum, hs.size() * sizeof(double), hipMemcpyDeviceToHost));
@@ -1964,6 +2028,7 @@ KMC_EXPORT kmc_status kmc_sampler_get_chain(kmc_sampler* s, double* chain, doubl
     if (!s) return fail(KMC_ERR_BAD_ARG, "null sampler");
     HIP_TRY(hipSetDevice(s->cfg.device));
     HIP_TRY(hipStreamSynchronize(s->stream));
+    KMC_TRY(check_p2p_err(s));
     const size_t rows = (size_t)samples_done(s) * (size_t)s->nlocal;
     if (chain) {
         if (!s->d_chain && s->nsamples > 0) return fail(KMC_ERR_BAD_ARG, "sampler was created without KMC_STORE_CHAIN");
@@ -1975,6 +2040,72 @@ KMC_EXPORT kmc_status kmc_sampler_get_chain(kmc_sampler* s, double* chain, doubl
     }
     return KMC_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// dealt sub-ensembles (include/kissmcmc_hip.h: "dealt sub-ensembles")
+// ------------------------------------------------------------------------------------------
+KMC_EXPORT uint64_t kmc_deal_seed(uint64_t seed, int32_t deal_rank) { return deal_seed(seed, deal_rank); }
+
+KMC_EXPORT kmc_status kmc_deal_perm(uint64_t seed, int64_t epoch, int32_t deal_rank, int64_t S, int64_t* A, int64_t* C)
+{
+    if (!A || !C || S < 2 || epoch < 0 || deal_rank < 0) return fail(KMC_ERR_BAD_ARG, "bad argument");
+    deal_perm(seed, epoch, deal_rank, S, A, C);
+    return KMC_OK;
+}
+
+namespace {
+DealArgs deal_args(kmc_sampler* s, void* buf)
+{
+    DealArgs a{};
+    a.pos = s->d_pos; a.logp = s->d_logp; a.naccept = s->d_naccept; a.ids = s->d_ids;
+    a.buf = static_cast<double*>(buf);
+    a.S = s->nrows; a.A = 1; a.C = 0;
+    a.ndim = (int32_t)s->cfg.ndim; a.ld = (int32_t)s->ld;
+    return a;
+}
+}  // namespace
+
+KMC_EXPORT kmc_status kmc_sampler_deal_pack(kmc_sampler* s, int64_t epoch, void* send_dev)
+{
+    if (!s || !send_dev || epoch < 0) return fail(KMC_ERR_BAD_ARG, "bad argument");
+    if (!s->d_ids) return fail(KMC_ERR_BAD_ARG, "sampler was created without kmc_config.deal_count");
+    if (!s->positions_set) return fail(KMC_ERR_BAD_ARG, "kmc_sampler_set_positions has not succeeded yet");
+    HIP_TRY(hipSetDevice(s->cfg.device));
+    KMC_TRY(flush_moments_now(s));          // the accumulators are per slot: settle them before walkers change slots
+    DealArgs a = deal_args(s, send_dev);
+    deal_perm(s->user_seed, epoch, s->cfg.deal_rank, s->nrows, &a.A, &a.C);
+    const int64_t n = a.S * ((int64_t)a.ndim + 2);
+    hipLaunchKernelGGL(deal_pack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, a);
+    HIP_TRY(hipGetLastError());
+    return KMC_OK;
+}
+
+KMC_EXPORT kmc_status kmc_sampler_deal_unpack(kmc_sampler* s, const void* recv_dev)
+{
+    if (!s || !recv_dev) return fail(KMC_ERR_BAD_ARG, "bad argument");
+    if (!s->d_ids) return fail(KMC_ERR_BAD_ARG, "sampler was created without kmc_config.deal_count");
+    HIP_TRY(hipSetDevice(s->cfg.device));
+    const DealArgs a = deal_args(s, const_cast<void*>(recv_dev));
+    const int64_t n = a.S * ((int64_t)a.ndim + 2);
+    hipLaunchKernelGGL(deal_unpack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, a);
+    HIP_TRY(hipGetLastError());
+    return KMC_OK;
+}
+
+KMC_EXPORT kmc_status kmc_sampler_get_walker_ids(kmc_sampler* s, int64_t* host)
+{
+    if (!s || !host) return fail(KMC_ERR_BAD_ARG, "null argument");
+    HIP_TRY(hipSetDevice(s->cfg.device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    if (!s->d_ids) { for (int64_t i = 0; i < s->nrows; ++i) host[i] = i; return KMC_OK; }
+    std::vector<uint32_t> tmp((size_t)s->nrows);
+    HIP_TRY(hipMemcpy(tmp.data(), s->d_ids, tmp.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < tmp.size(); ++i) host[i] = (int64_t)tmp[i];
+    return KMC_OK;
+}
+
+KMC_EXPORT int kmc_sizeof_config(void) { return (int)sizeof(kmc_config); }
+KMC_EXPORT int kmc_sizeof_metropolis_config(void) { return (int)sizeof(kmc_metropolis_config); }
 
 // ------------------------------------------------------------------------------------------
 // one-shot: emcee(), src/samplers.jl:188-216 + :232-293

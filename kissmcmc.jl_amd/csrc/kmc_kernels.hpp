@@ -393,14 +393,27 @@ __device__ __forceinline__ void wait_for_peers(const HalfStepArgs& a, unsigned l
         __builtin_amdgcn_s_sleep(2);
         ok = lane >= a.nranks ||
              __hip_atomic_load(a.flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= need;
-        if (++spins > 30000000u) {                // tens of seconds: a peer died -- flag it and fall through
+        if (++spins > 30000000u) {                // ~10 s: a peer died -- flag it and fall through
             if (lane == 0) __hip_atomic_store(a.err, need + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             break;
         }
     }
-    // No cache invalidate is needed: L1/L2 were invalidated at kernel start and no peer row has
-    // been loaded by this kernel before this point; the fence only pins the compiler's load order.
+    // The fence only pins the compiler's load order.  Coherence of the PEER ROWS does not rest on cache state: the pull
+    // kernels read them with system-scope loads (load_row_sys: sc0 sc1 -- a line of another agent's memory is fetched
+    // from its owner, never served from this XCD's L2), because whether the kernel-start invalidate of a launch inside a
+    // hipGraph chain covers remote memory depends on the acquire scope the runtime puts into the AQL packet, and that
+    // cannot be observed with every "peer" sharing one GPU's L2.  (A system-scope acquire fence here instead --
+    // buffer_inv sc0 sc1 in every workgroup -- was measured: 24 against 11 us per half-step at 2 x 65 536 walkers.)
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// A 16-byte piece of a peer's row, read at SYSTEM scope (two relaxed 8-byte atomic loads: global_load_dwordx2 sc0 sc1).
+__device__ __forceinline__ double2 load_row_sys(const double2* p)
+{
+    const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
+    const unsigned long long lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const unsigned long long hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return make_double2(__longlong_as_double((long long)lo), __longlong_as_double((long long)hi));
 }
 
 #ifdef KMC_PROBE   // diagnostic build only: per-wave 100 MHz timestamps of the last launch of each half
@@ -521,6 +534,13 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
             shadowB[it] = ((unsigned long long)hi << 32) | lo;          // (lazy: the local copy's address, kept or zeroed below)
             oth = reinterpret_cast<const V2*>(shadowB[it]);
         }
+        if constexpr (P2P) {
+            if (a.push == 0 && a.nranks > 1) {                          // pull: the row lives in its owner's memory
+#pragma unroll
+                for (int k = 0; k < K; ++k) xo[it][k] = cv[k] ? load_row_sys(reinterpret_cast<const double2*>(&oth[k * L + j])) : zero2;
+                return;
+            }
+        }
 #pragma unroll
         for (int k = 0; k < K; ++k) xo[it][k] = cv[k] ? load_row(&oth[k * L + j]) : zero2;
     };
@@ -593,9 +613,9 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
                 const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)(unsigned)(addrR >> 32));
                 const unsigned long long rem = ((unsigned long long)hi << 32) | lo;
                 if (rem != 0ull) {
-                    const V2* oth = reinterpret_cast<const V2*>(rem);
+                    const double2* oth = reinterpret_cast<const double2*>(rem);
 #pragma unroll
-                    for (int k = 0; k < K; ++k) xo[it][k] = cv[k] ? load_row(&oth[k * L + j]) : zero2;
+                    for (int k = 0; k < K; ++k) xo[it][k] = cv[k] ? load_row_sys(&oth[k * L + j]) : zero2;
                 } else {
                     shadowB[it] = 0ull;                                  // the copy was good: nothing to write back
                 }
@@ -924,18 +944,28 @@ __device__ __forceinline__ void half_step_generic_body(const HalfStepFront& f, c
         oth = reinterpret_cast<const T*>(base) + (a.oth_row0 + r) * ld;
     }
     const double p0 = a.logp[gw];
+    // partner element d: P2P rows live in their owner's memory and are read at system scope (see load_row_sys)
+    auto oth_at = [&](int d) -> double {
+        if constexpr (P2P) {
+            if (a.nranks > 1)
+                return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(oth) + d,
+                                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+        }
+        return (double)oth[d];
+    };
 
     constexpr bool kHost = HostEvalTrait<Dens>::value;
     if constexpr (kHost) {
         if (a.prop_out != nullptr) {                                    // PROPOSE pass
-            for (int d = 0; d < ndim; ++d) a.prop_out[(int64_t)tid * ld + d] = fma(dr.z, (double)own[d] - (double)oth[d], (double)oth[d]);
+            for (int d = 0; d < ndim; ++d) { const double o = oth_at(d); a.prop_out[(int64_t)tid * ld + d] = fma(dr.z, (double)own[d] - o, o); }
             return;
         }
     }
     typename Dens::Seq q;
     Dens::seq_init(q);
     for (int d = 0; d < ndim; ++d) {
-        const double y = as_stored<T>(fma(dr.z, (double)own[d] - (double)oth[d], (double)oth[d]));   // :255
+        const double o = oth_at(d);
+        const double y = as_stored<T>(fma(dr.z, (double)own[d] - o, o));   // :255
         Dens::seq_add(q, y, d, a.dp);
     }
     double p1 = Dens::seq_finish(q, ndim, a.dp);                         // :257
@@ -949,7 +979,8 @@ __device__ __forceinline__ void half_step_generic_body(const HalfStepFront& f, c
     if (acc || do_mom || do_chain) {
         for (int d = 0; d < ndim; ++d) {
             const double xcd = (double)own[d];
-            const double cur = acc ? as_stored<T>(fma(dr.z, xcd - (double)oth[d], (double)oth[d])) : xcd;
+            const double o = acc ? oth_at(d) : 0.0;
+            const double cur = acc ? as_stored<T>(fma(dr.z, xcd - o, o)) : xcd;
             if (acc) own[d] = (T)cur;                                   // :261
             if (do_chain) reinterpret_cast<T*>(a.chain)[row * ld + d] = (T)cur;   // :269
             if (do_mom) {
@@ -1123,6 +1154,52 @@ __global__ void p2p_signal(const SignalArgs a)
     __threadfence_system();
     if ((int)threadIdx.x < a.nranks)
         __hip_atomic_store(a.peer_flags[threadIdx.x] + a.me, done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// Walker re-deal between sub-ensembles (kmc_config.deal_count, kmc_sampler_deal_pack / _unpack): a walker travels as
+// one row of ndim + 2 doubles {its position, its log-pdf, (walker id << 32 | naccept)}.  PACK writes the row of local
+// slot j to position t = (A j + C) mod S of the send buffer (a state-independent affine shuffle of this sub-ensemble's
+// S slots; chunk t / (S / P) goes to sub-ensemble t / (S / P)); UNPACK takes row i of the receive buffer into slot i.
+struct DealArgs {
+    double*   pos;        // [S][ld]
+    double*   logp;       // [S]
+    uint32_t* naccept;    // [S]
+    uint32_t* ids;        // [S] global walker index the slot currently holds
+    double*   buf;        // [S][ndim + 2]
+    int64_t   S;
+    int64_t   A, C;       // pack only
+    int32_t   ndim, ld;
+};
+__global__ __launch_bounds__(256) void deal_pack(const DealArgs a)
+{
+    const int64_t w = (int64_t)a.ndim + 2;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= a.S * w) return;
+    const int64_t j = idx / w;
+    const int e = (int)(idx - j * w);
+    const int64_t t = (int64_t)(((uint64_t)a.A * (uint64_t)j + (uint64_t)a.C) % (uint64_t)a.S);
+    double v;
+    if (e < a.ndim) v = a.pos[j * a.ld + e];
+    else if (e == a.ndim) v = a.logp[j];
+    else v = __hiloint2double((int)a.ids[j], (int)a.naccept[j]);
+    a.buf[t * w + e] = v;
+}
+__global__ __launch_bounds__(256) void deal_unpack(const DealArgs a)
+{
+    const int64_t w = (int64_t)a.ndim + 2;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= a.S * w) return;
+    const int64_t j = idx / w;
+    const int e = (int)(idx - j * w);
+    const double v = a.buf[idx];
+    if (e < a.ndim) a.pos[j * a.ld + e] = v;
+    else if (e == a.ndim) a.logp[j] = v;
+    else { a.naccept[j] = (uint32_t)__double2loint(v); a.ids[j] = (uint32_t)__double2hiint(v); }
+}
+__global__ __launch_bounds__(256) void deal_init_ids(uint32_t* ids, int64_t S, uint32_t first)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < S) ids[i] = first + (uint32_t)i;
 }
 
 // Graph replay support: the device-side generation counter and the schedule table of the next

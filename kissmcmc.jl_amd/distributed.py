@@ -234,3 +234,208 @@ class ShardedEmcee:
         v = self._sum(self.ex.local_moments())
         nd = self.ndim
         return v[:nd], v[nd:2 * nd], int(round(v[2 * nd]))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Dealt sub-ensembles: the multi-GPU mode without a per-half-step exchange (opt-in; include/kissmcmc_hip.h)
+# ------------------------------------------------------------------------------------------------------------------
+class HipDealExecutor:
+    """This rank's sub-ensemble on its MI355X: an ordinary :class:`~.sampler.Sampler` (``deal_rank/deal_count``) running on
+    torch's current stream, plus the two exchange buffers as torch tensors (what RCCL sends from / receives into)."""
+
+    def __init__(self, pdf, nsub_walkers, ndim, ngenerations, nburnin=0, nthin=1, a_scale=2.0, seed=0, rank=0, world=1,
+                 device=None, moments=True):
+        from .sampler import Sampler
+        if torch is None or not torch.cuda.is_available():
+            raise RuntimeError("HipDealExecutor needs a HIP device (torch.cuda); there is no CPU fallback")
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        self.nwalkers, self.ndim = int(nsub_walkers), int(ndim)
+        self.sampler = Sampler(pdf, nsub_walkers, ndim, ngenerations, nburnin, nthin, a_scale, seed, moments=moments,
+                               device=self.device.index, deal_rank=rank, deal_count=world)
+        # a stream of its own (graph capture is not allowed on the legacy default stream); DealtEmcee issues the
+        # collective inside `torch.cuda.stream(self.stream)`, so RCCL orders itself against the sampler's kernels
+        self.stream = torch.cuda.Stream(self.device)
+        self.sampler.set_stream(self.stream.cuda_stream)
+        self.send = torch.empty((self.nwalkers, self.ndim + 2), dtype=torch.float64, device=self.device)
+        self.recv = torch.empty_like(self.send)
+
+    def set_positions(self, theta_sub):
+        self.sampler.set_positions(theta_sub)
+
+    def run(self, ngenerations):
+        self.sampler.run(ngenerations)
+
+    def pack(self, epoch):
+        self.sampler.deal_pack(epoch, self.send.data_ptr())
+        return self.send
+
+    def unpack(self, recv):
+        self.sampler.deal_unpack(recv.data_ptr())
+
+    def sync(self):
+        self.sampler.sync()
+
+    def results(self):
+        """``(walker_ids, positions, logp, naccept, (sum, sumsq, n))`` of this sub-ensemble's slots."""
+        s = self.sampler
+        return s.walker_ids(), s.positions(), s.logp(), s.naccept(), s.moments()
+
+    def close(self):
+        self.sampler.close()
+
+
+class DealtEmcee:
+    """``world`` sub-ensembles (one per rank / GPU), each running the reference's algorithm unchanged on its own
+    walkers for ``epoch_gens`` generations (``src/samplers.jl:245-274``; no fabric traffic, hipGraph replay as on one
+    GPU), then ONE ``all_to_all_single`` (RCCL over xGMI) re-deals the walkers across the ranks by a state-independent
+    permutation.  Same target distribution as ``emcee``; the partner pool (this rank's complementary half instead of
+    the whole ensemble's, ``:250``) is what differs -- opt-in, never what ``bench.py`` reports as ``value``.
+
+    Everything is enqueued: the sampler runs on torch's current stream, so kernels, pack, the collective and unpack are
+    ordered on the device and the host never waits inside :meth:`run`.  With a backend that cannot move device
+    memory (``gloo``: CPU tests, several ranks sharing one GPU) the exchange is staged through the host.
+    """
+
+    def __init__(self, executor, nwalkers_total: int, ndim: int, epoch_gens: int, group=None):
+        self.ex = executor
+        self.group = group
+        self.rank = dist.get_rank(group) if dist is not None and dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist is not None and dist.is_initialized() else 1
+        self.nwalkers, self.ndim, self.epoch_gens = int(nwalkers_total), int(ndim), int(epoch_gens)
+        if self.nwalkers % self.world != 0 or (self.nwalkers // self.world) % self.world != 0:
+            raise ValueError("nwalkers must be divisible by world^2 (equal chunks in the all-to-all)")
+        if self.epoch_gens < 1:
+            raise ValueError("epoch_gens must be >= 1")
+        self.nsub = self.nwalkers // self.world
+        self.generation = 0
+        self.deals = 0
+
+    def set_positions(self, theta_global):
+        """Sub-ensemble r starts with global walkers ``[r S, (r+1) S)``."""
+        th = np.asarray(theta_global, dtype=np.float64).reshape(self.nwalkers, self.ndim)
+        self.ex.set_positions(th[self.rank * self.nsub:(self.rank + 1) * self.nsub])
+        self.generation = 0
+        self.deals = 0
+
+    def _deal(self, epoch: int):
+        stream = getattr(self.ex, "stream", None)
+        if stream is not None:
+            with torch.cuda.stream(stream):
+                self._deal_on_current_stream(epoch)
+        else:
+            self._deal_on_current_stream(epoch)
+
+    def _deal_on_current_stream(self, epoch: int):
+        send = self.ex.pack(epoch)
+        if self.world == 1:
+            self.ex.unpack(send)                         # the shuffle alone
+        else:
+            backend = dist.get_backend(self.group)
+            if backend == "nccl" or not send.is_cuda:
+                recv = self.ex.recv
+                dist.all_to_all_single(recv, send, group=self.group)
+            else:                                        # e.g. gloo with device tensors: stage through the host
+                h_send = send.cpu()
+                h_recv = torch.empty_like(h_send)
+                dist.all_to_all_single(h_recv, h_send, group=self.group)
+                recv = self.ex.recv
+                recv.copy_(h_recv)
+            self.ex.unpack(recv)
+        self.deals += 1
+
+    def run(self, ngenerations: int):
+        n = int(ngenerations)
+        while n > 0:
+            k = min(n, self.epoch_gens - self.generation % self.epoch_gens)
+            self.ex.run(k)
+            self.generation += k
+            n -= k
+            if self.generation % self.epoch_gens == 0:   # after generation g with (g + 1) % E == 0
+                self._deal(self.generation // self.epoch_gens - 1)
+
+    def sync(self):
+        self.ex.sync()
+
+    # -- results, in GLOBAL WALKER order (collectives off the data path) ------------------------------------------
+    def results(self):
+        """``dict(positions, logp, naccept, sum, sumsq, n)``; per-walker arrays indexed by the walker's index in the
+        initial ensemble, identical on every rank."""
+        ids, pos, logp, nacc, (s, q, n) = self.ex.results()
+        parts = [(ids, pos, logp, nacc, s, q, n)]
+        if self.world > 1:
+            parts = [None] * self.world
+            dist.all_gather_object(parts, (ids, pos, logp, nacc, s, q, n), group=self.group)
+        P = np.empty((self.nwalkers, self.ndim))
+        L = np.empty(self.nwalkers)
+        A = np.empty(self.nwalkers, dtype=np.int64)
+        for i, p, l, a, *_ in parts:
+            P[i], L[i], A[i] = p, l, a
+        return dict(positions=P, logp=L, naccept=A, sum=sum(p[4] for p in parts), sumsq=sum(p[5] for p in parts),
+                    n=int(sum(p[6] for p in parts)))
+
+    def close(self):
+        self.sync()
+        if self.world > 1:
+            dist.barrier(group=self.group)
+        self.ex.close()
+
+
+class LocalDealtEmcee:
+    """All ``P`` sub-ensembles of :class:`DealtEmcee` in ONE process (``executors[r]`` = sub-ensemble r), the all-to-all
+    done with tensor copies: the same algorithm and results, for single-process tests and one-GPU rehearsal."""
+
+    def __init__(self, executors, nwalkers_total: int, ndim: int, epoch_gens: int):
+        self.exs = list(executors)
+        self.world = len(self.exs)
+        self.nwalkers, self.ndim, self.epoch_gens = int(nwalkers_total), int(ndim), int(epoch_gens)
+        if self.nwalkers % self.world != 0 or (self.nwalkers // self.world) % self.world != 0:
+            raise ValueError("nwalkers must be divisible by world^2")
+        self.nsub = self.nwalkers // self.world
+        self.generation = 0
+
+    def set_positions(self, theta_global):
+        th = np.asarray(theta_global, dtype=np.float64).reshape(self.nwalkers, self.ndim)
+        for r, ex in enumerate(self.exs):
+            ex.set_positions(th[r * self.nsub:(r + 1) * self.nsub])
+        self.generation = 0
+
+    def run(self, ngenerations: int):
+        n = int(ngenerations)
+        c = self.nsub // self.world
+        while n > 0:
+            k = min(n, self.epoch_gens - self.generation % self.epoch_gens)
+            for ex in self.exs:
+                ex.run(k)
+            self.generation += k
+            n -= k
+            if self.generation % self.epoch_gens == 0:
+                sends = [ex.pack(self.generation // self.epoch_gens - 1) for ex in self.exs]
+                for ex in self.exs:
+                    ex.sync()
+                for q, ex in enumerate(self.exs):
+                    for r in range(self.world):
+                        ex.recv[r * c:(r + 1) * c].copy_(sends[r][q * c:(q + 1) * c])
+                if torch is not None and torch.cuda.is_available():
+                    torch.cuda.synchronize()
+                for ex in self.exs:
+                    ex.unpack(ex.recv)
+
+    def sync(self):
+        for ex in self.exs:
+            ex.sync()
+
+    def results(self):
+        P = np.empty((self.nwalkers, self.ndim))
+        L = np.empty(self.nwalkers)
+        A = np.empty(self.nwalkers, dtype=np.int64)
+        S = Q = 0.0
+        N = 0
+        for ex in self.exs:
+            i, p, l, a, (s, q, n) = ex.results()
+            P[i], L[i], A[i] = p, l, a
+            S, Q, N = S + s, Q + q, N + n
+        return dict(positions=P, logp=L, naccept=A, sum=S, sumsq=Q, n=int(N))
+
+    def close(self):
+        for ex in self.exs:
+            ex.close()

@@ -23,7 +23,7 @@ class Sampler:
                  store_logp: bool = False, moments: bool = False, use_graph: bool = True,
                  device: int = 0, shard_rank: int = 0, shard_count: int = 1, p2p: bool = False,
                  island_gens: int = 0, island_size: int = 0, p2p_finegrained: bool = False, p2p_fold: bool = False, p2p_push: bool = False,
-                 dtype: str = "f64", p2p_lazy: bool = False):
+                 dtype: str = "f64", p2p_lazy: bool = False, deal_rank: int = 0, deal_count: int = 0):
         if not isinstance(pdf, DeviceLogPdf):
             raise TypeError(
                 "pdf must be a menu log-density (GaussianIso, Exponential, Rosenbrock, LogNormal, MvNormal2), "
@@ -71,6 +71,7 @@ class Sampler:
         cfg.flags = flags
         cfg.device = int(device)
         cfg.shard_rank, cfg.shard_count = int(shard_rank), int(shard_count)
+        cfg.deal_rank, cfg.deal_count = int(deal_rank), int(deal_count)   # dealt sub-ensembles (distributed.DealtEmcee)
         cfg.user_density = pdf.user_handle     # runtime-compiled density (ExprDensity) or None
         cb = getattr(pdf, "c_callback", None)  # host-evaluated density (HostLogPdf) or None
         if cb is not None:
@@ -139,6 +140,20 @@ class Sampler:
         assert len(raw) == _lib.P2P_HANDLE_BYTES * self.cfg.shard_count
         buf = C.create_string_buffer(raw, len(raw))
         _lib.check(self._L.kmc_sampler_p2p_connect(self._h, buf))
+
+    # -- dealt sub-ensembles (kmc_config.deal_count; see include/kissmcmc_hip.h) ---------------
+    def deal_pack(self, epoch: int, send_ptr: int):
+        """Enqueue the packing of this sub-ensemble's rows ([nwalkers][ndim + 2] doubles, shuffled for the deal of ``epoch``)."""
+        _lib.check(self._L.kmc_sampler_deal_pack(self._h, int(epoch), C.c_void_p(send_ptr)))
+
+    def deal_unpack(self, recv_ptr: int):
+        _lib.check(self._L.kmc_sampler_deal_unpack(self._h, C.c_void_p(recv_ptr)))
+
+    def walker_ids(self) -> np.ndarray:
+        """Global walker index held by each local slot (row order of positions / naccept)."""
+        out = np.empty(self.nrows, dtype=np.int64)
+        _lib.check(self._L.kmc_sampler_get_walker_ids(self._h, out.ctypes.data_as(C.POINTER(C.c_int64))))
+        return out
 
     def set_positions(self, theta):
         theta = np.ascontiguousarray(np.asarray(theta, dtype=np.float64).reshape(self.nwalkers, self.ndim))

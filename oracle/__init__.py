@@ -95,6 +95,12 @@ def lib() -> C.CDLL:
         L.kmco_emcee_islands.argtypes = [C.POINTER(Config), C.c_int64, C.c_int64, dp, dp, C.POINTER(C.c_int64),
                                          dp, dp, dp, dp, C.POINTER(C.c_int64)]
         assert L.kmco_sizeof_config() == C.sizeof(Config)
+        L.kmco_deal_seed.restype = C.c_uint64
+        L.kmco_deal_seed.argtypes = [C.c_uint64, C.c_int32]
+        L.kmco_deal_perm.restype = None
+        L.kmco_deal_perm.argtypes = [C.c_uint64, C.c_int64, C.c_int32, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.kmco_emcee_dealt.argtypes = [C.POINTER(Config), C.c_int32, C.c_int64, dp, dp, C.POINTER(C.c_int64), dp, dp,
+                                       C.POINTER(C.c_int64), dp, dp, C.POINTER(C.c_int64)]
         L.kmco_init_ball.restype = C.c_int64
         L.kmco_init_ball.argtypes = [C.c_int32, dp, dp, dp, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_uint64,
                                      dp, dp, C.POINTER(C.c_int64)]
@@ -240,6 +246,37 @@ def emcee_islands(cfg: Config, island_size, epoch_gens, theta0, moments=True):
         st = lib().kmco_emcee_islands(C.byref(cfg), int(island_size), int(epoch_gens), _dp(theta0), _dp(acc), _ip(nacc),
                                       _dp(fpos), _dp(flogp), _dp(msum), _dp(msq), C.byref(nmom))
     return dict(status=st, accept_ratio=acc, naccept=nacc, final_pos=fpos, final_logp=flogp, sum=msum, sumsq=msq,
+                nmoment=nmom.value)
+
+
+def deal_seed(seed, rank):
+    return int(lib().kmco_deal_seed(int(seed) & 0xFFFFFFFFFFFFFFFF, int(rank)))
+
+
+def deal_perm(seed, epoch, rank, S):
+    a = C.c_int64()
+    c = C.c_int64()
+    lib().kmco_deal_perm(int(seed) & 0xFFFFFFFFFFFFFFFF, int(epoch), int(rank), int(S), C.byref(a), C.byref(c))
+    return a.value, c.value
+
+
+def emcee_dealt(cfg: Config, nsub, epoch_gens, theta0, moments=True):
+    """Dealt sub-ensembles (kmc_oracle.c: kmco_emcee_dealt): ``cfg.nwalkers`` walkers in ``nsub`` sub-ensembles, re-dealt
+    every ``epoch_gens`` generations.  Per-walker outputs are in GLOBAL WALKER order; ``slot_ids`` = walker per final slot."""
+    nw, nd = cfg.nwalkers, cfg.ndim
+    theta0 = np.ascontiguousarray(np.asarray(theta0, dtype=np.float64).reshape(nw, nd))
+    acc = np.zeros(nw)
+    nacc = np.zeros(nw, dtype=np.int64)
+    fpos = np.zeros((nw, nd))
+    flogp = np.zeros(nw)
+    ids = np.zeros(nw, dtype=np.int64)
+    msum = np.zeros(nd) if moments else None
+    msq = np.zeros(nd) if moments else None
+    nmom = C.c_int64(0)
+    with np.errstate(all="ignore"):
+        st = lib().kmco_emcee_dealt(C.byref(cfg), int(nsub), int(epoch_gens), _dp(theta0), _dp(acc), _ip(nacc), _dp(fpos), _dp(flogp),
+                                    _ip(ids), _dp(msum), _dp(msq), C.byref(nmom))
+    return dict(status=st, accept_ratio=acc, naccept=nacc, final_pos=fpos, final_logp=flogp, slot_ids=ids, sum=msum, sumsq=msq,
                 nmoment=nmom.value)
 
 

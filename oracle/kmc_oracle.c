@@ -31,6 +31,9 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #define KMCO_API __attribute__((visibility("default")))
 
@@ -224,11 +227,34 @@ KMCO_API void kmco_half_step(const kmco_config* c, double* pos, double* logp, in
 #pragma omp parallel num_threads(c->nthreads > 1 ? c->nthreads : 1)
     {
         double* y = (double*)malloc(sizeof(double) * (size_t)nd);
-#pragma omp for schedule(static)
-        for (int64_t i = 0; i < n_active; ++i) {
+        /* static partition of the active walkers over the team, as `omp for schedule(static)` would cut it; done by
+         * hand so that a thread can look ahead inside its own range: the draws of walker i + KMCO_PF are computed
+         * KMCO_PF iterations early (each still computed exactly once) and the partner row they name is prefetched --
+         * with the team spread over several L3 domains the random partner row is otherwise a serial cache miss per
+         * walker-step.  Purely a memory-latency measure: every walker's arithmetic is unchanged. */
+        enum { KMCO_PF = 8 };
+        int nth = 1, tid = 0;
+#ifdef _OPENMP
+        nth = omp_get_num_threads(); tid = omp_get_thread_num();
+#endif
+        const int64_t per = n_active / nth, rem = n_active % nth;
+        const int64_t lo = tid * per + (tid < rem ? tid : rem), hi = lo + per + (tid < rem ? 1 : 0);
+        int64_t q_no[KMCO_PF]; double q_uz[KMCO_PF], q_ua[KMCO_PF];
+        for (int64_t i = lo; i < hi && i < lo + KMCO_PF; ++i) {
+            kmco_draw(c->seed, step, (uint64_t)(act0 + active_begin + i), h, &q_no[i % KMCO_PF], &q_uz[i % KMCO_PF], &q_ua[i % KMCO_PF]);
+            const char* pr = (const char*)(pos + (oth0 + q_no[i % KMCO_PF]) * nd);
+            for (int64_t b = 0; b < nd * 8; b += 64) __builtin_prefetch(pr + b, 0, 1);
+        }
+        for (int64_t i = lo; i < hi; ++i) {
             const int64_t nc = act0 + active_begin + i;           /* :248 */
-            int64_t no_rel; double uz, ua;
-            kmco_draw(c->seed, step, (uint64_t)nc, h, &no_rel, &uz, &ua);
+            const int64_t no_rel = q_no[i % KMCO_PF];
+            const double uz = q_uz[i % KMCO_PF], ua = q_ua[i % KMCO_PF];
+            if (i + KMCO_PF < hi) {                               /* the slot is free now: look ahead */
+                const int64_t s2 = (i + KMCO_PF) % KMCO_PF;
+                kmco_draw(c->seed, step, (uint64_t)(nc + KMCO_PF), h, &q_no[s2], &q_uz[s2], &q_ua[s2]);
+                const char* pr = (const char*)(pos + (oth0 + q_no[s2]) * nd);
+                for (int64_t b = 0; b < nd * 8; b += 64) __builtin_prefetch(pr + b, 0, 1);
+            }
             const int64_t no = oth0 + no_rel;                      /* :250 rand(ncos) */
             const double t = fma(uz, c1, c0);
             const double z = t * t;                                /* :252 sample_g */
@@ -559,6 +585,117 @@ KMCO_API int kmco_emcee_islands(const kmco_config* c, int64_t S, int64_t epoch_g
     if (nmoment) *nmoment = nmom;
     free(pos); free(logp); free(nacc);
     return KMCO_OK;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * DEALT SUB-ENSEMBLES (an extension of the build, NOT a reference feature; opt-in) -- the multi-GPU mode
+ * without a per-half-step exchange.  Restated independently of the product code.
+ *
+ * The N = P*S walkers are held by P sub-ensembles of S slots.  For an epoch of `epoch_gens` generations
+ * sub-ensemble r runs the reference's algorithm unchanged (kmco_half_step: src/samplers.jl:245-274) on the S
+ * walkers in its slots -- partners from ITS complementary half -- with its own Philox key
+ * seed + (r + 1) * 0x9E3779B97F4A7C15 and the slot index as walker index.  After generation g with
+ * (g + 1) % epoch_gens == 0 the walkers are re-dealt (epoch e = (g + 1) / epoch_gens - 1): slot j of
+ * sub-ensemble r goes to send position t = (A j + C) mod S with (A, C) from
+ * Philox(ctr = {e_lo, e_hi, 0x4445414c "DEAL", r}, key = seed), A made coprime to S by stepping upwards; with
+ * c = S / P, chunk q = t / c goes to sub-ensemble q and lands in its slot r c + t % c.  A walker carries its
+ * position, log-pdf, acceptance counter and global index; sub-ensemble r starts with walkers [r S, (r+1) S).
+ * Each sub-ensemble update is a valid emcee move for its walkers and the deal does not look at the state, so
+ * the target distribution is unchanged; the partner-selection rule is what differs from the reference.
+ * ---------------------------------------------------------------------------------------- */
+KMCO_API uint64_t kmco_deal_seed(uint64_t seed, int32_t rank) { return seed + (uint64_t)(rank + 1) * 0x9E3779B97F4A7C15ull; }
+
+KMCO_API void kmco_deal_perm(uint64_t seed, int64_t epoch, int32_t rank, int64_t S, int64_t* A, int64_t* C)
+{
+    uint32_t ctr[4] = {(uint32_t)epoch, (uint32_t)((uint64_t)epoch >> 32), 0x4445414cu, (uint32_t)rank};
+    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    uint32_t w[4];
+    kmco_philox4x32_10(ctr, key, w);
+    int64_t a = (int64_t)((((uint64_t)w[0] << 32) | w[1]) % (uint64_t)S);
+    if (a < 1) a = 1;
+    while (gcd64(a, S) != 1) a = a + 1 >= S ? 1 : a + 1;
+    *A = a;
+    *C = (int64_t)((((uint64_t)w[2] << 32) | w[3]) % (uint64_t)S);
+}
+
+/* c->nwalkers = N (all sub-ensembles).  Outputs (any may be NULL) are indexed by GLOBAL WALKER (the index a walker
+ * had in theta0), except slot_ids [N]: the walker each slot holds at the end (slot = r S + j). */
+KMCO_API int kmco_emcee_dealt(const kmco_config* c, int32_t P, int64_t epoch_gens, const double* theta0,
+                              double* accept_ratio, int64_t* naccept_out, double* final_pos, double* final_logp,
+                              int64_t* slot_ids, double* msum, double* msumsq, int64_t* nmoment)
+{
+    if (!c || P < 1 || epoch_gens < 1 || c->nwalkers % P != 0) return KMCO_ERR_BAD_ARG;
+    const int64_t N = c->nwalkers, nd = c->ndim, S = N / P;
+    kmco_config sub = *c;
+    sub.nwalkers = S;
+    int st = kmco_validate(&sub);                                   /* every sub-ensemble is an emcee ensemble: :200-205 */
+    if (st != KMCO_OK) return st;
+    if (S % P != 0) return KMCO_ERR_BAD_ARG;
+    const int64_t chunk = S / P;
+
+    double* pos = (double*)malloc(sizeof(double) * (size_t)(N * nd));
+    double* pos2 = (double*)malloc(sizeof(double) * (size_t)(N * nd));
+    double* logp = (double*)malloc(sizeof(double) * (size_t)N);
+    double* logp2 = (double*)malloc(sizeof(double) * (size_t)N);
+    int64_t* nacc = (int64_t*)calloc((size_t)N, sizeof(int64_t));
+    int64_t* nacc2 = (int64_t*)calloc((size_t)N, sizeof(int64_t));
+    int64_t* ids = (int64_t*)malloc(sizeof(int64_t) * (size_t)N);
+    int64_t* ids2 = (int64_t*)malloc(sizeof(int64_t) * (size_t)N);
+    memcpy(pos, theta0, sizeof(double) * (size_t)(N * nd));
+    int bad = 0;
+    for (int64_t w = 0; w < N; ++w) {
+        ids[w] = w;
+        logp[w] = kmco_logpdf(c->density, c->params, pos + w * nd, nd);    /* :209-210 */
+        if (!isfinite(logp[w])) bad = 1;
+    }
+    if (msum) memset(msum, 0, sizeof(double) * (size_t)nd);
+    if (msumsq) memset(msumsq, 0, sizeof(double) * (size_t)nd);
+    int64_t nmom = 0;
+    const int64_t nblk = (N + KMCO_MBLK - 1) / KMCO_MBLK;
+    double* mpart = (msum || msumsq) ? (double*)malloc(sizeof(double) * (size_t)(nblk * 2 * nd)) : NULL;
+    const int64_t nsamples = c->ngenerations > c->nburnin ? (c->ngenerations - c->nburnin) / c->nthin : 0;
+
+    for (int64_t g = 0; g < c->ngenerations && !bad; ++g) {
+        const int64_t n = g + 1 - c->nburnin;                              /* :245 */
+        for (int32_t r = 0; r < P; ++r) {
+            sub.seed = kmco_deal_seed(c->seed, r);
+            for (int half = 0; half < 2; ++half)                           /* :246-247, inside sub-ensemble r */
+                kmco_half_step(&sub, pos + r * S * nd, logp + r * S, nacc + r * S, g, half, 0, S / 2, n > 0);
+        }
+        if (n > 0 && n % c->nthin == 0 && n / c->nthin - 1 < nsamples) {   /* :268 */
+            if (msum || msumsq) moments_add(pos, N, nd, msum, msumsq, mpart, nblk, c->nthreads);
+            nmom += N;
+        }
+        if ((g + 1) % epoch_gens == 0) {                                   /* the deal */
+            const int64_t e = (g + 1) / epoch_gens - 1;
+            for (int32_t r = 0; r < P; ++r) {
+                int64_t A, C;
+                kmco_deal_perm(c->seed, e, r, S, &A, &C);
+                for (int64_t j = 0; j < S; ++j) {
+                    const int64_t t = (int64_t)(((__int128)A * j + C) % S);
+                    const int64_t from = r * S + j, to = (t / chunk) * S + r * chunk + t % chunk;
+                    memcpy(pos2 + to * nd, pos + from * nd, sizeof(double) * (size_t)nd);
+                    logp2[to] = logp[from]; nacc2[to] = nacc[from]; ids2[to] = ids[from];
+                }
+            }
+            double* tp = pos; pos = pos2; pos2 = tp;
+            tp = logp; logp = logp2; logp2 = tp;
+            int64_t* ti = nacc; nacc = nacc2; nacc2 = ti;
+            ti = ids; ids = ids2; ids2 = ti;
+        }
+    }
+    const double denom = (double)(c->ngenerations - c->nburnin);           /* :291 */
+    for (int64_t s = 0; s < N && !bad; ++s) {
+        const int64_t w = ids[s];
+        if (accept_ratio) accept_ratio[w] = (double)nacc[s] / denom;
+        if (naccept_out) naccept_out[w] = nacc[s];
+        if (final_pos) memcpy(final_pos + w * nd, pos + s * nd, sizeof(double) * (size_t)nd);
+        if (final_logp) final_logp[w] = logp[s];
+        if (slot_ids) slot_ids[s] = w;
+    }
+    if (nmoment) *nmoment = nmom;
+    free(pos); free(pos2); free(logp); free(logp2); free(nacc); free(nacc2); free(ids); free(ids2); free(mpart);
+    return bad ? KMCO_ERR_NONFINITE_LOGP : KMCO_OK;
 }
 
 /* ------------------------------------------------------------------------------------------
