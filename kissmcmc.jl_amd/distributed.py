@@ -137,7 +137,8 @@ class P2PEmcee:
             dist.barrier(group=self.group)
 
     def set_positions(self, theta_global):
-        self._barrier()                 # nobody is still reading this rank's rows or flags
+        self.sampler.sync()             # this rank's own half-steps have drained (an asynchronous run() may precede) ...
+        self._barrier()                 # ... and so have everybody else's: nobody is still reading this rank's rows or flags
         self.sampler.set_positions(theta_global)
         self._barrier()                 # every rank's rows are in place and its flags are zero
 

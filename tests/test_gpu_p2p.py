@@ -1,7 +1,9 @@
-"""GPU: peer-to-peer walker sharding (KMC_P2P).  One GPU is enough to validate the protocol:
-two PROCESSES on the same device exchange IPC handles, read each other's rows through the
-peer-mapped pointers and order their half-steps with the progress flags -- exactly what 8
-processes on 8 GPUs do over xGMI.  Results must equal the unsharded oracle run bit for bit."""
+"""GPU: peer-to-peer walker sharding (KMC_P2P).  One GPU validates the PROTOCOL: two (or more)
+PROCESSES on the same device exchange IPC handles, read each other's rows through the peer-mapped
+pointers and order their half-steps with the progress flags, as 8 processes on 8 GPUs do over xGMI;
+results must equal the unsharded oracle run bit for bit.  What one GPU cannot show is cross-GPU cache
+coherence (every "peer" shares one L2 and one HBM here): the pull kernels therefore read peer rows with
+system-scope loads, and bench.py verifies the timed multi-GPU run against the unsharded run."""
 import os
 import socket
 import sys
