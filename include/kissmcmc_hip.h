@@ -99,6 +99,15 @@ enum {
                                   fewer kernel boundaries and no HBM traffic inside an epoch.  Needs nwalkers % island_size == 0,
                                   island_size >= ndim + 2, ndim <= 32, shard_count == 1; no chain storage.  Works with user densities
                                   when island_size * (ndim + 3) * 8 B <= 60 KiB. */
+    KMC_STREAM_CHAIN = 1u << 11, /* with KMC_STORE_CHAIN / KMC_STORE_LOGP: the chain does NOT live in HBM.  The device keeps a ring of three
+                                    blocks of sample slots; every completed block is copied to the caller's host buffers
+                                    (kmc_sampler_set_chain_host) by a second stream while sampling goes on, so the number of stored
+                                    samples is bounded by host memory, not by the 288 GB of HBM (the reference grows per-walker
+                                    vectors without bound, src/samplers.jl:268-272; C2 with nthin = 1 is 84 GB, C5 336 GB).  The
+                                    host buffers are page-locked in place (hipHostRegister), so the copies are direct DMA into
+                                    their final position; if that fails they are ordinary (staged) copies.  KMC_F64, one GPU
+                                    (no KMC_P2P / sharding / KMC_ISLANDS); small ensembles then run the multi-launch kernels.
+                                    kmc_emcee_run switches it on by itself when the chain would not fit the device. */
     KMC_P2P_FINEGRAINED = 1u << 7, /* with KMC_P2P: keep the rows in fine-grained (coherent, uncached-for-peers) device memory */
     KMC_P2P_PUSH    = 1u << 9, /* with KMC_P2P: every rank keeps local copies ("shadows") of all the other shards and reads its
                                   partner rows from them; a rank that accepts a move writes the new row into its shadow on
@@ -248,6 +257,12 @@ kmc_status  kmc_sampler_init_ball(kmc_sampler* s, const double* theta0 /* [ndim]
  * one; moments restart at the restored generation.  Not with chain storage, single GPU. */
 kmc_status  kmc_sampler_set_state(kmc_sampler* s, const double* pos_host, const double* logp_host,
                                   const int64_t* naccept_host, int64_t generation);
+/* KMC_STREAM_CHAIN: where the chain goes -- host buffers chain_host [nsamples][nwalkers][ndim] (KMC_STORE_CHAIN) and
+ * chain_logp_host [nsamples][nwalkers] (KMC_STORE_LOGP), caller-owned, alive until the sampler is destroyed (or this is
+ * called again).  Call before kmc_sampler_run; sample k of a run is complete in these buffers after the kmc_sampler_sync
+ * that follows the generation which stored it.  kmc_sampler_get_chain then copies from them (or is a no-op for the same
+ * pointers). */
+kmc_status  kmc_sampler_set_chain_host(kmc_sampler* s, double* chain_host, double* chain_logp_host);
 /* Enqueue `ngenerations` generations (asynchronous).  shard_count must be 1. */
 kmc_status  kmc_sampler_run(kmc_sampler* s, int64_t ngenerations);
 /* Enqueue ONE half-step (src/samplers.jl:248-273) of the current generation over this shard's

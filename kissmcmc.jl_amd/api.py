@@ -40,7 +40,7 @@ def emcee_counts(niter: int, nwalkers: int, nburnin=None, nthin: int = 1):
 
 def emcee(pdf, theta0s, niter: int = 10 ** 5, nburnin=None, nthin: int = 1, a_scale: float = 2.0,
           use_progress_meter: bool = True, hasblob: bool = False, init_blobs=None, reduce_blob=None,
-          seed=None, device: int = 0, dtype: str = "f64"):
+          seed=None, device: int = 0, dtype: str = "f64", stream_chain=None):
     """The affine-invariant ensemble sampler, on one MI355X.  ``dtype="f32"`` keeps the walkers in single
     precision on the device (a throughput option, device densities; everything returned is still float64).
 
@@ -48,6 +48,11 @@ def emcee(pdf, theta0s, niter: int = 10 ** 5, nburnin=None, nthin: int = 1, a_sc
     (``src/samplers.jl:292``): ``thetas[w][k]`` is sample ``k`` of walker ``w``
     (shape ``[nwalkers, nsamples]`` for scalar walkers, ``[nwalkers, nsamples, ndim]`` otherwise),
     ``accept_ratio[w]``, ``logdensities[w][k]``, and ``blobs`` (``None`` unless ``hasblob``).
+
+    ``stream_chain``: ``True`` streams the stored samples to host memory block by block while sampling (the device
+    keeps a small ring; the chain is bounded by host RAM instead of HBM, like the reference's growing vectors,
+    ``:268-272``), ``False`` keeps the whole chain on the device until the end, ``None`` (default) streams when the
+    chain would take more than 16 GiB.
 
     ``hasblob=True`` (``:150-151, :194-196``): ``pdf`` is a host callable returning ``(p, blob)``; the blobs
     stay on the host and follow the device's accept decisions.  ``blobs[w] = init_blobs(blob0s[w],
@@ -89,8 +94,10 @@ def emcee(pdf, theta0s, niter: int = 10 ** 5, nburnin=None, nthin: int = 1, a_sc
     if seed is None:
         seed = _fresh_seed()
 
+    if stream_chain is None:
+        stream_chain = dtype == "f64" and nsamples_walker * nwalkers * (ndim + 1) * 8 > (16 << 30)
     with Sampler(pdf, nwalkers, ndim, niter_walker, nburnin_walker, nthin, a_scale, seed,
-                 store_chain=True, store_logp=True, device=device, dtype=dtype) as s:
+                 store_chain=True, store_logp=True, device=device, dtype=dtype, stream_chain=bool(stream_chain)) as s:
         try:
             s.set_positions(theta0s)
         except _lib.KmcError as e:

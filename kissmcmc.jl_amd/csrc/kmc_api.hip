@@ -482,6 +482,17 @@ struct kmc_sampler {
     uint32_t* d_klast = nullptr;      // vec kernels: samples already credited per walker (d_logp, d_naccept, d_klast: one block)
     double2* d_ring = nullptr;        // vec kernels: parked draws of the walkers' next steps, [4][nrows] x 32 B (HalfStepArgs::ring)
     int64_t macc_stride = 0, macc_elems = 0;
+    // KMC_STREAM_CHAIN: d_chain / d_chain_logp are rings of ring_slots = 3 * ring_blk sample slots; completed blocks go to
+    // the caller's host buffers on copy_stream while sampling goes on
+    bool stream_chain = false;
+    int64_t ring_blk = 0, ring_slots = 0;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_filled[3] = {}, ev_copied[3] = {};
+    double* dst_chain = nullptr;      // host [nsamples][nlocal][ndim]
+    double* dst_logp = nullptr;       // host [nsamples][nlocal]
+    bool dst_chain_reg = false, dst_logp_reg = false;      // page-locked in place by us
+    int64_t blocks_copied = 0;        // blocks [0, blocks_copied) have their device-to-host copy enqueued
+    int64_t blocks_waited = 0;        // compute stream already waits for the copies of the blocks that blocks < this overwrite
     uint32_t* d_ids = nullptr;        // dealt sub-ensembles: global walker index held by each slot
     uint64_t user_seed = 0;           //   the caller's seed (cfg.seed is then this sub-ensemble's Philox key)
     int64_t moment_base = 0;  // samples that precede the restored state (kmc_sampler_set_state)
@@ -557,7 +568,7 @@ HalfStepArgs make_args(const kmc_sampler* s, int half, bool graph_mode, int64_t 
     a.naccept = s->d_naccept;
     a.sched_table = s->d_sched;
     a.sched_index = graph_mode ? (int32_t)gen_offset : -1;
-    a.sched_inline = make_sched(gen_offset, s->cfg.nburnin, s->cfg.nthin, s->nsamples);
+    a.sched_inline = make_sched(gen_offset, s->cfg.nburnin, s->cfg.nthin, s->nsamples, s->ring_slots);
     a.gw0 = (int64_t)half * s->h + s->active_begin;
     a.own_row0 = s->p2p ? (int64_t)half * s->h_loc : a.gw0;
     a.oth_row0 = s->p2p ? (int64_t)(1 - half) * s->h_loc : (int64_t)(1 - half) * s->h;
@@ -685,7 +696,7 @@ hipError_t launch_sweep(kmc_sampler* s)
 void launch_advance(kmc_sampler* s, int n, int64_t by)
 {
     hipLaunchKernelGGL(advance_schedule, dim3(1), dim3(64), 0, s->stream, s->d_gen, s->d_sched, n, by,
-                       s->cfg.nburnin, s->cfg.nthin, s->nsamples);
+                       s->cfg.nburnin, s->cfg.nthin, s->nsamples, s->ring_slots);
 }
 
 kmc_status sync_device_counter(kmc_sampler* s)
@@ -835,6 +846,85 @@ int64_t samples_done(const kmc_sampler* s)
     return k < s->nsamples ? k : s->nsamples;
 }
 
+// ---- KMC_STREAM_CHAIN ---------------------------------------------------------------------------------------
+int64_t samples_done_at(const kmc_sampler* s, int64_t generation)
+{
+    const int64_t post = generation - s->cfg.nburnin;
+    if (post <= 0) return 0;
+    const int64_t k = post / s->cfg.nthin;
+    return k < s->nsamples ? k : s->nsamples;
+}
+
+// device ring -> host, samples [k0, k1) of ONE block, on the copy stream
+kmc_status chain_copy_range(kmc_sampler* s, int64_t k0, int64_t k1)
+{
+    if (k1 <= k0) return KMC_OK;
+    const size_t nl = (size_t)s->nlocal, nd = (size_t)s->cfg.ndim, ld = (size_t)s->ld, n = (size_t)(k1 - k0);
+    const size_t slot0 = (size_t)(k0 % s->ring_slots);
+    if (s->d_chain && s->dst_chain) {
+        const double* src = s->d_chain + slot0 * nl * ld;
+        double* dst = s->dst_chain + (size_t)k0 * nl * nd;
+        if (ld == nd) HIP_TRY(hipMemcpyAsync(dst, src, n * nl * nd * sizeof(double), hipMemcpyDeviceToHost, s->copy_stream));
+        else HIP_TRY(hipMemcpy2DAsync(dst, nd * sizeof(double), src, ld * sizeof(double), nd * sizeof(double), n * nl, hipMemcpyDeviceToHost, s->copy_stream));
+    }
+    if (s->d_chain_logp && s->dst_logp)
+        HIP_TRY(hipMemcpyAsync(s->dst_logp + (size_t)k0 * nl, s->d_chain_logp + slot0 * nl, n * nl * sizeof(double), hipMemcpyDeviceToHost, s->copy_stream));
+    return KMC_OK;
+}
+
+// Before enqueueing generations [.., g_end): the ring positions they will write must have been drained to the host.
+kmc_status chain_before(kmc_sampler* s, int64_t g_end)
+{
+    if (!s->stream_chain) return KMC_OK;
+    const int64_t k1 = samples_done_at(s, g_end);
+    if (k1 <= 0) return KMC_OK;
+    const int64_t bmax = (k1 - 1) / s->ring_blk;
+    if (bmax - 3 >= s->blocks_copied)
+        return fail(KMC_ERR_UNSUPPORTED, "KMC_STREAM_CHAIN: one launch unit would lap the device ring (internal)");
+    for (; s->blocks_waited <= bmax; ++s->blocks_waited)
+        if (s->blocks_waited >= 3)      // block b overwrites the ring position of block b - 3: its copy must be over
+            HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_copied[s->blocks_waited % 3], 0));
+    return KMC_OK;
+}
+
+// After enqueueing up to s->generation: every block that is complete now goes to the host behind the sampling.
+kmc_status chain_after(kmc_sampler* s)
+{
+    if (!s->stream_chain) return KMC_OK;
+    const int64_t done = samples_done(s);
+    while ((s->blocks_copied + 1) * s->ring_blk <= done) {
+        const int64_t b = s->blocks_copied;
+        const int r = (int)(b % 3);
+        HIP_TRY(hipEventRecord(s->ev_filled[r], s->stream));
+        HIP_TRY(hipStreamWaitEvent(s->copy_stream, s->ev_filled[r], 0));
+        KMC_TRY(chain_copy_range(s, b * s->ring_blk, (b + 1) * s->ring_blk));
+        HIP_TRY(hipEventRecord(s->ev_copied[r], s->copy_stream));
+        s->blocks_copied = b + 1;
+    }
+    return KMC_OK;
+}
+
+// At a synchronisation point: the samples of the last, incomplete block as well (it is copied again, whole, once complete).
+kmc_status chain_flush(kmc_sampler* s)
+{
+    if (!s->stream_chain) return KMC_OK;
+    KMC_TRY(chain_after(s));
+    const int64_t done = samples_done(s), k0 = s->blocks_copied * s->ring_blk;
+    if (done > k0) {
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        KMC_TRY(chain_copy_range(s, k0, done));
+    }
+    HIP_TRY(hipStreamSynchronize(s->copy_stream));
+    return KMC_OK;
+}
+
+void chain_unregister(kmc_sampler* s)
+{
+    if (s->dst_chain_reg) { (void)hipHostUnregister(s->dst_chain); s->dst_chain_reg = false; }
+    if (s->dst_logp_reg) { (void)hipHostUnregister(s->dst_logp); s->dst_logp_reg = false; }
+    (void)hipGetLastError();
+}
+
 // KMC_P2P: a half-step kernel that gave up waiting for a peer has flagged it in d_err, and everything computed after that
 // is invalid -- every read-out of a P2P sampler checks (call after the stream has drained).
 kmc_status check_p2p_err(kmc_sampler* s)
@@ -948,6 +1038,11 @@ KMC_EXPORT kmc_status kmc_validate(const kmc_config* c)
         if (c->density == KMC_USER_DENSITY && (size_t)S * (size_t)(2 * c->ndim + 9) * sizeof(double) > 60 * 1024)
             return fail(KMC_ERR_UNSUPPORTED, "KMC_ISLANDS with a user density: island_size * (ndim + 3) * 8 must stay below 60 KiB (use island_size 128 or 64)");
     }
+    if (c->flags & KMC_STREAM_CHAIN) {
+        if (!(c->flags & (KMC_STORE_CHAIN | KMC_STORE_LOGP))) return fail(KMC_ERR_BAD_ARG, "KMC_STREAM_CHAIN needs KMC_STORE_CHAIN and / or KMC_STORE_LOGP");
+        if (c->dtype != KMC_F64 || P != 1 || (c->flags & (KMC_P2P | KMC_ISLANDS)))
+            return fail(KMC_ERR_UNSUPPORTED, "KMC_STREAM_CHAIN: KMC_F64, one GPU, without KMC_P2P / KMC_ISLANDS / sharding");
+    }
     if (c->deal_count < 0 || (c->deal_count > 0 && (c->deal_rank < 0 || c->deal_rank >= c->deal_count)))
         return fail(KMC_ERR_BAD_ARG, "deal_rank / deal_count out of range");
     if (c->deal_count > 0) {
@@ -1010,7 +1105,7 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         int rK = 0, rK0 = 1;
         while (2 * rK0 < s->ld / 2) rK0 *= 2;
         const size_t rlds = ((size_t)cfg->nwalkers * (size_t)(4 * (rK0 + 1)) + (size_t)cfg->nwalkers) * sizeof(double);
-        if (!s->f32 && cfg->nwalkers <= 256 && cfg->ndim <= 32 && s->cfg.shard_count == 1 && !(cfg->flags & (KMC_P2P | KMC_NO_GRAPH | KMC_ISLANDS)) &&
+        if (!s->f32 && cfg->nwalkers <= 256 && cfg->ndim <= 32 && s->cfg.shard_count == 1 && !(cfg->flags & (KMC_P2P | KMC_NO_GRAPH | KMC_ISLANDS | KMC_STREAM_CHAIN)) &&
             rlds <= 60 * 1024 && std::getenv("KMC_NO_RESIDENT") == nullptr)
             rK = rK0;
         int iS = 0;
@@ -1059,7 +1154,7 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         if (ea != hipSuccess) { (void)hipGetLastError(); kmc_sampler_destroy(s); return fail(KMC_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(ea)); }
     }
     if (!s->islands && !s->f32 && cfg->density != KMC_USER_DENSITY && !s->host_eval && cfg->nwalkers <= 1024 && cfg->ndim <= 32 &&
-        s->cfg.shard_count == 1 && !(cfg->flags & (KMC_P2P | KMC_NO_GRAPH)) && std::getenv("KMC_NO_RESIDENT") == nullptr) {
+        s->cfg.shard_count == 1 && !(cfg->flags & (KMC_P2P | KMC_NO_GRAPH | KMC_STREAM_CHAIN)) && std::getenv("KMC_NO_RESIDENT") == nullptr) {
         const int64_t chunks = s->ld / 2;
         int K = 1;
         while (2 * K < chunks) K *= 2;
@@ -1196,10 +1291,34 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
             CREATE_TRY(hipHostMalloc((void**)&s->h_acc, (size_t)s->h, hipHostMallocDefault));
         }
     }
+    int64_t chain_slots = s->nsamples;
+    if ((cfg->flags & KMC_STREAM_CHAIN) && s->nsamples > 0) {
+        // a ring of three blocks; a block holds at least the samples of one launch unit (a graph replay), so a unit never
+        // touches more than two blocks, and about 512 MiB otherwise (measured at C2, nthin = 10: 128 MiB blocks stream 22-26 GB/s, 512 MiB 43 GB/s of the 56 GB/s this link copies alone; KMC_CHAIN_BLOCK = samples per block, for tests)
+        if (const char* e = std::getenv("KMC_UPD_CHUNK")) { const long v = std::atol(e); if (v >= 16 && v <= 1024) s->uchunk = v; }
+        const int64_t unit = std::max<int64_t>(kGraphChunk, s->uchunk);
+        const int64_t per_unit = (unit + cfg->nthin - 1) / cfg->nthin + 1;
+        const size_t sample_bytes = (size_t)s->nlocal * ldz * sizeof(double);
+        int64_t blk = (int64_t)(((size_t)512 << 20) / sample_bytes);
+        if (blk > (s->nsamples + 15) / 16) blk = (s->nsamples + 15) / 16;      // ... but at least ~16 blocks per run: the last block's copy overlaps nothing
+        if (blk < 1) blk = 1;
+        if (blk > 4096) blk = 4096;
+        if (const char* e = std::getenv("KMC_CHAIN_BLOCK")) { const long v = std::atol(e); if (v >= 1) blk = v; }
+        if (blk < per_unit) blk = per_unit;
+        s->stream_chain = true;
+        s->ring_blk = blk;
+        s->ring_slots = 3 * blk;
+        chain_slots = s->ring_slots;
+        CREATE_TRY(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
+        for (int i = 0; i < 3; ++i) {
+            CREATE_TRY(hipEventCreateWithFlags(&s->ev_filled[i], hipEventDisableTiming));
+            CREATE_TRY(hipEventCreateWithFlags(&s->ev_copied[i], hipEventDisableTiming));
+        }
+    }
     if ((cfg->flags & KMC_STORE_CHAIN) && s->nsamples > 0)
-        CREATE_TRY(hipMalloc(&s->d_chain, (size_t)s->nsamples * (size_t)s->nlocal * ldz * esz));
+        CREATE_TRY(hipMalloc(&s->d_chain, (size_t)chain_slots * (size_t)s->nlocal * ldz * esz));
     if ((cfg->flags & KMC_STORE_LOGP) && s->nsamples > 0)
-        CREATE_TRY(hipMalloc(&s->d_chain_logp, (size_t)s->nsamples * (size_t)s->nlocal * sizeof(double)));
+        CREATE_TRY(hipMalloc(&s->d_chain_logp, (size_t)chain_slots * (size_t)s->nlocal * sizeof(double)));
 #undef CREATE_TRY
     if (s->p2p) {
         s->peer_pos[s->cfg.shard_rank] = s->d_pos;
@@ -1235,6 +1354,12 @@ KMC_EXPORT void kmc_sampler_destroy(kmc_sampler* s)
         (void)hipFree(s->d_err);
         (void)hipFree(s->d_done);
     }
+    if (s->copy_stream) { (void)hipStreamSynchronize(s->copy_stream); (void)hipStreamDestroy(s->copy_stream); }
+    for (int i = 0; i < 3; ++i) {
+        if (s->ev_filled[i]) (void)hipEventDestroy(s->ev_filled[i]);
+        if (s->ev_copied[i]) (void)hipEventDestroy(s->ev_copied[i]);
+    }
+    chain_unregister(s);
     if (s->own_pos) (void)hipFree(s->d_pos);
     (void)hipFree(s->d_logp);          // the {logp, naccept, klast} block
     (void)hipFree(s->d_mring);
@@ -1431,6 +1556,7 @@ kmc_status reset_run_state(kmc_sampler* s, bool eval_logp, int64_t generation, u
     s->generation = generation;
     s->launches = 0;
     s->have_run_events = false;
+    if (s->stream_chain) { HIP_TRY(hipStreamSynchronize(s->copy_stream)); s->blocks_copied = 0; s->blocks_waited = 0; }
     for (size_t w = 0; w < nw; ++w)
         if (!std::isfinite(lp[w])) {
             s->positions_set = false;
@@ -1613,6 +1739,7 @@ KMC_EXPORT kmc_status kmc_sampler_set_positions(kmc_sampler* s, const double* th
     s->moment_base = 0;
     s->launches = 0;
     s->have_run_events = false;
+    if (s->stream_chain) { HIP_TRY(hipStreamSynchronize(s->copy_stream)); s->blocks_copied = 0; s->blocks_waited = 0; }
     for (size_t w = 0; w < nw; ++w)
         if (!std::isfinite(lp[w])) {
             s->positions_set = false;
@@ -1620,6 +1747,32 @@ KMC_EXPORT kmc_status kmc_sampler_set_positions(kmc_sampler* s, const double* th
                         "walker " + std::to_string(w) + " has a non-finite initial log-pdf");
         }
     s->positions_set = true;
+    return KMC_OK;
+}
+
+KMC_EXPORT kmc_status kmc_sampler_set_chain_host(kmc_sampler* s, double* chain_host, double* chain_logp_host)
+{
+    if (!s) return fail(KMC_ERR_BAD_ARG, "null sampler");
+    if (!s->stream_chain) return fail(KMC_ERR_BAD_ARG, "sampler was created without KMC_STREAM_CHAIN (or stores no samples)");
+    if ((s->d_chain && !chain_host) || (s->d_chain_logp && !chain_logp_host))
+        return fail(KMC_ERR_BAD_ARG, "KMC_STREAM_CHAIN: a host buffer is needed for every stored quantity (KMC_STORE_CHAIN / KMC_STORE_LOGP)");
+    HIP_TRY(hipSetDevice(s->cfg.device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(hipStreamSynchronize(s->copy_stream));
+    chain_unregister(s);
+    s->dst_chain = s->d_chain ? chain_host : nullptr;
+    s->dst_logp = s->d_chain_logp ? chain_logp_host : nullptr;
+    // page-lock the destination in place: the copies are then direct DMA into their final position and truly
+    // asynchronous; without it (registration refused: limits, already registered) they are staged by the runtime
+    const size_t nl = (size_t)s->nlocal, ns = (size_t)s->nsamples;
+    if (s->dst_chain && std::getenv("KMC_NO_HOST_REGISTER") == nullptr) {
+        if (hipHostRegister(s->dst_chain, ns * nl * (size_t)s->cfg.ndim * sizeof(double), hipHostRegisterDefault) == hipSuccess) s->dst_chain_reg = true;
+        else (void)hipGetLastError();
+    }
+    if (s->dst_logp && std::getenv("KMC_NO_HOST_REGISTER") == nullptr) {
+        if (hipHostRegister(s->dst_logp, ns * nl * sizeof(double), hipHostRegisterDefault) == hipSuccess) s->dst_logp_reg = true;
+        else (void)hipGetLastError();
+    }
     return KMC_OK;
 }
 
@@ -1631,6 +1784,8 @@ KMC_EXPORT kmc_status kmc_sampler_run(kmc_sampler* s, int64_t ngen)
         return fail(KMC_ERR_UNSUPPORTED, "kmc_sampler_run needs shard_count == 1 or KMC_P2P; replica-sharded drivers call kmc_sampler_half_step");
     if (s->p2p && !s->connected) return fail(KMC_ERR_BAD_ARG, "kmc_sampler_p2p_connect has not been called");
     if (s->generation + ngen >= (int64_t)1 << 31) return fail(KMC_ERR_UNSUPPORTED, "at most 2^31 - 1 generations (the step index is 32 bits)");
+    if (s->stream_chain && ((s->d_chain && !s->dst_chain) || (s->d_chain_logp && !s->dst_logp)))
+        return fail(KMC_ERR_BAD_ARG, "KMC_STREAM_CHAIN: call kmc_sampler_set_chain_host before kmc_sampler_run");
     HIP_TRY(hipSetDevice(s->cfg.device));
     HIP_TRY(hipEventRecord(s->ev0, s->stream));
     if (s->resident) {
@@ -1701,6 +1856,7 @@ KMC_EXPORT kmc_status kmc_sampler_run(kmc_sampler* s, int64_t ngen)
         // -> ACCEPT on the device (which recomputes the same proposals from the same draws)
         const size_t hh = (size_t)s->h, nd = (size_t)s->cfg.ndim, ld = (size_t)s->ld;
         for (; ngen > 0; --ngen) {
+            KMC_TRY(chain_before(s, s->generation + 1));
             for (int half = 0; half < 2; ++half) {
                 HalfStepArgs a = make_args(s, half, false, s->generation);
                 a.prop_out = s->d_prop;
@@ -1729,6 +1885,7 @@ KMC_EXPORT kmc_status kmc_sampler_run(kmc_sampler* s, int64_t ngen)
                 }
             }
             s->generation += 1;
+            KMC_TRY(chain_after(s));
         }
         HIP_TRY(hipEventRecord(s->ev1, s->stream));
         s->have_run_events = true;
@@ -1737,24 +1894,28 @@ KMC_EXPORT kmc_status kmc_sampler_run(kmc_sampler* s, int64_t ngen)
     auto graph_chunk = [&]() -> kmc_status {
         KMC_TRY(ensure_graph(s));
         KMC_TRY(sync_device_counter(s));
+        KMC_TRY(chain_before(s, s->generation + kGraphChunk));
         HIP_TRY(hipGraphLaunch(s->graph_exec, s->stream));
         HIP_TRY(launch_sweep(s));
         s->generation += kGraphChunk;
         s->dev_gen += kGraphChunk;
         s->launches += 2 * kGraphChunk;
         ngen -= kGraphChunk;
-        return KMC_OK;
+        return chain_after(s);
     };
     auto eager_generations = [&](int64_t n) -> kmc_status {
         for (; n > 0; --n, --ngen) {
+            KMC_TRY(chain_before(s, s->generation + 1));
             for (int half = 0; half < 2; ++half) KMC_TRY(launch_half(s, half, false, s->generation));
             s->generation += 1;
             s->launches += 2;
             if (++s->gens_since_sweep >= kSweepEvery) HIP_TRY(launch_sweep(s));
+            KMC_TRY(chain_after(s));
         }
         return KMC_OK;
     };
     auto updated_chunk = [&]() -> kmc_status {
+        KMC_TRY(chain_before(s, s->generation + s->uchunk));
         if (launch_updated_graph(s) != KMC_OK) {       // nothing was enqueued: fall back to the table graph for good
             s->launch_mode = 1;
             return graph_chunk();
@@ -1763,7 +1924,7 @@ KMC_EXPORT kmc_status kmc_sampler_run(kmc_sampler* s, int64_t ngen)
         s->generation += s->uchunk;
         s->launches += 2 * s->uchunk;
         ngen -= s->uchunk;
-        return KMC_OK;
+        return chain_after(s);
     };
     // How to issue the launches?  Same kernels, same results, three ways:
     //   1 table graph   -- hipGraph replay; the kernels read their generation from a device table (one scalar round
@@ -1828,11 +1989,13 @@ KMC_EXPORT kmc_status kmc_sampler_half_step(kmc_sampler* s, int half)
     if (s->resident) return fail(KMC_ERR_UNSUPPORTED, "this small ensemble runs in resident mode (whole generations per launch); create it with KMC_NO_GRAPH to step by halves");
     if (s->generation >= ((int64_t)1 << 31) - 1) return fail(KMC_ERR_UNSUPPORTED, "at most 2^31 - 1 generations (the step index is 32 bits)");
     HIP_TRY(hipSetDevice(s->cfg.device));
+    if (half == 0) KMC_TRY(chain_before(s, s->generation + 1));
     KMC_TRY(launch_half(s, half, false, s->generation));
     s->launches += 1;
     if (half == 1) {
         s->generation += 1;
         if (++s->gens_since_sweep >= kSweepEvery) HIP_TRY(launch_sweep(s));
+        KMC_TRY(chain_after(s));
     }
     return KMC_OK;
 }
@@ -1842,6 +2005,7 @@ KMC_EXPORT kmc_status kmc_sampler_sync(kmc_sampler* s)
     if (!s) return fail(KMC_ERR_BAD_ARG, "null sampler");
     HIP_TRY(hipSetDevice(s->cfg.device));
     HIP_TRY(hipStreamSynchronize(s->stream));
+    KMC_TRY(chain_flush(s));
     return check_p2p_err(s);
 }
 
@@ -1891,6 +2055,7 @@ KMC_EXPORT kmc_status kmc_sampler_describe(const kmc_sampler* s, char* buf, int6
     if (s->lazy) o << "; lazy pull into local copies (KMC_P2P_LAZY)";
     else if (s->push) o << "; accepted rows pushed into the peers' local copies (KMC_P2P_PUSH)";
     if (s->f32) o << "; rows kept in float (KMC_F32), arithmetic in double";
+    if (s->stream_chain) o << "; chain streamed to host memory in blocks of " << s->ring_blk << " samples (device ring of 3 blocks" << (s->dst_chain_reg || s->dst_logp_reg ? ", destination page-locked" : "") << ")";
     if (s->d_ids) o << "; dealt sub-ensemble " << s->cfg.deal_rank << "/" << s->cfg.deal_count << " (walkers re-dealt between epochs)";
     if (s->d_mring) o << "; moments through a ring of " << s->mring_depth << " posted rows per wave";
     if (s->user) o << "; runtime-compiled density";
@@ -2030,6 +2195,14 @@ KMC_EXPORT kmc_status kmc_sampler_get_chain(kmc_sampler* s, double* chain, doubl
     HIP_TRY(hipStreamSynchronize(s->stream));
     KMC_TRY(check_p2p_err(s));
     const size_t rows = (size_t)samples_done(s) * (size_t)s->nlocal;
+    if (s->stream_chain) {             // the chain is in the caller's host buffers already
+        KMC_TRY(chain_flush(s));
+        if (chain && !s->d_chain) return fail(KMC_ERR_BAD_ARG, "sampler was created without KMC_STORE_CHAIN");
+        if (chain_logp && !s->d_chain_logp) return fail(KMC_ERR_BAD_ARG, "sampler was created without KMC_STORE_LOGP");
+        if (chain && chain != s->dst_chain) std::memcpy(chain, s->dst_chain, rows * (size_t)s->cfg.ndim * sizeof(double));
+        if (chain_logp && chain_logp != s->dst_logp) std::memcpy(chain_logp, s->dst_logp, rows * sizeof(double));
+        return KMC_OK;
+    }
     if (chain) {
         if (!s->d_chain && s->nsamples > 0) return fail(KMC_ERR_BAD_ARG, "sampler was created without KMC_STORE_CHAIN");
         HIP_TRY(download_rows(s, chain, s->d_chain, rows));
@@ -2119,9 +2292,19 @@ KMC_EXPORT kmc_status kmc_emcee_run(const kmc_config* cfg, const double* theta0,
     if (out->sum || out->sumsq) c.flags |= KMC_MOMENTS;
     c.shard_rank = 0;
     c.shard_count = 1;
+    if ((out->chain || out->chain_logp) && c.dtype == KMC_F64 && !(c.flags & (KMC_ISLANDS | KMC_P2P)) && c.nthin > 0 && c.ngenerations > c.nburnin) {
+        // a chain that does not fit the device is streamed to the caller's buffers while sampling (KMC_STREAM_CHAIN)
+        size_t free_b = 0, total_b = 0;
+        const size_t ns = (size_t)((c.ngenerations - c.nburnin) / c.nthin), nw_ = (size_t)c.nwalkers;
+        const size_t need = ns * nw_ * ((out->chain ? (size_t)(c.ndim + (c.ndim & 1)) * sizeof(double) : 0) + (out->chain_logp ? sizeof(double) : 0));
+        if (hipSetDevice(c.device) == hipSuccess && hipMemGetInfo(&free_b, &total_b) == hipSuccess && need > free_b / 10 * 8) c.flags |= KMC_STREAM_CHAIN;
+        else (void)hipGetLastError();
+    }
     kmc_sampler* s = nullptr;
     KMC_TRY(kmc_sampler_create(&c, &s));
-    kmc_status st = kmc_sampler_set_positions(s, theta0);
+    kmc_status st = KMC_OK;
+    if (s->stream_chain) st = kmc_sampler_set_chain_host(s, out->chain, out->chain_logp);
+    if (st == KMC_OK) st = kmc_sampler_set_positions(s, theta0);
     if (st == KMC_OK) st = kmc_sampler_run(s, c.ngenerations);
     if (st == KMC_OK) st = kmc_sampler_sync(s);
     if (st == KMC_OK) st = kmc_sampler_last_run_ms(s, &out->device_ms);
@@ -2619,6 +2802,7 @@ KMC_EXPORT kmc_status kmc_sampler_int_acorr(kmc_sampler* s, double c, double* ta
 {
     if (!s) return fail(KMC_ERR_BAD_ARG, "null sampler");
     if (!s->d_chain) return fail(KMC_ERR_BAD_ARG, "sampler was created without KMC_STORE_CHAIN");
+    if (s->stream_chain) return fail(KMC_ERR_UNSUPPORTED, "KMC_STREAM_CHAIN: the chain is on the host; use kmc_int_acorr on it");
     if (s->ld != s->cfg.ndim) return fail(KMC_ERR_UNSUPPORTED, "odd ndim: rows are padded on the device; use kmc_int_acorr on the downloaded chain");
     if (s->f32) return fail(KMC_ERR_UNSUPPORTED, "KMC_F32: the device chain is float; use kmc_int_acorr on the downloaded chain");
     HIP_TRY(hipSetDevice(s->cfg.device));

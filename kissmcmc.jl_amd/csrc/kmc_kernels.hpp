@@ -65,7 +65,8 @@ struct SchedEntry {
 static_assert(sizeof(SchedEntry) == 32, "schedule_of loads an entry as eight dwords");
 enum : uint32_t { kCount = 1u, kSample = 2u };
 
-__host__ __device__ inline SchedEntry make_sched(int64_t gen, int64_t nburnin, int64_t nthin, int64_t nsamples)
+// ring_slots > 0 (KMC_STREAM_CHAIN): the device keeps only a ring of that many sample slots; sample k goes to slot k % ring_slots.
+__host__ __device__ inline SchedEntry make_sched(int64_t gen, int64_t nburnin, int64_t nthin, int64_t nsamples, int64_t ring_slots = 0)
 {
     SchedEntry e{gen, 0, 0u, 0u, {0u, 0u}};
     const int64_t n = gen + 1 - nburnin;
@@ -77,7 +78,7 @@ __host__ __device__ inline SchedEntry make_sched(int64_t gen, int64_t nburnin, i
         e.flags |= kCount;                              // :265, counters restart at n == 0 (:285-288)
         if (n % nthin == 0) {                           // :268
             const int64_t k = n / nthin - 1;
-            if (k < nsamples) { e.flags |= kSample; e.slot = k; }
+            if (k < nsamples) { e.flags |= kSample; e.slot = ring_slots > 0 ? k % ring_slots : k; }
         }
     }
     return e;
@@ -1205,11 +1206,11 @@ __global__ __launch_bounds__(256) void deal_init_ids(uint32_t* ids, int64_t S, u
 // Graph replay support: the device-side generation counter and the schedule table of the next
 // `n` generations (one thread each).  *gen += by happens before the table is rebuilt.
 __global__ void advance_schedule(int64_t* gen, SchedEntry* table, int n, int64_t by,
-                                 int64_t nburnin, int64_t nthin, int64_t nsamples)
+                                 int64_t nburnin, int64_t nthin, int64_t nsamples, int64_t ring_slots)
 {
     const int64_t base = *gen + by;
     __syncthreads();
-    if ((int)threadIdx.x < n) table[threadIdx.x] = make_sched(base + threadIdx.x, nburnin, nthin, nsamples);
+    if ((int)threadIdx.x < n) table[threadIdx.x] = make_sched(base + threadIdx.x, nburnin, nthin, nsamples, ring_slots);
     if (threadIdx.x == 0) *gen = base;
 }
 #endif  // KMC_DEFINE_DRIVER_KERNELS

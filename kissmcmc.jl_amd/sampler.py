@@ -23,7 +23,8 @@ class Sampler:
                  store_logp: bool = False, moments: bool = False, use_graph: bool = True,
                  device: int = 0, shard_rank: int = 0, shard_count: int = 1, p2p: bool = False,
                  island_gens: int = 0, island_size: int = 0, p2p_finegrained: bool = False, p2p_fold: bool = False, p2p_push: bool = False,
-                 dtype: str = "f64", p2p_lazy: bool = False, deal_rank: int = 0, deal_count: int = 0):
+                 dtype: str = "f64", p2p_lazy: bool = False, deal_rank: int = 0, deal_count: int = 0,
+                 stream_chain: bool = False):
         if not isinstance(pdf, DeviceLogPdf):
             raise TypeError(
                 "pdf must be a menu log-density (GaussianIso, Exponential, Rosenbrock, LogNormal, MvNormal2), "
@@ -53,6 +54,9 @@ class Sampler:
             flags |= _lib.MOMENTS
         if not use_graph:
             flags |= _lib.NO_GRAPH
+        if stream_chain and (store_chain or store_logp):
+            # KMC_STREAM_CHAIN: the chain goes to host arrays block by block while sampling (bounded by host RAM, not HBM)
+            flags |= _lib.STREAM_CHAIN
         if p2p:
             flags |= _lib.P2P
             if p2p_finegrained:
@@ -88,6 +92,13 @@ class Sampler:
         self.p2p = bool(p2p)
         # rows this object holds: the whole ensemble, or (P2P) this shard's slices of both halves
         self.nrows = self.nlocal if self.p2p else self.nwalkers
+        self._host_chain = self._host_logp = None
+        if flags & _lib.STREAM_CHAIN and self.nsamples > 0:
+            # the destination of the streamed chain: host arrays owned by this object (page-locked in place by the library)
+            self._host_chain = np.empty((self.nsamples, self.nlocal, self.ndim)) if store_chain else None
+            self._host_logp = np.empty((self.nsamples, self.nlocal)) if store_logp else None
+            _lib.check(self._L.kmc_sampler_set_chain_host(self._h, _dp(self._host_chain) if store_chain else None,
+                                                          _dp(self._host_logp) if store_logp else None))
 
     # -- lifecycle --------------------------------------------------------------------------
     def close(self):
@@ -281,6 +292,9 @@ class Sampler:
         ns = self.nsamples
         post = self.generation - self.cfg.nburnin
         done = 0 if post <= 0 else min(ns, post // self.cfg.nthin)
+        if self._host_chain is not None or self._host_logp is not None:
+            self.sync()                                   # KMC_STREAM_CHAIN: completes the copies of everything stored so far
+            return (None if self._host_chain is None else self._host_chain[:done]), (self._host_logp[:done] if (logp and self._host_logp is not None) else None)
         ch = np.empty((done, self.nlocal, self.ndim))
         lp = np.empty((done, self.nlocal)) if logp else None
         _lib.check(self._L.kmc_sampler_get_chain(self._h, _dp(ch), _dp(lp) if logp else None))

@@ -1,0 +1,141 @@
+"""GPU: KMC_STREAM_CHAIN -- the stored samples (reference src/samplers.jl:268-272: thetas[nc], logdensities[nc] grow by
+push!) leave the device block by block while sampling goes on: a ring of three sample blocks in HBM, a second stream
+copying completed blocks into the caller's (page-locked) host arrays.  The streamed chain must equal the oracle's chain
+entry for entry, across several laps of the ring, whatever the launch mode, thinning, row padding or run splitting."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_chain(oracle, did, params, th, G, nburn, nthin, seed):
+    nw, nd = th.shape
+    r = oracle.emcee(oracle.make_config(did, params, nw, nd, G, nburn, nthin, 2.0, seed, nthreads=8), th)
+    assert r["status"] == 0
+    return r
+
+
+def _equal(chain, clogp, ref):
+    np.testing.assert_array_equal(chain, ref["chain"])
+    assert np.all(np.abs(clogp - ref["chain_logp"]) <= 1e-12 * np.maximum(1.0, np.abs(ref["chain_logp"])))
+
+
+def test_streamed_chain_equals_oracle_over_three_ring_laps(kmc, oracle, monkeypatch):
+    """4096 x 32, nthin = 1, 640 stored samples through a ring of 3 x 65 sample slots: > 3 laps."""
+    monkeypatch.setenv("KMC_CHAIN_BLOCK", "1")            # smallest legal block: the samples of one graph replay (+1)
+    nw, nd, G, nburn, seed = 4096, 32, 700, 60, 5
+    th = np.random.default_rng(1).standard_normal((nw, nd))
+    with kmc.Sampler(kmc.GaussianIso(), nw, nd, G, nburn, 1, 2.0, seed, store_chain=True, store_logp=True, moments=True,
+                     stream_chain=True) as s:
+        assert "chain streamed to host memory in blocks of 65 samples" in s.describe()
+        s.set_positions(th)
+        s.run(G)
+        s.sync()
+        chain, clogp = s.chain()
+        assert chain.shape == (G - nburn, nw, nd) and (G - nburn) > 3 * 3 * 65
+        ref = _oracle_chain(oracle, oracle.GAUSSIAN_ISO, [0.0, 1.0], th, G, nburn, 1, seed)
+        _equal(chain, clogp, ref)
+        np.testing.assert_array_equal(s.positions(), ref["final_pos"])
+        np.testing.assert_array_equal(s.naccept(), ref["naccept"])
+        m = s.moments()
+        np.testing.assert_allclose(m[0], ref["sum"], rtol=1e-11, atol=1e-8)
+
+
+@pytest.mark.parametrize("case", ["thin3_odd_ndim", "pieces_with_syncs", "eager_launches", "logp_only", "chain_only", "rosen_draw_ring",
+                                  "small_ensemble", "unregistered_destination"])
+def test_streamed_chain_variants(kmc, oracle, monkeypatch, case):
+    monkeypatch.setenv("KMC_CHAIN_BLOCK", "1")
+    pdf, did, params, nw, nd, G, nburn, nthin, scale = kmc.GaussianIso(), oracle.GAUSSIAN_ISO, [0.0, 1.0], 1024, 8, 500, 37, 1, 1.0
+    kw = dict(store_chain=True, store_logp=True)
+    if case == "thin3_odd_ndim":
+        nd, nthin, G = 7, 3, 1900                        # padded device rows -> strided copies; 23 samples per replay
+    elif case == "eager_launches":
+        kw["use_graph"] = False
+    elif case == "logp_only":
+        kw = dict(store_chain=False, store_logp=True)
+    elif case == "chain_only":
+        kw = dict(store_chain=True, store_logp=False)
+    elif case == "rosen_draw_ring":
+        pdf, did, params, nd, scale = kmc.Rosenbrock(), oracle.ROSENBROCK, [1.0, 100.0, 20.0], 64, 0.1
+    elif case == "small_ensemble":
+        nw, nd = 100, 2                                  # would run in resident mode; streamed: multi-launch kernels
+    elif case == "unregistered_destination":
+        monkeypatch.setenv("KMC_NO_HOST_REGISTER", "1")  # staged copies instead of DMA into page-locked arrays
+    th = scale * np.random.default_rng(2).standard_normal((nw, nd))
+    seed = 77
+    with kmc.Sampler(pdf, nw, nd, G, nburn, nthin, 2.0, seed, stream_chain=True, **kw) as s:
+        s.set_positions(th)
+        if case == "pieces_with_syncs":
+            for n in (50, 1, 130, 64, 200, G - 445):      # syncs inside blocks: partial flush, then the whole block again
+                s.run(n)
+                s.sync()
+                c, l = s.chain()
+                assert len(c) == max(0, (s.generation - nburn) // nthin)
+        else:
+            s.run(G)
+        s.sync()
+        chain, clogp = s.chain()
+    ref = _oracle_chain(oracle, did, params, th, G, nburn, nthin, seed)
+    assert ref["nsamples"] > 6 * 65 // max(1, nthin) or nthin > 1
+    if kw["store_chain"]:
+        np.testing.assert_array_equal(chain, ref["chain"])
+    else:
+        assert chain is None
+    if kw["store_logp"]:
+        assert np.all(np.abs(clogp - ref["chain_logp"]) <= 1e-12 * np.maximum(1.0, np.abs(ref["chain_logp"])))
+    else:
+        assert clogp is None
+
+
+def test_streamed_chain_restart_and_emcee_front_end(kmc, oracle, monkeypatch):
+    monkeypatch.setenv("KMC_CHAIN_BLOCK", "1")
+    nw, nd, G, nburn = 512, 4, 400, 100
+    th = np.random.default_rng(3).standard_normal((nw, nd))
+    with kmc.Sampler(kmc.GaussianIso(), nw, nd, G, nburn, 1, 2.0, 9, store_chain=True, store_logp=True, stream_chain=True) as s:
+        for _ in range(2):                               # set_positions restarts the job: the ring bookkeeping too
+            s.set_positions(th)
+            s.run(G)
+            s.sync()
+        chain, clogp = s.chain()
+    _equal(chain, clogp, _oracle_chain(oracle, oracle.GAUSSIAN_ISO, [0.0, 1.0], th, G, nburn, 1, 9))
+    # the reference's front end: identical outputs with and without streaming
+    a = kmc.emcee(kmc.GaussianIso(), th, niter=nw * G, seed=4, use_progress_meter=False, stream_chain=True)
+    b = kmc.emcee(kmc.GaussianIso(), th, niter=nw * G, seed=4, use_progress_meter=False, stream_chain=False)
+    for x, y in zip(a[:3], b[:3]):
+        np.testing.assert_array_equal(x, y)
+
+
+def test_one_shot_c_abi_streams_into_the_callers_buffers(kmc, oracle, monkeypatch):
+    """kmc_emcee_run with KMC_STREAM_CHAIN: samples land in out->chain / out->chain_logp directly."""
+    from kissmcmc_jl_amd import _lib
+    monkeypatch.setenv("KMC_CHAIN_BLOCK", "1")
+    nw, nd, G, nburn, nthin, seed = 2048, 16, 460, 20, 2, 123
+    th = np.ascontiguousarray(np.random.default_rng(5).standard_normal((nw, nd)))
+    ns = (G - nburn) // nthin
+    cfg = _lib.Config()
+    cfg.dtype, cfg.density = _lib.F64, _lib.GAUSSIAN_ISO
+    cfg.params[0], cfg.params[1] = 0.0, 1.0
+    cfg.nwalkers, cfg.ndim, cfg.ngenerations, cfg.nburnin, cfg.nthin = nw, nd, G, nburn, nthin
+    cfg.a_scale, cfg.seed, cfg.flags, cfg.device = 2.0, seed, _lib.STREAM_CHAIN, 0
+    dp = C.POINTER(C.c_double)
+    chain = np.zeros((ns, nw, nd)); clogp = np.zeros((ns, nw)); fpos = np.zeros((nw, nd))
+    out = _lib.Outputs()
+    out.chain, out.chain_logp, out.final_pos = chain.ctypes.data_as(dp), clogp.ctypes.data_as(dp), fpos.ctypes.data_as(dp)
+    _lib.check(_lib.lib().kmc_emcee_run(C.byref(cfg), th.ctypes.data_as(dp), C.byref(out)))
+    ref = _oracle_chain(oracle, oracle.GAUSSIAN_ISO, [0.0, 1.0], th, G, nburn, nthin, seed)
+    assert out.nsamples == ns
+    _equal(chain, clogp, ref)
+    np.testing.assert_array_equal(fpos, ref["final_pos"])
+
+
+def test_stream_chain_argument_checks(kmc):
+    with pytest.raises(kmc.KmcError, match="KMC_F64"):
+        kmc.Sampler(kmc.GaussianIso(), 256, 4, 100, 10, store_chain=True, stream_chain=True, dtype="f32")
+    with kmc.Sampler(kmc.GaussianIso(), 256, 4, 100, 10, store_chain=True) as s:      # not streaming
+        from kissmcmc_jl_amd import _lib
+        a = np.zeros((90, 256, 4))
+        with pytest.raises(kmc.KmcError, match="KMC_STREAM_CHAIN"):
+            _lib.check(s._L.kmc_sampler_set_chain_host(s._h, a.ctypes.data_as(C.POINTER(C.c_double)), None))
