@@ -1294,13 +1294,14 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
     int64_t chain_slots = s->nsamples;
     if ((cfg->flags & KMC_STREAM_CHAIN) && s->nsamples > 0) {
         // a ring of three blocks; a block holds at least the samples of one launch unit (a graph replay), so a unit never
-        // touches more than two blocks, and about 512 MiB otherwise (measured at C2, nthin = 10: 128 MiB blocks stream 22-26 GB/s, 512 MiB 43 GB/s of the 56 GB/s this link copies alone; KMC_CHAIN_BLOCK = samples per block, for tests)
+        // touches more than two blocks, and about 512 MiB otherwise (measured at C2: 128 MiB blocks stream 22-26 GB/s at nthin = 10, 512 MiB blocks 43-45 GB/s of the
+        // 56 GB/s this link copies alone; many small blocks cost more at the block boundaries than their earlier start
+        // returns -- nthin = 100: +19 % on the loop with 64 MiB blocks, +6 % with 512 MiB; KMC_CHAIN_BLOCK = samples per block, for tests)
         if (const char* e = std::getenv("KMC_UPD_CHUNK")) { const long v = std::atol(e); if (v >= 16 && v <= 1024) s->uchunk = v; }
         const int64_t unit = std::max<int64_t>(kGraphChunk, s->uchunk);
         const int64_t per_unit = (unit + cfg->nthin - 1) / cfg->nthin + 1;
         const size_t sample_bytes = (size_t)s->nlocal * ldz * sizeof(double);
         int64_t blk = (int64_t)(((size_t)512 << 20) / sample_bytes);
-        if (blk > (s->nsamples + 15) / 16) blk = (s->nsamples + 15) / 16;      // ... but at least ~16 blocks per run: the last block's copy overlaps nothing
         if (blk < 1) blk = 1;
         if (blk > 4096) blk = 4096;
         if (const char* e = std::getenv("KMC_CHAIN_BLOCK")) { const long v = std::atol(e); if (v >= 1) blk = v; }

@@ -464,6 +464,9 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
     // dominates the wave's instruction count; with more (C2: 16) the extra load in the chain costs what it saves
     // (with the eager-form launches, where Philox starts at wave entry, it is worth +-2 %; it still pays +5 % under
     //  the table graph, e.g. for the P2P shards.  L = 64: slightly negative, off)
+    // (round 2, one more bounded try for L = 8 -- C2 -- in both launch modes: 4.83 against 4.27 us per half-step under the table
+    //  graph, 4.70 against 3.99 with the step preloaded: the ring entry is one more dependent load in front of the partner
+    //  row, and at 16 walkers per wave the Philox it replaces was already hidden.  Dropped; profiles/NOTES.md.)
     constexpr bool kRing = Q >= 2 && L >= 16 && L <= 32;
     const int64_t oth_row0 = (int64_t)(1 - half) * (int64_t)(P2P ? (uint32_t)nact : f.nhalf);
     const int  jq     = j / ITER, js = j - jq * ITER;
