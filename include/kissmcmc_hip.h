@@ -78,6 +78,11 @@ typedef int (*kmc_host_logpdf_fn)(const double* rows, int64_t nrows, int64_t ndi
 typedef int (*kmc_host_accepted_fn)(const uint8_t* accepted, int64_t nrows, int64_t row0, int64_t generation,
                                     int32_t stored, void* user);
 
+/* Many-chain Metropolis, optional: proposals from the host.  rows = current states, dense [nrows][ndim]; write
+   sample_ppdf(row) for every row to proposals_out [nrows][ndim] (a SYMMETRIC proposal, as the reference requires,
+   src/samplers.jl:41).  Return 0, or non-zero to abort the run. */
+typedef int (*kmc_host_propose_fn)(const double* rows, int64_t nrows, int64_t ndim, double* proposals_out, void* user);
+
 enum {
     KMC_F64 = 0, /* state and arithmetic in IEEE double, as the reference (Float64) */
     KMC_F32 = 1  /* throughput option: walker rows and the stored chain are kept in IEEE single ON THE DEVICE (half the
@@ -365,6 +370,15 @@ typedef struct kmc_metropolis_config {
     uint32_t flags;         /* KMC_STORE_CHAIN | KMC_STORE_LOGP | KMC_MOMENTS */
     int32_t  device;
     void*    user_density;  /* kmc_user_density* when density == KMC_USER_DENSITY */
+    /* Host route: ANY closure for `pdf` and / or `sample_ppdf` (the reference takes both as arbitrary functions,
+       src/samplers.jl:59-61).  One iteration of all chains per round trip: proposals on the device (the Gaussian step) or
+       from host_propose, their log-pdfs on the device (menu / runtime-compiled density) or from host_logpdf
+       (density == KMC_HOST_DENSITY), the accept test (:101), counters and storage always on the device.  Launch- and
+       PCIe-bound (tens of microseconds per iteration): the general route, not the fast one. */
+    kmc_host_logpdf_fn   host_logpdf;   /* density == KMC_HOST_DENSITY: log-pdfs of a batch of rows, else NULL */
+    void*                host_user;     /* passed to the three callbacks */
+    kmc_host_accepted_fn host_accepted; /* optional: accept outcomes per iteration (blobs: :100-103, :116-118); row0 = 0, generation = iteration */
+    kmc_host_propose_fn  host_propose;  /* optional: theta1 = sample_ppdf(theta0) for a batch of rows; `step` may then be NULL */
 } kmc_metropolis_config;
 
 typedef struct kmc_metropolis_outputs {

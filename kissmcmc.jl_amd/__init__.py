@@ -13,13 +13,13 @@ from .api import emcee, emcee_counts, make_theta0s, squash_walkers
 from .densities import (DeviceLogPdf, Exponential, ExprDensity, GaussianIso, HostLogPdf, LogNormal, MvNormal2,
                         Rosenbrock)
 from .diagnostics import eff_samples, int_acorr
-from .metropolis import GaussianStep, metropolis, metropolis_chains
+from .metropolis import GaussianStep, HostProposal, metropolis, metropolis_chains
 from .sampler import Sampler
 
 __all__ = [
     "emcee", "make_theta0s", "squash_walkers", "emcee_counts", "Sampler", "KmcError",
     "DeviceLogPdf", "GaussianIso", "Exponential", "Rosenbrock", "LogNormal", "MvNormal2", "ExprDensity", "HostLogPdf",
-    "cdf_g_inv", "g_pdf", "metropolis", "metropolis_chains", "GaussianStep", "int_acorr", "eff_samples",
+    "cdf_g_inv", "g_pdf", "metropolis", "metropolis_chains", "GaussianStep", "HostProposal", "int_acorr", "eff_samples",
 ]
 
 

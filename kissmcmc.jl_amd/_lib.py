@@ -20,6 +20,7 @@ GAUSSIAN_ISO, EXPONENTIAL, ROSENBROCK, LOGNORMAL, MVNORMAL2 = range(5)
 USER_DENSITY = 100
 HOST_DENSITY = 101
 HOST_LOGPDF_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int64, C.c_int64, C.POINTER(C.c_double), C.c_void_p)
+HOST_PROPOSE_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int64, C.c_int64, C.POINTER(C.c_double), C.c_void_p)
 HOST_ACCEPTED_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_uint8), C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_void_p)
 F64 = 0
 F32 = 1       # rows and chain kept in float on the device; arithmetic and host buffers stay double
@@ -101,6 +102,10 @@ class MetropolisConfig(C.Structure):
         ("flags", C.c_uint32),
         ("device", C.c_int32),
         ("user_density", C.c_void_p),
+        ("host_logpdf", C.c_void_p),
+        ("host_user", C.c_void_p),
+        ("host_accepted", C.c_void_p),
+        ("host_propose", C.c_void_p),
     ]
 
 

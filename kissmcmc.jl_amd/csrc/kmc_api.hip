@@ -2465,6 +2465,158 @@ struct MetroBuffers {
 
 }  // namespace
 
+namespace {
+
+// The host route of kmc_metropolis_run: `pdf` and / or `sample_ppdf` are caller's closures (src/samplers.jl:59-61).  One
+// iteration of all chains per pass: proposals (device Gaussian step, or host_propose on the current states), their
+// log-pdfs (host_logpdf on the proposals, or the device density), then the accept test, counters and storage on the device.
+kmc_status metropolis_host_route(const kmc_metropolis_config* c, const double* theta0, kmc_metropolis_outputs* out,
+                                 const DensityParams& dp, int64_t nsamples)
+{
+    const int64_t nc = c->nchains, nd = c->ndim;
+    const size_t rows = (size_t)nc * (size_t)nd * sizeof(double), vec = (size_t)nc * sizeof(double);
+    const bool host_pdf = c->density == KMC_HOST_DENSITY;
+    const bool want_chain = (c->flags & KMC_STORE_CHAIN) != 0, want_logp = (c->flags & KMC_STORE_LOGP) != 0, want_mom = (c->flags & KMC_MOMENTS) != 0;
+    struct Buf {
+        double *pos = nullptr, *logp = nullptr, *prop = nullptr, *p1 = nullptr, *chain = nullptr, *chain_logp = nullptr, *csum = nullptr,
+               *csumsq = nullptr, *step = nullptr, *h_rows = nullptr, *h_prop = nullptr, *h_p1 = nullptr;
+        uint32_t* naccept = nullptr;
+        unsigned char *acc = nullptr, *h_acc = nullptr;
+        hipModule_t mod = nullptr;
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        ~Buf()
+        {
+            (void)hipFree(pos); (void)hipFree(logp); (void)hipFree(prop); (void)hipFree(p1); (void)hipFree(chain); (void)hipFree(chain_logp);
+            (void)hipFree(csum); (void)hipFree(csumsq); (void)hipFree(step); (void)hipFree(naccept); (void)hipFree(acc);
+            if (h_rows) (void)hipHostFree(h_rows);
+            if (h_prop) (void)hipHostFree(h_prop);
+            if (h_p1) (void)hipHostFree(h_p1);
+            if (h_acc) (void)hipHostFree(h_acc);
+            if (mod) (void)hipModuleUnload(mod);
+            if (ev0) (void)hipEventDestroy(ev0);
+            if (ev1) (void)hipEventDestroy(ev1);
+        }
+    } b;
+    HIP_TRY(hipMalloc(&b.pos, rows));
+    HIP_TRY(hipMalloc(&b.prop, rows));
+    HIP_TRY(hipMalloc(&b.logp, vec));
+    HIP_TRY(hipMalloc(&b.p1, vec));
+    HIP_TRY(hipMalloc(&b.naccept, (size_t)nc * sizeof(uint32_t)));
+    HIP_TRY(hipMemset(b.naccept, 0, (size_t)nc * sizeof(uint32_t)));
+    HIP_TRY(hipMemcpy(b.pos, theta0, rows, hipMemcpyHostToDevice));                              // :68 deepcopy
+    if (c->step) {
+        HIP_TRY(hipMalloc(&b.step, (size_t)nd * sizeof(double)));
+        HIP_TRY(hipMemcpy(b.step, c->step, (size_t)nd * sizeof(double), hipMemcpyHostToDevice));
+    }
+    if (want_chain && nsamples > 0) HIP_TRY(hipMalloc(&b.chain, (size_t)nsamples * rows));
+    if (want_logp && nsamples > 0) HIP_TRY(hipMalloc(&b.chain_logp, (size_t)nsamples * vec));
+    if (want_mom) {
+        HIP_TRY(hipMalloc(&b.csum, rows));
+        HIP_TRY(hipMalloc(&b.csumsq, rows));
+        HIP_TRY(hipMemset(b.csum, 0, rows));
+        HIP_TRY(hipMemset(b.csumsq, 0, rows));
+    }
+    HIP_TRY(hipHostMalloc((void**)&b.h_rows, rows, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void**)&b.h_prop, rows, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void**)&b.h_p1, vec, hipHostMallocDefault));
+    if (c->host_accepted) {
+        HIP_TRY(hipMalloc((void**)&b.acc, (size_t)nc));
+        HIP_TRY(hipHostMalloc((void**)&b.h_acc, (size_t)nc, hipHostMallocDefault));
+    }
+    // log-pdf of device rows -> device vector, for a device density
+    LogpdfFn lp = nullptr;
+    hipFunction_t ulp = nullptr;
+    if (!host_pdf) {
+        if (c->density == KMC_USER_DENSITY) {
+            const std::vector<char>* code = nullptr;
+            KMC_TRY(compile_user_metropolis(static_cast<kmc_user_density*>(c->user_density), metropolis_nd(nd), &code));
+            HIP_TRY(hipModuleLoadData(&b.mod, code->data()));
+            HIP_TRY(hipModuleGetFunction(&ulp, b.mod, "kmc_user_logpdf"));
+        } else {
+            HalfStepFn v, g;
+            if (!lookup(c->density, 0, 0, 1, false, false, false, &v, &g, &lp)) return fail(KMC_ERR_BAD_ARG, "unknown density id");
+        }
+    }
+    const unsigned grid = (unsigned)((nc + 255) / 256);
+    auto device_logpdf = [&](const double* rows_dev, double* out_dev) -> hipError_t {
+        const LogpdfArgs la{rows_dev, out_dev, nc, (int32_t)nd, (int32_t)nd, dp};
+        if (ulp) return launch_module(ulp, grid, 256u, nullptr, la);
+        hipLaunchKernelGGL(lp, dim3(grid), dim3(256), 0, nullptr, la);
+        return hipGetLastError();
+    };
+    // p0 = pdf(theta0) (:70); whatever comes out is carried, -Inf included, as in the reference
+    if (host_pdf) {
+        if (c->host_logpdf(theta0, nc, nd, b.h_p1, c->host_user) != 0) return fail(KMC_ERR_BAD_ARG, "the host log-pdf callback failed on the initial states");
+        HIP_TRY(hipMemcpy(b.logp, b.h_p1, vec, hipMemcpyHostToDevice));
+    } else {
+        HIP_TRY(device_logpdf(b.pos, b.logp));
+    }
+    HIP_TRY(hipEventCreate(&b.ev0));
+    HIP_TRY(hipEventCreate(&b.ev1));
+    HIP_TRY(hipEventRecord(b.ev0, nullptr));
+    int64_t cnt = 0, slot = 0;
+    for (int64_t it = 0; it < c->niter; ++it) {
+        const int64_t n = it + 1 - c->nburnin;                                                   // :96
+        MetroHostArgs a{};
+        a.pos = b.pos; a.logp = b.logp; a.naccept = b.naccept; a.prop = b.prop; a.p1 = b.p1;
+        a.chain = b.chain; a.chain_logp = b.chain_logp; a.csum = b.csum; a.csumsq = b.csumsq; a.step = b.step; a.acc_out = b.acc;
+        a.nchains = nc; a.it = it; a.n = n; a.ndim = (int32_t)nd;
+        a.seed_lo = (uint32_t)c->seed; a.seed_hi = (uint32_t)(c->seed >> 32);
+        if (n > 0 && ++cnt == c->nthin) {                                                        // :108, :112
+            cnt = 0;
+            if (slot < nsamples) { a.store = 1; a.slot = slot; }
+            ++slot;
+        }
+        if (c->host_propose) {                                                                   // :98 theta1 = sample_ppdf(theta0)
+            HIP_TRY(hipMemcpy(b.h_rows, b.pos, rows, hipMemcpyDeviceToHost));
+            if (c->host_propose(b.h_rows, nc, nd, b.h_prop, c->host_user) != 0)
+                return fail(KMC_ERR_BAD_ARG, "the host proposal callback failed in iteration " + std::to_string(it));
+            HIP_TRY(hipMemcpy(b.prop, b.h_prop, rows, hipMemcpyHostToDevice));
+        } else {
+            hipLaunchKernelGGL(metro_host_propose, dim3(grid), dim3(256), 0, nullptr, a);
+            HIP_TRY(hipGetLastError());
+        }
+        if (host_pdf) {                                                                          // :99 p1 = pdf(theta1)
+            if (!c->host_propose) HIP_TRY(hipMemcpy(b.h_prop, b.prop, rows, hipMemcpyDeviceToHost));
+            if (c->host_logpdf(b.h_prop, nc, nd, b.h_p1, c->host_user) != 0)
+                return fail(KMC_ERR_BAD_ARG, "the host log-pdf callback failed in iteration " + std::to_string(it));
+            HIP_TRY(hipMemcpy(b.p1, b.h_p1, vec, hipMemcpyHostToDevice));
+        } else {
+            HIP_TRY(device_logpdf(b.prop, b.p1));
+        }
+        hipLaunchKernelGGL(metro_host_accept, dim3(grid), dim3(256), 0, nullptr, a);
+        HIP_TRY(hipGetLastError());
+        if (c->host_accepted) {
+            HIP_TRY(hipMemcpy(b.h_acc, b.acc, (size_t)nc, hipMemcpyDeviceToHost));
+            if (c->host_accepted(b.h_acc, nc, 0, it, a.store, c->host_user) != 0)
+                return fail(KMC_ERR_BAD_ARG, "the host accept callback failed in iteration " + std::to_string(it));
+        }
+    }
+    HIP_TRY(hipEventRecord(b.ev1, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, b.ev0, b.ev1));
+    out->device_ms = (double)ms;
+    if (out->chain && b.chain) HIP_TRY(hipMemcpy(out->chain, b.chain, (size_t)nsamples * rows, hipMemcpyDeviceToHost));
+    if (out->chain_logp && b.chain_logp) HIP_TRY(hipMemcpy(out->chain_logp, b.chain_logp, (size_t)nsamples * vec, hipMemcpyDeviceToHost));
+    if (out->final_pos) HIP_TRY(hipMemcpy(out->final_pos, b.pos, rows, hipMemcpyDeviceToHost));
+    if (out->final_logp) HIP_TRY(hipMemcpy(out->final_logp, b.logp, vec, hipMemcpyDeviceToHost));
+    if (out->chain_sum && b.csum) HIP_TRY(hipMemcpy(out->chain_sum, b.csum, rows, hipMemcpyDeviceToHost));
+    if (out->chain_sumsq && b.csumsq) HIP_TRY(hipMemcpy(out->chain_sumsq, b.csumsq, rows, hipMemcpyDeviceToHost));
+    if (out->naccept || out->accept_ratio) {
+        std::vector<uint32_t> na((size_t)nc);
+        HIP_TRY(hipMemcpy(na.data(), b.naccept, (size_t)nc * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        const double denom = (double)(c->niter - c->nburnin);                                   // :127
+        for (int64_t i = 0; i < nc; ++i) {
+            if (out->naccept) out->naccept[i] = (int64_t)na[(size_t)i];
+            if (out->accept_ratio) out->accept_ratio[i] = (double)na[(size_t)i] / denom;
+        }
+    }
+    return KMC_OK;
+}
+
+}  // namespace
+
 KMC_EXPORT kmc_status kmc_metropolis_validate(const kmc_metropolis_config* c)
 {
     if (!c) return fail(KMC_ERR_BAD_ARG, "null config");
@@ -2472,12 +2624,16 @@ KMC_EXPORT kmc_status kmc_metropolis_validate(const kmc_metropolis_config* c)
     if (c->nchains <= 0 || c->ndim <= 0 || c->nthin <= 0 || c->niter < 0 || c->nburnin < 0)
         return fail(KMC_ERR_BAD_ARG, "nchains, ndim, nthin must be positive; niter, nburnin non-negative");
     if (c->nchains > 0xffffffffll) return fail(KMC_ERR_BAD_ARG, "at most 2^32 - 1 chains (the chain index is one Philox counter word)");
-    if (!c->step) return fail(KMC_ERR_BAD_ARG, "step (proposal scale per dimension) is NULL");
-    for (int64_t d = 0; d < c->ndim; ++d)
+    if (!c->step && !c->host_propose) return fail(KMC_ERR_BAD_ARG, "step (proposal scale per dimension) is NULL and there is no host_propose");
+    for (int64_t d = 0; c->step && d < c->ndim; ++d)
         if (!std::isfinite(c->step[d])) return fail(KMC_ERR_BAD_ARG, "step must be finite");
     if (c->flags & ~(uint32_t)(KMC_STORE_CHAIN | KMC_STORE_LOGP | KMC_MOMENTS))
         return fail(KMC_ERR_BAD_ARG, "metropolis flags: KMC_STORE_CHAIN | KMC_STORE_LOGP | KMC_MOMENTS");
-    if (c->density == KMC_HOST_DENSITY) return fail(KMC_ERR_UNSUPPORTED, "KMC_HOST_DENSITY is not available for the many-chain Metropolis kernel");
+    if (c->density == KMC_HOST_DENSITY) {
+        if (!c->host_logpdf) return fail(KMC_ERR_BAD_ARG, "KMC_HOST_DENSITY needs kmc_metropolis_config.host_logpdf");
+        return KMC_OK;
+    }
+    if (c->host_logpdf) return fail(KMC_ERR_BAD_ARG, "host_logpdf needs density == KMC_HOST_DENSITY");
     if (c->density == KMC_USER_DENSITY) {
         if (!c->user_density) return fail(KMC_ERR_BAD_ARG, "KMC_USER_DENSITY needs kmc_metropolis_config.user_density");
         return KMC_OK;
@@ -2518,7 +2674,10 @@ KMC_EXPORT kmc_status kmc_metropolis_run(const kmc_metropolis_config* c, const d
     e.device = c->device;
     DensityParams dp{};
     if (c->density == KMC_USER_DENSITY) { for (int i = 0; i < 6; ++i) dp.p[i] = c->params[i]; dp.ndim = (int32_t)nd; }
+    else if (c->density == KMC_HOST_DENSITY) dp.ndim = (int32_t)nd;
     else KMC_TRY(digest_params(e, &dp));
+    if (c->density == KMC_HOST_DENSITY || c->host_propose)
+        return metropolis_host_route(c, theta0, out, dp, nsamples);
 
     MetroBuffers b;
     const size_t rows = (size_t)nc * (size_t)nd * sizeof(double);

@@ -235,7 +235,86 @@ __global__ __launch_bounds__(256) void metropolis_chains(const MetropolisArgs a)
     else metropolis_chains_any_body<Dens>(a);
 }
 
+// Host route (kmc_metropolis_config.host_logpdf / host_propose: ANY closure for `pdf` and / or `sample_ppdf`, reference
+// src/samplers.jl:59-61): one iteration of all chains per round trip.  PROPOSE draws the Gaussian step on the device (same
+// stream as the in-kernel chains) unless the proposals come from the host; ACCEPT takes the proposals' log-pdfs (from the
+// host callback or from the device density), runs the accept test of :101 with the stream's uniform, and stores.
+struct MetroHostArgs {
+    double*        pos;        // [nchains][ndim]
+    double*        logp;       // [nchains] p0
+    uint32_t*      naccept;
+    double*        prop;       // [nchains][ndim] theta1
+    const double*  p1;         // [nchains] pdf(theta1)
+    double*        chain;      // [nsamples][nchains][ndim] or nullptr
+    double*        chain_logp;
+    double*        csum;       // [nchains][ndim] or nullptr
+    double*        csumsq;
+    const double*  step;       // [ndim] (PROPOSE)
+    unsigned char* acc_out;    // [nchains] or nullptr
+    int64_t        nchains;
+    int64_t        it;         // 0-based iteration; reference n = it + 1 - nburnin (:96)
+    int64_t        n;
+    int64_t        slot;       // sample slot when store != 0
+    int32_t        store;      // this iteration stores the current state (:108-116)
+    int32_t        ndim;
+    uint32_t       seed_lo, seed_hi;
+};
+
 #ifdef KMC_DEFINE_DRIVER_KERNELS
+__global__ __launch_bounds__(256) void metro_host_propose(const MetroHostArgs a)
+{
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= a.nchains) return;
+    const uint32_t k0 = a.seed_lo ^ 0x4d455452u, k1 = a.seed_hi;
+    const uint32_t it_lo = (uint32_t)a.it, it_hi = (uint32_t)((uint64_t)a.it >> 32);
+    double n0 = 0.0, n1 = 0.0, n2 = 0.0, n3 = 0.0;
+    for (int d = 0; d < a.ndim; ++d) {
+        double nd;
+        if (d < 2) {
+            if (d == 0) { const U4 w = philox4x32_10(it_lo, it_hi, (uint32_t)c, 0u, k0, k1); normal_pair(w.x, w.y, n0, n1); }
+            nd = d == 0 ? n0 : n1;
+        } else {
+            const int r = (d - 2) & 3;
+            if (r == 0) {
+                const U4 v = philox4x32_10(it_lo, it_hi, (uint32_t)c, (uint32_t)(1 + ((d - 2) >> 2)), k0, k1);
+                normal_pair(v.x, v.y, n0, n1);
+                normal_pair(v.z, v.w, n2, n3);
+            }
+            nd = r == 0 ? n0 : r == 1 ? n1 : r == 2 ? n2 : n3;
+        }
+        a.prop[c * a.ndim + d] = fma(a.step[d], nd, a.pos[c * a.ndim + d]);          // :98 theta1 = sample_ppdf(theta0)
+    }
+}
+
+__global__ __launch_bounds__(256) void metro_host_accept(const MetroHostArgs a)
+{
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= a.nchains) return;
+    const U4 w = philox4x32_10((uint32_t)a.it, (uint32_t)((uint64_t)a.it >> 32), (uint32_t)c, 0u, a.seed_lo ^ 0x4d455452u, a.seed_hi);
+    const uint64_t kk = ((uint64_t)w.z << 20) | (uint64_t)(w.w >> 12);
+    const double lu = log_pos_normal(((double)kk + 0.5) * 0x1.0p-52);
+    const double p1 = a.p1[c];
+    double p0 = a.logp[c];
+    const bool acc = p1 - p0 > lu;                                                   // :101, strict >
+    if (acc) {
+        p0 = p1;                                                                     // :104
+        a.logp[c] = p1;
+        if (a.n > 0) a.naccept[c] += 1u;                                             // :105, counters restart at n == 0 (:122-125)
+    }
+    if (a.acc_out != nullptr) a.acc_out[c] = acc ? 1 : 0;
+    if (acc || a.store) {
+        for (int d = 0; d < a.ndim; ++d) {
+            const double v = acc ? a.prop[c * a.ndim + d] : a.pos[c * a.ndim + d];
+            if (acc) a.pos[c * a.ndim + d] = v;                                      // :102
+            if (a.store) {
+                if (a.chain != nullptr) a.chain[(a.slot * a.nchains + c) * a.ndim + d] = v;      // :113
+                if (a.csum != nullptr) { a.csum[c * a.ndim + d] += v; a.csumsq[c * a.ndim + d] += v * v; }
+            }
+        }
+        if (a.store && a.chain_logp != nullptr) a.chain_logp[a.slot * a.nchains + c] = p0;       // :115
+    }
+}
+
 __global__ __launch_bounds__(256) void metropolis_transpose(const TransposeArgs a)
 {
     const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;

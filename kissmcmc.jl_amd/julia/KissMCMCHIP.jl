@@ -1,19 +1,25 @@
 # KissMCMCHIP.jl -- thin `ccall` shim over libkissmcmc_hip.so (C ABI: include/kissmcmc_hip.h).
 #
-# Keeps the call surface of KissMCMC.jl's emcee path (reference src/samplers.jl:188-216, :311-349,
-# :372-428): `emcee(pdf, theta0s; niter, nburnin, nthin, a_scale, ...)`, `make_theta0s`,
-# `squash_walkers`.  `pdf` is one of the menu densities below or an `ExprDensity` (evaluated on the
-# device), or ANY Julia callable: that one stays on the host (`HostLogPdf`, KMC_HOST_DENSITY) and is
-# called on each half-step's batch of proposals while the moves, draws, accept test and storage run
-# on the GPU.  There is no CPU fallback for the sampler itself.
+# EXTENDS KissMCMC.jl, it does not replace it: `emcee` and `metropolis` get one more method each -- for a `pdf` that is
+# one of the device log-densities below (menu, `ExprDensity`) or a `HostLogPdf(f)` around any Julia callable (that one
+# stays on the host, KMC_HOST_DENSITY: called on each half-step's batch of proposals while moves, draws, accept test
+# and storage run on the GPU) -- with KissMCMC's own keywords and return values (reference src/samplers.jl:188-216,
+# :59-77).  `make_theta0s` (src/samplers.jl:311-349) and `squash_walkers` (:372-428) are host-side pre/post-processing
+# on exactly the containers these methods take and return, so they are KissMCMC's OWN functions, re-exported here, not
+# re-implemented: a device log-density is callable on the host with the kernels' formula, which is all `make_theta0s`
+# needs.  A plain closure as `pdf` still dispatches to KissMCMC's CPU methods; wrap it, `HostLogPdf(f)`, to move the
+# sampler to the GPU.  There is no CPU fallback inside this module.
 #
-# NOT EXECUTED in the build environment (no julia binary there).  Every call it makes is mirrored
-# 1:1 by the Python ctypes host (kissmcmc.jl_amd/_lib.py, api.py), which is what the tests drive.
+# NOT EXECUTED in the build environment (no julia binary there).  Every call it makes is mirrored 1:1 by the Python
+# ctypes host (kissmcmc.jl_amd/_lib.py, api.py), which is what the tests drive; struct layouts are checked against the
+# library when the module loads (`__init__`).
 module KissMCMCHIP
 
-export emcee, make_theta0s, squash_walkers, metropolis, metropolis_chains, GaussianStep, int_acorr, GaussianIso, Exponential, Rosenbrock, LogNormal, MvNormal2, ExprDensity, HostLogPdf
+import KissMCMC
+import KissMCMC: emcee, metropolis, make_theta0s, squash_walkers     # extended (emcee, metropolis) / re-exported as they are
 
-using Statistics: mean, median, std
+export emcee, make_theta0s, squash_walkers, metropolis, metropolis_chains, GaussianStep, HostProposal, int_acorr, GaussianIso, Exponential, Rosenbrock, LogNormal, MvNormal2, ExprDensity, HostLogPdf
+
 using LinearAlgebra: inv
 
 const LIB = get(ENV, "KMC_LIB_PATH", joinpath(@__DIR__, "..", "libkissmcmc_hip.so"))
@@ -61,7 +67,7 @@ user_handle(::DeviceLogPdf) = C_NULL
 function (d::ExprDensity)(x)
     xs = collect(Float64, x isa Number ? [x] : x); out = Ref(0.0)
     p8 = ntuple(i -> i <= length(d.p) ? d.p[i] : 0.0, 8)
-    cfg = Ref(KmcConfig(0, Cint(100), p8, 2, length(xs), 0, 0, 1, 2.0, UInt64(0), 0, 0, 0, 1, d.handle, 0, 0, C_NULL, C_NULL, C_NULL))
+    cfg = Ref(KmcConfig(density=Cint(100), params=p8, nwalkers=2, ndim=length(xs), user_density=d.handle))
     st = ccall((:kmc_logpdf_eval_host, LIB), Cint, (Ref{KmcConfig}, Ptr{Float64}, Ref{Float64}, Int64), cfg, xs, out, 1)
     st == 0 || error(last_error()); out[]
 end
@@ -118,24 +124,49 @@ function accepted_trampoline(accepted::Ptr{UInt8}, nrows::Int64, row0::Int64, ge
     end
 end
 
-# ---- C structs (layout checked against the header by tests/test_c_abi.py on the Python mirror) ---
-struct KmcConfig
-    dtype::Int32; density::Int32
-    params::NTuple{8,Float64}
-    nwalkers::Int64; ndim::Int64; ngenerations::Int64; nburnin::Int64; nthin::Int64
-    a_scale::Float64; seed::UInt64
-    flags::UInt32; device::Int32; shard_rank::Int32; shard_count::Int32
-    user_density::Ptr{Cvoid}
-    island_gens::Int32; island_size::Int32     # KMC_ISLANDS (opt-in island mode); 0 = defaults
-    host_logpdf::Ptr{Cvoid}; host_user::Ptr{Cvoid}   # KMC_HOST_DENSITY callback and its context
-    host_accepted::Ptr{Cvoid}                         # KMC_HOST_DENSITY: accept outcomes per half-step (blobs), or NULL
+# ---- C structs: field for field include/kissmcmc_hip.h (kmc_config, kmc_outputs).  Built by keyword, so a new field
+#      of the header needs one line here and no call site changes; `__init__` compares sizeof with the library's. ---
+Base.@kwdef struct KmcConfig
+    dtype::Int32 = 0                                  # KMC_F64 = 0, KMC_F32 = 1
+    density::Int32 = 0
+    params::NTuple{8,Float64} = ntuple(_ -> 0.0, 8)
+    nwalkers::Int64 = 0
+    ndim::Int64 = 0
+    ngenerations::Int64 = 0
+    nburnin::Int64 = 0
+    nthin::Int64 = 1
+    a_scale::Float64 = 2.0
+    seed::UInt64 = 0
+    flags::UInt32 = 0
+    device::Int32 = 0
+    shard_rank::Int32 = 0
+    shard_count::Int32 = 1
+    user_density::Ptr{Cvoid} = C_NULL
+    island_gens::Int32 = 0                            # KMC_ISLANDS (opt-in island mode); 0 = defaults
+    island_size::Int32 = 0
+    host_logpdf::Ptr{Cvoid} = C_NULL                  # KMC_HOST_DENSITY callback ...
+    host_user::Ptr{Cvoid} = C_NULL                    # ... and its context
+    host_accepted::Ptr{Cvoid} = C_NULL                # KMC_HOST_DENSITY: accept outcomes per half-step (blobs), or NULL
+    deal_rank::Int32 = 0                              # dealt sub-ensembles (multi-GPU, opt-in); deal_count = 0: off
+    deal_count::Int32 = 0
 end
 
-mutable struct KmcOutputs
-    chain::Ptr{Float64}; chain_logp::Ptr{Float64}; accept_ratio::Ptr{Float64}; naccept::Ptr{Int64}
-    final_pos::Ptr{Float64}; final_logp::Ptr{Float64}; sum::Ptr{Float64}; sumsq::Ptr{Float64}
-    nmoment::Int64; nsamples::Int64; device_ms::Float64
+Base.@kwdef mutable struct KmcOutputs
+    chain::Ptr{Float64} = C_NULL
+    chain_logp::Ptr{Float64} = C_NULL
+    accept_ratio::Ptr{Float64} = C_NULL
+    naccept::Ptr{Int64} = C_NULL
+    final_pos::Ptr{Float64} = C_NULL
+    final_logp::Ptr{Float64} = C_NULL
+    sum::Ptr{Float64} = C_NULL
+    sumsq::Ptr{Float64} = C_NULL
+    nmoment::Int64 = 0
+    nsamples::Int64 = 0
+    device_ms::Float64 = 0.0
 end
+
+const KMC_STORE_CHAIN = UInt32(1) << 0
+const KMC_STORE_LOGP = UInt32(1) << 1
 
 last_error() = unsafe_string(ccall((:kmc_last_error, LIB), Cstring, ()))
 
@@ -184,12 +215,15 @@ function emcee(pdf::DeviceLogPdf, theta0s; niter=10^5, nburnin=niter ÷ 2, nthin
             acc_fn = @cfunction(accepted_trampoline, Cint, (Ptr{UInt8}, Int64, Int64, Int64, Int32, Ptr{Cvoid}))
         end
     end
-    cfg = Ref(KmcConfig(dtype == :f32 ? 1 : 0, density_id(pdf), p8, nwalkers, ndim, niter_walker, nburnin_walker, nthin,
-                        a_scale, UInt64(seed), 0x3, Int32(device), 0, 1, user_handle(pdf), 0, 0, host_fn, host_ctx, acc_fn))   # flags: STORE_CHAIN | STORE_LOGP
+    cfg = Ref(KmcConfig(dtype=(dtype == :f32 ? 1 : 0), density=density_id(pdf), params=p8, nwalkers=nwalkers, ndim=ndim,
+                        ngenerations=niter_walker, nburnin=nburnin_walker, nthin=nthin, a_scale=a_scale, seed=UInt64(seed),
+                        flags=KMC_STORE_CHAIN | KMC_STORE_LOGP, device=Int32(device), user_density=user_handle(pdf),
+                        host_logpdf=host_fn, host_user=host_ctx, host_accepted=acc_fn))
+    # (a chain too large for the device is streamed into these arrays while sampling: kmc_emcee_run decides, KMC_STREAM_CHAIN)
     chain = Array{Float64}(undef, ndim, nwalkers, nsamples)
     clogp = Array{Float64}(undef, nwalkers, nsamples)
     acc = Vector{Float64}(undef, nwalkers)
-    out = KmcOutputs(pointer(chain), pointer(clogp), pointer(acc), C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, 0, 0, 0.0)
+    out = KmcOutputs(chain=pointer(chain), chain_logp=pointer(clogp), accept_ratio=pointer(acc))
     st = GC.@preserve pdf theta chain clogp acc ccall((:kmc_emcee_run, LIB), Cint,
                                                    (Ref{KmcConfig}, Ptr{Float64}, Ref{KmcOutputs}), cfg, theta, out)
     st == 0 || error("kmc_emcee_run failed ($st): $(last_error())")
@@ -198,56 +232,120 @@ function emcee(pdf::DeviceLogPdf, theta0s; niter=10^5, nburnin=niter ÷ 2, nthin
     logdensities = [[clogp[w, k] for k in 1:nsamples] for w in 1:nwalkers]
     return thetas, acc, logdensities, (pdf isa HostLogPdf && pdf.hasblob) ? pdf.blobs : nothing   # :292
 end
-# arbitrary closure: evaluated on the host
-emcee(pdf, theta0s; hasblob=false, kw...) = emcee(HostLogPdf(pdf; hasblob=hasblob), theta0s; hasblob=hasblob, kw...)
+# (a bare closure as `pdf` is KissMCMC.emcee's own CPU method; `emcee(HostLogPdf(f; hasblob), theta0s; ...)` runs the
+#  sampler on the GPU with `f` evaluated on the host)
 
 # ---- many-chain Metropolis: metropolis / _metropolis, src/samplers.jl:59-128 ---------------------
 "Symmetric proposal `theta -> scale .* randn(n) .+ theta` (the one all reference tests use, test/runtests.jl:54,59,64,75)."
 struct GaussianStep; scale::Vector{Float64}; end
 GaussianStep(c::Real) = GaussianStep([Float64(c)])
 
-struct KmcMetropolisConfig
-    dtype::Int32; density::Int32
-    params::NTuple{8,Float64}
-    nchains::Int64; ndim::Int64; niter::Int64; nburnin::Int64; nthin::Int64
-    step::Ptr{Float64}; seed::UInt64
-    flags::UInt32; device::Int32
-    user_density::Ptr{Cvoid}
+Base.@kwdef struct KmcMetropolisConfig
+    dtype::Int32 = 0
+    density::Int32 = 0
+    params::NTuple{8,Float64} = ntuple(_ -> 0.0, 8)
+    nchains::Int64 = 0
+    ndim::Int64 = 0
+    niter::Int64 = 0
+    nburnin::Int64 = 0
+    nthin::Int64 = 1
+    step::Ptr{Float64} = C_NULL
+    seed::UInt64 = 0
+    flags::UInt32 = 0
+    device::Int32 = 0
+    user_density::Ptr{Cvoid} = C_NULL
+    host_logpdf::Ptr{Cvoid} = C_NULL                  # host route: `pdf` is a closure (density == KMC_HOST_DENSITY) ...
+    host_user::Ptr{Cvoid} = C_NULL
+    host_accepted::Ptr{Cvoid} = C_NULL                # ... accept outcomes per iteration (blobs)
+    host_propose::Ptr{Cvoid} = C_NULL                 # ... `sample_ppdf` is a closure (then `step` may be NULL)
 end
 
-mutable struct KmcMetropolisOutputs
-    chain::Ptr{Float64}; chain_logp::Ptr{Float64}; accept_ratio::Ptr{Float64}; naccept::Ptr{Int64}
-    final_pos::Ptr{Float64}; final_logp::Ptr{Float64}; chain_sum::Ptr{Float64}; chain_sumsq::Ptr{Float64}
-    nsamples::Int64; device_ms::Float64
+Base.@kwdef mutable struct KmcMetropolisOutputs
+    chain::Ptr{Float64} = C_NULL
+    chain_logp::Ptr{Float64} = C_NULL
+    accept_ratio::Ptr{Float64} = C_NULL
+    naccept::Ptr{Int64} = C_NULL
+    final_pos::Ptr{Float64} = C_NULL
+    final_logp::Ptr{Float64} = C_NULL
+    chain_sum::Ptr{Float64} = C_NULL
+    chain_sumsq::Ptr{Float64} = C_NULL
+    nsamples::Int64 = 0
+    device_ms::Float64 = 0.0
+end
+
+# Layout drift between these mirrors and the library fails here, when the module loads -- not inside the first real ccall.
+function __init__()
+    for (sym, T) in ((:kmc_sizeof_config, KmcConfig), (:kmc_sizeof_metropolis_config, KmcMetropolisConfig))
+        n = sym === :kmc_sizeof_config ? ccall((:kmc_sizeof_config, LIB), Cint, ()) : ccall((:kmc_sizeof_metropolis_config, LIB), Cint, ())
+        n == sizeof(T) || error("$LIB: $(T) is $(sizeof(T)) bytes here but $n in the library (include/kissmcmc_hip.h changed: update the struct in KissMCMCHIP.jl)")
+    end
+end
+
+# `sample_ppdf` as ANY Julia callable (src/samplers.jl:41, :98), kept on the host: called once per iteration on every
+# chain's current state.  The host callbacks of one run share one context object, `MetroCtx`.
+mutable struct HostProposal{F}; f::F; scalar::Bool; end
+HostProposal(f) = HostProposal(f, false)
+mutable struct MetroCtx; pdf::Any; prop::Any; end
+function metro_pdf_trampoline(rows::Ptr{Float64}, nrows::Int64, ndim::Int64, out::Ptr{Float64}, user::Ptr{Cvoid})::Cint
+    ctx = unsafe_pointer_to_objref(user)::MetroCtx
+    return host_trampoline(rows, nrows, ndim, out, pointer_from_objref(ctx.pdf))
+end
+function metro_propose_trampoline(rows::Ptr{Float64}, nrows::Int64, ndim::Int64, out::Ptr{Float64}, user::Ptr{Cvoid})::Cint
+    try
+        d = (unsafe_pointer_to_objref(user)::MetroCtx).prop
+        X = unsafe_wrap(Array, rows, (ndim, nrows)); Y = unsafe_wrap(Array, out, (ndim, nrows))
+        for c in 1:nrows
+            Y[:, c] .= d.scalar ? d.f(X[1, c]) : d.f(X[:, c])                            # theta1 = sample_ppdf(theta0)  :98
+        end
+        return Cint(0)
+    catch
+        return Cint(1)
+    end
 end
 
 """
-    metropolis_chains(pdf::DeviceLogPdf, sample_ppdf::GaussianStep, theta0s; niter=10^5, nburnin=niter÷2, nthin=1, seed, device)
+    metropolis_chains(pdf::DeviceLogPdf, sample_ppdf::Union{GaussianStep,HostProposal}, theta0s; niter=10^5, nburnin=niter÷2, nthin=1, seed, device)
 
-One independent Metropolis chain (src/samplers.jl:96-126) per element of `theta0s`, one chain per GPU lane;
-`niter`/`nburnin` count steps per chain.  Returns `(thetas, accept_ratio, logdensities, nothing)` shaped like
-`emcee`'s output (`thetas[chain][sample]`), so `squash_walkers` applies.
+One independent Metropolis chain (src/samplers.jl:96-126) per element of `theta0s`; `niter`/`nburnin` count steps per
+chain.  With a menu / `ExprDensity` `pdf` and a `GaussianStep` the chains run inside one kernel, one chain per GPU lane;
+a `HostLogPdf(f)` and / or a `HostProposal(g)` keep those closures on the host (one batch call per iteration) while the
+accept test, counters and storage stay on the device.  Returns `(thetas, accept_ratio, logdensities, nothing)` shaped
+like `emcee`'s output (`thetas[chain][sample]`), so `squash_walkers` applies.
 """
-function metropolis_chains(pdf::DeviceLogPdf, sample_ppdf::GaussianStep, theta0s; niter=10^5, nburnin=niter ÷ 2, nthin=1,
+function metropolis_chains(pdf::DeviceLogPdf, sample_ppdf::Union{GaussianStep,HostProposal}, theta0s; niter=10^5, nburnin=niter ÷ 2, nthin=1,
                            hasblob=false, seed=rand(UInt64), device=0)
-    hasblob && error("hasblob=true is not supported by the HIP samplers")
-    pdf isa HostLogPdf && error("the many-chain Metropolis kernel needs a device log-density (menu or ExprDensity)")
+    hasblob && error("hasblob=true for metropolis is not wired in this shim (the C ABI carries it: kmc_metropolis_config.host_accepted)")
     nchains = length(theta0s); scalar = theta0s[1] isa Number; ndim = length(theta0s[1])
     nsamples = niter > nburnin ? (niter - nburnin) ÷ nthin : 0                            # :88
     theta = Matrix{Float64}(undef, ndim, nchains)          # column-major [dim, chain] == C row-major [chain][dim]
     for c in 1:nchains, d in 1:ndim
         theta[d, c] = scalar ? theta0s[c] : theta0s[c][d]                                # :68 deep copy
     end
-    step = length(sample_ppdf.scale) == 1 ? fill(sample_ppdf.scale[1], ndim) : copy(sample_ppdf.scale)
-    @assert length(step) == ndim
+    step = Float64[]
+    prop_fn = C_NULL
+    if sample_ppdf isa GaussianStep
+        step = length(sample_ppdf.scale) == 1 ? fill(sample_ppdf.scale[1], ndim) : copy(sample_ppdf.scale)
+        @assert length(step) == ndim
+    else
+        sample_ppdf.scalar = scalar
+        prop_fn = @cfunction(metro_propose_trampoline, Cint, (Ptr{Float64}, Int64, Int64, Ptr{Float64}, Ptr{Cvoid}))
+    end
+    pdf_fn = C_NULL
+    if pdf isa HostLogPdf
+        pdf.scalar = scalar
+        pdf_fn = @cfunction(metro_pdf_trampoline, Cint, (Ptr{Float64}, Int64, Int64, Ptr{Float64}, Ptr{Cvoid}))
+    end
+    ctx = MetroCtx(pdf, sample_ppdf)
     p = params(pdf); p8 = ntuple(i -> i <= length(p) ? p[i] : 0.0, 8)
     chain = Array{Float64}(undef, ndim, nchains, nsamples)
     clogp = Array{Float64}(undef, nchains, nsamples)
     acc = Vector{Float64}(undef, nchains)
-    out = KmcMetropolisOutputs(pointer(chain), pointer(clogp), pointer(acc), C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, 0, 0.0)
-    st = GC.@preserve pdf theta step chain clogp acc begin
-        cfg = Ref(KmcMetropolisConfig(0, density_id(pdf), p8, nchains, ndim, niter, nburnin, nthin, pointer(step), UInt64(seed),
-                                      0x3, Int32(device), user_handle(pdf)))                 # flags: STORE_CHAIN | STORE_LOGP
+    out = KmcMetropolisOutputs(chain=pointer(chain), chain_logp=pointer(clogp), accept_ratio=pointer(acc))
+    st = GC.@preserve pdf sample_ppdf ctx theta step chain clogp acc begin
+        cfg = Ref(KmcMetropolisConfig(density=density_id(pdf), params=p8, nchains=nchains, ndim=ndim, niter=niter, nburnin=nburnin,
+                                      nthin=nthin, step=(isempty(step) ? Ptr{Float64}(C_NULL) : pointer(step)), seed=UInt64(seed),
+                                      flags=KMC_STORE_CHAIN | KMC_STORE_LOGP, device=Int32(device), user_density=user_handle(pdf),
+                                      host_logpdf=pdf_fn, host_user=pointer_from_objref(ctx), host_propose=prop_fn))
         ccall((:kmc_metropolis_run, LIB), Cint, (Ref{KmcMetropolisConfig}, Ptr{Float64}, Ref{KmcMetropolisOutputs}), cfg, theta, out)
     end
     st == 0 || error("kmc_metropolis_run failed ($st): $(last_error())")
@@ -257,12 +355,13 @@ function metropolis_chains(pdf::DeviceLogPdf, sample_ppdf::GaussianStep, theta0s
 end
 
 """
-    metropolis(pdf::DeviceLogPdf, sample_ppdf::GaussianStep, theta0; niter=10^5, nburnin=niter÷2, nthin=1, ...)
+    metropolis(pdf::DeviceLogPdf, sample_ppdf::Union{GaussianStep,HostProposal}, theta0; niter=10^5, nburnin=niter÷2, nthin=1, ...)
 
-KissMCMC.metropolis' signature and return value (src/samplers.jl:59-77, :128) for one chain (a single lane:
-a drop-in, not a fast path -- use `metropolis_chains` for throughput).
+One more method of KissMCMC.metropolis, with its signature and return value (src/samplers.jl:59-77, :128), for one chain
+on the GPU (a single lane: a drop-in, not a fast path -- use `metropolis_chains` for throughput).  Two plain closures,
+`metropolis(pdf, sample_ppdf, theta0)`, remain KissMCMC's own CPU method.
 """
-function metropolis(pdf::DeviceLogPdf, sample_ppdf::GaussianStep, theta0; use_progress_meter=true, kw...)
+function metropolis(pdf::DeviceLogPdf, sample_ppdf::Union{GaussianStep,HostProposal}, theta0; use_progress_meter=true, kw...)
     thetas, acc, logd, _ = metropolis_chains(pdf, sample_ppdf, [theta0]; kw...)
     return thetas[1], acc[1], logd[1], nothing                                           # :128
 end
@@ -287,60 +386,6 @@ function int_acorr(thetas; c=5, device=0)
     return tau, conv
 end
 
-"src/samplers.jl:311-349 (host side, runs once)."
-function make_theta0s(theta0::T, ball_radius, pdf, nwalkers; ball_radius_halfing_steps=7, ntries=100, hasblob=false) where T
-    npara = length(theta0)
-    if ball_radius isa Number && !(T <: Number)
-        ball_radius = ones(npara) * ball_radius
-    end
-    @assert length(ball_radius) == npara
-    theta0s = T[]
-    for i = 1:nwalkers
-        for k = 1:ball_radius_halfing_steps
-            ball_radius *= 1 / 2^(k - 1)
-            for _ = 1:ntries
-                tmp = npara == 1 ? theta0 .+ randn() .* ball_radius : theta0 .+ randn(npara) .* ball_radius
-                p0 = hasblob ? pdf(tmp)[1] : pdf(tmp)                                   # :333-337
-                if p0 > -Inf
-                    push!(theta0s, tmp)
-                    break
-                end
-            end
-            length(theta0s) == i && break
-        end
-        length(theta0s) == i || error("Could not find suitable initial theta.  PDF is zero in too many places inside ball.")
-    end
-    return theta0s
-end
-
-"src/samplers.jl:372-428 (host post-processing)."
-function squash_walkers(thetas, accept_ratio, logdensities=nothing, blobs=nothing;
-                        drop_low_accept_ratio=false, drop_fact=2, verbose=true, order=false, merge_blobs! =append!)
-    nwalkers = length(accept_ratio)
-    walkers2keep = if drop_low_accept_ratio
-        ma, sa = median(accept_ratio), std(accept_ratio)
-        verbose && println("Median accept ratio is $ma, standard deviation is $sa\n")
-        [nc for nc in 1:nwalkers if !(accept_ratio[nc] <= ma - drop_fact * sa)]
-    else
-        collect(1:nwalkers)
-    end
-    t = reduce(vcat, thetas[walkers2keep])
-    l = logdensities === nothing ? nothing : reduce(vcat, logdensities[walkers2keep])
-    b = nothing
-    if blobs !== nothing                                                                  # :408-413
-        b = deepcopy(blobs[walkers2keep[1]])
-        for w in walkers2keep[2:end]
-            merge_blobs!(b, blobs[w])
-        end
-    end
-    if order
-        ns = length(thetas[1])
-        perm = sortperm(repeat(1:ns, length(walkers2keep)))
-        t = t[perm]
-        l === nothing || (l = l[perm])
-        b === nothing || (b = b[perm])
-    end
-    return t, mean(accept_ratio[walkers2keep]), l, b
-end
+# make_theta0s (src/samplers.jl:311-349) and squash_walkers (src/samplers.jl:372-428): KissMCMC's own, imported above.
 
 end # module

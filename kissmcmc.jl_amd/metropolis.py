@@ -6,9 +6,15 @@ plus its data-parallel form, many independent chains at once.
 * ``metropolis_chains(pdf, sample_ppdf, theta0s; ...)`` -- one chain per row of ``theta0s``, one chain per
   lane; returns the same ``[chain][sample]`` containers as ``emcee`` so ``squash_walkers`` applies.
 
-On the device ``sample_ppdf`` is a :class:`GaussianStep` -- the symmetric jump every reference test uses,
-``theta -> c .* randn(n) .+ theta`` (``test/runtests.jl:54,59,64,75``) -- and ``pdf`` a menu or
-runtime-compiled density.  An arbitrary closure for either cannot run inside the kernel and is refused.
+Fast path: ``sample_ppdf`` a :class:`GaussianStep` -- the symmetric jump every reference test uses,
+``theta -> c .* randn(n) .+ theta`` (``test/runtests.jl:54,59,64,75``) -- and ``pdf`` a menu or runtime-compiled
+density: the whole chain runs inside one kernel, one chain per lane.
+
+General path (the reference takes ANY two closures, ``src/samplers.jl:59-61``; its README-style call
+``metropolis(pdf, sample_prop_normal, theta0)`` works as it is): a callable ``pdf`` and / or a callable ``sample_ppdf``
+stay on the host and are called once per iteration on the batch of all chains, while the accept test (``:101``), the
+counters and the sample storage stay on the device -- launch- and PCIe-bound (tens of microseconds per iteration), the
+same trade as ``emcee``'s host-evaluated densities.  ``hasblob=True`` needs a callable ``pdf`` returning ``(p, blob)``.
 """
 from __future__ import annotations
 
@@ -41,23 +47,56 @@ def _dp(a):
     return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
 
 
+class HostProposal:
+    """ANY callable as ``sample_ppdf`` (``src/samplers.jl:41, :98``: a symmetric proposal ``theta0 -> theta1``), kept on
+    the host and called per iteration on every chain's current state (a float when ``scalar`` else a 1-D array; with
+    ``vectorized=True`` on the whole batch ``[nchains, ndim]`` at once)."""
+
+    def __init__(self, fn, scalar: bool = False, vectorized: bool = False):
+        if not callable(fn):
+            raise TypeError("sample_ppdf must be callable")
+        self.fn, self.scalar, self.vectorized = fn, bool(scalar), bool(vectorized)
+        self.error = None
+
+        def _cb(rows, nrows, ndim, out, _user):
+            try:
+                X = np.ctypeslib.as_array(rows, shape=(nrows, ndim))
+                Y = np.ctypeslib.as_array(out, shape=(nrows, ndim))
+                if self.vectorized:
+                    Y[:] = np.asarray(self.fn(X[:, 0] if self.scalar else X), dtype=np.float64).reshape(nrows, ndim)
+                else:
+                    for i in range(nrows):
+                        Y[i] = self.fn(float(X[i, 0])) if self.scalar else np.asarray(self.fn(X[i].copy()), dtype=np.float64)
+                return 0
+            except BaseException as e:      # never unwind through the C frames
+                self.error = e
+                return 1
+
+        self.c_callback = _lib.HOST_PROPOSE_FN(_cb)
+
+
 def run_chains(pdf, sample_ppdf, theta0s, niter, nburnin, nthin, seed, device=0, store_chain=True, store_logp=True,
-               moments=False):
+               moments=False, scalar=False):
     """``kmc_metropolis_run`` on dense arrays.  Returns a dict: ``chain [nsamples, nchains, ndim]``,
     ``chain_logp [nsamples, nchains]``, ``accept_ratio``, ``naccept``, ``final_pos``, ``final_logp``,
-    ``chain_sum``/``chain_sumsq [nchains, ndim]``, ``nsamples``, ``device_ms``."""
-    if isinstance(pdf, HostLogPdf) or not isinstance(pdf, DeviceLogPdf):
-        raise TypeError("the many-chain Metropolis kernel evaluates pdf on the device: pass a menu density "
-                        "(GaussianIso, Exponential, Rosenbrock, LogNormal, MvNormal2) or an ExprDensity")
-    if not isinstance(sample_ppdf, GaussianStep):
-        raise TypeError("sample_ppdf must be a GaussianStep (theta -> scale .* randn(n) .+ theta): an arbitrary "
-                        "proposal closure cannot run inside the kernel")
+    ``chain_sum``/``chain_sumsq [nchains, ndim]``, ``nsamples``, ``device_ms``.
+
+    ``pdf``: a device density, a :class:`~.densities.HostLogPdf` or any callable (wrapped in one); ``sample_ppdf``: a
+    :class:`GaussianStep`, a :class:`HostProposal` or any callable (wrapped in one).  ``scalar``: bare callables get a
+    float instead of a 1-element array (the reference's convention for a scalar ``theta0``)."""
+    if not isinstance(pdf, DeviceLogPdf):
+        if not callable(pdf):
+            raise TypeError(f"pdf must be a log-density object or a callable; got {type(pdf).__name__}")
+        pdf = HostLogPdf(pdf, scalar=scalar)             # an arbitrary closure, as in the reference (:99): evaluated on the host
+    if not isinstance(sample_ppdf, (GaussianStep, HostProposal)):
+        if not callable(sample_ppdf):
+            raise TypeError("sample_ppdf must be a GaussianStep (theta -> scale .* randn(n) .+ theta) or a callable")
+        sample_ppdf = HostProposal(sample_ppdf, scalar=scalar)
     theta0s = np.ascontiguousarray(np.asarray(theta0s, dtype=np.float64))
     if theta0s.ndim != 2:
         raise ValueError("theta0s must be [nchains, ndim]")
     nchains, ndim = theta0s.shape
     pdf.check_ndim(ndim)
-    step = sample_ppdf.scales(ndim)
     c = _lib.MetropolisConfig()
     c.dtype = _lib.F64
     c.density = pdf.density_id
@@ -65,11 +104,20 @@ def run_chains(pdf, sample_ppdf, theta0s, niter, nburnin, nthin, seed, device=0,
     for i in range(8):
         c.params[i] = float(p[i])
     c.nchains, c.ndim, c.niter, c.nburnin, c.nthin = nchains, ndim, int(niter), int(nburnin), int(nthin)
-    c.step = _dp(step)
+    step = None
+    if isinstance(sample_ppdf, GaussianStep):
+        step = sample_ppdf.scales(ndim)
+        c.step = _dp(step)
+    else:
+        c.host_propose = C.cast(sample_ppdf.c_callback, C.c_void_p)
     c.seed = int(seed)
     c.flags = (_lib.STORE_CHAIN if store_chain else 0) | (_lib.STORE_LOGP if store_logp else 0) | (_lib.MOMENTS if moments else 0)
     c.device = int(device)
     c.user_density = pdf.user_handle
+    if isinstance(pdf, HostLogPdf):
+        c.host_logpdf = C.cast(pdf.c_callback, C.c_void_p)
+        if pdf.c_accepted is not None:
+            c.host_accepted = C.cast(pdf.c_accepted, C.c_void_p)
     L = _lib.lib()
     _lib.check(L.kmc_metropolis_validate(C.byref(c)))
     ns = max(0, (int(niter) - int(nburnin)) // int(nthin)) if niter > nburnin else 0     # src/samplers.jl:88
@@ -86,7 +134,13 @@ def run_chains(pdf, sample_ppdf, theta0s, niter, nburnin, nthin, seed, device=0,
     o.naccept = nacc.ctypes.data_as(C.POINTER(C.c_int64))
     o.final_pos, o.final_logp, o.chain_sum, o.chain_sumsq = _dp(fpos), _dp(flogp), _dp(csum), _dp(csq)
     with np.errstate(all="ignore"):
-        _lib.check(L.kmc_metropolis_run(C.byref(c), _dp(theta0s), C.byref(o)))
+        status = L.kmc_metropolis_run(C.byref(c), _dp(theta0s), C.byref(o))
+    for obj in (pdf, sample_ppdf):                        # an exception raised inside a host callback: re-raise it here
+        err = getattr(obj, "error", None)
+        if status != _lib.OK and err is not None:
+            obj.error = None
+            raise err
+    _lib.check(status)
     assert o.nsamples == ns
     return dict(chain=chain, chain_logp=chain_logp, accept_ratio=acc, naccept=nacc, final_pos=fpos, final_logp=flogp,
                 chain_sum=csum, chain_sumsq=csq, nsamples=ns, device_ms=o.device_ms)
@@ -96,42 +150,87 @@ def _fresh_seed() -> int:
     return int(np.random.SeedSequence().generate_state(2, dtype=np.uint32).astype(np.uint64) @ np.array([1, 1 << 32], dtype=np.uint64))
 
 
-def _no_blobs(hasblob, init_blobs, reduce_blob):
-    if hasblob or init_blobs is not None or reduce_blob is not None:
-        raise NotImplementedError("blobs are arbitrary host objects and cannot cross the device boundary "
-                                  "(hasblob=True is not supported by the HIP samplers)")
+def _blob_plumbing(pdf, hasblob, init_blobs, reduce_blob, scalar, nchains, nsamples):
+    """The reference's blob handling (``src/samplers.jl:70-72, :100-103, :116-118``) on the host: ``pdf`` returns ``(p, blob)``;
+    ``blob0`` follows the device's accept decisions, ``reduce_blob(blobs, blob0)`` runs for every stored sample."""
+    if not hasblob:
+        if init_blobs is not None or reduce_blob is not None:
+            raise ValueError("init_blobs / reduce_blob need hasblob=True")
+        return pdf, None
+    if isinstance(pdf, HostLogPdf):
+        if not pdf.hasblob:
+            raise ValueError("hasblob=True needs HostLogPdf(..., hasblob=True)")
+    elif isinstance(pdf, DeviceLogPdf):
+        raise NotImplementedError("blobs are host objects: hasblob=True needs a host callable as pdf (device densities return the log-pdf alone)")
+    else:
+        pdf = HostLogPdf(pdf, scalar=scalar, hasblob=True)
+    if init_blobs is None:
+        init_blobs = lambda blob0, ns: []                 # init_output_vector :80-85
+    if reduce_blob is None:
+        reduce_blob = lambda bs, b: bs.append(b)          # push!  :67
+    state = dict(blob0s=None, blobs=None)
+
+    def on_accepted(accepted, row0, iteration, stored):
+        if state["blob0s"] is None:                       # first call: the blobs of the initial evaluation (:70) were replaced by
+            raise RuntimeError("initial blobs missing")   # the first batch's -- they are captured before the run (below)
+        batch = pdf.last_blobs
+        for i in np.nonzero(accepted)[0]:
+            state["blob0s"][i] = batch[i]                 # :103
+        if stored:
+            for w in range(nchains):
+                reduce_blob(state["blobs"][w], state["blob0s"][w])      # :117
+    pdf.on_accepted = on_accepted
+    return pdf, (state, init_blobs, nsamples)
 
 
 def metropolis(pdf, sample_ppdf, theta0, niter: int = 10 ** 5, nburnin=None, nthin: int = 1,
                use_progress_meter: bool = True, hasblob: bool = False, init_blobs=None, reduce_blob=None,
                seed=None, device: int = 0):
-    """One Metropolis chain with the reference's signature (``src/samplers.jl:59-77``).
+    """One Metropolis chain with the reference's signature (``src/samplers.jl:59-77``); ``pdf`` and ``sample_ppdf`` may be
+    device objects (fast: the chain runs in one kernel) or ANY callables, as in the reference (host route).
 
     Returns ``(thetas, accept_ratio, logdensities, blobs)`` (``:128``): ``thetas[k]`` is stored sample ``k``
     (shape ``[nsamples]`` for a scalar ``theta0``, ``[nsamples, ndim]`` for a vector), ``accept_ratio`` a float,
-    ``blobs = None``.  ``use_progress_meter`` is accepted and ignored (the chain runs in one device call).
+    ``blobs`` ``None`` unless ``hasblob``.  ``use_progress_meter`` is accepted and ignored.
     """
-    _no_blobs(hasblob, init_blobs, reduce_blob)
     if nburnin is None:
         nburnin = niter // 2                                              # :63
     scalar = np.ndim(theta0) == 0
     th = np.array(theta0, dtype=np.float64).reshape(1, -1)                # :68 deepcopy
     if seed is None:
         seed = _fresh_seed()
-    r = run_chains(pdf, sample_ppdf, th, niter, nburnin, nthin, seed, device)
-    thetas = r["chain"][:, 0, 0] if scalar else r["chain"][:, 0, :]
-    return np.ascontiguousarray(thetas), float(r["accept_ratio"][0]), np.ascontiguousarray(r["chain_logp"][:, 0]), None
+    thetas, acc, logd, blobs = _run(pdf, sample_ppdf, th, niter, nburnin, nthin, hasblob, init_blobs, reduce_blob, seed, device, scalar)
+    return (thetas[0], float(acc[0]), logd[0], None if blobs is None else blobs[0])
+
+
+def _run(pdf, sample_ppdf, th, niter, nburnin, nthin, hasblob, init_blobs, reduce_blob, seed, device, scalar):
+    nchains = th.shape[0]
+    ns = max(0, (int(niter) - int(nburnin)) // int(nthin)) if niter > nburnin else 0
+    pdf, blobctx = _blob_plumbing(pdf, hasblob, init_blobs, reduce_blob, scalar, nchains, ns)
+    try:
+        if blobctx is not None:
+            state, init_blobs, _ = blobctx
+            pdf.eval_rows(th)                                             # p0, blob0 = pdf(theta0)  :70 (the library evaluates it again)
+            state["blob0s"] = list(pdf.last_blobs)
+            state["blobs"] = [init_blobs(state["blob0s"][w], ns) for w in range(nchains)]       # :90
+        r = run_chains(pdf, sample_ppdf, th, niter, nburnin, nthin, seed, device, scalar=scalar)
+    finally:
+        if blobctx is not None:
+            pdf.on_accepted = None
+    thetas = np.ascontiguousarray(r["chain"].transpose(1, 0, 2))
+    if scalar:
+        thetas = thetas[:, :, 0]
+    return thetas, r["accept_ratio"], np.ascontiguousarray(r["chain_logp"].T), (None if blobctx is None else blobctx[0]["blobs"])
 
 
 def metropolis_chains(pdf, sample_ppdf, theta0s, niter: int = 10 ** 5, nburnin=None, nthin: int = 1,
-                      hasblob: bool = False, seed=None, device: int = 0):
+                      hasblob: bool = False, init_blobs=None, reduce_blob=None, seed=None, device: int = 0):
     """Many independent Metropolis chains, one per row of ``theta0s`` (``[nchains]`` scalars or
     ``[nchains, ndim]``); ``niter``/``nburnin`` count steps PER CHAIN, as in ``metropolis``.
 
-    Returns ``(thetas, accept_ratio, logdensities, None)`` shaped like ``emcee``'s output
+    Returns ``(thetas, accept_ratio, logdensities, blobs)`` shaped like ``emcee``'s output
     (``thetas[chain][sample]``), so ``squash_walkers(*result)`` concatenates the chains.
     """
-    _no_blobs(hasblob, None, None)
     if nburnin is None:
         nburnin = niter // 2
     theta0s = np.array(theta0s, dtype=np.float64)
@@ -140,8 +239,4 @@ def metropolis_chains(pdf, sample_ppdf, theta0s, niter: int = 10 ** 5, nburnin=N
         theta0s = theta0s[:, None]
     if seed is None:
         seed = _fresh_seed()
-    r = run_chains(pdf, sample_ppdf, theta0s, niter, nburnin, nthin, seed, device)
-    thetas = np.ascontiguousarray(r["chain"].transpose(1, 0, 2))
-    if scalar:
-        thetas = thetas[:, :, 0]
-    return thetas, r["accept_ratio"], np.ascontiguousarray(r["chain_logp"].T), None
+    return _run(pdf, sample_ppdf, theta0s, niter, nburnin, nthin, hasblob, init_blobs, reduce_blob, seed, device, scalar)

@@ -33,6 +33,11 @@ for name, kw in (("pull, signal kernel", {}), ("pull, folded signal", dict(p2p_f
                  ("lazy pull, signal kernel", dict(p2p_lazy=True)), ("lazy pull, folded signal", dict(p2p_lazy=True, p2p_fold=True))):
     shards = [kmc.Sampler(kmc.GaussianIso(), nw, nd, G, 0, 1, 2.0, 9, moments=True, shard_rank=r, shard_count=world, p2p=True, **kw)
               for r in range(world)]
+    if world == 2:       # streams of different priority never share a hardware queue (the shards spin on each other)
+        import torch
+        prio_streams = [torch.cuda.Stream(device=0, priority=-1), torch.cuda.Stream(device=0, priority=0)]
+        for sh, st in zip(shards, prio_streams):
+            sh.set_stream(st.cuda_stream)
     kmc.Sampler.p2p_connect_local(shards)
     best = None
     for rep in range(3):

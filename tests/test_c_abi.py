@@ -173,3 +173,26 @@ int main(int argc, char** argv) {
         want = oracle.philox4x32_10((step & 0xFFFFFFFF, step >> 32, walker & 0xFFFFFFFF, walker >> 32),
                                     (seed & 0xFFFFFFFF, seed >> 32))
         assert got == want
+
+
+def test_julia_shim_structs_mirror_the_header():
+    """No julia in this image: the shim cannot be executed, so its struct mirrors are checked statically -- field names,
+    order and sizes of the `Base.@kwdef struct`s in KissMCMCHIP.jl against the ctypes mirrors (which test_struct_layouts
+    checks against the C header with gcc).  At run time the shim's __init__ compares sizeof with kmc_sizeof_config()."""
+    import ctypes as C
+    import re
+    from kissmcmc_jl_amd import _lib
+    src = open(os.path.join(ROOT, "kissmcmc.jl_amd", "julia", "KissMCMCHIP.jl")).read()
+    jl_size = {"Int32": 4, "UInt32": 4, "Int64": 8, "UInt64": 8, "Float64": 8, "Ptr{Cvoid}": 8, "Ptr{Float64}": 8, "Ptr{Int64}": 8,
+               "NTuple{8,Float64}": 64}
+    for jl_name, mirror in (("KmcConfig", _lib.Config), ("KmcOutputs", _lib.Outputs), ("KmcMetropolisConfig", _lib.MetropolisConfig),
+                            ("KmcMetropolisOutputs", _lib.MetropolisOutputs)):
+        m = re.search(r"Base\.@kwdef (?:mutable )?struct " + jl_name + r"\n(.*?)\nend\n", src, re.S)
+        assert m, jl_name
+        fields = re.findall(r"^\s+(\w+)::([\w{},]+)", m.group(1), re.M)
+        assert [f for f, _ in fields] == [f for f, _ in mirror._fields_], jl_name
+        assert [jl_size[t] for _, t in fields] == [C.sizeof(t) for _, t in mirror._fields_], jl_name
+    assert "kmc_sizeof_config" in src and "function __init__()" in src
+    # the host-side pre/post-processing is KissMCMC's own, not re-typed here
+    assert "import KissMCMC: emcee, metropolis, make_theta0s, squash_walkers" in src
+    assert "function make_theta0s" not in src and "function squash_walkers" not in src

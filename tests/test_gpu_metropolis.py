@@ -116,3 +116,82 @@ def test_minus_inf_start_is_carried_like_the_reference(kmc):
     is accepted (p1 - (-Inf) = Inf > log u)."""
     th, acc, logd, _ = kmc.metropolis_chains(kmc.Exponential(), kmc.GaussianStep(2.0), np.full(64, -1.0), niter=400, nburnin=0, seed=2)
     assert np.all(th[:, -1] >= 0.0) and np.all(np.isfinite(logd[:, -1]))
+
+
+# ---- host route: ANY closures for pdf / sample_ppdf (reference src/samplers.jl:59-61), blobs (:100-118) ------------
+def test_closure_pdf_with_device_proposal_equals_the_oracle(kmc, oracle):
+    """pdf = a Python closure computing the oracle's density (so the log-pdfs are the oracle's own), sample_ppdf =
+    GaussianStep: proposals, accept decisions and counters are the in-kernel stream's -> equal to kmco_metropolis."""
+    from kissmcmc_jl_amd.metropolis import run_chains
+    nc, nd, niter, nburn, nthin, seed = 96, 3, 150, 40, 2, 17
+    th = 0.3 * np.random.default_rng(2).standard_normal((nc, nd))
+    pdf = kmc.HostLogPdf(lambda X: oracle.logpdf_batch(oracle.GAUSSIAN_ISO, [0.2, 1.5], X), vectorized=True)
+    r = run_chains(pdf, kmc.GaussianStep(0.8), th, niter, nburn, nthin, seed, moments=True)
+    ref = oracle.metropolis(oracle.GAUSSIAN_ISO, [0.2, 1.5], th, 0.8, niter, nburn, nthin, seed)
+    np.testing.assert_array_equal(r["naccept"], ref["naccept"])
+    np.testing.assert_allclose(r["chain"], ref["chain"], rtol=1e-11, atol=1e-11)
+    np.testing.assert_array_equal(r["chain_logp"], oracle.logpdf_batch(oracle.GAUSSIAN_ISO, [0.2, 1.5], r["chain"].reshape(-1, nd)).reshape(r["chain_logp"].shape))
+    np.testing.assert_allclose(r["chain_sum"], ref["chain_sum"], rtol=1e-10, atol=1e-10)
+    # and the in-kernel fast path gives the same chain
+    fast = run_chains(kmc.GaussianIso(0.2, 1.5), kmc.GaussianStep(0.8), th, niter, nburn, nthin, seed)
+    np.testing.assert_array_equal(fast["naccept"], r["naccept"])
+    np.testing.assert_allclose(fast["chain"], r["chain"], rtol=1e-11, atol=1e-11)
+
+
+def test_closure_proposal_with_device_density_equals_a_host_restatement(kmc, oracle):
+    """sample_ppdf = a deterministic Python closure, pdf = a menu density evaluated on the device: the chain must equal a
+    line-by-line host loop of src/samplers.jl:96-126 fed the same proposals and the stream's accept uniforms."""
+    from kissmcmc_jl_amd.metropolis import HostProposal, run_chains
+    nc, nd, niter, nburn, nthin, seed = 8, 2, 60, 20, 3, 5
+    th = np.linspace(-1, 1, nc * nd).reshape(nc, nd)
+    calls = {"n": 0}
+
+    def prop(X):                                  # symmetric in distribution is the user's business; here: a fixed schedule
+        calls["n"] += 1
+        return X + 0.4 * np.cos(calls["n"] + np.arange(X.size).reshape(X.shape))
+    r = run_chains(kmc.GaussianIso(), HostProposal(prop, vectorized=True), th, niter, nburn, nthin, seed)
+    x = th.copy()
+    p0 = np.array([oracle.logpdf(oracle.GAUSSIAN_ISO, [0.0, 1.0], v) for v in x])
+    nacc = np.zeros(nc, dtype=np.int64)
+    chain = []
+    for it in range(niter):
+        n = it + 1 - nburn
+        y = x + 0.4 * np.cos((it + 1) + np.arange(x.size).reshape(x.shape))
+        for c in range(nc):
+            p1 = oracle.logpdf(oracle.GAUSSIAN_ISO, [0.0, 1.0], y[c])
+            ua = oracle.metropolis_draw(seed, it, c, 1)[1]
+            if p1 - p0[c] > np.log(ua):                                   # :101
+                x[c], p0[c] = y[c], p1
+                nacc[c] += n > 0
+        if n > 0 and n % nthin == 0:
+            chain.append(x.copy())
+    np.testing.assert_array_equal(r["naccept"], nacc)
+    np.testing.assert_allclose(r["chain"], np.array(chain), rtol=1e-12, atol=1e-12)
+
+
+def test_readme_style_call_with_two_closures_and_blobs(kmc):
+    """metropolis(pdf, sample_ppdf, theta0) with two plain closures -- the reference's signature (src/samplers.jl:59) --
+    and hasblob: the blob of every stored sample is the blob of the state that was stored (:100-103, :116-118)."""
+    rng = np.random.default_rng(0)
+    thetas, acc, logd, blobs = kmc.metropolis(lambda x: -0.5 * (x + 5.0) ** 2 / 9.0, lambda x: x + 1.5 * rng.standard_normal(), -5.0,
+                                              niter=4000, use_progress_meter=False, seed=3)
+    assert thetas.shape == (2000,) and logd.shape == (2000,) and blobs is None and 0.3 < acc < 0.95
+    assert abs(thetas.mean() + 5.0) < 1.0 and abs(thetas.std() - 3.0) < 1.0
+    np.testing.assert_allclose(logd, -0.5 * (thetas + 5.0) ** 2 / 9.0, rtol=1e-13)
+    th, acc, logd, blobs = kmc.metropolis(lambda x: (-0.5 * float(x @ x), (x.copy(), "tag")), kmc.GaussianStep(0.7), np.array([0.1, -0.2]),
+                                          niter=600, nburnin=100, nthin=5, hasblob=True, seed=9)
+    assert th.shape == (100, 2) and len(blobs) == 100
+    for k in range(100):
+        np.testing.assert_array_equal(blobs[k][0], th[k])
+        assert blobs[k][1] == "tag"
+    # many chains, sum-reducing blobs (the reference's second blob case, test/runtests.jl:96-107)
+    th, acc, logd, blobs = kmc.metropolis_chains(lambda x: (-0.5 * x * x, x), kmc.GaussianStep(1.0), np.zeros(16), niter=300, nburnin=100,
+                                                 hasblob=True, init_blobs=lambda b0, ns: [0.0], reduce_blob=lambda bs, b: bs.__setitem__(0, bs[0] + b), seed=4)
+    np.testing.assert_allclose([b[0] for b in blobs], th.sum(axis=1), rtol=1e-12, atol=1e-12)
+
+
+def test_exceptions_in_host_closures_are_re_raised(kmc):
+    def bad(x):
+        raise KeyError("boom")
+    with pytest.raises(KeyError):
+        kmc.metropolis(kmc.GaussianIso(), bad, 0.0, niter=10)

@@ -227,11 +227,18 @@ def test_p2p_with_finegrained_rows(oracle, tmp_path):
 def test_two_shards_in_one_process(kmc, oracle, kw):
     """kmc_sampler_p2p_connect_local: both shards live in this process and run concurrently on their own streams,
     ordered by the same progress flags (what scripts/p2p_local_bench.py times); result = the oracle's."""
+    import torch
     th = _theta0()
     G = 128         # whole hipGraph chunks only: eager launches of two streams of ONE process are not reliably concurrent
     shards = [kmc.Sampler(kmc.GaussianIso(), NW, ND, G, NBURN, 1, 2.0, SEED, moments=True, shard_rank=r, shard_count=2, p2p=True, **kw)
               for r in range(2)]
+    # the shards spin on each other's progress flags, so their streams must sit on DIFFERENT hardware queues: streams of
+    # one process share a small pool of queues round-robin (which two land together depends on how many streams the
+    # process has created before), streams of different priority never share one
+    streams = [torch.cuda.Stream(device=0, priority=-1), torch.cuda.Stream(device=0, priority=0)]
     try:
+        for sh, st in zip(shards, streams):
+            sh.set_stream(st.cuda_stream)
         kmc.Sampler.p2p_connect_local(shards)
         for sh in shards:
             sh.set_positions(th)

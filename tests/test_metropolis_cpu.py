@@ -101,17 +101,27 @@ def test_threaded_metropolis_oracle_equals_serial(oracle):
 
 
 # ---- product host API (argument handling; compute needs the GPU) ------------------------------------------
-def test_host_api_rejects_what_cannot_run_on_the_device(kmc):
-    with pytest.raises(TypeError, match="GaussianStep"):
-        kmc.metropolis(kmc.GaussianIso(), lambda th: th + 1.0, 0.0, niter=10)
-    with pytest.raises(TypeError, match="menu density"):
-        kmc.metropolis(lambda x: -x * x, kmc.GaussianStep(1.0), 0.0, niter=10)
+def test_host_api_argument_handling(kmc):
+    """Closures for pdf / sample_ppdf are accepted (host route; compute needs the GPU) -- what is refused is what the
+    reference could not run either, or what cannot work by construction."""
+    from kissmcmc_jl_amd import _lib
+    with pytest.raises(TypeError, match="callable"):
+        kmc.metropolis(kmc.GaussianIso(), "not a proposal", 0.0, niter=10)
+    with pytest.raises(TypeError, match="callable"):
+        kmc.metropolis(42, kmc.GaussianStep(1.0), 0.0, niter=10)
     with pytest.raises(NotImplementedError, match="blobs"):
-        kmc.metropolis(kmc.GaussianIso(), kmc.GaussianStep(1.0), 0.0, niter=10, hasblob=True)
+        kmc.metropolis(kmc.GaussianIso(), kmc.GaussianStep(1.0), 0.0, niter=10, hasblob=True)      # a device density has no blob
+    with pytest.raises(ValueError, match="hasblob=True"):
+        kmc.metropolis(kmc.GaussianIso(), kmc.GaussianStep(1.0), 0.0, niter=10, reduce_blob=lambda b, x: None)
     with pytest.raises(ValueError):
         kmc.metropolis_chains(kmc.Rosenbrock(), kmc.GaussianStep(0.5), np.zeros(8), niter=10)      # 1-D Rosenbrock
     with pytest.raises(ValueError, match="scales"):
         kmc.metropolis_chains(kmc.GaussianIso(), kmc.GaussianStep([1.0, 2.0, 3.0]), np.zeros((8, 2)), niter=10)
+    if _lib.lib().kmc_device_count() == 0:
+        # the README-style call with two closures reaches the library; without a GPU it fails there: no CPU fallback
+        with pytest.raises(kmc.KmcError) as e:
+            kmc.metropolis(lambda x: -x * x, lambda th: th + 1.0, 0.0, niter=10)
+        assert e.value.status == _lib.ERR_NO_DEVICE
 
 
 def test_c_abi_metropolis_validate(kmc):
@@ -134,6 +144,11 @@ def test_c_abi_metropolis_validate(kmc):
     assert L.kmc_metropolis_validate(C.byref(cfg(nthin=0))) == _lib.ERR_BAD_ARG
     assert L.kmc_metropolis_validate(C.byref(cfg(step=None))) == _lib.ERR_BAD_ARG
     assert L.kmc_metropolis_validate(C.byref(cfg(density=_lib.ROSENBROCK, ndim=1))) == _lib.ERR_BAD_ARG
-    assert L.kmc_metropolis_validate(C.byref(cfg(density=_lib.HOST_DENSITY))) == _lib.ERR_UNSUPPORTED
+    assert L.kmc_metropolis_validate(C.byref(cfg(density=_lib.HOST_DENSITY))) == _lib.ERR_BAD_ARG       # no host_logpdf given
+    cb = _lib.HOST_LOGPDF_FN(lambda rows, n, nd, out, user: 0)
+    assert L.kmc_metropolis_validate(C.byref(cfg(density=_lib.HOST_DENSITY, host_logpdf=C.cast(cb, C.c_void_p)))) == _lib.OK
+    assert L.kmc_metropolis_validate(C.byref(cfg(host_logpdf=C.cast(cb, C.c_void_p)))) == _lib.ERR_BAD_ARG   # needs KMC_HOST_DENSITY
+    pb = _lib.HOST_PROPOSE_FN(lambda rows, n, nd, out, user: 0)
+    assert L.kmc_metropolis_validate(C.byref(cfg(step=None, host_propose=C.cast(pb, C.c_void_p)))) == _lib.OK
     assert L.kmc_metropolis_validate(C.byref(cfg(flags=_lib.P2P))) == _lib.ERR_BAD_ARG
     assert L.kmc_metropolis_validate(None) == _lib.ERR_BAD_ARG
