@@ -358,25 +358,39 @@ def main():
                 mode = "p2p"
         lazy_stats = (0, 0)
         if mode == "p2p":
-            drv.set_positions(th)
-            drv.run(args.warmup * GENS_PER_STEP)
-            drv.sync()
-            drv.set_positions(th)                # barriers inside; restart the job
-            dist.barrier()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            drv.run(G)
-            drv.sync()
-            torch.cuda.synchronize()
-            dist.barrier()
-            elapsed = time.perf_counter() - t0
-            event_ms = drv.sampler.last_run_ms()
-            launches = drv.sampler.launch_count
-            msum, msq, nmom = drv.moments()
-            fpos, facc = drv.positions(), drv.naccept()
-            acc = float(facc.sum() / nw / max(1, G - nburn))
-            lazy_stats = drv.sampler.p2p_stats()         # (remote partner draws, pulled) on this rank; (0, 0) unless lazy ran
-            drv.close()
+            ok = True
+            try:
+                drv.set_positions(th)
+                drv.run(args.warmup * GENS_PER_STEP)
+                drv.sync()
+                drv.set_positions(th)                # barriers inside; restart the job
+                dist.barrier()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                drv.run(G)
+                drv.sync()
+                torch.cuda.synchronize()
+                dist.barrier()
+                elapsed = time.perf_counter() - t0
+                event_ms = drv.sampler.last_run_ms()
+                launches = drv.sampler.launch_count
+                msum, msq, nmom = drv.moments()
+                fpos, facc = drv.positions(), drv.naccept()
+                acc = float(facc.sum() / nw / max(1, G - nburn))
+                lazy_stats = drv.sampler.p2p_stats()         # (remote partner draws, pulled) on this rank; (0, 0) unless lazy ran
+                drv.close()
+            except Exception as e:  # noqa: BLE001  (e.g. a peer wait that timed out: every rank then takes the fallback)
+                print(f"[rank {rank}] the p2p run failed ({e})", file=sys.stderr)
+                ok = False
+                try:
+                    drv.sampler.close()
+                except Exception:  # noqa: BLE001
+                    pass
+            if not all_ok(ok):
+                if rank == 0:
+                    print("[rank 0] falling back to the RCCL all-gather exchange", file=sys.stderr)
+                mode = "allgather"
+        if mode == "p2p":
             # the timed run itself, against the unsharded run of the whole job on one GPU (rank 0)
             if rank == 0:
                 rpos, racc, (rs, rq, rn) = unsharded(G)

@@ -26,6 +26,14 @@ def _fresh_seed() -> int:
     return int(np.random.SeedSequence().generate_state(2, dtype=np.uint32).astype(np.uint64) @ np.array([1, 1 << 32], dtype=np.uint64))
 
 
+def _free_device_bytes(device: int) -> float:
+    try:
+        import torch
+        return float(torch.cuda.mem_get_info(device)[0])
+    except Exception:  # noqa: BLE001
+        return float(200 << 30)
+
+
 def emcee_counts(niter: int, nwalkers: int, nburnin=None, nthin: int = 1):
     """The reference's integer bookkeeping: ``niter``/``nburnin`` count log-pdf evaluations over
     all walkers (``src/samplers.jl:159``); per-walker counts are the floor divisions of
@@ -52,7 +60,8 @@ def emcee(pdf, theta0s, niter: int = 10 ** 5, nburnin=None, nthin: int = 1, a_sc
     ``stream_chain``: ``True`` streams the stored samples to host memory block by block while sampling (the device
     keeps a small ring; the chain is bounded by host RAM instead of HBM, like the reference's growing vectors,
     ``:268-272``), ``False`` keeps the whole chain on the device until the end, ``None`` (default) streams when the
-    chain would take more than 16 GiB.
+    chain would not fit the device (more than 70 % of its free memory; page-locking the host arrays costs about as much
+    as downloading a chain that does fit).
 
     ``hasblob=True`` (``:150-151, :194-196``): ``pdf`` is a host callable returning ``(p, blob)``; the blobs
     stay on the host and follow the device's accept decisions.  ``blobs[w] = init_blobs(blob0s[w],
@@ -95,7 +104,7 @@ def emcee(pdf, theta0s, niter: int = 10 ** 5, nburnin=None, nthin: int = 1, a_sc
         seed = _fresh_seed()
 
     if stream_chain is None:
-        stream_chain = dtype == "f64" and nsamples_walker * nwalkers * (ndim + 1) * 8 > (16 << 30)
+        stream_chain = dtype == "f64" and nsamples_walker * nwalkers * (ndim + 1 + ndim % 2) * 8 > 0.7 * _free_device_bytes(device)
     with Sampler(pdf, nwalkers, ndim, niter_walker, nburnin_walker, nthin, a_scale, seed,
                  store_chain=True, store_logp=True, device=device, dtype=dtype, stream_chain=bool(stream_chain)) as s:
         try:

@@ -297,9 +297,10 @@ class DealtEmcee:
     memory (``gloo``: CPU tests, several ranks sharing one GPU) the exchange is staged through the host.
     """
 
-    def __init__(self, executor, nwalkers_total: int, ndim: int, epoch_gens: int, group=None):
+    def __init__(self, executor, nwalkers_total: int, ndim: int, epoch_gens: int, group=None, always_collective: bool = False):
         self.ex = executor
         self.group = group
+        self.always_collective = bool(always_collective)   # world size 1: still go through all_to_all_single (tests of the RCCL path)
         self.rank = dist.get_rank(group) if dist is not None and dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist is not None and dist.is_initialized() else 1
         self.nwalkers, self.ndim, self.epoch_gens = int(nwalkers_total), int(ndim), int(epoch_gens)
@@ -328,7 +329,7 @@ class DealtEmcee:
 
     def _deal_on_current_stream(self, epoch: int):
         send = self.ex.pack(epoch)
-        if self.world == 1:
+        if self.world == 1 and not (self.always_collective and dist is not None and dist.is_initialized()):
             self.ex.unpack(send)                         # the shuffle alone
         else:
             backend = dist.get_backend(self.group)

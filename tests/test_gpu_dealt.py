@@ -166,3 +166,34 @@ def test_two_processes_sharing_the_gpu_equal_the_oracle(oracle, tmp_path):
         z = dict(np.load(os.path.join(str(tmp_path), f"r{r}.npz")))
         z["n"] = int(z["n"])
         _check(z, ref)
+
+
+def test_dealt_driver_world1_through_rccl(kmc, oracle):
+    """World size 1 on the nccl (= RCCL) backend with the collective forced: all_to_all_single on the device buffers,
+    issued inside the executor's stream -- the call sequence of a multi-GPU run with its stream ordering."""
+    import torch
+    import torch.distributed as dist
+    from kissmcmc_jl_amd.distributed import DealtEmcee, HipDealExecutor
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    created = False
+    if not dist.is_initialized():
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1)
+        created = True
+    try:
+        nw, nd, G, nburn, E, seed = 4096, 32, 200, 40, 64, 3
+        th = np.random.default_rng(6).standard_normal((nw, nd))
+        ex = HipDealExecutor(kmc.GaussianIso(), nw, nd, G, nburn, 1, 2.0, seed, rank=0, world=1, device=0)
+        drv = DealtEmcee(ex, nw, nd, E, always_collective=True)
+        drv.set_positions(th)
+        drv.run(G)
+        drv.sync()
+        res = drv.results()
+        assert drv.deals == G // E
+        drv.close()
+        ref = oracle.emcee_dealt(oracle.make_config(oracle.GAUSSIAN_ISO, [0.0, 1.0], nw, nd, G, nburn, 1, 2.0, seed, nthreads=8), 1, E, th)
+        _check(res, ref)
+    finally:
+        if created:
+            dist.destroy_process_group()
