@@ -131,3 +131,32 @@ def test_c4_shape_eight_logical_shards_equal_unsharded(kmc):
     np.testing.assert_allclose(sum(s.moments()[0] for s in shards), ref["sum"], rtol=1e-11, atol=1e-8)
     for s in shards:
         s.close()
+
+
+def test_c4_size_dealt_sub_ensembles_sample_the_target(kmc):
+    """The C4 ensemble (8 x 65 536 walkers x 32-dim Gaussian) as dealt sub-ensembles -- 8 logical sub-ensembles on this one GPU,
+    re-dealt every 64 generations (the opt-in multi-GPU mode without a per-half-step exchange; bit-identity with the oracle at
+    smaller sizes: test_gpu_dealt.py).  Started at stationarity: acceptance 0.234 and posterior moments within 1 %, and walkers
+    do travel between sub-ensembles."""
+    from kissmcmc_jl_amd.distributed import HipDealExecutor, LocalDealtEmcee
+    P, S, nd, G, nburn, E = 8, 65536, 32, 1200, 200, 64
+    th = np.random.default_rng(9).standard_normal((P * S, nd))
+    exs = [HipDealExecutor(kmc.GaussianIso(), S, nd, G, nburn, 1, 2.0, 2024, rank=r, world=P, device=0) for r in range(P)]
+    drv = LocalDealtEmcee(exs, P * S, nd, E)
+    try:
+        drv.set_positions(th)
+        drv.run(G)
+        drv.sync()
+        ids0 = exs[0].sampler.walker_ids()
+        res = drv.results()
+    finally:
+        drv.close()
+    assert res["n"] == P * S * (G - nburn)
+    mean = res["sum"] / res["n"]
+    var = res["sumsq"] / res["n"] - mean ** 2
+    assert np.abs(mean).max() < 0.01 and np.abs(var - 1.0).max() < 0.01
+    acc = res["naccept"] / (G - nburn)
+    assert abs(acc.mean() - 0.234) < 0.00234 * 2 and acc.std() < 0.03
+    origin = np.bincount(ids0 // S, minlength=P)                     # where sub-ensemble 0's walkers started
+    assert origin.min() > S // P // 2                                # about S / P from each of the 8
+    assert np.all(np.isfinite(res["positions"])) and len(np.unique(res["positions"][:, 0])) > 0.99 * P * S
