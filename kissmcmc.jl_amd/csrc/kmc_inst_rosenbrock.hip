@@ -12,3 +12,10 @@ ResidentFn resident_rosenbrock(int tpb, int K, bool ragged) { return resident_lo
 InitBallFn init_ball_rosenbrock() { return init_ball<Rosenbrock>; }
 MetropolisFn metropolis_rosenbrock(int ndim) { return metropolis_lookup<Rosenbrock>(ndim); }
 }  // namespace kmc
+
+#ifdef KMC_PROBE   // diagnostic build only (scripts/probe_timeline.py C3): this translation unit's copy of the stamps
+extern "C" __attribute__((visibility("default"))) int kmc_probe_read_rosenbrock(void* out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(kmc::g_probe), sizeof(kmc::g_probe));
+}
+#endif

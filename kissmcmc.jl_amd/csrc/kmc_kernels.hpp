@@ -418,8 +418,22 @@ __device__ __forceinline__ double2 load_row_sys(const double2* p)
 }
 
 #ifdef KMC_PROBE   // diagnostic build only: per-wave 100 MHz timestamps of the last launch of each half
-static __device__ unsigned long long g_probe[2][8192][4];
-#define KMC_STAMP(i) do { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); stamp[i] = t_; } while (0)
+// Eight stamps per wave WITHOUT any wait at the stamp: s_memrealtime writes its result asynchronously into a fixed SGPR
+// pair above everything the kernels allocate (the C2 kernel uses 64 SGPRs; the clobber makes the pair part of the
+// kernel's allocation), and all eight are collected after one s_waitcnt at the very end -- a stamp that waited
+// (lgkmcnt(0)) would also wait for the argument struct's scalar loads and move the very thing it measures.
+static __device__ unsigned long long g_probe[2][8192][8];
+#define KMC_STAMP_AT(lo, hi) asm volatile("s_memrealtime s[" #lo ":" #hi "]" ::: "s" #lo, "s" #hi, "memory")
+#define KMC_STAMP(i) KMC_STAMP_##i
+#define KMC_STAMP_0 KMC_STAMP_AT(80, 81)
+#define KMC_STAMP_1 KMC_STAMP_AT(82, 83)
+#define KMC_STAMP_2 KMC_STAMP_AT(84, 85)
+#define KMC_STAMP_3 KMC_STAMP_AT(86, 87)
+#define KMC_STAMP_4 KMC_STAMP_AT(88, 89)
+#define KMC_STAMP_5 KMC_STAMP_AT(90, 91)
+#define KMC_STAMP_6 KMC_STAMP_AT(92, 93)
+#define KMC_STAMP_7 KMC_STAMP_AT(94, 95)
+#define KMC_STAMP_READ(dst, lo, hi) asm volatile("s_mov_b64 %0, s[" #lo ":" #hi "]" : "=s"(dst))
 #else
 #define KMC_STAMP(i) do { } while (0)
 #endif
@@ -451,10 +465,7 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
 #pragma unroll
     for (int k = 0; k < K; ++k) cv[k] = !RAGGED || 2 * (k * L + j) < (int)ld;
     const double2 zero2 = make_double2(0.0, 0.0);
-#ifdef KMC_PROBE
-    unsigned long long stamp[4];
-#endif
-    KMC_STAMP(0);
+    KMC_STAMP(0);                                       // wave entry
 
     // ---- scalar layout: one walker per lane.  Lane (g, j) carries walker slot js = j % ITER of its group and,
     //      when draws are computed, the walker's q-th next step, q = j / ITER < Q; the lanes with q == 0
@@ -519,6 +530,10 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
         bits = draw_bits(dcf, step + 2ull * (uint64_t)jq, (uint64_t)f.gw0 + (uint64_t)iAc);   // RNG keyed by the GLOBAL walker index
         partnerA = draw_partner(dcf, bits);
     }
+#ifdef KMC_PROBE
+    asm volatile("" :: "v"(partnerA));
+#endif
+    KMC_STAMP(1);                                       // Philox done: the partner index is known
 
     // ---- scalar -> row: the partner of slot it*G+g lives in lane gbase+it.  The partner-row loads of the first
     //      half of the iterations go out, then the first logarithm, then the other half, then the second
@@ -632,6 +647,7 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
         for (int it = 0; it < kFirst; ++it) load_partner_rows(it);
     }
     __builtin_amdgcn_sched_barrier(0);
+    KMC_STAMP(2);                                       // the first partner-row loads are issued
 
     // ---- from here on the argument struct: one scalar round trip for all of it (have every field the kernel
     //      uses later requested by now, otherwise the compiler fetches some lazily: a round trip each) ----------
@@ -679,7 +695,10 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
     if constexpr (kMomRing) {
         if (do_mom && a.mring != nullptr) { ring_posted = a.mcnt[tid >> 6]; ring_swept = a.mswept[tid >> 6]; }
     }
-    KMC_STAMP(1);
+#ifdef KMC_PROBE
+    asm volatile("" :: "s"(count ? 1 : 0), "s"(a.dc.c0));
+#endif
+    KMC_STAMP(3);                                       // the argument struct has arrived (schedule entry, constants)
     Draw dr;
     dr.partner = partnerA; dr.z = e1.x; dr.t1 = e0.x; dr.lu = e0.y;
     double ua = 0.5;
@@ -707,6 +726,10 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
             }
         }
     }
+#ifdef KMC_PROBE
+    asm volatile("" :: "v"(dr.lu), "v"(dr.t1));
+#endif
+    KMC_STAMP(4);                                       // both logarithms done, every partner-row load issued
     double zB[ITER];
 #pragma unroll
     for (int it = 0; it < ITER; ++it) zB[it] = bperm_f64((gbase + it) * 4, dr.z);
@@ -737,7 +760,10 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
         myp1 = (j == it) ? p1 : myp1;                                   // row -> scalar, no traffic
     }
 
-    KMC_STAMP(2);
+#ifdef KMC_PROBE
+    asm volatile("" :: "v"(myp1));
+#endif
+    KMC_STAMP(5);                                       // both rows have arrived, the proposal's log-pdf is reduced
     // ---- accept test in the scalar layout ---------------------------------------------------
     const bool acc = validA && accept_test(dr, myp1, p0);               // :260
     const unsigned long long accmask = __ballot(acc);
@@ -761,6 +787,7 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
     if (sample && a.chain_logp != nullptr && validA)                    // :271
         store_wt(&a.chain_logp[sch.slot * a.chain_rows + a.chain_row0 + iA], acc ? myp1 : p0);
 
+    KMC_STAMP(6);                                       // accept test done, per-walker scalars stored
     // ---- row layout again: store accepted proposals, samples, moments -----------------------
     double2 ms[K], mq[K];
 #pragma unroll
@@ -851,9 +878,15 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
             }
         }
     }
-    KMC_STAMP(3);
+    KMC_STAMP(7);                                       // the last store is issued
 #ifdef KMC_PROBE
-    if (lane == 0 && (tid >> 6) < 8192) for (int q = 0; q < 4; ++q) g_probe[half][tid >> 6][q] = stamp[q];
+    {
+        unsigned long long st[8];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        KMC_STAMP_READ(st[0], 80, 81); KMC_STAMP_READ(st[1], 82, 83); KMC_STAMP_READ(st[2], 84, 85); KMC_STAMP_READ(st[3], 86, 87);
+        KMC_STAMP_READ(st[4], 88, 89); KMC_STAMP_READ(st[5], 90, 91); KMC_STAMP_READ(st[6], 92, 93); KMC_STAMP_READ(st[7], 94, 95);
+        if (lane == 0 && (tid >> 6) < 8192) for (int q = 0; q < 8; ++q) g_probe[half][tid >> 6][q] = st[q];
+    }
 #endif
 }
 

@@ -1,6 +1,7 @@
 """Where does a half-step's time go?  Diagnostic build (-DKMC_PROBE) of the library: every wave of the
-vector kernel stamps the 100 MHz real-time counter at entry (0), once its partner index is known (1),
-once the proposal's log-pdf is reduced = both rows have arrived (2) and after its last store is issued (3).
+vector kernel stamps the 100 MHz real-time counter eight times (entry, Philox done, first partner loads issued, argument
+struct arrived, logarithms done, rows arrived + log-pdf reduced, accept + scalar stores, last store issued) without waiting
+at the stamps (kmc_kernels.hpp, KMC_STAMP).
 Prints the timeline of the last generation's two launches.
 Usage (GPU box): python scripts/probe_timeline.py [C2|C3|C5]   (builds libkmc_var_probe.so on first use)"""
 import ctypes
@@ -24,6 +25,10 @@ CONFIGS = {"C2": (kmc.GaussianIso(), 65536, 32), "C3": (kmc.Rosenbrock(), 16384,
            "C4s": (kmc.GaussianIso(), 524288, 32), "S8k": (kmc.GaussianIso(), 8192, 32)}    # S8k: one wave per CU
 
 
+STAMPS = ["entry", "philox done", "1st partner loads issued", "arg struct arrived", "logs done, all loads issued", "rows arrived + log-pdf",
+          "accept + scalar stores", "last store issued"]
+
+
 def main():
     name = sys.argv[1] if len(sys.argv) > 1 else "C2"
     pdf, nw, nd = CONFIGS[name]
@@ -34,26 +39,28 @@ def main():
         s.set_positions(th)
         s.run(1024)
         s.sync()
+        s.run(1024)
+        s.sync()
         ms = s.last_run_ms()
-        buf = np.zeros((2, 8192, 4), dtype=np.uint64)
-        rc = L.kmc_probe_read(buf.ctypes.data_as(ctypes.c_void_p))
+        buf = np.zeros((2, 8192, 8), dtype=np.uint64)
+        rc = (L.kmc_probe_read_rosenbrock if name == 'C3' else L.kmc_probe_read)(buf.ctypes.data_as(ctypes.c_void_p))
         assert rc == 0
-        print(f"== {name} moments={int(mom)}: {s.describe()}  {ms / 2048 * 1e3:.2f} us per half-step launch")
+        print(f"== {name} moments={int(mom)} KMC_LAUNCH={os.environ.get('KMC_LAUNCH', 'auto')}: {s.describe()}  {ms / 2048 * 1e3:.2f} us per half-step launch")
         nwave = int((buf[0, :, 0] != 0).sum())
         t = buf[:, :nwave, :].astype(np.int64)
         base = t[0, :, 0].min()
-        t = (t - base) * 10.0 / 1000.0            # us since the first wave of half 0 started
+        t = (t - base) * 10.0 / 1000.0            # us since the first wave of half 0 started (100 MHz counter)
         for half in (0, 1):
             a = t[half]
-            print(f" half {half}: {nwave} waves; entry min/med/max {a[:, 0].min():.2f}/{np.median(a[:, 0]):.2f}/{a[:, 0].max():.2f}  "
-                  f"partner-known med {np.median(a[:, 1]):.2f}  rows+logpdf med {np.median(a[:, 2]):.2f} max {a[:, 2].max():.2f}  "
-                  f"end med {np.median(a[:, 3]):.2f} max {a[:, 3].max():.2f}")
+            print(f" half {half}: {nwave} waves; absolute times (min / median / max over waves):")
+            for q, label in enumerate(STAMPS):
+                print(f"    {q} {label:30s} {a[:, q].min():6.2f} {np.median(a[:, q]):6.2f} {a[:, q].max():6.2f}")
             d = np.diff(a, axis=1)
-            print(f"         per wave: entry->partner {np.median(d[:, 0]):.2f} (p90 {np.percentile(d[:, 0], 90):.2f}), "
-                  f"partner->logpdf {np.median(d[:, 1]):.2f} (p90 {np.percentile(d[:, 1], 90):.2f}), "
-                  f"logpdf->end {np.median(d[:, 2]):.2f} (p90 {np.percentile(d[:, 2], 90):.2f})")
-        print(f" boundary: last wave of half 0 ends {t[0, :, 3].max():.2f}, first wave of half 1 enters {t[1, :, 0].min():.2f} "
-              f"-> gap {t[1, :, 0].min() - t[0, :, 3].max():.2f} us; launch period {t[1, :, 0].min() - t[0, :, 0].min():.2f} us")
+            print("    per wave, stage durations median (p10 .. p90): " +
+                  "; ".join(f"{q}->{q + 1} {np.median(d[:, q]):.2f} ({np.percentile(d[:, q], 10):.2f}..{np.percentile(d[:, q], 90):.2f})" for q in range(7)))
+            print(f"    wave duration median {np.median(a[:, 7] - a[:, 0]):.2f} (p90 {np.percentile(a[:, 7] - a[:, 0], 90):.2f})")
+        print(f" boundary: last wave of half 0 ends {t[0, :, 7].max():.2f}, first wave of half 1 enters {t[1, :, 0].min():.2f} "
+              f"-> gap {t[1, :, 0].min() - t[0, :, 7].max():.2f} us; launch period {t[1, :, 0].min() - t[0, :, 0].min():.2f} us")
         s.close()
 
 
