@@ -1,0 +1,74 @@
+// kmc_host.hpp -- what the host-side translation units of the library share (kmc_api.hip: samplers;
+// kmc_metropolis_api.hip: many-chain Metropolis; kmc_acorr.hip: autocorrelation diagnostics).  Internal.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
+
+#include <cstdint>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/kissmcmc_hip.h"
+#include "kmc_tables.hpp"
+
+#define KMC_EXPORT extern "C" __attribute__((visibility("default")))
+
+namespace kmc_host {
+
+// message of the last failure on the calling thread (kmc_last_error)
+extern thread_local std::string g_err;
+inline kmc_status fail(kmc_status st, const std::string& msg)
+{
+    g_err = msg;
+    return st;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            (void)hipGetLastError();                                                           \
+            return ::kmc_host::fail(e_ == hipErrorOutOfMemory ? KMC_ERR_OOM : KMC_ERR_HIP,     \
+                                    std::string(#expr) + ": " + hipGetErrorString(e_));        \
+        }                                                                                      \
+    } while (0)
+
+#define KMC_TRY(expr)                                                                          \
+    do {                                                                                       \
+        kmc_status s_ = (expr);                                                                \
+        if (s_ != KMC_OK) return s_;                                                           \
+    } while (0)
+
+// kernel tables of the menu densities (kmc_inst_*.hip) and the digest of kmc_config.params the kernels take
+bool lookup(int density, int L, int K, int iter, bool p2p, bool ragged, bool f32, kmc::HalfStepFn* vec, kmc::HalfStepFn* gen, kmc::LogpdfFn* lp);
+kmc_status digest_params(const kmc_config& c, kmc::DensityParams* dp);
+
+// runtime-compiled user densities (hiprtc)
+std::string user_functor_source(const kmc_user_density* ud);
+std::string user_header_dir();                      // where the kernel headers live (KMC_CSRC_DIR or <library dir>/csrc)
+std::string read_file(const std::string& path);
+
+template <class Args>
+hipError_t launch_module(hipFunction_t f, unsigned grid, unsigned tpb, hipStream_t st, const Args& args, unsigned lds_bytes = 0)
+{
+    Args copy = args;
+    size_t size = sizeof(Args);
+    void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &copy, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+    return hipModuleLaunchKernel(f, grid, 1, 1, tpb, 1, 1, lds_bytes, st, nullptr, extra);
+}
+
+// integrated autocorrelation time of a device-resident chain [nsamples][nwalkers][ndim] (kmc_acorr.hip)
+kmc_status int_acorr_check(int64_t nsamples, int64_t nwalkers, int64_t ndim, double c, const double* tau, const double* converged);
+kmc_status int_acorr_device(const double* chain_dev, int64_t nsamples, int64_t nwalkers, int64_t ndim, double c, double* tau, double* converged);
+
+}  // namespace kmc_host
+
+// The opaque handle of kmc_user_density_create: the two expressions and the code objects compiled from them so far.
+struct kmc_user_density {
+    std::string term, pair;
+    bool has_pair = false;
+    std::mutex mu;
+    std::map<std::string, std::vector<char>> code;   // geometry key -> gfx950 code object
+};

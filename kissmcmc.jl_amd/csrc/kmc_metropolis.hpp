@@ -260,7 +260,7 @@ struct MetroHostArgs {
     uint32_t       seed_lo, seed_hi;
 };
 
-#ifdef KMC_DEFINE_DRIVER_KERNELS
+#ifdef KMC_DEFINE_METROPOLIS_KERNELS   // non-template kernels: defined once, in kmc_metropolis_api.hip
 __global__ __launch_bounds__(256) void metro_host_propose(const MetroHostArgs a)
 {
     const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;

@@ -1,0 +1,429 @@
+// kmc_metropolis_api.hip -- host side of the many-chain Metropolis entry points of include/kissmcmc_hip.h
+// (kmc_metropolis_validate / kmc_metropolis_run; kernels: kmc_metropolis.hpp).
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <sstream>
+
+#define KMC_DEFINE_METROPOLIS_KERNELS
+#include "kmc_host.hpp"
+
+using namespace kmc;
+using namespace kmc_host;
+
+// ------------------------------------------------------------------------------------------
+// Many-chain Metropolis: metropolis / _metropolis, reference src/samplers.jl:59-128.
+// ------------------------------------------------------------------------------------------
+namespace {
+
+MetropolisFn metropolis_fn(int density, int ndim)
+{
+    switch (density) {
+    case KMC_GAUSSIAN_ISO: return metropolis_gaussian_iso(ndim);
+    case KMC_EXPONENTIAL: return metropolis_exponential(ndim);
+    case KMC_ROSENBROCK: return metropolis_rosenbrock(ndim);
+    case KMC_LOGNORMAL: return metropolis_lognormal(ndim);
+    case KMC_MVNORMAL2: return metropolis_mvnormal2(ndim);
+    default: return nullptr;
+    }
+}
+
+int metropolis_nd(int64_t ndim) { return ndim <= 1 ? 1 : ndim <= 2 ? 2 : ndim <= 4 ? 4 : ndim <= 8 ? 8 : ndim <= 16 ? 16 : ndim <= 32 ? 32 : 0; }
+
+// runtime-compiled density: the Metropolis kernel (and the initial log-pdf kernel) for one register geometry
+kmc_status compile_user_metropolis(kmc_user_density* ud, int ND, const std::vector<char>** out)
+{
+    char key[32];
+    std::snprintf(key, sizeof(key), "M:%d", ND);
+    std::lock_guard<std::mutex> lock(ud->mu);
+    auto it = ud->code.find(key);
+    if (it != ud->code.end()) { *out = &it->second; return KMC_OK; }
+    const std::string dir = user_header_dir();
+    const std::string h_dev = read_file(dir + "/kmc_device.hpp"), h_ker = read_file(dir + "/kmc_kernels.hpp"),
+                      h_met = read_file(dir + "/kmc_metropolis.hpp");
+    if (h_dev.empty() || h_ker.empty() || h_met.empty())
+        return fail(KMC_ERR_BAD_ARG, "user density: kernel headers not found in " + dir + " (set KMC_CSRC_DIR)");
+    std::ostringstream src;
+    src << "#include \"kmc_kernels.hpp\"\n#include \"kmc_metropolis.hpp\"\n" << user_functor_source(ud)
+        << "using UD = kmc::TermPairDensity<UserF>;\n"
+        << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_logpdf(const kmc::LogpdfArgs a) { kmc::logpdf_rows_body<UD>(a); }\n"
+        << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_metropolis(const kmc::MetropolisArgs a) { ";
+    if (ND > 0) src << "kmc::metropolis_chains_body<UD, " << ND << ">(a); }\n";
+    else src << "kmc::metropolis_chains_any_body<UD>(a); }\n";
+    const std::string text = src.str();
+    hiprtcProgram prog = nullptr;
+    const char* headers[3] = {h_ker.c_str(), h_dev.c_str(), h_met.c_str()};
+    const char* names[3] = {"kmc_kernels.hpp", "kmc_device.hpp", "kmc_metropolis.hpp"};
+    if (hiprtcCreateProgram(&prog, text.c_str(), "kmc_user_metropolis.hip", 3, headers, names) != HIPRTC_SUCCESS)
+        return fail(KMC_ERR_HIP, "hiprtcCreateProgram failed");
+    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"};
+    const hiprtcResult r = hiprtcCompileProgram(prog, 4, opts);
+    if (r != HIPRTC_SUCCESS) {
+        size_t n = 0;
+        hiprtcGetProgramLogSize(prog, &n);
+        std::string log(n, '\0');
+        if (n) hiprtcGetProgramLog(prog, &log[0]);
+        hiprtcDestroyProgram(&prog);
+        return fail(KMC_ERR_BAD_ARG, "user density does not compile:\n" + log);
+    }
+    size_t n = 0;
+    hiprtcGetCodeSize(prog, &n);
+    std::vector<char> code(n);
+    hiprtcGetCode(prog, code.data());
+    hiprtcDestroyProgram(&prog);
+    auto ins = ud->code.emplace(key, std::move(code));
+    *out = &ins.first->second;
+    return KMC_OK;
+}
+
+// device buffers of one kmc_metropolis_run call
+struct MetroBuffers {
+    double *pos = nullptr, *logp = nullptr, *chain = nullptr, *chain_logp = nullptr, *csum = nullptr, *csumsq = nullptr,
+           *step = nullptr, *xt = nullptr, *yt = nullptr, *st1 = nullptr, *st2 = nullptr;
+    uint32_t* naccept = nullptr;
+    hipModule_t mod = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    ~MetroBuffers()
+    {
+        (void)hipFree(pos); (void)hipFree(logp); (void)hipFree(chain); (void)hipFree(chain_logp); (void)hipFree(csum);
+        (void)hipFree(csumsq); (void)hipFree(step); (void)hipFree(xt); (void)hipFree(yt); (void)hipFree(st1); (void)hipFree(st2);
+        (void)hipFree(naccept);
+        if (mod) (void)hipModuleUnload(mod);
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+    }
+};
+
+}  // namespace
+
+namespace {
+
+// The host route of kmc_metropolis_run: `pdf` and / or `sample_ppdf` are caller's closures (src/samplers.jl:59-61).  One
+// iteration of all chains per pass: proposals (device Gaussian step, or host_propose on the current states), their
+// log-pdfs (host_logpdf on the proposals, or the device density), then the accept test, counters and storage on the device.
+kmc_status metropolis_host_route(const kmc_metropolis_config* c, const double* theta0, kmc_metropolis_outputs* out,
+                                 const DensityParams& dp, int64_t nsamples)
+{
+    const int64_t nc = c->nchains, nd = c->ndim;
+    const size_t rows = (size_t)nc * (size_t)nd * sizeof(double), vec = (size_t)nc * sizeof(double);
+    const bool host_pdf = c->density == KMC_HOST_DENSITY;
+    const bool want_chain = (c->flags & KMC_STORE_CHAIN) != 0, want_logp = (c->flags & KMC_STORE_LOGP) != 0, want_mom = (c->flags & KMC_MOMENTS) != 0;
+    struct Buf {
+        double *pos = nullptr, *logp = nullptr, *prop = nullptr, *p1 = nullptr, *chain = nullptr, *chain_logp = nullptr, *csum = nullptr,
+               *csumsq = nullptr, *step = nullptr, *h_rows = nullptr, *h_prop = nullptr, *h_p1 = nullptr;
+        uint32_t* naccept = nullptr;
+        unsigned char *acc = nullptr, *h_acc = nullptr;
+        hipModule_t mod = nullptr;
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        ~Buf()
+        {
+            (void)hipFree(pos); (void)hipFree(logp); (void)hipFree(prop); (void)hipFree(p1); (void)hipFree(chain); (void)hipFree(chain_logp);
+            (void)hipFree(csum); (void)hipFree(csumsq); (void)hipFree(step); (void)hipFree(naccept); (void)hipFree(acc);
+            if (h_rows) (void)hipHostFree(h_rows);
+            if (h_prop) (void)hipHostFree(h_prop);
+            if (h_p1) (void)hipHostFree(h_p1);
+            if (h_acc) (void)hipHostFree(h_acc);
+            if (mod) (void)hipModuleUnload(mod);
+            if (ev0) (void)hipEventDestroy(ev0);
+            if (ev1) (void)hipEventDestroy(ev1);
+        }
+    } b;
+    HIP_TRY(hipMalloc(&b.pos, rows));
+    HIP_TRY(hipMalloc(&b.prop, rows));
+    HIP_TRY(hipMalloc(&b.logp, vec));
+    HIP_TRY(hipMalloc(&b.p1, vec));
+    HIP_TRY(hipMalloc(&b.naccept, (size_t)nc * sizeof(uint32_t)));
+    HIP_TRY(hipMemset(b.naccept, 0, (size_t)nc * sizeof(uint32_t)));
+    HIP_TRY(hipMemcpy(b.pos, theta0, rows, hipMemcpyHostToDevice));                              // :68 deepcopy
+    if (c->step) {
+        HIP_TRY(hipMalloc(&b.step, (size_t)nd * sizeof(double)));
+        HIP_TRY(hipMemcpy(b.step, c->step, (size_t)nd * sizeof(double), hipMemcpyHostToDevice));
+    }
+    if (want_chain && nsamples > 0) HIP_TRY(hipMalloc(&b.chain, (size_t)nsamples * rows));
+    if (want_logp && nsamples > 0) HIP_TRY(hipMalloc(&b.chain_logp, (size_t)nsamples * vec));
+    if (want_mom) {
+        HIP_TRY(hipMalloc(&b.csum, rows));
+        HIP_TRY(hipMalloc(&b.csumsq, rows));
+        HIP_TRY(hipMemset(b.csum, 0, rows));
+        HIP_TRY(hipMemset(b.csumsq, 0, rows));
+    }
+    HIP_TRY(hipHostMalloc((void**)&b.h_rows, rows, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void**)&b.h_prop, rows, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void**)&b.h_p1, vec, hipHostMallocDefault));
+    if (c->host_accepted) {
+        HIP_TRY(hipMalloc((void**)&b.acc, (size_t)nc));
+        HIP_TRY(hipHostMalloc((void**)&b.h_acc, (size_t)nc, hipHostMallocDefault));
+    }
+    // log-pdf of device rows -> device vector, for a device density
+    LogpdfFn lp = nullptr;
+    hipFunction_t ulp = nullptr;
+    if (!host_pdf) {
+        if (c->density == KMC_USER_DENSITY) {
+            const std::vector<char>* code = nullptr;
+            KMC_TRY(compile_user_metropolis(static_cast<kmc_user_density*>(c->user_density), metropolis_nd(nd), &code));
+            HIP_TRY(hipModuleLoadData(&b.mod, code->data()));
+            HIP_TRY(hipModuleGetFunction(&ulp, b.mod, "kmc_user_logpdf"));
+        } else {
+            HalfStepFn v, g;
+            if (!lookup(c->density, 0, 0, 1, false, false, false, &v, &g, &lp)) return fail(KMC_ERR_BAD_ARG, "unknown density id");
+        }
+    }
+    const unsigned grid = (unsigned)((nc + 255) / 256);
+    auto device_logpdf = [&](const double* rows_dev, double* out_dev) -> hipError_t {
+        const LogpdfArgs la{rows_dev, out_dev, nc, (int32_t)nd, (int32_t)nd, dp};
+        if (ulp) return launch_module(ulp, grid, 256u, nullptr, la);
+        hipLaunchKernelGGL(lp, dim3(grid), dim3(256), 0, nullptr, la);
+        return hipGetLastError();
+    };
+    // p0 = pdf(theta0) (:70); whatever comes out is carried, -Inf included, as in the reference
+    if (host_pdf) {
+        if (c->host_logpdf(theta0, nc, nd, b.h_p1, c->host_user) != 0) return fail(KMC_ERR_BAD_ARG, "the host log-pdf callback failed on the initial states");
+        HIP_TRY(hipMemcpy(b.logp, b.h_p1, vec, hipMemcpyHostToDevice));
+    } else {
+        HIP_TRY(device_logpdf(b.pos, b.logp));
+    }
+    HIP_TRY(hipEventCreate(&b.ev0));
+    HIP_TRY(hipEventCreate(&b.ev1));
+    HIP_TRY(hipEventRecord(b.ev0, nullptr));
+    int64_t cnt = 0, slot = 0;
+    for (int64_t it = 0; it < c->niter; ++it) {
+        const int64_t n = it + 1 - c->nburnin;                                                   // :96
+        MetroHostArgs a{};
+        a.pos = b.pos; a.logp = b.logp; a.naccept = b.naccept; a.prop = b.prop; a.p1 = b.p1;
+        a.chain = b.chain; a.chain_logp = b.chain_logp; a.csum = b.csum; a.csumsq = b.csumsq; a.step = b.step; a.acc_out = b.acc;
+        a.nchains = nc; a.it = it; a.n = n; a.ndim = (int32_t)nd;
+        a.seed_lo = (uint32_t)c->seed; a.seed_hi = (uint32_t)(c->seed >> 32);
+        if (n > 0 && ++cnt == c->nthin) {                                                        // :108, :112
+            cnt = 0;
+            if (slot < nsamples) { a.store = 1; a.slot = slot; }
+            ++slot;
+        }
+        if (c->host_propose) {                                                                   // :98 theta1 = sample_ppdf(theta0)
+            HIP_TRY(hipMemcpy(b.h_rows, b.pos, rows, hipMemcpyDeviceToHost));
+            if (c->host_propose(b.h_rows, nc, nd, b.h_prop, c->host_user) != 0)
+                return fail(KMC_ERR_BAD_ARG, "the host proposal callback failed in iteration " + std::to_string(it));
+            HIP_TRY(hipMemcpy(b.prop, b.h_prop, rows, hipMemcpyHostToDevice));
+        } else {
+            hipLaunchKernelGGL(metro_host_propose, dim3(grid), dim3(256), 0, nullptr, a);
+            HIP_TRY(hipGetLastError());
+        }
+        if (host_pdf) {                                                                          // :99 p1 = pdf(theta1)
+            if (!c->host_propose) HIP_TRY(hipMemcpy(b.h_prop, b.prop, rows, hipMemcpyDeviceToHost));
+            if (c->host_logpdf(b.h_prop, nc, nd, b.h_p1, c->host_user) != 0)
+                return fail(KMC_ERR_BAD_ARG, "the host log-pdf callback failed in iteration " + std::to_string(it));
+            HIP_TRY(hipMemcpy(b.p1, b.h_p1, vec, hipMemcpyHostToDevice));
+        } else {
+            HIP_TRY(device_logpdf(b.prop, b.p1));
+        }
+        hipLaunchKernelGGL(metro_host_accept, dim3(grid), dim3(256), 0, nullptr, a);
+        HIP_TRY(hipGetLastError());
+        if (c->host_accepted) {
+            HIP_TRY(hipMemcpy(b.h_acc, b.acc, (size_t)nc, hipMemcpyDeviceToHost));
+            if (c->host_accepted(b.h_acc, nc, 0, it, a.store, c->host_user) != 0)
+                return fail(KMC_ERR_BAD_ARG, "the host accept callback failed in iteration " + std::to_string(it));
+        }
+    }
+    HIP_TRY(hipEventRecord(b.ev1, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, b.ev0, b.ev1));
+    out->device_ms = (double)ms;
+    if (out->chain && b.chain) HIP_TRY(hipMemcpy(out->chain, b.chain, (size_t)nsamples * rows, hipMemcpyDeviceToHost));
+    if (out->chain_logp && b.chain_logp) HIP_TRY(hipMemcpy(out->chain_logp, b.chain_logp, (size_t)nsamples * vec, hipMemcpyDeviceToHost));
+    if (out->final_pos) HIP_TRY(hipMemcpy(out->final_pos, b.pos, rows, hipMemcpyDeviceToHost));
+    if (out->final_logp) HIP_TRY(hipMemcpy(out->final_logp, b.logp, vec, hipMemcpyDeviceToHost));
+    if (out->chain_sum && b.csum) HIP_TRY(hipMemcpy(out->chain_sum, b.csum, rows, hipMemcpyDeviceToHost));
+    if (out->chain_sumsq && b.csumsq) HIP_TRY(hipMemcpy(out->chain_sumsq, b.csumsq, rows, hipMemcpyDeviceToHost));
+    if (out->naccept || out->accept_ratio) {
+        std::vector<uint32_t> na((size_t)nc);
+        HIP_TRY(hipMemcpy(na.data(), b.naccept, (size_t)nc * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        const double denom = (double)(c->niter - c->nburnin);                                   // :127
+        for (int64_t i = 0; i < nc; ++i) {
+            if (out->naccept) out->naccept[i] = (int64_t)na[(size_t)i];
+            if (out->accept_ratio) out->accept_ratio[i] = (double)na[(size_t)i] / denom;
+        }
+    }
+    return KMC_OK;
+}
+
+}  // namespace
+
+KMC_EXPORT kmc_status kmc_metropolis_validate(const kmc_metropolis_config* c)
+{
+    if (!c) return fail(KMC_ERR_BAD_ARG, "null config");
+    if (c->dtype != KMC_F64) return fail(KMC_ERR_UNSUPPORTED, "only KMC_F64 is implemented");
+    if (c->nchains <= 0 || c->ndim <= 0 || c->nthin <= 0 || c->niter < 0 || c->nburnin < 0)
+        return fail(KMC_ERR_BAD_ARG, "nchains, ndim, nthin must be positive; niter, nburnin non-negative");
+    if (c->nchains > 0xffffffffll) return fail(KMC_ERR_BAD_ARG, "at most 2^32 - 1 chains (the chain index is one Philox counter word)");
+    if (!c->step && !c->host_propose) return fail(KMC_ERR_BAD_ARG, "step (proposal scale per dimension) is NULL and there is no host_propose");
+    for (int64_t d = 0; c->step && d < c->ndim; ++d)
+        if (!std::isfinite(c->step[d])) return fail(KMC_ERR_BAD_ARG, "step must be finite");
+    if (c->flags & ~(uint32_t)(KMC_STORE_CHAIN | KMC_STORE_LOGP | KMC_MOMENTS))
+        return fail(KMC_ERR_BAD_ARG, "metropolis flags: KMC_STORE_CHAIN | KMC_STORE_LOGP | KMC_MOMENTS");
+    if (c->density == KMC_HOST_DENSITY) {
+        if (!c->host_logpdf) return fail(KMC_ERR_BAD_ARG, "KMC_HOST_DENSITY needs kmc_metropolis_config.host_logpdf");
+        return KMC_OK;
+    }
+    if (c->host_logpdf) return fail(KMC_ERR_BAD_ARG, "host_logpdf needs density == KMC_HOST_DENSITY");
+    if (c->density == KMC_USER_DENSITY) {
+        if (!c->user_density) return fail(KMC_ERR_BAD_ARG, "KMC_USER_DENSITY needs kmc_metropolis_config.user_density");
+        return KMC_OK;
+    }
+    if (c->density == KMC_ROSENBROCK && c->ndim < 2) return fail(KMC_ERR_BAD_ARG, "rosenbrock needs ndim >= 2");
+    if (c->density == KMC_MVNORMAL2 && c->ndim != 2) return fail(KMC_ERR_BAD_ARG, "mvnormal2 needs ndim == 2");
+    kmc_config e{};
+    e.density = c->density;
+    for (int i = 0; i < 8; ++i) e.params[i] = c->params[i];
+    e.ndim = c->ndim;
+    DensityParams dp;
+    return digest_params(e, &dp);
+}
+
+KMC_EXPORT kmc_status kmc_metropolis_run(const kmc_metropolis_config* c, const double* theta0, kmc_metropolis_outputs* out)
+{
+    if (!theta0 || !out) return fail(KMC_ERR_BAD_ARG, "null argument");
+    KMC_TRY(kmc_metropolis_validate(c));
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        (void)hipGetLastError();
+        return fail(KMC_ERR_NO_DEVICE, "no HIP device visible: the Metropolis path has no CPU fallback");
+    }
+    if (c->device < 0 || c->device >= ndev) return fail(KMC_ERR_BAD_ARG, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(c->device));
+    const int64_t nc = c->nchains, nd = c->ndim;
+    const int64_t nsamples = c->niter > c->nburnin ? (c->niter - c->nburnin) / c->nthin : 0;      // :88
+    out->nsamples = nsamples;
+    out->device_ms = 0.0;
+    const bool want_chain = (c->flags & KMC_STORE_CHAIN) != 0, want_logp = (c->flags & KMC_STORE_LOGP) != 0,
+               want_mom = (c->flags & KMC_MOMENTS) != 0;
+
+    kmc_config e{};
+    e.density = c->density;
+    for (int i = 0; i < 8; ++i) e.params[i] = c->params[i];
+    e.ndim = nd;
+    e.user_density = c->user_density;
+    e.device = c->device;
+    DensityParams dp{};
+    if (c->density == KMC_USER_DENSITY) { for (int i = 0; i < 6; ++i) dp.p[i] = c->params[i]; dp.ndim = (int32_t)nd; }
+    else if (c->density == KMC_HOST_DENSITY) dp.ndim = (int32_t)nd;
+    else KMC_TRY(digest_params(e, &dp));
+    if (c->density == KMC_HOST_DENSITY || c->host_propose)
+        return metropolis_host_route(c, theta0, out, dp, nsamples);
+
+    MetroBuffers b;
+    const size_t rows = (size_t)nc * (size_t)nd * sizeof(double);
+    HIP_TRY(hipMalloc(&b.pos, rows));
+    HIP_TRY(hipMalloc(&b.logp, (size_t)nc * sizeof(double)));
+    HIP_TRY(hipMalloc(&b.naccept, (size_t)nc * sizeof(uint32_t)));
+    HIP_TRY(hipMemset(b.naccept, 0, (size_t)nc * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&b.step, (size_t)nd * sizeof(double)));
+    HIP_TRY(hipMemcpy(b.step, c->step, (size_t)nd * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(b.pos, theta0, rows, hipMemcpyHostToDevice));                              // :68 deepcopy
+    if (want_chain && nsamples > 0) HIP_TRY(hipMalloc(&b.chain, (size_t)nsamples * rows));
+    if (want_logp && nsamples > 0) HIP_TRY(hipMalloc(&b.chain_logp, (size_t)nsamples * (size_t)nc * sizeof(double)));
+    if (want_mom) {
+        HIP_TRY(hipMalloc(&b.csum, rows));
+        HIP_TRY(hipMalloc(&b.csumsq, rows));
+        HIP_TRY(hipMemset(b.csum, 0, rows));
+        HIP_TRY(hipMemset(b.csumsq, 0, rows));
+    }
+    const int ND = metropolis_nd(nd);
+    if (ND == 0) {      // chains too long for registers: state kept dimension-major in memory
+        HIP_TRY(hipMalloc(&b.xt, rows));
+        HIP_TRY(hipMalloc(&b.yt, rows));
+        if (want_mom) {
+            HIP_TRY(hipMalloc(&b.st1, rows));
+            HIP_TRY(hipMalloc(&b.st2, rows));
+            HIP_TRY(hipMemset(b.st1, 0, rows));
+            HIP_TRY(hipMemset(b.st2, 0, rows));
+        }
+    }
+
+    MetropolisFn fn = nullptr;
+    hipFunction_t ufn = nullptr, ulp = nullptr;
+    if (c->density == KMC_USER_DENSITY) {
+        const std::vector<char>* code = nullptr;
+        KMC_TRY(compile_user_metropolis(static_cast<kmc_user_density*>(c->user_density), ND, &code));
+        HIP_TRY(hipModuleLoadData(&b.mod, code->data()));
+        HIP_TRY(hipModuleGetFunction(&ufn, b.mod, "kmc_user_metropolis"));
+        HIP_TRY(hipModuleGetFunction(&ulp, b.mod, "kmc_user_logpdf"));
+    } else {
+        fn = metropolis_fn(c->density, (int)std::min<int64_t>(nd, 1 << 20));    // the geometry follows ndim (registers <= 32)
+        if (!fn) return fail(KMC_ERR_BAD_ARG, "unknown density id");
+    }
+    const unsigned grid = (unsigned)((nc + 255) / 256);
+
+    // p0 = pdf(theta0)  (:70); unlike emcee the reference carries whatever comes out, -Inf included
+    const LogpdfArgs la{b.pos, b.logp, nc, (int32_t)nd, (int32_t)nd, dp};
+    if (ulp) HIP_TRY(launch_module(ulp, grid, 256u, nullptr, la));
+    else {
+        HalfStepFn v, g;
+        LogpdfFn lp = nullptr;
+        lookup(c->density, 0, 0, 1, false, false, false, &v, &g, &lp);
+        hipLaunchKernelGGL(lp, dim3(grid), dim3(256), 0, nullptr, la);
+        HIP_TRY(hipGetLastError());
+    }
+
+    auto transpose = [&](const double* src, double* dst, bool to_dim_major) {
+        const TransposeArgs ta{src, dst, nc, (int32_t)nd, to_dim_major ? 1 : 0};
+        hipLaunchKernelGGL(metropolis_transpose, dim3(grid), dim3(256), 0, nullptr, ta);
+        return hipGetLastError();
+    };
+    if (ND == 0) HIP_TRY(transpose(b.pos, b.xt, true));
+
+    HIP_TRY(hipEventCreate(&b.ev0));
+    HIP_TRY(hipEventCreate(&b.ev1));
+    HIP_TRY(hipEventRecord(b.ev0, nullptr));
+    constexpr int64_t kItersPerLaunch = 1 << 16;       // chains are independent: launches only bound a kernel's run time
+    for (int64_t it0 = 0; it0 < c->niter; it0 += kItersPerLaunch) {
+        MetropolisArgs a{};
+        a.pos = b.pos; a.logp = b.logp; a.naccept = b.naccept;
+        a.chain = b.chain; a.chain_logp = b.chain_logp; a.csum = b.csum; a.csumsq = b.csumsq;
+        a.step = b.step; a.xt = b.xt; a.yt = b.yt; a.st1 = b.st1; a.st2 = b.st2;
+        a.nchains = nc;
+        a.it0 = it0; a.it1 = std::min<int64_t>(c->niter, it0 + kItersPerLaunch);
+        a.nburnin = c->nburnin; a.nthin = c->nthin; a.nsamples = nsamples;
+        const int64_t npos = it0 - c->nburnin;          // steps with n > 0 taken before it0
+        a.cnt0 = npos > 0 ? npos % c->nthin : 0;
+        a.slot0 = npos > 0 ? npos / c->nthin : 0;
+        a.ndim = (int32_t)nd;
+        a.seed_lo = (uint32_t)c->seed; a.seed_hi = (uint32_t)(c->seed >> 32);
+        a.dp = dp;
+        if (ufn) HIP_TRY(launch_module(ufn, grid, 256u, nullptr, a));
+        else {
+            hipLaunchKernelGGL(fn, dim3(grid), dim3(256), 0, nullptr, a);
+            HIP_TRY(hipGetLastError());
+        }
+    }
+    HIP_TRY(hipEventRecord(b.ev1, nullptr));
+    if (ND == 0) {
+        HIP_TRY(transpose(b.xt, b.pos, false));
+        if (want_mom) { HIP_TRY(transpose(b.st1, b.csum, false)); HIP_TRY(transpose(b.st2, b.csumsq, false)); }
+    }
+    HIP_TRY(hipEventSynchronize(b.ev1));
+    HIP_TRY(hipDeviceSynchronize());
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, b.ev0, b.ev1));
+    out->device_ms = (double)ms;
+
+    if (out->chain && b.chain) HIP_TRY(hipMemcpy(out->chain, b.chain, (size_t)nsamples * rows, hipMemcpyDeviceToHost));
+    if (out->chain_logp && b.chain_logp)
+        HIP_TRY(hipMemcpy(out->chain_logp, b.chain_logp, (size_t)nsamples * (size_t)nc * sizeof(double), hipMemcpyDeviceToHost));
+    if (out->final_pos) HIP_TRY(hipMemcpy(out->final_pos, b.pos, rows, hipMemcpyDeviceToHost));
+    if (out->final_logp) HIP_TRY(hipMemcpy(out->final_logp, b.logp, (size_t)nc * sizeof(double), hipMemcpyDeviceToHost));
+    if (out->chain_sum && b.csum) HIP_TRY(hipMemcpy(out->chain_sum, b.csum, rows, hipMemcpyDeviceToHost));
+    if (out->chain_sumsq && b.csumsq) HIP_TRY(hipMemcpy(out->chain_sumsq, b.csumsq, rows, hipMemcpyDeviceToHost));
+    if (out->naccept || out->accept_ratio) {
+        std::vector<uint32_t> na((size_t)nc);
+        HIP_TRY(hipMemcpy(na.data(), b.naccept, (size_t)nc * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        const double denom = (double)(c->niter - c->nburnin);                                   // :127 (0/0 as in the reference)
+        for (int64_t i = 0; i < nc; ++i) {
+            if (out->naccept) out->naccept[i] = (int64_t)na[(size_t)i];
+            if (out->accept_ratio) out->accept_ratio[i] = (double)na[(size_t)i] / denom;
+        }
+    }
+    return KMC_OK;
+}
+
