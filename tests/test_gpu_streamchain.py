@@ -139,3 +139,33 @@ def test_stream_chain_argument_checks(kmc):
         a = np.zeros((90, 256, 4))
         with pytest.raises(kmc.KmcError, match="KMC_STREAM_CHAIN"):
             _lib.check(s._L.kmc_sampler_set_chain_host(s._h, a.ctypes.data_as(C.POINTER(C.c_double)), None))
+
+
+def test_streamed_chain_random_splits_and_thinnings(kmc, oracle, monkeypatch):
+    """Seeded random sweep of the ring bookkeeping: thinning, burn-in, block size, launch mode and the way a run is cut into
+    run() calls (with and without syncs in between) -- every streamed chain equals the oracle's."""
+    rng = np.random.default_rng(2026)
+    nw, nd = 512, 6
+    th = rng.standard_normal((nw, nd))
+    for trial in range(12):
+        nthin = int(rng.choice([1, 1, 2, 3, 7, 64, 65]))
+        G = int(rng.integers(150, 700))
+        nburn = int(rng.integers(0, G // 2))
+        monkeypatch.setenv("KMC_CHAIN_BLOCK", str(int(rng.choice([1, 3, 50, 1000]))))
+        monkeypatch.setenv("KMC_LAUNCH", str(rng.choice(["graph", "updated", "eager"])))
+        seed = int(rng.integers(1, 10 ** 6))
+        with kmc.Sampler(kmc.GaussianIso(), nw, nd, G, nburn, nthin, 2.0, seed, store_chain=True, store_logp=True, stream_chain=True) as s:
+            s.set_positions(th)
+            left = G
+            while left > 0:
+                n = int(min(left, rng.choice([1, 5, 63, 64, 65, 128, 300])))
+                s.run(n)
+                left -= n
+                if rng.random() < 0.4:
+                    s.sync()
+            s.sync()
+            chain, clogp = s.chain()
+        ref = _oracle_chain(oracle, oracle.GAUSSIAN_ISO, [0.0, 1.0], th, G, nburn, nthin, seed)
+        assert chain.shape[0] == ref["nsamples"] == (G - nburn) // nthin, (trial, nthin, G, nburn)
+        np.testing.assert_array_equal(chain, ref["chain"], err_msg=f"trial {trial}: nthin={nthin} G={G} nburn={nburn}")
+        assert np.all(np.abs(clogp - ref["chain_logp"]) <= 1e-12 * np.maximum(1.0, np.abs(ref["chain_logp"])))
