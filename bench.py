@@ -8,8 +8,8 @@ default --steps 10 is exactly the 10^4-generation job.  With --gpus N (launched 
 torch.distributed.run, one rank per GPU) the ensemble is 65 536 x N walkers, walker-sharded with the reference's EXACT
 partner rule and a peer-to-peer exchange over xGMI (KMC_P2P, pull of the drawn partner rows with system-scope loads +
 signal kernel; admitted by a bit-exact self-check, and the timed run itself is verified against the unsharded run;
-KMC_BENCH_EXCHANGE=all measures the other five variants too, =allgather -- or any failure -- runs the RCCL all-gather of
-the updated half per half-step) -- weak scaling, config C4 at N = 8.  Extra key `dealt_mode` (N > 1, never `value`):
+KMC_BENCH_EXCHANGE=all measures the other five variants too, =allgather -- or any failure -- runs the native RCCL all-gather
+of the updated half per half-step, enqueued by the library itself) -- weak scaling, config C4 at N = 8.  Extra key `dealt_mode` (N > 1, never `value`):
 the same job as dealt sub-ensembles, one RCCL all_to_all_single per 64 generations instead of an exchange per half-step.
 
 Prints ONE JSON line (rank 0).  `value` = all walker-steps of the timed region / wall time
@@ -401,35 +401,69 @@ def main():
             parallelism = (f"walker-sharded x{world}, exact partner rule, peer-to-peer exchange over xGMI (IPC): {p2p_memory}; "
                            "progress-flag ordering")
         else:
-            ex = HipShardExecutor(pdf, nw, NDIM, G, nburn, 1, 2.0, SEED, rank=rank, world=world, device=local_rank)
-            ex.set_positions(th)
-            sdrv = ShardedEmcee(ex, nw, NDIM)
-            sdrv.run(min(args.warmup * GENS_PER_STEP, 100))   # warm-up: kernels + RCCL rings
-            ex.sync()
-            ex.set_positions(th)
-            sdrv.generation = 0
-            dist.barrier()
-            torch.cuda.synchronize()
-            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            t0 = time.perf_counter()
-            ev0.record()                         # the executor launches on torch's current stream
-            sdrv.run(G)
-            ev1.record()
-            ex.sync()
-            torch.cuda.synchronize()
-            dist.barrier()
-            elapsed = time.perf_counter() - t0
-            event_ms = ev0.elapsed_time(ev1)
-            launches = 2 * G
-            msum, msq, nmom = sdrv.moments()
-            facc = sdrv.naccept()
-            fpos = sdrv.positions()
+            # The exchange the north star names: an RCCL all-gather of the updated half after every half-step.  Native form
+            # first (kmc_sampler_run enqueues kernel + ncclAllGather per half-step, inside the hipGraph chunks); if that cannot
+            # be set up on every rank, the same exchange as a torch collective per half-step from Python.
+            from kissmcmc_jl_amd.distributed import AllGatherEmcee
+            nat = None
+            ok = True
+            try:
+                nat = AllGatherEmcee(pdf, nw, NDIM, G, nburn, 1, 2.0, SEED, device=local_rank)
+            except Exception as e:  # noqa: BLE001
+                print(f"[rank {rank}] native RCCL all-gather set-up failed ({e})", file=sys.stderr)
+                ok = False
+            if all_ok(ok):
+                nat.set_positions(th)
+                nat.run(min(args.warmup * GENS_PER_STEP, 200))
+                nat.sync()
+                nat.set_positions(th)
+                dist.barrier()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                nat.run(G)
+                nat.sync()
+                torch.cuda.synchronize()
+                dist.barrier()
+                elapsed = time.perf_counter() - t0
+                event_ms = nat.sampler.last_run_ms()
+                launches = nat.sampler.launch_count
+                msum, msq, nmom = nat.moments()
+                facc, fpos = nat.naccept(), nat.positions()
+                how_nat = nat.sampler.describe()
+                nat.close()
+                parallelism = f"walker-sharded x{world}, exact partner rule, native RCCL all-gather of the updated half per half-step ({how_nat.split(';')[-1].strip()})"
+            else:
+                if nat is not None:
+                    nat.sampler.close()
+                ex = HipShardExecutor(pdf, nw, NDIM, G, nburn, 1, 2.0, SEED, rank=rank, world=world, device=local_rank)
+                ex.set_positions(th)
+                sdrv = ShardedEmcee(ex, nw, NDIM)
+                sdrv.run(min(args.warmup * GENS_PER_STEP, 100))   # warm-up: kernels + RCCL rings
+                ex.sync()
+                ex.set_positions(th)
+                sdrv.generation = 0
+                dist.barrier()
+                torch.cuda.synchronize()
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                t0 = time.perf_counter()
+                ev0.record()                         # the executor launches on torch's current stream
+                sdrv.run(G)
+                ev1.record()
+                ex.sync()
+                torch.cuda.synchronize()
+                dist.barrier()
+                elapsed = time.perf_counter() - t0
+                event_ms = ev0.elapsed_time(ev1)
+                launches = 2 * G
+                msum, msq, nmom = sdrv.moments()
+                facc = sdrv.naccept()
+                fpos = sdrv.positions()
+                ex.close()
+                parallelism = f"walker-sharded x{world}, exact partner rule, RCCL all-gather of the updated half per half-step (torch collective per half-step)"
             acc = float(facc.sum() / nw / max(1, G - nburn))
-            ex.close()
             if rank == 0:
                 rpos, racc, (rs, rq, rn) = unsharded(G)
                 verified = bool(np.array_equal(rpos, fpos) and np.array_equal(racc, facc))
-            parallelism = f"walker-sharded x{world}, exact partner rule, RCCL all-gather of the updated half per half-step"
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())

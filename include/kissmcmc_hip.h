@@ -137,6 +137,7 @@ enum {
 };
 
 #define KMC_P2P_HANDLE_BYTES 128
+#define KMC_RCCL_ID_BYTES 128
 
 typedef struct kmc_config {
     int32_t  dtype;         /* KMC_F64 or KMC_F32 (device storage of the rows) */
@@ -229,6 +230,15 @@ kmc_status  kmc_sampler_bind_positions(kmc_sampler* s, void* pos_dev);
  * second-half slice). */
 kmc_status  kmc_sampler_p2p_export(kmc_sampler* s, void* handle_out);
 kmc_status  kmc_sampler_p2p_connect(kmc_sampler* s, const void* handles /* [shard_count][KMC_P2P_HANDLE_BYTES] */);
+/* The all-gather exchange of the exact partner rule, native: a sampler created with shard_rank / shard_count (no KMC_P2P)
+ * holds a full replica of the ensemble and updates its slice of each half; with an RCCL communicator attached,
+ * kmc_sampler_run enqueues, per half-step, the kernel and an in-place ncclAllGather of the updated half on the sampler's
+ * stream (reference src/samplers.jl:273: the join, across GPUs) -- captured into the same hipGraph chunks as the
+ * single-GPU run where RCCL allows capture, enqueued launch by launch otherwise; no host involvement inside a run.
+ * kmc_rccl_unique_id: rank 0 creates the id (KMC_RCCL_ID_BYTES), the caller distributes it (any transport), every
+ * rank calls kmc_sampler_rccl_init (collective: ncclCommInitRank).  librccl.so is loaded on first use. */
+kmc_status  kmc_rccl_unique_id(void* id_out);
+kmc_status  kmc_sampler_rccl_init(kmc_sampler* s, const void* id /* KMC_RCCL_ID_BYTES */);
 /* The same wiring for shards that live in ONE process on one device (no IPC): shards[r] = the sampler of shard r.
    They run concurrently on their own streams like ranks on separate GPUs (single-process tests, timing, profiling). */
 kmc_status  kmc_sampler_p2p_connect_local(kmc_sampler* s, kmc_sampler* const* shards /* [shard_count] */);

@@ -28,6 +28,7 @@ STORE_CHAIN, STORE_LOGP, MOMENTS, NO_GRAPH, P2P, ISLANDS, P2P_FINEGRAINED, P2P_F
 P2P_LAZY = 1024
 STREAM_CHAIN = 2048
 P2P_HANDLE_BYTES = 128
+RCCL_ID_BYTES = 128
 
 # Every symbol include/kissmcmc_hip.h declares (tests check they are all exported).
 SYMBOLS = [
@@ -40,7 +41,7 @@ SYMBOLS = [
     "kmc_sampler_get_moments", "kmc_sampler_get_chain", "kmc_logpdf_eval", "kmc_logpdf_eval_host",
     "kmc_user_density_create", "kmc_user_density_destroy", "kmc_metropolis_validate", "kmc_metropolis_run", "kmc_int_acorr", "kmc_sampler_int_acorr",
     "kmc_sizeof_config", "kmc_sizeof_metropolis_config", "kmc_deal_seed", "kmc_deal_perm", "kmc_sampler_deal_pack", "kmc_sampler_deal_unpack",
-    "kmc_sampler_get_walker_ids", "kmc_sampler_set_chain_host",
+    "kmc_sampler_get_walker_ids", "kmc_sampler_set_chain_host", "kmc_rccl_unique_id", "kmc_sampler_rccl_init",
 ]
 
 
@@ -214,6 +215,8 @@ def lib() -> C.CDLL:
     L.kmc_sampler_deal_unpack.argtypes = [vp, vp]
     L.kmc_sampler_get_walker_ids.argtypes = [vp, ip]
     L.kmc_sampler_set_chain_host.argtypes = [vp, dp, dp]
+    L.kmc_rccl_unique_id.argtypes = [vp]
+    L.kmc_sampler_rccl_init.argtypes = [vp, vp]
     # layout drift between this mirror and the library fails here, at load, not inside the first real call
     if L.kmc_sizeof_config() != C.sizeof(Config) or L.kmc_sizeof_metropolis_config() != C.sizeof(MetropolisConfig):
         raise ImportError(f"{LIB_PATH}: struct layout mismatch (kmc_config {L.kmc_sizeof_config()} vs {C.sizeof(Config)} bytes, "

@@ -8,7 +8,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(_HERE, "libkissmcmc_hip.so")
-SOURCES = ["kmc_api.hip", "kmc_metropolis_api.hip", "kmc_acorr.hip", "kmc_inst_gaussian_iso.hip", "kmc_inst_exponential.hip", "kmc_inst_rosenbrock.hip",
+SOURCES = ["kmc_api.hip", "kmc_metropolis_api.hip", "kmc_acorr.hip", "kmc_rccl.hip", "kmc_inst_gaussian_iso.hip", "kmc_inst_exponential.hip", "kmc_inst_rosenbrock.hip",
            "kmc_inst_lognormal.hip", "kmc_inst_mvnormal2.hip", "kmc_inst_host.hip"]
 HEADERS = ["kmc_host.hpp", "kmc_device.hpp", "kmc_kernels.hpp", "kmc_islands.hpp", "kmc_metropolis.hpp", "kmc_tables.hpp", os.path.join("..", "..", "include", "kissmcmc_hip.h")]
 # kernarg preload: the half-step kernels' leading scalar parameters arrive in SGPRs at wave launch (kmc_kernels.hpp)

@@ -466,6 +466,8 @@ struct kmc_sampler {
     bool dst_chain_reg = false, dst_logp_reg = false;      // page-locked in place by us
     int64_t blocks_copied = 0;        // blocks [0, blocks_copied) have their device-to-host copy enqueued
     int64_t blocks_waited = 0;        // compute stream already waits for the copies of the blocks that blocks < this overwrite
+    void* comm = nullptr;             // replica sharding: RCCL communicator (kmc_sampler_rccl_init) for the all-gather after each half-step
+    bool comm_graph_ok = true;        //   the all-gather can be captured into the hipGraph chunks (decided at the first capture)
     uint32_t* d_ids = nullptr;        // dealt sub-ensembles: global walker index held by each slot
     uint64_t user_seed = 0;           //   the caller's seed (cfg.seed is then this sub-ensemble's Philox key)
     int64_t moment_base = 0;  // samples that precede the restored state (kmc_sampler_set_state)
@@ -635,6 +637,12 @@ kmc_status launch_half(kmc_sampler* s, int half, bool graph_mode, int64_t gen_of
         hipLaunchKernelGGL(p2p_signal, dim3(1), dim3(64), 0, s->stream, sg);
         HIP_TRY(hipGetLastError());
     }
+    if (s->comm) {
+        // replica sharding: every rank's slice of the half just updated, gathered in place (the join of :273, across GPUs)
+        double* base = s->d_pos + (size_t)half * (size_t)s->h * (size_t)s->ld;
+        const size_t count = (size_t)s->h_loc * (size_t)s->ld;
+        KMC_TRY(rccl_all_gather_f64(s->comm, base + (size_t)s->cfg.shard_rank * count, base, count, s->stream));
+    }
     return KMC_OK;
 }
 
@@ -693,10 +701,22 @@ kmc_status ensure_graph(kmc_sampler* s)
     if (st == KMC_OK) launch_advance(s, 0, kGraphChunk);   // device counter += chunk
     hipGraph_t graph = nullptr;
     hipError_t e = hipStreamEndCapture(s->stream, &graph);
-    if (st != KMC_OK) { if (graph) (void)hipGraphDestroy(graph); return st; }
-    HIP_TRY(e);
+    if (st != KMC_OK || e != hipSuccess) {
+        if (graph) (void)hipGraphDestroy(graph);
+        (void)hipGetLastError();
+        if (s->comm) { s->comm_graph_ok = false; return KMC_OK; }   // RCCL refused the capture: this sampler launches eagerly
+        if (st != KMC_OK) return st;
+        HIP_TRY(e);
+    }
     s->graph = graph;
-    HIP_TRY(hipGraphInstantiate(&s->graph_exec, graph, nullptr, nullptr, 0));
+    const hipError_t ei = hipGraphInstantiate(&s->graph_exec, graph, nullptr, nullptr, 0);
+    if (ei != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipGraphDestroy(graph);
+        s->graph = nullptr; s->graph_exec = nullptr;
+        if (s->comm) { s->comm_graph_ok = false; return KMC_OK; }
+        HIP_TRY(ei);
+    }
     return KMC_OK;
 }
 
@@ -726,7 +746,7 @@ hipKernelNodeParams node_params(const kmc_sampler* s, KernelParamPack* pk)
 
 bool updated_graph_possible(const kmc_sampler* s)
 {
-    return !s->user && !s->p2p && !s->host_eval && !s->islands && !s->resident && s->plan.fn != nullptr;
+    return !s->user && !s->p2p && !s->host_eval && !s->islands && !s->resident && !s->comm && s->plan.fn != nullptr;
 }
 
 kmc_status ensure_updated_graph(kmc_sampler* s)
@@ -1328,6 +1348,7 @@ KMC_EXPORT void kmc_sampler_destroy(kmc_sampler* s)
         (void)hipFree(s->d_err);
         (void)hipFree(s->d_done);
     }
+    if (s->comm) { rccl_comm_destroy(s->comm); s->comm = nullptr; }
     if (s->copy_stream) { (void)hipStreamSynchronize(s->copy_stream); (void)hipStreamDestroy(s->copy_stream); }
     for (int i = 0; i < 3; ++i) {
         if (s->ev_filled[i]) (void)hipEventDestroy(s->ev_filled[i]);
@@ -1392,6 +1413,24 @@ KMC_EXPORT kmc_status kmc_sampler_bind_positions(kmc_sampler* s, void* pos_dev)
     s->own_pos = false;
     s->positions_set = false;
     return KMC_OK;
+}
+
+// ---- replica sharding with a native RCCL all-gather ----------------------------------------
+KMC_EXPORT kmc_status kmc_rccl_unique_id(void* id_out)
+{
+    if (!id_out) return fail(KMC_ERR_BAD_ARG, "null argument");
+    return rccl_unique_id(id_out);
+}
+
+KMC_EXPORT kmc_status kmc_sampler_rccl_init(kmc_sampler* s, const void* id)
+{
+    if (!s || !id) return fail(KMC_ERR_BAD_ARG, "null argument");
+    if (s->p2p || s->islands || s->resident || s->host_eval || s->f32 || s->d_ids || s->stream_chain)
+        return fail(KMC_ERR_UNSUPPORTED, "kmc_sampler_rccl_init: a replica-sharded double sampler with a device density (shard_rank / shard_count, no KMC_P2P)");
+    if (s->comm) return KMC_OK;
+    HIP_TRY(hipSetDevice(s->cfg.device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return rccl_comm_create(id, s->cfg.shard_rank, s->cfg.shard_count, &s->comm);
 }
 
 // ---- peer-to-peer sharding ---------------------------------------------------------------
@@ -1754,8 +1793,9 @@ KMC_EXPORT kmc_status kmc_sampler_run(kmc_sampler* s, int64_t ngen)
 {
     if (!s || ngen < 0) return fail(KMC_ERR_BAD_ARG, "bad argument");
     if (!s->positions_set) return fail(KMC_ERR_BAD_ARG, "kmc_sampler_set_positions has not succeeded yet");
-    if (s->cfg.shard_count != 1 && !s->p2p)
-        return fail(KMC_ERR_UNSUPPORTED, "kmc_sampler_run needs shard_count == 1 or KMC_P2P; replica-sharded drivers call kmc_sampler_half_step");
+    if (s->cfg.shard_count != 1 && !s->p2p && !s->comm)
+        return fail(KMC_ERR_UNSUPPORTED, "kmc_sampler_run needs shard_count == 1, KMC_P2P or an RCCL communicator (kmc_sampler_rccl_init); "
+                                         "other replica-sharded drivers call kmc_sampler_half_step and exchange themselves");
     if (s->p2p && !s->connected) return fail(KMC_ERR_BAD_ARG, "kmc_sampler_p2p_connect has not been called");
     if (s->generation + ngen >= (int64_t)1 << 31) return fail(KMC_ERR_UNSUPPORTED, "at most 2^31 - 1 generations (the step index is 32 bits)");
     if (s->stream_chain && ((s->d_chain && !s->dst_chain) || (s->d_chain_logp && !s->dst_logp)))
@@ -1865,18 +1905,6 @@ KMC_EXPORT kmc_status kmc_sampler_run(kmc_sampler* s, int64_t ngen)
         s->have_run_events = true;
         return KMC_OK;
     }
-    auto graph_chunk = [&]() -> kmc_status {
-        KMC_TRY(ensure_graph(s));
-        KMC_TRY(sync_device_counter(s));
-        KMC_TRY(chain_before(s, s->generation + kGraphChunk));
-        HIP_TRY(hipGraphLaunch(s->graph_exec, s->stream));
-        HIP_TRY(launch_sweep(s));
-        s->generation += kGraphChunk;
-        s->dev_gen += kGraphChunk;
-        s->launches += 2 * kGraphChunk;
-        ngen -= kGraphChunk;
-        return chain_after(s);
-    };
     auto eager_generations = [&](int64_t n) -> kmc_status {
         for (; n > 0; --n, --ngen) {
             KMC_TRY(chain_before(s, s->generation + 1));
@@ -1887,6 +1915,19 @@ KMC_EXPORT kmc_status kmc_sampler_run(kmc_sampler* s, int64_t ngen)
             KMC_TRY(chain_after(s));
         }
         return KMC_OK;
+    };
+    auto graph_chunk = [&]() -> kmc_status {
+        KMC_TRY(ensure_graph(s));
+        if (!s->graph_exec) return eager_generations(kGraphChunk);      // (RCCL all-gather that cannot be captured)
+        KMC_TRY(sync_device_counter(s));
+        KMC_TRY(chain_before(s, s->generation + kGraphChunk));
+        HIP_TRY(hipGraphLaunch(s->graph_exec, s->stream));
+        HIP_TRY(launch_sweep(s));
+        s->generation += kGraphChunk;
+        s->dev_gen += kGraphChunk;
+        s->launches += 2 * kGraphChunk;
+        ngen -= kGraphChunk;
+        return chain_after(s);
     };
     auto updated_chunk = [&]() -> kmc_status {
         KMC_TRY(chain_before(s, s->generation + s->uchunk));
@@ -2034,7 +2075,10 @@ KMC_EXPORT kmc_status kmc_sampler_describe(const kmc_sampler* s, char* buf, int6
     if (s->d_mring) o << "; moments through a ring of " << s->mring_depth << " posted rows per wave";
     if (s->user) o << "; runtime-compiled density";
     if (s->p2p) o << "; P2P shard " << s->cfg.shard_rank << "/" << s->cfg.shard_count << (s->connected ? "" : " (not connected)");
-    else if (s->cfg.shard_count > 1) o << "; replica shard " << s->cfg.shard_rank << "/" << s->cfg.shard_count;
+    else if (s->cfg.shard_count > 1 || s->comm)
+        o << "; replica shard " << s->cfg.shard_rank << "/" << s->cfg.shard_count
+          << (s->comm ? ((s->comm_graph_ok && !(s->cfg.flags & KMC_NO_GRAPH) && s->launch_mode != 2) ? ", RCCL all-gather of the updated half after every half-step (captured in the graph)"
+                                                                                                         : ", RCCL all-gather of the updated half after every half-step (enqueued launch by launch)") : "");
     const std::string t = o.str();
     std::snprintf(buf, (size_t)buflen, "%s", t.c_str());
     return KMC_OK;

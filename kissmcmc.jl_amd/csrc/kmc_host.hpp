@@ -5,6 +5,7 @@
 #include <hip/hiprtc.h>
 
 #include <cstdint>
+#include <cstring>
 #include <map>
 #include <mutex>
 #include <string>
@@ -62,6 +63,12 @@ hipError_t launch_module(hipFunction_t f, unsigned grid, unsigned tpb, hipStream
 // integrated autocorrelation time of a device-resident chain [nsamples][nwalkers][ndim] (kmc_acorr.hip)
 kmc_status int_acorr_check(int64_t nsamples, int64_t nwalkers, int64_t ndim, double c, const double* tau, const double* converged);
 kmc_status int_acorr_device(const double* chain_dev, int64_t nsamples, int64_t nwalkers, int64_t ndim, double c, double* tau, double* converged);
+
+// RCCL, loaded on demand (kmc_rccl.hip)
+kmc_status rccl_unique_id(void* id_out);
+kmc_status rccl_comm_create(const void* id_bytes, int rank, int nranks, void** comm_out);
+void rccl_comm_destroy(void* comm);
+kmc_status rccl_all_gather_f64(void* comm, const double* send, double* recv, size_t count, hipStream_t stream);
 
 }  // namespace kmc_host
 

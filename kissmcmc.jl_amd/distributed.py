@@ -181,8 +181,84 @@ class P2PEmcee:
         return s, q, n
 
 
+class AllGatherEmcee:
+    """Walker-sharded emcee with the exchange the north star names -- an RCCL all-gather of the updated half after every
+    half-step (the join of ``src/samplers.jl:273``, across GPUs) -- driven natively: every rank's sampler holds a full
+    replica, updates its slice of each half, and ``kmc_sampler_run`` enqueues kernel + in-place ``ncclAllGather`` per
+    half-step on one stream (inside the hipGraph chunks where RCCL allows capture).  No host loop, no Python between
+    half-steps.  ``torch.distributed`` (any backend) only carries the RCCL unique id and assembles results.
+    Bit-identical to the unsharded run (RNG keyed by the global walker index)."""
+
+    def __init__(self, pdf, nwalkers, ndim, ngenerations, nburnin=0, nthin=1, a_scale=2.0, seed=0, device=0, moments=True,
+                 group=None, use_graph=True):
+        from .sampler import Sampler
+        self.group = group
+        self.rank = dist.get_rank(group) if dist is not None and dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist is not None and dist.is_initialized() else 1
+        self.nwalkers, self.ndim = int(nwalkers), int(ndim)
+        self.begin, self.count = shard_slice(self.nwalkers, self.rank, self.world)
+        self.sampler = Sampler(pdf, nwalkers, ndim, ngenerations, nburnin, nthin, a_scale, seed, moments=moments,
+                               use_graph=use_graph, device=device, shard_rank=self.rank, shard_count=self.world)
+        uid = [Sampler.rccl_unique_id() if self.rank == 0 else None]
+        if self.world > 1:
+            dist.broadcast_object_list(uid, src=0, group=group)
+        self.sampler.rccl_init(uid[0])
+
+    def set_positions(self, theta_global):
+        self.sampler.set_positions(theta_global)          # every rank: the whole ensemble (its replica)
+        if self.world > 1:
+            dist.barrier(group=self.group)
+
+    def run(self, ngenerations: int):
+        self.sampler.run(ngenerations)
+
+    def sync(self):
+        self.sampler.sync()
+
+    def _own(self, a):
+        """Keep this rank's slices of a per-walker array, zero the rest; a SUM over ranks assembles it."""
+        h = self.nwalkers // 2
+        out = np.zeros_like(a)
+        for half in (0, 1):
+            sl = slice(half * h + self.begin, half * h + self.begin + self.count)
+            out[sl] = a[sl]
+        return out
+
+    def _sum(self, a):
+        if self.world == 1:
+            return a
+        parts = [None] * self.world
+        dist.all_gather_object(parts, a, group=self.group)
+        return sum(parts)
+
+    def positions(self):
+        return self.sampler.positions()                   # the replica is complete on every rank
+
+    def logp(self):
+        return self._sum(self._own(self.sampler.logp()))
+
+    def naccept(self):
+        return self._sum(self._own(self.sampler.naccept()))
+
+    def moments(self):
+        s, q, n = self.sampler.moments()
+        if self.world > 1:
+            parts = [None] * self.world
+            dist.all_gather_object(parts, (s, q, n), group=self.group)
+            s, q, n = sum(p[0] for p in parts), sum(p[1] for p in parts), sum(p[2] for p in parts)
+        return s, q, n
+
+    def close(self):
+        self.sync()
+        if self.world > 1:
+            dist.barrier(group=self.group)
+        self.sampler.close()
+
+
 class ShardedEmcee:
-    """The generation loop of ``_emcee`` (``src/samplers.jl:245-290``) over ``world`` ranks."""
+    """The generation loop of ``_emcee`` (``src/samplers.jl:245-290``) over ``world`` ranks, the exchange as a torch
+    collective per half-step from Python (any backend: the CPU tests run it over gloo with the oracle as compute
+    stand-in; on GPUs :class:`AllGatherEmcee` is the native form of the same exchange)."""
 
     def __init__(self, executor, nwalkers: int, ndim: int, group=None):
         self.ex = executor

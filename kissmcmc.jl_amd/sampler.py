@@ -139,6 +139,20 @@ class Sampler:
         _lib.check(self._L.kmc_sampler_p2p_stats(self._h, v))
         return int(v[0]), int(v[1])
 
+    @staticmethod
+    def rccl_unique_id() -> bytes:
+        """A fresh RCCL unique id (rank 0 creates it; every rank of the communicator gets the same bytes)."""
+        buf = C.create_string_buffer(_lib.RCCL_ID_BYTES)
+        _lib.check(_lib.lib().kmc_rccl_unique_id(buf))
+        return buf.raw
+
+    def rccl_init(self, unique_id: bytes):
+        """Replica sharding (``shard_rank / shard_count``, no P2P): attach an RCCL communicator; :meth:`run` then enqueues an
+        in-place all-gather of the updated half after every half-step kernel.  Collective over all ``shard_count`` ranks."""
+        assert len(unique_id) == _lib.RCCL_ID_BYTES
+        buf = C.create_string_buffer(bytes(unique_id), _lib.RCCL_ID_BYTES)
+        _lib.check(self._L.kmc_sampler_rccl_init(self._h, buf))
+
     def p2p_export(self) -> bytes:
         """IPC handle blob of this shard (to be all-gathered across the ranks)."""
         buf = C.create_string_buffer(_lib.P2P_HANDLE_BYTES)
