@@ -111,3 +111,68 @@ def test_analytic_moments_of_menu_densities(oracle):
     m = r["sum"] / r["nmoment"]
     v = r["sumsq"] / r["nmoment"] - m ** 2
     assert np.all(np.abs(m) < 0.05) and np.all(np.abs(v - 1.0) < 0.08)
+
+
+def _numpy_stretch_variance(expo_off, nd=8, nw=512, G=1500, seed=0, a=2.0):
+    """An independent numpy restatement of src/samplers.jl:245-266 on the 8-D unit Gaussian with the exponent of the accept
+    test shifted by `expo_off` ((N - 1 + expo_off) log z): mean stationary variance and acceptance."""
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((nw, nd))
+    lp = -0.5 * (x ** 2).sum(1)
+    h = nw // 2
+    s1 = np.zeros(nd); s2 = np.zeros(nd); n = 0; acc = 0
+    for g in range(G):
+        for half in (0, 1):
+            act = slice(half * h, (half + 1) * h)
+            p = rng.integers(0, h, h) + (1 - half) * h                                    # :250
+            z = (rng.random(h) * (np.sqrt(a) - 1 / np.sqrt(a)) + 1 / np.sqrt(a)) ** 2     # :227
+            y = x[p] + z[:, None] * (x[act] - x[p])                                       # :255
+            ly = -0.5 * (y ** 2).sum(1)
+            ok = (nd - 1 + expo_off) * np.log(z) + ly - lp[act] >= np.log(rng.random(h))  # :260
+            xa, la = x[act], lp[act]
+            xa[ok], la[ok] = y[ok], ly[ok]
+            x[act], lp[act] = xa, la
+            acc += ok.sum()
+        if g >= G // 5:
+            s1 += x.sum(0); s2 += (x ** 2).sum(0); n += nw
+    m = s1 / n
+    return float((s2 / n - m ** 2).mean()), acc / (nw * G)
+
+
+def test_stretch_exponent_is_pinned_by_the_stationary_variance(oracle):
+    """The reference's statistical cases are 1-D and 2-D, where an off-by-one in the (N - 1) of the accept test
+    (src/samplers.jl:260) is invisible or nearly so.  In 8 dimensions it is not: with (N - 2) or N instead of (N - 1) the
+    sampler's stationary variance on the unit Gaussian is 0.88 / 1.13 and the acceptance 0.48 / 0.44 (numpy restatement
+    below; affine-invariance theory, Goodman & Weare 2010, gives z^(N-1)).  The oracle must sit at 1.00 and 0.46."""
+    v_lo, a_lo = _numpy_stretch_variance(-1)
+    v_hi, a_hi = _numpy_stretch_variance(+1)
+    assert v_lo < 0.92 and v_hi > 1.08 and a_lo > 0.47 and a_hi < 0.45             # the check below has power
+    nw, nd, G = 512, 8, 4000
+    th = np.random.default_rng(11).standard_normal((nw, nd))
+    r = oracle.emcee(oracle.make_config(oracle.GAUSSIAN_ISO, [0.0, 1.0], nw, nd, G, G // 5, 1, 2.0, seed=17, nthreads=4), th, store_chain=False)
+    m = r["sum"] / r["nmoment"]
+    v = r["sumsq"] / r["nmoment"] - m ** 2
+    assert abs(v.mean() - 1.0) < 0.03, v.mean()
+    assert abs(r["accept_ratio"].mean() - 0.460) < 0.008, r["accept_ratio"].mean()
+
+
+def test_storage_and_counting_rules_are_pinned_by_an_exact_identity(oracle):
+    """src/samplers.jl:268-271 stores the CURRENT state every kept generation whether or not the move was accepted, :265
+    counts accepted moves, :285-288 restarts the counters at the end of burn-in.  With nthin = 1 this forces, per walker,
+    an exact identity between the stored chain and the counter: the number of stored samples that differ from their
+    predecessor is naccept or naccept - 1 (the move of the first sampled generation is counted but has no stored
+    predecessor).  An implementation that stored only accepted states, counted during burn-in, or stored before the
+    accept test would break it."""
+    nw, nd, G, nburn = 64, 3, 400, 150
+    th = np.random.default_rng(5).standard_normal((nw, nd))
+    r = oracle.emcee(oracle.make_config(oracle.GAUSSIAN_ISO, [0.0, 1.0], nw, nd, G, nburn, 1, 2.0, seed=23), th)
+    chain = r["chain"]                                       # [sample][walker][dim]
+    assert chain.shape == (G - nburn, nw, nd)
+    changed = (np.any(chain[1:] != chain[:-1], axis=2)).sum(axis=0)
+    assert np.all((changed == r["naccept"]) | (changed == r["naccept"] - 1))
+    assert (changed == r["naccept"] - 1).any() and (changed == r["naccept"]).any()
+    np.testing.assert_array_equal(chain[-1], r["final_pos"])                       # the last stored sample is the final state
+    np.testing.assert_array_equal(r["accept_ratio"], r["naccept"] / (G - nburn))   # :291
+    # log-densities are stored alongside and belong to the stored states (:271)
+    lp = np.array([[oracle.logpdf(oracle.GAUSSIAN_ISO, [0.0, 1.0], chain[k, w]) for w in range(0, nw, 7)] for k in range(0, G - nburn, 37)])
+    np.testing.assert_allclose(r["chain_logp"][::37, ::7], lp, rtol=1e-14)
