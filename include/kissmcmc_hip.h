@@ -207,6 +207,13 @@ double      kmc_cdf_g_inv(double u, double a);
  *      A term may evaluate to -INFINITY to reject a proposal.  Works in the multi-launch, resident and
  *      island modes; not available with KMC_P2P. */
 kmc_status  kmc_user_density_create(const char* term_expr, const char* pair_expr, kmc_user_density** out);
+/* The general form: the BODY of a C++ function
+ *     double logpdf(const double* x, int n, const double* p) { BODY }
+ * over the whole proposal x[0..n-1] (n = ndim, p = params[0..5]); any coupling between the dimensions, loops, locals;
+ * return -INFINITY to reject.  Runs in the one-walker-per-lane kernels (the proposal is collected per lane, ndim <= 1024):
+ * emcee (multi-launch), initial log-pdfs, kmc_sampler_init_ball, many-chain Metropolis -- slower than a menu or term / pair
+ * density of the same form (those stripe a row over lanes), far faster than a host callback.  Not with KMC_ISLANDS / KMC_P2P. */
+kmc_status  kmc_user_density_create_body(const char* body, kmc_user_density** out);
 void        kmc_user_density_destroy(kmc_user_density* ud);
 
 /* ---- one-shot: emcee + _emcee, src/samplers.jl:188-293 ---- */

@@ -10,7 +10,7 @@ fallback -- without the library or a HIP device the sampler raises.
 from . import _lib
 from ._lib import KmcError
 from .api import emcee, emcee_counts, make_theta0s, squash_walkers
-from .densities import (DeviceLogPdf, Exponential, ExprDensity, GaussianIso, HostLogPdf, LogNormal, MvNormal2,
+from .densities import (CDensity, DeviceLogPdf, Exponential, ExprDensity, GaussianIso, HostLogPdf, LogNormal, MvNormal2,
                         Rosenbrock)
 from .diagnostics import eff_samples, int_acorr
 from .metropolis import GaussianStep, HostProposal, metropolis, metropolis_chains
@@ -18,7 +18,7 @@ from .sampler import Sampler
 
 __all__ = [
     "emcee", "make_theta0s", "squash_walkers", "emcee_counts", "Sampler", "KmcError",
-    "DeviceLogPdf", "GaussianIso", "Exponential", "Rosenbrock", "LogNormal", "MvNormal2", "ExprDensity", "HostLogPdf",
+    "DeviceLogPdf", "GaussianIso", "Exponential", "Rosenbrock", "LogNormal", "MvNormal2", "ExprDensity", "CDensity", "HostLogPdf",
     "cdf_g_inv", "g_pdf", "metropolis", "metropolis_chains", "GaussianStep", "HostProposal", "int_acorr", "eff_samples",
 ]
 

@@ -39,7 +39,7 @@ SYMBOLS = [
     "kmc_sampler_launch_count", "kmc_sampler_describe", "kmc_sampler_device_ptr", "kmc_sampler_get_positions",
     "kmc_sampler_get_logp", "kmc_sampler_get_naccept", "kmc_sampler_get_accept_ratio",
     "kmc_sampler_get_moments", "kmc_sampler_get_chain", "kmc_logpdf_eval", "kmc_logpdf_eval_host",
-    "kmc_user_density_create", "kmc_user_density_destroy", "kmc_metropolis_validate", "kmc_metropolis_run", "kmc_int_acorr", "kmc_sampler_int_acorr",
+    "kmc_user_density_create", "kmc_user_density_create_body", "kmc_user_density_destroy", "kmc_metropolis_validate", "kmc_metropolis_run", "kmc_int_acorr", "kmc_sampler_int_acorr",
     "kmc_sizeof_config", "kmc_sizeof_metropolis_config", "kmc_deal_seed", "kmc_deal_perm", "kmc_sampler_deal_pack", "kmc_sampler_deal_unpack",
     "kmc_sampler_get_walker_ids", "kmc_sampler_set_chain_host", "kmc_rccl_unique_id", "kmc_sampler_rccl_init",
 ]
@@ -202,6 +202,7 @@ def lib() -> C.CDLL:
     L.kmc_logpdf_eval.argtypes = [cfgp, vp, vp, C.c_int64, vp]
     L.kmc_logpdf_eval_host.argtypes = [cfgp, dp, dp, C.c_int64]
     L.kmc_user_density_create.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(vp)]
+    L.kmc_user_density_create_body.argtypes = [C.c_char_p, C.POINTER(vp)]
     L.kmc_user_density_destroy.restype = None
     L.kmc_user_density_destroy.argtypes = [vp]
     L.kmc_metropolis_validate.argtypes = [C.POINTER(MetropolisConfig)]

@@ -217,7 +217,8 @@ Plan make_plan(const kmc_config& c, int64_t n_active)
     }
     if (c.density == KMC_USER_DENSITY) {
         // kernels are compiled for exactly this geometry when the sampler is created
-        if (!force_generic && L > 0 && 2 * L * K >= c.ndim && iter <= L && iter * K <= 16) {
+        const bool body = c.user_density && static_cast<const kmc_user_density*>(c.user_density)->is_body;   // one walker per lane
+        if (!body && !force_generic && L > 0 && 2 * L * K >= c.ndim && iter <= L && iter * K <= 16) {
             p.vec = true; p.L = L; p.K = K; p.ITER = iter;
         } else {
             p.vec = false; p.L = 1; p.K = 1; p.ITER = 1;
@@ -309,9 +310,19 @@ std::string library_dir()
 
 // the user's two expressions as a functor for TermPairDensity
 }  // namespace
+std::string kmc_host::user_density_alias(const kmc_user_density* ud, int64_t ndim)
+{
+    if (!ud->is_body) return "using UD = kmc::TermPairDensity<UserF>;\n";
+    return "using UD = kmc::BodyDensity<UserB, " + std::to_string(ndim > 0 ? ndim : 1) + ">;\n";
+}
 std::string kmc_host::user_functor_source(const kmc_user_density* ud)
 {
     std::ostringstream src;
+    if (ud->is_body) {
+        src << "namespace {\nstruct UserB {\n"
+            << "  __device__ static double eval(const double* x, int n, const double* p) { (void)x; (void)n; (void)p;\n" << ud->body << "\n  }\n};\n}\n";
+        return src.str();
+    }
     src << "namespace {\nstruct UserF {\n"
         << "  static constexpr bool kHasPair = " << (ud->has_pair ? "true" : "false") << ";\n"
         << "  __device__ static double term(double x, int d, int n, const double* p) { (void)d; (void)n; (void)p; return (" << ud->term << "); }\n"
@@ -327,12 +338,14 @@ std::string kmc_host::user_header_dir()
 namespace {
 
 kmc_status compile_user(kmc_user_density* ud, bool with_vec, int L, int K, int iter, bool ragged,
-                        int resident_K, bool resident_ragged, int island_S, bool f32, const std::vector<char>** out)
+                        int resident_K, bool resident_ragged, int island_S, bool f32, const std::vector<char>** out, int64_t ndim = 0)
 {
     // resident_K also sizes the island kernel (same row striping: 2 lanes per walker, K chunks)
-    char key[96];
-    std::snprintf(key, sizeof(key), "%d:%d,%d,%d,%d|%d,%d|%d|%d", (int)with_vec, L, K, iter, (int)ragged, resident_K,
-                  (int)resident_ragged, island_S, (int)f32);
+    if (ud->is_body && (with_vec || resident_K > 0 || island_S > 0))
+        return fail(KMC_ERR_UNSUPPORTED, "a body density runs in the one-walker-per-lane kernels only");
+    char key[112];
+    std::snprintf(key, sizeof(key), "%d:%d,%d,%d,%d|%d,%d|%d|%d|%lld", (int)with_vec, L, K, iter, (int)ragged, resident_K,
+                  (int)resident_ragged, island_S, (int)f32, ud->is_body ? (long long)ndim : 0ll);
     const char* rowt = f32 ? "float" : "double";       // storage type of the walker rows (KMC_F32 / KMC_F64)
     std::lock_guard<std::mutex> lock(ud->mu);
     auto it = ud->code.find(key);
@@ -346,8 +359,7 @@ kmc_status compile_user(kmc_user_density* ud, bool with_vec, int L, int K, int i
         return fail(KMC_ERR_BAD_ARG, "user density: kernel headers not found in " + dir + " (set KMC_CSRC_DIR)");
 
     std::ostringstream src;
-    src << "#include \"kmc_islands.hpp\"\n" << user_functor_source(ud)
-        << "using UD = kmc::TermPairDensity<UserF>;\n"
+    src << "#include \"kmc_islands.hpp\"\n" << user_functor_source(ud) << user_density_alias(ud, ndim)
         << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_generic(KMC_FRONT_PARAMS, const kmc::HalfStepArgs a) { kmc::half_step_generic_body<UD, false, " << rowt << ">(KMC_FRONT_PACK, a); }\n"
         << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_logpdf(const kmc::LogpdfArgs a) { kmc::logpdf_rows_body<UD>(a); }\n"
         << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_init_ball(const kmc::InitBallArgs a) { kmc::init_ball_body<UD>(a); }\n";
@@ -388,10 +400,10 @@ kmc_status compile_user(kmc_user_density* ud, bool with_vec, int L, int K, int i
 }
 
 kmc_status load_user(kmc_user_density* ud, bool with_vec, int L, int K, int iter, bool ragged, UserKernels* uk,
-                     int resident_K = 0, bool resident_ragged = false, int island_S = 0, bool f32 = false)
+                     int resident_K = 0, bool resident_ragged = false, int island_S = 0, bool f32 = false, int64_t ndim = 0)
 {
     const std::vector<char>* code = nullptr;
-    KMC_TRY(compile_user(ud, with_vec, L, K, iter, ragged, resident_K, resident_ragged, island_S, f32, &code));
+    KMC_TRY(compile_user(ud, with_vec, L, K, iter, ragged, resident_K, resident_ragged, island_S, f32, &code, ndim));
     HIP_TRY(hipModuleLoadData(&uk->mod, code->data()));
     HIP_TRY(hipModuleGetFunction(&uk->generic, uk->mod, "kmc_user_generic"));
     HIP_TRY(hipModuleGetFunction(&uk->logpdf, uk->mod, "kmc_user_logpdf"));
@@ -415,6 +427,20 @@ KMC_EXPORT kmc_status kmc_user_density_create(const char* term_expr, const char*
     if (ud->has_pair) ud->pair = pair_expr;
     const std::vector<char>* code = nullptr;
     const kmc_status st = compile_user(ud, false, 0, 0, 0, false, 0, false, 0, false, &code);   // syntax check now, not at first use
+    if (st != KMC_OK) { delete ud; return st; }
+    *out = ud;
+    return KMC_OK;
+}
+
+KMC_EXPORT kmc_status kmc_user_density_create_body(const char* body, kmc_user_density** out)
+{
+    if (!body || !out) return fail(KMC_ERR_BAD_ARG, "null argument");
+    *out = nullptr;
+    kmc_user_density* ud = new kmc_user_density();
+    ud->body = body;
+    ud->is_body = true;
+    const std::vector<char>* code = nullptr;
+    const kmc_status st = compile_user(ud, false, 0, 0, 0, false, 0, false, 0, false, &code, 4);   // syntax check now (any ndim)
     if (st != KMC_OK) { delete ud; return st; }
     *out = ud;
     return KMC_OK;
@@ -1098,7 +1124,7 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         int rK = 0, rK0 = 1;
         while (2 * rK0 < s->ld / 2) rK0 *= 2;
         const size_t rlds = ((size_t)cfg->nwalkers * (size_t)(4 * (rK0 + 1)) + (size_t)cfg->nwalkers) * sizeof(double);
-        if (!s->f32 && cfg->nwalkers <= 256 && cfg->ndim <= 32 && s->cfg.shard_count == 1 && !(cfg->flags & (KMC_P2P | KMC_NO_GRAPH | KMC_ISLANDS | KMC_STREAM_CHAIN)) &&
+        if (!s->user->is_body && !s->f32 && cfg->nwalkers <= 256 && cfg->ndim <= 32 && s->cfg.shard_count == 1 && !(cfg->flags & (KMC_P2P | KMC_NO_GRAPH | KMC_ISLANDS | KMC_STREAM_CHAIN)) &&
             rlds <= 60 * 1024 && std::getenv("KMC_NO_RESIDENT") == nullptr)
             rK = rK0;
         int iS = 0;
@@ -1107,7 +1133,9 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
             rK = 1;
             while (2 * rK < s->ld / 2) rK *= 2;
         }
-        st = load_user(s->user, s->plan.vec, s->plan.L, s->plan.K, s->plan.ITER, s->plan.ragged, &s->uk, rK, 4 * rK != cfg->ndim, iS, s->f32);
+        if (s->user->is_body && iS > 0) { kmc_sampler_destroy(s); return fail(KMC_ERR_UNSUPPORTED, "KMC_ISLANDS needs a menu or term / pair density (a body density runs one walker per lane)"); }
+        if (s->user->is_body && cfg->ndim > 1024) { kmc_sampler_destroy(s); return fail(KMC_ERR_UNSUPPORTED, "a body density holds the proposal per lane: ndim <= 1024"); }
+        st = load_user(s->user, s->plan.vec, s->plan.L, s->plan.K, s->plan.ITER, s->plan.ragged, &s->uk, rK, 4 * rK != cfg->ndim, iS, s->f32, cfg->ndim);
         if (st != KMC_OK) { kmc_sampler_destroy(s); return st; }
         if (iS > 0) rK = 0;     // island mode is set up below, not resident mode
         if (rK > 0) {
@@ -2352,7 +2380,7 @@ KMC_EXPORT kmc_status kmc_logpdf_eval(const kmc_config* cfg, const double* pos_d
     const unsigned grid = (unsigned)((nrows + 255) / 256);
     if (cfg->density == KMC_USER_DENSITY) {
         UserKernels uk;
-        KMC_TRY(load_user(static_cast<kmc_user_density*>(cfg->user_density), false, 0, 0, 0, false, &uk));
+        KMC_TRY(load_user(static_cast<kmc_user_density*>(cfg->user_density), false, 0, 0, 0, false, &uk, 0, false, 0, false, cfg->ndim));
         const hipError_t e = launch_module(uk.logpdf, grid, 256u, (hipStream_t)hip_stream, la);
         if (e == hipSuccess) (void)hipStreamSynchronize((hipStream_t)hip_stream);   // the module is unloaded below
         (void)hipModuleUnload(uk.mod);

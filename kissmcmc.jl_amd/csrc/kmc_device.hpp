@@ -453,4 +453,18 @@ struct TermPairDensity {
     __device__ static double finish(double S, const DensityParams&) { return S; }
 };
 
+// ------------------------------------------------------------------------------------------
+// A log-density given as a whole function over the proposal vector (runtime-compiled, kmc_user_density_create_body):
+// the kernels that walk a row element by element (generic half-step, initial log-pdfs, initial ball, Metropolis) collect
+// the MAXD = ndim elements in per-lane storage and evaluate F::eval(x, n, p) once.  No lane-striped form (kHasFrag).
+// ------------------------------------------------------------------------------------------
+template <class F, int MAXD>
+struct BodyDensity {
+    static constexpr bool kHasFrag = false;
+    struct Seq { double x[MAXD]; };
+    __device__ static void seq_init(Seq&) {}
+    __device__ static void seq_add(Seq& q, double v, int d, const DensityParams&) { if (d < MAXD) q.x[d] = v; }
+    __device__ static double seq_finish(const Seq& q, int ndim, const DensityParams& P) { return F::eval(q.x, ndim, P.p); }
+};
+
 }  // namespace kmc

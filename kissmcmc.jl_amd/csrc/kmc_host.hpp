@@ -47,7 +47,8 @@ bool lookup(int density, int L, int K, int iter, bool p2p, bool ragged, bool f32
 kmc_status digest_params(const kmc_config& c, kmc::DensityParams* dp);
 
 // runtime-compiled user densities (hiprtc)
-std::string user_functor_source(const kmc_user_density* ud);
+std::string user_functor_source(const kmc_user_density* ud);      // the functor(s) ...
+std::string user_density_alias(const kmc_user_density* ud, int64_t ndim);   // ... and "using UD = ...;" over them
 std::string user_header_dir();                      // where the kernel headers live (KMC_CSRC_DIR or <library dir>/csrc)
 std::string read_file(const std::string& path);
 
@@ -76,6 +77,8 @@ kmc_status rccl_all_gather_f64(void* comm, const double* send, double* recv, siz
 struct kmc_user_density {
     std::string term, pair;
     bool has_pair = false;
+    std::string body;                                // kmc_user_density_create_body: the whole function body instead of term / pair
+    bool is_body = false;
     std::mutex mu;
     std::map<std::string, std::vector<char>> code;   // geometry key -> gfx950 code object
 };

@@ -33,10 +33,11 @@ MetropolisFn metropolis_fn(int density, int ndim)
 int metropolis_nd(int64_t ndim) { return ndim <= 1 ? 1 : ndim <= 2 ? 2 : ndim <= 4 ? 4 : ndim <= 8 ? 8 : ndim <= 16 ? 16 : ndim <= 32 ? 32 : 0; }
 
 // runtime-compiled density: the Metropolis kernel (and the initial log-pdf kernel) for one register geometry
-kmc_status compile_user_metropolis(kmc_user_density* ud, int ND, const std::vector<char>** out)
+kmc_status compile_user_metropolis(kmc_user_density* ud, int ND, const std::vector<char>** out, int64_t ndim = 0)
 {
-    char key[32];
-    std::snprintf(key, sizeof(key), "M:%d", ND);
+    if (ud->is_body) ND = 0;                     // a body density: the chain-in-memory kernel (the proposal is collected per lane)
+    char key[48];
+    std::snprintf(key, sizeof(key), "M:%d:%lld", ND, ud->is_body ? (long long)ndim : 0ll);
     std::lock_guard<std::mutex> lock(ud->mu);
     auto it = ud->code.find(key);
     if (it != ud->code.end()) { *out = &it->second; return KMC_OK; }
@@ -46,8 +47,7 @@ kmc_status compile_user_metropolis(kmc_user_density* ud, int ND, const std::vect
     if (h_dev.empty() || h_ker.empty() || h_met.empty())
         return fail(KMC_ERR_BAD_ARG, "user density: kernel headers not found in " + dir + " (set KMC_CSRC_DIR)");
     std::ostringstream src;
-    src << "#include \"kmc_kernels.hpp\"\n#include \"kmc_metropolis.hpp\"\n" << user_functor_source(ud)
-        << "using UD = kmc::TermPairDensity<UserF>;\n"
+    src << "#include \"kmc_kernels.hpp\"\n#include \"kmc_metropolis.hpp\"\n" << user_functor_source(ud) << user_density_alias(ud, ndim)
         << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_logpdf(const kmc::LogpdfArgs a) { kmc::logpdf_rows_body<UD>(a); }\n"
         << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_metropolis(const kmc::MetropolisArgs a) { ";
     if (ND > 0) src << "kmc::metropolis_chains_body<UD, " << ND << ">(a); }\n";
@@ -162,7 +162,7 @@ kmc_status metropolis_host_route(const kmc_metropolis_config* c, const double* t
     if (!host_pdf) {
         if (c->density == KMC_USER_DENSITY) {
             const std::vector<char>* code = nullptr;
-            KMC_TRY(compile_user_metropolis(static_cast<kmc_user_density*>(c->user_density), metropolis_nd(nd), &code));
+            KMC_TRY(compile_user_metropolis(static_cast<kmc_user_density*>(c->user_density), metropolis_nd(nd), &code, nd));
             HIP_TRY(hipModuleLoadData(&b.mod, code->data()));
             HIP_TRY(hipModuleGetFunction(&ulp, b.mod, "kmc_user_logpdf"));
         } else {
@@ -329,8 +329,9 @@ KMC_EXPORT kmc_status kmc_metropolis_run(const kmc_metropolis_config* c, const d
         HIP_TRY(hipMemset(b.csum, 0, rows));
         HIP_TRY(hipMemset(b.csumsq, 0, rows));
     }
-    const int ND = metropolis_nd(nd);
-    if (ND == 0) {      // chains too long for registers: state kept dimension-major in memory
+    int ND = metropolis_nd(nd);
+    if (c->density == KMC_USER_DENSITY && static_cast<const kmc_user_density*>(c->user_density)->is_body) ND = 0;   // body density: chain in memory
+    if (ND == 0) {      // chains too long for registers (or a body density): state kept dimension-major in memory
         HIP_TRY(hipMalloc(&b.xt, rows));
         HIP_TRY(hipMalloc(&b.yt, rows));
         if (want_mom) {
@@ -345,7 +346,7 @@ KMC_EXPORT kmc_status kmc_metropolis_run(const kmc_metropolis_config* c, const d
     hipFunction_t ufn = nullptr, ulp = nullptr;
     if (c->density == KMC_USER_DENSITY) {
         const std::vector<char>* code = nullptr;
-        KMC_TRY(compile_user_metropolis(static_cast<kmc_user_density*>(c->user_density), ND, &code));
+        KMC_TRY(compile_user_metropolis(static_cast<kmc_user_density*>(c->user_density), ND, &code, nd));
         HIP_TRY(hipModuleLoadData(&b.mod, code->data()));
         HIP_TRY(hipModuleGetFunction(&ufn, b.mod, "kmc_user_metropolis"));
         HIP_TRY(hipModuleGetFunction(&ulp, b.mod, "kmc_user_logpdf"));

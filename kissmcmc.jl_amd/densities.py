@@ -231,6 +231,39 @@ class ExprDensity(DeviceLogPdf):
         return self._eval_rows(X) > -np.inf
 
 
+class CDensity(ExprDensity):
+    """ANY log-density you can write as a C++ function body, compiled at run time (hiprtc) into the device kernels::
+
+        double logpdf(const double* x, int n, const double* p) { BODY }
+
+    over the whole proposal ``x[0..n-1]`` (``n`` = ndim, ``p`` = ``params``, up to 6 doubles): arbitrary coupling between
+    dimensions, loops, locals; ``return -INFINITY;`` rejects.  Example (a banana in any dimension)::
+
+        CDensity("double s = 0; for (int i = 0; i + 1 < n; ++i) { double d = x[i+1] - x[i]*x[i]; s += p[1]*d*d + (p[0]-x[i])*(p[0]-x[i]); } "
+                 "return -s / p[2];", params=[1, 100, 20])
+
+    It runs one walker per lane (the generic kernels), so it is slower than a menu density or an :class:`ExprDensity` of the
+    same form, and orders of magnitude faster than a host callable (:class:`HostLogPdf`).  ``kmc_user_density_create_body``.
+    """
+
+    name = "cbody"
+
+    def __init__(self, body: str, params=()):
+        import ctypes as C
+        if len(params) > 6:
+            raise ValueError("at most 6 parameters")
+        self.body = str(body)
+        self.term, self.pair = None, None
+        self._params = [float(v) for v in params]
+        self._L = _lib.lib()
+        h = C.c_void_p()
+        _lib.check(self._L.kmc_user_density_create_body(self.body.encode(), C.byref(h)))
+        self.user_handle = h
+
+    def __repr__(self):
+        return f"CDensity({self.body!r}, params={self._params})"
+
+
 class HostLogPdf(DeviceLogPdf):
     """ANY Python callable as the log-density -- the reference's ``pdf`` closure
     (``src/samplers.jl:257``) kept on the host.  The stretch move, the random draws, the accept test,

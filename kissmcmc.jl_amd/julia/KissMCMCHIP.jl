@@ -18,7 +18,7 @@ module KissMCMCHIP
 import KissMCMC
 import KissMCMC: emcee, metropolis, make_theta0s, squash_walkers     # extended (emcee, metropolis) / re-exported as they are
 
-export emcee, make_theta0s, squash_walkers, metropolis, metropolis_chains, GaussianStep, HostProposal, int_acorr, GaussianIso, Exponential, Rosenbrock, LogNormal, MvNormal2, ExprDensity, HostLogPdf
+export emcee, make_theta0s, squash_walkers, metropolis, metropolis_chains, GaussianStep, HostProposal, int_acorr, GaussianIso, Exponential, Rosenbrock, LogNormal, MvNormal2, ExprDensity, CDensity, HostLogPdf
 
 using LinearAlgebra: inv
 
@@ -52,6 +52,7 @@ density_id(::MvNormal2) = Cint(4);   params(d::MvNormal2) = [d.mean[1], d.mean[2
 # kmc_user_density_create in include/kissmcmc_hip.h.  The host call evaluates it on the device.
 mutable struct ExprDensity <: DeviceLogPdf
     handle::Ptr{Cvoid}; p::Vector{Float64}
+    ExprDensity(handle::Ptr{Cvoid}, p::Vector{Float64}) = new(handle, p)          # (an existing handle: CDensity below)
     function ExprDensity(term::String, pair::Union{String,Nothing}=nothing; params=Float64[])
         h = Ref{Ptr{Cvoid}}(C_NULL)
         st = ccall((:kmc_user_density_create, LIB), Cint, (Cstring, Cstring, Ref{Ptr{Cvoid}}), term, pair === nothing ? "" : pair, h)
@@ -60,6 +61,16 @@ mutable struct ExprDensity <: DeviceLogPdf
         finalizer(x -> ccall((:kmc_user_density_destroy, LIB), Cvoid, (Ptr{Cvoid},), x.handle), d)
         return d
     end
+end
+# The general device form: the BODY of `double logpdf(const double* x, int n, const double* p) { BODY }` (C++), any coupling
+# between the dimensions; runs one walker per lane (kmc_user_density_create_body).
+function CDensity(body::String; params=Float64[])
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    st = ccall((:kmc_user_density_create_body, LIB), Cint, (Cstring, Ref{Ptr{Cvoid}}), body, h)
+    st == 0 || error("kmc_user_density_create_body failed: $(last_error())")
+    d = ExprDensity(h[], collect(Float64, params))
+    finalizer(x -> ccall((:kmc_user_density_destroy, LIB), Cvoid, (Ptr{Cvoid},), x.handle), d)
+    return d
 end
 density_id(::ExprDensity) = Cint(100); params(d::ExprDensity) = d.p
 user_handle(d::ExprDensity) = d.handle

@@ -90,3 +90,70 @@ def test_expr_density_at_c2_size_speed_and_moments(kmc):
     var = msq / n - mean ** 2
     assert np.all(np.abs(mean) < 0.02) and np.all(np.abs(var - 1.0) < 0.02)
     assert ms / 4000 * 1e3 < 12.0, f"{ms / 4000 * 1e3:.2f} us per half-step"
+
+
+# ---- body densities (CDensity, kmc_user_density_create_body): the whole function over the proposal vector --------------
+C_GAUSS = "double s = 0.0; for (int i = 0; i < n; ++i) { double t = (x[i] - p[0]) * p[1]; s += t * t; } return -0.5 * s;"
+C_ROSEN = ("double s = 0.0; for (int i = 0; i + 1 < n; ++i) { double d = x[i + 1] - x[i] * x[i]; double e = p[0] - x[i]; s += p[1] * (d * d) + e * e; } "
+           "return -(s * (1.0 / p[2]));")
+C_EXPO = "double s = 0.0; for (int i = 0; i < n; ++i) { if (x[i] < 0.0) return -INFINITY; s += x[i]; } return -(p[0] * s);"
+
+
+@pytest.mark.parametrize("case", ["gauss_256x32", "gauss_1000x7", "rosen_128x2", "rosen_512x64", "expo_100x1", "expo_300x16"])
+def test_body_density_equals_the_oracle(kmc, oracle, case):
+    """A C++ function body that restates a menu density in the oracle's own element order: chains, counters AND log-pdfs
+    equal the oracle's (the one-walker-per-lane kernels sum in index order, as the oracle does)."""
+    name, shape = case.split("_")
+    nw, nd = (int(v) for v in shape.split("x"))
+    body, did, params, cparams, scale = {"gauss": (C_GAUSS, oracle.GAUSSIAN_ISO, [0.3, 1.5], [0.3, 1.0 / 1.5], 1.0),
+                                         "rosen": (C_ROSEN, oracle.ROSENBROCK, [1.0, 100.0, 20.0], [1.0, 100.0, 20.0], 0.1),
+                                         "expo": (C_EXPO, oracle.EXPONENTIAL, [1.0], [1.0], None)}[name]
+    rng = np.random.default_rng(7)
+    th = 0.5 + 0.1 * np.abs(rng.standard_normal((nw, nd))) if scale is None else scale * rng.standard_normal((nw, nd))
+    pdf = kmc.CDensity(body, params=cparams)
+    G, nburn, seed = 90, 25, 31
+    got = _run(kmc, pdf, th, G, nburn, seed)
+    _check(oracle, did, params, th, G, nburn, seed, got)
+    ref = oracle.emcee(oracle.make_config(did, params, nw, nd, G, nburn, 1, 2.0, seed), th)
+    if name != "gauss":                                  # same operations in the same order: not even a rounding difference
+        np.testing.assert_array_equal(got["logp"], ref["final_logp"])
+    assert pdf(th[0]) == pytest.approx(oracle.logpdf(did, params, th[0]), rel=1e-14)       # host call = device evaluation
+
+
+def test_body_density_with_real_coupling_samples_its_target(kmc):
+    """A density no term / pair form can express -- a correlated Gaussian with a dense precision matrix built in the body:
+    x' P x with P = (1 + rho) I - rho/n 11' ... here: -0.5 (sum x_i^2 + c (sum x_i)^2): variance of the mean direction
+    1 / (1 + c n), of every orthogonal direction 1."""
+    n, c = 6, 0.5
+    pdf = kmc.CDensity("double s = 0.0, t = 0.0; for (int i = 0; i < n; ++i) { s += x[i] * x[i]; t += x[i]; } return -0.5 * (s + p[0] * t * t);", params=[c])
+    th = np.random.default_rng(1).standard_normal((2048, n))
+    with kmc.Sampler(pdf, 2048, n, 3000, 500, 5, 2.0, 3, store_chain=True) as s:
+        assert "half_step_generic" in s.describe() and "runtime-compiled" in s.describe()
+        s.set_positions(th)
+        s.run(3000)
+        s.sync()
+        ch, _ = s.chain(logp=False)
+    flat = ch.reshape(-1, n)
+    mean_dir = flat.sum(axis=1) / np.sqrt(n)
+    assert abs(mean_dir.var() - 1.0 / (1.0 + c * n)) < 0.02
+    ortho = flat[:, 0] - flat[:, 1]
+    assert abs(ortho.var() / 2.0 - 1.0) < 0.04
+
+
+def test_body_density_other_entry_points(kmc, oracle):
+    """The same handle in the device-side initial ball and in the many-chain Metropolis kernel; errors are reported."""
+    from kissmcmc_jl_amd.metropolis import run_chains
+    pdf = kmc.CDensity(C_EXPO, params=[1.0])
+    ref = oracle.init_ball(oracle.EXPONENTIAL, [1.0], 0.02, 0.1, 2048, 3, seed=7)
+    with kmc.Sampler(pdf, 2048, 3, 10) as s:
+        s.init_ball(0.02, 0.1, seed=7)
+        np.testing.assert_allclose(s.positions(), ref["pos"], rtol=1e-11, atol=1e-13)
+    thm = 0.1 * np.random.default_rng(2).standard_normal((300, 2))
+    a = run_chains(kmc.CDensity(C_ROSEN, params=[1.0, 100.0, 20.0]), kmc.GaussianStep(0.5), thm, 120, 40, 2, 11)
+    b = oracle.metropolis(oracle.ROSENBROCK, [1.0, 100.0, 20.0], thm, 0.5, 120, 40, 2, 11)
+    np.testing.assert_array_equal(a["naccept"], b["naccept"])
+    np.testing.assert_allclose(a["chain"], b["chain"], rtol=1e-11, atol=1e-11)
+    with pytest.raises(kmc.KmcError, match="does not compile"):
+        kmc.CDensity("return x[0] +;")
+    with pytest.raises(kmc.KmcError, match="KMC_ISLANDS"):
+        kmc.Sampler(pdf, 1024, 3, 10, island_gens=8)
