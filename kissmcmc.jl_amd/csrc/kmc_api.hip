@@ -284,7 +284,14 @@ namespace {
 struct UserKernels {
     hipModule_t mod = nullptr;
     hipFunction_t vec = nullptr, generic = nullptr, logpdf = nullptr, resident = nullptr, island = nullptr, init_ball = nullptr;
+    hipFunction_t staged = nullptr;     // body densities, double rows, ndim <= kStagedMaxDim: half_step_staged_body
 };
+
+bool staged_possible(const kmc_user_density* ud, bool f32, int64_t ndim)
+{
+    const char* env = std::getenv("KMC_PLAN");
+    return ud->is_body && !f32 && ndim >= 1 && ndim <= kStagedMaxDim && !(env && std::strcmp(env, "generic") == 0);
+}
 
 }  // namespace
 std::string kmc_host::read_file(const std::string& path)
@@ -344,8 +351,8 @@ kmc_status compile_user(kmc_user_density* ud, bool with_vec, int L, int K, int i
     if (ud->is_body && (with_vec || resident_K > 0 || island_S > 0))
         return fail(KMC_ERR_UNSUPPORTED, "a body density runs in the one-walker-per-lane kernels only");
     char key[112];
-    std::snprintf(key, sizeof(key), "%d:%d,%d,%d,%d|%d,%d|%d|%d|%lld", (int)with_vec, L, K, iter, (int)ragged, resident_K,
-                  (int)resident_ragged, island_S, (int)f32, ud->is_body ? (long long)ndim : 0ll);
+    std::snprintf(key, sizeof(key), "%d:%d,%d,%d,%d|%d,%d|%d|%d|%lld|%d", (int)with_vec, L, K, iter, (int)ragged, resident_K,
+                  (int)resident_ragged, island_S, (int)f32, ud->is_body ? (long long)ndim : 0ll, (int)staged_possible(ud, f32, ndim));
     const char* rowt = f32 ? "float" : "double";       // storage type of the walker rows (KMC_F32 / KMC_F64)
     std::lock_guard<std::mutex> lock(ud->mu);
     auto it = ud->code.find(key);
@@ -363,6 +370,9 @@ kmc_status compile_user(kmc_user_density* ud, bool with_vec, int L, int K, int i
         << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_generic(KMC_FRONT_PARAMS, const kmc::HalfStepArgs a) { kmc::half_step_generic_body<UD, false, " << rowt << ">(KMC_FRONT_PACK, a); }\n"
         << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_logpdf(const kmc::LogpdfArgs a) { kmc::logpdf_rows_body<UD>(a); }\n"
         << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_init_ball(const kmc::InitBallArgs a) { kmc::init_ball_body<UD>(a); }\n";
+    if (staged_possible(ud, f32, ndim))
+        src << "extern \"C\" __global__ __launch_bounds__(" << kStagedTPB << ") void kmc_user_staged(KMC_FRONT_PARAMS, const kmc::HalfStepArgs a) { kmc::half_step_staged_body<UD, "
+            << ndim << ">(KMC_FRONT_PACK, a); }\n";
     if (with_vec)
         src << "extern \"C\" __global__ __launch_bounds__(" << vec_tpb(L) << ") void kmc_user_vec(KMC_FRONT_PARAMS, const kmc::HalfStepArgs a) { kmc::half_step_vec_body<UD, "
             << L << ", " << K << ", " << iter << ", false, " << (ragged ? "true" : "false") << ", " << rowt << ">(KMC_FRONT_PACK, a); }\n";
@@ -409,6 +419,7 @@ kmc_status load_user(kmc_user_density* ud, bool with_vec, int L, int K, int iter
     HIP_TRY(hipModuleGetFunction(&uk->logpdf, uk->mod, "kmc_user_logpdf"));
     HIP_TRY(hipModuleGetFunction(&uk->init_ball, uk->mod, "kmc_user_init_ball"));
     if (with_vec) HIP_TRY(hipModuleGetFunction(&uk->vec, uk->mod, "kmc_user_vec"));
+    if (staged_possible(ud, f32, ndim)) HIP_TRY(hipModuleGetFunction(&uk->staged, uk->mod, "kmc_user_staged"));
     if (resident_K > 0 && island_S == 0) HIP_TRY(hipModuleGetFunction(&uk->resident, uk->mod, "kmc_user_resident"));
     if (resident_K > 0 && island_S > 0) HIP_TRY(hipModuleGetFunction(&uk->island, uk->mod, "kmc_user_island"));
     return KMC_OK;
@@ -677,6 +688,7 @@ hipError_t launch_half_kernel(const kmc_sampler* s, const HalfStepArgs& a)
     const HalfStepFront f = front_of(a);
     if (s->user) {
         const HalfStepLaunch la{f, a};
+        if (s->uk.staged) return launch_module(s->uk.staged, (unsigned)s->grid, (unsigned)s->tpb, s->stream, la, (unsigned)staged_lds_bytes((int)s->cfg.ndim));
         return launch_module(s->plan.vec ? s->uk.vec : s->uk.generic, (unsigned)s->grid, (unsigned)s->tpb, s->stream, la);
     }
     hipLaunchKernelGGL(s->plan.fn, dim3(s->grid), dim3(s->tpb), 0, s->stream, f.pos, f.sched, f.ring_now, f.logp, f.gw0, f.nact_half,
@@ -1198,7 +1210,8 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         }
     }
     // vec kernels: vec_tpb(L) threads per workgroup; the generic kernel keeps 256
-    const int tpb = s->plan.vec ? vec_tpb(s->plan.L) : 256;
+    const bool staged = s->user && s->uk.staged != nullptr;         // a body density's staged kernel: two waves per workgroup
+    const int tpb = s->plan.vec ? vec_tpb(s->plan.L) : (staged ? kStagedTPB : 256);
     s->tpb = tpb;
     s->grid = (int)((waves * 64 + tpb - 1) / tpb);
     s->macc_stride = (int64_t)s->grid * tpb;
@@ -2094,7 +2107,8 @@ KMC_EXPORT kmc_status kmc_sampler_describe(const kmc_sampler* s, char* buf, int6
             o << b;
         }
     } else
-        o << "multi-launch (exact): half_step_generic (one walker per lane), grid " << s->grid << " x 256";
+        o << "multi-launch (exact): " << (s->user && s->uk.staged ? "half_step_staged (one walker per lane, rows staged through LDS)" : "half_step_generic (one walker per lane)")
+          << ", grid " << s->grid << " x " << s->tpb;
     if (s->lazy) o << "; lazy pull into local copies (KMC_P2P_LAZY)";
     else if (s->push) o << "; accepted rows pushed into the peers' local copies (KMC_P2P_PUSH)";
     if (s->f32) o << "; rows kept in float (KMC_F32), arithmetic in double";

@@ -1040,6 +1040,140 @@ __global__ __launch_bounds__(256) void half_step_generic(KMC_FRONT_PARAMS, const
     half_step_generic_body<Dens, P2P, T>(KMC_FRONT_PACK, a);
 }
 
+// ------------------------------------------------------------------------------------------
+// Staged kernel for body densities (BodyDensity: the whole proposal per lane; ndim = ND known when the runtime compiler
+// instantiates it).  One walker per lane like the generic kernel, but no lane ever walks its own row in memory (64 lanes
+// x one 8-byte element of 64 different rows = 64 cache lines per load instruction): a wave's 64 own rows and its 64
+// partner rows are fetched COOPERATIVELY -- 16 B per lane, consecutive lanes on consecutive chunks of a row, the own
+// block one contiguous stream -- through a per-wave LDS tile (64 rows x TD doubles, padded) and handed to the lanes as
+// private arrays, which the compiler keeps in registers for short rows.  Accepted rows go back the same way.  Same
+// draws, same arithmetic and element order as half_step_generic (results identical); double rows, one GPU.
+// ------------------------------------------------------------------------------------------
+constexpr int kStagedTPB = 128;                                          // two waves per workgroup, one LDS tile each
+constexpr int kStagedMaxDim = 64;                                        // two rows + the proposal per lane stay in registers
+__host__ __device__ constexpr int staged_tile_doubles(int nd) { return nd + (nd & 1) < 32 ? nd + (nd & 1) : 32; }
+__host__ __device__ constexpr size_t staged_lds_bytes(int nd) { return (size_t)(kStagedTPB / 64) * 64 * (size_t)(staged_tile_doubles(nd) + 1) * sizeof(double); }
+
+template <class Dens, int ND>
+__device__ __forceinline__ void half_step_staged_body(const HalfStepFront& f, const HalfStepArgs& a)
+{
+    constexpr int LD = ND + (ND & 1);                 // row stride in doubles
+    constexpr int TD = staged_tile_doubles(ND);       // tile width (doubles); TD / 2 16-byte chunks per row piece
+    constexpr int CPR = TD / 2;                       // chunks per row piece
+    constexpr int NT = (LD + TD - 1) / TD;            // tiles per row
+    extern __shared__ double staged_lds[];
+    const int lane = threadIdx.x & 63;
+    double* tile = staged_lds + (size_t)(threadIdx.x >> 6) * 64 * (TD + 1);
+    const int tid = blockIdx.x * kStagedTPB + threadIdx.x;
+    const int w0 = (tid >> 6) * 64;                   // first active index of this wave
+    const SchedEntry sch = schedule_of(f, a);
+    const uint64_t step = 2ull * (uint64_t)sch.gen + (uint64_t)a.half;
+    const int nact = a.n_active;
+    if (w0 >= nact) return;                           // (whole waves only)
+    const bool valid = tid < nact;
+    const int  ic = valid ? tid : nact - 1;
+    const bool count  = (sch.flags & kCount) != 0;
+    const bool sample = (sch.flags & kSample) != 0;
+    const int64_t gw = a.own_row0 + ic;
+    const Draw dr = draw_step(a.dc, step, (uint64_t)(a.gw0 + ic));
+    const double p0 = a.logp[gw];
+    const int rows_here = nact - w0 < 64 ? nact - w0 : 64;
+
+    // row r of the tile <- piece [c0, c0 + TD) of global row `grow(r)`; lane q handles chunk q % CPR of tile row q / CPR.
+    // All of a piece's loads are issued before the first LDS write (a chunk beyond the row's end re-reads the last one
+    // and lands in tile columns nobody reads), so that a wave has CPR loads in flight rather than one.
+    double xc[LD], xo[LD];
+    auto fetch = [&](auto grow, double (&dst)[LD]) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int c0 = t * TD;
+            double2 v[CPR];
+#pragma unroll
+            for (int i = 0; i < CPR; ++i) {
+                const int q = i * 64 + lane, r = q / CPR, ch = q - r * CPR;
+                const int col = c0 + 2 * ch < LD ? c0 + 2 * ch : LD - 2;
+                v[i] = *reinterpret_cast<const double2*>(a.pos + grow(r) * (int64_t)LD + col);
+            }
+#pragma unroll
+            for (int i = 0; i < CPR; ++i) {
+                const int q = i * 64 + lane, r = q / CPR, ch = q - r * CPR;
+                tile[r * (TD + 1) + 2 * ch] = v[i].x;
+                tile[r * (TD + 1) + 2 * ch + 1] = v[i].y;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int e = 0; e < TD; ++e)
+                if (c0 + e < LD) dst[c0 + e] = tile[lane * (TD + 1) + e];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    };
+    fetch([&](int r) { return a.own_row0 + w0 + (r < rows_here ? r : rows_here - 1); }, xc);
+    fetch([&](int r) { return a.oth_row0 + (int64_t)(uint32_t)__shfl((int)dr.partner, r); }, xo);
+
+    typename Dens::Seq q;
+    Dens::seq_init(q);
+#pragma unroll
+    for (int d = 0; d < ND; ++d) Dens::seq_add(q, fma(dr.z, xc[d] - xo[d], xo[d]), d, a.dp);   // :255
+    const double p1 = Dens::seq_finish(q, ND, a.dp);                    // :257
+    const bool acc = valid && accept_test(dr, p1, p0);                  // :260
+
+    const bool do_mom = valid && sample && a.msum != nullptr;
+    const bool do_chain = sample && a.chain != nullptr;
+    const int64_t crow = sch.slot * a.chain_rows + a.chain_row0;        // chain row of this launch's active walker 0
+    if (do_mom) {                                                       // per-lane accumulators, eight dimensions' loads in flight
+#pragma unroll
+        for (int d0 = 0; d0 < ND; d0 += 8) {
+            double s1[8], s2[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (d0 + k < ND) { s1[k] = a.msum[(int64_t)(d0 + k) * a.macc_stride + tid]; s2[k] = a.msumsq[(int64_t)(d0 + k) * a.macc_stride + tid]; }
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (d0 + k < ND) {
+                    const int d = d0 + k;
+                    const double cur = acc ? fma(dr.z, xc[d] - xo[d], xo[d]) : xc[d];
+                    a.msum[(int64_t)d * a.macc_stride + tid] = s1[k] + cur;
+                    a.msumsq[(int64_t)d * a.macc_stride + tid] = s2[k] + cur * cur;
+                }
+        }
+    }
+    // rows out: through the tile again, so that the stores are 16 B per lane on consecutive chunks (:261, :269)
+    const unsigned long long accmask = __ballot(acc);
+    if (accmask != 0ull || do_chain) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int c0 = t * TD;
+#pragma unroll
+            for (int e = 0; e < TD; ++e)
+                if (c0 + e < LD)                                        // (the pad column of an odd ndim stays zero)
+                    tile[lane * (TD + 1) + e] = c0 + e >= ND ? 0.0 : (acc ? fma(dr.z, xc[c0 + e] - xo[c0 + e], xo[c0 + e]) : xc[c0 + e]);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int q0 = 0; q0 < 64 * CPR; q0 += 64) {
+                const int qq = q0 + lane, r = qq / CPR, ch = qq - r * CPR;
+                if (c0 + 2 * ch < LD && r < rows_here) {
+                    const double2 v = make_double2(tile[r * (TD + 1) + 2 * ch], tile[r * (TD + 1) + 2 * ch + 1]);
+                    if ((accmask >> r) & 1ull)
+                        *reinterpret_cast<double2*>(a.pos + (a.own_row0 + w0 + r) * (int64_t)LD + c0 + 2 * ch) = v;
+                    if (do_chain)
+                        *reinterpret_cast<double2*>(a.chain + (crow + w0 + r) * (int64_t)LD + c0 + 2 * ch) = v;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (acc) {
+        a.logp[gw] = p1;                                                // :262
+        if (count) a.naccept[gw] += 1u;                                 // :265
+    }
+    if (valid && sample && a.chain_logp != nullptr) a.chain_logp[crow + tid] = acc ? p1 : p0;   // :271
+}
+
 // Initial log-pdfs, src/samplers.jl:209.
 struct LogpdfArgs {
     const double* pos;

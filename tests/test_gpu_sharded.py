@@ -9,12 +9,13 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("P", [2, 4, 8])
-def test_logical_shards_on_one_gpu_equal_unsharded(kmc, oracle, P):
+@pytest.mark.parametrize("P,form", [(2, "menu"), (4, "menu"), (8, "menu"), (2, "body"), (4, "body")])
+def test_logical_shards_on_one_gpu_equal_unsharded(kmc, oracle, P, form):
     import torch
     nw, nd, G, nburn, seed = 512, 32, 12, 4, 21
     th = np.random.default_rng(1).standard_normal((nw, nd))
-    pdf = kmc.GaussianIso()
+    # "body": the runtime-compiled function-body form of the same density (its staged one-walker-per-lane kernel)
+    pdf = kmc.GaussianIso() if form == "menu" else kmc.CDensity("double s = 0.0; for (int i = 0; i < n; ++i) { double t = (x[i] - p[0]) * p[1]; s += t * t; } return -0.5 * s;", params=[0.0, 1.0])
     pos = torch.empty((nw, nd), dtype=torch.float64, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
     shards = []

@@ -99,11 +99,14 @@ C_ROSEN = ("double s = 0.0; for (int i = 0; i + 1 < n; ++i) { double d = x[i + 1
 C_EXPO = "double s = 0.0; for (int i = 0; i < n; ++i) { if (x[i] < 0.0) return -INFINITY; s += x[i]; } return -(p[0] * s);"
 
 
-@pytest.mark.parametrize("case", ["gauss_256x32", "gauss_1000x7", "rosen_128x2", "rosen_512x64", "expo_100x1", "expo_300x16"])
-def test_body_density_equals_the_oracle(kmc, oracle, case):
+@pytest.mark.parametrize("case", ["gauss_256x32", "gauss_1000x7", "rosen_128x2", "rosen_512x64", "expo_100x1", "expo_300x16",
+                                  "gauss_200x33", "rosen_130x63", "gauss_96x65", "rosen_200x130", "gauss_256x32_generic"])
+def test_body_density_equals_the_oracle(kmc, oracle, case, monkeypatch):
     """A C++ function body that restates a menu density in the oracle's own element order: chains, counters AND log-pdfs
     equal the oracle's (the one-walker-per-lane kernels sum in index order, as the oracle does)."""
-    name, shape = case.split("_")
+    name, shape = case.split("_")[:2]
+    if case.endswith("_generic"):
+        monkeypatch.setenv("KMC_PLAN", "generic")        # the unstaged one-walker-per-lane kernel (what ndim > 64 runs)
     nw, nd = (int(v) for v in shape.split("x"))
     body, did, params, cparams, scale = {"gauss": (C_GAUSS, oracle.GAUSSIAN_ISO, [0.3, 1.5], [0.3, 1.0 / 1.5], 1.0),
                                          "rosen": (C_ROSEN, oracle.ROSENBROCK, [1.0, 100.0, 20.0], [1.0, 100.0, 20.0], 0.1),
@@ -112,6 +115,8 @@ def test_body_density_equals_the_oracle(kmc, oracle, case):
     th = 0.5 + 0.1 * np.abs(rng.standard_normal((nw, nd))) if scale is None else scale * rng.standard_normal((nw, nd))
     pdf = kmc.CDensity(body, params=cparams)
     G, nburn, seed = 90, 25, 31
+    with kmc.Sampler(pdf, nw, nd, G, nburn, 1, 2.0, seed) as s:
+        assert ("half_step_staged" in s.describe()) == (nd <= 64 and not case.endswith("_generic"))
     got = _run(kmc, pdf, th, G, nburn, seed)
     _check(oracle, did, params, th, G, nburn, seed, got)
     ref = oracle.emcee(oracle.make_config(did, params, nw, nd, G, nburn, 1, 2.0, seed), th)
@@ -128,7 +133,7 @@ def test_body_density_with_real_coupling_samples_its_target(kmc):
     pdf = kmc.CDensity("double s = 0.0, t = 0.0; for (int i = 0; i < n; ++i) { s += x[i] * x[i]; t += x[i]; } return -0.5 * (s + p[0] * t * t);", params=[c])
     th = np.random.default_rng(1).standard_normal((2048, n))
     with kmc.Sampler(pdf, 2048, n, 3000, 500, 5, 2.0, 3, store_chain=True) as s:
-        assert "half_step_generic" in s.describe() and "runtime-compiled" in s.describe()
+        assert "half_step_staged" in s.describe() and "runtime-compiled" in s.describe()
         s.set_positions(th)
         s.run(3000)
         s.sync()
