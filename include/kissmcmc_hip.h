@@ -205,7 +205,7 @@ double      kmc_cdf_g_inv(double u, double a);
  *        term_expr may use  x (= x_d), d, n (= ndim), p (const double*, = params[0..5]);
  *        pair_expr may use  x (= x_d), y (= x_{d+1}), d, n, p;   NULL/"" = no pair term.
  *      A term may evaluate to -INFINITY to reject a proposal.  Works in the multi-launch, resident and
- *      island modes; not available with KMC_P2P. */
+ *      island modes and under KMC_P2P (the plain pull; the push / lazy / folded-signal variants are menu densities only). */
 kmc_status  kmc_user_density_create(const char* term_expr, const char* pair_expr, kmc_user_density** out);
 /* The general form: the BODY of a C++ function
  *     double logpdf(const double* x, int n, const double* p) { BODY }
@@ -213,7 +213,7 @@ kmc_status  kmc_user_density_create(const char* term_expr, const char* pair_expr
  * return -INFINITY to reject.  Runs in the one-walker-per-lane kernels (the proposal is collected per lane, ndim <= 1024;
  * for double rows of ndim <= 64 the rows are staged through LDS so that memory is still read in whole rows):
  * emcee (multi-launch), initial log-pdfs, kmc_sampler_init_ball, many-chain Metropolis -- slower than a menu or term / pair
- * density of the same form (those stripe a row over lanes), far faster than a host callback.  Not with KMC_ISLANDS / KMC_P2P. */
+ * density of the same form (those stripe a row over lanes), far faster than a host callback.  Not with KMC_ISLANDS; under KMC_P2P the unstaged kernel. */
 kmc_status  kmc_user_density_create_body(const char* body, kmc_user_density** out);
 void        kmc_user_density_destroy(kmc_user_density* ud);
 

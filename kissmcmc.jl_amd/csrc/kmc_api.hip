@@ -287,10 +287,10 @@ struct UserKernels {
     hipFunction_t staged = nullptr;     // body densities, double rows, ndim <= kStagedMaxDim: half_step_staged_body
 };
 
-bool staged_possible(const kmc_user_density* ud, bool f32, int64_t ndim)
+bool staged_possible(const kmc_user_density* ud, bool f32, int64_t ndim, bool p2p = false)
 {
     const char* env = std::getenv("KMC_PLAN");
-    return ud->is_body && !f32 && ndim >= 1 && ndim <= kStagedMaxDim && !(env && std::strcmp(env, "generic") == 0);
+    return ud->is_body && !f32 && !p2p && ndim >= 1 && ndim <= kStagedMaxDim && !(env && std::strcmp(env, "generic") == 0);
 }
 
 }  // namespace
@@ -345,14 +345,16 @@ std::string kmc_host::user_header_dir()
 namespace {
 
 kmc_status compile_user(kmc_user_density* ud, bool with_vec, int L, int K, int iter, bool ragged,
-                        int resident_K, bool resident_ragged, int island_S, bool f32, const std::vector<char>** out, int64_t ndim = 0)
+                        int resident_K, bool resident_ragged, int island_S, bool f32, const std::vector<char>** out, int64_t ndim = 0,
+                        bool p2p = false)
 {
     // resident_K also sizes the island kernel (same row striping: 2 lanes per walker, K chunks)
     if (ud->is_body && (with_vec || resident_K > 0 || island_S > 0))
         return fail(KMC_ERR_UNSUPPORTED, "a body density runs in the one-walker-per-lane kernels only");
     char key[112];
-    std::snprintf(key, sizeof(key), "%d:%d,%d,%d,%d|%d,%d|%d|%d|%lld|%d", (int)with_vec, L, K, iter, (int)ragged, resident_K,
-                  (int)resident_ragged, island_S, (int)f32, ud->is_body ? (long long)ndim : 0ll, (int)staged_possible(ud, f32, ndim));
+    std::snprintf(key, sizeof(key), "%d:%d,%d,%d,%d|%d,%d|%d|%d|%lld|%d|%d", (int)with_vec, L, K, iter, (int)ragged, resident_K,
+                  (int)resident_ragged, island_S, (int)f32, ud->is_body ? (long long)ndim : 0ll, (int)staged_possible(ud, f32, ndim, p2p), (int)p2p);
+    const char* peer = p2p ? "true" : "false";         // KMC_P2P: partner rows read from their owners (pull)
     const char* rowt = f32 ? "float" : "double";       // storage type of the walker rows (KMC_F32 / KMC_F64)
     std::lock_guard<std::mutex> lock(ud->mu);
     auto it = ud->code.find(key);
@@ -367,15 +369,15 @@ kmc_status compile_user(kmc_user_density* ud, bool with_vec, int L, int K, int i
 
     std::ostringstream src;
     src << "#include \"kmc_islands.hpp\"\n" << user_functor_source(ud) << user_density_alias(ud, ndim)
-        << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_generic(KMC_FRONT_PARAMS, const kmc::HalfStepArgs a) { kmc::half_step_generic_body<UD, false, " << rowt << ">(KMC_FRONT_PACK, a); }\n"
+        << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_generic(KMC_FRONT_PARAMS, const kmc::HalfStepArgs a) { kmc::half_step_generic_body<UD, " << peer << ", " << rowt << ">(KMC_FRONT_PACK, a); }\n"
         << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_logpdf(const kmc::LogpdfArgs a) { kmc::logpdf_rows_body<UD>(a); }\n"
         << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_init_ball(const kmc::InitBallArgs a) { kmc::init_ball_body<UD>(a); }\n";
-    if (staged_possible(ud, f32, ndim))
+    if (staged_possible(ud, f32, ndim, p2p))
         src << "extern \"C\" __global__ __launch_bounds__(" << kStagedTPB << ") void kmc_user_staged(KMC_FRONT_PARAMS, const kmc::HalfStepArgs a) { kmc::half_step_staged_body<UD, "
             << ndim << ">(KMC_FRONT_PACK, a); }\n";
     if (with_vec)
         src << "extern \"C\" __global__ __launch_bounds__(" << vec_tpb(L) << ") void kmc_user_vec(KMC_FRONT_PARAMS, const kmc::HalfStepArgs a) { kmc::half_step_vec_body<UD, "
-            << L << ", " << K << ", " << iter << ", false, " << (ragged ? "true" : "false") << ", " << rowt << ">(KMC_FRONT_PACK, a); }\n";
+            << L << ", " << K << ", " << iter << ", " << peer << ", " << (ragged ? "true" : "false") << ", " << rowt << ">(KMC_FRONT_PACK, a); }\n";
     if (resident_K > 0 && island_S == 0)
         src << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_resident(const kmc::ResidentArgs a) { kmc::resident_body<UD, "
             << resident_K << ", " << (resident_ragged ? "true" : "false") << ">(a); }\n";
@@ -410,16 +412,16 @@ kmc_status compile_user(kmc_user_density* ud, bool with_vec, int L, int K, int i
 }
 
 kmc_status load_user(kmc_user_density* ud, bool with_vec, int L, int K, int iter, bool ragged, UserKernels* uk,
-                     int resident_K = 0, bool resident_ragged = false, int island_S = 0, bool f32 = false, int64_t ndim = 0)
+                     int resident_K = 0, bool resident_ragged = false, int island_S = 0, bool f32 = false, int64_t ndim = 0, bool p2p = false)
 {
     const std::vector<char>* code = nullptr;
-    KMC_TRY(compile_user(ud, with_vec, L, K, iter, ragged, resident_K, resident_ragged, island_S, f32, &code, ndim));
+    KMC_TRY(compile_user(ud, with_vec, L, K, iter, ragged, resident_K, resident_ragged, island_S, f32, &code, ndim, p2p));
     HIP_TRY(hipModuleLoadData(&uk->mod, code->data()));
     HIP_TRY(hipModuleGetFunction(&uk->generic, uk->mod, "kmc_user_generic"));
     HIP_TRY(hipModuleGetFunction(&uk->logpdf, uk->mod, "kmc_user_logpdf"));
     HIP_TRY(hipModuleGetFunction(&uk->init_ball, uk->mod, "kmc_user_init_ball"));
     if (with_vec) HIP_TRY(hipModuleGetFunction(&uk->vec, uk->mod, "kmc_user_vec"));
-    if (staged_possible(ud, f32, ndim)) HIP_TRY(hipModuleGetFunction(&uk->staged, uk->mod, "kmc_user_staged"));
+    if (staged_possible(ud, f32, ndim, p2p)) HIP_TRY(hipModuleGetFunction(&uk->staged, uk->mod, "kmc_user_staged"));
     if (resident_K > 0 && island_S == 0) HIP_TRY(hipModuleGetFunction(&uk->resident, uk->mod, "kmc_user_resident"));
     if (resident_K > 0 && island_S > 0) HIP_TRY(hipModuleGetFunction(&uk->island, uk->mod, "kmc_user_island"));
     return KMC_OK;
@@ -1130,7 +1132,6 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
     if (st != KMC_OK) { delete s; return st; }
     s->plan = make_plan(s->cfg, s->h_loc);
     if (cfg->density == KMC_USER_DENSITY) {
-        if (cfg->flags & KMC_P2P) { delete s; return fail(KMC_ERR_UNSUPPORTED, "user densities are not available with KMC_P2P yet"); }
         s->user = static_cast<kmc_user_density*>(cfg->user_density);
         // small ensembles: resident mode too (one workgroup, LDS within the default 64 KiB limit)
         int rK = 0, rK0 = 1;
@@ -1147,7 +1148,7 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         }
         if (s->user->is_body && iS > 0) { kmc_sampler_destroy(s); return fail(KMC_ERR_UNSUPPORTED, "KMC_ISLANDS needs a menu or term / pair density (a body density runs one walker per lane)"); }
         if (s->user->is_body && cfg->ndim > 1024) { kmc_sampler_destroy(s); return fail(KMC_ERR_UNSUPPORTED, "a body density holds the proposal per lane: ndim <= 1024"); }
-        st = load_user(s->user, s->plan.vec, s->plan.L, s->plan.K, s->plan.ITER, s->plan.ragged, &s->uk, rK, 4 * rK != cfg->ndim, iS, s->f32, cfg->ndim);
+        st = load_user(s->user, s->plan.vec, s->plan.L, s->plan.K, s->plan.ITER, s->plan.ragged, &s->uk, rK, 4 * rK != cfg->ndim, iS, s->f32, cfg->ndim, (cfg->flags & KMC_P2P) != 0);
         if (st != KMC_OK) { kmc_sampler_destroy(s); return st; }
         if (iS > 0) rK = 0;     // island mode is set up below, not resident mode
         if (rK > 0) {

@@ -255,3 +255,40 @@ def test_two_shards_in_one_process(kmc, oracle, kw):
     ref = oracle.emcee(oracle.make_config(oracle.GAUSSIAN_ISO, [0.0, 1.0], NW, ND, G, NBURN, 1, 2.0, SEED), th, store_chain=False)
     np.testing.assert_array_equal(pos, ref["final_pos"])
     np.testing.assert_array_equal(nacc, ref["naccept"])
+
+
+@pytest.mark.parametrize("form", ["expr", "body"])
+def test_two_p2p_shards_with_a_runtime_compiled_density(kmc, oracle, form):
+    """Runtime-compiled densities run under KMC_P2P too (the pull kernels are instantiated with the user's functor):
+    Rosenbrock as term / pair expressions (lane-striped kernel) and as a function body (one walker per lane),
+    two shards in one process, result = the oracle's menu Rosenbrock."""
+    import torch
+    nw, nd, G, nburn, seed = 1024, 16, 128, 30, 99
+    th = 0.1 * np.random.default_rng(3).standard_normal((nw, nd))
+    if form == "expr":
+        pdf = kmc.ExprDensity("d < n-1 ? -((p[0]-x)*(p[0]-x))/p[2] : 0.0", "-(p[1]*((y-x*x)*(y-x*x)))/p[2]", [1.0, 100.0, 20.0])
+    else:
+        pdf = kmc.CDensity("double s = 0.0; for (int i = 0; i + 1 < n; ++i) { double d = x[i + 1] - x[i] * x[i]; double e = p[0] - x[i]; "
+                           "s += p[1] * (d * d) + e * e; } return -(s * (1.0 / p[2]));", params=[1.0, 100.0, 20.0])
+    shards = [kmc.Sampler(pdf, nw, nd, G, nburn, 1, 2.0, seed, moments=True, shard_rank=r, shard_count=2, p2p=True) for r in range(2)]
+    streams = [torch.cuda.Stream(device=0, priority=-1), torch.cuda.Stream(device=0, priority=0)]
+    try:
+        assert ("half_step_vec" if form == "expr" else "half_step_generic") in shards[0].describe()
+        for sh, st in zip(shards, streams):
+            sh.set_stream(st.cuda_stream)
+        kmc.Sampler.p2p_connect_local(shards)
+        for sh in shards:
+            sh.set_positions(th)
+        for sh in shards:
+            sh.run(G)
+        for sh in shards:
+            sh.sync()
+        from kissmcmc_jl_amd.distributed import local_to_global
+        pos = local_to_global([sh.positions() for sh in shards], nw, 2)
+        nacc = local_to_global([sh.naccept() for sh in shards], nw, 2)
+    finally:
+        for sh in shards:
+            sh.close()
+    ref = oracle.emcee(oracle.make_config(oracle.ROSENBROCK, [1.0, 100.0, 20.0], nw, nd, G, nburn, 1, 2.0, seed), th, store_chain=False)
+    np.testing.assert_array_equal(pos, ref["final_pos"])
+    np.testing.assert_array_equal(nacc, ref["naccept"])
