@@ -113,6 +113,10 @@ enum {
                                     their final position; if that fails they are ordinary (staged) copies.  KMC_F64, one GPU
                                     (no KMC_P2P / sharding / KMC_ISLANDS); small ensembles then run the multi-launch kernels.
                                     kmc_emcee_run switches it on by itself when the chain would not fit the device. */
+    KMC_CHAIN_BY_WALKER = 1u << 12, /* kmc_emcee_run only: kmc_outputs.chain is [nwalkers][nsamples][ndim] and chain_logp
+                                    [nwalkers][nsamples] -- the reference's own order, thetas[w][k] (src/samplers.jl:219-221,
+                                    :268-272) -- instead of sample-major.  Transposed on the device before the copy
+                                    (kmc_sampler_get_chain_by_walker).  Refused when the chain has to be streamed. */
     KMC_P2P_FINEGRAINED = 1u << 7, /* with KMC_P2P: keep the rows in fine-grained (coherent, uncached-for-peers) device memory */
     KMC_P2P_PUSH    = 1u << 9, /* with KMC_P2P: every rank keeps local copies ("shadows") of all the other shards and reads its
                                   partner rows from them; a rank that accepts a move writes the new row into its shadow on
@@ -319,6 +323,11 @@ kmc_status  kmc_sampler_get_moments(kmc_sampler* s, double* sum, double* sumsq /
  * shard_count, local order = (first-half slice, second-half slice).  With shard_count == 1
  * this is the global walker order. */
 kmc_status  kmc_sampler_get_chain(kmc_sampler* s, double* chain, double* chain_logp);
+/* The same samples in the reference's order (thetas[w][k], logdensities[w][k], src/samplers.jl:219-221, :268-272):
+ * chain [nlocal][k][ndim], chain_logp [nlocal][k], k = samples stored so far (= nsamples after a complete run), dense.
+ * Transposed on the device in pieces of walkers and copied out contiguously, so the host never reorders gigabytes
+ * (what squash_walkers' default, walker-major, concatenation wants; src/samplers.jl:395-413).  Not with KMC_STREAM_CHAIN. */
+kmc_status  kmc_sampler_get_chain_by_walker(kmc_sampler* s, double* chain, double* chain_logp);
 
 /* ---- dealt sub-ensembles: the multi-GPU mode WITHOUT a per-half-step exchange (opt-in extension) ----
  *

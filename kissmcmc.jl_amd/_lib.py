@@ -27,6 +27,7 @@ F32 = 1       # rows and chain kept in float on the device; arithmetic and host 
 STORE_CHAIN, STORE_LOGP, MOMENTS, NO_GRAPH, P2P, ISLANDS, P2P_FINEGRAINED, P2P_FOLD_SIGNAL, P2P_PUSH = 1, 2, 4, 8, 16, 64, 128, 256, 512
 P2P_LAZY = 1024
 STREAM_CHAIN = 2048
+CHAIN_BY_WALKER = 4096
 P2P_HANDLE_BYTES = 128
 RCCL_ID_BYTES = 128
 
@@ -38,7 +39,7 @@ SYMBOLS = [
     "kmc_sampler_sync", "kmc_sampler_last_run_ms", "kmc_sampler_generation", "kmc_sampler_nsamples",
     "kmc_sampler_launch_count", "kmc_sampler_describe", "kmc_sampler_device_ptr", "kmc_sampler_get_positions",
     "kmc_sampler_get_logp", "kmc_sampler_get_naccept", "kmc_sampler_get_accept_ratio",
-    "kmc_sampler_get_moments", "kmc_sampler_get_chain", "kmc_logpdf_eval", "kmc_logpdf_eval_host",
+    "kmc_sampler_get_moments", "kmc_sampler_get_chain", "kmc_sampler_get_chain_by_walker", "kmc_logpdf_eval", "kmc_logpdf_eval_host",
     "kmc_user_density_create", "kmc_user_density_create_body", "kmc_user_density_destroy", "kmc_metropolis_validate", "kmc_metropolis_run", "kmc_int_acorr", "kmc_sampler_int_acorr",
     "kmc_sizeof_config", "kmc_sizeof_metropolis_config", "kmc_deal_seed", "kmc_deal_perm", "kmc_sampler_deal_pack", "kmc_sampler_deal_unpack",
     "kmc_sampler_get_walker_ids", "kmc_sampler_set_chain_host", "kmc_rccl_unique_id", "kmc_sampler_rccl_init",
@@ -199,6 +200,7 @@ def lib() -> C.CDLL:
     L.kmc_sampler_get_accept_ratio.argtypes = [vp, dp]
     L.kmc_sampler_get_moments.argtypes = [vp, dp, dp, ip]
     L.kmc_sampler_get_chain.argtypes = [vp, dp, dp]
+    L.kmc_sampler_get_chain_by_walker.argtypes = [vp, dp, dp]
     L.kmc_logpdf_eval.argtypes = [cfgp, vp, vp, C.c_int64, vp]
     L.kmc_logpdf_eval_host.argtypes = [cfgp, dp, dp, C.c_int64]
     L.kmc_user_density_create.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(vp)]

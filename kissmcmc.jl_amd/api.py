@@ -133,16 +133,14 @@ def emcee(pdf, theta0s, niter: int = 10 ** 5, nburnin=None, nthin: int = 1, a_sc
             pdf.on_accepted = on_accepted
         try:
             _run_generations(s, niter, nwalkers, niter_walker, nburnin_walker, use_progress_meter)
-            chain, chain_logp = s.chain(logp=True)
+            thetas, logdensities = s.chain(logp=True, by_walker=True)     # [walker][sample][dim], [walker][sample]: :219-221
             accept_ratio = s.accept_ratio()
         finally:
             if hasblob:
                 pdf.on_accepted = None                         # the closure holds this call's blob storage
 
-    thetas = np.ascontiguousarray(chain.transpose(1, 0, 2))    # [walker][sample][dim]
     if scalar_walkers:
         thetas = thetas[:, :, 0]
-    logdensities = np.ascontiguousarray(chain_logp.T)          # [walker][sample]
     assert thetas.shape[1] == nsamples_walker
     return thetas, accept_ratio, logdensities, blobs
 
@@ -257,7 +255,9 @@ def squash_walkers(thetas, accept_ratio, logdensities=None, blobs=None, drop_low
         walkers2keep = np.arange(nwalkers)                     # :395
 
     def flat(a):
-        a = np.asarray(a)[walkers2keep]                        # [kept][sample](...)
+        a = np.asarray(a)
+        if len(walkers2keep) != a.shape[0]:
+            a = a[walkers2keep]                                # [kept][sample](...); keeping all: a view, no copy
         if order:                                              # :415-426: stable sort by sample index
             a = np.swapaxes(a, 0, 1)
         return np.ascontiguousarray(a).reshape((-1,) + a.shape[2:])

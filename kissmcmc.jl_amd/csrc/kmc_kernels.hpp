@@ -1373,6 +1373,24 @@ __global__ __launch_bounds__(256) void deal_init_ids(uint32_t* ids, int64_t S, u
     if (i < S) ids[i] = first + (uint32_t)i;
 }
 
+// Chain read-out in the reference's order, thetas[walker][sample] (src/samplers.jl:219-221, :268-272): walkers
+// [w0, w0 + gridDim.x) of the stored chain [sample][walker][ld] -> dense [walker][sample][ndim] doubles (also the
+// log-pdfs, as rows of one element).  One workgroup column per walker; writes are contiguous, reads are whole rows.
+template <class T>
+__global__ __launch_bounds__(256) void chain_by_walker(const T* __restrict__ src, double* __restrict__ dst, int64_t nl, int32_t ld,
+                                                       int32_t nd, int64_t K, int64_t w0)
+{
+    const int64_t wl = blockIdx.x;
+    const int64_t per = K * nd;
+    const T* s = src + (w0 + wl) * ld;
+    double* d = dst + wl * per;
+    for (int64_t e = (int64_t)blockIdx.y * 256 + threadIdx.x; e < per; e += (int64_t)gridDim.y * 256) {
+        const int64_t k = e / nd;
+        const int c = (int)(e - k * nd);
+        d[e] = (double)s[k * nl * ld + c];
+    }
+}
+
 // Graph replay support: the device-side generation counter and the schedule table of the next
 // `n` generations (one thread each).  *gen += by happens before the table is rebuilt.
 __global__ void advance_schedule(int64_t* gen, SchedEntry* table, int n, int64_t by,

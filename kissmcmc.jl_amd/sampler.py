@@ -301,14 +301,27 @@ class Sampler:
         _lib.check(self._L.kmc_sampler_get_moments(self._h, _dp(s), _dp(q), C.byref(n)))
         return s, q, n.value
 
-    def chain(self, logp: bool = True):
-        """``(chain [nsamples_done, nlocal, ndim], chain_logp [nsamples_done, nlocal] | None)``."""
+    def chain(self, logp: bool = True, by_walker: bool = False):
+        """``(chain [nsamples_done, nlocal, ndim], chain_logp [nsamples_done, nlocal] | None)``; with ``by_walker`` in the
+        reference's order, ``thetas[w][k]`` (``src/samplers.jl:219-221``): ``[nlocal, nsamples_done, ndim]`` and
+        ``[nlocal, nsamples_done]``, transposed on the device (``kmc_sampler_get_chain_by_walker``; a streamed chain is
+        reordered on the host)."""
         ns = self.nsamples
         post = self.generation - self.cfg.nburnin
         done = 0 if post <= 0 else min(ns, post // self.cfg.nthin)
         if self._host_chain is not None or self._host_logp is not None:
             self.sync()                                   # KMC_STREAM_CHAIN: completes the copies of everything stored so far
-            return (None if self._host_chain is None else self._host_chain[:done]), (self._host_logp[:done] if (logp and self._host_logp is not None) else None)
+            ch = None if self._host_chain is None else self._host_chain[:done]
+            lp = self._host_logp[:done] if (logp and self._host_logp is not None) else None
+            if by_walker:
+                ch = None if ch is None else np.ascontiguousarray(ch.transpose(1, 0, 2))
+                lp = None if lp is None else np.ascontiguousarray(lp.T)
+            return ch, lp
+        if by_walker:
+            ch = np.empty((self.nlocal, done, self.ndim))
+            lp = np.empty((self.nlocal, done)) if logp else None
+            _lib.check(self._L.kmc_sampler_get_chain_by_walker(self._h, _dp(ch), _dp(lp) if logp else None))
+            return ch, lp
         ch = np.empty((done, self.nlocal, self.ndim))
         lp = np.empty((done, self.nlocal)) if logp else None
         _lib.check(self._L.kmc_sampler_get_chain(self._h, _dp(ch), _dp(lp) if logp else None))

@@ -26,9 +26,11 @@ def test_sampler_reproduces_golden(kmc, name):
         goldenlib.compare(z, s.positions(), s.logp(), s.naccept(), msum, msq, n, chain, chain_logp)
 
 
+@pytest.mark.parametrize("by_walker", [False, True], ids=["sample-major", "by-walker"])
 @pytest.mark.parametrize("name", ["gauss_64x4", "expo_100x1_readme", "rosen_256x64", "rosen_256x64_f32"])
-def test_one_shot_c_abi_reproduces_golden(kmc, name):
-    """kmc_emcee_run with caller-owned host buffers (the entry point a ccall binding uses)."""
+def test_one_shot_c_abi_reproduces_golden(kmc, name, by_walker):
+    """kmc_emcee_run with caller-owned host buffers (the entry point a ccall binding uses); with KMC_CHAIN_BY_WALKER the
+    chain arrives in the reference's order, thetas[w][k]."""
     from kissmcmc_jl_amd import _lib
     z = goldenlib.load(name)
     nw, nd = z["nwalkers"], z["ndim"]
@@ -38,9 +40,9 @@ def test_one_shot_c_abi_reproduces_golden(kmc, name):
     for i, v in enumerate(z["params"]):
         cfg.params[i] = float(v)
     cfg.nwalkers, cfg.ndim, cfg.ngenerations, cfg.nburnin, cfg.nthin = nw, nd, z["G"], z["nburnin"], z["nthin"]
-    cfg.a_scale, cfg.seed, cfg.flags, cfg.device = z["a_scale"], z["seed"], 0, 0
+    cfg.a_scale, cfg.seed, cfg.flags, cfg.device = z["a_scale"], z["seed"], (_lib.CHAIN_BY_WALKER if by_walker else 0), 0
     dp = C.POINTER(C.c_double)
-    chain = np.zeros((ns, nw, nd)); clogp = np.zeros((ns, nw)); acc = np.zeros(nw)
+    chain = np.zeros((nw, ns, nd) if by_walker else (ns, nw, nd)); clogp = np.zeros((nw, ns) if by_walker else (ns, nw)); acc = np.zeros(nw)
     nacc = np.zeros(nw, dtype=np.int64); fpos = np.zeros((nw, nd)); flogp = np.zeros(nw)
     msum = np.zeros(nd); msq = np.zeros(nd)
     out = _lib.Outputs()
@@ -53,5 +55,7 @@ def test_one_shot_c_abi_reproduces_golden(kmc, name):
     _lib.check(_lib.lib().kmc_emcee_run(C.byref(cfg), th.ctypes.data_as(dp), C.byref(out)))
     assert (th == th_before).all()                      # the caller's array is never mutated (samplers.jl:198)
     assert out.nsamples == ns and out.device_ms >= 0.0
+    if by_walker:
+        chain, clogp = chain.transpose(1, 0, 2), clogp.T
     goldenlib.compare(z, fpos, flogp, nacc, msum, msq, out.nmoment, chain, clogp)
     np.testing.assert_array_equal(acc, nacc / (z["G"] - z["nburnin"]))   # samplers.jl:291
