@@ -113,7 +113,7 @@ enum {
                                     their final position; if that fails they are ordinary (staged) copies.  KMC_F64, one GPU
                                     (no KMC_P2P / sharding / KMC_ISLANDS); small ensembles then run the multi-launch kernels.
                                     kmc_emcee_run switches it on by itself when the chain would not fit the device. */
-    KMC_CHAIN_BY_WALKER = 1u << 12, /* kmc_emcee_run only: kmc_outputs.chain is [nwalkers][nsamples][ndim] and chain_logp
+    KMC_CHAIN_BY_WALKER = 1u << 12, /* kmc_emcee_run and kmc_metropolis_run: kmc_outputs.chain is [nwalkers][nsamples][ndim] and chain_logp
                                     [nwalkers][nsamples] -- the reference's own order, thetas[w][k] (src/samplers.jl:219-221,
                                     :268-272) -- instead of sample-major.  Transposed on the device before the copy
                                     (kmc_sampler_get_chain_by_walker).  Refused when the chain has to be streamed. */
@@ -394,7 +394,8 @@ typedef struct kmc_metropolis_config {
     int64_t  nthin;         /*                                      src/samplers.jl:64 */
     const double* step;     /* host [ndim]: proposal scale per dimension (theta + step .* randn) */
     uint64_t seed;
-    uint32_t flags;         /* KMC_STORE_CHAIN | KMC_STORE_LOGP | KMC_MOMENTS */
+    uint32_t flags;         /* KMC_STORE_CHAIN | KMC_STORE_LOGP | KMC_MOMENTS | KMC_CHAIN_BY_WALKER (chain [nchains][nsamples][ndim],
+                               chain_logp [nchains][nsamples]: thetas[chain][sample], reordered on the device) */
     int32_t  device;
     void*    user_density;  /* kmc_user_density* when density == KMC_USER_DENSITY */
     /* Host route: ANY closure for `pdf` and / or `sample_ppdf` (the reference takes both as arbitrary functions,

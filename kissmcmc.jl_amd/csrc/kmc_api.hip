@@ -2275,6 +2275,40 @@ KMC_EXPORT kmc_status kmc_sampler_get_chain(kmc_sampler* s, double* chain, doubl
     return KMC_OK;
 }
 
+// Device chain [K][nl][ld] (T = float or double) -> host [nl][K][width] doubles: transposed on the device into a scratch
+// buffer, a piece of walkers (<= ~256 MiB, KMC_BY_WALKER_PIECE_MB) at a time, each piece one contiguous copy.
+kmc_status kmc_host::download_by_walker(const void* src, bool is_float, int64_t nl, int64_t ld, int64_t width, int64_t K, double* dst_host, hipStream_t st)
+{
+    if (K <= 0 || nl <= 0) return KMC_OK;
+    const size_t per_walker = (size_t)K * (size_t)width * sizeof(double);
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    size_t budget = (size_t)256 << 20;
+    if (const char* mb = std::getenv("KMC_BY_WALKER_PIECE_MB")) { const double v = std::atof(mb); if (v > 0.0) budget = (size_t)(v * 1048576.0); }
+    if (budget > free_b / 2) budget = free_b / 2;
+    int64_t wb = (int64_t)(budget / per_walker);
+    if (wb < 1) wb = 1;
+    if (wb > nl) wb = nl;
+    double* tmp = nullptr;
+    HIP_TRY(hipMalloc((void**)&tmp, (size_t)wb * per_walker));
+    hipError_t e = hipSuccess;
+    for (int64_t w0 = 0; w0 < nl && e == hipSuccess; w0 += wb) {
+        const int64_t n = nl - w0 < wb ? nl - w0 : wb;
+        int64_t gy = (K * width + 255) / 256;
+        if (gy > 4096) gy = 4096;
+        if (is_float)
+            hipLaunchKernelGGL(chain_by_walker<float>, dim3((unsigned)n, (unsigned)gy), dim3(256), 0, st, static_cast<const float*>(src), tmp, nl, (int32_t)ld, (int32_t)width, K, w0);
+        else
+            hipLaunchKernelGGL(chain_by_walker<double>, dim3((unsigned)n, (unsigned)gy), dim3(256), 0, st, static_cast<const double*>(src), tmp, nl, (int32_t)ld, (int32_t)width, K, w0);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(dst_host + (size_t)w0 * (size_t)K * (size_t)width, tmp, (size_t)n * per_walker, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);     // one scratch buffer: the next piece overwrites it
+    }
+    (void)hipFree(tmp);
+    HIP_TRY(e);
+    return KMC_OK;
+}
+
 // The chain in the reference's order: [walker][sample][ndim] and [walker][sample] (thetas[w][k], logdensities[w][k],
 // src/samplers.jl:219-221).  Transposed on the device, a block of walkers at a time, and copied out contiguously.
 KMC_EXPORT kmc_status kmc_sampler_get_chain_by_walker(kmc_sampler* s, double* chain, double* chain_logp)
@@ -2289,37 +2323,8 @@ KMC_EXPORT kmc_status kmc_sampler_get_chain_by_walker(kmc_sampler* s, double* ch
     if (chain && !s->d_chain && s->nsamples > 0) return fail(KMC_ERR_BAD_ARG, "sampler was created without KMC_STORE_CHAIN");
     if (chain_logp && !s->d_chain_logp && s->nsamples > 0) return fail(KMC_ERR_BAD_ARG, "sampler was created without KMC_STORE_LOGP");
     if (K == 0 || (!chain && !chain_logp)) return KMC_OK;
-    // walkers per piece: a transposed piece of at most ~256 MiB (less when the device is full)
-    const size_t per_walker = (size_t)K * (size_t)(chain ? nd : 1) * sizeof(double);
-    size_t free_b = 0, total_b = 0;
-    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-    size_t budget = (size_t)256 << 20;
-    if (const char* mb = std::getenv("KMC_BY_WALKER_PIECE_MB")) { const double v = std::atof(mb); if (v > 0.0) budget = (size_t)(v * 1048576.0); }
-    if (budget > free_b / 2) budget = free_b / 2;
-    int64_t wb = (int64_t)(budget / per_walker);
-    if (wb < 1) wb = 1;
-    if (wb > nl) wb = nl;
-    double* tmp = nullptr;
-    HIP_TRY(hipMalloc((void**)&tmp, (size_t)wb * per_walker));
-    hipError_t e = hipSuccess;
-    auto piece = [&](const void* src, bool is_float, int64_t ld, int64_t width, double* dst_host) {
-        for (int64_t w0 = 0; w0 < nl && e == hipSuccess; w0 += wb) {
-            const int64_t n = nl - w0 < wb ? nl - w0 : wb;
-            int64_t gy = (K * width + 255) / 256;
-            if (gy > 4096) gy = 4096;
-            if (is_float)
-                hipLaunchKernelGGL(chain_by_walker<float>, dim3((unsigned)n, (unsigned)gy), dim3(256), 0, s->stream, static_cast<const float*>(src), tmp, nl, (int32_t)ld, (int32_t)width, K, w0);
-            else
-                hipLaunchKernelGGL(chain_by_walker<double>, dim3((unsigned)n, (unsigned)gy), dim3(256), 0, s->stream, static_cast<const double*>(src), tmp, nl, (int32_t)ld, (int32_t)width, K, w0);
-            e = hipGetLastError();
-            if (e == hipSuccess) e = hipMemcpyAsync(dst_host + (size_t)w0 * (size_t)K * (size_t)width, tmp, (size_t)n * (size_t)K * (size_t)width * sizeof(double), hipMemcpyDeviceToHost, s->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(s->stream);     // one scratch buffer: the next piece overwrites it
-        }
-    };
-    if (chain) piece(s->d_chain, s->f32, s->ld, nd, chain);
-    if (chain_logp) piece(s->d_chain_logp, false, 1, 1, chain_logp);
-    (void)hipFree(tmp);
-    HIP_TRY(e);
+    if (chain) KMC_TRY(download_by_walker(s->d_chain, s->f32, nl, s->ld, nd, K, chain, s->stream));
+    if (chain_logp) KMC_TRY(download_by_walker(s->d_chain_logp, false, nl, 1, 1, K, chain_logp, s->stream));
     return KMC_OK;
 }
 

@@ -47,6 +47,7 @@ bool lookup(int density, int L, int K, int iter, bool p2p, bool ragged, bool f32
 kmc_status digest_params(const kmc_config& c, kmc::DensityParams* dp);
 
 // runtime-compiled user densities (hiprtc)
+kmc_status download_by_walker(const void* src_dev, bool is_float, int64_t nl, int64_t ld, int64_t width, int64_t K, double* dst_host, hipStream_t st);
 std::string user_functor_source(const kmc_user_density* ud);      // the functor(s) ...
 std::string user_density_alias(const kmc_user_density* ud, int64_t ndim);   // ... and "using UD = ...;" over them
 std::string user_header_dir();                      // where the kernel headers live (KMC_CSRC_DIR or <library dir>/csrc)

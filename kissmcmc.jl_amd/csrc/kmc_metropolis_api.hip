@@ -230,8 +230,13 @@ kmc_status metropolis_host_route(const kmc_metropolis_config* c, const double* t
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, b.ev0, b.ev1));
     out->device_ms = (double)ms;
-    if (out->chain && b.chain) HIP_TRY(hipMemcpy(out->chain, b.chain, (size_t)nsamples * rows, hipMemcpyDeviceToHost));
-    if (out->chain_logp && b.chain_logp) HIP_TRY(hipMemcpy(out->chain_logp, b.chain_logp, (size_t)nsamples * vec, hipMemcpyDeviceToHost));
+    if (c->flags & KMC_CHAIN_BY_WALKER) {       // thetas[chain][sample], as the reference returns them (:113, :128)
+        if (out->chain && b.chain) KMC_TRY(download_by_walker(b.chain, false, nc, nd, nd, nsamples, out->chain, nullptr));
+        if (out->chain_logp && b.chain_logp) KMC_TRY(download_by_walker(b.chain_logp, false, nc, 1, 1, nsamples, out->chain_logp, nullptr));
+    } else {
+        if (out->chain && b.chain) HIP_TRY(hipMemcpy(out->chain, b.chain, (size_t)nsamples * rows, hipMemcpyDeviceToHost));
+        if (out->chain_logp && b.chain_logp) HIP_TRY(hipMemcpy(out->chain_logp, b.chain_logp, (size_t)nsamples * vec, hipMemcpyDeviceToHost));
+    }
     if (out->final_pos) HIP_TRY(hipMemcpy(out->final_pos, b.pos, rows, hipMemcpyDeviceToHost));
     if (out->final_logp) HIP_TRY(hipMemcpy(out->final_logp, b.logp, vec, hipMemcpyDeviceToHost));
     if (out->chain_sum && b.csum) HIP_TRY(hipMemcpy(out->chain_sum, b.csum, rows, hipMemcpyDeviceToHost));
@@ -260,8 +265,8 @@ KMC_EXPORT kmc_status kmc_metropolis_validate(const kmc_metropolis_config* c)
     if (!c->step && !c->host_propose) return fail(KMC_ERR_BAD_ARG, "step (proposal scale per dimension) is NULL and there is no host_propose");
     for (int64_t d = 0; c->step && d < c->ndim; ++d)
         if (!std::isfinite(c->step[d])) return fail(KMC_ERR_BAD_ARG, "step must be finite");
-    if (c->flags & ~(uint32_t)(KMC_STORE_CHAIN | KMC_STORE_LOGP | KMC_MOMENTS))
-        return fail(KMC_ERR_BAD_ARG, "metropolis flags: KMC_STORE_CHAIN | KMC_STORE_LOGP | KMC_MOMENTS");
+    if (c->flags & ~(uint32_t)(KMC_STORE_CHAIN | KMC_STORE_LOGP | KMC_MOMENTS | KMC_CHAIN_BY_WALKER))
+        return fail(KMC_ERR_BAD_ARG, "metropolis flags: KMC_STORE_CHAIN | KMC_STORE_LOGP | KMC_MOMENTS | KMC_CHAIN_BY_WALKER");
     if (c->density == KMC_HOST_DENSITY) {
         if (!c->host_logpdf) return fail(KMC_ERR_BAD_ARG, "KMC_HOST_DENSITY needs kmc_metropolis_config.host_logpdf");
         return KMC_OK;
@@ -409,9 +414,14 @@ KMC_EXPORT kmc_status kmc_metropolis_run(const kmc_metropolis_config* c, const d
     HIP_TRY(hipEventElapsedTime(&ms, b.ev0, b.ev1));
     out->device_ms = (double)ms;
 
-    if (out->chain && b.chain) HIP_TRY(hipMemcpy(out->chain, b.chain, (size_t)nsamples * rows, hipMemcpyDeviceToHost));
-    if (out->chain_logp && b.chain_logp)
-        HIP_TRY(hipMemcpy(out->chain_logp, b.chain_logp, (size_t)nsamples * (size_t)nc * sizeof(double), hipMemcpyDeviceToHost));
+    if (c->flags & KMC_CHAIN_BY_WALKER) {       // thetas[chain][sample], as the reference returns them (:113, :128)
+        if (out->chain && b.chain) KMC_TRY(download_by_walker(b.chain, false, nc, nd, nd, nsamples, out->chain, nullptr));
+        if (out->chain_logp && b.chain_logp) KMC_TRY(download_by_walker(b.chain_logp, false, nc, 1, 1, nsamples, out->chain_logp, nullptr));
+    } else {
+        if (out->chain && b.chain) HIP_TRY(hipMemcpy(out->chain, b.chain, (size_t)nsamples * rows, hipMemcpyDeviceToHost));
+        if (out->chain_logp && b.chain_logp)
+            HIP_TRY(hipMemcpy(out->chain_logp, b.chain_logp, (size_t)nsamples * (size_t)nc * sizeof(double), hipMemcpyDeviceToHost));
+    }
     if (out->final_pos) HIP_TRY(hipMemcpy(out->final_pos, b.pos, rows, hipMemcpyDeviceToHost));
     if (out->final_logp) HIP_TRY(hipMemcpy(out->final_logp, b.logp, (size_t)nc * sizeof(double), hipMemcpyDeviceToHost));
     if (out->chain_sum && b.csum) HIP_TRY(hipMemcpy(out->chain_sum, b.csum, rows, hipMemcpyDeviceToHost));

@@ -76,7 +76,7 @@ class HostProposal:
 
 
 def run_chains(pdf, sample_ppdf, theta0s, niter, nburnin, nthin, seed, device=0, store_chain=True, store_logp=True,
-               moments=False, scalar=False):
+               moments=False, scalar=False, by_chain=False):
     """``kmc_metropolis_run`` on dense arrays.  Returns a dict: ``chain [nsamples, nchains, ndim]``,
     ``chain_logp [nsamples, nchains]``, ``accept_ratio``, ``naccept``, ``final_pos``, ``final_logp``,
     ``chain_sum``/``chain_sumsq [nchains, ndim]``, ``nsamples``, ``device_ms``.
@@ -112,6 +112,8 @@ def run_chains(pdf, sample_ppdf, theta0s, niter, nburnin, nthin, seed, device=0,
         c.host_propose = C.cast(sample_ppdf.c_callback, C.c_void_p)
     c.seed = int(seed)
     c.flags = (_lib.STORE_CHAIN if store_chain else 0) | (_lib.STORE_LOGP if store_logp else 0) | (_lib.MOMENTS if moments else 0)
+    if by_chain:                    # chain [nchains, nsamples, ndim], chain_logp [nchains, nsamples]: reordered on the device
+        c.flags |= _lib.CHAIN_BY_WALKER
     c.device = int(device)
     c.user_density = pdf.user_handle
     if isinstance(pdf, HostLogPdf):
@@ -121,8 +123,8 @@ def run_chains(pdf, sample_ppdf, theta0s, niter, nburnin, nthin, seed, device=0,
     L = _lib.lib()
     _lib.check(L.kmc_metropolis_validate(C.byref(c)))
     ns = max(0, (int(niter) - int(nburnin)) // int(nthin)) if niter > nburnin else 0     # src/samplers.jl:88
-    chain = np.zeros((ns, nchains, ndim)) if store_chain else None
-    chain_logp = np.zeros((ns, nchains)) if store_logp else None
+    chain = np.zeros((nchains, ns, ndim) if by_chain else (ns, nchains, ndim)) if store_chain else None
+    chain_logp = np.zeros((nchains, ns) if by_chain else (ns, nchains)) if store_logp else None
     acc = np.zeros(nchains)
     nacc = np.zeros(nchains, dtype=np.int64)
     fpos = np.zeros((nchains, ndim))
@@ -213,14 +215,14 @@ def _run(pdf, sample_ppdf, th, niter, nburnin, nthin, hasblob, init_blobs, reduc
             pdf.eval_rows(th)                                             # p0, blob0 = pdf(theta0)  :70 (the library evaluates it again)
             state["blob0s"] = list(pdf.last_blobs)
             state["blobs"] = [init_blobs(state["blob0s"][w], ns) for w in range(nchains)]       # :90
-        r = run_chains(pdf, sample_ppdf, th, niter, nburnin, nthin, seed, device, scalar=scalar)
+        r = run_chains(pdf, sample_ppdf, th, niter, nburnin, nthin, seed, device, scalar=scalar, by_chain=True)
     finally:
         if blobctx is not None:
             pdf.on_accepted = None
-    thetas = np.ascontiguousarray(r["chain"].transpose(1, 0, 2))
+    thetas = r["chain"]                                         # [chain][sample][dim], :113
     if scalar:
         thetas = thetas[:, :, 0]
-    return thetas, r["accept_ratio"], np.ascontiguousarray(r["chain_logp"].T), (None if blobctx is None else blobctx[0]["blobs"])
+    return thetas, r["accept_ratio"], r["chain_logp"], (None if blobctx is None else blobctx[0]["blobs"])
 
 
 def metropolis_chains(pdf, sample_ppdf, theta0s, niter: int = 10 ** 5, nburnin=None, nthin: int = 1,

@@ -63,3 +63,19 @@ def test_emcee_returns_the_reference_layout(kmc, oracle):
     sq = kmc.squash_walkers(thetas, acc, logd, verbose=False)
     np.testing.assert_array_equal(sq[0], thetas.reshape(-1, nd))          # walker-major concatenation (:398-399)
     assert np.shares_memory(sq[0], thetas)                                # ... is a view of what the device delivered
+
+
+@pytest.mark.parametrize("host", [False, True], ids=["device-chains", "host-closures"])
+def test_metropolis_chains_by_chain(kmc, host):
+    """kmc_metropolis_run with KMC_CHAIN_BY_WALKER (what metropolis() / metropolis_chains() return: thetas[chain][sample])
+    equals the sample-major chain, reordered; both routes (chains in one kernel; closures over one host round trip)."""
+    from kissmcmc_jl_amd.metropolis import run_chains
+    th = np.random.default_rng(4).standard_normal((96 if host else 3000, 3))
+    pdf = (lambda x: -0.5 * float(np.dot(x, x))) if host else kmc.GaussianIso()
+    niter = 40 if host else 200
+    a = run_chains(pdf, kmc.GaussianStep(0.7), th, niter, 10, 3, 5, by_chain=True)
+    b = run_chains(pdf, kmc.GaussianStep(0.7), th, niter, 10, 3, 5)
+    assert a["chain"].shape == (th.shape[0], (niter - 10) // 3, 3)
+    np.testing.assert_array_equal(a["chain"], b["chain"].transpose(1, 0, 2))
+    np.testing.assert_array_equal(a["chain_logp"], b["chain_logp"].T)
+    np.testing.assert_array_equal(a["naccept"], b["naccept"])
