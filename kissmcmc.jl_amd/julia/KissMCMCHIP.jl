@@ -178,6 +178,7 @@ end
 
 const KMC_STORE_CHAIN = UInt32(1) << 0
 const KMC_STORE_LOGP = UInt32(1) << 1
+const KMC_CHAIN_BY_WALKER = UInt32(1) << 12     # chain delivered as [walker][sample][dim]: thetas[w][k] are contiguous
 
 last_error() = unsafe_string(ccall((:kmc_last_error, LIB), Cstring, ()))
 
@@ -226,21 +227,31 @@ function emcee(pdf::DeviceLogPdf, theta0s; niter=10^5, nburnin=niter ÷ 2, nthin
             acc_fn = @cfunction(accepted_trampoline, Cint, (Ptr{UInt8}, Int64, Int64, Int64, Int32, Ptr{Cvoid}))
         end
     end
-    cfg = Ref(KmcConfig(dtype=(dtype == :f32 ? 1 : 0), density=density_id(pdf), params=p8, nwalkers=nwalkers, ndim=ndim,
-                        ngenerations=niter_walker, nburnin=nburnin_walker, nthin=nthin, a_scale=a_scale, seed=UInt64(seed),
-                        flags=KMC_STORE_CHAIN | KMC_STORE_LOGP, device=Int32(device), user_density=user_handle(pdf),
-                        host_logpdf=host_fn, host_user=host_ctx, host_accepted=acc_fn))
-    # (a chain too large for the device is streamed into these arrays while sampling: kmc_emcee_run decides, KMC_STREAM_CHAIN)
-    chain = Array{Float64}(undef, ndim, nwalkers, nsamples)
-    clogp = Array{Float64}(undef, nwalkers, nsamples)
+    chain = Array{Float64}(undef, ndim * nsamples * nwalkers)
+    clogp = Array{Float64}(undef, nsamples * nwalkers)
     acc = Vector{Float64}(undef, nwalkers)
     out = KmcOutputs(chain=pointer(chain), chain_logp=pointer(clogp), accept_ratio=pointer(acc))
-    st = GC.@preserve pdf theta chain clogp acc ccall((:kmc_emcee_run, LIB), Cint,
-                                                   (Ref{KmcConfig}, Ptr{Float64}, Ref{KmcOutputs}), cfg, theta, out)
+    # The chain in the reference's own order (thetas[w][k], :219-221), reordered on the device.  A chain too large for
+    # the device is streamed into these arrays while sampling (kmc_emcee_run decides, KMC_STREAM_CHAIN) and then arrives
+    # sample-major: that combination is refused (status 9) and the call is repeated without the flag.
+    st = 9; by_walker = true
+    for flag in (KMC_CHAIN_BY_WALKER, UInt32(0))
+        by_walker = flag != 0
+        cfg = Ref(KmcConfig(dtype=(dtype == :f32 ? 1 : 0), density=density_id(pdf), params=p8, nwalkers=nwalkers, ndim=ndim,
+                            ngenerations=niter_walker, nburnin=nburnin_walker, nthin=nthin, a_scale=a_scale, seed=UInt64(seed),
+                            flags=KMC_STORE_CHAIN | KMC_STORE_LOGP | flag, device=Int32(device), user_density=user_handle(pdf),
+                            host_logpdf=host_fn, host_user=host_ctx, host_accepted=acc_fn))
+        st = GC.@preserve pdf theta chain clogp acc ccall((:kmc_emcee_run, LIB), Cint,
+                                                       (Ref{KmcConfig}, Ptr{Float64}, Ref{KmcOutputs}), cfg, theta, out)
+        (st == 9 && by_walker && occursin("KMC_CHAIN_BY_WALKER", last_error())) || break
+    end
     st == 0 || error("kmc_emcee_run failed ($st): $(last_error())")
-    thetas = scalar ? [[chain[1, w, k] for k in 1:nsamples] for w in 1:nwalkers] :
-                      [[chain[:, w, k] for k in 1:nsamples] for w in 1:nwalkers]
-    logdensities = [[clogp[w, k] for k in 1:nsamples] for w in 1:nwalkers]
+    # column-major views of the C arrays: [dim, sample, walker] (by walker) or [dim, walker, sample]
+    ch = by_walker ? reshape(chain, ndim, nsamples, nwalkers) : permutedims(reshape(chain, ndim, nwalkers, nsamples), (1, 3, 2))
+    lp = by_walker ? reshape(clogp, nsamples, nwalkers) : permutedims(reshape(clogp, nwalkers, nsamples), (2, 1))
+    thetas = scalar ? [ch[1, :, w] for w in 1:nwalkers] :
+                      [[ch[:, k, w] for k in 1:nsamples] for w in 1:nwalkers]
+    logdensities = [lp[:, w] for w in 1:nwalkers]
     return thetas, acc, logdensities, (pdf isa HostLogPdf && pdf.hasblob) ? pdf.blobs : nothing   # :292
 end
 # (a bare closure as `pdf` is KissMCMC.emcee's own CPU method; `emcee(HostLogPdf(f; hasblob), theta0s; ...)` runs the
@@ -348,21 +359,21 @@ function metropolis_chains(pdf::DeviceLogPdf, sample_ppdf::Union{GaussianStep,Ho
     end
     ctx = MetroCtx(pdf, sample_ppdf)
     p = params(pdf); p8 = ntuple(i -> i <= length(p) ? p[i] : 0.0, 8)
-    chain = Array{Float64}(undef, ndim, nchains, nsamples)
-    clogp = Array{Float64}(undef, nchains, nsamples)
+    chain = Array{Float64}(undef, ndim, nsamples, nchains)      # column-major == C [chain][sample][dim] (KMC_CHAIN_BY_WALKER)
+    clogp = Array{Float64}(undef, nsamples, nchains)
     acc = Vector{Float64}(undef, nchains)
     out = KmcMetropolisOutputs(chain=pointer(chain), chain_logp=pointer(clogp), accept_ratio=pointer(acc))
     st = GC.@preserve pdf sample_ppdf ctx theta step chain clogp acc begin
         cfg = Ref(KmcMetropolisConfig(density=density_id(pdf), params=p8, nchains=nchains, ndim=ndim, niter=niter, nburnin=nburnin,
                                       nthin=nthin, step=(isempty(step) ? Ptr{Float64}(C_NULL) : pointer(step)), seed=UInt64(seed),
-                                      flags=KMC_STORE_CHAIN | KMC_STORE_LOGP, device=Int32(device), user_density=user_handle(pdf),
+                                      flags=KMC_STORE_CHAIN | KMC_STORE_LOGP | KMC_CHAIN_BY_WALKER, device=Int32(device), user_density=user_handle(pdf),
                                       host_logpdf=pdf_fn, host_user=pointer_from_objref(ctx), host_propose=prop_fn))
         ccall((:kmc_metropolis_run, LIB), Cint, (Ref{KmcMetropolisConfig}, Ptr{Float64}, Ref{KmcMetropolisOutputs}), cfg, theta, out)
     end
     st == 0 || error("kmc_metropolis_run failed ($st): $(last_error())")
-    thetas = scalar ? [[chain[1, c, k] for k in 1:nsamples] for c in 1:nchains] :
-                      [[chain[:, c, k] for k in 1:nsamples] for c in 1:nchains]
-    return thetas, acc, [[clogp[c, k] for k in 1:nsamples] for c in 1:nchains], nothing
+    thetas = scalar ? [chain[1, :, c] for c in 1:nchains] :
+                      [[chain[:, k, c] for k in 1:nsamples] for c in 1:nchains]
+    return thetas, acc, [clogp[:, c] for c in 1:nchains], nothing
 end
 
 """
