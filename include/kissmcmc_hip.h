@@ -116,7 +116,10 @@ enum {
     KMC_CHAIN_BY_WALKER = 1u << 12, /* kmc_emcee_run and kmc_metropolis_run: kmc_outputs.chain is [nwalkers][nsamples][ndim] and chain_logp
                                     [nwalkers][nsamples] -- the reference's own order, thetas[w][k] (src/samplers.jl:219-221,
                                     :268-272) -- instead of sample-major.  Transposed on the device before the copy
-                                    (kmc_sampler_get_chain_by_walker).  Refused when the chain has to be streamed. */
+                                    (kmc_sampler_get_chain_by_walker).  Together with KMC_STREAM_CHAIN (also in kmc_sampler_create):
+                                    the host buffers of kmc_sampler_set_chain_host are [nwalkers][nsamples][ndim] and
+                                    [nwalkers][nsamples], and a completed block is transposed into a device scratch block and
+                                    copied into them as a 2-D window by the copy stream. */
     KMC_P2P_FINEGRAINED = 1u << 7, /* with KMC_P2P: keep the rows in fine-grained (coherent, uncached-for-peers) device memory */
     KMC_P2P_PUSH    = 1u << 9, /* with KMC_P2P: every rank keeps local copies ("shadows") of all the other shards and reads its
                                   partner rows from them; a rank that accepts a move writes the new row into its shadow on
@@ -288,7 +291,8 @@ kmc_status  kmc_sampler_set_state(kmc_sampler* s, const double* pos_host, const 
  * chain_logp_host [nsamples][nwalkers] (KMC_STORE_LOGP), caller-owned, alive until the sampler is destroyed (or this is
  * called again).  Call before kmc_sampler_run; sample k of a run is complete in these buffers after the kmc_sampler_sync
  * that follows the generation which stored it.  kmc_sampler_get_chain then copies from them (or is a no-op for the same
- * pointers). */
+ * pointers).  A sampler created with KMC_CHAIN_BY_WALKER as well takes [nwalkers][nsamples][ndim] and [nwalkers][nsamples]
+ * (the stride between walkers is the whole run's nsamples) and answers kmc_sampler_get_chain_by_walker instead. */
 kmc_status  kmc_sampler_set_chain_host(kmc_sampler* s, double* chain_host, double* chain_logp_host);
 /* Enqueue `ngenerations` generations (asynchronous).  shard_count must be 1. */
 kmc_status  kmc_sampler_run(kmc_sampler* s, int64_t ngenerations);
@@ -326,7 +330,8 @@ kmc_status  kmc_sampler_get_chain(kmc_sampler* s, double* chain, double* chain_l
 /* The same samples in the reference's order (thetas[w][k], logdensities[w][k], src/samplers.jl:219-221, :268-272):
  * chain [nlocal][k][ndim], chain_logp [nlocal][k], k = samples stored so far (= nsamples after a complete run), dense.
  * Transposed on the device in pieces of walkers and copied out contiguously, so the host never reorders gigabytes
- * (what squash_walkers' default, walker-major, concatenation wants; src/samplers.jl:395-413).  Not with KMC_STREAM_CHAIN. */
+ * (what squash_walkers' default, walker-major, concatenation wants; src/samplers.jl:395-413).  With KMC_STREAM_CHAIN only
+ * for a sampler created with KMC_CHAIN_BY_WALKER (then a copy of / no-op on the streamed buffers, stride nsamples). */
 kmc_status  kmc_sampler_get_chain_by_walker(kmc_sampler* s, double* chain, double* chain_logp);
 
 /* ---- dealt sub-ensembles: the multi-GPU mode WITHOUT a per-half-step exchange (opt-in extension) ----

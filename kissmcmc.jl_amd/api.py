@@ -106,7 +106,7 @@ def emcee(pdf, theta0s, niter: int = 10 ** 5, nburnin=None, nthin: int = 1, a_sc
     if stream_chain is None:
         stream_chain = dtype == "f64" and nsamples_walker * nwalkers * (ndim + 1 + ndim % 2) * 8 > 0.7 * _free_device_bytes(device)
     with Sampler(pdf, nwalkers, ndim, niter_walker, nburnin_walker, nthin, a_scale, seed,
-                 store_chain=True, store_logp=True, device=device, dtype=dtype, stream_chain=bool(stream_chain)) as s:
+                 store_chain=True, store_logp=True, device=device, dtype=dtype, stream_chain=bool(stream_chain), chain_by_walker=True) as s:
         try:
             s.set_positions(theta0s)
         except _lib.KmcError as e:

@@ -561,6 +561,10 @@ struct kmc_sampler {
     unsigned long long* d_err = nullptr;
     uint32_t* d_done = nullptr;                          // KMC_P2P_FOLD_SIGNAL: workgroups drained, per launch
     bool fold_signal = false;
+    bool stream_by_walker = false;                       // KMC_STREAM_CHAIN | KMC_CHAIN_BY_WALKER: host buffers are [walker][nsamples][..]
+    double *dev_dst_chain = nullptr, *dev_dst_logp = nullptr;   // ... and these are their device-side addresses (page-locked)
+    double *bw_scratch = nullptr, *bw_scratch_logp = nullptr;   // ... or one transposed block on the device, copied out as a 2-D window
+    int64_t flushed_done = -1;                           // samples_done at the last flush of an incomplete block (nothing new: skip it)
     bool push = false;                                   // KMC_P2P_PUSH / KMC_P2P_LAZY: d_pos = (1 + shard_count) blocks, see HalfStepArgs::push
     bool lazy = false;                                   // KMC_P2P_LAZY: + accept-byte maps behind the blocks, stamps in d_lazy
     bool lazy_stats = false;                             // KMC_P2P_STATS=1: count remote draws / pulls (kmc_sampler_p2p_stats)
@@ -880,6 +884,7 @@ int64_t samples_done(const kmc_sampler* s)
 }
 
 // ---- KMC_STREAM_CHAIN ---------------------------------------------------------------------------------------
+constexpr unsigned kStreamWalkerGrid = 192;      // workgroups of the background by-walker copy kernel (KMC_STREAM_CHAIN | KMC_CHAIN_BY_WALKER)
 int64_t samples_done_at(const kmc_sampler* s, int64_t generation)
 {
     const int64_t post = generation - s->cfg.nburnin;
@@ -894,6 +899,40 @@ kmc_status chain_copy_range(kmc_sampler* s, int64_t k0, int64_t k1)
     if (k1 <= k0) return KMC_OK;
     const size_t nl = (size_t)s->nlocal, nd = (size_t)s->cfg.ndim, ld = (size_t)s->ld, n = (size_t)(k1 - k0);
     const size_t slot0 = (size_t)(k0 % s->ring_slots);
+    if (s->stream_by_walker) {
+        // the reference's order: the caller's arrays are [walker][nsamples][ndim], a block is a run of n * ndim doubles
+        // per walker.  Either transposed into a device scratch block and copied by the DMA engine as a 2-D window
+        // (default), or written straight into the page-locked arrays by the kernel (KMC_BYWALKER_COPY=kernel; few
+        // workgroups, so that it drains over PCIe without taking the sampler's wave slots).
+        const int64_t ns = s->nsamples;
+        if (s->d_chain && s->dst_chain) {
+            if (s->bw_scratch) {
+                hipLaunchKernelGGL(chain_by_walker<double>, dim3((unsigned)std::min<size_t>(nl, 65535u), 1), dim3(256), 0, s->copy_stream, s->d_chain + slot0 * nl * ld,
+                                   s->bw_scratch, (int64_t)nl, (int32_t)ld, (int32_t)nd, (int64_t)n, (int64_t)0, (int64_t)nl, (int64_t)(n * nd));
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipMemcpy2DAsync(s->dst_chain + (size_t)k0 * nd, (size_t)ns * nd * sizeof(double), s->bw_scratch, n * nd * sizeof(double),
+                                         n * nd * sizeof(double), nl, hipMemcpyDeviceToHost, s->copy_stream));
+            } else {
+                hipLaunchKernelGGL(chain_by_walker<double>, dim3(kStreamWalkerGrid, 1), dim3(256), 0, s->copy_stream, s->d_chain + slot0 * nl * ld,
+                                   s->dev_dst_chain + (size_t)k0 * nd, (int64_t)nl, (int32_t)ld, (int32_t)nd, (int64_t)n, (int64_t)0, (int64_t)nl, ns * (int64_t)nd);
+                HIP_TRY(hipGetLastError());
+            }
+        }
+        if (s->d_chain_logp && s->dst_logp) {
+            if (s->bw_scratch_logp) {
+                hipLaunchKernelGGL(chain_by_walker<double>, dim3((unsigned)std::min<size_t>(nl, 65535u), 1), dim3(256), 0, s->copy_stream, s->d_chain_logp + slot0 * nl,
+                                   s->bw_scratch_logp, (int64_t)nl, (int32_t)1, (int32_t)1, (int64_t)n, (int64_t)0, (int64_t)nl, (int64_t)n);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipMemcpy2DAsync(s->dst_logp + (size_t)k0, (size_t)ns * sizeof(double), s->bw_scratch_logp, n * sizeof(double), n * sizeof(double), nl,
+                                         hipMemcpyDeviceToHost, s->copy_stream));
+            } else {
+                hipLaunchKernelGGL(chain_by_walker<double>, dim3(kStreamWalkerGrid, 1), dim3(256), 0, s->copy_stream, s->d_chain_logp + slot0 * nl,
+                                   s->dev_dst_logp + (size_t)k0, (int64_t)nl, (int32_t)1, (int32_t)1, (int64_t)n, (int64_t)0, (int64_t)nl, ns);
+                HIP_TRY(hipGetLastError());
+            }
+        }
+        return KMC_OK;
+    }
     if (s->d_chain && s->dst_chain) {
         const double* src = s->d_chain + slot0 * nl * ld;
         double* dst = s->dst_chain + (size_t)k0 * nl * nd;
@@ -943,9 +982,10 @@ kmc_status chain_flush(kmc_sampler* s)
     if (!s->stream_chain) return KMC_OK;
     KMC_TRY(chain_after(s));
     const int64_t done = samples_done(s), k0 = s->blocks_copied * s->ring_blk;
-    if (done > k0) {
+    if (done > k0 && done != s->flushed_done) {      // (an unchanged tail is in the host arrays already)
         HIP_TRY(hipStreamSynchronize(s->stream));
         KMC_TRY(chain_copy_range(s, k0, done));
+        s->flushed_done = done;
     }
     HIP_TRY(hipStreamSynchronize(s->copy_stream));
     return KMC_OK;
@@ -1342,6 +1382,12 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         if (const char* e = std::getenv("KMC_CHAIN_BLOCK")) { const long v = std::atol(e); if (v >= 1) blk = v; }
         if (blk < per_unit) blk = per_unit;
         s->stream_chain = true;
+        s->stream_by_walker = (cfg->flags & KMC_CHAIN_BY_WALKER) != 0;
+        const char* bwc = std::getenv("KMC_BYWALKER_COPY");
+        if (s->stream_by_walker && !(bwc && std::strcmp(bwc, "kernel") == 0)) {
+            if (cfg->flags & KMC_STORE_CHAIN) CREATE_TRY(hipMalloc(&s->bw_scratch, (size_t)blk * (size_t)s->nlocal * (size_t)cfg->ndim * sizeof(double)));
+            if (cfg->flags & KMC_STORE_LOGP) CREATE_TRY(hipMalloc(&s->bw_scratch_logp, (size_t)blk * (size_t)s->nlocal * sizeof(double)));
+        }
         s->ring_blk = blk;
         s->ring_slots = 3 * blk;
         chain_slots = s->ring_slots;
@@ -1407,6 +1453,8 @@ KMC_EXPORT void kmc_sampler_destroy(kmc_sampler* s)
     (void)hipFree(s->d_gen);
     (void)hipFree(s->d_sched);
     (void)hipFree(s->d_chain);
+    (void)hipFree(s->bw_scratch);
+    (void)hipFree(s->bw_scratch_logp);
     (void)hipFree(s->d_chain_logp);
     (void)hipFree(s->d_msum);
     (void)hipFree(s->d_msumsq);
@@ -1611,7 +1659,7 @@ kmc_status reset_run_state(kmc_sampler* s, bool eval_logp, int64_t generation, u
     s->generation = generation;
     s->launches = 0;
     s->have_run_events = false;
-    if (s->stream_chain) { HIP_TRY(hipStreamSynchronize(s->copy_stream)); s->blocks_copied = 0; s->blocks_waited = 0; }
+    if (s->stream_chain) { HIP_TRY(hipStreamSynchronize(s->copy_stream)); s->blocks_copied = 0; s->blocks_waited = 0; s->flushed_done = -1; }
     for (size_t w = 0; w < nw; ++w)
         if (!std::isfinite(lp[w])) {
             s->positions_set = false;
@@ -1794,7 +1842,7 @@ KMC_EXPORT kmc_status kmc_sampler_set_positions(kmc_sampler* s, const double* th
     s->moment_base = 0;
     s->launches = 0;
     s->have_run_events = false;
-    if (s->stream_chain) { HIP_TRY(hipStreamSynchronize(s->copy_stream)); s->blocks_copied = 0; s->blocks_waited = 0; }
+    if (s->stream_chain) { HIP_TRY(hipStreamSynchronize(s->copy_stream)); s->blocks_copied = 0; s->blocks_waited = 0; s->flushed_done = -1; }
     for (size_t w = 0; w < nw; ++w)
         if (!std::isfinite(lp[w])) {
             s->positions_set = false;
@@ -1815,6 +1863,7 @@ KMC_EXPORT kmc_status kmc_sampler_set_chain_host(kmc_sampler* s, double* chain_h
     HIP_TRY(hipStreamSynchronize(s->stream));
     HIP_TRY(hipStreamSynchronize(s->copy_stream));
     chain_unregister(s);
+    s->flushed_done = -1;
     s->dst_chain = s->d_chain ? chain_host : nullptr;
     s->dst_logp = s->d_chain_logp ? chain_logp_host : nullptr;
     // page-lock the destination in place: the copies are then direct DMA into their final position and truly
@@ -1827,6 +1876,22 @@ KMC_EXPORT kmc_status kmc_sampler_set_chain_host(kmc_sampler* s, double* chain_h
     if (s->dst_logp && std::getenv("KMC_NO_HOST_REGISTER") == nullptr) {
         if (hipHostRegister(s->dst_logp, ns * nl * sizeof(double), hipHostRegisterDefault) == hipSuccess) s->dst_logp_reg = true;
         else (void)hipGetLastError();
+    }
+    s->dev_dst_chain = s->dev_dst_logp = nullptr;
+    if (s->stream_by_walker) {
+        // the by-walker copy is a kernel that writes into the caller's arrays: they must be mapped into the device's address space
+        if (s->dst_chain && !s->bw_scratch && (!s->dst_chain_reg || hipHostGetDevicePointer((void**)&s->dev_dst_chain, s->dst_chain, 0) != hipSuccess)) {
+            (void)hipGetLastError();
+            chain_unregister(s);
+            s->dst_chain = s->dst_logp = nullptr;
+            return fail(KMC_ERR_UNSUPPORTED, "KMC_STREAM_CHAIN | KMC_CHAIN_BY_WALKER: the chain buffer could not be page-locked (hipHostRegister); use the sample-major stream");
+        }
+        if (s->dst_logp && !s->bw_scratch_logp && (!s->dst_logp_reg || hipHostGetDevicePointer((void**)&s->dev_dst_logp, s->dst_logp, 0) != hipSuccess)) {
+            (void)hipGetLastError();
+            chain_unregister(s);
+            s->dst_chain = s->dst_logp = nullptr;
+            return fail(KMC_ERR_UNSUPPORTED, "KMC_STREAM_CHAIN | KMC_CHAIN_BY_WALKER: the log-pdf buffer could not be page-locked (hipHostRegister); use the sample-major stream");
+        }
     }
     return KMC_OK;
 }
@@ -2256,6 +2321,8 @@ KMC_EXPORT kmc_status kmc_sampler_get_chain(kmc_sampler* s, double* chain, doubl
     HIP_TRY(hipStreamSynchronize(s->stream));
     KMC_TRY(check_p2p_err(s));
     const size_t rows = (size_t)samples_done(s) * (size_t)s->nlocal;
+    if (s->stream_by_walker)
+        return fail(KMC_ERR_UNSUPPORTED, "this sampler streams its chain by walker into the caller's buffers (kmc_sampler_get_chain_by_walker)");
     if (s->stream_chain) {             // the chain is in the caller's host buffers already
         KMC_TRY(chain_flush(s));
         if (chain && !s->d_chain) return fail(KMC_ERR_BAD_ARG, "sampler was created without KMC_STORE_CHAIN");
@@ -2297,9 +2364,9 @@ kmc_status kmc_host::download_by_walker(const void* src, bool is_float, int64_t 
         int64_t gy = (K * width + 255) / 256;
         if (gy > 4096) gy = 4096;
         if (is_float)
-            hipLaunchKernelGGL(chain_by_walker<float>, dim3((unsigned)n, (unsigned)gy), dim3(256), 0, st, static_cast<const float*>(src), tmp, nl, (int32_t)ld, (int32_t)width, K, w0);
+            hipLaunchKernelGGL(chain_by_walker<float>, dim3((unsigned)n, (unsigned)gy), dim3(256), 0, st, static_cast<const float*>(src), tmp, nl, (int32_t)ld, (int32_t)width, K, w0, n, K * width);
         else
-            hipLaunchKernelGGL(chain_by_walker<double>, dim3((unsigned)n, (unsigned)gy), dim3(256), 0, st, static_cast<const double*>(src), tmp, nl, (int32_t)ld, (int32_t)width, K, w0);
+            hipLaunchKernelGGL(chain_by_walker<double>, dim3((unsigned)n, (unsigned)gy), dim3(256), 0, st, static_cast<const double*>(src), tmp, nl, (int32_t)ld, (int32_t)width, K, w0, n, K * width);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipMemcpyAsync(dst_host + (size_t)w0 * (size_t)K * (size_t)width, tmp, (size_t)n * per_walker, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);     // one scratch buffer: the next piece overwrites it
@@ -2317,6 +2384,13 @@ KMC_EXPORT kmc_status kmc_sampler_get_chain_by_walker(kmc_sampler* s, double* ch
     HIP_TRY(hipSetDevice(s->cfg.device));
     HIP_TRY(hipStreamSynchronize(s->stream));
     KMC_TRY(check_p2p_err(s));
+    if (s->stream_by_walker) {         // the chain is in the caller's buffers already: [nlocal][nsamples][ndim], [nlocal][nsamples]
+        KMC_TRY(chain_flush(s));
+        const size_t n = (size_t)s->nlocal * (size_t)s->nsamples;
+        if (chain && chain != s->dst_chain && s->dst_chain) std::memcpy(chain, s->dst_chain, n * (size_t)s->cfg.ndim * sizeof(double));
+        if (chain_logp && chain_logp != s->dst_logp && s->dst_logp) std::memcpy(chain_logp, s->dst_logp, n * sizeof(double));
+        return KMC_OK;
+    }
     if (s->stream_chain)
         return fail(KMC_ERR_UNSUPPORTED, "KMC_STREAM_CHAIN delivers the chain sample-major into the caller's buffers (kmc_sampler_get_chain)");
     const int64_t K = samples_done(s), nl = s->nlocal, nd = s->cfg.ndim;
@@ -2413,8 +2487,6 @@ KMC_EXPORT kmc_status kmc_emcee_run(const kmc_config* cfg, const double* theta0,
         const size_t need = ns * nw_ * ((out->chain ? (size_t)(c.ndim + (c.ndim & 1)) * sizeof(double) : 0) + (out->chain_logp ? sizeof(double) : 0));
         if (hipSetDevice(c.device) == hipSuccess && hipMemGetInfo(&free_b, &total_b) == hipSuccess && need > free_b / 10 * 8) c.flags |= KMC_STREAM_CHAIN;
         else (void)hipGetLastError();
-        if ((c.flags & KMC_STREAM_CHAIN) && (c.flags & KMC_CHAIN_BY_WALKER))
-            return fail(KMC_ERR_UNSUPPORTED, "KMC_CHAIN_BY_WALKER: this chain does not fit the device and would be streamed sample-major (KMC_STREAM_CHAIN); drop the flag");
     }
     kmc_sampler* s = nullptr;
     KMC_TRY(kmc_sampler_create(&c, &s));

@@ -1373,21 +1373,34 @@ __global__ __launch_bounds__(256) void deal_init_ids(uint32_t* ids, int64_t S, u
     if (i < S) ids[i] = first + (uint32_t)i;
 }
 
-// Chain read-out in the reference's order, thetas[walker][sample] (src/samplers.jl:219-221, :268-272): walkers
-// [w0, w0 + gridDim.x) of the stored chain [sample][walker][ld] -> dense [walker][sample][ndim] doubles (also the
-// log-pdfs, as rows of one element).  One workgroup column per walker; writes are contiguous, reads are whole rows.
+// Chain read-out in the reference's order, thetas[walker][sample] (src/samplers.jl:219-221, :268-272): K samples of the
+// stored chain src [sample][walker][ld], walkers [w0, w0 + nw) -> dst [walker][..][nd] doubles with `dst_stride` elements
+// from one walker to the next (K * nd: a dense piece; nsamples * nd: a block of a streamed chain written straight into the
+// caller's page-locked array).  Also the log-pdfs, as rows of one element.  Workgroup (x, y) takes walkers x, x + gridDim.x,
+// ...: writes are contiguous runs of K * nd doubles, reads are whole rows.
 template <class T>
 __global__ __launch_bounds__(256) void chain_by_walker(const T* __restrict__ src, double* __restrict__ dst, int64_t nl, int32_t ld,
-                                                       int32_t nd, int64_t K, int64_t w0)
+                                                       int32_t nd, int64_t K, int64_t w0, int64_t nw, int64_t dst_stride)
 {
-    const int64_t wl = blockIdx.x;
     const int64_t per = K * nd;
-    const T* s = src + (w0 + wl) * ld;
-    double* d = dst + wl * per;
-    for (int64_t e = (int64_t)blockIdx.y * 256 + threadIdx.x; e < per; e += (int64_t)gridDim.y * 256) {
-        const int64_t k = e / nd;
-        const int c = (int)(e - k * nd);
-        d[e] = (double)s[k * nl * ld + c];
+    for (int64_t wl = blockIdx.x; wl < nw; wl += gridDim.x) {
+        const T* s = src + (w0 + wl) * ld;
+        double* d = dst + wl * dst_stride;
+        if (sizeof(T) == 8 && (nd & 1) == 0 && (reinterpret_cast<uintptr_t>(d) & 15) == 0) {
+            // even rows: 16 bytes per lane (a wave writes 1 KiB contiguous -- what a store over PCIe wants)
+            const int hd = nd >> 1;
+            for (int64_t e = (int64_t)blockIdx.y * 256 + threadIdx.x; e < per / 2; e += (int64_t)gridDim.y * 256) {
+                const int64_t k = e / hd;
+                const int c = (int)(e - k * hd);
+                reinterpret_cast<double2*>(d)[e] = *reinterpret_cast<const double2*>(reinterpret_cast<const double*>(s) + k * nl * ld + 2 * c);
+            }
+            continue;
+        }
+        for (int64_t e = (int64_t)blockIdx.y * 256 + threadIdx.x; e < per; e += (int64_t)gridDim.y * 256) {
+            const int64_t k = e / nd;
+            const int c = (int)(e - k * nd);
+            d[e] = (double)s[k * nl * ld + c];
+        }
     }
 }
 

@@ -24,7 +24,7 @@ class Sampler:
                  device: int = 0, shard_rank: int = 0, shard_count: int = 1, p2p: bool = False,
                  island_gens: int = 0, island_size: int = 0, p2p_finegrained: bool = False, p2p_fold: bool = False, p2p_push: bool = False,
                  dtype: str = "f64", p2p_lazy: bool = False, deal_rank: int = 0, deal_count: int = 0,
-                 stream_chain: bool = False):
+                 stream_chain: bool = False, chain_by_walker: bool = False):
         if not isinstance(pdf, DeviceLogPdf):
             raise TypeError(
                 "pdf must be a menu log-density (GaussianIso, Exponential, Rosenbrock, LogNormal, MvNormal2), "
@@ -57,6 +57,9 @@ class Sampler:
         if stream_chain and (store_chain or store_logp):
             # KMC_STREAM_CHAIN: the chain goes to host arrays block by block while sampling (bounded by host RAM, not HBM)
             flags |= _lib.STREAM_CHAIN
+            if chain_by_walker:
+                # ... in the reference's order, thetas[w][k]: host arrays [nlocal, nsamples, ndim] / [nlocal, nsamples]
+                flags |= _lib.CHAIN_BY_WALKER
         if p2p:
             flags |= _lib.P2P
             if p2p_finegrained:
@@ -93,10 +96,16 @@ class Sampler:
         # rows this object holds: the whole ensemble, or (P2P) this shard's slices of both halves
         self.nrows = self.nlocal if self.p2p else self.nwalkers
         self._host_chain = self._host_logp = None
+        self._host_by_walker = False
         if flags & _lib.STREAM_CHAIN and self.nsamples > 0:
             # the destination of the streamed chain: host arrays owned by this object (page-locked in place by the library)
-            self._host_chain = np.empty((self.nsamples, self.nlocal, self.ndim)) if store_chain else None
-            self._host_logp = np.empty((self.nsamples, self.nlocal)) if store_logp else None
+            self._host_by_walker = bool(flags & _lib.CHAIN_BY_WALKER)
+            if self._host_by_walker:
+                self._host_chain = np.empty((self.nlocal, self.nsamples, self.ndim)) if store_chain else None
+                self._host_logp = np.empty((self.nlocal, self.nsamples)) if store_logp else None
+            else:
+                self._host_chain = np.empty((self.nsamples, self.nlocal, self.ndim)) if store_chain else None
+                self._host_logp = np.empty((self.nsamples, self.nlocal)) if store_logp else None
             _lib.check(self._L.kmc_sampler_set_chain_host(self._h, _dp(self._host_chain) if store_chain else None,
                                                           _dp(self._host_logp) if store_logp else None))
 
@@ -311,6 +320,13 @@ class Sampler:
         done = 0 if post <= 0 else min(ns, post // self.cfg.nthin)
         if self._host_chain is not None or self._host_logp is not None:
             self.sync()                                   # KMC_STREAM_CHAIN: completes the copies of everything stored so far
+            if self._host_by_walker:                       # streamed in the reference's order already
+                ch = None if self._host_chain is None else self._host_chain[:, :done]
+                lp = self._host_logp[:, :done] if (logp and self._host_logp is not None) else None
+                if not by_walker:
+                    ch = None if ch is None else np.ascontiguousarray(ch.transpose(1, 0, 2))
+                    lp = None if lp is None else np.ascontiguousarray(lp.T)
+                return ch, lp
             ch = None if self._host_chain is None else self._host_chain[:done]
             lp = self._host_logp[:done] if (logp and self._host_logp is not None) else None
             if by_walker:

@@ -25,3 +25,8 @@ with kmc.Sampler(kmc.GaussianIso(), nw, nd, G, G // 2, nthin, 2.0, 5, store_chai
           f"| sample-major D2H {t_sm * 1e3:7.1f} ms + numpy reorder {t_np * 1e3:7.1f} ms")
 t = time.perf_counter(); sq = kmc.squash_walkers(thetas, acc, logd, verbose=False); t_sq = time.perf_counter() - t
 print(f"  squash_walkers (walker-major: a view) {t_sq * 1e3:7.2f} ms -> {sq[0].shape}")
+t = time.perf_counter()
+thetas2, acc2, logd2, _ = kmc.emcee(kmc.GaussianIso(), th, niter=nw * G, nthin=nthin, use_progress_meter=False, seed=5, stream_chain=True)
+t_st = time.perf_counter() - t
+assert np.array_equal(thetas2, thetas) and np.array_equal(logd2, logd)
+print(f"kmc.emcee(..., stream_chain=True): chain streamed by walker into page-locked host arrays while sampling: {t_st * 1e3:8.1f} ms wall")

@@ -46,7 +46,10 @@ def test_streamed_chain_equals_oracle_over_three_ring_laps(kmc, oracle, monkeypa
 
 @pytest.mark.parametrize("case", ["thin3_odd_ndim", "pieces_with_syncs", "eager_launches", "logp_only", "chain_only", "rosen_draw_ring",
                                   "small_ensemble", "unregistered_destination"])
-def test_streamed_chain_variants(kmc, oracle, monkeypatch, case):
+@pytest.mark.parametrize("by_walker", [False, True], ids=["sample-major", "by-walker"])
+def test_streamed_chain_variants(kmc, oracle, monkeypatch, case, by_walker):
+    """by-walker: KMC_STREAM_CHAIN | KMC_CHAIN_BY_WALKER -- completed blocks are written by a kernel of the copy stream
+    into host arrays laid out [walker][nsamples][ndim] (the reference's thetas[w][k])."""
     monkeypatch.setenv("KMC_CHAIN_BLOCK", "1")
     pdf, did, params, nw, nd, G, nburn, nthin, scale = kmc.GaussianIso(), oracle.GAUSSIAN_ISO, [0.0, 1.0], 1024, 8, 500, 37, 1, 1.0
     kw = dict(store_chain=True, store_logp=True)
@@ -66,7 +69,7 @@ def test_streamed_chain_variants(kmc, oracle, monkeypatch, case):
         monkeypatch.setenv("KMC_NO_HOST_REGISTER", "1")  # staged copies instead of DMA into page-locked arrays
     th = scale * np.random.default_rng(2).standard_normal((nw, nd))
     seed = 77
-    with kmc.Sampler(pdf, nw, nd, G, nburn, nthin, 2.0, seed, stream_chain=True, **kw) as s:
+    with kmc.Sampler(pdf, nw, nd, G, nburn, nthin, 2.0, seed, stream_chain=True, chain_by_walker=by_walker, **kw) as s:
         s.set_positions(th)
         if case == "pieces_with_syncs":
             for n in (50, 1, 130, 64, 200, G - 445):      # syncs inside blocks: partial flush, then the whole block again
@@ -78,6 +81,11 @@ def test_streamed_chain_variants(kmc, oracle, monkeypatch, case):
             s.run(G)
         s.sync()
         chain, clogp = s.chain()
+        cw, lw = s.chain(by_walker=True)
+        if chain is not None:
+            np.testing.assert_array_equal(cw, chain.transpose(1, 0, 2))
+        if clogp is not None:
+            np.testing.assert_array_equal(lw, clogp.T)
     ref = _oracle_chain(oracle, did, params, th, G, nburn, nthin, seed)
     assert ref["nsamples"] > 6 * 65 // max(1, nthin) or nthin > 1
     if kw["store_chain"]:
@@ -88,6 +96,26 @@ def test_streamed_chain_variants(kmc, oracle, monkeypatch, case):
         assert np.all(np.abs(clogp - ref["chain_logp"]) <= 1e-12 * np.maximum(1.0, np.abs(ref["chain_logp"])))
     else:
         assert clogp is None
+
+
+def test_streamed_by_walker_with_the_copy_kernel(kmc, oracle, monkeypatch):
+    """KMC_BYWALKER_COPY=kernel: instead of transposing a block into a device scratch and copying it out as a 2-D window,
+    a kernel of the copy stream writes it straight into the page-locked host arrays -- which must then be page-lockable."""
+    monkeypatch.setenv("KMC_CHAIN_BLOCK", "1")
+    monkeypatch.setenv("KMC_BYWALKER_COPY", "kernel")
+    nw, nd, G, nburn, nthin, seed = 1024, 7, 600, 50, 2, 12
+    th = np.random.default_rng(6).standard_normal((nw, nd))
+    with kmc.Sampler(kmc.GaussianIso(), nw, nd, G, nburn, nthin, 2.0, seed, store_chain=True, store_logp=True, stream_chain=True, chain_by_walker=True) as s:
+        s.set_positions(th)
+        s.run(G)
+        s.sync()
+        cw, lw = s.chain(by_walker=True)
+    ref = _oracle_chain(oracle, oracle.GAUSSIAN_ISO, [0.0, 1.0], th, G, nburn, nthin, seed)
+    np.testing.assert_array_equal(cw, ref["chain"].transpose(1, 0, 2))
+    assert np.all(np.abs(lw - ref["chain_logp"].T) <= 1e-12 * np.maximum(1.0, np.abs(ref["chain_logp"].T)))
+    monkeypatch.setenv("KMC_NO_HOST_REGISTER", "1")
+    with pytest.raises(kmc.KmcError, match="could not be page-locked"):
+        kmc.Sampler(kmc.GaussianIso(), nw, nd, G, nburn, nthin, 2.0, seed, store_chain=True, stream_chain=True, chain_by_walker=True)
 
 
 def test_streamed_chain_restart_and_emcee_front_end(kmc, oracle, monkeypatch):
@@ -154,7 +182,8 @@ def test_streamed_chain_random_splits_and_thinnings(kmc, oracle, monkeypatch):
         monkeypatch.setenv("KMC_CHAIN_BLOCK", str(int(rng.choice([1, 3, 50, 1000]))))
         monkeypatch.setenv("KMC_LAUNCH", str(rng.choice(["graph", "updated", "eager"])))
         seed = int(rng.integers(1, 10 ** 6))
-        with kmc.Sampler(kmc.GaussianIso(), nw, nd, G, nburn, nthin, 2.0, seed, store_chain=True, store_logp=True, stream_chain=True) as s:
+        with kmc.Sampler(kmc.GaussianIso(), nw, nd, G, nburn, nthin, 2.0, seed, store_chain=True, store_logp=True, stream_chain=True,
+                         chain_by_walker=bool(trial % 2)) as s:       # every other trial streams in the reference's order
             s.set_positions(th)
             left = G
             while left > 0:
