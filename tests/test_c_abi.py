@@ -55,6 +55,22 @@ def test_struct_layout_matches_header(kmc, tmp_path):
     assert got == want
 
 
+def test_flag_and_id_constants_match_header(kmc, tmp_path):
+    """The enum values of include/kissmcmc_hip.h as gcc sees them == the constants of the ctypes module (and, through
+    test_julia_shim_structs_mirror_the_header, of the Julia shim)."""
+    from kissmcmc_jl_amd import _lib
+    names = ["STORE_CHAIN", "STORE_LOGP", "MOMENTS", "NO_GRAPH", "P2P", "ISLANDS", "P2P_FINEGRAINED", "P2P_FOLD_SIGNAL", "P2P_PUSH",
+             "P2P_LAZY", "STREAM_CHAIN", "CHAIN_BY_WALKER", "F64", "F32", "GAUSSIAN_ISO", "EXPONENTIAL", "ROSENBROCK", "LOGNORMAL",
+             "MVNORMAL2", "USER_DENSITY", "HOST_DENSITY", "P2P_HANDLE_BYTES", "RCCL_ID_BYTES"]
+    src = tmp_path / "enums.c"
+    src.write_text('#include <stdio.h>\n#include "kissmcmc_hip.h"\nint main(void){' +
+                   "".join(f'printf("%lld\\n", (long long)KMC_{n});' for n in names) + "return 0;}\n")
+    exe = tmp_path / "enums"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    assert got == [getattr(_lib, n) for n in names]
+
+
 def _cfg(_lib, **kw):
     c = _lib.Config()
     c.dtype, c.density = _lib.F64, _lib.GAUSSIAN_ISO
@@ -193,6 +209,9 @@ def test_julia_shim_structs_mirror_the_header():
         assert [f for f, _ in fields] == [f for f, _ in mirror._fields_], jl_name
         assert [jl_size[t] for _, t in fields] == [C.sizeof(t) for _, t in mirror._fields_], jl_name
     assert "kmc_sizeof_config" in src and "function __init__()" in src
+    # the flag constants the shim uses: same bits as the header's (via the ctypes module, itself checked against the header)
+    consts = dict(re.findall(r"^const (KMC_\w+) = UInt32\(1\) << (\d+)", src, re.M))
+    assert consts and all(1 << int(bit) == getattr(_lib, name[4:]) for name, bit in consts.items()), consts
     # the host-side pre/post-processing is KissMCMC's own, not re-typed here
     assert "import KissMCMC: emcee, metropolis, make_theta0s, squash_walkers" in src
     assert "function make_theta0s" not in src and "function squash_walkers" not in src

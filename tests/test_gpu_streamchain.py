@@ -136,8 +136,10 @@ def test_streamed_chain_restart_and_emcee_front_end(kmc, oracle, monkeypatch):
         np.testing.assert_array_equal(x, y)
 
 
-def test_one_shot_c_abi_streams_into_the_callers_buffers(kmc, oracle, monkeypatch):
-    """kmc_emcee_run with KMC_STREAM_CHAIN: samples land in out->chain / out->chain_logp directly."""
+@pytest.mark.parametrize("by_walker", [False, True], ids=["sample-major", "by-walker"])
+def test_one_shot_c_abi_streams_into_the_callers_buffers(kmc, oracle, monkeypatch, by_walker):
+    """kmc_emcee_run with KMC_STREAM_CHAIN: samples land in out->chain / out->chain_logp directly (with KMC_CHAIN_BY_WALKER
+    laid out [walker][sample][dim])."""
     from kissmcmc_jl_amd import _lib
     monkeypatch.setenv("KMC_CHAIN_BLOCK", "1")
     nw, nd, G, nburn, nthin, seed = 2048, 16, 460, 20, 2, 123
@@ -147,14 +149,16 @@ def test_one_shot_c_abi_streams_into_the_callers_buffers(kmc, oracle, monkeypatc
     cfg.dtype, cfg.density = _lib.F64, _lib.GAUSSIAN_ISO
     cfg.params[0], cfg.params[1] = 0.0, 1.0
     cfg.nwalkers, cfg.ndim, cfg.ngenerations, cfg.nburnin, cfg.nthin = nw, nd, G, nburn, nthin
-    cfg.a_scale, cfg.seed, cfg.flags, cfg.device = 2.0, seed, _lib.STREAM_CHAIN, 0
+    cfg.a_scale, cfg.seed, cfg.flags, cfg.device = 2.0, seed, _lib.STREAM_CHAIN | (_lib.CHAIN_BY_WALKER if by_walker else 0), 0
     dp = C.POINTER(C.c_double)
-    chain = np.zeros((ns, nw, nd)); clogp = np.zeros((ns, nw)); fpos = np.zeros((nw, nd))
+    chain = np.zeros((nw, ns, nd) if by_walker else (ns, nw, nd)); clogp = np.zeros((nw, ns) if by_walker else (ns, nw)); fpos = np.zeros((nw, nd))
     out = _lib.Outputs()
     out.chain, out.chain_logp, out.final_pos = chain.ctypes.data_as(dp), clogp.ctypes.data_as(dp), fpos.ctypes.data_as(dp)
     _lib.check(_lib.lib().kmc_emcee_run(C.byref(cfg), th.ctypes.data_as(dp), C.byref(out)))
     ref = _oracle_chain(oracle, oracle.GAUSSIAN_ISO, [0.0, 1.0], th, G, nburn, nthin, seed)
     assert out.nsamples == ns
+    if by_walker:
+        chain, clogp = chain.transpose(1, 0, 2), clogp.T
     _equal(chain, clogp, ref)
     np.testing.assert_array_equal(fpos, ref["final_pos"])
 
