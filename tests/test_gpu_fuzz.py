@@ -1,0 +1,90 @@
+"""GPU: a seeded random sweep of sampler configurations against the oracle -- shapes nobody picked by hand (odd ndim,
+ensembles just above ndim + 2, active halves that do not fill a wave, thinning that does not divide the run), every
+density of the menu, every launch mode, float / double rows excepted (f32 has its own statistical tests), with the job
+cut into random run() pieces.  Same bar as test_gpu_parity.py: identical counters, bit-identical positions and chains,
+log-pdfs to 1e-12, moments to 1e-11."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N_TRIALS = 120
+
+
+def _draw_config(rng):
+    name = str(rng.choice(["gauss", "gauss_shift", "expo", "rosen", "lognormal", "mvn2"]))
+    if name == "mvn2":
+        nd = 2
+    elif name == "rosen":
+        nd = int(rng.choice([2, 3, 5, 8, 17, 32, 33, 64, 100, 130]))
+    else:
+        nd = int(rng.choice([1, 2, 3, 4, 7, 8, 9, 15, 16, 31, 32, 33, 63, 64, 65, 127, 128, 200, 257, 600]))
+    lo = nd + 2 + (nd % 2)                                             # even and >= ndim + 2
+    nw = int(rng.choice([lo, lo + 2, 2 * (nd + 3), 64, 100, 130, 256, 258, 1000, 1026, 2050, 4096]))
+    nw = max(nw, lo)
+    nw += nw % 2
+    if nd >= 200:
+        nw = min(nw, 1026) if nw >= lo else lo
+        nw = max(nw, lo)
+    G = int(rng.integers(3, 140 if nd < 200 else 12))
+    nburn = int(rng.integers(0, G))
+    nthin = int(rng.choice([1, 1, 2, 3, 5]))
+    a = float(rng.choice([2.0, 2.0, 1.3, 3.5]))
+    launch = str(rng.choice(["", "graph", "updated", "eager"]))
+    resident = bool(rng.integers(0, 2))
+    return name, nw, nd, G, nburn, nthin, a, launch, resident
+
+
+@pytest.mark.parametrize("trial", range(N_TRIALS))
+def test_random_configuration_equals_the_oracle(kmc, oracle, monkeypatch, trial):
+    rng = np.random.default_rng(9000 + trial)
+    name, nw, nd, G, nburn, nthin, a, launch, resident = _draw_config(rng)
+    dens = {
+        "gauss": (kmc.GaussianIso(0.0, 1.0), oracle.GAUSSIAN_ISO, [0.0, 1.0]),
+        "gauss_shift": (kmc.GaussianIso(-5.0, 3.0), oracle.GAUSSIAN_ISO, [-5.0, 3.0]),
+        "expo": (kmc.Exponential(1.0), oracle.EXPONENTIAL, [1.0]),
+        "rosen": (kmc.Rosenbrock(1.0, 100.0, 20.0), oracle.ROSENBROCK, [1.0, 100.0, 20.0]),
+        "lognormal": (kmc.LogNormal(0.0, 1.0), oracle.LOGNORMAL, [0.0, 1.0]),
+        "mvn2": (kmc.MvNormal2([0.5, -0.25], [[0.47, 0.2], [0.2, 7.0]]), oracle.MVNORMAL2,
+                 kmc.MvNormal2([0.5, -0.25], [[0.47, 0.2], [0.2, 7.0]]).params()),
+    }
+    pdf, did, params = dens[name]
+    if name in ("expo", "lognormal"):
+        th = 0.55 + 0.1 * np.abs(rng.standard_normal((nw, nd)))
+    elif name == "gauss_shift":
+        th = -4.0 + 0.1 * rng.standard_normal((nw, nd))
+    else:
+        th = 0.1 * rng.standard_normal((nw, nd))
+    if launch:
+        monkeypatch.setenv("KMC_LAUNCH", launch)
+    if not resident:
+        monkeypatch.setenv("KMC_NO_RESIDENT", "1")
+    seed = int(rng.integers(1, 2 ** 40))
+    label = f"trial {trial}: {name} {nw}x{nd} G={G} nburn={nburn} nthin={nthin} a={a} launch={launch or 'auto'} resident={resident}"
+    ref = oracle.emcee(oracle.make_config(did, params, nw, nd, G, nburn, nthin, a, seed), th)
+    assert ref["status"] == 0, label
+    with kmc.Sampler(pdf, nw, nd, G, nburn, nthin, a, seed, store_chain=True, store_logp=True, moments=True) as s:
+        s.set_positions(th)
+        left = G
+        while left > 0:                                  # the job in random pieces
+            n = int(min(left, rng.choice([1, 2, 7, 63, 64, 65, 200])))
+            s.run(n)
+            left -= n
+            if rng.random() < 0.3:
+                s.sync()
+        s.sync()
+        chain, clogp = s.chain()
+        np.testing.assert_array_equal(s.naccept(), ref["naccept"], err_msg=label)
+        np.testing.assert_array_equal(s.positions(), ref["final_pos"], err_msg=label)
+        np.testing.assert_array_equal(chain, ref["chain"], err_msg=label)
+        tol = 1e-12 * np.maximum(1.0, np.abs(ref["final_logp"]))
+        assert np.all(np.abs(s.logp() - ref["final_logp"]) <= tol), label
+        tol = 1e-12 * np.maximum(1.0, np.abs(ref["chain_logp"]))
+        assert np.all(np.abs(clogp - ref["chain_logp"]) <= tol), label
+        msum, msq, n = s.moments()
+        assert n == ref["nmoment"], label
+        np.testing.assert_allclose(msum, ref["sum"], rtol=1e-11, atol=1e-9, err_msg=label)
+        np.testing.assert_allclose(msq, ref["sumsq"], rtol=1e-11, atol=1e-9, err_msg=label)
+        cw, lw = s.chain(by_walker=True)
+        np.testing.assert_array_equal(cw, chain.transpose(1, 0, 2), err_msg=label)
+        np.testing.assert_array_equal(lw, clogp.T, err_msg=label)
