@@ -143,6 +143,31 @@ def other_configs(kmc, device: int):
                 out[name] = rec
         except Exception as e:  # noqa: BLE001
             out[name] = {"error": str(e)}
+    # "report also one run with nthin such that the chain fits (e.g. 50 stored samples/walker)" -- the C2 job with its
+    # chain and log-pdfs stored (nthin = 100), then read out in the reference's order thetas[w][k] (device transposition + D2H)
+    try:
+        import time
+        nw, nd, G, nthin = 65536, 32, 10000, 100
+        th = np.random.default_rng(SEED).standard_normal((nw, nd))
+        with kmc.Sampler(kmc.GaussianIso(), nw, nd, G, G // 2, nthin, 2.0, SEED, device=device, moments=True, store_chain=True, store_logp=True) as s:
+            s.set_positions(th)
+            s.run(256)
+            s.sync()
+            s.set_positions(th)
+            s.run(G)
+            s.sync()
+            ms = s.last_run_ms()
+            t0 = time.perf_counter()
+            ch, lp = s.chain(by_walker=True)
+            t_read = time.perf_counter() - t0
+            us_half = ms * 1e3 / (2 * G)
+            out["C2_chain_on"] = {"workload": "C2 with the chain and log-pdfs stored, nthin = 100 (50 samples per walker)", "value": nw * G / (ms * 1e-3),
+                                  "unit": "walker-steps/s", "us_per_half_step": us_half, "chain_bytes": int(ch.nbytes + lp.nbytes),
+                                  "readout_by_walker_ms": t_read * 1e3, "readout": "thetas[w][k] order: transposed on the device, then one D2H copy per piece (pageable host array)",
+                                  "chain_shape": list(ch.shape)}
+            del ch, lp
+    except Exception as e:  # noqa: BLE001
+        out["C2_chain_on"] = {"error": str(e)}
     return out
 
 
