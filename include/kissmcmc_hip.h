@@ -15,6 +15,9 @@
  *   - extern "C", plain pointers and sizes, caller owns every host buffer.
  *   - Every function returns a kmc_status; kmc_last_error() gives the message of the last
  *     failure on the calling thread.  Nothing aborts the process.
+ *   - Threads: any number of handles may be used at once, each by one host thread at a time (the reference's own
+ *     call is a blocking function, src/samplers.jl:188).  The library never uses the legacy (null) stream, so one
+ *     thread's blocking copies do not disturb the hipGraph capture of another.
  *   - Ensembles are dense row-major [nwalkers][ndim] arrays of double, walker order = the
  *     reference's (walkers 0..nwalkers/2-1 are the first half of src/samplers.jl:247).
  *   - "generation" = one pass of src/samplers.jl:245 (two half-steps, every walker proposes

@@ -58,6 +58,7 @@ struct HipfftApi {
     decltype(&hipfftExecD2Z) exec_d2z = nullptr;
     decltype(&hipfftExecZ2D) exec_z2d = nullptr;
     decltype(&hipfftDestroy) destroy = nullptr;
+    decltype(&hipfftSetStream) set_stream = nullptr;
 };
 
 const HipfftApi* hipfft_api()
@@ -74,8 +75,9 @@ const HipfftApi* hipfft_api()
         api.exec_d2z = reinterpret_cast<decltype(api.exec_d2z)>(dlsym(api.lib, "hipfftExecD2Z"));
         api.exec_z2d = reinterpret_cast<decltype(api.exec_z2d)>(dlsym(api.lib, "hipfftExecZ2D"));
         api.destroy = reinterpret_cast<decltype(api.destroy)>(dlsym(api.lib, "hipfftDestroy"));
+        api.set_stream = reinterpret_cast<decltype(api.set_stream)>(dlsym(api.lib, "hipfftSetStream"));
     });
-    return (api.lib && api.plan_many && api.exec_d2z && api.exec_z2d && api.destroy) ? &api : nullptr;
+    return (api.lib && api.plan_many && api.exec_d2z && api.exec_z2d && api.destroy && api.set_stream) ? &api : nullptr;
 }
 
 struct AcorrBuffers {
@@ -100,6 +102,9 @@ kmc_status int_acorr_device(const double* chain_dev, int64_t nsamples, int64_t n
                             double* tau, double* converged)
 {
     const int64_t batch = nwalkers * ndim, nlag = nsamples / 2, nfreq = nsamples / 2 + 1;
+    ScopedStream ss;                              // never the legacy stream (kmc_host.hpp: copy_sync)
+    HIP_TRY(ss.create());
+    const hipStream_t st = ss.st;
     AcorrBuffers b;
     b.api = hipfft_api();
     if (!b.api) return fail(KMC_ERR_UNSUPPORTED, "libhipfft.so could not be loaded");
@@ -112,17 +117,18 @@ kmc_status int_acorr_device(const double* chain_dev, int64_t nsamples, int64_t n
     if (b.api->plan_many(&b.fwd, 1, n, inembed, (int)batch, 1, onembed, (int)batch, 1, HIPFFT_D2Z, (int)batch) != HIPFFT_SUCCESS ||
         b.api->plan_many(&b.inv, 1, n, onembed, (int)batch, 1, inembed, (int)batch, 1, HIPFFT_Z2D, (int)batch) != HIPFFT_SUCCESS)
         return fail(KMC_ERR_HIP, "hipfftPlanMany failed");
-    hipLaunchKernelGGL(acorr_center, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, nullptr, chain_dev, b.y, nsamples, batch);
+    if (b.api->set_stream(b.fwd, st) != HIPFFT_SUCCESS || b.api->set_stream(b.inv, st) != HIPFFT_SUCCESS) return fail(KMC_ERR_HIP, "hipfftSetStream failed");
+    hipLaunchKernelGGL(acorr_center, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, st, chain_dev, b.y, nsamples, batch);
     HIP_TRY(hipGetLastError());
     if (b.api->exec_d2z(b.fwd, b.y, reinterpret_cast<hipfftDoubleComplex*>(b.z)) != HIPFFT_SUCCESS) return fail(KMC_ERR_HIP, "hipfftExecD2Z failed");
     const int64_t nz = nfreq * batch;
-    hipLaunchKernelGGL(acorr_power, dim3((unsigned)((nz + 255) / 256)), dim3(256), 0, nullptr, b.z, nz);
+    hipLaunchKernelGGL(acorr_power, dim3((unsigned)((nz + 255) / 256)), dim3(256), 0, st, b.z, nz);
     HIP_TRY(hipGetLastError());
     if (b.api->exec_z2d(b.inv, reinterpret_cast<hipfftDoubleComplex*>(b.z), b.y) != HIPFFT_SUCCESS) return fail(KMC_ERR_HIP, "hipfftExecZ2D failed");
-    hipLaunchKernelGGL(acorr_rho, dim3((unsigned)((nlag * ndim + 255) / 256)), dim3(256), 0, nullptr, b.y, b.rho, nlag, nwalkers, ndim);
+    hipLaunchKernelGGL(acorr_rho, dim3((unsigned)((nlag * ndim + 255) / 256)), dim3(256), 0, st, b.y, b.rho, nlag, nwalkers, ndim);
     HIP_TRY(hipGetLastError());
     std::vector<double> rho((size_t)nlag * (size_t)ndim);
-    HIP_TRY(hipMemcpy(rho.data(), b.rho, rho.size() * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(copy_sync(rho.data(), b.rho, rho.size() * sizeof(double), hipMemcpyDeviceToHost, st));
     bool bad = false;
     for (int64_t d = 0; d < ndim; ++d) {
         const double* r = rho.data() + d * nlag;
@@ -168,7 +174,11 @@ KMC_EXPORT kmc_status kmc_int_acorr(const double* chain_host, int64_t nsamples, 
     AcorrBuffers b;
     const size_t nreal = (size_t)nsamples * (size_t)nwalkers * (size_t)ndim;
     HIP_TRY(hipMalloc(&b.chain, nreal * sizeof(double)));
-    HIP_TRY(hipMemcpy(b.chain, chain_host, nreal * sizeof(double), hipMemcpyHostToDevice));
+    {
+        ScopedStream up;
+        HIP_TRY(up.create());
+        HIP_TRY(copy_sync(b.chain, chain_host, nreal * sizeof(double), hipMemcpyHostToDevice, up.st));
+    }
     return int_acorr_device(b.chain, nsamples, nwalkers, ndim, c, tau, converged);
 }
 

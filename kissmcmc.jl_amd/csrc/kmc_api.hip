@@ -850,10 +850,10 @@ hipError_t upload_rows(const kmc_sampler* s, double* dst_dev, const double* src_
         std::vector<float> t(rows * ld, 0.0f);
         for (size_t r = 0; r < rows; ++r)
             for (size_t d = 0; d < nd; ++d) t[r * ld + d] = (float)src_host[r * nd + d];
-        return hipMemcpy(dst_dev, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice);
+        return copy_sync(dst_dev, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice, s->stream);
     }
-    if (ld == nd) return hipMemcpy(dst_dev, src_host, rows * nd * sizeof(double), hipMemcpyHostToDevice);
-    return hipMemcpy2D(dst_dev, ld * sizeof(double), src_host, nd * sizeof(double), nd * sizeof(double), rows, hipMemcpyHostToDevice);
+    if (ld == nd) return copy_sync(dst_dev, src_host, rows * nd * sizeof(double), hipMemcpyHostToDevice, s->stream);
+    return copy2d_sync(dst_dev, ld * sizeof(double), src_host, nd * sizeof(double), nd * sizeof(double), rows, hipMemcpyHostToDevice, s->stream);
 }
 hipError_t download_rows(const kmc_sampler* s, double* dst_host, const double* src_dev, size_t rows)
 {
@@ -864,15 +864,15 @@ hipError_t download_rows(const kmc_sampler* s, double* dst_host, const double* s
         std::vector<float> t((rows < slab ? rows : slab) * ld);
         for (size_t r0 = 0; r0 < rows; r0 += slab) {
             const size_t n = rows - r0 < slab ? rows - r0 : slab;
-            const hipError_t e = hipMemcpy(t.data(), reinterpret_cast<const float*>(src_dev) + r0 * ld, n * ld * sizeof(float), hipMemcpyDeviceToHost);
+            const hipError_t e = copy_sync(t.data(), reinterpret_cast<const float*>(src_dev) + r0 * ld, n * ld * sizeof(float), hipMemcpyDeviceToHost, s->stream);
             if (e != hipSuccess) return e;
             for (size_t r = 0; r < n; ++r)
                 for (size_t d = 0; d < nd; ++d) dst_host[(r0 + r) * nd + d] = (double)t[r * ld + d];
         }
         return hipSuccess;
     }
-    if (ld == nd) return hipMemcpy(dst_host, src_dev, rows * nd * sizeof(double), hipMemcpyDeviceToHost);
-    return hipMemcpy2D(dst_host, nd * sizeof(double), src_dev, ld * sizeof(double), nd * sizeof(double), rows, hipMemcpyDeviceToHost);
+    if (ld == nd) return copy_sync(dst_host, src_dev, rows * nd * sizeof(double), hipMemcpyDeviceToHost, s->stream);
+    return copy2d_sync(dst_host, nd * sizeof(double), src_dev, ld * sizeof(double), nd * sizeof(double), rows, hipMemcpyDeviceToHost, s->stream);
 }
 
 int64_t samples_done(const kmc_sampler* s)
@@ -1004,7 +1004,7 @@ kmc_status check_p2p_err(kmc_sampler* s)
 {
     if (!s->p2p || !s->d_err) return KMC_OK;
     unsigned long long e = 0;
-    HIP_TRY(hipMemcpy(&e, s->d_err, sizeof(e), hipMemcpyDeviceToHost));
+    HIP_TRY(copy_sync(&e, s->d_err, sizeof(e), hipMemcpyDeviceToHost, s->stream));
     if (e != 0)
         return fail(KMC_ERR_HIP, "p2p: timed out waiting for a peer before half-step " + std::to_string(e - 1) + " (results are invalid)");
     return KMC_OK;
@@ -1279,11 +1279,11 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
     const size_t nw = (size_t)s->nrows;
     if (s->p2p) {
         CREATE_TRY(hipExtMallocWithFlags((void**)&s->d_flags, 4096, hipDeviceMallocFinegrained));
-        CREATE_TRY(hipMemset(s->d_flags, 0, 4096));
+        CREATE_TRY(fill_sync(s->d_flags, 0, 4096, s->stream));
         CREATE_TRY(hipMalloc((void**)&s->d_err, 64));
-        CREATE_TRY(hipMemset(s->d_err, 0, 64));
+        CREATE_TRY(fill_sync(s->d_err, 0, 64, s->stream));
         CREATE_TRY(hipMalloc((void**)&s->d_done, 33 * 64));
-        CREATE_TRY(hipMemset(s->d_done, 0, 33 * 64));
+        CREATE_TRY(fill_sync(s->d_done, 0, 33 * 64, s->stream));
         // the kernel can publish its own completion only where all its stores are write-through: the vector kernels
         s->fold_signal = (cfg->flags & KMC_P2P_FOLD_SIGNAL) != 0 && s->plan.vec && s->user == nullptr;
         s->push = (cfg->flags & (KMC_P2P_PUSH | KMC_P2P_LAZY)) != 0 && s->plan.vec && s->user == nullptr && !(cfg->flags & KMC_P2P_FINEGRAINED) &&
@@ -1299,12 +1299,12 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         CREATE_TRY(hipExtMallocWithFlags((void**)&s->d_pos, nw * ldz * sizeof(double), hipDeviceMallocFinegrained));
     else
         CREATE_TRY(hipMalloc(&s->d_pos, (s->push ? 1 + (size_t)s->cfg.shard_count : 1) * nw * ldz * esz + amap_bytes));
-    CREATE_TRY(hipMemset(s->d_pos, 0, (s->push ? 1 + (size_t)s->cfg.shard_count : 1) * nw * ldz * esz + amap_bytes));   // the pad column of odd ndim stays 0
+    CREATE_TRY(fill_sync(s->d_pos, 0, (s->push ? 1 + (size_t)s->cfg.shard_count : 1) * nw * ldz * esz + amap_bytes, s->stream));   // the pad column of odd ndim stays 0
     if (s->lazy) {
         const size_t P = (size_t)s->cfg.shard_count, hl = (size_t)s->h_loc;
         const size_t nb = 2 * P * 2 * hl * sizeof(uint32_t) + 16;
         CREATE_TRY(hipMalloc((void**)&s->d_lazy, nb));
-        CREATE_TRY(hipMemset(s->d_lazy, 0, nb));
+        CREATE_TRY(fill_sync(s->d_lazy, 0, nb, s->stream));
         s->peer_amap_in[s->cfg.shard_rank] = reinterpret_cast<unsigned char*>(s->d_pos) + (1 + P) * nw * ldz * esz;
     }
     // per-walker block {logp[nrows], naccept[nrows], klast[nrows]}: one allocation, so the half-step kernels reach all
@@ -1312,25 +1312,25 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
     CREATE_TRY(hipMalloc(&s->d_logp, nw * (sizeof(double) + 2 * sizeof(uint32_t))));
     s->d_naccept = reinterpret_cast<uint32_t*>(s->d_logp + nw);
     s->d_klast = s->d_naccept + nw;
-    CREATE_TRY(hipMemset(s->d_klast, 0, nw * sizeof(uint32_t)));
+    CREATE_TRY(fill_sync(s->d_klast, 0, nw * sizeof(uint32_t), s->stream));
     static_assert(kGraphChunk <= 64, "advance_schedule runs one 64-thread block");
     CREATE_TRY(hipMalloc(&s->d_gen, 64));
-    CREATE_TRY(hipMemset(s->d_gen, 0, 64));
+    CREATE_TRY(fill_sync(s->d_gen, 0, 64, s->stream));
     CREATE_TRY(hipMalloc(&s->d_sched, (size_t)kGraphChunk * sizeof(SchedEntry)));
-    CREATE_TRY(hipMemset(s->d_naccept, 0, nw * sizeof(uint32_t)));
+    CREATE_TRY(fill_sync(s->d_naccept, 0, nw * sizeof(uint32_t), s->stream));
     if (cfg->deal_count > 0) CREATE_TRY(hipMalloc((void**)&s->d_ids, nw * sizeof(uint32_t)));
     if (s->plan.vec && !s->islands && !s->resident && s->plan.L >= 16 && s->plan.L <= 32 && s->plan.L / s->plan.ITER >= 2 &&
         std::getenv("KMC_NO_DRAW_RING") == nullptr) {
         // draw ring: 4 slots x rows x 32 B; tags start at 0xffffffff (no step carries it), so nothing is "parked" yet
         const size_t nb = 4 * (size_t)s->nrows * 2 * sizeof(double2);
         CREATE_TRY(hipMalloc((void**)&s->d_ring, nb));
-        CREATE_TRY(hipMemset(s->d_ring, 0xff, nb));
+        CREATE_TRY(fill_sync(s->d_ring, 0xff, nb, s->stream));
     }
     if (cfg->flags & KMC_MOMENTS) {
         CREATE_TRY(hipMalloc(&s->d_msum, (size_t)s->macc_elems * sizeof(double)));
         CREATE_TRY(hipMalloc(&s->d_msumsq, (size_t)s->macc_elems * sizeof(double)));
-        CREATE_TRY(hipMemset(s->d_msum, 0, (size_t)s->macc_elems * sizeof(double)));
-        CREATE_TRY(hipMemset(s->d_msumsq, 0, (size_t)s->macc_elems * sizeof(double)));
+        CREATE_TRY(fill_sync(s->d_msum, 0, (size_t)s->macc_elems * sizeof(double), s->stream));
+        CREATE_TRY(fill_sync(s->d_msumsq, 0, (size_t)s->macc_elems * sizeof(double), s->stream));
         if (s->plan.vec && s->plan.L == 64 && !s->islands && !s->resident && std::getenv("KMC_NO_MOMENT_RING") == nullptr) {
             // moment ring for long rows (kmc_kernels.hpp, HalfStepArgs::mring): up to 128 posted rows per wave,
             // within 512 MiB in all; swept every kSweepEvery generations
@@ -1343,7 +1343,7 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
                 CREATE_TRY(hipMalloc((void**)&s->d_mring, (size_t)nwaves * (size_t)depth * slot));
                 CREATE_TRY(hipMalloc((void**)&s->d_mring_w, (size_t)nwaves * (size_t)depth * sizeof(double)));
                 CREATE_TRY(hipMalloc((void**)&s->d_mcnt, 2 * (size_t)nwaves * sizeof(uint32_t)));
-                CREATE_TRY(hipMemset(s->d_mcnt, 0, 2 * (size_t)nwaves * sizeof(uint32_t)));
+                CREATE_TRY(fill_sync(s->d_mcnt, 0, 2 * (size_t)nwaves * sizeof(uint32_t), s->stream));
                 s->mring_depth = (int)depth;
                 s->mring_waves = nwaves;
             }
@@ -1352,8 +1352,8 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
             const size_t ne = (size_t)s->nislands * 4 * (size_t)s->island_K;
             CREATE_TRY(hipMalloc(&s->d_isum, ne * sizeof(double)));
             CREATE_TRY(hipMalloc(&s->d_isumsq, ne * sizeof(double)));
-            CREATE_TRY(hipMemset(s->d_isum, 0, ne * sizeof(double)));
-            CREATE_TRY(hipMemset(s->d_isumsq, 0, ne * sizeof(double)));
+            CREATE_TRY(fill_sync(s->d_isum, 0, ne * sizeof(double), s->stream));
+            CREATE_TRY(fill_sync(s->d_isumsq, 0, ne * sizeof(double), s->stream));
         }
     }
     if (s->host_eval) {
@@ -1589,7 +1589,7 @@ KMC_EXPORT kmc_status kmc_sampler_p2p_stats(kmc_sampler* s, uint64_t out[2])
     HIP_TRY(hipStreamSynchronize(s->stream));
     const size_t hl = (size_t)s->h_loc, P = (size_t)s->cfg.shard_count;
     unsigned long long v[2] = {0ull, 0ull};
-    HIP_TRY(hipMemcpy(v, s->d_lazy + 2 * P * 2 * hl * sizeof(uint32_t), sizeof(v), hipMemcpyDeviceToHost));
+    HIP_TRY(copy_sync(v, s->d_lazy + 2 * P * 2 * hl * sizeof(uint32_t), sizeof(v), hipMemcpyDeviceToHost, s->stream));
     out[0] = v[0]; out[1] = v[1];
     return KMC_OK;
 }
@@ -1685,13 +1685,13 @@ KMC_EXPORT kmc_status kmc_sampler_init_ball(kmc_sampler* s, const double* theta0
     unsigned long long* d_fail = nullptr;
     HIP_TRY(hipMalloc((void**)&d_par, 2 * nd * sizeof(double)));
     hipError_t e = hipMalloc((void**)&d_fail, sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMemcpy(d_par, theta0, nd * sizeof(double), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(d_par + nd, ball_radius, nd * sizeof(double), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemset(d_fail, 0, sizeof(unsigned long long));
+    if (e == hipSuccess) e = copy_sync(d_par, theta0, nd * sizeof(double), hipMemcpyHostToDevice, s->stream);
+    if (e == hipSuccess) e = copy_sync(d_par + nd, ball_radius, nd * sizeof(double), hipMemcpyHostToDevice, s->stream);
+    if (e == hipSuccess) e = fill_sync(d_fail, 0, sizeof(unsigned long long), s->stream);
     const size_t nelem = (size_t)s->nrows * (size_t)s->ld;
     double* d_ball = s->d_pos;                  // KMC_F32: the ball is drawn in double, then rounded into the float rows
     if (s->f32 && e == hipSuccess) e = hipMalloc((void**)&d_ball, nelem * sizeof(double));
-    if (e == hipSuccess) e = hipMemset(d_ball, 0, nelem * sizeof(double));
+    if (e == hipSuccess) e = fill_sync(d_ball, 0, nelem * sizeof(double), s->stream);
     InitBallFn fn = s->user ? nullptr : init_ball_fn(s->cfg.density);
     const int pieces = s->p2p ? 2 : 1;
     for (int piece = 0; piece < pieces && e == hipSuccess; ++piece) {
@@ -1718,7 +1718,7 @@ KMC_EXPORT kmc_status kmc_sampler_init_ball(kmc_sampler* s, const double* theta0
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
-    if (e == hipSuccess) e = hipMemcpy(&nfail, d_fail, sizeof(nfail), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = copy_sync(&nfail, d_fail, sizeof(nfail), hipMemcpyDeviceToHost, s->stream);
     (void)hipFree(d_par);
     (void)hipFree(d_fail);
     if (s->f32) (void)hipFree(d_ball);
@@ -1731,9 +1731,9 @@ KMC_EXPORT kmc_status kmc_sampler_init_ball(kmc_sampler* s, const double* theta0
     HIP_TRY(hipMemsetAsync(s->d_naccept, 0, (size_t)s->nrows * sizeof(uint32_t), s->stream));
     HIP_TRY(hipMemsetAsync(s->d_gen, 0, 64, s->stream));
     if (s->p2p) {
-        HIP_TRY(hipMemset(s->d_flags, 0, 4096));
-        HIP_TRY(hipMemset(s->d_err, 0, 64));
-        if (s->d_done) HIP_TRY(hipMemset(s->d_done, 0, 33 * 64));
+        HIP_TRY(fill_sync(s->d_flags, 0, 4096, s->stream));
+        HIP_TRY(fill_sync(s->d_err, 0, 64, s->stream));
+        if (s->d_done) HIP_TRY(fill_sync(s->d_done, 0, 33 * 64, s->stream));
     }
     s->dev_gen = 0;
     s->moment_base = 0;
@@ -1760,14 +1760,14 @@ KMC_EXPORT kmc_status kmc_sampler_set_state(kmc_sampler* s, const double* pos_ho
     HIP_TRY(hipStreamSynchronize(s->stream));
     const size_t nw = (size_t)s->nrows;
     HIP_TRY(upload_rows(s, s->d_pos, pos_host, nw));
-    HIP_TRY(hipMemcpy(s->d_logp, logp_host, nw * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(copy_sync(s->d_logp, logp_host, nw * sizeof(double), hipMemcpyHostToDevice, s->stream));
     std::vector<uint32_t> na(nw, 0u);
     if (naccept_host) for (size_t i = 0; i < nw; ++i) na[i] = (uint32_t)naccept_host[i];
-    HIP_TRY(hipMemcpy(s->d_naccept, na.data(), nw * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(copy_sync(s->d_naccept, na.data(), nw * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
     if (s->p2p) {
-        HIP_TRY(hipMemset(s->d_flags, 0, 4096));
-        HIP_TRY(hipMemset(s->d_err, 0, 64));
-        if (s->d_done) HIP_TRY(hipMemset(s->d_done, 0, 33 * 64));
+        HIP_TRY(fill_sync(s->d_flags, 0, 4096, s->stream));
+        HIP_TRY(fill_sync(s->d_err, 0, 64, s->stream));
+        if (s->d_done) HIP_TRY(fill_sync(s->d_done, 0, 33 * 64, s->stream));
     }
     s->generation = generation;            // the device counter follows at the next graph replay
     const int64_t done = samples_done(s);
@@ -1797,13 +1797,13 @@ KMC_EXPORT kmc_status kmc_sampler_set_positions(kmc_sampler* s, const double* th
                 HIP_TRY(upload_rows(s, blk + hl * (size_t)s->ld, theta_host + ((size_t)s->h + (size_t)q * hl) * nd, hl));
             }
         }
-        HIP_TRY(hipMemset(s->d_flags, 0, 4096));     // callers barrier across ranks before running
-        HIP_TRY(hipMemset(s->d_err, 0, 64));
-        if (s->d_done) HIP_TRY(hipMemset(s->d_done, 0, 33 * 64));
+        HIP_TRY(fill_sync(s->d_flags, 0, 4096, s->stream));     // callers barrier across ranks before running
+        HIP_TRY(fill_sync(s->d_err, 0, 64, s->stream));
+        if (s->d_done) HIP_TRY(fill_sync(s->d_done, 0, 33 * 64, s->stream));
         if (s->lazy) {                               // every shadow is current, nothing has been accepted yet
             const size_t P = (size_t)s->cfg.shard_count, hl = (size_t)s->h_loc;
-            HIP_TRY(hipMemset(s->d_lazy, 0, 2 * P * 2 * hl * sizeof(uint32_t) + 16));
-            HIP_TRY(hipMemset(s->peer_amap_in[s->cfg.shard_rank], 0, P * 4 * hl));
+            HIP_TRY(fill_sync(s->d_lazy, 0, 2 * P * 2 * hl * sizeof(uint32_t) + 16, s->stream));
+            HIP_TRY(fill_sync(s->peer_amap_in[s->cfg.shard_rank], 0, P * 4 * hl, s->stream));
         }
     }
     if (s->host_eval) {                                          // :209-210, on the caller's thread
@@ -1812,7 +1812,7 @@ KMC_EXPORT kmc_status kmc_sampler_set_positions(kmc_sampler* s, const double* th
             s->positions_set = false;
             return fail(KMC_ERR_BAD_ARG, "the host log-pdf callback failed on the initial ensemble");
         }
-        HIP_TRY(hipMemcpy(s->d_logp, lp0.data(), nw * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(copy_sync(s->d_logp, lp0.data(), nw * sizeof(double), hipMemcpyHostToDevice, s->stream));
     } else {
         KMC_TRY(eval_initial_logp(s));                           // :209-210
     }
@@ -2219,7 +2219,7 @@ KMC_EXPORT kmc_status kmc_sampler_get_logp(kmc_sampler* s, double* host)
     HIP_TRY(hipSetDevice(s->cfg.device));
     HIP_TRY(hipStreamSynchronize(s->stream));
     KMC_TRY(check_p2p_err(s));
-    HIP_TRY(hipMemcpy(host, s->d_logp, (size_t)s->nrows * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(copy_sync(host, s->d_logp, (size_t)s->nrows * sizeof(double), hipMemcpyDeviceToHost, s->stream));
     return KMC_OK;
 }
 
@@ -2230,7 +2230,7 @@ KMC_EXPORT kmc_status kmc_sampler_get_naccept(kmc_sampler* s, int64_t* host)
     HIP_TRY(hipStreamSynchronize(s->stream));
     KMC_TRY(check_p2p_err(s));
     std::vector<uint32_t> tmp((size_t)s->nrows);
-    HIP_TRY(hipMemcpy(tmp.data(), s->d_naccept, tmp.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(copy_sync(tmp.data(), s->d_naccept, tmp.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
     for (size_t i = 0; i < tmp.size(); ++i) host[i] = (int64_t)tmp[i];
     return KMC_OK;
 }
@@ -2255,8 +2255,8 @@ KMC_EXPORT kmc_status kmc_sampler_get_moments(kmc_sampler* s, double* sum, doubl
         const int64_t nd = s->cfg.ndim;
         const size_t per = 4 * (size_t)s->island_K, ne = (size_t)s->nislands * per;
         std::vector<double> hs(ne), hq(ne);
-        HIP_TRY(hipMemcpy(hs.data(), s->d_isum, ne * sizeof(double), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(hq.data(), s->d_isumsq, ne * sizeof(double), hipMemcpyDeviceToHost));
+        HIP_TRY(copy_sync(hs.data(), s->d_isum, ne * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(copy_sync(hq.data(), s->d_isumsq, ne * sizeof(double), hipMemcpyDeviceToHost, s->stream));
         std::vector<double> S((size_t)nd, 0.0), Q((size_t)nd, 0.0);
         for (int64_t b = 0; b < s->nislands; ++b)
             for (size_t e = 0; e < per; ++e)
@@ -2273,8 +2273,8 @@ KMC_EXPORT kmc_status kmc_sampler_get_moments(kmc_sampler* s, double* sum, doubl
     KMC_TRY(check_p2p_err(s));
     const int64_t nd = s->cfg.ndim;
     std::vector<double> hs((size_t)s->macc_elems), hq((size_t)s->macc_elems);
-    HIP_TRY(hipMemcpy(hs.data(), s->d_msum, hs.size() * sizeof(double), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(hq.data(), s->d_msumsq, hq.size() * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(copy_sync(hs.data(), s->d_msum, hs.size() * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(copy_sync(hq.data(), s->d_msumsq, hq.size() * sizeof(double), hipMemcpyDeviceToHost, s->stream));
     std::vector<double> S((size_t)nd, 0.0), Q((size_t)nd, 0.0);
     if (s->plan.vec && s->plan.K == 2 && (s->plan.L == 8 || s->plan.L == 16 || s->plan.L == 32)) {
         // transposed fold (kmc_kernels.hpp, FoldT): every lane of a wave owns NVL of the wave's 8 L / 64 * 64 sums
@@ -2337,7 +2337,7 @@ KMC_EXPORT kmc_status kmc_sampler_get_chain(kmc_sampler* s, double* chain, doubl
     }
     if (chain_logp) {
         if (!s->d_chain_logp && s->nsamples > 0) return fail(KMC_ERR_BAD_ARG, "sampler was created without KMC_STORE_LOGP");
-        if (rows) HIP_TRY(hipMemcpy(chain_logp, s->d_chain_logp, rows * sizeof(double), hipMemcpyDeviceToHost));
+        if (rows) HIP_TRY(copy_sync(chain_logp, s->d_chain_logp, rows * sizeof(double), hipMemcpyDeviceToHost, s->stream));
     }
     return KMC_OK;
 }
@@ -2460,7 +2460,7 @@ KMC_EXPORT kmc_status kmc_sampler_get_walker_ids(kmc_sampler* s, int64_t* host)
     HIP_TRY(hipStreamSynchronize(s->stream));
     if (!s->d_ids) { for (int64_t i = 0; i < s->nrows; ++i) host[i] = i; return KMC_OK; }
     std::vector<uint32_t> tmp((size_t)s->nrows);
-    HIP_TRY(hipMemcpy(tmp.data(), s->d_ids, tmp.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(copy_sync(tmp.data(), s->d_ids, tmp.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
     for (size_t i = 0; i < tmp.size(); ++i) host[i] = (int64_t)tmp[i];
     return KMC_OK;
 }
@@ -2551,15 +2551,17 @@ KMC_EXPORT kmc_status kmc_logpdf_eval_host(const kmc_config* cfg, const double* 
         return fail(KMC_ERR_NO_DEVICE, "no HIP device visible");
     }
     HIP_TRY(hipSetDevice(cfg->device));
+    ScopedStream ss;
+    HIP_TRY(ss.create());
     double *dpos = nullptr, *dlp = nullptr;
     const size_t nb = (size_t)nrows * (size_t)cfg->ndim * sizeof(double);
     HIP_TRY(hipMalloc(&dpos, nb));
     hipError_t e = hipMalloc(&dlp, (size_t)nrows * sizeof(double));
     kmc_status st = KMC_OK;
-    if (e == hipSuccess) e = hipMemcpy(dpos, pos_host, nb, hipMemcpyHostToDevice);
-    if (e == hipSuccess) st = kmc_logpdf_eval(cfg, dpos, dlp, nrows, nullptr);
-    if (e == hipSuccess && st == KMC_OK) e = hipDeviceSynchronize();
-    if (e == hipSuccess && st == KMC_OK) e = hipMemcpy(logp_host, dlp, (size_t)nrows * sizeof(double), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = copy_sync(dpos, pos_host, nb, hipMemcpyHostToDevice, ss.st);
+    if (e == hipSuccess) st = kmc_logpdf_eval(cfg, dpos, dlp, nrows, ss.st);
+    if (e == hipSuccess && st == KMC_OK) e = hipStreamSynchronize(ss.st);
+    if (e == hipSuccess && st == KMC_OK) e = copy_sync(logp_host, dlp, (size_t)nrows * sizeof(double), hipMemcpyDeviceToHost, ss.st);
     (void)hipFree(dpos);
     (void)hipFree(dlp);
     if (st != KMC_OK) return st;

@@ -47,6 +47,31 @@ bool lookup(int density, int L, int K, int iter, bool p2p, bool ragged, bool f32
 kmc_status digest_params(const kmc_config& c, kmc::DensityParams* dp);
 
 // runtime-compiled user densities (hiprtc)
+// Blocking copies / fills WITHOUT the legacy (null) stream: hipMemcpy, hipMemset and hipDeviceSynchronize go through it, and
+// a legacy-stream operation issued while ANOTHER host thread captures a hipGraph fails ("would make the legacy stream depend
+// on a capturing stream") and invalidates that capture.  Everything here runs on a stream the caller names and waits for it.
+inline hipError_t copy_sync(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t st)
+{
+    const hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, st);
+    return e != hipSuccess ? e : hipStreamSynchronize(st);
+}
+inline hipError_t copy2d_sync(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height, hipMemcpyKind kind, hipStream_t st)
+{
+    const hipError_t e = hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, kind, st);
+    return e != hipSuccess ? e : hipStreamSynchronize(st);
+}
+inline hipError_t fill_sync(void* dst, int value, size_t bytes, hipStream_t st)
+{
+    const hipError_t e = hipMemsetAsync(dst, value, bytes, st);
+    return e != hipSuccess ? e : hipStreamSynchronize(st);
+}
+// a private non-blocking stream for the duration of one call
+struct ScopedStream {
+    hipStream_t st = nullptr;
+    hipError_t create() { return hipStreamCreateWithFlags(&st, hipStreamNonBlocking); }
+    ~ScopedStream() { if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); } }
+};
+
 kmc_status download_by_walker(const void* src_dev, bool is_float, int64_t nl, int64_t ld, int64_t width, int64_t K, double* dst_host, hipStream_t st);
 std::string user_functor_source(const kmc_user_density* ud);      // the functor(s) ...
 std::string user_density_alias(const kmc_user_density* ud, int64_t ndim);   // ... and "using UD = ...;" over them

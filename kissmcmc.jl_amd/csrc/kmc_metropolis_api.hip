@@ -107,6 +107,9 @@ kmc_status metropolis_host_route(const kmc_metropolis_config* c, const double* t
                                  const DensityParams& dp, int64_t nsamples)
 {
     const int64_t nc = c->nchains, nd = c->ndim;
+    ScopedStream ss;                              // never the legacy stream (kmc_host.hpp: copy_sync)
+    HIP_TRY(ss.create());
+    const hipStream_t st = ss.st;
     const size_t rows = (size_t)nc * (size_t)nd * sizeof(double), vec = (size_t)nc * sizeof(double);
     const bool host_pdf = c->density == KMC_HOST_DENSITY;
     const bool want_chain = (c->flags & KMC_STORE_CHAIN) != 0, want_logp = (c->flags & KMC_STORE_LOGP) != 0, want_mom = (c->flags & KMC_MOMENTS) != 0;
@@ -135,19 +138,19 @@ kmc_status metropolis_host_route(const kmc_metropolis_config* c, const double* t
     HIP_TRY(hipMalloc(&b.logp, vec));
     HIP_TRY(hipMalloc(&b.p1, vec));
     HIP_TRY(hipMalloc(&b.naccept, (size_t)nc * sizeof(uint32_t)));
-    HIP_TRY(hipMemset(b.naccept, 0, (size_t)nc * sizeof(uint32_t)));
-    HIP_TRY(hipMemcpy(b.pos, theta0, rows, hipMemcpyHostToDevice));                              // :68 deepcopy
+    HIP_TRY(fill_sync(b.naccept, 0, (size_t)nc * sizeof(uint32_t), st));
+    HIP_TRY(copy_sync(b.pos, theta0, rows, hipMemcpyHostToDevice, st));                              // :68 deepcopy
     if (c->step) {
         HIP_TRY(hipMalloc(&b.step, (size_t)nd * sizeof(double)));
-        HIP_TRY(hipMemcpy(b.step, c->step, (size_t)nd * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(copy_sync(b.step, c->step, (size_t)nd * sizeof(double), hipMemcpyHostToDevice, st));
     }
     if (want_chain && nsamples > 0) HIP_TRY(hipMalloc(&b.chain, (size_t)nsamples * rows));
     if (want_logp && nsamples > 0) HIP_TRY(hipMalloc(&b.chain_logp, (size_t)nsamples * vec));
     if (want_mom) {
         HIP_TRY(hipMalloc(&b.csum, rows));
         HIP_TRY(hipMalloc(&b.csumsq, rows));
-        HIP_TRY(hipMemset(b.csum, 0, rows));
-        HIP_TRY(hipMemset(b.csumsq, 0, rows));
+        HIP_TRY(fill_sync(b.csum, 0, rows, st));
+        HIP_TRY(fill_sync(b.csumsq, 0, rows, st));
     }
     HIP_TRY(hipHostMalloc((void**)&b.h_rows, rows, hipHostMallocDefault));
     HIP_TRY(hipHostMalloc((void**)&b.h_prop, rows, hipHostMallocDefault));
@@ -173,20 +176,20 @@ kmc_status metropolis_host_route(const kmc_metropolis_config* c, const double* t
     const unsigned grid = (unsigned)((nc + 255) / 256);
     auto device_logpdf = [&](const double* rows_dev, double* out_dev) -> hipError_t {
         const LogpdfArgs la{rows_dev, out_dev, nc, (int32_t)nd, (int32_t)nd, dp};
-        if (ulp) return launch_module(ulp, grid, 256u, nullptr, la);
-        hipLaunchKernelGGL(lp, dim3(grid), dim3(256), 0, nullptr, la);
+        if (ulp) return launch_module(ulp, grid, 256u, st, la);
+        hipLaunchKernelGGL(lp, dim3(grid), dim3(256), 0, st, la);
         return hipGetLastError();
     };
     // p0 = pdf(theta0) (:70); whatever comes out is carried, -Inf included, as in the reference
     if (host_pdf) {
         if (c->host_logpdf(theta0, nc, nd, b.h_p1, c->host_user) != 0) return fail(KMC_ERR_BAD_ARG, "the host log-pdf callback failed on the initial states");
-        HIP_TRY(hipMemcpy(b.logp, b.h_p1, vec, hipMemcpyHostToDevice));
+        HIP_TRY(copy_sync(b.logp, b.h_p1, vec, hipMemcpyHostToDevice, st));
     } else {
         HIP_TRY(device_logpdf(b.pos, b.logp));
     }
     HIP_TRY(hipEventCreate(&b.ev0));
     HIP_TRY(hipEventCreate(&b.ev1));
-    HIP_TRY(hipEventRecord(b.ev0, nullptr));
+    HIP_TRY(hipEventRecord(b.ev0, st));
     int64_t cnt = 0, slot = 0;
     for (int64_t it = 0; it < c->niter; ++it) {
         const int64_t n = it + 1 - c->nburnin;                                                   // :96
@@ -201,49 +204,49 @@ kmc_status metropolis_host_route(const kmc_metropolis_config* c, const double* t
             ++slot;
         }
         if (c->host_propose) {                                                                   // :98 theta1 = sample_ppdf(theta0)
-            HIP_TRY(hipMemcpy(b.h_rows, b.pos, rows, hipMemcpyDeviceToHost));
+            HIP_TRY(copy_sync(b.h_rows, b.pos, rows, hipMemcpyDeviceToHost, st));
             if (c->host_propose(b.h_rows, nc, nd, b.h_prop, c->host_user) != 0)
                 return fail(KMC_ERR_BAD_ARG, "the host proposal callback failed in iteration " + std::to_string(it));
-            HIP_TRY(hipMemcpy(b.prop, b.h_prop, rows, hipMemcpyHostToDevice));
+            HIP_TRY(copy_sync(b.prop, b.h_prop, rows, hipMemcpyHostToDevice, st));
         } else {
-            hipLaunchKernelGGL(metro_host_propose, dim3(grid), dim3(256), 0, nullptr, a);
+            hipLaunchKernelGGL(metro_host_propose, dim3(grid), dim3(256), 0, st, a);
             HIP_TRY(hipGetLastError());
         }
         if (host_pdf) {                                                                          // :99 p1 = pdf(theta1)
-            if (!c->host_propose) HIP_TRY(hipMemcpy(b.h_prop, b.prop, rows, hipMemcpyDeviceToHost));
+            if (!c->host_propose) HIP_TRY(copy_sync(b.h_prop, b.prop, rows, hipMemcpyDeviceToHost, st));
             if (c->host_logpdf(b.h_prop, nc, nd, b.h_p1, c->host_user) != 0)
                 return fail(KMC_ERR_BAD_ARG, "the host log-pdf callback failed in iteration " + std::to_string(it));
-            HIP_TRY(hipMemcpy(b.p1, b.h_p1, vec, hipMemcpyHostToDevice));
+            HIP_TRY(copy_sync(b.p1, b.h_p1, vec, hipMemcpyHostToDevice, st));
         } else {
             HIP_TRY(device_logpdf(b.prop, b.p1));
         }
-        hipLaunchKernelGGL(metro_host_accept, dim3(grid), dim3(256), 0, nullptr, a);
+        hipLaunchKernelGGL(metro_host_accept, dim3(grid), dim3(256), 0, st, a);
         HIP_TRY(hipGetLastError());
         if (c->host_accepted) {
-            HIP_TRY(hipMemcpy(b.h_acc, b.acc, (size_t)nc, hipMemcpyDeviceToHost));
+            HIP_TRY(copy_sync(b.h_acc, b.acc, (size_t)nc, hipMemcpyDeviceToHost, st));
             if (c->host_accepted(b.h_acc, nc, 0, it, a.store, c->host_user) != 0)
                 return fail(KMC_ERR_BAD_ARG, "the host accept callback failed in iteration " + std::to_string(it));
         }
     }
-    HIP_TRY(hipEventRecord(b.ev1, nullptr));
-    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipEventRecord(b.ev1, st));
+    HIP_TRY(hipStreamSynchronize(st));
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, b.ev0, b.ev1));
     out->device_ms = (double)ms;
     if (c->flags & KMC_CHAIN_BY_WALKER) {       // thetas[chain][sample], as the reference returns them (:113, :128)
-        if (out->chain && b.chain) KMC_TRY(download_by_walker(b.chain, false, nc, nd, nd, nsamples, out->chain, nullptr));
-        if (out->chain_logp && b.chain_logp) KMC_TRY(download_by_walker(b.chain_logp, false, nc, 1, 1, nsamples, out->chain_logp, nullptr));
+        if (out->chain && b.chain) KMC_TRY(download_by_walker(b.chain, false, nc, nd, nd, nsamples, out->chain, st));
+        if (out->chain_logp && b.chain_logp) KMC_TRY(download_by_walker(b.chain_logp, false, nc, 1, 1, nsamples, out->chain_logp, st));
     } else {
-        if (out->chain && b.chain) HIP_TRY(hipMemcpy(out->chain, b.chain, (size_t)nsamples * rows, hipMemcpyDeviceToHost));
-        if (out->chain_logp && b.chain_logp) HIP_TRY(hipMemcpy(out->chain_logp, b.chain_logp, (size_t)nsamples * vec, hipMemcpyDeviceToHost));
+        if (out->chain && b.chain) HIP_TRY(copy_sync(out->chain, b.chain, (size_t)nsamples * rows, hipMemcpyDeviceToHost, st));
+        if (out->chain_logp && b.chain_logp) HIP_TRY(copy_sync(out->chain_logp, b.chain_logp, (size_t)nsamples * vec, hipMemcpyDeviceToHost, st));
     }
-    if (out->final_pos) HIP_TRY(hipMemcpy(out->final_pos, b.pos, rows, hipMemcpyDeviceToHost));
-    if (out->final_logp) HIP_TRY(hipMemcpy(out->final_logp, b.logp, vec, hipMemcpyDeviceToHost));
-    if (out->chain_sum && b.csum) HIP_TRY(hipMemcpy(out->chain_sum, b.csum, rows, hipMemcpyDeviceToHost));
-    if (out->chain_sumsq && b.csumsq) HIP_TRY(hipMemcpy(out->chain_sumsq, b.csumsq, rows, hipMemcpyDeviceToHost));
+    if (out->final_pos) HIP_TRY(copy_sync(out->final_pos, b.pos, rows, hipMemcpyDeviceToHost, st));
+    if (out->final_logp) HIP_TRY(copy_sync(out->final_logp, b.logp, vec, hipMemcpyDeviceToHost, st));
+    if (out->chain_sum && b.csum) HIP_TRY(copy_sync(out->chain_sum, b.csum, rows, hipMemcpyDeviceToHost, st));
+    if (out->chain_sumsq && b.csumsq) HIP_TRY(copy_sync(out->chain_sumsq, b.csumsq, rows, hipMemcpyDeviceToHost, st));
     if (out->naccept || out->accept_ratio) {
         std::vector<uint32_t> na((size_t)nc);
-        HIP_TRY(hipMemcpy(na.data(), b.naccept, (size_t)nc * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        HIP_TRY(copy_sync(na.data(), b.naccept, (size_t)nc * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         const double denom = (double)(c->niter - c->nburnin);                                   // :127
         for (int64_t i = 0; i < nc; ++i) {
             if (out->naccept) out->naccept[i] = (int64_t)na[(size_t)i];
@@ -317,22 +320,25 @@ KMC_EXPORT kmc_status kmc_metropolis_run(const kmc_metropolis_config* c, const d
     if (c->density == KMC_HOST_DENSITY || c->host_propose)
         return metropolis_host_route(c, theta0, out, dp, nsamples);
 
+    ScopedStream ss;                              // never the legacy stream (kmc_host.hpp: copy_sync)
+    HIP_TRY(ss.create());
+    const hipStream_t st = ss.st;
     MetroBuffers b;
     const size_t rows = (size_t)nc * (size_t)nd * sizeof(double);
     HIP_TRY(hipMalloc(&b.pos, rows));
     HIP_TRY(hipMalloc(&b.logp, (size_t)nc * sizeof(double)));
     HIP_TRY(hipMalloc(&b.naccept, (size_t)nc * sizeof(uint32_t)));
-    HIP_TRY(hipMemset(b.naccept, 0, (size_t)nc * sizeof(uint32_t)));
+    HIP_TRY(fill_sync(b.naccept, 0, (size_t)nc * sizeof(uint32_t), st));
     HIP_TRY(hipMalloc(&b.step, (size_t)nd * sizeof(double)));
-    HIP_TRY(hipMemcpy(b.step, c->step, (size_t)nd * sizeof(double), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(b.pos, theta0, rows, hipMemcpyHostToDevice));                              // :68 deepcopy
+    HIP_TRY(copy_sync(b.step, c->step, (size_t)nd * sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_TRY(copy_sync(b.pos, theta0, rows, hipMemcpyHostToDevice, st));                              // :68 deepcopy
     if (want_chain && nsamples > 0) HIP_TRY(hipMalloc(&b.chain, (size_t)nsamples * rows));
     if (want_logp && nsamples > 0) HIP_TRY(hipMalloc(&b.chain_logp, (size_t)nsamples * (size_t)nc * sizeof(double)));
     if (want_mom) {
         HIP_TRY(hipMalloc(&b.csum, rows));
         HIP_TRY(hipMalloc(&b.csumsq, rows));
-        HIP_TRY(hipMemset(b.csum, 0, rows));
-        HIP_TRY(hipMemset(b.csumsq, 0, rows));
+        HIP_TRY(fill_sync(b.csum, 0, rows, st));
+        HIP_TRY(fill_sync(b.csumsq, 0, rows, st));
     }
     int ND = metropolis_nd(nd);
     if (c->density == KMC_USER_DENSITY && static_cast<const kmc_user_density*>(c->user_density)->is_body) ND = 0;   // body density: chain in memory
@@ -342,8 +348,8 @@ KMC_EXPORT kmc_status kmc_metropolis_run(const kmc_metropolis_config* c, const d
         if (want_mom) {
             HIP_TRY(hipMalloc(&b.st1, rows));
             HIP_TRY(hipMalloc(&b.st2, rows));
-            HIP_TRY(hipMemset(b.st1, 0, rows));
-            HIP_TRY(hipMemset(b.st2, 0, rows));
+            HIP_TRY(fill_sync(b.st1, 0, rows, st));
+            HIP_TRY(fill_sync(b.st2, 0, rows, st));
         }
     }
 
@@ -363,25 +369,25 @@ KMC_EXPORT kmc_status kmc_metropolis_run(const kmc_metropolis_config* c, const d
 
     // p0 = pdf(theta0)  (:70); unlike emcee the reference carries whatever comes out, -Inf included
     const LogpdfArgs la{b.pos, b.logp, nc, (int32_t)nd, (int32_t)nd, dp};
-    if (ulp) HIP_TRY(launch_module(ulp, grid, 256u, nullptr, la));
+    if (ulp) HIP_TRY(launch_module(ulp, grid, 256u, st, la));
     else {
         HalfStepFn v, g;
         LogpdfFn lp = nullptr;
         lookup(c->density, 0, 0, 1, false, false, false, &v, &g, &lp);
-        hipLaunchKernelGGL(lp, dim3(grid), dim3(256), 0, nullptr, la);
+        hipLaunchKernelGGL(lp, dim3(grid), dim3(256), 0, st, la);
         HIP_TRY(hipGetLastError());
     }
 
     auto transpose = [&](const double* src, double* dst, bool to_dim_major) {
         const TransposeArgs ta{src, dst, nc, (int32_t)nd, to_dim_major ? 1 : 0};
-        hipLaunchKernelGGL(metropolis_transpose, dim3(grid), dim3(256), 0, nullptr, ta);
+        hipLaunchKernelGGL(metropolis_transpose, dim3(grid), dim3(256), 0, st, ta);
         return hipGetLastError();
     };
     if (ND == 0) HIP_TRY(transpose(b.pos, b.xt, true));
 
     HIP_TRY(hipEventCreate(&b.ev0));
     HIP_TRY(hipEventCreate(&b.ev1));
-    HIP_TRY(hipEventRecord(b.ev0, nullptr));
+    HIP_TRY(hipEventRecord(b.ev0, st));
     constexpr int64_t kItersPerLaunch = 1 << 16;       // chains are independent: launches only bound a kernel's run time
     for (int64_t it0 = 0; it0 < c->niter; it0 += kItersPerLaunch) {
         MetropolisArgs a{};
@@ -397,38 +403,38 @@ KMC_EXPORT kmc_status kmc_metropolis_run(const kmc_metropolis_config* c, const d
         a.ndim = (int32_t)nd;
         a.seed_lo = (uint32_t)c->seed; a.seed_hi = (uint32_t)(c->seed >> 32);
         a.dp = dp;
-        if (ufn) HIP_TRY(launch_module(ufn, grid, 256u, nullptr, a));
+        if (ufn) HIP_TRY(launch_module(ufn, grid, 256u, st, a));
         else {
-            hipLaunchKernelGGL(fn, dim3(grid), dim3(256), 0, nullptr, a);
+            hipLaunchKernelGGL(fn, dim3(grid), dim3(256), 0, st, a);
             HIP_TRY(hipGetLastError());
         }
     }
-    HIP_TRY(hipEventRecord(b.ev1, nullptr));
+    HIP_TRY(hipEventRecord(b.ev1, st));
     if (ND == 0) {
         HIP_TRY(transpose(b.xt, b.pos, false));
         if (want_mom) { HIP_TRY(transpose(b.st1, b.csum, false)); HIP_TRY(transpose(b.st2, b.csumsq, false)); }
     }
     HIP_TRY(hipEventSynchronize(b.ev1));
-    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipStreamSynchronize(st));
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, b.ev0, b.ev1));
     out->device_ms = (double)ms;
 
     if (c->flags & KMC_CHAIN_BY_WALKER) {       // thetas[chain][sample], as the reference returns them (:113, :128)
-        if (out->chain && b.chain) KMC_TRY(download_by_walker(b.chain, false, nc, nd, nd, nsamples, out->chain, nullptr));
-        if (out->chain_logp && b.chain_logp) KMC_TRY(download_by_walker(b.chain_logp, false, nc, 1, 1, nsamples, out->chain_logp, nullptr));
+        if (out->chain && b.chain) KMC_TRY(download_by_walker(b.chain, false, nc, nd, nd, nsamples, out->chain, st));
+        if (out->chain_logp && b.chain_logp) KMC_TRY(download_by_walker(b.chain_logp, false, nc, 1, 1, nsamples, out->chain_logp, st));
     } else {
-        if (out->chain && b.chain) HIP_TRY(hipMemcpy(out->chain, b.chain, (size_t)nsamples * rows, hipMemcpyDeviceToHost));
+        if (out->chain && b.chain) HIP_TRY(copy_sync(out->chain, b.chain, (size_t)nsamples * rows, hipMemcpyDeviceToHost, st));
         if (out->chain_logp && b.chain_logp)
-            HIP_TRY(hipMemcpy(out->chain_logp, b.chain_logp, (size_t)nsamples * (size_t)nc * sizeof(double), hipMemcpyDeviceToHost));
+            HIP_TRY(copy_sync(out->chain_logp, b.chain_logp, (size_t)nsamples * (size_t)nc * sizeof(double), hipMemcpyDeviceToHost, st));
     }
-    if (out->final_pos) HIP_TRY(hipMemcpy(out->final_pos, b.pos, rows, hipMemcpyDeviceToHost));
-    if (out->final_logp) HIP_TRY(hipMemcpy(out->final_logp, b.logp, (size_t)nc * sizeof(double), hipMemcpyDeviceToHost));
-    if (out->chain_sum && b.csum) HIP_TRY(hipMemcpy(out->chain_sum, b.csum, rows, hipMemcpyDeviceToHost));
-    if (out->chain_sumsq && b.csumsq) HIP_TRY(hipMemcpy(out->chain_sumsq, b.csumsq, rows, hipMemcpyDeviceToHost));
+    if (out->final_pos) HIP_TRY(copy_sync(out->final_pos, b.pos, rows, hipMemcpyDeviceToHost, st));
+    if (out->final_logp) HIP_TRY(copy_sync(out->final_logp, b.logp, (size_t)nc * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (out->chain_sum && b.csum) HIP_TRY(copy_sync(out->chain_sum, b.csum, rows, hipMemcpyDeviceToHost, st));
+    if (out->chain_sumsq && b.csumsq) HIP_TRY(copy_sync(out->chain_sumsq, b.csumsq, rows, hipMemcpyDeviceToHost, st));
     if (out->naccept || out->accept_ratio) {
         std::vector<uint32_t> na((size_t)nc);
-        HIP_TRY(hipMemcpy(na.data(), b.naccept, (size_t)nc * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        HIP_TRY(copy_sync(na.data(), b.naccept, (size_t)nc * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         const double denom = (double)(c->niter - c->nburnin);                                   // :127 (0/0 as in the reference)
         for (int64_t i = 0; i < nc; ++i) {
             if (out->naccept) out->naccept[i] = (int64_t)na[(size_t)i];
