@@ -1279,11 +1279,11 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
     const size_t nw = (size_t)s->nrows;
     if (s->p2p) {
         CREATE_TRY(hipExtMallocWithFlags((void**)&s->d_flags, 4096, hipDeviceMallocFinegrained));
-        CREATE_TRY(fill_sync(s->d_flags, 0, 4096, s->stream));
+        CREATE_TRY(hipMemsetAsync(s->d_flags, 0, 4096, s->stream));
         CREATE_TRY(hipMalloc((void**)&s->d_err, 64));
-        CREATE_TRY(fill_sync(s->d_err, 0, 64, s->stream));
+        CREATE_TRY(hipMemsetAsync(s->d_err, 0, 64, s->stream));
         CREATE_TRY(hipMalloc((void**)&s->d_done, 33 * 64));
-        CREATE_TRY(fill_sync(s->d_done, 0, 33 * 64, s->stream));
+        CREATE_TRY(hipMemsetAsync(s->d_done, 0, 33 * 64, s->stream));
         // the kernel can publish its own completion only where all its stores are write-through: the vector kernels
         s->fold_signal = (cfg->flags & KMC_P2P_FOLD_SIGNAL) != 0 && s->plan.vec && s->user == nullptr;
         s->push = (cfg->flags & (KMC_P2P_PUSH | KMC_P2P_LAZY)) != 0 && s->plan.vec && s->user == nullptr && !(cfg->flags & KMC_P2P_FINEGRAINED) &&
@@ -1299,12 +1299,12 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         CREATE_TRY(hipExtMallocWithFlags((void**)&s->d_pos, nw * ldz * sizeof(double), hipDeviceMallocFinegrained));
     else
         CREATE_TRY(hipMalloc(&s->d_pos, (s->push ? 1 + (size_t)s->cfg.shard_count : 1) * nw * ldz * esz + amap_bytes));
-    CREATE_TRY(fill_sync(s->d_pos, 0, (s->push ? 1 + (size_t)s->cfg.shard_count : 1) * nw * ldz * esz + amap_bytes, s->stream));   // the pad column of odd ndim stays 0
+    CREATE_TRY(hipMemsetAsync(s->d_pos, 0, (s->push ? 1 + (size_t)s->cfg.shard_count : 1) * nw * ldz * esz + amap_bytes, s->stream));   // the pad column of odd ndim stays 0
     if (s->lazy) {
         const size_t P = (size_t)s->cfg.shard_count, hl = (size_t)s->h_loc;
         const size_t nb = 2 * P * 2 * hl * sizeof(uint32_t) + 16;
         CREATE_TRY(hipMalloc((void**)&s->d_lazy, nb));
-        CREATE_TRY(fill_sync(s->d_lazy, 0, nb, s->stream));
+        CREATE_TRY(hipMemsetAsync(s->d_lazy, 0, nb, s->stream));
         s->peer_amap_in[s->cfg.shard_rank] = reinterpret_cast<unsigned char*>(s->d_pos) + (1 + P) * nw * ldz * esz;
     }
     // per-walker block {logp[nrows], naccept[nrows], klast[nrows]}: one allocation, so the half-step kernels reach all
@@ -1312,25 +1312,25 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
     CREATE_TRY(hipMalloc(&s->d_logp, nw * (sizeof(double) + 2 * sizeof(uint32_t))));
     s->d_naccept = reinterpret_cast<uint32_t*>(s->d_logp + nw);
     s->d_klast = s->d_naccept + nw;
-    CREATE_TRY(fill_sync(s->d_klast, 0, nw * sizeof(uint32_t), s->stream));
+    CREATE_TRY(hipMemsetAsync(s->d_klast, 0, nw * sizeof(uint32_t), s->stream));
     static_assert(kGraphChunk <= 64, "advance_schedule runs one 64-thread block");
     CREATE_TRY(hipMalloc(&s->d_gen, 64));
-    CREATE_TRY(fill_sync(s->d_gen, 0, 64, s->stream));
+    CREATE_TRY(hipMemsetAsync(s->d_gen, 0, 64, s->stream));
     CREATE_TRY(hipMalloc(&s->d_sched, (size_t)kGraphChunk * sizeof(SchedEntry)));
-    CREATE_TRY(fill_sync(s->d_naccept, 0, nw * sizeof(uint32_t), s->stream));
+    CREATE_TRY(hipMemsetAsync(s->d_naccept, 0, nw * sizeof(uint32_t), s->stream));
     if (cfg->deal_count > 0) CREATE_TRY(hipMalloc((void**)&s->d_ids, nw * sizeof(uint32_t)));
     if (s->plan.vec && !s->islands && !s->resident && s->plan.L >= 16 && s->plan.L <= 32 && s->plan.L / s->plan.ITER >= 2 &&
         std::getenv("KMC_NO_DRAW_RING") == nullptr) {
         // draw ring: 4 slots x rows x 32 B; tags start at 0xffffffff (no step carries it), so nothing is "parked" yet
         const size_t nb = 4 * (size_t)s->nrows * 2 * sizeof(double2);
         CREATE_TRY(hipMalloc((void**)&s->d_ring, nb));
-        CREATE_TRY(fill_sync(s->d_ring, 0xff, nb, s->stream));
+        CREATE_TRY(hipMemsetAsync(s->d_ring, 0xff, nb, s->stream));
     }
     if (cfg->flags & KMC_MOMENTS) {
         CREATE_TRY(hipMalloc(&s->d_msum, (size_t)s->macc_elems * sizeof(double)));
         CREATE_TRY(hipMalloc(&s->d_msumsq, (size_t)s->macc_elems * sizeof(double)));
-        CREATE_TRY(fill_sync(s->d_msum, 0, (size_t)s->macc_elems * sizeof(double), s->stream));
-        CREATE_TRY(fill_sync(s->d_msumsq, 0, (size_t)s->macc_elems * sizeof(double), s->stream));
+        CREATE_TRY(hipMemsetAsync(s->d_msum, 0, (size_t)s->macc_elems * sizeof(double), s->stream));
+        CREATE_TRY(hipMemsetAsync(s->d_msumsq, 0, (size_t)s->macc_elems * sizeof(double), s->stream));
         if (s->plan.vec && s->plan.L == 64 && !s->islands && !s->resident && std::getenv("KMC_NO_MOMENT_RING") == nullptr) {
             // moment ring for long rows (kmc_kernels.hpp, HalfStepArgs::mring): up to 128 posted rows per wave,
             // within 512 MiB in all; swept every kSweepEvery generations
@@ -1343,7 +1343,7 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
                 CREATE_TRY(hipMalloc((void**)&s->d_mring, (size_t)nwaves * (size_t)depth * slot));
                 CREATE_TRY(hipMalloc((void**)&s->d_mring_w, (size_t)nwaves * (size_t)depth * sizeof(double)));
                 CREATE_TRY(hipMalloc((void**)&s->d_mcnt, 2 * (size_t)nwaves * sizeof(uint32_t)));
-                CREATE_TRY(fill_sync(s->d_mcnt, 0, 2 * (size_t)nwaves * sizeof(uint32_t), s->stream));
+                CREATE_TRY(hipMemsetAsync(s->d_mcnt, 0, 2 * (size_t)nwaves * sizeof(uint32_t), s->stream));
                 s->mring_depth = (int)depth;
                 s->mring_waves = nwaves;
             }
@@ -1352,8 +1352,8 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
             const size_t ne = (size_t)s->nislands * 4 * (size_t)s->island_K;
             CREATE_TRY(hipMalloc(&s->d_isum, ne * sizeof(double)));
             CREATE_TRY(hipMalloc(&s->d_isumsq, ne * sizeof(double)));
-            CREATE_TRY(fill_sync(s->d_isum, 0, ne * sizeof(double), s->stream));
-            CREATE_TRY(fill_sync(s->d_isumsq, 0, ne * sizeof(double), s->stream));
+            CREATE_TRY(hipMemsetAsync(s->d_isum, 0, ne * sizeof(double), s->stream));
+            CREATE_TRY(hipMemsetAsync(s->d_isumsq, 0, ne * sizeof(double), s->stream));
         }
     }
     if (s->host_eval) {
@@ -1401,6 +1401,7 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         CREATE_TRY(hipMalloc(&s->d_chain, (size_t)chain_slots * (size_t)s->nlocal * ldz * esz));
     if ((cfg->flags & KMC_STORE_LOGP) && s->nsamples > 0)
         CREATE_TRY(hipMalloc(&s->d_chain_logp, (size_t)chain_slots * (size_t)s->nlocal * sizeof(double)));
+    CREATE_TRY(hipStreamSynchronize(s->stream));         // the fills above (asynchronous, one wait for all of them)
 #undef CREATE_TRY
     if (s->p2p) {
         s->peer_pos[s->cfg.shard_rank] = s->d_pos;
