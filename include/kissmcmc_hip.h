@@ -359,7 +359,11 @@ kmc_status  kmc_sampler_get_chain_by_walker(kmc_sampler* s, double* chain, doubl
  *     in order -- exactly what all_to_all_single(recv, send) with equal splits does;
  *   - a walker carries its position, log-pdf, acceptance counter and global index (kmc_sampler_get_walker_ids).
  * kmc_sampler_deal_pack first credits every walker's current value to the streaming moments (they are per slot).
- * Needs S % (2 P) == 0, KMC_F64, a device density, no chain storage / KMC_P2P / KMC_ISLANDS / sharding. */
+ * A stored chain (KMC_STORE_CHAIN / KMC_STORE_LOGP) is BY SLOT, as the kernels write it; the sample of a generation is taken
+ * before the deal that follows it, and which walker a slot held during an epoch follows from replaying kmc_deal_perm on
+ * the host (distributed.deal_slot_ids; DealtEmcee.chain / gather_chain re-file the samples by walker) -- pooling all
+ * samples, what squash_walkers does, needs no identities.
+ * Needs S % (2 P) == 0, KMC_F64, a device density, no KMC_STREAM_CHAIN / KMC_P2P / KMC_ISLANDS / sharding. */
 uint64_t    kmc_deal_seed(uint64_t seed, int32_t deal_rank);
 kmc_status  kmc_deal_perm(uint64_t seed, int64_t epoch, int32_t deal_rank, int64_t S, int64_t* A, int64_t* C);
 /* Enqueue (on the sampler's stream) the packing of this sub-ensemble's S rows of ndim + 2 doubles into send_dev

@@ -1119,8 +1119,9 @@ KMC_EXPORT kmc_status kmc_validate(const kmc_config* c)
     if (c->deal_count < 0 || (c->deal_count > 0 && (c->deal_rank < 0 || c->deal_rank >= c->deal_count)))
         return fail(KMC_ERR_BAD_ARG, "deal_rank / deal_count out of range");
     if (c->deal_count > 0) {
-        if (P != 1 || (c->flags & (KMC_P2P | KMC_ISLANDS | KMC_STORE_CHAIN | KMC_STORE_LOGP)) || c->dtype != KMC_F64 || c->density == KMC_HOST_DENSITY)
-            return fail(KMC_ERR_UNSUPPORTED, "dealt sub-ensembles: KMC_F64, a device density, one shard, no chain storage / KMC_P2P / KMC_ISLANDS");
+        // (a stored chain is by SLOT: which walker a slot held when a sample was taken follows from kmc_deal_perm, distributed.py)
+        if (P != 1 || (c->flags & (KMC_P2P | KMC_ISLANDS | KMC_STREAM_CHAIN)) || c->dtype != KMC_F64 || c->density == KMC_HOST_DENSITY)
+            return fail(KMC_ERR_UNSUPPORTED, "dealt sub-ensembles: KMC_F64, a device density, one shard, no KMC_P2P / KMC_ISLANDS / KMC_STREAM_CHAIN");
         if (c->nwalkers % c->deal_count != 0)
             return fail(KMC_ERR_BAD_ARG, "dealt sub-ensembles: nwalkers (this sub-ensemble's size) must be divisible by deal_count");
         if (c->nwalkers * (int64_t)c->deal_count >= (int64_t)1 << 32) return fail(KMC_ERR_UNSUPPORTED, "dealt sub-ensembles: at most 2^32 - 1 walkers in all");

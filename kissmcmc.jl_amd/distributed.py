@@ -321,14 +321,15 @@ class HipDealExecutor:
     torch's current stream, plus the two exchange buffers as torch tensors (what RCCL sends from / receives into)."""
 
     def __init__(self, pdf, nsub_walkers, ndim, ngenerations, nburnin=0, nthin=1, a_scale=2.0, seed=0, rank=0, world=1,
-                 device=None, moments=True):
+                 device=None, moments=True, store_chain=False, store_logp=False):
         from .sampler import Sampler
         if torch is None or not torch.cuda.is_available():
             raise RuntimeError("HipDealExecutor needs a HIP device (torch.cuda); there is no CPU fallback")
         self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
         self.nwalkers, self.ndim = int(nsub_walkers), int(ndim)
         self.sampler = Sampler(pdf, nsub_walkers, ndim, ngenerations, nburnin, nthin, a_scale, seed, moments=moments,
-                               device=self.device.index, deal_rank=rank, deal_count=world)
+                               store_chain=store_chain, store_logp=store_logp, device=self.device.index, deal_rank=rank, deal_count=world)
+        self.seed, self.nburnin, self.nthin = int(seed), int(nburnin), int(nthin)
         # a stream of its own (graph capture is not allowed on the legacy default stream); DealtEmcee issues the
         # collective inside `torch.cuda.stream(self.stream)`, so RCCL orders itself against the sampler's kernels
         self.stream = torch.cuda.Stream(self.device)
@@ -357,8 +358,40 @@ class HipDealExecutor:
         s = self.sampler
         return s.walker_ids(), s.positions(), s.logp(), s.naccept(), s.moments()
 
+    def chain(self):
+        """``(chain [nsamples_done, S, ndim] | None, chain_logp [nsamples_done, S] | None)`` BY SLOT (see DealtEmcee.chain)."""
+        store_chain = bool(self.sampler.cfg.flags & 1)
+        store_logp = bool(self.sampler.cfg.flags & 2)
+        if not (store_chain or store_logp):
+            return None, None
+        ch, lp = self.sampler.chain(logp=store_logp) if store_chain else (None, None)
+        if not store_chain:
+            raise RuntimeError("store_logp without store_chain is not supported by the dealt driver")
+        return ch, lp
+
     def close(self):
         self.sampler.close()
+
+
+def deal_slot_ids(seed: int, world: int, nsub: int, nepochs: int):
+    """Which walker every slot holds during epoch e, ``[nepochs + 1, world * nsub]`` (slot = r * nsub + j; row 0: the initial
+    deal, walker = slot): the deals are a pure function of ``(seed, epoch, sub-ensemble)`` (``kmc_deal_perm``), so every rank
+    can replay all of them on the host -- no device traffic, no collective."""
+    import ctypes as C
+    from . import _lib
+    L = _lib.lib()
+    S, P = int(nsub), int(world)
+    c = S // P
+    ids = np.empty((int(nepochs) + 1, P * S), dtype=np.int64)
+    ids[0] = np.arange(P * S)
+    j = np.arange(S, dtype=np.int64)
+    for e in range(int(nepochs)):
+        for r in range(P):
+            a, cc = C.c_int64(), C.c_int64()
+            _lib.check(L.kmc_deal_perm(C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), e, r, S, C.byref(a), C.byref(cc)))
+            t = (a.value * j + cc.value) % S                          # (S < 2^31: no overflow in 64 bits)
+            ids[e + 1, (t // c) * S + r * c + t % c] = ids[e, r * S + j]
+    return ids
 
 
 class DealtEmcee:
@@ -451,6 +484,42 @@ class DealtEmcee:
         return dict(positions=P, logp=L, naccept=A, sum=sum(p[4] for p in parts), sumsq=sum(p[5] for p in parts),
                     n=int(sum(p[6] for p in parts)))
 
+    def chain(self):
+        """This rank's stored samples: ``(chain [k, S, ndim], chain_logp [k, S] | None, walker [k, S])`` -- the chain is kept
+        BY SLOT (what the kernels write, coalesced), ``walker[i, j]`` is the global index of the walker slot ``j`` held when
+        sample ``i`` was taken (replayed from the deal permutations, :func:`deal_slot_ids`).  Pooling the samples of all
+        ranks needs no identities (``squash_walkers`` pools them anyway, ``src/samplers.jl:395-413``); per-walker series
+        (autocorrelation) take them."""
+        ch, lp = self.ex.chain()
+        if ch is None:
+            return None, None, None
+        k = ch.shape[0]
+        nburnin, nthin = self.ex.nburnin, self.ex.nthin
+        gens = nburnin + (np.arange(k, dtype=np.int64) + 1) * nthin - 1          # generation whose end state sample i is
+        epochs = gens // self.epoch_gens
+        hist = deal_slot_ids(self.ex.seed, self.world, self.nsub, int(epochs.max()) + 1 if k else 0)
+        walker = hist[epochs][:, self.rank * self.nsub:(self.rank + 1) * self.nsub]
+        return ch, lp, walker
+
+    def gather_chain(self):
+        """The whole chain BY WALKER, ``(thetas [nwalkers, k, ndim], logdensities [nwalkers, k])`` as ``emcee`` returns it,
+        identical on every rank -- every rank receives everybody's samples (all_gather_object): for ensembles whose chain
+        fits one host, and for tests."""
+        ch, lp, walker = self.chain()
+        parts = [(ch, lp, walker)]
+        if self.world > 1:
+            parts = [None] * self.world
+            dist.all_gather_object(parts, (ch, lp, walker), group=self.group)
+        k = ch.shape[0]
+        T = np.empty((self.nwalkers, k, self.ndim))
+        Lg = np.empty((self.nwalkers, k)) if lp is not None else None
+        rows = np.arange(k)[:, None]
+        for c_, l_, w_ in parts:
+            T[w_, rows] = c_
+            if Lg is not None:
+                Lg[w_, rows] = l_
+        return T, Lg
+
     def close(self):
         self.sync()
         if self.world > 1:
@@ -513,6 +582,27 @@ class LocalDealtEmcee:
             P[i], L[i], A[i] = p, l, a
             S, Q, N = S + s, Q + q, N + n
         return dict(positions=P, logp=L, naccept=A, sum=S, sumsq=Q, n=int(N))
+
+    def gather_chain(self):
+        """``(thetas [nwalkers, k, ndim], logdensities [nwalkers, k] | None)`` by walker (see DealtEmcee.chain / gather_chain)."""
+        ex0 = self.exs[0]
+        parts = [ex.chain() for ex in self.exs]
+        ch0 = parts[0][0]
+        if ch0 is None:
+            return None, None
+        k = ch0.shape[0]
+        gens = ex0.nburnin + (np.arange(k, dtype=np.int64) + 1) * ex0.nthin - 1
+        epochs = gens // self.epoch_gens
+        hist = deal_slot_ids(ex0.seed, self.world, self.nsub, int(epochs.max()) + 1 if k else 0)
+        T = np.empty((self.nwalkers, k, self.ndim))
+        Lg = np.empty((self.nwalkers, k)) if parts[0][1] is not None else None
+        rows = np.arange(k)[:, None]
+        for r, (c_, l_) in enumerate(parts):
+            w_ = hist[epochs][:, r * self.nsub:(r + 1) * self.nsub]
+            T[w_, rows] = c_
+            if Lg is not None:
+                Lg[w_, rows] = l_
+        return T, Lg
 
     def close(self):
         for ex in self.exs:

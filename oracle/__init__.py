@@ -99,6 +99,8 @@ def lib() -> C.CDLL:
         L.kmco_deal_seed.argtypes = [C.c_uint64, C.c_int32]
         L.kmco_deal_perm.restype = None
         L.kmco_deal_perm.argtypes = [C.c_uint64, C.c_int64, C.c_int32, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.kmco_emcee_dealt_chain.argtypes = [C.POINTER(Config), C.c_int32, C.c_int64, dp, dp, C.POINTER(C.c_int64), dp, dp,
+                                             C.POINTER(C.c_int64), dp, dp, C.POINTER(C.c_int64), dp, dp]
         L.kmco_emcee_dealt.argtypes = [C.POINTER(Config), C.c_int32, C.c_int64, dp, dp, C.POINTER(C.c_int64), dp, dp,
                                        C.POINTER(C.c_int64), dp, dp, C.POINTER(C.c_int64)]
         L.kmco_init_ball.restype = C.c_int64
@@ -260,9 +262,10 @@ def deal_perm(seed, epoch, rank, S):
     return a.value, c.value
 
 
-def emcee_dealt(cfg: Config, nsub, epoch_gens, theta0, moments=True):
-    """Dealt sub-ensembles (kmc_oracle.c: kmco_emcee_dealt): ``cfg.nwalkers`` walkers in ``nsub`` sub-ensembles, re-dealt
-    every ``epoch_gens`` generations.  Per-walker outputs are in GLOBAL WALKER order; ``slot_ids`` = walker per final slot."""
+def emcee_dealt(cfg: Config, nsub, epoch_gens, theta0, moments=True, store_chain=False):
+    """Dealt sub-ensembles (kmc_oracle.c: kmco_emcee_dealt_chain): ``cfg.nwalkers`` walkers in ``nsub`` sub-ensembles, re-dealt
+    every ``epoch_gens`` generations.  Per-walker outputs are in GLOBAL WALKER order; ``slot_ids`` = walker per final slot;
+    ``store_chain``: ``chain [nsamples, nwalkers, ndim]`` and ``chain_logp [nsamples, nwalkers]``, by walker as well."""
     nw, nd = cfg.nwalkers, cfg.ndim
     theta0 = np.ascontiguousarray(np.asarray(theta0, dtype=np.float64).reshape(nw, nd))
     acc = np.zeros(nw)
@@ -273,11 +276,14 @@ def emcee_dealt(cfg: Config, nsub, epoch_gens, theta0, moments=True):
     msum = np.zeros(nd) if moments else None
     msq = np.zeros(nd) if moments else None
     nmom = C.c_int64(0)
+    ns = (cfg.ngenerations - cfg.nburnin) // cfg.nthin if cfg.ngenerations > cfg.nburnin else 0
+    chain = np.zeros((ns, nw, nd)) if store_chain else None
+    chain_logp = np.zeros((ns, nw)) if store_chain else None
     with np.errstate(all="ignore"):
-        st = lib().kmco_emcee_dealt(C.byref(cfg), int(nsub), int(epoch_gens), _dp(theta0), _dp(acc), _ip(nacc), _dp(fpos), _dp(flogp),
-                                    _ip(ids), _dp(msum), _dp(msq), C.byref(nmom))
+        st = lib().kmco_emcee_dealt_chain(C.byref(cfg), int(nsub), int(epoch_gens), _dp(theta0), _dp(acc), _ip(nacc), _dp(fpos), _dp(flogp),
+                                          _ip(ids), _dp(msum), _dp(msq), C.byref(nmom), _dp(chain), _dp(chain_logp))
     return dict(status=st, accept_ratio=acc, naccept=nacc, final_pos=fpos, final_logp=flogp, slot_ids=ids, sum=msum, sumsq=msq,
-                nmoment=nmom.value)
+                nmoment=nmom.value, chain=chain, chain_logp=chain_logp)
 
 
 def metropolis_draw(seed, it, chain, ndim):

@@ -620,9 +620,12 @@ KMCO_API void kmco_deal_perm(uint64_t seed, int64_t epoch, int32_t rank, int64_t
 
 /* c->nwalkers = N (all sub-ensembles).  Outputs (any may be NULL) are indexed by GLOBAL WALKER (the index a walker
  * had in theta0), except slot_ids [N]: the walker each slot holds at the end (slot = r S + j). */
-KMCO_API int kmco_emcee_dealt(const kmco_config* c, int32_t P, int64_t epoch_gens, const double* theta0,
-                              double* accept_ratio, int64_t* naccept_out, double* final_pos, double* final_logp,
-                              int64_t* slot_ids, double* msum, double* msumsq, int64_t* nmoment)
+/* chain [nsamples][N][ndim], chain_logp [nsamples][N]: by GLOBAL WALKER as well -- a walker's stored samples (:268-272) follow
+ * it through the deals (the sample of a generation is taken before the deal that follows it). */
+KMCO_API int kmco_emcee_dealt_chain(const kmco_config* c, int32_t P, int64_t epoch_gens, const double* theta0,
+                                    double* accept_ratio, int64_t* naccept_out, double* final_pos, double* final_logp,
+                                    int64_t* slot_ids, double* msum, double* msumsq, int64_t* nmoment,
+                                    double* chain, double* chain_logp)
 {
     if (!c || P < 1 || epoch_gens < 1 || c->nwalkers % P != 0) return KMCO_ERR_BAD_ARG;
     const int64_t N = c->nwalkers, nd = c->ndim, S = N / P;
@@ -665,6 +668,12 @@ KMCO_API int kmco_emcee_dealt(const kmco_config* c, int32_t P, int64_t epoch_gen
         if (n > 0 && n % c->nthin == 0 && n / c->nthin - 1 < nsamples) {   /* :268 */
             if (msum || msumsq) moments_add(pos, N, nd, msum, msumsq, mpart, nblk, c->nthreads);
             nmom += N;
+            const int64_t k = n / c->nthin - 1;
+            for (int64_t sl = 0; sl < N && (chain || chain_logp); ++sl) {  /* :269-271, filed under the walker the slot holds */
+                const int64_t w = ids[sl];
+                if (chain) memcpy(chain + (k * N + w) * nd, pos + sl * nd, sizeof(double) * (size_t)nd);
+                if (chain_logp) chain_logp[k * N + w] = logp[sl];
+            }
         }
         if ((g + 1) % epoch_gens == 0) {                                   /* the deal */
             const int64_t e = (g + 1) / epoch_gens - 1;
@@ -696,6 +705,14 @@ KMCO_API int kmco_emcee_dealt(const kmco_config* c, int32_t P, int64_t epoch_gen
     if (nmoment) *nmoment = nmom;
     free(pos); free(pos2); free(logp); free(logp2); free(nacc); free(nacc2); free(ids); free(ids2); free(mpart);
     return bad ? KMCO_ERR_NONFINITE_LOGP : KMCO_OK;
+}
+
+KMCO_API int kmco_emcee_dealt(const kmco_config* c, int32_t P, int64_t epoch_gens, const double* theta0,
+                              double* accept_ratio, int64_t* naccept_out, double* final_pos, double* final_logp,
+                              int64_t* slot_ids, double* msum, double* msumsq, int64_t* nmoment)
+{
+    return kmco_emcee_dealt_chain(c, P, epoch_gens, theta0, accept_ratio, naccept_out, final_pos, final_logp, slot_ids, msum, msumsq,
+                                  nmoment, NULL, NULL);
 }
 
 /* ------------------------------------------------------------------------------------------

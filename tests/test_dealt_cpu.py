@@ -47,6 +47,14 @@ def test_oracle_dealt_invariants(oracle):
     r2 = oracle.emcee(cfg1, th, store_chain=False)
     np.testing.assert_array_equal(r1["final_pos"], r2["final_pos"])
     np.testing.assert_array_equal(r1["naccept"], r2["naccept"])
+    # ... its chain too; and a walker's last stored sample is where it ended (G - NBURN stored, nthin = 1)
+    r1c = oracle.emcee_dealt(cfg, 1, 10 ** 9, th, store_chain=True)
+    r2c = oracle.emcee(cfg1, th)
+    np.testing.assert_array_equal(r1c["chain"], r2c["chain"])
+    rc = oracle.emcee_dealt(cfg, 4, E, th, store_chain=True)
+    np.testing.assert_array_equal(rc["chain"][-1], rc["final_pos"])
+    np.testing.assert_array_equal(rc["chain_logp"][-1], rc["final_logp"])
+    np.testing.assert_array_equal(rc["final_pos"], r["final_pos"])
     # every sub-ensemble must itself be a valid emcee ensemble (src/samplers.jl:202-205)
     bad = oracle.make_config(oracle.GAUSSIAN_ISO, [0.0, 1.0], 24, ND, 5, 0, 1, 2.0, SEED)
     assert oracle.emcee_dealt(bad, 4, 2, np.zeros((24, ND)))["status"] == oracle.ERR_TOO_FEW_WALKERS   # S = 6 < ndim + 2
@@ -77,6 +85,8 @@ class OracleDealExecutor:
         self.pos = np.zeros((self.S, nd)); self.logp = np.zeros(self.S); self.nacc = np.zeros(self.S, dtype=np.int64)
         self.ids = np.arange(rank * self.S, (rank + 1) * self.S, dtype=np.int64)
         self.msum = np.zeros(nd); self.msq = np.zeros(nd); self.nmom = 0
+        self.seed, self.nburnin, self.nthin = cfg_total.seed, cfg_total.nburnin, cfg_total.nthin      # (what DealtEmcee.chain reads)
+        self.chain_rows, self.chain_lp = [], []           # by slot, as the device stores it
         self.gen = 0
         self.recv = torch.zeros((self.S, nd + 2), dtype=torch.float64)
 
@@ -91,6 +101,7 @@ class OracleDealExecutor:
                 self.oracle.half_step(self.cfg, self.pos, self.logp, self.nacc, self.gen, half, 0, self.S // 2, count_accept=k > 0)
             if k > 0 and k % self.cfg.nthin == 0:
                 self.msum += self.pos.sum(axis=0); self.msq += (self.pos ** 2).sum(axis=0); self.nmom += self.S
+                self.chain_rows.append(self.pos.copy()); self.chain_lp.append(self.logp.copy())
             self.gen += 1
 
     def pack(self, epoch):
@@ -116,6 +127,9 @@ class OracleDealExecutor:
     def results(self):
         return self.ids.copy(), self.pos.copy(), self.logp.copy(), self.nacc.copy(), (self.msum, self.msq, self.nmom)
 
+    def chain(self):
+        return np.array(self.chain_rows).reshape(-1, self.S, self.pos.shape[1]), np.array(self.chain_lp).reshape(-1, self.S)
+
     def close(self):
         pass
 
@@ -135,6 +149,7 @@ def _worker(rank, world, port, outdir):
         drv.run(G - 13)
         res = drv.results()
         assert drv.deals == G // E
+        res["thetas"], res["logd"] = drv.gather_chain()
         np.savez(os.path.join(outdir, f"r{rank}.npz"), **res)
         drv.close()
     finally:
@@ -151,10 +166,12 @@ def _free_port():
 def test_gloo_ranks_equal_the_oracle_run(oracle, tmp_path, world):
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     cfg = oracle.make_config(oracle.GAUSSIAN_ISO, [0.0, 1.0], NW, ND, G, NBURN, 1, 2.0, SEED)
-    ref = oracle.emcee_dealt(cfg, world, E, _theta0())
+    ref = oracle.emcee_dealt(cfg, world, E, _theta0(), store_chain=True)
     assert ref["status"] == 0
     for r in range(world):
         z = np.load(os.path.join(str(tmp_path), f"r{r}.npz"))
+        np.testing.assert_array_equal(z["thetas"], ref["chain"].transpose(1, 0, 2))      # by walker, through every deal
+        np.testing.assert_array_equal(z["logd"], ref["chain_logp"].T)
         np.testing.assert_array_equal(z["positions"], ref["final_pos"])
         np.testing.assert_array_equal(z["logp"], ref["final_logp"])
         np.testing.assert_array_equal(z["naccept"], ref["naccept"])
@@ -172,7 +189,10 @@ def test_local_driver_equals_the_oracle_run(oracle):
     drv.set_positions(_theta0())
     drv.run(G)
     res = drv.results()
-    ref = oracle.emcee_dealt(cfg, 4, E, _theta0())
+    ref = oracle.emcee_dealt(cfg, 4, E, _theta0(), store_chain=True)
     np.testing.assert_array_equal(res["positions"], ref["final_pos"])
     np.testing.assert_array_equal(res["naccept"], ref["naccept"])
     assert res["n"] == ref["nmoment"]
+    thetas, logd = drv.gather_chain()
+    np.testing.assert_array_equal(thetas, ref["chain"].transpose(1, 0, 2))
+    np.testing.assert_array_equal(logd, ref["chain_logp"].T)

@@ -45,7 +45,7 @@ def test_logical_sub_ensembles_on_one_gpu_equal_the_oracle(kmc, oracle, case):
     N = P * S
     rng = np.random.default_rng(3)
     th = 0.5 + 0.1 * np.abs(rng.standard_normal((N, nd))) if scale is None else scale * rng.standard_normal((N, nd))
-    exs = [HipDealExecutor(pdf, S, nd, G, nburn, nthin, 2.0, 4242, rank=r, world=P, device=0) for r in range(P)]
+    exs = [HipDealExecutor(pdf, S, nd, G, nburn, nthin, 2.0, 4242, rank=r, world=P, device=0, store_chain=True, store_logp=True) for r in range(P)]
     drv = LocalDealtEmcee(exs, N, nd, E)
     try:
         drv.set_positions(th)
@@ -53,11 +53,14 @@ def test_logical_sub_ensembles_on_one_gpu_equal_the_oracle(kmc, oracle, case):
         drv.run(G - G // 2)
         drv.sync()
         res = drv.results()
+        thetas, logd = drv.gather_chain()               # stored by slot on the device, re-filed by walker through every deal
         assert "dealt sub-ensemble" in exs[0].sampler.describe()
     finally:
         drv.close()
-    ref = oracle.emcee_dealt(oracle.make_config(did, params, N, nd, G, nburn, nthin, 2.0, 4242, nthreads=8), P, E, th)
+    ref = oracle.emcee_dealt(oracle.make_config(did, params, N, nd, G, nburn, nthin, 2.0, 4242, nthreads=8), P, E, th, store_chain=True)
     _check(res, ref)
+    np.testing.assert_array_equal(thetas, ref["chain"].transpose(1, 0, 2))
+    assert np.all(np.abs(logd - ref["chain_logp"].T) <= 1e-12 * np.maximum(1.0, np.abs(ref["chain_logp"].T)))
 
 
 def test_deal_pack_layout_and_walker_ids(kmc, oracle):
@@ -110,7 +113,7 @@ def test_dealt_config_validation(kmc):
     with pytest.raises(kmc.KmcError, match="divisible by deal_count"):
         kmc.Sampler(kmc.GaussianIso(), 100, 2, 10, deal_rank=0, deal_count=3)
     with pytest.raises(kmc.KmcError, match="dealt sub-ensembles"):
-        kmc.Sampler(kmc.GaussianIso(), 128, 2, 10, deal_rank=0, deal_count=2, store_chain=True)
+        kmc.Sampler(kmc.GaussianIso(), 128, 2, 10, deal_rank=0, deal_count=2, store_chain=True, stream_chain=True)
     with pytest.raises(kmc.KmcError, match="deal_rank"):
         kmc.Sampler(kmc.GaussianIso(), 128, 2, 10, deal_rank=2, deal_count=2)
     with kmc.Sampler(kmc.GaussianIso(), 128, 2, 10) as s:
@@ -138,12 +141,16 @@ def _worker(rank, world, port, outdir):
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        ex = HipDealExecutor(kmc.GaussianIso(), NW2 // world, ND2, G2, NB2, 1, 2.0, SEED2, rank=rank, world=world, device=0)
+        ex = HipDealExecutor(kmc.GaussianIso(), NW2 // world, ND2, G2, NB2, 10, 2.0, SEED2, rank=rank, world=world, device=0,
+                             store_chain=True, store_logp=True)
         drv = DealtEmcee(ex, NW2, ND2, E2)
         drv.set_positions(_theta2())
         drv.run(G2)
         drv.sync()
         res = drv.results()
+        res["thetas"], res["logd"] = drv.gather_chain()
+        local, _, walker = drv.chain()
+        assert local.shape == (11, NW2 // world, ND2) and walker.shape == (11, NW2 // world)
         np.savez(os.path.join(outdir, f"r{rank}.npz"), **res)
         drv.close()
     finally:
@@ -161,11 +168,13 @@ def test_two_processes_sharing_the_gpu_equal_the_oracle(oracle, tmp_path):
     import torch.multiprocessing as mp
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
-    ref = oracle.emcee_dealt(oracle.make_config(oracle.GAUSSIAN_ISO, [0.0, 1.0], NW2, ND2, G2, NB2, 1, 2.0, SEED2, nthreads=8), world, E2, _theta2())
+    ref = oracle.emcee_dealt(oracle.make_config(oracle.GAUSSIAN_ISO, [0.0, 1.0], NW2, ND2, G2, NB2, 10, 2.0, SEED2, nthreads=8), world, E2, _theta2(),
+                             store_chain=True)
     for r in range(world):
         z = dict(np.load(os.path.join(str(tmp_path), f"r{r}.npz")))
         z["n"] = int(z["n"])
         _check(z, ref)
+        np.testing.assert_array_equal(z["thetas"], ref["chain"].transpose(1, 0, 2))       # 11 samples per walker, through 2 deals
 
 
 def test_dealt_driver_world1_through_rccl(kmc, oracle):
