@@ -372,6 +372,9 @@ kmc_status  kmc_sampler_deal_pack(kmc_sampler* s, int64_t epoch, void* send_dev)
 kmc_status  kmc_sampler_deal_unpack(kmc_sampler* s, const void* recv_dev);
 /* Global walker index held by each local slot (host, [nwalkers]); row order of get_positions / get_naccept. */
 kmc_status  kmc_sampler_get_walker_ids(kmc_sampler* s, int64_t* host);
+/* Checkpoint / resume of a sub-ensemble: kmc_sampler_set_state restores the slots' contents and the generation, this the
+ * slot -> walker map that goes with that generation's epoch (host, [nwalkers]; replayed from kmc_deal_perm). */
+kmc_status  kmc_sampler_set_walker_ids(kmc_sampler* s, const int64_t* host);
 
 /* ---- stateless device ops on caller-owned device memory ---- */
 /* logp[i] = log pdf(pos[i]) for nrows rows, src/samplers.jl:209. */

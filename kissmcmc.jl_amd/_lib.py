@@ -42,7 +42,7 @@ SYMBOLS = [
     "kmc_sampler_get_moments", "kmc_sampler_get_chain", "kmc_sampler_get_chain_by_walker", "kmc_logpdf_eval", "kmc_logpdf_eval_host",
     "kmc_user_density_create", "kmc_user_density_create_body", "kmc_user_density_destroy", "kmc_metropolis_validate", "kmc_metropolis_run", "kmc_int_acorr", "kmc_sampler_int_acorr",
     "kmc_sizeof_config", "kmc_sizeof_metropolis_config", "kmc_deal_seed", "kmc_deal_perm", "kmc_sampler_deal_pack", "kmc_sampler_deal_unpack",
-    "kmc_sampler_get_walker_ids", "kmc_sampler_set_chain_host", "kmc_rccl_unique_id", "kmc_sampler_rccl_init",
+    "kmc_sampler_get_walker_ids", "kmc_sampler_set_walker_ids", "kmc_sampler_set_chain_host", "kmc_rccl_unique_id", "kmc_sampler_rccl_init",
 ]
 
 
@@ -217,6 +217,7 @@ def lib() -> C.CDLL:
     L.kmc_sampler_deal_pack.argtypes = [vp, C.c_int64, vp]
     L.kmc_sampler_deal_unpack.argtypes = [vp, vp]
     L.kmc_sampler_get_walker_ids.argtypes = [vp, ip]
+    L.kmc_sampler_set_walker_ids.argtypes = [vp, ip]
     L.kmc_sampler_set_chain_host.argtypes = [vp, dp, dp]
     L.kmc_rccl_unique_id.argtypes = [vp]
     L.kmc_sampler_rccl_init.argtypes = [vp, vp]

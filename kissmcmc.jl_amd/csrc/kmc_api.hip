@@ -1755,7 +1755,6 @@ KMC_EXPORT kmc_status kmc_sampler_set_state(kmc_sampler* s, const double* pos_ho
 {
     if (!s || !pos_host || !logp_host || generation < 0) return fail(KMC_ERR_BAD_ARG, "bad argument");
     if (s->d_chain || s->d_chain_logp) return fail(KMC_ERR_UNSUPPORTED, "kmc_sampler_set_state: not with chain storage (download the chain before checkpointing)");
-    if (s->d_ids) return fail(KMC_ERR_UNSUPPORTED, "kmc_sampler_set_state: not for dealt sub-ensembles (the slot -> walker map is not part of the state yet)");
     if (s->p2p && s->cfg.shard_count > 1)
         return fail(KMC_ERR_UNSUPPORTED, "kmc_sampler_set_state: P2P progress flags restart at 0; restore is single-GPU for now");
     HIP_TRY(hipSetDevice(s->cfg.device));
@@ -2464,6 +2463,23 @@ KMC_EXPORT kmc_status kmc_sampler_get_walker_ids(kmc_sampler* s, int64_t* host)
     std::vector<uint32_t> tmp((size_t)s->nrows);
     HIP_TRY(copy_sync(tmp.data(), s->d_ids, tmp.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
     for (size_t i = 0; i < tmp.size(); ++i) host[i] = (int64_t)tmp[i];
+    return KMC_OK;
+}
+
+// dealt sub-ensembles, after kmc_sampler_set_state: which global walker each slot holds (a function of the restored generation's
+// epoch alone: replay kmc_deal_perm on the host, distributed.deal_slot_ids)
+KMC_EXPORT kmc_status kmc_sampler_set_walker_ids(kmc_sampler* s, const int64_t* host)
+{
+    if (!s || !host) return fail(KMC_ERR_BAD_ARG, "null argument");
+    if (!s->d_ids) return fail(KMC_ERR_BAD_ARG, "sampler was created without kmc_config.deal_count");
+    HIP_TRY(hipSetDevice(s->cfg.device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    std::vector<uint32_t> tmp((size_t)s->nrows);
+    for (size_t i = 0; i < tmp.size(); ++i) {
+        if (host[i] < 0 || host[i] >= (int64_t)1 << 32) return fail(KMC_ERR_BAD_ARG, "walker index out of range");
+        tmp[i] = (uint32_t)host[i];
+    }
+    HIP_TRY(copy_sync(s->d_ids, tmp.data(), tmp.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
     return KMC_OK;
 }
 

@@ -358,6 +358,13 @@ class HipDealExecutor:
         s = self.sampler
         return s.walker_ids(), s.positions(), s.logp(), s.naccept(), s.moments()
 
+    def state(self):
+        return self.sampler.state()
+
+    def restore(self, state, ids):
+        self.sampler.restore(state)
+        self.sampler.set_walker_ids(ids)
+
     def chain(self):
         """``(chain [nsamples_done, S, ndim] | None, chain_logp [nsamples_done, S] | None)`` BY SLOT (see DealtEmcee.chain)."""
         store_chain = bool(self.sampler.cfg.flags & 1)
@@ -484,6 +491,21 @@ class DealtEmcee:
         return dict(positions=P, logp=L, naccept=A, sum=sum(p[4] for p in parts), sumsq=sum(p[5] for p in parts),
                     n=int(sum(p[6] for p in parts)))
 
+    def state(self):
+        """Checkpoint of THIS rank's sub-ensemble (slots' positions, log-pdfs, counters, the generation); every rank saves its
+        own.  The slot -> walker map is not stored: it is a function of the generation's epoch."""
+        return self.ex.state()
+
+    def restore(self, state):
+        """Resume from :meth:`state` (same configuration, seed, world size, epoch length): the continued run equals the
+        uninterrupted one.  Moments restart at the restored generation."""
+        g = int(state["generation"])
+        epoch = g // self.epoch_gens                     # deals done so far
+        ids = deal_slot_ids(self.ex.seed, self.world, self.nsub, epoch)[epoch]
+        self.ex.restore(state, ids[self.rank * self.nsub:(self.rank + 1) * self.nsub])
+        self.generation = g
+        self.deals = epoch
+
     def chain(self):
         """This rank's stored samples: ``(chain [k, S, ndim], chain_logp [k, S] | None, walker [k, S])`` -- the chain is kept
         BY SLOT (what the kernels write, coalesced), ``walker[i, j]`` is the global index of the walker slot ``j`` held when
@@ -582,6 +604,17 @@ class LocalDealtEmcee:
             P[i], L[i], A[i] = p, l, a
             S, Q, N = S + s, Q + q, N + n
         return dict(positions=P, logp=L, naccept=A, sum=S, sumsq=Q, n=int(N))
+
+    def state(self):
+        return [ex.state() for ex in self.exs]
+
+    def restore(self, states):
+        g = int(states[0]["generation"])
+        epoch = g // self.epoch_gens
+        ids = deal_slot_ids(self.exs[0].seed, self.world, self.nsub, epoch)[epoch]
+        for r, (ex, st) in enumerate(zip(self.exs, states)):
+            ex.restore(st, ids[r * self.nsub:(r + 1) * self.nsub])
+        self.generation = g
 
     def gather_chain(self):
         """``(thetas [nwalkers, k, ndim], logdensities [nwalkers, k] | None)`` by walker (see DealtEmcee.chain / gather_chain)."""

@@ -189,6 +189,11 @@ class Sampler:
         _lib.check(self._L.kmc_sampler_get_walker_ids(self._h, out.ctypes.data_as(C.POINTER(C.c_int64))))
         return out
 
+    def set_walker_ids(self, ids):
+        """Dealt sub-ensembles, after :meth:`restore`: the global walker each slot holds (``distributed.deal_slot_ids``)."""
+        ids = np.ascontiguousarray(np.asarray(ids, dtype=np.int64).reshape(self.nrows))
+        _lib.check(self._L.kmc_sampler_set_walker_ids(self._h, ids.ctypes.data_as(C.POINTER(C.c_int64))))
+
     def set_positions(self, theta):
         theta = np.ascontiguousarray(np.asarray(theta, dtype=np.float64).reshape(self.nwalkers, self.ndim))
         self._check_host(self._L.kmc_sampler_set_positions(self._h, _dp(theta)))

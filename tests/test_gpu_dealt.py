@@ -206,3 +206,35 @@ def test_dealt_driver_world1_through_rccl(kmc, oracle):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("stop_at", [37, 48, 5])
+def test_dealt_checkpoint_resume_equals_the_uninterrupted_oracle_run(kmc, oracle, stop_at):
+    """state() / restore() of the sub-ensembles (the slot -> walker map is replayed from the deal permutations): stop inside
+    an epoch, exactly after a deal, and before the first deal; the resumed run ends where the oracle's uninterrupted run does."""
+    from kissmcmc_jl_amd.distributed import HipDealExecutor, LocalDealtEmcee
+    P, S, nd, G, nburn, E, seed = 4, 512, 8, 90, 20, 16, 777
+    N = P * S
+    th = np.random.default_rng(6).standard_normal((N, nd))
+    mk = lambda: LocalDealtEmcee([HipDealExecutor(kmc.GaussianIso(), S, nd, G, nburn, 1, 2.0, seed, rank=r, world=P, device=0) for r in range(P)], N, nd, E)
+    a = mk()
+    try:
+        a.set_positions(th)
+        a.run(stop_at)
+        a.sync()
+        states = a.state()
+    finally:
+        a.close()
+    b = mk()
+    try:
+        b.restore(states)
+        b.run(G - stop_at)
+        b.sync()
+        res = b.results()
+    finally:
+        b.close()
+    ref = oracle.emcee_dealt(oracle.make_config(oracle.GAUSSIAN_ISO, [0.0, 1.0], N, nd, G, nburn, 1, 2.0, seed, nthreads=8), P, E, th)
+    assert ref["status"] == 0
+    np.testing.assert_array_equal(res["positions"], ref["final_pos"])
+    np.testing.assert_array_equal(res["naccept"], ref["naccept"])
+    assert np.all(np.abs(res["logp"] - ref["final_logp"]) <= 1e-12 * np.maximum(1.0, np.abs(ref["final_logp"])))
