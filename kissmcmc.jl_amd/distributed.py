@@ -356,7 +356,8 @@ class HipDealExecutor:
     def results(self):
         """``(walker_ids, positions, logp, naccept, (sum, sumsq, n))`` of this sub-ensemble's slots."""
         s = self.sampler
-        return s.walker_ids(), s.positions(), s.logp(), s.naccept(), s.moments()
+        mom = s.moments() if s.cfg.flags & 4 else (np.zeros(self.ndim), np.zeros(self.ndim), 0)      # (KMC_MOMENTS)
+        return s.walker_ids(), s.positions(), s.logp(), s.naccept(), mom
 
     def state(self):
         return self.sampler.state()
@@ -640,3 +641,49 @@ class LocalDealtEmcee:
     def close(self):
         for ex in self.exs:
             ex.close()
+
+
+def emcee_dealt(pdf, theta0s, niter: int = 10 ** 5, nburnin=None, nthin: int = 1, a_scale: float = 2.0, seed: int = 0,
+                epoch_gens: int = 64, group=None, gather: bool = True):
+    """``emcee`` (reference ``src/samplers.jl:188-293``, same ``niter`` / ``nburnin`` / ``nthin`` bookkeeping) over the ranks of a
+    ``torch.distributed`` job in the dealt-sub-ensemble mode: call it on every rank (``torchrun``, one rank per GPU) with the
+    same arguments.  Returns the reference's tuple ``(thetas [nwalkers, nsamples, ndim], accept_ratio [nwalkers],
+    logdensities [nwalkers, nsamples], None)``, identical on every rank, with per-walker series re-filed through the deals
+    (``gather=False``: this rank's samples by slot instead, ``(chain [k, S, ndim], accept_ratio, chain_logp [k, S], walker
+    [k, S])`` -- no collective on the chain).  ``seed`` must be the same on all ranks.  Opt-in: the partner pool is the rank's
+    own complementary half (``:250``), the target distribution is unchanged."""
+    from .api import emcee_counts
+    th = np.asarray(theta0s, dtype=np.float64)
+    scalar = th.ndim == 1
+    th = th.reshape(th.shape[0], -1)
+    nw, nd = th.shape
+    if not a_scale > 1:
+        raise AssertionError("a_scale>1")
+    if nw % 2 != 0:
+        raise AssertionError("Use an even number of walkers.")
+    G, nburn, ns = emcee_counts(niter, nw, nburnin, nthin)
+    world = dist.get_world_size(group) if dist is not None and dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist is not None and dist.is_initialized() else 0
+    if nw % (world * world) != 0:
+        raise ValueError("nwalkers must be divisible by world^2")
+    if nw // world < nd + 2:
+        raise AssertionError("Use more walkers: at least DOF+2, but better many more.")     # per sub-ensemble
+    ex = HipDealExecutor(pdf, nw // world, nd, G, nburn, nthin, a_scale, seed, rank=rank, world=world, moments=False,
+                         store_chain=True, store_logp=True)
+    drv = DealtEmcee(ex, nw, nd, epoch_gens, group=group)
+    try:
+        drv.set_positions(th)
+        drv.run(G)
+        drv.sync()
+        res = drv.results()
+        acc = res["naccept"] / float(G - nburn) if G > nburn else np.full(nw, np.nan)         # :291
+        if not gather:
+            ch, lp, walker = drv.chain()
+            return ch, acc, lp, walker
+        thetas, logd = drv.gather_chain()
+    finally:
+        drv.close()
+    if scalar:
+        thetas = thetas[:, :, 0]
+    assert thetas.shape[1] == ns
+    return thetas, acc, logd, None

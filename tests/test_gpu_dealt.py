@@ -238,3 +238,17 @@ def test_dealt_checkpoint_resume_equals_the_uninterrupted_oracle_run(kmc, oracle
     np.testing.assert_array_equal(res["positions"], ref["final_pos"])
     np.testing.assert_array_equal(res["naccept"], ref["naccept"])
     assert np.all(np.abs(res["logp"] - ref["final_logp"]) <= 1e-12 * np.maximum(1.0, np.abs(ref["final_logp"])))
+
+
+def test_emcee_dealt_front_end_returns_the_reference_tuple(kmc, oracle):
+    """distributed.emcee_dealt (world 1 here: one sub-ensemble, re-shuffled every epoch): the reference's bookkeeping and tuple."""
+    from kissmcmc_jl_amd.distributed import emcee_dealt
+    nw, nd = 256, 3
+    th = np.random.default_rng(2).standard_normal((nw, nd))
+    thetas, acc, logd, blobs = emcee_dealt(kmc.GaussianIso(), th, niter=nw * 120, nthin=2, seed=19, epoch_gens=25)
+    ref = oracle.emcee_dealt(oracle.make_config(oracle.GAUSSIAN_ISO, [0.0, 1.0], nw, nd, 120, 60, 2, 2.0, 19), 1, 25, th, store_chain=True)
+    assert blobs is None and thetas.shape == (nw, 30, nd) and logd.shape == (nw, 30)
+    np.testing.assert_array_equal(thetas, ref["chain"].transpose(1, 0, 2))
+    np.testing.assert_array_equal(acc, ref["accept_ratio"])
+    sq = kmc.squash_walkers(thetas, acc, logd, verbose=False)
+    assert sq[0].shape == (nw * 30, nd)
