@@ -116,7 +116,8 @@ class P2PEmcee:
     """
 
     def __init__(self, pdf, nwalkers, ndim, ngenerations, nburnin=0, nthin=1, a_scale=2.0, seed=0,
-                 device=0, moments=True, group=None, use_graph=True, finegrained=False, fold_signal=False, push=False, lazy=False):
+                 device=0, moments=True, group=None, use_graph=True, finegrained=False, fold_signal=False, push=False, lazy=False,
+                 store_chain=False, store_logp=False):
         from .sampler import Sampler
         self.group = group
         self.rank = dist.get_rank(group) if dist is not None and dist.is_initialized() else 0
@@ -124,7 +125,7 @@ class P2PEmcee:
         self.nwalkers, self.ndim = int(nwalkers), int(ndim)
         shard_slice(self.nwalkers, self.rank, self.world)
         self.sampler = Sampler(pdf, nwalkers, ndim, ngenerations, nburnin, nthin, a_scale, seed,
-                               moments=moments, use_graph=use_graph, device=device,
+                               moments=moments, use_graph=use_graph, device=device, store_chain=store_chain, store_logp=store_logp,
                                shard_rank=self.rank, shard_count=self.world, p2p=True, p2p_finegrained=finegrained,
                                p2p_fold=fold_signal, p2p_push=push, p2p_lazy=lazy)
         if self.world > 1:
@@ -179,6 +180,56 @@ class P2PEmcee:
             q = sum(p[1] for p in parts)
             n = sum(p[2] for p in parts)
         return s, q, n
+
+    def local_chain(self, logp=True):
+        """This rank's walkers' samples in the reference's order, ``(thetas [nlocal, k, ndim], logdensities [nlocal, k] | None)``
+        (local order: its slice of the first half, then of the second half; transposed on the device)."""
+        return self.sampler.chain(logp=logp, by_walker=True)
+
+    def gather_chain(self, logp=True):
+        """The whole chain by walker, ``(thetas [nwalkers, k, ndim], logdensities [nwalkers, k] | None)`` in global walker
+        order, identical on every rank (every rank receives everybody's samples: chains that fit one host, and tests)."""
+        ch, lp = self.local_chain(logp)
+        return self._gather(ch), (self._gather(lp) if lp is not None else None)
+
+
+def emcee_p2p(pdf, theta0s, niter: int = 10 ** 5, nburnin=None, nthin: int = 1, a_scale: float = 2.0, seed: int = 0,
+              device=None, group=None, gather: bool = True):
+    """``emcee`` (reference ``src/samplers.jl:188-293``) with the walkers sharded over the ranks of a ``torch.distributed`` job,
+    the reference's partner rule exactly (bit-identical to the one-GPU run with the same ``seed``): call it on every rank with
+    the same arguments.  Returns the reference's tuple ``(thetas, accept_ratio, logdensities, None)`` in global walker order,
+    identical on every rank (``gather=False``: this rank's walkers only, in its local order)."""
+    from .api import emcee_counts
+    th = np.asarray(theta0s, dtype=np.float64)
+    scalar = th.ndim == 1
+    th = th.reshape(th.shape[0], -1)
+    nw, nd = th.shape
+    if not a_scale > 1:
+        raise AssertionError("a_scale>1")
+    if nw % 2 != 0:
+        raise AssertionError("Use an even number of walkers.")
+    G, nburn, ns = emcee_counts(niter, nw, nburnin, nthin)
+    if nw < nd + 2:
+        raise AssertionError("Use more walkers: at least DOF+2, but better many more.")
+    if device is None:
+        device = torch.cuda.current_device() if torch is not None and torch.cuda.is_available() else 0
+    drv = P2PEmcee(pdf, nw, nd, G, nburn, nthin, a_scale, seed, device=device, moments=False, group=group, store_chain=True, store_logp=True)
+    try:
+        drv.set_positions(th)
+        drv.run(G)
+        drv.sync()
+        denom = float(G - nburn)
+        if gather:
+            thetas, logd = drv.gather_chain()
+            acc = drv.naccept() / denom if G > nburn else np.full(nw, np.nan)                # :291
+        else:
+            thetas, logd = drv.local_chain()
+            acc = drv.sampler.naccept() / denom if G > nburn else np.full(thetas.shape[0], np.nan)
+    finally:
+        drv.close()
+    if scalar:
+        thetas = thetas[:, :, 0]
+    return thetas, acc, logd, None
 
 
 class AllGatherEmcee:

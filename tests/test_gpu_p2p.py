@@ -83,14 +83,20 @@ def _worker_rosen(rank, world, port, outdir):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        drv = P2PEmcee(kmc.Rosenbrock(), RNW, RND, RG, 30, 1, 2.0, 99, device=0)
+        drv = P2PEmcee(kmc.Rosenbrock(), RNW, RND, RG, 30, 1, 2.0, 99, device=0, store_chain=True, store_logp=True)
         drv.set_positions(_rosen_theta0())
         drv.run(RG)
         drv.sync()
         pos, nacc = drv.positions(), drv.naccept()
+        thetas, logd = drv.gather_chain()                # every shard's samples by walker, in global walker order
         if rank == 0:
-            np.savez(os.path.join(outdir, "rosen.npz"), pos=pos, nacc=nacc)
+            np.savez(os.path.join(outdir, "rosen.npz"), pos=pos, nacc=nacc, thetas=thetas, logd=logd)
         drv.close()
+        # the reference's call over the ranks: same tuple as the one-GPU emcee with this seed
+        from kissmcmc_jl_amd.distributed import emcee_p2p
+        t2, acc2, l2, _ = emcee_p2p(kmc.Rosenbrock(), _rosen_theta0(), niter=RNW * RG, nburnin=RNW * 30, seed=99, device=0)
+        if rank == 0:
+            np.savez(os.path.join(outdir, "rosen_front.npz"), thetas=t2, acc=acc2, logd=l2)
     finally:
         dist.destroy_process_group()
 
@@ -98,11 +104,15 @@ def _worker_rosen(rank, world, port, outdir):
 def test_p2p_rosenbrock_odd_ndim(oracle, tmp_path):
     import torch.multiprocessing as mp
     mp.spawn(_worker, args=(3, _free_port(), str(tmp_path), "rosen-ragged"), nprocs=3, join=True)
-    ref = oracle.emcee(oracle.make_config(oracle.ROSENBROCK, [1.0, 100.0, 20.0], RNW, RND, RG, 30, 1, 2.0, 99),
-                       _rosen_theta0(), store_chain=False)
+    ref = oracle.emcee(oracle.make_config(oracle.ROSENBROCK, [1.0, 100.0, 20.0], RNW, RND, RG, 30, 1, 2.0, 99), _rosen_theta0())
     z = np.load(os.path.join(str(tmp_path), "rosen.npz"))
     np.testing.assert_array_equal(z["nacc"], ref["naccept"])
     np.testing.assert_array_equal(z["pos"], ref["final_pos"])
+    np.testing.assert_array_equal(z["thetas"], ref["chain"].transpose(1, 0, 2))           # three shards' chains, by walker
+    assert np.all(np.abs(z["logd"] - ref["chain_logp"].T) <= 1e-12 * np.maximum(1.0, np.abs(ref["chain_logp"].T)))
+    f = np.load(os.path.join(str(tmp_path), "rosen_front.npz"))                            # distributed.emcee_p2p
+    np.testing.assert_array_equal(f["thetas"], ref["chain"].transpose(1, 0, 2))
+    np.testing.assert_array_equal(f["acc"], ref["accept_ratio"])
 
 
 def _free_port():
