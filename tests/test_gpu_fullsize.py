@@ -160,3 +160,35 @@ def test_c4_size_dealt_sub_ensembles_sample_the_target(kmc):
     origin = np.bincount(ids0 // S, minlength=P)                     # where sub-ensemble 0's walkers started
     assert origin.min() > S // P // 2                                # about S / P from each of the 8
     assert np.all(np.isfinite(res["positions"])) and len(np.unique(res["positions"][:, 0])) > 0.99 * P * S
+
+
+def test_c2_chain_beyond_4g_elements(kmc):
+    """A device-resident chain of 18.5 GB (C2, 1100 samples per walker: element offsets beyond 2^31, byte offsets beyond 2^33):
+    stored samples equal the positions of independent runs stopped at the generations that produced them, the last sample
+    is where the run ended, and the read-out by walker (transposed on the device in pieces) is the same data."""
+    nw, nd, nthin, nsamp, seed = 65536, 32, 3, 1100, 2027
+    G = nthin * nsamp
+    th = np.random.default_rng(11).standard_normal((nw, nd))
+    with kmc.Sampler(kmc.GaussianIso(), nw, nd, G, 0, nthin, 2.0, seed, store_chain=True, store_logp=True) as s:
+        s.set_positions(th)
+        s.run(G)
+        s.sync()
+        final, flogp = s.positions(), s.logp()
+        ch, lp = s.chain()
+        assert ch.shape == (nsamp, nw, nd) and ch.size > 2 ** 31 and ch.nbytes > 2 ** 33
+        np.testing.assert_array_equal(ch[-1], final)
+        np.testing.assert_array_equal(lp[-1], flogp)
+        bw, lw = s.chain(by_walker=True)
+        for k in (0, 1, 127, 128, 255, 256, 511, 777, 1023, 1024, 1099):   # byte offsets 0 ... 18.4 GB
+            np.testing.assert_array_equal(bw[:, k], ch[k])
+            np.testing.assert_array_equal(lw[:, k], lp[k])
+        for w in (0, 1, 32767, 32768, 65535):
+            np.testing.assert_array_equal(bw[w], ch[:, w])
+        del bw, lw
+    for k in (0, 130, 640, 1098):                                       # independent runs up to the generation of sample k
+        with kmc.Sampler(kmc.GaussianIso(), nw, nd, G, 0, nthin, 2.0, seed) as t:
+            t.set_positions(th)
+            t.run((k + 1) * nthin)
+            t.sync()
+            np.testing.assert_array_equal(t.positions(), ch[k])
+            np.testing.assert_array_equal(t.logp(), lp[k])
