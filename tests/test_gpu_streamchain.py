@@ -202,3 +202,19 @@ def test_streamed_chain_random_splits_and_thinnings(kmc, oracle, monkeypatch):
         assert chain.shape[0] == ref["nsamples"] == (G - nburn) // nthin, (trial, nthin, G, nburn)
         np.testing.assert_array_equal(chain, ref["chain"], err_msg=f"trial {trial}: nthin={nthin} G={G} nburn={nburn}")
         assert np.all(np.abs(clogp - ref["chain_logp"]) <= 1e-12 * np.maximum(1.0, np.abs(ref["chain_logp"])))
+
+
+def test_chain_larger_than_the_device_is_an_error_not_a_crash(kmc):
+    """A device-resident chain beyond HBM (C2 with 200 000 stored samples per walker: 336 GB): KMC_ERR_OOM from
+    kmc_sampler_create, nothing leaks, and the next sampler works (kmc_emcee_run / emcee() switch to KMC_STREAM_CHAIN by
+    themselves in this situation)."""
+    from kissmcmc_jl_amd import _lib
+    with pytest.raises(kmc.KmcError) as ei:
+        kmc.Sampler(kmc.GaussianIso(), 65536, 32, 200000, 0, 1, store_chain=True)
+    assert ei.value.status == _lib.ERR_OOM
+    th = np.random.default_rng(0).standard_normal((256, 4))
+    with kmc.Sampler(kmc.GaussianIso(), 256, 4, 20, 0, 1, store_chain=True) as s:
+        s.set_positions(th)
+        s.run(20)
+        s.sync()
+        assert s.chain(logp=False)[0].shape == (20, 256, 4)
