@@ -214,6 +214,8 @@ double      kmc_cdf_g_inv(double u, double a);
  *      same kernels:  log p(x) = sum_d TERM + sum_{d<n-1} PAIR, where
  *        term_expr may use  x (= x_d), d, n (= ndim), p (const double*, = params[0..5]);
  *        pair_expr may use  x (= x_d), y (= x_{d+1}), d, n, p;   NULL/"" = no pair term.
+ *      Compiled code objects are cached on disk ($KMC_CACHE_DIR, else ~/.cache/kissmcmc_hip; keyed by the program, the kernel
+ *      headers, the options and the hiprtc version; KMC_NO_DISK_CACHE=1 disables), so later processes skip the compiler.
  *      A term may evaluate to -INFINITY to reject a proposal.  Works in the multi-launch, resident and
  *      island modes and under KMC_P2P (the plain pull; the push / lazy / folded-signal variants are menu densities only). */
 kmc_status  kmc_user_density_create(const char* term_expr, const char* pair_expr, kmc_user_density** out);

@@ -5,6 +5,8 @@
 // two dependent launches per generation, replayed from a hipGraph in chunks of
 // kGraphChunk generations (the kernel boundary is the join of src/samplers.jl:273).
 #include <dlfcn.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <cmath>
@@ -275,6 +277,85 @@ namespace {
 
 }  // namespace
 
+// ---- hiprtc with a disk cache (kmc_host.hpp) -----------------------------------------------------------------
+namespace {
+uint64_t fnv1a(uint64_t h, const void* data, size_t n)
+{
+    const unsigned char* p = static_cast<const unsigned char*>(data);
+    for (size_t i = 0; i < n; ++i) { h ^= p[i]; h *= 0x100000001b3ull; }
+    return h;
+}
+std::string rtc_cache_dir()
+{
+    if (std::getenv("KMC_NO_DISK_CACHE")) return std::string();
+    if (const char* d = std::getenv("KMC_CACHE_DIR")) return std::string(d);
+    if (const char* x = std::getenv("XDG_CACHE_HOME")) if (x[0]) return std::string(x) + "/kissmcmc_hip";
+    if (const char* h = std::getenv("HOME")) if (h[0]) return std::string(h) + "/.cache/kissmcmc_hip";
+    return std::string();
+}
+}  // namespace
+
+kmc_status kmc_host::rtc_compile_cached(const std::string& text, const char* program_name, int nheaders, const char* const* header_text,
+                                        const char* const* header_names, int nopts, const char* const* opts, std::vector<char>* code, std::string* log)
+{
+    // key
+    uint64_t h1 = 0xcbf29ce484222325ull, h2 = 0x84222325cbf29ce4ull;
+    auto mix = [&](const void* p, size_t n) { h1 = fnv1a(h1, p, n); h2 = fnv1a(h2 ^ (uint64_t)n, p, n); h2 = (h2 << 7) | (h2 >> 57); };
+    mix(text.data(), text.size());
+    for (int i = 0; i < nheaders; ++i) { mix(header_names[i], std::strlen(header_names[i])); mix(header_text[i], std::strlen(header_text[i])); }
+    for (int i = 0; i < nopts; ++i) mix(opts[i], std::strlen(opts[i]));
+    int vmaj = 0, vmin = 0;
+    (void)hiprtcVersion(&vmaj, &vmin);
+    mix(&vmaj, sizeof(vmaj)); mix(&vmin, sizeof(vmin));
+    const std::string dir = rtc_cache_dir();
+    char name[64];
+    std::snprintf(name, sizeof(name), "/%016llx%016llx.co", (unsigned long long)h1, (unsigned long long)h2);
+    const std::string path = dir.empty() ? std::string() : dir + name;
+    if (!path.empty()) {
+        std::ifstream f(path, std::ios::binary | std::ios::ate);
+        if (f) {
+            const std::streamsize n = f.tellg();
+            if (n > 64) {
+                code->resize((size_t)n);
+                f.seekg(0);
+                if (f.read(code->data(), n) && f.gcount() == n) return KMC_OK;        // (a code object bundle or ELF, as hiprtc gave it)
+            }
+            code->clear();
+        }
+    }
+    hiprtcProgram prog = nullptr;
+    if (hiprtcCreateProgram(&prog, text.c_str(), program_name, nheaders, const_cast<const char**>(header_text), const_cast<const char**>(header_names)) != HIPRTC_SUCCESS)
+        return fail(KMC_ERR_HIP, "hiprtcCreateProgram failed");
+    const hiprtcResult r = hiprtcCompileProgram(prog, nopts, const_cast<const char**>(opts));
+    if (r != HIPRTC_SUCCESS) {
+        size_t n = 0;
+        hiprtcGetProgramLogSize(prog, &n);
+        log->assign(n, '\0');
+        if (n) hiprtcGetProgramLog(prog, &(*log)[0]);
+        hiprtcDestroyProgram(&prog);
+        return KMC_ERR_BAD_ARG;                          // the caller words the message
+    }
+    size_t n = 0;
+    hiprtcGetCodeSize(prog, &n);
+    code->resize(n);
+    hiprtcGetCode(prog, code->data());
+    hiprtcDestroyProgram(&prog);
+    if (!path.empty()) {                                 // best effort: write beside, then rename (concurrent processes: last one wins, same bytes)
+        (void)::mkdir(dir.substr(0, dir.find_last_of('/')).c_str(), 0755);
+        (void)::mkdir(dir.c_str(), 0755);
+        char tmp[96];
+        std::snprintf(tmp, sizeof(tmp), ".tmp.%ld", (long)::getpid());
+        const std::string tpath = path + tmp;
+        std::ofstream o(tpath, std::ios::binary | std::ios::trunc);
+        if (o && o.write(code->data(), (std::streamsize)code->size()) && (o.close(), !o.fail())) {
+            if (std::rename(tpath.c_str(), path.c_str()) != 0) (void)std::remove(tpath.c_str());
+        } else {
+            (void)std::remove(tpath.c_str());
+        }
+    }
+    return KMC_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // User-supplied densities: two C expressions compiled at run time (hiprtc) into the same kernels.
 // ------------------------------------------------------------------------------------------
@@ -386,26 +467,14 @@ kmc_status compile_user(kmc_user_density* ud, bool with_vec, int L, int K, int i
             << island_S << ", " << resident_K << ", " << (resident_ragged ? "true" : "false") << ">(a); }\n";
     const std::string text = src.str();
 
-    hiprtcProgram prog = nullptr;
     const char* headers[3] = {h_ker.c_str(), h_dev.c_str(), h_isl.c_str()};
     const char* names[3] = {"kmc_kernels.hpp", "kmc_device.hpp", "kmc_islands.hpp"};
-    if (hiprtcCreateProgram(&prog, text.c_str(), "kmc_user_density.hip", 3, headers, names) != HIPRTC_SUCCESS)
-        return fail(KMC_ERR_HIP, "hiprtcCreateProgram failed");
     const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-mllvm", "-amdgpu-kernarg-preload-count=14"};
-    const hiprtcResult r = hiprtcCompileProgram(prog, 6, opts);
-    if (r != HIPRTC_SUCCESS) {
-        size_t n = 0;
-        hiprtcGetProgramLogSize(prog, &n);
-        std::string log(n, '\0');
-        if (n) hiprtcGetProgramLog(prog, &log[0]);
-        hiprtcDestroyProgram(&prog);
-        return fail(KMC_ERR_BAD_ARG, "user density does not compile:\n" + log);
-    }
-    size_t n = 0;
-    hiprtcGetCodeSize(prog, &n);
-    std::vector<char> code(n);
-    hiprtcGetCode(prog, code.data());
-    hiprtcDestroyProgram(&prog);
+    std::vector<char> code;
+    std::string log;
+    const kmc_status cst = rtc_compile_cached(text, "kmc_user_density.hip", 3, headers, names, 6, opts, &code, &log);
+    if (cst == KMC_ERR_BAD_ARG) return fail(KMC_ERR_BAD_ARG, "user density does not compile:\n" + log);
+    if (cst != KMC_OK) return cst;
     auto ins = ud->code.emplace(key, std::move(code));
     *out = &ins.first->second;
     return KMC_OK;

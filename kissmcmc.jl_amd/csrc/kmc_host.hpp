@@ -72,6 +72,14 @@ struct ScopedStream {
     ~ScopedStream() { if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); } }
 };
 
+// hiprtc compilation of `text` (+ named headers) for gfx950, with a DISK CACHE of the code objects: a script that defines its
+// density in source pays the compiler (0.2-0.5 s per density and kernel geometry) once, not in every process.  Key: two
+// 64-bit hashes over the program, every header, the options and the hiprtc version; directory $KMC_CACHE_DIR, else
+// $XDG_CACHE_HOME/kissmcmc_hip, else $HOME/.cache/kissmcmc_hip; KMC_NO_DISK_CACHE=1 switches it off; a cache that cannot be
+// read or written is simply not used.  On a compile error *log holds the compiler's messages.
+kmc_status rtc_compile_cached(const std::string& text, const char* program_name, int nheaders, const char* const* header_text,
+                              const char* const* header_names, int nopts, const char* const* opts, std::vector<char>* code, std::string* log);
+
 kmc_status download_by_walker(const void* src_dev, bool is_float, int64_t nl, int64_t ld, int64_t width, int64_t K, double* dst_host, hipStream_t st);
 std::string user_functor_source(const kmc_user_density* ud);      // the functor(s) ...
 std::string user_density_alias(const kmc_user_density* ud, int64_t ndim);   // ... and "using UD = ...;" over them

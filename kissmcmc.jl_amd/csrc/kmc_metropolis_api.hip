@@ -53,26 +53,14 @@ kmc_status compile_user_metropolis(kmc_user_density* ud, int ND, const std::vect
     if (ND > 0) src << "kmc::metropolis_chains_body<UD, " << ND << ">(a); }\n";
     else src << "kmc::metropolis_chains_any_body<UD>(a); }\n";
     const std::string text = src.str();
-    hiprtcProgram prog = nullptr;
     const char* headers[3] = {h_ker.c_str(), h_dev.c_str(), h_met.c_str()};
     const char* names[3] = {"kmc_kernels.hpp", "kmc_device.hpp", "kmc_metropolis.hpp"};
-    if (hiprtcCreateProgram(&prog, text.c_str(), "kmc_user_metropolis.hip", 3, headers, names) != HIPRTC_SUCCESS)
-        return fail(KMC_ERR_HIP, "hiprtcCreateProgram failed");
     const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"};
-    const hiprtcResult r = hiprtcCompileProgram(prog, 4, opts);
-    if (r != HIPRTC_SUCCESS) {
-        size_t n = 0;
-        hiprtcGetProgramLogSize(prog, &n);
-        std::string log(n, '\0');
-        if (n) hiprtcGetProgramLog(prog, &log[0]);
-        hiprtcDestroyProgram(&prog);
-        return fail(KMC_ERR_BAD_ARG, "user density does not compile:\n" + log);
-    }
-    size_t n = 0;
-    hiprtcGetCodeSize(prog, &n);
-    std::vector<char> code(n);
-    hiprtcGetCode(prog, code.data());
-    hiprtcDestroyProgram(&prog);
+    std::vector<char> code;
+    std::string log;
+    const kmc_status cst = rtc_compile_cached(text, "kmc_user_metropolis.hip", 3, headers, names, 4, opts, &code, &log);
+    if (cst == KMC_ERR_BAD_ARG) return fail(KMC_ERR_BAD_ARG, "user density does not compile:\n" + log);
+    if (cst != KMC_OK) return cst;
     auto ins = ud->code.emplace(key, std::move(code));
     *out = &ins.first->second;
     return KMC_OK;

@@ -8,6 +8,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# runtime-compiled densities cache their code objects on disk (default: ~/.cache/kissmcmc_hip); the tests keep theirs inside the tree
+os.environ.setdefault("KMC_CACHE_DIR", os.path.join(ROOT, ".kmc_cache"))
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
