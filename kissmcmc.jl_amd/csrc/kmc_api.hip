@@ -318,7 +318,10 @@ kmc_status kmc_host::rtc_compile_cached(const std::string& text, const char* pro
             if (n > 64) {
                 code->resize((size_t)n);
                 f.seekg(0);
-                if (f.read(code->data(), n) && f.gcount() == n) return KMC_OK;        // (a code object bundle or ELF, as hiprtc gave it)
+                const bool read_ok = f.read(code->data(), n) && f.gcount() == n;
+                const bool elf = read_ok && std::memcmp(code->data(), "\x7f" "ELF", 4) == 0;
+                const bool bundle = read_ok && std::memcmp(code->data(), "__CLANG_OFFLOAD_BUNDLE__", 24) == 0;
+                if (elf || bundle) return KMC_OK;                                       // a code object as hiprtc gave it
             }
             code->clear();
         }
