@@ -8,7 +8,10 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-N_TRIALS = 120
+import os
+
+N_TRIALS = int(os.environ.get("KMC_FUZZ_TRIALS", 120))          # (a longer hunt: KMC_FUZZ_TRIALS=4000 KMC_FUZZ_BASE=...)
+BASE = int(os.environ.get("KMC_FUZZ_BASE", 9000))
 
 
 def _draw_config(rng):
@@ -37,7 +40,7 @@ def _draw_config(rng):
 
 @pytest.mark.parametrize("trial", range(N_TRIALS))
 def test_random_configuration_equals_the_oracle(kmc, oracle, monkeypatch, trial):
-    rng = np.random.default_rng(9000 + trial)
+    rng = np.random.default_rng(BASE + trial)
     name, nw, nd, G, nburn, nthin, a, launch, resident = _draw_config(rng)
     dens = {
         "gauss": (kmc.GaussianIso(0.0, 1.0), oracle.GAUSSIAN_ISO, [0.0, 1.0]),
