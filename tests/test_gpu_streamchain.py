@@ -176,10 +176,10 @@ def test_stream_chain_argument_checks(kmc):
 def test_streamed_chain_random_splits_and_thinnings(kmc, oracle, monkeypatch):
     """Seeded random sweep of the ring bookkeeping: thinning, burn-in, block size, launch mode and the way a run is cut into
     run() calls (with and without syncs in between) -- every streamed chain equals the oracle's."""
-    rng = np.random.default_rng(2026)
+    rng = np.random.default_rng(int(os.environ.get("KMC_FUZZ_BASE", 2026)))
     nw, nd = 512, 6
     th = rng.standard_normal((nw, nd))
-    for trial in range(12):
+    for trial in range(int(os.environ.get("KMC_FUZZ_TRIALS", 12))):
         nthin = int(rng.choice([1, 1, 2, 3, 7, 64, 65]))
         G = int(rng.integers(150, 700))
         nburn = int(rng.integers(0, G // 2))
