@@ -91,3 +91,33 @@ def test_random_configuration_equals_the_oracle(kmc, oracle, monkeypatch, trial)
         cw, lw = s.chain(by_walker=True)
         np.testing.assert_array_equal(cw, chain.transpose(1, 0, 2), err_msg=label)
         np.testing.assert_array_equal(lw, clogp.T, err_msg=label)
+
+
+@pytest.mark.parametrize("trial", range(max(8, N_TRIALS // 6)))
+def test_random_metropolis_configuration_equals_the_oracle(kmc, oracle, trial):
+    """Many-chain Metropolis (src/samplers.jl:59-128): random chain counts, dimensions (register geometries and the
+    from-memory kernel), steps, thinning; counters identical, states within 1e-11 (the tolerance of test_gpu_metropolis.py:
+    device log / sin / cos differ from glibc's by <= 1 ulp in the Box-Muller normals), both chain layouts."""
+    from kissmcmc_jl_amd.metropolis import run_chains
+    rng = np.random.default_rng(BASE + 77000 + trial)
+    name = str(rng.choice(["gauss", "expo", "rosen", "lognormal"]))
+    nd = int(rng.choice([2, 3, 5, 8, 16, 33]) if name == "rosen" else rng.choice([1, 2, 3, 4, 7, 8, 9, 16, 17, 31, 32, 33, 48]))
+    nc = int(rng.choice([1, 2, 63, 64, 65, 255, 256, 777, 4096, 5001]))
+    niter = int(rng.integers(1, 160))
+    nburn = int(rng.integers(0, niter))
+    nthin = int(rng.choice([1, 1, 2, 5]))
+    seed = int(rng.integers(1, 2 ** 40))
+    pdf, did, params = {"gauss": (kmc.GaussianIso(0.1, 1.3), oracle.GAUSSIAN_ISO, [0.1, 1.3]), "expo": (kmc.Exponential(1.0), oracle.EXPONENTIAL, [1.0]),
+                        "rosen": (kmc.Rosenbrock(), oracle.ROSENBROCK, [1.0, 100.0, 20.0]), "lognormal": (kmc.LogNormal(0.0, 1.0), oracle.LOGNORMAL, [0.0, 1.0])}[name]
+    th = 0.6 + 0.1 * np.abs(rng.standard_normal((nc, nd))) if name in ("expo", "lognormal") else 0.3 * rng.standard_normal((nc, nd))
+    step = rng.uniform(0.05, 0.9, nd) if rng.random() < 0.5 else float(rng.uniform(0.05, 0.9))
+    label = f"trial {trial}: {name} {nc} chains x {nd}, niter={niter} nburn={nburn} nthin={nthin}"
+    r = run_chains(pdf, kmc.GaussianStep(step), th, niter, nburn, nthin, seed, moments=True, by_chain=bool(trial % 2))
+    ref = oracle.metropolis(did, params, th, step, niter, nburn, nthin, seed)
+    np.testing.assert_array_equal(r["naccept"], ref["naccept"], err_msg=label)
+    chain = r["chain"].transpose(1, 0, 2) if trial % 2 else r["chain"]
+    clogp = r["chain_logp"].T if trial % 2 else r["chain_logp"]
+    np.testing.assert_allclose(chain, ref["chain"], rtol=1e-11, atol=1e-11, err_msg=label)
+    np.testing.assert_allclose(clogp, ref["chain_logp"], rtol=1e-10, atol=1e-10, err_msg=label)
+    np.testing.assert_allclose(r["final_pos"], ref["final_pos"], rtol=1e-11, atol=1e-11, err_msg=label)
+    np.testing.assert_allclose(r["chain_sum"], ref["chain_sum"], rtol=1e-10, atol=1e-10, err_msg=label)
