@@ -121,3 +121,47 @@ def test_random_metropolis_configuration_equals_the_oracle(kmc, oracle, trial):
     np.testing.assert_allclose(clogp, ref["chain_logp"], rtol=1e-10, atol=1e-10, err_msg=label)
     np.testing.assert_allclose(r["final_pos"], ref["final_pos"], rtol=1e-11, atol=1e-11, err_msg=label)
     np.testing.assert_allclose(r["chain_sum"], ref["chain_sum"], rtol=1e-10, atol=1e-10, err_msg=label)
+
+
+@pytest.mark.parametrize("trial", range(max(6, N_TRIALS // 10)))
+def test_random_logical_shards_equal_the_oracle(kmc, oracle, trial):
+    """Walker sharding (replica form: P samplers with shard_rank r on one position buffer, the device-local stand-in for the
+    all-gather): random shard counts, shapes and densities; the sharded run is the oracle's unsharded run bit for bit."""
+    import torch
+    rng = np.random.default_rng(BASE + 33000 + trial)
+    P = int(rng.choice([2, 4, 8]))
+    nd = int(rng.choice([2, 4, 8, 16, 32, 64, 100]))                   # (bind_positions: even ndim)
+    per = int(rng.choice([2, 3, 8, 33, 64]))                           # active walkers per shard and half
+    nw = max(2 * P * per, ((nd + 2 + 2 * P - 1) // (2 * P)) * 2 * P)
+    name = str(rng.choice(["gauss", "rosen", "expo"]))
+    pdf, did, params = {"gauss": (kmc.GaussianIso(), oracle.GAUSSIAN_ISO, [0.0, 1.0]), "rosen": (kmc.Rosenbrock(), oracle.ROSENBROCK, [1.0, 100.0, 20.0]),
+                        "expo": (kmc.Exponential(), oracle.EXPONENTIAL, [1.0])}[name]
+    G = int(rng.integers(2, 40)); nburn = int(rng.integers(0, G)); seed = int(rng.integers(1, 2 ** 40))
+    th = 0.6 + 0.1 * np.abs(rng.standard_normal((nw, nd))) if name == "expo" else 0.3 * rng.standard_normal((nw, nd))
+    pos = torch.empty((nw, nd), dtype=torch.float64, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    shards = []
+    try:
+        for r in range(P):
+            s = kmc.Sampler(pdf, nw, nd, G, nburn, 1, 2.0, seed, moments=True, use_graph=False, shard_rank=r, shard_count=P)
+            s.bind_positions(pos.data_ptr())
+            s.set_stream(stream)
+            s.set_positions(th)
+            shards.append(s)
+        for g in range(G):
+            for half in (0, 1):
+                for s in shards:
+                    s.half_step(half)
+        torch.cuda.synchronize()
+        nacc = sum(s.naccept() for s in shards)
+        n = sum(s.moments()[2] for s in shards)
+        S = sum(s.moments()[0] for s in shards)
+    finally:
+        for s in shards:
+            s.close()
+    label = f"trial {trial}: {name} {nw}x{nd} in {P} shards, G={G} nburn={nburn}"
+    ref = oracle.emcee(oracle.make_config(did, params, nw, nd, G, nburn, 1, 2.0, seed), th, store_chain=False)
+    np.testing.assert_array_equal(pos.cpu().numpy(), ref["final_pos"], err_msg=label)
+    np.testing.assert_array_equal(nacc, ref["naccept"], err_msg=label)
+    assert n == ref["nmoment"], label
+    np.testing.assert_allclose(S, ref["sum"], rtol=1e-11, atol=1e-9, err_msg=label)
