@@ -165,3 +165,42 @@ def test_random_logical_shards_equal_the_oracle(kmc, oracle, trial):
     np.testing.assert_array_equal(nacc, ref["naccept"], err_msg=label)
     assert n == ref["nmoment"], label
     np.testing.assert_allclose(S, ref["sum"], rtol=1e-11, atol=1e-9, err_msg=label)
+
+
+@pytest.mark.parametrize("trial", range(max(6, N_TRIALS // 10)))
+def test_random_dealt_sub_ensembles_equal_the_oracle(kmc, oracle, trial):
+    """Dealt sub-ensembles (the multi-GPU mode without a per-half-step exchange) with random sub-ensemble counts, sizes,
+    epoch lengths and run splits: per-walker results and the per-walker chain equal the oracle's restatement."""
+    from kissmcmc_jl_amd.distributed import HipDealExecutor, LocalDealtEmcee
+    rng = np.random.default_rng(BASE + 55000 + trial)
+    P = int(rng.choice([1, 2, 4, 8]))
+    nd = int(rng.choice([1, 2, 5, 8, 32, 33, 64]))
+    S = int(rng.choice([2, 4, 16, 33, 128])) * 2 * P                    # S % (2 P) == 0
+    while S < nd + 2:
+        S += 2 * P
+    G = int(rng.integers(2, 80)); nburn = int(rng.integers(0, G)); nthin = int(rng.choice([1, 1, 2, 3])); E = int(rng.integers(1, 40))
+    seed = int(rng.integers(1, 2 ** 40))
+    N = P * S
+    th = rng.standard_normal((N, nd))
+    exs = [HipDealExecutor(kmc.GaussianIso(), S, nd, G, nburn, nthin, 2.0, seed, rank=r, world=P, device=0, store_chain=True, store_logp=True) for r in range(P)]
+    drv = LocalDealtEmcee(exs, N, nd, E)
+    try:
+        drv.set_positions(th)
+        left = G
+        while left > 0:
+            n = int(min(left, rng.choice([1, 7, 64, 100])))
+            drv.run(n)
+            left -= n
+        drv.sync()
+        res = drv.results()
+        thetas, logd = drv.gather_chain()
+    finally:
+        drv.close()
+    label = f"trial {trial}: {P} x {S} x {nd}, G={G} nburn={nburn} nthin={nthin} E={E}"
+    ref = oracle.emcee_dealt(oracle.make_config(oracle.GAUSSIAN_ISO, [0.0, 1.0], N, nd, G, nburn, nthin, 2.0, seed, nthreads=4), P, E, th, store_chain=True)
+    assert ref["status"] == 0, label
+    np.testing.assert_array_equal(res["naccept"], ref["naccept"], err_msg=label)
+    np.testing.assert_array_equal(res["positions"], ref["final_pos"], err_msg=label)
+    np.testing.assert_array_equal(thetas, ref["chain"].transpose(1, 0, 2), err_msg=label)
+    assert res["n"] == ref["nmoment"], label
+    np.testing.assert_allclose(res["sum"], ref["sum"], rtol=1e-11, atol=1e-8, err_msg=label)
