@@ -204,3 +204,44 @@ def test_random_dealt_sub_ensembles_equal_the_oracle(kmc, oracle, trial):
     np.testing.assert_array_equal(thetas, ref["chain"].transpose(1, 0, 2), err_msg=label)
     assert res["n"] == ref["nmoment"], label
     np.testing.assert_allclose(res["sum"], ref["sum"], rtol=1e-11, atol=1e-8, err_msg=label)
+
+
+@pytest.mark.parametrize("trial", range(max(6, N_TRIALS // 15)))
+def test_random_runtime_compiled_density_equals_the_oracle(kmc, oracle, monkeypatch, trial):
+    """Runtime-compiled densities (term / pair expressions in the lane-striped kernels, function bodies in the staged and
+    generic one-walker-per-lane kernels) restating a menu density, random shapes and launch modes: identical counters and
+    positions, log-pdfs to 1e-12."""
+    rng = np.random.default_rng(BASE + 88000 + trial)
+    form = str(rng.choice(["expr", "body"]))
+    name = str(rng.choice(["gauss", "rosen"]))
+    nd = int(rng.choice([2, 3, 8, 17, 32, 64, 65, 130]) if name == "rosen" else rng.choice([1, 2, 5, 8, 16, 31, 32, 33, 64, 100]))
+    nw = int(rng.choice([nd + 2 + nd % 2, 64, 130, 256, 1000, 2050]))
+    nw = max(nw, nd + 2 + nd % 2); nw += nw % 2
+    G = int(rng.integers(3, 100)); nburn = int(rng.integers(0, G)); nthin = int(rng.choice([1, 2, 3])); seed = int(rng.integers(1, 2 ** 40))
+    launch = str(rng.choice(["", "graph", "eager"]))
+    if launch:
+        monkeypatch.setenv("KMC_LAUNCH", launch)
+    if rng.random() < 0.5:
+        monkeypatch.setenv("KMC_NO_RESIDENT", "1")
+    if name == "gauss":
+        did, params = oracle.GAUSSIAN_ISO, [0.3, 1.5]
+        pdf = (kmc.ExprDensity("-0.5*((x-p[0])*p[1])*((x-p[0])*p[1])", params=[0.3, 1.0 / 1.5]) if form == "expr" else
+               kmc.CDensity("double s = 0.0; for (int i = 0; i < n; ++i) { double t = (x[i] - p[0]) * p[1]; s += t * t; } return -0.5 * s;", params=[0.3, 1.0 / 1.5]))
+        th = 0.3 + rng.standard_normal((nw, nd))
+    else:
+        did, params = oracle.ROSENBROCK, [1.0, 100.0, 20.0]
+        pdf = (kmc.ExprDensity("d < n-1 ? -((p[0]-x)*(p[0]-x))/p[2] : 0.0", "-(p[1]*((y-x*x)*(y-x*x)))/p[2]", params) if form == "expr" else
+               kmc.CDensity("double s = 0.0; for (int i = 0; i + 1 < n; ++i) { double d = x[i + 1] - x[i] * x[i]; double e = p[0] - x[i]; s += p[1] * (d * d) + e * e; } "
+                            "return -(s * (1.0 / p[2]));", params=params))
+        th = 0.1 * rng.standard_normal((nw, nd))
+    label = f"trial {trial}: {form} {name} {nw}x{nd} G={G} nburn={nburn} nthin={nthin} launch={launch or 'auto'}"
+    ref = oracle.emcee(oracle.make_config(did, params, nw, nd, G, nburn, nthin, 2.0, seed), th)
+    with kmc.Sampler(pdf, nw, nd, G, nburn, nthin, 2.0, seed, store_chain=True, moments=True) as s:
+        s.set_positions(th)
+        s.run(G // 2); s.run(G - G // 2)
+        s.sync()
+        np.testing.assert_array_equal(s.naccept(), ref["naccept"], err_msg=label)
+        np.testing.assert_array_equal(s.positions(), ref["final_pos"], err_msg=label)
+        np.testing.assert_array_equal(s.chain(logp=False)[0], ref["chain"], err_msg=label)
+        assert np.all(np.abs(s.logp() - ref["final_logp"]) <= 1e-12 * np.maximum(1.0, np.abs(ref["final_logp"]))), label
+        assert s.moments()[2] == ref["nmoment"], label
