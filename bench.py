@@ -530,6 +530,53 @@ def main():
         except Exception as e:  # noqa: BLE001
             dealt = {"error": str(e)}
 
+    # Extra, NOT `value` (N > 1, when the peer-to-peer pull supplied `value`): the exchange the north star names -- one RCCL all-gather
+    # of the updated half after every half-step, enqueued with the kernels inside the hipGraph chunks -- on a bounded piece
+    # of the same job, so that both exchanges are on record from the same node.
+    allgather_extra = None
+    if world > 1 and mode == "p2p" and os.environ.get("KMC_BENCH_NO_ALLGATHER_EXTRA") is None:
+        try:
+            from kissmcmc_jl_amd.distributed import AllGatherEmcee
+            ag, okag = None, True
+            try:
+                ag = AllGatherEmcee(pdf, nw, NDIM, G, nburn, 1, 2.0, SEED, device=local_rank)
+            except Exception as e:  # noqa: BLE001
+                print(f"[rank {rank}] native RCCL all-gather set-up failed ({e})", file=sys.stderr)
+                okag = False
+            if all_ok(okag):
+                gens = min(G, 1024)
+                ag.set_positions(th)
+                ag.run(128)
+                ag.sync()
+                ag.set_positions(th)
+                dist.barrier()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                ag.run(gens)
+                ag.sync()
+                torch.cuda.synchronize()
+                dist.barrier()
+                dta = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+                dist.all_reduce(dta, op=dist.ReduceOp.MAX)
+                apos, aacc = ag.positions(), ag.naccept()
+                how_ag = ag.sampler.describe()
+                ag.close()
+                same = None
+                if rank == 0:
+                    rp, ra, _ = unsharded(gens)
+                    same = bool(np.array_equal(rp, apos) and np.array_equal(ra, aacc))
+                allgather_extra = {"value": float(nw) * gens / float(dta.item()), "unit": "walker-steps/s", "generations": gens,
+                                   "us_per_half_step": float(dta.item()) / (2 * gens) * 1e6, "equals_unsharded_run": same,
+                                   "bytes_received_per_gpu_per_half_step": (world - 1) * (NWALKERS_PER_GPU // 2) * NDIM * 8,
+                                   "execution": how_ag.split(";")[-1].strip(),
+                                   "note": "exact partner rule; full replica per rank, in-place ncclAllGather of the updated half per half-step"}
+            else:
+                if ag is not None:
+                    ag.sampler.close()
+                allgather_extra = {"error": "native RCCL all-gather could not be set up on every rank (see stderr)"}
+        except Exception as e:  # noqa: BLE001
+            allgather_extra = {"error": str(e)}
+
     if rank == 0:
         steps_total = float(nw) * G
         value = steps_total / elapsed
@@ -573,6 +620,8 @@ def main():
         if world > 1:
             out["check"]["timed_run_equals_unsharded_run"] = verified
             out["dealt_mode"] = dealt
+            if allgather_extra is not None:
+                out["allgather_mode"] = allgather_extra
             # what the exchange has to move: partners are uniform over the whole complementary half,
             # so (P-1)/P of a rank's partner rows are remote, 1/P from each peer over that pair's single xGMI link
             rows_per_peer = walkers_per_launch / world
