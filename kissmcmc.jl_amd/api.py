@@ -105,8 +105,16 @@ def emcee(pdf, theta0s, niter: int = 10 ** 5, nburnin=None, nthin: int = 1, a_sc
 
     if stream_chain is None:
         stream_chain = dtype == "f64" and nsamples_walker * nwalkers * (ndim + 1 + ndim % 2) * 8 > 0.7 * _free_device_bytes(device)
-    with Sampler(pdf, nwalkers, ndim, niter_walker, nburnin_walker, nthin, a_scale, seed,
-                 store_chain=True, store_logp=True, device=device, dtype=dtype, stream_chain=bool(stream_chain), chain_by_walker=True) as s:
+    def make(by_walker):
+        return Sampler(pdf, nwalkers, ndim, niter_walker, nburnin_walker, nthin, a_scale, seed, store_chain=True, store_logp=True,
+                       device=device, dtype=dtype, stream_chain=bool(stream_chain), chain_by_walker=by_walker)
+    try:
+        sampler = make(True)
+    except _lib.KmcError as e:                                 # a streamed chain whose host arrays cannot be page-locked:
+        if e.status != _lib.ERR_UNSUPPORTED or not stream_chain:   # stream it sample-major, reorder on the host
+            raise
+        sampler = make(False)
+    with sampler as s:
         try:
             s.set_positions(theta0s)
         except _lib.KmcError as e:

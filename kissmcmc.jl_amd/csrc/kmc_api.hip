@@ -5,6 +5,9 @@
 // two dependent launches per generation, replayed from a hipGraph in chunks of
 // kGraphChunk generations (the kernel boundary is the join of src/samplers.jl:273).
 #include <dlfcn.h>
+#include <execinfo.h>
+#include <fcntl.h>
+#include <signal.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -925,7 +928,11 @@ hipError_t upload_rows(const kmc_sampler* s, double* dst_dev, const double* src_
         return copy_sync(dst_dev, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice, s->stream);
     }
     if (ld == nd) return copy_sync(dst_dev, src_host, rows * nd * sizeof(double), hipMemcpyHostToDevice, s->stream);
-    return copy2d_sync(dst_dev, ld * sizeof(double), src_host, nd * sizeof(double), nd * sizeof(double), rows, hipMemcpyHostToDevice, s->stream);
+    // padded rows (odd ndim): repacked on the host and copied contiguously -- not hipMemcpy2DAsync from pageable memory (an
+    // abort inside the runtime, intermittent, was traced to kmc_sampler_set_positions with odd ndim while that was in use)
+    std::vector<double> t(rows * ld, 0.0);
+    for (size_t r = 0; r < rows; ++r) std::memcpy(&t[r * ld], src_host + r * nd, nd * sizeof(double));
+    return copy_sync(dst_dev, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice, s->stream);
 }
 hipError_t download_rows(const kmc_sampler* s, double* dst_host, const double* src_dev, size_t rows)
 {
@@ -944,7 +951,15 @@ hipError_t download_rows(const kmc_sampler* s, double* dst_host, const double* s
         return hipSuccess;
     }
     if (ld == nd) return copy_sync(dst_host, src_dev, rows * nd * sizeof(double), hipMemcpyDeviceToHost, s->stream);
-    return copy2d_sync(dst_host, nd * sizeof(double), src_dev, ld * sizeof(double), nd * sizeof(double), rows, hipMemcpyDeviceToHost, s->stream);
+    const size_t slab = (size_t)1 << 21;                       // padded rows: contiguous copies of slabs, unpacked on the host (see upload_rows)
+    std::vector<double> t((rows < slab ? rows : slab) * ld);
+    for (size_t r0 = 0; r0 < rows; r0 += slab) {
+        const size_t n = rows - r0 < slab ? rows - r0 : slab;
+        const hipError_t e = copy_sync(t.data(), src_dev + r0 * ld, n * ld * sizeof(double), hipMemcpyDeviceToHost, s->stream);
+        if (e != hipSuccess) return e;
+        for (size_t r = 0; r < n; ++r) std::memcpy(dst_host + (r0 + r) * nd, &t[r * ld], nd * sizeof(double));
+    }
+    return hipSuccess;
 }
 
 int64_t samples_done(const kmc_sampler* s)
@@ -1008,8 +1023,15 @@ kmc_status chain_copy_range(kmc_sampler* s, int64_t k0, int64_t k1)
     if (s->d_chain && s->dst_chain) {
         const double* src = s->d_chain + slot0 * nl * ld;
         double* dst = s->dst_chain + (size_t)k0 * nl * nd;
-        if (ld == nd) HIP_TRY(hipMemcpyAsync(dst, src, n * nl * nd * sizeof(double), hipMemcpyDeviceToHost, s->copy_stream));
-        else HIP_TRY(hipMemcpy2DAsync(dst, nd * sizeof(double), src, ld * sizeof(double), nd * sizeof(double), n * nl, hipMemcpyDeviceToHost, s->copy_stream));
+        if (ld == nd) {
+            HIP_TRY(hipMemcpyAsync(dst, src, n * nl * nd * sizeof(double), hipMemcpyDeviceToHost, s->copy_stream));
+        } else {                                         // padded rows: compacted into the scratch block, then one contiguous copy
+            int64_t grid = (int64_t)((n * nl * nd + 255) / 256);
+            if (grid > 8192) grid = 8192;
+            hipLaunchKernelGGL(rows_compact, dim3((unsigned)grid), dim3(256), 0, s->copy_stream, src, s->bw_scratch, (int64_t)(n * nl), (int32_t)ld, (int32_t)nd);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(dst, s->bw_scratch, n * nl * nd * sizeof(double), hipMemcpyDeviceToHost, s->copy_stream));
+        }
     }
     if (s->d_chain_logp && s->dst_logp)
         HIP_TRY(hipMemcpyAsync(s->dst_logp + (size_t)k0 * nl, s->d_chain_logp + slot0 * nl, n * nl * sizeof(double), hipMemcpyDeviceToHost, s->copy_stream));
@@ -1125,6 +1147,27 @@ KMC_EXPORT int kmc_device_count(void)
 }
 
 KMC_EXPORT const char* kmc_last_error(void) { return g_err.c_str(); }
+
+// Diagnostics (KMC_ABORT_BACKTRACE=1 in the environment when the library is loaded): the native call stack of an abort()
+// raised anywhere in the process (the HIP runtime aborts on internal errors without a message), on stderr.
+namespace {
+void abort_backtrace(int sig)
+{
+    void* frames[64];
+    const int n = backtrace(frames, 64);
+    const char msg[] = "\n[kissmcmc_hip] SIGABRT, native stack:\n";
+    int fd = 2;                                          // KMC_ABORT_BACKTRACE=/path/to/file: there (a test runner may have captured fd 2)
+    const char* where = std::getenv("KMC_ABORT_BACKTRACE");
+    if (where && where[0] == '/') { const int f = open(where, O_WRONLY | O_CREAT | O_APPEND, 0644); if (f >= 0) fd = f; }
+    (void)!write(fd, msg, sizeof(msg) - 1);
+    backtrace_symbols_fd(frames, n, fd);
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
+struct AbortBacktraceInstaller {
+    AbortBacktraceInstaller() { if (std::getenv("KMC_ABORT_BACKTRACE")) signal(SIGABRT, abort_backtrace); }
+} g_abort_backtrace_installer;
+}  // namespace
 
 KMC_EXPORT const char* kmc_status_string(kmc_status st)
 {
@@ -1460,6 +1503,8 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         if (s->stream_by_walker && !(bwc && std::strcmp(bwc, "kernel") == 0)) {
             if (cfg->flags & KMC_STORE_CHAIN) CREATE_TRY(hipMalloc(&s->bw_scratch, (size_t)blk * (size_t)s->nlocal * (size_t)cfg->ndim * sizeof(double)));
             if (cfg->flags & KMC_STORE_LOGP) CREATE_TRY(hipMalloc(&s->bw_scratch_logp, (size_t)blk * (size_t)s->nlocal * sizeof(double)));
+        } else if (!s->stream_by_walker && (cfg->flags & KMC_STORE_CHAIN) && s->ld != cfg->ndim) {
+            CREATE_TRY(hipMalloc(&s->bw_scratch, (size_t)blk * (size_t)s->nlocal * (size_t)cfg->ndim * sizeof(double)));   // (rows_compact)
         }
         s->ring_blk = blk;
         s->ring_slots = 3 * blk;
@@ -1468,6 +1513,20 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         for (int i = 0; i < 3; ++i) {
             CREATE_TRY(hipEventCreateWithFlags(&s->ev_filled[i], hipEventDisableTiming));
             CREATE_TRY(hipEventCreateWithFlags(&s->ev_copied[i], hipEventDisableTiming));
+        }
+    }
+    if ((cfg->flags & (KMC_STORE_CHAIN | KMC_STORE_LOGP)) && s->nsamples > 0) {
+        // A chain that cannot fit is refused HERE, not by a failing hipMalloc: after a failed allocation of hundreds of GB the
+        // runtime aborted the process a few calls later (observed: 4 of 5 runs, in the first HIP call of the next sampler).
+        size_t free_b = 0, total_b = 0;
+        CREATE_TRY(hipMemGetInfo(&free_b, &total_b));
+        const size_t need = (size_t)chain_slots * (size_t)s->nlocal *
+                            (((cfg->flags & KMC_STORE_CHAIN) ? ldz * esz : 0) + ((cfg->flags & KMC_STORE_LOGP) ? sizeof(double) : 0));
+        if (need > free_b) {
+            kmc_status r_ = fail(KMC_ERR_OOM, "the chain needs " + std::to_string(need >> 20) + " MiB of device memory, " + std::to_string(free_b >> 20) +
+                                              " MiB are free: thin it (nthin), or stream it to host memory (KMC_STREAM_CHAIN)");
+            kmc_sampler_destroy(s);
+            return r_;
         }
     }
     if ((cfg->flags & KMC_STORE_CHAIN) && s->nsamples > 0)
@@ -1851,6 +1910,7 @@ KMC_EXPORT kmc_status kmc_sampler_set_state(kmc_sampler* s, const double* pos_ho
 KMC_EXPORT kmc_status kmc_sampler_set_positions(kmc_sampler* s, const double* theta_host)
 {
     if (!s || !theta_host) return fail(KMC_ERR_BAD_ARG, "null argument");
+    if (std::getenv("KMC_ABORT_BACKTRACE")) signal(SIGABRT, abort_backtrace);      // (diagnostics: somebody may have replaced it)
     HIP_TRY(hipSetDevice(s->cfg.device));
     const size_t nw = (size_t)s->nrows, nd = (size_t)s->cfg.ndim;
     HIP_TRY(hipStreamSynchronize(s->stream));
@@ -1951,6 +2011,13 @@ KMC_EXPORT kmc_status kmc_sampler_set_chain_host(kmc_sampler* s, double* chain_h
         else (void)hipGetLastError();
     }
     s->dev_dst_chain = s->dev_dst_logp = nullptr;
+    if (s->stream_by_walker && ((s->dst_chain && !s->dst_chain_reg) || (s->dst_logp && !s->dst_logp_reg))) {
+        // the by-walker copies are 2-D windows (or a kernel's stores) into the caller's arrays: page-locked memory only -- a 2-D
+        // asynchronous copy into pageable memory is the call that aborted inside the runtime (upload_rows)
+        chain_unregister(s);
+        s->dst_chain = s->dst_logp = nullptr;
+        return fail(KMC_ERR_UNSUPPORTED, "KMC_STREAM_CHAIN | KMC_CHAIN_BY_WALKER: the host buffers could not be page-locked (hipHostRegister); use the sample-major stream");
+    }
     if (s->stream_by_walker) {
         // the by-walker copy is a kernel that writes into the caller's arrays: they must be mapped into the device's address space
         if (s->dst_chain && !s->bw_scratch && (!s->dst_chain_reg || hipHostGetDevicePointer((void**)&s->dev_dst_chain, s->dst_chain, 0) != hipSuccess)) {

@@ -1404,6 +1404,17 @@ __global__ __launch_bounds__(256) void chain_by_walker(const T* __restrict__ src
     }
 }
 
+// Padded rows [rows][ld] -> dense rows [rows][nd] (a streamed chain of odd ndim: compacted on the device, so that the copy to the
+// host is one contiguous transfer).
+__global__ __launch_bounds__(256) void rows_compact(const double* __restrict__ src, double* __restrict__ dst, int64_t rows, int32_t ld, int32_t nd)
+{
+    const int64_t n = rows * nd;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+        const int64_t r = e / nd;
+        dst[e] = src[r * ld + (e - r * nd)];
+    }
+}
+
 // Graph replay support: the device-side generation counter and the schedule table of the next
 // `n` generations (one thread each).  *gen += by happens before the table is rebuilt.
 __global__ void advance_schedule(int64_t* gen, SchedEntry* table, int n, int64_t by,

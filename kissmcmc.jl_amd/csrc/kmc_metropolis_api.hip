@@ -132,6 +132,8 @@ kmc_status metropolis_host_route(const kmc_metropolis_config* c, const double* t
         HIP_TRY(hipMalloc(&b.step, (size_t)nd * sizeof(double)));
         HIP_TRY(copy_sync(b.step, c->step, (size_t)nd * sizeof(double), hipMemcpyHostToDevice, st));
     }
+    if ((want_chain || want_logp) && nsamples > 0)
+        KMC_TRY(check_device_room((size_t)nsamples * ((want_chain ? rows : 0) + (want_logp ? vec : 0)), "the Metropolis chain"));
     if (want_chain && nsamples > 0) HIP_TRY(hipMalloc(&b.chain, (size_t)nsamples * rows));
     if (want_logp && nsamples > 0) HIP_TRY(hipMalloc(&b.chain_logp, (size_t)nsamples * vec));
     if (want_mom) {
@@ -320,6 +322,8 @@ KMC_EXPORT kmc_status kmc_metropolis_run(const kmc_metropolis_config* c, const d
     HIP_TRY(hipMalloc(&b.step, (size_t)nd * sizeof(double)));
     HIP_TRY(copy_sync(b.step, c->step, (size_t)nd * sizeof(double), hipMemcpyHostToDevice, st));
     HIP_TRY(copy_sync(b.pos, theta0, rows, hipMemcpyHostToDevice, st));                              // :68 deepcopy
+    if ((want_chain || want_logp) && nsamples > 0)
+        KMC_TRY(check_device_room((size_t)nsamples * ((want_chain ? rows : 0) + (want_logp ? (size_t)nc * sizeof(double) : 0)), "the Metropolis chain"));
     if (want_chain && nsamples > 0) HIP_TRY(hipMalloc(&b.chain, (size_t)nsamples * rows));
     if (want_logp && nsamples > 0) HIP_TRY(hipMalloc(&b.chain_logp, (size_t)nsamples * (size_t)nc * sizeof(double)));
     if (want_mom) {

@@ -69,6 +69,10 @@ def test_streamed_chain_variants(kmc, oracle, monkeypatch, case, by_walker):
         monkeypatch.setenv("KMC_NO_HOST_REGISTER", "1")  # staged copies instead of DMA into page-locked arrays
     th = scale * np.random.default_rng(2).standard_normal((nw, nd))
     seed = 77
+    if by_walker and case == "unregistered_destination":     # 2-D windows into the caller's arrays need page-locked memory
+        with pytest.raises(kmc.KmcError, match="could not be page-locked"):
+            kmc.Sampler(pdf, nw, nd, G, nburn, nthin, 2.0, seed, stream_chain=True, chain_by_walker=True, **kw)
+        return
     with kmc.Sampler(pdf, nw, nd, G, nburn, nthin, 2.0, seed, stream_chain=True, chain_by_walker=by_walker, **kw) as s:
         s.set_positions(th)
         if case == "pieces_with_syncs":
