@@ -12,6 +12,9 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <thread>
+#include <deque>
+#include <condition_variable>
 #include <cmath>
 #include <fstream>
 #include <map>
@@ -279,6 +282,165 @@ kmc_status kmc_host::digest_params(const kmc_config& c, DensityParams* dp)
 namespace {
 
 }  // namespace
+
+// ---- copy_sync (kmc_host.hpp): blocking copies on a named stream, pageable memory staged through page-locked bounce buffers ----
+namespace {
+constexpr size_t kBounceBytes = (size_t)16 << 20;
+struct Bounce {
+    void* buf[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    int device = -1;
+};
+std::mutex g_bounce_mu;
+std::vector<Bounce*> g_bounce_free;          // never released: a handful of 32 MiB pairs for the life of the process
+
+Bounce* bounce_acquire(hipError_t* e)
+{
+    int dev = 0;
+    *e = hipGetDevice(&dev);
+    if (*e != hipSuccess) return nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_bounce_mu);
+        for (size_t i = 0; i < g_bounce_free.size(); ++i)
+            if (g_bounce_free[i]->device == dev) { Bounce* b = g_bounce_free[i]; g_bounce_free.erase(g_bounce_free.begin() + (long)i); return b; }
+    }
+    Bounce* b = new Bounce();
+    b->device = dev;
+    for (int i = 0; i < 2 && *e == hipSuccess; ++i) {
+        *e = hipHostMalloc(&b->buf[i], kBounceBytes, hipHostMallocDefault);
+        if (*e == hipSuccess) *e = hipEventCreateWithFlags(&b->ev[i], hipEventDisableTiming);
+    }
+    if (*e != hipSuccess) {
+        for (int i = 0; i < 2; ++i) { if (b->buf[i]) (void)hipHostFree(b->buf[i]); if (b->ev[i]) (void)hipEventDestroy(b->ev[i]); }
+        delete b;
+        return nullptr;
+    }
+    return b;
+}
+void bounce_release(Bounce* b)
+{
+    std::lock_guard<std::mutex> lock(g_bounce_mu);
+    g_bounce_free.push_back(b);
+}
+// memcpy of a bounce chunk by a few threads: one thread moves ~12 GB/s (and takes the first-touch page faults of a fresh
+// destination), which would make a chain download slower than the runtime's own pageable path was
+class CopyPool {
+public:
+    void copy(char* d, const char* s, size_t n)
+    {
+        constexpr size_t kMin = (size_t)2 << 20;
+        if (n < 2 * kMin) { std::memcpy(d, s, n); return; }
+        start();
+        const size_t parts = std::min<size_t>(nworkers_ + 1, n / kMin);
+        const size_t each = (n / parts + 4095) & ~(size_t)4095;
+        {
+            std::lock_guard<std::mutex> lock(m_);
+            for (size_t p = 1; p < parts; ++p) {
+                const size_t off = p * each;
+                if (off >= n) break;
+                q_.push_back(Job{d + off, s + off, std::min(each, n - off)});
+                ++pending_;
+            }
+        }
+        cv_.notify_all();
+        std::memcpy(d, s, std::min(each, n));
+        std::unique_lock<std::mutex> lock(m_);
+        done_.wait(lock, [&] { return pending_ == 0; });
+    }
+private:
+    struct Job { char* d; const char* s; size_t n; };
+    void start()
+    {
+        std::lock_guard<std::mutex> lock(m_);
+        if (started_) return;
+        started_ = true;
+        unsigned hw = std::thread::hardware_concurrency();
+        nworkers_ = hw >= 8 ? 3 : (hw >= 4 ? 1 : 0);
+        for (size_t i = 0; i < nworkers_; ++i)
+            std::thread([this] {
+                for (;;) {
+                    Job j;
+                    {
+                        std::unique_lock<std::mutex> lock(m_);
+                        cv_.wait(lock, [&] { return !q_.empty(); });
+                        j = q_.front();
+                        q_.pop_front();
+                    }
+                    std::memcpy(j.d, j.s, j.n);
+                    {
+                        std::lock_guard<std::mutex> lock(m_);
+                        if (--pending_ == 0) done_.notify_all();
+                    }
+                }
+            }).detach();                              // parked on the condition variable for the life of the process
+    }
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    std::deque<Job> q_;
+    size_t pending_ = 0, nworkers_ = 0;
+    bool started_ = false;
+};
+CopyPool& copy_pool() { static CopyPool* p = new CopyPool(); return *p; }       // (leaked on purpose: its threads outlive static destruction)
+std::mutex g_pool_mu;                               // one big copy at a time uses the helpers
+
+void big_memcpy(void* d, const void* s, size_t n)
+{
+    if (n < ((size_t)4 << 20)) { std::memcpy(d, s, n); return; }
+    std::lock_guard<std::mutex> lock(g_pool_mu);
+    copy_pool().copy(static_cast<char*>(d), static_cast<const char*>(s), n);
+}
+
+bool host_is_page_locked(const void* p)
+{
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }     // unknown to the runtime: pageable
+    return at.type == hipMemoryTypeHost;
+}
+}  // namespace
+
+hipError_t kmc_host::copy_sync(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t st)
+{
+    if (bytes == 0) return hipSuccess;
+    const bool h2d = kind == hipMemcpyHostToDevice, d2h = kind == hipMemcpyDeviceToHost;
+    if ((!h2d && !d2h) || host_is_page_locked(h2d ? src : dst)) {
+        const hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, st);
+        return e != hipSuccess ? e : hipStreamSynchronize(st);
+    }
+    hipError_t e = hipSuccess;
+    Bounce* b = bounce_acquire(&e);
+    if (!b) return e;
+    const size_t nchunks = (bytes + kBounceBytes - 1) / kBounceBytes;
+    auto len = [&](size_t c) { return c + 1 < nchunks ? kBounceBytes : bytes - c * kBounceBytes; };
+    if (h2d) {
+        for (size_t c = 0; c < nchunks && e == hipSuccess; ++c) {
+            const int i = (int)(c & 1);
+            if (c >= 2) e = hipEventSynchronize(b->ev[i]);                       // the DMA that read this buffer two chunks ago
+            if (e != hipSuccess) break;
+            big_memcpy(b->buf[i], static_cast<const char*>(src) + c * kBounceBytes, len(c));
+            e = hipMemcpyAsync(static_cast<char*>(dst) + c * kBounceBytes, b->buf[i], len(c), hipMemcpyHostToDevice, st);
+            if (e == hipSuccess) e = hipEventRecord(b->ev[i], st);
+        }
+        const hipError_t es = hipStreamSynchronize(st);
+        if (e == hipSuccess) e = es;
+    } else {
+        e = hipMemcpyAsync(b->buf[0], src, len(0), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipEventRecord(b->ev[0], st);
+        for (size_t c = 0; c < nchunks && e == hipSuccess; ++c) {
+            const int i = (int)(c & 1);
+            if (c + 1 < nchunks) {                                                // the next chunk's DMA runs under this chunk's memcpy
+                e = hipMemcpyAsync(b->buf[1 - i], static_cast<const char*>(src) + (c + 1) * kBounceBytes, len(c + 1), hipMemcpyDeviceToHost, st);
+                if (e == hipSuccess) e = hipEventRecord(b->ev[1 - i], st);
+                if (e != hipSuccess) break;
+            }
+            e = hipEventSynchronize(b->ev[i]);
+            if (e == hipSuccess) big_memcpy(static_cast<char*>(dst) + c * kBounceBytes, b->buf[i], len(c));
+        }
+        const hipError_t es = hipStreamSynchronize(st);
+        if (e == hipSuccess) e = es;
+    }
+    bounce_release(b);
+    return e;
+}
 
 // ---- hiprtc with a disk cache (kmc_host.hpp) -----------------------------------------------------------------
 namespace {
@@ -1023,18 +1185,24 @@ kmc_status chain_copy_range(kmc_sampler* s, int64_t k0, int64_t k1)
     if (s->d_chain && s->dst_chain) {
         const double* src = s->d_chain + slot0 * nl * ld;
         double* dst = s->dst_chain + (size_t)k0 * nl * nd;
+        const bool locked = s->dst_chain_reg;            // else: a blocking copy through the bounce buffers (copy_sync), never an
+                                                         //   asynchronous copy into pageable memory
         if (ld == nd) {
-            HIP_TRY(hipMemcpyAsync(dst, src, n * nl * nd * sizeof(double), hipMemcpyDeviceToHost, s->copy_stream));
+            if (locked) HIP_TRY(hipMemcpyAsync(dst, src, n * nl * nd * sizeof(double), hipMemcpyDeviceToHost, s->copy_stream));
+            else HIP_TRY(copy_sync(dst, src, n * nl * nd * sizeof(double), hipMemcpyDeviceToHost, s->copy_stream));
         } else {                                         // padded rows: compacted into the scratch block, then one contiguous copy
             int64_t grid = (int64_t)((n * nl * nd + 255) / 256);
             if (grid > 8192) grid = 8192;
             hipLaunchKernelGGL(rows_compact, dim3((unsigned)grid), dim3(256), 0, s->copy_stream, src, s->bw_scratch, (int64_t)(n * nl), (int32_t)ld, (int32_t)nd);
             HIP_TRY(hipGetLastError());
-            HIP_TRY(hipMemcpyAsync(dst, s->bw_scratch, n * nl * nd * sizeof(double), hipMemcpyDeviceToHost, s->copy_stream));
+            if (locked) HIP_TRY(hipMemcpyAsync(dst, s->bw_scratch, n * nl * nd * sizeof(double), hipMemcpyDeviceToHost, s->copy_stream));
+            else HIP_TRY(copy_sync(dst, s->bw_scratch, n * nl * nd * sizeof(double), hipMemcpyDeviceToHost, s->copy_stream));
         }
     }
-    if (s->d_chain_logp && s->dst_logp)
-        HIP_TRY(hipMemcpyAsync(s->dst_logp + (size_t)k0 * nl, s->d_chain_logp + slot0 * nl, n * nl * sizeof(double), hipMemcpyDeviceToHost, s->copy_stream));
+    if (s->d_chain_logp && s->dst_logp) {
+        if (s->dst_logp_reg) HIP_TRY(hipMemcpyAsync(s->dst_logp + (size_t)k0 * nl, s->d_chain_logp + slot0 * nl, n * nl * sizeof(double), hipMemcpyDeviceToHost, s->copy_stream));
+        else HIP_TRY(copy_sync(s->dst_logp + (size_t)k0 * nl, s->d_chain_logp + slot0 * nl, n * nl * sizeof(double), hipMemcpyDeviceToHost, s->copy_stream));
+    }
     return KMC_OK;
 }
 
@@ -1150,6 +1318,9 @@ KMC_EXPORT const char* kmc_last_error(void) { return g_err.c_str(); }
 
 // Diagnostics (KMC_ABORT_BACKTRACE=1 in the environment when the library is loaded): the native call stack of an abort()
 // raised anywhere in the process (the HIP runtime aborts on internal errors without a message), on stderr.
+#ifndef KMC_DIAG_ALWAYS
+#define KMC_DIAG_ALWAYS 0          // -DKMC_DIAG_ALWAYS=1: a diagnostics build that always installs the handler (file /tmp/kmc_abort_bt.txt)
+#endif
 namespace {
 void abort_backtrace(int sig)
 {
@@ -1158,14 +1329,25 @@ void abort_backtrace(int sig)
     const char msg[] = "\n[kissmcmc_hip] SIGABRT, native stack:\n";
     int fd = 2;                                          // KMC_ABORT_BACKTRACE=/path/to/file: there (a test runner may have captured fd 2)
     const char* where = std::getenv("KMC_ABORT_BACKTRACE");
+    if (!where && KMC_DIAG_ALWAYS) where = "/tmp/kmc_abort_bt.txt";
     if (where && where[0] == '/') { const int f = open(where, O_WRONLY | O_CREAT | O_APPEND, 0644); if (f >= 0) fd = f; }
     (void)!write(fd, msg, sizeof(msg) - 1);
     backtrace_symbols_fd(frames, n, fd);
+    // what the runtime printed before it aborted: a test runner that captures fd 2 keeps it in a temporary file
+    struct stat st;
+    if (fd != 2 && fstat(2, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+        static char buf[8192];
+        const off_t from = st.st_size > (off_t)sizeof(buf) ? st.st_size - (off_t)sizeof(buf) : 0;
+        const ssize_t got = pread(2, buf, sizeof(buf), from);
+        const char hdr[] = "[kissmcmc_hip] tail of the captured stderr:\n";
+        (void)!write(fd, hdr, sizeof(hdr) - 1);
+        if (got > 0) (void)!write(fd, buf, (size_t)got);
+    }
     signal(sig, SIG_DFL);
     raise(sig);
 }
 struct AbortBacktraceInstaller {
-    AbortBacktraceInstaller() { if (std::getenv("KMC_ABORT_BACKTRACE")) signal(SIGABRT, abort_backtrace); }
+    AbortBacktraceInstaller() { if (std::getenv("KMC_ABORT_BACKTRACE") || KMC_DIAG_ALWAYS) signal(SIGABRT, abort_backtrace); }
 } g_abort_backtrace_installer;
 }  // namespace
 
@@ -1776,7 +1958,7 @@ kmc_status reset_run_state(kmc_sampler* s, bool eval_logp, int64_t generation, u
     const size_t nw = (size_t)s->nrows;
     if (eval_logp) KMC_TRY(eval_initial_logp(s));
     std::vector<double> lp(nw);
-    HIP_TRY(hipMemcpyAsync(lp.data(), s->d_logp, nw * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(copy_sync(lp.data(), s->d_logp, nw * sizeof(double), hipMemcpyDeviceToHost, s->stream));
     if (s->d_msum) {
         HIP_TRY(hipMemsetAsync(s->d_msum, 0, (size_t)s->macc_elems * sizeof(double), s->stream));
         HIP_TRY(hipMemsetAsync(s->d_msumsq, 0, (size_t)s->macc_elems * sizeof(double), s->stream));
@@ -1910,7 +2092,7 @@ KMC_EXPORT kmc_status kmc_sampler_set_state(kmc_sampler* s, const double* pos_ho
 KMC_EXPORT kmc_status kmc_sampler_set_positions(kmc_sampler* s, const double* theta_host)
 {
     if (!s || !theta_host) return fail(KMC_ERR_BAD_ARG, "null argument");
-    if (std::getenv("KMC_ABORT_BACKTRACE")) signal(SIGABRT, abort_backtrace);      // (diagnostics: somebody may have replaced it)
+    if (std::getenv("KMC_ABORT_BACKTRACE") || KMC_DIAG_ALWAYS) signal(SIGABRT, abort_backtrace);      // (diagnostics: somebody may have replaced it)
     HIP_TRY(hipSetDevice(s->cfg.device));
     const size_t nw = (size_t)s->nrows, nd = (size_t)s->cfg.ndim;
     HIP_TRY(hipStreamSynchronize(s->stream));
@@ -1950,7 +2132,7 @@ KMC_EXPORT kmc_status kmc_sampler_set_positions(kmc_sampler* s, const double* th
         KMC_TRY(eval_initial_logp(s));                           // :209-210
     }
     std::vector<double> lp(nw);
-    HIP_TRY(hipMemcpyAsync(lp.data(), s->d_logp, nw * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(copy_sync(lp.data(), s->d_logp, nw * sizeof(double), hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipMemsetAsync(s->d_naccept, 0, nw * sizeof(uint32_t), s->stream));
     HIP_TRY(hipMemsetAsync(s->d_gen, 0, 64, s->stream));
     if (s->d_msum) {
@@ -2508,8 +2690,7 @@ kmc_status kmc_host::download_by_walker(const void* src, bool is_float, int64_t 
         else
             hipLaunchKernelGGL(chain_by_walker<double>, dim3((unsigned)n, (unsigned)gy), dim3(256), 0, st, static_cast<const double*>(src), tmp, nl, (int32_t)ld, (int32_t)width, K, w0, n, K * width);
         e = hipGetLastError();
-        if (e == hipSuccess) e = hipMemcpyAsync(dst_host + (size_t)w0 * (size_t)K * (size_t)width, tmp, (size_t)n * per_walker, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);     // one scratch buffer: the next piece overwrites it
+        if (e == hipSuccess) e = copy_sync(dst_host + (size_t)w0 * (size_t)K * (size_t)width, tmp, (size_t)n * per_walker, hipMemcpyDeviceToHost, st);   // (waits: one scratch buffer)
     }
     (void)hipFree(tmp);
     HIP_TRY(e);

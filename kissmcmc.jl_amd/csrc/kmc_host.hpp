@@ -50,13 +50,15 @@ kmc_status digest_params(const kmc_config& c, kmc::DensityParams* dp);
 // Blocking copies / fills WITHOUT the legacy (null) stream: hipMemcpy, hipMemset and hipDeviceSynchronize go through it, and
 // a legacy-stream operation issued while ANOTHER host thread captures a hipGraph fails ("would make the legacy stream depend
 // on a capturing stream") and invalidates that capture.  Everything here runs on a stream the caller names and waits for it.
-inline hipError_t copy_sync(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t st)
-{
-    const hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, st);
-    return e != hipSuccess ? e : hipStreamSynchronize(st);
-}
-// (no 2-D variant on purpose: hipMemcpy2DAsync between pageable host memory and the device aborted inside the runtime,
-//  intermittently -- padded rows are repacked on the host or compacted on the device and then copied contiguously)
+//
+// And WITHOUT handing pageable host memory to an asynchronous copy: for those the runtime page-locks the caller's pages itself
+// and keeps the mapping in a cache -- read-only when the memory was a copy's source.  A later device-to-host copy into a
+// heap block that malloc placed on the same pages then died with "Memory access fault by GPU ... Write access to a read-only
+// page" (intermittent, layout-dependent; found by running the tests in another order).  copy_sync stages pageable memory
+// through page-locked bounce buffers of its own (two, so that the host memcpy of one chunk overlaps the DMA of the next); host
+// memory that IS page-locked (hipHostMalloc, hipHostRegister) goes straight through.
+hipError_t copy_sync(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t st);
+// (no 2-D variant on purpose: padded rows are repacked on the host or compacted on the device, then copied contiguously)
 inline hipError_t fill_sync(void* dst, int value, size_t bytes, hipStream_t st)
 {
     const hipError_t e = hipMemsetAsync(dst, value, bytes, st);
