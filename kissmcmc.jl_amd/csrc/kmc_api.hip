@@ -5,6 +5,7 @@
 // two dependent launches per generation, replayed from a hipGraph in chunks of
 // kGraphChunk generations (the kernel boundary is the join of src/samplers.jl:273).
 #include <dlfcn.h>
+#include <pthread.h>
 #include <execinfo.h>
 #include <fcntl.h>
 #include <signal.h>
@@ -329,7 +330,7 @@ public:
     void copy(char* d, const char* s, size_t n)
     {
         constexpr size_t kMin = (size_t)2 << 20;
-        if (n < 2 * kMin) { std::memcpy(d, s, n); return; }
+        if (n < 2 * kMin || forked_child()) { std::memcpy(d, s, n); return; }      // (a forked child has no helper threads)
         start();
         const size_t parts = std::min<size_t>(nworkers_ + 1, n / kMin);
         const size_t each = (n / parts + 4095) & ~(size_t)4095;
@@ -349,11 +350,13 @@ public:
     }
 private:
     struct Job { char* d; const char* s; size_t n; };
+    static bool& forked_child() { static bool f = false; return f; }
     void start()
     {
         std::lock_guard<std::mutex> lock(m_);
         if (started_) return;
         started_ = true;
+        pthread_atfork(nullptr, nullptr, [] { forked_child() = true; });
         unsigned hw = std::thread::hardware_concurrency();
         nworkers_ = hw >= 8 ? 3 : (hw >= 4 ? 1 : 0);
         for (size_t i = 0; i < nworkers_; ++i)
