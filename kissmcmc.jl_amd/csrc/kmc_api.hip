@@ -13,6 +13,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <thread>
 #include <deque>
 #include <condition_variable>
@@ -753,7 +754,7 @@ struct kmc_sampler {
     int64_t generation = 0;   // generations enqueued so far
     int64_t dev_gen = 0;      // value the device counter will hold once the stream drains
     int64_t launches = 0;
-    int launch_mode = 0;      // 0: not decided, 1: table graph, 2: eager launches, 3: updated graph (kmc_sampler_run)
+    int launch_mode = 0;      // 0: not decided, 1: table graph, 2: eager launches, 3: updated graph, KMC_LAUNCH=updated only (kmc_sampler_run)
     float calib_graph_ms = 0.f, calib_eager_ms = 0.f;   // one chunk each, when measured
     hipGraphExec_t graph_exec = nullptr;
     hipGraph_t graph = nullptr;
@@ -769,6 +770,7 @@ struct kmc_sampler {
     int unext = 0;
     std::vector<hipGraphNode_t> unodes;
     int64_t uchunk = 64;      // generations per replay of the updated graph
+    bool updated_forced = false;   // KMC_LAUNCH=updated: no budget
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool have_run_events = false;
     bool positions_set = false;
@@ -1058,10 +1060,24 @@ kmc_status ensure_updated_graph(kmc_sampler* s)
     return KMC_OK;
 }
 
+// hipGraphExecKernelNodeSetParams leaks ~80 bytes per call inside the runtime (kmc_sampler_run: launch modes): a process-wide
+// budget of such calls -- 64 MiB worth by default
+std::atomic<int64_t> g_update_calls{0};
+bool update_budget_left()
+{
+    static const int64_t budget = [] {
+        double mb = 64.0;
+        if (const char* e = std::getenv("KMC_UPDATED_BUDGET_MB")) mb = std::atof(e);
+        return (int64_t)(mb * 1048576.0 / 80.0);
+    }();
+    return g_update_calls.load(std::memory_order_relaxed) < budget;
+}
+
 // one replay of kGraphChunk generations starting at s->generation
 kmc_status launch_updated_graph(kmc_sampler* s)
 {
     KMC_TRY(ensure_updated_graph(s));
+    g_update_calls.fetch_add(2 * s->uchunk, std::memory_order_relaxed);
     const int i = s->unext;
     if (s->uinflight[i]) { HIP_TRY(hipEventSynchronize(s->udone[i])); s->uinflight[i] = false; }
     KernelParamPack pk;
@@ -2375,50 +2391,66 @@ KMC_EXPORT kmc_status kmc_sampler_run(kmc_sampler* s, int64_t ngen)
     };
     // How to issue the launches?  Same kernels, same results, three ways:
     //   1 table graph   -- hipGraph replay; the kernels read their generation from a device table (one scalar round
-    //                      trip in front of Philox);
-    //   2 eager         -- the step travels among the preloaded kernel parameters, Philox starts at wave entry (C2:
-    //                      4.15 against 4.35 us per half-step) -- while the host launches faster than the GPU drains;
-    //                      measured: it does for ~2000 launches, then settles at ~4.8 us per launch;
+    //                      trip in front of Philox: C2 4.32 us per half-step); the host is free after ~16 ms per 10^4
+    //                      generations;
+    //   2 eager         -- the step travels among the preloaded kernel parameters, Philox starts at wave entry (C2 4.03 us)
+    //                      -- as long as the host launches as fast as the GPU drains, which it does not reliably (three
+    //                      bench runs: 8.7, 6.5, 8.6 x 10^9 walker-steps/s; C3 3.7-4.8 us against 3.25);
     //   3 updated graph -- the eager form of the kernels inside a graph whose node parameters are rewritten before
-    //                      every replay (two executables alternate).
-    // A long run measures 1 against 3 once (four chunks each, HIP events: a starved GPU shows as idle time between
-    // the events) and keeps the faster; KMC_LAUNCH=graph|eager|updated decides without measuring.
+    //                      every replay (C2 4.00 us, C3 3.25 us; steady).  But hipGraphExecKernelNodeSetParams leaks ~80
+    //                      bytes of host memory per call inside the runtime (1.6 MB per 10^4 generations, not returned
+    //                      when the executables are destroyed; scripts/exp/leak_check.py), so the process has a BUDGET
+    //                      of such calls (kUpdateBudgetCalls, KMC_UPDATED_BUDGET_MB): beyond it samplers choose
+    //                      between 1 and 2.
+    // A long run measures 1 against 3 (or 2) once -- four chunks each, HIP events: a starved GPU shows as idle time
+    // between the events -- and keeps the faster; KMC_LAUNCH=graph|eager|updated decides without measuring.
     bool use_graph = !(s->cfg.flags & KMC_NO_GRAPH);
+    const int64_t calib_min = 11 * std::max<int64_t>(kGraphChunk, s->uchunk) + kGraphChunk;
+    auto calibrate = [&](bool with_updated) -> kmc_status {
+        hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        HIP_TRY(hipEventCreate(&e2));
+        const int64_t gens = 4 * std::max<int64_t>(kGraphChunk, s->uchunk);
+        kmc_status st = graph_chunk();                                    // warm: instantiation, code objects
+        if (st == KMC_OK) st = with_updated ? updated_chunk() : eager_generations(kGraphChunk);
+        if (st == KMC_OK) st = with_updated ? updated_chunk() : eager_generations(kGraphChunk);
+        if (st == KMC_OK && hipEventRecord(e0, s->stream) != hipSuccess) st = KMC_ERR_HIP;
+        for (int64_t r = 0; r < gens / kGraphChunk && st == KMC_OK; ++r) st = graph_chunk();
+        if (st == KMC_OK && hipEventRecord(e1, s->stream) != hipSuccess) st = KMC_ERR_HIP;
+        if (with_updated) { for (int64_t r = 0; r < gens / s->uchunk && st == KMC_OK && s->launch_mode == 0; ++r) st = updated_chunk(); }
+        else if (st == KMC_OK) st = eager_generations(gens);
+        if (st == KMC_OK && hipEventRecord(e2, s->stream) != hipSuccess) st = KMC_ERR_HIP;
+        float tg = 0.f, tu = 0.f;
+        if (st == KMC_OK && (hipEventSynchronize(e2) != hipSuccess || hipEventElapsedTime(&tg, e0, e1) != hipSuccess ||
+                             hipEventElapsedTime(&tu, e1, e2) != hipSuccess)) st = KMC_ERR_HIP;
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
+        if (st != KMC_OK) return st == KMC_ERR_HIP ? fail(st, "launch-mode calibration failed") : st;
+        if (s->launch_mode == 0) {
+            s->launch_mode = tu < 0.98f * tg ? (with_updated ? 3 : 2) : 1;        // the alternative must win clearly
+            s->calib_graph_ms = tg * (float)kGraphChunk / (float)gens; s->calib_eager_ms = tu * (float)kGraphChunk / (float)gens;
+        }
+        return KMC_OK;
+    };
     if (use_graph && s->launch_mode == 0) {
         if (!s->uexec[0])
             if (const char* e = std::getenv("KMC_UPD_CHUNK")) { const long v = std::atol(e); if (v >= 16 && v <= 1024) s->uchunk = v; }
         const char* env = std::getenv("KMC_LAUNCH");
         if (env && std::strcmp(env, "graph") == 0) s->launch_mode = 1;
         else if (env && std::strcmp(env, "eager") == 0) s->launch_mode = 2;
-        else if (env && std::strcmp(env, "updated") == 0 && updated_graph_possible(s)) s->launch_mode = 3;
+        else if (env && std::strcmp(env, "updated") == 0 && updated_graph_possible(s)) { s->launch_mode = 3; s->updated_forced = true; }
         else if (!updated_graph_possible(s)) s->launch_mode = 1;
-        else if (ngen >= 11 * std::max<int64_t>(kGraphChunk, s->uchunk) + kGraphChunk) {
-            hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
-            HIP_TRY(hipEventCreate(&e0));
-            HIP_TRY(hipEventCreate(&e1));
-            HIP_TRY(hipEventCreate(&e2));
-            kmc_status st = graph_chunk();                                    // warm: instantiation, code objects
-            if (st == KMC_OK) st = updated_chunk();
-            if (st == KMC_OK) st = updated_chunk();
-            if (st == KMC_OK && hipEventRecord(e0, s->stream) != hipSuccess) st = KMC_ERR_HIP;
-            const int64_t gens = 4 * std::max<int64_t>(kGraphChunk, s->uchunk);
-            for (int64_t r = 0; r < gens / kGraphChunk && st == KMC_OK; ++r) st = graph_chunk();
-            if (st == KMC_OK && hipEventRecord(e1, s->stream) != hipSuccess) st = KMC_ERR_HIP;
-            for (int64_t r = 0; r < gens / s->uchunk && st == KMC_OK && s->launch_mode == 0; ++r) st = updated_chunk();
-            if (st == KMC_OK && hipEventRecord(e2, s->stream) != hipSuccess) st = KMC_ERR_HIP;
-            float tg = 0.f, tu = 0.f;
-            if (st == KMC_OK && (hipEventSynchronize(e2) != hipSuccess || hipEventElapsedTime(&tg, e0, e1) != hipSuccess ||
-                                 hipEventElapsedTime(&tu, e1, e2) != hipSuccess)) st = KMC_ERR_HIP;
-            (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
-            if (st != KMC_OK) return st == KMC_ERR_HIP ? fail(st, "launch-mode calibration failed") : st;
-            if (s->launch_mode == 0) {
-                s->launch_mode = tu < 0.98f * tg ? 3 : 1;                     // the updated graph must win clearly
-                s->calib_graph_ms = tg * (float)kGraphChunk / (float)gens; s->calib_eager_ms = tu * (float)kGraphChunk / (float)gens;
-            }
+        else if (ngen >= calib_min) KMC_TRY(calibrate(update_budget_left()));
+    }
+    while (use_graph && s->launch_mode == 3 && ngen >= s->uchunk) {
+        if (!s->updated_forced && !update_budget_left()) {             // the process has used up its leak budget: decide again, between 1 and 2
+            s->launch_mode = 0;
+            if (ngen >= calib_min) KMC_TRY(calibrate(false));
+            break;
         }
+        KMC_TRY(updated_chunk());
     }
     if (s->launch_mode == 2) use_graph = false;
-    while (use_graph && s->launch_mode == 3 && ngen >= s->uchunk) KMC_TRY(updated_chunk());
     while (use_graph && ngen >= kGraphChunk) KMC_TRY(graph_chunk());
     KMC_TRY(eager_generations(ngen));
     HIP_TRY(hipEventRecord(s->ev1, s->stream));
@@ -2489,12 +2521,12 @@ KMC_EXPORT kmc_status kmc_sampler_describe(const kmc_sampler* s, char* buf, int6
     else if (s->plan.vec) {
         o << "multi-launch (exact): half_step_vec L=" << s->plan.L << " K=" << s->plan.K << " ITER=" << s->plan.ITER
           << (s->plan.ragged ? " ragged" : " exact-size") << ", grid " << s->grid << " x " << s->tpb
-          << (((s->cfg.flags & KMC_NO_GRAPH) || s->launch_mode == 2) ? ", eager launches"
+          << (((s->cfg.flags & KMC_NO_GRAPH) || s->launch_mode == 2) ? ", eager launches (step among the preloaded kernel parameters)"
               : s->launch_mode == 3 ? ", hipGraph replay of 64 generations with per-replay parameter updates (step preloaded)"
                                     : ", hipGraph replay of 64 generations");
         if (s->calib_graph_ms > 0.f) {
             char b[128];
-            std::snprintf(b, sizeof(b), " (measured per 64 generations: table graph %.3f ms, updated graph %.3f ms)", s->calib_graph_ms, s->calib_eager_ms);
+            std::snprintf(b, sizeof(b), " (measured per 64 generations: table graph %.3f ms, %s %.3f ms)", s->calib_graph_ms, s->launch_mode == 2 ? "eager launches" : "updated graph", s->calib_eager_ms);
             o << b;
         }
     } else
