@@ -25,6 +25,31 @@ def sampler_cycle(pdf, nw, nd, G, run=True, **kw):
                 s.run(G)
                 s.sync()
     return f
+def chain_cycle(i):
+    with kmc.Sampler(kmc.GaussianIso(), 512, 7, 40, 0, 1, 2.0, i + 1, store_chain=True, store_logp=True) as s:
+        s.set_positions(rng.standard_normal((512, 7)))
+        s.run(40); s.sync()
+        s.chain(); s.chain(by_walker=True)
+
+def dealt_cycle(i):
+    from kissmcmc_jl_amd.distributed import HipDealExecutor, LocalDealtEmcee
+    exs = [HipDealExecutor(kmc.GaussianIso(), 128, 4, 20, 5, 1, 2.0, i + 1, rank=r, world=2, device=0) for r in range(2)]
+    drv = LocalDealtEmcee(exs, 256, 4, 8)
+    try:
+        drv.set_positions(rng.standard_normal((256, 4)))
+        drv.run(20); drv.sync(); drv.results()
+    finally:
+        drv.close()
+
+def state_cycle(i):
+    with kmc.Sampler(kmc.Exponential(), 256, 3, 30, 0, 1, 2.0, i + 1) as s:
+        s.init_ball([0.5, 0.5, 0.5], 0.1, seed=i + 1)
+        s.run(10); s.sync()
+        st = s.state()
+    with kmc.Sampler(kmc.Exponential(), 256, 3, 30, 0, 1, 2.0, i + 1) as t:
+        t.restore(st)
+        t.run(20); t.sync()
+
 kinds = [
     ("create + destroy only (multi-launch)", sampler_cycle(kmc.GaussianIso(), 2048, 8, 70, run=False)),
     ("eager run (20 generations)", sampler_cycle(kmc.GaussianIso(), 2048, 8, 20)),
@@ -35,6 +60,12 @@ kinds = [
     ("streamed chain", sampler_cycle(kmc.GaussianIso(), 512, 8, 200, store_chain=True, stream_chain=True)),
     ("metropolis", lambda i: run_chains(kmc.GaussianIso(), kmc.GaussianStep(0.5), rng.standard_normal((256, 3)), 40, 10, 1, i + 1)),
     ("torch stream create only", lambda i: torch.cuda.Stream()),
+    ("new ExprDensity each cycle", lambda i: sampler_cycle(kmc.ExprDensity("-0.5*x*x"), 512, 8, 20)(i)),
+    ("host callable density", sampler_cycle(kmc.HostLogPdf(lambda x: -0.5 * (x * x).sum(axis=1), vectorized=True), 128, 4, 10)),
+    ("chain read-out both orders", lambda i: chain_cycle(i)),
+    ("int_acorr", lambda i: kmc.int_acorr(rng.standard_normal((64, 128, 3)))),
+    ("dealt sub-ensembles (local driver)", lambda i: dealt_cycle(i)),
+    ("init_ball + state round trip", lambda i: state_cycle(i)),
 ]
 for name, f in kinds:
     for i in range(200):
