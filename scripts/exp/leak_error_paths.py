@@ -1,4 +1,5 @@
-"""Failing calls (validation errors, a chain beyond HBM, a density that does not compile, a non-finite start) by the thousand:\nhost RSS and free device memory before and after."""
+"""Failing calls (validation errors, a chain beyond HBM, a density that does not compile, a non-finite start) by the thousand:
+host RSS and free device memory before and after."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
