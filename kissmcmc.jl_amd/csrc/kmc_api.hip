@@ -1460,6 +1460,18 @@ KMC_EXPORT double kmc_cdf_g_inv(double u, double a)   // src/samplers.jl:227
 // ------------------------------------------------------------------------------------------
 // sampler
 // ------------------------------------------------------------------------------------------
+// hipMalloc does not clear memory.  KMC_POISON=1 (diagnostics): every allocation of a sampler starts as 0xFF bytes (NaN doubles,
+// 4 294 967 295 counters), so that anything the code forgot to initialise shows up in the tests instead of depending on what the
+// allocator happened to return.
+template <class T>
+hipError_t dev_alloc(kmc_sampler* s, T** p, size_t bytes)
+{
+    static const bool poison = std::getenv("KMC_POISON") != nullptr;
+    const hipError_t e = hipMalloc(reinterpret_cast<void**>(p), bytes);
+    if (e != hipSuccess || !poison || bytes == 0) return e;
+    return hipMemsetAsync(*p, 0xFF, bytes, s->stream);
+}
+
 KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** out)
 {
     if (!out) return fail(KMC_ERR_BAD_ARG, "null out");
@@ -1597,9 +1609,9 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
     if (s->p2p) {
         CREATE_TRY(hipExtMallocWithFlags((void**)&s->d_flags, 4096, hipDeviceMallocFinegrained));
         CREATE_TRY(hipMemsetAsync(s->d_flags, 0, 4096, s->stream));
-        CREATE_TRY(hipMalloc((void**)&s->d_err, 64));
+        CREATE_TRY(dev_alloc(s, (void**)&s->d_err, 64));
         CREATE_TRY(hipMemsetAsync(s->d_err, 0, 64, s->stream));
-        CREATE_TRY(hipMalloc((void**)&s->d_done, 33 * 64));
+        CREATE_TRY(dev_alloc(s, (void**)&s->d_done, 33 * 64));
         CREATE_TRY(hipMemsetAsync(s->d_done, 0, 33 * 64, s->stream));
         // the kernel can publish its own completion only where all its stores are write-through: the vector kernels
         s->fold_signal = (cfg->flags & KMC_P2P_FOLD_SIGNAL) != 0 && s->plan.vec && s->user == nullptr;
@@ -1615,37 +1627,37 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
     if (s->p2p && (cfg->flags & KMC_P2P_FINEGRAINED))   // peers map the rows uncached: nothing of them can go stale in a reader's L2
         CREATE_TRY(hipExtMallocWithFlags((void**)&s->d_pos, nw * ldz * sizeof(double), hipDeviceMallocFinegrained));
     else
-        CREATE_TRY(hipMalloc(&s->d_pos, (s->push ? 1 + (size_t)s->cfg.shard_count : 1) * nw * ldz * esz + amap_bytes));
+        CREATE_TRY(dev_alloc(s, &s->d_pos, (s->push ? 1 + (size_t)s->cfg.shard_count : 1) * nw * ldz * esz + amap_bytes));
     CREATE_TRY(hipMemsetAsync(s->d_pos, 0, (s->push ? 1 + (size_t)s->cfg.shard_count : 1) * nw * ldz * esz + amap_bytes, s->stream));   // the pad column of odd ndim stays 0
     if (s->lazy) {
         const size_t P = (size_t)s->cfg.shard_count, hl = (size_t)s->h_loc;
         const size_t nb = 2 * P * 2 * hl * sizeof(uint32_t) + 16;
-        CREATE_TRY(hipMalloc((void**)&s->d_lazy, nb));
+        CREATE_TRY(dev_alloc(s, (void**)&s->d_lazy, nb));
         CREATE_TRY(hipMemsetAsync(s->d_lazy, 0, nb, s->stream));
         s->peer_amap_in[s->cfg.shard_rank] = reinterpret_cast<unsigned char*>(s->d_pos) + (1 + P) * nw * ldz * esz;
     }
     // per-walker block {logp[nrows], naccept[nrows], klast[nrows]}: one allocation, so the half-step kernels reach all
     // three from one preloaded pointer (HalfStepFront::logp)
-    CREATE_TRY(hipMalloc(&s->d_logp, nw * (sizeof(double) + 2 * sizeof(uint32_t))));
+    CREATE_TRY(dev_alloc(s, &s->d_logp, nw * (sizeof(double) + 2 * sizeof(uint32_t))));
     s->d_naccept = reinterpret_cast<uint32_t*>(s->d_logp + nw);
     s->d_klast = s->d_naccept + nw;
     CREATE_TRY(hipMemsetAsync(s->d_klast, 0, nw * sizeof(uint32_t), s->stream));
     static_assert(kGraphChunk <= 64, "advance_schedule runs one 64-thread block");
-    CREATE_TRY(hipMalloc(&s->d_gen, 64));
+    CREATE_TRY(dev_alloc(s, &s->d_gen, 64));
     CREATE_TRY(hipMemsetAsync(s->d_gen, 0, 64, s->stream));
-    CREATE_TRY(hipMalloc(&s->d_sched, (size_t)kGraphChunk * sizeof(SchedEntry)));
+    CREATE_TRY(dev_alloc(s, &s->d_sched, (size_t)kGraphChunk * sizeof(SchedEntry)));
     CREATE_TRY(hipMemsetAsync(s->d_naccept, 0, nw * sizeof(uint32_t), s->stream));
-    if (cfg->deal_count > 0) CREATE_TRY(hipMalloc((void**)&s->d_ids, nw * sizeof(uint32_t)));
+    if (cfg->deal_count > 0) CREATE_TRY(dev_alloc(s, (void**)&s->d_ids, nw * sizeof(uint32_t)));
     if (s->plan.vec && !s->islands && !s->resident && s->plan.L >= 16 && s->plan.L <= 32 && s->plan.L / s->plan.ITER >= 2 &&
         std::getenv("KMC_NO_DRAW_RING") == nullptr) {
         // draw ring: 4 slots x rows x 32 B; tags start at 0xffffffff (no step carries it), so nothing is "parked" yet
         const size_t nb = 4 * (size_t)s->nrows * 2 * sizeof(double2);
-        CREATE_TRY(hipMalloc((void**)&s->d_ring, nb));
+        CREATE_TRY(dev_alloc(s, (void**)&s->d_ring, nb));
         CREATE_TRY(hipMemsetAsync(s->d_ring, 0xff, nb, s->stream));
     }
     if (cfg->flags & KMC_MOMENTS) {
-        CREATE_TRY(hipMalloc(&s->d_msum, (size_t)s->macc_elems * sizeof(double)));
-        CREATE_TRY(hipMalloc(&s->d_msumsq, (size_t)s->macc_elems * sizeof(double)));
+        CREATE_TRY(dev_alloc(s, &s->d_msum, (size_t)s->macc_elems * sizeof(double)));
+        CREATE_TRY(dev_alloc(s, &s->d_msumsq, (size_t)s->macc_elems * sizeof(double)));
         CREATE_TRY(hipMemsetAsync(s->d_msum, 0, (size_t)s->macc_elems * sizeof(double), s->stream));
         CREATE_TRY(hipMemsetAsync(s->d_msumsq, 0, (size_t)s->macc_elems * sizeof(double), s->stream));
         if (s->plan.vec && s->plan.L == 64 && !s->islands && !s->resident && std::getenv("KMC_NO_MOMENT_RING") == nullptr) {
@@ -1657,9 +1669,9 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
             if (depth > 128) depth = 128;
             if (const char* e = std::getenv("KMC_MOMENT_RING_DEPTH")) { const long v = std::atol(e); if (v >= 1 && v < depth) depth = v; }   // tests: force overflows
             if (depth >= 4 || (depth >= 2 && std::getenv("KMC_MOMENT_RING_DEPTH") != nullptr)) {
-                CREATE_TRY(hipMalloc((void**)&s->d_mring, (size_t)nwaves * (size_t)depth * slot));
-                CREATE_TRY(hipMalloc((void**)&s->d_mring_w, (size_t)nwaves * (size_t)depth * sizeof(double)));
-                CREATE_TRY(hipMalloc((void**)&s->d_mcnt, 2 * (size_t)nwaves * sizeof(uint32_t)));
+                CREATE_TRY(dev_alloc(s, (void**)&s->d_mring, (size_t)nwaves * (size_t)depth * slot));
+                CREATE_TRY(dev_alloc(s, (void**)&s->d_mring_w, (size_t)nwaves * (size_t)depth * sizeof(double)));
+                CREATE_TRY(dev_alloc(s, (void**)&s->d_mcnt, 2 * (size_t)nwaves * sizeof(uint32_t)));
                 CREATE_TRY(hipMemsetAsync(s->d_mcnt, 0, 2 * (size_t)nwaves * sizeof(uint32_t), s->stream));
                 s->mring_depth = (int)depth;
                 s->mring_waves = nwaves;
@@ -1667,19 +1679,19 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         }
         if (s->islands || s->resident) {
             const size_t ne = (size_t)s->nislands * 4 * (size_t)s->island_K;
-            CREATE_TRY(hipMalloc(&s->d_isum, ne * sizeof(double)));
-            CREATE_TRY(hipMalloc(&s->d_isumsq, ne * sizeof(double)));
+            CREATE_TRY(dev_alloc(s, &s->d_isum, ne * sizeof(double)));
+            CREATE_TRY(dev_alloc(s, &s->d_isumsq, ne * sizeof(double)));
             CREATE_TRY(hipMemsetAsync(s->d_isum, 0, ne * sizeof(double), s->stream));
             CREATE_TRY(hipMemsetAsync(s->d_isumsq, 0, ne * sizeof(double), s->stream));
         }
     }
     if (s->host_eval) {
-        CREATE_TRY(hipMalloc(&s->d_prop, (size_t)s->h * ldz * sizeof(double)));
-        CREATE_TRY(hipMalloc(&s->d_p1, (size_t)s->h * sizeof(double)));
+        CREATE_TRY(dev_alloc(s, &s->d_prop, (size_t)s->h * ldz * sizeof(double)));
+        CREATE_TRY(dev_alloc(s, &s->d_p1, (size_t)s->h * sizeof(double)));
         CREATE_TRY(hipHostMalloc((void**)&s->h_prop, (size_t)s->h * (size_t)cfg->ndim * sizeof(double), hipHostMallocDefault));
         CREATE_TRY(hipHostMalloc((void**)&s->h_p1, (size_t)s->h * sizeof(double), hipHostMallocDefault));
         if (cfg->host_accepted) {
-            CREATE_TRY(hipMalloc(&s->d_acc, (size_t)s->h));
+            CREATE_TRY(dev_alloc(s, &s->d_acc, (size_t)s->h));
             CREATE_TRY(hipHostMalloc((void**)&s->h_acc, (size_t)s->h, hipHostMallocDefault));
         }
     }
@@ -1702,10 +1714,10 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         s->stream_by_walker = (cfg->flags & KMC_CHAIN_BY_WALKER) != 0;
         const char* bwc = std::getenv("KMC_BYWALKER_COPY");
         if (s->stream_by_walker && !(bwc && std::strcmp(bwc, "kernel") == 0)) {
-            if (cfg->flags & KMC_STORE_CHAIN) CREATE_TRY(hipMalloc(&s->bw_scratch, (size_t)blk * (size_t)s->nlocal * (size_t)cfg->ndim * sizeof(double)));
-            if (cfg->flags & KMC_STORE_LOGP) CREATE_TRY(hipMalloc(&s->bw_scratch_logp, (size_t)blk * (size_t)s->nlocal * sizeof(double)));
+            if (cfg->flags & KMC_STORE_CHAIN) CREATE_TRY(dev_alloc(s, &s->bw_scratch, (size_t)blk * (size_t)s->nlocal * (size_t)cfg->ndim * sizeof(double)));
+            if (cfg->flags & KMC_STORE_LOGP) CREATE_TRY(dev_alloc(s, &s->bw_scratch_logp, (size_t)blk * (size_t)s->nlocal * sizeof(double)));
         } else if (!s->stream_by_walker && (cfg->flags & KMC_STORE_CHAIN) && s->ld != cfg->ndim) {
-            CREATE_TRY(hipMalloc(&s->bw_scratch, (size_t)blk * (size_t)s->nlocal * (size_t)cfg->ndim * sizeof(double)));   // (rows_compact)
+            CREATE_TRY(dev_alloc(s, &s->bw_scratch, (size_t)blk * (size_t)s->nlocal * (size_t)cfg->ndim * sizeof(double)));   // (rows_compact)
         }
         s->ring_blk = blk;
         s->ring_slots = 3 * blk;
@@ -1731,9 +1743,9 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         }
     }
     if ((cfg->flags & KMC_STORE_CHAIN) && s->nsamples > 0)
-        CREATE_TRY(hipMalloc(&s->d_chain, (size_t)chain_slots * (size_t)s->nlocal * ldz * esz));
+        CREATE_TRY(dev_alloc(s, &s->d_chain, (size_t)chain_slots * (size_t)s->nlocal * ldz * esz));
     if ((cfg->flags & KMC_STORE_LOGP) && s->nsamples > 0)
-        CREATE_TRY(hipMalloc(&s->d_chain_logp, (size_t)chain_slots * (size_t)s->nlocal * sizeof(double)));
+        CREATE_TRY(dev_alloc(s, &s->d_chain_logp, (size_t)chain_slots * (size_t)s->nlocal * sizeof(double)));
     CREATE_TRY(hipStreamSynchronize(s->stream));         // the fills above (asynchronous, one wait for all of them)
 #undef CREATE_TRY
     if (s->p2p) {
