@@ -771,6 +771,7 @@ struct kmc_sampler {
     std::vector<hipGraphNode_t> unodes;
     int64_t uchunk = 64;      // generations per replay of the updated graph
     bool updated_forced = false;   // KMC_LAUNCH=updated: no budget
+    std::vector<std::pair<char*, size_t>> guards;      // KMC_POISON: (guard address, size of the allocation in front of it)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool have_run_events = false;
     bool positions_set = false;
@@ -1463,13 +1464,34 @@ KMC_EXPORT double kmc_cdf_g_inv(double u, double a)   // src/samplers.jl:227
 // hipMalloc does not clear memory.  KMC_POISON=1 (diagnostics): every allocation of a sampler starts as 0xFF bytes (NaN doubles,
 // 4 294 967 295 counters), so that anything the code forgot to initialise shows up in the tests instead of depending on what the
 // allocator happened to return.
+// ... and is followed by a 4 KiB guard of 0xA5 that kmc_sampler_destroy checks: a kernel that writes past the end of one of
+// its buffers aborts the process there, with the size of the allocation (the tests then fail loudly).
+constexpr size_t kGuardBytes = 4096;
 template <class T>
 hipError_t dev_alloc(kmc_sampler* s, T** p, size_t bytes)
 {
     static const bool poison = std::getenv("KMC_POISON") != nullptr;
-    const hipError_t e = hipMalloc(reinterpret_cast<void**>(p), bytes);
-    if (e != hipSuccess || !poison || bytes == 0) return e;
-    return hipMemsetAsync(*p, 0xFF, bytes, s->stream);
+    if (!poison || bytes == 0) return hipMalloc(reinterpret_cast<void**>(p), bytes);
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(p), bytes + kGuardBytes);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(*p, 0xFF, bytes, s->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(reinterpret_cast<char*>(*p) + bytes, 0xA5, kGuardBytes, s->stream);
+    s->guards.emplace_back(reinterpret_cast<char*>(*p) + bytes, bytes);
+    return e;
+}
+void check_guards(kmc_sampler* s)
+{
+    std::vector<unsigned char> h(kGuardBytes);
+    for (const auto& g : s->guards) {
+        if (copy_sync(h.data(), g.first, kGuardBytes, hipMemcpyDeviceToHost, s->stream) != hipSuccess) { (void)hipGetLastError(); continue; }
+        for (size_t i = 0; i < kGuardBytes; ++i)
+            if (h[i] != 0xA5) {
+                std::fprintf(stderr, "[kissmcmc_hip] KMC_POISON: byte %zu behind a device allocation of %zu bytes was overwritten (%s)\n", i, g.second,
+                             s->plan.vec ? "vec kernels" : "generic / staged kernels");
+                std::abort();
+            }
+    }
+    s->guards.clear();
 }
 
 KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** out)
@@ -1762,6 +1784,8 @@ KMC_EXPORT void kmc_sampler_destroy(kmc_sampler* s)
     if (!s) return;
     (void)hipSetDevice(s->cfg.device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
+    if (s->copy_stream) (void)hipStreamSynchronize(s->copy_stream);
+    if (!s->guards.empty() && s->stream) check_guards(s);
     for (int i = 0; i < kUExec; ++i) {
         if (s->uexec[i]) (void)hipGraphExecDestroy(s->uexec[i]);
         if (s->udone[i]) (void)hipEventDestroy(s->udone[i]);
@@ -1844,7 +1868,11 @@ KMC_EXPORT kmc_status kmc_sampler_bind_positions(kmc_sampler* s, void* pos_dev)
         s->uinflight[i] = false;
     }
     if (s->ugraph) { (void)hipGraphDestroy(s->ugraph); s->ugraph = nullptr; }
-    if (s->own_pos) (void)hipFree(s->d_pos);
+    if (s->own_pos) {
+        for (size_t i = 0; i < s->guards.size(); ++i)                   // (KMC_POISON: this allocation's guard goes with it)
+            if (s->guards[i].first - s->guards[i].second == reinterpret_cast<char*>(s->d_pos)) { s->guards.erase(s->guards.begin() + (long)i); break; }
+        (void)hipFree(s->d_pos);
+    }
     s->d_pos = static_cast<double*>(pos_dev);
     s->own_pos = false;
     s->positions_set = false;
