@@ -113,7 +113,8 @@ enum {
                                     samples is bounded by host memory, not by the 288 GB of HBM (the reference grows per-walker
                                     vectors without bound, src/samplers.jl:268-272; C2 with nthin = 1 is 84 GB, C5 336 GB).  The
                                     host buffers are page-locked in place (hipHostRegister), so the copies are direct DMA into
-                                    their final position; if that fails they are ordinary (staged) copies.  KMC_F64, one GPU
+                                    their final position; if that fails the copies are blocking and staged through the library's own page-locked
+                                    buffers (the sampling then waits for them).  KMC_F64, one GPU
                                     (no KMC_P2P / sharding / KMC_ISLANDS); small ensembles then run the multi-launch kernels.
                                     kmc_emcee_run switches it on by itself when the chain would not fit the device. */
     KMC_CHAIN_BY_WALKER = 1u << 12, /* kmc_emcee_run and kmc_metropolis_run: kmc_outputs.chain is [nwalkers][nsamples][ndim] and chain_logp
