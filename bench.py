@@ -12,6 +12,10 @@ KMC_BENCH_EXCHANGE=all measures the other five variants too, =allgather -- or an
 of the updated half per half-step, enqueued by the library itself) -- weak scaling, config C4 at N = 8.  Extra key `dealt_mode` (N > 1, never `value`):
 the same job as dealt sub-ensembles, one RCCL all_to_all_single per 64 generations instead of an exchange per half-step.
 
+`python3 bench.py --gpus N` from a plain shell (no WORLD_SIZE in the environment) starts its own N ranks -- child processes,
+one per GPU, created BEFORE this process touches the GPU -- relays rank 0's JSON line and exits with the job's status; under
+`python -m torch.distributed.run` (WORLD_SIZE set) it is one rank of the job, as the driver launches it.
+
 Prints ONE JSON line (rank 0).  `value` = all walker-steps of the timed region / wall time
 (max over ranks) with the ensemble resident in HBM.  `roofline` prices the half-step kernel
 against the 8 TB/s HBM spec using ALGORITHMIC read bytes ((2*ndim+1)*8 B per walker-step,
@@ -105,6 +109,107 @@ def cpu_baseline(budget_s: float = 10.0):
             "note": "CPU restatement of the reference algorithm (allocation-free C + OpenMP), not KissMCMC.jl itself (no julia in this image)"}
 
 
+def spawn_ranks(n: int, argv) -> int:
+    """`--gpus n` without a launcher: start the n ranks ourselves (one child process per rank with RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* in its environment -- what torch.distributed.run would set), BEFORE anything in this process
+    touches the GPU; never exec.  Rank 0's stdout is relayed (its JSON line last), the other ranks' goes to stderr.  The first
+    rank that fails takes the others down; the whole job is bounded by KMC_BENCH_TIMEOUT seconds (a hung collective must end
+    in a non-zero exit, not in the caller's lease).  Returns the job's exit status."""
+    import signal
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = os.environ.copy()
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "KMC_BENCH_SELF_SPAWNED": "1"})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # the host driver only supports dmabuf IPC (RCCL, shared device memory)
+        # like torch.distributed.run: bound each rank's CPU thread pools -- a GPU box's container sees every hardware thread of
+        # the host but is throttled to its share; N ranks x 256 OpenMP threads on 16 CPUs made the host-driven rungs 100x slower
+        env.setdefault("OMP_NUM_THREADS", str(max(1, host_threads() // n)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env, start_new_session=True,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr, text=r == 0))
+
+    def stop_all(sig):
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, sig)        # each rank is its own session: the exact process groups we started
+                except ProcessLookupError:
+                    pass
+
+    import threading
+    lines = []
+    reader = threading.Thread(target=lambda: lines.extend(procs[0].stdout), daemon=True)
+    reader.start()
+    deadline = time.monotonic() + float(os.environ.get("KMC_BENCH_TIMEOUT", 1500))
+    status = 0
+    while any(p.poll() is None for p in procs):
+        bad = [p.returncode for p in procs if p.poll() is not None and p.returncode != 0]
+        if bad or time.monotonic() > deadline:
+            status = bad[0] if bad else 124
+            print(f"[bench launcher] {'a rank exited with status ' + str(status) if bad else 'the job ran out of time (KMC_BENCH_TIMEOUT)'}: stopping the others", file=sys.stderr)
+            time.sleep(5.0 if bad else 0.0)      # (a failing rank's peers usually follow by themselves)
+            stop_all(signal.SIGTERM)
+            t_end = time.monotonic() + 10.0
+            while any(p.poll() is None for p in procs) and time.monotonic() < t_end:
+                time.sleep(0.1)
+            stop_all(signal.SIGKILL)
+            break
+        time.sleep(0.05)
+    for p in procs:
+        p.wait()
+    reader.join(timeout=5.0)
+    if status == 0:
+        status = next((p.returncode for p in procs if p.returncode != 0), 0)
+    js = [l for l in lines if l.lstrip().startswith('{"metric"')]
+    for l in lines:
+        if l not in js[-1:]:
+            sys.stderr.write(l)
+    if js:
+        sys.stdout.write(js[-1] if js[-1].endswith("\n") else js[-1] + "\n")
+        sys.stdout.flush()
+    elif status == 0:
+        print("[bench launcher] rank 0 printed no result line", file=sys.stderr)
+        status = 1
+    return status if status >= 0 else 128 - status
+
+
+class rung:
+    """Bound one rung of the N > 1 ladder (set-up + self-check, a timed run, an extra): when it has not finished after
+    `seconds`, this rank reports where it hung and exits non-zero -- the launcher (spawn_ranks, or torch.distributed.run) then
+    ends the job.  A collective that never returns cannot be interrupted from Python, hence a watchdog thread + os._exit."""
+
+    def __init__(self, what: str, seconds: float = None):
+        self.what = what
+        self.seconds = float(os.environ.get("KMC_BENCH_RUNG_TIMEOUT", 300)) if seconds is None else seconds
+        self.timer = None
+
+    def __enter__(self):
+        import threading
+
+        def expired():
+            print(f"[rank {os.environ.get('RANK', '0')}] bench.py: '{self.what}' did not finish within {self.seconds:.0f} s (hung collective or "
+                  f"peer wait?): giving up; Python stacks of this rank:", file=sys.stderr, flush=True)
+            try:
+                import faulthandler
+                faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+            except Exception:  # noqa: BLE001
+                pass
+            os._exit(3)
+        self.timer = threading.Timer(self.seconds, expired)
+        self.timer.daemon = True
+        self.timer.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.timer.cancel()
+        return False
+
+
 def other_configs(kmc, device: int):
     """'C3, C5: report absolute walker-steps/s and roofline fraction' (+ C1, the README call) --
     driver-timed here, NOT `value`.  Each: the whole job resident in HBM, a warm-up piece, then the timed run (HIP events
@@ -181,6 +286,10 @@ def main():
     ap.add_argument("--no-island", action="store_true", help="skip the extra island-mode run (profiling passes)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around us: be the launcher (nothing in this process has touched the GPU yet, and nothing will)
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+
     import torch
     import kissmcmc_jl_amd as kmc
 
@@ -188,9 +297,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run --nproc-per-node {args.gpus}")
-        args.gpus = world
+        args.gpus = world                        # the launcher decides (python -m torch.distributed.run --nproc-per-node N)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP emcee path has no CPU fallback")
     # one rank per GPU; (testing only: KMC_BENCH_BACKEND=gloo lets several ranks share one GPU,
@@ -201,10 +308,24 @@ def main():
     if world > 1:
         import torch.distributed as dist
         backend = os.environ.get("KMC_BENCH_BACKEND", "nccl")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
+        import datetime
+        with rung("process-group rendezvous"):
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=600))
+            else:
+                dist.init_process_group(backend, timeout=datetime.timedelta(seconds=600))
+            # did the collective backend really see every rank?  one all-reduce of ones (on the device: RCCL over xGMI for "nccl")
+            seen = torch.ones(1, device="cuda")
+            dist.all_reduce(seen)
+            torch.cuda.synchronize()
+        try:
+            rv = torch.cuda.nccl.version()
+            rccl_version = ".".join(str(v) for v in rv) if isinstance(rv, tuple) else str(rv)
+        except Exception:  # noqa: BLE001
+            rccl_version = None
+        collective = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks_seen_by_all_reduce": int(seen.item()),
+                      "rccl_version": rccl_version, "native_rccl_version": kmc.Sampler.rccl_version(),
+                      "launcher": "bench.py itself (one child process per rank)" if os.environ.get("KMC_BENCH_SELF_SPAWNED") else "external (torch.distributed.run)"}
 
     nw = NWALKERS_PER_GPU * world
     G = args.steps * GENS_PER_STEP
@@ -355,13 +476,15 @@ def main():
                           ("lazy pull into local copies, signal kernel", False, False, True),
                           ("lazy pull into local copies, signal folded into the kernel", True, False, True)]
             for label, fold, push, lazy in cands:
-                cand = try_p2p(False, fold, push, lazy)
+                with rung(f"p2p set-up + self-check ({label})"):
+                    cand = try_p2p(False, fold, push, lazy)
                 if cand is None:
                     continue
                 if len(cands) == 1:
                     drv, p2p_memory = cand, label
                     break
-                tc = time_short(cand)
+                with rung(f"p2p short timing ({label})"):
+                    tc = time_short(cand)
                 tried.append((label, tc))
                 if drv is None or tc < best_t:
                     if drv is not None:
@@ -370,7 +493,8 @@ def main():
                 else:
                     cand.close()
             if drv is None:
-                drv = try_p2p(True, False)
+                with rung("p2p set-up + self-check (fine-grained rows)"):
+                    drv = try_p2p(True, False)
                 if drv is not None:
                     p2p_memory = "pull of drawn rows, rows in fine-grained memory, signal kernel"
             if rank == 0 and tried:
@@ -385,25 +509,26 @@ def main():
         if mode == "p2p":
             ok = True
             try:
-                drv.set_positions(th)
-                drv.run(args.warmup * GENS_PER_STEP)
-                drv.sync()
-                drv.set_positions(th)                # barriers inside; restart the job
-                dist.barrier()
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                drv.run(G)
-                drv.sync()
-                torch.cuda.synchronize()
-                dist.barrier()
-                elapsed = time.perf_counter() - t0
-                event_ms = drv.sampler.last_run_ms()
-                launches = drv.sampler.launch_count
-                msum, msq, nmom = drv.moments()
-                fpos, facc = drv.positions(), drv.naccept()
-                acc = float(facc.sum() / nw / max(1, G - nburn))
-                lazy_stats = drv.sampler.p2p_stats()         # (remote partner draws, pulled) on this rank; (0, 0) unless lazy ran
-                drv.close()
+                with rung('p2p warm-up + timed run'):
+                    drv.set_positions(th)
+                    drv.run(args.warmup * GENS_PER_STEP)
+                    drv.sync()
+                    drv.set_positions(th)                # barriers inside; restart the job
+                    dist.barrier()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    drv.run(G)
+                    drv.sync()
+                    torch.cuda.synchronize()
+                    dist.barrier()
+                    elapsed = time.perf_counter() - t0
+                    event_ms = drv.sampler.last_run_ms()
+                    launches = drv.sampler.launch_count
+                    msum, msq, nmom = drv.moments()
+                    fpos, facc = drv.positions(), drv.naccept()
+                    acc = float(facc.sum() / nw / max(1, G - nburn))
+                    lazy_stats = drv.sampler.p2p_stats()         # (remote partner draws, pulled) on this rank; (0, 0) unless lazy ran
+                    drv.close()
             except Exception as e:  # noqa: BLE001  (e.g. a peer wait that timed out: every rank then takes the fallback)
                 print(f"[rank {rank}] the p2p run failed ({e})", file=sys.stderr)
                 ok = False
@@ -433,57 +558,60 @@ def main():
             nat = None
             ok = True
             try:
-                nat = AllGatherEmcee(pdf, nw, NDIM, G, nburn, 1, 2.0, SEED, device=local_rank)
+                with rung('native RCCL all-gather set-up (ncclCommInitRank)'):
+                    nat = AllGatherEmcee(pdf, nw, NDIM, G, nburn, 1, 2.0, SEED, device=local_rank)
             except Exception as e:  # noqa: BLE001
                 print(f"[rank {rank}] native RCCL all-gather set-up failed ({e})", file=sys.stderr)
                 ok = False
             if all_ok(ok):
-                nat.set_positions(th)
-                nat.run(min(args.warmup * GENS_PER_STEP, 200))
-                nat.sync()
-                nat.set_positions(th)
-                dist.barrier()
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                nat.run(G)
-                nat.sync()
-                torch.cuda.synchronize()
-                dist.barrier()
-                elapsed = time.perf_counter() - t0
-                event_ms = nat.sampler.last_run_ms()
-                launches = nat.sampler.launch_count
-                msum, msq, nmom = nat.moments()
-                facc, fpos = nat.naccept(), nat.positions()
-                how_nat = nat.sampler.describe()
-                nat.close()
+                with rung('native RCCL all-gather warm-up + timed run'):
+                    nat.set_positions(th)
+                    nat.run(min(args.warmup * GENS_PER_STEP, 200))
+                    nat.sync()
+                    nat.set_positions(th)
+                    dist.barrier()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    nat.run(G)
+                    nat.sync()
+                    torch.cuda.synchronize()
+                    dist.barrier()
+                    elapsed = time.perf_counter() - t0
+                    event_ms = nat.sampler.last_run_ms()
+                    launches = nat.sampler.launch_count
+                    msum, msq, nmom = nat.moments()
+                    facc, fpos = nat.naccept(), nat.positions()
+                    how_nat = nat.sampler.describe()
+                    nat.close()
                 parallelism = f"walker-sharded x{world}, exact partner rule, native RCCL all-gather of the updated half per half-step ({how_nat.split(';')[-1].strip()})"
             else:
                 if nat is not None:
                     nat.sampler.close()
-                ex = HipShardExecutor(pdf, nw, NDIM, G, nburn, 1, 2.0, SEED, rank=rank, world=world, device=local_rank)
-                ex.set_positions(th)
-                sdrv = ShardedEmcee(ex, nw, NDIM)
-                sdrv.run(min(args.warmup * GENS_PER_STEP, 100))   # warm-up: kernels + RCCL rings
-                ex.sync()
-                ex.set_positions(th)
-                sdrv.generation = 0
-                dist.barrier()
-                torch.cuda.synchronize()
-                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                t0 = time.perf_counter()
-                ev0.record()                         # the executor launches on torch's current stream
-                sdrv.run(G)
-                ev1.record()
-                ex.sync()
-                torch.cuda.synchronize()
-                dist.barrier()
-                elapsed = time.perf_counter() - t0
-                event_ms = ev0.elapsed_time(ev1)
-                launches = 2 * G
-                msum, msq, nmom = sdrv.moments()
-                facc = sdrv.naccept()
-                fpos = sdrv.positions()
-                ex.close()
+                with rung('torch-collective all-gather warm-up + timed run'):
+                    ex = HipShardExecutor(pdf, nw, NDIM, G, nburn, 1, 2.0, SEED, rank=rank, world=world, device=local_rank)
+                    ex.set_positions(th)
+                    sdrv = ShardedEmcee(ex, nw, NDIM)
+                    sdrv.run(min(args.warmup * GENS_PER_STEP, 100))   # warm-up: kernels + RCCL rings
+                    ex.sync()
+                    ex.set_positions(th)
+                    sdrv.generation = 0
+                    dist.barrier()
+                    torch.cuda.synchronize()
+                    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    t0 = time.perf_counter()
+                    ev0.record()                         # the executor launches on torch's current stream
+                    sdrv.run(G)
+                    ev1.record()
+                    ex.sync()
+                    torch.cuda.synchronize()
+                    dist.barrier()
+                    elapsed = time.perf_counter() - t0
+                    event_ms = ev0.elapsed_time(ev1)
+                    launches = 2 * G
+                    msum, msq, nmom = sdrv.moments()
+                    facc = sdrv.naccept()
+                    fpos = sdrv.positions()
+                    ex.close()
                 parallelism = f"walker-sharded x{world}, exact partner rule, RCCL all-gather of the updated half per half-step (torch collective per half-step)"
             acc = float(facc.sum() / nw / max(1, G - nburn))
             if rank == 0:
@@ -500,23 +628,24 @@ def main():
         try:
             from kissmcmc_jl_amd.distributed import DealtEmcee, HipDealExecutor
             epoch = int(os.environ.get("KMC_BENCH_DEAL_EPOCH", 64))
-            dex = HipDealExecutor(pdf, NWALKERS_PER_GPU, NDIM, G, nburn, 1, 2.0, SEED, rank=rank, world=world, device=local_rank)
-            dd = DealtEmcee(dex, nw, NDIM, epoch)
-            dd.set_positions(th)
-            dd.run(args.warmup * GENS_PER_STEP)
-            dd.sync()
-            dd.set_positions(th)
-            dist.barrier()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            dd.run(G)
-            dd.sync()
-            torch.cuda.synchronize()
-            dist.barrier()
-            dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
-            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-            res = dd.results()
-            dd.close()
+            with rung('dealt sub-ensembles (extra)'):
+                dex = HipDealExecutor(pdf, NWALKERS_PER_GPU, NDIM, G, nburn, 1, 2.0, SEED, rank=rank, world=world, device=local_rank)
+                dd = DealtEmcee(dex, nw, NDIM, epoch)
+                dd.set_positions(th)
+                dd.run(args.warmup * GENS_PER_STEP)
+                dd.sync()
+                dd.set_positions(th)
+                dist.barrier()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                dd.run(G)
+                dd.sync()
+                torch.cuda.synchronize()
+                dist.barrier()
+                dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+                dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+                res = dd.results()
+                dd.close()
             dmean = res["sum"] / max(1, res["n"])
             dvar = res["sumsq"] / max(1, res["n"]) - dmean ** 2
             dealt = {"value": float(nw) * G / float(dt.item()), "unit": "walker-steps/s", "epoch_generations": epoch, "deals": dd.deals,
@@ -539,28 +668,30 @@ def main():
             from kissmcmc_jl_amd.distributed import AllGatherEmcee
             ag, okag = None, True
             try:
-                ag = AllGatherEmcee(pdf, nw, NDIM, G, nburn, 1, 2.0, SEED, device=local_rank)
+                with rung('native RCCL all-gather set-up (extra)'):
+                    ag = AllGatherEmcee(pdf, nw, NDIM, G, nburn, 1, 2.0, SEED, device=local_rank)
             except Exception as e:  # noqa: BLE001
                 print(f"[rank {rank}] native RCCL all-gather set-up failed ({e})", file=sys.stderr)
                 okag = False
             if all_ok(okag):
-                gens = min(G, 1024)
-                ag.set_positions(th)
-                ag.run(128)
-                ag.sync()
-                ag.set_positions(th)
-                dist.barrier()
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                ag.run(gens)
-                ag.sync()
-                torch.cuda.synchronize()
-                dist.barrier()
-                dta = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
-                dist.all_reduce(dta, op=dist.ReduceOp.MAX)
-                apos, aacc = ag.positions(), ag.naccept()
-                how_ag = ag.sampler.describe()
-                ag.close()
+                with rung('native RCCL all-gather (extra)'):
+                    gens = min(G, 1024)
+                    ag.set_positions(th)
+                    ag.run(128)
+                    ag.sync()
+                    ag.set_positions(th)
+                    dist.barrier()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    ag.run(gens)
+                    ag.sync()
+                    torch.cuda.synchronize()
+                    dist.barrier()
+                    dta = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+                    dist.all_reduce(dta, op=dist.ReduceOp.MAX)
+                    apos, aacc = ag.positions(), ag.naccept()
+                    how_ag = ag.sampler.describe()
+                    ag.close()
                 same = None
                 if rank == 0:
                     rp, ra, _ = unsharded(gens)
@@ -618,6 +749,7 @@ def main():
                       "nmoment": int(nmom)},
         }
         if world > 1:
+            out["collective"] = collective
             out["check"]["timed_run_equals_unsharded_run"] = verified
             out["dealt_mode"] = dealt
             if allgather_extra is not None:

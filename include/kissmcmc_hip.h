@@ -200,6 +200,9 @@ int         kmc_version(void);
 int         kmc_sizeof_config(void);
 int         kmc_sizeof_metropolis_config(void);
 int         kmc_device_count(void);
+/* hipMemGetInfo of a device (a caller deciding between a device-resident chain and KMC_STREAM_CHAIN; reference
+ * src/samplers.jl:268-272 grows the chain without bound). */
+kmc_status  kmc_device_free_bytes(int device, uint64_t* free_bytes, uint64_t* total_bytes);
 const char* kmc_last_error(void);
 const char* kmc_status_string(kmc_status st);
 
@@ -260,6 +263,15 @@ kmc_status  kmc_sampler_p2p_connect(kmc_sampler* s, const void* handles /* [shar
  * rank calls kmc_sampler_rccl_init (collective: ncclCommInitRank).  librccl.so is loaded on first use. */
 kmc_status  kmc_rccl_unique_id(void* id_out);
 kmc_status  kmc_sampler_rccl_init(kmc_sampler* s, const void* id /* KMC_RCCL_ID_BYTES */);
+/* Whether the chunk (kernels + all-gathers) is replayed from a captured hipGraph or enqueued launch by launch must be the SAME on
+ * every rank: kmc_sampler_rccl_capture captures now and reports this rank's outcome (1 / 0; 0 also with KMC_NO_GRAPH); the
+ * driver reduces the answers over the ranks (MIN) and passes the result to kmc_sampler_rccl_set_capture on every rank
+ * (0: drop the captured chunk, launch by launch from now on).  Results are identical either way. */
+kmc_status  kmc_sampler_rccl_capture(kmc_sampler* s, int* captured);
+kmc_status  kmc_sampler_rccl_set_capture(kmc_sampler* s, int use_captured);
+/* librccl.so as this process resolves it (dlopen): ncclGetVersion's code (major*10000 + minor*100 + patch) and its path;
+ * KMC_ERR_UNSUPPORTED when the library or one of the entry points used here cannot be resolved.  Needs no device. */
+kmc_status  kmc_rccl_version(int* version, char* path_buf /* may be NULL */, int64_t path_buflen);
 /* The same wiring for shards that live in ONE process on one device (no IPC): shards[r] = the sampler of shard r.
    They run concurrently on their own streams like ranks on separate GPUs (single-process tests, timing, profiling). */
 kmc_status  kmc_sampler_p2p_connect_local(kmc_sampler* s, kmc_sampler* const* shards /* [shard_count] */);
@@ -298,7 +310,9 @@ kmc_status  kmc_sampler_set_state(kmc_sampler* s, const double* pos_host, const 
  * called again).  Call before kmc_sampler_run; sample k of a run is complete in these buffers after the kmc_sampler_sync
  * that follows the generation which stored it.  kmc_sampler_get_chain then copies from them (or is a no-op for the same
  * pointers).  A sampler created with KMC_CHAIN_BY_WALKER as well takes [nwalkers][nsamples][ndim] and [nwalkers][nsamples]
- * (the stride between walkers is the whole run's nsamples) and answers kmc_sampler_get_chain_by_walker instead. */
+ * (the stride between walkers is the whole run's nsamples) and answers kmc_sampler_get_chain_by_walker instead.
+ * The buffers are page-locked in place (hipHostRegister) so that blocks arrive by DMA behind the sampling; where that is
+ * refused (a container's RLIMIT_MEMLOCK) the blocks come through bounce buffers on the caller's thread -- slower, same result. */
 kmc_status  kmc_sampler_set_chain_host(kmc_sampler* s, double* chain_host, double* chain_logp_host);
 /* Enqueue `ngenerations` generations (asynchronous).  shard_count must be 1. */
 kmc_status  kmc_sampler_run(kmc_sampler* s, int64_t ngenerations);
@@ -315,6 +329,19 @@ int64_t     kmc_sampler_nsamples(const kmc_sampler* s);
 /* Number of half-step kernel launches enqueued so far and the algorithmic bytes each moves
  * (read (2 ndim + 1) * 8, write (ndim + 1) * 8 per walker-step). */
 int64_t     kmc_sampler_launch_count(const kmc_sampler* s);
+/* How kmc_sampler_run issues this sampler's launches (same kernels, same results in every mode; reference
+ * src/samplers.jl:245-247 -- the generation x half-step loop -- is what the modes enqueue).  *budget_fallback (may be NULL)
+ * becomes 1 when the sampler is not in the updated-graph mode because the PROCESS-WIDE budget of graph parameter updates was
+ * spent (the HIP runtime leaks ~80 B of host memory per update; 64 MiB worth by default, KMC_UPDATED_BUDGET_MB in the
+ * environment or kmc_set_updated_budget_mb): said once on stderr, in kmc_sampler_describe, and here. */
+#define KMC_LAUNCH_UNDECIDED     0   /* only short runs so far: whole chunks from the table graph, the rest eagerly */
+#define KMC_LAUNCH_TABLE_GRAPH   1   /* hipGraph replay of 64 generations, schedule read from a device table */
+#define KMC_LAUNCH_EAGER         2   /* one launch per half-step from the host */
+#define KMC_LAUNCH_UPDATED_GRAPH 3   /* hipGraph replay with per-replay kernel-node parameter updates */
+#define KMC_LAUNCH_SINGLE        4   /* resident / island kernels (many generations per launch), host-evaluated density */
+int         kmc_sampler_launch_mode(const kmc_sampler* s, int* budget_fallback);
+void        kmc_updated_budget(int64_t* calls_used, int64_t* calls_budget);   /* parameter updates so far / allowed, this process */
+void        kmc_set_updated_budget_mb(double mb);                              /* 80 B per update; <= 0: no updated-graph mode from now on */
 
 /* One line describing how this sampler executes (kernel family and geometry, exchange scheme). */
 kmc_status  kmc_sampler_describe(const kmc_sampler* s, char* buf, int64_t buflen);
@@ -455,6 +482,15 @@ kmc_status  kmc_int_acorr(const double* chain_host, int64_t nsamples, int64_t nw
                           int device, double* tau /* [ndim] */, double* converged /* [ndim] */);
 /* The same on the chain a sampler holds on the device (KMC_STORE_CHAIN, the samples stored so far; even ndim). */
 kmc_status  kmc_sampler_int_acorr(kmc_sampler* s, double c, double* tau, double* converged);
+
+/* ---- diagnostics ----
+ * The random side of the accept test of reference src/samplers.jl:260, "(N-1)*log(z) + p1 - p0 >= log(rand())", exactly as
+ * the half-step kernels compute it, for walkers walker0 .. walker0 + n - 1 of one step (= 2 * generation + half): the partner
+ * index (:250; may be NULL), z (:252), t1 = (ndim - 1) * log z and lu = log u, into host arrays.  The kernels take the two
+ * logarithms from their own < 1 ulp routine, a CPU implementation from its libm: this export lets a test measure that gap
+ * and the probability that it flips an accept decision (tests/test_gpu_accept_margin.py). */
+kmc_status  kmc_debug_accept_terms(uint64_t seed, uint64_t step, uint64_t walker0, int64_t n, int64_t nhalf, double a_scale,
+                                   int64_t ndim, int device, int64_t* partner_host, double* z_host, double* t1_host, double* lu_host);
 
 #ifdef __cplusplus
 }

@@ -43,6 +43,8 @@ SYMBOLS = [
     "kmc_user_density_create", "kmc_user_density_create_body", "kmc_user_density_destroy", "kmc_metropolis_validate", "kmc_metropolis_run", "kmc_int_acorr", "kmc_sampler_int_acorr",
     "kmc_sizeof_config", "kmc_sizeof_metropolis_config", "kmc_deal_seed", "kmc_deal_perm", "kmc_sampler_deal_pack", "kmc_sampler_deal_unpack",
     "kmc_sampler_get_walker_ids", "kmc_sampler_set_walker_ids", "kmc_sampler_set_chain_host", "kmc_rccl_unique_id", "kmc_sampler_rccl_init",
+    "kmc_sampler_rccl_capture", "kmc_sampler_rccl_set_capture", "kmc_rccl_version", "kmc_device_free_bytes",
+    "kmc_sampler_launch_mode", "kmc_updated_budget", "kmc_set_updated_budget_mb", "kmc_debug_accept_terms",
 ]
 
 
@@ -221,6 +223,17 @@ def lib() -> C.CDLL:
     L.kmc_sampler_set_chain_host.argtypes = [vp, dp, dp]
     L.kmc_rccl_unique_id.argtypes = [vp]
     L.kmc_sampler_rccl_init.argtypes = [vp, vp]
+    L.kmc_sampler_rccl_capture.argtypes = [vp, C.POINTER(C.c_int)]
+    L.kmc_sampler_rccl_set_capture.argtypes = [vp, C.c_int]
+    L.kmc_rccl_version.argtypes = [C.POINTER(C.c_int), C.c_char_p, C.c_int64]
+    L.kmc_device_free_bytes.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.kmc_sampler_launch_mode.restype = C.c_int
+    L.kmc_sampler_launch_mode.argtypes = [vp, C.POINTER(C.c_int)]
+    L.kmc_updated_budget.restype = None
+    L.kmc_updated_budget.argtypes = [ip, ip]
+    L.kmc_set_updated_budget_mb.restype = None
+    L.kmc_set_updated_budget_mb.argtypes = [C.c_double]
+    L.kmc_debug_accept_terms.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int64, C.c_int64, C.c_double, C.c_int64, C.c_int, ip, dp, dp, dp]
     # layout drift between this mirror and the library fails here, at load, not inside the first real call
     if L.kmc_sizeof_config() != C.sizeof(Config) or L.kmc_sizeof_metropolis_config() != C.sizeof(MetropolisConfig):
         raise ImportError(f"{LIB_PATH}: struct layout mismatch (kmc_config {L.kmc_sizeof_config()} vs {C.sizeof(Config)} bytes, "

@@ -27,11 +27,11 @@ def _fresh_seed() -> int:
 
 
 def _free_device_bytes(device: int) -> float:
-    try:
-        import torch
-        return float(torch.cuda.mem_get_info(device)[0])
-    except Exception:  # noqa: BLE001
-        return float(200 << 30)
+    """hipMemGetInfo through the library (no torch: importing it and creating its HIP context costs seconds and hundreds of MiB)."""
+    import ctypes as C
+    free, total = C.c_uint64(0), C.c_uint64(0)
+    _lib.check(_lib.lib().kmc_device_free_bytes(int(device), C.byref(free), C.byref(total)))
+    return float(free.value)
 
 
 def emcee_counts(niter: int, nwalkers: int, nburnin=None, nthin: int = 1):
@@ -104,17 +104,13 @@ def emcee(pdf, theta0s, niter: int = 10 ** 5, nburnin=None, nthin: int = 1, a_sc
         seed = _fresh_seed()
 
     if stream_chain is None:
-        stream_chain = dtype == "f64" and nsamples_walker * nwalkers * (ndim + 1 + ndim % 2) * 8 > 0.7 * _free_device_bytes(device)
-    def make(by_walker):
-        return Sampler(pdf, nwalkers, ndim, niter_walker, nburnin_walker, nthin, a_scale, seed, store_chain=True, store_logp=True,
-                       device=device, dtype=dtype, stream_chain=bool(stream_chain), chain_by_walker=by_walker)
-    try:
-        sampler = make(True)
-    except _lib.KmcError as e:                                 # a streamed chain whose host arrays cannot be page-locked:
-        if e.status != _lib.ERR_UNSUPPORTED or not stream_chain:   # stream it sample-major, reorder on the host
-            raise
-        sampler = make(False)
-    with sampler as s:
+        # a chain that would not fit the device is streamed to host memory while sampling; the device is only asked when the
+        # chain is large at all (> 1 GiB)
+        chain_bytes = nsamples_walker * nwalkers * (ndim + 1 + ndim % 2) * 8
+        stream_chain = dtype == "f64" and chain_bytes > (1 << 30) and chain_bytes > 0.7 * _free_device_bytes(device)
+    # (host arrays that cannot be page-locked are no reason to fail: the library then stages the by-walker blocks itself)
+    with Sampler(pdf, nwalkers, ndim, niter_walker, nburnin_walker, nthin, a_scale, seed, store_chain=True, store_logp=True,
+                 device=device, dtype=dtype, stream_chain=bool(stream_chain), chain_by_walker=True) as s:
         try:
             s.set_positions(theta0s)
         except _lib.KmcError as e:

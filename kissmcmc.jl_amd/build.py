@@ -8,9 +8,9 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(_HERE, "libkissmcmc_hip.so")
-SOURCES = ["kmc_api.hip", "kmc_metropolis_api.hip", "kmc_acorr.hip", "kmc_rccl.hip", "kmc_inst_gaussian_iso.hip", "kmc_inst_exponential.hip", "kmc_inst_rosenbrock.hip",
-           "kmc_inst_lognormal.hip", "kmc_inst_mvnormal2.hip", "kmc_inst_host.hip"]
-HEADERS = ["kmc_host.hpp", "kmc_device.hpp", "kmc_kernels.hpp", "kmc_islands.hpp", "kmc_metropolis.hpp", "kmc_tables.hpp", os.path.join("..", "..", "include", "kissmcmc_hip.h")]
+SOURCES = ["kmc_sampler.hip", "kmc_launch.hip", "kmc_state.hip", "kmc_copy.hip", "kmc_rtc.hip", "kmc_p2p.hip", "kmc_metropolis_api.hip", "kmc_acorr.hip", "kmc_rccl.hip", "kmc_diag.hip", "kmc_inst_host.hip"] + \
+          [f"kmc_inst_{d}{part}.hip" for part in ("", "_var", "_p2p", "_lds") for d in ("lognormal", "exponential", "gaussian_iso", "rosenbrock", "mvnormal2")]   # (longest jobs first)
+HEADERS = ["kmc_host.hpp", "kmc_sampler.hpp", "kmc_device.hpp", "kmc_kernels.hpp", "kmc_islands.hpp", "kmc_metropolis.hpp", "kmc_tables.hpp", os.path.join("..", "..", "include", "kissmcmc_hip.h")]
 # kernarg preload: the half-step kernels' leading scalar parameters arrive in SGPRs at wave launch (kmc_kernels.hpp)
 PRELOAD = ["-mllvm", "-amdgpu-kernarg-preload-count=14"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
@@ -51,8 +51,9 @@ def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str =
         subprocess.check_call(cmd)
         return obj
 
+    order = sorted(SOURCES, key=lambda f: not f.startswith("kmc_inst_"))       # the kernel instantiations are the long jobs: start them first
     with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as ex:
-        objs = list(ex.map(compile_one, SOURCES))
+        objs = list(ex.map(compile_one, order))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", out + ".tmp", "-lhiprtc", "-ldl"]
     if verbose:
         print(" ".join(cmd))

@@ -1,0 +1,158 @@
+// kmc_diag.hip -- diagnostics: the accept-term probe of the C ABI (include/kissmcmc_hip.h: "diagnostics"), the native
+// backtrace of an abort() (KMC_ABORT_BACKTRACE), the guard bands behind a sampler's device allocations (KMC_POISON), and the
+// device's free memory.
+//
+// kmc_debug_accept_terms: the random side of the accept test of reference src/samplers.jl:260,
+//     (N-1) * log(z) + p1 - p0 >= log(rand()),
+// exactly as the half-step kernels compute it (kmc_device.hpp: draw_step -- Philox block, z = (u c1 + c0)^2 and the two
+// logarithms from the kernels' own log_pos_normal), for a run of walkers of one step.  The kernels and the CPU oracle take
+// these two logarithms from different implementations (each < 1 ulp); tests/test_gpu_accept_margin.py measures the gap and
+// what it means for "identical accept decisions".
+#include <execinfo.h>
+#include <fcntl.h>
+#include <signal.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+
+#include "kmc_sampler.hpp"
+
+using namespace kmc;
+using namespace kmc_host;
+
+// Diagnostics (KMC_ABORT_BACKTRACE=1 in the environment when the library is loaded): the native call stack of an abort()
+// raised anywhere in the process (the HIP runtime aborts on internal errors without a message), on stderr.
+namespace {
+#ifndef KMC_DIAG_ALWAYS
+#define KMC_DIAG_ALWAYS 0          // -DKMC_DIAG_ALWAYS=1: a diagnostics build that always installs the handler (file /tmp/kmc_abort_bt.txt)
+#endif
+void abort_backtrace(int sig)
+{
+    void* frames[64];
+    const int n = backtrace(frames, 64);
+    const char msg[] = "\n[kissmcmc_hip] SIGABRT, native stack:\n";
+    int fd = 2;                                          // KMC_ABORT_BACKTRACE=/path/to/file: there (a test runner may have captured fd 2)
+    const char* where = std::getenv("KMC_ABORT_BACKTRACE");
+    if (!where && KMC_DIAG_ALWAYS) where = "/tmp/kmc_abort_bt.txt";
+    if (where && where[0] == '/') { const int f = open(where, O_WRONLY | O_CREAT | O_APPEND, 0644); if (f >= 0) fd = f; }
+    (void)!write(fd, msg, sizeof(msg) - 1);
+    backtrace_symbols_fd(frames, n, fd);
+    // what the runtime printed before it aborted: a test runner that captures fd 2 keeps it in a temporary file
+    struct stat st;
+    if (fd != 2 && fstat(2, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+        static char buf[8192];
+        const off_t from = st.st_size > (off_t)sizeof(buf) ? st.st_size - (off_t)sizeof(buf) : 0;
+        const ssize_t got = pread(2, buf, sizeof(buf), from);
+        const char hdr[] = "[kissmcmc_hip] tail of the captured stderr:\n";
+        (void)!write(fd, hdr, sizeof(hdr) - 1);
+        if (got > 0) (void)!write(fd, buf, (size_t)got);
+    }
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
+struct AbortBacktraceInstaller {
+    AbortBacktraceInstaller() { if (std::getenv("KMC_ABORT_BACKTRACE") || KMC_DIAG_ALWAYS) signal(SIGABRT, abort_backtrace); }
+} g_abort_backtrace_installer;
+}  // namespace
+
+void kmc_host::reinstall_abort_backtrace()
+{
+    if (std::getenv("KMC_ABORT_BACKTRACE") || KMC_DIAG_ALWAYS) signal(SIGABRT, abort_backtrace);      // (somebody may have replaced it)
+}
+
+namespace kmc_host {
+void check_guards(kmc_sampler* s)
+{
+    std::vector<unsigned char> h(kGuardBytes);
+    for (const auto& g : s->guards) {
+        if (copy_sync(h.data(), g.first, kGuardBytes, hipMemcpyDeviceToHost, s->stream) != hipSuccess) { (void)hipGetLastError(); continue; }
+        for (size_t i = 0; i < kGuardBytes; ++i)
+            if (h[i] != 0xA5) {
+                std::fprintf(stderr, "[kissmcmc_hip] KMC_POISON: byte %zu behind a device allocation of %zu bytes was overwritten (%s)\n", i, g.second,
+                             s->plan.vec ? "vec kernels" : "generic / staged kernels");
+                std::abort();
+            }
+    }
+    s->guards.clear();
+}
+}  // namespace kmc_host
+
+// free / total bytes of a device's memory (hipMemGetInfo), for callers that decide between a device chain and a streamed one
+KMC_EXPORT kmc_status kmc_device_free_bytes(int device, uint64_t* free_bytes, uint64_t* total_bytes)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { (void)hipGetLastError(); return fail(KMC_ERR_NO_DEVICE, "no HIP device visible"); }
+    if (device < 0 || device >= ndev) return fail(KMC_ERR_BAD_ARG, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(device));
+    size_t f = 0, t = 0;
+    HIP_TRY(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = (uint64_t)f;
+    if (total_bytes) *total_bytes = (uint64_t)t;
+    return KMC_OK;
+}
+
+
+namespace {
+
+__global__ __launch_bounds__(256) void accept_terms_kernel(DrawConsts dc, uint64_t step, uint64_t walker0, int64_t n,
+                                                           uint32_t* partner, double* z, double* t1, double* lu)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const Draw d = draw_step(dc, step, walker0 + (uint64_t)i);
+    if (partner) partner[i] = d.partner;
+    z[i] = d.z;
+    t1[i] = d.t1;
+    lu[i] = d.lu;
+}
+
+}  // namespace
+
+KMC_EXPORT kmc_status kmc_debug_accept_terms(uint64_t seed, uint64_t step, uint64_t walker0, int64_t n, int64_t nhalf, double a_scale,
+                                             int64_t ndim, int device, int64_t* partner_host, double* z_host, double* t1_host, double* lu_host)
+{
+    if (n < 0 || nhalf <= 0 || nhalf >= (int64_t)1 << 31 || !(a_scale > 1.0) || ndim < 1 || !z_host || !t1_host || !lu_host)
+        return fail(KMC_ERR_BAD_ARG, "bad argument");
+    if (n == 0) return KMC_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { (void)hipGetLastError(); return fail(KMC_ERR_NO_DEVICE, "no HIP device visible"); }
+    if (device < 0 || device >= ndev) return fail(KMC_ERR_BAD_ARG, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(device));
+    ScopedStream ss;
+    HIP_TRY(ss.create());
+    DrawConsts dc{};
+    dc.seed_lo = (uint32_t)seed; dc.seed_hi = (uint32_t)(seed >> 32);
+    dc.nhalf = (uint32_t)nhalf;
+    dc.c0 = std::sqrt(1.0 / a_scale);                                  // as make_args (src/samplers.jl:227, hoisted)
+    dc.c1 = std::sqrt(a_scale) - std::sqrt(1.0 / a_scale);
+    dc.nm1 = (double)(ndim - 1);
+    const int64_t piece = (int64_t)1 << 22;                             // 4 Mi draws per launch: 112 MiB of device scratch
+    const int64_t m = n < piece ? n : piece;
+    char* buf = nullptr;
+    HIP_TRY(hipMalloc((void**)&buf, (size_t)m * (3 * sizeof(double) + sizeof(uint32_t))));
+    double* dz = reinterpret_cast<double*>(buf);
+    double* dt1 = dz + m;
+    double* dlu = dt1 + m;
+    uint32_t* dpart = reinterpret_cast<uint32_t*>(dlu + m);
+    std::vector<uint32_t> hp(partner_host ? (size_t)m : 0);
+    hipError_t e = hipSuccess;
+    for (int64_t i0 = 0; i0 < n && e == hipSuccess; i0 += m) {
+        const int64_t k = n - i0 < m ? n - i0 : m;
+        hipLaunchKernelGGL(accept_terms_kernel, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, ss.st, dc, step, walker0 + (uint64_t)i0, k,
+                           partner_host ? dpart : nullptr, dz, dt1, dlu);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = copy_sync(z_host + i0, dz, (size_t)k * sizeof(double), hipMemcpyDeviceToHost, ss.st);
+        if (e == hipSuccess) e = copy_sync(t1_host + i0, dt1, (size_t)k * sizeof(double), hipMemcpyDeviceToHost, ss.st);
+        if (e == hipSuccess) e = copy_sync(lu_host + i0, dlu, (size_t)k * sizeof(double), hipMemcpyDeviceToHost, ss.st);
+        if (e == hipSuccess && partner_host) {
+            e = copy_sync(hp.data(), dpart, (size_t)k * sizeof(uint32_t), hipMemcpyDeviceToHost, ss.st);
+            for (int64_t j = 0; j < k; ++j) partner_host[i0 + j] = (int64_t)hp[(size_t)j];
+        }
+    }
+    (void)hipFree(buf);
+    HIP_TRY(e);
+    return KMC_OK;
+}

@@ -109,6 +109,7 @@ kmc_status int_acorr_check(int64_t nsamples, int64_t nwalkers, int64_t ndim, dou
 kmc_status int_acorr_device(const double* chain_dev, int64_t nsamples, int64_t nwalkers, int64_t ndim, double c, double* tau, double* converged);
 
 // RCCL, loaded on demand (kmc_rccl.hip)
+kmc_status rccl_version(int* version, const char** path);
 kmc_status rccl_unique_id(void* id_out);
 kmc_status rccl_comm_create(const void* id_bytes, int rank, int nranks, void** comm_out);
 void rccl_comm_destroy(void* comm);

@@ -1,0 +1,10 @@
+// Kernel instantiations for the exponential (README.md:15) log-density, part 3 of 4: the LDS-resident kernels (islands, resident mode) and
+// the many-chain Metropolis kernels.
+#define KMC_TABLES_IMPL
+#include "kmc_tables.hpp"
+
+namespace kmc {
+IslandFn island_exponential(int S, int K, bool ragged) { return island_lookup<Exponential>(S, K, ragged); }
+ResidentFn resident_exponential(int tpb, int K, bool ragged) { return resident_lookup<Exponential>(tpb, K, ragged); }
+MetropolisFn metropolis_exponential(int ndim) { return metropolis_lookup<Exponential>(ndim); }
+}  // namespace kmc

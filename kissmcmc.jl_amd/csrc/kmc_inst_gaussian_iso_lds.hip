@@ -1,0 +1,10 @@
+// Kernel instantiations for the isotropic Gaussian log-density, part 3 of 4: the LDS-resident kernels (islands, resident mode) and
+// the many-chain Metropolis kernels.
+#define KMC_TABLES_IMPL
+#include "kmc_tables.hpp"
+
+namespace kmc {
+IslandFn island_gaussian_iso(int S, int K, bool ragged) { return island_lookup<GaussianIso>(S, K, ragged); }
+ResidentFn resident_gaussian_iso(int tpb, int K, bool ragged) { return resident_lookup<GaussianIso>(tpb, K, ragged); }
+MetropolisFn metropolis_gaussian_iso(int ndim) { return metropolis_lookup<GaussianIso>(ndim); }
+}  // namespace kmc

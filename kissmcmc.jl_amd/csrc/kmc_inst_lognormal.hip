@@ -1,14 +1,15 @@
-// Kernel instantiations for the LogNormal log-density (one translation unit per density).
+// Kernel instantiations for the LogNormal log-density, part 0 of 4 (kmc_tables.hpp: vec_pick): double rows of exact size on
+// one GPU, the generic kernel, the log-pdf and initial-ball kernels -- and the dispatch to the other parts.
 #define KMC_TABLES_IMPL
 #include "kmc_tables.hpp"
 
 namespace kmc {
 void table_lognormal(int L, int K, int iter, bool p2p, bool ragged, bool f32, HalfStepFn* vec, HalfStepFn* gen, LogpdfFn* lp)
 {
-    density_fns<LogNormal>(L, K, iter, p2p, ragged, f32, vec, gen, lp);
+    *lp = logpdf_rows<LogNormal>;
+    if (p2p) { if (f32) { *vec = nullptr; *gen = nullptr; } else part_p2p_lognormal(L, K, iter, ragged, vec, gen); }
+    else if (ragged || f32) part_var_lognormal(L, K, iter, ragged, f32, vec, gen);
+    else density_part<LogNormal, 0>(L, K, iter, false, false, vec, gen);
 }
-IslandFn island_lognormal(int S, int K, bool ragged) { return island_lookup<LogNormal>(S, K, ragged); }
-ResidentFn resident_lognormal(int tpb, int K, bool ragged) { return resident_lookup<LogNormal>(tpb, K, ragged); }
 InitBallFn init_ball_lognormal() { return init_ball<LogNormal>; }
-MetropolisFn metropolis_lognormal(int ndim) { return metropolis_lookup<LogNormal>(ndim); }
 }  // namespace kmc

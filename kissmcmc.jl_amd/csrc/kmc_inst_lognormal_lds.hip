@@ -1,0 +1,10 @@
+// Kernel instantiations for the LogNormal log-density, part 3 of 4: the LDS-resident kernels (islands, resident mode) and
+// the many-chain Metropolis kernels.
+#define KMC_TABLES_IMPL
+#include "kmc_tables.hpp"
+
+namespace kmc {
+IslandFn island_lognormal(int S, int K, bool ragged) { return island_lookup<LogNormal>(S, K, ragged); }
+ResidentFn resident_lognormal(int tpb, int K, bool ragged) { return resident_lookup<LogNormal>(tpb, K, ragged); }
+MetropolisFn metropolis_lognormal(int ndim) { return metropolis_lookup<LogNormal>(ndim); }
+}  // namespace kmc

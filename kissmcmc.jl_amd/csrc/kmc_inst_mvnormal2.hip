@@ -1,14 +1,15 @@
-// Kernel instantiations for the MvNormal2 log-density (one translation unit per density).
+// Kernel instantiations for the 2-D correlated normal (test/runtests.jl:60) log-density, part 0 of 4 (kmc_tables.hpp: vec_pick): double rows of exact size on
+// one GPU, the generic kernel, the log-pdf and initial-ball kernels -- and the dispatch to the other parts.
 #define KMC_TABLES_IMPL
 #include "kmc_tables.hpp"
 
 namespace kmc {
 void table_mvnormal2(int L, int K, int iter, bool p2p, bool ragged, bool f32, HalfStepFn* vec, HalfStepFn* gen, LogpdfFn* lp)
 {
-    density_fns<MvNormal2>(L, K, iter, p2p, ragged, f32, vec, gen, lp);
+    *lp = logpdf_rows<MvNormal2>;
+    if (p2p) { if (f32) { *vec = nullptr; *gen = nullptr; } else part_p2p_mvnormal2(L, K, iter, ragged, vec, gen); }
+    else if (ragged || f32) part_var_mvnormal2(L, K, iter, ragged, f32, vec, gen);
+    else density_part<MvNormal2, 0>(L, K, iter, false, false, vec, gen);
 }
-IslandFn island_mvnormal2(int S, int K, bool ragged) { return island_lookup<MvNormal2>(S, K, ragged); }
-ResidentFn resident_mvnormal2(int tpb, int K, bool ragged) { return resident_lookup<MvNormal2>(tpb, K, ragged); }
 InitBallFn init_ball_mvnormal2() { return init_ball<MvNormal2>; }
-MetropolisFn metropolis_mvnormal2(int ndim) { return metropolis_lookup<MvNormal2>(ndim); }
 }  // namespace kmc

@@ -1,0 +1,10 @@
+// Kernel instantiations for the 2-D correlated normal (test/runtests.jl:60) log-density, part 3 of 4: the LDS-resident kernels (islands, resident mode) and
+// the many-chain Metropolis kernels.
+#define KMC_TABLES_IMPL
+#include "kmc_tables.hpp"
+
+namespace kmc {
+IslandFn island_mvnormal2(int S, int K, bool ragged) { return island_lookup<MvNormal2>(S, K, ragged); }
+ResidentFn resident_mvnormal2(int tpb, int K, bool ragged) { return resident_lookup<MvNormal2>(tpb, K, ragged); }
+MetropolisFn metropolis_mvnormal2(int ndim) { return metropolis_lookup<MvNormal2>(ndim); }
+}  // namespace kmc

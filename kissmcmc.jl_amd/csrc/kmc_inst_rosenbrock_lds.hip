@@ -1,0 +1,10 @@
+// Kernel instantiations for the chained Rosenbrock (test/runtests.jl:68 at N = 2) log-density, part 3 of 4: the LDS-resident kernels (islands, resident mode) and
+// the many-chain Metropolis kernels.
+#define KMC_TABLES_IMPL
+#include "kmc_tables.hpp"
+
+namespace kmc {
+IslandFn island_rosenbrock(int S, int K, bool ragged) { return island_lookup<Rosenbrock>(S, K, ragged); }
+ResidentFn resident_rosenbrock(int tpb, int K, bool ragged) { return resident_lookup<Rosenbrock>(tpb, K, ragged); }
+MetropolisFn metropolis_rosenbrock(int ndim) { return metropolis_lookup<Rosenbrock>(ndim); }
+}  // namespace kmc

@@ -1,0 +1,7 @@
+// Kernel instantiations for the chained Rosenbrock (test/runtests.jl:68 at N = 2) log-density, part 2 of 4: the peer-to-peer kernels (KMC_P2P).
+#define KMC_TABLES_IMPL
+#include "kmc_tables.hpp"
+
+namespace kmc {
+void part_p2p_rosenbrock(int L, int K, int iter, bool ragged, HalfStepFn* vec, HalfStepFn* gen) { density_part<Rosenbrock, 2>(L, K, iter, ragged, false, vec, gen); }
+}  // namespace kmc

@@ -1289,7 +1289,8 @@ struct SweepArgs {
     int32_t        K, depth;
 };
 
-#ifdef KMC_DEFINE_DRIVER_KERNELS   // non-template kernels: defined once, in kmc_api.hip
+// Non-template kernels of the host driver: each group is defined once, in the translation unit that launches it.
+#ifdef KMC_DEFINE_LAUNCH_KERNELS   // kmc_launch.hip
 // one 64-lane workgroup per (wave of the half-step grid, chunk k): sum += x w, sumsq += x^2 w over the wave's posted rows
 __global__ __launch_bounds__(64) void moments_sweep(const SweepArgs a)
 {
@@ -1327,6 +1328,9 @@ __global__ void p2p_signal(const SignalArgs a)
         __hip_atomic_store(a.peer_flags[threadIdx.x] + a.me, done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+#endif  // KMC_DEFINE_LAUNCH_KERNELS (advance_schedule: below)
+
+#ifdef KMC_DEFINE_STATE_KERNELS    // kmc_state.hip
 // Walker re-deal between sub-ensembles (kmc_config.deal_count, kmc_sampler_deal_pack / _unpack): a walker travels as
 // one row of ndim + 2 doubles {its position, its log-pdf, (walker id << 32 | naccept)}.  PACK writes the row of local
 // slot j to position t = (A j + C) mod S of the send buffer (a state-independent affine shuffle of this sub-ensemble's
@@ -1373,6 +1377,9 @@ __global__ __launch_bounds__(256) void deal_init_ids(uint32_t* ids, int64_t S, u
     if (i < S) ids[i] = first + (uint32_t)i;
 }
 
+#endif  // KMC_DEFINE_STATE_KERNELS
+
+#ifdef KMC_DEFINE_COPY_KERNELS     // kmc_copy.hip
 // Chain read-out in the reference's order, thetas[walker][sample] (src/samplers.jl:219-221, :268-272): K samples of the
 // stored chain src [sample][walker][ld], walkers [w0, w0 + nw) -> dst [walker][..][nd] doubles with `dst_stride` elements
 // from one walker to the next (K * nd: a dense piece; nsamples * nd: a block of a streamed chain written straight into the
@@ -1415,6 +1422,9 @@ __global__ __launch_bounds__(256) void rows_compact(const double* __restrict__ s
     }
 }
 
+#endif  // KMC_DEFINE_COPY_KERNELS
+
+#ifdef KMC_DEFINE_LAUNCH_KERNELS
 // Graph replay support: the device-side generation counter and the schedule table of the next
 // `n` generations (one thread each).  *gen += by happens before the table is rebuilt.
 __global__ void advance_schedule(int64_t* gen, SchedEntry* table, int n, int64_t by,
@@ -1425,6 +1435,6 @@ __global__ void advance_schedule(int64_t* gen, SchedEntry* table, int n, int64_t
     if ((int)threadIdx.x < n) table[threadIdx.x] = make_sched(base + threadIdx.x, nburnin, nthin, nsamples, ring_slots);
     if (threadIdx.x == 0) *gen = base;
 }
-#endif  // KMC_DEFINE_DRIVER_KERNELS
+#endif  // KMC_DEFINE_LAUNCH_KERNELS
 
 }  // namespace kmc

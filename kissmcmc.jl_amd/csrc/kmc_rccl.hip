@@ -17,6 +17,8 @@ struct RcclApi {
     decltype(&ncclCommDestroy) comm_destroy = nullptr;
     decltype(&ncclAllGather) all_gather = nullptr;
     decltype(&ncclGetErrorString) error_string = nullptr;
+    decltype(&ncclGetVersion) get_version = nullptr;
+    std::string path;                 // where the library was found (dladdr of one of its symbols)
 };
 
 const RcclApi* rccl_api()
@@ -34,8 +36,11 @@ const RcclApi* rccl_api()
         api.comm_destroy = reinterpret_cast<decltype(api.comm_destroy)>(dlsym(api.lib, "ncclCommDestroy"));
         api.all_gather = reinterpret_cast<decltype(api.all_gather)>(dlsym(api.lib, "ncclAllGather"));
         api.error_string = reinterpret_cast<decltype(api.error_string)>(dlsym(api.lib, "ncclGetErrorString"));
+        api.get_version = reinterpret_cast<decltype(api.get_version)>(dlsym(api.lib, "ncclGetVersion"));
+        Dl_info info;
+        if (api.all_gather && dladdr(reinterpret_cast<void*>(api.all_gather), &info) && info.dli_fname) api.path = info.dli_fname;
     });
-    return (api.lib && api.get_unique_id && api.comm_init_rank && api.comm_destroy && api.all_gather && api.error_string) ? &api : nullptr;
+    return (api.lib && api.get_unique_id && api.comm_init_rank && api.comm_destroy && api.all_gather && api.error_string && api.get_version) ? &api : nullptr;
 }
 
 kmc_status rccl_fail(const RcclApi* a, const char* what, ncclResult_t r)
@@ -45,6 +50,19 @@ kmc_status rccl_fail(const RcclApi* a, const char* what, ncclResult_t r)
 }  // namespace
 
 static_assert(NCCL_UNIQUE_ID_BYTES == KMC_RCCL_ID_BYTES, "unique id blob size");
+
+// every entry point the library uses resolved from the librccl.so this process finds; its version code and path
+kmc_status rccl_version(int* version, const char** path)
+{
+    const RcclApi* a = rccl_api();
+    if (!a) return fail(KMC_ERR_UNSUPPORTED, "librccl.so could not be loaded (or lacks one of ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllGather / ncclGetErrorString / ncclGetVersion)");
+    int v = 0;
+    const ncclResult_t r = a->get_version(&v);
+    if (r != ncclSuccess) return rccl_fail(a, "ncclGetVersion", r);
+    if (version) *version = v;
+    if (path) *path = a->path.c_str();
+    return KMC_OK;
+}
 
 kmc_status rccl_unique_id(void* id_out)
 {

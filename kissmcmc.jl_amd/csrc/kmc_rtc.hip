@@ -1,0 +1,262 @@
+// kmc_rtc.hip -- user-supplied log-densities compiled at run time (hiprtc) into the same kernels as the menu densities
+// (the reference's arbitrary closure `pdf(theta)`, src/samplers.jl:257), with a disk cache of the code objects.
+#include <dlfcn.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <sstream>
+
+#include "kmc_sampler.hpp"
+
+using namespace kmc;
+using namespace kmc_host;
+
+namespace {
+uint64_t fnv1a(uint64_t h, const void* data, size_t n)
+{
+    const unsigned char* p = static_cast<const unsigned char*>(data);
+    for (size_t i = 0; i < n; ++i) { h ^= p[i]; h *= 0x100000001b3ull; }
+    return h;
+}
+std::string rtc_cache_dir()
+{
+    if (std::getenv("KMC_NO_DISK_CACHE")) return std::string();
+    if (const char* d = std::getenv("KMC_CACHE_DIR")) return std::string(d);
+    if (const char* x = std::getenv("XDG_CACHE_HOME")) if (x[0]) return std::string(x) + "/kissmcmc_hip";
+    if (const char* h = std::getenv("HOME")) if (h[0]) return std::string(h) + "/.cache/kissmcmc_hip";
+    return std::string();
+}
+}  // namespace
+
+kmc_status kmc_host::rtc_compile_cached(const std::string& text, const char* program_name, int nheaders, const char* const* header_text,
+                                        const char* const* header_names, int nopts, const char* const* opts, std::vector<char>* code, std::string* log)
+{
+    // key
+    uint64_t h1 = 0xcbf29ce484222325ull, h2 = 0x84222325cbf29ce4ull;
+    auto mix = [&](const void* p, size_t n) { h1 = fnv1a(h1, p, n); h2 = fnv1a(h2 ^ (uint64_t)n, p, n); h2 = (h2 << 7) | (h2 >> 57); };
+    mix(text.data(), text.size());
+    for (int i = 0; i < nheaders; ++i) { mix(header_names[i], std::strlen(header_names[i])); mix(header_text[i], std::strlen(header_text[i])); }
+    for (int i = 0; i < nopts; ++i) mix(opts[i], std::strlen(opts[i]));
+    int vmaj = 0, vmin = 0;
+    (void)hiprtcVersion(&vmaj, &vmin);
+    mix(&vmaj, sizeof(vmaj)); mix(&vmin, sizeof(vmin));
+    int vrt = 0, vdrv = 0;                                  // ... and the runtime / driver builds (a patch update keeps hiprtc's major.minor)
+    if (hipRuntimeGetVersion(&vrt) != hipSuccess) (void)hipGetLastError();
+    if (hipDriverGetVersion(&vdrv) != hipSuccess) (void)hipGetLastError();
+    mix(&vrt, sizeof(vrt)); mix(&vdrv, sizeof(vdrv));
+    const std::string dir = rtc_cache_dir();
+    char name[64];
+    std::snprintf(name, sizeof(name), "/%016llx%016llx.co", (unsigned long long)h1, (unsigned long long)h2);
+    const std::string path = dir.empty() ? std::string() : dir + name;
+    if (!path.empty()) {
+        std::ifstream f(path, std::ios::binary | std::ios::ate);
+        if (f) {
+            const std::streamsize n = f.tellg();
+            if (n > 64) {
+                code->resize((size_t)n);
+                f.seekg(0);
+                const bool read_ok = f.read(code->data(), n) && f.gcount() == n;
+                const bool elf = read_ok && std::memcmp(code->data(), "\x7f" "ELF", 4) == 0;
+                const bool bundle = read_ok && std::memcmp(code->data(), "__CLANG_OFFLOAD_BUNDLE__", 24) == 0;
+                if (elf || bundle) return KMC_OK;                                       // a code object as hiprtc gave it
+            }
+            code->clear();
+        }
+    }
+    hiprtcProgram prog = nullptr;
+    if (hiprtcCreateProgram(&prog, text.c_str(), program_name, nheaders, const_cast<const char**>(header_text), const_cast<const char**>(header_names)) != HIPRTC_SUCCESS)
+        return fail(KMC_ERR_HIP, "hiprtcCreateProgram failed");
+    const hiprtcResult r = hiprtcCompileProgram(prog, nopts, const_cast<const char**>(opts));
+    if (r != HIPRTC_SUCCESS) {
+        size_t n = 0;
+        hiprtcGetProgramLogSize(prog, &n);
+        log->assign(n, '\0');
+        if (n) hiprtcGetProgramLog(prog, &(*log)[0]);
+        hiprtcDestroyProgram(&prog);
+        return KMC_ERR_BAD_ARG;                          // the caller words the message
+    }
+    size_t n = 0;
+    hiprtcGetCodeSize(prog, &n);
+    code->resize(n);
+    hiprtcGetCode(prog, code->data());
+    hiprtcDestroyProgram(&prog);
+    if (!path.empty()) {                                 // best effort: write beside, then rename (concurrent processes: last one wins, same bytes)
+        (void)::mkdir(dir.substr(0, dir.find_last_of('/')).c_str(), 0755);
+        (void)::mkdir(dir.c_str(), 0755);
+        char tmp[96];
+        std::snprintf(tmp, sizeof(tmp), ".tmp.%ld", (long)::getpid());
+        const std::string tpath = path + tmp;
+        std::ofstream o(tpath, std::ios::binary | std::ios::trunc);
+        if (o && o.write(code->data(), (std::streamsize)code->size()) && (o.close(), !o.fail())) {
+            if (std::rename(tpath.c_str(), path.c_str()) != 0) (void)std::remove(tpath.c_str());
+        } else {
+            (void)std::remove(tpath.c_str());
+        }
+    }
+    return KMC_OK;
+}
+
+namespace kmc_host {
+bool staged_possible(const kmc_user_density* ud, bool f32, int64_t ndim, bool p2p = false)
+{
+    const char* env = std::getenv("KMC_PLAN");
+    return ud->is_body && !f32 && !p2p && ndim >= 1 && ndim <= kStagedMaxDim && !(env && std::strcmp(env, "generic") == 0);
+}
+
+}  // namespace kmc_host
+std::string kmc_host::read_file(const std::string& path)
+{
+    std::ifstream f(path, std::ios::binary);
+    std::stringstream ss;
+    ss << f.rdbuf();
+    return ss.str();
+}
+
+namespace {
+// directory of this shared library (the kernel headers are shipped next to it in csrc/)
+std::string library_dir()
+{
+    Dl_info info;
+    if (dladdr(reinterpret_cast<void*>(&kmc_version), &info) && info.dli_fname) {
+        std::string p(info.dli_fname);
+        const size_t k = p.find_last_of('/');
+        return k == std::string::npos ? std::string(".") : p.substr(0, k);
+    }
+    return ".";
+}
+
+}  // namespace
+
+std::string kmc_host::user_density_alias(const kmc_user_density* ud, int64_t ndim)
+{
+    if (!ud->is_body) return "using UD = kmc::TermPairDensity<UserF>;\n";
+    return "using UD = kmc::BodyDensity<UserB, " + std::to_string(ndim > 0 ? ndim : 1) + ">;\n";
+}
+std::string kmc_host::user_functor_source(const kmc_user_density* ud)
+{
+    std::ostringstream src;
+    if (ud->is_body) {
+        src << "namespace {\nstruct UserB {\n"
+            << "  __device__ static double eval(const double* x, int n, const double* p) { (void)x; (void)n; (void)p;\n" << ud->body << "\n  }\n};\n}\n";
+        return src.str();
+    }
+    src << "namespace {\nstruct UserF {\n"
+        << "  static constexpr bool kHasPair = " << (ud->has_pair ? "true" : "false") << ";\n"
+        << "  __device__ static double term(double x, int d, int n, const double* p) { (void)d; (void)n; (void)p; return (" << ud->term << "); }\n"
+        << "  __device__ static double pair(double x, double y, int d, int n, const double* p) { (void)x; (void)y; (void)d; (void)n; (void)p; return ("
+        << (ud->has_pair ? ud->pair : std::string("0.0")) << "); }\n};\n}\n";
+    return src.str();
+}
+std::string kmc_host::user_header_dir()
+{
+    const char* envdir = std::getenv("KMC_CSRC_DIR");
+    return envdir ? std::string(envdir) : library_dir() + "/csrc";
+}
+
+namespace kmc_host {
+kmc_status compile_user(kmc_user_density* ud, bool with_vec, int L, int K, int iter, bool ragged,
+                        int resident_K, bool resident_ragged, int island_S, bool f32, const std::vector<char>** out, int64_t ndim = 0,
+                        bool p2p = false)
+{
+    // resident_K also sizes the island kernel (same row striping: 2 lanes per walker, K chunks)
+    if (ud->is_body && (with_vec || resident_K > 0 || island_S > 0))
+        return fail(KMC_ERR_UNSUPPORTED, "a body density runs in the one-walker-per-lane kernels only");
+    char key[112];
+    std::snprintf(key, sizeof(key), "%d:%d,%d,%d,%d|%d,%d|%d|%d|%lld|%d|%d", (int)with_vec, L, K, iter, (int)ragged, resident_K,
+                  (int)resident_ragged, island_S, (int)f32, ud->is_body ? (long long)ndim : 0ll, (int)staged_possible(ud, f32, ndim, p2p), (int)p2p);
+    const char* peer = p2p ? "true" : "false";         // KMC_P2P: partner rows read from their owners (pull)
+    const char* rowt = f32 ? "float" : "double";       // storage type of the walker rows (KMC_F32 / KMC_F64)
+    std::lock_guard<std::mutex> lock(ud->mu);
+    auto it = ud->code.find(key);
+    if (it != ud->code.end()) { *out = &it->second; return KMC_OK; }
+
+    const char* envdir = std::getenv("KMC_CSRC_DIR");
+    const std::string dir = envdir ? std::string(envdir) : library_dir() + "/csrc";
+    const std::string h_dev = read_file(dir + "/kmc_device.hpp"), h_ker = read_file(dir + "/kmc_kernels.hpp"),
+                      h_isl = read_file(dir + "/kmc_islands.hpp");
+    if (h_dev.empty() || h_ker.empty() || h_isl.empty())
+        return fail(KMC_ERR_BAD_ARG, "user density: kernel headers not found in " + dir + " (set KMC_CSRC_DIR)");
+
+    std::ostringstream src;
+    src << "#include \"kmc_islands.hpp\"\n" << user_functor_source(ud) << user_density_alias(ud, ndim)
+        << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_generic(KMC_FRONT_PARAMS, const kmc::HalfStepArgs a) { kmc::half_step_generic_body<UD, " << peer << ", " << rowt << ">(KMC_FRONT_PACK, a); }\n"
+        << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_logpdf(const kmc::LogpdfArgs a) { kmc::logpdf_rows_body<UD>(a); }\n"
+        << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_init_ball(const kmc::InitBallArgs a) { kmc::init_ball_body<UD>(a); }\n";
+    if (staged_possible(ud, f32, ndim, p2p))
+        src << "extern \"C\" __global__ __launch_bounds__(" << kStagedTPB << ") void kmc_user_staged(KMC_FRONT_PARAMS, const kmc::HalfStepArgs a) { kmc::half_step_staged_body<UD, "
+            << ndim << ">(KMC_FRONT_PACK, a); }\n";
+    if (with_vec)
+        src << "extern \"C\" __global__ __launch_bounds__(" << vec_tpb(L) << ") void kmc_user_vec(KMC_FRONT_PARAMS, const kmc::HalfStepArgs a) { kmc::half_step_vec_body<UD, "
+            << L << ", " << K << ", " << iter << ", " << peer << ", " << (ragged ? "true" : "false") << ", " << rowt << ">(KMC_FRONT_PACK, a); }\n";
+    if (resident_K > 0 && island_S == 0)
+        src << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_resident(const kmc::ResidentArgs a) { kmc::resident_body<UD, "
+            << resident_K << ", " << (resident_ragged ? "true" : "false") << ">(a); }\n";
+    if (resident_K > 0 && island_S > 0)
+        src << "extern \"C\" __global__ __launch_bounds__(" << island_S << ") void kmc_user_island(const kmc::IslandArgs a) { kmc::island_epoch_body<UD, "
+            << island_S << ", " << resident_K << ", " << (resident_ragged ? "true" : "false") << ">(a); }\n";
+    const std::string text = src.str();
+
+    const char* headers[3] = {h_ker.c_str(), h_dev.c_str(), h_isl.c_str()};
+    const char* names[3] = {"kmc_kernels.hpp", "kmc_device.hpp", "kmc_islands.hpp"};
+    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-mllvm", "-amdgpu-kernarg-preload-count=14"};
+    std::vector<char> code;
+    std::string log;
+    const kmc_status cst = rtc_compile_cached(text, "kmc_user_density.hip", 3, headers, names, 6, opts, &code, &log);
+    if (cst == KMC_ERR_BAD_ARG) return fail(KMC_ERR_BAD_ARG, "user density does not compile:\n" + log);
+    if (cst != KMC_OK) return cst;
+    auto ins = ud->code.emplace(key, std::move(code));
+    *out = &ins.first->second;
+    return KMC_OK;
+}
+
+kmc_status load_user(kmc_user_density* ud, bool with_vec, int L, int K, int iter, bool ragged, UserKernels* uk,
+                     int resident_K, bool resident_ragged, int island_S, bool f32, int64_t ndim, bool p2p)
+{
+    const std::vector<char>* code = nullptr;
+    KMC_TRY(compile_user(ud, with_vec, L, K, iter, ragged, resident_K, resident_ragged, island_S, f32, &code, ndim, p2p));
+    HIP_TRY(hipModuleLoadData(&uk->mod, code->data()));
+    HIP_TRY(hipModuleGetFunction(&uk->generic, uk->mod, "kmc_user_generic"));
+    HIP_TRY(hipModuleGetFunction(&uk->logpdf, uk->mod, "kmc_user_logpdf"));
+    HIP_TRY(hipModuleGetFunction(&uk->init_ball, uk->mod, "kmc_user_init_ball"));
+    if (with_vec) HIP_TRY(hipModuleGetFunction(&uk->vec, uk->mod, "kmc_user_vec"));
+    if (staged_possible(ud, f32, ndim, p2p)) HIP_TRY(hipModuleGetFunction(&uk->staged, uk->mod, "kmc_user_staged"));
+    if (resident_K > 0 && island_S == 0) HIP_TRY(hipModuleGetFunction(&uk->resident, uk->mod, "kmc_user_resident"));
+    if (resident_K > 0 && island_S > 0) HIP_TRY(hipModuleGetFunction(&uk->island, uk->mod, "kmc_user_island"));
+    return KMC_OK;
+}
+
+}  // namespace kmc_host
+KMC_EXPORT kmc_status kmc_user_density_create(const char* term_expr, const char* pair_expr, kmc_user_density** out)
+{
+    if (!term_expr || !out) return fail(KMC_ERR_BAD_ARG, "null argument");
+    *out = nullptr;
+    kmc_user_density* ud = new kmc_user_density();
+    ud->term = term_expr;
+    ud->has_pair = pair_expr != nullptr && pair_expr[0] != '\0';
+    if (ud->has_pair) ud->pair = pair_expr;
+    const std::vector<char>* code = nullptr;
+    const kmc_status st = compile_user(ud, false, 0, 0, 0, false, 0, false, 0, false, &code);   // syntax check now, not at first use
+    if (st != KMC_OK) { delete ud; return st; }
+    *out = ud;
+    return KMC_OK;
+}
+
+KMC_EXPORT kmc_status kmc_user_density_create_body(const char* body, kmc_user_density** out)
+{
+    if (!body || !out) return fail(KMC_ERR_BAD_ARG, "null argument");
+    *out = nullptr;
+    kmc_user_density* ud = new kmc_user_density();
+    ud->body = body;
+    ud->is_body = true;
+    const std::vector<char>* code = nullptr;
+    const kmc_status st = compile_user(ud, false, 0, 0, 0, false, 0, false, 0, false, &code, 4);   // syntax check now (any ndim)
+    if (st != KMC_OK) { delete ud; return st; }
+    *out = ud;
+    return KMC_OK;
+}
+
+KMC_EXPORT void kmc_user_density_destroy(kmc_user_density* ud) { delete ud; }
+

@@ -1,0 +1,782 @@
+// kmc_sampler.hip -- the sampler's lifecycle behind the C ABI (include/kissmcmc_hip.h): validation of a configuration
+// (the reference's asserts, src/samplers.jl:200-205), the launch plan per ndim, creation / destruction of the device state of
+// the `emcee` front-end (src/samplers.jl:188-216), and the description of how a sampler executes.
+// The generation loop (src/samplers.jl:232-293) is kmc_launch.hip; state in and out is kmc_state.hip; copies and the chain
+// ring are kmc_copy.hip; runtime-compiled densities kmc_rtc.hip; multi-GPU wiring kmc_p2p.hip; diagnostics kmc_diag.hip.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <sstream>
+
+#include "kmc_sampler.hpp"
+
+using namespace kmc;
+using namespace kmc_host;
+
+thread_local std::string kmc_host::g_err;
+
+bool kmc_host::lookup(int density, int L, int K, int iter, bool p2p, bool ragged, bool f32, HalfStepFn* vec, HalfStepFn* gen, LogpdfFn* lp)
+{
+    switch (density) {
+    case KMC_GAUSSIAN_ISO: table_gaussian_iso(L, K, iter, p2p, ragged, f32, vec, gen, lp); return true;
+    case KMC_EXPONENTIAL: table_exponential(L, K, iter, p2p, ragged, f32, vec, gen, lp); return true;
+    case KMC_ROSENBROCK: table_rosenbrock(L, K, iter, p2p, ragged, f32, vec, gen, lp); return true;
+    case KMC_LOGNORMAL: table_lognormal(L, K, iter, p2p, ragged, f32, vec, gen, lp); return true;
+    case KMC_MVNORMAL2: table_mvnormal2(L, K, iter, p2p, ragged, f32, vec, gen, lp); return true;
+    default: return false;
+    }
+}
+
+namespace kmc_host {
+IslandFn island_fn(int density, int S, int K, bool ragged)
+{
+    switch (density) {
+    case KMC_GAUSSIAN_ISO: return island_gaussian_iso(S, K, ragged);
+    case KMC_EXPONENTIAL: return island_exponential(S, K, ragged);
+    case KMC_ROSENBROCK: return island_rosenbrock(S, K, ragged);
+    case KMC_LOGNORMAL: return island_lognormal(S, K, ragged);
+    case KMC_MVNORMAL2: return island_mvnormal2(S, K, ragged);
+    default: return nullptr;
+    }
+}
+
+ResidentFn resident_fn(int density, int tpb, int K, bool ragged)
+{
+    switch (density) {
+    case KMC_GAUSSIAN_ISO: return resident_gaussian_iso(tpb, K, ragged);
+    case KMC_EXPONENTIAL: return resident_exponential(tpb, K, ragged);
+    case KMC_ROSENBROCK: return resident_rosenbrock(tpb, K, ragged);
+    case KMC_LOGNORMAL: return resident_lognormal(tpb, K, ragged);
+    case KMC_MVNORMAL2: return resident_mvnormal2(tpb, K, ragged);
+    default: return nullptr;
+    }
+}
+
+InitBallFn init_ball_fn(int density)
+{
+    switch (density) {
+    case KMC_GAUSSIAN_ISO: return init_ball_gaussian_iso();
+    case KMC_EXPONENTIAL: return init_ball_exponential();
+    case KMC_ROSENBROCK: return init_ball_rosenbrock();
+    case KMC_LOGNORMAL: return init_ball_lognormal();
+    case KMC_MVNORMAL2: return init_ball_mvnormal2();
+    default: return nullptr;
+    }
+}
+
+// Philox4x32-10 on the host (only for the island deal; Salmon et al., SC'11).
+void philox_host(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c0 = n0; c1 = (uint32_t)p1; c2 = n2; c3 = (uint32_t)p0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// The deal of epoch e: slot s holds walker (A*s + C) mod N.  Epoch 0 is the identity; later epochs
+// take A (made coprime to N by stepping upwards) and C from Philox(ctr = {e, "ISLA", 0}, key = seed).
+void island_perm(uint64_t seed, int64_t epoch, int64_t N, int64_t* A, int64_t* C)
+{
+    if (epoch == 0 || N <= 2) { *A = 1; *C = 0; return; }
+    const uint32_t ctr[4] = {(uint32_t)epoch, (uint32_t)((uint64_t)epoch >> 32), 0x49534c41u, 0u};
+    const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    uint32_t w[4];
+    philox_host(ctr, key, w);
+    auto gcd = [](int64_t a, int64_t b) { while (b) { const int64_t t = a % b; a = b; b = t; } return a; };
+    int64_t a = (int64_t)((((uint64_t)w[0] << 32) | w[1]) % (uint64_t)N);
+    if (a < 1) a = 1;
+    while (gcd(a, N) != 1) a = (a % N + 1 >= N) ? 1 : a + 1;
+    *A = a;
+    *C = (int64_t)((((uint64_t)w[2] << 32) | w[3]) % (uint64_t)N);
+}
+
+// Dealt sub-ensembles (kmc_config.deal_count): the Philox key of sub-ensemble r, and the affine shuffle (A, C) its S
+// slots go through before the deal of `epoch` (A coprime to S) -- from Philox(ctr = {epoch, "DEAL", r}, key = seed).
+constexpr uint64_t kDealSeedStride = 0x9E3779B97F4A7C15ull;
+uint64_t deal_seed(uint64_t seed, int32_t rank) { return seed + (uint64_t)(rank + 1) * kDealSeedStride; }
+void deal_perm(uint64_t seed, int64_t epoch, int32_t rank, int64_t S, int64_t* A, int64_t* C)
+{
+    const uint32_t ctr[4] = {(uint32_t)epoch, (uint32_t)((uint64_t)epoch >> 32), 0x4445414cu, (uint32_t)rank};
+    const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    uint32_t w[4];
+    philox_host(ctr, key, w);
+    auto gcd = [](int64_t a, int64_t b) { while (b) { const int64_t t = a % b; a = b; b = t; } return a; };
+    int64_t a = (int64_t)((((uint64_t)w[0] << 32) | w[1]) % (uint64_t)S);
+    if (a < 1) a = 1;
+    while (gcd(a, S) != 1) a = (a + 1 >= S) ? 1 : a + 1;
+    *A = a;
+    *C = (int64_t)((((uint64_t)w[2] << 32) | w[3]) % (uint64_t)S);
+}
+
+// Default geometry per ndim; KMC_PLAN="L,K,ITER" (or "generic") overrides for tuning.
+Plan make_plan(const kmc_config& c, int64_t n_active)
+{
+    Plan p;
+    HalfStepFn vec = nullptr, gen = nullptr;
+    LogpdfFn lp = nullptr;
+    int L = 0, K = 0, iter = 1;
+    const char* env = std::getenv("KMC_PLAN");
+    bool force_generic = false;
+    if (env && std::strcmp(env, "generic") == 0) force_generic = true;
+    else if (env && std::sscanf(env, "%d,%d,%d", &L, &K, &iter) == 3) { /* forced */ }
+    else {
+        L = 0;
+        // a row = ceil(ndim/2) 16-byte chunks, striped over L lanes x K chunks (2*L*K >= ndim; the
+        // ragged tail is masked).  Measured on MI355X (scripts/quick_bench.py): 4 lanes x 2 chunks
+        // per 64 B of row is the sweet spot.
+        const int64_t chunks = (c.ndim + 1) / 2;
+        auto pow2ceil = [](int64_t v) { int p = 1; while (p < v) p <<= 1; return p; };
+        if (chunks <= 4) { L = pow2ceil(chunks); K = 1; }
+        else if (chunks <= 128) { L = pow2ceil((chunks + 1) / 2); K = 2; }
+        else if (chunks <= 256) { L = 64; K = 4; }
+        else if (chunks <= 512) { L = 64; K = 8; }
+        // walkers per group (ITER): two amortise the per-walker scalar work (Philox, two logs) over
+        // the wave -- once that still leaves 1.5 waves per SIMD (measured: 2048 single-walker waves run 3-6 % faster
+        // as they are, C3 and 32 768 x 32; 3072 and more are faster paired); more only while the grid keeps >= 4096
+        // waves (large ensembles)
+        iter = 1;
+        if (L > 0) {
+            const int64_t waves1 = n_active * L / 64;
+            if (2 <= L && 2 * K <= 16 && waves1 >= 3072) iter = 2;
+            while (iter >= 2 && iter * 2 <= L && iter * 2 * K <= 16 && waves1 / (iter * 2) >= 4096 && iter < 16) iter *= 2;
+        }
+    }
+    const bool ragged = L > 0 && 2 * L * K != c.ndim;
+    const bool f32 = c.dtype == KMC_F32;
+    if ((ragged || f32) && iter > 4) iter = 4;
+    if ((c.flags & KMC_P2P) && iter > 8) iter = 8;
+    p.ragged = ragged;
+    if (c.density == KMC_HOST_DENSITY) {
+        // bound by the host callback: the one-walker-per-lane kernel, any ndim
+        p.fn = half_step_host(); p.vec = false; p.ragged = false; p.L = 1; p.K = 1; p.ITER = 1;
+        return p;
+    }
+    if (c.density == KMC_USER_DENSITY) {
+        // kernels are compiled for exactly this geometry when the sampler is created
+        const bool body = c.user_density && static_cast<const kmc_user_density*>(c.user_density)->is_body;   // one walker per lane
+        if (!body && !force_generic && L > 0 && 2 * L * K >= c.ndim && iter <= L && iter * K <= 16) {
+            p.vec = true; p.L = L; p.K = K; p.ITER = iter;
+        } else {
+            p.vec = false; p.L = 1; p.K = 1; p.ITER = 1;
+        }
+        return p;
+    }
+    lookup(c.density, L, K, iter, (c.flags & KMC_P2P) != 0, ragged, f32, &vec, &gen, &lp);
+    if (!force_generic && L > 0 && 2 * L * K >= c.ndim && vec != nullptr) {
+        p.fn = vec; p.vec = true; p.L = L; p.K = K; p.ITER = iter;
+    } else {
+        p.fn = gen; p.vec = false; p.L = 1; p.K = 1; p.ITER = 1;
+    }
+    return p;
+}
+
+}  // namespace kmc_host
+kmc_status kmc_host::digest_params(const kmc_config& c, DensityParams* dp)
+{
+    for (double& v : dp->p) v = 0.0;
+    dp->ndim = (int32_t)c.ndim;
+    dp->pad_ = 0;
+    const double* p = c.params;
+    switch (c.density) {
+    case KMC_USER_DENSITY:
+        if (!c.user_density) return fail(KMC_ERR_BAD_ARG, "KMC_USER_DENSITY needs kmc_config.user_density");
+        for (int i = 0; i < 6; ++i) dp->p[i] = p[i];
+        return KMC_OK;
+    case KMC_HOST_DENSITY:
+        return KMC_OK;
+    case KMC_GAUSSIAN_ISO:
+        if (!(p[1] > 0.0)) return fail(KMC_ERR_BAD_ARG, "gaussian: sigma must be > 0");
+        dp->p[0] = p[0]; dp->p[1] = 1.0 / p[1];
+        return KMC_OK;
+    case KMC_EXPONENTIAL:
+        if (!(p[0] > 0.0)) return fail(KMC_ERR_BAD_ARG, "exponential: rate must be > 0");
+        dp->p[0] = p[0];
+        return KMC_OK;
+    case KMC_ROSENBROCK:
+        if (!(p[2] > 0.0)) return fail(KMC_ERR_BAD_ARG, "rosenbrock: scale must be > 0");
+        dp->p[0] = p[0]; dp->p[1] = p[1]; dp->p[2] = 1.0 / p[2];
+        return KMC_OK;
+    case KMC_LOGNORMAL:
+        if (!(p[1] > 0.0)) return fail(KMC_ERR_BAD_ARG, "lognormal: sigma must be > 0");
+        dp->p[0] = p[0]; dp->p[1] = p[1];
+        return KMC_OK;
+    case KMC_MVNORMAL2:
+        for (int i = 0; i < 5; ++i) dp->p[i] = p[i];
+        return KMC_OK;
+    default:
+        return fail(KMC_ERR_BAD_ARG, "unknown density id");
+    }
+}
+
+KMC_EXPORT int kmc_version(void) { return KMC_VERSION; }
+
+KMC_EXPORT int kmc_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+KMC_EXPORT const char* kmc_last_error(void) { return g_err.c_str(); }
+
+KMC_EXPORT const char* kmc_status_string(kmc_status st)
+{
+    switch (st) {
+    case KMC_OK: return "ok";
+    case KMC_ERR_A_SCALE: return "a_scale must be > 1";
+    case KMC_ERR_ODD_WALKERS: return "Use an even number of walkers.";
+    case KMC_ERR_TOO_FEW_WALKERS: return "Use more walkers: at least DOF+2, but better many more.";
+    case KMC_ERR_BAD_ARG: return "bad argument";
+    case KMC_ERR_NONFINITE_LOGP: return "initial walker with non-finite log-pdf";
+    case KMC_ERR_HIP: return "HIP runtime error";
+    case KMC_ERR_OOM: return "out of device memory";
+    case KMC_ERR_NO_DEVICE: return "no HIP device";
+    case KMC_ERR_UNSUPPORTED: return "unsupported configuration";
+    }
+    return "unknown status";
+}
+
+// src/samplers.jl:200-205
+KMC_EXPORT kmc_status kmc_validate(const kmc_config* c)
+{
+    if (!c) return fail(KMC_ERR_BAD_ARG, "null config");
+    if (c->nwalkers <= 0 || c->ndim <= 0 || c->nthin <= 0 || c->ngenerations < 0 || c->nburnin < 0)
+        return fail(KMC_ERR_BAD_ARG, "nwalkers, ndim, nthin must be > 0 and ngenerations, nburnin >= 0");
+    if (!(c->a_scale > 1.0)) return fail(KMC_ERR_A_SCALE, kmc_status_string(KMC_ERR_A_SCALE));
+    if (c->nwalkers % 2 != 0) return fail(KMC_ERR_ODD_WALKERS, kmc_status_string(KMC_ERR_ODD_WALKERS));
+    if (c->nwalkers < c->ndim + 2) return fail(KMC_ERR_TOO_FEW_WALKERS, kmc_status_string(KMC_ERR_TOO_FEW_WALKERS));
+    if (c->nwalkers >= (int64_t)1 << 31 || c->ndim >= (int64_t)1 << 24)
+        return fail(KMC_ERR_UNSUPPORTED, "ensemble too large");
+    if (c->ngenerations >= (int64_t)1 << 31) return fail(KMC_ERR_UNSUPPORTED, "at most 2^31 - 1 generations (the step index is 32 bits)");
+    if (c->density == KMC_USER_DENSITY && !c->user_density) return fail(KMC_ERR_BAD_ARG, "KMC_USER_DENSITY needs kmc_config.user_density");
+    if (c->density == KMC_HOST_DENSITY) {
+        if (!c->host_logpdf) return fail(KMC_ERR_BAD_ARG, "KMC_HOST_DENSITY needs kmc_config.host_logpdf");
+        if ((c->flags & (KMC_P2P | KMC_ISLANDS)) || c->shard_count > 1)
+            return fail(KMC_ERR_UNSUPPORTED, "KMC_HOST_DENSITY runs on one GPU, without KMC_P2P / KMC_ISLANDS / sharding");
+    }
+    if (c->dtype != KMC_F64 && c->dtype != KMC_F32) return fail(KMC_ERR_UNSUPPORTED, "dtype must be KMC_F64 or KMC_F32");
+    if (c->dtype == KMC_F32) {
+        if ((c->flags & (KMC_P2P | KMC_ISLANDS)) || c->shard_count > 1)
+            return fail(KMC_ERR_UNSUPPORTED, "KMC_F32 rows: one GPU, without KMC_P2P / KMC_ISLANDS / sharding");
+        if (c->density == KMC_HOST_DENSITY)
+            return fail(KMC_ERR_UNSUPPORTED, "KMC_F32 rows: densities evaluated on the device only (built-in or runtime-compiled)");
+    }
+    if (c->host_accepted && c->density != KMC_HOST_DENSITY) return fail(KMC_ERR_BAD_ARG, "kmc_config.host_accepted needs KMC_HOST_DENSITY");
+    if (c->density == KMC_ROSENBROCK && c->ndim < 2) return fail(KMC_ERR_BAD_ARG, "rosenbrock needs ndim >= 2");
+    if (c->density == KMC_MVNORMAL2 && c->ndim != 2) return fail(KMC_ERR_BAD_ARG, "mvnormal2 needs ndim == 2");
+    const int P = c->shard_count <= 0 ? 1 : c->shard_count;
+    if (c->shard_rank < 0 || c->shard_rank >= P) return fail(KMC_ERR_BAD_ARG, "shard_rank out of range");
+    if ((c->nwalkers / 2) % P != 0) return fail(KMC_ERR_BAD_ARG, "nwalkers/2 must be divisible by shard_count");
+    if ((c->flags & KMC_P2P) && P > 8) return fail(KMC_ERR_UNSUPPORTED, "KMC_P2P supports at most 8 shards (one node)");
+    if (c->flags & KMC_ISLANDS) {
+        const int64_t S = c->island_size > 0 ? c->island_size : kIslandSizeDefault;
+        if ((S != 64 && S != 128 && S != 256) || c->nwalkers % S != 0 || c->ndim > 32 || c->ndim + 2 > S || P != 1 ||
+            (c->flags & (KMC_P2P | KMC_STORE_CHAIN | KMC_STORE_LOGP)) || c->island_gens < 0)
+            return fail(KMC_ERR_UNSUPPORTED, "KMC_ISLANDS needs island_size in {64,128,256} >= ndim+2 dividing nwalkers, ndim <= 32, one shard and no chain storage");
+        if (c->density == KMC_USER_DENSITY && (size_t)S * (size_t)(2 * c->ndim + 9) * sizeof(double) > 60 * 1024)
+            return fail(KMC_ERR_UNSUPPORTED, "KMC_ISLANDS with a user density: island_size * (ndim + 3) * 8 must stay below 60 KiB (use island_size 128 or 64)");
+    }
+    if (c->flags & KMC_STREAM_CHAIN) {
+        if (!(c->flags & (KMC_STORE_CHAIN | KMC_STORE_LOGP))) return fail(KMC_ERR_BAD_ARG, "KMC_STREAM_CHAIN needs KMC_STORE_CHAIN and / or KMC_STORE_LOGP");
+        if (c->dtype != KMC_F64 || P != 1 || (c->flags & (KMC_P2P | KMC_ISLANDS)))
+            return fail(KMC_ERR_UNSUPPORTED, "KMC_STREAM_CHAIN: KMC_F64, one GPU, without KMC_P2P / KMC_ISLANDS / sharding");
+    }
+    if (c->deal_count < 0 || (c->deal_count > 0 && (c->deal_rank < 0 || c->deal_rank >= c->deal_count)))
+        return fail(KMC_ERR_BAD_ARG, "deal_rank / deal_count out of range");
+    if (c->deal_count > 0) {
+        // (a stored chain is by SLOT: which walker a slot held when a sample was taken follows from kmc_deal_perm, distributed.py)
+        if (P != 1 || (c->flags & (KMC_P2P | KMC_ISLANDS | KMC_STREAM_CHAIN)) || c->dtype != KMC_F64 || c->density == KMC_HOST_DENSITY)
+            return fail(KMC_ERR_UNSUPPORTED, "dealt sub-ensembles: KMC_F64, a device density, one shard, no KMC_P2P / KMC_ISLANDS / KMC_STREAM_CHAIN");
+        if (c->nwalkers % c->deal_count != 0)
+            return fail(KMC_ERR_BAD_ARG, "dealt sub-ensembles: nwalkers (this sub-ensemble's size) must be divisible by deal_count");
+        if (c->nwalkers * (int64_t)c->deal_count >= (int64_t)1 << 32) return fail(KMC_ERR_UNSUPPORTED, "dealt sub-ensembles: at most 2^32 - 1 walkers in all");
+    }
+    DensityParams dp;
+    return digest_params(*c, &dp);
+}
+
+KMC_EXPORT double kmc_g_pdf(double z, double a)   // src/samplers.jl:224
+{
+    return (1.0 / a <= z && z <= a) ? 1.0 / std::sqrt(z) * 1.0 / (2.0 * (std::sqrt(a) - std::sqrt(1.0 / a))) : 0.0;
+}
+
+KMC_EXPORT double kmc_cdf_g_inv(double u, double a)   // src/samplers.jl:227
+{
+    const double t = std::fma(u, std::sqrt(a) - std::sqrt(1.0 / a), std::sqrt(1.0 / a));
+    return t * t;
+}
+
+// hipMalloc does not clear memory.  KMC_POISON=1 (diagnostics): every allocation of a sampler starts as 0xFF bytes (NaN doubles,
+// 4 294 967 295 counters), so that anything the code forgot to initialise shows up in the tests instead of depending on what the
+// allocator happened to return.
+// ... and is followed by a 4 KiB guard of 0xA5 that kmc_sampler_destroy checks: a kernel that writes past the end of one of
+// its buffers aborts the process there, with the size of the allocation (the tests then fail loudly).
+template <class T>
+hipError_t dev_alloc(kmc_sampler* s, T** p, size_t bytes)
+{
+    static const bool poison = std::getenv("KMC_POISON") != nullptr;
+    if (!poison || bytes == 0) return hipMalloc(reinterpret_cast<void**>(p), bytes);
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(p), bytes + kGuardBytes);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(*p, 0xFF, bytes, s->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(reinterpret_cast<char*>(*p) + bytes, 0xA5, kGuardBytes, s->stream);
+    s->guards.emplace_back(reinterpret_cast<char*>(*p) + bytes, bytes);
+    return e;
+}
+
+KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** out)
+{
+    if (!out) return fail(KMC_ERR_BAD_ARG, "null out");
+    *out = nullptr;
+    KMC_TRY(kmc_validate(cfg));
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        (void)hipGetLastError();
+        return fail(KMC_ERR_NO_DEVICE, "no HIP device visible: the emcee hot path has no CPU fallback");
+    }
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(KMC_ERR_BAD_ARG, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(cfg->device));
+
+    kmc_sampler* s = new kmc_sampler();
+    s->cfg = *cfg;
+    s->user_seed = cfg->seed;
+    if (cfg->deal_count > 0) s->cfg.seed = deal_seed(cfg->seed, cfg->deal_rank);    // this sub-ensemble's Philox key
+    if (s->cfg.shard_count <= 0) s->cfg.shard_count = 1;
+    s->h = cfg->nwalkers / 2;
+    s->h_loc = s->h / s->cfg.shard_count;
+    s->active_begin = s->h_loc * s->cfg.shard_rank;
+    s->nlocal = 2 * s->h_loc;
+    s->nsamples = cfg->ngenerations > cfg->nburnin ? (cfg->ngenerations - cfg->nburnin) / cfg->nthin : 0;   // :234
+    s->ld = cfg->ndim + (cfg->ndim & 1);      // whole two-element chunks: 16-byte aligned double rows, 8-byte aligned float rows
+    s->f32 = cfg->dtype == KMC_F32;
+    kmc_status st = digest_params(*cfg, &s->dp);
+    if (st != KMC_OK) { delete s; return st; }
+    s->plan = make_plan(s->cfg, s->h_loc);
+    if (cfg->density == KMC_USER_DENSITY) {
+        s->user = static_cast<kmc_user_density*>(cfg->user_density);
+        // small ensembles: resident mode too (one workgroup, LDS within the default 64 KiB limit)
+        int rK = 0, rK0 = 1;
+        while (2 * rK0 < s->ld / 2) rK0 *= 2;
+        const size_t rlds = ((size_t)cfg->nwalkers * (size_t)(4 * (rK0 + 1)) + (size_t)cfg->nwalkers) * sizeof(double);
+        if (!s->user->is_body && !s->f32 && cfg->nwalkers <= 256 && cfg->ndim <= 32 && s->cfg.shard_count == 1 && !(cfg->flags & (KMC_P2P | KMC_NO_GRAPH | KMC_ISLANDS | KMC_STREAM_CHAIN)) &&
+            rlds <= 60 * 1024 && std::getenv("KMC_NO_RESIDENT") == nullptr)
+            rK = rK0;
+        int iS = 0;
+        if (cfg->flags & KMC_ISLANDS) {
+            iS = cfg->island_size > 0 ? cfg->island_size : kIslandSizeDefault;
+            rK = 1;
+            while (2 * rK < s->ld / 2) rK *= 2;
+        }
+        if (s->user->is_body && iS > 0) { kmc_sampler_destroy(s); return fail(KMC_ERR_UNSUPPORTED, "KMC_ISLANDS needs a menu or term / pair density (a body density runs one walker per lane)"); }
+        if (s->user->is_body && cfg->ndim > 1024) { kmc_sampler_destroy(s); return fail(KMC_ERR_UNSUPPORTED, "a body density holds the proposal per lane: ndim <= 1024"); }
+        st = load_user(s->user, s->plan.vec, s->plan.L, s->plan.K, s->plan.ITER, s->plan.ragged, &s->uk, rK, 4 * rK != cfg->ndim, iS, s->f32, cfg->ndim, (cfg->flags & KMC_P2P) != 0);
+        if (st != KMC_OK) { kmc_sampler_destroy(s); return st; }
+        if (iS > 0) rK = 0;     // island mode is set up below, not resident mode
+        if (rK > 0) {
+            s->resident = true;
+            s->island_K = rK;
+            s->nislands = 1;
+            s->island_lds = rlds < 4096 ? 4096 : rlds;
+        }
+    } else if (cfg->density == KMC_HOST_DENSITY) {
+        s->host_eval = true;
+    } else {
+        HalfStepFn v, g;
+        lookup(cfg->density, 0, 0, 1, false, false, false, &v, &g, &s->logpdf_fn);
+    }
+    // vec: a wave owns W = (64/L)*ITER walkers; generic: one walker per lane
+    const int64_t per_wave = s->plan.vec ? (int64_t)(64 / s->plan.L) * s->plan.ITER : 64;
+    const int64_t waves = (s->h_loc + per_wave - 1) / per_wave;
+    if (cfg->flags & KMC_ISLANDS) {
+        s->islands = true;
+        s->island_gens = cfg->island_gens > 0 ? cfg->island_gens : 32;
+        s->island_size = cfg->island_size > 0 ? cfg->island_size : kIslandSizeDefault;
+        s->nislands = cfg->nwalkers / s->island_size;
+        const int64_t chunks = s->ld / 2;                   // 16-byte chunks per row, 2 lanes per walker
+        int K = 1;
+        while (2 * K < chunks) K *= 2;
+        s->island_K = K;
+        s->island_ragged = 4 * K != cfg->ndim;
+        s->island_lds = ((size_t)s->island_size * (size_t)(4 * (K + 1)) + (size_t)s->island_size) * sizeof(double);
+        if (s->island_lds < 4096) s->island_lds = 4096;          // the moment reduction reuses the buffer
+        hipError_t ea = hipSuccess;
+        if (!s->user) {
+            s->island_kernel = island_fn(cfg->density, (int)s->island_size, K, s->island_ragged);
+            if (!s->island_kernel) { kmc_sampler_destroy(s); return fail(KMC_ERR_UNSUPPORTED, "no island kernel for this density / ndim"); }
+            ea = hipFuncSetAttribute(reinterpret_cast<const void*>(s->island_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->island_lds);
+        }
+        if (ea != hipSuccess) { (void)hipGetLastError(); kmc_sampler_destroy(s); return fail(KMC_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(ea)); }
+    }
+    if (!s->islands && !s->f32 && cfg->density != KMC_USER_DENSITY && !s->host_eval && cfg->nwalkers <= 1024 && cfg->ndim <= 32 &&
+        s->cfg.shard_count == 1 && !(cfg->flags & (KMC_P2P | KMC_NO_GRAPH | KMC_STREAM_CHAIN)) && std::getenv("KMC_NO_RESIDENT") == nullptr) {
+        const int64_t chunks = s->ld / 2;
+        int K = 1;
+        while (2 * K < chunks) K *= 2;
+        const int rtpb = cfg->nwalkers <= 256 ? 256 : (cfg->nwalkers <= 512 ? 512 : 1024);
+        const size_t need = ((size_t)cfg->nwalkers * (size_t)(4 * (K + 1)) + (size_t)cfg->nwalkers) * sizeof(double);
+        ResidentFn rf = need <= 156 * 1024 ? resident_fn(cfg->density, rtpb, K, 4 * K != cfg->ndim) : nullptr;
+        if (rf) {
+            s->resident_tpb = rtpb;
+            s->island_lds = need;
+            if (s->island_lds < 8192) s->island_lds = 8192;     // the moment reduction reuses the buffer
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(rf), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)s->island_lds) == hipSuccess) {
+                s->resident = true;
+                s->resident_kernel = rf;
+                s->island_K = K;
+                s->nislands = 1;
+            } else {
+                (void)hipGetLastError();
+            }
+        }
+    }
+    // vec kernels: vec_tpb(L) threads per workgroup; the generic kernel keeps 256
+    const bool staged = s->user && s->uk.staged != nullptr;         // a body density's staged kernel: two waves per workgroup
+    const int tpb = s->plan.vec ? vec_tpb(s->plan.L) : (staged ? kStagedTPB : 256);
+    s->tpb = tpb;
+    s->grid = (int)((waves * 64 + tpb - 1) / tpb);
+    s->macc_stride = (int64_t)s->grid * tpb;
+    s->macc_elems = s->plan.vec ? s->macc_stride * 2 * s->plan.K : s->macc_stride * cfg->ndim;
+
+#define CREATE_TRY(expr)                                                                       \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            (void)hipGetLastError();                                                           \
+            kmc_status r_ = fail(e_ == hipErrorOutOfMemory ? KMC_ERR_OOM : KMC_ERR_HIP,        \
+                                 std::string(#expr) + ": " + hipGetErrorString(e_));           \
+            kmc_sampler_destroy(s);                                                            \
+            return r_;                                                                         \
+        }                                                                                      \
+    } while (0)
+
+    CREATE_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    s->own_stream = true;
+    CREATE_TRY(hipEventCreate(&s->ev0));
+    CREATE_TRY(hipEventCreate(&s->ev1));
+    s->p2p = (cfg->flags & KMC_P2P) != 0;
+    s->nrows = s->p2p ? s->nlocal : cfg->nwalkers;
+    const size_t nw = (size_t)s->nrows;
+    if (s->p2p) {
+        CREATE_TRY(hipExtMallocWithFlags((void**)&s->d_flags, 4096, hipDeviceMallocFinegrained));
+        CREATE_TRY(hipMemsetAsync(s->d_flags, 0, 4096, s->stream));
+        CREATE_TRY(dev_alloc(s, (void**)&s->d_err, 64));
+        CREATE_TRY(hipMemsetAsync(s->d_err, 0, 64, s->stream));
+        CREATE_TRY(dev_alloc(s, (void**)&s->d_done, 33 * 64));
+        CREATE_TRY(hipMemsetAsync(s->d_done, 0, 33 * 64, s->stream));
+        // the kernel can publish its own completion only where all its stores are write-through: the vector kernels
+        s->fold_signal = (cfg->flags & KMC_P2P_FOLD_SIGNAL) != 0 && s->plan.vec && s->user == nullptr;
+        s->push = (cfg->flags & (KMC_P2P_PUSH | KMC_P2P_LAZY)) != 0 && s->plan.vec && s->user == nullptr && !(cfg->flags & KMC_P2P_FINEGRAINED) &&
+                  s->cfg.shard_count > 1;
+        s->lazy = s->push && (cfg->flags & KMC_P2P_LAZY) != 0 && s->h_loc % 16 == 0 && !s->f32;
+        if (const char* e = std::getenv("KMC_P2P_STATS")) s->lazy_stats = s->lazy && e[0] == '1';
+    }
+    // KMC_P2P_LAZY: room for every rank's accept-byte maps behind the row blocks (peers write them: same allocation)
+    const size_t amap_bytes = s->lazy ? (size_t)s->cfg.shard_count * 4 * (size_t)s->h_loc : 0;
+    const size_t ldz = (size_t)s->ld;
+    const size_t esz = s->f32 ? sizeof(float) : sizeof(double);      // element size of rows and chain
+    if (s->p2p && (cfg->flags & KMC_P2P_FINEGRAINED))   // peers map the rows uncached: nothing of them can go stale in a reader's L2
+        CREATE_TRY(hipExtMallocWithFlags((void**)&s->d_pos, nw * ldz * sizeof(double), hipDeviceMallocFinegrained));
+    else
+        CREATE_TRY(dev_alloc(s, &s->d_pos, (s->push ? 1 + (size_t)s->cfg.shard_count : 1) * nw * ldz * esz + amap_bytes));
+    CREATE_TRY(hipMemsetAsync(s->d_pos, 0, (s->push ? 1 + (size_t)s->cfg.shard_count : 1) * nw * ldz * esz + amap_bytes, s->stream));   // the pad column of odd ndim stays 0
+    if (s->lazy) {
+        const size_t P = (size_t)s->cfg.shard_count, hl = (size_t)s->h_loc;
+        const size_t nb = 2 * P * 2 * hl * sizeof(uint32_t) + 16;
+        CREATE_TRY(dev_alloc(s, (void**)&s->d_lazy, nb));
+        CREATE_TRY(hipMemsetAsync(s->d_lazy, 0, nb, s->stream));
+        s->peer_amap_in[s->cfg.shard_rank] = reinterpret_cast<unsigned char*>(s->d_pos) + (1 + P) * nw * ldz * esz;
+    }
+    // per-walker block {logp[nrows], naccept[nrows], klast[nrows]}: one allocation, so the half-step kernels reach all
+    // three from one preloaded pointer (HalfStepFront::logp)
+    CREATE_TRY(dev_alloc(s, &s->d_logp, nw * (sizeof(double) + 2 * sizeof(uint32_t))));
+    s->d_naccept = reinterpret_cast<uint32_t*>(s->d_logp + nw);
+    s->d_klast = s->d_naccept + nw;
+    CREATE_TRY(hipMemsetAsync(s->d_klast, 0, nw * sizeof(uint32_t), s->stream));
+    static_assert(kGraphChunk <= 64, "advance_schedule runs one 64-thread block");
+    CREATE_TRY(dev_alloc(s, &s->d_gen, 64));
+    CREATE_TRY(hipMemsetAsync(s->d_gen, 0, 64, s->stream));
+    CREATE_TRY(dev_alloc(s, &s->d_sched, (size_t)kGraphChunk * sizeof(SchedEntry)));
+    CREATE_TRY(hipMemsetAsync(s->d_naccept, 0, nw * sizeof(uint32_t), s->stream));
+    if (cfg->deal_count > 0) CREATE_TRY(dev_alloc(s, (void**)&s->d_ids, nw * sizeof(uint32_t)));
+    if (s->plan.vec && !s->islands && !s->resident && s->plan.L >= 16 && s->plan.L <= 32 && s->plan.L / s->plan.ITER >= 2 &&
+        std::getenv("KMC_NO_DRAW_RING") == nullptr) {
+        // draw ring: 4 slots x rows x 32 B; tags start at 0xffffffff (no step carries it), so nothing is "parked" yet
+        const size_t nb = 4 * (size_t)s->nrows * 2 * sizeof(double2);
+        CREATE_TRY(dev_alloc(s, (void**)&s->d_ring, nb));
+        CREATE_TRY(hipMemsetAsync(s->d_ring, 0xff, nb, s->stream));
+    }
+    if (cfg->flags & KMC_MOMENTS) {
+        CREATE_TRY(dev_alloc(s, &s->d_msum, (size_t)s->macc_elems * sizeof(double)));
+        CREATE_TRY(dev_alloc(s, &s->d_msumsq, (size_t)s->macc_elems * sizeof(double)));
+        CREATE_TRY(hipMemsetAsync(s->d_msum, 0, (size_t)s->macc_elems * sizeof(double), s->stream));
+        CREATE_TRY(hipMemsetAsync(s->d_msumsq, 0, (size_t)s->macc_elems * sizeof(double), s->stream));
+        if (s->plan.vec && s->plan.L == 64 && !s->islands && !s->resident && std::getenv("KMC_NO_MOMENT_RING") == nullptr) {
+            // moment ring for long rows (kmc_kernels.hpp, HalfStepArgs::mring): up to 128 posted rows per wave,
+            // within 512 MiB in all; swept every kSweepEvery generations
+            const int64_t nwaves = s->macc_stride / 64;
+            const size_t slot = (size_t)s->plan.K * 64 * sizeof(double2);       // one row
+            int64_t depth = (int64_t)(((size_t)1 << 29) / ((size_t)nwaves * slot));
+            if (depth > 128) depth = 128;
+            if (const char* e = std::getenv("KMC_MOMENT_RING_DEPTH")) { const long v = std::atol(e); if (v >= 1 && v < depth) depth = v; }   // tests: force overflows
+            if (depth >= 4 || (depth >= 2 && std::getenv("KMC_MOMENT_RING_DEPTH") != nullptr)) {
+                CREATE_TRY(dev_alloc(s, (void**)&s->d_mring, (size_t)nwaves * (size_t)depth * slot));
+                CREATE_TRY(dev_alloc(s, (void**)&s->d_mring_w, (size_t)nwaves * (size_t)depth * sizeof(double)));
+                CREATE_TRY(dev_alloc(s, (void**)&s->d_mcnt, 2 * (size_t)nwaves * sizeof(uint32_t)));
+                CREATE_TRY(hipMemsetAsync(s->d_mcnt, 0, 2 * (size_t)nwaves * sizeof(uint32_t), s->stream));
+                s->mring_depth = (int)depth;
+                s->mring_waves = nwaves;
+            }
+        }
+        if (s->islands || s->resident) {
+            const size_t ne = (size_t)s->nislands * 4 * (size_t)s->island_K;
+            CREATE_TRY(dev_alloc(s, &s->d_isum, ne * sizeof(double)));
+            CREATE_TRY(dev_alloc(s, &s->d_isumsq, ne * sizeof(double)));
+            CREATE_TRY(hipMemsetAsync(s->d_isum, 0, ne * sizeof(double), s->stream));
+            CREATE_TRY(hipMemsetAsync(s->d_isumsq, 0, ne * sizeof(double), s->stream));
+        }
+    }
+    if (s->host_eval) {
+        CREATE_TRY(dev_alloc(s, &s->d_prop, (size_t)s->h * ldz * sizeof(double)));
+        CREATE_TRY(dev_alloc(s, &s->d_p1, (size_t)s->h * sizeof(double)));
+        CREATE_TRY(hipHostMalloc((void**)&s->h_prop, (size_t)s->h * (size_t)cfg->ndim * sizeof(double), hipHostMallocDefault));
+        CREATE_TRY(hipHostMalloc((void**)&s->h_p1, (size_t)s->h * sizeof(double), hipHostMallocDefault));
+        if (cfg->host_accepted) {
+            CREATE_TRY(dev_alloc(s, &s->d_acc, (size_t)s->h));
+            CREATE_TRY(hipHostMalloc((void**)&s->h_acc, (size_t)s->h, hipHostMallocDefault));
+        }
+    }
+    int64_t chain_slots = s->nsamples;
+    if ((cfg->flags & KMC_STREAM_CHAIN) && s->nsamples > 0) {
+        // a ring of three blocks; a block holds at least the samples of one launch unit (a graph replay), so a unit never
+        // touches more than two blocks, and about 512 MiB otherwise (measured at C2: 128 MiB blocks stream 22-26 GB/s at nthin = 10, 512 MiB blocks 43-45 GB/s of the
+        // 56 GB/s this link copies alone; many small blocks cost more at the block boundaries than their earlier start
+        // returns -- nthin = 100: +19 % on the loop with 64 MiB blocks, +6 % with 512 MiB; KMC_CHAIN_BLOCK = samples per block, for tests)
+        if (const char* e = std::getenv("KMC_UPD_CHUNK")) { const long v = std::atol(e); if (v >= 16 && v <= 1024) s->uchunk = v; }
+        const int64_t unit = std::max<int64_t>(kGraphChunk, s->uchunk);
+        const int64_t per_unit = (unit + cfg->nthin - 1) / cfg->nthin + 1;
+        const size_t sample_bytes = (size_t)s->nlocal * ldz * sizeof(double);
+        int64_t blk = (int64_t)(((size_t)512 << 20) / sample_bytes);
+        if (blk < 1) blk = 1;
+        if (blk > 4096) blk = 4096;
+        if (const char* e = std::getenv("KMC_CHAIN_BLOCK")) { const long v = std::atol(e); if (v >= 1) blk = v; }
+        if (blk < per_unit) blk = per_unit;
+        s->stream_chain = true;
+        s->stream_by_walker = (cfg->flags & KMC_CHAIN_BY_WALKER) != 0;
+        const char* bwc = std::getenv("KMC_BYWALKER_COPY");
+        if (s->stream_by_walker && !(bwc && std::strcmp(bwc, "kernel") == 0)) {
+            if (cfg->flags & KMC_STORE_CHAIN) CREATE_TRY(dev_alloc(s, &s->bw_scratch, (size_t)blk * (size_t)s->nlocal * (size_t)cfg->ndim * sizeof(double)));
+            if (cfg->flags & KMC_STORE_LOGP) CREATE_TRY(dev_alloc(s, &s->bw_scratch_logp, (size_t)blk * (size_t)s->nlocal * sizeof(double)));
+        } else if (!s->stream_by_walker && (cfg->flags & KMC_STORE_CHAIN) && s->ld != cfg->ndim) {
+            CREATE_TRY(dev_alloc(s, &s->bw_scratch, (size_t)blk * (size_t)s->nlocal * (size_t)cfg->ndim * sizeof(double)));   // (rows_compact)
+        }
+        s->ring_blk = blk;
+        s->ring_slots = 3 * blk;
+        chain_slots = s->ring_slots;
+        CREATE_TRY(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
+        for (int i = 0; i < 3; ++i) {
+            CREATE_TRY(hipEventCreateWithFlags(&s->ev_filled[i], hipEventDisableTiming));
+            CREATE_TRY(hipEventCreateWithFlags(&s->ev_copied[i], hipEventDisableTiming));
+        }
+    }
+    if ((cfg->flags & (KMC_STORE_CHAIN | KMC_STORE_LOGP)) && s->nsamples > 0) {
+        // A chain that cannot fit is refused HERE, not by a failing hipMalloc: after a failed allocation of hundreds of GB the
+        // runtime aborted the process a few calls later (observed: 4 of 5 runs, in the first HIP call of the next sampler).
+        size_t free_b = 0, total_b = 0;
+        CREATE_TRY(hipMemGetInfo(&free_b, &total_b));
+        const size_t need = (size_t)chain_slots * (size_t)s->nlocal *
+                            (((cfg->flags & KMC_STORE_CHAIN) ? ldz * esz : 0) + ((cfg->flags & KMC_STORE_LOGP) ? sizeof(double) : 0));
+        if (need > free_b) {
+            kmc_status r_ = fail(KMC_ERR_OOM, "the chain needs " + std::to_string(need >> 20) + " MiB of device memory, " + std::to_string(free_b >> 20) +
+                                              " MiB are free: thin it (nthin), or stream it to host memory (KMC_STREAM_CHAIN)");
+            kmc_sampler_destroy(s);
+            return r_;
+        }
+    }
+    if ((cfg->flags & KMC_STORE_CHAIN) && s->nsamples > 0)
+        CREATE_TRY(dev_alloc(s, &s->d_chain, (size_t)chain_slots * (size_t)s->nlocal * ldz * esz));
+    if ((cfg->flags & KMC_STORE_LOGP) && s->nsamples > 0)
+        CREATE_TRY(dev_alloc(s, &s->d_chain_logp, (size_t)chain_slots * (size_t)s->nlocal * sizeof(double)));
+    CREATE_TRY(hipStreamSynchronize(s->stream));         // the fills above (asynchronous, one wait for all of them)
+#undef CREATE_TRY
+    if (s->p2p) {
+        s->peer_pos[s->cfg.shard_rank] = s->d_pos;
+        s->peer_flags[s->cfg.shard_rank] = s->d_flags;
+        s->connected = s->cfg.shard_count == 1;
+    }
+    *out = s;
+    return KMC_OK;
+}
+
+KMC_EXPORT void kmc_sampler_destroy(kmc_sampler* s)
+{
+    if (!s) return;
+    (void)hipSetDevice(s->cfg.device);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    if (s->copy_stream) (void)hipStreamSynchronize(s->copy_stream);
+    if (!s->guards.empty() && s->stream) check_guards(s);
+    for (int i = 0; i < kUExec; ++i) {
+        if (s->uexec[i]) (void)hipGraphExecDestroy(s->uexec[i]);
+        if (s->udone[i]) (void)hipEventDestroy(s->udone[i]);
+    }
+    if (s->ugraph) (void)hipGraphDestroy(s->ugraph);
+    if (s->graph_exec) (void)hipGraphExecDestroy(s->graph_exec);
+    if (s->uk.mod) (void)hipModuleUnload(s->uk.mod);
+    if (s->graph) (void)hipGraphDestroy(s->graph);
+    if (s->ev0) (void)hipEventDestroy(s->ev0);
+    if (s->ev1) (void)hipEventDestroy(s->ev1);
+    if (s->p2p) {
+        for (int r = 0; r < 8; ++r) {
+            if (r == s->cfg.shard_rank) continue;
+            if (s->peer_pos[r]) (void)hipIpcCloseMemHandle(s->peer_pos[r]);
+            if (s->peer_flags[r]) (void)hipIpcCloseMemHandle(s->peer_flags[r]);
+        }
+        (void)hipFree(s->d_flags);
+        (void)hipFree(s->d_err);
+        (void)hipFree(s->d_done);
+    }
+    if (s->comm) { rccl_comm_destroy(s->comm); s->comm = nullptr; }
+    if (s->copy_stream) { (void)hipStreamSynchronize(s->copy_stream); (void)hipStreamDestroy(s->copy_stream); }
+    for (int i = 0; i < 3; ++i) {
+        if (s->ev_filled[i]) (void)hipEventDestroy(s->ev_filled[i]);
+        if (s->ev_copied[i]) (void)hipEventDestroy(s->ev_copied[i]);
+    }
+    chain_unregister(s);
+    if (s->own_pos) (void)hipFree(s->d_pos);
+    (void)hipFree(s->d_logp);          // the {logp, naccept, klast} block
+    (void)hipFree(s->d_mring);
+    (void)hipFree(s->d_ids);
+    (void)hipFree(s->d_lazy);
+    (void)hipFree(s->d_mring_w);
+    (void)hipFree(s->d_mcnt);
+    (void)hipFree(s->d_gen);
+    (void)hipFree(s->d_sched);
+    (void)hipFree(s->d_chain);
+    (void)hipFree(s->bw_scratch);
+    (void)hipFree(s->bw_scratch_logp);
+    (void)hipFree(s->d_chain_logp);
+    (void)hipFree(s->d_msum);
+    (void)hipFree(s->d_msumsq);
+    (void)hipFree(s->d_ring);
+    (void)hipFree(s->d_isum);
+    (void)hipFree(s->d_isumsq);
+    (void)hipFree(s->d_prop);
+    (void)hipFree(s->d_p1);
+    if (s->h_prop) (void)hipHostFree(s->h_prop);
+    if (s->h_p1) (void)hipHostFree(s->h_p1);
+    (void)hipFree(s->d_acc);
+    if (s->h_acc) (void)hipHostFree(s->h_acc);
+    if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
+    (void)hipGetLastError();
+    delete s;
+}
+
+KMC_EXPORT kmc_status kmc_sampler_set_stream(kmc_sampler* s, void* hip_stream)
+{
+    if (!s) return fail(KMC_ERR_BAD_ARG, "null sampler");
+    HIP_TRY(hipSetDevice(s->cfg.device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
+    s->stream = (hipStream_t)hip_stream;
+    s->own_stream = false;
+    return KMC_OK;
+}
+
+KMC_EXPORT kmc_status kmc_sampler_bind_positions(kmc_sampler* s, void* pos_dev)
+{
+    if (!s || !pos_dev) return fail(KMC_ERR_BAD_ARG, "null argument");
+    if (s->p2p) return fail(KMC_ERR_UNSUPPORTED, "KMC_P2P samplers export their own position buffer");
+    if (s->f32) return fail(KMC_ERR_UNSUPPORTED, "kmc_sampler_bind_positions takes double rows; a KMC_F32 sampler keeps its own float rows");
+    if (s->ld != s->cfg.ndim) return fail(KMC_ERR_UNSUPPORTED, "kmc_sampler_bind_positions needs an even ndim (16-byte rows)");
+    HIP_TRY(hipSetDevice(s->cfg.device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    if (s->graph_exec) { (void)hipGraphExecDestroy(s->graph_exec); s->graph_exec = nullptr; }
+    if (s->graph) { (void)hipGraphDestroy(s->graph); s->graph = nullptr; }
+    for (int i = 0; i < kUExec; ++i) {
+        if (s->uexec[i]) { (void)hipGraphExecDestroy(s->uexec[i]); s->uexec[i] = nullptr; }
+        if (s->udone[i]) { (void)hipEventDestroy(s->udone[i]); s->udone[i] = nullptr; }      // (ensure_updated_graph creates them anew)
+        s->uinflight[i] = false;
+    }
+    s->unext = 0;
+    if (s->ugraph) { (void)hipGraphDestroy(s->ugraph); s->ugraph = nullptr; }
+    if (s->own_pos) {
+        for (size_t i = 0; i < s->guards.size(); ++i)                   // (KMC_POISON: this allocation's guard goes with it)
+            if (s->guards[i].first - s->guards[i].second == reinterpret_cast<char*>(s->d_pos)) { s->guards.erase(s->guards.begin() + (long)i); break; }
+        (void)hipFree(s->d_pos);
+    }
+    s->d_pos = static_cast<double*>(pos_dev);
+    s->own_pos = false;
+    s->positions_set = false;
+    return KMC_OK;
+}
+
+KMC_EXPORT int64_t kmc_sampler_generation(const kmc_sampler* s) { return s ? s->generation : -1; }
+KMC_EXPORT int64_t kmc_sampler_nsamples(const kmc_sampler* s) { return s ? s->nsamples : -1; }
+KMC_EXPORT int64_t kmc_sampler_launch_count(const kmc_sampler* s) { return s ? s->launches : -1; }
+
+// Human-readable description of how this sampler executes (kernel family, geometry, exchange).
+KMC_EXPORT kmc_status kmc_sampler_describe(const kmc_sampler* s, char* buf, int64_t buflen)
+{
+    if (!s || !buf || buflen <= 0) return fail(KMC_ERR_BAD_ARG, "bad argument");
+    std::ostringstream o;
+    if (s->islands)
+        o << "island mode: " << s->nislands << " islands of " << s->island_size << " walkers in LDS, " << s->island_gens
+          << " generations per launch, rows 2 lanes x " << s->island_K << " chunks";
+    else if (s->resident)
+        o << "resident mode (exact): whole ensemble in one workgroup's LDS (" << (s->user ? 256 : s->resident_tpb)
+          << " threads), up to 4096 generations per launch, rows 2 lanes x " << s->island_K << " chunks";
+    else if (s->host_eval)
+        o << "host-evaluated density (exact): per half-step propose kernel -> D2H -> callback -> H2D -> accept kernel, grid "
+          << s->grid << " x 256";
+    else if (s->plan.vec) {
+        o << "multi-launch (exact): half_step_vec L=" << s->plan.L << " K=" << s->plan.K << " ITER=" << s->plan.ITER
+          << (s->plan.ragged ? " ragged" : " exact-size") << ", grid " << s->grid << " x " << s->tpb
+          << (((s->cfg.flags & KMC_NO_GRAPH) || s->launch_mode == 2) ? ", eager launches (step among the preloaded kernel parameters)"
+              : s->launch_mode == 3 ? ", hipGraph replay of 64 generations with per-replay parameter updates (step preloaded)"
+                                    : ", hipGraph replay of 64 generations");
+        if (s->calib_graph_ms > 0.f) {
+            char b[128];
+            std::snprintf(b, sizeof(b), " (measured per 64 generations: table graph %.3f ms, %s %.3f ms)", s->calib_graph_ms, s->launch_mode == 2 ? "eager launches" : "updated graph", s->calib_eager_ms);
+            o << b;
+        }
+    } else
+        o << "multi-launch (exact): " << (s->user && s->uk.staged ? "half_step_staged (one walker per lane, rows staged through LDS)" : "half_step_generic (one walker per lane)")
+          << ", grid " << s->grid << " x " << s->tpb;
+    if (s->budget_fallback) o << "; updated-graph budget of the process spent (KMC_UPDATED_BUDGET_MB): fell back to " << (s->launch_mode == 2 ? "eager launches" : "the table graph");
+    if (s->lazy) o << "; lazy pull into local copies (KMC_P2P_LAZY)";
+    else if (s->push) o << "; accepted rows pushed into the peers' local copies (KMC_P2P_PUSH)";
+    if (s->f32) o << "; rows kept in float (KMC_F32), arithmetic in double";
+    if (s->stream_chain) o << "; chain streamed to host memory in blocks of " << s->ring_blk << " samples (device ring of 3 blocks" << (s->dst_chain_reg || s->dst_logp_reg ? ", destination page-locked" : "") << ")";
+    if (s->d_ids) o << "; dealt sub-ensemble " << s->cfg.deal_rank << "/" << s->cfg.deal_count << " (walkers re-dealt between epochs)";
+    if (s->d_mring) o << "; moments through a ring of " << s->mring_depth << " posted rows per wave";
+    if (s->user) o << "; runtime-compiled density";
+    if (s->p2p) o << "; P2P shard " << s->cfg.shard_rank << "/" << s->cfg.shard_count << (s->connected ? "" : " (not connected)");
+    else if (s->cfg.shard_count > 1 || s->comm)
+        o << "; replica shard " << s->cfg.shard_rank << "/" << s->cfg.shard_count
+          << (s->comm ? ((s->comm_graph_ok && !(s->cfg.flags & KMC_NO_GRAPH) && s->launch_mode != 2) ? ", RCCL all-gather of the updated half after every half-step (captured in the graph)"
+                                                                                                         : ", RCCL all-gather of the updated half after every half-step (enqueued launch by launch)") : "");
+    const std::string t = o.str();
+    std::snprintf(buf, (size_t)buflen, "%s", t.c_str());
+    return KMC_OK;
+}
+
+KMC_EXPORT void* kmc_sampler_device_ptr(kmc_sampler* s, int which)
+{
+    if (!s) return nullptr;
+    switch (which) {
+    case 0: return s->d_pos;
+    case 1: return s->d_logp;
+    case 2: return s->d_naccept;
+    default: return nullptr;
+    }
+}
+
+KMC_EXPORT int kmc_sizeof_config(void) { return (int)sizeof(kmc_config); }
+KMC_EXPORT int kmc_sizeof_metropolis_config(void) { return (int)sizeof(kmc_metropolis_config); }
+

@@ -39,44 +39,49 @@ HalfStepFn vec_iter(int iter)
     }
 }
 
-template <class D, int L, int K>
-HalfStepFn vec_pick(int iter, bool p2p, bool ragged, bool f32)
+// A density's kernels are instantiated in FOUR translation units, so that the build's longest job is a quarter of a density
+// (kmc_inst_<density>{,_var,_p2p,_lds}.hip): PART 0 = double rows, exact size, one GPU (incl. the tuning geometries);
+// PART 1 = ragged sizes and KMC_F32 rows, one GPU; PART 2 = the peer-to-peer kernels; (the LDS-resident and Metropolis
+// kernels are the fourth).  Each part only names -- and therefore only compiles -- its own instantiations.
+template <class D, int L, int K, int PART>
+HalfStepFn vec_pick(int iter, bool ragged, bool f32)
 {
-    if (f32) {      // KMC_F32: single rows, one GPU
-        if (p2p) return nullptr;
-        return ragged ? vec_iter<D, L, K, false, true, float>(iter) : vec_iter<D, L, K, false, false, float>(iter);
-    }
-    if (ragged) return p2p ? vec_iter<D, L, K, true, true, double>(iter) : vec_iter<D, L, K, false, true, double>(iter);
-    return p2p ? vec_iter<D, L, K, true, false, double>(iter) : vec_iter<D, L, K, false, false, double>(iter);
+    if constexpr (PART == 0) return vec_iter<D, L, K, false, false, double>(iter);
+    else if constexpr (PART == 1) {
+        if (f32) return ragged ? vec_iter<D, L, K, false, true, float>(iter) : vec_iter<D, L, K, false, false, float>(iter);   // KMC_F32: single rows, one GPU
+        return vec_iter<D, L, K, false, true, double>(iter);
+    } else return ragged ? vec_iter<D, L, K, true, true, double>(iter) : vec_iter<D, L, K, true, false, double>(iter);
 }
 
 // geometries make_plan can pick: exact + ragged, single-GPU + P2P; the extra exact single-GPU ones
 // exist for tuning (KMC_PLAN)
-template <class D>
-HalfStepFn vec_lookup(int L, int K, int iter, bool p2p, bool ragged, bool f32)
+template <class D, int PART>
+HalfStepFn vec_lookup(int L, int K, int iter, bool ragged, bool f32)
 {
     if constexpr (!D::kHasFrag) {
         return nullptr;
     } else {
-#define KMC_LK(l, k) if (L == l && K == k) return vec_pick<D, l, k>(iter, p2p, ragged, f32);
+#define KMC_LK(l, k) if (L == l && K == k) return vec_pick<D, l, k, PART>(iter, ragged, f32);
         KMC_LK(1, 1) KMC_LK(2, 1) KMC_LK(4, 1) KMC_LK(4, 2) KMC_LK(8, 2) KMC_LK(16, 2) KMC_LK(32, 2) KMC_LK(64, 2)
         KMC_LK(64, 4) KMC_LK(64, 8)
 #undef KMC_LK
-        if (ragged || p2p || f32) return nullptr;
+        if constexpr (PART == 0) {
 #define KMC_LK(l, k) if (L == l && K == k) return vec_iter<D, l, k, false, false, double>(iter);
-        KMC_LK(8, 1) KMC_LK(16, 1) KMC_LK(32, 1) KMC_LK(64, 1) KMC_LK(4, 4) KMC_LK(8, 4)
+            KMC_LK(8, 1) KMC_LK(16, 1) KMC_LK(32, 1) KMC_LK(64, 1) KMC_LK(4, 4) KMC_LK(8, 4)
 #undef KMC_LK
+        }
         return nullptr;
     }
 }
 
-template <class D>
-void density_fns(int L, int K, int iter, bool p2p, bool ragged, bool f32, HalfStepFn* vec, HalfStepFn* gen, LogpdfFn* lp)
+// (the part's vector kernel for this geometry or nullptr, its generic kernel)
+template <class D, int PART>
+void density_part(int L, int K, int iter, bool ragged, bool f32, HalfStepFn* vec, HalfStepFn* gen)
 {
-    *vec = vec_lookup<D>(L, K, iter, p2p, ragged, f32);
-    if (f32) *gen = p2p ? nullptr : half_step_generic<D, false, float>;
-    else *gen = p2p ? half_step_generic<D, true, double> : half_step_generic<D, false, double>;
-    *lp = logpdf_rows<D>;
+    *vec = vec_lookup<D, PART>(L, K, iter, ragged, f32);
+    if constexpr (PART == 0) *gen = half_step_generic<D, false, double>;
+    else if constexpr (PART == 1) *gen = f32 ? half_step_generic<D, false, float> : half_step_generic<D, false, double>;
+    else *gen = half_step_generic<D, true, double>;
 }
 
 // island mode: one workgroup per S-walker island, rows of up to 4*K doubles
@@ -147,14 +152,18 @@ MetropolisFn metropolis_lookup(int ndim)
 }
 #endif  // KMC_TABLES_IMPL
 
-// one entry point per density (defined in kmc_inst_<density>.hip)
+// entry points per density: table_<density> (kmc_inst_<density>.hip: PART 0, the log-pdf and initial-ball kernels, and the
+// dispatch to the other parts), part_var_ / part_p2p_<density> (kmc_inst_<density>_var.hip / _p2p.hip), and the LDS-resident +
+// Metropolis tables below (kmc_inst_<density>_lds.hip)
 #define KMC_DECLARE_DENSITY_TABLE(name) \
-    void name(int L, int K, int iter, bool p2p, bool ragged, bool f32, HalfStepFn* vec, HalfStepFn* gen, LogpdfFn* lp)
-KMC_DECLARE_DENSITY_TABLE(table_gaussian_iso);
-KMC_DECLARE_DENSITY_TABLE(table_exponential);
-KMC_DECLARE_DENSITY_TABLE(table_rosenbrock);
-KMC_DECLARE_DENSITY_TABLE(table_lognormal);
-KMC_DECLARE_DENSITY_TABLE(table_mvnormal2);
+    void table_##name(int L, int K, int iter, bool p2p, bool ragged, bool f32, HalfStepFn* vec, HalfStepFn* gen, LogpdfFn* lp); \
+    void part_var_##name(int L, int K, int iter, bool ragged, bool f32, HalfStepFn* vec, HalfStepFn* gen);                      \
+    void part_p2p_##name(int L, int K, int iter, bool ragged, HalfStepFn* vec, HalfStepFn* gen)
+KMC_DECLARE_DENSITY_TABLE(gaussian_iso);
+KMC_DECLARE_DENSITY_TABLE(exponential);
+KMC_DECLARE_DENSITY_TABLE(rosenbrock);
+KMC_DECLARE_DENSITY_TABLE(lognormal);
+KMC_DECLARE_DENSITY_TABLE(mvnormal2);
 HalfStepFn half_step_host();
 IslandFn island_gaussian_iso(int S, int K, bool ragged);
 ResidentFn resident_gaussian_iso(int tpb, int K, bool ragged);

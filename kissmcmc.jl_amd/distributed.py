@@ -254,6 +254,18 @@ class AllGatherEmcee:
         if self.world > 1:
             dist.broadcast_object_list(uid, src=0, group=group)
         self.sampler.rccl_init(uid[0])
+        # captured all-gathers on every rank, or launch by launch on every rank: each rank captures its chunk now and the
+        # outcomes are reduced (MIN) before the first replay -- a rank never decides alone
+        got = self.sampler.rccl_capture() if use_graph else False
+        if self.world > 1:
+            votes = [None] * self.world
+            dist.all_gather_object(votes, bool(got), group=group)
+            agreed = all(votes)
+        else:
+            agreed = got
+        self.captured = bool(agreed)
+        if use_graph:
+            self.sampler.rccl_set_capture(self.captured)
 
     def set_positions(self, theta_global):
         self.sampler.set_positions(theta_global)          # every rank: the whole ensemble (its replica)

@@ -162,6 +162,32 @@ class Sampler:
         buf = C.create_string_buffer(bytes(unique_id), _lib.RCCL_ID_BYTES)
         _lib.check(self._L.kmc_sampler_rccl_init(self._h, buf))
 
+    def rccl_capture(self) -> bool:
+        """Capture the chunk of kernels + all-gathers now; whether THIS rank got a graph (reduce over the ranks with MIN,
+        then :meth:`rccl_set_capture` on every rank: all replay captured all-gathers, or all enqueue them one by one)."""
+        got = C.c_int(0)
+        _lib.check(self._L.kmc_sampler_rccl_capture(self._h, C.byref(got)))
+        return bool(got.value)
+
+    def rccl_set_capture(self, use_captured: bool):
+        _lib.check(self._L.kmc_sampler_rccl_set_capture(self._h, 1 if use_captured else 0))
+
+    @staticmethod
+    def rccl_version():
+        """``"major.minor.patch"`` of the librccl.so the library resolves (``None`` when it cannot be loaded); no device needed."""
+        v = C.c_int(0)
+        if _lib.lib().kmc_rccl_version(C.byref(v), None, 0) != _lib.OK:
+            return None
+        return f"{v.value // 10000}.{v.value // 100 % 100}.{v.value % 100}"
+
+    LAUNCH_MODES = {0: "undecided", 1: "table graph", 2: "eager", 3: "updated graph", 4: "single launch per many generations"}
+
+    def launch_mode(self):
+        """``(mode, budget_fallback)``: how :meth:`run` issues the launches (a key of ``LAUNCH_MODES``) and whether the
+        sampler is outside the updated-graph mode because the process's budget of graph parameter updates was spent."""
+        fb = C.c_int(0)
+        return int(self._L.kmc_sampler_launch_mode(self._h, C.byref(fb))), bool(fb.value)
+
     def p2p_export(self) -> bytes:
         """IPC handle blob of this shard (to be all-gathered across the ranks)."""
         buf = C.create_string_buffer(_lib.P2P_HANDLE_BYTES)

@@ -83,6 +83,9 @@ def lib() -> C.CDLL:
         L.kmco_sample_g.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_double]
         L.kmco_draw.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int64,
                                 C.POINTER(C.c_int64), dp, dp]
+        L.kmco_accept_terms.restype = None
+        L.kmco_accept_terms.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int64, C.c_int64, C.c_double, C.c_double,
+                                        C.POINTER(C.c_int64), dp, dp, dp]
         L.kmco_logpdf.restype = C.c_double
         L.kmco_logpdf.argtypes = [C.c_int32, dp, dp, C.c_int64]
         L.kmco_validate.argtypes = [C.POINTER(Config)]
@@ -163,6 +166,15 @@ def draw(seed, step, walker, nhalf):
     ua = C.c_double()
     lib().kmco_draw(seed, step, walker, nhalf, C.byref(p), C.byref(uz), C.byref(ua))
     return p.value, uz.value, ua.value
+
+
+def accept_terms(seed, step, walker0, n, nhalf, a_scale, ndim):
+    """``(partner, z, t1, lu)`` of walkers ``walker0 .. walker0 + n - 1`` at ``step``: the random side of the accept test
+    (``src/samplers.jl:260``) with the oracle's arithmetic (glibc ``log``)."""
+    part = np.empty(n, dtype=np.int64)
+    z, t1, lu = np.empty(n), np.empty(n), np.empty(n)
+    lib().kmco_accept_terms(seed, step, walker0, n, nhalf, float(a_scale), float(ndim - 1), _ip(part), _dp(z), _dp(t1), _dp(lu))
+    return part, z, t1, lu
 
 
 def logpdf(density, params, x):

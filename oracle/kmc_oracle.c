@@ -126,6 +126,26 @@ KMCO_API void kmco_draw(uint64_t seed, uint64_t step, uint64_t walker, int64_t n
     *u_acc = ((double)k + 0.5) * 0x1.0p-52;
 }
 
+/* The random side of the accept test, src/samplers.jl:260 "(N-1)*log(z) + p1 - p0 >= log(rand())", for walkers
+ * walker0 .. walker0 + n - 1 of one step, with THIS file's arithmetic (glibc log; the same expressions as kmco_half_step):
+ * z (:252), t1 = nm1 * log(z), lu = log(u).  tests/test_gpu_accept_margin.py compares them with the device's. */
+KMCO_API void kmco_accept_terms(uint64_t seed, uint64_t step, uint64_t walker0, int64_t n, int64_t nhalf, double a, double nm1,
+                                int64_t* partner, double* z_out, double* t1_out, double* lu_out)
+{
+    const double c0 = g_c0(a), c1 = g_c1(a);
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+        int64_t p; double uz, ua;
+        kmco_draw(seed, step, walker0 + (uint64_t)i, nhalf, &p, &uz, &ua);
+        const double t = fma(uz, c1, c0);
+        const double z = t * t;
+        if (partner) partner[i] = p;
+        z_out[i] = z;
+        t1_out[i] = nm1 * log(z);
+        lu_out[i] = log(ua);
+    }
+}
+
 /* sample_g for a seeded stream: src/samplers.jl:230 */
 KMCO_API double kmco_sample_g(uint64_t seed, uint64_t step, uint64_t walker, double a)
 {

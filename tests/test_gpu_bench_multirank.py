@@ -1,0 +1,61 @@
+"""GPU: bench.py's N > 1 path end to end -- the launcher, the self-check, the fallback ladder, the extras and the JSON fields --
+with two ranks sharing ONE GPU (gloo carries the rendezvous; the peer-to-peer exchange, the sharded kernels and the dealt mode
+are the same code as on two devices; RCCL itself refuses two ranks on one device, which exercises the ladder's fallbacks).
+The join being distributed: reference src/samplers.jl:246-248, :273."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(extra_env, *args):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update({"KMC_BENCH_BACKEND": "gloo", "KMC_BENCH_WALKERS": "4096", "KMC_BENCH_TIMEOUT": "600", "KMC_BENCH_RUNG_TIMEOUT": "240"})
+    env.update(extra_env)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", *args],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    assert r.stdout.strip().splitlines()[-1] == lines[0]          # the result is the LAST line of stdout
+    return json.loads(lines[0]), r.stderr
+
+
+def common_checks(out):
+    assert out["n_gpus"] == 2 and out["steps"] == 1 and out["warmup"] == 1
+    assert out["metric"] == "walker-steps/sec" and out["scaling"] == "weak" and out["dtype"] == "f64"
+    assert out["config"]["nwalkers_total"] == 2 * 4096 and out["config"]["generations"] == 1000
+    assert out["check"]["timed_run_equals_unsharded_run"] is True
+    assert out["check"]["nmoment"] == 2 * 4096 * 500
+    assert abs(out["check"]["accept_ratio_mean"] - 0.234) < 0.01
+    c = out["collective"]
+    assert c["backend"] == "gloo" and c["world_size"] == 2 and c["ranks_seen_by_all_reduce"] == 2
+    assert c["launcher"].startswith("bench.py itself")
+    assert c["native_rccl_version"] and c["native_rccl_version"].startswith("2.")
+    d = out["dealt_mode"]
+    assert "error" not in d, d
+    assert d["value"] > 0 and d["deals"] == 1000 // 64 and abs(d["accept_ratio_mean"] - 0.234) < 0.01
+    assert out["value"] == pytest.approx(2 * 4096 * 1000 / (out["ms_per_step"] * 1e-3), rel=1e-9)
+    assert "roofline" in out and out["roofline"]["launches"] == 2000
+
+
+def test_bench_two_ranks_p2p_from_a_plain_shell():
+    out, err = run_bench({})
+    common_checks(out)
+    assert "peer-to-peer exchange" in out["config"]["parallelism"]
+    assert "allgather_mode" in out                      # the north star's exchange, on record next to the pull (here: RCCL refuses one device)
+
+
+def test_bench_two_ranks_allgather_ladder():
+    out, err = run_bench({"KMC_BENCH_EXCHANGE": "allgather"})
+    common_checks(out)
+    assert "all-gather of the updated half per half-step" in out["config"]["parallelism"]
+    # two ranks on one device: ncclCommInitRank refuses, every rank takes the torch-collective rung together
+    assert "native RCCL all-gather set-up failed" in err
+    assert "torch collective per half-step" in out["config"]["parallelism"]

@@ -225,6 +225,55 @@ def test_launch_modes_are_the_same_sampler(kmc, oracle, mode, monkeypatch):
         assert "eager" in how
 
 
+@pytest.mark.parametrize("when", ["spent_before_the_run", "spent_during_the_run"])
+def test_updated_graph_budget_fallbacks_are_the_same_sampler(kmc, oracle, when, monkeypatch, capfd):
+    """The updated-graph mode has a process-wide budget of parameter updates (the runtime leaks ~80 B per update).  A sampler
+    that finds it spent -- before its first long run, or in the middle of one -- goes on with the table graph or eager
+    launches: same results as the oracle, and it SAYS so (stderr once per process, describe(), kmc_sampler_launch_mode)."""
+    import ctypes as C
+    from kissmcmc_jl_amd import _lib
+    L = _lib.lib()
+    used, budget = C.c_int64(0), C.c_int64(0)
+    L.kmc_updated_budget(C.byref(used), C.byref(budget))
+    nw, nd, G, nburn, nthin, seed = 2048, 32, 1000, 301, 7, 29
+    th = np.random.default_rng(5).standard_normal((nw, nd))
+    try:
+        if when == "spent_before_the_run":
+            monkeypatch.delenv("KMC_LAUNCH", raising=False)
+            L.kmc_set_updated_budget_mb(1.0 / 1024.0)                       # 1 KiB: 13 updates, fewer than one replay needs
+        else:
+            monkeypatch.setenv("KMC_LAUNCH", "updated,budget")              # in the updated-graph mode, budget applies
+            L.kmc_set_updated_budget_mb((used.value + 3 * 128) * 80.0 / 1048576.0 + 1e-9)   # room for three replays
+        with kmc.Sampler(kmc.GaussianIso(), nw, nd, G, nburn, nthin, 2.0, seed, store_chain=True, store_logp=True, moments=True) as s:
+            s.set_positions(th)
+            s.run(900)
+            s.run(37)
+            s.run(63)
+            s.sync()
+            pos, nacc = s.positions(), s.naccept()
+            chain, clogp = s.chain()
+            msum, msq, n = s.moments()
+            how = s.describe()
+            mode, fell_back = s.launch_mode()
+            assert s.generation == G
+    finally:
+        L.kmc_set_updated_budget_mb(budget.value * 80.0 / 1048576.0)
+    assert fell_back and mode in (0, 1, 2), (mode, fell_back, how)
+    assert "budget of the process spent" in how
+    u2, b2 = C.c_int64(0), C.c_int64(0)
+    L.kmc_updated_budget(C.byref(u2), C.byref(b2))
+    assert b2.value == budget.value
+    if when == "spent_during_the_run":
+        assert 3 * 128 <= u2.value - used.value <= 4 * 128               # it stopped updating when the budget ran out
+    ref = oracle.emcee(oracle.make_config(oracle.GAUSSIAN_ISO, [0.0, 1.0], nw, nd, G, nburn, nthin, 2.0, seed, nthreads=8), th)
+    np.testing.assert_array_equal(nacc, ref["naccept"])
+    np.testing.assert_array_equal(pos, ref["final_pos"])
+    np.testing.assert_array_equal(chain, ref["chain"])
+    assert n == ref["nmoment"]
+    np.testing.assert_allclose(msum, ref["sum"], rtol=1e-11, atol=1e-9)
+    np.testing.assert_allclose(msq, ref["sumsq"], rtol=1e-11, atol=1e-9)
+
+
 @pytest.mark.parametrize("depth", [None, 2, "off"])
 def test_moment_ring_of_long_rows(kmc, oracle, depth, monkeypatch):
     """ndim > 256: waves with an accepted move post the replaced row into a per-wave ring and moments_sweep folds the
