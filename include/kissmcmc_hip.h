@@ -124,6 +124,10 @@ enum {
                                     the host buffers of kmc_sampler_set_chain_host are [nwalkers][nsamples][ndim] and
                                     [nwalkers][nsamples], and a completed block is transposed into a device scratch block and
                                     copied into them as a 2-D window by the copy stream. */
+    KMC_STORE_BLOBS = 1u << 13, /* a body density with blobs (kmc_user_density_create_body_blob; the reference's hasblob=true,
+                                   src/samplers.jl:194-196): keep the blob of every stored sample, [nsamples][nwalkers][nblob]
+                                   (reduce_blob! with the default push!, :196, :270); read with kmc_sampler_get_blobs.  The
+                                   blob of every walker's CURRENT position (blob0s, :210, :264) is kept regardless. */
     KMC_P2P_FINEGRAINED = 1u << 7, /* with KMC_P2P: keep the rows in fine-grained (coherent, uncached-for-peers) device memory */
     KMC_P2P_PUSH    = 1u << 9, /* with KMC_P2P: every rank keeps local copies ("shadows") of all the other shards and reads its
                                   partner rows from them; a rank that accepts a move writes the new row into its shadow on
@@ -188,6 +192,8 @@ typedef struct kmc_outputs {
     int64_t  nmoment;       /* out: number of (sample, walker) pairs accumulated */
     int64_t  nsamples;      /* out: (ngenerations - nburnin) / nthin  src/samplers.jl:234 */
     double   device_ms;     /* out: generation loop only, HIP events on the sampler's stream */
+    double*  blobs;         /* [nsamples][nwalkers][nblob] ([nwalkers][nsamples][nblob] with KMC_CHAIN_BY_WALKER): the blobs of a
+                               body density created with kmc_user_density_create_body_blob (src/samplers.jl:270) */
 } kmc_outputs;
 
 typedef struct kmc_sampler kmc_sampler; /* opaque */
@@ -231,6 +237,18 @@ kmc_status  kmc_user_density_create(const char* term_expr, const char* pair_expr
  * emcee (multi-launch), initial log-pdfs, kmc_sampler_init_ball, many-chain Metropolis -- slower than a menu or term / pair
  * density of the same form (those stripe a row over lanes), far faster than a host callback.  Not with KMC_ISLANDS; under KMC_P2P the unstaged kernel. */
 kmc_status  kmc_user_density_create_body(const char* body, kmc_user_density** out);
+/* ... returning a BLOB with the log-density -- the reference's `pdf(theta) -> (p, blob)` under hasblob=true
+ * (src/samplers.jl:150-151, :194-196, :257) for device densities -- the body of
+ *     double logpdf(const double* x, int n, const double* p, double* blob) { BODY }
+ * which fills blob[0 .. nblob) (1 <= nblob <= 1024 doubles per evaluation; zero on entry).  A sampler over such a density
+ * carries, next to every walker's log-pdf, the blob of its current position (blob0s[nc] = blob1 on accept, :264; initial
+ * blobs from the initial evaluations, :209-210) and, with KMC_STORE_BLOBS, the blob of every stored sample (:270).
+ * One GPU, double rows, no KMC_ISLANDS / KMC_P2P / KMC_STREAM_CHAIN / dealt sub-ensembles (KMC_ERR_UNSUPPORTED). */
+kmc_status  kmc_user_density_create_body_blob(const char* body, int nblob, kmc_user_density** out);
+int         kmc_user_density_nblob(const kmc_user_density* ud);   /* 0 for densities without blobs */
+/* log-pdfs AND blobs of dense host rows pos_host [nrows][ndim] (evaluated on the device): the reference's `pdf.(theta0s)` under
+ * hasblob=true (src/samplers.jl:209-210) -- e.g. the blob0 a caller's init_blobs(blob0, nsamples) receives (:238). */
+kmc_status  kmc_logpdf_blob_eval_host(const kmc_config* cfg, const double* pos_host, double* logp_host, double* blob_host /* [nrows][nblob] */, int64_t nrows);
 void        kmc_user_density_destroy(kmc_user_density* ud);
 
 /* ---- one-shot: emcee + _emcee, src/samplers.jl:188-293 ---- */
@@ -366,6 +384,10 @@ kmc_status  kmc_sampler_get_chain(kmc_sampler* s, double* chain, double* chain_l
  * (what squash_walkers' default, walker-major, concatenation wants; src/samplers.jl:395-413).  With KMC_STREAM_CHAIN only
  * for a sampler created with KMC_CHAIN_BY_WALKER (then a copy of / no-op on the streamed buffers, stride nsamples). */
 kmc_status  kmc_sampler_get_chain_by_walker(kmc_sampler* s, double* chain, double* chain_logp);
+/* Blobs of a body density with blobs (any pointer may be NULL): current [nwalkers][nblob] = the blob of every walker's present
+ * position (blob0s, src/samplers.jl:210, :264); stored (needs KMC_STORE_BLOBS) = the blobs of the samples stored so far,
+ * [k][nwalkers][nblob] sample-major, or with by_walker != 0 [nwalkers][k][nblob]: blobs[w][k] in the reference's order (:238, :270). */
+kmc_status  kmc_sampler_get_blobs(kmc_sampler* s, double* current, double* stored, int by_walker);
 
 /* ---- dealt sub-ensembles: the multi-GPU mode WITHOUT a per-half-step exchange (opt-in extension) ----
  *

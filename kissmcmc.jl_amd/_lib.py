@@ -28,6 +28,7 @@ STORE_CHAIN, STORE_LOGP, MOMENTS, NO_GRAPH, P2P, ISLANDS, P2P_FINEGRAINED, P2P_F
 P2P_LAZY = 1024
 STREAM_CHAIN = 2048
 CHAIN_BY_WALKER = 4096
+STORE_BLOBS = 8192
 P2P_HANDLE_BYTES = 128
 RCCL_ID_BYTES = 128
 
@@ -45,6 +46,7 @@ SYMBOLS = [
     "kmc_sampler_get_walker_ids", "kmc_sampler_set_walker_ids", "kmc_sampler_set_chain_host", "kmc_rccl_unique_id", "kmc_sampler_rccl_init",
     "kmc_sampler_rccl_capture", "kmc_sampler_rccl_set_capture", "kmc_rccl_version", "kmc_device_free_bytes",
     "kmc_sampler_launch_mode", "kmc_updated_budget", "kmc_set_updated_budget_mb", "kmc_debug_accept_terms",
+    "kmc_user_density_create_body_blob", "kmc_user_density_nblob", "kmc_logpdf_blob_eval_host", "kmc_sampler_get_blobs",
 ]
 
 
@@ -88,6 +90,7 @@ class Outputs(C.Structure):
         ("nmoment", C.c_int64),
         ("nsamples", C.c_int64),
         ("device_ms", C.c_double),
+        ("blobs", C.POINTER(C.c_double)),
     ]
 
 
@@ -207,6 +210,11 @@ def lib() -> C.CDLL:
     L.kmc_logpdf_eval_host.argtypes = [cfgp, dp, dp, C.c_int64]
     L.kmc_user_density_create.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(vp)]
     L.kmc_user_density_create_body.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.kmc_user_density_create_body_blob.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
+    L.kmc_user_density_nblob.restype = C.c_int
+    L.kmc_user_density_nblob.argtypes = [vp]
+    L.kmc_logpdf_blob_eval_host.argtypes = [cfgp, dp, dp, dp, C.c_int64]
+    L.kmc_sampler_get_blobs.argtypes = [vp, dp, dp, C.c_int]
     L.kmc_user_density_destroy.restype = None
     L.kmc_user_density_destroy.argtypes = [vp]
     L.kmc_metropolis_validate.argtypes = [C.POINTER(MetropolisConfig)]

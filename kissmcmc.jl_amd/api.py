@@ -66,7 +66,10 @@ def emcee(pdf, theta0s, niter: int = 10 ** 5, nburnin=None, nthin: int = 1, a_sc
     ``hasblob=True`` (``:150-151, :194-196``): ``pdf`` is a host callable returning ``(p, blob)``; the blobs
     stay on the host and follow the device's accept decisions.  ``blobs[w] = init_blobs(blob0s[w],
     nsamples_walker)`` (default: an empty list) and ``reduce_blob(blobs[w], blob)`` (default: append) is
-    called for every stored sample with the walker's current blob (``:270``).
+    called for every stored sample with the walker's current blob (``:270``).  Or ``pdf`` is a ``CDensity(..., nblob=m)``:
+    the blob is then ``m`` doubles computed on the device with the log-pdf, carried next to it by the kernels, and ``blobs``
+    comes back as an array ``[nwalkers, nsamples, m]`` (``blobs[w][k]``, the default ``push!`` reduction) -- or, with
+    ``init_blobs`` / ``reduce_blob`` given, whatever they build when fed each walker's stored series in order.
     """
     theta0s = np.array(theta0s, dtype=np.float64)              # :198 deepcopy
     scalar_walkers = theta0s.ndim == 1
@@ -77,8 +80,10 @@ def emcee(pdf, theta0s, niter: int = 10 ** 5, nburnin=None, nthin: int = 1, a_sc
             if not pdf.hasblob:
                 raise ValueError("hasblob=True needs HostLogPdf(..., hasblob=True)")
         elif isinstance(pdf, DeviceLogPdf):
-            raise NotImplementedError("blobs are host objects: hasblob=True needs a host callable as pdf "
-                                      "(device densities return the log-pdf alone)")
+            if int(getattr(pdf, "nblob", 0) or 0) <= 0:
+                raise NotImplementedError("hasblob=True needs a pdf that returns a blob: a host callable returning (p, blob), or a "
+                                          "CDensity(..., nblob=m) whose body fills blob[0..m) on the device (menu and term / pair "
+                                          "densities return the log-pdf alone)")
         elif callable(pdf):
             pdf = HostLogPdf(pdf, scalar=scalar_walkers, hasblob=True)
     if not isinstance(pdf, DeviceLogPdf):
@@ -103,6 +108,11 @@ def emcee(pdf, theta0s, niter: int = 10 ** 5, nburnin=None, nthin: int = 1, a_sc
     if seed is None:
         seed = _fresh_seed()
 
+    device_blobs = bool(hasblob and not isinstance(pdf, HostLogPdf))     # a CDensity(..., nblob=m): blobs computed and carried on the device
+    if device_blobs and stream_chain:
+        raise NotImplementedError("device blobs with a streamed chain: not supported (thin the chain, or stream_chain=False)")
+    if device_blobs:
+        stream_chain = False
     if stream_chain is None:
         # a chain that would not fit the device is streamed to host memory while sampling; the device is only asked when the
         # chain is large at all (> 1 GiB)
@@ -110,7 +120,7 @@ def emcee(pdf, theta0s, niter: int = 10 ** 5, nburnin=None, nthin: int = 1, a_sc
         stream_chain = dtype == "f64" and chain_bytes > (1 << 30) and chain_bytes > 0.7 * _free_device_bytes(device)
     # (host arrays that cannot be page-locked are no reason to fail: the library then stages the by-walker blocks itself)
     with Sampler(pdf, nwalkers, ndim, niter_walker, nburnin_walker, nthin, a_scale, seed, store_chain=True, store_logp=True,
-                 device=device, dtype=dtype, stream_chain=bool(stream_chain), chain_by_walker=True) as s:
+                 device=device, dtype=dtype, stream_chain=bool(stream_chain), chain_by_walker=True, store_blobs=device_blobs) as s:
         try:
             s.set_positions(theta0s)
         except _lib.KmcError as e:
@@ -118,7 +128,9 @@ def emcee(pdf, theta0s, niter: int = 10 ** 5, nburnin=None, nthin: int = 1, a_sc
                 raise ValueError(f"{e} (use make_theta0s to build an initial ensemble with pdf > -Inf)") from e
             raise
         blobs = None
-        if hasblob:
+        if device_blobs:
+            blob0s = s.current_blobs()                             # :209-210, from the initial evaluations (on the device)
+        elif hasblob:
             if init_blobs is None:
                 init_blobs = lambda blob0, nsamples: []        # init_output_vector :80-85
             if reduce_blob is None:
@@ -139,8 +151,19 @@ def emcee(pdf, theta0s, niter: int = 10 ** 5, nburnin=None, nthin: int = 1, a_sc
             _run_generations(s, niter, nwalkers, niter_walker, nburnin_walker, use_progress_meter)
             thetas, logdensities = s.chain(logp=True, by_walker=True)     # [walker][sample][dim], [walker][sample]: :219-221
             accept_ratio = s.accept_ratio()
+            if device_blobs:
+                series = s.blobs(by_walker=True)               # [walker][sample][m]: the walker's current blob at every stored sample (:270)
+                if init_blobs is None and reduce_blob is None:
+                    blobs = series                             # push! into an empty vector, densely
+                else:                                          # the caller's reduction, fed the same series in the same order
+                    ib = init_blobs if init_blobs is not None else (lambda blob0, nsamples: [])
+                    rb = reduce_blob if reduce_blob is not None else (lambda bs, b: bs.append(b))
+                    blobs = [ib(blob0s[w], nsamples_walker) for w in range(nwalkers)]        # :238
+                    for w in range(nwalkers):
+                        for k in range(series.shape[1]):
+                            rb(blobs[w], series[w, k])
         finally:
-            if hasblob:
+            if hasblob and not device_blobs:
                 pdf.on_accepted = None                         # the closure holds this call's blob storage
 
     if scalar_walkers:
@@ -187,7 +210,9 @@ def make_theta0s(theta0, ball_radius, pdf, nwalkers: int, ball_radius_halfing_st
     if not callable(pdf):
         raise TypeError("pdf must be callable")
     if hasblob and isinstance(pdf, DeviceLogPdf) and not getattr(pdf, "hasblob", False):
-        raise NotImplementedError("hasblob=True needs a host callable returning (p, blob)")
+        if int(getattr(pdf, "nblob", 0) or 0) <= 0:
+            raise NotImplementedError("hasblob=True needs a host callable returning (p, blob), or a CDensity(..., nblob=m)")
+        hasblob = False                                        # a device density with blobs: calling it returns pdf(tmp)[1] alone (:336)
     if hasblob and not getattr(pdf, "hasblob", False):          # :333-337  p0, blob0 = pdf(tmp)
         pdf_blob = pdf
         pdf = lambda t: pdf_blob(t)[0]
@@ -269,7 +294,9 @@ def squash_walkers(thetas, accept_ratio, logdensities=None, blobs=None, drop_low
     t = flat(thetas)                                           # :398-399
     l = None if logdensities is None else flat(logdensities)   # :401-406
     b = None
-    if blobs is not None:                                      # :408-413
+    if isinstance(blobs, np.ndarray) and blobs.ndim >= 2 and merge_blobs is None:
+        b = flat(blobs)                                        # a dense series [walker][sample](m) (device blobs): append! = concatenation
+    elif blobs is not None:                                    # :408-413
         import copy
         if merge_blobs is None:
             merge_blobs = lambda b1, b2: b1.extend(b2)         # append!

@@ -467,4 +467,23 @@ struct BodyDensity {
     __device__ static double seq_finish(const Seq& q, int ndim, const DensityParams& P) { return F::eval(q.x, ndim, P.p); }
 };
 
+// ... returning a BLOB next to the log-density: the reference's `pdf(theta) -> (p, blob)` with hasblob=true
+// (src/samplers.jl:150-151, :194-196, :257), as NB doubles per evaluation.  F::eval(x, n, p, blob) fills blob[0..NB); the
+// kernels keep the blob of every walker's CURRENT position next to its log-pdf (blob0s[nc] = blob1 on accept, :264) and
+// store it with every sample (reduce_blob!, :270).
+template <class F, int MAXD, int NB>
+struct BodyBlobDensity {
+    static constexpr bool kHasFrag = false;
+    static constexpr int kBlob = NB;
+    struct Seq { double x[MAXD]; double blob[NB]; };
+    __device__ static void seq_init(Seq& q) {
+#pragma unroll 1
+        for (int i = 0; i < NB; ++i) q.blob[i] = 0.0;
+    }
+    __device__ static void seq_add(Seq& q, double v, int d, const DensityParams&) { if (d < MAXD) q.x[d] = v; }
+    __device__ static double seq_finish(Seq& q, int ndim, const DensityParams& P) { return F::eval(q.x, ndim, P.p, q.blob); }
+};
+template <class D, class = void> struct BlobTrait { static constexpr int n = 0; };
+template <class D> struct BlobTrait<D, decltype((void)D::kBlob)> { static constexpr int n = D::kBlob; };
+
 }  // namespace kmc

@@ -1,4 +1,4 @@
-// kmc_host.hpp -- what the host-side translation units of the library share (kmc_api.hip: samplers;
+// kmc_host.hpp -- what the host-side translation units of the library share (kmc_sampler.hip and its siblings: samplers;
 // kmc_metropolis_api.hip: many-chain Metropolis; kmc_acorr.hip: autocorrelation diagnostics).  Internal.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -123,6 +123,7 @@ struct kmc_user_density {
     bool has_pair = false;
     std::string body;                                // kmc_user_density_create_body: the whole function body instead of term / pair
     bool is_body = false;
+    int nblob = 0;                                   // kmc_user_density_create_body_blob: doubles the body writes to blob[] per evaluation
     std::mutex mu;
     std::map<std::string, std::vector<char>> code;   // geometry key -> gfx950 code object
 };

@@ -156,6 +156,9 @@ struct HalfStepArgs {
     // holds two stamps (step + 1; 0 = never; lz_stamps): modified, the last accept it has heard of (absorbed from the byte
     // maps, one launch late), and fetched, its last pull.  A row is pulled when the newest map flags it, when
     // modified > fetched, or when fetched carries THIS step (another wave is rewriting the shadow right now).
+    // blobs of a body density (BodyBlobDensity, NB doubles per evaluation; one walker per lane kernels only)
+    double*           blob;         // [rows][NB]: the blob of every walker's current position (blob0s, src/samplers.jl:210, :264)
+    double*           chain_blob;   // [nsamples][chain_rows][NB] (reduce_blob!, :270) or nullptr
     const unsigned char* lz_amap_in;   // [nranks][4][hloc]  (inside the exported row allocation: peers write it)
     uint2*            lz_stamps;       // [nranks][2][hloc] {x: fetched, y: modified} -- one 8-byte load per walker-step
     unsigned long long* lz_stats;      // diagnostics, or nullptr: [0] remote partner draws, [1] of them pulled over the fabric
@@ -1032,6 +1035,19 @@ __device__ __forceinline__ void half_step_generic_body(const HalfStepFront& f, c
         if (count) a.naccept[gw] += 1u;                                 // :265
     }
     if (sample && a.chain_logp != nullptr) a.chain_logp[row] = acc ? p1 : p0;   // :271
+    if constexpr (BlobTrait<Dens>::n > 0) {
+        constexpr int NB = BlobTrait<Dens>::n;
+        double* cur = a.blob + gw * NB;
+        const bool keep = sample && a.chain_blob != nullptr;
+        if (acc || keep) {
+#pragma unroll 1
+            for (int i = 0; i < NB; ++i) {
+                const double b = acc ? q.blob[i] : cur[i];
+                if (acc) cur[i] = b;                                    // :264
+                if (keep) a.chain_blob[row * NB + i] = b;               // :270
+            }
+        }
+    }
 }
 
 template <class Dens, bool P2P, class T = double>
@@ -1172,6 +1188,19 @@ __device__ __forceinline__ void half_step_staged_body(const HalfStepFront& f, co
         if (count) a.naccept[gw] += 1u;                                 // :265
     }
     if (valid && sample && a.chain_logp != nullptr) a.chain_logp[crow + tid] = acc ? p1 : p0;   // :271
+    if constexpr (BlobTrait<Dens>::n > 0) {
+        constexpr int NB = BlobTrait<Dens>::n;
+        double* cur = a.blob + gw * NB;
+        const bool keep = valid && sample && a.chain_blob != nullptr;
+        if (acc || keep) {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const double b = acc ? q.blob[i] : cur[i];
+                if (acc) cur[i] = b;                                    // :264
+                if (keep) a.chain_blob[(crow + tid) * NB + i] = b;      // :270
+            }
+        }
+    }
 }
 
 // Initial log-pdfs, src/samplers.jl:209.
@@ -1182,6 +1211,7 @@ struct LogpdfArgs {
     int32_t       ndim;
     int32_t       ld;
     DensityParams dp;
+    double*       blob;       // body densities with blobs: [nrows][NB] (or nullptr: log-pdfs only)
 };
 
 template <class Dens>
@@ -1193,6 +1223,12 @@ __device__ __forceinline__ void logpdf_rows_body(const LogpdfArgs& a)
     Dens::seq_init(q);
     for (int d = 0; d < a.ndim; ++d) Dens::seq_add(q, a.pos[r * a.ld + d], d, a.dp);
     a.logp[r] = Dens::seq_finish(q, a.ndim, a.dp);
+    if constexpr (BlobTrait<Dens>::n > 0) {
+        if (a.blob != nullptr) {
+#pragma unroll 1
+            for (int i = 0; i < BlobTrait<Dens>::n; ++i) a.blob[r * BlobTrait<Dens>::n + i] = q.blob[i];   // :209-210
+        }
+    }
 }
 
 template <class Dens>
@@ -1230,6 +1266,7 @@ struct InitBallArgs {
     uint32_t      seed_lo, seed_hi;
     DensityParams dp;
     unsigned long long* fail;
+    double*       blob;       // body densities with blobs: [nrows][NB] of the admitted points, or nullptr
 };
 
 template <class Dens>
@@ -1263,7 +1300,16 @@ __device__ __forceinline__ void init_ball_body(const InitBallArgs& a)
                 }
             }
             const double p = Dens::seq_finish(q, a.ndim, a.dp);
-            if (p > -INFINITY && p == p) { a.logp[r] = p; return; }           // :338
+            if (p > -INFINITY && p == p) {                                    // :338
+                a.logp[r] = p;
+                if constexpr (BlobTrait<Dens>::n > 0) {
+                    if (a.blob != nullptr) {
+#pragma unroll 1
+                        for (int i = 0; i < BlobTrait<Dens>::n; ++i) a.blob[r * BlobTrait<Dens>::n + i] = q.blob[i];
+                    }
+                }
+                return;
+            }
         }
     }
     a.logp[r] = -INFINITY;

@@ -94,6 +94,8 @@ HalfStepArgs make_args(const kmc_sampler* s, int half, bool graph_mode, int64_t 
     a.dp = s->dp;
     a.chain = s->d_chain;
     a.chain_logp = s->d_chain_logp;
+    a.blob = s->d_blob;
+    a.chain_blob = s->d_chain_blob;
     a.chain_rows = s->nlocal;
     a.chain_row0 = (int64_t)half * s->h_loc;
     a.msum = s->d_msum;

@@ -103,7 +103,8 @@ namespace kmc_host {
 bool staged_possible(const kmc_user_density* ud, bool f32, int64_t ndim, bool p2p = false)
 {
     const char* env = std::getenv("KMC_PLAN");
-    return ud->is_body && !f32 && !p2p && ndim >= 1 && ndim <= kStagedMaxDim && !(env && std::strcmp(env, "generic") == 0);
+    // (a blob of more than a few doubles per lane would push the staged kernel's rows out of the registers)
+    return ud->is_body && ud->nblob <= 8 && !f32 && !p2p && ndim >= 1 && ndim <= kStagedMaxDim && !(env && std::strcmp(env, "generic") == 0);
 }
 
 }  // namespace kmc_host
@@ -133,6 +134,7 @@ std::string library_dir()
 std::string kmc_host::user_density_alias(const kmc_user_density* ud, int64_t ndim)
 {
     if (!ud->is_body) return "using UD = kmc::TermPairDensity<UserF>;\n";
+    if (ud->nblob > 0) return "using UD = kmc::BodyBlobDensity<UserB, " + std::to_string(ndim > 0 ? ndim : 1) + ", " + std::to_string(ud->nblob) + ">;\n";
     return "using UD = kmc::BodyDensity<UserB, " + std::to_string(ndim > 0 ? ndim : 1) + ">;\n";
 }
 std::string kmc_host::user_functor_source(const kmc_user_density* ud)
@@ -140,7 +142,8 @@ std::string kmc_host::user_functor_source(const kmc_user_density* ud)
     std::ostringstream src;
     if (ud->is_body) {
         src << "namespace {\nstruct UserB {\n"
-            << "  __device__ static double eval(const double* x, int n, const double* p) { (void)x; (void)n; (void)p;\n" << ud->body << "\n  }\n};\n}\n";
+            << "  __device__ static double eval(const double* x, int n, const double* p" << (ud->nblob > 0 ? ", double* blob" : "") << ") { (void)x; (void)n; (void)p;\n"
+            << ud->body << "\n  }\n};\n}\n";
         return src.str();
     }
     src << "namespace {\nstruct UserF {\n"
@@ -165,8 +168,8 @@ kmc_status compile_user(kmc_user_density* ud, bool with_vec, int L, int K, int i
     if (ud->is_body && (with_vec || resident_K > 0 || island_S > 0))
         return fail(KMC_ERR_UNSUPPORTED, "a body density runs in the one-walker-per-lane kernels only");
     char key[112];
-    std::snprintf(key, sizeof(key), "%d:%d,%d,%d,%d|%d,%d|%d|%d|%lld|%d|%d", (int)with_vec, L, K, iter, (int)ragged, resident_K,
-                  (int)resident_ragged, island_S, (int)f32, ud->is_body ? (long long)ndim : 0ll, (int)staged_possible(ud, f32, ndim, p2p), (int)p2p);
+    std::snprintf(key, sizeof(key), "%d:%d,%d,%d,%d|%d,%d|%d|%d|%lld|%d|%d|%d", (int)with_vec, L, K, iter, (int)ragged, resident_K,
+                  (int)resident_ragged, island_S, (int)f32, ud->is_body ? (long long)ndim : 0ll, (int)staged_possible(ud, f32, ndim, p2p), (int)p2p, ud->nblob);
     const char* peer = p2p ? "true" : "false";         // KMC_P2P: partner rows read from their owners (pull)
     const char* rowt = f32 ? "float" : "double";       // storage type of the walker rows (KMC_F32 / KMC_F64)
     std::lock_guard<std::mutex> lock(ud->mu);
@@ -257,6 +260,25 @@ KMC_EXPORT kmc_status kmc_user_density_create_body(const char* body, kmc_user_de
     *out = ud;
     return KMC_OK;
 }
+
+// ... whose body also fills blob[0 .. nblob): double logpdf(const double* x, int n, const double* p, double* blob)
+KMC_EXPORT kmc_status kmc_user_density_create_body_blob(const char* body, int nblob, kmc_user_density** out)
+{
+    if (!body || !out) return fail(KMC_ERR_BAD_ARG, "null argument");
+    if (nblob < 1 || nblob > 1024) return fail(KMC_ERR_BAD_ARG, "nblob must be in 1 .. 1024 (doubles per evaluation)");
+    *out = nullptr;
+    kmc_user_density* ud = new kmc_user_density();
+    ud->body = body;
+    ud->is_body = true;
+    ud->nblob = nblob;
+    const std::vector<char>* code = nullptr;
+    const kmc_status st = compile_user(ud, false, 0, 0, 0, false, 0, false, 0, false, &code, 4);   // syntax check now (any ndim)
+    if (st != KMC_OK) { delete ud; return st; }
+    *out = ud;
+    return KMC_OK;
+}
+
+KMC_EXPORT int kmc_user_density_nblob(const kmc_user_density* ud) { return ud ? ud->nblob : -1; }
 
 KMC_EXPORT void kmc_user_density_destroy(kmc_user_density* ud) { delete ud; }
 

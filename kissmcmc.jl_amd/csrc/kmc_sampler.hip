@@ -286,6 +286,13 @@ KMC_EXPORT kmc_status kmc_validate(const kmc_config* c)
         if (c->dtype != KMC_F64 || P != 1 || (c->flags & (KMC_P2P | KMC_ISLANDS)))
             return fail(KMC_ERR_UNSUPPORTED, "KMC_STREAM_CHAIN: KMC_F64, one GPU, without KMC_P2P / KMC_ISLANDS / sharding");
     }
+    {
+        const int nb = c->density == KMC_USER_DENSITY && c->user_density ? static_cast<const kmc_user_density*>(c->user_density)->nblob : 0;
+        if ((c->flags & KMC_STORE_BLOBS) && nb == 0)
+            return fail(KMC_ERR_BAD_ARG, "KMC_STORE_BLOBS needs a body density with blobs (kmc_user_density_create_body_blob)");
+        if (nb > 0 && (c->dtype != KMC_F64 || P != 1 || c->deal_count > 0 || (c->flags & (KMC_P2P | KMC_ISLANDS | KMC_STREAM_CHAIN))))
+            return fail(KMC_ERR_UNSUPPORTED, "a density with blobs: KMC_F64, one GPU, without KMC_P2P / KMC_ISLANDS / KMC_STREAM_CHAIN / sharding / dealt sub-ensembles");
+    }
     if (c->deal_count < 0 || (c->deal_count > 0 && (c->deal_rank < 0 || c->deal_rank >= c->deal_count)))
         return fail(KMC_ERR_BAD_ARG, "deal_rank / deal_count out of range");
     if (c->deal_count > 0) {
@@ -359,6 +366,7 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
     s->plan = make_plan(s->cfg, s->h_loc);
     if (cfg->density == KMC_USER_DENSITY) {
         s->user = static_cast<kmc_user_density*>(cfg->user_density);
+        s->nblob = s->user->nblob;
         // small ensembles: resident mode too (one workgroup, LDS within the default 64 KiB limit)
         int rK = 0, rK0 = 1;
         while (2 * rK0 < s->ld / 2) rK0 *= 2;
@@ -603,6 +611,21 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         CREATE_TRY(dev_alloc(s, &s->d_chain, (size_t)chain_slots * (size_t)s->nlocal * ldz * esz));
     if ((cfg->flags & KMC_STORE_LOGP) && s->nsamples > 0)
         CREATE_TRY(dev_alloc(s, &s->d_chain_logp, (size_t)chain_slots * (size_t)s->nlocal * sizeof(double)));
+    if (s->nblob > 0) {
+        CREATE_TRY(dev_alloc(s, &s->d_blob, nw * (size_t)s->nblob * sizeof(double)));
+        CREATE_TRY(hipMemsetAsync(s->d_blob, 0, nw * (size_t)s->nblob * sizeof(double), s->stream));
+        if ((cfg->flags & KMC_STORE_BLOBS) && s->nsamples > 0) {
+            const size_t need_b = (size_t)s->nsamples * (size_t)s->nlocal * (size_t)s->nblob * sizeof(double);
+            size_t free_b = 0, total_b = 0;
+            CREATE_TRY(hipMemGetInfo(&free_b, &total_b));
+            if (need_b > free_b) {
+                kmc_status r_ = fail(KMC_ERR_OOM, "the stored blobs need " + std::to_string(need_b >> 20) + " MiB of device memory, " + std::to_string(free_b >> 20) + " MiB are free: thin the chain (nthin)");
+                kmc_sampler_destroy(s);
+                return r_;
+            }
+            CREATE_TRY(dev_alloc(s, &s->d_chain_blob, need_b));
+        }
+    }
     CREATE_TRY(hipStreamSynchronize(s->stream));         // the fills above (asynchronous, one wait for all of them)
 #undef CREATE_TRY
     if (s->p2p) {
@@ -661,6 +684,8 @@ KMC_EXPORT void kmc_sampler_destroy(kmc_sampler* s)
     (void)hipFree(s->bw_scratch);
     (void)hipFree(s->bw_scratch_logp);
     (void)hipFree(s->d_chain_logp);
+    (void)hipFree(s->d_blob);
+    (void)hipFree(s->d_chain_blob);
     (void)hipFree(s->d_msum);
     (void)hipFree(s->d_msumsq);
     (void)hipFree(s->d_ring);
@@ -756,6 +781,7 @@ KMC_EXPORT kmc_status kmc_sampler_describe(const kmc_sampler* s, char* buf, int6
     if (s->d_ids) o << "; dealt sub-ensemble " << s->cfg.deal_rank << "/" << s->cfg.deal_count << " (walkers re-dealt between epochs)";
     if (s->d_mring) o << "; moments through a ring of " << s->mring_depth << " posted rows per wave";
     if (s->user) o << "; runtime-compiled density";
+    if (s->nblob > 0) o << " with a blob of " << s->nblob << " doubles per walker" << (s->d_chain_blob ? " (stored with every sample)" : "");
     if (s->p2p) o << "; P2P shard " << s->cfg.shard_rank << "/" << s->cfg.shard_count << (s->connected ? "" : " (not connected)");
     else if (s->cfg.shard_count > 1 || s->comm)
         o << "; replica shard " << s->cfg.shard_rank << "/" << s->cfg.shard_count

@@ -55,6 +55,9 @@ struct kmc_sampler {
     kmc::SchedEntry* d_sched = nullptr;
     double* d_chain = nullptr;
     double* d_chain_logp = nullptr;
+    int nblob = 0;                     // body density with blobs: doubles per evaluation (kmc_user_density::nblob)
+    double* d_blob = nullptr;          //   [nrows][nblob]: blob of every walker's current position (blob0s, src/samplers.jl:210, :264)
+    double* d_chain_blob = nullptr;    //   [nsamples][nlocal][nblob]: KMC_STORE_BLOBS (:270)
     double* d_msum = nullptr;
     double* d_msumsq = nullptr;
     double2* d_mring = nullptr;       // moment ring (HalfStepArgs::mring): [waves][mring_depth][K][64] rows

@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void narrow_rows(const double* src, float* dst
     if (i < n) dst[i] = (float)src[i];
 }
 
-kmc_status eval_initial_logp(kmc_sampler* s)
+kmc_status eval_initial_logp(kmc_sampler* s, double* logp_out = nullptr)      // (logp_out: somewhere else than d_logp -- a caller that only wants the blobs)
 {
     const size_t nw = (size_t)s->nrows, nd = (size_t)s->cfg.ndim;
     double* rows = s->d_pos;
@@ -37,7 +37,7 @@ kmc_status eval_initial_logp(kmc_sampler* s)
         hipLaunchKernelGGL(widen_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, reinterpret_cast<const float*>(s->d_pos), scratch, n);
         rows = scratch;
     }
-    const LogpdfArgs la{rows, s->d_logp, (int64_t)nw, (int32_t)nd, (int32_t)s->ld, s->dp};
+    const LogpdfArgs la{rows, logp_out ? logp_out : s->d_logp, (int64_t)nw, (int32_t)nd, (int32_t)s->ld, s->dp, s->d_blob};   // (blobs of the initial evaluations, :209-210)
     hipError_t e = hipSuccess;
     if (s->user) {
         e = launch_module(s->uk.logpdf, (unsigned)((nw + 255) / 256), 256u, s->stream, la);
@@ -124,6 +124,7 @@ KMC_EXPORT kmc_status kmc_sampler_init_ball(kmc_sampler* s, const double* theta0
         a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
         a.dp = s->dp;
         a.fail = d_fail;
+        a.blob = s->d_blob;
         const unsigned grid = (unsigned)((rows + 255) / 256);
         if (s->user) e = launch_module(s->uk.init_ball, grid, 256u, s->stream, a);
         else { hipLaunchKernelGGL(fn, dim3(grid), dim3(256), 0, s->stream, a); e = hipGetLastError(); }
@@ -183,6 +184,17 @@ KMC_EXPORT kmc_status kmc_sampler_set_state(kmc_sampler* s, const double* pos_ho
         HIP_TRY(fill_sync(s->d_flags, 0, 4096, s->stream));
         HIP_TRY(fill_sync(s->d_err, 0, 64, s->stream));
         if (s->d_done) HIP_TRY(fill_sync(s->d_done, 0, 33 * 64, s->stream));
+    }
+    if (s->d_blob) {
+        // the blobs of the restored positions: evaluated again (same kernel and order as the initial evaluation: same bits);
+        // the restored log-pdfs stay as given
+        double* scratch = nullptr;
+        HIP_TRY(hipMalloc((void**)&scratch, nw * sizeof(double)));
+        const kmc_status bst = eval_initial_logp(s, scratch);
+        const hipError_t be = hipStreamSynchronize(s->stream);
+        (void)hipFree(scratch);
+        KMC_TRY(bst);
+        HIP_TRY(be);
     }
     s->generation = generation;            // the device counter follows at the next graph replay
     const int64_t done = samples_done(s);
@@ -380,6 +392,26 @@ KMC_EXPORT kmc_status kmc_sampler_get_moments(kmc_sampler* s, double* sum, doubl
     return KMC_OK;
 }
 
+// Blobs of a body density with blobs (include/kissmcmc_hip.h): the current ones, and the stored series (KMC_STORE_BLOBS).
+KMC_EXPORT kmc_status kmc_sampler_get_blobs(kmc_sampler* s, double* current, double* stored, int by_walker)
+{
+    if (!s) return fail(KMC_ERR_BAD_ARG, "null sampler");
+    if (s->nblob == 0) return fail(KMC_ERR_BAD_ARG, "this sampler's density returns no blobs (kmc_user_density_create_body_blob)");
+    HIP_TRY(hipSetDevice(s->cfg.device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    const size_t nb = (size_t)s->nblob;
+    if (current) HIP_TRY(copy_sync(current, s->d_blob, (size_t)s->nrows * nb * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    if (stored) {
+        if (!s->d_chain_blob && s->nsamples > 0) return fail(KMC_ERR_BAD_ARG, "sampler was created without KMC_STORE_BLOBS");
+        const int64_t K = samples_done(s);
+        if (K > 0) {
+            if (by_walker) KMC_TRY(download_by_walker(s->d_chain_blob, false, s->nlocal, (int64_t)nb, (int64_t)nb, K, stored, s->stream));
+            else HIP_TRY(copy_sync(stored, s->d_chain_blob, (size_t)K * (size_t)s->nlocal * nb * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+        }
+    }
+    return KMC_OK;
+}
+
 KMC_EXPORT uint64_t kmc_deal_seed(uint64_t seed, int32_t deal_rank) { return deal_seed(seed, deal_rank); }
 
 KMC_EXPORT kmc_status kmc_deal_perm(uint64_t seed, int64_t epoch, int32_t deal_rank, int64_t S, int64_t* A, int64_t* C)
@@ -461,10 +493,12 @@ KMC_EXPORT kmc_status kmc_emcee_run(const kmc_config* cfg, const double* theta0,
     kmc_config c = *cfg;
     if (out->chain) c.flags |= KMC_STORE_CHAIN;
     if (out->chain_logp) c.flags |= KMC_STORE_LOGP;
+    if (out->blobs) c.flags |= KMC_STORE_BLOBS;
     if (out->sum || out->sumsq) c.flags |= KMC_MOMENTS;
     c.shard_rank = 0;
     c.shard_count = 1;
-    if ((out->chain || out->chain_logp) && c.dtype == KMC_F64 && !(c.flags & (KMC_ISLANDS | KMC_P2P)) && c.nthin > 0 && c.ngenerations > c.nburnin) {
+    const bool has_blobs = c.density == KMC_USER_DENSITY && c.user_density && static_cast<const kmc_user_density*>(c.user_density)->nblob > 0;
+    if ((out->chain || out->chain_logp) && !has_blobs && c.dtype == KMC_F64 && !(c.flags & (KMC_ISLANDS | KMC_P2P)) && c.nthin > 0 && c.ngenerations > c.nburnin) {
         // a chain that does not fit the device is streamed to the caller's buffers while sampling (KMC_STREAM_CHAIN)
         size_t free_b = 0, total_b = 0;
         const size_t ns = (size_t)((c.ngenerations - c.nburnin) / c.nthin), nw_ = (size_t)c.nwalkers;
@@ -482,6 +516,7 @@ KMC_EXPORT kmc_status kmc_emcee_run(const kmc_config* cfg, const double* theta0,
     if (st == KMC_OK) st = kmc_sampler_last_run_ms(s, &out->device_ms);
     if (st == KMC_OK && (out->chain || out->chain_logp))
         st = (c.flags & KMC_CHAIN_BY_WALKER) ? kmc_sampler_get_chain_by_walker(s, out->chain, out->chain_logp) : kmc_sampler_get_chain(s, out->chain, out->chain_logp);
+    if (st == KMC_OK && out->blobs) st = kmc_sampler_get_blobs(s, nullptr, out->blobs, (c.flags & KMC_CHAIN_BY_WALKER) ? 1 : 0);
     if (st == KMC_OK && out->accept_ratio) st = kmc_sampler_get_accept_ratio(s, out->accept_ratio);
     if (st == KMC_OK && out->naccept) st = kmc_sampler_get_naccept(s, out->naccept);
     if (st == KMC_OK && out->final_pos) st = kmc_sampler_get_positions(s, out->final_pos);
@@ -548,6 +583,45 @@ KMC_EXPORT kmc_status kmc_logpdf_eval_host(const kmc_config* cfg, const double* 
     if (e == hipSuccess && st == KMC_OK) e = copy_sync(logp_host, dlp, (size_t)nrows * sizeof(double), hipMemcpyDeviceToHost, ss.st);
     (void)hipFree(dpos);
     (void)hipFree(dlp);
+    if (st != KMC_OK) return st;
+    HIP_TRY(e);
+    return KMC_OK;
+}
+
+// ... and the blobs with them (a body density with blobs; the reference's `pdf.(theta0s)` under hasblob=true, src/samplers.jl:209-210,
+// and make_theta0s' `pdf(theta)[1]`, :336): blob_host [nrows][nblob].
+KMC_EXPORT kmc_status kmc_logpdf_blob_eval_host(const kmc_config* cfg, const double* pos_host, double* logp_host, double* blob_host, int64_t nrows)
+{
+    if (!cfg || !pos_host || !logp_host || !blob_host || nrows < 0) return fail(KMC_ERR_BAD_ARG, "bad argument");
+    const kmc_user_density* ud = cfg->density == KMC_USER_DENSITY ? static_cast<const kmc_user_density*>(cfg->user_density) : nullptr;
+    if (!ud || ud->nblob == 0) return fail(KMC_ERR_BAD_ARG, "kmc_logpdf_blob_eval_host needs a body density with blobs (kmc_user_density_create_body_blob)");
+    if (nrows == 0) return KMC_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { (void)hipGetLastError(); return fail(KMC_ERR_NO_DEVICE, "no HIP device visible"); }
+    HIP_TRY(hipSetDevice(cfg->device));
+    DensityParams dp;
+    KMC_TRY(digest_params(*cfg, &dp));
+    ScopedStream ss;
+    HIP_TRY(ss.create());
+    const size_t nb = (size_t)nrows * (size_t)cfg->ndim * sizeof(double), bb = (size_t)nrows * (size_t)ud->nblob * sizeof(double);
+    char* buf = nullptr;
+    HIP_TRY(hipMalloc((void**)&buf, nb + (size_t)nrows * sizeof(double) + bb));
+    double* dpos = reinterpret_cast<double*>(buf);
+    double* dlp = dpos + (size_t)nrows * (size_t)cfg->ndim;
+    double* dbl = dlp + nrows;
+    UserKernels uk;
+    kmc_status st = load_user(const_cast<kmc_user_density*>(ud), false, 0, 0, 0, false, &uk, 0, false, 0, false, cfg->ndim);
+    hipError_t e = hipSuccess;
+    if (st == KMC_OK) {
+        e = copy_sync(dpos, pos_host, nb, hipMemcpyHostToDevice, ss.st);
+        const LogpdfArgs la{dpos, dlp, nrows, (int32_t)cfg->ndim, (int32_t)cfg->ndim, dp, dbl};
+        if (e == hipSuccess) e = launch_module(uk.logpdf, (unsigned)((nrows + 255) / 256), 256u, ss.st, la);
+        if (e == hipSuccess) e = hipStreamSynchronize(ss.st);
+        if (e == hipSuccess) e = copy_sync(logp_host, dlp, (size_t)nrows * sizeof(double), hipMemcpyDeviceToHost, ss.st);
+        if (e == hipSuccess) e = copy_sync(blob_host, dbl, bb, hipMemcpyDeviceToHost, ss.st);
+        (void)hipModuleUnload(uk.mod);
+    }
+    (void)hipFree(buf);
     if (st != KMC_OK) return st;
     HIP_TRY(e);
     return KMC_OK;

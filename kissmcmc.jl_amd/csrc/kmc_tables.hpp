@@ -1,5 +1,5 @@
 // kmc_tables.hpp -- kernel instantiation tables.  Each density's table is compiled in its own
-// translation unit (kmc_inst_<density>.hip) so the build can run them in parallel; kmc_api.hip only
+// translation unit (kmc_inst_<density>.hip) so the build can run them in parallel; the host driver only
 // sees the per-density entry points declared at the bottom.
 #pragma once
 #include "kmc_islands.hpp"

@@ -244,24 +244,53 @@ class CDensity(ExprDensity):
 
     It runs one walker per lane (rows staged through LDS up to ndim 64, the generic kernel above), so it is about half as
     fast as a menu density or an :class:`ExprDensity` of the same form, and orders of magnitude faster than a host callable (:class:`HostLogPdf`).  ``kmc_user_density_create_body``.
+
+    ``nblob=m`` makes it the reference's ``pdf(theta) -> (p, blob)`` of ``hasblob=true`` (``src/samplers.jl:150-151, :194-196``)
+    on the device: the body is then that of ``double logpdf(const double* x, int n, const double* p, double* blob)`` and fills
+    ``blob[0..m)`` (zero on entry); the sampler carries each walker's current blob next to its log-pdf and ``emcee(...,
+    hasblob=True)`` returns ``blobs[w][k]`` as an array ``[nwalkers, nsamples, m]`` (or whatever ``init_blobs`` / ``reduce_blob``
+    build from that series) -- without the host round trip per half-step a Python callable costs.
     """
 
     name = "cbody"
 
-    def __init__(self, body: str, params=()):
+    def __init__(self, body: str, params=(), nblob: int = 0):
         import ctypes as C
         if len(params) > 6:
             raise ValueError("at most 6 parameters")
         self.body = str(body)
         self.term, self.pair = None, None
         self._params = [float(v) for v in params]
+        self.nblob = int(nblob)
         self._L = _lib.lib()
         h = C.c_void_p()
-        _lib.check(self._L.kmc_user_density_create_body(self.body.encode(), C.byref(h)))
+        if self.nblob > 0:
+            _lib.check(self._L.kmc_user_density_create_body_blob(self.body.encode(), self.nblob, C.byref(h)))
+        else:
+            _lib.check(self._L.kmc_user_density_create_body(self.body.encode(), C.byref(h)))
         self.user_handle = h
 
     def __repr__(self):
-        return f"CDensity({self.body!r}, params={self._params})"
+        return f"CDensity({self.body!r}, params={self._params}" + (f", nblob={self.nblob})" if self.nblob else ")")
+
+    def eval_with_blobs(self, X):
+        """``(logp [n], blobs [n, nblob])`` of the rows of ``X`` (evaluated on the device): ``pdf.(theta0s)`` of ``src/samplers.jl:209-210``."""
+        import ctypes as C
+        if self.nblob <= 0:
+            raise ValueError("this density returns no blobs (CDensity(..., nblob=m))")
+        X = np.ascontiguousarray(np.atleast_2d(np.asarray(X, dtype=np.float64)))
+        n, nd = X.shape
+        cfg = _lib.Config()
+        cfg.density = self.density_id
+        p = list(self.params()) + [0.0] * 8
+        for i in range(8):
+            cfg.params[i] = float(p[i])
+        cfg.nwalkers, cfg.ndim, cfg.nthin, cfg.a_scale = max(2, n + n % 2), nd, 1, 2.0
+        cfg.user_density = self.user_handle
+        lp, bl = np.empty(n), np.empty((n, self.nblob))
+        dp = C.POINTER(C.c_double)
+        _lib.check(self._L.kmc_logpdf_blob_eval_host(C.byref(cfg), X.ctypes.data_as(dp), lp.ctypes.data_as(dp), bl.ctypes.data_as(dp), n))
+        return lp, bl
 
 
 class HostLogPdf(DeviceLogPdf):

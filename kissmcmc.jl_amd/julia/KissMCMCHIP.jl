@@ -51,24 +51,27 @@ density_id(::MvNormal2) = Cint(4);   params(d::MvNormal2) = [d.mean[1], d.mean[2
 # Runtime-compiled user density (hiprtc): log p = sum_d term(x_d) + sum_{d<n-1} pair(x_d, x_{d+1}); see
 # kmc_user_density_create in include/kissmcmc_hip.h.  The host call evaluates it on the device.
 mutable struct ExprDensity <: DeviceLogPdf
-    handle::Ptr{Cvoid}; p::Vector{Float64}
-    ExprDensity(handle::Ptr{Cvoid}, p::Vector{Float64}) = new(handle, p)          # (an existing handle: CDensity below)
+    handle::Ptr{Cvoid}; p::Vector{Float64}; nblob::Int
+    ExprDensity(handle::Ptr{Cvoid}, p::Vector{Float64}, nblob::Int=0) = new(handle, p, nblob)   # (an existing handle: CDensity below)
     function ExprDensity(term::String, pair::Union{String,Nothing}=nothing; params=Float64[])
         h = Ref{Ptr{Cvoid}}(C_NULL)
         st = ccall((:kmc_user_density_create, LIB), Cint, (Cstring, Cstring, Ref{Ptr{Cvoid}}), term, pair === nothing ? "" : pair, h)
         st == 0 || error("kmc_user_density_create failed: $(last_error())")
-        d = new(h[], collect(Float64, params))
+        d = new(h[], collect(Float64, params), 0)
         finalizer(x -> ccall((:kmc_user_density_destroy, LIB), Cvoid, (Ptr{Cvoid},), x.handle), d)
         return d
     end
 end
 # The general device form: the BODY of `double logpdf(const double* x, int n, const double* p) { BODY }` (C++), any coupling
-# between the dimensions; runs one walker per lane (kmc_user_density_create_body).
-function CDensity(body::String; params=Float64[])
+# between the dimensions; runs one walker per lane (kmc_user_density_create_body).  `nblob=m`: the reference's
+# `pdf(theta) -> (p, blob)` of hasblob=true (src/samplers.jl:150-151) on the device -- the body is then that of
+# `double logpdf(const double* x, int n, const double* p, double* blob)` and fills blob[0..m) (kmc_user_density_create_body_blob).
+function CDensity(body::String; params=Float64[], nblob::Int=0)
     h = Ref{Ptr{Cvoid}}(C_NULL)
-    st = ccall((:kmc_user_density_create_body, LIB), Cint, (Cstring, Ref{Ptr{Cvoid}}), body, h)
+    st = nblob > 0 ? ccall((:kmc_user_density_create_body_blob, LIB), Cint, (Cstring, Cint, Ref{Ptr{Cvoid}}), body, nblob, h) :
+                     ccall((:kmc_user_density_create_body, LIB), Cint, (Cstring, Ref{Ptr{Cvoid}}), body, h)
     st == 0 || error("kmc_user_density_create_body failed: $(last_error())")
-    d = ExprDensity(h[], collect(Float64, params))
+    d = ExprDensity(h[], collect(Float64, params), nblob)
     finalizer(x -> ccall((:kmc_user_density_destroy, LIB), Cvoid, (Ptr{Cvoid},), x.handle), d)
     return d
 end
@@ -174,6 +177,7 @@ Base.@kwdef mutable struct KmcOutputs
     nmoment::Int64 = 0
     nsamples::Int64 = 0
     device_ms::Float64 = 0.0
+    blobs::Ptr{Float64} = C_NULL
 end
 
 const KMC_STORE_CHAIN = UInt32(1) << 0
@@ -188,15 +192,17 @@ last_error() = unsafe_string(ccall((:kmc_last_error, LIB), Cstring, ()))
 
 Same meaning as KissMCMC.emcee (src/samplers.jl:188-197); returns
 `(thetas, accept_ratio, logdensities, blobs)` with `thetas[w][k]` (src/samplers.jl:292).
-`hasblob=true` needs a host closure as `pdf` (blobs are host objects).
+`hasblob=true` needs a `pdf` that returns a blob: a host closure (`HostLogPdf(f; hasblob=true)`, blobs of any type, kept on
+the host) or a `CDensity(body; nblob=m)` (m doubles computed and carried on the device; `blobs[w][k]::Vector{Float64}`).
 """
 function emcee(pdf::DeviceLogPdf, theta0s; niter=10^5, nburnin=niter ÷ 2, nthin=1, a_scale=2.0,
                use_progress_meter=true, hasblob=false,
                init_blobs=(blob0, nsamples) -> sizehint!(typeof(blob0)[], nsamples),      # init_output_vector :80-85
                reduce_blob! =(blobs, blob) -> push!(blobs, blob),                         # :196
                seed=rand(UInt64), device=0, dtype=:f64)     # dtype=:f32: float rows on the device (KMC_F32), built-in densities
-    hasblob && !(pdf isa HostLogPdf && pdf.hasblob) &&
-        error("hasblob=true needs a host closure as pdf: device densities return the log-pdf alone")
+    device_blobs = hasblob && pdf isa ExprDensity && pdf.nblob > 0
+    hasblob && !device_blobs && !(pdf isa HostLogPdf && pdf.hasblob) &&
+        error("hasblob=true needs a pdf that returns a blob: HostLogPdf(f; hasblob=true) or CDensity(body; nblob=m)")
     nwalkers = length(theta0s)
     scalar = theta0s[1] isa Number
     ndim = length(theta0s[1])
@@ -230,7 +236,9 @@ function emcee(pdf::DeviceLogPdf, theta0s; niter=10^5, nburnin=niter ÷ 2, nthin
     chain = Array{Float64}(undef, ndim * nsamples * nwalkers)
     clogp = Array{Float64}(undef, nsamples * nwalkers)
     acc = Vector{Float64}(undef, nwalkers)
-    out = KmcOutputs(chain=pointer(chain), chain_logp=pointer(clogp), accept_ratio=pointer(acc))
+    nblob = device_blobs ? pdf.nblob : 0
+    bl = Array{Float64}(undef, nblob * nsamples * nwalkers)          # device blobs: [walker][sample][nblob] (src/samplers.jl:270)
+    out = KmcOutputs(chain=pointer(chain), chain_logp=pointer(clogp), accept_ratio=pointer(acc), blobs=(device_blobs ? pointer(bl) : C_NULL))
     # The chain in the reference's own order (thetas[w][k], :219-221), reordered on the device.  A chain too large for
     # the device is streamed into these arrays while sampling (kmc_emcee_run decides, KMC_STREAM_CHAIN) and then arrives
     # sample-major: that combination is refused (status 9) and the call is repeated without the flag.
@@ -241,7 +249,7 @@ function emcee(pdf::DeviceLogPdf, theta0s; niter=10^5, nburnin=niter ÷ 2, nthin
                             ngenerations=niter_walker, nburnin=nburnin_walker, nthin=nthin, a_scale=a_scale, seed=UInt64(seed),
                             flags=KMC_STORE_CHAIN | KMC_STORE_LOGP | flag, device=Int32(device), user_density=user_handle(pdf),
                             host_logpdf=host_fn, host_user=host_ctx, host_accepted=acc_fn))
-        st = GC.@preserve pdf theta chain clogp acc ccall((:kmc_emcee_run, LIB), Cint,
+        st = GC.@preserve pdf theta chain clogp acc bl ccall((:kmc_emcee_run, LIB), Cint,
                                                        (Ref{KmcConfig}, Ptr{Float64}, Ref{KmcOutputs}), cfg, theta, out)
         (st == 9 && by_walker && occursin("KMC_CHAIN_BY_WALKER", last_error())) || break
     end
@@ -252,6 +260,20 @@ function emcee(pdf::DeviceLogPdf, theta0s; niter=10^5, nburnin=niter ÷ 2, nthin
     thetas = scalar ? [ch[1, :, w] for w in 1:nwalkers] :
                       [[ch[:, k, w] for k in 1:nsamples] for w in 1:nwalkers]
     logdensities = [lp[:, w] for w in 1:nwalkers]
+    if device_blobs
+        # blob0s = the blobs of the initial evaluations (:209-210); then the caller's init_blobs / reduce_blob! over each
+        # walker's stored series, in order (:238, :270)
+        lp0 = Vector{Float64}(undef, nwalkers); b0 = Matrix{Float64}(undef, nblob, nwalkers)
+        cfg0 = Ref(KmcConfig(density=density_id(pdf), params=p8, nwalkers=nwalkers, ndim=ndim, user_density=user_handle(pdf), device=Int32(device)))
+        st0 = ccall((:kmc_logpdf_blob_eval_host, LIB), Cint, (Ref{KmcConfig}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64), cfg0, theta, lp0, b0, nwalkers)
+        st0 == 0 || error("kmc_logpdf_blob_eval_host failed ($st0): $(last_error())")
+        B = by_walker ? reshape(bl, nblob, nsamples, nwalkers) : permutedims(reshape(bl, nblob, nwalkers, nsamples), (1, 3, 2))
+        blobs = [init_blobs(b0[:, w], nsamples) for w in 1:nwalkers]
+        for w in 1:nwalkers, k in 1:nsamples
+            reduce_blob!(blobs[w], B[:, k, w])
+        end
+        return thetas, acc, logdensities, blobs
+    end
     return thetas, acc, logdensities, (pdf isa HostLogPdf && pdf.hasblob) ? pdf.blobs : nothing   # :292
 end
 # (a bare closure as `pdf` is KissMCMC.emcee's own CPU method; `emcee(HostLogPdf(f; hasblob), theta0s; ...)` runs the

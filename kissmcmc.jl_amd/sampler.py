@@ -24,7 +24,7 @@ class Sampler:
                  device: int = 0, shard_rank: int = 0, shard_count: int = 1, p2p: bool = False,
                  island_gens: int = 0, island_size: int = 0, p2p_finegrained: bool = False, p2p_fold: bool = False, p2p_push: bool = False,
                  dtype: str = "f64", p2p_lazy: bool = False, deal_rank: int = 0, deal_count: int = 0,
-                 stream_chain: bool = False, chain_by_walker: bool = False):
+                 stream_chain: bool = False, chain_by_walker: bool = False, store_blobs: bool = False):
         if not isinstance(pdf, DeviceLogPdf):
             raise TypeError(
                 "pdf must be a menu log-density (GaussianIso, Exponential, Rosenbrock, LogNormal, MvNormal2), "
@@ -54,6 +54,9 @@ class Sampler:
             flags |= _lib.MOMENTS
         if not use_graph:
             flags |= _lib.NO_GRAPH
+        if store_blobs:
+            flags |= _lib.STORE_BLOBS      # a CDensity(..., nblob=m): keep the blob of every stored sample (src/samplers.jl:270)
+        self.nblob = int(getattr(pdf, "nblob", 0) or 0)
         if stream_chain and (store_chain or store_logp):
             # KMC_STREAM_CHAIN: the chain goes to host arrays block by block while sampling (bounded by host RAM, not HBM)
             flags |= _lib.STREAM_CHAIN
@@ -340,6 +343,24 @@ class Sampler:
         n = C.c_int64()
         _lib.check(self._L.kmc_sampler_get_moments(self._h, _dp(s), _dp(q), C.byref(n)))
         return s, q, n.value
+
+    def blobs(self, by_walker: bool = True):
+        """Stored blobs of a ``CDensity(..., nblob=m)`` sampler created with ``store_blobs=True``: ``[nwalkers, k, m]`` --
+        ``blobs[w][k]``, the reference's order (``src/samplers.jl:238, :270``) -- or ``[k, nwalkers, m]`` sample-major."""
+        if self.nblob <= 0:
+            raise ValueError("this sampler's density returns no blobs (CDensity(..., nblob=m))")
+        k = max(0, min(self.nsamples, (self.generation - self.cfg.nburnin) // self.cfg.nthin))
+        out = np.empty((self.nlocal, k, self.nblob) if by_walker else (k, self.nlocal, self.nblob))
+        _lib.check(self._L.kmc_sampler_get_blobs(self._h, None, _dp(out), 1 if by_walker else 0))
+        return out
+
+    def current_blobs(self):
+        """The blob of every walker's current position, ``[nwalkers, m]`` (``blob0s``, ``src/samplers.jl:210, :264``)."""
+        if self.nblob <= 0:
+            raise ValueError("this sampler's density returns no blobs (CDensity(..., nblob=m))")
+        out = np.empty((self.nrows, self.nblob))
+        _lib.check(self._L.kmc_sampler_get_blobs(self._h, _dp(out), None, 0))
+        return out
 
     def chain(self, logp: bool = True, by_walker: bool = False):
         """``(chain [nsamples_done, nlocal, ndim], chain_logp [nsamples_done, nlocal] | None)``; with ``by_walker`` in the

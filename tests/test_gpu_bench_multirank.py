@@ -59,3 +59,24 @@ def test_bench_two_ranks_allgather_ladder():
     # two ranks on one device: ncclCommInitRank refuses, every rank takes the torch-collective rung together
     assert "native RCCL all-gather set-up failed" in err
     assert "torch collective per half-step" in out["config"]["parallelism"]
+
+
+def test_bench_two_ranks_under_torch_distributed_run():
+    """The driver's own form: python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2 -- bench.py is then ONE rank
+    of the job and must not spawn anything itself."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update({"KMC_BENCH_BACKEND": "gloo", "KMC_BENCH_WALKERS": "4096", "KMC_BENCH_RUNG_TIMEOUT": "240", "KMC_BENCH_NO_ALLGATHER_EXTRA": "1"})
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["check"]["timed_run_equals_unsharded_run"] is True
+    assert out["collective"]["launcher"].startswith("external") and "allgather_mode" not in out
+    assert "[bench launcher]" not in r.stderr
