@@ -461,7 +461,7 @@ typedef struct kmc_metropolis_config {
     int64_t  nthin;         /*                                      src/samplers.jl:64 */
     const double* step;     /* host [ndim]: proposal scale per dimension (theta + step .* randn) */
     uint64_t seed;
-    uint32_t flags;         /* KMC_STORE_CHAIN | KMC_STORE_LOGP | KMC_MOMENTS | KMC_CHAIN_BY_WALKER (chain [nchains][nsamples][ndim],
+    uint32_t flags;         /* KMC_STORE_CHAIN | KMC_STORE_LOGP | KMC_MOMENTS | KMC_STORE_BLOBS | KMC_CHAIN_BY_WALKER (chain [nchains][nsamples][ndim],
                                chain_logp [nchains][nsamples]: thetas[chain][sample], reordered on the device) */
     int32_t  device;
     void*    user_density;  /* kmc_user_density* when density == KMC_USER_DENSITY */
@@ -487,6 +487,10 @@ typedef struct kmc_metropolis_outputs {
     double*  chain_sumsq;   /* [nchains][ndim] */
     int64_t  nsamples;      /* out: (niter - nburnin) / nthin   src/samplers.jl:88 */
     double   device_ms;     /* out: the sampling kernels only (HIP events) */
+    double*  blobs;         /* [nsamples][nchains][nblob] ([nchains][nsamples][nblob] with KMC_CHAIN_BY_WALKER): the blob of every stored
+                               sample (hasblob=true, src/samplers.jl:70-72, :103, :117) of a body density created with
+                               kmc_user_density_create_body_blob; in-kernel chains only (no host_propose) */
+    double*  final_blob;    /* [nchains][nblob]: blob0 of every chain at the end */
 } kmc_metropolis_outputs;
 
 /* Argument sanity only (the reference asserts nothing for metropolis).  No device needed. */

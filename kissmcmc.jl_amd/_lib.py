@@ -128,6 +128,8 @@ class MetropolisOutputs(C.Structure):
         ("chain_sumsq", C.POINTER(C.c_double)),
         ("nsamples", C.c_int64),
         ("device_ms", C.c_double),
+        ("blobs", C.POINTER(C.c_double)),
+        ("final_blob", C.POINTER(C.c_double)),
     ]
 
 

@@ -73,6 +73,14 @@ def emcee(pdf, theta0s, niter: int = 10 ** 5, nburnin=None, nthin: int = 1, a_sc
     """
     theta0s = np.array(theta0s, dtype=np.float64)              # :198 deepcopy
     scalar_walkers = theta0s.ndim == 1
+    # walkers of any array shape (the reference asks of theta0s[1] only `.+`, `.*` and `length`, :156 -- a Matrix qualifies):
+    # the sampler sees them flattened (N = length(theta0s[1]), :243), a host callable and the caller see the shape
+    walker_shape = theta0s.shape[1:] if theta0s.ndim > 2 else None
+    if walker_shape is not None:
+        theta0s = theta0s.reshape(theta0s.shape[0], -1)
+        if callable(pdf) and not isinstance(pdf, DeviceLogPdf):
+            fn_shaped = pdf
+            pdf = lambda x: fn_shaped(np.asarray(x).reshape(walker_shape))
     if not hasblob and (init_blobs is not None or reduce_blob is not None):
         raise ValueError("init_blobs / reduce_blob need hasblob=True")
     if hasblob:
@@ -169,6 +177,8 @@ def emcee(pdf, theta0s, niter: int = 10 ** 5, nburnin=None, nthin: int = 1, a_sc
     if scalar_walkers:
         thetas = thetas[:, :, 0]
     assert thetas.shape[1] == nsamples_walker
+    if walker_shape is not None:
+        thetas = thetas.reshape(thetas.shape[:2] + tuple(walker_shape))
     return thetas, accept_ratio, logdensities, blobs
 
 

@@ -45,6 +45,9 @@ struct MetropolisArgs {
     int32_t       ndim;
     uint32_t      seed_lo, seed_hi;
     DensityParams dp;
+    // blobs of a body density (BodyBlobDensity, NB doubles per evaluation; the any-ndim kernel): hasblob=true, src/samplers.jl:70-72
+    double*       blob;        // [nchains][NB]: blob0 of every chain (:72, :103)
+    double*       chain_blob;  // [nsamples][nchains][NB] (reduce_blob!, :117) or nullptr
 };
 
 __device__ __forceinline__ void normal_pair(uint32_t a, uint32_t b, double& n0, double& n1)
@@ -199,6 +202,19 @@ __device__ __forceinline__ void metropolis_chains_any_body(const MetropolisArgs&
             cnt = 0;
             store = slot < a.nsamples;
             if (!store) ++slot;
+        }
+        if constexpr (BlobTrait<Dens>::n > 0) {
+            constexpr int NB = BlobTrait<Dens>::n;
+            double* cur = a.blob + c * NB;
+            const bool keep = store && a.chain_blob != nullptr;
+            if (acc || keep) {
+#pragma unroll 1
+                for (int i = 0; i < NB; ++i) {
+                    const double bv = acc ? q.blob[i] : cur[i];
+                    if (acc) cur[i] = bv;                                    // :103 blob0 = blob1
+                    if (keep) a.chain_blob[(slot * nc + c) * NB + i] = bv;   // :117 reduce_blob!(blobs, blob0)
+                }
+            }
         }
         if (acc || store) {
             for (int d = 0; d < ndim; ++d) {

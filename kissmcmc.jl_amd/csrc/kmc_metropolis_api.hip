@@ -69,7 +69,7 @@ kmc_status compile_user_metropolis(kmc_user_density* ud, int ND, const std::vect
 // device buffers of one kmc_metropolis_run call
 struct MetroBuffers {
     double *pos = nullptr, *logp = nullptr, *chain = nullptr, *chain_logp = nullptr, *csum = nullptr, *csumsq = nullptr,
-           *step = nullptr, *xt = nullptr, *yt = nullptr, *st1 = nullptr, *st2 = nullptr;
+           *step = nullptr, *xt = nullptr, *yt = nullptr, *st1 = nullptr, *st2 = nullptr, *blob = nullptr, *chain_blob = nullptr;
     uint32_t* naccept = nullptr;
     hipModule_t mod = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -77,7 +77,7 @@ struct MetroBuffers {
     {
         (void)hipFree(pos); (void)hipFree(logp); (void)hipFree(chain); (void)hipFree(chain_logp); (void)hipFree(csum);
         (void)hipFree(csumsq); (void)hipFree(step); (void)hipFree(xt); (void)hipFree(yt); (void)hipFree(st1); (void)hipFree(st2);
-        (void)hipFree(naccept);
+        (void)hipFree(naccept); (void)hipFree(blob); (void)hipFree(chain_blob);
         if (mod) (void)hipModuleUnload(mod);
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
@@ -258,8 +258,15 @@ KMC_EXPORT kmc_status kmc_metropolis_validate(const kmc_metropolis_config* c)
     if (!c->step && !c->host_propose) return fail(KMC_ERR_BAD_ARG, "step (proposal scale per dimension) is NULL and there is no host_propose");
     for (int64_t d = 0; c->step && d < c->ndim; ++d)
         if (!std::isfinite(c->step[d])) return fail(KMC_ERR_BAD_ARG, "step must be finite");
-    if (c->flags & ~(uint32_t)(KMC_STORE_CHAIN | KMC_STORE_LOGP | KMC_MOMENTS | KMC_CHAIN_BY_WALKER))
-        return fail(KMC_ERR_BAD_ARG, "metropolis flags: KMC_STORE_CHAIN | KMC_STORE_LOGP | KMC_MOMENTS | KMC_CHAIN_BY_WALKER");
+    if (c->flags & ~(uint32_t)(KMC_STORE_CHAIN | KMC_STORE_LOGP | KMC_MOMENTS | KMC_CHAIN_BY_WALKER | KMC_STORE_BLOBS))
+        return fail(KMC_ERR_BAD_ARG, "metropolis flags: KMC_STORE_CHAIN | KMC_STORE_LOGP | KMC_MOMENTS | KMC_CHAIN_BY_WALKER | KMC_STORE_BLOBS");
+    {
+        const int nb = c->density == KMC_USER_DENSITY && c->user_density ? static_cast<const kmc_user_density*>(c->user_density)->nblob : 0;
+        if ((c->flags & KMC_STORE_BLOBS) && nb == 0)
+            return fail(KMC_ERR_BAD_ARG, "KMC_STORE_BLOBS needs a body density with blobs (kmc_user_density_create_body_blob)");
+        if (nb > 0 && c->host_propose)
+            return fail(KMC_ERR_UNSUPPORTED, "a density with blobs runs in the in-kernel chains: not with host_propose (use a host log-pdf returning blobs)");
+    }
     if (c->density == KMC_HOST_DENSITY) {
         if (!c->host_logpdf) return fail(KMC_ERR_BAD_ARG, "KMC_HOST_DENSITY needs kmc_metropolis_config.host_logpdf");
         return KMC_OK;
@@ -309,6 +316,8 @@ KMC_EXPORT kmc_status kmc_metropolis_run(const kmc_metropolis_config* c, const d
     else KMC_TRY(digest_params(e, &dp));
     if (c->density == KMC_HOST_DENSITY || c->host_propose)
         return metropolis_host_route(c, theta0, out, dp, nsamples);
+    const int nblob = c->density == KMC_USER_DENSITY ? static_cast<const kmc_user_density*>(c->user_density)->nblob : 0;
+    const bool want_blobs = nblob > 0 && ((c->flags & KMC_STORE_BLOBS) != 0 || out->blobs != nullptr);
 
     ScopedStream ss;                              // never the legacy stream (kmc_host.hpp: copy_sync)
     HIP_TRY(ss.create());
@@ -331,6 +340,15 @@ KMC_EXPORT kmc_status kmc_metropolis_run(const kmc_metropolis_config* c, const d
         HIP_TRY(hipMalloc(&b.csumsq, rows));
         HIP_TRY(fill_sync(b.csum, 0, rows, st));
         HIP_TRY(fill_sync(b.csumsq, 0, rows, st));
+    }
+    if (nblob > 0) {
+        const size_t bb = (size_t)nc * (size_t)nblob * sizeof(double);
+        HIP_TRY(hipMalloc(&b.blob, bb));
+        HIP_TRY(fill_sync(b.blob, 0, bb, st));
+        if (want_blobs && nsamples > 0) {
+            KMC_TRY(check_device_room((size_t)nsamples * bb, "the stored blobs"));
+            HIP_TRY(hipMalloc(&b.chain_blob, (size_t)nsamples * bb));
+        }
     }
     int ND = metropolis_nd(nd);
     if (c->density == KMC_USER_DENSITY && static_cast<const kmc_user_density*>(c->user_density)->is_body) ND = 0;   // body density: chain in memory
@@ -360,7 +378,7 @@ KMC_EXPORT kmc_status kmc_metropolis_run(const kmc_metropolis_config* c, const d
     const unsigned grid = (unsigned)((nc + 255) / 256);
 
     // p0 = pdf(theta0)  (:70); unlike emcee the reference carries whatever comes out, -Inf included
-    const LogpdfArgs la{b.pos, b.logp, nc, (int32_t)nd, (int32_t)nd, dp};
+    const LogpdfArgs la{b.pos, b.logp, nc, (int32_t)nd, (int32_t)nd, dp, b.blob};      // (and blob0, :70-72)
     if (ulp) HIP_TRY(launch_module(ulp, grid, 256u, st, la));
     else {
         HalfStepFn v, g;
@@ -395,6 +413,7 @@ KMC_EXPORT kmc_status kmc_metropolis_run(const kmc_metropolis_config* c, const d
         a.ndim = (int32_t)nd;
         a.seed_lo = (uint32_t)c->seed; a.seed_hi = (uint32_t)(c->seed >> 32);
         a.dp = dp;
+        a.blob = b.blob; a.chain_blob = b.chain_blob;
         if (ufn) HIP_TRY(launch_module(ufn, grid, 256u, st, a));
         else {
             hipLaunchKernelGGL(fn, dim3(grid), dim3(256), 0, st, a);
@@ -420,6 +439,11 @@ KMC_EXPORT kmc_status kmc_metropolis_run(const kmc_metropolis_config* c, const d
         if (out->chain_logp && b.chain_logp)
             HIP_TRY(copy_sync(out->chain_logp, b.chain_logp, (size_t)nsamples * (size_t)nc * sizeof(double), hipMemcpyDeviceToHost, st));
     }
+    if (out->blobs && b.chain_blob) {            // blobs[chain][sample] (KMC_CHAIN_BY_WALKER) or [sample][chain], nblob doubles each (:117)
+        if (c->flags & KMC_CHAIN_BY_WALKER) KMC_TRY(download_by_walker(b.chain_blob, false, nc, nblob, nblob, nsamples, out->blobs, st));
+        else HIP_TRY(copy_sync(out->blobs, b.chain_blob, (size_t)nsamples * (size_t)nc * (size_t)nblob * sizeof(double), hipMemcpyDeviceToHost, st));
+    }
+    if (out->final_blob && b.blob) HIP_TRY(copy_sync(out->final_blob, b.blob, (size_t)nc * (size_t)nblob * sizeof(double), hipMemcpyDeviceToHost, st));
     if (out->final_pos) HIP_TRY(copy_sync(out->final_pos, b.pos, rows, hipMemcpyDeviceToHost, st));
     if (out->final_logp) HIP_TRY(copy_sync(out->final_logp, b.logp, (size_t)nc * sizeof(double), hipMemcpyDeviceToHost, st));
     if (out->chain_sum && b.csum) HIP_TRY(copy_sync(out->chain_sum, b.csum, rows, hipMemcpyDeviceToHost, st));

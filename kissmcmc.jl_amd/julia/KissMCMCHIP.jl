@@ -183,6 +183,7 @@ end
 const KMC_STORE_CHAIN = UInt32(1) << 0
 const KMC_STORE_LOGP = UInt32(1) << 1
 const KMC_CHAIN_BY_WALKER = UInt32(1) << 12     # chain delivered as [walker][sample][dim]: thetas[w][k] are contiguous
+const KMC_STORE_BLOBS = UInt32(1) << 13         # a CDensity(body; nblob=m): the blob of every stored sample (src/samplers.jl:270, :117)
 
 last_error() = unsafe_string(ccall((:kmc_last_error, LIB), Cstring, ()))
 
@@ -315,6 +316,8 @@ Base.@kwdef mutable struct KmcMetropolisOutputs
     chain_sumsq::Ptr{Float64} = C_NULL
     nsamples::Int64 = 0
     device_ms::Float64 = 0.0
+    blobs::Ptr{Float64} = C_NULL
+    final_blob::Ptr{Float64} = C_NULL
 end
 
 # Layout drift between these mirrors and the library fails here, when the module loads -- not inside the first real ccall.
@@ -357,8 +360,11 @@ accept test, counters and storage stay on the device.  Returns `(thetas, accept_
 like `emcee`'s output (`thetas[chain][sample]`), so `squash_walkers` applies.
 """
 function metropolis_chains(pdf::DeviceLogPdf, sample_ppdf::Union{GaussianStep,HostProposal}, theta0s; niter=10^5, nburnin=niter ÷ 2, nthin=1,
-                           hasblob=false, seed=rand(UInt64), device=0)
-    hasblob && error("hasblob=true for metropolis is not wired in this shim (the C ABI carries it: kmc_metropolis_config.host_accepted)")
+                           hasblob=false, init_blobs=(blob0, nsamples) -> sizehint!(typeof(blob0)[], nsamples),
+                           reduce_blob! =(blobs, blob) -> push!(blobs, blob), seed=rand(UInt64), device=0)
+    device_blobs = hasblob && pdf isa ExprDensity && pdf.nblob > 0 && sample_ppdf isa GaussianStep
+    hasblob && !device_blobs &&
+        error("hasblob=true for metropolis: a CDensity(body; nblob=m) with a GaussianStep (blobs carried on the device); host closures with blobs are not wired in this shim (the C ABI carries them: kmc_metropolis_config.host_accepted)")
     nchains = length(theta0s); scalar = theta0s[1] isa Number; ndim = length(theta0s[1])
     nsamples = niter > nburnin ? (niter - nburnin) ÷ nthin : 0                            # :88
     theta = Matrix{Float64}(undef, ndim, nchains)          # column-major [dim, chain] == C row-major [chain][dim]
@@ -384,18 +390,31 @@ function metropolis_chains(pdf::DeviceLogPdf, sample_ppdf::Union{GaussianStep,Ho
     chain = Array{Float64}(undef, ndim, nsamples, nchains)      # column-major == C [chain][sample][dim] (KMC_CHAIN_BY_WALKER)
     clogp = Array{Float64}(undef, nsamples, nchains)
     acc = Vector{Float64}(undef, nchains)
-    out = KmcMetropolisOutputs(chain=pointer(chain), chain_logp=pointer(clogp), accept_ratio=pointer(acc))
-    st = GC.@preserve pdf sample_ppdf ctx theta step chain clogp acc begin
+    nblob = device_blobs ? pdf.nblob : 0
+    bl = Array{Float64}(undef, nblob, nsamples, nchains)         # blobs[chain][sample] (:117), nblob doubles each
+    out = KmcMetropolisOutputs(chain=pointer(chain), chain_logp=pointer(clogp), accept_ratio=pointer(acc), blobs=(device_blobs ? pointer(bl) : C_NULL))
+    st = GC.@preserve pdf sample_ppdf ctx theta step chain clogp acc bl begin
         cfg = Ref(KmcMetropolisConfig(density=density_id(pdf), params=p8, nchains=nchains, ndim=ndim, niter=niter, nburnin=nburnin,
                                       nthin=nthin, step=(isempty(step) ? Ptr{Float64}(C_NULL) : pointer(step)), seed=UInt64(seed),
-                                      flags=KMC_STORE_CHAIN | KMC_STORE_LOGP | KMC_CHAIN_BY_WALKER, device=Int32(device), user_density=user_handle(pdf),
+                                      flags=KMC_STORE_CHAIN | KMC_STORE_LOGP | KMC_CHAIN_BY_WALKER | (device_blobs ? KMC_STORE_BLOBS : UInt32(0)), device=Int32(device), user_density=user_handle(pdf),
                                       host_logpdf=pdf_fn, host_user=pointer_from_objref(ctx), host_propose=prop_fn))
         ccall((:kmc_metropolis_run, LIB), Cint, (Ref{KmcMetropolisConfig}, Ptr{Float64}, Ref{KmcMetropolisOutputs}), cfg, theta, out)
     end
     st == 0 || error("kmc_metropolis_run failed ($st): $(last_error())")
     thetas = scalar ? [chain[1, :, c] for c in 1:nchains] :
                       [[chain[:, k, c] for k in 1:nsamples] for c in 1:nchains]
-    return thetas, acc, [clogp[:, c] for c in 1:nchains], nothing
+    blobs = nothing
+    if device_blobs       # p0, blob0 = pdf(theta0) (:70) for init_blobs (:90), then reduce_blob! over each chain's stored series (:117)
+        lp0 = Vector{Float64}(undef, nchains); b0 = Matrix{Float64}(undef, nblob, nchains)
+        cfg0 = Ref(KmcConfig(density=density_id(pdf), params=p8, nwalkers=nchains + isodd(nchains), ndim=ndim, user_density=user_handle(pdf), device=Int32(device)))
+        st0 = ccall((:kmc_logpdf_blob_eval_host, LIB), Cint, (Ref{KmcConfig}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64), cfg0, theta, lp0, b0, nchains)
+        st0 == 0 || error("kmc_logpdf_blob_eval_host failed ($st0): $(last_error())")
+        blobs = [init_blobs(b0[:, c], nsamples) for c in 1:nchains]
+        for c in 1:nchains, k in 1:nsamples
+            reduce_blob!(blobs[c], bl[:, k, c])
+        end
+    end
+    return thetas, acc, [clogp[:, c] for c in 1:nchains], blobs
 end
 
 """
@@ -406,8 +425,8 @@ on the GPU (a single lane: a drop-in, not a fast path -- use `metropolis_chains`
 `metropolis(pdf, sample_ppdf, theta0)`, remain KissMCMC's own CPU method.
 """
 function metropolis(pdf::DeviceLogPdf, sample_ppdf::Union{GaussianStep,HostProposal}, theta0; use_progress_meter=true, kw...)
-    thetas, acc, logd, _ = metropolis_chains(pdf, sample_ppdf, [theta0]; kw...)
-    return thetas[1], acc[1], logd[1], nothing                                           # :128
+    thetas, acc, logd, blobs = metropolis_chains(pdf, sample_ppdf, [theta0]; kw...)
+    return thetas[1], acc[1], logd[1], blobs === nothing ? nothing : blobs[1]             # :128
 end
 
 """

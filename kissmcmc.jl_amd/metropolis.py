@@ -76,10 +76,11 @@ class HostProposal:
 
 
 def run_chains(pdf, sample_ppdf, theta0s, niter, nburnin, nthin, seed, device=0, store_chain=True, store_logp=True,
-               moments=False, scalar=False, by_chain=False):
+               moments=False, scalar=False, by_chain=False, store_blobs=False):
     """``kmc_metropolis_run`` on dense arrays.  Returns a dict: ``chain [nsamples, nchains, ndim]``,
     ``chain_logp [nsamples, nchains]``, ``accept_ratio``, ``naccept``, ``final_pos``, ``final_logp``,
-    ``chain_sum``/``chain_sumsq [nchains, ndim]``, ``nsamples``, ``device_ms``.
+    ``chain_sum``/``chain_sumsq [nchains, ndim]``, ``nsamples``, ``device_ms``; with ``store_blobs`` (a ``CDensity(..., nblob=m)``)
+    also ``blobs [nsamples, nchains, m]`` (``[nchains, nsamples, m]`` with ``by_chain``) and ``final_blob [nchains, m]``.
 
     ``pdf``: a device density, a :class:`~.densities.HostLogPdf` or any callable (wrapped in one); ``sample_ppdf``: a
     :class:`GaussianStep`, a :class:`HostProposal` or any callable (wrapped in one).  ``scalar``: bare callables get a
@@ -114,6 +115,11 @@ def run_chains(pdf, sample_ppdf, theta0s, niter, nburnin, nthin, seed, device=0,
     c.flags = (_lib.STORE_CHAIN if store_chain else 0) | (_lib.STORE_LOGP if store_logp else 0) | (_lib.MOMENTS if moments else 0)
     if by_chain:                    # chain [nchains, nsamples, ndim], chain_logp [nchains, nsamples]: reordered on the device
         c.flags |= _lib.CHAIN_BY_WALKER
+    nblob = int(getattr(pdf, "nblob", 0) or 0)
+    if store_blobs:
+        if nblob <= 0:
+            raise ValueError("store_blobs needs a CDensity(..., nblob=m)")
+        c.flags |= _lib.STORE_BLOBS
     c.device = int(device)
     c.user_density = pdf.user_handle
     if isinstance(pdf, HostLogPdf):
@@ -135,6 +141,9 @@ def run_chains(pdf, sample_ppdf, theta0s, niter, nburnin, nthin, seed, device=0,
     o.chain, o.chain_logp, o.accept_ratio = _dp(chain), _dp(chain_logp), _dp(acc)
     o.naccept = nacc.ctypes.data_as(C.POINTER(C.c_int64))
     o.final_pos, o.final_logp, o.chain_sum, o.chain_sumsq = _dp(fpos), _dp(flogp), _dp(csum), _dp(csq)
+    blobs = np.zeros((nchains, ns, nblob) if by_chain else (ns, nchains, nblob)) if store_blobs else None
+    fblob = np.zeros((nchains, nblob)) if store_blobs else None
+    o.blobs, o.final_blob = _dp(blobs), _dp(fblob)
     with np.errstate(all="ignore"):
         status = L.kmc_metropolis_run(C.byref(c), _dp(theta0s), C.byref(o))
     for obj in (pdf, sample_ppdf):                        # an exception raised inside a host callback: re-raise it here
@@ -145,7 +154,7 @@ def run_chains(pdf, sample_ppdf, theta0s, niter, nburnin, nthin, seed, device=0,
     _lib.check(status)
     assert o.nsamples == ns
     return dict(chain=chain, chain_logp=chain_logp, accept_ratio=acc, naccept=nacc, final_pos=fpos, final_logp=flogp,
-                chain_sum=csum, chain_sumsq=csq, nsamples=ns, device_ms=o.device_ms)
+                chain_sum=csum, chain_sumsq=csq, nsamples=ns, device_ms=o.device_ms, blobs=blobs, final_blob=fblob)
 
 
 def _fresh_seed() -> int:
@@ -163,7 +172,7 @@ def _blob_plumbing(pdf, hasblob, init_blobs, reduce_blob, scalar, nchains, nsamp
         if not pdf.hasblob:
             raise ValueError("hasblob=True needs HostLogPdf(..., hasblob=True)")
     elif isinstance(pdf, DeviceLogPdf):
-        raise NotImplementedError("blobs are host objects: hasblob=True needs a host callable as pdf (device densities return the log-pdf alone)")
+        raise NotImplementedError("hasblob=True needs a pdf that returns a blob: a host callable returning (p, blob), or a CDensity(..., nblob=m)")
     else:
         pdf = HostLogPdf(pdf, scalar=scalar, hasblob=True)
     if init_blobs is None:
@@ -208,6 +217,25 @@ def metropolis(pdf, sample_ppdf, theta0, niter: int = 10 ** 5, nburnin=None, nth
 def _run(pdf, sample_ppdf, th, niter, nburnin, nthin, hasblob, init_blobs, reduce_blob, seed, device, scalar):
     nchains = th.shape[0]
     ns = max(0, (int(niter) - int(nburnin)) // int(nthin)) if niter > nburnin else 0
+    if hasblob and isinstance(pdf, DeviceLogPdf) and not isinstance(pdf, HostLogPdf) and int(getattr(pdf, "nblob", 0) or 0) > 0:
+        # a CDensity(..., nblob=m): blob0 follows the chain on the device (:72, :103), the blob of every stored sample comes back
+        # (:117); a caller's init_blobs / reduce_blob are then fed each chain's series in order
+        if not isinstance(sample_ppdf, GaussianStep):
+            raise NotImplementedError("device blobs run in the in-kernel chains: sample_ppdf must be a GaussianStep")
+        r = run_chains(pdf, sample_ppdf, th, niter, nburnin, nthin, seed, device, scalar=scalar, by_chain=True, store_blobs=True)
+        series = r["blobs"]
+        if init_blobs is None and reduce_blob is None:
+            blobs = series
+        else:
+            ib = init_blobs if init_blobs is not None else (lambda blob0, n: [])
+            rb = reduce_blob if reduce_blob is not None else (lambda bs, b: bs.append(b))
+            _, blob0s = pdf.eval_with_blobs(th)                                # p0, blob0 = pdf(theta0)  :70
+            blobs = [ib(blob0s[w], ns) for w in range(nchains)]               # :90
+            for w in range(nchains):
+                for k in range(series.shape[1]):
+                    rb(blobs[w], series[w, k])                                 # :117
+        thetas = r["chain"][:, :, 0] if scalar else r["chain"]
+        return thetas, r["accept_ratio"], r["chain_logp"], blobs
     pdf, blobctx = _blob_plumbing(pdf, hasblob, init_blobs, reduce_blob, scalar, nchains, ns)
     try:
         if blobctx is not None:

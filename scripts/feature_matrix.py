@@ -234,7 +234,8 @@ def readme_block() -> str:
 
 def main():
     if "--write-from" in sys.argv:       # a table generated on the GPU box (gpurun_out/...), pasted into README.md here
-        table = open(sys.argv[sys.argv.index("--write-from") + 1]).read().strip("\n")
+        # (only the table's own lines: RCCL prints a version banner on stdout when a communicator is created)
+        table = "\n".join(l for l in open(sys.argv[sys.argv.index("--write-from") + 1]).read().splitlines() if l.startswith("|"))
     else:
         import kissmcmc_jl_amd as kmc
         table = render(kmc)

@@ -133,3 +133,52 @@ def test_device_blobs_resume_init_ball_and_refusals(kmc):
         kmc.emcee(kmc.GaussianIso(), th, niter=nw * 10, hasblob=True, use_progress_meter=False)
     with pytest.raises(kmc.KmcError, match="nblob must be in 1"):
         kmc.CDensity("return 0.0;", nblob=5000)
+
+
+def test_blob_call_sequence_in_plain_c(tmp_path):
+    """examples/blob_call.c: the reference's blob case through the C ABI alone (kmc_user_density_create_body_blob,
+    kmc_logpdf_blob_eval_host, kmc_outputs.blobs) -- compiled with gcc, no Python or torch in the process."""
+    import os
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    exe = str(tmp_path / "blob_call")
+    libdir = os.path.join(root, "kissmcmc.jl_amd")
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "blob_call.c"),
+                           "-o", exe, "-L", libdir, "-lkissmcmc_hip", "-lm", f"-Wl,-rpath,{libdir}"])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120, env=dict(os.environ, KMC_CACHE_DIR=str(tmp_path / "cache")))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.startswith("samples 5000 blobs-that-do-not-follow-their-walker 0 ")
+
+
+def test_metropolis_device_blobs(kmc, oracle):
+    """The reference's `metropolis` carries blobs too (src/samplers.jl:70-72, :103, :117; the same blob cases run through
+    test/metro.jl).  Many chains at once with a CDensity(nblob=m): blob0 follows each chain on the device; stored blobs equal the
+    blob function of the stored states; the chains themselves equal the oracle's restatement of the same density."""
+    nc, nd, niter, nburn, nthin, seed = 700, 5, 90, 20, 3, 17
+    th = np.random.default_rng(4).standard_normal((nc, nd))
+    pdf = kmc.CDensity(BODY, nblob=4)
+    thetas, acc, logd, blobs = kmc.metropolis_chains(pdf, kmc.GaussianStep(0.7), th, niter=niter, nburnin=nburn, nthin=nthin, hasblob=True, seed=seed)
+    ns = (niter - nburn) // nthin
+    assert thetas.shape == (nc, ns, nd) and blobs.shape == (nc, ns, 4)
+    np.testing.assert_array_equal(blobs[:, :, 0], thetas[:, :, 0])
+    np.testing.assert_array_equal(blobs[:, :, 1], thetas[:, :, nd - 1])
+    np.testing.assert_array_equal(blobs[:, :, 2], thetas[:, :, 0] * thetas[:, :, 1])
+    np.testing.assert_array_equal(blobs[:, :, 3], logd)
+    ref = oracle.metropolis(oracle.GAUSSIAN_ISO, [0.0, 1.0], th, 0.7, niter, nburn, nthin, seed)
+    np.testing.assert_array_equal(np.rint(acc * (niter - nburn)).astype(np.int64), ref["naccept"])
+    np.testing.assert_allclose(thetas.transpose(1, 0, 2), ref["chain"], rtol=1e-11, atol=1e-11)
+    # the caller's reduction, fed each chain's series in order: the reference's sum case (test/runtests.jl:94-107), here on blob[2]
+    def add(bs, b):
+        bs[0] += b[2]
+    _, _, _, sums = kmc.metropolis_chains(pdf, kmc.GaussianStep(0.7), th, niter=niter, nburnin=nburn, nthin=nthin, hasblob=True, seed=seed,
+                                          init_blobs=lambda blob0, n: [0.0], reduce_blob=add)
+    np.testing.assert_allclose([s[0] for s in sums], (thetas[:, :, 0] * thetas[:, :, 1]).sum(axis=1), rtol=1e-12, atol=1e-12)
+    # one chain, the reference's signature and its blob case: pdf = x -> (-(x+5)^2/18, ones(...)); blob_truths = nsamples x ones
+    one = kmc.CDensity("for (int i = 0; i < 16; ++i) blob[i] = 1.0; const double t = x[0] + 5.0; return -(t * t) / 18.0;", nblob=16)
+    t1, a1, l1, b1 = kmc.metropolis(one, kmc.GaussianStep(9.0), -4.0, niter=10 ** 4, hasblob=True, use_progress_meter=False, seed=3)
+    assert len(t1) == 5000 and len(b1) == 5000 and np.array_equal(b1, np.ones((5000, 16))) and 0.15 < a1 < 0.45   # test/metro.jl:14-17
+    with pytest.raises(NotImplementedError, match="GaussianStep"):
+        kmc.metropolis_chains(pdf, lambda t: t + 0.1, th, niter=10, hasblob=True, seed=1)

@@ -103,3 +103,28 @@ def test_readme_call_sequence_in_plain_c(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.startswith("samples 50000 ")
+
+
+def test_walkers_of_matrix_shape(kmc):
+    """The reference asks of a walker only `.+`, `.*` and `length` (src/samplers.jl:156): a 2 x 3 Matrix per walker works there
+    (N = length(theta0s[1]) = 6, :243).  Here: theta0s [nwalkers, 2, 3] -- a device density sees the flattened walker, a host
+    callable the shaped one -- and thetas come back [nwalkers, nsamples, 2, 3]; same chain as the flat call, bit for bit."""
+    nw, shape = 64, (2, 3)
+    th = np.random.default_rng(3).standard_normal((nw,) + shape)
+    kw = dict(niter=nw * 40, use_progress_meter=False, seed=12)
+    t_shaped, acc, lp, _ = kmc.emcee(kmc.GaussianIso(), th, **kw)
+    t_flat, acc_f, lp_f, _ = kmc.emcee(kmc.GaussianIso(), th.reshape(nw, 6), **kw)
+    assert t_shaped.shape == (nw, 20, 2, 3)
+    np.testing.assert_array_equal(t_shaped.reshape(nw, 20, 6), t_flat)
+    np.testing.assert_array_equal(acc, acc_f)
+    seen = []
+
+    def closure(x):                                   # a host callable receives the walker in ITS shape
+        seen.append(np.shape(x))
+        return -0.5 * float((x * x).sum())
+
+    t_host, acc_h, lp_h, _ = kmc.emcee(closure, th, **kw)
+    assert set(seen) == {shape}
+    np.testing.assert_array_equal(t_host, t_shaped)          # same draws, same density values up to summation order -> same decisions
+    flat, ar, _, _ = kmc.squash_walkers(t_shaped, acc, lp, verbose=False)
+    assert flat.shape == (nw * 20, 2, 3)

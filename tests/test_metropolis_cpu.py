@@ -109,8 +109,8 @@ def test_host_api_argument_handling(kmc):
         kmc.metropolis(kmc.GaussianIso(), "not a proposal", 0.0, niter=10)
     with pytest.raises(TypeError, match="callable"):
         kmc.metropolis(42, kmc.GaussianStep(1.0), 0.0, niter=10)
-    with pytest.raises(NotImplementedError, match="blobs"):
-        kmc.metropolis(kmc.GaussianIso(), kmc.GaussianStep(1.0), 0.0, niter=10, hasblob=True)      # a device density has no blob
+    with pytest.raises(NotImplementedError, match="returns a blob"):
+        kmc.metropolis(kmc.GaussianIso(), kmc.GaussianStep(1.0), 0.0, niter=10, hasblob=True)      # a menu density returns the log-pdf alone
     with pytest.raises(ValueError, match="hasblob=True"):
         kmc.metropolis(kmc.GaussianIso(), kmc.GaussianStep(1.0), 0.0, niter=10, reduce_blob=lambda b, x: None)
     with pytest.raises(ValueError):
