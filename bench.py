@@ -307,8 +307,15 @@ def main():
                          "(KMC_BENCH_BACKEND=gloo rehearses several ranks on fewer devices)")
     local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
+    # KMC_BENCH_FORCE_SHARDED=1 (testing): take the N > 1 code path with ONE rank -- the whole ladder over the real collective
+    # backend (RCCL communicator of one rank, captured all-gathers, all_to_all_single of the dealt mode) on a one-GPU box
+    sharded = world > 1 or os.environ.get("KMC_BENCH_FORCE_SHARDED") == "1"
     dist = None
-    if world > 1:
+    if sharded:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         import torch.distributed as dist
         backend = os.environ.get("KMC_BENCH_BACKEND", "nccl")
         import datetime
@@ -337,7 +344,7 @@ def main():
     th = theta0_c2(nw)
     launches = 0
 
-    if world == 1:
+    if not sharded:
         s = kmc.Sampler(pdf, nw, NDIM, G, nburn, 1, 2.0, SEED, moments=True, device=local_rank)
         s.set_positions(th)
         for _ in range(args.warmup):
@@ -666,7 +673,7 @@ def main():
     # of the updated half after every half-step, enqueued with the kernels inside the hipGraph chunks -- on a bounded piece
     # of the same job, so that both exchanges are on record from the same node.
     allgather_extra = None
-    if world > 1 and mode == "p2p" and os.environ.get("KMC_BENCH_NO_ALLGATHER_EXTRA") is None:
+    if sharded and mode == "p2p" and os.environ.get("KMC_BENCH_NO_ALLGATHER_EXTRA") is None:
         try:
             from kissmcmc_jl_amd.distributed import AllGatherEmcee
             ag, okag = None, True
@@ -724,7 +731,7 @@ def main():
         achieved = walkers_per_launch * b_read / (launch_us * 1e-6) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_c2.json")
-        if world == 1 and os.path.exists(tpath):
+        if not sharded and os.path.exists(tpath):
             try:
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
             except Exception:
@@ -736,8 +743,8 @@ def main():
             "config": {"workload": f"C2: emcee stretch move, {NWALKERS_PER_GPU} walkers/GPU x {NDIM}-dim isotropic Gaussian, "
                                    f"{G} generations (burn-in {nburn}), a=2, streaming moments on, chain off",
                        "nwalkers_total": nw, "ndim": NDIM, "generations": G, "gens_per_step": GENS_PER_STEP,
-                       "parallelism": "single GPU" if world == 1 else parallelism,
-                       "execution": how if world == 1 else None},
+                       "parallelism": "single GPU" if not sharded else parallelism,
+                       "execution": how if not sharded else None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "half_step_vec<GaussianIso>", "launches": launches, "avg_launch_us": launch_us,
@@ -751,7 +758,7 @@ def main():
                       "posterior_var_min": float(var.min()), "posterior_var_max": float(var.max()),
                       "nmoment": int(nmom)},
         }
-        if world > 1:
+        if sharded:
             out["collective"] = collective
             out["check"]["timed_run_equals_unsharded_run"] = verified
             out["dealt_mode"] = dealt
@@ -770,11 +777,11 @@ def main():
                                      "accepted rows only (push_bytes_per_link to each peer); link figure = one xGMI link, one "
                                      "direction (~77 GB/s); config.parallelism names the variant that ran (default: one variant; "
                                      "KMC_BENCH_EXCHANGE=all measures all six)"}
-        if world == 1:
+        if not sharded:
             out["island_mode"] = island
             if not args.no_other_configs:
                 out["other_configs"] = other_configs(kmc, local_rank)
-        if world == 1 and not args.no_cpu_baseline:
+        if not sharded and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -80,3 +80,27 @@ def test_bench_two_ranks_under_torch_distributed_run():
     assert out["n_gpus"] == 2 and out["check"]["timed_run_equals_unsharded_run"] is True
     assert out["collective"]["launcher"].startswith("external") and "allgather_mode" not in out
     assert "[bench launcher]" not in r.stderr
+
+
+def test_bench_sharded_ladder_over_real_rccl_with_one_rank():
+    """KMC_BENCH_FORCE_SHARDED=1: the N > 1 code path with ONE rank over the REAL collective backend ("nccl" = RCCL), which two ranks
+    on one device cannot have: process group with a device id, all-reduce / all-gather-object / all_to_all_single through RCCL, and
+    the native exchange -- ncclCommInitRank, the all-gathers captured into the hipGraph chunks -- inside bench.py's own ladder."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "KMC_BENCH_BACKEND")}
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env.update({"KMC_BENCH_FORCE_SHARDED": "1", "KMC_BENCH_WALKERS": "8192", "KMC_BENCH_RUNG_TIMEOUT": "240", "MASTER_PORT": str(port)})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-4000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith('{"metric"')][-1])
+    c = out["collective"]
+    assert c["backend"] == "nccl" and c["world_size"] == 1 and c["ranks_seen_by_all_reduce"] == 1 and c["rccl_version"]
+    assert out["n_gpus"] == 1 and out["check"]["timed_run_equals_unsharded_run"] is True
+    assert "peer-to-peer exchange" in out["config"]["parallelism"]
+    ag = out["allgather_mode"]
+    assert "error" not in ag, ag
+    assert ag["equals_unsharded_run"] is True and "captured in the graph" in ag["execution"]
+    assert "error" not in out["dealt_mode"] and out["dealt_mode"]["deals"] == 1000 // 64
