@@ -245,3 +245,42 @@ def test_random_runtime_compiled_density_equals_the_oracle(kmc, oracle, monkeypa
         np.testing.assert_array_equal(s.chain(logp=False)[0], ref["chain"], err_msg=label)
         assert np.all(np.abs(s.logp() - ref["final_logp"]) <= 1e-12 * np.maximum(1.0, np.abs(ref["final_logp"]))), label
         assert s.moments()[2] == ref["nmoment"], label
+
+
+@pytest.mark.parametrize("trial", range(max(6, N_TRIALS // 15)))
+def test_random_blob_density_equals_the_oracle_and_its_own_chain(kmc, oracle, monkeypatch, trial):
+    """Body densities WITH blobs (reference hasblob=true on the device; src/samplers.jl:194-196, :264, :270), random shapes, blob
+    widths (staged kernel up to 8 doubles, generic beyond) and launch modes: the sampler equals the oracle's run of the same
+    density, and every stored blob equals the blob function of the stored position it belongs to."""
+    rng = np.random.default_rng(BASE + 99000 + trial)
+    nd = int(rng.choice([1, 2, 5, 8, 16, 31, 32, 33, 64, 65, 100]))
+    nb = int(rng.choice([1, 2, 3, 8, 9, 20]))
+    nw = int(rng.choice([nd + 2 + nd % 2, 64, 130, 256, 1000, 2050]))
+    nw = max(nw, nd + 2 + nd % 2); nw += nw % 2
+    G = int(rng.integers(3, 100)); nburn = int(rng.integers(0, G)); nthin = int(rng.choice([1, 2, 3])); seed = int(rng.integers(1, 2 ** 40))
+    launch = str(rng.choice(["", "graph", "eager"]))
+    if launch:
+        monkeypatch.setenv("KMC_LAUNCH", launch)
+    # blob[i] = x[i mod n] * (i + 1) for i < nb - 1 (exact in double), blob[nb - 1] = the log-density
+    body = ("double s = 0.0; for (int i = 0; i < n; ++i) { double t = (x[i] - p[0]) * p[1]; s += t * t; } "
+            f"for (int i = 0; i < {nb - 1}; ++i) blob[i] = x[i % n] * (double)(i + 1); blob[{nb - 1}] = -0.5 * s; return -0.5 * s;")
+    pdf = kmc.CDensity(body, params=[0.3, 1.0 / 1.5], nblob=nb)
+    th = 0.3 + rng.standard_normal((nw, nd))
+    label = f"trial {trial}: blob density {nw}x{nd} nblob={nb} G={G} nburn={nburn} nthin={nthin} launch={launch or 'auto'}"
+    ref = oracle.emcee(oracle.make_config(oracle.GAUSSIAN_ISO, [0.3, 1.5], nw, nd, G, nburn, nthin, 2.0, seed), th)
+    with kmc.Sampler(pdf, nw, nd, G, nburn, nthin, 2.0, seed, store_chain=True, store_logp=True, store_blobs=True) as s:
+        s.set_positions(th)
+        s.run(G // 3); s.sync(); s.run(G - G // 3)
+        s.sync()
+        np.testing.assert_array_equal(s.naccept(), ref["naccept"], err_msg=label)
+        np.testing.assert_array_equal(s.positions(), ref["final_pos"], err_msg=label)
+        chain, clogp = s.chain()
+        blobs = s.blobs(by_walker=False)
+        cur, pos, lp = s.current_blobs(), s.positions(), s.logp()
+    np.testing.assert_array_equal(chain, ref["chain"], err_msg=label)
+    assert blobs.shape == (chain.shape[0], nw, nb), label
+    for i in range(nb - 1):
+        np.testing.assert_array_equal(blobs[:, :, i], chain[:, :, i % nd] * float(i + 1), err_msg=label)
+        np.testing.assert_array_equal(cur[:, i], pos[:, i % nd] * float(i + 1), err_msg=label)
+    np.testing.assert_array_equal(blobs[:, :, nb - 1], clogp, err_msg=label)
+    np.testing.assert_array_equal(cur[:, nb - 1], lp, err_msg=label)
