@@ -71,7 +71,9 @@ typedef enum kmc_density {
 
 /* KMC_HOST_DENSITY callback: rows = dense [nrows][ndim]; write the log-pdf of every row to logp_out[nrows].
    Return 0, or non-zero to abort the run (kmc_sampler_run then returns KMC_ERR_BAD_ARG).  Called on the
-   thread that called kmc_sampler_set_positions / kmc_sampler_run / kmc_emcee_run. */
+   thread that called kmc_sampler_set_positions / kmc_sampler_run / kmc_emcee_run.  A large half-step's proposals may arrive
+   in several calls (consecutive pieces of the batch, evaluated while the next piece is still crossing PCIe); with
+   kmc_config.host_accepted set it is exactly one call per half-step, so that batch state (blobs) lines up with the outcomes. */
 typedef int (*kmc_host_logpdf_fn)(const double* rows, int64_t nrows, int64_t ndim, double* logp_out, void* user);
 /* KMC_HOST_DENSITY, optional: called after the accept test of every half-step with its outcome, so the caller can
    carry per-walker side data of its density (the reference's blobs: `blob0s[nc] = blob1` on accept :264,

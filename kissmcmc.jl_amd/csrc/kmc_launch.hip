@@ -453,16 +453,39 @@ KMC_EXPORT kmc_status kmc_sampler_run(kmc_sampler* s, int64_t ngen)
         // per half-step: PROPOSE on the device -> proposals to the host -> callback -> log-pdfs back
         // -> ACCEPT on the device (which recomputes the same proposals from the same draws)
         const size_t hh = (size_t)s->h, nd = (size_t)s->cfg.ndim, ld = (size_t)s->ld;
+        // Large batches travel in pieces, each behind its own event: the callback works on piece c while piece c + 1 is still
+        // on the link (the D2H of the proposals is the larger half of a half-step's time once the closure is cheap).  Not when
+        // accept outcomes go back to the host as well: that caller keeps per-batch state (blobs) between the two callbacks.
+        int npiece = (!s->cfg.host_accepted && hh >= 8192) ? 4 : 1;
+        if (const char* e = std::getenv("KMC_HOST_PIECES")) { const long v = std::atol(e); if (v >= 1 && v <= kHostPieces && !s->cfg.host_accepted) npiece = (int)v; }
+        for (int i = 0; i < npiece && npiece > 1; ++i)
+            if (!s->host_ev[i]) HIP_TRY(hipEventCreateWithFlags(&s->host_ev[i], hipEventDisableTiming));
         for (; ngen > 0; --ngen) {
             KMC_TRY(chain_before(s, s->generation + 1));
             for (int half = 0; half < 2; ++half) {
                 HalfStepArgs a = make_args(s, half, false, s->generation);
                 a.prop_out = s->d_prop;
                 HIP_TRY(launch_half_kernel(s, a));
-                HIP_TRY(hipMemcpy2DAsync(s->h_prop, nd * sizeof(double), s->d_prop, ld * sizeof(double), nd * sizeof(double), hh,
-                                         hipMemcpyDeviceToHost, s->stream));
-                HIP_TRY(hipStreamSynchronize(s->stream));
-                if (s->cfg.host_logpdf(s->h_prop, (int64_t)hh, (int64_t)nd, s->h_p1, s->cfg.host_user) != 0) {   // :257
+                bool cb_failed = false;
+                if (npiece == 1) {
+                    HIP_TRY(hipMemcpy2DAsync(s->h_prop, nd * sizeof(double), s->d_prop, ld * sizeof(double), nd * sizeof(double), hh,
+                                             hipMemcpyDeviceToHost, s->stream));
+                    HIP_TRY(hipStreamSynchronize(s->stream));
+                    cb_failed = s->cfg.host_logpdf(s->h_prop, (int64_t)hh, (int64_t)nd, s->h_p1, s->cfg.host_user) != 0;   // :257
+                } else {
+                    auto r0 = [&](int c) { return hh * (size_t)c / (size_t)npiece; };
+                    for (int c = 0; c < npiece; ++c) {
+                        HIP_TRY(hipMemcpy2DAsync(s->h_prop + r0(c) * nd, nd * sizeof(double), s->d_prop + r0(c) * ld, ld * sizeof(double), nd * sizeof(double),
+                                                 r0(c + 1) - r0(c), hipMemcpyDeviceToHost, s->stream));
+                        HIP_TRY(hipEventRecord(s->host_ev[c], s->stream));
+                    }
+                    for (int c = 0; c < npiece; ++c) {
+                        HIP_TRY(hipEventSynchronize(s->host_ev[c]));
+                        if (!cb_failed)
+                            cb_failed = s->cfg.host_logpdf(s->h_prop + r0(c) * nd, (int64_t)(r0(c + 1) - r0(c)), (int64_t)nd, s->h_p1 + r0(c), s->cfg.host_user) != 0;   // :257
+                    }
+                }
+                if (cb_failed) {
                     s->positions_set = false;
                     return fail(KMC_ERR_BAD_ARG, "the host log-pdf callback failed in generation " + std::to_string(s->generation));
                 }

@@ -697,6 +697,7 @@ KMC_EXPORT void kmc_sampler_destroy(kmc_sampler* s)
     if (s->h_p1) (void)hipHostFree(s->h_p1);
     (void)hipFree(s->d_acc);
     if (s->h_acc) (void)hipHostFree(s->h_acc);
+    for (int i = 0; i < kHostPieces; ++i) if (s->host_ev[i]) (void)hipEventDestroy(s->host_ev[i]);
     if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
     (void)hipGetLastError();
     delete s;

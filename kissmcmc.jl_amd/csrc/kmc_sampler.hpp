@@ -16,6 +16,7 @@ namespace kmc_host {
 constexpr int64_t kGraphChunk = 64;   // generations per hipGraph replay (128 kernel nodes + 1)
 constexpr int kUExec = 6;             // executables of the "updated graph" launch mode (kmc_sampler::uexec)
 constexpr size_t kGuardBytes = 4096;  // KMC_POISON: guard band behind every device allocation of a sampler
+constexpr int kHostPieces = 8;        // KMC_HOST_DENSITY: most pieces a half-step's proposals travel to the host in
 
 struct Plan {
     kmc::HalfStepFn fn = nullptr;
@@ -118,6 +119,7 @@ struct kmc_sampler {
     double* h_p1 = nullptr;            // pinned [h]
     uint8_t* d_acc = nullptr;          // [h] accept outcomes of the current half-step (host_accepted only)
     uint8_t* h_acc = nullptr;          // pinned [h]
+    hipEvent_t host_ev[kmc_host::kHostPieces] = {};   // proposals of a large half-step reach the host in pieces, each behind its event (kmc_sampler_run)
     // resident mode: exact sampler, whole (small) ensemble in one workgroup's LDS, many generations per launch
     bool resident = false;
     kmc::ResidentFn resident_kernel = nullptr;
