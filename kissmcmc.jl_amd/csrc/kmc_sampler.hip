@@ -602,7 +602,7 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
                             (((cfg->flags & KMC_STORE_CHAIN) ? ldz * esz : 0) + ((cfg->flags & KMC_STORE_LOGP) ? sizeof(double) : 0));
         if (need > free_b) {
             kmc_status r_ = fail(KMC_ERR_OOM, "the chain needs " + std::to_string(need >> 20) + " MiB of device memory, " + std::to_string(free_b >> 20) +
-                                              " MiB are free: thin it (nthin), or stream it to host memory (KMC_STREAM_CHAIN)");
+                                              (s->nblob > 0 ? " MiB are free: thin it (nthin)" : " MiB are free: thin it (nthin), or stream it to host memory (KMC_STREAM_CHAIN)"));
             kmc_sampler_destroy(s);
             return r_;
         }
