@@ -163,6 +163,11 @@ def test_sampler_fails_loudly_without_a_device(kmc):
     with pytest.raises(kmc.KmcError, match="no CPU fallback") as e:
         kmc.Sampler(kmc.GaussianIso(), 10, 2, 10)
     assert e.value.status == _lib.ERR_NO_DEVICE
+    import ctypes as C
+    free, total = C.c_uint64(0), C.c_uint64(0)
+    assert _lib.lib().kmc_device_free_bytes(0, C.byref(free), C.byref(total)) == _lib.ERR_NO_DEVICE
+    z = (C.c_double * 4)()
+    assert _lib.lib().kmc_debug_accept_terms(1, 0, 0, 4, 8, 2.0, 2, 0, None, z, z, z) == _lib.ERR_NO_DEVICE
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not available")

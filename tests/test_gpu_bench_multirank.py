@@ -86,7 +86,7 @@ def test_bench_sharded_ladder_over_real_rccl_with_one_rank():
     """KMC_BENCH_FORCE_SHARDED=1: the N > 1 code path with ONE rank over the REAL collective backend ("nccl" = RCCL), which two ranks
     on one device cannot have: process group with a device id, all-reduce / all-gather-object / all_to_all_single through RCCL, and
     the native exchange -- ncclCommInitRank, the all-gathers captured into the hipGraph chunks -- inside bench.py's own ladder."""
-    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "KMC_BENCH_BACKEND")}
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "KMC_BENCH_BACKEND", "KMC_LAUNCH")}
     import socket
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))

@@ -100,3 +100,38 @@ def test_native_rccl_allgather_world1_equals_oracle(kmc, oracle, use_graph):
     assert n == ref["nmoment"]
     np.testing.assert_allclose(s, ref["sum"], rtol=1e-11, atol=1e-9)
     print(how)
+
+
+def test_rccl_capture_vote_overrides_this_ranks_own_capture(kmc, oracle, monkeypatch):
+    """kmc_sampler_rccl_capture / _set_capture: a rank whose own capture succeeded still launches one by one when the ranks'
+    vote (MIN over the capture outcomes, distributed.AllGatherEmcee) says so -- never a mixture of replaying and enqueueing
+    ranks.  Same result either way; describe() and kmc_sampler_launch_mode() report what runs."""
+    monkeypatch.delenv("KMC_LAUNCH", raising=False)         # (a forced launch mode would decide instead of the vote)
+    nw, nd, G, nburn, seed = 2048, 32, 150, 30, 5
+    th = np.random.default_rng(9).standard_normal((nw, nd))
+    ref = oracle.emcee(oracle.make_config(oracle.GAUSSIAN_ISO, [0.0, 1.0], nw, nd, G, nburn, 1, 2.0, seed, nthreads=8), th, store_chain=False)
+    for vote in (True, False):
+        with kmc.Sampler(kmc.GaussianIso(), nw, nd, G, nburn, 1, 2.0, seed, moments=True, shard_rank=0, shard_count=1) as s:
+            s.rccl_init(kmc.Sampler.rccl_unique_id())
+            assert s.rccl_capture() is True                 # RCCL 2.26 accepts the capture of its all-gathers
+            s.rccl_set_capture(vote)
+            s.set_positions(th)
+            s.run(G)
+            s.sync()
+            how, (mode, _) = s.describe(), s.launch_mode()
+            assert ("captured in the graph" in how) == vote and ("launch by launch" in how) == (not vote), how
+            assert (mode == 2) == (not vote)
+            np.testing.assert_array_equal(s.positions(), ref["final_pos"])
+            np.testing.assert_array_equal(s.naccept(), ref["naccept"])
+            if not vote:
+                with pytest.raises(kmc.KmcError, match="holds no captured chunk"):
+                    s.rccl_set_capture(True)                # the chunk is gone: a rank cannot go back alone
+
+
+def test_device_free_bytes(kmc):
+    import ctypes as C
+    from kissmcmc_jl_amd import _lib
+    free, total = C.c_uint64(0), C.c_uint64(0)
+    _lib.check(_lib.lib().kmc_device_free_bytes(0, C.byref(free), C.byref(total)))
+    assert 0 < free.value <= total.value and total.value > 200 * 2 ** 30       # 288 GB of HBM3E
+    assert _lib.lib().kmc_device_free_bytes(99, C.byref(free), C.byref(total)) == _lib.ERR_BAD_ARG
