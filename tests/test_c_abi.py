@@ -220,3 +220,65 @@ def test_julia_shim_structs_mirror_the_header():
     # the host-side pre/post-processing is KissMCMC's own, not re-typed here
     assert "import KissMCMC: emcee, metropolis, make_theta0s, squash_walkers" in src
     assert "function make_theta0s" not in src and "function squash_walkers" not in src
+
+
+def test_julia_shim_ccalls_match_the_header_prototypes():
+    """No julia here: every `ccall((:name, LIB), Ret, (ArgTypes...), ...)` of the shim is checked statically against the prototype
+    of `name` in include/kissmcmc_hip.h -- the function exists, the argument count matches, and each Julia type is of the same
+    kind (pointer / 32-bit int / 64-bit int / double / C string) as the C parameter in that position, the return type likewise."""
+    import re
+    hdr = open(os.path.join(ROOT, "include", "kissmcmc_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", " ", hdr, flags=re.S)                       # comments out
+    protos = {}
+    for m in re.finditer(r"\b([A-Za-z_][\w\s\*]*?)\b(kmc_\w+)\s*\(([^;{}]*?)\)\s*;", hdr):
+        ret, name, args = m.group(1).strip(), m.group(2), m.group(3).strip()
+        if "typedef" in ret or "(" in ret:
+            continue
+        protos[name] = (ret, [] if args in ("", "void") else [a.strip() for a in args.split(",")])
+
+    def ckind(t):
+        t = t.strip()
+        if "*" in t or "[" in t:
+            return "cstring" if re.match(r"(const\s+)?char\s*\*", t) else "ptr"
+        base = re.sub(r"\b(const|unsigned)\b", "", t).split()
+        base = base[0] if base else t
+        return {"int": "i32", "int32_t": "i32", "uint32_t": "i32", "kmc_status": "i32", "int64_t": "i64", "uint64_t": "i64", "double": "f64",
+                "void": "void"}.get(base, base)
+
+    def jkind(t):
+        t = t.strip()
+        if t == "Cstring":
+            return "cstring"
+        if t.startswith("Ptr{") or t.startswith("Ref{"):
+            return "ptr"
+        return {"Cint": "i32", "Int32": "i32", "UInt32": "i32", "Int64": "i64", "UInt64": "i64", "Float64": "f64", "Cvoid": "void"}[t]
+
+    def split_top(s):
+        out, depth, cur = [], 0, ""
+        for ch in s:
+            if ch in "{(":
+                depth += 1
+            elif ch in "})":
+                depth -= 1
+            if ch == "," and depth == 0:
+                out.append(cur)
+                cur = ""
+            else:
+                cur += ch
+        return [x.strip() for x in out + [cur] if x.strip()]
+
+    src = open(os.path.join(ROOT, "kissmcmc.jl_amd", "julia", "KissMCMCHIP.jl")).read()
+    calls = re.findall(r"ccall\(\(:(\w+), LIB\),\s*(\w+),\s*\((.*?)\)\s*(?:,|\))", src, re.S)
+    assert len(calls) >= 12
+    seen = set()
+    for name, ret, argt in calls:
+        assert name in protos, f"{name}: not declared in include/kissmcmc_hip.h"
+        cret, cargs = protos[name]
+        jargs = split_top(argt)
+        assert len(jargs) == len(cargs), f"{name}: ccall passes {len(jargs)} arguments, the header declares {len(cargs)}"
+        for i, (j, c) in enumerate(zip(jargs, cargs)):
+            assert jkind(j) == ckind(c), f"{name}: argument {i + 1} is {j} in the shim, `{c}` in the header"
+        rk = ckind(cret)
+        assert jkind(ret) == rk or (rk == "cstring" and ret == "Cstring"), f"{name}: return type {ret} vs `{cret}`"
+        seen.add(name)
+    assert {"kmc_emcee_run", "kmc_metropolis_run", "kmc_user_density_create_body_blob", "kmc_logpdf_blob_eval_host", "kmc_int_acorr"} <= seen
