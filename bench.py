@@ -75,6 +75,22 @@ def host_threads() -> int:
 
 
 def cpu_baseline(budget_s: float = 10.0):
+    """The CPU leg, in a process of its own: OpenMP reads its thread placement when it starts, and this process has long
+    started it (torch).  The worker runs with the threads BOUND to adjacent cores (OMP_PROC_BIND=close, OMP_PLACES=cores unless the
+    caller set them): the 16 MB ensemble then stays in one or two CCDs' L3 instead of following threads that float over both
+    sockets of the host -- measured on the GPU box, 16 threads: 0.7-1.35e8 walker-steps/s unbound (run to run), 1.5-1.65e8 bound."""
+    import subprocess
+    env = os.environ.copy()
+    env.setdefault("OMP_PROC_BIND", "close")
+    env.setdefault("OMP_PLACES", "cores")
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(budget_s)], env=env, capture_output=True, text=True, timeout=300)
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"value"')]
+    if r.returncode != 0 or not lines:
+        return {"error": f"the CPU baseline worker failed (status {r.returncode}): {r.stderr[-500:]}"}
+    return json.loads(lines[-1])
+
+
+def cpu_baseline_worker(budget_s: float = 10.0):
     """Oracle (C + OpenMP over the active half, like Threads.@threads at src/samplers.jl:248; streaming moments summed
     in per-thread blocks) on C2's shape -- same inputs, seed, burn-in and moment settings as the GPU run -- for a bounded
     number of generations, on all the threads this process may use and on one."""
@@ -95,7 +111,7 @@ def cpu_baseline(budget_s: float = 10.0):
         probe = 4
         run(2, nthreads)             # thread pool start, first touch of the state
         t = run(probe, nthreads)
-        G = int(max(probe, min(20000, budget / repeats / max(t / probe, 1e-6))))
+        G = int(max(50, min(20000, budget / repeats / max(t / probe, 1e-6))))
         t = min(run(G, nthreads) for _ in range(repeats))      # (a shared host: the quieter of the runs)
         return NWALKERS_PER_GPU * G / t, G, t
 
@@ -106,6 +122,7 @@ def cpu_baseline(budget_s: float = 10.0):
             "sample": f"C2 shape (65536 walkers x 32-dim Gaussian, fp64, moments on after burn-in), {g_all} generations = "
                       f"{NWALKERS_PER_GPU * g_all:.3g} walker-steps in {t_all:.1f} s on {cores} threads (affinity mask capped by the cgroup CPU quota; the faster of two such runs); "
                       f"1 thread: {g_one} generations in {t_one:.1f} s",
+            "thread_placement": f"OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND')} OMP_PLACES={os.environ.get('OMP_PLACES')}",
             "note": "CPU restatement of the reference algorithm (allocation-free C + OpenMP), not KissMCMC.jl itself (no julia in this image)"}
 
 
@@ -284,6 +301,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the extra driver-timed C1/C3/C5 runs (profiling passes)")
     ap.add_argument("--no-island", action="store_true", help="skip the extra island-mode run (profiling passes)")
+    if len(sys.argv) >= 2 and sys.argv[1] == "--cpu-baseline-worker":       # (the CPU leg's own process, see cpu_baseline)
+        print(json.dumps(cpu_baseline_worker(float(sys.argv[2]) if len(sys.argv) > 2 else 10.0)), flush=True)
+        return
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
