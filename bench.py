@@ -450,7 +450,14 @@ def main():
                 try:
                     d.set_positions(th)
                     d.run(vgen)
-                    d.sync()
+                    d.sync()                                  # (a peer wait that timed out surfaces here, on the ranks that waited)
+                except Exception as e:  # noqa: BLE001
+                    print(f"[rank {rank}] p2p self-check failed ({e})", file=sys.stderr)
+                    ok = False
+                ok = all_ok(ok)                               # every rank's kernels ran through: only then the result collectives
+                try:
+                    if not ok:
+                        raise RuntimeError("a rank failed before the results were gathered")
                     vpos, vacc = d.positions(), d.naccept()
                     if rank == 0:
                         rpos, racc, _ = unsharded(vgen)
@@ -548,8 +555,15 @@ def main():
                     torch.cuda.synchronize()
                     t0 = time.perf_counter()
                     drv.run(G)
-                    drv.sync()
+                    try:
+                        drv.sync()
+                        ran = True
+                    except Exception as e:  # noqa: BLE001  (a timed-out peer wait: the other ranks must not be left inside a collective)
+                        print(f"[rank {rank}] the p2p run failed ({e})", file=sys.stderr)
+                        ran = False
                     torch.cuda.synchronize()
+                    if not all_ok(ran):
+                        raise RuntimeError("a rank's peer-to-peer run did not complete")
                     dist.barrier()
                     elapsed = time.perf_counter() - t0
                     event_ms = drv.sampler.last_run_ms()
