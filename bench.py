@@ -420,6 +420,12 @@ def main():
         mode = os.environ.get("KMC_BENCH_EXCHANGE", "p2p")
         drv = None
 
+        def fault(point: str):
+            """KMC_BENCH_FAULT=<point>:<rank> (testing): that rank fails at that point of the ladder -- every rank must then take
+            the next rung together."""
+            if os.environ.get("KMC_BENCH_FAULT") == f"{point}:{rank}":
+                raise RuntimeError(f"injected fault at {point}")
+
         def all_ok(flag: bool) -> bool:
             t = torch.tensor([1.0 if flag else 0.0], device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
@@ -440,17 +446,26 @@ def main():
             d = None
             ok = True
             try:
+                fault("p2p_setup")
                 d = P2PEmcee(pdf, nw, NDIM, G, nburn, 1, 2.0, SEED, device=local_rank, finegrained=finegrained,
-                             fold_signal=fold_signal, push=push, lazy=lazy)
+                             fold_signal=fold_signal, push=push, lazy=lazy, connect=False)      # local part only: no collective yet
             except Exception as e:  # noqa: BLE001
                 print(f"[rank {rank}] p2p set-up failed ({e})", file=sys.stderr)
                 ok = False
+            if all_ok(ok):                                   # every rank has its sampler and handles: now the exchange
+                try:
+                    d.connect()
+                    fault("p2p_connect")
+                except Exception as e:  # noqa: BLE001
+                    print(f"[rank {rank}] p2p connect failed ({e})", file=sys.stderr)
+                    ok = False
             if all_ok(ok):
                 vgen = 240
                 try:
                     d.set_positions(th)
                     d.run(vgen)
                     d.sync()                                  # (a peer wait that timed out surfaces here, on the ranks that waited)
+                    fault("p2p_selfcheck")
                 except Exception as e:  # noqa: BLE001
                     print(f"[rank {rank}] p2p self-check failed ({e})", file=sys.stderr)
                     ok = False
@@ -479,6 +494,34 @@ def main():
                         pass
                 return None
             return d
+
+        def make_allgather(what):
+            """The native all-gather exchange, set up in two votes: every rank's local part (its replica sampler), then the
+            collective part (unique id, ncclCommInitRank, the capture vote).  The connected driver, or None on EVERY rank."""
+            from kissmcmc_jl_amd.distributed import AllGatherEmcee
+            d, ok = None, True
+            try:
+                fault("allgather_setup")
+                d = AllGatherEmcee(pdf, nw, NDIM, G, nburn, 1, 2.0, SEED, device=local_rank, connect=False)
+            except Exception as e:  # noqa: BLE001
+                print(f"[rank {rank}] native RCCL all-gather set-up failed ({e})", file=sys.stderr)
+                ok = False
+            if all_ok(ok):
+                try:
+                    with rung(what):
+                        d.connect()
+                except Exception as e:  # noqa: BLE001
+                    print(f"[rank {rank}] native RCCL all-gather set-up failed ({e})", file=sys.stderr)
+                    ok = False
+                ok = all_ok(ok)
+            else:
+                ok = False
+            if not ok and d is not None:
+                try:
+                    d.sampler.close()
+                except Exception:  # noqa: BLE001
+                    pass
+            return d if ok else None
 
         def time_short(d, gens=1024):       # long enough to reach the steady state of the replayed graphs (16 chunks)
             """Seconds for `gens` generations (max over ranks), from a common start."""
@@ -557,6 +600,7 @@ def main():
                     drv.run(G)
                     try:
                         drv.sync()
+                        fault("p2p_run")
                         ran = True
                     except Exception as e:  # noqa: BLE001  (a timed-out peer wait: the other ranks must not be left inside a collective)
                         print(f"[rank {rank}] the p2p run failed ({e})", file=sys.stderr)
@@ -599,15 +643,8 @@ def main():
             # first (kmc_sampler_run enqueues kernel + ncclAllGather per half-step, inside the hipGraph chunks); if that cannot
             # be set up on every rank, the same exchange as a torch collective per half-step from Python.
             from kissmcmc_jl_amd.distributed import AllGatherEmcee
-            nat = None
-            ok = True
-            try:
-                with rung('native RCCL all-gather set-up (ncclCommInitRank)'):
-                    nat = AllGatherEmcee(pdf, nw, NDIM, G, nburn, 1, 2.0, SEED, device=local_rank)
-            except Exception as e:  # noqa: BLE001
-                print(f"[rank {rank}] native RCCL all-gather set-up failed ({e})", file=sys.stderr)
-                ok = False
-            if all_ok(ok):
+            nat = make_allgather('native RCCL all-gather set-up (ncclCommInitRank)')
+            if nat is not None:
                 with rung('native RCCL all-gather warm-up + timed run'):
                     nat.set_positions(th)
                     nat.run(min(args.warmup * GENS_PER_STEP, 200))
@@ -629,8 +666,6 @@ def main():
                     nat.close()
                 parallelism = f"walker-sharded x{world}, exact partner rule, native RCCL all-gather of the updated half per half-step ({how_nat.split(';')[-1].strip()})"
             else:
-                if nat is not None:
-                    nat.sampler.close()
                 with rung('torch-collective all-gather warm-up + timed run'):
                     ex = HipShardExecutor(pdf, nw, NDIM, G, nburn, 1, 2.0, SEED, rank=rank, world=world, device=local_rank)
                     ex.set_positions(th)
@@ -672,8 +707,18 @@ def main():
         try:
             from kissmcmc_jl_amd.distributed import DealtEmcee, HipDealExecutor
             epoch = int(os.environ.get("KMC_BENCH_DEAL_EPOCH", 64))
-            with rung('dealt sub-ensembles (extra)'):
+            dex, okd = None, True
+            try:                                         # local part first, then a vote: nobody enters the collectives alone
+                fault("dealt_setup")
                 dex = HipDealExecutor(pdf, NWALKERS_PER_GPU, NDIM, G, nburn, 1, 2.0, SEED, rank=rank, world=world, device=local_rank)
+            except Exception as e:  # noqa: BLE001
+                print(f"[rank {rank}] dealt sub-ensembles: set-up failed ({e})", file=sys.stderr)
+                okd = False
+            if not all_ok(okd):
+                if dex is not None:
+                    dex.close()
+                raise RuntimeError("the dealt mode could not be set up on every rank (see stderr)")
+            with rung('dealt sub-ensembles (extra)'):
                 dd = DealtEmcee(dex, nw, NDIM, epoch)
                 dd.set_positions(th)
                 dd.run(args.warmup * GENS_PER_STEP)
@@ -710,14 +755,8 @@ def main():
     if sharded and mode == "p2p" and os.environ.get("KMC_BENCH_NO_ALLGATHER_EXTRA") is None:
         try:
             from kissmcmc_jl_amd.distributed import AllGatherEmcee
-            ag, okag = None, True
-            try:
-                with rung('native RCCL all-gather set-up (extra)'):
-                    ag = AllGatherEmcee(pdf, nw, NDIM, G, nburn, 1, 2.0, SEED, device=local_rank)
-            except Exception as e:  # noqa: BLE001
-                print(f"[rank {rank}] native RCCL all-gather set-up failed ({e})", file=sys.stderr)
-                okag = False
-            if all_ok(okag):
+            ag = make_allgather('native RCCL all-gather set-up (extra)')
+            if ag is not None:
                 with rung('native RCCL all-gather (extra)'):
                     gens = min(G, 1024)
                     ag.set_positions(th)
@@ -746,8 +785,6 @@ def main():
                                    "execution": how_ag.split(";")[-1].strip(),
                                    "note": "exact partner rule; full replica per rank, in-place ncclAllGather of the updated half per half-step"}
             else:
-                if ag is not None:
-                    ag.sampler.close()
                 allgather_extra = {"error": "native RCCL all-gather could not be set up on every rank (see stderr)"}
         except Exception as e:  # noqa: BLE001
             allgather_extra = {"error": str(e)}

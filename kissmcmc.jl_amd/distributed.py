@@ -117,7 +117,9 @@ class P2PEmcee:
 
     def __init__(self, pdf, nwalkers, ndim, ngenerations, nburnin=0, nthin=1, a_scale=2.0, seed=0,
                  device=0, moments=True, group=None, use_graph=True, finegrained=False, fold_signal=False, push=False, lazy=False,
-                 store_chain=False, store_logp=False):
+                 store_chain=False, store_logp=False, connect=True):
+        """``connect=False``: only this rank's LOCAL set-up (sampler, buffers) -- a driver that must survive one rank failing
+        here votes on the outcome before it calls :meth:`connect`, the collective part (handle exchange + IPC open)."""
         from .sampler import Sampler
         self.group = group
         self.rank = dist.get_rank(group) if dist is not None and dist.is_initialized() else 0
@@ -128,9 +130,15 @@ class P2PEmcee:
                                moments=moments, use_graph=use_graph, device=device, store_chain=store_chain, store_logp=store_logp,
                                shard_rank=self.rank, shard_count=self.world, p2p=True, p2p_finegrained=finegrained,
                                p2p_fold=fold_signal, p2p_push=push, p2p_lazy=lazy)
+        self._handle = self.sampler.p2p_export() if self.world > 1 else None      # (local: the IPC handles of this rank's buffers)
+        if connect:
+            self.connect()
+
+    def connect(self):
+        """Collective: exchange the IPC handles and open the peers' buffers."""
         if self.world > 1:
             blobs = [None] * self.world
-            dist.all_gather_object(blobs, self.sampler.p2p_export(), group=group)
+            dist.all_gather_object(blobs, self._handle, group=self.group)
             self.sampler.p2p_connect(blobs)
 
     def _barrier(self):
@@ -241,7 +249,9 @@ class AllGatherEmcee:
     Bit-identical to the unsharded run (RNG keyed by the global walker index)."""
 
     def __init__(self, pdf, nwalkers, ndim, ngenerations, nburnin=0, nthin=1, a_scale=2.0, seed=0, device=0, moments=True,
-                 group=None, use_graph=True):
+                 group=None, use_graph=True, connect=True):
+        """``connect=False``: only this rank's local set-up (its replica sampler); :meth:`connect` is the collective part (unique id
+        broadcast, ``ncclCommInitRank``, the vote on the graph capture)."""
         from .sampler import Sampler
         self.group = group
         self.rank = dist.get_rank(group) if dist is not None and dist.is_initialized() else 0
@@ -250,6 +260,15 @@ class AllGatherEmcee:
         self.begin, self.count = shard_slice(self.nwalkers, self.rank, self.world)
         self.sampler = Sampler(pdf, nwalkers, ndim, ngenerations, nburnin, nthin, a_scale, seed, moments=moments,
                                use_graph=use_graph, device=device, shard_rank=self.rank, shard_count=self.world)
+        self._use_graph = bool(use_graph)
+        self.captured = False
+        if connect:
+            self.connect()
+
+    def connect(self):
+        """Collective over all ranks."""
+        from .sampler import Sampler
+        group, use_graph = self.group, self._use_graph
         uid = [Sampler.rccl_unique_id() if self.rank == 0 else None]
         if self.world > 1:
             dist.broadcast_object_list(uid, src=0, group=group)

@@ -104,3 +104,34 @@ def test_bench_sharded_ladder_over_real_rccl_with_one_rank():
     assert "error" not in ag, ag
     assert ag["equals_unsharded_run"] is True and "captured in the graph" in ag["execution"]
     assert "error" not in out["dealt_mode"] and out["dealt_mode"]["deals"] == 1000 // 64
+
+
+@pytest.mark.parametrize("point", ["p2p_setup:1", "p2p_connect:0", "p2p_selfcheck:0", "p2p_run:1"])
+def test_bench_ladder_falls_through_together_when_one_rank_fails(point):
+    """KMC_BENCH_FAULT: ONE rank fails at a point of the peer-to-peer rung (set-up, self-check, after the timed run).  Every rank
+    must then take the next rung together -- the all-gather exchange -- and the line must still be a verified result; nobody may be
+    left inside a collective (the job would end in the watchdog's status 3)."""
+    out, err = run_bench({"KMC_BENCH_FAULT": point, "KMC_BENCH_RUNG_TIMEOUT": "120"})
+    common_checks(out)
+    assert "injected fault" in err and "falling back to the RCCL all-gather exchange" in err
+    assert "all-gather of the updated half per half-step" in out["config"]["parallelism"]
+    assert "allgather_mode" not in out          # (the extra only accompanies the pull)
+
+
+@pytest.mark.parametrize("point,key", [("dealt_setup:1", "dealt_mode"), ("allgather_setup:0", "allgather_mode")])
+def test_bench_extras_fail_together_without_taking_the_result_down(point, key):
+    """One rank failing in the local set-up of an EXTRA (dealt mode, all-gather record): every rank skips that extra together;
+    `value` -- measured before -- stands, the extra carries an error instead of numbers, the job ends with status 0."""
+    env = {"KMC_BENCH_FAULT": point, "KMC_BENCH_RUNG_TIMEOUT": "120"}
+    r_env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r_env.update({"KMC_BENCH_BACKEND": "gloo", "KMC_BENCH_WALKERS": "4096", "KMC_BENCH_TIMEOUT": "600"})
+    r_env.update(env)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"],
+                       env=r_env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-4000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith('{"metric"')][-1])
+    assert out["check"]["timed_run_equals_unsharded_run"] is True and "peer-to-peer exchange" in out["config"]["parallelism"]
+    assert "error" in out[key], out[key]
+    other = "allgather_mode" if key == "dealt_mode" else "dealt_mode"
+    if other == "dealt_mode":
+        assert "error" not in out[other]
