@@ -13,3 +13,10 @@ void table_gaussian_iso(int L, int K, int iter, bool p2p, bool ragged, bool f32,
 }
 InitBallFn init_ball_gaussian_iso() { return init_ball<GaussianIso>; }
 }  // namespace kmc
+
+#ifdef KMC_PROBE   // diagnostic build only (scripts/probe_timeline.py): the stamps of THIS translation unit's kernels (part 0)
+extern "C" __attribute__((visibility("default"))) int kmc_probe_read(void* out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(kmc::g_probe), sizeof(kmc::g_probe));
+}
+#endif

@@ -13,3 +13,10 @@ void table_rosenbrock(int L, int K, int iter, bool p2p, bool ragged, bool f32, H
 }
 InitBallFn init_ball_rosenbrock() { return init_ball<Rosenbrock>; }
 }  // namespace kmc
+
+#ifdef KMC_PROBE   // diagnostic build only (scripts/probe_timeline.py C3): this translation unit's copy of the stamps
+extern "C" __attribute__((visibility("default"))) int kmc_probe_read_rosenbrock(void* out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(kmc::g_probe), sizeof(kmc::g_probe));
+}
+#endif
