@@ -208,6 +208,8 @@ struct ResidentArgs {
     int32_t       pad_;
     double*       chain;        // [nsamples][S][ld] or nullptr
     double*       chain_logp;   // [nsamples][S] or nullptr
+    double*       blob;         // body densities with blobs (resident_lane_body): [S][NB] current blobs, or nullptr
+    double*       chain_blob;   //   [nsamples][S][NB] or nullptr
 };
 
 template <class Dens, int K, bool RAGGED, int TPB = 256>
@@ -351,6 +353,130 @@ template <class Dens, int K, bool RAGGED, int TPB>
 __global__ __launch_bounds__(TPB) void resident_epoch(const ResidentArgs a)
 {
     resident_body<Dens, K, RAGGED, TPB>(a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// RESIDENT mode, ONE WALKER PER THREAD (short rows: ndim <= 8 for the menu and term / pair densities, ndim <= 32 for body
+// densities, which hold the whole proposal per lane anyway): the same exact sampler out of one workgroup's LDS -- thread t
+// owns walker t (first half: t < S/2).  A generation: every thread draws its walker's step (both half-steps' draws at once:
+// the stream is keyed by (step, walker)), then the first half's threads move against the second half's rows, barrier (the
+// join of src/samplers.jl:273), and the other way round.  A thread's own row is written only by itself and, during its
+// half-step, read only by itself (partners come from the other half), so an accepted move goes straight into LDS.  No
+// cross-lane traffic at all (the two-lanes-per-walker kernel above pays three ds_bpermute round trips and a DPP reduction per
+// half-step): measured 0.39 against 0.61 us per half-step at the README shape (100 walkers, 1-D), 0.42 / 0.59 at 2-D,
+// 0.53 / 0.63 at 8-D, 1.39 / 1.12 at 32-D -- hence ndim <= 8.  Log-densities are summed in index order (the Seq interface),
+// like half_step_generic and the oracle.  EXACT_ND: ndim == ND at compile time (runtime-compiled body densities).
+// ------------------------------------------------------------------------------------------------
+template <class Dens, int ND, bool EXACT_ND>
+__device__ __forceinline__ void resident_lane_body(const ResidentArgs& ra)
+{
+    const IslandArgs& a = ra.is;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int S = ra.S, HS = S / 2;
+    const int ndim = EXACT_ND ? ND : a.ndim;              // <= ND
+    constexpr int LS = ND | 1;                            // LDS row stride in doubles (odd: rows start on different banks)
+    double* lpos  = lds;                                  // [S][LS]
+    double* llogp = lds + (size_t)S * LS;                 // [S]
+    const int t = threadIdx.x;
+    const bool live = t < S;
+    if (live) {
+#pragma unroll
+        for (int d = 0; d < ND; ++d) lpos[t * LS + d] = d < ndim ? a.pos[(int64_t)t * a.ld + d] : 0.0;
+        llogp[t] = a.logp[t];
+    }
+    __syncthreads();
+    const int myhalf = t >= HS ? 1 : 0;
+    uint32_t nacc = 0u;
+    double s1[ND], s2[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d) { s1[d] = 0.0; s2[d] = 0.0; }
+
+    for (int gg = 0; gg < a.ngen; ++gg) {
+        const int64_t gen = a.gen0 + gg;
+        const int64_t n = gen + 1 - a.nburnin;            // the reference's loop variable (:245)
+        const bool count = n > 0;
+        bool sample = false;
+        int64_t slot = 0;
+        if (n > 0 && n % a.nthin == 0) { slot = n / a.nthin - 1; sample = slot < a.nsamples; }   // :268
+        const Draw dr = draw_step(a.dc, 2ull * (uint64_t)gen + (uint64_t)myhalf, (uint64_t)(live ? t : 0));   // :250, :252
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+            if (live && myhalf == half) {                                         // :247
+                const double* oth = lpos + ((1 - half) * HS + (int)dr.partner) * LS;
+                const double* own = lpos + t * LS;
+                typename Dens::Seq q;
+                Dens::seq_init(q);
+                double y[ND];
+#pragma unroll
+                for (int d = 0; d < ND; ++d) {
+                    if (d < ndim) {
+                        y[d] = fma(dr.z, own[d] - oth[d], oth[d]);               // :255
+                        Dens::seq_add(q, y[d], d, a.dp);
+                    }
+                }
+                const double p1 = Dens::seq_finish(q, ndim, a.dp);                // :257
+                if (accept_test(dr, p1, llogp[t])) {                              // :260
+#pragma unroll
+                    for (int d = 0; d < ND; ++d) if (d < ndim) lpos[t * LS + d] = y[d];   // :261
+                    llogp[t] = p1;                                                // :262
+                    if (count) nacc += 1u;                                        // :265
+                    if constexpr (BlobTrait<Dens>::n > 0) {
+#pragma unroll 1
+                        for (int i = 0; i < BlobTrait<Dens>::n; ++i) ra.blob[(int64_t)t * BlobTrait<Dens>::n + i] = q.blob[i];   // :264
+                    }
+                }
+            }
+            __syncthreads();                              // the join of :273
+        }
+        if (sample && live) {                             // the walker's state after its update (:268-271); own row, own thread
+            if (ra.chain != nullptr) {
+                double* dst = ra.chain + (slot * S + t) * (int64_t)a.ld;
+#pragma unroll
+                for (int d = 0; d < ND; ++d) if (d < ndim) dst[d] = lpos[t * LS + d];
+                if (a.ld > ndim) dst[ndim] = 0.0;                               // the pad column of an odd ndim
+            }
+            if (ra.chain_logp != nullptr) ra.chain_logp[slot * S + t] = llogp[t];
+            if constexpr (BlobTrait<Dens>::n > 0) {
+                if (ra.chain_blob != nullptr) {
+#pragma unroll 1
+                    for (int i = 0; i < BlobTrait<Dens>::n; ++i)
+                        ra.chain_blob[(slot * S + t) * BlobTrait<Dens>::n + i] = ra.blob[(int64_t)t * BlobTrait<Dens>::n + i];   // :270
+                }
+            }
+            if (a.msum != nullptr) {
+#pragma unroll
+                for (int d = 0; d < ND; ++d) { const double v = lpos[t * LS + d]; s1[d] += v; s2[d] += v * v; }
+            }
+        }
+    }
+
+    if (live) {
+#pragma unroll
+        for (int d = 0; d < ND; ++d) if (d < ndim) a.pos[(int64_t)t * a.ld + d] = lpos[t * LS + d];
+        a.logp[t] = llogp[t];
+        if (nacc) a.naccept[t] += nacc;
+    }
+    if (a.msum != nullptr) {                              // per-thread sums -> per-dimension sums, in thread order (deterministic)
+        for (int pass = 0; pass < 2; ++pass) {
+            __syncthreads();                              // LDS is free again (rows written back / the previous pass consumed)
+            if (live) {
+#pragma unroll
+                for (int d = 0; d < ND; ++d) lds[(size_t)d * S + t] = pass == 0 ? s1[d] : s2[d];
+            }
+            __syncthreads();
+            if (t < ndim) {
+                double acc = 0.0;
+                for (int u = 0; u < S; ++u) acc += lds[(size_t)t * S + u];
+                if (pass == 0) a.msum[t] += acc; else a.msumsq[t] += acc;
+            }
+        }
+    }
+}
+
+template <class Dens, int ND>
+__global__ __launch_bounds__(1024) void resident_lane(const ResidentArgs a)
+{
+    resident_lane_body<Dens, ND, true>(a);
 }
 
 }  // namespace kmc

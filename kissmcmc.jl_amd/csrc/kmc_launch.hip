@@ -403,8 +403,9 @@ KMC_EXPORT kmc_status kmc_sampler_run(kmc_sampler* s, int64_t ngen)
             ia.msum = s->d_isum; ia.msumsq = s->d_isumsq;
             ra.S = (int32_t)s->cfg.nwalkers;
             ra.chain = s->d_chain; ra.chain_logp = s->d_chain_logp;
+            ra.blob = s->d_blob; ra.chain_blob = s->d_chain_blob;
             if (s->user) {
-                HIP_TRY(launch_module(s->uk.resident, 1u, 256u, s->stream, ra, (unsigned)s->island_lds));
+                HIP_TRY(launch_module(s->uk.resident, 1u, (unsigned)s->resident_tpb, s->stream, ra, (unsigned)s->island_lds));
             } else {
                 hipLaunchKernelGGL(s->resident_kernel, dim3(1), dim3((unsigned)s->resident_tpb), s->island_lds, s->stream, ra);
                 HIP_TRY(hipGetLastError());

@@ -165,7 +165,7 @@ kmc_status compile_user(kmc_user_density* ud, bool with_vec, int L, int K, int i
                         bool p2p = false)
 {
     // resident_K also sizes the island kernel (same row striping: 2 lanes per walker, K chunks)
-    if (ud->is_body && (with_vec || resident_K > 0 || island_S > 0))
+    if (ud->is_body && (with_vec || island_S > 0))
         return fail(KMC_ERR_UNSUPPORTED, "a body density runs in the one-walker-per-lane kernels only");
     char key[112];
     std::snprintf(key, sizeof(key), "%d:%d,%d,%d,%d|%d,%d|%d|%d|%lld|%d|%d|%d", (int)with_vec, L, K, iter, (int)ragged, resident_K,
@@ -194,9 +194,13 @@ kmc_status compile_user(kmc_user_density* ud, bool with_vec, int L, int K, int i
     if (with_vec)
         src << "extern \"C\" __global__ __launch_bounds__(" << vec_tpb(L) << ") void kmc_user_vec(KMC_FRONT_PARAMS, const kmc::HalfStepArgs a) { kmc::half_step_vec_body<UD, "
             << L << ", " << K << ", " << iter << ", " << peer << ", " << (ragged ? "true" : "false") << ", " << rowt << ">(KMC_FRONT_PACK, a); }\n";
-    if (resident_K > 0 && island_S == 0)
+    if (resident_K > 0 && island_S == 0 && ud->is_body)       // one walker per thread, up to 1024 threads
+        src << "extern \"C\" __global__ __launch_bounds__(1024) void kmc_user_resident(const kmc::ResidentArgs a) { kmc::resident_lane_body<UD, " << ndim << ", true>(a); }\n";
+    if (resident_K > 0 && island_S == 0 && !ud->is_body)
         src << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_resident(const kmc::ResidentArgs a) { kmc::resident_body<UD, "
             << resident_K << ", " << (resident_ragged ? "true" : "false") << ">(a); }\n";
+    if (resident_K < 0 && island_S == 0 && !ud->is_body)      // short rows: one walker per thread, ndim <= ND = -resident_K
+        src << "extern \"C\" __global__ __launch_bounds__(1024) void kmc_user_resident(const kmc::ResidentArgs a) { kmc::resident_lane_body<UD, " << -resident_K << ", true>(a); }\n";
     if (resident_K > 0 && island_S > 0)
         src << "extern \"C\" __global__ __launch_bounds__(" << island_S << ") void kmc_user_island(const kmc::IslandArgs a) { kmc::island_epoch_body<UD, "
             << island_S << ", " << resident_K << ", " << (resident_ragged ? "true" : "false") << ">(a); }\n";
@@ -226,7 +230,7 @@ kmc_status load_user(kmc_user_density* ud, bool with_vec, int L, int K, int iter
     HIP_TRY(hipModuleGetFunction(&uk->init_ball, uk->mod, "kmc_user_init_ball"));
     if (with_vec) HIP_TRY(hipModuleGetFunction(&uk->vec, uk->mod, "kmc_user_vec"));
     if (staged_possible(ud, f32, ndim, p2p)) HIP_TRY(hipModuleGetFunction(&uk->staged, uk->mod, "kmc_user_staged"));
-    if (resident_K > 0 && island_S == 0) HIP_TRY(hipModuleGetFunction(&uk->resident, uk->mod, "kmc_user_resident"));
+    if (resident_K != 0 && island_S == 0) HIP_TRY(hipModuleGetFunction(&uk->resident, uk->mod, "kmc_user_resident"));
     if (resident_K > 0 && island_S > 0) HIP_TRY(hipModuleGetFunction(&uk->island, uk->mod, "kmc_user_island"));
     return KMC_OK;
 }

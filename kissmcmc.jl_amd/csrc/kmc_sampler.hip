@@ -53,6 +53,27 @@ ResidentFn resident_fn(int density, int tpb, int K, bool ragged)
     }
 }
 
+ResidentFn resident_lane_fn(int density, int ndim)
+{
+    switch (density) {
+    case KMC_GAUSSIAN_ISO: return resident_lane_gaussian_iso(ndim);
+    case KMC_EXPONENTIAL: return resident_lane_exponential(ndim);
+    case KMC_ROSENBROCK: return resident_lane_rosenbrock(ndim);
+    case KMC_LOGNORMAL: return resident_lane_lognormal(ndim);
+    case KMC_MVNORMAL2: return resident_lane_mvnormal2(ndim);
+    default: return nullptr;
+    }
+}
+
+// resident mode with one walker per thread (short rows) or two lanes per walker: KMC_RESIDENT=lane|pair decides for tests
+bool resident_lane_wanted(int64_t ndim)
+{
+    const char* e = std::getenv("KMC_RESIDENT");
+    if (e && std::strcmp(e, "pair") == 0) return false;
+    return ndim <= 8;
+}
+int lane_nd(int64_t ndim) { return (int)ndim; }          // (the lane kernels are instantiated for the exact row length)
+
 InitBallFn init_ball_fn(int density)
 {
     switch (density) {
@@ -370,8 +391,13 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         // small ensembles: resident mode too (one workgroup, LDS within the default 64 KiB limit)
         int rK = 0, rK0 = 1;
         while (2 * rK0 < s->ld / 2) rK0 *= 2;
-        const size_t rlds = ((size_t)cfg->nwalkers * (size_t)(4 * (rK0 + 1)) + (size_t)cfg->nwalkers) * sizeof(double);
-        if (!s->user->is_body && !s->f32 && cfg->nwalkers <= 256 && cfg->ndim <= 32 && s->cfg.shard_count == 1 && !(cfg->flags & (KMC_P2P | KMC_NO_GRAPH | KMC_ISLANDS | KMC_STREAM_CHAIN)) &&
+        size_t rlds = ((size_t)cfg->nwalkers * (size_t)(4 * (rK0 + 1)) + (size_t)cfg->nwalkers) * sizeof(double);
+        // a body density: one walker per thread (kmc_islands.hpp: resident_lane_body), rows of ndim | 1 doubles, up to 1024 walkers
+        if (s->user->is_body) rlds = ((size_t)cfg->nwalkers * (size_t)((cfg->ndim | 1) + 1)) * sizeof(double);
+        const bool expr_lane = !s->user->is_body && resident_lane_wanted(cfg->ndim);     // term / pair density, short rows: the lane kernel too
+        if (expr_lane) rlds = ((size_t)cfg->nwalkers * (size_t)((lane_nd(cfg->ndim) | 1) + 1)) * sizeof(double);
+        if (!s->f32 && cfg->nwalkers <= ((s->user->is_body || expr_lane) ? 1024 : 256) && cfg->ndim <= 32 && s->cfg.shard_count == 1 && !(s->user->is_body && cfg->deal_count > 0) &&
+            !(cfg->flags & (KMC_P2P | KMC_NO_GRAPH | KMC_ISLANDS | KMC_STREAM_CHAIN)) &&
             rlds <= 60 * 1024 && std::getenv("KMC_NO_RESIDENT") == nullptr)
             rK = rK0;
         int iS = 0;
@@ -382,7 +408,8 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         }
         if (s->user->is_body && iS > 0) { kmc_sampler_destroy(s); return fail(KMC_ERR_UNSUPPORTED, "KMC_ISLANDS needs a menu or term / pair density (a body density runs one walker per lane)"); }
         if (s->user->is_body && cfg->ndim > 1024) { kmc_sampler_destroy(s); return fail(KMC_ERR_UNSUPPORTED, "a body density holds the proposal per lane: ndim <= 1024"); }
-        st = load_user(s->user, s->plan.vec, s->plan.L, s->plan.K, s->plan.ITER, s->plan.ragged, &s->uk, rK, 4 * rK != cfg->ndim, iS, s->f32, cfg->ndim, (cfg->flags & KMC_P2P) != 0);
+        st = load_user(s->user, s->plan.vec, s->plan.L, s->plan.K, s->plan.ITER, s->plan.ragged, &s->uk, (expr_lane && rK > 0 && iS == 0) ? -lane_nd(cfg->ndim) : rK, 4 * rK != cfg->ndim, iS, s->f32,
+                       cfg->ndim, (cfg->flags & KMC_P2P) != 0);
         if (st != KMC_OK) { kmc_sampler_destroy(s); return st; }
         if (iS > 0) rK = 0;     // island mode is set up below, not resident mode
         if (rK > 0) {
@@ -390,6 +417,8 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
             s->island_K = rK;
             s->nislands = 1;
             s->island_lds = rlds < 4096 ? 4096 : rlds;
+            s->resident_lane = s->user->is_body || expr_lane;
+            s->resident_tpb = s->resident_lane ? (int)((cfg->nwalkers + 63) / 64 * 64) : 256;
         }
     } else if (cfg->density == KMC_HOST_DENSITY) {
         s->host_eval = true;
@@ -426,9 +455,18 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         const int64_t chunks = s->ld / 2;
         int K = 1;
         while (2 * K < chunks) K *= 2;
-        const int rtpb = cfg->nwalkers <= 256 ? 256 : (cfg->nwalkers <= 512 ? 512 : 1024);
-        const size_t need = ((size_t)cfg->nwalkers * (size_t)(4 * (K + 1)) + (size_t)cfg->nwalkers) * sizeof(double);
+        int rtpb = cfg->nwalkers <= 256 ? 256 : (cfg->nwalkers <= 512 ? 512 : 1024);
+        size_t need = ((size_t)cfg->nwalkers * (size_t)(4 * (K + 1)) + (size_t)cfg->nwalkers) * sizeof(double);
         ResidentFn rf = need <= 156 * 1024 ? resident_fn(cfg->density, rtpb, K, 4 * K != cfg->ndim) : nullptr;
+        if (resident_lane_wanted(cfg->ndim)) {            // short rows: one walker per thread (measured faster up to ndim 8)
+            ResidentFn lf = resident_lane_fn(cfg->density, (int)cfg->ndim);
+            if (lf) {
+                rf = lf;
+                rtpb = (int)((cfg->nwalkers + 63) / 64 * 64);
+                need = ((size_t)cfg->nwalkers * (size_t)((lane_nd(cfg->ndim) | 1) + 1)) * sizeof(double);
+                s->resident_lane = true;
+            }
+        }
         if (rf) {
             s->resident_tpb = rtpb;
             s->island_lds = need;
@@ -755,8 +793,8 @@ KMC_EXPORT kmc_status kmc_sampler_describe(const kmc_sampler* s, char* buf, int6
         o << "island mode: " << s->nislands << " islands of " << s->island_size << " walkers in LDS, " << s->island_gens
           << " generations per launch, rows 2 lanes x " << s->island_K << " chunks";
     else if (s->resident)
-        o << "resident mode (exact): whole ensemble in one workgroup's LDS (" << (s->user ? 256 : s->resident_tpb)
-          << " threads), up to 4096 generations per launch, rows 2 lanes x " << s->island_K << " chunks";
+        o << "resident mode (exact): whole ensemble in one workgroup's LDS (" << s->resident_tpb
+          << " threads), up to 4096 generations per launch, " << (s->resident_lane ? std::string("one walker per thread") : "rows 2 lanes x " + std::to_string(s->island_K) + " chunks");
     else if (s->host_eval)
         o << "host-evaluated density (exact): per half-step propose kernel -> D2H -> callback -> H2D -> accept kernel, grid "
           << s->grid << " x 256";

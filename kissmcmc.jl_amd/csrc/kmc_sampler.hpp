@@ -124,6 +124,7 @@ struct kmc_sampler {
     bool resident = false;
     kmc::ResidentFn resident_kernel = nullptr;
     int resident_tpb = 256;
+    bool resident_lane = false;        // ... one walker per thread (kmc_islands.hpp: resident_lane_body) instead of two lanes per walker
     // island mode (KMC_ISLANDS)
     bool islands = false;
     kmc::IslandFn island_kernel = nullptr;

@@ -166,10 +166,22 @@ def test_graph_replay_equals_eager(kmc, oracle):
 @pytest.mark.parametrize("name,nw,nd", [("expo", 100, 1), ("rosen", 100, 2), ("gauss", 256, 32), ("gauss", 34, 32), ("lognormal", 64, 3),
                                         ("gauss", 512, 32), ("rosen", 400, 16), ("expo", 1024, 8), ("gauss", 1000, 3)])
 def test_resident_small_ensemble_kernel_is_the_same_sampler(kmc, oracle, name, nw, nd, monkeypatch):
-    """nwalkers <= 256: the whole ensemble runs out of one workgroup's LDS, many generations per launch
-    (resident mode).  It must be indistinguishable from the launch-per-half-step kernels and the oracle."""
+    """nwalkers <= 1024: the whole ensemble runs out of one workgroup's LDS, many generations per launch
+    (resident mode) -- one walker per thread for short rows (ndim <= 8), two lanes per walker otherwise; KMC_RESIDENT=pair
+    keeps the two-lane kernel on short rows as well.  Each must be indistinguishable from the launch-per-half-step kernels
+    and the oracle."""
     ref, res = _run_both(kmc, oracle, name, nw, nd, 200, 60, 2, seed=321)
     _compare(ref, res)
+    if nd <= 8:
+        monkeypatch.setenv("KMC_RESIDENT", "pair")
+        with kmc.Sampler(_densities(kmc, oracle)[name][0], nw, nd, 10) as s:
+            assert "resident mode" in s.describe() and "2 lanes" in s.describe()
+        ref1, pair = _run_both(kmc, oracle, name, nw, nd, 200, 60, 2, seed=321)
+        _compare(ref1, pair)
+        np.testing.assert_array_equal(res["chain"], pair["chain"])
+        monkeypatch.delenv("KMC_RESIDENT")
+        with kmc.Sampler(_densities(kmc, oracle)[name][0], nw, nd, 10) as s:
+            assert "one walker per thread" in s.describe()
     monkeypatch.setenv("KMC_NO_RESIDENT", "1")
     ref2, multi = _run_both(kmc, oracle, name, nw, nd, 200, 60, 2, seed=321)
     _compare(ref2, multi)

@@ -134,8 +134,11 @@ def test_streamed_chain_restart_and_emcee_front_end(kmc, oracle, monkeypatch):
     # the reference's front end: identical outputs with and without streaming
     a = kmc.emcee(kmc.GaussianIso(), th, niter=nw * G, seed=4, use_progress_meter=False, stream_chain=True)
     b = kmc.emcee(kmc.GaussianIso(), th, niter=nw * G, seed=4, use_progress_meter=False, stream_chain=False)
-    for x, y in zip(a[:3], b[:3]):
-        np.testing.assert_array_equal(x, y)
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[1], b[1])
+    # (log-densities to rounding: the streamed run uses the multi-launch kernels, which sum a row's terms lane-striped; the
+    #  other runs resident, one walker per thread, summing in index order)
+    assert np.all(np.abs(a[2] - b[2]) <= 1e-12 * np.maximum(1.0, np.abs(b[2])))
 
 
 @pytest.mark.parametrize("by_walker", [False, True], ids=["sample-major", "by-walker"])

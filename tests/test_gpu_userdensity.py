@@ -105,6 +105,8 @@ def test_body_density_equals_the_oracle(kmc, oracle, case, monkeypatch):
     """A C++ function body that restates a menu density in the oracle's own element order: chains, counters AND log-pdfs
     equal the oracle's (the one-walker-per-lane kernels sum in index order, as the oracle does)."""
     name, shape = case.split("_")[:2]
+    monkeypatch.setenv("KMC_NO_RESIDENT", "1")           # the multi-launch kernels are the subject here (small ensembles with ndim <= 32
+                                                         #  would run resident: test_body_density_runs_resident_on_small_ensembles)
     if case.endswith("_generic"):
         monkeypatch.setenv("KMC_PLAN", "generic")        # the unstaged one-walker-per-lane kernel (what ndim > 64 runs)
     nw, nd = (int(v) for v in shape.split("x"))
@@ -162,3 +164,72 @@ def test_body_density_other_entry_points(kmc, oracle):
         kmc.CDensity("return x[0] +;")
     with pytest.raises(kmc.KmcError, match="KMC_ISLANDS"):
         kmc.Sampler(pdf, 1024, 3, 10, island_gens=8)
+
+
+ROSEN_BODY = ("double s = 0.0; for (int i = 0; i + 1 < n; ++i) { double d = x[i + 1] - x[i] * x[i]; double e = p[0] - x[i]; s += p[1] * (d * d) + e * e; } "
+              "return -(s * (1.0 / p[2]));")
+
+
+@pytest.mark.parametrize("nw,nd,G,nburn,nthin", [(100, 2, 700, 300, 1), (6, 4, 300, 100, 3), (1000, 5, 150, 40, 2), (1024, 4, 120, 0, 1), (200, 31, 90, 30, 1),
+                                                  (64, 1, 400, 100, 1)])
+def test_body_density_runs_resident_on_small_ensembles(kmc, oracle, monkeypatch, nw, nd, G, nburn, nthin):
+    """A CDensity on the reference's own problem sizes: the whole ensemble in one workgroup's LDS, one walker per thread, many
+    generations per launch (kmc_islands.hpp: resident_lane_body) -- same draws and element order as the multi-launch kernels:
+    identical to the oracle's run of the menu density AND to the same sampler with KMC_NO_RESIDENT (chain, log-pdfs, counters,
+    moments), across run() pieces and a restart."""
+    if nd == 1:
+        pdf, did, params = kmc.CDensity("return x[0] < 0.0 ? -INFINITY : -x[0];"), oracle.EXPONENTIAL, [1.0]
+        th = 0.5 + 0.1 * np.abs(np.random.default_rng(5).standard_normal((nw, nd)))
+    else:
+        pdf, did, params = kmc.CDensity(ROSEN_BODY, params=[1.0, 100.0, 20.0]), oracle.ROSENBROCK, [1.0, 100.0, 20.0]
+        th = 0.1 * np.random.default_rng(5).standard_normal((nw, nd))
+    seed = 31
+    ref = oracle.emcee(oracle.make_config(did, params, nw, nd, G, nburn, nthin, 2.0, seed), th)
+
+    def run():
+        with kmc.Sampler(pdf, nw, nd, G, nburn, nthin, 2.0, seed, store_chain=True, store_logp=True, moments=True) as s:
+            for attempt in range(2):
+                s.set_positions(th)
+                for n in (1, G // 3, G - 1 - G // 3):
+                    s.run(n)
+                s.sync()
+            chain, clogp = s.chain()
+            return dict(how=s.describe(), pos=s.positions(), logp=s.logp(), nacc=s.naccept(), chain=chain, clogp=clogp, mom=s.moments(),
+                        launches=s.launch_count)
+
+    res = run()
+    assert "resident mode" in res["how"] and "one walker per thread" in res["how"], res["how"]
+    assert res["launches"] <= 3                                           # three run() pieces, not 2 G launches
+    monkeypatch.setenv("KMC_NO_RESIDENT", "1")
+    ml = run()
+    assert "resident" not in ml["how"]
+    for got in (res, ml):
+        np.testing.assert_array_equal(got["nacc"], ref["naccept"])
+        np.testing.assert_array_equal(got["pos"], ref["final_pos"])
+        np.testing.assert_array_equal(got["chain"], ref["chain"])
+        assert np.all(np.abs(got["clogp"] - ref["chain_logp"]) <= 1e-12 * np.maximum(1.0, np.abs(ref["chain_logp"])))
+        assert got["mom"][2] == ref["nmoment"]
+        np.testing.assert_allclose(got["mom"][0], ref["sum"], rtol=1e-11, atol=1e-9)
+        np.testing.assert_allclose(got["mom"][1], ref["sumsq"], rtol=1e-11, atol=1e-9)
+    np.testing.assert_array_equal(res["clogp"], ml["clogp"])               # the same function evaluated in the same order: same bits
+    np.testing.assert_array_equal(res["logp"], ml["logp"])
+
+
+def test_body_density_with_blobs_runs_resident(kmc):
+    """... and carries its blobs there too (hasblob=true on the reference's own sizes: 100 walkers)."""
+    body = "const double t = x[0] + 5.0; const double lp = -(t * t) / 18.0; blob[0] = x[0]; blob[1] = lp; return lp;"
+    pdf = kmc.CDensity(body, nblob=2)
+    th = -4.0 + 0.1 * np.random.default_rng(2).standard_normal((100, 1))
+    with kmc.Sampler(pdf, 100, 1, 1000, 500, 1, 2.0, 4, store_chain=True, store_logp=True, store_blobs=True) as s:
+        s.set_positions(th)
+        s.run(1000)
+        s.sync()
+        assert "resident mode" in s.describe() and s.launch_count == 1
+        chain, clogp = s.chain()
+        blobs = s.blobs(by_walker=False)
+        cur, pos, lp = s.current_blobs(), s.positions(), s.logp()
+    np.testing.assert_array_equal(blobs[:, :, 0], chain[:, :, 0])
+    np.testing.assert_array_equal(blobs[:, :, 1], clogp)
+    np.testing.assert_array_equal(cur[:, 0], pos[:, 0])
+    np.testing.assert_array_equal(cur[:, 1], lp)
+    assert abs(chain.mean() + 5.0) < 0.9
