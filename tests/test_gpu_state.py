@@ -170,3 +170,53 @@ def test_checkpoint_resume_is_bit_identical(kmc, nw, nd):
         assert m1[2] + m2[2] == ref["mom"][2]                         # moments restart at the checkpoint
         np.testing.assert_allclose(m1[0] + m2[0], ref["mom"][0], rtol=1e-11, atol=1e-8)
         np.testing.assert_allclose(m1[1] + m2[1], ref["mom"][1], rtol=1e-11, atol=1e-8)
+
+
+def test_samplers_give_their_device_memory_back(kmc):
+    """Every kind of sampler, created, run and destroyed a few times over: the device's free memory afterwards is what it was
+    before (kmc_device_free_bytes) -- the destroy path knows every buffer, event and stream the create path made, including the
+    ones behind blobs, streamed chains, the host route's pieces, P2P shards and the resident kernels."""
+    import ctypes as C
+    from kissmcmc_jl_amd import _lib
+
+    def free_bytes():
+        f, t = C.c_uint64(0), C.c_uint64(0)
+        _lib.check(_lib.lib().kmc_device_free_bytes(0, C.byref(f), C.byref(t)))
+        return f.value
+
+    nd = 8
+    th = lambda nw: np.random.default_rng(1).standard_normal((nw, nd))
+    blob = kmc.CDensity("double s = 0.0; for (int i = 0; i < n; ++i) s += x[i] * x[i]; blob[0] = x[0]; blob[1] = s; return -0.5 * s;", nblob=2)
+    host = kmc.HostLogPdf(lambda X: -0.5 * (X * X).sum(axis=1), vectorized=True)
+    kinds = [
+        (kmc.GaussianIso(), 4096, dict(store_chain=True, store_logp=True, moments=True)),
+        (kmc.GaussianIso(), 100, dict(store_chain=True, moments=True)),                              # resident, one walker per thread
+        (kmc.GaussianIso(), 4096, dict(store_chain=True, store_logp=True, stream_chain=True, chain_by_walker=True)),
+        (kmc.GaussianIso(), 4096, dict(moments=True, island_gens=8, island_size=64)),
+        (kmc.GaussianIso(), 4096, dict(store_chain=True, dtype="f32")),
+        (blob, 4096, dict(store_chain=True, store_blobs=True)),
+        (blob, 128, dict(store_chain=True, store_blobs=True)),                                       # resident with blobs
+        (kmc.ExprDensity("-0.5 * x * x"), 4096, dict(moments=True)),
+        (host, 16384, dict(store_chain=True)),                                                       # proposals in pieces: events
+        (kmc.GaussianIso(), 4096, dict(moments=True, deal_rank=0, deal_count=2)),
+    ]
+
+    def cycle():
+        for pdf, nw, kw in kinds:
+            with kmc.Sampler(pdf, nw, nd, 80, 10, 1, 2.0, 3, **kw) as s:
+                s.set_positions(th(nw))
+                s.run(80 if not kw.get("island_gens") else 64)
+                s.sync()
+        shards = [kmc.Sampler(kmc.GaussianIso(), 2048, nd, 64, 0, 1, 2.0, 3, p2p=True, shard_rank=r, shard_count=2) for r in range(2)]
+        kmc.Sampler.p2p_connect_local(shards)
+        for sh in shards:
+            sh.close()
+        from kissmcmc_jl_amd.metropolis import run_chains
+        run_chains(blob, kmc.GaussianStep(0.5), th(512), 60, 10, 1, 4, store_blobs=True)
+
+    cycle()                                         # first use: code objects, graph pools, bounce buffers stay with the process
+    base = free_bytes()
+    for _ in range(3):
+        cycle()
+    drift = base - free_bytes()
+    assert abs(drift) <= 32 << 20, f"device memory drifted by {drift / 2 ** 20:.1f} MiB over three cycles"
