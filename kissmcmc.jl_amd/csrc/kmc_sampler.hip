@@ -408,7 +408,10 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         }
         if (s->user->is_body && iS > 0) { kmc_sampler_destroy(s); return fail(KMC_ERR_UNSUPPORTED, "KMC_ISLANDS needs a menu or term / pair density (a body density runs one walker per lane)"); }
         if (s->user->is_body && cfg->ndim > 1024) { kmc_sampler_destroy(s); return fail(KMC_ERR_UNSUPPORTED, "a body density holds the proposal per lane: ndim <= 1024"); }
-        st = load_user(s->user, s->plan.vec, s->plan.L, s->plan.K, s->plan.ITER, s->plan.ragged, &s->uk, (expr_lane && rK > 0 && iS == 0) ? -lane_nd(cfg->ndim) : rK, 4 * rK != cfg->ndim, iS, s->f32,
+        // (what the resident kernel is compiled as: term / pair density on short rows -> -ndim = one walker per thread; body density ->
+        //  the workgroup size bound, 256 or 1024: a body of 32 dimensions needs its registers; else the two-lane kernel's K)
+        const int rcode = (rK > 0 && iS == 0) ? (s->user->is_body ? (cfg->nwalkers <= 256 ? 256 : 1024) : (expr_lane ? -lane_nd(cfg->ndim) : rK)) : rK;
+        st = load_user(s->user, s->plan.vec, s->plan.L, s->plan.K, s->plan.ITER, s->plan.ragged, &s->uk, rcode, 4 * rK != cfg->ndim, iS, s->f32,
                        cfg->ndim, (cfg->flags & KMC_P2P) != 0);
         if (st != KMC_OK) { kmc_sampler_destroy(s); return st; }
         if (iS > 0) rK = 0;     // island mode is set up below, not resident mode
