@@ -116,6 +116,14 @@ __device__ __forceinline__ Draw draw_step(const DrawConsts& dc, uint64_t step, u
     return draw_finish(dc, draw_bits(dc, step, walker));
 }
 
+// Workgroup barrier for kernels whose shared state is in LDS only: wait for this wave's LDS operations, then the barrier.
+// __syncthreads() also waits for every outstanding GLOBAL load (its fence is over all address spaces), which would put a
+// load issued a generation ahead of its use back on the critical path.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // (N-1) log z + p1 - p0 >= log u, evaluated left to right like the reference (:260).
 __device__ __forceinline__ bool accept_test(const Draw& d, double p1, double p0)
 {

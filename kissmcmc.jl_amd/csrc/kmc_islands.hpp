@@ -25,6 +25,26 @@ namespace kmc {
 
 constexpr int kIslandSizeDefault = 256;   // walkers per island (= threads per workgroup): 64, 128 or 256
 
+// The sample test of src/samplers.jl:268 (n > 0 && n % nthin == 0 -> slot n / nthin - 1), carried from one generation to
+// the next: the 64-bit division it takes literally is ~180 scalar instructions, a quarter of a generation of the resident
+// kernels at the reference's own sizes.  One division per launch instead.
+struct ThinClock {
+    int64_t n, phase, q;
+    __device__ __forceinline__ ThinClock(int64_t gen0, int64_t nburnin, int64_t nthin)
+    {
+        n = gen0 - nburnin;                               // the loop variable (:245) of the generation before the launch's first
+        if (n > 0) { q = n / nthin; phase = n - q * nthin; } else { q = 0; phase = 0; }
+    }
+    // on to the next generation: true when it is a thinning hit (its slot is q - 1; the caller compares with nsamples)
+    __device__ __forceinline__ bool tick(int64_t nthin)
+    {
+        ++n;
+        if (n <= 0) return false;
+        if (++phase == nthin) { phase = 0; ++q; return true; }
+        return false;
+    }
+};
+
 struct IslandArgs {
     double*       pos;        // [nwalkers][ld], walker-id order
     double*       logp;       // [nwalkers]
@@ -95,12 +115,12 @@ __device__ __forceinline__ void island_epoch_body(const IslandArgs& a)
     const int ownA = hA * HS + (wave << 5) + (lane & 31);             // its walker's local index
     uint32_t naccA = 0u;
 
+    ThinClock clk(a.gen0, a.nburnin, a.nthin);
     for (int gg = 0; gg < a.ngen; ++gg) {
         const int64_t gen = a.gen0 + gg;
-        const int64_t n = gen + 1 - a.nburnin;            // the reference's loop variable (:245)
-        const bool count = n > 0;
-        bool sample = false;
-        if (n > 0 && n % a.nthin == 0) sample = (n / a.nthin - 1) < a.nsamples;   // :268
+        const bool hit = clk.tick(a.nthin);               // clk.n: the reference's loop variable (:245)
+        const bool count = clk.n > 0;
+        const bool sample = hit && (clk.q - 1) < a.nsamples;                      // :268
         const Draw drA = draw_step(a.dc, 2ull * (uint64_t)gen + (uint64_t)hA, (uint64_t)(slot0 + ownA));   // :250, :252
         const double p0A = llogp[ownA];                   // only this walker's own update changes it
 #pragma unroll 1
@@ -210,7 +230,48 @@ struct ResidentArgs {
     double*       chain_logp;   // [nsamples][S] or nullptr
     double*       blob;         // body densities with blobs (resident_lane_body): [S][NB] current blobs, or nullptr
     double*       chain_blob;   //   [nsamples][S][NB] or nullptr
+    const double2* draws;       // resident_lane_body: the launch's draws, [ngen][S] x 32 B {z, (N-1) log z | log u, partner} from
+                                //   draw_table_fill (the two-lanes-per-walker kernel draws itself)
 };
+
+// ------------------------------------------------------------------------------------------------
+// Draw table of a resident launch.  The draws {partner, z, (N-1) log z, log u} of a walker-step are pure functions of
+// (seed, step, walker) -- no state -- and in the one-walker-per-thread resident kernel they are most of the work: Philox
+// and two logarithms are ~350 instructions a generation, the move itself a few dozen; timing-only builds without them run
+// 0.26 instead of 0.41 us per half-step at 100 x 2 and 0.54 instead of 1.04 at 1000 x 4.  The resident kernel has one CU;
+// the other 255 are idle.  So a wide kernel computes the draws of the launch's generations first (same function, same
+// bits), and the resident kernel streams them, one generation ahead of their use.
+// ------------------------------------------------------------------------------------------------
+constexpr int kDrawBatch = 4;  // generations per load batch of the resident kernel (the table is padded to whole batches)
+struct DrawTableArgs {
+    DrawConsts dc;
+    int64_t    gen0;
+    int32_t    ngen, S;
+    double2*   out;             // [ngen][S][2]
+};
+__device__ __forceinline__ Draw draw_table_load(const double2* tab, int64_t idx)
+{
+    const double2 e0 = tab[2 * idx], e1 = tab[2 * idx + 1];
+    Draw d;
+    d.z = e0.x; d.t1 = e0.y; d.lu = e1.x;
+    // (both words carry the index: a destination register nobody reads would be handed out again at once, and whoever gets
+    //  it waits for the load)
+    d.partner = (uint32_t)__double2loint(e1.y) | (uint32_t)__double2hiint(e1.y);
+    return d;
+}
+#ifdef KMC_DEFINE_LAUNCH_KERNELS   // kmc_launch.hip
+__global__ __launch_bounds__(256) void draw_table_fill(const DrawTableArgs a)
+{
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)a.ngen * a.S) return;
+    const int64_t g = idx / a.S;
+    const int t = (int)(idx - g * a.S);
+    const int half = t >= a.S / 2 ? 1 : 0;
+    const Draw d = draw_step(a.dc, 2ull * (uint64_t)(a.gen0 + g) + (uint64_t)half, (uint64_t)t);   // as resident_lane_body draws
+    a.out[2 * idx]     = make_double2(d.z, d.t1);
+    a.out[2 * idx + 1] = make_double2(d.lu, __hiloint2double((int)d.partner, (int)d.partner));
+}
+#endif
 
 template <class Dens, int K, bool RAGGED, int TPB = 256>
 __device__ __forceinline__ void resident_body(const ResidentArgs& ra)
@@ -251,13 +312,13 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& ra)
     const int ownA = hA * HS + (scv ? iA : 0);
     uint32_t naccA = 0u;
 
+    ThinClock clk(a.gen0, a.nburnin, a.nthin);
     for (int gg = 0; gg < a.ngen; ++gg) {
         const int64_t gen = a.gen0 + gg;
-        const int64_t n = gen + 1 - a.nburnin;            // the reference's loop variable (:245)
-        const bool count = n > 0;
-        bool sample = false;
-        int64_t slot = 0;
-        if (n > 0 && n % a.nthin == 0) { slot = n / a.nthin - 1; sample = slot < a.nsamples; }   // :268
+        const bool hit = clk.tick(a.nthin);               // clk.n: the reference's loop variable (:245)
+        const bool count = clk.n > 0;
+        const int64_t slot = clk.q - 1;
+        const bool sample = hit && slot < a.nsamples;                                            // :268
         const Draw drA = draw_step(a.dc, 2ull * (uint64_t)gen + (uint64_t)hA, (uint64_t)ownA);   // keyed by the walker index
         const double p0A = llogp[ownA];
 #pragma unroll 1
@@ -364,7 +425,8 @@ __global__ __launch_bounds__(TPB) void resident_epoch(const ResidentArgs a)
 // half-step, read only by itself (partners come from the other half), so an accepted move goes straight into LDS.  No
 // cross-lane traffic at all (the two-lanes-per-walker kernel above pays three ds_bpermute round trips and a DPP reduction per
 // half-step): measured 0.39 against 0.61 us per half-step at the README shape (100 walkers, 1-D), 0.42 / 0.59 at 2-D,
-// 0.53 / 0.63 at 8-D, 1.39 / 1.12 at 32-D -- hence ndim <= 8.  Log-densities are summed in index order (the Seq interface),
+// 0.53 / 0.63 at 8-D, 1.39 / 1.12 at 32-D -- hence ndim <= 8 for the menu densities -- and with the draws taken from the
+// table above instead of made here 0.22, 0.25, 0.42 and (body density, 32-D) 0.90.  Log-densities are summed in index order (the Seq interface),
 // like half_step_generic and the oracle.  EXACT_ND: ndim == ND at compile time (runtime-compiled body densities).
 // ------------------------------------------------------------------------------------------------
 template <class Dens, int ND, bool EXACT_ND>
@@ -390,15 +452,43 @@ __device__ __forceinline__ void resident_lane_body(const ResidentArgs& ra)
     double s1[ND], s2[ND];
 #pragma unroll
     for (int d = 0; d < ND; ++d) { s1[d] = 0.0; s2[d] = 0.0; }
+    // The draws come from draw_table_fill (ra.draws: the host driver's job), kDrawBatch generations per load and one batch
+    // ahead of their use: the table was written by other CUs a moment ago and a load takes about a microsecond to come
+    // back -- more than a generation takes here.  (One generation ahead: 0.40 us per half-step at 100 x 2 against 0.30
+    // with loads that always hit.)  The batch's generations are unrolled, so each reads its draws from registers of its
+    // own: no rotation of registers -- a copy of a register a load is still in flight to would wait for it.
+    // (long rows: a generation outlasts a load by itself, and four copies of a 32-dimensional body spill)
+    constexpr int B = ND <= 8 ? kDrawBatch : (ND <= 16 ? 2 : 1);
+    static_assert(kDrawBatch % B == 0, "the host pads the table to kDrawBatch generations");
+    const int tl = live ? t : 0;
+    const int nb = (a.ngen + B - 1) / B;                  // the table is padded to whole batches
+    Draw cur[B], nxt[B];
+#pragma unroll
+    for (int u = 0; u < B; ++u) { cur[u] = Draw{}; nxt[u] = Draw{}; }
+    if (nb > 0) {
+#pragma unroll
+        for (int u = 0; u < B; ++u) nxt[u] = draw_table_load(ra.draws, (int64_t)u * S + tl);
+    }
 
-    for (int gg = 0; gg < a.ngen; ++gg) {
-        const int64_t gen = a.gen0 + gg;
-        const int64_t n = gen + 1 - a.nburnin;            // the reference's loop variable (:245)
-        const bool count = n > 0;
-        bool sample = false;
-        int64_t slot = 0;
-        if (n > 0 && n % a.nthin == 0) { slot = n / a.nthin - 1; sample = slot < a.nsamples; }   // :268
-        const Draw dr = draw_step(a.dc, 2ull * (uint64_t)gen + (uint64_t)myhalf, (uint64_t)(live ? t : 0));   // :250, :252
+    ThinClock clk(a.gen0, a.nburnin, a.nthin);
+#pragma unroll 1
+    for (int b = 0; b < nb; ++b) {
+#pragma unroll
+      for (int u = 0; u < B; ++u) cur[u] = nxt[u];        // (waits for the batch loaded during the previous one)
+      {
+        const int bn = b + 1 < nb ? b + 1 : b;            // (the last one reloads itself)
+#pragma unroll
+        for (int u = 0; u < B; ++u) nxt[u] = draw_table_load(ra.draws, ((int64_t)bn * B + u) * S + tl);
+      }
+      // (unrolled: with a loop here the compiler drains every outstanding load before entering it)
+#pragma unroll
+      for (int sub = 0; sub < B; ++sub) {
+        if (b * B + sub >= a.ngen) break;
+        const bool hit = clk.tick(a.nthin);               // clk.n: the reference's loop variable (:245)
+        const bool count = clk.n > 0;
+        const int64_t slot = clk.q - 1;
+        const bool sample = hit && slot < a.nsamples;                                            // :268
+        const Draw dr = cur[sub];                                                                // :250, :252
 #pragma unroll 1
         for (int half = 0; half < 2; ++half) {
             if (live && myhalf == half) {                                         // :247
@@ -426,7 +516,7 @@ __device__ __forceinline__ void resident_lane_body(const ResidentArgs& ra)
                     }
                 }
             }
-            __syncthreads();                              // the join of :273
+            lds_barrier();                                // the join of :273 (rows live in LDS; the prefetched draws stay in flight)
         }
         if (sample && live) {                             // the walker's state after its update (:268-271); own row, own thread
             if (ra.chain != nullptr) {
@@ -448,7 +538,8 @@ __device__ __forceinline__ void resident_lane_body(const ResidentArgs& ra)
                 for (int d = 0; d < ND; ++d) { const double v = lpos[t * LS + d]; s1[d] += v; s2[d] += v * v; }
             }
         }
-    }
+      }   // generation of the batch
+    }     // batch
 
     if (live) {
 #pragma unroll

@@ -387,9 +387,10 @@ KMC_EXPORT kmc_status kmc_sampler_run(kmc_sampler* s, int64_t ngen)
     HIP_TRY(hipSetDevice(s->cfg.device));
     HIP_TRY(hipEventRecord(s->ev0, s->stream));
     if (s->resident) {
-        // the whole ensemble lives in one workgroup's LDS; a launch carries up to 4096 generations
+        // the whole ensemble lives in one workgroup's LDS; a launch carries up to 4096 generations (1024 when a wide kernel
+        // computes the launch's draws first: draw_table_fill, kmc_islands.hpp)
         while (ngen > 0) {
-            const int64_t n = std::min<int64_t>(ngen, 4096);
+            const int64_t n = std::min<int64_t>(ngen, s->d_draws ? kDrawTableGens : 4096);
             ResidentArgs ra{};
             IslandArgs& ia = ra.is;
             ia.pos = s->d_pos; ia.logp = s->d_logp; ia.naccept = s->d_naccept;
@@ -404,6 +405,15 @@ KMC_EXPORT kmc_status kmc_sampler_run(kmc_sampler* s, int64_t ngen)
             ra.S = (int32_t)s->cfg.nwalkers;
             ra.chain = s->d_chain; ra.chain_logp = s->d_chain_logp;
             ra.blob = s->d_blob; ra.chain_blob = s->d_chain_blob;
+            if (s->d_draws) {
+                DrawTableArgs ta{};
+                const int64_t npad = (n + kDrawBatch - 1) / kDrawBatch * kDrawBatch;      // whole batches (<= kDrawTableGens, a multiple)
+                ta.dc = ia.dc; ta.gen0 = s->generation; ta.ngen = (int32_t)npad; ta.S = ra.S; ta.out = s->d_draws;
+                hipLaunchKernelGGL(draw_table_fill, dim3((unsigned)((npad * ra.S + 255) / 256)), dim3(256), 0, s->stream, ta);
+                HIP_TRY(hipGetLastError());
+                ra.draws = s->d_draws;
+                s->launches += 1;
+            }
             if (s->user) {
                 HIP_TRY(launch_module(s->uk.resident, 1u, (unsigned)s->resident_tpb, s->stream, ra, (unsigned)s->island_lds));
             } else {

@@ -13,6 +13,8 @@ KMC_EXPORT int kmc_version(void);
 
 namespace kmc_host {
 
+static_assert(1024 % kmc::kDrawBatch == 0, "the draw table holds whole batches");
+constexpr int64_t kDrawTableGens = 1024;   // resident mode with a draw table: generations per launch (table = 32 B x nwalkers x this)
 constexpr int64_t kGraphChunk = 64;   // generations per hipGraph replay (128 kernel nodes + 1)
 constexpr int kUExec = 6;             // executables of the "updated graph" launch mode (kmc_sampler::uexec)
 constexpr size_t kGuardBytes = 4096;  // KMC_POISON: guard band behind every device allocation of a sampler
@@ -68,6 +70,7 @@ struct kmc_sampler {
     int64_t mring_waves = 0;
     int64_t gens_since_sweep = 0;
     uint32_t* d_klast = nullptr;      // vec kernels: samples already credited per walker (d_logp, d_naccept, d_klast: one block)
+    double2* d_draws = nullptr;       // resident mode, one walker per thread: the draws of a launch's generations, [kDrawTableGens][nwalkers] x 32 B
     double2* d_ring = nullptr;        // vec kernels: parked draws of the walkers' next steps, [4][nrows] x 32 B (HalfStepArgs::ring)
     int64_t macc_stride = 0, macc_elems = 0;
     // KMC_STREAM_CHAIN: d_chain / d_chain_logp are rings of ring_slots = 3 * ring_blk sample slots; completed blocks go to

@@ -199,7 +199,7 @@ def test_body_density_runs_resident_on_small_ensembles(kmc, oracle, monkeypatch,
 
     res = run()
     assert "resident mode" in res["how"] and "one walker per thread" in res["how"], res["how"]
-    assert res["launches"] <= 3                                           # three run() pieces, not 2 G launches
+    assert res["launches"] <= 6                                           # three run() pieces (draw table + resident kernel each), not 2 G launches
     monkeypatch.setenv("KMC_NO_RESIDENT", "1")
     ml = run()
     assert "resident" not in ml["how"]
@@ -224,7 +224,7 @@ def test_body_density_with_blobs_runs_resident(kmc):
         s.set_positions(th)
         s.run(1000)
         s.sync()
-        assert "resident mode" in s.describe() and s.launch_count == 1
+        assert "resident mode" in s.describe() and s.launch_count <= 2        # (the draw table's kernel + the resident one)
         chain, clogp = s.chain()
         blobs = s.blobs(by_walker=False)
         cur, pos, lp = s.current_blobs(), s.positions(), s.logp()
