@@ -230,8 +230,8 @@ struct ResidentArgs {
     double*       chain_logp;   // [nsamples][S] or nullptr
     double*       blob;         // body densities with blobs (resident_lane_body): [S][NB] current blobs, or nullptr
     double*       chain_blob;   //   [nsamples][S][NB] or nullptr
-    const double2* draws;       // resident_lane_body: the launch's draws, [ngen][S] x 32 B {z, (N-1) log z | log u, partner} from
-                                //   draw_table_fill (the two-lanes-per-walker kernel draws itself)
+    const double2* draws;       // the launch's draws, [ngen padded to kDrawBatch][S] x 32 B {z, (N-1) log z | log u, partner} from
+                                //   draw_table_fill
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -311,15 +311,19 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& ra)
     const bool scv = iA < HS;
     const int ownA = hA * HS + (scv ? iA : 0);
     uint32_t naccA = 0u;
+    // the launch's draws come from draw_table_fill (see there), one generation ahead of their use: a generation of these
+    // longer rows outlasts the load
+    Draw nxt{};
+    if (a.ngen > 0) nxt = draw_table_load(ra.draws, ownA);
 
     ThinClock clk(a.gen0, a.nburnin, a.nthin);
     for (int gg = 0; gg < a.ngen; ++gg) {
-        const int64_t gen = a.gen0 + gg;
         const bool hit = clk.tick(a.nthin);               // clk.n: the reference's loop variable (:245)
         const bool count = clk.n > 0;
         const int64_t slot = clk.q - 1;
         const bool sample = hit && slot < a.nsamples;                                            // :268
-        const Draw drA = draw_step(a.dc, 2ull * (uint64_t)gen + (uint64_t)hA, (uint64_t)ownA);   // keyed by the walker index
+        const Draw drA = nxt;                             // row (step, walker ownA) of the table: keyed by the walker index
+        nxt = draw_table_load(ra.draws, (int64_t)(gg + 1 < a.ngen ? gg + 1 : gg) * S + ownA);
         const double p0A = llogp[ownA];
 #pragma unroll 1
         for (int half = 0; half < 2; ++half) {
@@ -361,7 +365,7 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& ra)
                     mq[k].x += cur.x * cur.x; mq[k].y += cur.y * cur.y;
                 }
             }
-            __syncthreads();                              // the join of :273
+            lds_barrier();                                // the join of :273 (LDS only: the prefetched draws stay in flight)
         }
         if (sample && (ra.chain != nullptr || ra.chain_logp != nullptr)) {       // :268-271
             if (t < S) {
@@ -374,7 +378,7 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& ra)
             }
             // rows are only read here; the next generation's first writes come after its own barrier-free
             // reads, by other threads -> order them
-            __syncthreads();
+            lds_barrier();
         }
     }
 

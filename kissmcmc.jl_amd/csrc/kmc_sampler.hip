@@ -561,7 +561,7 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         CREATE_TRY(dev_alloc(s, (void**)&s->d_ring, nb));
         CREATE_TRY(hipMemsetAsync(s->d_ring, 0xff, nb, s->stream));
     }
-    if (s->resident && s->resident_lane)             // one walker per thread: the launch's draws come from a wide kernel (draw_table_fill)
+    if (s->resident)                                 // the launch's draws come from a wide kernel (draw_table_fill, kmc_islands.hpp)
         CREATE_TRY(dev_alloc(s, (void**)&s->d_draws, (size_t)kDrawTableGens * nw * 2 * sizeof(double2)));
     if (cfg->flags & KMC_MOMENTS) {
         CREATE_TRY(dev_alloc(s, &s->d_msum, (size_t)s->macc_elems * sizeof(double)));
@@ -801,8 +801,8 @@ KMC_EXPORT kmc_status kmc_sampler_describe(const kmc_sampler* s, char* buf, int6
     else if (s->resident)
         o << "resident mode (exact): whole ensemble in one workgroup's LDS (" << s->resident_tpb
           << " threads), up to " << (s->d_draws ? kDrawTableGens : (int64_t)4096) << " generations per launch, "
-          << (s->resident_lane ? std::string("one walker per thread") + (s->d_draws ? ", the launch's draws from a wide kernel before it" : "")
-                               : "rows 2 lanes x " + std::to_string(s->island_K) + " chunks");
+          << (s->resident_lane ? std::string("one walker per thread") : "rows 2 lanes x " + std::to_string(s->island_K) + " chunks")
+          << ", the launch's draws from a wide kernel before it";
     else if (s->host_eval)
         o << "host-evaluated density (exact): per half-step propose kernel -> D2H -> callback -> H2D -> accept kernel, grid "
           << s->grid << " x 256";
