@@ -6,6 +6,6 @@
 namespace kmc {
 IslandFn island_gaussian_iso(int S, int K, bool ragged) { return island_lookup<GaussianIso>(S, K, ragged); }
 ResidentFn resident_gaussian_iso(int tpb, int K, bool ragged) { return resident_lookup<GaussianIso>(tpb, K, ragged); }
-ResidentFn resident_lane_gaussian_iso(int ndim) { return resident_lane_lookup<GaussianIso>(ndim); }
+ResidentFn resident_lane_gaussian_iso(int ndim, bool f32) { return resident_lane_lookup<GaussianIso>(ndim, f32); }
 MetropolisFn metropolis_gaussian_iso(int ndim) { return metropolis_lookup<GaussianIso>(ndim); }
 }  // namespace kmc

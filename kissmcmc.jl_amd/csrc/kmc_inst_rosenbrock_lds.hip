@@ -6,6 +6,6 @@
 namespace kmc {
 IslandFn island_rosenbrock(int S, int K, bool ragged) { return island_lookup<Rosenbrock>(S, K, ragged); }
 ResidentFn resident_rosenbrock(int tpb, int K, bool ragged) { return resident_lookup<Rosenbrock>(tpb, K, ragged); }
-ResidentFn resident_lane_rosenbrock(int ndim) { return resident_lane_lookup<Rosenbrock>(ndim); }
+ResidentFn resident_lane_rosenbrock(int ndim, bool f32) { return resident_lane_lookup<Rosenbrock>(ndim, f32); }
 MetropolisFn metropolis_rosenbrock(int ndim) { return metropolis_lookup<Rosenbrock>(ndim); }
 }  // namespace kmc

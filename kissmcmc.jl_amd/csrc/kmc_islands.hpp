@@ -433,7 +433,8 @@ __global__ __launch_bounds__(TPB) void resident_epoch(const ResidentArgs a)
 // table above instead of made here 0.22, 0.25, 0.42 and (body density, 32-D) 0.90.  Log-densities are summed in index order (the Seq interface),
 // like half_step_generic and the oracle.  EXACT_ND: ndim == ND at compile time (runtime-compiled body densities).
 // ------------------------------------------------------------------------------------------------
-template <class Dens, int ND, bool EXACT_ND>
+// T: the storage type of rows and chain (KMC_F32: float rows, double arithmetic, proposals rounded before their density).
+template <class Dens, int ND, bool EXACT_ND, class T = double>
 __device__ __forceinline__ void resident_lane_body(const ResidentArgs& ra)
 {
     const IslandArgs& a = ra.is;
@@ -447,7 +448,7 @@ __device__ __forceinline__ void resident_lane_body(const ResidentArgs& ra)
     const bool live = t < S;
     if (live) {
 #pragma unroll
-        for (int d = 0; d < ND; ++d) lpos[t * LS + d] = d < ndim ? a.pos[(int64_t)t * a.ld + d] : 0.0;
+        for (int d = 0; d < ND; ++d) lpos[t * LS + d] = d < ndim ? (double)reinterpret_cast<const T*>(a.pos)[(int64_t)t * a.ld + d] : 0.0;
         llogp[t] = a.logp[t];
     }
     __syncthreads();
@@ -462,7 +463,9 @@ __device__ __forceinline__ void resident_lane_body(const ResidentArgs& ra)
     // with loads that always hit.)  The batch's generations are unrolled, so each reads its draws from registers of its
     // own: no rotation of registers -- a copy of a register a load is still in flight to would wait for it.
     // (long rows: a generation outlasts a load by itself, and four copies of a 32-dimensional body spill)
-    constexpr int B = ND <= 8 ? kDrawBatch : (ND <= 16 ? 2 : 1);
+    // (float rows: one generation ahead -- the option exists for large ensembles; here it only has to not fall off a cliff,
+    //  and four copies of the generation for every row length and density are 10 s of build time)
+    constexpr int B = sizeof(T) == 4 ? 1 : (ND <= 4 ? kDrawBatch : (ND <= 16 ? 2 : 1));    // (a batch in flight for >= 1.5 us)
     static_assert(kDrawBatch % B == 0, "the host pads the table to kDrawBatch generations");
     const int tl = live ? t : 0;
     const int nb = (a.ngen + B - 1) / B;                  // the table is padded to whole batches
@@ -504,7 +507,7 @@ __device__ __forceinline__ void resident_lane_body(const ResidentArgs& ra)
 #pragma unroll
                 for (int d = 0; d < ND; ++d) {
                     if (d < ndim) {
-                        y[d] = fma(dr.z, own[d] - oth[d], oth[d]);               // :255
+                        y[d] = as_stored<T>(fma(dr.z, own[d] - oth[d], oth[d])); // :255
                         Dens::seq_add(q, y[d], d, a.dp);
                     }
                 }
@@ -524,10 +527,10 @@ __device__ __forceinline__ void resident_lane_body(const ResidentArgs& ra)
         }
         if (sample && live) {                             // the walker's state after its update (:268-271); own row, own thread
             if (ra.chain != nullptr) {
-                double* dst = ra.chain + (slot * S + t) * (int64_t)a.ld;
+                T* dst = reinterpret_cast<T*>(ra.chain) + (slot * S + t) * (int64_t)a.ld;
 #pragma unroll
-                for (int d = 0; d < ND; ++d) if (d < ndim) dst[d] = lpos[t * LS + d];
-                if (a.ld > ndim) dst[ndim] = 0.0;                               // the pad column of an odd ndim
+                for (int d = 0; d < ND; ++d) if (d < ndim) dst[d] = (T)lpos[t * LS + d];
+                if (a.ld > ndim) dst[ndim] = (T)0;                              // the pad column of an odd ndim
             }
             if (ra.chain_logp != nullptr) ra.chain_logp[slot * S + t] = llogp[t];
             if constexpr (BlobTrait<Dens>::n > 0) {
@@ -547,7 +550,7 @@ __device__ __forceinline__ void resident_lane_body(const ResidentArgs& ra)
 
     if (live) {
 #pragma unroll
-        for (int d = 0; d < ND; ++d) if (d < ndim) a.pos[(int64_t)t * a.ld + d] = lpos[t * LS + d];
+        for (int d = 0; d < ND; ++d) if (d < ndim) reinterpret_cast<T*>(a.pos)[(int64_t)t * a.ld + d] = (T)lpos[t * LS + d];
         a.logp[t] = llogp[t];
         if (nacc) a.naccept[t] += nacc;
     }
@@ -568,10 +571,10 @@ __device__ __forceinline__ void resident_lane_body(const ResidentArgs& ra)
     }
 }
 
-template <class Dens, int ND>
+template <class Dens, int ND, class T = double>
 __global__ __launch_bounds__(1024) void resident_lane(const ResidentArgs a)
 {
-    resident_lane_body<Dens, ND, true>(a);
+    resident_lane_body<Dens, ND, true, T>(a);
 }
 
 }  // namespace kmc

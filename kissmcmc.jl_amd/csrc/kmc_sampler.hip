@@ -53,14 +53,14 @@ ResidentFn resident_fn(int density, int tpb, int K, bool ragged)
     }
 }
 
-ResidentFn resident_lane_fn(int density, int ndim)
+ResidentFn resident_lane_fn(int density, int ndim, bool f32)
 {
     switch (density) {
-    case KMC_GAUSSIAN_ISO: return resident_lane_gaussian_iso(ndim);
-    case KMC_EXPONENTIAL: return resident_lane_exponential(ndim);
-    case KMC_ROSENBROCK: return resident_lane_rosenbrock(ndim);
-    case KMC_LOGNORMAL: return resident_lane_lognormal(ndim);
-    case KMC_MVNORMAL2: return resident_lane_mvnormal2(ndim);
+    case KMC_GAUSSIAN_ISO: return resident_lane_gaussian_iso(ndim, f32);
+    case KMC_EXPONENTIAL: return resident_lane_exponential(ndim, f32);
+    case KMC_ROSENBROCK: return resident_lane_rosenbrock(ndim, f32);
+    case KMC_LOGNORMAL: return resident_lane_lognormal(ndim, f32);
+    case KMC_MVNORMAL2: return resident_lane_mvnormal2(ndim, f32);
     default: return nullptr;
     }
 }
@@ -396,7 +396,8 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         if (s->user->is_body) rlds = ((size_t)cfg->nwalkers * (size_t)((cfg->ndim | 1) + 1)) * sizeof(double);
         const bool expr_lane = !s->user->is_body && resident_lane_wanted(cfg->ndim);     // term / pair density, short rows: the lane kernel too
         if (expr_lane) rlds = ((size_t)cfg->nwalkers * (size_t)((lane_nd(cfg->ndim) | 1) + 1)) * sizeof(double);
-        if (!s->f32 && cfg->nwalkers <= ((s->user->is_body || expr_lane) ? 1024 : 256) && cfg->ndim <= 32 && s->cfg.shard_count == 1 && !(s->user->is_body && cfg->deal_count > 0) &&
+        // (float rows: the one-walker-per-thread kernels only -- their LDS rows are double either way)
+        if ((!s->f32 || s->user->is_body || expr_lane) && cfg->nwalkers <= ((s->user->is_body || expr_lane) ? 1024 : 256) && cfg->ndim <= 32 && s->cfg.shard_count == 1 && !(s->user->is_body && cfg->deal_count > 0) &&
             !(cfg->flags & (KMC_P2P | KMC_NO_GRAPH | KMC_ISLANDS | KMC_STREAM_CHAIN)) &&
             rlds <= 60 * 1024 && std::getenv("KMC_NO_RESIDENT") == nullptr)
             rK = rK0;
@@ -453,16 +454,16 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         }
         if (ea != hipSuccess) { (void)hipGetLastError(); kmc_sampler_destroy(s); return fail(KMC_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(ea)); }
     }
-    if (!s->islands && !s->f32 && cfg->density != KMC_USER_DENSITY && !s->host_eval && cfg->nwalkers <= 1024 && cfg->ndim <= 32 &&
+    if (!s->islands && cfg->density != KMC_USER_DENSITY && !s->host_eval && cfg->nwalkers <= 1024 && cfg->ndim <= 32 &&
         s->cfg.shard_count == 1 && !(cfg->flags & (KMC_P2P | KMC_NO_GRAPH | KMC_STREAM_CHAIN)) && std::getenv("KMC_NO_RESIDENT") == nullptr) {
         const int64_t chunks = s->ld / 2;
         int K = 1;
         while (2 * K < chunks) K *= 2;
         int rtpb = cfg->nwalkers <= 256 ? 256 : (cfg->nwalkers <= 512 ? 512 : 1024);
         size_t need = ((size_t)cfg->nwalkers * (size_t)(4 * (K + 1)) + (size_t)cfg->nwalkers) * sizeof(double);
-        ResidentFn rf = need <= 156 * 1024 ? resident_fn(cfg->density, rtpb, K, 4 * K != cfg->ndim) : nullptr;
+        ResidentFn rf = (!s->f32 && need <= 156 * 1024) ? resident_fn(cfg->density, rtpb, K, 4 * K != cfg->ndim) : nullptr;   // (float rows: the lane kernels only)
         if (resident_lane_wanted(cfg->ndim)) {            // short rows: one walker per thread (measured faster up to ndim 8)
-            ResidentFn lf = resident_lane_fn(cfg->density, (int)cfg->ndim);
+            ResidentFn lf = resident_lane_fn(cfg->density, (int)cfg->ndim, s->f32);
             if (lf) {
                 rf = lf;
                 rtpb = (int)((cfg->nwalkers + 63) / 64 * 64);

@@ -138,21 +138,26 @@ ResidentFn resident_lookup(int tpb, int K, bool ragged)
         }
     }
 }
-// resident mode, one walker per thread (short rows: ndim <= ND <= 8)
-template <class D>
-ResidentFn resident_lane_lookup(int ndim)
+// resident mode, one walker per thread (short rows: ndim <= ND <= 8); double or float rows
+template <class D, class T>
+ResidentFn resident_lane_lookup_t(int ndim)
 {
     switch (ndim) {           // exact row lengths: no per-element guards in the kernel
-    case 1: return resident_lane<D, 1>;
-    case 2: return resident_lane<D, 2>;
-    case 3: return resident_lane<D, 3>;
-    case 4: return resident_lane<D, 4>;
-    case 5: return resident_lane<D, 5>;
-    case 6: return resident_lane<D, 6>;
-    case 7: return resident_lane<D, 7>;
-    case 8: return resident_lane<D, 8>;
+    case 1: return resident_lane<D, 1, T>;
+    case 2: return resident_lane<D, 2, T>;
+    case 3: return resident_lane<D, 3, T>;
+    case 4: return resident_lane<D, 4, T>;
+    case 5: return resident_lane<D, 5, T>;
+    case 6: return resident_lane<D, 6, T>;
+    case 7: return resident_lane<D, 7, T>;
+    case 8: return resident_lane<D, 8, T>;
     default: return nullptr;
     }
+}
+template <class D>
+ResidentFn resident_lane_lookup(int ndim, bool f32)
+{
+    return f32 ? resident_lane_lookup_t<D, float>(ndim) : resident_lane_lookup_t<D, double>(ndim);
 }
 // many-chain Metropolis: the chain in registers up to 32 dimensions, in memory beyond
 template <class D>
@@ -183,27 +188,27 @@ KMC_DECLARE_DENSITY_TABLE(mvnormal2);
 HalfStepFn half_step_host();
 IslandFn island_gaussian_iso(int S, int K, bool ragged);
 ResidentFn resident_gaussian_iso(int tpb, int K, bool ragged);
-ResidentFn resident_lane_gaussian_iso(int ndim);
+ResidentFn resident_lane_gaussian_iso(int ndim, bool f32);
 InitBallFn init_ball_gaussian_iso();
 MetropolisFn metropolis_gaussian_iso(int ndim);
 IslandFn island_exponential(int S, int K, bool ragged);
 ResidentFn resident_exponential(int tpb, int K, bool ragged);
-ResidentFn resident_lane_exponential(int ndim);
+ResidentFn resident_lane_exponential(int ndim, bool f32);
 InitBallFn init_ball_exponential();
 MetropolisFn metropolis_exponential(int ndim);
 IslandFn island_rosenbrock(int S, int K, bool ragged);
 ResidentFn resident_rosenbrock(int tpb, int K, bool ragged);
-ResidentFn resident_lane_rosenbrock(int ndim);
+ResidentFn resident_lane_rosenbrock(int ndim, bool f32);
 InitBallFn init_ball_rosenbrock();
 MetropolisFn metropolis_rosenbrock(int ndim);
 IslandFn island_lognormal(int S, int K, bool ragged);
 ResidentFn resident_lognormal(int tpb, int K, bool ragged);
-ResidentFn resident_lane_lognormal(int ndim);
+ResidentFn resident_lane_lognormal(int ndim, bool f32);
 InitBallFn init_ball_lognormal();
 MetropolisFn metropolis_lognormal(int ndim);
 IslandFn island_mvnormal2(int S, int K, bool ragged);
 ResidentFn resident_mvnormal2(int tpb, int K, bool ragged);
-ResidentFn resident_lane_mvnormal2(int ndim);
+ResidentFn resident_lane_mvnormal2(int ndim, bool f32);
 InitBallFn init_ball_mvnormal2();
 MetropolisFn metropolis_mvnormal2(int ndim);
 

@@ -27,6 +27,8 @@ CASES = [
     ("rosen", 130, 9, 80, 20, 1),
     ("gauss", 1040, 1026, 4, 1, 1),      # beyond the vector kernels: generic kernel
     ("gauss", 34, 32, 100, 30, 1),
+    ("gauss", 1000, 4, 1100, 500, 7),    # resident mode, one walker per thread, more than one launch (draw table refilled)
+    ("expo", 256, 3, 200, 50, 3),
 ]
 
 
@@ -40,16 +42,27 @@ def _run_f32(kmc, oracle, name, nw, nd, G, nburn, nthin, seed, use_graph=True):
         s.set_positions(th)
         s.run(G)
         s.sync()
-        got = dict(final_pos=s.positions(), final_logp=s.logp(), naccept=s.naccept(), accept_ratio=s.accept_ratio())
+        got = dict(final_pos=s.positions(), final_logp=s.logp(), naccept=s.naccept(), accept_ratio=s.accept_ratio(), how=s.describe())
         got["chain"], got["chain_logp"] = s.chain()
         got["sum"], got["sumsq"], got["nmoment"] = s.moments()
     return ref, got, th
 
 
 @pytest.mark.parametrize("name,nw,nd,G,nburn,nthin", CASES)
-def test_f32_rows_match_the_oracle(kmc, oracle, name, nw, nd, G, nburn, nthin):
+def test_f32_rows_match_the_oracle(kmc, oracle, name, nw, nd, G, nburn, nthin, monkeypatch):
     ref, got, th = _run_f32(kmc, oracle, name, nw, nd, G, nburn, nthin, seed=77 + nd)
     _compare(ref, got)
+    if nw <= 1024 and nd <= 8:
+        # short rows of a small ensemble run out of one workgroup's LDS (float rows widened on the way in, proposals rounded
+        # before their density, as everywhere); the multi-launch kernels on the same job must agree too
+        assert "resident mode" in got["how"] and "one walker per thread" in got["how"], got["how"]
+        monkeypatch.setenv("KMC_NO_RESIDENT", "1")
+        ref2, got2, _ = _run_f32(kmc, oracle, name, nw, nd, G, nburn, nthin, seed=77 + nd)
+        assert "multi-launch" in got2["how"], got2["how"]
+        _compare(ref2, got2)
+        monkeypatch.delenv("KMC_NO_RESIDENT")
+    else:
+        assert "resident" not in got["how"], got["how"]
     # everything stored is representable in single, and the run differs from the double one
     assert np.array_equal(got["chain"], got["chain"].astype(np.float32).astype(np.float64))
     assert np.array_equal(got["final_pos"], got["final_pos"].astype(np.float32).astype(np.float64))
@@ -144,7 +157,38 @@ def test_f32_rows_with_runtime_compiled_densities(kmc, oracle, nw, nd, plan, mon
         s.set_positions(th)
         s.run(G)
         s.sync()
-        got = dict(final_pos=s.positions(), final_logp=s.logp(), naccept=s.naccept(), accept_ratio=s.accept_ratio())
+        got = dict(final_pos=s.positions(), final_logp=s.logp(), naccept=s.naccept(), accept_ratio=s.accept_ratio(), how=s.describe())
         got["chain"], got["chain_logp"] = s.chain()
         got["sum"], got["sumsq"], got["nmoment"] = s.moments()
     _compare(ref, got)
+
+
+def test_f32_body_density_runs_resident(kmc, oracle, monkeypatch):
+    """A user-written function body on float rows: one walker per thread out of LDS, equal to the multi-launch kernels
+    bit for bit (same rounding points)."""
+    body = "double s = 0; for (int i = 0; i < n; ++i) { double d = x[i] - p[0]; s += d * d; } return -0.5 * s / (p[1] * p[1]);"
+    nw, nd, G = 200, 5, 300
+    th = np.random.default_rng(12).standard_normal((nw, nd)).astype(np.float32).astype(np.float64)
+
+    def run():
+        with kmc.Sampler(kmc.CDensity(body, params=[0.5, 2.0]), nw, nd, G, 100, 2, 2.0, 9, store_chain=True, store_logp=True,
+                         moments=True, dtype="f32") as s:
+            s.set_positions(th)
+            s.run(G)
+            s.sync()
+            ch, cl = s.chain()
+            return dict(how=s.describe(), pos=s.positions(), logp=s.logp(), nacc=s.naccept(), chain=ch, clogp=cl, mom=s.moments())
+
+    res = run()
+    assert "resident mode" in res["how"] and "float" in res["how"], res["how"]
+    monkeypatch.setenv("KMC_NO_RESIDENT", "1")
+    ml = run()
+    assert "multi-launch" in ml["how"], ml["how"]
+    for k in ("pos", "nacc", "chain"):
+        np.testing.assert_array_equal(res[k], ml[k], err_msg=k)
+    np.testing.assert_allclose(res["logp"], ml["logp"], rtol=1e-12)
+    np.testing.assert_allclose(res["clogp"], ml["clogp"], rtol=1e-12)
+    for a_, b_ in zip(res["mom"][:2], ml["mom"][:2]):
+        np.testing.assert_allclose(a_, b_, rtol=1e-11)
+    assert np.array_equal(res["chain"], res["chain"].astype(np.float32).astype(np.float64))
+    assert abs(res["chain"].mean() - 0.5) < 0.25
