@@ -8,4 +8,5 @@ IslandFn island_lognormal(int S, int K, bool ragged) { return island_lookup<LogN
 ResidentFn resident_lognormal(int tpb, int K, bool ragged) { return resident_lookup<LogNormal>(tpb, K, ragged); }
 ResidentFn resident_lane_lognormal(int ndim, bool f32) { return resident_lane_lookup<LogNormal>(ndim, f32); }
 MetropolisFn metropolis_lognormal(int ndim) { return metropolis_lookup<LogNormal>(ndim); }
+MetropolisTabledFn metropolis_tabled_lognormal(int ndim) { return metropolis_tabled_lookup<LogNormal>(ndim); }
 }  // namespace kmc

@@ -149,6 +149,184 @@ __device__ __forceinline__ void metropolis_chains_body(const MetropolisArgs& a)
     a.naccept[c] = na;
 }
 
+// ------------------------------------------------------------------------------------------------
+// FEW chains (the reference's own call is ONE): the draws come from a table.
+//
+// A chain is serial, and with the draws made in the loop above a step is ~1400 cycles of Philox, Box-Muller and a
+// logarithm around ~100 cycles of proposal, density and accept test: 1.5e6 steps/s however few chains there are, with the
+// rest of the chip idle.  The draws {normal per dimension, log u} are pure functions of (seed, iteration, chain), so a
+// wide kernel (metro_draw_fill) computes them for a stretch of iterations first -- parallel over iterations, which the
+// chain is not -- and the chains then only read them.
+//
+// Table of one launch: per wave of 64 chains (nl = the chains the wave really has), [step][k][nl] doubles with k = 0..ndim-1
+// the normals and k = ndim the log-uniform; waves one after the other (a full wave takes 64 * T * (ndim + 1) doubles).
+// Kernel: workgroups of TWO waves -- wave 0 runs the chains, wave 1 is their loader: it copies the next tile of the table
+// (contiguous, so coalesced whatever nl is) into the other half of a double buffer in LDS while wave 0 works through the
+// current one; one barrier per tile.  The loader waits for its loads where it issues them -- nothing has to be kept in
+// flight across a loop by the compiler's leave -- and wave 0's barrier waits for LDS only.
+// Same stream, same arithmetic: bit-identical to metropolis_chains_body.
+// ------------------------------------------------------------------------------------------------
+constexpr int kMetroTileBytes = 32 * 1024;      // one half of the LDS double buffer (64 KiB per workgroup)
+
+struct MetroDrawArgs {
+    double*  out;
+    int64_t  nchains;
+    int64_t  it0;
+    int32_t  nsteps;           // table length T (a multiple of the tile's steps)
+    int32_t  ndim;
+    uint32_t seed_lo, seed_hi;
+};
+
+__host__ __device__ __forceinline__ int metro_tile_steps(int nl, int ndim)
+{
+    const int per_step = (ndim + 1) * nl * 8;
+    const int ts = (kMetroTileBytes / per_step) & ~1;                        // even: tiles start on 16-byte boundaries whatever nl is
+    return ts < 1 ? 1 : ts;                                                  // (one step per tile: nl = 64, an even number of doubles)
+}
+
+template <class Dens, int ND>
+__device__ __forceinline__ void metropolis_chains_tabled_body(const MetropolisArgs& a, const double* draws, int nsteps)
+{
+    extern __shared__ __attribute__((aligned(16))) double mlds[];
+    const int lane = threadIdx.x & 63;
+    const bool loader = threadIdx.x >= 64;
+    const int64_t c0 = (int64_t)blockIdx.x * 64;
+    const int nl = (int)(a.nchains - c0 < 64 ? a.nchains - c0 : 64);
+    const int ndim = a.ndim;
+    __builtin_assume(ndim > ND / 2 && ndim <= ND);                           // how the host picks ND (metropolis_nd)
+    const int ts = metro_tile_steps(nl, ndim);
+    const int tile_doubles = ts * (ndim + 1) * nl;
+    const int ntiles = (nsteps + ts - 1) / ts;                               // the table is padded to whole tiles
+    const double* wtab = draws + c0 * (int64_t)nsteps * (ndim + 1);
+    constexpr int kHalf = kMetroTileBytes / 8;
+    if (loader) {
+        for (int t = 0; t <= ntiles; ++t) {
+            if (t < ntiles) {
+                const double* src = wtab + (int64_t)t * tile_doubles;
+                double* dst = mlds + (t & 1) * kHalf;
+                const int64_t left = (int64_t)nsteps * (ndim + 1) * nl - (int64_t)t * tile_doubles;      // (the last tile may be short)
+                const int ncopy = left < tile_doubles ? (int)left : tile_doubles;
+                // the whole tile in flight at once (<= 32 x 16 B per lane), then into LDS: one memory round trip per tile
+                constexpr int kMax = kMetroTileBytes / (64 * 16);
+                const double2* src2 = reinterpret_cast<const double2*>(src);
+                double2* dst2 = reinterpret_cast<double2*>(dst);
+                const int n2 = ncopy >> 1;
+                double2 r[kMax];
+#pragma unroll
+                for (int j = 0; j < kMax; ++j) { const int i = lane + 64 * j; r[j] = src2[i < n2 ? i : 0]; }   // (unconditional: a load in a branch is waited for at its end)
+                __builtin_amdgcn_sched_barrier(0);                           // (all the loads first: the scheduler would keep six in flight)
+#pragma unroll
+                for (int j = 0; j < kMax; ++j) dst2[lane + 64 * j] = r[j];       // (past the tile's end: slots of this half nobody reads)
+                if (ncopy & 1) { if (lane == 0) dst[ncopy - 1] = src[ncopy - 1]; }
+            }
+            __syncthreads();                                                 // tile t is in LDS; the chains are done with tile t - 1
+        }
+        return;
+    }
+    const int64_t c = c0 + lane;
+    const bool live = lane < nl;
+    const int64_t cc = live ? c : c0;
+    double x[ND], y[ND], sc[ND], s1[ND], s2[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+        x[d]  = d < ndim ? a.pos[cc * ndim + d] : 0.0;
+        sc[d] = d < ndim ? a.step[d] : 0.0;
+        s1[d] = (a.csum != nullptr && d < ndim) ? a.csum[cc * ndim + d] : 0.0;
+        s2[d] = (a.csum != nullptr && d < ndim) ? a.csumsq[cc * ndim + d] : 0.0;
+    }
+    double   p0  = a.logp[cc];
+    uint32_t na  = a.naccept[cc];
+    int64_t  cnt = a.cnt0, slot = a.slot0;
+    int64_t  n   = a.it0 + 1 - a.nburnin;                                    // :96
+    const int64_t nit = a.it1 - a.it0;
+    lds_barrier();                                                           // tile 0 is in LDS
+    // Every lane runs the loop (a wave's spare lanes shadow its first chain and store nothing): the iteration counters then
+    // stay scalar.  The draws of step s + 1 are read from LDS before step s's dependent chain starts.
+    const int64_t sample_stride = a.nchains * ndim;
+    const bool has_chain = a.chain != nullptr, has_logp = a.chain_logp != nullptr, has_mom = a.csum != nullptr;
+    double* chain_p = a.chain + (slot * a.nchains + cc) * ndim;              // where the next stored sample goes (if has_chain)
+    double* logp_p = a.chain_logp + slot * a.nchains + cc;
+    const int estep = (ndim + 1) * nl;
+    for (int t = 0; t < ntiles; ++t) {
+        const double* tile = mlds + (t & 1) * kHalf + (live ? lane : 0);
+        const int s_end = (int)(nit - (int64_t)t * ts < ts ? nit - (int64_t)t * ts : ts);
+        double nrm[ND], lu_n;
+#pragma unroll
+        for (int d = 0; d < ND; ++d) nrm[d] = d < ndim ? tile[d * nl] : 0.0;
+        lu_n = tile[ndim * nl];
+        for (int s = 0; s < s_end; ++s, ++n) {
+            double nr[ND];
+#pragma unroll
+            for (int d = 0; d < ND; ++d) nr[d] = nrm[d];
+            const double lu = lu_n;
+            {
+                const double* e = tile + (s + 1 < s_end ? s + 1 : s) * estep;
+#pragma unroll
+                for (int d = 0; d < ND; ++d) nrm[d] = d < ndim ? e[d * nl] : 0.0;
+                lu_n = e[ndim * nl];
+            }
+            typename Dens::Seq q;
+            Dens::seq_init(q);
+#pragma unroll
+            for (int d = 0; d < ND; ++d) {
+                if (d < ndim) {
+                    y[d] = fma(sc[d], nr[d], x[d]);                          // :98  theta1 = sample_ppdf(theta0)
+                    Dens::seq_add(q, y[d], d, a.dp);
+                }
+            }
+            const double p1 = Dens::seq_finish(q, ndim, a.dp);               // :99
+            const bool acc = p1 - p0 > lu;                                   // :101, note the strict >
+#pragma unroll
+            for (int d = 0; d < ND; ++d) x[d] = acc ? y[d] : x[d];           // :102
+            p0 = acc ? p1 : p0;                                              // :104
+            na += (acc && n > 0) ? 1u : 0u;                                  // :105
+            if (n > 0 && ++cnt == a.nthin) {                                 // :108, :112 (uniform)
+                cnt = 0;
+                if (slot < a.nsamples) {
+                    if (live) {
+                        if (has_chain) {
+#pragma unroll
+                            for (int d = 0; d < ND; ++d) if (d < ndim) chain_p[d] = x[d];        // :113
+                        }
+                        if (has_logp) *logp_p = p0;                                              // :115
+                    }
+                    chain_p += sample_stride;
+                    logp_p += a.nchains;
+                    if (has_mom) {
+#pragma unroll
+                        for (int d = 0; d < ND; ++d) { s1[d] += x[d]; s2[d] += x[d] * x[d]; }
+                    }
+                }
+                ++slot;
+            }
+        }
+        lds_barrier();                                                       // done with tile t; tile t + 1 is in LDS
+    }
+    if (live) {
+#pragma unroll
+        for (int d = 0; d < ND; ++d) {
+            if (d < ndim) {
+                a.pos[c * ndim + d] = x[d];
+                if (a.csum != nullptr) { a.csum[c * ndim + d] = s1[d]; a.csumsq[c * ndim + d] = s2[d]; }
+            }
+        }
+        a.logp[c] = p0;
+        a.naccept[c] = na;
+    }
+}
+
+struct MetropolisTabledArgs {      // (one struct: how the runtime-compiled kernels are launched)
+    MetropolisArgs a;
+    const double*  draws;
+    int32_t        nsteps, pad_;
+};
+
+template <class Dens, int ND>
+__global__ __launch_bounds__(128) void metropolis_chains_tabled(const MetropolisArgs a, const double* draws, int nsteps)
+{
+    metropolis_chains_tabled_body<Dens, ND>(a, draws, nsteps);
+}
+
 // Any ndim: the chain stays in memory, dimension-major ([ndim][nchains]) so that the 64 chains of a wave
 // read and write consecutive doubles; pos / csum (chain-major, the C ABI's layout) are converted by
 // metropolis_transpose before the first and after the last launch.
@@ -277,6 +455,42 @@ struct MetroHostArgs {
 };
 
 #ifdef KMC_DEFINE_METROPOLIS_KERNELS   // non-template kernels: defined once, in kmc_metropolis_api.hip
+// the draw table of metropolis_chains_tabled: one thread per (step, chain), the stream of metropolis_chains_body
+__global__ __launch_bounds__(256) void metro_draw_fill(const MetroDrawArgs a)
+{
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)a.nsteps * a.nchains) return;
+    const int64_t s = idx / a.nchains;
+    const int64_t c = idx - s * a.nchains;
+    const int64_t it = a.it0 + s;
+    const int ndim = a.ndim;
+    const int64_t c0 = c & ~(int64_t)63;
+    const int nl = (int)(a.nchains - c0 < 64 ? a.nchains - c0 : 64);
+    double* e = a.out + c0 * (int64_t)a.nsteps * (ndim + 1) + s * (int64_t)(ndim + 1) * nl + (c - c0);
+    const uint32_t k0 = a.seed_lo ^ 0x4d455452u, k1 = a.seed_hi;
+    const U4 w = philox4x32_10((uint32_t)it, (uint32_t)((uint64_t)it >> 32), (uint32_t)c, 0u, k0, k1);
+    if (ndim == 1) {
+        e[0] = normal_first(w.x, w.y);
+    } else {
+        double n0, n1;
+        normal_pair(w.x, w.y, n0, n1);
+        e[0] = n0;
+        e[nl] = n1;
+        for (int b = 1; 4 * b - 2 < ndim; ++b) {
+            const U4 v = philox4x32_10((uint32_t)it, (uint32_t)((uint64_t)it >> 32), (uint32_t)c, (uint32_t)b, k0, k1);
+            double m0, m1, m2, m3;
+            normal_pair(v.x, v.y, m0, m1);
+            normal_pair(v.z, v.w, m2, m3);
+            const int d0 = 4 * b - 2;
+            e[(int64_t)d0 * nl] = m0;
+            if (d0 + 1 < ndim) e[(int64_t)(d0 + 1) * nl] = m1;
+            if (d0 + 2 < ndim) e[(int64_t)(d0 + 2) * nl] = m2;
+            if (d0 + 3 < ndim) e[(int64_t)(d0 + 3) * nl] = m3;
+        }
+    }
+    const uint64_t kk = ((uint64_t)w.z << 20) | (uint64_t)(w.w >> 12);
+    e[(int64_t)ndim * nl] = log_pos_normal(((double)kk + 0.5) * 0x1.0p-52);
+}
 __global__ __launch_bounds__(256) void metro_host_propose(const MetroHostArgs a)
 {
     const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;

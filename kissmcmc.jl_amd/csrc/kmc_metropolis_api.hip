@@ -30,14 +30,27 @@ MetropolisFn metropolis_fn(int density, int ndim)
     }
 }
 
+MetropolisTabledFn metropolis_tabled_fn(int density, int ndim)
+{
+    switch (density) {
+    case KMC_GAUSSIAN_ISO: return metropolis_tabled_gaussian_iso(ndim);
+    case KMC_EXPONENTIAL: return metropolis_tabled_exponential(ndim);
+    case KMC_ROSENBROCK: return metropolis_tabled_rosenbrock(ndim);
+    case KMC_LOGNORMAL: return metropolis_tabled_lognormal(ndim);
+    case KMC_MVNORMAL2: return metropolis_tabled_mvnormal2(ndim);
+    default: return nullptr;
+    }
+}
+
 int metropolis_nd(int64_t ndim) { return ndim <= 1 ? 1 : ndim <= 2 ? 2 : ndim <= 4 ? 4 : ndim <= 8 ? 8 : ndim <= 16 ? 16 : ndim <= 32 ? 32 : 0; }
 
 // runtime-compiled density: the Metropolis kernel (and the initial log-pdf kernel) for one register geometry
-kmc_status compile_user_metropolis(kmc_user_density* ud, int ND, const std::vector<char>** out, int64_t ndim = 0)
+// (TND > 0: also the few-chains kernel that reads its draws from a table, chains in registers -- body densities included)
+kmc_status compile_user_metropolis(kmc_user_density* ud, int ND, const std::vector<char>** out, int64_t ndim = 0, int TND = 0)
 {
     if (ud->is_body) ND = 0;                     // a body density: the chain-in-memory kernel (the proposal is collected per lane)
-    char key[48];
-    std::snprintf(key, sizeof(key), "M:%d:%lld", ND, ud->is_body ? (long long)ndim : 0ll);
+    char key[64];
+    std::snprintf(key, sizeof(key), "M:%d:%lld:%d", ND, ud->is_body ? (long long)ndim : 0ll, TND);
     std::lock_guard<std::mutex> lock(ud->mu);
     auto it = ud->code.find(key);
     if (it != ud->code.end()) { *out = &it->second; return KMC_OK; }
@@ -52,6 +65,9 @@ kmc_status compile_user_metropolis(kmc_user_density* ud, int ND, const std::vect
         << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_metropolis(const kmc::MetropolisArgs a) { ";
     if (ND > 0) src << "kmc::metropolis_chains_body<UD, " << ND << ">(a); }\n";
     else src << "kmc::metropolis_chains_any_body<UD>(a); }\n";
+    if (TND > 0)
+        src << "extern \"C\" __global__ __launch_bounds__(128) void kmc_user_metropolis_tabled(const kmc::MetropolisTabledArgs t) { "
+            << "kmc::metropolis_chains_tabled_body<UD, " << TND << ">(t.a, t.draws, t.nsteps); }\n";
     const std::string text = src.str();
     const char* headers[3] = {h_ker.c_str(), h_dev.c_str(), h_met.c_str()};
     const char* names[3] = {"kmc_kernels.hpp", "kmc_device.hpp", "kmc_metropolis.hpp"};
@@ -71,13 +87,14 @@ struct MetroBuffers {
     double *pos = nullptr, *logp = nullptr, *chain = nullptr, *chain_logp = nullptr, *csum = nullptr, *csumsq = nullptr,
            *step = nullptr, *xt = nullptr, *yt = nullptr, *st1 = nullptr, *st2 = nullptr, *blob = nullptr, *chain_blob = nullptr;
     uint32_t* naccept = nullptr;
+    double* draws = nullptr;          // few chains: the draw table of a launch (metro_draw_fill)
     hipModule_t mod = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     ~MetroBuffers()
     {
         (void)hipFree(pos); (void)hipFree(logp); (void)hipFree(chain); (void)hipFree(chain_logp); (void)hipFree(csum);
         (void)hipFree(csumsq); (void)hipFree(step); (void)hipFree(xt); (void)hipFree(yt); (void)hipFree(st1); (void)hipFree(st2);
-        (void)hipFree(naccept); (void)hipFree(blob); (void)hipFree(chain_blob);
+        (void)hipFree(naccept); (void)hipFree(blob); (void)hipFree(chain_blob); (void)hipFree(draws);
         if (mod) (void)hipModuleUnload(mod);
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
@@ -363,19 +380,43 @@ KMC_EXPORT kmc_status kmc_metropolis_run(const kmc_metropolis_config* c, const d
         }
     }
 
+    // Few chains (the reference's call is one): the draws of a stretch of iterations come from a wide kernel first, the chains
+    // only read them (kmc_metropolis.hpp: metropolis_chains_tabled).  Up to a wave per CU (measured: x6.8 at one chain, x4 at
+    // 4096, x2 at 16 384, x0.5 at 65 536 -- there the chains fill the chip themselves).  KMC_METRO_TABLE=0|1 forces it off / on.
+    bool tabled = false;
+    {
+        const char* e = std::getenv("KMC_METRO_TABLE");
+        const bool off = e && e[0] == '0', on = e && e[0] == '1';
+        tabled = !off && nd <= 8 && nblob == 0 && (nc <= 16384 || on);
+    }
     MetropolisFn fn = nullptr;
-    hipFunction_t ufn = nullptr, ulp = nullptr;
+    hipFunction_t ufn = nullptr, ulp = nullptr, utfn = nullptr;
     if (c->density == KMC_USER_DENSITY) {
         const std::vector<char>* code = nullptr;
-        KMC_TRY(compile_user_metropolis(static_cast<kmc_user_density*>(c->user_density), ND, &code, nd));
+        KMC_TRY(compile_user_metropolis(static_cast<kmc_user_density*>(c->user_density), ND, &code, nd, tabled ? metropolis_nd(nd) : 0));
         HIP_TRY(hipModuleLoadData(&b.mod, code->data()));
         HIP_TRY(hipModuleGetFunction(&ufn, b.mod, "kmc_user_metropolis"));
         HIP_TRY(hipModuleGetFunction(&ulp, b.mod, "kmc_user_logpdf"));
+        if (tabled) HIP_TRY(hipModuleGetFunction(&utfn, b.mod, "kmc_user_metropolis_tabled"));
     } else {
         fn = metropolis_fn(c->density, (int)std::min<int64_t>(nd, 1 << 20));    // the geometry follows ndim (registers <= 32)
         if (!fn) return fail(KMC_ERR_BAD_ARG, "unknown density id");
     }
     const unsigned grid = (unsigned)((nc + 255) / 256);
+    MetropolisTabledFn tfn = nullptr;
+    int64_t table_steps = 0;
+    if (tabled) {
+        if (c->density != KMC_USER_DENSITY) {
+            tfn = metropolis_tabled_fn(c->density, (int)nd);
+            if (!tfn) return fail(KMC_ERR_BAD_ARG, "unknown density id");
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(tfn), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kMetroTileBytes));
+        }
+        const int64_t per_step = nc * (nd + 1) * (int64_t)sizeof(double);
+        table_steps = std::max<int64_t>(64, std::min<int64_t>(1 << 16, ((int64_t)128 << 20) / per_step));
+        if (const char* ts = std::getenv("KMC_METRO_TABLE_STEPS")) table_steps = std::max<int64_t>(1, std::atoll(ts));   // (tests: seams)
+        table_steps = std::min<int64_t>(table_steps, std::max<int64_t>(c->niter, 1));
+        HIP_TRY(hipMalloc(&b.draws, (size_t)(table_steps * per_step)));
+    }
 
     // p0 = pdf(theta0)  (:70); unlike emcee the reference carries whatever comes out, -Inf included
     const LogpdfArgs la{b.pos, b.logp, nc, (int32_t)nd, (int32_t)nd, dp, b.blob};      // (and blob0, :70-72)
@@ -393,12 +434,12 @@ KMC_EXPORT kmc_status kmc_metropolis_run(const kmc_metropolis_config* c, const d
         hipLaunchKernelGGL(metropolis_transpose, dim3(grid), dim3(256), 0, st, ta);
         return hipGetLastError();
     };
-    if (ND == 0) HIP_TRY(transpose(b.pos, b.xt, true));
+    if (ND == 0 && !tabled) HIP_TRY(transpose(b.pos, b.xt, true));     // (the few-chains kernel keeps its chains in registers whatever the density)
 
     HIP_TRY(hipEventCreate(&b.ev0));
     HIP_TRY(hipEventCreate(&b.ev1));
     HIP_TRY(hipEventRecord(b.ev0, st));
-    constexpr int64_t kItersPerLaunch = 1 << 16;       // chains are independent: launches only bound a kernel's run time
+    const int64_t kItersPerLaunch = tabled ? table_steps : (int64_t)1 << 16;   // chains are independent: launches only bound a kernel's run time (and the table)
     for (int64_t it0 = 0; it0 < c->niter; it0 += kItersPerLaunch) {
         MetropolisArgs a{};
         a.pos = b.pos; a.logp = b.logp; a.naccept = b.naccept;
@@ -414,14 +455,29 @@ KMC_EXPORT kmc_status kmc_metropolis_run(const kmc_metropolis_config* c, const d
         a.seed_lo = (uint32_t)c->seed; a.seed_hi = (uint32_t)(c->seed >> 32);
         a.dp = dp;
         a.blob = b.blob; a.chain_blob = b.chain_blob;
-        if (ufn) HIP_TRY(launch_module(ufn, grid, 256u, st, a));
+        if (tabled) {
+            const int64_t nit = a.it1 - a.it0;
+            MetroDrawArgs da{};
+            da.out = b.draws; da.nchains = nc; da.it0 = it0; da.nsteps = (int32_t)nit; da.ndim = (int32_t)nd;
+            da.seed_lo = a.seed_lo; da.seed_hi = a.seed_hi;
+            hipLaunchKernelGGL(metro_draw_fill, dim3((unsigned)((nit * nc + 255) / 256)), dim3(256), 0, st, da);
+            HIP_TRY(hipGetLastError());
+            if (utfn) {
+                MetropolisTabledArgs ta{};
+                ta.a = a; ta.draws = b.draws; ta.nsteps = (int32_t)nit;
+                HIP_TRY(launch_module(utfn, (unsigned)((nc + 63) / 64), 128u, st, ta, 2u * kMetroTileBytes));
+            } else {
+                hipLaunchKernelGGL(tfn, dim3((unsigned)((nc + 63) / 64)), dim3(128), 2 * kMetroTileBytes, st, a, (const double*)b.draws, (int)nit);
+                HIP_TRY(hipGetLastError());
+            }
+        } else if (ufn) HIP_TRY(launch_module(ufn, grid, 256u, st, a));
         else {
             hipLaunchKernelGGL(fn, dim3(grid), dim3(256), 0, st, a);
             HIP_TRY(hipGetLastError());
         }
     }
     HIP_TRY(hipEventRecord(b.ev1, st));
-    if (ND == 0) {
+    if (ND == 0 && !tabled) {
         HIP_TRY(transpose(b.xt, b.pos, false));
         if (want_mom) { HIP_TRY(transpose(b.st1, b.csum, false)); HIP_TRY(transpose(b.st2, b.csumsq, false)); }
     }

@@ -14,6 +14,7 @@ using IslandFn = void (*)(const IslandArgs);
 using ResidentFn = void (*)(const ResidentArgs);
 using InitBallFn = void (*)(const InitBallArgs);
 using MetropolisFn = void (*)(const MetropolisArgs);
+using MetropolisTabledFn = void (*)(const MetropolisArgs, const double*, int);
 
 #ifdef KMC_TABLES_IMPL
 template <class D, int L, int K, int ITER, bool P2P, bool RAGGED, class T>
@@ -171,6 +172,16 @@ MetropolisFn metropolis_lookup(int ndim)
     if (ndim <= 32) return metropolis_chains<D, 32>;
     return metropolis_chains<D, 0>;
 }
+// few chains: the draws from a table (kmc_metropolis.hpp: metropolis_chains_tabled), chains in registers up to 8 dimensions
+template <class D>
+MetropolisTabledFn metropolis_tabled_lookup(int ndim)
+{
+    if (ndim <= 1) return metropolis_chains_tabled<D, 1>;
+    if (ndim <= 2) return metropolis_chains_tabled<D, 2>;
+    if (ndim <= 4) return metropolis_chains_tabled<D, 4>;
+    if (ndim <= 8) return metropolis_chains_tabled<D, 8>;
+    return nullptr;
+}
 #endif  // KMC_TABLES_IMPL
 
 // entry points per density: table_<density> (kmc_inst_<density>.hip: PART 0, the log-pdf and initial-ball kernels, and the
@@ -191,25 +202,30 @@ ResidentFn resident_gaussian_iso(int tpb, int K, bool ragged);
 ResidentFn resident_lane_gaussian_iso(int ndim, bool f32);
 InitBallFn init_ball_gaussian_iso();
 MetropolisFn metropolis_gaussian_iso(int ndim);
+MetropolisTabledFn metropolis_tabled_gaussian_iso(int ndim);
 IslandFn island_exponential(int S, int K, bool ragged);
 ResidentFn resident_exponential(int tpb, int K, bool ragged);
 ResidentFn resident_lane_exponential(int ndim, bool f32);
 InitBallFn init_ball_exponential();
 MetropolisFn metropolis_exponential(int ndim);
+MetropolisTabledFn metropolis_tabled_exponential(int ndim);
 IslandFn island_rosenbrock(int S, int K, bool ragged);
 ResidentFn resident_rosenbrock(int tpb, int K, bool ragged);
 ResidentFn resident_lane_rosenbrock(int ndim, bool f32);
 InitBallFn init_ball_rosenbrock();
 MetropolisFn metropolis_rosenbrock(int ndim);
+MetropolisTabledFn metropolis_tabled_rosenbrock(int ndim);
 IslandFn island_lognormal(int S, int K, bool ragged);
 ResidentFn resident_lognormal(int tpb, int K, bool ragged);
 ResidentFn resident_lane_lognormal(int ndim, bool f32);
 InitBallFn init_ball_lognormal();
 MetropolisFn metropolis_lognormal(int ndim);
+MetropolisTabledFn metropolis_tabled_lognormal(int ndim);
 IslandFn island_mvnormal2(int S, int K, bool ragged);
 ResidentFn resident_mvnormal2(int tpb, int K, bool ragged);
 ResidentFn resident_lane_mvnormal2(int ndim, bool f32);
 InitBallFn init_ball_mvnormal2();
 MetropolisFn metropolis_mvnormal2(int ndim);
+MetropolisTabledFn metropolis_tabled_mvnormal2(int ndim);
 
 }  // namespace kmc

@@ -24,8 +24,16 @@ def _pdf(kmc, z):
     return _DENS[z["density"]](kmc, z["params"])
 
 
+@pytest.fixture(params=["table", "kernel"])
+def draws(request, monkeypatch):
+    """Where the chains' draws are made: by a wide kernel first, read from a table (few chains: the default up to 16 384), or
+    in the chains' own loop (many chains).  Same stream, same results; the parity tests run both whatever the chain count."""
+    monkeypatch.setenv("KMC_METRO_TABLE", "1" if request.param == "table" else "0")
+    return request.param
+
+
 @pytest.mark.parametrize("name", golden_names())
-def test_kernel_reproduces_metropolis_golden(kmc, name):
+def test_kernel_reproduces_metropolis_golden(kmc, name, draws):
     from kissmcmc_jl_amd.metropolis import run_chains
     z = load_golden(name)
     r = run_chains(_pdf(kmc, z), kmc.GaussianStep(z["step"]), z["theta0"], z["niter"], z["nburnin"], z["nthin"], z["seed"],
@@ -35,7 +43,7 @@ def test_kernel_reproduces_metropolis_golden(kmc, name):
 
 
 @pytest.mark.parametrize("ndim", [1, 2, 3, 5, 8, 13, 16, 17, 32, 33, 40])
-def test_every_register_geometry_equals_the_oracle(kmc, oracle, ndim):
+def test_every_register_geometry_equals_the_oracle(kmc, oracle, ndim, draws):
     """ndim 1..32 run in registers (6 kernel geometries), beyond that from memory; odd sizes mask the tail."""
     from kissmcmc_jl_amd.metropolis import run_chains
     nc, niter, nburn, nthin, seed = 777, 70, 21, 3, 100 + ndim          # a ragged last workgroup
@@ -51,7 +59,7 @@ def test_every_register_geometry_equals_the_oracle(kmc, oracle, ndim):
     np.testing.assert_allclose(r["chain_sumsq"], ref["chain_sumsq"], rtol=1e-10, atol=1e-10)
 
 
-def test_long_run_is_cut_into_launches_without_a_seam(kmc, oracle):
+def test_long_run_is_cut_into_launches_without_a_seam(kmc, oracle, draws):
     """More iterations than one launch carries (65 536): thinning phase, sample slots and counters continue."""
     from kissmcmc_jl_amd.metropolis import run_chains
     nc, niter, nburn, nthin = 64, 140001, 30000, 7
@@ -100,7 +108,56 @@ def test_many_chains_recover_the_slow_reference_cases(kmc):
     refcases.check_mean_std(th.reshape(-1, 2), c, c["tolm"])
 
 
-def test_user_density_runs_in_the_metropolis_kernel(kmc, oracle):
+@pytest.mark.parametrize("nc,nd,niter,nburn,nthin", [(1, 1, 9000, 3000, 1), (1, 2, 5000, 1000, 3), (63, 3, 700, 100, 2), (64, 1, 4100, 0, 1),
+                                                     (65, 8, 300, 50, 1), (200, 5, 400, 399, 1), (1, 8, 2500, 2499, 1), (130, 2, 3, 1, 1)])
+def test_few_chains_read_their_draws_from_a_table(kmc, oracle, monkeypatch, nc, nd, niter, nburn, nthin):
+    """One chain is the reference's own call (src/samplers.jl:59-77): partial waves, tiles of the table that end inside a run
+    (an LDS tile is 32 KiB: 2048 steps of one 1-D chain, 3 steps of 64 8-D chains), tables shorter than the run (KMC_METRO_TABLE_STEPS),
+    all stored samples in burn-in -- against the oracle, and equal to the in-kernel draws to the last bit."""
+    from kissmcmc_jl_amd.metropolis import run_chains
+    th = 0.3 * np.random.default_rng(nc + nd).standard_normal((nc, nd))
+    step = np.linspace(0.4, 0.9, nd)
+    pdf = kmc.Rosenbrock(1.0, 100.0, 20.0) if nd >= 2 else kmc.GaussianIso(-1.0, 2.0)
+    did, params = (oracle.ROSENBROCK, [1.0, 100.0, 20.0]) if nd >= 2 else (oracle.GAUSSIAN_ISO, [-1.0, 2.0])
+    ref = oracle.metropolis(did, params, th, step, niter, nburn, nthin, 31)
+    got = {}
+    for mode, steps in (("1", None), ("1", "257"), ("0", None)):
+        monkeypatch.setenv("KMC_METRO_TABLE", mode)
+        if steps:
+            monkeypatch.setenv("KMC_METRO_TABLE_STEPS", steps)
+        else:
+            monkeypatch.delenv("KMC_METRO_TABLE_STEPS", raising=False)
+        r = run_chains(pdf, kmc.GaussianStep(step), th, niter, nburn, nthin, 31, moments=True)
+        np.testing.assert_array_equal(r["naccept"], ref["naccept"])
+        np.testing.assert_allclose(r["chain"], ref["chain"], rtol=1e-10, atol=1e-10)
+        np.testing.assert_allclose(r["chain_logp"], ref["chain_logp"], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(r["final_pos"], ref["final_pos"], rtol=1e-10, atol=1e-10)
+        np.testing.assert_allclose(r["chain_sum"], ref["chain_sum"], rtol=1e-9, atol=1e-9)
+        got[(mode, steps)] = r
+    for k in ("chain", "chain_logp", "final_pos", "final_logp", "naccept", "chain_sum", "chain_sumsq"):
+        np.testing.assert_array_equal(got[("1", None)][k], got[("0", None)][k], err_msg=k)
+        np.testing.assert_array_equal(got[("1", "257")][k], got[("0", None)][k], err_msg=k)
+
+
+def test_body_density_few_chains_run_in_registers(kmc, oracle, monkeypatch):
+    """A function-body density (CDensity) with the table: chains in registers instead of in memory; equal to the chain-in-memory
+    kernel and to the menu density it restates."""
+    from kissmcmc_jl_amd.metropolis import run_chains
+    body = "double s = 0; for (int i = 0; i < n; ++i) { double d = (x[i] - p[0]) * p[1]; s += d * d; } return -0.5 * s;"
+    th = np.random.default_rng(2).standard_normal((70, 3))
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("KMC_METRO_TABLE", mode)
+        out[mode] = run_chains(kmc.CDensity(body, params=[0.2, 1.0 / 1.5]), kmc.GaussianStep(0.8), th, 600, 200, 2, 9, moments=True)
+    menu = run_chains(kmc.GaussianIso(0.2, 1.5), kmc.GaussianStep(0.8), th, 600, 200, 2, 9, moments=True)
+    for k in ("naccept", "chain", "final_pos"):
+        np.testing.assert_array_equal(out["1"][k], out["0"][k], err_msg=k)
+    np.testing.assert_array_equal(out["1"]["naccept"], menu["naccept"])
+    np.testing.assert_allclose(out["1"]["chain"], menu["chain"], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(out["1"]["chain_sum"], out["0"]["chain_sum"], rtol=1e-12)
+
+
+def test_user_density_runs_in_the_metropolis_kernel(kmc, oracle, draws):
     """Runtime-compiled log-density (hiprtc) in the many-chain kernel = the menu Gaussian, bit for bit."""
     from kissmcmc_jl_amd.metropolis import run_chains
     th = np.random.default_rng(1).standard_normal((500, 3))
