@@ -211,6 +211,11 @@ int         kmc_device_count(void);
 /* hipMemGetInfo of a device (a caller deciding between a device-resident chain and KMC_STREAM_CHAIN; reference
  * src/samplers.jl:268-272 grows the chain without bound). */
 kmc_status  kmc_device_free_bytes(int device, uint64_t* free_bytes, uint64_t* total_bytes);
+/* Small device buffers of samplers are recycled through a per-device cache (blocks of up to 8 MiB, at most 128 MiB held;
+ * KMC_NO_ALLOC_CACHE=1 turns it off): a sampler of the reference's own sizes otherwise spends more time in hipMalloc / hipFree
+ * than sampling (the README call: 1.7 ms -> 1.0 ms).  This returns every block the cache holds to the device; kmc_device_free_bytes
+ * counts held blocks as free. */
+void        kmc_device_cache_release(void);
 const char* kmc_last_error(void);
 const char* kmc_status_string(kmc_status st);
 

@@ -458,7 +458,7 @@ kmc_status kmc_host::download_by_walker(const void* src, bool is_float, int64_t 
     if (wb < 1) wb = 1;
     if (wb > nl) wb = nl;
     double* tmp = nullptr;
-    HIP_TRY(hipMalloc((void**)&tmp, (size_t)wb * per_walker));
+    HIP_TRY(cache_alloc((void**)&tmp, (size_t)wb * per_walker));
     hipError_t e = hipSuccess;
     for (int64_t w0 = 0; w0 < nl && e == hipSuccess; w0 += wb) {
         const int64_t n = nl - w0 < wb ? nl - w0 : wb;
@@ -471,7 +471,8 @@ kmc_status kmc_host::download_by_walker(const void* src, bool is_float, int64_t 
         e = hipGetLastError();
         if (e == hipSuccess) e = copy_sync(dst_host + (size_t)w0 * (size_t)K * (size_t)width, tmp, (size_t)n * per_walker, hipMemcpyDeviceToHost, st);   // (waits: one scratch buffer)
     }
-    (void)hipFree(tmp);
+    if (e != hipSuccess) (void)hipStreamSynchronize(st);        // (every successful piece has waited already)
+    cache_free(tmp);
     HIP_TRY(e);
     return KMC_OK;
 }

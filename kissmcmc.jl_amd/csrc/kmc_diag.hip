@@ -78,7 +78,108 @@ void check_guards(kmc_sampler* s)
     }
     s->guards.clear();
 }
+// ---- the allocation cache (kmc_host.hpp) ----------------------------------------------------------------------------
+namespace {
+constexpr size_t kCacheMaxBlock = (size_t)8 << 20, kCacheCap = (size_t)128 << 20;
+struct DevCache {
+    std::map<size_t, std::vector<void*>> free_blocks;
+    size_t held = 0;
+};
+std::mutex g_cache_mu;
+std::map<int, DevCache> g_cache;                       // by device ordinal
+std::map<void*, std::pair<int, size_t>> g_cache_live;  // blocks handed out: device, rounded size
+bool cache_enabled()
+{
+    static const bool on = std::getenv("KMC_POISON") == nullptr && std::getenv("KMC_NO_ALLOC_CACHE") == nullptr;
+    return on;
+}
+}  // namespace
+
+hipError_t cache_alloc(void** p, size_t bytes)
+{
+    const size_t r = (bytes + 255) & ~(size_t)255;
+    if (!cache_enabled() || bytes == 0 || r > kCacheMaxBlock) {
+        const hipError_t e0 = hipMalloc(p, bytes);
+        if (e0 == hipSuccess && cache_enabled()) {      // (an address the cache once handed out and somebody gave to hipFree: forget it)
+            std::lock_guard<std::mutex> lock(g_cache_mu);
+            g_cache_live.erase(*p);
+        }
+        return e0;
+    }
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    {
+        std::lock_guard<std::mutex> lock(g_cache_mu);
+        DevCache& c = g_cache[dev];
+        auto it = c.free_blocks.find(r);
+        if (it != c.free_blocks.end() && !it->second.empty()) {
+            *p = it->second.back();
+            it->second.pop_back();
+            c.held -= r;
+            g_cache_live[*p] = {dev, r};
+            return hipSuccess;
+        }
+    }
+    e = hipMalloc(p, r);
+    if (e != hipSuccess) {                             // out of memory: give the cache back and try once more
+        (void)hipGetLastError();
+        kmc_device_cache_release();
+        e = hipMalloc(p, r);
+        if (e != hipSuccess) return e;
+    }
+    std::lock_guard<std::mutex> lock(g_cache_mu);
+    g_cache_live[*p] = {dev, r};
+    return hipSuccess;
+}
+
+void cache_free(void* p)
+{
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lock(g_cache_mu);
+        auto it = g_cache_live.find(p);
+        if (it != g_cache_live.end()) {
+            const int dev = it->second.first;
+            const size_t r = it->second.second;
+            g_cache_live.erase(it);
+            DevCache& c = g_cache[dev];
+            if (c.held + r <= kCacheCap) {
+                c.free_blocks[r].push_back(p);
+                c.held += r;
+                return;
+            }
+        }
+    }
+    (void)hipFree(p);
+}
+
+size_t cache_held_bytes(int device)
+{
+    std::lock_guard<std::mutex> lock(g_cache_mu);
+    auto it = g_cache.find(device);
+    return it == g_cache.end() ? 0 : it->second.held;
+}
+
 }  // namespace kmc_host
+
+// every block the allocation cache holds goes back to the device (all devices); the cache fills again as samplers come and go
+KMC_EXPORT void kmc_device_cache_release(void)
+{
+    std::map<int, kmc_host::DevCache> taken;
+    {
+        std::lock_guard<std::mutex> lock(kmc_host::g_cache_mu);
+        taken.swap(kmc_host::g_cache);
+    }
+    int cur = 0;
+    const bool have = hipGetDevice(&cur) == hipSuccess;
+    for (auto& d : taken) {
+        (void)hipSetDevice(d.first);
+        for (auto& b : d.second.free_blocks) for (void* p : b.second) (void)hipFree(p);
+    }
+    if (have) (void)hipSetDevice(cur);
+    (void)hipGetLastError();
+}
 
 // free / total bytes of a device's memory (hipMemGetInfo), for callers that decide between a device chain and a streamed one
 KMC_EXPORT kmc_status kmc_device_free_bytes(int device, uint64_t* free_bytes, uint64_t* total_bytes)
@@ -89,6 +190,7 @@ KMC_EXPORT kmc_status kmc_device_free_bytes(int device, uint64_t* free_bytes, ui
     HIP_TRY(hipSetDevice(device));
     size_t f = 0, t = 0;
     HIP_TRY(hipMemGetInfo(&f, &t));
+    f += kmc_host::cache_held_bytes(device);            // (blocks the allocation cache holds are the caller's to have)
     if (free_bytes) *free_bytes = (uint64_t)f;
     if (total_bytes) *total_bytes = (uint64_t)t;
     return KMC_OK;

@@ -104,6 +104,15 @@ hipError_t launch_module(hipFunction_t f, unsigned grid, unsigned tpb, hipStream
     return hipModuleLaunchKernel(f, grid, 1, 1, tpb, 1, 1, lds_bytes, st, nullptr, extra);
 }
 
+// Small device allocations, cached per device (kmc_diag.hip).  A sampler of the reference's own size lives for a millisecond or
+// two, and hipMalloc / hipFree of its dozen buffers were more than half of that (create 0.35 ms, destroy 0.85 ms of a 1.7 ms
+// README call): blocks of up to 8 MiB go back to a free list instead (at most 128 MiB held per device, exact rounded sizes, so
+// samplers of one shape reuse each other's blocks).  A block is handed back only after its owner has synchronised the streams that
+// touched it.  Off with KMC_POISON (guard bands) or KMC_NO_ALLOC_CACHE=1; kmc_device_cache_release() returns everything.
+hipError_t cache_alloc(void** p, size_t bytes);        // on the current device
+void cache_free(void* p);                              // nullptr is fine; pointers the cache did not hand out go to hipFree
+size_t cache_held_bytes(int device);
+
 // integrated autocorrelation time of a device-resident chain [nsamples][nwalkers][ndim] (kmc_acorr.hip)
 kmc_status int_acorr_check(int64_t nsamples, int64_t nwalkers, int64_t ndim, double c, const double* tau, const double* converged);
 kmc_status int_acorr_device(const double* chain_dev, int64_t nsamples, int64_t nwalkers, int64_t ndim, double c, double* tau, double* converged);

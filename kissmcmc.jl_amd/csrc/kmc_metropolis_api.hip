@@ -82,6 +82,9 @@ kmc_status compile_user_metropolis(kmc_user_density* ud, int ND, const std::vect
     return KMC_OK;
 }
 
+template <class T>
+hipError_t metro_alloc(T** p, size_t bytes) { return cache_alloc(reinterpret_cast<void**>(p), bytes); }
+
 // device buffers of one kmc_metropolis_run call
 struct MetroBuffers {
     double *pos = nullptr, *logp = nullptr, *chain = nullptr, *chain_logp = nullptr, *csum = nullptr, *csumsq = nullptr,
@@ -90,11 +93,13 @@ struct MetroBuffers {
     double* draws = nullptr;          // few chains: the draw table of a launch (metro_draw_fill)
     hipModule_t mod = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipStream_t stream = nullptr;     // the stream the buffers were used on: waited for before they go back to the allocation cache
     ~MetroBuffers()
     {
-        (void)hipFree(pos); (void)hipFree(logp); (void)hipFree(chain); (void)hipFree(chain_logp); (void)hipFree(csum);
-        (void)hipFree(csumsq); (void)hipFree(step); (void)hipFree(xt); (void)hipFree(yt); (void)hipFree(st1); (void)hipFree(st2);
-        (void)hipFree(naccept); (void)hipFree(blob); (void)hipFree(chain_blob); (void)hipFree(draws);
+        if (stream) (void)hipStreamSynchronize(stream);
+        cache_free(pos); cache_free(logp); cache_free(chain); cache_free(chain_logp); cache_free(csum);
+        cache_free(csumsq); cache_free(step); cache_free(xt); cache_free(yt); cache_free(st1); cache_free(st2);
+        cache_free(naccept); cache_free(blob); cache_free(chain_blob); cache_free(draws);
         if (mod) (void)hipModuleUnload(mod);
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
@@ -125,10 +130,12 @@ kmc_status metropolis_host_route(const kmc_metropolis_config* c, const double* t
         unsigned char *acc = nullptr, *h_acc = nullptr;
         hipModule_t mod = nullptr;
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        hipStream_t stream = nullptr;     // waited for before the buffers go back to the allocation cache
         ~Buf()
         {
-            (void)hipFree(pos); (void)hipFree(logp); (void)hipFree(prop); (void)hipFree(p1); (void)hipFree(chain); (void)hipFree(chain_logp);
-            (void)hipFree(csum); (void)hipFree(csumsq); (void)hipFree(step); (void)hipFree(naccept); (void)hipFree(acc);
+            if (stream) (void)hipStreamSynchronize(stream);
+            cache_free(pos); cache_free(logp); cache_free(prop); cache_free(p1); cache_free(chain); cache_free(chain_logp);
+            cache_free(csum); cache_free(csumsq); cache_free(step); cache_free(naccept); cache_free(acc);
             if (h_rows) (void)hipHostFree(h_rows);
             if (h_prop) (void)hipHostFree(h_prop);
             if (h_p1) (void)hipHostFree(h_p1);
@@ -138,24 +145,25 @@ kmc_status metropolis_host_route(const kmc_metropolis_config* c, const double* t
             if (ev1) (void)hipEventDestroy(ev1);
         }
     } b;
-    HIP_TRY(hipMalloc(&b.pos, rows));
-    HIP_TRY(hipMalloc(&b.prop, rows));
-    HIP_TRY(hipMalloc(&b.logp, vec));
-    HIP_TRY(hipMalloc(&b.p1, vec));
-    HIP_TRY(hipMalloc(&b.naccept, (size_t)nc * sizeof(uint32_t)));
+    b.stream = st;
+    HIP_TRY(metro_alloc(&b.pos, rows));
+    HIP_TRY(metro_alloc(&b.prop, rows));
+    HIP_TRY(metro_alloc(&b.logp, vec));
+    HIP_TRY(metro_alloc(&b.p1, vec));
+    HIP_TRY(metro_alloc(&b.naccept, (size_t)nc * sizeof(uint32_t)));
     HIP_TRY(fill_sync(b.naccept, 0, (size_t)nc * sizeof(uint32_t), st));
     HIP_TRY(copy_sync(b.pos, theta0, rows, hipMemcpyHostToDevice, st));                              // :68 deepcopy
     if (c->step) {
-        HIP_TRY(hipMalloc(&b.step, (size_t)nd * sizeof(double)));
+        HIP_TRY(metro_alloc(&b.step, (size_t)nd * sizeof(double)));
         HIP_TRY(copy_sync(b.step, c->step, (size_t)nd * sizeof(double), hipMemcpyHostToDevice, st));
     }
     if ((want_chain || want_logp) && nsamples > 0)
         KMC_TRY(check_device_room((size_t)nsamples * ((want_chain ? rows : 0) + (want_logp ? vec : 0)), "the Metropolis chain"));
-    if (want_chain && nsamples > 0) HIP_TRY(hipMalloc(&b.chain, (size_t)nsamples * rows));
-    if (want_logp && nsamples > 0) HIP_TRY(hipMalloc(&b.chain_logp, (size_t)nsamples * vec));
+    if (want_chain && nsamples > 0) HIP_TRY(metro_alloc(&b.chain, (size_t)nsamples * rows));
+    if (want_logp && nsamples > 0) HIP_TRY(metro_alloc(&b.chain_logp, (size_t)nsamples * vec));
     if (want_mom) {
-        HIP_TRY(hipMalloc(&b.csum, rows));
-        HIP_TRY(hipMalloc(&b.csumsq, rows));
+        HIP_TRY(metro_alloc(&b.csum, rows));
+        HIP_TRY(metro_alloc(&b.csumsq, rows));
         HIP_TRY(fill_sync(b.csum, 0, rows, st));
         HIP_TRY(fill_sync(b.csumsq, 0, rows, st));
     }
@@ -340,41 +348,42 @@ KMC_EXPORT kmc_status kmc_metropolis_run(const kmc_metropolis_config* c, const d
     HIP_TRY(ss.create());
     const hipStream_t st = ss.st;
     MetroBuffers b;
+    b.stream = st;
     const size_t rows = (size_t)nc * (size_t)nd * sizeof(double);
-    HIP_TRY(hipMalloc(&b.pos, rows));
-    HIP_TRY(hipMalloc(&b.logp, (size_t)nc * sizeof(double)));
-    HIP_TRY(hipMalloc(&b.naccept, (size_t)nc * sizeof(uint32_t)));
+    HIP_TRY(metro_alloc(&b.pos, rows));
+    HIP_TRY(metro_alloc(&b.logp, (size_t)nc * sizeof(double)));
+    HIP_TRY(metro_alloc(&b.naccept, (size_t)nc * sizeof(uint32_t)));
     HIP_TRY(fill_sync(b.naccept, 0, (size_t)nc * sizeof(uint32_t), st));
-    HIP_TRY(hipMalloc(&b.step, (size_t)nd * sizeof(double)));
+    HIP_TRY(metro_alloc(&b.step, (size_t)nd * sizeof(double)));
     HIP_TRY(copy_sync(b.step, c->step, (size_t)nd * sizeof(double), hipMemcpyHostToDevice, st));
     HIP_TRY(copy_sync(b.pos, theta0, rows, hipMemcpyHostToDevice, st));                              // :68 deepcopy
     if ((want_chain || want_logp) && nsamples > 0)
         KMC_TRY(check_device_room((size_t)nsamples * ((want_chain ? rows : 0) + (want_logp ? (size_t)nc * sizeof(double) : 0)), "the Metropolis chain"));
-    if (want_chain && nsamples > 0) HIP_TRY(hipMalloc(&b.chain, (size_t)nsamples * rows));
-    if (want_logp && nsamples > 0) HIP_TRY(hipMalloc(&b.chain_logp, (size_t)nsamples * (size_t)nc * sizeof(double)));
+    if (want_chain && nsamples > 0) HIP_TRY(metro_alloc(&b.chain, (size_t)nsamples * rows));
+    if (want_logp && nsamples > 0) HIP_TRY(metro_alloc(&b.chain_logp, (size_t)nsamples * (size_t)nc * sizeof(double)));
     if (want_mom) {
-        HIP_TRY(hipMalloc(&b.csum, rows));
-        HIP_TRY(hipMalloc(&b.csumsq, rows));
+        HIP_TRY(metro_alloc(&b.csum, rows));
+        HIP_TRY(metro_alloc(&b.csumsq, rows));
         HIP_TRY(fill_sync(b.csum, 0, rows, st));
         HIP_TRY(fill_sync(b.csumsq, 0, rows, st));
     }
     if (nblob > 0) {
         const size_t bb = (size_t)nc * (size_t)nblob * sizeof(double);
-        HIP_TRY(hipMalloc(&b.blob, bb));
+        HIP_TRY(metro_alloc(&b.blob, bb));
         HIP_TRY(fill_sync(b.blob, 0, bb, st));
         if (want_blobs && nsamples > 0) {
             KMC_TRY(check_device_room((size_t)nsamples * bb, "the stored blobs"));
-            HIP_TRY(hipMalloc(&b.chain_blob, (size_t)nsamples * bb));
+            HIP_TRY(metro_alloc(&b.chain_blob, (size_t)nsamples * bb));
         }
     }
     int ND = metropolis_nd(nd);
     if (c->density == KMC_USER_DENSITY && static_cast<const kmc_user_density*>(c->user_density)->is_body) ND = 0;   // body density: chain in memory
     if (ND == 0) {      // chains too long for registers (or a body density): state kept dimension-major in memory
-        HIP_TRY(hipMalloc(&b.xt, rows));
-        HIP_TRY(hipMalloc(&b.yt, rows));
+        HIP_TRY(metro_alloc(&b.xt, rows));
+        HIP_TRY(metro_alloc(&b.yt, rows));
         if (want_mom) {
-            HIP_TRY(hipMalloc(&b.st1, rows));
-            HIP_TRY(hipMalloc(&b.st2, rows));
+            HIP_TRY(metro_alloc(&b.st1, rows));
+            HIP_TRY(metro_alloc(&b.st2, rows));
             HIP_TRY(fill_sync(b.st1, 0, rows, st));
             HIP_TRY(fill_sync(b.st2, 0, rows, st));
         }
@@ -415,7 +424,7 @@ KMC_EXPORT kmc_status kmc_metropolis_run(const kmc_metropolis_config* c, const d
         table_steps = std::max<int64_t>(64, std::min<int64_t>(1 << 16, ((int64_t)128 << 20) / per_step));
         if (const char* ts = std::getenv("KMC_METRO_TABLE_STEPS")) table_steps = std::max<int64_t>(1, std::atoll(ts));   // (tests: seams)
         table_steps = std::min<int64_t>(table_steps, std::max<int64_t>(c->niter, 1));
-        HIP_TRY(hipMalloc(&b.draws, (size_t)(table_steps * per_step)));
+        HIP_TRY(metro_alloc(&b.draws, (size_t)(table_steps * per_step)));
     }
 
     // p0 = pdf(theta0)  (:70); unlike emcee the reference carries whatever comes out, -Inf included

@@ -348,7 +348,11 @@ template <class T>
 hipError_t dev_alloc(kmc_sampler* s, T** p, size_t bytes)
 {
     static const bool poison = std::getenv("KMC_POISON") != nullptr;
-    if (!poison || bytes == 0) return hipMalloc(reinterpret_cast<void**>(p), bytes);
+    if (!poison || bytes == 0) {
+        // (IPC-exported buffers stay plain allocations: a peer maps them by their base address)
+        if (s->cfg.flags & KMC_P2P) return hipMalloc(reinterpret_cast<void**>(p), bytes);
+        return cache_alloc(reinterpret_cast<void**>(p), bytes);
+    }
     hipError_t e = hipMalloc(reinterpret_cast<void**>(p), bytes + kGuardBytes);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(*p, 0xFF, bytes, s->stream);
@@ -704,9 +708,9 @@ KMC_EXPORT void kmc_sampler_destroy(kmc_sampler* s)
             if (s->peer_pos[r]) (void)hipIpcCloseMemHandle(s->peer_pos[r]);
             if (s->peer_flags[r]) (void)hipIpcCloseMemHandle(s->peer_flags[r]);
         }
-        (void)hipFree(s->d_flags);
-        (void)hipFree(s->d_err);
-        (void)hipFree(s->d_done);
+        cache_free(s->d_flags);
+        cache_free(s->d_err);
+        cache_free(s->d_done);
     }
     if (s->comm) { rccl_comm_destroy(s->comm); s->comm = nullptr; }
     if (s->copy_stream) { (void)hipStreamSynchronize(s->copy_stream); (void)hipStreamDestroy(s->copy_stream); }
@@ -715,32 +719,32 @@ KMC_EXPORT void kmc_sampler_destroy(kmc_sampler* s)
         if (s->ev_copied[i]) (void)hipEventDestroy(s->ev_copied[i]);
     }
     chain_unregister(s);
-    if (s->own_pos) (void)hipFree(s->d_pos);
-    (void)hipFree(s->d_logp);          // the {logp, naccept, klast} block
-    (void)hipFree(s->d_mring);
-    (void)hipFree(s->d_ids);
-    (void)hipFree(s->d_lazy);
-    (void)hipFree(s->d_mring_w);
-    (void)hipFree(s->d_mcnt);
-    (void)hipFree(s->d_gen);
-    (void)hipFree(s->d_sched);
-    (void)hipFree(s->d_chain);
-    (void)hipFree(s->bw_scratch);
-    (void)hipFree(s->bw_scratch_logp);
-    (void)hipFree(s->d_chain_logp);
-    (void)hipFree(s->d_blob);
-    (void)hipFree(s->d_chain_blob);
-    (void)hipFree(s->d_msum);
-    (void)hipFree(s->d_msumsq);
-    (void)hipFree(s->d_ring);
-    (void)hipFree(s->d_draws);
-    (void)hipFree(s->d_isum);
-    (void)hipFree(s->d_isumsq);
-    (void)hipFree(s->d_prop);
-    (void)hipFree(s->d_p1);
+    if (s->own_pos) cache_free(s->d_pos);
+    cache_free(s->d_logp);          // the {logp, naccept, klast} block
+    cache_free(s->d_mring);
+    cache_free(s->d_ids);
+    cache_free(s->d_lazy);
+    cache_free(s->d_mring_w);
+    cache_free(s->d_mcnt);
+    cache_free(s->d_gen);
+    cache_free(s->d_sched);
+    cache_free(s->d_chain);
+    cache_free(s->bw_scratch);
+    cache_free(s->bw_scratch_logp);
+    cache_free(s->d_chain_logp);
+    cache_free(s->d_blob);
+    cache_free(s->d_chain_blob);
+    cache_free(s->d_msum);
+    cache_free(s->d_msumsq);
+    cache_free(s->d_ring);
+    cache_free(s->d_draws);
+    cache_free(s->d_isum);
+    cache_free(s->d_isumsq);
+    cache_free(s->d_prop);
+    cache_free(s->d_p1);
     if (s->h_prop) (void)hipHostFree(s->h_prop);
     if (s->h_p1) (void)hipHostFree(s->h_p1);
-    (void)hipFree(s->d_acc);
+    cache_free(s->d_acc);
     if (s->h_acc) (void)hipHostFree(s->h_acc);
     for (int i = 0; i < kHostPieces; ++i) if (s->host_ev[i]) (void)hipEventDestroy(s->host_ev[i]);
     if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
@@ -779,7 +783,7 @@ KMC_EXPORT kmc_status kmc_sampler_bind_positions(kmc_sampler* s, void* pos_dev)
     if (s->own_pos) {
         for (size_t i = 0; i < s->guards.size(); ++i)                   // (KMC_POISON: this allocation's guard goes with it)
             if (s->guards[i].first - s->guards[i].second == reinterpret_cast<char*>(s->d_pos)) { s->guards.erase(s->guards.begin() + (long)i); break; }
-        (void)hipFree(s->d_pos);
+        cache_free(s->d_pos);
     }
     s->d_pos = static_cast<double*>(pos_dev);
     s->own_pos = false;

@@ -220,3 +220,40 @@ def test_samplers_give_their_device_memory_back(kmc):
         cycle()
     drift = base - free_bytes()
     assert abs(drift) <= 32 << 20, f"device memory drifted by {drift / 2 ** 20:.1f} MiB over three cycles"
+
+
+def test_small_buffers_are_recycled_and_can_be_released(kmc):
+    """The allocation cache (kmc_host.hpp: cache_alloc): samplers of one shape reuse each other's blocks -- what the device reports
+    free does not move between the second and the tenth sampler --, results do not depend on what a recycled block held, and
+    kmc_device_cache_release hands everything back."""
+    import ctypes as C
+    from kissmcmc_jl_amd import _lib
+    L = _lib.lib()
+
+    def raw_free():                                   # hipMemGetInfo itself, without the cache's blocks counted in
+        import torch
+        return torch.cuda.mem_get_info(0)[0]
+
+    def one(seed):
+        with kmc.Sampler(kmc.GaussianIso(), 100, 3, 200, 50, 1, 2.0, seed, store_chain=True, store_logp=True, moments=True) as s:
+            s.set_positions(np.random.default_rng(4).standard_normal((100, 3)))
+            s.run(200)
+            s.sync()
+            return s.positions(), s.chain()[0], s.moments()
+
+    first = one(5)
+    one(6)
+    f0 = raw_free()
+    for k in range(8):
+        one(7 + k)
+    assert abs(raw_free() - f0) <= 4 << 20, "same-shaped samplers should reuse cached blocks"
+    again = one(5)                                    # recycled blocks, dirty with other runs' data: same results
+    for a, b in zip(first, again):
+        if isinstance(a, tuple):
+            for x, y in zip(a, b):
+                np.testing.assert_array_equal(x, y)
+        else:
+            np.testing.assert_array_equal(a, b)
+    L.kmc_device_cache_release()
+    assert raw_free() >= f0, "released blocks go back to the device"
+    np.testing.assert_array_equal(one(5)[1], first[1])
