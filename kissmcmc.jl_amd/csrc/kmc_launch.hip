@@ -387,10 +387,10 @@ KMC_EXPORT kmc_status kmc_sampler_run(kmc_sampler* s, int64_t ngen)
     HIP_TRY(hipSetDevice(s->cfg.device));
     HIP_TRY(hipEventRecord(s->ev0, s->stream));
     if (s->resident) {
-        // the whole ensemble lives in one workgroup's LDS; a launch carries up to 4096 generations (1024 when a wide kernel
-        // computes the launch's draws first: draw_table_fill, kmc_islands.hpp)
+        // the whole ensemble lives in one workgroup's LDS; a launch carries up to 1024 generations, whose draws a wide kernel
+        // computes first (draw_table_fill, kmc_islands.hpp)
         while (ngen > 0) {
-            const int64_t n = std::min<int64_t>(ngen, s->d_draws ? kDrawTableGens : 4096);
+            const int64_t n = std::min<int64_t>(ngen, kDrawTableGens);
             ResidentArgs ra{};
             IslandArgs& ia = ra.is;
             ia.pos = s->d_pos; ia.logp = s->d_logp; ia.naccept = s->d_naccept;
@@ -405,7 +405,7 @@ KMC_EXPORT kmc_status kmc_sampler_run(kmc_sampler* s, int64_t ngen)
             ra.S = (int32_t)s->cfg.nwalkers;
             ra.chain = s->d_chain; ra.chain_logp = s->d_chain_logp;
             ra.blob = s->d_blob; ra.chain_blob = s->d_chain_blob;
-            if (s->d_draws) {
+            {                                    // (d_draws: allocated with every resident sampler)
                 DrawTableArgs ta{};
                 const int64_t npad = (n + kDrawBatch - 1) / kDrawBatch * kDrawBatch;      // whole batches (<= kDrawTableGens, a multiple)
                 ta.dc = ia.dc; ta.gen0 = s->generation; ta.ngen = (int32_t)npad; ta.S = ra.S; ta.out = s->d_draws;

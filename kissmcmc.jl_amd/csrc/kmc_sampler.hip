@@ -805,7 +805,7 @@ KMC_EXPORT kmc_status kmc_sampler_describe(const kmc_sampler* s, char* buf, int6
           << " generations per launch, rows 2 lanes x " << s->island_K << " chunks";
     else if (s->resident)
         o << "resident mode (exact): whole ensemble in one workgroup's LDS (" << s->resident_tpb
-          << " threads), up to " << (s->d_draws ? kDrawTableGens : (int64_t)4096) << " generations per launch, "
+          << " threads), up to " << kDrawTableGens << " generations per launch, "
           << (s->resident_lane ? std::string("one walker per thread") : "rows 2 lanes x " + std::to_string(s->island_K) + " chunks")
           << ", the launch's draws from a wide kernel before it";
     else if (s->host_eval)
