@@ -189,6 +189,31 @@ def test_resident_small_ensemble_kernel_is_the_same_sampler(kmc, oracle, name, n
     np.testing.assert_array_equal(res["naccept"], multi["naccept"])
 
 
+@pytest.mark.parametrize("name,nw,nd,G,nburn,nthin,pieces", [
+    ("expo", 100, 1, 2500, 1100, 7, None),                 # three launches (1024 generations each at most); burn-in ends inside the second
+    ("gauss", 300, 5, 2100, 1024, 3, (1, 1022, 3, 1074)),  # run() pieces that end one short of a launch / a batch of draws
+    ("gauss", 100, 20, 1500, 700, 5, (1023, 2, 475)),      # two lanes per walker
+    ("rosen", 64, 2, 3000, 0, 1000, (7, 2993)),            # no burn-in, thinning longer than a launch
+])
+def test_resident_runs_longer_than_a_launch_have_no_seam(kmc, oracle, name, nw, nd, G, nburn, nthin, pieces):
+    """A resident launch carries at most 1024 generations and its own table of draws (batches of four generations); the thinning
+    phase is carried, not recomputed.  Launch boundaries, run() calls and batch tails must not show: the oracle's uninterrupted run."""
+    pdf, did, params = _densities(kmc, oracle)[name]
+    th = _theta0(name, nw, nd, 9)
+    ref = oracle.emcee(oracle.make_config(did, params, nw, nd, G, nburn, nthin, 2.0, 77), th)
+    with kmc.Sampler(pdf, nw, nd, G, nburn, nthin, 2.0, 77, store_chain=True, store_logp=True, moments=True) as s:
+        assert "resident mode" in s.describe()
+        s.set_positions(th)
+        for n in (pieces or (G,)):
+            s.run(n)
+        s.sync()
+        assert s.generation == G
+        got = dict(final_pos=s.positions(), final_logp=s.logp(), naccept=s.naccept(), accept_ratio=s.accept_ratio())
+        got["chain"], got["chain_logp"] = s.chain()
+        got["sum"], got["sumsq"], got["nmoment"] = s.moments()
+    _compare(ref, got)
+
+
 def test_describe_reports_the_execution_mode(kmc):
     with kmc.Sampler(kmc.GaussianIso(), 65536, 32, 10) as s:
         assert "half_step_vec L=8 K=2 ITER=2 exact-size" in s.describe() and "hipGraph" in s.describe()
