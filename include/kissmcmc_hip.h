@@ -117,7 +117,7 @@ enum {
                                     host buffers are page-locked in place (hipHostRegister), so the copies are direct DMA into
                                     their final position; if that fails the copies are blocking and staged through the library's own page-locked
                                     buffers (the sampling then waits for them).  KMC_F64, one GPU
-                                    (no KMC_P2P / sharding / KMC_ISLANDS); small ensembles then run the multi-launch kernels.
+                                    (no KMC_P2P / sharding / KMC_ISLANDS); small ensembles stay in resident mode (their launches are cut to less than a block).
                                     kmc_emcee_run switches it on by itself when the chain would not fit the device. */
     KMC_CHAIN_BY_WALKER = 1u << 12, /* kmc_emcee_run and kmc_metropolis_run: kmc_outputs.chain is [nwalkers][nsamples][ndim] and chain_logp
                                     [nwalkers][nsamples] -- the reference's own order, thetas[w][k] (src/samplers.jl:219-221,

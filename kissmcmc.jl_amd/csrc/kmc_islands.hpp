@@ -30,19 +30,29 @@ constexpr int kIslandSizeDefault = 256;   // walkers per island (= threads per w
 // kernels at the reference's own sizes.  One division per launch instead.
 struct ThinClock {
     int64_t n, phase, q;
-    __device__ __forceinline__ ThinClock(int64_t gen0, int64_t nburnin, int64_t nthin)
+    int64_t ring, rs, rnext;                              // KMC_STREAM_CHAIN: the chain is a ring of `ring` slots; rs = (q - 1) mod ring at a hit
+    __device__ __forceinline__ ThinClock(int64_t gen0, int64_t nburnin, int64_t nthin, int64_t ring_slots = 0)
     {
         n = gen0 - nburnin;                               // the loop variable (:245) of the generation before the launch's first
         if (n > 0) { q = n / nthin; phase = n - q * nthin; } else { q = 0; phase = 0; }
+        ring = ring_slots; rs = 0;
+        rnext = ring_slots > 0 ? q % ring_slots : 0;
     }
     // on to the next generation: true when it is a thinning hit (its slot is q - 1; the caller compares with nsamples)
     __device__ __forceinline__ bool tick(int64_t nthin)
     {
         ++n;
         if (n <= 0) return false;
-        if (++phase == nthin) { phase = 0; ++q; return true; }
+        if (++phase == nthin) {
+            phase = 0; ++q;
+            rs = rnext;
+            if (++rnext == ring) rnext = 0;               // (ring == 0: never equal, rnext just counts)
+            return true;
+        }
         return false;
     }
+    // where the hit's sample goes in the chain buffer
+    __device__ __forceinline__ int64_t wslot() const { return ring > 0 ? rs : q - 1; }
 };
 
 struct IslandArgs {
@@ -230,6 +240,7 @@ struct ResidentArgs {
     double*       chain_logp;   // [nsamples][S] or nullptr
     double*       blob;         // body densities with blobs (resident_lane_body): [S][NB] current blobs, or nullptr
     double*       chain_blob;   //   [nsamples][S][NB] or nullptr
+    int64_t       ring_slots;   // KMC_STREAM_CHAIN: chain / chain_logp are rings of this many sample slots (0: one slot per sample)
     const double2* draws;       // the launch's draws, [ngen padded to kDrawBatch][S] x 32 B {z, (N-1) log z | log u, partner} from
                                 //   draw_table_fill
 };
@@ -316,12 +327,13 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& ra)
     Draw nxt{};
     if (a.ngen > 0) nxt = draw_table_load(ra.draws, ownA);
 
-    ThinClock clk(a.gen0, a.nburnin, a.nthin);
+    ThinClock clk(a.gen0, a.nburnin, a.nthin, ra.ring_slots);
     for (int gg = 0; gg < a.ngen; ++gg) {
         const bool hit = clk.tick(a.nthin);               // clk.n: the reference's loop variable (:245)
         const bool count = clk.n > 0;
         const int64_t slot = clk.q - 1;
         const bool sample = hit && slot < a.nsamples;                                            // :268
+        const int64_t wslot = clk.wslot();                // (the slot itself, or its place in the streamed chain's ring)
         const Draw drA = nxt;                             // row (step, walker ownA) of the table: keyed by the walker index
         nxt = draw_table_load(ra.draws, (int64_t)(gg + 1 < a.ngen ? gg + 1 : gg) * S + ownA);
         const double p0A = llogp[ownA];
@@ -370,11 +382,11 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& ra)
         if (sample && (ra.chain != nullptr || ra.chain_logp != nullptr)) {       // :268-271
             if (t < S) {
                 if (ra.chain != nullptr) {
-                    double2* dst = reinterpret_cast<double2*>(ra.chain + (slot * S + t) * (int64_t)a.ld);
+                    double2* dst = reinterpret_cast<double2*>(ra.chain + (wslot * S + t) * (int64_t)a.ld);
                     const double2* src2 = reinterpret_cast<const double2*>(lpos + t * lld);
                     for (int c = 0; c < ld / 2; ++c) dst[c] = src2[(c & 1) * (K + 1) + (c >> 1)];
                 }
-                if (ra.chain_logp != nullptr) ra.chain_logp[slot * S + t] = llogp[t];
+                if (ra.chain_logp != nullptr) ra.chain_logp[wslot * S + t] = llogp[t];
             }
             // rows are only read here; the next generation's first writes come after its own barrier-free
             // reads, by other threads -> order them
@@ -477,7 +489,7 @@ __device__ __forceinline__ void resident_lane_body(const ResidentArgs& ra)
         for (int u = 0; u < B; ++u) nxt[u] = draw_table_load(ra.draws, (int64_t)u * S + tl);
     }
 
-    ThinClock clk(a.gen0, a.nburnin, a.nthin);
+    ThinClock clk(a.gen0, a.nburnin, a.nthin, ra.ring_slots);
 #pragma unroll 1
     for (int b = 0; b < nb; ++b) {
 #pragma unroll
@@ -495,6 +507,7 @@ __device__ __forceinline__ void resident_lane_body(const ResidentArgs& ra)
         const bool count = clk.n > 0;
         const int64_t slot = clk.q - 1;
         const bool sample = hit && slot < a.nsamples;                                            // :268
+        const int64_t wslot = clk.wslot();                // (the slot itself, or its place in the streamed chain's ring)
         const Draw dr = cur[sub];                                                                // :250, :252
 #pragma unroll 1
         for (int half = 0; half < 2; ++half) {
@@ -527,12 +540,12 @@ __device__ __forceinline__ void resident_lane_body(const ResidentArgs& ra)
         }
         if (sample && live) {                             // the walker's state after its update (:268-271); own row, own thread
             if (ra.chain != nullptr) {
-                T* dst = reinterpret_cast<T*>(ra.chain) + (slot * S + t) * (int64_t)a.ld;
+                T* dst = reinterpret_cast<T*>(ra.chain) + (wslot * S + t) * (int64_t)a.ld;
 #pragma unroll
                 for (int d = 0; d < ND; ++d) if (d < ndim) dst[d] = (T)lpos[t * LS + d];
                 if (a.ld > ndim) dst[ndim] = (T)0;                              // the pad column of an odd ndim
             }
-            if (ra.chain_logp != nullptr) ra.chain_logp[slot * S + t] = llogp[t];
+            if (ra.chain_logp != nullptr) ra.chain_logp[wslot * S + t] = llogp[t];
             if constexpr (BlobTrait<Dens>::n > 0) {
                 if (ra.chain_blob != nullptr) {
 #pragma unroll 1

@@ -390,7 +390,9 @@ KMC_EXPORT kmc_status kmc_sampler_run(kmc_sampler* s, int64_t ngen)
         // the whole ensemble lives in one workgroup's LDS; a launch carries up to 1024 generations, whose draws a wide kernel
         // computes first (draw_table_fill, kmc_islands.hpp)
         while (ngen > 0) {
-            const int64_t n = std::min<int64_t>(ngen, kDrawTableGens);
+            int64_t n = std::min<int64_t>(ngen, kDrawTableGens);
+            if (s->stream_chain) n = std::min<int64_t>(n, std::max<int64_t>(1, (s->ring_blk - 1) * s->cfg.nthin));   // a launch fills less than a block of the ring
+            KMC_TRY(chain_before(s, s->generation + n));
             ResidentArgs ra{};
             IslandArgs& ia = ra.is;
             ia.pos = s->d_pos; ia.logp = s->d_logp; ia.naccept = s->d_naccept;
@@ -405,6 +407,7 @@ KMC_EXPORT kmc_status kmc_sampler_run(kmc_sampler* s, int64_t ngen)
             ra.S = (int32_t)s->cfg.nwalkers;
             ra.chain = s->d_chain; ra.chain_logp = s->d_chain_logp;
             ra.blob = s->d_blob; ra.chain_blob = s->d_chain_blob;
+            ra.ring_slots = s->stream_chain ? s->ring_slots : 0;
             {                                    // (d_draws: allocated with every resident sampler)
                 DrawTableArgs ta{};
                 const int64_t npad = (n + kDrawBatch - 1) / kDrawBatch * kDrawBatch;      // whole batches (<= kDrawTableGens, a multiple)
@@ -423,6 +426,7 @@ KMC_EXPORT kmc_status kmc_sampler_run(kmc_sampler* s, int64_t ngen)
             s->generation += n;
             s->launches += 1;
             ngen -= n;
+            KMC_TRY(chain_after(s));
         }
         HIP_TRY(hipEventRecord(s->ev1, s->stream));
         s->have_run_events = true;

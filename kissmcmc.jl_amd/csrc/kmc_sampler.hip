@@ -402,7 +402,7 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         if (expr_lane) rlds = ((size_t)cfg->nwalkers * (size_t)((lane_nd(cfg->ndim) | 1) + 1)) * sizeof(double);
         // (float rows: the one-walker-per-thread kernels only -- their LDS rows are double either way)
         if ((!s->f32 || s->user->is_body || expr_lane) && cfg->nwalkers <= ((s->user->is_body || expr_lane) ? 1024 : 256) && cfg->ndim <= 32 && s->cfg.shard_count == 1 && !(s->user->is_body && cfg->deal_count > 0) &&
-            !(cfg->flags & (KMC_P2P | KMC_NO_GRAPH | KMC_ISLANDS | KMC_STREAM_CHAIN)) &&
+            !(cfg->flags & (KMC_P2P | KMC_NO_GRAPH | KMC_ISLANDS)) &&
             rlds <= 60 * 1024 && std::getenv("KMC_NO_RESIDENT") == nullptr)
             rK = rK0;
         int iS = 0;
@@ -459,7 +459,7 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         if (ea != hipSuccess) { (void)hipGetLastError(); kmc_sampler_destroy(s); return fail(KMC_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(ea)); }
     }
     if (!s->islands && cfg->density != KMC_USER_DENSITY && !s->host_eval && cfg->nwalkers <= 1024 && cfg->ndim <= 32 &&
-        s->cfg.shard_count == 1 && !(cfg->flags & (KMC_P2P | KMC_NO_GRAPH | KMC_STREAM_CHAIN)) && std::getenv("KMC_NO_RESIDENT") == nullptr) {
+        s->cfg.shard_count == 1 && !(cfg->flags & (KMC_P2P | KMC_NO_GRAPH)) && std::getenv("KMC_NO_RESIDENT") == nullptr) {
         const int64_t chunks = s->ld / 2;
         int K = 1;
         while (2 * K < chunks) K *= 2;
@@ -615,7 +615,7 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         // 56 GB/s this link copies alone; many small blocks cost more at the block boundaries than their earlier start
         // returns -- nthin = 100: +19 % on the loop with 64 MiB blocks, +6 % with 512 MiB; KMC_CHAIN_BLOCK = samples per block, for tests)
         if (const char* e = std::getenv("KMC_UPD_CHUNK")) { const long v = std::atol(e); if (v >= 16 && v <= 1024) s->uchunk = v; }
-        const int64_t unit = std::max<int64_t>(kGraphChunk, s->uchunk);
+        const int64_t unit = s->resident ? 1 : std::max<int64_t>(kGraphChunk, s->uchunk);     // (a resident launch is cut to the block: kmc_sampler_run)
         const int64_t per_unit = (unit + cfg->nthin - 1) / cfg->nthin + 1;
         const size_t sample_bytes = (size_t)s->nlocal * ldz * sizeof(double);
         int64_t blk = (int64_t)(((size_t)512 << 20) / sample_bytes);

@@ -47,10 +47,15 @@ def test_streamed_chain_equals_oracle_over_three_ring_laps(kmc, oracle, monkeypa
 @pytest.mark.parametrize("case", ["thin3_odd_ndim", "pieces_with_syncs", "eager_launches", "logp_only", "chain_only", "rosen_draw_ring",
                                   "small_ensemble", "unregistered_destination"])
 @pytest.mark.parametrize("by_walker", [False, True], ids=["sample-major", "by-walker"])
-def test_streamed_chain_variants(kmc, oracle, monkeypatch, case, by_walker):
+@pytest.mark.parametrize("resident", [True, False], ids=["resident-where-it-fits", "multi-launch"])
+def test_streamed_chain_variants(kmc, oracle, monkeypatch, case, by_walker, resident):
     """by-walker: KMC_STREAM_CHAIN | KMC_CHAIN_BY_WALKER -- completed blocks are written by a kernel of the copy stream
-    into host arrays laid out [walker][nsamples][ndim] (the reference's thetas[w][k])."""
+    into host arrays laid out [walker][nsamples][ndim] (the reference's thetas[w][k]).  Ensembles of up to 1024 walkers run in
+    resident mode (launches cut to less than a block of the ring, ring positions carried by the kernel); KMC_NO_RESIDENT keeps
+    the same jobs on the multi-launch kernels."""
     monkeypatch.setenv("KMC_CHAIN_BLOCK", "1")
+    if not resident:
+        monkeypatch.setenv("KMC_NO_RESIDENT", "1")
     pdf, did, params, nw, nd, G, nburn, nthin, scale = kmc.GaussianIso(), oracle.GAUSSIAN_ISO, [0.0, 1.0], 1024, 8, 500, 37, 1, 1.0
     kw = dict(store_chain=True, store_logp=True)
     if case == "thin3_odd_ndim":
@@ -64,7 +69,7 @@ def test_streamed_chain_variants(kmc, oracle, monkeypatch, case, by_walker):
     elif case == "rosen_draw_ring":
         pdf, did, params, nd, scale = kmc.Rosenbrock(), oracle.ROSENBROCK, [1.0, 100.0, 20.0], 64, 0.1
     elif case == "small_ensemble":
-        nw, nd = 100, 2                                  # would run in resident mode; streamed: multi-launch kernels
+        nw, nd = 100, 2                                  # the reference's own size
     elif case == "unregistered_destination":
         monkeypatch.setenv("KMC_NO_HOST_REGISTER", "1")  # staged copies instead of DMA into page-locked arrays
     th = scale * np.random.default_rng(2).standard_normal((nw, nd))
@@ -72,6 +77,10 @@ def test_streamed_chain_variants(kmc, oracle, monkeypatch, case, by_walker):
     # (by walker into arrays that cannot be page-locked -- a container's RLIMIT_MEMLOCK is enough: the transposed blocks come
     #  through the library's bounce buffers and are put in place by the host; never refused, kmc_emcee_run relies on it)
     with kmc.Sampler(pdf, nw, nd, G, nburn, nthin, 2.0, seed, stream_chain=True, chain_by_walker=by_walker, **kw) as s:
+        if resident and nd <= 32 and kw.get("use_graph", True):
+            assert "resident mode" in s.describe() and "streamed" in s.describe(), s.describe()
+        else:
+            assert "resident" not in s.describe(), s.describe()
         s.set_positions(th)
         if case == "pieces_with_syncs":
             for n in (50, 1, 130, 64, 200, G - 445):      # syncs inside blocks: partial flush, then the whole block again
@@ -223,3 +232,22 @@ def test_chain_larger_than_the_device_is_an_error_not_a_crash(kmc):
         s.run(20)
         s.sync()
         assert s.chain(logp=False)[0].shape == (20, 256, 4)
+
+
+def test_small_ensemble_streams_a_long_chain_from_resident_mode(kmc, oracle):
+    """The reference's own size with the default block (4096 samples): launches of 1024 generations, several laps of the ring,
+    thinning -- equal to the oracle, and about as fast as the unstreamed resident run."""
+    nw, nd, G, nburn, nthin, seed = 100, 1, 40000, 1000, 2, 3
+    th = 0.5 + 0.1 * np.abs(np.random.default_rng(8).standard_normal((nw, nd)))
+    with kmc.Sampler(kmc.Exponential(1.0), nw, nd, G, nburn, nthin, 2.0, seed, store_chain=True, store_logp=True, stream_chain=True) as s:
+        assert "resident mode" in s.describe()
+        s.set_positions(th)
+        s.run(G)
+        s.sync()
+        chain, clogp = s.chain()
+        assert s.launch_count <= 2 * (G // 1024 + 1)
+        ms = s.last_run_ms()
+    ref = _oracle_chain(oracle, oracle.EXPONENTIAL, [1.0], th, G, nburn, nthin, seed)
+    assert chain.shape[0] == (G - nburn) // nthin > 3 * 4096
+    _equal(chain, clogp, ref)
+    assert ms < 2 * G * 1.0e-3, f"{ms:.1f} ms for {G} generations: not the resident kernel's speed"       # (< 1 us per half-step; 0.22 measured)
