@@ -240,7 +240,7 @@ kmc_status  kmc_user_density_create(const char* term_expr, const char* pair_expr
  *     double logpdf(const double* x, int n, const double* p) { BODY }
  * over the whole proposal x[0..n-1] (n = ndim, p = params[0..5]); any coupling between the dimensions, loops, locals;
  * return -INFINITY to reject.  Runs in the one-walker-per-lane kernels (the proposal is collected per lane, ndim <= 1024;
- * for double rows of ndim <= 64 the rows are staged through LDS so that memory is still read in whole rows):
+ * for double rows of ndim <= 256 the rows are staged through LDS so that memory is still read in whole rows):
  * emcee (multi-launch), initial log-pdfs, kmc_sampler_init_ball, many-chain Metropolis -- slower than a menu or term / pair
  * density of the same form (those stripe a row over lanes), far faster than a host callback.  Not with KMC_ISLANDS; under KMC_P2P the unstaged kernel. */
 kmc_status  kmc_user_density_create_body(const char* body, kmc_user_density** out);

@@ -1066,8 +1066,10 @@ __global__ __launch_bounds__(256) void half_step_generic(KMC_FRONT_PARAMS, const
 // draws, same arithmetic and element order as half_step_generic (results identical); double rows, one GPU.
 // ------------------------------------------------------------------------------------------
 constexpr int kStagedTPB = 128;                                          // two waves per workgroup, one LDS tile each
-constexpr int kStagedMaxDim = 64;                                        // two rows + the proposal per lane stay in registers
+constexpr int kStagedMaxDim = 256;                                       // up to 64: two rows + the proposal per lane in registers; beyond: in scratch (spilled)
 __host__ __device__ constexpr int staged_tile_doubles(int nd) { return nd + (nd & 1) < 32 ? nd + (nd & 1) : 32; }
+// the staged kernel's moment accumulators are rows [wave][ld] (true) or per-lane columns [d][tid] like half_step_generic's (false)
+__host__ __device__ constexpr bool staged_tile_moments(int nd) { return 64 % (staged_tile_doubles(nd) / 2) == 0; }
 __host__ __device__ constexpr size_t staged_lds_bytes(int nd) { return (size_t)(kStagedTPB / 64) * 64 * (size_t)(staged_tile_doubles(nd) + 1) * sizeof(double); }
 
 template <class Dens, int ND>
@@ -1091,43 +1093,77 @@ __device__ __forceinline__ void half_step_staged_body(const HalfStepFront& f, co
     const bool count  = (sch.flags & kCount) != 0;
     const bool sample = (sch.flags & kSample) != 0;
     const int64_t gw = a.own_row0 + ic;
-    const Draw dr = draw_step(a.dc, step, (uint64_t)(a.gw0 + ic));
-    const double p0 = a.logp[gw];
     const int rows_here = nact - w0 < 64 ? nact - w0 : 64;
 
-    // row r of the tile <- piece [c0, c0 + TD) of global row `grow(r)`; lane q handles chunk q % CPR of tile row q / CPR.
-    // All of a piece's loads are issued before the first LDS write (a chunk beyond the row's end re-reads the last one
-    // and lands in tile columns nobody reads), so that a wave has CPR loads in flight rather than one.
-    double xc[LD], xo[LD];
-    auto fetch = [&](auto grow, double (&dst)[LD]) {
+    // Row r of a tile <- piece [c0, c0 + TD) of a global row; lane q handles chunk q % CPR of tile row q / CPR (a chunk beyond
+    // the row's end re-reads the last one and lands in tile columns nobody reads).  ALL the loads of the wave go out before
+    // anything waits: the own rows at once (they do not depend on the draw), the partner rows as soon as Philox has given the
+    // partner indices, the two logarithms of the draw while they fly -- then the pieces are transposed through LDS.  (Measured
+    // at 65 536 x 32: worth 2 % against loading and transposing piece by piece -- a wave here is ~2000 instructions for its 64
+    // walkers with one wave per SIMD, so it is instruction issue, not the memory round trips, that bounds this kernel.)
+    // Beyond 64 dimensions the pieces go one at a time (own and partner piece of a tile together): the staging registers of a whole
+    // row pair would spill, and the rows themselves already live in scratch there (the compiler's spill of xc / xo -- lane-
+    // interleaved private memory, still far better than the generic kernel's element-wise loads of 64 different rows).
+    constexpr bool kAllAtOnce = ND <= 64;
+    auto issue_tile = [&](auto grow, int t, double2 (&v)[CPR]) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int c0 = t * TD;
-            double2 v[CPR];
-#pragma unroll
-            for (int i = 0; i < CPR; ++i) {
-                const int q = i * 64 + lane, r = q / CPR, ch = q - r * CPR;
-                const int col = c0 + 2 * ch < LD ? c0 + 2 * ch : LD - 2;
-                v[i] = *reinterpret_cast<const double2*>(a.pos + grow(r) * (int64_t)LD + col);
-            }
-#pragma unroll
-            for (int i = 0; i < CPR; ++i) {
-                const int q = i * 64 + lane, r = q / CPR, ch = q - r * CPR;
-                tile[r * (TD + 1) + 2 * ch] = v[i].x;
-                tile[r * (TD + 1) + 2 * ch + 1] = v[i].y;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-            for (int e = 0; e < TD; ++e)
-                if (c0 + e < LD) dst[c0 + e] = tile[lane * (TD + 1) + e];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+        for (int i = 0; i < CPR; ++i) {
+            const int q = i * 64 + lane, r = q / CPR, ch = q - r * CPR;
+            const int col = t * TD + 2 * ch < LD ? t * TD + 2 * ch : LD - 2;
+            v[i] = *reinterpret_cast<const double2*>(a.pos + grow(r) * (int64_t)LD + col);
         }
     };
-    fetch([&](int r) { return a.own_row0 + w0 + (r < rows_here ? r : rows_here - 1); }, xc);
-    fetch([&](int r) { return a.oth_row0 + (int64_t)(uint32_t)__shfl((int)dr.partner, r); }, xo);
+    double xc[LD], xo[LD];
+    auto land_tile = [&](const double2 (&v)[CPR], int t, double (&dst)[LD]) {
+        const int c0 = t * TD;
+#pragma unroll
+        for (int i = 0; i < CPR; ++i) {
+            const int q = i * 64 + lane, r = q / CPR, ch = q - r * CPR;
+            tile[r * (TD + 1) + 2 * ch] = v[i].x;
+            tile[r * (TD + 1) + 2 * ch + 1] = v[i].y;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int e = 0; e < TD; ++e)
+            if (c0 + e < LD) dst[c0 + e] = tile[lane * (TD + 1) + e];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto own_row = [&](int r) { return a.own_row0 + w0 + (r < rows_here ? r : rows_here - 1); };
+    Draw dr;
+    double p0;
+    if constexpr (kAllAtOnce) {
+        double2 vown[NT][CPR], voth[NT][CPR];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) issue_tile(own_row, t, vown[t]);
+        p0 = a.logp[gw];
+        const U4 bits = draw_bits(a.dc, step, (uint64_t)(a.gw0 + ic));
+        const uint32_t partner = draw_partner(a.dc, bits);              // :250
+        auto oth_row = [&](int r) { return a.oth_row0 + (int64_t)(uint32_t)__shfl((int)partner, r); };
+#pragma unroll
+        for (int t = 0; t < NT; ++t) issue_tile(oth_row, t, voth[t]);
+        dr = draw_finish(a.dc, bits);                                   // :252, and the accept test's logarithms
+#pragma unroll
+        for (int t = 0; t < NT; ++t) land_tile(vown[t], t, xc);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) land_tile(voth[t], t, xo);
+    } else {
+        p0 = a.logp[gw];
+        const U4 bits = draw_bits(a.dc, step, (uint64_t)(a.gw0 + ic));
+        const uint32_t partner = draw_partner(a.dc, bits);              // :250
+        auto oth_row = [&](int r) { return a.oth_row0 + (int64_t)(uint32_t)__shfl((int)partner, r); };
+        dr = draw_finish(a.dc, bits);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            double2 vown[CPR], voth[CPR];
+            issue_tile(own_row, t, vown);
+            issue_tile(oth_row, t, voth);
+            land_tile(vown, t, xc);
+            land_tile(voth, t, xo);
+        }
+    }
 
     typename Dens::Seq q;
     Dens::seq_init(q);
@@ -1136,7 +1172,13 @@ __device__ __forceinline__ void half_step_staged_body(const HalfStepFront& f, co
     const double p1 = Dens::seq_finish(q, ND, a.dp);                    // :257
     const bool acc = valid && accept_test(dr, p1, p0);                  // :260
 
-    const bool do_mom = valid && sample && a.msum != nullptr;
+    // Streaming moments.  When a lane keeps the same chunk of the row through the cooperative write-out below (CPR divides 64),
+    // the sums are taken there: a lane adds the chunk's two elements of its 64 / CPR rows, the lanes that share a chunk fold, and
+    // the wave updates ONE contiguous accumulator row [wave][LD] (staged_tile_moments(): the read-out knows) -- instead of every
+    // lane reading and writing all ND of its own, which doubled the kernel's traffic and was a third of its instructions.
+    constexpr bool kTileMoments = staged_tile_moments(ND);
+    const bool mom_wave = sample && a.msum != nullptr;                  // (uniform)
+    const bool do_mom = !kTileMoments && valid && mom_wave;
     const bool do_chain = sample && a.chain != nullptr;
     const int64_t crow = sch.slot * a.chain_rows + a.chain_row0;        // chain row of this launch's active walker 0
     if (do_mom) {                                                       // per-lane accumulators, eight dimensions' loads in flight
@@ -1158,7 +1200,7 @@ __device__ __forceinline__ void half_step_staged_body(const HalfStepFront& f, co
     }
     // rows out: through the tile again, so that the stores are 16 B per lane on consecutive chunks (:261, :269)
     const unsigned long long accmask = __ballot(acc);
-    if (accmask != 0ull || do_chain) {
+    if (accmask != 0ull || do_chain || (kTileMoments && mom_wave)) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int c0 = t * TD;
@@ -1169,6 +1211,7 @@ __device__ __forceinline__ void half_step_staged_body(const HalfStepFront& f, co
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            double2 ms = make_double2(0.0, 0.0), mq = make_double2(0.0, 0.0);
 #pragma unroll
             for (int q0 = 0; q0 < 64 * CPR; q0 += 64) {
                 const int qq = q0 + lane, r = qq / CPR, ch = qq - r * CPR;
@@ -1178,6 +1221,23 @@ __device__ __forceinline__ void half_step_staged_body(const HalfStepFront& f, co
                         *reinterpret_cast<double2*>(a.pos + (a.own_row0 + w0 + r) * (int64_t)LD + c0 + 2 * ch) = v;
                     if (do_chain)
                         *reinterpret_cast<double2*>(a.chain + (crow + w0 + r) * (int64_t)LD + c0 + 2 * ch) = v;
+                    if constexpr (kTileMoments) { ms.x += v.x; ms.y += v.y; mq.x += v.x * v.x; mq.y += v.y * v.y; }
+                }
+            }
+            if constexpr (kTileMoments) {
+                if (mom_wave) {                                         // lane l holds chunk l % CPR in every pass above
+#pragma unroll
+                    for (int off = CPR; off < 64; off <<= 1) {
+                        ms.x += __shfl_xor(ms.x, off); ms.y += __shfl_xor(ms.y, off);
+                        mq.x += __shfl_xor(mq.x, off); mq.y += __shfl_xor(mq.y, off);
+                    }
+                    if (lane < CPR && c0 + 2 * lane < LD) {             // (the pad column of an odd ndim sums zeros)
+                        double2* s1 = reinterpret_cast<double2*>(a.msum + (int64_t)(tid >> 6) * LD + c0) + lane;
+                        double2* s2 = reinterpret_cast<double2*>(a.msumsq + (int64_t)(tid >> 6) * LD + c0) + lane;
+                        const double2 o1 = *s1, o2 = *s2;
+                        *s1 = make_double2(o1.x + ms.x, o1.y + ms.y);
+                        *s2 = make_double2(o2.x + mq.x, o2.y + mq.y);
+                    }
                 }
             }
             __builtin_amdgcn_wave_barrier();

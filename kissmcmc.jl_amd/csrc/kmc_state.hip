@@ -377,6 +377,13 @@ KMC_EXPORT kmc_status kmc_sampler_get_moments(kmc_sampler* s, double* sum, doubl
                 if (d0 < nd) { S[d0] += hs[idx]; Q[d0] += hq[idx]; }
                 if (d0 + 1 < nd) { S[d0 + 1] += hs[idx + 1]; Q[d0 + 1] += hq[idx + 1]; }
             }
+    } else if (s->user && s->uk.staged != nullptr && staged_tile_moments((int)nd)) {
+        // half_step_staged: one accumulator row [ld] per wave
+        for (int64_t w = 0; w < s->macc_stride / 64; ++w)
+            for (int64_t d = 0; d < nd; ++d) {
+                S[d] += hs[w * s->ld + d];
+                Q[d] += hq[w * s->ld + d];
+            }
     } else {
         for (int64_t d = 0; d < nd; ++d)
             for (int64_t t = 0; t < s->macc_stride; ++t) {

@@ -242,7 +242,7 @@ class CDensity(ExprDensity):
         CDensity("double s = 0; for (int i = 0; i + 1 < n; ++i) { double d = x[i+1] - x[i]*x[i]; s += p[1]*d*d + (p[0]-x[i])*(p[0]-x[i]); } "
                  "return -s / p[2];", params=[1, 100, 20])
 
-    It runs one walker per lane (rows staged through LDS up to ndim 64, the generic kernel above), so it is about half as
+    It runs one walker per lane (rows staged through LDS up to ndim 256, the generic kernel above), so it is about half as
     fast as a menu density or an :class:`ExprDensity` of the same form, and orders of magnitude faster than a host callable (:class:`HostLogPdf`).  ``kmc_user_density_create_body``.
 
     ``nblob=m`` makes it the reference's ``pdf(theta) -> (p, blob)`` of ``hasblob=true`` (``src/samplers.jl:150-151, :194-196``)
