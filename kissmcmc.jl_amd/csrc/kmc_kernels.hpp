@@ -134,8 +134,10 @@ struct HalfStepArgs {
     double2*          ring;         // or nullptr
     int64_t           ring_rows;    // rows per slot
     int32_t           ring_slot;    // slot of this generation (generation & 3)
+    int32_t           prop_ld;      // (host-evaluated densities) row stride of prop_out in doubles
     // host-evaluated densities (HostEval) only
-    double*           prop_out;     // PROPOSE pass: proposals [n_active][ld]; nothing else is touched
+    double*           prop_out;     // PROPOSE pass: proposals [n_active][prop_ld]; nothing else is touched.  Device memory, or -- small
+                                    //   batches -- the caller-facing page-locked host array itself (dense rows), written over the link
     const double*     p1_in;        // ACCEPT pass: log-pdf of proposal i as evaluated by the host
     unsigned char*    acc_out;      // ACCEPT pass, optional: 1 where proposal i replaced its walker (:261), else 0
     // moment ring (long rows: L == 64, ndim > 128, where the accumulators are NOT prefetched): a wave with an accepted move
@@ -997,7 +999,7 @@ __device__ __forceinline__ void half_step_generic_body(const HalfStepFront& f, c
     constexpr bool kHost = HostEvalTrait<Dens>::value;
     if constexpr (kHost) {
         if (a.prop_out != nullptr) {                                    // PROPOSE pass
-            for (int d = 0; d < ndim; ++d) { const double o = oth_at(d); a.prop_out[(int64_t)tid * ld + d] = fma(dr.z, (double)own[d] - o, o); }
+            for (int d = 0; d < ndim; ++d) { const double o = oth_at(d); a.prop_out[(int64_t)tid * a.prop_ld + d] = fma(dr.z, (double)own[d] - o, o); }
             return;
         }
     }

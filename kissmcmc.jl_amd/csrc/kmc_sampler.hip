@@ -603,6 +603,11 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         CREATE_TRY(dev_alloc(s, &s->d_p1, (size_t)s->h * sizeof(double)));
         CREATE_TRY(hipHostMalloc((void**)&s->h_prop, (size_t)s->h * (size_t)cfg->ndim * sizeof(double), hipHostMallocDefault));
         CREATE_TRY(hipHostMalloc((void**)&s->h_p1, (size_t)s->h * sizeof(double), hipHostMallocDefault));
+        if (hipHostGetDevicePointer((void**)&s->h_prop_dev, s->h_prop, 0) != hipSuccess ||
+            hipHostGetDevicePointer((void**)&s->h_p1_dev, s->h_p1, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            s->h_prop_dev = s->h_p1_dev = nullptr;          // (then every batch goes through the copies)
+        }
         if (cfg->host_accepted) {
             CREATE_TRY(dev_alloc(s, &s->d_acc, (size_t)s->h));
             CREATE_TRY(hipHostMalloc((void**)&s->h_acc, (size_t)s->h, hipHostMallocDefault));

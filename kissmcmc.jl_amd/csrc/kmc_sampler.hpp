@@ -120,6 +120,8 @@ struct kmc_sampler {
     double* d_p1 = nullptr;            // [h] their log-pdfs, as returned by the callback
     double* h_prop = nullptr;          // pinned, dense [h][ndim]
     double* h_p1 = nullptr;            // pinned [h]
+    double* h_prop_dev = nullptr;      // the same two arrays as the device addresses them (small batches: the kernels write the proposals
+    double* h_p1_dev = nullptr;        //   straight into h_prop and read the log-pdfs straight from h_p1 -- no copies, one synchronisation)
     uint8_t* d_acc = nullptr;          // [h] accept outcomes of the current half-step (host_accepted only)
     uint8_t* h_acc = nullptr;          // pinned [h]
     hipEvent_t host_ev[kmc_host::kHostPieces] = {};   // proposals of a large half-step reach the host in pieces, each behind its event (kmc_sampler_run)

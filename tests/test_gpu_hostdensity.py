@@ -243,3 +243,22 @@ def test_accept_outcomes_through_the_c_abi(kmc, oracle):
     # the callback belongs to KMC_HOST_DENSITY
     c.density, c.host_logpdf = 0, None
     assert L.kmc_validate(C.byref(c)) == _lib.ERR_BAD_ARG
+
+
+@pytest.mark.parametrize("zero_copy", ["0", "1"])
+def test_small_batches_with_and_without_the_copies(kmc, oracle, monkeypatch, zero_copy):
+    """Up to 256 KiB of proposals the kernels address the page-locked host arrays directly (KMC_HOST_ZEROCOPY); forced on for a batch
+    the copies would take, and off for one they would not: the same chain as the device density either way."""
+    monkeypatch.setenv("KMC_HOST_ZEROCOPY", zero_copy)
+    nw, nd, G = 600, 3, 60
+    th = np.random.default_rng(3).standard_normal((nw, nd))
+    host = kmc.HostLogPdf(lambda X: -0.5 * (X * X).sum(axis=1), vectorized=True)
+    out = []
+    for pdf in (host, kmc.GaussianIso(0.0, 1.0)):
+        with kmc.Sampler(pdf, nw, nd, G, 10, 1, 2.0, 5, store_chain=True, use_graph=True) as s:
+            s.set_positions(th)
+            s.run(G)
+            s.sync()
+            out.append((s.chain(logp=False)[0], s.naccept()))
+    np.testing.assert_array_equal(out[0][1], out[1][1])
+    np.testing.assert_array_equal(out[0][0], out[1][0])
