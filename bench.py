@@ -290,6 +290,20 @@ def other_configs(kmc, device: int):
             del ch, lp
     except Exception as e:  # noqa: BLE001
         out["C2_chain_on"] = {"error": str(e)}
+    # the general route for a caller's own log-density: a function body compiled at run time (CDensity), at the C2 shape and at
+    # the reference's own (one walker per lane either way: staged through LDS / resident in LDS)
+    try:
+        body = "double s = 0; for (int i = 0; i < n; ++i) s += x[i] * x[i]; return -0.5 * s;"
+        for key, nw, nd, G in (("C2_user_density", 65536, 32, 2000), ("C1_user_density", 100, 1, 20000)):
+            with kmc.Sampler(kmc.CDensity(body), nw, nd, G, G // 2, 1, 2.0, 12345, moments=True) as s:
+                s.set_positions(np.random.default_rng(12345).standard_normal((nw, nd)))
+                s.run(G)
+                s.sync()
+                ms = s.last_run_ms()
+                out[key] = {"workload": f"{nw} walkers x {nd}-D Gaussian written as a C function body (hiprtc), {G} generations", "value": nw * G / (ms * 1e-3),
+                            "unit": "walker-steps/s", "us_per_half_step": ms * 1e3 / (2 * G), "execution": s.describe()}
+    except Exception as e:  # noqa: BLE001
+        out["C2_user_density"] = {"error": str(e)}
     return out
 
 
