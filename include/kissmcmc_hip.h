@@ -352,7 +352,7 @@ kmc_status  kmc_sampler_last_run_ms(kmc_sampler* s, double* ms);
 int64_t     kmc_sampler_generation(const kmc_sampler* s);
 int64_t     kmc_sampler_nsamples(const kmc_sampler* s);
 /* Number of half-step kernel launches enqueued so far and the algorithmic bytes each moves
- * (read (2 ndim + 1) * 8, write (ndim + 1) * 8 per walker-step).  Resident mode (<= 1024 walkers): a launch
+ * (read (2 ndim + 1) * 8, write (ndim + 1) * 8 per walker-step).  Resident mode (<= 1024 walkers, <= 2048 for menu densities with ndim <= 8): a launch
  * carries up to 1024 whole generations and is preceded by the kernel that computes its draws; both are counted. */
 int64_t     kmc_sampler_launch_count(const kmc_sampler* s);
 /* How kmc_sampler_run issues this sampler's launches (same kernels, same results in every mode; reference

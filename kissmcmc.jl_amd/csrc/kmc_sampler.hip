@@ -65,6 +65,18 @@ ResidentFn resident_lane_fn(int density, int ndim, bool f32)
     }
 }
 
+ResidentFn resident_lane2_fn(int density, int ndim)
+{
+    switch (density) {
+    case KMC_GAUSSIAN_ISO: return resident_lane2_gaussian_iso(ndim);
+    case KMC_EXPONENTIAL: return resident_lane2_exponential(ndim);
+    case KMC_ROSENBROCK: return resident_lane2_rosenbrock(ndim);
+    case KMC_LOGNORMAL: return resident_lane2_lognormal(ndim);
+    case KMC_MVNORMAL2: return resident_lane2_mvnormal2(ndim);
+    default: return nullptr;
+    }
+}
+
 // resident mode with one walker per thread (short rows) or two lanes per walker: KMC_RESIDENT=lane|pair decides for tests
 bool resident_lane_wanted(int64_t ndim)
 {
@@ -458,14 +470,25 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         }
         if (ea != hipSuccess) { (void)hipGetLastError(); kmc_sampler_destroy(s); return fail(KMC_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(ea)); }
     }
-    if (!s->islands && cfg->density != KMC_USER_DENSITY && !s->host_eval && cfg->nwalkers <= 1024 && cfg->ndim <= 32 &&
+    if (!s->islands && cfg->density != KMC_USER_DENSITY && !s->host_eval && cfg->nwalkers <= 2048 && cfg->ndim <= 32 &&
         s->cfg.shard_count == 1 && !(cfg->flags & (KMC_P2P | KMC_NO_GRAPH)) && std::getenv("KMC_NO_RESIDENT") == nullptr) {
         const int64_t chunks = s->ld / 2;
         int K = 1;
         while (2 * K < chunks) K *= 2;
         int rtpb = cfg->nwalkers <= 256 ? 256 : (cfg->nwalkers <= 512 ? 512 : 1024);
         size_t need = ((size_t)cfg->nwalkers * (size_t)(4 * (K + 1)) + (size_t)cfg->nwalkers) * sizeof(double);
-        ResidentFn rf = (!s->f32 && need <= 156 * 1024) ? resident_fn(cfg->density, rtpb, K, 4 * K != cfg->ndim) : nullptr;   // (float rows: the lane kernels only)
+        ResidentFn rf = (!s->f32 && need <= 156 * 1024 && cfg->nwalkers <= 1024) ? resident_fn(cfg->density, rtpb, K, 4 * K != cfg->ndim) : nullptr;   // (float rows: the lane kernels only)
+        if (cfg->nwalkers > 1024) {                       // 1026 .. 2048 walkers: two walkers per thread, short double rows, as LDS allows
+            const size_t need2 = ((size_t)cfg->nwalkers * (size_t)((lane_nd(cfg->ndim) | 1) + 1)) * sizeof(double);
+            ResidentFn l2 = (!s->f32 && resident_lane_wanted(cfg->ndim) && need2 <= 156 * 1024) ? resident_lane2_fn(cfg->density, (int)cfg->ndim) : nullptr;
+            if (l2) {
+                rf = l2;
+                rtpb = (int)((cfg->nwalkers / 2 + 63) / 64 * 64);
+                need = need2;
+                s->resident_lane = true;
+                s->resident_lane2 = true;
+            }
+        } else
         if (resident_lane_wanted(cfg->ndim)) {            // short rows: one walker per thread (measured faster up to ndim 8)
             ResidentFn lf = resident_lane_fn(cfg->density, (int)cfg->ndim, s->f32);
             if (lf) {
@@ -811,7 +834,7 @@ KMC_EXPORT kmc_status kmc_sampler_describe(const kmc_sampler* s, char* buf, int6
     else if (s->resident)
         o << "resident mode (exact): whole ensemble in one workgroup's LDS (" << s->resident_tpb
           << " threads), up to " << kDrawTableGens << " generations per launch, "
-          << (s->resident_lane ? std::string("one walker per thread") : "rows 2 lanes x " + std::to_string(s->island_K) + " chunks")
+          << (s->resident_lane2 ? std::string("two walkers per thread") : s->resident_lane ? std::string("one walker per thread") : "rows 2 lanes x " + std::to_string(s->island_K) + " chunks")
           << ", the launch's draws from a wide kernel before it";
     else if (s->host_eval)
         o << "host-evaluated density (exact): per half-step propose kernel -> D2H -> callback -> H2D -> accept kernel, grid "

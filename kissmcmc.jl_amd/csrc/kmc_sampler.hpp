@@ -129,6 +129,7 @@ struct kmc_sampler {
     bool resident = false;
     kmc::ResidentFn resident_kernel = nullptr;
     int resident_tpb = 256;
+    bool resident_lane2 = false;       // ... two walkers per thread (1026 .. 2048 walkers: resident_lane2_body)
     bool resident_lane = false;        // ... one walker per thread (kmc_islands.hpp: resident_lane_body) instead of two lanes per walker
     // island mode (KMC_ISLANDS)
     bool islands = false;

@@ -160,6 +160,22 @@ ResidentFn resident_lane_lookup(int ndim, bool f32)
 {
     return f32 ? resident_lane_lookup_t<D, float>(ndim) : resident_lane_lookup_t<D, double>(ndim);
 }
+// ... two walkers per thread (1026 .. 2048 walkers, double rows)
+template <class D>
+ResidentFn resident_lane2_lookup(int ndim)
+{
+    switch (ndim) {
+    case 1: return resident_lane2<D, 1>;
+    case 2: return resident_lane2<D, 2>;
+    case 3: return resident_lane2<D, 3>;
+    case 4: return resident_lane2<D, 4>;
+    case 5: return resident_lane2<D, 5>;
+    case 6: return resident_lane2<D, 6>;
+    case 7: return resident_lane2<D, 7>;
+    case 8: return resident_lane2<D, 8>;
+    default: return nullptr;
+    }
+}
 // many-chain Metropolis: the chain in registers up to 32 dimensions, in memory beyond
 template <class D>
 MetropolisFn metropolis_lookup(int ndim)
@@ -200,30 +216,35 @@ HalfStepFn half_step_host();
 IslandFn island_gaussian_iso(int S, int K, bool ragged);
 ResidentFn resident_gaussian_iso(int tpb, int K, bool ragged);
 ResidentFn resident_lane_gaussian_iso(int ndim, bool f32);
+ResidentFn resident_lane2_gaussian_iso(int ndim);
 InitBallFn init_ball_gaussian_iso();
 MetropolisFn metropolis_gaussian_iso(int ndim);
 MetropolisTabledFn metropolis_tabled_gaussian_iso(int ndim);
 IslandFn island_exponential(int S, int K, bool ragged);
 ResidentFn resident_exponential(int tpb, int K, bool ragged);
 ResidentFn resident_lane_exponential(int ndim, bool f32);
+ResidentFn resident_lane2_exponential(int ndim);
 InitBallFn init_ball_exponential();
 MetropolisFn metropolis_exponential(int ndim);
 MetropolisTabledFn metropolis_tabled_exponential(int ndim);
 IslandFn island_rosenbrock(int S, int K, bool ragged);
 ResidentFn resident_rosenbrock(int tpb, int K, bool ragged);
 ResidentFn resident_lane_rosenbrock(int ndim, bool f32);
+ResidentFn resident_lane2_rosenbrock(int ndim);
 InitBallFn init_ball_rosenbrock();
 MetropolisFn metropolis_rosenbrock(int ndim);
 MetropolisTabledFn metropolis_tabled_rosenbrock(int ndim);
 IslandFn island_lognormal(int S, int K, bool ragged);
 ResidentFn resident_lognormal(int tpb, int K, bool ragged);
 ResidentFn resident_lane_lognormal(int ndim, bool f32);
+ResidentFn resident_lane2_lognormal(int ndim);
 InitBallFn init_ball_lognormal();
 MetropolisFn metropolis_lognormal(int ndim);
 MetropolisTabledFn metropolis_tabled_lognormal(int ndim);
 IslandFn island_mvnormal2(int S, int K, bool ragged);
 ResidentFn resident_mvnormal2(int tpb, int K, bool ragged);
 ResidentFn resident_lane_mvnormal2(int ndim, bool f32);
+ResidentFn resident_lane2_mvnormal2(int ndim);
 InitBallFn init_ball_mvnormal2();
 MetropolisFn metropolis_mvnormal2(int ndim);
 MetropolisTabledFn metropolis_tabled_mvnormal2(int ndim);

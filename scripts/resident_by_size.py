@@ -2,7 +2,7 @@ import sys
 sys.path.insert(0, '.')
 import numpy as np
 import kissmcmc_jl_amd as kmc
-for nw in (32, 64, 66, 100, 128, 130, 256, 512, 1000):
+for nw in (32, 64, 66, 100, 128, 130, 256, 512, 1000, 1024, 1026, 1500, 2048, 2050, 4096):
     for nd in (1, 4):
         pdf = kmc.Exponential(1.0) if nd == 1 else kmc.GaussianIso(0.0, 1.0)
         G = 20000

@@ -214,6 +214,24 @@ def test_resident_runs_longer_than_a_launch_have_no_seam(kmc, oracle, name, nw, 
     _compare(ref, got)
 
 
+@pytest.mark.parametrize("name,nw,nd,G,nburn,nthin", [("gauss", 1026, 4, 150, 40, 3), ("expo", 2048, 1, 120, 0, 1), ("rosen", 1500, 2, 200, 60, 2),
+                                                    ("lognormal", 1100, 7, 100, 30, 1), ("gauss_shift", 2000, 5, 90, 10, 4), ("gauss", 1990, 8, 60, 20, 1),
+                                                    ("gauss", 1300, 3, 2100, 1000, 50)])
+def test_resident_two_walkers_per_thread(kmc, oracle, name, nw, nd, G, nburn, nthin, monkeypatch):
+    """1026 .. 2048 walkers with short rows (as LDS allows): resident mode with two walkers per thread -- the oracle's chain, and the
+    multi-launch kernels' to the last bit (an ensemble of 1100 walkers used to run 4.7x slower than one of 1000)."""
+    ref, res = _run_both(kmc, oracle, name, nw, nd, G, nburn, nthin, seed=99)
+    _compare(ref, res)
+    with kmc.Sampler(_densities(kmc, oracle)[name][0], nw, nd, 10) as s:
+        fits = nw * ((nd | 1) + 1) * 8 <= 156 * 1024
+        assert ("two walkers per thread" in s.describe()) == fits, s.describe()
+    monkeypatch.setenv("KMC_NO_RESIDENT", "1")
+    ref2, multi = _run_both(kmc, oracle, name, nw, nd, G, nburn, nthin, seed=99)
+    np.testing.assert_array_equal(res["chain"], multi["chain"])
+    np.testing.assert_array_equal(res["naccept"], multi["naccept"])
+    np.testing.assert_array_equal(res["final_pos"], multi["final_pos"])
+
+
 def test_describe_reports_the_execution_mode(kmc):
     with kmc.Sampler(kmc.GaussianIso(), 65536, 32, 10) as s:
         assert "half_step_vec L=8 K=2 ITER=2 exact-size" in s.describe() and "hipGraph" in s.describe()
