@@ -45,7 +45,7 @@ def test_streamed_chain_equals_oracle_over_three_ring_laps(kmc, oracle, monkeypa
 
 
 @pytest.mark.parametrize("case", ["thin3_odd_ndim", "pieces_with_syncs", "eager_launches", "logp_only", "chain_only", "rosen_draw_ring",
-                                  "small_ensemble", "unregistered_destination"])
+                                  "small_ensemble", "unregistered_destination", "two_walkers_per_thread"])
 @pytest.mark.parametrize("by_walker", [False, True], ids=["sample-major", "by-walker"])
 @pytest.mark.parametrize("resident", [True, False], ids=["resident-where-it-fits", "multi-launch"])
 def test_streamed_chain_variants(kmc, oracle, monkeypatch, case, by_walker, resident):
@@ -70,6 +70,8 @@ def test_streamed_chain_variants(kmc, oracle, monkeypatch, case, by_walker, resi
         pdf, did, params, nd, scale = kmc.Rosenbrock(), oracle.ROSENBROCK, [1.0, 100.0, 20.0], 64, 0.1
     elif case == "small_ensemble":
         nw, nd = 100, 2                                  # the reference's own size
+    elif case == "two_walkers_per_thread":
+        nw, nd = 1500, 3                                 # resident mode beyond 1024 walkers
     elif case == "unregistered_destination":
         monkeypatch.setenv("KMC_NO_HOST_REGISTER", "1")  # staged copies instead of DMA into page-locked arrays
     th = scale * np.random.default_rng(2).standard_normal((nw, nd))
