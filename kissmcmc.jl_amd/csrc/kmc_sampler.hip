@@ -415,7 +415,7 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         // (float rows: the one-walker-per-thread kernels only -- their LDS rows are double either way)
         if ((!s->f32 || s->user->is_body || expr_lane) && cfg->nwalkers <= ((s->user->is_body || expr_lane) ? 1024 : 256) && cfg->ndim <= 32 && s->cfg.shard_count == 1 && !(s->user->is_body && cfg->deal_count > 0) &&
             !(cfg->flags & (KMC_P2P | KMC_NO_GRAPH | KMC_ISLANDS)) &&
-            rlds <= 60 * 1024 && std::getenv("KMC_NO_RESIDENT") == nullptr)
+            rlds <= 156 * 1024 && std::getenv("KMC_NO_RESIDENT") == nullptr)    // (hipModuleLaunchKernel takes dynamic LDS beyond 64 KiB as it is)
             rK = rK0;
         int iS = 0;
         if (cfg->flags & KMC_ISLANDS) {
@@ -427,7 +427,7 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         if (s->user->is_body && cfg->ndim > 1024) { kmc_sampler_destroy(s); return fail(KMC_ERR_UNSUPPORTED, "a body density holds the proposal per lane: ndim <= 1024"); }
         // (what the resident kernel is compiled as: term / pair density on short rows -> -ndim = one walker per thread; body density ->
         //  the workgroup size bound, 256 or 1024: a body of 32 dimensions needs its registers; else the two-lane kernel's K)
-        const int rcode = (rK > 0 && iS == 0) ? (s->user->is_body ? (cfg->nwalkers <= 256 ? 256 : 1024) : (expr_lane ? -lane_nd(cfg->ndim) : rK)) : rK;
+        const int rcode = (rK > 0 && iS == 0) ? (s->user->is_body ? (cfg->nwalkers <= 256 ? 256 : cfg->nwalkers <= 512 ? 512 : 1024) : (expr_lane ? -lane_nd(cfg->ndim) : rK)) : rK;
         st = load_user(s->user, s->plan.vec, s->plan.L, s->plan.K, s->plan.ITER, s->plan.ragged, &s->uk, rcode, 4 * rK != cfg->ndim, iS, s->f32,
                        cfg->ndim, (cfg->flags & KMC_P2P) != 0);
         if (st != KMC_OK) { kmc_sampler_destroy(s); return st; }

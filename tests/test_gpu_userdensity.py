@@ -172,7 +172,7 @@ ROSEN_BODY = ("double s = 0.0; for (int i = 0; i + 1 < n; ++i) { double d = x[i 
 
 
 @pytest.mark.parametrize("nw,nd,G,nburn,nthin", [(100, 2, 700, 300, 1), (6, 4, 300, 100, 3), (1000, 5, 150, 40, 2), (1024, 4, 120, 0, 1), (200, 31, 90, 30, 1),
-                                                  (64, 1, 400, 100, 1)])
+                                                  (64, 1, 400, 100, 1), (1000, 8, 100, 30, 1), (512, 32, 60, 20, 1), (1024, 12, 60, 10, 2), (600, 24, 50, 10, 1)])
 def test_body_density_runs_resident_on_small_ensembles(kmc, oracle, monkeypatch, nw, nd, G, nburn, nthin):
     """A CDensity on the reference's own problem sizes: the whole ensemble in one workgroup's LDS, one walker per thread, many
     generations per launch (kmc_islands.hpp: resident_lane_body) -- same draws and element order as the multi-launch kernels:
