@@ -194,12 +194,16 @@ kmc_status compile_user(kmc_user_density* ud, bool with_vec, int L, int K, int i
     if (with_vec)
         src << "extern \"C\" __global__ __launch_bounds__(" << vec_tpb(L) << ") void kmc_user_vec(KMC_FRONT_PARAMS, const kmc::HalfStepArgs a) { kmc::half_step_vec_body<UD, "
             << L << ", " << K << ", " << iter << ", " << peer << ", " << (ragged ? "true" : "false") << ", " << rowt << ">(KMC_FRONT_PACK, a); }\n";
-    if (resident_K > 0 && island_S == 0 && ud->is_body)       // one walker per thread; resident_K = the workgroup size it is launched with at most
+    if (resident_K == 2048 && island_S == 0 && ud->is_body)   // two walkers per thread (1026 .. 2048 walkers)
+        src << "extern \"C\" __global__ __launch_bounds__(1024) void kmc_user_resident(const kmc::ResidentArgs a) { kmc::resident_lane2_body<UD, " << ndim << ">(a); }\n";
+    else if (resident_K <= -100 && island_S == 0 && !ud->is_body)
+        src << "extern \"C\" __global__ __launch_bounds__(1024) void kmc_user_resident(const kmc::ResidentArgs a) { kmc::resident_lane2_body<UD, " << -resident_K - 100 << ">(a); }\n";
+    else if (resident_K > 0 && island_S == 0 && ud->is_body)       // one walker per thread; resident_K = the workgroup size it is launched with at most
         src << "extern \"C\" __global__ __launch_bounds__(" << resident_K << ") void kmc_user_resident(const kmc::ResidentArgs a) { kmc::resident_lane_body<UD, " << ndim << ", true, " << rowt << ">(a); }\n";
     if (resident_K > 0 && island_S == 0 && !ud->is_body)
         src << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_resident(const kmc::ResidentArgs a) { kmc::resident_body<UD, "
             << resident_K << ", " << (resident_ragged ? "true" : "false") << ">(a); }\n";
-    if (resident_K < 0 && island_S == 0 && !ud->is_body)      // short rows: one walker per thread, ndim <= ND = -resident_K
+    if (resident_K < 0 && resident_K > -100 && island_S == 0 && !ud->is_body)      // short rows: one walker per thread, ndim <= ND = -resident_K
         src << "extern \"C\" __global__ __launch_bounds__(1024) void kmc_user_resident(const kmc::ResidentArgs a) { kmc::resident_lane_body<UD, " << -resident_K << ", true, " << rowt << ">(a); }\n";
     if (resident_K > 0 && island_S > 0)
         src << "extern \"C\" __global__ __launch_bounds__(" << island_S << ") void kmc_user_island(const kmc::IslandArgs a) { kmc::island_epoch_body<UD, "

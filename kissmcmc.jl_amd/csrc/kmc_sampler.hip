@@ -413,7 +413,10 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         const bool expr_lane = !s->user->is_body && resident_lane_wanted(cfg->ndim);     // term / pair density, short rows: the lane kernel too
         if (expr_lane) rlds = ((size_t)cfg->nwalkers * (size_t)((lane_nd(cfg->ndim) | 1) + 1)) * sizeof(double);
         // (float rows: the one-walker-per-thread kernels only -- their LDS rows are double either way)
-        if ((!s->f32 || s->user->is_body || expr_lane) && cfg->nwalkers <= ((s->user->is_body || expr_lane) ? 1024 : 256) && cfg->ndim <= 32 && s->cfg.shard_count == 1 && !(s->user->is_body && cfg->deal_count > 0) &&
+        // 1026 .. 2048 walkers: two walkers per thread (kmc_islands.hpp: resident_lane2_body; double rows, ndim <= 8, no blobs)
+        const bool lane2 = cfg->nwalkers > 1024 && cfg->nwalkers <= 2048 && !s->f32 && cfg->ndim <= 8 && s->user->nblob == 0 && resident_lane_wanted(cfg->ndim);
+        if (lane2) rlds = ((size_t)cfg->nwalkers * (size_t)((cfg->ndim | 1) + 1)) * sizeof(double);
+        if ((!s->f32 || s->user->is_body || expr_lane) && (cfg->nwalkers <= ((s->user->is_body || expr_lane) ? 1024 : 256) || lane2) && cfg->ndim <= 32 && s->cfg.shard_count == 1 && !(s->user->is_body && cfg->deal_count > 0) &&
             !(cfg->flags & (KMC_P2P | KMC_NO_GRAPH | KMC_ISLANDS)) &&
             rlds <= 156 * 1024 && std::getenv("KMC_NO_RESIDENT") == nullptr)    // (hipModuleLaunchKernel takes dynamic LDS beyond 64 KiB as it is)
             rK = rK0;
@@ -427,7 +430,9 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         if (s->user->is_body && cfg->ndim > 1024) { kmc_sampler_destroy(s); return fail(KMC_ERR_UNSUPPORTED, "a body density holds the proposal per lane: ndim <= 1024"); }
         // (what the resident kernel is compiled as: term / pair density on short rows -> -ndim = one walker per thread; body density ->
         //  the workgroup size bound, 256 or 1024: a body of 32 dimensions needs its registers; else the two-lane kernel's K)
-        const int rcode = (rK > 0 && iS == 0) ? (s->user->is_body ? (cfg->nwalkers <= 256 ? 256 : cfg->nwalkers <= 512 ? 512 : 1024) : (expr_lane ? -lane_nd(cfg->ndim) : rK)) : rK;
+        //  two walkers per thread: 2048 for a body, -(100 + ndim) for a term / pair density)
+        const int rcode = (rK > 0 && iS == 0) ? (lane2 ? (s->user->is_body ? 2048 : -(100 + (int)cfg->ndim))
+                                                       : s->user->is_body ? (cfg->nwalkers <= 256 ? 256 : cfg->nwalkers <= 512 ? 512 : 1024) : (expr_lane ? -lane_nd(cfg->ndim) : rK)) : rK;
         st = load_user(s->user, s->plan.vec, s->plan.L, s->plan.K, s->plan.ITER, s->plan.ragged, &s->uk, rcode, 4 * rK != cfg->ndim, iS, s->f32,
                        cfg->ndim, (cfg->flags & KMC_P2P) != 0);
         if (st != KMC_OK) { kmc_sampler_destroy(s); return st; }
@@ -437,8 +442,9 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
             s->island_K = rK;
             s->nislands = 1;
             s->island_lds = rlds < 4096 ? 4096 : rlds;
-            s->resident_lane = s->user->is_body || expr_lane;
-            s->resident_tpb = s->resident_lane ? (int)((cfg->nwalkers + 63) / 64 * 64) : 256;
+            s->resident_lane = s->user->is_body || expr_lane || lane2;
+            s->resident_lane2 = lane2;
+            s->resident_tpb = lane2 ? (int)((cfg->nwalkers / 2 + 63) / 64 * 64) : s->resident_lane ? (int)((cfg->nwalkers + 63) / 64 * 64) : 256;
         }
     } else if (cfg->density == KMC_HOST_DENSITY) {
         s->host_eval = true;

@@ -184,7 +184,7 @@ def f_blobs(kmc, pdf):
 
 FEATURES = [
     ("hipGraph replay", f_graph),
-    ("resident mode (≤ 1024 walkers)", f_resident),
+    ("resident mode (≤ 1024 walkers; ≤ 2048 with ndim ≤ 8)", f_resident),
     ("islands (`KMC_ISLANDS`)", f_islands),
     ("float rows (`KMC_F32`)", f_f32),
     ("streamed chain (`KMC_STREAM_CHAIN`)", f_stream),

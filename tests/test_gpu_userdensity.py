@@ -128,11 +128,12 @@ def test_body_density_equals_the_oracle(kmc, oracle, case, monkeypatch):
     assert pdf(th[0]) == pytest.approx(oracle.logpdf(did, params, th[0]), rel=1e-14)       # host call = device evaluation
 
 
-def test_body_density_with_real_coupling_samples_its_target(kmc):
+def test_body_density_with_real_coupling_samples_its_target(kmc, monkeypatch):
     """A density no term / pair form can express -- a correlated Gaussian with a dense precision matrix built in the body:
     x' P x with P = (1 + rho) I - rho/n 11' ... here: -0.5 (sum x_i^2 + c (sum x_i)^2): variance of the mean direction
     1 / (1 + c n), of every orthogonal direction 1."""
     n, c = 6, 0.5
+    monkeypatch.setenv("KMC_NO_RESIDENT", "1")           # (2048 x 6 would run resident, two walkers per thread: the staged kernel is the subject)
     pdf = kmc.CDensity("double s = 0.0, t = 0.0; for (int i = 0; i < n; ++i) { s += x[i] * x[i]; t += x[i]; } return -0.5 * (s + p[0] * t * t);", params=[c])
     th = np.random.default_rng(1).standard_normal((2048, n))
     with kmc.Sampler(pdf, 2048, n, 3000, 500, 5, 2.0, 3, store_chain=True) as s:
@@ -172,7 +173,8 @@ ROSEN_BODY = ("double s = 0.0; for (int i = 0; i + 1 < n; ++i) { double d = x[i 
 
 
 @pytest.mark.parametrize("nw,nd,G,nburn,nthin", [(100, 2, 700, 300, 1), (6, 4, 300, 100, 3), (1000, 5, 150, 40, 2), (1024, 4, 120, 0, 1), (200, 31, 90, 30, 1),
-                                                  (64, 1, 400, 100, 1), (1000, 8, 100, 30, 1), (512, 32, 60, 20, 1), (1024, 12, 60, 10, 2), (600, 24, 50, 10, 1)])
+                                                  (64, 1, 400, 100, 1), (1000, 8, 100, 30, 1), (512, 32, 60, 20, 1), (1024, 12, 60, 10, 2), (600, 24, 50, 10, 1),
+                                                  (1500, 3, 90, 30, 2), (2048, 1, 70, 0, 1), (1030, 8, 60, 20, 1)])
 def test_body_density_runs_resident_on_small_ensembles(kmc, oracle, monkeypatch, nw, nd, G, nburn, nthin):
     """A CDensity on the reference's own problem sizes: the whole ensemble in one workgroup's LDS, one walker per thread, many
     generations per launch (kmc_islands.hpp: resident_lane_body) -- same draws and element order as the multi-launch kernels:
@@ -199,7 +201,7 @@ def test_body_density_runs_resident_on_small_ensembles(kmc, oracle, monkeypatch,
                         launches=s.launch_count)
 
     res = run()
-    assert "resident mode" in res["how"] and "one walker per thread" in res["how"], res["how"]
+    assert "resident mode" in res["how"] and ("two walkers per thread" if nw > 1024 else "one walker per thread") in res["how"], res["how"]
     assert res["launches"] <= 6                                           # three run() pieces (draw table + resident kernel each), not 2 G launches
     monkeypatch.setenv("KMC_NO_RESIDENT", "1")
     ml = run()
@@ -234,3 +236,26 @@ def test_body_density_with_blobs_runs_resident(kmc):
     np.testing.assert_array_equal(cur[:, 0], pos[:, 0])
     np.testing.assert_array_equal(cur[:, 1], lp)
     assert abs(chain.mean() + 5.0) < 0.9
+
+
+def test_term_pair_density_runs_two_walkers_per_thread_beyond_1024(kmc, oracle, monkeypatch):
+    """An ExprDensity on 1026 .. 2048 walkers with short rows: resident mode with two walkers per thread, equal to the menu density's
+    multi-launch run bit for bit."""
+    nw, nd, G, nburn = 1800, 4, 120, 30
+    th = np.random.default_rng(3).standard_normal((nw, nd))
+
+    def run(pdf):
+        with kmc.Sampler(pdf, nw, nd, G, nburn, 1, 2.0, 17, store_chain=True, store_logp=True, moments=True) as s:
+            s.set_positions(th)
+            s.run(G)
+            s.sync()
+            return dict(how=s.describe(), chain=s.chain()[0], nacc=s.naccept(), mom=s.moments())
+
+    a = run(kmc.ExprDensity("-0.5*x*x"))
+    assert "two walkers per thread" in a["how"], a["how"]
+    monkeypatch.setenv("KMC_NO_RESIDENT", "1")
+    b = run(kmc.GaussianIso(0.0, 1.0))
+    assert "multi-launch" in b["how"]
+    np.testing.assert_array_equal(a["chain"], b["chain"])
+    np.testing.assert_array_equal(a["nacc"], b["nacc"])
+    np.testing.assert_allclose(a["mom"][0], b["mom"][0], rtol=1e-11, atol=1e-8)
