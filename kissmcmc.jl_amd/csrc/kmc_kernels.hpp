@@ -1517,6 +1517,7 @@ __global__ __launch_bounds__(256) void chain_by_walker(const T* __restrict__ src
             d[e] = (double)s[k * nl * ld + c];
         }
     }
+    __threadfence_system();        // (dst may be the caller's page-locked host array: nothing of it may trail the kernel's completion)
 }
 
 // Padded rows [rows][ld] -> dense rows [rows][nd] (a streamed chain of odd ndim: compacted on the device, so that the copy to the
