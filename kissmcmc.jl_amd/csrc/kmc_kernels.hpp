@@ -1107,12 +1107,16 @@ __device__ __forceinline__ void half_step_staged_body(const HalfStepFront& f, co
     // row pair would spill, and the rows themselves already live in scratch there (the compiler's spill of xc / xo -- lane-
     // interleaved private memory, still far better than the generic kernel's element-wise loads of 64 different rows).
     constexpr bool kAllAtOnce = ND <= 64;
-    auto issue_tile = [&](auto grow, int t, double2 (&v)[CPR]) {
+    // (addresses: a wave-uniform base + a 32-bit lane offset wherever the row is one of the wave's own 64 -- the 64-bit address
+    //  arithmetic of every load and store was a quarter of this kernel's instructions)
+    const int w0u = __builtin_amdgcn_readfirstlane(w0);
+    double* const own_base = a.pos + (a.own_row0 + (int64_t)w0u) * LD;
+    auto issue_tile = [&](auto rowptr, int t, double2 (&v)[CPR]) {
 #pragma unroll
         for (int i = 0; i < CPR; ++i) {
             const int q = i * 64 + lane, r = q / CPR, ch = q - r * CPR;
             const int col = t * TD + 2 * ch < LD ? t * TD + 2 * ch : LD - 2;
-            v[i] = *reinterpret_cast<const double2*>(a.pos + grow(r) * (int64_t)LD + col);
+            v[i] = *reinterpret_cast<const double2*>(rowptr(r) + (unsigned)col);
         }
     };
     double xc[LD], xo[LD];
@@ -1133,7 +1137,7 @@ __device__ __forceinline__ void half_step_staged_body(const HalfStepFront& f, co
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     };
-    auto own_row = [&](int r) { return a.own_row0 + w0 + (r < rows_here ? r : rows_here - 1); };
+    auto own_row = [&](int r) { return own_base + (unsigned)(r < rows_here ? r : rows_here - 1) * (unsigned)LD; };
     Draw dr;
     double p0;
     if constexpr (kAllAtOnce) {
@@ -1143,7 +1147,7 @@ __device__ __forceinline__ void half_step_staged_body(const HalfStepFront& f, co
         p0 = a.logp[gw];
         const U4 bits = draw_bits(a.dc, step, (uint64_t)(a.gw0 + ic));
         const uint32_t partner = draw_partner(a.dc, bits);              // :250
-        auto oth_row = [&](int r) { return a.oth_row0 + (int64_t)(uint32_t)__shfl((int)partner, r); };
+        auto oth_row = [&](int r) { return a.pos + (a.oth_row0 + (int64_t)(uint32_t)__shfl((int)partner, r)) * (int64_t)LD; };
 #pragma unroll
         for (int t = 0; t < NT; ++t) issue_tile(oth_row, t, voth[t]);
         dr = draw_finish(a.dc, bits);                                   // :252, and the accept test's logarithms
@@ -1155,7 +1159,7 @@ __device__ __forceinline__ void half_step_staged_body(const HalfStepFront& f, co
         p0 = a.logp[gw];
         const U4 bits = draw_bits(a.dc, step, (uint64_t)(a.gw0 + ic));
         const uint32_t partner = draw_partner(a.dc, bits);              // :250
-        auto oth_row = [&](int r) { return a.oth_row0 + (int64_t)(uint32_t)__shfl((int)partner, r); };
+        auto oth_row = [&](int r) { return a.pos + (a.oth_row0 + (int64_t)(uint32_t)__shfl((int)partner, r)) * (int64_t)LD; };
         dr = draw_finish(a.dc, bits);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -1183,6 +1187,7 @@ __device__ __forceinline__ void half_step_staged_body(const HalfStepFront& f, co
     const bool do_mom = !kTileMoments && valid && mom_wave;
     const bool do_chain = sample && a.chain != nullptr;
     const int64_t crow = sch.slot * a.chain_rows + a.chain_row0;        // chain row of this launch's active walker 0
+    double* const chain_base = a.chain + (crow + (int64_t)w0u) * LD;
     if (do_mom) {                                                       // per-lane accumulators, eight dimensions' loads in flight
 #pragma unroll
         for (int d0 = 0; d0 < ND; d0 += 8) {
@@ -1219,10 +1224,9 @@ __device__ __forceinline__ void half_step_staged_body(const HalfStepFront& f, co
                 const int qq = q0 + lane, r = qq / CPR, ch = qq - r * CPR;
                 if (c0 + 2 * ch < LD && r < rows_here) {
                     const double2 v = make_double2(tile[r * (TD + 1) + 2 * ch], tile[r * (TD + 1) + 2 * ch + 1]);
-                    if ((accmask >> r) & 1ull)
-                        *reinterpret_cast<double2*>(a.pos + (a.own_row0 + w0 + r) * (int64_t)LD + c0 + 2 * ch) = v;
-                    if (do_chain)
-                        *reinterpret_cast<double2*>(a.chain + (crow + w0 + r) * (int64_t)LD + c0 + 2 * ch) = v;
+                    const unsigned off = (unsigned)r * (unsigned)LD + (unsigned)(c0 + 2 * ch);
+                    if ((accmask >> r) & 1ull) *reinterpret_cast<double2*>(own_base + off) = v;
+                    if (do_chain) *reinterpret_cast<double2*>(chain_base + off) = v;
                     if constexpr (kTileMoments) { ms.x += v.x; ms.y += v.y; mq.x += v.x * v.x; mq.y += v.y * v.y; }
                 }
             }
