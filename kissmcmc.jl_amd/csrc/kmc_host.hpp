@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -135,4 +136,7 @@ struct kmc_user_density {
     int nblob = 0;                                   // kmc_user_density_create_body_blob: doubles the body writes to blob[] per evaluation
     std::mutex mu;
     std::map<std::string, std::vector<char>> code;   // geometry key -> gfx950 code object
+    // ... and the modules loaded from them, per device: shared by every sampler over this density (hipModuleLoadData is ~0.5 ms,
+    // half of what a sampler of the reference's sizes lives); unloaded when the last holder -- this object or a sampler -- lets go
+    std::map<std::pair<const void*, int>, std::shared_ptr<void>> modules;
 };

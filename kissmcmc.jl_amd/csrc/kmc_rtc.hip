@@ -228,7 +228,19 @@ kmc_status load_user(kmc_user_density* ud, bool with_vec, int L, int K, int iter
 {
     const std::vector<char>* code = nullptr;
     KMC_TRY(compile_user(ud, with_vec, L, K, iter, ragged, resident_K, resident_ragged, island_S, f32, &code, ndim, p2p));
-    HIP_TRY(hipModuleLoadData(&uk->mod, code->data()));
+    {
+        int dev = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        std::lock_guard<std::mutex> lock(ud->mu);
+        auto& slot = ud->modules[{static_cast<const void*>(code), dev}];
+        if (!slot) {
+            hipModule_t m = nullptr;
+            HIP_TRY(hipModuleLoadData(&m, code->data()));
+            slot = std::shared_ptr<void>(static_cast<void*>(m), [](void* p) { if (p) (void)hipModuleUnload(static_cast<hipModule_t>(p)); });
+        }
+        uk->keep = slot;
+        uk->mod = static_cast<hipModule_t>(slot.get());
+    }
     HIP_TRY(hipModuleGetFunction(&uk->generic, uk->mod, "kmc_user_generic"));
     HIP_TRY(hipModuleGetFunction(&uk->logpdf, uk->mod, "kmc_user_logpdf"));
     HIP_TRY(hipModuleGetFunction(&uk->init_ball, uk->mod, "kmc_user_init_ball"));

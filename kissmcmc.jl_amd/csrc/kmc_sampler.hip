@@ -732,7 +732,7 @@ KMC_EXPORT void kmc_sampler_destroy(kmc_sampler* s)
     }
     if (s->ugraph) (void)hipGraphDestroy(s->ugraph);
     if (s->graph_exec) (void)hipGraphExecDestroy(s->graph_exec);
-    if (s->uk.mod) (void)hipModuleUnload(s->uk.mod);
+    s->uk.keep.reset();                 // (the module goes when its last holder does: the density's cache, other samplers)
     if (s->graph) (void)hipGraphDestroy(s->graph);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);

@@ -29,7 +29,8 @@ struct Plan {
 
 // kernels of a runtime-compiled density, loaded from its code object (kmc_rtc.hip)
 struct UserKernels {
-    hipModule_t mod = nullptr;
+    hipModule_t mod = nullptr;          // (owned by `keep`, shared with the density's cache and other samplers)
+    std::shared_ptr<void> keep;
     hipFunction_t vec = nullptr, generic = nullptr, logpdf = nullptr, resident = nullptr, island = nullptr, init_ball = nullptr;
     hipFunction_t staged = nullptr;     // body densities, double rows, ndim <= kStagedMaxDim: half_step_staged_body
 };

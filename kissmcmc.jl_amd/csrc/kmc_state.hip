@@ -551,8 +551,7 @@ KMC_EXPORT kmc_status kmc_logpdf_eval(const kmc_config* cfg, const double* pos_d
         UserKernels uk;
         KMC_TRY(load_user(static_cast<kmc_user_density*>(cfg->user_density), false, 0, 0, 0, false, &uk, 0, false, 0, false, cfg->ndim));
         const hipError_t e = launch_module(uk.logpdf, grid, 256u, (hipStream_t)hip_stream, la);
-        if (e == hipSuccess) (void)hipStreamSynchronize((hipStream_t)hip_stream);   // the module is unloaded below
-        (void)hipModuleUnload(uk.mod);
+        if (e == hipSuccess) (void)hipStreamSynchronize((hipStream_t)hip_stream);   // (uk's hold on the module ends with this scope)
         HIP_TRY(e);
         return KMC_OK;
     }
@@ -626,7 +625,6 @@ KMC_EXPORT kmc_status kmc_logpdf_blob_eval_host(const kmc_config* cfg, const dou
         if (e == hipSuccess) e = hipStreamSynchronize(ss.st);
         if (e == hipSuccess) e = copy_sync(logp_host, dlp, (size_t)nrows * sizeof(double), hipMemcpyDeviceToHost, ss.st);
         if (e == hipSuccess) e = copy_sync(blob_host, dbl, bb, hipMemcpyDeviceToHost, ss.st);
-        (void)hipModuleUnload(uk.mod);
     }
     (void)hipFree(buf);
     if (st != KMC_OK) return st;
