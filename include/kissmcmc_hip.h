@@ -108,7 +108,7 @@ enum {
                                   half; walkers are re-dealt to islands between launches.  Same target distribution, far
                                   fewer kernel boundaries and no HBM traffic inside an epoch.  Needs nwalkers % island_size == 0,
                                   island_size >= ndim + 2, ndim <= 32, shard_count == 1; no chain storage.  Works with user densities
-                                  when island_size * (ndim + 3) * 8 B <= 60 KiB. */
+                                  (their island's rows fit the 160 KiB of LDS for every permitted island_size and ndim). */
     KMC_STREAM_CHAIN = 1u << 11, /* with KMC_STORE_CHAIN / KMC_STORE_LOGP: the chain does NOT live in HBM.  The device keeps a ring of three
                                     blocks of sample slots; every completed block is copied to the caller's host buffers
                                     (kmc_sampler_set_chain_host) by a second stream while sampling goes on, so the number of stored

@@ -311,8 +311,8 @@ KMC_EXPORT kmc_status kmc_validate(const kmc_config* c)
         if ((S != 64 && S != 128 && S != 256) || c->nwalkers % S != 0 || c->ndim > 32 || c->ndim + 2 > S || P != 1 ||
             (c->flags & (KMC_P2P | KMC_STORE_CHAIN | KMC_STORE_LOGP)) || c->island_gens < 0)
             return fail(KMC_ERR_UNSUPPORTED, "KMC_ISLANDS needs island_size in {64,128,256} >= ndim+2 dividing nwalkers, ndim <= 32, one shard and no chain storage");
-        if (c->density == KMC_USER_DENSITY && (size_t)S * (size_t)(2 * c->ndim + 9) * sizeof(double) > 60 * 1024)
-            return fail(KMC_ERR_UNSUPPORTED, "KMC_ISLANDS with a user density: island_size * (ndim + 3) * 8 must stay below 60 KiB (use island_size 128 or 64)");
+        if (c->density == KMC_USER_DENSITY && (size_t)S * (size_t)(2 * c->ndim + 9) * sizeof(double) > 156 * 1024)
+            return fail(KMC_ERR_UNSUPPORTED, "KMC_ISLANDS with a user density: island_size * (2 ndim + 9) * 8 must stay below 156 KiB");
     }
     if (c->flags & KMC_STREAM_CHAIN) {
         if (!(c->flags & (KMC_STORE_CHAIN | KMC_STORE_LOGP))) return fail(KMC_ERR_BAD_ARG, "KMC_STREAM_CHAIN needs KMC_STORE_CHAIN and / or KMC_STORE_LOGP");

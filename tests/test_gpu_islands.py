@@ -118,3 +118,19 @@ def test_island_mode_with_a_runtime_compiled_density(kmc, oracle, S):
     np.testing.assert_array_equal(pos, ref["final_pos"])
     assert mom[2] == ref["nmoment"]
     np.testing.assert_allclose(mom[0], ref["sum"], rtol=1e-11, atol=1e-9)
+
+
+def test_island_mode_with_a_user_density_at_the_largest_island(kmc):
+    """A term / pair density in island mode with 256-walker islands of 32-dimensional rows (146 KiB of LDS -- runtime-compiled
+    kernels used to be held to 60 KiB): the menu density's run, bit for bit."""
+    nd, S = 32, 256
+    out = {}
+    for name, pdf in (("menu", kmc.GaussianIso()), ("expr", kmc.ExprDensity("-0.5*x*x"))):
+        with kmc.Sampler(pdf, 4096, nd, 128, 32, 1, 2.0, 5, moments=True, island_gens=32, island_size=S) as s:
+            assert "island mode" in s.describe()
+            s.set_positions(np.random.default_rng(1).standard_normal((4096, nd)))
+            s.run(128)
+            s.sync()
+            out[name] = (s.positions(), s.naccept())
+    np.testing.assert_array_equal(out["menu"][0], out["expr"][0])
+    np.testing.assert_array_equal(out["menu"][1], out["expr"][1])
