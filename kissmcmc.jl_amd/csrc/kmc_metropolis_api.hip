@@ -85,13 +85,31 @@ kmc_status compile_user_metropolis(kmc_user_density* ud, int ND, const std::vect
 template <class T>
 hipError_t metro_alloc(T** p, size_t bytes) { return cache_alloc(reinterpret_cast<void**>(p), bytes); }
 
+// the loaded module of a code object, shared per (density, code object, device) like the samplers' (kmc_rtc.hip: load_user)
+kmc_status shared_module(kmc_user_density* ud, const std::vector<char>* code, std::shared_ptr<void>* keep, hipModule_t* mod)
+{
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(ud->mu);
+    auto& slot = ud->modules[{static_cast<const void*>(code), dev}];
+    if (!slot) {
+        hipModule_t m = nullptr;
+        HIP_TRY(hipModuleLoadData(&m, code->data()));
+        slot = std::shared_ptr<void>(static_cast<void*>(m), [](void* p) { if (p) (void)hipModuleUnload(static_cast<hipModule_t>(p)); });
+    }
+    *keep = slot;
+    *mod = static_cast<hipModule_t>(slot.get());
+    return KMC_OK;
+}
+
 // device buffers of one kmc_metropolis_run call
 struct MetroBuffers {
     double *pos = nullptr, *logp = nullptr, *chain = nullptr, *chain_logp = nullptr, *csum = nullptr, *csumsq = nullptr,
            *step = nullptr, *xt = nullptr, *yt = nullptr, *st1 = nullptr, *st2 = nullptr, *blob = nullptr, *chain_blob = nullptr;
     uint32_t* naccept = nullptr;
     double* draws = nullptr;          // few chains: the draw table of a launch (metro_draw_fill)
-    hipModule_t mod = nullptr;
+    hipModule_t mod = nullptr;        // (held through keep)
+    std::shared_ptr<void> keep;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipStream_t stream = nullptr;     // the stream the buffers were used on: waited for before they go back to the allocation cache
     ~MetroBuffers()
@@ -100,7 +118,6 @@ struct MetroBuffers {
         cache_free(pos); cache_free(logp); cache_free(chain); cache_free(chain_logp); cache_free(csum);
         cache_free(csumsq); cache_free(step); cache_free(xt); cache_free(yt); cache_free(st1); cache_free(st2);
         cache_free(naccept); cache_free(blob); cache_free(chain_blob); cache_free(draws);
-        if (mod) (void)hipModuleUnload(mod);
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
     }
@@ -128,7 +145,8 @@ kmc_status metropolis_host_route(const kmc_metropolis_config* c, const double* t
                *csumsq = nullptr, *step = nullptr, *h_rows = nullptr, *h_prop = nullptr, *h_p1 = nullptr;
         uint32_t* naccept = nullptr;
         unsigned char *acc = nullptr, *h_acc = nullptr;
-        hipModule_t mod = nullptr;
+        hipModule_t mod = nullptr;        // (held through keep)
+        std::shared_ptr<void> keep;
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
         hipStream_t stream = nullptr;     // waited for before the buffers go back to the allocation cache
         ~Buf()
@@ -140,7 +158,6 @@ kmc_status metropolis_host_route(const kmc_metropolis_config* c, const double* t
             if (h_prop) (void)hipHostFree(h_prop);
             if (h_p1) (void)hipHostFree(h_p1);
             if (h_acc) (void)hipHostFree(h_acc);
-            if (mod) (void)hipModuleUnload(mod);
             if (ev0) (void)hipEventDestroy(ev0);
             if (ev1) (void)hipEventDestroy(ev1);
         }
@@ -181,7 +198,7 @@ kmc_status metropolis_host_route(const kmc_metropolis_config* c, const double* t
         if (c->density == KMC_USER_DENSITY) {
             const std::vector<char>* code = nullptr;
             KMC_TRY(compile_user_metropolis(static_cast<kmc_user_density*>(c->user_density), metropolis_nd(nd), &code, nd));
-            HIP_TRY(hipModuleLoadData(&b.mod, code->data()));
+            KMC_TRY(shared_module(static_cast<kmc_user_density*>(c->user_density), code, &b.keep, &b.mod));
             HIP_TRY(hipModuleGetFunction(&ulp, b.mod, "kmc_user_logpdf"));
         } else {
             HalfStepFn v, g;
@@ -403,7 +420,7 @@ KMC_EXPORT kmc_status kmc_metropolis_run(const kmc_metropolis_config* c, const d
     if (c->density == KMC_USER_DENSITY) {
         const std::vector<char>* code = nullptr;
         KMC_TRY(compile_user_metropolis(static_cast<kmc_user_density*>(c->user_density), ND, &code, nd, tabled ? metropolis_nd(nd) : 0));
-        HIP_TRY(hipModuleLoadData(&b.mod, code->data()));
+        KMC_TRY(shared_module(static_cast<kmc_user_density*>(c->user_density), code, &b.keep, &b.mod));
         HIP_TRY(hipModuleGetFunction(&ufn, b.mod, "kmc_user_metropolis"));
         HIP_TRY(hipModuleGetFunction(&ulp, b.mod, "kmc_user_logpdf"));
         if (tabled) HIP_TRY(hipModuleGetFunction(&utfn, b.mod, "kmc_user_metropolis_tabled"));
