@@ -124,7 +124,16 @@ def test_streamed_by_walker_with_the_copy_kernel(kmc, oracle, monkeypatch):
         s.sync()
         cw, lw = s.chain(by_walker=True)
     ref = _oracle_chain(oracle, oracle.GAUSSIAN_ISO, [0.0, 1.0], th, G, nburn, nthin, seed)
-    np.testing.assert_array_equal(cw, ref["chain"].transpose(1, 0, 2))
+    want = ref["chain"].transpose(1, 0, 2)
+    if not np.array_equal(cw, want):
+        # (seen once, never reproduced -- profiles/NOTES.md: say exactly WHAT differs, as addresses in the host array)
+        bad = np.flatnonzero(cw.ravel() != want.ravel())
+        runs = np.split(bad, np.flatnonzero(np.diff(bad) > 1) + 1)
+        where = ", ".join(f"[{r[0]}..{r[-1]}] (byte {(cw.ctypes.data + 8 * r[0]) % 4096} of its page)" for r in runs[:8])
+        wrong = cw.ravel()[bad[:4]]
+        elsewhere = [np.flatnonzero(want.ravel() == v)[:3].tolist() for v in wrong]
+        pytest.fail(f"{len(bad)} of {cw.size} elements differ, {len(runs)} contiguous runs: {where}; first wrong values {wrong} occur in the "
+                    f"expected array at flat indices {elsewhere}; array base {cw.ctypes.data:#x}, aligned {cw.ctypes.data % 4096}")
     assert np.all(np.abs(lw - ref["chain_logp"].T) <= 1e-12 * np.maximum(1.0, np.abs(ref["chain_logp"].T)))
     monkeypatch.setenv("KMC_NO_HOST_REGISTER", "1")
     with pytest.raises(kmc.KmcError, match="could not be page-locked"):
