@@ -305,7 +305,8 @@ std::atomic<int64_t>& update_budget()
     }()};
     return budget;
 }
-bool update_budget_left() { return g_update_calls.load(std::memory_order_relaxed) < update_budget().load(std::memory_order_relaxed); }
+// room for `need` more parameter updates (a replay of this sampler: 2 * uchunk)?  A replay that would overshoot the budget is not started.
+bool update_budget_left(int64_t need) { return g_update_calls.load(std::memory_order_relaxed) + need <= update_budget().load(std::memory_order_relaxed); }
 
 void note_budget_spent(kmc_sampler* s)
 {
@@ -630,16 +631,16 @@ KMC_EXPORT kmc_status kmc_sampler_run(kmc_sampler* s, int64_t ngen)
         if (env && std::strcmp(env, "graph") == 0) s->launch_mode = 1;
         else if (env && std::strcmp(env, "eager") == 0) s->launch_mode = 2;
         else if (env && std::strcmp(env, "updated") == 0 && updated_graph_possible(s)) { s->launch_mode = 3; s->updated_forced = true; }
-        else if (env && std::strcmp(env, "updated,budget") == 0 && updated_graph_possible(s) && update_budget_left()) s->launch_mode = 3;   // (as if measured: the budget applies)
+        else if (env && std::strcmp(env, "updated,budget") == 0 && updated_graph_possible(s) && update_budget_left(2 * s->uchunk)) s->launch_mode = 3;   // (as if measured: the budget applies)
         else if (!updated_graph_possible(s)) s->launch_mode = 1;
         else if (ngen >= calib_min) {
-            const bool left = update_budget_left();
+            const bool left = update_budget_left(2 * s->uchunk);      // (the measurement itself may overshoot by its six replays; the run after it may not)
             if (!left) note_budget_spent(s);
             KMC_TRY(calibrate(left));
         }
     }
     while (use_graph && s->launch_mode == 3 && ngen >= s->uchunk) {
-        if (!s->updated_forced && !update_budget_left()) {             // the process has used up its leak budget: decide again, between 1 and 2
+        if (!s->updated_forced && !update_budget_left(2 * s->uchunk)) {             // the process has used up its leak budget: decide again, between 1 and 2
             note_budget_spent(s);
             s->launch_mode = 0;
             if (ngen >= calib_min) KMC_TRY(calibrate(false));
