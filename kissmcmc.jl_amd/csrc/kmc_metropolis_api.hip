@@ -413,7 +413,9 @@ KMC_EXPORT kmc_status kmc_metropolis_run(const kmc_metropolis_config* c, const d
     {
         const char* e = std::getenv("KMC_METRO_TABLE");
         const bool off = e && e[0] == '0', on = e && e[0] == '1';
-        tabled = !off && nd <= 8 && nblob == 0 && (nc <= 16384 || on);
+        // (up to 8 dimensions for up to 16 384 chains -- measured --; longer rows for the few chains that leave most of the chip idle)
+        const int64_t nd_max = c->density == KMC_USER_DENSITY ? 32 : 8;       // (menu densities: instantiated up to 8 -- build time)
+        tabled = !off && nblob == 0 && ((nd <= 8 && nc <= 16384) || (nd <= nd_max && nc <= 1024) || (on && nd <= nd_max));
     }
     MetropolisFn fn = nullptr;
     hipFunction_t ufn = nullptr, ulp = nullptr, utfn = nullptr;

@@ -2,6 +2,7 @@
 // translation unit (kmc_inst_<density>.hip) so the build can run them in parallel; the host driver only
 // sees the per-density entry points declared at the bottom.
 #pragma once
+#include <type_traits>
 #include "kmc_islands.hpp"
 #include "kmc_metropolis.hpp"
 
@@ -66,7 +67,7 @@ HalfStepFn vec_lookup(int L, int K, int iter, bool ragged, bool f32)
         KMC_LK(1, 1) KMC_LK(2, 1) KMC_LK(4, 1) KMC_LK(4, 2) KMC_LK(8, 2) KMC_LK(16, 2) KMC_LK(32, 2) KMC_LK(64, 2)
         KMC_LK(64, 4) KMC_LK(64, 8)
 #undef KMC_LK
-        if constexpr (PART == 0) {
+        if constexpr (PART == 0 && std::is_same<D, GaussianIso>::value) {       // (tuning geometries, KMC_PLAN: the bench density only -- build time)
 #define KMC_LK(l, k) if (L == l && K == k) return vec_iter<D, l, k, false, false, double>(iter);
             KMC_LK(8, 1) KMC_LK(16, 1) KMC_LK(32, 1) KMC_LK(64, 1) KMC_LK(4, 4) KMC_LK(8, 4)
 #undef KMC_LK
@@ -188,7 +189,7 @@ MetropolisFn metropolis_lookup(int ndim)
     if (ndim <= 32) return metropolis_chains<D, 32>;
     return metropolis_chains<D, 0>;
 }
-// few chains: the draws from a table (kmc_metropolis.hpp: metropolis_chains_tabled), chains in registers up to 8 dimensions
+// few chains: the draws from a table (kmc_metropolis.hpp: metropolis_chains_tabled), chains in registers up to 8 dimensions (menu densities -- build time; runtime-compiled ones up to 32)
 template <class D>
 MetropolisTabledFn metropolis_tabled_lookup(int ndim)
 {
