@@ -40,6 +40,97 @@ NDIM = 32
 GENS_PER_STEP = 1000
 SEED = 12345
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy rate is 6290 GB/s
+HBM_COPY_GBS = 6290.0   # what a float4 copy achieves on this chip (MI355X_MICROARCH.md:36)
+MALL_BYTES = 256 << 20  # Infinity Cache: a working set below this is served on-die between two uses (MI355X_MICROARCH.md:303-310)
+
+
+def kernel_geometry(describe: str):
+    """The part of kmc_sampler_describe that names the kernel and its launch geometry, e.g.
+    'half_step_vec L=8 K=2 ITER=2 exact-size, grid 1024 x 128' -- what a tracked profile record is matched on."""
+    import re
+    m = re.search(r"half_step_\w+[^;]*?, grid \d+ x \d+", describe or "")
+    return m.group(0) if m else None
+
+
+def kernel_name(pdf, describe: str):
+    """The template instance the describe string stands for, as the kernel trace names it (density first, then L, K, ITER)."""
+    import re
+    m = re.search(r"(half_step_\w+) L=(\d+) K=(\d+) ITER=(\d+) (ragged|exact-size)", describe or "")
+    if m:
+        return f"{m.group(1)}<{type(pdf).__name__}, L={m.group(2)}, K={m.group(3)}, ITER={m.group(4)}, {m.group(5)}>"
+    m = re.search(r"half_step_\w+", describe or "")
+    return f"{m.group(0)}<{type(pdf).__name__}>" if m else (describe or "").split(":")[0]
+
+
+def moment_bytes(describe: str) -> int:
+    """Bytes of streaming-moment accumulators the vector kernel of `describe` touches (kmc_kernels.hpp: accumulate_wave): the
+    transposed fold (K = 2, L = 8/16/32) keeps 8 L / 64 doubles per thread, the plain one 2 K double2 per thread of group 0's slots."""
+    import re
+    m = re.search(r"L=(\d+) K=(\d+) ITER=\d+ \S+, grid (\d+) x (\d+)", describe or "")
+    if not m:
+        return 0
+    L, K, grid, tpb = (int(v) for v in m.groups())
+    threads = grid * tpb
+    return threads * (8 * L // 64) * 8 if (K == 2 and L in (8, 16, 32)) else threads * 2 * K * 16
+
+
+def state_bytes(nrows: int, ndim: int, moments: int = 0) -> int:
+    """Bytes a generation touches: the rows (ld = ndim rounded up to even), the per-walker block {logp f64, naccept u32, klast u32}
+    and the streaming-moment accumulators."""
+    ld = ndim + (ndim & 1)
+    return nrows * ld * 8 + nrows * 16 + moments
+
+
+def profile_record(name: str, geometry):
+    """profiles/traffic_<name>.json -- the tracked record of the rocprofv3 PMC passes and the -DKMC_PROBE build for ONE kernel geometry
+    (scripts/profile_r04.sh + scripts/summarize_r04.py write it).  It is only used when the run it is attached to executed that
+    very geometry; otherwise (None, reason)."""
+    path = os.path.join(ROOT, "profiles", f"traffic_{name}.json")
+    if not os.path.exists(path):
+        return None, f"profiles/traffic_{name}.json is missing"
+    try:
+        rec = json.load(open(path))
+    except Exception as e:  # noqa: BLE001
+        return None, f"profiles/traffic_{name}.json is unreadable ({e})"
+    if rec.get("geometry") != geometry:
+        return None, (f"profiles/traffic_{name}.json was taken from '{rec.get('geometry')}', this run executed '{geometry}': refused")
+    return rec, None
+
+
+def roofline_block(pdf, describe: str, nwalkers_launch: int, ndim: int, launch_us: float, launches: int, state_b: int, record_name: str, use_record: bool = True):
+    """`roofline` of the dominant kernel (one launch = one half-step).  achieved = ALGORITHMIC read bytes ((2 ndim + 1) * 8 per walker-step,
+    SURVEY 8d) / average launch-to-launch time (HIP events).  What is not measured in this run -- PMC traffic, the in-kernel body /
+    boundary split -- comes from the tracked record of that kernel geometry, or is null when the geometries differ."""
+    b_read, b_total = (2 * ndim + 1) * 8, (3 * ndim + 2) * 8
+    alg_read = nwalkers_launch * b_read
+    achieved = alg_read / (launch_us * 1e-6) / 1e9
+    geometry = kernel_geometry(describe)
+    rec, why = profile_record(record_name, geometry) if use_record else (None, "not a single-GPU run")
+    served = "infinity_cache" if state_b <= MALL_BYTES else "hbm"
+    body_us = rec.get("body_us") if rec else None
+    boundary_us = rec.get("boundary_us") if rec else None
+    body_frac = (alg_read / (body_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if body_us else None
+    if served == "hbm":
+        limited = "HBM bandwidth (the state does not fit the Infinity Cache: every row comes from memory each generation)"
+    elif boundary_us and boundary_us / launch_us >= 0.2:
+        limited = (f"kernel boundary + cache latency: the state ({state_b / 2**20:.0f} MiB) is Infinity-Cache resident, the kernel body takes {body_us:.2f} us "
+                   f"of the {launch_us:.2f} us launch period, the dependent-launch boundary the rest")
+    else:
+        limited = f"cache latency / launch boundary: the state ({state_b / 2**20:.0f} MiB) is Infinity-Cache resident (no body / boundary split on record for this geometry)"
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": rec.get("hbm_bytes_per_launch") if rec else None,
+            "frac_of_measured_copy_rate": achieved / HBM_COPY_GBS,
+            "kernel": kernel_name(pdf, describe), "geometry": geometry, "launches": launches, "avg_launch_us": launch_us,
+            "algorithmic_read_bytes_per_launch": alg_read, "algorithmic_total_bytes_per_launch": nwalkers_launch * b_total,
+            "state_bytes": state_b, "served_from": served, "limited_by": limited,
+            "body_us": body_us, "boundary_us": boundary_us, "body_frac": body_frac,
+            "profile_record": ({k: rec.get(k) for k in ("head", "period_us_unprofiled", "hbm_read_bytes_per_launch", "hbm_write_bytes_per_launch", "l2_hit_rate", "source")}
+                               if rec else {"refused": why}),
+            "traffic_source": f"profiles/traffic_{record_name}.json: rocprofv3 --pmc passes (2 x FETCH_SIZE + WRITE_SIZE per launch, gfx950 read correction) and the "
+                              "-DKMC_PROBE in-kernel timeline (body_us = first wave in .. last store issued, boundary_us = the gap to the next launch's first wave) "
+                              "of this kernel geometry, collected separately (scripts/profile_r04.sh) -- a tracked file, matched on `geometry`, not measured in this run",
+            "note": "achieved / frac = algorithmic READ bytes / average launch-to-launch time from HIP events over the timed region (includes the kernel boundary); "
+                    "body_frac = the same bytes / body_us / 8 TB/s; `bound` names the roofline the fraction is priced against, `served_from` / `limited_by` what the data say"}
 
 
 def theta0_c2(nwalkers: int) -> np.ndarray:
@@ -83,6 +174,7 @@ def cpu_baseline(budget_s: float = 10.0):
     env = os.environ.copy()
     env.setdefault("OMP_PROC_BIND", "close")
     env.setdefault("OMP_PLACES", "cores")
+    env.pop("OMP_NUM_THREADS", None)       # (a launcher's per-rank bound -- torch.distributed.run sets 1 -- is not this leg's: it asks for its threads itself)
     r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(budget_s)], env=env, capture_output=True, text=True, timeout=300)
     lines = [l for l in r.stdout.splitlines() if l.startswith('{"value"')]
     if r.returncode != 0 or not lines:
@@ -126,6 +218,16 @@ def cpu_baseline_worker(budget_s: float = 10.0):
             "note": "CPU restatement of the reference algorithm (allocation-free C + OpenMP), not KissMCMC.jl itself (no julia in this image)"}
 
 
+def rank_env_defaults(env, world: int) -> None:
+    """What every rank of an N-rank job needs in its environment BEFORE it imports torch -- set by spawn_ranks for the ranks it
+    starts and by main() for a rank started by torch.distributed.run (the driver's form):
+    HSA_ENABLE_IPC_MODE_LEGACY=0 -- the host driver only supports dmabuf IPC (RCCL, shared device memory);
+    OMP_NUM_THREADS -- a GPU box's container sees every hardware thread of the host but is throttled to its share; N ranks x 256
+    OpenMP threads on 16 CPUs made the host-driven rungs 100x slower (torch.distributed.run itself sets 1 when it is unset)."""
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_threads() // max(1, world))))
+
+
 def spawn_ranks(n: int, argv) -> int:
     """`--gpus n` without a launcher: start the n ranks ourselves (one child process per rank with RANK / LOCAL_RANK /
     WORLD_SIZE / MASTER_* in its environment -- what torch.distributed.run would set), BEFORE anything in this process
@@ -139,16 +241,37 @@ def spawn_ranks(n: int, argv) -> int:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     procs = []
-    for r in range(n):
-        env = os.environ.copy()
-        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
-                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "KMC_BENCH_SELF_SPAWNED": "1"})
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # the host driver only supports dmabuf IPC (RCCL, shared device memory)
-        # like torch.distributed.run: bound each rank's CPU thread pools -- a GPU box's container sees every hardware thread of
-        # the host but is throttled to its share; N ranks x 256 OpenMP threads on 16 CPUs made the host-driven rungs 100x slower
-        env.setdefault("OMP_NUM_THREADS", str(max(1, host_threads() // n)))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env, start_new_session=True,
-                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr, text=r == 0))
+
+    def die_with_parent():
+        """In the child, before exec: SIGTERM when the launcher dies (even by SIGKILL, which it cannot relay itself)."""
+        try:
+            import ctypes
+            ctypes.CDLL(None, use_errno=True).prctl(1, int(signal.SIGTERM), 0, 0, 0)      # PR_SET_PDEATHSIG
+        except Exception:  # noqa: BLE001
+            pass
+
+    # The ranks are sessions of their own (so that exactly their process groups can be signalled): a launcher that is
+    # itself told to stop -- the harness's timeout, Ctrl-C -- must take them with it, or they stay on the GPUs as orphans.
+    stopped_by = []
+
+    def on_signal(signum, _frame):
+        stopped_by.append(signum)
+        raise KeyboardInterrupt
+
+    previous = {sg: signal.signal(sg, on_signal) for sg in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP)}
+    try:
+        for r in range(n):
+            env = os.environ.copy()
+            env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                        "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "KMC_BENCH_SELF_SPAWNED": "1"})
+            rank_env_defaults(env, n)
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env, start_new_session=True, preexec_fn=die_with_parent,
+                                          stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr, text=r == 0))
+    except KeyboardInterrupt:
+        pass
+    if not procs:
+        return 128 + (stopped_by[-1] if stopped_by else signal.SIGINT)
+    print(f"[bench launcher] started ranks: {' '.join(str(p.pid) for p in procs)}", file=sys.stderr, flush=True)
 
     def stop_all(sig):
         for p in procs:
@@ -164,19 +287,38 @@ def spawn_ranks(n: int, argv) -> int:
     reader.start()
     deadline = time.monotonic() + float(os.environ.get("KMC_BENCH_TIMEOUT", 1500))
     status = 0
-    while any(p.poll() is None for p in procs):
-        bad = [p.returncode for p in procs if p.poll() is not None and p.returncode != 0]
-        if bad or time.monotonic() > deadline:
-            status = bad[0] if bad else 124
-            print(f"[bench launcher] {'a rank exited with status ' + str(status) if bad else 'the job ran out of time (KMC_BENCH_TIMEOUT)'}: stopping the others", file=sys.stderr)
-            time.sleep(5.0 if bad else 0.0)      # (a failing rank's peers usually follow by themselves)
-            stop_all(signal.SIGTERM)
-            t_end = time.monotonic() + 10.0
-            while any(p.poll() is None for p in procs) and time.monotonic() < t_end:
-                time.sleep(0.1)
-            stop_all(signal.SIGKILL)
-            break
-        time.sleep(0.05)
+
+    def end_ranks(grace: float = 10.0):
+        """SIGTERM to every rank's process group, a grace period, then SIGKILL."""
+        stop_all(signal.SIGTERM)
+        t_end = time.monotonic() + grace
+        while any(p.poll() is None for p in procs) and time.monotonic() < t_end:
+            time.sleep(0.1)
+        stop_all(signal.SIGKILL)
+
+    try:
+        if stopped_by:
+            raise KeyboardInterrupt
+        while any(p.poll() is None for p in procs):
+            bad = [p.returncode for p in procs if p.poll() is not None and p.returncode != 0]
+            if bad or time.monotonic() > deadline:
+                status = bad[0] if bad else 124
+                print(f"[bench launcher] {'a rank exited with status ' + str(status) if bad else 'the job ran out of time (KMC_BENCH_TIMEOUT)'}: stopping the others", file=sys.stderr)
+                time.sleep(5.0 if bad else 0.0)      # (a failing rank's peers usually follow by themselves)
+                end_ranks()
+                break
+            time.sleep(0.05)
+    except KeyboardInterrupt:
+        sg = stopped_by[-1] if stopped_by else signal.SIGINT
+        print(f"[bench launcher] stopped by signal {sg}: stopping the ranks", file=sys.stderr)
+        status = 128 + sg
+    finally:
+        for sg, h in previous.items():
+            signal.signal(sg, signal.SIG_IGN)        # (nothing may interrupt the clean-up itself)
+        if any(p.poll() is None for p in procs):
+            end_ranks()
+        for sg, h in previous.items():
+            signal.signal(sg, h)
     for p in procs:
         p.wait()
     reader.join(timeout=5.0)
@@ -195,15 +337,21 @@ def spawn_ranks(n: int, argv) -> int:
     return status if status >= 0 else 128 - status
 
 
+LADDER = []      # [{"rung", "ok", "s"}]: every rung of the N > 1 ladder this rank went through, in order (printed with the line)
+
+
 class rung:
     """Bound one rung of the N > 1 ladder (set-up + self-check, a timed run, an extra): when it has not finished after
     `seconds`, this rank reports where it hung and exits non-zero -- the launcher (spawn_ranks, or torch.distributed.run) then
-    ends the job.  A collective that never returns cannot be interrupted from Python, hence a watchdog thread + os._exit."""
+    ends the job.  A collective that never returns cannot be interrupted from Python, hence a watchdog thread + os._exit.
+    Every rung leaves a record {rung, ok, s} in LADDER (ok: no exception left the block and nobody cleared `.ok`), so that a first
+    hardware run can be diagnosed from the JSON line alone."""
 
     def __init__(self, what: str, seconds: float = None):
         self.what = what
         self.seconds = float(os.environ.get("KMC_BENCH_RUNG_TIMEOUT", 300)) if seconds is None else seconds
         self.timer = None
+        self.ok = True
 
     def __enter__(self):
         import threading
@@ -211,6 +359,7 @@ class rung:
         def expired():
             print(f"[rank {os.environ.get('RANK', '0')}] bench.py: '{self.what}' did not finish within {self.seconds:.0f} s (hung collective or "
                   f"peer wait?): giving up; Python stacks of this rank:", file=sys.stderr, flush=True)
+            print(f"[rank {os.environ.get('RANK', '0')}] ladder so far: {json.dumps(LADDER)}", file=sys.stderr, flush=True)
             try:
                 import faulthandler
                 faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
@@ -220,10 +369,12 @@ class rung:
         self.timer = threading.Timer(self.seconds, expired)
         self.timer.daemon = True
         self.timer.start()
+        self.t0 = time.perf_counter()
         return self
 
     def __exit__(self, *exc):
         self.timer.cancel()
+        LADDER.append({"rung": self.what, "ok": bool(self.ok and exc[0] is None), "s": round(time.perf_counter() - self.t0, 3)})
         return False
 
 
@@ -257,17 +408,52 @@ def other_configs(kmc, device: int):
                     launches = s.launch_count        # (counted from set_positions)
                 ms = min(runs)
                 us_half = ms * 1e3 / (2 * G)
-                b_read = (2 * nd + 1) * 8
-                achieved = (nw // 2) * b_read / (us_half * 1e-6) / 1e9
+                how = s.describe()
+                roof = roofline_block(pdf, how, nw // 2, nd, us_half, launches, state_bytes(nw, nd, moment_bytes(how) if kw.get("moments") else 0), name.lower())
                 rec = {"workload": what, "value": nw * G / (ms * 1e-3), "unit": "walker-steps/s", "us_per_half_step": us_half,
                        "us_per_half_step_runs": [r * 1e3 / (2 * G) for r in runs],
-                       "kernel_launches": launches, "algorithmic_read_GBs": achieved, "frac_of_8TBs": achieved / HBM_PEAK_GBS,
-                       "accept_ratio_mean": float(s.accept_ratio().mean()), "execution": s.describe()}
+                       "kernel_launches": launches, "algorithmic_read_GBs": roof["achieved"], "frac_of_8TBs": roof["frac"],
+                       "frac_of_measured_copy_rate": roof["frac_of_measured_copy_rate"], "state_bytes": roof["state_bytes"], "served_from": roof["served_from"],
+                       "accept_ratio_mean": float(s.accept_ratio().mean()), "execution": how}
+                if name != "C1":
+                    rec["roofline"] = roof
                 if kw.get("moments"):
                     msum, msq, n = s.moments()
                     mean = msum / max(1, n)
                     rec["posterior_mean_minmax"] = [float(mean.min()), float(mean.max())]
                 out[name] = rec
+        except Exception as e:  # noqa: BLE001
+            out[name] = {"error": str(e)}
+    # A working set that really lives in HBM (every configuration BASELINE names is Infinity-Cache resident: 8-64 MiB against 256 MiB):
+    # the same kernels, exact rule, on ensembles whose state is 512 MiB -- the initial ensemble drawn on the device (kmc_sampler_init_ball,
+    # N(0, I): nothing of that size crosses the link), a warm-up piece, then the timed piece twice.
+    for name, nw, nd, G in (("HBM_2Mx32", 2097152, 32, 200), ("HBM_512Kx128", 524288, 128, 200)):
+        if os.environ.get("KMC_BENCH_NO_HBM_SHAPES"):
+            break
+        try:
+            pdf = kmc.GaussianIso()
+            with kmc.Sampler(pdf, nw, nd, 2 * G + 64, 64, 1, 2.0, SEED, device=device, moments=True) as s:      # (burn-in = the warm-up piece)
+                s.init_ball(np.zeros(nd), np.ones(nd), seed=SEED)
+                s.run(64)
+                s.sync()
+                runs = []
+                for _ in range(2):
+                    l0 = s.launch_count
+                    s.run(G)
+                    s.sync()
+                    runs.append(s.last_run_ms())
+                    launches = s.launch_count - l0
+                ms = min(runs)
+                us_half = ms * 1e3 / (2 * G)
+                how = s.describe()
+                roof = roofline_block(pdf, how, nw // 2, nd, us_half, launches, state_bytes(nw, nd, moment_bytes(how)), name.lower())
+                msum, msq, n = s.moments()
+                out[name] = {"workload": f"{nw} walkers x {nd}-dim isotropic Gaussian (state {roof['state_bytes'] / 2**20:.0f} MiB > the 256 MiB Infinity Cache), exact partner rule, "
+                                         f"moments on, {G} generations timed after 64 of warm-up (the run continues: no restart)",
+                             "value": nw * G / (ms * 1e-3), "unit": "walker-steps/s", "us_per_half_step": us_half,
+                             "us_per_half_step_runs": [r * 1e3 / (2 * G) for r in runs], "kernel_launches": launches,
+                             "algorithmic_read_GBs": roof["achieved"], "frac_of_8TBs": roof["frac"], "frac_of_measured_copy_rate": roof["frac_of_measured_copy_rate"],
+                             "accept_ratio_mean": float(s.accept_ratio().mean()), "nmoment": int(n), "execution": how, "roofline": roof}
         except Exception as e:  # noqa: BLE001
             out[name] = {"error": str(e)}
     # "report also one run with nthin such that the chain fits (e.g. 50 stored samples/walker)" -- the C2 job with its
@@ -320,6 +506,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the extra driver-timed C1/C3/C5 runs (profiling passes)")
     ap.add_argument("--no-island", action="store_true", help="skip the extra island-mode run (profiling passes)")
+    ap.add_argument("--test-sleep", type=float, default=0.0, help=argparse.SUPPRESS)   # (tests of the launcher: every rank just sleeps)
     if len(sys.argv) >= 2 and sys.argv[1] == "--cpu-baseline-worker":       # (the CPU leg's own process, see cpu_baseline)
         print(json.dumps(cpu_baseline_worker(float(sys.argv[2]) if len(sys.argv) > 2 else 10.0)), flush=True)
         return
@@ -328,6 +515,15 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # no launcher around us: be the launcher (nothing in this process has touched the GPU yet, and nothing will)
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+    if args.test_sleep > 0.0:
+        time.sleep(args.test_sleep)
+        return
+
+    # a rank of an N-rank job started by somebody else (torch.distributed.run, the driver's form): what spawn_ranks gives the
+    # ranks it starts, BEFORE torch -- and with it OpenMP and the HSA runtime -- is loaded
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        rank_env_defaults(os.environ, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ["WORLD_SIZE"])))
 
     import torch
     import kissmcmc_jl_amd as kmc
@@ -374,7 +570,8 @@ def main():
             rccl_version = None
         collective = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks_seen_by_all_reduce": int(seen.item()),
                       "rccl_version": rccl_version, "native_rccl_version": kmc.Sampler.rccl_version(),
-                      "launcher": "bench.py itself (one child process per rank)" if os.environ.get("KMC_BENCH_SELF_SPAWNED") else "external (torch.distributed.run)"}
+                      "launcher": "bench.py itself (one child process per rank)" if os.environ.get("KMC_BENCH_SELF_SPAWNED") else "external (torch.distributed.run)",
+                      "rank_env": {k: os.environ.get(k) for k in ("HSA_ENABLE_IPC_MODE_LEGACY", "OMP_NUM_THREADS")}}
 
     nw = NWALKERS_PER_GPU * world
     G = args.steps * GENS_PER_STEP
@@ -529,6 +726,7 @@ def main():
                 try:
                     with rung(what):
                         d.connect()
+                        fault("allgather_connect")
                 except Exception as e:  # noqa: BLE001
                     print(f"[rank {rank}] native RCCL all-gather set-up failed ({e})", file=sys.stderr)
                     ok = False
@@ -575,8 +773,9 @@ def main():
                           ("lazy pull into local copies, signal kernel", False, False, True),
                           ("lazy pull into local copies, signal folded into the kernel", True, False, True)]
             for label, fold, push, lazy in cands:
-                with rung(f"p2p set-up + self-check ({label})"):
+                with rung(f"p2p set-up + self-check ({label})") as rg:
                     cand = try_p2p(False, fold, push, lazy)
+                    rg.ok = cand is not None
                 if cand is None:
                     continue
                 if len(cands) == 1:
@@ -592,8 +791,9 @@ def main():
                 else:
                     cand.close()
             if drv is None:
-                with rung("p2p set-up + self-check (fine-grained rows)"):
+                with rung("p2p set-up + self-check (fine-grained rows)") as rg:
                     drv = try_p2p(True, False)
+                    rg.ok = drv is not None
                 if drv is not None:
                     p2p_memory = "pull of drawn rows, rows in fine-grained memory, signal kernel"
             if rank == 0 and tried:
@@ -635,6 +835,7 @@ def main():
                     fpos, facc = drv.positions(), drv.naccept()
                     acc = float(facc.sum() / nw / max(1, G - nburn))
                     lazy_stats = drv.sampler.p2p_stats()         # (remote partner draws, pulled) on this rank; (0, 0) unless lazy ran
+                    how = drv.sampler.describe()
                     drv.close()
             except Exception as e:  # noqa: BLE001  (e.g. a peer wait that timed out: every rank then takes the fallback)
                 print(f"[rank {rank}] the p2p run failed ({e})", file=sys.stderr)
@@ -657,6 +858,7 @@ def main():
                     print("[rank 0] the TIMED sharded run differs from the unsharded run of the same job", file=sys.stderr)
             parallelism = (f"walker-sharded x{world}, exact partner rule, peer-to-peer exchange over xGMI (IPC): {p2p_memory}; "
                            "progress-flag ordering")
+            value_from = 'p2p warm-up + timed run'
         else:
             # The exchange the north star names: an RCCL all-gather of the updated half after every half-step.  Native form
             # first (kmc_sampler_run enqueues kernel + ncclAllGather per half-step, inside the hipGraph chunks); if that cannot
@@ -681,9 +883,10 @@ def main():
                     launches = nat.sampler.launch_count
                     msum, msq, nmom = nat.moments()
                     facc, fpos = nat.naccept(), nat.positions()
-                    how_nat = nat.sampler.describe()
+                    how_nat = how = nat.sampler.describe()
                     nat.close()
                 parallelism = f"walker-sharded x{world}, exact partner rule, native RCCL all-gather of the updated half per half-step ({how_nat.split(';')[-1].strip()})"
+                value_from = 'native RCCL all-gather warm-up + timed run'
             else:
                 with rung('torch-collective all-gather warm-up + timed run'):
                     ex = HipShardExecutor(pdf, nw, NDIM, G, nburn, 1, 2.0, SEED, rank=rank, world=world, device=local_rank)
@@ -709,8 +912,10 @@ def main():
                     msum, msq, nmom = sdrv.moments()
                     facc = sdrv.naccept()
                     fpos = sdrv.positions()
+                    how = ex.sampler.describe()
                     ex.close()
                 parallelism = f"walker-sharded x{world}, exact partner rule, RCCL all-gather of the updated half per half-step (torch collective per half-step)"
+                value_from = 'torch-collective all-gather warm-up + timed run'
             acc = float(facc.sum() / nw / max(1, G - nburn))
             if rank == 0:
                 rpos, racc, (rs, rq, rn) = unsharded(G)
@@ -813,19 +1018,11 @@ def main():
         value = steps_total / elapsed
         mean = msum / max(1, nmom)
         var = msq / max(1, nmom) - mean ** 2
-        # dominant kernel: half_step_vec<GaussianIso,...>; one launch = one half-step of this rank
+        # dominant kernel: the half-step kernel `how` describes; one launch = one half-step of this rank
         walkers_per_launch = NWALKERS_PER_GPU // 2
-        b_read = (2 * NDIM + 1) * 8
-        b_total = (3 * NDIM + 2) * 8
         launch_us = event_ms * 1e3 / max(1, launches)
-        achieved = walkers_per_launch * b_read / (launch_us * 1e-6) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_c2.json")
-        if not sharded and os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        rows_here = NWALKERS_PER_GPU if (sharded and mode == "p2p") else nw             # (replica modes hold the whole ensemble)
+        roof = roofline_block(pdf, how, walkers_per_launch, NDIM, launch_us, launches, state_bytes(rows_here, NDIM, moment_bytes(how)), "c2", use_record=not sharded)
         out = {
             "metric": "walker-steps/sec", "value": value, "unit": "walker-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps,
@@ -834,22 +1031,16 @@ def main():
                                    f"{G} generations (burn-in {nburn}), a=2, streaming moments on, chain off",
                        "nwalkers_total": nw, "ndim": NDIM, "generations": G, "gens_per_step": GENS_PER_STEP,
                        "parallelism": "single GPU" if not sharded else parallelism,
-                       "execution": how if not sharded else None},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "half_step_vec<GaussianIso>", "launches": launches, "avg_launch_us": launch_us,
-                         "algorithmic_read_bytes_per_launch": walkers_per_launch * b_read,
-                         "algorithmic_total_bytes_per_launch": walkers_per_launch * b_total,
-                         "traffic_source": "profiles/traffic_c2.json: rocprofv3 --pmc passes of this same command (2 x FETCH_SIZE + WRITE_SIZE "
-                                           "per launch, gfx950 read correction), collected separately -- a tracked file, not measured in this run",
-                         "note": "achieved = algorithmic READ bytes ((2*ndim+1)*8 B per walker-step) / average launch-to-launch "
-                                 "time from HIP events over the timed region (includes the ~1.5 us kernel boundary)"},
+                       "execution": how},
+            "roofline": roof,
             "check": {"accept_ratio_mean": acc, "posterior_mean_absmax": float(np.abs(mean).max()),
                       "posterior_var_min": float(var.min()), "posterior_var_max": float(var.max()),
                       "nmoment": int(nmom)},
         }
         if sharded:
             out["collective"] = collective
+            out["ladder"] = LADDER                   # every rung rank 0 went through: {rung, ok, s}
+            out["value_from"] = value_from           # the rung whose timed run is `value`
             out["check"]["timed_run_equals_unsharded_run"] = verified
             out["dealt_mode"] = dealt
             if allgather_extra is not None:

@@ -61,6 +61,16 @@ def main():
             print(f"    wave duration median {np.median(a[:, 7] - a[:, 0]):.2f} (p90 {np.percentile(a[:, 7] - a[:, 0], 90):.2f})")
         print(f" boundary: last wave of half 0 ends {t[0, :, 7].max():.2f}, first wave of half 1 enters {t[1, :, 0].min():.2f} "
               f"-> gap {t[1, :, 0].min() - t[0, :, 7].max():.2f} us; launch period {t[1, :, 0].min() - t[0, :, 0].min():.2f} us")
+        # machine-readable: what scripts/summarize_r04.py puts into profiles/traffic_<config>.json (body = first wave in .. last
+        # store issued; boundary = the gap to the next launch's first wave; both of the -DKMC_PROBE build, whose stamps cost a little)
+        import json
+        import re
+        how = s.describe()
+        m = re.search(r"half_step_\w+[^;]*?, grid \d+ x \d+", how)
+        print("PROBE_JSON " + json.dumps({"config": name, "moments": int(mom), "geometry": m.group(0) if m else None, "waves_stamped": nwave,
+                                          "body_us": float(t[0, :, 7].max() - t[0, :, 0].min()), "boundary_us": float(t[1, :, 0].min() - t[0, :, 7].max()),
+                                          "period_us_in_kernel": float(t[1, :, 0].min() - t[0, :, 0].min()), "period_us_hip_events_probe_build": ms / 2048 * 1e3,
+                                          "wave_duration_median_us": float(np.median(t[0, :, 7] - t[0, :, 0]))}))
         s.close()
 
 

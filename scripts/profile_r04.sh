@@ -1,0 +1,44 @@
+#!/bin/bash
+# Round-4 rocprofv3 passes (GPU box): bash scripts/profile_r04.sh
+#   c2/kt                 kernel trace + stats of the headline command (bench.py, C2)
+#   c2/{fetch,write,l2}   PMC passes of the same command (one counter group per pass, --kernel-trace only, as the pool requires)
+#   c3, c5, hbm32, hbm128 the same four passes over scripts/run_cfg.py (bench.py's other_configs shapes; hbm*: state 512 MiB)
+#   probe_<cfg>.txt       in-kernel timeline of the -DKMC_PROBE build (scripts/probe_timeline.py): body / boundary per launch
+# The program itself follows "--" (python3 <script>), never a wrapper.  Condense HERE (the build container has git) with
+# scripts/summarize_r04.py -> profiles/r04_*_summary.json and profiles/traffic_<cfg>.json.
+set -e
+cd /tmp && export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$R/gpurun_out/prof_r04
+rm -rf $OUT && mkdir -p $OUT
+BENCH="python3 $R/bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs --no-island"
+$BENCH > $OUT/c2_unprofiled.json 2> $OUT/c2_unprofiled.err
+echo "unprofiled bench done"
+mkdir -p $OUT/c2
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c2/kt -o t -- $BENCH > $OUT/c2/kt.json 2> $OUT/c2/kt.err
+echo "c2 kernel trace done"
+for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" "l2 TCC_HIT_sum TCC_MISS_sum"; do
+    set -- $pass; name=$1; shift
+    rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/c2/$name -o t -- $BENCH > $OUT/c2/$name.json 2> $OUT/c2/$name.err
+    echo "c2 $name done"
+done
+for spec in "C3 1024 c3" "C5 256 c5" "HBM32 100 hbm32" "HBM128 100 hbm128"; do
+    set -- $spec; cfg=$1; G=$2; lc=$3
+    mkdir -p $OUT/$lc
+    python3 $R/scripts/run_cfg.py $cfg $G 1 > $OUT/$lc/unprofiled.txt 2>&1
+    rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$lc/kt -o t -- python3 $R/scripts/run_cfg.py $cfg $G 1 > $OUT/$lc/kt.txt 2>&1
+    for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" "l2 TCC_HIT_sum TCC_MISS_sum"; do
+        set -- $pass; name=$1; shift
+        rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$lc/$name -o t -- python3 $R/scripts/run_cfg.py $cfg $G 1 > $OUT/$lc/$name.txt 2>&1
+    done
+    echo "$lc passes done"
+done
+# the counter CSVs of the PMC passes carry their own kernel-trace rows; drop duplicate big traces
+find $OUT -path "*fetch*" -name "*kernel_trace.csv" -delete
+find $OUT -path "*write*" -name "*kernel_trace.csv" -delete
+find $OUT -path "*l2*" -name "*kernel_trace.csv" -delete
+for cfg in C2 C3 C5; do
+    python3 $R/scripts/probe_timeline.py $cfg > $OUT/probe_$cfg.txt 2>&1
+    echo "probe $cfg done"
+done
+du -sh $OUT

@@ -1,5 +1,6 @@
 """Run one BASELINE config twice for a number of generations -- warm-up, then timed (a plain target for rocprofv3).
-Usage: python3 scripts/run_cfg.py C5 [generations] [moments 0/1]"""
+Usage: python3 scripts/run_cfg.py C5 [generations] [moments 0/1]
+HBM32 / HBM128: the HBM-resident shapes of bench.py's other_configs (state 512 MiB; initial ensemble drawn on the device)."""
 import os
 import sys
 
@@ -13,19 +14,24 @@ CONFIGS = {
     "C3": (kmc.Rosenbrock(), 16384, 64),
     "C5": (kmc.GaussianIso(), 8192, 1024),
     "C1": (kmc.Exponential(), 100, 1),
+    "HBM32": (kmc.GaussianIso(), 2097152, 32),
+    "HBM128": (kmc.GaussianIso(), 524288, 128),
 }
 name = sys.argv[1]
 G = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 mom = bool(int(sys.argv[3])) if len(sys.argv) > 3 else True
 pdf, nw, nd = CONFIGS[name]
-rng = np.random.default_rng(0)
-th = rng.standard_normal((nw, nd))
-if name == "C1":
-    th = 0.5 + 0.1 * np.abs(th)
-if name == "C3":
-    th *= 0.1
 with kmc.Sampler(pdf, nw, nd, 10 ** 9, 0, 1, 2.0, 7, moments=mom) as s:
-    s.set_positions(th)
+    if name.startswith("HBM"):
+        s.init_ball(np.zeros(nd), np.ones(nd), seed=7)
+    else:
+        rng = np.random.default_rng(0)
+        th = rng.standard_normal((nw, nd))
+        if name == "C1":
+            th = 0.5 + 0.1 * np.abs(th)
+        if name == "C3":
+            th *= 0.1
+        s.set_positions(th)
     s.run(G)            # warm-up: code objects, graph instantiation, launch-mode measurement
     s.sync()
     s.run(G)            # timed (HIP events on the sampler's stream); a trace's second half of dispatches is this run

@@ -80,6 +80,61 @@ def test_bench_two_ranks_under_torch_distributed_run():
     assert out["n_gpus"] == 2 and out["check"]["timed_run_equals_unsharded_run"] is True
     assert out["collective"]["launcher"].startswith("external") and "allgather_mode" not in out
     assert "[bench launcher]" not in r.stderr
+    # the peer-to-peer rung supplied `value` (not a fallback), every rank was seen, the dealt extra ran
+    assert "peer-to-peer exchange" in out["config"]["parallelism"]
+    assert out["collective"]["ranks_seen_by_all_reduce"] == 2 and out["collective"]["world_size"] == 2
+    assert "error" not in out["dealt_mode"], out["dealt_mode"]
+    assert out["dealt_mode"]["deals"] == 1000 // 64
+    assert out["value_from"] == "p2p warm-up + timed run"
+    rungs = {r_["rung"]: r_ for r_ in out["ladder"]}
+    assert all(r_["ok"] for r_ in out["ladder"]), out["ladder"]
+    assert {"process-group rendezvous", "p2p warm-up + timed run", "dealt sub-ensembles (extra)"} <= set(rungs)
+    assert any(k.startswith("p2p set-up + self-check") for k in rungs)
+    assert all(r_["s"] >= 0.0 for r_ in out["ladder"])
+    # a rank started by torch.distributed.run gets the same environment as one bench.py starts itself
+    assert out["collective"]["rank_env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert int(out["collective"]["rank_env"]["OMP_NUM_THREADS"]) >= 1
+    assert out["roofline"]["kernel"].startswith("half_step_vec<GaussianIso") and out["roofline"]["traffic"] is None
+
+
+def test_bench_ladder_records_the_failed_rung():
+    """A rung that fails on one rank is on record as not ok -- on every rank, rank 0's list is printed -- and `value_from` names the
+    rung that supplied `value` instead."""
+    out, err = run_bench({"KMC_BENCH_FAULT": "p2p_selfcheck:0", "KMC_BENCH_RUNG_TIMEOUT": "120"})
+    common_checks(out)
+    failed = [r_ for r_ in out["ladder"] if not r_["ok"]]
+    assert len(failed) >= 1 and failed[0]["rung"].startswith("p2p set-up + self-check")
+    assert out["value_from"].endswith("all-gather warm-up + timed run")
+
+
+def bench_single(env_extra, launcher):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "OMP_NUM_THREADS")}
+    env.update(env_extra)
+    tail = [os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-other-configs", "--no-island"]
+    r = subprocess.run([sys.executable, *launcher, *tail], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-4000:]
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith('{"metric"')][-1])
+
+
+def test_bench_one_gpu_under_torch_distributed_run_equals_the_plain_call():
+    """The N = 1 point of a scaling series launched like the N > 1 points (python -m torch.distributed.run --nproc-per-node 1: WORLD_SIZE=1,
+    OMP_NUM_THREADS=1, ...) must be the same measurement as the plain `python bench.py`: same kernel and launch mode, `value` within 3 %."""
+    import socket
+    for attempt in range(2):                                        # (a shared box: one repetition of the pair)
+        plain = bench_single({}, [])
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        under = bench_single({}, ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port)])
+        assert under["n_gpus"] == 1 and plain["n_gpus"] == 1
+        assert under["config"]["parallelism"] == plain["config"]["parallelism"] == "single GPU"
+        assert under["config"]["execution"].split(" (measured")[0] == plain["config"]["execution"].split(" (measured")[0]
+        assert under["roofline"]["geometry"] == plain["roofline"]["geometry"] and under["roofline"]["kernel"] == plain["roofline"]["kernel"]
+        assert under["check"] == plain["check"]                     # the same job, bit for bit
+        rel = abs(under["value"] / plain["value"] - 1.0)
+        if rel <= 0.03:
+            break
+    assert rel <= 0.03, (plain["value"], under["value"])
 
 
 def test_bench_sharded_ladder_over_real_rccl_with_one_rank():

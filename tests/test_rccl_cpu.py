@@ -63,3 +63,40 @@ def test_bench_launcher_is_not_used_under_a_launcher():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "needs an MI355X" in r.stderr and "[bench launcher]" not in r.stderr
+
+
+def test_bench_launcher_takes_its_ranks_down_when_it_is_stopped():
+    """The ranks are sessions of their own; a launcher that is told to stop (the harness's timeout sends SIGTERM) must end them -- not
+    leave them on the GPUs as orphans -- and exit non-zero.  (--test-sleep: every rank just sleeps; no GPU involved.)"""
+    import re
+    import signal
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--test-sleep", "120"], env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    line = ""
+    t_end = time.monotonic() + 60
+    while "started ranks:" not in line and time.monotonic() < t_end:
+        line = p.stderr.readline()
+    pids = [int(v) for v in re.findall(r"\d+", line.split("started ranks:")[1])]
+    assert len(pids) == 2
+    time.sleep(0.5)
+    for pid in pids:
+        os.kill(pid, 0)                          # alive
+    p.send_signal(signal.SIGTERM)
+    rc = p.wait(timeout=40)
+    assert rc == 128 + signal.SIGTERM
+    t_end = time.monotonic() + 15
+    alive = pids
+    while alive and time.monotonic() < t_end:
+        nxt = []
+        for pid in alive:
+            try:
+                os.kill(pid, 0)
+                nxt.append(pid)
+            except ProcessLookupError:
+                pass
+        alive = nxt
+        time.sleep(0.1)
+    assert not alive, f"ranks {alive} outlived their launcher"
+    assert "stopping the ranks" in p.stderr.read()
