@@ -31,6 +31,8 @@ SHAPES = {"c2": ("c2", 65536, 32, "65536 x 32 GaussianIso, moments on"),
 
 
 def head():
+    if os.environ.get("KMC_PROFILE_HEAD"):          # (the passes ran on a snapshot of that commit; the tree has moved on since)
+        return os.environ["KMC_PROFILE_HEAD"]
     try:
         h = subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
         dirty = subprocess.run(["git", "status", "--porcelain", "--", "kissmcmc.jl_amd/csrc", "bench.py"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
@@ -119,8 +121,8 @@ def main():
         if pr is not None and pr.get("geometry") == out["geometry"]:
             body, boundary, src = pr["body_us"], pr["boundary_us"], f"-DKMC_PROBE build, gpurun_out/prof_r04/probe_{cfg.upper()}.txt (profiles/{tag}_probe_timeline.txt)"
             out["probe"] = pr
-        elif live and dur < 0.98 * live and live > 30.0:
-            body, boundary, src = dur, live - dur, "kernel trace mean duration (a ~100 us kernel: the tool's per-dispatch cost is < 2 %); boundary = unprofiled period - duration"
+        elif live and live > 30.0 and dur <= 1.02 * live:
+            body, boundary, src = dur, max(live - dur, 0.0), "kernel trace mean duration (a ~100 us kernel: the tool's per-dispatch cost is < 2 %); boundary = unprofiled period - duration"
         else:
             body = boundary = None
             src = "none on record (probe geometry differs or trace distorted)"
