@@ -35,7 +35,20 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-NWALKERS_PER_GPU = int(os.environ.get("KMC_BENCH_WALKERS", 65536))   # (override: rehearsing several ranks on ONE GPU only)
+
+
+def bench_test_opt(name: str, default=None):
+    """KMC_BENCH_TEST="opt[=value],opt,...": the switches only the tests of this file use (README): backend=gloo and walkers=n
+    (several ranks rehearsed on ONE GPU), force-sharded (the N > 1 code path with one rank over real RCCL), fault=point:rank (one rank
+    fails at a point of the ladder), no-allgather-extra, deal-epoch=n, no-hbm-shapes."""
+    for item in os.environ.get("KMC_BENCH_TEST", "").split(","):
+        k, _, v = item.partition("=")
+        if k == name:
+            return v if v else True
+    return default
+
+
+NWALKERS_PER_GPU = int(bench_test_opt("walkers", 65536))   # (override: rehearsing several ranks on ONE GPU only)
 NDIM = 32
 GENS_PER_STEP = 1000
 SEED = 12345
@@ -428,7 +441,7 @@ def other_configs(kmc, device: int):
     # the same kernels, exact rule, on ensembles whose state is 512 MiB -- the initial ensemble drawn on the device (kmc_sampler_init_ball,
     # N(0, I): nothing of that size crosses the link), a warm-up piece, then the timed piece twice.
     for name, nw, nd, G in (("HBM_2Mx32", 2097152, 32, 200), ("HBM_512Kx128", 524288, 128, 200)):
-        if os.environ.get("KMC_BENCH_NO_HBM_SHAPES"):
+        if bench_test_opt("no-hbm-shapes"):
             break
         try:
             pdf = kmc.GaussianIso()
@@ -535,16 +548,16 @@ def main():
         args.gpus = world                        # the launcher decides (python -m torch.distributed.run --nproc-per-node N)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP emcee path has no CPU fallback")
-    # one rank per GPU; (testing only: KMC_BENCH_BACKEND=gloo lets several ranks share one GPU,
+    # one rank per GPU; (testing only: KMC_BENCH_TEST=backend=gloo lets several ranks share one GPU,
     # which RCCL refuses -- the peer-to-peer exchange itself is the same code)
-    if world > torch.cuda.device_count() and os.environ.get("KMC_BENCH_BACKEND", "nccl") == "nccl":
+    if world > torch.cuda.device_count() and bench_test_opt("backend", "nccl") == "nccl":
         raise SystemExit(f"bench.py --gpus {world}: one rank per GPU over RCCL, but this node shows {torch.cuda.device_count()} device(s) "
-                         "(KMC_BENCH_BACKEND=gloo rehearses several ranks on fewer devices)")
+                         "(KMC_BENCH_TEST=backend=gloo rehearses several ranks on fewer devices)")
     local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
-    # KMC_BENCH_FORCE_SHARDED=1 (testing): take the N > 1 code path with ONE rank -- the whole ladder over the real collective
+    # KMC_BENCH_TEST=force-sharded (testing): take the N > 1 code path with ONE rank -- the whole ladder over the real collective
     # backend (RCCL communicator of one rank, captured all-gathers, all_to_all_single of the dealt mode) on a one-GPU box
-    sharded = world > 1 or os.environ.get("KMC_BENCH_FORCE_SHARDED") == "1"
+    sharded = world > 1 or bool(bench_test_opt("force-sharded"))
     dist = None
     if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -552,7 +565,7 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         import torch.distributed as dist
-        backend = os.environ.get("KMC_BENCH_BACKEND", "nccl")
+        backend = bench_test_opt("backend", "nccl")
         import datetime
         with rung("process-group rendezvous"):
             if backend == "nccl":
@@ -637,9 +650,9 @@ def main():
         drv = None
 
         def fault(point: str):
-            """KMC_BENCH_FAULT=<point>:<rank> (testing): that rank fails at that point of the ladder -- every rank must then take
+            """KMC_BENCH_TEST=fault=<point>:<rank> (testing): that rank fails at that point of the ladder -- every rank must then take
             the next rung together."""
-            if os.environ.get("KMC_BENCH_FAULT") == f"{point}:{rank}":
+            if bench_test_opt("fault") == f"{point}:{rank}":
                 raise RuntimeError(f"injected fault at {point}")
 
         def all_ok(flag: bool) -> bool:
@@ -930,7 +943,7 @@ def main():
         dealt = None
         try:
             from kissmcmc_jl_amd.distributed import DealtEmcee, HipDealExecutor
-            epoch = int(os.environ.get("KMC_BENCH_DEAL_EPOCH", 64))
+            epoch = int(bench_test_opt("deal-epoch", 64))
             dex, okd = None, True
             try:                                         # local part first, then a vote: nobody enters the collectives alone
                 fault("dealt_setup")
@@ -976,7 +989,7 @@ def main():
     # of the updated half after every half-step, enqueued with the kernels inside the hipGraph chunks -- on a bounded piece
     # of the same job, so that both exchanges are on record from the same node.
     allgather_extra = None
-    if sharded and mode == "p2p" and os.environ.get("KMC_BENCH_NO_ALLGATHER_EXTRA") is None:
+    if sharded and mode == "p2p" and not bench_test_opt("no-allgather-extra"):
         try:
             from kissmcmc_jl_amd.distributed import AllGatherEmcee
             ag = make_allgather('native RCCL all-gather set-up (extra)')

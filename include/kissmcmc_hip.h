@@ -131,6 +131,10 @@ enum {
                                    (reduce_blob! with the default push!, :196, :270); read with kmc_sampler_get_blobs.  The
                                    blob of every walker's CURRENT position (blob0s, :210, :264) is kept regardless. */
     KMC_P2P_FINEGRAINED = 1u << 7, /* with KMC_P2P: keep the rows in fine-grained (coherent, uncached-for-peers) device memory */
+    /* The next three exist only in a library built with -DKMC_P2P_EXPERIMENTAL (kmc_has_p2p_experimental() == 1; the default
+       library answers KMC_ERR_UNSUPPORTED): peers write into plain device memory that the local kernel reads through its own
+       L2, which no test on ONE GPU can validate.  The default exchange under KMC_P2P is the pull of the drawn rows with
+       system-scope loads, ordered by a separate signal kernel. */
     KMC_P2P_PUSH    = 1u << 9, /* with KMC_P2P: every rank keeps local copies ("shadows") of all the other shards and reads its
                                   partner rows from them; a rank that accepts a move writes the new row into its shadow on
                                   every peer as well (posted write-through stores over xGMI).  Only accepted rows cross the
@@ -203,16 +207,21 @@ typedef struct kmc_user_density kmc_user_density; /* opaque */
 
 /* ---- library ---- */
 int         kmc_version(void);
-/* sizeof(kmc_config) / sizeof(kmc_metropolis_config) as this library was built: a binding checks them against its own
-   mirror of the structs when it loads the library, so layout drift fails loudly before the first real call. */
+/* sizeof(kmc_config) / sizeof(kmc_metropolis_config) / sizeof(kmc_outputs) / sizeof(kmc_metropolis_outputs) as this library was
+   built: a binding checks them against its own mirror of the structs when it loads the library, so layout drift fails loudly
+   before the first real call (a SHORTER stale kmc_outputs would have the library read -- and write through -- `blobs` past its end). */
 int         kmc_sizeof_config(void);
 int         kmc_sizeof_metropolis_config(void);
+int         kmc_sizeof_outputs(void);
+int         kmc_sizeof_metropolis_outputs(void);
+/* 1 when the library was built with -DKMC_P2P_EXPERIMENTAL (KMC_P2P_PUSH / KMC_P2P_LAZY / KMC_P2P_FOLD_SIGNAL are accepted), else 0. */
+int         kmc_has_p2p_experimental(void);
 int         kmc_device_count(void);
 /* hipMemGetInfo of a device (a caller deciding between a device-resident chain and KMC_STREAM_CHAIN; reference
  * src/samplers.jl:268-272 grows the chain without bound). */
 kmc_status  kmc_device_free_bytes(int device, uint64_t* free_bytes, uint64_t* total_bytes);
 /* Small device buffers of samplers are recycled through a per-device cache (blocks of up to 8 MiB, at most 128 MiB held;
- * KMC_NO_ALLOC_CACHE=1 turns it off): a sampler of the reference's own sizes otherwise spends more time in hipMalloc / hipFree
+ * KMC_DEBUG=poison turns it off): a sampler of the reference's own sizes otherwise spends more time in hipMalloc / hipFree
  * than sampling (the README call: 1.7 ms -> 1.0 ms).  This returns every block the cache holds to the device; kmc_device_free_bytes
  * counts held blocks as free. */
 void        kmc_device_cache_release(void);
@@ -232,7 +241,7 @@ double      kmc_cdf_g_inv(double u, double a);
  *        term_expr may use  x (= x_d), d, n (= ndim), p (const double*, = params[0..5]);
  *        pair_expr may use  x (= x_d), y (= x_{d+1}), d, n, p;   NULL/"" = no pair term.
  *      Compiled code objects are cached on disk ($KMC_CACHE_DIR, else ~/.cache/kissmcmc_hip; keyed by the program, the kernel
- *      headers, the options and the hiprtc version; KMC_NO_DISK_CACHE=1 disables), so later processes skip the compiler.
+ *      headers, the options and the hiprtc version; KMC_CACHE_DIR=off disables), so later processes skip the compiler.
  *      A term may evaluate to -INFINITY to reject a proposal.  Works in the multi-launch, resident and
  *      island modes and under KMC_P2P (the plain pull; the push / lazy / folded-signal variants are menu densities only). */
 kmc_status  kmc_user_density_create(const char* term_expr, const char* pair_expr, kmc_user_density** out);
@@ -300,7 +309,7 @@ kmc_status  kmc_rccl_version(int* version, char* path_buf /* may be NULL */, int
 /* The same wiring for shards that live in ONE process on one device (no IPC): shards[r] = the sampler of shard r.
    They run concurrently on their own streams like ranks on separate GPUs (single-process tests, timing, profiling). */
 kmc_status  kmc_sampler_p2p_connect_local(kmc_sampler* s, kmc_sampler* const* shards /* [shard_count] */);
-/* KMC_P2P_LAZY, sampler created with KMC_P2P_STATS=1 in the environment (diagnostics: the counting costs same-address
+/* KMC_P2P_LAZY, sampler created with KMC_DEBUG=p2p-stats in the environment (diagnostics: the counting costs same-address
    atomics; zeros otherwise): counts since kmc_sampler_set_positions -- out[0] = partner draws that fell on another rank's rows,
    out[1] = those of them that were pulled over the fabric (the others were served by the local copy). */
 kmc_status  kmc_sampler_p2p_stats(kmc_sampler* s, uint64_t out[2]);

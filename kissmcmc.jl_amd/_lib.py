@@ -42,12 +42,12 @@ SYMBOLS = [
     "kmc_sampler_get_logp", "kmc_sampler_get_naccept", "kmc_sampler_get_accept_ratio",
     "kmc_sampler_get_moments", "kmc_sampler_get_chain", "kmc_sampler_get_chain_by_walker", "kmc_logpdf_eval", "kmc_logpdf_eval_host",
     "kmc_user_density_create", "kmc_user_density_create_body", "kmc_user_density_destroy", "kmc_metropolis_validate", "kmc_metropolis_run", "kmc_int_acorr", "kmc_sampler_int_acorr",
-    "kmc_sizeof_config", "kmc_sizeof_metropolis_config", "kmc_deal_seed", "kmc_deal_perm", "kmc_sampler_deal_pack", "kmc_sampler_deal_unpack",
+    "kmc_sizeof_config", "kmc_sizeof_metropolis_config", "kmc_sizeof_outputs", "kmc_sizeof_metropolis_outputs", "kmc_deal_seed", "kmc_deal_perm", "kmc_sampler_deal_pack", "kmc_sampler_deal_unpack",
     "kmc_sampler_get_walker_ids", "kmc_sampler_set_walker_ids", "kmc_sampler_set_chain_host", "kmc_rccl_unique_id", "kmc_sampler_rccl_init",
     "kmc_sampler_rccl_capture", "kmc_sampler_rccl_set_capture", "kmc_rccl_version", "kmc_device_free_bytes",
     "kmc_sampler_launch_mode", "kmc_updated_budget", "kmc_set_updated_budget_mb", "kmc_debug_accept_terms",
     "kmc_user_density_create_body_blob", "kmc_user_density_nblob", "kmc_logpdf_blob_eval_host", "kmc_sampler_get_blobs",
-    "kmc_device_cache_release",
+    "kmc_device_cache_release", "kmc_has_p2p_experimental",
 ]
 
 
@@ -152,7 +152,7 @@ def lib() -> C.CDLL:
     # PyTorch wheels bundle their own HIP/HSA runtime.  If this library (linked against
     # /opt/rocm) initialises HIP before torch's copies are loaded, torch later finds no GPU; loading
     # torch's libraries first keeps both usable in one process.  Pure C-ABI users are unaffected.
-    if os.environ.get("KMC_NO_TORCH_PRELOAD") != "1":
+    if "no-torch-preload" not in os.environ.get("KMC_DEBUG", "").split(","):
         try:
             import torch  # noqa: F401
         except Exception:
@@ -238,6 +238,8 @@ def lib() -> C.CDLL:
     L.kmc_sampler_rccl_set_capture.argtypes = [vp, C.c_int]
     L.kmc_rccl_version.argtypes = [C.POINTER(C.c_int), C.c_char_p, C.c_int64]
     L.kmc_device_free_bytes.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.kmc_has_p2p_experimental.restype = C.c_int
+    L.kmc_has_p2p_experimental.argtypes = []
     L.kmc_device_cache_release.argtypes = []
     L.kmc_device_cache_release.restype = None
     L.kmc_sampler_launch_mode.restype = C.c_int
@@ -248,9 +250,11 @@ def lib() -> C.CDLL:
     L.kmc_set_updated_budget_mb.argtypes = [C.c_double]
     L.kmc_debug_accept_terms.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int64, C.c_int64, C.c_double, C.c_int64, C.c_int, ip, dp, dp, dp]
     # layout drift between this mirror and the library fails here, at load, not inside the first real call
-    if L.kmc_sizeof_config() != C.sizeof(Config) or L.kmc_sizeof_metropolis_config() != C.sizeof(MetropolisConfig):
-        raise ImportError(f"{LIB_PATH}: struct layout mismatch (kmc_config {L.kmc_sizeof_config()} vs {C.sizeof(Config)} bytes, "
-                          f"kmc_metropolis_config {L.kmc_sizeof_metropolis_config()} vs {C.sizeof(MetropolisConfig)}): rebuild the library")
+    for fn, T in ((L.kmc_sizeof_config, Config), (L.kmc_sizeof_metropolis_config, MetropolisConfig),
+                  (L.kmc_sizeof_outputs, Outputs), (L.kmc_sizeof_metropolis_outputs, MetropolisOutputs)):
+        if fn() != C.sizeof(T):
+            raise ImportError(f"{LIB_PATH}: struct layout mismatch ({fn.__name__}() = {fn()}, the ctypes mirror {T.__name__} is {C.sizeof(T)} bytes): "
+                              "rebuild the library or update kissmcmc_jl_amd/_lib.py from include/kissmcmc_hip.h")
     _lib = L
     return L
 

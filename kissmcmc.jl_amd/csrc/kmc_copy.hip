@@ -224,7 +224,6 @@ hipError_t download_rows(const kmc_sampler* s, double* dst_host, const double* s
 }
 
 // ---- KMC_STREAM_CHAIN ---------------------------------------------------------------------------------------
-constexpr unsigned kStreamWalkerGrid = 192;      // workgroups of the background by-walker copy kernel (KMC_STREAM_CHAIN | KMC_CHAIN_BY_WALKER)
 int64_t samples_done_at(const kmc_sampler* s, int64_t generation)
 {
     const int64_t post = generation - s->cfg.nburnin;
@@ -241,51 +240,39 @@ kmc_status chain_copy_range(kmc_sampler* s, int64_t k0, int64_t k1)
     const size_t slot0 = (size_t)(k0 % s->ring_slots);
     if (s->stream_by_walker) {
         // the reference's order: the caller's arrays are [walker][nsamples][ndim], a block is a run of n * ndim doubles
-        // per walker.  Either transposed into a device scratch block and copied by the DMA engine as a 2-D window
-        // (default), or written straight into the page-locked arrays by the kernel (KMC_BYWALKER_COPY=kernel; few
-        // workgroups, so that it drains over PCIe without taking the sampler's wave slots).
+        // per walker: transposed into a device scratch block and copied out by the DMA engine as a 2-D window.  (A variant whose
+        // kernel wrote straight into the page-locked arrays returned 1 543 wrong elements once in ~15 runs, page-granular, and was
+        // never reproduced or explained: removed in round 4, profiles/NOTES.md.)
         const int64_t ns = s->nsamples;
         if (s->d_chain && s->dst_chain) {
-            if (s->bw_scratch) {
-                hipLaunchKernelGGL(chain_by_walker<double>, dim3((unsigned)std::min<size_t>(nl, 65535u), 1), dim3(256), 0, s->copy_stream, s->d_chain + slot0 * nl * ld,
-                                   s->bw_scratch, (int64_t)nl, (int32_t)ld, (int32_t)nd, (int64_t)n, (int64_t)0, (int64_t)nl, (int64_t)(n * nd));
-                HIP_TRY(hipGetLastError());
-                if (s->dst_chain_reg) {
-                    HIP_TRY(hipMemcpy2DAsync(s->dst_chain + (size_t)k0 * nd, (size_t)ns * nd * sizeof(double), s->bw_scratch, n * nd * sizeof(double),
-                                             n * nd * sizeof(double), nl, hipMemcpyDeviceToHost, s->copy_stream));
-                } else {
-                    // pageable destination (hipHostRegister refused: RLIMIT_MEMLOCK in a container is enough): never a 2-D asynchronous
-                    // copy into it -- the transposed block comes over contiguously through the bounce buffers (blocking), then
-                    // each walker's run of n samples is put in place by the host
-                    if (s->bw_host.size() < n * nl * nd) s->bw_host.resize(n * nl * nd);
-                    HIP_TRY(copy_sync(s->bw_host.data(), s->bw_scratch, n * nl * nd * sizeof(double), hipMemcpyDeviceToHost, s->copy_stream));
-                    for (size_t w = 0; w < nl; ++w)
-                        std::memcpy(s->dst_chain + (w * (size_t)ns + (size_t)k0) * nd, s->bw_host.data() + w * n * nd, n * nd * sizeof(double));
-                }
+            hipLaunchKernelGGL(chain_by_walker<double>, dim3((unsigned)std::min<size_t>(nl, 65535u), 1), dim3(256), 0, s->copy_stream, s->d_chain + slot0 * nl * ld,
+                               s->bw_scratch, (int64_t)nl, (int32_t)ld, (int32_t)nd, (int64_t)n, (int64_t)0, (int64_t)nl, (int64_t)(n * nd));
+            HIP_TRY(hipGetLastError());
+            if (s->dst_chain_reg) {
+                HIP_TRY(hipMemcpy2DAsync(s->dst_chain + (size_t)k0 * nd, (size_t)ns * nd * sizeof(double), s->bw_scratch, n * nd * sizeof(double),
+                                         n * nd * sizeof(double), nl, hipMemcpyDeviceToHost, s->copy_stream));
             } else {
-                hipLaunchKernelGGL(chain_by_walker<double>, dim3(kStreamWalkerGrid, 1), dim3(256), 0, s->copy_stream, s->d_chain + slot0 * nl * ld,
-                                   s->dev_dst_chain + (size_t)k0 * nd, (int64_t)nl, (int32_t)ld, (int32_t)nd, (int64_t)n, (int64_t)0, (int64_t)nl, ns * (int64_t)nd);
-                HIP_TRY(hipGetLastError());
+                // pageable destination (hipHostRegister refused: RLIMIT_MEMLOCK in a container is enough): never a 2-D asynchronous
+                // copy into it -- the transposed block comes over contiguously through the bounce buffers (blocking), then
+                // each walker's run of n samples is put in place by the host
+                if (s->bw_host.size() < n * nl * nd) s->bw_host.resize(n * nl * nd);
+                HIP_TRY(copy_sync(s->bw_host.data(), s->bw_scratch, n * nl * nd * sizeof(double), hipMemcpyDeviceToHost, s->copy_stream));
+                for (size_t w = 0; w < nl; ++w)
+                    std::memcpy(s->dst_chain + (w * (size_t)ns + (size_t)k0) * nd, s->bw_host.data() + w * n * nd, n * nd * sizeof(double));
             }
         }
         if (s->d_chain_logp && s->dst_logp) {
-            if (s->bw_scratch_logp) {
-                hipLaunchKernelGGL(chain_by_walker<double>, dim3((unsigned)std::min<size_t>(nl, 65535u), 1), dim3(256), 0, s->copy_stream, s->d_chain_logp + slot0 * nl,
-                                   s->bw_scratch_logp, (int64_t)nl, (int32_t)1, (int32_t)1, (int64_t)n, (int64_t)0, (int64_t)nl, (int64_t)n);
-                HIP_TRY(hipGetLastError());
-                if (s->dst_logp_reg) {
-                    HIP_TRY(hipMemcpy2DAsync(s->dst_logp + (size_t)k0, (size_t)ns * sizeof(double), s->bw_scratch_logp, n * sizeof(double), n * sizeof(double), nl,
-                                             hipMemcpyDeviceToHost, s->copy_stream));
-                } else {
-                    if (s->bw_host.size() < n * nl) s->bw_host.resize(n * nl);
-                    HIP_TRY(copy_sync(s->bw_host.data(), s->bw_scratch_logp, n * nl * sizeof(double), hipMemcpyDeviceToHost, s->copy_stream));
-                    for (size_t w = 0; w < nl; ++w)
-                        std::memcpy(s->dst_logp + w * (size_t)ns + (size_t)k0, s->bw_host.data() + w * n, n * sizeof(double));
-                }
+            hipLaunchKernelGGL(chain_by_walker<double>, dim3((unsigned)std::min<size_t>(nl, 65535u), 1), dim3(256), 0, s->copy_stream, s->d_chain_logp + slot0 * nl,
+                               s->bw_scratch_logp, (int64_t)nl, (int32_t)1, (int32_t)1, (int64_t)n, (int64_t)0, (int64_t)nl, (int64_t)n);
+            HIP_TRY(hipGetLastError());
+            if (s->dst_logp_reg) {
+                HIP_TRY(hipMemcpy2DAsync(s->dst_logp + (size_t)k0, (size_t)ns * sizeof(double), s->bw_scratch_logp, n * sizeof(double), n * sizeof(double), nl,
+                                         hipMemcpyDeviceToHost, s->copy_stream));
             } else {
-                hipLaunchKernelGGL(chain_by_walker<double>, dim3(kStreamWalkerGrid, 1), dim3(256), 0, s->copy_stream, s->d_chain_logp + slot0 * nl,
-                                   s->dev_dst_logp + (size_t)k0, (int64_t)nl, (int32_t)1, (int32_t)1, (int64_t)n, (int64_t)0, (int64_t)nl, ns);
-                HIP_TRY(hipGetLastError());
+                if (s->bw_host.size() < n * nl) s->bw_host.resize(n * nl);
+                HIP_TRY(copy_sync(s->bw_host.data(), s->bw_scratch_logp, n * nl * sizeof(double), hipMemcpyDeviceToHost, s->copy_stream));
+                for (size_t w = 0; w < nl; ++w)
+                    std::memcpy(s->dst_logp + w * (size_t)ns + (size_t)k0, s->bw_host.data() + w * n, n * sizeof(double));
             }
         }
         return KMC_OK;
@@ -385,33 +372,16 @@ KMC_EXPORT kmc_status kmc_sampler_set_chain_host(kmc_sampler* s, double* chain_h
     // page-lock the destination in place: the copies are then direct DMA into their final position and truly
     // asynchronous; without it (registration refused: limits, already registered) they are staged by the runtime
     const size_t nl = (size_t)s->nlocal, ns = (size_t)s->nsamples;
-    if (s->dst_chain && std::getenv("KMC_NO_HOST_REGISTER") == nullptr) {
+    if (s->dst_chain && !debug_opt("no-host-register")) {
         if (hipHostRegister(s->dst_chain, ns * nl * (size_t)s->cfg.ndim * sizeof(double), hipHostRegisterDefault) == hipSuccess) s->dst_chain_reg = true;
         else (void)hipGetLastError();
     }
-    if (s->dst_logp && std::getenv("KMC_NO_HOST_REGISTER") == nullptr) {
+    if (s->dst_logp && !debug_opt("no-host-register")) {
         if (hipHostRegister(s->dst_logp, ns * nl * sizeof(double), hipHostRegisterDefault) == hipSuccess) s->dst_logp_reg = true;
         else (void)hipGetLastError();
     }
-    s->dev_dst_chain = s->dev_dst_logp = nullptr;
     // by walker into arrays that could NOT be page-locked: the transposed blocks come through the bounce buffers and are put in
-    // place by the host (chain_copy_range) -- slower (blocking), never refused; only the kernel-store variant below
-    // (KMC_BYWALKER_COPY=kernel) needs the arrays mapped into the device's address space
-    if (s->stream_by_walker) {
-        // the by-walker copy is a kernel that writes into the caller's arrays: they must be mapped into the device's address space
-        if (s->dst_chain && !s->bw_scratch && (!s->dst_chain_reg || hipHostGetDevicePointer((void**)&s->dev_dst_chain, s->dst_chain, 0) != hipSuccess)) {
-            (void)hipGetLastError();
-            chain_unregister(s);
-            s->dst_chain = s->dst_logp = nullptr;
-            return fail(KMC_ERR_UNSUPPORTED, "KMC_STREAM_CHAIN | KMC_CHAIN_BY_WALKER: the chain buffer could not be page-locked (hipHostRegister); use the sample-major stream");
-        }
-        if (s->dst_logp && !s->bw_scratch_logp && (!s->dst_logp_reg || hipHostGetDevicePointer((void**)&s->dev_dst_logp, s->dst_logp, 0) != hipSuccess)) {
-            (void)hipGetLastError();
-            chain_unregister(s);
-            s->dst_chain = s->dst_logp = nullptr;
-            return fail(KMC_ERR_UNSUPPORTED, "KMC_STREAM_CHAIN | KMC_CHAIN_BY_WALKER: the log-pdf buffer could not be page-locked (hipHostRegister); use the sample-major stream");
-        }
-    }
+    // place by the host (chain_copy_range) -- slower (blocking), never refused
     return KMC_OK;
 }
 
@@ -444,7 +414,7 @@ KMC_EXPORT kmc_status kmc_sampler_get_chain(kmc_sampler* s, double* chain, doubl
 }
 
 // Device chain [K][nl][ld] (T = float or double) -> host [nl][K][width] doubles: transposed on the device into a scratch
-// buffer, a piece of walkers (<= ~256 MiB, KMC_BY_WALKER_PIECE_MB) at a time, each piece one contiguous copy.
+// buffer, a piece of walkers (<= ~256 MiB; KMC_DEBUG=by-walker-piece-mb=n for tests) at a time, each piece one contiguous copy.
 kmc_status kmc_host::download_by_walker(const void* src, bool is_float, int64_t nl, int64_t ld, int64_t width, int64_t K, double* dst_host, hipStream_t st)
 {
     if (K <= 0 || nl <= 0) return KMC_OK;
@@ -452,7 +422,7 @@ kmc_status kmc_host::download_by_walker(const void* src, bool is_float, int64_t 
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     size_t budget = (size_t)256 << 20;
-    if (const char* mb = std::getenv("KMC_BY_WALKER_PIECE_MB")) { const double v = std::atof(mb); if (v > 0.0) budget = (size_t)(v * 1048576.0); }
+    { std::string mb; if (debug_opt("by-walker-piece-mb", &mb)) { const double v = std::atof(mb.c_str()); if (v > 0.0) budget = (size_t)(v * 1048576.0); } }
     if (budget > free_b / 2) budget = free_b / 2;
     int64_t wb = (int64_t)(budget / per_walker);
     if (wb < 1) wb = 1;

@@ -63,6 +63,19 @@ struct DrawConsts {
 // The fdlibm / musl algorithm (argument reduced to [sqrt(1/2), sqrt(2)), s = f / (2 + f), degree-7 polynomial in
 // s^2, split ln 2), error < 1 ulp -- about 45 instructions where the device libm's log takes 80-135, and these two
 // logarithms are a quarter of the half-step kernel's VALU work.  Not used for log-pdfs.
+//
+// The constants (ln2_hi, ln2_lo, Lg1..Lg7) and the evaluation order are those of FreeBSD msun's e_log.c as carried by
+// musl 1.2.x (src/math/log.c, the pre-1.2.0 fdlibm form; checked against fdlibm 5.3's e_log.c: identical values), whose
+// notice is preserved here as it asks:
+//
+//   ====================================================
+//   Copyright (C) 1993 by Sun Microsystems, Inc. All rights reserved.
+//
+//   Developed at SunSoft, a Sun Microsystems, Inc. business.
+//   Permission to use, copy, modify, and distribute this
+//   software is freely granted, provided that this notice
+//   is preserved.
+//   ====================================================
 __device__ __forceinline__ double log_pos_normal(double x)
 {
     constexpr double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,

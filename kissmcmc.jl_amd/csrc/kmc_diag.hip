@@ -1,5 +1,5 @@
 // kmc_diag.hip -- diagnostics: the accept-term probe of the C ABI (include/kissmcmc_hip.h: "diagnostics"), the native
-// backtrace of an abort() (KMC_ABORT_BACKTRACE), the guard bands behind a sampler's device allocations (KMC_POISON), and the
+// backtrace of an abort() (KMC_ABORT_BACKTRACE), the guard bands behind a sampler's device allocations (KMC_DEBUG=poison), and the
 // device's free memory.
 //
 // kmc_debug_accept_terms: the random side of the accept test of reference src/samplers.jl:260,
@@ -71,7 +71,7 @@ void check_guards(kmc_sampler* s)
         if (copy_sync(h.data(), g.first, kGuardBytes, hipMemcpyDeviceToHost, s->stream) != hipSuccess) { (void)hipGetLastError(); continue; }
         for (size_t i = 0; i < kGuardBytes; ++i)
             if (h[i] != 0xA5) {
-                std::fprintf(stderr, "[kissmcmc_hip] KMC_POISON: byte %zu behind a device allocation of %zu bytes was overwritten (%s)\n", i, g.second,
+                std::fprintf(stderr, "[kissmcmc_hip] KMC_DEBUG=poison: byte %zu behind a device allocation of %zu bytes was overwritten (%s)\n", i, g.second,
                              s->plan.vec ? "vec kernels" : "generic / staged kernels");
                 std::abort();
             }
@@ -90,7 +90,7 @@ std::map<int, DevCache> g_cache;                       // by device ordinal
 std::map<void*, std::pair<int, size_t>> g_cache_live;  // blocks handed out: device, rounded size
 bool cache_enabled()
 {
-    static const bool on = std::getenv("KMC_POISON") == nullptr && std::getenv("KMC_NO_ALLOC_CACHE") == nullptr;
+    static const bool on = !debug_opt("poison");
     return on;
 }
 }  // namespace

@@ -5,6 +5,7 @@
 #include <hip/hiprtc.h>
 
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -42,6 +43,32 @@ inline kmc_status fail(kmc_status st, const std::string& msg)
         kmc_status s_ = (expr);                                                                \
         if (s_ != KMC_OK) return s_;                                                           \
     } while (0)
+
+// KMC_DEBUG="opt[=value],opt,...": the test-only, A/B and diagnostic switches of the library behind ONE environment variable (the
+// documented ones are in README.md; none is needed in normal use).  Read anew at every call (tests set it between samplers).
+// Returns whether `name` is listed; *value gets what follows its '=' ("" when nothing does).
+inline bool debug_opt(const char* name, std::string* value = nullptr)
+{
+    const char* e = std::getenv("KMC_DEBUG");
+    if (!e) return false;
+    const size_t n = std::strlen(name);
+    for (const char* p = e; *p;) {
+        const char* q = std::strchr(p, ',');
+        const size_t len = q ? (size_t)(q - p) : std::strlen(p);
+        if (len >= n && std::strncmp(p, name, n) == 0 && (len == n || p[n] == '=')) {
+            if (value) *value = len > n ? std::string(p + n + 1, len - n - 1) : std::string();
+            return true;
+        }
+        if (!q) break;
+        p = q + 1;
+    }
+    return false;
+}
+inline long debug_opt_long(const char* name, long absent)
+{
+    std::string v;
+    return debug_opt(name, &v) && !v.empty() ? std::atol(v.c_str()) : absent;
+}
 
 // kernel tables of the menu densities (kmc_inst_*.hip) and the digest of kmc_config.params the kernels take
 bool lookup(int density, int L, int K, int iter, bool p2p, bool ragged, bool f32, kmc::HalfStepFn* vec, kmc::HalfStepFn* gen, kmc::LogpdfFn* lp);
@@ -85,7 +112,7 @@ struct ScopedStream {
 // hiprtc compilation of `text` (+ named headers) for gfx950, with a DISK CACHE of the code objects: a script that defines its
 // density in source pays the compiler (0.2-0.5 s per density and kernel geometry) once, not in every process.  Key: two
 // 64-bit hashes over the program, every header, the options and the hiprtc version; directory $KMC_CACHE_DIR, else
-// $XDG_CACHE_HOME/kissmcmc_hip, else $HOME/.cache/kissmcmc_hip; KMC_NO_DISK_CACHE=1 switches it off; a cache that cannot be
+// $XDG_CACHE_HOME/kissmcmc_hip, else $HOME/.cache/kissmcmc_hip; KMC_CACHE_DIR=off switches it off; a cache that cannot be
 // read or written is simply not used.  On a compile error *log holds the compiler's messages.
 kmc_status rtc_compile_cached(const std::string& text, const char* program_name, int nheaders, const char* const* header_text,
                               const char* const* header_names, int nopts, const char* const* opts, std::vector<char>* code, std::string* log);
@@ -109,7 +136,7 @@ hipError_t launch_module(hipFunction_t f, unsigned grid, unsigned tpb, hipStream
 // two, and hipMalloc / hipFree of its dozen buffers were more than half of that (create 0.35 ms, destroy 0.85 ms of a 1.7 ms
 // README call): blocks of up to 8 MiB go back to a free list instead (at most 128 MiB held per device, exact rounded sizes, so
 // samplers of one shape reuse each other's blocks).  A block is handed back only after its owner has synchronised the streams that
-// touched it.  Off with KMC_POISON (guard bands) or KMC_NO_ALLOC_CACHE=1; kmc_device_cache_release() returns everything.
+// touched it (kmc_sampler_destroy: its own streams; the whole device when a caller's stream was ever bound or the sampler is a shard).  Off with KMC_DEBUG=poison (guard bands); kmc_device_cache_release() returns everything.
 hipError_t cache_alloc(void** p, size_t bytes);        // on the current device
 void cache_free(void* p);                              // nullptr is fine; pointers the cache did not hand out go to hipFree
 size_t cache_held_bytes(int device);

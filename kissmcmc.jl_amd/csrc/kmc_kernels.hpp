@@ -106,6 +106,7 @@ struct HalfStepArgs {
     double*           peer_pos[8];
     const unsigned long long* flags; // flags[r] = number of half-steps rank r has completed
     unsigned long long* err;         // set non-zero when a wait times out
+#ifdef KMC_P2P_EXPERIMENTAL
     // KMC_P2P_FOLD_SIGNAL: the kernel publishes its own completion (vec kernels)
     unsigned long long* peer_flags[8]; // peer_flags[r] = rank r's flags array
     uint32_t*         done_count;    // [33][16]: workgroups of this launch that have drained their stores (32 sub-counters +
@@ -116,6 +117,7 @@ struct HalfStepArgs {
     // every peer (peer_pos[r] = rank r's pos)
     int32_t           push;
     int64_t           shard_stride;
+#endif
     DrawConsts        dc;
     DensityParams     dp;
     double*           chain;        // [nsamples][chain_rows][ndim] or nullptr          (:269)
@@ -151,6 +153,10 @@ struct HalfStepArgs {
     uint32_t*         mcnt;         // [waves]
     const uint32_t*   mswept;       // [waves]
     int32_t           mring_depth;
+    // blobs of a body density (BodyBlobDensity, NB doubles per evaluation; one walker per lane kernels only)
+    double*           blob;         // [rows][NB]: the blob of every walker's current position (blob0s, src/samplers.jl:210, :264)
+    double*           chain_blob;   // [nsamples][chain_rows][NB] (reduce_blob!, :270) or nullptr
+#ifdef KMC_P2P_EXPERIMENTAL
     // KMC_P2P_LAZY (push == 2): the shadow blocks of KMC_P2P_PUSH, filled on demand.  Nobody pushes rows; a rank
     // publishes the ACCEPT BYTES of each half-step instead (one byte per active walker, written into every peer's
     // lz_amap_in by the half-step kernel, slot = step & 3), and a reader pulls a drawn remote row only when its shadow
@@ -158,14 +164,24 @@ struct HalfStepArgs {
     // holds two stamps (step + 1; 0 = never; lz_stamps): modified, the last accept it has heard of (absorbed from the byte
     // maps, one launch late), and fetched, its last pull.  A row is pulled when the newest map flags it, when
     // modified > fetched, or when fetched carries THIS step (another wave is rewriting the shadow right now).
-    // blobs of a body density (BodyBlobDensity, NB doubles per evaluation; one walker per lane kernels only)
-    double*           blob;         // [rows][NB]: the blob of every walker's current position (blob0s, src/samplers.jl:210, :264)
-    double*           chain_blob;   // [nsamples][chain_rows][NB] (reduce_blob!, :270) or nullptr
     const unsigned char* lz_amap_in;   // [nranks][4][hloc]  (inside the exported row allocation: peers write it)
     uint2*            lz_stamps;       // [nranks][2][hloc] {x: fetched, y: modified} -- one 8-byte load per walker-step
     unsigned long long* lz_stats;      // diagnostics, or nullptr: [0] remote partner draws, [1] of them pulled over the fabric
     unsigned char*    lz_peer_amap[8]; // rank r's lz_amap_in: the kernel writes its accept bytes there itself
+#endif
 };
+
+// The peer-to-peer exchange of the default library is ONE variant: pull of the drawn partner rows from their owner with
+// system-scope loads, ordered by a separate signal kernel (correctness does not rest on any cache state).  Five more -- push of
+// accepted rows / lazy pull into local copies, each with the progress signal optionally folded into the half-step kernel -- have
+// peers write into plain device memory that the local kernel reads through its own L2; they are bit-exact with every "peer" on
+// ONE GPU and have never run on two.  They exist only in builds with -DKMC_P2P_EXPERIMENTAL (the whole library: the argument
+// struct changes; `python -m kissmcmc_jl_amd.build --p2p-experimental` -> libkmc_var_p2pexp.so, tests/test_gpu_p2p_experimental.py).
+#ifdef KMC_P2P_EXPERIMENTAL
+constexpr bool kP2PExperimental = true;
+#else
+constexpr bool kP2PExperimental = false;
+#endif
 
 // The fields a wave needs before it can issue its first loads travel as LEADING SCALAR kernel parameters, ahead
 // of the argument struct: built with -mllvm -amdgpu-kernarg-preload-count=14, gfx950 delivers them in SGPRs at
@@ -545,7 +561,9 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
     //      logarithm: measured best at C2 (all loads first: +0.15 us per half-step; loads after both logs: same),
     //      and pinned with scheduling barriers because the compiler's own placement moves with unrelated edits ----
     unsigned long long addrA = 0ull;                                    // P2P: the partner row's address
+#ifdef KMC_P2P_EXPERIMENTAL
     unsigned long long shadowB[ITER];                                   // KMC_P2P_LAZY: where a pulled row goes in the local shadow (0: not pulled)
+#endif
     auto load_partner_rows = [&](int it) {
         const V2* oth;
         if constexpr (!P2P) {
@@ -555,11 +573,19 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
             const int src = (gbase + it) * 4;
             const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)(unsigned)addrA);
             const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)(unsigned)(addrA >> 32));
-            shadowB[it] = ((unsigned long long)hi << 32) | lo;          // (lazy: the local copy's address, kept or zeroed below)
-            oth = reinterpret_cast<const V2*>(shadowB[it]);
+            const unsigned long long ad = ((unsigned long long)hi << 32) | lo;
+#ifdef KMC_P2P_EXPERIMENTAL
+            shadowB[it] = ad;                                           // (lazy: the local copy's address, kept or zeroed below)
+#endif
+            oth = reinterpret_cast<const V2*>(ad);
         }
         if constexpr (P2P) {
-            if (a.push == 0 && a.nranks > 1) {                          // pull: the row lives in its owner's memory
+#ifdef KMC_P2P_EXPERIMENTAL
+            const bool pull = a.push == 0;
+#else
+            constexpr bool pull = true;
+#endif
+            if (pull && a.nranks > 1) {                                 // pull: the row lives in its owner's memory
 #pragma unroll
                 for (int k = 0; k < K; ++k) xo[it][k] = cv[k] ? load_row_sys(reinterpret_cast<const double2*>(&oth[k * L + j])) : zero2;
                 return;
@@ -568,18 +594,27 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
 #pragma unroll
         for (int k = 0; k < K; ++k) xo[it][k] = cv[k] ? load_row(&oth[k * L + j]) : zero2;
     };
+#ifdef KMC_P2P_EXPERIMENTAL
     bool lazy = false;
+#else
+    constexpr bool lazy = false;
+#endif
     if constexpr (P2P) {
+#ifdef KMC_P2P_EXPERIMENTAL
         lazy = a.push == 2;
+#endif
         // owner rank and row of the partner, resolved once per walker; the row address travels
         const uint32_t q = a.hloc_shift >= 0 ? partnerA >> a.hloc_shift : partnerA / a.hloc;
         const uint32_t r = partnerA - q * a.hloc;
         const double* base = a.peer_pos[0];
 #pragma unroll
         for (int t = 1; t < 8; ++t) base = (q == (uint32_t)t) ? a.peer_pos[t] : base;
+#ifdef KMC_P2P_EXPERIMENTAL
         const double* remote_base = base;
         if (a.push) base = (q == (uint32_t)a.me) ? a.pos : a.pos + (int64_t)(1u + q) * a.shard_stride;   // local copy of rank q's shard
+#endif
         addrA = (unsigned long long)(base + (oth_row0 + r) * ld);
+#ifdef KMC_P2P_EXPERIMENTAL
         // KMC_P2P_LAZY: the local copies and this reader's stamps do not depend on the peers' progress -- request them
         // now, speculatively; whether a copy is still good is decided after the wait (newest accept bytes)
         const bool remoteA = lazy && q != (uint32_t)a.me && validA;
@@ -590,12 +625,14 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
 #pragma unroll
             for (int it = 0; it < ITER; ++it) load_partner_rows(it);
         }
+#endif
         if (a.nranks > 1) {
             // every rank must have finished half-step `step - 1`: one polling wave per workgroup (the
             // flags sit in uncached fine-grained memory), the other waves wait at the barrier
             if ((threadIdx.x >> 6) == 0) wait_for_peers(a, step, lane);
             __syncthreads();
         }
+#ifdef KMC_P2P_EXPERIMENTAL
         if (lazy) {
             const uint32_t stamp = (uint32_t)step + 1u;
             const int64_t hl = (int64_t)a.hloc;
@@ -623,7 +660,7 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
                     a.lz_stamps[xs].x = stamp;
                 }
             }
-            if (a.lz_stats != nullptr) {                                 // diagnostics only (KMC_P2P_STATS=1): same-address atomics
+            if (a.lz_stats != nullptr) {                                 // diagnostics only (KMC_DEBUG=p2p-stats): same-address atomics
                 const unsigned long long nrem = __ballot(remoteA), npul = __ballot(addrR != 0ull);
                 if (lane == 0 && nrem != 0ull) {
                     atomicAdd(&a.lz_stats[0], (unsigned long long)__popcll(nrem));
@@ -645,6 +682,7 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
                 }
             }
         }
+#endif
     }
     constexpr int kFirst = ITER >= 2 ? ITER / 2 : ITER;                 // iterations whose loads precede the first logarithm
     if (!lazy) {
@@ -739,6 +777,7 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
 #pragma unroll
     for (int it = 0; it < ITER; ++it) zB[it] = bperm_f64((gbase + it) * 4, dr.z);
 
+#ifdef KMC_P2P_EXPERIMENTAL
     if constexpr (P2P) {
         if (a.push == 2) {                                              // keep the rows just pulled
 #pragma unroll
@@ -751,6 +790,7 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
             }
         }
     }
+#endif
     // ---- stretch move + log-pdf; xo becomes the proposal ------------------------------------
     double myp1 = 0.0;
 #pragma unroll
@@ -777,6 +817,7 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
         if (count) store_wt(&naccept_p[rowA], na + 1u);                 // :265
         if (do_mom) store_wt(&klast_p[rowA], sch.nbefore);
     }
+#ifdef KMC_P2P_EXPERIMENTAL
     if constexpr (P2P) {
         if (a.push == 2 && validA) {
             // straight into every peer's map (write-through: in the peer's memory once drained, i.e. before this
@@ -787,6 +828,7 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
                 if (r != a.me) store_wt(&a.lz_peer_amap[r][at], byte);
         }
     }
+#endif
     const uint32_t wA = (acc && do_mom) ? sch.nbefore - kl : 0u;        // samples the replaced value stood for
     const bool any_w = __ballot(wA != 0u) != 0ull;
     if (sample && a.chain_logp != nullptr && validA)                    // :271
@@ -807,6 +849,7 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
             V2* own = reinterpret_cast<V2*>(posT + (own_row0 + w0 + it * G + g) * ld);
 #pragma unroll
             for (int k = 0; k < K; ++k) if (cv[k]) store_row(&own[k * L + j], xo[it][k]);
+#ifdef KMC_P2P_EXPERIMENTAL
             if constexpr (P2P) {
                 if (a.push == 1) {                                      // ... and into this rank's shadow on every peer
                     const int64_t off = (int64_t)(1 + a.me) * a.shard_stride + (own_row0 + w0 + it * G + g) * ld;
@@ -818,6 +861,7 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
                     }
                 }
             }
+#endif
         }
         if (any_w) {
             const double wB = (double)(uint32_t)__builtin_amdgcn_ds_bpermute((gbase + it) * 4, (int)wA);
@@ -852,6 +896,7 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
             else accumulate_wave<L, K, false>(a.msum, a.msumsq, a.macc_stride, tid, g, ms, mq, accs, accq, acct);
         }
     }
+#ifdef KMC_P2P_EXPERIMENTAL
     if constexpr (P2P) {
         // KMC_P2P_FOLD_SIGNAL: every store above is write-through, so once a workgroup's stores have drained they are
         // in memory, where the peers read them; the last workgroup to get there tells every rank that this rank has
@@ -883,6 +928,7 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
             }
         }
     }
+#endif
     KMC_STAMP(7);                                       // the last store is issued
 #ifdef KMC_PROBE
     {

@@ -69,6 +69,7 @@ HalfStepArgs make_args(const kmc_sampler* s, int half, bool graph_mode, int64_t 
     for (int r = 0; r < 8; ++r) a.peer_pos[r] = s->peer_pos[r];
     a.flags = s->d_flags;
     a.err = s->d_err;
+#ifdef KMC_P2P_EXPERIMENTAL
     for (int r = 0; r < 8; ++r) a.peer_flags[r] = s->peer_flags[r];
     a.done_count = s->fold_signal ? s->d_done : nullptr;
     a.me = s->cfg.shard_rank;
@@ -81,6 +82,7 @@ HalfStepArgs make_args(const kmc_sampler* s, int half, bool graph_mode, int64_t 
         for (int r = 0; r < 8; ++r) a.lz_peer_amap[r] = s->peer_amap_in[r];
     }
     a.shard_stride = (int64_t)s->nrows * s->ld;
+#endif
     a.n_active = (int32_t)s->h_loc;
     a.half = half;
     a.ndim = (int32_t)s->cfg.ndim;
@@ -473,15 +475,15 @@ KMC_EXPORT kmc_status kmc_sampler_run(kmc_sampler* s, int64_t ngen)
         // on the link (the D2H of the proposals is the larger half of a half-step's time once the closure is cheap).  Not when
         // accept outcomes go back to the host as well: that caller keeps per-batch state (blobs) between the two callbacks.
         int npiece = (!s->cfg.host_accepted && hh >= 8192) ? 4 : 1;
-        if (const char* e = std::getenv("KMC_HOST_PIECES")) { const long v = std::atol(e); if (v >= 1 && v <= kHostPieces && !s->cfg.host_accepted) npiece = (int)v; }
+        { const long v = debug_opt_long("host-pieces", 0); if (v >= 1 && v <= kHostPieces && !s->cfg.host_accepted) npiece = (int)v; }
         for (int i = 0; i < npiece && npiece > 1; ++i)
             if (!s->host_ev[i]) HIP_TRY(hipEventCreateWithFlags(&s->host_ev[i], hipEventDisableTiming));
         // Small batches (the reference's own sizes) skip the copies: the propose kernel writes the dense proposal rows straight into
         // the page-locked host array over the link and the accept kernel reads the log-pdfs straight from theirs -- a half-step is
         // then two launches, one synchronisation and the callback (100 walkers: 32 -> ~15 us with a Python callable).
-        // KMC_HOST_ZEROCOPY=0|1 forces it off / on.
+        // KMC_DEBUG=host-zerocopy=0|1 forces it off / on.
         bool zero_copy = npiece == 1 && s->h_prop_dev != nullptr && hh * nd * sizeof(double) <= ((size_t)256 << 10);
-        if (const char* e = std::getenv("KMC_HOST_ZEROCOPY")) zero_copy = e[0] == '1' && npiece == 1 && s->h_prop_dev != nullptr;
+        { std::string e; if (debug_opt("host-zerocopy", &e)) zero_copy = e == "1" && npiece == 1 && s->h_prop_dev != nullptr; }
         for (; ngen > 0; --ngen) {
             KMC_TRY(chain_before(s, s->generation + 1));
             for (int half = 0; half < 2; ++half) {
@@ -625,8 +627,6 @@ KMC_EXPORT kmc_status kmc_sampler_run(kmc_sampler* s, int64_t ngen)
         return KMC_OK;
     };
     if (use_graph && s->launch_mode == 0) {
-        if (!s->uexec[0])
-            if (const char* e = std::getenv("KMC_UPD_CHUNK")) { const long v = std::atol(e); if (v >= 16 && v <= 1024) s->uchunk = v; }
         const char* env = std::getenv("KMC_LAUNCH");
         if (env && std::strcmp(env, "graph") == 0) s->launch_mode = 1;
         else if (env && std::strcmp(env, "eager") == 0) s->launch_mode = 2;

@@ -408,11 +408,12 @@ KMC_EXPORT kmc_status kmc_metropolis_run(const kmc_metropolis_config* c, const d
 
     // Few chains (the reference's call is one): the draws of a stretch of iterations come from a wide kernel first, the chains
     // only read them (kmc_metropolis.hpp: metropolis_chains_tabled).  Up to a wave per CU (measured: x6.8 at one chain, x4 at
-    // 4096, x2 at 16 384, x0.5 at 65 536 -- there the chains fill the chip themselves).  KMC_METRO_TABLE=0|1 forces it off / on.
+    // 4096, x2 at 16 384, x0.5 at 65 536 -- there the chains fill the chip themselves).  KMC_DEBUG=metro-table=0|1 forces it off / on.
     bool tabled = false;
     {
-        const char* e = std::getenv("KMC_METRO_TABLE");
-        const bool off = e && e[0] == '0', on = e && e[0] == '1';
+        std::string e;
+        const bool have = debug_opt("metro-table", &e);
+        const bool off = have && e == "0", on = have && e == "1";
         // (up to 8 dimensions for up to 16 384 chains -- measured --; longer rows for the few chains that leave most of the chip idle)
         const int64_t nd_max = c->density == KMC_USER_DENSITY ? 32 : 8;       // (menu densities: instantiated up to 8 -- build time)
         tabled = !off && nblob == 0 && ((nd <= 8 && nc <= 16384) || (nd <= nd_max && nc <= 1024) || (on && nd <= nd_max));
@@ -441,7 +442,7 @@ KMC_EXPORT kmc_status kmc_metropolis_run(const kmc_metropolis_config* c, const d
         }
         const int64_t per_step = nc * (nd + 1) * (int64_t)sizeof(double);
         table_steps = std::max<int64_t>(64, std::min<int64_t>(1 << 16, ((int64_t)128 << 20) / per_step));
-        if (const char* ts = std::getenv("KMC_METRO_TABLE_STEPS")) table_steps = std::max<int64_t>(1, std::atoll(ts));   // (tests: seams)
+        { const long ts = debug_opt_long("metro-table-steps", 0); if (ts > 0) table_steps = ts; }   // (tests: seams)
         table_steps = std::min<int64_t>(table_steps, std::max<int64_t>(c->niter, 1));
         HIP_TRY(metro_alloc(&b.draws, (size_t)(table_steps * per_step)));
     }

@@ -23,8 +23,7 @@ uint64_t fnv1a(uint64_t h, const void* data, size_t n)
 }
 std::string rtc_cache_dir()
 {
-    if (std::getenv("KMC_NO_DISK_CACHE")) return std::string();
-    if (const char* d = std::getenv("KMC_CACHE_DIR")) return std::string(d);
+    if (const char* d = std::getenv("KMC_CACHE_DIR")) return std::strcmp(d, "off") == 0 ? std::string() : std::string(d);     // KMC_CACHE_DIR=off: no disk cache
     if (const char* x = std::getenv("XDG_CACHE_HOME")) if (x[0]) return std::string(x) + "/kissmcmc_hip";
     if (const char* h = std::getenv("HOME")) if (h[0]) return std::string(h) + "/.cache/kissmcmc_hip";
     return std::string();

@@ -77,11 +77,11 @@ ResidentFn resident_lane2_fn(int density, int ndim)
     }
 }
 
-// resident mode with one walker per thread (short rows) or two lanes per walker: KMC_RESIDENT=lane|pair decides for tests
+// resident mode with one walker per thread (short rows) or two lanes per walker: KMC_DEBUG=resident=pair decides for tests
 bool resident_lane_wanted(int64_t ndim)
 {
-    const char* e = std::getenv("KMC_RESIDENT");
-    if (e && std::strcmp(e, "pair") == 0) return false;
+    std::string e;
+    if (debug_opt("resident", &e) && e == "pair") return false;
     return ndim <= 8;
 }
 int lane_nd(int64_t ndim) { return (int)ndim; }          // (the lane kernels are instantiated for the exact row length)
@@ -306,6 +306,11 @@ KMC_EXPORT kmc_status kmc_validate(const kmc_config* c)
     if (c->shard_rank < 0 || c->shard_rank >= P) return fail(KMC_ERR_BAD_ARG, "shard_rank out of range");
     if ((c->nwalkers / 2) % P != 0) return fail(KMC_ERR_BAD_ARG, "nwalkers/2 must be divisible by shard_count");
     if ((c->flags & KMC_P2P) && P > 8) return fail(KMC_ERR_UNSUPPORTED, "KMC_P2P supports at most 8 shards (one node)");
+#ifndef KMC_P2P_EXPERIMENTAL
+    if (c->flags & (KMC_P2P_PUSH | KMC_P2P_LAZY | KMC_P2P_FOLD_SIGNAL))
+        return fail(KMC_ERR_UNSUPPORTED, "KMC_P2P_PUSH / KMC_P2P_LAZY / KMC_P2P_FOLD_SIGNAL exist only in builds with -DKMC_P2P_EXPERIMENTAL "
+                                         "(python -m kissmcmc_jl_amd.build --p2p-experimental): the default library's exchange is the pull of drawn rows with system-scope loads");
+#endif
     if (c->flags & KMC_ISLANDS) {
         const int64_t S = c->island_size > 0 ? c->island_size : kIslandSizeDefault;
         if ((S != 64 && S != 128 && S != 256) || c->nwalkers % S != 0 || c->ndim > 32 || c->ndim + 2 > S || P != 1 ||
@@ -351,7 +356,7 @@ KMC_EXPORT double kmc_cdf_g_inv(double u, double a)   // src/samplers.jl:227
     return t * t;
 }
 
-// hipMalloc does not clear memory.  KMC_POISON=1 (diagnostics): every allocation of a sampler starts as 0xFF bytes (NaN doubles,
+// hipMalloc does not clear memory.  KMC_DEBUG=poison (diagnostics): every allocation of a sampler starts as 0xFF bytes (NaN doubles,
 // 4 294 967 295 counters), so that anything the code forgot to initialise shows up in the tests instead of depending on what the
 // allocator happened to return.
 // ... and is followed by a 4 KiB guard of 0xA5 that kmc_sampler_destroy checks: a kernel that writes past the end of one of
@@ -359,7 +364,7 @@ KMC_EXPORT double kmc_cdf_g_inv(double u, double a)   // src/samplers.jl:227
 template <class T>
 hipError_t dev_alloc(kmc_sampler* s, T** p, size_t bytes)
 {
-    static const bool poison = std::getenv("KMC_POISON") != nullptr;
+    static const bool poison = debug_opt("poison");
     if (!poison || bytes == 0) {
         // (IPC-exported buffers stay plain allocations: a peer maps them by their base address)
         if (s->cfg.flags & KMC_P2P) return hipMalloc(reinterpret_cast<void**>(p), bytes);
@@ -551,6 +556,7 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         CREATE_TRY(hipMemsetAsync(s->d_flags, 0, 4096, s->stream));
         CREATE_TRY(dev_alloc(s, (void**)&s->d_err, 64));
         CREATE_TRY(hipMemsetAsync(s->d_err, 0, 64, s->stream));
+#ifdef KMC_P2P_EXPERIMENTAL
         CREATE_TRY(dev_alloc(s, (void**)&s->d_done, 33 * 64));
         CREATE_TRY(hipMemsetAsync(s->d_done, 0, 33 * 64, s->stream));
         // the kernel can publish its own completion only where all its stores are write-through: the vector kernels
@@ -558,7 +564,8 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         s->push = (cfg->flags & (KMC_P2P_PUSH | KMC_P2P_LAZY)) != 0 && s->plan.vec && s->user == nullptr && !(cfg->flags & KMC_P2P_FINEGRAINED) &&
                   s->cfg.shard_count > 1;
         s->lazy = s->push && (cfg->flags & KMC_P2P_LAZY) != 0 && s->h_loc % 16 == 0 && !s->f32;
-        if (const char* e = std::getenv("KMC_P2P_STATS")) s->lazy_stats = s->lazy && e[0] == '1';
+        s->lazy_stats = s->lazy && debug_opt("p2p-stats");
+#endif
     }
     // KMC_P2P_LAZY: room for every rank's accept-byte maps behind the row blocks (peers write them: same allocation)
     const size_t amap_bytes = s->lazy ? (size_t)s->cfg.shard_count * 4 * (size_t)s->h_loc : 0;
@@ -588,8 +595,7 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
     CREATE_TRY(dev_alloc(s, &s->d_sched, (size_t)kGraphChunk * sizeof(SchedEntry)));
     CREATE_TRY(hipMemsetAsync(s->d_naccept, 0, nw * sizeof(uint32_t), s->stream));
     if (cfg->deal_count > 0) CREATE_TRY(dev_alloc(s, (void**)&s->d_ids, nw * sizeof(uint32_t)));
-    if (s->plan.vec && !s->islands && !s->resident && s->plan.L >= 16 && s->plan.L <= 32 && s->plan.L / s->plan.ITER >= 2 &&
-        std::getenv("KMC_NO_DRAW_RING") == nullptr) {
+    if (s->plan.vec && !s->islands && !s->resident && s->plan.L >= 16 && s->plan.L <= 32 && s->plan.L / s->plan.ITER >= 2) {
         // draw ring: 4 slots x rows x 32 B; tags start at 0xffffffff (no step carries it), so nothing is "parked" yet
         const size_t nb = 4 * (size_t)s->nrows * 2 * sizeof(double2);
         CREATE_TRY(dev_alloc(s, (void**)&s->d_ring, nb));
@@ -602,15 +608,16 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         CREATE_TRY(dev_alloc(s, &s->d_msumsq, (size_t)s->macc_elems * sizeof(double)));
         CREATE_TRY(hipMemsetAsync(s->d_msum, 0, (size_t)s->macc_elems * sizeof(double), s->stream));
         CREATE_TRY(hipMemsetAsync(s->d_msumsq, 0, (size_t)s->macc_elems * sizeof(double), s->stream));
-        if (s->plan.vec && s->plan.L == 64 && !s->islands && !s->resident && std::getenv("KMC_NO_MOMENT_RING") == nullptr) {
+        if (s->plan.vec && s->plan.L == 64 && !s->islands && !s->resident && !debug_opt("no-moment-ring")) {
             // moment ring for long rows (kmc_kernels.hpp, HalfStepArgs::mring): up to 128 posted rows per wave,
             // within 512 MiB in all; swept every kSweepEvery generations
             const int64_t nwaves = s->macc_stride / 64;
             const size_t slot = (size_t)s->plan.K * 64 * sizeof(double2);       // one row
             int64_t depth = (int64_t)(((size_t)1 << 29) / ((size_t)nwaves * slot));
             if (depth > 128) depth = 128;
-            if (const char* e = std::getenv("KMC_MOMENT_RING_DEPTH")) { const long v = std::atol(e); if (v >= 1 && v < depth) depth = v; }   // tests: force overflows
-            if (depth >= 4 || (depth >= 2 && std::getenv("KMC_MOMENT_RING_DEPTH") != nullptr)) {
+            const long forced_depth = debug_opt_long("moment-ring-depth", 0);                         // tests: force overflows
+            if (forced_depth >= 1 && forced_depth < depth) depth = forced_depth;
+            if (depth >= 4 || (depth >= 2 && forced_depth > 0)) {
                 CREATE_TRY(dev_alloc(s, (void**)&s->d_mring, (size_t)nwaves * (size_t)depth * slot));
                 CREATE_TRY(dev_alloc(s, (void**)&s->d_mring_w, (size_t)nwaves * (size_t)depth * sizeof(double)));
                 CREATE_TRY(dev_alloc(s, (void**)&s->d_mcnt, 2 * (size_t)nwaves * sizeof(uint32_t)));
@@ -647,20 +654,18 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         // a ring of three blocks; a block holds at least the samples of one launch unit (a graph replay), so a unit never
         // touches more than two blocks, and about 512 MiB otherwise (measured at C2: 128 MiB blocks stream 22-26 GB/s at nthin = 10, 512 MiB blocks 43-45 GB/s of the
         // 56 GB/s this link copies alone; many small blocks cost more at the block boundaries than their earlier start
-        // returns -- nthin = 100: +19 % on the loop with 64 MiB blocks, +6 % with 512 MiB; KMC_CHAIN_BLOCK = samples per block, for tests)
-        if (const char* e = std::getenv("KMC_UPD_CHUNK")) { const long v = std::atol(e); if (v >= 16 && v <= 1024) s->uchunk = v; }
+        // returns -- nthin = 100: +19 % on the loop with 64 MiB blocks, +6 % with 512 MiB; KMC_DEBUG=chain-block=n: samples per block, for tests)
         const int64_t unit = s->resident ? 1 : std::max<int64_t>(kGraphChunk, s->uchunk);     // (a resident launch is cut to the block: kmc_sampler_run)
         const int64_t per_unit = (unit + cfg->nthin - 1) / cfg->nthin + 1;
         const size_t sample_bytes = (size_t)s->nlocal * ldz * sizeof(double);
         int64_t blk = (int64_t)(((size_t)512 << 20) / sample_bytes);
         if (blk < 1) blk = 1;
         if (blk > 4096) blk = 4096;
-        if (const char* e = std::getenv("KMC_CHAIN_BLOCK")) { const long v = std::atol(e); if (v >= 1) blk = v; }
+        { const long v = debug_opt_long("chain-block", 0); if (v >= 1) blk = v; }
         if (blk < per_unit) blk = per_unit;
         s->stream_chain = true;
         s->stream_by_walker = (cfg->flags & KMC_CHAIN_BY_WALKER) != 0;
-        const char* bwc = std::getenv("KMC_BYWALKER_COPY");
-        if (s->stream_by_walker && !(bwc && std::strcmp(bwc, "kernel") == 0)) {
+        if (s->stream_by_walker) {
             if (cfg->flags & KMC_STORE_CHAIN) CREATE_TRY(dev_alloc(s, &s->bw_scratch, (size_t)blk * (size_t)s->nlocal * (size_t)cfg->ndim * sizeof(double)));
             if (cfg->flags & KMC_STORE_LOGP) CREATE_TRY(dev_alloc(s, &s->bw_scratch_logp, (size_t)blk * (size_t)s->nlocal * sizeof(double)));
         } else if (!s->stream_by_walker && (cfg->flags & KMC_STORE_CHAIN) && s->ld != cfg->ndim) {
@@ -725,6 +730,10 @@ KMC_EXPORT void kmc_sampler_destroy(kmc_sampler* s)
     (void)hipSetDevice(s->cfg.device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     if (s->copy_stream) (void)hipStreamSynchronize(s->copy_stream);
+    // The buffers go back to the allocation cache below, without the device-wide wait hipFree used to imply.  Work that OTHER
+    // streams may still have in flight on them -- a caller's stream bound earlier (kmc_sampler_set_stream), a framework's
+    // collectives on a replica shard's rows -- is waited for here; a plain single-GPU sampler (its own stream only) pays nothing.
+    if (s->foreign_stream_seen || s->cfg.shard_count > 1 || s->comm) (void)hipDeviceSynchronize();
     if (!s->guards.empty() && s->stream) check_guards(s);
     for (int i = 0; i < kUExec; ++i) {
         if (s->uexec[i]) (void)hipGraphExecDestroy(s->uexec[i]);
@@ -794,6 +803,7 @@ KMC_EXPORT kmc_status kmc_sampler_set_stream(kmc_sampler* s, void* hip_stream)
     if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
     s->stream = (hipStream_t)hip_stream;
     s->own_stream = false;
+    s->foreign_stream_seen = true;
     return KMC_OK;
 }
 
@@ -815,7 +825,7 @@ KMC_EXPORT kmc_status kmc_sampler_bind_positions(kmc_sampler* s, void* pos_dev)
     s->unext = 0;
     if (s->ugraph) { (void)hipGraphDestroy(s->ugraph); s->ugraph = nullptr; }
     if (s->own_pos) {
-        for (size_t i = 0; i < s->guards.size(); ++i)                   // (KMC_POISON: this allocation's guard goes with it)
+        for (size_t i = 0; i < s->guards.size(); ++i)                   // (KMC_DEBUG=poison: this allocation's guard goes with it)
             if (s->guards[i].first - s->guards[i].second == reinterpret_cast<char*>(s->d_pos)) { s->guards.erase(s->guards.begin() + (long)i); break; }
         cache_free(s->d_pos);
     }
@@ -889,6 +899,18 @@ KMC_EXPORT void* kmc_sampler_device_ptr(kmc_sampler* s, int which)
     }
 }
 
+// 1 when this library was built with -DKMC_P2P_EXPERIMENTAL (the push / lazy / folded-signal exchange variants exist), else 0
+KMC_EXPORT int kmc_has_p2p_experimental(void)
+{
+#ifdef KMC_P2P_EXPERIMENTAL
+    return 1;
+#else
+    return 0;
+#endif
+}
+
 KMC_EXPORT int kmc_sizeof_config(void) { return (int)sizeof(kmc_config); }
 KMC_EXPORT int kmc_sizeof_metropolis_config(void) { return (int)sizeof(kmc_metropolis_config); }
+KMC_EXPORT int kmc_sizeof_outputs(void) { return (int)sizeof(kmc_outputs); }
+KMC_EXPORT int kmc_sizeof_metropolis_outputs(void) { return (int)sizeof(kmc_metropolis_outputs); }
 

@@ -17,7 +17,7 @@ static_assert(1024 % kmc::kDrawBatch == 0, "the draw table holds whole batches")
 constexpr int64_t kDrawTableGens = 1024;   // resident mode with a draw table: generations per launch (table = 32 B x nwalkers x this)
 constexpr int64_t kGraphChunk = 64;   // generations per hipGraph replay (128 kernel nodes + 1)
 constexpr int kUExec = 6;             // executables of the "updated graph" launch mode (kmc_sampler::uexec)
-constexpr size_t kGuardBytes = 4096;  // KMC_POISON: guard band behind every device allocation of a sampler
+constexpr size_t kGuardBytes = 4096;  // KMC_DEBUG=poison: guard band behind every device allocation of a sampler
 constexpr int kHostPieces = 8;        // KMC_HOST_DENSITY: most pieces a half-step's proposals travel to the host in
 
 struct Plan {
@@ -50,6 +50,7 @@ struct kmc_sampler {
     int tpb = 256;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    bool foreign_stream_seen = false;                    // a caller's stream was bound at some point: destroy waits for the whole device before recycling buffers
     double* d_pos = nullptr;           // rows [nrows][ld]; float elements when f32 (KMC_F32)
     bool f32 = false;
     bool own_pos = true;
@@ -111,7 +112,7 @@ struct kmc_sampler {
     int64_t uchunk = 64;      // generations per replay of the updated graph
     bool updated_forced = false;   // KMC_LAUNCH=updated: no budget
     bool budget_fallback = false;  // this sampler left (or never entered) the updated-graph mode because the process budget was spent
-    std::vector<std::pair<char*, size_t>> guards;      // KMC_POISON: (guard address, size of the allocation in front of it)
+    std::vector<std::pair<char*, size_t>> guards;      // KMC_DEBUG=poison: (guard address, size of the allocation in front of it)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool have_run_events = false;
     bool positions_set = false;
@@ -150,13 +151,12 @@ struct kmc_sampler {
     uint32_t* d_done = nullptr;                          // KMC_P2P_FOLD_SIGNAL: workgroups drained, per launch
     bool fold_signal = false;
     bool stream_by_walker = false;                       // KMC_STREAM_CHAIN | KMC_CHAIN_BY_WALKER: host buffers are [walker][nsamples][..]
-    double *dev_dst_chain = nullptr, *dev_dst_logp = nullptr;   // ... and these are their device-side addresses (page-locked)
-    double *bw_scratch = nullptr, *bw_scratch_logp = nullptr;   // ... or one transposed block on the device, copied out as a 2-D window
+    double *bw_scratch = nullptr, *bw_scratch_logp = nullptr;   // ... one transposed block on the device, copied out as a 2-D window (also: rows_compact of odd ndim)
     std::vector<double> bw_host;                         // ... (host buffers that could not be page-locked: a block lands here, then is scattered by memcpy)
     int64_t flushed_done = -1;                           // samples_done at the last flush of an incomplete block (nothing new: skip it)
     bool push = false;                                   // KMC_P2P_PUSH / KMC_P2P_LAZY: d_pos = (1 + shard_count) blocks, see HalfStepArgs::push
     bool lazy = false;                                   // KMC_P2P_LAZY: + accept-byte maps behind the blocks, stamps in d_lazy
-    bool lazy_stats = false;                             // KMC_P2P_STATS=1: count remote draws / pulls (kmc_sampler_p2p_stats)
+    bool lazy_stats = false;                             // KMC_DEBUG=p2p-stats: count remote draws / pulls (kmc_sampler_p2p_stats)
     unsigned char* d_lazy = nullptr;                     // {stamps[P][2][h_loc] {fetched, modified}, stats[2]}
     unsigned char* peer_amap_in[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     double* peer_pos[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -199,7 +199,7 @@ kmc_status load_user(kmc_user_density* ud, bool with_vec, int L, int K, int iter
 kmc_status check_p2p_err(kmc_sampler* s);                // a peer wait that timed out invalidates everything after it
 
 // kmc_diag.hip
-void check_guards(kmc_sampler* s);                       // KMC_POISON: abort when a guard band was overwritten
+void check_guards(kmc_sampler* s);                       // KMC_DEBUG=poison: abort when a guard band was overwritten
 void reinstall_abort_backtrace();                        // KMC_ABORT_BACKTRACE: (re)install the SIGABRT handler
 
 }  // namespace kmc_host

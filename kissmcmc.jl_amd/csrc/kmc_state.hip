@@ -169,7 +169,9 @@ KMC_EXPORT kmc_status kmc_sampler_set_state(kmc_sampler* s, const double* pos_ho
                                             const int64_t* naccept_host, int64_t generation)
 {
     if (!s || !pos_host || !logp_host || generation < 0) return fail(KMC_ERR_BAD_ARG, "bad argument");
-    if (s->d_chain || s->d_chain_logp) return fail(KMC_ERR_UNSUPPORTED, "kmc_sampler_set_state: not with chain storage (download the chain before checkpointing)");
+    // (stored blobs are chain storage too: after a resume past burn-in kmc_sampler_get_blobs would return rows never written)
+    if (s->d_chain || s->d_chain_logp || s->d_chain_blob)
+        return fail(KMC_ERR_UNSUPPORTED, "kmc_sampler_set_state: not with chain / blob storage (download the chain before checkpointing)");
     if (s->p2p && s->cfg.shard_count > 1)
         return fail(KMC_ERR_UNSUPPORTED, "kmc_sampler_set_state: P2P progress flags restart at 0; restore is single-GPU for now");
     HIP_TRY(hipSetDevice(s->cfg.device));

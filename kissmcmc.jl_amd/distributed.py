@@ -97,6 +97,14 @@ def local_to_global(local, nwalkers: int, world: int):
     return np.concatenate(first + second, axis=0)
 
 
+def _raise_together(votes, what: str, own_error=None):
+    """`votes[r]` = None, or rank r's error text (already gathered from every rank): when any rank failed, raise on THIS rank too."""
+    bad = [(r, v) for r, v in enumerate(votes) if v is not None]
+    if bad:
+        msg = f"{what} failed on rank(s) " + "; ".join(f"{r}: {v}" for r, v in bad)
+        raise RuntimeError(msg) from own_error
+
+
 class P2PEmcee:
     """Walker-sharded emcee with peer-to-peer partner reads (``KMC_P2P``): each rank holds only its
     own walkers, the half-step kernel reads partner rows straight from the owning GPU's HBM over
@@ -135,11 +143,20 @@ class P2PEmcee:
             self.connect()
 
     def connect(self):
-        """Collective: exchange the IPC handles and open the peers' buffers."""
+        """Collective: exchange the IPC handles and open the peers' buffers.  A rank whose part fails (``hipIpcOpenMemHandle``
+        refusing a handle, ...) still reaches the vote that follows, and then EVERY rank raises: nobody is left waiting in the
+        next collective for a rank that has already given up."""
         if self.world > 1:
             blobs = [None] * self.world
             dist.all_gather_object(blobs, self._handle, group=self.group)
-            self.sampler.p2p_connect(blobs)
+            err = None
+            try:
+                self.sampler.p2p_connect(blobs)
+            except Exception as e:  # noqa: BLE001
+                err = e
+            votes = [None] * self.world
+            dist.all_gather_object(votes, None if err is None else f"{type(err).__name__}: {err}", group=self.group)
+            _raise_together(votes, "P2PEmcee.connect (kmc_sampler_p2p_connect)", err)
 
     def _barrier(self):
         if self.world > 1:
@@ -266,21 +283,38 @@ class AllGatherEmcee:
             self.connect()
 
     def connect(self):
-        """Collective over all ranks."""
+        """Collective over all ranks.  Every step that can fail on ONE rank (loading librccl for the unique id, ``ncclCommInitRank``,
+        the graph capture) is followed by a vote every rank reaches, and a failure anywhere raises on EVERY rank -- the library
+        call itself never leaves the other ranks blocked in a collective."""
         from .sampler import Sampler
         group, use_graph = self.group, self._use_graph
-        uid = [Sampler.rccl_unique_id() if self.rank == 0 else None]
+        uid, err = [None, None], None
+        if self.rank == 0:
+            try:
+                uid[0] = Sampler.rccl_unique_id()
+            except Exception as e:  # noqa: BLE001
+                err = e
+                uid[1] = f"{type(e).__name__}: {e}"
         if self.world > 1:
             dist.broadcast_object_list(uid, src=0, group=group)
-        self.sampler.rccl_init(uid[0])
-        # captured all-gathers on every rank, or launch by launch on every rank: each rank captures its chunk now and the
-        # outcomes are reduced (MIN) before the first replay -- a rank never decides alone
-        got = self.sampler.rccl_capture() if use_graph else False
+        if uid[0] is None:
+            raise RuntimeError(f"AllGatherEmcee.connect: rank 0 could not create the RCCL unique id ({uid[1]})") from err
+        got = False
+        try:
+            self.sampler.rccl_init(uid[0])
+            # captured all-gathers on every rank, or launch by launch on every rank: each rank captures its chunk now and the
+            # outcomes are reduced (MIN) before the first replay -- a rank never decides alone
+            got = self.sampler.rccl_capture() if use_graph else False
+        except Exception as e:  # noqa: BLE001
+            err = e
         if self.world > 1:
             votes = [None] * self.world
-            dist.all_gather_object(votes, bool(got), group=group)
-            agreed = all(votes)
+            dist.all_gather_object(votes, (None if err is None else f"{type(err).__name__}: {err}", bool(got)), group=group)
+            _raise_together([v[0] for v in votes], "AllGatherEmcee.connect (kmc_sampler_rccl_init / _rccl_capture)", err)
+            agreed = all(v[1] for v in votes)
         else:
+            if err is not None:
+                raise err
             agreed = got
         self.captured = bool(agreed)
         if use_graph:

@@ -322,8 +322,8 @@ end
 
 # Layout drift between these mirrors and the library fails here, when the module loads -- not inside the first real ccall.
 function __init__()
-    for (sym, T) in ((:kmc_sizeof_config, KmcConfig), (:kmc_sizeof_metropolis_config, KmcMetropolisConfig))
-        n = sym === :kmc_sizeof_config ? ccall((:kmc_sizeof_config, LIB), Cint, ()) : ccall((:kmc_sizeof_metropolis_config, LIB), Cint, ())
+    for (n, T) in ((ccall((:kmc_sizeof_config, LIB), Cint, ()), KmcConfig), (ccall((:kmc_sizeof_metropolis_config, LIB), Cint, ()), KmcMetropolisConfig),
+                   (ccall((:kmc_sizeof_outputs, LIB), Cint, ()), KmcOutputs), (ccall((:kmc_sizeof_metropolis_outputs, LIB), Cint, ()), KmcMetropolisOutputs))
         n == sizeof(T) || error("$LIB: $(T) is $(sizeof(T)) bytes here but $n in the library (include/kissmcmc_hip.h changed: update the struct in KissMCMCHIP.jl)")
     end
 end

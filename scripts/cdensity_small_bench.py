@@ -30,7 +30,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "worker":
             print(f"{nw:5d} x {nd:2d} Rosenbrock as a CDensity, {G} generations: {ms * 1e3 / (2 * G):7.3f} us per half-step (device), {nw * G / wall:.3e} walker-steps/s wall, "
                   f"{s.launch_count} launches -- {s.describe().split(',')[0]}")
 elif len(sys.argv) > 1 and sys.argv[1] == "menu":
-    # the same small problems with the MENU densities next to their CDensity restatements, both resident (KMC_RESIDENT=pair: the
+    # the same small problems with the MENU densities next to their CDensity restatements, both resident (KMC_DEBUG=resident=pair: the
     # two-lanes-per-walker kernel instead of one walker per thread for ndim <= 8)
     import kissmcmc_jl_amd as kmc
     cases = [("exponential 100 x 1", kmc.Exponential(), kmc.CDensity("return x[0] < 0.0 ? -INFINITY : -x[0];"), 100, 1),
@@ -49,7 +49,7 @@ elif len(sys.argv) > 1 and sys.argv[1] == "menu":
                 s.run(4096)
                 s.sync()
                 out.append(s.last_run_ms() * 1e3 / 8192)
-        print(f"{label:22s}: menu density {out[0]:6.3f} us per half-step, CDensity {out[1]:6.3f}   [KMC_RESIDENT={os.environ.get('KMC_RESIDENT', 'default')}]")
+        print(f"{label:22s}: menu density {out[0]:6.3f} us per half-step, CDensity {out[1]:6.3f}   [KMC_DEBUG={os.environ.get('KMC_DEBUG', '')}]")
 else:
     for env in ({}, {"KMC_NO_RESIDENT": "1"}):
         print("==", env or "default")

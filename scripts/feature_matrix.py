@@ -76,7 +76,7 @@ def f_f32(kmc, pdf):
 
 
 def f_stream(kmc, pdf):
-    os.environ["KMC_CHAIN_BLOCK"] = "8"
+    os.environ["KMC_DEBUG"] = "chain-block=8"
     try:
         with kmc.Sampler(pdf, 2048, ND, 100, 20, 1, 2.0, SEED, store_chain=True, store_logp=True, stream_chain=True, chain_by_walker=True) as s:
             s.set_positions(theta(2048))
@@ -85,7 +85,7 @@ def f_stream(kmc, pdf):
             assert ch.shape == (2048, 80, ND)
             return "yes"
     finally:
-        del os.environ["KMC_CHAIN_BLOCK"]
+        del os.environ["KMC_DEBUG"]
 
 
 def _p2p(kmc, pdf, **kw):
@@ -115,18 +115,6 @@ def _p2p(kmc, pdf, **kw):
 def f_p2p_pull(kmc, pdf):
     _p2p(kmc, pdf)
     return "yes"
-
-
-def f_p2p_variants(kmc, pdf):
-    out = []
-    for name, kw, marker in (("push", dict(p2p_push=True), "pushed into the peers"), ("lazy", dict(p2p_push=True, p2p_lazy=True), "lazy pull"),
-                             ("folded signal", dict(p2p_fold=True), None)):
-        try:
-            how = _p2p(kmc, pdf, **kw)
-            out.append(f"{name}: " + ("yes" if marker is None or marker in how else "runs as pull"))
-        except kmc.KmcError as e:
-            out.append(f"{name}: no")
-    return "; ".join(out)
 
 
 def f_allgather(kmc, pdf):
@@ -189,7 +177,6 @@ FEATURES = [
     ("float rows (`KMC_F32`)", f_f32),
     ("streamed chain (`KMC_STREAM_CHAIN`)", f_stream),
     ("P2P pull (`KMC_P2P`)", f_p2p_pull),
-    ("P2P push / lazy / folded signal", f_p2p_variants),
     ("RCCL all-gather shards", f_allgather),
     ("dealt sub-ensembles", f_dealt),
     ("`set_state` (resume)", f_set_state),

@@ -10,7 +10,8 @@ import time
 
 import numpy as np
 
-os.environ.setdefault("KMC_P2P_STATS", "1" if "--stats" in sys.argv else "0")
+if "--stats" in sys.argv:
+    os.environ.setdefault("KMC_DEBUG", "p2p-stats")
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # one hardware queue per shard stream: shards spin on each other
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -9,7 +9,8 @@ import time
 
 import numpy as np
 
-os.environ.setdefault("KMC_P2P_STATS", "1" if "--stats" in sys.argv else "0")
+if "--stats" in sys.argv:
+    os.environ.setdefault("KMC_DEBUG", "p2p-stats")
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

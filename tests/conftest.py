@@ -46,3 +46,27 @@ def kmc():
         mod.build(force=True)
     import kissmcmc_jl_amd
     return kissmcmc_jl_amd
+
+
+@pytest.fixture
+def kmc_debug(monkeypatch):
+    """The library's test-only / A-B switches live in ONE variable, KMC_DEBUG="opt[=value],opt,..." (kmc_host.hpp: debug_opt):
+    `kmc_debug.set("chain-block", 1)`, `kmc_debug.unset("chain-block")`; undone with the test."""
+    class _Debug:
+        def __init__(self):
+            self.opts = {}
+
+        def _write(self):
+            if self.opts:
+                monkeypatch.setenv("KMC_DEBUG", ",".join(k if v is None else f"{k}={v}" for k, v in self.opts.items()))
+            else:
+                monkeypatch.delenv("KMC_DEBUG", raising=False)
+
+        def set(self, name, value=None):
+            self.opts[name] = value
+            self._write()
+
+        def unset(self, name):
+            self.opts.pop(name, None)
+            self._write()
+    return _Debug()

@@ -53,6 +53,10 @@ def test_struct_layout_matches_header(kmc, tmp_path):
     want = [C.sizeof(_lib.MetropolisConfig), _lib.MetropolisConfig.nchains.offset, _lib.MetropolisConfig.step.offset,
             _lib.MetropolisConfig.user_density.offset, C.sizeof(_lib.MetropolisOutputs), _lib.MetropolisOutputs.device_ms.offset]
     assert got == want
+    # ... and what the LIBRARY was compiled with (the load-time guard of every binding: config AND output structs)
+    L = _lib.lib()
+    assert L.kmc_sizeof_config() == C.sizeof(_lib.Config) and L.kmc_sizeof_outputs() == C.sizeof(_lib.Outputs)
+    assert L.kmc_sizeof_metropolis_config() == C.sizeof(_lib.MetropolisConfig) and L.kmc_sizeof_metropolis_outputs() == C.sizeof(_lib.MetropolisOutputs)
 
 
 def test_flag_and_id_constants_match_header(kmc, tmp_path):
@@ -213,7 +217,9 @@ def test_julia_shim_structs_mirror_the_header():
         fields = re.findall(r"^\s+(\w+)::([\w{},]+)", m.group(1), re.M)
         assert [f for f, _ in fields] == [f for f, _ in mirror._fields_], jl_name
         assert [jl_size[t] for _, t in fields] == [C.sizeof(t) for _, t in mirror._fields_], jl_name
-    assert "kmc_sizeof_config" in src and "function __init__()" in src
+    assert "function __init__()" in src
+    for fn in ("kmc_sizeof_config", "kmc_sizeof_metropolis_config", "kmc_sizeof_outputs", "kmc_sizeof_metropolis_outputs"):
+        assert f"(:{fn}, LIB)" in src, f"the shim's __init__ does not check {fn}()"
     # the flag constants the shim uses: same bits as the header's (via the ctypes module, itself checked against the header)
     consts = dict(re.findall(r"^const (KMC_\w+) = UInt32\(1\) << (\d+)", src, re.M))
     assert consts and all(1 << int(bit) == getattr(_lib, name[4:]) for name, bit in consts.items()), consts

@@ -116,3 +116,68 @@ def test_shard_slice(kmc):
         shard_slice(100, 0, 4)
     with pytest.raises(AssertionError):
         shard_slice(101, 0, 1)
+
+
+class _FailingSampler:
+    """Stands in for the HIP sampler inside P2PEmcee / AllGatherEmcee (no device here): the collective wiring is what is under test."""
+
+    def __init__(self, fail):
+        self.fail = fail
+
+    def p2p_connect(self, blobs):
+        assert all(b is not None for b in blobs)
+        if self.fail:
+            raise RuntimeError("hipIpcOpenMemHandle: invalid argument")
+
+    def rccl_init(self, uid):
+        assert uid == b"u" * 128
+        if self.fail:
+            raise RuntimeError("hipStreamBeginCapture: operation not permitted")
+
+    def rccl_capture(self):
+        return True
+
+    def rccl_set_capture(self, flag):
+        self.captured = flag
+
+
+def _connect_worker(rank, world, port, outdir, which, failing_rank):
+    sys.path.insert(0, ROOT)
+    from kissmcmc_jl_amd import distributed as D
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    try:
+        if which == "p2p":
+            d = D.P2PEmcee.__new__(D.P2PEmcee)
+            d.group, d.rank, d.world, d._handle = None, rank, world, b"h%d" % rank
+        else:
+            from kissmcmc_jl_amd import sampler as S
+            S.Sampler.rccl_unique_id = staticmethod(lambda: b"u" * 128)
+            d = D.AllGatherEmcee.__new__(D.AllGatherEmcee)
+            d.group, d.rank, d.world, d._use_graph, d.captured = None, rank, world, True, False
+        d.sampler = _FailingSampler(rank == failing_rank)
+        try:
+            d.connect()
+            outcome = "connected"
+        except RuntimeError as e:
+            outcome = str(e)
+        dist.barrier()                       # every rank came out of connect(): nobody is stuck in a collective
+        open(os.path.join(outdir, f"{which}{rank}.txt"), "w").write(outcome)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("which", ["p2p", "allgather"])
+@pytest.mark.parametrize("failing_rank", [-1, 1])
+def test_connect_fails_on_every_rank_when_it_fails_on_one(tmp_path, which, failing_rank):
+    """P2PEmcee.connect / AllGatherEmcee.connect: a rank whose local part raises (IPC open, ncclCommInitRank, graph capture) must not
+    leave the others blocked in the next collective -- every rank learns of it in a vote and raises the same error."""
+    mp.spawn(_connect_worker, args=(2, _free_port(), str(tmp_path), which, failing_rank), nprocs=2, join=True)
+    got = [open(os.path.join(str(tmp_path), f"{which}{r}.txt")).read() for r in range(2)]
+    if failing_rank < 0:
+        assert got == ["connected", "connected"]
+    else:
+        for g in got:
+            assert "failed on rank(s) 1:" in g and ("hipIpcOpenMemHandle" in g or "hipStreamBeginCapture" in g)

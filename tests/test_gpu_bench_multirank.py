@@ -14,10 +14,17 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_bench(extra_env, *args):
-    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    env.update({"KMC_BENCH_BACKEND": "gloo", "KMC_BENCH_WALKERS": "4096", "KMC_BENCH_TIMEOUT": "600", "KMC_BENCH_RUNG_TIMEOUT": "240"})
-    env.update(extra_env)
+def bench_env(test_opts, extra_env=None):
+    """The environment of a bench.py run: without any launcher's variables, the test switches in KMC_BENCH_TEST ("opt=value,...")."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "KMC_BENCH_TEST", "KMC_LAUNCH")}
+    env["KMC_BENCH_TEST"] = ",".join(k if v is True else f"{k}={v}" for k, v in test_opts.items())
+    env.update(extra_env or {})
+    return env
+
+
+def run_bench(extra_env, *args, **test_opts):
+    env = bench_env({"backend": "gloo", "walkers": 4096, **{k.replace("_", "-"): v for k, v in test_opts.items()}},
+                    {"KMC_BENCH_TIMEOUT": "600", "KMC_BENCH_RUNG_TIMEOUT": "240", **extra_env})
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", *args],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-4000:]
@@ -64,8 +71,7 @@ def test_bench_two_ranks_allgather_ladder():
 def test_bench_two_ranks_under_torch_distributed_run():
     """The driver's own form: python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2 -- bench.py is then ONE rank
     of the job and must not spawn anything itself."""
-    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    env.update({"KMC_BENCH_BACKEND": "gloo", "KMC_BENCH_WALKERS": "4096", "KMC_BENCH_RUNG_TIMEOUT": "240", "KMC_BENCH_NO_ALLGATHER_EXTRA": "1"})
+    env = bench_env({"backend": "gloo", "walkers": 4096, "no-allgather-extra": True}, {"KMC_BENCH_RUNG_TIMEOUT": "240"})
     import socket
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
@@ -100,7 +106,7 @@ def test_bench_two_ranks_under_torch_distributed_run():
 def test_bench_ladder_records_the_failed_rung():
     """A rung that fails on one rank is on record as not ok -- on every rank, rank 0's list is printed -- and `value_from` names the
     rung that supplied `value` instead."""
-    out, err = run_bench({"KMC_BENCH_FAULT": "p2p_selfcheck:0", "KMC_BENCH_RUNG_TIMEOUT": "120"})
+    out, err = run_bench({"KMC_BENCH_RUNG_TIMEOUT": "120"}, fault="p2p_selfcheck:0")
     common_checks(out)
     failed = [r_ for r_ in out["ladder"] if not r_["ok"]]
     assert len(failed) >= 1 and failed[0]["rung"].startswith("p2p set-up + self-check")
@@ -108,8 +114,8 @@ def test_bench_ladder_records_the_failed_rung():
 
 
 def bench_single(env_extra, launcher):
-    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "OMP_NUM_THREADS")}
-    env.update(env_extra)
+    env = bench_env({}, env_extra)
+    env.pop("OMP_NUM_THREADS", None)
     tail = [os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-other-configs", "--no-island"]
     r = subprocess.run([sys.executable, *launcher, *tail], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-4000:]
@@ -138,15 +144,14 @@ def test_bench_one_gpu_under_torch_distributed_run_equals_the_plain_call():
 
 
 def test_bench_sharded_ladder_over_real_rccl_with_one_rank():
-    """KMC_BENCH_FORCE_SHARDED=1: the N > 1 code path with ONE rank over the REAL collective backend ("nccl" = RCCL), which two ranks
+    """KMC_BENCH_TEST=force-sharded: the N > 1 code path with ONE rank over the REAL collective backend ("nccl" = RCCL), which two ranks
     on one device cannot have: process group with a device id, all-reduce / all-gather-object / all_to_all_single through RCCL, and
     the native exchange -- ncclCommInitRank, the all-gathers captured into the hipGraph chunks -- inside bench.py's own ladder."""
-    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "KMC_BENCH_BACKEND", "KMC_LAUNCH")}
     import socket
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    env.update({"KMC_BENCH_FORCE_SHARDED": "1", "KMC_BENCH_WALKERS": "8192", "KMC_BENCH_RUNG_TIMEOUT": "240", "MASTER_PORT": str(port)})
+    env = bench_env({"force-sharded": True, "walkers": 8192}, {"KMC_BENCH_RUNG_TIMEOUT": "240", "MASTER_PORT": str(port)})
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-4000:]
@@ -163,10 +168,10 @@ def test_bench_sharded_ladder_over_real_rccl_with_one_rank():
 
 @pytest.mark.parametrize("point", ["p2p_setup:1", "p2p_connect:0", "p2p_selfcheck:0", "p2p_run:1"])
 def test_bench_ladder_falls_through_together_when_one_rank_fails(point):
-    """KMC_BENCH_FAULT: ONE rank fails at a point of the peer-to-peer rung (set-up, self-check, after the timed run).  Every rank
+    """KMC_BENCH_TEST=fault=point:rank: ONE rank fails at a point of the peer-to-peer rung (set-up, self-check, after the timed run).  Every rank
     must then take the next rung together -- the all-gather exchange -- and the line must still be a verified result; nobody may be
     left inside a collective (the job would end in the watchdog's status 3)."""
-    out, err = run_bench({"KMC_BENCH_FAULT": point, "KMC_BENCH_RUNG_TIMEOUT": "120"})
+    out, err = run_bench({"KMC_BENCH_RUNG_TIMEOUT": "120"}, fault=point)
     common_checks(out)
     assert "injected fault" in err and "falling back to the RCCL all-gather exchange" in err
     assert "all-gather of the updated half per half-step" in out["config"]["parallelism"]
@@ -177,10 +182,7 @@ def test_bench_ladder_falls_through_together_when_one_rank_fails(point):
 def test_bench_extras_fail_together_without_taking_the_result_down(point, key):
     """One rank failing in the local set-up of an EXTRA (dealt mode, all-gather record): every rank skips that extra together;
     `value` -- measured before -- stands, the extra carries an error instead of numbers, the job ends with status 0."""
-    env = {"KMC_BENCH_FAULT": point, "KMC_BENCH_RUNG_TIMEOUT": "120"}
-    r_env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    r_env.update({"KMC_BENCH_BACKEND": "gloo", "KMC_BENCH_WALKERS": "4096", "KMC_BENCH_TIMEOUT": "600"})
-    r_env.update(env)
+    r_env = bench_env({"backend": "gloo", "walkers": 4096, "fault": point}, {"KMC_BENCH_TIMEOUT": "600", "KMC_BENCH_RUNG_TIMEOUT": "120"})
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"],
                        env=r_env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-4000:]

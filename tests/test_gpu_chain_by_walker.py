@@ -34,8 +34,8 @@ def test_by_walker_equals_reordered_sample_major(kmc, nw, nd, G, nburn, nthin, k
         np.testing.assert_array_equal(only, a)
 
 
-def test_by_walker_in_small_pieces(kmc, monkeypatch):
-    """The transposition runs in pieces of walkers that fit a scratch buffer; KMC_BY_WALKER_PIECE_MB shrinks it so that a
+def test_by_walker_in_small_pieces(kmc, monkeypatch, kmc_debug):
+    """The transposition runs in pieces of walkers that fit a scratch buffer; KMC_DEBUG=by-walker-piece-mb shrinks it so that a
     small chain takes many pieces (one walker per piece at the end of the range)."""
     nw, nd, G = 512, 16, 64
     th = np.random.default_rng(2).standard_normal((nw, nd))
@@ -45,7 +45,7 @@ def test_by_walker_in_small_pieces(kmc, monkeypatch):
         s.sync()
         b, lb = s.chain()
         for mb in ("0.05", "0.008", "0.001"):       # 6 walkers, 1 walker, less than one walker (-> one)
-            monkeypatch.setenv("KMC_BY_WALKER_PIECE_MB", mb)
+            kmc_debug.set("by-walker-piece-mb", mb)
             a, la = s.chain(by_walker=True)
             np.testing.assert_array_equal(a, b.transpose(1, 0, 2))
             np.testing.assert_array_equal(la, lb.T)

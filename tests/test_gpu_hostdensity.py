@@ -246,10 +246,10 @@ def test_accept_outcomes_through_the_c_abi(kmc, oracle):
 
 
 @pytest.mark.parametrize("zero_copy", ["0", "1"])
-def test_small_batches_with_and_without_the_copies(kmc, oracle, monkeypatch, zero_copy):
-    """Up to 256 KiB of proposals the kernels address the page-locked host arrays directly (KMC_HOST_ZEROCOPY); forced on for a batch
+def test_small_batches_with_and_without_the_copies(kmc, oracle, monkeypatch, zero_copy, kmc_debug):
+    """Up to 256 KiB of proposals the kernels address the page-locked host arrays directly (KMC_DEBUG=host-zerocopy); forced on for a batch
     the copies would take, and off for one they would not: the same chain as the device density either way."""
-    monkeypatch.setenv("KMC_HOST_ZEROCOPY", zero_copy)
+    kmc_debug.set("host-zerocopy", zero_copy)
     nw, nd, G = 600, 3, 60
     th = np.random.default_rng(3).standard_normal((nw, nd))
     host = kmc.HostLogPdf(lambda X: -0.5 * (X * X).sum(axis=1), vectorized=True)

@@ -25,10 +25,10 @@ def _pdf(kmc, z):
 
 
 @pytest.fixture(params=["table", "kernel"])
-def draws(request, monkeypatch):
+def draws(request, monkeypatch, kmc_debug):
     """Where the chains' draws are made: by a wide kernel first, read from a table (few chains: the default up to 16 384), or
     in the chains' own loop (many chains).  Same stream, same results; the parity tests run both whatever the chain count."""
-    monkeypatch.setenv("KMC_METRO_TABLE", "1" if request.param == "table" else "0")
+    kmc_debug.set("metro-table", "1" if request.param == "table" else "0")
     return request.param
 
 
@@ -110,9 +110,9 @@ def test_many_chains_recover_the_slow_reference_cases(kmc):
 
 @pytest.mark.parametrize("nc,nd,niter,nburn,nthin", [(1, 1, 9000, 3000, 1), (1, 2, 5000, 1000, 3), (63, 3, 700, 100, 2), (64, 1, 4100, 0, 1),
                                                      (65, 8, 300, 50, 1), (200, 5, 400, 399, 1), (1, 8, 2500, 2499, 1), (130, 2, 3, 1, 1)])
-def test_few_chains_read_their_draws_from_a_table(kmc, oracle, monkeypatch, nc, nd, niter, nburn, nthin):
+def test_few_chains_read_their_draws_from_a_table(kmc, oracle, monkeypatch, nc, nd, niter, nburn, nthin, kmc_debug):
     """One chain is the reference's own call (src/samplers.jl:59-77): partial waves, tiles of the table that end inside a run
-    (an LDS tile is 32 KiB: 2048 steps of one 1-D chain, 3 steps of 64 8-D chains), tables shorter than the run (KMC_METRO_TABLE_STEPS),
+    (an LDS tile is 32 KiB: 2048 steps of one 1-D chain, 3 steps of 64 8-D chains), tables shorter than the run (KMC_DEBUG=metro-table-steps),
     all stored samples in burn-in -- against the oracle, and equal to the in-kernel draws to the last bit."""
     from kissmcmc_jl_amd.metropolis import run_chains
     th = 0.3 * np.random.default_rng(nc + nd).standard_normal((nc, nd))
@@ -122,11 +122,11 @@ def test_few_chains_read_their_draws_from_a_table(kmc, oracle, monkeypatch, nc, 
     ref = oracle.metropolis(did, params, th, step, niter, nburn, nthin, 31)
     got = {}
     for mode, steps in (("1", None), ("1", "257"), ("0", None)):
-        monkeypatch.setenv("KMC_METRO_TABLE", mode)
+        kmc_debug.set("metro-table", mode)
         if steps:
-            monkeypatch.setenv("KMC_METRO_TABLE_STEPS", steps)
+            kmc_debug.set("metro-table-steps", steps)
         else:
-            monkeypatch.delenv("KMC_METRO_TABLE_STEPS", raising=False)
+            kmc_debug.unset("metro-table-steps")
         r = run_chains(pdf, kmc.GaussianStep(step), th, niter, nburn, nthin, 31, moments=True)
         np.testing.assert_array_equal(r["naccept"], ref["naccept"])
         np.testing.assert_allclose(r["chain"], ref["chain"], rtol=1e-10, atol=1e-10)
@@ -139,7 +139,7 @@ def test_few_chains_read_their_draws_from_a_table(kmc, oracle, monkeypatch, nc, 
         np.testing.assert_array_equal(got[("1", "257")][k], got[("0", None)][k], err_msg=k)
 
 
-def test_body_density_few_chains_run_in_registers(kmc, oracle, monkeypatch):
+def test_body_density_few_chains_run_in_registers(kmc, oracle, monkeypatch, kmc_debug):
     """A function-body density (CDensity) with the table: chains in registers instead of in memory; equal to the chain-in-memory
     kernel and to the menu density it restates."""
     from kissmcmc_jl_amd.metropolis import run_chains
@@ -147,7 +147,7 @@ def test_body_density_few_chains_run_in_registers(kmc, oracle, monkeypatch):
     th = np.random.default_rng(2).standard_normal((70, 3))
     out = {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("KMC_METRO_TABLE", mode)
+        kmc_debug.set("metro-table", mode)
         out[mode] = run_chains(kmc.CDensity(body, params=[0.2, 1.0 / 1.5]), kmc.GaussianStep(0.8), th, 600, 200, 2, 9, moments=True)
     menu = run_chains(kmc.GaussianIso(0.2, 1.5), kmc.GaussianStep(0.8), th, 600, 200, 2, 9, moments=True)
     for k in ("naccept", "chain", "final_pos"):

@@ -121,8 +121,8 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world,plan", [(2, ""), (4, ""), (2, "generic"), (2, "fold"), (4, "fold"), (2, "push"), (4, "push"),
-                                        (2, "push-fold"), (2, "lazy"), (4, "lazy"), (2, "lazy-fold"), (4, "lazy-fold")])   # the GPU box allows 6 processes on the card: parent + 4 ranks at most
+# (the push / lazy / folded-signal plans of _worker: tests/p2p_experimental_cases.py, against the -DKMC_P2P_EXPERIMENTAL library)
+@pytest.mark.parametrize("world,plan", [(2, ""), (4, ""), (2, "generic")])   # the GPU box allows 6 processes on the card: parent + 4 ranks at most
 def test_p2p_processes_sharing_one_gpu_equal_oracle(oracle, tmp_path, world, plan):
     import torch.multiprocessing as mp
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), plan), nprocs=world, join=True)
@@ -141,13 +141,6 @@ def test_p2p_tolerates_a_late_rank(oracle, tmp_path):
     the late rank's progress flag) and the result is still bit-exact."""
     import torch.multiprocessing as mp
     mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), "", 1), nprocs=2, join=True)
-    ref = oracle.emcee(oracle.make_config(oracle.GAUSSIAN_ISO, [0.0, 1.0], NW, ND, G, NBURN, 1, 2.0, SEED),
-                       _theta0(), store_chain=False)
-    z = np.load(os.path.join(str(tmp_path), "out.npz"))
-    np.testing.assert_array_equal(z["nacc"], ref["naccept"])
-    np.testing.assert_array_equal(z["pos"], ref["final_pos"])
-    # the same with the progress signal folded into the half-step kernel (KMC_P2P_FOLD_SIGNAL)
-    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), "fold", 1), nprocs=2, join=True)
     ref = oracle.emcee(oracle.make_config(oracle.GAUSSIAN_ISO, [0.0, 1.0], NW, ND, G, NBURN, 1, 2.0, SEED),
                        _theta0(), store_chain=False)
     z = np.load(os.path.join(str(tmp_path), "out.npz"))
@@ -232,8 +225,7 @@ def test_p2p_with_finegrained_rows(oracle, tmp_path):
     np.testing.assert_array_equal(z["pos"], ref["final_pos"])
 
 
-@pytest.mark.parametrize("kw", [dict(), dict(p2p_push=True), dict(p2p_lazy=True), dict(p2p_lazy=True, p2p_fold=True)],
-                         ids=["pull", "push", "lazy", "lazy-fold"])
+@pytest.mark.parametrize("kw", [dict()], ids=["pull"])
 def test_two_shards_in_one_process(kmc, oracle, kw):
     """kmc_sampler_p2p_connect_local: both shards live in this process and run concurrently on their own streams,
     ordered by the same progress flags (what scripts/p2p_local_bench.py times); result = the oracle's."""
@@ -302,3 +294,14 @@ def test_two_p2p_shards_with_a_runtime_compiled_density(kmc, oracle, form):
     ref = oracle.emcee(oracle.make_config(oracle.ROSENBROCK, [1.0, 100.0, 20.0], nw, nd, G, nburn, 1, 2.0, seed), th, store_chain=False)
     np.testing.assert_array_equal(pos, ref["final_pos"])
     np.testing.assert_array_equal(nacc, ref["naccept"])
+
+
+def test_default_library_refuses_the_experimental_exchange_variants(kmc):
+    """Push / lazy pull / folded signal have peers write into plain device memory the local kernel reads through its own L2 -- nothing
+    one GPU can validate -- so the default library does not contain them: the flags are refused with the reason, by validation."""
+    from kissmcmc_jl_amd import _lib
+    assert _lib.lib().kmc_has_p2p_experimental() == 0
+    for kw in (dict(p2p_push=True), dict(p2p_lazy=True), dict(p2p_fold=True)):
+        with pytest.raises(kmc.KmcError, match="KMC_P2P_EXPERIMENTAL") as e:
+            kmc.Sampler(kmc.GaussianIso(), NW, ND, G, NBURN, 1, 2.0, SEED, shard_rank=0, shard_count=2, p2p=True, **kw)
+        assert e.value.status == _lib.ERR_UNSUPPORTED

@@ -165,21 +165,21 @@ def test_graph_replay_equals_eager(kmc, oracle):
 
 @pytest.mark.parametrize("name,nw,nd", [("expo", 100, 1), ("rosen", 100, 2), ("gauss", 256, 32), ("gauss", 34, 32), ("lognormal", 64, 3),
                                         ("gauss", 512, 32), ("rosen", 400, 16), ("expo", 1024, 8), ("gauss", 1000, 3)])
-def test_resident_small_ensemble_kernel_is_the_same_sampler(kmc, oracle, name, nw, nd, monkeypatch):
+def test_resident_small_ensemble_kernel_is_the_same_sampler(kmc, oracle, name, nw, nd, monkeypatch, kmc_debug):
     """nwalkers <= 1024: the whole ensemble runs out of one workgroup's LDS, many generations per launch
-    (resident mode) -- one walker per thread for short rows (ndim <= 8), two lanes per walker otherwise; KMC_RESIDENT=pair
+    (resident mode) -- one walker per thread for short rows (ndim <= 8), two lanes per walker otherwise; KMC_DEBUG=resident=pair
     keeps the two-lane kernel on short rows as well.  Each must be indistinguishable from the launch-per-half-step kernels
     and the oracle."""
     ref, res = _run_both(kmc, oracle, name, nw, nd, 200, 60, 2, seed=321)
     _compare(ref, res)
     if nd <= 8:
-        monkeypatch.setenv("KMC_RESIDENT", "pair")
+        kmc_debug.set("resident", "pair")
         with kmc.Sampler(_densities(kmc, oracle)[name][0], nw, nd, 10) as s:
             assert "resident mode" in s.describe() and "2 lanes" in s.describe()
         ref1, pair = _run_both(kmc, oracle, name, nw, nd, 200, 60, 2, seed=321)
         _compare(ref1, pair)
         np.testing.assert_array_equal(res["chain"], pair["chain"])
-        monkeypatch.delenv("KMC_RESIDENT")
+        kmc_debug.unset("resident")
         with kmc.Sampler(_densities(kmc, oracle)[name][0], nw, nd, 10) as s:
             assert "one walker per thread" in s.describe()
     monkeypatch.setenv("KMC_NO_RESIDENT", "1")
@@ -330,15 +330,15 @@ def test_updated_graph_budget_fallbacks_are_the_same_sampler(kmc, oracle, when, 
 
 
 @pytest.mark.parametrize("depth", [None, 2, "off"])
-def test_moment_ring_of_long_rows(kmc, oracle, depth, monkeypatch):
+def test_moment_ring_of_long_rows(kmc, oracle, depth, monkeypatch, kmc_debug):
     """ndim > 256: waves with an accepted move post the replaced row into a per-wave ring and moments_sweep folds the
     entries between graph chunks (HalfStepArgs::mring).  Same sums with the default depth, with a two-entry ring that
     overflows into the read-modify-write path all the time, and without the ring; 200 generations cross three graph
     chunks, an eager tail and a read-out in the middle."""
     if depth == "off":
-        monkeypatch.setenv("KMC_NO_MOMENT_RING", "1")
+        kmc_debug.set("no-moment-ring")
     elif depth is not None:
-        monkeypatch.setenv("KMC_MOMENT_RING_DEPTH", str(depth))
+        kmc_debug.set("moment-ring-depth", str(depth))
     nw, nd, G, nburn, nthin, seed = 1040, 600, 200, 20, 1, 5
     th = np.random.default_rng(3).standard_normal((nw, nd))
     with kmc.Sampler(kmc.GaussianIso(), nw, nd, G, nburn, nthin, 2.0, seed, moments=True) as s:

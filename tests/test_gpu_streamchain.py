@@ -23,9 +23,9 @@ def _equal(chain, clogp, ref):
     assert np.all(np.abs(clogp - ref["chain_logp"]) <= 1e-12 * np.maximum(1.0, np.abs(ref["chain_logp"])))
 
 
-def test_streamed_chain_equals_oracle_over_three_ring_laps(kmc, oracle, monkeypatch):
+def test_streamed_chain_equals_oracle_over_three_ring_laps(kmc, oracle, monkeypatch, kmc_debug):
     """4096 x 32, nthin = 1, 640 stored samples through a ring of 3 x 65 sample slots: > 3 laps."""
-    monkeypatch.setenv("KMC_CHAIN_BLOCK", "1")            # smallest legal block: the samples of one graph replay (+1)
+    kmc_debug.set("chain-block", "1")            # smallest legal block: the samples of one graph replay (+1)
     nw, nd, G, nburn, seed = 4096, 32, 700, 60, 5
     th = np.random.default_rng(1).standard_normal((nw, nd))
     with kmc.Sampler(kmc.GaussianIso(), nw, nd, G, nburn, 1, 2.0, seed, store_chain=True, store_logp=True, moments=True,
@@ -48,12 +48,12 @@ def test_streamed_chain_equals_oracle_over_three_ring_laps(kmc, oracle, monkeypa
                                   "small_ensemble", "unregistered_destination", "two_walkers_per_thread"])
 @pytest.mark.parametrize("by_walker", [False, True], ids=["sample-major", "by-walker"])
 @pytest.mark.parametrize("resident", [True, False], ids=["resident-where-it-fits", "multi-launch"])
-def test_streamed_chain_variants(kmc, oracle, monkeypatch, case, by_walker, resident):
+def test_streamed_chain_variants(kmc, oracle, monkeypatch, case, by_walker, resident, kmc_debug):
     """by-walker: KMC_STREAM_CHAIN | KMC_CHAIN_BY_WALKER -- completed blocks are written by a kernel of the copy stream
     into host arrays laid out [walker][nsamples][ndim] (the reference's thetas[w][k]).  Ensembles of up to 1024 walkers run in
     resident mode (launches cut to less than a block of the ring, ring positions carried by the kernel); KMC_NO_RESIDENT keeps
     the same jobs on the multi-launch kernels."""
-    monkeypatch.setenv("KMC_CHAIN_BLOCK", "1")
+    kmc_debug.set("chain-block", "1")
     if not resident:
         monkeypatch.setenv("KMC_NO_RESIDENT", "1")
     pdf, did, params, nw, nd, G, nburn, nthin, scale = kmc.GaussianIso(), oracle.GAUSSIAN_ISO, [0.0, 1.0], 1024, 8, 500, 37, 1, 1.0
@@ -73,7 +73,7 @@ def test_streamed_chain_variants(kmc, oracle, monkeypatch, case, by_walker, resi
     elif case == "two_walkers_per_thread":
         nw, nd = 1500, 3                                 # resident mode beyond 1024 walkers
     elif case == "unregistered_destination":
-        monkeypatch.setenv("KMC_NO_HOST_REGISTER", "1")  # staged copies instead of DMA into page-locked arrays
+        kmc_debug.set("no-host-register")  # staged copies instead of DMA into page-locked arrays
     th = scale * np.random.default_rng(2).standard_normal((nw, nd))
     seed = 77
     # (by walker into arrays that cannot be page-locked -- a container's RLIMIT_MEMLOCK is enough: the transposed blocks come
@@ -111,37 +111,8 @@ def test_streamed_chain_variants(kmc, oracle, monkeypatch, case, by_walker, resi
         assert clogp is None
 
 
-def test_streamed_by_walker_with_the_copy_kernel(kmc, oracle, monkeypatch):
-    """KMC_BYWALKER_COPY=kernel: instead of transposing a block into a device scratch and copying it out as a 2-D window,
-    a kernel of the copy stream writes it straight into the page-locked host arrays -- which must then be page-lockable."""
-    monkeypatch.setenv("KMC_CHAIN_BLOCK", "1")
-    monkeypatch.setenv("KMC_BYWALKER_COPY", "kernel")
-    nw, nd, G, nburn, nthin, seed = 1024, 7, 600, 50, 2, 12
-    th = np.random.default_rng(6).standard_normal((nw, nd))
-    with kmc.Sampler(kmc.GaussianIso(), nw, nd, G, nburn, nthin, 2.0, seed, store_chain=True, store_logp=True, stream_chain=True, chain_by_walker=True) as s:
-        s.set_positions(th)
-        s.run(G)
-        s.sync()
-        cw, lw = s.chain(by_walker=True)
-    ref = _oracle_chain(oracle, oracle.GAUSSIAN_ISO, [0.0, 1.0], th, G, nburn, nthin, seed)
-    want = ref["chain"].transpose(1, 0, 2)
-    if not np.array_equal(cw, want):
-        # (seen once, never reproduced -- profiles/NOTES.md: say exactly WHAT differs, as addresses in the host array)
-        bad = np.flatnonzero(cw.ravel() != want.ravel())
-        runs = np.split(bad, np.flatnonzero(np.diff(bad) > 1) + 1)
-        where = ", ".join(f"[{r[0]}..{r[-1]}] (byte {(cw.ctypes.data + 8 * r[0]) % 4096} of its page)" for r in runs[:8])
-        wrong = cw.ravel()[bad[:4]]
-        elsewhere = [np.flatnonzero(want.ravel() == v)[:3].tolist() for v in wrong]
-        pytest.fail(f"{len(bad)} of {cw.size} elements differ, {len(runs)} contiguous runs: {where}; first wrong values {wrong} occur in the "
-                    f"expected array at flat indices {elsewhere}; array base {cw.ctypes.data:#x}, aligned {cw.ctypes.data % 4096}")
-    assert np.all(np.abs(lw - ref["chain_logp"].T) <= 1e-12 * np.maximum(1.0, np.abs(ref["chain_logp"].T)))
-    monkeypatch.setenv("KMC_NO_HOST_REGISTER", "1")
-    with pytest.raises(kmc.KmcError, match="could not be page-locked"):
-        kmc.Sampler(kmc.GaussianIso(), nw, nd, G, nburn, nthin, 2.0, seed, store_chain=True, stream_chain=True, chain_by_walker=True)
-
-
-def test_streamed_chain_restart_and_emcee_front_end(kmc, oracle, monkeypatch):
-    monkeypatch.setenv("KMC_CHAIN_BLOCK", "1")
+def test_streamed_chain_restart_and_emcee_front_end(kmc, oracle, monkeypatch, kmc_debug):
+    kmc_debug.set("chain-block", "1")
     nw, nd, G, nburn = 512, 4, 400, 100
     th = np.random.default_rng(3).standard_normal((nw, nd))
     with kmc.Sampler(kmc.GaussianIso(), nw, nd, G, nburn, 1, 2.0, 9, store_chain=True, store_logp=True, stream_chain=True) as s:
@@ -162,11 +133,11 @@ def test_streamed_chain_restart_and_emcee_front_end(kmc, oracle, monkeypatch):
 
 
 @pytest.mark.parametrize("by_walker", [False, True], ids=["sample-major", "by-walker"])
-def test_one_shot_c_abi_streams_into_the_callers_buffers(kmc, oracle, monkeypatch, by_walker):
+def test_one_shot_c_abi_streams_into_the_callers_buffers(kmc, oracle, monkeypatch, by_walker, kmc_debug):
     """kmc_emcee_run with KMC_STREAM_CHAIN: samples land in out->chain / out->chain_logp directly (with KMC_CHAIN_BY_WALKER
     laid out [walker][sample][dim])."""
     from kissmcmc_jl_amd import _lib
-    monkeypatch.setenv("KMC_CHAIN_BLOCK", "1")
+    kmc_debug.set("chain-block", "1")
     nw, nd, G, nburn, nthin, seed = 2048, 16, 460, 20, 2, 123
     th = np.ascontiguousarray(np.random.default_rng(5).standard_normal((nw, nd)))
     ns = (G - nburn) // nthin
@@ -198,7 +169,7 @@ def test_stream_chain_argument_checks(kmc):
             _lib.check(s._L.kmc_sampler_set_chain_host(s._h, a.ctypes.data_as(C.POINTER(C.c_double)), None))
 
 
-def test_streamed_chain_random_splits_and_thinnings(kmc, oracle, monkeypatch):
+def test_streamed_chain_random_splits_and_thinnings(kmc, oracle, monkeypatch, kmc_debug):
     """Seeded random sweep of the ring bookkeeping: thinning, burn-in, block size, launch mode and the way a run is cut into
     run() calls (with and without syncs in between) -- every streamed chain equals the oracle's."""
     rng = np.random.default_rng(int(os.environ.get("KMC_FUZZ_BASE", 2026)))
@@ -208,7 +179,7 @@ def test_streamed_chain_random_splits_and_thinnings(kmc, oracle, monkeypatch):
         nthin = int(rng.choice([1, 1, 2, 3, 7, 64, 65]))
         G = int(rng.integers(150, 700))
         nburn = int(rng.integers(0, G // 2))
-        monkeypatch.setenv("KMC_CHAIN_BLOCK", str(int(rng.choice([1, 3, 50, 1000]))))
+        kmc_debug.set("chain-block", str(int(rng.choice([1, 3, 50, 1000]))))
         monkeypatch.setenv("KMC_LAUNCH", str(rng.choice(["graph", "updated", "eager"])))
         seed = int(rng.integers(1, 10 ** 6))
         with kmc.Sampler(kmc.GaussianIso(), nw, nd, G, nburn, nthin, 2.0, seed, store_chain=True, store_logp=True, stream_chain=True,
