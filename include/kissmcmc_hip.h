@@ -251,8 +251,16 @@ kmc_status  kmc_user_density_create(const char* term_expr, const char* pair_expr
  * return -INFINITY to reject.  Runs in the one-walker-per-lane kernels (the proposal is collected per lane, ndim <= 1024;
  * for double rows of ndim <= 256 the rows are staged through LDS so that memory is still read in whole rows):
  * emcee (multi-launch), initial log-pdfs, kmc_sampler_init_ball, many-chain Metropolis -- slower than a menu or term / pair
- * density of the same form (those stripe a row over lanes), far faster than a host callback.  Not with KMC_ISLANDS; under KMC_P2P the unstaged kernel. */
+ * density of the same form (those stripe a row over lanes), far faster than a host callback.  Not with KMC_ISLANDS; under KMC_P2P the unstaged kernel.
+ * A body that IS a sum over elements --
+ *     double s = 0; for (int i = 0; i < n; ++i) s += f(x[i]);  return g(s);       (or: i + 1 < n, reading x[i] and x[i + 1])
+ * with the loop body any statements that read the proposal only as x[i] (x[i + 1]) and change s only by `s +=` -- is recognised as
+ * such (kmc_user_density_is_separable) and the emcee samplers run it in the lane-striped kernels of the menu densities, the loop
+ * body as the per-element function and g as the finish: same operations per element, the sum in lane order instead of index
+ * order (log-pdfs equal to rounding, like a menu density's).  Early returns, several accumulators or other indices are not
+ * recognised and run one walker per lane as above.  Reference: the arbitrary closure pdf(theta), src/samplers.jl:257. */
 kmc_status  kmc_user_density_create_body(const char* body, kmc_user_density** out);
+int         kmc_user_density_is_separable(const kmc_user_density* ud);
 /* ... returning a BLOB with the log-density -- the reference's `pdf(theta) -> (p, blob)` under hasblob=true
  * (src/samplers.jl:150-151, :194-196, :257) for device densities -- the body of
  *     double logpdf(const double* x, int n, const double* p, double* blob) { BODY }

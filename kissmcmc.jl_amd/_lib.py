@@ -47,7 +47,7 @@ SYMBOLS = [
     "kmc_sampler_rccl_capture", "kmc_sampler_rccl_set_capture", "kmc_rccl_version", "kmc_device_free_bytes",
     "kmc_sampler_launch_mode", "kmc_updated_budget", "kmc_set_updated_budget_mb", "kmc_debug_accept_terms",
     "kmc_user_density_create_body_blob", "kmc_user_density_nblob", "kmc_logpdf_blob_eval_host", "kmc_sampler_get_blobs",
-    "kmc_device_cache_release", "kmc_has_p2p_experimental",
+    "kmc_device_cache_release", "kmc_has_p2p_experimental", "kmc_user_density_is_separable",
 ]
 
 
@@ -214,6 +214,8 @@ def lib() -> C.CDLL:
     L.kmc_user_density_create.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(vp)]
     L.kmc_user_density_create_body.argtypes = [C.c_char_p, C.POINTER(vp)]
     L.kmc_user_density_create_body_blob.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
+    L.kmc_user_density_is_separable.restype = C.c_int
+    L.kmc_user_density_is_separable.argtypes = [vp]
     L.kmc_user_density_nblob.restype = C.c_int
     L.kmc_user_density_nblob.argtypes = [vp]
     L.kmc_logpdf_blob_eval_host.argtypes = [cfgp, dp, dp, dp, C.c_int64]

@@ -474,6 +474,14 @@ struct TermPairDensity {
     __device__ static double finish(double S, const DensityParams&) { return S; }
 };
 
+// A function body recognised as a sum over elements (kmc_rtc.hip: recognise_separable): F::term / F::pair are the loop body,
+// F::finish the return expression over the sum.
+template <class F>
+struct SepDensity : TermPairDensity<F> {
+    __device__ static double seq_finish(const typename TermPairDensity<F>::Seq& q, int, const DensityParams& P) { return F::finish(q.s, P.ndim, P.p); }
+    __device__ static double finish(double S, const DensityParams& P) { return F::finish(S, P.ndim, P.p); }
+};
+
 // ------------------------------------------------------------------------------------------
 // A log-density given as a whole function over the proposal vector (runtime-compiled, kmc_user_density_create_body):
 // the kernels that walk a row element by element (generic half-step, initial log-pdfs, initial ball, Metropolis) collect

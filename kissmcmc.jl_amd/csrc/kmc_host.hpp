@@ -161,6 +161,13 @@ struct kmc_user_density {
     std::string body;                                // kmc_user_density_create_body: the whole function body instead of term / pair
     bool is_body = false;
     int nblob = 0;                                   // kmc_user_density_create_body_blob: doubles the body writes to blob[] per evaluation
+    // A body of the form  `double s = 0; for (int i = 0; i < n; ++i) s += f(x[i]);  return g(s);`  (optionally with the neighbour
+    // x[i + 1] and the bound i + 1 < n) is a sum over elements: kmc_user_density_create_body recognises it (kmc_rtc.hip:
+    // recognise_separable) and the samplers then run it in the lane-striped vector kernels like a term / pair density, with g as
+    // the finish.  Everything else about the density (initial log-pdfs, resident kernels, Metropolis) keeps evaluating the body.
+    bool sep = false;
+    bool sep_pair = false;                           // the loop reads x[i + 1] / runs to n - 1: its body is the PAIR function
+    std::string sep_functor;                         // "struct UserS { term, pair, finish };" generated from the body
     std::mutex mu;
     std::map<std::string, std::vector<char>> code;   // geometry key -> gfx950 code object
     // ... and the modules loaded from them, per device: shared by every sampler over this density (hipModuleLoadData is ~0.5 ms,

@@ -256,7 +256,9 @@ struct KernelParamPack {      // storage the kernelParams pointers of one node r
 hipKernelNodeParams node_params(const kmc_sampler* s, KernelParamPack* pk)
 {
     hipKernelNodeParams np{};
-    np.func = reinterpret_cast<void*>(s->plan.fn);
+    // (a runtime-compiled density's lane-striped kernel is a module function: the runtime accepts its hipFunction_t as the node's
+    //  function -- ensure_updated_graph tries it once and the sampler stays with the table graph if it does not)
+    np.func = s->user ? reinterpret_cast<void*>(s->uk.vec) : reinterpret_cast<void*>(s->plan.fn);
     np.gridDim = dim3((unsigned)s->grid);
     np.blockDim = dim3((unsigned)s->tpb);
     np.sharedMemBytes = 0;
@@ -267,7 +269,8 @@ hipKernelNodeParams node_params(const kmc_sampler* s, KernelParamPack* pk)
 
 bool updated_graph_possible(const kmc_sampler* s)
 {
-    return !s->user && !s->p2p && !s->host_eval && !s->islands && !s->resident && !s->comm && s->plan.fn != nullptr;
+    if (s->p2p || s->host_eval || s->islands || s->resident || s->comm || s->updated_refused) return false;
+    return s->user ? (s->plan.vec && s->uk.vec != nullptr && s->nblob == 0) : s->plan.fn != nullptr;
 }
 
 kmc_status ensure_updated_graph(kmc_sampler* s)
@@ -626,6 +629,18 @@ KMC_EXPORT kmc_status kmc_sampler_run(kmc_sampler* s, int64_t ngen)
         }
         return KMC_OK;
     };
+    if (use_graph && s->launch_mode == 0 && s->user && updated_graph_possible(s) && !s->uexec[0]) {
+        // module functions as graph kernel nodes: build the graph now; a runtime that refuses leaves this sampler with the table graph
+        if (ensure_updated_graph(s) != KMC_OK) {
+            (void)hipGetLastError();
+            for (int i = 0; i < kUExec; ++i) {
+                if (s->uexec[i]) { (void)hipGraphExecDestroy(s->uexec[i]); s->uexec[i] = nullptr; }
+                if (s->udone[i]) { (void)hipEventDestroy(s->udone[i]); s->udone[i] = nullptr; }
+            }
+            if (s->ugraph) { (void)hipGraphDestroy(s->ugraph); s->ugraph = nullptr; }
+            s->updated_refused = true;
+        }
+    }
     if (use_graph && s->launch_mode == 0) {
         const char* env = std::getenv("KMC_LAUNCH");
         if (env && std::strcmp(env, "graph") == 0) s->launch_mode = 1;

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
+#include <regex>
 #include <sstream>
 
 #include "kmc_sampler.hpp"
@@ -99,6 +100,180 @@ kmc_status kmc_host::rtc_compile_cached(const std::string& text, const char* pro
 }
 
 namespace kmc_host {
+// ---- a function body that is a sum over elements ------------------------------------------------------------------------
+// Recognised form (after comments are dropped; whitespace free):
+//     [declarations not touching x]                       e.g.  const double w = p[1];
+//     double ACC = 0;                                     the accumulator (exactly one)
+//     for (int I = 0; I < n; ++I)  STMT | { STMTS }       or  I + 1 < n  /  I < n - 1  when x[I + 1] is read
+//     return EXPR;                                        any expression of ACC, n, p and the declarations
+// where the loop's statements read the proposal only as x[I] (and x[I + 1]), change ACC only by `ACC += ...`, and contain no
+// return / break / continue / goto / nested loop.  Then  logpdf = EXPR(ACC = sum over I of the loop body's increments), and the
+// loop body is exactly a term (or pair) function of a TermPairDensity -- same operations per element, only the ORDER of the sum
+// differs (lane-striped, like the menu densities).  Anything else -- early returns, two accumulators, x[j] with another index --
+// is not recognised and keeps running one walker per lane.  KMC_DEBUG=no-body-routing switches the recognition off.
+namespace {
+std::string strip_comments(const std::string& t)
+{
+    std::string o;
+    for (size_t i = 0; i < t.size();) {
+        if (t.compare(i, 2, "//") == 0) { while (i < t.size() && t[i] != '\n') ++i; }
+        else if (t.compare(i, 2, "/*") == 0) { const size_t e = t.find("*/", i + 2); i = e == std::string::npos ? t.size() : e + 2; o += ' '; }
+        else o += t[i++];
+    }
+    return o;
+}
+std::string squeeze(const std::string& t)          // every run of white space -> nothing (identifiers stay apart: see callers)
+{
+    std::string o;
+    for (char c : t) if (!std::isspace((unsigned char)c)) o += c;
+    return o;
+}
+bool has_word(const std::string& t, const std::string& w)
+{
+    return std::regex_search(t, std::regex("\\b" + w + "\\b"));
+}
+}  // namespace
+
+bool recognise_separable(kmc_user_density* ud)
+{
+    if (!ud->is_body || ud->nblob > 0 || debug_opt("no-body-routing")) return false;
+    const std::string t = strip_comments(ud->body);
+    // one loop, of the canonical header
+    static const std::regex head("for\\s*\\(\\s*int\\s+(\\w+)\\s*=\\s*0\\s*;([^;]*);([^)]*)\\)");
+    std::smatch m;
+    if (!std::regex_search(t, m, head)) return false;
+    if (std::regex_search(m.suffix().first, t.end(), std::regex("\\b(for|while|do)\\b"))) return false;      // a second loop
+    const std::string I = m[1].str(), cond = squeeze(m[2].str()), inc = squeeze(m[3].str());
+    if (I == "x" || I == "n" || I == "p") return false;
+    if (inc != "++" + I && inc != I + "++" && inc != I + "+=1") return false;
+    bool to_n1;
+    if (cond == I + "<n") to_n1 = false;
+    else if (cond == I + "+1<n" || cond == I + "<n-1") to_n1 = true;
+    else return false;
+    // the loop's statement(s)
+    size_t b = (size_t)(m.suffix().first - t.begin());
+    while (b < t.size() && std::isspace((unsigned char)t[b])) ++b;
+    std::string loop;
+    size_t after;
+    if (b < t.size() && t[b] == '{') {
+        int depth = 0;
+        size_t e = b;
+        for (; e < t.size(); ++e) { if (t[e] == '{') ++depth; else if (t[e] == '}' && --depth == 0) break; }
+        if (e >= t.size()) return false;
+        loop = t.substr(b + 1, e - b - 1);
+        after = e + 1;
+    } else {
+        const size_t e = t.find(';', b);
+        if (e == std::string::npos) return false;
+        loop = t.substr(b, e - b + 1);
+        after = e + 1;
+    }
+    if (std::regex_search(loop, std::regex("\\b(return|break|continue|goto|for|while|do|switch)\\b"))) return false;
+    // what follows the loop: exactly one return statement
+    std::smatch r;
+    const std::string tail = t.substr(after);
+    if (!std::regex_match(tail, r, std::regex("\\s*return\\b([^;]*);\\s*"))) return false;
+    const std::string ret = r[1].str();
+    if (has_word(ret, "x") || has_word(ret, I)) return false;
+    // the accumulator: the one name the loop changes by +=, declared `double ACC = 0` in front of the loop
+    std::string acc;
+    {
+        static const std::regex pluseq("\\b(\\w+)\\s*\\+=");
+        for (auto it = std::sregex_iterator(loop.begin(), loop.end(), pluseq); it != std::sregex_iterator(); ++it) {
+            const std::string name = (*it)[1].str();
+            if (acc.empty()) acc = name;
+            else if (name != acc) return false;                              // two accumulators: not one sum
+        }
+        if (acc.empty() || acc == I) return false;
+        // every other mention of ACC inside the loop would make the increments depend on the running sum
+        const std::regex any_acc("\\b" + acc + "\\b"), inc_acc("\\b" + acc + "\\s*\\+=");
+        const auto n_all = std::distance(std::sregex_iterator(loop.begin(), loop.end(), any_acc), std::sregex_iterator());
+        const auto n_pe = std::distance(std::sregex_iterator(loop.begin(), loop.end(), inc_acc), std::sregex_iterator());
+        if (n_all != n_pe) return false;
+        if (std::regex_search(loop, std::regex("[-*/%&|^]=|<<=|>>=|\\+\\+|--")))  {
+            // compound assignments / increments of OTHER variables are fine only for names declared inside the loop body; keep it simple
+            return false;
+        }
+    }
+    // the proposal is read as x[I] and x[I + 1] only
+    bool reads_next = false;
+    {
+        static const std::regex xs("\\bx\\b\\s*(\\[([^\\]]*)\\])?");
+        for (auto it = std::sregex_iterator(loop.begin(), loop.end(), xs); it != std::sregex_iterator(); ++it) {
+            if (!(*it)[1].matched) return false;                              // x without an index (passed on, x + k, ...)
+            const std::string idx = squeeze((*it)[2].str());
+            if (idx == I) continue;
+            if (idx == I + "+1" || idx == "1+" + I) { reads_next = true; continue; }
+            return false;
+        }
+    }
+    if (reads_next && !to_n1) return false;                                   // (would read past the row's end anyway)
+    // the declarations in front of the loop: `[const] double|int a = e[, b = f];` only, ACC among them with the value 0
+    const std::string pre = t.substr(0, (size_t)m.position(0));
+    std::string prelude;                                                      // everything but ACC, for both generated functions
+    bool acc_declared = false;
+    {
+        size_t i = 0;
+        while (i < pre.size()) {
+            const size_t e = pre.find(';', i);
+            const std::string st = pre.substr(i, (e == std::string::npos ? pre.size() : e) - i);
+            i = e == std::string::npos ? pre.size() : e + 1;
+            if (squeeze(st).empty()) continue;
+            std::smatch d;
+            if (!std::regex_match(st, d, std::regex("\\s*(const\\s+)?(double|int)\\s+(.*)"))) return false;
+            if (has_word(st, "x") || st.find('{') != std::string::npos) return false;
+            // split the declarators at top-level commas
+            std::vector<std::string> decls;
+            {
+                std::string cur;
+                int depth = 0;
+                for (char c : d[3].str()) {
+                    if (c == '(' || c == '[') ++depth;
+                    if (c == ')' || c == ']') --depth;
+                    if (c == ',' && depth == 0) { decls.push_back(cur); cur.clear(); } else cur += c;
+                }
+                decls.push_back(cur);
+            }
+            std::string kept;
+            for (const std::string& dc : decls) {
+                std::smatch a;
+                if (std::regex_match(dc, a, std::regex("\\s*(\\w+)\\s*=\\s*(.*?)\\s*")) && a[1].str() == acc) {
+                    if (d[2].str() != "double" || !std::regex_match(a[2].str(), std::regex("[-+]?0*\\.?0*"))) return false;    // ACC must start at 0
+                    if (squeeze(a[2].str()).empty()) return false;
+                    acc_declared = true;
+                    continue;
+                }
+                if (has_word(dc, acc)) return false;
+                if (std::regex_match(dc, a, std::regex("\\s*(\\w+)\\b.*")) &&
+                    std::regex_search(loop, std::regex("\\b" + a[1].str() + "\\s*(\\[[^\\]]*\\]\\s*)?=[^=]")))
+                    return false;                                             // a declaration the loop assigns to: state carried between elements
+                kept += (kept.empty() ? "" : ", ") + dc;
+            }
+            if (!kept.empty()) prelude += (d[1].matched ? "const " : "") + d[2].str() + " " + kept + "; ";
+        }
+    }
+    if (!acc_declared) return false;
+    // the loop body as a function of (x[I] -> kmc_x, x[I + 1] -> kmc_y)
+    std::string fn = std::regex_replace(loop, std::regex("\\bx\\s*\\[\\s*(" + I + "\\s*\\+\\s*1|1\\s*\\+\\s*" + I + ")\\s*\\]"), "kmc_y");
+    fn = std::regex_replace(fn, std::regex("\\bx\\s*\\[\\s*" + I + "\\s*\\]"), "kmc_x");
+    const std::string body_fn = "(void)kmc_x; (void)kmc_y; (void)" + I + "; (void)n; (void)p; " + prelude + "double " + acc + " = 0.0; { " + fn + " } return " + acc + ";";
+    std::ostringstream o;
+    o << "namespace {\nstruct UserS {\n"
+      << "  static constexpr bool kHasPair = " << (to_n1 ? "true" : "false") << ";\n";
+    if (to_n1) {
+        o << "  __device__ static double term(double, int, int, const double*) { return 0.0; }\n"
+          << "  __device__ static double pair(double kmc_x, double kmc_y, int " << I << ", int n, const double* p) { " << body_fn << " }\n";
+    } else {
+        o << "  __device__ static double term(double kmc_x, int " << I << ", int n, const double* p) { const double kmc_y = 0.0; " << body_fn << " }\n"
+          << "  __device__ static double pair(double, double, int, int, const double*) { return 0.0; }\n";
+    }
+    o << "  __device__ static double finish(double " << acc << ", int n, const double* p) { (void)n; (void)p; " << prelude << "return (" << ret << "); }\n};\n}\n";
+    ud->sep = true;
+    ud->sep_pair = to_n1;
+    ud->sep_functor = o.str();
+    return true;
+}
+
 bool staged_possible(const kmc_user_density* ud, bool f32, int64_t ndim, bool p2p = false)
 {
     const char* env = std::getenv("KMC_PLAN");
@@ -164,11 +339,12 @@ kmc_status compile_user(kmc_user_density* ud, bool with_vec, int L, int K, int i
                         bool p2p = false)
 {
     // resident_K also sizes the island kernel (same row striping: 2 lanes per walker, K chunks)
-    if (ud->is_body && (with_vec || island_S > 0))
-        return fail(KMC_ERR_UNSUPPORTED, "a body density runs in the one-walker-per-lane kernels only");
+    if (ud->is_body && ((with_vec && !ud->sep) || island_S > 0))
+        return fail(KMC_ERR_UNSUPPORTED, "a body density runs in the one-walker-per-lane kernels only (unless it is a recognised sum over elements)");
+    const bool staged = !with_vec && staged_possible(ud, f32, ndim, p2p);
     char key[112];
     std::snprintf(key, sizeof(key), "%d:%d,%d,%d,%d|%d,%d|%d|%d|%lld|%d|%d|%d", (int)with_vec, L, K, iter, (int)ragged, resident_K,
-                  (int)resident_ragged, island_S, (int)f32, ud->is_body ? (long long)ndim : 0ll, (int)staged_possible(ud, f32, ndim, p2p), (int)p2p, ud->nblob);
+                  (int)resident_ragged, island_S, (int)f32, ud->is_body ? (long long)ndim : 0ll, (int)staged, (int)p2p, ud->nblob);
     const char* peer = p2p ? "true" : "false";         // KMC_P2P: partner rows read from their owners (pull)
     const char* rowt = f32 ? "float" : "double";       // storage type of the walker rows (KMC_F32 / KMC_F64)
     std::lock_guard<std::mutex> lock(ud->mu);
@@ -184,14 +360,15 @@ kmc_status compile_user(kmc_user_density* ud, bool with_vec, int L, int K, int i
 
     std::ostringstream src;
     src << "#include \"kmc_islands.hpp\"\n" << user_functor_source(ud) << user_density_alias(ud, ndim)
+        << (ud->is_body && with_vec ? ud->sep_functor + "using UDV = kmc::SepDensity<UserS>;\n" : std::string("using UDV = UD;\n"))
         << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_generic(KMC_FRONT_PARAMS, const kmc::HalfStepArgs a) { kmc::half_step_generic_body<UD, " << peer << ", " << rowt << ">(KMC_FRONT_PACK, a); }\n"
         << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_logpdf(const kmc::LogpdfArgs a) { kmc::logpdf_rows_body<UD>(a); }\n"
         << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_init_ball(const kmc::InitBallArgs a) { kmc::init_ball_body<UD>(a); }\n";
-    if (staged_possible(ud, f32, ndim, p2p))
+    if (staged)
         src << "extern \"C\" __global__ __launch_bounds__(" << kStagedTPB << ") void kmc_user_staged(KMC_FRONT_PARAMS, const kmc::HalfStepArgs a) { kmc::half_step_staged_body<UD, "
             << ndim << ">(KMC_FRONT_PACK, a); }\n";
     if (with_vec)
-        src << "extern \"C\" __global__ __launch_bounds__(" << vec_tpb(L) << ") void kmc_user_vec(KMC_FRONT_PARAMS, const kmc::HalfStepArgs a) { kmc::half_step_vec_body<UD, "
+        src << "extern \"C\" __global__ __launch_bounds__(" << vec_tpb(L) << ") void kmc_user_vec(KMC_FRONT_PARAMS, const kmc::HalfStepArgs a) { kmc::half_step_vec_body<UDV, "
             << L << ", " << K << ", " << iter << ", " << peer << ", " << (ragged ? "true" : "false") << ", " << rowt << ">(KMC_FRONT_PACK, a); }\n";
     if (resident_K == 2048 && island_S == 0 && ud->is_body)   // two walkers per thread (1026 .. 2048 walkers)
         src << "extern \"C\" __global__ __launch_bounds__(1024) void kmc_user_resident(const kmc::ResidentArgs a) { kmc::resident_lane2_body<UD, " << ndim << ">(a); }\n";
@@ -244,7 +421,7 @@ kmc_status load_user(kmc_user_density* ud, bool with_vec, int L, int K, int iter
     HIP_TRY(hipModuleGetFunction(&uk->logpdf, uk->mod, "kmc_user_logpdf"));
     HIP_TRY(hipModuleGetFunction(&uk->init_ball, uk->mod, "kmc_user_init_ball"));
     if (with_vec) HIP_TRY(hipModuleGetFunction(&uk->vec, uk->mod, "kmc_user_vec"));
-    if (staged_possible(ud, f32, ndim, p2p)) HIP_TRY(hipModuleGetFunction(&uk->staged, uk->mod, "kmc_user_staged"));
+    if (!with_vec && staged_possible(ud, f32, ndim, p2p)) HIP_TRY(hipModuleGetFunction(&uk->staged, uk->mod, "kmc_user_staged"));
     if (resident_K != 0 && island_S == 0) HIP_TRY(hipModuleGetFunction(&uk->resident, uk->mod, "kmc_user_resident"));
     if (resident_K > 0 && island_S > 0) HIP_TRY(hipModuleGetFunction(&uk->island, uk->mod, "kmc_user_island"));
     return KMC_OK;
@@ -276,9 +453,17 @@ KMC_EXPORT kmc_status kmc_user_density_create_body(const char* body, kmc_user_de
     const std::vector<char>* code = nullptr;
     const kmc_status st = compile_user(ud, false, 0, 0, 0, false, 0, false, 0, false, &code, 4);   // syntax check now (any ndim)
     if (st != KMC_OK) { delete ud; return st; }
+    if (recognise_separable(ud)) {
+        // the generated functor must compile too (a body the recogniser misread: then it is simply not routed)
+        const std::vector<char>* vcode = nullptr;
+        if (compile_user(ud, true, 4, 1, 1, false, 0, false, 0, false, &vcode, 8) != KMC_OK) { ud->sep = false; ud->sep_functor.clear(); }
+    }
     *out = ud;
     return KMC_OK;
 }
+
+// 1 when the samplers run this body density in the lane-striped vector kernels (a recognised sum over elements), else 0
+KMC_EXPORT int kmc_user_density_is_separable(const kmc_user_density* ud) { return ud && ud->sep ? 1 : 0; }
 
 // ... whose body also fills blob[0 .. nblob): double logpdf(const double* x, int n, const double* p, double* blob)
 KMC_EXPORT kmc_status kmc_user_density_create_body_blob(const char* body, int nblob, kmc_user_density** out)

@@ -191,7 +191,10 @@ Plan make_plan(const kmc_config& c, int64_t n_active)
     }
     if (c.density == KMC_USER_DENSITY) {
         // kernels are compiled for exactly this geometry when the sampler is created
-        const bool body = c.user_density && static_cast<const kmc_user_density*>(c.user_density)->is_body;   // one walker per lane
+        const kmc_user_density* ud = static_cast<const kmc_user_density*>(c.user_density);
+        // a function body runs one walker per lane -- unless it was recognised as a sum over elements: lane-striped like term / pair
+        // (double rows, one GPU or the pull exchange; not for ensembles small enough for the resident kernels: decided by the caller)
+        const bool body = ud && ud->is_body && !(ud->sep && c.dtype == KMC_F64 && c.deal_count == 0);
         if (!body && !force_generic && L > 0 && 2 * L * K >= c.ndim && iter <= L && iter * K <= 16) {
             p.vec = true; p.L = L; p.K = K; p.ITER = iter;
         } else {
@@ -877,6 +880,7 @@ KMC_EXPORT kmc_status kmc_sampler_describe(const kmc_sampler* s, char* buf, int6
     if (s->d_ids) o << "; dealt sub-ensemble " << s->cfg.deal_rank << "/" << s->cfg.deal_count << " (walkers re-dealt between epochs)";
     if (s->d_mring) o << "; moments through a ring of " << s->mring_depth << " posted rows per wave";
     if (s->user) o << "; runtime-compiled density";
+    if (s->user && s->user->is_body && s->plan.vec && !s->resident && !s->islands) o << " (function body recognised as a sum over elements: lane-striped)";
     if (s->nblob > 0) o << " with a blob of " << s->nblob << " doubles per walker" << (s->d_chain_blob ? " (stored with every sample)" : "");
     if (s->p2p) o << "; P2P shard " << s->cfg.shard_rank << "/" << s->cfg.shard_count << (s->connected ? "" : " (not connected)");
     else if (s->cfg.shard_count > 1 || s->comm)

@@ -111,6 +111,7 @@ struct kmc_sampler {
     std::vector<hipGraphNode_t> unodes;
     int64_t uchunk = 64;      // generations per replay of the updated graph
     bool updated_forced = false;   // KMC_LAUNCH=updated: no budget
+    bool updated_refused = false;  // a runtime-compiled kernel the runtime would not take as a graph kernel node: table graph / eager only
     bool budget_fallback = false;  // this sampler left (or never entered) the updated-graph mode because the process budget was spent
     std::vector<std::pair<char*, size_t>> guards;      // KMC_DEBUG=poison: (guard address, size of the allocation in front of it)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;

@@ -244,6 +244,8 @@ class CDensity(ExprDensity):
 
     It runs one walker per lane (rows staged through LDS up to ndim 256, the generic kernel above), so it is about half as
     fast as a menu density or an :class:`ExprDensity` of the same form, and orders of magnitude faster than a host callable (:class:`HostLogPdf`).  ``kmc_user_density_create_body``.
+    A body that IS a sum over elements -- ``double s = 0; for (int i = 0; i < n; ++i) s += f(x[i]); return g(s);`` (or ``i + 1 < n``
+    with ``x[i + 1]``, like the example above) -- is recognised (:attr:`separable`) and runs in the lane-striped kernels at the menu densities' rate.
 
     ``nblob=m`` makes it the reference's ``pdf(theta) -> (p, blob)`` of ``hasblob=true`` (``src/samplers.jl:150-151, :194-196``)
     on the device: the body is then that of ``double logpdf(const double* x, int n, const double* p, double* blob)`` and fills
@@ -269,6 +271,11 @@ class CDensity(ExprDensity):
         else:
             _lib.check(self._L.kmc_user_density_create_body(self.body.encode(), C.byref(h)))
         self.user_handle = h
+
+    @property
+    def separable(self) -> bool:
+        """Whether the library recognised the body as a sum over elements (then the samplers stripe its rows over lanes)."""
+        return bool(self._L.kmc_user_density_is_separable(self.user_handle))
 
     def __repr__(self):
         return f"CDensity({self.body!r}, params={self._params}" + (f", nblob={self.nblob})" if self.nblob else ")")

@@ -149,6 +149,25 @@ def test_user_density_compiles_and_reports_syntax_errors(kmc):
     assert _lib.lib().kmc_validate(C.byref(c)) == _lib.OK
 
 
+def test_bodies_that_are_not_sums_over_elements_are_not_routed(kmc):
+    # (hiprtc compiles without a device: the recogniser and the functor it generates are checked here, the routed kernels in -m gpu)
+    """What the recogniser must leave alone (each would change meaning as a per-element function): early returns, two accumulators,
+    another index, state carried between elements, the running sum read inside the loop, no loop at all."""
+    assert not kmc.CDensity("double s = 0.0; for (int i = 0; i < n; ++i) { if (x[i] < 0.0) return -INFINITY; s += x[i]; } return -(p[0] * s);", params=[1.0]).separable
+    for body in ("double s = 0.0, t = 0.0; for (int i = 0; i < n; ++i) { s += x[i] * x[i]; t += x[i]; } return -0.5 * (s + p[0] * t * t);",
+                 "double s = 0; for (int i = 0; i < n; ++i) s += x[i] * x[0]; return -s;",
+                 "double s = 0; double c = 1.0; for (int i = 0; i < n; ++i) { c = c * 0.5; s += c * x[i]; } return -s;",
+                 "double s = 0; for (int i = 0; i < n; ++i) { s += x[i] * (1.0 + s); } return -s;",
+                 "double s = 0; for (int i = 0; i < n; ++i) s += x[i + 1]; return -s;",
+                 "const double t = x[0] + 5.0; return -(t * t) / 18.0;"):
+        assert not kmc.CDensity(body, params=[0.5]).separable, body
+    for body in ("double s = 0; for (int i = 0; i < n; ++i) s += x[i] * x[i]; return -0.5 * s;",
+                 "const double w = p[1] * p[1]; double s = 0; for (int i = 0; i < n; i++) { s += w * x[i] * x[i]; } return -0.5 * s / w;",
+                 "double s = 0; /* sum */ for (int i = 0; i < n - 1; ++i) { // pairs\n s += (x[i+1]-x[i])*(x[i+1]-x[i]); } return -0.5*s;",
+                 "double s = 0; for (int i = 0; i < n; ++i) { if (x[i] > 0) s += x[i]; else s += -2.0 * x[i]; } return -s;"):
+        assert kmc.CDensity(body, params=[0.5, 2.0]).separable, body
+
+
 def test_product_never_touches_the_oracle():
     """The product package must not import, link or execute anything under oracle/."""
     pkg = os.path.join(ROOT, "kissmcmc.jl_amd")

@@ -259,14 +259,16 @@ def test_two_shards_in_one_process(kmc, oracle, kw):
     np.testing.assert_array_equal(nacc, ref["naccept"])
 
 
-@pytest.mark.parametrize("form", ["expr", "body"])
-def test_two_p2p_shards_with_a_runtime_compiled_density(kmc, oracle, form):
+@pytest.mark.parametrize("form", ["expr", "body", "body-routed"])
+def test_two_p2p_shards_with_a_runtime_compiled_density(kmc, oracle, form, kmc_debug):
     """Runtime-compiled densities run under KMC_P2P too (the pull kernels are instantiated with the user's functor):
     Rosenbrock as term / pair expressions (lane-striped kernel) and as a function body (one walker per lane),
     two shards in one process, result = the oracle's menu Rosenbrock."""
     import torch
     nw, nd, G, nburn, seed = 1024, 16, 128, 30, 99
     th = 0.1 * np.random.default_rng(3).standard_normal((nw, nd))
+    if form == "body":
+        kmc_debug.set("no-body-routing")          # the one-walker-per-lane pull kernel; "body-routed": the same body, recognised as a sum over elements
     if form == "expr":
         pdf = kmc.ExprDensity("d < n-1 ? -((p[0]-x)*(p[0]-x))/p[2] : 0.0", "-(p[1]*((y-x*x)*(y-x*x)))/p[2]", [1.0, 100.0, 20.0])
     else:
@@ -275,7 +277,7 @@ def test_two_p2p_shards_with_a_runtime_compiled_density(kmc, oracle, form):
     shards = [kmc.Sampler(pdf, nw, nd, G, nburn, 1, 2.0, seed, moments=True, shard_rank=r, shard_count=2, p2p=True) for r in range(2)]
     streams = [torch.cuda.Stream(device=0, priority=-1), torch.cuda.Stream(device=0, priority=0)]
     try:
-        assert ("half_step_vec" if form == "expr" else "half_step_generic") in shards[0].describe()
+        assert ("half_step_generic" if form == "body" else "half_step_vec") in shards[0].describe()
         for sh, st in zip(shards, streams):
             sh.set_stream(st.cuda_stream)
         kmc.Sampler.p2p_connect_local(shards)

@@ -102,10 +102,12 @@ C_EXPO = "double s = 0.0; for (int i = 0; i < n; ++i) { if (x[i] < 0.0) return -
 @pytest.mark.parametrize("case", ["gauss_256x32", "gauss_1000x7", "rosen_128x2", "rosen_512x64", "expo_100x1", "expo_300x16",
                                   "gauss_200x33", "rosen_130x63", "gauss_96x65", "rosen_200x130", "gauss_256x32_generic",
                                   "gauss_300x256", "expo_170x97", "gauss_300x257", "rosen_196x130_generic"])
-def test_body_density_equals_the_oracle(kmc, oracle, case, monkeypatch):
+def test_body_density_equals_the_oracle(kmc, oracle, case, monkeypatch, kmc_debug):
     """A C++ function body that restates a menu density in the oracle's own element order: chains, counters AND log-pdfs
     equal the oracle's (the one-walker-per-lane kernels sum in index order, as the oracle does)."""
     name, shape = case.split("_")[:2]
+    kmc_debug.set("no-body-routing")                     # the one-walker-per-lane kernels are the subject: these bodies are sums over elements and
+                                                         #  would otherwise run lane-striped (test_separable_body_runs_lane_striped_and_equals_the_oracle)
     monkeypatch.setenv("KMC_NO_RESIDENT", "1")           # the multi-launch kernels are the subject here (small ensembles with ndim <= 32
                                                          #  would run resident: test_body_density_runs_resident_on_small_ensembles)
     if case.endswith("_generic"):
@@ -126,6 +128,29 @@ def test_body_density_equals_the_oracle(kmc, oracle, case, monkeypatch):
     if name != "gauss":                                  # same operations in the same order: not even a rounding difference
         np.testing.assert_array_equal(got["logp"], ref["final_logp"])
     assert pdf(th[0]) == pytest.approx(oracle.logpdf(did, params, th[0]), rel=1e-14)       # host call = device evaluation
+
+
+@pytest.mark.parametrize("case", ["gauss_256x32", "gauss_1000x7", "rosen_128x2", "rosen_512x64", "gauss_200x33", "rosen_130x63", "gauss_96x65",
+                                  "rosen_200x130", "gauss_300x256", "gauss_300x257", "gauss_2200x4", "rosen_4096x32"])
+def test_separable_body_runs_lane_striped_and_equals_the_oracle(kmc, oracle, case, monkeypatch):
+    """A function body that is a sum over elements (`double s = 0; for (i < n) s += f(x[i]); return g(s);`, or the neighbour form with
+    x[i + 1]) is recognised by kmc_user_density_create_body and runs in the lane-striped vector kernels of the menu densities: same
+    chains and counters as the oracle, bit for bit; log-pdfs to rounding (lane-order sum).  The user's closure pdf(theta), src/samplers.jl:257."""
+    name, shape = case.split("_")[:2]
+    monkeypatch.setenv("KMC_NO_RESIDENT", "1")
+    nw, nd = (int(v) for v in shape.split("x"))
+    body, did, params, cparams, scale = {"gauss": (C_GAUSS, oracle.GAUSSIAN_ISO, [0.3, 1.5], [0.3, 1.0 / 1.5], 1.0),
+                                         "rosen": (C_ROSEN, oracle.ROSENBROCK, [1.0, 100.0, 20.0], [1.0, 100.0, 20.0], 0.1)}[name]
+    th = scale * np.random.default_rng(7).standard_normal((nw, nd))
+    pdf = kmc.CDensity(body, params=cparams)
+    assert pdf.separable
+    G, nburn, seed = 90, 25, 31
+    with kmc.Sampler(pdf, nw, nd, G, nburn, 1, 2.0, seed) as s:
+        how = s.describe()
+        assert "half_step_vec" in how and "recognised as a sum over elements" in how
+    got = _run(kmc, pdf, th, G, nburn, seed)
+    _check(oracle, did, params, th, G, nburn, seed, got)
+    assert pdf(th[0]) == pytest.approx(oracle.logpdf(did, params, th[0]), rel=1e-14)       # the host call still evaluates the body itself
 
 
 def test_body_density_with_real_coupling_samples_its_target(kmc, monkeypatch):
@@ -175,11 +200,12 @@ ROSEN_BODY = ("double s = 0.0; for (int i = 0; i + 1 < n; ++i) { double d = x[i 
 @pytest.mark.parametrize("nw,nd,G,nburn,nthin", [(100, 2, 700, 300, 1), (6, 4, 300, 100, 3), (1000, 5, 150, 40, 2), (1024, 4, 120, 0, 1), (200, 31, 90, 30, 1),
                                                   (64, 1, 400, 100, 1), (1000, 8, 100, 30, 1), (512, 32, 60, 20, 1), (1024, 12, 60, 10, 2), (600, 24, 50, 10, 1),
                                                   (1500, 3, 90, 30, 2), (2048, 1, 70, 0, 1), (1030, 8, 60, 20, 1)])
-def test_body_density_runs_resident_on_small_ensembles(kmc, oracle, monkeypatch, nw, nd, G, nburn, nthin):
+def test_body_density_runs_resident_on_small_ensembles(kmc, oracle, monkeypatch, nw, nd, G, nburn, nthin, kmc_debug):
     """A CDensity on the reference's own problem sizes: the whole ensemble in one workgroup's LDS, one walker per thread, many
     generations per launch (kmc_islands.hpp: resident_lane_body) -- same draws and element order as the multi-launch kernels:
     identical to the oracle's run of the menu density AND to the same sampler with KMC_NO_RESIDENT (chain, log-pdfs, counters,
     moments), across run() pieces and a restart."""
+    kmc_debug.set("no-body-routing")        # (the comparison below is with the one-walker-per-lane multi-launch kernels: same order, same bits)
     if nd == 1:
         pdf, did, params = kmc.CDensity("return x[0] < 0.0 ? -INFINITY : -x[0];"), oracle.EXPONENTIAL, [1.0]
         th = 0.5 + 0.1 * np.abs(np.random.default_rng(5).standard_normal((nw, nd)))
