@@ -213,9 +213,12 @@ def cpu_baseline_worker(budget_s: float = 10.0):
         return time.perf_counter() - t0
 
     def timed(nthreads, budget, repeats=1):
-        probe = 4
         run(2, nthreads)             # thread pool start, first touch of the state
-        t = run(probe, nthreads)
+        run(4, nthreads)             # (the first calls are mostly start-up: 0.2-0.6 s for a few generations, then 2 ms per generation)
+        probe, t = 16, run(16, nthreads)
+        while t < 0.5 and probe < 20000:                        # grow the probe until it takes half a second
+            probe = int(min(20000, max(2 * probe, probe * 0.6 / max(t, 1e-3))))
+            t = run(probe, nthreads)
         G = int(max(50, min(20000, budget / repeats / max(t / probe, 1e-6))))
         t = min(run(G, nthreads) for _ in range(repeats))      # (a shared host: the quieter of the runs)
         return NWALKERS_PER_GPU * G / t, G, t
@@ -353,31 +356,47 @@ def spawn_ranks(n: int, argv) -> int:
 LADDER = []      # [{"rung", "ok", "s"}]: every rung of the N > 1 ladder this rank went through, in order (printed with the line)
 
 
+PENDING = {"line": None}      # once `value` is measured: a callable(reason) -> the result line as it stands (an extra that hangs must not take it down)
+
+
 class rung:
     """Bound one rung of the N > 1 ladder (set-up + self-check, a timed run, an extra): when it has not finished after
     `seconds`, this rank reports where it hung and exits non-zero -- the launcher (spawn_ranks, or torch.distributed.run) then
     ends the job.  A collective that never returns cannot be interrupted from Python, hence a watchdog thread + os._exit.
     Every rung leaves a record {rung, ok, s} in LADDER (ok: no exception left the block and nobody cleared `.ok`), so that a first
-    hardware run can be diagnosed from the JSON line alone."""
+    hardware run can be diagnosed from the JSON line alone.
+    `fatal=False` (the extras that run AFTER `value` has been measured): on expiry rank 0 prints the result line as it stands, the
+    extra marked as timed out, and every rank leaves with status 0 -- a hung extra costs its own numbers, not the job's."""
 
-    def __init__(self, what: str, seconds: float = None):
+    def __init__(self, what: str, seconds: float = None, fatal: bool = True):
         self.what = what
         self.seconds = float(os.environ.get("KMC_BENCH_RUNG_TIMEOUT", 300)) if seconds is None else seconds
         self.timer = None
         self.ok = True
+        self.fatal = fatal
 
     def __enter__(self):
         import threading
 
         def expired():
-            print(f"[rank {os.environ.get('RANK', '0')}] bench.py: '{self.what}' did not finish within {self.seconds:.0f} s (hung collective or "
+            rank = os.environ.get("RANK", "0")
+            print(f"[rank {rank}] bench.py: '{self.what}' did not finish within {self.seconds:.0f} s (hung collective or "
                   f"peer wait?): giving up; Python stacks of this rank:", file=sys.stderr, flush=True)
-            print(f"[rank {os.environ.get('RANK', '0')}] ladder so far: {json.dumps(LADDER)}", file=sys.stderr, flush=True)
+            LADDER.append({"rung": self.what, "ok": False, "s": round(time.perf_counter() - self.t0, 3), "timed_out": True})
+            print(f"[rank {rank}] ladder so far: {json.dumps(LADDER)}", file=sys.stderr, flush=True)
             try:
                 import faulthandler
                 faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
             except Exception:  # noqa: BLE001
                 pass
+            if not self.fatal and PENDING["line"] is not None:
+                try:
+                    if rank == "0":
+                        print(json.dumps(PENDING["line"](f"'{self.what}' did not finish within {self.seconds:.0f} s")), flush=True)
+                    sys.stderr.flush()
+                    os._exit(0)
+                except Exception as e:  # noqa: BLE001
+                    print(f"[rank {rank}] could not print the result line ({e})", file=sys.stderr, flush=True)
             os._exit(3)
         self.timer = threading.Timer(self.seconds, expired)
         self.timer.daemon = True
@@ -595,6 +614,58 @@ def main():
                       "launcher": "bench.py itself (one child process per rank)" if os.environ.get("KMC_BENCH_SELF_SPAWNED") else "external (torch.distributed.run)",
                       "rank_env": {k: os.environ.get(k) for k in ("HSA_ENABLE_IPC_MODE_LEGACY", "OMP_NUM_THREADS")}}
 
+    extras = {"dealt": None, "allgather": None, "allgather_started": False}
+
+    def result_line(timed_out=None):
+        """The JSON line from what has been measured so far (rank 0; called at the end -- or by the watchdog of an extra that hangs)."""
+        steps_total = float(nw) * G
+        value = steps_total / elapsed
+        mean = msum / max(1, nmom)
+        var = msq / max(1, nmom) - mean ** 2
+        # dominant kernel: the half-step kernel `how` describes; one launch = one half-step of this rank
+        walkers_per_launch = NWALKERS_PER_GPU // 2
+        launch_us = event_ms * 1e3 / max(1, launches)
+        rows_here = NWALKERS_PER_GPU if (sharded and mode == "p2p") else nw             # (replica modes hold the whole ensemble)
+        roof = roofline_block(pdf, how, walkers_per_launch, NDIM, launch_us, launches, state_bytes(rows_here, NDIM, moment_bytes(how)), "c2", use_record=not sharded)
+        out = {
+            "metric": "walker-steps/sec", "value": value, "unit": "walker-steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"C2: emcee stretch move, {NWALKERS_PER_GPU} walkers/GPU x {NDIM}-dim isotropic Gaussian, "
+                                   f"{G} generations (burn-in {nburn}), a=2, streaming moments on, chain off",
+                       "nwalkers_total": nw, "ndim": NDIM, "generations": G, "gens_per_step": GENS_PER_STEP,
+                       "parallelism": "single GPU" if not sharded else parallelism,
+                       "execution": how},
+            "roofline": roof,
+            "check": {"accept_ratio_mean": acc, "posterior_mean_absmax": float(np.abs(mean).max()),
+                      "posterior_var_min": float(var.min()), "posterior_var_max": float(var.max()),
+                      "nmoment": int(nmom)},
+        }
+        if sharded:
+            out["collective"] = collective
+            out["ladder"] = LADDER                   # every rung rank 0 went through: {rung, ok, s}
+            out["value_from"] = value_from           # the rung whose timed run is `value`
+            out["check"]["timed_run_equals_unsharded_run"] = verified
+            out["dealt_mode"] = extras["dealt"] if extras["dealt"] is not None else {"error": timed_out or "not run"}
+            if extras["allgather"] is not None or (timed_out and extras["allgather_started"]):
+                out["allgather_mode"] = extras["allgather"] if extras["allgather"] is not None else {"error": timed_out}
+            if timed_out:
+                out["extras_timed_out"] = timed_out
+            # what the exchange has to move (DESIGN.md section 6): partners are uniform over the whole complementary half,
+            # so (P-1)/P of a rank's partner rows are remote, 1/P from each peer over that pair's single xGMI link
+            rows_per_peer = walkers_per_launch / world
+            out["fabric"] = {"remote_partner_bytes_per_gpu_per_launch": rows_per_peer * (world - 1) * NDIM * 8,
+                             "bytes_per_link_per_launch": rows_per_peer * NDIM * 8,
+                             "link_bound_us_at_77GBs": rows_per_peer * NDIM * 8 / 77e9 * 1e6,
+                             "push_bytes_per_link_per_launch": acc * walkers_per_launch * NDIM * 8,
+                             "variants_us_per_launch": {label: tc / 2048 * 1e6 for label, tc in tried},   # 1024 generations each
+                             "lazy_pulled_fraction_rank0": (lazy_stats[1] / lazy_stats[0]) if (mode == "p2p" and lazy_stats[0]) else None,
+                             "note": "pull variants move every drawn row once (bytes_per_link from each peer); push variants move "
+                                     "accepted rows only (push_bytes_per_link to each peer); link figure = one xGMI link, one "
+                                     "direction (~77 GB/s); config.parallelism names the variant that ran (default: one variant; "
+                                     "KMC_BENCH_EXCHANGE=all measures all six)"}
+        return out
+
     nw = NWALKERS_PER_GPU * world
     G = args.steps * GENS_PER_STEP
     nburn = G // 2
@@ -663,6 +734,8 @@ def main():
             the next rung together."""
             if bench_test_opt("fault") == f"{point}:{rank}":
                 raise RuntimeError(f"injected fault at {point}")
+            if bench_test_opt("fault") == f"{point}_hang:{rank}":      # ... or never comes back (the peers then block in their next collective)
+                time.sleep(10 ** 6)
 
         def all_ok(flag: bool) -> bool:
             t = torch.tensor([1.0 if flag else 0.0], device="cuda")
@@ -733,7 +806,7 @@ def main():
                 return None
             return d
 
-        def make_allgather(what):
+        def make_allgather(what, fatal=True):
             """The native all-gather exchange, set up in two votes: every rank's local part (its replica sampler), then the
             collective part (unique id, ncclCommInitRank, the capture vote).  The connected driver, or None on EVERY rank."""
             from kissmcmc_jl_amd.distributed import AllGatherEmcee
@@ -746,7 +819,7 @@ def main():
                 ok = False
             if all_ok(ok):
                 try:
-                    with rung(what):
+                    with rung(what, fatal=fatal):
                         d.connect()
                         fault("allgather_connect")
                 except Exception as e:  # noqa: BLE001
@@ -949,7 +1022,7 @@ def main():
         # Extra, NOT `value`: dealt sub-ensembles -- every GPU runs the reference's algorithm unchanged on its own 65 536
         # walkers (partners from its own complementary half) for an epoch, then ONE RCCL all_to_all_single re-deals the
         # walkers across the GPUs (state-independent permutation).  Same target distribution, no per-half-step exchange.
-        dealt = None
+        PENDING["line"] = result_line          # `value` stands from here on: an extra that hangs costs its own numbers only
         try:
             from kissmcmc_jl_amd.distributed import DealtEmcee, HipDealExecutor
             epoch = int(bench_test_opt("deal-epoch", 64))
@@ -964,7 +1037,8 @@ def main():
                 if dex is not None:
                     dex.close()
                 raise RuntimeError("the dealt mode could not be set up on every rank (see stderr)")
-            with rung('dealt sub-ensembles (extra)'):
+            with rung('dealt sub-ensembles (extra)', fatal=False):
+                fault("dealt_run")
                 dd = DealtEmcee(dex, nw, NDIM, epoch)
                 dd.set_positions(th)
                 dd.run(args.warmup * GENS_PER_STEP)
@@ -983,7 +1057,7 @@ def main():
                 dd.close()
             dmean = res["sum"] / max(1, res["n"])
             dvar = res["sumsq"] / max(1, res["n"]) - dmean ** 2
-            dealt = {"value": float(nw) * G / float(dt.item()), "unit": "walker-steps/s", "epoch_generations": epoch, "deals": dd.deals,
+            extras["dealt"] = {"value": float(nw) * G / float(dt.item()), "unit": "walker-steps/s", "epoch_generations": epoch, "deals": dd.deals,
                      "all_to_all_bytes_per_gpu_per_deal": NWALKERS_PER_GPU * (NDIM + 2) * 8,
                      "accept_ratio_mean": float(res["naccept"].sum() / nw / max(1, G - nburn)),
                      "posterior_mean_absmax": float(np.abs(dmean).max()),
@@ -992,18 +1066,18 @@ def main():
                              "half (not the reference's whole-ensemble rule), walkers re-dealt across the GPUs by one RCCL all_to_all_single "
                              "per epoch; bit-identical to the oracle's restatement kmco_emcee_dealt (tests/test_gpu_dealt.py)"}
         except Exception as e:  # noqa: BLE001
-            dealt = {"error": str(e)}
+            extras["dealt"] = {"error": str(e)}
 
     # Extra, NOT `value` (N > 1, when the peer-to-peer pull supplied `value`): the exchange the north star names -- one RCCL all-gather
     # of the updated half after every half-step, enqueued with the kernels inside the hipGraph chunks -- on a bounded piece
     # of the same job, so that both exchanges are on record from the same node.
-    allgather_extra = None
     if sharded and mode == "p2p" and not bench_test_opt("no-allgather-extra"):
         try:
             from kissmcmc_jl_amd.distributed import AllGatherEmcee
-            ag = make_allgather('native RCCL all-gather set-up (extra)')
+            extras["allgather_started"] = True
+            ag = make_allgather('native RCCL all-gather set-up (extra)', fatal=False)
             if ag is not None:
-                with rung('native RCCL all-gather (extra)'):
+                with rung('native RCCL all-gather (extra)', fatal=False):
                     gens = min(G, 1024)
                     ag.set_positions(th)
                     ag.run(128)
@@ -1025,67 +1099,25 @@ def main():
                 if rank == 0:
                     rp, ra, _ = unsharded(gens)
                     same = bool(np.array_equal(rp, apos) and np.array_equal(ra, aacc))
-                allgather_extra = {"value": float(nw) * gens / float(dta.item()), "unit": "walker-steps/s", "generations": gens,
+                extras["allgather"] = {"value": float(nw) * gens / float(dta.item()), "unit": "walker-steps/s", "generations": gens,
                                    "us_per_half_step": float(dta.item()) / (2 * gens) * 1e6, "equals_unsharded_run": same,
                                    "bytes_received_per_gpu_per_half_step": (world - 1) * (NWALKERS_PER_GPU // 2) * NDIM * 8,
                                    "execution": how_ag.split(";")[-1].strip(),
                                    "note": "exact partner rule; full replica per rank, in-place ncclAllGather of the updated half per half-step"}
             else:
-                allgather_extra = {"error": "native RCCL all-gather could not be set up on every rank (see stderr)"}
+                extras["allgather"] = {"error": "native RCCL all-gather could not be set up on every rank (see stderr)"}
         except Exception as e:  # noqa: BLE001
-            allgather_extra = {"error": str(e)}
+            extras["allgather"] = {"error": str(e)}
 
     if rank == 0:
-        steps_total = float(nw) * G
-        value = steps_total / elapsed
-        mean = msum / max(1, nmom)
-        var = msq / max(1, nmom) - mean ** 2
-        # dominant kernel: the half-step kernel `how` describes; one launch = one half-step of this rank
-        walkers_per_launch = NWALKERS_PER_GPU // 2
-        launch_us = event_ms * 1e3 / max(1, launches)
-        rows_here = NWALKERS_PER_GPU if (sharded and mode == "p2p") else nw             # (replica modes hold the whole ensemble)
-        roof = roofline_block(pdf, how, walkers_per_launch, NDIM, launch_us, launches, state_bytes(rows_here, NDIM, moment_bytes(how)), "c2", use_record=not sharded)
-        out = {
-            "metric": "walker-steps/sec", "value": value, "unit": "walker-steps/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"C2: emcee stretch move, {NWALKERS_PER_GPU} walkers/GPU x {NDIM}-dim isotropic Gaussian, "
-                                   f"{G} generations (burn-in {nburn}), a=2, streaming moments on, chain off",
-                       "nwalkers_total": nw, "ndim": NDIM, "generations": G, "gens_per_step": GENS_PER_STEP,
-                       "parallelism": "single GPU" if not sharded else parallelism,
-                       "execution": how},
-            "roofline": roof,
-            "check": {"accept_ratio_mean": acc, "posterior_mean_absmax": float(np.abs(mean).max()),
-                      "posterior_var_min": float(var.min()), "posterior_var_max": float(var.max()),
-                      "nmoment": int(nmom)},
-        }
-        if sharded:
-            out["collective"] = collective
-            out["ladder"] = LADDER                   # every rung rank 0 went through: {rung, ok, s}
-            out["value_from"] = value_from           # the rung whose timed run is `value`
-            out["check"]["timed_run_equals_unsharded_run"] = verified
-            out["dealt_mode"] = dealt
-            if allgather_extra is not None:
-                out["allgather_mode"] = allgather_extra
-            # what the exchange has to move: partners are uniform over the whole complementary half,
-            # so (P-1)/P of a rank's partner rows are remote, 1/P from each peer over that pair's single xGMI link
-            rows_per_peer = walkers_per_launch / world
-            out["fabric"] = {"remote_partner_bytes_per_gpu_per_launch": rows_per_peer * (world - 1) * NDIM * 8,
-                             "bytes_per_link_per_launch": rows_per_peer * NDIM * 8,
-                             "link_bound_us_at_77GBs": rows_per_peer * NDIM * 8 / 77e9 * 1e6,
-                             "push_bytes_per_link_per_launch": acc * walkers_per_launch * NDIM * 8,
-                             "variants_us_per_launch": {label: tc / 2048 * 1e6 for label, tc in tried},   # 1024 generations each
-                             "lazy_pulled_fraction_rank0": (lazy_stats[1] / lazy_stats[0]) if (mode == "p2p" and lazy_stats[0]) else None,
-                             "note": "pull variants move every drawn row once (bytes_per_link from each peer); push variants move "
-                                     "accepted rows only (push_bytes_per_link to each peer); link figure = one xGMI link, one "
-                                     "direction (~77 GB/s); config.parallelism names the variant that ran (default: one variant; "
-                                     "KMC_BENCH_EXCHANGE=all measures all six)"}
+        out = result_line()
         if not sharded:
             out["island_mode"] = island
             if not args.no_other_configs:
                 out["other_configs"] = other_configs(kmc, local_rank)
         if not sharded and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+        PENDING["line"] = None
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

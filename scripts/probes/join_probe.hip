@@ -14,7 +14,7 @@
 // Every partner row is CHECKED: row content is a pure function of (walker, last accepted step), and the reader recomputes the
 // step the partner was last accepted at -- a stale row (a hand-off that does not hold) is counted, not assumed away.
 //
-// Build + run (GPU box):  hipcc -O3 --offload-arch=gfx950 scripts/probes/join_probe.hip -o gpurun_out/join_probe && gpurun_out/join_probe
+// Build + run (GPU box):  hipcc -O3 -ffp-contract=off --offload-arch=gfx950 scripts/probes/join_probe.hip -o gpurun_out/join_probe && gpurun_out/join_probe
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -111,7 +111,8 @@ __global__ void join_probe(const Args a)
         if (accepted(walker, (uint32_t)s)) {
             last[half] = (uint32_t)s + 1u;
             double* own = a.pos + (size_t)walker * ND;
-            store_sc1(own, row_value(walker, last[half], 0) + 0.0 * (r1 + r2), row_value(walker, last[half], 1));
+            asm volatile("" :: "v"(r1), "v"(r2));                     // (the whole partner row was requested: keep both pieces alive)
+            store_sc1(own, row_value(walker, last[half], 0), row_value(walker, last[half], 1));
             store_sc1(own + 2, row_value(walker, last[half], 2), row_value(walker, last[half], 3));
         }
         if (!a.skip_join) {

@@ -192,3 +192,19 @@ def test_bench_extras_fail_together_without_taking_the_result_down(point, key):
     other = "allgather_mode" if key == "dealt_mode" else "dealt_mode"
     if other == "dealt_mode":
         assert "error" not in out[other]
+
+
+def test_bench_an_extra_that_hangs_does_not_take_the_result_down():
+    """One rank never comes back from the dealt-mode extra (KMC_BENCH_TEST=fault=dealt_run_hang:1): the peers block in its collectives, the
+    rung's watchdog expires on every rank -- and since `value` was measured before, rank 0 prints the line as it stands (the extra
+    marked as timed out) and the job ends with status 0 instead of losing the measurement."""
+    env = bench_env({"backend": "gloo", "walkers": 4096, "fault": "dealt_run_hang:1", "no-allgather-extra": True},
+                    {"KMC_BENCH_TIMEOUT": "600", "KMC_BENCH_RUNG_TIMEOUT": "45"})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-4000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith('{"metric"')][-1])
+    assert out["check"]["timed_run_equals_unsharded_run"] is True and "peer-to-peer exchange" in out["config"]["parallelism"]
+    assert out["value"] > 0 and "did not finish within" in out["extras_timed_out"]
+    assert "error" in out["dealt_mode"]
+    assert out["ladder"][-1]["rung"] == "dealt sub-ensembles (extra)" and out["ladder"][-1]["timed_out"] is True
