@@ -490,11 +490,19 @@ struct SepDensity : TermPairDensity<F> {
 template <class F, int MAXD>
 struct BodyDensity {
     static constexpr bool kHasFrag = false;
+    static constexpr int kRowEval = MAXD;            // the vector kernel may hand it whole proposals: eval_row(x[0..MAXD), n, P)
     struct Seq { double x[MAXD]; };
     __device__ static void seq_init(Seq&) {}
     __device__ static void seq_add(Seq& q, double v, int d, const DensityParams&) { if (d < MAXD) q.x[d] = v; }
     __device__ static double seq_finish(const Seq& q, int ndim, const DensityParams& P) { return F::eval(q.x, ndim, P.p); }
+    __device__ static double eval_row(const double* x, int ndim, const DensityParams& P) { return F::eval(x, ndim, P.p); }
+    // (never called: a body has no lane-striped form; the vector kernel evaluates whole rows instead, see RowEvalTrait)
+    template <int L, int K> __device__ static double frag_partial(const double2 (&)[K], int, int, const DensityParams&) { return 0.0; }
+    __device__ static double finish(double S, const DensityParams&) { return S; }
 };
+// A density the vector kernel evaluates per WALKER on the whole proposal (collected through LDS) instead of per lane on its chunks
+template <class D, class = void> struct RowEvalTrait { static constexpr int n = 0; };
+template <class D> struct RowEvalTrait<D, decltype((void)D::kRowEval)> { static constexpr int n = D::kRowEval; };
 
 // ... returning a BLOB next to the log-density: the reference's `pdf(theta) -> (p, blob)` with hasblob=true
 // (src/samplers.jl:150-151, :194-196, :257), as NB doubles per evaluation.  F::eval(x, n, p, blob) fills blob[0..NB); the

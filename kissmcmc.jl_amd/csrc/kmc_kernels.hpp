@@ -793,6 +793,7 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
 #endif
     // ---- stretch move + log-pdf; xo becomes the proposal ------------------------------------
     double myp1 = 0.0;
+    constexpr int kRowND = RowEvalTrait<Dens>::n;                       // > 0: a function body over the whole proposal (see below)
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
 #pragma unroll
@@ -800,9 +801,38 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
             xo[it][k].x = as_stored<T>(fma(zB[it], xc[it][k].x - xo[it][k].x, xo[it][k].x));
             xo[it][k].y = as_stored<T>(fma(zB[it], xc[it][k].y - xo[it][k].y, xo[it][k].y));
         }
-        const double S  = group_sum<L>(Dens::template frag_partial<L, K>(xo[it], j, ndim, a.dp));
-        const double p1 = Dens::finish(S, a.dp);                         // :257
-        myp1 = (j == it) ? p1 : myp1;                                   // row -> scalar, no traffic
+        if constexpr (kRowND == 0) {
+            const double S  = group_sum<L>(Dens::template frag_partial<L, K>(xo[it], j, ndim, a.dp));
+            const double p1 = Dens::finish(S, a.dp);                     // :257
+            myp1 = (j == it) ? p1 : myp1;                               // row -> scalar, no traffic
+        }
+    }
+    if constexpr (kRowND > 0) {
+        // A caller's function body over the whole proposal (BodyDensity): rows are loaded, moved and stored lane-striped like
+        // everybody's, and only the evaluation is per walker -- the wave's W proposals go through a per-wave LDS tile (row stride
+        // 2 L K + 2 doubles: 16-byte aligned chunks) and the scalar-layout lane of each walker, the one that holds its draws and
+        // runs its accept test, reads its row back as a private array and calls the body once (src/samplers.jl:257), elements in
+        // index order: the same value, bit for bit, as the one-walker-per-lane kernels give.
+        extern __shared__ __attribute__((aligned(16))) double vec_rows[];
+        constexpr int TS = 2 * L * K + 2;
+        double* tile = vec_rows + (size_t)(threadIdx.x >> 6) * (size_t)(W * TS);
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+                if (cv[k]) *reinterpret_cast<double2*>(&tile[(it * G + g) * TS + 2 * (k * L + j)]) = xo[it][k];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (useA) {
+            double xrow[kRowND];
+            const double* src = &tile[(js * G + g) * TS];
+#pragma unroll
+            for (int d = 0; d + 1 < kRowND; d += 2) { const double2 v = *reinterpret_cast<const double2*>(&src[d]); xrow[d] = v.x; xrow[d + 1] = v.y; }
+            if constexpr (kRowND & 1) xrow[kRowND - 1] = src[kRowND - 1];
+            myp1 = Dens::eval_row(xrow, ndim, a.dp);
+        }
     }
 
 #ifdef KMC_PROBE
@@ -1113,6 +1143,9 @@ __global__ __launch_bounds__(256) void half_step_generic(KMC_FRONT_PARAMS, const
 // private arrays, which the compiler keeps in registers for short rows.  Accepted rows go back the same way.  Same
 // draws, same arithmetic and element order as half_step_generic (results identical); double rows, one GPU.
 // ------------------------------------------------------------------------------------------
+constexpr int kBodyVecMaxDim = 64;                                       // a body evaluated per walker inside the vector kernel: the proposal as a private array
+// LDS of the vector kernel when it evaluates a body per walker: one tile of W rows x (2 L K + 2) doubles per wave
+__host__ __device__ constexpr size_t body_vec_lds_bytes(int L, int K, int iter) { return (size_t)(vec_tpb(L) / 64) * (size_t)((64 / L) * iter) * (size_t)(2 * L * K + 2) * sizeof(double); }
 constexpr int kStagedTPB = 128;                                          // two waves per workgroup, one LDS tile each
 constexpr int kStagedMaxDim = 256;                                       // up to 64: two rows + the proposal per lane in registers; beyond: in scratch (spilled)
 __host__ __device__ constexpr int staged_tile_doubles(int nd) { return nd + (nd & 1) < 32 ? nd + (nd & 1) : 32; }

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 
@@ -171,7 +172,7 @@ hipError_t launch_half_kernel(const kmc_sampler* s, const HalfStepArgs& a)
     if (s->user) {
         const HalfStepLaunch la{f, a};
         if (s->uk.staged) return launch_module(s->uk.staged, (unsigned)s->grid, (unsigned)s->tpb, s->stream, la, (unsigned)staged_lds_bytes((int)s->cfg.ndim));
-        return launch_module(s->plan.vec ? s->uk.vec : s->uk.generic, (unsigned)s->grid, (unsigned)s->tpb, s->stream, la);
+        return launch_module(s->plan.vec ? s->uk.vec : s->uk.generic, (unsigned)s->grid, (unsigned)s->tpb, s->stream, la, s->plan.vec ? s->vec_lds : 0u);
     }
     hipLaunchKernelGGL(s->plan.fn, dim3(s->grid), dim3(s->tpb), 0, s->stream, f.pos, f.sched, f.ring_now, f.logp, f.gw0, f.nact_half,
                        f.seed_lo, f.seed_hi, f.nhalf, f.step, a);
@@ -261,7 +262,7 @@ hipKernelNodeParams node_params(const kmc_sampler* s, KernelParamPack* pk)
     np.func = s->user ? reinterpret_cast<void*>(s->uk.vec) : reinterpret_cast<void*>(s->plan.fn);
     np.gridDim = dim3((unsigned)s->grid);
     np.blockDim = dim3((unsigned)s->tpb);
-    np.sharedMemBytes = 0;
+    np.sharedMemBytes = s->user ? s->vec_lds : 0u;
     np.kernelParams = pk->ptrs;
     np.extra = nullptr;
     return np;
@@ -332,7 +333,9 @@ kmc_status launch_updated_graph(kmc_sampler* s, bool* launched)
     KMC_TRY(ensure_updated_graph(s));
     g_update_calls.fetch_add(2 * s->uchunk, std::memory_order_relaxed);
     const int i = s->unext;
+    const auto t_wait0 = std::chrono::steady_clock::now();
     if (s->uinflight[i]) { HIP_TRY(hipEventSynchronize(s->udone[i])); s->uinflight[i] = false; }
+    const auto t_upd0 = std::chrono::steady_clock::now();
     KernelParamPack pk;
     pk.bind();
     for (int64_t g = 0; g < s->uchunk; ++g)
@@ -342,7 +345,15 @@ kmc_status launch_updated_graph(kmc_sampler* s, bool* launched)
             const hipKernelNodeParams np = node_params(s, &pk);
             HIP_TRY(hipGraphExecKernelNodeSetParams(s->uexec[i], s->unodes[(size_t)(2 * g + half)], &np));
         }
+    const auto t_upd1 = std::chrono::steady_clock::now();
     HIP_TRY(hipGraphLaunch(s->uexec[i], s->stream));
+    const auto t_launch1 = std::chrono::steady_clock::now();
+    // where the feeding thread's time goes (kmc_sampler_describe with KMC_DEBUG=feed-stats): waiting for a free executable = the GPU is
+    // the bottleneck; updating + launching = the host's own cost per replay, which must stay below the replay's GPU time
+    s->feed_wait_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(t_upd0 - t_wait0).count();
+    s->feed_update_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(t_upd1 - t_upd0).count();
+    s->feed_launch_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(t_launch1 - t_upd1).count();
+    s->feed_replays += 1;
     *launched = true;
     HIP_TRY(hipEventRecord(s->udone[i], s->stream));
     s->uinflight[i] = true;

@@ -274,6 +274,12 @@ bool recognise_separable(kmc_user_density* ud)
     return true;
 }
 
+// a function body in the vector kernels, evaluated per walker on the whole proposal (KMC_DEBUG=no-body-vec: the staged kernel instead)
+bool body_vec_possible(const kmc_user_density* ud, int64_t ndim)
+{
+    return ud->is_body && ud->nblob == 0 && ndim >= 1 && ndim <= kBodyVecMaxDim && !debug_opt("no-body-vec");
+}
+
 bool staged_possible(const kmc_user_density* ud, bool f32, int64_t ndim, bool p2p = false)
 {
     const char* env = std::getenv("KMC_PLAN");
@@ -339,12 +345,14 @@ kmc_status compile_user(kmc_user_density* ud, bool with_vec, int L, int K, int i
                         bool p2p = false)
 {
     // resident_K also sizes the island kernel (same row striping: 2 lanes per walker, K chunks)
-    if (ud->is_body && ((with_vec && !ud->sep) || island_S > 0))
-        return fail(KMC_ERR_UNSUPPORTED, "a body density runs in the one-walker-per-lane kernels only (unless it is a recognised sum over elements)");
+    // a body in the vector kernels: lane-striped when it is a recognised sum over elements (sep), else rows lane-striped and the body
+    // evaluated per walker on the whole proposal (kmc_kernels.hpp, RowEvalTrait; no blobs, ndim <= kBodyVecMaxDim)
+    if (ud->is_body && ((with_vec && !ud->sep && !body_vec_possible(ud, ndim)) || island_S > 0))
+        return fail(KMC_ERR_UNSUPPORTED, "a body density with blobs or more than 64 dimensions runs in the one-walker-per-lane kernels only");
     const bool staged = !with_vec && staged_possible(ud, f32, ndim, p2p);
     char key[112];
-    std::snprintf(key, sizeof(key), "%d:%d,%d,%d,%d|%d,%d|%d|%d|%lld|%d|%d|%d", (int)with_vec, L, K, iter, (int)ragged, resident_K,
-                  (int)resident_ragged, island_S, (int)f32, ud->is_body ? (long long)ndim : 0ll, (int)staged, (int)p2p, ud->nblob);
+    std::snprintf(key, sizeof(key), "%d:%d,%d,%d,%d|%d,%d|%d|%d|%lld|%d|%d|%d|%d", (int)with_vec, L, K, iter, (int)ragged, resident_K,
+                  (int)resident_ragged, island_S, (int)f32, ud->is_body ? (long long)ndim : 0ll, (int)staged, (int)p2p, ud->nblob, (int)ud->sep);
     const char* peer = p2p ? "true" : "false";         // KMC_P2P: partner rows read from their owners (pull)
     const char* rowt = f32 ? "float" : "double";       // storage type of the walker rows (KMC_F32 / KMC_F64)
     std::lock_guard<std::mutex> lock(ud->mu);
@@ -360,7 +368,7 @@ kmc_status compile_user(kmc_user_density* ud, bool with_vec, int L, int K, int i
 
     std::ostringstream src;
     src << "#include \"kmc_islands.hpp\"\n" << user_functor_source(ud) << user_density_alias(ud, ndim)
-        << (ud->is_body && with_vec ? ud->sep_functor + "using UDV = kmc::SepDensity<UserS>;\n" : std::string("using UDV = UD;\n"))
+        << (ud->is_body && with_vec && ud->sep ? ud->sep_functor + "using UDV = kmc::SepDensity<UserS>;\n" : std::string("using UDV = UD;\n"))
         << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_generic(KMC_FRONT_PARAMS, const kmc::HalfStepArgs a) { kmc::half_step_generic_body<UD, " << peer << ", " << rowt << ">(KMC_FRONT_PACK, a); }\n"
         << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_logpdf(const kmc::LogpdfArgs a) { kmc::logpdf_rows_body<UD>(a); }\n"
         << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_init_ball(const kmc::InitBallArgs a) { kmc::init_ball_body<UD>(a); }\n";

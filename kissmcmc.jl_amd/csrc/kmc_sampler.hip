@@ -194,7 +194,8 @@ Plan make_plan(const kmc_config& c, int64_t n_active)
         const kmc_user_density* ud = static_cast<const kmc_user_density*>(c.user_density);
         // a function body runs one walker per lane -- unless it was recognised as a sum over elements: lane-striped like term / pair
         // (double rows, one GPU or the pull exchange; not for ensembles small enough for the resident kernels: decided by the caller)
-        const bool body = ud && ud->is_body && !(ud->sep && c.dtype == KMC_F64 && c.deal_count == 0);
+        // ... or, without blobs and up to 64 dimensions, with its rows lane-striped and only the evaluation per walker (RowEvalTrait)
+        const bool body = ud && ud->is_body && !((ud->sep || body_vec_possible(ud, c.ndim)) && c.dtype == KMC_F64 && c.deal_count == 0);
         if (!body && !force_generic && L > 0 && 2 * L * K >= c.ndim && iter <= L && iter * K <= 16) {
             p.vec = true; p.L = L; p.K = K; p.ITER = iter;
         } else {
@@ -529,6 +530,7 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
     }
     // vec kernels: vec_tpb(L) threads per workgroup; the generic kernel keeps 256
     const bool staged = s->user && s->uk.staged != nullptr;         // a body density's staged kernel: two waves per workgroup
+    s->vec_lds = (s->user && s->user->is_body && !s->user->sep && s->plan.vec) ? (unsigned)body_vec_lds_bytes(s->plan.L, s->plan.K, s->plan.ITER) : 0u;
     const int tpb = s->plan.vec ? vec_tpb(s->plan.L) : (staged ? kStagedTPB : 256);
     s->tpb = tpb;
     s->grid = (int)((waves * 64 + tpb - 1) / tpb);
@@ -872,6 +874,12 @@ KMC_EXPORT kmc_status kmc_sampler_describe(const kmc_sampler* s, char* buf, int6
     } else
         o << "multi-launch (exact): " << (s->user && s->uk.staged ? "half_step_staged (one walker per lane, rows staged through LDS)" : "half_step_generic (one walker per lane)")
           << ", grid " << s->grid << " x " << s->tpb;
+    if (s->feed_replays > 0 && debug_opt("feed-stats")) {
+        char b[200];
+        std::snprintf(b, sizeof(b), "; feeding thread per replay of %lld generations: wait for a free executable %.1f us, parameter updates %.1f us, hipGraphLaunch %.1f us (%lld replays)",
+                      (long long)s->uchunk, s->feed_wait_ns / 1e3 / s->feed_replays, s->feed_update_ns / 1e3 / s->feed_replays, s->feed_launch_ns / 1e3 / s->feed_replays, (long long)s->feed_replays);
+        o << b;
+    }
     if (s->budget_fallback) o << "; updated-graph budget of the process spent (KMC_UPDATED_BUDGET_MB): fell back to " << (s->launch_mode == 2 ? "eager launches" : "the table graph");
     if (s->lazy) o << "; lazy pull into local copies (KMC_P2P_LAZY)";
     else if (s->push) o << "; accepted rows pushed into the peers' local copies (KMC_P2P_PUSH)";
@@ -880,7 +888,8 @@ KMC_EXPORT kmc_status kmc_sampler_describe(const kmc_sampler* s, char* buf, int6
     if (s->d_ids) o << "; dealt sub-ensemble " << s->cfg.deal_rank << "/" << s->cfg.deal_count << " (walkers re-dealt between epochs)";
     if (s->d_mring) o << "; moments through a ring of " << s->mring_depth << " posted rows per wave";
     if (s->user) o << "; runtime-compiled density";
-    if (s->user && s->user->is_body && s->plan.vec && !s->resident && !s->islands) o << " (function body recognised as a sum over elements: lane-striped)";
+    if (s->user && s->user->is_body && s->plan.vec && !s->resident && !s->islands)
+        o << (s->user->sep ? " (function body recognised as a sum over elements: lane-striped)" : " (function body: rows lane-striped, the body evaluated per walker on the whole proposal)");
     if (s->nblob > 0) o << " with a blob of " << s->nblob << " doubles per walker" << (s->d_chain_blob ? " (stored with every sample)" : "");
     if (s->p2p) o << "; P2P shard " << s->cfg.shard_rank << "/" << s->cfg.shard_count << (s->connected ? "" : " (not connected)");
     else if (s->cfg.shard_count > 1 || s->comm)

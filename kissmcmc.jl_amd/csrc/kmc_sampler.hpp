@@ -111,6 +111,8 @@ struct kmc_sampler {
     std::vector<hipGraphNode_t> unodes;
     int64_t uchunk = 64;      // generations per replay of the updated graph
     bool updated_forced = false;   // KMC_LAUNCH=updated: no budget
+    int64_t feed_wait_ns = 0, feed_update_ns = 0, feed_launch_ns = 0, feed_replays = 0;   // updated-graph mode: the feeding thread's time per phase
+    unsigned vec_lds = 0;          // dynamic LDS of the vector kernel (a function body evaluated per walker: one tile of proposals per wave)
     bool updated_refused = false;  // a runtime-compiled kernel the runtime would not take as a graph kernel node: table graph / eager only
     bool budget_fallback = false;  // this sampler left (or never entered) the updated-graph mode because the process budget was spent
     std::vector<std::pair<char*, size_t>> guards;      // KMC_DEBUG=poison: (guard address, size of the allocation in front of it)
@@ -195,6 +197,7 @@ void chain_unregister(kmc_sampler* s);
 // kmc_rtc.hip
 kmc_status load_user(kmc_user_density* ud, bool with_vec, int L, int K, int iter, bool ragged, UserKernels* uk,
                      int resident_K = 0, bool resident_ragged = false, int island_S = 0, bool f32 = false, int64_t ndim = 0, bool p2p = false);
+bool body_vec_possible(const kmc_user_density* ud, int64_t ndim);     // a function body inside the vector kernels, evaluated per walker (kmc_rtc.hip)
 
 // kmc_p2p.hip
 kmc_status check_p2p_err(kmc_sampler* s);                // a peer wait that timed out invalidates everything after it

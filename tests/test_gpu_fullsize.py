@@ -57,6 +57,15 @@ def test_c5_full_size_matches_oracle(kmc, oracle):
     _check_vs_oracle(oracle, oracle.GAUSSIAN_ISO, [0.0, 1.0], th, 12, 4, 4242, got)
 
 
+@pytest.mark.parametrize("nw,nd,G", [(2097152, 32, 70), (524288, 128, 66)])
+def test_hbm_resident_shapes_match_oracle(kmc, oracle, nw, nd, G):
+    """The two shapes bench.py times as `other_configs.HBM_*` -- state 512 MiB, beyond the 256 MiB Infinity Cache, the only lines of
+    the bench that are served from HBM -- at full size: one graph replay + an eager tail, bit-exact against the oracle (moments on)."""
+    th = np.random.default_rng(nd).standard_normal((nw, nd))
+    got = _run(kmc, kmc.GaussianIso(), th, G, 3, 2024)
+    _check_vs_oracle(oracle, oracle.GAUSSIAN_ISO, [0.0, 1.0], th, G, 3, 2024, got)
+
+
 def test_c1_readme_shape_matches_oracle(kmc, oracle):
     """100 walkers x 1-D exponential, niter = 10^5 -> 1000 generations, 500 burn-in."""
     th = 0.5 + 0.1 * np.abs(np.random.default_rng(1).standard_normal((100, 1)))

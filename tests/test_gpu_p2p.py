@@ -259,7 +259,7 @@ def test_two_shards_in_one_process(kmc, oracle, kw):
     np.testing.assert_array_equal(nacc, ref["naccept"])
 
 
-@pytest.mark.parametrize("form", ["expr", "body", "body-routed"])
+@pytest.mark.parametrize("form", ["expr", "body", "body-routed", "body-vec"])
 def test_two_p2p_shards_with_a_runtime_compiled_density(kmc, oracle, form, kmc_debug):
     """Runtime-compiled densities run under KMC_P2P too (the pull kernels are instantiated with the user's functor):
     Rosenbrock as term / pair expressions (lane-striped kernel) and as a function body (one walker per lane),
@@ -269,6 +269,9 @@ def test_two_p2p_shards_with_a_runtime_compiled_density(kmc, oracle, form, kmc_d
     th = 0.1 * np.random.default_rng(3).standard_normal((nw, nd))
     if form == "body":
         kmc_debug.set("no-body-routing")          # the one-walker-per-lane pull kernel; "body-routed": the same body, recognised as a sum over elements
+        kmc_debug.set("no-body-vec")
+    if form == "body-vec":
+        kmc_debug.set("no-body-routing")          # a general body under the pull exchange: rows lane-striped, the body evaluated per walker
     if form == "expr":
         pdf = kmc.ExprDensity("d < n-1 ? -((p[0]-x)*(p[0]-x))/p[2] : 0.0", "-(p[1]*((y-x*x)*(y-x*x)))/p[2]", [1.0, 100.0, 20.0])
     else:

@@ -99,15 +99,22 @@ C_ROSEN = ("double s = 0.0; for (int i = 0; i + 1 < n; ++i) { double d = x[i + 1
 C_EXPO = "double s = 0.0; for (int i = 0; i < n; ++i) { if (x[i] < 0.0) return -INFINITY; s += x[i]; } return -(p[0] * s);"
 
 
+@pytest.mark.parametrize("kernel", ["default", "one-walker-per-lane"])
 @pytest.mark.parametrize("case", ["gauss_256x32", "gauss_1000x7", "rosen_128x2", "rosen_512x64", "expo_100x1", "expo_300x16",
                                   "gauss_200x33", "rosen_130x63", "gauss_96x65", "rosen_200x130", "gauss_256x32_generic",
                                   "gauss_300x256", "expo_170x97", "gauss_300x257", "rosen_196x130_generic"])
-def test_body_density_equals_the_oracle(kmc, oracle, case, monkeypatch, kmc_debug):
+def test_body_density_equals_the_oracle(kmc, oracle, case, kernel, monkeypatch, kmc_debug):
     """A C++ function body that restates a menu density in the oracle's own element order: chains, counters AND log-pdfs
-    equal the oracle's (the one-walker-per-lane kernels sum in index order, as the oracle does)."""
+    equal the oracle's (the body is evaluated per walker, elements in index order, as the oracle does).  Up to 64 dimensions the
+    rows travel lane-striped in the vector kernel and only the evaluation is per walker; beyond (and with `no-body-vec`, and for
+    blobs) the one-walker-per-lane kernels: staged through LDS up to 256 dimensions, generic above."""
     name, shape = case.split("_")[:2]
-    kmc_debug.set("no-body-routing")                     # the one-walker-per-lane kernels are the subject: these bodies are sums over elements and
-                                                         #  would otherwise run lane-striped (test_separable_body_runs_lane_striped_and_equals_the_oracle)
+    kmc_debug.set("no-body-routing")                     # a general body is the subject: these ones are sums over elements and would
+                                                         #  otherwise run lane-striped (test_separable_body_runs_lane_striped_and_equals_the_oracle)
+    if kernel == "one-walker-per-lane":
+        if int(shape.split("x")[1]) > 64 or case.endswith("_generic"):
+            pytest.skip("runs one walker per lane anyway")
+        kmc_debug.set("no-body-vec")
     monkeypatch.setenv("KMC_NO_RESIDENT", "1")           # the multi-launch kernels are the subject here (small ensembles with ndim <= 32
                                                          #  would run resident: test_body_density_runs_resident_on_small_ensembles)
     if case.endswith("_generic"):
@@ -121,7 +128,10 @@ def test_body_density_equals_the_oracle(kmc, oracle, case, monkeypatch, kmc_debu
     pdf = kmc.CDensity(body, params=cparams)
     G, nburn, seed = 90, 25, 31
     with kmc.Sampler(pdf, nw, nd, G, nburn, 1, 2.0, seed) as s:
-        assert ("half_step_staged" in s.describe()) == (nd <= 256 and not case.endswith("_generic"))   # (beyond 64: rows in scratch)
+        how = s.describe()
+        want = ("half_step_generic" if (case.endswith("_generic") or nd > 256) else
+                "half_step_vec" if (nd <= 64 and kernel == "default") else "half_step_staged")
+        assert want in how and ("evaluated per walker" in how) == (want == "half_step_vec"), how
     got = _run(kmc, pdf, th, G, nburn, seed)
     _check(oracle, did, params, th, G, nburn, seed, got)
     ref = oracle.emcee(oracle.make_config(did, params, nw, nd, G, nburn, 1, 2.0, seed), th)
@@ -158,11 +168,11 @@ def test_body_density_with_real_coupling_samples_its_target(kmc, monkeypatch):
     x' P x with P = (1 + rho) I - rho/n 11' ... here: -0.5 (sum x_i^2 + c (sum x_i)^2): variance of the mean direction
     1 / (1 + c n), of every orthogonal direction 1."""
     n, c = 6, 0.5
-    monkeypatch.setenv("KMC_NO_RESIDENT", "1")           # (2048 x 6 would run resident, two walkers per thread: the staged kernel is the subject)
+    monkeypatch.setenv("KMC_NO_RESIDENT", "1")           # (2048 x 6 would run resident, two walkers per thread: the multi-launch kernel is the subject)
     pdf = kmc.CDensity("double s = 0.0, t = 0.0; for (int i = 0; i < n; ++i) { s += x[i] * x[i]; t += x[i]; } return -0.5 * (s + p[0] * t * t);", params=[c])
     th = np.random.default_rng(1).standard_normal((2048, n))
     with kmc.Sampler(pdf, 2048, n, 3000, 500, 5, 2.0, 3, store_chain=True) as s:
-        assert "half_step_staged" in s.describe() and "runtime-compiled" in s.describe()
+        assert "half_step_vec" in s.describe() and "evaluated per walker" in s.describe() and "runtime-compiled" in s.describe()
         s.set_positions(th)
         s.run(3000)
         s.sync()
