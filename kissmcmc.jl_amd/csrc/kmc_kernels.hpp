@@ -811,8 +811,8 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
         // A caller's function body over the whole proposal (BodyDensity): rows are loaded, moved and stored lane-striped like
         // everybody's, and only the evaluation is per walker -- the wave's W proposals go through a per-wave LDS tile (row stride
         // 2 L K + 2 doubles: 16-byte aligned chunks) and the scalar-layout lane of each walker, the one that holds its draws and
-        // runs its accept test, reads its row back as a private array and calls the body once (src/samplers.jl:257), elements in
-        // index order: the same value, bit for bit, as the one-walker-per-lane kernels give.
+        // runs its accept test, calls the body once on its row there (src/samplers.jl:257), elements in index order: the same
+        // value, bit for bit, as the one-walker-per-lane kernels give.
         extern __shared__ __attribute__((aligned(16))) double vec_rows[];
         constexpr int TS = 2 * L * K + 2;
         double* tile = vec_rows + (size_t)(threadIdx.x >> 6) * (size_t)(W * TS);
@@ -825,14 +825,7 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (useA) {
-            double xrow[kRowND];
-            const double* src = &tile[(js * G + g) * TS];
-#pragma unroll
-            for (int d = 0; d + 1 < kRowND; d += 2) { const double2 v = *reinterpret_cast<const double2*>(&src[d]); xrow[d] = v.x; xrow[d + 1] = v.y; }
-            if constexpr (kRowND & 1) xrow[kRowND - 1] = src[kRowND - 1];
-            myp1 = Dens::eval_row(xrow, ndim, a.dp);
-        }
+        if (useA) myp1 = Dens::eval_row(&tile[(js * G + g) * TS], ndim, a.dp);      // (inlined: the body's x[i] become LDS reads of this lane's row)
     }
 
 #ifdef KMC_PROBE
@@ -1143,7 +1136,7 @@ __global__ __launch_bounds__(256) void half_step_generic(KMC_FRONT_PARAMS, const
 // private arrays, which the compiler keeps in registers for short rows.  Accepted rows go back the same way.  Same
 // draws, same arithmetic and element order as half_step_generic (results identical); double rows, one GPU.
 // ------------------------------------------------------------------------------------------
-constexpr int kBodyVecMaxDim = 64;                                       // a body evaluated per walker inside the vector kernel: the proposal as a private array
+constexpr int kBodyVecMaxDim = 1024;                                     // a body evaluated per walker inside the vector kernel (every row length the vector kernel has)
 // LDS of the vector kernel when it evaluates a body per walker: one tile of W rows x (2 L K + 2) doubles per wave
 __host__ __device__ constexpr size_t body_vec_lds_bytes(int L, int K, int iter) { return (size_t)(vec_tpb(L) / 64) * (size_t)((64 / L) * iter) * (size_t)(2 * L * K + 2) * sizeof(double); }
 constexpr int kStagedTPB = 128;                                          // two waves per workgroup, one LDS tile each

@@ -197,6 +197,8 @@ Plan make_plan(const kmc_config& c, int64_t n_active)
         // ... or, without blobs and up to 64 dimensions, with its rows lane-striped and only the evaluation per walker (RowEvalTrait)
         const bool body = ud && ud->is_body && !((ud->sep || body_vec_possible(ud, c.ndim)) && c.dtype == KMC_F64 && c.deal_count == 0);
         if (!body && !force_generic && L > 0 && 2 * L * K >= c.ndim && iter <= L && iter * K <= 16) {
+            // (a body evaluated per walker keeps a tile of the wave's proposals in LDS: at most 64 KiB per workgroup)
+            if (ud && ud->is_body && !ud->sep) while (iter > 1 && body_vec_lds_bytes(L, K, iter) > 65536) iter /= 2;
             p.vec = true; p.L = L; p.K = K; p.ITER = iter;
         } else {
             p.vec = false; p.L = 1; p.K = 1; p.ITER = 1;

@@ -242,9 +242,9 @@ class CDensity(ExprDensity):
         CDensity("double s = 0; for (int i = 0; i + 1 < n; ++i) { double d = x[i+1] - x[i]*x[i]; s += p[1]*d*d + (p[0]-x[i])*(p[0]-x[i]); } "
                  "return -s / p[2];", params=[1, 100, 20])
 
-    Up to 64 dimensions its rows travel lane-striped like a menu density's and only the evaluation is per walker (about 3/4 of a menu
-    density's rate at 65 536 x 32); longer rows and bodies with blobs run one walker per lane (rows staged through LDS up to ndim 256,
-    the generic kernel above: about half the rate) -- orders of magnitude faster than a host callable (:class:`HostLogPdf`).  ``kmc_user_density_create_body``.
+    Its rows travel lane-striped like a menu density's and only the evaluation is per walker (about 3/4 of a menu
+    density's rate at 65 536 x 32); bodies with blobs run one walker per lane (rows staged through LDS up to ndim 256,
+    the generic kernel above) -- orders of magnitude faster than a host callable (:class:`HostLogPdf`).  ``kmc_user_density_create_body``.
     A body that IS a sum over elements -- ``double s = 0; for (int i = 0; i < n; ++i) s += f(x[i]); return g(s);`` (or ``i + 1 < n``
     with ``x[i + 1]``, like the example above) -- is recognised (:attr:`separable`) and runs in the lane-striped kernels at the menu densities' rate.
 

@@ -105,14 +105,14 @@ C_EXPO = "double s = 0.0; for (int i = 0; i < n; ++i) { if (x[i] < 0.0) return -
                                   "gauss_300x256", "expo_170x97", "gauss_300x257", "rosen_196x130_generic"])
 def test_body_density_equals_the_oracle(kmc, oracle, case, kernel, monkeypatch, kmc_debug):
     """A C++ function body that restates a menu density in the oracle's own element order: chains, counters AND log-pdfs
-    equal the oracle's (the body is evaluated per walker, elements in index order, as the oracle does).  Up to 64 dimensions the
-    rows travel lane-striped in the vector kernel and only the evaluation is per walker; beyond (and with `no-body-vec`, and for
-    blobs) the one-walker-per-lane kernels: staged through LDS up to 256 dimensions, generic above."""
+    equal the oracle's (the body is evaluated per walker, elements in index order, as the oracle does).  By default the rows
+    travel lane-striped in the vector kernel and only the evaluation is per walker; with `no-body-vec` (and for blobs) the
+    one-walker-per-lane kernels: staged through LDS up to 256 dimensions, generic above."""
     name, shape = case.split("_")[:2]
     kmc_debug.set("no-body-routing")                     # a general body is the subject: these ones are sums over elements and would
                                                          #  otherwise run lane-striped (test_separable_body_runs_lane_striped_and_equals_the_oracle)
     if kernel == "one-walker-per-lane":
-        if int(shape.split("x")[1]) > 64 or case.endswith("_generic"):
+        if case.endswith("_generic"):
             pytest.skip("runs one walker per lane anyway")
         kmc_debug.set("no-body-vec")
     monkeypatch.setenv("KMC_NO_RESIDENT", "1")           # the multi-launch kernels are the subject here (small ensembles with ndim <= 32
@@ -129,8 +129,8 @@ def test_body_density_equals_the_oracle(kmc, oracle, case, kernel, monkeypatch, 
     G, nburn, seed = 90, 25, 31
     with kmc.Sampler(pdf, nw, nd, G, nburn, 1, 2.0, seed) as s:
         how = s.describe()
-        want = ("half_step_generic" if (case.endswith("_generic") or nd > 256) else
-                "half_step_vec" if (nd <= 64 and kernel == "default") else "half_step_staged")
+        want = ("half_step_generic" if case.endswith("_generic") else "half_step_vec" if kernel == "default" else
+                "half_step_staged" if nd <= 256 else "half_step_generic")
         assert want in how and ("evaluated per walker" in how) == (want == "half_step_vec"), how
     got = _run(kmc, pdf, th, G, nburn, seed)
     _check(oracle, did, params, th, G, nburn, seed, got)
