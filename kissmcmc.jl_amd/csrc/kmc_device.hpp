@@ -519,6 +519,11 @@ struct BodyBlobDensity {
     }
     __device__ static void seq_add(Seq& q, double v, int d, const DensityParams&) { if (d < MAXD) q.x[d] = v; }
     __device__ static double seq_finish(Seq& q, int ndim, const DensityParams& P) { return F::eval(q.x, ndim, P.p, q.blob); }
+    // the vector kernel hands it whole proposals like a BodyDensity; blob[0..NB) is zero on entry
+    static constexpr int kRowEval = MAXD;
+    __device__ static double eval_row(const double* x, int ndim, const DensityParams& P, double* blob) { return F::eval(x, ndim, P.p, blob); }
+    template <int L, int K> __device__ static double frag_partial(const double2 (&)[K], int, int, const DensityParams&) { return 0.0; }
+    __device__ static double finish(double S, const DensityParams&) { return S; }
 };
 template <class D, class = void> struct BlobTrait { static constexpr int n = 0; };
 template <class D> struct BlobTrait<D, decltype((void)D::kBlob)> { static constexpr int n = D::kBlob; };

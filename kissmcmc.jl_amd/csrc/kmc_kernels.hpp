@@ -794,6 +794,7 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
     // ---- stretch move + log-pdf; xo becomes the proposal ------------------------------------
     double myp1 = 0.0;
     constexpr int kRowND = RowEvalTrait<Dens>::n;                       // > 0: a function body over the whole proposal (see below)
+    double blob1[BlobTrait<Dens>::n > 0 ? BlobTrait<Dens>::n : 1];      // ... and the blob it returned (blob1 of src/samplers.jl:257), scalar layout
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
 #pragma unroll
@@ -825,7 +826,15 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (useA) myp1 = Dens::eval_row(&tile[(js * G + g) * TS], ndim, a.dp);      // (inlined: the body's x[i] become LDS reads of this lane's row)
+        if constexpr (BlobTrait<Dens>::n > 0) {
+            if (useA) {
+#pragma unroll 1
+                for (int i = 0; i < BlobTrait<Dens>::n; ++i) blob1[i] = 0.0;
+                myp1 = Dens::eval_row(&tile[(js * G + g) * TS], ndim, a.dp, blob1);
+            }
+        } else {
+            if (useA) myp1 = Dens::eval_row(&tile[(js * G + g) * TS], ndim, a.dp);  // (inlined: the body's x[i] become LDS reads of this lane's row)
+        }
     }
 
 #ifdef KMC_PROBE
@@ -852,6 +861,21 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
         }
     }
 #endif
+    if constexpr (BlobTrait<Dens>::n > 0) {
+        // the blob of the walker's CURRENT position follows it (blob0s[nc] = blob1 on accept, :264) and is stored with every sample (:270)
+        constexpr int NB = BlobTrait<Dens>::n;
+        const bool keep = validA && sample && a.chain_blob != nullptr;
+        if (acc || keep) {
+            double* cur = a.blob + rowA * NB;
+            double* dst = a.chain_blob + (sch.slot * a.chain_rows + a.chain_row0 + iA) * NB;
+#pragma unroll 1
+            for (int i = 0; i < NB; ++i) {
+                const double b = acc ? blob1[i] : cur[i];
+                if (acc) cur[i] = b;
+                if (keep) dst[i] = b;
+            }
+        }
+    }
     const uint32_t wA = (acc && do_mom) ? sch.nbefore - kl : 0u;        // samples the replaced value stood for
     const bool any_w = __ballot(wA != 0u) != 0ull;
     if (sample && a.chain_logp != nullptr && validA)                    // :271

@@ -271,7 +271,7 @@ hipKernelNodeParams node_params(const kmc_sampler* s, KernelParamPack* pk)
 bool updated_graph_possible(const kmc_sampler* s)
 {
     if (s->p2p || s->host_eval || s->islands || s->resident || s->comm || s->updated_refused) return false;
-    return s->user ? (s->plan.vec && s->uk.vec != nullptr && s->nblob == 0) : s->plan.fn != nullptr;
+    return s->user ? (s->plan.vec && s->uk.vec != nullptr) : s->plan.fn != nullptr;
 }
 
 kmc_status ensure_updated_graph(kmc_sampler* s)

@@ -277,7 +277,7 @@ bool recognise_separable(kmc_user_density* ud)
 // a function body in the vector kernels, evaluated per walker on the whole proposal (KMC_DEBUG=no-body-vec: the staged kernel instead)
 bool body_vec_possible(const kmc_user_density* ud, int64_t ndim)
 {
-    return ud->is_body && ud->nblob == 0 && ndim >= 1 && ndim <= kBodyVecMaxDim && !debug_opt("no-body-vec");
+    return ud->is_body && ndim >= 1 && ndim <= kBodyVecMaxDim && !debug_opt("no-body-vec");
 }
 
 bool staged_possible(const kmc_user_density* ud, bool f32, int64_t ndim, bool p2p = false)
@@ -348,7 +348,7 @@ kmc_status compile_user(kmc_user_density* ud, bool with_vec, int L, int K, int i
     // a body in the vector kernels: lane-striped when it is a recognised sum over elements (sep), else rows lane-striped and the body
     // evaluated per walker on the whole proposal (kmc_kernels.hpp, RowEvalTrait; no blobs, ndim <= kBodyVecMaxDim)
     if (ud->is_body && ((with_vec && !ud->sep && !body_vec_possible(ud, ndim)) || island_S > 0))
-        return fail(KMC_ERR_UNSUPPORTED, "a body density with blobs runs in the one-walker-per-lane kernels only");
+        return fail(KMC_ERR_UNSUPPORTED, "this body density runs in the one-walker-per-lane kernels only");
     const bool staged = !with_vec && staged_possible(ud, f32, ndim, p2p);
     char key[112];
     std::snprintf(key, sizeof(key), "%d:%d,%d,%d,%d|%d,%d|%d|%d|%lld|%d|%d|%d|%d", (int)with_vec, L, K, iter, (int)ragged, resident_K,

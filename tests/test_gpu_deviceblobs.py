@@ -13,11 +13,15 @@ BODY = ("double s = 0.0; for (int i = 0; i < n; ++i) s += x[i] * x[i]; "
         "blob[0] = x[0]; blob[1] = x[n - 1]; blob[2] = x[0] * x[1]; blob[3] = -0.5 * s; return -0.5 * s;")
 
 
+@pytest.mark.parametrize("kernel", ["default", "one-walker-per-lane"])
 @pytest.mark.parametrize("nw,nd,nthin", [(24, 4, 3), (4096, 32, 1), (2048, 70, 2), (640, 7, 1)])
-def test_device_blobs_follow_the_walkers_exactly(kmc, oracle, nw, nd, nthin):
+def test_device_blobs_follow_the_walkers_exactly(kmc, oracle, nw, nd, nthin, kernel, kmc_debug):
     """blob0s[nc] = blob1 exactly when theta0s[nc] = theta1 (:261-264), reduce_blob! exactly when stored (:268-271): the stored
     blobs equal the blob function of the stored thetas, entry by entry; and carrying blobs does not change the sampler
-    (same chain as the oracle's run of the same density).  Staged kernel (ndim <= 64) and generic kernel (70)."""
+    (same chain as the oracle's run of the same density).  Resident kernel (24, 640 walkers), the vector kernel with the body
+    evaluated per walker (default beyond), and with `no-body-vec` the staged (ndim <= 64) and generic (70) one-walker-per-lane kernels."""
+    if kernel == "one-walker-per-lane":
+        kmc_debug.set("no-body-vec")
     G, nburn, seed = 60, 13, 4
     th = np.random.default_rng(2).standard_normal((nw, nd))
     pdf = kmc.CDensity(BODY, nblob=4)
@@ -33,7 +37,10 @@ def test_device_blobs_follow_the_walkers_exactly(kmc, oracle, nw, nd, nthin):
         blobs = s.blobs(by_walker=True)
         blobs_sm = s.blobs(by_walker=False)
         cur, pos, lp = s.current_blobs(), s.positions(), s.logp()
-        assert "blob of 4 doubles" in s.describe()
+        how = s.describe()
+        assert "blob of 4 doubles" in how
+        if nw > 1024:
+            assert ("half_step_vec" in how and "evaluated per walker" in how) == (kernel == "default"), how
     ns = (G - nburn) // nthin
     assert blobs.shape == (nw, ns, 4) and blobs_sm.shape == (ns, nw, 4)
     np.testing.assert_array_equal(blobs_sm.transpose(1, 0, 2), blobs)
