@@ -248,8 +248,8 @@ kmc_status  kmc_user_density_create(const char* term_expr, const char* pair_expr
 /* The general form: the BODY of a C++ function
  *     double logpdf(const double* x, int n, const double* p) { BODY }
  * over the whole proposal x[0..n-1] (n = ndim, p = params[0..5]); any coupling between the dimensions, loops, locals;
- * return -INFINITY to reject.  With double rows and no blob the emcee samplers keep the rows lane-striped like a menu
- * density's and evaluate the body once per walker on the whole proposal (collected through LDS); otherwise it runs in the
+ * return -INFINITY to reject.  The emcee samplers keep the rows lane-striped like a menu density's and evaluate the body once
+ * per walker on the whole proposal (collected through LDS); with KMC_DEBUG=no-body-vec, and beyond 1024 dimensions, it runs in the
  * one-walker-per-lane kernels (the proposal is collected per lane, ndim <= 1024; for double rows of ndim <= 256 the rows are staged
  * through LDS so that memory is still read in whole rows):
  * emcee (multi-launch), initial log-pdfs, kmc_sampler_init_ball, many-chain Metropolis -- slower than a menu or term / pair

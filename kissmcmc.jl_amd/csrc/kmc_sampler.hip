@@ -192,10 +192,10 @@ Plan make_plan(const kmc_config& c, int64_t n_active)
     if (c.density == KMC_USER_DENSITY) {
         // kernels are compiled for exactly this geometry when the sampler is created
         const kmc_user_density* ud = static_cast<const kmc_user_density*>(c.user_density);
-        // a function body runs one walker per lane -- unless it was recognised as a sum over elements: lane-striped like term / pair
-        // (double rows, one GPU or the pull exchange; not for ensembles small enough for the resident kernels: decided by the caller)
-        // ... or, without blobs and up to 64 dimensions, with its rows lane-striped and only the evaluation per walker (RowEvalTrait)
-        const bool body = ud && ud->is_body && !((ud->sep || body_vec_possible(ud, c.ndim)) && c.dtype == KMC_F64 && c.deal_count == 0);
+        // a function body in the vector kernel: lane-striped like term / pair when it was recognised as a sum over elements, else
+        // with its rows lane-striped and only the evaluation per walker (RowEvalTrait); KMC_DEBUG=no-body-routing / no-body-vec
+        // keep it one walker per lane (ensembles small enough for the resident kernels: decided by the caller)
+        const bool body = ud && ud->is_body && !(ud->sep || body_vec_possible(ud, c.ndim));
         if (!body && !force_generic && L > 0 && 2 * L * K >= c.ndim && iter <= L && iter * K <= 16) {
             // (a body evaluated per walker keeps a tile of the wave's proposals in LDS: at most 64 KiB per workgroup)
             if (ud && ud->is_body && !ud->sep) while (iter > 1 && body_vec_lds_bytes(L, K, iter) > 65536) iter /= 2;

@@ -243,8 +243,7 @@ class CDensity(ExprDensity):
                  "return -s / p[2];", params=[1, 100, 20])
 
     Its rows travel lane-striped like a menu density's and only the evaluation is per walker (about 3/4 of a menu
-    density's rate at 65 536 x 32); bodies with blobs run one walker per lane (rows staged through LDS up to ndim 256,
-    the generic kernel above) -- orders of magnitude faster than a host callable (:class:`HostLogPdf`).  ``kmc_user_density_create_body``.
+    density's rate at 65 536 x 32), orders of magnitude faster than a host callable (:class:`HostLogPdf`).  ``kmc_user_density_create_body``.
     A body that IS a sum over elements -- ``double s = 0; for (int i = 0; i < n; ++i) s += f(x[i]); return g(s);`` (or ``i + 1 < n``
     with ``x[i + 1]``, like the example above) -- is recognised (:attr:`separable`) and runs in the lane-striped kernels at the menu densities' rate.
 
