@@ -121,7 +121,7 @@ def main():
         if pr is not None and pr.get("geometry") == out["geometry"]:
             body, boundary, src = pr["body_us"], pr["boundary_us"], f"-DKMC_PROBE build, gpurun_out/prof_r04/probe_{cfg.upper()}.txt (profiles/{tag}_probe_timeline.txt)"
             out["probe"] = pr
-        elif live and live > 30.0 and dur <= 1.02 * live:
+        elif live and live > 30.0 and dur <= 1.10 * live:
             body, boundary, src = dur, max(live - dur, 0.0), "kernel trace mean duration (a ~100 us kernel: the tool's per-dispatch cost is < 2 %); boundary = unprofiled period - duration"
         else:
             body = boundary = None
