@@ -360,7 +360,12 @@ __device__ __forceinline__ void accumulate_wave(double* msum, double* msumsq, in
             const bool hi = (lane & 8) != 0;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const double keep = hi ? v[i + 4] : v[i], send = hi ? v[i] : v[i + 4];
+                // (both candidates as opaque register values first: an older compiler -- the comgr a PyTorch wheel bundles, which is
+                //  what hiprtc resolves to inside a torch process -- otherwise folds "hi ? v[i + 4] : v[i]" into a dynamically
+                //  indexed read of v[] and emits an 8-way select chain per value: +150 instructions, -20 % on runtime-compiled kernels)
+                double lo_v = v[i], hi_v = v[i + 4];
+                asm volatile("" : "+v"(lo_v), "+v"(hi_v));
+                const double keep = hi ? hi_v : lo_v, send = hi ? lo_v : hi_v;
                 v[i] = keep + dpp_f64<0x128>(send);      // row_ror:8
             }
             n = 4;

@@ -174,6 +174,15 @@ hipError_t launch_half_kernel(const kmc_sampler* s, const HalfStepArgs& a)
         if (s->uk.staged) return launch_module(s->uk.staged, (unsigned)s->grid, (unsigned)s->tpb, s->stream, la, (unsigned)staged_lds_bytes((int)s->cfg.ndim));
         return launch_module(s->plan.vec ? s->uk.vec : s->uk.generic, (unsigned)s->grid, (unsigned)s->tpb, s->stream, la, s->plan.vec ? s->vec_lds : 0u);
     }
+    if (debug_opt("menu-via-module")) {
+        // experiment: the compiled-in kernel launched the way runtime-compiled ones are (hipFunction_t + argument buffer) -- is it the
+        // launch path or the code object that makes those 7-19 % slower?  (profiles/NOTES.md round 4)
+        hipFunction_t fn = nullptr;
+        const hipError_t e = hipGetFuncBySymbol(&fn, reinterpret_cast<const void*>(s->plan.fn));
+        if (e != hipSuccess) return e;
+        const HalfStepLaunch la{f, a};
+        return launch_module(fn, (unsigned)s->grid, (unsigned)s->tpb, s->stream, la);
+    }
     hipLaunchKernelGGL(s->plan.fn, dim3(s->grid), dim3(s->tpb), 0, s->stream, f.pos, f.sched, f.ring_now, f.logp, f.gw0, f.nact_half,
                        f.seed_lo, f.seed_hi, f.nhalf, f.step, a);
     return hipGetLastError();

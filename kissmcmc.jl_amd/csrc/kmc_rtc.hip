@@ -1,8 +1,14 @@
 // kmc_rtc.hip -- user-supplied log-densities compiled at run time (hiprtc) into the same kernels as the menu densities
 // (the reference's arbitrary closure `pdf(theta)`, src/samplers.jl:257), with a disk cache of the code objects.
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <spawn.h>
 #include <sys/stat.h>
+#include <sys/wait.h>
 #include <unistd.h>
+
+#include <cerrno>
+#include <csignal>
 
 #include <cstdio>
 #include <cstdlib>
@@ -15,12 +21,96 @@
 using namespace kmc;
 using namespace kmc_host;
 
+extern "C" char** environ;
+
 namespace {
 uint64_t fnv1a(uint64_t h, const void* data, size_t n)
 {
     const unsigned char* p = static_cast<const unsigned char*>(data);
     for (size_t i = 0; i < n; ++i) { h ^= p[i]; h *= 0x100000001b3ull; }
     return h;
+}
+// The ROCm installation's offline compiler as a child process, instead of hiprtc in this process.  Why: inside a PyTorch process
+// hiprtc resolves to the comgr the torch wheel bundles (an older compiler: `dlopen("libamd_comgr.so.3")` by name finds the copy torch
+// loaded first), whose code for these kernels was measured 8-20 % slower than what the installation's own clang emits for the same
+// source (profiles/NOTES.md round 4).  A compile costs ~1.2 s instead of ~0.4 s, once per (density, kernel geometry): the code objects
+// are cached on disk like hiprtc's.  KMC_DEBUG=rtc=hipcc asks for it (any compile), KMC_DEBUG=rtc=hiprtc forbids it; unset: the samplers ask
+// for it for big ensembles only (kmc_sampler_create: >= 16 384 walkers, multi-launch kernels), where it pays.
+thread_local int g_offline_wanted = 0;
+bool offline_compiler_wanted()
+{
+    std::string e;
+    if (debug_opt("rtc", &e)) {
+        if (e == "hiprtc") return false;
+        if (e == "hipcc") return true;
+    }
+    return g_offline_wanted != 0;
+}
+std::string find_hipcc()
+{
+    for (const char* var : {"HIP_PATH", "ROCM_PATH"})
+        if (const char* r = std::getenv(var)) { const std::string p = std::string(r) + "/bin/hipcc"; if (::access(p.c_str(), X_OK) == 0) return p; }
+    if (::access("/opt/rocm/bin/hipcc", X_OK) == 0) return "/opt/rocm/bin/hipcc";
+    return std::string();
+}
+// KMC_OK: *code holds the object; KMC_ERR_BAD_ARG: the compiler ran and rejected the program (*log); anything else: could not run it
+kmc_status compile_offline(const std::string& text, int nheaders, const char* const* header_text, const char* const* header_names,
+                           int nopts, const char* const* opts, std::vector<char>* code, std::string* log)
+{
+    static const std::string hipcc = find_hipcc();
+    if (hipcc.empty()) return KMC_ERR_UNSUPPORTED;
+    char tmpl[] = "/tmp/kmc_rtc_XXXXXX";
+    const char* dir = ::mkdtemp(tmpl);
+    if (!dir) return KMC_ERR_UNSUPPORTED;
+    const std::string d(dir);
+    auto put = [&](const std::string& name, const char* body, size_t n) { std::ofstream o(d + "/" + name, std::ios::binary); o.write(body, (std::streamsize)n); return (bool)o; };
+    bool ok = put("prog.hip", text.data(), text.size());
+    for (int i = 0; i < nheaders && ok; ++i) ok = put(header_names[i], header_text[i], std::strlen(header_text[i]));
+    kmc_status st = KMC_ERR_UNSUPPORTED;
+    if (ok) {
+        std::vector<std::string> args = {hipcc};
+        for (int i = 0; i < nopts; ++i) args.push_back(opts[i]);
+        for (const char* a : {"--cuda-device-only", "--no-gpu-bundle-output", "-Wno-unused-command-line-argument", "-c"}) args.push_back(a);
+        args.push_back("-I" + d);
+        args.push_back(d + "/prog.hip");
+        args.push_back("-o");
+        args.push_back(d + "/prog.co");
+        std::vector<char*> argv;
+        for (std::string& a : args) argv.push_back(&a[0]);
+        argv.push_back(nullptr);
+        posix_spawn_file_actions_t fa;
+        posix_spawn_file_actions_init(&fa);
+        const std::string errf = d + "/err.txt";
+        posix_spawn_file_actions_addopen(&fa, 1, "/dev/null", O_WRONLY, 0);
+        posix_spawn_file_actions_addopen(&fa, 2, errf.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0600);
+        pid_t pid = 0;
+        const int rc = posix_spawn(&pid, hipcc.c_str(), &fa, nullptr, argv.data(), environ);     // a CHILD process: this one is never replaced
+        posix_spawn_file_actions_destroy(&fa);
+        if (rc == 0) {
+            int status = 0;
+            // (bounded: a compiler that does not come back within two minutes is killed and hiprtc takes over)
+            bool done = false;
+            for (int tick = 0; tick < 12000 && !done; ++tick) {
+                const pid_t w = ::waitpid(pid, &status, WNOHANG);
+                if (w == pid) done = true;
+                else if (w < 0 && errno != EINTR) break;
+                else ::usleep(10000);
+            }
+            if (!done) { (void)::kill(pid, SIGKILL); while (::waitpid(pid, &status, 0) < 0 && errno == EINTR) {} status = 0x7f00; }
+            if (WIFEXITED(status) && WEXITSTATUS(status) == 0) {
+                std::ifstream f(d + "/prog.co", std::ios::binary | std::ios::ate);
+                const std::streamsize n = f ? (std::streamsize)f.tellg() : 0;
+                if (n > 64) { code->resize((size_t)n); f.seekg(0); if (f.read(code->data(), n)) st = KMC_OK; }
+            } else if (WIFEXITED(status) && WEXITSTATUS(status) == 1) {       // clang's status for diagnostics
+                *log = kmc_host::read_file(errf);
+                st = KMC_ERR_BAD_ARG;
+            }
+        }
+    }
+    for (const char* n : {"prog.hip", "prog.co", "err.txt"}) (void)::unlink((d + "/" + n).c_str());
+    for (int i = 0; i < nheaders; ++i) (void)::unlink((d + "/" + header_names[i]).c_str());
+    (void)::rmdir(dir);
+    return st;
 }
 std::string rtc_cache_dir()
 {
@@ -47,6 +137,8 @@ kmc_status kmc_host::rtc_compile_cached(const std::string& text, const char* pro
     if (hipRuntimeGetVersion(&vrt) != hipSuccess) (void)hipGetLastError();
     if (hipDriverGetVersion(&vdrv) != hipSuccess) (void)hipGetLastError();
     mix(&vrt, sizeof(vrt)); mix(&vdrv, sizeof(vdrv));
+    const int offline = offline_compiler_wanted() ? 1 : 0;        // (the two compilers' objects are not interchangeable in the cache)
+    mix(&offline, sizeof(offline));
     const std::string dir = rtc_cache_dir();
     char name[64];
     std::snprintf(name, sizeof(name), "/%016llx%016llx.co", (unsigned long long)h1, (unsigned long long)h2);
@@ -66,6 +158,12 @@ kmc_status kmc_host::rtc_compile_cached(const std::string& text, const char* pro
             code->clear();
         }
     }
+    if (offline_compiler_wanted()) {
+        const kmc_status ost = compile_offline(text, nheaders, header_text, header_names, nopts, opts, code, log);
+        if (ost == KMC_ERR_BAD_ARG) return ost;                       // the program does not compile: the caller words the message
+        if (ost != KMC_OK) code->clear();                             // no offline compiler here (or it failed to run): hiprtc below
+    }
+    if (code->empty()) {
     hiprtcProgram prog = nullptr;
     if (hiprtcCreateProgram(&prog, text.c_str(), program_name, nheaders, const_cast<const char**>(header_text), const_cast<const char**>(header_names)) != HIPRTC_SUCCESS)
         return fail(KMC_ERR_HIP, "hiprtcCreateProgram failed");
@@ -83,6 +181,7 @@ kmc_status kmc_host::rtc_compile_cached(const std::string& text, const char* pro
     code->resize(n);
     hiprtcGetCode(prog, code->data());
     hiprtcDestroyProgram(&prog);
+    }
     if (!path.empty()) {                                 // best effort: write beside, then rename (concurrent processes: last one wins, same bytes)
         (void)::mkdir(dir.substr(0, dir.find_last_of('/')).c_str(), 0755);
         (void)::mkdir(dir.c_str(), 0755);
@@ -100,6 +199,9 @@ kmc_status kmc_host::rtc_compile_cached(const std::string& text, const char* pro
 }
 
 namespace kmc_host {
+// the samplers' hint for the compiles of the calling thread: a big ensemble is worth the offline compiler's extra second (see offline_compiler_wanted)
+void set_offline_compiler_hint(bool wanted) { g_offline_wanted = wanted ? 1 : 0; }
+
 // ---- a function body that is a sum over elements ------------------------------------------------------------------------
 // Recognised form (after comments are dropped; whitespace free):
 //     [declarations not touching x]                       e.g.  const double w = p[1];
@@ -352,7 +454,7 @@ kmc_status compile_user(kmc_user_density* ud, bool with_vec, int L, int K, int i
     const bool staged = !with_vec && staged_possible(ud, f32, ndim, p2p);
     char key[112];
     std::snprintf(key, sizeof(key), "%d:%d,%d,%d,%d|%d,%d|%d|%d|%lld|%d|%d|%d|%d", (int)with_vec, L, K, iter, (int)ragged, resident_K,
-                  (int)resident_ragged, island_S, (int)f32, ud->is_body ? (long long)ndim : 0ll, (int)staged, (int)p2p, ud->nblob, (int)ud->sep);
+                  (int)resident_ragged, island_S, (int)f32, ud->is_body ? (long long)ndim : 0ll, (int)staged, (int)p2p, ud->nblob, (int)ud->sep + 2 * (int)offline_compiler_wanted());
     const char* peer = p2p ? "true" : "false";         // KMC_P2P: partner rows read from their owners (pull)
     const char* rowt = f32 ? "float" : "double";       // storage type of the walker rows (KMC_F32 / KMC_F64)
     std::lock_guard<std::mutex> lock(ud->mu);

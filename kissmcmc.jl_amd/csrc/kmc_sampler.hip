@@ -444,8 +444,12 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         //  two walkers per thread: 2048 for a body, -(100 + ndim) for a term / pair density)
         const int rcode = (rK > 0 && iS == 0) ? (lane2 ? (s->user->is_body ? 2048 : -(100 + (int)cfg->ndim))
                                                        : s->user->is_body ? (cfg->nwalkers <= 256 ? 256 : cfg->nwalkers <= 512 ? 512 : 1024) : (expr_lane ? -lane_nd(cfg->ndim) : rK)) : rK;
+        // a big ensemble's kernels are worth the better compiler (hipcc as a child process: ~1.2 s once per density and geometry, then
+        // cached on disk): inside a PyTorch process hiprtc means the older comgr the wheel bundles (kmc_rtc.hip: offline_compiler_wanted)
+        set_offline_compiler_hint(s->h_loc >= 8192 && rK == 0 && iS == 0);
         st = load_user(s->user, s->plan.vec, s->plan.L, s->plan.K, s->plan.ITER, s->plan.ragged, &s->uk, rcode, 4 * rK != cfg->ndim, iS, s->f32,
                        cfg->ndim, (cfg->flags & KMC_P2P) != 0);
+        set_offline_compiler_hint(false);
         if (st != KMC_OK) { kmc_sampler_destroy(s); return st; }
         if (iS > 0) rK = 0;     // island mode is set up below, not resident mode
         if (rK > 0) {

@@ -197,6 +197,7 @@ void chain_unregister(kmc_sampler* s);
 // kmc_rtc.hip
 kmc_status load_user(kmc_user_density* ud, bool with_vec, int L, int K, int iter, bool ragged, UserKernels* uk,
                      int resident_K = 0, bool resident_ragged = false, int island_S = 0, bool f32 = false, int64_t ndim = 0, bool p2p = false);
+void set_offline_compiler_hint(bool wanted);                          // runtime-compiled kernels of this thread: hipcc as a child process instead of hiprtc (kmc_rtc.hip)
 bool body_vec_possible(const kmc_user_density* ud, int64_t ndim);     // a function body inside the vector kernels, evaluated per walker (kmc_rtc.hip)
 
 // kmc_p2p.hip

@@ -168,6 +168,24 @@ def test_bodies_that_are_not_sums_over_elements_are_not_routed(kmc):
         assert kmc.CDensity(body, params=[0.5, 2.0]).separable, body
 
 
+def test_runtime_compiled_densities_through_the_offline_compiler(kmc, kmc_debug, tmp_path, monkeypatch):
+    """KMC_DEBUG=rtc=hipcc: the ROCm installation's clang as a CHILD process builds the code objects instead of hiprtc in this process
+    (inside a PyTorch process hiprtc resolves to the older comgr the torch wheel bundles, whose code for the half-step kernels is
+    8-20 % slower; the samplers ask for the offline compiler by themselves for big ensembles).  Same results, cached on disk, syntax
+    errors reported with the compiler's message; no device needed."""
+    monkeypatch.setenv("KMC_CACHE_DIR", str(tmp_path))
+    kmc_debug.set("rtc", "hipcc")
+    d = kmc.CDensity("double s = 0; for (int i = 0; i < n; ++i) s += x[i] * x[i]; return -0.5 * s;")
+    assert d.separable
+    assert len(list(tmp_path.glob("*.co"))) >= 1
+    with pytest.raises(kmc.KmcError, match="does not compile"):
+        kmc.CDensity("return x[0] +;")
+    kmc_debug.set("rtc", "hiprtc")
+    n_before = len(list(tmp_path.glob("*.co")))
+    kmc.CDensity("double s = 0; for (int i = 0; i < n; ++i) s += x[i] * x[i]; return -0.5 * s;")      # the other compiler: its own cache entries
+    assert len(list(tmp_path.glob("*.co"))) > n_before
+
+
 def test_product_never_touches_the_oracle():
     """The product package must not import, link or execute anything under oracle/."""
     pkg = os.path.join(ROOT, "kissmcmc.jl_amd")

@@ -163,6 +163,38 @@ def test_separable_body_runs_lane_striped_and_equals_the_oracle(kmc, oracle, cas
     assert pdf(th[0]) == pytest.approx(oracle.logpdf(did, params, th[0]), rel=1e-14)       # the host call still evaluates the body itself
 
 
+@pytest.mark.parametrize("form", ["expr", "sum-body", "coupled-body"])
+def test_offline_compiled_kernels_equal_the_oracle(kmc, oracle, form, monkeypatch, kmc_debug):
+    """The same kernels built by hipcc as a child process (what the samplers choose by themselves for >= 16 384 walkers; forced here
+    with KMC_DEBUG=rtc=hipcc) instead of hiprtc: chains, counters and moments equal to the oracle as ever."""
+    kmc_debug.set("rtc", "hipcc")
+    monkeypatch.setenv("KMC_NO_RESIDENT", "1")
+    nw, nd, G, nburn, seed = 1536, 32, 90, 25, 31
+    th = np.random.default_rng(7).standard_normal((nw, nd))
+    if form == "expr":
+        pdf, did, params = kmc.ExprDensity("-0.5*((x-p[0])*p[1])*((x-p[0])*p[1])", None, [0.3, 1.0 / 1.5]), oracle.GAUSSIAN_ISO, [0.3, 1.5]
+    elif form == "sum-body":
+        pdf, did, params = kmc.CDensity(C_GAUSS, params=[0.3, 1.0 / 1.5]), oracle.GAUSSIAN_ISO, [0.3, 1.5]
+    else:
+        kmc_debug.set("no-body-routing")
+        pdf, did, params = kmc.CDensity(C_GAUSS, params=[0.3, 1.0 / 1.5]), oracle.GAUSSIAN_ISO, [0.3, 1.5]
+    got = _run(kmc, pdf, th, G, nburn, seed)
+    _check(oracle, did, params, th, G, nburn, seed, got)
+
+
+def test_big_ensembles_ask_for_the_offline_compiler_by_themselves(kmc, oracle, tmp_path, monkeypatch):
+    """>= 16 384 walkers in the multi-launch kernels: the vector kernel's code object comes from the offline compiler (a second cache entry
+    next to hiprtc's), and the sampler is the oracle's."""
+    monkeypatch.setenv("KMC_CACHE_DIR", str(tmp_path))
+    pdf = kmc.CDensity(C_GAUSS, params=[0.3, 1.0 / 1.5])
+    n0 = len(list(tmp_path.glob("*.co")))
+    nw, nd, G, nburn, seed = 16384, 8, 40, 10, 5
+    th = np.random.default_rng(3).standard_normal((nw, nd))
+    got = _run(kmc, pdf, th, G, nburn, seed)
+    assert len(list(tmp_path.glob("*.co"))) == n0 + 1
+    _check(oracle, oracle.GAUSSIAN_ISO, [0.3, 1.5], th, G, nburn, seed, got)
+
+
 def test_body_density_with_real_coupling_samples_its_target(kmc, monkeypatch):
     """A density no term / pair form can express -- a correlated Gaussian with a dense precision matrix built in the body:
     x' P x with P = (1 + rho) I - rho/n 11' ... here: -0.5 (sum x_i^2 + c (sum x_i)^2): variance of the mean direction
