@@ -207,12 +207,18 @@ def test_random_dealt_sub_ensembles_equal_the_oracle(kmc, oracle, trial):
 
 
 @pytest.mark.parametrize("trial", range(max(6, N_TRIALS // 15)))
-def test_random_runtime_compiled_density_equals_the_oracle(kmc, oracle, monkeypatch, trial):
-    """Runtime-compiled densities (term / pair expressions in the lane-striped kernels, function bodies in the staged and
-    generic one-walker-per-lane kernels) restating a menu density, random shapes and launch modes: identical counters and
-    positions, log-pdfs to 1e-12."""
+def test_random_runtime_compiled_density_equals_the_oracle(kmc, oracle, monkeypatch, trial, kmc_debug):
+    """Runtime-compiled densities restating a menu density -- term / pair expressions and function bodies recognised as sums over
+    elements (lane-striped kernels), general bodies (rows lane-striped, evaluated per walker: `no-body-routing`), and the staged /
+    generic one-walker-per-lane kernels (`no-body-vec`) -- random shapes and launch modes: identical counters and positions,
+    log-pdfs to 1e-12."""
     rng = np.random.default_rng(BASE + 88000 + trial)
-    form = str(rng.choice(["expr", "body"]))
+    form = str(rng.choice(["expr", "body", "body-general", "body-lane"]))
+    if form in ("body-general", "body-lane"):
+        kmc_debug.set("no-body-routing")
+    if form == "body-lane":
+        kmc_debug.set("no-body-vec")
+    form_label, form = form, ("expr" if form == "expr" else "body")
     name = str(rng.choice(["gauss", "rosen"]))
     nd = int(rng.choice([2, 3, 8, 17, 32, 64, 65, 130]) if name == "rosen" else rng.choice([1, 2, 5, 8, 16, 31, 32, 33, 64, 100]))
     nw = int(rng.choice([nd + 2 + nd % 2, 64, 130, 256, 1000, 2050]))
@@ -234,7 +240,7 @@ def test_random_runtime_compiled_density_equals_the_oracle(kmc, oracle, monkeypa
                kmc.CDensity("double s = 0.0; for (int i = 0; i + 1 < n; ++i) { double d = x[i + 1] - x[i] * x[i]; double e = p[0] - x[i]; s += p[1] * (d * d) + e * e; } "
                             "return -(s * (1.0 / p[2]));", params=params))
         th = 0.1 * rng.standard_normal((nw, nd))
-    label = f"trial {trial}: {form} {name} {nw}x{nd} G={G} nburn={nburn} nthin={nthin} launch={launch or 'auto'}"
+    label = f"trial {trial}: {form_label} {name} {nw}x{nd} G={G} nburn={nburn} nthin={nthin} launch={launch or 'auto'}"
     ref = oracle.emcee(oracle.make_config(did, params, nw, nd, G, nburn, nthin, 2.0, seed), th)
     with kmc.Sampler(pdf, nw, nd, G, nburn, nthin, 2.0, seed, store_chain=True, moments=True) as s:
         s.set_positions(th)
