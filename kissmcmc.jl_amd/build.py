@@ -46,7 +46,7 @@ def build_p2p_experimental(force: bool = False) -> str:
 def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str = LIB, preload: bool = True) -> str:
     """Compile csrc/*.hip (one translation unit per density, in parallel) and link
     libkissmcmc_hip.so next to this file (in-tree, so it travels with the snapshot).
-    ``extra_flags``/``out`` build experiment variants (e.g. ``-DKMC_TPB=128``) side by side."""
+    ``extra_flags``/``out`` build variants side by side (``-DKMC_PROBE``, ``-DKMC_P2P_EXPERIMENTAL``)."""
     if not (force or out != LIB or stale()):
         return out
     from concurrent.futures import ThreadPoolExecutor

@@ -32,27 +32,13 @@
 #pragma once
 #include "kmc_device.hpp"
 
-#ifndef KMC_TPB
-#define KMC_TPB 256   // threads per workgroup of the half-step kernels (waves are independent)
-#else
-#define KMC_TPB_FORCED 1
-#endif
-
 namespace kmc {
 
-constexpr int kTPB = KMC_TPB;
+constexpr int kTPB = 256;   // threads per workgroup of the half-step kernels with long rows (waves are independent)
 // Workgroup size of the vector kernels by lane-group width, from repeated A/B runs of forced sizes: L <= 8 (ndim <= 32,
 // C2) 128 threads (-3 % against 256), L = 16 (C3) 64 threads (-2.5 %; 128 is 8 % SLOWER there with moments on), longer
-// rows (C5) 256
-// (-DKMC_TPB=n forces one size for every geometry).
-__host__ __device__ constexpr int vec_tpb(int L)
-{
-#ifdef KMC_TPB_FORCED
-    return kTPB;
-#else
-    return L <= 8 ? 128 : L == 16 ? 64 : kTPB;
-#endif
-}
+// rows (C5) 256.
+__host__ __device__ constexpr int vec_tpb(int L) { return L <= 8 ? 128 : L == 16 ? 64 : kTPB; }
 
 // What the reference's loop variable n (src/samplers.jl:245) implies for one generation.
 struct SchedEntry {
@@ -233,54 +219,32 @@ __device__ __forceinline__ SchedEntry schedule_of(const HalfStepFront& f, const 
 // Stores of the half-step kernels are WRITE-THROUGH (sc0 sc1): the line goes to memory while the kernel is still
 // running instead of sitting dirty in the XCD's L2 until the end-of-kernel write-back, which is part of the
 // dependent-kernel boundary every half-step pays (C2: 4.27 -> 3.92 us per half-step; the next launch's readers sit
-// on other XCDs and must get the data from memory anyway).  -DKMC_STORE_PLAIN: ordinary stores (A/B builds).
+// on other XCDs and must get the data from memory anyway; ordinary stores were the A/B build of round 1).
 // The s_nop covers the store-data hazard the compiler cannot see through the asm.
 __device__ __forceinline__ void store_wt(double2* p, const double2& v)
 {
-#ifndef KMC_STORE_PLAIN
     typedef double v2d __attribute__((ext_vector_type(2)));
     const v2d t = {v.x, v.y};
     asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(p), "v"(t) : "memory");
-#else
-    *p = v;
-#endif
 }
 __device__ __forceinline__ void store_wt(double* p, double v)
 {
-#ifndef KMC_STORE_PLAIN
     asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
-#else
-    *p = v;
-#endif
 }
 __device__ __forceinline__ void store_wt(uint32_t* p, uint32_t v)
 {
-#ifndef KMC_STORE_PLAIN
     asm volatile("global_store_dword %0, %1, off sc0 sc1\n\ts_nop 0" :: "v"(p), "v"(v) : "memory");
-#else
-    *p = v;
-#endif
 }
 __device__ __forceinline__ void store_wt(unsigned char* p, unsigned char v)
 {
-#ifndef KMC_STORE_PLAIN
     const uint32_t t = v;
     asm volatile("global_store_byte %0, %1, off sc0 sc1\n\ts_nop 0" :: "v"(p), "v"(t) : "memory");
-#else
-    *p = v;
-#endif
 }
 __device__ __forceinline__ void store_row16(double2* p, const double2& v) { store_wt(p, v); }
-// Row load: every row is read once per launch.  -DKMC_LOAD_NT: non-temporal (A/B builds).
+// Row load: every row is read once per launch (a non-temporal variant was measured in round 1: no gain).
 __device__ __forceinline__ double2 load_row16(const double2* p)
 {
-#ifdef KMC_LOAD_NT
-    typedef double v2d __attribute__((ext_vector_type(2)));
-    const v2d t = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(p));
-    return make_double2(t.x, t.y);
-#else
     return *p;
-#endif
 }
 
 // Storage type T of the walker rows and the chain: double (KMC_F64) or float (KMC_F32: half the row bytes; the
@@ -291,13 +255,9 @@ template <> struct RowOf<double> { using V2 = double2; };
 template <> struct RowOf<float>  { using V2 = float2; };
 __device__ __forceinline__ void store_wt(float2* p, const float2& v)
 {
-#ifndef KMC_STORE_PLAIN
     typedef float v2f __attribute__((ext_vector_type(2)));
     const v2f t = {v.x, v.y};
     asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(p), "v"(t) : "memory");
-#else
-    *p = v;
-#endif
 }
 __device__ __forceinline__ double2 load_row(const double2* p) { return load_row16(p); }
 __device__ __forceinline__ double2 load_row(const float2* p) { const float2 v = *p; return make_double2((double)v.x, (double)v.y); }
