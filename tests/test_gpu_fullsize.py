@@ -66,6 +66,21 @@ def test_hbm_resident_shapes_match_oracle(kmc, oracle, nw, nd, G):
     _check_vs_oracle(oracle, oracle.GAUSSIAN_ISO, [0.0, 1.0], th, G, 3, 2024, got)
 
 
+def test_c2_written_as_a_function_body_is_the_menu_run(kmc):
+    """The C2 ensemble with the Gaussian written as a C function body (a sum over elements: recognised, lane-striped, built by the offline
+    compiler at this size): the same arithmetic per element in the same lane order as the menu density, so positions, counters AND
+    log-pdfs equal the menu run bit for bit -- the caller's closure pdf(theta) of src/samplers.jl:257 costs nothing in fidelity."""
+    th = np.random.default_rng(2).standard_normal((65536, 32))
+    body = kmc.CDensity("double s = 0; for (int i = 0; i < n; ++i) s += x[i] * x[i]; return -0.5 * s;")
+    assert body.separable
+    got = _run(kmc, body, th, 200, 50, 12345)
+    ref = _run(kmc, kmc.GaussianIso(), th, 200, 50, 12345)
+    for k in ("pos", "nacc", "logp"):
+        np.testing.assert_array_equal(got[k], ref[k], err_msg=k)
+    assert got["n"] == ref["n"]
+    np.testing.assert_array_equal(got["sum"], ref["sum"])
+
+
 def test_c1_readme_shape_matches_oracle(kmc, oracle):
     """100 walkers x 1-D exponential, niter = 10^5 -> 1000 generations, 500 burn-in."""
     th = 0.5 + 0.1 * np.abs(np.random.default_rng(1).standard_normal((100, 1)))
