@@ -157,9 +157,8 @@ def _worker(rank, world, port, outdir):
 
 
 def _free_port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
+    from portpick import rendezvous_port
+    return rendezvous_port()
 
 
 @pytest.mark.parametrize("world", [2, 4])

@@ -88,9 +88,8 @@ def _worker(rank, world, port, outdir):
 
 
 def _free_port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
+    from portpick import rendezvous_port
+    return rendezvous_port()
 
 
 def test_two_rank_run_is_bit_identical_to_one_rank(oracle, tmp_path):

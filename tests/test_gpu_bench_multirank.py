@@ -72,10 +72,8 @@ def test_bench_two_ranks_under_torch_distributed_run():
     """The driver's own form: python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2 -- bench.py is then ONE rank
     of the job and must not spawn anything itself."""
     env = bench_env({"backend": "gloo", "walkers": 4096, "no-allgather-extra": True}, {"KMC_BENCH_RUNG_TIMEOUT": "240"})
-    import socket
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
+    from portpick import rendezvous_port
+    port = rendezvous_port()
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"],
                        env=env, capture_output=True, text=True, timeout=900)
@@ -125,12 +123,10 @@ def bench_single(env_extra, launcher):
 def test_bench_one_gpu_under_torch_distributed_run_equals_the_plain_call():
     """The N = 1 point of a scaling series launched like the N > 1 points (python -m torch.distributed.run --nproc-per-node 1: WORLD_SIZE=1,
     OMP_NUM_THREADS=1, ...) must be the same measurement as the plain `python bench.py`: same kernel and launch mode, `value` within 3 %."""
-    import socket
+    from portpick import rendezvous_port
     for attempt in range(2):                                        # (a shared box: one repetition of the pair)
         plain = bench_single({}, [])
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0))
-            port = sk.getsockname()[1]
+        port = rendezvous_port()
         under = bench_single({}, ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port)])
         assert under["n_gpus"] == 1 and plain["n_gpus"] == 1
         assert under["config"]["parallelism"] == plain["config"]["parallelism"] == "single GPU"
@@ -147,10 +143,8 @@ def test_bench_sharded_ladder_over_real_rccl_with_one_rank():
     """KMC_BENCH_TEST=force-sharded: the N > 1 code path with ONE rank over the REAL collective backend ("nccl" = RCCL), which two ranks
     on one device cannot have: process group with a device id, all-reduce / all-gather-object / all_to_all_single through RCCL, and
     the native exchange -- ncclCommInitRank, the all-gathers captured into the hipGraph chunks -- inside bench.py's own ladder."""
-    import socket
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
+    from portpick import rendezvous_port
+    port = rendezvous_port()
     env = bench_env({"force-sharded": True, "walkers": 8192}, {"KMC_BENCH_RUNG_TIMEOUT": "240", "MASTER_PORT": str(port)})
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1"],
                        env=env, capture_output=True, text=True, timeout=900)

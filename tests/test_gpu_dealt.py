@@ -158,9 +158,8 @@ def _worker(rank, world, port, outdir):
 
 
 def _free_port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
+    from portpick import rendezvous_port
+    return rendezvous_port()
 
 
 def test_two_processes_sharing_the_gpu_equal_the_oracle(oracle, tmp_path):

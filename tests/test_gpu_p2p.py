@@ -116,9 +116,8 @@ def test_p2p_rosenbrock_odd_ndim(oracle, tmp_path):
 
 
 def _free_port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
+    from portpick import rendezvous_port
+    return rendezvous_port()
 
 
 # (the push / lazy / folded-signal plans of _worker: tests/p2p_experimental_cases.py, against the -DKMC_P2P_EXPERIMENTAL library)
