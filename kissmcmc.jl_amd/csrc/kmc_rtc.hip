@@ -271,6 +271,7 @@ bool recognise_separable(kmc_user_density* ud)
         after = e + 1;
     }
     if (std::regex_search(loop, std::regex("\\b(return|break|continue|goto|for|while|do|switch)\\b"))) return false;
+    if (std::regex_search(loop, std::regex("&\\s*x\\b"))) return false;                              // the address of an element: not a value any more
     // what follows the loop: exactly one return statement
     std::smatch r;
     const std::string tail = t.substr(after);

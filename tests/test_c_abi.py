@@ -159,6 +159,9 @@ def test_bodies_that_are_not_sums_over_elements_are_not_routed(kmc):
                  "double s = 0; double c = 1.0; for (int i = 0; i < n; ++i) { c = c * 0.5; s += c * x[i]; } return -s;",
                  "double s = 0; for (int i = 0; i < n; ++i) { s += x[i] * (1.0 + s); } return -s;",
                  "double s = 0; for (int i = 0; i < n; ++i) s += x[i + 1]; return -s;",
+                 "double s = 0; for (int i = 0; i + 1 < n; ++i) { const double* q = &x[i]; s += q[0] * q[1]; } return -s;",
+                 "double s = 0; for (int i = 0; i < n; i += 2) s += x[i]; return -s;",
+                 "double s = 1.0; for (int i = 0; i < n; ++i) s += x[i]; return -s;",
                  "const double t = x[0] + 5.0; return -(t * t) / 18.0;"):
         assert not kmc.CDensity(body, params=[0.5]).separable, body
     for body in ("double s = 0; for (int i = 0; i < n; ++i) s += x[i] * x[i]; return -0.5 * s;",
