@@ -534,12 +534,14 @@ def other_configs(kmc, device: int):
         out["C2_chain_on"] = {"error": str(e)}
     # the general route for a caller's own log-density: a function body compiled at run time (CDensity), at the C2 shape and at
     # the reference's own.  C2_user_density: the Gaussian as anybody would write it -- a sum over elements, which the library
-    # recognises and runs lane-striped like a menu density; C2_user_density_coupled: a body no per-element form can express
-    # (-0.5 (sum x_i^2 + c (sum x_i)^2)), which runs one walker per lane, rows staged through LDS.
+    # recognises and runs lane-striped like a menu density; C2_user_density_two_sums: a rank-one coupling, -0.5 (sum x_i^2 + c (sum x_i)^2):
+    # two sums fed by one pass, recognised as well; C2_user_density_coupled: a body no per-element form can express (second-neighbour
+    # coupling, two loops), whose rows travel lane-striped while the body is evaluated once per walker on the whole proposal.
     body = "double s = 0; for (int i = 0; i < n; ++i) s += x[i] * x[i]; return -0.5 * s;"
-    coupled = "double s = 0, t = 0; for (int i = 0; i < n; ++i) { s += x[i] * x[i]; t += x[i]; } return -0.5 * (s + p[0] * t * t);"
-    for key, src, params, nw, nd, G in (("C2_user_density", body, [], 65536, 32, 2000), ("C2_user_density_coupled", coupled, [0.05], 65536, 32, 2000),
-                                        ("C1_user_density", body, [], 100, 1, 20000)):
+    two_sums = "double s = 0, t = 0; for (int i = 0; i < n; ++i) { s += x[i] * x[i]; t += x[i]; } return -0.5 * (s + p[0] * t * t);"
+    coupled = "double s = 0; for (int i = 0; i < n; ++i) s += x[i] * x[i]; for (int i = 0; i + 2 < n; ++i) s += p[0] * x[i] * x[i + 2]; return -0.5 * s;"
+    for key, src, params, nw, nd, G in (("C2_user_density", body, [], 65536, 32, 2000), ("C2_user_density_two_sums", two_sums, [0.05], 65536, 32, 2000),
+                                        ("C2_user_density_coupled", coupled, [0.2], 65536, 32, 2000), ("C1_user_density", body, [], 100, 1, 20000)):
         try:
             pdf = kmc.CDensity(src, params=params)
             with kmc.Sampler(pdf, nw, nd, G, G // 2, 1, 2.0, 12345, moments=True) as s:

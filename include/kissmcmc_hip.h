@@ -256,7 +256,8 @@ kmc_status  kmc_user_density_create(const char* term_expr, const char* pair_expr
  * density of the same form (those stripe a row over lanes), far faster than a host callback.  Not with KMC_ISLANDS; under KMC_P2P the unstaged kernel.
  * A body that IS a sum over elements --
  *     double s = 0; for (int i = 0; i < n; ++i) s += f(x[i]);  return g(s);       (or: i + 1 < n, reading x[i] and x[i + 1])
- * with the loop body any statements that read the proposal only as x[i] (x[i + 1]) and change s only by `s +=` -- is recognised as
+ * with the loop body any statements that read the proposal only as x[i] (x[i + 1]) and change s only by `s +=` (up to four such
+ * accumulators, `return g(s, t, ...)`) -- is recognised as
  * such (kmc_user_density_is_separable) and the emcee samplers run it in the lane-striped kernels of the menu densities, the loop
  * body as the per-element function and g as the finish: same operations per element, the sum in lane order instead of index
  * order (log-pdfs equal to rounding, like a menu density's).  Early returns, several accumulators or other indices are not

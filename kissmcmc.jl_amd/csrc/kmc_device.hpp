@@ -482,6 +482,58 @@ struct SepDensity : TermPairDensity<F> {
     __device__ static double finish(double S, const DensityParams& P) { return F::finish(S, P.ndim, P.p); }
 };
 
+// ... with SEVERAL sums (2..4): F::elem(x_d, x_{d+1}, d, n, p, acc) adds one element's increments to all of them in one pass
+// (the loop body, verbatim), F::finish(acc, n, p) is the return expression.  kHasPair: the loop ran over d < n - 1 and may read x_{d+1}.
+template <class F>
+struct SepDensityN {
+    static constexpr bool kHasFrag = true;
+    static constexpr int kNSums = F::kNAcc;
+    struct Seq { double s[F::kNAcc]; double prev; };
+    __device__ static void seq_init(Seq& q) {
+#pragma unroll
+        for (int a = 0; a < F::kNAcc; ++a) q.s[a] = 0.0;
+        q.prev = 0.0;
+    }
+    __device__ static void seq_add(Seq& q, double x, int d, const DensityParams& P)
+    {
+        if constexpr (F::kHasPair) { if (d > 0) F::elem(q.prev, x, d - 1, P.ndim, P.p, q.s); }
+        else F::elem(x, 0.0, d, P.ndim, P.p, q.s);
+        q.prev = x;
+    }
+    __device__ static double seq_finish(const Seq& q, int, const DensityParams& P) { return F::finish(q.s, P.ndim, P.p); }
+
+    // this lane's chunks' increments to every sum (same element <-> lane map as TermPairDensity::frag_partial)
+    template <int L, int K>
+    __device__ static void frag_partial_n(const double2 (&y)[K], int j, int ndim, const DensityParams& P, double (&S)[F::kNAcc])
+    {
+#pragma unroll
+        for (int a = 0; a < F::kNAcc; ++a) S[a] = 0.0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int e0 = 2 * (k * L + j);
+            const double x0 = y[k].x, x1 = y[k].y;
+            if constexpr (F::kHasPair) {
+                double nxt = group_shfl_down1<L>(x0);           // executed by every lane (no divergence)
+                if (k + 1 < K) {
+                    const double wrap = group_bcast0<L>(y[k + 1 < K ? k + 1 : k].x);
+                    nxt = (j == L - 1) ? wrap : nxt;
+                }
+                if (e0 < ndim - 1) F::elem(x0, x1, e0, ndim, P.p, S);
+                if (e0 + 1 < ndim - 1) F::elem(x1, nxt, e0 + 1, ndim, P.p, S);
+            } else {
+                if (e0 < ndim) F::elem(x0, 0.0, e0, ndim, P.p, S);
+                if (e0 + 1 < ndim) F::elem(x1, 0.0, e0 + 1, ndim, P.p, S);
+            }
+        }
+    }
+    __device__ static double finish_n(const double (&S)[F::kNAcc], const DensityParams& P) { return F::finish(S, P.ndim, P.p); }
+    // (unused single-sum forms, so that every vector-kernel instantiation finds the names)
+    template <int L, int K> __device__ static double frag_partial(const double2 (&)[K], int, int, const DensityParams&) { return 0.0; }
+    __device__ static double finish(double S, const DensityParams&) { return S; }
+};
+template <class D, class = void> struct MultiSumTrait { static constexpr int n = 0; };
+template <class D> struct MultiSumTrait<D, decltype((void)D::kNSums)> { static constexpr int n = D::kNSums; };
+
 // ------------------------------------------------------------------------------------------
 // A log-density given as a whole function over the proposal vector (runtime-compiled, kmc_user_density_create_body):
 // the kernels that walk a row element by element (generic half-step, initial log-pdfs, initial ball, Metropolis) collect

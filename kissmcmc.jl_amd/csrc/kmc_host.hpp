@@ -167,6 +167,7 @@ struct kmc_user_density {
     // the finish.  Everything else about the density (initial log-pdfs, resident kernels, Metropolis) keeps evaluating the body.
     bool sep = false;
     bool sep_pair = false;                           // the loop reads x[i + 1] / runs to n - 1: its body is the PAIR function
+    int sep_nacc = 1;                                // sums the loop feeds (1: SepDensity; 2..4: SepDensityN)
     std::string sep_functor;                         // "struct UserS { term, pair, finish };" generated from the body
     std::mutex mu;
     std::map<std::string, std::vector<char>> code;   // geometry key -> gfx950 code object

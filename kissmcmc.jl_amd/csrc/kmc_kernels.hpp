@@ -767,7 +767,14 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
             xo[it][k].x = as_stored<T>(fma(zB[it], xc[it][k].x - xo[it][k].x, xo[it][k].x));
             xo[it][k].y = as_stored<T>(fma(zB[it], xc[it][k].y - xo[it][k].y, xo[it][k].y));
         }
-        if constexpr (kRowND == 0) {
+        if constexpr (MultiSumTrait<Dens>::n > 0) {                    // a function body feeding several sums over the elements
+            double S[MultiSumTrait<Dens>::n];
+            Dens::template frag_partial_n<L, K>(xo[it], j, ndim, a.dp, S);
+#pragma unroll
+            for (int q = 0; q < MultiSumTrait<Dens>::n; ++q) S[q] = group_sum<L>(S[q]);
+            const double p1 = Dens::finish_n(S, a.dp);                   // :257
+            myp1 = (j == it) ? p1 : myp1;
+        } else if constexpr (kRowND == 0) {
             const double S  = group_sum<L>(Dens::template frag_partial<L, K>(xo[it], j, ndim, a.dp));
             const double p1 = Dens::finish(S, a.dp);                     // :257
             myp1 = (j == it) ? p1 : myp1;                               // row -> scalar, no traffic

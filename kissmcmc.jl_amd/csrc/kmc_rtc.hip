@@ -7,6 +7,7 @@
 #include <sys/wait.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <cerrno>
 #include <csignal>
 
@@ -205,13 +206,14 @@ void set_offline_compiler_hint(bool wanted) { g_offline_wanted = wanted ? 1 : 0;
 // ---- a function body that is a sum over elements ------------------------------------------------------------------------
 // Recognised form (after comments are dropped; whitespace free):
 //     [declarations not touching x]                       e.g.  const double w = p[1];
-//     double ACC = 0;                                     the accumulator (exactly one)
+//     double ACC = 0[, ACC2 = 0 ...];                     the accumulators (one to four)
 //     for (int I = 0; I < n; ++I)  STMT | { STMTS }       or  I + 1 < n  /  I < n - 1  when x[I + 1] is read
 //     return EXPR;                                        any expression of ACC, n, p and the declarations
 // where the loop's statements read the proposal only as x[I] (and x[I + 1]), change ACC only by `ACC += ...`, and contain no
 // return / break / continue / goto / nested loop.  Then  logpdf = EXPR(ACC = sum over I of the loop body's increments), and the
 // loop body is exactly a term (or pair) function of a TermPairDensity -- same operations per element, only the ORDER of the sum
-// differs (lane-striped, like the menu densities).  Anything else -- early returns, two accumulators, x[j] with another index --
+// differs (lane-striped, like the menu densities); with several accumulators one pass over the elements feeds all the sums
+// (SepDensityN).  Anything else -- early returns, x[j] with another index, a running sum read inside the loop --
 // is not recognised and keeps running one walker per lane.  KMC_DEBUG=no-body-routing switches the recognition off.
 namespace {
 std::string strip_comments(const std::string& t)
@@ -278,26 +280,27 @@ bool recognise_separable(kmc_user_density* ud)
     if (!std::regex_match(tail, r, std::regex("\\s*return\\b([^;]*);\\s*"))) return false;
     const std::string ret = r[1].str();
     if (has_word(ret, "x") || has_word(ret, I)) return false;
-    // the accumulator: the one name the loop changes by +=, declared `double ACC = 0` in front of the loop
-    std::string acc;
+    // the accumulators: every name the loop changes by += (at most four), each declared `double ACC = 0` in front of the loop
+    std::vector<std::string> accs;
     {
         static const std::regex pluseq("\\b(\\w+)\\s*\\+=");
         for (auto it = std::sregex_iterator(loop.begin(), loop.end(), pluseq); it != std::sregex_iterator(); ++it) {
             const std::string name = (*it)[1].str();
-            if (acc.empty()) acc = name;
-            else if (name != acc) return false;                              // two accumulators: not one sum
+            if (std::find(accs.begin(), accs.end(), name) == accs.end()) accs.push_back(name);
         }
-        if (acc.empty() || acc == I) return false;
-        // every other mention of ACC inside the loop would make the increments depend on the running sum
-        const std::regex any_acc("\\b" + acc + "\\b"), inc_acc("\\b" + acc + "\\s*\\+=");
-        const auto n_all = std::distance(std::sregex_iterator(loop.begin(), loop.end(), any_acc), std::sregex_iterator());
-        const auto n_pe = std::distance(std::sregex_iterator(loop.begin(), loop.end(), inc_acc), std::sregex_iterator());
-        if (n_all != n_pe) return false;
-        if (std::regex_search(loop, std::regex("[-*/%&|^]=|<<=|>>=|\\+\\+|--")))  {
-            // compound assignments / increments of OTHER variables are fine only for names declared inside the loop body; keep it simple
-            return false;
+        if (accs.empty() || accs.size() > 4) return false;
+        for (const std::string& acc : accs) {
+            if (acc == I || acc == "x" || acc == "n" || acc == "p") return false;
+            // every other mention of an accumulator inside the loop would make the increments depend on a running sum
+            const std::regex any_acc("\\b" + acc + "\\b"), inc_acc("\\b" + acc + "\\s*\\+=");
+            const auto n_all = std::distance(std::sregex_iterator(loop.begin(), loop.end(), any_acc), std::sregex_iterator());
+            const auto n_pe = std::distance(std::sregex_iterator(loop.begin(), loop.end(), inc_acc), std::sregex_iterator());
+            if (n_all != n_pe) return false;
         }
+        // compound assignments / increments of other variables: state carried between elements, or too clever for a text matcher
+        if (std::regex_search(loop, std::regex("[-*/%&|^]=|<<=|>>=|\\+\\+|--"))) return false;
     }
+    auto is_acc = [&](const std::string& name) { return std::find(accs.begin(), accs.end(), name) != accs.end(); };
     // the proposal is read as x[I] and x[I + 1] only
     bool reads_next = false;
     {
@@ -311,10 +314,10 @@ bool recognise_separable(kmc_user_density* ud)
         }
     }
     if (reads_next && !to_n1) return false;                                   // (would read past the row's end anyway)
-    // the declarations in front of the loop: `[const] double|int a = e[, b = f];` only, ACC among them with the value 0
+    // the declarations in front of the loop: `[const] double|int a = e[, b = f];` only, the accumulators among them with the value 0
     const std::string pre = t.substr(0, (size_t)m.position(0));
-    std::string prelude;                                                      // everything but ACC, for both generated functions
-    bool acc_declared = false;
+    std::string prelude;                                                      // everything but the accumulators, for every generated function
+    size_t acc_declared = 0;
     {
         size_t i = 0;
         while (i < pre.size()) {
@@ -340,13 +343,13 @@ bool recognise_separable(kmc_user_density* ud)
             std::string kept;
             for (const std::string& dc : decls) {
                 std::smatch a;
-                if (std::regex_match(dc, a, std::regex("\\s*(\\w+)\\s*=\\s*(.*?)\\s*")) && a[1].str() == acc) {
-                    if (d[2].str() != "double" || !std::regex_match(a[2].str(), std::regex("[-+]?0*\\.?0*"))) return false;    // ACC must start at 0
+                if (std::regex_match(dc, a, std::regex("\\s*(\\w+)\\s*=\\s*(.*?)\\s*")) && is_acc(a[1].str())) {
+                    if (d[2].str() != "double" || !std::regex_match(a[2].str(), std::regex("[-+]?0*\\.?0*"))) return false;    // an accumulator must start at 0
                     if (squeeze(a[2].str()).empty()) return false;
-                    acc_declared = true;
+                    ++acc_declared;
                     continue;
                 }
-                if (has_word(dc, acc)) return false;
+                for (const std::string& acc : accs) if (has_word(dc, acc)) return false;
                 if (std::regex_match(dc, a, std::regex("\\s*(\\w+)\\b.*")) &&
                     std::regex_search(loop, std::regex("\\b" + a[1].str() + "\\s*(\\[[^\\]]*\\]\\s*)?=[^=]")))
                     return false;                                             // a declaration the loop assigns to: state carried between elements
@@ -355,22 +358,40 @@ bool recognise_separable(kmc_user_density* ud)
             if (!kept.empty()) prelude += (d[1].matched ? "const " : "") + d[2].str() + " " + kept + "; ";
         }
     }
-    if (!acc_declared) return false;
+    if (acc_declared != accs.size()) return false;
     // the loop body as a function of (x[I] -> kmc_x, x[I + 1] -> kmc_y)
     std::string fn = std::regex_replace(loop, std::regex("\\bx\\s*\\[\\s*(" + I + "\\s*\\+\\s*1|1\\s*\\+\\s*" + I + ")\\s*\\]"), "kmc_y");
     fn = std::regex_replace(fn, std::regex("\\bx\\s*\\[\\s*" + I + "\\s*\\]"), "kmc_x");
-    const std::string body_fn = "(void)kmc_x; (void)kmc_y; (void)" + I + "; (void)n; (void)p; " + prelude + "double " + acc + " = 0.0; { " + fn + " } return " + acc + ";";
+    const size_t N = accs.size();
     std::ostringstream o;
     o << "namespace {\nstruct UserS {\n"
       << "  static constexpr bool kHasPair = " << (to_n1 ? "true" : "false") << ";\n";
-    if (to_n1) {
-        o << "  __device__ static double term(double, int, int, const double*) { return 0.0; }\n"
-          << "  __device__ static double pair(double kmc_x, double kmc_y, int " << I << ", int n, const double* p) { " << body_fn << " }\n";
+    if (N == 1) {
+        // one sum: the term / pair functor of a TermPairDensity, the return expression as its finish (SepDensity)
+        const std::string& acc = accs[0];
+        const std::string body_fn = "(void)kmc_x; (void)kmc_y; (void)" + I + "; (void)n; (void)p; " + prelude + "double " + acc + " = 0.0; { " + fn + " } return " + acc + ";";
+        if (to_n1) {
+            o << "  __device__ static double term(double, int, int, const double*) { return 0.0; }\n"
+              << "  __device__ static double pair(double kmc_x, double kmc_y, int " << I << ", int n, const double* p) { " << body_fn << " }\n";
+        } else {
+            o << "  __device__ static double term(double kmc_x, int " << I << ", int n, const double* p) { const double kmc_y = 0.0; " << body_fn << " }\n"
+              << "  __device__ static double pair(double, double, int, int, const double*) { return 0.0; }\n";
+        }
+        o << "  __device__ static double finish(double " << acc << ", int n, const double* p) { (void)n; (void)p; " << prelude << "return (" << ret << "); }\n};\n}\n";
     } else {
-        o << "  __device__ static double term(double kmc_x, int " << I << ", int n, const double* p) { const double kmc_y = 0.0; " << body_fn << " }\n"
-          << "  __device__ static double pair(double, double, int, int, const double*) { return 0.0; }\n";
+        // several sums: one pass over the elements adds to all of them (SepDensityN), the return expression sees them by name
+        std::string zero, add, take;
+        for (size_t q = 0; q < N; ++q) {
+            zero += (q ? ", " : "double ") + accs[q] + " = 0.0";
+            add += "kmc_acc[" + std::to_string(q) + "] += " + accs[q] + "; ";
+            take += (q ? ", " : "const double ") + accs[q] + " = kmc_acc[" + std::to_string(q) + "]";
+        }
+        const std::string body_fn = "(void)kmc_x; (void)kmc_y; (void)" + I + "; (void)n; (void)p; " + prelude + zero + "; { " + fn + " } " + add;
+        o << "  static constexpr int kNAcc = " << N << ";\n"
+          << "  __device__ static void elem(double kmc_x, double kmc_y, int " << I << ", int n, const double* p, double (&kmc_acc)[" << N << "]) { " << body_fn << "}\n"
+          << "  __device__ static double finish(const double (&kmc_acc)[" << N << "], int n, const double* p) { (void)n; (void)p; " << prelude << take << "; return (" << ret << "); }\n};\n}\n";
     }
-    o << "  __device__ static double finish(double " << acc << ", int n, const double* p) { (void)n; (void)p; " << prelude << "return (" << ret << "); }\n};\n}\n";
+    ud->sep_nacc = (int)N;
     ud->sep = true;
     ud->sep_pair = to_n1;
     ud->sep_functor = o.str();
@@ -471,7 +492,8 @@ kmc_status compile_user(kmc_user_density* ud, bool with_vec, int L, int K, int i
 
     std::ostringstream src;
     src << "#include \"kmc_islands.hpp\"\n" << user_functor_source(ud) << user_density_alias(ud, ndim)
-        << (ud->is_body && with_vec && ud->sep ? ud->sep_functor + "using UDV = kmc::SepDensity<UserS>;\n" : std::string("using UDV = UD;\n"))
+        << (ud->is_body && with_vec && ud->sep ? ud->sep_functor + (ud->sep_nacc > 1 ? "using UDV = kmc::SepDensityN<UserS>;\n" : "using UDV = kmc::SepDensity<UserS>;\n")
+                                                : std::string("using UDV = UD;\n"))
         << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_generic(KMC_FRONT_PARAMS, const kmc::HalfStepArgs a) { kmc::half_step_generic_body<UD, " << peer << ", " << rowt << ">(KMC_FRONT_PACK, a); }\n"
         << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_logpdf(const kmc::LogpdfArgs a) { kmc::logpdf_rows_body<UD>(a); }\n"
         << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_init_ball(const kmc::InitBallArgs a) { kmc::init_ball_body<UD>(a); }\n";

@@ -151,10 +151,13 @@ def test_user_density_compiles_and_reports_syntax_errors(kmc):
 
 def test_bodies_that_are_not_sums_over_elements_are_not_routed(kmc):
     # (hiprtc compiles without a device: the recogniser and the functor it generates are checked here, the routed kernels in -m gpu)
-    """What the recogniser must leave alone (each would change meaning as a per-element function): early returns, two accumulators,
-    another index, state carried between elements, the running sum read inside the loop, no loop at all."""
+    """What the recogniser must leave alone (each would change meaning as a per-element function): early returns, more than four
+    sums, a sum that reads another, another index, a second loop, state carried between elements, the running sum read inside the
+    loop, no loop at all -- and what it must take: one to four sums fed by one pass over the elements."""
     assert not kmc.CDensity("double s = 0.0; for (int i = 0; i < n; ++i) { if (x[i] < 0.0) return -INFINITY; s += x[i]; } return -(p[0] * s);", params=[1.0]).separable
-    for body in ("double s = 0.0, t = 0.0; for (int i = 0; i < n; ++i) { s += x[i] * x[i]; t += x[i]; } return -0.5 * (s + p[0] * t * t);",
+    for body in ("double a=0,b=0,c=0,d=0,e=0; for (int i = 0; i < n; ++i) { a += x[i]; b += x[i]; c += x[i]; d += x[i]; e += x[i]; } return -(a+b+c+d+e);",   # five sums
+                 "double s = 0, t = 0; for (int i = 0; i < n; ++i) { s += x[i] * x[i]; t += s; } return -t;",          # a sum that reads another
+                 "double s = 0; for (int i = 0; i < n; ++i) s += x[i]*x[i]; for (int i = 0; i + 2 < n; ++i) s += p[0]*x[i]*x[i+2]; return -0.5*s;",   # two loops
                  "double s = 0; for (int i = 0; i < n; ++i) s += x[i] * x[0]; return -s;",
                  "double s = 0; double c = 1.0; for (int i = 0; i < n; ++i) { c = c * 0.5; s += c * x[i]; } return -s;",
                  "double s = 0; for (int i = 0; i < n; ++i) { s += x[i] * (1.0 + s); } return -s;",
@@ -165,6 +168,8 @@ def test_bodies_that_are_not_sums_over_elements_are_not_routed(kmc):
                  "const double t = x[0] + 5.0; return -(t * t) / 18.0;"):
         assert not kmc.CDensity(body, params=[0.5]).separable, body
     for body in ("double s = 0; for (int i = 0; i < n; ++i) s += x[i] * x[i]; return -0.5 * s;",
+                 "double s = 0.0, t = 0.0; for (int i = 0; i < n; ++i) { s += x[i] * x[i]; t += x[i]; } return -0.5 * (s + p[0] * t * t);",   # two sums, one pass
+                 "double s = 0.0; double t = 0.0; double u = 0; for (int i = 0; i + 1 < n; ++i) { double d = x[i+1]-x[i]; s += d*d; t += x[i]; u += x[i+1]*x[i]; } return -(s + 0.1*t*t + 0.01*u);",
                  "const double w = p[1] * p[1]; double s = 0; for (int i = 0; i < n; i++) { s += w * x[i] * x[i]; } return -0.5 * s / w;",
                  "double s = 0; /* sum */ for (int i = 0; i < n - 1; ++i) { // pairs\n s += (x[i+1]-x[i])*(x[i+1]-x[i]); } return -0.5*s;",
                  "double s = 0; for (int i = 0; i < n; ++i) { if (x[i] > 0) s += x[i]; else s += -2.0 * x[i]; } return -s;"):

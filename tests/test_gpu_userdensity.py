@@ -195,6 +195,37 @@ def test_big_ensembles_ask_for_the_offline_compiler_by_themselves(kmc, oracle, t
     _check(oracle, oracle.GAUSSIAN_ISO, [0.3, 1.5], th, G, nburn, seed, got)
 
 
+@pytest.mark.parametrize("case", ["two-sums_3000x6", "two-sums_512x33", "three-sums-neighbour_1200x32", "three-sums-neighbour_300x130"])
+def test_bodies_feeding_several_sums_run_lane_striped(kmc, case, monkeypatch, kmc_debug):
+    """`double s = 0, t = 0; for (i < n) { s += f(x[i]); t += g(x[i]); } return h(s, t);` -- up to four sums fed by one pass over the
+    elements (the neighbour form included) -- is recognised like the one-sum form and runs lane-striped (SepDensityN); the same
+    body evaluated per walker (`no-body-routing`) gives the same chain and counters, log-pdfs to rounding (lane-order sums)."""
+    name, shape = case.split("_")
+    nw, nd = (int(v) for v in shape.split("x"))
+    body = ("double s = 0.0, t = 0.0; for (int i = 0; i < n; ++i) { s += x[i] * x[i]; t += x[i]; } return -0.5 * (s + p[0] * t * t);" if name == "two-sums" else
+            "double s = 0.0; double t = 0.0; double u = 0; for (int i = 0; i + 1 < n; ++i) { double d = x[i+1]-x[i]; s += d*d; t += x[i]*x[i]; u += x[i+1]*x[i]; } "
+            "return -(p[0]*s + 0.5*t + 0.01*u);")
+    monkeypatch.setenv("KMC_NO_RESIDENT", "1")
+    th = np.random.default_rng(4).standard_normal((nw, nd))
+    G, nburn, seed = 80, 20, 17
+    routed = kmc.CDensity(body, params=[0.3])
+    assert routed.separable
+    with kmc.Sampler(routed, nw, nd, G, nburn, 1, 2.0, seed) as s:
+        assert "recognised as a sum over elements" in s.describe()
+    a = _run(kmc, routed, th, G, nburn, seed)
+    kmc_debug.set("no-body-routing")
+    plain = kmc.CDensity(body, params=[0.3])
+    assert not plain.separable
+    with kmc.Sampler(plain, nw, nd, G, nburn, 1, 2.0, seed) as s:
+        assert "evaluated per walker" in s.describe()
+    b = _run(kmc, plain, th, G, nburn, seed)
+    for k in ("pos", "nacc", "chain"):
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    assert np.all(np.abs(a["logp"] - b["logp"]) <= 1e-12 * np.maximum(1.0, np.abs(b["logp"])))
+    assert a["n"] == b["n"]
+    np.testing.assert_allclose(a["sum"], b["sum"], rtol=1e-11, atol=1e-9)
+
+
 def test_body_density_with_real_coupling_samples_its_target(kmc, monkeypatch):
     """A density no term / pair form can express -- a correlated Gaussian with a dense precision matrix built in the body:
     x' P x with P = (1 + rho) I - rho/n 11' ... here: -0.5 (sum x_i^2 + c (sum x_i)^2): variance of the mean direction
@@ -204,7 +235,7 @@ def test_body_density_with_real_coupling_samples_its_target(kmc, monkeypatch):
     pdf = kmc.CDensity("double s = 0.0, t = 0.0; for (int i = 0; i < n; ++i) { s += x[i] * x[i]; t += x[i]; } return -0.5 * (s + p[0] * t * t);", params=[c])
     th = np.random.default_rng(1).standard_normal((2048, n))
     with kmc.Sampler(pdf, 2048, n, 3000, 500, 5, 2.0, 3, store_chain=True) as s:
-        assert "half_step_vec" in s.describe() and "evaluated per walker" in s.describe() and "runtime-compiled" in s.describe()
+        assert "half_step_vec" in s.describe() and "recognised as a sum over elements" in s.describe() and "runtime-compiled" in s.describe()
         s.set_positions(th)
         s.run(3000)
         s.sync()
