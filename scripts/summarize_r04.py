@@ -142,6 +142,31 @@ def main():
         json.dump(rec, open(os.path.join(DST, f"traffic_{name}.json"), "w"), indent=1)
         print(json.dumps({k: out.get(k) for k in ("config", "geometry", "hbm_bytes_per_launch", "read_traffic_over_algorithmic_read", "l2_hit_rate", "fractions")}, indent=1))
         print(json.dumps(rec))
+    # the HBM-resident shapes in one place (what VERDICT r03 asked for by this name): counters, hit rate, fractions against both peaks
+    hbm = {"tag": tag, "head": hd, "what": "the two ensembles of bench.py's other_configs whose state (512 MiB) does not fit the 256 MiB Infinity Cache: "
+                                            "same kernels, exact partner rule, moments on; per launch = per half-step",
+           "peaks_GBs": {"hbm_spec": 8000.0, "measured_copy": 6290.0}, "shapes": {}}
+    for cfg in ("hbm32", "hbm128"):
+        path = os.path.join(DST, f"{tag}_{cfg}_summary.json")
+        if not os.path.exists(path):
+            continue
+        o = json.load(open(path))
+        fr = o.get("fractions", {})
+        pm = o.get("pmc_per_launch", {})
+        hbm["shapes"][SHAPES[cfg][0]] = {
+            "shape": o["shape"], "kernel": o["kernel_name"], "geometry": o["geometry"],
+            "FETCH_SIZE_KiB_per_launch": pm.get("FETCH_SIZE", {}).get("second_half_mean"), "WRITE_SIZE_KiB_per_launch": pm.get("WRITE_SIZE", {}).get("second_half_mean"),
+            "TCC_HIT_sum_per_launch": pm.get("TCC_HIT_sum", {}).get("second_half_mean"), "TCC_MISS_sum_per_launch": pm.get("TCC_MISS_sum", {}).get("second_half_mean"),
+            "l2_hit_rate": o.get("l2_hit_rate"),
+            "hbm_read_bytes_per_launch_corrected": o.get("hbm_read_bytes_per_launch_corrected"), "hbm_write_bytes_per_launch": o.get("hbm_write_bytes_per_launch"),
+            "algorithmic_read_bytes_per_launch": o["algorithmic_read_bytes_per_launch"], "read_traffic_over_algorithmic_read": o.get("read_traffic_over_algorithmic_read"),
+            "hip_event_us_per_launch_unprofiled": o.get("hip_event_us_per_launch_unprofiled"), "kernel_trace_mean_duration_us": o["duration_us"]["mean"],
+            "algorithmic_read_GBs": fr.get("algorithmic_read_GBs"), "frac_of_8.0_TBs": fr.get("frac_of_8TBs"), "frac_of_6.29_TBs": fr.get("frac_of_6.29TBs_measured_copy"),
+            "counter_read_plus_write_GBs": fr.get("pmc_total_GBs_over_period"),
+            "counter_read_plus_write_over_6.29_TBs": (fr.get("pmc_total_GBs_over_period") or 0) / 6290.0 or None,
+            "full_summary": f"profiles/{tag}_{cfg}_summary.json", "record_bench_attaches": f"profiles/traffic_{SHAPES[cfg][0]}.json"}
+    if hbm["shapes"]:
+        json.dump(hbm, open(os.path.join(DST, f"{tag}_hbm_summary.json"), "w"), indent=1)
     # the probe timelines, as text
     with open(os.path.join(DST, f"{tag}_probe_timeline.txt"), "w") as f:
         for cfg in ("C2", "C3", "C5"):
