@@ -29,9 +29,13 @@ with kmc.Sampler(kmc.GaussianIso(), nw, nd, G, 0, 1, 2.0, 9, moments=True) as s:
     s.sync()
     ref_pos, ref_acc = s.positions(), s.naccept()
     print(f"unsharded {nw} x {nd}: {s.last_run_ms() / (2 * G) * 1e3:.2f} us per half-step")
-for name, kw in (("pull, signal kernel", {}), ("pull, folded signal", dict(p2p_fold=True)),
-                 ("push, signal kernel", dict(p2p_push=True)), ("push, folded signal", dict(p2p_push=True, p2p_fold=True)),
-                 ("lazy pull, signal kernel", dict(p2p_lazy=True)), ("lazy pull, folded signal", dict(p2p_lazy=True, p2p_fold=True))):
+from kissmcmc_jl_amd import _lib
+variants = [("pull, signal kernel", {})]
+if _lib.lib().kmc_has_p2p_experimental():        # (KMC_LIB_PATH=kissmcmc.jl_amd/libkmc_var_p2pexp.so: the -DKMC_P2P_EXPERIMENTAL build)
+    variants += [("pull, folded signal", dict(p2p_fold=True)), ("push, signal kernel", dict(p2p_push=True)), ("push, folded signal", dict(p2p_push=True, p2p_fold=True)),
+                 ("lazy pull, signal kernel", dict(p2p_lazy=True)), ("lazy pull, folded signal", dict(p2p_lazy=True, p2p_fold=True))]
+print("library:", _lib.LIB_PATH, "(experimental exchange variants)" if len(variants) > 1 else "(default: pull only)")
+for name, kw in variants:
     shards = [kmc.Sampler(kmc.GaussianIso(), nw, nd, G, 0, 1, 2.0, 9, moments=True, shard_rank=r, shard_count=world, p2p=True, **kw)
               for r in range(world)]
     if world == 2:       # streams of different priority never share a hardware queue (the shards spin on each other)
