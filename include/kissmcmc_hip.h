@@ -284,6 +284,11 @@ kmc_status  kmc_emcee_run(const kmc_config* cfg, const double* theta0 /* host [n
 
 /* ---- stateful sampler (device-resident state; what bench.py and the distributed driver use) ---- */
 kmc_status  kmc_sampler_create(const kmc_config* cfg, kmc_sampler** out);
+/* Waits for the sampler's own streams; small device buffers then go back to a per-device cache WITHOUT the device-wide wait a
+ * hipFree implies.  When a caller's stream was ever bound (kmc_sampler_set_stream) or the sampler is a shard (shard_count > 1, an RCCL
+ * communicator attached) the whole device is waited for first, so work other streams still have in flight on the sampler's buffers
+ * (a framework's collectives on the rows, ...) cannot race the next owner of a recycled block.  Work on a buffer handed out by
+ * kmc_sampler_device_ptr that the library cannot know of must have completed before this call. */
 void        kmc_sampler_destroy(kmc_sampler* s);
 /* Run on a caller-owned HIP stream (hipStream_t) instead of the sampler's own. */
 kmc_status  kmc_sampler_set_stream(kmc_sampler* s, void* hip_stream);
