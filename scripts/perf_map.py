@@ -7,7 +7,9 @@ import kissmcmc_jl_amd as kmc
 body = "double s = 0; for (int i = 0; i < n; ++i) s += x[i] * x[i]; return -0.5 * s;"
 NW = (100, 1000, 2048, 4096, 16384, 65536, 262144)
 ND = (1, 4, 32, 128)
-for name, make in (("menu GaussianIso", lambda: kmc.GaussianIso()), ("CDensity (function body)", lambda: kmc.CDensity(body))):
+general = "double s = 0; for (int i = 0; i < n; ++i) s += x[i] * x[i]; for (int i = 0; i + 2 < n; ++i) s += p[0] * x[i] * x[i + 2]; return -0.5 * s;"
+for name, make in (("menu GaussianIso", lambda: kmc.GaussianIso()), ("CDensity, a sum over elements (recognised: lane-striped)", lambda: kmc.CDensity(body)),
+                   ("CDensity, a general body (second-neighbour coupling, two loops: rows lane-striped, evaluated per walker)", lambda: kmc.CDensity(general, params=[0.2]))):
     print(f"\n{name}: walker-steps/s (us per half-step) [mode]")
     print("walkers \\ ndim | " + " | ".join(f"{d:>24d}" for d in ND))
     for nw in NW:
