@@ -36,6 +36,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
+def note(msg: str) -> None:
+    """One line on stderr in ONE write: the ranks share the terminal, and print() hands the text and the newline over separately."""
+    sys.stderr.write(msg + "\n")
+    sys.stderr.flush()
+
 
 def bench_test_opt(name: str, default=None):
     """KMC_BENCH_TEST="opt[=value],opt,...": the switches only the tests of this file use (README): backend=gloo and walkers=n
@@ -306,7 +311,7 @@ def spawn_ranks(n: int, argv) -> int:
         pass
     if not procs:
         return 128 + (stopped_by[-1] if stopped_by else signal.SIGINT)
-    print(f"[bench launcher] started ranks: {' '.join(str(p.pid) for p in procs)}", file=sys.stderr, flush=True)
+    note(f"[bench launcher] started ranks: {' '.join(str(p.pid) for p in procs)}")
 
     def stop_all(sig):
         for p in procs:
@@ -338,14 +343,14 @@ def spawn_ranks(n: int, argv) -> int:
             bad = [p.returncode for p in procs if p.poll() is not None and p.returncode != 0]
             if bad or time.monotonic() > deadline:
                 status = bad[0] if bad else 124
-                print(f"[bench launcher] {'a rank exited with status ' + str(status) if bad else 'the job ran out of time (KMC_BENCH_TIMEOUT)'}: stopping the others", file=sys.stderr)
+                note(f"[bench launcher] {'a rank exited with status ' + str(status) if bad else 'the job ran out of time (KMC_BENCH_TIMEOUT)'}: stopping the others")
                 time.sleep(5.0 if bad else 0.0)      # (a failing rank's peers usually follow by themselves)
                 end_ranks()
                 break
             time.sleep(0.05)
     except KeyboardInterrupt:
         sg = stopped_by[-1] if stopped_by else signal.SIGINT
-        print(f"[bench launcher] stopped by signal {sg}: stopping the ranks", file=sys.stderr)
+        note(f"[bench launcher] stopped by signal {sg}: stopping the ranks")
         status = 128 + sg
     finally:
         for sg, h in previous.items():
@@ -367,7 +372,7 @@ def spawn_ranks(n: int, argv) -> int:
         sys.stdout.write(js[-1] if js[-1].endswith("\n") else js[-1] + "\n")
         sys.stdout.flush()
     elif status == 0:
-        print("[bench launcher] rank 0 printed no result line", file=sys.stderr)
+        note("[bench launcher] rank 0 printed no result line")
         status = 1
     return status if status >= 0 else 128 - status
 
@@ -399,10 +404,10 @@ class rung:
 
         def expired():
             rank = os.environ.get("RANK", "0")
-            print(f"[rank {rank}] bench.py: '{self.what}' did not finish within {self.seconds:.0f} s (hung collective or "
-                  f"peer wait?): giving up; Python stacks of this rank:", file=sys.stderr, flush=True)
+            note(f"[rank {rank}] bench.py: '{self.what}' did not finish within {self.seconds:.0f} s (hung collective or "
+                 f"peer wait?): giving up; Python stacks of this rank:")
             LADDER.append({"rung": self.what, "ok": False, "s": round(time.perf_counter() - self.t0, 3), "timed_out": True})
-            print(f"[rank {rank}] ladder so far: {json.dumps(LADDER)}", file=sys.stderr, flush=True)
+            note(f"[rank {rank}] ladder so far: {json.dumps(LADDER)}")
             try:
                 import faulthandler
                 faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
@@ -415,7 +420,7 @@ class rung:
                     sys.stderr.flush()
                     os._exit(0)
                 except Exception as e:  # noqa: BLE001
-                    print(f"[rank {rank}] could not print the result line ({e})", file=sys.stderr, flush=True)
+                    note(f"[rank {rank}] could not print the result line ({e})")
             os._exit(3)
         self.timer = threading.Timer(self.seconds, expired)
         self.timer.daemon = True
@@ -782,14 +787,14 @@ def main():
                 d = P2PEmcee(pdf, nw, NDIM, G, nburn, 1, 2.0, SEED, device=local_rank, finegrained=finegrained,
                              fold_signal=fold_signal, push=push, lazy=lazy, connect=False)      # local part only: no collective yet
             except Exception as e:  # noqa: BLE001
-                print(f"[rank {rank}] p2p set-up failed ({e})", file=sys.stderr)
+                note(f"[rank {rank}] p2p set-up failed ({e})")
                 ok = False
             if all_ok(ok):                                   # every rank has its sampler and handles: now the exchange
                 try:
                     d.connect()
                     fault("p2p_connect")
                 except Exception as e:  # noqa: BLE001
-                    print(f"[rank {rank}] p2p connect failed ({e})", file=sys.stderr)
+                    note(f"[rank {rank}] p2p connect failed ({e})")
                     ok = False
             if all_ok(ok):
                 vgen = 240
@@ -799,7 +804,7 @@ def main():
                     d.sync()                                  # (a peer wait that timed out surfaces here, on the ranks that waited)
                     fault("p2p_selfcheck")
                 except Exception as e:  # noqa: BLE001
-                    print(f"[rank {rank}] p2p self-check failed ({e})", file=sys.stderr)
+                    note(f"[rank {rank}] p2p self-check failed ({e})")
                     ok = False
                 ok = all_ok(ok)                               # every rank's kernels ran through: only then the result collectives
                 try:
@@ -809,11 +814,11 @@ def main():
                     if rank == 0:
                         rpos, racc, _ = unsharded(vgen)
                         if not (np.array_equal(rpos, vpos) and np.array_equal(racc, vacc)):
-                            print(f"[rank 0] p2p self-check (finegrained={finegrained}, fold_signal={fold_signal}, push={push}, lazy={lazy}): "
-                                  "sharded run differs from the single-GPU run", file=sys.stderr)
+                            note(f"[rank 0] p2p self-check (finegrained={finegrained}, fold_signal={fold_signal}, push={push}, lazy={lazy}): "
+                                 "sharded run differs from the single-GPU run")
                             ok = False
                 except Exception as e:  # noqa: BLE001
-                    print(f"[rank {rank}] p2p self-check failed ({e})", file=sys.stderr)
+                    note(f"[rank {rank}] p2p self-check failed ({e})")
                     ok = False
                 ok = all_ok(ok)
             else:
@@ -836,7 +841,7 @@ def main():
                 fault("allgather_setup")
                 d = AllGatherEmcee(pdf, nw, NDIM, G, nburn, 1, 2.0, SEED, device=local_rank, connect=False)
             except Exception as e:  # noqa: BLE001
-                print(f"[rank {rank}] native RCCL all-gather set-up failed ({e})", file=sys.stderr)
+                note(f"[rank {rank}] native RCCL all-gather set-up failed ({e})")
                 ok = False
             if all_ok(ok):
                 try:
@@ -844,7 +849,7 @@ def main():
                         d.connect()
                         fault("allgather_connect")
                 except Exception as e:  # noqa: BLE001
-                    print(f"[rank {rank}] native RCCL all-gather set-up failed ({e})", file=sys.stderr)
+                    note(f"[rank {rank}] native RCCL all-gather set-up failed ({e})")
                     ok = False
                 ok = all_ok(ok)
             else:
@@ -913,10 +918,10 @@ def main():
                 if drv is not None:
                     p2p_memory = "pull of drawn rows, rows in fine-grained memory, signal kernel"
             if rank == 0 and tried:
-                print("[rank 0] p2p variants, s per 1024 generations: " + "; ".join(f"{l}: {t:.4f}" for l, t in tried), file=sys.stderr)
+                note("[rank 0] p2p variants, s per 1024 generations: " + "; ".join(f"{l}: {t:.4f}" for l, t in tried))
             if drv is None:
                 if rank == 0:
-                    print("[rank 0] falling back to the RCCL all-gather exchange", file=sys.stderr)
+                    note("[rank 0] falling back to the RCCL all-gather exchange")
                 mode = "allgather"
             else:
                 mode = "p2p"
@@ -938,7 +943,7 @@ def main():
                         fault("p2p_run")
                         ran = True
                     except Exception as e:  # noqa: BLE001  (a timed-out peer wait: the other ranks must not be left inside a collective)
-                        print(f"[rank {rank}] the p2p run failed ({e})", file=sys.stderr)
+                        note(f"[rank {rank}] the p2p run failed ({e})")
                         ran = False
                     torch.cuda.synchronize()
                     if not all_ok(ran):
@@ -954,7 +959,7 @@ def main():
                     how = drv.sampler.describe()
                     drv.close()
             except Exception as e:  # noqa: BLE001  (e.g. a peer wait that timed out: every rank then takes the fallback)
-                print(f"[rank {rank}] the p2p run failed ({e})", file=sys.stderr)
+                note(f"[rank {rank}] the p2p run failed ({e})")
                 ok = False
                 try:
                     drv.sampler.close()
@@ -962,7 +967,7 @@ def main():
                     pass
             if not all_ok(ok):
                 if rank == 0:
-                    print("[rank 0] falling back to the RCCL all-gather exchange", file=sys.stderr)
+                    note("[rank 0] falling back to the RCCL all-gather exchange")
                 mode = "allgather"
         if mode == "p2p":
             # the timed run itself, against the unsharded run of the whole job on one GPU (rank 0)
@@ -971,7 +976,7 @@ def main():
                 verified = bool(np.array_equal(rpos, fpos) and np.array_equal(racc, facc) and rn == nmom and
                                 np.allclose(rs, msum, rtol=1e-10, atol=1e-6) and np.allclose(rq, msq, rtol=1e-10, atol=1e-6))
                 if not verified:
-                    print("[rank 0] the TIMED sharded run differs from the unsharded run of the same job", file=sys.stderr)
+                    note("[rank 0] the TIMED sharded run differs from the unsharded run of the same job")
             parallelism = (f"walker-sharded x{world}, exact partner rule, peer-to-peer exchange over xGMI (IPC): {p2p_memory}; "
                            "progress-flag ordering")
             value_from = 'p2p warm-up + timed run'
@@ -1052,7 +1057,7 @@ def main():
                 fault("dealt_setup")
                 dex = HipDealExecutor(pdf, NWALKERS_PER_GPU, NDIM, G, nburn, 1, 2.0, SEED, rank=rank, world=world, device=local_rank)
             except Exception as e:  # noqa: BLE001
-                print(f"[rank {rank}] dealt sub-ensembles: set-up failed ({e})", file=sys.stderr)
+                note(f"[rank {rank}] dealt sub-ensembles: set-up failed ({e})")
                 okd = False
             if not all_ok(okd):
                 if dex is not None:
