@@ -260,8 +260,10 @@ kmc_status  kmc_user_density_create(const char* term_expr, const char* pair_expr
  * accumulators, `return g(s, t, ...)`) -- is recognised as
  * such (kmc_user_density_is_separable) and the emcee samplers run it in the lane-striped kernels of the menu densities, the loop
  * body as the per-element function and g as the finish: same operations per element, the sum in lane order instead of index
- * order (log-pdfs equal to rounding, like a menu density's).  Early returns, several accumulators or other indices are not
- * recognised and run one walker per lane as above.  Reference: the arbitrary closure pdf(theta), src/samplers.jl:257. */
+ * order (log-pdfs equal to rounding, like a menu density's).  Early returns, other indices, state carried between elements are
+ * not recognised and are evaluated per walker as above.  The recognition reads text, so the first sampler over the density
+ * evaluates the generated form next to the body itself on 256 test rows and keeps the route only if they agree (else: per walker,
+ * as written; kmc_user_density_is_separable then returns 0 and kmc_sampler_describe says why).  Reference: the arbitrary closure pdf(theta), src/samplers.jl:257. */
 kmc_status  kmc_user_density_create_body(const char* body, kmc_user_density** out);
 int         kmc_user_density_is_separable(const kmc_user_density* ud);
 /* ... returning a BLOB with the log-density -- the reference's `pdf(theta) -> (p, blob)` under hasblob=true

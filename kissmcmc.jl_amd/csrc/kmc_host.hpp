@@ -169,6 +169,11 @@ struct kmc_user_density {
     bool sep_pair = false;                           // the loop reads x[i + 1] / runs to n - 1: its body is the PAIR function
     int sep_nacc = 1;                                // sums the loop feeds (1: SepDensity; 2..4: SepDensityN)
     std::string sep_functor;                         // "struct UserS { term, pair, finish };" generated from the body
+    // The recogniser reads TEXT; before the first sampler runs the generated form it is evaluated next to the body itself on test
+    // points (kmc_sampler.hip: check_sum_form): 0 not yet, 1 they agree, 2 they do not (or no test point had a finite value: nothing
+    // was shown) -> `sep` is cleared and the body is evaluated per walker, as written.
+    int sep_verdict = 0;
+    std::string sep_note;                            // why not (describe())
     std::mutex mu;
     std::map<std::string, std::vector<char>> code;   // geometry key -> gfx950 code object
     // ... and the modules loaded from them, per device: shared by every sampler over this density (hipModuleLoadData is ~0.5 ms,

@@ -272,8 +272,11 @@ bool recognise_separable(kmc_user_density* ud)
         loop = t.substr(b, e - b + 1);
         after = e + 1;
     }
-    if (std::regex_search(loop, std::regex("\\b(return|break|continue|goto|for|while|do|switch)\\b"))) return false;
-    if (std::regex_search(loop, std::regex("&\\s*x\\b"))) return false;                              // the address of an element: not a value any more
+    if (t.find('#') != std::string::npos) return false;                                              // a macro can hide anything from a text matcher
+    if (std::regex_search(loop, std::regex("\\b(return|break|continue|goto|for|while|do|switch|static|thread_local|extern|volatile|register|asm|__asm__|__shared__|"
+                                           "auto|struct|class|union|enum|typedef|using|new|delete|throw|try|catch|operator|template|decltype)\\b"))) return false;
+    if (std::regex_search(loop, std::regex("(^|[^&])&([^&]|$)"))) return false;                      // an address taken (an element's, or a variable a callee may write)
+    if (std::regex_search(loop, std::regex("(^|[^\\w\\]\\)\\s])\\s*\\["))) return false;               // a lambda
     // what follows the loop: exactly one return statement
     std::smatch r;
     const std::string tail = t.substr(after);
@@ -301,6 +304,49 @@ bool recognise_separable(kmc_user_density* ud)
         if (std::regex_search(loop, std::regex("[-*/%&|^]=|<<=|>>=|\\+\\+|--"))) return false;
     }
     auto is_acc = [&](const std::string& name) { return std::find(accs.begin(), accs.end(), name) != accs.end(); };
+    auto word_before = [&](size_t& j) {                       // the identifier ending just before loop[j] (white space skipped); j moves to its start
+        while (j > 0 && std::isspace((unsigned char)loop[j - 1])) --j;
+        const size_t e = j;
+        while (j > 0 && (std::isalnum((unsigned char)loop[j - 1]) || loop[j - 1] == '_')) --j;
+        return loop.substr(j, e - j);
+    };
+    // every `ACC +=` is a statement of its own (not a value inside an expression): at the start, after ; { } or `else`, or after the `)` of an if
+    for (const std::string& acc : accs) {
+        const std::regex inc_acc("\\b" + acc + "\\s*\\+=");
+        for (auto it = std::sregex_iterator(loop.begin(), loop.end(), inc_acc); it != std::sregex_iterator(); ++it) {
+            size_t j = (size_t)it->position(0);
+            while (j > 0 && std::isspace((unsigned char)loop[j - 1])) --j;
+            if (j == 0) continue;
+            const char c = loop[j - 1];
+            if (c == ';' || c == '{' || c == '}') continue;
+            if (c == ')') {
+                int depth = 0;
+                size_t k = j;
+                while (k > 0) { --k; if (loop[k] == ')') ++depth; else if (loop[k] == '(' && --depth == 0) break; }
+                if (depth != 0) return false;
+                if (word_before(k) != "if") return false;
+                continue;
+            }
+            size_t k = j;
+            if (word_before(k) != "else") return false;
+        }
+    }
+    // every plain assignment is the initialiser of a declaration of a NEW scalar name: `double|int|... name = e` (anything else the loop
+    // assigns to -- a variable from outside, the loop index, a static -- is state carried between elements)
+    for (size_t k = 0; k < loop.size(); ++k) {
+        if (loop[k] != '=') continue;
+        if (k + 1 < loop.size() && loop[k + 1] == '=') { ++k; continue; }                              // ==
+        if (k > 0 && std::strchr("=!<>+", loop[k - 1])) continue;                                     // == != <= >= += (the compound ones are gone)
+        size_t j = k;
+        const std::string name = word_before(j);
+        if (name.empty() || std::isdigit((unsigned char)name[0])) return false;                       // a[i] = ..., *q = ..., (..) = ...
+        if (name == I || name == "x" || name == "n" || name == "p" || is_acc(name)) return false;      // ... shadowed: x[I] would mean something else
+        const std::string type = word_before(j);
+        if (type != "double" && type != "int" && type != "float" && type != "bool" && type != "long" && type != "unsigned") return false;
+    }
+    // (declarations without an initialiser cannot shadow either)
+    for (const std::string& name : {I, std::string("x"), std::string("n"), std::string("p")})
+        if (std::regex_search(loop, std::regex("\\b(double|int|float|bool|long|unsigned|short|char|const)\\s+" + name + "\\b"))) return false;
     // the proposal is read as x[I] and x[I + 1] only
     bool reads_next = false;
     {
@@ -497,6 +543,8 @@ kmc_status compile_user(kmc_user_density* ud, bool with_vec, int L, int K, int i
         << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_generic(KMC_FRONT_PARAMS, const kmc::HalfStepArgs a) { kmc::half_step_generic_body<UD, " << peer << ", " << rowt << ">(KMC_FRONT_PACK, a); }\n"
         << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_logpdf(const kmc::LogpdfArgs a) { kmc::logpdf_rows_body<UD>(a); }\n"
         << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_init_ball(const kmc::InitBallArgs a) { kmc::init_ball_body<UD>(a); }\n";
+    if (ud->is_body && with_vec && ud->sep)
+        src << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_logpdf_sep(const kmc::LogpdfArgs a) { kmc::logpdf_rows_body<UDV>(a); }\n";
     if (staged)
         src << "extern \"C\" __global__ __launch_bounds__(" << kStagedTPB << ") void kmc_user_staged(KMC_FRONT_PARAMS, const kmc::HalfStepArgs a) { kmc::half_step_staged_body<UD, "
             << ndim << ">(KMC_FRONT_PACK, a); }\n";
@@ -554,6 +602,8 @@ kmc_status load_user(kmc_user_density* ud, bool with_vec, int L, int K, int iter
     HIP_TRY(hipModuleGetFunction(&uk->logpdf, uk->mod, "kmc_user_logpdf"));
     HIP_TRY(hipModuleGetFunction(&uk->init_ball, uk->mod, "kmc_user_init_ball"));
     if (with_vec) HIP_TRY(hipModuleGetFunction(&uk->vec, uk->mod, "kmc_user_vec"));
+    uk->logpdf_sep = nullptr;
+    if (with_vec && ud->is_body && ud->sep) HIP_TRY(hipModuleGetFunction(&uk->logpdf_sep, uk->mod, "kmc_user_logpdf_sep"));
     if (!with_vec && staged_possible(ud, f32, ndim, p2p)) HIP_TRY(hipModuleGetFunction(&uk->staged, uk->mod, "kmc_user_staged"));
     if (resident_K != 0 && island_S == 0) HIP_TRY(hipModuleGetFunction(&uk->resident, uk->mod, "kmc_user_resident"));
     if (resident_K > 0 && island_S > 0) HIP_TRY(hipModuleGetFunction(&uk->island, uk->mod, "kmc_user_island"));

@@ -7,6 +7,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
+#include <random>
 #include <sstream>
 
 #include "kmc_sampler.hpp"
@@ -384,6 +386,90 @@ hipError_t dev_alloc(kmc_sampler* s, T** p, size_t bytes)
     return e;
 }
 
+namespace {
+// A body that kmc_user_density_create_body recognised as a sum over elements (kmc_rtc.hip: recognise_separable -- a TEXT matcher) is
+// run in its generated per-element form only after that form has been evaluated next to the body itself: 256 test rows of the
+// sampler's ndim (normal / half-normal / uniform entries on several scales, so that densities on the line, the half-line and the
+// unit box all see admissible points), both through the sequential log-pdf kernels of the module just loaded.  They must agree on
+// every row (both non-finite alike, or within 1e-9 relative) and at least 8 rows must carry a finite value; otherwise the density's
+// `sep` is cleared -- the body then runs as written, evaluated per walker -- and describe() says why.  Once per density.
+// KMC_DEBUG=sum-form-check=fail / =blind force the two negative outcomes (tests).
+kmc_status check_sum_form(kmc_sampler* s)
+{
+    kmc_user_density* ud = s->user;
+    constexpr int kRows = 256, kFamilies = 8;
+    const int64_t nd = s->cfg.ndim, ld = s->ld;
+    std::vector<double> rows((size_t)kRows * (size_t)ld, 0.0);
+    std::mt19937_64 gen(0x6b6d632d73756d21ull);
+    std::normal_distribution<double> normal(0.0, 1.0);
+    std::uniform_real_distribution<double> unit(0.0, 1.0);
+    for (int r = 0; r < kRows; ++r) {
+        const int fam = r % kFamilies;
+        for (int64_t d = 0; d < nd; ++d) {
+            const double z = normal(gen), u = unit(gen);
+            double v = z;
+            switch (fam) {
+                case 1: v = 0.01 * z; break;
+                case 2: v = 10.0 * z; break;
+                case 3: v = std::fabs(z); break;
+                case 4: v = 0.01 * std::fabs(z); break;
+                case 5: v = 10.0 * std::fabs(z); break;
+                case 6: v = u; break;
+                case 7: v = -std::fabs(z); break;
+                default: break;
+            }
+            rows[(size_t)r * (size_t)ld + (size_t)d] = v;
+        }
+    }
+    double *d_rows = nullptr, *d_out = nullptr;
+    std::vector<double> out(2 * kRows);
+    hipError_t e = hipMalloc((void**)&d_rows, rows.size() * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_out, out.size() * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpy(d_rows, rows.data(), rows.size() * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        const LogpdfArgs la{d_rows, d_out, (int64_t)kRows, (int32_t)nd, (int32_t)ld, s->dp, nullptr};
+        e = launch_module(s->uk.logpdf, 1u, 256u, nullptr, la);
+    }
+    if (e == hipSuccess) {
+        const LogpdfArgs lb{d_rows, d_out + kRows, (int64_t)kRows, (int32_t)nd, (int32_t)ld, s->dp, nullptr};
+        e = launch_module(s->uk.logpdf_sep, 1u, 256u, nullptr, lb);
+    }
+    if (e == hipSuccess) e = hipMemcpy(out.data(), d_out, out.size() * sizeof(double), hipMemcpyDeviceToHost);
+    if (d_rows) (void)hipFree(d_rows);
+    if (d_out) (void)hipFree(d_out);
+    HIP_TRY(e);
+    int informative = 0, differ = 0, first = -1;
+    for (int r = 0; r < kRows; ++r) {
+        const double a = out[r], b = out[kRows + r];
+        const bool fa = std::isfinite(a), fb = std::isfinite(b);
+        bool same;
+        if (!fa || !fb) same = (fa == fb) && (std::isnan(a) == std::isnan(b)) && (std::isnan(a) || (a < 0) == (b < 0));
+        else { same = std::fabs(a - b) <= 1e-9 * std::fmax(1.0, std::fmax(std::fabs(a), std::fabs(b))); ++informative; }
+        if (!same) { if (first < 0) first = r; ++differ; }
+    }
+    std::string forced;
+    if (debug_opt("sum-form-check", &forced)) {
+        if (forced == "fail") { differ = 1; first = 0; }
+        if (forced == "blind") { differ = 0; informative = 0; }
+    }
+    std::lock_guard<std::mutex> lock(ud->mu);
+    if (differ == 0 && informative >= 8) { ud->sep_verdict = 1; return KMC_OK; }
+    char why[256];
+    if (differ)
+        std::snprintf(why, sizeof(why), "its per-element form disagrees with the body on %d of %d test rows (row %d: body %.17g, per-element form %.17g)",
+                      differ, kRows, first, out[first], out[kRows + first]);
+    else
+        std::snprintf(why, sizeof(why), "only %d of %d test rows had a finite log-density: its per-element form could not be checked", informative, kRows);
+    ud->sep_verdict = 2;
+    ud->sep_note = why;
+    ud->sep = false;
+    if (differ)
+        std::fprintf(stderr, "kissmcmc_hip: a function body was recognised as a sum over elements, but %s -- it is evaluated per walker, as written "
+                             "(please report the body; KMC_DEBUG=no-body-routing skips the attempt)\n", why);
+    return KMC_OK;
+}
+}  // namespace
+
 KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** out)
 {
     if (!out) return fail(KMC_ERR_BAD_ARG, "null out");
@@ -446,10 +532,23 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
                                                        : s->user->is_body ? (cfg->nwalkers <= 256 ? 256 : cfg->nwalkers <= 512 ? 512 : 1024) : (expr_lane ? -lane_nd(cfg->ndim) : rK)) : rK;
         // a big ensemble's kernels are worth the better compiler (hipcc as a child process: ~1.2 s once per density and geometry, then
         // cached on disk): inside a PyTorch process hiprtc means the older comgr the wheel bundles (kmc_rtc.hip: offline_compiler_wanted)
-        set_offline_compiler_hint(s->h_loc >= 8192 && rK == 0 && iS == 0);
-        st = load_user(s->user, s->plan.vec, s->plan.L, s->plan.K, s->plan.ITER, s->plan.ragged, &s->uk, rcode, 4 * rK != cfg->ndim, iS, s->f32,
-                       cfg->ndim, (cfg->flags & KMC_P2P) != 0);
-        set_offline_compiler_hint(false);
+        auto load = [&]() {
+            set_offline_compiler_hint(s->h_loc >= 8192 && rK == 0 && iS == 0);
+            const kmc_status lst = load_user(s->user, s->plan.vec, s->plan.L, s->plan.K, s->plan.ITER, s->plan.ragged, &s->uk, rcode, 4 * rK != cfg->ndim, iS, s->f32,
+                                             cfg->ndim, (cfg->flags & KMC_P2P) != 0);
+            set_offline_compiler_hint(false);
+            return lst;
+        };
+        st = load();
+        // a body taken for a sum over elements: its generated form against the body itself, once, before anything runs it
+        if (st == KMC_OK && s->uk.logpdf_sep && s->user->sep_verdict != 1) {
+            st = check_sum_form(s);
+            if (st == KMC_OK && !s->user->sep) {          // not shown equal: plan and kernels for the body as written
+                s->uk = UserKernels{};
+                s->plan = make_plan(s->cfg, s->h_loc);
+                st = load();
+            }
+        }
         if (st != KMC_OK) { kmc_sampler_destroy(s); return st; }
         if (iS > 0) rK = 0;     // island mode is set up below, not resident mode
         if (rK > 0) {
@@ -895,7 +994,8 @@ KMC_EXPORT kmc_status kmc_sampler_describe(const kmc_sampler* s, char* buf, int6
     if (s->d_mring) o << "; moments through a ring of " << s->mring_depth << " posted rows per wave";
     if (s->user) o << "; runtime-compiled density";
     if (s->user && s->user->is_body && s->plan.vec && !s->resident && !s->islands)
-        o << (s->user->sep ? " (function body recognised as a sum over elements: lane-striped)" : " (function body: rows lane-striped, the body evaluated per walker on the whole proposal)");
+        o << (s->user->sep ? " (function body recognised as a sum over elements and checked against the body on test rows: lane-striped)"
+                           : " (function body: rows lane-striped, the body evaluated per walker on the whole proposal" + (s->user->sep_note.empty() ? std::string() : "; taken for a sum over elements, but " + s->user->sep_note) + ")");
     if (s->nblob > 0) o << " with a blob of " << s->nblob << " doubles per walker" << (s->d_chain_blob ? " (stored with every sample)" : "");
     if (s->p2p) o << "; P2P shard " << s->cfg.shard_rank << "/" << s->cfg.shard_count << (s->connected ? "" : " (not connected)");
     else if (s->cfg.shard_count > 1 || s->comm)

@@ -33,6 +33,7 @@ struct UserKernels {
     std::shared_ptr<void> keep;
     hipFunction_t vec = nullptr, generic = nullptr, logpdf = nullptr, resident = nullptr, island = nullptr, init_ball = nullptr;
     hipFunction_t staged = nullptr;     // body densities, double rows, ndim <= kStagedMaxDim: half_step_staged_body
+    hipFunction_t logpdf_sep = nullptr; // a body recognised as a sum over elements: the generated form, row by row (check_sum_form)
 };
 
 }  // namespace kmc_host

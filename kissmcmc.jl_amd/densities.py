@@ -274,7 +274,9 @@ class CDensity(ExprDensity):
 
     @property
     def separable(self) -> bool:
-        """Whether the library recognised the body as a sum over elements (then the samplers stripe its rows over lanes)."""
+        """Whether the library recognised the body as a sum over elements (then the samplers stripe its rows over lanes).  The first
+        sampler over the density checks the generated per-element form against the body on test rows; if they differ (or no test row
+        has a finite value) this turns False and the body is evaluated per walker, as written."""
         return bool(self._L.kmc_user_density_is_separable(self.user_handle))
 
     def __repr__(self):

@@ -165,14 +165,25 @@ def test_bodies_that_are_not_sums_over_elements_are_not_routed(kmc):
                  "double s = 0; for (int i = 0; i + 1 < n; ++i) { const double* q = &x[i]; s += q[0] * q[1]; } return -s;",
                  "double s = 0; for (int i = 0; i < n; i += 2) s += x[i]; return -s;",
                  "double s = 1.0; for (int i = 0; i < n; ++i) s += x[i]; return -s;",
-                 "const double t = x[0] + 5.0; return -(t * t) / 18.0;"):
+                 "const double t = x[0] + 5.0; return -(t * t) / 18.0;",
+                 # state carried between elements in ways a first matcher let through (round 4 review): the loop index
+                 # assigned, the increment used as a value, a shadowed index, a variable written through its address, a macro
+                 "double s = 0; for (int i = 0; i < n; ++i) { s += x[i]; i = i + 1; } return -s;",
+                 "double s = 0; for (int i = 0; i < n; ++i) { double t = (s += x[i]); s += t; } return -s;",
+                 "double s = 0; for (int i = 0; i < n; ++i) { { int i = 3; s += x[i]; } } return -s;",
+                 "double s = 0; double c = 0; for (int i = 0; i < n; ++i) { s += modf(x[i] + c, &c); } return -s;",
+                 "double s = 0; for (int i = 0; i < n; ++i) s += x[i] > 0 ? (s += 1.0) : x[i]; return -s;",
+                 "#define Z x\ndouble s = 0; for (int i = 0; i < n; ++i) s += Z[i]*Z[(i+2)%n]; return -s;",
+                 "double s = 0; for (int i = 0; i < n; ++i) s += x[i]*x[i]; return -s + x[0];",
+                 "double m = x[0]; double s = 0; for (int i = 0; i < n; ++i) s += (x[i]-m)*(x[i]-m); return -s;"):
         assert not kmc.CDensity(body, params=[0.5]).separable, body
     for body in ("double s = 0; for (int i = 0; i < n; ++i) s += x[i] * x[i]; return -0.5 * s;",
                  "double s = 0.0, t = 0.0; for (int i = 0; i < n; ++i) { s += x[i] * x[i]; t += x[i]; } return -0.5 * (s + p[0] * t * t);",   # two sums, one pass
                  "double s = 0.0; double t = 0.0; double u = 0; for (int i = 0; i + 1 < n; ++i) { double d = x[i+1]-x[i]; s += d*d; t += x[i]; u += x[i+1]*x[i]; } return -(s + 0.1*t*t + 0.01*u);",
                  "const double w = p[1] * p[1]; double s = 0; for (int i = 0; i < n; i++) { s += w * x[i] * x[i]; } return -0.5 * s / w;",
                  "double s = 0; /* sum */ for (int i = 0; i < n - 1; ++i) { // pairs\n s += (x[i+1]-x[i])*(x[i+1]-x[i]); } return -0.5*s;",
-                 "double s = 0; for (int i = 0; i < n; ++i) { if (x[i] > 0) s += x[i]; else s += -2.0 * x[i]; } return -s;"):
+                 "double s = 0; for (int i = 0; i < n; ++i) { if (x[i] > 0) s += x[i]; else s += -2.0 * x[i]; } return -s;",
+                 "double s = 0; for (int i = 0; i < n; ++i) { const double t = x[i] - p[0]; s += (i + 1) * t * t / n; } return -0.5 * s;"):
         assert kmc.CDensity(body, params=[0.5, 2.0]).separable, body
 
 

@@ -226,6 +226,42 @@ def test_bodies_feeding_several_sums_run_lane_striped(kmc, case, monkeypatch, km
     np.testing.assert_allclose(a["sum"], b["sum"], rtol=1e-11, atol=1e-9)
 
 
+@pytest.mark.parametrize("outcome", ["agree", "fail", "blind-forced", "blind"])
+def test_sum_form_is_checked_against_the_body_before_it_runs(kmc, outcome, monkeypatch, kmc_debug, capfd):
+    """The recogniser reads text.  Before a sampler runs the generated per-element form, that form and the body itself are evaluated
+    on 256 test rows (kmc_sampler.hip: check_sum_form): agreement -> lane-striped; a difference (forced here: sum-form-check=fail) or
+    no test row with a finite value (forced, and for real: a density supported on [100, 101] only) -> the density is evaluated per walker,
+    as written, describe() says why, and the run equals the run with the recogniser switched off."""
+    monkeypatch.setenv("KMC_NO_RESIDENT", "1")
+    nw, nd, G, nburn, seed = 256, 8, 60, 10, 5
+    if outcome == "blind":
+        body = ("double s = 0; for (int i = 0; i < n; ++i) { const double t = x[i] - 100.5; s += (t < -0.5 || t > 0.5) ? -INFINITY : -0.5 * t * t; } return s;")
+        th = 100.5 + 0.1 * np.random.default_rng(3).standard_normal((nw, nd))
+    else:
+        body = "double s = 0; for (int i = 0; i < n; ++i) { const double t = x[i] - p[0]; s += t * t; } return -0.5 * s;"
+        th = np.random.default_rng(3).standard_normal((nw, nd))
+    if outcome in ("fail", "blind-forced"):
+        kmc_debug.set("sum-form-check", outcome.split("-")[0])
+    pdf = kmc.CDensity(body, params=[0.3])
+    assert pdf.separable                                   # the recogniser took it ...
+    with kmc.Sampler(pdf, nw, nd, G, nburn, 1, 2.0, seed) as s:
+        how = s.describe()
+    err = capfd.readouterr().err
+    if outcome == "agree":
+        assert "recognised as a sum over elements and checked against the body" in how and pdf.separable
+        return
+    assert not pdf.separable                               # ... and the check took it back
+    assert "evaluated per walker" in how and "taken for a sum over elements, but" in how
+    assert ("disagrees with the body" in how and "please report" in err) if outcome == "fail" else ("could not be checked" in how and "please report" not in err)
+    a = _run(kmc, pdf, th, G, nburn, seed)
+    kmc_debug.set("no-body-routing")
+    plain = kmc.CDensity(body, params=[0.3])
+    b = _run(kmc, plain, th, G, nburn, seed)
+    for k in ("pos", "nacc", "chain", "logp"):
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    assert a["nacc"].sum() > 0
+
+
 def test_body_density_with_real_coupling_samples_its_target(kmc, monkeypatch):
     """A density no term / pair form can express -- a correlated Gaussian with a dense precision matrix built in the body:
     x' P x with P = (1 + rho) I - rho/n 11' ... here: -0.5 (sum x_i^2 + c (sum x_i)^2): variance of the mean direction
