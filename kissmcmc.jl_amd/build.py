@@ -8,7 +8,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(_HERE, "libkissmcmc_hip.so")
-SOURCES = ["kmc_sampler.hip", "kmc_launch.hip", "kmc_state.hip", "kmc_copy.hip", "kmc_rtc.hip", "kmc_p2p.hip", "kmc_metropolis_api.hip", "kmc_acorr.hip", "kmc_rccl.hip", "kmc_diag.hip", "kmc_inst_host.hip"] + \
+SOURCES = ["kmc_sampler.hip", "kmc_plan.hip", "kmc_launch.hip", "kmc_state.hip", "kmc_copy.hip", "kmc_rtc.hip", "kmc_p2p.hip", "kmc_metropolis_api.hip", "kmc_acorr.hip", "kmc_rccl.hip", "kmc_diag.hip", "kmc_inst_host.hip"] + \
           [f"kmc_inst_{d}{part}.hip" for part in ("", "_var", "_p2p", "_lds") for d in ("lognormal", "exponential", "gaussian_iso", "rosenbrock", "mvnormal2")]   # (longest jobs first)
 HEADERS = ["kmc_host.hpp", "kmc_sampler.hpp", "kmc_device.hpp", "kmc_kernels.hpp", "kmc_islands.hpp", "kmc_metropolis.hpp", "kmc_tables.hpp", os.path.join("..", "..", "include", "kissmcmc_hip.h")]
 # kernarg preload: the half-step kernels' leading scalar parameters arrive in SGPRs at wave launch (kmc_kernels.hpp)

@@ -177,7 +177,14 @@ inline int64_t samples_done(const kmc_sampler* s)
     return k < s->nsamples ? k : s->nsamples;
 }
 
-// kmc_sampler.hip
+// kmc_plan.hip
+Plan make_plan(const kmc_config& c, int64_t n_active);
+kmc::IslandFn island_fn(int density, int S, int K, bool ragged);
+kmc::ResidentFn resident_fn(int density, int tpb, int K, bool ragged);
+kmc::ResidentFn resident_lane_fn(int density, int ndim, bool f32);
+kmc::ResidentFn resident_lane2_fn(int density, int ndim);
+bool resident_lane_wanted(int64_t ndim);
+int lane_nd(int64_t ndim);
 void island_perm(uint64_t seed, int64_t epoch, int64_t N, int64_t* A, int64_t* C);
 uint64_t deal_seed(uint64_t seed, int32_t rank);
 void deal_perm(uint64_t seed, int64_t epoch, int32_t rank, int64_t S, int64_t* A, int64_t* C);
