@@ -124,7 +124,7 @@ def test_bench_one_gpu_under_torch_distributed_run_equals_the_plain_call():
     """The N = 1 point of a scaling series launched like the N > 1 points (python -m torch.distributed.run --nproc-per-node 1: WORLD_SIZE=1,
     OMP_NUM_THREADS=1, ...) must be the same measurement as the plain `python bench.py`: same kernel and launch mode, `value` within 3 %."""
     from portpick import rendezvous_port
-    for attempt in range(2):                                        # (a shared box: one repetition of the pair)
+    for attempt in range(3):                                        # (a shared box: up to two repetitions of the pair)
         plain = bench_single({}, [])
         port = rendezvous_port()
         under = bench_single({}, ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port)])
