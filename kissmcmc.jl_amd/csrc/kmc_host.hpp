@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -172,7 +173,8 @@ struct kmc_user_density {
     // The recogniser reads TEXT; before the first sampler runs the generated form it is evaluated next to the body itself on test
     // points (kmc_sampler.hip: check_sum_form): 0 not yet, 1 they agree, 2 they do not (or no test point had a finite value: nothing
     // was shown) -> `sep` is cleared and the body is evaluated per walker, as written.
-    int sep_verdict = 0;
+    std::atomic<int> sep_verdict{0};
+    std::mutex check_mu;                             // held by the sampler that finds out (plan, load, check): others over the same density wait
     std::string sep_note;                            // why not (describe())
     std::mutex mu;
     std::map<std::string, std::vector<char>> code;   // geometry key -> gfx950 code object

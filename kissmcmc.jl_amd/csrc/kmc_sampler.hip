@@ -185,20 +185,24 @@ kmc_status check_sum_form(kmc_sampler* s)
             rows[(size_t)r * (size_t)ld + (size_t)d] = v;
         }
     }
+    // (a stream of its own and copy_sync: nothing here may touch the legacy stream -- another thread may be capturing a graph, kmc_host.hpp)
     double *d_rows = nullptr, *d_out = nullptr;
     std::vector<double> out(2 * kRows);
-    hipError_t e = hipMalloc((void**)&d_rows, rows.size() * sizeof(double));
+    ScopedStream ss;
+    hipError_t e = ss.create();
+    if (e == hipSuccess) e = hipMalloc((void**)&d_rows, rows.size() * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&d_out, out.size() * sizeof(double));
-    if (e == hipSuccess) e = hipMemcpy(d_rows, rows.data(), rows.size() * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = copy_sync(d_rows, rows.data(), rows.size() * sizeof(double), hipMemcpyHostToDevice, ss.st);
     if (e == hipSuccess) {
         const LogpdfArgs la{d_rows, d_out, (int64_t)kRows, (int32_t)nd, (int32_t)ld, s->dp, nullptr};
-        e = launch_module(s->uk.logpdf, 1u, 256u, nullptr, la);
+        e = launch_module(s->uk.logpdf, 1u, 256u, ss.st, la);
     }
     if (e == hipSuccess) {
         const LogpdfArgs lb{d_rows, d_out + kRows, (int64_t)kRows, (int32_t)nd, (int32_t)ld, s->dp, nullptr};
-        e = launch_module(s->uk.logpdf_sep, 1u, 256u, nullptr, lb);
+        e = launch_module(s->uk.logpdf_sep, 1u, 256u, ss.st, lb);
     }
-    if (e == hipSuccess) e = hipMemcpy(out.data(), d_out, out.size() * sizeof(double), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = copy_sync(out.data(), d_out, out.size() * sizeof(double), hipMemcpyDeviceToHost, ss.st);
+    if (ss.st) (void)hipStreamSynchronize(ss.st);
     if (d_rows) (void)hipFree(d_rows);
     if (d_out) (void)hipFree(d_out);
     HIP_TRY(e);
@@ -296,6 +300,13 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
                                                        : s->user->is_body ? (cfg->nwalkers <= 256 ? 256 : cfg->nwalkers <= 512 ? 512 : 1024) : (expr_lane ? -lane_nd(cfg->ndim) : rK)) : rK;
         // a big ensemble's kernels are worth the better compiler (hipcc as a child process: ~1.2 s once per density and geometry, then
         // cached on disk): inside a PyTorch process hiprtc means the older comgr the wheel bundles (kmc_rtc.hip: offline_compiler_wanted)
+        // the first sampler over a body taken for a sum over elements finds out whether it is one (check_sum_form); samplers created
+        // meanwhile on other threads wait for the answer instead of planning on a guess
+        std::unique_lock<std::mutex> first_use;
+        if (s->user->is_body && s->user->sep && s->user->sep_verdict.load() == 0) {
+            first_use = std::unique_lock<std::mutex>(s->user->check_mu);
+            s->plan = make_plan(s->cfg, s->h_loc);
+        }
         auto load = [&]() {
             set_offline_compiler_hint(s->h_loc >= 8192 && rK == 0 && iS == 0);
             const kmc_status lst = load_user(s->user, s->plan.vec, s->plan.L, s->plan.K, s->plan.ITER, s->plan.ragged, &s->uk, rcode, 4 * rK != cfg->ndim, iS, s->f32,
@@ -305,7 +316,7 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         };
         st = load();
         // a body taken for a sum over elements: its generated form against the body itself, once, before anything runs it
-        if (st == KMC_OK && s->uk.logpdf_sep && s->user->sep_verdict != 1) {
+        if (st == KMC_OK && s->uk.logpdf_sep && s->user->sep_verdict.load() != 1) {
             st = check_sum_form(s);
             if (st == KMC_OK && !s->user->sep) {          // not shown equal: plan and kernels for the body as written
                 s->uk = UserKernels{};

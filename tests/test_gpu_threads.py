@@ -20,6 +20,8 @@ def test_concurrent_samplers_from_many_threads(kmc, oracle):
         ("expr a", shared, oracle.GAUSSIAN_ISO, [0.0, 1.0], 512, 16, 250),
         ("expr b", shared, oracle.GAUSSIAN_ISO, [0.0, 1.0], 512, 16, 250),
         ("body", body, oracle.GAUSSIAN_ISO, [0.0, 1.0], 640, 9, 200),
+        ("body b", body, oracle.GAUSSIAN_ISO, [0.0, 1.0], 640, 9, 200),      # the same recognised body, first used by three threads at once:
+        ("body c", body, oracle.GAUSSIAN_ISO, [0.0, 1.0], 512, 12, 150),     # one of them checks its per-element form, the others wait
         ("resident", kmc.Exponential(), oracle.EXPONENTIAL, [1.0], 100, 1, 1000),
     ]
     results, errors = {}, []
