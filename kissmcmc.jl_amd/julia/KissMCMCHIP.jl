@@ -24,6 +24,56 @@ using LinearAlgebra: inv
 
 const LIB = get(ENV, "KMC_LIB_PATH", joinpath(@__DIR__, "..", "libkissmcmc_hip.so"))
 
+# ---- C structs: field for field include/kissmcmc_hip.h (kmc_config, kmc_outputs).  Built by keyword, so a new field
+#      of the header needs one line here and no call site changes; `__init__` compares sizeof with the library's.
+#      (They come first: a ccall's argument types are resolved when the enclosing method is defined.) ---
+Base.@kwdef struct KmcConfig
+    dtype::Int32 = 0                                  # KMC_F64 = 0, KMC_F32 = 1
+    density::Int32 = 0
+    params::NTuple{8,Float64} = ntuple(_ -> 0.0, 8)
+    nwalkers::Int64 = 0
+    ndim::Int64 = 0
+    ngenerations::Int64 = 0
+    nburnin::Int64 = 0
+    nthin::Int64 = 1
+    a_scale::Float64 = 2.0
+    seed::UInt64 = 0
+    flags::UInt32 = 0
+    device::Int32 = 0
+    shard_rank::Int32 = 0
+    shard_count::Int32 = 1
+    user_density::Ptr{Cvoid} = C_NULL
+    island_gens::Int32 = 0                            # KMC_ISLANDS (opt-in island mode); 0 = defaults
+    island_size::Int32 = 0
+    host_logpdf::Ptr{Cvoid} = C_NULL                  # KMC_HOST_DENSITY callback ...
+    host_user::Ptr{Cvoid} = C_NULL                    # ... and its context
+    host_accepted::Ptr{Cvoid} = C_NULL                # KMC_HOST_DENSITY: accept outcomes per half-step (blobs), or NULL
+    deal_rank::Int32 = 0                              # dealt sub-ensembles (multi-GPU, opt-in); deal_count = 0: off
+    deal_count::Int32 = 0
+end
+
+Base.@kwdef mutable struct KmcOutputs
+    chain::Ptr{Float64} = C_NULL
+    chain_logp::Ptr{Float64} = C_NULL
+    accept_ratio::Ptr{Float64} = C_NULL
+    naccept::Ptr{Int64} = C_NULL
+    final_pos::Ptr{Float64} = C_NULL
+    final_logp::Ptr{Float64} = C_NULL
+    sum::Ptr{Float64} = C_NULL
+    sumsq::Ptr{Float64} = C_NULL
+    nmoment::Int64 = 0
+    nsamples::Int64 = 0
+    device_ms::Float64 = 0.0
+    blobs::Ptr{Float64} = C_NULL
+end
+
+const KMC_STORE_CHAIN = UInt32(1) << 0
+const KMC_STORE_LOGP = UInt32(1) << 1
+const KMC_CHAIN_BY_WALKER = UInt32(1) << 12     # chain delivered as [walker][sample][dim]: thetas[w][k] are contiguous
+const KMC_STORE_BLOBS = UInt32(1) << 13         # a CDensity(body; nblob=m): the blob of every stored sample (src/samplers.jl:270, :117)
+
+last_error() = unsafe_string(ccall((:kmc_last_error, LIB), Cstring, ()))
+
 # ---- menu densities: callable on the host with the same formula the kernels use ----------------
 abstract type DeviceLogPdf end
 struct GaussianIso <: DeviceLogPdf; mu::Float64; sigma::Float64; end
@@ -137,55 +187,6 @@ function accepted_trampoline(accepted::Ptr{UInt8}, nrows::Int64, row0::Int64, ge
         return Cint(1)
     end
 end
-
-# ---- C structs: field for field include/kissmcmc_hip.h (kmc_config, kmc_outputs).  Built by keyword, so a new field
-#      of the header needs one line here and no call site changes; `__init__` compares sizeof with the library's. ---
-Base.@kwdef struct KmcConfig
-    dtype::Int32 = 0                                  # KMC_F64 = 0, KMC_F32 = 1
-    density::Int32 = 0
-    params::NTuple{8,Float64} = ntuple(_ -> 0.0, 8)
-    nwalkers::Int64 = 0
-    ndim::Int64 = 0
-    ngenerations::Int64 = 0
-    nburnin::Int64 = 0
-    nthin::Int64 = 1
-    a_scale::Float64 = 2.0
-    seed::UInt64 = 0
-    flags::UInt32 = 0
-    device::Int32 = 0
-    shard_rank::Int32 = 0
-    shard_count::Int32 = 1
-    user_density::Ptr{Cvoid} = C_NULL
-    island_gens::Int32 = 0                            # KMC_ISLANDS (opt-in island mode); 0 = defaults
-    island_size::Int32 = 0
-    host_logpdf::Ptr{Cvoid} = C_NULL                  # KMC_HOST_DENSITY callback ...
-    host_user::Ptr{Cvoid} = C_NULL                    # ... and its context
-    host_accepted::Ptr{Cvoid} = C_NULL                # KMC_HOST_DENSITY: accept outcomes per half-step (blobs), or NULL
-    deal_rank::Int32 = 0                              # dealt sub-ensembles (multi-GPU, opt-in); deal_count = 0: off
-    deal_count::Int32 = 0
-end
-
-Base.@kwdef mutable struct KmcOutputs
-    chain::Ptr{Float64} = C_NULL
-    chain_logp::Ptr{Float64} = C_NULL
-    accept_ratio::Ptr{Float64} = C_NULL
-    naccept::Ptr{Int64} = C_NULL
-    final_pos::Ptr{Float64} = C_NULL
-    final_logp::Ptr{Float64} = C_NULL
-    sum::Ptr{Float64} = C_NULL
-    sumsq::Ptr{Float64} = C_NULL
-    nmoment::Int64 = 0
-    nsamples::Int64 = 0
-    device_ms::Float64 = 0.0
-    blobs::Ptr{Float64} = C_NULL
-end
-
-const KMC_STORE_CHAIN = UInt32(1) << 0
-const KMC_STORE_LOGP = UInt32(1) << 1
-const KMC_CHAIN_BY_WALKER = UInt32(1) << 12     # chain delivered as [walker][sample][dim]: thetas[w][k] are contiguous
-const KMC_STORE_BLOBS = UInt32(1) << 13         # a CDensity(body; nblob=m): the blob of every stored sample (src/samplers.jl:270, :117)
-
-last_error() = unsafe_string(ccall((:kmc_last_error, LIB), Cstring, ()))
 
 """
     emcee(pdf::DeviceLogPdf, theta0s; niter=10^5, nburnin=niter÷2, nthin=1, a_scale=2.0,
