@@ -99,6 +99,15 @@ def state_bytes(nrows: int, ndim: int, moments: int = 0) -> int:
     return nrows * ld * 8 + nrows * 16 + moments
 
 
+def kernel_sources_sha16() -> str:
+    """sha256[:16] of the two headers every half-step kernel is made of -- what a profile record was taken from."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("kmc_kernels.hpp", "kmc_device.hpp"):
+        h.update(open(os.path.join(ROOT, "kissmcmc.jl_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def profile_record(name: str, geometry):
     """profiles/traffic_<name>.json -- the tracked record of the rocprofv3 PMC passes and the -DKMC_PROBE build for ONE kernel geometry
     (scripts/profile_r04.sh + scripts/summarize_r04.py write it).  It is only used when the run it is attached to executed that
@@ -110,6 +119,7 @@ def profile_record(name: str, geometry):
         rec = json.load(open(path))
     except Exception as e:  # noqa: BLE001
         return None, f"profiles/traffic_{name}.json is unreadable ({e})"
+    rec["kernel_sources_unchanged"] = rec.get("kernel_sources_sha16") == kernel_sources_sha16()     # (reported, not a reason to refuse)
     if rec.get("geometry") != geometry:
         return None, (f"profiles/traffic_{name}.json was taken from '{rec.get('geometry')}', this run executed '{geometry}': refused")
     return rec, None
@@ -142,7 +152,7 @@ def roofline_block(pdf, describe: str, nwalkers_launch: int, ndim: int, launch_u
             "algorithmic_read_bytes_per_launch": alg_read, "algorithmic_total_bytes_per_launch": nwalkers_launch * b_total,
             "state_bytes": state_b, "served_from": served, "limited_by": limited,
             "body_us": body_us, "boundary_us": boundary_us, "body_frac": body_frac,
-            "profile_record": ({k: rec.get(k) for k in ("head", "period_us_unprofiled", "hbm_read_bytes_per_launch", "hbm_write_bytes_per_launch", "l2_hit_rate", "source")}
+            "profile_record": ({k: rec.get(k) for k in ("head", "kernel_sources_unchanged", "period_us_unprofiled", "hbm_read_bytes_per_launch", "hbm_write_bytes_per_launch", "l2_hit_rate", "source")}
                                if rec else {"refused": why}),
             "traffic_source": f"profiles/traffic_{record_name}.json: rocprofv3 --pmc passes (2 x FETCH_SIZE + WRITE_SIZE per launch, gfx950 read correction) and the "
                               "-DKMC_PROBE in-kernel timeline (body_us = first wave in .. last store issued, boundary_us = the gap to the next launch's first wave) "

@@ -2,7 +2,7 @@
 profiles/<tag>_<cfg>_summary.json (+ kernel-stats CSVs) and the tracked per-geometry records profiles/traffic_<name>.json that
 bench.py attaches to a run ONLY when that run executed the same kernel geometry:
 
-    {kernel, geometry, workload, head, hbm_bytes_per_launch, hbm_read_bytes_per_launch, hbm_write_bytes_per_launch, l2_hit_rate,
+    {kernel, geometry, workload, head, kernel_sources_sha16, hbm_bytes_per_launch, hbm_read_bytes_per_launch, hbm_write_bytes_per_launch, l2_hit_rate,
      body_us, boundary_us, period_us_unprofiled, rocprof_avg_duration_us, source}
 
 body_us / boundary_us: the -DKMC_PROBE build's in-kernel s_memrealtime stamps (first wave in .. last store issued; gap to the next
@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "scripts"))
 import summarize_r02 as base          # trace_stats, counters, bench_line, runcfg_us, one
-from bench import kernel_geometry     # the same matcher bench.py applies
+from bench import kernel_geometry, kernel_sources_sha16     # the same matcher / source hash bench.py applies
 
 SRC = os.path.join(ROOT, "gpurun_out", "prof_r04")
 DST = os.path.join(ROOT, "profiles")
@@ -134,7 +134,7 @@ def main():
                                 "pmc_read_GBs_over_period": (out.get("hbm_read_bytes_per_launch_corrected", 0) / live / 1e3) or None,
                                 "pmc_total_GBs_over_period": (out.get("hbm_bytes_per_launch", 0) / live / 1e3) or None}
         json.dump(out, open(os.path.join(DST, f"{tag}_{cfg}_summary.json"), "w"), indent=1)
-        rec = {"kernel": out["kernel_name"], "geometry": out["geometry"], "workload": workload, "head": hd,
+        rec = {"kernel": out["kernel_name"], "geometry": out["geometry"], "workload": workload, "head": hd, "kernel_sources_sha16": kernel_sources_sha16(),
                "hbm_bytes_per_launch": out.get("hbm_bytes_per_launch"), "hbm_read_bytes_per_launch": out.get("hbm_read_bytes_per_launch_corrected"),
                "hbm_write_bytes_per_launch": out.get("hbm_write_bytes_per_launch"), "l2_hit_rate": out.get("l2_hit_rate"),
                "body_us": body, "boundary_us": boundary, "body_boundary_source": src, "period_us_unprofiled": live,

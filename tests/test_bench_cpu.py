@@ -37,6 +37,12 @@ def test_tracked_record_is_used_only_for_its_own_geometry():
     assert abs(r["achieved"] - 32768 * 520 / 3.78e-6 / 1e9) < 1e-6 and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-12
     assert abs(r["body_frac"] - 32768 * 520 / (rec["body_us"] * 1e-6) / 1e9 / 8000.0) < 1e-12
     assert r["served_from"] == "infinity_cache" and "boundary" in r["limited_by"] and r["bound"] == "hbm"
+    # ... and every tracked record was taken from the kernel sources of THIS tree (edit kmc_kernels.hpp / kmc_device.hpp -> profile again:
+    # scripts/profile_r04.sh + scripts/summarize_r04.py)
+    assert r["profile_record"]["kernel_sources_unchanged"] is True
+    import glob
+    for path in glob.glob(os.path.join(ROOT, "profiles", "traffic_*.json")):
+        assert json.load(open(path)).get("kernel_sources_sha16") == bench.kernel_sources_sha16(), path
     # another geometry of the same workload (say, a forced plan): the record is refused, nothing of it leaks into the line
     other = C2.replace("ITER=2", "ITER=4").replace("grid 1024", "grid 512")
     r2 = bench.roofline_block(GaussianIso(), other, 32768, 32, launch_us, 40000, bench.state_bytes(65536, 32, 0), "c2")
