@@ -213,23 +213,35 @@ def test_random_runtime_compiled_density_equals_the_oracle(kmc, oracle, monkeypa
     generic one-walker-per-lane kernels (`no-body-vec`) -- random shapes and launch modes: identical counters and positions,
     log-pdfs to 1e-12."""
     rng = np.random.default_rng(BASE + 88000 + trial)
-    form = str(rng.choice(["expr", "body", "body-general", "body-lane"]))
+    form = str(rng.choice(["expr", "body", "body-general", "body-lane", "body-two-sums"]))
     if form in ("body-general", "body-lane"):
         kmc_debug.set("no-body-routing")
     if form == "body-lane":
         kmc_debug.set("no-body-vec")
+    two_sums = form == "body-two-sums"          # a second accumulator that does not change the value: SepDensityN against the oracle's density
     form_label, form = form, ("expr" if form == "expr" else "body")
     name = str(rng.choice(["gauss", "rosen"]))
     nd = int(rng.choice([2, 3, 8, 17, 32, 64, 65, 130]) if name == "rosen" else rng.choice([1, 2, 5, 8, 16, 31, 32, 33, 64, 100]))
     nw = int(rng.choice([nd + 2 + nd % 2, 64, 130, 256, 1000, 2050]))
     nw = max(nw, nd + 2 + nd % 2); nw += nw % 2
     G = int(rng.integers(3, 100)); nburn = int(rng.integers(0, G)); nthin = int(rng.choice([1, 2, 3])); seed = int(rng.integers(1, 2 ** 40))
-    launch = str(rng.choice(["", "graph", "eager"]))
+    launch = str(rng.choice(["", "graph", "eager", "updated"]))
     if launch:
         monkeypatch.setenv("KMC_LAUNCH", launch)
     if rng.random() < 0.5:
         monkeypatch.setenv("KMC_NO_RESIDENT", "1")
-    if name == "gauss":
+    if two_sums and name == "gauss":
+        did, params = oracle.GAUSSIAN_ISO, [0.3, 1.5]
+        pdf = kmc.CDensity("double s = 0.0, u = 0.0; for (int i = 0; i < n; ++i) { double t = (x[i] - p[0]) * p[1]; s += t * t; u += x[i]; } return -0.5 * s + 0.0 * u;", params=[0.3, 1.0 / 1.5])
+        assert pdf.separable
+        th = 0.3 + rng.standard_normal((nw, nd))
+    elif two_sums:
+        did, params = oracle.ROSENBROCK, [1.0, 100.0, 20.0]
+        pdf = kmc.CDensity("double s = 0.0; double u = 0.0; for (int i = 0; i + 1 < n; ++i) { double d = x[i + 1] - x[i] * x[i]; double e = p[0] - x[i]; s += p[1] * (d * d) + e * e; u += x[i + 1]; } "
+                           "return -(s * (1.0 / p[2])) + 0.0 * u;", params=params)
+        assert pdf.separable
+        th = 0.1 * rng.standard_normal((nw, nd))
+    elif name == "gauss":
         did, params = oracle.GAUSSIAN_ISO, [0.3, 1.5]
         pdf = (kmc.ExprDensity("-0.5*((x-p[0])*p[1])*((x-p[0])*p[1])", params=[0.3, 1.0 / 1.5]) if form == "expr" else
                kmc.CDensity("double s = 0.0; for (int i = 0; i < n; ++i) { double t = (x[i] - p[0]) * p[1]; s += t * t; } return -0.5 * s;", params=[0.3, 1.0 / 1.5]))
@@ -264,7 +276,7 @@ def test_random_blob_density_equals_the_oracle_and_its_own_chain(kmc, oracle, mo
     nw = int(rng.choice([nd + 2 + nd % 2, 64, 130, 256, 1000, 2050]))
     nw = max(nw, nd + 2 + nd % 2); nw += nw % 2
     G = int(rng.integers(3, 100)); nburn = int(rng.integers(0, G)); nthin = int(rng.choice([1, 2, 3])); seed = int(rng.integers(1, 2 ** 40))
-    launch = str(rng.choice(["", "graph", "eager"]))
+    launch = str(rng.choice(["", "graph", "eager", "updated"]))
     if launch:
         monkeypatch.setenv("KMC_LAUNCH", launch)
     # blob[i] = x[i mod n] * (i + 1) for i < nb - 1 (exact in double), blob[nb - 1] = the log-density
