@@ -241,7 +241,7 @@ bool has_word(const std::string& t, const std::string& w)
 bool recognise_separable(kmc_user_density* ud)
 {
     if (!ud->is_body || ud->nblob > 0 || debug_opt("no-body-routing")) return false;
-    if (ud->body.size() > 16384) return false;           // (generated code: std::regex recurses per matched character, and nobody writes a sum that long by hand)
+    if (ud->body.size() > 4096) return false;            // (generated code: std::regex recurses per matched character -- stack -- and nobody writes a sum that long by hand)
     const std::string t = strip_comments(ud->body);
     // one loop, of the canonical header
     static const std::regex head("for\\s*\\(\\s*int\\s+(\\w+)\\s*=\\s*0\\s*;([^;]*);([^)]*)\\)");
