@@ -207,7 +207,7 @@ kmc_status metropolis_host_route(const kmc_metropolis_config* c, const double* t
     }
     const unsigned grid = (unsigned)((nc + 255) / 256);
     auto device_logpdf = [&](const double* rows_dev, double* out_dev) -> hipError_t {
-        const LogpdfArgs la{rows_dev, out_dev, nc, (int32_t)nd, (int32_t)nd, dp};
+        const LogpdfArgs la{rows_dev, out_dev, nc, (int32_t)nd, (int32_t)nd, dp, nullptr};
         if (ulp) return launch_module(ulp, grid, 256u, st, la);
         hipLaunchKernelGGL(lp, dim3(grid), dim3(256), 0, st, la);
         return hipGetLastError();
@@ -411,9 +411,9 @@ KMC_EXPORT kmc_status kmc_metropolis_run(const kmc_metropolis_config* c, const d
     // 4096, x2 at 16 384, x0.5 at 65 536 -- there the chains fill the chip themselves).  KMC_DEBUG=metro-table=0|1 forces it off / on.
     bool tabled = false;
     {
-        std::string e;
-        const bool have = debug_opt("metro-table", &e);
-        const bool off = have && e == "0", on = have && e == "1";
+        std::string opt;
+        const bool have = debug_opt("metro-table", &opt);
+        const bool off = have && opt == "0", on = have && opt == "1";
         // (up to 8 dimensions for up to 16 384 chains -- measured --; longer rows for the few chains that leave most of the chip idle)
         const int64_t nd_max = c->density == KMC_USER_DENSITY ? 32 : 8;       // (menu densities: instantiated up to 8 -- build time)
         tabled = !off && nblob == 0 && ((nd <= 8 && nc <= 16384) || (nd <= nd_max && nc <= 1024) || (on && nd <= nd_max));

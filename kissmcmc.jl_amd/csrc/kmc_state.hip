@@ -231,9 +231,9 @@ KMC_EXPORT kmc_status kmc_sampler_set_positions(kmc_sampler* s, const double* th
         HIP_TRY(fill_sync(s->d_err, 0, 64, s->stream));
         if (s->d_done) HIP_TRY(fill_sync(s->d_done, 0, 33 * 64, s->stream));
         if (s->lazy) {                               // every shadow is current, nothing has been accepted yet
-            const size_t P = (size_t)s->cfg.shard_count, hl = (size_t)s->h_loc;
-            HIP_TRY(fill_sync(s->d_lazy, 0, 2 * P * 2 * hl * sizeof(uint32_t) + 16, s->stream));
-            HIP_TRY(fill_sync(s->peer_amap_in[s->cfg.shard_rank], 0, P * 4 * hl, s->stream));
+            const size_t nshards = (size_t)s->cfg.shard_count;
+            HIP_TRY(fill_sync(s->d_lazy, 0, 2 * nshards * 2 * hl * sizeof(uint32_t) + 16, s->stream));
+            HIP_TRY(fill_sync(s->peer_amap_in[s->cfg.shard_rank], 0, nshards * 4 * hl, s->stream));
         }
     }
     if (s->host_eval) {                                          // :209-210, on the caller's thread
@@ -547,7 +547,7 @@ KMC_EXPORT kmc_status kmc_logpdf_eval(const kmc_config* cfg, const double* pos_d
     DensityParams dp;
     KMC_TRY(digest_params(*cfg, &dp));
     if (nrows == 0) return KMC_OK;
-    const LogpdfArgs la{pos_dev, logp_dev, nrows, (int32_t)cfg->ndim, (int32_t)cfg->ndim, dp};
+    const LogpdfArgs la{pos_dev, logp_dev, nrows, (int32_t)cfg->ndim, (int32_t)cfg->ndim, dp, nullptr};
     const unsigned grid = (unsigned)((nrows + 255) / 256);
     if (cfg->density == KMC_USER_DENSITY) {
         UserKernels uk;
