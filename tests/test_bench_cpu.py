@@ -72,3 +72,17 @@ def test_test_switches_of_the_bench_live_in_one_variable(monkeypatch):
     assert bench.bench_test_opt("backend") == "gloo" and bench.bench_test_opt("walkers") == "4096"
     assert bench.bench_test_opt("force-sharded") is True and bench.bench_test_opt("fault") == "p2p_run:1"
     assert bench.bench_test_opt("deal-epoch", 64) == 64 and bench.bench_test_opt("no-hbm-shapes") is None
+
+
+def test_every_fraction_of_the_committed_bench_line_follows_from_profiles():
+    """scripts/recompute_roofline.py: the fractions of the newest committed bench line (headline and every other_configs entry with a
+    roofline) recomputed from the algorithmic bytes, the line's own HIP-event period and the tracked records under profiles/ --
+    all within 3 %."""
+    import glob
+    import subprocess
+    import sys
+    newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "bench_r04*.json")))[-1]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "recompute_roofline.py"), newest], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "largest deviation" in r.stdout and "DIFFERS" not in r.stdout
+
