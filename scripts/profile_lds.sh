@@ -1,0 +1,34 @@
+#!/bin/bash
+# LDS counters of the kernels that use LDS (GPU box): bash scripts/profile_lds.sh
+#   body    a general function body at C2: the wave's proposals go through a per-wave LDS tile, each walker's lane reads its row back
+#   c1      the resident kernel (README size: the whole ensemble lives in one workgroup's LDS for the run)
+# one counter group per pass, --kernel-trace only (as the pool requires); the program itself follows "--".
+cd /tmp && export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$R/gpurun_out/prof_lds
+rm -rf $OUT && mkdir -p $OUT
+python3 $R/scripts/run_body.py coupled 256 > $OUT/body_unprofiled.txt 2>&1
+rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES SQ_INSTS_VALU --kernel-trace --output-format csv -d $OUT/body -o t -- python3 $R/scripts/run_body.py coupled 256 > $OUT/body.txt 2>&1
+echo "body pass done"
+rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES SQ_INSTS_VALU --kernel-trace --output-format csv -d $OUT/c1 -o t -- python3 $R/scripts/run_cfg.py C1 20000 1 > $OUT/c1.txt 2>&1
+echo "c1 pass done"
+python3 - <<PY
+import csv, glob, collections, statistics
+for sub, pat in (("body", "kmc_user_vec"), ("c1", "resident")):
+    f = glob.glob("$OUT/%s/**/*counter_collection.csv" % sub, recursive=True)
+    if not f:
+        print("no counters in", sub); continue
+    d = collections.defaultdict(list); names = set()
+    for r in csv.DictReader(open(f[0])):
+        if pat in r["Kernel_Name"]:
+            d[r["Counter_Name"]].append(float(r["Counter_Value"])); names.add(r["Kernel_Name"][:90])
+    print(sub, "kernel:", "; ".join(sorted(names)))
+    m = {k: statistics.mean(v[len(v) // 2:]) for k, v in d.items()}
+    for k, v in sorted(m.items()):
+        print(f"  {k:24s} mean per launch {v:16.1f}  (n={len(d[k])})")
+    if m.get("SQ_LDS_IDX_ACTIVE"):
+        print(f"  bank-conflict cycles / LDS active cycles = {m.get('SQ_LDS_BANK_CONFLICT', 0) / m['SQ_LDS_IDX_ACTIVE']:.3f}")
+    if m.get("SQ_WAVE_CYCLES"):
+        print(f"  LDS instruction-active cycles / wave cycles = {m.get('SQ_ACTIVE_INST_LDS', 0) / m['SQ_WAVE_CYCLES']:.3f}")
+PY
+for f in $OUT/body_unprofiled.txt $OUT/body.txt $OUT/c1.txt; do tail -n 2 $f; done
