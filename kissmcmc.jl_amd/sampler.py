@@ -296,8 +296,8 @@ class Sampler:
 
     def describe(self) -> str:
         """How this sampler executes: kernel family, geometry, exchange scheme."""
-        buf = C.create_string_buffer(512)
-        _lib.check(self._L.kmc_sampler_describe(self._h, buf, 512))
+        buf = C.create_string_buffer(2048)
+        _lib.check(self._L.kmc_sampler_describe(self._h, buf, 2048))
         return buf.value.decode()
 
     def __repr__(self):
