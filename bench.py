@@ -529,6 +529,41 @@ def other_configs(kmc, device: int):
                              "accept_ratio_mean": float(s.accept_ratio().mean()), "nmoment": int(n), "execution": how, "roofline": roof}
         except Exception as e:  # noqa: BLE001
             out[name] = {"error": str(e)}
+    # Mid-size ensembles with short rows (where the reference's users live: 10^2-10^4 walkers of a few parameters): one launch per
+    # generation (kmc_generation.hpp), and the same job on the two-launch kernels (KMC_DEBUG=fused=0) beside it.
+    for name, nw, nd, G in (("MID_4096x4", 4096, 4, 20000), ("MID_16384x4", 16384, 4, 20000)):
+        try:
+            th = np.random.default_rng(SEED).standard_normal((nw, nd))
+            rec = {"workload": f"{nw} walkers x {nd}-dim isotropic Gaussian, {G} generations (burn-in {G // 2}), moments on"}
+            for label, dbg in (("", None), ("two_launches_", "fused=0")):
+                old = os.environ.get("KMC_DEBUG")
+                if dbg:
+                    os.environ["KMC_DEBUG"] = (old + "," if old else "") + dbg
+                try:
+                    with kmc.Sampler(kmc.GaussianIso(), nw, nd, G, G // 2, 1, 2.0, SEED, device=device, moments=True) as s:
+                        s.set_positions(th)
+                        s.run(256)
+                        s.sync()
+                        s.set_positions(th)
+                        s.run(G)
+                        s.sync()
+                        ms = s.last_run_ms()
+                        rec[label + "value"] = nw * G / (ms * 1e-3)
+                        rec[label + "us_per_half_step"] = ms * 1e3 / (2 * G)
+                        rec[label + "kernel_launches"] = s.launch_count
+                        rec[label + "execution"] = s.describe()
+                        if not dbg:
+                            rec["unit"] = "walker-steps/s"
+                            rec["accept_ratio_mean"] = float(s.accept_ratio().mean())
+                finally:
+                    if dbg:
+                        if old is None:
+                            os.environ.pop("KMC_DEBUG", None)
+                        else:
+                            os.environ["KMC_DEBUG"] = old
+            out[name] = rec
+        except Exception as e:  # noqa: BLE001
+            out[name] = {"error": str(e)}
     # "report also one run with nthin such that the chain fits (e.g. 50 stored samples/walker)" -- the C2 job with its
     # chain and log-pdfs stored (nthin = 100), then read out in the reference's order thetas[w][k] (device transposition + D2H)
     try:

@@ -8,6 +8,7 @@ IslandFn island_gaussian_iso(int S, int K, bool ragged) { return island_lookup<G
 ResidentFn resident_gaussian_iso(int tpb, int K, bool ragged) { return resident_lookup<GaussianIso>(tpb, K, ragged); }
 ResidentFn resident_lane_gaussian_iso(int ndim, bool f32) { return resident_lane_lookup<GaussianIso>(ndim, f32); }
 ResidentFn resident_lane2_gaussian_iso(int ndim) { return resident_lane2_lookup<GaussianIso>(ndim); }
+GenerationFn generation_lane_gaussian_iso(int ndim) { return generation_lane_lookup<GaussianIso>(ndim); }
 MetropolisFn metropolis_gaussian_iso(int ndim) { return metropolis_lookup<GaussianIso>(ndim); }
 MetropolisTabledFn metropolis_tabled_gaussian_iso(int ndim) { return metropolis_tabled_lookup<GaussianIso>(ndim); }
 }  // namespace kmc

@@ -220,6 +220,48 @@ kmc_status sync_device_counter(kmc_sampler* s)
     return KMC_OK;
 }
 
+// ---- one launch per generation (kmc_generation.hpp) ---------------------------------------------------------
+// `from`: which copy of the state the generation reads (0: d_pos / d_logp, 1: d_pos2 / d_logp2); it writes the other.
+GenerationArgs make_generation_args(const kmc_sampler* s, int from, bool graph_mode, int64_t gen_offset)
+{
+    GenerationArgs a{};
+    double* const pos[2] = {s->d_pos, s->d_pos2};
+    double* const lp[2] = {s->d_logp, s->d_logp2};
+    a.pin = pos[from]; a.pout = pos[1 - from];
+    a.lin = lp[from]; a.lout = lp[1 - from];
+    a.naccept = s->d_naccept;
+    a.sched = graph_mode ? s->d_sched + gen_offset : nullptr;
+    a.sched_inline = make_sched(gen_offset, s->cfg.nburnin, s->cfg.nthin, s->nsamples, s->ring_slots);
+    a.dc = make_args(s, 0, false, 0).dc;
+    a.dp = s->dp;
+    a.h = (uint32_t)s->h;
+    a.nb = (uint32_t)((s->h + kGenerationTPB - 1) / kGenerationTPB);
+    a.ld = (int32_t)s->ld;
+    a.chain = s->d_chain;
+    a.chain_logp = s->d_chain_logp;
+    a.msum = s->d_isum;
+    a.msumsq = s->d_isumsq;
+    return a;
+}
+
+hipError_t launch_generation(const kmc_sampler* s, int from, bool graph_mode, int64_t gen_offset)
+{
+    const GenerationArgs a = make_generation_args(s, from, graph_mode, gen_offset);
+    if (s->user) return launch_module(s->uk.generation, 2u * a.nb, (unsigned)kGenerationTPB, s->stream, a);
+    hipLaunchKernelGGL(s->generation_kernel, dim3(2u * a.nb), dim3(kGenerationTPB), 0, s->stream, a);
+    return hipGetLastError();
+}
+
+// the state back into the sampler's canonical arrays (after an odd number of generations)
+hipError_t generation_settle(kmc_sampler* s)
+{
+    if (s->fused_cur == 0) return hipSuccess;
+    hipError_t e = hipMemcpyAsync(s->d_pos, s->d_pos2, (size_t)s->nrows * (size_t)s->ld * sizeof(double), hipMemcpyDeviceToDevice, s->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(s->d_logp, s->d_logp2, (size_t)s->nrows * sizeof(double), hipMemcpyDeviceToDevice, s->stream);
+    if (e == hipSuccess) s->fused_cur = 0;
+    return e;
+}
+
 kmc_status ensure_graph(kmc_sampler* s)
 {
     if (s->graph_exec) return KMC_OK;
@@ -227,8 +269,11 @@ kmc_status ensure_graph(kmc_sampler* s)
     HIP_TRY(hipStreamBeginCapture(s->stream, hipStreamCaptureModeRelaxed));
     kmc_status st = KMC_OK;
     launch_advance(s, (int)kGraphChunk, 0);                 // schedule table of this chunk
-    for (int64_t g = 0; g < kGraphChunk && st == KMC_OK; ++g)
+    static_assert(kGraphChunk % 2 == 0, "a chunk of fused generations ends in the copy of the state it started from");
+    for (int64_t g = 0; g < kGraphChunk && st == KMC_OK; ++g) {
+        if (s->fused) { if (launch_generation(s, (int)(g & 1), true, g) != hipSuccess) st = KMC_ERR_HIP; continue; }
         for (int half = 0; half < 2 && st == KMC_OK; ++half) st = launch_half(s, half, true, g);
+    }
     if (st == KMC_OK) launch_advance(s, 0, kGraphChunk);   // device counter += chunk
     hipGraph_t graph = nullptr;
     hipError_t e = hipStreamEndCapture(s->stream, &graph);
@@ -279,7 +324,7 @@ hipKernelNodeParams node_params(const kmc_sampler* s, KernelParamPack* pk)
 
 bool updated_graph_possible(const kmc_sampler* s)
 {
-    if (s->p2p || s->host_eval || s->islands || s->resident || s->comm || s->updated_refused) return false;
+    if (s->p2p || s->host_eval || s->islands || s->resident || s->fused || s->comm || s->updated_refused) return false;
     return s->user ? (s->plan.vec && s->uk.vec != nullptr) : s->plan.fn != nullptr;
 }
 
@@ -375,7 +420,7 @@ kmc_status launch_updated_graph(kmc_sampler* s, bool* launched)
 // it every klast equals the number of samples taken).  Before a read-out, and before walkers change slots (deal).
 kmc_status flush_moments_now(kmc_sampler* s)
 {
-    if (!s->d_msum || s->islands || s->resident) return KMC_OK;
+    if (!s->d_msum || s->islands || s->resident || s->fused) return KMC_OK;
     HIP_TRY(launch_sweep(s));                                   // posted ring entries first, in their order
     if (s->plan.vec) {
         FlushFn fl = flush_lookup(s->plan.L, s->plan.K, s->plan.ITER, s->f32);
@@ -454,6 +499,35 @@ KMC_EXPORT kmc_status kmc_sampler_run(kmc_sampler* s, int64_t ngen)
             ngen -= n;
             KMC_TRY(chain_after(s));
         }
+        HIP_TRY(hipEventRecord(s->ev1, s->stream));
+        s->have_run_events = true;
+        return KMC_OK;
+    }
+    if (s->fused) {
+        // one launch per generation: whole chunks from the table graph (an even number of generations: the state ends where it
+        // started, in d_pos / d_logp), the rest launch by launch; the state is moved back into d_pos / d_logp at the end
+        const bool use_graph = !(s->cfg.flags & KMC_NO_GRAPH);
+        while (use_graph && ngen >= kGraphChunk) {
+            HIP_TRY(generation_settle(s));
+            KMC_TRY(ensure_graph(s));
+            KMC_TRY(sync_device_counter(s));
+            KMC_TRY(chain_before(s, s->generation + kGraphChunk));
+            HIP_TRY(hipGraphLaunch(s->graph_exec, s->stream));
+            s->generation += kGraphChunk;
+            s->dev_gen += kGraphChunk;
+            s->launches += kGraphChunk;
+            ngen -= kGraphChunk;
+            KMC_TRY(chain_after(s));
+        }
+        for (; ngen > 0; --ngen) {
+            KMC_TRY(chain_before(s, s->generation + 1));
+            HIP_TRY(launch_generation(s, s->fused_cur, false, s->generation));
+            s->fused_cur ^= 1;
+            s->generation += 1;
+            s->launches += 1;
+            KMC_TRY(chain_after(s));
+        }
+        HIP_TRY(generation_settle(s));
         HIP_TRY(hipEventRecord(s->ev1, s->stream));
         s->have_run_events = true;
         return KMC_OK;
@@ -699,6 +773,7 @@ KMC_EXPORT kmc_status kmc_sampler_half_step(kmc_sampler* s, int half)
     if (s->islands) return fail(KMC_ERR_UNSUPPORTED, "island mode advances whole generations: use kmc_sampler_run");
     if (s->host_eval) return fail(KMC_ERR_UNSUPPORTED, "KMC_HOST_DENSITY: a half-step includes the host callback; use kmc_sampler_run");
     if (s->resident) return fail(KMC_ERR_UNSUPPORTED, "this small ensemble runs in resident mode (whole generations per launch); create it with KMC_NO_GRAPH to step by halves");
+    if (s->fused) return fail(KMC_ERR_UNSUPPORTED, "this ensemble runs one launch per generation (kmc_generation.hpp); create it with KMC_NO_GRAPH to step by halves");
     if (s->generation >= ((int64_t)1 << 31) - 1) return fail(KMC_ERR_UNSUPPORTED, "at most 2^31 - 1 generations (the step index is 32 bits)");
     HIP_TRY(hipSetDevice(s->cfg.device));
     if (half == 0) KMC_TRY(chain_before(s, s->generation + 1));
@@ -742,6 +817,7 @@ KMC_EXPORT int kmc_sampler_launch_mode(const kmc_sampler* s, int* budget_fallbac
     if (!s) return -1;
     if (budget_fallback) *budget_fallback = s->budget_fallback ? 1 : 0;
     if (s->resident || s->islands || s->host_eval) return KMC_LAUNCH_SINGLE;
+    if (s->fused) return KMC_LAUNCH_TABLE_GRAPH;
     if ((s->cfg.flags & KMC_NO_GRAPH) || (s->comm && !s->comm_graph_ok)) return KMC_LAUNCH_EAGER;
     return s->launch_mode;
 }

@@ -72,6 +72,18 @@ ResidentFn resident_lane2_fn(int density, int ndim)
     }
 }
 
+GenerationFn generation_fn(int density, int ndim)
+{
+    switch (density) {
+    case KMC_GAUSSIAN_ISO: return generation_lane_gaussian_iso(ndim);
+    case KMC_EXPONENTIAL: return generation_lane_exponential(ndim);
+    case KMC_ROSENBROCK: return generation_lane_rosenbrock(ndim);
+    case KMC_LOGNORMAL: return generation_lane_lognormal(ndim);
+    case KMC_MVNORMAL2: return generation_lane_mvnormal2(ndim);
+    default: return nullptr;
+    }
+}
+
 // resident mode with one walker per thread (short rows) or two lanes per walker: KMC_DEBUG=resident=pair decides for tests
 bool resident_lane_wanted(int64_t ndim)
 {

@@ -513,7 +513,7 @@ std::string kmc_host::user_header_dir()
 namespace kmc_host {
 kmc_status compile_user(kmc_user_density* ud, bool with_vec, int L, int K, int iter, bool ragged,
                         int resident_K, bool resident_ragged, int island_S, bool f32, const std::vector<char>** out, int64_t ndim = 0,
-                        bool p2p = false)
+                        bool p2p = false, int generation_nd = 0)
 {
     // resident_K also sizes the island kernel (same row striping: 2 lanes per walker, K chunks)
     // a body in the vector kernels: lane-striped when it is a recognised sum over elements (sep), else rows lane-striped and the body
@@ -521,9 +521,10 @@ kmc_status compile_user(kmc_user_density* ud, bool with_vec, int L, int K, int i
     if (ud->is_body && ((with_vec && !ud->sep && !body_vec_possible(ud, ndim)) || island_S > 0))
         return fail(KMC_ERR_UNSUPPORTED, "this body density runs in the one-walker-per-lane kernels only");
     const bool staged = !with_vec && staged_possible(ud, f32, ndim, p2p);
-    char key[112];
-    std::snprintf(key, sizeof(key), "%d:%d,%d,%d,%d|%d,%d|%d|%d|%lld|%d|%d|%d|%d", (int)with_vec, L, K, iter, (int)ragged, resident_K,
-                  (int)resident_ragged, island_S, (int)f32, ud->is_body ? (long long)ndim : 0ll, (int)staged, (int)p2p, ud->nblob, (int)ud->sep + 2 * (int)offline_compiler_wanted());
+    char key[128];
+    std::snprintf(key, sizeof(key), "%d:%d,%d,%d,%d|%d,%d|%d|%d|%lld|%d|%d|%d|%d|%d", (int)with_vec, L, K, iter, (int)ragged, resident_K,
+                  (int)resident_ragged, island_S, (int)f32, ud->is_body ? (long long)ndim : 0ll, (int)staged, (int)p2p, ud->nblob, (int)ud->sep + 2 * (int)offline_compiler_wanted(),
+                  generation_nd);
     const char* peer = p2p ? "true" : "false";         // KMC_P2P: partner rows read from their owners (pull)
     const char* rowt = f32 ? "float" : "double";       // storage type of the walker rows (KMC_F32 / KMC_F64)
     std::lock_guard<std::mutex> lock(ud->mu);
@@ -533,12 +534,12 @@ kmc_status compile_user(kmc_user_density* ud, bool with_vec, int L, int K, int i
     const char* envdir = std::getenv("KMC_CSRC_DIR");
     const std::string dir = envdir ? std::string(envdir) : library_dir() + "/csrc";
     const std::string h_dev = read_file(dir + "/kmc_device.hpp"), h_ker = read_file(dir + "/kmc_kernels.hpp"),
-                      h_isl = read_file(dir + "/kmc_islands.hpp");
-    if (h_dev.empty() || h_ker.empty() || h_isl.empty())
+                      h_isl = read_file(dir + "/kmc_islands.hpp"), h_gen = read_file(dir + "/kmc_generation.hpp");
+    if (h_dev.empty() || h_ker.empty() || h_isl.empty() || h_gen.empty())
         return fail(KMC_ERR_BAD_ARG, "user density: kernel headers not found in " + dir + " (set KMC_CSRC_DIR)");
 
     std::ostringstream src;
-    src << "#include \"kmc_islands.hpp\"\n" << user_functor_source(ud) << user_density_alias(ud, ndim)
+    src << "#include \"kmc_islands.hpp\"\n#include \"kmc_generation.hpp\"\n" << user_functor_source(ud) << user_density_alias(ud, ndim)
         << (ud->is_body && with_vec && ud->sep ? ud->sep_functor + (ud->sep_nacc > 1 ? "using UDV = kmc::SepDensityN<UserS>;\n" : "using UDV = kmc::SepDensity<UserS>;\n")
                                                 : std::string("using UDV = UD;\n"))
         << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_generic(KMC_FRONT_PARAMS, const kmc::HalfStepArgs a) { kmc::half_step_generic_body<UD, " << peer << ", " << rowt << ">(KMC_FRONT_PACK, a); }\n"
@@ -566,14 +567,17 @@ kmc_status compile_user(kmc_user_density* ud, bool with_vec, int L, int K, int i
     if (resident_K > 0 && island_S > 0)
         src << "extern \"C\" __global__ __launch_bounds__(" << island_S << ") void kmc_user_island(const kmc::IslandArgs a) { kmc::island_epoch_body<UD, "
             << island_S << ", " << resident_K << ", " << (resident_ragged ? "true" : "false") << ">(a); }\n";
+    if (generation_nd > 0)          // one launch per generation, one walker per lane (kmc_generation.hpp): the density element by element / the body as written
+        src << "extern \"C\" __global__ __launch_bounds__(" << kGenerationTPB << ") void kmc_user_generation(const kmc::GenerationArgs a) { kmc::generation_lane_body<UD, "
+            << generation_nd << ">(a); }\n";
     const std::string text = src.str();
 
-    const char* headers[3] = {h_ker.c_str(), h_dev.c_str(), h_isl.c_str()};
-    const char* names[3] = {"kmc_kernels.hpp", "kmc_device.hpp", "kmc_islands.hpp"};
+    const char* headers[4] = {h_ker.c_str(), h_dev.c_str(), h_isl.c_str(), h_gen.c_str()};
+    const char* names[4] = {"kmc_kernels.hpp", "kmc_device.hpp", "kmc_islands.hpp", "kmc_generation.hpp"};
     const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-mllvm", "-amdgpu-kernarg-preload-count=14"};
     std::vector<char> code;
     std::string log;
-    const kmc_status cst = rtc_compile_cached(text, "kmc_user_density.hip", 3, headers, names, 6, opts, &code, &log);
+    const kmc_status cst = rtc_compile_cached(text, "kmc_user_density.hip", 4, headers, names, 6, opts, &code, &log);
     if (cst == KMC_ERR_BAD_ARG) return fail(KMC_ERR_BAD_ARG, "user density does not compile:\n" + log);
     if (cst != KMC_OK) return cst;
     auto ins = ud->code.emplace(key, std::move(code));
@@ -582,10 +586,10 @@ kmc_status compile_user(kmc_user_density* ud, bool with_vec, int L, int K, int i
 }
 
 kmc_status load_user(kmc_user_density* ud, bool with_vec, int L, int K, int iter, bool ragged, UserKernels* uk,
-                     int resident_K, bool resident_ragged, int island_S, bool f32, int64_t ndim, bool p2p)
+                     int resident_K, bool resident_ragged, int island_S, bool f32, int64_t ndim, bool p2p, int generation_nd)
 {
     const std::vector<char>* code = nullptr;
-    KMC_TRY(compile_user(ud, with_vec, L, K, iter, ragged, resident_K, resident_ragged, island_S, f32, &code, ndim, p2p));
+    KMC_TRY(compile_user(ud, with_vec, L, K, iter, ragged, resident_K, resident_ragged, island_S, f32, &code, ndim, p2p, generation_nd));
     {
         int dev = 0;
         HIP_TRY(hipGetDevice(&dev));
@@ -608,6 +612,8 @@ kmc_status load_user(kmc_user_density* ud, bool with_vec, int L, int K, int iter
     if (!with_vec && staged_possible(ud, f32, ndim, p2p)) HIP_TRY(hipModuleGetFunction(&uk->staged, uk->mod, "kmc_user_staged"));
     if (resident_K != 0 && island_S == 0) HIP_TRY(hipModuleGetFunction(&uk->resident, uk->mod, "kmc_user_resident"));
     if (resident_K > 0 && island_S > 0) HIP_TRY(hipModuleGetFunction(&uk->island, uk->mod, "kmc_user_island"));
+    uk->generation = nullptr;
+    if (generation_nd > 0) HIP_TRY(hipModuleGetFunction(&uk->generation, uk->mod, "kmc_user_generation"));
     return KMC_OK;
 }
 

@@ -238,6 +238,24 @@ kmc_status check_sum_form(kmc_sampler* s)
 }
 }  // namespace
 
+namespace {
+// Mid-size ensembles with short double rows: one launch per generation (kmc_generation.hpp) -- the dependent-launch boundary, which is
+// most of a half-step at these sizes, is paid once per generation instead of twice.  Measured against the two-launch kernels
+// (profiles/r04_generation_map.txt): 1.2-1.75 x ahead up to 32 768 walkers (1.06-1.25 x at ndim 8), 1.2-1.36 x at 65 536 walkers of one or
+// two doubles, behind beyond that (there the lane-striped gathers of the two-launch kernels win).  KMC_DEBUG=fused=0 / =1: never / at any
+// size.  (Resident and island mode are decided by the caller.)
+bool generation_wanted(const kmc_sampler* s)
+{
+    const kmc_config& c = s->cfg;
+    if (c.density == KMC_HOST_DENSITY || s->f32 || s->nblob != 0 || c.ndim > 8 || c.shard_count != 1 || c.deal_count != 0 ||
+        (c.flags & (KMC_P2P | KMC_NO_GRAPH | KMC_ISLANDS)))
+        return false;
+    std::string forced;
+    if (debug_opt("fused", &forced)) return forced != "0";
+    return c.nwalkers <= 32768 || (c.nwalkers <= 65536 && s->ld <= 2);
+}
+}  // namespace
+
 KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** out)
 {
     if (!out) return fail(KMC_ERR_BAD_ARG, "null out");
@@ -310,7 +328,7 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         auto load = [&]() {
             set_offline_compiler_hint(s->h_loc >= 8192 && rK == 0 && iS == 0);
             const kmc_status lst = load_user(s->user, s->plan.vec, s->plan.L, s->plan.K, s->plan.ITER, s->plan.ragged, &s->uk, rcode, 4 * rK != cfg->ndim, iS, s->f32,
-                                             cfg->ndim, (cfg->flags & KMC_P2P) != 0);
+                                             cfg->ndim, (cfg->flags & KMC_P2P) != 0, (rK == 0 && iS == 0 && generation_wanted(s)) ? (int)cfg->ndim : 0);
             set_offline_compiler_hint(false);
             return lst;
         };
@@ -406,6 +424,15 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
             } else {
                 (void)hipGetLastError();
             }
+        }
+    }
+    if (!s->islands && !s->resident && generation_wanted(s)) {          // one launch per generation (see generation_wanted)
+        if (s->user) s->fused = s->uk.generation != nullptr;
+        else { s->generation_kernel = generation_fn(cfg->density, (int)cfg->ndim); s->fused = s->generation_kernel != nullptr; }
+        if (s->fused) {
+            s->launch_mode = 1;
+            s->nislands = cfg->nwalkers;                  // per-walker moment sums [4 island_K >= ndim][nwalkers] (kmc_sampler_get_moments)
+            s->island_K = cfg->ndim <= 4 ? 1 : 2;
         }
     }
     // vec kernels: vec_tpb(L) threads per workgroup; the generic kernel keeps 256
@@ -511,13 +538,18 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
                 s->mring_waves = nwaves;
             }
         }
-        if (s->islands || s->resident) {
+        if (s->islands || s->resident || s->fused) {
             const size_t ne = (size_t)s->nislands * 4 * (size_t)s->island_K;
             CREATE_TRY(dev_alloc(s, &s->d_isum, ne * sizeof(double)));
             CREATE_TRY(dev_alloc(s, &s->d_isumsq, ne * sizeof(double)));
             CREATE_TRY(hipMemsetAsync(s->d_isum, 0, ne * sizeof(double), s->stream));
             CREATE_TRY(hipMemsetAsync(s->d_isumsq, 0, ne * sizeof(double), s->stream));
         }
+    }
+    if (s->fused) {                                  // the second copy of the state (pad column of an odd ndim: 0 in both)
+        CREATE_TRY(dev_alloc(s, &s->d_pos2, nw * ldz * sizeof(double)));
+        CREATE_TRY(hipMemsetAsync(s->d_pos2, 0, nw * ldz * sizeof(double), s->stream));
+        CREATE_TRY(dev_alloc(s, &s->d_logp2, nw * sizeof(double)));
     }
     if (s->host_eval) {
         CREATE_TRY(dev_alloc(s, &s->d_prop, (size_t)s->h * ldz * sizeof(double)));
@@ -668,6 +700,8 @@ KMC_EXPORT void kmc_sampler_destroy(kmc_sampler* s)
     cache_free(s->d_draws);
     cache_free(s->d_isum);
     cache_free(s->d_isumsq);
+    cache_free(s->d_pos2);
+    cache_free(s->d_logp2);
     cache_free(s->d_prop);
     cache_free(s->d_p1);
     if (s->h_prop) (void)hipHostFree(s->h_prop);
@@ -737,6 +771,9 @@ KMC_EXPORT kmc_status kmc_sampler_describe(const kmc_sampler* s, char* buf, int6
           << " threads), up to " << kDrawTableGens << " generations per launch, "
           << (s->resident_lane2 ? std::string("two walkers per thread") : s->resident_lane ? std::string("one walker per thread") : "rows 2 lanes x " + std::to_string(s->island_K) + " chunks")
           << ", the launch's draws from a wide kernel before it";
+    else if (s->fused)
+        o << "one launch per generation (exact): generation_lane ND=" << s->cfg.ndim << ", one walker per lane, second-half walkers recompute their partner's first-half move, grid "
+          << 2 * ((s->h + kGenerationTPB - 1) / kGenerationTPB) << " x " << kGenerationTPB << ", hipGraph replay of 64 generations";
     else if (s->host_eval)
         o << "host-evaluated density (exact): per half-step propose kernel -> D2H -> callback -> H2D -> accept kernel, grid "
           << s->grid << " x 256";
@@ -768,7 +805,8 @@ KMC_EXPORT kmc_status kmc_sampler_describe(const kmc_sampler* s, char* buf, int6
     if (s->d_ids) o << "; dealt sub-ensemble " << s->cfg.deal_rank << "/" << s->cfg.deal_count << " (walkers re-dealt between epochs)";
     if (s->d_mring) o << "; moments through a ring of " << s->mring_depth << " posted rows per wave";
     if (s->user) o << "; runtime-compiled density";
-    if (s->user && s->user->is_body && s->plan.vec && !s->resident && !s->islands)
+    if (s->user && s->user->is_body && s->fused) o << " (function body, evaluated as written: one walker per lane)";
+    else if (s->user && s->user->is_body && s->plan.vec && !s->resident && !s->islands)
         o << (s->user->sep ? " (function body recognised as a sum over elements and checked against the body on test rows: lane-striped)"
                            : " (function body: rows lane-striped, the body evaluated per walker on the whole proposal" + (s->user->sep_note.empty() ? std::string() : "; taken for a sum over elements, but " + s->user->sep_note) + ")");
     if (s->nblob > 0) o << " with a blob of " << s->nblob << " doubles per walker" << (s->d_chain_blob ? " (stored with every sample)" : "");

@@ -32,6 +32,7 @@ struct UserKernels {
     hipModule_t mod = nullptr;          // (owned by `keep`, shared with the density's cache and other samplers)
     std::shared_ptr<void> keep;
     hipFunction_t vec = nullptr, generic = nullptr, logpdf = nullptr, resident = nullptr, island = nullptr, init_ball = nullptr;
+    hipFunction_t generation = nullptr; // one launch per generation (kmc_generation.hpp), when the sampler asked for it
     hipFunction_t staged = nullptr;     // body densities, double rows, ndim <= kStagedMaxDim: half_step_staged_body
     hipFunction_t logpdf_sep = nullptr; // a body recognised as a sum over elements: the generated form, row by row (check_sum_form)
 };
@@ -137,6 +138,13 @@ struct kmc_sampler {
     int resident_tpb = 256;
     bool resident_lane2 = false;       // ... two walkers per thread (1026 .. 2048 walkers: resident_lane2_body)
     bool resident_lane = false;        // ... one walker per thread (kmc_islands.hpp: resident_lane_body) instead of two lanes per walker
+    // one launch per generation (kmc_generation.hpp): mid-size ensembles with short double rows, exact.  The state ping-pongs between
+    // (d_pos, d_logp) and (d_pos2, d_logp2) generation by generation; kmc_sampler_run leaves it in the first pair.
+    bool fused = false;
+    kmc::GenerationFn generation_kernel = nullptr;
+    double* d_pos2 = nullptr;
+    double* d_logp2 = nullptr;
+    int fused_cur = 0;                 // which pair holds the state at the tail of the stream (0 between kmc_sampler_run calls)
     // island mode (KMC_ISLANDS)
     bool islands = false;
     kmc::IslandFn island_kernel = nullptr;
@@ -183,6 +191,7 @@ kmc::IslandFn island_fn(int density, int S, int K, bool ragged);
 kmc::ResidentFn resident_fn(int density, int tpb, int K, bool ragged);
 kmc::ResidentFn resident_lane_fn(int density, int ndim, bool f32);
 kmc::ResidentFn resident_lane2_fn(int density, int ndim);
+kmc::GenerationFn generation_fn(int density, int ndim);
 bool resident_lane_wanted(int64_t ndim);
 int lane_nd(int64_t ndim);
 void island_perm(uint64_t seed, int64_t epoch, int64_t N, int64_t* A, int64_t* C);
@@ -204,7 +213,8 @@ void chain_unregister(kmc_sampler* s);
 
 // kmc_rtc.hip
 kmc_status load_user(kmc_user_density* ud, bool with_vec, int L, int K, int iter, bool ragged, UserKernels* uk,
-                     int resident_K = 0, bool resident_ragged = false, int island_S = 0, bool f32 = false, int64_t ndim = 0, bool p2p = false);
+                     int resident_K = 0, bool resident_ragged = false, int island_S = 0, bool f32 = false, int64_t ndim = 0, bool p2p = false,
+                     int generation_nd = 0);
 void set_offline_compiler_hint(bool wanted);                          // runtime-compiled kernels of this thread: hipcc as a child process instead of hiprtc (kmc_rtc.hip)
 bool body_vec_possible(const kmc_user_density* ud, int64_t ndim);     // a function body inside the vector kernels, evaluated per walker (kmc_rtc.hip)
 

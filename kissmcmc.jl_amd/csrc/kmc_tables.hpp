@@ -4,6 +4,7 @@
 #pragma once
 #include <type_traits>
 #include "kmc_islands.hpp"
+#include "kmc_generation.hpp"
 #include "kmc_metropolis.hpp"
 
 namespace kmc {
@@ -13,6 +14,7 @@ using LogpdfFn = void (*)(const LogpdfArgs);
 using FlushFn = void (*)(const FlushArgs);
 using IslandFn = void (*)(const IslandArgs);
 using ResidentFn = void (*)(const ResidentArgs);
+using GenerationFn = void (*)(const GenerationArgs);
 using InitBallFn = void (*)(const InitBallArgs);
 using MetropolisFn = void (*)(const MetropolisArgs);
 using MetropolisTabledFn = void (*)(const MetropolisArgs, const double*, int);
@@ -177,6 +179,22 @@ ResidentFn resident_lane2_lookup(int ndim)
     default: return nullptr;
     }
 }
+// one launch per generation, one walker per lane (mid-size ensembles, short double rows: kmc_generation.hpp)
+template <class D>
+GenerationFn generation_lane_lookup(int ndim)
+{
+    switch (ndim) {
+    case 1: return generation_lane<D, 1>;
+    case 2: return generation_lane<D, 2>;
+    case 3: return generation_lane<D, 3>;
+    case 4: return generation_lane<D, 4>;
+    case 5: return generation_lane<D, 5>;
+    case 6: return generation_lane<D, 6>;
+    case 7: return generation_lane<D, 7>;
+    case 8: return generation_lane<D, 8>;
+    default: return nullptr;
+    }
+}
 // many-chain Metropolis: the chain in registers up to 32 dimensions, in memory beyond
 template <class D>
 MetropolisFn metropolis_lookup(int ndim)
@@ -218,6 +236,7 @@ IslandFn island_gaussian_iso(int S, int K, bool ragged);
 ResidentFn resident_gaussian_iso(int tpb, int K, bool ragged);
 ResidentFn resident_lane_gaussian_iso(int ndim, bool f32);
 ResidentFn resident_lane2_gaussian_iso(int ndim);
+GenerationFn generation_lane_gaussian_iso(int ndim);
 InitBallFn init_ball_gaussian_iso();
 MetropolisFn metropolis_gaussian_iso(int ndim);
 MetropolisTabledFn metropolis_tabled_gaussian_iso(int ndim);
@@ -225,6 +244,7 @@ IslandFn island_exponential(int S, int K, bool ragged);
 ResidentFn resident_exponential(int tpb, int K, bool ragged);
 ResidentFn resident_lane_exponential(int ndim, bool f32);
 ResidentFn resident_lane2_exponential(int ndim);
+GenerationFn generation_lane_exponential(int ndim);
 InitBallFn init_ball_exponential();
 MetropolisFn metropolis_exponential(int ndim);
 MetropolisTabledFn metropolis_tabled_exponential(int ndim);
@@ -232,6 +252,7 @@ IslandFn island_rosenbrock(int S, int K, bool ragged);
 ResidentFn resident_rosenbrock(int tpb, int K, bool ragged);
 ResidentFn resident_lane_rosenbrock(int ndim, bool f32);
 ResidentFn resident_lane2_rosenbrock(int ndim);
+GenerationFn generation_lane_rosenbrock(int ndim);
 InitBallFn init_ball_rosenbrock();
 MetropolisFn metropolis_rosenbrock(int ndim);
 MetropolisTabledFn metropolis_tabled_rosenbrock(int ndim);
@@ -239,6 +260,7 @@ IslandFn island_lognormal(int S, int K, bool ragged);
 ResidentFn resident_lognormal(int tpb, int K, bool ragged);
 ResidentFn resident_lane_lognormal(int ndim, bool f32);
 ResidentFn resident_lane2_lognormal(int ndim);
+GenerationFn generation_lane_lognormal(int ndim);
 InitBallFn init_ball_lognormal();
 MetropolisFn metropolis_lognormal(int ndim);
 MetropolisTabledFn metropolis_tabled_lognormal(int ndim);
@@ -246,6 +268,7 @@ IslandFn island_mvnormal2(int S, int K, bool ragged);
 ResidentFn resident_mvnormal2(int tpb, int K, bool ragged);
 ResidentFn resident_lane_mvnormal2(int ndim, bool f32);
 ResidentFn resident_lane2_mvnormal2(int ndim);
+GenerationFn generation_lane_mvnormal2(int ndim);
 InitBallFn init_ball_mvnormal2();
 MetropolisFn metropolis_mvnormal2(int ndim);
 MetropolisTabledFn metropolis_tabled_mvnormal2(int ndim);

@@ -1,0 +1,190 @@
+"""One launch per generation (kissmcmc.jl_amd/csrc/kmc_generation.hpp) against the CPU oracle and against the two-launch kernels.
+
+Mid-size ensembles with short double rows run a whole generation (reference src/samplers.jl:246-274, both batches) per launch:
+second-half walkers recompute their partner's first-half move instead of waiting for it.  The bars are those of
+tests/test_gpu_parity.py: accept counters, positions and the chain bit-identical to the oracle, log-pdfs to 1e-12, moments to 1e-11.
+"""
+import numpy as np
+import pytest
+
+from test_gpu_parity import _compare, _densities, _run_both, _theta0
+
+pytestmark = pytest.mark.gpu
+
+
+def _mode(kmc, pdf, nw, nd, **kw):
+    with kmc.Sampler(pdf, nw, nd, 10, 0, 1, 2.0, 1, **kw) as s:
+        return s.describe()
+
+
+@pytest.mark.parametrize("name,nw,nd", [
+    ("gauss", 2050, 4), ("gauss", 4096, 4), ("gauss", 10000, 4), ("gauss", 16384, 4), ("gauss", 4096, 1), ("gauss", 4096, 2),
+    ("gauss", 4098, 3), ("gauss_shift", 2500, 5), ("gauss", 4096, 7), ("gauss", 4096, 8), ("gauss", 65536, 2),
+    ("expo", 4096, 1), ("expo", 3000, 3), ("rosen", 4096, 2), ("rosen", 2600, 6), ("lognormal", 4096, 1), ("lognormal", 5000, 4),
+])
+def test_one_launch_per_generation_equals_the_oracle(kmc, oracle, name, nw, nd):
+    """The whole surface of a run: 70 generations = one graph chunk of 64 + 6 launched one by one, burn-in 13, every 3rd generation
+    stored (chain, log-pdfs, moments), counters restarted at the end of burn-in."""
+    pdf = _densities(kmc, oracle)[name][0]
+    assert "one launch per generation" in _mode(kmc, pdf, nw, nd)
+    ref, got = _run_both(kmc, oracle, name, nw, nd, 70, 13, 3, 11)
+    _compare(ref, got)
+
+
+@pytest.mark.parametrize("G,nburn,nthin", [(1, 0, 1), (2, 1, 1), (63, 0, 1), (64, 64, 1), (65, 10, 7), (129, 0, 2), (200, 199, 1)])
+def test_run_lengths_and_schedules(kmc, oracle, G, nburn, nthin):
+    """Odd and even numbers of generations (the state ends in either copy and is moved back), whole chunks and tails, burn-in up to
+    the whole run, thinning."""
+    ref, got = _run_both(kmc, oracle, "gauss", 4096, 4, G, nburn, nthin, 5)
+    _compare(ref, got)
+
+
+def test_split_runs_and_state_between_them(kmc, oracle):
+    """kmc_sampler_run in pieces of odd lengths: between the calls the state is in the sampler's canonical arrays (read out, compared),
+    and the pieces add up to the oracle's uninterrupted run."""
+    nw, nd, G, nburn, seed = 4096, 4, 150, 20, 8
+    th = _theta0("gauss", nw, nd, 3)
+    pdf = kmc.GaussianIso()
+    with kmc.Sampler(pdf, nw, nd, G, nburn, 1, 2.0, seed, store_chain=True, store_logp=True, moments=True) as s:
+        assert "one launch per generation" in s.describe()
+        s.set_positions(th)
+        done = 0
+        for piece in (1, 64, 3, 65, 17):
+            s.run(piece)
+            done += piece
+            s.sync()
+            part = oracle.emcee(oracle.make_config(oracle.GAUSSIAN_ISO, [0.0, 1.0], nw, nd, done, min(nburn, done), 1, 2.0, seed), th, store_chain=False)
+            np.testing.assert_array_equal(s.positions(), part["final_pos"])
+        assert done == G
+        got = dict(final_pos=s.positions(), final_logp=s.logp(), naccept=s.naccept(), accept_ratio=s.accept_ratio())
+        got["chain"], got["chain_logp"] = s.chain()
+        got["sum"], got["sumsq"], got["nmoment"] = s.moments()
+        assert s.launch_count == G
+    ref = oracle.emcee(oracle.make_config(oracle.GAUSSIAN_ISO, [0.0, 1.0], nw, nd, G, nburn, 1, 2.0, seed), th)
+    _compare(ref, got)
+
+
+def test_same_run_as_the_two_launch_kernels(kmc, kmc_debug):
+    """KMC_DEBUG=fused=0 keeps the two-launch kernels for the same ensemble: positions, counters and chain bit for bit, log-pdfs to
+    rounding (their sums run lane-striped)."""
+    nw, nd, G, seed = 8192, 4, 100, 21
+    th = _theta0("gauss", nw, nd, 9)
+    out = {}
+    for label in ("fused", "two"):
+        if label == "two":
+            kmc_debug.set("fused", 0)
+        with kmc.Sampler(kmc.GaussianIso(), nw, nd, G, 10, 1, 2.0, seed, store_chain=True, moments=True) as s:
+            assert ("one launch per generation" in s.describe()) == (label == "fused"), s.describe()
+            s.set_positions(th)
+            s.run(G)
+            s.sync()
+            out[label] = (s.positions(), s.naccept(), s.chain(logp=False)[0], s.logp(), s.moments())
+    np.testing.assert_array_equal(out["fused"][0], out["two"][0])
+    np.testing.assert_array_equal(out["fused"][1], out["two"][1])
+    np.testing.assert_array_equal(out["fused"][2], out["two"][2])
+    np.testing.assert_allclose(out["fused"][3], out["two"][3], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(out["fused"][4][0], out["two"][4][0], rtol=1e-11, atol=1e-9)
+    assert out["fused"][4][2] == out["two"][4][2]
+
+
+def test_what_keeps_the_two_launch_kernels(kmc):
+    """Stepping by halves needs the half-step kernels (KMC_NO_GRAPH), and long rows / big ensembles stay with them."""
+    pdf = kmc.GaussianIso()
+    assert "one launch per generation" not in _mode(kmc, pdf, 4096, 4, use_graph=False)
+    assert "one launch per generation" not in _mode(kmc, pdf, 4096, 32)
+    assert "one launch per generation" not in _mode(kmc, pdf, 262144, 4)
+    assert "resident" in _mode(kmc, pdf, 2048, 4)
+    with kmc.Sampler(pdf, 4096, 4, 10, 0, 1, 2.0, 1) as s:
+        s.set_positions(_theta0("gauss", 4096, 4, 1))
+        with pytest.raises(kmc.KmcError, match="one launch per generation"):
+            s.half_step(0)
+
+
+def test_streamed_chain_and_checkpoint(kmc, oracle, kmc_debug):
+    """The chain streamed to host memory through the device ring (small blocks forced), and a run resumed from a checkpoint: both
+    the oracle's uninterrupted run."""
+    nw, nd, G, nburn, seed = 4096, 4, 300, 10, 13
+    th = _theta0("gauss", nw, nd, 4)
+    ref = oracle.emcee(oracle.make_config(oracle.GAUSSIAN_ISO, [0.0, 1.0], nw, nd, G, nburn, 1, 2.0, seed), th)
+    kmc_debug.set("chain-block", 70)
+    with kmc.Sampler(kmc.GaussianIso(), nw, nd, G, nburn, 1, 2.0, seed, store_chain=True, store_logp=True, stream_chain=True) as s:
+        assert "one launch per generation" in s.describe() and "streamed" in s.describe()
+        s.set_positions(th)
+        s.run(G)
+        s.sync()
+        chain, clogp = s.chain()
+    kmc_debug.unset("chain-block")
+    np.testing.assert_array_equal(chain, ref["chain"])
+    np.testing.assert_allclose(clogp, ref["chain_logp"], rtol=1e-12, atol=1e-12)
+    with kmc.Sampler(kmc.GaussianIso(), nw, nd, G, nburn, 1, 2.0, seed, moments=True) as s:
+        s.set_positions(th)
+        s.run(77)
+        s.sync()
+        state = s.state()
+    with kmc.Sampler(kmc.GaussianIso(), nw, nd, G, nburn, 1, 2.0, seed, moments=True) as s:
+        s.restore(state)
+        s.run(G - 77)
+        s.sync()
+        np.testing.assert_array_equal(s.positions(), ref["final_pos"])
+        np.testing.assert_array_equal(s.naccept(), ref["naccept"])
+
+
+GAUSS_BODY = "double s = 0.0; for (int i = 0; i < n; ++i) { double t = (x[i] - p[0]) * p[1]; s += t * t; } return -0.5 * s;"
+COUPLED_BODY = "double s = 0.0; for (int i = 0; i < n; ++i) s += x[i] * x[i]; for (int i = 0; i + 1 < n; ++i) s += p[0] * x[i] * x[i + 1]; return -0.5 * s;"
+
+
+@pytest.mark.parametrize("form", ["expr", "body", "body_as_written"])
+def test_runtime_compiled_densities_equal_the_oracle(kmc, oracle, kmc_debug, form):
+    """The caller's own density (reference src/samplers.jl:257) in the one-launch-per-generation kernel: a term expression, a C function
+    body (a sum over elements: here it is evaluated as written, one walker per lane -- the oracle's element order), and the same body
+    with the recogniser off.  The Gaussian restated: the oracle's run, bit for bit."""
+    nw, nd, G, nburn, nthin, seed = 4096, 4, 70, 13, 3, 11
+    if form == "body_as_written":
+        kmc_debug.set("no-body-routing")
+    pdf = kmc.ExprDensity("-0.5*x*x") if form == "expr" else kmc.CDensity(GAUSS_BODY, params=[0.0, 1.0])
+    th = _theta0("gauss", nw, nd, seed)
+    ref = oracle.emcee(oracle.make_config(oracle.GAUSSIAN_ISO, [0.0, 1.0], nw, nd, G, nburn, nthin, 2.0, seed), th)
+    with kmc.Sampler(pdf, nw, nd, G, nburn, nthin, 2.0, seed, store_chain=True, store_logp=True, moments=True) as s:
+        how = s.describe()
+        assert "one launch per generation" in how and "runtime-compiled" in how, how
+        s.set_positions(th)
+        s.run(G)
+        s.sync()
+        got = dict(final_pos=s.positions(), final_logp=s.logp(), naccept=s.naccept(), accept_ratio=s.accept_ratio())
+        got["chain"], got["chain_logp"] = s.chain()
+        got["sum"], got["sumsq"], got["nmoment"] = s.moments()
+    _compare(ref, got)
+
+
+def test_coupled_body_equals_its_two_launch_run(kmc, kmc_debug):
+    """A body with a coupling between neighbouring elements (no menu density restates it): the one-launch-per-generation run against the
+    same body in the two-launch kernels (KMC_DEBUG=fused=0)."""
+    nw, nd, G, seed = 6000, 6, 90, 5
+    th = _theta0("gauss", nw, nd, 2)
+    out = {}
+    for label in ("fused", "two"):
+        if label == "two":
+            kmc_debug.set("fused", 0)
+        with kmc.Sampler(kmc.CDensity(COUPLED_BODY, params=[0.3]), nw, nd, G, 20, 2, 2.0, seed, store_chain=True, moments=True) as s:
+            assert ("one launch per generation" in s.describe()) == (label == "fused"), s.describe()
+            s.set_positions(th)
+            s.run(G)
+            s.sync()
+            out[label] = (s.positions(), s.naccept(), s.chain(logp=False)[0], s.logp(), s.moments())
+    np.testing.assert_array_equal(out["fused"][0], out["two"][0])
+    np.testing.assert_array_equal(out["fused"][1], out["two"][1])
+    np.testing.assert_array_equal(out["fused"][2], out["two"][2])
+    np.testing.assert_allclose(out["fused"][3], out["two"][3], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(out["fused"][4][0], out["two"][4][0], rtol=1e-11, atol=1e-9)
+
+
+def test_drop_in_call_on_a_mid_size_ensemble(kmc, oracle):
+    """The reference's own call (src/samplers.jl:188) on 4 096 walkers: chain, accept ratios and log-densities as the oracle returns them."""
+    nw, nd, gens, seed = 4096, 2, 40, 19
+    th = _theta0("gauss", nw, nd, 6)
+    thetas, accept_ratio, logdensities, blobs = kmc.emcee(kmc.GaussianIso(), th, niter=gens * nw, nburnin=10 * nw, use_progress_meter=False, seed=seed)
+    ref = oracle.emcee(oracle.make_config(oracle.GAUSSIAN_ISO, [0.0, 1.0], nw, nd, gens, 10, 1, 2.0, seed), th)
+    assert blobs is None and thetas.shape == (nw, gens - 10, nd)
+    np.testing.assert_array_equal(np.transpose(thetas, (1, 0, 2)), ref["chain"])
+    np.testing.assert_array_equal(accept_ratio, ref["accept_ratio"])
+    np.testing.assert_allclose(np.transpose(logdensities), ref["chain_logp"], rtol=1e-12, atol=1e-12)

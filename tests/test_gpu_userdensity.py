@@ -117,6 +117,7 @@ def test_body_density_equals_the_oracle(kmc, oracle, case, kernel, monkeypatch, 
         kmc_debug.set("no-body-vec")
     monkeypatch.setenv("KMC_NO_RESIDENT", "1")           # the multi-launch kernels are the subject here (small ensembles with ndim <= 32
                                                          #  would run resident: test_body_density_runs_resident_on_small_ensembles)
+    kmc_debug.set("fused", 0)                            #  ... and short rows one launch per generation: tests/test_gpu_generation.py
     if case.endswith("_generic"):
         monkeypatch.setenv("KMC_PLAN", "generic")        # the unstaged one-walker-per-lane kernel (what ndim > 256 runs)
     nw, nd = (int(v) for v in shape.split("x"))
@@ -142,12 +143,13 @@ def test_body_density_equals_the_oracle(kmc, oracle, case, kernel, monkeypatch, 
 
 @pytest.mark.parametrize("case", ["gauss_256x32", "gauss_1000x7", "rosen_128x2", "rosen_512x64", "gauss_200x33", "rosen_130x63", "gauss_96x65",
                                   "rosen_200x130", "gauss_300x256", "gauss_300x257", "gauss_2200x4", "rosen_4096x32"])
-def test_separable_body_runs_lane_striped_and_equals_the_oracle(kmc, oracle, case, monkeypatch):
+def test_separable_body_runs_lane_striped_and_equals_the_oracle(kmc, oracle, case, monkeypatch, kmc_debug):
     """A function body that is a sum over elements (`double s = 0; for (i < n) s += f(x[i]); return g(s);`, or the neighbour form with
     x[i + 1]) is recognised by kmc_user_density_create_body and runs in the lane-striped vector kernels of the menu densities: same
     chains and counters as the oracle, bit for bit; log-pdfs to rounding (lane-order sum).  The user's closure pdf(theta), src/samplers.jl:257."""
     name, shape = case.split("_")[:2]
     monkeypatch.setenv("KMC_NO_RESIDENT", "1")
+    kmc_debug.set("fused", 0)                            # (short rows would run one launch per generation, the body as written: tests/test_gpu_generation.py)
     nw, nd = (int(v) for v in shape.split("x"))
     body, did, params, cparams, scale = {"gauss": (C_GAUSS, oracle.GAUSSIAN_ISO, [0.3, 1.5], [0.3, 1.0 / 1.5], 1.0),
                                          "rosen": (C_ROSEN, oracle.ROSENBROCK, [1.0, 100.0, 20.0], [1.0, 100.0, 20.0], 0.1)}[name]
@@ -206,6 +208,7 @@ def test_bodies_feeding_several_sums_run_lane_striped(kmc, case, monkeypatch, km
             "double s = 0.0; double t = 0.0; double u = 0; for (int i = 0; i + 1 < n; ++i) { double d = x[i+1]-x[i]; s += d*d; t += x[i]*x[i]; u += x[i+1]*x[i]; } "
             "return -(p[0]*s + 0.5*t + 0.01*u);")
     monkeypatch.setenv("KMC_NO_RESIDENT", "1")
+    kmc_debug.set("fused", 0)                            # (3000 x 6 would run one launch per generation, the body as written)
     th = np.random.default_rng(4).standard_normal((nw, nd))
     G, nburn, seed = 80, 20, 17
     routed = kmc.CDensity(body, params=[0.3])
@@ -233,6 +236,7 @@ def test_sum_form_is_checked_against_the_body_before_it_runs(kmc, outcome, monke
     no test row with a finite value (forced, and for real: a density supported on [100, 101] only) -> the density is evaluated per walker,
     as written, describe() says why, and the run equals the run with the recogniser switched off."""
     monkeypatch.setenv("KMC_NO_RESIDENT", "1")
+    kmc_debug.set("fused", 0)                            # (the lane-striped route of the two-launch kernels is the subject)
     nw, nd, G, nburn, seed = 256, 8, 60, 10, 5
     if outcome == "blind":
         body = ("double s = 0; for (int i = 0; i < n; ++i) { const double t = x[i] - 100.5; s += (t < -0.5 || t > 0.5) ? -INFINITY : -0.5 * t * t; } return s;")
@@ -262,12 +266,13 @@ def test_sum_form_is_checked_against_the_body_before_it_runs(kmc, outcome, monke
     assert a["nacc"].sum() > 0
 
 
-def test_body_density_with_real_coupling_samples_its_target(kmc, monkeypatch):
+def test_body_density_with_real_coupling_samples_its_target(kmc, monkeypatch, kmc_debug):
     """A density no term / pair form can express -- a correlated Gaussian with a dense precision matrix built in the body:
     x' P x with P = (1 + rho) I - rho/n 11' ... here: -0.5 (sum x_i^2 + c (sum x_i)^2): variance of the mean direction
     1 / (1 + c n), of every orthogonal direction 1."""
     n, c = 6, 0.5
     monkeypatch.setenv("KMC_NO_RESIDENT", "1")           # (2048 x 6 would run resident, two walkers per thread: the multi-launch kernel is the subject)
+    kmc_debug.set("fused", 0)                            # (... or one launch per generation)
     pdf = kmc.CDensity("double s = 0.0, t = 0.0; for (int i = 0; i < n; ++i) { s += x[i] * x[i]; t += x[i]; } return -0.5 * (s + p[0] * t * t);", params=[c])
     th = np.random.default_rng(1).standard_normal((2048, n))
     with kmc.Sampler(pdf, 2048, n, 3000, 500, 5, 2.0, 3, store_chain=True) as s:
@@ -390,7 +395,7 @@ def test_term_pair_density_runs_two_walkers_per_thread_beyond_1024(kmc, oracle, 
     assert "two walkers per thread" in a["how"], a["how"]
     monkeypatch.setenv("KMC_NO_RESIDENT", "1")
     b = run(kmc.GaussianIso(0.0, 1.0))
-    assert "multi-launch" in b["how"]
+    assert "resident" not in b["how"]
     np.testing.assert_array_equal(a["chain"], b["chain"])
     np.testing.assert_array_equal(a["nacc"], b["nacc"])
     np.testing.assert_allclose(a["mom"][0], b["mom"][0], rtol=1e-11, atol=1e-8)
