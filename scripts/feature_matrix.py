@@ -61,6 +61,13 @@ def f_resident(kmc, pdf):
         return "yes" if "resident mode" in s.describe() else "no: runs in the multi-launch kernels"
 
 
+def f_generation(kmc, pdf):
+    with kmc.Sampler(pdf, 4096, ND, 200, 20, 1, 2.0, SEED, store_chain=True) as s:
+        s.set_positions(theta(4096))
+        _run(s)
+        return "yes" if "one launch per generation" in s.describe() else "no: runs in the two-launch kernels"
+
+
 def f_islands(kmc, pdf):
     with kmc.Sampler(pdf, 2048, ND, 200, 20, 1, 2.0, SEED, moments=True, island_gens=8, island_size=64) as s:
         s.set_positions(theta(2048))
@@ -173,6 +180,7 @@ def f_blobs(kmc, pdf):
 FEATURES = [
     ("hipGraph replay", f_graph),
     ("resident mode (≤ 1024 walkers; ≤ 2048 with ndim ≤ 8)", f_resident),
+    ("one launch per generation (2 050 … 32 768 walkers, ndim ≤ 8)", f_generation),
     ("islands (`KMC_ISLANDS`)", f_islands),
     ("float rows (`KMC_F32`)", f_f32),
     ("streamed chain (`KMC_STREAM_CHAIN`)", f_stream),
