@@ -38,10 +38,10 @@ struct GenerationArgs {
     uint32_t          h;            // walkers per half
     uint32_t          nb;           // workgroups per half
     int32_t           ld;           // row stride (doubles; ndim rounded up to even)
-    int32_t           pad_;
+    int32_t           ndim;
     double*           chain;        // [nsamples][nwalkers][ld] or nullptr              (:269)
     double*           chain_logp;   // [nsamples][nwalkers] or nullptr                  (:271)
-    double*           msum;         // [ND][nwalkers] per-walker sums of the stored samples (read out in walker order), or nullptr
+    double*           msum;         // [nwalkers][ld] per-walker sums of the stored samples (laid out like the rows; read out in walker order), or nullptr
     double*           msumsq;
 };
 
@@ -101,15 +101,20 @@ __device__ __forceinline__ void generation_lane_body(const GenerationArgs& a)
     double m1[ND], m2[ND];
     const bool moments = sample && a.msum != nullptr;
     if (moments) {                                                       // (issued here, used at the end)
-#pragma unroll
-        for (int d = 0; d < ND; ++d) { m1[d] = a.msum[(size_t)d * (2u * a.h) + me]; m2[d] = a.msumsq[(size_t)d * (2u * a.h) + me]; }
+        gen_load_row<ND>(a.msum + (size_t)me * ld, m1);
+        gen_load_row<ND>(a.msumsq + (size_t)me * ld, m2);
     }
+    // both moves' draws now, while the rows are on their way (z, (N-1) log z, log u: two logarithms each -- off the second move's chain)
+    const Draw dr_mine = draw_finish(a.dc, mybits);                      // :252
+    Draw dr_first = dr_mine;
+    if (second) dr_first = draw_finish(a.dc, bits);                      // (uniform per workgroup)
     bool acc = false;
     double p1 = 0.0;
     double y[ND];
 #pragma unroll 1
     for (int level = second ? 0 : 1; level < 2; ++level) {               // ONE copy of the move: my partner's and my own are the same instructions
-        const Draw dr = draw_finish(a.dc, bits);                         // :252
+        Draw dr = dr_mine;
+        if (level == 0) dr = dr_first;
         typename Dens::Seq q;
         Dens::seq_init(q);
 #pragma unroll
@@ -123,7 +128,6 @@ __device__ __forceinline__ void generation_lane_body(const GenerationArgs& a)
 #pragma unroll
             for (int d = 0; d < ND; ++d) { oth[d] = acc ? y[d] : own[d]; own[d] = myown[d]; }
             p0 = myp0;
-            bits = mybits;
         }
     }
 #pragma unroll
@@ -138,10 +142,9 @@ __device__ __forceinline__ void generation_lane_body(const GenerationArgs& a)
         if (a.chain_logp != nullptr) a.chain_logp[row] = pnew;
         if (moments) {
 #pragma unroll
-            for (int d = 0; d < ND; ++d) {
-                a.msum[(size_t)d * (2u * a.h) + me] = m1[d] + y[d];
-                a.msumsq[(size_t)d * (2u * a.h) + me] = m2[d] + y[d] * y[d];
-            }
+            for (int d = 0; d < ND; ++d) { m1[d] += y[d]; m2[d] += y[d] * y[d]; }
+            gen_store_row<ND>(a.msum + (size_t)me * ld, m1);
+            gen_store_row<ND>(a.msumsq + (size_t)me * ld, m2);
         }
     }
 }
@@ -150,6 +153,135 @@ template <class Dens, int ND>
 __global__ __launch_bounds__(kGenerationTPB) void generation_lane(const GenerationArgs a)
 {
     generation_lane_body<Dens, ND>(a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same generation for longer rows: a walker's row striped over the L lanes of a group, K chunks of two doubles per lane (lane j,
+// chunk k holds elements 2 (k L + j), 2 (k L + j) + 1 -- the layout, the lane-striped density code and the group reduction of
+// half_step_vec, so the log-pdfs are its bits).  Every lane of a group computes its walker's draws itself (redundantly: at these
+// sizes most SIMDs are idle, and it keeps the chain free of cross-lane traffic); the accept decision is therefore the same in all of
+// them.  Workgroups of blockDim.x / L walkers; blocks [0, nb) carry the second half.  Used where the ensemble's state is small enough
+// that reading 2.5 x the rows and writing every row per generation costs less than the boundary saved (kmc_sampler.hip).
+// ------------------------------------------------------------------------------------------------
+template <class Dens, int L, int K>
+__device__ __forceinline__ void generation_group_body(const GenerationArgs& a)
+{
+    static_assert(BlobTrait<Dens>::n == 0 && RowEvalTrait<Dens>::n == 0, "lane-striped densities only");
+    const uint32_t gpb = blockDim.x / L;                                 // walkers per workgroup
+    const bool second = blockIdx.x < a.nb;
+    const uint32_t i0 = (second ? blockIdx.x : blockIdx.x - a.nb) * gpb + threadIdx.x / L;
+    const bool valid = i0 < a.h;
+    const uint32_t i = valid ? i0 : a.h - 1u;                            // (idle groups of the last workgroup move the last walker and store nothing:
+    const int j = (int)(threadIdx.x & (L - 1));                          //  the cross-lane sums want whole waves)
+    const SchedEntry sch = a.sched != nullptr ? *a.sched : a.sched_inline;
+    const uint64_t step0 = 2ull * (uint64_t)sch.gen;
+    const uint32_t me = (second ? a.h : 0u) + i;
+    const int ld = a.ld, ndim = a.ndim;
+    const double2 zero2 = make_double2(0.0, 0.0);
+    bool cv[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) cv[k] = 2 * (k * L + j) < ld;
+    auto row = [&](const double* base, uint32_t w, double2 (&x)[K]) {
+        const double2* r = reinterpret_cast<const double2*>(base + (size_t)w * (size_t)ld);
+#pragma unroll
+        for (int k = 0; k < K; ++k) x[k] = cv[k] ? r[k * L + j] : zero2;
+    };
+    const U4 mybits = draw_bits(a.dc, step0 + (second ? 1u : 0u), me);
+    const uint32_t mypartner = (second ? 0u : a.h) + draw_partner(a.dc, mybits);      // :250
+    double2 own[K], oth[K], myown[K];
+    double p0, myp0 = 0.0;
+    U4 bits;
+    if (second) {
+        const uint32_t w = mypartner;                                    // a first-half walker: its move of step0
+        bits = draw_bits(a.dc, step0, w);
+        const uint32_t jp = a.h + draw_partner(a.dc, bits);
+        row(a.pin, jp, oth);
+        row(a.pin, w, own);
+        p0 = a.lin[w];
+        row(a.pin, me, myown);
+        myp0 = a.lin[me];
+    } else {
+        bits = mybits;
+        row(a.pin, mypartner, oth);
+        row(a.pin, me, own);
+        p0 = a.lin[me];
+#pragma unroll
+        for (int k = 0; k < K; ++k) myown[k] = zero2;
+    }
+    const bool count = (sch.flags & kCount) != 0u, sample = (sch.flags & kSample) != 0u;
+    const bool moments = sample && a.msum != nullptr;
+    double2 m1[K], m2[K];
+    if (moments) { row(a.msum, me, m1); row(a.msumsq, me, m2); }
+    const Draw dr_mine = draw_finish(a.dc, mybits);                      // :252 (both moves' draws now: see generation_lane_body)
+    Draw dr_first = dr_mine;
+    if (second) dr_first = draw_finish(a.dc, bits);
+    bool acc = false;
+    double p1 = 0.0;
+    double2 y[K];
+#pragma unroll 1
+    for (int level = second ? 0 : 1; level < 2; ++level) {               // ONE copy of the move (see generation_lane_body)
+        Draw dr = dr_mine;
+        if (level == 0) dr = dr_first;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {                                    // :255
+            y[k].x = fma(dr.z, own[k].x - oth[k].x, oth[k].x);
+            y[k].y = fma(dr.z, own[k].y - oth[k].y, oth[k].y);
+        }
+        if constexpr (MultiSumTrait<Dens>::n > 0) {                      // a function body feeding several sums over the elements
+            double S[MultiSumTrait<Dens>::n];
+            Dens::template frag_partial_n<L, K>(y, j, ndim, a.dp, S);
+#pragma unroll
+            for (int q = 0; q < MultiSumTrait<Dens>::n; ++q) S[q] = group_sum<L>(S[q]);
+            p1 = Dens::finish_n(S, a.dp);                                // :257
+        } else {
+            p1 = Dens::finish(group_sum<L>(Dens::template frag_partial<L, K>(y, j, ndim, a.dp)), a.dp);   // :257
+        }
+        acc = accept_test(dr, p1, p0);                                   // :260 (the same bits, hence the same decision, in every lane of the group)
+        if (level == 0) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                oth[k].x = acc ? y[k].x : own[k].x; oth[k].y = acc ? y[k].y : own[k].y;
+                own[k] = myown[k];
+            }
+            p0 = myp0;
+        }
+    }
+    if (!valid) return;
+#pragma unroll
+    for (int k = 0; k < K; ++k) { y[k].x = acc ? y[k].x : own[k].x; y[k].y = acc ? y[k].y : own[k].y; }   // :261
+    const double pnew = acc ? p1 : p0;                                   // :262
+    double2* out = reinterpret_cast<double2*>(a.pout + (size_t)me * (size_t)ld);
+#pragma unroll
+    for (int k = 0; k < K; ++k) if (cv[k]) out[k * L + j] = y[k];       // (elements past ndim of the last chunk: 0 in, 0 out -- the lane-striped densities ignore them)
+    if (j == 0) {
+        a.lout[me] = pnew;
+        if (acc && count) a.naccept[me] += 1u;                           // :265
+    }
+    if (sample) {                                                        // :268-271
+        const size_t srow = (size_t)sch.slot * (2u * (size_t)a.h) + me;
+        if (a.chain != nullptr) {
+            double2* dst = reinterpret_cast<double2*>(a.chain + srow * (size_t)ld);
+#pragma unroll
+            for (int k = 0; k < K; ++k) if (cv[k]) dst[k * L + j] = y[k];
+        }
+        if (a.chain_logp != nullptr && j == 0) a.chain_logp[srow] = pnew;
+        if (moments) {
+            double2* s1 = reinterpret_cast<double2*>(a.msum + (size_t)me * (size_t)ld);
+            double2* s2 = reinterpret_cast<double2*>(a.msumsq + (size_t)me * (size_t)ld);
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+                if (cv[k]) {
+                    s1[k * L + j] = make_double2(m1[k].x + y[k].x, m1[k].y + y[k].y);
+                    s2[k * L + j] = make_double2(m2[k].x + y[k].x * y[k].x, m2[k].y + y[k].y * y[k].y);
+                }
+        }
+    }
+}
+
+template <class Dens, int L, int K>
+__global__ __launch_bounds__(256) void generation_group(const GenerationArgs a)
+{
+    generation_group_body<Dens, L, K>(a);
 }
 
 }  // namespace kmc

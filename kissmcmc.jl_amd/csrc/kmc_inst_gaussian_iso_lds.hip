@@ -9,6 +9,7 @@ ResidentFn resident_gaussian_iso(int tpb, int K, bool ragged) { return resident_
 ResidentFn resident_lane_gaussian_iso(int ndim, bool f32) { return resident_lane_lookup<GaussianIso>(ndim, f32); }
 ResidentFn resident_lane2_gaussian_iso(int ndim) { return resident_lane2_lookup<GaussianIso>(ndim); }
 GenerationFn generation_lane_gaussian_iso(int ndim) { return generation_lane_lookup<GaussianIso>(ndim); }
+GenerationFn generation_group_gaussian_iso(int L, int K) { return generation_group_lookup<GaussianIso>(L, K); }
 MetropolisFn metropolis_gaussian_iso(int ndim) { return metropolis_lookup<GaussianIso>(ndim); }
 MetropolisTabledFn metropolis_tabled_gaussian_iso(int ndim) { return metropolis_tabled_lookup<GaussianIso>(ndim); }
 }  // namespace kmc

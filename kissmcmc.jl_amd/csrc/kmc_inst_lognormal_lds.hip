@@ -9,6 +9,7 @@ ResidentFn resident_lognormal(int tpb, int K, bool ragged) { return resident_loo
 ResidentFn resident_lane_lognormal(int ndim, bool f32) { return resident_lane_lookup<LogNormal>(ndim, f32); }
 ResidentFn resident_lane2_lognormal(int ndim) { return resident_lane2_lookup<LogNormal>(ndim); }
 GenerationFn generation_lane_lognormal(int ndim) { return generation_lane_lookup<LogNormal>(ndim); }
+GenerationFn generation_group_lognormal(int L, int K) { return generation_group_lookup<LogNormal>(L, K); }
 MetropolisFn metropolis_lognormal(int ndim) { return metropolis_lookup<LogNormal>(ndim); }
 MetropolisTabledFn metropolis_tabled_lognormal(int ndim) { return metropolis_tabled_lookup<LogNormal>(ndim); }
 }  // namespace kmc

@@ -9,6 +9,7 @@ ResidentFn resident_mvnormal2(int tpb, int K, bool ragged) { return resident_loo
 ResidentFn resident_lane_mvnormal2(int ndim, bool f32) { return resident_lane_lookup<MvNormal2>(ndim, f32); }
 ResidentFn resident_lane2_mvnormal2(int ndim) { return resident_lane2_lookup<MvNormal2>(ndim); }
 GenerationFn generation_lane_mvnormal2(int ndim) { return generation_lane_lookup<MvNormal2>(ndim); }
+GenerationFn generation_group_mvnormal2(int L, int K) { return generation_group_lookup<MvNormal2>(L, K); }
 MetropolisFn metropolis_mvnormal2(int ndim) { return metropolis_lookup<MvNormal2>(ndim); }
 MetropolisTabledFn metropolis_tabled_mvnormal2(int ndim) { return metropolis_tabled_lookup<MvNormal2>(ndim); }
 }  // namespace kmc

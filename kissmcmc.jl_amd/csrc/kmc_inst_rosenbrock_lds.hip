@@ -9,6 +9,7 @@ ResidentFn resident_rosenbrock(int tpb, int K, bool ragged) { return resident_lo
 ResidentFn resident_lane_rosenbrock(int ndim, bool f32) { return resident_lane_lookup<Rosenbrock>(ndim, f32); }
 ResidentFn resident_lane2_rosenbrock(int ndim) { return resident_lane2_lookup<Rosenbrock>(ndim); }
 GenerationFn generation_lane_rosenbrock(int ndim) { return generation_lane_lookup<Rosenbrock>(ndim); }
+GenerationFn generation_group_rosenbrock(int L, int K) { return generation_group_lookup<Rosenbrock>(L, K); }
 MetropolisFn metropolis_rosenbrock(int ndim) { return metropolis_lookup<Rosenbrock>(ndim); }
 MetropolisTabledFn metropolis_tabled_rosenbrock(int ndim) { return metropolis_tabled_lookup<Rosenbrock>(ndim); }
 }  // namespace kmc

@@ -235,8 +235,10 @@ GenerationArgs make_generation_args(const kmc_sampler* s, int from, bool graph_m
     a.dc = make_args(s, 0, false, 0).dc;
     a.dp = s->dp;
     a.h = (uint32_t)s->h;
-    a.nb = (uint32_t)((s->h + kGenerationTPB - 1) / kGenerationTPB);
+    const int64_t per_wg = s->fused_L > 0 ? s->fused_tpb / s->fused_L : kGenerationTPB;       // walkers per workgroup
+    a.nb = (uint32_t)((s->h + per_wg - 1) / per_wg);
     a.ld = (int32_t)s->ld;
+    a.ndim = (int32_t)s->cfg.ndim;
     a.chain = s->d_chain;
     a.chain_logp = s->d_chain_logp;
     a.msum = s->d_isum;
@@ -247,8 +249,9 @@ GenerationArgs make_generation_args(const kmc_sampler* s, int from, bool graph_m
 hipError_t launch_generation(const kmc_sampler* s, int from, bool graph_mode, int64_t gen_offset)
 {
     const GenerationArgs a = make_generation_args(s, from, graph_mode, gen_offset);
-    if (s->user) return launch_module(s->uk.generation, 2u * a.nb, (unsigned)kGenerationTPB, s->stream, a);
-    hipLaunchKernelGGL(s->generation_kernel, dim3(2u * a.nb), dim3(kGenerationTPB), 0, s->stream, a);
+    const unsigned tpb = s->fused_L > 0 ? (unsigned)s->fused_tpb : (unsigned)kGenerationTPB;
+    if (s->user) return launch_module(s->uk.generation, 2u * a.nb, tpb, s->stream, a);
+    hipLaunchKernelGGL(s->generation_kernel, dim3(2u * a.nb), dim3(tpb), 0, s->stream, a);
     return hipGetLastError();
 }
 
@@ -506,7 +509,8 @@ KMC_EXPORT kmc_status kmc_sampler_run(kmc_sampler* s, int64_t ngen)
     if (s->fused) {
         // one launch per generation: whole chunks from the table graph (an even number of generations: the state ends where it
         // started, in d_pos / d_logp), the rest launch by launch; the state is moved back into d_pos / d_logp at the end
-        const bool use_graph = !(s->cfg.flags & KMC_NO_GRAPH);
+        const char* forced = std::getenv("KMC_LAUNCH");
+        const bool use_graph = !(s->cfg.flags & KMC_NO_GRAPH) && !(forced && std::strcmp(forced, "eager") == 0);
         while (use_graph && ngen >= kGraphChunk) {
             HIP_TRY(generation_settle(s));
             KMC_TRY(ensure_graph(s));

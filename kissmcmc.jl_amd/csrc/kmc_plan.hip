@@ -84,6 +84,18 @@ GenerationFn generation_fn(int density, int ndim)
     }
 }
 
+GenerationFn generation_group_fn(int density, int L, int K)
+{
+    switch (density) {
+    case KMC_GAUSSIAN_ISO: return generation_group_gaussian_iso(L, K);
+    case KMC_EXPONENTIAL: return generation_group_exponential(L, K);
+    case KMC_ROSENBROCK: return generation_group_rosenbrock(L, K);
+    case KMC_LOGNORMAL: return generation_group_lognormal(L, K);
+    case KMC_MVNORMAL2: return generation_group_mvnormal2(L, K);
+    default: return nullptr;
+    }
+}
+
 // resident mode with one walker per thread (short rows) or two lanes per walker: KMC_DEBUG=resident=pair decides for tests
 bool resident_lane_wanted(int64_t ndim)
 {

@@ -570,6 +570,9 @@ kmc_status compile_user(kmc_user_density* ud, bool with_vec, int L, int K, int i
     if (generation_nd > 0)          // one launch per generation, one walker per lane (kmc_generation.hpp): the density element by element / the body as written
         src << "extern \"C\" __global__ __launch_bounds__(" << kGenerationTPB << ") void kmc_user_generation(const kmc::GenerationArgs a) { kmc::generation_lane_body<UD, "
             << generation_nd << ">(a); }\n";
+    if (generation_nd < 0)          // ... rows lane-striped (L = -generation_nd / 100, K = -generation_nd % 100): term / pair densities, bodies recognised as sums
+        src << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_generation(const kmc::GenerationArgs a) { kmc::generation_group_body<UDV, "
+            << (-generation_nd) / 100 << ", " << (-generation_nd) % 100 << ">(a); }\n";
     const std::string text = src.str();
 
     const char* headers[4] = {h_ker.c_str(), h_dev.c_str(), h_isl.c_str(), h_gen.c_str()};
@@ -613,7 +616,7 @@ kmc_status load_user(kmc_user_density* ud, bool with_vec, int L, int K, int iter
     if (resident_K != 0 && island_S == 0) HIP_TRY(hipModuleGetFunction(&uk->resident, uk->mod, "kmc_user_resident"));
     if (resident_K > 0 && island_S > 0) HIP_TRY(hipModuleGetFunction(&uk->island, uk->mod, "kmc_user_island"));
     uk->generation = nullptr;
-    if (generation_nd > 0) HIP_TRY(hipModuleGetFunction(&uk->generation, uk->mod, "kmc_user_generation"));
+    if (generation_nd != 0) HIP_TRY(hipModuleGetFunction(&uk->generation, uk->mod, "kmc_user_generation"));
     return KMC_OK;
 }
 

@@ -239,20 +239,24 @@ kmc_status check_sum_form(kmc_sampler* s)
 }  // namespace
 
 namespace {
-// Mid-size ensembles with short double rows: one launch per generation (kmc_generation.hpp) -- the dependent-launch boundary, which is
-// most of a half-step at these sizes, is paid once per generation instead of twice.  Measured against the two-launch kernels
-// (profiles/r04_generation_map.txt): 1.2-1.75 x ahead up to 32 768 walkers (1.06-1.25 x at ndim 8), 1.2-1.36 x at 65 536 walkers of one or
-// two doubles, behind beyond that (there the lane-striped gathers of the two-launch kernels win).  KMC_DEBUG=fused=0 / =1: never / at any
-// size.  (Resident and island mode are decided by the caller.)
-bool generation_wanted(const kmc_sampler* s)
+// One launch per generation (kmc_generation.hpp) -- the dependent-launch boundary, which is most of a half-step for small states, is paid
+// once per generation instead of twice.  0: no; 1: one walker per lane (ndim <= 8); 2: rows lane-striped like the vector kernels (longer
+// rows; lane-striped densities).  Measured against the two-launch kernels (profiles/r04_generation_map.txt): short rows 1.3-1.75 x ahead up
+// to 32 768 walkers (1.1-1.2 x at ndim 8 up to 16 384), 1.25-1.4 x at 65 536 walkers of one or two doubles, behind beyond that; longer rows
+// 1.07-1.45 x ahead while the state stays within 2 MiB (the kernel reads 2.5 x the rows and writes every row), behind beyond.
+// KMC_DEBUG=fused=0 / =1: never / wherever a kernel exists.  (Resident and island mode are decided by the caller.)
+int generation_wanted(const kmc_sampler* s)
 {
     const kmc_config& c = s->cfg;
-    if (c.density == KMC_HOST_DENSITY || s->f32 || s->nblob != 0 || c.ndim > 8 || c.shard_count != 1 || c.deal_count != 0 ||
-        (c.flags & (KMC_P2P | KMC_NO_GRAPH | KMC_ISLANDS)))
-        return false;
+    if (c.density == KMC_HOST_DENSITY || s->f32 || s->nblob != 0 || c.shard_count != 1 || c.deal_count != 0 ||
+        (c.flags & (KMC_P2P | KMC_NO_GRAPH | KMC_ISLANDS)) || std::getenv("KMC_PLAN") != nullptr)      // (KMC_PLAN: a geometry of the two-launch kernels was asked for)
+        return 0;
+    const int kind = c.ndim <= 8 ? 1 : 2;
+    if (kind == 2 && (!s->plan.vec || (s->user && s->user->is_body && !s->user->sep))) return 0;
     std::string forced;
-    if (debug_opt("fused", &forced)) return forced != "0";
-    return c.nwalkers <= 32768 || (c.nwalkers <= 65536 && s->ld <= 2);
+    if (debug_opt("fused", &forced)) return forced != "0" ? kind : 0;
+    if (kind == 1) return ((c.nwalkers <= 32768 && c.nwalkers * s->ld <= 196608) || (c.nwalkers <= 65536 && s->ld <= 2)) ? 1 : 0;
+    return c.nwalkers * s->ld <= 262144 ? 2 : 0;
 }
 }  // namespace
 
@@ -328,7 +332,7 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         auto load = [&]() {
             set_offline_compiler_hint(s->h_loc >= 8192 && rK == 0 && iS == 0);
             const kmc_status lst = load_user(s->user, s->plan.vec, s->plan.L, s->plan.K, s->plan.ITER, s->plan.ragged, &s->uk, rcode, 4 * rK != cfg->ndim, iS, s->f32,
-                                             cfg->ndim, (cfg->flags & KMC_P2P) != 0, (rK == 0 && iS == 0 && generation_wanted(s)) ? (int)cfg->ndim : 0);
+                                             cfg->ndim, (cfg->flags & KMC_P2P) != 0, (rK != 0 || iS != 0) ? 0 : generation_wanted(s) == 1 ? (int)cfg->ndim : generation_wanted(s) == 2 ? -(100 * s->plan.L + s->plan.K) : 0);
             set_offline_compiler_hint(false);
             return lst;
         };
@@ -426,13 +430,19 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
             }
         }
     }
-    if (!s->islands && !s->resident && generation_wanted(s)) {          // one launch per generation (see generation_wanted)
+    if (const int kind = (!s->islands && !s->resident) ? generation_wanted(s) : 0) {          // one launch per generation (see generation_wanted)
         if (s->user) s->fused = s->uk.generation != nullptr;
-        else { s->generation_kernel = generation_fn(cfg->density, (int)cfg->ndim); s->fused = s->generation_kernel != nullptr; }
+        else {
+            s->generation_kernel = kind == 1 ? generation_fn(cfg->density, (int)cfg->ndim) : generation_group_fn(cfg->density, s->plan.L, s->plan.K);
+            s->fused = s->generation_kernel != nullptr;
+        }
         if (s->fused) {
             s->launch_mode = 1;
-            s->nislands = cfg->nwalkers;                  // per-walker moment sums [4 island_K >= ndim][nwalkers] (kmc_sampler_get_moments)
-            s->island_K = cfg->ndim <= 4 ? 1 : 2;
+            s->fused_L = kind == 1 ? 0 : s->plan.L;
+            // lane-striped: one wave per workgroup while the half's waves fit the chip's SIMDs about once, four beyond (workgroup dispatch rate)
+            s->fused_tpb = (kind == 2 && s->h * s->plan.L > 64 * 512) ? 256 : 64;
+            s->nislands = cfg->nwalkers;                  // per-walker moment sums [nwalkers][ld], within [nislands][4 island_K] (kmc_sampler_get_moments)
+            s->island_K = (int)((s->ld + 3) / 4);
         }
     }
     // vec kernels: vec_tpb(L) threads per workgroup; the generic kernel keeps 256
@@ -771,10 +781,14 @@ KMC_EXPORT kmc_status kmc_sampler_describe(const kmc_sampler* s, char* buf, int6
           << " threads), up to " << kDrawTableGens << " generations per launch, "
           << (s->resident_lane2 ? std::string("two walkers per thread") : s->resident_lane ? std::string("one walker per thread") : "rows 2 lanes x " + std::to_string(s->island_K) + " chunks")
           << ", the launch's draws from a wide kernel before it";
-    else if (s->fused)
-        o << "one launch per generation (exact): generation_lane ND=" << s->cfg.ndim << ", one walker per lane, second-half walkers recompute their partner's first-half move, grid "
-          << 2 * ((s->h + kGenerationTPB - 1) / kGenerationTPB) << " x " << kGenerationTPB << ", hipGraph replay of 64 generations";
-    else if (s->host_eval)
+    else if (s->fused) {
+        if (s->fused_L == 0)
+            o << "one launch per generation (exact): generation_lane ND=" << s->cfg.ndim << ", one walker per lane, second-half walkers recompute their partner's first-half move, grid "
+              << 2 * ((s->h + kGenerationTPB - 1) / kGenerationTPB) << " x " << kGenerationTPB << ", hipGraph replay of 64 generations";
+        else
+            o << "one launch per generation (exact): generation_group L=" << s->fused_L << " K=" << s->plan.K << ", rows lane-striped, second-half walkers recompute their partner's first-half move, grid "
+              << 2 * ((s->h + s->fused_tpb / s->fused_L - 1) / (s->fused_tpb / s->fused_L)) << " x " << s->fused_tpb << ", hipGraph replay of 64 generations";
+    } else if (s->host_eval)
         o << "host-evaluated density (exact): per half-step propose kernel -> D2H -> callback -> H2D -> accept kernel, grid "
           << s->grid << " x 256";
     else if (s->plan.vec) {
@@ -805,7 +819,9 @@ KMC_EXPORT kmc_status kmc_sampler_describe(const kmc_sampler* s, char* buf, int6
     if (s->d_ids) o << "; dealt sub-ensemble " << s->cfg.deal_rank << "/" << s->cfg.deal_count << " (walkers re-dealt between epochs)";
     if (s->d_mring) o << "; moments through a ring of " << s->mring_depth << " posted rows per wave";
     if (s->user) o << "; runtime-compiled density";
-    if (s->user && s->user->is_body && s->fused) o << " (function body, evaluated as written: one walker per lane)";
+    if (s->user && s->user->is_body && s->fused)
+        o << (s->fused_L == 0 ? " (function body, evaluated as written: one walker per lane)"
+                              : " (function body recognised as a sum over elements and checked against the body on test rows: lane-striped)");
     else if (s->user && s->user->is_body && s->plan.vec && !s->resident && !s->islands)
         o << (s->user->sep ? " (function body recognised as a sum over elements and checked against the body on test rows: lane-striped)"
                            : " (function body: rows lane-striped, the body evaluated per walker on the whole proposal" + (s->user->sep_note.empty() ? std::string() : "; taken for a sum over elements, but " + s->user->sep_note) + ")");

@@ -145,6 +145,8 @@ struct kmc_sampler {
     double* d_pos2 = nullptr;
     double* d_logp2 = nullptr;
     int fused_cur = 0;                 // which pair holds the state at the tail of the stream (0 between kmc_sampler_run calls)
+    int fused_L = 0;                   // 0: one walker per lane (generation_lane, ndim <= 8); else rows striped over L lanes (generation_group<L, plan.K>)
+    int fused_tpb = 64;                //   threads per workgroup of the lane-striped form
     // island mode (KMC_ISLANDS)
     bool islands = false;
     kmc::IslandFn island_kernel = nullptr;
@@ -192,6 +194,7 @@ kmc::ResidentFn resident_fn(int density, int tpb, int K, bool ragged);
 kmc::ResidentFn resident_lane_fn(int density, int ndim, bool f32);
 kmc::ResidentFn resident_lane2_fn(int density, int ndim);
 kmc::GenerationFn generation_fn(int density, int ndim);
+kmc::GenerationFn generation_group_fn(int density, int L, int K);
 bool resident_lane_wanted(int64_t ndim);
 int lane_nd(int64_t ndim);
 void island_perm(uint64_t seed, int64_t epoch, int64_t N, int64_t* A, int64_t* C);

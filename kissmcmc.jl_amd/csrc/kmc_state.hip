@@ -331,17 +331,18 @@ KMC_EXPORT kmc_status kmc_sampler_get_moments(kmc_sampler* s, double* sum, doubl
     if (!s->d_msum) return fail(KMC_ERR_BAD_ARG, "sampler was created without KMC_MOMENTS");
     HIP_TRY(hipSetDevice(s->cfg.device));
     if (s->fused) {
-        // one launch per generation: per-walker sums [d][nwalkers], added up in walker order
+        // one launch per generation: per-walker sums [nwalkers][ld] (laid out like the rows), added up in walker order
         HIP_TRY(hipStreamSynchronize(s->stream));
-        const int64_t nd = s->cfg.ndim, nw = s->cfg.nwalkers;
-        std::vector<double> hs((size_t)(nd * nw)), hq((size_t)(nd * nw));
+        const int64_t nd = s->cfg.ndim, nw = s->cfg.nwalkers, ld = s->ld;
+        std::vector<double> hs((size_t)(ld * nw)), hq((size_t)(ld * nw));
         HIP_TRY(copy_sync(hs.data(), s->d_isum, hs.size() * sizeof(double), hipMemcpyDeviceToHost, s->stream));
         HIP_TRY(copy_sync(hq.data(), s->d_isumsq, hq.size() * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+        std::vector<double> S((size_t)nd, 0.0), Q((size_t)nd, 0.0);
+        for (int64_t w = 0; w < nw; ++w)
+            for (int64_t d = 0; d < nd; ++d) { S[(size_t)d] += hs[(size_t)(w * ld + d)]; Q[(size_t)d] += hq[(size_t)(w * ld + d)]; }
         for (int64_t d = 0; d < nd; ++d) {
-            double S = 0.0, Q = 0.0;
-            for (int64_t w = 0; w < nw; ++w) { S += hs[(size_t)(d * nw + w)]; Q += hq[(size_t)(d * nw + w)]; }
-            if (sum) sum[d] = S;
-            if (sumsq) sumsq[d] = Q;
+            if (sum) sum[d] = S[(size_t)d];
+            if (sumsq) sumsq[d] = Q[(size_t)d];
         }
         if (n) *n = (samples_done(s) - s->moment_base) * s->nlocal;
         return KMC_OK;

@@ -195,6 +195,20 @@ GenerationFn generation_lane_lookup(int ndim)
     default: return nullptr;
     }
 }
+// ... and lane-striped (longer rows of small ensembles): the geometries make_plan picks for the vector kernels
+template <class D>
+GenerationFn generation_group_lookup(int L, int K)
+{
+    if constexpr (!D::kHasFrag) {
+        return nullptr;
+    } else {
+#define KMC_LK(l, k) if (L == l && K == k) return generation_group<D, l, k>;
+        KMC_LK(1, 1) KMC_LK(2, 1) KMC_LK(4, 1) KMC_LK(4, 2) KMC_LK(8, 2) KMC_LK(16, 2) KMC_LK(32, 2) KMC_LK(64, 2)
+        KMC_LK(64, 4) KMC_LK(64, 8)
+#undef KMC_LK
+        return nullptr;
+    }
+}
 // many-chain Metropolis: the chain in registers up to 32 dimensions, in memory beyond
 template <class D>
 MetropolisFn metropolis_lookup(int ndim)
@@ -237,6 +251,7 @@ ResidentFn resident_gaussian_iso(int tpb, int K, bool ragged);
 ResidentFn resident_lane_gaussian_iso(int ndim, bool f32);
 ResidentFn resident_lane2_gaussian_iso(int ndim);
 GenerationFn generation_lane_gaussian_iso(int ndim);
+GenerationFn generation_group_gaussian_iso(int L, int K);
 InitBallFn init_ball_gaussian_iso();
 MetropolisFn metropolis_gaussian_iso(int ndim);
 MetropolisTabledFn metropolis_tabled_gaussian_iso(int ndim);
@@ -245,6 +260,7 @@ ResidentFn resident_exponential(int tpb, int K, bool ragged);
 ResidentFn resident_lane_exponential(int ndim, bool f32);
 ResidentFn resident_lane2_exponential(int ndim);
 GenerationFn generation_lane_exponential(int ndim);
+GenerationFn generation_group_exponential(int L, int K);
 InitBallFn init_ball_exponential();
 MetropolisFn metropolis_exponential(int ndim);
 MetropolisTabledFn metropolis_tabled_exponential(int ndim);
@@ -253,6 +269,7 @@ ResidentFn resident_rosenbrock(int tpb, int K, bool ragged);
 ResidentFn resident_lane_rosenbrock(int ndim, bool f32);
 ResidentFn resident_lane2_rosenbrock(int ndim);
 GenerationFn generation_lane_rosenbrock(int ndim);
+GenerationFn generation_group_rosenbrock(int L, int K);
 InitBallFn init_ball_rosenbrock();
 MetropolisFn metropolis_rosenbrock(int ndim);
 MetropolisTabledFn metropolis_tabled_rosenbrock(int ndim);
@@ -261,6 +278,7 @@ ResidentFn resident_lognormal(int tpb, int K, bool ragged);
 ResidentFn resident_lane_lognormal(int ndim, bool f32);
 ResidentFn resident_lane2_lognormal(int ndim);
 GenerationFn generation_lane_lognormal(int ndim);
+GenerationFn generation_group_lognormal(int L, int K);
 InitBallFn init_ball_lognormal();
 MetropolisFn metropolis_lognormal(int ndim);
 MetropolisTabledFn metropolis_tabled_lognormal(int ndim);
@@ -269,6 +287,7 @@ ResidentFn resident_mvnormal2(int tpb, int K, bool ragged);
 ResidentFn resident_lane_mvnormal2(int ndim, bool f32);
 ResidentFn resident_lane2_mvnormal2(int ndim);
 GenerationFn generation_lane_mvnormal2(int ndim);
+GenerationFn generation_group_mvnormal2(int L, int K);
 InitBallFn init_ball_mvnormal2();
 MetropolisFn metropolis_mvnormal2(int ndim);
 MetropolisTabledFn metropolis_tabled_mvnormal2(int ndim);

@@ -25,6 +25,7 @@ for name, make in (("menu GaussianIso", lambda: kmc.GaussianIso()), ("CDensity, 
                 s.run(G); s.sync()
                 ms = s.last_run_ms()
                 how = s.describe()
-            mode = "res2" if "two walkers" in how else "res" if "resident" in how else "vec" if "half_step_vec" in how else "stg" if "staged" in how else "gen"
+            mode = ("res2" if "two walkers" in how else "res" if "resident" in how else "one" if "generation_lane" in how else "oneg" if "generation_group" in how else
+                    "vec" if "half_step_vec" in how else "stg" if "staged" in how else "gen")
             cells.append(f"{nw * G / (ms * 1e-3):9.2e} ({1e3 * ms / (2 * G):6.2f}) {mode:>4s}")
         print(f"{nw:>14d} | " + " | ".join(cells), flush=True)

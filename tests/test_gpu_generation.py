@@ -21,10 +21,16 @@ def _mode(kmc, pdf, nw, nd, **kw):
     ("gauss", 2050, 4), ("gauss", 4096, 4), ("gauss", 10000, 4), ("gauss", 16384, 4), ("gauss", 4096, 1), ("gauss", 4096, 2),
     ("gauss", 4098, 3), ("gauss_shift", 2500, 5), ("gauss", 4096, 7), ("gauss", 4096, 8), ("gauss", 65536, 2),
     ("expo", 4096, 1), ("expo", 3000, 3), ("rosen", 4096, 2), ("rosen", 2600, 6), ("lognormal", 4096, 1), ("lognormal", 5000, 4),
+    # longer rows, lane-striped (generation_group): every row geometry of the vector kernels, ragged and odd row lengths
+    ("gauss", 2048, 32), ("gauss", 4096, 32), ("rosen", 4096, 64), ("gauss", 1200, 100), ("gauss", 3000, 33), ("expo", 2600, 16),
+    ("lognormal", 4096, 12), ("gauss", 512, 128), ("gauss", 600, 300), ("gauss", 520, 500), ("rosen", 1400, 9), ("gauss", 16384, 10),
+    ("rosen", 2050, 130), ("gauss", 2000, 257),
 ])
-def test_one_launch_per_generation_equals_the_oracle(kmc, oracle, name, nw, nd):
+def test_one_launch_per_generation_equals_the_oracle(kmc, oracle, kmc_debug, name, nw, nd):
     """The whole surface of a run: 70 generations = one graph chunk of 64 + 6 launched one by one, burn-in 13, every 3rd generation
-    stored (chain, log-pdfs, moments), counters restarted at the end of burn-in."""
+    stored (chain, log-pdfs, moments), counters restarted at the end of burn-in.  (KMC_DEBUG=fused=1: the kernel wherever it exists,
+    whatever the planner's size rule says -- test_what_keeps_the_two_launch_kernels is about that rule.)"""
+    kmc_debug.set("fused", 1)
     pdf = _densities(kmc, oracle)[name][0]
     assert "one launch per generation" in _mode(kmc, pdf, nw, nd)
     ref, got = _run_both(kmc, oracle, name, nw, nd, 70, 13, 3, 11)
@@ -91,8 +97,10 @@ def test_what_keeps_the_two_launch_kernels(kmc):
     """Stepping by halves needs the half-step kernels (KMC_NO_GRAPH), and long rows / big ensembles stay with them."""
     pdf = kmc.GaussianIso()
     assert "one launch per generation" not in _mode(kmc, pdf, 4096, 4, use_graph=False)
-    assert "one launch per generation" not in _mode(kmc, pdf, 4096, 32)
+    assert "one launch per generation" not in _mode(kmc, pdf, 65536, 32)
     assert "one launch per generation" not in _mode(kmc, pdf, 262144, 4)
+    assert "one launch per generation" not in _mode(kmc, pdf, 16384, 32)
+    assert "generation_lane" in _mode(kmc, pdf, 32768, 4) and "generation_group" in _mode(kmc, pdf, 8192, 32)
     assert "resident" in _mode(kmc, pdf, 2048, 4)
     with kmc.Sampler(pdf, 4096, 4, 10, 0, 1, 2.0, 1) as s:
         s.set_positions(_theta0("gauss", 4096, 4, 1))
@@ -131,6 +139,41 @@ def test_streamed_chain_and_checkpoint(kmc, oracle, kmc_debug):
 
 GAUSS_BODY = "double s = 0.0; for (int i = 0; i < n; ++i) { double t = (x[i] - p[0]) * p[1]; s += t * t; } return -0.5 * s;"
 COUPLED_BODY = "double s = 0.0; for (int i = 0; i < n; ++i) s += x[i] * x[i]; for (int i = 0; i + 1 < n; ++i) s += p[0] * x[i] * x[i + 1]; return -0.5 * s;"
+
+
+@pytest.mark.parametrize("form", ["expr", "body", "two_sums"])
+def test_runtime_compiled_densities_with_longer_rows(kmc, oracle, kmc_debug, form):
+    """Lane-striped runtime-compiled densities in the one-launch-per-generation kernel (ndim 32): a term expression, a body recognised as
+    a sum over elements, a body feeding two sums -- against the oracle where the Gaussian is restated, else against the same body in the
+    two-launch kernels; a body with real coupling keeps the two-launch kernels."""
+    nw, nd, G, nburn, nthin, seed = 4096, 32, 70, 13, 3, 11
+    th = _theta0("gauss", nw, nd, seed)
+    pdf = (kmc.ExprDensity("-0.5*x*x") if form == "expr" else kmc.CDensity(GAUSS_BODY, params=[0.0, 1.0]) if form == "body" else
+           kmc.CDensity("double s = 0.0, t = 0.0; for (int i = 0; i < n; ++i) { s += x[i] * x[i]; t += x[i]; } return -0.5 * (s + p[0] * t * t);", params=[0.05]))
+
+    def run():
+        with kmc.Sampler(pdf, nw, nd, G, nburn, nthin, 2.0, seed, store_chain=True, store_logp=True, moments=True) as s:
+            how = s.describe()
+            s.set_positions(th)
+            s.run(G)
+            s.sync()
+            got = dict(final_pos=s.positions(), final_logp=s.logp(), naccept=s.naccept(), accept_ratio=s.accept_ratio())
+            got["chain"], got["chain_logp"] = s.chain()
+            got["sum"], got["sumsq"], got["nmoment"] = s.moments()
+            return how, got
+
+    how, got = run()
+    assert "one launch per generation" in how and "generation_group" in how and "runtime-compiled" in how, how
+    if form == "two_sums":
+        kmc_debug.set("fused", 0)
+        how2, two = run()
+        assert "half_step_vec" in how2
+        ref = dict(two, status=0)
+    else:
+        ref = oracle.emcee(oracle.make_config(oracle.GAUSSIAN_ISO, [0.0, 1.0], nw, nd, G, nburn, nthin, 2.0, seed), th)
+    _compare(ref, got)
+    with kmc.Sampler(kmc.CDensity(COUPLED_BODY, params=[0.3]), nw, nd, G, nburn, nthin, 2.0, seed) as s:
+        assert "one launch per generation" not in s.describe()
 
 
 @pytest.mark.parametrize("form", ["expr", "body", "body_as_written"])

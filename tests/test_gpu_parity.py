@@ -255,6 +255,7 @@ def test_launch_modes_are_the_same_sampler(kmc, oracle, mode, monkeypatch):
         monkeypatch.delenv("KMC_LAUNCH", raising=False)
     else:
         monkeypatch.setenv("KMC_LAUNCH", mode)
+    monkeypatch.setenv("KMC_DEBUG", "fused=0")      # the launch modes of the two-launch kernels (this small state would run one launch per generation)
     nw, nd, G, nburn, nthin, seed = 2048, 32, 1000, 301, 7, 23
     th = np.random.default_rng(4).standard_normal((nw, nd))
     with kmc.Sampler(kmc.GaussianIso(), nw, nd, G, nburn, nthin, 2.0, seed, store_chain=True, store_logp=True, moments=True) as s:
@@ -292,6 +293,7 @@ def test_updated_graph_budget_fallbacks_are_the_same_sampler(kmc, oracle, when, 
     L.kmc_updated_budget(C.byref(used), C.byref(budget))
     nw, nd, G, nburn, nthin, seed = 2048, 32, 1000, 301, 7, 29
     th = np.random.default_rng(5).standard_normal((nw, nd))
+    monkeypatch.setenv("KMC_DEBUG", "fused=0")      # (the two-launch kernels' launch modes: this small state would run one launch per generation)
     try:
         if when == "spent_before_the_run":
             monkeypatch.delenv("KMC_LAUNCH", raising=False)
