@@ -370,7 +370,9 @@ kmc_status  kmc_sampler_set_chain_host(kmc_sampler* s, double* chain_host, doubl
 kmc_status  kmc_sampler_run(kmc_sampler* s, int64_t ngenerations);
 /* Enqueue ONE half-step (src/samplers.jl:248-273) of the current generation over this shard's
  * slice; half = 1 also advances the generation counter.  For walker-sharded drivers that
- * exchange the updated slice between half-steps. */
+ * exchange the updated slice between half-steps.  An unsharded sampler whose kmc_sampler_run covers whole generations per
+ * launch (resident mode; small states, one launch per generation: kmc_sampler_describe) answers KMC_ERR_UNSUPPORTED unless it
+ * was created with KMC_NO_GRAPH, which keeps the half-step kernels. */
 kmc_status  kmc_sampler_half_step(kmc_sampler* s, int half);
 kmc_status  kmc_sampler_sync(kmc_sampler* s);
 /* Milliseconds between the start of the first and the end of the last generation enqueued by
@@ -388,7 +390,7 @@ int64_t     kmc_sampler_launch_count(const kmc_sampler* s);
  * spent (the HIP runtime leaks ~80 B of host memory per update; 64 MiB worth by default, KMC_UPDATED_BUDGET_MB in the
  * environment or kmc_set_updated_budget_mb): said once on stderr, in kmc_sampler_describe, and here. */
 #define KMC_LAUNCH_UNDECIDED     0   /* only short runs so far: whole chunks from the table graph, the rest eagerly */
-#define KMC_LAUNCH_TABLE_GRAPH   1   /* hipGraph replay of 64 generations, schedule read from a device table */
+#define KMC_LAUNCH_TABLE_GRAPH   1   /* hipGraph replay of 64 generations, schedule read from a device table (also: one launch per generation) */
 #define KMC_LAUNCH_EAGER         2   /* one launch per half-step from the host */
 #define KMC_LAUNCH_UPDATED_GRAPH 3   /* hipGraph replay with per-replay kernel-node parameter updates */
 #define KMC_LAUNCH_SINGLE        4   /* resident / island kernels (many generations per launch), host-evaluated density */
