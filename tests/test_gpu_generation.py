@@ -231,3 +231,25 @@ def test_drop_in_call_on_a_mid_size_ensemble(kmc, oracle):
     np.testing.assert_array_equal(np.transpose(thetas, (1, 0, 2)), ref["chain"])
     np.testing.assert_array_equal(accept_ratio, ref["accept_ratio"])
     np.testing.assert_allclose(np.transpose(logdensities), ref["chain_logp"], rtol=1e-12, atol=1e-12)
+
+
+def test_bound_position_buffer_and_callers_stream(kmc, oracle):
+    """kmc_sampler_bind_positions + kmc_sampler_set_stream on a one-launch-per-generation sampler: the caller's buffer is the canonical
+    copy of the state (current after every kmc_sampler_run, odd run lengths included), the second copy stays the library's."""
+    import torch
+    nw, nd, G, seed = 4096, 4, 131, 17
+    th = _theta0("gauss", nw, nd, 8)
+    pos = torch.zeros((nw, nd), dtype=torch.float64, device="cuda")
+    with kmc.Sampler(kmc.GaussianIso(), nw, nd, G, 0, 1, 2.0, seed) as s:
+        s.bind_positions(pos.data_ptr())
+        s.set_stream(torch.cuda.current_stream().cuda_stream)
+        assert "one launch per generation" in s.describe()
+        s.set_positions(th)
+        s.run(65)
+        s.run(66)
+        torch.cuda.synchronize()
+        nacc = s.naccept()
+        mine = pos.cpu().numpy()
+    ref = oracle.emcee(oracle.make_config(oracle.GAUSSIAN_ISO, [0.0, 1.0], nw, nd, G, 0, 1, 2.0, seed), th, store_chain=False)
+    np.testing.assert_array_equal(mine, ref["final_pos"])
+    np.testing.assert_array_equal(nacc, ref["naccept"])
