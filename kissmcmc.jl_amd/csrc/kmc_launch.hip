@@ -269,6 +269,18 @@ kmc_status ensure_graph(kmc_sampler* s)
 {
     if (s->graph_exec) return KMC_OK;
     if (s->comm && !s->comm_graph_ok) return KMC_OK;      // RCCL refused the capture once (or a peer's did): launch by launch, for good
+    // A caller's stream may be the legacy default stream (torch's current stream usually is): that one cannot be captured.  The capture
+    // then runs on a stream of its own -- a graph does not remember the stream it was recorded on; the replays go to the caller's.
+    hipStream_t const users = s->stream;
+    hipStream_t tmp = nullptr;
+    if (users == nullptr || users == hipStreamPerThread) {
+        HIP_TRY(hipStreamCreateWithFlags(&tmp, hipStreamNonBlocking));
+        s->stream = tmp;
+    }
+    struct Restore {
+        kmc_sampler* s; hipStream_t users, tmp;
+        ~Restore() { s->stream = users; if (tmp) (void)hipStreamDestroy(tmp); }
+    } restore{s, users, tmp};
     HIP_TRY(hipStreamBeginCapture(s->stream, hipStreamCaptureModeRelaxed));
     kmc_status st = KMC_OK;
     launch_advance(s, (int)kGraphChunk, 0);                 // schedule table of this chunk

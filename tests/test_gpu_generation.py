@@ -233,17 +233,20 @@ def test_drop_in_call_on_a_mid_size_ensemble(kmc, oracle):
     np.testing.assert_allclose(np.transpose(logdensities), ref["chain_logp"], rtol=1e-12, atol=1e-12)
 
 
-def test_bound_position_buffer_and_callers_stream(kmc, oracle):
+@pytest.mark.parametrize("nw,nd", [(4096, 4), (16384, 32)])
+def test_bound_position_buffer_and_callers_stream(kmc, oracle, nw, nd):
     """kmc_sampler_bind_positions + kmc_sampler_set_stream on a one-launch-per-generation sampler: the caller's buffer is the canonical
-    copy of the state (current after every kmc_sampler_run, odd run lengths included), the second copy stays the library's."""
+    copy of the state (current after every kmc_sampler_run, odd run lengths included), the second copy stays the library's.  The stream
+    is torch's current one -- the legacy default stream, which cannot be captured: the graph chunk is recorded on a stream of the library's
+    own and replayed on the caller's (the two-launch kernels likewise: 16384 x 32)."""
     import torch
-    nw, nd, G, seed = 4096, 4, 131, 17
+    G, seed = 131, 17
     th = _theta0("gauss", nw, nd, 8)
     pos = torch.zeros((nw, nd), dtype=torch.float64, device="cuda")
     with kmc.Sampler(kmc.GaussianIso(), nw, nd, G, 0, 1, 2.0, seed) as s:
         s.bind_positions(pos.data_ptr())
         s.set_stream(torch.cuda.current_stream().cuda_stream)
-        assert "one launch per generation" in s.describe()
+        assert ("one launch per generation" in s.describe()) == (nd == 4)
         s.set_positions(th)
         s.run(65)
         s.run(66)
