@@ -54,7 +54,11 @@ def kmc_debug(monkeypatch):
     `kmc_debug.set("chain-block", 1)`, `kmc_debug.unset("chain-block")`; undone with the test."""
     class _Debug:
         def __init__(self):
+            # options the whole run was started with (KMC_DEBUG=poison pytest ...) stay in force; a test's own come after them and win
             self.opts = {}
+            for item in filter(None, os.environ.get("KMC_DEBUG", "").split(",")):
+                k, _, v = item.partition("=")
+                self.opts[k] = v if v else None
 
         def _write(self):
             if self.opts:

@@ -256,3 +256,15 @@ def test_bound_position_buffer_and_callers_stream(kmc, oracle, nw, nd):
     ref = oracle.emcee(oracle.make_config(oracle.GAUSSIAN_ISO, [0.0, 1.0], nw, nd, G, 0, 1, 2.0, seed), th, store_chain=False)
     np.testing.assert_array_equal(mine, ref["final_pos"])
     np.testing.assert_array_equal(nacc, ref["naccept"])
+
+
+@pytest.mark.parametrize("name,nw,nd", [("gauss", 4096, 4), ("gauss", 4096, 32), ("rosen", 4096, 64), ("expo", 2600, 16), ("gauss", 1200, 100),
+                                        ("gauss", 3000, 33), ("lognormal", 5000, 4), ("rosen", 2600, 6)])
+def test_two_launch_kernels_on_the_shapes_that_default_to_one(kmc, oracle, kmc_debug, name, nw, nd):
+    """The two-launch kernels stay the path of every ensemble beyond the planner's size rule (and of every sharded one): on the small
+    states that now run one launch per generation by default they are kept under test with KMC_DEBUG=fused=0 -- the oracle's run as well."""
+    kmc_debug.set("fused", 0)
+    pdf = _densities(kmc, oracle)[name][0]
+    assert "one launch per generation" not in _mode(kmc, pdf, nw, nd)
+    ref, got = _run_both(kmc, oracle, name, nw, nd, 70, 13, 3, 11)
+    _compare(ref, got)
