@@ -45,6 +45,46 @@ struct GenerationArgs {
     double*           msumsq;
 };
 
+// What the head of a wave's chain needs, as the kernel's LEADING scalar parameters: the build preloads the first 14 dwords of the
+// arguments into SGPRs (-amdgpu-kernarg-preload-count), so the schedule entry's load is issued at wave entry instead of behind the
+// load of the argument struct that used to carry its address -- two dependent scalar round trips in front of the first Philox block were
+// 0.45 us of a 3.5 us launch (profiles/r04_generation_timeline.txt).  An eager launch (sched == nullptr) has its generation here too.
+struct GenerationFront {
+    const SchedEntry* sched;        // = GenerationArgs::sched
+    const double*     pin;
+    const double*     lin;
+    double*           pout;
+    uint32_t          seed_lo, seed_hi;
+    uint32_t          h, nb;
+    int32_t           ld;
+    uint32_t          gen;          // eager launches: the generation (sched == nullptr)
+};
+static_assert(sizeof(GenerationFront) == 56, "14 preloaded dwords");
+#define KMC_GEN_FRONT_PARAMS const kmc::SchedEntry* g_sched, const double* g_pin, const double* g_lin, double* g_pout, uint32_t g_seed_lo, uint32_t g_seed_hi, \
+                             uint32_t g_h, uint32_t g_nb, int32_t g_ld, uint32_t g_gen
+#define KMC_GEN_FRONT_PACK kmc::GenerationFront{g_sched, g_pin, g_lin, g_pout, g_seed_lo, g_seed_hi, g_h, g_nb, g_ld, g_gen}
+#define KMC_GEN_FRONT_TYPES const kmc::SchedEntry*, const double*, const double*, double*, uint32_t, uint32_t, uint32_t, uint32_t, int32_t, uint32_t
+// kernarg image of (KMC_GEN_FRONT_PARAMS, const GenerationArgs): module launches of runtime-compiled kernels pass it as one block
+struct GenerationLaunch {
+    GenerationFront f;
+    GenerationArgs  a;
+};
+
+// the schedule entry and the draw constants of a launch, from the preloaded head where the chain starts and from the struct for the rest
+__device__ __forceinline__ SchedEntry generation_schedule(const GenerationFront& f, const GenerationArgs& a)
+{
+    if (f.sched != nullptr) return *f.sched;
+    SchedEntry e = a.sched_inline;
+    e.gen = (int64_t)f.gen;
+    return e;
+}
+__device__ __forceinline__ DrawConsts generation_draw_consts(const GenerationFront& f, const GenerationArgs& a)
+{
+    DrawConsts dc = a.dc;
+    dc.seed_lo = f.seed_lo; dc.seed_hi = f.seed_hi; dc.nhalf = f.h;
+    return dc;
+}
+
 template <int ND>
 __device__ __forceinline__ void gen_load_row(const double* p, double (&x)[ND])
 {
@@ -66,36 +106,50 @@ __device__ __forceinline__ void gen_store_row(double* p, const double (&x)[ND])
 }
 
 template <class Dens, int ND>
-__device__ __forceinline__ void generation_lane_body(const GenerationArgs& a)
+__device__ __forceinline__ void generation_lane_body(const GenerationFront& f, const GenerationArgs& a)
 {
     static_assert(BlobTrait<Dens>::n == 0, "blobs: the multi-launch kernels");
-    const bool second = blockIdx.x < a.nb;
-    const uint32_t i = (second ? blockIdx.x : blockIdx.x - a.nb) * (uint32_t)kGenerationTPB + threadIdx.x;
-    if (i >= a.h) return;
-    const SchedEntry sch = a.sched != nullptr ? *a.sched : a.sched_inline;
+    KMC_STAMP(0);                                                        // (-DKMC_PROBE builds only: scripts/probe_generation.py) wave entry
+    const bool second = blockIdx.x < f.nb;
+    const uint32_t i = (second ? blockIdx.x : blockIdx.x - f.nb) * (uint32_t)kGenerationTPB + threadIdx.x;
+    if (i >= f.h) return;
+    const SchedEntry sch = generation_schedule(f, a);
+    const DrawConsts dc = generation_draw_consts(f, a);
     const uint64_t step0 = 2ull * (uint64_t)sch.gen;                     // the first half-step of this generation (:246, batch 1)
-    const uint32_t me = (second ? a.h : 0u) + i;
-    const size_t ld = (size_t)a.ld;
+#ifdef KMC_PROBE
+    asm volatile("" :: "s"(step0));
+#endif
+    KMC_STAMP(1);                                                        // the schedule entry has arrived
+    const uint32_t me = (second ? f.h : 0u) + i;
+    const size_t ld = (size_t)f.ld;
     // level 1 = my own move; level 0 (second half only) = my partner's move in the first half-step
-    const U4 mybits = draw_bits(a.dc, step0 + (second ? 1u : 0u), me);
-    const uint32_t mypartner = (second ? 0u : a.h) + draw_partner(a.dc, mybits);      // :250
+    const U4 mybits = draw_bits(dc, step0 + (second ? 1u : 0u), me);
+    const uint32_t mypartner = (second ? 0u : f.h) + draw_partner(dc, mybits);      // :250
+#ifdef KMC_PROBE
+    asm volatile("" :: "v"(mypartner));
+#endif
+    KMC_STAMP(2);                                                        // my Philox block is done
     double own[ND], oth[ND], myown[ND];
     double p0, myp0 = 0.0;
     U4 bits;
     if (second) {
         const uint32_t w = mypartner;                                    // a first-half walker: its move of step0
-        bits = draw_bits(a.dc, step0, w);
-        const uint32_t jp = a.h + draw_partner(a.dc, bits);              // its partner: a second-half row, unchanged by the first half-step
-        gen_load_row<ND>(a.pin + (size_t)jp * ld, oth);
-        gen_load_row<ND>(a.pin + (size_t)w * ld, own);
-        p0 = a.lin[w];
-        gen_load_row<ND>(a.pin + (size_t)me * ld, myown);
-        myp0 = a.lin[me];
+        bits = draw_bits(dc, step0, w);
+        const uint32_t jp = f.h + draw_partner(dc, bits);              // its partner: a second-half row, unchanged by the first half-step
+#ifdef KMC_PROBE
+        asm volatile("" :: "v"(jp));
+#endif
+        KMC_STAMP(3);                                                    // (second half) my partner's Philox block is done
+        gen_load_row<ND>(f.pin + (size_t)jp * ld, oth);
+        gen_load_row<ND>(f.pin + (size_t)w * ld, own);
+        p0 = f.lin[w];
+        gen_load_row<ND>(f.pin + (size_t)me * ld, myown);
+        myp0 = f.lin[me];
     } else {
         bits = mybits;
-        gen_load_row<ND>(a.pin + (size_t)mypartner * ld, oth);
-        gen_load_row<ND>(a.pin + (size_t)me * ld, own);
-        p0 = a.lin[me];
+        gen_load_row<ND>(f.pin + (size_t)mypartner * ld, oth);
+        gen_load_row<ND>(f.pin + (size_t)me * ld, own);
+        p0 = f.lin[me];
     }
     const bool count = (sch.flags & kCount) != 0u, sample = (sch.flags & kSample) != 0u;
     double m1[ND], m2[ND];
@@ -105,9 +159,13 @@ __device__ __forceinline__ void generation_lane_body(const GenerationArgs& a)
         gen_load_row<ND>(a.msumsq + (size_t)me * ld, m2);
     }
     // both moves' draws now, while the rows are on their way (z, (N-1) log z, log u: two logarithms each -- off the second move's chain)
-    const Draw dr_mine = draw_finish(a.dc, mybits);                      // :252
+    const Draw dr_mine = draw_finish(dc, mybits);                      // :252
     Draw dr_first = dr_mine;
-    if (second) dr_first = draw_finish(a.dc, bits);                      // (uniform per workgroup)
+    if (second) dr_first = draw_finish(dc, bits);                      // (uniform per workgroup; without the branch the four logarithms serialise: measured)
+#ifdef KMC_PROBE
+    asm volatile("" :: "v"(dr_first.lu), "v"(dr_mine.lu));
+#endif
+    KMC_STAMP(4);                                                        // loads issued, logarithms done
     bool acc = false;
     double p1 = 0.0;
     double y[ND];
@@ -115,6 +173,12 @@ __device__ __forceinline__ void generation_lane_body(const GenerationArgs& a)
     for (int level = second ? 0 : 1; level < 2; ++level) {               // ONE copy of the move: my partner's and my own are the same instructions
         Draw dr = dr_mine;
         if (level == 0) dr = dr_first;
+        if (level == 1) {
+#ifdef KMC_PROBE
+            asm volatile("" :: "v"(oth[0]), "v"(own[0]));
+#endif
+            KMC_STAMP(5);                                                // rows arrived (first half) / my partner's move done (second half)
+        }
         typename Dens::Seq q;
         Dens::seq_init(q);
 #pragma unroll
@@ -133,11 +197,16 @@ __device__ __forceinline__ void generation_lane_body(const GenerationArgs& a)
 #pragma unroll
     for (int d = 0; d < ND; ++d) y[d] = acc ? y[d] : own[d];             // :261
     const double pnew = acc ? p1 : p0;                                   // :262
-    gen_store_row<ND>(a.pout + (size_t)me * ld, y);
+#ifdef KMC_PROBE
+    asm volatile("" :: "v"(pnew));
+#endif
+    KMC_STAMP(6);                                                        // my move is done
+    gen_store_row<ND>(f.pout + (size_t)me * ld, y);
     a.lout[me] = pnew;
-    if (acc && count) a.naccept[me] += 1u;                               // :265 (counted after burn-in only, :285-288)
+    if (acc && count) a.naccept[me] += 1u;                               // :265 (counted after burn-in only, :285-288; loading the counter early, with
+                                                                         //  the rows, measured SLOWER: its address arrives with the argument struct, after the preloaded head)
     if (sample) {                                                        // the walker's state after its update, accepted or not (:268-271)
-        const size_t row = (size_t)sch.slot * (2u * (size_t)a.h) + me;
+        const size_t row = (size_t)sch.slot * (2u * (size_t)f.h) + me;
         if (a.chain != nullptr) gen_store_row<ND, true>(a.chain + row * ld, y);
         if (a.chain_logp != nullptr) a.chain_logp[row] = pnew;
         if (moments) {
@@ -147,12 +216,23 @@ __device__ __forceinline__ void generation_lane_body(const GenerationArgs& a)
             gen_store_row<ND>(a.msumsq + (size_t)me * ld, m2);
         }
     }
+    KMC_STAMP(7);                                                        // the last store is issued
+#ifdef KMC_PROBE
+    {
+        unsigned long long st[8];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        KMC_STAMP_READ(st[0], 80, 81); KMC_STAMP_READ(st[1], 82, 83); KMC_STAMP_READ(st[2], 84, 85); KMC_STAMP_READ(st[3], 86, 87);
+        KMC_STAMP_READ(st[4], 88, 89); KMC_STAMP_READ(st[5], 90, 91); KMC_STAMP_READ(st[6], 92, 93); KMC_STAMP_READ(st[7], 94, 95);
+        if (!second) st[3] = st[2];                                      // (first half: no second Philox block)
+        if (threadIdx.x == 0 && blockIdx.x < 8192) for (int q = 0; q < 8; ++q) g_probe[sch.gen & 1][blockIdx.x][q] = st[q];   // [generation parity][workgroup = wave]
+    }
+#endif
 }
 
 template <class Dens, int ND>
-__global__ __launch_bounds__(kGenerationTPB) void generation_lane(const GenerationArgs a)
+__global__ __launch_bounds__(kGenerationTPB) void generation_lane(KMC_GEN_FRONT_PARAMS, const GenerationArgs a)
 {
-    generation_lane_body<Dens, ND>(a);
+    generation_lane_body<Dens, ND>(KMC_GEN_FRONT_PACK, a);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -164,19 +244,20 @@ __global__ __launch_bounds__(kGenerationTPB) void generation_lane(const Generati
 // that reading 2.5 x the rows and writing every row per generation costs less than the boundary saved (kmc_sampler.hip).
 // ------------------------------------------------------------------------------------------------
 template <class Dens, int L, int K>
-__device__ __forceinline__ void generation_group_body(const GenerationArgs& a)
+__device__ __forceinline__ void generation_group_body(const GenerationFront& f, const GenerationArgs& a)
 {
     static_assert(BlobTrait<Dens>::n == 0 && RowEvalTrait<Dens>::n == 0, "lane-striped densities only");
     const uint32_t gpb = blockDim.x / L;                                 // walkers per workgroup
-    const bool second = blockIdx.x < a.nb;
-    const uint32_t i0 = (second ? blockIdx.x : blockIdx.x - a.nb) * gpb + threadIdx.x / L;
-    const bool valid = i0 < a.h;
-    const uint32_t i = valid ? i0 : a.h - 1u;                            // (idle groups of the last workgroup move the last walker and store nothing:
+    const bool second = blockIdx.x < f.nb;
+    const uint32_t i0 = (second ? blockIdx.x : blockIdx.x - f.nb) * gpb + threadIdx.x / L;
+    const bool valid = i0 < f.h;
+    const uint32_t i = valid ? i0 : f.h - 1u;                            // (idle groups of the last workgroup move the last walker and store nothing:
     const int j = (int)(threadIdx.x & (L - 1));                          //  the cross-lane sums want whole waves)
-    const SchedEntry sch = a.sched != nullptr ? *a.sched : a.sched_inline;
+    const SchedEntry sch = generation_schedule(f, a);
+    const DrawConsts dc = generation_draw_consts(f, a);
     const uint64_t step0 = 2ull * (uint64_t)sch.gen;
-    const uint32_t me = (second ? a.h : 0u) + i;
-    const int ld = a.ld, ndim = a.ndim;
+    const uint32_t me = (second ? f.h : 0u) + i;
+    const int ld = f.ld, ndim = a.ndim;
     const double2 zero2 = make_double2(0.0, 0.0);
     bool cv[K];
 #pragma unroll
@@ -186,25 +267,25 @@ __device__ __forceinline__ void generation_group_body(const GenerationArgs& a)
 #pragma unroll
         for (int k = 0; k < K; ++k) x[k] = cv[k] ? r[k * L + j] : zero2;
     };
-    const U4 mybits = draw_bits(a.dc, step0 + (second ? 1u : 0u), me);
-    const uint32_t mypartner = (second ? 0u : a.h) + draw_partner(a.dc, mybits);      // :250
+    const U4 mybits = draw_bits(dc, step0 + (second ? 1u : 0u), me);
+    const uint32_t mypartner = (second ? 0u : f.h) + draw_partner(dc, mybits);      // :250
     double2 own[K], oth[K], myown[K];
     double p0, myp0 = 0.0;
     U4 bits;
     if (second) {
         const uint32_t w = mypartner;                                    // a first-half walker: its move of step0
-        bits = draw_bits(a.dc, step0, w);
-        const uint32_t jp = a.h + draw_partner(a.dc, bits);
-        row(a.pin, jp, oth);
-        row(a.pin, w, own);
-        p0 = a.lin[w];
-        row(a.pin, me, myown);
-        myp0 = a.lin[me];
+        bits = draw_bits(dc, step0, w);
+        const uint32_t jp = f.h + draw_partner(dc, bits);
+        row(f.pin, jp, oth);
+        row(f.pin, w, own);
+        p0 = f.lin[w];
+        row(f.pin, me, myown);
+        myp0 = f.lin[me];
     } else {
         bits = mybits;
-        row(a.pin, mypartner, oth);
-        row(a.pin, me, own);
-        p0 = a.lin[me];
+        row(f.pin, mypartner, oth);
+        row(f.pin, me, own);
+        p0 = f.lin[me];
 #pragma unroll
         for (int k = 0; k < K; ++k) myown[k] = zero2;
     }
@@ -212,9 +293,28 @@ __device__ __forceinline__ void generation_group_body(const GenerationArgs& a)
     const bool moments = sample && a.msum != nullptr;
     double2 m1[K], m2[K];
     if (moments) { row(a.msum, me, m1); row(a.msumsq, me, m2); }
-    const Draw dr_mine = draw_finish(a.dc, mybits);                      // :252 (both moves' draws now: see generation_lane_body)
-    Draw dr_first = dr_mine;
-    if (second) dr_first = draw_finish(a.dc, bits);
+    // :252 -- both moves' draws now (see generation_lane_body).  Their four logarithms are most of a lane's chain here (~0.2 us each: dependent
+    // fp64 operations of a wave that has its SIMD to itself), and the lanes of a quad belong to one walker when L >= 4: each computes ONE of
+    // them -- same function, same argument, hence the same bits as draw_finish -- and the quad shares the results.
+    Draw dr_mine, dr_first;
+    if constexpr (L >= 4) {
+        dr_mine.partner = draw_partner(dc, mybits); dr_first.partner = draw_partner(dc, bits);
+        const double t_m = fma(((double)mybits.y + 0.5) * 0x1.0p-32, dc.c1, dc.c0), t_f = fma(((double)bits.y + 0.5) * 0x1.0p-32, dc.c1, dc.c0);
+        dr_mine.z = t_m * t_m; dr_first.z = t_f * t_f;
+        const double ua_m = ((double)(((uint64_t)mybits.z << 20) | (uint64_t)(mybits.w >> 12)) + 0.5) * 0x1.0p-52;
+        const double ua_f = ((double)(((uint64_t)bits.z << 20) | (uint64_t)(bits.w >> 12)) + 0.5) * 0x1.0p-52;
+        const int q4 = j & 3;
+        const double arg = q4 == 0 ? dr_mine.z : q4 == 1 ? ua_m : q4 == 2 ? dr_first.z : ua_f;
+        const double lg = log_pos_normal(arg);
+        dr_mine.t1 = dc.nm1 * dpp_f64<0x00>(lg);                         // quad_perm [0,0,0,0]
+        dr_mine.lu = dpp_f64<0x55>(lg);                                  // quad_perm [1,1,1,1]
+        dr_first.t1 = dc.nm1 * dpp_f64<0xAA>(lg);                        // quad_perm [2,2,2,2]
+        dr_first.lu = dpp_f64<0xFF>(lg);                                 // quad_perm [3,3,3,3]
+    } else {
+        dr_mine = draw_finish(dc, mybits);
+        dr_first = dr_mine;
+        if (second) dr_first = draw_finish(dc, bits);
+    }
     bool acc = false;
     double p1 = 0.0;
     double2 y[K];
@@ -250,7 +350,7 @@ __device__ __forceinline__ void generation_group_body(const GenerationArgs& a)
 #pragma unroll
     for (int k = 0; k < K; ++k) { y[k].x = acc ? y[k].x : own[k].x; y[k].y = acc ? y[k].y : own[k].y; }   // :261
     const double pnew = acc ? p1 : p0;                                   // :262
-    double2* out = reinterpret_cast<double2*>(a.pout + (size_t)me * (size_t)ld);
+    double2* out = reinterpret_cast<double2*>(f.pout + (size_t)me * (size_t)ld);
 #pragma unroll
     for (int k = 0; k < K; ++k) if (cv[k]) out[k * L + j] = y[k];       // (elements past ndim of the last chunk: 0 in, 0 out -- the lane-striped densities ignore them)
     if (j == 0) {
@@ -258,7 +358,7 @@ __device__ __forceinline__ void generation_group_body(const GenerationArgs& a)
         if (acc && count) a.naccept[me] += 1u;                           // :265
     }
     if (sample) {                                                        // :268-271
-        const size_t srow = (size_t)sch.slot * (2u * (size_t)a.h) + me;
+        const size_t srow = (size_t)sch.slot * (2u * (size_t)f.h) + me;
         if (a.chain != nullptr) {
             double2* dst = reinterpret_cast<double2*>(a.chain + srow * (size_t)ld);
 #pragma unroll
@@ -279,9 +379,9 @@ __device__ __forceinline__ void generation_group_body(const GenerationArgs& a)
 }
 
 template <class Dens, int L, int K>
-__global__ __launch_bounds__(256) void generation_group(const GenerationArgs a)
+__global__ __launch_bounds__(256) void generation_group(KMC_GEN_FRONT_PARAMS, const GenerationArgs a)
 {
-    generation_group_body<Dens, L, K>(a);
+    generation_group_body<Dens, L, K>(KMC_GEN_FRONT_PACK, a);
 }
 
 }  // namespace kmc

@@ -13,3 +13,10 @@ GenerationFn generation_group_gaussian_iso(int L, int K) { return generation_gro
 MetropolisFn metropolis_gaussian_iso(int ndim) { return metropolis_lookup<GaussianIso>(ndim); }
 MetropolisTabledFn metropolis_tabled_gaussian_iso(int ndim) { return metropolis_tabled_lookup<GaussianIso>(ndim); }
 }  // namespace kmc
+
+#ifdef KMC_PROBE   // diagnostic build only (scripts/probe_generation.py): the stamps of THIS translation unit's kernels (generation_lane)
+extern "C" __attribute__((visibility("default"))) int kmc_probe_read_generation(void* out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(kmc::g_probe), sizeof(kmc::g_probe));
+}
+#endif

@@ -246,12 +246,19 @@ GenerationArgs make_generation_args(const kmc_sampler* s, int from, bool graph_m
     return a;
 }
 
+static_assert(offsetof(GenerationLaunch, a) == 56 && offsetof(GenerationFront, gen) == 52, "kernarg layout of the generation kernels");
+
 hipError_t launch_generation(const kmc_sampler* s, int from, bool graph_mode, int64_t gen_offset)
 {
     const GenerationArgs a = make_generation_args(s, from, graph_mode, gen_offset);
+    // the head of the chain among the preloaded kernel parameters (GenerationFront)
+    const GenerationFront f{a.sched, a.pin, a.lin, a.pout, a.dc.seed_lo, a.dc.seed_hi, a.h, a.nb, a.ld, (uint32_t)a.sched_inline.gen};
     const unsigned tpb = s->fused_L > 0 ? (unsigned)s->fused_tpb : (unsigned)kGenerationTPB;
-    if (s->user) return launch_module(s->uk.generation, 2u * a.nb, tpb, s->stream, a);
-    hipLaunchKernelGGL(s->generation_kernel, dim3(2u * a.nb), dim3(tpb), 0, s->stream, a);
+    if (s->user) {
+        const GenerationLaunch la{f, a};
+        return launch_module(s->uk.generation, 2u * a.nb, tpb, s->stream, la);
+    }
+    hipLaunchKernelGGL(s->generation_kernel, dim3(2u * a.nb), dim3(tpb), 0, s->stream, f.sched, f.pin, f.lin, f.pout, f.seed_lo, f.seed_hi, f.h, f.nb, f.ld, f.gen, a);
     return hipGetLastError();
 }
 

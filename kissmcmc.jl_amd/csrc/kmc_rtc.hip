@@ -568,11 +568,11 @@ kmc_status compile_user(kmc_user_density* ud, bool with_vec, int L, int K, int i
         src << "extern \"C\" __global__ __launch_bounds__(" << island_S << ") void kmc_user_island(const kmc::IslandArgs a) { kmc::island_epoch_body<UD, "
             << island_S << ", " << resident_K << ", " << (resident_ragged ? "true" : "false") << ">(a); }\n";
     if (generation_nd > 0)          // one launch per generation, one walker per lane (kmc_generation.hpp): the density element by element / the body as written
-        src << "extern \"C\" __global__ __launch_bounds__(" << kGenerationTPB << ") void kmc_user_generation(const kmc::GenerationArgs a) { kmc::generation_lane_body<UD, "
-            << generation_nd << ">(a); }\n";
+        src << "extern \"C\" __global__ __launch_bounds__(" << kGenerationTPB << ") void kmc_user_generation(KMC_GEN_FRONT_PARAMS, const kmc::GenerationArgs a) { kmc::generation_lane_body<UD, "
+            << generation_nd << ">(KMC_GEN_FRONT_PACK, a); }\n";
     if (generation_nd < 0)          // ... rows lane-striped (L = -generation_nd / 100, K = -generation_nd % 100): term / pair densities, bodies recognised as sums
-        src << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_generation(const kmc::GenerationArgs a) { kmc::generation_group_body<UDV, "
-            << (-generation_nd) / 100 << ", " << (-generation_nd) % 100 << ">(a); }\n";
+        src << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_generation(KMC_GEN_FRONT_PARAMS, const kmc::GenerationArgs a) { kmc::generation_group_body<UDV, "
+            << (-generation_nd) / 100 << ", " << (-generation_nd) % 100 << ">(KMC_GEN_FRONT_PACK, a); }\n";
     const std::string text = src.str();
 
     const char* headers[4] = {h_ker.c_str(), h_dev.c_str(), h_isl.c_str(), h_gen.c_str()};

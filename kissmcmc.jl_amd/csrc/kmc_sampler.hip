@@ -241,9 +241,9 @@ kmc_status check_sum_form(kmc_sampler* s)
 namespace {
 // One launch per generation (kmc_generation.hpp) -- the dependent-launch boundary, which is most of a half-step for small states, is paid
 // once per generation instead of twice.  0: no; 1: one walker per lane (ndim <= 8); 2: rows lane-striped like the vector kernels (longer
-// rows; lane-striped densities).  Measured against the two-launch kernels (profiles/r04_generation_map.txt): short rows 1.3-1.75 x ahead up
-// to 32 768 walkers (1.1-1.2 x at ndim 8 up to 16 384), 1.25-1.4 x at 65 536 walkers of one or two doubles, behind beyond that; longer rows
-// 1.07-1.45 x ahead while the state stays within 2 MiB (the kernel reads 2.5 x the rows and writes every row), behind beyond.
+// rows; lane-striped densities).  Measured against the two-launch kernels (profiles/r04_generation_map.txt): short rows 1.3-1.9 x ahead up
+// to 32 768 walkers, 1.25-1.4 x at 65 536 walkers of one or two doubles, behind beyond that; longer rows 1.1-1.55 x ahead while the state
+// stays within ~2.3 MiB (the kernel reads 2.5 x the rows and writes every row), behind beyond.
 // KMC_DEBUG=fused=0 / =1: never / wherever a kernel exists.  (Resident and island mode are decided by the caller.)
 int generation_wanted(const kmc_sampler* s)
 {
@@ -251,12 +251,20 @@ int generation_wanted(const kmc_sampler* s)
     if (c.density == KMC_HOST_DENSITY || s->f32 || s->nblob != 0 || c.shard_count != 1 || c.deal_count != 0 ||
         (c.flags & (KMC_P2P | KMC_NO_GRAPH | KMC_ISLANDS)) || std::getenv("KMC_PLAN") != nullptr)      // (KMC_PLAN: a geometry of the two-launch kernels was asked for)
         return 0;
-    const int kind = c.ndim <= 8 ? 1 : 2;
-    if (kind == 2 && (!s->plan.vec || (s->user && s->user->is_body && !s->user->sep))) return 0;
+    // lane-striped forms need a lane-striped density (menu, term / pair, a body recognised as a sum) and the vector kernels' plan
+    const bool striped = s->plan.vec && !(s->user && s->user->is_body && !s->user->sep);
+    // ndim <= 8: one walker per lane -- or, from 5 dimensions on, the row over a quad (generation_group<4, 1>: the quad shares the draws' four
+    // logarithms; measured 1.65 against 1.95 us per half-step at 4 096 x 8, 1.65 against 1.76 at 4 096 x 6, behind at 16 384 x 6)
+    int kind = c.ndim <= 8 ? 1 : 2;
+    if (kind == 2 && !striped) return 0;
     std::string forced;
-    if (debug_opt("fused", &forced)) return forced != "0" ? kind : 0;
+    const bool have = debug_opt("fused", &forced);
+    if (have && forced == "0") return 0;
+    if (kind == 1 && c.ndim >= 5 && striped && forced != "lane" && (have || c.nwalkers <= (s->ld == 8 ? 32768 : 8192))) kind = 3;
+    if (have) return kind;                                   // (=1 / =lane: wherever a kernel exists; =lane keeps short rows one walker per lane)
+    if (kind == 3) return 3;
     if (kind == 1) return ((c.nwalkers <= 32768 && c.nwalkers * s->ld <= 196608) || (c.nwalkers <= 65536 && s->ld <= 2)) ? 1 : 0;
-    return c.nwalkers * s->ld <= 262144 ? 2 : 0;
+    return c.nwalkers * s->ld <= 300000 ? 2 : 0;            // (about 2.3 MiB of state)
 }
 }  // namespace
 
@@ -332,7 +340,7 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         auto load = [&]() {
             set_offline_compiler_hint(s->h_loc >= 8192 && rK == 0 && iS == 0);
             const kmc_status lst = load_user(s->user, s->plan.vec, s->plan.L, s->plan.K, s->plan.ITER, s->plan.ragged, &s->uk, rcode, 4 * rK != cfg->ndim, iS, s->f32,
-                                             cfg->ndim, (cfg->flags & KMC_P2P) != 0, (rK != 0 || iS != 0) ? 0 : generation_wanted(s) == 1 ? (int)cfg->ndim : generation_wanted(s) == 2 ? -(100 * s->plan.L + s->plan.K) : 0);
+                                             cfg->ndim, (cfg->flags & KMC_P2P) != 0, (rK != 0 || iS != 0) ? 0 : generation_wanted(s) == 1 ? (int)cfg->ndim : generation_wanted(s) == 2 ? -(100 * s->plan.L + s->plan.K) : generation_wanted(s) == 3 ? -401 : 0);
             set_offline_compiler_hint(false);
             return lst;
         };
@@ -433,12 +441,13 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
     if (const int kind = (!s->islands && !s->resident) ? generation_wanted(s) : 0) {          // one launch per generation (see generation_wanted)
         if (s->user) s->fused = s->uk.generation != nullptr;
         else {
-            s->generation_kernel = kind == 1 ? generation_fn(cfg->density, (int)cfg->ndim) : generation_group_fn(cfg->density, s->plan.L, s->plan.K);
+            s->generation_kernel = kind == 1 ? generation_fn(cfg->density, (int)cfg->ndim) : kind == 3 ? generation_group_fn(cfg->density, 4, 1)
+                                                                                             : generation_group_fn(cfg->density, s->plan.L, s->plan.K);
             s->fused = s->generation_kernel != nullptr;
         }
         if (s->fused) {
             s->launch_mode = 1;
-            s->fused_L = kind == 1 ? 0 : s->plan.L;
+            s->fused_L = kind == 1 ? 0 : kind == 3 ? 4 : s->plan.L;
             // lane-striped: one wave per workgroup while the half's waves fit the chip's SIMDs about once, four beyond (workgroup dispatch rate)
             s->fused_tpb = (kind == 2 && s->h * s->plan.L > 64 * 512) ? 256 : 64;
             s->nislands = cfg->nwalkers;                  // per-walker moment sums [nwalkers][ld], within [nislands][4 island_K] (kmc_sampler_get_moments)

@@ -14,7 +14,7 @@ using LogpdfFn = void (*)(const LogpdfArgs);
 using FlushFn = void (*)(const FlushArgs);
 using IslandFn = void (*)(const IslandArgs);
 using ResidentFn = void (*)(const ResidentArgs);
-using GenerationFn = void (*)(const GenerationArgs);
+using GenerationFn = void (*)(KMC_GEN_FRONT_TYPES, const GenerationArgs);
 using InitBallFn = void (*)(const InitBallArgs);
 using MetropolisFn = void (*)(const MetropolisArgs);
 using MetropolisTabledFn = void (*)(const MetropolisArgs, const double*, int);

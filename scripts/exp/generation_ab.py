@@ -2,7 +2,10 @@ import os, sys
 sys.path.insert(0, '.')
 import numpy as np
 import kissmcmc_jl_amd as kmc
-for nw, nd in ((4096, 1), (4096, 4), (16384, 4), (32768, 4), (65536, 2), (4096, 8), (4096, 12), (4096, 32), (8192, 32), (2050, 128)):
+SHAPES = ((4096, 1), (4096, 4), (16384, 4), (32768, 4), (65536, 2), (4096, 8), (4096, 12), (4096, 32), (8192, 32), (2050, 128))
+if len(sys.argv) > 1:           # e.g. 4096x6,8192x8
+    SHAPES = tuple(tuple(int(v) for v in item.split("x")) for item in sys.argv[1].split(","))
+for nw, nd in SHAPES:
     G = 8192 if nw <= 16384 else 2048
     best = 1e9
     for rep in range(3):

@@ -37,6 +37,17 @@ def test_one_launch_per_generation_equals_the_oracle(kmc, oracle, kmc_debug, nam
     _compare(ref, got)
 
 
+@pytest.mark.parametrize("name,nw,nd", [("gauss", 4096, 7), ("gauss", 4096, 8), ("gauss_shift", 2500, 5), ("rosen", 2600, 6), ("expo", 3000, 5)])
+def test_rows_of_five_to_eight_doubles_one_walker_per_lane(kmc, oracle, kmc_debug, name, nw, nd):
+    """Rows of 5 ... 8 doubles run striped over a quad by default (generation_group<4, 1>: the cases of the test above); KMC_DEBUG=fused=lane
+    keeps them one walker per lane -- the form bodies with real coupling take at these row lengths."""
+    kmc_debug.set("fused", "lane")
+    pdf = _densities(kmc, oracle)[name][0]
+    assert "generation_lane" in _mode(kmc, pdf, nw, nd)
+    ref, got = _run_both(kmc, oracle, name, nw, nd, 70, 13, 3, 11)
+    _compare(ref, got)
+
+
 @pytest.mark.parametrize("G,nburn,nthin", [(1, 0, 1), (2, 1, 1), (63, 0, 1), (64, 64, 1), (65, 10, 7), (129, 0, 2), (200, 199, 1)])
 def test_run_lengths_and_schedules(kmc, oracle, G, nburn, nthin):
     """Odd and even numbers of generations (the state ends in either copy and is moved back), whole chunks and tails, burn-in up to
@@ -101,6 +112,8 @@ def test_what_keeps_the_two_launch_kernels(kmc):
     assert "one launch per generation" not in _mode(kmc, pdf, 262144, 4)
     assert "one launch per generation" not in _mode(kmc, pdf, 16384, 32)
     assert "generation_lane" in _mode(kmc, pdf, 32768, 4) and "generation_group" in _mode(kmc, pdf, 8192, 32)
+    assert "generation_group L=4 K=1" in _mode(kmc, pdf, 4096, 8) and "generation_group L=4 K=1" in _mode(kmc, pdf, 8192, 5)
+    assert "generation_lane" in _mode(kmc, pdf, 16384, 6) and "generation_lane" in _mode(kmc, pdf, 4096, 4)
     assert "resident" in _mode(kmc, pdf, 2048, 4)
     with kmc.Sampler(pdf, 4096, 4, 10, 0, 1, 2.0, 1) as s:
         s.set_positions(_theta0("gauss", 4096, 4, 1))
