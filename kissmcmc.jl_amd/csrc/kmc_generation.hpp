@@ -203,8 +203,9 @@ __device__ __forceinline__ void generation_lane_body(const GenerationFront& f, c
     KMC_STAMP(6);                                                        // my move is done
     gen_store_row<ND>(f.pout + (size_t)me * ld, y);
     a.lout[me] = pnew;
-    if (acc && count) a.naccept[me] += 1u;                               // :265 (counted after burn-in only, :285-288; loading the counter early, with
-                                                                         //  the rows, measured SLOWER: its address arrives with the argument struct, after the preloaded head)
+    // :265 (counted after burn-in only, :285-288).  A no-return atomic: nothing at the wave's end waits for the counter's old value (the
+    // owner is the only one who adds; loading it early, with the rows, measured SLOWER -- its address arrives with the argument struct)
+    if (acc && count) (void)__hip_atomic_fetch_add(&a.naccept[me], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (sample) {                                                        // the walker's state after its update, accepted or not (:268-271)
         const size_t row = (size_t)sch.slot * (2u * (size_t)f.h) + me;
         if (a.chain != nullptr) gen_store_row<ND, true>(a.chain + row * ld, y);
@@ -355,7 +356,7 @@ __device__ __forceinline__ void generation_group_body(const GenerationFront& f, 
     for (int k = 0; k < K; ++k) if (cv[k]) out[k * L + j] = y[k];       // (elements past ndim of the last chunk: 0 in, 0 out -- the lane-striped densities ignore them)
     if (j == 0) {
         a.lout[me] = pnew;
-        if (acc && count) a.naccept[me] += 1u;                           // :265
+        if (acc && count) (void)__hip_atomic_fetch_add(&a.naccept[me], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // :265 (see generation_lane_body)
     }
     if (sample) {                                                        // :268-271
         const size_t srow = (size_t)sch.slot * (2u * (size_t)f.h) + me;
