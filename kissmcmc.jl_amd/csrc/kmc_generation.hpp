@@ -23,7 +23,8 @@
 
 namespace kmc {
 
-constexpr int kGenerationTPB = 64;          // one wave per workgroup: a mid-size ensemble spreads over as many CUs as it has waves
+constexpr int kGenerationTPB = 256;         // most threads per workgroup (the host launches one wave per workgroup while the waves are few: a mid-size ensemble
+                                            //   then spreads over as many CUs as it has waves)
 
 struct GenerationArgs {
     const double*     pin;          // [nwalkers][ld]   state before the generation
@@ -111,7 +112,7 @@ __device__ __forceinline__ void generation_lane_body(const GenerationFront& f, c
     static_assert(BlobTrait<Dens>::n == 0, "blobs: the multi-launch kernels");
     KMC_STAMP(0);                                                        // (-DKMC_PROBE builds only: scripts/probe_generation.py) wave entry
     const bool second = blockIdx.x < f.nb;
-    const uint32_t i = (second ? blockIdx.x : blockIdx.x - f.nb) * (uint32_t)kGenerationTPB + threadIdx.x;
+    const uint32_t i = (second ? blockIdx.x : blockIdx.x - f.nb) * blockDim.x + threadIdx.x;
     if (i >= f.h) return;
     const SchedEntry sch = generation_schedule(f, a);
     const DrawConsts dc = generation_draw_consts(f, a);
@@ -225,7 +226,7 @@ __device__ __forceinline__ void generation_lane_body(const GenerationFront& f, c
         KMC_STAMP_READ(st[0], 80, 81); KMC_STAMP_READ(st[1], 82, 83); KMC_STAMP_READ(st[2], 84, 85); KMC_STAMP_READ(st[3], 86, 87);
         KMC_STAMP_READ(st[4], 88, 89); KMC_STAMP_READ(st[5], 90, 91); KMC_STAMP_READ(st[6], 92, 93); KMC_STAMP_READ(st[7], 94, 95);
         if (!second) st[3] = st[2];                                      // (first half: no second Philox block)
-        if (threadIdx.x == 0 && blockIdx.x < 8192) for (int q = 0; q < 8; ++q) g_probe[sch.gen & 1][blockIdx.x][q] = st[q];   // [generation parity][workgroup = wave]
+        if (threadIdx.x == 0 && blockIdx.x < 8192) for (int q = 0; q < 8; ++q) g_probe[sch.gen & 1][blockIdx.x][q] = st[q];   // [generation parity][workgroup (its first wave)]
     }
 #endif
 }

@@ -235,7 +235,7 @@ GenerationArgs make_generation_args(const kmc_sampler* s, int from, bool graph_m
     a.dc = make_args(s, 0, false, 0).dc;
     a.dp = s->dp;
     a.h = (uint32_t)s->h;
-    const int64_t per_wg = s->fused_L > 0 ? s->fused_tpb / s->fused_L : kGenerationTPB;       // walkers per workgroup
+    const int64_t per_wg = s->fused_L > 0 ? s->fused_tpb / s->fused_L : s->fused_tpb;       // walkers per workgroup
     a.nb = (uint32_t)((s->h + per_wg - 1) / per_wg);
     a.ld = (int32_t)s->ld;
     a.ndim = (int32_t)s->cfg.ndim;
@@ -253,7 +253,7 @@ hipError_t launch_generation(const kmc_sampler* s, int from, bool graph_mode, in
     const GenerationArgs a = make_generation_args(s, from, graph_mode, gen_offset);
     // the head of the chain among the preloaded kernel parameters (GenerationFront)
     const GenerationFront f{a.sched, a.pin, a.lin, a.pout, a.dc.seed_lo, a.dc.seed_hi, a.h, a.nb, a.ld, (uint32_t)a.sched_inline.gen};
-    const unsigned tpb = s->fused_L > 0 ? (unsigned)s->fused_tpb : (unsigned)kGenerationTPB;
+    const unsigned tpb = (unsigned)s->fused_tpb;
     if (s->user) {
         const GenerationLaunch la{f, a};
         return launch_module(s->uk.generation, 2u * a.nb, tpb, s->stream, la);

@@ -448,8 +448,10 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         if (s->fused) {
             s->launch_mode = 1;
             s->fused_L = kind == 1 ? 0 : kind == 3 ? 4 : s->plan.L;
-            // lane-striped: one wave per workgroup while the half's waves fit the chip's SIMDs about once, four beyond (workgroup dispatch rate)
-            s->fused_tpb = (kind == 2 && s->h * s->plan.L > 64 * 512) ? 256 : 64;
+            // one wave per workgroup (measured best at every size for one walker per lane, `profiles/r04_generation_variants_ab.txt`); lane-striped:
+            // two once the half's waves exceed the chip's SIMDs about once
+            s->fused_tpb = (kind == 2 && s->h * s->plan.L > 64 * 512) ? 128 : 64;
+            { const long v = debug_opt_long("gen-tpb", 0); if (v == 64 || v == 128 || v == 256) s->fused_tpb = (int)v; }      // (A/B)
             s->nislands = cfg->nwalkers;                  // per-walker moment sums [nwalkers][ld], within [nislands][4 island_K] (kmc_sampler_get_moments)
             s->island_K = (int)((s->ld + 3) / 4);
         }
@@ -793,7 +795,7 @@ KMC_EXPORT kmc_status kmc_sampler_describe(const kmc_sampler* s, char* buf, int6
     else if (s->fused) {
         if (s->fused_L == 0)
             o << "one launch per generation (exact): generation_lane ND=" << s->cfg.ndim << ", one walker per lane, second-half walkers recompute their partner's first-half move, grid "
-              << 2 * ((s->h + kGenerationTPB - 1) / kGenerationTPB) << " x " << kGenerationTPB << ", hipGraph replay of 64 generations";
+              << 2 * ((s->h + s->fused_tpb - 1) / s->fused_tpb) << " x " << s->fused_tpb << ", hipGraph replay of 64 generations";
         else
             o << "one launch per generation (exact): generation_group L=" << s->fused_L << " K=" << s->plan.K << ", rows lane-striped, second-half walkers recompute their partner's first-half move, grid "
               << 2 * ((s->h + s->fused_tpb / s->fused_L - 1) / (s->fused_tpb / s->fused_L)) << " x " << s->fused_tpb << ", hipGraph replay of 64 generations";
