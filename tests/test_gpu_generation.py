@@ -281,3 +281,27 @@ def test_two_launch_kernels_on_the_shapes_that_default_to_one(kmc, oracle, kmc_d
     assert "one launch per generation" not in _mode(kmc, pdf, nw, nd)
     ref, got = _run_both(kmc, oracle, name, nw, nd, 70, 13, 3, 11)
     _compare(ref, got)
+
+
+@pytest.mark.parametrize("nw,nd", [(4096, 4), (8192, 7), (4096, 32)])
+def test_long_run_equals_the_two_launch_kernels(kmc, kmc_debug, nw, nd):
+    """50 000 generations (780 graph replays + a tail) in each of the three forms -- one walker per lane, rows over a quad, rows lane-striped --
+    against the same run on the two-launch kernels: positions and acceptance counters (no-return atomic adds in the new kernels) bit for bit,
+    moments to rounding."""
+    G, seed = 50007, 77
+    th = _theta0("gauss", nw, nd, 12)
+    out = {}
+    for label in ("one", "two"):
+        if label == "two":
+            kmc_debug.set("fused", 0)
+        with kmc.Sampler(kmc.GaussianIso(), nw, nd, G, 1000, 1, 2.0, seed, moments=True) as s:
+            assert ("one launch per generation" in s.describe()) == (label == "one")
+            s.set_positions(th)
+            s.run(G)
+            s.sync()
+            out[label] = (s.positions(), s.naccept(), s.moments())
+    np.testing.assert_array_equal(out["one"][0], out["two"][0])
+    np.testing.assert_array_equal(out["one"][1], out["two"][1])
+    assert out["one"][2][2] == out["two"][2][2]
+    np.testing.assert_allclose(out["one"][2][0], out["two"][2][0], rtol=1e-10, atol=1e-6)
+    np.testing.assert_allclose(out["one"][2][1], out["two"][2][1], rtol=1e-10)
