@@ -451,7 +451,6 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
             // one wave per workgroup (measured best at every size for one walker per lane, `profiles/r04_generation_variants_ab.txt`); lane-striped:
             // two once the half's waves exceed the chip's SIMDs about once
             s->fused_tpb = (kind == 2 && s->h * s->plan.L > 64 * 512) ? 128 : 64;
-            { const long v = debug_opt_long("gen-tpb", 0); if (v == 64 || v == 128 || v == 256) s->fused_tpb = (int)v; }      // (A/B)
             s->nislands = cfg->nwalkers;                  // per-walker moment sums [nwalkers][ld], within [nislands][4 island_K] (kmc_sampler_get_moments)
             s->island_K = (int)((s->ld + 3) / 4);
         }
