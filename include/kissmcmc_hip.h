@@ -225,6 +225,11 @@ kmc_status  kmc_device_free_bytes(int device, uint64_t* free_bytes, uint64_t* to
  * than sampling (the README call: 1.7 ms -> 1.0 ms).  This returns every block the cache holds to the device; kmc_device_free_bytes
  * counts held blocks as free. */
 void        kmc_device_cache_release(void);
+/* Touch every page of a host buffer (one read-modify-write of a byte per 4 KiB, up to `nthreads` threads; contents unchanged): the
+ * reference returns per-walker vectors that grew during the run (src/samplers.jl:269-271); a drop-in host allocates the dense output
+ * arrays BEFORE the run and has them faulted in by a helper thread while the device samples, so that the chain read-out afterwards
+ * copies into resident pages (4 096 walkers x 4 doubles x 1 000 samples: read-out 15.6 -> ~5 ms).  No device involved. */
+void        kmc_host_prefault(void* buffer, uint64_t nbytes, int nthreads);
 const char* kmc_last_error(void);
 const char* kmc_status_string(kmc_status st);
 

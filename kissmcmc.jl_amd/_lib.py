@@ -47,7 +47,7 @@ SYMBOLS = [
     "kmc_sampler_rccl_capture", "kmc_sampler_rccl_set_capture", "kmc_rccl_version", "kmc_device_free_bytes",
     "kmc_sampler_launch_mode", "kmc_updated_budget", "kmc_set_updated_budget_mb", "kmc_debug_accept_terms",
     "kmc_user_density_create_body_blob", "kmc_user_density_nblob", "kmc_logpdf_blob_eval_host", "kmc_sampler_get_blobs",
-    "kmc_device_cache_release", "kmc_has_p2p_experimental", "kmc_user_density_is_separable",
+    "kmc_device_cache_release", "kmc_has_p2p_experimental", "kmc_user_density_is_separable", "kmc_host_prefault",
 ]
 
 
@@ -244,6 +244,8 @@ def lib() -> C.CDLL:
     L.kmc_has_p2p_experimental.argtypes = []
     L.kmc_device_cache_release.argtypes = []
     L.kmc_device_cache_release.restype = None
+    L.kmc_host_prefault.argtypes = [C.c_void_p, C.c_uint64, C.c_int]
+    L.kmc_host_prefault.restype = None
     L.kmc_sampler_launch_mode.restype = C.c_int
     L.kmc_sampler_launch_mode.argtypes = [vp, C.POINTER(C.c_int)]
     L.kmc_updated_budget.restype = None

@@ -155,9 +155,21 @@ def emcee(pdf, theta0s, niter: int = 10 ** 5, nburnin=None, nthin: int = 1, a_sc
                         reduce_blob(blobs[w], blob0s[w])       # :270
 
             pdf.on_accepted = on_accepted
+        # the dense output arrays (:219-221) exist before the run and are faulted in by a helper thread while the device samples: a fresh
+        # allocation's pages are otherwise created one fault at a time by the read-out's copy threads (4 096 x 4, 1 000 samples per walker:
+        # 15.6 ms of read-out after 6.4 ms of sampling)
+        out_arrays = warm = None
+        if not stream_chain and nsamples_walker > 0 and nwalkers * nsamples_walker * (ndim + 1) * 8 >= (8 << 20):
+            import threading
+            out_arrays = (np.empty((nwalkers, nsamples_walker, ndim)), np.empty((nwalkers, nsamples_walker)))
+            L = _lib.lib()
+            warm = threading.Thread(target=lambda: [L.kmc_host_prefault(a.ctypes.data, a.nbytes, 4) for a in out_arrays], daemon=True)
+            warm.start()
         try:
             _run_generations(s, niter, nwalkers, niter_walker, nburnin_walker, use_progress_meter)
-            thetas, logdensities = s.chain(logp=True, by_walker=True)     # [walker][sample][dim], [walker][sample]: :219-221
+            if warm is not None:
+                warm.join()
+            thetas, logdensities = s.chain(logp=True, by_walker=True, out=out_arrays)     # [walker][sample][dim], [walker][sample]: :219-221
             accept_ratio = s.accept_ratio()
             if device_blobs:
                 series = s.blobs(by_walker=True)               # [walker][sample][m]: the walker's current blob at every stored sample (:270)

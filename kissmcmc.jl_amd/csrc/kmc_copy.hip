@@ -1,6 +1,7 @@
 // kmc_copy.hip -- host <-> device movement: blocking copies staged through page-locked bounce buffers (kmc_host.hpp: copy_sync),
 // the walkers' rows in and out, and sample storage (reference src/samplers.jl:268-272): the streamed chain ring
 // (KMC_STREAM_CHAIN) and the read-out of a device chain, sample-major or in the reference's thetas[w][k] order.
+#include <chrono>
 #include <pthread.h>
 
 #include <algorithm>
@@ -223,6 +224,26 @@ hipError_t download_rows(const kmc_sampler* s, double* dst_host, const double* s
     return hipSuccess;
 }
 
+// the tiled transposition [sample][walker][ld] -> [walker][sample][nd] (kmc_kernels.hpp: chain_by_walker), walkers [w0, w0 + nw), K samples
+hipError_t launch_by_walker(const void* src, bool is_float, double* dst, int64_t nl, int64_t ld, int64_t nd, int64_t K, int64_t w0, int64_t nw,
+                            int64_t dst_stride, hipStream_t st)
+{
+    if (K <= 0 || nw <= 0) return hipSuccess;
+    const ByWalkerTile t = by_walker_tile((int32_t)nd);
+    const int64_t gx = (nw + t.TW - 1) / t.TW, gy = (K + t.TK - 1) / t.TK, gz = (nd + t.NC - 1) / t.NC;
+    // (gridDim.y <= 65535: runs of more samples go in slices of samples -- same kernel, the destination shifted)
+    for (int64_t y0 = 0; y0 < gy; y0 += 65535) {
+        const int64_t ny = std::min<int64_t>(65535, gy - y0), ks = y0 * t.TK, kn = std::min<int64_t>(K - ks, ny * t.TK);
+        if (is_float)
+            hipLaunchKernelGGL(chain_by_walker<float>, dim3((unsigned)gx, (unsigned)ny, (unsigned)gz), dim3(256), t.lds_bytes, st, static_cast<const float*>(src) + ks * nl * ld,
+                               dst + ks * nd, nl, (int32_t)ld, (int32_t)nd, kn, w0, nw, dst_stride, t.TW, t.TK, t.NC);
+        else
+            hipLaunchKernelGGL(chain_by_walker<double>, dim3((unsigned)gx, (unsigned)ny, (unsigned)gz), dim3(256), t.lds_bytes, st, static_cast<const double*>(src) + ks * nl * ld,
+                               dst + ks * nd, nl, (int32_t)ld, (int32_t)nd, kn, w0, nw, dst_stride, t.TW, t.TK, t.NC);
+    }
+    return hipGetLastError();
+}
+
 // ---- KMC_STREAM_CHAIN ---------------------------------------------------------------------------------------
 int64_t samples_done_at(const kmc_sampler* s, int64_t generation)
 {
@@ -245,9 +266,7 @@ kmc_status chain_copy_range(kmc_sampler* s, int64_t k0, int64_t k1)
         // never reproduced or explained: removed in round 4, profiles/NOTES.md.)
         const int64_t ns = s->nsamples;
         if (s->d_chain && s->dst_chain) {
-            hipLaunchKernelGGL(chain_by_walker<double>, dim3((unsigned)std::min<size_t>(nl, 65535u), 1), dim3(256), 0, s->copy_stream, s->d_chain + slot0 * nl * ld,
-                               s->bw_scratch, (int64_t)nl, (int32_t)ld, (int32_t)nd, (int64_t)n, (int64_t)0, (int64_t)nl, (int64_t)(n * nd));
-            HIP_TRY(hipGetLastError());
+            HIP_TRY(launch_by_walker(s->d_chain + slot0 * nl * ld, false, s->bw_scratch, (int64_t)nl, (int64_t)ld, (int64_t)nd, (int64_t)n, 0, (int64_t)nl, (int64_t)(n * nd), s->copy_stream));
             if (s->dst_chain_reg) {
                 HIP_TRY(hipMemcpy2DAsync(s->dst_chain + (size_t)k0 * nd, (size_t)ns * nd * sizeof(double), s->bw_scratch, n * nd * sizeof(double),
                                          n * nd * sizeof(double), nl, hipMemcpyDeviceToHost, s->copy_stream));
@@ -262,9 +281,7 @@ kmc_status chain_copy_range(kmc_sampler* s, int64_t k0, int64_t k1)
             }
         }
         if (s->d_chain_logp && s->dst_logp) {
-            hipLaunchKernelGGL(chain_by_walker<double>, dim3((unsigned)std::min<size_t>(nl, 65535u), 1), dim3(256), 0, s->copy_stream, s->d_chain_logp + slot0 * nl,
-                               s->bw_scratch_logp, (int64_t)nl, (int32_t)1, (int32_t)1, (int64_t)n, (int64_t)0, (int64_t)nl, (int64_t)n);
-            HIP_TRY(hipGetLastError());
+            HIP_TRY(launch_by_walker(s->d_chain_logp + slot0 * nl, false, s->bw_scratch_logp, (int64_t)nl, 1, 1, (int64_t)n, 0, (int64_t)nl, (int64_t)n, s->copy_stream));
             if (s->dst_logp_reg) {
                 HIP_TRY(hipMemcpy2DAsync(s->dst_logp + (size_t)k0, (size_t)ns * sizeof(double), s->bw_scratch_logp, n * sizeof(double), n * sizeof(double), nl,
                                          hipMemcpyDeviceToHost, s->copy_stream));
@@ -428,21 +445,29 @@ kmc_status kmc_host::download_by_walker(const void* src, bool is_float, int64_t 
     if (wb < 1) wb = 1;
     if (wb > nl) wb = nl;
     double* tmp = nullptr;
+    const bool stats = debug_opt("readout-stats");
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const auto t0 = now();
     HIP_TRY(cache_alloc((void**)&tmp, (size_t)wb * per_walker));
+    const auto t1 = now();
+    double t_kernel = 0.0, t_copy = 0.0;
     hipError_t e = hipSuccess;
     for (int64_t w0 = 0; w0 < nl && e == hipSuccess; w0 += wb) {
+        const auto ta = now();
         const int64_t n = nl - w0 < wb ? nl - w0 : wb;
-        int64_t gy = (K * width + 255) / 256;
-        if (gy > 4096) gy = 4096;
-        if (is_float)
-            hipLaunchKernelGGL(chain_by_walker<float>, dim3((unsigned)n, (unsigned)gy), dim3(256), 0, st, static_cast<const float*>(src), tmp, nl, (int32_t)ld, (int32_t)width, K, w0, n, K * width);
-        else
-            hipLaunchKernelGGL(chain_by_walker<double>, dim3((unsigned)n, (unsigned)gy), dim3(256), 0, st, static_cast<const double*>(src), tmp, nl, (int32_t)ld, (int32_t)width, K, w0, n, K * width);
-        e = hipGetLastError();
+        e = launch_by_walker(src, is_float, tmp, nl, ld, width, K, w0, n, K * width, st);
+        if (stats) { (void)hipStreamSynchronize(st); t_kernel += ms(ta, now()); }
+        const auto tb = now();
         if (e == hipSuccess) e = copy_sync(dst_host + (size_t)w0 * (size_t)K * (size_t)width, tmp, (size_t)n * per_walker, hipMemcpyDeviceToHost, st);   // (waits: one scratch buffer)
+        t_copy += ms(tb, now());
     }
     if (e != hipSuccess) (void)hipStreamSynchronize(st);        // (every successful piece has waited already)
+    const auto t2 = now();
     cache_free(tmp);
+    if (stats)
+        std::fprintf(stderr, "[kissmcmc_hip] by-walker read-out of %.0f MB: scratch allocation %.2f ms, transposition %.2f ms, device-to-host copy %.2f ms, scratch release %.2f ms\n",
+                     (double)nl * (double)per_walker / 1e6, ms(t0, t1), t_kernel, t_copy, ms(t2, now()));
     HIP_TRY(e);
     return KMC_OK;
 }

@@ -8,6 +8,7 @@
 // logarithms from the kernels' own log_pos_normal), for a run of walkers of one step.  The kernels and the CPU oracle take
 // these two logarithms from different implementations (each < 1 ulp); tests/test_gpu_accept_margin.py measures the gap and
 // what it means for "identical accept decisions".
+#include <thread>
 #include <execinfo.h>
 #include <fcntl.h>
 #include <signal.h>
@@ -179,6 +180,28 @@ KMC_EXPORT void kmc_device_cache_release(void)
     }
     if (have) (void)hipSetDevice(cur);
     (void)hipGetLastError();
+}
+
+// Fault a host buffer in (include/kissmcmc_hip.h): a fresh allocation's pages are created one fault at a time by whoever writes
+// first -- after a run that is the chain read-out's copy threads, at 2-3 GB/s each; done here, by a helper thread of the caller's while
+// the device samples, it is off the call's critical path.
+KMC_EXPORT void kmc_host_prefault(void* buffer, uint64_t nbytes, int nthreads)
+{
+    if (!buffer || nbytes == 0) return;
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 16) nthreads = 16;
+    constexpr uint64_t kPage = 4096;
+    const uint64_t npages = (nbytes + kPage - 1) / kPage;
+    if ((uint64_t)nthreads > npages) nthreads = (int)npages;
+    auto work = [=](int t) {
+        volatile unsigned char* base = static_cast<volatile unsigned char*>(buffer);
+        const uint64_t p0 = npages * (uint64_t)t / (uint64_t)nthreads, p1 = npages * (uint64_t)(t + 1) / (uint64_t)nthreads;
+        for (uint64_t pg = p0; pg < p1; ++pg) { const uint64_t off = pg * kPage; base[off] = base[off]; }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nthreads; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto& x : th) x.join();
 }
 
 // free / total bytes of a device's memory (hipMemGetInfo), for callers that decide between a device chain and a streamed one

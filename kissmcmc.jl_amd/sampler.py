@@ -362,11 +362,12 @@ class Sampler:
         _lib.check(self._L.kmc_sampler_get_blobs(self._h, _dp(out), None, 0))
         return out
 
-    def chain(self, logp: bool = True, by_walker: bool = False):
+    def chain(self, logp: bool = True, by_walker: bool = False, out=None):
         """``(chain [nsamples_done, nlocal, ndim], chain_logp [nsamples_done, nlocal] | None)``; with ``by_walker`` in the
         reference's order, ``thetas[w][k]`` (``src/samplers.jl:219-221``): ``[nlocal, nsamples_done, ndim]`` and
         ``[nlocal, nsamples_done]``, transposed on the device (``kmc_sampler_get_chain_by_walker``; a streamed chain is
-        reordered on the host)."""
+        reordered on the host).  ``out=(chain, chain_logp)``: C-contiguous float64 arrays of exactly those shapes to fill (by-walker
+        read-out of a device chain) -- a caller that allocated and faulted them in while the device was sampling (``api.emcee``)."""
         ns = self.nsamples
         post = self.generation - self.cfg.nburnin
         done = 0 if post <= 0 else min(ns, post // self.cfg.nthin)
@@ -386,10 +387,18 @@ class Sampler:
                 lp = None if lp is None else np.ascontiguousarray(lp.T)
             return ch, lp
         if by_walker:
-            ch = np.empty((self.nlocal, done, self.ndim))
-            lp = np.empty((self.nlocal, done)) if logp else None
+            ch = lp = None
+            if out is not None:
+                ch, lp = out
+                ok = (isinstance(ch, np.ndarray) and ch.dtype == np.float64 and ch.flags.c_contiguous and ch.shape == (self.nlocal, done, self.ndim) and
+                      (not logp or (isinstance(lp, np.ndarray) and lp.dtype == np.float64 and lp.flags.c_contiguous and lp.shape == (self.nlocal, done))))
+                if not ok:
+                    raise ValueError("out: C-contiguous float64 arrays of shapes (nlocal, samples_done, ndim) and (nlocal, samples_done)")
+            else:
+                ch = np.empty((self.nlocal, done, self.ndim))
+                lp = np.empty((self.nlocal, done)) if logp else None
             _lib.check(self._L.kmc_sampler_get_chain_by_walker(self._h, _dp(ch), _dp(lp) if logp else None))
-            return ch, lp
+            return ch, (lp if logp else None)
         ch = np.empty((done, self.nlocal, self.ndim))
         lp = np.empty((done, self.nlocal)) if logp else None
         _lib.check(self._L.kmc_sampler_get_chain(self._h, _dp(ch), _dp(lp) if logp else None))
