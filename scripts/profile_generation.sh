@@ -11,6 +11,11 @@ for cfg in MID4K MID16K; do
         if [ $mode = two ]; then export KMC_DEBUG=fused=0; else unset KMC_DEBUG; fi
         python3 $R/scripts/run_cfg.py $cfg 4096 1 > $OUT/${cfg}_${mode}_unprofiled.txt 2>&1
         rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${cfg}_${mode} -o t -- python3 $R/scripts/run_cfg.py $cfg 4096 1 > $OUT/${cfg}_${mode}_kt.txt 2>&1
+        for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" "l2 TCC_HIT_sum TCC_MISS_sum"; do       # (PMC: one group per pass, kernel trace only)
+            set -- $pass; name=$1; shift
+            rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/${cfg}_${mode}_$name -o t -- python3 $R/scripts/run_cfg.py $cfg 1024 1 > $OUT/${cfg}_${mode}_$name.txt 2>&1
+        done
+        find $OUT -path "*_fetch*" -name "*kernel_trace.csv" -delete; find $OUT -path "*_write*" -name "*kernel_trace.csv" -delete; find $OUT -path "*_l2*" -name "*kernel_trace.csv" -delete
         echo "$cfg $mode done"
     done
 done
