@@ -34,6 +34,20 @@ __device__ __forceinline__ void ld_sc(const double* p, double (&x)[ND])
     asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(t), "=&v"(u) : "v"(p) : "memory");
     x[0] = t.x; x[1] = t.y; x[2] = u.x; x[3] = u.y;
 }
+// `sc0` loads: this CU's L1 is bypassed, the XCD's L2 answers -- enough when every reader and writer sits on ONE XCD
+__device__ __forceinline__ void ld_sc0(const double* p, double (&x)[ND])
+{
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    v2d t, u;
+    asm volatile("global_load_dwordx4 %0, %2, off sc0\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(t), "=&v"(u) : "v"(p) : "memory");
+    x[0] = t.x; x[1] = t.y; x[2] = u.x; x[3] = u.y;
+}
+__device__ __forceinline__ double ld_sc0(const double* p)
+{
+    double v;
+    asm volatile("global_load_dwordx2 %0, %1, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
 __device__ __forceinline__ double ld_sc(const double* p)
 {
     double v;
@@ -52,7 +66,7 @@ __device__ __forceinline__ void st_wt(double* p, double a)
 }
 
 // dp.pad_ selects the coherence form (uniform): bit 0 `buffer_inv sc1` at wave entry (agent-scope invalidate of this CU's L1 and this XCD's
-// non-coherent L2 lines), bit 1 write-through stores, bit 2 `buffer_wbl2 sc1` + wait at the end, bit 3 row loads `sc1`
+// non-coherent L2 lines), bit 1 write-through stores, bit 2 `buffer_wbl2 sc1` + wait at the end, bit 3 row loads `sc1`, bit 4 row loads `sc0` (one-XCD queues)
 template <bool SC>
 __device__ __forceinline__ void body(const Args& a)
 {
@@ -65,7 +79,8 @@ __device__ __forceinline__ void body(const Args& a)
     const U4 bits = draw_bits(a.dc, (uint64_t)a.step, w);
     const uint32_t j = (1u - half) * a.h + draw_partner(a.dc, bits);
     double own[ND], oth[ND], p0;
-    if (SC || (mode & 8)) { ld_sc(a.pos + (size_t)j * ND, oth); ld_sc(a.pos + (size_t)w * ND, own); p0 = ld_sc(a.logp + w); }
+    if (mode & 16) { ld_sc0(a.pos + (size_t)j * ND, oth); ld_sc0(a.pos + (size_t)w * ND, own); p0 = ld_sc0(a.logp + w); }
+    else if (SC || (mode & 8)) { ld_sc(a.pos + (size_t)j * ND, oth); ld_sc(a.pos + (size_t)w * ND, own); p0 = ld_sc(a.logp + w); }
     else { ld_plain(a.pos + (size_t)j * ND, oth); ld_plain(a.pos + (size_t)w * ND, own); p0 = a.logp[w]; }
     const Draw dr = draw_finish(a.dc, bits);
     GaussianIso::Seq q;
@@ -88,3 +103,13 @@ __device__ __forceinline__ void body(const Args& a)
 
 extern "C" __global__ __launch_bounds__(64) void half_step_plain(const Args a) { body<false>(a); }
 extern "C" __global__ __launch_bounds__(64) void half_step_sc(const Args a) { body<true>(a); }
+
+// where does a workgroup run?  out[blockIdx.x] = XCC_ID (bits 3:0) | HW_ID << 8  (one-XCD queue masks: which mask bits are which XCD)
+extern "C" __global__ __launch_bounds__(64) void where_am_i(uint32_t* out)
+{
+    uint32_t xcc, hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    if (threadIdx.x == 0) out[blockIdx.x] = (xcc & 0xfu) | (hw << 8);
+    for (volatile int spin = 0; spin < 2000; ++spin) { }                 // (stay a while: later workgroups must go elsewhere)
+}

@@ -98,6 +98,52 @@ int main(int argc, char** argv)
     HK(hsa_queue_create(g_gpu, QSIZE, HSA_QUEUE_TYPE_SINGLE, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &q));
     hsa_signal_t done;
     HK(hsa_signal_create(1, 0, nullptr, &done));
+    // a second queue for the one-XCD experiment: which bits of a CU mask are which XCD?  (where_am_i reports each workgroup's XCC_ID)
+    hsa_queue_t* q1 = nullptr;
+    HK(hsa_queue_create(g_gpu, QSIZE, HSA_QUEUE_TYPE_SINGLE, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &q1));
+    const Kernel k_where = symbol(exe, "where_am_i");
+    uint32_t* d_where = nullptr;
+    CK(hipMalloc(&d_where, 4096 * 4));
+    uint64_t* d_warg = nullptr;
+    CK(hipMalloc(&d_warg, 64));
+    { const uint64_t pw = reinterpret_cast<uint64_t>(d_where); CK(hipMemcpy(d_warg, &pw, 8, hipMemcpyHostToDevice)); }
+    auto where = [&](const char* what, const uint32_t (&mask)[8]) -> int {
+        HK(hsa_amd_queue_cu_set_mask(q1, 256, mask));
+        CK(hipMemset(d_where, 0xff, 4096 * 4)); CK(hipDeviceSynchronize());
+        hsa_signal_store_relaxed(done, 1);
+        const uint64_t idx = hsa_queue_add_write_index_relaxed(q1, 1);
+        hsa_kernel_dispatch_packet_t* p = reinterpret_cast<hsa_kernel_dispatch_packet_t*>(q1->base_address) + (idx & (QSIZE - 1));
+        p->setup = 1 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS;
+        p->workgroup_size_x = 64; p->workgroup_size_y = 1; p->workgroup_size_z = 1; p->reserved0 = 0;
+        p->grid_size_x = 2048 * 64; p->grid_size_y = 1; p->grid_size_z = 1;
+        p->private_segment_size = k_where.priv; p->group_segment_size = k_where.group;
+        p->kernel_object = k_where.object; p->kernarg_address = d_warg; p->reserved2 = 0; p->completion_signal = done;
+        const uint16_t header = (uint16_t)((HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
+                                           (HSA_FENCE_SCOPE_SYSTEM << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (HSA_FENCE_SCOPE_SYSTEM << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE));
+        __atomic_store_n(reinterpret_cast<uint16_t*>(p), header, __ATOMIC_RELEASE);
+        hsa_signal_store_screlease(q1->doorbell_signal, (hsa_signal_value_t)idx);
+        const auto t0 = std::chrono::steady_clock::now();
+        while (hsa_signal_wait_scacquire(done, HSA_SIGNAL_CONDITION_LT, 1, 2000000000ull, HSA_WAIT_STATE_ACTIVE) != 0)
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) { std::fprintf(stderr, "where_am_i timed out\n"); std::exit(3); }
+        std::vector<uint32_t> w(2048);
+        CK(hipMemcpy(w.data(), d_where, 2048 * 4, hipMemcpyDeviceToHost));
+        int hist[16] = {0}, used = 0;
+        for (uint32_t v : w) if (v != 0xffffffffu) ++hist[v & 0xf];
+        std::string hs;
+        for (int x = 0; x < 16; ++x) if (hist[x]) { ++used; hs += " xcc" + std::to_string(x) + ":" + std::to_string(hist[x]); }
+        std::printf("CU mask %-44s -> workgroups by XCC_ID:%s\n", what, hs.c_str());
+        return used;
+    };
+    uint32_t m_all[8], m_first32[8] = {0xffffffffu, 0, 0, 0, 0, 0, 0, 0}, m_every8[8], m_low4each[8];
+    for (int i = 0; i < 8; ++i) { m_all[i] = 0xffffffffu; m_every8[i] = 0x01010101u; m_low4each[i] = 0x0000000fu; }
+    where("all 256 bits", m_all);
+    const int used_first = where("bits 0..31", m_first32);
+    const int used_every8 = where("every 8th bit (32 bits)", m_every8);
+    where("bits 0..3 of every word (32 bits)", m_low4each);
+    const uint32_t* one_xcd = used_first == 1 ? m_first32 : (used_every8 == 1 ? m_every8 : nullptr);
+    std::printf("one-XCD mask: %s\n", one_xcd == m_first32 ? "bits 0..31" : one_xcd == m_every8 ? "every 8th bit" : "none of the patterns tried");
+    if (one_xcd) HK(hsa_amd_queue_cu_set_mask(q1, 256, one_xcd));
+    hsa_queue_t* Q = q;                                     // the queue `series` submits to
     hipStream_t st;
     CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
 
@@ -156,10 +202,10 @@ int main(int argc, char** argv)
             for (int rep = 0; rep < 2; ++rep) {                       // first pass warm-up (state continues: compare after a fresh third pass below)
                 if (rep == 1) reset();
                 hsa_signal_store_relaxed(done, 1);
-                const uint64_t first = hsa_queue_add_write_index_relaxed(q, (uint64_t)N);
+                const uint64_t first = hsa_queue_add_write_index_relaxed(Q, (uint64_t)N);
                 // (the queue is idle between series, so N < QSIZE slots are free)
                 for (int i = 0; i < N; ++i) {
-                    hsa_kernel_dispatch_packet_t* p = reinterpret_cast<hsa_kernel_dispatch_packet_t*>(q->base_address) + ((first + (uint64_t)i) & (QSIZE - 1));
+                    hsa_kernel_dispatch_packet_t* p = reinterpret_cast<hsa_kernel_dispatch_packet_t*>(Q->base_address) + ((first + (uint64_t)i) & (QSIZE - 1));
                     p->setup = 1 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS;
                     p->workgroup_size_x = 64; p->workgroup_size_y = 1; p->workgroup_size_z = 1;
                     p->reserved0 = 0;
@@ -177,7 +223,7 @@ int main(int argc, char** argv)
                     __atomic_store_n(reinterpret_cast<uint16_t*>(p), header, __ATOMIC_RELEASE);
                 }
                 const auto t0 = std::chrono::steady_clock::now();
-                hsa_signal_store_screlease(q->doorbell_signal, (hsa_signal_value_t)(first + (uint64_t)N - 1));
+                hsa_signal_store_screlease(Q->doorbell_signal, (hsa_signal_value_t)(first + (uint64_t)N - 1));
                 while (hsa_signal_wait_scacquire(done, HSA_SIGNAL_CONDITION_LT, 1, 2000000000ull, HSA_WAIT_STATE_ACTIVE) != 0) {
                     if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) { std::fprintf(stderr, "series timed out\n"); std::exit(3); }
                 }
@@ -211,6 +257,20 @@ int main(int argc, char** argv)
             double u; std::string vd;
             series(k_plain, v.acq, v.rel, &u, &vd, v.mode);
             std::printf("         |            | %8.3f  %s: %s\n", u, v.what, vd.c_str());
+        }
+        if (one_xcd) {
+            Q = q1;
+            const V xs[] = {
+                {"one XCD (CU mask): AGENT / AGENT, ordinary loads and stores", HSA_FENCE_SCOPE_AGENT, HSA_FENCE_SCOPE_AGENT, 0},
+                {"one XCD (CU mask): NONE / NONE, sc0 loads (L1 bypassed, the XCD's L2 answers), ordinary stores", HSA_FENCE_SCOPE_NONE, HSA_FENCE_SCOPE_NONE, 16},
+                {"one XCD (CU mask): NONE / NONE, ordinary loads and stores", HSA_FENCE_SCOPE_NONE, HSA_FENCE_SCOPE_NONE, 0},
+            };
+            for (const V& v : xs) {
+                double u; std::string vd;
+                series(k_plain, v.acq, v.rel, &u, &vd, v.mode);
+                std::printf("         |            | %8.3f  %s: %s\n", u, v.what, vd.c_str());
+            }
+            Q = q;
         }
         std::fflush(stdout);
         CK(hipFree(pos)); CK(hipFree(logp)); CK(hipFree(nacc)); CK(hipFree(kargs));
