@@ -10,8 +10,8 @@
 #include <deque>
 #include <thread>
 
-#define KMC_DEFINE_COPY_KERNELS
 #include "kmc_sampler.hpp"
+#include "kmc_copy_kernels.hpp"
 
 using namespace kmc;
 using namespace kmc_host;
@@ -224,7 +224,7 @@ hipError_t download_rows(const kmc_sampler* s, double* dst_host, const double* s
     return hipSuccess;
 }
 
-// the tiled transposition [sample][walker][ld] -> [walker][sample][nd] (kmc_kernels.hpp: chain_by_walker), walkers [w0, w0 + nw), K samples
+// the tiled transposition [sample][walker][ld] -> [walker][sample][nd] (kmc_copy_kernels.hpp: chain_by_walker), walkers [w0, w0 + nw), K samples
 hipError_t launch_by_walker(const void* src, bool is_float, double* dst, int64_t nl, int64_t ld, int64_t nd, int64_t K, int64_t w0, int64_t nw,
                             int64_t dst_stride, hipStream_t st)
 {

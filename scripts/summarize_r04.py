@@ -121,7 +121,9 @@ def main():
         if pr is not None and pr.get("geometry") == out["geometry"]:
             body, boundary, src = pr["body_us"], pr["boundary_us"], f"-DKMC_PROBE build, gpurun_out/prof_r04/probe_{cfg.upper()}.txt (profiles/{tag}_probe_timeline.txt)"
             out["probe"] = pr
-        elif live and live > 30.0 and dur <= 1.10 * live:
+        elif live and live > 30.0 and dur <= 1.15 * live:
+            # (the HBM-resident launches are bimodal from process to process -- 98-100 or 105-109 us at 2 097 152 x 32 --: the traced process and the
+            #  unprofiled one of a set of passes may sit in different modes, profiles/NOTES.md)
             body, boundary, src = dur, max(live - dur, 0.0), "kernel trace mean duration (a ~100 us kernel: the tool's per-dispatch cost is < 2 %); boundary = unprofiled period - duration"
         else:
             body = boundary = None
@@ -139,7 +141,12 @@ def main():
                "hbm_write_bytes_per_launch": out.get("hbm_write_bytes_per_launch"), "l2_hit_rate": out.get("l2_hit_rate"),
                "body_us": body, "boundary_us": boundary, "body_boundary_source": src, "period_us_unprofiled": live,
                "rocprof_avg_duration_us": dur, "source": f"profiles/{tag}_{cfg}_summary.json"}
-        json.dump(rec, open(os.path.join(DST, f"traffic_{name}.json"), "w"), indent=1)
+        tpath = os.path.join(DST, f"traffic_{name}.json")
+        if os.path.exists(tpath):                     # (the periods other boxes measured for this geometry stay on record: scripts/recompute_roofline.py)
+            old = json.load(open(tpath))
+            if "period_us_unprofiled_other_runs" in old and old.get("geometry") == rec.get("geometry"):
+                rec["period_us_unprofiled_other_runs"] = old["period_us_unprofiled_other_runs"]
+        json.dump(rec, open(tpath, "w"), indent=1)
         print(json.dumps({k: out.get(k) for k in ("config", "geometry", "hbm_bytes_per_launch", "read_traffic_over_algorithmic_read", "l2_hit_rate", "fractions")}, indent=1))
         print(json.dumps(rec))
     # the HBM-resident shapes in one place (what VERDICT r03 asked for by this name): counters, hit rate, fractions against both peaks
