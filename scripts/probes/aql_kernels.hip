@@ -66,7 +66,7 @@ __device__ __forceinline__ void st_wt(double* p, double a)
 }
 
 // dp.pad_ selects the coherence form (uniform): bit 0 `buffer_inv sc1` at wave entry (agent-scope invalidate of this CU's L1 and this XCD's
-// non-coherent L2 lines), bit 1 write-through stores, bit 2 `buffer_wbl2 sc1` + wait at the end, bit 3 row loads `sc1`, bit 4 row loads `sc0` (one-XCD queues)
+// non-coherent L2 lines), bit 1 write-through stores, bit 2 `buffer_wbl2 sc1` + wait at the end, bit 3 row loads `sc1`, bit 4 row loads `sc0` (one-XCD queues), bit 5 wait for every store's acknowledgement before the wave ends
 template <bool SC>
 __device__ __forceinline__ void body(const Args& a)
 {
@@ -99,6 +99,7 @@ __device__ __forceinline__ void body(const Args& a)
         a.nacc[w] += 1u;          // (owner-only: the same lane's value of the launch two back)
     }
     if (mode & 4) asm volatile("s_waitcnt vmcnt(0)\n\tbuffer_wbl2 sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
+    if (mode & 32) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 extern "C" __global__ __launch_bounds__(64) void half_step_plain(const Args a) { body<false>(a); }

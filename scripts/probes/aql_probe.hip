@@ -247,6 +247,7 @@ int main(int argc, char** argv)
         struct V { const char* what; hsa_fence_scope_t acq, rel; int mode; };
         const V more[] = {
             {"acquire AGENT, release NONE, write-through stores", HSA_FENCE_SCOPE_AGENT, HSA_FENCE_SCOPE_NONE, 2},
+            {"acquire AGENT, release NONE, write-through stores, every wave waits for its stores' acknowledgements", HSA_FENCE_SCOPE_AGENT, HSA_FENCE_SCOPE_NONE, 2 | 32},
             {"acquire NONE, release AGENT, buffer_inv sc1 at wave entry", HSA_FENCE_SCOPE_NONE, HSA_FENCE_SCOPE_AGENT, 1},
             {"NONE / NONE, buffer_inv sc1 at entry + write-through stores", HSA_FENCE_SCOPE_NONE, HSA_FENCE_SCOPE_NONE, 3},
             {"NONE / NONE, buffer_inv sc1 at entry + buffer_wbl2 sc1 at the end", HSA_FENCE_SCOPE_NONE, HSA_FENCE_SCOPE_NONE, 5},
