@@ -126,9 +126,13 @@ def profile_record(name: str, geometry):
 
 
 def roofline_block(pdf, describe: str, nwalkers_launch: int, ndim: int, launch_us: float, launches: int, state_b: int, record_name: str, use_record: bool = True):
-    """`roofline` of the dominant kernel (one launch = one half-step).  achieved = ALGORITHMIC read bytes ((2 ndim + 1) * 8 per walker-step,
-    SURVEY 8d) / average launch-to-launch time (HIP events).  What is not measured in this run -- PMC traffic, the in-kernel body /
-    boundary split -- comes from the tracked record of that kernel geometry, or is null when the geometries differ."""
+    """`roofline` of the dominant kernel (one launch = one half-step): numbers and short enums only (the prose lives in DESIGN.md section 5).
+    achieved / frac = ALGORITHMIC read bytes ((2 ndim + 1) * 8 per walker-step) / average launch-to-launch time from HIP events over
+    the timed region (includes the kernel boundary), priced against the 8 TB/s HBM spec (`peak`).  `served_from` says where the rows really
+    come from (a state below 256 MiB lives in the Infinity Cache between two generations) and `bound` follows it.  What is not measured in
+    this run -- `traffic` (rocprofv3 --pmc passes: 2 x FETCH_SIZE + WRITE_SIZE per launch, gfx950 read correction) and the in-kernel body /
+    boundary split (-DKMC_PROBE build; body_frac = the same bytes / body_us / 8 TB/s) -- comes from the tracked record of that very kernel
+    geometry, profiles/traffic_<record>.json (scripts/profile_r04.sh), or is null when the geometries differ."""
     b_read, b_total = (2 * ndim + 1) * 8, (3 * ndim + 2) * 8
     alg_read = nwalkers_launch * b_read
     achieved = alg_read / (launch_us * 1e-6) / 1e9
@@ -139,26 +143,21 @@ def roofline_block(pdf, describe: str, nwalkers_launch: int, ndim: int, launch_u
     boundary_us = rec.get("boundary_us") if rec else None
     body_frac = (alg_read / (body_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if body_us else None
     if served == "hbm":
-        limited = "HBM bandwidth (the state does not fit the Infinity Cache: every row comes from memory each generation)"
+        limited = "hbm_bandwidth"
     elif boundary_us and boundary_us / launch_us >= 0.2:
-        limited = (f"kernel boundary + cache latency: the state ({state_b / 2**20:.0f} MiB) is Infinity-Cache resident, the kernel body takes {body_us:.2f} us "
-                   f"of the {launch_us:.2f} us launch period, the dependent-launch boundary the rest")
+        limited = "kernel_boundary+cache_latency"
     else:
-        limited = f"cache latency / launch boundary: the state ({state_b / 2**20:.0f} MiB) is Infinity-Cache resident (no body / boundary split on record for this geometry)"
-    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+        limited = "cache_latency"
+    return {"bound": served, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": rec.get("hbm_bytes_per_launch") if rec else None,
-            "frac_of_measured_copy_rate": achieved / HBM_COPY_GBS,
+            "priced_against": "hbm_spec", "frac_of_measured_copy_rate": achieved / HBM_COPY_GBS,
             "kernel": kernel_name(pdf, describe), "geometry": geometry, "launches": launches, "avg_launch_us": launch_us,
             "algorithmic_read_bytes_per_launch": alg_read, "algorithmic_total_bytes_per_launch": nwalkers_launch * b_total,
             "state_bytes": state_b, "served_from": served, "limited_by": limited,
             "body_us": body_us, "boundary_us": boundary_us, "body_frac": body_frac,
-            "profile_record": ({k: rec.get(k) for k in ("head", "kernel_sources_unchanged", "period_us_unprofiled", "hbm_read_bytes_per_launch", "hbm_write_bytes_per_launch", "l2_hit_rate", "source")}
-                               if rec else {"refused": why}),
-            "traffic_source": f"profiles/traffic_{record_name}.json: rocprofv3 --pmc passes (2 x FETCH_SIZE + WRITE_SIZE per launch, gfx950 read correction) and the "
-                              "-DKMC_PROBE in-kernel timeline (body_us = first wave in .. last store issued, boundary_us = the gap to the next launch's first wave) "
-                              "of this kernel geometry, collected separately (scripts/profile_r04.sh) -- a tracked file, matched on `geometry`, not measured in this run",
-            "note": "achieved / frac = algorithmic READ bytes / average launch-to-launch time from HIP events over the timed region (includes the kernel boundary); "
-                    "body_frac = the same bytes / body_us / 8 TB/s; `bound` names the roofline the fraction is priced against, `served_from` / `limited_by` what the data say"}
+            "profile_record": ({"record": f"profiles/traffic_{record_name}.json",
+                                **{k: rec.get(k) for k in ("head", "kernel_sources_unchanged", "period_us_unprofiled", "hbm_read_bytes_per_launch", "hbm_write_bytes_per_launch", "l2_hit_rate", "source")}}
+                               if rec else {"refused": why})}
 
 
 def theta0_c2(nwalkers: int) -> np.ndarray:
@@ -241,6 +240,7 @@ def cpu_baseline_worker(budget_s: float = 10.0):
     v_all, g_all, t_all = timed(cores, budget_s, repeats=2)
     v_one, g_one, t_one = (v_all, g_all, t_all) if cores == 1 else timed(1, min(budget_s, 6.0))
     return {"value": v_all, "unit": "walker-steps/s", "cores": cores, "kind": "port",
+            "sample_short": f"C2 shape, {g_all} generations = {NWALKERS_PER_GPU * g_all:.3g} walker-steps in {t_all:.1f} s on {cores} threads; 1 thread: {g_one} in {t_one:.1f} s",
             "single_thread_value": v_one, "thread_scaling": v_all / v_one,
             "sample": f"C2 shape (65536 walkers x 32-dim Gaussian, fp64, moments on after burn-in), {g_all} generations = "
                       f"{NWALKERS_PER_GPU * g_all:.3g} walker-steps in {t_all:.1f} s on {cores} threads (affinity mask capped by the cgroup CPU quota; the faster of two such runs); "
@@ -375,9 +375,12 @@ def spawn_ranks(n: int, argv) -> int:
     if status == 0:
         status = next((p.returncode for p in procs if p.returncode != 0), 0)
     js = [l for l in lines if l.lstrip().startswith('{"metric"')]
+    detail = [l for l in lines if l.lstrip().startswith('{"bench_detail"')]
     for l in lines:
-        if l not in js[-1:]:
+        if l not in js[-1:] and l not in detail[-1:]:
             sys.stderr.write(l)
+    if detail:
+        sys.stdout.write(detail[-1] if detail[-1].endswith("\n") else detail[-1] + "\n")
     if js:
         sys.stdout.write(js[-1] if js[-1].endswith("\n") else js[-1] + "\n")
         sys.stdout.flush()
@@ -387,10 +390,13 @@ def spawn_ranks(n: int, argv) -> int:
     return status if status >= 0 else 128 - status
 
 
-LADDER = []      # [{"rung", "ok", "s"}]: every rung of the N > 1 ladder this rank went through, in order (printed with the line)
+LADDER = []      # [{"rung", "ok", "s"}]: every rung of the N > 1 ladder this rank went through, in order (printed with the line).  Rung names (short:
+#                  the line has 4 KB): rendezvous; p2p-check:<variant> (set-up + bit-exact self-check), p2p-time:<variant> (KMC_BENCH_EXCHANGE=all),
+#                  p2p-run (warm-up + timed run); allgather-setup (ncclCommInitRank), allgather-run, torch-allgather-run (the same exchange as a
+#                  torch collective per half-step); the extras after `value`: dealt-extra, allgather-extra-setup, allgather-extra
 
 
-PENDING = {"line": None}      # once `value` is measured: a callable(reason) -> the result line as it stands (an extra that hangs must not take it down)
+PENDING = {"line": None}      # once `value` is measured: a callable(reason) that PRINTS the result as it stands (an extra that hangs must not take it down)
 
 
 class rung:
@@ -426,7 +432,7 @@ class rung:
             if not self.fatal and PENDING["line"] is not None:
                 try:
                     if rank == "0":
-                        print(json.dumps(PENDING["line"](f"'{self.what}' did not finish within {self.seconds:.0f} s")), flush=True)
+                        PENDING["line"](f"'{self.what}' did not finish within {self.seconds:.0f} s")
                     sys.stderr.flush()
                     os._exit(0)
                 except Exception as e:  # noqa: BLE001
@@ -617,6 +623,635 @@ def other_configs(kmc, device: int):
     return out
 
 
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# The result: a FULL record (every block as measured, with its strings; `bench_detail.json` beside this file and an earlier stdout line
+# {"bench_detail": ...}) and the ONE result line, the last line of stdout, which must survive a reader that keeps a few KB of the tail:
+# numbers and short enums only, under LINE_LIMIT characters in the N = 1 and the N > 1 form (tests/test_bench_cpu.py).
+# ---------------------------------------------------------------------------------------------------------------------------------
+LINE_LIMIT = 4000
+
+
+def sig(v, digits: int = 6):
+    """Floats to `digits` significant digits (the line is read by people and by a 4 KB window); everything else as it is."""
+    if isinstance(v, float):
+        return float(f"{v:.{digits}g}") if v == v and abs(v) != float("inf") else None
+    if isinstance(v, (list, tuple)):
+        return [sig(x, digits) for x in v]
+    if isinstance(v, dict):
+        return {k: sig(x, digits) for k, x in v.items()}
+    return v
+
+
+def clip(text, n: int):
+    return text if text is None or len(text) <= n else text[: n - 1] + "~"
+
+
+def compact_roofline(roof: dict) -> dict:
+    keep = ("bound", "achieved", "peak", "unit", "frac", "traffic", "served_from", "limited_by", "body_frac", "avg_launch_us", "launches",
+            "kernel", "geometry", "algorithmic_read_bytes_per_launch", "state_bytes", "frac_of_measured_copy_rate")
+    out = {k: roof.get(k) for k in keep}
+    rec = roof.get("profile_record") or {}
+    out["profile_record"] = {"record": rec.get("record"), "head": rec.get("head"), "source": rec.get("source")} if "refused" not in rec else {"refused": True}
+    return sig(out)
+
+
+def compact_line(full: dict) -> str:
+    """The result line from the full record: the contract's keys whole, every block reduced to its numbers and enums, other_configs to
+    {value, us_per_half_step, frac, served_from}; if it still exceeds LINE_LIMIT the optional blocks go, least important first."""
+    cfg = dict(full["config"])
+    cfg["execution"] = clip(cfg.get("execution"), 150)
+    cfg["parallelism"] = clip(cfg.get("parallelism"), 150)
+    cfg["workload"] = clip(cfg.get("workload"), 160)
+    line = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    line["config"] = cfg
+    line["roofline"] = compact_roofline(full["roofline"])
+    cb = full.get("cpu_baseline")
+    if cb is not None:
+        line["cpu_baseline"] = ({"error": clip(str(cb["error"]), 160)} if "error" in cb else
+                                sig({**{k: cb.get(k) for k in ("value", "unit", "cores", "kind", "single_thread_value")}, "sample": clip(cb.get("sample_short") or cb.get("sample"), 140)}))
+    line["check"] = sig(full["check"], 8)
+    if "collective" in full:
+        c = full["collective"]
+        line["collective"] = {**{k: c.get(k) for k in ("backend", "world_size", "ranks_seen_by_all_reduce", "rccl_version", "native_rccl_version", "rank_env")},
+                              "launcher": clip(c.get("launcher"), 16)}
+        line["value_from"] = full.get("value_from")
+        line["ladder"] = [{k: r[k] for k in ("rung", "ok", "s", "timed_out") if k in r} for r in full.get("ladder", [])]
+        for key, keep in (("dealt_mode", ("value", "epoch_generations", "deals", "accept_ratio_mean", "posterior_mean_absmax", "posterior_var_minmax")),
+                          ("allgather_mode", ("value", "generations", "us_per_half_step", "equals_unsharded_run"))):
+            if key in full:
+                b = full[key]
+                line[key] = {"error": clip(str(b["error"]), 120)} if "error" in b else sig({k: b.get(k) for k in keep})
+                if key == "allgather_mode" and "error" not in b:
+                    line[key]["captured_in_graph"] = "captured in the graph" in (b.get("execution") or "")
+        if "extras_timed_out" in full:
+            line["extras_timed_out"] = clip(full["extras_timed_out"], 120)
+        fab = full.get("fabric") or {}
+        line["fabric"] = sig({k: fab.get(k) for k in ("bytes_per_link_per_launch", "link_bound_us_at_77GBs", "push_bytes_per_link_per_launch", "variants_us_per_launch") if fab.get(k) not in (None, {})})
+    isl = full.get("island_mode")
+    if isl is not None:
+        line["island_mode"] = {"error": clip(str(isl["error"]), 80)} if "error" in isl else sig({k: isl.get(k) for k in ("value", "accept_ratio_mean")})
+    oc = full.get("other_configs")
+    if oc:
+        line["other_configs"] = {}
+        for name, e in oc.items():
+            if "error" in e:
+                line["other_configs"][name] = {"error": clip(str(e["error"]), 60)}
+                continue
+            c = {"value": e.get("value"), "us_per_half_step": e.get("us_per_half_step")}
+            roof = e.get("roofline")
+            if roof:
+                c.update(frac=roof["frac"], served_from=roof["served_from"], traffic=roof.get("traffic"))
+            elif "two_launches_us_per_half_step" in e:
+                c["two_launches_us_per_half_step"] = e["two_launches_us_per_half_step"]
+            line["other_configs"][name] = sig(c, 5)
+    line["detail"] = "bench_detail.json; earlier stdout line {\"bench_detail\": ...}"
+
+    def size():
+        return len(json.dumps(line))
+
+    # too long (many ladder rungs, long error strings): the optional blocks go, least important first
+    for drop in (lambda: line.pop("island_mode", None),
+                 lambda: line.__setitem__("other_configs", {k: {kk: v.get(kk) for kk in ("value", "frac", "error") if kk in v} for k, v in line.get("other_configs", {}).items()}) if "other_configs" in line else None,
+                 lambda: line.pop("fabric", None),
+                 lambda: line.__setitem__("ladder", [[r["rung"], r["ok"], r["s"]] for r in line["ladder"]]) if "ladder" in line else None,
+                 lambda: line.pop("other_configs", None),
+                 lambda: line["config"].__setitem__("execution", clip(line["config"].get("execution"), 60)),
+                 lambda: line.__setitem__("ladder", line["ladder"][-8:]) if "ladder" in line else None):
+        if size() <= LINE_LIMIT:
+            break
+        drop()
+    text = json.dumps(line)
+    assert len(text) <= LINE_LIMIT, f"the result line is {len(text)} characters"
+    return text
+
+
+def emit(full: dict) -> None:
+    """Rank 0: the full record (file + an earlier stdout line), then the result line -- the LAST line of stdout."""
+    detail = json.dumps({"bench_detail": full})
+    try:
+        with open(os.path.join(ROOT, "bench_detail.json"), "w") as f:
+            f.write(json.dumps(full, indent=1) + "\n")
+    except OSError as e:
+        note(f"bench.py: could not write bench_detail.json ({e})")
+    sys.stdout.write(detail + "\n")
+    sys.stdout.write(compact_line(full) + "\n")
+    sys.stdout.flush()
+
+
+class Job:
+    """What every leg of a run shares: the arguments, this rank's place in the job, the workload."""
+
+    def __init__(self, args, torch, kmc):
+        self.args, self.torch, self.kmc = args, torch, kmc
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
+        # KMC_BENCH_TEST=force-sharded (testing): take the N > 1 code path with ONE rank -- the whole ladder over the real collective
+        # backend (RCCL communicator of one rank, captured all-gathers, all_to_all_single of the dealt mode) on a one-GPU box
+        self.sharded = self.world > 1 or bool(bench_test_opt("force-sharded"))
+        self.dist = None
+        self.collective = None
+        self.nw = NWALKERS_PER_GPU * self.world
+        self.G = args.steps * GENS_PER_STEP
+        self.nburn = self.G // 2
+        self.pdf = kmc.GaussianIso()
+        self.th = theta0_c2(self.nw)
+
+    def all_ok(self, flag: bool) -> bool:
+        """A vote: true only if every rank says so (nobody enters the next collective alone)."""
+        t = self.torch.tensor([1.0 if flag else 0.0], device="cuda")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        return t.item() != 0
+
+    def fault(self, point: str):
+        """KMC_BENCH_TEST=fault=<point>:<rank> (testing): that rank fails at that point of the ladder -- every rank must then take
+        the next rung together."""
+        if bench_test_opt("fault") == f"{point}:{self.rank}":
+            raise RuntimeError(f"injected fault at {point}")
+        if bench_test_opt("fault") == f"{point}_hang:{self.rank}":      # ... or never comes back (the peers then block in their next collective)
+            time.sleep(10 ** 6)
+
+    def unsharded(self, gens):
+        """(positions, naccept, moments) of the whole ensemble after `gens` generations on ONE GPU (this rank's)."""
+        with self.kmc.Sampler(self.pdf, self.nw, NDIM, self.G, self.nburn, 1, 2.0, SEED, moments=True, device=self.local_rank) as ref:
+            ref.set_positions(self.th)
+            ref.run(gens)
+            ref.sync()
+            return ref.positions(), ref.naccept(), ref.moments()
+
+    def timed(self, d, gens, warm):
+        """`warm` generations, restart, then `gens` generations from a common start: seconds (this rank's; the caller takes the max)."""
+        torch, dist = self.torch, self.dist
+        if warm > 0:
+            d.set_positions(self.th)
+            d.run(warm)
+            d.sync()
+        d.set_positions(self.th)
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        d.run(gens)
+        d.sync()
+        torch.cuda.synchronize()
+        dist.barrier()
+        return time.perf_counter() - t0
+
+    def max_over_ranks(self, seconds: float) -> float:
+        t = self.torch.tensor([seconds], dtype=self.torch.float64, device="cuda")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+
+def rendezvous(job: Job) -> None:
+    """The process group of an N > 1 job (one rank per GPU, "nccl" = RCCL), and what the collective backend really saw."""
+    torch = job.torch
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("WORLD_SIZE", "1")
+    import datetime
+    import torch.distributed as dist
+    job.dist = dist
+    backend = bench_test_opt("backend", "nccl")
+    with rung("rendezvous"):
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", job.local_rank), timeout=datetime.timedelta(seconds=600))
+        else:
+            dist.init_process_group(backend, timeout=datetime.timedelta(seconds=600))
+        seen = torch.ones(1, device="cuda")              # did the backend see every rank?  one all-reduce of ones (RCCL over xGMI for "nccl")
+        dist.all_reduce(seen)
+        torch.cuda.synchronize()
+    try:
+        rv = torch.cuda.nccl.version()
+        rccl_version = ".".join(str(v) for v in rv) if isinstance(rv, tuple) else str(rv)
+    except Exception:  # noqa: BLE001
+        rccl_version = None
+    job.collective = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks_seen_by_all_reduce": int(seen.item()),
+                      "rccl_version": rccl_version, "native_rccl_version": job.kmc.Sampler.rccl_version(),
+                      "launcher": "bench.py itself (one child process per rank)" if os.environ.get("KMC_BENCH_SELF_SPAWNED") else "external (torch.distributed.run)",
+                      "rank_env": {k: os.environ.get(k) for k in ("HSA_ENABLE_IPC_MODE_LEGACY", "OMP_NUM_THREADS")}}
+
+
+def run_single(job: Job) -> dict:
+    """N = 1: the whole C2 job on one GPU -- `value` -- and, NOT `value`, the opt-in island mode on the same job."""
+    kmc, torch, args = job.kmc, job.torch, job.args
+    s = kmc.Sampler(job.pdf, job.nw, NDIM, job.G, job.nburn, 1, 2.0, SEED, moments=True, device=job.local_rank)
+    s.set_positions(job.th)
+    for _ in range(args.warmup):
+        s.run(GENS_PER_STEP)
+    s.sync()
+    s.set_positions(job.th)                  # restart: the timed region is the whole C2 job
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    s.run(job.G)                             # exactly `steps` steps of GENS_PER_STEP generations
+    s.sync()
+    torch.cuda.synchronize()
+    res = {"elapsed": time.perf_counter() - t0, "event_ms": s.last_run_ms(),      # HIP events on the sampler's own stream
+           "launches": s.launch_count, "how": s.describe(), "mode": "single"}
+    res["msum"], res["msq"], res["nmom"] = s.moments()
+    res["acc"] = float(s.accept_ratio().mean())
+    s.close()
+    # Extra, NOT `value`: the opt-in island mode (256-walker islands resident in LDS, partners drawn inside the island, walkers
+    # re-dealt every 64 generations) on the same job.
+    try:
+        if args.no_island:
+            raise RuntimeError("skipped (--no-island)")
+        with kmc.Sampler(job.pdf, job.nw, NDIM, job.G, job.nburn, 1, 2.0, SEED, moments=True, device=job.local_rank, island_gens=64, island_size=256) as si:
+            si.set_positions(job.th)
+            si.run(GENS_PER_STEP)
+            si.sync()
+            si.set_positions(job.th)
+            si.run(job.G)
+            si.sync()
+            ims = si.last_run_ms()
+            isum, isq, inm = si.moments()
+            imean = isum / max(1, inm)
+            res["island"] = {"value": float(job.nw) * job.G / (ims * 1e-3), "unit": "walker-steps/s", "island_size": 256, "island_gens": 64,
+                             "accept_ratio_mean": float(si.accept_ratio().mean()), "posterior_mean_absmax": float(np.abs(imean).max()),
+                             "posterior_var_minmax": [float((isq / inm - imean ** 2).min()), float((isq / inm - imean ** 2).max())],
+                             "note": "KMC_ISLANDS: same target distribution, partner pool = the island's complementary half "
+                                     "(not the reference's whole-ensemble rule); bit-exact against the oracle's island restatement"}
+    except Exception as e:  # noqa: BLE001
+        res["island"] = {"error": str(e)}
+    return res
+
+
+P2P_VARIANTS = [   # (rung tag, what it is, fold_signal, push, lazy).  Default: the first only; KMC_BENCH_EXCHANGE=all tries every one the library has.
+    ("pull", "pull of drawn rows (system-scope loads), signal kernel", False, False, False),
+    ("pull-fold", "pull of drawn rows (system-scope loads), signal folded into the kernel", True, False, False),
+    ("push", "push of accepted rows into local copies, signal kernel", False, True, False),
+    ("push-fold", "push of accepted rows into local copies, signal folded into the kernel", True, True, False),
+    ("lazy", "lazy pull into local copies, signal kernel", False, False, True),
+    ("lazy-fold", "lazy pull into local copies, signal folded into the kernel", True, False, True),
+]
+
+
+def try_p2p(job: Job, finegrained, fold_signal=False, push=False, lazy=False):
+    """Set up the peer-to-peer exchange and self-check it: 240 generations (hipGraph replays + an eager tail) must reproduce, bit
+    for bit, the same generations of the whole ensemble on ONE GPU (rank 0 runs it unsharded).  Any error, time-out or mismatch
+    on any rank -> None on every rank."""
+    from kissmcmc_jl_amd.distributed import P2PEmcee
+    rank = job.rank
+    d, ok = None, True
+    try:
+        job.fault("p2p_setup")
+        d = P2PEmcee(job.pdf, job.nw, NDIM, job.G, job.nburn, 1, 2.0, SEED, device=job.local_rank, finegrained=finegrained,
+                     fold_signal=fold_signal, push=push, lazy=lazy, connect=False)      # local part only: no collective yet
+    except Exception as e:  # noqa: BLE001
+        note(f"[rank {rank}] p2p set-up failed ({e})")
+        ok = False
+    if job.all_ok(ok):                                   # every rank has its sampler and handles: now the exchange
+        try:
+            d.connect()
+            job.fault("p2p_connect")
+        except Exception as e:  # noqa: BLE001
+            note(f"[rank {rank}] p2p connect failed ({e})")
+            ok = False
+    if job.all_ok(ok):
+        vgen = 240
+        try:
+            d.set_positions(job.th)
+            d.run(vgen)
+            d.sync()                                      # (a peer wait that timed out surfaces here, on the ranks that waited)
+            job.fault("p2p_selfcheck")
+        except Exception as e:  # noqa: BLE001
+            note(f"[rank {rank}] p2p self-check failed ({e})")
+            ok = False
+        ok = job.all_ok(ok)                               # every rank's kernels ran through: only then the result collectives
+        try:
+            if not ok:
+                raise RuntimeError("a rank failed before the results were gathered")
+            vpos, vacc = d.positions(), d.naccept()
+            if rank == 0:
+                rpos, racc, _ = job.unsharded(vgen)
+                if not (np.array_equal(rpos, vpos) and np.array_equal(racc, vacc)):
+                    note(f"[rank 0] p2p self-check (finegrained={finegrained}, fold_signal={fold_signal}, push={push}, lazy={lazy}): "
+                         "sharded run differs from the single-GPU run")
+                    ok = False
+        except Exception as e:  # noqa: BLE001
+            note(f"[rank {rank}] p2p self-check failed ({e})")
+            ok = False
+        ok = job.all_ok(ok)
+    else:
+        ok = False
+    if not ok:
+        if d is not None:
+            try:
+                d.sampler.close()
+            except Exception:  # noqa: BLE001
+                pass
+        return None
+    return d
+
+
+def make_allgather(job: Job, what, fatal=True):
+    """The native all-gather exchange, set up in two votes: every rank's local part (its replica sampler), then the collective part
+    (unique id, ncclCommInitRank, the capture vote).  The connected driver, or None on EVERY rank."""
+    from kissmcmc_jl_amd.distributed import AllGatherEmcee
+    d, ok = None, True
+    try:
+        job.fault("allgather_setup")
+        d = AllGatherEmcee(job.pdf, job.nw, NDIM, job.G, job.nburn, 1, 2.0, SEED, device=job.local_rank, connect=False)
+    except Exception as e:  # noqa: BLE001
+        note(f"[rank {job.rank}] native RCCL all-gather set-up failed ({e})")
+        ok = False
+    if job.all_ok(ok):
+        try:
+            with rung(what, fatal=fatal):
+                d.connect()
+                job.fault("allgather_connect")
+        except Exception as e:  # noqa: BLE001
+            note(f"[rank {job.rank}] native RCCL all-gather set-up failed ({e})")
+            ok = False
+        ok = job.all_ok(ok)
+    else:
+        ok = False
+    if not ok and d is not None:
+        try:
+            d.sampler.close()
+        except Exception:  # noqa: BLE001
+            pass
+    return d if ok else None
+
+
+def run_sharded(job: Job) -> dict:
+    """N > 1: walker-sharded, one rank per GPU, EXACT partner rule (reference src/samplers.jl:250: partners from the whole complementary
+    half).  The ladder: peer-to-peer partner reads over xGMI (KMC_P2P: only the rows that are drawn cross the fabric, the whole run is
+    enqueued like the single-GPU case) -- by default ONE variant, pull of the drawn rows with system-scope loads + a signal kernel (the
+    one whose correctness does not depend on cache state), admitted by a bit-exact self-check; KMC_BENCH_EXCHANGE=all also tries the
+    other variants the library has and runs the fastest admitted one; KMC_BENCH_EXCHANGE=allgather (or any failure) uses the RCCL
+    all-gather of the updated half per half-step.  The TIMED run itself is then verified against the unsharded run of the whole
+    ensemble on rank 0.  Returns the measurements; `value` stands once this returns (the extras run afterwards)."""
+    torch, dist, args, rank, world = job.torch, job.dist, job.args, job.rank, job.world
+    G, nw, nburn, th = job.G, job.nw, job.nburn, job.th
+    from kissmcmc_jl_amd.distributed import HipShardExecutor, ShardedEmcee
+    mode = os.environ.get("KMC_BENCH_EXCHANGE", "p2p")
+    res = {"tried": [], "verified": None, "lazy_stats": (0, 0), "p2p_variant": None}
+    drv, best_t = None, None
+    if mode in ("p2p", "all"):
+        # push / lazy have peers write into plain device memory the local kernel then reads through its own L2: whether that L2 can
+        # serve stale lines could never be observed on one GPU -- they run only on request and only if their self-check passes.
+        cands = P2P_VARIANTS if mode == "all" else P2P_VARIANTS[:1]
+        for tag, label, fold, push, lazy in cands:
+            with rung(f"p2p-check:{tag}") as rg:
+                cand = try_p2p(job, False, fold, push, lazy)
+                rg.ok = cand is not None
+            if cand is None:
+                continue
+            if len(cands) == 1:
+                drv, res["p2p_variant"] = cand, label
+                break
+            with rung(f"p2p-time:{tag}"):
+                tc = job.max_over_ranks(job.timed(cand, 1024, 0))      # long enough to reach the steady state of the replayed graphs (16 chunks)
+            res["tried"].append((tag, tc))
+            if drv is None or tc < best_t:
+                if drv is not None:
+                    drv.close()
+                drv, best_t, res["p2p_variant"] = cand, tc, label
+            else:
+                cand.close()
+        if drv is None:
+            with rung("p2p-check:pull-finegrained") as rg:
+                drv = try_p2p(job, True, False)
+                rg.ok = drv is not None
+            if drv is not None:
+                res["p2p_variant"] = "pull of drawn rows, rows in fine-grained memory, signal kernel"
+        if rank == 0 and res["tried"]:
+            note("[rank 0] p2p variants, s per 1024 generations: " + "; ".join(f"{l}: {t:.4f}" for l, t in res["tried"]))
+        if drv is None and rank == 0:
+            note("[rank 0] falling back to the RCCL all-gather exchange")
+        mode = "p2p" if drv is not None else "allgather"
+    if mode == "p2p":
+        ok = True
+        try:
+            with rung("p2p-run"):
+                drv.set_positions(th)
+                drv.run(args.warmup * GENS_PER_STEP)
+                drv.sync()
+                drv.set_positions(th)                # barriers inside; restart the job
+                dist.barrier()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                drv.run(G)
+                try:
+                    drv.sync()
+                    job.fault("p2p_run")
+                    ran = True
+                except Exception as e:  # noqa: BLE001  (a timed-out peer wait: the other ranks must not be left inside a collective)
+                    note(f"[rank {rank}] the p2p run failed ({e})")
+                    ran = False
+                torch.cuda.synchronize()
+                if not job.all_ok(ran):
+                    raise RuntimeError("a rank's peer-to-peer run did not complete")
+                dist.barrier()
+                res["elapsed"] = time.perf_counter() - t0
+                res["event_ms"] = drv.sampler.last_run_ms()
+                res["launches"] = drv.sampler.launch_count
+                res["msum"], res["msq"], res["nmom"] = drv.moments()
+                fpos, facc = drv.positions(), drv.naccept()
+                res["lazy_stats"] = drv.sampler.p2p_stats()         # (remote partner draws, pulled) on this rank; (0, 0) unless lazy ran
+                res["how"] = drv.sampler.describe()
+                drv.close()
+        except Exception as e:  # noqa: BLE001  (e.g. a peer wait that timed out: every rank then takes the fallback)
+            note(f"[rank {rank}] the p2p run failed ({e})")
+            ok = False
+            try:
+                drv.sampler.close()
+            except Exception:  # noqa: BLE001
+                pass
+        if not job.all_ok(ok):
+            if rank == 0:
+                note("[rank 0] falling back to the RCCL all-gather exchange")
+            mode = "allgather"
+    if mode == "p2p":
+        if rank == 0:                                # the timed run itself, against the unsharded run of the whole job on one GPU
+            rpos, racc, (rs, rq, rn) = job.unsharded(G)
+            res["verified"] = bool(np.array_equal(rpos, fpos) and np.array_equal(racc, facc) and rn == res["nmom"] and
+                                   np.allclose(rs, res["msum"], rtol=1e-10, atol=1e-6) and np.allclose(rq, res["msq"], rtol=1e-10, atol=1e-6))
+            if not res["verified"]:
+                note("[rank 0] the TIMED sharded run differs from the unsharded run of the same job")
+        res["parallelism"] = f"walker-sharded x{world}, exact partner rule, peer-to-peer exchange over xGMI (IPC): {res['p2p_variant']}; progress-flag ordering"
+        res["value_from"] = "p2p-run"
+    else:
+        # The exchange the north star names: an RCCL all-gather of the updated half after every half-step.  Native form first
+        # (kmc_sampler_run enqueues kernel + ncclAllGather per half-step, inside the hipGraph chunks); if that cannot be set up on
+        # every rank, the same exchange as a torch collective per half-step from Python.
+        nat = make_allgather(job, "allgather-setup")
+        if nat is not None:
+            with rung("allgather-run"):
+                res["elapsed"] = job.timed(nat, G, min(args.warmup * GENS_PER_STEP, 200))
+                res["event_ms"] = nat.sampler.last_run_ms()
+                res["launches"] = nat.sampler.launch_count
+                res["msum"], res["msq"], res["nmom"] = nat.moments()
+                facc, fpos = nat.naccept(), nat.positions()
+                res["how"] = nat.sampler.describe()
+                nat.close()
+            res["parallelism"] = f"walker-sharded x{world}, exact partner rule, native RCCL all-gather of the updated half per half-step ({res['how'].split(';')[-1].strip()})"
+            res["value_from"] = "allgather-run"
+        else:
+            with rung("torch-allgather-run"):
+                ex = HipShardExecutor(job.pdf, nw, NDIM, G, nburn, 1, 2.0, SEED, rank=rank, world=world, device=job.local_rank)
+                ex.set_positions(th)
+                sdrv = ShardedEmcee(ex, nw, NDIM)
+                sdrv.run(min(args.warmup * GENS_PER_STEP, 100))   # warm-up: kernels + RCCL rings
+                ex.sync()
+                ex.set_positions(th)
+                sdrv.generation = 0
+                dist.barrier()
+                torch.cuda.synchronize()
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                t0 = time.perf_counter()
+                ev0.record()                         # the executor launches on torch's current stream
+                sdrv.run(G)
+                ev1.record()
+                ex.sync()
+                torch.cuda.synchronize()
+                dist.barrier()
+                res["elapsed"] = time.perf_counter() - t0
+                res["event_ms"] = ev0.elapsed_time(ev1)
+                res["launches"] = 2 * G
+                res["msum"], res["msq"], res["nmom"] = sdrv.moments()
+                facc, fpos = sdrv.naccept(), sdrv.positions()
+                res["how"] = ex.sampler.describe()
+                ex.close()
+            res["parallelism"] = f"walker-sharded x{world}, exact partner rule, RCCL all-gather of the updated half per half-step (torch collective per half-step)"
+            res["value_from"] = "torch-allgather-run"
+        if rank == 0:
+            rpos, racc, _ = job.unsharded(G)
+            res["verified"] = bool(np.array_equal(rpos, fpos) and np.array_equal(racc, facc))
+    res["acc"] = float(facc.sum() / nw / max(1, G - nburn))
+    res["elapsed"] = job.max_over_ranks(res["elapsed"])
+    res["mode"] = mode
+    res["extras"] = {"dealt": None, "allgather": None, "allgather_started": False}
+    return res
+
+
+def run_extras(job: Job, res: dict) -> None:
+    """After `value` (N > 1), never `value`: (1) dealt sub-ensembles -- every GPU runs the reference's algorithm unchanged on its own 65 536
+    walkers (partners from its own complementary half) for an epoch, then ONE RCCL all_to_all_single re-deals the walkers across the
+    GPUs (state-independent permutation): same target distribution, no per-half-step exchange; (2) when the pull supplied `value`,
+    the exchange the north star names -- one RCCL all-gather of the updated half per half-step, enqueued with the kernels inside
+    the hipGraph chunks -- on a bounded piece of the same job, so that both exchanges are on record from the same node."""
+    torch, dist, args, rank, world = job.torch, job.dist, job.args, job.rank, job.world
+    G, nw, nburn = job.G, job.nw, job.nburn
+    extras = res["extras"]
+    try:
+        from kissmcmc_jl_amd.distributed import DealtEmcee, HipDealExecutor
+        epoch = int(bench_test_opt("deal-epoch", 64))
+        dex, okd = None, True
+        try:                                         # local part first, then a vote: nobody enters the collectives alone
+            job.fault("dealt_setup")
+            dex = HipDealExecutor(job.pdf, NWALKERS_PER_GPU, NDIM, G, nburn, 1, 2.0, SEED, rank=rank, world=world, device=job.local_rank)
+        except Exception as e:  # noqa: BLE001
+            note(f"[rank {rank}] dealt sub-ensembles: set-up failed ({e})")
+            okd = False
+        if not job.all_ok(okd):
+            if dex is not None:
+                dex.close()
+            raise RuntimeError("the dealt mode could not be set up on every rank (see stderr)")
+        with rung("dealt-extra", fatal=False):
+            job.fault("dealt_run")
+            dd = DealtEmcee(dex, nw, NDIM, epoch)
+            dt = job.max_over_ranks(job.timed(dd, G, args.warmup * GENS_PER_STEP))
+            r = dd.results()
+            dd.close()
+        dmean = r["sum"] / max(1, r["n"])
+        dvar = r["sumsq"] / max(1, r["n"]) - dmean ** 2
+        extras["dealt"] = {"value": float(nw) * G / dt, "unit": "walker-steps/s", "epoch_generations": epoch, "deals": dd.deals,
+                           "all_to_all_bytes_per_gpu_per_deal": NWALKERS_PER_GPU * (NDIM + 2) * 8,
+                           "accept_ratio_mean": float(r["naccept"].sum() / nw / max(1, G - nburn)),
+                           "posterior_mean_absmax": float(np.abs(dmean).max()),
+                           "posterior_var_minmax": [float(dvar.min()), float(dvar.max())], "nmoment": int(r["n"]),
+                           "note": "dealt sub-ensembles (kmc_config.deal_count): same target distribution, partner pool = this GPU's complementary "
+                                   "half (not the reference's whole-ensemble rule), walkers re-dealt across the GPUs by one RCCL all_to_all_single "
+                                   "per epoch; bit-identical to the oracle's restatement kmco_emcee_dealt (tests/test_gpu_dealt.py)"}
+    except Exception as e:  # noqa: BLE001
+        extras["dealt"] = {"error": str(e)}
+
+    if res["mode"] == "p2p" and not bench_test_opt("no-allgather-extra"):
+        try:
+            extras["allgather_started"] = True
+            ag = make_allgather(job, "allgather-extra-setup", fatal=False)
+            if ag is not None:
+                with rung("allgather-extra", fatal=False):
+                    gens = min(G, 1024)
+                    dta = job.max_over_ranks(job.timed(ag, gens, 128))
+                    apos, aacc = ag.positions(), ag.naccept()
+                    how_ag = ag.sampler.describe()
+                    ag.close()
+                same = None
+                if rank == 0:
+                    rp, ra, _ = job.unsharded(gens)
+                    same = bool(np.array_equal(rp, apos) and np.array_equal(ra, aacc))
+                extras["allgather"] = {"value": float(nw) * gens / dta, "unit": "walker-steps/s", "generations": gens,
+                                       "us_per_half_step": dta / (2 * gens) * 1e6, "equals_unsharded_run": same,
+                                       "bytes_received_per_gpu_per_half_step": (world - 1) * (NWALKERS_PER_GPU // 2) * NDIM * 8,
+                                       "execution": how_ag.split(";")[-1].strip(),
+                                       "note": "exact partner rule; full replica per rank, in-place ncclAllGather of the updated half per half-step"}
+            else:
+                extras["allgather"] = {"error": "native RCCL all-gather could not be set up on every rank (see stderr)"}
+        except Exception as e:  # noqa: BLE001
+            extras["allgather"] = {"error": str(e)}
+
+
+def full_record(job: Job, res: dict, timed_out=None) -> dict:
+    """Everything measured so far as one record (rank 0; at the end -- or from the watchdog of an extra that hangs)."""
+    args, world = job.args, job.world
+    value = float(job.nw) * job.G / res["elapsed"]
+    mean = res["msum"] / max(1, res["nmom"])
+    var = res["msq"] / max(1, res["nmom"]) - mean ** 2
+    # dominant kernel: the half-step kernel `how` describes; one launch = one half-step of this rank
+    walkers_per_launch = NWALKERS_PER_GPU // 2
+    launch_us = res["event_ms"] * 1e3 / max(1, res["launches"])
+    rows_here = NWALKERS_PER_GPU if (job.sharded and res["mode"] == "p2p") else job.nw             # (replica modes hold the whole ensemble)
+    how = res["how"]
+    roof = roofline_block(job.pdf, how, walkers_per_launch, NDIM, launch_us, res["launches"], state_bytes(rows_here, NDIM, moment_bytes(how)), "c2", use_record=not job.sharded)
+    out = {
+        "metric": "walker-steps/sec", "value": value, "unit": "walker-steps/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["elapsed"] * 1e3 / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"C2: emcee stretch move, {NWALKERS_PER_GPU} walkers/GPU x {NDIM}-dim isotropic Gaussian, "
+                               f"{job.G} generations (burn-in {job.nburn}), a=2, moments on, chain off",
+                   "nwalkers_total": job.nw, "ndim": NDIM, "generations": job.G, "gens_per_step": GENS_PER_STEP,
+                   "parallelism": "single GPU" if not job.sharded else res["parallelism"],
+                   "execution": how},
+        "roofline": roof,
+        "check": {"accept_ratio_mean": res["acc"], "posterior_mean_absmax": float(np.abs(mean).max()),
+                  "posterior_var_min": float(var.min()), "posterior_var_max": float(var.max()),
+                  "nmoment": int(res["nmom"])},
+    }
+    if job.sharded:
+        extras = res["extras"]
+        out["collective"] = job.collective
+        out["ladder"] = list(LADDER)             # every rung rank 0 went through: {rung, ok, s}
+        out["value_from"] = res["value_from"]    # the rung whose timed run is `value`
+        out["check"]["timed_run_equals_unsharded_run"] = res["verified"]
+        out["dealt_mode"] = extras["dealt"] if extras["dealt"] is not None else {"error": timed_out or "not run"}
+        if extras["allgather"] is not None or (timed_out and extras["allgather_started"]):
+            out["allgather_mode"] = extras["allgather"] if extras["allgather"] is not None else {"error": timed_out}
+        if timed_out:
+            out["extras_timed_out"] = timed_out
+        # what the exchange has to move (DESIGN.md section 7): partners are uniform over the whole complementary half, so (P-1)/P of a
+        # rank's partner rows are remote, 1/P from each peer over that pair's single xGMI link (~77 GB/s one direction); pull variants move
+        # every drawn row once (bytes_per_link from each peer), push variants accepted rows only (push_bytes_per_link to each peer)
+        rows_per_peer = walkers_per_launch / world
+        lazy = res["lazy_stats"]
+        out["fabric"] = {"remote_partner_bytes_per_gpu_per_launch": rows_per_peer * (world - 1) * NDIM * 8,
+                         "bytes_per_link_per_launch": rows_per_peer * NDIM * 8,
+                         "link_bound_us_at_77GBs": rows_per_peer * NDIM * 8 / 77e9 * 1e6,
+                         "push_bytes_per_link_per_launch": res["acc"] * walkers_per_launch * NDIM * 8,
+                         "variants_us_per_launch": {tag: tc / 2048 * 1e6 for tag, tc in res["tried"]},   # 1024 generations each
+                         "lazy_pulled_fraction_rank0": (lazy[1] / lazy[0]) if (res["mode"] == "p2p" and lazy[0]) else None}
+    else:
+        out["island_mode"] = res.get("island")
+    for key in ("other_configs", "cpu_baseline"):
+        if key in res:
+            out[key] = res[key]
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -647,558 +1282,35 @@ def main():
     import torch
     import kissmcmc_jl_amd as kmc
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        args.gpus = world                        # the launcher decides (python -m torch.distributed.run --nproc-per-node N)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP emcee path has no CPU fallback")
-    # one rank per GPU; (testing only: KMC_BENCH_TEST=backend=gloo lets several ranks share one GPU,
-    # which RCCL refuses -- the peer-to-peer exchange itself is the same code)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    args.gpus = world                            # the launcher decides (python -m torch.distributed.run --nproc-per-node N)
+    # one rank per GPU; (testing only: KMC_BENCH_TEST=backend=gloo lets several ranks share one GPU, which RCCL refuses -- the
+    # peer-to-peer exchange itself is the same code)
     if world > torch.cuda.device_count() and bench_test_opt("backend", "nccl") == "nccl":
         raise SystemExit(f"bench.py --gpus {world}: one rank per GPU over RCCL, but this node shows {torch.cuda.device_count()} device(s) "
                          "(KMC_BENCH_TEST=backend=gloo rehearses several ranks on fewer devices)")
-    local_rank = local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(local_rank)
-    # KMC_BENCH_TEST=force-sharded (testing): take the N > 1 code path with ONE rank -- the whole ladder over the real collective
-    # backend (RCCL communicator of one rank, captured all-gathers, all_to_all_single of the dealt mode) on a one-GPU box
-    sharded = world > 1 or bool(bench_test_opt("force-sharded"))
-    dist = None
-    if sharded:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        import torch.distributed as dist
-        backend = bench_test_opt("backend", "nccl")
-        import datetime
-        with rung("process-group rendezvous"):
-            if backend == "nccl":
-                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=600))
-            else:
-                dist.init_process_group(backend, timeout=datetime.timedelta(seconds=600))
-            # did the collective backend really see every rank?  one all-reduce of ones (on the device: RCCL over xGMI for "nccl")
-            seen = torch.ones(1, device="cuda")
-            dist.all_reduce(seen)
-            torch.cuda.synchronize()
-        try:
-            rv = torch.cuda.nccl.version()
-            rccl_version = ".".join(str(v) for v in rv) if isinstance(rv, tuple) else str(rv)
-        except Exception:  # noqa: BLE001
-            rccl_version = None
-        collective = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks_seen_by_all_reduce": int(seen.item()),
-                      "rccl_version": rccl_version, "native_rccl_version": kmc.Sampler.rccl_version(),
-                      "launcher": "bench.py itself (one child process per rank)" if os.environ.get("KMC_BENCH_SELF_SPAWNED") else "external (torch.distributed.run)",
-                      "rank_env": {k: os.environ.get(k) for k in ("HSA_ENABLE_IPC_MODE_LEGACY", "OMP_NUM_THREADS")}}
+    job = Job(args, torch, kmc)
+    torch.cuda.set_device(job.local_rank)
 
-    extras = {"dealt": None, "allgather": None, "allgather_started": False}
-
-    def result_line(timed_out=None):
-        """The JSON line from what has been measured so far (rank 0; called at the end -- or by the watchdog of an extra that hangs)."""
-        steps_total = float(nw) * G
-        value = steps_total / elapsed
-        mean = msum / max(1, nmom)
-        var = msq / max(1, nmom) - mean ** 2
-        # dominant kernel: the half-step kernel `how` describes; one launch = one half-step of this rank
-        walkers_per_launch = NWALKERS_PER_GPU // 2
-        launch_us = event_ms * 1e3 / max(1, launches)
-        rows_here = NWALKERS_PER_GPU if (sharded and mode == "p2p") else nw             # (replica modes hold the whole ensemble)
-        roof = roofline_block(pdf, how, walkers_per_launch, NDIM, launch_us, launches, state_bytes(rows_here, NDIM, moment_bytes(how)), "c2", use_record=not sharded)
-        out = {
-            "metric": "walker-steps/sec", "value": value, "unit": "walker-steps/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"C2: emcee stretch move, {NWALKERS_PER_GPU} walkers/GPU x {NDIM}-dim isotropic Gaussian, "
-                                   f"{G} generations (burn-in {nburn}), a=2, streaming moments on, chain off",
-                       "nwalkers_total": nw, "ndim": NDIM, "generations": G, "gens_per_step": GENS_PER_STEP,
-                       "parallelism": "single GPU" if not sharded else parallelism,
-                       "execution": how},
-            "roofline": roof,
-            "check": {"accept_ratio_mean": acc, "posterior_mean_absmax": float(np.abs(mean).max()),
-                      "posterior_var_min": float(var.min()), "posterior_var_max": float(var.max()),
-                      "nmoment": int(nmom)},
-        }
-        if sharded:
-            out["collective"] = collective
-            out["ladder"] = LADDER                   # every rung rank 0 went through: {rung, ok, s}
-            out["value_from"] = value_from           # the rung whose timed run is `value`
-            out["check"]["timed_run_equals_unsharded_run"] = verified
-            out["dealt_mode"] = extras["dealt"] if extras["dealt"] is not None else {"error": timed_out or "not run"}
-            if extras["allgather"] is not None or (timed_out and extras["allgather_started"]):
-                out["allgather_mode"] = extras["allgather"] if extras["allgather"] is not None else {"error": timed_out}
-            if timed_out:
-                out["extras_timed_out"] = timed_out
-            # what the exchange has to move (DESIGN.md section 6): partners are uniform over the whole complementary half,
-            # so (P-1)/P of a rank's partner rows are remote, 1/P from each peer over that pair's single xGMI link
-            rows_per_peer = walkers_per_launch / world
-            out["fabric"] = {"remote_partner_bytes_per_gpu_per_launch": rows_per_peer * (world - 1) * NDIM * 8,
-                             "bytes_per_link_per_launch": rows_per_peer * NDIM * 8,
-                             "link_bound_us_at_77GBs": rows_per_peer * NDIM * 8 / 77e9 * 1e6,
-                             "push_bytes_per_link_per_launch": acc * walkers_per_launch * NDIM * 8,
-                             "variants_us_per_launch": {label: tc / 2048 * 1e6 for label, tc in tried},   # 1024 generations each
-                             "lazy_pulled_fraction_rank0": (lazy_stats[1] / lazy_stats[0]) if (mode == "p2p" and lazy_stats[0]) else None,
-                             "note": "pull variants move every drawn row once (bytes_per_link from each peer); push variants move "
-                                     "accepted rows only (push_bytes_per_link to each peer); link figure = one xGMI link, one "
-                                     "direction (~77 GB/s); config.parallelism names the variant that ran (default: one variant; "
-                                     "KMC_BENCH_EXCHANGE=all measures all six)"}
-        return out
-
-    nw = NWALKERS_PER_GPU * world
-    G = args.steps * GENS_PER_STEP
-    nburn = G // 2
-    pdf = kmc.GaussianIso()
-    th = theta0_c2(nw)
-    launches = 0
-
-    if not sharded:
-        s = kmc.Sampler(pdf, nw, NDIM, G, nburn, 1, 2.0, SEED, moments=True, device=local_rank)
-        s.set_positions(th)
-        for _ in range(args.warmup):
-            s.run(GENS_PER_STEP)
-        s.sync()
-        s.set_positions(th)                      # restart: the timed region is the whole C2 job
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        s.run(G)                                 # exactly `steps` steps of GENS_PER_STEP generations
-        s.sync()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-        event_ms = s.last_run_ms()               # HIP events on the sampler's own stream
-        launches = s.launch_count
-        how = s.describe()
-        msum, msq, nmom = s.moments()
-        acc = float(s.accept_ratio().mean())
-        s.close()
-        # Extra, NOT `value`: the opt-in island mode (256-walker islands resident in LDS, partners drawn
-        # inside the island, walkers re-dealt every 64 generations) on the same job.
-        island = None
-        try:
-            if args.no_island:
-                raise RuntimeError("skipped (--no-island)")
-            with kmc.Sampler(pdf, nw, NDIM, G, nburn, 1, 2.0, SEED, moments=True, device=local_rank,
-                             island_gens=64, island_size=256) as si:
-                si.set_positions(th)
-                si.run(GENS_PER_STEP)
-                si.sync()
-                si.set_positions(th)
-                si.run(G)
-                si.sync()
-                ims = si.last_run_ms()
-                isum, isq, inm = si.moments()
-                imean = isum / max(1, inm)
-                island = {"value": float(nw) * G / (ims * 1e-3), "unit": "walker-steps/s", "island_size": 256, "island_gens": 64,
-                          "accept_ratio_mean": float(si.accept_ratio().mean()),
-                          "posterior_mean_absmax": float(np.abs(imean).max()),
-                          "posterior_var_minmax": [float((isq / inm - imean ** 2).min()), float((isq / inm - imean ** 2).max())],
-                          "note": "KMC_ISLANDS: same target distribution, partner pool = the island's complementary half "
-                                  "(not the reference's whole-ensemble rule); bit-exact against the oracle's island restatement"}
-        except Exception as e:  # noqa: BLE001
-            island = {"error": str(e)}
+    if not job.sharded:
+        res = run_single(job)
+        if not args.no_other_configs:
+            res["other_configs"] = other_configs(kmc, job.local_rank)
+        if not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline()
     else:
-        # Walker-sharded, one rank per GPU, EXACT partner rule (reference src/samplers.jl:250: partners from the whole
-        # complementary half).  Exchange: peer-to-peer partner reads over xGMI (KMC_P2P: only the rows that are drawn cross
-        # the fabric, the whole run is enqueued like the single-GPU case).  By default ONE variant is set up -- pull of the
-        # drawn rows (system-scope loads), separate signal kernel: the one whose correctness does not depend on cache state
-        # -- admitted by a bit-exact self-check; KMC_BENCH_EXCHANGE=all also tries the other variants and runs the fastest
-        # admitted one; KMC_BENCH_EXCHANGE=allgather (or any failure) uses the RCCL all-gather of the updated half per
-        # half-step.  The TIMED run itself is then verified against the unsharded run of the whole ensemble on rank 0.
-        from kissmcmc_jl_amd.distributed import HipShardExecutor, P2PEmcee, ShardedEmcee
-        mode = os.environ.get("KMC_BENCH_EXCHANGE", "p2p")
-        drv = None
-
-        def fault(point: str):
-            """KMC_BENCH_TEST=fault=<point>:<rank> (testing): that rank fails at that point of the ladder -- every rank must then take
-            the next rung together."""
-            if bench_test_opt("fault") == f"{point}:{rank}":
-                raise RuntimeError(f"injected fault at {point}")
-            if bench_test_opt("fault") == f"{point}_hang:{rank}":      # ... or never comes back (the peers then block in their next collective)
-                time.sleep(10 ** 6)
-
-        def all_ok(flag: bool) -> bool:
-            t = torch.tensor([1.0 if flag else 0.0], device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MIN)
-            return t.item() != 0
-
-        def unsharded(gens):
-            """(positions, naccept, moments) of the whole ensemble after `gens` generations on ONE GPU (this rank's)."""
-            with kmc.Sampler(pdf, nw, NDIM, G, nburn, 1, 2.0, SEED, moments=True, device=local_rank) as ref:
-                ref.set_positions(th)
-                ref.run(gens)
-                ref.sync()
-                return ref.positions(), ref.naccept(), ref.moments()
-
-        def try_p2p(finegrained, fold_signal=False, push=False, lazy=False):
-            """Set up the peer-to-peer exchange and self-check it: 240 generations (hipGraph replays + an eager tail)
-            must reproduce, bit for bit, the same generations of the whole ensemble on ONE GPU (rank 0 runs it
-            unsharded).  Any error, time-out or mismatch on any rank -> None on every rank."""
-            d = None
-            ok = True
-            try:
-                fault("p2p_setup")
-                d = P2PEmcee(pdf, nw, NDIM, G, nburn, 1, 2.0, SEED, device=local_rank, finegrained=finegrained,
-                             fold_signal=fold_signal, push=push, lazy=lazy, connect=False)      # local part only: no collective yet
-            except Exception as e:  # noqa: BLE001
-                note(f"[rank {rank}] p2p set-up failed ({e})")
-                ok = False
-            if all_ok(ok):                                   # every rank has its sampler and handles: now the exchange
-                try:
-                    d.connect()
-                    fault("p2p_connect")
-                except Exception as e:  # noqa: BLE001
-                    note(f"[rank {rank}] p2p connect failed ({e})")
-                    ok = False
-            if all_ok(ok):
-                vgen = 240
-                try:
-                    d.set_positions(th)
-                    d.run(vgen)
-                    d.sync()                                  # (a peer wait that timed out surfaces here, on the ranks that waited)
-                    fault("p2p_selfcheck")
-                except Exception as e:  # noqa: BLE001
-                    note(f"[rank {rank}] p2p self-check failed ({e})")
-                    ok = False
-                ok = all_ok(ok)                               # every rank's kernels ran through: only then the result collectives
-                try:
-                    if not ok:
-                        raise RuntimeError("a rank failed before the results were gathered")
-                    vpos, vacc = d.positions(), d.naccept()
-                    if rank == 0:
-                        rpos, racc, _ = unsharded(vgen)
-                        if not (np.array_equal(rpos, vpos) and np.array_equal(racc, vacc)):
-                            note(f"[rank 0] p2p self-check (finegrained={finegrained}, fold_signal={fold_signal}, push={push}, lazy={lazy}): "
-                                 "sharded run differs from the single-GPU run")
-                            ok = False
-                except Exception as e:  # noqa: BLE001
-                    note(f"[rank {rank}] p2p self-check failed ({e})")
-                    ok = False
-                ok = all_ok(ok)
-            else:
-                ok = False
-            if not ok:
-                if d is not None:
-                    try:
-                        d.sampler.close()
-                    except Exception:  # noqa: BLE001
-                        pass
-                return None
-            return d
-
-        def make_allgather(what, fatal=True):
-            """The native all-gather exchange, set up in two votes: every rank's local part (its replica sampler), then the
-            collective part (unique id, ncclCommInitRank, the capture vote).  The connected driver, or None on EVERY rank."""
-            from kissmcmc_jl_amd.distributed import AllGatherEmcee
-            d, ok = None, True
-            try:
-                fault("allgather_setup")
-                d = AllGatherEmcee(pdf, nw, NDIM, G, nburn, 1, 2.0, SEED, device=local_rank, connect=False)
-            except Exception as e:  # noqa: BLE001
-                note(f"[rank {rank}] native RCCL all-gather set-up failed ({e})")
-                ok = False
-            if all_ok(ok):
-                try:
-                    with rung(what, fatal=fatal):
-                        d.connect()
-                        fault("allgather_connect")
-                except Exception as e:  # noqa: BLE001
-                    note(f"[rank {rank}] native RCCL all-gather set-up failed ({e})")
-                    ok = False
-                ok = all_ok(ok)
-            else:
-                ok = False
-            if not ok and d is not None:
-                try:
-                    d.sampler.close()
-                except Exception:  # noqa: BLE001
-                    pass
-            return d if ok else None
-
-        def time_short(d, gens=1024):       # long enough to reach the steady state of the replayed graphs (16 chunks)
-            """Seconds for `gens` generations (max over ranks), from a common start."""
-            d.set_positions(th)
-            dist.barrier()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            d.run(gens)
-            d.sync()
-            torch.cuda.synchronize()
-            dist.barrier()
-            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            return float(t.item())
-
-        p2p_memory = None
-        tried = []
-        verified = None
-        if mode in ("p2p", "all"):
-            #   pull: partner rows are read from the owning GPU (every drawn row crosses the fabric once);
-            #   push: every rank keeps local copies of the other shards, accepted rows are written to all peers;
-            #   lazy pull: local copies filled on demand (accept bytes published, rows pulled when stale);
-            #   folded signal: the half-step kernel publishes its own progress flag instead of a separate signal kernel.
-            # push / lazy have peers write into plain device memory the local kernel then reads through its own L2: whether
-            # that L2 can serve stale lines could never be observed on one GPU -- they run only on request and only if
-            # their self-check passes.
-            cands = [("pull of drawn rows (system-scope loads), signal kernel", False, False, False)]
-            if mode == "all":
-                cands += [("pull of drawn rows (system-scope loads), signal folded into the kernel", True, False, False),
-                          ("push of accepted rows into local copies, signal kernel", False, True, False),
-                          ("push of accepted rows into local copies, signal folded into the kernel", True, True, False),
-                          ("lazy pull into local copies, signal kernel", False, False, True),
-                          ("lazy pull into local copies, signal folded into the kernel", True, False, True)]
-            for label, fold, push, lazy in cands:
-                with rung(f"p2p set-up + self-check ({label})") as rg:
-                    cand = try_p2p(False, fold, push, lazy)
-                    rg.ok = cand is not None
-                if cand is None:
-                    continue
-                if len(cands) == 1:
-                    drv, p2p_memory = cand, label
-                    break
-                with rung(f"p2p short timing ({label})"):
-                    tc = time_short(cand)
-                tried.append((label, tc))
-                if drv is None or tc < best_t:
-                    if drv is not None:
-                        drv.close()
-                    drv, best_t, p2p_memory = cand, tc, label
-                else:
-                    cand.close()
-            if drv is None:
-                with rung("p2p set-up + self-check (fine-grained rows)") as rg:
-                    drv = try_p2p(True, False)
-                    rg.ok = drv is not None
-                if drv is not None:
-                    p2p_memory = "pull of drawn rows, rows in fine-grained memory, signal kernel"
-            if rank == 0 and tried:
-                note("[rank 0] p2p variants, s per 1024 generations: " + "; ".join(f"{l}: {t:.4f}" for l, t in tried))
-            if drv is None:
-                if rank == 0:
-                    note("[rank 0] falling back to the RCCL all-gather exchange")
-                mode = "allgather"
-            else:
-                mode = "p2p"
-        lazy_stats = (0, 0)
-        if mode == "p2p":
-            ok = True
-            try:
-                with rung('p2p warm-up + timed run'):
-                    drv.set_positions(th)
-                    drv.run(args.warmup * GENS_PER_STEP)
-                    drv.sync()
-                    drv.set_positions(th)                # barriers inside; restart the job
-                    dist.barrier()
-                    torch.cuda.synchronize()
-                    t0 = time.perf_counter()
-                    drv.run(G)
-                    try:
-                        drv.sync()
-                        fault("p2p_run")
-                        ran = True
-                    except Exception as e:  # noqa: BLE001  (a timed-out peer wait: the other ranks must not be left inside a collective)
-                        note(f"[rank {rank}] the p2p run failed ({e})")
-                        ran = False
-                    torch.cuda.synchronize()
-                    if not all_ok(ran):
-                        raise RuntimeError("a rank's peer-to-peer run did not complete")
-                    dist.barrier()
-                    elapsed = time.perf_counter() - t0
-                    event_ms = drv.sampler.last_run_ms()
-                    launches = drv.sampler.launch_count
-                    msum, msq, nmom = drv.moments()
-                    fpos, facc = drv.positions(), drv.naccept()
-                    acc = float(facc.sum() / nw / max(1, G - nburn))
-                    lazy_stats = drv.sampler.p2p_stats()         # (remote partner draws, pulled) on this rank; (0, 0) unless lazy ran
-                    how = drv.sampler.describe()
-                    drv.close()
-            except Exception as e:  # noqa: BLE001  (e.g. a peer wait that timed out: every rank then takes the fallback)
-                note(f"[rank {rank}] the p2p run failed ({e})")
-                ok = False
-                try:
-                    drv.sampler.close()
-                except Exception:  # noqa: BLE001
-                    pass
-            if not all_ok(ok):
-                if rank == 0:
-                    note("[rank 0] falling back to the RCCL all-gather exchange")
-                mode = "allgather"
-        if mode == "p2p":
-            # the timed run itself, against the unsharded run of the whole job on one GPU (rank 0)
-            if rank == 0:
-                rpos, racc, (rs, rq, rn) = unsharded(G)
-                verified = bool(np.array_equal(rpos, fpos) and np.array_equal(racc, facc) and rn == nmom and
-                                np.allclose(rs, msum, rtol=1e-10, atol=1e-6) and np.allclose(rq, msq, rtol=1e-10, atol=1e-6))
-                if not verified:
-                    note("[rank 0] the TIMED sharded run differs from the unsharded run of the same job")
-            parallelism = (f"walker-sharded x{world}, exact partner rule, peer-to-peer exchange over xGMI (IPC): {p2p_memory}; "
-                           "progress-flag ordering")
-            value_from = 'p2p warm-up + timed run'
-        else:
-            # The exchange the north star names: an RCCL all-gather of the updated half after every half-step.  Native form
-            # first (kmc_sampler_run enqueues kernel + ncclAllGather per half-step, inside the hipGraph chunks); if that cannot
-            # be set up on every rank, the same exchange as a torch collective per half-step from Python.
-            from kissmcmc_jl_amd.distributed import AllGatherEmcee
-            nat = make_allgather('native RCCL all-gather set-up (ncclCommInitRank)')
-            if nat is not None:
-                with rung('native RCCL all-gather warm-up + timed run'):
-                    nat.set_positions(th)
-                    nat.run(min(args.warmup * GENS_PER_STEP, 200))
-                    nat.sync()
-                    nat.set_positions(th)
-                    dist.barrier()
-                    torch.cuda.synchronize()
-                    t0 = time.perf_counter()
-                    nat.run(G)
-                    nat.sync()
-                    torch.cuda.synchronize()
-                    dist.barrier()
-                    elapsed = time.perf_counter() - t0
-                    event_ms = nat.sampler.last_run_ms()
-                    launches = nat.sampler.launch_count
-                    msum, msq, nmom = nat.moments()
-                    facc, fpos = nat.naccept(), nat.positions()
-                    how_nat = how = nat.sampler.describe()
-                    nat.close()
-                parallelism = f"walker-sharded x{world}, exact partner rule, native RCCL all-gather of the updated half per half-step ({how_nat.split(';')[-1].strip()})"
-                value_from = 'native RCCL all-gather warm-up + timed run'
-            else:
-                with rung('torch-collective all-gather warm-up + timed run'):
-                    ex = HipShardExecutor(pdf, nw, NDIM, G, nburn, 1, 2.0, SEED, rank=rank, world=world, device=local_rank)
-                    ex.set_positions(th)
-                    sdrv = ShardedEmcee(ex, nw, NDIM)
-                    sdrv.run(min(args.warmup * GENS_PER_STEP, 100))   # warm-up: kernels + RCCL rings
-                    ex.sync()
-                    ex.set_positions(th)
-                    sdrv.generation = 0
-                    dist.barrier()
-                    torch.cuda.synchronize()
-                    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    t0 = time.perf_counter()
-                    ev0.record()                         # the executor launches on torch's current stream
-                    sdrv.run(G)
-                    ev1.record()
-                    ex.sync()
-                    torch.cuda.synchronize()
-                    dist.barrier()
-                    elapsed = time.perf_counter() - t0
-                    event_ms = ev0.elapsed_time(ev1)
-                    launches = 2 * G
-                    msum, msq, nmom = sdrv.moments()
-                    facc = sdrv.naccept()
-                    fpos = sdrv.positions()
-                    how = ex.sampler.describe()
-                    ex.close()
-                parallelism = f"walker-sharded x{world}, exact partner rule, RCCL all-gather of the updated half per half-step (torch collective per half-step)"
-                value_from = 'torch-collective all-gather warm-up + timed run'
-            acc = float(facc.sum() / nw / max(1, G - nburn))
-            if rank == 0:
-                rpos, racc, (rs, rq, rn) = unsharded(G)
-                verified = bool(np.array_equal(rpos, fpos) and np.array_equal(racc, facc))
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-        # Extra, NOT `value`: dealt sub-ensembles -- every GPU runs the reference's algorithm unchanged on its own 65 536
-        # walkers (partners from its own complementary half) for an epoch, then ONE RCCL all_to_all_single re-deals the
-        # walkers across the GPUs (state-independent permutation).  Same target distribution, no per-half-step exchange.
-        PENDING["line"] = result_line          # `value` stands from here on: an extra that hangs costs its own numbers only
-        try:
-            from kissmcmc_jl_amd.distributed import DealtEmcee, HipDealExecutor
-            epoch = int(bench_test_opt("deal-epoch", 64))
-            dex, okd = None, True
-            try:                                         # local part first, then a vote: nobody enters the collectives alone
-                fault("dealt_setup")
-                dex = HipDealExecutor(pdf, NWALKERS_PER_GPU, NDIM, G, nburn, 1, 2.0, SEED, rank=rank, world=world, device=local_rank)
-            except Exception as e:  # noqa: BLE001
-                note(f"[rank {rank}] dealt sub-ensembles: set-up failed ({e})")
-                okd = False
-            if not all_ok(okd):
-                if dex is not None:
-                    dex.close()
-                raise RuntimeError("the dealt mode could not be set up on every rank (see stderr)")
-            with rung('dealt sub-ensembles (extra)', fatal=False):
-                fault("dealt_run")
-                dd = DealtEmcee(dex, nw, NDIM, epoch)
-                dd.set_positions(th)
-                dd.run(args.warmup * GENS_PER_STEP)
-                dd.sync()
-                dd.set_positions(th)
-                dist.barrier()
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                dd.run(G)
-                dd.sync()
-                torch.cuda.synchronize()
-                dist.barrier()
-                dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
-                dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-                res = dd.results()
-                dd.close()
-            dmean = res["sum"] / max(1, res["n"])
-            dvar = res["sumsq"] / max(1, res["n"]) - dmean ** 2
-            extras["dealt"] = {"value": float(nw) * G / float(dt.item()), "unit": "walker-steps/s", "epoch_generations": epoch, "deals": dd.deals,
-                     "all_to_all_bytes_per_gpu_per_deal": NWALKERS_PER_GPU * (NDIM + 2) * 8,
-                     "accept_ratio_mean": float(res["naccept"].sum() / nw / max(1, G - nburn)),
-                     "posterior_mean_absmax": float(np.abs(dmean).max()),
-                     "posterior_var_minmax": [float(dvar.min()), float(dvar.max())], "nmoment": int(res["n"]),
-                     "note": "dealt sub-ensembles (kmc_config.deal_count): same target distribution, partner pool = this GPU's complementary "
-                             "half (not the reference's whole-ensemble rule), walkers re-dealt across the GPUs by one RCCL all_to_all_single "
-                             "per epoch; bit-identical to the oracle's restatement kmco_emcee_dealt (tests/test_gpu_dealt.py)"}
-        except Exception as e:  # noqa: BLE001
-            extras["dealt"] = {"error": str(e)}
-
-    # Extra, NOT `value` (N > 1, when the peer-to-peer pull supplied `value`): the exchange the north star names -- one RCCL all-gather
-    # of the updated half after every half-step, enqueued with the kernels inside the hipGraph chunks -- on a bounded piece
-    # of the same job, so that both exchanges are on record from the same node.
-    if sharded and mode == "p2p" and not bench_test_opt("no-allgather-extra"):
-        try:
-            from kissmcmc_jl_amd.distributed import AllGatherEmcee
-            extras["allgather_started"] = True
-            ag = make_allgather('native RCCL all-gather set-up (extra)', fatal=False)
-            if ag is not None:
-                with rung('native RCCL all-gather (extra)', fatal=False):
-                    gens = min(G, 1024)
-                    ag.set_positions(th)
-                    ag.run(128)
-                    ag.sync()
-                    ag.set_positions(th)
-                    dist.barrier()
-                    torch.cuda.synchronize()
-                    t0 = time.perf_counter()
-                    ag.run(gens)
-                    ag.sync()
-                    torch.cuda.synchronize()
-                    dist.barrier()
-                    dta = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
-                    dist.all_reduce(dta, op=dist.ReduceOp.MAX)
-                    apos, aacc = ag.positions(), ag.naccept()
-                    how_ag = ag.sampler.describe()
-                    ag.close()
-                same = None
-                if rank == 0:
-                    rp, ra, _ = unsharded(gens)
-                    same = bool(np.array_equal(rp, apos) and np.array_equal(ra, aacc))
-                extras["allgather"] = {"value": float(nw) * gens / float(dta.item()), "unit": "walker-steps/s", "generations": gens,
-                                   "us_per_half_step": float(dta.item()) / (2 * gens) * 1e6, "equals_unsharded_run": same,
-                                   "bytes_received_per_gpu_per_half_step": (world - 1) * (NWALKERS_PER_GPU // 2) * NDIM * 8,
-                                   "execution": how_ag.split(";")[-1].strip(),
-                                   "note": "exact partner rule; full replica per rank, in-place ncclAllGather of the updated half per half-step"}
-            else:
-                extras["allgather"] = {"error": "native RCCL all-gather could not be set up on every rank (see stderr)"}
-        except Exception as e:  # noqa: BLE001
-            extras["allgather"] = {"error": str(e)}
-
-    if rank == 0:
-        out = result_line()
-        if not sharded:
-            out["island_mode"] = island
-            if not args.no_other_configs:
-                out["other_configs"] = other_configs(kmc, local_rank)
-        if not sharded and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+        rendezvous(job)
+        res = run_sharded(job)
+        # `value` stands from here on: an extra that hangs costs its own numbers only (the watchdog prints the result as it stands)
+        PENDING["line"] = lambda reason: emit(full_record(job, res, reason))
+        run_extras(job, res)
+    if job.rank == 0:
         PENDING["line"] = None
-        print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+        emit(full_record(job, res))
+    if job.dist is not None:
+        job.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -38,14 +38,42 @@ uint64_t fnv1a(uint64_t h, const void* data, size_t n)
 // are cached on disk like hiprtc's.  KMC_DEBUG=rtc=hipcc asks for it (any compile), KMC_DEBUG=rtc=hiprtc forbids it; unset: the samplers ask
 // for it for big ensembles only (kmc_sampler_create: >= 16 384 walkers, multi-launch kernels), where it pays.
 thread_local int g_offline_wanted = 0;
+// A profiler's environment: its preloaded library initialises the GPU in every process that inherits it, and hipcc is a driver that
+// execs clang and lld -- the launcher-hop-under-the-profiler pattern this pool's machines do not survive.  Two guards: under a profiler
+// no child compiler is started at all (in-process hiprtc instead), and a child never inherits these variables (child_environment).
+bool tool_variable(const char* entry)
+{
+    for (const char* prefix : {"LD_PRELOAD=", "HSA_TOOLS_LIB=", "HSA_TOOLS_REPORT_LOAD_FAILURE=", "ROCP_", "ROCPROFILER_", "ROCPROF", "ROCTRACER_", "HSA_VEN_AMD_AQLPROFILE", "AQLPROFILE_"})
+        if (std::strncmp(entry, prefix, std::strlen(prefix)) == 0) return true;
+    return false;
+}
+bool under_a_profiler()
+{
+    for (const char* var : {"LD_PRELOAD", "HSA_TOOLS_LIB"})
+        if (const char* v = std::getenv(var))
+            for (const char* lib : {"rocprof", "roctracer", "rocprofiler", "librocp", "omnitrace", "rocsys"})
+                if (std::strstr(v, lib)) return true;
+    return std::getenv("ROCPROFILER_LIBRARY_CTOR") != nullptr || std::getenv("ROCP_TOOL_LIBRARIES") != nullptr;
+}
 bool offline_compiler_wanted()
 {
+    static const bool profiled = under_a_profiler();
+    if (profiled) return false;                          // (whatever KMC_DEBUG=rtc says: the child compiler is never started under a tool)
     std::string e;
     if (debug_opt("rtc", &e)) {
         if (e == "hiprtc") return false;
         if (e == "hipcc") return true;
     }
     return g_offline_wanted != 0;
+}
+// the parent's environment without any tool / preload variable: what a child compiler is started with
+std::vector<char*> child_environment()
+{
+    std::vector<char*> env;
+    for (char** e = environ; e && *e; ++e)
+        if (!tool_variable(*e)) env.push_back(*e);
+    env.push_back(nullptr);
+    return env;
 }
 std::string find_hipcc()
 {
@@ -85,19 +113,29 @@ kmc_status compile_offline(const std::string& text, int nheaders, const char* co
         posix_spawn_file_actions_addopen(&fa, 1, "/dev/null", O_WRONLY, 0);
         posix_spawn_file_actions_addopen(&fa, 2, errf.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0600);
         pid_t pid = 0;
-        const int rc = posix_spawn(&pid, hipcc.c_str(), &fa, nullptr, argv.data(), environ);     // a CHILD process: this one is never replaced
+        std::vector<char*> envp = child_environment();
+        const int rc = posix_spawn(&pid, hipcc.c_str(), &fa, nullptr, argv.data(), envp.data());     // a CHILD process: this one is never replaced
         posix_spawn_file_actions_destroy(&fa);
         if (rc == 0) {
             int status = 0;
             // (bounded: a compiler that does not come back within two minutes is killed and hiprtc takes over)
-            bool done = false;
+            bool done = false, reaped_elsewhere = false, not_ours = false;
             for (int tick = 0; tick < 12000 && !done; ++tick) {
                 const pid_t w = ::waitpid(pid, &status, WNOHANG);
                 if (w == pid) done = true;
+                else if (w < 0 && errno == ECHILD) {
+                    // the host reaps children itself (SIGCHLD set to SIG_IGN, or a handler that waits for any child): no status to
+                    // be had, and the pid may already be somebody else's -- never signal it; the object file says how the compile went
+                    not_ours = true;
+                    if (::kill(pid, 0) != 0) { reaped_elsewhere = done = true; }
+                    else ::usleep(10000);
+                }
                 else if (w < 0 && errno != EINTR) break;
                 else ::usleep(10000);
             }
-            if (!done) { (void)::kill(pid, SIGKILL); while (::waitpid(pid, &status, 0) < 0 && errno == EINTR) {} status = 0x7f00; }
+            if (reaped_elsewhere) status = (::access((d + "/prog.co").c_str(), R_OK) == 0) ? 0 : 0x0100;
+            else if (!done && not_ours) status = 0x7f00;                      // (still a process of that number after two minutes: not known to be ours)
+            else if (!done) { (void)::kill(pid, SIGKILL); while (::waitpid(pid, &status, 0) < 0 && errno == EINTR) {} status = 0x7f00; }
             if (WIFEXITED(status) && WEXITSTATUS(status) == 0) {
                 std::ifstream f(d + "/prog.co", std::ios::binary | std::ios::ate);
                 const std::streamsize n = f ? (std::streamsize)f.tellg() : 0;
@@ -542,6 +580,7 @@ kmc_status compile_user(kmc_user_density* ud, bool with_vec, int L, int K, int i
     src << "#include \"kmc_islands.hpp\"\n#include \"kmc_generation.hpp\"\n" << user_functor_source(ud) << user_density_alias(ud, ndim)
         << (ud->is_body && with_vec && ud->sep ? ud->sep_functor + (ud->sep_nacc > 1 ? "using UDV = kmc::SepDensityN<UserS>;\n" : "using UDV = kmc::SepDensity<UserS>;\n")
                                                 : std::string("using UDV = UD;\n"))
+        << "extern \"C\" __device__ const unsigned kmc_user_args_bytes[4] = {(unsigned)sizeof(kmc::HalfStepArgs), (unsigned)sizeof(kmc::GenerationArgs), (unsigned)sizeof(kmc::ResidentArgs), (unsigned)sizeof(kmc::LogpdfArgs)};\n"
         << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_generic(KMC_FRONT_PARAMS, const kmc::HalfStepArgs a) { kmc::half_step_generic_body<UD, " << peer << ", " << rowt << ">(KMC_FRONT_PACK, a); }\n"
         << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_logpdf(const kmc::LogpdfArgs a) { kmc::logpdf_rows_body<UD>(a); }\n"
         << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_init_ball(const kmc::InitBallArgs a) { kmc::init_ball_body<UD>(a); }\n";
@@ -577,10 +616,11 @@ kmc_status compile_user(kmc_user_density* ud, bool with_vec, int L, int K, int i
 
     const char* headers[4] = {h_ker.c_str(), h_dev.c_str(), h_isl.c_str(), h_gen.c_str()};
     const char* names[4] = {"kmc_kernels.hpp", "kmc_device.hpp", "kmc_islands.hpp", "kmc_generation.hpp"};
-    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-mllvm", "-amdgpu-kernarg-preload-count=14"};
+    // (the same -D the library itself was built with: the argument structs have more fields in an experimental build; the options are part of the cache key)
+    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-mllvm", "-amdgpu-kernarg-preload-count=14", "-DKMC_P2P_EXPERIMENTAL"};
     std::vector<char> code;
     std::string log;
-    const kmc_status cst = rtc_compile_cached(text, "kmc_user_density.hip", 4, headers, names, 6, opts, &code, &log);
+    const kmc_status cst = rtc_compile_cached(text, "kmc_user_density.hip", 4, headers, names, kmc::kP2PExperimental ? 7 : 6, opts, &code, &log);
     if (cst == KMC_ERR_BAD_ARG) return fail(KMC_ERR_BAD_ARG, "user density does not compile:\n" + log);
     if (cst != KMC_OK) return cst;
     auto ins = ud->code.emplace(key, std::move(code));
@@ -605,6 +645,20 @@ kmc_status load_user(kmc_user_density* ud, bool with_vec, int L, int K, int iter
         }
         uk->keep = slot;
         uk->mod = static_cast<hipModule_t>(slot.get());
+    }
+    {   // the module's argument structs must be the host's, byte for byte (a module built with other options would read every field
+        // after the first difference from the wrong offset -- silently)
+        hipDeviceptr_t sym = nullptr;
+        size_t nbytes = 0;
+        unsigned theirs[4] = {0, 0, 0, 0};
+        HIP_TRY(hipModuleGetGlobal(&sym, &nbytes, uk->mod, "kmc_user_args_bytes"));
+        if (nbytes != sizeof(theirs)) return fail(KMC_ERR_HIP, "runtime-compiled module: kmc_user_args_bytes has an unexpected size");
+        HIP_TRY(hipMemcpyDtoH(theirs, sym, sizeof(theirs)));
+        const unsigned ours[4] = {(unsigned)sizeof(kmc::HalfStepArgs), (unsigned)sizeof(kmc::GenerationArgs), (unsigned)sizeof(kmc::ResidentArgs), (unsigned)sizeof(kmc::LogpdfArgs)};
+        for (int i = 0; i < 4; ++i)
+            if (ours[i] != theirs[i])
+                return fail(KMC_ERR_HIP, "runtime-compiled module and library disagree on a kernel argument layout (" + std::to_string(theirs[i]) + " against " + std::to_string(ours[i]) +
+                                         " bytes): stale cache or mismatched build options");
     }
     HIP_TRY(hipModuleGetFunction(&uk->generic, uk->mod, "kmc_user_generic"));
     HIP_TRY(hipModuleGetFunction(&uk->logpdf, uk->mod, "kmc_user_logpdf"));

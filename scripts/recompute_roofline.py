@@ -46,7 +46,7 @@ def check(name, roof, nw, nd, tol, out, after_burnin_us=None):
     dev("frac of the 6.29 TB/s copy rate", alg / (roof["avg_launch_us"] * 1e-6) / 1e9 / COPY, roof["frac_of_measured_copy_rate"])
     served = "infinity_cache" if roof["state_bytes"] <= MALL else "hbm"
     out.append(f"    served_from: state {roof['state_bytes'] / 2 ** 20:.0f} MiB -> {served}" + ("" if served == roof["served_from"] else "   <-- the line says " + roof["served_from"]))
-    rec_name = re.search(r"profiles/(traffic_\w+\.json)", roof.get("traffic_source", ""))
+    rec_name = re.search(r"profiles/(traffic_\w+\.json)", (roof.get("profile_record") or {}).get("record") or roof.get("traffic_source", ""))    # (round-4 lines: in the prose)
     rec = json.load(open(os.path.join(ROOT, "profiles", rec_name.group(1)))) if rec_name and roof.get("traffic") else None
     if rec is None:
         out.append("    (no profile record attached to this entry)")
@@ -81,7 +81,13 @@ def check(name, roof, nw, nd, tol, out, after_burnin_us=None):
 def main():
     path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "bench_r04i.json")
     tol = float(sys.argv[2]) if len(sys.argv) > 2 else 0.03
-    line = json.loads([l for l in open(path).read().splitlines() if l.lstrip().startswith("{")][-1])
+    text = open(path).read()
+    try:
+        lines = [json.loads(text)]               # bench_detail.json itself (one indented record)
+    except ValueError:
+        lines = [json.loads(l) for l in text.splitlines() if l.lstrip().startswith("{")]
+    detail = [l["bench_detail"] for l in lines if "bench_detail" in l]      # since round 5 the full record is a line of its own (or bench_detail.json itself)
+    line = detail[-1] if detail else lines[-1]
     out = [f"{os.path.relpath(path, ROOT)}: value {line['value']:.4g} {line['unit']}, {line['ms_per_step']:.3f} ms per step of {line['config']['gens_per_step']} generations"]
     launches = line["steps"] * line["config"]["gens_per_step"] * 2
     out.append(f"  ms_per_step / launches per step = {line['ms_per_step'] * 1e3 / (launches / line['steps']):.4f} us per launch (the line's avg_launch_us: {line['roofline']['avg_launch_us']:.4f})")

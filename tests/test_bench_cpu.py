@@ -36,7 +36,10 @@ def test_tracked_record_is_used_only_for_its_own_geometry():
     assert r["kernel"].startswith("half_step_vec<GaussianIso") and r["geometry"] == rec["geometry"]
     assert abs(r["achieved"] - 32768 * 520 / 3.78e-6 / 1e9) < 1e-6 and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-12
     assert abs(r["body_frac"] - 32768 * 520 / (rec["body_us"] * 1e-6) / 1e9 / 8000.0) < 1e-12
-    assert r["served_from"] == "infinity_cache" and "boundary" in r["limited_by"] and r["bound"] == "hbm"
+    assert r["served_from"] == "infinity_cache" and r["limited_by"] == "kernel_boundary+cache_latency"
+    assert r["bound"] == r["served_from"] and r["priced_against"] == "hbm_spec" and r["peak"] == 8000.0      # `bound` follows where the rows come from
+    assert r["profile_record"]["record"] == "profiles/traffic_c2.json"
+    assert all(not isinstance(v, str) or len(v) < 80 for v in r.values()), "numbers and short enums only: the prose lives in DESIGN.md"
     # ... and every tracked record was taken from the kernel sources of THIS tree (edit kmc_kernels.hpp / kmc_device.hpp -> profile again:
     # scripts/profile_r04.sh + scripts/summarize_r04.py)
     assert r["profile_record"]["kernel_sources_unchanged"] is True
@@ -58,7 +61,7 @@ def test_a_state_beyond_the_infinity_cache_is_served_from_hbm():
     sb = bench.state_bytes(2097152, 32, bench.moment_bytes(how))
     assert sb > bench.MALL_BYTES
     r = bench.roofline_block(GaussianIso(), how, 1048576, 32, 108.9, 400, sb, "hbm_2mx32")
-    assert r["served_from"] == "hbm" and r["limited_by"].startswith("HBM bandwidth")
+    assert r["served_from"] == "hbm" and r["limited_by"] == "hbm_bandwidth" and r["bound"] == "hbm"
     assert abs(r["frac"] - 1048576 * 520 / 108.9e-6 / 1e9 / 8000.0) < 1e-12
     assert abs(r["frac_of_measured_copy_rate"] - r["achieved"] / 6290.0) < 1e-12
     rec = json.load(open(os.path.join(ROOT, "profiles", "traffic_hbm_2mx32.json")))
@@ -81,8 +84,118 @@ def test_every_fraction_of_the_committed_bench_line_follows_from_profiles():
     import glob
     import subprocess
     import sys
-    newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "bench_r04*.json")))[-1]
+    newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "bench_r0[45]*.json")))[-1]
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "recompute_roofline.py"), newest], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "largest deviation" in r.stdout and "DIFFERS" not in r.stdout
 
+
+
+# ---- the result line must fit a reader that keeps a few KB of stdout (BENCH_r04.parsed was null, the line was 20.6 KB) ----
+
+def _roof(name, nw, nd, us, how):
+    return bench.roofline_block(GaussianIso(), how, nw // 2, nd, us, 20000, bench.state_bytes(nw, nd, bench.moment_bytes(how)), name)
+
+
+def _full_single():
+    """A full N = 1 record as bench.py builds it: headline + every other_configs entry (with the strings the full record carries)."""
+    how3 = "multi-launch (exact): half_step_vec L=16 K=2 ITER=1 exact-size, grid 1024 x 128, hipGraph replay of 64 generations with per-replay parameter updates (step preloaded)"
+    long = "x" * 400
+    oc = {"C1": {"workload": long, "value": 2.08e8, "unit": "walker-steps/s", "us_per_half_step": 0.24018123456, "execution": long},
+          "C3": {"workload": long, "value": 2.5452e9, "us_per_half_step": 3.2186123, "us_per_half_step_runs": [3.2, 3.3], "execution": how3, "roofline": _roof("c3", 16384, 64, 3.2186, how3)},
+          "C5": {"workload": long, "value": 3.7191e8, "us_per_half_step": 11.013, "execution": long, "roofline": _roof("c5", 8192, 1024, 11.013, how3)},
+          "HBM_2Mx32": {"workload": long, "value": 9.6283e9, "us_per_half_step": 108.91, "roofline": _roof("hbm_2mx32", 2097152, 32, 108.91, how3)},
+          "HBM_512Kx128": {"workload": long, "value": 2.4467e9, "us_per_half_step": 107.14, "roofline": _roof("hbm_512kx128", 524288, 128, 107.14, how3)},
+          "MID_4096x4": {"workload": long, "value": 1.2902e9, "us_per_half_step": 1.5874, "two_launches_us_per_half_step": 2.4592, "execution": long, "two_launches_execution": long},
+          "MID_16384x4": {"workload": long, "value": 4.6831e9, "us_per_half_step": 1.7493, "two_launches_us_per_half_step": 2.5174, "execution": long},
+          "C3_generation": {"workload": long, "value": 2.9e9, "us_per_half_step": 2.7, "two_launches_us_per_half_step": 3.22, "execution": long},
+          "C2_chain_on": {"workload": long, "value": 8.9623e9, "us_per_half_step": 3.6562, "readout": long},
+          "C2_user_density": {"workload": long, "value": 8.6441e9, "us_per_half_step": 3.7908, "execution": long},
+          "C2_user_density_two_sums": {"error": "hiprtc: " + long},
+          "C2_user_density_coupled": {"workload": long, "value": 6.4382e9, "us_per_half_step": 5.0896, "execution": long},
+          "C1_user_density": {"workload": long, "value": 2.3696e8, "us_per_half_step": 0.211, "execution": long}}
+    return {"metric": "walker-steps/sec", "value": 8701926704.69613, "unit": "walker-steps/s", "n_gpus": 1, "steps": 20, "warmup": 5, "ms_per_step": 7.531205700070132,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "C2: emcee stretch move, 65536 walkers/GPU x 32-dim isotropic Gaussian, 20000 generations (burn-in 10000), a=2, moments on, chain off",
+                       "nwalkers_total": 65536, "ndim": 32, "generations": 20000, "gens_per_step": 1000, "parallelism": "single GPU", "execution": C2},
+            "roofline": _roof("c2", 65536, 32, 3.763, C2),
+            "check": {"accept_ratio_mean": 0.23435239, "posterior_mean_absmax": 0.0029173337, "posterior_var_min": 0.99746123, "posterior_var_max": 1.0025636, "nmoment": 655360000},
+            "island_mode": {"value": 2.94856e10, "accept_ratio_mean": 0.234367, "note": long},
+            "other_configs": oc,
+            "cpu_baseline": {"value": 180101190.9551766, "unit": "walker-steps/s", "cores": 16, "kind": "port", "single_thread_value": 19408781.0, "thread_scaling": 9.28,
+                             "sample": long, "sample_short": "C2 shape, 13383 generations = 8.77e+08 walker-steps in 4.9 s on 16 threads; 1 thread: 1852 in 6.3 s", "note": long}}
+
+
+def test_the_single_gpu_result_line_fits_4_kb_and_keeps_what_the_driver_reads():
+    full = _full_single()
+    text = bench.compact_line(full)
+    assert len(text) < 4096, len(text)
+    line = json.loads(text)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "check"):
+        assert key in line, key
+    assert line["value"] == full["value"] and line["ms_per_step"] == full["ms_per_step"]
+    r = line["roofline"]
+    assert abs(r["frac"] - full["roofline"]["frac"]) < 1e-5 and r["bound"] == r["served_from"] == "infinity_cache" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert r["traffic"] is not None and r["body_frac"] and r["kernel"].startswith("half_step_vec<GaussianIso") and r["profile_record"]["record"] == "profiles/traffic_c2.json"
+    c = line["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 16 and abs(c["value"] / 180101190.9551766 - 1) < 1e-5 and "16 threads" in c["sample"]
+    assert set(line["other_configs"]) == set(full["other_configs"])                       # every config is still named in the line ...
+    assert line["other_configs"]["C3"]["served_from"] == "infinity_cache" and abs(line["other_configs"]["C3"]["frac"] - full["other_configs"]["C3"]["roofline"]["frac"]) < 1e-4
+    assert line["other_configs"]["HBM_2Mx32"]["served_from"] == "hbm" and "error" in line["other_configs"]["C2_user_density_two_sums"]
+    assert all(len(json.dumps(v)) < 160 for v in line["other_configs"].values())          # ... as numbers, not prose
+    assert line["config"]["workload"].startswith("C2:") and "model" not in line["config"]
+
+
+def _full_sharded(world=8, all_variants=True):
+    full = {k: v for k, v in _full_single().items() if k not in ("island_mode", "other_configs", "cpu_baseline")}
+    full["n_gpus"] = world
+    full["config"]["parallelism"] = f"walker-sharded x{world}, exact partner rule, peer-to-peer exchange over xGMI (IPC): pull of drawn rows (system-scope loads), signal kernel; progress-flag ordering"
+    full["roofline"] = bench.roofline_block(GaussianIso(), C2, 32768, 32, 14.2, 40000, bench.state_bytes(65536, 32, 0), "c2", use_record=False)
+    full["check"]["timed_run_equals_unsharded_run"] = True
+    full["collective"] = {"backend": "nccl", "world_size": world, "ranks_seen_by_all_reduce": world, "rccl_version": "2.26.6", "native_rccl_version": "2.26.6",
+                          "launcher": "external (torch.distributed.run)", "rank_env": {"HSA_ENABLE_IPC_MODE_LEGACY": "0", "OMP_NUM_THREADS": "2"}}
+    tags = [v[0] for v in bench.P2P_VARIANTS] if all_variants else ["pull"]
+    full["ladder"] = ([{"rung": "rendezvous", "ok": True, "s": 3.217}] + [{"rung": f"p2p-{k}:{t}", "ok": True, "s": 12.345} for t in tags for k in ("check", "time")] +
+                      [{"rung": "p2p-run", "ok": True, "s": 4.5}, {"rung": "dealt-extra", "ok": True, "s": 3.1}, {"rung": "allgather-extra-setup", "ok": True, "s": 2.2},
+                       {"rung": "allgather-extra", "ok": False, "s": 300.0, "timed_out": True}])
+    full["value_from"] = "p2p-run"
+    full["dealt_mode"] = {"value": 6.1e10, "unit": "walker-steps/s", "epoch_generations": 64, "deals": 312, "all_to_all_bytes_per_gpu_per_deal": 17825792, "accept_ratio_mean": 0.2343,
+                          "posterior_mean_absmax": 0.0011, "posterior_var_minmax": [0.998, 1.002], "nmoment": 2621440000, "note": "y" * 300}
+    full["allgather_mode"] = {"value": 2.3e9, "unit": "walker-steps/s", "generations": 1024, "us_per_half_step": 113.2, "equals_unsharded_run": True,
+                              "bytes_received_per_gpu_per_half_step": 58720256, "execution": "RCCL all-gather of the updated half after every half-step (captured in the graph)", "note": "z" * 200}
+    full["extras_timed_out"] = "'allgather-extra' did not finish within 300 s"
+    full["fabric"] = {"remote_partner_bytes_per_gpu_per_launch": 7340032.0, "bytes_per_link_per_launch": 1048576.0, "link_bound_us_at_77GBs": 13.6, "push_bytes_per_link_per_launch": 1966080.0,
+                      "variants_us_per_launch": {t: 14.2 for t in tags}, "lazy_pulled_fraction_rank0": None}
+    return full
+
+
+def test_the_sharded_result_line_fits_4_kb_with_every_rung_of_the_ladder():
+    for world, allv in ((8, True), (2, False)):
+        full = _full_sharded(world, allv)
+        text = bench.compact_line(full)
+        assert len(text) < 4096, len(text)
+        line = json.loads(text)
+        assert line["n_gpus"] == world and line["roofline"]["frac"] > 0 and line["roofline"]["traffic"] is None
+        assert line["value_from"] == "p2p-run" and line["collective"]["ranks_seen_by_all_reduce"] == world and line["collective"]["launcher"].startswith("external")
+        assert [r["rung"] for r in line["ladder"]] == [r["rung"] for r in full["ladder"]] and line["ladder"][-1]["timed_out"] is True
+        assert line["dealt_mode"]["deals"] == 312 and line["allgather_mode"]["captured_in_graph"] is True and line["allgather_mode"]["equals_unsharded_run"] is True
+        assert line["check"]["timed_run_equals_unsharded_run"] is True and "did not finish" in line["extras_timed_out"]
+
+
+def test_a_result_line_that_would_not_fit_loses_its_optional_blocks_first():
+    full = _full_sharded(8, True)
+    full["ladder"] = full["ladder"] * 6                  # (a pathological ladder)
+    text = bench.compact_line(full)
+    assert len(text) <= bench.LINE_LIMIT
+    line = json.loads(text)
+    assert line["value"] == full["value"] and line["roofline"]["frac"] > 0 and line["check"]["timed_run_equals_unsharded_run"] is True
+
+
+def test_emit_prints_the_full_record_first_and_the_result_line_last(capsys, tmp_path, monkeypatch):
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    full = _full_single()
+    bench.emit(full)
+    out = capsys.readouterr().out.splitlines()
+    assert len(out) == 2 and out[0].startswith('{"bench_detail"') and out[1].startswith('{"metric"') and len(out[1]) < 4096
+    assert json.loads(out[0])["bench_detail"]["other_configs"]["C3"]["roofline"]["geometry"] == full["other_configs"]["C3"]["roofline"]["geometry"]
+    assert json.load(open(tmp_path / "bench_detail.json"))["value"] == full["value"]
