@@ -44,6 +44,11 @@ struct GenerationArgs {
     double*           chain_logp;   // [nsamples][nwalkers] or nullptr                  (:271)
     double*           msum;         // [nwalkers][ld] per-walker sums of the stored samples (laid out like the rows; read out in walker order), or nullptr
     double*           msumsq;
+    // lane-striped form (generation_group) only:
+    uint32_t*         klast;        // [nwalkers] samples a walker's CURRENT value has already been credited for: its moments are sojourn-weighted like the
+                                    //   two-launch kernels' (a value is credited, times the samples it stood for, when it is replaced; the read-out credits the rest)
+    uint32_t*         glast;        // [nwalkers] 1 + the generation of the walker's last accepted move (0: none): a row is written to the output copy only
+                                    //   when that copy does not hold it already (see generation_group_body)
 };
 
 // What the head of a wave's chain needs, as the kernel's LEADING scalar parameters: the build preloads the first 14 dwords of the
@@ -292,9 +297,12 @@ __device__ __forceinline__ void generation_group_body(const GenerationFront& f, 
         for (int k = 0; k < K; ++k) myown[k] = zero2;
     }
     const bool count = (sch.flags & kCount) != 0u, sample = (sch.flags & kSample) != 0u;
-    const bool moments = sample && a.msum != nullptr;
+    const bool moments = count && a.msum != nullptr;
+    const uint32_t gl = a.glast[me];
+    uint32_t kl = 0u;
+    if (moments) kl = a.klast[me];
     double2 m1[K], m2[K];
-    if (moments) { row(a.msum, me, m1); row(a.msumsq, me, m2); }
+    if (moments) { row(a.msum, me, m1); row(a.msumsq, me, m2); }                     // (issued with the rows, used -- and rewritten -- only if my move is accepted)
     // :252 -- both moves' draws now (see generation_lane_body).  Their four logarithms are most of a lane's chain here (~0.2 us each: dependent
     // fp64 operations of a wave that has its SIMD to itself), and the lanes of a quad belong to one walker when L >= 4: each computes ONE of
     // them -- same function, same argument, hence the same bits as draw_finish -- and the quad shares the results.
@@ -349,15 +357,41 @@ __device__ __forceinline__ void generation_group_body(const GenerationFront& f, 
         }
     }
     if (!valid) return;
+    // Streaming moments, sojourn-weighted (the two-launch kernels' rule, kmc_kernels.hpp): the value this move replaces is credited now, times the samples it
+    // stood for; nothing is written for a walker that stays.  Round 4 rewrote both sums of every walker with every sample (7.5 x the state per generation in
+    // all; now 4.5 x read + what is accepted: 8 192 x 64 3.46 -> 2.59 us per half-step).  Tried instead of reading the sums with the rows: no-return fp64
+    // atomic adds on accept (nothing read for a walker that stays) -- slower at every shape, the L2 retires about one 8-byte add per channel per 3-4 cycles
+    // (C2-sized: 6.82 against 6.16 us, 32 768 x 16: 3.46 against 2.85; profiles/r05_generation_mid.txt).  `own` is my row before my move.
+    if (acc && moments) {
+        const double wgt = (double)(sch.nbefore - kl);
+        if (wgt != 0.0) {
+            double* s1 = a.msum + (size_t)me * (size_t)ld;
+            double* s2 = a.msumsq + (size_t)me * (size_t)ld;
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+                if (cv[k]) {
+                    const int e = 2 * (k * L + j);
+                    *reinterpret_cast<double2*>(&s1[e]) = make_double2(m1[k].x + own[k].x * wgt, m1[k].y + own[k].y * wgt);
+                    *reinterpret_cast<double2*>(&s2[e]) = make_double2(m2[k].x + (own[k].x * own[k].x) * wgt, m2[k].y + (own[k].y * own[k].y) * wgt);
+                }
+        }
+        if (j == 0) a.klast[me] = sch.nbefore;
+    }
 #pragma unroll
     for (int k = 0; k < K; ++k) { y[k].x = acc ? y[k].x : own[k].x; y[k].y = acc ? y[k].y : own[k].y; }   // :261
     const double pnew = acc ? p1 : p0;                                   // :262
-    double2* out = reinterpret_cast<double2*>(f.pout + (size_t)me * (size_t)ld);
+    // The output copy already holds my row unless I moved in this generation or in the one before (it was last written two generations ago or
+    // earlier, and is valid as long as nothing was accepted since: by induction from two equal copies at the start of a run, kmc_launch.hip).
+    // A stale glast -- a restart -- can only ask for a write too many.
+    if (acc || gl == (uint32_t)sch.gen) {
+        double2* out = reinterpret_cast<double2*>(f.pout + (size_t)me * (size_t)ld);
 #pragma unroll
-    for (int k = 0; k < K; ++k) if (cv[k]) out[k * L + j] = y[k];       // (elements past ndim of the last chunk: 0 in, 0 out -- the lane-striped densities ignore them)
-    if (j == 0) {
-        a.lout[me] = pnew;
-        if (acc && count) (void)__hip_atomic_fetch_add(&a.naccept[me], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // :265 (see generation_lane_body)
+        for (int k = 0; k < K; ++k) if (cv[k]) out[k * L + j] = y[k];   // (elements past ndim of the last chunk: 0 in, 0 out -- the lane-striped densities ignore them)
+        if (j == 0) a.lout[me] = pnew;
+    }
+    if (acc && j == 0) {
+        a.glast[me] = (uint32_t)sch.gen + 1u;
+        if (count) (void)__hip_atomic_fetch_add(&a.naccept[me], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // :265 (see generation_lane_body)
     }
     if (sample) {                                                        // :268-271
         const size_t srow = (size_t)sch.slot * (2u * (size_t)f.h) + me;
@@ -367,16 +401,6 @@ __device__ __forceinline__ void generation_group_body(const GenerationFront& f, 
             for (int k = 0; k < K; ++k) if (cv[k]) dst[k * L + j] = y[k];
         }
         if (a.chain_logp != nullptr && j == 0) a.chain_logp[srow] = pnew;
-        if (moments) {
-            double2* s1 = reinterpret_cast<double2*>(a.msum + (size_t)me * (size_t)ld);
-            double2* s2 = reinterpret_cast<double2*>(a.msumsq + (size_t)me * (size_t)ld);
-#pragma unroll
-            for (int k = 0; k < K; ++k)
-                if (cv[k]) {
-                    s1[k * L + j] = make_double2(m1[k].x + y[k].x, m1[k].y + y[k].y);
-                    s2[k * L + j] = make_double2(m2[k].x + y[k].x * y[k].x, m2[k].y + y[k].y * y[k].y);
-                }
-        }
     }
 }
 

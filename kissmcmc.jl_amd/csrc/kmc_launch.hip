@@ -243,6 +243,8 @@ GenerationArgs make_generation_args(const kmc_sampler* s, int from, bool graph_m
     a.chain_logp = s->d_chain_logp;
     a.msum = s->d_isum;
     a.msumsq = s->d_isumsq;
+    a.klast = s->d_klast;
+    a.glast = s->d_glast;
     return a;
 }
 
@@ -270,6 +272,27 @@ hipError_t generation_settle(kmc_sampler* s)
     if (e == hipSuccess) e = hipMemcpyAsync(s->d_logp, s->d_logp2, (size_t)s->nrows * sizeof(double), hipMemcpyDeviceToDevice, s->stream);
     if (e == hipSuccess) s->fused_cur = 0;
     return e;
+}
+
+// A sampler that runs one launch per generation goes back to its two-launch kernels, in place and for good (everything they need was set up
+// at creation): for a caller that steps by halves (kmc_sampler_half_step) or attaches an RCCL communicator (an all-gather follows every
+// half-step).  Moments credited so far stay where they are (per-walker sums, d_isum) and are added at read-out; the one-walker-per-lane
+// form has credited every sample taken, so the walkers' current values stand for the samples from here on.
+kmc_status unfuse(kmc_sampler* s)
+{
+    if (!s->fused) return KMC_OK;
+    HIP_TRY(generation_settle(s));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    if (s->graph_exec) { (void)hipGraphExecDestroy(s->graph_exec); s->graph_exec = nullptr; }
+    if (s->graph) { (void)hipGraphDestroy(s->graph); s->graph = nullptr; }
+    if (s->d_msum && s->d_isum && s->generation > 0) {
+        if (s->fused_L == 0 && s->d_klast)
+            HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)s->d_klast, (int)(uint32_t)samples_done(s), (size_t)s->nrows, s->stream));
+        s->isum_carry = true;
+    }
+    s->fused = false;
+    s->launch_mode = 0;
+    return KMC_OK;
 }
 
 kmc_status ensure_graph(kmc_sampler* s)
@@ -530,6 +553,12 @@ KMC_EXPORT kmc_status kmc_sampler_run(kmc_sampler* s, int64_t ngen)
         // started, in d_pos / d_logp), the rest launch by launch; the state is moved back into d_pos / d_logp at the end
         const char* forced = std::getenv("KMC_LAUNCH");
         const bool use_graph = !(s->cfg.flags & KMC_NO_GRAPH) && !(forced && std::strcmp(forced, "eager") == 0);
+        if (s->fused_L > 0 && ngen > 0) {
+            // the lane-striped form writes a row to the output copy only when that copy does not hold it already: both copies start a run equal
+            // (whoever changed d_pos / d_logp since the last run -- set_positions, set_state, the initial ball -- changed only the first pair)
+            HIP_TRY(hipMemcpyAsync(s->d_pos2, s->d_pos, (size_t)s->nrows * (size_t)s->ld * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+            HIP_TRY(hipMemcpyAsync(s->d_logp2, s->d_logp, (size_t)s->nrows * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+        }
         while (use_graph && ngen >= kGraphChunk) {
             HIP_TRY(generation_settle(s));
             KMC_TRY(ensure_graph(s));
@@ -796,7 +825,7 @@ KMC_EXPORT kmc_status kmc_sampler_half_step(kmc_sampler* s, int half)
     if (s->islands) return fail(KMC_ERR_UNSUPPORTED, "island mode advances whole generations: use kmc_sampler_run");
     if (s->host_eval) return fail(KMC_ERR_UNSUPPORTED, "KMC_HOST_DENSITY: a half-step includes the host callback; use kmc_sampler_run");
     if (s->resident) return fail(KMC_ERR_UNSUPPORTED, "this small ensemble runs in resident mode (whole generations per launch); create it with KMC_NO_GRAPH to step by halves");
-    if (s->fused) return fail(KMC_ERR_UNSUPPORTED, "this ensemble runs one launch per generation (kmc_generation.hpp); create it with KMC_NO_GRAPH to step by halves");
+    if (s->fused) KMC_TRY(unfuse(s));                 // stepping by halves: the two-launch kernels from here on (same chain, bit for bit)
     if (s->generation >= ((int64_t)1 << 31) - 1) return fail(KMC_ERR_UNSUPPORTED, "at most 2^31 - 1 generations (the step index is 32 bits)");
     HIP_TRY(hipSetDevice(s->cfg.device));
     if (half == 0) KMC_TRY(chain_before(s, s->generation + 1));

@@ -37,14 +37,9 @@ KMC_EXPORT kmc_status kmc_sampler_rccl_init(kmc_sampler* s, const void* id)
     if (s->comm) return KMC_OK;
     HIP_TRY(hipSetDevice(s->cfg.device));
     HIP_TRY(hipStreamSynchronize(s->stream));
-    if (s->fused) {
-        // a communicator on an unsharded sampler (shard_count 1: tests, a one-rank job): the all-gather follows every HALF-step, so the
-        // sampler goes back to its two-launch kernels (everything they need was set up at creation; nothing has run yet that would differ)
-        if (s->graph_exec) { (void)hipGraphExecDestroy(s->graph_exec); s->graph_exec = nullptr; }
-        if (s->graph) { (void)hipGraphDestroy(s->graph); s->graph = nullptr; }
-        s->fused = false;
-        s->launch_mode = 0;
-    }
+    // a communicator on an unsharded sampler (shard_count 1: tests, a one-rank job): the all-gather follows every HALF-step, so the
+    // sampler goes back to its two-launch kernels (moments credited so far are kept: unfuse)
+    if (s->fused) KMC_TRY(unfuse(s));
     return rccl_comm_create(id, s->cfg.shard_rank, s->cfg.shard_count, &s->comm);
 }
 

@@ -242,8 +242,9 @@ namespace {
 // One launch per generation (kmc_generation.hpp) -- the dependent-launch boundary, which is most of a half-step for small states, is paid
 // once per generation instead of twice.  0: no; 1: one walker per lane (ndim <= 8); 2: rows lane-striped like the vector kernels (longer
 // rows; lane-striped densities).  Measured against the two-launch kernels (profiles/r04_generation_map.txt): short rows 1.3-1.9 x ahead up
-// to 32 768 walkers, 1.25-1.4 x at 65 536 walkers of one or two doubles, behind beyond that; longer rows 1.1-1.55 x ahead while the state
-// stays within ~2.3 MiB (the kernel reads 2.5 x the rows and writes every row), behind beyond.
+// to 32 768 walkers, 1.25-1.4 x at 65 536 walkers of one or two doubles, behind beyond that; longer rows 1.15-1.55 x ahead while the state
+// stays within ~2.3 MiB, 1.04-1.08 x at 4 MiB (8 192 x 64, 32 768 x 16, 16 384 x 32), behind at 8 MiB (C3: 0.91 x) -- the kernel reads 2.5 x the
+// rows (profiles/r05_generation_mid.txt).
 // KMC_DEBUG=fused=0 / =1: never / wherever a kernel exists.  (Resident and island mode are decided by the caller.)
 int generation_wanted(const kmc_sampler* s)
 {
@@ -264,7 +265,7 @@ int generation_wanted(const kmc_sampler* s)
     if (have) return kind;                                   // (=1 / =lane: wherever a kernel exists; =lane keeps short rows one walker per lane)
     if (kind == 3) return 3;
     if (kind == 1) return ((c.nwalkers <= 32768 && c.nwalkers * s->ld <= 196608) || (c.nwalkers <= 65536 && s->ld <= 2)) ? 1 : 0;
-    return c.nwalkers * s->ld <= 300000 ? 2 : 0;            // (about 2.3 MiB of state)
+    return c.nwalkers * s->ld <= 524288 ? 2 : 0;            // (4 MiB of state; round 4: 2.3 MiB, before the moments became sojourn-weighted and unchanged rows stayed unwritten)
 }
 }  // namespace
 
@@ -570,6 +571,10 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         CREATE_TRY(dev_alloc(s, &s->d_pos2, nw * ldz * sizeof(double)));
         CREATE_TRY(hipMemsetAsync(s->d_pos2, 0, nw * ldz * sizeof(double), s->stream));
         CREATE_TRY(dev_alloc(s, &s->d_logp2, nw * sizeof(double)));
+        if (s->fused_L > 0) {
+            CREATE_TRY(dev_alloc(s, (void**)&s->d_glast, nw * sizeof(uint32_t)));
+            CREATE_TRY(hipMemsetAsync(s->d_glast, 0, nw * sizeof(uint32_t), s->stream));
+        }
     }
     if (s->host_eval) {
         CREATE_TRY(dev_alloc(s, &s->d_prop, (size_t)s->h * ldz * sizeof(double)));
@@ -722,6 +727,7 @@ KMC_EXPORT void kmc_sampler_destroy(kmc_sampler* s)
     cache_free(s->d_isumsq);
     cache_free(s->d_pos2);
     cache_free(s->d_logp2);
+    cache_free(s->d_glast);
     cache_free(s->d_prop);
     cache_free(s->d_p1);
     if (s->h_prop) (void)hipHostFree(s->h_prop);

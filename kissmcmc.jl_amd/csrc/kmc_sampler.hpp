@@ -144,6 +144,8 @@ struct kmc_sampler {
     kmc::GenerationFn generation_kernel = nullptr;
     double* d_pos2 = nullptr;
     double* d_logp2 = nullptr;
+    bool isum_carry = false;           // a sampler that left this mode after it had run (unfuse): d_isum / d_isumsq hold moments credited so far
+    uint32_t* d_glast = nullptr;       // lane-striped form: 1 + the generation of every walker's last accepted move (GenerationArgs::glast)
     int fused_cur = 0;                 // which pair holds the state at the tail of the stream (0 between kmc_sampler_run calls)
     int fused_L = 0;                   // 0: one walker per lane (generation_lane, ndim <= 8); else rows striped over L lanes (generation_group<L, plan.K>)
     int fused_tpb = 64;                //   threads per workgroup of the lane-striped form
@@ -218,6 +220,7 @@ void chain_unregister(kmc_sampler* s);
 kmc_status load_user(kmc_user_density* ud, bool with_vec, int L, int K, int iter, bool ragged, UserKernels* uk,
                      int resident_K = 0, bool resident_ragged = false, int island_S = 0, bool f32 = false, int64_t ndim = 0, bool p2p = false,
                      int generation_nd = 0);
+kmc_status unfuse(kmc_sampler* s);                                     // back to the two-launch kernels, in place (kmc_launch.hip)
 void set_offline_compiler_hint(bool wanted);                          // runtime-compiled kernels of this thread: hipcc as a child process instead of hiprtc (kmc_rtc.hip)
 bool body_vec_possible(const kmc_user_density* ud, int64_t ndim);     // a function body inside the vector kernels, evaluated per walker (kmc_rtc.hip)
 

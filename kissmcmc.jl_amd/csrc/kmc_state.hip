@@ -340,6 +340,24 @@ KMC_EXPORT kmc_status kmc_sampler_get_moments(kmc_sampler* s, double* sum, doubl
         std::vector<double> S((size_t)nd, 0.0), Q((size_t)nd, 0.0);
         for (int64_t w = 0; w < nw; ++w)
             for (int64_t d = 0; d < nd; ++d) { S[(size_t)d] += hs[(size_t)(w * ld + d)]; Q[(size_t)d] += hq[(size_t)(w * ld + d)]; }
+        if (s->fused_L > 0) {
+            // the lane-striped form credits a value when it is replaced (sojourn weights, like the two-launch kernels): every walker's CURRENT value
+            // still stands for the samples taken since its last move -- credited here, on the host, leaving the device state as it is
+            std::vector<double> hp((size_t)(ld * nw));
+            std::vector<uint32_t> kl((size_t)nw);
+            HIP_TRY(copy_sync(hp.data(), s->d_pos, hp.size() * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+            HIP_TRY(copy_sync(kl.data(), s->d_klast, kl.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+            const uint32_t done = (uint32_t)samples_done(s);
+            for (int64_t w = 0; w < nw; ++w) {
+                const double wgt = (double)(done - kl[(size_t)w]);
+                if (wgt == 0.0) continue;
+                for (int64_t d = 0; d < nd; ++d) {
+                    const double x = hp[(size_t)(w * ld + d)];
+                    S[(size_t)d] += x * wgt;
+                    Q[(size_t)d] += (x * x) * wgt;
+                }
+            }
+        }
         for (int64_t d = 0; d < nd; ++d) {
             if (sum) sum[d] = S[(size_t)d];
             if (sumsq) sumsq[d] = Q[(size_t)d];
@@ -409,6 +427,15 @@ KMC_EXPORT kmc_status kmc_sampler_get_moments(kmc_sampler* s, double* sum, doubl
                 S[d] += hs[d * s->macc_stride + t];
                 Q[d] += hq[d * s->macc_stride + t];
             }
+    }
+    if (s->isum_carry) {
+        // what the sampler credited while it ran one launch per generation (unfuse): per-walker sums laid out like the rows
+        const int64_t nw = s->cfg.nwalkers, ld = s->ld;
+        std::vector<double> cs((size_t)(ld * nw)), cq((size_t)(ld * nw));
+        HIP_TRY(copy_sync(cs.data(), s->d_isum, cs.size() * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(copy_sync(cq.data(), s->d_isumsq, cq.size() * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+        for (int64_t w = 0; w < nw; ++w)
+            for (int64_t d = 0; d < nd; ++d) { S[(size_t)d] += cs[(size_t)(w * ld + d)]; Q[(size_t)d] += cq[(size_t)(w * ld + d)]; }
     }
     for (int64_t d = 0; d < nd; ++d) {
         if (sum) sum[d] = S[d];

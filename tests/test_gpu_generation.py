@@ -110,15 +110,35 @@ def test_what_keeps_the_two_launch_kernels(kmc):
     assert "one launch per generation" not in _mode(kmc, pdf, 4096, 4, use_graph=False)
     assert "one launch per generation" not in _mode(kmc, pdf, 65536, 32)
     assert "one launch per generation" not in _mode(kmc, pdf, 262144, 4)
-    assert "one launch per generation" not in _mode(kmc, pdf, 16384, 32)
+    assert "one launch per generation" not in _mode(kmc, pdf, 32768, 32) and "one launch per generation" not in _mode(kmc, kmc.Rosenbrock(), 16384, 64)
     assert "generation_lane" in _mode(kmc, pdf, 32768, 4) and "generation_group" in _mode(kmc, pdf, 8192, 32)
+    assert "generation_group" in _mode(kmc, pdf, 16384, 32) and "generation_group" in _mode(kmc, pdf, 8192, 64)      # 4 MiB of state (round 5)
     assert "generation_group L=4 K=1" in _mode(kmc, pdf, 4096, 8) and "generation_group L=4 K=1" in _mode(kmc, pdf, 8192, 5)
     assert "generation_lane" in _mode(kmc, pdf, 16384, 6) and "generation_lane" in _mode(kmc, pdf, 4096, 4)
     assert "resident" in _mode(kmc, pdf, 2048, 4)
-    with kmc.Sampler(pdf, 4096, 4, 10, 0, 1, 2.0, 1) as s:
-        s.set_positions(_theta0("gauss", 4096, 4, 1))
-        with pytest.raises(kmc.KmcError, match="one launch per generation"):
-            s.half_step(0)
+
+
+def test_stepping_by_halves_takes_the_two_launch_kernels_in_place(kmc, oracle):
+    """kmc_sampler_half_step on a sampler that runs one launch per generation: it goes back to its two-launch kernels where it stands -- after
+    generations already run, moments already credited -- and the whole run is still the oracle's (this used to be refused)."""
+    for nw, nd in ((4096, 4), (4096, 32)):                  # generation_lane (per-sample sums) and generation_group (sojourn-weighted sums)
+        G, nburn, seed = 90, 7, 5
+        th = _theta0("gauss", nw, nd, 2)
+        with kmc.Sampler(kmc.GaussianIso(), nw, nd, G, nburn, 2, 2.0, seed, store_chain=True, store_logp=True, moments=True) as s:
+            assert "one launch per generation" in s.describe()
+            s.set_positions(th)
+            s.run(41)
+            for _ in range(9):
+                s.half_step(0)
+                s.half_step(1)
+            assert "one launch per generation" not in s.describe()
+            s.run(G - 50)
+            s.sync()
+            got = dict(final_pos=s.positions(), final_logp=s.logp(), naccept=s.naccept(), accept_ratio=s.accept_ratio())
+            got["chain"], got["chain_logp"] = s.chain()
+            got["sum"], got["sumsq"], got["nmoment"] = s.moments()
+        ref = oracle.emcee(oracle.make_config(oracle.GAUSSIAN_ISO, [0.0, 1.0], nw, nd, G, nburn, 2, 2.0, seed), th)
+        _compare(ref, got)
 
 
 def test_streamed_chain_and_checkpoint(kmc, oracle, kmc_debug):
@@ -246,12 +266,12 @@ def test_drop_in_call_on_a_mid_size_ensemble(kmc, oracle):
     np.testing.assert_allclose(np.transpose(logdensities), ref["chain_logp"], rtol=1e-12, atol=1e-12)
 
 
-@pytest.mark.parametrize("nw,nd", [(4096, 4), (16384, 32)])
+@pytest.mark.parametrize("nw,nd", [(4096, 4), (16384, 32), (32768, 32)])
 def test_bound_position_buffer_and_callers_stream(kmc, oracle, nw, nd):
     """kmc_sampler_bind_positions + kmc_sampler_set_stream on a one-launch-per-generation sampler: the caller's buffer is the canonical
     copy of the state (current after every kmc_sampler_run, odd run lengths included), the second copy stays the library's.  The stream
     is torch's current one -- the legacy default stream, which cannot be captured: the graph chunk is recorded on a stream of the library's
-    own and replayed on the caller's (the two-launch kernels likewise: 16384 x 32)."""
+    own and replayed on the caller's (the lane-striped form: 16384 x 32; the two-launch kernels likewise: 32768 x 32)."""
     import torch
     G, seed = 131, 17
     th = _theta0("gauss", nw, nd, 8)
@@ -259,7 +279,7 @@ def test_bound_position_buffer_and_callers_stream(kmc, oracle, nw, nd):
     with kmc.Sampler(kmc.GaussianIso(), nw, nd, G, 0, 1, 2.0, seed) as s:
         s.bind_positions(pos.data_ptr())
         s.set_stream(torch.cuda.current_stream().cuda_stream)
-        assert ("one launch per generation" in s.describe()) == (nd == 4)
+        assert ("one launch per generation" in s.describe()) == (nw <= 16384)
         s.set_positions(th)
         s.run(65)
         s.run(66)
