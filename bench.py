@@ -8,7 +8,8 @@ default --steps 10 is exactly the 10^4-generation job.  With --gpus N (launched 
 torch.distributed.run, one rank per GPU) the ensemble is 65 536 x N walkers, walker-sharded with the reference's EXACT
 partner rule and a peer-to-peer exchange over xGMI (KMC_P2P, pull of the drawn partner rows with system-scope loads +
 signal kernel; admitted by a bit-exact self-check, and the timed run itself is verified against the unsharded run;
-KMC_BENCH_EXCHANGE=all measures the other five variants too, =allgather -- or any failure -- runs the native RCCL all-gather
+the push of accepted rows is the second rung, the faster admitted one supplies `value`;
+KMC_BENCH_EXCHANGE=pull keeps the pull, =all measures the experimental variants too, =allgather -- or any failure -- runs the native RCCL all-gather
 of the updated half per half-step, enqueued by the library itself) -- weak scaling, config C4 at N = 8.  Extra key `dealt_mode` (N > 1, never `value`):
 the same job as dealt sub-ensembles, one RCCL all_to_all_single per 64 generations instead of an exchange per half-step.
 
@@ -878,10 +879,12 @@ def run_single(job: Job) -> dict:
     return res
 
 
-P2P_VARIANTS = [   # (rung tag, what it is, fold_signal, push, lazy).  Default: the first only; KMC_BENCH_EXCHANGE=all tries every one the library has.
+P2P_VARIANTS = [   # (rung tag, what it is, fold_signal, push, lazy).  Default: the first two -- the exchanges of the default library, both read with system-scope
+    #                    loads, each admitted by its bit-exact self-check, the faster of the admitted ones runs; KMC_BENCH_EXCHANGE=pull: the first only;
+    #                    =all (with the -DKMC_P2P_EXPERIMENTAL library): every one.
     ("pull", "pull of drawn rows (system-scope loads), signal kernel", False, False, False),
+    ("push", "push of accepted rows into local copies read with system-scope loads, signal kernel", False, True, False),
     ("pull-fold", "pull of drawn rows (system-scope loads), signal folded into the kernel", True, False, False),
-    ("push", "push of accepted rows into local copies, signal kernel", False, True, False),
     ("push-fold", "push of accepted rows into local copies, signal folded into the kernel", True, True, False),
     ("lazy", "lazy pull into local copies, signal kernel", False, False, True),
     ("lazy-fold", "lazy pull into local copies, signal folded into the kernel", True, False, True),
@@ -990,10 +993,10 @@ def run_sharded(job: Job) -> dict:
     mode = os.environ.get("KMC_BENCH_EXCHANGE", "p2p")
     res = {"tried": [], "verified": None, "lazy_stats": (0, 0), "p2p_variant": None}
     drv, best_t = None, None
-    if mode in ("p2p", "all"):
-        # push / lazy have peers write into plain device memory the local kernel then reads through its own L2: whether that L2 can
-        # serve stale lines could never be observed on one GPU -- they run only on request and only if their self-check passes.
-        cands = P2P_VARIANTS if mode == "all" else P2P_VARIANTS[:1]
+    if mode in ("p2p", "all", "pull"):
+        # lazy / folded-signal variants have peers write into plain device memory the local kernel then reads through its own L2 (or publish completion
+        # from inside the kernel): whether that L2 can serve stale lines could never be observed on one GPU -- only on request, only in the experimental library.
+        cands = P2P_VARIANTS if mode == "all" else P2P_VARIANTS[:1] if mode == "pull" else P2P_VARIANTS[:2]
         for tag, label, fold, push, lazy in cands:
             with rung(f"p2p-check:{tag}") as rg:
                 cand = try_p2p(job, False, fold, push, lazy)

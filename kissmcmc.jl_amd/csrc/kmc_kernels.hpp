@@ -88,7 +88,8 @@ struct HalfStepArgs {
     // peer-to-peer sharding (P2P kernels only): partner p of the complementary half lives on rank
     // p / hloc at row oth_row0 + p % hloc of that rank's pos
     uint32_t          hloc;
-    int32_t           nranks;
+    int32_t           nranks;       // bits 0-7: ranks; bits 8-15: this rank; bit 16: KMC_P2P_PUSH (pack_ranks / p2p_nranks, p2p_me, p2p_push: no field of its own --
+                                    //   the struct every half-step kernel takes stays as short as round 4 left it)
     double*           peer_pos[8];
     const unsigned long long* flags; // flags[r] = number of half-steps rank r has completed
     unsigned long long* err;         // set non-zero when a wait times out
@@ -157,12 +158,19 @@ struct HalfStepArgs {
 #endif
 };
 
-// The peer-to-peer exchange of the default library is ONE variant: pull of the drawn partner rows from their owner with
-// system-scope loads, ordered by a separate signal kernel (correctness does not rest on any cache state).  Five more -- push of
-// accepted rows / lazy pull into local copies, each with the progress signal optionally folded into the half-step kernel -- have
-// peers write into plain device memory that the local kernel reads through its own L2; they are bit-exact with every "peer" on
-// ONE GPU and have never run on two.  They exist only in builds with -DKMC_P2P_EXPERIMENTAL (the whole library: the argument
-// struct changes; `python -m kissmcmc_jl_amd.build --p2p-experimental` -> libkmc_var_p2pexp.so, tests/test_gpu_p2p_experimental.py).
+// The peer-to-peer exchange of the default library has TWO variants, both ordered by a separate signal kernel and neither resting on any cache
+// state: PULL of the drawn partner rows from their owner, and PUSH (KMC_P2P_PUSH, round 5) of every accepted row into a local copy of the owner's
+// shard on every peer -- in both the partner rows are read with system-scope loads (sc0 sc1: never served from the reader's L2, whether the line
+// belongs to a peer's memory or to local memory a peer writes over the fabric), and every row store is write-through.  Push moves acc * h_loc rows
+// per link and half-step, pull h_loc / P: push wins while the acceptance is below 1 / P (C4's 0.234: P = 2 25 against 54 us per link, P = 4 25
+// against 27, P = 8 25 against 13.6 -- DESIGN.md section 7).  Four more -- lazy pull into local copies, and the progress signal folded into the
+// half-step kernel -- read peer-written memory through the local L2 or publish completion from inside the kernel; bit-exact with every "peer" on
+// ONE GPU, never run on two.  They exist only in builds with -DKMC_P2P_EXPERIMENTAL (the whole library: the argument struct changes;
+// `python -m kissmcmc_jl_amd.build --p2p-experimental` -> libkmc_var_p2pexp.so, tests/test_gpu_p2p_experimental.py).
+__host__ __device__ inline int32_t pack_ranks(int nranks, int me, bool push) { return (int32_t)(nranks | (me << 8) | (push ? 1 << 16 : 0)); }
+__device__ __forceinline__ int  p2p_nranks(const HalfStepArgs& a) { return a.nranks & 0xff; }
+__device__ __forceinline__ int  p2p_me(const HalfStepArgs& a) { return (a.nranks >> 8) & 0xff; }
+__device__ __forceinline__ bool p2p_push(const HalfStepArgs& a) { return ((a.nranks >> 16) & 1) != 0; }
 #ifdef KMC_P2P_EXPERIMENTAL
 constexpr bool kP2PExperimental = true;
 #else
@@ -306,15 +314,13 @@ __device__ __forceinline__ double swap32_sum(double a, double b)
     return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
 }
 
-template <int L, int K, bool HAVE_OLD>
-__device__ __forceinline__ void accumulate_wave(double* msum, double* msumsq, int64_t stride, int tid, int g,
-                                                double2 (&ms)[K], double2 (&mq)[K],
-                                                const double2 (&olds)[K], const double2 (&oldq)[K], const double (&oldt)[4])
+// the transposed fold itself: afterwards v[0 .. NVL) are this lane's pieces of the wave's sums (see above)
+template <int L, int K>
+__device__ __forceinline__ void fold_scatter(int lane, const double2 (&ms)[K], const double2 (&mq)[K], double (&v)[8])
 {
-    if constexpr (FoldT<L, K>::on) {
-        constexpr int NVL = FoldT<L, K>::NVL;
-        const int lane = tid & 63;
-        double v[8] = {ms[0].x, ms[0].y, ms[1].x, ms[1].y, mq[0].x, mq[0].y, mq[1].x, mq[1].y};
+    static_assert(FoldT<L, K>::on, "K == 2, L = 8 / 16 / 32");
+    {
+        v[0] = ms[0].x; v[1] = ms[0].y; v[2] = ms[1].x; v[3] = ms[1].y; v[4] = mq[0].x; v[5] = mq[0].y; v[6] = mq[1].x; v[7] = mq[1].y;
         int n = 8;
         if constexpr (L == 8) {                          // lane ^ 8, inside the 16-lane row
             const bool hi = (lane & 8) != 0;
@@ -337,6 +343,19 @@ __device__ __forceinline__ void accumulate_wave(double* msum, double* msumsq, in
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) if (i < n / 2) v[i] = swap32_sum(v[i], v[i + n / 2]);
+    }
+}
+
+template <int L, int K, bool HAVE_OLD>
+__device__ __forceinline__ void accumulate_wave(double* msum, double* msumsq, int64_t stride, int tid, int g,
+                                                double2 (&ms)[K], double2 (&mq)[K],
+                                                const double2 (&olds)[K], const double2 (&oldq)[K], const double (&oldt)[4])
+{
+    if constexpr (FoldT<L, K>::on) {
+        constexpr int NVL = FoldT<L, K>::NVL;
+        const int lane = tid & 63;
+        double v[8];
+        fold_scatter<L, K>(lane, ms, mq, v);
         double* slot = msum + ((int64_t)(tid >> 6) * NVL) * 64 + lane;
 #pragma unroll
         for (int r = 0; r < NVL; ++r) store_wt(&slot[r * 64], (HAVE_OLD ? oldt[r] : slot[r * 64]) + v[r]);
@@ -371,14 +390,15 @@ __device__ __forceinline__ void accumulate_wave(double* msum, double* msumsq, in
 // rank's fine-grained progress array, written by the peers' signal kernels over xGMI.
 __device__ __forceinline__ void wait_for_peers(const HalfStepArgs& a, unsigned long long need, int lane)
 {
-    bool ok = lane >= a.nranks ||
+    const int nranks = p2p_nranks(a);
+    bool ok = lane >= nranks ||
               __hip_atomic_load(a.flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= need;
     unsigned spins = 0;
     // once a wait has timed out the run is invalid: do not pay the timeout again at every step
     if (__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) ok = true;
     while (!__all(ok)) {
         __builtin_amdgcn_s_sleep(2);
-        ok = lane >= a.nranks ||
+        ok = lane >= nranks ||
              __hip_atomic_load(a.flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= need;
         if (++spins > 30000000u) {                // ~10 s: a peer died -- flag it and fall through
             if (lane == 0) __hip_atomic_store(a.err, need + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -526,6 +546,13 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
     //      logarithm: measured best at C2 (all loads first: +0.15 us per half-step; loads after both logs: same),
     //      and pinned with scheduling barriers because the compiler's own placement moves with unrelated edits ----
     unsigned long long addrA = 0ull;                                    // P2P: the partner row's address
+    const int nranks = P2P ? p2p_nranks(a) : 1, me_rank = P2P ? p2p_me(a) : 0;
+#ifdef KMC_P2P_EXPERIMENTAL
+    const int pushmode = P2P ? a.push : 0;                              // 0: pull, 1: push, 2: lazy pull into local copies
+#else
+    const int pushmode = (P2P && p2p_push(a)) ? 1 : 0;
+#endif
+    const int64_t shard_stride = 2 * (int64_t)a.hloc * ld;              // push: pos is (1 + nranks) blocks of a shard's rows -- block 0 this rank's, block 1 + q a copy of rank q's
 #ifdef KMC_P2P_EXPERIMENTAL
     unsigned long long shadowB[ITER];                                   // KMC_P2P_LAZY: where a pulled row goes in the local shadow (0: not pulled)
 #endif
@@ -545,12 +572,9 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
             oth = reinterpret_cast<const V2*>(ad);
         }
         if constexpr (P2P) {
-#ifdef KMC_P2P_EXPERIMENTAL
-            const bool pull = a.push == 0;
-#else
-            constexpr bool pull = true;
-#endif
-            if (pull && a.nranks > 1) {                                 // pull: the row lives in its owner's memory
+            // pull: the row lives in its owner's memory; push: in a local copy that the owner writes over the fabric -- either way read at
+            // system scope, never from this XCD's L2 (lazy, experimental builds: the shadows are read like local rows)
+            if (pushmode != 2 && nranks > 1) {
 #pragma unroll
                 for (int k = 0; k < K; ++k) xo[it][k] = cv[k] ? load_row_sys(reinterpret_cast<const double2*>(&oth[k * L + j])) : zero2;
                 return;
@@ -576,13 +600,13 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
         for (int t = 1; t < 8; ++t) base = (q == (uint32_t)t) ? a.peer_pos[t] : base;
 #ifdef KMC_P2P_EXPERIMENTAL
         const double* remote_base = base;
-        if (a.push) base = (q == (uint32_t)a.me) ? a.pos : a.pos + (int64_t)(1u + q) * a.shard_stride;   // local copy of rank q's shard
 #endif
+        if (pushmode != 0) base = (q == (uint32_t)me_rank) ? a.pos : a.pos + (int64_t)(1u + q) * shard_stride;   // local copy of rank q's shard
         addrA = (unsigned long long)(base + (oth_row0 + r) * ld);
 #ifdef KMC_P2P_EXPERIMENTAL
         // KMC_P2P_LAZY: the local copies and this reader's stamps do not depend on the peers' progress -- request them
         // now, speculatively; whether a copy is still good is decided after the wait (newest accept bytes)
-        const bool remoteA = lazy && q != (uint32_t)a.me && validA;
+        const bool remoteA = lazy && q != (uint32_t)me_rank && validA;
         const int64_t xs = ((int64_t)q * 2 + (1 - half)) * (int64_t)a.hloc + r;
         uint32_t fe = 0u, mo = 0u;
         if (remoteA) { const uint2 st = a.lz_stamps[xs]; fe = st.x; mo = st.y; }
@@ -591,7 +615,7 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
             for (int it = 0; it < ITER; ++it) load_partner_rows(it);
         }
 #endif
-        if (a.nranks > 1) {
+        if (nranks > 1) {
             // every rank must have finished half-step `step - 1`: one polling wave per workgroup (the
             // flags sit in uncached fine-grained memory), the other waves wait at the barrier
             if ((threadIdx.x >> 6) == 0) wait_for_peers(a, step, lane);
@@ -605,7 +629,7 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
                 // absorb the accept bytes of half-step step - 1 (the partner half's last update) into the stamps
                 const uint32_t* maps = reinterpret_cast<const uint32_t*>(a.lz_amap_in);
                 const int64_t wpr = hl / 4, nthr = (int64_t)gridDim.x * vec_tpb(L);
-                for (int64_t w = tid; w < (int64_t)a.nranks * wpr; w += nthr) {
+                for (int64_t w = tid; w < (int64_t)p2p_nranks(a) * wpr; w += nthr) {
                     const int64_t qq = w / wpr, ww = w - qq * wpr;
                     if (qq == a.me) continue;
                     const uint32_t word = maps[(qq * 4 + (int64_t)((step - 1) & 3)) * wpr + ww];
@@ -684,8 +708,14 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
     if constexpr (kMomRing) asm volatile("" :: "s"(a.mring), "s"(a.mring_w), "s"(a.mcnt), "s"(a.mswept), "s"(a.mring_depth));
     double2 accs[K], accq[K];
     double  acct[4] = {0.0, 0.0, 0.0, 0.0};
+    // Large ensembles (ITER >= 4: the planner's choice from 16 384 waves on -- states that live in HBM) with several waves per workgroup: the
+    // waves' sums are added up through LDS and ONE wave per workgroup reads and rewrites accumulator slots (its own; the others' stay as the
+    // read-out and the flush kernel find them), in a fixed order -- a quarter (L = 32) or half (L = 8) of the accumulator bytes, which were 10 %
+    // of a launch's HBM traffic at 524 288 x 128 (33.5 MB in + 33.5 MB out of 656 MB; profiles/traffic_hbm_512kx128.json).
+    constexpr bool kWgFold = FoldT<L, K>::on && vec_tpb(L) > 64 && ITER >= 4;
+    const bool acc_owner = !kWgFold || (threadIdx.x >> 6) == 0;
     if constexpr (FoldT<L, K>::on) {
-        if (do_mom) {
+        if (do_mom && acc_owner) {
 #pragma unroll
             for (int r = 0; r < FoldT<L, K>::NVL; ++r) acct[r] = a.msum[((int64_t)(tid >> 6) * FoldT<L, K>::NVL + r) * 64 + lane];
         }
@@ -828,7 +858,7 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
             // half-step's progress flag -- from the signal kernel one boundary later, or from this kernel's last workgroup)
             const unsigned char byte = acc ? 1 : 0;
             const int64_t at = ((int64_t)a.me * 4 + (int64_t)(step & 3)) * (int64_t)a.hloc + iA;
-            for (int r = 0; r < a.nranks; ++r)
+            for (int r = 0; r < p2p_nranks(a); ++r)
                 if (r != a.me) store_wt(&a.lz_peer_amap[r][at], byte);
         }
     }
@@ -868,19 +898,17 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
             V2* own = reinterpret_cast<V2*>(posT + (own_row0 + w0 + it * G + g) * ld);
 #pragma unroll
             for (int k = 0; k < K; ++k) if (cv[k]) store_row(&own[k * L + j], xo[it][k]);
-#ifdef KMC_P2P_EXPERIMENTAL
             if constexpr (P2P) {
-                if (a.push == 1) {                                      // ... and into this rank's shadow on every peer
-                    const int64_t off = (int64_t)(1 + a.me) * a.shard_stride + (own_row0 + w0 + it * G + g) * ld;
-                    for (int r = 0; r < a.nranks; ++r) {
-                        if (r == a.me) continue;
+                if (pushmode == 1) {                                    // ... and into this rank's copy on every peer (write-through, over the fabric)
+                    const int64_t off = (int64_t)(1 + me_rank) * shard_stride + (own_row0 + w0 + it * G + g) * ld;
+                    for (int r = 0; r < nranks; ++r) {
+                        if (r == me_rank) continue;
                         double2* rem = reinterpret_cast<double2*>(a.peer_pos[r] + off);
 #pragma unroll
                         for (int k = 0; k < K; ++k) if (cv[k]) store_wt(&rem[k * L + j], xo[it][k]);
                     }
                 }
             }
-#endif
         }
         if (any_w) {
             const double wB = (double)(uint32_t)__builtin_amdgcn_ds_bpermute((gbase + it) * 4, (int)wA);
@@ -907,7 +935,30 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
             for (int k = 0; k < K; ++k) if (cv[k]) store_row(&dst[k * L + j], sel2(accB, xo[it][k], xc[it][k]));
         }
     }
-    if (any_w) {
+    if constexpr (kWgFold) {
+        if (do_mom) {                                                   // (uniform over the launch: every wave of the workgroup arrives)
+            constexpr int NVL = FoldT<L, K>::NVL, NWV = vec_tpb(L) / 64;
+            __shared__ double wg_fold[NWV - 1][NVL][64];
+            const int wv = (int)(threadIdx.x >> 6);
+            double v[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            if (any_w) fold_scatter<L, K>(lane, ms, mq, v);
+            if (wv != 0) {
+#pragma unroll
+                for (int r = 0; r < NVL; ++r) wg_fold[wv - 1][r][lane] = v[r];
+            }
+            lds_barrier();
+            if (wv == 0) {
+                double* slot = a.msum + ((int64_t)(tid >> 6) * NVL) * 64 + lane;
+#pragma unroll
+                for (int r = 0; r < NVL; ++r) {
+                    double t = v[r];
+#pragma unroll
+                    for (int w = 0; w < NWV - 1; ++w) t += wg_fold[w][r][lane];
+                    store_wt(&slot[r * 64], acct[r] + t);
+                }
+            }
+        }
+    } else if (any_w) {
         if (use_ring) {
             if (lane == 0) a.mcnt[tid >> 6] = ring_posted + ring_new;
         } else {
@@ -920,7 +971,7 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
         // KMC_P2P_FOLD_SIGNAL: every store above is write-through, so once a workgroup's stores have drained they are
         // in memory, where the peers read them; the last workgroup to get there tells every rank that this rank has
         // completed half-step `step` (flag = step + 1) -- what the separate p2p_signal kernel does one boundary later
-        if (a.nranks > 1 && a.done_count != nullptr) {
+        if (p2p_nranks(a) > 1 && a.done_count != nullptr) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (threadIdx.x == 0) {
@@ -940,7 +991,7 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
                     if (__hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nsub - 1u) {
                         __hip_atomic_store(top, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         __threadfence_system();
-                        for (int r = 0; r < a.nranks; ++r)
+                        for (int r = 0; r < p2p_nranks(a); ++r)
                             __hip_atomic_store(a.peer_flags[r] + a.me, (unsigned long long)step + 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
                     }
                 }
@@ -1030,7 +1081,7 @@ __device__ __forceinline__ void half_step_generic_body(const HalfStepFront& f, c
     const int tid = blockIdx.x * 256 + threadIdx.x;
     const SchedEntry sch = schedule_of(f, a);
     const uint64_t step = 2ull * (uint64_t)sch.gen + (uint64_t)a.half;      // (eager: sched_inline.gen)
-    if constexpr (P2P) { if (a.nranks > 1) wait_for_peers(a, step, (int)(threadIdx.x & 63)); }   // whole waves, before any exit
+    if constexpr (P2P) { if (p2p_nranks(a) > 1) wait_for_peers(a, step, (int)(threadIdx.x & 63)); }   // whole waves, before any exit
     if (tid >= a.n_active) return;
     const int ndim = a.ndim;
     const bool count  = (sch.flags & kCount) != 0;
@@ -1054,7 +1105,7 @@ __device__ __forceinline__ void half_step_generic_body(const HalfStepFront& f, c
     // partner element d: P2P rows live in their owner's memory and are read at system scope (see load_row_sys)
     auto oth_at = [&](int d) -> double {
         if constexpr (P2P) {
-            if (a.nranks > 1)
+            if (p2p_nranks(a) > 1)
                 return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(oth) + d,
                                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
         }

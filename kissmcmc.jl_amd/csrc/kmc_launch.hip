@@ -66,7 +66,7 @@ HalfStepArgs make_args(const kmc_sampler* s, int half, bool graph_mode, int64_t 
     a.hloc = (uint32_t)s->h_loc;
     a.hloc_shift = -1;
     if (s->h_loc > 0 && (s->h_loc & (s->h_loc - 1)) == 0) { a.hloc_shift = 0; while (((int64_t)1 << a.hloc_shift) < s->h_loc) ++a.hloc_shift; }
-    a.nranks = s->cfg.shard_count;
+    a.nranks = pack_ranks(s->cfg.shard_count, s->cfg.shard_rank, s->push && !s->lazy);
     for (int r = 0; r < 8; ++r) a.peer_pos[r] = s->peer_pos[r];
     a.flags = s->d_flags;
     a.err = s->d_err;

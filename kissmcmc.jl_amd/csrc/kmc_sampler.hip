@@ -79,10 +79,12 @@ KMC_EXPORT kmc_status kmc_validate(const kmc_config* c)
     if ((c->nwalkers / 2) % P != 0) return fail(KMC_ERR_BAD_ARG, "nwalkers/2 must be divisible by shard_count");
     if ((c->flags & KMC_P2P) && P > 8) return fail(KMC_ERR_UNSUPPORTED, "KMC_P2P supports at most 8 shards (one node)");
 #ifndef KMC_P2P_EXPERIMENTAL
-    if (c->flags & (KMC_P2P_PUSH | KMC_P2P_LAZY | KMC_P2P_FOLD_SIGNAL))
-        return fail(KMC_ERR_UNSUPPORTED, "KMC_P2P_PUSH / KMC_P2P_LAZY / KMC_P2P_FOLD_SIGNAL exist only in builds with -DKMC_P2P_EXPERIMENTAL "
-                                         "(python -m kissmcmc_jl_amd.build --p2p-experimental): the default library's exchange is the pull of drawn rows with system-scope loads");
+    if (c->flags & (KMC_P2P_LAZY | KMC_P2P_FOLD_SIGNAL))
+        return fail(KMC_ERR_UNSUPPORTED, "KMC_P2P_LAZY / KMC_P2P_FOLD_SIGNAL exist only in builds with -DKMC_P2P_EXPERIMENTAL "
+                                         "(python -m kissmcmc_jl_amd.build --p2p-experimental): the default library's exchanges are the pull of drawn rows and "
+                                         "the push of accepted rows (KMC_P2P_PUSH), both read with system-scope loads");
 #endif
+    if ((c->flags & KMC_P2P_PUSH) && !(c->flags & KMC_P2P)) return fail(KMC_ERR_BAD_ARG, "KMC_P2P_PUSH needs KMC_P2P");
     if (c->flags & KMC_ISLANDS) {
         const int64_t S = c->island_size > 0 ? c->island_size : kIslandSizeDefault;
         if ((S != 64 && S != 128 && S != 256) || c->nwalkers % S != 0 || c->ndim > 32 || c->ndim + 2 > S || P != 1 ||
@@ -489,13 +491,15 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         CREATE_TRY(hipMemsetAsync(s->d_flags, 0, 4096, s->stream));
         CREATE_TRY(dev_alloc(s, (void**)&s->d_err, 64));
         CREATE_TRY(hipMemsetAsync(s->d_err, 0, 64, s->stream));
+        // KMC_P2P_PUSH: local copies of the other shards, which their owners write; the menu densities' vector kernels carry it (anything
+        // else keeps the pull -- kmc_sampler_describe says which runs)
+        s->push = (cfg->flags & (KMC_P2P_PUSH | KMC_P2P_LAZY)) != 0 && s->plan.vec && s->user == nullptr && !(cfg->flags & KMC_P2P_FINEGRAINED) &&
+                  s->cfg.shard_count > 1;
 #ifdef KMC_P2P_EXPERIMENTAL
         CREATE_TRY(dev_alloc(s, (void**)&s->d_done, 33 * 64));
         CREATE_TRY(hipMemsetAsync(s->d_done, 0, 33 * 64, s->stream));
         // the kernel can publish its own completion only where all its stores are write-through: the vector kernels
         s->fold_signal = (cfg->flags & KMC_P2P_FOLD_SIGNAL) != 0 && s->plan.vec && s->user == nullptr;
-        s->push = (cfg->flags & (KMC_P2P_PUSH | KMC_P2P_LAZY)) != 0 && s->plan.vec && s->user == nullptr && !(cfg->flags & KMC_P2P_FINEGRAINED) &&
-                  s->cfg.shard_count > 1;
         s->lazy = s->push && (cfg->flags & KMC_P2P_LAZY) != 0 && s->h_loc % 16 == 0 && !s->f32;
         s->lazy_stats = s->lazy && debug_opt("p2p-stats");
 #endif

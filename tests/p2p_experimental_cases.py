@@ -47,3 +47,21 @@ def test_folded_signal_tolerates_a_late_rank(oracle, tmp_path):
                          ids=["push", "lazy", "lazy-fold", "fold"])
 def test_two_variant_shards_in_one_process(kmc, oracle, kw):
     base.test_two_shards_in_one_process(kmc, oracle, kw)
+
+
+def test_runtime_compiled_density_under_the_experimental_build(kmc, oracle, kmc_debug):
+    """The argument struct of this build is longer (HalfStepArgs: the experimental fields sit in the middle): runtime-compiled kernels must be built with the
+    same -DKMC_P2P_EXPERIMENTAL, or every field behind the first difference is read from the wrong offset (kmc_rtc.hip also compares the
+    struct sizes of module and library at load)."""
+    base.test_two_p2p_shards_with_a_runtime_compiled_density(kmc, oracle, "expr", kmc_debug)
+    nw, nd, G = 4096, 32, 70                                # ... and an unsharded sampler over a function body
+    th = np.random.default_rng(5).standard_normal((nw, nd))
+    pdf = kmc.CDensity("double s = 0; for (int i = 0; i < n; ++i) s += x[i] * x[i]; return -0.5 * s;")
+    with kmc.Sampler(pdf, nw, nd, G, 10, 1, 2.0, 3, moments=True) as s:
+        s.set_positions(th)
+        s.run(G)
+        s.sync()
+        pos, nacc = s.positions(), s.naccept()
+    ref = oracle.emcee(oracle.make_config(oracle.GAUSSIAN_ISO, [0.0, 1.0], nw, nd, G, 10, 1, 2.0, 3), th, store_chain=False)
+    np.testing.assert_array_equal(pos, ref["final_pos"])
+    np.testing.assert_array_equal(nacc, ref["naccept"])

@@ -53,6 +53,8 @@ def _worker(rank, world, port, outdir, plan, late_rank=-1):
         drv = P2PEmcee(kmc.GaussianIso(), NW, ND, G, NBURN, 1, 2.0, SEED, device=0, fold_signal=fold, push=push, lazy=lazy)
         if lazy:
             assert "lazy" in drv.sampler.describe()
+        if push and not lazy:
+            assert "KMC_P2P_PUSH" in drv.sampler.describe()
         drv.set_positions(_theta0())
         if rank == late_rank:
             import time
@@ -120,8 +122,9 @@ def _free_port():
     return rendezvous_port()
 
 
-# (the push / lazy / folded-signal plans of _worker: tests/p2p_experimental_cases.py, against the -DKMC_P2P_EXPERIMENTAL library)
-@pytest.mark.parametrize("world,plan", [(2, ""), (4, ""), (2, "generic")])   # the GPU box allows 6 processes on the card: parent + 4 ranks at most
+# (the lazy / folded-signal plans of _worker: tests/p2p_experimental_cases.py, against the -DKMC_P2P_EXPERIMENTAL library; "push": accepted rows written
+#  into every peer's local copy of the shard, read there with system-scope loads -- in the default library since round 5)
+@pytest.mark.parametrize("world,plan", [(2, ""), (4, ""), (2, "generic"), (2, "push"), (4, "push")])   # the GPU box allows 6 processes on the card: parent + 4 ranks at most
 def test_p2p_processes_sharing_one_gpu_equal_oracle(oracle, tmp_path, world, plan):
     import torch.multiprocessing as mp
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), plan), nprocs=world, join=True)
@@ -224,7 +227,7 @@ def test_p2p_with_finegrained_rows(oracle, tmp_path):
     np.testing.assert_array_equal(z["pos"], ref["final_pos"])
 
 
-@pytest.mark.parametrize("kw", [dict()], ids=["pull"])
+@pytest.mark.parametrize("kw", [dict(), dict(p2p_push=True)], ids=["pull", "push"])
 def test_two_shards_in_one_process(kmc, oracle, kw):
     """kmc_sampler_p2p_connect_local: both shards live in this process and run concurrently on their own streams,
     ordered by the same progress flags (what scripts/p2p_local_bench.py times); result = the oracle's."""
@@ -301,11 +304,14 @@ def test_two_p2p_shards_with_a_runtime_compiled_density(kmc, oracle, form, kmc_d
 
 
 def test_default_library_refuses_the_experimental_exchange_variants(kmc):
-    """Push / lazy pull / folded signal have peers write into plain device memory the local kernel reads through its own L2 -- nothing
-    one GPU can validate -- so the default library does not contain them: the flags are refused with the reason, by validation."""
+    """Lazy pull / folded signal have peers write into plain device memory the local kernel reads through its own L2 (or publish completion from
+    inside the kernel) -- nothing one GPU can validate -- so the default library does not contain them: the flags are refused with the reason, by
+    validation.  (The push of accepted rows is in since round 5: its readers use system-scope loads, like the pull's.)"""
     from kissmcmc_jl_amd import _lib
     assert _lib.lib().kmc_has_p2p_experimental() == 0
-    for kw in (dict(p2p_push=True), dict(p2p_lazy=True), dict(p2p_fold=True)):
+    with kmc.Sampler(kmc.GaussianIso(), NW, ND, G, NBURN, 1, 2.0, SEED, shard_rank=0, shard_count=2, p2p=True, p2p_push=True) as s:
+        assert "KMC_P2P_PUSH" in s.describe()
+    for kw in (dict(p2p_lazy=True), dict(p2p_fold=True)):
         with pytest.raises(kmc.KmcError, match="KMC_P2P_EXPERIMENTAL") as e:
             kmc.Sampler(kmc.GaussianIso(), NW, ND, G, NBURN, 1, 2.0, SEED, shard_rank=0, shard_count=2, p2p=True, **kw)
         assert e.value.status == _lib.ERR_UNSUPPORTED

@@ -23,4 +23,4 @@ def test_experimental_variants_equal_the_oracle_under_their_own_build(kmc):
     tail = (r.stdout + r.stderr)[-3000:]
     assert r.returncode == 0, tail
     m = re.search(r"(\d+) passed", r.stdout)
-    assert m and int(m.group(1)) == 12, tail
+    assert m and int(m.group(1)) == 13, tail

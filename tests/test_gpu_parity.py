@@ -111,6 +111,14 @@ def test_matches_oracle(kmc, oracle, name, nw, nd, G, nburn, nthin):
     _compare(ref, got)
 
 
+@pytest.mark.parametrize("name,nw,nd,plan", [("gauss", 2048, 128, "32,2,4"), ("gauss", 4100, 128, "32,2,8"), ("rosen", 1030, 100, "32,2,4"), ("gauss_shift", 2048, 32, "8,2,8")])
+def test_moments_folded_per_workgroup(kmc, oracle, name, nw, nd, plan, monkeypatch):
+    """ITER >= 4 (the planner's geometries for ensembles that live in HBM) with several waves per workgroup: the waves' moment sums are added up through
+    LDS and one wave per workgroup rewrites its accumulator slots (kmc_kernels.hpp: kWgFold) -- same chain, moments to 1e-11, partly idle last workgroups."""
+    ref, got = _run_both(kmc, oracle, name, nw, nd, 70, 20, 3, seed=7, plan=plan, monkeypatch=monkeypatch)
+    _compare(ref, got)
+
+
 @pytest.mark.parametrize("plan", ["generic", "16,1,1", "16,1,2", "16,1,4", "16,1,8", "16,1,16", "8,2,1", "8,2,4", "8,2,8", "4,4,1", "4,4,4", "4,2,2"])
 def test_every_geometry_gives_the_same_chain(kmc, oracle, plan, monkeypatch):
     """The result is a pure function of (seed, inputs): launch geometry must not matter."""
