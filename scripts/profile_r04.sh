@@ -6,11 +6,15 @@
 #   probe_<cfg>.txt       in-kernel timeline of the -DKMC_PROBE build (scripts/probe_timeline.py): body / boundary per launch
 # The program itself follows "--" (python3 <script>), never a wrapper.  Condense HERE (the build container has git) with
 # scripts/summarize_r04.py -> profiles/r04_*_summary.json and profiles/traffic_<cfg>.json.
+# Started by scripts/profile_passes.sh (build container), which refuses a tree with uncommitted kernel / bench edits and leaves the commit the snapshot was taken
+# from in .kmc_profile_head: the records name a commit a reader can check out (the round-4 records said "+uncommitted kernel/bench edits").
 set -e
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof_r04
+if [ ! -s $R/.kmc_profile_head ]; then echo "profile_r04.sh: no .kmc_profile_head -- start the passes with scripts/profile_passes.sh (it refuses a dirty tree)"; exit 2; fi
 rm -rf $OUT && mkdir -p $OUT
+cp $R/.kmc_profile_head $OUT/head.txt
 BENCH="python3 $R/bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs --no-island"
 $BENCH > $OUT/c2_unprofiled.json 2> $OUT/c2_unprofiled.err
 echo "unprofiled bench done"

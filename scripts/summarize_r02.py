@@ -76,7 +76,7 @@ def bench_line(path):
         return None
     for line in open(path):
         line = line.strip()
-        if line.startswith("{") and '"metric"' in line:
+        if line.startswith('{"metric"'):             # (the result line; since round 5 the full record precedes it as {"bench_detail": ...})
             return json.loads(line)
     return None
 

@@ -31,14 +31,11 @@ SHAPES = {"c2": ("c2", 65536, 32, "65536 x 32 GaussianIso, moments on"),
 
 
 def head():
-    if os.environ.get("KMC_PROFILE_HEAD"):          # (the passes ran on a snapshot of that commit; the tree has moved on since)
-        return os.environ["KMC_PROFILE_HEAD"]
-    try:
-        h = subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
-        dirty = subprocess.run(["git", "status", "--porcelain", "--", "kissmcmc.jl_amd/csrc", "bench.py"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
-        return h + ("+uncommitted kernel/bench edits" if dirty else "")
-    except Exception:  # noqa: BLE001
-        return None
+    """The commit the passes ran on: scripts/profile_passes.sh refuses a dirty tree and writes it into the snapshot; the box-side script copies it beside its output."""
+    p = os.path.join(SRC, "head.txt")
+    if not os.path.exists(p):
+        raise SystemExit(f"{p} is missing: the passes were not started by scripts/profile_passes.sh (which refuses a tree with uncommitted kernel / bench edits)")
+    return open(p).read().strip()
 
 
 def probe(cfg):
@@ -60,7 +57,7 @@ def describe_of(path):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
     hd = head()
     for cfg, (name, nw, nd, workload) in SHAPES.items():
         b = os.path.join(SRC, cfg)
