@@ -46,7 +46,8 @@ def note(msg: str) -> None:
 def bench_test_opt(name: str, default=None):
     """KMC_BENCH_TEST="opt[=value],opt,...": the switches only the tests of this file use (README): backend=gloo and walkers=n
     (several ranks rehearsed on ONE GPU), force-sharded (the N > 1 code path with one rank over real RCCL), fault=point:rank (one rank
-    fails at a point of the ladder), no-allgather-extra, deal-epoch=n, no-hbm-shapes."""
+    fails at a point of the ladder), no-allgather-extra, deal-epoch=n, no-hbm-shapes, timeout=s (the whole N > 1 job, default 1500) and rung-timeout=s
+    (each rung of its ladder, default 300: a hung collective ends in a non-zero exit)."""
     for item in os.environ.get("KMC_BENCH_TEST", "").split(","):
         k, _, v = item.partition("=")
         if k == name:
@@ -285,7 +286,7 @@ def spawn_ranks(n: int, argv) -> int:
     """`--gpus n` without a launcher: start the n ranks ourselves (one child process per rank with RANK / LOCAL_RANK /
     WORLD_SIZE / MASTER_* in its environment -- what torch.distributed.run would set), BEFORE anything in this process
     touches the GPU; never exec.  Rank 0's stdout is relayed (its JSON line last), the other ranks' goes to stderr.  The first
-    rank that fails takes the others down; the whole job is bounded by KMC_BENCH_TIMEOUT seconds (a hung collective must end
+    rank that fails takes the others down; the whole job is bounded by KMC_BENCH_TEST=timeout=<seconds> (default 1500) (a hung collective must end
     in a non-zero exit, not in the caller's lease).  Returns the job's exit status."""
     import signal
     import socket
@@ -336,7 +337,7 @@ def spawn_ranks(n: int, argv) -> int:
     lines = []
     reader = threading.Thread(target=lambda: lines.extend(procs[0].stdout), daemon=True)
     reader.start()
-    deadline = time.monotonic() + float(os.environ.get("KMC_BENCH_TIMEOUT", 1500))
+    deadline = time.monotonic() + float(bench_test_opt("timeout", 1500))
     status = 0
 
     def end_ranks(grace: float = 10.0):
@@ -354,7 +355,7 @@ def spawn_ranks(n: int, argv) -> int:
             bad = [p.returncode for p in procs if p.poll() is not None and p.returncode != 0]
             if bad or time.monotonic() > deadline:
                 status = bad[0] if bad else 124
-                note(f"[bench launcher] {'a rank exited with status ' + str(status) if bad else 'the job ran out of time (KMC_BENCH_TIMEOUT)'}: stopping the others")
+                note(f"[bench launcher] {'a rank exited with status ' + str(status) if bad else 'the job ran out of time (KMC_BENCH_TEST=timeout=s)'}: stopping the others")
                 time.sleep(5.0 if bad else 0.0)      # (a failing rank's peers usually follow by themselves)
                 end_ranks()
                 break
@@ -411,7 +412,7 @@ class rung:
 
     def __init__(self, what: str, seconds: float = None, fatal: bool = True):
         self.what = what
-        self.seconds = float(os.environ.get("KMC_BENCH_RUNG_TIMEOUT", 300)) if seconds is None else seconds
+        self.seconds = float(bench_test_opt("rung-timeout", 300)) if seconds is None else seconds
         self.timer = None
         self.ok = True
         self.fatal = fatal

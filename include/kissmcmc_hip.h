@@ -392,7 +392,7 @@ int64_t     kmc_sampler_launch_count(const kmc_sampler* s);
 /* How kmc_sampler_run issues this sampler's launches (same kernels, same results in every mode; reference
  * src/samplers.jl:245-247 -- the generation x half-step loop -- is what the modes enqueue).  *budget_fallback (may be NULL)
  * becomes 1 when the sampler is not in the updated-graph mode because the PROCESS-WIDE budget of graph parameter updates was
- * spent (the HIP runtime leaks ~80 B of host memory per update; 64 MiB worth by default, KMC_UPDATED_BUDGET_MB in the
+ * spent (the HIP runtime leaks ~80 B of host memory per update; 64 MiB worth by default, KMC_DEBUG=updated-budget-mb=n in the
  * environment or kmc_set_updated_budget_mb): said once on stderr, in kmc_sampler_describe, and here. */
 #define KMC_LAUNCH_UNDECIDED     0   /* only short runs so far: whole chunks from the table graph, the rest eagerly */
 #define KMC_LAUNCH_TABLE_GRAPH   1   /* hipGraph replay of 64 generations, schedule read from a device table (also: one launch per generation) */

@@ -1,5 +1,5 @@
 // kmc_diag.hip -- diagnostics: the accept-term probe of the C ABI (include/kissmcmc_hip.h: "diagnostics"), the native
-// backtrace of an abort() (KMC_ABORT_BACKTRACE), the guard bands behind a sampler's device allocations (KMC_DEBUG=poison), and the
+// backtrace of an abort() (KMC_DEBUG=abort-backtrace), the guard bands behind a sampler's device allocations (KMC_DEBUG=poison), and the
 // device's free memory.
 //
 // kmc_debug_accept_terms: the random side of the accept test of reference src/samplers.jl:260,
@@ -24,19 +24,27 @@
 using namespace kmc;
 using namespace kmc_host;
 
-// Diagnostics (KMC_ABORT_BACKTRACE=1 in the environment when the library is loaded): the native call stack of an abort()
+// Diagnostics (KMC_DEBUG=abort-backtrace[=/path/to/file] in the environment when the library is loaded): the native call stack of an abort()
 // raised anywhere in the process (the HIP runtime aborts on internal errors without a message), on stderr.
 namespace {
 #ifndef KMC_DIAG_ALWAYS
 #define KMC_DIAG_ALWAYS 0          // -DKMC_DIAG_ALWAYS=1: a diagnostics build that always installs the handler (file /tmp/kmc_abort_bt.txt)
 #endif
+char g_abort_path[512] = "";
+bool abort_backtrace_wanted()
+{
+    std::string v;
+    if (!debug_opt("abort-backtrace", &v)) return KMC_DIAG_ALWAYS != 0;
+    if (!v.empty() && v[0] == '/') std::snprintf(g_abort_path, sizeof(g_abort_path), "%s", v.c_str());
+    return true;
+}
 void abort_backtrace(int sig)
 {
     void* frames[64];
     const int n = backtrace(frames, 64);
     const char msg[] = "\n[kissmcmc_hip] SIGABRT, native stack:\n";
-    int fd = 2;                                          // KMC_ABORT_BACKTRACE=/path/to/file: there (a test runner may have captured fd 2)
-    const char* where = std::getenv("KMC_ABORT_BACKTRACE");
+    int fd = 2;                                          // abort-backtrace=/path/to/file: there (a test runner may have captured fd 2)
+    const char* where = g_abort_path[0] ? g_abort_path : nullptr;       // (resolved when the handler was installed: nothing here may allocate)
     if (!where && KMC_DIAG_ALWAYS) where = "/tmp/kmc_abort_bt.txt";
     if (where && where[0] == '/') { const int f = open(where, O_WRONLY | O_CREAT | O_APPEND, 0644); if (f >= 0) fd = f; }
     (void)!write(fd, msg, sizeof(msg) - 1);
@@ -55,13 +63,13 @@ void abort_backtrace(int sig)
     raise(sig);
 }
 struct AbortBacktraceInstaller {
-    AbortBacktraceInstaller() { if (std::getenv("KMC_ABORT_BACKTRACE") || KMC_DIAG_ALWAYS) signal(SIGABRT, abort_backtrace); }
+    AbortBacktraceInstaller() { if (abort_backtrace_wanted()) signal(SIGABRT, abort_backtrace); }
 } g_abort_backtrace_installer;
 }  // namespace
 
 void kmc_host::reinstall_abort_backtrace()
 {
-    if (std::getenv("KMC_ABORT_BACKTRACE") || KMC_DIAG_ALWAYS) signal(SIGABRT, abort_backtrace);      // (somebody may have replaced it)
+    if (abort_backtrace_wanted()) signal(SIGABRT, abort_backtrace);      // (somebody may have replaced it)
 }
 
 namespace kmc_host {

@@ -170,10 +170,12 @@ struct kmc_user_density {
     bool sep_pair = false;                           // the loop reads x[i + 1] / runs to n - 1: its body is the PAIR function
     int sep_nacc = 1;                                // sums the loop feeds (1: SepDensity; 2..4: SepDensityN)
     std::string sep_functor;                         // "struct UserS { term, pair, finish };" generated from the body
-    // The recogniser reads TEXT; before the first sampler runs the generated form it is evaluated next to the body itself on test
-    // points (kmc_sampler.hip: check_sum_form): 0 not yet, 1 they agree, 2 they do not (or no test point had a finite value: nothing
-    // was shown) -> `sep` is cleared and the body is evaluated per walker, as written.
-    std::atomic<int> sep_verdict{0};
+    // The recogniser reads TEXT; before a sampler runs the generated form it is evaluated next to the body itself on test points
+    // (kmc_sampler.hip: check_sum_form) -- once per (ndim, parameter values): what agrees at one row length and one parameter set says
+    // nothing about another.  sep_case: 1 they agree there; 3 no test point had a finite value there (nothing was shown: THAT sampler runs the
+    // body as written, the density keeps its routing for other cases).  A case where the two DISAGREE refutes the recogniser: `sep` is
+    // cleared for good (sep_note says why) and every later sampler evaluates the body per walker, as written.
+    std::map<std::pair<int64_t, uint64_t>, int> sep_case;    // (ndim, digest of the parameter values) -> verdict; under `mu`
     std::mutex check_mu;                             // held by the sampler that finds out (plan, load, check): others over the same density wait
     std::string sep_note;                            // why not (describe())
     std::mutex mu;
@@ -182,3 +184,8 @@ struct kmc_user_density {
     // half of what a sampler of the reference's sizes lives); unloaded when the last holder -- this object or a sampler -- lets go
     std::map<std::pair<const void*, int>, std::shared_ptr<void>> modules;
 };
+// Is the body run in its per-element form BY THE SAMPLER BEING BUILT on this thread?  The density's own flag, unless that sampler's check was blind
+// (kmc_sampler_create holds a SepOff for the rest of its set-up; afterwards the sampler's own `sep_off` says it).
+inline thread_local bool g_sep_off = false;
+struct SepOff { bool prev; explicit SepOff(bool off) : prev(g_sep_off) { if (off) g_sep_off = true; } ~SepOff() { g_sep_off = prev; } };
+inline bool sep_routed(const kmc_user_density* ud) { return ud && ud->sep && !g_sep_off; }

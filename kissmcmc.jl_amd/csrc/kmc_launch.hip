@@ -405,7 +405,8 @@ std::atomic<int64_t>& update_budget()
 {
     static std::atomic<int64_t> budget{[] {
         double mb = 64.0;
-        if (const char* e = std::getenv("KMC_UPDATED_BUDGET_MB")) mb = std::atof(e);
+        std::string v;
+        if (debug_opt("updated-budget-mb", &v) && !v.empty()) mb = std::atof(v.c_str());
         return (int64_t)(mb * 1048576.0 / 80.0);
     }()};
     return budget;
@@ -419,7 +420,7 @@ void note_budget_spent(kmc_sampler* s)
     static std::atomic<bool> said{false};
     if (!said.exchange(true))
         std::fprintf(stderr, "[kissmcmc_hip] the updated-graph launch mode has used up this process's budget (%lld parameter updates, "
-                             "KMC_UPDATED_BUDGET_MB / kmc_set_updated_budget_mb; the HIP runtime leaks ~80 B per update): samplers now "
+                             "kmc_set_updated_budget_mb / KMC_DEBUG=updated-budget-mb=n; the HIP runtime leaks ~80 B per update): samplers now "
                              "choose between the table graph and eager launches (up to ~9 %% slower per half-step; results are identical)\n",
                      (long long)g_update_calls.load(std::memory_order_relaxed));
 }
@@ -742,7 +743,7 @@ KMC_EXPORT kmc_status kmc_sampler_run(kmc_sampler* s, int64_t ngen)
     //                      every replay (C2 4.00 us, C3 3.25 us; steady).  But hipGraphExecKernelNodeSetParams leaks ~80
     //                      bytes of host memory per call inside the runtime (1.6 MB per 10^4 generations, not returned
     //                      when the executables are destroyed; scripts/exp/leak_check.py), so the process has a BUDGET
-    //                      of such calls (kUpdateBudgetCalls, KMC_UPDATED_BUDGET_MB): beyond it samplers choose
+    //                      of such calls (kmc_set_updated_budget_mb): beyond it samplers choose
     //                      between 1 and 2.
     // A long run measures 1 against 3 (or 2) once -- four chunks each, HIP events: a starved GPU shows as idle time
     // between the events -- and keeps the faster; KMC_LAUNCH=graph|eager|updated decides without measuring.

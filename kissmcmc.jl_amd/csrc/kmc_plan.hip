@@ -214,10 +214,10 @@ Plan make_plan(const kmc_config& c, int64_t n_active)
         // a function body in the vector kernel: lane-striped like term / pair when it was recognised as a sum over elements, else
         // with its rows lane-striped and only the evaluation per walker (RowEvalTrait); KMC_DEBUG=no-body-routing / no-body-vec
         // keep it one walker per lane (ensembles small enough for the resident kernels: decided by the caller)
-        const bool body = ud && ud->is_body && !(ud->sep || body_vec_possible(ud, c.ndim));
+        const bool body = ud && ud->is_body && !(sep_routed(ud) || body_vec_possible(ud, c.ndim));
         if (!body && !force_generic && L > 0 && 2 * L * K >= c.ndim && iter <= L && iter * K <= 16) {
             // (a body evaluated per walker keeps a tile of the wave's proposals in LDS: at most 64 KiB per workgroup)
-            if (ud && ud->is_body && !ud->sep) while (iter > 1 && body_vec_lds_bytes(L, K, iter) > 65536) iter /= 2;
+            if (ud && ud->is_body && !sep_routed(ud)) while (iter > 1 && body_vec_lds_bytes(L, K, iter) > 65536) iter /= 2;
             p.vec = true; p.L = L; p.K = K; p.ITER = iter;
         } else {
             p.vec = false; p.L = 1; p.K = 1; p.ITER = 1;

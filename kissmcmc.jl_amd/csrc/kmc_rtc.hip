@@ -556,12 +556,12 @@ kmc_status compile_user(kmc_user_density* ud, bool with_vec, int L, int K, int i
     // resident_K also sizes the island kernel (same row striping: 2 lanes per walker, K chunks)
     // a body in the vector kernels: lane-striped when it is a recognised sum over elements (sep), else rows lane-striped and the body
     // evaluated per walker on the whole proposal (kmc_kernels.hpp, RowEvalTrait; no blobs, ndim <= kBodyVecMaxDim)
-    if (ud->is_body && ((with_vec && !ud->sep && !body_vec_possible(ud, ndim)) || island_S > 0))
+    if (ud->is_body && ((with_vec && !sep_routed(ud) && !body_vec_possible(ud, ndim)) || island_S > 0))
         return fail(KMC_ERR_UNSUPPORTED, "this body density runs in the one-walker-per-lane kernels only");
     const bool staged = !with_vec && staged_possible(ud, f32, ndim, p2p);
     char key[128];
     std::snprintf(key, sizeof(key), "%d:%d,%d,%d,%d|%d,%d|%d|%d|%lld|%d|%d|%d|%d|%d", (int)with_vec, L, K, iter, (int)ragged, resident_K,
-                  (int)resident_ragged, island_S, (int)f32, ud->is_body ? (long long)ndim : 0ll, (int)staged, (int)p2p, ud->nblob, (int)ud->sep + 2 * (int)offline_compiler_wanted(),
+                  (int)resident_ragged, island_S, (int)f32, ud->is_body ? (long long)ndim : 0ll, (int)staged, (int)p2p, ud->nblob, (int)sep_routed(ud) + 2 * (int)offline_compiler_wanted(),
                   generation_nd);
     const char* peer = p2p ? "true" : "false";         // KMC_P2P: partner rows read from their owners (pull)
     const char* rowt = f32 ? "float" : "double";       // storage type of the walker rows (KMC_F32 / KMC_F64)
@@ -578,13 +578,13 @@ kmc_status compile_user(kmc_user_density* ud, bool with_vec, int L, int K, int i
 
     std::ostringstream src;
     src << "#include \"kmc_islands.hpp\"\n#include \"kmc_generation.hpp\"\n" << user_functor_source(ud) << user_density_alias(ud, ndim)
-        << (ud->is_body && with_vec && ud->sep ? ud->sep_functor + (ud->sep_nacc > 1 ? "using UDV = kmc::SepDensityN<UserS>;\n" : "using UDV = kmc::SepDensity<UserS>;\n")
+        << (ud->is_body && with_vec && sep_routed(ud) ? ud->sep_functor + (ud->sep_nacc > 1 ? "using UDV = kmc::SepDensityN<UserS>;\n" : "using UDV = kmc::SepDensity<UserS>;\n")
                                                 : std::string("using UDV = UD;\n"))
         << "extern \"C\" __device__ const unsigned kmc_user_args_bytes[4] = {(unsigned)sizeof(kmc::HalfStepArgs), (unsigned)sizeof(kmc::GenerationArgs), (unsigned)sizeof(kmc::ResidentArgs), (unsigned)sizeof(kmc::LogpdfArgs)};\n"
         << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_generic(KMC_FRONT_PARAMS, const kmc::HalfStepArgs a) { kmc::half_step_generic_body<UD, " << peer << ", " << rowt << ">(KMC_FRONT_PACK, a); }\n"
         << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_logpdf(const kmc::LogpdfArgs a) { kmc::logpdf_rows_body<UD>(a); }\n"
         << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_init_ball(const kmc::InitBallArgs a) { kmc::init_ball_body<UD>(a); }\n";
-    if (ud->is_body && with_vec && ud->sep)
+    if (ud->is_body && with_vec && sep_routed(ud))
         src << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_logpdf_sep(const kmc::LogpdfArgs a) { kmc::logpdf_rows_body<UDV>(a); }\n";
     if (staged)
         src << "extern \"C\" __global__ __launch_bounds__(" << kStagedTPB << ") void kmc_user_staged(KMC_FRONT_PARAMS, const kmc::HalfStepArgs a) { kmc::half_step_staged_body<UD, "
@@ -665,7 +665,7 @@ kmc_status load_user(kmc_user_density* ud, bool with_vec, int L, int K, int iter
     HIP_TRY(hipModuleGetFunction(&uk->init_ball, uk->mod, "kmc_user_init_ball"));
     if (with_vec) HIP_TRY(hipModuleGetFunction(&uk->vec, uk->mod, "kmc_user_vec"));
     uk->logpdf_sep = nullptr;
-    if (with_vec && ud->is_body && ud->sep) HIP_TRY(hipModuleGetFunction(&uk->logpdf_sep, uk->mod, "kmc_user_logpdf_sep"));
+    if (with_vec && ud->is_body && sep_routed(ud)) HIP_TRY(hipModuleGetFunction(&uk->logpdf_sep, uk->mod, "kmc_user_logpdf_sep"));
     if (!with_vec && staged_possible(ud, f32, ndim, p2p)) HIP_TRY(hipModuleGetFunction(&uk->staged, uk->mod, "kmc_user_staged"));
     if (resident_K != 0 && island_S == 0) HIP_TRY(hipModuleGetFunction(&uk->resident, uk->mod, "kmc_user_resident"));
     if (resident_K > 0 && island_S > 0) HIP_TRY(hipModuleGetFunction(&uk->island, uk->mod, "kmc_user_island"));

@@ -158,8 +158,25 @@ namespace {
 // sampler's ndim (normal / half-normal / uniform entries on several scales, so that densities on the line, the half-line and the
 // unit box all see admissible points), both through the sequential log-pdf kernels of the module just loaded.  They must agree on
 // every row (both non-finite alike, or within 1e-9 relative) and at least 8 rows must carry a finite value; otherwise the density's
-// `sep` is cleared -- the body then runs as written, evaluated per walker -- and describe() says why.  Once per density.
+// density loses its routing.  Once per (ndim, parameter values) of a density -- what agrees at one row length and one parameter set says nothing
+// about another: a case where the forms DISAGREE refutes the recogniser (`sep` cleared for every later sampler, describe() says why);
+// a case where too few rows are finite shows nothing: THIS sampler runs the body as written (kmc_sampler::sep_off), the density keeps its routing.
 // KMC_DEBUG=sum-form-check=fail / =blind force the two negative outcomes (tests).
+uint64_t sum_form_case_digest(const kmc_sampler* s)
+{
+    uint64_t h = 0xcbf29ce484222325ull;
+    const unsigned char* b = reinterpret_cast<const unsigned char*>(s->dp.p);
+    for (size_t i = 0; i < sizeof(s->dp.p); ++i) { h ^= b[i]; h *= 0x100000001b3ull; }
+    return h;
+}
+// 0: not checked yet for this sampler's (ndim, parameters); 1: agreed; 3: blind
+int sum_form_case(kmc_sampler* s)
+{
+    kmc_user_density* ud = s->user;
+    std::lock_guard<std::mutex> lock(ud->mu);
+    auto it = ud->sep_case.find({s->cfg.ndim, sum_form_case_digest(s)});
+    return it == ud->sep_case.end() ? 0 : it->second;
+}
 kmc_status check_sum_form(kmc_sampler* s)
 {
     kmc_user_density* ud = s->user;
@@ -223,16 +240,21 @@ kmc_status check_sum_form(kmc_sampler* s)
         if (forced == "blind") { differ = 0; informative = 0; }
     }
     std::lock_guard<std::mutex> lock(ud->mu);
-    if (differ == 0 && informative >= 8) { ud->sep_verdict = 1; return KMC_OK; }
+    const std::pair<int64_t, uint64_t> key{s->cfg.ndim, sum_form_case_digest(s)};
+    if (differ == 0 && informative >= 8) { ud->sep_case[key] = 1; return KMC_OK; }
     char why[256];
-    if (differ)
+    if (differ) {
         std::snprintf(why, sizeof(why), "its per-element form disagrees with the body on %d of %d test rows (row %d: body %.17g, per-element form %.17g)",
                       differ, kRows, first, out[first], out[kRows + first]);
-    else
-        std::snprintf(why, sizeof(why), "only %d of %d test rows had a finite log-density: its per-element form could not be checked", informative, kRows);
-    ud->sep_verdict = 2;
-    ud->sep_note = why;
-    ud->sep = false;
+        ud->sep_note = why;
+        ud->sep = false;                         // refuted: no later sampler routes this body
+    } else {
+        std::snprintf(why, sizeof(why), "only %d of %d test rows had a finite log-density at ndim %lld with these parameters: its per-element form could not be checked",
+                      informative, kRows, (long long)s->cfg.ndim);
+        ud->sep_case[key] = 3;                   // nothing shown HERE: this sampler runs the body as written; other cases are checked on their own
+        s->sep_off = true;
+        s->sep_off_note = why;
+    }
     if (differ)
         std::fprintf(stderr, "kissmcmc_hip: a function body was recognised as a sum over elements, but %s -- it is evaluated per walker, as written "
                              "(please report the body; KMC_DEBUG=no-body-routing skips the attempt)\n", why);
@@ -255,7 +277,7 @@ int generation_wanted(const kmc_sampler* s)
         (c.flags & (KMC_P2P | KMC_NO_GRAPH | KMC_ISLANDS)) || std::getenv("KMC_PLAN") != nullptr)      // (KMC_PLAN: a geometry of the two-launch kernels was asked for)
         return 0;
     // lane-striped forms need a lane-striped density (menu, term / pair, a body recognised as a sum) and the vector kernels' plan
-    const bool striped = s->plan.vec && !(s->user && s->user->is_body && !s->user->sep);
+    const bool striped = s->plan.vec && !(s->user && s->user->is_body && !(s->user->sep && !s->sep_off));
     // ndim <= 8: one walker per lane -- or, from 5 dimensions on, the row over a quad (generation_group<4, 1>: the quad shares the draws' four
     // logarithms; measured 1.65 against 1.95 us per half-step at 4 096 x 8, 1.65 against 1.76 at 4 096 x 6, behind at 16 384 x 6)
     int kind = c.ndim <= 8 ? 1 : 2;
@@ -316,7 +338,7 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         if (lane2) rlds = ((size_t)cfg->nwalkers * (size_t)((cfg->ndim | 1) + 1)) * sizeof(double);
         if ((!s->f32 || s->user->is_body || expr_lane) && (cfg->nwalkers <= ((s->user->is_body || expr_lane) ? 1024 : 256) || lane2) && cfg->ndim <= 32 && s->cfg.shard_count == 1 && !(s->user->is_body && cfg->deal_count > 0) &&
             !(cfg->flags & (KMC_P2P | KMC_NO_GRAPH | KMC_ISLANDS)) &&
-            rlds <= 156 * 1024 && std::getenv("KMC_NO_RESIDENT") == nullptr)    // (hipModuleLaunchKernel takes dynamic LDS beyond 64 KiB as it is)
+            rlds <= 156 * 1024 && !debug_opt("no-resident"))    // (hipModuleLaunchKernel takes dynamic LDS beyond 64 KiB as it is)
             rK = rK0;
         int iS = 0;
         if (cfg->flags & KMC_ISLANDS) {
@@ -336,10 +358,16 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         // the first sampler over a body taken for a sum over elements finds out whether it is one (check_sum_form); samplers created
         // meanwhile on other threads wait for the answer instead of planning on a guess
         std::unique_lock<std::mutex> first_use;
-        if (s->user->is_body && s->user->sep && s->user->sep_verdict.load() == 0) {
+        if (s->user->is_body && s->user->sep && sum_form_case(s) == 0) {
             first_use = std::unique_lock<std::mutex>(s->user->check_mu);
             s->plan = make_plan(s->cfg, s->h_loc);
         }
+        if (s->user->is_body && s->user->sep && sum_form_case(s) == 3) {       // (an earlier sampler of this very case found nothing to check the form against)
+            s->sep_off = true;
+            s->sep_off_note = "no test row had a finite log-density at this ndim with these parameters: its per-element form could not be checked";
+        }
+        SepOff sep_off_scope(s->sep_off);        // (for make_plan / compile_user / load_user below, which see the density, not the sampler; the rest of the set-up reads s->sep_off)
+        if (s->sep_off) s->plan = make_plan(s->cfg, s->h_loc);
         auto load = [&]() {
             set_offline_compiler_hint(s->h_loc >= 8192 && rK == 0 && iS == 0);
             const kmc_status lst = load_user(s->user, s->plan.vec, s->plan.L, s->plan.K, s->plan.ITER, s->plan.ragged, &s->uk, rcode, 4 * rK != cfg->ndim, iS, s->f32,
@@ -349,9 +377,10 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         };
         st = load();
         // a body taken for a sum over elements: its generated form against the body itself, once, before anything runs it
-        if (st == KMC_OK && s->uk.logpdf_sep && s->user->sep_verdict.load() != 1) {
+        if (st == KMC_OK && s->uk.logpdf_sep && sum_form_case(s) != 1) {
             st = check_sum_form(s);
-            if (st == KMC_OK && !s->user->sep) {          // not shown equal: plan and kernels for the body as written
+            if (st == KMC_OK && (!s->user->sep || s->sep_off)) {          // not shown equal: plan and kernels for the body as written
+                g_sep_off = g_sep_off || s->sep_off;                      // (restored by sep_off_scope at the end of this block)
                 s->uk = UserKernels{};
                 s->plan = make_plan(s->cfg, s->h_loc);
                 st = load();
@@ -399,7 +428,7 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         if (ea != hipSuccess) { (void)hipGetLastError(); kmc_sampler_destroy(s); return fail(KMC_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(ea)); }
     }
     if (!s->islands && cfg->density != KMC_USER_DENSITY && !s->host_eval && cfg->nwalkers <= 2048 && cfg->ndim <= 32 &&
-        s->cfg.shard_count == 1 && !(cfg->flags & (KMC_P2P | KMC_NO_GRAPH)) && std::getenv("KMC_NO_RESIDENT") == nullptr) {
+        s->cfg.shard_count == 1 && !(cfg->flags & (KMC_P2P | KMC_NO_GRAPH)) && !debug_opt("no-resident")) {
         const int64_t chunks = s->ld / 2;
         int K = 1;
         while (2 * K < chunks) K *= 2;
@@ -460,7 +489,7 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
     }
     // vec kernels: vec_tpb(L) threads per workgroup; the generic kernel keeps 256
     const bool staged = s->user && s->uk.staged != nullptr;         // a body density's staged kernel: two waves per workgroup
-    s->vec_lds = (s->user && s->user->is_body && !s->user->sep && s->plan.vec) ? (unsigned)body_vec_lds_bytes(s->plan.L, s->plan.K, s->plan.ITER) : 0u;
+    s->vec_lds = (s->user && s->user->is_body && !(s->user->sep && !s->sep_off) && s->plan.vec) ? (unsigned)body_vec_lds_bytes(s->plan.L, s->plan.K, s->plan.ITER) : 0u;
     const int tpb = s->plan.vec ? vec_tpb(s->plan.L) : (staged ? kStagedTPB : 256);
     s->tpb = tpb;
     s->grid = (int)((waves * 64 + tpb - 1) / tpb);
@@ -831,7 +860,7 @@ KMC_EXPORT kmc_status kmc_sampler_describe(const kmc_sampler* s, char* buf, int6
                       (long long)s->uchunk, s->feed_wait_ns / 1e3 / s->feed_replays, s->feed_update_ns / 1e3 / s->feed_replays, s->feed_launch_ns / 1e3 / s->feed_replays, (long long)s->feed_replays);
         o << b;
     }
-    if (s->budget_fallback) o << "; updated-graph budget of the process spent (KMC_UPDATED_BUDGET_MB): fell back to " << (s->launch_mode == 2 ? "eager launches" : "the table graph");
+    if (s->budget_fallback) o << "; updated-graph budget of the process spent (kmc_set_updated_budget_mb): fell back to " << (s->launch_mode == 2 ? "eager launches" : "the table graph");
     if (s->lazy) o << "; lazy pull into local copies (KMC_P2P_LAZY)";
     else if (s->push) o << "; accepted rows pushed into the peers' local copies (KMC_P2P_PUSH)";
     if (s->f32) o << "; rows kept in float (KMC_F32), arithmetic in double";
@@ -843,8 +872,11 @@ KMC_EXPORT kmc_status kmc_sampler_describe(const kmc_sampler* s, char* buf, int6
         o << (s->fused_L == 0 ? " (function body, evaluated as written: one walker per lane)"
                               : " (function body recognised as a sum over elements and checked against the body on test rows: lane-striped)");
     else if (s->user && s->user->is_body && s->plan.vec && !s->resident && !s->islands)
-        o << (s->user->sep ? " (function body recognised as a sum over elements and checked against the body on test rows: lane-striped)"
-                           : " (function body: rows lane-striped, the body evaluated per walker on the whole proposal" + (s->user->sep_note.empty() ? std::string() : "; taken for a sum over elements, but " + s->user->sep_note) + ")");
+    {
+        const std::string& why_not = s->sep_off ? s->sep_off_note : s->user->sep_note;
+        o << ((s->user->sep && !s->sep_off) ? " (function body recognised as a sum over elements and checked against the body on test rows: lane-striped)"
+                                            : " (function body: rows lane-striped, the body evaluated per walker on the whole proposal" + (why_not.empty() ? std::string() : "; taken for a sum over elements, but " + why_not) + ")");
+    }
     if (s->nblob > 0) o << " with a blob of " << s->nblob << " doubles per walker" << (s->d_chain_blob ? " (stored with every sample)" : "");
     if (s->p2p) o << "; P2P shard " << s->cfg.shard_rank << "/" << s->cfg.shard_count << (s->connected ? "" : " (not connected)");
     else if (s->cfg.shard_count > 1 || s->comm)

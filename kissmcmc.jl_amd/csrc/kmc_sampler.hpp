@@ -144,6 +144,8 @@ struct kmc_sampler {
     kmc::GenerationFn generation_kernel = nullptr;
     double* d_pos2 = nullptr;
     double* d_logp2 = nullptr;
+    bool sep_off = false;              // a body density recognised as a sum over elements whose check was blind at THIS sampler's ndim / parameters: run as written
+    std::string sep_off_note;
     bool isum_carry = false;           // a sampler that left this mode after it had run (unfuse): d_isum / d_isumsq hold moments credited so far
     uint32_t* d_glast = nullptr;       // lane-striped form: 1 + the generation of every walker's last accepted move (GenerationArgs::glast)
     int fused_cur = 0;                 // which pair holds the state at the tail of the stream (0 between kmc_sampler_run calls)
@@ -229,6 +231,6 @@ kmc_status check_p2p_err(kmc_sampler* s);                // a peer wait that tim
 
 // kmc_diag.hip
 void check_guards(kmc_sampler* s);                       // KMC_DEBUG=poison: abort when a guard band was overwritten
-void reinstall_abort_backtrace();                        // KMC_ABORT_BACKTRACE: (re)install the SIGABRT handler
+void reinstall_abort_backtrace();                        // KMC_DEBUG=abort-backtrace: (re)install the SIGABRT handler
 
 }  // namespace kmc_host

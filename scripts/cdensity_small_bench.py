@@ -1,5 +1,5 @@
 """A user-written C++ density (CDensity) on the reference's own problem sizes: resident mode (one workgroup, one walker per thread,
-many generations per launch) against the multi-launch kernels (KMC_NO_RESIDENT=1).  python scripts/cdensity_small_bench.py"""
+many generations per launch) against the multi-launch kernels (KMC_DEBUG=no-resident).  python scripts/cdensity_small_bench.py"""
 import os
 import subprocess
 import sys
@@ -51,7 +51,7 @@ elif len(sys.argv) > 1 and sys.argv[1] == "menu":
                 out.append(s.last_run_ms() * 1e3 / 8192)
         print(f"{label:22s}: menu density {out[0]:6.3f} us per half-step, CDensity {out[1]:6.3f}   [KMC_DEBUG={os.environ.get('KMC_DEBUG', '')}]")
 else:
-    for env in ({}, {"KMC_NO_RESIDENT": "1"}):
+    for env in ({}, {"KMC_DEBUG": "no-resident"}):
         print("==", env or "default")
         sys.stdout.flush()
         subprocess.run([sys.executable, os.path.abspath(__file__), "worker"], env=dict(os.environ, **env))

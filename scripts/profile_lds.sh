@@ -1,4 +1,8 @@
 #!/bin/bash
+# NOTE: under rocprofv3 the library never starts its child compiler (kmc_rtc.hip: under_a_profiler -- a hipcc started with the profiler's preload in its
+# environment is the launcher-hop that takes this pool's machines down); runtime-compiled kernels are then built by in-process hiprtc (cached on disk under their
+# own key: run the program once unprofiled with KMC_DEBUG=rtc=hiprtc to warm that cache).  hiprtc's code for ensembles of >= 16 384 walkers is 8-20 % slower than
+# what an unprofiled run uses: these passes answer counter questions, not timing ones.
 # LDS counters of the kernels that use LDS (GPU box): bash scripts/profile_lds.sh
 #   body    a general function body at C2: the wave's proposals go through a per-wave LDS tile, each walker's lane reads its row back
 #   c1      the resident kernel (README size: the whole ensemble lives in one workgroup's LDS for the run)

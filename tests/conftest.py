@@ -61,6 +61,8 @@ def kmc_debug(monkeypatch):
                 self.opts[k] = v if v else None
 
         def _write(self):
+            if "no-resident" in os.environ.get("KMC_DEBUG", "").split(","):       # (set by kmcenv.no_resident in the same test: keep it)
+                self.opts.setdefault("no-resident", None)
             if self.opts:
                 monkeypatch.setenv("KMC_DEBUG", ",".join(k if v is None else f"{k}={v}" for k, v in self.opts.items()))
             else:

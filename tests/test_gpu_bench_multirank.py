@@ -23,8 +23,7 @@ def bench_env(test_opts, extra_env=None):
 
 
 def run_bench(extra_env, *args, **test_opts):
-    env = bench_env({"backend": "gloo", "walkers": 4096, **{k.replace("_", "-"): v for k, v in test_opts.items()}},
-                    {"KMC_BENCH_TIMEOUT": "600", "KMC_BENCH_RUNG_TIMEOUT": "240", **extra_env})
+    env = bench_env({"backend": "gloo", "walkers": 4096, "timeout": 600, "rung-timeout": 240, **{k.replace("_", "-"): v for k, v in test_opts.items()}}, extra_env)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", *args],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-4000:]
@@ -74,7 +73,7 @@ def test_bench_two_ranks_allgather_ladder():
 def test_bench_two_ranks_under_torch_distributed_run():
     """The driver's own form: python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2 -- bench.py is then ONE rank
     of the job and must not spawn anything itself."""
-    env = bench_env({"backend": "gloo", "walkers": 4096, "no-allgather-extra": True}, {"KMC_BENCH_RUNG_TIMEOUT": "240"})
+    env = bench_env({"backend": "gloo", "walkers": 4096, "no-allgather-extra": True, "rung-timeout": 240})
     from portpick import rendezvous_port
     port = rendezvous_port()
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
@@ -106,7 +105,7 @@ def test_bench_two_ranks_under_torch_distributed_run():
 def test_bench_ladder_records_the_failed_rung():
     """A rung that fails on one rank is on record as not ok -- on every rank, rank 0's list is printed -- and `value_from` names the
     rung that supplied `value` instead."""
-    out, err = run_bench({"KMC_BENCH_RUNG_TIMEOUT": "120"}, fault="p2p_selfcheck:0")
+    out, err = run_bench({}, fault="p2p_selfcheck:0", rung_timeout=120)
     common_checks(out)
     failed = [r_ for r_ in out["ladder"] if not r_["ok"]]
     assert len(failed) >= 1 and failed[0]["rung"].startswith("p2p-check:")
@@ -147,7 +146,7 @@ def test_bench_sharded_ladder_over_real_rccl_with_one_rank():
     the native exchange -- ncclCommInitRank, the all-gathers captured into the hipGraph chunks -- inside bench.py's own ladder."""
     from portpick import rendezvous_port
     port = rendezvous_port()
-    env = bench_env({"force-sharded": True, "walkers": 8192}, {"KMC_BENCH_RUNG_TIMEOUT": "240", "MASTER_PORT": str(port)})
+    env = bench_env({"force-sharded": True, "walkers": 8192, "rung-timeout": 240}, {"MASTER_PORT": str(port)})
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-4000:]
@@ -167,7 +166,7 @@ def test_bench_ladder_falls_through_together_when_one_rank_fails(point):
     """KMC_BENCH_TEST=fault=point:rank: ONE rank fails at a point of the peer-to-peer rung (set-up, self-check, after the timed run).  Every rank
     must then take the next rung together -- the all-gather exchange -- and the line must still be a verified result; nobody may be
     left inside a collective (the job would end in the watchdog's status 3)."""
-    out, err = run_bench({"KMC_BENCH_RUNG_TIMEOUT": "120"}, fault=point)
+    out, err = run_bench({}, fault=point, rung_timeout=120)
     common_checks(out)
     assert "injected fault" in err and "falling back to the RCCL all-gather exchange" in err
     assert "all-gather of the updated half per half-step" in out["config"]["parallelism"]
@@ -178,7 +177,7 @@ def test_bench_ladder_falls_through_together_when_one_rank_fails(point):
 def test_bench_extras_fail_together_without_taking_the_result_down(point, key):
     """One rank failing in the local set-up of an EXTRA (dealt mode, all-gather record): every rank skips that extra together;
     `value` -- measured before -- stands, the extra carries an error instead of numbers, the job ends with status 0."""
-    r_env = bench_env({"backend": "gloo", "walkers": 4096, "fault": point}, {"KMC_BENCH_TIMEOUT": "600", "KMC_BENCH_RUNG_TIMEOUT": "120"})
+    r_env = bench_env({"backend": "gloo", "walkers": 4096, "fault": point, "timeout": 600, "rung-timeout": 120})
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"],
                        env=r_env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-4000:]
@@ -194,8 +193,7 @@ def test_bench_an_extra_that_hangs_does_not_take_the_result_down():
     """One rank never comes back from the dealt-mode extra (KMC_BENCH_TEST=fault=dealt_run_hang:1): the peers block in its collectives, the
     rung's watchdog expires on every rank -- and since `value` was measured before, rank 0 prints the line as it stands (the extra
     marked as timed out) and the job ends with status 0 instead of losing the measurement."""
-    env = bench_env({"backend": "gloo", "walkers": 4096, "fault": "dealt_run_hang:1", "no-allgather-extra": True},
-                    {"KMC_BENCH_TIMEOUT": "600", "KMC_BENCH_RUNG_TIMEOUT": "20"})
+    env = bench_env({"backend": "gloo", "walkers": 4096, "fault": "dealt_run_hang:1", "no-allgather-extra": True, "timeout": 600, "rung-timeout": 20})
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-4000:]

@@ -7,6 +7,8 @@ import ctypes as C
 import numpy as np
 import pytest
 
+import kmcenv
+
 from test_gpu_parity import _compare, _densities, _theta0
 
 pytestmark = pytest.mark.gpu
@@ -56,11 +58,11 @@ def test_f32_rows_match_the_oracle(kmc, oracle, name, nw, nd, G, nburn, nthin, m
         # short rows of a small ensemble run out of one workgroup's LDS (float rows widened on the way in, proposals rounded
         # before their density, as everywhere); the multi-launch kernels on the same job must agree too
         assert "resident mode" in got["how"] and "one walker per thread" in got["how"], got["how"]
-        monkeypatch.setenv("KMC_NO_RESIDENT", "1")
+        kmcenv.no_resident(monkeypatch)
         ref2, got2, _ = _run_f32(kmc, oracle, name, nw, nd, G, nburn, nthin, seed=77 + nd)
         assert "multi-launch" in got2["how"], got2["how"]
         _compare(ref2, got2)
-        monkeypatch.delenv("KMC_NO_RESIDENT")
+        kmcenv.resident_again(monkeypatch)
     else:
         assert "resident" not in got["how"], got["how"]
     # everything stored is representable in single, and the run differs from the double one
@@ -181,7 +183,7 @@ def test_f32_body_density_runs_resident(kmc, oracle, monkeypatch):
 
     res = run()
     assert "resident mode" in res["how"] and "float" in res["how"], res["how"]
-    monkeypatch.setenv("KMC_NO_RESIDENT", "1")
+    kmcenv.no_resident(monkeypatch)
     ml = run()
     assert "multi-launch" in ml["how"], ml["how"]
     for k in ("pos", "nacc", "chain"):

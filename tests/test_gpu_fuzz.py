@@ -6,6 +6,8 @@ log-pdfs to 1e-12, moments to 1e-11."""
 import numpy as np
 import pytest
 
+import kmcenv
+
 pytestmark = pytest.mark.gpu
 
 import os
@@ -61,7 +63,7 @@ def test_random_configuration_equals_the_oracle(kmc, oracle, monkeypatch, trial)
     if launch:
         monkeypatch.setenv("KMC_LAUNCH", launch)
     if not resident:
-        monkeypatch.setenv("KMC_NO_RESIDENT", "1")
+        kmcenv.no_resident(monkeypatch)
     seed = int(rng.integers(1, 2 ** 40))
     label = f"trial {trial}: {name} {nw}x{nd} G={G} nburn={nburn} nthin={nthin} a={a} launch={launch or 'auto'} resident={resident}"
     ref = oracle.emcee(oracle.make_config(did, params, nw, nd, G, nburn, nthin, a, seed), th)
@@ -229,7 +231,7 @@ def test_random_runtime_compiled_density_equals_the_oracle(kmc, oracle, monkeypa
     if launch:
         monkeypatch.setenv("KMC_LAUNCH", launch)
     if rng.random() < 0.5:
-        monkeypatch.setenv("KMC_NO_RESIDENT", "1")
+        kmcenv.no_resident(monkeypatch)
     if two_sums and name == "gauss":
         did, params = oracle.GAUSSIAN_ISO, [0.3, 1.5]
         pdf = kmc.CDensity("double s = 0.0, u = 0.0; for (int i = 0; i < n; ++i) { double t = (x[i] - p[0]) * p[1]; s += t * t; u += x[i]; } return -0.5 * s + 0.0 * u;", params=[0.3, 1.0 / 1.5])

@@ -9,6 +9,8 @@ Tolerances (fp64):
 import numpy as np
 import pytest
 
+import kmcenv
+
 pytestmark = pytest.mark.gpu
 
 LOGP_RTOL = 1e-12
@@ -190,7 +192,7 @@ def test_resident_small_ensemble_kernel_is_the_same_sampler(kmc, oracle, name, n
         kmc_debug.unset("resident")
         with kmc.Sampler(_densities(kmc, oracle)[name][0], nw, nd, 10) as s:
             assert "one walker per thread" in s.describe()
-    monkeypatch.setenv("KMC_NO_RESIDENT", "1")
+    kmcenv.no_resident(monkeypatch)
     ref2, multi = _run_both(kmc, oracle, name, nw, nd, 200, 60, 2, seed=321)
     _compare(ref2, multi)
     np.testing.assert_array_equal(res["chain"], multi["chain"])
@@ -233,7 +235,7 @@ def test_resident_two_walkers_per_thread(kmc, oracle, name, nw, nd, G, nburn, nt
     with kmc.Sampler(_densities(kmc, oracle)[name][0], nw, nd, 10) as s:
         fits = nw * ((nd | 1) + 1) * 8 <= 156 * 1024
         assert ("two walkers per thread" in s.describe()) == fits, s.describe()
-    monkeypatch.setenv("KMC_NO_RESIDENT", "1")
+    kmcenv.no_resident(monkeypatch)
     ref2, multi = _run_both(kmc, oracle, name, nw, nd, G, nburn, nthin, seed=99)
     np.testing.assert_array_equal(res["chain"], multi["chain"])
     np.testing.assert_array_equal(res["naccept"], multi["naccept"])

@@ -8,6 +8,8 @@ import os
 import numpy as np
 import pytest
 
+import kmcenv
+
 pytestmark = pytest.mark.gpu
 
 
@@ -51,11 +53,11 @@ def test_streamed_chain_equals_oracle_over_three_ring_laps(kmc, oracle, monkeypa
 def test_streamed_chain_variants(kmc, oracle, monkeypatch, case, by_walker, resident, kmc_debug):
     """by-walker: KMC_STREAM_CHAIN | KMC_CHAIN_BY_WALKER -- completed blocks are written by a kernel of the copy stream
     into host arrays laid out [walker][nsamples][ndim] (the reference's thetas[w][k]).  Ensembles of up to 1024 walkers run in
-    resident mode (launches cut to less than a block of the ring, ring positions carried by the kernel); KMC_NO_RESIDENT keeps
+    resident mode (launches cut to less than a block of the ring, ring positions carried by the kernel); KMC_DEBUG=no-resident keeps
     the same jobs on the multi-launch kernels."""
     kmc_debug.set("chain-block", "1")
     if not resident:
-        monkeypatch.setenv("KMC_NO_RESIDENT", "1")
+        kmcenv.no_resident(monkeypatch)
     pdf, did, params, nw, nd, G, nburn, nthin, scale = kmc.GaussianIso(), oracle.GAUSSIAN_ISO, [0.0, 1.0], 1024, 8, 500, 37, 1, 1.0
     kw = dict(store_chain=True, store_logp=True)
     if case == "thin3_odd_ndim":

@@ -5,6 +5,8 @@ log-pdfs to 1e-12 (different but equivalent arithmetic)."""
 import numpy as np
 import pytest
 
+import kmcenv
+
 pytestmark = pytest.mark.gpu
 
 GAUSS = ("-0.5*x*x", None, [])
@@ -115,7 +117,7 @@ def test_body_density_equals_the_oracle(kmc, oracle, case, kernel, monkeypatch, 
         if case.endswith("_generic"):
             pytest.skip("runs one walker per lane anyway")
         kmc_debug.set("no-body-vec")
-    monkeypatch.setenv("KMC_NO_RESIDENT", "1")           # the multi-launch kernels are the subject here (small ensembles with ndim <= 32
+    kmcenv.no_resident(monkeypatch)           # the multi-launch kernels are the subject here (small ensembles with ndim <= 32
                                                          #  would run resident: test_body_density_runs_resident_on_small_ensembles)
     kmc_debug.set("fused", 0)                            #  ... and short rows one launch per generation: tests/test_gpu_generation.py
     if case.endswith("_generic"):
@@ -148,7 +150,7 @@ def test_separable_body_runs_lane_striped_and_equals_the_oracle(kmc, oracle, cas
     x[i + 1]) is recognised by kmc_user_density_create_body and runs in the lane-striped vector kernels of the menu densities: same
     chains and counters as the oracle, bit for bit; log-pdfs to rounding (lane-order sum).  The user's closure pdf(theta), src/samplers.jl:257."""
     name, shape = case.split("_")[:2]
-    monkeypatch.setenv("KMC_NO_RESIDENT", "1")
+    kmcenv.no_resident(monkeypatch)
     kmc_debug.set("fused", 0)                            # (short rows would run one launch per generation, the body as written: tests/test_gpu_generation.py)
     nw, nd = (int(v) for v in shape.split("x"))
     body, did, params, cparams, scale = {"gauss": (C_GAUSS, oracle.GAUSSIAN_ISO, [0.3, 1.5], [0.3, 1.0 / 1.5], 1.0),
@@ -170,7 +172,7 @@ def test_offline_compiled_kernels_equal_the_oracle(kmc, oracle, form, monkeypatc
     """The same kernels built by hipcc as a child process (what the samplers choose by themselves for >= 16 384 walkers; forced here
     with KMC_DEBUG=rtc=hipcc) instead of hiprtc: chains, counters and moments equal to the oracle as ever."""
     kmc_debug.set("rtc", "hipcc")
-    monkeypatch.setenv("KMC_NO_RESIDENT", "1")
+    kmcenv.no_resident(monkeypatch)
     nw, nd, G, nburn, seed = 1536, 32, 90, 25, 31
     th = np.random.default_rng(7).standard_normal((nw, nd))
     if form == "expr":
@@ -207,7 +209,7 @@ def test_bodies_feeding_several_sums_run_lane_striped(kmc, case, monkeypatch, km
     body = ("double s = 0.0, t = 0.0; for (int i = 0; i < n; ++i) { s += x[i] * x[i]; t += x[i]; } return -0.5 * (s + p[0] * t * t);" if name == "two-sums" else
             "double s = 0.0; double t = 0.0; double u = 0; for (int i = 0; i + 1 < n; ++i) { double d = x[i+1]-x[i]; s += d*d; t += x[i]*x[i]; u += x[i+1]*x[i]; } "
             "return -(p[0]*s + 0.5*t + 0.01*u);")
-    monkeypatch.setenv("KMC_NO_RESIDENT", "1")
+    kmcenv.no_resident(monkeypatch)
     kmc_debug.set("fused", 0)                            # (3000 x 6 would run one launch per generation, the body as written)
     th = np.random.default_rng(4).standard_normal((nw, nd))
     G, nburn, seed = 80, 20, 17
@@ -235,7 +237,7 @@ def test_sum_form_is_checked_against_the_body_before_it_runs(kmc, outcome, monke
     on 256 test rows (kmc_sampler.hip: check_sum_form): agreement -> lane-striped; a difference (forced here: sum-form-check=fail) or
     no test row with a finite value (forced, and for real: a density supported on [100, 101] only) -> the density is evaluated per walker,
     as written, describe() says why, and the run equals the run with the recogniser switched off."""
-    monkeypatch.setenv("KMC_NO_RESIDENT", "1")
+    kmcenv.no_resident(monkeypatch)
     kmc_debug.set("fused", 0)                            # (the lane-striped route of the two-launch kernels is the subject)
     nw, nd, G, nburn, seed = 256, 8, 60, 10, 5
     if outcome == "blind":
@@ -254,7 +256,9 @@ def test_sum_form_is_checked_against_the_body_before_it_runs(kmc, outcome, monke
     if outcome == "agree":
         assert "recognised as a sum over elements and checked against the body" in how and pdf.separable
         return
-    assert not pdf.separable                               # ... and the check took it back
+    # ... and the check took it back: for good where the two forms DISAGREE (the recogniser misread the body), for this sampler's (ndim, parameters)
+    # only where no test row was finite (nothing shown there; another row length or parameter set is checked on its own -- ADVICE r04)
+    assert pdf.separable == (outcome != "fail")
     assert "evaluated per walker" in how and "taken for a sum over elements, but" in how
     assert ("disagrees with the body" in how and "please report" in err) if outcome == "fail" else ("could not be checked" in how and "please report" not in err)
     a = _run(kmc, pdf, th, G, nburn, seed)
@@ -266,12 +270,37 @@ def test_sum_form_is_checked_against_the_body_before_it_runs(kmc, outcome, monke
     assert a["nacc"].sum() > 0
 
 
+def test_sum_form_verdict_belongs_to_one_ndim_and_parameter_set(kmc, oracle, monkeypatch, kmc_debug):
+    """A density whose support moves with a parameter: at p = 100.5 no test row is finite -- that sampler runs the body as written; at p = 0 (same
+    density object created anew, and the SAME object with other parameters cannot exist: parameters belong to the density) and at another ndim the check
+    sees finite rows and the routing stands.  A blind check no longer switches the routing off for every later sampler of the density."""
+    kmcenv.no_resident(monkeypatch)
+    kmc_debug.set("fused", 0)
+    body = "double s = 0; for (int i = 0; i < n; ++i) { const double t = x[i] - p[0]; s += (t < -3.0 || t > 3.0) ? -INFINITY : -0.5 * t * t; } return s;"
+    blind = kmc.CDensity(body, params=[100.5])
+    with kmc.Sampler(blind, 256, 8, 20, 0, 1, 2.0, 1) as s:
+        assert "could not be checked" in s.describe() and "evaluated per walker" in s.describe()
+    assert blind.separable                                  # (not refuted: only unchecked there)
+    with kmc.Sampler(blind, 256, 8, 20, 0, 1, 2.0, 1) as s:        # the same case again: decided already, the same way
+        assert "could not be checked" in s.describe()
+    seen = kmc.CDensity(body, params=[0.0])
+    for nd in (8, 16):
+        with kmc.Sampler(seen, 256, nd, 20, 0, 1, 2.0, 1) as s:
+            assert "recognised as a sum over elements and checked against the body" in s.describe(), s.describe()
+    # ... and the unrouted sampler is the oracle's run of the same truncated Gaussian (here: never leaves the support)
+    th = 100.5 + 0.1 * np.random.default_rng(3).standard_normal((256, 8))
+    a = _run(kmc, blind, th, 60, 10, 5)
+    ref = oracle.emcee(oracle.make_config(oracle.GAUSSIAN_ISO, [100.5, 1.0], 256, 8, 60, 10, 1, 2.0, 5), th)
+    np.testing.assert_array_equal(a["pos"], ref["final_pos"])
+    np.testing.assert_array_equal(a["nacc"], ref["naccept"])
+
+
 def test_body_density_with_real_coupling_samples_its_target(kmc, monkeypatch, kmc_debug):
     """A density no term / pair form can express -- a correlated Gaussian with a dense precision matrix built in the body:
     x' P x with P = (1 + rho) I - rho/n 11' ... here: -0.5 (sum x_i^2 + c (sum x_i)^2): variance of the mean direction
     1 / (1 + c n), of every orthogonal direction 1."""
     n, c = 6, 0.5
-    monkeypatch.setenv("KMC_NO_RESIDENT", "1")           # (2048 x 6 would run resident, two walkers per thread: the multi-launch kernel is the subject)
+    kmcenv.no_resident(monkeypatch)           # (2048 x 6 would run resident, two walkers per thread: the multi-launch kernel is the subject)
     kmc_debug.set("fused", 0)                            # (... or one launch per generation)
     pdf = kmc.CDensity("double s = 0.0, t = 0.0; for (int i = 0; i < n; ++i) { s += x[i] * x[i]; t += x[i]; } return -0.5 * (s + p[0] * t * t);", params=[c])
     th = np.random.default_rng(1).standard_normal((2048, n))
@@ -317,7 +346,7 @@ ROSEN_BODY = ("double s = 0.0; for (int i = 0; i + 1 < n; ++i) { double d = x[i 
 def test_body_density_runs_resident_on_small_ensembles(kmc, oracle, monkeypatch, nw, nd, G, nburn, nthin, kmc_debug):
     """A CDensity on the reference's own problem sizes: the whole ensemble in one workgroup's LDS, one walker per thread, many
     generations per launch (kmc_islands.hpp: resident_lane_body) -- same draws and element order as the multi-launch kernels:
-    identical to the oracle's run of the menu density AND to the same sampler with KMC_NO_RESIDENT (chain, log-pdfs, counters,
+    identical to the oracle's run of the menu density AND to the same sampler with KMC_DEBUG=no-resident (chain, log-pdfs, counters,
     moments), across run() pieces and a restart."""
     kmc_debug.set("no-body-routing")        # (the comparison below is with the one-walker-per-lane multi-launch kernels: same order, same bits)
     if nd == 1:
@@ -343,7 +372,7 @@ def test_body_density_runs_resident_on_small_ensembles(kmc, oracle, monkeypatch,
     res = run()
     assert "resident mode" in res["how"] and ("two walkers per thread" if nw > 1024 else "one walker per thread") in res["how"], res["how"]
     assert res["launches"] <= 6                                           # three run() pieces (draw table + resident kernel each), not 2 G launches
-    monkeypatch.setenv("KMC_NO_RESIDENT", "1")
+    kmcenv.no_resident(monkeypatch)
     ml = run()
     assert "resident" not in ml["how"]
     for got in (res, ml):
@@ -393,7 +422,7 @@ def test_term_pair_density_runs_two_walkers_per_thread_beyond_1024(kmc, oracle, 
 
     a = run(kmc.ExprDensity("-0.5*x*x"))
     assert "two walkers per thread" in a["how"], a["how"]
-    monkeypatch.setenv("KMC_NO_RESIDENT", "1")
+    kmcenv.no_resident(monkeypatch)
     b = run(kmc.GaussianIso(0.0, 1.0))
     assert "resident" not in b["how"]
     np.testing.assert_array_equal(a["chain"], b["chain"])

@@ -40,7 +40,7 @@ def test_bench_launcher_starts_its_own_ranks_and_relays_failure():
     around it).  Without a GPU both ranks refuse to run; the launcher must come back promptly with a non-zero status and the
     ranks' message -- never hang, never report success without a result line."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    env["KMC_BENCH_TIMEOUT"] = "240"
+    env["KMC_BENCH_TEST"] = "timeout=240"
     try:
         import torch
         if torch.cuda.is_available():
