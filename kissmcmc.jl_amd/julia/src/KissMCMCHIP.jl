@@ -10,6 +10,7 @@
 # needs.  A plain closure as `pdf` still dispatches to KissMCMC's CPU methods; wrap it, `HostLogPdf(f)`, to move the
 # sampler to the GPU.  There is no CPU fallback inside this module.
 #
+# A package (julia/Project.toml, julia/test/runtests.jl: `] dev path/to/kissmcmc.jl_amd/julia`, `] test KissMCMCHIP` on a machine with Julia and an MI355X).
 # NOT EXECUTED in the build environment (no julia binary there).  Every call it makes is mirrored 1:1 by the Python
 # ctypes host (kissmcmc.jl_amd/_lib.py, api.py), which is what the tests drive; struct layouts are checked against the
 # library when the module loads (`__init__`).
@@ -22,7 +23,7 @@ export emcee, make_theta0s, squash_walkers, metropolis, metropolis_chains, Gauss
 
 using LinearAlgebra: inv
 
-const LIB = get(ENV, "KMC_LIB_PATH", joinpath(@__DIR__, "..", "libkissmcmc_hip.so"))
+const LIB = get(ENV, "KMC_LIB_PATH", joinpath(@__DIR__, "..", "..", "libkissmcmc_hip.so"))     # julia/src/ -> the package directory that holds the built library
 
 # ---- C structs: field for field include/kissmcmc_hip.h (kmc_config, kmc_outputs).  Built by keyword, so a new field
 #      of the header needs one line here and no call site changes; `__init__` compares sizeof with the library's.

@@ -263,7 +263,7 @@ def test_julia_shim_structs_mirror_the_header():
     import ctypes as C
     import re
     from kissmcmc_jl_amd import _lib
-    src = open(os.path.join(ROOT, "kissmcmc.jl_amd", "julia", "KissMCMCHIP.jl")).read()
+    src = open(os.path.join(ROOT, "kissmcmc.jl_amd", "julia", "src", "KissMCMCHIP.jl")).read()
     jl_size = {"Int32": 4, "UInt32": 4, "Int64": 8, "UInt64": 8, "Float64": 8, "Ptr{Cvoid}": 8, "Ptr{Float64}": 8, "Ptr{Int64}": 8,
                "NTuple{8,Float64}": 64}
     for jl_name, mirror in (("KmcConfig", _lib.Config), ("KmcOutputs", _lib.Outputs), ("KmcMetropolisConfig", _lib.MetropolisConfig),
@@ -329,7 +329,7 @@ def test_julia_shim_ccalls_match_the_header_prototypes():
                 cur += ch
         return [x.strip() for x in out + [cur] if x.strip()]
 
-    src = open(os.path.join(ROOT, "kissmcmc.jl_amd", "julia", "KissMCMCHIP.jl")).read()
+    src = open(os.path.join(ROOT, "kissmcmc.jl_amd", "julia", "src", "KissMCMCHIP.jl")).read()
     calls = re.findall(r"ccall\(\(:(\w+), LIB\),\s*(\w+),\s*\((.*?)\)\s*(?:,|\))", src, re.S)
     assert len(calls) >= 12
     seen = set()
@@ -344,3 +344,42 @@ def test_julia_shim_ccalls_match_the_header_prototypes():
         assert jkind(ret) == rk or (rk == "cstring" and ret == "Cstring"), f"{name}: return type {ret} vs `{cret}`"
         seen.add(name)
     assert {"kmc_emcee_run", "kmc_metropolis_run", "kmc_user_density_create_body_blob", "kmc_logpdf_blob_eval_host", "kmc_int_acorr"} <= seen
+
+
+def test_julia_package_layout_and_its_test_file_use_only_what_the_module_has():
+    """kissmcmc.jl_amd/julia is a package a maintainer with Julia can `] dev` and `] test`: Project.toml (depends on KissMCMC by its registered
+    uuid), src/KissMCMCHIP.jl, test/runtests.jl -- the reference's emcee test (test/emcee.jl:17-48 over the four cases without blobs of test/runtests.jl:52-79)
+    on device densities, plus the README call.  No julia here: checked statically -- every name the test file calls is exported by the module (or is Base /
+    Test / Statistics), every keyword it passes to `emcee` is one the shim's method takes, the library path of the module points at the built library."""
+    import re
+    jdir = os.path.join(ROOT, "kissmcmc.jl_amd", "julia")
+    proj = open(os.path.join(jdir, "Project.toml")).read()
+    assert 'name = "KissMCMCHIP"' in proj and re.search(r'^uuid = "[0-9a-f-]{36}"', proj, re.M)
+    assert 'KissMCMC = "79d62d8d-4dfd-5781-bc85-ce78e0ac132a"' in proj               # KissMCMC.jl's uuid (the reference's Project.toml:2)
+    assert re.search(r'\[targets\]\s*test = \[[^\]]*"Test"', proj)
+    src = open(os.path.join(jdir, "src", "KissMCMCHIP.jl")).read()
+    test = open(os.path.join(jdir, "test", "runtests.jl")).read()
+    test = re.sub(r"#.*", "", test)                                                   # comments out
+    test = re.sub(r'"(?:[^"\\]|\\.)*"', '""', test)                                  # string literals out (the C body of the CDensity case)
+    exports = set(re.search(r"^export (.*)$", src, re.M).group(1).replace(",", " ").split())
+    assert {"emcee", "make_theta0s", "squash_walkers", "GaussianIso", "LogNormal", "MvNormal2", "Rosenbrock", "Exponential", "CDensity"} <= exports
+    known = {"Test", "Statistics", "KissMCMCHIP", "DeviceCase", "UInt64", "AssertionError", "Base", "String", "Int", "Float64"}
+    called = set(re.findall(r"\b([A-Za-z_]\w*)\(", test))
+    base_fns = {"sqrt", "var", "exp", "length", "mean", "median", "std", "abs", "all", "isapprox", "zeros", "stds"}
+    for name in sorted(called - base_fns - known):
+        assert name in exports, f"test/runtests.jl calls {name}(...), which KissMCMCHIP does not export"
+    # the keywords of every emcee call are keywords of the device method
+    sig = re.search(r"function emcee\(pdf::DeviceLogPdf, theta0s;(.*?)\)\s*\n\s+device_blobs", src, re.S).group(1)
+    takes = set(re.findall(r"(\w+!?)\s*=", sig))
+    for call in re.findall(r"emcee\([^;()]*;([^()]*(?:\([^()]*\)[^()]*)*)\)", test):
+        for kw in re.findall(r"(\w+)\s*=", call):
+            assert kw in takes, f"emcee(...; {kw}=...) in test/runtests.jl: not a keyword of the device method ({sorted(takes)})"
+    # constructors with the arities the test file uses
+    assert "struct LogNormal <: DeviceLogPdf; mu::Float64; sigma::Float64; end" in src and "MvNormal2(mean, cov::AbstractMatrix)" in src
+    assert "struct Rosenbrock <: DeviceLogPdf; a::Float64; b::Float64; scale::Float64; end" in src
+    # src/ sits two levels below the directory that holds the built library
+    assert 'joinpath(@__DIR__, "..", "..", "libkissmcmc_hip.so")' in src
+    assert os.path.exists(os.path.join(jdir, "..", "build.py"))
+    # the test set is the reference's: shapes, acceptance bound, squash, the three moment checks
+    for needle in ("tc.niter ÷ tc.nwalkers ÷ 2", "accept_ratio > 0.1", "squash_walkers(samples...", "length(thetas) == tc.niter ÷ 2", "median(thetas)"):
+        assert needle in test, needle
