@@ -131,15 +131,18 @@ enum {
                                    (reduce_blob! with the default push!, :196, :270); read with kmc_sampler_get_blobs.  The
                                    blob of every walker's CURRENT position (blob0s, :210, :264) is kept regardless. */
     KMC_P2P_FINEGRAINED = 1u << 7, /* with KMC_P2P: keep the rows in fine-grained (coherent, uncached-for-peers) device memory */
-    /* The next three exist only in a library built with -DKMC_P2P_EXPERIMENTAL (kmc_has_p2p_experimental() == 1; the default
-       library answers KMC_ERR_UNSUPPORTED): peers write into plain device memory that the local kernel reads through its own
-       L2, which no test on ONE GPU can validate.  The default exchange under KMC_P2P is the pull of the drawn rows with
-       system-scope loads, ordered by a separate signal kernel. */
-    KMC_P2P_PUSH    = 1u << 9, /* with KMC_P2P: every rank keeps local copies ("shadows") of all the other shards and reads its
-                                  partner rows from them; a rank that accepts a move writes the new row into its shadow on
-                                  every peer as well (posted write-through stores over xGMI).  Only accepted rows cross the
-                                  fabric (C2: 23 %), once per peer, instead of every drawn row once: less per link for few
-                                  ranks, more for many.  Not with KMC_P2P_FINEGRAINED / kmc_sampler_init_ball. */
+    /* The default exchange under KMC_P2P is the pull of the drawn rows with system-scope loads, ordered by a separate signal kernel. */
+    KMC_P2P_PUSH    = 1u << 9, /* with KMC_P2P: every rank keeps local copies of all the other shards and reads its partner rows
+                                  from them -- with system-scope loads, like the pull (never from the reader's L2: peers write
+                                  that memory); a rank that accepts a move writes the new row into its copy on every peer as
+                                  well (write-through stores over xGMI).  Only accepted rows cross the fabric (C2: 23 %), once
+                                  per peer, instead of every drawn row once: less per link while the acceptance is below
+                                  1 / shard_count (2 ranks: half the bytes; 8 ranks: 1.9 x).  Menu densities in the vector
+                                  kernels (anything else keeps the pull: kmc_sampler_describe).  Not with KMC_P2P_FINEGRAINED /
+                                  kmc_sampler_init_ball.  In the default library since round 5. */
+    /* The next two exist only in a library built with -DKMC_P2P_EXPERIMENTAL (kmc_has_p2p_experimental() == 1; the default
+       library answers KMC_ERR_UNSUPPORTED): they read peer-written memory through the local L2, or publish completion from
+       inside the half-step kernel -- which no test on ONE GPU can validate. */
     KMC_P2P_LAZY    = 1u << 10, /* with KMC_P2P: the local copies of KMC_P2P_PUSH, filled on demand.  A rank publishes the
                                    accept bytes of each half-step (one byte per active walker, to every peer, with the progress
                                    flag) instead of any rows; a reader pulls a drawn row from its owner only when its local
@@ -214,7 +217,7 @@ int         kmc_sizeof_config(void);
 int         kmc_sizeof_metropolis_config(void);
 int         kmc_sizeof_outputs(void);
 int         kmc_sizeof_metropolis_outputs(void);
-/* 1 when the library was built with -DKMC_P2P_EXPERIMENTAL (KMC_P2P_PUSH / KMC_P2P_LAZY / KMC_P2P_FOLD_SIGNAL are accepted), else 0. */
+/* 1 when the library was built with -DKMC_P2P_EXPERIMENTAL (KMC_P2P_LAZY / KMC_P2P_FOLD_SIGNAL are accepted), else 0. */
 int         kmc_has_p2p_experimental(void);
 int         kmc_device_count(void);
 /* hipMemGetInfo of a device (a caller deciding between a device-resident chain and KMC_STREAM_CHAIN; reference
@@ -375,8 +378,9 @@ kmc_status  kmc_sampler_set_chain_host(kmc_sampler* s, double* chain_host, doubl
 kmc_status  kmc_sampler_run(kmc_sampler* s, int64_t ngenerations);
 /* Enqueue ONE half-step (src/samplers.jl:248-273) of the current generation over this shard's
  * slice; half = 1 also advances the generation counter.  For walker-sharded drivers that
- * exchange the updated slice between half-steps.  An unsharded sampler whose kmc_sampler_run covers whole generations per
- * launch (resident mode; small states, one launch per generation: kmc_sampler_describe) answers KMC_ERR_UNSUPPORTED unless it
+ * exchange the updated slice between half-steps.  A sampler that runs one launch per generation (small states:
+ * kmc_sampler_describe) goes back to its two-launch kernels at the first such call, in place and for good (same chain, moments
+ * credited so far kept); a resident-mode sampler (whole ensemble in one workgroup's LDS) answers KMC_ERR_UNSUPPORTED unless it
  * was created with KMC_NO_GRAPH, which keeps the half-step kernels. */
 kmc_status  kmc_sampler_half_step(kmc_sampler* s, int half);
 kmc_status  kmc_sampler_sync(kmc_sampler* s);
