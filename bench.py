@@ -9,7 +9,7 @@ torch.distributed.run, one rank per GPU) the ensemble is 65 536 x N walkers, wal
 partner rule and a peer-to-peer exchange over xGMI (KMC_P2P, pull of the drawn partner rows with system-scope loads +
 signal kernel; admitted by a bit-exact self-check, and the timed run itself is verified against the unsharded run;
 the push of accepted rows is the second rung, the faster admitted one supplies `value`;
-KMC_BENCH_EXCHANGE=pull keeps the pull, =all measures the experimental variants too, =allgather -- or any failure -- runs the native RCCL all-gather
+KMC_BENCH_EXCHANGE=pull keeps the pull, =allgather -- or any failure -- runs the native RCCL all-gather
 of the updated half per half-step, enqueued by the library itself) -- weak scaling, config C4 at N = 8.  Extra key `dealt_mode` (N > 1, never `value`):
 the same job as dealt sub-ensembles, one RCCL all_to_all_single per 64 generations instead of an exchange per half-step.
 
@@ -880,19 +880,14 @@ def run_single(job: Job) -> dict:
     return res
 
 
-P2P_VARIANTS = [   # (rung tag, what it is, fold_signal, push, lazy).  Default: the first two -- the exchanges of the default library, both read with system-scope
-    #                    loads, each admitted by its bit-exact self-check, the faster of the admitted ones runs; KMC_BENCH_EXCHANGE=pull: the first only;
-    #                    =all (with the -DKMC_P2P_EXPERIMENTAL library): every one.
-    ("pull", "pull of drawn rows (system-scope loads), signal kernel", False, False, False),
-    ("push", "push of accepted rows into local copies read with system-scope loads, signal kernel", False, True, False),
-    ("pull-fold", "pull of drawn rows (system-scope loads), signal folded into the kernel", True, False, False),
-    ("push-fold", "push of accepted rows into local copies, signal folded into the kernel", True, True, False),
-    ("lazy", "lazy pull into local copies, signal kernel", False, False, True),
-    ("lazy-fold", "lazy pull into local copies, signal folded into the kernel", True, False, True),
+P2P_VARIANTS = [   # (rung tag, what it is, push).  Both read partner rows with system-scope loads; each is admitted by its bit-exact self-check and timed, the
+    #                    faster admitted one runs.  KMC_BENCH_EXCHANGE=pull: the first only.
+    ("pull", "pull of drawn rows (system-scope loads), signal kernel", False),
+    ("push", "push of accepted rows into local copies read with system-scope loads, signal kernel", True),
 ]
 
 
-def try_p2p(job: Job, finegrained, fold_signal=False, push=False, lazy=False):
+def try_p2p(job: Job, finegrained, push=False):
     """Set up the peer-to-peer exchange and self-check it: 240 generations (hipGraph replays + an eager tail) must reproduce, bit
     for bit, the same generations of the whole ensemble on ONE GPU (rank 0 runs it unsharded).  Any error, time-out or mismatch
     on any rank -> None on every rank."""
@@ -901,8 +896,7 @@ def try_p2p(job: Job, finegrained, fold_signal=False, push=False, lazy=False):
     d, ok = None, True
     try:
         job.fault("p2p_setup")
-        d = P2PEmcee(job.pdf, job.nw, NDIM, job.G, job.nburn, 1, 2.0, SEED, device=job.local_rank, finegrained=finegrained,
-                     fold_signal=fold_signal, push=push, lazy=lazy, connect=False)      # local part only: no collective yet
+        d = P2PEmcee(job.pdf, job.nw, NDIM, job.G, job.nburn, 1, 2.0, SEED, device=job.local_rank, finegrained=finegrained, push=push, connect=False)      # local part only: no collective yet
     except Exception as e:  # noqa: BLE001
         note(f"[rank {rank}] p2p set-up failed ({e})")
         ok = False
@@ -931,7 +925,7 @@ def try_p2p(job: Job, finegrained, fold_signal=False, push=False, lazy=False):
             if rank == 0:
                 rpos, racc, _ = job.unsharded(vgen)
                 if not (np.array_equal(rpos, vpos) and np.array_equal(racc, vacc)):
-                    note(f"[rank 0] p2p self-check (finegrained={finegrained}, fold_signal={fold_signal}, push={push}, lazy={lazy}): "
+                    note(f"[rank 0] p2p self-check (finegrained={finegrained}, push={push}): "
                          "sharded run differs from the single-GPU run")
                     ok = False
         except Exception as e:  # noqa: BLE001
@@ -984,23 +978,21 @@ def run_sharded(job: Job) -> dict:
     """N > 1: walker-sharded, one rank per GPU, EXACT partner rule (reference src/samplers.jl:250: partners from the whole complementary
     half).  The ladder: peer-to-peer partner reads over xGMI (KMC_P2P: only the rows that are drawn cross the fabric, the whole run is
     enqueued like the single-GPU case) -- by default ONE variant, pull of the drawn rows with system-scope loads + a signal kernel (the
-    one whose correctness does not depend on cache state), admitted by a bit-exact self-check; KMC_BENCH_EXCHANGE=all also tries the
-    other variants the library has and runs the fastest admitted one; KMC_BENCH_EXCHANGE=allgather (or any failure) uses the RCCL
+    one whose correctness does not depend on cache state), then the push of accepted rows (same loads), each admitted by a bit-exact self-check, the
+    faster one runs; KMC_BENCH_EXCHANGE=allgather (or any failure) uses the RCCL
     all-gather of the updated half per half-step.  The TIMED run itself is then verified against the unsharded run of the whole
     ensemble on rank 0.  Returns the measurements; `value` stands once this returns (the extras run afterwards)."""
     torch, dist, args, rank, world = job.torch, job.dist, job.args, job.rank, job.world
     G, nw, nburn, th = job.G, job.nw, job.nburn, job.th
     from kissmcmc_jl_amd.distributed import HipShardExecutor, ShardedEmcee
     mode = os.environ.get("KMC_BENCH_EXCHANGE", "p2p")
-    res = {"tried": [], "verified": None, "lazy_stats": (0, 0), "p2p_variant": None}
+    res = {"tried": [], "verified": None, "p2p_variant": None}
     drv, best_t = None, None
-    if mode in ("p2p", "all", "pull"):
-        # lazy / folded-signal variants have peers write into plain device memory the local kernel then reads through its own L2 (or publish completion
-        # from inside the kernel): whether that L2 can serve stale lines could never be observed on one GPU -- only on request, only in the experimental library.
-        cands = P2P_VARIANTS if mode == "all" else P2P_VARIANTS[:1] if mode == "pull" else P2P_VARIANTS[:2]
-        for tag, label, fold, push, lazy in cands:
+    if mode in ("p2p", "pull"):
+        cands = P2P_VARIANTS[:1] if mode == "pull" else P2P_VARIANTS
+        for tag, label, push in cands:
             with rung(f"p2p-check:{tag}") as rg:
-                cand = try_p2p(job, False, fold, push, lazy)
+                cand = try_p2p(job, False, push)
                 rg.ok = cand is not None
             if cand is None:
                 continue
@@ -1018,7 +1010,7 @@ def run_sharded(job: Job) -> dict:
                 cand.close()
         if drv is None:
             with rung("p2p-check:pull-finegrained") as rg:
-                drv = try_p2p(job, True, False)
+                drv = try_p2p(job, True)
                 rg.ok = drv is not None
             if drv is not None:
                 res["p2p_variant"] = "pull of drawn rows, rows in fine-grained memory, signal kernel"
@@ -1055,7 +1047,6 @@ def run_sharded(job: Job) -> dict:
                 res["launches"] = drv.sampler.launch_count
                 res["msum"], res["msq"], res["nmom"] = drv.moments()
                 fpos, facc = drv.positions(), drv.naccept()
-                res["lazy_stats"] = drv.sampler.p2p_stats()         # (remote partner draws, pulled) on this rank; (0, 0) unless lazy ran
                 res["how"] = drv.sampler.describe()
                 drv.close()
         except Exception as e:  # noqa: BLE001  (e.g. a peer wait that timed out: every rank then takes the fallback)
@@ -1241,13 +1232,11 @@ def full_record(job: Job, res: dict, timed_out=None) -> dict:
         # rank's partner rows are remote, 1/P from each peer over that pair's single xGMI link (~77 GB/s one direction); pull variants move
         # every drawn row once (bytes_per_link from each peer), push variants accepted rows only (push_bytes_per_link to each peer)
         rows_per_peer = walkers_per_launch / world
-        lazy = res["lazy_stats"]
         out["fabric"] = {"remote_partner_bytes_per_gpu_per_launch": rows_per_peer * (world - 1) * NDIM * 8,
                          "bytes_per_link_per_launch": rows_per_peer * NDIM * 8,
                          "link_bound_us_at_77GBs": rows_per_peer * NDIM * 8 / 77e9 * 1e6,
                          "push_bytes_per_link_per_launch": res["acc"] * walkers_per_launch * NDIM * 8,
-                         "variants_us_per_launch": {tag: tc / 2048 * 1e6 for tag, tc in res["tried"]},   # 1024 generations each
-                         "lazy_pulled_fraction_rank0": (lazy[1] / lazy[0]) if (res["mode"] == "p2p" and lazy[0]) else None}
+                         "variants_us_per_launch": {tag: tc / 2048 * 1e6 for tag, tc in res["tried"]}}   # 1024 generations each
     else:
         out["island_mode"] = res.get("island")
     for key in ("other_configs", "cpu_baseline"):

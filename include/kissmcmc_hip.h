@@ -140,20 +140,7 @@ enum {
                                   1 / shard_count (2 ranks: half the bytes; 8 ranks: 1.9 x).  Menu densities in the vector
                                   kernels (anything else keeps the pull: kmc_sampler_describe).  Not with KMC_P2P_FINEGRAINED /
                                   kmc_sampler_init_ball.  In the default library since round 5. */
-    /* The next two exist only in a library built with -DKMC_P2P_EXPERIMENTAL (kmc_has_p2p_experimental() == 1; the default
-       library answers KMC_ERR_UNSUPPORTED): they read peer-written memory through the local L2, or publish completion from
-       inside the half-step kernel -- which no test on ONE GPU can validate. */
-    KMC_P2P_LAZY    = 1u << 10, /* with KMC_P2P: the local copies of KMC_P2P_PUSH, filled on demand.  A rank publishes the
-                                   accept bytes of each half-step (one byte per active walker, to every peer, with the progress
-                                   flag) instead of any rows; a reader pulls a drawn row from its owner only when its local
-                                   copy is older than the row's last accept, and keeps it.  Expected share of draws that
-                                   cross a link at C2's acceptance: 0.38 / 0.55 / 0.71 at 2 / 4 / 8 ranks.  Needs
-                                   nwalkers / 2 / shard_count to be a multiple of 16; not with KMC_P2P_FINEGRAINED /
-                                   kmc_sampler_init_ball.  With KMC_P2P_FOLD_SIGNAL the half-step kernel writes its accept
-                                   bytes to the peers itself. */
-    KMC_P2P_FOLD_SIGNAL = 1u << 8, /* with KMC_P2P: the half-step kernel itself publishes the progress flag (its stores are
-                                      write-through; the last workgroup to drain them signals every rank) instead of a separate
-                                      signal kernel after it: one kernel boundary less per half-step */
+    /* (bits 8 and 10 were KMC_P2P_FOLD_SIGNAL and KMC_P2P_LAZY of rounds 1-4: removed in round 5, refused with KMC_ERR_UNSUPPORTED) */
     KMC_P2P         = 1u << 4  /* walker sharding with peer-to-peer partner reads over xGMI: the sampler holds only
                                   its shard ([2][nwalkers/2/shard_count][ndim], halves back to back), reads partner
                                   rows straight from the owning rank's HBM and synchronises half-steps with
@@ -217,8 +204,6 @@ int         kmc_sizeof_config(void);
 int         kmc_sizeof_metropolis_config(void);
 int         kmc_sizeof_outputs(void);
 int         kmc_sizeof_metropolis_outputs(void);
-/* 1 when the library was built with -DKMC_P2P_EXPERIMENTAL (KMC_P2P_LAZY / KMC_P2P_FOLD_SIGNAL are accepted), else 0. */
-int         kmc_has_p2p_experimental(void);
 int         kmc_device_count(void);
 /* hipMemGetInfo of a device (a caller deciding between a device-resident chain and KMC_STREAM_CHAIN; reference
  * src/samplers.jl:268-272 grows the chain without bound). */
@@ -251,7 +236,7 @@ double      kmc_cdf_g_inv(double u, double a);
  *      Compiled code objects are cached on disk ($KMC_CACHE_DIR, else ~/.cache/kissmcmc_hip; keyed by the program, the kernel
  *      headers, the options and the hiprtc version; KMC_CACHE_DIR=off disables), so later processes skip the compiler.
  *      A term may evaluate to -INFINITY to reject a proposal.  Works in the multi-launch, resident and
- *      island modes and under KMC_P2P (the plain pull; the push / lazy / folded-signal variants are menu densities only). */
+ *      island modes and under KMC_P2P (the plain pull; the push is for menu densities only). */
 kmc_status  kmc_user_density_create(const char* term_expr, const char* pair_expr, kmc_user_density** out);
 /* The general form: the BODY of a C++ function
  *     double logpdf(const double* x, int n, const double* p) { BODY }
@@ -335,10 +320,6 @@ kmc_status  kmc_rccl_version(int* version, char* path_buf /* may be NULL */, int
 /* The same wiring for shards that live in ONE process on one device (no IPC): shards[r] = the sampler of shard r.
    They run concurrently on their own streams like ranks on separate GPUs (single-process tests, timing, profiling). */
 kmc_status  kmc_sampler_p2p_connect_local(kmc_sampler* s, kmc_sampler* const* shards /* [shard_count] */);
-/* KMC_P2P_LAZY, sampler created with KMC_DEBUG=p2p-stats in the environment (diagnostics: the counting costs same-address
-   atomics; zeros otherwise): counts since kmc_sampler_set_positions -- out[0] = partner draws that fell on another rank's rows,
-   out[1] = those of them that were pulled over the fabric (the others were served by the local copy). */
-kmc_status  kmc_sampler_p2p_stats(kmc_sampler* s, uint64_t out[2]);
 /* Upload the ensemble (host, [nwalkers][ndim], global order), evaluate the initial log-pdfs on
  * the device (src/samplers.jl:209-210), reset generation/counters.  Fails with
  * KMC_ERR_NONFINITE_LOGP if any is not finite. */

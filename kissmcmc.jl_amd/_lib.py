@@ -24,8 +24,7 @@ HOST_PROPOSE_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int64, C.c_int
 HOST_ACCEPTED_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_uint8), C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_void_p)
 F64 = 0
 F32 = 1       # rows and chain kept in float on the device; arithmetic and host buffers stay double
-STORE_CHAIN, STORE_LOGP, MOMENTS, NO_GRAPH, P2P, ISLANDS, P2P_FINEGRAINED, P2P_FOLD_SIGNAL, P2P_PUSH = 1, 2, 4, 8, 16, 64, 128, 256, 512
-P2P_LAZY = 1024
+STORE_CHAIN, STORE_LOGP, MOMENTS, NO_GRAPH, P2P, ISLANDS, P2P_FINEGRAINED, P2P_PUSH = 1, 2, 4, 8, 16, 64, 128, 512
 STREAM_CHAIN = 2048
 CHAIN_BY_WALKER = 4096
 STORE_BLOBS = 8192
@@ -36,7 +35,7 @@ RCCL_ID_BYTES = 128
 SYMBOLS = [
     "kmc_version", "kmc_device_count", "kmc_last_error", "kmc_status_string", "kmc_validate",
     "kmc_g_pdf", "kmc_cdf_g_inv", "kmc_emcee_run", "kmc_sampler_create", "kmc_sampler_destroy",
-    "kmc_sampler_set_stream", "kmc_sampler_bind_positions", "kmc_sampler_p2p_export", "kmc_sampler_p2p_connect", "kmc_sampler_p2p_connect_local", "kmc_sampler_p2p_stats", "kmc_sampler_set_positions", "kmc_sampler_init_ball", "kmc_sampler_set_state", "kmc_sampler_run", "kmc_sampler_half_step",
+    "kmc_sampler_set_stream", "kmc_sampler_bind_positions", "kmc_sampler_p2p_export", "kmc_sampler_p2p_connect", "kmc_sampler_p2p_connect_local", "kmc_sampler_set_positions", "kmc_sampler_init_ball", "kmc_sampler_set_state", "kmc_sampler_run", "kmc_sampler_half_step",
     "kmc_sampler_sync", "kmc_sampler_last_run_ms", "kmc_sampler_generation", "kmc_sampler_nsamples",
     "kmc_sampler_launch_count", "kmc_sampler_describe", "kmc_sampler_device_ptr", "kmc_sampler_get_positions",
     "kmc_sampler_get_logp", "kmc_sampler_get_naccept", "kmc_sampler_get_accept_ratio",
@@ -47,7 +46,7 @@ SYMBOLS = [
     "kmc_sampler_rccl_capture", "kmc_sampler_rccl_set_capture", "kmc_rccl_version", "kmc_device_free_bytes",
     "kmc_sampler_launch_mode", "kmc_updated_budget", "kmc_set_updated_budget_mb", "kmc_debug_accept_terms",
     "kmc_user_density_create_body_blob", "kmc_user_density_nblob", "kmc_logpdf_blob_eval_host", "kmc_sampler_get_blobs",
-    "kmc_device_cache_release", "kmc_has_p2p_experimental", "kmc_user_density_is_separable", "kmc_host_prefault",
+    "kmc_device_cache_release", "kmc_user_density_is_separable", "kmc_host_prefault",
 ]
 
 
@@ -184,7 +183,6 @@ def lib() -> C.CDLL:
     L.kmc_sampler_bind_positions.argtypes = [vp, vp]
     L.kmc_sampler_p2p_export.argtypes = [vp, vp]
     L.kmc_sampler_p2p_connect.argtypes = [vp, vp]
-    L.kmc_sampler_p2p_stats.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.kmc_sampler_p2p_connect_local.argtypes = [vp, C.POINTER(C.c_void_p)]
     L.kmc_sampler_set_positions.argtypes = [vp, dp]
     L.kmc_sampler_init_ball.argtypes = [vp, dp, dp, C.c_uint64, C.c_int, C.c_int]
@@ -240,8 +238,6 @@ def lib() -> C.CDLL:
     L.kmc_sampler_rccl_set_capture.argtypes = [vp, C.c_int]
     L.kmc_rccl_version.argtypes = [C.POINTER(C.c_int), C.c_char_p, C.c_int64]
     L.kmc_device_free_bytes.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
-    L.kmc_has_p2p_experimental.restype = C.c_int
-    L.kmc_has_p2p_experimental.argtypes = []
     L.kmc_device_cache_release.argtypes = []
     L.kmc_device_cache_release.restype = None
     L.kmc_host_prefault.argtypes = [C.c_void_p, C.c_uint64, C.c_int]

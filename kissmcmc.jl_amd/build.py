@@ -24,7 +24,6 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found: the HIP library cannot be built")
 
 
-P2PEXP_LIB = os.path.join(_HERE, "libkmc_var_p2pexp.so")      # the library with the experimental exchange variants (-DKMC_P2P_EXPERIMENTAL)
 
 
 def stale(lib: str = LIB) -> bool:
@@ -35,18 +34,10 @@ def stale(lib: str = LIB) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_p2p_experimental(force: bool = False) -> str:
-    """The same library with -DKMC_P2P_EXPERIMENTAL: KMC_P2P_PUSH / KMC_P2P_LAZY / KMC_P2P_FOLD_SIGNAL exist (kmc_kernels.hpp).  Used by
-    tests/test_gpu_p2p_experimental.py through KMC_LIB_PATH; never the default."""
-    if force or stale(P2PEXP_LIB):
-        build(extra_flags=["-DKMC_P2P_EXPERIMENTAL"], out=P2PEXP_LIB)
-    return P2PEXP_LIB
-
-
 def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str = LIB, preload: bool = True) -> str:
     """Compile csrc/*.hip (one translation unit per density, in parallel) and link
     libkissmcmc_hip.so next to this file (in-tree, so it travels with the snapshot).
-    ``extra_flags``/``out`` build variants side by side (``-DKMC_PROBE``, ``-DKMC_P2P_EXPERIMENTAL``)."""
+    ``extra_flags``/``out`` build variants side by side (``-DKMC_PROBE``)."""
     if not (force or out != LIB or stale()):
         return out
     from concurrent.futures import ThreadPoolExecutor
@@ -75,8 +66,4 @@ def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str =
 
 
 if __name__ == "__main__":
-    import sys
-    if "--p2p-experimental" in sys.argv[1:]:
-        print(build_p2p_experimental(force=True))
-    else:
-        print(build(force=True, verbose=True))
+    print(build(force=True, verbose=True))

@@ -93,18 +93,6 @@ struct HalfStepArgs {
     double*           peer_pos[8];
     const unsigned long long* flags; // flags[r] = number of half-steps rank r has completed
     unsigned long long* err;         // set non-zero when a wait times out
-#ifdef KMC_P2P_EXPERIMENTAL
-    // KMC_P2P_FOLD_SIGNAL: the kernel publishes its own completion (vec kernels)
-    unsigned long long* peer_flags[8]; // peer_flags[r] = rank r's flags array
-    uint32_t*         done_count;    // [33][16]: workgroups of this launch that have drained their stores (32 sub-counters +
-                                     //   a top counter, one 64-byte line each); nullptr: separate signal kernel
-    int32_t           me;            // this rank
-    // KMC_P2P_PUSH: pos is (1 + nranks) blocks of shard_stride doubles -- block 0 this rank's rows, block 1 + q a local
-    // copy of rank q's; partner rows are read from the local copies, accepted rows are also written to block 1 + me of
-    // every peer (peer_pos[r] = rank r's pos)
-    int32_t           push;
-    int64_t           shard_stride;
-#endif
     DrawConsts        dc;
     DensityParams     dp;
     double*           chain;        // [nsamples][chain_rows][ndim] or nullptr          (:269)
@@ -143,39 +131,20 @@ struct HalfStepArgs {
     // blobs of a body density (BodyBlobDensity, NB doubles per evaluation; one walker per lane kernels only)
     double*           blob;         // [rows][NB]: the blob of every walker's current position (blob0s, src/samplers.jl:210, :264)
     double*           chain_blob;   // [nsamples][chain_rows][NB] (reduce_blob!, :270) or nullptr
-#ifdef KMC_P2P_EXPERIMENTAL
-    // KMC_P2P_LAZY (push == 2): the shadow blocks of KMC_P2P_PUSH, filled on demand.  Nobody pushes rows; a rank
-    // publishes the ACCEPT BYTES of each half-step instead (one byte per active walker, written into every peer's
-    // lz_amap_in by the half-step kernel, slot = step & 3), and a reader pulls a drawn remote row only when its shadow
-    // copy is older than the row's last accept -- it then keeps the row in the shadow.  Per remote row the reader
-    // holds two stamps (step + 1; 0 = never; lz_stamps): modified, the last accept it has heard of (absorbed from the byte
-    // maps, one launch late), and fetched, its last pull.  A row is pulled when the newest map flags it, when
-    // modified > fetched, or when fetched carries THIS step (another wave is rewriting the shadow right now).
-    const unsigned char* lz_amap_in;   // [nranks][4][hloc]  (inside the exported row allocation: peers write it)
-    uint2*            lz_stamps;       // [nranks][2][hloc] {x: fetched, y: modified} -- one 8-byte load per walker-step
-    unsigned long long* lz_stats;      // diagnostics, or nullptr: [0] remote partner draws, [1] of them pulled over the fabric
-    unsigned char*    lz_peer_amap[8]; // rank r's lz_amap_in: the kernel writes its accept bytes there itself
-#endif
 };
 
-// The peer-to-peer exchange of the default library has TWO variants, both ordered by a separate signal kernel and neither resting on any cache
-// state: PULL of the drawn partner rows from their owner, and PUSH (KMC_P2P_PUSH, round 5) of every accepted row into a local copy of the owner's
-// shard on every peer -- in both the partner rows are read with system-scope loads (sc0 sc1: never served from the reader's L2, whether the line
-// belongs to a peer's memory or to local memory a peer writes over the fabric), and every row store is write-through.  Push moves acc * h_loc rows
-// per link and half-step, pull h_loc / P: push wins while the acceptance is below 1 / P (C4's 0.234: P = 2 25 against 54 us per link, P = 4 25
-// against 27, P = 8 25 against 13.6 -- DESIGN.md section 7).  Four more -- lazy pull into local copies, and the progress signal folded into the
-// half-step kernel -- read peer-written memory through the local L2 or publish completion from inside the kernel; bit-exact with every "peer" on
-// ONE GPU, never run on two.  They exist only in builds with -DKMC_P2P_EXPERIMENTAL (the whole library: the argument struct changes;
-// `python -m kissmcmc_jl_amd.build --p2p-experimental` -> libkmc_var_p2pexp.so, tests/test_gpu_p2p_experimental.py).
+// The peer-to-peer exchange has TWO variants, both ordered by a separate signal kernel and neither resting on any cache state: PULL of the drawn partner
+// rows from their owner, and PUSH (KMC_P2P_PUSH, round 5) of every accepted row into a local copy of the owner's shard on every peer -- in both the
+// partner rows are read with system-scope loads (sc0 sc1: never served from the reader's L2, whether the line belongs to a peer's memory or to local
+// memory a peer writes over the fabric), and every row store is write-through.  Push moves acc * h_loc rows per link and half-step, pull h_loc / P: push
+// wins while the acceptance is below 1 / P (C4's 0.234: P = 2 25 against 54 us per link, P = 4 25 against 27, P = 8 25 against 13.6 -- DESIGN.md
+// section 7).  (Rounds 1-4 carried four more variants -- lazy pull into local copies driven by per-row stamps, and the progress signal folded into the
+// half-step kernel -- behind -DKMC_P2P_EXPERIMENTAL: bit-exact with every "peer" on one GPU, never run on two, and by section 7's arithmetic unable to
+// move the bound; deleted in round 5, `git show b051b2c:kissmcmc.jl_amd/csrc/kmc_kernels.hpp`.)
 __host__ __device__ inline int32_t pack_ranks(int nranks, int me, bool push) { return (int32_t)(nranks | (me << 8) | (push ? 1 << 16 : 0)); }
 __device__ __forceinline__ int  p2p_nranks(const HalfStepArgs& a) { return a.nranks & 0xff; }
 __device__ __forceinline__ int  p2p_me(const HalfStepArgs& a) { return (a.nranks >> 8) & 0xff; }
 __device__ __forceinline__ bool p2p_push(const HalfStepArgs& a) { return ((a.nranks >> 16) & 1) != 0; }
-#ifdef KMC_P2P_EXPERIMENTAL
-constexpr bool kP2PExperimental = true;
-#else
-constexpr bool kP2PExperimental = false;
-#endif
 
 // The fields a wave needs before it can issue its first loads travel as LEADING SCALAR kernel parameters, ahead
 // of the argument struct: built with -mllvm -amdgpu-kernarg-preload-count=14, gfx950 delivers them in SGPRs at
@@ -547,15 +516,8 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
     //      and pinned with scheduling barriers because the compiler's own placement moves with unrelated edits ----
     unsigned long long addrA = 0ull;                                    // P2P: the partner row's address
     const int nranks = P2P ? p2p_nranks(a) : 1, me_rank = P2P ? p2p_me(a) : 0;
-#ifdef KMC_P2P_EXPERIMENTAL
-    const int pushmode = P2P ? a.push : 0;                              // 0: pull, 1: push, 2: lazy pull into local copies
-#else
-    const int pushmode = (P2P && p2p_push(a)) ? 1 : 0;
-#endif
+    const bool push = P2P && p2p_push(a);
     const int64_t shard_stride = 2 * (int64_t)a.hloc * ld;              // push: pos is (1 + nranks) blocks of a shard's rows -- block 0 this rank's, block 1 + q a copy of rank q's
-#ifdef KMC_P2P_EXPERIMENTAL
-    unsigned long long shadowB[ITER];                                   // KMC_P2P_LAZY: where a pulled row goes in the local shadow (0: not pulled)
-#endif
     auto load_partner_rows = [&](int it) {
         const V2* oth;
         if constexpr (!P2P) {
@@ -566,15 +528,12 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
             const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)(unsigned)addrA);
             const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)(unsigned)(addrA >> 32));
             const unsigned long long ad = ((unsigned long long)hi << 32) | lo;
-#ifdef KMC_P2P_EXPERIMENTAL
-            shadowB[it] = ad;                                           // (lazy: the local copy's address, kept or zeroed below)
-#endif
             oth = reinterpret_cast<const V2*>(ad);
         }
         if constexpr (P2P) {
             // pull: the row lives in its owner's memory; push: in a local copy that the owner writes over the fabric -- either way read at
-            // system scope, never from this XCD's L2 (lazy, experimental builds: the shadows are read like local rows)
-            if (pushmode != 2 && nranks > 1) {
+            // system scope, never from this XCD's L2
+            if (nranks > 1) {
 #pragma unroll
                 for (int k = 0; k < K; ++k) xo[it][k] = cv[k] ? load_row_sys(reinterpret_cast<const double2*>(&oth[k * L + j])) : zero2;
                 return;
@@ -583,101 +542,25 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
 #pragma unroll
         for (int k = 0; k < K; ++k) xo[it][k] = cv[k] ? load_row(&oth[k * L + j]) : zero2;
     };
-#ifdef KMC_P2P_EXPERIMENTAL
-    bool lazy = false;
-#else
-    constexpr bool lazy = false;
-#endif
     if constexpr (P2P) {
-#ifdef KMC_P2P_EXPERIMENTAL
-        lazy = a.push == 2;
-#endif
         // owner rank and row of the partner, resolved once per walker; the row address travels
         const uint32_t q = a.hloc_shift >= 0 ? partnerA >> a.hloc_shift : partnerA / a.hloc;
         const uint32_t r = partnerA - q * a.hloc;
         const double* base = a.peer_pos[0];
 #pragma unroll
         for (int t = 1; t < 8; ++t) base = (q == (uint32_t)t) ? a.peer_pos[t] : base;
-#ifdef KMC_P2P_EXPERIMENTAL
-        const double* remote_base = base;
-#endif
-        if (pushmode != 0) base = (q == (uint32_t)me_rank) ? a.pos : a.pos + (int64_t)(1u + q) * shard_stride;   // local copy of rank q's shard
+        if (push) base = (q == (uint32_t)me_rank) ? a.pos : a.pos + (int64_t)(1u + q) * shard_stride;   // local copy of rank q's shard
         addrA = (unsigned long long)(base + (oth_row0 + r) * ld);
-#ifdef KMC_P2P_EXPERIMENTAL
-        // KMC_P2P_LAZY: the local copies and this reader's stamps do not depend on the peers' progress -- request them
-        // now, speculatively; whether a copy is still good is decided after the wait (newest accept bytes)
-        const bool remoteA = lazy && q != (uint32_t)me_rank && validA;
-        const int64_t xs = ((int64_t)q * 2 + (1 - half)) * (int64_t)a.hloc + r;
-        uint32_t fe = 0u, mo = 0u;
-        if (remoteA) { const uint2 st = a.lz_stamps[xs]; fe = st.x; mo = st.y; }
-        if (lazy) {
-#pragma unroll
-            for (int it = 0; it < ITER; ++it) load_partner_rows(it);
-        }
-#endif
         if (nranks > 1) {
             // every rank must have finished half-step `step - 1`: one polling wave per workgroup (the
             // flags sit in uncached fine-grained memory), the other waves wait at the barrier
             if ((threadIdx.x >> 6) == 0) wait_for_peers(a, step, lane);
             __syncthreads();
         }
-#ifdef KMC_P2P_EXPERIMENTAL
-        if (lazy) {
-            const uint32_t stamp = (uint32_t)step + 1u;
-            const int64_t hl = (int64_t)a.hloc;
-            if (step > 0) {
-                // absorb the accept bytes of half-step step - 1 (the partner half's last update) into the stamps
-                const uint32_t* maps = reinterpret_cast<const uint32_t*>(a.lz_amap_in);
-                const int64_t wpr = hl / 4, nthr = (int64_t)gridDim.x * vec_tpb(L);
-                for (int64_t w = tid; w < (int64_t)p2p_nranks(a) * wpr; w += nthr) {
-                    const int64_t qq = w / wpr, ww = w - qq * wpr;
-                    if (qq == a.me) continue;
-                    const uint32_t word = maps[(qq * 4 + (int64_t)((step - 1) & 3)) * wpr + ww];
-                    if (word != 0u) {
-                        uint2* m = a.lz_stamps + (qq * 2 + (1 - half)) * hl + 4 * ww;
-#pragma unroll
-                        for (int b = 0; b < 4; ++b) if ((word >> (8 * b)) & 0xffu) m[b].y = (uint32_t)step;   // = (step - 1) + 1
-                    }
-                }
-            }
-            // this walker's partner: the local copy unless the owner's row is newer -- then from the owner, again
-            unsigned long long addrR = 0ull;
-            if (remoteA) {
-                const unsigned am = step > 0 ? a.lz_amap_in[((int64_t)q * 4 + (int64_t)((step - 1) & 3)) * hl + r] : 0u;
-                if (am != 0u || mo > fe || fe == stamp) {
-                    addrR = (unsigned long long)(remote_base + (oth_row0 + r) * ld);
-                    a.lz_stamps[xs].x = stamp;
-                }
-            }
-            if (a.lz_stats != nullptr) {                                 // diagnostics only (KMC_DEBUG=p2p-stats): same-address atomics
-                const unsigned long long nrem = __ballot(remoteA), npul = __ballot(addrR != 0ull);
-                if (lane == 0 && nrem != 0ull) {
-                    atomicAdd(&a.lz_stats[0], (unsigned long long)__popcll(nrem));
-                    if (npul != 0ull) atomicAdd(&a.lz_stats[1], (unsigned long long)__popcll(npul));
-                }
-            }
-#pragma unroll
-            for (int it = 0; it < ITER; ++it) {
-                const int src = (gbase + it) * 4;
-                const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)(unsigned)addrR);
-                const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)(unsigned)(addrR >> 32));
-                const unsigned long long rem = ((unsigned long long)hi << 32) | lo;
-                if (rem != 0ull) {
-                    const double2* oth = reinterpret_cast<const double2*>(rem);
-#pragma unroll
-                    for (int k = 0; k < K; ++k) xo[it][k] = cv[k] ? load_row_sys(&oth[k * L + j]) : zero2;
-                } else {
-                    shadowB[it] = 0ull;                                  // the copy was good: nothing to write back
-                }
-            }
-        }
-#endif
     }
     constexpr int kFirst = ITER >= 2 ? ITER / 2 : ITER;                 // iterations whose loads precede the first logarithm
-    if (!lazy) {
 #pragma unroll
-        for (int it = 0; it < kFirst; ++it) load_partner_rows(it);
-    }
+    for (int it = 0; it < kFirst; ++it) load_partner_rows(it);
     __builtin_amdgcn_sched_barrier(0);
     KMC_STAMP(2);                                       // the first partner-row loads are issued
 
@@ -749,10 +632,8 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
         dr.t1 = dc.nm1 * log_pos_normal(dr.z);
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (!lazy) {
 #pragma unroll
-        for (int it = kFirst; it < ITER; ++it) load_partner_rows(it);
-    }
+    for (int it = kFirst; it < ITER; ++it) load_partner_rows(it);
     __builtin_amdgcn_sched_barrier(0);
     if (!fresh) {
         dr.lu = log_pos_normal(ua);                                     // :260
@@ -772,20 +653,6 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
 #pragma unroll
     for (int it = 0; it < ITER; ++it) zB[it] = bperm_f64((gbase + it) * 4, dr.z);
 
-#ifdef KMC_P2P_EXPERIMENTAL
-    if constexpr (P2P) {
-        if (a.push == 2) {                                              // keep the rows just pulled
-#pragma unroll
-            for (int it = 0; it < ITER; ++it) {
-                if (shadowB[it] != 0ull) {
-                    double2* sh = reinterpret_cast<double2*>(shadowB[it]);
-#pragma unroll
-                    for (int k = 0; k < K; ++k) if (cv[k]) store_wt(&sh[k * L + j], xo[it][k]);
-                }
-            }
-        }
-    }
-#endif
     // ---- stretch move + log-pdf; xo becomes the proposal ------------------------------------
     double myp1 = 0.0;
     constexpr int kRowND = RowEvalTrait<Dens>::n;                       // > 0: a function body over the whole proposal (see below)
@@ -851,18 +718,6 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
         if (count) store_wt(&naccept_p[rowA], na + 1u);                 // :265
         if (do_mom) store_wt(&klast_p[rowA], sch.nbefore);
     }
-#ifdef KMC_P2P_EXPERIMENTAL
-    if constexpr (P2P) {
-        if (a.push == 2 && validA) {
-            // straight into every peer's map (write-through: in the peer's memory once drained, i.e. before this
-            // half-step's progress flag -- from the signal kernel one boundary later, or from this kernel's last workgroup)
-            const unsigned char byte = acc ? 1 : 0;
-            const int64_t at = ((int64_t)a.me * 4 + (int64_t)(step & 3)) * (int64_t)a.hloc + iA;
-            for (int r = 0; r < p2p_nranks(a); ++r)
-                if (r != a.me) store_wt(&a.lz_peer_amap[r][at], byte);
-        }
-    }
-#endif
     if constexpr (BlobTrait<Dens>::n > 0) {
         // the blob of the walker's CURRENT position follows it (blob0s[nc] = blob1 on accept, :264) and is stored with every sample (:270)
         constexpr int NB = BlobTrait<Dens>::n;
@@ -899,7 +754,7 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
 #pragma unroll
             for (int k = 0; k < K; ++k) if (cv[k]) store_row(&own[k * L + j], xo[it][k]);
             if constexpr (P2P) {
-                if (pushmode == 1) {                                    // ... and into this rank's copy on every peer (write-through, over the fabric)
+                if (push) {                                    // ... and into this rank's copy on every peer (write-through, over the fabric)
                     const int64_t off = (int64_t)(1 + me_rank) * shard_stride + (own_row0 + w0 + it * G + g) * ld;
                     for (int r = 0; r < nranks; ++r) {
                         if (r == me_rank) continue;
@@ -966,39 +821,6 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
             else accumulate_wave<L, K, false>(a.msum, a.msumsq, a.macc_stride, tid, g, ms, mq, accs, accq, acct);
         }
     }
-#ifdef KMC_P2P_EXPERIMENTAL
-    if constexpr (P2P) {
-        // KMC_P2P_FOLD_SIGNAL: every store above is write-through, so once a workgroup's stores have drained they are
-        // in memory, where the peers read them; the last workgroup to get there tells every rank that this rank has
-        // completed half-step `step` (flag = step + 1) -- what the separate p2p_signal kernel does one boundary later
-        if (p2p_nranks(a) > 1 && a.done_count != nullptr) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                // relaxed: the data are already in memory (write-through stores, drained above); an acquire here would
-                // invalidate the L2 once per workgroup under the waves that are still loading
-                // two levels: 32 sub-counters (every 32nd workgroup shares one, each in its own 64-byte line), then one
-                // top counter -- a thousand arrivals on ONE address serialise for ~20 us (measured: the folded signal ran
-                // at 27 against 11 us per half-step with 1024 workgroups)
-                constexpr uint32_t kSub = 32u;
-                const uint32_t sub = blockIdx.x & (kSub - 1u);
-                const uint32_t expect = (gridDim.x - sub + kSub - 1u) / kSub;           // workgroups with this sub-counter
-                uint32_t* cnt = a.done_count + 16u * sub;
-                if (__hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == expect - 1u) {
-                    __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    uint32_t* top = a.done_count + 16u * kSub;
-                    const uint32_t nsub = gridDim.x < kSub ? gridDim.x : kSub;
-                    if (__hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nsub - 1u) {
-                        __hip_atomic_store(top, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __threadfence_system();
-                        for (int r = 0; r < p2p_nranks(a); ++r)
-                            __hip_atomic_store(a.peer_flags[r] + a.me, (unsigned long long)step + 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-                    }
-                }
-            }
-        }
-    }
-#endif
     KMC_STAMP(7);                                       // the last store is issued
 #ifdef KMC_PROBE
     {

@@ -66,24 +66,10 @@ HalfStepArgs make_args(const kmc_sampler* s, int half, bool graph_mode, int64_t 
     a.hloc = (uint32_t)s->h_loc;
     a.hloc_shift = -1;
     if (s->h_loc > 0 && (s->h_loc & (s->h_loc - 1)) == 0) { a.hloc_shift = 0; while (((int64_t)1 << a.hloc_shift) < s->h_loc) ++a.hloc_shift; }
-    a.nranks = pack_ranks(s->cfg.shard_count, s->cfg.shard_rank, s->push && !s->lazy);
+    a.nranks = pack_ranks(s->cfg.shard_count, s->cfg.shard_rank, s->push);
     for (int r = 0; r < 8; ++r) a.peer_pos[r] = s->peer_pos[r];
     a.flags = s->d_flags;
     a.err = s->d_err;
-#ifdef KMC_P2P_EXPERIMENTAL
-    for (int r = 0; r < 8; ++r) a.peer_flags[r] = s->peer_flags[r];
-    a.done_count = s->fold_signal ? s->d_done : nullptr;
-    a.me = s->cfg.shard_rank;
-    a.push = s->lazy ? 2 : s->push ? 1 : 0;
-    if (s->lazy) {
-        const size_t hl = (size_t)s->h_loc, P = (size_t)s->cfg.shard_count;
-        a.lz_amap_in = s->peer_amap_in[s->cfg.shard_rank];
-        a.lz_stamps = reinterpret_cast<uint2*>(s->d_lazy);
-        a.lz_stats = s->lazy_stats ? reinterpret_cast<unsigned long long*>(a.lz_stamps + P * 2 * hl) : nullptr;
-        for (int r = 0; r < 8; ++r) a.lz_peer_amap[r] = s->peer_amap_in[r];
-    }
-    a.shard_stride = (int64_t)s->nrows * s->ld;
-#endif
     a.n_active = (int32_t)s->h_loc;
     a.half = half;
     a.ndim = (int32_t)s->cfg.ndim;
@@ -144,7 +130,7 @@ kmc_status launch_half(kmc_sampler* s, int half, bool graph_mode, int64_t gen_of
 {
     const HalfStepArgs a = make_args(s, half, graph_mode, gen_offset);
     HIP_TRY(launch_half_kernel(s, a));
-    if (s->p2p && s->cfg.shard_count > 1 && !s->fold_signal) {
+    if (s->p2p && s->cfg.shard_count > 1) {
         // the kernel boundary puts this half-step's rows in memory; then publish the progress
         SignalArgs sg{};
         for (int r = 0; r < 8; ++r) sg.peer_flags[r] = s->peer_flags[r];

@@ -113,8 +113,6 @@ KMC_EXPORT kmc_status kmc_sampler_p2p_connect(kmc_sampler* s, const void* handle
         void* p = nullptr;
         HIP_TRY(hipIpcOpenMemHandle(&p, h[r].pos, hipIpcMemLazyEnablePeerAccess));
         s->peer_pos[r] = static_cast<double*>(p);
-        if (s->lazy)
-            s->peer_amap_in[r] = static_cast<unsigned char*>(p) + (size_t)(1 + s->cfg.shard_count) * (size_t)s->nrows * (size_t)s->ld * sizeof(double);
         HIP_TRY(hipIpcOpenMemHandle(&p, h[r].flags, hipIpcMemLazyEnablePeerAccess));
         s->peer_flags[r] = static_cast<unsigned long long*>(p);
     }
@@ -132,27 +130,11 @@ KMC_EXPORT kmc_status kmc_sampler_p2p_connect_local(kmc_sampler* s, kmc_sampler*
     for (int r = 0; r < s->cfg.shard_count; ++r) {
         const kmc_sampler* o = shards[r];
         if (!o || !o->p2p || o->cfg.shard_count != s->cfg.shard_count || o->cfg.shard_rank != r || o->cfg.device != s->cfg.device ||
-            o->nrows != s->nrows || o->ld != s->ld || o->lazy != s->lazy || o->push != s->push)
+            o->nrows != s->nrows || o->ld != s->ld || o->push != s->push)
             return fail(KMC_ERR_BAD_ARG, "kmc_sampler_p2p_connect_local: shards[r] must be shard r of the same configuration on the same device");
         s->peer_pos[r] = o->d_pos;
         s->peer_flags[r] = o->d_flags;
-        s->peer_amap_in[r] = o->peer_amap_in[r];
     }
     s->connected = true;
     return KMC_OK;
 }
-
-KMC_EXPORT kmc_status kmc_sampler_p2p_stats(kmc_sampler* s, uint64_t out[2])
-{
-    if (!s || !out) return fail(KMC_ERR_BAD_ARG, "null argument");
-    out[0] = out[1] = 0;
-    if (!s->lazy) return KMC_OK;
-    HIP_TRY(hipSetDevice(s->cfg.device));
-    HIP_TRY(hipStreamSynchronize(s->stream));
-    const size_t hl = (size_t)s->h_loc, P = (size_t)s->cfg.shard_count;
-    unsigned long long v[2] = {0ull, 0ull};
-    HIP_TRY(copy_sync(v, s->d_lazy + 2 * P * 2 * hl * sizeof(uint32_t), sizeof(v), hipMemcpyDeviceToHost, s->stream));
-    out[0] = v[0]; out[1] = v[1];
-    return KMC_OK;
-}
-

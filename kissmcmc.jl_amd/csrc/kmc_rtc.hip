@@ -616,11 +616,10 @@ kmc_status compile_user(kmc_user_density* ud, bool with_vec, int L, int K, int i
 
     const char* headers[4] = {h_ker.c_str(), h_dev.c_str(), h_isl.c_str(), h_gen.c_str()};
     const char* names[4] = {"kmc_kernels.hpp", "kmc_device.hpp", "kmc_islands.hpp", "kmc_generation.hpp"};
-    // (the same -D the library itself was built with: the argument structs have more fields in an experimental build; the options are part of the cache key)
-    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-mllvm", "-amdgpu-kernarg-preload-count=14", "-DKMC_P2P_EXPERIMENTAL"};
+    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-mllvm", "-amdgpu-kernarg-preload-count=14"};
     std::vector<char> code;
     std::string log;
-    const kmc_status cst = rtc_compile_cached(text, "kmc_user_density.hip", 4, headers, names, kmc::kP2PExperimental ? 7 : 6, opts, &code, &log);
+    const kmc_status cst = rtc_compile_cached(text, "kmc_user_density.hip", 4, headers, names, 6, opts, &code, &log);
     if (cst == KMC_ERR_BAD_ARG) return fail(KMC_ERR_BAD_ARG, "user density does not compile:\n" + log);
     if (cst != KMC_OK) return cst;
     auto ins = ud->code.emplace(key, std::move(code));

@@ -78,12 +78,10 @@ KMC_EXPORT kmc_status kmc_validate(const kmc_config* c)
     if (c->shard_rank < 0 || c->shard_rank >= P) return fail(KMC_ERR_BAD_ARG, "shard_rank out of range");
     if ((c->nwalkers / 2) % P != 0) return fail(KMC_ERR_BAD_ARG, "nwalkers/2 must be divisible by shard_count");
     if ((c->flags & KMC_P2P) && P > 8) return fail(KMC_ERR_UNSUPPORTED, "KMC_P2P supports at most 8 shards (one node)");
-#ifndef KMC_P2P_EXPERIMENTAL
-    if (c->flags & (KMC_P2P_LAZY | KMC_P2P_FOLD_SIGNAL))
-        return fail(KMC_ERR_UNSUPPORTED, "KMC_P2P_LAZY / KMC_P2P_FOLD_SIGNAL exist only in builds with -DKMC_P2P_EXPERIMENTAL "
-                                         "(python -m kissmcmc_jl_amd.build --p2p-experimental): the default library's exchanges are the pull of drawn rows and "
-                                         "the push of accepted rows (KMC_P2P_PUSH), both read with system-scope loads");
-#endif
+    if (c->flags & ((1u << 8) | (1u << 10)))                 // (KMC_P2P_FOLD_SIGNAL, KMC_P2P_LAZY of rounds 1-4)
+        return fail(KMC_ERR_UNSUPPORTED, "the lazy-pull and folded-signal exchange variants were removed in round 5 (they read peer-written memory through the local L2 and could "
+                                         "not move the fabric bound): the exchanges are the pull of drawn rows and the push of accepted rows (KMC_P2P_PUSH), both read with "
+                                         "system-scope loads");
     if ((c->flags & KMC_P2P_PUSH) && !(c->flags & KMC_P2P)) return fail(KMC_ERR_BAD_ARG, "KMC_P2P_PUSH needs KMC_P2P");
     if (c->flags & KMC_ISLANDS) {
         const int64_t S = c->island_size > 0 ? c->island_size : kIslandSizeDefault;
@@ -522,33 +520,16 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
         CREATE_TRY(hipMemsetAsync(s->d_err, 0, 64, s->stream));
         // KMC_P2P_PUSH: local copies of the other shards, which their owners write; the menu densities' vector kernels carry it (anything
         // else keeps the pull -- kmc_sampler_describe says which runs)
-        s->push = (cfg->flags & (KMC_P2P_PUSH | KMC_P2P_LAZY)) != 0 && s->plan.vec && s->user == nullptr && !(cfg->flags & KMC_P2P_FINEGRAINED) &&
+        s->push = (cfg->flags & KMC_P2P_PUSH) != 0 && s->plan.vec && s->user == nullptr && !(cfg->flags & KMC_P2P_FINEGRAINED) &&
                   s->cfg.shard_count > 1;
-#ifdef KMC_P2P_EXPERIMENTAL
-        CREATE_TRY(dev_alloc(s, (void**)&s->d_done, 33 * 64));
-        CREATE_TRY(hipMemsetAsync(s->d_done, 0, 33 * 64, s->stream));
-        // the kernel can publish its own completion only where all its stores are write-through: the vector kernels
-        s->fold_signal = (cfg->flags & KMC_P2P_FOLD_SIGNAL) != 0 && s->plan.vec && s->user == nullptr;
-        s->lazy = s->push && (cfg->flags & KMC_P2P_LAZY) != 0 && s->h_loc % 16 == 0 && !s->f32;
-        s->lazy_stats = s->lazy && debug_opt("p2p-stats");
-#endif
     }
-    // KMC_P2P_LAZY: room for every rank's accept-byte maps behind the row blocks (peers write them: same allocation)
-    const size_t amap_bytes = s->lazy ? (size_t)s->cfg.shard_count * 4 * (size_t)s->h_loc : 0;
     const size_t ldz = (size_t)s->ld;
     const size_t esz = s->f32 ? sizeof(float) : sizeof(double);      // element size of rows and chain
     if (s->p2p && (cfg->flags & KMC_P2P_FINEGRAINED))   // peers map the rows uncached: nothing of them can go stale in a reader's L2
         CREATE_TRY(hipExtMallocWithFlags((void**)&s->d_pos, nw * ldz * sizeof(double), hipDeviceMallocFinegrained));
     else
-        CREATE_TRY(dev_alloc(s, &s->d_pos, (s->push ? 1 + (size_t)s->cfg.shard_count : 1) * nw * ldz * esz + amap_bytes));
-    CREATE_TRY(hipMemsetAsync(s->d_pos, 0, (s->push ? 1 + (size_t)s->cfg.shard_count : 1) * nw * ldz * esz + amap_bytes, s->stream));   // the pad column of odd ndim stays 0
-    if (s->lazy) {
-        const size_t P = (size_t)s->cfg.shard_count, hl = (size_t)s->h_loc;
-        const size_t nb = 2 * P * 2 * hl * sizeof(uint32_t) + 16;
-        CREATE_TRY(dev_alloc(s, (void**)&s->d_lazy, nb));
-        CREATE_TRY(hipMemsetAsync(s->d_lazy, 0, nb, s->stream));
-        s->peer_amap_in[s->cfg.shard_rank] = reinterpret_cast<unsigned char*>(s->d_pos) + (1 + P) * nw * ldz * esz;
-    }
+        CREATE_TRY(dev_alloc(s, &s->d_pos, (s->push ? 1 + (size_t)s->cfg.shard_count : 1) * nw * ldz * esz ));
+    CREATE_TRY(hipMemsetAsync(s->d_pos, 0, (s->push ? 1 + (size_t)s->cfg.shard_count : 1) * nw * ldz * esz, s->stream));   // the pad column of odd ndim stays 0
     // per-walker block {logp[nrows], naccept[nrows], klast[nrows]}: one allocation, so the half-step kernels reach all
     // three from one preloaded pointer (HalfStepFront::logp)
     CREATE_TRY(dev_alloc(s, &s->d_logp, nw * (sizeof(double) + 2 * sizeof(uint32_t))));
@@ -728,7 +709,6 @@ KMC_EXPORT void kmc_sampler_destroy(kmc_sampler* s)
         }
         cache_free(s->d_flags);
         cache_free(s->d_err);
-        cache_free(s->d_done);
     }
     if (s->comm) { rccl_comm_destroy(s->comm); s->comm = nullptr; }
     if (s->copy_stream) { (void)hipStreamSynchronize(s->copy_stream); (void)hipStreamDestroy(s->copy_stream); }
@@ -741,7 +721,6 @@ KMC_EXPORT void kmc_sampler_destroy(kmc_sampler* s)
     cache_free(s->d_logp);          // the {logp, naccept, klast} block
     cache_free(s->d_mring);
     cache_free(s->d_ids);
-    cache_free(s->d_lazy);
     cache_free(s->d_mring_w);
     cache_free(s->d_mcnt);
     cache_free(s->d_gen);
@@ -861,8 +840,7 @@ KMC_EXPORT kmc_status kmc_sampler_describe(const kmc_sampler* s, char* buf, int6
         o << b;
     }
     if (s->budget_fallback) o << "; updated-graph budget of the process spent (kmc_set_updated_budget_mb): fell back to " << (s->launch_mode == 2 ? "eager launches" : "the table graph");
-    if (s->lazy) o << "; lazy pull into local copies (KMC_P2P_LAZY)";
-    else if (s->push) o << "; accepted rows pushed into the peers' local copies (KMC_P2P_PUSH)";
+    if (s->push) o << "; accepted rows pushed into the peers' local copies (KMC_P2P_PUSH)";
     if (s->f32) o << "; rows kept in float (KMC_F32), arithmetic in double";
     if (s->stream_chain) o << "; chain streamed to host memory in blocks of " << s->ring_blk << " samples (device ring of 3 blocks" << (s->dst_chain_reg || s->dst_logp_reg ? ", destination page-locked" : "") << ")";
     if (s->d_ids) o << "; dealt sub-ensemble " << s->cfg.deal_rank << "/" << s->cfg.deal_count << " (walkers re-dealt between epochs)";
@@ -899,15 +877,6 @@ KMC_EXPORT void* kmc_sampler_device_ptr(kmc_sampler* s, int which)
     }
 }
 
-// 1 when this library was built with -DKMC_P2P_EXPERIMENTAL (the push / lazy / folded-signal exchange variants exist), else 0
-KMC_EXPORT int kmc_has_p2p_experimental(void)
-{
-#ifdef KMC_P2P_EXPERIMENTAL
-    return 1;
-#else
-    return 0;
-#endif
-}
 
 KMC_EXPORT int kmc_sizeof_config(void) { return (int)sizeof(kmc_config); }
 KMC_EXPORT int kmc_sizeof_metropolis_config(void) { return (int)sizeof(kmc_metropolis_config); }

@@ -166,17 +166,11 @@ struct kmc_sampler {
     int64_t nrows = 0;                                   // rows held by this sampler (nwalkers, or nlocal for P2P)
     unsigned long long* d_flags = nullptr;               // fine-grained progress flags [shard_count]
     unsigned long long* d_err = nullptr;
-    uint32_t* d_done = nullptr;                          // KMC_P2P_FOLD_SIGNAL: workgroups drained, per launch
-    bool fold_signal = false;
     bool stream_by_walker = false;                       // KMC_STREAM_CHAIN | KMC_CHAIN_BY_WALKER: host buffers are [walker][nsamples][..]
     double *bw_scratch = nullptr, *bw_scratch_logp = nullptr;   // ... one transposed block on the device, copied out as a 2-D window (also: rows_compact of odd ndim)
     std::vector<double> bw_host;                         // ... (host buffers that could not be page-locked: a block lands here, then is scattered by memcpy)
     int64_t flushed_done = -1;                           // samples_done at the last flush of an incomplete block (nothing new: skip it)
-    bool push = false;                                   // KMC_P2P_PUSH / KMC_P2P_LAZY: d_pos = (1 + shard_count) blocks, see HalfStepArgs::push
-    bool lazy = false;                                   // KMC_P2P_LAZY: + accept-byte maps behind the blocks, stamps in d_lazy
-    bool lazy_stats = false;                             // KMC_DEBUG=p2p-stats: count remote draws / pulls (kmc_sampler_p2p_stats)
-    unsigned char* d_lazy = nullptr;                     // {stamps[P][2][h_loc] {fetched, modified}, stats[2]}
-    unsigned char* peer_amap_in[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool push = false;                                   // KMC_P2P_PUSH: d_pos = (1 + shard_count) blocks, see HalfStepArgs::push
     double* peer_pos[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     unsigned long long* peer_flags[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };

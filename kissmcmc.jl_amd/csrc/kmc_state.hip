@@ -150,7 +150,6 @@ KMC_EXPORT kmc_status kmc_sampler_init_ball(kmc_sampler* s, const double* theta0
     if (s->p2p) {
         HIP_TRY(fill_sync(s->d_flags, 0, 4096, s->stream));
         HIP_TRY(fill_sync(s->d_err, 0, 64, s->stream));
-        if (s->d_done) HIP_TRY(fill_sync(s->d_done, 0, 33 * 64, s->stream));
     }
     s->dev_gen = 0;
     s->moment_base = 0;
@@ -185,7 +184,6 @@ KMC_EXPORT kmc_status kmc_sampler_set_state(kmc_sampler* s, const double* pos_ho
     if (s->p2p) {
         HIP_TRY(fill_sync(s->d_flags, 0, 4096, s->stream));
         HIP_TRY(fill_sync(s->d_err, 0, 64, s->stream));
-        if (s->d_done) HIP_TRY(fill_sync(s->d_done, 0, 33 * 64, s->stream));
     }
     if (s->d_blob) {
         // the blobs of the restored positions: evaluated again (same kernel and order as the initial evaluation: same bits);
@@ -229,12 +227,6 @@ KMC_EXPORT kmc_status kmc_sampler_set_positions(kmc_sampler* s, const double* th
         }
         HIP_TRY(fill_sync(s->d_flags, 0, 4096, s->stream));     // callers barrier across ranks before running
         HIP_TRY(fill_sync(s->d_err, 0, 64, s->stream));
-        if (s->d_done) HIP_TRY(fill_sync(s->d_done, 0, 33 * 64, s->stream));
-        if (s->lazy) {                               // every shadow is current, nothing has been accepted yet
-            const size_t nshards = (size_t)s->cfg.shard_count;
-            HIP_TRY(fill_sync(s->d_lazy, 0, 2 * nshards * 2 * hl * sizeof(uint32_t) + 16, s->stream));
-            HIP_TRY(fill_sync(s->peer_amap_in[s->cfg.shard_rank], 0, nshards * 4 * hl, s->stream));
-        }
     }
     if (s->host_eval) {                                          // :209-210, on the caller's thread
         std::vector<double> lp0(nw);

@@ -113,18 +113,16 @@ class P2PEmcee:
     replay) like the single-GPU case.  Compared with all-gathering the updated half after every
     half-step this moves only the rows that are actually drawn (1/P of the bytes).
 
-    Variants of the exchange (all bit-identical; ``bench.py`` picks by measurement): ``push`` keeps local copies of
-    the other shards and writes accepted rows to every peer (``KMC_P2P_PUSH``); ``lazy`` keeps the same copies but
-    fills them on demand -- ranks publish their accept bytes, a reader pulls a row only when its copy is older than
-    the row's last accept (``KMC_P2P_LAZY``, ``Sampler.p2p_stats()``); ``fold_signal`` lets the half-step kernel
-    publish its own progress flag (``KMC_P2P_FOLD_SIGNAL``); ``finegrained`` puts the rows in fine-grained memory.
+    Variants of the exchange (both bit-identical, both reading partner rows with system-scope loads; ``bench.py`` checks and times both and runs the faster):
+    the default pulls every drawn row from its owner; ``push`` keeps local copies of the other shards and writes accepted rows to every peer
+    (``KMC_P2P_PUSH``: fewer bytes per link while the acceptance is below 1 / world size); ``finegrained`` puts the rows in fine-grained memory.
 
     ``torch.distributed`` (any backend) is used for the rendezvous (IPC handle exchange, barriers)
     and for assembling results.
     """
 
     def __init__(self, pdf, nwalkers, ndim, ngenerations, nburnin=0, nthin=1, a_scale=2.0, seed=0,
-                 device=0, moments=True, group=None, use_graph=True, finegrained=False, fold_signal=False, push=False, lazy=False,
+                 device=0, moments=True, group=None, use_graph=True, finegrained=False, push=False,
                  store_chain=False, store_logp=False, connect=True):
         """``connect=False``: only this rank's LOCAL set-up (sampler, buffers) -- a driver that must survive one rank failing
         here votes on the outcome before it calls :meth:`connect`, the collective part (handle exchange + IPC open)."""
@@ -137,7 +135,7 @@ class P2PEmcee:
         self.sampler = Sampler(pdf, nwalkers, ndim, ngenerations, nburnin, nthin, a_scale, seed,
                                moments=moments, use_graph=use_graph, device=device, store_chain=store_chain, store_logp=store_logp,
                                shard_rank=self.rank, shard_count=self.world, p2p=True, p2p_finegrained=finegrained,
-                               p2p_fold=fold_signal, p2p_push=push, p2p_lazy=lazy)
+                               p2p_push=push)
         self._handle = self.sampler.p2p_export() if self.world > 1 else None      # (local: the IPC handles of this rank's buffers)
         if connect:
             self.connect()

@@ -22,8 +22,8 @@ class Sampler:
                  nthin: int = 1, a_scale: float = 2.0, seed: int = 0, store_chain: bool = False,
                  store_logp: bool = False, moments: bool = False, use_graph: bool = True,
                  device: int = 0, shard_rank: int = 0, shard_count: int = 1, p2p: bool = False,
-                 island_gens: int = 0, island_size: int = 0, p2p_finegrained: bool = False, p2p_fold: bool = False, p2p_push: bool = False,
-                 dtype: str = "f64", p2p_lazy: bool = False, deal_rank: int = 0, deal_count: int = 0,
+                 island_gens: int = 0, island_size: int = 0, p2p_finegrained: bool = False, p2p_push: bool = False,
+                 dtype: str = "f64", deal_rank: int = 0, deal_count: int = 0,
                  stream_chain: bool = False, chain_by_walker: bool = False, store_blobs: bool = False):
         if not isinstance(pdf, DeviceLogPdf):
             raise TypeError(
@@ -67,12 +67,8 @@ class Sampler:
             flags |= _lib.P2P
             if p2p_finegrained:
                 flags |= _lib.P2P_FINEGRAINED
-            if p2p_fold:
-                flags |= _lib.P2P_FOLD_SIGNAL
             if p2p_push:
                 flags |= _lib.P2P_PUSH
-            if p2p_lazy:
-                flags |= _lib.P2P_LAZY
         if island_gens:
             # ISLAND MODE: 256-walker islands resident in LDS for `island_gens` generations per launch
             flags |= _lib.ISLANDS
@@ -144,12 +140,6 @@ class Sampler:
         arr = (C.c_void_p * len(shards))(*[s._h for s in shards])
         for s in shards:
             _lib.check(s._L.kmc_sampler_p2p_connect_local(s._h, arr))
-
-    def p2p_stats(self):
-        """KMC_P2P_LAZY: (partner draws on other ranks' rows, those pulled over the fabric) since set_positions."""
-        v = (C.c_uint64 * 2)()
-        _lib.check(self._L.kmc_sampler_p2p_stats(self._h, v))
-        return int(v[0]), int(v[1])
 
     @staticmethod
     def rccl_unique_id() -> bytes:

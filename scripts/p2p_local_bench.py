@@ -10,8 +10,6 @@ import time
 
 import numpy as np
 
-if "--stats" in sys.argv:
-    os.environ.setdefault("KMC_DEBUG", "p2p-stats")
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # one hardware queue per shard stream: shards spin on each other
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -29,12 +27,7 @@ with kmc.Sampler(kmc.GaussianIso(), nw, nd, G, 0, 1, 2.0, 9, moments=True) as s:
     s.sync()
     ref_pos, ref_acc = s.positions(), s.naccept()
     print(f"unsharded {nw} x {nd}: {s.last_run_ms() / (2 * G) * 1e3:.2f} us per half-step")
-from kissmcmc_jl_amd import _lib
-variants = [("pull, signal kernel", {})]
-if _lib.lib().kmc_has_p2p_experimental():        # (KMC_LIB_PATH=kissmcmc.jl_amd/libkmc_var_p2pexp.so: the -DKMC_P2P_EXPERIMENTAL build)
-    variants += [("pull, folded signal", dict(p2p_fold=True)), ("push, signal kernel", dict(p2p_push=True)), ("push, folded signal", dict(p2p_push=True, p2p_fold=True)),
-                 ("lazy pull, signal kernel", dict(p2p_lazy=True)), ("lazy pull, folded signal", dict(p2p_lazy=True, p2p_fold=True))]
-print("library:", _lib.LIB_PATH, "(experimental exchange variants)" if len(variants) > 1 else "(default: pull only)")
+variants = [("pull of drawn rows", {}), ("push of accepted rows", dict(p2p_push=True))]
 for name, kw in variants:
     shards = [kmc.Sampler(kmc.GaussianIso(), nw, nd, G, 0, 1, 2.0, 9, moments=True, shard_rank=r, shard_count=world, p2p=True, **kw)
               for r in range(world)]
@@ -59,9 +52,6 @@ for name, kw in variants:
     pos = local_to_global([sh.positions() for sh in shards], nw, world)
     ok = np.array_equal(pos, ref_pos)
     extra = ""
-    if kw.get("p2p_lazy"):
-        rem, pul = shards[0].p2p_stats()
-        extra = f"; pulled {pul / rem:.3f} of remote draws" if rem else ""
     print(f"{world} shards, {name:26s}: {best / (2 * G) * 1e6:6.2f} us per half-step (wall, all shards concurrent); "
           f"{'bit-identical' if ok else 'MISMATCH'}{extra}", flush=True)
     for sh in shards:

@@ -9,9 +9,6 @@ import time
 
 import numpy as np
 
-if "--stats" in sys.argv:
-    os.environ.setdefault("KMC_DEBUG", "p2p-stats")
-
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 NW, ND, NBURN, SEED = 8192, 32, 100, 31337
@@ -21,7 +18,7 @@ def theta0():
     return np.random.default_rng(5).standard_normal((NW, ND))
 
 
-def worker(rank, world, port, outdir, fold, push, G, lazy=False):
+def worker(rank, world, port, outdir, push, G):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     import kissmcmc_jl_amd as kmc
@@ -30,15 +27,11 @@ def worker(rank, world, port, outdir, fold, push, G, lazy=False):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        drv = P2PEmcee(kmc.GaussianIso(), NW, ND, G, NBURN, 1, 2.0, SEED, device=0, fold_signal=fold, push=push, lazy=lazy)
+        drv = P2PEmcee(kmc.GaussianIso(), NW, ND, G, NBURN, 1, 2.0, SEED, device=0, push=push)
         drv.set_positions(theta0())
         drv.run(G)
         drv.sync()
         pos, nacc = drv.positions(), drv.naccept()
-        if lazy:
-            rem, pul = drv.sampler.p2p_stats()
-            if rem:
-                print(f"   rank {rank}: {rem} remote partner draws, {pul} pulled over the fabric ({pul / rem:.3f})", flush=True)
         s, q, n = drv.moments()
         if rank == 0:
             np.savez(os.path.join(outdir, "out.npz"), pos=pos, nacc=nacc, s=s, n=n)
@@ -64,15 +57,15 @@ def main():
         pos, nacc, mom = s.positions(), s.naccept(), s.moments()
     bad = 0
     for world in (2, 4):
-        for fold, push, lazy in ((False, False, False), (True, False, False), (False, True, False), (True, True, False), (False, False, True), (True, False, True)):
+        for push in (False, True):
             with tempfile.TemporaryDirectory() as d:
                 t0 = time.time()
-                mp.spawn(worker, args=(world, free_port(), d, fold, push, G, lazy), nprocs=world, join=True)
+                mp.spawn(worker, args=(world, free_port(), d, push, G), nprocs=world, join=True)
                 z = np.load(os.path.join(d, "out.npz"))
                 ok = (np.array_equal(z["pos"], pos) and np.array_equal(z["nacc"], nacc) and int(z["n"]) == mom[2]
                       and np.allclose(z["s"], mom[0], rtol=1e-11, atol=1e-8))
                 bad += 0 if ok else 1
-                print(f"{world} ranks, {'lazy pull' if lazy else 'push' if push else 'pull'}, {'folded signal' if fold else 'signal kernel'}: "
+                print(f"{world} ranks, {'push of accepted rows' if push else 'pull of drawn rows'}: "
                       f"{G} generations {'bit-identical to the unsharded run' if ok else 'MISMATCH'}  ({time.time() - t0:.1f} s)", flush=True)
     sys.exit(1 if bad else 0)
 

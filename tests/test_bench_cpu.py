@@ -165,7 +165,7 @@ def _full_sharded(world=8, all_variants=True):
                               "bytes_received_per_gpu_per_half_step": 58720256, "execution": "RCCL all-gather of the updated half after every half-step (captured in the graph)", "note": "z" * 200}
     full["extras_timed_out"] = "'allgather-extra' did not finish within 300 s"
     full["fabric"] = {"remote_partner_bytes_per_gpu_per_launch": 7340032.0, "bytes_per_link_per_launch": 1048576.0, "link_bound_us_at_77GBs": 13.6, "push_bytes_per_link_per_launch": 1966080.0,
-                      "variants_us_per_launch": {t: 14.2 for t in tags}, "lazy_pulled_fraction_rank0": None}
+                      "variants_us_per_launch": {t: 14.2 for t in tags}}
     return full
 
 

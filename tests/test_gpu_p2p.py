@@ -41,19 +41,15 @@ def _worker(rank, world, port, outdir, plan, late_rank=-1):
     from kissmcmc_jl_amd.distributed import P2PEmcee
     if plan == "rosen-ragged":
         return _worker_rosen(rank, world, port, outdir)
-    fold = plan in ("fold", "push-fold", "lazy-fold")
-    push = plan in ("push", "push-fold")
-    lazy = plan in ("lazy", "lazy-fold")
-    if plan and not (fold or push or lazy):
+    push = plan == "push"
+    if plan and not push:
         os.environ["KMC_PLAN"] = plan
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)   # rendezvous only (same GPU: RCCL would refuse)
     try:
-        drv = P2PEmcee(kmc.GaussianIso(), NW, ND, G, NBURN, 1, 2.0, SEED, device=0, fold_signal=fold, push=push, lazy=lazy)
-        if lazy:
-            assert "lazy" in drv.sampler.describe()
-        if push and not lazy:
+        drv = P2PEmcee(kmc.GaussianIso(), NW, ND, G, NBURN, 1, 2.0, SEED, device=0, push=push)
+        if push:
             assert "KMC_P2P_PUSH" in drv.sampler.describe()
         drv.set_positions(_theta0())
         if rank == late_rank:
@@ -122,8 +118,7 @@ def _free_port():
     return rendezvous_port()
 
 
-# (the lazy / folded-signal plans of _worker: tests/p2p_experimental_cases.py, against the -DKMC_P2P_EXPERIMENTAL library; "push": accepted rows written
-#  into every peer's local copy of the shard, read there with system-scope loads -- in the default library since round 5)
+# ("push": accepted rows written into every peer's local copy of the shard, read there with system-scope loads -- round 5)
 @pytest.mark.parametrize("world,plan", [(2, ""), (4, ""), (2, "generic"), (2, "push"), (4, "push")])   # the GPU box allows 6 processes on the card: parent + 4 ranks at most
 def test_p2p_processes_sharing_one_gpu_equal_oracle(oracle, tmp_path, world, plan):
     import torch.multiprocessing as mp
@@ -303,15 +298,17 @@ def test_two_p2p_shards_with_a_runtime_compiled_density(kmc, oracle, form, kmc_d
     np.testing.assert_array_equal(nacc, ref["naccept"])
 
 
-def test_default_library_refuses_the_experimental_exchange_variants(kmc):
-    """Lazy pull / folded signal have peers write into plain device memory the local kernel reads through its own L2 (or publish completion from
-    inside the kernel) -- nothing one GPU can validate -- so the default library does not contain them: the flags are refused with the reason, by
-    validation.  (The push of accepted rows is in since round 5: its readers use system-scope loads, like the pull's.)"""
+def test_removed_exchange_variants_are_refused(kmc):
+    """Lazy pull and the folded signal (rounds 1-4, behind -DKMC_P2P_EXPERIMENTAL) read peer-written memory through the local L2 or published completion from
+    inside the kernel -- nothing one GPU can validate, and by DESIGN section 7's bytes per link unable to move the fabric bound: removed in round 5, their
+    flag bits refused by validation with the reason.  The push of accepted rows stays: its readers use system-scope loads, like the pull's."""
+    import ctypes as C
     from kissmcmc_jl_amd import _lib
-    assert _lib.lib().kmc_has_p2p_experimental() == 0
     with kmc.Sampler(kmc.GaussianIso(), NW, ND, G, NBURN, 1, 2.0, SEED, shard_rank=0, shard_count=2, p2p=True, p2p_push=True) as s:
         assert "KMC_P2P_PUSH" in s.describe()
-    for kw in (dict(p2p_lazy=True), dict(p2p_fold=True)):
-        with pytest.raises(kmc.KmcError, match="KMC_P2P_EXPERIMENTAL") as e:
-            kmc.Sampler(kmc.GaussianIso(), NW, ND, G, NBURN, 1, 2.0, SEED, shard_rank=0, shard_count=2, p2p=True, **kw)
-        assert e.value.status == _lib.ERR_UNSUPPORTED
+    for bit in (1 << 8, 1 << 10):
+        cfg = _lib.Config(dtype=_lib.F64, density=_lib.GAUSSIAN_ISO, nwalkers=NW, ndim=ND, ngenerations=G, nburnin=NBURN, nthin=1, a_scale=2.0, seed=SEED,
+                          flags=_lib.P2P | bit, device=0, shard_rank=0, shard_count=2)
+        cfg.params[0], cfg.params[1] = 0.0, 1.0
+        assert _lib.lib().kmc_validate(C.byref(cfg)) == _lib.ERR_UNSUPPORTED
+        assert b"removed in round 5" in _lib.lib().kmc_last_error()
