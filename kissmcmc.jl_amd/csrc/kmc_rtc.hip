@@ -580,7 +580,6 @@ kmc_status compile_user(kmc_user_density* ud, bool with_vec, int L, int K, int i
     src << "#include \"kmc_islands.hpp\"\n#include \"kmc_generation.hpp\"\n" << user_functor_source(ud) << user_density_alias(ud, ndim)
         << (ud->is_body && with_vec && sep_routed(ud) ? ud->sep_functor + (ud->sep_nacc > 1 ? "using UDV = kmc::SepDensityN<UserS>;\n" : "using UDV = kmc::SepDensity<UserS>;\n")
                                                 : std::string("using UDV = UD;\n"))
-        << "extern \"C\" __device__ const unsigned kmc_user_args_bytes[4] = {(unsigned)sizeof(kmc::HalfStepArgs), (unsigned)sizeof(kmc::GenerationArgs), (unsigned)sizeof(kmc::ResidentArgs), (unsigned)sizeof(kmc::LogpdfArgs)};\n"
         << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_generic(KMC_FRONT_PARAMS, const kmc::HalfStepArgs a) { kmc::half_step_generic_body<UD, " << peer << ", " << rowt << ">(KMC_FRONT_PACK, a); }\n"
         << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_logpdf(const kmc::LogpdfArgs a) { kmc::logpdf_rows_body<UD>(a); }\n"
         << "extern \"C\" __global__ __launch_bounds__(256) void kmc_user_init_ball(const kmc::InitBallArgs a) { kmc::init_ball_body<UD>(a); }\n";
@@ -644,20 +643,6 @@ kmc_status load_user(kmc_user_density* ud, bool with_vec, int L, int K, int iter
         }
         uk->keep = slot;
         uk->mod = static_cast<hipModule_t>(slot.get());
-    }
-    {   // the module's argument structs must be the host's, byte for byte (a module built with other options would read every field
-        // after the first difference from the wrong offset -- silently)
-        hipDeviceptr_t sym = nullptr;
-        size_t nbytes = 0;
-        unsigned theirs[4] = {0, 0, 0, 0};
-        HIP_TRY(hipModuleGetGlobal(&sym, &nbytes, uk->mod, "kmc_user_args_bytes"));
-        if (nbytes != sizeof(theirs)) return fail(KMC_ERR_HIP, "runtime-compiled module: kmc_user_args_bytes has an unexpected size");
-        HIP_TRY(hipMemcpyDtoH(theirs, sym, sizeof(theirs)));
-        const unsigned ours[4] = {(unsigned)sizeof(kmc::HalfStepArgs), (unsigned)sizeof(kmc::GenerationArgs), (unsigned)sizeof(kmc::ResidentArgs), (unsigned)sizeof(kmc::LogpdfArgs)};
-        for (int i = 0; i < 4; ++i)
-            if (ours[i] != theirs[i])
-                return fail(KMC_ERR_HIP, "runtime-compiled module and library disagree on a kernel argument layout (" + std::to_string(theirs[i]) + " against " + std::to_string(ours[i]) +
-                                         " bytes): stale cache or mismatched build options");
     }
     HIP_TRY(hipModuleGetFunction(&uk->generic, uk->mod, "kmc_user_generic"));
     HIP_TRY(hipModuleGetFunction(&uk->logpdf, uk->mod, "kmc_user_logpdf"));
