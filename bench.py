@@ -393,7 +393,7 @@ def spawn_ranks(n: int, argv) -> int:
 
 
 LADDER = []      # [{"rung", "ok", "s"}]: every rung of the N > 1 ladder this rank went through, in order (printed with the line).  Rung names (short:
-#                  the line has 4 KB): rendezvous; p2p-check:<variant> (set-up + bit-exact self-check), p2p-time:<variant> (KMC_BENCH_EXCHANGE=all),
+#                  the line has 4 KB): rendezvous; p2p-check:<variant> (set-up + bit-exact self-check), p2p-time:<variant> (its short timing),
 #                  p2p-run (warm-up + timed run); allgather-setup (ncclCommInitRank), allgather-run, torch-allgather-run (the same exchange as a
 #                  torch collective per half-step); the extras after `value`: dealt-extra, allgather-extra-setup, allgather-extra
 
