@@ -42,7 +42,9 @@ struct GenerationArgs {
     int32_t           ndim;
     double*           chain;        // [nsamples][nwalkers][ld] or nullptr              (:269)
     double*           chain_logp;   // [nsamples][nwalkers] or nullptr                  (:271)
-    double*           msum;         // [nwalkers][ld] per-walker sums of the stored samples (laid out like the rows; read out in walker order), or nullptr
+    double*           msum;         // [nwalkers][ld] per-walker sums of the stored samples (laid out like the rows; read out in walker order), or nullptr;
+                                    //   generation_group with K == 2 and L = 8 / 16 / 32: per-WAVE accumulators [waves][NVL][64] in half_step_vec's transposed
+                                    //   layout (kmc_kernels.hpp: FoldT) -- msumsq unused
     double*           msumsq;
     // lane-striped form (generation_group) only:
     uint32_t*         klast;        // [nwalkers] samples a walker's CURRENT value has already been credited for: its moments are sojourn-weighted like the
@@ -301,8 +303,22 @@ __device__ __forceinline__ void generation_group_body(const GenerationFront& f, 
     const uint32_t gl = a.glast[me];
     uint32_t kl = 0u;
     if (moments) kl = a.klast[me];
+    // Moment accumulators.  K == 2, L = 8 / 16 / 32: one set per WAVE in half_step_vec's transposed layout (the wave's 64 / L walkers fold their credits with
+    // the same reduce-scatter; 8 L / 64 doubles per lane) -- a per-walker pair of sums read with every row was 47 % of this kernel's read bytes at 16 384 x 64
+    // (profiles/r05_generation_summary.json: 35.8 MB per generation, 16.8 of them the sums).  Other geometries: per-walker sums laid out like the rows.
+    constexpr bool kFold = FoldT<L, K>::on;
+    const int lane = (int)(threadIdx.x & 63u);
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     double2 m1[K], m2[K];
-    if (moments) { row(a.msum, me, m1); row(a.msumsq, me, m2); }                     // (issued with the rows, used -- and rewritten -- only if my move is accepted)
+    double acct[4] = {0.0, 0.0, 0.0, 0.0};
+    if constexpr (kFold) {
+        if (moments) {
+#pragma unroll
+            for (int r = 0; r < FoldT<L, K>::NVL; ++r) acct[r] = a.msum[(wave * FoldT<L, K>::NVL + r) * 64 + lane];
+        }
+    } else {
+        if (moments) { row(a.msum, me, m1); row(a.msumsq, me, m2); }                 // (issued with the rows, used -- and rewritten -- only if my move is accepted)
+    }
     // :252 -- both moves' draws now (see generation_lane_body).  Their four logarithms are most of a lane's chain here (~0.2 us each: dependent
     // fp64 operations of a wave that has its SIMD to itself), and the lanes of a quad belong to one walker when L >= 4: each computes ONE of
     // them -- same function, same argument, hence the same bits as draw_finish -- and the quad shares the results.
@@ -356,14 +372,28 @@ __device__ __forceinline__ void generation_group_body(const GenerationFront& f, 
             p0 = myp0;
         }
     }
-    if (!valid) return;
     // Streaming moments, sojourn-weighted (the two-launch kernels' rule, kmc_kernels.hpp): the value this move replaces is credited now, times the samples it
     // stood for; nothing is written for a walker that stays.  Round 4 rewrote both sums of every walker with every sample (7.5 x the state per generation in
-    // all; now 4.5 x read + what is accepted: 8 192 x 64 3.46 -> 2.59 us per half-step).  Tried instead of reading the sums with the rows: no-return fp64
-    // atomic adds on accept (nothing read for a walker that stays) -- slower at every shape, the L2 retires about one 8-byte add per channel per 3-4 cycles
-    // (C2-sized: 6.82 against 6.16 us, 32 768 x 16: 3.46 against 2.85; profiles/r05_generation_mid.txt).  `own` is my row before my move.
-    if (acc && moments) {
-        const double wgt = (double)(sch.nbefore - kl);
+    // all; 8 192 x 64 3.46 -> 2.59 us per half-step without that).  Tried instead of reading accumulators up front: no-return fp64 atomic adds on accept --
+    // slower at every shape, the L2 retires about one 8-byte add per channel per 3-4 cycles (profiles/r05_generation_mid.txt).  `own` is my row before my move.
+    const double wgt = (valid && acc && moments) ? (double)(sch.nbefore - kl) : 0.0;
+    if constexpr (kFold) {
+        if (moments && __ballot(wgt != 0.0) != 0ull) {                   // (wave-uniform: every lane takes part in the fold, idle groups with zeros)
+            double2 ms[K], mq[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                ms[k] = make_double2(own[k].x * wgt, own[k].y * wgt);
+                mq[k] = make_double2((own[k].x * own[k].x) * wgt, (own[k].y * own[k].y) * wgt);
+            }
+            double v[8];
+            fold_scatter<L, K>(lane, ms, mq, v);
+            double* slot = a.msum + (wave * FoldT<L, K>::NVL) * 64 + lane;
+#pragma unroll
+            for (int r = 0; r < FoldT<L, K>::NVL; ++r) slot[r * 64] = acct[r] + v[r];
+        }
+    }
+    if (!valid) return;
+    if constexpr (!kFold) {
         if (wgt != 0.0) {
             double* s1 = a.msum + (size_t)me * (size_t)ld;
             double* s2 = a.msumsq + (size_t)me * (size_t)ld;
@@ -375,8 +405,8 @@ __device__ __forceinline__ void generation_group_body(const GenerationFront& f, 
                     *reinterpret_cast<double2*>(&s2[e]) = make_double2(m2[k].x + (own[k].x * own[k].x) * wgt, m2[k].y + (own[k].y * own[k].y) * wgt);
                 }
         }
-        if (j == 0) a.klast[me] = sch.nbefore;
     }
+    if (acc && moments && j == 0) a.klast[me] = sch.nbefore;
 #pragma unroll
     for (int k = 0; k < K; ++k) { y[k].x = acc ? y[k].x : own[k].x; y[k].y = acc ? y[k].y : own[k].y; }   // :261
     const double pnew = acc ? p1 : p0;                                   // :262

@@ -262,20 +262,23 @@ hipError_t generation_settle(kmc_sampler* s)
 
 // A sampler that runs one launch per generation goes back to its two-launch kernels, in place and for good (everything they need was set up
 // at creation): for a caller that steps by halves (kmc_sampler_half_step) or attaches an RCCL communicator (an all-gather follows every
-// half-step).  Moments credited so far stay where they are (per-walker sums, d_isum) and are added at read-out; the one-walker-per-lane
-// form has credited every sample taken, so the walkers' current values stand for the samples from here on.
+// half-step).  The moments credited so far -- every walker's current value included, up to now -- are read out once and carried on the host
+// (added at every later read-out); the walkers' current values stand for the samples from here on (klast = samples taken).
 kmc_status unfuse(kmc_sampler* s)
 {
     if (!s->fused) return KMC_OK;
     HIP_TRY(generation_settle(s));
     HIP_TRY(hipStreamSynchronize(s->stream));
+    if (s->d_msum && s->d_isum && s->generation > 0) {
+        std::vector<double> S((size_t)s->cfg.ndim), Q((size_t)s->cfg.ndim);
+        int64_t n = 0;
+        KMC_TRY(kmc_sampler_get_moments(s, S.data(), Q.data(), &n));         // (still the fused read-out: sums + the walkers' current values)
+        if (s->carry_sum.empty()) { s->carry_sum.assign(S.size(), 0.0); s->carry_sumsq.assign(Q.size(), 0.0); }
+        for (size_t d = 0; d < S.size(); ++d) { s->carry_sum[d] += S[d]; s->carry_sumsq[d] += Q[d]; }
+        if (s->d_klast) HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)s->d_klast, (int)(uint32_t)samples_done(s), (size_t)s->nrows, s->stream));
+    }
     if (s->graph_exec) { (void)hipGraphExecDestroy(s->graph_exec); s->graph_exec = nullptr; }
     if (s->graph) { (void)hipGraphDestroy(s->graph); s->graph = nullptr; }
-    if (s->d_msum && s->d_isum && s->generation > 0) {
-        if (s->fused_L == 0 && s->d_klast)
-            HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)s->d_klast, (int)(uint32_t)samples_done(s), (size_t)s->nrows, s->stream));
-        s->isum_carry = true;
-    }
     s->fused = false;
     s->launch_mode = 0;
     return KMC_OK;

@@ -486,6 +486,12 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
             s->fused_tpb = (kind == 2 && s->h * s->plan.L > 64 * 512) ? 128 : 64;
             s->nislands = cfg->nwalkers;                  // per-walker moment sums [nwalkers][ld], within [nislands][4 island_K] (kmc_sampler_get_moments)
             s->island_K = (int)((s->ld + 3) / 4);
+            s->fused_fold = s->fused_L > 0 && s->plan.K == 2 && (s->fused_L == 8 || s->fused_L == 16 || s->fused_L == 32) && kind == 2;
+            if (s->fused_fold) {                          // ... or per-wave accumulators [waves][NVL][64] (generation_group, FoldT): the same sizing fields
+                const int64_t per_wg = s->fused_tpb / s->fused_L;
+                s->nislands = 2 * ((s->h + per_wg - 1) / per_wg) * (s->fused_tpb / 64);      // waves of a launch
+                s->island_K = (8 * s->fused_L / 64) * 16;                                     // 4 island_K = NVL * 64 doubles per wave
+            }
         }
     }
     // vec kernels: vec_tpb(L) threads per workgroup; the generic kernel keeps 256

@@ -146,7 +146,8 @@ struct kmc_sampler {
     double* d_logp2 = nullptr;
     bool sep_off = false;              // a body density recognised as a sum over elements whose check was blind at THIS sampler's ndim / parameters: run as written
     std::string sep_off_note;
-    bool isum_carry = false;           // a sampler that left this mode after it had run (unfuse): d_isum / d_isumsq hold moments credited so far
+    bool fused_fold = false;           // lane-striped form with K == 2, L = 8 / 16 / 32: moment accumulators per WAVE in the vector kernels' transposed layout (d_isum)
+    std::vector<double> carry_sum, carry_sumsq;   // a sampler that left this mode after it had run (unfuse): the moments credited until then, per dimension
     uint32_t* d_glast = nullptr;       // lane-striped form: 1 + the generation of every walker's last accepted move (GenerationArgs::glast)
     int fused_cur = 0;                 // which pair holds the state at the tail of the stream (0 between kmc_sampler_run calls)
     int fused_L = 0;                   // 0: one walker per lane (generation_lane, ndim <= 8); else rows striped over L lanes (generation_group<L, plan.K>)

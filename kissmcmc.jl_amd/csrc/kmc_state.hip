@@ -71,6 +71,7 @@ kmc_status reset_run_state(kmc_sampler* s, bool eval_logp, int64_t generation, u
             HIP_TRY(hipMemsetAsync(s->d_isum, 0, ne * sizeof(double), s->stream));
             HIP_TRY(hipMemsetAsync(s->d_isumsq, 0, ne * sizeof(double), s->stream));
         }
+        s->carry_sum.clear(); s->carry_sumsq.clear();
     }
     HIP_TRY(hipStreamSynchronize(s->stream));
     s->generation = generation;
@@ -252,6 +253,7 @@ KMC_EXPORT kmc_status kmc_sampler_set_positions(kmc_sampler* s, const double* th
             HIP_TRY(hipMemsetAsync(s->d_isum, 0, ne * sizeof(double), s->stream));
             HIP_TRY(hipMemsetAsync(s->d_isumsq, 0, ne * sizeof(double), s->stream));
         }
+        s->carry_sum.clear(); s->carry_sumsq.clear();
     }
     if (s->d_ids) {                                              // dealt sub-ensembles: slot i holds global walker r S + i
         hipLaunchKernelGGL(deal_init_ids, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s->stream, s->d_ids, (int64_t)nw,
@@ -323,15 +325,33 @@ KMC_EXPORT kmc_status kmc_sampler_get_moments(kmc_sampler* s, double* sum, doubl
     if (!s->d_msum) return fail(KMC_ERR_BAD_ARG, "sampler was created without KMC_MOMENTS");
     HIP_TRY(hipSetDevice(s->cfg.device));
     if (s->fused) {
-        // one launch per generation: per-walker sums [nwalkers][ld] (laid out like the rows), added up in walker order
+        // one launch per generation: per-walker sums [nwalkers][ld] (laid out like the rows), added up in walker order -- or, lane-striped rows with
+        // K == 2 and L = 8 / 16 / 32, per-wave accumulators in the vector kernels' transposed layout (kmc_kernels.hpp: FoldT), added up in wave order
         HIP_TRY(hipStreamSynchronize(s->stream));
         const int64_t nd = s->cfg.ndim, nw = s->cfg.nwalkers, ld = s->ld;
-        std::vector<double> hs((size_t)(ld * nw)), hq((size_t)(ld * nw));
-        HIP_TRY(copy_sync(hs.data(), s->d_isum, hs.size() * sizeof(double), hipMemcpyDeviceToHost, s->stream));
-        HIP_TRY(copy_sync(hq.data(), s->d_isumsq, hq.size() * sizeof(double), hipMemcpyDeviceToHost, s->stream));
         std::vector<double> S((size_t)nd, 0.0), Q((size_t)nd, 0.0);
-        for (int64_t w = 0; w < nw; ++w)
-            for (int64_t d = 0; d < nd; ++d) { S[(size_t)d] += hs[(size_t)(w * ld + d)]; Q[(size_t)d] += hq[(size_t)(w * ld + d)]; }
+        if (s->fused_fold) {
+            const int L = s->fused_L, NVL = 8 * L / 64;
+            const int64_t nwaves = s->nislands;
+            std::vector<double> hs((size_t)(nwaves * NVL * 64));
+            HIP_TRY(copy_sync(hs.data(), s->d_isum, hs.size() * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+            for (int64_t w = 0; w < nwaves; ++w)
+                for (int r = 0; r < NVL; ++r)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int b3 = (lane >> 3) & 1, b4 = (lane >> 4) & 1, b5 = (lane >> 5) & 1;
+                        const int v = L == 8 ? 4 * b3 + 2 * b4 + b5 : L == 16 ? 4 * b4 + 2 * b5 + r : 4 * b5 + r;
+                        const int64_t d = 2 * ((int64_t)((v >> 1) & 1) * L + (lane & (L - 1))) + (v & 1);
+                        if (d >= nd) continue;
+                        const double x = hs[(size_t)((w * NVL + r) * 64 + lane)];
+                        if (v >> 2) Q[(size_t)d] += x; else S[(size_t)d] += x;
+                    }
+        } else {
+            std::vector<double> hs((size_t)(ld * nw)), hq((size_t)(ld * nw));
+            HIP_TRY(copy_sync(hs.data(), s->d_isum, hs.size() * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+            HIP_TRY(copy_sync(hq.data(), s->d_isumsq, hq.size() * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+            for (int64_t w = 0; w < nw; ++w)
+                for (int64_t d = 0; d < nd; ++d) { S[(size_t)d] += hs[(size_t)(w * ld + d)]; Q[(size_t)d] += hq[(size_t)(w * ld + d)]; }
+        }
         if (s->fused_L > 0) {
             // the lane-striped form credits a value when it is replaced (sojourn weights, like the two-launch kernels): every walker's CURRENT value
             // still stands for the samples taken since its last move -- credited here, on the host, leaving the device state as it is
@@ -420,15 +440,8 @@ KMC_EXPORT kmc_status kmc_sampler_get_moments(kmc_sampler* s, double* sum, doubl
                 Q[d] += hq[d * s->macc_stride + t];
             }
     }
-    if (s->isum_carry) {
-        // what the sampler credited while it ran one launch per generation (unfuse): per-walker sums laid out like the rows
-        const int64_t nw = s->cfg.nwalkers, ld = s->ld;
-        std::vector<double> cs((size_t)(ld * nw)), cq((size_t)(ld * nw));
-        HIP_TRY(copy_sync(cs.data(), s->d_isum, cs.size() * sizeof(double), hipMemcpyDeviceToHost, s->stream));
-        HIP_TRY(copy_sync(cq.data(), s->d_isumsq, cq.size() * sizeof(double), hipMemcpyDeviceToHost, s->stream));
-        for (int64_t w = 0; w < nw; ++w)
-            for (int64_t d = 0; d < nd; ++d) { S[(size_t)d] += cs[(size_t)(w * ld + d)]; Q[(size_t)d] += cq[(size_t)(w * ld + d)]; }
-    }
+    if (!s->carry_sum.empty())                    // what the sampler credited while it ran one launch per generation (unfuse)
+        for (int64_t d = 0; d < nd; ++d) { S[(size_t)d] += s->carry_sum[(size_t)d]; Q[(size_t)d] += s->carry_sumsq[(size_t)d]; }
     for (int64_t d = 0; d < nd; ++d) {
         if (sum) sum[d] = S[d];
         if (sumsq) sumsq[d] = Q[d];

@@ -1,7 +1,7 @@
 """Run one BASELINE config twice for a number of generations -- warm-up, then timed (a plain target for rocprofv3).
 Usage: python3 scripts/run_cfg.py C5 [generations] [moments 0/1]
 HBM32 / HBM128: the HBM-resident shapes of bench.py's other_configs (state 512 MiB; initial ensemble drawn on the device);
-MID4K / MID16K: 4096 / 16384 walkers x 4 dims (bench.py's MID_* lines)."""
+MID4K / MID16K: 4096 / 16384 walkers x 4 dims (bench.py's MID_* lines); MID8Kx64 / MID16Kx32: 4 MiB of state."""
 import os
 import sys
 
@@ -19,6 +19,8 @@ CONFIGS = {
     "HBM128": (kmc.GaussianIso(), 524288, 128),
     "MID4K": (kmc.GaussianIso(), 4096, 4),          # mid-size ensembles with short rows: one launch per generation (KMC_DEBUG=fused=0: two)
     "MID16K": (kmc.GaussianIso(), 16384, 4),
+    "MID8Kx64": (kmc.GaussianIso(), 8192, 64),      # 4 MiB of state: the lane-striped one-launch-per-generation form since round 5 (KMC_DEBUG=fused=0: two launches)
+    "MID16Kx32": (kmc.GaussianIso(), 16384, 32),
 }
 name = sys.argv[1]
 G = int(sys.argv[2]) if len(sys.argv) > 2 else 256

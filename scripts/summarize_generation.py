@@ -1,4 +1,4 @@
-"""Condense the passes of scripts/profile_generation.sh (gpurun_out/prof_gen/<cfg>_<one|two>/) into profiles/r04_generation_summary.json:
+"""Condense the passes of scripts/profile_generation.sh (gpurun_out/prof_gen/<cfg>_<one|two>/) into profiles/<tag>_generation_summary.json (python scripts/summarize_generation.py <tag> [cfg ...]):
 per job and mode the dominant kernel's dispatch count, duration and begin-to-begin period from the kernel trace (second half of the
 dispatches), next to the HIP-event figure of the same profiled process and of an unprofiled one."""
 import glob
@@ -23,13 +23,19 @@ def us_of(path):
     return (float(m.group(1)) if m else None), (how[-1] if how else None)
 
 
-out = {"tag": "r04", "command": "rocprofv3 --kernel-trace --stats --output-format csv -- python3 scripts/run_cfg.py <MID4K|MID16K> 4096 1 (KMC_DEBUG=fused=0 for the two-launch rows)", "jobs": {}}
-for cfg, shape in (("MID4K", "4096 walkers x 4 dims"), ("MID16K", "16384 walkers x 4 dims")):
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"
+SHAPES = {"MID4K": "4096 walkers x 4 dims", "MID16K": "16384 walkers x 4 dims", "MID8Kx64": "8192 walkers x 64 dims", "MID16Kx32": "16384 walkers x 32 dims",
+          "C3": "16384 walkers x 64 dims, chained Rosenbrock"}
+CFGS = sys.argv[2:] or ["MID4K", "MID16K"]
+out = {"tag": TAG, "command": "rocprofv3 --kernel-trace --stats --output-format csv -- python3 scripts/run_cfg.py <cfg> 4096 1 (KMC_DEBUG=fused=1 / fused=0 for the one- / two-launch rows); "
+                              "PMC: the same under --pmc <group> --kernel-trace, one group per pass", "jobs": {}}
+for cfg in CFGS:
+    shape = SHAPES[cfg]
     for mode in ("one", "two"):
         tr = glob.glob(os.path.join(SRC, f"{cfg}_{mode}", "**", "*kernel_trace.csv"), recursive=True)
         if not tr:
             continue
-        base.KEY = "generation_lane" if mode == "one" else "half_step"
+        base.KEY = "generation_" if mode == "one" else "half_step"
         st = base.trace_stats(tr[0])
         st.pop("excerpt_12_consecutive_dispatches", None)
         us_prof, how = us_of(os.path.join(SRC, f"{cfg}_{mode}_kt.txt"))
@@ -51,7 +57,7 @@ for cfg, shape in (("MID4K", "4096 walkers x 4 dims"), ("MID16K", "16384 walkers
                    "us_per_half_step_hip_events_profiled_process": us_prof, "us_per_half_step_hip_events_unprofiled": us_plain,
                    "us_per_half_step_from_trace_period": st["period_us_from_trace"]["mean"] * per_gen / 2.0})
         out["jobs"][f"{cfg}_{mode}_launch{'es' if per_gen == 2 else ''}_per_generation"] = st
-json.dump(out, open(os.path.join(ROOT, "profiles", "r04_generation_summary.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(ROOT, "profiles", f"{TAG}_generation_summary.json"), "w"), indent=1)
 for k, v in out["jobs"].items():
     if "pmc_per_launch" in v:
         print("   PMC per launch: read", round(v["pmc_per_launch"]["hbm_read_bytes"] / 1e6, 3), "MB, written", round(v["pmc_per_launch"]["hbm_write_bytes"] / 1e6, 3), "MB, L2 hit", v["pmc_per_launch"]["l2_hit_rate"])
