@@ -543,11 +543,13 @@ KMC_EXPORT kmc_status kmc_sampler_run(kmc_sampler* s, int64_t ngen)
         // started, in d_pos / d_logp), the rest launch by launch; the state is moved back into d_pos / d_logp at the end
         const char* forced = std::getenv("KMC_LAUNCH");
         const bool use_graph = !(s->cfg.flags & KMC_NO_GRAPH) && !(forced && std::strcmp(forced, "eager") == 0);
-        if (s->fused_L > 0 && ngen > 0) {
-            // the lane-striped form writes a row to the output copy only when that copy does not hold it already: both copies start a run equal
-            // (whoever changed d_pos / d_logp since the last run -- set_positions, set_state, the initial ball -- changed only the first pair)
+        if (s->fused_L > 0 && ngen > 0 && !(s->pos2_current && s->own_pos && !s->pos_exposed)) {
+            // the lane-striped form writes a row to the output copy only when that copy does not hold it already: the copies are made equal whenever
+            // somebody may have changed d_pos / d_logp since the last run (set_positions, set_state, the initial ball: they write the first pair only;
+            // a caller-owned buffer -- kmc_sampler_bind_positions -- may change at any time: every run); between runs the kernels keep them consistent
             HIP_TRY(hipMemcpyAsync(s->d_pos2, s->d_pos, (size_t)s->nrows * (size_t)s->ld * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
             HIP_TRY(hipMemcpyAsync(s->d_logp2, s->d_logp, (size_t)s->nrows * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+            s->pos2_current = true;
         }
         while (use_graph && ngen >= kGraphChunk) {
             HIP_TRY(generation_settle(s));

@@ -797,6 +797,7 @@ KMC_EXPORT kmc_status kmc_sampler_bind_positions(kmc_sampler* s, void* pos_dev)
     }
     s->d_pos = static_cast<double*>(pos_dev);
     s->own_pos = false;
+    s->pos2_current = false;
     s->positions_set = false;
     return KMC_OK;
 }
@@ -878,6 +879,7 @@ KMC_EXPORT kmc_status kmc_sampler_describe(const kmc_sampler* s, char* buf, int6
 KMC_EXPORT void* kmc_sampler_device_ptr(kmc_sampler* s, int which)
 {
     if (!s) return nullptr;
+    if (which == 0 || which == 1) s->pos_exposed = true;         // (the caller may write there: a one-launch-per-generation sampler then re-synchronises its second copy before every run)
     switch (which) {
     case 0: return s->d_pos;
     case 1: return s->d_logp;

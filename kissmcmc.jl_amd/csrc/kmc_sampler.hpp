@@ -146,6 +146,8 @@ struct kmc_sampler {
     double* d_logp2 = nullptr;
     bool sep_off = false;              // a body density recognised as a sum over elements whose check was blind at THIS sampler's ndim / parameters: run as written
     std::string sep_off_note;
+    bool pos_exposed = false;          // kmc_sampler_device_ptr handed d_pos / d_logp out
+    bool pos2_current = false;         // lane-striped form: the second copy of the state is consistent with the first (nobody has written d_pos / d_logp since the last run)
     bool fused_fold = false;           // lane-striped form with K == 2, L = 8 / 16 / 32: moment accumulators per WAVE in the vector kernels' transposed layout (d_isum)
     std::vector<double> carry_sum, carry_sumsq;   // a sampler that left this mode after it had run (unfuse): the moments credited until then, per dimension
     uint32_t* d_glast = nullptr;       // lane-striped form: 1 + the generation of every walker's last accepted move (GenerationArgs::glast)

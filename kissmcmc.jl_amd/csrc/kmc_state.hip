@@ -74,6 +74,7 @@ kmc_status reset_run_state(kmc_sampler* s, bool eval_logp, int64_t generation, u
         s->carry_sum.clear(); s->carry_sumsq.clear();
     }
     HIP_TRY(hipStreamSynchronize(s->stream));
+    s->pos2_current = false;
     s->generation = generation;
     s->launches = 0;
     s->have_run_events = false;
@@ -261,6 +262,7 @@ KMC_EXPORT kmc_status kmc_sampler_set_positions(kmc_sampler* s, const double* th
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipStreamSynchronize(s->stream));
+    s->pos2_current = false;
     s->generation = 0;
     s->dev_gen = 0;
     s->moment_base = 0;
