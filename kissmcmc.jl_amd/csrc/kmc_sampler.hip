@@ -551,8 +551,19 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
     CREATE_TRY(dev_alloc(s, &s->d_sched, (size_t)kGraphChunk * sizeof(SchedEntry)));
     CREATE_TRY(hipMemsetAsync(s->d_naccept, 0, nw * sizeof(uint32_t), s->stream));
     if (cfg->deal_count > 0) CREATE_TRY(dev_alloc(s, (void**)&s->d_ids, nw * sizeof(uint32_t)));
-    if (s->plan.vec && !s->islands && !s->resident && s->plan.L >= 16 && s->plan.L <= 32 && s->plan.L / s->plan.ITER >= 2) {
-        // draw ring: 4 slots x rows x 32 B; tags start at 0xffffffff (no step carries it), so nothing is "parked" yet
+    // Draw ring (kmc_kernels.hpp: kRing; possible for L = 16 / 32 with L / ITER >= 2): a wave computes its walkers' next steps' draws with its idle lanes and parks
+    // them, 4 slots x rows x 32 B; tags start at 0xffffffff (no step carries it), so nothing is "parked" yet.  Where it pays was re-measured in round 5
+    // (scripts/probes/ring_ab.py, profiles/r05_ring_ab.txt) -- since the launches carry their step among the preloaded parameters Philox starts at wave entry and the
+    // ring's entry is one more dependent load in front of the partner row: ragged rows gain 6-10 % from it (ITER <= 2), exact-size rows LOSE 1-8 % (ITER = 2; L = 32)
+    // and 6-14 % in the large-ensemble geometries (ITER >= 4: bandwidth-bound, the ring is bytes); C3's own geometry (L = 16, ITER = 1, exact) is neutral and keeps it.
+    // KMC_DEBUG=ring=0|1 forces it off / on wherever the kernel has one.
+    bool want_ring = s->plan.vec && !s->islands && !s->resident && s->plan.L >= 16 && s->plan.L <= 32 && s->plan.L / s->plan.ITER >= 2;
+    {
+        std::string forced;
+        if (want_ring && debug_opt("ring", &forced)) want_ring = forced != "0";
+        else if (want_ring) want_ring = s->plan.ragged ? s->plan.ITER < 4 : (s->plan.L == 16 && s->plan.ITER == 1);
+    }
+    if (want_ring) {
         const size_t nb = 4 * (size_t)s->nrows * 2 * sizeof(double2);
         CREATE_TRY(dev_alloc(s, (void**)&s->d_ring, nb));
         CREATE_TRY(hipMemsetAsync(s->d_ring, 0xff, nb, s->stream));
