@@ -377,7 +377,7 @@ int64_t     kmc_sampler_launch_count(const kmc_sampler* s);
 /* How kmc_sampler_run issues this sampler's launches (same kernels, same results in every mode; reference
  * src/samplers.jl:245-247 -- the generation x half-step loop -- is what the modes enqueue).  *budget_fallback (may be NULL)
  * becomes 1 when the sampler is not in the updated-graph mode because the PROCESS-WIDE budget of graph parameter updates was
- * spent (the HIP runtime leaks ~80 B of host memory per update; 64 MiB worth by default, KMC_DEBUG=updated-budget-mb=n in the
+ * spent (the HIP runtime keeps host memory per update, ~80 B in HIP 7.0 -- the runtime a PyTorch wheel brings -- and ~1.4 B in 7.2; 64 MiB worth by default, priced by hipRuntimeGetVersion, KMC_DEBUG=updated-budget-mb=n in the
  * environment or kmc_set_updated_budget_mb): said once on stderr, in kmc_sampler_describe, and here. */
 #define KMC_LAUNCH_UNDECIDED     0   /* only short runs so far: whole chunks from the table graph, the rest eagerly */
 #define KMC_LAUNCH_TABLE_GRAPH   1   /* hipGraph replay of 64 generations, schedule read from a device table (also: one launch per generation) */
@@ -386,7 +386,7 @@ int64_t     kmc_sampler_launch_count(const kmc_sampler* s);
 #define KMC_LAUNCH_SINGLE        4   /* resident / island kernels (many generations per launch), host-evaluated density */
 int         kmc_sampler_launch_mode(const kmc_sampler* s, int* budget_fallback);
 void        kmc_updated_budget(int64_t* calls_used, int64_t* calls_budget);   /* parameter updates so far / allowed, this process */
-void        kmc_set_updated_budget_mb(double mb);                              /* 80 B per update; <= 0: no updated-graph mode from now on */
+void        kmc_set_updated_budget_mb(double mb);                              /* priced at 80 B (HIP < 7.2) or 2 B per update; <= 0: no updated-graph mode from now on */
 
 /* One line describing how this sampler executes (kernel family and geometry, exchange scheme). */
 kmc_status  kmc_sampler_describe(const kmc_sampler* s, char* buf, int64_t buflen);

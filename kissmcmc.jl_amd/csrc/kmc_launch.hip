@@ -387,8 +387,17 @@ kmc_status ensure_updated_graph(kmc_sampler* s)
     return KMC_OK;
 }
 
-// hipGraphExecKernelNodeSetParams leaks ~80 bytes per call inside the runtime (kmc_sampler_run: launch modes): a process-wide
-// budget of such calls -- 64 MiB worth by default
+// hipGraphExecKernelNodeSetParams keeps host memory inside the runtime, per call and for good (kmc_sampler_run: launch modes): ~80 bytes in the HIP 7.0 runtime (the one
+// PyTorch's wheel bundles and a Python process therefore runs on), ~1.4 bytes in 7.2 (/opt/rocm of this image; scripts/probes/updated_graph_rss.py, profiles/r05_updated_graph_rss.txt).
+// A process-wide budget of such calls -- 64 MiB worth by default, priced by the runtime this process actually loaded.
+double update_bytes_each()
+{
+    static const double b = [] {
+        int v = 0;
+        return (hipRuntimeGetVersion(&v) == hipSuccess && v >= 70200000) ? 2.0 : 80.0;
+    }();
+    return b;
+}
 std::atomic<int64_t> g_update_calls{0};
 std::atomic<int64_t>& update_budget()
 {
@@ -396,7 +405,7 @@ std::atomic<int64_t>& update_budget()
         double mb = 64.0;
         std::string v;
         if (debug_opt("updated-budget-mb", &v) && !v.empty()) mb = std::atof(v.c_str());
-        return (int64_t)(mb * 1048576.0 / 80.0);
+        return (int64_t)(mb * 1048576.0 / update_bytes_each());
     }()};
     return budget;
 }
@@ -409,9 +418,9 @@ void note_budget_spent(kmc_sampler* s)
     static std::atomic<bool> said{false};
     if (!said.exchange(true))
         std::fprintf(stderr, "[kissmcmc_hip] the updated-graph launch mode has used up this process's budget (%lld parameter updates, "
-                             "kmc_set_updated_budget_mb / KMC_DEBUG=updated-budget-mb=n; the HIP runtime leaks ~80 B per update): samplers now "
+                             "kmc_set_updated_budget_mb / KMC_DEBUG=updated-budget-mb=n; this HIP runtime keeps ~%.0f B per update): samplers now "
                              "choose between the table graph and eager launches (up to ~9 %% slower per half-step; results are identical)\n",
-                     (long long)g_update_calls.load(std::memory_order_relaxed));
+                     (long long)g_update_calls.load(std::memory_order_relaxed), update_bytes_each());
 }
 
 // one replay of s->uchunk generations starting at s->generation.  *launched tells a failure BEFORE the replay was
@@ -731,9 +740,9 @@ KMC_EXPORT kmc_status kmc_sampler_run(kmc_sampler* s, int64_t ngen)
     //                      -- as long as the host launches as fast as the GPU drains, which it does not reliably (three
     //                      bench runs: 8.7, 6.5, 8.6 x 10^9 walker-steps/s; C3 3.7-4.8 us against 3.25);
     //   3 updated graph -- the eager form of the kernels inside a graph whose node parameters are rewritten before
-    //                      every replay (C2 4.00 us, C3 3.25 us; steady).  But hipGraphExecKernelNodeSetParams leaks ~80
-    //                      bytes of host memory per call inside the runtime (1.6 MB per 10^4 generations, not returned
-    //                      when the executables are destroyed; scripts/exp/leak_check.py), so the process has a BUDGET
+    //                      every replay (C2 4.00 us, C3 3.25 us; steady).  But hipGraphExecKernelNodeSetParams keeps host
+    //                      memory per call inside the runtime -- ~80 bytes in HIP 7.0 (1.6 MB per 10^4 generations, not returned
+    //                      when the executables are destroyed), ~1.4 in 7.2: update_bytes_each above -- so the process has a BUDGET
     //                      of such calls (kmc_set_updated_budget_mb): beyond it samplers choose
     //                      between 1 and 2.
     // A long run measures 1 against 3 (or 2) once -- four chunks each, HIP events: a starved GPU shows as idle time
@@ -874,6 +883,6 @@ KMC_EXPORT void kmc_updated_budget(int64_t* calls_used, int64_t* calls_budget)
 
 KMC_EXPORT void kmc_set_updated_budget_mb(double mb)
 {
-    update_budget().store(mb <= 0.0 ? 0 : (int64_t)(mb * 1048576.0 / 80.0), std::memory_order_relaxed);
+    update_budget().store(mb <= 0.0 ? 0 : (int64_t)(mb * 1048576.0 / update_bytes_each()), std::memory_order_relaxed);
 }
 

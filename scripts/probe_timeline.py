@@ -3,7 +3,7 @@ vector kernel stamps the 100 MHz real-time counter eight times (entry, Philox do
 struct arrived, logarithms done, rows arrived + log-pdf reduced, accept + scalar stores, last store issued) without waiting
 at the stamps (kmc_kernels.hpp, KMC_STAMP).
 Prints the timeline of the last generation's two launches.
-Usage (GPU box): python scripts/probe_timeline.py [C2|C3|C5]   (builds libkmc_var_probe.so on first use)"""
+Usage (GPU box): python scripts/probe_timeline.py [C2|C3|C5|R31|R63|E64]   (builds libkmc_var_probe.so on first use)"""
 import ctypes
 import os
 import sys
@@ -22,7 +22,8 @@ import kissmcmc_jl_amd as kmc
 from kissmcmc_jl_amd import _lib
 
 CONFIGS = {"C2": (kmc.GaussianIso(), 65536, 32), "C3": (kmc.Rosenbrock(), 16384, 64), "C5": (kmc.GaussianIso(), 8192, 1024),
-           "C4s": (kmc.GaussianIso(), 524288, 32), "S8k": (kmc.GaussianIso(), 8192, 32)}    # S8k: one wave per CU
+           "C4s": (kmc.GaussianIso(), 524288, 32), "S8k": (kmc.GaussianIso(), 8192, 32),    # S8k: one wave per CU
+           "R31": (kmc.GaussianIso(), 65536, 31), "R63": (kmc.GaussianIso(), 16384, 63), "E64": (kmc.GaussianIso(), 16384, 64)}   # ragged rows against exact ones
 
 
 STAMPS = ["entry", "philox done", "1st partner loads issued", "arg struct arrived", "logs done, all loads issued", "rows arrived + log-pdf",
@@ -43,7 +44,7 @@ def main():
         s.sync()
         ms = s.last_run_ms()
         buf = np.zeros((2, 8192, 8), dtype=np.uint64)
-        rc = (L.kmc_probe_read_rosenbrock if name == 'C3' else L.kmc_probe_read)(buf.ctypes.data_as(ctypes.c_void_p))
+        rc = (L.kmc_probe_read_rosenbrock if name == 'C3' else L.kmc_probe_read_var if name[0] == 'R' else L.kmc_probe_read)(buf.ctypes.data_as(ctypes.c_void_p))
         assert rc == 0
         print(f"== {name} moments={int(mom)} KMC_LAUNCH={os.environ.get('KMC_LAUNCH', 'auto')}: {s.describe()}  {ms / 2048 * 1e3:.2f} us per half-step launch")
         nwave = int((buf[0, :, 0] != 0).sum())

@@ -293,7 +293,7 @@ def test_launch_modes_are_the_same_sampler(kmc, oracle, mode, monkeypatch):
 
 @pytest.mark.parametrize("when", ["spent_before_the_run", "spent_during_the_run"])
 def test_updated_graph_budget_fallbacks_are_the_same_sampler(kmc, oracle, when, monkeypatch, capfd):
-    """The updated-graph mode has a process-wide budget of parameter updates (the runtime leaks ~80 B per update).  A sampler
+    """The updated-graph mode has a process-wide budget of parameter updates (the runtime keeps ~80 B per update -- HIP 7.0, PyTorch's -- or ~1.4 B -- 7.2).  A sampler
     that finds it spent -- before its first long run, or in the middle of one -- goes on with the table graph or eager
     launches: same results as the oracle, and it SAYS so (stderr once per process, describe(), kmc_sampler_launch_mode)."""
     import ctypes as C
@@ -301,16 +301,22 @@ def test_updated_graph_budget_fallbacks_are_the_same_sampler(kmc, oracle, when, 
     L = _lib.lib()
     used, budget = C.c_int64(0), C.c_int64(0)
     L.kmc_updated_budget(C.byref(used), C.byref(budget))
+    L.kmc_set_updated_budget_mb(1.0)                   # what the library prices an update at: 80 B on the HIP 7.0 runtime (PyTorch's), 2 B on 7.2
+    one_mib = C.c_int64(0)
+    L.kmc_updated_budget(None, C.byref(one_mib))
+    each = 1048576.0 / one_mib.value
+    assert abs(each - 80.0) < 0.01 or abs(each - 2.0) < 0.01, each
+    each = float(round(each))
     nw, nd, G, nburn, nthin, seed = 2048, 32, 1000, 301, 7, 29
     th = np.random.default_rng(5).standard_normal((nw, nd))
     monkeypatch.setenv("KMC_DEBUG", "fused=0")      # (the two-launch kernels' launch modes: this small state would run one launch per generation)
     try:
         if when == "spent_before_the_run":
             monkeypatch.delenv("KMC_LAUNCH", raising=False)
-            L.kmc_set_updated_budget_mb(1.0 / 1024.0)                       # 1 KiB: 13 updates, fewer than one replay needs
+            L.kmc_set_updated_budget_mb(13 * each / 1048576.0)              # 13 updates, fewer than one replay needs
         else:
             monkeypatch.setenv("KMC_LAUNCH", "updated,budget")              # in the updated-graph mode, budget applies
-            L.kmc_set_updated_budget_mb((used.value + 3 * 128) * 80.0 / 1048576.0 + 1e-9)   # room for three replays
+            L.kmc_set_updated_budget_mb((used.value + 3 * 128) * each / 1048576.0 + 1e-9)   # room for three replays
         with kmc.Sampler(kmc.GaussianIso(), nw, nd, G, nburn, nthin, 2.0, seed, store_chain=True, store_logp=True, moments=True) as s:
             s.set_positions(th)
             s.run(900)
@@ -324,7 +330,7 @@ def test_updated_graph_budget_fallbacks_are_the_same_sampler(kmc, oracle, when, 
             mode, fell_back = s.launch_mode()
             assert s.generation == G
     finally:
-        L.kmc_set_updated_budget_mb(budget.value * 80.0 / 1048576.0)
+        L.kmc_set_updated_budget_mb(budget.value * each / 1048576.0 + 1e-9)
     assert fell_back and mode in (0, 1, 2), (mode, fell_back, how)
     assert "budget of the process spent" in how
     u2, b2 = C.c_int64(0), C.c_int64(0)
