@@ -66,10 +66,16 @@ MALL_BYTES = 256 << 20  # Infinity Cache: a working set below this is served on-
 
 def kernel_geometry(describe: str):
     """The part of kmc_sampler_describe that names the kernel and its launch geometry, e.g.
-    'half_step_vec L=8 K=2 ITER=2 exact-size, grid 1024 x 128' -- what a tracked profile record is matched on."""
+    'half_step_vec L=8 K=2 ITER=2 exact-size, grid 1024 x 128' (or 'generation_group L=16 K=2, ..., grid 2048 x 128': one launch per generation) --
+    what a tracked profile record is matched on."""
     import re
-    m = re.search(r"half_step_\w+[^;]*?, grid \d+ x \d+", describe or "")
+    m = re.search(r"(?:half_step|generation)_\w+[^;]*?, grid \d+ x \d+", describe or "")
     return m.group(0) if m else None
+
+
+def launches_per_generation(describe: str) -> int:
+    """2: one launch per half-step (src/samplers.jl:246-273); 1: the one-launch-per-generation kernels (kmc_generation.hpp)."""
+    return 1 if "one launch per generation" in (describe or "") else 2
 
 
 def kernel_name(pdf, describe: str):
@@ -78,7 +84,10 @@ def kernel_name(pdf, describe: str):
     m = re.search(r"(half_step_\w+) L=(\d+) K=(\d+) ITER=(\d+) (ragged|exact-size)", describe or "")
     if m:
         return f"{m.group(1)}<{type(pdf).__name__}, L={m.group(2)}, K={m.group(3)}, ITER={m.group(4)}, {m.group(5)}>"
-    m = re.search(r"half_step_\w+", describe or "")
+    m = re.search(r"(generation_group) L=(\d+) K=(\d+)", describe or "")
+    if m:
+        return f"{m.group(1)}<{type(pdf).__name__}, L={m.group(2)}, K={m.group(3)}>"
+    m = re.search(r"(?:half_step|generation)_\w+", describe or "")
     return f"{m.group(0)}<{type(pdf).__name__}>" if m else (describe or "").split(":")[0]
 
 
@@ -86,11 +95,13 @@ def moment_bytes(describe: str) -> int:
     """Bytes of streaming-moment accumulators the vector kernel of `describe` touches (kmc_kernels.hpp: accumulate_wave): the
     transposed fold (K = 2, L = 8/16/32) keeps 8 L / 64 doubles per thread, the plain one 2 K double2 per thread of group 0's slots."""
     import re
-    m = re.search(r"L=(\d+) K=(\d+) ITER=\d+ \S+, grid (\d+) x (\d+)", describe or "")
+    m = re.search(r"L=(\d+) K=(\d+) ITER=\d+ \S+, grid (\d+) x (\d+)", describe or "") or re.search(r"generation_group L=(\d+) K=(\d+),.*?, grid (\d+) x (\d+)", describe or "")
     if not m:
         return 0
     L, K, grid, tpb = (int(v) for v in m.groups())
     threads = grid * tpb
+    if "generation_group" in describe and not (K == 2 and L in (8, 16, 32)):
+        return 0                     # (per-walker sums laid out like the rows: counted with the rows' walkers by the caller -- not a geometry the bench runs)
     return threads * (8 * L // 64) * 8 if (K == 2 and L in (8, 16, 32)) else threads * 2 * K * 16
 
 
@@ -102,10 +113,10 @@ def state_bytes(nrows: int, ndim: int, moments: int = 0) -> int:
 
 
 def kernel_sources_sha16() -> str:
-    """sha256[:16] of the two headers every half-step kernel is made of -- what a profile record was taken from."""
+    """sha256[:16] of the three headers the half-step and generation kernels are made of -- what a profile record was taken from."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("kmc_kernels.hpp", "kmc_device.hpp"):
+    for f in ("kmc_kernels.hpp", "kmc_device.hpp", "kmc_generation.hpp"):
         h.update(open(os.path.join(ROOT, "kissmcmc.jl_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -128,7 +139,8 @@ def profile_record(name: str, geometry):
 
 
 def roofline_block(pdf, describe: str, nwalkers_launch: int, ndim: int, launch_us: float, launches: int, state_b: int, record_name: str, use_record: bool = True):
-    """`roofline` of the dominant kernel (one launch = one half-step): numbers and short enums only (the prose lives in DESIGN.md section 5).
+    """`roofline` of the dominant kernel (one launch = one half-step; the callers pass walkers and microseconds PER HALF-STEP, and where the sampler runs one launch
+    per generation -- `half_steps_per_launch` 2 -- both are doubled here): numbers and short enums only (the prose lives in DESIGN.md section 5).
     achieved / frac = ALGORITHMIC read bytes ((2 ndim + 1) * 8 per walker-step) / average launch-to-launch time from HIP events over
     the timed region (includes the kernel boundary), priced against the 8 TB/s HBM spec (`peak`).  `served_from` says where the rows really
     come from (a state below 256 MiB lives in the Infinity Cache between two generations) and `bound` follows it.  What is not measured in
@@ -136,6 +148,8 @@ def roofline_block(pdf, describe: str, nwalkers_launch: int, ndim: int, launch_u
     boundary split (-DKMC_PROBE build; body_frac = the same bytes / body_us / 8 TB/s) -- comes from the tracked record of that very kernel
     geometry, profiles/traffic_<record>.json (scripts/profile_r04.sh), or is null when the geometries differ."""
     b_read, b_total = (2 * ndim + 1) * 8, (3 * ndim + 2) * 8
+    hs = 2 if launches_per_generation(describe) == 1 else 1
+    nwalkers_launch, launch_us = nwalkers_launch * hs, launch_us * hs
     alg_read = nwalkers_launch * b_read
     achieved = alg_read / (launch_us * 1e-6) / 1e9
     geometry = kernel_geometry(describe)
@@ -153,7 +167,7 @@ def roofline_block(pdf, describe: str, nwalkers_launch: int, ndim: int, launch_u
     return {"bound": served, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": rec.get("hbm_bytes_per_launch") if rec else None,
             "priced_against": "hbm_spec", "frac_of_measured_copy_rate": achieved / HBM_COPY_GBS,
-            "kernel": kernel_name(pdf, describe), "geometry": geometry, "launches": launches, "avg_launch_us": launch_us,
+            "kernel": kernel_name(pdf, describe), "geometry": geometry, "launches": launches, "avg_launch_us": launch_us, "half_steps_per_launch": hs,
             "algorithmic_read_bytes_per_launch": alg_read, "algorithmic_total_bytes_per_launch": nwalkers_launch * b_total,
             "state_bytes": state_b, "served_from": served, "limited_by": limited,
             "body_us": body_us, "boundary_us": boundary_us, "body_frac": body_frac,
@@ -498,6 +512,25 @@ def other_configs(kmc, device: int):
                        "accept_ratio_mean": float(s.accept_ratio().mean()), "execution": how}
                 if name != "C1":
                     rec["roofline"] = roof
+                if launches_per_generation(how) == 1 and name == "C3":
+                    # one launch per generation (8 MiB of state, <= 16 384 walkers): the same job on the two-launch kernels beside it
+                    old = os.environ.get("KMC_DEBUG")
+                    os.environ["KMC_DEBUG"] = (old + "," if old else "") + "fused=0"
+                    try:
+                        with kmc.Sampler(pdf, nw, nd, G, G // 2, 1, 2.0, SEED, device=device, **kw) as s2:
+                            s2.set_positions(th)
+                            s2.run(min(G, 1024))
+                            s2.sync()
+                            s2.set_positions(th)
+                            s2.run(G)
+                            s2.sync()
+                            rec["two_launches_us_per_half_step"] = s2.last_run_ms() * 1e3 / (2 * G)
+                            rec["two_launches_execution"] = s2.describe()
+                    finally:
+                        if old is None:
+                            os.environ.pop("KMC_DEBUG", None)
+                        else:
+                            os.environ["KMC_DEBUG"] = old
                 if kw.get("moments"):
                     msum, msq, n = s.moments()
                     mean = msum / max(1, n)
@@ -705,7 +738,7 @@ def compact_line(full: dict) -> str:
             roof = e.get("roofline")
             if roof:
                 c.update(frac=roof["frac"], served_from=roof["served_from"], traffic=roof.get("traffic"))
-            elif "two_launches_us_per_half_step" in e:
+            if "two_launches_us_per_half_step" in e:
                 c["two_launches_us_per_half_step"] = e["two_launches_us_per_half_step"]
             line["other_configs"][name] = sig(c, 5)
     line["detail"] = "bench_detail.json; earlier stdout line {\"bench_detail\": ...}"

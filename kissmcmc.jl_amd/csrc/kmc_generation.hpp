@@ -64,7 +64,7 @@ struct GenerationFront {
     double*           pout;
     uint32_t          seed_lo, seed_hi;
     uint32_t          h, nb;
-    int32_t           ld;
+    int32_t           ld;           // row stride in the low 16 bits, ndim above them (a row of these kernels is at most 512 elements): both in front of the first loads
     uint32_t          gen;          // eager launches: the generation (sched == nullptr)
 };
 static_assert(sizeof(GenerationFront) == 56, "14 preloaded dwords");
@@ -129,7 +129,7 @@ __device__ __forceinline__ void generation_lane_body(const GenerationFront& f, c
 #endif
     KMC_STAMP(1);                                                        // the schedule entry has arrived
     const uint32_t me = (second ? f.h : 0u) + i;
-    const size_t ld = (size_t)f.ld;
+    const size_t ld = (size_t)(f.ld & 0xffff);
     // level 1 = my own move; level 0 (second half only) = my partner's move in the first half-step
     const U4 mybits = draw_bits(dc, step0 + (second ? 1u : 0u), me);
     const uint32_t mypartner = (second ? 0u : f.h) + draw_partner(dc, mybits);      // :250
@@ -256,6 +256,7 @@ template <class Dens, int L, int K>
 __device__ __forceinline__ void generation_group_body(const GenerationFront& f, const GenerationArgs& a)
 {
     static_assert(BlobTrait<Dens>::n == 0 && RowEvalTrait<Dens>::n == 0, "lane-striped densities only");
+    KMC_STAMP(0);                                                        // (-DKMC_PROBE builds only: scripts/probe_timeline.py) wave entry
     const uint32_t gpb = blockDim.x / L;                                 // walkers per workgroup
     const bool second = blockIdx.x < f.nb;
     const uint32_t i0 = (second ? blockIdx.x : blockIdx.x - f.nb) * gpb + threadIdx.x / L;
@@ -266,15 +267,18 @@ __device__ __forceinline__ void generation_group_body(const GenerationFront& f, 
     const DrawConsts dc = generation_draw_consts(f, a);
     const uint64_t step0 = 2ull * (uint64_t)sch.gen;
     const uint32_t me = (second ? f.h : 0u) + i;
-    const int ld = f.ld, ndim = a.ndim;
+    const int ld = f.ld & 0xffff, ndim = f.ld >> 16;
     const double2 zero2 = make_double2(0.0, 0.0);
-    bool cv[K];
+    // No masks on a row's last chunk (as in half_step_vec, kmc_kernels.hpp): a lane whose chunk lies past the row's end works on the row's LAST chunk instead -- it loads
+    // what that chunk's real lane loads, computes the same bits and stores them to the same address; the densities select by element index against ndim.
+    int ck[K];
 #pragma unroll
-    for (int k = 0; k < K; ++k) cv[k] = 2 * (k * L + j) < ld;
+    for (int k = 0; k < K; ++k) ck[k] = 2 * (k * L + j) < ld ? k * L + j : (ld >> 1) - 1;
+    auto row_off = [&](uint32_t w) -> size_t { return (size_t)((uint64_t)w * (uint64_t)(uint32_t)ld); };
     auto row = [&](const double* base, uint32_t w, double2 (&x)[K]) {
-        const double2* r = reinterpret_cast<const double2*>(base + (size_t)w * (size_t)ld);
+        const double2* r = reinterpret_cast<const double2*>(base + row_off(w));
 #pragma unroll
-        for (int k = 0; k < K; ++k) x[k] = cv[k] ? r[k * L + j] : zero2;
+        for (int k = 0; k < K; ++k) x[k] = r[ck[k]];
     };
     const U4 mybits = draw_bits(dc, step0 + (second ? 1u : 0u), me);
     const uint32_t mypartner = (second ? 0u : f.h) + draw_partner(dc, mybits);      // :250
@@ -395,15 +399,14 @@ __device__ __forceinline__ void generation_group_body(const GenerationFront& f, 
     if (!valid) return;
     if constexpr (!kFold) {
         if (wgt != 0.0) {
-            double* s1 = a.msum + (size_t)me * (size_t)ld;
-            double* s2 = a.msumsq + (size_t)me * (size_t)ld;
+            double* s1 = a.msum + row_off(me);
+            double* s2 = a.msumsq + row_off(me);
 #pragma unroll
-            for (int k = 0; k < K; ++k)
-                if (cv[k]) {
-                    const int e = 2 * (k * L + j);
-                    *reinterpret_cast<double2*>(&s1[e]) = make_double2(m1[k].x + own[k].x * wgt, m1[k].y + own[k].y * wgt);
-                    *reinterpret_cast<double2*>(&s2[e]) = make_double2(m2[k].x + (own[k].x * own[k].x) * wgt, m2[k].y + (own[k].y * own[k].y) * wgt);
-                }
+            for (int k = 0; k < K; ++k) {
+                const int e = 2 * ck[k];
+                *reinterpret_cast<double2*>(&s1[e]) = make_double2(m1[k].x + own[k].x * wgt, m1[k].y + own[k].y * wgt);
+                *reinterpret_cast<double2*>(&s2[e]) = make_double2(m2[k].x + (own[k].x * own[k].x) * wgt, m2[k].y + (own[k].y * own[k].y) * wgt);
+            }
         }
     }
     if (acc && moments && j == 0) a.klast[me] = sch.nbefore;
@@ -414,9 +417,9 @@ __device__ __forceinline__ void generation_group_body(const GenerationFront& f, 
     // earlier, and is valid as long as nothing was accepted since: by induction from two equal copies at the start of a run, kmc_launch.hip).
     // A stale glast -- a restart -- can only ask for a write too many.
     if (acc || gl == (uint32_t)sch.gen) {
-        double2* out = reinterpret_cast<double2*>(f.pout + (size_t)me * (size_t)ld);
+        double2* out = reinterpret_cast<double2*>(f.pout + row_off(me));
 #pragma unroll
-        for (int k = 0; k < K; ++k) if (cv[k]) out[k * L + j] = y[k];   // (elements past ndim of the last chunk: 0 in, 0 out -- the lane-striped densities ignore them)
+        for (int k = 0; k < K; ++k) out[ck[k]] = y[k];
         if (j == 0) a.lout[me] = pnew;
     }
     if (acc && j == 0) {
@@ -428,10 +431,20 @@ __device__ __forceinline__ void generation_group_body(const GenerationFront& f, 
         if (a.chain != nullptr) {
             double2* dst = reinterpret_cast<double2*>(a.chain + srow * (size_t)ld);
 #pragma unroll
-            for (int k = 0; k < K; ++k) if (cv[k]) dst[k * L + j] = y[k];
+            for (int k = 0; k < K; ++k) dst[ck[k]] = y[k];
         }
         if (a.chain_logp != nullptr && j == 0) a.chain_logp[srow] = pnew;
     }
+    KMC_STAMP(7);                                                        // the last store is issued
+#ifdef KMC_PROBE
+    {
+        unsigned long long st[8] = {};
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        KMC_STAMP_READ(st[0], 80, 81); KMC_STAMP_READ(st[7], 94, 95);
+        for (int q = 1; q < 7; ++q) st[q] = st[0];                       // (entry and end only: body and boundary of a launch)
+        if (threadIdx.x == 0 && blockIdx.x < 8192) for (int q = 0; q < 8; ++q) g_probe[sch.gen & 1][blockIdx.x][q] = st[q];   // [generation parity][workgroup (its first wave)]
+    }
+#endif
 }
 
 template <class Dens, int L, int K>

@@ -13,3 +13,10 @@ GenerationFn generation_group_rosenbrock(int L, int K) { return generation_group
 MetropolisFn metropolis_rosenbrock(int ndim) { return metropolis_lookup<Rosenbrock>(ndim); }
 MetropolisTabledFn metropolis_tabled_rosenbrock(int ndim) { return metropolis_tabled_lookup<Rosenbrock>(ndim); }
 }  // namespace kmc
+
+#ifdef KMC_PROBE   // diagnostic build only (scripts/probe_timeline.py C3): the stamps of THIS translation unit's kernels (generation_group)
+extern "C" __attribute__((visibility("default"))) int kmc_probe_read_generation_rosenbrock(void* out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(kmc::g_probe), sizeof(kmc::g_probe));
+}
+#endif

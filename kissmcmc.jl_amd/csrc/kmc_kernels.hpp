@@ -217,7 +217,6 @@ __device__ __forceinline__ void store_wt(unsigned char* p, unsigned char v)
     const uint32_t t = v;
     asm volatile("global_store_byte %0, %1, off sc0 sc1\n\ts_nop 0" :: "v"(p), "v"(t) : "memory");
 }
-__device__ __forceinline__ void store_row16(double2* p, const double2& v) { store_wt(p, v); }
 // Row load: every row is read once per launch (a non-temporal variant was measured in round 1: no gain).
 __device__ __forceinline__ double2 load_row16(const double2* p)
 {
@@ -414,7 +413,7 @@ static __device__ unsigned long long g_probe[2][8192][8];
 #endif
 
 // RAGGED = false: ndim == 2*L*K exactly (row stride and every mask fold at compile time);
-// RAGGED = true : ndim < 2*L*K, runtime row stride a.ld and masked tail chunks.
+// RAGGED = true : ndim < 2*L*K, runtime ndim and row stride (preloaded, see the body), tail chunks folded onto the row's last chunk.
 template <class Dens, int L, int K, int ITER, bool P2P, bool RAGGED, class T = double>
 __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const HalfStepArgs& a)
 {
@@ -425,8 +424,15 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
     static_assert(ITER >= 1 && ITER <= L, "a group's scalar lanes must cover its iterations");
     constexpr int G = 64 / L;          // groups = walkers in flight per wave
     constexpr int W = G * ITER;        // walkers per wave
-    const int ndim = RAGGED ? a.ndim : 2 * L * K;        // ragged: chunks past the row's end are skipped
-    const int64_t ld = RAGGED ? (int64_t)a.ld : (int64_t)(2 * L * K);
+    // Ragged rows: the row stride stands in front of the very first loads and ndim in front of the log-density.  Read from the argument struct they cost a scalar round
+    // trip each where the compiler happens to put the wait (measured: in front of the own rows, and again -- sharing a counter with ds_bpermute -- in front of the partner
+    // rows) that the exact-size kernels do not pay: everything in front of THEIR loads is a preloaded parameter.  So ndim travels among the preloaded parameters too, in the
+    // 16 bits above a device address (kmc_launch.hip: front_of packs it for exactly these kernels); ld = ndim rounded up to even (kmc_sampler_create).
+    // (pointer arithmetic, not an integer cast back: the loads stay global_load -- a flat_load would count on lgkmcnt and stall the scalar pipeline's waits)
+    const uint64_t ndim_tag = RAGGED ? reinterpret_cast<uint64_t>(f.logp) >> 48 : 0ull;
+    double* const logp_p = RAGGED ? reinterpret_cast<double*>(reinterpret_cast<char*>(f.logp) - (ndim_tag << 48)) : f.logp;
+    const int ndim = RAGGED ? (int)ndim_tag : 2 * L * K;
+    const int64_t ld = RAGGED ? (int64_t)((ndim + 1) & ~1) : (int64_t)(2 * L * K);
     const int tid   = blockIdx.x * vec_tpb(L) + threadIdx.x;
     const int lane  = threadIdx.x & 63;
     const int j     = lane & (L - 1);
@@ -439,6 +445,14 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
     bool cv[K];                                         // chunk k of this lane lies inside the row
 #pragma unroll
     for (int k = 0; k < K; ++k) cv[k] = !RAGGED || 2 * (k * L + j) < (int)ld;
+    // Ragged rows are loaded AND stored without masks: a lane whose chunk lies past the row's end works on the row's LAST chunk instead (same cache line; no exec-mask
+    // region around every load and store, nothing to zero).  It then computes what the chunk's real lane computes, from the same inputs, and stores the same bits to the
+    // same address; what it holds never counts -- the densities select by element index against ndim, the moment read-out stops at ndim.
+    // Row offsets: rows < 2^31 and ld < 2^31, one 32 x 32 -> 64 multiply instead of the 64-bit product.
+    int ck[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) ck[k] = cv[k] ? k * L + j : (int)(ld >> 1) - 1;
+    auto row_off = [&](int64_t row) -> int64_t { return RAGGED ? (int64_t)((uint64_t)(uint32_t)row * (uint64_t)(uint32_t)ld) : row * ld; };
     const double2 zero2 = make_double2(0.0, 0.0);
     KMC_STAMP(0);                                       // wave entry
 
@@ -474,16 +488,16 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
     for (int it = 0; it < ITER; ++it) {
         const int i = w0 + it * G + g;
         validB[it] = i < nact;
-        const V2* own = reinterpret_cast<const V2*>(posT + (own_row0 + (validB[it] ? i : nact - 1)) * ld);
+        const V2* own = reinterpret_cast<const V2*>(posT + row_off(own_row0 + (validB[it] ? i : nact - 1)));
 #pragma unroll
-        for (int k = 0; k < K; ++k) xc[it][k] = cv[k] ? load_row(&own[k * L + j]) : zero2;
+        for (int k = 0; k < K; ++k) xc[it][k] = load_row(&own[ck[k]]);
     }
 
     // ---- the walker's log-pdf and counters: same block, addressed from the preloaded parameters alone -------------
     const int64_t nrows_blk = 2 * (int64_t)(P2P ? (uint32_t)nact : f.nhalf);
-    uint32_t* const naccept_p = reinterpret_cast<uint32_t*>(f.logp + nrows_blk);
+    uint32_t* const naccept_p = reinterpret_cast<uint32_t*>(logp_p + nrows_blk);
     uint32_t* const klast_p = naccept_p + nrows_blk;
-    const double   p0 = f.logp[rowA];
+    const double   p0 = logp_p[rowA];
     const uint32_t na = naccept_p[rowA];
     const uint32_t kl = klast_p[rowA];
 
@@ -522,7 +536,7 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
         const V2* oth;
         if constexpr (!P2P) {
             const uint32_t partner = (uint32_t)__builtin_amdgcn_ds_bpermute((gbase + it) * 4, (int)partnerA);
-            oth = reinterpret_cast<const V2*>(posT + (oth_row0 + partner) * ld);
+            oth = reinterpret_cast<const V2*>(posT + row_off(oth_row0 + partner));
         } else {
             const int src = (gbase + it) * 4;
             const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)(unsigned)addrA);
@@ -535,12 +549,12 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
             // system scope, never from this XCD's L2
             if (nranks > 1) {
 #pragma unroll
-                for (int k = 0; k < K; ++k) xo[it][k] = cv[k] ? load_row_sys(reinterpret_cast<const double2*>(&oth[k * L + j])) : zero2;
+                for (int k = 0; k < K; ++k) xo[it][k] = load_row_sys(reinterpret_cast<const double2*>(&oth[ck[k]]));
                 return;
             }
         }
 #pragma unroll
-        for (int k = 0; k < K; ++k) xo[it][k] = cv[k] ? load_row(&oth[k * L + j]) : zero2;
+        for (int k = 0; k < K; ++k) xo[it][k] = load_row(&oth[ck[k]]);
     };
     if constexpr (P2P) {
         // owner rank and row of the partner, resolved once per walker; the row address travels
@@ -690,7 +704,7 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
         for (int it = 0; it < ITER; ++it) {
 #pragma unroll
             for (int k = 0; k < K; ++k)
-                if (cv[k]) *reinterpret_cast<double2*>(&tile[(it * G + g) * TS + 2 * (k * L + j)]) = xo[it][k];
+                *reinterpret_cast<double2*>(&tile[(it * G + g) * TS + 2 * (k * L + j)]) = xo[it][k];     // (a tile row is 2 L K + 2 wide: chunks past a ragged row's end land behind it, unread)
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -714,7 +728,7 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
     const bool acc = validA && accept_test(dr, myp1, p0);               // :260
     const unsigned long long accmask = __ballot(acc);
     if (acc) {
-        store_wt(&f.logp[rowA], myp1);                                  // :262
+        store_wt(&logp_p[rowA], myp1);                                  // :262
         if (count) store_wt(&naccept_p[rowA], na + 1u);                 // :265
         if (do_mom) store_wt(&klast_p[rowA], sch.nbefore);
     }
@@ -750,9 +764,9 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
     for (int it = 0; it < ITER; ++it) {
         const bool accB = ((accmask >> (gbase + it)) & 1ull) != 0;
         if (accB) {                                                     // :261
-            V2* own = reinterpret_cast<V2*>(posT + (own_row0 + w0 + it * G + g) * ld);
+            V2* own = reinterpret_cast<V2*>(posT + row_off(own_row0 + w0 + it * G + g));
 #pragma unroll
-            for (int k = 0; k < K; ++k) if (cv[k]) store_row(&own[k * L + j], xo[it][k]);
+            for (int k = 0; k < K; ++k) store_row(&own[ck[k]], xo[it][k]);
             if constexpr (P2P) {
                 if (push) {                                    // ... and into this rank's copy on every peer (write-through, over the fabric)
                     const int64_t off = (int64_t)(1 + me_rank) * shard_stride + (own_row0 + w0 + it * G + g) * ld;
@@ -760,7 +774,7 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
                         if (r == me_rank) continue;
                         double2* rem = reinterpret_cast<double2*>(a.peer_pos[r] + off);
 #pragma unroll
-                        for (int k = 0; k < K; ++k) if (cv[k]) store_wt(&rem[k * L + j], xo[it][k]);
+                        for (int k = 0; k < K; ++k) store_wt(&rem[ck[k]], xo[it][k]);
                     }
                 }
             }
@@ -787,7 +801,7 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
         if (sample && a.chain != nullptr && validB[it]) {               // :268-269
             V2* dst = reinterpret_cast<V2*>(reinterpret_cast<T*>(a.chain) + (sch.slot * a.chain_rows + a.chain_row0 + w0 + it * G + g) * ld);
 #pragma unroll
-            for (int k = 0; k < K; ++k) if (cv[k]) store_row(&dst[k * L + j], sel2(accB, xo[it][k], xc[it][k]));
+            for (int k = 0; k < K; ++k) store_row(&dst[ck[k]], sel2(accB, xo[it][k], xc[it][k]));
         }
     }
     if constexpr (kWgFold) {

@@ -103,14 +103,15 @@ HalfStepArgs make_args(const kmc_sampler* s, int half, bool graph_mode, int64_t 
 }
 
 // the leading scalar kernel parameters (kernarg preload, see HalfStepFront)
-HalfStepFront front_of(const HalfStepArgs& a)
+// ragged_vec: for half_step_vec<..., RAGGED = true> (and only for it: kmc_sampler::ragged_vec()) ndim (and with it the row stride) rides in the 16 bits above the log-pdf block's address
+HalfStepFront front_of(const HalfStepArgs& a, bool ragged_vec)
 {
     HalfStepFront f{};
     f.pos = a.pos;
     f.sched = a.sched_index < 0 ? nullptr : a.sched_table + a.sched_index;
     f.step = (uint32_t)(2ull * (uint64_t)a.sched_inline.gen + (uint64_t)a.half);       // used when sched == nullptr
     f.gw0 = (uint32_t)a.gw0;
-    f.logp = a.logp;
+    f.logp = ragged_vec ? reinterpret_cast<double*>(reinterpret_cast<uint64_t>(a.logp) | ((uint64_t)a.ndim << 48)) : a.logp;
     f.nact_half = (uint32_t)a.n_active | ((uint32_t)a.half << 31);
     f.ring_now = a.ring ? a.ring + (int64_t)a.ring_slot * a.ring_rows * 2 : nullptr;
     f.seed_lo = a.dc.seed_lo; f.seed_hi = a.dc.seed_hi; f.nhalf = a.dc.nhalf;
@@ -154,7 +155,7 @@ kmc_status launch_half(kmc_sampler* s, int half, bool graph_mode, int64_t gen_of
 
 hipError_t launch_half_kernel(const kmc_sampler* s, const HalfStepArgs& a)
 {
-    const HalfStepFront f = front_of(a);
+    const HalfStepFront f = front_of(a, s->ragged_vec());
     if (s->user) {
         const HalfStepLaunch la{f, a};
         if (s->uk.staged) return launch_module(s->uk.staged, (unsigned)s->grid, (unsigned)s->tpb, s->stream, la, (unsigned)staged_lds_bytes((int)s->cfg.ndim));
@@ -240,7 +241,7 @@ hipError_t launch_generation(const kmc_sampler* s, int from, bool graph_mode, in
 {
     const GenerationArgs a = make_generation_args(s, from, graph_mode, gen_offset);
     // the head of the chain among the preloaded kernel parameters (GenerationFront)
-    const GenerationFront f{a.sched, a.pin, a.lin, a.pout, a.dc.seed_lo, a.dc.seed_hi, a.h, a.nb, a.ld, (uint32_t)a.sched_inline.gen};
+    const GenerationFront f{a.sched, a.pin, a.lin, a.pout, a.dc.seed_lo, a.dc.seed_hi, a.h, a.nb, a.ld | (a.ndim << 16), (uint32_t)a.sched_inline.gen};
     const unsigned tpb = (unsigned)s->fused_tpb;
     if (s->user) {
         const GenerationLaunch la{f, a};
@@ -373,7 +374,7 @@ kmc_status ensure_updated_graph(kmc_sampler* s)
     for (int64_t g = 0; g < s->uchunk; ++g)
         for (int half = 0; half < 2; ++half) {
             pk.a = make_args(s, half, false, g);
-            pk.f = front_of(pk.a);
+            pk.f = front_of(pk.a, s->ragged_vec());
             const hipKernelNodeParams np = node_params(s, &pk);
             hipGraphNode_t node = nullptr;
             HIP_TRY(hipGraphAddKernelNode(&node, s->ugraph, prev ? &prev : nullptr, prev ? 1 : 0, &np));
@@ -439,7 +440,7 @@ kmc_status launch_updated_graph(kmc_sampler* s, bool* launched)
     for (int64_t g = 0; g < s->uchunk; ++g)
         for (int half = 0; half < 2; ++half) {
             pk.a = make_args(s, half, false, s->generation + g);
-            pk.f = front_of(pk.a);
+            pk.f = front_of(pk.a, s->ragged_vec());
             const hipKernelNodeParams np = node_params(s, &pk);
             HIP_TRY(hipGraphExecKernelNodeSetParams(s->uexec[i], s->unodes[(size_t)(2 * g + half)], &np));
         }

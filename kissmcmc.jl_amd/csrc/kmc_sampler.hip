@@ -268,8 +268,9 @@ namespace {
 // once per generation instead of twice.  0: no; 1: one walker per lane (ndim <= 8); 2: rows lane-striped like the vector kernels (longer
 // rows; lane-striped densities).  Measured against the two-launch kernels (profiles/r04_generation_map.txt): short rows 1.3-1.9 x ahead up
 // to 32 768 walkers, 1.25-1.4 x at 65 536 walkers of one or two doubles, behind beyond that; longer rows 1.15-1.55 x ahead while the state
-// stays within ~2.3 MiB, 1.04-1.08 x at 4 MiB (8 192 x 64, 32 768 x 16, 16 384 x 32), behind at 8 MiB (C3: 0.91 x) -- the kernel reads 2.5 x the
-// rows (profiles/r05_generation_mid.txt).
+// stays within ~2.3 MiB, 1.12-1.2 x at 4 MiB (8 192 x 64, 32 768 x 16, 16 384 x 32); between 4 and 8 MiB it depends on the number of walkers -- the kernel moves
+// 1.5 x the walkers and reads 2.5 x the rows: up to 16 384 walkers 1.02-1.19 x ahead (C3 1.04 x, 16 384 x 48 1.09, 4 096 x 256 1.19), from 24 576 walkers on
+// 0.90-0.97 x; behind at 10 MiB (profiles/r05_generation_mid.txt, profiles/r05_generation_limit.txt -- measured again after the row masks went: C3 was 0.95 x before).
 // KMC_DEBUG=fused=0 / =1: never / wherever a kernel exists.  (Resident and island mode are decided by the caller.)
 int generation_wanted(const kmc_sampler* s)
 {
@@ -290,7 +291,7 @@ int generation_wanted(const kmc_sampler* s)
     if (have) return kind;                                   // (=1 / =lane: wherever a kernel exists; =lane keeps short rows one walker per lane)
     if (kind == 3) return 3;
     if (kind == 1) return ((c.nwalkers <= 32768 && c.nwalkers * s->ld <= 196608) || (c.nwalkers <= 65536 && s->ld <= 2)) ? 1 : 0;
-    return c.nwalkers * s->ld <= 524288 ? 2 : 0;            // (4 MiB of state; round 4: 2.3 MiB, before the moments became sojourn-weighted and unchanged rows stayed unwritten)
+    return c.nwalkers * s->ld <= (c.nwalkers <= 16384 ? 1048576 : 524288) ? 2 : 0;     // (8 MiB of state up to 16 384 walkers, 4 MiB beyond)
 }
 }  // namespace
 
@@ -554,14 +555,15 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
     // Draw ring (kmc_kernels.hpp: kRing; possible for L = 16 / 32 with L / ITER >= 2): a wave computes its walkers' next steps' draws with its idle lanes and parks
     // them, 4 slots x rows x 32 B; tags start at 0xffffffff (no step carries it), so nothing is "parked" yet.  Where it pays was re-measured in round 5
     // (scripts/probes/ring_ab.py, profiles/r05_ring_ab.txt) -- since the launches carry their step among the preloaded parameters Philox starts at wave entry and the
-    // ring's entry is one more dependent load in front of the partner row: ragged rows gain 6-10 % from it (ITER <= 2), exact-size rows LOSE 1-8 % (ITER = 2; L = 32)
-    // and 6-14 % in the large-ensemble geometries (ITER >= 4: bandwidth-bound, the ring is bytes); C3's own geometry (L = 16, ITER = 1, exact) is neutral and keeps it.
+    // ring's entry is one more dependent load in front of the partner row: rows LOSE 2-7 % with it at ITER = 2 and at L = 32, exact-size and ragged alike (the ragged
+    // kernels gained 6-10 % from it only while their loads sat behind exec-mask regions and scalar waits; without those they behave like the exact-size ones), and
+    // 6-14 % in the large-ensemble geometries (ITER >= 4: bandwidth-bound, the ring is bytes); L = 16, ITER = 1 (C3's geometry) is +-1 % exact-size, -1..2 % ragged, and keeps it.
     // KMC_DEBUG=ring=0|1 forces it off / on wherever the kernel has one.
     bool want_ring = s->plan.vec && !s->islands && !s->resident && s->plan.L >= 16 && s->plan.L <= 32 && s->plan.L / s->plan.ITER >= 2;
     {
         std::string forced;
         if (want_ring && debug_opt("ring", &forced)) want_ring = forced != "0";
-        else if (want_ring) want_ring = s->plan.ragged ? s->plan.ITER < 4 : (s->plan.L == 16 && s->plan.ITER == 1);
+        else if (want_ring) want_ring = s->plan.L == 16 && s->plan.ITER == 1;
     }
     if (want_ring) {
         const size_t nb = 4 * (size_t)s->nrows * 2 * sizeof(double2);

@@ -45,6 +45,7 @@ struct kmc_sampler {
     int64_t ld = 0;                    // device row stride in doubles (ndim rounded up to even)
     kmc::DensityParams dp{};
     kmc_host::Plan plan{};
+    bool ragged_vec() const { return plan.vec && plan.ragged; }   // the half-step kernel is half_step_vec<..., RAGGED = true> (menu or runtime-compiled): ndim among its preloaded parameters
     kmc::LogpdfFn logpdf_fn = nullptr;
     kmc_user_density* user = nullptr;     // KMC_USER_DENSITY: kernels come from a runtime-compiled module
     kmc_host::UserKernels uk{};

@@ -39,11 +39,12 @@ def one(pdf, nw, nd, scale, forced, extra=""):
     return 1e3 * ms / (2 * G), how, acc, msum / max(1, n)
 
 
-print(f"{G} generations (burn-in {G // 2}), moments {'on' if MOMENTS else 'off'}: us per half-step, two launches per generation | one launch per generation (ratio) | planner's pick")
-for name, pdf, nw, nd, scale in CASES:
-    two, how2, acc2, m2 = one(pdf, nw, nd, scale, 0)
-    fus, how1, acc1, m1 = one(pdf, nw, nd, scale, 1)
-    _, howp, _, _ = one(pdf, nw, nd, scale, None)
-    same = bool(acc1 == acc2 and np.allclose(m1, m2, rtol=1e-9, atol=1e-12))
-    print(f"{name:>26s} | {two:6.2f} | {fus:6.2f} ({two / fus:4.2f}x) | pick: {'one' if 'one launch per generation' in howp else 'two'} | accept {acc1:.4f} | same accept ratio and means as the two-launch run: {same}", flush=True)
-    print(f"{'':>26s}   two: {how2.split(', hipGraph')[0]}\n{'':>26s}   one: {how1.split(', hipGraph')[0]}", flush=True)
+if __name__ == "__main__":
+    print(f"{G} generations (burn-in {G // 2}), moments {'on' if MOMENTS else 'off'}: us per half-step, two launches per generation | one launch per generation (ratio) | planner's pick")
+    for name, pdf, nw, nd, scale in CASES:
+        two, how2, acc2, m2 = one(pdf, nw, nd, scale, 0)
+        fus, how1, acc1, m1 = one(pdf, nw, nd, scale, 1)
+        _, howp, _, _ = one(pdf, nw, nd, scale, None)
+        same = bool(acc1 == acc2 and np.allclose(m1, m2, rtol=1e-9, atol=1e-12))
+        print(f"{name:>26s} | {two:6.2f} | {fus:6.2f} ({two / fus:4.2f}x) | pick: {'one' if 'one launch per generation' in howp else 'two'} | accept {acc1:.4f} | same accept ratio and means as the two-launch run: {same}", flush=True)
+        print(f"{'':>26s}   two: {how2.split(', hipGraph')[0]}\n{'':>26s}   one: {how1.split(', hipGraph')[0]}", flush=True)

@@ -44,9 +44,31 @@ def main():
         s.sync()
         ms = s.last_run_ms()
         buf = np.zeros((2, 8192, 8), dtype=np.uint64)
+        how = s.describe()
+        if "generation_" in how:
+            # one launch per generation (kmc_generation.hpp): entry and end stamps of every workgroup's first wave, by generation parity
+            rc = (L.kmc_probe_read_generation_rosenbrock if name == 'C3' else L.kmc_probe_read_generation)(buf.ctypes.data_as(ctypes.c_void_p))
+            assert rc == 0
+            import json
+            import re
+            nwg = int((buf[0, :, 0] != 0).sum())
+            t = buf[:, :nwg, :].astype(np.int64)
+            order = (0, 1) if t[0, :, 0].min() < t[1, :, 0].min() else (1, 0)          # the run's last two launches, earlier first
+            t = (t[list(order)] - t[order[0], :, 0].min()) * 10.0 / 1000.0
+            body, gap = float(t[0, :, 7].max() - t[0, :, 0].min()), float(t[1, :, 0].min() - t[0, :, 7].max())
+            print(f"== {name} moments={int(mom)} KMC_LAUNCH={os.environ.get('KMC_LAUNCH', 'auto')}: {how}  {ms / 1024 * 1e3:.2f} us per generation launch ({ms / 2048 * 1e3:.2f} per half-step)")
+            print(f" {nwg} workgroups stamped (first wave of each): entry spread {t[0, :, 0].max() - t[0, :, 0].min():.2f} us, wave duration median {np.median(t[0, :, 7] - t[0, :, 0]):.2f} "
+                  f"(p90 {np.percentile(t[0, :, 7] - t[0, :, 0], 90):.2f}); first wave in .. last store issued {body:.2f} us; gap to the next launch's first wave {gap:.2f} us; "
+                  f"launch period {t[1, :, 0].min() - t[0, :, 0].min():.2f} us")
+            m = re.search(r"generation_\w+[^;]*?, grid \d+ x \d+", how)
+            print("PROBE_JSON " + json.dumps({"config": name, "moments": int(mom), "geometry": m.group(0) if m else None, "waves_stamped": nwg, "launches_per_generation": 1,
+                                              "body_us": body, "boundary_us": gap, "period_us_in_kernel": float(t[1, :, 0].min() - t[0, :, 0].min()),
+                                              "period_us_hip_events_probe_build": ms / 1024 * 1e3, "wave_duration_median_us": float(np.median(t[0, :, 7] - t[0, :, 0]))}))
+            s.close()
+            continue
         rc = (L.kmc_probe_read_rosenbrock if name == 'C3' else L.kmc_probe_read_var if name[0] == 'R' else L.kmc_probe_read)(buf.ctypes.data_as(ctypes.c_void_p))
         assert rc == 0
-        print(f"== {name} moments={int(mom)} KMC_LAUNCH={os.environ.get('KMC_LAUNCH', 'auto')}: {s.describe()}  {ms / 2048 * 1e3:.2f} us per half-step launch")
+        print(f"== {name} moments={int(mom)} KMC_LAUNCH={os.environ.get('KMC_LAUNCH', 'auto')}: {how}  {ms / 2048 * 1e3:.2f} us per half-step launch")
         nwave = int((buf[0, :, 0] != 0).sum())
         t = buf[:, :nwave, :].astype(np.int64)
         base = t[0, :, 0].min()
@@ -66,7 +88,6 @@ def main():
         # store issued; boundary = the gap to the next launch's first wave; both of the -DKMC_PROBE build, whose stamps cost a little)
         import json
         import re
-        how = s.describe()
         m = re.search(r"half_step_\w+[^;]*?, grid \d+ x \d+", how)
         print("PROBE_JSON " + json.dumps({"config": name, "moments": int(mom), "geometry": m.group(0) if m else None, "waves_stamped": nwave,
                                           "body_us": float(t[0, :, 7].max() - t[0, :, 0].min()), "boundary_us": float(t[1, :, 0].min() - t[0, :, 7].max()),

@@ -5,7 +5,7 @@ sys.path.insert(0, '.')
 import numpy as np
 import kissmcmc_jl_amd as kmc
 SMALL = "--small" in sys.argv
-for nw, nd in (((16384, 64), (32768, 64), (65536, 64), (8192, 128), (16384, 128), (32768, 128), (16384, 60), (32768, 60), (8192, 120), (16384, 100), (32768, 50), (8192, 66), (16384, 36)) if SMALL else ((65536, 128), (131072, 64), (262144, 64), (131072, 128), (524288, 64), (1048576, 64))):
+for nw, nd in (((16384, 64), (32768, 64), (65536, 64), (8192, 128), (16384, 128), (32768, 128), (16384, 60), (32768, 60), (8192, 120), (16384, 100), (32768, 50), (8192, 66), (16384, 36), (16384, 63), (8192, 127), (4096, 100), (32768, 127), (65536, 63)) if SMALL else ((65536, 128), (131072, 64), (262144, 64), (131072, 128), (524288, 64), (1048576, 64))):
     res = []
     for dbg in ("ring=0", "ring=1"):
         if dbg: os.environ["KMC_DEBUG"] = dbg

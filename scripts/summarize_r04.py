@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "scripts"))
 import summarize_r02 as base          # trace_stats, counters, bench_line, runcfg_us, one
-from bench import kernel_geometry, kernel_sources_sha16     # the same matcher / source hash bench.py applies
+from bench import kernel_geometry, kernel_sources_sha16, launches_per_generation     # the same matcher / source hash bench.py applies
 
 SRC = os.path.join(ROOT, "gpurun_out", "prof_r04")
 DST = os.path.join(ROOT, "profiles")
@@ -51,7 +51,7 @@ def describe_of(path):
     if not path or not os.path.exists(path):
         return None
     for line in open(path):
-        if "half_step_" in line and "grid" in line:
+        if ("half_step_" in line or "generation_" in line) and "grid" in line:
             return line.strip()
     return None
 
@@ -91,6 +91,10 @@ def main():
             how_prof, how = describe_of(os.path.join(b, "kt.txt")), describe_of(os.path.join(b, "unprofiled.txt"))
         out["execution_unprofiled"], out["execution_in_profiled_run"] = how, how_prof
         out["geometry"] = kernel_geometry(how)
+        hs = 2 if launches_per_generation(how) == 1 else 1          # half-steps a launch carries (one launch per generation: 2)
+        out["half_steps_per_launch"] = hs
+        if hs == 2:                                                 # (run_cfg.py prints microseconds per half-step)
+            live, inprof = (live * 2 if live else live), (inprof * 2 if inprof else inprof)
         out["hip_event_us_per_launch_unprofiled"], out["hip_event_us_per_launch_in_profiled_run"] = live, inprof
         pm = {}
         for sub in ("fetch", "write", "l2"):
@@ -99,8 +103,8 @@ def main():
                 pm.update(base.counters(p, out["kernel_name"]))
         out["pmc_per_launch"] = pm
         b_read, b_write = (2 * nd + 1) * 8, (nd + 1) * 8
-        out["algorithmic_read_bytes_per_launch"] = (nw // 2) * b_read
-        out["algorithmic_write_bytes_per_launch_if_all_accepted"] = (nw // 2) * b_write
+        out["algorithmic_read_bytes_per_launch"] = hs * (nw // 2) * b_read
+        out["algorithmic_write_bytes_per_launch_if_all_accepted"] = hs * (nw // 2) * b_write
         if "FETCH_SIZE" in pm and "WRITE_SIZE" in pm:
             # steady state: the second half of the dispatches (the timed piece); the first half holds warm-up and calibration
             fetch = 2.0 * pm["FETCH_SIZE"]["second_half_mean"] * 1024.0
@@ -136,7 +140,7 @@ def main():
         rec = {"kernel": out["kernel_name"], "geometry": out["geometry"], "workload": workload, "head": hd, "kernel_sources_sha16": kernel_sources_sha16(),
                "hbm_bytes_per_launch": out.get("hbm_bytes_per_launch"), "hbm_read_bytes_per_launch": out.get("hbm_read_bytes_per_launch_corrected"),
                "hbm_write_bytes_per_launch": out.get("hbm_write_bytes_per_launch"), "l2_hit_rate": out.get("l2_hit_rate"),
-               "body_us": body, "boundary_us": boundary, "body_boundary_source": src, "period_us_unprofiled": live,
+               "half_steps_per_launch": hs, "body_us": body, "boundary_us": boundary, "body_boundary_source": src, "period_us_unprofiled": live,
                "rocprof_avg_duration_us": dur, "source": f"profiles/{tag}_{cfg}_summary.json"}
         tpath = os.path.join(DST, f"traffic_{name}.json")
         if os.path.exists(tpath):                     # (the periods other boxes measured for this geometry stay on record: scripts/recompute_roofline.py)

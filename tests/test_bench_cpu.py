@@ -23,6 +23,16 @@ def test_geometry_and_kernel_name_come_from_describe():
     staged = "multi-launch (exact): half_step_staged (one walker per lane, rows staged through LDS), grid 512 x 128; runtime-compiled density"
     assert bench.kernel_geometry(staged) == "half_step_staged (one walker per lane, rows staged through LDS), grid 512 x 128"
     assert bench.kernel_geometry("resident mode (exact): whole ensemble in one workgroup's LDS") is None
+    gen = ("one launch per generation (exact): generation_group L=16 K=2, rows lane-striped, second-half walkers recompute their partner's first-half move, grid 2048 x 128, "
+           "hipGraph replay of 64 generations")
+    assert bench.kernel_geometry(gen) == "generation_group L=16 K=2, rows lane-striped, second-half walkers recompute their partner's first-half move, grid 2048 x 128"
+    assert bench.kernel_name(GaussianIso(), gen) == "generation_group<GaussianIso, L=16, K=2>"
+    assert bench.launches_per_generation(gen) == 1 and bench.launches_per_generation(C2) == 2
+    assert bench.moment_bytes(gen) == 2048 * 128 * 2 * 8                  # the transposed fold's per-wave accumulators: 8 L / 64 doubles per thread
+    # a launch of it carries both half-steps: walkers and period doubled, the fraction is the one of the half-step figures passed in
+    r = bench.roofline_block(GaussianIso(), gen, 8192, 64, 3.1, 10000, bench.state_bytes(16384, 64, bench.moment_bytes(gen)), "no_such_record")
+    assert r["half_steps_per_launch"] == 2 and r["avg_launch_us"] == 6.2 and r["algorithmic_read_bytes_per_launch"] == 16384 * 129 * 8
+    assert abs(r["achieved"] - 8192 * 129 * 8 / 3.1e-6 / 1e9) < 1e-6 and r["traffic"] is None
 
 
 def test_tracked_record_is_used_only_for_its_own_geometry():

@@ -110,7 +110,8 @@ def test_what_keeps_the_two_launch_kernels(kmc):
     assert "one launch per generation" not in _mode(kmc, pdf, 4096, 4, use_graph=False)
     assert "one launch per generation" not in _mode(kmc, pdf, 65536, 32)
     assert "one launch per generation" not in _mode(kmc, pdf, 262144, 4)
-    assert "one launch per generation" not in _mode(kmc, pdf, 32768, 32) and "one launch per generation" not in _mode(kmc, kmc.Rosenbrock(), 16384, 64)
+    assert "one launch per generation" not in _mode(kmc, pdf, 32768, 32) and "one launch per generation" not in _mode(kmc, pdf, 20480, 64)       # 8 MiB beyond 16 384 walkers, 10 MiB
+    assert "generation_group" in _mode(kmc, kmc.Rosenbrock(), 16384, 64) and "generation_group" in _mode(kmc, pdf, 4096, 256)    # 8 MiB of state, <= 16 384 walkers (C3; round 5, after the row masks went)
     assert "generation_lane" in _mode(kmc, pdf, 32768, 4) and "generation_group" in _mode(kmc, pdf, 8192, 32)
     assert "generation_group" in _mode(kmc, pdf, 16384, 32) and "generation_group" in _mode(kmc, pdf, 8192, 64)      # 4 MiB of state (round 5)
     assert "generation_group L=4 K=1" in _mode(kmc, pdf, 4096, 8) and "generation_group L=4 K=1" in _mode(kmc, pdf, 8192, 5)
