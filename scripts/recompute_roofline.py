@@ -38,7 +38,10 @@ def check(name, roof, nw, nd, tol, out, after_burnin_us=None):
         worst = max(worst, d)
         out.append(f"    {label:34s} recomputed {mine:14.6g}   line {theirs:14.6g}   dev {100 * d:5.2f} %" + ("   <-- beyond tolerance" if d > tol else ""))
 
-    alg = (roof.get("half_steps_per_launch") or (2 if "generation_" in (roof.get("geometry") or "") else 1)) * (nw // 2) * (2 * nd + 1) * 8     # (one launch per generation: two half-steps' walkers)
+    hs = roof.get("half_steps_per_launch") or (2 if "generation_" in (roof.get("geometry") or "") else 1)      # one launch per generation: two half-steps' walkers and time
+    alg = hs * (nw // 2) * (2 * nd + 1) * 8
+    if after_burnin_us:
+        after_burnin_us *= hs                                                                                  # (the line quotes microseconds per half-step)
     out.append(f"  {name}: {nw} x {nd}, kernel {roof['kernel']}, {roof['geometry']}")
     dev("algorithmic read bytes / launch", alg, roof["algorithmic_read_bytes_per_launch"])
     dev("achieved GB/s (line's HIP events)", alg / (roof["avg_launch_us"] * 1e-6) / 1e9, roof["achieved"])

@@ -35,7 +35,7 @@ def pct(v, p):
 
 
 def trace_stats(path):
-    rows = [r for r in csv.DictReader(open(path)) if KEY in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(path)) if KEY in r["Kernel_Name"] or (KEY == "half_step_vec" and "generation_group" in r["Kernel_Name"])]   # (C3 runs one launch per generation since round 5)
     by = collections.Counter(r["Kernel_Name"] for r in rows)
     name = by.most_common(1)[0][0]
     rows = [r for r in rows if r["Kernel_Name"] == name]
