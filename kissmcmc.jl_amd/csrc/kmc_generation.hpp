@@ -63,7 +63,8 @@ struct GenerationFront {
     const double*     lin;
     double*           pout;
     uint32_t          seed_lo, seed_hi;
-    uint32_t          h, nb;
+    uint32_t          h, nb;        // nb: workgroups per half in the low 30 bits, threads per workgroup / 64 - 1 above them (blockDim.x is a hidden kernel argument: read from
+                                    // there it costs every wave a scalar round trip before its first instruction of substance -- 0.3-0.5 us of a launch of 3)
     int32_t           ld;           // row stride in the low 16 bits, ndim above them (a row of these kernels is at most 512 elements): both in front of the first loads
     uint32_t          gen;          // eager launches: the generation (sched == nullptr)
 };
@@ -79,12 +80,40 @@ struct GenerationLaunch {
 };
 
 // the schedule entry and the draw constants of a launch, from the preloaded head where the chain starts and from the struct for the rest
-__device__ __forceinline__ SchedEntry generation_schedule(const GenerationFront& f, const GenerationArgs& a)
+// The head of a wave's chain touches nothing but preloaded parameters (as in half_step_vec, kmc_kernels.hpp).  Table graph: one scalar round trip for the schedule entry,
+// waited for HERE (the argument struct's fields ride the same round trip); eager form / updated graph (f.sched == nullptr): the generation is a preloaded parameter and
+// Philox starts at wave entry -- the rest of the entry is in the argument struct and is first looked at when the rows are on their way (generation_schedule_late).
+__device__ __forceinline__ SchedEntry generation_schedule_early(const GenerationFront& f)
 {
-    if (f.sched != nullptr) return *f.sched;
-    SchedEntry e = a.sched_inline;
-    e.gen = (int64_t)f.gen;
+    SchedEntry t{0, 0, 0u, 0u, {0u, 0u}};
+    if (f.sched != nullptr) {
+        typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+        u32x8 r;
+        asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(f.sched));
+        t.gen     = (int64_t)(((uint64_t)r[1] << 32) | r[0]);
+        t.slot    = (int64_t)(((uint64_t)r[3] << 32) | r[2]);
+        t.flags   = r[4];
+        t.nbefore = r[5];
+    } else {
+        t.gen = (int64_t)f.gen;
+    }
+    return t;
+}
+__device__ __forceinline__ SchedEntry generation_schedule_late(const GenerationFront& f, const GenerationArgs& a, const SchedEntry& early)
+{
+    // (the launch kind again, opaque to the optimiser: merged with the branch in generation_schedule_early it would pull the struct's first use -- and the wait for it -- in front of Philox)
+    int eager_late = f.sched == nullptr ? 1 : 0;
+    asm volatile("" : "+v"(eager_late));
+    eager_late = __builtin_amdgcn_readfirstlane(eager_late);
+    SchedEntry e = early;
+    if (eager_late != 0) { e = a.sched_inline; e.gen = early.gen; }
     return e;
+}
+__device__ __forceinline__ DrawConsts generation_draw_consts_early(const GenerationFront& f)        // what Philox and the partner index need
+{
+    DrawConsts dc{};
+    dc.seed_lo = f.seed_lo; dc.seed_hi = f.seed_hi; dc.nhalf = f.h;
+    return dc;
 }
 __device__ __forceinline__ DrawConsts generation_draw_consts(const GenerationFront& f, const GenerationArgs& a)
 {
@@ -118,12 +147,13 @@ __device__ __forceinline__ void generation_lane_body(const GenerationFront& f, c
 {
     static_assert(BlobTrait<Dens>::n == 0, "blobs: the multi-launch kernels");
     KMC_STAMP(0);                                                        // (-DKMC_PROBE builds only: scripts/probe_generation.py) wave entry
-    const bool second = blockIdx.x < f.nb;
-    const uint32_t i = (second ? blockIdx.x : blockIdx.x - f.nb) * blockDim.x + threadIdx.x;
+    const uint32_t nb = f.nb & 0x3fffffffu, tpb = 64u * ((f.nb >> 30) + 1u);
+    const bool second = blockIdx.x < nb;
+    const uint32_t i = (second ? blockIdx.x : blockIdx.x - nb) * tpb + threadIdx.x;
     if (i >= f.h) return;
-    const SchedEntry sch = generation_schedule(f, a);
-    const DrawConsts dc = generation_draw_consts(f, a);
-    const uint64_t step0 = 2ull * (uint64_t)sch.gen;                     // the first half-step of this generation (:246, batch 1)
+    const SchedEntry sch_e = generation_schedule_early(f);
+    const DrawConsts dcf = generation_draw_consts_early(f);
+    const uint64_t step0 = 2ull * (uint64_t)sch_e.gen;                   // the first half-step of this generation (:246, batch 1)
 #ifdef KMC_PROBE
     asm volatile("" :: "s"(step0));
 #endif
@@ -131,8 +161,8 @@ __device__ __forceinline__ void generation_lane_body(const GenerationFront& f, c
     const uint32_t me = (second ? f.h : 0u) + i;
     const size_t ld = (size_t)(f.ld & 0xffff);
     // level 1 = my own move; level 0 (second half only) = my partner's move in the first half-step
-    const U4 mybits = draw_bits(dc, step0 + (second ? 1u : 0u), me);
-    const uint32_t mypartner = (second ? 0u : f.h) + draw_partner(dc, mybits);      // :250
+    const U4 mybits = draw_bits(dcf, step0 + (second ? 1u : 0u), me);
+    const uint32_t mypartner = (second ? 0u : f.h) + draw_partner(dcf, mybits);     // :250
 #ifdef KMC_PROBE
     asm volatile("" :: "v"(mypartner));
 #endif
@@ -142,8 +172,8 @@ __device__ __forceinline__ void generation_lane_body(const GenerationFront& f, c
     U4 bits;
     if (second) {
         const uint32_t w = mypartner;                                    // a first-half walker: its move of step0
-        bits = draw_bits(dc, step0, w);
-        const uint32_t jp = f.h + draw_partner(dc, bits);              // its partner: a second-half row, unchanged by the first half-step
+        bits = draw_bits(dcf, step0, w);
+        const uint32_t jp = f.h + draw_partner(dcf, bits);             // its partner: a second-half row, unchanged by the first half-step
 #ifdef KMC_PROBE
         asm volatile("" :: "v"(jp));
 #endif
@@ -159,6 +189,8 @@ __device__ __forceinline__ void generation_lane_body(const GenerationFront& f, c
         gen_load_row<ND>(f.pin + (size_t)me * ld, own);
         p0 = f.lin[me];
     }
+    const SchedEntry sch = generation_schedule_late(f, a, sch_e);        // from here on the argument struct
+    const DrawConsts dc = generation_draw_consts(f, a);
     const bool count = (sch.flags & kCount) != 0u, sample = (sch.flags & kSample) != 0u;
     double m1[ND], m2[ND];
     const bool moments = sample && a.msum != nullptr;
@@ -257,15 +289,16 @@ __device__ __forceinline__ void generation_group_body(const GenerationFront& f, 
 {
     static_assert(BlobTrait<Dens>::n == 0 && RowEvalTrait<Dens>::n == 0, "lane-striped densities only");
     KMC_STAMP(0);                                                        // (-DKMC_PROBE builds only: scripts/probe_timeline.py) wave entry
-    const uint32_t gpb = blockDim.x / L;                                 // walkers per workgroup
-    const bool second = blockIdx.x < f.nb;
-    const uint32_t i0 = (second ? blockIdx.x : blockIdx.x - f.nb) * gpb + threadIdx.x / L;
+    const uint32_t nb = f.nb & 0x3fffffffu, tpb = 64u * ((f.nb >> 30) + 1u);
+    const uint32_t gpb = tpb / L;                                        // walkers per workgroup
+    const bool second = blockIdx.x < nb;
+    const uint32_t i0 = (second ? blockIdx.x : blockIdx.x - nb) * gpb + threadIdx.x / L;
     const bool valid = i0 < f.h;
     const uint32_t i = valid ? i0 : f.h - 1u;                            // (idle groups of the last workgroup move the last walker and store nothing:
     const int j = (int)(threadIdx.x & (L - 1));                          //  the cross-lane sums want whole waves)
-    const SchedEntry sch = generation_schedule(f, a);
-    const DrawConsts dc = generation_draw_consts(f, a);
-    const uint64_t step0 = 2ull * (uint64_t)sch.gen;
+    const SchedEntry sch_e = generation_schedule_early(f);
+    const DrawConsts dcf = generation_draw_consts_early(f);
+    const uint64_t step0 = 2ull * (uint64_t)sch_e.gen;
     const uint32_t me = (second ? f.h : 0u) + i;
     const int ld = f.ld & 0xffff, ndim = f.ld >> 16;
     const double2 zero2 = make_double2(0.0, 0.0);
@@ -280,15 +313,15 @@ __device__ __forceinline__ void generation_group_body(const GenerationFront& f, 
 #pragma unroll
         for (int k = 0; k < K; ++k) x[k] = r[ck[k]];
     };
-    const U4 mybits = draw_bits(dc, step0 + (second ? 1u : 0u), me);
-    const uint32_t mypartner = (second ? 0u : f.h) + draw_partner(dc, mybits);      // :250
+    const U4 mybits = draw_bits(dcf, step0 + (second ? 1u : 0u), me);
+    const uint32_t mypartner = (second ? 0u : f.h) + draw_partner(dcf, mybits);     // :250
     double2 own[K], oth[K], myown[K];
     double p0, myp0 = 0.0;
     U4 bits;
     if (second) {
         const uint32_t w = mypartner;                                    // a first-half walker: its move of step0
-        bits = draw_bits(dc, step0, w);
-        const uint32_t jp = f.h + draw_partner(dc, bits);
+        bits = draw_bits(dcf, step0, w);
+        const uint32_t jp = f.h + draw_partner(dcf, bits);
         row(f.pin, jp, oth);
         row(f.pin, w, own);
         p0 = f.lin[w];
@@ -302,6 +335,8 @@ __device__ __forceinline__ void generation_group_body(const GenerationFront& f, 
 #pragma unroll
         for (int k = 0; k < K; ++k) myown[k] = zero2;
     }
+    const SchedEntry sch = generation_schedule_late(f, a, sch_e);        // from here on the argument struct
+    const DrawConsts dc = generation_draw_consts(f, a);
     const bool count = (sch.flags & kCount) != 0u, sample = (sch.flags & kSample) != 0u;
     const bool moments = count && a.msum != nullptr;
     const uint32_t gl = a.glast[me];
@@ -312,7 +347,7 @@ __device__ __forceinline__ void generation_group_body(const GenerationFront& f, 
     // (profiles/r05_generation_summary.json: 35.8 MB per generation, 16.8 of them the sums).  Other geometries: per-walker sums laid out like the rows.
     constexpr bool kFold = FoldT<L, K>::on;
     const int lane = (int)(threadIdx.x & 63u);
-    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t wave = (int64_t)blockIdx.x * (tpb >> 6) + (threadIdx.x >> 6);
     double2 m1[K], m2[K];
     double acct[4] = {0.0, 0.0, 0.0, 0.0};
     if constexpr (kFold) {

@@ -1,7 +1,7 @@
-// kmc_launch.hip -- the `_emcee` generation loop (reference src/samplers.jl:232-293) as a stream of half-step kernel
-// launches: two dependent launches per generation (the kernel boundary is the join of src/samplers.jl:273), replayed from a
-// hipGraph in chunks of kGraphChunk generations -- table-driven, or with per-replay parameter updates -- or issued eagerly;
-// the calibration that picks between them and the process-wide budget of the updated-graph mode.
+// kmc_launch.hip -- the `_emcee` generation loop (reference src/samplers.jl:232-293) as a stream of kernel launches: two dependent
+// half-step launches per generation (the kernel boundary is the join of src/samplers.jl:273) -- or, for small states, one launch per
+// generation (kmc_generation.hpp) --, replayed from a hipGraph in chunks of kGraphChunk generations -- table-driven, or with per-replay
+// parameter updates -- or issued eagerly; the calibration that picks between them and the process-wide budget of the updated-graph mode.
 #include <algorithm>
 #include <atomic>
 #include <cmath>
@@ -237,11 +237,16 @@ GenerationArgs make_generation_args(const kmc_sampler* s, int from, bool graph_m
 
 static_assert(offsetof(GenerationLaunch, a) == 56 && offsetof(GenerationFront, gen) == 52, "kernarg layout of the generation kernels");
 
+// the head of the chain among the preloaded kernel parameters (GenerationFront)
+GenerationFront generation_front_of(const GenerationArgs& a, int tpb)
+{
+    return GenerationFront{a.sched, a.pin, a.lin, a.pout, a.dc.seed_lo, a.dc.seed_hi, a.h, a.nb | ((uint32_t)(tpb / 64 - 1) << 30), a.ld | (a.ndim << 16), (uint32_t)a.sched_inline.gen};
+}
+
 hipError_t launch_generation(const kmc_sampler* s, int from, bool graph_mode, int64_t gen_offset)
 {
     const GenerationArgs a = make_generation_args(s, from, graph_mode, gen_offset);
-    // the head of the chain among the preloaded kernel parameters (GenerationFront)
-    const GenerationFront f{a.sched, a.pin, a.lin, a.pout, a.dc.seed_lo, a.dc.seed_hi, a.h, a.nb, a.ld | (a.ndim << 16), (uint32_t)a.sched_inline.gen};
+    const GenerationFront f = generation_front_of(a, s->fused_tpb);
     const unsigned tpb = (unsigned)s->fused_tpb;
     if (s->user) {
         const GenerationLaunch la{f, a};
@@ -265,6 +270,17 @@ hipError_t generation_settle(kmc_sampler* s)
 // at creation): for a caller that steps by halves (kmc_sampler_half_step) or attaches an RCCL communicator (an all-gather follows every
 // half-step).  The moments credited so far -- every walker's current value included, up to now -- are read out once and carried on the host
 // (added at every later read-out); the walkers' current values stand for the samples from here on (klast = samples taken).
+void drop_updated_graph(kmc_sampler* s)
+{
+    for (int i = 0; i < kUExec; ++i) {
+        if (s->uexec[i]) { (void)hipGraphExecDestroy(s->uexec[i]); s->uexec[i] = nullptr; }
+        if (s->udone[i]) { (void)hipEventDestroy(s->udone[i]); s->udone[i] = nullptr; }      // (ensure_updated_graph creates them anew)
+        s->uinflight[i] = false;
+    }
+    s->unext = 0;
+    if (s->ugraph) { (void)hipGraphDestroy(s->ugraph); s->ugraph = nullptr; }
+}
+
 kmc_status unfuse(kmc_sampler* s)
 {
     if (!s->fused) return KMC_OK;
@@ -280,8 +296,10 @@ kmc_status unfuse(kmc_sampler* s)
     }
     if (s->graph_exec) { (void)hipGraphExecDestroy(s->graph_exec); s->graph_exec = nullptr; }
     if (s->graph) { (void)hipGraphDestroy(s->graph); s->graph = nullptr; }
+    drop_updated_graph(s);                                  // (its nodes are generation kernels)
     s->fused = false;
     s->launch_mode = 0;
+    s->calib_graph_ms = s->calib_eager_ms = 0.f;
     return KMC_OK;
 }
 
@@ -343,6 +361,29 @@ struct KernelParamPack {      // storage the kernelParams pointers of one node r
     }
 };
 
+struct GenerationParamPack {  // the same for a generation kernel's node (one launch per generation)
+    GenerationFront f;
+    GenerationArgs a;
+    void* ptrs[11];
+    void bind()
+    {
+        ptrs[0] = &f.sched; ptrs[1] = &f.pin; ptrs[2] = &f.lin; ptrs[3] = &f.pout; ptrs[4] = &f.seed_lo; ptrs[5] = &f.seed_hi;
+        ptrs[6] = &f.h; ptrs[7] = &f.nb; ptrs[8] = &f.ld; ptrs[9] = &f.gen; ptrs[10] = &a;
+    }
+};
+
+hipKernelNodeParams generation_node_params(const kmc_sampler* s, GenerationParamPack* pk)
+{
+    hipKernelNodeParams np{};
+    np.func = s->user ? reinterpret_cast<void*>(s->uk.generation) : reinterpret_cast<void*>(s->generation_kernel);
+    np.gridDim = dim3(2u * pk->a.nb);
+    np.blockDim = dim3((unsigned)s->fused_tpb);
+    np.sharedMemBytes = 0u;
+    np.kernelParams = pk->ptrs;
+    np.extra = nullptr;
+    return np;
+}
+
 hipKernelNodeParams node_params(const kmc_sampler* s, KernelParamPack* pk)
 {
     hipKernelNodeParams np{};
@@ -359,7 +400,8 @@ hipKernelNodeParams node_params(const kmc_sampler* s, KernelParamPack* pk)
 
 bool updated_graph_possible(const kmc_sampler* s)
 {
-    if (s->p2p || s->host_eval || s->islands || s->resident || s->fused || s->comm || s->updated_refused) return false;
+    if (s->p2p || s->host_eval || s->islands || s->resident || s->comm || s->updated_refused) return false;
+    if (s->fused) return s->user ? s->uk.generation != nullptr : s->generation_kernel != nullptr;      // (one node per generation: the generation among the preloaded parameters)
     return s->user ? (s->plan.vec && s->uk.vec != nullptr) : s->plan.fn != nullptr;
 }
 
@@ -367,11 +409,25 @@ kmc_status ensure_updated_graph(kmc_sampler* s)
 {
     if (s->uexec[0]) return KMC_OK;
     HIP_TRY(hipGraphCreate(&s->ugraph, 0));
-    s->unodes.assign((size_t)(2 * s->uchunk), nullptr);
+    s->unodes.assign((size_t)((s->fused ? 1 : 2) * s->uchunk), nullptr);
+    hipGraphNode_t prev = nullptr;
+    if (s->fused) {
+        // one node per generation, reading copy g & 1 of the state and writing the other (uchunk is even: a replay ends in the copy it started from)
+        GenerationParamPack gp;
+        gp.bind();
+        for (int64_t g = 0; g < s->uchunk; ++g) {
+            gp.a = make_generation_args(s, (int)(g & 1), false, g);
+            gp.f = generation_front_of(gp.a, s->fused_tpb);
+            const hipKernelNodeParams np = generation_node_params(s, &gp);
+            hipGraphNode_t node = nullptr;
+            HIP_TRY(hipGraphAddKernelNode(&node, s->ugraph, prev ? &prev : nullptr, prev ? 1 : 0, &np));
+            s->unodes[(size_t)g] = node;
+            prev = node;
+        }
+    }
     KernelParamPack pk;
     pk.bind();
-    hipGraphNode_t prev = nullptr;
-    for (int64_t g = 0; g < s->uchunk; ++g)
+    for (int64_t g = 0; g < s->uchunk && !s->fused; ++g)
         for (int half = 0; half < 2; ++half) {
             pk.a = make_args(s, half, false, g);
             pk.f = front_of(pk.a, s->ragged_vec());
@@ -430,14 +486,24 @@ kmc_status launch_updated_graph(kmc_sampler* s, bool* launched)
 {
     *launched = false;
     KMC_TRY(ensure_updated_graph(s));
-    g_update_calls.fetch_add(2 * s->uchunk, std::memory_order_relaxed);
+    g_update_calls.fetch_add((s->fused ? 1 : 2) * s->uchunk, std::memory_order_relaxed);
     const int i = s->unext;
     const auto t_wait0 = std::chrono::steady_clock::now();
     if (s->uinflight[i]) { HIP_TRY(hipEventSynchronize(s->udone[i])); s->uinflight[i] = false; }
     const auto t_upd0 = std::chrono::steady_clock::now();
+    if (s->fused) {
+        GenerationParamPack gp;
+        gp.bind();
+        for (int64_t g = 0; g < s->uchunk; ++g) {
+            gp.a = make_generation_args(s, (int)(g & 1), false, s->generation + g);
+            gp.f = generation_front_of(gp.a, s->fused_tpb);
+            const hipKernelNodeParams np = generation_node_params(s, &gp);
+            HIP_TRY(hipGraphExecKernelNodeSetParams(s->uexec[i], s->unodes[(size_t)g], &np));
+        }
+    }
     KernelParamPack pk;
     pk.bind();
-    for (int64_t g = 0; g < s->uchunk; ++g)
+    for (int64_t g = 0; g < s->uchunk && !s->fused; ++g)
         for (int half = 0; half < 2; ++half) {
             pk.a = make_args(s, half, false, s->generation + g);
             pk.f = front_of(pk.a, s->ragged_vec());
@@ -548,43 +614,14 @@ KMC_EXPORT kmc_status kmc_sampler_run(kmc_sampler* s, int64_t ngen)
         s->have_run_events = true;
         return KMC_OK;
     }
-    if (s->fused) {
-        // one launch per generation: whole chunks from the table graph (an even number of generations: the state ends where it
-        // started, in d_pos / d_logp), the rest launch by launch; the state is moved back into d_pos / d_logp at the end
-        const char* forced = std::getenv("KMC_LAUNCH");
-        const bool use_graph = !(s->cfg.flags & KMC_NO_GRAPH) && !(forced && std::strcmp(forced, "eager") == 0);
-        if (s->fused_L > 0 && ngen > 0 && !(s->pos2_current && s->own_pos && !s->pos_exposed)) {
-            // the lane-striped form writes a row to the output copy only when that copy does not hold it already: the copies are made equal whenever
-            // somebody may have changed d_pos / d_logp since the last run (set_positions, set_state, the initial ball: they write the first pair only;
-            // a caller-owned buffer -- kmc_sampler_bind_positions -- may change at any time: every run); between runs the kernels keep them consistent
-            HIP_TRY(hipMemcpyAsync(s->d_pos2, s->d_pos, (size_t)s->nrows * (size_t)s->ld * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
-            HIP_TRY(hipMemcpyAsync(s->d_logp2, s->d_logp, (size_t)s->nrows * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
-            s->pos2_current = true;
-        }
-        while (use_graph && ngen >= kGraphChunk) {
-            HIP_TRY(generation_settle(s));
-            KMC_TRY(ensure_graph(s));
-            KMC_TRY(sync_device_counter(s));
-            KMC_TRY(chain_before(s, s->generation + kGraphChunk));
-            HIP_TRY(hipGraphLaunch(s->graph_exec, s->stream));
-            s->generation += kGraphChunk;
-            s->dev_gen += kGraphChunk;
-            s->launches += kGraphChunk;
-            ngen -= kGraphChunk;
-            KMC_TRY(chain_after(s));
-        }
-        for (; ngen > 0; --ngen) {
-            KMC_TRY(chain_before(s, s->generation + 1));
-            HIP_TRY(launch_generation(s, s->fused_cur, false, s->generation));
-            s->fused_cur ^= 1;
-            s->generation += 1;
-            s->launches += 1;
-            KMC_TRY(chain_after(s));
-        }
-        HIP_TRY(generation_settle(s));
-        HIP_TRY(hipEventRecord(s->ev1, s->stream));
-        s->have_run_events = true;
-        return KMC_OK;
+    if (s->fused && s->fused_L > 0 && ngen > 0 && !(s->pos2_current && s->own_pos && !s->pos_exposed)) {
+        // One launch per generation reads one copy of the state and writes the other.  The lane-striped form writes a row to the output copy only when that
+        // copy does not hold it already: the copies are made equal whenever somebody may have changed d_pos / d_logp since the last run (set_positions,
+        // set_state, the initial ball: they write the first pair only; a caller-owned buffer -- kmc_sampler_bind_positions -- may change at any time: every
+        // run); between runs the kernels keep them consistent.  (Launch modes: below, with the two-launch kernels' -- whole chunks start in copy 0.)
+        HIP_TRY(hipMemcpyAsync(s->d_pos2, s->d_pos, (size_t)s->nrows * (size_t)s->ld * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+        HIP_TRY(hipMemcpyAsync(s->d_logp2, s->d_logp, (size_t)s->nrows * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+        s->pos2_current = true;
     }
     if (s->islands) {
         // one launch per epoch (or per piece of one, when a run stops inside an epoch)
@@ -691,31 +728,39 @@ KMC_EXPORT kmc_status kmc_sampler_run(kmc_sampler* s, int64_t ngen)
         s->have_run_events = true;
         return KMC_OK;
     }
+    const int64_t lpg = s->fused ? 1 : 2;                    // launches per generation
     auto eager_generations = [&](int64_t n) -> kmc_status {
         for (; n > 0; --n, --ngen) {
             KMC_TRY(chain_before(s, s->generation + 1));
-            for (int half = 0; half < 2; ++half) KMC_TRY(launch_half(s, half, false, s->generation));
+            if (s->fused) {
+                HIP_TRY(launch_generation(s, s->fused_cur, false, s->generation));
+                s->fused_cur ^= 1;
+            } else {
+                for (int half = 0; half < 2; ++half) KMC_TRY(launch_half(s, half, false, s->generation));
+            }
             s->generation += 1;
-            s->launches += 2;
-            if (++s->gens_since_sweep >= kSweepEvery) HIP_TRY(launch_sweep(s));
+            s->launches += lpg;
+            if (!s->fused && ++s->gens_since_sweep >= kSweepEvery) HIP_TRY(launch_sweep(s));
             KMC_TRY(chain_after(s));
         }
         return KMC_OK;
     };
     auto graph_chunk = [&]() -> kmc_status {
+        if (s->fused) HIP_TRY(generation_settle(s));                    // (a chunk of generation kernels starts in copy 0 and ends there)
         KMC_TRY(ensure_graph(s));
         if (!s->graph_exec) return eager_generations(kGraphChunk);      // (RCCL all-gather that cannot be captured)
         KMC_TRY(sync_device_counter(s));
         KMC_TRY(chain_before(s, s->generation + kGraphChunk));
         HIP_TRY(hipGraphLaunch(s->graph_exec, s->stream));
-        HIP_TRY(launch_sweep(s));
+        if (!s->fused) HIP_TRY(launch_sweep(s));
         s->generation += kGraphChunk;
         s->dev_gen += kGraphChunk;
-        s->launches += 2 * kGraphChunk;
+        s->launches += lpg * kGraphChunk;
         ngen -= kGraphChunk;
         return chain_after(s);
     };
     auto updated_chunk = [&]() -> kmc_status {
+        if (s->fused) HIP_TRY(generation_settle(s));
         KMC_TRY(chain_before(s, s->generation + s->uchunk));
         bool launched = false;
         if (launch_updated_graph(s, &launched) != KMC_OK) {
@@ -724,12 +769,13 @@ KMC_EXPORT kmc_status kmc_sampler_run(kmc_sampler* s, int64_t ngen)
             // ran, nothing to account.  Failed after it (the event of this executable): the replay is running -- account
             // it; without its event the executable is not reused, which leaving this mode guarantees.
             s->launch_mode = 1;
+            if (debug_opt("feed-stats")) std::fprintf(stderr, "[kissmcmc_hip] the updated-graph replay failed (%s): table graph from here on\n", kmc_last_error());
             if (!launched) return KMC_OK;
             HIP_TRY(hipStreamSynchronize(s->stream));
         }
-        HIP_TRY(launch_sweep(s));
+        if (!s->fused) HIP_TRY(launch_sweep(s));
         s->generation += s->uchunk;
-        s->launches += 2 * s->uchunk;
+        s->launches += lpg * s->uchunk;
         ngen -= s->uchunk;
         return chain_after(s);
     };
@@ -781,11 +827,7 @@ KMC_EXPORT kmc_status kmc_sampler_run(kmc_sampler* s, int64_t ngen)
         // module functions as graph kernel nodes: build the graph now; a runtime that refuses leaves this sampler with the table graph
         if (ensure_updated_graph(s) != KMC_OK) {
             (void)hipGetLastError();
-            for (int i = 0; i < kUExec; ++i) {
-                if (s->uexec[i]) { (void)hipGraphExecDestroy(s->uexec[i]); s->uexec[i] = nullptr; }
-                if (s->udone[i]) { (void)hipEventDestroy(s->udone[i]); s->udone[i] = nullptr; }
-            }
-            if (s->ugraph) { (void)hipGraphDestroy(s->ugraph); s->ugraph = nullptr; }
+            drop_updated_graph(s);
             s->updated_refused = true;
         }
     }
@@ -814,6 +856,7 @@ KMC_EXPORT kmc_status kmc_sampler_run(kmc_sampler* s, int64_t ngen)
     if (s->launch_mode == 2) use_graph = false;
     while (use_graph && ngen >= kGraphChunk) KMC_TRY(graph_chunk());
     KMC_TRY(eager_generations(ngen));
+    if (s->fused) HIP_TRY(generation_settle(s));                        // the state back in d_pos / d_logp (after an odd number of generations)
     HIP_TRY(hipEventRecord(s->ev1, s->stream));
     s->have_run_events = true;
     return KMC_OK;
@@ -871,7 +914,6 @@ KMC_EXPORT int kmc_sampler_launch_mode(const kmc_sampler* s, int* budget_fallbac
     if (!s) return -1;
     if (budget_fallback) *budget_fallback = s->budget_fallback ? 1 : 0;
     if (s->resident || s->islands || s->host_eval) return KMC_LAUNCH_SINGLE;
-    if (s->fused) return KMC_LAUNCH_TABLE_GRAPH;
     if ((s->cfg.flags & KMC_NO_GRAPH) || (s->comm && !s->comm_graph_ok)) return KMC_LAUNCH_EAGER;
     return s->launch_mode;
 }

@@ -480,7 +480,6 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
             s->fused = s->generation_kernel != nullptr;
         }
         if (s->fused) {
-            s->launch_mode = 1;
             s->fused_L = kind == 1 ? 0 : kind == 3 ? 4 : s->plan.L;
             // one wave per workgroup (measured best at every size for one walker per lane, `profiles/r04_generation_variants_ab.txt`); lane-striped:
             // two once the half's waves exceed the chip's SIMDs about once
@@ -713,11 +712,7 @@ KMC_EXPORT void kmc_sampler_destroy(kmc_sampler* s)
     // collectives on a replica shard's rows -- is waited for here; a plain single-GPU sampler (its own stream only) pays nothing.
     if (s->foreign_stream_seen || s->cfg.shard_count > 1 || s->comm) (void)hipDeviceSynchronize();
     if (!s->guards.empty() && s->stream) check_guards(s);
-    for (int i = 0; i < kUExec; ++i) {
-        if (s->uexec[i]) (void)hipGraphExecDestroy(s->uexec[i]);
-        if (s->udone[i]) (void)hipEventDestroy(s->udone[i]);
-    }
-    if (s->ugraph) (void)hipGraphDestroy(s->ugraph);
+    drop_updated_graph(s);
     if (s->graph_exec) (void)hipGraphExecDestroy(s->graph_exec);
     s->uk.keep.reset();                 // (the module goes when its last holder does: the density's cache, other samplers)
     if (s->graph) (void)hipGraphDestroy(s->graph);
@@ -796,13 +791,7 @@ KMC_EXPORT kmc_status kmc_sampler_bind_positions(kmc_sampler* s, void* pos_dev)
     HIP_TRY(hipStreamSynchronize(s->stream));
     if (s->graph_exec) { (void)hipGraphExecDestroy(s->graph_exec); s->graph_exec = nullptr; }
     if (s->graph) { (void)hipGraphDestroy(s->graph); s->graph = nullptr; }
-    for (int i = 0; i < kUExec; ++i) {
-        if (s->uexec[i]) { (void)hipGraphExecDestroy(s->uexec[i]); s->uexec[i] = nullptr; }
-        if (s->udone[i]) { (void)hipEventDestroy(s->udone[i]); s->udone[i] = nullptr; }      // (ensure_updated_graph creates them anew)
-        s->uinflight[i] = false;
-    }
-    s->unext = 0;
-    if (s->ugraph) { (void)hipGraphDestroy(s->ugraph); s->ugraph = nullptr; }
+    drop_updated_graph(s);                                              // (ensure_updated_graph builds it anew)
     if (s->own_pos) {
         for (size_t i = 0; i < s->guards.size(); ++i)                   // (KMC_DEBUG=poison: this allocation's guard goes with it)
             if (s->guards[i].first - s->guards[i].second == reinterpret_cast<char*>(s->d_pos)) { s->guards.erase(s->guards.begin() + (long)i); break; }
@@ -818,6 +807,22 @@ KMC_EXPORT kmc_status kmc_sampler_bind_positions(kmc_sampler* s, void* pos_dev)
 KMC_EXPORT int64_t kmc_sampler_generation(const kmc_sampler* s) { return s ? s->generation : -1; }
 KMC_EXPORT int64_t kmc_sampler_nsamples(const kmc_sampler* s) { return s ? s->nsamples : -1; }
 KMC_EXPORT int64_t kmc_sampler_launch_count(const kmc_sampler* s) { return s ? s->launches : -1; }
+
+namespace {
+// how kmc_sampler_run issues the launches of the multi-launch kernels (two per generation, or one): kmc_launch.hip
+std::string launch_mode_text(const kmc_sampler* s, const char* what)
+{
+    std::string t = ((s->cfg.flags & KMC_NO_GRAPH) || s->launch_mode == 2) ? std::string(", eager launches (") + what + " among the preloaded kernel parameters)"
+                    : s->launch_mode == 3 ? std::string(", hipGraph replay of 64 generations with per-replay parameter updates (") + what + " preloaded)"
+                                          : std::string(", hipGraph replay of 64 generations");
+    if (s->calib_graph_ms > 0.f) {
+        char b[128];
+        std::snprintf(b, sizeof(b), " (measured per 64 generations: table graph %.3f ms, %s %.3f ms)", s->calib_graph_ms, s->launch_mode == 2 ? "eager launches" : "updated graph", s->calib_eager_ms);
+        t += b;
+    }
+    return t;
+}
+}  // namespace
 
 // Human-readable description of how this sampler executes (kernel family, geometry, exchange).
 KMC_EXPORT kmc_status kmc_sampler_describe(const kmc_sampler* s, char* buf, int64_t buflen)
@@ -835,24 +840,18 @@ KMC_EXPORT kmc_status kmc_sampler_describe(const kmc_sampler* s, char* buf, int6
     else if (s->fused) {
         if (s->fused_L == 0)
             o << "one launch per generation (exact): generation_lane ND=" << s->cfg.ndim << ", one walker per lane, second-half walkers recompute their partner's first-half move, grid "
-              << 2 * ((s->h + s->fused_tpb - 1) / s->fused_tpb) << " x " << s->fused_tpb << ", hipGraph replay of 64 generations";
+              << 2 * ((s->h + s->fused_tpb - 1) / s->fused_tpb) << " x " << s->fused_tpb;
         else
             o << "one launch per generation (exact): generation_group L=" << s->fused_L << " K=" << s->plan.K << ", rows lane-striped, second-half walkers recompute their partner's first-half move, grid "
-              << 2 * ((s->h + s->fused_tpb / s->fused_L - 1) / (s->fused_tpb / s->fused_L)) << " x " << s->fused_tpb << ", hipGraph replay of 64 generations";
+              << 2 * ((s->h + s->fused_tpb / s->fused_L - 1) / (s->fused_tpb / s->fused_L)) << " x " << s->fused_tpb;
+        o << launch_mode_text(s, "generation");
     } else if (s->host_eval)
         o << "host-evaluated density (exact): per half-step propose kernel -> D2H -> callback -> H2D -> accept kernel, grid "
           << s->grid << " x 256";
     else if (s->plan.vec) {
         o << "multi-launch (exact): half_step_vec L=" << s->plan.L << " K=" << s->plan.K << " ITER=" << s->plan.ITER
           << (s->plan.ragged ? " ragged" : " exact-size") << ", grid " << s->grid << " x " << s->tpb
-          << (((s->cfg.flags & KMC_NO_GRAPH) || s->launch_mode == 2) ? ", eager launches (step among the preloaded kernel parameters)"
-              : s->launch_mode == 3 ? ", hipGraph replay of 64 generations with per-replay parameter updates (step preloaded)"
-                                    : ", hipGraph replay of 64 generations");
-        if (s->calib_graph_ms > 0.f) {
-            char b[128];
-            std::snprintf(b, sizeof(b), " (measured per 64 generations: table graph %.3f ms, %s %.3f ms)", s->calib_graph_ms, s->launch_mode == 2 ? "eager launches" : "updated graph", s->calib_eager_ms);
-            o << b;
-        }
+          << launch_mode_text(s, "step");
     } else
         o << "multi-launch (exact): " << (s->user && s->uk.staged ? "half_step_staged (one walker per lane, rows staged through LDS)" : "half_step_generic (one walker per lane)")
           << ", grid " << s->grid << " x " << s->tpb;

@@ -97,11 +97,11 @@ struct kmc_sampler {
     int64_t generation = 0;   // generations enqueued so far
     int64_t dev_gen = 0;      // value the device counter will hold once the stream drains
     int64_t launches = 0;
-    int launch_mode = 0;      // 0: not decided, 1: table graph, 2: eager launches, 3: updated graph, KMC_LAUNCH=updated only (kmc_sampler_run)
+    int launch_mode = 0;      // 0: not decided, 1: table graph, 2: eager launches, 3: updated graph (kmc_sampler_run; the two-launch kernels and, since round 5, the generation kernels)
     float calib_graph_ms = 0.f, calib_eager_ms = 0.f;   // one chunk each, when measured
     hipGraphExec_t graph_exec = nullptr;
     hipGraph_t graph = nullptr;
-    // "updated graph": a chain of kGraphChunk * 2 kernel nodes launched in the eager form (step among the preloaded
+    // "updated graph": a chain of kGraphChunk * 2 kernel nodes (generation kernels: kGraphChunk) launched in the eager form (step among the preloaded
     // parameters, schedule entry in the args), their parameters rewritten before every replay; kUExec executables
     // take turns, so the host updates up to kUExec - 1 replays ahead of the one that is running (two were enough for
     // a quiet host -- the update of 128 nodes takes about as long as their replay -- but left a single replay of
@@ -220,6 +220,7 @@ void chain_unregister(kmc_sampler* s);
 kmc_status load_user(kmc_user_density* ud, bool with_vec, int L, int K, int iter, bool ragged, UserKernels* uk,
                      int resident_K = 0, bool resident_ragged = false, int island_S = 0, bool f32 = false, int64_t ndim = 0, bool p2p = false,
                      int generation_nd = 0);
+void drop_updated_graph(kmc_sampler* s);                               // the updated-graph mode's executables, events and template graph (kmc_launch.hip)
 kmc_status unfuse(kmc_sampler* s);                                     // back to the two-launch kernels, in place (kmc_launch.hip)
 void set_offline_compiler_hint(bool wanted);                          // runtime-compiled kernels of this thread: hipcc as a child process instead of hiprtc (kmc_rtc.hip)
 bool body_vec_possible(const kmc_user_density* ud, int64_t ndim);     // a function body inside the vector kernels, evaluated per walker (kmc_rtc.hip)

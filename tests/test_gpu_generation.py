@@ -326,3 +326,84 @@ def test_long_run_equals_the_two_launch_kernels(kmc, kmc_debug, nw, nd):
     assert out["one"][2][2] == out["two"][2][2]
     np.testing.assert_allclose(out["one"][2][0], out["two"][2][0], rtol=1e-10, atol=1e-6)
     np.testing.assert_allclose(out["one"][2][1], out["two"][2][1], rtol=1e-10)
+
+
+@pytest.mark.parametrize("launch", ["graph", "updated", "eager", None])
+@pytest.mark.parametrize("name,nw,nd", [("gauss", 4096, 4), ("rosen", 4096, 64), ("gauss", 3000, 33)])
+def test_every_launch_mode_of_the_generation_kernels_is_the_oracles_run(kmc, oracle, monkeypatch, launch, name, nw, nd):
+    """One launch per generation from the table graph, from a graph whose node parameters are rewritten before every replay (the generation among the
+    preloaded kernel parameters: round 5), eagerly, or as measured (None: a run long enough to calibrate): uneven pieces -- whole chunks, odd tails, a
+    piece that starts in the second copy of the state -- end in the oracle's uninterrupted run, chain and moments included."""
+    if launch is None:
+        monkeypatch.delenv("KMC_LAUNCH", raising=False)
+    else:
+        monkeypatch.setenv("KMC_LAUNCH", launch)
+    pdf, did, params = _densities(kmc, oracle)[name]
+    G, nburn, nthin, seed = 1100, 301, 7, 17
+    th = _theta0(name, nw, nd, seed)
+    with kmc.Sampler(pdf, nw, nd, G, nburn, nthin, 2.0, seed, store_chain=True, store_logp=True, moments=True) as s:
+        assert "one launch per generation" in s.describe()
+        s.set_positions(th)
+        for piece in (1, 64, 65, 129, 1100 - 259):           # (the last piece is long enough for the launch-mode measurement when nothing is forced)
+            s.run(piece)
+        s.sync()
+        how = s.describe()
+        got = dict(final_pos=s.positions(), final_logp=s.logp(), naccept=s.naccept(), accept_ratio=s.accept_ratio())
+        got["chain"], got["chain_logp"] = s.chain()
+        got["sum"], got["sumsq"], got["nmoment"] = s.moments()
+        mode, _ = s.launch_mode()
+        assert s.generation == G and s.launch_count == G
+    if launch == "updated":
+        assert mode == 3 and "generation preloaded" in how, how
+    elif launch == "graph":
+        assert mode == 1 and "preloaded" not in how, how
+    elif launch == "eager":
+        assert mode == 2 and "eager launches" in how, how
+    else:
+        assert mode in (1, 2, 3) and "measured per 64 generations" in how, how
+    ref = oracle.emcee(oracle.make_config(did, params, nw, nd, G, nburn, nthin, 2.0, seed), th)
+    _compare(ref, got)
+
+
+def test_generation_kernels_leave_the_updated_graph_when_the_budget_is_spent_or_the_caller_steps_by_halves(kmc, oracle, monkeypatch):
+    """The updated-graph mode of a one-launch-per-generation sampler draws on the same process-wide budget of parameter updates (one per generation); it
+    goes on with the table graph when that is spent in the middle of a run, and kmc_sampler_half_step takes the sampler to its two-launch kernels with
+    the updated graph of generation kernels gone -- all of it the oracle's run."""
+    import ctypes as C
+    from kissmcmc_jl_amd import _lib
+    L = _lib.lib()
+    used, budget = C.c_int64(0), C.c_int64(0)
+    L.kmc_updated_budget(C.byref(used), C.byref(budget))
+    L.kmc_set_updated_budget_mb(1.0)
+    one_mib = C.c_int64(0)
+    L.kmc_updated_budget(None, C.byref(one_mib))
+    each = float(round(1048576.0 / one_mib.value))
+    nw, nd, G, nburn, seed = 4096, 4, 700, 100, 23
+    th = _theta0("gauss", nw, nd, seed)
+    monkeypatch.setenv("KMC_LAUNCH", "updated,budget")
+    try:
+        L.kmc_set_updated_budget_mb((used.value + 3 * 128) * each / 1048576.0 + 1e-9)     # room for three replays as the two-launch kernels count them (2 x 64 updates)
+        with kmc.Sampler(kmc.GaussianIso(), nw, nd, G, nburn, 1, 2.0, seed, moments=True) as s:
+            s.set_positions(th)
+            s.run(640)
+            s.sync()
+            how = s.describe()
+            mode, fell_back = s.launch_mode()
+            assert fell_back and mode in (0, 1, 2) and "budget of the process spent" in how, (mode, fell_back, how)      # (0: too little left to measure -- whole chunks from the table graph)
+            u2 = C.c_int64(0)
+            L.kmc_updated_budget(C.byref(u2), None)
+            assert 64 <= u2.value - used.value <= 3 * 128
+            s.half_step(0)
+            s.half_step(1)                                   # generation 641, by halves: the two-launch kernels from here on
+            assert "one launch per generation" not in s.describe()
+            s.run(G - 641)
+            s.sync()
+            pos, nacc = s.positions(), s.naccept()
+            msum, msq, n = s.moments()
+    finally:
+        L.kmc_set_updated_budget_mb(budget.value * each / 1048576.0 + 1e-9)
+    ref = oracle.emcee(oracle.make_config(oracle.GAUSSIAN_ISO, [0.0, 1.0], nw, nd, G, nburn, 1, 2.0, seed), th, store_chain=False)
+    np.testing.assert_array_equal(pos, ref["final_pos"])
+    np.testing.assert_array_equal(nacc, ref["naccept"])
+    assert n == ref["nmoment"]
+    np.testing.assert_allclose(msum, ref["sum"], rtol=1e-11, atol=1e-9)
