@@ -428,7 +428,7 @@ __device__ __forceinline__ void generation_group_body(const GenerationFront& f, 
             fold_scatter<L, K>(lane, ms, mq, v);
             double* slot = a.msum + (wave * FoldT<L, K>::NVL) * 64 + lane;
 #pragma unroll
-            for (int r = 0; r < FoldT<L, K>::NVL; ++r) slot[r * 64] = acct[r] + v[r];
+            for (int r = 0; r < FoldT<L, K>::NVL; ++r) store_wt(&slot[r * 64], acct[r] + v[r]);
         }
     }
     if (!valid) return;
@@ -444,7 +444,7 @@ __device__ __forceinline__ void generation_group_body(const GenerationFront& f, 
             }
         }
     }
-    if (acc && moments && j == 0) a.klast[me] = sch.nbefore;
+    if (acc && moments && j == 0) store_wt(&a.klast[me], sch.nbefore);
 #pragma unroll
     for (int k = 0; k < K; ++k) { y[k].x = acc ? y[k].x : own[k].x; y[k].y = acc ? y[k].y : own[k].y; }   // :261
     const double pnew = acc ? p1 : p0;                                   // :262
@@ -454,11 +454,11 @@ __device__ __forceinline__ void generation_group_body(const GenerationFront& f, 
     if (acc || gl == (uint32_t)sch.gen) {
         double2* out = reinterpret_cast<double2*>(f.pout + row_off(me));
 #pragma unroll
-        for (int k = 0; k < K; ++k) out[ck[k]] = y[k];
-        if (j == 0) a.lout[me] = pnew;
+        for (int k = 0; k < K; ++k) store_wt(&out[ck[k]], y[k]);
+        if (j == 0) store_wt(&a.lout[me], pnew);
     }
     if (acc && j == 0) {
-        a.glast[me] = (uint32_t)sch.gen + 1u;
+        store_wt(&a.glast[me], (uint32_t)sch.gen + 1u);
         if (count) (void)__hip_atomic_fetch_add(&a.naccept[me], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // :265 (see generation_lane_body)
     }
     if (sample) {                                                        // :268-271

@@ -268,9 +268,10 @@ namespace {
 // once per generation instead of twice.  0: no; 1: one walker per lane (ndim <= 8); 2: rows lane-striped like the vector kernels (longer
 // rows; lane-striped densities).  Measured against the two-launch kernels (profiles/r04_generation_map.txt): short rows 1.3-1.9 x ahead up
 // to 32 768 walkers, 1.25-1.4 x at 65 536 walkers of one or two doubles, behind beyond that; longer rows 1.15-1.55 x ahead while the state
-// stays within ~2.3 MiB, 1.12-1.2 x at 4 MiB (8 192 x 64, 32 768 x 16, 16 384 x 32); between 4 and 8 MiB it depends on the number of walkers -- the kernel moves
-// 1.5 x the walkers and reads 2.5 x the rows: up to 16 384 walkers 1.02-1.19 x ahead (C3 1.04 x, 16 384 x 48 1.09, 4 096 x 256 1.19), from 24 576 walkers on
-// 0.90-0.97 x; behind at 10 MiB (profiles/r05_generation_mid.txt, profiles/r05_generation_limit.txt -- measured again after the row masks went: C3 was 0.95 x before).
+// stays within ~2.3 MiB, 1.25-1.4 x at 4 MiB (8 192 x 64, 32 768 x 16, 16 384 x 32), 1.06-1.3 x between 4 and 8 MiB (C3 1.17 x, 16 384 x 48 1.33, 24 576 x 32 1.18,
+// 32 768 x 32 1.06, 49 152 x 16 1.10) except with 65 536 walkers (x 16: 0.94), mixed at 10 MiB (0.91-1.07) and behind from 12 MiB on -- the kernel moves 1.5 x the
+// walkers and reads 2.5 x the rows (profiles/r05_generation_mid.txt, profiles/r05_generation_limit.txt: measured again after the row masks went and the stores became
+// write-through; C3 was 0.95 x before both).
 // KMC_DEBUG=fused=0 / =1: never / wherever a kernel exists.  (Resident and island mode are decided by the caller.)
 int generation_wanted(const kmc_sampler* s)
 {
@@ -291,7 +292,7 @@ int generation_wanted(const kmc_sampler* s)
     if (have) return kind;                                   // (=1 / =lane: wherever a kernel exists; =lane keeps short rows one walker per lane)
     if (kind == 3) return 3;
     if (kind == 1) return ((c.nwalkers <= 32768 && c.nwalkers * s->ld <= 196608) || (c.nwalkers <= 65536 && s->ld <= 2)) ? 1 : 0;
-    return c.nwalkers * s->ld <= (c.nwalkers <= 16384 ? 1048576 : 524288) ? 2 : 0;     // (8 MiB of state up to 16 384 walkers, 4 MiB beyond)
+    return c.nwalkers * s->ld <= (c.nwalkers <= 49152 ? 1048576 : 524288) ? 2 : 0;     // (8 MiB of state up to 49 152 walkers, 4 MiB beyond)
 }
 }  // namespace
 

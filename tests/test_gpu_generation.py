@@ -110,8 +110,8 @@ def test_what_keeps_the_two_launch_kernels(kmc):
     assert "one launch per generation" not in _mode(kmc, pdf, 4096, 4, use_graph=False)
     assert "one launch per generation" not in _mode(kmc, pdf, 65536, 32)
     assert "one launch per generation" not in _mode(kmc, pdf, 262144, 4)
-    assert "one launch per generation" not in _mode(kmc, pdf, 32768, 32) and "one launch per generation" not in _mode(kmc, pdf, 20480, 64)       # 8 MiB beyond 16 384 walkers, 10 MiB
-    assert "generation_group" in _mode(kmc, kmc.Rosenbrock(), 16384, 64) and "generation_group" in _mode(kmc, pdf, 4096, 256)    # 8 MiB of state, <= 16 384 walkers (C3; round 5, after the row masks went)
+    assert "one launch per generation" not in _mode(kmc, pdf, 65536, 16) and "one launch per generation" not in _mode(kmc, pdf, 20480, 64)       # 8 MiB beyond 49 152 walkers, 10 MiB
+    assert "generation_group" in _mode(kmc, kmc.Rosenbrock(), 16384, 64) and "generation_group" in _mode(kmc, pdf, 32768, 32)   # 8 MiB of state, <= 49 152 walkers (C3; round 5, after the row masks went)
     assert "generation_lane" in _mode(kmc, pdf, 32768, 4) and "generation_group" in _mode(kmc, pdf, 8192, 32)
     assert "generation_group" in _mode(kmc, pdf, 16384, 32) and "generation_group" in _mode(kmc, pdf, 8192, 64)      # 4 MiB of state (round 5)
     assert "generation_group L=4 K=1" in _mode(kmc, pdf, 4096, 8) and "generation_group L=4 K=1" in _mode(kmc, pdf, 8192, 5)
@@ -267,12 +267,12 @@ def test_drop_in_call_on_a_mid_size_ensemble(kmc, oracle):
     np.testing.assert_allclose(np.transpose(logdensities), ref["chain_logp"], rtol=1e-12, atol=1e-12)
 
 
-@pytest.mark.parametrize("nw,nd", [(4096, 4), (16384, 32), (32768, 32)])
+@pytest.mark.parametrize("nw,nd", [(4096, 4), (16384, 32), (65536, 16)])
 def test_bound_position_buffer_and_callers_stream(kmc, oracle, nw, nd):
     """kmc_sampler_bind_positions + kmc_sampler_set_stream on a one-launch-per-generation sampler: the caller's buffer is the canonical
     copy of the state (current after every kmc_sampler_run, odd run lengths included), the second copy stays the library's.  The stream
     is torch's current one -- the legacy default stream, which cannot be captured: the graph chunk is recorded on a stream of the library's
-    own and replayed on the caller's (the lane-striped form: 16384 x 32; the two-launch kernels likewise: 32768 x 32)."""
+    own and replayed on the caller's (the lane-striped form: 16384 x 32; the two-launch kernels likewise: 65536 x 16)."""
     import torch
     G, seed = 131, 17
     th = _theta0("gauss", nw, nd, 8)
