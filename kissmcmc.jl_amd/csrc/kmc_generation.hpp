@@ -315,6 +315,10 @@ __device__ __forceinline__ void generation_group_body(const GenerationFront& f, 
     };
     const U4 mybits = draw_bits(dcf, step0 + (second ? 1u : 0u), me);
     const uint32_t mypartner = (second ? 0u : f.h) + draw_partner(dcf, mybits);     // :250
+#ifdef KMC_PROBE
+    asm volatile("" :: "v"(mypartner));
+#endif
+    KMC_STAMP(1);                                                        // my Philox block is done
     double2 own[K], oth[K], myown[K];
     double p0, myp0 = 0.0;
     U4 bits;
@@ -335,6 +339,7 @@ __device__ __forceinline__ void generation_group_body(const GenerationFront& f, 
 #pragma unroll
         for (int k = 0; k < K; ++k) myown[k] = zero2;
     }
+    KMC_STAMP(2);                                                        // rows requested
     const SchedEntry sch = generation_schedule_late(f, a, sch_e);        // from here on the argument struct
     const DrawConsts dc = generation_draw_consts(f, a);
     const bool count = (sch.flags & kCount) != 0u, sample = (sch.flags & kSample) != 0u;
@@ -383,6 +388,10 @@ __device__ __forceinline__ void generation_group_body(const GenerationFront& f, 
     bool acc = false;
     double p1 = 0.0;
     double2 y[K];
+#ifdef KMC_PROBE
+    asm volatile("" :: "v"(dr_mine.lu), "v"(dr_first.lu));
+#endif
+    KMC_STAMP(3);                                                        // draws finished (logarithms), accumulators requested
 #pragma unroll 1
     for (int level = second ? 0 : 1; level < 2; ++level) {               // ONE copy of the move (see generation_lane_body)
         Draw dr = dr_mine;
@@ -416,6 +425,10 @@ __device__ __forceinline__ void generation_group_body(const GenerationFront& f, 
     // all; 8 192 x 64 3.46 -> 2.59 us per half-step without that).  Tried instead of reading accumulators up front: no-return fp64 atomic adds on accept --
     // slower at every shape, the L2 retires about one 8-byte add per channel per 3-4 cycles (profiles/r05_generation_mid.txt).  `own` is my row before my move.
     const double wgt = (valid && acc && moments) ? (double)(sch.nbefore - kl) : 0.0;
+#ifdef KMC_PROBE
+    asm volatile("" :: "v"(wgt));
+#endif
+    KMC_STAMP(4);                                                        // rows arrived, both moves done
     if constexpr (kFold) {
         if (moments && __ballot(wgt != 0.0) != 0ull) {                   // (wave-uniform: every lane takes part in the fold, idle groups with zeros)
             double2 ms[K], mq[K];
@@ -431,6 +444,7 @@ __device__ __forceinline__ void generation_group_body(const GenerationFront& f, 
             for (int r = 0; r < FoldT<L, K>::NVL; ++r) store_wt(&slot[r * 64], acct[r] + v[r]);
         }
     }
+    KMC_STAMP(5);                                                        // moments folded, accumulator stores issued
     if (!valid) return;
     if constexpr (!kFold) {
         if (wgt != 0.0) {
@@ -475,8 +489,9 @@ __device__ __forceinline__ void generation_group_body(const GenerationFront& f, 
     {
         unsigned long long st[8] = {};
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        KMC_STAMP_READ(st[0], 80, 81); KMC_STAMP_READ(st[7], 94, 95);
-        for (int q = 1; q < 7; ++q) st[q] = st[0];                       // (entry and end only: body and boundary of a launch)
+        KMC_STAMP_READ(st[0], 80, 81); KMC_STAMP_READ(st[1], 82, 83); KMC_STAMP_READ(st[2], 84, 85); KMC_STAMP_READ(st[3], 86, 87);
+        KMC_STAMP_READ(st[4], 88, 89); KMC_STAMP_READ(st[5], 90, 91); KMC_STAMP_READ(st[7], 94, 95);
+        st[6] = st[5];
         if (threadIdx.x == 0 && blockIdx.x < 8192) for (int q = 0; q < 8; ++q) g_probe[sch.gen & 1][blockIdx.x][q] = st[q];   // [generation parity][workgroup (its first wave)]
     }
 #endif

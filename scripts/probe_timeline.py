@@ -60,6 +60,13 @@ def main():
             print(f" {nwg} workgroups stamped (first wave of each): entry spread {t[0, :, 0].max() - t[0, :, 0].min():.2f} us, wave duration median {np.median(t[0, :, 7] - t[0, :, 0]):.2f} "
                   f"(p90 {np.percentile(t[0, :, 7] - t[0, :, 0], 90):.2f}); first wave in .. last store issued {body:.2f} us; gap to the next launch's first wave {gap:.2f} us; "
                   f"launch period {t[1, :, 0].min() - t[0, :, 0].min():.2f} us")
+            if "generation_group" in how:
+                half = nwg // 2                                  # workgroups [0, nb) carry the second half (they recompute their partner's first-half move)
+                for label, sl in (("second-half workgroups", slice(0, half)), ("first-half workgroups", slice(half, nwg))):
+                    dd = np.diff(t[0, sl][:, [0, 1, 2, 3, 4, 5, 7]], axis=1)
+                    print(f"   {label}: entry -> Philox {np.median(dd[:, 0]):.2f}; -> rows requested {np.median(dd[:, 1]):.2f}; -> logarithms done {np.median(dd[:, 2]):.2f}; "
+                          f"-> rows in, move(s) done {np.median(dd[:, 3]):.2f}; -> moments folded {np.median(dd[:, 4]):.2f}; -> last store issued {np.median(dd[:, 5]):.2f}; "
+                          f"wave {np.median(t[0, sl, 7] - t[0, sl, 0]):.2f} us")
             m = re.search(r"generation_\w+[^;]*?, grid \d+ x \d+", how)
             print("PROBE_JSON " + json.dumps({"config": name, "moments": int(mom), "geometry": m.group(0) if m else None, "waves_stamped": nwg, "launches_per_generation": 1,
                                               "body_us": body, "boundary_us": gap, "period_us_in_kernel": float(t[1, :, 0].min() - t[0, :, 0].min()),
