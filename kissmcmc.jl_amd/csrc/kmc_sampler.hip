@@ -545,6 +545,10 @@ KMC_EXPORT kmc_status kmc_sampler_create(const kmc_config* cfg, kmc_sampler** ou
     CREATE_TRY(dev_alloc(s, &s->d_logp, nw * (sizeof(double) + 2 * sizeof(uint32_t))));
     s->d_naccept = reinterpret_cast<uint32_t*>(s->d_logp + nw);
     s->d_klast = s->d_naccept + nw;
+    if (s->ragged_vec() && (reinterpret_cast<uint64_t>(s->d_logp) >> 48) != 0) {   // (kmc_launch.hip: front_of -- ndim rides in the 16 bits above this address)
+        kmc_sampler_destroy(s);
+        return fail(KMC_ERR_UNSUPPORTED, "device addresses beyond 2^48: the ragged vector kernels carry ndim in the upper 16 bits of a pointer");
+    }
     CREATE_TRY(hipMemsetAsync(s->d_klast, 0, nw * sizeof(uint32_t), s->stream));
     static_assert(kGraphChunk <= 64, "advance_schedule runs one 64-thread block");
     CREATE_TRY(dev_alloc(s, &s->d_gen, 64));
