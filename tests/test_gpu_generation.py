@@ -267,13 +267,19 @@ def test_drop_in_call_on_a_mid_size_ensemble(kmc, oracle):
     np.testing.assert_allclose(np.transpose(logdensities), ref["chain_logp"], rtol=1e-12, atol=1e-12)
 
 
+@pytest.mark.parametrize("launch", [None, "updated"])
 @pytest.mark.parametrize("nw,nd", [(4096, 4), (16384, 32), (65536, 16)])
-def test_bound_position_buffer_and_callers_stream(kmc, oracle, nw, nd):
+def test_bound_position_buffer_and_callers_stream(kmc, oracle, monkeypatch, nw, nd, launch):
     """kmc_sampler_bind_positions + kmc_sampler_set_stream on a one-launch-per-generation sampler: the caller's buffer is the canonical
     copy of the state (current after every kmc_sampler_run, odd run lengths included), the second copy stays the library's.  The stream
     is torch's current one -- the legacy default stream, which cannot be captured: the graph chunk is recorded on a stream of the library's
-    own and replayed on the caller's (the lane-striped form: 16384 x 32; the two-launch kernels likewise: 65536 x 16)."""
+    own and replayed on the caller's (the lane-striped form: 16384 x 32; the two-launch kernels likewise: 65536 x 16).  KMC_LAUNCH=updated: the same through the
+    graph whose node parameters are rewritten before every replay (the bound buffer's address is among them)."""
     import torch
+    if launch:
+        monkeypatch.setenv("KMC_LAUNCH", launch)
+    else:
+        monkeypatch.delenv("KMC_LAUNCH", raising=False)
     G, seed = 131, 17
     th = _theta0("gauss", nw, nd, 8)
     pos = torch.zeros((nw, nd), dtype=torch.float64, device="cuda")
