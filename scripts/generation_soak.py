@@ -1,11 +1,12 @@
-"""Soak of the lane-striped one-launch-per-generation kernels at the 4 MiB states round 5 opened to them: 2 x 10^5 generations in uneven pieces against the two-launch kernels
+"""Soak of the one-launch-per-generation kernels at the 4-8 MiB states round 5 opened to them (launch mode as measured: table or updated graph): 2 x 10^5 generations in uneven pieces against the two-launch kernels
 (KMC_DEBUG=fused=0) -- positions and counters bit for bit, moments to 1e-10.   python scripts/generation_soak.py   -> profiles/r05_generation_soak.txt"""
 import os, sys
 sys.path.insert(0, '.')
 import numpy as np
 import kissmcmc_jl_amd as kmc
 rng = np.random.default_rng(1)
-for name, pdf, nw, nd, scale in (("8192x64 gauss", kmc.GaussianIso, 8192, 64, 1.0), ("16384x32 gauss", kmc.GaussianIso, 16384, 32, 1.0), ("8192x60 rosen", kmc.Rosenbrock, 8192, 60, 0.1), ("32768x16 expo", kmc.Exponential, 32768, 16, None)):
+for name, pdf, nw, nd, scale in (("8192x64 gauss", kmc.GaussianIso, 8192, 64, 1.0), ("16384x32 gauss", kmc.GaussianIso, 16384, 32, 1.0), ("8192x60 rosen", kmc.Rosenbrock, 8192, 60, 0.1), ("32768x16 expo", kmc.Exponential, 32768, 16, None),
+                                  ("16384x64 rosen (C3)", kmc.Rosenbrock, 16384, 64, 0.1), ("32768x31 gauss", kmc.GaussianIso, 32768, 31, 1.0), ("4096x4 gauss", kmc.GaussianIso, 4096, 4, 1.0)):      # (8 MiB states, a ragged one and generation_lane: the second half of round 5)
     G = 200000
     th = (0.5 + 0.1 * np.abs(rng.standard_normal((nw, nd)))) if scale is None else scale * rng.standard_normal((nw, nd))
     out = {}
