@@ -644,7 +644,7 @@ def other_configs(kmc, device: int):
             pdf = kmc.CDensity(src, params=params)
             with kmc.Sampler(pdf, nw, nd, G, G // 2, 1, 2.0, 12345, moments=True) as s:
                 s.set_positions(np.random.default_rng(12345).standard_normal((nw, nd)))
-                s.run(min(G, 1024))                  # warm-up: code objects, graph instantiation and the launch-mode measurement (>= 768 generations)
+                s.run(min(G, 1024))                  # warm-up: code objects, graph instantiation and the launch-mode measurement (>= 896 generations)
                 s.sync()
                 s.set_positions(np.random.default_rng(12345).standard_normal((nw, nd)))
                 s.run(G)

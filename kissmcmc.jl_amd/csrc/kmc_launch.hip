@@ -792,17 +792,18 @@ KMC_EXPORT kmc_status kmc_sampler_run(kmc_sampler* s, int64_t ngen)
     //                      when the executables are destroyed), ~1.4 in 7.2: update_bytes_each above -- so the process has a BUDGET
     //                      of such calls (kmc_set_updated_budget_mb): beyond it samplers choose
     //                      between 1 and 2.
-    // A long run measures 1 against 3 (or 2) once -- four chunks each, HIP events: a starved GPU shows as idle time
+    // A long run (>= 896 generations) measures 1 against 3 (or 2) once -- 256 generations each, HIP events: a starved GPU shows as idle time
     // between the events -- and keeps the faster; KMC_LAUNCH=graph|eager|updated decides without measuring.
     bool use_graph = !(s->cfg.flags & KMC_NO_GRAPH);
     if (s->comm && !s->comm_graph_ok) use_graph = false;    // (decided at the first capture, kmc_sampler_rccl_capture)
-    const int64_t calib_min = 11 * std::max<int64_t>(kGraphChunk, s->uchunk) + kGraphChunk;
+    const int64_t calib_gens = std::max<int64_t>(4 * kGraphChunk, 2 * s->uchunk);                               // generations measured in each mode
+    const int64_t calib_min = kGraphChunk + 2 * std::max<int64_t>(kGraphChunk, s->uchunk) + 2 * calib_gens + kGraphChunk;    // warm-up pieces + both measurements + a chunk to spare (896)
     auto calibrate = [&](bool with_updated) -> kmc_status {
         hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
         HIP_TRY(hipEventCreate(&e0));
         HIP_TRY(hipEventCreate(&e1));
         HIP_TRY(hipEventCreate(&e2));
-        const int64_t gens = 4 * std::max<int64_t>(kGraphChunk, s->uchunk);
+        const int64_t gens = calib_gens;
         kmc_status st = graph_chunk();                                    // warm: instantiation, code objects
         if (st == KMC_OK) st = with_updated ? updated_chunk() : eager_generations(kGraphChunk);
         if (st == KMC_OK) st = with_updated ? updated_chunk() : eager_generations(kGraphChunk);

@@ -818,7 +818,7 @@ namespace {
 std::string launch_mode_text(const kmc_sampler* s, const char* what)
 {
     std::string t = ((s->cfg.flags & KMC_NO_GRAPH) || s->launch_mode == 2) ? std::string(", eager launches (") + what + " among the preloaded kernel parameters)"
-                    : s->launch_mode == 3 ? std::string(", hipGraph replay of 64 generations with per-replay parameter updates (") + what + " preloaded)"
+                    : s->launch_mode == 3 ? ", hipGraph replay of " + std::to_string(s->uchunk) + " generations with per-replay parameter updates (" + what + " preloaded)"
                                           : std::string(", hipGraph replay of 64 generations");
     if (s->calib_graph_ms > 0.f) {
         char b[128];

@@ -112,7 +112,7 @@ struct kmc_sampler {
     bool uinflight[kmc_host::kUExec] = {};
     int unext = 0;
     std::vector<hipGraphNode_t> unodes;
-    int64_t uchunk = 64;      // generations per replay of the updated graph
+    int64_t uchunk = 128;     // generations per replay of the updated graph (consecutive replays are ~10 us apart on the GPU: 64 -> 128 is 1-3 % of a launch-bound period; profiles/NOTES.md round 5)
     bool updated_forced = false;   // KMC_LAUNCH=updated: no budget
     int64_t feed_wait_ns = 0, feed_update_ns = 0, feed_launch_ns = 0, feed_replays = 0;   // updated-graph mode: the feeding thread's time per phase
     unsigned vec_lds = 0;          // dynamic LDS of the vector kernel (a function body evaluated per walker: one tile of proposals per wave)

@@ -345,12 +345,12 @@ def test_every_launch_mode_of_the_generation_kernels_is_the_oracles_run(kmc, ora
     else:
         monkeypatch.setenv("KMC_LAUNCH", launch)
     pdf, did, params = _densities(kmc, oracle)[name]
-    G, nburn, nthin, seed = 1100, 301, 7, 17
+    G, nburn, nthin, seed = 1200, 301, 7, 17
     th = _theta0(name, nw, nd, seed)
     with kmc.Sampler(pdf, nw, nd, G, nburn, nthin, 2.0, seed, store_chain=True, store_logp=True, moments=True) as s:
         assert "one launch per generation" in s.describe()
         s.set_positions(th)
-        for piece in (1, 64, 65, 129, 1100 - 259):           # (the last piece is long enough for the launch-mode measurement when nothing is forced)
+        for piece in (1, 64, 65, 129, 1200 - 259):           # (the last piece is long enough -- 896 generations -- for the launch-mode measurement when nothing is forced)
             s.run(piece)
         s.sync()
         how = s.describe()
@@ -360,7 +360,7 @@ def test_every_launch_mode_of_the_generation_kernels_is_the_oracles_run(kmc, ora
         mode, _ = s.launch_mode()
         assert s.generation == G and s.launch_count == G
     if launch == "updated":
-        assert mode == 3 and "generation preloaded" in how, how
+        assert mode == 3 and "generation preloaded" in how and "replay of 128 generations" in how, how
     elif launch == "graph":
         assert mode == 1 and "preloaded" not in how, how
     elif launch == "eager":
@@ -388,7 +388,7 @@ def test_generation_kernels_leave_the_updated_graph_when_the_budget_is_spent_or_
     th = _theta0("gauss", nw, nd, seed)
     monkeypatch.setenv("KMC_LAUNCH", "updated,budget")
     try:
-        L.kmc_set_updated_budget_mb((used.value + 3 * 128) * each / 1048576.0 + 1e-9)     # room for three replays as the two-launch kernels count them (2 x 64 updates)
+        L.kmc_set_updated_budget_mb((used.value + 3 * 128) * each / 1048576.0 + 1e-9)     # room for three replays of 128 generations, one update each (the check before a replay asks for 2 x 128: two get through)
         with kmc.Sampler(kmc.GaussianIso(), nw, nd, G, nburn, 1, 2.0, seed, moments=True) as s:
             s.set_positions(th)
             s.run(640)
@@ -398,7 +398,7 @@ def test_generation_kernels_leave_the_updated_graph_when_the_budget_is_spent_or_
             assert fell_back and mode in (0, 1, 2) and "budget of the process spent" in how, (mode, fell_back, how)      # (0: too little left to measure -- whole chunks from the table graph)
             u2 = C.c_int64(0)
             L.kmc_updated_budget(C.byref(u2), None)
-            assert 64 <= u2.value - used.value <= 3 * 128
+            assert 128 <= u2.value - used.value <= 3 * 128
             s.half_step(0)
             s.half_step(1)                                   # generation 641, by halves: the two-launch kernels from here on
             assert "one launch per generation" not in s.describe()

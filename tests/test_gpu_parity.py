@@ -316,7 +316,7 @@ def test_updated_graph_budget_fallbacks_are_the_same_sampler(kmc, oracle, when, 
             L.kmc_set_updated_budget_mb(13 * each / 1048576.0)              # 13 updates, fewer than one replay needs
         else:
             monkeypatch.setenv("KMC_LAUNCH", "updated,budget")              # in the updated-graph mode, budget applies
-            L.kmc_set_updated_budget_mb((used.value + 3 * 128) * each / 1048576.0 + 1e-9)   # room for three replays
+            L.kmc_set_updated_budget_mb((used.value + 3 * 256) * each / 1048576.0 + 1e-9)   # room for three replays (128 generations, two updates each)
         with kmc.Sampler(kmc.GaussianIso(), nw, nd, G, nburn, nthin, 2.0, seed, store_chain=True, store_logp=True, moments=True) as s:
             s.set_positions(th)
             s.run(900)
@@ -337,7 +337,7 @@ def test_updated_graph_budget_fallbacks_are_the_same_sampler(kmc, oracle, when, 
     L.kmc_updated_budget(C.byref(u2), C.byref(b2))
     assert b2.value == budget.value
     if when == "spent_during_the_run":
-        assert 3 * 128 <= u2.value - used.value <= 4 * 128               # it stopped updating when the budget ran out
+        assert 3 * 256 <= u2.value - used.value <= 4 * 256               # it stopped updating when the budget ran out
     ref = oracle.emcee(oracle.make_config(oracle.GAUSSIAN_ISO, [0.0, 1.0], nw, nd, G, nburn, nthin, 2.0, seed, nthreads=8), th)
     np.testing.assert_array_equal(nacc, ref["naccept"])
     np.testing.assert_array_equal(pos, ref["final_pos"])

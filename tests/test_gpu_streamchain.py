@@ -26,18 +26,18 @@ def _equal(chain, clogp, ref):
 
 
 def test_streamed_chain_equals_oracle_over_three_ring_laps(kmc, oracle, monkeypatch, kmc_debug):
-    """4096 x 32, nthin = 1, 640 stored samples through a ring of 3 x 65 sample slots: > 3 laps."""
+    """4096 x 32, nthin = 1, 1340 stored samples through a ring of 3 x 129 sample slots (a block holds a replay of 128 generations + 1): > 3 laps."""
     kmc_debug.set("chain-block", "1")            # smallest legal block: the samples of one graph replay (+1)
-    nw, nd, G, nburn, seed = 4096, 32, 700, 60, 5
+    nw, nd, G, nburn, seed = 4096, 32, 1400, 60, 5
     th = np.random.default_rng(1).standard_normal((nw, nd))
     with kmc.Sampler(kmc.GaussianIso(), nw, nd, G, nburn, 1, 2.0, seed, store_chain=True, store_logp=True, moments=True,
                      stream_chain=True) as s:
-        assert "chain streamed to host memory in blocks of 65 samples" in s.describe()
+        assert "chain streamed to host memory in blocks of 129 samples" in s.describe()
         s.set_positions(th)
         s.run(G)
         s.sync()
         chain, clogp = s.chain()
-        assert chain.shape == (G - nburn, nw, nd) and (G - nburn) > 3 * 3 * 65
+        assert chain.shape == (G - nburn, nw, nd) and (G - nburn) > 3 * 3 * 129
         ref = _oracle_chain(oracle, oracle.GAUSSIAN_ISO, [0.0, 1.0], th, G, nburn, 1, seed)
         _equal(chain, clogp, ref)
         np.testing.assert_array_equal(s.positions(), ref["final_pos"])
@@ -58,7 +58,7 @@ def test_streamed_chain_variants(kmc, oracle, monkeypatch, case, by_walker, resi
     kmc_debug.set("chain-block", "1")
     if not resident:
         kmcenv.no_resident(monkeypatch)
-    pdf, did, params, nw, nd, G, nburn, nthin, scale = kmc.GaussianIso(), oracle.GAUSSIAN_ISO, [0.0, 1.0], 1024, 8, 500, 37, 1, 1.0
+    pdf, did, params, nw, nd, G, nburn, nthin, scale = kmc.GaussianIso(), oracle.GAUSSIAN_ISO, [0.0, 1.0], 1024, 8, 900, 37, 1, 1.0
     kw = dict(store_chain=True, store_logp=True)
     if case == "thin3_odd_ndim":
         nd, nthin, G = 7, 3, 1900                        # padded device rows -> strided copies; 23 samples per replay
@@ -102,7 +102,7 @@ def test_streamed_chain_variants(kmc, oracle, monkeypatch, case, by_walker, resi
         if clogp is not None:
             np.testing.assert_array_equal(lw, clogp.T)
     ref = _oracle_chain(oracle, did, params, th, G, nburn, nthin, seed)
-    assert ref["nsamples"] > 6 * 65 // max(1, nthin) or nthin > 1
+    assert ref["nsamples"] > 6 * 129 // max(1, nthin) or nthin > 1
     if kw["store_chain"]:
         np.testing.assert_array_equal(chain, ref["chain"])
     else:
