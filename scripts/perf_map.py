@@ -6,7 +6,7 @@ import kissmcmc_jl_amd as kmc
 
 body = "double s = 0; for (int i = 0; i < n; ++i) s += x[i] * x[i]; return -0.5 * s;"
 NW = (100, 1000, 2048, 4096, 16384, 65536, 262144)
-ND = (1, 4, 32, 128)
+ND = (1, 4, 32, 128) if '--ragged' not in sys.argv else (3, 10, 20, 31, 50, 100, 200)      # --ragged: row lengths that are not powers of two (what callers mostly have)
 general = "double s = 0; for (int i = 0; i < n; ++i) s += x[i] * x[i]; for (int i = 0; i + 2 < n; ++i) s += p[0] * x[i] * x[i + 2]; return -0.5 * s;"
 for name, make in (("menu GaussianIso", lambda: kmc.GaussianIso()), ("CDensity, a sum over elements (recognised: lane-striped)", lambda: kmc.CDensity(body)),
                    ("CDensity, a general body (second-neighbour coupling, two loops: rows lane-striped, evaluated per walker)", lambda: kmc.CDensity(general, params=[0.2]))):
