@@ -288,10 +288,10 @@ int generation_wanted(const kmc_sampler* s)
     std::string forced;
     const bool have = debug_opt("fused", &forced);
     if (have && forced == "0") return 0;
-    if (kind == 1 && c.ndim >= 5 && striped && forced != "lane" && (have || c.nwalkers <= (s->ld == 8 ? 32768 : 8192))) kind = 3;
+    if (kind == 1 && c.ndim >= 5 && striped && forced != "lane" && (have || c.nwalkers <= (s->ld == 8 ? 49152 : 8192))) kind = 3;     // (49 152 x 8: 1.12 x the two launches; 65 536 x 8: 1.01)
     if (have) return kind;                                   // (=1 / =lane: wherever a kernel exists; =lane keeps short rows one walker per lane)
     if (kind == 3) return 3;
-    if (kind == 1) return ((c.nwalkers <= 32768 && c.nwalkers * s->ld <= 196608) || (c.nwalkers <= 65536 && s->ld <= 2)) ? 1 : 0;
+    if (kind == 1) return ((c.nwalkers <= 49152 && c.nwalkers * s->ld <= 196608) || (c.nwalkers <= 65536 && s->ld <= 2)) ? 1 : 0;       // (49 152 x 4: 1.09 x; 65 536 x 3 / x 4: 1.03 / 0.99)
     return c.nwalkers * s->ld <= (c.nwalkers <= 49152 ? 1048576 : 524288) ? 2 : 0;     // (8 MiB of state up to 49 152 walkers, 4 MiB beyond)
 }
 }  // namespace
