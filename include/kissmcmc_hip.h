@@ -382,7 +382,7 @@ int64_t     kmc_sampler_launch_count(const kmc_sampler* s);
 #define KMC_LAUNCH_UNDECIDED     0   /* only short runs so far: whole chunks from the table graph, the rest eagerly */
 #define KMC_LAUNCH_TABLE_GRAPH   1   /* hipGraph replay of 64 generations, schedule read from a device table */
 #define KMC_LAUNCH_EAGER         2   /* one launch per half-step from the host */
-#define KMC_LAUNCH_UPDATED_GRAPH 3   /* hipGraph replay with per-replay kernel-node parameter updates (two launches per generation or one: both kinds of kernel) */
+#define KMC_LAUNCH_UPDATED_GRAPH 3   /* hipGraph replay (128 generations) with per-replay kernel-node parameter updates (two launches per generation or one: both kinds of kernel) */
 #define KMC_LAUNCH_SINGLE        4   /* resident / island kernels (many generations per launch), host-evaluated density */
 int         kmc_sampler_launch_mode(const kmc_sampler* s, int* budget_fallback);
 void        kmc_updated_budget(int64_t* calls_used, int64_t* calls_budget);   /* parameter updates so far / allowed, this process */
