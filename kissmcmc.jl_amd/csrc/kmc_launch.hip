@@ -44,7 +44,7 @@ FlushFn flush_lookup(int L, int K, int iter, bool f32)
     KMC_LK(1, 1) KMC_LK(2, 1) KMC_LK(4, 1) KMC_LK(8, 1) KMC_LK(16, 1) KMC_LK(32, 1) KMC_LK(64, 1)
     KMC_LK(4, 2) KMC_LK(8, 2) KMC_LK(16, 2) KMC_LK(32, 2) KMC_LK(64, 2)
     KMC_LK(4, 4) KMC_LK(8, 4) KMC_LK(64, 4)
-    KMC_LK(64, 8)
+    KMC_LK(64, 8) KMC_LK(16, 8)      // (16 x 8: function bodies evaluated per walker on rows of 129 ... 256 doubles, kmc_plan.hip)
 #undef KMC_LK
     return nullptr;
 }

@@ -187,6 +187,13 @@ Plan make_plan(const kmc_config& c, int64_t n_active)
         else if (chunks <= 128) { L = pow2ceil((chunks + 1) / 2); K = 2; }
         else if (chunks <= 256) { L = 64; K = 4; }
         else if (chunks <= 512) { L = 64; K = 8; }
+        if (c.density == KMC_USER_DENSITY && chunks > 64 && chunks <= 128) {
+            // a function body evaluated once per walker (RowEvalTrait) on rows of 129 ... 256 doubles: one lane walks the whole row, so the walkers per wave
+            // count -- 16 lanes x 8 chunks (4 walkers per wave) instead of 64 x 2 (one): 16 384 x 256 30.1 -> 22.7 us per half-step, 4 096 x 256 22.1 -> 16.0, 2 048 x 256
+            // 16.9 -> 13.7, 8 192 x 200 26.2 -> 24.7 (profiles/NOTES.md round 5; shorter and longer rows measured no better that way)
+            const kmc_user_density* ud = static_cast<const kmc_user_density*>(c.user_density);
+            if (ud && ud->is_body && !sep_routed(ud) && body_vec_possible(ud, c.ndim)) { L = 16; K = 8; }
+        }
         // walkers per group (ITER): two amortise the per-walker scalar work (Philox, two logs) over
         // the wave -- once that still leaves 1.5 waves per SIMD (measured: 2048 single-walker waves run 3-6 % faster
         // as they are, C3 and 32 768 x 32; 3072 and more are faster paired); more only while the grid keeps >= 4096
