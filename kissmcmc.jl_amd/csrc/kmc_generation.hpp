@@ -480,9 +480,9 @@ __device__ __forceinline__ void generation_group_body(const GenerationFront& f, 
         if (a.chain != nullptr) {
             double2* dst = reinterpret_cast<double2*>(a.chain + srow * (size_t)ld);
 #pragma unroll
-            for (int k = 0; k < K; ++k) dst[ck[k]] = y[k];
+            for (int k = 0; k < K; ++k) store_wt(&dst[ck[k]], y[k]);
         }
-        if (a.chain_logp != nullptr && j == 0) a.chain_logp[srow] = pnew;
+        if (a.chain_logp != nullptr && j == 0) store_wt(&a.chain_logp[srow], pnew);
     }
     KMC_STAMP(7);                                                        // the last store is issued
 #ifdef KMC_PROBE

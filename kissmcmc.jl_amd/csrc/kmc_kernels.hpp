@@ -774,7 +774,7 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
                         if (r == me_rank) continue;
                         double2* rem = reinterpret_cast<double2*>(a.peer_pos[r] + off);
 #pragma unroll
-                        for (int k = 0; k < K; ++k) store_wt(&rem[ck[k]], xo[it][k]);
+                        for (int k = 0; k < K; ++k) if (cv[k]) store_wt(&rem[k * L + j], xo[it][k]);      // (over the fabric: a folded tail chunk would be sent twice)
                     }
                 }
             }
