@@ -638,8 +638,8 @@ def other_configs(kmc, device: int):
     body = "double s = 0; for (int i = 0; i < n; ++i) s += x[i] * x[i]; return -0.5 * s;"
     two_sums = "double s = 0, t = 0; for (int i = 0; i < n; ++i) { s += x[i] * x[i]; t += x[i]; } return -0.5 * (s + p[0] * t * t);"
     coupled = "double s = 0; for (int i = 0; i < n; ++i) s += x[i] * x[i]; for (int i = 0; i + 2 < n; ++i) s += p[0] * x[i] * x[i + 2]; return -0.5 * s;"
-    for key, src, params, nw, nd, G in (("C2_user_density", body, [], 65536, 32, 2000), ("C2_user_density_two_sums", two_sums, [0.05], 65536, 32, 2000),
-                                        ("C2_user_density_coupled", coupled, [0.2], 65536, 32, 2000), ("C1_user_density", body, [], 100, 1, 20000)):
+    for key, src, params, nw, nd, G in (("C2_user_density", body, [], 65536, 32, 4096), ("C2_user_density_two_sums", two_sums, [0.05], 65536, 32, 4096),
+                                        ("C2_user_density_coupled", coupled, [0.2], 65536, 32, 4096), ("C1_user_density", body, [], 100, 1, 20000)):     # (a job planned >= 4096 generations measures its launch modes in the warm-up piece)
         try:
             pdf = kmc.CDensity(src, params=params)
             with kmc.Sampler(pdf, nw, nd, G, G // 2, 1, 2.0, 12345, moments=True) as s:

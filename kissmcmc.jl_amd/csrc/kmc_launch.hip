@@ -824,7 +824,14 @@ KMC_EXPORT kmc_status kmc_sampler_run(kmc_sampler* s, int64_t ngen)
         }
         return KMC_OK;
     };
-    if (use_graph && s->launch_mode == 0 && s->user && updated_graph_possible(s) && !s->uexec[0]) {
+    // The measurement and the updated graph's set-up (six executables of 128 or 256 nodes) cost about a millisecond once: worth it for a job planned long
+    // (kmc_config::ngenerations) or a sampler that has come this far anyway, not for a one-shot run of a few thousand generations (4 096 x 4, one run of 1 024
+    // generations: 4.3 ms with the measurement, 3.4 ms from the table graph alone; break-even ~2 000 generations at C2, ~10 000 for a short-row ensemble)
+    constexpr int64_t kWorthMeasuring = 4096;
+    const bool long_job = s->cfg.ngenerations >= kWorthMeasuring || s->generation + ngen >= kWorthMeasuring;
+    const char* const launch_env = std::getenv("KMC_LAUNCH");
+    const bool updated_asked = launch_env && (std::strcmp(launch_env, "updated") == 0 || std::strcmp(launch_env, "updated,budget") == 0);
+    if (use_graph && s->launch_mode == 0 && s->user && updated_graph_possible(s) && !s->uexec[0] && (updated_asked || (long_job && ngen >= calib_min))) {
         // module functions as graph kernel nodes: build the graph now; a runtime that refuses leaves this sampler with the table graph
         if (ensure_updated_graph(s) != KMC_OK) {
             (void)hipGetLastError();
@@ -839,7 +846,7 @@ KMC_EXPORT kmc_status kmc_sampler_run(kmc_sampler* s, int64_t ngen)
         else if (env && std::strcmp(env, "updated") == 0 && updated_graph_possible(s)) { s->launch_mode = 3; s->updated_forced = true; }
         else if (env && std::strcmp(env, "updated,budget") == 0 && updated_graph_possible(s) && update_budget_left(2 * s->uchunk)) s->launch_mode = 3;   // (as if measured: the budget applies)
         else if (!updated_graph_possible(s)) s->launch_mode = 1;
-        else if (ngen >= calib_min) {
+        else if (ngen >= calib_min && long_job) {
             const bool left = update_budget_left(2 * s->uchunk);      // (the measurement itself may overshoot by its six replays; the run after it may not)
             if (!left) note_budget_spent(s);
             KMC_TRY(calibrate(left));

@@ -347,7 +347,8 @@ def test_every_launch_mode_of_the_generation_kernels_is_the_oracles_run(kmc, ora
     pdf, did, params = _densities(kmc, oracle)[name]
     G, nburn, nthin, seed = 1200, 301, 7, 17
     th = _theta0(name, nw, nd, seed)
-    with kmc.Sampler(pdf, nw, nd, G, nburn, nthin, 2.0, seed, store_chain=True, store_logp=True, moments=True) as s:
+    planned = 4200 if launch is None else G                    # (nothing forced: the modes are measured for a job PLANNED long -- >= 4096 generations -- at its first call of >= 896; run here: 1200 of them)
+    with kmc.Sampler(pdf, nw, nd, planned, nburn, nthin, 2.0, seed, store_chain=True, store_logp=True, moments=True) as s:
         assert "one launch per generation" in s.describe()
         s.set_positions(th)
         for piece in (1, 64, 65, 129, 1200 - 259):           # (the last piece is long enough -- 896 generations -- for the launch-mode measurement when nothing is forced)

@@ -268,7 +268,8 @@ def test_launch_modes_are_the_same_sampler(kmc, oracle, mode, monkeypatch):
     monkeypatch.setenv("KMC_DEBUG", "fused=0")      # the launch modes of the two-launch kernels (this small state would run one launch per generation)
     nw, nd, G, nburn, nthin, seed = 2048, 32, 1000, 301, 7, 23
     th = np.random.default_rng(4).standard_normal((nw, nd))
-    with kmc.Sampler(kmc.GaussianIso(), nw, nd, G, nburn, nthin, 2.0, seed, store_chain=True, store_logp=True, moments=True) as s:
+    planned = 4200 if mode is None else G          # (not forced: a job PLANNED long -- >= 4096 generations -- measures the modes at its first call of >= 896; 1000 of them run here)
+    with kmc.Sampler(kmc.GaussianIso(), nw, nd, planned, nburn, nthin, 2.0, seed, store_chain=True, store_logp=True, moments=True) as s:
         s.set_positions(th)
         s.run(900)          # long enough for the one-off measurement when the mode is not forced
         s.run(37)
@@ -287,6 +288,8 @@ def test_launch_modes_are_the_same_sampler(kmc, oracle, mode, monkeypatch):
     np.testing.assert_allclose(msq, ref["sumsq"], rtol=1e-11, atol=1e-9)
     if mode == "updated":
         assert "parameter updates" in how
+    if mode is None:
+        assert "measured per 64 generations" in how, how
     if mode == "eager":
         assert "eager" in how
 
@@ -317,7 +320,8 @@ def test_updated_graph_budget_fallbacks_are_the_same_sampler(kmc, oracle, when, 
         else:
             monkeypatch.setenv("KMC_LAUNCH", "updated,budget")              # in the updated-graph mode, budget applies
             L.kmc_set_updated_budget_mb((used.value + 3 * 256) * each / 1048576.0 + 1e-9)   # room for three replays (128 generations, two updates each)
-        with kmc.Sampler(kmc.GaussianIso(), nw, nd, G, nburn, nthin, 2.0, seed, store_chain=True, store_logp=True, moments=True) as s:
+        planned = 4200          # (a job planned long -- >= 4096 generations -- is what measures its launch modes, and so meets the budget; 1000 of them run here)
+        with kmc.Sampler(kmc.GaussianIso(), nw, nd, planned, nburn, nthin, 2.0, seed, store_chain=True, store_logp=True, moments=True) as s:
             s.set_positions(th)
             s.run(900)
             s.run(37)
