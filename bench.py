@@ -58,6 +58,7 @@ def bench_test_opt(name: str, default=None):
 NWALKERS_PER_GPU = int(bench_test_opt("walkers", 65536))   # (override: rehearsing several ranks on ONE GPU only)
 NDIM = 32
 GENS_PER_STEP = 1000
+REPS = 3                # timed repetitions of the whole job after the warm-up: `value` is their median, `value_min` / `value_max` the spread
 SEED = 12345
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy rate is 6290 GB/s
 HBM_COPY_GBS = 6290.0   # what a float4 copy achieves on this chip (MI355X_MICROARCH.md:36)
@@ -546,24 +547,24 @@ def other_configs(kmc, device: int):
             break
         try:
             pdf = kmc.GaussianIso()
-            with kmc.Sampler(pdf, nw, nd, 2 * G + 64, 64, 1, 2.0, SEED, device=device, moments=True) as s:      # (burn-in = the warm-up piece)
+            with kmc.Sampler(pdf, nw, nd, REPS * G + 64, 64, 1, 2.0, SEED, device=device, moments=True) as s:      # (burn-in = the warm-up piece)
                 s.init_ball(np.zeros(nd), np.ones(nd), seed=SEED)
                 s.run(64)
                 s.sync()
                 runs = []
-                for _ in range(2):
+                for _ in range(REPS):
                     l0 = s.launch_count
                     s.run(G)
                     s.sync()
                     runs.append(s.last_run_ms())
                     launches = s.launch_count - l0
-                ms = min(runs)
+                ms = sorted(runs)[len(runs) // 2]          # the median (these launches are two-valued by process, not by run: profiles/r05_hbm_bimodal.txt)
                 us_half = ms * 1e3 / (2 * G)
                 how = s.describe()
                 roof = roofline_block(pdf, how, nw // 2, nd, us_half, launches, state_bytes(nw, nd, moment_bytes(how)), name.lower())
                 msum, msq, n = s.moments()
                 out[name] = {"workload": f"{nw} walkers x {nd}-dim isotropic Gaussian (state {roof['state_bytes'] / 2**20:.0f} MiB > the 256 MiB Infinity Cache), exact partner rule, "
-                                         f"moments on, {G} generations timed after 64 of warm-up (the run continues: no restart)",
+                                         f"moments on, {G} generations timed {REPS} times after 64 of warm-up (the run continues: no restart; median)",
                              "value": nw * G / (ms * 1e-3), "unit": "walker-steps/s", "us_per_half_step": us_half,
                              "us_per_half_step_runs": [r * 1e3 / (2 * G) for r in runs], "kernel_launches": launches,
                              "algorithmic_read_GBs": roof["achieved"], "frac_of_8TBs": roof["frac"], "frac_of_measured_copy_rate": roof["frac_of_measured_copy_rate"],
@@ -699,7 +700,7 @@ def compact_line(full: dict) -> str:
     cfg["execution"] = clip(cfg.get("execution"), 150)
     cfg["parallelism"] = clip(cfg.get("parallelism"), 150)
     cfg["workload"] = clip(cfg.get("workload"), 160)
-    line = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    line = {k: full[k] for k in ("metric", "value", "value_min", "value_max", "repetitions", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
     line["config"] = cfg
     line["roofline"] = compact_roofline(full["roofline"])
     cb = full.get("cpu_baseline")
@@ -735,6 +736,8 @@ def compact_line(full: dict) -> str:
                 line["other_configs"][name] = {"error": clip(str(e["error"]), 60)}
                 continue
             c = {"value": e.get("value"), "us_per_half_step": e.get("us_per_half_step")}
+            if name.startswith("HBM_") and e.get("us_per_half_step_runs"):
+                c["us_minmax"] = [min(e["us_per_half_step_runs"]), max(e["us_per_half_step_runs"])]
             roof = e.get("roofline")
             if roof:
                 c.update(frac=roof["frac"], served_from=roof["served_from"], traffic=roof.get("traffic"))
@@ -833,6 +836,12 @@ class Job:
         dist.barrier()
         return time.perf_counter() - t0
 
+    @staticmethod
+    def take_median(res: dict, runs) -> None:
+        """`runs`: (seconds -- max over ranks --, HIP-event ms, launches) per repetition; `value` comes from the median one."""
+        res["elapsed_runs"] = [r[0] for r in runs]
+        res["elapsed"], res["event_ms"], res["launches"] = sorted(runs)[len(runs) // 2]
+
     def max_over_ranks(self, seconds: float) -> float:
         t = self.torch.tensor([seconds], dtype=self.torch.float64, device="cuda")
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
@@ -877,14 +886,17 @@ def run_single(job: Job) -> dict:
     for _ in range(args.warmup):
         s.run(GENS_PER_STEP)
     s.sync()
-    s.set_positions(job.th)                  # restart: the timed region is the whole C2 job
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    s.run(job.G)                             # exactly `steps` steps of GENS_PER_STEP generations
-    s.sync()
-    torch.cuda.synchronize()
-    res = {"elapsed": time.perf_counter() - t0, "event_ms": s.last_run_ms(),      # HIP events on the sampler's own stream
-           "launches": s.launch_count, "how": s.describe(), "mode": "single"}
+    runs = []
+    for _ in range(REPS):                    # the whole C2 job REPS times from the same start (>= 3 repetitions after a warm-up run)
+        s.set_positions(job.th)              # restart: the timed region is the whole C2 job
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        s.run(job.G)                         # exactly `steps` steps of GENS_PER_STEP generations
+        s.sync()
+        torch.cuda.synchronize()
+        runs.append((time.perf_counter() - t0, s.last_run_ms(), s.launch_count))      # (wall; HIP events on the sampler's own stream; launches since set_positions)
+    res = {"how": s.describe(), "mode": "single"}
+    Job.take_median(res, runs)               # `value`: the median repetition
     res["msum"], res["msq"], res["nmom"] = s.moments()
     res["acc"] = float(s.accept_ratio().mean())
     s.close()
@@ -1059,25 +1071,26 @@ def run_sharded(job: Job) -> dict:
                 drv.set_positions(th)
                 drv.run(args.warmup * GENS_PER_STEP)
                 drv.sync()
-                drv.set_positions(th)                # barriers inside; restart the job
-                dist.barrier()
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                drv.run(G)
-                try:
-                    drv.sync()
-                    job.fault("p2p_run")
-                    ran = True
-                except Exception as e:  # noqa: BLE001  (a timed-out peer wait: the other ranks must not be left inside a collective)
-                    note(f"[rank {rank}] the p2p run failed ({e})")
-                    ran = False
-                torch.cuda.synchronize()
-                if not job.all_ok(ran):
-                    raise RuntimeError("a rank's peer-to-peer run did not complete")
-                dist.barrier()
-                res["elapsed"] = time.perf_counter() - t0
-                res["event_ms"] = drv.sampler.last_run_ms()
-                res["launches"] = drv.sampler.launch_count
+                runs = []
+                for _ in range(REPS):                    # the whole job REPS times from the same start, as at N = 1
+                    drv.set_positions(th)                # barriers inside; restart the job
+                    dist.barrier()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    drv.run(G)
+                    try:
+                        drv.sync()
+                        job.fault("p2p_run")
+                        ran = True
+                    except Exception as e:  # noqa: BLE001  (a timed-out peer wait: the other ranks must not be left inside a collective)
+                        note(f"[rank {rank}] the p2p run failed ({e})")
+                        ran = False
+                    torch.cuda.synchronize()
+                    if not job.all_ok(ran):
+                        raise RuntimeError("a rank's peer-to-peer run did not complete")
+                    dist.barrier()
+                    runs.append((job.max_over_ranks(time.perf_counter() - t0), drv.sampler.last_run_ms(), drv.sampler.launch_count))
+                job.take_median(res, runs)
                 res["msum"], res["msq"], res["nmom"] = drv.moments()
                 fpos, facc = drv.positions(), drv.naccept()
                 res["how"] = drv.sampler.describe()
@@ -1109,9 +1122,11 @@ def run_sharded(job: Job) -> dict:
         nat = make_allgather(job, "allgather-setup")
         if nat is not None:
             with rung("allgather-run"):
-                res["elapsed"] = job.timed(nat, G, min(args.warmup * GENS_PER_STEP, 200))
-                res["event_ms"] = nat.sampler.last_run_ms()
-                res["launches"] = nat.sampler.launch_count
+                runs = []
+                for rep in range(REPS):
+                    t = job.max_over_ranks(job.timed(nat, G, min(args.warmup * GENS_PER_STEP, 200) if rep == 0 else 0))
+                    runs.append((t, nat.sampler.last_run_ms(), nat.sampler.launch_count))
+                job.take_median(res, runs)
                 res["msum"], res["msq"], res["nmom"] = nat.moments()
                 facc, fpos = nat.naccept(), nat.positions()
                 res["how"] = nat.sampler.describe()
@@ -1150,7 +1165,9 @@ def run_sharded(job: Job) -> dict:
             rpos, racc, _ = job.unsharded(G)
             res["verified"] = bool(np.array_equal(rpos, fpos) and np.array_equal(racc, facc))
     res["acc"] = float(facc.sum() / nw / max(1, G - nburn))
-    res["elapsed"] = job.max_over_ranks(res["elapsed"])
+    if "elapsed_runs" not in res:                        # (the torch-collective fallback: one timed run)
+        res["elapsed"] = job.max_over_ranks(res["elapsed"])
+        res["elapsed_runs"] = [res["elapsed"]]
     res["mode"] = mode
     res["extras"] = {"dealt": None, "allgather": None, "allgather_started": False}
     return res
@@ -1238,6 +1255,7 @@ def full_record(job: Job, res: dict, timed_out=None) -> dict:
     roof = roofline_block(job.pdf, how, walkers_per_launch, NDIM, launch_us, res["launches"], state_bytes(rows_here, NDIM, moment_bytes(how)), "c2", use_record=not job.sharded)
     out = {
         "metric": "walker-steps/sec", "value": value, "unit": "walker-steps/s", "n_gpus": world,
+        "value_min": float(job.nw) * job.G / max(res["elapsed_runs"]), "value_max": float(job.nw) * job.G / min(res["elapsed_runs"]), "repetitions": len(res["elapsed_runs"]),
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["elapsed"] * 1e3 / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"C2: emcee stretch move, {NWALKERS_PER_GPU} walkers/GPU x {NDIM}-dim isotropic Gaussian, "

@@ -377,7 +377,9 @@ int64_t     kmc_sampler_launch_count(const kmc_sampler* s);
 /* How kmc_sampler_run issues this sampler's launches (same kernels, same results in every mode; reference
  * src/samplers.jl:245-247 -- the generation x half-step loop -- is what the modes enqueue).
  * A sampler measures the table graph against the updated graph (or eager launches) once, at its first kmc_sampler_run of >= 896 generations -- if the
- * job was planned long (kmc_config::ngenerations >= 4096) or the sampler has come that far; until then, and for short jobs, whole chunks replay the table graph.
+ * job was planned long (kmc_config::ngenerations >= 4096) or the sampler has come that far; until then, and for short jobs, whole chunks replay the table graph
+ * (up to ~9 % slower per half-step at C2's size): a caller that drives a long job in pieces -- a progress or checkpoint loop -- should make them >= 896 generations
+ * (the Python front end's progress loop does), or decide with KMC_LAUNCH=updated,budget in the environment.
  * *budget_fallback (may be NULL)
  * becomes 1 when the sampler is not in the updated-graph mode because the PROCESS-WIDE budget of graph parameter updates was
  * spent (the HIP runtime keeps host memory per update, ~80 B in HIP 7.0 -- the runtime a PyTorch wheel brings -- and ~1.4 B in 7.2; 64 MiB worth by default, priced by hipRuntimeGetVersion, KMC_DEBUG=updated-budget-mb=n in the

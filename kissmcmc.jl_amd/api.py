@@ -198,7 +198,8 @@ def _run_generations(s, niter, nwalkers, niter_walker, nburnin_walker, use_progr
     """All generations of one emcee call, in up to 20 pieces with a progress line on stderr after each
     (the reference's ProgressMeter values, ``src/samplers.jl:275-284``) or in one piece."""
     if use_progress_meter and niter_walker > 0:
-        nchunks = min(20, niter_walker)
+        # (a long job -- >= 4096 generations -- in pieces of >= 1024: a sampler measures its launch modes in a run of >= 896 generations, kissmcmc_hip.h)
+        nchunks = min(20, niter_walker if niter_walker < 4096 else niter_walker // 1024)
         done = 0
         for c in range(nchunks):
             upto = (niter_walker * (c + 1)) // nchunks

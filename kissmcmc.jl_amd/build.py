@@ -10,7 +10,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(_HERE, "libkissmcmc_hip.so")
 SOURCES = ["kmc_sampler.hip", "kmc_plan.hip", "kmc_launch.hip", "kmc_state.hip", "kmc_copy.hip", "kmc_rtc.hip", "kmc_p2p.hip", "kmc_metropolis_api.hip", "kmc_acorr.hip", "kmc_rccl.hip", "kmc_diag.hip", "kmc_inst_host.hip"] + \
           [f"kmc_inst_{d}{part}.hip" for part in ("", "_var", "_p2p", "_lds") for d in ("lognormal", "exponential", "gaussian_iso", "rosenbrock", "mvnormal2")]   # (longest jobs first)
-HEADERS = ["kmc_host.hpp", "kmc_sampler.hpp", "kmc_device.hpp", "kmc_kernels.hpp", "kmc_islands.hpp", "kmc_generation.hpp", "kmc_copy_kernels.hpp", "kmc_metropolis.hpp", "kmc_tables.hpp", os.path.join("..", "..", "include", "kissmcmc_hip.h")]
+HEADERS = ["kmc_host.hpp", "kmc_sampler.hpp", "kmc_device.hpp", "kmc_kernels.hpp", "kmc_islands.hpp", "kmc_generation.hpp", "kmc_copy_kernels.hpp", "kmc_metropolis.hpp", "kmc_tables.hpp", "kmc_recognise.hpp", os.path.join("..", "..", "include", "kissmcmc_hip.h")]
 # kernarg preload: the half-step kernels' leading scalar parameters arrive in SGPRs at wave launch (kmc_kernels.hpp)
 PRELOAD = ["-mllvm", "-amdgpu-kernarg-preload-count=14"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",

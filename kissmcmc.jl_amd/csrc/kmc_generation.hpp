@@ -154,7 +154,7 @@ __device__ __forceinline__ void generation_lane_body(const GenerationFront& f, c
     const SchedEntry sch_e = generation_schedule_early(f);
     const DrawConsts dcf = generation_draw_consts_early(f);
     const uint64_t step0 = 2ull * (uint64_t)sch_e.gen;                   // the first half-step of this generation (:246, batch 1)
-#ifdef KMC_PROBE
+#if KMC_PROBE_PINS
     asm volatile("" :: "s"(step0));
 #endif
     KMC_STAMP(1);                                                        // the schedule entry has arrived
@@ -163,7 +163,7 @@ __device__ __forceinline__ void generation_lane_body(const GenerationFront& f, c
     // level 1 = my own move; level 0 (second half only) = my partner's move in the first half-step
     const U4 mybits = draw_bits(dcf, step0 + (second ? 1u : 0u), me);
     const uint32_t mypartner = (second ? 0u : f.h) + draw_partner(dcf, mybits);     // :250
-#ifdef KMC_PROBE
+#if KMC_PROBE_PINS
     asm volatile("" :: "v"(mypartner));
 #endif
     KMC_STAMP(2);                                                        // my Philox block is done
@@ -174,7 +174,7 @@ __device__ __forceinline__ void generation_lane_body(const GenerationFront& f, c
         const uint32_t w = mypartner;                                    // a first-half walker: its move of step0
         bits = draw_bits(dcf, step0, w);
         const uint32_t jp = f.h + draw_partner(dcf, bits);             // its partner: a second-half row, unchanged by the first half-step
-#ifdef KMC_PROBE
+#if KMC_PROBE_PINS
         asm volatile("" :: "v"(jp));
 #endif
         KMC_STAMP(3);                                                    // (second half) my partner's Philox block is done
@@ -202,7 +202,7 @@ __device__ __forceinline__ void generation_lane_body(const GenerationFront& f, c
     const Draw dr_mine = draw_finish(dc, mybits);                      // :252
     Draw dr_first = dr_mine;
     if (second) dr_first = draw_finish(dc, bits);                      // (uniform per workgroup; without the branch the four logarithms serialise: measured)
-#ifdef KMC_PROBE
+#if KMC_PROBE_PINS
     asm volatile("" :: "v"(dr_first.lu), "v"(dr_mine.lu));
 #endif
     KMC_STAMP(4);                                                        // loads issued, logarithms done
@@ -214,7 +214,7 @@ __device__ __forceinline__ void generation_lane_body(const GenerationFront& f, c
         Draw dr = dr_mine;
         if (level == 0) dr = dr_first;
         if (level == 1) {
-#ifdef KMC_PROBE
+#if KMC_PROBE_PINS
             asm volatile("" :: "v"(oth[0]), "v"(own[0]));
 #endif
             KMC_STAMP(5);                                                // rows arrived (first half) / my partner's move done (second half)
@@ -237,7 +237,7 @@ __device__ __forceinline__ void generation_lane_body(const GenerationFront& f, c
 #pragma unroll
     for (int d = 0; d < ND; ++d) y[d] = acc ? y[d] : own[d];             // :261
     const double pnew = acc ? p1 : p0;                                   // :262
-#ifdef KMC_PROBE
+#if KMC_PROBE_PINS
     asm volatile("" :: "v"(pnew));
 #endif
     KMC_STAMP(6);                                                        // my move is done
@@ -265,7 +265,7 @@ __device__ __forceinline__ void generation_lane_body(const GenerationFront& f, c
         KMC_STAMP_READ(st[0], 80, 81); KMC_STAMP_READ(st[1], 82, 83); KMC_STAMP_READ(st[2], 84, 85); KMC_STAMP_READ(st[3], 86, 87);
         KMC_STAMP_READ(st[4], 88, 89); KMC_STAMP_READ(st[5], 90, 91); KMC_STAMP_READ(st[6], 92, 93); KMC_STAMP_READ(st[7], 94, 95);
         if (!second) st[3] = st[2];                                      // (first half: no second Philox block)
-        if (threadIdx.x == 0 && blockIdx.x < 8192) for (int q = 0; q < 8; ++q) g_probe[sch.gen & 1][blockIdx.x][q] = st[q];   // [generation parity][workgroup (its first wave)]
+        if (threadIdx.x == 0 && blockIdx.x < 8192) for (int q = 0; q < 8; q += (KMC_PROBE == 2 ? 7 : 1)) g_probe[sch.gen & 1][blockIdx.x][q] = st[q];   // [generation parity][workgroup (its first wave)]
     }
 #endif
 }
@@ -315,7 +315,7 @@ __device__ __forceinline__ void generation_group_body(const GenerationFront& f, 
     };
     const U4 mybits = draw_bits(dcf, step0 + (second ? 1u : 0u), me);
     const uint32_t mypartner = (second ? 0u : f.h) + draw_partner(dcf, mybits);     // :250
-#ifdef KMC_PROBE
+#if KMC_PROBE_PINS
     asm volatile("" :: "v"(mypartner));
 #endif
     KMC_STAMP(1);                                                        // my Philox block is done
@@ -388,7 +388,7 @@ __device__ __forceinline__ void generation_group_body(const GenerationFront& f, 
     bool acc = false;
     double p1 = 0.0;
     double2 y[K];
-#ifdef KMC_PROBE
+#if KMC_PROBE_PINS
     asm volatile("" :: "v"(dr_mine.lu), "v"(dr_first.lu));
 #endif
     KMC_STAMP(3);                                                        // draws finished (logarithms), accumulators requested
@@ -425,7 +425,7 @@ __device__ __forceinline__ void generation_group_body(const GenerationFront& f, 
     // all; 8 192 x 64 3.46 -> 2.59 us per half-step without that).  Tried instead of reading accumulators up front: no-return fp64 atomic adds on accept --
     // slower at every shape, the L2 retires about one 8-byte add per channel per 3-4 cycles (profiles/r05_generation_mid.txt).  `own` is my row before my move.
     const double wgt = (valid && acc && moments) ? (double)(sch.nbefore - kl) : 0.0;
-#ifdef KMC_PROBE
+#if KMC_PROBE_PINS
     asm volatile("" :: "v"(wgt));
 #endif
     KMC_STAMP(4);                                                        // rows arrived, both moves done
@@ -492,7 +492,7 @@ __device__ __forceinline__ void generation_group_body(const GenerationFront& f, 
         KMC_STAMP_READ(st[0], 80, 81); KMC_STAMP_READ(st[1], 82, 83); KMC_STAMP_READ(st[2], 84, 85); KMC_STAMP_READ(st[3], 86, 87);
         KMC_STAMP_READ(st[4], 88, 89); KMC_STAMP_READ(st[5], 90, 91); KMC_STAMP_READ(st[7], 94, 95);
         st[6] = st[5];
-        if (threadIdx.x == 0 && blockIdx.x < 8192) for (int q = 0; q < 8; ++q) g_probe[sch.gen & 1][blockIdx.x][q] = st[q];   // [generation parity][workgroup (its first wave)]
+        if (threadIdx.x == 0 && blockIdx.x < 8192) for (int q = 0; q < 8; q += (KMC_PROBE == 2 ? 7 : 1)) g_probe[sch.gen & 1][blockIdx.x][q] = st[q];   // [generation parity][workgroup (its first wave)]
     }
 #endif
 }

@@ -397,18 +397,33 @@ __device__ __forceinline__ double2 load_row_sys(const double2* p)
 // kernel's allocation), and all eight are collected after one s_waitcnt at the very end -- a stamp that waited
 // (lgkmcnt(0)) would also wait for the argument struct's scalar loads and move the very thing it measures.
 static __device__ unsigned long long g_probe[2][8192][8];
+// -DKMC_PROBE=2, the LIGHT probe: only wave entry and "last store issued" are stamped and nothing pins the schedule at the other six points --
+// body / boundary of a launch at (nearly) the production kernel's own period, the duration source of the profile records (scripts/summarize_r04.py).
 #define KMC_STAMP_AT(lo, hi) asm volatile("s_memrealtime s[" #lo ":" #hi "]" ::: "s" #lo, "s" #hi, "memory")
 #define KMC_STAMP(i) KMC_STAMP_##i
 #define KMC_STAMP_0 KMC_STAMP_AT(80, 81)
+#define KMC_STAMP_7 KMC_STAMP_AT(94, 95)
+#if KMC_PROBE == 2
+#define KMC_PROBE_PINS 0
+#define KMC_STAMP_1 do { } while (0)
+#define KMC_STAMP_2 do { } while (0)
+#define KMC_STAMP_3 do { } while (0)
+#define KMC_STAMP_4 do { } while (0)
+#define KMC_STAMP_5 do { } while (0)
+#define KMC_STAMP_6 do { } while (0)
+#define KMC_STAMP_READ(dst, lo, hi) do { if ((lo) == 80 || (lo) == 94) asm volatile("s_mov_b64 %0, s[" #lo ":" #hi "]" : "=s"(dst)); else (dst) = 0ull; } while (0)
+#else
+#define KMC_PROBE_PINS 1
 #define KMC_STAMP_1 KMC_STAMP_AT(82, 83)
 #define KMC_STAMP_2 KMC_STAMP_AT(84, 85)
 #define KMC_STAMP_3 KMC_STAMP_AT(86, 87)
 #define KMC_STAMP_4 KMC_STAMP_AT(88, 89)
 #define KMC_STAMP_5 KMC_STAMP_AT(90, 91)
 #define KMC_STAMP_6 KMC_STAMP_AT(92, 93)
-#define KMC_STAMP_7 KMC_STAMP_AT(94, 95)
 #define KMC_STAMP_READ(dst, lo, hi) asm volatile("s_mov_b64 %0, s[" #lo ":" #hi "]" : "=s"(dst))
+#endif
 #else
+#define KMC_PROBE_PINS 0
 #define KMC_STAMP(i) do { } while (0)
 #endif
 
@@ -519,7 +534,7 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
         bits = draw_bits(dcf, step + 2ull * (uint64_t)jq, (uint64_t)f.gw0 + (uint64_t)iAc);   // RNG keyed by the GLOBAL walker index
         partnerA = draw_partner(dcf, bits);
     }
-#ifdef KMC_PROBE
+#if KMC_PROBE_PINS
     asm volatile("" :: "v"(partnerA));
 #endif
     KMC_STAMP(1);                                       // Philox done: the partner index is known
@@ -630,7 +645,7 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
     if constexpr (kMomRing) {
         if (do_mom && a.mring != nullptr) { ring_posted = a.mcnt[tid >> 6]; ring_swept = a.mswept[tid >> 6]; }
     }
-#ifdef KMC_PROBE
+#if KMC_PROBE_PINS
     asm volatile("" :: "s"(count ? 1 : 0), "s"(a.dc.c0));
 #endif
     KMC_STAMP(3);                                       // the argument struct has arrived (schedule entry, constants)
@@ -659,7 +674,7 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
             }
         }
     }
-#ifdef KMC_PROBE
+#if KMC_PROBE_PINS
     asm volatile("" :: "v"(dr.lu), "v"(dr.t1));
 #endif
     KMC_STAMP(4);                                       // both logarithms done, every partner-row load issued
@@ -720,7 +735,7 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
         }
     }
 
-#ifdef KMC_PROBE
+#if KMC_PROBE_PINS
     asm volatile("" :: "v"(myp1));
 #endif
     KMC_STAMP(5);                                       // both rows have arrived, the proposal's log-pdf is reduced
@@ -842,7 +857,7 @@ __device__ __forceinline__ void half_step_vec_body(const HalfStepFront& f, const
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         KMC_STAMP_READ(st[0], 80, 81); KMC_STAMP_READ(st[1], 82, 83); KMC_STAMP_READ(st[2], 84, 85); KMC_STAMP_READ(st[3], 86, 87);
         KMC_STAMP_READ(st[4], 88, 89); KMC_STAMP_READ(st[5], 90, 91); KMC_STAMP_READ(st[6], 92, 93); KMC_STAMP_READ(st[7], 94, 95);
-        if (lane == 0 && (tid >> 6) < 8192) for (int q = 0; q < 8; ++q) g_probe[half][tid >> 6][q] = st[q];
+        if (lane == 0 && (tid >> 6) < 8192) for (int q = 0; q < 8; q += (KMC_PROBE == 2 ? 7 : 1)) g_probe[half][tid >> 6][q] = st[q];
     }
 #endif
 }

@@ -619,6 +619,7 @@ KMC_EXPORT kmc_status kmc_sampler_run(kmc_sampler* s, int64_t ngen)
         // copy does not hold it already: the copies are made equal whenever somebody may have changed d_pos / d_logp since the last run (set_positions,
         // set_state, the initial ball: they write the first pair only; a caller-owned buffer -- kmc_sampler_bind_positions -- may change at any time: every
         // run); between runs the kernels keep them consistent.  (Launch modes: below, with the two-launch kernels' -- whole chunks start in copy 0.)
+        HIP_TRY(generation_settle(s));         // (a run that failed after an odd number of generations left the newest state in copy 1: bring it home before copy 0 overwrites it)
         HIP_TRY(hipMemcpyAsync(s->d_pos2, s->d_pos, (size_t)s->nrows * (size_t)s->ld * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
         HIP_TRY(hipMemcpyAsync(s->d_logp2, s->d_logp, (size_t)s->nrows * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
         s->pos2_current = true;
@@ -844,16 +845,16 @@ KMC_EXPORT kmc_status kmc_sampler_run(kmc_sampler* s, int64_t ngen)
         if (env && std::strcmp(env, "graph") == 0) s->launch_mode = 1;
         else if (env && std::strcmp(env, "eager") == 0) s->launch_mode = 2;
         else if (env && std::strcmp(env, "updated") == 0 && updated_graph_possible(s)) { s->launch_mode = 3; s->updated_forced = true; }
-        else if (env && std::strcmp(env, "updated,budget") == 0 && updated_graph_possible(s) && update_budget_left(2 * s->uchunk)) s->launch_mode = 3;   // (as if measured: the budget applies)
+        else if (env && std::strcmp(env, "updated,budget") == 0 && updated_graph_possible(s) && update_budget_left(lpg * s->uchunk)) s->launch_mode = 3;   // (as if measured: the budget applies)
         else if (!updated_graph_possible(s)) s->launch_mode = 1;
         else if (ngen >= calib_min && long_job) {
-            const bool left = update_budget_left(2 * s->uchunk);      // (the measurement itself may overshoot by its six replays; the run after it may not)
+            const bool left = update_budget_left(lpg * s->uchunk);      // (the measurement itself may overshoot by its six replays; the run after it may not)
             if (!left) note_budget_spent(s);
             KMC_TRY(calibrate(left));
         }
     }
     while (use_graph && s->launch_mode == 3 && ngen >= s->uchunk) {
-        if (!s->updated_forced && !update_budget_left(2 * s->uchunk)) {             // the process has used up its leak budget: decide again, between 1 and 2
+        if (!s->updated_forced && !update_budget_left(lpg * s->uchunk)) {             // the process has used up its leak budget: decide again, between 1 and 2
             note_budget_spent(s);
             s->launch_mode = 0;
             if (ngen >= calib_min) KMC_TRY(calibrate(false));
@@ -878,9 +879,9 @@ KMC_EXPORT kmc_status kmc_sampler_half_step(kmc_sampler* s, int half)
     if (s->islands) return fail(KMC_ERR_UNSUPPORTED, "island mode advances whole generations: use kmc_sampler_run");
     if (s->host_eval) return fail(KMC_ERR_UNSUPPORTED, "KMC_HOST_DENSITY: a half-step includes the host callback; use kmc_sampler_run");
     if (s->resident) return fail(KMC_ERR_UNSUPPORTED, "this small ensemble runs in resident mode (whole generations per launch); create it with KMC_NO_GRAPH to step by halves");
+    HIP_TRY(hipSetDevice(s->cfg.device));             // (before unfuse: its copies, graph destruction and moment read-out belong to this sampler's device)
     if (s->fused) KMC_TRY(unfuse(s));                 // stepping by halves: the two-launch kernels from here on (same chain, bit for bit)
     if (s->generation >= ((int64_t)1 << 31) - 1) return fail(KMC_ERR_UNSUPPORTED, "at most 2^31 - 1 generations (the step index is 32 bits)");
-    HIP_TRY(hipSetDevice(s->cfg.device));
     if (half == 0) KMC_TRY(chain_before(s, s->generation + 1));
     KMC_TRY(launch_half(s, half, false, s->generation));
     s->launches += 1;

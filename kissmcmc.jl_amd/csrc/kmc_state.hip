@@ -75,6 +75,7 @@ kmc_status reset_run_state(kmc_sampler* s, bool eval_logp, int64_t generation, u
     }
     HIP_TRY(hipStreamSynchronize(s->stream));
     s->pos2_current = false;
+    s->fused_cur = 0;                  // (the caller's state is in d_pos / d_logp: whatever a failed run left in copy 1 is void)
     s->generation = generation;
     s->launches = 0;
     s->have_run_events = false;
@@ -263,6 +264,7 @@ KMC_EXPORT kmc_status kmc_sampler_set_positions(kmc_sampler* s, const double* th
     }
     HIP_TRY(hipStreamSynchronize(s->stream));
     s->pos2_current = false;
+    s->fused_cur = 0;                  // (the caller's state is in d_pos / d_logp: whatever a failed run left in copy 1 is void)
     s->generation = 0;
     s->dev_gen = 0;
     s->moment_base = 0;

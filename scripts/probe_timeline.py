@@ -12,12 +12,13 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-VAR = os.path.join(ROOT, "kissmcmc.jl_amd", "libkmc_var_probe.so")
+LIGHT = os.environ.get("KMC_PROBE_LIGHT") == "1"        # -DKMC_PROBE=2: entry and last-store stamps only, nothing pinned in between (the records' duration source)
+VAR = os.path.join(ROOT, "kissmcmc.jl_amd", "libkmc_var_probe2.so" if LIGHT else "libkmc_var_probe.so")
 os.environ["KMC_LIB_PATH"] = VAR
 if not os.path.exists(VAR):
     import importlib
     b = importlib.import_module("kissmcmc.jl_amd.build".replace("kissmcmc.jl_amd", "kissmcmc_jl_amd"))
-    b.build(extra_flags=["-DKMC_PROBE"], out=VAR)
+    b.build(extra_flags=["-DKMC_PROBE=2" if LIGHT else "-DKMC_PROBE"], out=VAR)
 import kissmcmc_jl_amd as kmc
 from kissmcmc_jl_amd import _lib
 
@@ -60,7 +61,7 @@ def main():
             print(f" {nwg} workgroups stamped (first wave of each): entry spread {t[0, :, 0].max() - t[0, :, 0].min():.2f} us, wave duration median {np.median(t[0, :, 7] - t[0, :, 0]):.2f} "
                   f"(p90 {np.percentile(t[0, :, 7] - t[0, :, 0], 90):.2f}); first wave in .. last store issued {body:.2f} us; gap to the next launch's first wave {gap:.2f} us; "
                   f"launch period {t[1, :, 0].min() - t[0, :, 0].min():.2f} us")
-            if "generation_group" in how:
+            if "generation_group" in how and not LIGHT:
                 half = nwg // 2                                  # workgroups [0, nb) carry the second half (they recompute their partner's first-half move)
                 for label, sl in (("second-half workgroups", slice(0, half)), ("first-half workgroups", slice(half, nwg))):
                     dd = np.diff(t[0, sl][:, [0, 1, 2, 3, 4, 5, 7]], axis=1)
@@ -68,7 +69,7 @@ def main():
                           f"-> rows in, move(s) done {np.median(dd[:, 3]):.2f}; -> moments folded {np.median(dd[:, 4]):.2f}; -> last store issued {np.median(dd[:, 5]):.2f}; "
                           f"wave {np.median(t[0, sl, 7] - t[0, sl, 0]):.2f} us")
             m = re.search(r"generation_\w+[^;]*?, grid \d+ x \d+", how)
-            print("PROBE_JSON " + json.dumps({"config": name, "moments": int(mom), "geometry": m.group(0) if m else None, "waves_stamped": nwg, "launches_per_generation": 1,
+            print("PROBE_JSON " + json.dumps({"config": name, "moments": int(mom), "probe": "light" if LIGHT else "full", "execution": how, "geometry": m.group(0) if m else None, "waves_stamped": nwg, "launches_per_generation": 1,
                                               "body_us": body, "boundary_us": gap, "period_us_in_kernel": float(t[1, :, 0].min() - t[0, :, 0].min()),
                                               "period_us_hip_events_probe_build": ms / 1024 * 1e3, "wave_duration_median_us": float(np.median(t[0, :, 7] - t[0, :, 0]))}))
             s.close()
@@ -80,7 +81,7 @@ def main():
         t = buf[:, :nwave, :].astype(np.int64)
         base = t[0, :, 0].min()
         t = (t - base) * 10.0 / 1000.0            # us since the first wave of half 0 started (100 MHz counter)
-        for half in (0, 1):
+        for half in (() if LIGHT else (0, 1)):
             a = t[half]
             print(f" half {half}: {nwave} waves; absolute times (min / median / max over waves):")
             for q, label in enumerate(STAMPS):
@@ -96,7 +97,7 @@ def main():
         import json
         import re
         m = re.search(r"half_step_\w+[^;]*?, grid \d+ x \d+", how)
-        print("PROBE_JSON " + json.dumps({"config": name, "moments": int(mom), "geometry": m.group(0) if m else None, "waves_stamped": nwave,
+        print("PROBE_JSON " + json.dumps({"config": name, "moments": int(mom), "probe": "light" if LIGHT else "full", "execution": how, "geometry": m.group(0) if m else None, "waves_stamped": nwave,
                                           "body_us": float(t[0, :, 7].max() - t[0, :, 0].min()), "boundary_us": float(t[1, :, 0].min() - t[0, :, 7].max()),
                                           "period_us_in_kernel": float(t[1, :, 0].min() - t[0, :, 0].min()), "period_us_hip_events_probe_build": ms / 2048 * 1e3,
                                           "wave_duration_median_us": float(np.median(t[0, :, 7] - t[0, :, 0]))}))

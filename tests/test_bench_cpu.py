@@ -114,7 +114,7 @@ def _full_single():
     oc = {"C1": {"workload": long, "value": 2.08e8, "unit": "walker-steps/s", "us_per_half_step": 0.24018123456, "execution": long},
           "C3": {"workload": long, "value": 2.5452e9, "us_per_half_step": 3.2186123, "us_per_half_step_runs": [3.2, 3.3], "execution": how3, "roofline": _roof("c3", 16384, 64, 3.2186, how3)},
           "C5": {"workload": long, "value": 3.7191e8, "us_per_half_step": 11.013, "execution": long, "roofline": _roof("c5", 8192, 1024, 11.013, how3)},
-          "HBM_2Mx32": {"workload": long, "value": 9.6283e9, "us_per_half_step": 108.91, "roofline": _roof("hbm_2mx32", 2097152, 32, 108.91, how3)},
+          "HBM_2Mx32": {"workload": long, "value": 9.6283e9, "us_per_half_step": 108.91, "us_per_half_step_runs": [108.91234, 98.41234, 109.01234], "roofline": _roof("hbm_2mx32", 2097152, 32, 108.91, how3)},
           "HBM_512Kx128": {"workload": long, "value": 2.4467e9, "us_per_half_step": 107.14, "roofline": _roof("hbm_512kx128", 524288, 128, 107.14, how3)},
           "MID_4096x4": {"workload": long, "value": 1.2902e9, "us_per_half_step": 1.5874, "two_launches_us_per_half_step": 2.4592, "execution": long, "two_launches_execution": long},
           "MID_16384x4": {"workload": long, "value": 4.6831e9, "us_per_half_step": 1.7493, "two_launches_us_per_half_step": 2.5174, "execution": long},
@@ -124,7 +124,8 @@ def _full_single():
           "C2_user_density_two_sums": {"error": "hiprtc: " + long},
           "C2_user_density_coupled": {"workload": long, "value": 6.4382e9, "us_per_half_step": 5.0896, "execution": long},
           "C1_user_density": {"workload": long, "value": 2.3696e8, "us_per_half_step": 0.211, "execution": long}}
-    return {"metric": "walker-steps/sec", "value": 8701926704.69613, "unit": "walker-steps/s", "n_gpus": 1, "steps": 20, "warmup": 5, "ms_per_step": 7.531205700070132,
+    return {"metric": "walker-steps/sec", "value": 8701926704.69613, "value_min": 8655926704.123456, "value_max": 8745926704.654321, "repetitions": 3,
+            "unit": "walker-steps/s", "n_gpus": 1, "steps": 20, "warmup": 5, "ms_per_step": 7.531205700070132,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "C2: emcee stretch move, 65536 walkers/GPU x 32-dim isotropic Gaussian, 20000 generations (burn-in 10000), a=2, moments on, chain off",
                        "nwalkers_total": 65536, "ndim": 32, "generations": 20000, "gens_per_step": 1000, "parallelism": "single GPU", "execution": C2},
@@ -144,6 +145,8 @@ def test_the_single_gpu_result_line_fits_4_kb_and_keeps_what_the_driver_reads():
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "check"):
         assert key in line, key
     assert line["value"] == full["value"] and line["ms_per_step"] == full["ms_per_step"]
+    assert line["value_min"] <= line["value"] <= line["value_max"] and line["repetitions"] == 3       # >= 3 timed repetitions, the spread in the line
+    assert line["other_configs"]["HBM_2Mx32"]["us_minmax"] == [98.412, 109.01]                        # (the two-valued HBM shapes carry theirs)
     r = line["roofline"]
     assert abs(r["frac"] - full["roofline"]["frac"]) < 1e-5 and r["bound"] == r["served_from"] == "infinity_cache" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert r["traffic"] is not None and r["body_frac"] and r["kernel"].startswith("half_step_vec<GaussianIso") and r["profile_record"]["record"] == "profiles/traffic_c2.json"
