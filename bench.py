@@ -79,6 +79,16 @@ def launches_per_generation(describe: str) -> int:
     return 1 if "one launch per generation" in (describe or "") else 2
 
 
+def launch_mode_of(describe: str) -> str:
+    """How the launches of `describe` were issued: 'updated_graph_128' / 'table_graph_64' / 'eager' / 'single' (kissmcmc_hip.h: KMC_LAUNCH_*) -- a profile
+    record is only evidence for a line that ran in the record's mode (VERDICT r05 #1)."""
+    import re
+    m = re.search(r"hipGraph replay of (\d+) generations( with per-replay parameter updates)?", describe or "")
+    if m:
+        return ("updated_graph_" if m.group(2) else "table_graph_") + m.group(1)
+    return "eager" if "eager launches" in (describe or "") else "single"
+
+
 def kernel_name(pdf, describe: str):
     """The template instance the describe string stands for, as the kernel trace names it (density first, then L, K, ITER)."""
     import re
@@ -159,6 +169,10 @@ def roofline_block(pdf, describe: str, nwalkers_launch: int, ndim: int, launch_u
     body_us = rec.get("body_us") if rec else None
     boundary_us = rec.get("boundary_us") if rec else None
     body_frac = (alg_read / (body_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if body_us else None
+    # the kernel-duration figure between the two: the rocprofv3 trace's average duration where the tool does not inflate it (launches of ~100 us), else --
+    # the record says so -- the launch period the light in-kernel probe stamps (first wave in .. next launch's first wave: an upper bound of the duration)
+    duration_us = rec.get("duration_us") if rec else None
+    duration_frac = (alg_read / (duration_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if duration_us else None
     if served == "hbm":
         limited = "hbm_bandwidth"
     elif boundary_us and boundary_us / launch_us >= 0.2:
@@ -172,8 +186,11 @@ def roofline_block(pdf, describe: str, nwalkers_launch: int, ndim: int, launch_u
             "algorithmic_read_bytes_per_launch": alg_read, "algorithmic_total_bytes_per_launch": nwalkers_launch * b_total,
             "state_bytes": state_b, "served_from": served, "limited_by": limited,
             "body_us": body_us, "boundary_us": boundary_us, "body_frac": body_frac,
+            "duration_us": duration_us, "duration_frac": duration_frac, "duration_source": rec.get("duration_source") if rec else None,
+            "launch_mode": launch_mode_of(describe),
             "profile_record": ({"record": f"profiles/traffic_{record_name}.json",
-                                **{k: rec.get(k) for k in ("head", "kernel_sources_unchanged", "period_us_unprofiled", "hbm_read_bytes_per_launch", "hbm_write_bytes_per_launch", "l2_hit_rate", "source")}}
+                                **{k: rec.get(k) for k in ("head", "kernel_sources_unchanged", "launch_mode", "period_us_unprofiled", "rocprof_avg_duration_us", "rocprof_inflated",
+                                                           "hbm_read_bytes_per_launch", "hbm_write_bytes_per_launch", "l2_hit_rate", "source")}}
                                if rec else {"refused": why})}
 
 
@@ -408,7 +425,8 @@ def spawn_ranks(n: int, argv) -> int:
 
 
 LADDER = []      # [{"rung", "ok", "s"}]: every rung of the N > 1 ladder this rank went through, in order (printed with the line).  Rung names (short:
-#                  the line has 4 KB): rendezvous; p2p-check:<variant> (set-up + bit-exact self-check), p2p-time:<variant> (its short timing),
+#                  the line has 4 KB): rendezvous; p2p-check:<variant> (set-up + bit-exact self-check), p2p-time:<variant> (its short timing), link-probe (one
+#                  fabric link with the pull's access pattern + this GPU alone),
 #                  p2p-run (warm-up + timed run); allgather-setup (ncclCommInitRank), allgather-run, torch-allgather-run (the same exchange as a
 #                  torch collective per half-step); the extras after `value`: dealt-extra, allgather-extra-setup, allgather-extra
 
@@ -685,11 +703,12 @@ def clip(text, n: int):
 
 
 def compact_roofline(roof: dict) -> dict:
-    keep = ("bound", "achieved", "peak", "unit", "frac", "traffic", "served_from", "limited_by", "body_frac", "avg_launch_us", "launches",
+    keep = ("bound", "achieved", "peak", "unit", "frac", "duration_frac", "body_frac", "duration_source", "launch_mode", "traffic", "served_from", "limited_by", "avg_launch_us", "launches",
             "kernel", "geometry", "algorithmic_read_bytes_per_launch", "state_bytes", "frac_of_measured_copy_rate")
     out = {k: roof.get(k) for k in keep}
     rec = roof.get("profile_record") or {}
-    out["profile_record"] = {"record": rec.get("record"), "head": rec.get("head"), "source": rec.get("source")} if "refused" not in rec else {"refused": True}
+    out["profile_record"] = ({"record": rec.get("record"), "head": rec.get("head"), "launch_mode": rec.get("launch_mode"), "rocprof_inflated": rec.get("rocprof_inflated")}
+                             if "refused" not in rec else {"refused": True})
     return sig(out)
 
 
@@ -724,7 +743,9 @@ def compact_line(full: dict) -> str:
         if "extras_timed_out" in full:
             line["extras_timed_out"] = clip(full["extras_timed_out"], 120)
         fab = full.get("fabric") or {}
-        line["fabric"] = sig({k: fab.get(k) for k in ("bytes_per_link_per_launch", "link_bound_us_at_77GBs", "push_bytes_per_link_per_launch", "variants_us_per_launch") if fab.get(k) not in (None, {})})
+        line["fabric"] = sig({k: fab.get(k) for k in ("bytes_per_link_per_launch", "link_gather_GBs", "link_copy_GBs", "local_gather_GBs", "link_rate_source", "link_bound_us", "single_gpu_us_per_launch",
+                                                      "projected_exact_speedup", "measured_speedup", "ge6x_expected_under_exact_rule", "push_bytes_per_link_per_launch", "variants_us_per_launch")
+                              if fab.get(k) not in (None, {})}, 4)
     isl = full.get("island_mode")
     if isl is not None:
         line["island_mode"] = {"error": clip(str(isl["error"]), 80)} if "error" in isl else sig({k: isl.get(k) for k in ("value", "accept_ratio_mean")})
@@ -897,6 +918,16 @@ def run_single(job: Job) -> dict:
         runs.append((time.perf_counter() - t0, s.last_run_ms(), s.launch_count))      # (wall; HIP events on the sampler's own stream; launches since set_positions)
     res = {"how": s.describe(), "mode": "single"}
     Job.take_median(res, runs)               # `value`: the median repetition
+    # not `value`: the same job once more in its two phases -- burn-in (no moments credited) and the credited half -- because the profile records
+    # (profiles/traffic_c2.json) are taken per phase: launches that credit moments are ~0.4 us longer
+    s.set_positions(job.th)
+    phase = []
+    for gens in (job.nburn, job.G - job.nburn):
+        l0 = s.launch_count
+        s.run(gens)
+        s.sync()
+        phase.append(s.last_run_ms() * 1e3 / max(1, s.launch_count - l0))
+    res["phase_us"] = phase
     res["msum"], res["msq"], res["nmom"] = s.moments()
     res["acc"] = float(s.accept_ratio().mean())
     s.close()
@@ -1065,6 +1096,26 @@ def run_sharded(job: Job) -> dict:
             note("[rank 0] falling back to the RCCL all-gather exchange")
         mode = "p2p" if drv is not None else "allgather"
     if mode == "p2p":
+        # one fabric link measured with the pull's own access pattern, and this GPU alone on its 65 536 walkers: what the exact rule can reach (`fabric`)
+        with rung("link-probe") as rg:
+            lp = drv.link_probe()
+            t1 = float("nan")
+            try:
+                with job.kmc.Sampler(job.pdf, NWALKERS_PER_GPU, NDIM, G, 1024, 1, 2.0, SEED, moments=True, device=job.local_rank) as s1:
+                    for gens in (1024, 2048):            # warm-up (launch modes measured), then half burn-in, half credited like the job
+                        s1.set_positions(th[:NWALKERS_PER_GPU])
+                        s1.run(gens)
+                        s1.sync()
+                    t1 = s1.last_run_ms() * 1e3 / (2 * 2048)
+            except Exception as e:  # noqa: BLE001
+                note(f"[rank {rank}] link-probe: the single-GPU reference failed ({e})")
+            v = torch.tensor([lp.get("link_gather_GBs", float("nan")), lp.get("link_copy_GBs", float("nan")), lp.get("local_gather_GBs", float("nan")), -t1],
+                             dtype=torch.float64, device="cuda")
+            dist.all_reduce(v, op=dist.ReduceOp.MIN)     # the slowest link, the slowest GPU
+            vals = [None if x != x else x for x in v.tolist()]
+            res["link"] = {"link_gather_GBs": vals[0], "link_copy_GBs": vals[1], "local_gather_GBs": vals[2],
+                           "single_gpu_us_per_launch": None if vals[3] is None else -vals[3], "rows": lp["rows"], "error": lp.get("error")}
+            rg.ok = vals[0] is not None and vals[3] is not None
         ok = True
         try:
             with rung("p2p-run"):
@@ -1253,6 +1304,8 @@ def full_record(job: Job, res: dict, timed_out=None) -> dict:
     rows_here = NWALKERS_PER_GPU if (job.sharded and res["mode"] == "p2p") else job.nw             # (replica modes hold the whole ensemble)
     how = res["how"]
     roof = roofline_block(job.pdf, how, walkers_per_launch, NDIM, launch_us, res["launches"], state_bytes(rows_here, NDIM, moment_bytes(how)), "c2", use_record=not job.sharded)
+    if res.get("phase_us"):
+        roof["avg_launch_us_burnin"], roof["avg_launch_us_credited"] = res["phase_us"]
     out = {
         "metric": "walker-steps/sec", "value": value, "unit": "walker-steps/s", "n_gpus": world,
         "value_min": float(job.nw) * job.G / max(res["elapsed_runs"]), "value_max": float(job.nw) * job.G / min(res["elapsed_runs"]), "repetitions": len(res["elapsed_runs"]),
@@ -1279,13 +1332,24 @@ def full_record(job: Job, res: dict, timed_out=None) -> dict:
             out["allgather_mode"] = extras["allgather"] if extras["allgather"] is not None else {"error": timed_out}
         if timed_out:
             out["extras_timed_out"] = timed_out
-        # what the exchange has to move: partners are uniform over the whole complementary half, so (P-1)/P of a
-        # rank's partner rows are remote, 1/P from each peer over that pair's single xGMI link (~77 GB/s one direction); pull variants move
-        # every drawn row once (bytes_per_link from each peer), push variants accepted rows only (push_bytes_per_link to each peer)
+        # what the exchange has to move: partners are uniform over the whole complementary half (src/samplers.jl:250), so (P-1)/P of a
+        # rank's partner rows are remote, 1/P from each peer over that pair's single xGMI link; pull variants move every drawn row once (bytes_per_link from
+        # each peer), push variants accepted rows only (push_bytes_per_link to each peer).  The link's rate is MEASURED by the `link-probe` rung with the pull's
+        # own access pattern (77 GB/s assumed only if that rung failed: `link_rate_source`); projected_exact_speedup = P t1 / max(t1, link_bound_us), t1 = one
+        # GPU alone on 65 536 walkers in this run -- what the reference's partner rule can reach on this fabric, next to measured_speedup.
         rows_per_peer = walkers_per_launch / world
+        link = res.get("link") or {}
+        rate = link.get("link_gather_GBs")
+        t1 = link.get("single_gpu_us_per_launch")
+        bound = rows_per_peer * NDIM * 8 / ((rate or 77.0) * 1e9) * 1e6
+        proj = world * t1 / max(t1, bound) if t1 else None
         out["fabric"] = {"remote_partner_bytes_per_gpu_per_launch": rows_per_peer * (world - 1) * NDIM * 8,
                          "bytes_per_link_per_launch": rows_per_peer * NDIM * 8,
-                         "link_bound_us_at_77GBs": rows_per_peer * NDIM * 8 / 77e9 * 1e6,
+                         "link_gather_GBs": rate, "link_copy_GBs": link.get("link_copy_GBs"), "local_gather_GBs": link.get("local_gather_GBs"),
+                         "link_rate_source": "link-probe" if rate else "assumed_77GBs", "link_bound_us": bound,
+                         "single_gpu_us_per_launch": t1, "projected_exact_speedup": proj,
+                         "measured_speedup": (value / (NWALKERS_PER_GPU / (2 * t1 * 1e-6))) if t1 else None,
+                         "ge6x_expected_under_exact_rule": (proj >= 6.0) if proj else None,      # (north star: >= 6x at 8 GPUs; DESIGN section 7 says no for rand(ncos) over the whole half)
                          "push_bytes_per_link_per_launch": res["acc"] * walkers_per_launch * NDIM * 8,
                          "variants_us_per_launch": {tag: tc / 2048 * 1e6 for tag, tc in res["tried"]}}   # 1024 generations each
     else:

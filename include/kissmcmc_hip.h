@@ -320,6 +320,10 @@ kmc_status  kmc_rccl_version(int* version, char* path_buf /* may be NULL */, int
 /* The same wiring for shards that live in ONE process on one device (no IPC): shards[r] = the sampler of shard r.
    They run concurrently on their own streams like ranks on separate GPUs (single-process tests, timing, profiling). */
 kmc_status  kmc_sampler_p2p_connect_local(kmc_sampler* s, kmc_sampler* const* shards /* [shard_count] */);
+/* One fabric link measured with the pull's own access pattern (a connected KMC_P2P sampler with double rows; the peers must be idle): `nrows` whole rows of shard
+ * `peer` read at random row indices -- uniform with replacement, what src/samplers.jl:250 makes a link serve -- with the kernels' system-scope loads, `reps`
+ * launches -> *gather_gbs; the same shard copied whole by the runtime's device-to-device copy -> *copy_gbs.  Read-only.  peer == own rank: local memory. */
+kmc_status  kmc_sampler_p2p_link_probe(kmc_sampler* s, int peer, int64_t nrows, int reps, double* gather_gbs, double* copy_gbs);
 /* Upload the ensemble (host, [nwalkers][ndim], global order), evaluate the initial log-pdfs on
  * the device (src/samplers.jl:209-210), reset generation/counters.  Fails with
  * KMC_ERR_NONFINITE_LOGP if any is not finite. */

@@ -35,7 +35,7 @@ RCCL_ID_BYTES = 128
 SYMBOLS = [
     "kmc_version", "kmc_device_count", "kmc_last_error", "kmc_status_string", "kmc_validate",
     "kmc_g_pdf", "kmc_cdf_g_inv", "kmc_emcee_run", "kmc_sampler_create", "kmc_sampler_destroy",
-    "kmc_sampler_set_stream", "kmc_sampler_bind_positions", "kmc_sampler_p2p_export", "kmc_sampler_p2p_connect", "kmc_sampler_p2p_connect_local", "kmc_sampler_set_positions", "kmc_sampler_init_ball", "kmc_sampler_set_state", "kmc_sampler_run", "kmc_sampler_half_step",
+    "kmc_sampler_set_stream", "kmc_sampler_bind_positions", "kmc_sampler_p2p_export", "kmc_sampler_p2p_connect", "kmc_sampler_p2p_connect_local", "kmc_sampler_p2p_link_probe", "kmc_sampler_set_positions", "kmc_sampler_init_ball", "kmc_sampler_set_state", "kmc_sampler_run", "kmc_sampler_half_step",
     "kmc_sampler_sync", "kmc_sampler_last_run_ms", "kmc_sampler_generation", "kmc_sampler_nsamples",
     "kmc_sampler_launch_count", "kmc_sampler_describe", "kmc_sampler_device_ptr", "kmc_sampler_get_positions",
     "kmc_sampler_get_logp", "kmc_sampler_get_naccept", "kmc_sampler_get_accept_ratio",
@@ -184,6 +184,7 @@ def lib() -> C.CDLL:
     L.kmc_sampler_p2p_export.argtypes = [vp, vp]
     L.kmc_sampler_p2p_connect.argtypes = [vp, vp]
     L.kmc_sampler_p2p_connect_local.argtypes = [vp, C.POINTER(C.c_void_p)]
+    L.kmc_sampler_p2p_link_probe.argtypes = [vp, C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.kmc_sampler_set_positions.argtypes = [vp, dp]
     L.kmc_sampler_init_ball.argtypes = [vp, dp, dp, C.c_uint64, C.c_int, C.c_int]
     L.kmc_sampler_set_state.argtypes = [vp, dp, dp, ip, C.c_int64]

@@ -4,6 +4,7 @@
 #include <cstdio>
 
 #include "kmc_sampler.hpp"
+#include "kmc_kernels.hpp"      // load_row_sys: the link probe reads with the pull's own loads
 
 using namespace kmc;
 using namespace kmc_host;
@@ -138,3 +139,59 @@ KMC_EXPORT kmc_status kmc_sampler_p2p_connect_local(kmc_sampler* s, kmc_sampler*
     s->connected = true;
     return KMC_OK;
 }
+
+// ---- one fabric link, measured (bench.py's `link-probe` rung; DESIGN.md section 7 prices the exact rule by bytes per link) ------------------
+// The pull's access pattern: lane groups read WHOLE ROWS of the peer's shard at random row indices with the half-step kernels' own system-scope
+// loads (load_row_sys), nothing else in the kernel -- the rate one xGMI link sustains for what `rand(ncos)` (src/samplers.jl:250) makes it serve.
+namespace {
+__global__ __launch_bounds__(256) void link_probe_gather(const double2* peer, uint32_t rows_peer, uint32_t chunks, int64_t nrows, uint32_t salt, double* sink)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t row = t / chunks;
+    if (row >= nrows) return;
+    uint32_t h = ((uint32_t)row + salt) * 2654435761u;
+    h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    const uint64_t src = ((uint64_t)h * (uint64_t)rows_peer) >> 32;                  // uniform over the peer's rows, with replacement (:250)
+    const double2 v = kmc::load_row_sys(peer + src * chunks + (uint32_t)(t % chunks));
+    if (v.x == 1.2345e300 && v.y == -v.x) sink[0] = v.x;                             // (never: keeps the loads)
+}
+}  // namespace
+
+KMC_EXPORT kmc_status kmc_sampler_p2p_link_probe(kmc_sampler* s, int peer, int64_t nrows, int reps, double* gather_gbs, double* copy_gbs)
+{
+    if (!s || !gather_gbs || !copy_gbs || nrows < 1 || reps < 1) return fail(KMC_ERR_BAD_ARG, "bad argument");
+    if (!s->p2p || !s->connected || s->f32) return fail(KMC_ERR_BAD_ARG, "kmc_sampler_p2p_link_probe needs a connected KMC_P2P sampler with double rows");
+    if (peer < 0 || peer >= s->cfg.shard_count) return fail(KMC_ERR_BAD_ARG, "no such shard");
+    HIP_TRY(hipSetDevice(s->cfg.device));
+    const double* src = peer == s->cfg.shard_rank ? s->d_pos : s->peer_pos[peer];    // (own rank: the same pattern on local memory, for comparison)
+    const size_t shard_bytes = (size_t)s->nrows * (size_t)s->ld * sizeof(double);
+    const uint32_t chunks = (uint32_t)(s->ld / 2);
+    double* scratch = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+    kmc_status st = KMC_OK;
+    auto ok = [&](hipError_t e) { if (e != hipSuccess && st == KMC_OK) st = fail(KMC_ERR_HIP, std::string("link probe: ") + hipGetErrorString(e)); return st == KMC_OK; };
+    if (ok(hipMalloc(reinterpret_cast<void**>(&scratch), shard_bytes)) && ok(hipEventCreate(&e0)) && ok(hipEventCreate(&e1)) && ok(hipEventCreate(&e2))) {
+        const unsigned grid = (unsigned)((nrows * chunks + 255) / 256);
+        for (int r = -2; r < reps && st == KMC_OK; ++r) {                            // (two untimed launches first)
+            if (r == 0) ok(hipEventRecord(e0, s->stream));
+            hipLaunchKernelGGL(link_probe_gather, dim3(grid), dim3(256), 0, s->stream, reinterpret_cast<const double2*>(src), (uint32_t)s->nrows, chunks, nrows,
+                               (uint32_t)(r + 7) * 40503u, scratch);
+            ok(hipGetLastError());
+        }
+        ok(hipEventRecord(e1, s->stream));
+        for (int r = 0; r < 4 && st == KMC_OK; ++r) ok(hipMemcpyAsync(scratch, src, shard_bytes, hipMemcpyDeviceToDevice, s->stream));    // the runtime's own copy of the whole shard
+        ok(hipEventRecord(e2, s->stream));
+        ok(hipEventSynchronize(e2));
+        float tg = 0.f, tc = 0.f;
+        if (ok(hipEventElapsedTime(&tg, e0, e1)) && ok(hipEventElapsedTime(&tc, e1, e2))) {
+            *gather_gbs = (double)nrows * (double)s->ld * 8.0 * (double)reps / ((double)tg * 1e-3) / 1e9;
+            *copy_gbs = (double)shard_bytes * 4.0 / ((double)tc * 1e-3) / 1e9;
+        }
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (e2) (void)hipEventDestroy(e2);
+    if (scratch) (void)hipFree(scratch);
+    return st;
+}
+

@@ -160,6 +160,25 @@ class P2PEmcee:
         if self.world > 1:
             dist.barrier(group=self.group)
 
+    def link_probe(self, nrows=None, reps=20):
+        """Collective: every rank measures the link to its next peer (and its own memory) with the pull's access pattern while nobody
+        samples: {"link_gather_GBs", "link_copy_GBs", "local_gather_GBs", "rows"} of THIS rank (``Sampler.p2p_link_probe``); a rank whose
+        probe fails still reaches every barrier and returns {"error": ...}."""
+        self.sampler.sync()
+        self._barrier()                 # nobody is sampling (or writing rows) while the links are measured
+        nrows = int(nrows or self.nwalkers // self.world // 2 * max(1, self.world - 1))        # the remote rows one half-step draws
+        out = {"rows": nrows}
+        for key, peer in (("link", (self.rank + 1) % self.world), ("local", self.rank)):     # (the local figure without a peer reading this rank's memory)
+            try:
+                g, c = self.sampler.p2p_link_probe(peer, nrows, reps)
+                out[key + "_gather_GBs"] = g
+                if key == "link":
+                    out["link_copy_GBs"] = c
+            except Exception as e:  # noqa: BLE001
+                out["error"] = f"{type(e).__name__}: {e}"
+            self._barrier()
+        return out
+
     def set_positions(self, theta_global):
         self.sampler.sync()             # this rank's own half-steps have drained (an asynchronous run() may precede) ...
         self._barrier()                 # ... and so have everybody else's: nobody is still reading this rank's rows or flags

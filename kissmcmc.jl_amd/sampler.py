@@ -141,6 +141,13 @@ class Sampler:
         for s in shards:
             _lib.check(s._L.kmc_sampler_p2p_connect_local(s._h, arr))
 
+    def p2p_link_probe(self, peer: int, nrows: int, reps: int = 20):
+        """(GB/s of whole rows of shard ``peer`` gathered at random row indices with the pull's system-scope loads, GB/s of the runtime's
+        copy of that shard): one fabric link -- or local memory for ``peer`` = own rank -- measured; the peers must be idle."""
+        g, c = C.c_double(0.0), C.c_double(0.0)
+        _lib.check(self._L.kmc_sampler_p2p_link_probe(self._h, int(peer), int(nrows), int(reps), C.byref(g), C.byref(c)))
+        return g.value, c.value
+
     @staticmethod
     def rccl_unique_id() -> bytes:
         """A fresh RCCL unique id (rank 0 creates it; every rank of the communicator gets the same bytes)."""

@@ -9,7 +9,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "scripts"))
-import summarize_r02 as base
+import summarize_r04 as base
 
 SRC = os.path.join(ROOT, "gpurun_out", "prof_gen")
 

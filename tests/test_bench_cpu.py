@@ -177,8 +177,9 @@ def _full_sharded(world=8, all_variants=True):
     full["allgather_mode"] = {"value": 2.3e9, "unit": "walker-steps/s", "generations": 1024, "us_per_half_step": 113.2, "equals_unsharded_run": True,
                               "bytes_received_per_gpu_per_half_step": 58720256, "execution": "RCCL all-gather of the updated half after every half-step (captured in the graph)", "note": "z" * 200}
     full["extras_timed_out"] = "'allgather-extra' did not finish within 300 s"
-    full["fabric"] = {"remote_partner_bytes_per_gpu_per_launch": 7340032.0, "bytes_per_link_per_launch": 1048576.0, "link_bound_us_at_77GBs": 13.6, "push_bytes_per_link_per_launch": 1966080.0,
-                      "variants_us_per_launch": {t: 14.2 for t in tags}}
+    full["fabric"] = {"remote_partner_bytes_per_gpu_per_launch": 7340032.0, "bytes_per_link_per_launch": 1048576.0, "link_gather_GBs": 61.234567, "link_copy_GBs": 48.123456, "local_gather_GBs": 2345.6789,
+                      "link_rate_source": "link-probe", "link_bound_us": 17.123456, "single_gpu_us_per_launch": 3.7891234, "projected_exact_speedup": 1.7701234, "measured_speedup": 1.6123456,
+                      "ge6x_expected_under_exact_rule": False, "push_bytes_per_link_per_launch": 1966080.0, "variants_us_per_launch": {t: 14.2 for t in tags}}
     return full
 
 
@@ -193,6 +194,10 @@ def test_the_sharded_result_line_fits_4_kb_with_every_rung_of_the_ladder():
         assert [r["rung"] for r in line["ladder"]] == [r["rung"] for r in full["ladder"]] and line["ladder"][-1]["timed_out"] is True
         assert line["dealt_mode"]["deals"] == 312 and line["allgather_mode"]["captured_in_graph"] is True and line["allgather_mode"]["equals_unsharded_run"] is True
         assert line["check"]["timed_run_equals_unsharded_run"] is True and "did not finish" in line["extras_timed_out"]
+        # SCALE readiness: the measured link rate, the exact rule's projected speed-up next to the measured one, and ">= 6x not expected" as a field
+        fab = line["fabric"]
+        assert fab["link_rate_source"] == "link-probe" and fab["link_gather_GBs"] == 61.23 and fab["projected_exact_speedup"] == 1.77 and fab["measured_speedup"] == 1.612
+        assert fab["ge6x_expected_under_exact_rule"] is False and "link_bound_us_at_77GBs" not in fab
 
 
 def test_a_result_line_that_would_not_fit_loses_its_optional_blocks_first():

@@ -58,6 +58,15 @@ def test_bench_two_ranks_p2p_from_a_plain_shell():
     out, err = run_bench({})
     common_checks(out)
     assert "peer-to-peer exchange" in out["config"]["parallelism"]
+    # the link-probe rung: one "link" measured with the pull's access pattern (here: this GPU's own memory through an IPC mapping), this GPU alone
+    # on its share of the walkers, and what the exact partner rule (src/samplers.jl:250) can reach from those two numbers -- in the line itself
+    fab = out["fabric"]
+    assert "link-probe" in [r_["rung"] for r_ in out["ladder"]] and fab["link_rate_source"] == "link-probe"
+    assert fab["link_gather_GBs"] > 1.0 and fab["link_copy_GBs"] > 1.0 and fab["local_gather_GBs"] > 1.0 and fab["single_gpu_us_per_launch"] > 0.5
+    assert fab["link_bound_us"] == pytest.approx(fab["bytes_per_link_per_launch"] / (fab["link_gather_GBs"] * 1e3), rel=1e-2)
+    assert fab["projected_exact_speedup"] == pytest.approx(2 * fab["single_gpu_us_per_launch"] / max(fab["single_gpu_us_per_launch"], fab["link_bound_us"]), rel=1e-2)
+    assert fab["ge6x_expected_under_exact_rule"] is False and fab["measured_speedup"] > 0
+    assert out["repetitions"] == 3 and out["value_min"] <= out["value"] <= out["value_max"]
     assert "allgather_mode" in out                      # the north star's exchange, on record next to the pull (here: RCCL refuses one device)
 
 

@@ -256,6 +256,34 @@ def test_two_shards_in_one_process(kmc, oracle, kw):
     np.testing.assert_array_equal(nacc, ref["naccept"])
 
 
+def test_link_probe_reads_a_peers_rows_without_changing_anything(kmc):
+    """kmc_sampler_p2p_link_probe (bench.py's `link-probe` rung): whole rows of a peer's shard gathered at random row indices with the pull's
+    system-scope loads + the runtime's copy of the shard -- here both "links" are this GPU's own memory.  Rates are positive and plausible,
+    the probe is read-only, and it refuses a sampler that is not a connected KMC_P2P shard."""
+    th = _theta0()
+    shards = [kmc.Sampler(kmc.GaussianIso(), NW, ND, 64, 0, 1, 2.0, SEED, shard_rank=r, shard_count=2, p2p=True) for r in range(2)]
+    try:
+        with pytest.raises(kmc.KmcError, match="connected"):
+            shards[0].p2p_link_probe(1, 1024)
+        kmc.Sampler.p2p_connect_local(shards)
+        for sh in shards:
+            sh.set_positions(th)
+        before = [sh.positions() for sh in shards]
+        for me, peer in ((0, 1), (1, 0), (0, 0)):
+            g, c = shards[me].p2p_link_probe(peer, 1 << 16, reps=5)
+            assert 1.0 < g < 8000.0 and 1.0 < c < 8000.0, (me, peer, g, c)          # GB/s: above a crawl, below the HBM spec
+        with pytest.raises(kmc.KmcError):
+            shards[0].p2p_link_probe(2, 1024)
+        for sh, b in zip(shards, before):
+            np.testing.assert_array_equal(sh.positions(), b)
+    finally:
+        for sh in shards:
+            sh.close()
+    with kmc.Sampler(kmc.GaussianIso(), NW, ND, 64, 0, 1, 2.0, SEED) as plain:
+        with pytest.raises(kmc.KmcError):
+            plain.p2p_link_probe(0, 1024)
+
+
 @pytest.mark.parametrize("form", ["expr", "body", "body-routed", "body-vec"])
 def test_two_p2p_shards_with_a_runtime_compiled_density(kmc, oracle, form, kmc_debug):
     """Runtime-compiled densities run under KMC_P2P too (the pull kernels are instantiated with the user's functor):
