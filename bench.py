@@ -169,8 +169,8 @@ def roofline_block(pdf, describe: str, nwalkers_launch: int, ndim: int, launch_u
     body_us = rec.get("body_us") if rec else None
     boundary_us = rec.get("boundary_us") if rec else None
     body_frac = (alg_read / (body_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if body_us else None
-    # the kernel-duration figure between the two: the rocprofv3 trace's average duration where the tool does not inflate it (launches of ~100 us), else --
-    # the record says so -- the launch period the light in-kernel probe stamps (first wave in .. next launch's first wave: an upper bound of the duration)
+    # the kernel-duration figure between the two (`duration_source`): "rocprof_trace" -- the trace's average duration where the tool does not inflate it --, else
+    # "light_probe_stamps" -- the record says `rocprof_inflated` -- first wave in .. last store issued of the light in-kernel probe (then equal to body_frac)
     duration_us = rec.get("duration_us") if rec else None
     duration_frac = (alg_read / (duration_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if duration_us else None
     if served == "hbm":

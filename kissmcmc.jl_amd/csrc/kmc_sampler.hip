@@ -140,9 +140,6 @@ hipError_t dev_alloc(kmc_sampler* s, T** p, size_t bytes)
     if (!poison || bytes == 0) {
         // (IPC-exported buffers stay plain allocations: a peer maps them by their base address)
         const hipError_t e0 = (s->cfg.flags & KMC_P2P) ? hipMalloc(reinterpret_cast<void**>(p), bytes) : cache_alloc(reinterpret_cast<void**>(p), bytes);
-#ifdef KMC_PROBE   // diagnostic build only (scripts/probes/hbm_addresses.py): where a sampler's larger buffers landed
-        if (e0 == hipSuccess && bytes >= ((size_t)1 << 20)) std::fprintf(stderr, "[kissmcmc_hip] alloc %zu bytes at %p\n", bytes, (void*)*p);
-#endif
         return e0;
     }
     hipError_t e = hipMalloc(reinterpret_cast<void**>(p), bytes + kGuardBytes);

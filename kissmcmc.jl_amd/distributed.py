@@ -164,12 +164,17 @@ class P2PEmcee:
         """Collective: every rank measures the link to its next peer (and its own memory) with the pull's access pattern while nobody
         samples: {"link_gather_GBs", "link_copy_GBs", "local_gather_GBs", "rows"} of THIS rank (``Sampler.p2p_link_probe``); a rank whose
         probe fails still reaches every barrier and returns {"error": ...}."""
-        self.sampler.sync()
-        self._barrier()                 # nobody is sampling (or writing rows) while the links are measured
         nrows = int(nrows or self.nwalkers // self.world // 2 * max(1, self.world - 1))        # the remote rows one half-step draws
         out = {"rows": nrows}
+        try:
+            self.sampler.sync()
+        except Exception as e:  # noqa: BLE001  (nothing may keep this rank from the barriers below)
+            out["error"] = f"{type(e).__name__}: {e}"
+        self._barrier()                 # nobody is sampling (or writing rows) while the links are measured
         for key, peer in (("link", (self.rank + 1) % self.world), ("local", self.rank)):     # (the local figure without a peer reading this rank's memory)
             try:
+                if "error" in out:
+                    raise RuntimeError(out["error"])
                 g, c = self.sampler.p2p_link_probe(peer, nrows, reps)
                 out[key + "_gather_GBs"] = g
                 if key == "link":

@@ -180,7 +180,7 @@ def f_blobs(kmc, pdf):
 FEATURES = [
     ("hipGraph replay", f_graph),
     ("resident mode (≤ 1024 walkers; ≤ 2048 with ndim ≤ 8)", f_resident),
-    ("one launch per generation (small states: ndim ≤ 8 up to 32 768 walkers, longer rows up to 8 MiB of state with up to 49 152 walkers)", f_generation),
+    ("one launch per generation (small states: ndim ≤ 8 up to 49 152 walkers and 196 608 doubles of state, longer rows up to 8 MiB of state with up to 49 152 walkers)", f_generation),
     ("islands (`KMC_ISLANDS`)", f_islands),
     ("float rows (`KMC_F32`)", f_f32),
     ("streamed chain (`KMC_STREAM_CHAIN`)", f_stream),

@@ -11,8 +11,9 @@ reader to be able to make, hardened in round 6: for the headlin
 and FAILS (exit status 1) when
   * a fraction of the line deviates from its recomputation by more than the tolerance (default 3 %);
   * the record attached to an entry was taken in another LAUNCH MODE than the line ran (`launch_mode`: table graph / updated graph / eager);
-  * the record's kernel duration does not fit the line: duration_us x launches > the time that contains them (per phase where the line has the phases;
-    probe-derived durations get PROBE_TOL = 5 %: the light probe's own cost), or body_us > duration_us;
+  * the record's kernel duration does not fit the line: duration_us x launches > the time that contains them (per phase where the line has the phases), or
+    body_us > duration_us; a probe build whose in-kernel launch period is more than PROBE_TOL = 5 % off the production build's period of the same passes;
+    a record whose production period is more than BOX_TOL = 4 % off the line's (another box);
   * the rocprofv3 mean duration exceeds the launch period and the record does not say so (`rocprof_inflated`) -- a kernel cannot take longer than the
     period that contains it; an inflated trace is allowed on record only next to another duration source.
 No GPU needed.   python scripts/recompute_roofline.py [profiles/bench_r06a.json] [tolerance, default 0.03]"""
@@ -26,7 +27,8 @@ sys.path.insert(0, ROOT)
 from bench import launch_mode_of
 
 PEAK, COPY, MALL = 8000.0, 6290.0, 256 * 2 ** 20
-PROBE_TOL = 0.05
+PROBE_TOL = 0.05      # what the light probe build may cost: its in-kernel launch period against the production build's period of the SAME passes (same box)
+BOX_TOL = 0.04        # launch periods of one build on different boxes (round 6, five boxes: C2 credited 3.97-4.03 us, C3 credited 5.96-6.18)
 
 
 def shape_of(name, line, entry):
@@ -80,9 +82,9 @@ def check(name, roof, nw, nd, tol, out, execution, credited_us=None, burnin_us=N
         fail(f"the record was taken in launch mode {rec['launch_mode']}, the line ran {launch_mode_of(execution)}: not evidence for this line")
     # the record's own unprofiled period against the line's (per phase where both have it; the HBM-resident launches are two-valued by process: the nearest on record)
     if credited_us and rec.get("period_us_unprofiled"):
-        dev("record's period (credited) vs line's", rec["period_us_unprofiled"], credited_us)
+        dev("record's period (credited) vs line's", rec["period_us_unprofiled"], credited_us, BOX_TOL)
         if burnin_us and rec.get("period_us_unprofiled_burnin"):
-            dev("record's period (burn-in) vs line's", rec["period_us_unprofiled_burnin"], burnin_us)
+            dev("record's period (burn-in) vs line's", rec["period_us_unprofiled_burnin"], burnin_us, BOX_TOL)
     else:
         periods = [rec["period_us_unprofiled"]] + list(rec.get("period_us_unprofiled_other_runs", {}).get("values", []))
         nearest = min(periods, key=lambda p: abs(p - period))
@@ -96,7 +98,7 @@ def check(name, roof, nw, nd, tol, out, execution, credited_us=None, burnin_us=N
     out.append(f"    fractions of 8 TB/s: period-based {roof['frac']:.3f}   duration-based {roof.get('duration_frac') or float('nan'):.3f} ({rec.get('duration_source', 'no duration on record')})   "
                f"body-based {roof.get('body_frac') or float('nan'):.3f}")
     if "rocprof_inflated" in rec:                                 # (records since round 6)
-        if rec["rocprof_avg_duration_us"] > held * (1.0 + tol) and not rec["rocprof_inflated"]:
+        if rec["rocprof_avg_duration_us"] > held * (1.0 + tol) and not rec["rocprof_inflated"] and not (served == "hbm" and rec.get("two_valued_note")):
             fail(f"rocprofv3's mean duration {rec['rocprof_avg_duration_us']:.2f} us exceeds the launch period {held:.2f} us and the record does not say so")
         if rec["rocprof_inflated"]:
             out.append(f"    rocprofv3's mean duration {rec['rocprof_avg_duration_us']:.2f} us > the period {held:.2f} us: on record as INFLATED BY THE TOOL, not used; duration source: {rec.get('duration_source')}")
@@ -104,20 +106,25 @@ def check(name, roof, nw, nd, tol, out, execution, credited_us=None, burnin_us=N
                 fail("the rocprofv3 duration is inflated and the record has no other duration source")
         if dur is not None:
             limit = PROBE_TOL if probe_source else tol
-            if dur > held * (1.0 + limit):
-                fail(f"duration_us {dur:.2f} x launches does not fit the time that contains them ({held:.2f} us per launch, + {100 * limit:.0f} %)")
-            else:
+            own = rec.get("period_us_in_profiled_run")
+            if dur <= held * (1.0 + limit):
                 out.append(f"    duration {dur:.2f} us <= {held:.2f} us per launch (+ {100 * limit:.0f} %): fits")
+            elif served == "hbm" and rec.get("two_valued_note") and own and dur <= own * (1.0 + tol):
+                # (the HBM-resident launches are two-valued by process: the traced process sat in the other mode than this line's; its duration fits its own period)
+                out.append(f"    duration {dur:.2f} us > this line's {held:.2f} us but <= the traced process's own HIP-event period {own:.2f} us: two-valued by process, on record as such")
+            else:
+                fail(f"duration_us {dur:.2f} x launches does not fit the time that contains them ({held:.2f} us per launch, + {100 * limit:.0f} %)")
             dev("duration_frac", alg / (dur * 1e-6) / 1e9 / PEAK, roof.get("duration_frac"))
             if body is not None and body > dur * (1.0 + tol):
                 fail(f"body_us {body:.2f} exceeds duration_us {dur:.2f}")
     if body is not None and rec.get("boundary_us") is not None:
-        if rec.get("period_us_in_kernel") is not None:            # light probe: held to PROBE_TOL against the line's period of that phase
-            dev("probe's launch period vs line's", rec["period_us_in_kernel"], held, PROBE_TOL)
-            if burnin_us and rec.get("burnin"):
-                dev("probe's period (burn-in) vs line's", rec["burnin"]["period_us_in_kernel"], burnin_us, PROBE_TOL)
+        if rec.get("period_us_in_kernel") is not None:            # light probe: body + boundary of the probe build against the production build's period of the same passes
+            dev("probe build's period vs production's", rec["period_us_in_kernel"], rec["period_us_unprofiled"], PROBE_TOL)
+            if rec.get("burnin") and rec.get("period_us_unprofiled_burnin"):
+                dev("... in burn-in", rec["burnin"]["period_us_in_kernel"], rec["period_us_unprofiled_burnin"], PROBE_TOL)
         else:
-            out.append(f"    body + boundary in the full probe build  {body:.2f} + {rec['boundary_us']:.2f} = {body + rec['boundary_us']:.2f} us against the line's {period:.2f} us (round-5 record: eight stamps per wave)")
+            out.append(f"    body + boundary ({'trace duration, period - duration' if 'kernel trace' in (rec.get('body_boundary_source') or '') else 'full probe build, a round-5 record'})  "
+                       f"{body:.2f} + {rec['boundary_us']:.2f} = {body + rec['boundary_us']:.2f} us against the line's {period:.2f} us")
         dev("body_frac", alg / (body * 1e-6) / 1e9 / PEAK, roof["body_frac"])
     summ = json.load(open(os.path.join(ROOT, rec["source"])))
     if "pmc_per_launch" in summ:
@@ -154,7 +161,7 @@ def main():
             nw, nd = shape_of(key, line, entry)
             w, f = check(key, entry["roofline"], nw, nd, tol, out, entry.get("execution"), entry.get("us_per_half_step_after_burnin"), entry.get("us_per_half_step_burnin"))
             worst, fails = max(worst, w), fails + f
-    out.append(f"largest deviation: {100 * worst:.2f} % (tolerance {100 * tol:.0f} %; probe-derived periods are held to {100 * PROBE_TOL:.0f} %, shown normalised)")
+    out.append(f"largest deviation: {100 * worst:.2f} % of a 3 % tolerance (normalised: probe-build periods are held to {100 * PROBE_TOL:.0f} %, periods of another box to {100 * BOX_TOL:.0f} %)")
     out += [f"FAILED: {f}" for f in fails]
     print("\n".join(out))
     return 0 if worst <= tol and not fails else 1

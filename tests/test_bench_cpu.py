@@ -87,18 +87,80 @@ def test_test_switches_of_the_bench_live_in_one_variable(monkeypatch):
     assert bench.bench_test_opt("deal-epoch", 64) == 64 and bench.bench_test_opt("no-hbm-shapes") is None
 
 
+def _recompute(path, root=None):
+    import importlib
+    import io
+    import contextlib
+    sys_path = os.path.join(ROOT, "scripts")
+    import sys
+    if sys_path not in sys.path:
+        sys.path.insert(0, sys_path)
+    mod = importlib.import_module("recompute_roofline")
+    old_root, old_argv = mod.ROOT, sys.argv
+    buf = io.StringIO()
+    try:
+        mod.ROOT = root or ROOT
+        sys.argv = ["recompute_roofline.py", path]
+        with contextlib.redirect_stdout(buf):
+            rc = mod.main()
+    finally:
+        mod.ROOT, sys.argv = old_root, old_argv
+    return rc, buf.getvalue()
+
+
+def _newest_line():
+    import glob
+    return sorted(glob.glob(os.path.join(ROOT, "profiles", "bench_r06*.json")))[-1]
+
+
 def test_every_fraction_of_the_committed_bench_line_follows_from_profiles():
     """scripts/recompute_roofline.py: the fractions of the newest committed bench line (headline and every other_configs entry with a
-    roofline) recomputed from the algorithmic bytes, the line's own HIP-event period and the tracked records under profiles/ --
-    all within 3 %."""
-    import glob
-    import subprocess
-    import sys
-    newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "bench_r0[45]*.json")))[-1]
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "recompute_roofline.py"), newest], capture_output=True, text=True, timeout=120)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert "largest deviation" in r.stdout and "DIFFERS" not in r.stdout
+    roofline) recomputed from the algorithmic bytes, the line's own HIP-event period and the tracked records under profiles/ -- period-,
+    duration- and body-based side by side, every record in the line's launch mode, every duration inside the time that contains it (VERDICT r05 #1)."""
+    rc, out = _recompute(_newest_line())
+    assert rc == 0, out[-4000:]
+    assert "largest deviation" in out and "DIFFERS" not in out and "FAIL" not in out
+    assert "launch mode updated_graph_128" in out and "INFLATED BY THE TOOL" in out and "duration-based" in out      # C2: the mode the bench runs; the trace's duration on record as inflated
+    assert "informative" not in out                                                                                # (no figure escapes its tolerance any more)
 
+
+def test_recompute_fails_on_another_launch_mode_and_on_durations_that_do_not_fit(tmp_path):
+    """The three ways a record stops being evidence for a line (VERDICT r05 #1): the line ran another launch mode than the record's passes; the record's kernel
+    duration x launches exceeds the time that contains them; the rocprofv3 duration exceeds the launch period and the record does not say so."""
+    import shutil
+    text = open(_newest_line()).read().splitlines()
+    full = json.loads(text[0])["bench_detail"]
+
+    def write(rec, name="line.json"):
+        p = tmp_path / name
+        p.write_text(json.dumps({"bench_detail": rec}) + "\n")
+        return str(p)
+
+    rc, out = _recompute(write(full))
+    assert rc == 0, out[-3000:]
+    # (1) the same numbers from a run in the table-graph mode: the updated-graph record is refused
+    other = json.loads(json.dumps(full))
+    other["config"]["execution"] = other["config"]["execution"].replace("hipGraph replay of 128 generations with per-replay parameter updates (step preloaded)", "hipGraph replay of 64 generations")
+    rc, out = _recompute(write(other))
+    assert rc == 1 and "the record was taken in launch mode updated_graph_128, the line ran table_graph_64" in out
+    # (2) a line whose launches are shorter than the record's kernel duration (ms_per_step < duration x launches)
+    fast = json.loads(json.dumps(full))
+    for k in ("avg_launch_us", "avg_launch_us_credited", "avg_launch_us_burnin"):
+        fast["roofline"][k] = 2.5
+    fast["roofline"]["achieved"] = 32768 * 520 / 2.5e-6 / 1e9
+    fast["roofline"]["frac"] = fast["roofline"]["achieved"] / 8000.0
+    fast["roofline"]["frac_of_measured_copy_rate"] = fast["roofline"]["achieved"] / 6290.0
+    rc, out = _recompute(write(fast))
+    assert rc == 1 and "does not fit the time that contains them" in out
+    # (3) a record that hides an inflated trace: profiles copied, traffic_c2.json says rocprof_inflated false and takes the trace as its duration
+    root = tmp_path / "root"
+    shutil.copytree(os.path.join(ROOT, "profiles"), root / "profiles", ignore=shutil.ignore_patterns("bench_r0[1-5]*", "*.csv", "*.txt", "r0[1-5]*"))
+    rec = json.load(open(root / "profiles" / "traffic_c2.json"))
+    assert rec["rocprof_inflated"] is True and rec["launch_mode"] == "updated_graph_128" and rec["duration_source"] == "light_probe_stamps"
+    rec["rocprof_inflated"], rec["duration_us"], rec["duration_source"] = False, rec["rocprof_avg_duration_us"], "rocprof_trace"
+    json.dump(rec, open(root / "profiles" / "traffic_c2.json", "w"))
+    rc, out = _recompute(write(full), root=str(root))
+    assert rc == 1 and "exceeds the launch period" in out and "does not say so" in out
 
 
 # ---- the result line must fit a reader that keeps a few KB of stdout (VERDICT r04 #1: BENCH_r04.parsed was null, the line was 20.6 KB) ----

@@ -117,6 +117,11 @@ def test_what_keeps_the_two_launch_kernels(kmc):
     assert "generation_group L=4 K=1" in _mode(kmc, pdf, 4096, 8) and "generation_group L=4 K=1" in _mode(kmc, pdf, 8192, 5)
     assert "generation_lane" in _mode(kmc, pdf, 16384, 6) and "generation_lane" in _mode(kmc, pdf, 4096, 4)
     assert "resident" in _mode(kmc, pdf, 2048, 4)
+    # the short-row limit the documents quote (README, DESIGN section 4, scripts/feature_matrix.py: "ndim <= 8 up to 49 152 walkers", 196 608 doubles of state;
+    # 65 536 walkers of one or two doubles): pinned here so that documents and planner cannot drift apart
+    assert "generation_lane" in _mode(kmc, pdf, 49152, 4) and "one launch per generation" not in _mode(kmc, pdf, 65536, 4)
+    assert "generation_group L=4 K=1" in _mode(kmc, pdf, 49152, 8) and "one launch per generation" not in _mode(kmc, pdf, 65536, 8)
+    assert "generation_lane" in _mode(kmc, pdf, 65536, 2) and "one launch per generation" not in _mode(kmc, pdf, 65536, 3)
 
 
 def test_stepping_by_halves_takes_the_two_launch_kernels_in_place(kmc, oracle):
