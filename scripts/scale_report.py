@@ -1,7 +1,7 @@
 """Read a multi-GPU record of bench.py -- SCALE_rNN.json as the driver writes it, a file of bench.py's JSON lines, or several files --
 and say, per N, what ran and what bounded it: value, efficiency against N = 1, the rung that supplied `value`, every rung of the ladder
-that failed or timed out, whether the timed run equalled the unsharded run, and the fabric arithmetic (bytes per link per launch, the
-link-bound time at 77 GB/s against the measured launch period).  No GPU needed.  python scripts/scale_report.py SCALE_r04.json [more.json ...]"""
+that failed or timed out, whether the timed run equalled the unsharded run, and the fabric arithmetic (bytes per link per launch, the link's
+MEASURED rate, the link-bound time against the measured launch period, the exact rule's projected speed-up next to the measured one).  No GPU needed.  python scripts/scale_report.py SCALE_r04.json [more.json ...]"""
 import json
 import sys
 
@@ -51,8 +51,15 @@ def main():
                     print(f"   rung NOT ok: {rung['rung']} after {rung['s']} s" + (" (timed out)" if rung.get("timed_out") else ""))
             fab = r.get("fabric", {})
             if fab:
-                print(f"   fabric: {fab['bytes_per_link_per_launch'] / 1e6:.2f} MB per link per launch -> >= {fab['link_bound_us_at_77GBs']:.1f} us at 77 GB/s "
-                      f"against the measured {roof.get('avg_launch_us', float('nan')):.1f} us")
+                if "link_bound_us" in fab:            # since round 6: the link's rate is measured by the line's own `link-probe` rung
+                    print(f"   fabric: {fab['bytes_per_link_per_launch'] / 1e6:.2f} MB per link per launch at {fab.get('link_gather_GBs') or 77.0:.1f} GB/s ({fab.get('link_rate_source')}; "
+                          f"runtime copy {fab.get('link_copy_GBs') or float('nan'):.1f}, same pattern on local memory {fab.get('local_gather_GBs') or float('nan'):.0f}) -> >= {fab['link_bound_us']:.1f} us "
+                          f"against the measured {roof.get('avg_launch_us', float('nan')):.1f} us; one GPU alone {fab.get('single_gpu_us_per_launch') or float('nan'):.2f} us per launch")
+                    print(f"   exact partner rule (src/samplers.jl:250): projected speed-up {fab.get('projected_exact_speedup') or float('nan'):.2f} x, measured {fab.get('measured_speedup') or float('nan'):.2f} x; "
+                          f">= 6 x expected: {fab.get('ge6x_expected_under_exact_rule')}")
+                else:
+                    print(f"   fabric: {fab['bytes_per_link_per_launch'] / 1e6:.2f} MB per link per launch -> >= {fab['link_bound_us_at_77GBs']:.1f} us at an ASSUMED 77 GB/s "
+                          f"against the measured {roof.get('avg_launch_us', float('nan')):.1f} us")
             col = r.get("collective", {})
             print(f"   collective: {col.get('backend')} world {col.get('world_size')} (seen by all-reduce: {col.get('ranks_seen_by_all_reduce')}), RCCL {col.get('rccl_version')}, "
                   f"launcher: {col.get('launcher')}, rank env {col.get('rank_env')}")
