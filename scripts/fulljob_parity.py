@@ -51,7 +51,7 @@ def compare(name, job, cores=None):
     dlogp = float(np.max(np.abs(logp - ref["final_logp"]) / np.maximum(1.0, np.abs(ref["final_logp"]))))
     dsum = float(np.max(np.abs(msum - ref["sum"]) / np.maximum(1e-9 * n, np.abs(ref["sum"]))))
     dsq = float(np.max(np.abs(msq - ref["sumsq"]) / np.abs(ref["sumsq"])))
-    ok = same_pos and same_acc and n == ref["nmoment"] and dlogp < 1e-12 and dsq < 1e-10 and dsum < 1e-10
+    ok = same_pos and same_acc and n == ref["nmoment"] and dlogp < 1e-12 and dsq < 1e-11 and dsum < 1e-11
     line = (f"{name}: final positions bit-identical: {same_pos}; acceptance counters identical: {same_acc} "
             f"({int(nacc.sum())} accepted of {nw * (G - nburn)} counted proposals); max rel. log-pdf difference {dlogp:.2e}; "
             f"moments: nmoment {n} == {ref['nmoment']}, max rel. difference sum {dsum:.2e}, sumsq {dsq:.2e} -> {'OK' if ok else 'MISMATCH'}")
