@@ -279,3 +279,18 @@ def test_emit_prints_the_full_record_first_and_the_result_line_last(capsys, tmp_
     assert len(out) == 2 and out[0].startswith('{"bench_detail"') and out[1].startswith('{"metric"') and len(out[1]) < 4096
     assert json.loads(out[0])["bench_detail"]["other_configs"]["C3"]["roofline"]["geometry"] == full["other_configs"]["C3"]["roofline"]["geometry"]
     assert json.load(open(tmp_path / "bench_detail.json"))["value"] == full["value"]
+
+
+def test_scale_report_reads_the_measured_fabric_block(tmp_path):
+    """scripts/scale_report.py on an N > 1 line of round 6 (the link's measured rate, the exact rule's projected speed-up next to the measured one) and on a
+    round-5 line (the assumed 77 GB/s, labelled as an assumption): what a reader gets from the driver's SCALE record without a GPU."""
+    import subprocess
+    import sys
+    new = tmp_path / "n8.json"
+    new.write_text(bench.compact_line(_full_sharded(8, True)) + "\n")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "scale_report.py"), str(new), os.path.join(ROOT, "profiles", "r05_rehearsal", "bench_2rank_drv.json")],
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "at 61.2 GB/s (link-probe" in r.stdout and "projected speed-up 1.77 x, measured 1.61 x; >= 6 x expected: False" in r.stdout
+    assert "at an ASSUMED 77 GB/s" in r.stdout                      # (the round-5 rehearsal line)
+
